@@ -1,0 +1,184 @@
+/*
+ * tsim_hip.h - C ABI of the MI355X (gfx950) stabilizer-rank sampling engine.
+ *
+ * This is the drop-in boundary for the one hot path of QuEraComputing/tsim:
+ *
+ *     tsim.sampler.sample_program(program, f_params, key) -> bool[B, num_outputs]
+ *                                       (reference: src/tsim/sampler.py:117-167)
+ *     tsim.compile.evaluate.evaluate(circuit, param_vals) -> complex64[B]
+ *                                       (reference: src/tsim/compile/evaluate.py:15-59)
+ *
+ * The reference is pure Python/JAX and has no FFI of its own; these entry
+ * points are what a binding for that seam binds (the ctypes stub is shown in
+ * INTEGRATION.md, the shipped one is tsim_amd/_lib.py).  Plain pointers and
+ * sizes only - no torch / numpy / jax types.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative TSIM_E* code and never
+ *     throws or prints; tsim_last_error() returns a thread-local message;
+ *   - "program description" arrays use EXACTLY the reference layout: one byte
+ *     per bit, row-major, padded to the per-family maximum term count
+ *     (src/tsim/compile/compile.py:21-37, src/tsim/compile/terms.py:42-207);
+ *     the library bit-packs them and uploads them once per device;
+ *   - a handle is bound to one HIP device; calls on one handle must not race;
+ *   - packed shot rows are little-endian bit strings: bit i of a row lives in
+ *     64-bit word i/64 at position i%64 (== numpy.packbits(bitorder="little")).
+ */
+#ifndef TSIM_HIP_H
+#define TSIM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TSIM_OK 0
+#define TSIM_EINVAL (-22)      /* bad argument / malformed program           */
+#define TSIM_ENOMEM (-12)      /* host or device allocation failed            */
+#define TSIM_EHIP (-5)         /* a HIP runtime call failed                   */
+#define TSIM_ENOTSUP (-95)     /* program exceeds a compiled-in limit         */
+#define TSIM_ESTATE (-1)       /* call not valid in the handle's state        */
+
+#define TSIM_MAX_PARAMS 512    /* max n_params (f bits + outputs) per level   */
+
+typedef struct tsim_program tsim_program;
+
+/*
+ * One autoregressive level == one reference CompiledScalarGraphs
+ * (src/tsim/compile/compile.py:21-37).  G = num_graphs, P = n_params.
+ */
+typedef struct tsim_level_desc {
+  int32_t num_graphs;            /* G */
+  int32_t n_params;              /* P */
+  int32_t ta, tb, tc, td;        /* padded term counts of the four families   */
+  /* NodePhases   (terms.py:42-73)   */
+  const uint8_t *a_phases;       /* [G, ta]     values 0..7                   */
+  const uint8_t *a_params;       /* [G, ta, P]  0/1                           */
+  const int32_t *a_counts;       /* [G]         real terms per graph          */
+  /* HalfPiPhases (terms.py:76-107)  */
+  const uint8_t *b_coeffs;       /* [G, tb]     0,2,4,6 (0 = padding)         */
+  const uint8_t *b_params;       /* [G, tb, P]                                */
+  /* PiProducts   (terms.py:110-144) */
+  const uint8_t *c_psi_const;    /* [G, tc]                                   */
+  const uint8_t *c_psi_params;   /* [G, tc, P]                                */
+  const uint8_t *c_phi_const;    /* [G, tc]                                   */
+  const uint8_t *c_phi_params;   /* [G, tc, P]                                */
+  /* PhasePairs   (terms.py:147-187) */
+  const uint8_t *d_alpha;        /* [G, td]     values 0..7                   */
+  const uint8_t *d_alpha_params; /* [G, td, P]                                */
+  const uint8_t *d_beta;         /* [G, td]                                   */
+  const uint8_t *d_beta_params;  /* [G, td, P]                                */
+  const int32_t *d_counts;       /* [G]                                       */
+  /* ScalarPrefactor (terms.py:190-207) */
+  const uint8_t *phase_indices;  /* [G]   0..7                                */
+  const int32_t *floatfactor;    /* [G,4] (a,b,c,d) on basis (1,w,i,conj w)   */
+  const int32_t *power2;         /* [G]                                       */
+  const float *approx;           /* [G,2] complex64 (re,im); may be NULL      */
+  int32_t has_approx;            /* static flag has_approximate_floatfactors  */
+} tsim_level_desc;
+
+/* ---- program construction (replaces the device upload implied by
+ *      jnp.asarray of a CompiledProgram, src/tsim/core/types.py:80-107) ---- */
+
+/* direct_f_indices/direct_flips: [n_direct]; output_order: [num_outputs]
+ * (direct entries first, then the compiled components in processing order). */
+int tsim_program_create(int32_t num_outputs, int32_t num_detectors, int32_t n_direct,
+                        const int32_t *direct_f_indices, const uint8_t *direct_flips,
+                        const int32_t *output_order, tsim_program **out);
+
+/* Adds a CompiledComponent (types.py:55-77); components must be added in the
+ * reference's processing order.  n_levels is n_out+1 (sequential mode) or 2
+ * (joint mode, evaluate-only).  Returns the component index (>= 0). */
+int tsim_program_add_component(tsim_program *p, int32_t n_out, const int32_t *output_indices,
+                               int32_t F, const int32_t *f_selection, int32_t n_levels);
+
+/* Adds the next level of component `component` (arrays are copied/packed). */
+int tsim_program_add_level(tsim_program *p, int32_t component, const tsim_level_desc *level);
+
+/* Packs all levels into the device image and uploads it to HIP device `device`. */
+int tsim_program_finalize(tsim_program *p, int32_t device);
+
+void tsim_program_destroy(tsim_program *p);
+
+/* ---- the hot path ---------------------------------------------------- */
+
+/*
+ * sample_program for one batch, host buffers in the reference layout
+ * (replaces src/tsim/sampler.py:117-167 incl. the H2D at :398 and D2H at :415).
+ *   f            uint8 [B, num_f], nonzero == 1
+ *   key_hi/lo    the post-split Threefry-2x32 subkey handed to sample_program
+ *                (src/tsim/sampler.py:399)
+ *   shot_offset  in-batch index of row 0 (Threefry counter of shot s is
+ *                shot_offset+s): a batch sharded over devices reproduces the
+ *                unsharded result bit for bit
+ *   out          out_packed == 0: uint8 [B, num_outputs] (0/1)
+ *                out_packed != 0: uint8 [B, 8*ceil(num_outputs/64)] little-endian bits
+ *   max_norm_dev float [n_components] (may be NULL): max |norm-1| of the
+ *                normalisation check of src/tsim/sampler.py:71-72, valid only
+ *                when the call contains in-batch shot 0 (else left untouched)
+ */
+int tsim_sample_batch(tsim_program *p, const uint8_t *f, int64_t B, int32_t num_f,
+                      uint32_t key_hi, uint32_t key_lo, int64_t shot_offset,
+                      uint8_t *out, int32_t out_packed, float *max_norm_dev);
+
+/*
+ * Same, on device-resident packed buffers (no host transfer, asynchronous on
+ * `stream`; pass NULL for the handle's own stream):
+ *   d_f    uint64 [B, ceil(num_f/64)]   packed error-mechanism rows
+ *   d_out  uint64 [B, ceil(num_outputs/64)]
+ *   d_max_norm_dev  device float [n_components] or NULL
+ */
+int tsim_sample_batch_device(tsim_program *p, const uint64_t *d_f, int64_t B, int32_t num_f,
+                             uint32_t key_hi, uint32_t key_lo, int64_t shot_offset,
+                             uint64_t *d_out, float *d_max_norm_dev, void *stream);
+
+/*
+ * evaluate(circuit, param_vals) for level `level` of component `component`
+ * (replaces src/tsim/compile/evaluate.py:15-59).
+ *   params        uint8 [B, n_params]
+ *   re, im        float [B]  complex64 amplitude
+ *   coeffs_power  optional int32 [B,5]: exact (a,b,c,d,power) of the summed
+ *                 amplitude on the exact branch (zeros on the approximate one)
+ */
+int tsim_evaluate(tsim_program *p, int32_t component, int32_t level, const uint8_t *params,
+                  int64_t B, float *re, float *im, int32_t *coeffs_power);
+
+/* ---- device-side data-format kernels either side of the path ---------- */
+
+/* uint8 [B,num_f] (device) -> packed uint64 [B,ceil(num_f/64)] (device)      */
+int tsim_pack_bits_device(tsim_program *p, const uint8_t *d_in, int64_t B, int32_t nbits,
+                          uint64_t *d_out, void *stream);
+/* packed uint64 [B,ceil(nbits/64)] (device) -> uint8 [B,nbits] (device)      */
+int tsim_unpack_bits_device(tsim_program *p, const uint64_t *d_in, int64_t B, int32_t nbits,
+                            uint8_t *d_out, void *stream);
+
+/* ---- plumbing: memory, streams, timing (replaces utils/cuda_helpers.py:73-141) */
+
+int tsim_device_count(int32_t *count);
+int tsim_malloc_device(tsim_program *p, int64_t nbytes, void **d_ptr);
+int tsim_free_device(tsim_program *p, void *d_ptr);
+int tsim_malloc_pinned(int64_t nbytes, void **h_ptr);      /* hipHostMalloc   */
+int tsim_free_pinned(void *h_ptr);
+int tsim_memcpy_h2d(tsim_program *p, void *d_dst, const void *h_src, int64_t nbytes);
+int tsim_memcpy_d2h(tsim_program *p, void *h_dst, const void *d_src, int64_t nbytes);
+int tsim_synchronize(tsim_program *p);                      /* handle's stream */
+
+/* HIP-event timing of the sampling kernel launches on the handle's stream.   */
+int tsim_profile_enable(tsim_program *p, int32_t on);
+/* Sum of kernel durations (ms) and number of launches since the last reset;
+ * synchronises the stream.                                                   */
+int tsim_profile_read(tsim_program *p, double *kernel_ms, int64_t *launches, int32_t reset);
+
+/* ---- introspection ---------------------------------------------------- */
+
+int tsim_program_info(const tsim_program *p, int32_t *n_components, int32_t *num_outputs,
+                      int64_t *image_bytes, int64_t *total_graphs, int64_t *total_rows);
+
+const char *tsim_last_error(void);
+const char *tsim_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TSIM_HIP_H */

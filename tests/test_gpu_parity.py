@@ -1,0 +1,131 @@
+"""GPU parity: the HIP path (through the C ABI) against the numpy oracle and the reference KATs."""
+
+import warnings
+
+import numpy as np
+import pytest
+
+from conftest import run_batches
+from oracle import oracle_np as O
+from tsim_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def hip_sample(hip):
+    def fn(program, f, key):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            hp = hip.get_hip_program(program)
+            out, _ = hp.sample_batch(f, key)
+        return out
+
+    return fn
+
+
+# ---- the reference's seeded known-answer tests, through the HIP kernels ----
+
+
+def test_kat_seed_counts(hip):
+    """test/unit/test_sampler.py:223-233: H 0; M 0, seed 0 -> 48, 53, 52, 50."""
+    outs = run_batches(hip_sample(hip), synth.kat_h_m(), 0, [100] * 4)
+    assert [int(o.sum()) for o in outs] == [48, 53, 52, 50]
+
+
+def test_kat_t_gate(hip):
+    """test/integration/test_sampler_circuits.py:40-49 -> 9 of 100."""
+    (o,) = run_batches(hip_sample(hip), synth.kat_t_gate(), 0, [100])
+    assert int(o.sum()) == 9
+
+
+def test_kat_r_gate(hip):
+    """test_sampler_circuits.py:90-105 -> 7, 4, 0 of 10 (key threading across components)."""
+    (o,) = run_batches(hip_sample(hip), synth.kat_r_gate(), 0, [10])
+    assert o.sum(axis=0).tolist() == [7, 4, 0]
+
+
+def test_kat_bell(hip):
+    """test_sampler_circuits.py:10-22 -> 48 of 100, both bits equal."""
+    (o,) = run_batches(hip_sample(hip), synth.kat_bell(), 0, [100])
+    assert np.array_equal(o[:, 0], o[:, 1]) and int(o[:, 0].sum()) == 48
+
+
+# ---- HIP vs oracle on seeded synthetic programs -----------------------------
+
+SMALL = dict(
+    num_f=40,
+    n_direct=6,
+    components=[
+        dict(n=1, F=5, G=[2, 3], ta=(0, 4), tb=(0, 5), tc=(0, 6), td=(0, 2)),
+        dict(n=3, F=12, G=[3, 4, 5, 6], ta=(0, 6), tb=(0, 8), tc=(0, 8), td=(0, 3)),
+    ],
+)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+@pytest.mark.parametrize("approx", [False, True])
+def test_sample_matches_oracle_small(hip, seed, approx):
+    comps = [dict(c, approx=approx) for c in SMALL["components"]]
+    prog = synth.synth_program(
+        num_f=SMALL["num_f"], n_direct=SMALL["n_direct"], components=comps, seed=seed,
+        shuffle_outputs=True, direct_flip_fraction=0.3, identity_direct=False,
+    )
+    f = synth.synth_f(777, SMALL["num_f"], 0.1, seed=seed)
+    key = (123 + seed, 456)
+    want, wdev = O.sample_program(prog, f, key, return_devs=True)
+    hp = hip.get_hip_program(prog)
+    got, gdev = hp.sample_batch(f, key)
+    assert got.shape == want.shape and got.dtype == np.bool_
+    np.testing.assert_array_equal(got, want)
+    np.testing.assert_array_equal(np.asarray(gdev, np.float32), np.asarray(wdev, np.float32))
+
+
+@pytest.mark.parametrize("approx", [False, True])
+def test_evaluate_matches_oracle_exact_ints(hip, approx):
+    rng = np.random.default_rng(5)
+    lv = synth.synth_level(rng, 37, 12, approx=approx)
+    from tsim_amd.program import CompiledComponent, empty_scalar_graphs, make_program
+
+    comp = CompiledComponent(tuple(range(37)), np.zeros(0, np.int32), (empty_scalar_graphs(0), lv))
+    prog = make_program([comp], [], 37, 0)
+    hp = hip.HipProgram(prog)
+    pv = (rng.random((500, 37)) < 0.4).astype(np.uint8)
+    z, ex = hp.evaluate(0, 1, pv, exact=True)
+    want = O.evaluate(lv, pv)
+    np.testing.assert_array_equal(z.view(np.float32), want.view(np.float32))  # bit-exact floats
+    if not approx:
+        coeffs, power = O.evaluate_exact(lv, pv)
+        np.testing.assert_array_equal(ex[:, :4], coeffs)
+        nz = np.any(coeffs != 0, axis=1)
+        np.testing.assert_array_equal(ex[nz, 4], power[nz])
+
+
+def test_c2_shape_program_matches_oracle(hip):
+    """BASELINE config C2 (35-qubit distillation shape), 2000 shots, against the oracle."""
+    prog, cfg = synth.config_program("C2")
+    f = synth.synth_f(2000, cfg["num_f"], cfg["p_bit"], seed=cfg["seed"])
+    key = (7, 9)
+    want = O.sample_program(prog, f, key)
+    got, _ = hip.get_hip_program(prog).sample_batch(f, key)
+    np.testing.assert_array_equal(got, want)
+
+
+def test_shard_invariance(hip):
+    """Sharding a batch over launches (shot_offset) reproduces the unsharded bits."""
+    prog, cfg = synth.config_program("C2")
+    f = synth.synth_f(3000, cfg["num_f"], cfg["p_bit"], seed=1)
+    hp = hip.get_hip_program(prog)
+    key = (11, 13)
+    full, _ = hp.sample_batch(f, key)
+    parts = [hp.sample_batch(f[a:b], key, shot_offset=a)[0] for a, b in [(0, 1000), (1000, 1001), (1001, 3000)]]
+    np.testing.assert_array_equal(np.concatenate(parts), full)
+
+
+def test_bit_packed_output(hip):
+    prog, cfg = synth.config_program("C2")
+    f = synth.synth_f(500, cfg["num_f"], cfg["p_bit"], seed=2)
+    hp = hip.get_hip_program(prog)
+    a, _ = hp.sample_batch(f, (1, 2))
+    b, _ = hp.sample_batch(f, (1, 2), bit_packed=True)
+    want = np.packbits(a, axis=1, bitorder="little")
+    np.testing.assert_array_equal(b[:, : want.shape[1]], want)

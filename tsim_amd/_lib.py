@@ -1,0 +1,143 @@
+"""ctypes binding of ``libtsim_hip.so`` (C ABI: ``include/tsim_hip.h``).
+
+The library is built in-tree by ``__graft_entry__.build()`` /
+``python -m tsim_amd.build``.  There is deliberately **no fallback**: if the
+shared object is missing or cannot be loaded, importing the backend fails
+loudly with ``HipBackendError`` - the product path never routes through a CPU
+implementation.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+import numpy as np
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = _HERE / "libtsim_hip.so"
+
+
+class HipBackendError(RuntimeError):
+    """The HIP extension is missing, failed to load, or a call into it failed."""
+
+
+class LevelDesc(C.Structure):
+    """``tsim_level_desc`` (include/tsim_hip.h)."""
+
+    _fields_ = [
+        ("num_graphs", C.c_int32),
+        ("n_params", C.c_int32),
+        ("ta", C.c_int32),
+        ("tb", C.c_int32),
+        ("tc", C.c_int32),
+        ("td", C.c_int32),
+        ("a_phases", C.c_void_p),
+        ("a_params", C.c_void_p),
+        ("a_counts", C.c_void_p),
+        ("b_coeffs", C.c_void_p),
+        ("b_params", C.c_void_p),
+        ("c_psi_const", C.c_void_p),
+        ("c_psi_params", C.c_void_p),
+        ("c_phi_const", C.c_void_p),
+        ("c_phi_params", C.c_void_p),
+        ("d_alpha", C.c_void_p),
+        ("d_alpha_params", C.c_void_p),
+        ("d_beta", C.c_void_p),
+        ("d_beta_params", C.c_void_p),
+        ("d_counts", C.c_void_p),
+        ("phase_indices", C.c_void_p),
+        ("floatfactor", C.c_void_p),
+        ("power2", C.c_void_p),
+        ("approx", C.c_void_p),
+        ("has_approx", C.c_int32),
+    ]
+
+
+# every symbol include/tsim_hip.h declares: name -> (restype, argtypes)
+_P = C.c_void_p
+_I32, _I64, _U32 = C.c_int32, C.c_int64, C.c_uint32
+SYMBOLS: dict[str, tuple] = {
+    "tsim_program_create": (C.c_int, [_I32, _I32, _I32, _P, _P, _P, C.POINTER(_P)]),
+    "tsim_program_add_component": (C.c_int, [_P, _I32, _P, _I32, _P, _I32]),
+    "tsim_program_add_level": (C.c_int, [_P, _I32, C.POINTER(LevelDesc)]),
+    "tsim_program_finalize": (C.c_int, [_P, _I32]),
+    "tsim_program_destroy": (None, [_P]),
+    "tsim_sample_batch": (C.c_int, [_P, _P, _I64, _I32, _U32, _U32, _I64, _P, _I32, _P]),
+    "tsim_sample_batch_device": (C.c_int, [_P, _P, _I64, _I32, _U32, _U32, _I64, _P, _P, _P]),
+    "tsim_evaluate": (C.c_int, [_P, _I32, _I32, _P, _I64, _P, _P, _P]),
+    "tsim_pack_bits_device": (C.c_int, [_P, _P, _I64, _I32, _P, _P]),
+    "tsim_unpack_bits_device": (C.c_int, [_P, _P, _I64, _I32, _P, _P]),
+    "tsim_device_count": (C.c_int, [C.POINTER(_I32)]),
+    "tsim_malloc_device": (C.c_int, [_P, _I64, C.POINTER(_P)]),
+    "tsim_free_device": (C.c_int, [_P, _P]),
+    "tsim_malloc_pinned": (C.c_int, [_I64, C.POINTER(_P)]),
+    "tsim_free_pinned": (C.c_int, [_P]),
+    "tsim_memcpy_h2d": (C.c_int, [_P, _P, _P, _I64]),
+    "tsim_memcpy_d2h": (C.c_int, [_P, _P, _P, _I64]),
+    "tsim_synchronize": (C.c_int, [_P]),
+    "tsim_profile_enable": (C.c_int, [_P, _I32]),
+    "tsim_profile_read": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(_I64), _I32]),
+    "tsim_program_info": (
+        C.c_int,
+        [_P, C.POINTER(_I32), C.POINTER(_I32), C.POINTER(_I64), C.POINTER(_I64), C.POINTER(_I64)],
+    ),
+    "tsim_last_error": (C.c_char_p, []),
+    "tsim_version": (C.c_char_p, []),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load ``libtsim_hip.so`` and bind every declared symbol (raises if absent)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = Path(os.environ.get("TSIM_AMD_LIB", LIB_PATH))
+    if not path.exists():
+        raise HipBackendError(
+            f"{path} not found - build it with `python -m tsim_amd.build` "
+            "(hipcc --offload-arch=gfx950); there is no CPU fallback"
+        )
+    try:
+        lib = C.CDLL(str(path))
+    except OSError as exc:  # pragma: no cover - depends on the host
+        raise HipBackendError(f"cannot load {path}: {exc}") from exc
+    for name, (res, args) in SYMBOLS.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as exc:
+            raise HipBackendError(f"{path} does not export {name}") from exc
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    return load().tsim_last_error().decode("utf-8", "replace")
+
+
+def check(rc: int, what: str) -> int:
+    """Raise on a negative return code: -22 -> ValueError, others -> HipBackendError."""
+    if rc >= 0:
+        return rc
+    msg = f"{what}: {last_error()} (code {rc})"
+    if rc == -22:
+        raise ValueError(msg)
+    raise HipBackendError(msg)
+
+
+def ptr(a: np.ndarray | None):
+    """Raw data pointer of a C-contiguous array (``None`` -> NULL)."""
+    if a is None:
+        return None
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def device_count() -> int:
+    n = C.c_int32(0)
+    rc = load().tsim_device_count(C.byref(n))
+    return int(n.value) if rc == 0 else 0

@@ -1,0 +1,357 @@
+"""HIP backend: the reference's L3 functions, served by ``libtsim_hip.so``.
+
+Mirrors, with the same names, argument meaning and error behaviour:
+
+* ``sample_program(program, f_params, key) -> bool[B, num_outputs]``
+  (reference: src/tsim/sampler.py:117-167) - raises ``ValueError`` on a
+  vanishing marginal (normalisation deviation ~ 1) and ``warnings.warn`` s above
+  1e-5 (sampler.py:149-161);
+* ``evaluate(circuit, param_vals) -> complex64[B]``
+  (reference: src/tsim/compile/evaluate.py:15-59).
+
+Host orchestration only: ctypes + numpy, no torch, no jax.  All arithmetic is in
+the HIP kernels; if the extension is missing the import of ``_lib`` raises.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import warnings
+import weakref
+
+import numpy as np
+
+from . import _lib
+from .program import CompiledProgram, CompiledScalarGraphs, from_tsim, validate_program
+
+
+def _c(a, dtype) -> np.ndarray:
+    return np.ascontiguousarray(np.asarray(a), dtype=dtype)
+
+
+def _level_desc(lv: CompiledScalarGraphs, keep: list) -> _lib.LevelDesc:
+    """Fill a ``tsim_level_desc`` with pointers into C-contiguous copies (kept alive in ``keep``)."""
+    a, b, c, d, pre = lv.node_phases, lv.halfpi_phases, lv.pi_products, lv.phase_pairs, lv.prefactor
+    G, P = int(lv.num_graphs), int(lv.n_params)
+    arrs = dict(
+        a_phases=_c(a.phases, np.uint8),
+        a_params=_c(a.params, np.uint8),
+        a_counts=_c(a.counts, np.int32),
+        b_coeffs=_c(b.coeffs, np.uint8),
+        b_params=_c(b.params, np.uint8),
+        c_psi_const=_c(c.psi_const, np.uint8),
+        c_psi_params=_c(c.psi_params, np.uint8),
+        c_phi_const=_c(c.phi_const, np.uint8),
+        c_phi_params=_c(c.phi_params, np.uint8),
+        d_alpha=_c(d.alpha, np.uint8),
+        d_alpha_params=_c(d.alpha_params, np.uint8),
+        d_beta=_c(d.beta, np.uint8),
+        d_beta_params=_c(d.beta_params, np.uint8),
+        d_counts=_c(d.counts, np.int32),
+        phase_indices=_c(pre.phase_indices, np.uint8),
+        floatfactor=_c(pre.floatfactor, np.int32).reshape(-1, 4),
+        power2=_c(pre.power2, np.int32),
+        approx=_c(pre.approximate_floatfactors, np.complex64),
+    )
+
+    def dim1(x):
+        return int(x.shape[1]) if x.ndim >= 2 else 0
+
+    desc = _lib.LevelDesc()
+    desc.num_graphs, desc.n_params = G, P
+    desc.ta = dim1(arrs["a_phases"]) if G else 0
+    desc.tb = dim1(arrs["b_coeffs"]) if G else 0
+    desc.tc = dim1(arrs["c_psi_const"]) if G else 0
+    desc.td = dim1(arrs["d_alpha"]) if G else 0
+    # shape checks the C side cannot do (it only sees pointers)
+    want = {
+        "a_phases": (G, desc.ta), "a_params": (G, desc.ta, P), "a_counts": (G,),
+        "b_coeffs": (G, desc.tb), "b_params": (G, desc.tb, P),
+        "c_psi_const": (G, desc.tc), "c_psi_params": (G, desc.tc, P),
+        "c_phi_const": (G, desc.tc), "c_phi_params": (G, desc.tc, P),
+        "d_alpha": (G, desc.td), "d_alpha_params": (G, desc.td, P),
+        "d_beta": (G, desc.td), "d_beta_params": (G, desc.td, P), "d_counts": (G,),
+        "phase_indices": (G,), "floatfactor": (G, 4), "power2": (G,), "approx": (G,),
+    }
+    for name, shape in want.items():
+        if G and arrs[name].size != int(np.prod(shape)):
+            raise ValueError(f"{name}: expected shape {shape}, got {arrs[name].shape}")
+    for name, arr in arrs.items():
+        keep.append(arr)
+        setattr(desc, name, arr.ctypes.data if arr.size else None)
+    desc.has_approx = 1 if pre.has_approximate_floatfactors else 0
+    return desc
+
+
+class DeviceBuffer:
+    """A ``hipMalloc`` allocation owned by a :class:`HipProgram`."""
+
+    def __init__(self, prog: "HipProgram", nbytes: int):
+        self._prog = prog
+        self.nbytes = int(nbytes)
+        p = C.c_void_p()
+        _lib.check(prog._lib.tsim_malloc_device(prog._h, self.nbytes, C.byref(p)), "tsim_malloc_device")
+        self.ptr = p.value or 0
+
+    def free(self) -> None:
+        if self.ptr and self._prog._h:
+            self._prog._lib.tsim_free_device(self._prog._h, C.c_void_p(self.ptr))
+        self.ptr = 0
+
+    def __del__(self):  # pragma: no cover - best effort
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class HipProgram:
+    """A compiled program uploaded to one MI355X (handle over ``tsim_program*``)."""
+
+    def __init__(self, program, device: int = 0):
+        self._lib = _lib.load()
+        self._h = None
+        program = from_tsim(program)
+        validate_program(program)
+        self.program = program
+        self.device = int(device)
+        self.num_outputs = int(program.num_outputs)
+        self.n_components = len(program.components)
+        lib = self._lib
+        dfi = _c(program.direct_f_indices, np.int32)
+        flips = _c(np.asarray(program.direct_flips).astype(np.uint8), np.uint8)
+        order = _c(program.output_order, np.int32)
+        h = C.c_void_p()
+        _lib.check(
+            lib.tsim_program_create(
+                self.num_outputs, int(program.num_detectors), len(dfi),
+                _lib.ptr(dfi), _lib.ptr(flips), _lib.ptr(order), C.byref(h),
+            ),
+            "tsim_program_create",
+        )
+        self._h = h
+        try:
+            for comp in program.components:
+                oi = _c(comp.output_indices, np.int32)
+                fs = _c(comp.f_selection, np.int32)
+                ci = _lib.check(
+                    lib.tsim_program_add_component(
+                        h, len(oi), _lib.ptr(oi), len(fs), _lib.ptr(fs), len(comp.compiled_scalar_graphs)
+                    ),
+                    "tsim_program_add_component",
+                )
+                for lv in comp.compiled_scalar_graphs:
+                    keep: list = []
+                    desc = _level_desc(lv, keep)
+                    _lib.check(lib.tsim_program_add_level(h, ci, C.byref(desc)), "tsim_program_add_level")
+            _lib.check(lib.tsim_program_finalize(h, self.device), "tsim_program_finalize")
+        except Exception:
+            lib.tsim_program_destroy(h)
+            self._h = None
+            raise
+        self._finalizer = weakref.finalize(self, lib.tsim_program_destroy, h)
+
+    # -- info ---------------------------------------------------------------
+    def info(self) -> dict:
+        nc, no = C.c_int32(), C.c_int32()
+        ib, tg, tr = C.c_int64(), C.c_int64(), C.c_int64()
+        _lib.check(
+            self._lib.tsim_program_info(self._h, C.byref(nc), C.byref(no), C.byref(ib), C.byref(tg), C.byref(tr)),
+            "tsim_program_info",
+        )
+        return dict(n_components=nc.value, num_outputs=no.value, image_bytes=ib.value,
+                    total_graphs=tg.value, total_rows=tr.value)
+
+    # -- the hot path, host buffers -------------------------------------------
+    def sample_batch(self, f_params: np.ndarray, key, *, shot_offset: int = 0, bit_packed: bool = False):
+        """One batch through the fused kernel.  Returns ``(samples, max_norm_dev[n_components])``."""
+        f = np.asarray(f_params)
+        if f.ndim != 2:
+            raise ValueError(f"f_params must be 2-D (batch, num_f), got shape {f.shape}")
+        if f.dtype != np.uint8:
+            f = (f != 0).astype(np.uint8)
+        f = np.ascontiguousarray(f)
+        B, num_f = f.shape
+        wo = (self.num_outputs + 63) // 64
+        if bit_packed:
+            out = np.zeros((B, wo * 8), dtype=np.uint8)
+        else:
+            out = np.zeros((B, self.num_outputs), dtype=np.uint8)
+        devs = np.zeros(max(1, self.n_components), dtype=np.float32)
+        _lib.check(
+            self._lib.tsim_sample_batch(
+                self._h, _lib.ptr(f), B, num_f, int(key[0]) & 0xFFFFFFFF, int(key[1]) & 0xFFFFFFFF,
+                int(shot_offset), _lib.ptr(out), 1 if bit_packed else 0, _lib.ptr(devs),
+            ),
+            "tsim_sample_batch",
+        )
+        if not bit_packed:
+            out = out.view(np.bool_)
+        return out, devs[: self.n_components]
+
+    # -- the hot path, device-resident ----------------------------------------
+    def malloc(self, nbytes: int) -> DeviceBuffer:
+        return DeviceBuffer(self, nbytes)
+
+    def h2d(self, dst: DeviceBuffer | int, src: np.ndarray) -> None:
+        src = np.ascontiguousarray(src)
+        d = dst.ptr if isinstance(dst, DeviceBuffer) else int(dst)
+        _lib.check(self._lib.tsim_memcpy_h2d(self._h, C.c_void_p(d), _lib.ptr(src), src.nbytes), "tsim_memcpy_h2d")
+
+    def d2h(self, dst: np.ndarray, src: DeviceBuffer | int) -> None:
+        assert dst.flags.c_contiguous
+        s = src.ptr if isinstance(src, DeviceBuffer) else int(src)
+        _lib.check(self._lib.tsim_memcpy_d2h(self._h, _lib.ptr(dst), C.c_void_p(s), dst.nbytes), "tsim_memcpy_d2h")
+
+    def pack_bits_device(self, d_in: int, B: int, nbits: int, d_out: int) -> None:
+        _lib.check(
+            self._lib.tsim_pack_bits_device(self._h, C.c_void_p(d_in), B, nbits, C.c_void_p(d_out), None),
+            "tsim_pack_bits_device",
+        )
+
+    def unpack_bits_device(self, d_in: int, B: int, nbits: int, d_out: int) -> None:
+        _lib.check(
+            self._lib.tsim_unpack_bits_device(self._h, C.c_void_p(d_in), B, nbits, C.c_void_p(d_out), None),
+            "tsim_unpack_bits_device",
+        )
+
+    def sample_batch_device(self, d_f: int, B: int, num_f: int, key, d_out: int, *,
+                            shot_offset: int = 0, d_norm_dev: int = 0) -> None:
+        """Asynchronous launch on the handle's stream; buffers are raw device pointers."""
+        _lib.check(
+            self._lib.tsim_sample_batch_device(
+                self._h, C.c_void_p(d_f), int(B), int(num_f), int(key[0]) & 0xFFFFFFFF,
+                int(key[1]) & 0xFFFFFFFF, int(shot_offset), C.c_void_p(d_out),
+                C.c_void_p(d_norm_dev) if d_norm_dev else None, None,
+            ),
+            "tsim_sample_batch_device",
+        )
+
+    def synchronize(self) -> None:
+        _lib.check(self._lib.tsim_synchronize(self._h), "tsim_synchronize")
+
+    def profile_enable(self, on: bool = True) -> None:
+        _lib.check(self._lib.tsim_profile_enable(self._h, 1 if on else 0), "tsim_profile_enable")
+
+    def profile_read(self, reset: bool = True) -> tuple[float, int]:
+        ms, n = C.c_double(), C.c_int64()
+        _lib.check(self._lib.tsim_profile_read(self._h, C.byref(ms), C.byref(n), 1 if reset else 0), "tsim_profile_read")
+        return float(ms.value), int(n.value)
+
+    # -- evaluate seam ----------------------------------------------------------
+    def evaluate(self, component: int, level: int, param_vals: np.ndarray, *, exact: bool = False):
+        pv = np.asarray(param_vals)
+        if pv.ndim != 2:
+            raise ValueError(f"param_vals must be 2-D (batch, n_params), got shape {pv.shape}")
+        if pv.dtype != np.uint8:
+            pv = (pv != 0).astype(np.uint8)
+        pv = np.ascontiguousarray(pv)
+        B = pv.shape[0]
+        lv = self.program.components[component].compiled_scalar_graphs[level]
+        if pv.shape[1] != lv.n_params:
+            raise ValueError(f"param_vals has {pv.shape[1]} columns, level expects {lv.n_params}")
+        re = np.zeros(B, np.float32)
+        im = np.zeros(B, np.float32)
+        ex = np.zeros((B, 5), np.int32) if exact else None
+        _lib.check(
+            self._lib.tsim_evaluate(self._h, component, level, _lib.ptr(pv), B, _lib.ptr(re), _lib.ptr(im), _lib.ptr(ex)),
+            "tsim_evaluate",
+        )
+        z = np.empty(B, np.complex64)
+        z.real, z.imag = re, im
+        return (z, ex) if exact else z
+
+
+# ---------------------------------------------------------------------------
+# module-level mirrors of the reference's seam functions
+# ---------------------------------------------------------------------------
+
+
+def get_hip_program(program, device: int = 0) -> HipProgram:
+    """Upload ``program`` once per device and cache the handle on the program object."""
+    if isinstance(program, HipProgram):
+        return program
+    cache = getattr(program, "_backend_cache", None)
+    if cache is None:
+        try:
+            cache = {}
+            object.__setattr__(program, "_backend_cache", cache)
+        except Exception:  # frozen foreign object: no caching
+            return HipProgram(program, device)
+    hp = cache.get(device)
+    if hp is None:
+        hp = HipProgram(program, device)
+        cache[device] = hp
+    return hp
+
+
+def check_norm_deviation(max_norm_deviation: float) -> None:
+    """The error/warning policy of reference src/tsim/sampler.py:149-161."""
+    if np.isclose(max_norm_deviation, 1):
+        raise ValueError(
+            "A vanishing marginal probability distribution was encountered (normalization 0). "
+            "This is likely the result of an underflow error."
+        )
+    if max_norm_deviation > 1e-5:
+        warnings.warn(
+            "A marginal probability was not normalized correctly "
+            f"(normalization deviated from 1 by {max_norm_deviation:.1e}). "
+            "This is likely a floating point precision issue.",
+            stacklevel=3,
+        )
+
+
+def sample_program(program, f_params, key, *, device: int = 0) -> np.ndarray:
+    """Drop-in for ``tsim.sampler.sample_program`` (sampler.py:117-167).
+
+    ``key`` is the post-split subkey, either a ``(hi, lo)`` uint32 pair or a JAX
+    typed key (``jax.random.key_data`` is applied when jax is importable).
+    """
+    key = _key_pair(key)
+    f = np.asarray(f_params)
+    if int(getattr(program, "num_outputs")) == 0:
+        return np.zeros((f.shape[0], 0), dtype=np.bool_)
+    hp = get_hip_program(program, device)
+    out, devs = hp.sample_batch(f, key)
+    for dev in devs:
+        check_norm_deviation(float(dev))
+    return out
+
+
+def evaluate(circuit: CompiledScalarGraphs, param_vals) -> np.ndarray:
+    """Drop-in for ``tsim.compile.evaluate.evaluate`` (evaluate.py:15-59)."""
+    from .program import CompiledComponent, make_program, scalar_graphs_from_tsim
+
+    pv = np.asarray(param_vals)
+    cache = getattr(circuit, "_eval_handle", None)
+    if cache is None:
+        lv = scalar_graphs_from_tsim(circuit)
+        # wrap the single level as a joint-mode component: [empty norm level, this level]
+        from .program import empty_scalar_graphs
+
+        comp = CompiledComponent(
+            tuple(range(lv.n_params)), np.zeros(0, np.int32), (empty_scalar_graphs(0), lv)
+        )
+        prog = make_program([comp], [], lv.n_params, 0)
+        cache = HipProgram(prog)
+        try:
+            object.__setattr__(circuit, "_eval_handle", cache)
+        except Exception:
+            pass
+    return cache.evaluate(0, 1, pv)
+
+
+def _key_pair(key) -> tuple[int, int]:
+    if isinstance(key, (tuple, list)) and len(key) == 2:
+        return int(key[0]), int(key[1])
+    arr = None
+    try:  # a JAX typed key
+        import jax  # type: ignore
+
+        arr = np.asarray(jax.random.key_data(key))
+    except Exception:
+        arr = np.asarray(key)
+    arr = arr.reshape(-1)
+    if arr.shape[0] != 2:
+        raise ValueError("key must be a (hi, lo) uint32 pair or a threefry2x32 JAX key")
+    return int(arr[0]), int(arr[1])

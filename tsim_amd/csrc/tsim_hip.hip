@@ -1,0 +1,781 @@
+// tsim_hip.hip - C ABI (include/tsim_hip.h) + host-side packer for the gfx950 engine.
+//
+// Host responsibilities (all native, no Python in here):
+//   * bit-pack the reference-layout program description into one uint32 image
+//     that the kernels read through the scalar cache;
+//   * own device memory, the stream and HIP-event timing.
+#include "../../include/tsim_hip.h"
+#include "tsim_kernels.hip.h"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace tsimk;
+
+// ---------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                        \
+  do {                                                                                       \
+    hipError_t e_ = (expr);                                                                  \
+    if (e_ != hipSuccess) return fail(TSIM_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+extern "C" const char *tsim_last_error(void) { return g_err; }
+extern "C" const char *tsim_version(void) { return "tsim_amd-hip 0.1 (gfx950)"; }
+
+// ---------------------------------------------------------------------------
+// host-side program
+// ---------------------------------------------------------------------------
+namespace {
+
+struct HostLevel {
+  int G = 0, P = 0;
+  bool approx = false;
+  // per graph
+  std::vector<uint32_t> graph_rec;        // G * G_WORDS (row offsets relative to `rows`)
+  std::vector<uint32_t> rows;             // packed rows, built for word count W
+  long long n_rows = 0;
+  // raw copy of the description (packing happens at finalize when W is known)
+  tsim_level_desc d{};
+  std::vector<uint8_t> u8[14];
+  std::vector<int32_t> i32[4];
+  std::vector<float> approx_v;
+};
+
+struct HostComponent {
+  int n_out = 0, F = 0, n_levels = 0;
+  std::vector<int32_t> output_indices, f_selection;
+  std::vector<HostLevel> levels;
+};
+
+static const int kWVariants[] = {1, 2, 3, 4, 6, 8, 12, 16};
+
+static int round_w(int w) {
+  for (int v : kWVariants)
+    if (w <= v) return v;
+  return -1;
+}
+
+}  // namespace
+
+struct tsim_program {
+  // description
+  int num_outputs = 0, num_detectors = 0, n_direct = 0;
+  std::vector<int32_t> direct_f, output_order;
+  std::vector<uint8_t> direct_flips;
+  std::vector<HostComponent> comps;
+  bool finalized = false;
+  // packed image
+  std::vector<uint32_t> img;
+  int direct_off = 0, comp_off = 0;
+  int total_keys = 0;  // total compiled outputs (sequential components)
+  bool sampleable = true;
+  long long total_graphs = 0, total_rows = 0;
+  int max_f_index = -1;
+  std::vector<int> level_off;  // flattened [component][level] -> offset of level record
+  std::vector<int> level_base; // per component index into level_off
+  std::vector<int> comp_w;
+  // device
+  int device = -1;
+  uint32_t *d_img = nullptr;
+  uint32_t *d_keys = nullptr;
+  float *d_dev = nullptr;
+  hipStream_t stream = nullptr;
+  // scratch (host-buffer API)
+  void *scratch[4] = {nullptr, nullptr, nullptr, nullptr};
+  size_t scratch_sz[4] = {0, 0, 0, 0};
+  // profiling
+  bool profiling = false;
+  std::vector<hipEvent_t> ev_pool;
+  size_t ev_used = 0;
+  double prof_ms = 0.0;
+  long long prof_launches = 0;
+};
+
+static int set_device(const tsim_program *p) {
+  HIP_TRY(hipSetDevice(p->device));
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// construction
+// ---------------------------------------------------------------------------
+extern "C" int tsim_program_create(int32_t num_outputs, int32_t num_detectors, int32_t n_direct,
+                                   const int32_t *direct_f_indices, const uint8_t *direct_flips,
+                                   const int32_t *output_order, tsim_program **out) {
+  if (!out) return fail(TSIM_EINVAL, "out is NULL");
+  if (num_outputs < 0 || n_direct < 0 || n_direct > num_outputs || num_detectors < 0)
+    return fail(TSIM_EINVAL, "bad counts: num_outputs=%d n_direct=%d num_detectors=%d", num_outputs,
+                n_direct, num_detectors);
+  if (n_direct > 0 && (!direct_f_indices || !direct_flips)) return fail(TSIM_EINVAL, "direct arrays NULL");
+  if (num_outputs > 0 && !output_order) return fail(TSIM_EINVAL, "output_order is NULL");
+  tsim_program *p = new (std::nothrow) tsim_program();
+  if (!p) return fail(TSIM_ENOMEM, "out of host memory");
+  p->num_outputs = num_outputs;
+  p->num_detectors = num_detectors;
+  p->n_direct = n_direct;
+  p->direct_f.assign(direct_f_indices, direct_f_indices + n_direct);
+  p->direct_flips.assign(direct_flips, direct_flips + n_direct);
+  p->output_order.assign(output_order, output_order + num_outputs);
+  std::vector<char> seen(num_outputs, 0);
+  for (int i = 0; i < num_outputs; ++i) {
+    int o = p->output_order[i];
+    if (o < 0 || o >= num_outputs || seen[o]) {
+      delete p;
+      return fail(TSIM_EINVAL, "output_order is not a permutation of 0..%d", num_outputs - 1);
+    }
+    seen[o] = 1;
+  }
+  for (int i = 0; i < n_direct; ++i) {
+    if (p->direct_f[i] < 0) {
+      delete p;
+      return fail(TSIM_EINVAL, "negative direct_f_indices[%d]", i);
+    }
+    p->max_f_index = std::max(p->max_f_index, p->direct_f[i]);
+  }
+  *out = p;
+  return TSIM_OK;
+}
+
+extern "C" int tsim_program_add_component(tsim_program *p, int32_t n_out, const int32_t *output_indices,
+                                          int32_t F, const int32_t *f_selection, int32_t n_levels) {
+  if (!p) return fail(TSIM_EINVAL, "program is NULL");
+  if (p->finalized) return fail(TSIM_ESTATE, "program already finalized");
+  if (n_out < 0 || F < 0) return fail(TSIM_EINVAL, "negative n_out/F");
+  if (n_levels != n_out + 1 && n_levels != 2)
+    return fail(TSIM_EINVAL, "component with %d outputs needs %d (sequential) or 2 (joint) levels, got %d",
+                n_out, n_out + 1, n_levels);
+  if ((n_out > 0 && !output_indices) || (F > 0 && !f_selection)) return fail(TSIM_EINVAL, "NULL index array");
+  HostComponent c;
+  c.n_out = n_out;
+  c.F = F;
+  c.n_levels = n_levels;
+  c.output_indices.assign(output_indices, output_indices + n_out);
+  c.f_selection.assign(f_selection, f_selection + F);
+  for (int i = 0; i < F; ++i) {
+    if (c.f_selection[i] < 0) return fail(TSIM_EINVAL, "negative f_selection[%d]", i);
+    p->max_f_index = std::max(p->max_f_index, c.f_selection[i]);
+  }
+  p->comps.push_back(std::move(c));
+  return (int)p->comps.size() - 1;
+}
+
+template <class T>
+static void copy_arr(std::vector<T> &dst, const T *src, size_t n) {
+  if (n && src) dst.assign(src, src + n);
+  else dst.assign(n, T());
+}
+
+extern "C" int tsim_program_add_level(tsim_program *p, int32_t component, const tsim_level_desc *L) {
+  if (!p || !L) return fail(TSIM_EINVAL, "NULL argument");
+  if (p->finalized) return fail(TSIM_ESTATE, "program already finalized");
+  if (component < 0 || component >= (int)p->comps.size()) return fail(TSIM_EINVAL, "bad component index %d", component);
+  HostComponent &c = p->comps[component];
+  if ((int)c.levels.size() >= c.n_levels) return fail(TSIM_EINVAL, "component %d already has all %d levels", component, c.n_levels);
+  const int k = (int)c.levels.size();
+  const bool sequential = (c.n_levels == c.n_out + 1);
+  const int want_P = c.F + (sequential ? k : (k == 0 ? 0 : c.n_out));
+  if (L->n_params != want_P)
+    return fail(TSIM_EINVAL, "component %d level %d: n_params=%d, expected %d", component, k, L->n_params, want_P);
+  if (L->num_graphs < 0 || L->ta < 0 || L->tb < 0 || L->tc < 0 || L->td < 0) return fail(TSIM_EINVAL, "negative sizes");
+  if (L->n_params > TSIM_MAX_PARAMS)
+    return fail(TSIM_ENOTSUP, "n_params=%d exceeds TSIM_MAX_PARAMS=%d", L->n_params, TSIM_MAX_PARAMS);
+  const size_t G = L->num_graphs, P = L->n_params;
+  if (G > 0) {
+    const void *req[] = {L->phase_indices, L->floatfactor, L->power2};
+    for (const void *q : req)
+      if (!q) return fail(TSIM_EINVAL, "prefactor array is NULL");
+    if ((L->ta && (!L->a_phases || !L->a_counts || (P && !L->a_params))) ||
+        (L->tb && (!L->b_coeffs || (P && !L->b_params))) ||
+        (L->tc && (!L->c_psi_const || !L->c_phi_const || (P && (!L->c_psi_params || !L->c_phi_params)))) ||
+        (L->td && (!L->d_alpha || !L->d_beta || !L->d_counts || (P && (!L->d_alpha_params || !L->d_beta_params)))))
+      return fail(TSIM_EINVAL, "term array is NULL");
+    if (L->has_approx && !L->approx) return fail(TSIM_EINVAL, "has_approx set but approx is NULL");
+  }
+  HostLevel h;
+  h.G = (int)G;
+  h.P = (int)P;
+  h.approx = L->has_approx != 0;
+  h.d = *L;
+  copy_arr(h.u8[0], L->a_phases, G * L->ta);
+  copy_arr(h.u8[1], L->a_params, G * L->ta * P);
+  copy_arr(h.u8[2], L->b_coeffs, G * L->tb);
+  copy_arr(h.u8[3], L->b_params, G * L->tb * P);
+  copy_arr(h.u8[4], L->c_psi_const, G * L->tc);
+  copy_arr(h.u8[5], L->c_psi_params, G * L->tc * P);
+  copy_arr(h.u8[6], L->c_phi_const, G * L->tc);
+  copy_arr(h.u8[7], L->c_phi_params, G * L->tc * P);
+  copy_arr(h.u8[8], L->d_alpha, G * L->td);
+  copy_arr(h.u8[9], L->d_alpha_params, G * L->td * P);
+  copy_arr(h.u8[10], L->d_beta, G * L->td);
+  copy_arr(h.u8[11], L->d_beta_params, G * L->td * P);
+  copy_arr(h.u8[12], L->phase_indices, G);
+  copy_arr(h.i32[0], L->a_counts, L->ta ? G : 0);
+  copy_arr(h.i32[1], L->d_counts, L->td ? G : 0);
+  copy_arr(h.i32[2], L->floatfactor, G * 4);
+  copy_arr(h.i32[3], L->power2, G);
+  if (L->approx) copy_arr(h.approx_v, L->approx, G * 2);
+  else { h.approx_v.assign(G * 2, 0.0f); for (size_t g = 0; g < G; ++g) h.approx_v[2 * g] = 1.0f; }
+  for (size_t g = 0; g < G; ++g) {
+    if (L->ta && (h.i32[0][g] < 0 || h.i32[0][g] > L->ta)) return fail(TSIM_EINVAL, "a_counts[%zu] out of range", g);
+    if (L->td && (h.i32[1][g] < 0 || h.i32[1][g] > L->td)) return fail(TSIM_EINVAL, "d_counts[%zu] out of range", g);
+  }
+  c.levels.push_back(std::move(h));
+  return TSIM_OK;
+}
+
+// pack one byte-per-bit row into W 32-bit words appended to `dst`; returns true if any bit set
+static bool pack_row(std::vector<uint32_t> &dst, const uint8_t *bits, int P, int W) {
+  bool any = false;
+  size_t base = dst.size();
+  dst.resize(base + W, 0u);
+  for (int i = 0; i < P; ++i)
+    if (bits[i] & 1) {  // reference bit-matrices hold 0/1 (compile.py:40-238)
+      dst[base + (i >> 5)] |= 1u << (i & 31);
+      any = true;
+    }
+  return any;
+}
+
+static const int8_t kUnit[8][4] = {{1, 0, 0, 0}, {0, 1, 0, 0},  {0, 0, 1, 0},  {0, 0, 0, -1},
+                                   {-1, 0, 0, 0}, {0, -1, 0, 0}, {0, 0, -1, 0}, {0, 0, 0, 1}};
+
+// Build graph records + rows for a level with W words per row.
+static void pack_level(HostLevel &h, int W) {
+  const int G = h.G, P = h.P;
+  const tsim_level_desc &d = h.d;
+  h.graph_rec.assign((size_t)G * G_WORDS, 0u);
+  h.rows.clear();
+  h.n_rows = 0;
+  std::vector<uint32_t> tmp;
+  for (int g = 0; g < G; ++g) {
+    uint32_t *rec = &h.graph_rec[(size_t)g * G_WORDS];
+    rec[G_ROWS] = (uint32_t)h.rows.size();
+    // A: the first counts[g] slots are real (terms.py:70-71)
+    const int nA = d.ta ? h.i32[0][g] : 0;
+    for (int t = 0; t < nA; ++t) {
+      h.rows.push_back((uint32_t)(h.u8[0][(size_t)g * d.ta + t] & 7));
+      pack_row(h.rows, &h.u8[1][((size_t)g * d.ta + t) * P], P, W);
+    }
+    rec[G_NA] = (uint32_t)nA;
+    // B: zero coefficient or empty parity contributes exponent 0 (terms.py:104-106) -> dropped
+    int nB = 0;
+    for (int t = 0; t < d.tb; ++t) {
+      const uint32_t coeff = h.u8[2][(size_t)g * d.tb + t] & 7u;  // (rowsum*coeff) % 8
+      if (!coeff) continue;
+      tmp.clear();
+      if (!pack_row(tmp, &h.u8[3][((size_t)g * d.tb + t) * P], P, W)) continue;
+      h.rows.push_back(coeff);
+      h.rows.insert(h.rows.end(), tmp.begin(), tmp.end());
+      ++nB;
+    }
+    rec[G_NB] = (uint32_t)nB;
+    // C: a slot whose psi or phi is identically 0 contributes (-1)^0 (terms.py:136-141) -> dropped
+    int nC = 0;
+    for (int t = 0; t < d.tc; ++t) {
+      const uint32_t pc = h.u8[4][(size_t)g * d.tc + t] & 1u, qc = h.u8[6][(size_t)g * d.tc + t] & 1u;
+      std::vector<uint32_t> r1, r2;
+      const bool any1 = pack_row(r1, &h.u8[5][((size_t)g * d.tc + t) * P], P, W);
+      const bool any2 = pack_row(r2, &h.u8[7][((size_t)g * d.tc + t) * P], P, W);
+      if ((!any1 && !pc) || (!any2 && !qc)) continue;
+      h.rows.push_back(pc | (qc << 1));
+      h.rows.insert(h.rows.end(), r1.begin(), r1.end());
+      h.rows.insert(h.rows.end(), r2.begin(), r2.end());
+      ++nC;
+    }
+    rec[G_NC] = (uint32_t)nC;
+    // D: first counts[g] slots are real; the four possible term values are tabulated
+    const int nD = d.td ? h.i32[1][g] : 0;
+    for (int t = 0; t < nD; ++t) {
+      const int al = h.u8[8][(size_t)g * d.td + t] & 7, be = h.u8[10][(size_t)g * d.td + t] & 7;
+      for (int idx = 0; idx < 4; ++idx) {
+        const int pa = idx & 1, pb = idx >> 1;
+        const int a1 = (al + 4 * pa) & 7, b1 = (be + 4 * pb) & 7, g1 = (a1 + b1) & 7;
+        uint32_t w = 0;
+        for (int j = 0; j < 4; ++j) {
+          const int v = (j == 0 ? 1 : 0) + kUnit[a1][j] + kUnit[b1][j] - kUnit[g1][j];
+          w |= (uint32_t)(uint8_t)(int8_t)v << (8 * j);
+        }
+        h.rows.push_back(w);
+      }
+      pack_row(h.rows, &h.u8[9][((size_t)g * d.td + t) * P], P, W);
+      pack_row(h.rows, &h.u8[11][((size_t)g * d.td + t) * P], P, W);
+    }
+    rec[G_ND] = (uint32_t)nD;
+    h.n_rows += nA + nB + 2 * nC + 2 * nD;
+    rec[G_PHASE] = h.u8[12][g] & 7u;
+    const int32_t *ff = &h.i32[2][(size_t)g * 4];
+    rec[G_FFA] = (uint32_t)ff[0]; rec[G_FFB] = (uint32_t)ff[1];
+    rec[G_FFC] = (uint32_t)ff[2]; rec[G_FFD] = (uint32_t)ff[3];
+    rec[G_POW2] = (uint32_t)h.i32[3][g];
+    memcpy(&rec[G_APRE], &h.approx_v[2 * (size_t)g], 4);
+    memcpy(&rec[G_APIM], &h.approx_v[2 * (size_t)g + 1], 4);
+    rec[G_FLAGS] = (ff[0] == 1 && ff[1] == 0 && ff[2] == 0 && ff[3] == 0) ? TSIMK_GFLAG_FF_IS_ONE : 0u;
+  }
+}
+
+extern "C" int tsim_program_finalize(tsim_program *p, int32_t device) {
+  if (!p) return fail(TSIM_EINVAL, "program is NULL");
+  if (p->finalized) return fail(TSIM_ESTATE, "program already finalized");
+  // ---- validate the output bookkeeping (pipeline.py:83-102) ----
+  int pos = p->n_direct;
+  for (size_t ci = 0; ci < p->comps.size(); ++ci) {
+    HostComponent &c = p->comps[ci];
+    if ((int)c.levels.size() != c.n_levels)
+      return fail(TSIM_EINVAL, "component %zu has %zu of %d levels", ci, c.levels.size(), c.n_levels);
+    for (int j = 0; j < c.n_out; ++j) {
+      if (pos >= p->num_outputs || p->output_order[pos] != c.output_indices[j])
+        return fail(TSIM_EINVAL, "output_order[%d] does not match component %zu output %d", pos, ci, j);
+      ++pos;
+    }
+  }
+  if (pos != p->num_outputs)
+    return fail(TSIM_EINVAL, "direct entries + component outputs cover %d of %d outputs", pos, p->num_outputs);
+
+  // ---- build the image ----
+  std::vector<uint32_t> &img = p->img;
+  img.clear();
+  img.resize(16, 0u);  // word 0..15 reserved (keeps every offset non-zero)
+  p->direct_off = (int)img.size();
+  for (int j = 0; j < p->n_direct; ++j) {
+    img.push_back((uint32_t)p->direct_f[j] | ((p->direct_flips[j] ? 1u : 0u) << 31));
+    img.push_back((uint32_t)p->output_order[j]);
+  }
+  p->comp_off = (int)img.size();
+  img.resize(img.size() + p->comps.size() * C_WORDS, 0u);
+  p->total_keys = 0;
+  p->sampleable = true;
+  p->total_graphs = p->total_rows = 0;
+  p->level_off.clear();
+  p->level_base.clear();
+  p->comp_w.clear();
+  for (size_t ci = 0; ci < p->comps.size(); ++ci) {
+    HostComponent &c = p->comps[ci];
+    int maxP = 1;
+    for (auto &lv : c.levels) maxP = std::max(maxP, lv.P);
+    // sampling appends the trial bit at position F+i (< F+n_out)
+    const bool sequential = (c.n_levels == c.n_out + 1);
+    if (sequential) maxP = std::max(maxP, c.F + c.n_out);
+    const int W = round_w((maxP + 31) / 32);
+    if (W < 0) return fail(TSIM_ENOTSUP, "component %zu needs %d parameter bits (max %d)", ci, maxP, TSIM_MAX_PARAMS);
+    p->comp_w.push_back(W);
+    if (!sequential && c.n_out != 1) p->sampleable = false;
+    uint32_t rec[C_WORDS] = {0};
+    rec[C_NOUT] = (uint32_t)c.n_out;
+    rec[C_F] = (uint32_t)c.F;
+    rec[C_W] = (uint32_t)W;
+    rec[C_NLEVELS] = (uint32_t)c.n_levels;
+    rec[C_KEYBASE] = (uint32_t)p->total_keys;
+    rec[C_FSEL] = (uint32_t)img.size();
+    for (int v : c.f_selection) img.push_back((uint32_t)v);
+    rec[C_OUTPOS] = (uint32_t)img.size();
+    for (int v : c.output_indices) img.push_back((uint32_t)v);
+    // level records, then graph records + rows of every level
+    rec[C_LEVELS] = (uint32_t)img.size();
+    const size_t lrec = img.size();
+    img.resize(img.size() + (size_t)c.n_levels * L_WORDS, 0u);
+    p->level_base.push_back((int)p->level_off.size());
+    for (int k = 0; k < c.n_levels; ++k) {
+      HostLevel &h = c.levels[k];
+      pack_level(h, W);
+      // align graph records to 16 words (one s_load_dwordx16 each)
+      while (img.size() % 16) img.push_back(0u);
+      const uint32_t goff = (uint32_t)img.size();
+      img.insert(img.end(), h.graph_rec.begin(), h.graph_rec.end());
+      const uint32_t roff = (uint32_t)img.size();
+      img.insert(img.end(), h.rows.begin(), h.rows.end());
+      for (int g = 0; g < h.G; ++g) img[goff + (size_t)g * G_WORDS + G_ROWS] += roff;
+      uint32_t *lr = &img[lrec + (size_t)k * L_WORDS];
+      lr[L_G] = (uint32_t)h.G;
+      lr[L_GRAPHS] = goff;
+      lr[L_FLAGS] = h.approx ? TSIMK_LFLAG_APPROX : 0u;
+      lr[L_NPARAMS] = (uint32_t)h.P;
+      p->level_off.push_back((int)(lrec + (size_t)k * L_WORDS));
+      p->total_graphs += h.G;
+      p->total_rows += h.n_rows;
+    }
+    if (sequential) p->total_keys += c.n_out;
+    memcpy(&img[p->comp_off + ci * C_WORDS], rec, sizeof rec);
+  }
+  img.resize(img.size() + 64, 0u);  // tail padding: wide scalar loads may over-read
+  if (img.size() >= (1ull << 31)) return fail(TSIM_ENOTSUP, "program image too large");
+
+  // ---- upload ----
+  int ndev = 0;
+  HIP_TRY(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev) return fail(TSIM_EINVAL, "device %d out of range (%d visible)", device, ndev);
+  p->device = device;
+  HIP_TRY(hipSetDevice(device));
+  HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+  HIP_TRY(hipMalloc((void **)&p->d_img, img.size() * 4));
+  HIP_TRY(hipMemcpy(p->d_img, img.data(), img.size() * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMalloc((void **)&p->d_keys, std::max(1, p->total_keys) * 8));
+  HIP_TRY(hipMalloc((void **)&p->d_dev, std::max<size_t>(1, p->comps.size()) * 4));
+  HIP_TRY(hipMemset(p->d_dev, 0, std::max<size_t>(1, p->comps.size()) * 4));
+  p->finalized = true;
+  return TSIM_OK;
+}
+
+extern "C" void tsim_program_destroy(tsim_program *p) {
+  if (!p) return;
+  if (p->finalized && p->device >= 0) {
+    (void)hipSetDevice(p->device);
+    if (p->stream) (void)hipStreamSynchronize(p->stream);
+    for (hipEvent_t e : p->ev_pool) (void)hipEventDestroy(e);
+    for (void *s : p->scratch)
+      if (s) (void)hipFree(s);
+    if (p->d_img) (void)hipFree(p->d_img);
+    if (p->d_keys) (void)hipFree(p->d_keys);
+    if (p->d_dev) (void)hipFree(p->d_dev);
+    if (p->stream) (void)hipStreamDestroy(p->stream);
+  }
+  delete p;
+}
+
+extern "C" int tsim_program_info(const tsim_program *p, int32_t *n_components, int32_t *num_outputs,
+                                 int64_t *image_bytes, int64_t *total_graphs, int64_t *total_rows) {
+  if (!p) return fail(TSIM_EINVAL, "program is NULL");
+  if (n_components) *n_components = (int32_t)p->comps.size();
+  if (num_outputs) *num_outputs = p->num_outputs;
+  if (image_bytes) *image_bytes = (int64_t)p->img.size() * 4;
+  if (total_graphs) *total_graphs = p->total_graphs;
+  if (total_rows) *total_rows = p->total_rows;
+  return TSIM_OK;
+}
+
+// ---------------------------------------------------------------------------
+// launches
+// ---------------------------------------------------------------------------
+static int need_final(const tsim_program *p) {
+  if (!p) return fail(TSIM_EINVAL, "program is NULL");
+  if (!p->finalized) return fail(TSIM_ESTATE, "program not finalized");
+  return 0;
+}
+
+static int ensure_scratch(tsim_program *p, int slot, size_t bytes) {
+  if (p->scratch_sz[slot] >= bytes) return 0;
+  if (p->scratch[slot]) {
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    HIP_TRY(hipFree(p->scratch[slot]));
+    p->scratch[slot] = nullptr;
+    p->scratch_sz[slot] = 0;
+  }
+  size_t cap = std::max<size_t>(bytes, 256);
+  hipError_t e = hipMalloc(&p->scratch[slot], cap);
+  if (e != hipSuccess) return fail(TSIM_ENOMEM, "hipMalloc(%zu) failed: %s", cap, hipGetErrorString(e));
+  p->scratch_sz[slot] = cap;
+  return 0;
+}
+
+static int prof_event(tsim_program *p, hipStream_t s) {
+  if (p->ev_used == p->ev_pool.size()) {
+    hipEvent_t e;
+    HIP_TRY(hipEventCreate(&e));
+    p->ev_pool.push_back(e);
+  }
+  HIP_TRY(hipEventRecord(p->ev_pool[p->ev_used++], s));
+  return 0;
+}
+
+static int prof_drain(tsim_program *p) {
+  for (size_t i = 0; i + 1 < p->ev_used; i += 2) {
+    HIP_TRY(hipEventSynchronize(p->ev_pool[i + 1]));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, p->ev_pool[i], p->ev_pool[i + 1]));
+    p->prof_ms += ms;
+    p->prof_launches += 1;
+  }
+  p->ev_used = 0;
+  return 0;
+}
+
+static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_t num_f, uint32_t key_hi,
+                         uint32_t key_lo, int64_t shot_offset, uint64_t *d_out, float *d_dev, hipStream_t s) {
+  if (!p->sampleable) return fail(TSIM_ESTATE, "program has joint-mode components (evaluate-only)");
+  if (B < 0 || num_f < 0 || shot_offset < 0) return fail(TSIM_EINVAL, "negative B/num_f/shot_offset");
+  if (p->max_f_index >= num_f)
+    return fail(TSIM_EINVAL, "program references f index %d but num_f=%d", p->max_f_index, num_f);
+  if (B == 0 || p->num_outputs == 0) return 0;
+  if (!d_f && num_f > 0) return fail(TSIM_EINVAL, "f buffer is NULL");
+  if (!d_out) return fail(TSIM_EINVAL, "out buffer is NULL");
+  // per-output subkeys: key, subkey = split(key) once per output, threaded through the
+  // components in processing order (sampler.py:74,147-148)
+  if (p->total_keys > 0) {
+    hipLaunchKernelGGL(k_keygen, dim3(1), dim3(1), 0, s, key_hi, key_lo, p->total_keys, p->d_keys);
+    HIP_TRY(hipGetLastError());
+  }
+  SampleArgs a;
+  a.img = p->d_img;
+  a.f = d_f;
+  a.out = d_out;
+  a.subkeys = p->d_keys;
+  a.norm_dev = d_dev;
+  a.B = B;
+  a.shot_offset = shot_offset;
+  a.WF = std::max(1, (num_f + 63) / 64);
+  a.WO = (p->num_outputs + 63) / 64;
+  a.n_direct = p->n_direct;
+  a.direct_off = p->direct_off;
+  a.n_comp = (int)p->comps.size();
+  a.comp_off = p->comp_off;
+  if (num_f == 0) a.WF = 0;
+  int block = 256;
+  size_t lds = (size_t)(2 * a.WF + 2 * a.WO) * block * 4;
+  if (lds > 60 * 1024) { block = 64; lds = (size_t)(2 * a.WF + 2 * a.WO) * block * 4; }
+  if (lds > 60 * 1024) return fail(TSIM_ENOTSUP, "num_f + num_outputs too large for LDS staging (%zu B)", lds);
+  const long long grid = (B + block - 1) / block;
+  if (grid > 0x7FFFFFFFll) return fail(TSIM_ENOTSUP, "batch too large");
+  if (p->profiling) { int r = prof_event(p, s); if (r) return r; }
+  int wmax = 1;
+  for (int w : p->comp_w) wmax = std::max(wmax, w);
+  switch (wmax) {
+#define TSIM_LAUNCH(WV) \
+  case WV: hipLaunchKernelGGL(k_sample<WV>, dim3((unsigned)grid), dim3(block), lds, s, a); break;
+    TSIM_LAUNCH(1) TSIM_LAUNCH(2) TSIM_LAUNCH(3) TSIM_LAUNCH(4) TSIM_LAUNCH(6) TSIM_LAUNCH(8)
+    TSIM_LAUNCH(12) TSIM_LAUNCH(16)
+#undef TSIM_LAUNCH
+    default: return fail(TSIM_ENOTSUP, "unsupported word count %d", wmax);
+  }
+  HIP_TRY(hipGetLastError());
+  if (p->profiling) { int r = prof_event(p, s); if (r) return r; }
+  return 0;
+}
+
+extern "C" int tsim_sample_batch_device(tsim_program *p, const uint64_t *d_f, int64_t B, int32_t num_f,
+                                        uint32_t key_hi, uint32_t key_lo, int64_t shot_offset,
+                                        uint64_t *d_out, float *d_max_norm_dev, void *stream) {
+  if (int r = need_final(p)) return r;
+  if (int r = set_device(p)) return r;
+  hipStream_t s = stream ? (hipStream_t)stream : p->stream;
+  return launch_sample(p, d_f, B, num_f, key_hi, key_lo, shot_offset, d_out, d_max_norm_dev, s);
+}
+
+static int launch_pack(tsim_program *p, const uint8_t *d_in, int64_t B, int32_t nbits, uint64_t *d_out, hipStream_t s) {
+  const int WQ = (nbits + 63) / 64;
+  const long long n = B * WQ;
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_pack_bits, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_in, d_out, (long long)B, nbits, WQ);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+static int launch_unpack(tsim_program *p, const uint64_t *d_in, int64_t B, int32_t nbits, uint8_t *d_out, hipStream_t s) {
+  const int WQ = (nbits + 63) / 64;
+  const long long n = B * (long long)nbits;
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_unpack_bits, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_in, d_out, (long long)B, nbits, WQ);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" int tsim_pack_bits_device(tsim_program *p, const uint8_t *d_in, int64_t B, int32_t nbits,
+                                     uint64_t *d_out, void *stream) {
+  if (int r = need_final(p)) return r;
+  if (int r = set_device(p)) return r;
+  if (B < 0 || nbits < 0) return fail(TSIM_EINVAL, "negative size");
+  return launch_pack(p, d_in, B, nbits, d_out, stream ? (hipStream_t)stream : p->stream);
+}
+
+extern "C" int tsim_unpack_bits_device(tsim_program *p, const uint64_t *d_in, int64_t B, int32_t nbits,
+                                       uint8_t *d_out, void *stream) {
+  if (int r = need_final(p)) return r;
+  if (int r = set_device(p)) return r;
+  if (B < 0 || nbits < 0) return fail(TSIM_EINVAL, "negative size");
+  return launch_unpack(p, d_in, B, nbits, d_out, stream ? (hipStream_t)stream : p->stream);
+}
+
+extern "C" int tsim_sample_batch(tsim_program *p, const uint8_t *f, int64_t B, int32_t num_f, uint32_t key_hi,
+                                 uint32_t key_lo, int64_t shot_offset, uint8_t *out, int32_t out_packed,
+                                 float *max_norm_dev) {
+  if (int r = need_final(p)) return r;
+  if (int r = set_device(p)) return r;
+  if (B < 0 || num_f < 0) return fail(TSIM_EINVAL, "negative B/num_f");
+  if (B == 0 || p->num_outputs == 0) return 0;
+  if (!out) return fail(TSIM_EINVAL, "out is NULL");
+  if (!f && num_f > 0) return fail(TSIM_EINVAL, "f is NULL");
+  const int WF = std::max(1, (num_f + 63) / 64), WO = (p->num_outputs + 63) / 64;
+  hipStream_t s = p->stream;
+  if (int r = ensure_scratch(p, 0, (size_t)B * std::max(1, num_f))) return r;
+  if (int r = ensure_scratch(p, 1, (size_t)B * WF * 8)) return r;
+  if (int r = ensure_scratch(p, 2, (size_t)B * WO * 8)) return r;
+  if (num_f > 0) {
+    HIP_TRY(hipMemcpyAsync(p->scratch[0], f, (size_t)B * num_f, hipMemcpyHostToDevice, s));
+    if (int r = launch_pack(p, (const uint8_t *)p->scratch[0], B, num_f, (uint64_t *)p->scratch[1], s)) return r;
+  }
+  if (int r = launch_sample(p, (const uint64_t *)p->scratch[1], B, num_f, key_hi, key_lo, shot_offset,
+                            (uint64_t *)p->scratch[2], p->d_dev, s))
+    return r;
+  if (out_packed) {
+    HIP_TRY(hipMemcpyAsync(out, p->scratch[2], (size_t)B * WO * 8, hipMemcpyDeviceToHost, s));
+  } else {
+    if (int r = ensure_scratch(p, 3, (size_t)B * p->num_outputs)) return r;
+    if (int r = launch_unpack(p, (const uint64_t *)p->scratch[2], B, p->num_outputs, (uint8_t *)p->scratch[3], s)) return r;
+    HIP_TRY(hipMemcpyAsync(out, p->scratch[3], (size_t)B * p->num_outputs, hipMemcpyDeviceToHost, s));
+  }
+  if (max_norm_dev && shot_offset == 0 && !p->comps.empty())
+    HIP_TRY(hipMemcpyAsync(max_norm_dev, p->d_dev, p->comps.size() * 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  return TSIM_OK;
+}
+
+template <int W>
+static void launch_eval_w(const EvalArgs &a, hipStream_t s) {
+  hipLaunchKernelGGL(k_evaluate<W>, dim3((unsigned)((a.B + 255) / 256)), dim3(256), 0, s, a);
+}
+
+extern "C" int tsim_evaluate(tsim_program *p, int32_t component, int32_t level, const uint8_t *params,
+                             int64_t B, float *re, float *im, int32_t *coeffs_power) {
+  if (int r = need_final(p)) return r;
+  if (int r = set_device(p)) return r;
+  if (component < 0 || component >= (int)p->comps.size()) return fail(TSIM_EINVAL, "bad component %d", component);
+  const HostComponent &c = p->comps[component];
+  if (level < 0 || level >= c.n_levels) return fail(TSIM_EINVAL, "bad level %d", level);
+  if (B < 0) return fail(TSIM_EINVAL, "negative B");
+  if (B == 0) return 0;
+  if (!re || !im) return fail(TSIM_EINVAL, "output is NULL");
+  const int P = c.levels[level].P, W = p->comp_w[component];
+  if (P > 0 && !params) return fail(TSIM_EINVAL, "params is NULL");
+  // host-side pack to W 32-bit words per row (astype(bool): nonzero == 1)
+  std::vector<uint32_t> x((size_t)B * W, 0u);
+  for (int64_t r = 0; r < B; ++r) {
+    const uint8_t *src = params + (size_t)r * P;
+    uint32_t *dst = &x[(size_t)r * W];
+    for (int i = 0; i < P; ++i)
+      if (src[i]) dst[i >> 5] |= 1u << (i & 31);
+  }
+  hipStream_t s = p->stream;
+  if (int r = ensure_scratch(p, 0, x.size() * 4)) return r;
+  if (int r = ensure_scratch(p, 1, (size_t)B * 8)) return r;
+  if (int r = ensure_scratch(p, 2, (size_t)B * 20)) return r;
+  HIP_TRY(hipMemcpyAsync(p->scratch[0], x.data(), x.size() * 4, hipMemcpyHostToDevice, s));
+  EvalArgs a;
+  a.img = p->d_img;
+  a.x = (const uint32_t *)p->scratch[0];
+  a.re = (float *)p->scratch[1];
+  a.im = a.re + B;
+  a.exact = coeffs_power ? (int *)p->scratch[2] : nullptr;
+  a.B = B;
+  a.level_off = p->level_off[p->level_base[component] + level];
+  a.W = W;
+  switch (W) {
+    case 1: launch_eval_w<1>(a, s); break;
+    case 2: launch_eval_w<2>(a, s); break;
+    case 3: launch_eval_w<3>(a, s); break;
+    case 4: launch_eval_w<4>(a, s); break;
+    case 6: launch_eval_w<6>(a, s); break;
+    case 8: launch_eval_w<8>(a, s); break;
+    case 12: launch_eval_w<12>(a, s); break;
+    case 16: launch_eval_w<16>(a, s); break;
+    default: return fail(TSIM_ENOTSUP, "unsupported word count %d", W);
+  }
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(re, a.re, (size_t)B * 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(im, a.im, (size_t)B * 4, hipMemcpyDeviceToHost, s));
+  if (coeffs_power) HIP_TRY(hipMemcpyAsync(coeffs_power, a.exact, (size_t)B * 20, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  return TSIM_OK;
+}
+
+// ---------------------------------------------------------------------------
+// plumbing
+// ---------------------------------------------------------------------------
+extern "C" int tsim_device_count(int32_t *count) {
+  if (!count) return fail(TSIM_EINVAL, "count is NULL");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    *count = 0;
+    return fail(TSIM_EHIP, "hipGetDeviceCount failed: %s", hipGetErrorString(e));
+  }
+  *count = n;
+  return TSIM_OK;
+}
+
+extern "C" int tsim_malloc_device(tsim_program *p, int64_t nbytes, void **d_ptr) {
+  if (int r = need_final(p)) return r;
+  if (int r = set_device(p)) return r;
+  if (!d_ptr || nbytes < 0) return fail(TSIM_EINVAL, "bad argument");
+  hipError_t e = hipMalloc(d_ptr, (size_t)std::max<int64_t>(nbytes, 1));
+  if (e != hipSuccess) return fail(TSIM_ENOMEM, "hipMalloc(%lld) failed: %s", (long long)nbytes, hipGetErrorString(e));
+  return TSIM_OK;
+}
+
+extern "C" int tsim_free_device(tsim_program *p, void *d_ptr) {
+  if (int r = need_final(p)) return r;
+  if (int r = set_device(p)) return r;
+  HIP_TRY(hipFree(d_ptr));
+  return TSIM_OK;
+}
+
+extern "C" int tsim_malloc_pinned(int64_t nbytes, void **h_ptr) {
+  if (!h_ptr || nbytes < 0) return fail(TSIM_EINVAL, "bad argument");
+  hipError_t e = hipHostMalloc(h_ptr, (size_t)std::max<int64_t>(nbytes, 1), hipHostMallocDefault);
+  if (e != hipSuccess) return fail(TSIM_ENOMEM, "hipHostMalloc(%lld) failed: %s", (long long)nbytes, hipGetErrorString(e));
+  return TSIM_OK;
+}
+
+extern "C" int tsim_free_pinned(void *h_ptr) {
+  HIP_TRY(hipHostFree(h_ptr));
+  return TSIM_OK;
+}
+
+extern "C" int tsim_memcpy_h2d(tsim_program *p, void *d_dst, const void *h_src, int64_t nbytes) {
+  if (int r = need_final(p)) return r;
+  if (int r = set_device(p)) return r;
+  if (nbytes < 0) return fail(TSIM_EINVAL, "negative size");
+  if (nbytes == 0) return TSIM_OK;
+  HIP_TRY(hipMemcpyAsync(d_dst, h_src, (size_t)nbytes, hipMemcpyHostToDevice, p->stream));
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  return TSIM_OK;
+}
+
+extern "C" int tsim_memcpy_d2h(tsim_program *p, void *h_dst, const void *d_src, int64_t nbytes) {
+  if (int r = need_final(p)) return r;
+  if (int r = set_device(p)) return r;
+  if (nbytes < 0) return fail(TSIM_EINVAL, "negative size");
+  if (nbytes == 0) return TSIM_OK;
+  HIP_TRY(hipMemcpyAsync(h_dst, d_src, (size_t)nbytes, hipMemcpyDeviceToHost, p->stream));
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  return TSIM_OK;
+}
+
+extern "C" int tsim_synchronize(tsim_program *p) {
+  if (int r = need_final(p)) return r;
+  if (int r = set_device(p)) return r;
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  return TSIM_OK;
+}
+
+extern "C" int tsim_profile_enable(tsim_program *p, int32_t on) {
+  if (int r = need_final(p)) return r;
+  if (int r = set_device(p)) return r;
+  if (!on && p->ev_used) { if (int r = prof_drain(p)) return r; }
+  p->profiling = on != 0;
+  return TSIM_OK;
+}
+
+extern "C" int tsim_profile_read(tsim_program *p, double *kernel_ms, int64_t *launches, int32_t reset) {
+  if (int r = need_final(p)) return r;
+  if (int r = set_device(p)) return r;
+  if (int r = prof_drain(p)) return r;
+  if (kernel_ms) *kernel_ms = p->prof_ms;
+  if (launches) *launches = p->prof_launches;
+  if (reset) { p->prof_ms = 0.0; p->prof_launches = 0; }
+  return TSIM_OK;
+}

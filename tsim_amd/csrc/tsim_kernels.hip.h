@@ -1,0 +1,490 @@
+// tsim_kernels.hip.h - gfx950 device code of the stabilizer-rank sampling engine.
+//
+// One lane = one shot.  The whole autoregressive loop of a batch
+// (reference: src/tsim/sampler.py:28-167) runs in ONE kernel: the shot's packed
+// f row is staged in LDS, every level's GF(2) rows are wave-uniform and come
+// in through the scalar data cache (s_load -> SGPR operands of v_and/v_bcnt),
+// parities feed the exact Z[omega]*2^k arithmetic held in VGPRs
+// (reference: src/tsim/core/exact_scalar.py), the marginal is formed in float32
+// and the Bernoulli draw uses an in-kernel Threefry-2x32 keyed by the global
+// in-batch shot index, so results do not depend on how a batch is sharded.
+//
+// Integer semantics deliberately mirror the reference's int32 arithmetic
+// (wrap-around, one /2 step per multiply/add, fix-point at the end of each
+// scan) so that integer amplitudes are bit-identical, not just equal in value.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace tsimk {
+
+// program image is read through the constant address space => scalar loads
+typedef const __attribute__((address_space(4))) uint32_t *cptr;
+
+// ---- image layout constants (uint32 words) --------------------------------
+// component record
+enum { C_NOUT = 0, C_F, C_W, C_FSEL, C_LEVELS, C_OUTPOS, C_KEYBASE, C_NLEVELS, C_WORDS = 8 };
+// level record
+enum { L_G = 0, L_GRAPHS, L_FLAGS, L_NPARAMS, L_WORDS = 4 };
+// graph record
+enum {
+  G_NA = 0, G_NB, G_NC, G_ND, G_ROWS, G_PHASE, G_FFA, G_FFB, G_FFC, G_FFD, G_POW2,
+  G_APRE, G_APIM, G_FLAGS, G_WORDS = 16
+};
+#define TSIMK_LFLAG_APPROX 1u
+#define TSIMK_GFLAG_FF_IS_ONE 1u
+
+struct SampleArgs {
+  const uint32_t *img;      // program image
+  const uint64_t *f;        // [B, WF] packed error-mechanism rows
+  uint64_t *out;            // [B, WO] packed outputs
+  const uint32_t *subkeys;  // [total compiled outputs, 2] Threefry subkeys
+  float *norm_dev;          // [n_components] or nullptr
+  long long B;              // rows in this launch
+  long long shot_offset;    // in-batch index of row 0
+  int WF, WO;               // 64-bit words per f row / out row
+  int n_direct, direct_off; // direct table: (src | flip<<31, dst) pairs
+  int n_comp, comp_off;
+};
+
+struct EvalArgs {
+  const uint32_t *img;
+  const uint32_t *x;        // [B, W] packed params (32-bit words)
+  float *re, *im;           // [B]
+  int *exact;               // [B,5] or nullptr
+  long long B;
+  int level_off;            // offset of the level record
+  int W;
+};
+
+// ---------------------------------------------------------------------------
+// exact scalar helpers (int32, wrap-around == XLA)
+// ---------------------------------------------------------------------------
+
+// exact_scalar.py:42-49
+__device__ __forceinline__ void reduce1(int &a, int &b, int &c, int &d, int &p) {
+  int o = a | b | c | d;
+  int sh = (((o & 1) == 0) & (o != 0)) ? 1 : 0;
+  a >>= sh; b >>= sh; c >>= sh; d >>= sh;
+  p += sh;
+}
+
+// fix-point of reduce1 (exact_scalar.py:119-136): strip all common factors of 2
+__device__ __forceinline__ void canon(int &a, int &b, int &c, int &d, int &p) {
+  int o = a | b | c | d;
+  int tz = (o != 0) ? __builtin_ctz((unsigned)o) : 0;
+  a >>= tz; b >>= tz; c >>= tz; d >>= tz;
+  p += tz;
+}
+
+// exact_scalar.py:19-39 on basis (1, w, i, conj w)
+__device__ __forceinline__ void zmul(int &a1, int &b1, int &c1, int &d1, int a2, int b2, int c2,
+                                     int d2) {
+  unsigned ua1 = a1, ub1 = b1, uc1 = c1, ud1 = d1, ua2 = a2, ub2 = b2, uc2 = c2, ud2 = d2;
+  unsigned A = ua1 * ua2 + ub1 * ud2 - uc1 * uc2 + ud1 * ub2;
+  unsigned B = ua1 * ub2 + ub1 * ua2 + uc1 * ud2 + ud1 * uc2;
+  unsigned C = ua1 * uc2 + ub1 * ub2 + uc1 * ua2 - ud1 * ud2;
+  unsigned D = ua1 * ud2 - ub1 * uc2 - uc1 * ub2 + ud1 * ua2;
+  a1 = (int)A; b1 = (int)B; c1 = (int)C; d1 = (int)D;
+}
+
+// x << s with XLA semantics (s >= 32 -> 0), s >= 0
+__device__ __forceinline__ int shl_sat(int x, int s) {
+  return (s >= 32) ? 0 : (int)((unsigned)x << (s & 31));
+}
+
+// float32 constants of exact_scalar.py:15-16
+#define TSIMK_E4 0.70710677f
+
+// exact_scalar.py:87-89,218-222: one rounding per operation, no FMA
+__device__ __forceinline__ void to_complex(int a, int b, int c, int d, int p, float &re, float &im) {
+  float fa = (float)a, fb = (float)b, fc = (float)c, fd = (float)d;
+  float r = __fadd_rn(__fadd_rn(fa, __fmul_rn(fb, TSIMK_E4)), __fmul_rn(fd, TSIMK_E4));
+  float i = __fadd_rn(__fadd_rn(__fmul_rn(fb, TSIMK_E4), fc), __fmul_rn(fd, -TSIMK_E4));
+  float s = ldexpf(1.0f, p);
+  re = __fmul_rn(r, s);
+  im = __fmul_rn(i, s);
+}
+
+// jnp.abs(complex64): max * sqrt(1 + (min/max)^2)
+__device__ __forceinline__ float cabs32(float re, float im) {
+  float ar = fabsf(re), ai = fabsf(im);
+  float mx = fmaxf(ar, ai), mn = fminf(ar, ai);
+  float r = __fdiv_rn(mn, mx);
+  float v = __fmul_rn(mx, __fsqrt_rn(__fadd_rn(1.0f, __fmul_rn(r, r))));
+  if (mx == 0.0f) v = 0.0f;
+  if (isinf(mx)) v = INFINITY;
+  if (isnan(re) || isnan(im)) v = NAN;
+  return v;
+}
+
+// ---------------------------------------------------------------------------
+// Threefry-2x32-20 (jax.random, threefry_partitionable)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
+
+__device__ __forceinline__ void threefry2x32(uint32_t k0, uint32_t k1, uint32_t &x0, uint32_t &x1) {
+  const uint32_t k2 = k0 ^ k1 ^ 0x1BD11BDAu;
+  x0 += k0; x1 += k1;
+#define TF_R(r) x0 += x1; x1 = rotl32(x1, r); x1 ^= x0;
+  TF_R(13) TF_R(15) TF_R(26) TF_R(6)
+  x0 += k1; x1 += k2 + 1u;
+  TF_R(17) TF_R(29) TF_R(16) TF_R(24)
+  x0 += k2; x1 += k0 + 2u;
+  TF_R(13) TF_R(15) TF_R(26) TF_R(6)
+  x0 += k0; x1 += k1 + 3u;
+  TF_R(17) TF_R(29) TF_R(16) TF_R(24)
+  x0 += k1; x1 += k2 + 4u;
+  TF_R(13) TF_R(15) TF_R(26) TF_R(6)
+  x0 += k2; x1 += k0 + 5u;
+#undef TF_R
+}
+
+// jax.random.uniform(key, (B,), float32)[s]
+__device__ __forceinline__ float uniform01(uint32_t k0, uint32_t k1, unsigned long long s) {
+  uint32_t x0 = (uint32_t)(s >> 32), x1 = (uint32_t)s;
+  threefry2x32(k0, k1, x0, x1);
+  uint32_t bits = x0 ^ x1;
+  float f = __uint_as_float((bits >> 9) | 0x3F800000u) - 1.0f;
+  return fmaxf(0.0f, f);
+}
+
+// ---------------------------------------------------------------------------
+// GF(2) row parity: popcount(AND) over W 32-bit words (+ constant)
+// ---------------------------------------------------------------------------
+template <int W>
+__device__ __forceinline__ uint32_t row_par(cptr r, const uint32_t (&x)[W], uint32_t c) {
+  uint32_t t = r[0] & x[0];
+#pragma unroll
+  for (int w = 1; w < W; ++w) t ^= r[w] & x[w];
+  return (uint32_t)__builtin_popcount(t) + c;  // caller masks bit 0
+}
+
+// ---------------------------------------------------------------------------
+// evaluate() of one level for one shot (compile/evaluate.py:15-59)
+// ---------------------------------------------------------------------------
+template <int W>
+__device__ __forceinline__ void eval_level(cptr img, cptr lvl, const uint32_t (&x)[W], float &out_re,
+                                           float &out_im, int *exact5) {
+  const uint32_t G = lvl[L_G];
+  const bool approx = (lvl[L_FLAGS] & TSIMK_LFLAG_APPROX) != 0;
+  cptr gr = img + lvl[L_GRAPHS];
+
+  int sa = 0, sb = 0, sc = 0, sd = 0, sp = 0;  // running exact sum
+  float fre = 0.0f, fim = 0.0f;                // running float sum (approximate branch)
+
+  for (uint32_t g = 0; g < G; ++g, gr += G_WORDS) {
+    const uint32_t nA = gr[G_NA], nB = gr[G_NB], nC = gr[G_NC], nD = gr[G_ND];
+    cptr row = img + gr[G_ROWS];
+
+    // ---- NodePhases (terms.py:56-73): prod_t (1 + w^(4 par + phase)) ----
+    int a = 1, b = 0, c = 0, d = 0, p = 0;
+    for (uint32_t t = 0; t < nA; ++t) {
+      const uint32_t ph = row[0];
+      const int par = (int)(row_par<W>(row + 1, x, ph >> 2) & 1u);
+      row += 1 + W;
+      // acc *= (1 + s w^j), j = ph & 3 (wave-uniform), s = par ? -1 : +1
+      int ra, rb, rc, rd;
+      switch (ph & 3u) {
+        case 0: ra = a; rb = b; rc = c; rd = d; break;
+        case 1: ra = d; rb = a; rc = b; rd = -c; break;
+        case 2: ra = -c; rb = d; rc = a; rd = -b; break;
+        default: ra = -b; rb = -c; rc = d; rd = -a; break;
+      }
+      const int nm = -par;
+      a += (ra ^ nm) - nm; b += (rb ^ nm) - nm; c += (rc ^ nm) - nm; d += (rd ^ nm) - nm;
+      if (t > 0) reduce1(a, b, c, d, p);  // the scan's first element is taken as is
+    }
+    canon(a, b, c, d, p);
+
+    // ---- HalfPiPhases (terms.py:94-107) + static phase: exponent of w ----
+    uint32_t k = gr[G_PHASE];
+    for (uint32_t t = 0; t < nB; ++t) {
+      const uint32_t coeff = row[0];
+      k += (row_par<W>(row + 1, x, 0) & 1u) * coeff;
+      row += 1 + W;
+    }
+
+    // ---- PiProducts (terms.py:125-144): (-1)^(sum psi*phi) ----
+    uint32_t e = 0;
+    for (uint32_t t = 0; t < nC; ++t) {
+      const uint32_t cc = row[0];
+      const uint32_t psi = row_par<W>(row + 1, x, cc & 1u);
+      const uint32_t phi = row_par<W>(row + 1 + W, x, cc >> 1);
+      e ^= psi & phi;
+      row += 1 + 2 * W;
+    }
+    k += (e & 1u) << 2;
+
+    // ---- PhasePairs (terms.py:164-187): prod_t (1 + w^al + w^be - w^(al+be)) ----
+    if (nD) {
+      int da = 1, db = 0, dc = 0, dd = 0, dp = 0;
+      for (uint32_t t = 0; t < nD; ++t) {
+        const uint32_t pa = row_par<W>(row + 4, x, 0) & 1u;
+        const uint32_t pb = row_par<W>(row + 4 + W, x, 0) & 1u;
+        const uint32_t w0 = pa ? row[1] : row[0];
+        const uint32_t w1 = pa ? row[3] : row[2];
+        const uint32_t tw = pb ? w1 : w0;  // packed int8 x4 term for (pa, pb)
+        row += 4 + 2 * W;
+        const int ta = (int)(int8_t)(tw), tb = (int)(int8_t)(tw >> 8), tc = (int)(int8_t)(tw >> 16),
+                  td = (int)(int8_t)(tw >> 24);
+        if (t == 0) {
+          da = ta; db = tb; dc = tc; dd = td;
+        } else {
+          zmul(da, db, dc, dd, ta, tb, tc, td);
+          reduce1(da, db, dc, dd, dp);
+        }
+      }
+      canon(da, db, dc, dd, dp);
+      zmul(a, b, c, d, da, db, dc, dd);
+      p += dp;
+    }
+
+    // ---- static prefactor (evaluate.py:37-50): * w^phase * floatfactor ----
+    if (!(gr[G_FLAGS] & TSIMK_GFLAG_FF_IS_ONE))
+      zmul(a, b, c, d, (int)gr[G_FFA], (int)gr[G_FFB], (int)gr[G_FFC], (int)gr[G_FFD]);
+    // rotate by w^k (k differs per lane)
+    {
+      const bool k1 = (k & 1u) != 0, k2 = (k & 2u) != 0;
+      int t0 = k1 ? d : a, t1 = k1 ? a : b, t2 = k1 ? b : c, t3 = k1 ? -c : d;
+      a = k2 ? -t2 : t0; b = k2 ? t3 : t1; c = k2 ? t0 : t2; d = k2 ? -t1 : t3;
+      const int nm = -(int)((k >> 2) & 1u);
+      a = (a ^ nm) - nm; b = (b ^ nm) - nm; c = (c ^ nm) - nm; d = (d ^ nm) - nm;
+    }
+
+    if (!approx) {
+      // ---- exact sum over graphs (exact_scalar.py:74-84,173-189) ----
+      p += (int)gr[G_POW2];
+      if (g == 0) {
+        sa = a; sb = b; sc = c; sd = d; sp = p;
+      } else {
+        const int d1 = max(sp - p, 0), d2 = max(p - sp, 0);
+        sa = (int)((unsigned)shl_sat(sa, d1) + (unsigned)shl_sat(a, d2));
+        sb = (int)((unsigned)shl_sat(sb, d1) + (unsigned)shl_sat(b, d2));
+        sc = (int)((unsigned)shl_sat(sc, d1) + (unsigned)shl_sat(c, d2));
+        sd = (int)((unsigned)shl_sat(sd, d1) + (unsigned)shl_sat(d, d2));
+        sp = min(sp, p);
+        reduce1(sa, sb, sc, sd, sp);
+      }
+    } else {
+      // ---- approximate branch (evaluate.py:56-59), sequential in g ----
+      float zr, zi;
+      to_complex(a, b, c, d, p, zr, zi);
+      const float ar = __uint_as_float(gr[G_APRE]), ai = __uint_as_float(gr[G_APIM]);
+      const float tr = __fsub_rn(__fmul_rn(zr, ar), __fmul_rn(zi, ai));
+      const float ti = __fadd_rn(__fmul_rn(zr, ai), __fmul_rn(zi, ar));
+      const float s = ldexpf(1.0f, (int)gr[G_POW2]);
+      fre = __fadd_rn(fre, __fmul_rn(tr, s));
+      fim = __fadd_rn(fim, __fmul_rn(ti, s));
+    }
+  }
+
+  if (!approx) {
+    canon(sa, sb, sc, sd, sp);
+    to_complex(sa, sb, sc, sd, sp, out_re, out_im);
+    if (exact5) { exact5[0] = sa; exact5[1] = sb; exact5[2] = sc; exact5[3] = sd; exact5[4] = sp; }
+  } else {
+    out_re = fre; out_im = fim;
+    if (exact5) { exact5[0] = exact5[1] = exact5[2] = exact5[3] = exact5[4] = 0; }
+  }
+}
+
+// jnp.maximum semantics (NaN propagates)
+__device__ __forceinline__ float nanmax(float a, float b) {
+  return (isnan(a) || isnan(b)) ? NAN : fmaxf(a, b);
+}
+
+// ---------------------------------------------------------------------------
+// one component: _sample_component (sampler.py:28-81)
+// ---------------------------------------------------------------------------
+template <int W>
+__device__ __forceinline__ void run_component(const SampleArgs &A, cptr img, cptr comp, const uint32_t *lds_f,
+                                              uint32_t *lds_o, int nthr, unsigned long long shot,
+                                              bool check_lane, int comp_index) {
+  const uint32_t n_out = comp[C_NOUT], F = comp[C_F];
+  cptr fsel = img + comp[C_FSEL];
+  cptr levels = img + comp[C_LEVELS];
+  cptr outpos = img + comp[C_OUTPOS];
+  const uint32_t *keys = A.subkeys + 2 * comp[C_KEYBASE];
+
+  // K1: gather the component's f bits (sampler.py:48) from the LDS-staged row
+  uint32_t x[W];
+#pragma unroll
+  for (int w = 0; w < W; ++w) {
+    uint32_t v = 0;
+    const int lo = w * 32;
+    const int hi = min((int)F, lo + 32);
+    for (int j = lo; j < hi; ++j) {
+      const uint32_t src = fsel[j];
+      v |= ((lds_f[(src >> 5) * nthr] >> (src & 31u)) & 1u) << (j - lo);
+    }
+    x[w] = v;
+  }
+
+  float re, im;
+  eval_level<W>(img, levels, x, re, im, nullptr);  // normalisation (sampler.py:54)
+  float prev = cabs32(re, im);
+  float maxdev = 0.0f;
+
+  for (uint32_t i = 0; i < n_out; ++i) {
+    cptr lvl = levels + (i + 1) * L_WORDS;
+    const uint32_t bitpos = F + i;
+    const uint32_t wi = bitpos >> 5, bm = 1u << (bitpos & 31u);
+    // trial bit = 1 (sampler.py:65); the check lane also evaluates trial bit = 0 (:66)
+    float pr[2] = {0.0f, 0.0f};
+    const int npass = check_lane ? 2 : 1;
+    for (int pass = 0; pass < npass; ++pass) {
+#pragma unroll
+      for (int w = 0; w < W; ++w)
+        if ((uint32_t)w == wi) x[w] = (pass == 0) ? (x[w] | bm) : (x[w] & ~bm);
+      eval_level<W>(img, lvl, x, re, im, nullptr);
+      const float v = cabs32(re, im);
+      if (pass == 0) pr[0] = v; else pr[1] = v;
+    }
+    const float p1 = pr[0];
+    if (check_lane) {
+      const float norm = __fdiv_rn(__fadd_rn(pr[1], p1), prev);  // sampler.py:71
+      maxdev = nanmax(maxdev, fabsf(__fsub_rn(norm, 1.0f)));      // sampler.py:72
+    }
+    // sampler.py:74-79
+    const float u = uniform01(keys[2 * i], keys[2 * i + 1], shot);
+    const bool bit = u < __fdiv_rn(p1, prev);
+#pragma unroll
+    for (int w = 0; w < W; ++w)
+      if ((uint32_t)w == wi) x[w] = bit ? (x[w] | bm) : (x[w] & ~bm);
+    prev = bit ? p1 : __fsub_rn(prev, p1);
+    // K15: scatter to the final column (sampler.py:164-166)
+    const uint32_t dst = outpos[i];
+    lds_o[(dst >> 5) * nthr] |= (bit ? 1u : 0u) << (dst & 31u);
+  }
+  if (check_lane && A.norm_dev) A.norm_dev[comp_index] = maxdev;
+}
+
+// ---------------------------------------------------------------------------
+// sample_program for one batch (sampler.py:117-167), one lane per shot
+// ---------------------------------------------------------------------------
+extern __shared__ uint32_t tsimk_lds[];
+
+// WMAX = largest per-component word count in the program: the kernel is instantiated per
+// WMAX so that narrow programs are not charged the registers of the wide variants.
+template <int WMAX>
+__global__ void __launch_bounds__(256) k_sample(SampleArgs A) {
+  const int nthr = blockDim.x;
+  const long long row = (long long)blockIdx.x * nthr + threadIdx.x;
+  if (row >= A.B) return;  // no barriers below: every lane owns its LDS columns
+  const unsigned long long shot = (unsigned long long)(A.shot_offset + row);
+  const bool check_lane = (shot == 0ull);
+  cptr img = (cptr)(uintptr_t)A.img;
+
+  const int WF32 = 2 * A.WF, WO32 = 2 * A.WO;
+  uint32_t *lds_f = tsimk_lds + threadIdx.x;                // [WF32][nthr]
+  uint32_t *lds_o = tsimk_lds + WF32 * nthr + threadIdx.x;  // [WO32][nthr]
+
+  // stage this shot's packed f row (the only per-shot HBM read)
+  const uint64_t *frow = A.f + row * A.WF;
+  for (int w = 0; w < A.WF; ++w) {
+    const uint64_t v = frow[w];
+    lds_f[(2 * w) * nthr] = (uint32_t)v;
+    lds_f[(2 * w + 1) * nthr] = (uint32_t)(v >> 32);
+  }
+  for (int w = 0; w < WO32; ++w) lds_o[w * nthr] = 0u;
+
+  // K14: direct outputs f[idx] ^ flip (sampler.py:140-145)
+  cptr dt = img + A.direct_off;
+  for (int j = 0; j < A.n_direct; ++j) {
+    const uint32_t s = dt[2 * j], dst = dt[2 * j + 1];
+    const uint32_t src = s & 0x7FFFFFFFu;
+    const uint32_t bit = ((lds_f[(src >> 5) * nthr] >> (src & 31u)) ^ (s >> 31)) & 1u;
+    lds_o[(dst >> 5) * nthr] |= bit << (dst & 31u);
+  }
+
+  // compiled components, in processing order (sampler.py:147-162)
+  for (int ci = 0; ci < A.n_comp; ++ci) {
+    cptr comp = img + A.comp_off + ci * C_WORDS;
+    switch (comp[C_W]) {
+#define TSIMK_CASE(WV)                                                                        \
+  case WV:                                                                                    \
+    if constexpr (WV <= WMAX) run_component<WV>(A, img, comp, lds_f, lds_o, nthr, shot, check_lane, ci); \
+    break;
+      TSIMK_CASE(1) TSIMK_CASE(2) TSIMK_CASE(3) TSIMK_CASE(4) TSIMK_CASE(6) TSIMK_CASE(8)
+      TSIMK_CASE(12) TSIMK_CASE(16)
+#undef TSIMK_CASE
+      default: break;
+    }
+  }
+
+  // the only per-shot HBM write: the packed output row
+  uint64_t *orow = A.out + row * A.WO;
+  for (int w = 0; w < A.WO; ++w)
+    orow[w] = (uint64_t)lds_o[(2 * w) * nthr] | ((uint64_t)lds_o[(2 * w + 1) * nthr] << 32);
+}
+
+// ---------------------------------------------------------------------------
+// evaluate() seam (compile/evaluate.py:16)
+// ---------------------------------------------------------------------------
+template <int W>
+__global__ void __launch_bounds__(256) k_evaluate(EvalArgs A) {
+  const long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= A.B) return;
+  cptr img = (cptr)(uintptr_t)A.img;
+  uint32_t x[W];
+#pragma unroll
+  for (int w = 0; w < W; ++w) x[w] = A.x[row * W + w];
+  float re, im;
+  int ex[5];
+  eval_level<W>(img, img + A.level_off, x, re, im, ex);
+  A.re[row] = re;
+  A.im[row] = im;
+  if (A.exact) {
+#pragma unroll
+    for (int i = 0; i < 5; ++i) A.exact[row * 5 + i] = ex[i];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// per-output subkeys: `key, subkey = jax.random.split(key)` once per compiled
+// output, threaded through the components in processing order
+// (sampler.py:74,147-148).  A sequential chain, one thread, stream-ordered.
+// ---------------------------------------------------------------------------
+__global__ void k_keygen(uint32_t k0, uint32_t k1, int n, uint32_t *__restrict__ subkeys) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  for (int i = 0; i < n; ++i) {
+    uint32_t a0 = 0u, a1 = 0u, b0 = 0u, b1 = 1u;
+    threefry2x32(k0, k1, a0, a1);  // split(key)[0] -> next key
+    threefry2x32(k0, k1, b0, b1);  // split(key)[1] -> this output's subkey
+    subkeys[2 * i] = b0;
+    subkeys[2 * i + 1] = b1;
+    k0 = a0;
+    k1 = a1;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// data-format kernels either side of the path (HBM-bound)
+// ---------------------------------------------------------------------------
+
+// uint8 [B, nbits] -> uint64 [B, ceil(nbits/64)]; one thread per output word
+__global__ void __launch_bounds__(256) k_pack_bits(const uint8_t *__restrict__ in, uint64_t *__restrict__ out,
+                                                    long long B, int nbits, int WQ) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * WQ) return;
+  const long long row = idx / WQ;
+  const int w = (int)(idx - row * WQ);
+  const uint8_t *src = in + row * (long long)nbits + 64 * w;
+  const int n = min(64, nbits - 64 * w);
+  uint64_t v = 0;
+  for (int i = 0; i < n; ++i) v |= (uint64_t)(src[i] != 0) << i;
+  out[idx] = v;
+}
+
+// uint64 [B, ceil(nbits/64)] -> uint8 [B, nbits]; one thread per output byte
+__global__ void __launch_bounds__(256) k_unpack_bits(const uint64_t *__restrict__ in, uint8_t *__restrict__ out,
+                                                      long long B, int nbits, int WQ) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * (long long)nbits) return;
+  const long long row = idx / nbits;
+  const int j = (int)(idx - row * nbits);
+  out[idx] = (uint8_t)((in[row * WQ + (j >> 6)] >> (j & 63)) & 1ull);
+}
+
+}  // namespace tsimk

@@ -111,7 +111,8 @@ __device__ __forceinline__ float cabs32(float re, float im) {
   float ar = fabsf(re), ai = fabsf(im);
   float mx = fmaxf(ar, ai), mn = fminf(ar, ai);
   float r = __fdiv_rn(mn, mx);
-  float v = __fmul_rn(mx, __fsqrt_rn(__fadd_rn(1.0f, __fmul_rn(r, r))));
+  // sqrtf is correctly rounded; __fsqrt_rn is a bare v_sqrt_f32 (1 ulp) on gfx950
+  float v = __fmul_rn(mx, sqrtf(__fadd_rn(1.0f, __fmul_rn(r, r))));
   if (mx == 0.0f) v = 0.0f;
   if (isinf(mx)) v = INFINITY;
   if (isnan(re) || isnan(im)) v = NAN;

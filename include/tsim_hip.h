@@ -138,11 +138,13 @@ int tsim_sample_batch_device(tsim_program *p, const uint64_t *d_f, int64_t B, in
  * (replaces src/tsim/compile/evaluate.py:15-59).
  *   params        uint8 [B, n_params]
  *   re, im        float [B]  complex64 amplitude
+ *   abs_out       optional float [B]: |amplitude| as jnp.abs(complex64) forms it
+ *                 (the marginal of src/tsim/sampler.py:54,67,945,951)
  *   coeffs_power  optional int32 [B,5]: exact (a,b,c,d,power) of the summed
  *                 amplitude on the exact branch (zeros on the approximate one)
  */
 int tsim_evaluate(tsim_program *p, int32_t component, int32_t level, const uint8_t *params,
-                  int64_t B, float *re, float *im, int32_t *coeffs_power);
+                  int64_t B, float *re, float *im, float *abs_out, int32_t *coeffs_power);
 
 /* ---- device-side data-format kernels either side of the path ---------- */
 

@@ -1,0 +1,126 @@
+"""End-to-end sampler classes on the MI355X (real HIP backend), vs oracle-driven twins."""
+
+import numpy as np
+import pytest
+
+import tsim_amd.sampler as sampler_module
+from oracle import oracle_np as O
+from tsim_amd import synth
+from tsim_amd.channels import error_probs, pauli_channel_1_probs
+from tsim_amd.program import CompiledComponent, make_program, scalar_graphs_from_terms
+from tsim_amd.sampler import CompiledDetectorSampler, CompiledMeasurementSampler, CompiledStateProbs
+
+pytestmark = pytest.mark.gpu
+
+NO_NOISE = dict(channel_probs=[], error_transform=np.zeros((0, 0), np.uint8))
+
+
+def oracle_sample_program(program, f_params, key):
+    return O.sample_program(program, np.asarray(f_params), key)
+
+
+def test_seed_kat_through_hip_sampler(hip):
+    s = CompiledMeasurementSampler(synth.kat_h_m(), seed=0, **NO_NOISE)
+    assert [int(np.count_nonzero(s.sample(100))) for _ in range(4)] == [48, 53, 52, 50]
+    s = CompiledMeasurementSampler(synth.kat_t_gate(), seed=0, **NO_NOISE)
+    assert int(np.count_nonzero(s.sample(100))) == 9
+
+
+def noisy_program():
+    """Two noisy-T components + two direct detectors driven by a small Pauli noise model."""
+    comps = [synth.noisy_t_component(2, 1), synth.noisy_t_component(3, 3)]
+    prog = make_program(comps, [(0, 0, False), (1, 2, True)], 4, 2)
+    probs = [error_probs(0.2), pauli_channel_1_probs(0.05, 0.1, 0.15), error_probs(0.3)]
+    T = np.array([[1, 0, 0, 0], [0, 1, 0, 1], [0, 0, 1, 0], [1, 0, 1, 1]], np.uint8)
+    return prog, dict(channel_probs=probs, error_transform=T)
+
+
+@pytest.mark.parametrize("kwargs", [
+    dict(),
+    dict(append_observables=True, bit_packed=True),
+    dict(separate_observables=True, use_detector_reference_sample=True, use_observable_reference_sample=True),
+    dict(append_observables=True, postselection_mask=np.array([True, False])),
+    dict(prepend_observables=True, postselection_mask=np.array([True, True]), use_detector_reference_sample=True),
+])
+def test_detector_sampler_matches_oracle_twin(hip, monkeypatch, kwargs):
+    """Same seed, same batch size: the HIP-backed sampler equals the oracle-backed one bit for bit."""
+    prog, noise = noisy_program()
+    a = CompiledDetectorSampler(prog, seed=11, **noise).sample(1000, batch_size=300, **kwargs)
+    monkeypatch.setattr(sampler_module, "sample_program", oracle_sample_program)
+    b = CompiledDetectorSampler(prog, seed=11, **noise).sample(1000, batch_size=300, **kwargs)
+    if isinstance(a, tuple):
+        assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    else:
+        assert np.array_equal(a, b)
+
+
+def test_noisy_t_statistics(hip):
+    """Physically consistent program: P(m=1 | f) = sin^2(pi/8) or cos^2(pi/8); 4 sigma check."""
+    prog = make_program([synth.noisy_t_component(0, 0)], [], 1, 0)
+    s = CompiledMeasurementSampler(prog, channel_probs=[error_probs(0.25)], error_transform=np.array([[1]], np.uint8), seed=5)
+    n = 200_000
+    m = s.sample(n, batch_size=50_000)[:, 0]
+    p = 0.75 * np.sin(np.pi / 8) ** 2 + 0.25 * np.cos(np.pi / 8) ** 2
+    assert abs(m.mean() - p) < 4 * np.sqrt(p * (1 - p) / n)
+
+
+def test_state_probs_matches_oracle(hip):
+    """CompiledStateProbs.probability_of (sampler.py:906-953) on a joint-mode program."""
+    rng = np.random.default_rng(3)
+    F, n = 6, 3
+    lv0 = synth.synth_level(rng, F, 4, ta=(0, 4), tb=(0, 4), tc=(0, 4), td=(0, 2))
+    lv1 = synth.synth_level(rng, F + n, 6, ta=(0, 4), tb=(0, 4), tc=(0, 4), td=(0, 2))
+    comp = CompiledComponent((1, 2, 3), np.array([0, 2, 3, 4, 6, 7], np.int32), (lv0, lv1))
+    prog = make_program([comp], [(0, 1, True)], 4, 0)
+    probs = [error_probs(0.3)] * 8
+    T = np.eye(8, dtype=np.uint8)
+    state = np.array([1, 0, 1, 1], np.uint8)
+    sp = CompiledStateProbs(prog, channel_probs=probs, error_transform=T, seed=2)
+    got = sp.probability_of(state, batch_size=64)
+    # oracle twin: same channel stream
+    from tsim_amd.channels import ChannelSampler
+
+    cs = ChannelSampler(probs, T, seed=int(np.random.default_rng(2).integers(0, 2**30)))
+    f = cs.sample(64)
+    fsel = f[:, comp.f_selection]
+    pn = O.complex_abs(O.evaluate(lv0, fsel))
+    pj = O.complex_abs(O.evaluate(lv1, np.hstack([fsel, np.tile(state[[1, 2, 3]], (64, 1))])))
+    pj = pj * ((f[:, 1].astype(bool) ^ True) == bool(state[0]))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        want = (pj / pn).astype(np.float32)
+    np.testing.assert_array_equal(got, want)
+    with pytest.raises(ValueError, match="state must have shape"):
+        sp.probability_of(np.zeros(3), batch_size=4)
+    with pytest.raises(ValueError, match="batch_size must be at least 1"):
+        sp.probability_of(state, batch_size=0)
+
+
+def test_evaluate_seam_function(hip):
+    """tsim_amd.backend.evaluate(circuit, param_vals) mirrors compile/evaluate.py:16."""
+    rng = np.random.default_rng(8)
+    lv = synth.synth_level(rng, 20, 5)
+    pv = (rng.random((100, 20)) < 0.5).astype(np.uint8)
+    z = hip.evaluate(lv, pv)
+    assert z.dtype == np.complex64
+    np.testing.assert_array_equal(z.view(np.float32), O.evaluate(lv, pv).view(np.float32))
+    from tsim_amd.program import empty_scalar_graphs
+
+    assert np.array_equal(hip.evaluate(empty_scalar_graphs(2), np.ones((3, 2), np.uint8)), np.zeros(3, complex))
+
+
+def test_vanishing_marginal_raises_and_warns(hip):
+    """sampler.py:149-161: deviation ~1 -> ValueError; > 1e-5 -> warning."""
+    bad = CompiledComponent(
+        (0,), np.zeros(0, np.int32),
+        (scalar_graphs_from_terms(0, [dict()]), scalar_graphs_from_terms(1, [dict(power2=-40)])),
+    )
+    # p0 + p1 = 2^-40 + 2^-40 -> norm ~ 0 -> |norm - 1| ~ 1
+    prog = make_program([bad], [], 1, 0)
+    with pytest.raises(ValueError, match="vanishing marginal"):
+        hip.sample_program(prog, np.zeros((4, 0), np.uint8), (1, 2))
+    off = CompiledComponent(
+        (0,), np.zeros(0, np.int32),
+        (scalar_graphs_from_terms(0, [dict()]), scalar_graphs_from_terms(1, [dict(floatfactor=(3, 0, 0, 0), power2=-3)])),
+    )
+    with pytest.warns(UserWarning, match="not normalized"):
+        hip.sample_program(make_program([off], [], 1, 0), np.zeros((4, 0), np.uint8), (1, 2))

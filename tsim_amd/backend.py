@@ -239,7 +239,8 @@ class HipProgram:
         return float(ms.value), int(n.value)
 
     # -- evaluate seam ----------------------------------------------------------
-    def evaluate(self, component: int, level: int, param_vals: np.ndarray, *, exact: bool = False):
+    def evaluate(self, component: int, level: int, param_vals: np.ndarray, *, exact: bool = False,
+                 return_abs: bool = False):
         pv = np.asarray(param_vals)
         if pv.ndim != 2:
             raise ValueError(f"param_vals must be 2-D (batch, n_params), got shape {pv.shape}")
@@ -253,10 +254,14 @@ class HipProgram:
         re = np.zeros(B, np.float32)
         im = np.zeros(B, np.float32)
         ex = np.zeros((B, 5), np.int32) if exact else None
+        ab = np.zeros(B, np.float32) if return_abs else None
         _lib.check(
-            self._lib.tsim_evaluate(self._h, component, level, _lib.ptr(pv), B, _lib.ptr(re), _lib.ptr(im), _lib.ptr(ex)),
+            self._lib.tsim_evaluate(self._h, component, level, _lib.ptr(pv), B, _lib.ptr(re), _lib.ptr(im),
+                                    _lib.ptr(ab), _lib.ptr(ex)),
             "tsim_evaluate",
         )
+        if return_abs:
+            return ab  # |amplitude| formed on the device exactly as the sampling kernel forms it
         z = np.empty(B, np.complex64)
         z.real, z.imag = re, im
         return (z, ex) if exact else z

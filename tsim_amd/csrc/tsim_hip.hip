@@ -640,7 +640,7 @@ static void launch_eval_w(const EvalArgs &a, hipStream_t s) {
 }
 
 extern "C" int tsim_evaluate(tsim_program *p, int32_t component, int32_t level, const uint8_t *params,
-                             int64_t B, float *re, float *im, int32_t *coeffs_power) {
+                             int64_t B, float *re, float *im, float *abs_out, int32_t *coeffs_power) {
   if (int r = need_final(p)) return r;
   if (int r = set_device(p)) return r;
   if (component < 0 || component >= (int)p->comps.size()) return fail(TSIM_EINVAL, "bad component %d", component);
@@ -661,7 +661,7 @@ extern "C" int tsim_evaluate(tsim_program *p, int32_t component, int32_t level, 
   }
   hipStream_t s = p->stream;
   if (int r = ensure_scratch(p, 0, x.size() * 4)) return r;
-  if (int r = ensure_scratch(p, 1, (size_t)B * 8)) return r;
+  if (int r = ensure_scratch(p, 1, (size_t)B * 12)) return r;
   if (int r = ensure_scratch(p, 2, (size_t)B * 20)) return r;
   HIP_TRY(hipMemcpyAsync(p->scratch[0], x.data(), x.size() * 4, hipMemcpyHostToDevice, s));
   EvalArgs a;
@@ -669,6 +669,7 @@ extern "C" int tsim_evaluate(tsim_program *p, int32_t component, int32_t level, 
   a.x = (const uint32_t *)p->scratch[0];
   a.re = (float *)p->scratch[1];
   a.im = a.re + B;
+  a.abs = abs_out ? a.re + 2 * B : nullptr;
   a.exact = coeffs_power ? (int *)p->scratch[2] : nullptr;
   a.B = B;
   a.level_off = p->level_off[p->level_base[component] + level];
@@ -687,6 +688,7 @@ extern "C" int tsim_evaluate(tsim_program *p, int32_t component, int32_t level, 
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(re, a.re, (size_t)B * 4, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipMemcpyAsync(im, a.im, (size_t)B * 4, hipMemcpyDeviceToHost, s));
+  if (abs_out) HIP_TRY(hipMemcpyAsync(abs_out, a.abs, (size_t)B * 4, hipMemcpyDeviceToHost, s));
   if (coeffs_power) HIP_TRY(hipMemcpyAsync(coeffs_power, a.exact, (size_t)B * 20, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   return TSIM_OK;

@@ -51,6 +51,7 @@ struct EvalArgs {
   const uint32_t *img;
   const uint32_t *x;        // [B, W] packed params (32-bit words)
   float *re, *im;           // [B]
+  float *abs;               // [B] or nullptr
   int *exact;               // [B,5] or nullptr
   long long B;
   int level_off;            // offset of the level record
@@ -436,6 +437,7 @@ __global__ void __launch_bounds__(256) k_evaluate(EvalArgs A) {
   eval_level<W>(img, img + A.level_off, x, re, im, ex);
   A.re[row] = re;
   A.im[row] = im;
+  if (A.abs) A.abs[row] = cabs32(re, im);
   if (A.exact) {
 #pragma unroll
     for (int i = 0; i < 5; ++i) A.exact[row * 5 + i] = ex[i];

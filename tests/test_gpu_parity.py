@@ -129,3 +129,37 @@ def test_bit_packed_output(hip):
     b, _ = hp.sample_batch(f, (1, 2), bit_packed=True)
     want = np.packbits(a, axis=1, bitorder="little")
     np.testing.assert_array_equal(b[:, : want.shape[1]], want)
+
+
+def test_multi_device_sharding_same_bits(hip):
+    """tsim_amd.dist.sample_program_multi_device over [0, 0, 0] == one launch (device-side pack path)."""
+    from tsim_amd import dist as tdist
+
+    prog, cfg = synth.config_program("C2")
+    f = synth.synth_f(5003, cfg["num_f"], cfg["p_bit"], seed=4)
+    key = (31, 37)
+    full, _ = hip.get_hip_program(prog).sample_batch(f, key)
+    got = tdist.sample_program_multi_device(prog, f, key, [0, 0, 0])
+    np.testing.assert_array_equal(got, full)
+
+
+def test_pack_unpack_kernels(hip):
+    """k_pack_bits / k_unpack_bits against numpy.packbits for ragged widths."""
+    prog, _ = synth.config_program("C2")
+    hp = hip.get_hip_program(prog)
+    rng = np.random.default_rng(0)
+    for nbits in (1, 7, 63, 64, 65, 200):
+        a = (rng.random((333, nbits)) < 0.5).astype(np.uint8) * rng.integers(1, 255, size=(333, nbits), dtype=np.uint8)
+        wq = (nbits + 63) // 64
+        d_in, d_p, d_out = hp.malloc(a.nbytes), hp.malloc(333 * wq * 8), hp.malloc(a.nbytes)
+        hp.h2d(d_in, a)
+        hp.pack_bits_device(d_in.ptr, 333, nbits, d_p.ptr)
+        packed = np.zeros((333, wq * 8), np.uint8)
+        hp.d2h(packed, d_p)
+        want = np.packbits(a != 0, axis=1, bitorder="little")
+        np.testing.assert_array_equal(packed[:, : want.shape[1]], want)
+        assert not packed[:, want.shape[1]:].any()
+        hp.unpack_bits_device(d_p.ptr, 333, nbits, d_out.ptr)
+        back = np.zeros_like(a)
+        hp.d2h(back, d_out)
+        np.testing.assert_array_equal(back, (a != 0).astype(np.uint8))

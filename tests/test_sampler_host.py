@@ -44,11 +44,8 @@ def det_obs_sampler(seed=None):
 
     No noise: three deterministic outputs (0, 0, 1) as compiled single-output components.
     """
-    one = CompiledComponent(
-        (2,), np.zeros(0, np.int32),
-        (scalar_graphs_from_terms(0, [dict()]), scalar_graphs_from_terms(1, [dict()])),
-    )
-    comps = [synth.single_output_component(0, zero=True), synth.single_output_component(1, zero=True), one]
+    comps = [synth.single_output_component(0, zero=True), synth.single_output_component(1, zero=True),
+             synth.single_output_component(2, one=True)]
     prog = make_program(comps, [], 3, 2)
     return CompiledDetectorSampler(prog, seed=seed, **NO_NOISE)
 

@@ -36,14 +36,22 @@ def _const_level(n_params: int, floatfactor=(1, 0, 0, 0), power2=0, **terms) -> 
     return scalar_graphs_from_terms(n_params, [g])
 
 
-def single_output_component(output_index: int, ff1=(1, 0, 0, 0), power2_1=-1, zero=False) -> CompiledComponent:
+def single_output_component(output_index: int, ff1=(1, 0, 0, 0), power2_1=-1, zero=False, one=False,
+                            level1=None) -> CompiledComponent:
     """One output, no noise: level 0 amplitude 1, level 1 amplitude ``ff1 * 2^power2_1``.
 
-    ``zero=True`` gives a level 1 with no graphs (the compile step drops zero
-    scalars, compile.py:357), i.e. a deterministic 0 outcome.
+    ``zero=True`` / ``one=True`` give a deterministic outcome through a delta term
+    ``(1 +- (-1)^m)/2`` (a NodePhases factor with phase 0 / 4 on the output bit), so that the
+    marginals still sum to the normalisation (sampler.py:71-72).  ``level1`` overrides the
+    level-1 graph list.
     """
     lv0 = _const_level(0)
-    lv1 = empty_scalar_graphs(1) if zero else _const_level(1, floatfactor=ff1, power2=power2_1)
+    if level1 is not None:
+        lv1 = scalar_graphs_from_terms(1, level1)
+    elif zero or one:
+        lv1 = _const_level(1, power2=-1, A=[(4 if one else 0, [0])])
+    else:
+        lv1 = _const_level(1, floatfactor=ff1, power2=power2_1)
     return CompiledComponent((output_index,), np.zeros(0, np.int32), (lv0, lv1))
 
 
@@ -53,11 +61,14 @@ def kat_h_m() -> CompiledProgram:
 
 
 def kat_t_gate() -> CompiledProgram:
-    """``RX 0; S[T] 0; H 0; M 0`` - P(1) = sin^2(pi/8) = (2 - sqrt2)/4 (test_sampler_circuits.py:40-49).
+    """``RX 0; S[T] 0; H 0; M 0`` - P(m) = 1/2 + (-1)^m sqrt2/4 (test_sampler_circuits.py:40-49).
 
-    sqrt2 = omega + conj(omega) -> coefficients (2,-1,0,-1) * 2^-2.
+    Two stabiliser terms: ``1/2`` and ``sqrt2/4 * w^(4m)`` with sqrt2 = w + conj(w), i.e.
+    floatfactor (0,1,0,1) * 2^-2 and a HalfPi term of coefficient 4 on the output bit.
+    P(1) = (2 - sqrt2)/4 = sin^2(pi/8): exact sum (2,-1,0,-1) * 2^-2.
     """
-    return make_program([single_output_component(0, ff1=(2, -1, 0, -1), power2_1=-2)], [], 1, 0)
+    level1 = [dict(power2=-1), dict(floatfactor=(0, 1, 0, 1), power2=-2, B=[(4, [0])])]
+    return make_program([single_output_component(0, level1=level1)], [], 1, 0)
 
 
 def kat_r_gate() -> CompiledProgram:

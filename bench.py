@@ -261,10 +261,15 @@ def main() -> None:
         }
         if N == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(program, cfg, args.cpu_seconds)
-        print(json.dumps(res), flush=True)
-
     if use_dist:
         dist.destroy_process_group()
+    # RCCL prints its banner through C stdio: drain that buffer first so that the JSON line is
+    # the LAST line on stdout.
+    import ctypes
+
+    ctypes.CDLL(None).fflush(None)
+    if rank == 0:
+        print(json.dumps(res), flush=True)
 
 
 if __name__ == "__main__":

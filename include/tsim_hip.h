@@ -96,6 +96,23 @@ int tsim_program_add_component(tsim_program *p, int32_t n_out, const int32_t *ou
 /* Adds the next level of component `component` (arrays are copied/packed). */
 int tsim_program_add_level(tsim_program *p, int32_t component, const tsim_level_desc *level);
 
+/*
+ * Evaluation formulation, to be set before finalize (default TSIM_MODE_AUTO; the environment
+ * variable TSIM_AMD_MODE=faithful forces TSIM_MODE_FAITHFUL):
+ *   TSIM_MODE_FAITHFUL  operation-by-operation mirror of the reference's int32 arithmetic
+ *                       (src/tsim/core/exact_scalar.py:19-137), identical even where it wraps;
+ *   TSIM_MODE_AUTO      use the faster exact-value formulation (NodePhases by class counting +
+ *                       pack-time tables) whenever every graph qualifies (<= 30 NodePhases terms,
+ *                       even HalfPi coefficients, small floatfactors); it yields the same canonical
+ *                       (a,b,c,d,power) and float32 amplitude as the reference whenever the
+ *                       reference's own int32 arithmetic does not wrap.
+ */
+#define TSIM_MODE_AUTO 0
+#define TSIM_MODE_FAITHFUL 1
+int tsim_program_set_mode(tsim_program *p, int32_t mode);
+/* after finalize: *fast = 1 if the exact-value formulation was selected */
+int tsim_program_get_mode(const tsim_program *p, int32_t *fast);
+
 /* Packs all levels into the device image and uploads it to HIP device `device`. */
 int tsim_program_finalize(tsim_program *p, int32_t device);
 

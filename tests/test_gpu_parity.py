@@ -163,3 +163,59 @@ def test_pack_unpack_kernels(hip):
         back = np.zeros_like(a)
         hp.d2h(back, d_out)
         np.testing.assert_array_equal(back, (a != 0).astype(np.uint8))
+
+
+# ---- both evaluation formulations against the oracle ---------------------------
+
+
+@pytest.mark.parametrize("mode", ["auto", "faithful"])
+@pytest.mark.parametrize("name", ["C2", "C3", "C4", "C5"])
+def test_modes_match_oracle_on_baseline_shapes(hip, mode, name):
+    from oracle import oracle_c as OC
+
+    prog, cfg = synth.config_program(name)
+    n = 600 if name == "C4" else 3000
+    f = synth.synth_f(n, cfg["num_f"], cfg["p_bit"] * 2, seed=17)
+    hp = hip.HipProgram(prog, mode=mode)
+    assert hp.fast == (mode == "auto")
+    want, wdev, ov = OC.OracleProgram(prog).sample_program(f, (41, 43), return_devs=True, return_overflow=True)
+    assert not ov
+    got, gdev = hp.sample_batch(f, (41, 43))
+    np.testing.assert_array_equal(got, want)
+    np.testing.assert_array_equal(np.asarray(gdev, np.float32), np.asarray(wdev, np.float32))
+
+
+@pytest.mark.parametrize("mode", ["auto", "faithful"])
+@pytest.mark.parametrize("approx", [False, True])
+def test_modes_evaluate_exact(hip, mode, approx):
+    from oracle import oracle_c as OC
+    from tsim_amd.program import CompiledComponent, empty_scalar_graphs, make_program
+
+    rng = np.random.default_rng(23)
+    lv = synth.synth_level(rng, 45, 20, approx=approx, zero_phase_fraction=0.3)
+    comp = CompiledComponent(tuple(range(45)), np.zeros(0, np.int32), (empty_scalar_graphs(0), lv))
+    prog = make_program([comp], [], 45, 0)
+    pv = (rng.random((2000, 45)) < 0.5).astype(np.uint8)
+    z, ex = hip.HipProgram(prog, mode=mode).evaluate(0, 1, pv, exact=True)
+    wz, wex, ov = OC.OracleProgram(prog).evaluate(0, 1, pv, exact=True)
+    assert not ov
+    np.testing.assert_array_equal(z.view(np.float32), wz.view(np.float32))
+    if not approx:
+        np.testing.assert_array_equal(ex[:, :4], wex[:, :4])
+        nz = np.any(wex[:, :4] != 0, axis=1)
+        np.testing.assert_array_equal(ex[nz, 4], wex[nz, 4])
+
+
+def test_auto_falls_back_to_faithful_when_not_eligible(hip):
+    """> 30 NodePhases terms in one graph: the reference's int32 scan may wrap -> faithful layout."""
+    from tsim_amd.program import CompiledComponent, empty_scalar_graphs, make_program, scalar_graphs_from_terms
+
+    lv = scalar_graphs_from_terms(3, [dict(A=[(1 + 2 * (t % 4), [t % 3]) for t in range(31)])])
+    comp = CompiledComponent((0, 1, 2), np.zeros(0, np.int32), (empty_scalar_graphs(0), lv))
+    prog = make_program([comp], [], 3, 0)
+    hp = hip.HipProgram(prog)
+    assert not hp.fast
+    pv = np.array([[0, 0, 0], [1, 0, 1], [1, 1, 1]], np.uint8)
+    z, ex = hp.evaluate(0, 1, pv, exact=True)
+    coeffs, power = O.evaluate_exact(lv, pv)
+    np.testing.assert_array_equal(ex[:, :4], coeffs)

@@ -108,7 +108,11 @@ class DeviceBuffer:
 class HipProgram:
     """A compiled program uploaded to one MI355X (handle over ``tsim_program*``)."""
 
-    def __init__(self, program, device: int = 0):
+    def __init__(self, program, device: int = 0, mode: str = "auto"):
+        """``mode``: "auto" (exact-value fast formulation when every graph qualifies) or
+        "faithful" (operation-by-operation int32 mirror of the reference); see include/tsim_hip.h."""
+        if mode not in ("auto", "faithful"):
+            raise ValueError("mode must be 'auto' or 'faithful'")
         self._lib = _lib.load()
         self._h = None
         program = from_tsim(program)
@@ -144,7 +148,11 @@ class HipProgram:
                     keep: list = []
                     desc = _level_desc(lv, keep)
                     _lib.check(lib.tsim_program_add_level(h, ci, C.byref(desc)), "tsim_program_add_level")
+            _lib.check(lib.tsim_program_set_mode(h, 1 if mode == "faithful" else 0), "tsim_program_set_mode")
             _lib.check(lib.tsim_program_finalize(h, self.device), "tsim_program_finalize")
+            fast = C.c_int32(0)
+            _lib.check(lib.tsim_program_get_mode(h, C.byref(fast)), "tsim_program_get_mode")
+            self.fast = bool(fast.value)
         except Exception:
             lib.tsim_program_destroy(h)
             self._h = None

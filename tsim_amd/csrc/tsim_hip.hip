@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -86,6 +87,8 @@ struct tsim_program {
   int direct_off = 0, comp_off = 0;
   int total_keys = 0;  // total compiled outputs (sequential components)
   bool sampleable = true;
+  int mode = TSIM_MODE_AUTO;  // requested
+  bool fast = false;          // chosen at finalize: counting formulation (eval_level_fast)
   long long total_graphs = 0, total_rows = 0;
   int max_f_index = -1;
   std::vector<int> level_off;  // flattened [component][level] -> offset of level record
@@ -330,9 +333,191 @@ static void pack_level(HostLevel &h, int W) {
   }
 }
 
+// ---------------------------------------------------------------------------
+// "fast exact" packing (kernel: eval_level_fast)
+// ---------------------------------------------------------------------------
+namespace {
+
+// exact element of Z[w] * 2^p on basis (1, w, i, conj w), int64 coefficients, kept canonical
+struct ZW {
+  long long c[4];
+  int p;
+};
+
+static void zw_canon(ZW &z) {
+  if (!(z.c[0] | z.c[1] | z.c[2] | z.c[3])) return;
+  while (!((z.c[0] | z.c[1] | z.c[2] | z.c[3]) & 1)) {
+    for (auto &v : z.c) v >>= 1;
+    ++z.p;
+  }
+}
+
+static void zw_mul(ZW &x, const long long y[4]) {  // exact_scalar.py:19-39, then canonicalise
+  const long long a1 = x.c[0], b1 = x.c[1], c1 = x.c[2], d1 = x.c[3];
+  const long long a2 = y[0], b2 = y[1], c2 = y[2], d2 = y[3];
+  x.c[0] = a1 * a2 + b1 * d2 - c1 * c2 + d1 * b2;
+  x.c[1] = a1 * b2 + b1 * a2 + c1 * d2 + d1 * c2;
+  x.c[2] = a1 * c2 + b1 * b2 + c1 * a2 - d1 * d2;
+  x.c[3] = a1 * d2 - b1 * c2 - c1 * b2 + d1 * a2;
+  zw_canon(x);
+}
+
+static void unit_plus_one(int k, long long out[4]) {  // 1 + w^k
+  for (int j = 0; j < 4; ++j) out[j] = kUnit[k & 7][j];
+  out[0] += 1;
+}
+
+// Can this level be evaluated by the counting formulation?  (see eval_level_fast)
+static bool level_fast_eligible(const HostLevel &h) {
+  const tsim_level_desc &d = h.d;
+  for (int g = 0; g < h.G; ++g) {
+    const int nA = d.ta ? h.i32[0][g] : 0;
+    if (nA > 30) return false;  // beyond this the reference's own int32 scan may wrap
+    for (int t = 0; t < d.tb; ++t) {
+      const unsigned c = h.u8[2][(size_t)g * d.tb + t] & 7u;
+      if (c & 1u) return false;  // odd eighth-turn coefficients never come out of the compiler
+    }
+    if (d.tb > 60000 || d.tc > 60000 || d.td > 60000) return false;
+    for (int j = 0; j < 4; ++j)
+      if (std::llabs((long long)h.i32[2][(size_t)g * 4 + j]) > (1ll << 20)) return false;
+  }
+  return true;
+}
+
+// Build graph records + class-sorted rows + NodePhases tables.  Returns false if a table entry
+// does not fit int32 (the caller then falls back to the faithful layout).
+static bool pack_level_fast(HostLevel &h, int W, std::vector<uint32_t> &tables) {
+  const int G = h.G, P = h.P;
+  const tsim_level_desc &d = h.d;
+  h.graph_rec.assign((size_t)G * G_WORDS, 0u);
+  h.rows.clear();
+  h.n_rows = 0;
+  tables.clear();
+  std::vector<uint32_t> tmp;
+  for (int g = 0; g < G; ++g) {
+    uint32_t *rec = &h.graph_rec[(size_t)g * G_WORDS];
+    rec[GF_ROWS] = (uint32_t)h.rows.size();
+    // ---- NodePhases rows, grouped by phase class (phase & 3); the row constant is phase >> 2
+    const int nA = d.ta ? h.i32[0][g] : 0;
+    int n[4] = {0, 0, 0, 0};
+    for (int cls = 0; cls < 4; ++cls)
+      for (int t = 0; t < nA; ++t) {
+        const unsigned ph = h.u8[0][(size_t)g * d.ta + t] & 7u;
+        if ((int)(ph & 3u) != cls) continue;
+        h.rows.push_back(ph >> 2);
+        pack_row(h.rows, &h.u8[1][((size_t)g * d.ta + t) * P], P, W);
+        ++n[cls];
+      }
+    rec[GF_NA01] = (uint32_t)n[0] | ((uint32_t)n[1] << 16);
+    rec[GF_NA23] = (uint32_t)n[2] | ((uint32_t)n[3] << 16);
+    rec[GF_N1] = (uint32_t)n[1];
+    // ---- table over delta = m3 - m1 in [-n1, n3] (entry index delta + n1), 8 words per entry:
+    //      canon( 2^n0 (1+i)^n2 (1+w)^(n1-m1) (1-w)^m1 (1+w^3)^(n3-m3) (1-w^3)^m3 * i^(m1+m3)
+    //             * floatfactor * w^static_phase )   with m3 = max(delta,0), m1 = max(-delta,0)
+    rec[GF_TBL] = (uint32_t)tables.size();
+    const long long ff[4] = {h.i32[2][(size_t)g * 4], h.i32[2][(size_t)g * 4 + 1], h.i32[2][(size_t)g * 4 + 2],
+                             h.i32[2][(size_t)g * 4 + 3]};
+    for (int delta = -n[1]; delta <= n[3]; ++delta) {
+      const int m3 = delta > 0 ? delta : 0, m1 = delta < 0 ? -delta : 0;
+      ZW z{{1, 0, 0, 0}, 0};
+      long long f[4];
+      auto mul_k = [&](int k, int times) {
+        unit_plus_one(k, f);
+        for (int i = 0; i < times; ++i) zw_mul(z, f);
+      };
+      mul_k(0, n[0]);
+      mul_k(2, n[2]);
+      mul_k(1, n[1] - m1);
+      mul_k(5, m1);
+      mul_k(3, n[3] - m3);
+      mul_k(7, m3);
+      const long long rot[4] = {kUnit[(2 * (m1 + m3)) & 7][0], kUnit[(2 * (m1 + m3)) & 7][1],
+                                kUnit[(2 * (m1 + m3)) & 7][2], kUnit[(2 * (m1 + m3)) & 7][3]};
+      zw_mul(z, rot);
+      zw_mul(z, ff);
+      const int sp = h.u8[12][g] & 7;
+      const long long st[4] = {kUnit[sp][0], kUnit[sp][1], kUnit[sp][2], kUnit[sp][3]};
+      zw_mul(z, st);
+      for (int j = 0; j < 4; ++j)
+        if (z.c[j] > INT32_MAX || z.c[j] < INT32_MIN) return false;
+      for (int j = 0; j < 4; ++j) tables.push_back((uint32_t)(int32_t)z.c[j]);
+      tables.push_back((uint32_t)z.p);
+      tables.push_back(0u); tables.push_back(0u); tables.push_back(0u);
+    }
+    // ---- HalfPi rows grouped by coefficient 2, 4, 6 (no meta word)
+    int nb[3] = {0, 0, 0};
+    for (int grp = 0; grp < 3; ++grp)
+      for (int t = 0; t < d.tb; ++t) {
+        const uint32_t coeff = h.u8[2][(size_t)g * d.tb + t] & 7u;
+        if (coeff != (uint32_t)(2 * grp + 2)) continue;
+        tmp.clear();
+        if (!pack_row(tmp, &h.u8[3][((size_t)g * d.tb + t) * P], P, W)) continue;
+        h.rows.insert(h.rows.end(), tmp.begin(), tmp.end());
+        ++nb[grp];
+      }
+    rec[GF_NB24] = (uint32_t)nb[0] | ((uint32_t)nb[1] << 16);
+    // ---- PiProducts (identical layout to the faithful path)
+    int nC = 0;
+    for (int t = 0; t < d.tc; ++t) {
+      const uint32_t pc = h.u8[4][(size_t)g * d.tc + t] & 1u, qc = h.u8[6][(size_t)g * d.tc + t] & 1u;
+      std::vector<uint32_t> r1, r2;
+      const bool any1 = pack_row(r1, &h.u8[5][((size_t)g * d.tc + t) * P], P, W);
+      const bool any2 = pack_row(r2, &h.u8[7][((size_t)g * d.tc + t) * P], P, W);
+      if ((!any1 && !pc) || (!any2 && !qc)) continue;
+      h.rows.push_back(pc | (qc << 1));
+      h.rows.insert(h.rows.end(), r1.begin(), r1.end());
+      h.rows.insert(h.rows.end(), r2.begin(), r2.end());
+      ++nC;
+    }
+    rec[GF_NB6C] = (uint32_t)nb[2] | ((uint32_t)nC << 16);
+    // ---- PhasePairs (identical layout to the faithful path)
+    const int nD = d.td ? h.i32[1][g] : 0;
+    for (int t = 0; t < nD; ++t) {
+      const int al = h.u8[8][(size_t)g * d.td + t] & 7, be = h.u8[10][(size_t)g * d.td + t] & 7;
+      for (int idx = 0; idx < 4; ++idx) {
+        const int pa = idx & 1, pb = idx >> 1;
+        const int a1 = (al + 4 * pa) & 7, b1 = (be + 4 * pb) & 7, g1 = (a1 + b1) & 7;
+        uint32_t w = 0;
+        for (int j = 0; j < 4; ++j) {
+          const int v = (j == 0 ? 1 : 0) + kUnit[a1][j] + kUnit[b1][j] - kUnit[g1][j];
+          w |= (uint32_t)(uint8_t)(int8_t)v << (8 * j);
+        }
+        h.rows.push_back(w);
+      }
+      pack_row(h.rows, &h.u8[9][((size_t)g * d.td + t) * P], P, W);
+      pack_row(h.rows, &h.u8[11][((size_t)g * d.td + t) * P], P, W);
+    }
+    rec[GF_ND] = (uint32_t)nD;
+    h.n_rows += nA + nb[0] + nb[1] + nb[2] + 2 * nC + 2 * nD;
+    rec[GF_POW2] = (uint32_t)h.i32[3][g];
+    memcpy(&rec[GF_APRE], &h.approx_v[2 * (size_t)g], 4);
+    memcpy(&rec[GF_APIM], &h.approx_v[2 * (size_t)g + 1], 4);
+  }
+  return true;
+}
+
+}  // namespace
+
+extern "C" int tsim_program_set_mode(tsim_program *p, int32_t mode) {
+  if (!p) return fail(TSIM_EINVAL, "program is NULL");
+  if (p->finalized) return fail(TSIM_ESTATE, "program already finalized");
+  if (mode != TSIM_MODE_AUTO && mode != TSIM_MODE_FAITHFUL) return fail(TSIM_EINVAL, "bad mode %d", mode);
+  p->mode = mode;
+  return TSIM_OK;
+}
+
 extern "C" int tsim_program_finalize(tsim_program *p, int32_t device) {
   if (!p) return fail(TSIM_EINVAL, "program is NULL");
   if (p->finalized) return fail(TSIM_ESTATE, "program already finalized");
+  // ---- choose the evaluation formulation ----
+  {
+    const char *env = getenv("TSIM_AMD_MODE");
+    bool fast = (p->mode == TSIM_MODE_AUTO) && !(env && strcmp(env, "faithful") == 0);
+    for (auto &c : p->comps)
+      for (auto &lv : c.levels) fast = fast && level_fast_eligible(lv);
+    p->fast = fast;
+  }
+retry_pack:
   // ---- validate the output bookkeeping (pipeline.py:83-102) ----
   int pos = p->n_direct;
   for (size_t ci = 0; ci < p->comps.size(); ++ci) {
@@ -393,14 +578,29 @@ extern "C" int tsim_program_finalize(tsim_program *p, int32_t device) {
     p->level_base.push_back((int)p->level_off.size());
     for (int k = 0; k < c.n_levels; ++k) {
       HostLevel &h = c.levels[k];
-      pack_level(h, W);
+      std::vector<uint32_t> tables;
+      if (p->fast) {
+        if (!pack_level_fast(h, W, tables)) {  // a table entry exceeds int32: use the faithful layout
+          p->fast = false;
+          goto retry_pack;
+        }
+      } else {
+        pack_level(h, W);
+      }
       // align graph records to 16 words (one s_load_dwordx16 each)
       while (img.size() % 16) img.push_back(0u);
       const uint32_t goff = (uint32_t)img.size();
       img.insert(img.end(), h.graph_rec.begin(), h.graph_rec.end());
       const uint32_t roff = (uint32_t)img.size();
       img.insert(img.end(), h.rows.begin(), h.rows.end());
+      static_assert((int)G_ROWS == (int)GF_ROWS, "row offset slot is shared by both layouts");
       for (int g = 0; g < h.G; ++g) img[goff + (size_t)g * G_WORDS + G_ROWS] += roff;
+      if (p->fast) {
+        while (img.size() % 8) img.push_back(0u);  // 32-byte aligned table entries (uint4 loads)
+        const uint32_t toff = (uint32_t)img.size();
+        img.insert(img.end(), tables.begin(), tables.end());
+        for (int g = 0; g < h.G; ++g) img[goff + (size_t)g * G_WORDS + GF_TBL] += toff;
+      }
       uint32_t *lr = &img[lrec + (size_t)k * L_WORDS];
       lr[L_G] = (uint32_t)h.G;
       lr[L_GRAPHS] = goff;
@@ -413,7 +613,7 @@ extern "C" int tsim_program_finalize(tsim_program *p, int32_t device) {
     if (sequential) p->total_keys += c.n_out;
     memcpy(&img[p->comp_off + ci * C_WORDS], rec, sizeof rec);
   }
-  img.resize(img.size() + 64, 0u);  // tail padding: wide scalar loads may over-read
+  img.resize(img.size() + 256, 0u);  // tail padding: wide scalar loads may over-read
   if (img.size() >= (1ull << 31)) return fail(TSIM_ENOTSUP, "program image too large");
 
   // ---- upload ----
@@ -446,6 +646,13 @@ extern "C" void tsim_program_destroy(tsim_program *p) {
     if (p->stream) (void)hipStreamDestroy(p->stream);
   }
   delete p;
+}
+
+extern "C" int tsim_program_get_mode(const tsim_program *p, int32_t *fast) {
+  if (!p || !fast) return fail(TSIM_EINVAL, "NULL argument");
+  if (!p->finalized) return fail(TSIM_ESTATE, "program not finalized");
+  *fast = p->fast ? 1 : 0;
+  return TSIM_OK;
 }
 
 extern "C" int tsim_program_info(const tsim_program *p, int32_t *n_components, int32_t *num_outputs,
@@ -545,8 +752,11 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
   int wmax = 1;
   for (int w : p->comp_w) wmax = std::max(wmax, w);
   switch (wmax) {
-#define TSIM_LAUNCH(WV) \
-  case WV: hipLaunchKernelGGL(k_sample<WV>, dim3((unsigned)grid), dim3(block), lds, s, a); break;
+#define TSIM_LAUNCH(WV)                                                                             \
+  case WV:                                                                                          \
+    if (p->fast) hipLaunchKernelGGL((k_sample<WV, true>), dim3((unsigned)grid), dim3(block), lds, s, a);  \
+    else hipLaunchKernelGGL((k_sample<WV, false>), dim3((unsigned)grid), dim3(block), lds, s, a);   \
+    break;
     TSIM_LAUNCH(1) TSIM_LAUNCH(2) TSIM_LAUNCH(3) TSIM_LAUNCH(4) TSIM_LAUNCH(6) TSIM_LAUNCH(8)
     TSIM_LAUNCH(12) TSIM_LAUNCH(16)
 #undef TSIM_LAUNCH
@@ -635,8 +845,10 @@ extern "C" int tsim_sample_batch(tsim_program *p, const uint8_t *f, int64_t B, i
 }
 
 template <int W>
-static void launch_eval_w(const EvalArgs &a, hipStream_t s) {
-  hipLaunchKernelGGL(k_evaluate<W>, dim3((unsigned)((a.B + 255) / 256)), dim3(256), 0, s, a);
+static void launch_eval_w(const EvalArgs &a, hipStream_t s, bool fast) {
+  const dim3 grid((unsigned)((a.B + 255) / 256));
+  if (fast) hipLaunchKernelGGL((k_evaluate<W, true>), grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((k_evaluate<W, false>), grid, dim3(256), 0, s, a);
 }
 
 extern "C" int tsim_evaluate(tsim_program *p, int32_t component, int32_t level, const uint8_t *params,
@@ -675,14 +887,14 @@ extern "C" int tsim_evaluate(tsim_program *p, int32_t component, int32_t level, 
   a.level_off = p->level_off[p->level_base[component] + level];
   a.W = W;
   switch (W) {
-    case 1: launch_eval_w<1>(a, s); break;
-    case 2: launch_eval_w<2>(a, s); break;
-    case 3: launch_eval_w<3>(a, s); break;
-    case 4: launch_eval_w<4>(a, s); break;
-    case 6: launch_eval_w<6>(a, s); break;
-    case 8: launch_eval_w<8>(a, s); break;
-    case 12: launch_eval_w<12>(a, s); break;
-    case 16: launch_eval_w<16>(a, s); break;
+    case 1: launch_eval_w<1>(a, s, p->fast); break;
+    case 2: launch_eval_w<2>(a, s, p->fast); break;
+    case 3: launch_eval_w<3>(a, s, p->fast); break;
+    case 4: launch_eval_w<4>(a, s, p->fast); break;
+    case 6: launch_eval_w<6>(a, s, p->fast); break;
+    case 8: launch_eval_w<8>(a, s, p->fast); break;
+    case 12: launch_eval_w<12>(a, s, p->fast); break;
+    case 16: launch_eval_w<16>(a, s, p->fast); break;
     default: return fail(TSIM_ENOTSUP, "unsupported word count %d", W);
   }
   HIP_TRY(hipGetLastError());

@@ -32,6 +32,18 @@ enum {
   G_APRE, G_APIM, G_FLAGS, G_WORDS = 16
 };
 #define TSIMK_LFLAG_APPROX 1u
+// Unroll factors of the row loops: the rows of one unrolled body are fetched by a few wide
+// s_loads ahead of a single s_waitcnt, so SMEM latency (an L2 hit, ~300 cycles: the 130 KB image
+// does not fit the 16 KB scalar cache) is amortised over several rows instead of paid per row.
+#ifndef TSIMK_UNROLL_A
+#define TSIMK_UNROLL_A 4
+#endif
+#ifndef TSIMK_UNROLL_B
+#define TSIMK_UNROLL_B 8
+#endif
+#ifndef TSIMK_UNROLL_C
+#define TSIMK_UNROLL_C 4
+#endif
 #define TSIMK_GFLAG_FF_IS_ONE 1u
 
 struct SampleArgs {
@@ -181,6 +193,7 @@ __device__ __forceinline__ void eval_level(cptr img, cptr lvl, const uint32_t (&
 
     // ---- NodePhases (terms.py:56-73): prod_t (1 + w^(4 par + phase)) ----
     int a = 1, b = 0, c = 0, d = 0, p = 0;
+#pragma unroll TSIMK_UNROLL_A
     for (uint32_t t = 0; t < nA; ++t) {
       const uint32_t ph = row[0];
       const int par = (int)(row_par<W>(row + 1, x, ph >> 2) & 1u);
@@ -201,6 +214,7 @@ __device__ __forceinline__ void eval_level(cptr img, cptr lvl, const uint32_t (&
 
     // ---- HalfPiPhases (terms.py:94-107) + static phase: exponent of w ----
     uint32_t k = gr[G_PHASE];
+#pragma unroll TSIMK_UNROLL_B
     for (uint32_t t = 0; t < nB; ++t) {
       const uint32_t coeff = row[0];
       k += (row_par<W>(row + 1, x, 0) & 1u) * coeff;
@@ -209,6 +223,7 @@ __device__ __forceinline__ void eval_level(cptr img, cptr lvl, const uint32_t (&
 
     // ---- PiProducts (terms.py:125-144): (-1)^(sum psi*phi) ----
     uint32_t e = 0;
+#pragma unroll TSIMK_UNROLL_C
     for (uint32_t t = 0; t < nC; ++t) {
       const uint32_t cc = row[0];
       const uint32_t psi = row_par<W>(row + 1, x, cc & 1u);
@@ -291,6 +306,187 @@ __device__ __forceinline__ void eval_level(cptr img, cptr lvl, const uint32_t (&
   }
 }
 
+// ---------------------------------------------------------------------------
+// evaluate() of one level, "fast exact" formulation.
+//
+// Same exact Z[w]*2^k value as eval_level for every graph, hence - the canonical form being
+// unique - the same summed (a,b,c,d,power) and the same float32 amplitude whenever the
+// reference's own int32 arithmetic does not wrap (the packer only selects this path when
+// nA <= 30 per graph, for which the NodePhases scan provably cannot wrap).  What changes is how
+// the per-graph value is obtained:
+//   * NodePhases rows are grouped by phase class j = phase & 3 at pack time.  With m_j the number
+//     of class-j rows whose (parity ^ phase>>2) is 1,
+//         prod_t (1 + w^(4 par_t + phase_t))
+//           = [m_0 == 0] * BASE * (-i)^(m_1+m_2+m_3) * (sqrt2 + 1)^(m_3 - m_1),
+//     because (1-i) = (1+i)(-i), (1-w) = (1+w)(-i)(sqrt2-1), (1-w^3) = (1+w^3)(-i)(sqrt2+1).
+//     The lane only COUNTS parities (2 VALU ops per row after the parity) and fetches
+//     TABLE[m_3 - m_1] = canon(BASE * (sqrt2+1)^(m_3-m_1) * floatfactor * w^static_phase),
+//     built exactly at pack time; (-i)^M joins the per-lane phase exponent as 6*M.
+//   * HalfPi rows are grouped by coefficient (2, 4, 6): two counters and one XOR accumulator.
+// PiProducts, PhasePairs, the per-lane w^k rotation, the graph sum and the float epilogue are
+// the same code as the faithful path.
+// ---------------------------------------------------------------------------
+enum {
+  GF_NA01 = 0, GF_NA23, GF_NB24, GF_NB6C, GF_ROWS, GF_TBL, GF_N1, GF_ND, GF_POW2 = 10,
+  GF_APRE = 11, GF_APIM = 12, GF_FLAGS = 13
+};
+#define TSIMK_ZERO_POWER (1 << 20)  // power given to an exactly-zero term: a no-op in the aligned add
+
+template <int W>
+__device__ __forceinline__ uint32_t rows_count(cptr &row, uint32_t n, const uint32_t (&x)[W]) {
+  // sum over n rows [const, w0..] of ((popcount(row & x) + const) & 1)
+  uint32_t cnt = 0;
+#pragma unroll 4
+  for (uint32_t t = 0; t < n; ++t) {
+    cnt += row_par<W>(row + 1, x, row[0]) & 1u;
+    row += 1 + W;
+  }
+  return cnt;
+}
+
+template <int W>
+__device__ __forceinline__ uint32_t rows_count_nometa(cptr &row, uint32_t n, const uint32_t (&x)[W]) {
+  uint32_t cnt = 0;
+#pragma unroll 4
+  for (uint32_t t = 0; t < n; ++t) {
+    cnt += row_par<W>(row, x, 0) & 1u;
+    row += W;
+  }
+  return cnt;
+}
+
+template <int W>
+__device__ __forceinline__ void eval_level_fast(const uint32_t *gimg, cptr img, cptr lvl, const uint32_t (&x)[W],
+                                                float &out_re, float &out_im, int *exact5) {
+  const uint32_t G = lvl[L_G];
+  const bool approx = (lvl[L_FLAGS] & TSIMK_LFLAG_APPROX) != 0;
+  cptr gr = img + lvl[L_GRAPHS];
+
+  int sa = 0, sb = 0, sc = 0, sd = 0, sp = TSIMK_ZERO_POWER;
+  float fre = 0.0f, fim = 0.0f;
+
+  for (uint32_t g = 0; g < G; ++g, gr += G_WORDS) {
+    const uint32_t na01 = gr[GF_NA01], na23 = gr[GF_NA23], nb24 = gr[GF_NB24], nb6c = gr[GF_NB6C];
+    cptr row = img + gr[GF_ROWS];
+
+    // ---- NodePhases: count minus signs per phase class ----
+    const uint32_t m0 = rows_count<W>(row, na01 & 0xFFFFu, x);
+    const uint32_t m1 = rows_count<W>(row, na01 >> 16, x);
+    const uint32_t m2 = rows_count<W>(row, na23 & 0xFFFFu, x);
+    const uint32_t m3 = rows_count<W>(row, na23 >> 16, x);
+    // per-lane gather of the tabulated product (global memory, L1/L2 resident); issued here,
+    // consumed after the B/C/D rows so its latency hides behind them
+    const uint32_t *te = gimg + gr[GF_TBL] + 8u * (m3 - m1 + gr[GF_N1]);
+    const uint4 tv = *reinterpret_cast<const uint4 *>(te);
+    const uint32_t tpw = te[4];
+
+    // ---- HalfPiPhases grouped by coefficient + (-i)^M of the NodePhases ----
+    uint32_t k = 6u * (m1 + m2 + m3);
+    k += 2u * rows_count_nometa<W>(row, nb24 & 0xFFFFu, x);
+    {
+      uint32_t x4 = 0;
+      const uint32_t n4 = nb24 >> 16;
+#pragma unroll 4
+      for (uint32_t t = 0; t < n4; ++t) {
+        x4 ^= row_par<W>(row, x, 0);  // only bit 0 matters
+        row += W;
+      }
+      k += (x4 & 1u) << 2;
+    }
+    k += 6u * rows_count_nometa<W>(row, nb6c & 0xFFFFu, x);
+
+    // ---- PiProducts ----
+    uint32_t e = 0;
+    const uint32_t nC = nb6c >> 16;
+#pragma unroll 4
+    for (uint32_t t = 0; t < nC; ++t) {
+      const uint32_t cc = row[0];
+      const uint32_t psi = row_par<W>(row + 1, x, cc & 1u);
+      const uint32_t phi = row_par<W>(row + 1 + W, x, cc >> 1);
+      e ^= psi & phi;
+      row += 1 + 2 * W;
+    }
+    k += (e & 1u) << 2;
+
+    int a = (int)tv.x, b = (int)tv.y, c = (int)tv.z, d = (int)tv.w, p = (int)tpw;
+
+    // ---- PhasePairs (same sequential scan as the faithful path) ----
+    const uint32_t nD = gr[GF_ND];
+    if (nD) {
+      int da = 1, db = 0, dc = 0, dd = 0, dp = 0;
+      for (uint32_t t = 0; t < nD; ++t) {
+        const uint32_t pa = row_par<W>(row + 4, x, 0) & 1u;
+        const uint32_t pb = row_par<W>(row + 4 + W, x, 0) & 1u;
+        const uint32_t w0 = pa ? row[1] : row[0];
+        const uint32_t w1 = pa ? row[3] : row[2];
+        const uint32_t tw = pb ? w1 : w0;
+        row += 4 + 2 * W;
+        const int ta = (int)(int8_t)(tw), tb = (int)(int8_t)(tw >> 8), tc = (int)(int8_t)(tw >> 16),
+                  td = (int)(int8_t)(tw >> 24);
+        if (t == 0) {
+          da = ta; db = tb; dc = tc; dd = td;
+        } else {
+          zmul(da, db, dc, dd, ta, tb, tc, td);
+          reduce1(da, db, dc, dd, dp);
+        }
+      }
+      canon(da, db, dc, dd, dp);
+      zmul(a, b, c, d, da, db, dc, dd);
+      p += dp;
+    }
+
+    // rotate by w^k (k differs per lane)
+    {
+      const bool k1 = (k & 1u) != 0, k2 = (k & 2u) != 0;
+      int t0 = k1 ? d : a, t1 = k1 ? a : b, t2 = k1 ? b : c, t3 = k1 ? -c : d;
+      a = k2 ? -t2 : t0; b = k2 ? t3 : t1; c = k2 ? t0 : t2; d = k2 ? -t1 : t3;
+      const int nm = -(int)((k >> 2) & 1u);
+      a = (a ^ nm) - nm; b = (b ^ nm) - nm; c = (c ^ nm) - nm; d = (d ^ nm) - nm;
+    }
+    // a vanished NodePhases product (some 1 + w^4 factor): the term is exactly zero
+    if (m0 != 0) { a = 0; b = 0; c = 0; d = 0; }
+
+    if (!approx) {
+      p += (int)gr[GF_POW2];
+      // exactly-zero terms get a huge power, which makes the aligned add below a no-op for them
+      if ((a | b | c | d) == 0) p = TSIMK_ZERO_POWER;
+      const int d1 = max(sp - p, 0), d2 = max(p - sp, 0);
+      sa = (int)((unsigned)shl_sat(sa, d1) + (unsigned)shl_sat(a, d2));
+      sb = (int)((unsigned)shl_sat(sb, d1) + (unsigned)shl_sat(b, d2));
+      sc = (int)((unsigned)shl_sat(sc, d1) + (unsigned)shl_sat(c, d2));
+      sd = (int)((unsigned)shl_sat(sd, d1) + (unsigned)shl_sat(d, d2));
+      sp = min(sp, p);
+      reduce1(sa, sb, sc, sd, sp);
+    } else {
+      float zr, zi;
+      to_complex(a, b, c, d, p, zr, zi);
+      const float ar = __uint_as_float(gr[GF_APRE]), ai = __uint_as_float(gr[GF_APIM]);
+      const float tr = __fsub_rn(__fmul_rn(zr, ar), __fmul_rn(zi, ai));
+      const float ti = __fadd_rn(__fmul_rn(zr, ai), __fmul_rn(zi, ar));
+      const float s = ldexpf(1.0f, (int)gr[GF_POW2]);
+      fre = __fadd_rn(fre, __fmul_rn(tr, s));
+      fim = __fadd_rn(fim, __fmul_rn(ti, s));
+    }
+  }
+
+  if (!approx) {
+    canon(sa, sb, sc, sd, sp);
+    if ((sa | sb | sc | sd) == 0) sp = 0;
+    to_complex(sa, sb, sc, sd, sp, out_re, out_im);
+    if (exact5) { exact5[0] = sa; exact5[1] = sb; exact5[2] = sc; exact5[3] = sd; exact5[4] = sp; }
+  } else {
+    out_re = fre; out_im = fim;
+    if (exact5) { exact5[0] = exact5[1] = exact5[2] = exact5[3] = exact5[4] = 0; }
+  }
+}
+
+template <int W, bool FAST>
+__device__ __forceinline__ void eval_any(const uint32_t *gimg, cptr img, cptr lvl, const uint32_t (&x)[W],
+                                         float &re, float &im, int *exact5) {
+  if constexpr (FAST) eval_level_fast<W>(gimg, img, lvl, x, re, im, exact5);
+  else eval_level<W>(img, lvl, x, re, im, exact5);
+}
+
 // jnp.maximum semantics (NaN propagates)
 __device__ __forceinline__ float nanmax(float a, float b) {
   return (isnan(a) || isnan(b)) ? NAN : fmaxf(a, b);
@@ -299,7 +495,7 @@ __device__ __forceinline__ float nanmax(float a, float b) {
 // ---------------------------------------------------------------------------
 // one component: _sample_component (sampler.py:28-81)
 // ---------------------------------------------------------------------------
-template <int W>
+template <int W, bool FAST>
 __device__ __forceinline__ void run_component(const SampleArgs &A, cptr img, cptr comp, const uint32_t *lds_f,
                                               uint32_t *lds_o, int nthr, unsigned long long shot,
                                               bool check_lane, int comp_index) {
@@ -324,7 +520,7 @@ __device__ __forceinline__ void run_component(const SampleArgs &A, cptr img, cpt
   }
 
   float re, im;
-  eval_level<W>(img, levels, x, re, im, nullptr);  // normalisation (sampler.py:54)
+  eval_any<W, FAST>(A.img, img, levels, x, re, im, nullptr);  // normalisation (sampler.py:54)
   float prev = cabs32(re, im);
   float maxdev = 0.0f;
 
@@ -339,7 +535,7 @@ __device__ __forceinline__ void run_component(const SampleArgs &A, cptr img, cpt
 #pragma unroll
       for (int w = 0; w < W; ++w)
         if ((uint32_t)w == wi) x[w] = (pass == 0) ? (x[w] | bm) : (x[w] & ~bm);
-      eval_level<W>(img, lvl, x, re, im, nullptr);
+      eval_any<W, FAST>(A.img, img, lvl, x, re, im, nullptr);
       const float v = cabs32(re, im);
       if (pass == 0) pr[0] = v; else pr[1] = v;
     }
@@ -369,7 +565,7 @@ extern __shared__ uint32_t tsimk_lds[];
 
 // WMAX = largest per-component word count in the program: the kernel is instantiated per
 // WMAX so that narrow programs are not charged the registers of the wide variants.
-template <int WMAX>
+template <int WMAX, bool FAST>
 __global__ void __launch_bounds__(256) k_sample(SampleArgs A) {
   const int nthr = blockDim.x;
   const long long row = (long long)blockIdx.x * nthr + threadIdx.x;
@@ -406,7 +602,7 @@ __global__ void __launch_bounds__(256) k_sample(SampleArgs A) {
     switch (comp[C_W]) {
 #define TSIMK_CASE(WV)                                                                        \
   case WV:                                                                                    \
-    if constexpr (WV <= WMAX) run_component<WV>(A, img, comp, lds_f, lds_o, nthr, shot, check_lane, ci); \
+    if constexpr (WV <= WMAX) run_component<WV, FAST>(A, img, comp, lds_f, lds_o, nthr, shot, check_lane, ci); \
     break;
       TSIMK_CASE(1) TSIMK_CASE(2) TSIMK_CASE(3) TSIMK_CASE(4) TSIMK_CASE(6) TSIMK_CASE(8)
       TSIMK_CASE(12) TSIMK_CASE(16)
@@ -424,7 +620,7 @@ __global__ void __launch_bounds__(256) k_sample(SampleArgs A) {
 // ---------------------------------------------------------------------------
 // evaluate() seam (compile/evaluate.py:16)
 // ---------------------------------------------------------------------------
-template <int W>
+template <int W, bool FAST>
 __global__ void __launch_bounds__(256) k_evaluate(EvalArgs A) {
   const long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (row >= A.B) return;
@@ -434,7 +630,7 @@ __global__ void __launch_bounds__(256) k_evaluate(EvalArgs A) {
   for (int w = 0; w < W; ++w) x[w] = A.x[row * W + w];
   float re, im;
   int ex[5];
-  eval_level<W>(img, img + A.level_off, x, re, im, ex);
+  eval_any<W, FAST>(A.img, img, img + A.level_off, x, re, im, ex);
   A.re[row] = re;
   A.im[row] = im;
   if (A.abs) A.abs[row] = cabs32(re, im);

@@ -367,6 +367,116 @@ static void unit_plus_one(int k, long long out[4]) {  // 1 + w^k
   out[0] += 1;
 }
 
+// ---- GF(2) algebra used by the fast packer -------------------------------------------------
+// An affine form c ^ <m, x> over the level's P parameters.
+struct Affine {
+  std::vector<uint64_t> m;
+  bool c = false;
+};
+
+static Affine affine_from(const uint8_t *bits, int P, bool c) {
+  Affine a;
+  a.m.assign((size_t)(P + 63) / 64 + 1, 0ull);
+  for (int i = 0; i < P; ++i)
+    if (bits[i] & 1) a.m[i >> 6] ^= 1ull << (i & 63);
+  a.c = c;
+  return a;
+}
+
+// A quadratic form over GF(2): q(x) = sum_{i<j} B[i][j] x_i x_j  ^  <lin, x>  ^  c.
+// B is kept symmetric with zero diagonal (x_i^2 = x_i goes to `lin`).
+struct QForm {
+  int P = 0, PW = 0;
+  std::vector<uint64_t> B;  // P rows x PW words
+  std::vector<uint64_t> lin;
+  bool c = false;
+  explicit QForm(int p) : P(p), PW((p + 63) / 64 + 1), B((size_t)p * ((p + 63) / 64 + 1), 0ull), lin((p + 63) / 64 + 1, 0ull) {}
+  uint64_t *row(int i) { return &B[(size_t)i * PW]; }
+  void add_linear(const Affine &a) {
+    for (int w = 0; w < PW && w < (int)a.m.size(); ++w) lin[w] ^= a.m[w];
+    c ^= a.c;
+  }
+  // q ^= (a.c ^ <a.m,x>) * (b.c ^ <b.m,x>)
+  void add_product(const Affine &a, const Affine &b) {
+    for (int i = 0; i < P; ++i) {
+      if (!((a.m[i >> 6] >> (i & 63)) & 1)) continue;
+      uint64_t *ri = row(i);
+      for (int w = 0; w < PW && w < (int)b.m.size(); ++w) ri[w] ^= b.m[w];  // row i ^= b (may set the diagonal)
+    }
+    // symmetrise: the loop above added the ordered pairs (i in a, j in b); fold (i,j) and (j,i) together
+    // by rebuilding the symmetric part lazily in `finish()`.
+    if (a.c) for (int w = 0; w < PW && w < (int)b.m.size(); ++w) lin[w] ^= b.m[w];
+    if (b.c) for (int w = 0; w < PW && w < (int)a.m.size(); ++w) lin[w] ^= a.m[w];
+    c ^= (a.c && b.c);
+  }
+  // After all add_product calls B holds an arbitrary (non-symmetric) bilinear matrix M with
+  // q = x^T M x.  Convert to the canonical alternating form: B'[i][j] = M[i][j] ^ M[j][i], diagonal -> lin.
+  void finish() {
+    for (int i = 0; i < P; ++i)
+      if ((row(i)[i >> 6] >> (i & 63)) & 1) {
+        lin[i >> 6] ^= 1ull << (i & 63);
+        row(i)[i >> 6] ^= 1ull << (i & 63);
+      }
+    for (int i = 0; i < P; ++i)
+      for (int j = i + 1; j < P; ++j) {
+        const bool mij = (row(i)[j >> 6] >> (j & 63)) & 1, mji = (row(j)[i >> 6] >> (i & 63)) & 1;
+        const bool s = mij ^ mji;
+        if (mij != s) row(i)[j >> 6] ^= 1ull << (j & 63);
+        if (mji != s) row(j)[i >> 6] ^= 1ull << (i & 63);
+      }
+  }
+  bool get(int i, int j) { return (row(i)[j >> 6] >> (j & 63)) & 1; }
+};
+
+// Dickson reduction: q = XOR_s <u_s,x><v_s,x> ^ <lin,x> ^ c with rank(B)/2 product pairs.
+// Pivot on (i,j) with B[i][j] = 1: with alpha = B[i] \ {i,j}, beta = B[j] \ {i,j},
+//   x_i x_j ^ x_i<alpha,x> ^ x_j<beta,x> = (x_i ^ <beta,x>)(x_j ^ <alpha,x>) ^ <alpha,x><beta,x>.
+static void dickson_reduce(QForm &q, std::vector<std::vector<uint64_t>> &us, std::vector<std::vector<uint64_t>> &vs) {
+  const int P = q.P, PW = q.PW;
+  for (int i = 0; i < P; ++i) {
+    for (;;) {
+      int j = -1;
+      for (int t = 0; t < P; ++t)
+        if (q.get(i, t)) { j = t; break; }
+      if (j < 0) break;
+      std::vector<uint64_t> alpha(q.row(i), q.row(i) + PW), beta(q.row(j), q.row(j) + PW);
+      alpha[j >> 6] &= ~(1ull << (j & 63));  // B[i][i] is 0 already
+      beta[i >> 6] &= ~(1ull << (i & 63));
+      std::vector<uint64_t> u = beta, v = alpha;
+      u[i >> 6] ^= 1ull << (i & 63);
+      v[j >> 6] ^= 1ull << (j & 63);
+      us.push_back(u);
+      vs.push_back(v);
+      // remove variables i and j from B
+      for (int w = 0; w < PW; ++w) q.row(i)[w] = q.row(j)[w] = 0ull;
+      for (int k = 0; k < P; ++k) {
+        q.row(k)[i >> 6] &= ~(1ull << (i & 63));
+        q.row(k)[j >> 6] &= ~(1ull << (j & 63));
+      }
+      // q ^= <alpha,x><beta,x>: B[k][l] ^= alpha_k beta_l ^ alpha_l beta_k ; lin_k ^= alpha_k beta_k
+      for (int k = 0; k < P; ++k) {
+        const bool ak = (alpha[k >> 6] >> (k & 63)) & 1, bk = (beta[k >> 6] >> (k & 63)) & 1;
+        if (ak) for (int w = 0; w < PW; ++w) q.row(k)[w] ^= beta[w];
+        if (bk) for (int w = 0; w < PW; ++w) q.row(k)[w] ^= alpha[w];
+        if (ak && bk) q.lin[k >> 6] ^= 1ull << (k & 63);
+        q.row(k)[k >> 6] &= ~(1ull << (k & 63));  // diagonal stays zero
+      }
+    }
+  }
+}
+
+static bool push_mask_row(std::vector<uint32_t> &dst, const std::vector<uint64_t> &m, int P, int W) {
+  bool any = false;
+  const size_t base = dst.size();
+  dst.resize(base + W, 0u);
+  for (int i = 0; i < P; ++i)
+    if ((m[i >> 6] >> (i & 63)) & 1) {
+      dst[base + (i >> 5)] |= 1u << (i & 31);
+      any = true;
+    }
+  return any;
+}
+
 // Can this level be evaluated by the counting formulation?  (see eval_level_fast)
 static bool level_fast_eligible(const HostLevel &h) {
   const tsim_level_desc &d = h.d;
@@ -377,15 +487,22 @@ static bool level_fast_eligible(const HostLevel &h) {
       const unsigned c = h.u8[2][(size_t)g * d.tb + t] & 7u;
       if (c & 1u) return false;  // odd eighth-turn coefficients never come out of the compiler
     }
-    if (d.tb > 60000 || d.tc > 60000 || d.td > 60000) return false;
+    if (d.td > 60000 || h.P > 60000) return false;
     for (int j = 0; j < 4; ++j)
       if (std::llabs((long long)h.i32[2][(size_t)g * 4 + j]) > (1ll << 20)) return false;
   }
   return true;
 }
 
-// Build graph records + class-sorted rows + NodePhases tables.  Returns false if a table entry
-// does not fit int32 (the caller then falls back to the faithful layout).
+// Build graph records + rows + NodePhases tables for eval_level_fast.  Returns false if a table
+// entry does not fit int32 (the caller then falls back to the faithful layout).
+//
+// Per graph the w-exponent contributed by HalfPi rows (coefficients 2,4,6), PiProducts and the
+// (-i)^(m1+m2+m3) of the NodePhases is rewritten at pack time as
+//     k(x) = k0 + 2 * <lam, x> + 4 * ( <lin, x> ^ XOR_s <u_s,x><v_s,x> )          (mod 8)
+// using  2*(sum of bits p_t) = 2*(XOR p_t) + 4*e2(p)  (mod 8)  for the list of bits that enter with
+// coefficient 2 (coefficient 6 = 2 + 4), e2 = second elementary symmetric polynomial, and the Dickson
+// normal form of the resulting GF(2) quadratic form.  k0 is folded into the table as a rotation.
 static bool pack_level_fast(HostLevel &h, int W, std::vector<uint32_t> &tables) {
   const int G = h.G, P = h.P;
   const tsim_level_desc &d = h.d;
@@ -393,27 +510,84 @@ static bool pack_level_fast(HostLevel &h, int W, std::vector<uint32_t> &tables) 
   h.rows.clear();
   h.n_rows = 0;
   tables.clear();
-  std::vector<uint32_t> tmp;
   for (int g = 0; g < G; ++g) {
     uint32_t *rec = &h.graph_rec[(size_t)g * G_WORDS];
     rec[GF_ROWS] = (uint32_t)h.rows.size();
-    // ---- NodePhases rows, grouped by phase class (phase & 3); the row constant is phase >> 2
     const int nA = d.ta ? h.i32[0][g] : 0;
+    std::vector<Affine> two;  // bits entering the exponent with coefficient 2
+    QForm q4(P);              // bit entering with coefficient 4
+    int k0 = h.u8[12][g] & 7; // static phase
+    auto add_six = [&](const Affine &a) {  // 6*p = 2*p + 4*p
+      two.push_back(a);
+      q4.add_linear(a);
+    };
+    // ---- NodePhases rows counted per class 0, 1, 3 (class 2 only feeds the exponent)
     int n[4] = {0, 0, 0, 0};
     for (int cls = 0; cls < 4; ++cls)
       for (int t = 0; t < nA; ++t) {
         const unsigned ph = h.u8[0][(size_t)g * d.ta + t] & 7u;
         if ((int)(ph & 3u) != cls) continue;
-        h.rows.push_back(ph >> 2);
-        pack_row(h.rows, &h.u8[1][((size_t)g * d.ta + t) * P], P, W);
+        const uint8_t *bits = &h.u8[1][((size_t)g * d.ta + t) * P];
         ++n[cls];
+        if (cls != 0) add_six(affine_from(bits, P, (ph >> 2) != 0));  // (-i)^(par')
+        if (cls == 2) continue;
+        h.rows.push_back(ph >> 2);
+        pack_row(h.rows, bits, P, W);
       }
-    rec[GF_NA01] = (uint32_t)n[0] | ((uint32_t)n[1] << 16);
-    rec[GF_NA23] = (uint32_t)n[2] | ((uint32_t)n[3] << 16);
+    rec[GF_N01] = (uint32_t)n[0] | ((uint32_t)n[1] << 16);
     rec[GF_N1] = (uint32_t)n[1];
+    // ---- HalfPi rows
+    for (int t = 0; t < d.tb; ++t) {
+      const uint32_t coeff = h.u8[2][(size_t)g * d.tb + t] & 7u;
+      if (!coeff) continue;
+      const Affine a = affine_from(&h.u8[3][((size_t)g * d.tb + t) * P], P, false);
+      if (coeff == 2) two.push_back(a);
+      else if (coeff == 4) q4.add_linear(a);
+      else add_six(a);
+    }
+    // ---- PiProducts: 4 * psi * phi
+    for (int t = 0; t < d.tc; ++t) {
+      const Affine psi = affine_from(&h.u8[5][((size_t)g * d.tc + t) * P], P, h.u8[4][(size_t)g * d.tc + t] & 1u);
+      const Affine phi = affine_from(&h.u8[7][((size_t)g * d.tc + t) * P], P, h.u8[6][(size_t)g * d.tc + t] & 1u);
+      q4.add_product(psi, phi);
+    }
+    // ---- 2 * sum(two) = 2 * XOR(two) + 4 * e2(two)
+    Affine lam;
+    lam.m.assign((size_t)(P + 63) / 64 + 1, 0ull);
+    for (size_t s = 0; s < two.size(); ++s) {
+      for (size_t w = 0; w < lam.m.size(); ++w) lam.m[w] ^= two[s].m[w];
+      lam.c ^= two[s].c;
+      for (size_t t2 = s + 1; t2 < two.size(); ++t2) q4.add_product(two[s], two[t2]);
+    }
+    // 2*(1 ^ y) = 2 + 6*y = 2 + 2*y + 4*y
+    if (lam.c) {
+      k0 += 2;
+      Affine y = lam;
+      y.c = false;
+      q4.add_linear(y);
+    }
+    q4.finish();
+    std::vector<std::vector<uint64_t>> us, vs;
+    dickson_reduce(q4, us, vs);
+    if (q4.c) k0 += 4;
+    // ---- rows: lam, lin, then the product pairs
+    uint32_t flags = 0;
+    {
+      std::vector<uint32_t> tmp;
+      if (push_mask_row(tmp, lam.m, P, W)) { flags |= 1u; h.rows.insert(h.rows.end(), tmp.begin(), tmp.end()); }
+      tmp.clear();
+      if (push_mask_row(tmp, q4.lin, P, W)) { flags |= 2u; h.rows.insert(h.rows.end(), tmp.begin(), tmp.end()); }
+    }
+    for (size_t s = 0; s < us.size(); ++s) {
+      push_mask_row(h.rows, us[s], P, W);
+      push_mask_row(h.rows, vs[s], P, W);
+    }
+    if (us.size() > 60000) return false;
+    rec[GF_N3H] = (uint32_t)n[3] | ((uint32_t)us.size() << 16);
+    rec[GF_FLAGS] = flags;
     // ---- table over delta = m3 - m1 in [-n1, n3] (entry index delta + n1), 8 words per entry:
     //      canon( 2^n0 (1+i)^n2 (1+w)^(n1-m1) (1-w)^m1 (1+w^3)^(n3-m3) (1-w^3)^m3 * i^(m1+m3)
-    //             * floatfactor * w^static_phase )   with m3 = max(delta,0), m1 = max(-delta,0)
+    //             * floatfactor * w^k0 )   with m3 = max(delta,0), m1 = max(-delta,0)
     rec[GF_TBL] = (uint32_t)tables.size();
     const long long ff[4] = {h.i32[2][(size_t)g * 4], h.i32[2][(size_t)g * 4 + 1], h.i32[2][(size_t)g * 4 + 2],
                              h.i32[2][(size_t)g * 4 + 3]};
@@ -431,45 +605,16 @@ static bool pack_level_fast(HostLevel &h, int W, std::vector<uint32_t> &tables) 
       mul_k(5, m1);
       mul_k(3, n[3] - m3);
       mul_k(7, m3);
-      const long long rot[4] = {kUnit[(2 * (m1 + m3)) & 7][0], kUnit[(2 * (m1 + m3)) & 7][1],
-                                kUnit[(2 * (m1 + m3)) & 7][2], kUnit[(2 * (m1 + m3)) & 7][3]};
+      const int r = (2 * (m1 + m3) + k0) & 7;
+      const long long rot[4] = {kUnit[r][0], kUnit[r][1], kUnit[r][2], kUnit[r][3]};
       zw_mul(z, rot);
       zw_mul(z, ff);
-      const int sp = h.u8[12][g] & 7;
-      const long long st[4] = {kUnit[sp][0], kUnit[sp][1], kUnit[sp][2], kUnit[sp][3]};
-      zw_mul(z, st);
       for (int j = 0; j < 4; ++j)
         if (z.c[j] > INT32_MAX || z.c[j] < INT32_MIN) return false;
       for (int j = 0; j < 4; ++j) tables.push_back((uint32_t)(int32_t)z.c[j]);
       tables.push_back((uint32_t)z.p);
       tables.push_back(0u); tables.push_back(0u); tables.push_back(0u);
     }
-    // ---- HalfPi rows grouped by coefficient 2, 4, 6 (no meta word)
-    int nb[3] = {0, 0, 0};
-    for (int grp = 0; grp < 3; ++grp)
-      for (int t = 0; t < d.tb; ++t) {
-        const uint32_t coeff = h.u8[2][(size_t)g * d.tb + t] & 7u;
-        if (coeff != (uint32_t)(2 * grp + 2)) continue;
-        tmp.clear();
-        if (!pack_row(tmp, &h.u8[3][((size_t)g * d.tb + t) * P], P, W)) continue;
-        h.rows.insert(h.rows.end(), tmp.begin(), tmp.end());
-        ++nb[grp];
-      }
-    rec[GF_NB24] = (uint32_t)nb[0] | ((uint32_t)nb[1] << 16);
-    // ---- PiProducts (identical layout to the faithful path)
-    int nC = 0;
-    for (int t = 0; t < d.tc; ++t) {
-      const uint32_t pc = h.u8[4][(size_t)g * d.tc + t] & 1u, qc = h.u8[6][(size_t)g * d.tc + t] & 1u;
-      std::vector<uint32_t> r1, r2;
-      const bool any1 = pack_row(r1, &h.u8[5][((size_t)g * d.tc + t) * P], P, W);
-      const bool any2 = pack_row(r2, &h.u8[7][((size_t)g * d.tc + t) * P], P, W);
-      if ((!any1 && !pc) || (!any2 && !qc)) continue;
-      h.rows.push_back(pc | (qc << 1));
-      h.rows.insert(h.rows.end(), r1.begin(), r1.end());
-      h.rows.insert(h.rows.end(), r2.begin(), r2.end());
-      ++nC;
-    }
-    rec[GF_NB6C] = (uint32_t)nb[2] | ((uint32_t)nC << 16);
     // ---- PhasePairs (identical layout to the faithful path)
     const int nD = d.td ? h.i32[1][g] : 0;
     for (int t = 0; t < nD; ++t) {
@@ -488,7 +633,7 @@ static bool pack_level_fast(HostLevel &h, int W, std::vector<uint32_t> &tables) 
       pack_row(h.rows, &h.u8[11][((size_t)g * d.td + t) * P], P, W);
     }
     rec[GF_ND] = (uint32_t)nD;
-    h.n_rows += nA + nb[0] + nb[1] + nb[2] + 2 * nC + 2 * nD;
+    h.n_rows += n[0] + n[1] + n[3] + (flags & 1u) + ((flags >> 1) & 1u) + 2 * (long long)us.size() + 2 * nD;
     rec[GF_POW2] = (uint32_t)h.i32[3][g];
     memcpy(&rec[GF_APRE], &h.approx_v[2 * (size_t)g], 4);
     memcpy(&rec[GF_APIM], &h.approx_v[2 * (size_t)g + 1], 4);

@@ -166,11 +166,16 @@ __device__ __forceinline__ float uniform01(uint32_t k0, uint32_t k1, unsigned lo
 // ---------------------------------------------------------------------------
 // GF(2) row parity: popcount(AND) over W 32-bit words (+ constant)
 // ---------------------------------------------------------------------------
+// (a & b) ^ c in ONE full-rate VALU op (v_bitop3_b32, truth table 0x6A)
+__device__ __forceinline__ uint32_t and_xor(uint32_t a, uint32_t b, uint32_t c) {
+  return __builtin_amdgcn_bitop3_b32(a, b, c, 0x6A);
+}
+
 template <int W>
 __device__ __forceinline__ uint32_t row_par(cptr r, const uint32_t (&x)[W], uint32_t c) {
-  uint32_t t = r[0] & x[0];
+  uint32_t t = r[W - 1] & x[W - 1];
 #pragma unroll
-  for (int w = 1; w < W; ++w) t ^= r[w] & x[w];
+  for (int w = W - 2; w >= 0; --w) t = and_xor(r[w], x[w], t);
   return (uint32_t)__builtin_popcount(t) + c;  // caller masks bit 0
 }
 
@@ -327,8 +332,10 @@ __device__ __forceinline__ void eval_level(cptr img, cptr lvl, const uint32_t (&
 // the same code as the faithful path.
 // ---------------------------------------------------------------------------
 enum {
-  GF_NA01 = 0, GF_NA23, GF_NB24, GF_NB6C, GF_ROWS, GF_TBL, GF_N1, GF_ND, GF_POW2 = 10,
-  GF_APRE = 11, GF_APIM = 12, GF_FLAGS = 13
+  GF_N01 = 0,   // n0 | n1 << 16   NodePhases rows of phase class 0 / 1 (counted)
+  GF_N3H = 1,   // n3 | h << 16    class-3 rows (counted) / number of product pairs
+  GF_FLAGS = 2, // bit0: a lambda row is present, bit1: a linear row is present
+  GF_ND = 3, GF_ROWS = 4, GF_TBL = 5, GF_N1 = 6, GF_POW2 = 10, GF_APRE = 11, GF_APIM = 12
 };
 #define TSIMK_ZERO_POWER (1 << 20)  // power given to an exactly-zero term: a no-op in the aligned add
 
@@ -366,45 +373,30 @@ __device__ __forceinline__ void eval_level_fast(const uint32_t *gimg, cptr img, 
   float fre = 0.0f, fim = 0.0f;
 
   for (uint32_t g = 0; g < G; ++g, gr += G_WORDS) {
-    const uint32_t na01 = gr[GF_NA01], na23 = gr[GF_NA23], nb24 = gr[GF_NB24], nb6c = gr[GF_NB6C];
+    const uint32_t n01 = gr[GF_N01], n3h = gr[GF_N3H], flags = gr[GF_FLAGS];
     cptr row = img + gr[GF_ROWS];
 
-    // ---- NodePhases: count minus signs per phase class ----
-    const uint32_t m0 = rows_count<W>(row, na01 & 0xFFFFu, x);
-    const uint32_t m1 = rows_count<W>(row, na01 >> 16, x);
-    const uint32_t m2 = rows_count<W>(row, na23 & 0xFFFFu, x);
-    const uint32_t m3 = rows_count<W>(row, na23 >> 16, x);
+    // ---- NodePhases: count minus signs in the phase classes that need an integer count ----
+    const uint32_t m0 = rows_count<W>(row, n01 & 0xFFFFu, x);
+    const uint32_t m1 = rows_count<W>(row, n01 >> 16, x);
+    const uint32_t m3 = rows_count<W>(row, n3h & 0xFFFFu, x);
     // per-lane gather of the tabulated product (global memory, L1/L2 resident); issued here,
-    // consumed after the B/C/D rows so its latency hides behind them
+    // consumed after the remaining rows so its latency hides behind them
     const uint32_t *te = gimg + gr[GF_TBL] + 8u * (m3 - m1 + gr[GF_N1]);
     const uint4 tv = *reinterpret_cast<const uint4 *>(te);
     const uint32_t tpw = te[4];
 
-    // ---- HalfPiPhases grouped by coefficient + (-i)^M of the NodePhases ----
-    uint32_t k = 6u * (m1 + m2 + m3);
-    k += 2u * rows_count_nometa<W>(row, nb24 & 0xFFFFu, x);
-    {
-      uint32_t x4 = 0;
-      const uint32_t n4 = nb24 >> 16;
+    // ---- exponent of w: k = 2 <lam,x> + 4 ( <lin,x> ^ XOR_s <u_s,x><v_s,x> ) (k0 is in the table)
+    uint32_t k = 0, e = 0;
+    if (flags & 1u) { k = (row_par<W>(row, x, 0) & 1u) << 1; row += W; }
+    if (flags & 2u) { e = row_par<W>(row, x, 0); row += W; }
+    const uint32_t nH = n3h >> 16;
 #pragma unroll 4
-      for (uint32_t t = 0; t < n4; ++t) {
-        x4 ^= row_par<W>(row, x, 0);  // only bit 0 matters
-        row += W;
-      }
-      k += (x4 & 1u) << 2;
-    }
-    k += 6u * rows_count_nometa<W>(row, nb6c & 0xFFFFu, x);
-
-    // ---- PiProducts ----
-    uint32_t e = 0;
-    const uint32_t nC = nb6c >> 16;
-#pragma unroll 4
-    for (uint32_t t = 0; t < nC; ++t) {
-      const uint32_t cc = row[0];
-      const uint32_t psi = row_par<W>(row + 1, x, cc & 1u);
-      const uint32_t phi = row_par<W>(row + 1 + W, x, cc >> 1);
-      e ^= psi & phi;
-      row += 1 + 2 * W;
+    for (uint32_t t = 0; t < nH; ++t) {
+      const uint32_t pu = row_par<W>(row, x, 0);
+      const uint32_t pv = row_par<W>(row + W, x, 0);
+      e = and_xor(pu, pv, e);
+      row += 2 * W;
     }
     k += (e & 1u) << 2;
 

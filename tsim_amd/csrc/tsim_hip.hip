@@ -8,6 +8,7 @@
 #include "tsim_kernels.hip.h"
 
 #include <algorithm>
+#include <array>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -503,13 +504,17 @@ static bool level_fast_eligible(const HostLevel &h) {
 // using  2*(sum of bits p_t) = 2*(XOR p_t) + 4*e2(p)  (mod 8)  for the list of bits that enter with
 // coefficient 2 (coefficient 6 = 2 + 4), e2 = second elementary symmetric polynomial, and the Dickson
 // normal form of the resulting GF(2) quadratic form.  k0 is folded into the table as a rotation.
-static bool pack_level_fast(HostLevel &h, int W, std::vector<uint32_t> &tables) {
+static bool pack_level_fast(HostLevel &h, int W, std::vector<uint32_t> &tables, bool &fixed_out, int &frame_out) {
   const int G = h.G, P = h.P;
   const tsim_level_desc &d = h.d;
   h.graph_rec.assign((size_t)G * G_WORDS, 0u);
   h.rows.clear();
   h.n_rows = 0;
   tables.clear();
+  fixed_out = false;
+  frame_out = 0;
+  std::vector<std::vector<ZW>> entries((size_t)G);  // per graph: the non-zero table entries
+  bool all_tabled = true;
   for (int g = 0; g < G; ++g) {
     uint32_t *rec = &h.graph_rec[(size_t)g * G_WORDS];
     rec[GF_ROWS] = (uint32_t)h.rows.size();
@@ -536,6 +541,30 @@ static bool pack_level_fast(HostLevel &h, int W, std::vector<uint32_t> &tables) 
       }
     rec[GF_N01] = (uint32_t)n[0] | ((uint32_t)n[1] << 16);
     rec[GF_N1] = (uint32_t)n[1];
+    // ---- PhasePairs rows: two table-index bits per term when the combined table stays small,
+    //      else the faithful sequential scan (rows carry the four tabulated term values)
+    const int nD = d.td ? h.i32[1][g] : 0;
+    const long long combos = nD <= 3 ? (long long)(n[1] + n[3] + 1) << (2 * nD) : (1ll << 40);
+    const bool d_tabled = nD > 0 && combos <= 256;
+    if (nD > 0 && !d_tabled) all_tabled = false;
+    std::vector<std::array<std::array<int, 4>, 4>> dterm((size_t)nD);  // [t][pa + 2 pb] -> term value
+    for (int t = 0; t < nD; ++t) {
+      const int al = h.u8[8][(size_t)g * d.td + t] & 7, be = h.u8[10][(size_t)g * d.td + t] & 7;
+      for (int idx = 0; idx < 4; ++idx) {
+        const int pa = idx & 1, pb = idx >> 1;
+        const int a1 = (al + 4 * pa) & 7, b1 = (be + 4 * pb) & 7, g1 = (a1 + b1) & 7;
+        uint32_t w = 0;
+        for (int j = 0; j < 4; ++j) {
+          const int v = (j == 0 ? 1 : 0) + kUnit[a1][j] + kUnit[b1][j] - kUnit[g1][j];
+          dterm[t][idx][j] = v;
+          w |= (uint32_t)(uint8_t)(int8_t)v << (8 * j);
+        }
+        if (!d_tabled) h.rows.push_back(w);
+      }
+      pack_row(h.rows, &h.u8[9][((size_t)g * d.td + t) * P], P, W);
+      pack_row(h.rows, &h.u8[11][((size_t)g * d.td + t) * P], P, W);
+    }
+    rec[GF_ND] = (uint32_t)nD;
     // ---- HalfPi rows
     for (int t = 0; t < d.tb; ++t) {
       const uint32_t coeff = h.u8[2][(size_t)g * d.tb + t] & 7u;
@@ -559,8 +588,7 @@ static bool pack_level_fast(HostLevel &h, int W, std::vector<uint32_t> &tables) 
       lam.c ^= two[s].c;
       for (size_t t2 = s + 1; t2 < two.size(); ++t2) q4.add_product(two[s], two[t2]);
     }
-    // 2*(1 ^ y) = 2 + 6*y = 2 + 2*y + 4*y
-    if (lam.c) {
+    if (lam.c) {  // 2*(1 ^ y) = 2 + 6*y = 2 + 2*y + 4*y
       k0 += 2;
       Affine y = lam;
       y.c = false;
@@ -570,27 +598,30 @@ static bool pack_level_fast(HostLevel &h, int W, std::vector<uint32_t> &tables) 
     std::vector<std::vector<uint64_t>> us, vs;
     dickson_reduce(q4, us, vs);
     if (q4.c) k0 += 4;
+    if (us.size() > 60000) return false;
     // ---- rows: lam, lin, then the product pairs
-    uint32_t flags = 0;
+    uint32_t flags = d_tabled ? TSIMK_GFLAG_D_TABLED : 0u;
     {
       std::vector<uint32_t> tmp;
-      if (push_mask_row(tmp, lam.m, P, W)) { flags |= 1u; h.rows.insert(h.rows.end(), tmp.begin(), tmp.end()); }
+      if (push_mask_row(tmp, lam.m, P, W)) { flags |= TSIMK_GFLAG_LAM; h.rows.insert(h.rows.end(), tmp.begin(), tmp.end()); }
       tmp.clear();
-      if (push_mask_row(tmp, q4.lin, P, W)) { flags |= 2u; h.rows.insert(h.rows.end(), tmp.begin(), tmp.end()); }
+      if (push_mask_row(tmp, q4.lin, P, W)) { flags |= TSIMK_GFLAG_LIN; h.rows.insert(h.rows.end(), tmp.begin(), tmp.end()); }
     }
     for (size_t s = 0; s < us.size(); ++s) {
       push_mask_row(h.rows, us[s], P, W);
       push_mask_row(h.rows, vs[s], P, W);
     }
-    if (us.size() > 60000) return false;
     rec[GF_N3H] = (uint32_t)n[3] | ((uint32_t)us.size() << 16);
     rec[GF_FLAGS] = flags;
-    // ---- table over delta = m3 - m1 in [-n1, n3] (entry index delta + n1), 8 words per entry:
-    //      canon( 2^n0 (1+i)^n2 (1+w)^(n1-m1) (1-w)^m1 (1+w^3)^(n3-m3) (1-w^3)^m3 * i^(m1+m3)
-    //             * floatfactor * w^k0 )   with m3 = max(delta,0), m1 = max(-delta,0)
-    rec[GF_TBL] = (uint32_t)tables.size();
+    h.n_rows += n[0] + n[1] + n[3] + ((flags & TSIMK_GFLAG_LAM) ? 1 : 0) + ((flags & TSIMK_GFLAG_LIN) ? 1 : 0) +
+                2 * (long long)us.size() + 2 * nD;
+    // ---- table entries (index: ((delta + n1) << 2 nD | dbits) + 1; entry 0 is the exact zero)
+    //   canon( 2^n0 (1+i)^n2 (1+w)^(n1-m1) (1-w)^m1 (1+w^3)^(n3-m3) (1-w^3)^m3 * i^(m1+m3)
+    //          * floatfactor * w^k0 * [product of the PhasePairs terms selected by dbits] ) * 2^power2
+    //   with m3 = max(delta,0), m1 = max(-delta,0)
     const long long ff[4] = {h.i32[2][(size_t)g * 4], h.i32[2][(size_t)g * 4 + 1], h.i32[2][(size_t)g * 4 + 2],
                              h.i32[2][(size_t)g * 4 + 3]};
+    const int ndb = d_tabled ? (1 << (2 * nD)) : 1;
     for (int delta = -n[1]; delta <= n[3]; ++delta) {
       const int m3 = delta > 0 ? delta : 0, m1 = delta < 0 ? -delta : 0;
       ZW z{{1, 0, 0, 0}, 0};
@@ -609,35 +640,65 @@ static bool pack_level_fast(HostLevel &h, int W, std::vector<uint32_t> &tables) 
       const long long rot[4] = {kUnit[r][0], kUnit[r][1], kUnit[r][2], kUnit[r][3]};
       zw_mul(z, rot);
       zw_mul(z, ff);
-      for (int j = 0; j < 4; ++j)
-        if (z.c[j] > INT32_MAX || z.c[j] < INT32_MIN) return false;
-      for (int j = 0; j < 4; ++j) tables.push_back((uint32_t)(int32_t)z.c[j]);
-      tables.push_back((uint32_t)z.p);
-      tables.push_back(0u); tables.push_back(0u); tables.push_back(0u);
-    }
-    // ---- PhasePairs (identical layout to the faithful path)
-    const int nD = d.td ? h.i32[1][g] : 0;
-    for (int t = 0; t < nD; ++t) {
-      const int al = h.u8[8][(size_t)g * d.td + t] & 7, be = h.u8[10][(size_t)g * d.td + t] & 7;
-      for (int idx = 0; idx < 4; ++idx) {
-        const int pa = idx & 1, pb = idx >> 1;
-        const int a1 = (al + 4 * pa) & 7, b1 = (be + 4 * pb) & 7, g1 = (a1 + b1) & 7;
-        uint32_t w = 0;
-        for (int j = 0; j < 4; ++j) {
-          const int v = (j == 0 ? 1 : 0) + kUnit[a1][j] + kUnit[b1][j] - kUnit[g1][j];
-          w |= (uint32_t)(uint8_t)(int8_t)v << (8 * j);
+      z.p += h.i32[3][g];  // power2
+      for (int db = 0; db < ndb; ++db) {
+        ZW e = z;
+        for (int t = 0; t < nD && d_tabled; ++t) {
+          const int sel = (db >> (2 * (nD - 1 - t))) & 3;  // term 0 holds the most significant pair
+          const long long tv[4] = {dterm[t][sel][0], dterm[t][sel][1], dterm[t][sel][2], dterm[t][sel][3]};
+          zw_mul(e, tv);
         }
-        h.rows.push_back(w);
+        for (int j = 0; j < 4; ++j)
+          if (e.c[j] > INT32_MAX || e.c[j] < INT32_MIN) return false;
+        if (!(e.c[0] | e.c[1] | e.c[2] | e.c[3])) e.p = h.approx ? 0 : TSIMK_ZERO_POWER;
+        entries[g].push_back(e);
       }
-      pack_row(h.rows, &h.u8[9][((size_t)g * d.td + t) * P], P, W);
-      pack_row(h.rows, &h.u8[11][((size_t)g * d.td + t) * P], P, W);
     }
-    rec[GF_ND] = (uint32_t)nD;
-    h.n_rows += n[0] + n[1] + n[3] + (flags & 1u) + ((flags >> 1) & 1u) + 2 * (long long)us.size() + 2 * nD;
-    rec[GF_POW2] = (uint32_t)h.i32[3][g];
     memcpy(&rec[GF_APRE], &h.approx_v[2 * (size_t)g], 4);
     memcpy(&rec[GF_APIM], &h.approx_v[2 * (size_t)g + 1], 4);
   }
+  // ---- fixed frame: every term of the level comes straight from a table and, shifted to the
+  //      level's smallest power, the worst-case sum of all graphs stays inside int32
+  bool fixed = !h.approx && all_tabled && G > 0;
+  int frame = INT32_MAX;
+  if (fixed) {
+    for (auto &ge : entries)
+      for (auto &e : ge)
+        if (e.c[0] | e.c[1] | e.c[2] | e.c[3]) frame = std::min(frame, e.p);
+    if (frame == INT32_MAX) frame = 0;
+    long double total = 0;
+    for (auto &ge : entries) {
+      long double worst = 0;
+      for (auto &e : ge) {
+        if (!(e.c[0] | e.c[1] | e.c[2] | e.c[3])) continue;
+        const int sh = e.p - frame;
+        if (sh > 40) { fixed = false; break; }
+        // a rotation by i permutes/negates coefficients: bound by the largest one
+        long double m = 0;
+        for (auto v : e.c) m = std::max(m, (long double)std::llabs(v));
+        worst = std::max(worst, m * (long double)(1ll << sh));
+      }
+      total += worst;
+      if (!fixed) break;
+    }
+    if (total >= 2147483000.0L) fixed = false;
+  }
+  for (int g = 0; g < G; ++g) {
+    uint32_t *rec = &h.graph_rec[(size_t)g * G_WORDS];
+    rec[GF_TBL] = (uint32_t)tables.size();
+    for (int j = 0; j < 4; ++j) tables.push_back(0u);  // entry 0: exact zero
+    tables.push_back((uint32_t)(h.approx ? 0 : TSIMK_ZERO_POWER));
+    tables.push_back(0u); tables.push_back(0u); tables.push_back(0u);
+    for (auto &e : entries[g]) {
+      const bool nz = (e.c[0] | e.c[1] | e.c[2] | e.c[3]) != 0;
+      const int sh = (fixed && nz) ? e.p - frame : 0;
+      for (int j = 0; j < 4; ++j) tables.push_back((uint32_t)(int32_t)(e.c[j] * (1ll << sh)));
+      tables.push_back((uint32_t)(fixed ? frame : e.p));
+      tables.push_back(0u); tables.push_back(0u); tables.push_back(0u);
+    }
+  }
+  fixed_out = fixed;
+  frame_out = fixed ? frame : 0;
   return true;
 }
 
@@ -724,8 +785,10 @@ retry_pack:
     for (int k = 0; k < c.n_levels; ++k) {
       HostLevel &h = c.levels[k];
       std::vector<uint32_t> tables;
+      bool fixed = false;
+      int frame = 0;
       if (p->fast) {
-        if (!pack_level_fast(h, W, tables)) {  // a table entry exceeds int32: use the faithful layout
+        if (!pack_level_fast(h, W, tables, fixed, frame)) {  // a table entry exceeds int32: use the faithful layout
           p->fast = false;
           goto retry_pack;
         }
@@ -749,7 +812,8 @@ retry_pack:
       uint32_t *lr = &img[lrec + (size_t)k * L_WORDS];
       lr[L_G] = (uint32_t)h.G;
       lr[L_GRAPHS] = goff;
-      lr[L_FLAGS] = h.approx ? TSIMK_LFLAG_APPROX : 0u;
+      lr[L_FLAGS] = (h.approx ? TSIMK_LFLAG_APPROX : 0u) | (fixed ? TSIMK_LFLAG_FIXED : 0u);
+      lr[L_FRAME] = (uint32_t)frame;
       lr[L_NPARAMS] = (uint32_t)h.P;
       p->level_off.push_back((int)(lrec + (size_t)k * L_WORDS));
       p->total_graphs += h.G;

@@ -25,13 +25,17 @@ typedef const __attribute__((address_space(4))) uint32_t *cptr;
 // component record
 enum { C_NOUT = 0, C_F, C_W, C_FSEL, C_LEVELS, C_OUTPOS, C_KEYBASE, C_NLEVELS, C_WORDS = 8 };
 // level record
-enum { L_G = 0, L_GRAPHS, L_FLAGS, L_NPARAMS, L_WORDS = 4 };
+enum { L_G = 0, L_GRAPHS, L_FLAGS, L_NPARAMS, L_FRAME, L_WORDS = 8 };
 // graph record
 enum {
   G_NA = 0, G_NB, G_NC, G_ND, G_ROWS, G_PHASE, G_FFA, G_FFB, G_FFC, G_FFD, G_POW2,
   G_APRE, G_APIM, G_FLAGS, G_WORDS = 16
 };
 #define TSIMK_LFLAG_APPROX 1u
+#define TSIMK_LFLAG_FIXED 2u   // fast layout: table entries pre-shifted to the power L_FRAME
+#define TSIMK_GFLAG_LAM 1u
+#define TSIMK_GFLAG_LIN 2u
+#define TSIMK_GFLAG_D_TABLED 4u
 // Unroll factors of the row loops: the rows of one unrolled body are fetched by a few wide
 // s_loads ahead of a single s_waitcnt, so SMEM latency (an L2 hit, ~300 cycles: the 130 KB image
 // does not fit the 16 KB scalar cache) is amortised over several rows instead of paid per row.
@@ -334,7 +338,7 @@ __device__ __forceinline__ void eval_level(cptr img, cptr lvl, const uint32_t (&
 enum {
   GF_N01 = 0,   // n0 | n1 << 16   NodePhases rows of phase class 0 / 1 (counted)
   GF_N3H = 1,   // n3 | h << 16    class-3 rows (counted) / number of product pairs
-  GF_FLAGS = 2, // bit0: a lambda row is present, bit1: a linear row is present
+  GF_FLAGS = 2, // TSIMK_GFLAG_LAM | _LIN | _D_TABLED
   GF_ND = 3, GF_ROWS = 4, GF_TBL = 5, GF_N1 = 6, GF_POW2 = 10, GF_APRE = 11, GF_APIM = 12
 };
 #define TSIMK_ZERO_POWER (1 << 20)  // power given to an exactly-zero term: a no-op in the aligned add
@@ -367,6 +371,7 @@ __device__ __forceinline__ void eval_level_fast(const uint32_t *gimg, cptr img, 
                                                 float &out_re, float &out_im, int *exact5) {
   const uint32_t G = lvl[L_G];
   const bool approx = (lvl[L_FLAGS] & TSIMK_LFLAG_APPROX) != 0;
+  const bool fixed = (lvl[L_FLAGS] & TSIMK_LFLAG_FIXED) != 0;
   cptr gr = img + lvl[L_GRAPHS];
 
   int sa = 0, sb = 0, sc = 0, sd = 0, sp = TSIMK_ZERO_POWER;
@@ -380,32 +385,20 @@ __device__ __forceinline__ void eval_level_fast(const uint32_t *gimg, cptr img, 
     const uint32_t m0 = rows_count<W>(row, n01 & 0xFFFFu, x);
     const uint32_t m1 = rows_count<W>(row, n01 >> 16, x);
     const uint32_t m3 = rows_count<W>(row, n3h & 0xFFFFu, x);
-    // per-lane gather of the tabulated product (global memory, L1/L2 resident); issued here,
-    // consumed after the remaining rows so its latency hides behind them
-    const uint32_t *te = gimg + gr[GF_TBL] + 8u * (m3 - m1 + gr[GF_N1]);
-    const uint4 tv = *reinterpret_cast<const uint4 *>(te);
-    const uint32_t tpw = te[4];
+    uint32_t idx = m3 - m1 + gr[GF_N1];
 
-    // ---- exponent of w: k = 2 <lam,x> + 4 ( <lin,x> ^ XOR_s <u_s,x><v_s,x> ) (k0 is in the table)
-    uint32_t k = 0, e = 0;
-    if (flags & 1u) { k = (row_par<W>(row, x, 0) & 1u) << 1; row += W; }
-    if (flags & 2u) { e = row_par<W>(row, x, 0); row += W; }
-    const uint32_t nH = n3h >> 16;
-#pragma unroll 4
-    for (uint32_t t = 0; t < nH; ++t) {
-      const uint32_t pu = row_par<W>(row, x, 0);
-      const uint32_t pv = row_par<W>(row + W, x, 0);
-      e = and_xor(pu, pv, e);
-      row += 2 * W;
-    }
-    k += (e & 1u) << 2;
-
-    int a = (int)tv.x, b = (int)tv.y, c = (int)tv.z, d = (int)tv.w, p = (int)tpw;
-
-    // ---- PhasePairs (same sequential scan as the faithful path) ----
+    // ---- PhasePairs: either two index bits per term into the combined table, or the scan ----
     const uint32_t nD = gr[GF_ND];
-    if (nD) {
-      int da = 1, db = 0, dc = 0, dd = 0, dp = 0;
+    int da = 1, db = 0, dc = 0, dd = 0, dp = 0;
+    const bool d_tabled = (flags & TSIMK_GFLAG_D_TABLED) != 0;
+    if (d_tabled) {
+      for (uint32_t t = 0; t < nD; ++t) {
+        const uint32_t pa = row_par<W>(row, x, 0) & 1u;
+        const uint32_t pb = row_par<W>(row + W, x, 0) & 1u;
+        idx = (idx << 2) | pa | (pb << 1);
+        row += 2 * W;
+      }
+    } else if (nD) {
       for (uint32_t t = 0; t < nD; ++t) {
         const uint32_t pa = row_par<W>(row + 4, x, 0) & 1u;
         const uint32_t pb = row_par<W>(row + 4 + W, x, 0) & 1u;
@@ -423,23 +416,48 @@ __device__ __forceinline__ void eval_level_fast(const uint32_t *gimg, cptr img, 
         }
       }
       canon(da, db, dc, dd, dp);
+    }
+    // entry 0 of every table is the exact zero (a vanished NodePhases product: some 1 + w^4 factor)
+    idx = (m0 != 0) ? 0u : idx + 1u;
+    // per-lane gather of the tabulated term (global memory, L1/L2 resident); issued here, consumed
+    // after the remaining rows so its latency hides behind them
+    const uint32_t *te = gimg + gr[GF_TBL] + 8u * idx;
+    const uint4 tv = *reinterpret_cast<const uint4 *>(te);
+    const uint32_t tpw = te[4];
+
+    // ---- exponent of w: k = 2 <lam,x> + 4 ( <lin,x> ^ XOR_s <u_s,x><v_s,x> ) (k0 is in the table)
+    uint32_t k = 0, e = 0;
+    if (flags & TSIMK_GFLAG_LAM) { k = (row_par<W>(row, x, 0) & 1u) << 1; row += W; }
+    if (flags & TSIMK_GFLAG_LIN) { e = row_par<W>(row, x, 0); row += W; }
+    const uint32_t nH = n3h >> 16;
+#pragma unroll 4
+    for (uint32_t t = 0; t < nH; ++t) {
+      const uint32_t pu = row_par<W>(row, x, 0);
+      const uint32_t pv = row_par<W>(row + W, x, 0);
+      e = and_xor(pu, pv, e);
+      row += 2 * W;
+    }
+    k += (e & 1u) << 2;
+
+    int a = (int)tv.x, b = (int)tv.y, c = (int)tv.z, d = (int)tv.w, p = (int)tpw;
+    if (!d_tabled && nD) {
       zmul(a, b, c, d, da, db, dc, dd);
       p += dp;
     }
 
-    // rotate by w^k (k differs per lane)
+    // rotate by w^k, k in {0, 2, 4, 6} (differs per lane)
     {
-      const bool k1 = (k & 1u) != 0, k2 = (k & 2u) != 0;
-      int t0 = k1 ? d : a, t1 = k1 ? a : b, t2 = k1 ? b : c, t3 = k1 ? -c : d;
-      a = k2 ? -t2 : t0; b = k2 ? t3 : t1; c = k2 ? t0 : t2; d = k2 ? -t1 : t3;
+      const bool k2 = (k & 2u) != 0;
+      const int t0 = k2 ? -c : a, t1 = k2 ? d : b, t2 = k2 ? a : c, t3 = k2 ? -b : d;
       const int nm = -(int)((k >> 2) & 1u);
-      a = (a ^ nm) - nm; b = (b ^ nm) - nm; c = (c ^ nm) - nm; d = (d ^ nm) - nm;
+      a = (t0 ^ nm) - nm; b = (t1 ^ nm) - nm; c = (t2 ^ nm) - nm; d = (t3 ^ nm) - nm;
     }
-    // a vanished NodePhases product (some 1 + w^4 factor): the term is exactly zero
-    if (m0 != 0) { a = 0; b = 0; c = 0; d = 0; }
 
-    if (!approx) {
-      p += (int)gr[GF_POW2];
+    if (fixed) {
+      // every table entry of this level is pre-shifted to the level's frame power: plain adds,
+      // the pack-time bound guarantees no int32 overflow (see pack_level_fast)
+      sa += a; sb += b; sc += c; sd += d;
+    } else if (!approx) {
       // exactly-zero terms get a huge power, which makes the aligned add below a no-op for them
       if ((a | b | c | d) == 0) p = TSIMK_ZERO_POWER;
       const int d1 = max(sp - p, 0), d2 = max(p - sp, 0);
@@ -451,17 +469,17 @@ __device__ __forceinline__ void eval_level_fast(const uint32_t *gimg, cptr img, 
       reduce1(sa, sb, sc, sd, sp);
     } else {
       float zr, zi;
-      to_complex(a, b, c, d, p, zr, zi);
+      to_complex(a, b, c, d, p, zr, zi);  // the table power already contains power2
       const float ar = __uint_as_float(gr[GF_APRE]), ai = __uint_as_float(gr[GF_APIM]);
       const float tr = __fsub_rn(__fmul_rn(zr, ar), __fmul_rn(zi, ai));
       const float ti = __fadd_rn(__fmul_rn(zr, ai), __fmul_rn(zi, ar));
-      const float s = ldexpf(1.0f, (int)gr[GF_POW2]);
-      fre = __fadd_rn(fre, __fmul_rn(tr, s));
-      fim = __fadd_rn(fim, __fmul_rn(ti, s));
+      fre = __fadd_rn(fre, tr);
+      fim = __fadd_rn(fim, ti);
     }
   }
 
   if (!approx) {
+    if (fixed) sp = (int)lvl[L_FRAME];
     canon(sa, sb, sc, sd, sp);
     if ((sa | sb | sc | sd) == 0) sp = 0;
     to_complex(sa, sb, sc, sd, sp, out_re, out_im);

@@ -194,6 +194,11 @@ int tsim_profile_read(tsim_program *p, double *kernel_ms, int64_t *launches, int
 int tsim_program_info(const tsim_program *p, int32_t *n_components, int32_t *num_outputs,
                       int64_t *image_bytes, int64_t *total_graphs, int64_t *total_rows);
 
+/* packer statistics: out[0] fast formulation selected, [1] levels, [2] fixed-frame levels,
+ * [3] product pairs, [4] counted NodePhases rows, [5] table entries, [6] graphs with tabled
+ * PhasePairs, [7] reserved */
+int tsim_program_stats(const tsim_program *p, int64_t out[8]);
+
 const char *tsim_last_error(void);
 const char *tsim_version(void);
 

@@ -85,6 +85,7 @@ SYMBOLS: dict[str, tuple] = {
         C.c_int,
         [_P, C.POINTER(_I32), C.POINTER(_I32), C.POINTER(_I64), C.POINTER(_I64), C.POINTER(_I64)],
     ),
+    "tsim_program_stats": (C.c_int, [_P, C.POINTER(_I64)]),
     "tsim_last_error": (C.c_char_p, []),
     "tsim_version": (C.c_char_p, []),
 }

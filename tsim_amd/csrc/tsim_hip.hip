@@ -91,6 +91,7 @@ struct tsim_program {
   int mode = TSIM_MODE_AUTO;  // requested
   bool fast = false;          // chosen at finalize: counting formulation (eval_level_fast)
   long long total_graphs = 0, total_rows = 0;
+  long long stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // see tsim_program_stats
   int max_f_index = -1;
   std::vector<int> level_off;  // flattened [component][level] -> offset of level record
   std::vector<int> level_base; // per component index into level_off
@@ -513,8 +514,8 @@ static bool pack_level_fast(HostLevel &h, int W, std::vector<uint32_t> &tables, 
   tables.clear();
   fixed_out = false;
   frame_out = 0;
-  std::vector<std::vector<ZW>> entries((size_t)G);  // per graph: the non-zero table entries
-  bool all_tabled = true;
+  std::vector<std::vector<ZW>> entries((size_t)G);   // per graph: the main table (entry 0 excluded)
+  std::vector<std::vector<ZW>> dentries((size_t)G);  // per graph: the separate PhasePairs table, if any
   for (int g = 0; g < G; ++g) {
     uint32_t *rec = &h.graph_rec[(size_t)g * G_WORDS];
     rec[GF_ROWS] = (uint32_t)h.rows.size();
@@ -544,9 +545,9 @@ static bool pack_level_fast(HostLevel &h, int W, std::vector<uint32_t> &tables, 
     // ---- PhasePairs rows: two table-index bits per term when the combined table stays small,
     //      else the faithful sequential scan (rows carry the four tabulated term values)
     const int nD = d.td ? h.i32[1][g] : 0;
-    const long long combos = nD <= 3 ? (long long)(n[1] + n[3] + 1) << (2 * nD) : (1ll << 40);
-    const bool d_tabled = nD > 0 && combos <= 256;
-    if (nD > 0 && !d_tabled) all_tabled = false;
+    if (nD > 5) return false;  // 4^nD table entries: beyond this use the faithful layout
+    const long long combos = (long long)(n[1] + n[3] + 1) << (2 * nD);
+    const bool d_tabled = nD > 0 && combos <= 256;   // combined table, else a separate one
     std::vector<std::array<std::array<int, 4>, 4>> dterm((size_t)nD);  // [t][pa + 2 pb] -> term value
     for (int t = 0; t < nD; ++t) {
       const int al = h.u8[8][(size_t)g * d.td + t] & 7, be = h.u8[10][(size_t)g * d.td + t] & 7;
@@ -559,7 +560,7 @@ static bool pack_level_fast(HostLevel &h, int W, std::vector<uint32_t> &tables, 
           dterm[t][idx][j] = v;
           w |= (uint32_t)(uint8_t)(int8_t)v << (8 * j);
         }
-        if (!d_tabled) h.rows.push_back(w);
+        (void)w;
       }
       pack_row(h.rows, &h.u8[9][((size_t)g * d.td + t) * P], P, W);
       pack_row(h.rows, &h.u8[11][((size_t)g * d.td + t) * P], P, W);
@@ -654,12 +655,23 @@ static bool pack_level_fast(HostLevel &h, int W, std::vector<uint32_t> &tables, 
         entries[g].push_back(e);
       }
     }
+    if (nD > 0 && !d_tabled) {  // separate PhasePairs table over the 4^nD parity patterns
+      for (int db = 0; db < (1 << (2 * nD)); ++db) {
+        ZW e{{1, 0, 0, 0}, 0};
+        for (int t = 0; t < nD; ++t) {
+          const int sel = (db >> (2 * (nD - 1 - t))) & 3;
+          const long long tv[4] = {dterm[t][sel][0], dterm[t][sel][1], dterm[t][sel][2], dterm[t][sel][3]};
+          zw_mul(e, tv);
+        }
+        dentries[g].push_back(e);
+      }
+    }
     memcpy(&rec[GF_APRE], &h.approx_v[2 * (size_t)g], 4);
     memcpy(&rec[GF_APIM], &h.approx_v[2 * (size_t)g + 1], 4);
   }
   // ---- fixed frame: every term of the level comes straight from a table and, shifted to the
   //      level's smallest power, the worst-case sum of all graphs stays inside int32
-  bool fixed = !h.approx && all_tabled && G > 0;
+  bool fixed = !h.approx && G > 0;
   int frame = INT32_MAX;
   if (fixed) {
     for (auto &ge : entries)
@@ -667,9 +679,9 @@ static bool pack_level_fast(HostLevel &h, int W, std::vector<uint32_t> &tables, 
         if (e.c[0] | e.c[1] | e.c[2] | e.c[3]) frame = std::min(frame, e.p);
     if (frame == INT32_MAX) frame = 0;
     long double total = 0;
-    for (auto &ge : entries) {
+    for (int g = 0; g < G && fixed; ++g) {
       long double worst = 0;
-      for (auto &e : ge) {
+      for (auto &e : entries[g]) {
         if (!(e.c[0] | e.c[1] | e.c[2] | e.c[3])) continue;
         const int sh = e.p - frame;
         if (sh > 40) { fixed = false; break; }
@@ -678,8 +690,17 @@ static bool pack_level_fast(HostLevel &h, int W, std::vector<uint32_t> &tables, 
         for (auto v : e.c) m = std::max(m, (long double)std::llabs(v));
         worst = std::max(worst, m * (long double)(1ll << sh));
       }
+      // separate PhasePairs table: entries become plain integers c * 2^p (p >= 0); the product
+      // with the main entry is a sum of four coefficient products
+      long double dworst = 0;
+      for (auto &e : dentries[g]) {
+        if (e.p < 0 || e.p > 40) { fixed = false; break; }
+        long double m = 0;
+        for (auto v : e.c) m = std::max(m, (long double)std::llabs(v));
+        dworst = std::max(dworst, m * (long double)(1ll << e.p));
+      }
+      if (!dentries[g].empty()) worst = 4 * worst * dworst;
       total += worst;
-      if (!fixed) break;
     }
     if (total >= 2147483000.0L) fixed = false;
   }
@@ -694,6 +715,21 @@ static bool pack_level_fast(HostLevel &h, int W, std::vector<uint32_t> &tables, 
       const int sh = (fixed && nz) ? e.p - frame : 0;
       for (int j = 0; j < 4; ++j) tables.push_back((uint32_t)(int32_t)(e.c[j] * (1ll << sh)));
       tables.push_back((uint32_t)(fixed ? frame : e.p));
+      tables.push_back(0u); tables.push_back(0u); tables.push_back(0u);
+    }
+  }
+  for (int g = 0; g < G; ++g) {
+    if (dentries[g].empty()) continue;
+    uint32_t *rec = &h.graph_rec[(size_t)g * G_WORDS];
+    rec[GF_TBL2] = (uint32_t)tables.size();
+    for (auto &e : dentries[g]) {
+      const int sh = fixed ? e.p : 0;
+      for (int j = 0; j < 4; ++j) {
+        const long long v = e.c[j] * (1ll << sh);
+        if (v > INT32_MAX || v < INT32_MIN) return false;
+        tables.push_back((uint32_t)(int32_t)v);
+      }
+      tables.push_back((uint32_t)(fixed ? 0 : e.p));
       tables.push_back(0u); tables.push_back(0u); tables.push_back(0u);
     }
   }
@@ -753,6 +789,7 @@ retry_pack:
   p->total_keys = 0;
   p->sampleable = true;
   p->total_graphs = p->total_rows = 0;
+  for (auto &v : p->stats) v = 0;
   p->level_off.clear();
   p->level_base.clear();
   p->comp_w.clear();
@@ -807,13 +844,26 @@ retry_pack:
         while (img.size() % 8) img.push_back(0u);  // 32-byte aligned table entries (uint4 loads)
         const uint32_t toff = (uint32_t)img.size();
         img.insert(img.end(), tables.begin(), tables.end());
-        for (int g = 0; g < h.G; ++g) img[goff + (size_t)g * G_WORDS + GF_TBL] += toff;
+        for (int g = 0; g < h.G; ++g) {
+          img[goff + (size_t)g * G_WORDS + GF_TBL] += toff;
+          if (img[goff + (size_t)g * G_WORDS + GF_TBL2]) img[goff + (size_t)g * G_WORDS + GF_TBL2] += toff;
+        }
       }
       uint32_t *lr = &img[lrec + (size_t)k * L_WORDS];
       lr[L_G] = (uint32_t)h.G;
       lr[L_GRAPHS] = goff;
       lr[L_FLAGS] = (h.approx ? TSIMK_LFLAG_APPROX : 0u) | (fixed ? TSIMK_LFLAG_FIXED : 0u);
       lr[L_FRAME] = (uint32_t)frame;
+      p->stats[1] += 1;
+      p->stats[2] += fixed ? 1 : 0;
+      p->stats[5] += (long long)tables.size() / 8;
+      if (p->fast)
+        for (int g = 0; g < h.G; ++g) {
+          const uint32_t *r = &h.graph_rec[(size_t)g * G_WORDS];
+          p->stats[3] += r[GF_N3H] >> 16;
+          p->stats[4] += (r[GF_N01] & 0xFFFF) + (r[GF_N01] >> 16) + (r[GF_N3H] & 0xFFFF);
+          p->stats[6] += (r[GF_FLAGS] & TSIMK_GFLAG_D_TABLED) ? 1 : 0;
+        }
       lr[L_NPARAMS] = (uint32_t)h.P;
       p->level_off.push_back((int)(lrec + (size_t)k * L_WORDS));
       p->total_graphs += h.G;
@@ -855,6 +905,14 @@ extern "C" void tsim_program_destroy(tsim_program *p) {
     if (p->stream) (void)hipStreamDestroy(p->stream);
   }
   delete p;
+}
+
+extern "C" int tsim_program_stats(const tsim_program *p, int64_t out[8]) {
+  if (!p || !out) return fail(TSIM_EINVAL, "NULL argument");
+  if (!p->finalized) return fail(TSIM_ESTATE, "program not finalized");
+  for (int i = 0; i < 8; ++i) out[i] = p->stats[i];
+  out[0] = p->fast ? 1 : 0;
+  return TSIM_OK;
 }
 
 extern "C" int tsim_program_get_mode(const tsim_program *p, int32_t *fast) {

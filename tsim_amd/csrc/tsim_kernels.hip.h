@@ -339,7 +339,7 @@ enum {
   GF_N01 = 0,   // n0 | n1 << 16   NodePhases rows of phase class 0 / 1 (counted)
   GF_N3H = 1,   // n3 | h << 16    class-3 rows (counted) / number of product pairs
   GF_FLAGS = 2, // TSIMK_GFLAG_LAM | _LIN | _D_TABLED
-  GF_ND = 3, GF_ROWS = 4, GF_TBL = 5, GF_N1 = 6, GF_POW2 = 10, GF_APRE = 11, GF_APIM = 12
+  GF_ND = 3, GF_ROWS = 4, GF_TBL = 5, GF_N1 = 6, GF_TBL2 = 7, GF_APRE = 11, GF_APIM = 12
 };
 #define TSIMK_ZERO_POWER (1 << 20)  // power given to an exactly-zero term: a no-op in the aligned add
 
@@ -399,23 +399,18 @@ __device__ __forceinline__ void eval_level_fast(const uint32_t *gimg, cptr img, 
         row += 2 * W;
       }
     } else if (nD) {
+      // a separate PhasePairs table (the combined one would be too large): index bits only
+      uint32_t dbits = 0;
       for (uint32_t t = 0; t < nD; ++t) {
-        const uint32_t pa = row_par<W>(row + 4, x, 0) & 1u;
-        const uint32_t pb = row_par<W>(row + 4 + W, x, 0) & 1u;
-        const uint32_t w0 = pa ? row[1] : row[0];
-        const uint32_t w1 = pa ? row[3] : row[2];
-        const uint32_t tw = pb ? w1 : w0;
-        row += 4 + 2 * W;
-        const int ta = (int)(int8_t)(tw), tb = (int)(int8_t)(tw >> 8), tc = (int)(int8_t)(tw >> 16),
-                  td = (int)(int8_t)(tw >> 24);
-        if (t == 0) {
-          da = ta; db = tb; dc = tc; dd = td;
-        } else {
-          zmul(da, db, dc, dd, ta, tb, tc, td);
-          reduce1(da, db, dc, dd, dp);
-        }
+        const uint32_t pa = row_par<W>(row, x, 0) & 1u;
+        const uint32_t pb = row_par<W>(row + W, x, 0) & 1u;
+        dbits = (dbits << 2) | pa | (pb << 1);
+        row += 2 * W;
       }
-      canon(da, db, dc, dd, dp);
+      const uint32_t *td = gimg + gr[GF_TBL2] + 8u * dbits;
+      const uint4 dv = *reinterpret_cast<const uint4 *>(td);
+      da = (int)dv.x; db = (int)dv.y; dc = (int)dv.z; dd = (int)dv.w;
+      dp = (int)td[4];
     }
     // entry 0 of every table is the exact zero (a vanished NodePhases product: some 1 + w^4 factor)
     idx = (m0 != 0) ? 0u : idx + 1u;

@@ -172,7 +172,7 @@ class HipProgram:
         return dict(n_components=nc.value, num_outputs=no.value, image_bytes=ib.value,
                     total_graphs=tg.value, total_rows=tr.value, fast=bool(st[0]), levels=st[1],
                     fixed_frame_levels=st[2], product_pairs=st[3], counted_rows=st[4],
-                    table_entries=st[5], graphs_d_tabled=st[6])
+                    table_entries=st[5], graphs_d_tabled=st[6], chunk_table_kernel=bool(st[7]))
 
     # -- the hot path, host buffers -------------------------------------------
     def sample_batch(self, f_params: np.ndarray, key, *, shot_offset: int = 0, bit_packed: bool = False):

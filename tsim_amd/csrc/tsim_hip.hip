@@ -6,6 +6,7 @@
 //   * own device memory, the stream and HIP-event timing.
 #include "../../include/tsim_hip.h"
 #include "tsim_kernels.hip.h"
+#include "tsim_kernel4.hip.h"
 
 #include <algorithm>
 #include <array>
@@ -46,7 +47,21 @@ extern "C" const char *tsim_version(void) { return "tsim_amd-hip 0.1 (gfx950)"; 
 // ---------------------------------------------------------------------------
 namespace {
 
+// per-graph result of the fast packer's algebra, kept for the v4 (chunk table) emitter
+struct FastGraph {
+  std::vector<std::vector<uint64_t>> c0, c1, c3;  // counted NodePhases rows per class (masks)
+  std::vector<uint8_t> c0c, c1c, c3c;             // their constants
+  std::vector<std::vector<uint64_t>> dal, dbe;    // PhasePairs alpha / beta masks
+  std::vector<uint64_t> lam, lin;
+  std::vector<std::vector<uint64_t>> us, vs;      // Dickson product pairs
+  int n1 = 0, nD = 0;
+  bool d_tabled = false;
+};
+
 struct HostLevel {
+  std::vector<FastGraph> fg;
+  bool fixed = false;
+  int frame = 0;
   int G = 0, P = 0;
   bool approx = false;
   // per graph
@@ -90,6 +105,10 @@ struct tsim_program {
   bool sampleable = true;
   int mode = TSIM_MODE_AUTO;  // requested
   bool fast = false;          // chosen at finalize: counting formulation (eval_level_fast)
+  bool v4 = false;            // chunk-table layout present (k_sample4)
+  int v4_gt = 4;              // graphs per LDS tile
+  int comp4_off = 0;
+  int v4_max_nch = 1;
   long long total_graphs = 0, total_rows = 0;
   long long stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // see tsim_program_stats
   int max_f_index = -1;
@@ -516,7 +535,9 @@ static bool pack_level_fast(HostLevel &h, int W, std::vector<uint32_t> &tables, 
   frame_out = 0;
   std::vector<std::vector<ZW>> entries((size_t)G);   // per graph: the main table (entry 0 excluded)
   std::vector<std::vector<ZW>> dentries((size_t)G);  // per graph: the separate PhasePairs table, if any
+  h.fg.assign((size_t)G, FastGraph());
   for (int g = 0; g < G; ++g) {
+    FastGraph &fg = h.fg[(size_t)g];
     uint32_t *rec = &h.graph_rec[(size_t)g * G_WORDS];
     rec[GF_ROWS] = (uint32_t)h.rows.size();
     const int nA = d.ta ? h.i32[0][g] : 0;
@@ -539,8 +560,13 @@ static bool pack_level_fast(HostLevel &h, int W, std::vector<uint32_t> &tables, 
         if (cls == 2) continue;
         h.rows.push_back(ph >> 2);
         pack_row(h.rows, bits, P, W);
+        auto &dstm = cls == 0 ? fg.c0 : (cls == 1 ? fg.c1 : fg.c3);
+        auto &dstc = cls == 0 ? fg.c0c : (cls == 1 ? fg.c1c : fg.c3c);
+        dstm.push_back(affine_from(bits, P, false).m);
+        dstc.push_back((uint8_t)(ph >> 2));
       }
     rec[GF_N01] = (uint32_t)n[0] | ((uint32_t)n[1] << 16);
+    fg.n1 = n[1];
     rec[GF_N1] = (uint32_t)n[1];
     // ---- PhasePairs rows: two table-index bits per term when the combined table stays small,
     //      else the faithful sequential scan (rows carry the four tabulated term values)
@@ -564,8 +590,12 @@ static bool pack_level_fast(HostLevel &h, int W, std::vector<uint32_t> &tables, 
       }
       pack_row(h.rows, &h.u8[9][((size_t)g * d.td + t) * P], P, W);
       pack_row(h.rows, &h.u8[11][((size_t)g * d.td + t) * P], P, W);
+      fg.dal.push_back(affine_from(&h.u8[9][((size_t)g * d.td + t) * P], P, false).m);
+      fg.dbe.push_back(affine_from(&h.u8[11][((size_t)g * d.td + t) * P], P, false).m);
     }
     rec[GF_ND] = (uint32_t)nD;
+    fg.nD = nD;
+    fg.d_tabled = d_tabled;
     // ---- HalfPi rows
     for (int t = 0; t < d.tb; ++t) {
       const uint32_t coeff = h.u8[2][(size_t)g * d.tb + t] & 7u;
@@ -614,6 +644,10 @@ static bool pack_level_fast(HostLevel &h, int W, std::vector<uint32_t> &tables, 
     }
     rec[GF_N3H] = (uint32_t)n[3] | ((uint32_t)us.size() << 16);
     rec[GF_FLAGS] = flags;
+    fg.lam = lam.m;
+    fg.lin = q4.lin;
+    fg.us = us;
+    fg.vs = vs;
     h.n_rows += n[0] + n[1] + n[3] + ((flags & TSIMK_GFLAG_LAM) ? 1 : 0) + ((flags & TSIMK_GFLAG_LIN) ? 1 : 0) +
                 2 * (long long)us.size() + 2 * nD;
     // ---- table entries (index: ((delta + n1) << 2 nD | dbits) + 1; entry 0 is the exact zero)
@@ -735,7 +769,89 @@ static bool pack_level_fast(HostLevel &h, int W, std::vector<uint32_t> &tables, 
   }
   fixed_out = fixed;
   frame_out = fixed ? frame : 0;
+  h.fixed = fixed;
+  h.frame = frame_out;
   return true;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// v4 layout: per-tile 4-bit chunk tables (kernel: k_sample4, tsim_kernel4.hip.h)
+// ---------------------------------------------------------------------------
+namespace {
+
+static bool level_v4_eligible(const HostLevel &h) {
+  if (h.P > 64) return false;
+  for (const FastGraph &fg : h.fg) {
+    if (fg.us.size() > 32) return false;
+    if (fg.c0.size() + fg.c1.size() + fg.c3.size() > 32) return false;
+    if (2 * fg.nD > 28) return false;
+  }
+  return true;
+}
+
+static inline bool mask_bit(const std::vector<uint64_t> &m, int i) { return (m[(size_t)i >> 6] >> (i & 63)) & 1; }
+
+// recs4: G x G4_WORDS; tabs4: ntiles x nch x 16 x GT x 4 words.  `v3recs` are the level's patched
+// fast-layout graph records (for the term-table offsets and the approximate floatfactors).
+static void emit_level4(const HostLevel &h, int GT, const uint32_t *v3recs, std::vector<uint32_t> &recs4,
+                        std::vector<uint32_t> &tabs4, int &nch_out, int &ntiles_out) {
+  const int G = h.G, P = h.P;
+  const int nch = std::max(1, (P + 3) / 4), ntiles = (G + GT - 1) / GT;
+  nch_out = nch;
+  ntiles_out = ntiles;
+  recs4.assign((size_t)G * G4_WORDS, 0u);
+  tabs4.assign((size_t)ntiles * nch * 16 * GT * 4, 0u);
+  std::vector<std::array<uint32_t, 4>> col((size_t)std::max(P, 1));
+  for (int g = 0; g < G; ++g) {
+    const FastGraph &fg = h.fg[(size_t)g];
+    for (auto &c : col) c = {0u, 0u, 0u, 0u};
+    std::array<uint32_t, 4> cst = {0u, 0u, 0u, 0u};
+    auto place = [&](const std::vector<uint64_t> &m, int word, int bit) {
+      for (int i = 0; i < P; ++i)
+        if (mask_bit(m, i)) col[(size_t)i][(size_t)word] |= 1u << bit;
+    };
+    const int h2 = (int)fg.us.size();
+    for (int s = 0; s < h2; ++s) {
+      place(fg.us[(size_t)s], 0, s);
+      place(fg.vs[(size_t)s], 1, s);
+    }
+    uint32_t M0 = 0, M1 = 0, M3 = 0;
+    int b = 0;
+    for (size_t t = 0; t < fg.c0.size(); ++t, ++b) { place(fg.c0[t], 2, b); M0 |= 1u << b; if (fg.c0c[t]) cst[2] |= 1u << b; }
+    for (size_t t = 0; t < fg.c1.size(); ++t, ++b) { place(fg.c1[t], 2, b); M1 |= 1u << b; if (fg.c1c[t]) cst[2] |= 1u << b; }
+    for (size_t t = 0; t < fg.c3.size(); ++t, ++b) { place(fg.c3[t], 2, b); M3 |= 1u << b; if (fg.c3c[t]) cst[2] |= 1u << b; }
+    for (int t = 0; t < fg.nD; ++t) {  // index bits: term 0 holds the most significant pair
+      place(fg.dal[(size_t)t], 3, 2 * (fg.nD - 1 - t));
+      place(fg.dbe[(size_t)t], 3, 2 * (fg.nD - 1 - t) + 1);
+    }
+    place(fg.lam, 3, 30);
+    place(fg.lin, 3, 31);
+    const int tile = g / GT, j = g % GT;
+    for (int c = 0; c < nch; ++c)
+      for (int v = 0; v < 16; ++v) {
+        std::array<uint32_t, 4> val = (c == 0) ? cst : std::array<uint32_t, 4>{0u, 0u, 0u, 0u};
+        for (int bb = 0; bb < 4; ++bb) {
+          const int i = 4 * c + bb;
+          if (!((v >> bb) & 1) || i >= P) continue;
+          for (int w = 0; w < 4; ++w) val[(size_t)w] ^= col[(size_t)i][(size_t)w];
+        }
+        uint32_t *dst = &tabs4[((((size_t)tile * nch + c) * 16 + v) * GT + j) * 4];
+        for (int w = 0; w < 4; ++w) dst[w] = val[(size_t)w];
+      }
+    uint32_t *r4 = &recs4[(size_t)g * G4_WORDS];
+    const uint32_t *r3 = v3recs + (size_t)g * G_WORDS;
+    r4[G4_M0] = M0; r4[G4_M1] = M1; r4[G4_M3] = M3;
+    r4[G4_PM] = h2 >= 32 ? 0xFFFFFFFFu : ((1u << h2) - 1u);
+    r4[G4_N1] = (uint32_t)fg.n1;
+    r4[G4_DBITS] = (uint32_t)(2 * fg.nD);
+    r4[G4_TBL] = r3[GF_TBL];
+    r4[G4_TBL2] = r3[GF_TBL2];
+    r4[G4_FLAGS] = fg.nD == 0 ? 0u : (fg.d_tabled ? TSIMK_G4FLAG_D_COMBINED : TSIMK_G4FLAG_D_SEPARATE);
+    r4[G4_APRE] = r3[GF_APRE];
+    r4[G4_APIM] = r3[GF_APIM];
+  }
 }
 
 }  // namespace
@@ -872,6 +988,57 @@ retry_pack:
     if (sequential) p->total_keys += c.n_out;
     memcpy(&img[p->comp_off + ci * C_WORDS], rec, sizeof rec);
   }
+  // ---- v4 (chunk table) layout, when every sampled component qualifies ----
+  p->v4 = false;
+  if (p->fast && p->sampleable) {
+    bool ok = !p->comps.empty();
+    for (auto &c : p->comps)
+      for (auto &lv : c.levels) ok = ok && level_v4_eligible(lv);
+    const char *kenv = getenv("TSIM_AMD_KERNEL");
+    if (kenv && strcmp(kenv, "v3") == 0) ok = false;
+    const char *genv = getenv("TSIM_AMD_V4_GT");
+    p->v4_gt = (genv && atoi(genv) == 8) ? 8 : 4;
+    if (ok) {
+      while (img.size() % 16) img.push_back(0u);
+      p->comp4_off = (int)img.size();
+      img.resize(img.size() + p->comps.size() * C4_WORDS, 0u);
+      p->v4_max_nch = 1;
+      for (size_t ci = 0; ci < p->comps.size(); ++ci) {
+        HostComponent &c = p->comps[ci];
+        for (int w = 0; w < 8; ++w) img[p->comp4_off + ci * C4_WORDS + w] = img[p->comp_off + ci * C_WORDS + w];
+        while (img.size() % 16) img.push_back(0u);
+        const size_t l4 = img.size();
+        img[p->comp4_off + ci * C4_WORDS + C4_LEVELS] = (uint32_t)l4;
+        img.resize(img.size() + (size_t)c.n_levels * L4_WORDS, 0u);
+        for (int k = 0; k < c.n_levels; ++k) {
+          HostLevel &h = c.levels[k];
+          const uint32_t v3lvl = (uint32_t)p->level_off[p->level_base[ci] + k];
+          const uint32_t v3recs = img[v3lvl + L_GRAPHS];
+          std::vector<uint32_t> recs4, tabs4;
+          int nch = 1, ntiles = 0;
+          std::vector<uint32_t> v3copy(img.begin() + v3recs, img.begin() + v3recs + (size_t)h.G * G_WORDS);
+          emit_level4(h, p->v4_gt, v3copy.data(), recs4, tabs4, nch, ntiles);
+          p->v4_max_nch = std::max(p->v4_max_nch, nch);
+          while (img.size() % 16) img.push_back(0u);
+          const uint32_t roff = (uint32_t)img.size();
+          img.insert(img.end(), recs4.begin(), recs4.end());
+          while (img.size() % 16) img.push_back(0u);
+          const uint32_t toff = (uint32_t)img.size();
+          img.insert(img.end(), tabs4.begin(), tabs4.end());
+          uint32_t *lr = &img[l4 + (size_t)k * L4_WORDS];
+          lr[L4_G] = (uint32_t)h.G;
+          lr[L4_NTILES] = (uint32_t)ntiles;
+          lr[L4_TABLES] = toff;
+          lr[L4_RECS] = roff;
+          lr[L4_NCH] = (uint32_t)nch;
+          lr[L4_FLAGS] = (h.approx ? TSIMK_LFLAG_APPROX : 0u) | (h.fixed ? TSIMK_LFLAG_FIXED : 0u);
+          lr[L4_FRAME] = (uint32_t)h.frame;
+        }
+      }
+      p->v4 = true;
+    }
+  }
+  p->stats[7] = p->v4 ? 1 : 0;
   img.resize(img.size() + 256, 0u);  // tail padding: wide scalar loads may over-read
   if (img.size() >= (1ull << 31)) return fail(TSIM_ENOTSUP, "program image too large");
 
@@ -1016,6 +1183,23 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
   const long long grid = (B + block - 1) / block;
   if (grid > 0x7FFFFFFFll) return fail(TSIM_ENOTSUP, "batch too large");
   if (p->profiling) { int r = prof_event(p, s); if (r) return r; }
+  if (p->v4) {
+    // chunk-table kernel: LDS = f/out staging + two tile buffers; one extra block replays shot 0
+    Sample4Args a4;
+    a4.s = a;
+    a4.comp4_off = p->comp4_off;
+    a4.has_check = (shot_offset == 0) ? 1 : 0;
+    const int blk = 256;
+    const size_t tile_bytes = (size_t)p->v4_max_nch * 16 * p->v4_gt * 16;
+    const size_t lds4 = (size_t)(2 * a.WF + 2 * a.WO) * blk * 4 + 2 * tile_bytes;
+    if (lds4 > 64 * 1024) return fail(TSIM_ENOTSUP, "v4 kernel needs %zu B of LDS", lds4);
+    const long long grid4 = (B + blk - 1) / blk + a4.has_check;
+    if (p->v4_gt == 8) hipLaunchKernelGGL((k_sample4<8>), dim3((unsigned)grid4), dim3(blk), lds4, s, a4);
+    else hipLaunchKernelGGL((k_sample4<4>), dim3((unsigned)grid4), dim3(blk), lds4, s, a4);
+    HIP_TRY(hipGetLastError());
+    if (p->profiling) { int r = prof_event(p, s); if (r) return r; }
+    return 0;
+  }
   int wmax = 1;
   for (int w : p->comp_w) wmax = std::max(wmax, w);
   switch (wmax) {

@@ -1,0 +1,279 @@
+// tsim_kernel4.hip.h - "Four Russians" sampling kernel (k_sample4) for gfx950.
+//
+// Same results as k_sample<., true> (the fast exact formulation), different way of getting the
+// GF(2) parities.  For one graph (stabiliser term) every row parity <r, x> the formulation needs
+// is ONE BIT of a 128-bit word Y_g = R_g x.  The packer cuts x into 4-bit chunks and tabulates, per
+// chunk c and chunk value v, the partial product R_g[:, 4c..4c+3] v (16 bytes per graph).  A tile
+// of GT graphs shares one LDS table [chunk][v][graph] (GT*256 bytes per chunk); a lane forms
+//     Y_g = XOR_c  TABLE[c][ (x >> 4c) & 15 ][g]                       (one ds_read_b128 per chunk)
+// and then consumes the bits word-parallel:
+//     word U, V : the Dickson product pairs  ->  e = parity(popcount(U & V & PM))
+//     word O1   : counted NodePhases rows    ->  m0 = any(O1 & M0), m1 = popc(O1 & M1), m3 = popc(O1 & M3)
+//     word O2   : PhasePairs index bits, lambda (bit 30), linear bit (bit 31)
+// The per-graph VALU work drops from ~3 ops per ROW to ~2 XORs per CHUNK plus ~45 ops.  Row
+// constants are folded into chunk 0's entries.  Tables of the next tile are prefetched from L2 into
+// registers while the current tile is consumed from LDS (one barrier per tile).
+//
+// All lanes of a block walk the levels in lock step (they share the LDS tables), so the
+// normalisation check of sampler.py:66-72 - a second evaluation per level for in-batch shot 0 - is
+// done by ONE EXTRA BLOCK that replays shot 0 alone and evaluates both trial values.
+#pragma once
+#include "tsim_kernels.hip.h"
+
+namespace tsimk {
+
+// level record of the v4 layout
+enum { L4_G = 0, L4_NTILES, L4_TABLES, L4_RECS, L4_NCH, L4_FLAGS, L4_FRAME, L4_WORDS = 8 };
+// graph record of the v4 layout
+enum {
+  G4_M0 = 0, G4_M1, G4_M3, G4_PM, G4_N1, G4_DBITS /* 2*nD */, G4_TBL, G4_TBL2, G4_FLAGS,
+  G4_APRE = 11, G4_APIM = 12, G4_WORDS = 16
+};
+#define TSIMK_G4FLAG_D_COMBINED 1u
+#define TSIMK_G4FLAG_D_SEPARATE 2u
+// component record extension (words appended to the C_* record)
+enum { C4_LEVELS = 8, C4_WORDS = 16 };
+
+struct Sample4Args {
+  SampleArgs s;
+  int comp4_off;   // offset of the v4 component records (C4_WORDS each)
+  int has_check;   // 1: the last block replays in-batch shot 0 for the normalisation check
+};
+
+template <int GT>
+struct Tile4 {
+  static constexpr int kChunkBytes = 16 * GT * 16;  // 16 chunk values x GT graphs x 16 B
+};
+
+// evaluate() of one level with LDS chunk tables.  All threads of the block must call this together.
+template <int GT>
+__device__ __forceinline__ void eval_level4(const uint32_t *gimg, cptr img, cptr lvl, uint32_t x0, uint32_t x1,
+                                            uint8_t *lds_tab /* 2 * tile bytes */, float &out_re, float &out_im) {
+  const uint32_t G = lvl[L4_G], ntiles = lvl[L4_NTILES], nch = lvl[L4_NCH];
+  const uint32_t lflags = lvl[L4_FLAGS];
+  const bool approx = (lflags & TSIMK_LFLAG_APPROX) != 0, fixed = (lflags & TSIMK_LFLAG_FIXED) != 0;
+  const uint32_t tile_bytes = nch * Tile4<GT>::kChunkBytes;
+  const uint32_t tile_vec = tile_bytes >> 4;  // uint4 elements per tile
+  const uint4 *gtab = reinterpret_cast<const uint4 *>(gimg + lvl[L4_TABLES]);
+  cptr recs = img + lvl[L4_RECS];
+  const int tid = threadIdx.x, nthr = blockDim.x;
+
+  // per-chunk byte offset of this lane's entry: chunk value * (GT * 16)
+  uint32_t off[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {
+    const uint32_t w = (c < 8) ? x0 : x1;
+    off[c] = ((w >> (4 * (c & 7))) & 15u) * (GT * 16) + c * Tile4<GT>::kChunkBytes;
+  }
+
+  int sa = 0, sb = 0, sc = 0, sd = 0, sp = TSIMK_ZERO_POWER;
+  float fre = 0.0f, fim = 0.0f;
+
+  // tile 0 -> LDS buffer 0
+  __syncthreads();  // previous users of the buffers are done
+  if (ntiles)
+    for (uint32_t e = tid; e < tile_vec; e += nthr) reinterpret_cast<uint4 *>(lds_tab)[e] = gtab[e];
+  __syncthreads();
+
+  for (uint32_t t = 0; t < ntiles; ++t) {
+    // prefetch tile t+1 into registers (consumed after this tile's compute)
+    uint4 pre[4];
+    const bool more = (t + 1 < ntiles);
+    if (more) {
+      const uint4 *src = gtab + (size_t)(t + 1) * tile_vec;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const uint32_t e = tid + i * nthr;
+        if (e < tile_vec) pre[i] = src[e];
+      }
+    }
+    const uint8_t *buf = lds_tab + (t & 1u) * tile_bytes;
+#pragma unroll
+    for (int j = 0; j < GT; ++j) {
+      const uint32_t g = t * GT + j;
+      if (g >= G) break;
+      // ---- Y_g = XOR over chunks of the lane's table entries ----
+      uint32_t U = 0, V = 0, O1 = 0, O2 = 0;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        if ((uint32_t)c >= nch) break;
+        const uint4 v = *reinterpret_cast<const uint4 *>(buf + off[c] + j * 16);
+        U ^= v.x; V ^= v.y; O1 ^= v.z; O2 ^= v.w;
+      }
+      cptr gr = recs + g * G4_WORDS;
+      const uint32_t gflags = gr[G4_FLAGS];
+      // ---- counted NodePhases rows and the table index ----
+      const bool z = (O1 & gr[G4_M0]) != 0;
+      const uint32_t m1 = (uint32_t)__builtin_popcount(O1 & gr[G4_M1]);
+      const uint32_t m3 = (uint32_t)__builtin_popcount(O1 & gr[G4_M3]);
+      uint32_t idx = m3 - m1 + gr[G4_N1];
+      const uint32_t dsh = gr[G4_DBITS];
+      const uint32_t dbits = O2 & ((1u << dsh) - 1u);
+      if (gflags & TSIMK_G4FLAG_D_COMBINED) idx = (idx << dsh) | dbits;
+      idx = z ? 0u : idx + 1u;
+      const uint32_t *te = gimg + gr[G4_TBL] + 8u * idx;
+      const uint4 tv = *reinterpret_cast<const uint4 *>(te);
+      int a = (int)tv.x, b = (int)tv.y, c = (int)tv.z, d = (int)tv.w, p = 0;
+      if (!fixed) p = (int)te[4];
+      if (gflags & TSIMK_G4FLAG_D_SEPARATE) {
+        const uint32_t *td = gimg + gr[G4_TBL2] + 8u * dbits;
+        const uint4 dv = *reinterpret_cast<const uint4 *>(td);
+        zmul(a, b, c, d, (int)dv.x, (int)dv.y, (int)dv.z, (int)dv.w);
+        if (!fixed) p += (int)td[4];
+      }
+      // ---- exponent of w: k = 2 lambda + 4 (lin ^ parity(U & V & PM)) ----
+      const uint32_t e = (uint32_t)__builtin_popcount(U & V & gr[G4_PM]) + (O2 >> 31);
+      const uint32_t k = ((O2 >> 29) & 2u) | ((e & 1u) << 2);
+      {
+        const bool k2 = (k & 2u) != 0;
+        const int t0 = k2 ? -c : a, t1 = k2 ? d : b, t2 = k2 ? a : c, t3 = k2 ? -b : d;
+        const int nm = -(int)((k >> 2) & 1u);
+        a = (t0 ^ nm) - nm; b = (t1 ^ nm) - nm; c = (t2 ^ nm) - nm; d = (t3 ^ nm) - nm;
+      }
+      if (fixed) {
+        sa += a; sb += b; sc += c; sd += d;
+      } else if (!approx) {
+        if ((a | b | c | d) == 0) p = TSIMK_ZERO_POWER;
+        const int d1 = max(sp - p, 0), d2 = max(p - sp, 0);
+        sa = (int)((unsigned)shl_sat(sa, d1) + (unsigned)shl_sat(a, d2));
+        sb = (int)((unsigned)shl_sat(sb, d1) + (unsigned)shl_sat(b, d2));
+        sc = (int)((unsigned)shl_sat(sc, d1) + (unsigned)shl_sat(c, d2));
+        sd = (int)((unsigned)shl_sat(sd, d1) + (unsigned)shl_sat(d, d2));
+        sp = min(sp, p);
+        reduce1(sa, sb, sc, sd, sp);
+      } else {
+        float zr, zi;
+        to_complex(a, b, c, d, p, zr, zi);
+        const float ar = __uint_as_float(gr[G4_APRE]), ai = __uint_as_float(gr[G4_APIM]);
+        const float tr = __fsub_rn(__fmul_rn(zr, ar), __fmul_rn(zi, ai));
+        const float ti = __fadd_rn(__fmul_rn(zr, ai), __fmul_rn(zi, ar));
+        fre = __fadd_rn(fre, tr);
+        fim = __fadd_rn(fim, ti);
+      }
+    }
+    // stage tile t+1 in the other buffer: nobody reads it (its last readers passed the barrier
+    // that ended iteration t-1); one barrier makes it visible for iteration t+1
+    if (more) {
+      uint4 *dst = reinterpret_cast<uint4 *>(lds_tab + ((t + 1) & 1u) * tile_bytes);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const uint32_t e = tid + i * nthr;
+        if (e < tile_vec) dst[e] = pre[i];
+      }
+    }
+    __syncthreads();
+  }
+
+  if (!approx) {
+    if (fixed) sp = (int)lvl[L4_FRAME];
+    canon(sa, sb, sc, sd, sp);
+    if ((sa | sb | sc | sd) == 0) sp = 0;
+    to_complex(sa, sb, sc, sd, sp, out_re, out_im);
+  } else {
+    out_re = fre;
+    out_im = fim;
+  }
+}
+
+// sample_program for one batch, LDS chunk-table formulation.  Requires every sampled component to
+// have at most 64 parameters (2 words of x) - checked by the packer (p->v4).
+template <int GT>
+__global__ void __launch_bounds__(256) k_sample4(Sample4Args A4) {
+  const SampleArgs &A = A4.s;
+  const int nthr = blockDim.x;
+  const bool check_block = A4.has_check && (blockIdx.x == gridDim.x - 1);
+  long long row = (long long)blockIdx.x * nthr + threadIdx.x;
+  bool active = row < A.B;
+  if (check_block) {  // replay in-batch shot 0 (row 0 of this launch) in lane 0
+    row = 0;
+    active = (threadIdx.x == 0);
+  }
+  const unsigned long long shot = (unsigned long long)(A.shot_offset + row);
+  cptr img = (cptr)(uintptr_t)A.img;
+
+  const int WF32 = 2 * A.WF, WO32 = 2 * A.WO;
+  uint32_t *lds_f = tsimk_lds + threadIdx.x;                // [WF32][nthr]
+  uint32_t *lds_o = tsimk_lds + WF32 * nthr + threadIdx.x;  // [WO32][nthr]
+  uint8_t *lds_tab = reinterpret_cast<uint8_t *>(tsimk_lds + (WF32 + WO32) * nthr);
+
+  if (active) {
+    const uint64_t *frow = A.f + row * A.WF;
+    for (int w = 0; w < A.WF; ++w) {
+      const uint64_t v = frow[w];
+      lds_f[(2 * w) * nthr] = (uint32_t)v;
+      lds_f[(2 * w + 1) * nthr] = (uint32_t)(v >> 32);
+    }
+  } else {
+    for (int w = 0; w < WF32; ++w) lds_f[w * nthr] = 0u;
+  }
+  for (int w = 0; w < WO32; ++w) lds_o[w * nthr] = 0u;
+
+  // direct outputs (sampler.py:140-145)
+  cptr dt = img + A.direct_off;
+  for (int j = 0; j < A.n_direct; ++j) {
+    const uint32_t s = dt[2 * j], dst = dt[2 * j + 1];
+    const uint32_t src = s & 0x7FFFFFFFu;
+    const uint32_t bit = ((lds_f[(src >> 5) * nthr] >> (src & 31u)) ^ (s >> 31)) & 1u;
+    lds_o[(dst >> 5) * nthr] |= bit << (dst & 31u);
+  }
+
+  for (int ci = 0; ci < A.n_comp; ++ci) {
+    cptr comp = img + A4.comp4_off + ci * C4_WORDS;
+    const uint32_t n_out = comp[C_NOUT], F = comp[C_F];
+    cptr fsel = img + comp[C_FSEL];
+    cptr levels = img + comp[C4_LEVELS];
+    cptr outpos = img + comp[C_OUTPOS];
+    const uint32_t *keys = A.subkeys + 2 * comp[C_KEYBASE];
+
+    uint32_t x[2] = {0u, 0u};
+#pragma unroll
+    for (int w = 0; w < 2; ++w) {
+      uint32_t v = 0;
+      const int lo = w * 32;
+      const int hi = min((int)F, lo + 32);
+      for (int j = lo; j < hi; ++j) {
+        const uint32_t src = fsel[j];
+        v |= ((lds_f[(src >> 5) * nthr] >> (src & 31u)) & 1u) << (j - lo);
+      }
+      x[w] = v;
+    }
+
+    float re, im;
+    eval_level4<GT>(A.img, img, levels, x[0], x[1], lds_tab, re, im);
+    float prev = cabs32(re, im);
+    float maxdev = 0.0f;
+
+    for (uint32_t i = 0; i < n_out; ++i) {
+      cptr lvl = levels + (i + 1) * L4_WORDS;
+      const uint32_t bitpos = F + i;
+      const uint32_t bm = 1u << (bitpos & 31u);
+      const bool hiw = bitpos >= 32u;
+      if (hiw) x[1] |= bm; else x[0] |= bm;  // trial bit = 1 (sampler.py:65)
+      eval_level4<GT>(A.img, img, lvl, x[0], x[1], lds_tab, re, im);
+      const float p1 = cabs32(re, im);
+      if (check_block) {  // uniform branch: the whole block takes it together
+        if (hiw) x[1] &= ~bm; else x[0] &= ~bm;
+        eval_level4<GT>(A.img, img, lvl, x[0], x[1], lds_tab, re, im);
+        const float p0 = cabs32(re, im);
+        const float norm = __fdiv_rn(__fadd_rn(p0, p1), prev);        // sampler.py:71
+        maxdev = nanmax(maxdev, fabsf(__fsub_rn(norm, 1.0f)));       // sampler.py:72
+      }
+      const float u = uniform01(keys[2 * i], keys[2 * i + 1], shot);
+      const bool bit = u < __fdiv_rn(p1, prev);
+      if (hiw) x[1] = bit ? (x[1] | bm) : (x[1] & ~bm);
+      else x[0] = bit ? (x[0] | bm) : (x[0] & ~bm);
+      prev = bit ? p1 : __fsub_rn(prev, p1);
+      const uint32_t dst = outpos[i];
+      lds_o[(dst >> 5) * nthr] |= (bit ? 1u : 0u) << (dst & 31u);
+    }
+    if (check_block && threadIdx.x == 0 && A.norm_dev) A.norm_dev[ci] = maxdev;
+  }
+
+  if (active && !check_block) {
+    uint64_t *orow = A.out + row * A.WO;
+    for (int w = 0; w < A.WO; ++w)
+      orow[w] = (uint64_t)lds_o[(2 * w) * nthr] | ((uint64_t)lds_o[(2 * w + 1) * nthr] << 32);
+  }
+}
+
+}  // namespace tsimk

@@ -14,7 +14,7 @@ from pathlib import Path
 
 HERE = Path(__file__).resolve().parent
 SRC = HERE / "csrc" / "tsim_hip.hip"
-DEPS = [SRC, HERE / "csrc" / "tsim_kernels.hip.h", HERE.parent / "include" / "tsim_hip.h"]
+DEPS = sorted((HERE / "csrc").glob("*")) + [HERE.parent / "include" / "tsim_hip.h"]
 OUT = HERE / "libtsim_hip.so"
 
 FLAGS = [

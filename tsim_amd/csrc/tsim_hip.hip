@@ -741,15 +741,30 @@ static bool pack_level_fast(HostLevel &h, int W, std::vector<uint32_t> &tables, 
   for (int g = 0; g < G; ++g) {
     uint32_t *rec = &h.graph_rec[(size_t)g * G_WORDS];
     rec[GF_TBL] = (uint32_t)tables.size();
-    for (int j = 0; j < 4; ++j) tables.push_back(0u);  // entry 0: exact zero
-    tables.push_back((uint32_t)(h.approx ? 0 : TSIMK_ZERO_POWER));
-    tables.push_back(0u); tables.push_back(0u); tables.push_back(0u);
-    for (auto &e : entries[g]) {
-      const bool nz = (e.c[0] | e.c[1] | e.c[2] | e.c[3]) != 0;
-      const int sh = (fixed && nz) ? e.p - frame : 0;
-      for (int j = 0; j < 4; ++j) tables.push_back((uint32_t)(int32_t)(e.c[j] * (1ll << sh)));
-      tables.push_back((uint32_t)(fixed ? frame : e.p));
+    if (fixed) {
+      // fixed-frame levels: an entry is 16 words = the value times i^r for r = 0..3 (4 words each),
+      // pre-shifted to the frame power, so the kernel adds the selected rotation without any
+      // per-lane rotate/shift.  Entry 0 is the exact zero.
+      for (int j = 0; j < 16; ++j) tables.push_back(0u);
+      for (auto &e : entries[g]) {
+        const bool nz = (e.c[0] | e.c[1] | e.c[2] | e.c[3]) != 0;
+        const int sh = nz ? e.p - frame : 0;
+        long long v[4] = {e.c[0] * (1ll << sh), e.c[1] * (1ll << sh), e.c[2] * (1ll << sh), e.c[3] * (1ll << sh)};
+        for (int r = 0; r < 4; ++r) {
+          for (int j = 0; j < 4; ++j) tables.push_back((uint32_t)(int32_t)v[j]);
+          const long long t[4] = {-v[2], v[3], v[0], -v[1]};  // times i: (a,b,c,d) -> (-c, d, a, -b)
+          for (int j = 0; j < 4; ++j) v[j] = t[j];
+        }
+      }
+    } else {
+      for (int j = 0; j < 4; ++j) tables.push_back(0u);  // entry 0: exact zero
+      tables.push_back((uint32_t)(h.approx ? 0 : TSIMK_ZERO_POWER));
       tables.push_back(0u); tables.push_back(0u); tables.push_back(0u);
+      for (auto &e : entries[g]) {
+        for (int j = 0; j < 4; ++j) tables.push_back((uint32_t)(int32_t)e.c[j]);
+        tables.push_back((uint32_t)e.p);
+        tables.push_back(0u); tables.push_back(0u); tables.push_back(0u);
+      }
     }
   }
   for (int g = 0; g < G; ++g) {
@@ -795,10 +810,10 @@ static inline bool mask_bit(const std::vector<uint64_t> &m, int i) { return (m[(
 
 // recs4: G x G4_WORDS; tabs4: ntiles x nch x 16 x GT x 4 words.  `v3recs` are the level's patched
 // fast-layout graph records (for the term-table offsets and the approximate floatfactors).
-static void emit_level4(const HostLevel &h, int GT, const uint32_t *v3recs, std::vector<uint32_t> &recs4,
+static void emit_level4(const HostLevel &h, int GT, int nch, const uint32_t *v3recs, std::vector<uint32_t> &recs4,
                         std::vector<uint32_t> &tabs4, int &nch_out, int &ntiles_out) {
   const int G = h.G, P = h.P;
-  const int nch = std::max(1, (P + 3) / 4), ntiles = (G + GT - 1) / GT;
+  const int ntiles = (G + GT - 1) / GT;  // nch: chunks per tile, the same for every level (zero padded)
   nch_out = nch;
   ntiles_out = ntiles;
   recs4.assign((size_t)G * G4_WORDS, 0u);
@@ -957,7 +972,7 @@ retry_pack:
       static_assert((int)G_ROWS == (int)GF_ROWS, "row offset slot is shared by both layouts");
       for (int g = 0; g < h.G; ++g) img[goff + (size_t)g * G_WORDS + G_ROWS] += roff;
       if (p->fast) {
-        while (img.size() % 8) img.push_back(0u);  // 32-byte aligned table entries (uint4 loads)
+        while (img.size() % 16) img.push_back(0u);  // 64-byte aligned table entries (uint4 loads)
         const uint32_t toff = (uint32_t)img.size();
         img.insert(img.end(), tables.begin(), tables.end());
         for (int g = 0; g < h.G; ++g) {
@@ -972,7 +987,7 @@ retry_pack:
       lr[L_FRAME] = (uint32_t)frame;
       p->stats[1] += 1;
       p->stats[2] += fixed ? 1 : 0;
-      p->stats[5] += (long long)tables.size() / 8;
+      p->stats[5] += (long long)tables.size() * 4;  // table bytes
       if (p->fast)
         for (int g = 0; g < h.G; ++g) {
           const uint32_t *r = &h.graph_rec[(size_t)g * G_WORDS];
@@ -997,12 +1012,19 @@ retry_pack:
     const char *kenv = getenv("TSIM_AMD_KERNEL");
     if (kenv && strcmp(kenv, "v3") == 0) ok = false;
     const char *genv = getenv("TSIM_AMD_V4_GT");
-    p->v4_gt = (genv && atoi(genv) == 8) ? 8 : 4;
+    p->v4_gt = 4;
+    (void)genv;
     if (ok) {
       while (img.size() % 16) img.push_back(0u);
       p->comp4_off = (int)img.size();
       img.resize(img.size() + p->comps.size() * C4_WORDS, 0u);
-      p->v4_max_nch = 1;
+      int maxp = 1;
+      for (auto &c : p->comps)
+        for (auto &lv : c.levels) maxp = std::max(maxp, lv.P);
+      static const int kNch[] = {2, 4, 6, 8, 10, 12, 14, 16};
+      p->v4_max_nch = 16;
+      for (int v : kNch)
+        if (4 * v >= maxp) { p->v4_max_nch = v; break; }
       for (size_t ci = 0; ci < p->comps.size(); ++ci) {
         HostComponent &c = p->comps[ci];
         for (int w = 0; w < 8; ++w) img[p->comp4_off + ci * C4_WORDS + w] = img[p->comp_off + ci * C_WORDS + w];
@@ -1017,8 +1039,7 @@ retry_pack:
           std::vector<uint32_t> recs4, tabs4;
           int nch = 1, ntiles = 0;
           std::vector<uint32_t> v3copy(img.begin() + v3recs, img.begin() + v3recs + (size_t)h.G * G_WORDS);
-          emit_level4(h, p->v4_gt, v3copy.data(), recs4, tabs4, nch, ntiles);
-          p->v4_max_nch = std::max(p->v4_max_nch, nch);
+          emit_level4(h, p->v4_gt, p->v4_max_nch, v3copy.data(), recs4, tabs4, nch, ntiles);
           while (img.size() % 16) img.push_back(0u);
           const uint32_t roff = (uint32_t)img.size();
           img.insert(img.end(), recs4.begin(), recs4.end());
@@ -1189,13 +1210,18 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
     a4.s = a;
     a4.comp4_off = p->comp4_off;
     a4.has_check = (shot_offset == 0) ? 1 : 0;
-    const int blk = 256;
+    const char *benv = getenv("TSIM_AMD_V4_BLOCK");
+    const int blk = (benv && atoi(benv) == 512) ? 512 : ((benv && atoi(benv) == 128) ? 128 : 256);
     const size_t tile_bytes = (size_t)p->v4_max_nch * 16 * p->v4_gt * 16;
     const size_t lds4 = (size_t)(2 * a.WF + 2 * a.WO) * blk * 4 + 2 * tile_bytes;
     if (lds4 > 64 * 1024) return fail(TSIM_ENOTSUP, "v4 kernel needs %zu B of LDS", lds4);
     const long long grid4 = (B + blk - 1) / blk + a4.has_check;
-    if (p->v4_gt == 8) hipLaunchKernelGGL((k_sample4<8>), dim3((unsigned)grid4), dim3(blk), lds4, s, a4);
-    else hipLaunchKernelGGL((k_sample4<4>), dim3((unsigned)grid4), dim3(blk), lds4, s, a4);
+    switch (p->v4_max_nch) {
+#define TSIM_L4(N) case N: hipLaunchKernelGGL((k_sample4<4, N>), dim3((unsigned)grid4), dim3(blk), lds4, s, a4); break;
+      TSIM_L4(2) TSIM_L4(4) TSIM_L4(6) TSIM_L4(8) TSIM_L4(10) TSIM_L4(12) TSIM_L4(14)
+#undef TSIM_L4
+      default: hipLaunchKernelGGL((k_sample4<4, 16>), dim3((unsigned)grid4), dim3(blk), lds4, s, a4); break;
+    }
     HIP_TRY(hipGetLastError());
     if (p->profiling) { int r = prof_event(p, s); if (r) return r; }
     return 0;

@@ -40,16 +40,33 @@ struct Sample4Args {
   int has_check;   // 1: the last block replays in-batch shot 0 for the normalisation check
 };
 
+// a ^ b ^ c in one full-rate VALU op
+__device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) {
+  return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
+}
+
+// Linear global -> LDS copy of n16 uint4 elements by the whole block with the async LDS-DMA path
+// (global_load_lds_dwordx4: per-lane source, wave-uniform LDS base + lane*16).
+__device__ __forceinline__ void tile_copy(const uint4 *src, uint8_t *lds_dst, uint32_t n16, int tid, int nthr) {
+  typedef __attribute__((address_space(3))) void *lds_ptr_t;
+  typedef const __attribute__((address_space(1))) void *glb_ptr_t;
+  const uint32_t lane = tid & 63;
+  for (uint32_t base = (uint32_t)(tid & ~63); base < n16; base += nthr)
+    if (base + lane < n16)
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)(src + base + lane), (lds_ptr_t)(lds_dst + (size_t)base * 16), 16, 0, 0);
+}
+
 template <int GT>
 struct Tile4 {
   static constexpr int kChunkBytes = 16 * GT * 16;  // 16 chunk values x GT graphs x 16 B
 };
 
 // evaluate() of one level with LDS chunk tables.  All threads of the block must call this together.
-template <int GT>
+template <int GT, int NCH>
 __device__ __forceinline__ void eval_level4(const uint32_t *gimg, cptr img, cptr lvl, uint32_t x0, uint32_t x1,
                                             uint8_t *lds_tab /* 2 * tile bytes */, float &out_re, float &out_im) {
-  const uint32_t G = lvl[L4_G], ntiles = lvl[L4_NTILES], nch = lvl[L4_NCH];
+  const uint32_t G = lvl[L4_G], ntiles = lvl[L4_NTILES];
+  constexpr uint32_t nch = NCH;  // chunks per tile: compile-time, so the reads below are branch-free
   const uint32_t lflags = lvl[L4_FLAGS];
   const bool approx = (lflags & TSIMK_LFLAG_APPROX) != 0, fixed = (lflags & TSIMK_LFLAG_FIXED) != 0;
   const uint32_t tile_bytes = nch * Tile4<GT>::kChunkBytes;
@@ -58,47 +75,43 @@ __device__ __forceinline__ void eval_level4(const uint32_t *gimg, cptr img, cptr
   cptr recs = img + lvl[L4_RECS];
   const int tid = threadIdx.x, nthr = blockDim.x;
 
-  // per-chunk byte offset of this lane's entry: chunk value * (GT * 16)
-  uint32_t off[16];
+  // this lane's table entry per chunk (LDS address in buffer 0): chunk base + chunk value * (GT*16)
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  typedef const __attribute__((address_space(3))) u32x4 *lds_u4p;  // 32-bit LDS addresses
+  const uint32_t tab0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)lds_tab;
+  uint32_t ent[NCH];
 #pragma unroll
-  for (int c = 0; c < 16; ++c) {
+  for (int c = 0; c < NCH; ++c) {
     const uint32_t w = (c < 8) ? x0 : x1;
-    off[c] = ((w >> (4 * (c & 7))) & 15u) * (GT * 16) + c * Tile4<GT>::kChunkBytes;
+    ent[c] = tab0 + ((w >> (4 * (c & 7))) & 15u) * (GT * 16) + c * Tile4<GT>::kChunkBytes;
   }
+  int delta = (int)tile_bytes;  // +tile_bytes / -tile_bytes: toggles ent[] between the two buffers
 
   int sa = 0, sb = 0, sc = 0, sd = 0, sp = TSIMK_ZERO_POWER;
   float fre = 0.0f, fim = 0.0f;
 
-  // tile 0 -> LDS buffer 0
+  // tile 0 -> LDS buffer 0 (async global->LDS copies, 1 KiB per wave-instruction)
   __syncthreads();  // previous users of the buffers are done
-  if (ntiles)
-    for (uint32_t e = tid; e < tile_vec; e += nthr) reinterpret_cast<uint4 *>(lds_tab)[e] = gtab[e];
+  if (ntiles) tile_copy(gtab, lds_tab, tile_vec, tid, nthr);
   __syncthreads();
 
   for (uint32_t t = 0; t < ntiles; ++t) {
-    // prefetch tile t+1 into registers (consumed after this tile's compute)
-    uint4 pre[4];
+    // prefetch tile t+1 straight into the other LDS buffer: its last readers passed the barrier
+    // that ended iteration t-1; the barrier ending this iteration makes it visible
     const bool more = (t + 1 < ntiles);
-    if (more) {
-      const uint4 *src = gtab + (size_t)(t + 1) * tile_vec;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const uint32_t e = tid + i * nthr;
-        if (e < tile_vec) pre[i] = src[e];
-      }
-    }
-    const uint8_t *buf = lds_tab + (t & 1u) * tile_bytes;
+    if (more) tile_copy(gtab + (size_t)(t + 1) * tile_vec, lds_tab + ((t + 1) & 1u) * tile_bytes, tile_vec, tid, nthr);
 #pragma unroll
     for (int j = 0; j < GT; ++j) {
       const uint32_t g = t * GT + j;
       if (g >= G) break;
-      // ---- Y_g = XOR over chunks of the lane's table entries ----
+      // ---- Y_g = XOR over chunks of the lane's table entries (3-input XORs: v_bitop3 0x96) ----
       uint32_t U = 0, V = 0, O1 = 0, O2 = 0;
+      static_assert(NCH % 2 == 0, "chunks are consumed in pairs");
 #pragma unroll
-      for (int c = 0; c < 16; ++c) {
-        if ((uint32_t)c >= nch) break;
-        const uint4 v = *reinterpret_cast<const uint4 *>(buf + off[c] + j * 16);
-        U ^= v.x; V ^= v.y; O1 ^= v.z; O2 ^= v.w;
+      for (int c = 0; c < NCH; c += 2) {
+        const u32x4 v = *(lds_u4p)(uintptr_t)(ent[c] + j * 16);
+        const u32x4 w = *(lds_u4p)(uintptr_t)(ent[c + 1] + j * 16);
+        U = xor3(U, v.x, w.x); V = xor3(V, v.y, w.y); O1 = xor3(O1, v.z, w.z); O2 = xor3(O2, v.w, w.w);
       }
       cptr gr = recs + g * G4_WORDS;
       const uint32_t gflags = gr[G4_FLAGS];
@@ -111,7 +124,11 @@ __device__ __forceinline__ void eval_level4(const uint32_t *gimg, cptr img, cptr
       const uint32_t dbits = O2 & ((1u << dsh) - 1u);
       if (gflags & TSIMK_G4FLAG_D_COMBINED) idx = (idx << dsh) | dbits;
       idx = z ? 0u : idx + 1u;
-      const uint32_t *te = gimg + gr[G4_TBL] + 8u * idx;
+      // ---- exponent of w: k = 2 lambda + 4 (lin ^ parity(U & V & PM)); r = k / 2 ----
+      const uint32_t pc = (uint32_t)__builtin_popcount(U & V & gr[G4_PM]);
+      const uint32_t r = (O2 >> 30) ^ ((pc & 1u) << 1);
+      // fixed-frame levels: 4 pre-rotated copies per entry (value * i^r), 16 words per entry
+      const uint32_t *te = gimg + gr[G4_TBL] + (fixed ? (16u * idx + 4u * r) : 8u * idx);
       const uint4 tv = *reinterpret_cast<const uint4 *>(te);
       int a = (int)tv.x, b = (int)tv.y, c = (int)tv.z, d = (int)tv.w, p = 0;
       if (!fixed) p = (int)te[4];
@@ -121,13 +138,10 @@ __device__ __forceinline__ void eval_level4(const uint32_t *gimg, cptr img, cptr
         zmul(a, b, c, d, (int)dv.x, (int)dv.y, (int)dv.z, (int)dv.w);
         if (!fixed) p += (int)td[4];
       }
-      // ---- exponent of w: k = 2 lambda + 4 (lin ^ parity(U & V & PM)) ----
-      const uint32_t e = (uint32_t)__builtin_popcount(U & V & gr[G4_PM]) + (O2 >> 31);
-      const uint32_t k = ((O2 >> 29) & 2u) | ((e & 1u) << 2);
-      {
-        const bool k2 = (k & 2u) != 0;
+      if (!fixed) {  // rotate by i^r
+        const bool k2 = (r & 1u) != 0;
         const int t0 = k2 ? -c : a, t1 = k2 ? d : b, t2 = k2 ? a : c, t3 = k2 ? -b : d;
-        const int nm = -(int)((k >> 2) & 1u);
+        const int nm = -(int)((r >> 1) & 1u);
         a = (t0 ^ nm) - nm; b = (t1 ^ nm) - nm; c = (t2 ^ nm) - nm; d = (t3 ^ nm) - nm;
       }
       if (fixed) {
@@ -151,15 +165,10 @@ __device__ __forceinline__ void eval_level4(const uint32_t *gimg, cptr img, cptr
         fim = __fadd_rn(fim, ti);
       }
     }
-    // stage tile t+1 in the other buffer: nobody reads it (its last readers passed the barrier
-    // that ended iteration t-1); one barrier makes it visible for iteration t+1
     if (more) {
-      uint4 *dst = reinterpret_cast<uint4 *>(lds_tab + ((t + 1) & 1u) * tile_bytes);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const uint32_t e = tid + i * nthr;
-        if (e < tile_vec) dst[e] = pre[i];
-      }
+      for (int c = 0; c < NCH; ++c) ent[c] += (uint32_t)delta;
+      delta = -delta;
     }
     __syncthreads();
   }
@@ -177,8 +186,8 @@ __device__ __forceinline__ void eval_level4(const uint32_t *gimg, cptr img, cptr
 
 // sample_program for one batch, LDS chunk-table formulation.  Requires every sampled component to
 // have at most 64 parameters (2 words of x) - checked by the packer (p->v4).
-template <int GT>
-__global__ void __launch_bounds__(256) k_sample4(Sample4Args A4) {
+template <int GT, int NCH>
+__global__ void __launch_bounds__(512) k_sample4(Sample4Args A4) {
   const SampleArgs &A = A4.s;
   const int nthr = blockDim.x;
   const bool check_block = A4.has_check && (blockIdx.x == gridDim.x - 1);
@@ -239,7 +248,7 @@ __global__ void __launch_bounds__(256) k_sample4(Sample4Args A4) {
     }
 
     float re, im;
-    eval_level4<GT>(A.img, img, levels, x[0], x[1], lds_tab, re, im);
+    eval_level4<GT, NCH>(A.img, img, levels, x[0], x[1], lds_tab, re, im);
     float prev = cabs32(re, im);
     float maxdev = 0.0f;
 
@@ -249,11 +258,11 @@ __global__ void __launch_bounds__(256) k_sample4(Sample4Args A4) {
       const uint32_t bm = 1u << (bitpos & 31u);
       const bool hiw = bitpos >= 32u;
       if (hiw) x[1] |= bm; else x[0] |= bm;  // trial bit = 1 (sampler.py:65)
-      eval_level4<GT>(A.img, img, lvl, x[0], x[1], lds_tab, re, im);
+      eval_level4<GT, NCH>(A.img, img, lvl, x[0], x[1], lds_tab, re, im);
       const float p1 = cabs32(re, im);
       if (check_block) {  // uniform branch: the whole block takes it together
         if (hiw) x[1] &= ~bm; else x[0] &= ~bm;
-        eval_level4<GT>(A.img, img, lvl, x[0], x[1], lds_tab, re, im);
+        eval_level4<GT, NCH>(A.img, img, lvl, x[0], x[1], lds_tab, re, im);
         const float p0 = cabs32(re, im);
         const float norm = __fdiv_rn(__fadd_rn(p0, p1), prev);        // sampler.py:71
         maxdev = nanmax(maxdev, fabsf(__fsub_rn(norm, 1.0f)));       // sampler.py:72

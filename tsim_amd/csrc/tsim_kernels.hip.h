@@ -202,7 +202,7 @@ __device__ __forceinline__ void eval_level(cptr img, cptr lvl, const uint32_t (&
 
     // ---- NodePhases (terms.py:56-73): prod_t (1 + w^(4 par + phase)) ----
     int a = 1, b = 0, c = 0, d = 0, p = 0;
-#pragma unroll TSIMK_UNROLL_A
+#pragma unroll 4
     for (uint32_t t = 0; t < nA; ++t) {
       const uint32_t ph = row[0];
       const int par = (int)(row_par<W>(row + 1, x, ph >> 2) & 1u);
@@ -223,7 +223,7 @@ __device__ __forceinline__ void eval_level(cptr img, cptr lvl, const uint32_t (&
 
     // ---- HalfPiPhases (terms.py:94-107) + static phase: exponent of w ----
     uint32_t k = gr[G_PHASE];
-#pragma unroll TSIMK_UNROLL_B
+#pragma unroll 8
     for (uint32_t t = 0; t < nB; ++t) {
       const uint32_t coeff = row[0];
       k += (row_par<W>(row + 1, x, 0) & 1u) * coeff;
@@ -232,7 +232,7 @@ __device__ __forceinline__ void eval_level(cptr img, cptr lvl, const uint32_t (&
 
     // ---- PiProducts (terms.py:125-144): (-1)^(sum psi*phi) ----
     uint32_t e = 0;
-#pragma unroll TSIMK_UNROLL_C
+#pragma unroll 4
     for (uint32_t t = 0; t < nC; ++t) {
       const uint32_t cc = row[0];
       const uint32_t psi = row_par<W>(row + 1, x, cc & 1u);
@@ -414,11 +414,9 @@ __device__ __forceinline__ void eval_level_fast(const uint32_t *gimg, cptr img, 
     }
     // entry 0 of every table is the exact zero (a vanished NodePhases product: some 1 + w^4 factor)
     idx = (m0 != 0) ? 0u : idx + 1u;
-    // per-lane gather of the tabulated term (global memory, L1/L2 resident); issued here, consumed
-    // after the remaining rows so its latency hides behind them
-    const uint32_t *te = gimg + gr[GF_TBL] + 8u * idx;
-    const uint4 tv = *reinterpret_cast<const uint4 *>(te);
-    const uint32_t tpw = te[4];
+    // per-lane gather of the tabulated term (global memory, L1/L2 resident).  Fixed-frame levels
+    // hold four pre-rotated copies per entry (value * i^r), selected by the exponent below.
+    const uint32_t *te = gimg + gr[GF_TBL] + (fixed ? 16u : 8u) * idx;
 
     // ---- exponent of w: k = 2 <lam,x> + 4 ( <lin,x> ^ XOR_s <u_s,x><v_s,x> ) (k0 is in the table)
     uint32_t k = 0, e = 0;
@@ -434,14 +432,15 @@ __device__ __forceinline__ void eval_level_fast(const uint32_t *gimg, cptr img, 
     }
     k += (e & 1u) << 2;
 
-    int a = (int)tv.x, b = (int)tv.y, c = (int)tv.z, d = (int)tv.w, p = (int)tpw;
+    const uint4 tv = *reinterpret_cast<const uint4 *>(te + (fixed ? (k << 1) : 0u));  // r = k/2, 4 words each
+    int a = (int)tv.x, b = (int)tv.y, c = (int)tv.z, d = (int)tv.w, p = 0;
+    if (!fixed) p = (int)te[4];
     if (!d_tabled && nD) {
       zmul(a, b, c, d, da, db, dc, dd);
       p += dp;
     }
 
-    // rotate by w^k, k in {0, 2, 4, 6} (differs per lane)
-    {
+    if (!fixed) {  // rotate by w^k, k in {0, 2, 4, 6} (differs per lane)
       const bool k2 = (k & 2u) != 0;
       const int t0 = k2 ? -c : a, t1 = k2 ? d : b, t2 = k2 ? a : c, t3 = k2 ? -b : d;
       const int nm = -(int)((k >> 2) & 1u);

@@ -64,6 +64,54 @@ def algorithmic_ops_per_shot(program) -> int:
     return total
 
 
+def valu_block(ref_ops_per_shot: int, shots: int, kernel_s: float, config: str) -> dict:
+    """The bound that actually binds: integer VALU issue.
+
+    `reference_algorithm_*` prices the reference's un-reduced algorithm (SURVEY 8(d) op count); the
+    kernel executes far fewer instructions than that because the packer reduces the program
+    algebraically.  When a rocprofv3 PMC summary of this workload is committed (profiles/), the
+    executed VALU wave-instructions per launch are taken from it and turned into issue-cycles per
+    instruction per SIMD (gfx950 issues the int ops used here at ~4 cycles per wave-instruction).
+    """
+    out = {
+        "bound": "valu_issue",
+        "reference_algorithm_ops_per_shot": ref_ops_per_shot,
+        "reference_algorithm_equiv_Tlaneops": ref_ops_per_shot * shots / kernel_s / 1e12,
+        "peak_Tlaneops_at_2cyc_issue": VALU_PEAK_TOPS,
+    }
+    pmc = os.path.join(ROOT, "profiles", "latest_pmc.json")
+    try:
+        d = json.load(open(pmc))
+        if d.get("_config") == config and d.get("_shots") == shots:
+            insts = float(d["SQ_INSTS_VALU"])
+            simd_cycles = kernel_s * 2.4e9 * 1024
+            out.update({
+                "executed_valu_wave_insts_per_launch": insts,
+                "executed_valu_wave_insts_per_64_shots": insts / (shots / 64.0),
+                "cycles_per_valu_inst_per_simd_at_2p4GHz": simd_cycles / insts,
+                "valu_issue_busy_frac_at_4cyc": min(1.0, 4.0 * insts / simd_cycles),
+                "pmc_source": "profiles/latest_pmc.json (rocprofv3 --pmc SQ_INSTS_VALU, same workload)",
+            })
+    except Exception:
+        pass
+    return out
+
+
+def pmc_traffic_bytes(config: str, shots: int):
+    """HBM bytes per launch from the committed PMC summary of this workload (None if absent).
+
+    FETCH_SIZE/WRITE_SIZE are in KB; on gfx950 FETCH_SIZE reports half of a coalesced stream
+    (guides/MI355X_MICROARCH.md, HBM section), hence the factor 2 on the read side.
+    """
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "latest_pmc.json")))
+        if d.get("_config") == config and d.get("_shots") == shots:
+            return (2.0 * float(d["FETCH_SIZE"]) + float(d["WRITE_SIZE"])) * 1024.0
+    except Exception:
+        pass
+    return None
+
+
 def host_cpu_budget() -> tuple[int, str]:
     """CPUs this process may actually use: min(affinity, cgroup v2 quota)."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -243,21 +291,15 @@ def main() -> None:
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved_gbs / HBM_PEAK_GBS,
-                "traffic": None,
-                "kernel": "tsimk::k_sample",
+                "traffic": pmc_traffic_bytes(args.config, B),
+                "traffic_unit": "bytes per launch, rocprofv3 PMC: 2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction)",
+                "kernel": "tsimk::k_sample4 (LDS chunk tables)" if info.get("chunk_table_kernel") else "tsimk::k_sample",
                 "kernel_avg_ms": avg_kernel_s * 1e3,
                 "launches": launches,
                 "algorithmic_bytes_per_shot": bytes_per_shot,
                 "note": "fused kernel is integer-VALU bound, not HBM bound (DESIGN.md); see `valu`",
             },
-            "valu": {
-                "bound": "valu_int32",
-                "algorithmic_ops_per_shot": ops_per_shot,
-                "achieved": achieved_tops,
-                "peak": VALU_PEAK_TOPS,
-                "unit": "Tlane-op/s",
-                "frac": achieved_tops / VALU_PEAK_TOPS,
-            },
+            "valu": valu_block(ops_per_shot, B, avg_kernel_s, args.config),
         }
         if N == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(program, cfg, args.cpu_seconds)

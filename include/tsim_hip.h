@@ -101,14 +101,18 @@ int tsim_program_add_level(tsim_program *p, int32_t component, const tsim_level_
  * variable TSIM_AMD_MODE=faithful forces TSIM_MODE_FAITHFUL):
  *   TSIM_MODE_FAITHFUL  operation-by-operation mirror of the reference's int32 arithmetic
  *                       (src/tsim/core/exact_scalar.py:19-137), identical even where it wraps;
- *   TSIM_MODE_AUTO      use the faster exact-value formulation (NodePhases by class counting +
- *                       pack-time tables) whenever every graph qualifies (<= 30 NodePhases terms,
+ *   TSIM_MODE_AUTO      use the faster exact-value formulation (NodePhases by class counting,
+ *                       phase exponent as a Dickson-reduced GF(2) quadratic form, pack-time term
+ *                       tables; LDS chunk-table kernel when every component has <= 64 parameters)
+ *                       whenever every graph qualifies (<= 30 NodePhases terms,
  *                       even HalfPi coefficients, small floatfactors); it yields the same canonical
  *                       (a,b,c,d,power) and float32 amplitude as the reference whenever the
  *                       reference's own int32 arithmetic does not wrap.
  */
 #define TSIM_MODE_AUTO 0
 #define TSIM_MODE_FAITHFUL 1
+#define TSIM_MODE_ROW_KERNEL 2   /* exact-value formulation, but the row-by-row kernel instead of the
+                                    LDS chunk-table kernel (k_sample4); for tests and A/B timing */
 int tsim_program_set_mode(tsim_program *p, int32_t mode);
 /* after finalize: *fast = 1 if the exact-value formulation was selected */
 int tsim_program_get_mode(const tsim_program *p, int32_t *fast);

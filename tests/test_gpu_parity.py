@@ -168,7 +168,7 @@ def test_pack_unpack_kernels(hip):
 # ---- both evaluation formulations against the oracle ---------------------------
 
 
-@pytest.mark.parametrize("mode", ["auto", "faithful"])
+@pytest.mark.parametrize("mode", ["auto", "rows", "faithful"])
 @pytest.mark.parametrize("name", ["C2", "C3", "C4", "C5"])
 def test_modes_match_oracle_on_baseline_shapes(hip, mode, name):
     from oracle import oracle_c as OC
@@ -177,7 +177,8 @@ def test_modes_match_oracle_on_baseline_shapes(hip, mode, name):
     n = 600 if name == "C4" else 3000
     f = synth.synth_f(n, cfg["num_f"], cfg["p_bit"] * 2, seed=17)
     hp = hip.HipProgram(prog, mode=mode)
-    assert hp.fast == (mode == "auto")
+    assert hp.fast == (mode != "faithful")
+    assert hp.info()["chunk_table_kernel"] == (mode == "auto" and name != "C5")
     want, wdev, ov = OC.OracleProgram(prog).sample_program(f, (41, 43), return_devs=True, return_overflow=True)
     assert not ov
     got, gdev = hp.sample_batch(f, (41, 43))
@@ -185,7 +186,7 @@ def test_modes_match_oracle_on_baseline_shapes(hip, mode, name):
     np.testing.assert_array_equal(np.asarray(gdev, np.float32), np.asarray(wdev, np.float32))
 
 
-@pytest.mark.parametrize("mode", ["auto", "faithful"])
+@pytest.mark.parametrize("mode", ["auto", "rows", "faithful"])
 @pytest.mark.parametrize("approx", [False, True])
 def test_modes_evaluate_exact(hip, mode, approx):
     from oracle import oracle_c as OC
@@ -219,3 +220,44 @@ def test_auto_falls_back_to_faithful_when_not_eligible(hip):
     z, ex = hp.evaluate(0, 1, pv, exact=True)
     coeffs, power = O.evaluate_exact(lv, pv)
     np.testing.assert_array_equal(ex[:, :4], coeffs)
+
+
+@pytest.mark.parametrize("mode", ["auto", "rows", "faithful"])
+@pytest.mark.parametrize("approx", [False, True])
+def test_modes_small_programs_with_norm_check(hip, mode, approx):
+    """Small multi-component programs (incl. shuffled outputs): samples + normalisation deviation."""
+    comps = [dict(c, approx=approx) for c in SMALL["components"]]
+    for seed in (5, 6):
+        prog = synth.synth_program(
+            num_f=SMALL["num_f"], n_direct=SMALL["n_direct"], components=comps, seed=seed,
+            shuffle_outputs=True, direct_flip_fraction=0.3, identity_direct=False,
+        )
+        f = synth.synth_f(1500, SMALL["num_f"], 0.15, seed=seed)
+        want, wdev = O.sample_program(prog, f, (9, seed), return_devs=True)
+        got, gdev = hip.HipProgram(prog, mode=mode).sample_batch(f, (9, seed))
+        np.testing.assert_array_equal(got, want)
+        np.testing.assert_array_equal(np.asarray(gdev, np.float32), np.asarray(wdev, np.float32))
+
+
+def test_large_batch_properties(hip):
+    """BASELINE size (1e6 shots): size-independent properties instead of an oracle run.
+
+    * sharding invariance: two launches with shot_offset reproduce one launch bit for bit;
+    * the three kernels (chunk tables / rows / faithful) agree on every shot;
+    * direct detector columns equal the f columns they copy.
+    """
+    prog, cfg = synth.config_program("C2")
+    B = 1_000_000
+    f = synth.synth_f(B, cfg["num_f"], cfg["p_bit"], seed=123)
+    key = (77, 78)
+    a, _ = hip.HipProgram(prog, mode="auto").sample_batch(f, key, bit_packed=True)
+    b, _ = hip.HipProgram(prog, mode="rows").sample_batch(f, key, bit_packed=True)
+    c, _ = hip.HipProgram(prog, mode="faithful").sample_batch(f, key, bit_packed=True)
+    assert np.array_equal(a, b) and np.array_equal(a, c)
+    hp = hip.HipProgram(prog)
+    h1, _ = hp.sample_batch(f[:400_001], key, bit_packed=True)
+    h2, _ = hp.sample_batch(f[400_001:], key, shot_offset=400_001, bit_packed=True)
+    assert np.array_equal(np.concatenate([h1, h2]), a)
+    bits = np.unpackbits(a[:, :3], axis=1, bitorder="little")[:, :20]
+    nd = len(prog.direct_f_indices)
+    assert np.array_equal(bits[:, prog.output_order[:nd]], f[:, prog.direct_f_indices] ^ prog.direct_flips)

@@ -110,9 +110,11 @@ class HipProgram:
 
     def __init__(self, program, device: int = 0, mode: str = "auto"):
         """``mode``: "auto" (exact-value fast formulation when every graph qualifies) or
-        "faithful" (operation-by-operation int32 mirror of the reference); see include/tsim_hip.h."""
-        if mode not in ("auto", "faithful"):
-            raise ValueError("mode must be 'auto' or 'faithful'")
+        "faithful" (operation-by-operation int32 mirror of the reference) or "rows" (exact-value
+        formulation on the row-by-row kernel instead of the LDS chunk-table kernel); see
+        include/tsim_hip.h."""
+        if mode not in ("auto", "faithful", "rows"):
+            raise ValueError("mode must be 'auto', 'faithful' or 'rows'")
         self._lib = _lib.load()
         self._h = None
         program = from_tsim(program)
@@ -148,7 +150,7 @@ class HipProgram:
                     keep: list = []
                     desc = _level_desc(lv, keep)
                     _lib.check(lib.tsim_program_add_level(h, ci, C.byref(desc)), "tsim_program_add_level")
-            _lib.check(lib.tsim_program_set_mode(h, 1 if mode == "faithful" else 0), "tsim_program_set_mode")
+            _lib.check(lib.tsim_program_set_mode(h, {"auto": 0, "faithful": 1, "rows": 2}[mode]), "tsim_program_set_mode")
             _lib.check(lib.tsim_program_finalize(h, self.device), "tsim_program_finalize")
             fast = C.c_int32(0)
             _lib.check(lib.tsim_program_get_mode(h, C.byref(fast)), "tsim_program_get_mode")

@@ -573,7 +573,8 @@ static bool pack_level_fast(HostLevel &h, int W, std::vector<uint32_t> &tables, 
     const int nD = d.td ? h.i32[1][g] : 0;
     if (nD > 5) return false;  // 4^nD table entries: beyond this use the faithful layout
     const long long combos = (long long)(n[1] + n[3] + 1) << (2 * nD);
-    const bool d_tabled = nD > 0 && combos <= 256;   // combined table, else a separate one
+    static const long long kMaxCombined = getenv("TSIM_AMD_COMBINED") ? atoll(getenv("TSIM_AMD_COMBINED")) : 1024;
+    const bool d_tabled = nD > 0 && combos <= kMaxCombined;   // combined table, else a separate one
     std::vector<std::array<std::array<int, 4>, 4>> dterm((size_t)nD);  // [t][pa + 2 pb] -> term value
     for (int t = 0; t < nD; ++t) {
       const int al = h.u8[8][(size_t)g * d.td + t] & 7, be = h.u8[10][(size_t)g * d.td + t] & 7;
@@ -874,7 +875,8 @@ static void emit_level4(const HostLevel &h, int GT, int nch, const uint32_t *v3r
 extern "C" int tsim_program_set_mode(tsim_program *p, int32_t mode) {
   if (!p) return fail(TSIM_EINVAL, "program is NULL");
   if (p->finalized) return fail(TSIM_ESTATE, "program already finalized");
-  if (mode != TSIM_MODE_AUTO && mode != TSIM_MODE_FAITHFUL) return fail(TSIM_EINVAL, "bad mode %d", mode);
+  if (mode != TSIM_MODE_AUTO && mode != TSIM_MODE_FAITHFUL && mode != TSIM_MODE_ROW_KERNEL)
+    return fail(TSIM_EINVAL, "bad mode %d", mode);
   p->mode = mode;
   return TSIM_OK;
 }
@@ -885,7 +887,7 @@ extern "C" int tsim_program_finalize(tsim_program *p, int32_t device) {
   // ---- choose the evaluation formulation ----
   {
     const char *env = getenv("TSIM_AMD_MODE");
-    bool fast = (p->mode == TSIM_MODE_AUTO) && !(env && strcmp(env, "faithful") == 0);
+    bool fast = (p->mode != TSIM_MODE_FAITHFUL) && !(env && strcmp(env, "faithful") == 0);
     for (auto &c : p->comps)
       for (auto &lv : c.levels) fast = fast && level_fast_eligible(lv);
     p->fast = fast;
@@ -1011,6 +1013,7 @@ retry_pack:
       for (auto &lv : c.levels) ok = ok && level_v4_eligible(lv);
     const char *kenv = getenv("TSIM_AMD_KERNEL");
     if (kenv && strcmp(kenv, "v3") == 0) ok = false;
+    if (p->mode == TSIM_MODE_ROW_KERNEL) ok = false;
     const char *genv = getenv("TSIM_AMD_V4_GT");
     p->v4_gt = 4;
     (void)genv;

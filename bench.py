@@ -209,25 +209,45 @@ def main() -> None:
     del f
 
     if use_dist:
-        out_t = torch.zeros((B, WO * 8), dtype=torch.uint8, device=f"cuda:{local_rank}")
-        gather_list = [torch.empty_like(out_t) for _ in range(N)] if rank == 0 else None
-        d_out_ptr = out_t.data_ptr()
+        # Two output buffers: the RCCL gather of step i (async, ordered after kernel i on the
+        # engine's own stream) overlaps the kernel of step i+1.
+        dev = torch.device("cuda", local_rank)
+        ext = torch.cuda.ExternalStream(hp.stream_ptr(), device=dev)
+        out_bufs = [torch.zeros((B, WO * 8), dtype=torch.uint8, device=dev) for _ in range(2)]
+        gather_lists = [[torch.empty_like(out_bufs[0]) for _ in range(N)] if rank == 0 else None for _ in range(2)]
+        pending = [None, None]
     else:
         d_out = hp.malloc(B * WO * 8)
-        d_out_ptr = d_out.ptr
 
     key = prng.key(cfg["seed"])
     shot_offset = rank * B
+    step_no = [0]
 
     def step():
         nonlocal key
         key, sub = prng.split(key)  # one host split per batch (sampler.py:399)
-        hp.sample_batch_device(d_f.ptr, B, num_f, sub, d_out_ptr, shot_offset=shot_offset)
+        if not use_dist:
+            hp.sample_batch_device(d_f.ptr, B, num_f, sub, d_out.ptr, shot_offset=shot_offset)
+            return
+        b = step_no[0] & 1
+        step_no[0] += 1
+        with torch.cuda.stream(ext):
+            if pending[b] is not None:
+                pending[b].wait()  # the engine's stream waits until gather(i-2) released buffer b
+                pending[b] = None
+            hp.sample_batch_device(d_f.ptr, B, num_f, sub, out_bufs[b].data_ptr(), shot_offset=shot_offset)
+            pending[b] = dist.gather(out_bufs[b], gather_lists[b], dst=0, async_op=True)
+
+    def drain():
         if use_dist:
-            hp.synchronize()
-            dist.gather(out_t, gather_list, dst=0)
+            with torch.cuda.stream(ext):
+                for b in range(2):
+                    if pending[b] is not None:
+                        pending[b].wait()
+                        pending[b] = None
 
     def fence():
+        drain()
         hp.synchronize()
         if use_dist:
             dist.barrier()
@@ -241,6 +261,7 @@ def main() -> None:
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    drain()
     hp.synchronize()
     torch.cuda.synchronize()
     if use_dist:

@@ -186,6 +186,8 @@ int tsim_free_pinned(void *h_ptr);
 int tsim_memcpy_h2d(tsim_program *p, void *d_dst, const void *h_src, int64_t nbytes);
 int tsim_memcpy_d2h(tsim_program *p, void *h_dst, const void *d_src, int64_t nbytes);
 int tsim_synchronize(tsim_program *p);                      /* handle's stream */
+/* the handle's hipStream_t, e.g. to order a collective after the sampling kernel */
+int tsim_get_stream(tsim_program *p, void **stream);
 
 /* HIP-event timing of the sampling kernel launches on the handle's stream.   */
 int tsim_profile_enable(tsim_program *p, int32_t on);

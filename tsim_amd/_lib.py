@@ -79,6 +79,7 @@ SYMBOLS: dict[str, tuple] = {
     "tsim_memcpy_h2d": (C.c_int, [_P, _P, _P, _I64]),
     "tsim_memcpy_d2h": (C.c_int, [_P, _P, _P, _I64]),
     "tsim_synchronize": (C.c_int, [_P]),
+    "tsim_get_stream": (C.c_int, [_P, C.POINTER(_P)]),
     "tsim_profile_enable": (C.c_int, [_P, _I32]),
     "tsim_profile_read": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(_I64), _I32]),
     "tsim_program_info": (

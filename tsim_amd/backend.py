@@ -241,6 +241,12 @@ class HipProgram:
             "tsim_sample_batch_device",
         )
 
+    def stream_ptr(self) -> int:
+        """The handle's ``hipStream_t`` as an integer (to order foreign work after the kernels)."""
+        st = C.c_void_p()
+        _lib.check(self._lib.tsim_get_stream(self._h, C.byref(st)), "tsim_get_stream")
+        return int(st.value or 0)
+
     def synchronize(self) -> None:
         _lib.check(self._lib.tsim_synchronize(self._h), "tsim_synchronize")
 

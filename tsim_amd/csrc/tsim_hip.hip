@@ -1449,6 +1449,13 @@ extern "C" int tsim_memcpy_d2h(tsim_program *p, void *h_dst, const void *d_src, 
   return TSIM_OK;
 }
 
+extern "C" int tsim_get_stream(tsim_program *p, void **stream) {
+  if (int r = need_final(p)) return r;
+  if (!stream) return fail(TSIM_EINVAL, "stream is NULL");
+  *stream = (void *)p->stream;
+  return TSIM_OK;
+}
+
 extern "C" int tsim_synchronize(tsim_program *p) {
   if (int r = need_final(p)) return r;
   if (int r = set_device(p)) return r;

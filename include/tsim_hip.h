@@ -176,6 +176,22 @@ int tsim_pack_bits_device(tsim_program *p, const uint8_t *d_in, int64_t B, int32
 int tsim_unpack_bits_device(tsim_program *p, const uint64_t *d_in, int64_t B, int32_t nbits,
                             uint8_t *d_out, void *stream);
 
+/* ---- device-side noise sampler (statistical replacement of ChannelSampler.sample,
+ *      src/tsim/noise/channels.py:578-658; the numpy PCG64 stream is not reproduced) ---------- */
+typedef struct tsim_noise tsim_noise;
+
+/* Channel tables exactly as ChannelSampler._precompute_sparse builds them (channels.py:578-622):
+ *   p_fire[n_channels]; n_outcomes[c] = number of non-identity outcomes of channel c;
+ *   cond_cdf = the concatenated conditional CDFs; xor_patterns = uint8 [sum n_outcomes, num_f].
+ * The sampler lives on the program's device and stream. */
+int tsim_noise_create(tsim_program *p, int32_t num_f, int32_t n_channels, const double *p_fire,
+                      const int32_t *n_outcomes, const double *cond_cdf, const uint8_t *xor_patterns,
+                      tsim_noise **out);
+/* d_f: uint64 [B, ceil(num_f/64)] (device); overwritten with a fresh batch keyed by (key_hi, key_lo). */
+int tsim_noise_sample_device(tsim_noise *n, int64_t B, uint32_t key_hi, uint32_t key_lo, uint64_t *d_f,
+                             void *stream);
+void tsim_noise_destroy(tsim_noise *n);
+
 /* ---- plumbing: memory, streams, timing (replaces utils/cuda_helpers.py:73-141) */
 
 int tsim_device_count(int32_t *count);

@@ -124,3 +124,26 @@ def test_vanishing_marginal_raises_and_warns(hip):
     )
     with pytest.warns(UserWarning, match="not normalized"):
         hip.sample_program(make_program([off], [], 1, 0), np.zeros((4, 0), np.uint8), (1, 2))
+
+
+def test_device_noise_pipeline_statistics(hip):
+    """noise="device": the whole pipeline stays on the GPU; statistics equal the host-noise sampler's."""
+    prog, noise = noisy_program()
+    n = 400_000
+    a = CompiledDetectorSampler(prog, seed=3, noise="device", **noise).sample(n, batch_size=100_000, append_observables=True)
+    b = CompiledDetectorSampler(prog, seed=3, noise="host", **noise).sample(n, batch_size=100_000, append_observables=True)
+    assert a.shape == b.shape == (n, 4) and a.dtype == np.bool_
+    pa, pb = a.mean(axis=0), b.mean(axis=0)
+    sigma = np.sqrt(np.maximum(pb * (1 - pb), 1e-9) * 2 / n)
+    assert np.all(np.abs(pa - pb) < 6 * sigma + 1e-6), (pa, pb)
+    # correlations between a direct detector and an observable it shares an error with
+    ca, cb = (a[:, 1] & a[:, 3]).mean(), (b[:, 1] & b[:, 3]).mean()
+    assert abs(ca - cb) < 6 * np.sqrt(max(cb * (1 - cb), 1e-9) * 2 / n) + 1e-6
+    # reproducible for a fixed seed, reference-sample flags work
+    a2 = CompiledDetectorSampler(prog, seed=3, noise="device", **noise).sample(n, batch_size=100_000, append_observables=True)
+    assert np.array_equal(a, a2)
+    d, o = CompiledDetectorSampler(prog, seed=3, noise="device", **noise).sample(
+        1000, separate_observables=True, use_detector_reference_sample=True)
+    assert d.shape == (1000, 2) and o.shape == (1000, 2)
+    with pytest.raises(ValueError):
+        CompiledDetectorSampler(prog, seed=3, noise="gpu", **noise)

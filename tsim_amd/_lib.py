@@ -71,6 +71,9 @@ SYMBOLS: dict[str, tuple] = {
     "tsim_evaluate": (C.c_int, [_P, _I32, _I32, _P, _I64, _P, _P, _P, _P]),
     "tsim_pack_bits_device": (C.c_int, [_P, _P, _I64, _I32, _P, _P]),
     "tsim_unpack_bits_device": (C.c_int, [_P, _P, _I64, _I32, _P, _P]),
+    "tsim_noise_create": (C.c_int, [_P, _I32, _I32, _P, _P, _P, _P, C.POINTER(_P)]),
+    "tsim_noise_sample_device": (C.c_int, [_P, _I64, _U32, _U32, _P, _P]),
+    "tsim_noise_destroy": (None, [_P]),
     "tsim_device_count": (C.c_int, [C.POINTER(_I32)]),
     "tsim_malloc_device": (C.c_int, [_P, _I64, C.POINTER(_P)]),
     "tsim_free_device": (C.c_int, [_P, _P]),

@@ -380,3 +380,83 @@ def _key_pair(key) -> tuple[int, int]:
     if arr.shape[0] != 2:
         raise ValueError("key must be a (hi, lo) uint32 pair or a threefry2x32 JAX key")
     return int(arr[0]), int(arr[1])
+
+
+class DeviceNoiseSampler:
+    """Device-side twin of ``ChannelSampler.sample`` (reference src/tsim/noise/channels.py:624-658).
+
+    Built from a host :class:`tsim_amd.channels.ChannelSampler` (which performs the channel
+    simplification once, exactly like the reference) and bound to a :class:`HipProgram`'s device and
+    stream.  ``sample_into`` fills a packed ``uint64[B, ceil(num_f/64)]`` device buffer; the result
+    is statistically equivalent to the host sampler, not stream-identical (numpy's PCG64 stream is
+    sequential by construction).
+    """
+
+    def __init__(self, hip_program: HipProgram, channel_sampler):
+        self._prog = hip_program
+        self._lib = hip_program._lib
+        data = channel_sampler._sparse_data
+        self.num_f = int(channel_sampler.signature_matrix.shape[1])
+        p_fire = np.ascontiguousarray([d[0] for d in data], dtype=np.float64)
+        n_out = np.ascontiguousarray([len(d[1]) for d in data], dtype=np.int32)
+        cdf = np.ascontiguousarray(np.concatenate([d[1] for d in data]) if data else np.zeros(0), dtype=np.float64)
+        pats = (
+            np.ascontiguousarray(np.concatenate([d[2] for d in data], axis=0), dtype=np.uint8)
+            if data else np.zeros((0, self.num_f), np.uint8)
+        )
+        h = C.c_void_p()
+        _lib.check(
+            self._lib.tsim_noise_create(
+                hip_program._h, self.num_f, len(data), _lib.ptr(p_fire), _lib.ptr(n_out), _lib.ptr(cdf),
+                _lib.ptr(pats), C.byref(h),
+            ),
+            "tsim_noise_create",
+        )
+        self._h = h
+        self._finalizer = weakref.finalize(self, self._lib.tsim_noise_destroy, h)
+
+    def sample_into(self, d_f: int, B: int, key) -> None:
+        """Asynchronous on the program's stream."""
+        _lib.check(
+            self._lib.tsim_noise_sample_device(
+                self._h, int(B), int(key[0]) & 0xFFFFFFFF, int(key[1]) & 0xFFFFFFFF, C.c_void_p(d_f), None
+            ),
+            "tsim_noise_sample_device",
+        )
+
+    def sample(self, B: int, key) -> np.ndarray:
+        """Convenience: ``uint8[B, num_f]`` on the host (for tests)."""
+        wf = max(1, (self.num_f + 63) // 64)
+        buf = self._prog.malloc(max(1, B) * wf * 8)
+        self.sample_into(buf.ptr, B, key)
+        packed = np.zeros((B, wf * 8), np.uint8)
+        self._prog.d2h(packed, buf)
+        buf.free()
+        return np.unpackbits(packed, axis=1, bitorder="little")[:, : self.num_f]
+
+
+class _PinnedBuf:
+    """Owns one ``hipHostMalloc`` allocation (freed when the last numpy view dies)."""
+
+    def __init__(self, nbytes: int):
+        self._lib = _lib.load()
+        p = C.c_void_p()
+        _lib.check(self._lib.tsim_malloc_pinned(int(nbytes), C.byref(p)), "tsim_malloc_pinned")
+        self.ptr = int(p.value or 0)
+        self.nbytes = int(nbytes)
+
+    def __del__(self):  # pragma: no cover - interpreter teardown order is not guaranteed
+        try:
+            if self.ptr:
+                self._lib.tsim_free_pinned(C.c_void_p(self.ptr))
+                self.ptr = 0
+        except Exception:
+            pass
+
+
+def alloc_pinned_numpy(nbytes: int, dtype, shape) -> np.ndarray:
+    """Pinned host ndarray (mirror of reference src/tsim/utils/cuda_helpers.py:73-102, on hipHostMalloc)."""
+    buf = _PinnedBuf(max(1, int(nbytes)))
+    carr = (C.c_uint8 * buf.nbytes).from_address(buf.ptr)
+    carr._owner = buf  # keeps the allocation alive as long as any view exists
+    return np.frombuffer(carr, dtype=np.uint8)[: int(np.prod(shape)) * np.dtype(dtype).itemsize].view(dtype).reshape(shape)

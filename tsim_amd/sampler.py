@@ -28,7 +28,15 @@ from math import ceil
 import numpy as np
 
 from . import prng
-from .backend import HipProgram, evaluate, get_hip_program, sample_program  # noqa: F401
+from .backend import (  # noqa: F401
+    DeviceNoiseSampler,
+    HipProgram,
+    alloc_pinned_numpy,
+    check_norm_deviation,
+    evaluate,
+    get_hip_program,
+    sample_program,
+)
 from .channels import ChannelSampler
 from .program import CompiledProgram, from_tsim, load_npz
 
@@ -46,7 +54,16 @@ class _CompiledSamplerBase:
         error_transform: np.ndarray,
         seed: int | None = None,
         device: int = 0,
+        noise: str = "host",
     ):
+        """``noise="host"`` reproduces the reference's numpy channel stream bit for bit;
+        ``noise="device"`` samples the channels on the GPU (statistically equivalent, the error
+        bits never leave HBM) - the throughput mode of SURVEY.md section 7, hard part 3."""
+        if noise not in ("host", "device"):
+            raise ValueError("noise must be 'host' or 'device'")
+        self._noise = noise
+        self._noise_key = None
+        self._device_state = None
         if seed is None:
             seed = int(np.random.default_rng().integers(0, 2**30))
         self._key = prng.key(seed)
@@ -57,6 +74,7 @@ class _CompiledSamplerBase:
             channel_probs=channel_probs, error_transform=error_transform, seed=channel_seed
         )
         self._num_detectors = int(self._program.num_detectors)
+        self._noise_key = prng.key(channel_seed)  # key chain of the device noise sampler
 
         prog = self._program
         self._direct_f_indices = np.asarray(prog.direct_f_indices)
@@ -150,6 +168,8 @@ class _CompiledSamplerBase:
         if not self._program.components:
             samples = self._sample_direct(shots)
             return (samples, self._compute_reference_sample()) if compute_reference else samples
+        if self._noise == "device":
+            return self._sample_batches_device(shots, batch_size, compute_reference=compute_reference)
 
         if batch_size is None:
             max_batch_size = self._estimate_batch_size()
@@ -178,6 +198,58 @@ class _CompiledSamplerBase:
             assert reference is not None
             return result, reference
         return result
+
+    # -- device-resident pipeline (noise="device") ---------------------------------------------
+    def _sample_batches_device(self, shots: int, batch_size: int | None, *, compute_reference: bool = False):
+        """noise -> f -> sample_program -> unpack, all on the GPU; one pinned D2H at the end.
+
+        Per batch: one split of the noise key chain for the device channel sampler and one split
+        of the sampler key for ``sample_program`` (as reference sampler.py:399).  The reference
+        sample, when requested, is its own 1-row call with f = 0 (sampler.py:263-276).
+        """
+        hp = get_hip_program(self._program, self._device)
+        st = self._device_state
+        if st is None or st["hp"] is not hp:
+            st = self._device_state = dict(hp=hp, noise=DeviceNoiseSampler(hp, self._channel_sampler), bufs=None)
+        if batch_size is None:
+            max_batch_size = self._estimate_batch_size()
+            num_batches = max(1, ceil(shots / max_batch_size))
+            batch_size = ceil(shots / num_batches)
+        else:
+            num_batches = ceil(shots / batch_size)
+        reference = self._compute_reference_sample() if compute_reference else None
+        num_f = int(self._channel_sampler.signature_matrix.shape[1])
+        n_out = int(self._program.num_outputs)
+        wf, wo = max(1, (num_f + 63) // 64), (n_out + 63) // 64
+        total = num_batches * batch_size
+        n_comp = max(1, len(self._program.components))
+        need = (batch_size, total)
+        if st["bufs"] is None or st["bufs"]["need"] != need:
+            st["bufs"] = dict(
+                need=need,
+                f=hp.malloc(batch_size * wf * 8),
+                out=hp.malloc(total * wo * 8),
+                u8=hp.malloc(total * n_out),
+                devs=hp.malloc(num_batches * n_comp * 4),
+            )
+        b = st["bufs"]
+        for i in range(num_batches):
+            self._noise_key, nk = prng.split(self._noise_key)
+            st["noise"].sample_into(b["f"].ptr, batch_size, nk)
+            self._key, subkey = prng.split(self._key)
+            hp.sample_batch_device(
+                b["f"].ptr, batch_size, num_f, subkey, b["out"].ptr + i * batch_size * wo * 8,
+                d_norm_dev=b["devs"].ptr + i * n_comp * 4,
+            )
+        hp.unpack_bits_device(b["out"].ptr, total, n_out, b["u8"].ptr)
+        result = alloc_pinned_numpy(total * n_out, np.uint8, (total, n_out))
+        hp.d2h(result, b["u8"])
+        devs = np.zeros(num_batches * n_comp, np.float32)
+        hp.d2h(devs, b["devs"])
+        for dev in devs[: num_batches * len(self._program.components)]:
+            check_norm_deviation(float(dev))
+        result = result.view(np.bool_)[:shots]
+        return (result, reference) if compute_reference else result
 
     # -- post-selection ------------------------------------------------------------------
     def _sample_batches_with_postselection(

@@ -148,7 +148,7 @@ def test_pack_unpack_kernels(hip):
     prog, _ = synth.config_program("C2")
     hp = hip.get_hip_program(prog)
     rng = np.random.default_rng(0)
-    for nbits in (1, 7, 63, 64, 65, 200):
+    for nbits in (1, 7, 16, 20, 63, 64, 65, 128, 200, 320):
         a = (rng.random((333, nbits)) < 0.5).astype(np.uint8) * rng.integers(1, 255, size=(333, nbits), dtype=np.uint8)
         wq = (nbits + 63) // 64
         d_in, d_p, d_out = hp.malloc(a.nbytes), hp.malloc(333 * wq * 8), hp.malloc(a.nbytes)

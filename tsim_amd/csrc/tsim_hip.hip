@@ -8,6 +8,7 @@
 #include "tsim_kernels.hip.h"
 #include "tsim_kernel4.hip.h"
 #include "tsim_noise.hip.h"
+#include "tsim_format.hip.h"
 
 #include <algorithm>
 #include <array>
@@ -1259,19 +1260,41 @@ extern "C" int tsim_sample_batch_device(tsim_program *p, const uint64_t *d_f, in
 }
 
 static int launch_pack(tsim_program *p, const uint8_t *d_in, int64_t B, int32_t nbits, uint64_t *d_out, hipStream_t s) {
-  const int WQ = (nbits + 63) / 64;
-  const long long n = B * WQ;
+  const int n32 = 2 * ((nbits + 63) / 64);
+  const long long n = B * n32;
   if (n == 0) return 0;
-  hipLaunchKernelGGL(k_pack_bits, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_in, d_out, (long long)B, nbits, WQ);
+  if ((nbits & 15) == 0 && ((uintptr_t)d_in & 15) == 0) {
+    const long long nw = B * (n32 / 2);
+    hipLaunchKernelGGL(k_pack_bits_a16, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, s, (const uint4 *)d_in, d_out,
+                       (long long)B, nbits, n32 / 2);
+    HIP_TRY(hipGetLastError());
+    return 0;
+  }
+  const long long in_dwords = (B * (long long)nbits + 3) / 4;  // the last dword may be partial
+  hipLaunchKernelGGL(k_pack_bits, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_in, (uint32_t *)d_out,
+                     (long long)B, nbits, n32, in_dwords);
   HIP_TRY(hipGetLastError());
   return 0;
 }
 
 static int launch_unpack(tsim_program *p, const uint64_t *d_in, int64_t B, int32_t nbits, uint8_t *d_out, hipStream_t s) {
-  const int WQ = (nbits + 63) / 64;
-  const long long n = B * (long long)nbits;
-  if (n == 0) return 0;
-  hipLaunchKernelGGL(k_unpack_bits, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_in, d_out, (long long)B, nbits, WQ);
+  const int n32 = 2 * ((nbits + 63) / 64);
+  const long long total = B * (long long)nbits;
+  if (total == 0) return 0;
+  if (total >= (1ll << 32)) return fail(TSIM_ENOTSUP, "unpack of %lld bytes in one call (limit 2^32)", total);
+  if ((nbits & 15) == 0 && ((uintptr_t)d_out & 15) == 0) {
+    const long long total16 = total >> 4;
+    const unsigned long long per = (unsigned long long)(nbits >> 4);
+    const unsigned long long magic16 = ((1ull << 40) + per - 1ull) / per;
+    hipLaunchKernelGGL(k_unpack_bits_a16, dim3((unsigned)((total16 + 255) / 256)), dim3(256), 0, s, (const uint32_t *)d_in,
+                       (uint4 *)d_out, total16, nbits, n32, magic16);
+    HIP_TRY(hipGetLastError());
+    return 0;
+  }
+  const long long nthreads = (total + 3) / 4;
+  const unsigned long long magic = ((1ull << 40) + (unsigned long long)nbits - 1ull) / (unsigned long long)nbits;
+  hipLaunchKernelGGL(k_unpack_bits, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, s, (const uint32_t *)d_in,
+                     (uint32_t *)d_out, d_out, total, nbits, n32, magic, (long long)B * n32);
   HIP_TRY(hipGetLastError());
   return 0;
 }

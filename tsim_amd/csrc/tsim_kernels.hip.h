@@ -662,32 +662,4 @@ __global__ void k_keygen(uint32_t k0, uint32_t k1, int n, uint32_t *__restrict__
   }
 }
 
-// ---------------------------------------------------------------------------
-// data-format kernels either side of the path (HBM-bound)
-// ---------------------------------------------------------------------------
-
-// uint8 [B, nbits] -> uint64 [B, ceil(nbits/64)]; one thread per output word
-__global__ void __launch_bounds__(256) k_pack_bits(const uint8_t *__restrict__ in, uint64_t *__restrict__ out,
-                                                    long long B, int nbits, int WQ) {
-  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= B * WQ) return;
-  const long long row = idx / WQ;
-  const int w = (int)(idx - row * WQ);
-  const uint8_t *src = in + row * (long long)nbits + 64 * w;
-  const int n = min(64, nbits - 64 * w);
-  uint64_t v = 0;
-  for (int i = 0; i < n; ++i) v |= (uint64_t)(src[i] != 0) << i;
-  out[idx] = v;
-}
-
-// uint64 [B, ceil(nbits/64)] -> uint8 [B, nbits]; one thread per output byte
-__global__ void __launch_bounds__(256) k_unpack_bits(const uint64_t *__restrict__ in, uint8_t *__restrict__ out,
-                                                      long long B, int nbits, int WQ) {
-  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= B * (long long)nbits) return;
-  const long long row = idx / nbits;
-  const int j = (int)(idx - row * nbits);
-  out[idx] = (uint8_t)((in[row * WQ + (j >> 6)] >> (j & 63)) & 1ull);
-}
-
 }  // namespace tsimk

@@ -155,6 +155,24 @@ int tsim_sample_batch_device(tsim_program *p, const uint64_t *d_f, int64_t B, in
                              uint64_t *d_out, float *d_max_norm_dev, void *stream);
 
 /*
+ * Device-side post-selection (the shot-skipping of src/tsim/sampler.py:422-545, done in HBM):
+ *   tsim_postselect_device writes every row's DIRECT output bits to d_out (compiled columns 0),
+ *   tests ((row ^ ref) & mask) != 0 per row (mask/ref: packed uint64 [ceil(num_outputs/64)] in final
+ *   column order; ref may be NULL) and appends the surviving row numbers to d_row_index
+ *   (uint32 [B], unordered), their count to d_row_count; d_discarded (uint8 [B]) is optional.
+ *   tsim_sample_rows_device then samples only the listed rows (overwriting their d_out rows with
+ *   direct + compiled bits).  The Threefry counter of a row stays its own in-batch index, so the
+ *   result does not depend on the order of the list.
+ */
+int tsim_postselect_device(tsim_program *p, const uint64_t *d_f, int64_t B, int32_t num_f,
+                           const uint64_t *d_mask, const uint64_t *d_ref, uint64_t *d_out,
+                           uint32_t *d_row_index, uint32_t *d_row_count, uint8_t *d_discarded, void *stream);
+int tsim_sample_rows_device(tsim_program *p, const uint64_t *d_f, int64_t B, int32_t num_f,
+                            uint32_t key_hi, uint32_t key_lo, int64_t shot_offset, uint64_t *d_out,
+                            float *d_max_norm_dev, const uint32_t *d_row_index, const uint32_t *d_row_count,
+                            void *stream);
+
+/*
  * evaluate(circuit, param_vals) for level `level` of component `component`
  * (replaces src/tsim/compile/evaluate.py:15-59).
  *   params        uint8 [B, n_params]

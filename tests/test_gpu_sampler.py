@@ -147,3 +147,37 @@ def test_device_noise_pipeline_statistics(hip):
     assert d.shape == (1000, 2) and o.shape == (1000, 2)
     with pytest.raises(ValueError):
         CompiledDetectorSampler(prog, seed=3, noise="gpu", **noise)
+
+
+def test_device_postselection(hip):
+    """noise="device" + postselection_mask: discarded rows never reach the sampling kernel.
+
+    Checks the reference's contract (sampler.py:776-781): all rows returned; a discarded row keeps
+    its direct detector columns and has False in every compiled column; survivors are complete; the
+    statistics of the survivors equal those of the host path.
+    """
+    prog, noise = noisy_program()  # det0 = f0 (direct), det1 = f2 ^ 1 (direct), obs 2, 3 compiled
+    n = 200_000
+    mask = np.array([True, False])
+    dev = CompiledDetectorSampler(prog, seed=8, noise="device", **noise)
+    a = dev.sample(n, batch_size=64_000, append_observables=True, postselection_mask=mask)
+    assert a.shape == (n, 4)
+    disc = a[:, 0] & mask[0]
+    assert disc.any() and (~disc).any()
+    assert not a[disc, 2:].any()  # compiled columns of discarded rows are False
+    host = CompiledDetectorSampler(prog, seed=8, noise="host", **noise)
+    b = host.sample(n, batch_size=64_000, append_observables=True, postselection_mask=mask)
+    sa, sb = a[~disc], b[~(b[:, 0] & mask[0])]
+    pa, pb = sa.mean(axis=0), sb.mean(axis=0)
+    sig = np.sqrt(np.maximum(pb * (1 - pb), 1e-9) * (1 / len(sa) + 1 / len(sb)))
+    assert np.all(np.abs(pa - pb) < 6 * sig + 1e-6), (pa, pb)
+    assert abs(disc.mean() - 0.2) < 0.01  # P(f0 = 1) = 0.2 in the noise model
+    # with the detector reference XOR: det1's reference value is 1, so it reads f2 afterwards
+    c = CompiledDetectorSampler(prog, seed=8, noise="device", **noise).sample(
+        50_000, batch_size=20_000, postselection_mask=np.array([False, True]), use_detector_reference_sample=True)
+    assert c.shape == (50_000, 2) and 0.05 < c[:, 1].mean() < 0.6
+    # a mask that discards everything: nothing is sampled, compiled columns all False
+    alld = CompiledDetectorSampler(prog, seed=8, noise="device", channel_probs=[error_probs(1.0)] + noise["channel_probs"][1:],
+                                   error_transform=noise["error_transform"])
+    z = alld.sample(5000, batch_size=2000, append_observables=True, postselection_mask=mask)
+    assert z[:, 0].all() and not z[:, 2:].any()

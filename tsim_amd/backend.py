@@ -247,6 +247,31 @@ class HipProgram:
         _lib.check(self._lib.tsim_get_stream(self._h, C.byref(st)), "tsim_get_stream")
         return int(st.value or 0)
 
+    def postselect_device(self, d_f: int, B: int, num_f: int, d_mask: int, d_ref: int, d_out: int,
+                          d_row_index: int, d_row_count: int, d_discarded: int = 0) -> None:
+        """Direct bits for every row + survivor list (asynchronous); see include/tsim_hip.h."""
+        _lib.check(
+            self._lib.tsim_postselect_device(
+                self._h, C.c_void_p(d_f), int(B), int(num_f), C.c_void_p(d_mask),
+                C.c_void_p(d_ref) if d_ref else None, C.c_void_p(d_out), C.c_void_p(d_row_index),
+                C.c_void_p(d_row_count), C.c_void_p(d_discarded) if d_discarded else None, None,
+            ),
+            "tsim_postselect_device",
+        )
+
+    def sample_rows_device(self, d_f: int, B: int, num_f: int, key, d_out: int, d_row_index: int,
+                           d_row_count: int, *, shot_offset: int = 0, d_norm_dev: int = 0) -> None:
+        """Sample only the listed rows (asynchronous)."""
+        _lib.check(
+            self._lib.tsim_sample_rows_device(
+                self._h, C.c_void_p(d_f), int(B), int(num_f), int(key[0]) & 0xFFFFFFFF,
+                int(key[1]) & 0xFFFFFFFF, int(shot_offset), C.c_void_p(d_out),
+                C.c_void_p(d_norm_dev) if d_norm_dev else None, C.c_void_p(d_row_index),
+                C.c_void_p(d_row_count), None,
+            ),
+            "tsim_sample_rows_device",
+        )
+
     def synchronize(self) -> None:
         _lib.check(self._lib.tsim_synchronize(self._h), "tsim_synchronize")
 

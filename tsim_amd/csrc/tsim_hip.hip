@@ -1174,7 +1174,8 @@ static int prof_drain(tsim_program *p) {
 }
 
 static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_t num_f, uint32_t key_hi,
-                         uint32_t key_lo, int64_t shot_offset, uint64_t *d_out, float *d_dev, hipStream_t s) {
+                         uint32_t key_lo, int64_t shot_offset, uint64_t *d_out, float *d_dev, hipStream_t s,
+                         const uint32_t *d_row_index = nullptr, const uint32_t *d_row_count = nullptr) {
   if (!p->sampleable) return fail(TSIM_ESTATE, "program has joint-mode components (evaluate-only)");
   if (B < 0 || num_f < 0 || shot_offset < 0) return fail(TSIM_EINVAL, "negative B/num_f/shot_offset");
   if (p->max_f_index >= num_f)
@@ -1202,6 +1203,8 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
   a.direct_off = p->direct_off;
   a.n_comp = (int)p->comps.size();
   a.comp_off = p->comp_off;
+  a.row_index = d_row_index;
+  a.row_count = d_row_index ? d_row_count : nullptr;
   if (num_f == 0) a.WF = 0;
   int block = 256;
   size_t lds = (size_t)(2 * a.WF + 2 * a.WO) * block * 4;
@@ -1215,7 +1218,7 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
     Sample4Args a4;
     a4.s = a;
     a4.comp4_off = p->comp4_off;
-    a4.has_check = (shot_offset == 0) ? 1 : 0;
+    a4.has_check = (shot_offset == 0 || d_row_index) ? 1 : 0;
     const char *benv = getenv("TSIM_AMD_V4_BLOCK");
     const int blk = (benv && atoi(benv) == 512) ? 512 : ((benv && atoi(benv) == 128) ? 128 : 256);
     const size_t tile_bytes = (size_t)p->v4_max_nch * 16 * p->v4_gt * 16;
@@ -1297,6 +1300,55 @@ static int launch_unpack(tsim_program *p, const uint64_t *d_in, int64_t B, int32
                      (uint32_t *)d_out, d_out, total, nbits, n32, magic, (long long)B * n32);
   HIP_TRY(hipGetLastError());
   return 0;
+}
+
+extern "C" int tsim_sample_rows_device(tsim_program *p, const uint64_t *d_f, int64_t B, int32_t num_f,
+                                       uint32_t key_hi, uint32_t key_lo, int64_t shot_offset, uint64_t *d_out,
+                                       float *d_max_norm_dev, const uint32_t *d_row_index,
+                                       const uint32_t *d_row_count, void *stream) {
+  if (int r = need_final(p)) return r;
+  if (int r = set_device(p)) return r;
+  if (!d_row_index || !d_row_count) return fail(TSIM_EINVAL, "row list is NULL");
+  if (B >= (1ll << 32)) return fail(TSIM_ENOTSUP, "row indices are 32-bit");
+  hipStream_t s = stream ? (hipStream_t)stream : p->stream;
+  return launch_sample(p, d_f, B, num_f, key_hi, key_lo, shot_offset, d_out, d_max_norm_dev, s, d_row_index,
+                       d_row_count);
+}
+
+extern "C" int tsim_postselect_device(tsim_program *p, const uint64_t *d_f, int64_t B, int32_t num_f,
+                                      const uint64_t *d_mask, const uint64_t *d_ref, uint64_t *d_out,
+                                      uint32_t *d_row_index, uint32_t *d_row_count, uint8_t *d_discarded,
+                                      void *stream) {
+  if (int r = need_final(p)) return r;
+  if (int r = set_device(p)) return r;
+  if (B < 0 || num_f < 0) return fail(TSIM_EINVAL, "negative size");
+  if (B >= (1ll << 32)) return fail(TSIM_ENOTSUP, "row indices are 32-bit");
+  if (p->max_f_index >= num_f) return fail(TSIM_EINVAL, "program references f index %d but num_f=%d", p->max_f_index, num_f);
+  if (!d_mask || !d_out || !d_row_index || !d_row_count) return fail(TSIM_EINVAL, "NULL buffer");
+  hipStream_t s = stream ? (hipStream_t)stream : p->stream;
+  HIP_TRY(hipMemsetAsync(d_row_count, 0, 4, s));
+  if (B == 0 || p->num_outputs == 0) return TSIM_OK;
+  FilterArgs a;
+  a.img = p->d_img;
+  a.f = d_f;
+  a.out = d_out;
+  a.mask = d_mask;
+  a.ref = d_ref;
+  a.row_index = d_row_index;
+  a.row_count = d_row_count;
+  a.discarded = d_discarded;
+  a.B = B;
+  a.WF = num_f == 0 ? 0 : std::max(1, (num_f + 63) / 64);
+  a.WO = (p->num_outputs + 63) / 64;
+  a.n_direct = p->n_direct;
+  a.direct_off = p->direct_off;
+  int block = 256;
+  size_t lds = (size_t)(2 * a.WF + 2 * a.WO) * block * 4;
+  if (lds > 60 * 1024) { block = 64; lds = (size_t)(2 * a.WF + 2 * a.WO) * block * 4; }
+  if (lds > 60 * 1024) return fail(TSIM_ENOTSUP, "num_f + num_outputs too large for LDS staging (%zu B)", lds);
+  hipLaunchKernelGGL(k_direct_filter, dim3((unsigned)((B + block - 1) / block)), dim3(block), lds, s, a);
+  HIP_TRY(hipGetLastError());
+  return TSIM_OK;
 }
 
 extern "C" int tsim_pack_bits_device(tsim_program *p, const uint8_t *d_in, int64_t B, int32_t nbits,

@@ -193,7 +193,13 @@ __global__ void __launch_bounds__(512) k_sample4(Sample4Args A4) {
   const bool check_block = A4.has_check && (blockIdx.x == gridDim.x - 1);
   long long row = (long long)blockIdx.x * nthr + threadIdx.x;
   bool active = row < A.B;
-  if (check_block) {  // replay in-batch shot 0 (row 0 of this launch) in lane 0
+  if (A.row_index) {  // device-side post-selection: slots map to listed survivor rows
+    const long long n = (long long)*A.row_count;
+    if (!check_block && (long long)blockIdx.x * nthr >= n) return;  // block-uniform: no barrier skipped
+    active = row < n;
+    if (check_block) { row = 0; active = (threadIdx.x == 0) && n > 0; }
+    row = active ? (long long)A.row_index[row] : 0;
+  } else if (check_block) {  // replay in-batch shot 0 (row 0 of this launch) in lane 0
     row = 0;
     active = (threadIdx.x == 0);
   }
@@ -275,7 +281,7 @@ __global__ void __launch_bounds__(512) k_sample4(Sample4Args A4) {
       const uint32_t dst = outpos[i];
       lds_o[(dst >> 5) * nthr] |= (bit ? 1u : 0u) << (dst & 31u);
     }
-    if (check_block && threadIdx.x == 0 && A.norm_dev) A.norm_dev[ci] = maxdev;
+    if (check_block && threadIdx.x == 0 && active && A.norm_dev) A.norm_dev[ci] = maxdev;
   }
 
   if (active && !check_block) {

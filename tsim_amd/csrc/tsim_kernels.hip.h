@@ -61,6 +61,11 @@ struct SampleArgs {
   int WF, WO;               // 64-bit words per f row / out row
   int n_direct, direct_off; // direct table: (src | flip<<31, dst) pairs
   int n_comp, comp_off;
+  // optional row indirection (device-side post-selection): launch slot i handles row
+  // row_index[i] for i < *row_count; the Threefry counter stays the row's own in-batch index,
+  // so results do not depend on the order of the list.  nullptr = identity.
+  const uint32_t *row_index;
+  const uint32_t *row_count;
 };
 
 struct EvalArgs {
@@ -572,10 +577,17 @@ extern __shared__ uint32_t tsimk_lds[];
 template <int WMAX, bool FAST>
 __global__ void __launch_bounds__(256) k_sample(SampleArgs A) {
   const int nthr = blockDim.x;
-  const long long row = (long long)blockIdx.x * nthr + threadIdx.x;
-  if (row >= A.B) return;  // no barriers below: every lane owns its LDS columns
+  const long long slot = (long long)blockIdx.x * nthr + threadIdx.x;
+  long long row = slot;
+  if (A.row_index) {
+    if (slot >= (long long)*A.row_count) return;
+    row = A.row_index[slot];
+  } else if (slot >= A.B) {
+    return;  // no barriers below: every lane owns its LDS columns
+  }
   const unsigned long long shot = (unsigned long long)(A.shot_offset + row);
-  const bool check_lane = (shot == 0ull);
+  // normalisation check (sampler.py:66-72): in-batch shot 0, or the first listed survivor
+  const bool check_lane = A.row_index ? (slot == 0) : (shot == 0ull);
   cptr img = (cptr)(uintptr_t)A.img;
 
   const int WF32 = 2 * A.WF, WO32 = 2 * A.WO;
@@ -642,6 +654,59 @@ __global__ void __launch_bounds__(256) k_evaluate(EvalArgs A) {
 #pragma unroll
     for (int i = 0; i < 5; ++i) A.exact[row * 5 + i] = ex[i];
   }
+}
+
+// ---------------------------------------------------------------------------
+// device-side post-selection (reference: src/tsim/sampler.py:422-545, the part that decides
+// which shots reach the sampling kernel): every row gets its DIRECT output bits written; rows in
+// which a masked direct detector fires (after the optional XOR with the reference sample) are
+// discarded, the others are appended to the survivor list.
+// ---------------------------------------------------------------------------
+struct FilterArgs {
+  const uint32_t *img;
+  const uint64_t *f;       // [B, WF]
+  uint64_t *out;           // [B, WO] direct bits, zero elsewhere
+  const uint64_t *mask;    // [WO] masked direct detector columns
+  const uint64_t *ref;     // [WO] reference bits XORed before the test (or nullptr)
+  uint32_t *row_index;     // [B] survivors (unordered)
+  uint32_t *row_count;     // zeroed by the caller
+  uint8_t *discarded;      // [B] 0/1 (or nullptr)
+  long long B;
+  int WF, WO, n_direct, direct_off;
+};
+
+__global__ void __launch_bounds__(256) k_direct_filter(FilterArgs A) {
+  const int nthr = blockDim.x;
+  const long long row = (long long)blockIdx.x * nthr + threadIdx.x;
+  if (row >= A.B) return;
+  cptr img = (cptr)(uintptr_t)A.img;
+  const int WF32 = 2 * A.WF, WO32 = 2 * A.WO;
+  uint32_t *lds_f = tsimk_lds + threadIdx.x;
+  uint32_t *lds_o = tsimk_lds + WF32 * nthr + threadIdx.x;
+  const uint64_t *frow = A.f + row * A.WF;
+  for (int w = 0; w < A.WF; ++w) {
+    const uint64_t v = frow[w];
+    lds_f[(2 * w) * nthr] = (uint32_t)v;
+    lds_f[(2 * w + 1) * nthr] = (uint32_t)(v >> 32);
+  }
+  for (int w = 0; w < WO32; ++w) lds_o[w * nthr] = 0u;
+  cptr dt = img + A.direct_off;
+  for (int j = 0; j < A.n_direct; ++j) {
+    const uint32_t s = dt[2 * j], dst = dt[2 * j + 1];
+    const uint32_t src = s & 0x7FFFFFFFu;
+    const uint32_t bit = ((lds_f[(src >> 5) * nthr] >> (src & 31u)) ^ (s >> 31)) & 1u;
+    lds_o[(dst >> 5) * nthr] |= bit << (dst & 31u);
+  }
+  bool discard = false;
+  uint64_t *orow = A.out + row * A.WO;
+  for (int w = 0; w < A.WO; ++w) {
+    const uint64_t v = (uint64_t)lds_o[(2 * w) * nthr] | ((uint64_t)lds_o[(2 * w + 1) * nthr] << 32);
+    orow[w] = v;
+    const uint64_t r = A.ref ? A.ref[w] : 0ull;
+    discard = discard || (((v ^ r) & A.mask[w]) != 0ull);
+  }
+  if (A.discarded) A.discarded[row] = discard ? 1 : 0;
+  if (!discard) A.row_index[atomicAdd(A.row_count, 1u)] = (uint32_t)row;
 }
 
 // ---------------------------------------------------------------------------

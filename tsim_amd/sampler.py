@@ -251,6 +251,72 @@ class _CompiledSamplerBase:
         result = result.view(np.bool_)[:shots]
         return (result, reference) if compute_reference else result
 
+    def _postselect_device(self, shots, batch_size, *, postselect_direct, compute_reference, xor_detector_ref):
+        """Post-selection with everything on the GPU: ``k_noise`` -> ``k_direct_filter`` (direct bits
+        for all rows + survivor list) -> the sampling kernel on the survivors only.  Same return
+        contract as the host path: ``(result, reference, was_discarded)``."""
+        hp = get_hip_program(self._program, self._device)
+        st = self._device_state
+        if st is None or st["hp"] is not hp:
+            st = self._device_state = dict(hp=hp, noise=DeviceNoiseSampler(hp, self._channel_sampler), bufs=None)
+        if batch_size is None:
+            batch_size = self._resolve_batch_size(shots, batch_size, compute_reference=False)
+        num_batches = ceil(shots / batch_size)
+        reference = self._compute_reference_sample() if compute_reference else None
+        nd = self._num_detectors
+        num_f = int(self._channel_sampler.signature_matrix.shape[1])
+        n_out = int(self._program.num_outputs)
+        wf, wo = max(1, (num_f + 63) // 64), (n_out + 63) // 64
+        total = num_batches * batch_size
+        n_comp = max(1, len(self._program.components))
+
+        def pack_cols(bits_nd):
+            full = np.zeros(wo * 64, np.uint8)
+            full[:nd] = np.asarray(bits_nd, np.uint8)
+            return np.packbits(full, bitorder="little").view(np.uint64)
+
+        mask_w = pack_cols(postselect_direct)
+        use_ref = xor_detector_ref and reference is not None
+        ref_w = pack_cols(reference[:nd]) if use_ref else None
+        d_f, d_out = hp.malloc(batch_size * wf * 8), hp.malloc(total * wo * 8)
+        d_u8, d_disc = hp.malloc(total * n_out), hp.malloc(total)
+        d_idx, d_cnt = hp.malloc(batch_size * 4), hp.malloc(4)
+        d_devs, d_mask = hp.malloc(num_batches * n_comp * 4), hp.malloc(wo * 8)
+        d_ref = hp.malloc(wo * 8)
+        hp.h2d(d_mask, mask_w)
+        if use_ref:
+            hp.h2d(d_ref, ref_w)
+        hp.h2d(d_devs, np.zeros(num_batches * n_comp, np.float32))
+        for i in range(num_batches):
+            self._noise_key, nk = prng.split(self._noise_key)
+            st["noise"].sample_into(d_f.ptr, batch_size, nk)
+            out_i = d_out.ptr + i * batch_size * wo * 8
+            hp.postselect_device(d_f.ptr, batch_size, num_f, d_mask.ptr, d_ref.ptr if use_ref else 0, out_i,
+                                 d_idx.ptr, d_cnt.ptr, d_disc.ptr + i * batch_size)
+            self._key, subkey = prng.split(self._key)
+            hp.sample_rows_device(d_f.ptr, batch_size, num_f, subkey, out_i, d_idx.ptr, d_cnt.ptr,
+                                  d_norm_dev=d_devs.ptr + i * n_comp * 4)
+        hp.unpack_bits_device(d_out.ptr, total, n_out, d_u8.ptr)
+        result = alloc_pinned_numpy(total * n_out, np.uint8, (total, n_out))
+        hp.d2h(result, d_u8)
+        disc = np.zeros(total, np.uint8)
+        hp.d2h(disc, d_disc)
+        devs = np.zeros(num_batches * n_comp, np.float32)
+        hp.d2h(devs, d_devs)
+        for dev in devs[: num_batches * len(self._program.components)]:
+            check_norm_deviation(float(dev))
+        for buf in (d_f, d_out, d_u8, d_disc, d_idx, d_cnt, d_devs, d_mask, d_ref):
+            buf.free()
+        result = result.view(np.bool_)[:shots]
+        was_discarded = disc[:shots].astype(np.bool_)
+        # discarded rows keep their direct DETECTOR columns only (reference sampler.py:519-521)
+        result[was_discarded, nd:] = False
+        if use_ref:
+            det_ref = reference[:nd]
+            result[~was_discarded, :nd] ^= det_ref
+            result[was_discarded, :nd] ^= det_ref & self._direct_detector_mask
+        return result, reference, was_discarded
+
     # -- post-selection ------------------------------------------------------------------
     def _sample_batches_with_postselection(
         self,
@@ -275,6 +341,11 @@ class _CompiledSamplerBase:
             return empty, ref0, none_discarded
 
         postselect_direct = postselection_mask & self._direct_detector_mask
+        if self._noise == "device" and self._program.components:
+            return self._postselect_device(
+                shots, batch_size, postselect_direct=postselect_direct,
+                compute_reference=compute_reference, xor_detector_ref=xor_detector_ref,
+            )
         if not self._program.components:
             samples = self._sample_direct(shots)
             reference = None

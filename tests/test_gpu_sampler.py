@@ -42,10 +42,11 @@ def noisy_program():
     dict(append_observables=True, postselection_mask=np.array([True, False])),
     dict(prepend_observables=True, postselection_mask=np.array([True, True]), use_detector_reference_sample=True),
 ])
-def test_detector_sampler_matches_oracle_twin(hip, monkeypatch, kwargs):
+@pytest.mark.parametrize("mode", ["auto", "rows", "faithful"])
+def test_detector_sampler_matches_oracle_twin(hip, monkeypatch, kwargs, mode):
     """Same seed, same batch size: the HIP-backed sampler equals the oracle-backed one bit for bit."""
     prog, noise = noisy_program()
-    a = CompiledDetectorSampler(prog, seed=11, **noise).sample(1000, batch_size=300, **kwargs)
+    a = CompiledDetectorSampler(prog, seed=11, mode=mode, **noise).sample(1000, batch_size=300, **kwargs)
     monkeypatch.setattr(sampler_module, "sample_program", oracle_sample_program)
     b = CompiledDetectorSampler(prog, seed=11, **noise).sample(1000, batch_size=300, **kwargs)
     if isinstance(a, tuple):
@@ -149,7 +150,8 @@ def test_device_noise_pipeline_statistics(hip):
         CompiledDetectorSampler(prog, seed=3, noise="gpu", **noise)
 
 
-def test_device_postselection(hip):
+@pytest.mark.parametrize("mode", ["auto", "rows", "faithful"])
+def test_device_postselection(hip, mode):
     """noise="device" + postselection_mask: discarded rows never reach the sampling kernel.
 
     Checks the reference's contract (sampler.py:776-781): all rows returned; a discarded row keeps
@@ -159,7 +161,7 @@ def test_device_postselection(hip):
     prog, noise = noisy_program()  # det0 = f0 (direct), det1 = f2 ^ 1 (direct), obs 2, 3 compiled
     n = 200_000
     mask = np.array([True, False])
-    dev = CompiledDetectorSampler(prog, seed=8, noise="device", **noise)
+    dev = CompiledDetectorSampler(prog, seed=8, noise="device", mode=mode, **noise)
     a = dev.sample(n, batch_size=64_000, append_observables=True, postselection_mask=mask)
     assert a.shape == (n, 4)
     disc = a[:, 0] & mask[0]

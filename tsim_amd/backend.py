@@ -317,8 +317,8 @@ class HipProgram:
 # ---------------------------------------------------------------------------
 
 
-def get_hip_program(program, device: int = 0) -> HipProgram:
-    """Upload ``program`` once per device and cache the handle on the program object."""
+def get_hip_program(program, device: int = 0, mode: str = "auto") -> HipProgram:
+    """Upload ``program`` once per (device, mode) and cache the handle on the program object."""
     if isinstance(program, HipProgram):
         return program
     cache = getattr(program, "_backend_cache", None)
@@ -327,11 +327,11 @@ def get_hip_program(program, device: int = 0) -> HipProgram:
             cache = {}
             object.__setattr__(program, "_backend_cache", cache)
         except Exception:  # frozen foreign object: no caching
-            return HipProgram(program, device)
-    hp = cache.get(device)
+            return HipProgram(program, device, mode)
+    hp = cache.get((device, mode))
     if hp is None:
-        hp = HipProgram(program, device)
-        cache[device] = hp
+        hp = HipProgram(program, device, mode)
+        cache[(device, mode)] = hp
     return hp
 
 
@@ -351,7 +351,7 @@ def check_norm_deviation(max_norm_deviation: float) -> None:
         )
 
 
-def sample_program(program, f_params, key, *, device: int = 0) -> np.ndarray:
+def sample_program(program, f_params, key, *, device: int = 0, mode: str = "auto") -> np.ndarray:
     """Drop-in for ``tsim.sampler.sample_program`` (sampler.py:117-167).
 
     ``key`` is the post-split subkey, either a ``(hi, lo)`` uint32 pair or a JAX
@@ -361,7 +361,7 @@ def sample_program(program, f_params, key, *, device: int = 0) -> np.ndarray:
     f = np.asarray(f_params)
     if int(getattr(program, "num_outputs")) == 0:
         return np.zeros((f.shape[0], 0), dtype=np.bool_)
-    hp = get_hip_program(program, device)
+    hp = get_hip_program(program, device, mode)
     out, devs = hp.sample_batch(f, key)
     for dev in devs:
         check_norm_deviation(float(dev))

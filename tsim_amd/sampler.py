@@ -55,6 +55,7 @@ class _CompiledSamplerBase:
         seed: int | None = None,
         device: int = 0,
         noise: str = "host",
+        mode: str = "auto",
     ):
         """``noise="host"`` reproduces the reference's numpy channel stream bit for bit;
         ``noise="device"`` samples the channels on the GPU (statistically equivalent, the error
@@ -62,6 +63,7 @@ class _CompiledSamplerBase:
         if noise not in ("host", "device"):
             raise ValueError("noise must be 'host' or 'device'")
         self._noise = noise
+        self._mode = mode  # kernel formulation: "auto" | "rows" | "faithful" (see HipProgram)
         self._noise_key = None
         self._device_state = None
         if seed is None:
@@ -207,7 +209,7 @@ class _CompiledSamplerBase:
         of the sampler key for ``sample_program`` (as reference sampler.py:399).  The reference
         sample, when requested, is its own 1-row call with f = 0 (sampler.py:263-276).
         """
-        hp = get_hip_program(self._program, self._device)
+        hp = get_hip_program(self._program, self._device, self._mode)
         st = self._device_state
         if st is None or st["hp"] is not hp:
             st = self._device_state = dict(hp=hp, noise=DeviceNoiseSampler(hp, self._channel_sampler), bufs=None)
@@ -255,7 +257,7 @@ class _CompiledSamplerBase:
         """Post-selection with everything on the GPU: ``k_noise`` -> ``k_direct_filter`` (direct bits
         for all rows + survivor list) -> the sampling kernel on the survivors only.  Same return
         contract as the host path: ``(result, reference, was_discarded)``."""
-        hp = get_hip_program(self._program, self._device)
+        hp = get_hip_program(self._program, self._device, self._mode)
         st = self._device_state
         if st is None or st["hp"] is not hp:
             st = self._device_state = dict(hp=hp, noise=DeviceNoiseSampler(hp, self._channel_sampler), bufs=None)
@@ -454,7 +456,7 @@ def _call_sample_program(sampler: _CompiledSamplerBase, f_params: np.ndarray, su
     """Late-bound call of this module's ``sample_program`` (so tests can replace it)."""
     fn = globals()["sample_program"]
     if fn is _backend_sample_program:
-        return fn(sampler._program, f_params, subkey, device=sampler._device)
+        return fn(sampler._program, f_params, subkey, device=sampler._device, mode=sampler._mode)
     return fn(sampler._program, f_params, subkey)  # a replacement with the reference's 3-arg signature
 
 
@@ -555,7 +557,7 @@ class CompiledStateProbs(_CompiledSamplerBase):
             direct_bits = f_samples[:, self._direct_f_indices].astype(np.bool_) ^ self._direct_flips
             targets = state[np.asarray(self._program.output_order[:n_direct])].astype(np.bool_)
             p_joint = p_joint * (direct_bits == targets).all(axis=1).astype(np.float32)
-        hp = get_hip_program(self._program, self._device)
+        hp = get_hip_program(self._program, self._device, self._mode)
         for ci, comp in enumerate(self._program.components):
             assert len(comp.compiled_scalar_graphs) == 2
             f_sel = f_samples[:, np.asarray(comp.f_selection, dtype=np.int64)]

@@ -1,0 +1,23 @@
+import sys; sys.path.insert(0, "."); sys.path.insert(0, "tests")
+import numpy as np, warnings
+warnings.simplefilter("ignore")
+from tsim_amd import backend as hip, synth
+from oracle import oracle_c as OC
+from test_gpu_fuzz import random_program
+bad = skipped = 0
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+for seed in range(n):
+    rng = np.random.default_rng(5000 + seed)
+    prog, num_f = random_program(rng)
+    B = int(rng.choice([1, 64, 65, 257, 1000]))
+    f = synth.synth_f(B, num_f, float(rng.choice([0.0, 0.02, 0.3])), seed=seed)
+    key = (int(rng.integers(0, 2**32)), int(rng.integers(0, 2**32)))
+    want, wdev, ov = OC.OracleProgram(prog).sample_program(f, key, return_devs=True, return_overflow=True)
+    if ov:
+        skipped += 1; continue
+    for mode in ("auto", "rows", "faithful"):
+        hp = hip.HipProgram(prog, mode=mode)
+        got, gdev = hp.sample_batch(f, key)
+        if not (np.array_equal(got, want) and np.array_equal(np.asarray(gdev, np.float32), np.asarray(wdev, np.float32), equal_nan=True)):
+            bad += 1; print("MISMATCH seed", seed, mode, hp.info())
+print("done", n, "programs; mismatches", bad, "skipped(overflow)", skipped)

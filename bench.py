@@ -166,6 +166,7 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--shots", type=int, default=1_000_000, help="shots per step per GPU")
     ap.add_argument("--config", default="C2")
+    ap.add_argument("--p-bit", type=float, default=None, help="override the per-bit fire probability of the synthetic f batch (experiments only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
@@ -192,6 +193,8 @@ def main() -> None:
     from tsim_amd import backend, prng, synth
 
     program, cfg = synth.config_program(args.config)
+    if args.p_bit is not None:
+        cfg = dict(cfg, p_bit=float(args.p_bit))
     hp = backend.HipProgram(program, device=local_rank)
     info = hp.info()
     num_f, n_out = cfg["num_f"], program.num_outputs

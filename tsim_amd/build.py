@@ -41,7 +41,8 @@ def build(force: bool = False, verbose: bool = True) -> Path:
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found; cannot build libtsim_hip.so")
     tmp = OUT.with_suffix(".so.tmp")
-    cmd = [hipcc, *FLAGS, str(SRC), "-o", str(tmp)]
+    extra = os.environ.get("TSIM_AMD_EXTRA_FLAGS", "").split()
+    cmd = [hipcc, *FLAGS, *extra, str(SRC), "-o", str(tmp)]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)

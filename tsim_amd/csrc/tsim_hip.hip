@@ -112,6 +112,7 @@ struct tsim_program {
   int v4_gt = 4;              // graphs per LDS tile
   int comp4_off = 0;
   int v4_max_nch = 1;
+  int v4_max_sent = 0;        // entries per tile of the sparse-f tables (0: none)
   long long total_graphs = 0, total_rows = 0;
   long long stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // see tsim_program_stats
   int max_f_index = -1;
@@ -814,14 +815,20 @@ static inline bool mask_bit(const std::vector<uint64_t> &m, int i) { return (m[(
 
 // recs4: G x G4_WORDS; tabs4: ntiles x nch x 16 x GT x 4 words.  `v3recs` are the level's patched
 // fast-layout graph records (for the term-table offsets and the approximate floatfactors).
+// `stabs4` (optional, sparse_F >= 0): the "sparse f" table of the same tile: one entry per f COLUMN
+// (bits 0..F-1), one all-zero entry, then 2 x 16 entries for the two 4-bit chunks of the output
+// bits F..F+7 (row constants live in the first of them): [tile][entry][graph][4 words].
 static void emit_level4(const HostLevel &h, int GT, int nch, const uint32_t *v3recs, std::vector<uint32_t> &recs4,
-                        std::vector<uint32_t> &tabs4, int &nch_out, int &ntiles_out) {
+                        std::vector<uint32_t> &tabs4, int &nch_out, int &ntiles_out, int sparse_F,
+                        std::vector<uint32_t> &stabs4) {
   const int G = h.G, P = h.P;
   const int ntiles = (G + GT - 1) / GT;  // nch: chunks per tile, the same for every level (zero padded)
   nch_out = nch;
   ntiles_out = ntiles;
   recs4.assign((size_t)G * G4_WORDS, 0u);
   tabs4.assign((size_t)ntiles * nch * 16 * GT * 4, 0u);
+  const int sent = sparse_F >= 0 ? sparse_F + 1 + 32 : 0;
+  stabs4.assign((size_t)ntiles * sent * GT * 4, 0u);
   std::vector<std::array<uint32_t, 4>> col((size_t)std::max(P, 1));
   for (int g = 0; g < G; ++g) {
     const FastGraph &fg = h.fg[(size_t)g];
@@ -859,6 +866,23 @@ static void emit_level4(const HostLevel &h, int GT, int nch, const uint32_t *v3r
         uint32_t *dst = &tabs4[((((size_t)tile * nch + c) * 16 + v) * GT + j) * 4];
         for (int w = 0; w < 4; ++w) dst[w] = val[(size_t)w];
       }
+    if (sent) {
+      auto put = [&](int e, const std::array<uint32_t, 4> &val) {
+        uint32_t *dst = &stabs4[(((size_t)tile * sent + e) * GT + j) * 4];
+        for (int w = 0; w < 4; ++w) dst[w] = val[(size_t)w];
+      };
+      for (int i = 0; i < sparse_F && i < P; ++i) put(i, col[(size_t)i]);
+      for (int c = 0; c < 2; ++c)
+        for (int v = 0; v < 16; ++v) {
+          std::array<uint32_t, 4> val = (c == 0) ? cst : std::array<uint32_t, 4>{0u, 0u, 0u, 0u};
+          for (int bb = 0; bb < 4; ++bb) {
+            const int i = sparse_F + 4 * c + bb;
+            if (!((v >> bb) & 1) || i >= P) continue;
+            for (int w = 0; w < 4; ++w) val[(size_t)w] ^= col[(size_t)i][(size_t)w];
+          }
+          put(sparse_F + 1 + 16 * c + v, val);
+        }
+    }
     uint32_t *r4 = &recs4[(size_t)g * G4_WORDS];
     const uint32_t *r3 = v3recs + (size_t)g * G_WORDS;
     r4[G4_M0] = M0; r4[G4_M1] = M1; r4[G4_M3] = M3;
@@ -1024,6 +1048,7 @@ retry_pack:
       while (img.size() % 16) img.push_back(0u);
       p->comp4_off = (int)img.size();
       img.resize(img.size() + p->comps.size() * C4_WORDS, 0u);
+      p->v4_max_sent = 0;
       int maxp = 1;
       for (auto &c : p->comps)
         for (auto &lv : c.levels) maxp = std::max(maxp, lv.P);
@@ -1042,17 +1067,24 @@ retry_pack:
           HostLevel &h = c.levels[k];
           const uint32_t v3lvl = (uint32_t)p->level_off[p->level_base[ci] + k];
           const uint32_t v3recs = img[v3lvl + L_GRAPHS];
-          std::vector<uint32_t> recs4, tabs4;
+          std::vector<uint32_t> recs4, tabs4, stabs4;
           int nch = 1, ntiles = 0;
+          const bool sequential = (c.n_levels == c.n_out + 1);
+          const int sparse_F = (sequential && c.n_out <= 8 && c.F + c.n_out <= 64) ? c.F : -1;
           std::vector<uint32_t> v3copy(img.begin() + v3recs, img.begin() + v3recs + (size_t)h.G * G_WORDS);
-          emit_level4(h, p->v4_gt, p->v4_max_nch, v3copy.data(), recs4, tabs4, nch, ntiles);
+          emit_level4(h, p->v4_gt, p->v4_max_nch, v3copy.data(), recs4, tabs4, nch, ntiles, sparse_F, stabs4);
           while (img.size() % 16) img.push_back(0u);
           const uint32_t roff = (uint32_t)img.size();
           img.insert(img.end(), recs4.begin(), recs4.end());
           while (img.size() % 16) img.push_back(0u);
           const uint32_t toff = (uint32_t)img.size();
           img.insert(img.end(), tabs4.begin(), tabs4.end());
+          while (img.size() % 16) img.push_back(0u);
+          const uint32_t stoff = stabs4.empty() ? 0u : (uint32_t)img.size();
+          img.insert(img.end(), stabs4.begin(), stabs4.end());
+          p->v4_max_sent = std::max(p->v4_max_sent, sparse_F >= 0 ? sparse_F + 33 : 0);
           uint32_t *lr = &img[l4 + (size_t)k * L4_WORDS];
+          lr[L4_STAB] = stoff;
           lr[L4_G] = (uint32_t)h.G;
           lr[L4_NTILES] = (uint32_t)ntiles;
           lr[L4_TABLES] = toff;
@@ -1221,7 +1253,7 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
     a4.has_check = (shot_offset == 0 || d_row_index) ? 1 : 0;
     const char *benv = getenv("TSIM_AMD_V4_BLOCK");
     const int blk = (benv && atoi(benv) == 512) ? 512 : ((benv && atoi(benv) == 128) ? 128 : 256);
-    const size_t tile_bytes = (size_t)p->v4_max_nch * 16 * p->v4_gt * 16;
+    const size_t tile_bytes = std::max((size_t)p->v4_max_nch * 16, (size_t)p->v4_max_sent) * p->v4_gt * 16;
     const size_t lds4 = (size_t)(2 * a.WF + 2 * a.WO) * blk * 4 + 2 * tile_bytes;
     if (lds4 > 64 * 1024) return fail(TSIM_ENOTSUP, "v4 kernel needs %zu B of LDS", lds4);
     const long long grid4 = (B + blk - 1) / blk + a4.has_check;

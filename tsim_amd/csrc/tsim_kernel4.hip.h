@@ -23,7 +23,7 @@
 namespace tsimk {
 
 // level record of the v4 layout
-enum { L4_G = 0, L4_NTILES, L4_TABLES, L4_RECS, L4_NCH, L4_FLAGS, L4_FRAME, L4_WORDS = 8 };
+enum { L4_G = 0, L4_NTILES, L4_TABLES, L4_RECS, L4_NCH, L4_FLAGS, L4_FRAME, L4_STAB, L4_WORDS = 8 };
 // graph record of the v4 layout
 enum {
   G4_M0 = 0, G4_M1, G4_M3, G4_PM, G4_N1, G4_DBITS /* 2*nD */, G4_TBL, G4_TBL2, G4_FLAGS,
@@ -33,6 +33,10 @@ enum {
 #define TSIMK_G4FLAG_D_SEPARATE 2u
 // component record extension (words appended to the C_* record)
 enum { C4_LEVELS = 8, C4_WORDS = 16 };
+
+#ifndef TSIMK_V4_WAVES
+#define TSIMK_V4_WAVES 6  // register budget: at least this many waves per SIMD (<= 80 VGPRs)
+#endif
 
 struct Sample4Args {
   SampleArgs s;
@@ -62,29 +66,27 @@ struct Tile4 {
 };
 
 // evaluate() of one level with LDS chunk tables.  All threads of the block must call this together.
-template <int GT, int NCH>
-__device__ __forceinline__ void eval_level4(const uint32_t *gimg, cptr img, cptr lvl, uint32_t x0, uint32_t x1,
+// NR = LDS reads per graph: the caller passes this lane's NR entry offsets inside a tile table
+// (`ent0`, bytes from the start of the tile), the tile size and the table's offset in the image.
+template <int GT, int NR, bool FIXED>
+__device__ __forceinline__ void eval_level4(const uint32_t *gimg, cptr img, cptr lvl, const uint32_t (&ent0)[NR],
+                                            uint32_t tile_bytes, uint32_t table_off,
                                             uint8_t *lds_tab /* 2 * tile bytes */, float &out_re, float &out_im) {
   const uint32_t G = lvl[L4_G], ntiles = lvl[L4_NTILES];
-  constexpr uint32_t nch = NCH;  // chunks per tile: compile-time, so the reads below are branch-free
   const uint32_t lflags = lvl[L4_FLAGS];
-  const bool approx = (lflags & TSIMK_LFLAG_APPROX) != 0, fixed = (lflags & TSIMK_LFLAG_FIXED) != 0;
-  const uint32_t tile_bytes = nch * Tile4<GT>::kChunkBytes;
+  const bool approx = (lflags & TSIMK_LFLAG_APPROX) != 0;
+  constexpr bool fixed = FIXED;  // (lflags & TSIMK_LFLAG_FIXED), resolved by the caller
   const uint32_t tile_vec = tile_bytes >> 4;  // uint4 elements per tile
-  const uint4 *gtab = reinterpret_cast<const uint4 *>(gimg + lvl[L4_TABLES]);
+  const uint4 *gtab = reinterpret_cast<const uint4 *>(gimg + table_off);
   cptr recs = img + lvl[L4_RECS];
   const int tid = threadIdx.x, nthr = blockDim.x;
 
-  // this lane's table entry per chunk (LDS address in buffer 0): chunk base + chunk value * (GT*16)
   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
   typedef const __attribute__((address_space(3))) u32x4 *lds_u4p;  // 32-bit LDS addresses
   const uint32_t tab0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)lds_tab;
-  uint32_t ent[NCH];
+  uint32_t ent[NR];
 #pragma unroll
-  for (int c = 0; c < NCH; ++c) {
-    const uint32_t w = (c < 8) ? x0 : x1;
-    ent[c] = tab0 + ((w >> (4 * (c & 7))) & 15u) * (GT * 16) + c * Tile4<GT>::kChunkBytes;
-  }
+  for (int c = 0; c < NR; ++c) ent[c] = tab0 + ent0[c];
   int delta = (int)tile_bytes;  // +tile_bytes / -tile_bytes: toggles ent[] between the two buffers
 
   int sa = 0, sb = 0, sc = 0, sd = 0, sp = TSIMK_ZERO_POWER;
@@ -94,6 +96,11 @@ __device__ __forceinline__ void eval_level4(const uint32_t *gimg, cptr img, cptr
   __syncthreads();  // previous users of the buffers are done
   if (ntiles) tile_copy(gtab, lds_tab, tile_vec, tid, nthr);
   __syncthreads();
+
+  // Fixed-frame levels: the table gather of graph g is consumed while graph g+1 is being formed
+  // (software pipelining of the VMEM latency); `pend_*` hold the in-flight entry.
+  uint4 pend_tv = {0u, 0u, 0u, 0u}, pend_dv = {1u, 0u, 0u, 0u};
+  bool pend_sep = false;
 
   for (uint32_t t = 0; t < ntiles; ++t) {
     // prefetch tile t+1 straight into the other LDS buffer: its last readers passed the barrier
@@ -106,9 +113,9 @@ __device__ __forceinline__ void eval_level4(const uint32_t *gimg, cptr img, cptr
       if (g >= G) break;
       // ---- Y_g = XOR over chunks of the lane's table entries (3-input XORs: v_bitop3 0x96) ----
       uint32_t U = 0, V = 0, O1 = 0, O2 = 0;
-      static_assert(NCH % 2 == 0, "chunks are consumed in pairs");
+      static_assert(NR % 2 == 0, "entries are consumed in pairs");
 #pragma unroll
-      for (int c = 0; c < NCH; c += 2) {
+      for (int c = 0; c < NR; c += 2) {
         const u32x4 v = *(lds_u4p)(uintptr_t)(ent[c] + j * 16);
         const u32x4 w = *(lds_u4p)(uintptr_t)(ent[c + 1] + j * 16);
         U = xor3(U, v.x, w.x); V = xor3(V, v.y, w.y); O1 = xor3(O1, v.z, w.z); O2 = xor3(O2, v.w, w.w);
@@ -130,6 +137,19 @@ __device__ __forceinline__ void eval_level4(const uint32_t *gimg, cptr img, cptr
       // fixed-frame levels: 4 pre-rotated copies per entry (value * i^r), 16 words per entry
       const uint32_t *te = gimg + gr[G4_TBL] + (fixed ? (16u * idx + 4u * r) : 8u * idx);
       const uint4 tv = *reinterpret_cast<const uint4 *>(te);
+      if constexpr (fixed) {
+        uint4 dv = {1u, 0u, 0u, 0u};
+        const bool sep = (gflags & TSIMK_G4FLAG_D_SEPARATE) != 0;
+        if (sep) dv = *reinterpret_cast<const uint4 *>(gimg + gr[G4_TBL2] + 8u * dbits);
+        // retire the previous graph's entry (zero-initialised before the first graph)
+        {
+          int a = (int)pend_tv.x, b = (int)pend_tv.y, c = (int)pend_tv.z, d = (int)pend_tv.w;
+          if (pend_sep) zmul(a, b, c, d, (int)pend_dv.x, (int)pend_dv.y, (int)pend_dv.z, (int)pend_dv.w);
+          sa += a; sb += b; sc += c; sd += d;
+        }
+        pend_tv = tv; pend_dv = dv; pend_sep = sep;
+        continue;
+      }
       int a = (int)tv.x, b = (int)tv.y, c = (int)tv.z, d = (int)tv.w, p = 0;
       if (!fixed) p = (int)te[4];
       if (gflags & TSIMK_G4FLAG_D_SEPARATE) {
@@ -167,10 +187,16 @@ __device__ __forceinline__ void eval_level4(const uint32_t *gimg, cptr img, cptr
     }
     if (more) {
 #pragma unroll
-      for (int c = 0; c < NCH; ++c) ent[c] += (uint32_t)delta;
+      for (int c = 0; c < NR; ++c) ent[c] += (uint32_t)delta;
       delta = -delta;
     }
     __syncthreads();
+  }
+
+  if constexpr (fixed) {  // retire the last in-flight entry
+    int a = (int)pend_tv.x, b = (int)pend_tv.y, c = (int)pend_tv.z, d = (int)pend_tv.w;
+    if (pend_sep) zmul(a, b, c, d, (int)pend_dv.x, (int)pend_dv.y, (int)pend_dv.z, (int)pend_dv.w);
+    sa += a; sb += b; sc += c; sd += d;
   }
 
   if (!approx) {
@@ -187,7 +213,8 @@ __device__ __forceinline__ void eval_level4(const uint32_t *gimg, cptr img, cptr
 // sample_program for one batch, LDS chunk-table formulation.  Requires every sampled component to
 // have at most 64 parameters (2 words of x) - checked by the packer (p->v4).
 template <int GT, int NCH>
-__global__ void __launch_bounds__(512) k_sample4(Sample4Args A4) {
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(TSIMK_V4_WAVES, 8)))
+k_sample4(Sample4Args A4) {
   const SampleArgs &A = A4.s;
   const int nthr = blockDim.x;
   const bool check_block = A4.has_check && (blockIdx.x == gridDim.x - 1);
@@ -253,25 +280,62 @@ __global__ void __launch_bounds__(512) k_sample4(Sample4Args A4) {
       x[w] = v;
     }
 
-    float re, im;
-    eval_level4<GT, NCH>(A.img, img, levels, x[0], x[1], lds_tab, re, im);
-    float prev = cabs32(re, im);
-    float maxdev = 0.0f;
-
-    for (uint32_t i = 0; i < n_out; ++i) {
-      cptr lvl = levels + (i + 1) * L4_WORDS;
-      const uint32_t bitpos = F + i;
-      const uint32_t bm = 1u << (bitpos & 31u);
-      const bool hiw = bitpos >= 32u;
-      if (hiw) x[1] |= bm; else x[0] |= bm;  // trial bit = 1 (sampler.py:65)
-      eval_level4<GT, NCH>(A.img, img, lvl, x[0], x[1], lds_tab, re, im);
-      const float p1 = cabs32(re, im);
-      if (check_block) {  // uniform branch: the whole block takes it together
-        if (hiw) x[1] &= ~bm; else x[0] &= ~bm;
-        eval_level4<GT, NCH>(A.img, img, lvl, x[0], x[1], lds_tab, re, im);
-        const float p0 = cabs32(re, im);
-        const float norm = __fdiv_rn(__fadd_rn(p0, p1), prev);        // sampler.py:71
-        maxdev = nanmax(maxdev, fabsf(__fsub_rn(norm, 1.0f)));       // sampler.py:72
+    // Sparse-f decision, block-uniform: every lane has at most 4 set f bits and the component has
+    // at most 8 outputs (the packer then emitted the column tables, L4_STAB != 0).
+    const unsigned long long xf = ((unsigned long long)x[1] << 32) | x[0];
+    const bool sparse = (n_out <= 8u) && (levels[L4_STAB] != 0u) && (__syncthreads_and(__popcll(xf) <= 4) != 0);
+    uint32_t col_off[4];
+    {
+      unsigned long long rem = xf;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const uint32_t pos = rem ? (uint32_t)__builtin_ctzll(rem) : F;  // F = the all-zero column
+        rem &= rem - 1ull;
+        col_off[k] = pos * (GT * 16);
+      }
+    }
+    float prev = 0.0f, maxdev = 0.0f;
+    // level 0 is the normalisation (sampler.py:54); level li > 0 evaluates output li-1 with trial
+    // bit 1 (sampler.py:65) and - in the check block only - once more with trial bit 0 (sampler.py:66)
+    for (uint32_t li = 0; li <= n_out; ++li) {
+      cptr lvl = levels + li * L4_WORDS;
+      const uint32_t bitpos = F + li - 1u;
+      const uint32_t bm = (li > 0) ? (1u << (bitpos & 31u)) : 0u;
+      const bool hiw = (li > 0) && bitpos >= 32u;
+      const bool lvl_fixed = (lvl[L4_FLAGS] & TSIMK_LFLAG_FIXED) != 0;
+      const int npass = (li > 0 && check_block) ? 2 : 1;  // block-uniform
+      float val[2] = {0.0f, 0.0f};
+      for (int pass = 0; pass < npass; ++pass) {
+        if (pass == 0) { if (hiw) x[1] |= bm; else x[0] |= bm; }
+        else { if (hiw) x[1] &= ~bm; else x[0] &= ~bm; }
+        float re, im;
+        if (sparse && lvl_fixed) {
+          // sparse-f tables: <= 4 set f bits in every lane of the block -> 4 column reads + the two
+          // 4-bit chunks of the output bits, instead of one read per 4-bit chunk of all of x
+          const unsigned long long xx = ((unsigned long long)x[1] << 32) | x[0];
+          const uint32_t mb = (uint32_t)(xx >> F);
+          const uint32_t e6[6] = {col_off[0], col_off[1], col_off[2], col_off[3],
+                                  (F + 1u + (mb & 15u)) * (GT * 16), (F + 17u + ((mb >> 4) & 15u)) * (GT * 16)};
+          eval_level4<GT, 6, true>(A.img, img, lvl, e6, (F + 33u) * (GT * 16), lvl[L4_STAB], lds_tab, re, im);
+        } else {
+          uint32_t en[NCH];
+#pragma unroll
+          for (int c = 0; c < NCH; ++c) {
+            const uint32_t w = (c < 8) ? x[0] : x[1];
+            en[c] = ((w >> (4 * (c & 7))) & 15u) * (GT * 16) + c * Tile4<GT>::kChunkBytes;
+          }
+          if (lvl_fixed) eval_level4<GT, NCH, true>(A.img, img, lvl, en, NCH * Tile4<GT>::kChunkBytes, lvl[L4_TABLES], lds_tab, re, im);
+          else eval_level4<GT, NCH, false>(A.img, img, lvl, en, NCH * Tile4<GT>::kChunkBytes, lvl[L4_TABLES], lds_tab, re, im);
+        }
+        const float v = cabs32(re, im);
+        if (pass == 0) val[0] = v; else val[1] = v;
+      }
+      if (li == 0) { prev = val[0]; continue; }
+      const uint32_t i = li - 1u;
+      const float p1 = val[0];
+      if (check_block) {
+        const float norm = __fdiv_rn(__fadd_rn(val[1], p1), prev);   // sampler.py:71
+        maxdev = nanmax(maxdev, fabsf(__fsub_rn(norm, 1.0f)));      // sampler.py:72
       }
       const float u = uniform01(keys[2 * i], keys[2 * i + 1], shot);
       const bool bit = u < __fdiv_rn(p1, prev);

@@ -36,7 +36,7 @@ enum {
 enum { C4_LEVELS = 8, C4_WORDS = 16 };
 
 #ifndef TSIMK_V4_WAVES
-#define TSIMK_V4_WAVES 6  // register budget: at least this many waves per SIMD (<= 80 VGPRs)
+#define TSIMK_V4_WAVES 1  // no forced register budget (forcing 6 waves/SIMD spills ~100 B/lane to scratch)
 #endif
 
 struct Sample4Args {
@@ -120,6 +120,9 @@ __device__ __forceinline__ void eval_level4(const uint32_t *gimg, cptr img, cptr
         const u32x4 v = *(lds_u4p)(uintptr_t)(ent[c] + j * 16);
         const u32x4 w = *(lds_u4p)(uintptr_t)(ent[c + 1] + j * 16);
         U = xor3(U, v.x, w.x); V = xor3(V, v.y, w.y); O1 = xor3(O1, v.z, w.z); O2 = xor3(O2, v.w, w.w);
+        // at most six 16-byte reads in flight: more only costs VGPRs (24 per six) without hiding
+        // any more LDS latency
+        if (c % 6 == 4 && c + 2 < NR) __builtin_amdgcn_sched_barrier(0);
       }
       cptr gr = recs + g * G4_WORDS;
       const uint32_t gflags = gr[G4_FLAGS];
@@ -285,16 +288,6 @@ k_sample4(Sample4Args A4) {
     // at most 8 outputs (the packer then emitted the column tables, L4_STAB != 0).
     const unsigned long long xf = ((unsigned long long)x[1] << 32) | x[0];
     const bool sparse = (n_out <= 8u) && (levels[L4_STAB] != 0u) && (__syncthreads_and(__popcll(xf) <= 4) != 0);
-    uint32_t col_off[4];
-    {
-      unsigned long long rem = xf;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const uint32_t pos = rem ? (uint32_t)__builtin_ctzll(rem) : F;  // F = the all-zero column
-        rem &= rem - 1ull;
-        col_off[k] = pos * (GT * 16);
-      }
-    }
     float prev = 0.0f, maxdev = 0.0f;
     // level 0 is the normalisation (sampler.py:54); level li > 0 evaluates output li-1 with trial
     // bit 1 (sampler.py:65) and - in the check block only - once more with trial bit 0 (sampler.py:66)
@@ -315,6 +308,18 @@ k_sample4(Sample4Args A4) {
           // 4-bit chunks of the output bits, instead of one read per 4-bit chunk of all of x
           const unsigned long long xx = ((unsigned long long)x[1] << 32) | x[0];
           const uint32_t mb = (uint32_t)(xx >> F);
+          // the (at most four) set f bits -> column entries; F = the all-zero column.  Recomputed per
+          // level (a dozen VALU ops) rather than kept live across the component.
+          uint32_t col_off[4];
+          {
+            unsigned long long rem = F >= 64u ? xx : (xx & ((1ull << F) - 1ull));
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const uint32_t pos = rem ? (uint32_t)__builtin_ctzll(rem) : F;
+              rem &= rem - 1ull;
+              col_off[k] = pos * (GT * 16);
+            }
+          }
           const uint32_t e6[6] = {col_off[0], col_off[1], col_off[2], col_off[3],
                                   (F + 1u + (mb & 15u)) * (GT * 16), (F + 17u + ((mb >> 4) & 15u)) * (GT * 16)};
           eval_level4<GT, 6, true>(A.img, img, lvl, e6, (F + 33u) * (GT * 16), lvl[L4_STAB], lds_tab, re, im);

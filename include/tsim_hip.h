@@ -117,6 +117,23 @@ int tsim_program_set_mode(tsim_program *p, int32_t mode);
 /* after finalize: *fast = 1 if the exact-value formulation was selected */
 int tsim_program_get_mode(const tsim_program *p, int32_t *fast);
 
+/*
+ * Low-weight error-pattern tables (before finalize).  The Bernoulli thresholds p1/prev of
+ * _sample_component (sampler.py:54-79) depend on a shot only through the component's selected
+ * f bits and the outcome prefix; for f_sel patterns of weight <= max_weight (0..3, as many as fit a
+ * 2 MiB table per component) they are tabulated at finalize by the sampling kernels' own
+ * arithmetic, and shots carrying such patterns in every component are finished by a light first
+ * pass (one Threefry draw + one table read per output); only the remaining rows run the full
+ * kernel.  Bit-identical results.  Requires <= 10 outputs and <= 64 parameters per component.
+ *   enable: 1 on, 0 off, -1 default (on in TSIM_MODE_AUTO);  max_weight: 0..3, -1 = 3.
+ * The environment variable TSIM_AMD_PATTERN_TABLES=0/1 overrides `enable`.
+ */
+int tsim_program_set_pattern_tables(tsim_program *p, int32_t enable, int32_t max_weight);
+/* after finalize: *enabled, table bytes, and max tabulated weight per component ([n_components],
+ * may be NULL) */
+int tsim_program_pattern_table_info(const tsim_program *p, int32_t *enabled, int64_t *table_bytes,
+                                    int32_t *max_weight);
+
 /* Packs all levels into the device image and uploads it to HIP device `device`. */
 int tsim_program_finalize(tsim_program *p, int32_t device);
 

@@ -1,0 +1,129 @@
+"""Low-weight error-pattern tables (tsim_lw.hip.h): the two-pass launch must give exactly the bits
+and the normalisation deviation of the full kernel and of the oracle, for every table depth."""
+
+import numpy as np
+import pytest
+
+from oracle import oracle_c as OC
+from tsim_amd import prng, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle(prog, f, key):
+    want, wdev, ov = OC.OracleProgram(prog).sample_program(f, key, return_devs=True, return_overflow=True)
+    assert not ov
+    return want, np.asarray(wdev, np.float32)
+
+
+def test_tables_selected_for_c2(hip):
+    prog, _ = synth.config_program("C2")
+    info = hip.HipProgram(prog).info()
+    assert info["pattern_tables"] and info["pattern_max_weight"] == [3]
+    assert 0 < info["pattern_table_bytes"] <= 2 << 20
+    assert not hip.HipProgram(prog, pattern_tables=False).info()["pattern_tables"]
+    assert not hip.HipProgram(prog, mode="faithful").info()["pattern_tables"]  # default: auto mode only
+    assert hip.HipProgram(prog, mode="faithful", pattern_tables=True).info()["pattern_tables"]
+    assert hip.HipProgram(prog, pattern_tables=1).info()["pattern_max_weight"] == [1]
+
+
+@pytest.mark.parametrize("p_bit", [0.0, 0.01, 0.05, 0.2])
+@pytest.mark.parametrize("cap", [0, 1, 2, 3])
+def test_c2_every_depth_matches_oracle(hip, p_bit, cap):
+    prog, cfg = synth.config_program("C2")
+    B = 3000
+    f = synth.synth_f(B, cfg["num_f"], p_bit, seed=7 + cap)
+    key = prng.key(1234)
+    want, wdev = _oracle(prog, f, key)
+    hp = hip.HipProgram(prog, pattern_tables=cap)
+    got, gdev = hp.sample_batch(f, key)
+    np.testing.assert_array_equal(got, want)
+    np.testing.assert_array_equal(np.asarray(gdev, np.float32), wdev)
+
+
+@pytest.mark.parametrize("mode", ["auto", "rows", "faithful"])
+def test_tables_with_every_full_kernel(hip, mode):
+    prog, cfg = synth.config_program("C2")
+    f = synth.synth_f(2000, cfg["num_f"], 0.06, seed=3)
+    key = prng.key(99)
+    want, wdev = _oracle(prog, f, key)
+    on = hip.HipProgram(prog, mode=mode, pattern_tables=True)
+    off = hip.HipProgram(prog, mode=mode, pattern_tables=False)
+    a, da = on.sample_batch(f, key)
+    b, db = off.sample_batch(f, key)
+    np.testing.assert_array_equal(a, want)
+    np.testing.assert_array_equal(b, want)
+    np.testing.assert_array_equal(np.asarray(da, np.float32), wdev)
+    np.testing.assert_array_equal(np.asarray(db, np.float32), wdev)
+
+
+def test_multi_component_and_shards(hip):
+    prog, cfg = synth.config_program("C4")
+    B = 1500
+    f = synth.synth_f(B, cfg["num_f"], 0.03, seed=11)
+    key = prng.key(5)
+    want, wdev = _oracle(prog, f, key)
+    hp = hip.HipProgram(prog)
+    assert hp.info()["pattern_tables"]
+    got, gdev = hp.sample_batch(f, key)
+    np.testing.assert_array_equal(got, want)
+    np.testing.assert_array_equal(np.asarray(gdev, np.float32), wdev)
+    # any split of the batch with shot_offset reproduces the unsplit bits (no check row for offset > 0)
+    parts = [hp.sample_batch(f[a:b], key, shot_offset=a)[0] for a, b in [(0, 1), (1, 700), (700, 1500)]]
+    np.testing.assert_array_equal(np.concatenate(parts), want)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_fuzz_tables_vs_oracle(hip, seed):
+    rng = np.random.default_rng(5000 + seed)
+    num_f = int(rng.integers(1, 90))
+    comps = []
+    for _ in range(int(rng.integers(1, 4))):
+        n = int(rng.integers(0, 7))
+        F = int(rng.integers(0, min(num_f, 50) + 1))
+        comps.append(dict(n=n, F=F, G=[int(rng.integers(0, 6)) for _ in range(n + 1)],
+                          ta=(0, 6), tb=(0, 6), tc=(0, 6), td=(0, 3), density=0.3,
+                          approx=bool(seed % 3 == 0)))
+    prog = synth.synth_program(num_f=num_f, n_direct=int(rng.integers(0, num_f + 1)), components=comps,
+                               seed=int(rng.integers(0, 2**31)), shuffle_outputs=True,
+                               direct_flip_fraction=0.3, identity_direct=False)
+    B = int(rng.choice([1, 64, 65, 300, 1000]))
+    f = synth.synth_f(B, num_f, float(rng.choice([0.0, 0.02, 0.08])), seed=seed)
+    key = (int(rng.integers(0, 2**32)), int(rng.integers(0, 2**32)))
+    want, wdev, ov = OC.OracleProgram(prog).sample_program(f, key, return_devs=True, return_overflow=True)
+    if ov:
+        pytest.skip("the reference's int32 arithmetic would wrap on this input")
+    for cap in (3, 1):
+        hp = hip.HipProgram(prog, pattern_tables=cap)
+        assert hp.info()["pattern_tables"]
+        got, gdev = hp.sample_batch(f, key)
+        np.testing.assert_array_equal(got, want, err_msg=f"cap={cap}")
+        np.testing.assert_array_equal(np.asarray(gdev, np.float32), np.asarray(wdev, np.float32))
+
+
+def test_postselection_list_feeds_pass_one(hip):
+    """Survivor list -> pass 1 -> hard list -> full kernel: same bits as the unfiltered launch on the
+    surviving rows."""
+    from tsim_amd.sampler import CompiledDetectorSampler
+
+    prog, cfg = synth.config_program("C2")
+    nf = cfg["num_f"]
+    probs = [np.array([0.97, 0.03]) for _ in range(nf)]
+    et = np.eye(nf, dtype=np.uint8)
+    mask = np.zeros(prog.num_detectors, dtype=bool)
+    mask[:3] = True
+    outs = []
+    for pt in (None, False):
+        import os
+
+        if pt is False:
+            os.environ["TSIM_AMD_PATTERN_TABLES"] = "0"
+        try:
+            prog2, _ = synth.config_program("C2")  # fresh object: no cached handle
+            s = CompiledDetectorSampler(prog2, channel_probs=probs, error_transform=et, seed=3, noise="device")
+            outs.append(s.sample(20000, batch_size=8192, postselection_mask=mask, append_observables=True))
+        finally:
+            os.environ.pop("TSIM_AMD_PATTERN_TABLES", None)
+    a, b = outs
+    np.testing.assert_array_equal(a, b)
+    assert a[:, prog.num_detectors:].any()

@@ -108,11 +108,14 @@ class DeviceBuffer:
 class HipProgram:
     """A compiled program uploaded to one MI355X (handle over ``tsim_program*``)."""
 
-    def __init__(self, program, device: int = 0, mode: str = "auto"):
+    def __init__(self, program, device: int = 0, mode: str = "auto", pattern_tables=None):
         """``mode``: "auto" (exact-value fast formulation when every graph qualifies) or
         "faithful" (operation-by-operation int32 mirror of the reference) or "rows" (exact-value
         formulation on the row-by-row kernel instead of the LDS chunk-table kernel); see
-        include/tsim_hip.h."""
+        include/tsim_hip.h.
+
+        ``pattern_tables``: None = default (low-weight error-pattern tables on in "auto" mode),
+        False = off, True = on, or an int 0..3 = on with that maximum tabulated weight."""
         if mode not in ("auto", "faithful", "rows"):
             raise ValueError("mode must be 'auto', 'faithful' or 'rows'")
         self._lib = _lib.load()
@@ -151,6 +154,12 @@ class HipProgram:
                     desc = _level_desc(lv, keep)
                     _lib.check(lib.tsim_program_add_level(h, ci, C.byref(desc)), "tsim_program_add_level")
             _lib.check(lib.tsim_program_set_mode(h, {"auto": 0, "faithful": 1, "rows": 2}[mode]), "tsim_program_set_mode")
+            if pattern_tables is not None:
+                if isinstance(pattern_tables, bool):
+                    en, cap = (1 if pattern_tables else 0), -1
+                else:
+                    en, cap = 1, int(pattern_tables)
+                _lib.check(lib.tsim_program_set_pattern_tables(h, en, cap), "tsim_program_set_pattern_tables")
             _lib.check(lib.tsim_program_finalize(h, self.device), "tsim_program_finalize")
             fast = C.c_int32(0)
             _lib.check(lib.tsim_program_get_mode(h, C.byref(fast)), "tsim_program_get_mode")
@@ -171,10 +180,16 @@ class HipProgram:
         )
         st = (C.c_int64 * 8)()
         _lib.check(self._lib.tsim_program_stats(self._h, st), "tsim_program_stats")
+        en, tb = C.c_int32(), C.c_int64()
+        mw = (C.c_int32 * max(1, nc.value))()
+        _lib.check(self._lib.tsim_program_pattern_table_info(self._h, C.byref(en), C.byref(tb), mw),
+                   "tsim_program_pattern_table_info")
         return dict(n_components=nc.value, num_outputs=no.value, image_bytes=ib.value,
                     total_graphs=tg.value, total_rows=tr.value, fast=bool(st[0]), levels=st[1],
                     fixed_frame_levels=st[2], product_pairs=st[3], counted_rows=st[4],
-                    table_entries=st[5], graphs_d_tabled=st[6], chunk_table_kernel=bool(st[7]))
+                    table_bytes=st[5], graphs_d_tabled=st[6], chunk_table_kernel=bool(st[7]),
+                    pattern_tables=bool(en.value), pattern_table_bytes=tb.value,
+                    pattern_max_weight=[int(mw[i]) for i in range(nc.value)])
 
     # -- the hot path, host buffers -------------------------------------------
     def sample_batch(self, f_params: np.ndarray, key, *, shot_offset: int = 0, bit_packed: bool = False):
@@ -317,8 +332,9 @@ class HipProgram:
 # ---------------------------------------------------------------------------
 
 
-def get_hip_program(program, device: int = 0, mode: str = "auto") -> HipProgram:
-    """Upload ``program`` once per (device, mode) and cache the handle on the program object."""
+def get_hip_program(program, device: int = 0, mode: str = "auto", pattern_tables=None) -> HipProgram:
+    """Upload ``program`` once per (device, mode, pattern_tables) and cache the handle on the
+    program object."""
     if isinstance(program, HipProgram):
         return program
     cache = getattr(program, "_backend_cache", None)
@@ -327,11 +343,12 @@ def get_hip_program(program, device: int = 0, mode: str = "auto") -> HipProgram:
             cache = {}
             object.__setattr__(program, "_backend_cache", cache)
         except Exception:  # frozen foreign object: no caching
-            return HipProgram(program, device, mode)
-    hp = cache.get((device, mode))
+            return HipProgram(program, device, mode, pattern_tables)
+    ck = (device, mode) if pattern_tables is None else (device, mode, pattern_tables)
+    hp = cache.get(ck)
     if hp is None:
-        hp = HipProgram(program, device, mode)
-        cache[(device, mode)] = hp
+        hp = HipProgram(program, device, mode, pattern_tables)
+        cache[ck] = hp
     return hp
 
 

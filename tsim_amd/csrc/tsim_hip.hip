@@ -7,6 +7,7 @@
 #include "../../include/tsim_hip.h"
 #include "tsim_kernels.hip.h"
 #include "tsim_kernel4.hip.h"
+#include "tsim_lw.hip.h"
 #include "tsim_noise.hip.h"
 #include "tsim_format.hip.h"
 
@@ -125,9 +126,18 @@ struct tsim_program {
   uint32_t *d_keys = nullptr;
   float *d_dev = nullptr;
   hipStream_t stream = nullptr;
-  // scratch (host-buffer API)
-  void *scratch[4] = {nullptr, nullptr, nullptr, nullptr};
-  size_t scratch_sz[4] = {0, 0, 0, 0};
+  // low-weight pattern tables (tsim_lw.hip.h)
+  int lw_request = -1;        // -1 default (on in TSIM_MODE_AUTO), 0 off, 1 on
+  int lw_weight_cap = -1;     // -1 = TSIMK_LW_MAX_WEIGHT
+  bool lw = false;            // tables built, pass 1 active
+  int lw_off = 0;             // image offset of the LW component records
+  std::vector<int> lw_wmax;   // per component
+  long long lw_bytes = 0;
+  float *d_lw_tab = nullptr;
+  uint32_t *d_lw_ctl = nullptr;  // [0] hard count, [1] check row
+  // scratch (host-buffer API: 0..3; hard-row list: 4)
+  void *scratch[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  size_t scratch_sz[5] = {0, 0, 0, 0, 0};
   // profiling
   bool profiling = false;
   std::vector<hipEvent_t> ev_pool;
@@ -908,6 +918,83 @@ extern "C" int tsim_program_set_mode(tsim_program *p, int32_t mode) {
   return TSIM_OK;
 }
 
+extern "C" int tsim_program_set_pattern_tables(tsim_program *p, int32_t enable, int32_t max_weight) {
+  if (!p) return fail(TSIM_EINVAL, "program is NULL");
+  if (p->finalized) return fail(TSIM_ESTATE, "program already finalized");
+  if (enable < -1 || enable > 1 || max_weight < -1 || max_weight > TSIMK_LW_MAX_WEIGHT)
+    return fail(TSIM_EINVAL, "bad pattern-table setting (%d, %d)", enable, max_weight);
+  p->lw_request = enable;
+  p->lw_weight_cap = max_weight;
+  return TSIM_OK;
+}
+
+extern "C" int tsim_program_pattern_table_info(const tsim_program *p, int32_t *enabled, int64_t *table_bytes,
+                                               int32_t *max_weight) {
+  if (!p) return fail(TSIM_EINVAL, "program is NULL");
+  if (!p->finalized) return fail(TSIM_ESTATE, "program not finalized");
+  if (enabled) *enabled = p->lw ? 1 : 0;
+  if (table_bytes) *table_bytes = p->lw ? p->lw_bytes : 0;
+  if (max_weight)
+    for (size_t i = 0; i < p->comps.size(); ++i) max_weight[i] = p->lw ? p->lw_wmax[i] : -1;
+  return TSIM_OK;
+}
+
+// ---------------------------------------------------------------------------
+// low-weight pattern tables (tsim_lw.hip.h): enumerate the patterns of every component in table
+// order and let k_lw_build fill the thresholds with the sampling kernels' own arithmetic
+// ---------------------------------------------------------------------------
+template <int W>
+static void launch_lw_build(const LwBuildArgs &a, long long lanes, hipStream_t s, bool fast) {
+  const dim3 grid((unsigned)((lanes + 255) / 256));
+  if (fast) hipLaunchKernelGGL((k_lw_build<W, true>), grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((k_lw_build<W, false>), grid, dim3(256), 0, s, a);
+}
+
+static int build_pattern_tables(tsim_program *p, const std::vector<long long> &npat) {
+  HIP_TRY(hipMalloc((void **)&p->d_lw_tab, std::max<size_t>(16, (size_t)p->lw_bytes)));
+  HIP_TRY(hipMalloc((void **)&p->d_lw_ctl, 16));
+  HIP_TRY(hipMemset(p->d_lw_ctl, 0, 16));
+  long long tab_off = 0;
+  for (size_t ci = 0; ci < p->comps.size(); ++ci) {
+    const HostComponent &c = p->comps[ci];
+    const int F = c.F, wmax = p->lw_wmax[ci];
+    std::vector<unsigned long long> pats;
+    pats.reserve((size_t)npat[ci]);
+    pats.push_back(0ull);
+    if (wmax >= 1)
+      for (int b0 = 0; b0 < F; ++b0) pats.push_back(1ull << b0);
+    if (wmax >= 2)
+      for (int b1 = 1; b1 < F; ++b1)
+        for (int b0 = 0; b0 < b1; ++b0) pats.push_back((1ull << b1) | (1ull << b0));
+    if (wmax >= 3)
+      for (int b2 = 2; b2 < F; ++b2)
+        for (int b1 = 1; b1 < b2; ++b1)
+          for (int b0 = 0; b0 < b1; ++b0) pats.push_back((1ull << b2) | (1ull << b1) | (1ull << b0));
+    if ((long long)pats.size() != npat[ci]) return fail(TSIM_ESTATE, "pattern enumeration mismatch");
+    unsigned long long *d_pats = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_pats, pats.size() * 8));
+    HIP_TRY(hipMemcpy(d_pats, pats.data(), pats.size() * 8, hipMemcpyHostToDevice));
+    LwBuildArgs a;
+    a.img = p->d_img;
+    a.patbits = d_pats;
+    a.tab = p->d_lw_tab + tab_off;
+    a.comp_off = p->comp_off + (int)ci * C_WORDS;
+    a.npat = (int)npat[ci];
+    const long long lanes = npat[ci] << c.n_out;
+    switch (p->comp_w[ci]) {
+      case 1: launch_lw_build<1>(a, lanes, p->stream, p->fast); break;
+      case 2: launch_lw_build<2>(a, lanes, p->stream, p->fast); break;
+      default: (void)hipFree(d_pats); return fail(TSIM_ESTATE, "pattern tables need <= 64 parameters");
+    }
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
+    (void)hipFree(d_pats);
+    if (e != hipSuccess) return fail(TSIM_EHIP, "pattern table build failed: %s", hipGetErrorString(e));
+    tab_off += lanes;
+  }
+  return 0;
+}
+
 extern "C" int tsim_program_finalize(tsim_program *p, int32_t device) {
   if (!p) return fail(TSIM_EINVAL, "program is NULL");
   if (p->finalized) return fail(TSIM_ESTATE, "program already finalized");
@@ -1041,9 +1128,7 @@ retry_pack:
     const char *kenv = getenv("TSIM_AMD_KERNEL");
     if (kenv && strcmp(kenv, "v3") == 0) ok = false;
     if (p->mode == TSIM_MODE_ROW_KERNEL) ok = false;
-    const char *genv = getenv("TSIM_AMD_V4_GT");
     p->v4_gt = 4;
-    (void)genv;
     if (ok) {
       while (img.size() % 16) img.push_back(0u);
       p->comp4_off = (int)img.size();
@@ -1098,6 +1183,57 @@ retry_pack:
     }
   }
   p->stats[7] = p->v4 ? 1 : 0;
+
+  // ---- low-weight pattern tables: plan (records + sizes); built on the device after upload ----
+  p->lw = false;
+  p->lw_wmax.clear();
+  p->lw_bytes = 0;
+  std::vector<long long> lw_npat;
+  {
+    bool want = p->lw_request < 0 ? (p->mode == TSIM_MODE_AUTO) : (p->lw_request != 0);
+    if (const char *e = getenv("TSIM_AMD_PATTERN_TABLES")) want = atoi(e) != 0;
+    bool ok = want && p->sampleable && !p->comps.empty();
+    for (auto &c : p->comps)
+      ok = ok && (c.n_levels == c.n_out + 1) && c.n_out <= TSIMK_LW_MAX_NOUT && c.F + c.n_out <= 64;
+    if (ok) {
+      const int cap = p->lw_weight_cap < 0 ? TSIMK_LW_MAX_WEIGHT : std::min(p->lw_weight_cap, TSIMK_LW_MAX_WEIGHT);
+      const long long budget = 2ll << 20;  // bytes per component: stays L2-resident
+      while (img.size() % 16) img.push_back(0u);
+      p->lw_off = (int)img.size();
+      img.resize(img.size() + p->comps.size() * LW_WORDS, 0u);
+      long long tab_off = 0;
+      for (size_t ci = 0; ci < p->comps.size(); ++ci) {
+        const HostComponent &c = p->comps[ci];
+        const long long F = c.F;
+        const long long cnt[4] = {1, F, F * (F - 1) / 2, F * (F - 1) * (F - 2) / 6};
+        long long npat = 0;
+        int wmax = -1;
+        for (int w = 0; w <= cap; ++w) {
+          if (((npat + cnt[w]) << c.n_out) * 4 > budget) break;
+          npat += cnt[w];
+          wmax = w;
+        }
+        if (wmax < 0) { ok = false; break; }
+        const uint32_t *crec = &img[p->comp_off + ci * C_WORDS];
+        uint32_t *r = &img[p->lw_off + ci * LW_WORDS];
+        r[LW_NOUT] = (uint32_t)c.n_out;
+        r[LW_F] = (uint32_t)c.F;
+        r[LW_FSEL] = crec[C_FSEL];
+        r[LW_OUTPOS] = crec[C_OUTPOS];
+        r[LW_KEYBASE] = crec[C_KEYBASE];
+        r[LW_WMAX] = (uint32_t)wmax;
+        r[LW_TAB] = (uint32_t)tab_off;
+        r[LW_OFF2] = (uint32_t)(1 + F);
+        r[LW_OFF3] = (uint32_t)(1 + F + cnt[2]);
+        r[LW_NPAT] = (uint32_t)npat;
+        p->lw_wmax.push_back(wmax);
+        lw_npat.push_back(npat);
+        tab_off += npat << c.n_out;
+      }
+      if (ok) { p->lw = true; p->lw_bytes = tab_off * 4; }
+      else p->lw_wmax.clear();
+    }
+  }
   img.resize(img.size() + 256, 0u);  // tail padding: wide scalar loads may over-read
   if (img.size() >= (1ull << 31)) return fail(TSIM_ENOTSUP, "program image too large");
 
@@ -1113,6 +1249,9 @@ retry_pack:
   HIP_TRY(hipMalloc((void **)&p->d_keys, std::max(1, p->total_keys) * 8));
   HIP_TRY(hipMalloc((void **)&p->d_dev, std::max<size_t>(1, p->comps.size()) * 4));
   HIP_TRY(hipMemset(p->d_dev, 0, std::max<size_t>(1, p->comps.size()) * 4));
+  if (p->lw) {
+    if (int r = build_pattern_tables(p, lw_npat)) return r;
+  }
   p->finalized = true;
   return TSIM_OK;
 }
@@ -1128,6 +1267,8 @@ extern "C" void tsim_program_destroy(tsim_program *p) {
     if (p->d_img) (void)hipFree(p->d_img);
     if (p->d_keys) (void)hipFree(p->d_keys);
     if (p->d_dev) (void)hipFree(p->d_dev);
+    if (p->d_lw_tab) (void)hipFree(p->d_lw_tab);
+    if (p->d_lw_ctl) (void)hipFree(p->d_lw_ctl);
     if (p->stream) (void)hipStreamDestroy(p->stream);
   }
   delete p;
@@ -1221,7 +1362,7 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
     hipLaunchKernelGGL(k_keygen, dim3(1), dim3(1), 0, s, key_hi, key_lo, p->total_keys, p->d_keys);
     HIP_TRY(hipGetLastError());
   }
-  SampleArgs a;
+  SampleArgs a{};
   a.img = p->d_img;
   a.f = d_f;
   a.out = d_out;
@@ -1237,20 +1378,50 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
   a.comp_off = p->comp_off;
   a.row_index = d_row_index;
   a.row_count = d_row_index ? d_row_count : nullptr;
+  a.check_row = nullptr;
+  a.no_check = 0;
   if (num_f == 0) a.WF = 0;
+  if (B > 0x7FFFFFFFll * 64) return fail(TSIM_ENOTSUP, "batch too large");
+  if (p->profiling) { int r = prof_event(p, s); if (r) return r; }
+  // the normalisation check applies to in-batch shot 0 (sampler.py:66-72) or the first listed row
+  bool has_check = (shot_offset == 0 || d_row_index);
+  if (p->lw) {
+    // pass 1: shots whose f_sel patterns are tabulated finish here, the others go to the hard list
+    if (B > 0xFFFFFFFFll) return fail(TSIM_ENOTSUP, "batch too large for the row list");
+    if (int r = ensure_scratch(p, 4, (size_t)B * 4)) return r;
+    HIP_TRY(hipMemsetAsync(p->d_lw_ctl, 0, 8, s));
+    LwArgs l;
+    l.s = a;
+    l.tab = p->d_lw_tab;
+    l.lw_off = p->lw_off;
+    l.has_check = has_check ? 1 : 0;
+    l.hard_index = (uint32_t *)p->scratch[4];
+    l.ctl = p->d_lw_ctl;
+    const int blk1 = 256;
+    const size_t lds1 = (size_t)(2 * a.WF + 2 * a.WO) * blk1 * 4;
+    if (lds1 > 64 * 1024) return fail(TSIM_ENOTSUP, "num_f + num_outputs too large for LDS staging (%zu B)", lds1);
+    hipLaunchKernelGGL(k_sample_lw, dim3((unsigned)((B + blk1 - 1) / blk1)), dim3(blk1), lds1, s, l);
+    HIP_TRY(hipGetLastError());
+    // pass 2 below runs on the hard list; the check row was forced into it
+    a.row_index = l.hard_index;
+    a.row_count = p->d_lw_ctl;
+    a.check_row = has_check ? p->d_lw_ctl + 1 : nullptr;
+    a.no_check = has_check ? 0 : 1;
+  } else if (!has_check) {
+    a.no_check = 1;
+  }
   int block = 256;
   size_t lds = (size_t)(2 * a.WF + 2 * a.WO) * block * 4;
   if (lds > 60 * 1024) { block = 64; lds = (size_t)(2 * a.WF + 2 * a.WO) * block * 4; }
   if (lds > 60 * 1024) return fail(TSIM_ENOTSUP, "num_f + num_outputs too large for LDS staging (%zu B)", lds);
   const long long grid = (B + block - 1) / block;
   if (grid > 0x7FFFFFFFll) return fail(TSIM_ENOTSUP, "batch too large");
-  if (p->profiling) { int r = prof_event(p, s); if (r) return r; }
   if (p->v4) {
     // chunk-table kernel: LDS = f/out staging + two tile buffers; one extra block replays shot 0
     Sample4Args a4;
     a4.s = a;
     a4.comp4_off = p->comp4_off;
-    a4.has_check = (shot_offset == 0 || d_row_index) ? 1 : 0;
+    a4.has_check = has_check ? 1 : 0;
     const char *benv = getenv("TSIM_AMD_V4_BLOCK");
     const int blk = (benv && atoi(benv) == 512) ? 512 : ((benv && atoi(benv) == 128) ? 128 : 256);
     const size_t tile_bytes = std::max((size_t)p->v4_max_nch * 16, (size_t)p->v4_max_sent) * p->v4_gt * 16;

@@ -229,7 +229,7 @@ k_sample4(Sample4Args A4) {
     if (!check_block && (long long)blockIdx.x * nthr >= n) return;  // block-uniform: no barrier skipped
     active = row < n;
     if (check_block) { row = 0; active = (threadIdx.x == 0) && n > 0; }
-    row = active ? (long long)A.row_index[row] : 0;
+    row = !active ? 0 : (check_block && A.check_row) ? (long long)*A.check_row : (long long)A.row_index[row];
   } else if (check_block) {  // replay in-batch shot 0 (row 0 of this launch) in lane 0
     row = 0;
     active = (threadIdx.x == 0);

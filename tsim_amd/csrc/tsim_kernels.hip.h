@@ -36,18 +36,6 @@ enum {
 #define TSIMK_GFLAG_LAM 1u
 #define TSIMK_GFLAG_LIN 2u
 #define TSIMK_GFLAG_D_TABLED 4u
-// Unroll factors of the row loops: the rows of one unrolled body are fetched by a few wide
-// s_loads ahead of a single s_waitcnt, so SMEM latency (an L2 hit, ~300 cycles: the 130 KB image
-// does not fit the 16 KB scalar cache) is amortised over several rows instead of paid per row.
-#ifndef TSIMK_UNROLL_A
-#define TSIMK_UNROLL_A 4
-#endif
-#ifndef TSIMK_UNROLL_B
-#define TSIMK_UNROLL_B 8
-#endif
-#ifndef TSIMK_UNROLL_C
-#define TSIMK_UNROLL_C 4
-#endif
 #define TSIMK_GFLAG_FF_IS_ONE 1u
 
 struct SampleArgs {
@@ -66,6 +54,11 @@ struct SampleArgs {
   // so results do not depend on the order of the list.  nullptr = identity.
   const uint32_t *row_index;
   const uint32_t *row_count;
+  // normalisation-check row (sampler.py:66-72).  Default: in-batch shot 0, or the first listed row
+  // when a row list is given.  check_row != nullptr: the listed row whose index equals *check_row
+  // (two-pass launches: the list is unordered).  no_check != 0: nobody.
+  const uint32_t *check_row;
+  int no_check;
 };
 
 struct EvalArgs {
@@ -587,7 +580,9 @@ __global__ void __launch_bounds__(256) k_sample(SampleArgs A) {
   }
   const unsigned long long shot = (unsigned long long)(A.shot_offset + row);
   // normalisation check (sampler.py:66-72): in-batch shot 0, or the first listed survivor
-  const bool check_lane = A.row_index ? (slot == 0) : (shot == 0ull);
+  const bool check_lane = A.no_check ? false
+                          : A.check_row ? (row == (long long)*A.check_row)
+                          : A.row_index ? (slot == 0) : (shot == 0ull);
   cptr img = (cptr)(uintptr_t)A.img;
 
   const int WF32 = 2 * A.WF, WO32 = 2 * A.WO;

@@ -131,6 +131,8 @@ struct tsim_program {
   int lw_weight_cap = -1;     // -1 = TSIMK_LW_MAX_WEIGHT
   bool lw = false;            // tables built, pass 1 active
   int lw_off = 0;             // image offset of the LW component records
+  int lw_direct_prog = 0;     // image offset of the direct-output gather program
+  int lw_direct_chunks = 0;
   std::vector<int> lw_wmax;   // per component
   long long lw_bytes = 0;
   float *d_lw_tab = nullptr;
@@ -918,6 +920,36 @@ extern "C" int tsim_program_set_mode(tsim_program *p, int32_t mode) {
   return TSIM_OK;
 }
 
+// Gather program (tsim_lw.hip.h): bit moves (src f bit -> dst bit, flip) merged into runs that are
+// contiguous in both the source and the destination word; 4-word runs, padded to chunks of four.
+static std::vector<uint32_t> emit_gather_program(std::vector<std::array<int, 3>> e) {
+  std::sort(e.begin(), e.end(), [](const std::array<int, 3> &a, const std::array<int, 3> &b) {
+    if ((a[0] >> 5) != (b[0] >> 5)) return (a[0] >> 5) < (b[0] >> 5);
+    if ((a[1] >> 5) != (b[1] >> 5)) return (a[1] >> 5) < (b[1] >> 5);
+    return a[0] < b[0];
+  });
+  std::vector<uint32_t> out;
+  size_t i = 0;
+  while (i < e.size()) {
+    size_t j = i + 1;
+    while (j < e.size() && e[j][0] == e[j - 1][0] + 1 && e[j][1] == e[j - 1][1] + 1 &&
+           (e[j][0] >> 5) == (e[i][0] >> 5) && (e[j][1] >> 5) == (e[i][1] >> 5))
+      ++j;
+    const int len = (int)(j - i);
+    uint32_t flip = 0;
+    for (size_t k = i; k < j; ++k) flip |= (uint32_t)(e[k][2] & 1) << (k - i);
+    const uint32_t mask = len >= 32 ? 0xFFFFFFFFu : ((1u << len) - 1u);
+    out.push_back((uint32_t)(e[i][0] & 31) | ((uint32_t)(e[i][1] & 31) << 8) | ((uint32_t)(e[i][1] >> 5) << 16) |
+                  ((uint32_t)(e[i][0] >> 5) << 24));
+    out.push_back(mask);
+    out.push_back(flip);
+    out.push_back(0u);
+    i = j;
+  }
+  while (out.size() % 16) out.push_back(0u);  // mask = 0 runs: no-ops
+  return out;
+}
+
 extern "C" int tsim_program_set_pattern_tables(tsim_program *p, int32_t enable, int32_t max_weight) {
   if (!p) return fail(TSIM_EINVAL, "program is NULL");
   if (p->finalized) return fail(TSIM_ESTATE, "program already finalized");
@@ -952,8 +984,8 @@ static void launch_lw_build(const LwBuildArgs &a, long long lanes, hipStream_t s
 
 static int build_pattern_tables(tsim_program *p, const std::vector<long long> &npat) {
   HIP_TRY(hipMalloc((void **)&p->d_lw_tab, std::max<size_t>(16, (size_t)p->lw_bytes)));
-  HIP_TRY(hipMalloc((void **)&p->d_lw_ctl, 16));
-  HIP_TRY(hipMemset(p->d_lw_ctl, 0, 16));
+  HIP_TRY(hipMalloc((void **)&p->d_lw_ctl, (TSIMK_LW_LISTS + 1) * 128));
+  HIP_TRY(hipMemset(p->d_lw_ctl, 0, (TSIMK_LW_LISTS + 1) * 128));
   long long tab_off = 0;
   for (size_t ci = 0; ci < p->comps.size(); ++ci) {
     const HostComponent &c = p->comps[ci];
@@ -1189,6 +1221,7 @@ retry_pack:
   p->lw_wmax.clear();
   p->lw_bytes = 0;
   std::vector<long long> lw_npat;
+  std::vector<std::vector<std::array<int, 3>>> lw_fsel_progs;
   {
     bool want = p->lw_request < 0 ? (p->mode == TSIM_MODE_AUTO) : (p->lw_request != 0);
     if (const char *e = getenv("TSIM_AMD_PATTERN_TABLES")) want = atoi(e) != 0;
@@ -1218,7 +1251,8 @@ retry_pack:
         uint32_t *r = &img[p->lw_off + ci * LW_WORDS];
         r[LW_NOUT] = (uint32_t)c.n_out;
         r[LW_F] = (uint32_t)c.F;
-        r[LW_FSEL] = crec[C_FSEL];
+        lw_fsel_progs.push_back({});
+        for (int j = 0; j < c.F; ++j) lw_fsel_progs.back().push_back({c.f_selection[j], j, 0});
         r[LW_OUTPOS] = crec[C_OUTPOS];
         r[LW_KEYBASE] = crec[C_KEYBASE];
         r[LW_WMAX] = (uint32_t)wmax;
@@ -1230,8 +1264,26 @@ retry_pack:
         lw_npat.push_back(npat);
         tab_off += npat << c.n_out;
       }
-      if (ok) { p->lw = true; p->lw_bytes = tab_off * 4; }
-      else p->lw_wmax.clear();
+      if (ok) {
+        p->lw = true;
+        p->lw_bytes = tab_off * 4;
+        // gather programs: direct outputs, then every component's f_sel
+        std::vector<std::array<int, 3>> de;
+        for (int j = 0; j < p->n_direct; ++j) de.push_back({p->direct_f[j], p->output_order[j], p->direct_flips[j] ? 1 : 0});
+        std::vector<uint32_t> prog = emit_gather_program(de);
+        while (img.size() % 16) img.push_back(0u);
+        p->lw_direct_prog = (int)img.size();
+        p->lw_direct_chunks = (int)(prog.size() / 16);
+        img.insert(img.end(), prog.begin(), prog.end());
+        for (size_t ci = 0; ci < p->comps.size(); ++ci) {
+          prog = emit_gather_program(lw_fsel_progs[ci]);
+          img[p->lw_off + ci * LW_WORDS + LW_FSELP] = (uint32_t)img.size();
+          img[p->lw_off + ci * LW_WORDS + LW_FSELN] = (uint32_t)(prog.size() / 16);
+          img.insert(img.end(), prog.begin(), prog.end());
+        }
+      } else {
+        p->lw_wmax.clear();
+      }
     }
   }
   img.resize(img.size() + 256, 0u);  // tail padding: wide scalar loads may over-read
@@ -1359,8 +1411,12 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
   // per-output subkeys: key, subkey = split(key) once per output, threaded through the
   // components in processing order (sampler.py:74,147-148)
   if (p->total_keys > 0) {
-    hipLaunchKernelGGL(k_keygen, dim3(1), dim3(1), 0, s, key_hi, key_lo, p->total_keys, p->d_keys);
+    hipLaunchKernelGGL(k_keygen, dim3(1), dim3(p->lw ? 128 : 1), 0, s, key_hi, key_lo, p->total_keys, p->d_keys,
+                       p->lw ? p->d_lw_ctl : (uint32_t *)nullptr, (int)TSIMK_LW_LISTS);
     HIP_TRY(hipGetLastError());
+  } else if (p->lw) {
+    HIP_TRY(hipMemsetAsync(p->d_lw_ctl, 0, TSIMK_LW_LISTS * 128, s));
+    HIP_TRY(hipMemsetAsync(p->d_lw_ctl + 32 * TSIMK_LW_LISTS, 0xFF, 4, s));
   }
   SampleArgs a{};
   a.img = p->d_img;
@@ -1378,6 +1434,8 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
   a.comp_off = p->comp_off;
   a.row_index = d_row_index;
   a.row_count = d_row_index ? d_row_count : nullptr;
+  a.row_lists = 0;
+  a.row_list_cap = 0;
   a.check_row = nullptr;
   a.no_check = 0;
   if (num_f == 0) a.WF = 0;
@@ -1385,28 +1443,38 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
   if (p->profiling) { int r = prof_event(p, s); if (r) return r; }
   // the normalisation check applies to in-batch shot 0 (sampler.py:66-72) or the first listed row
   bool has_check = (shot_offset == 0 || d_row_index);
+  long long B2 = B;  // slots per row list of the full kernel's launch
   if (p->lw) {
     // pass 1: shots whose f_sel patterns are tabulated finish here, the others go to the hard list
     if (B > 0xFFFFFFFFll) return fail(TSIM_ENOTSUP, "batch too large for the row list");
-    if (int r = ensure_scratch(p, 4, (size_t)B * 4)) return r;
-    HIP_TRY(hipMemsetAsync(p->d_lw_ctl, 0, 8, s));
+    const char *b1env = getenv("TSIM_AMD_LW_BLOCK");
+    const int blk1 = b1env ? std::max(64, std::min(1024, atoi(b1env) & ~63)) : 256;
+    const long long grid1 = (B + blk1 - 1) / blk1;
+    const long long list_cap = (grid1 + TSIMK_LW_LISTS - 1) / TSIMK_LW_LISTS * blk1;
+    if (list_cap > 0x7FFFFFFFll) return fail(TSIM_ENOTSUP, "batch too large for the row lists");
+    if (int r = ensure_scratch(p, 4, (size_t)list_cap * TSIMK_LW_LISTS * 4)) return r;
     LwArgs l;
     l.s = a;
     l.tab = p->d_lw_tab;
     l.lw_off = p->lw_off;
+    l.direct_prog = p->lw_direct_prog;
+    l.direct_chunks = p->lw_direct_chunks;
     l.has_check = has_check ? 1 : 0;
     l.hard_index = (uint32_t *)p->scratch[4];
     l.ctl = p->d_lw_ctl;
-    const int blk1 = 256;
+    l.list_cap = (int)list_cap;
     const size_t lds1 = (size_t)(2 * a.WF + 2 * a.WO) * blk1 * 4;
     if (lds1 > 64 * 1024) return fail(TSIM_ENOTSUP, "num_f + num_outputs too large for LDS staging (%zu B)", lds1);
-    hipLaunchKernelGGL(k_sample_lw, dim3((unsigned)((B + blk1 - 1) / blk1)), dim3(blk1), lds1, s, l);
+    hipLaunchKernelGGL(k_sample_lw, dim3((unsigned)grid1), dim3(blk1), lds1, s, l);
     HIP_TRY(hipGetLastError());
-    // pass 2 below runs on the hard list; the check row was forced into it
+    // pass 2 below runs on the hard lists; the check row was forced into one of them
     a.row_index = l.hard_index;
     a.row_count = p->d_lw_ctl;
-    a.check_row = has_check ? p->d_lw_ctl + 1 : nullptr;
+    a.row_lists = TSIMK_LW_LISTS;
+    a.row_list_cap = (int)list_cap;
+    a.check_row = has_check ? p->d_lw_ctl + 32 * TSIMK_LW_LISTS : nullptr;
     a.no_check = has_check ? 0 : 1;
+    B2 = list_cap;
   } else if (!has_check) {
     a.no_check = 1;
   }
@@ -1414,7 +1482,8 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
   size_t lds = (size_t)(2 * a.WF + 2 * a.WO) * block * 4;
   if (lds > 60 * 1024) { block = 64; lds = (size_t)(2 * a.WF + 2 * a.WO) * block * 4; }
   if (lds > 60 * 1024) return fail(TSIM_ENOTSUP, "num_f + num_outputs too large for LDS staging (%zu B)", lds);
-  const long long grid = (B + block - 1) / block;
+  const long long nlists = a.row_lists > 1 ? a.row_lists : 1;
+  const long long grid = (B2 + block - 1) / block * nlists;
   if (grid > 0x7FFFFFFFll) return fail(TSIM_ENOTSUP, "batch too large");
   if (p->v4) {
     // chunk-table kernel: LDS = f/out staging + two tile buffers; one extra block replays shot 0
@@ -1427,7 +1496,7 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
     const size_t tile_bytes = std::max((size_t)p->v4_max_nch * 16, (size_t)p->v4_max_sent) * p->v4_gt * 16;
     const size_t lds4 = (size_t)(2 * a.WF + 2 * a.WO) * blk * 4 + 2 * tile_bytes;
     if (lds4 > 64 * 1024) return fail(TSIM_ENOTSUP, "v4 kernel needs %zu B of LDS", lds4);
-    const long long grid4 = (B + blk - 1) / blk + a4.has_check;
+    const long long grid4 = (B2 + blk - 1) / blk * nlists + a4.has_check;
     switch (p->v4_max_nch) {
 #define TSIM_L4(N) case N: hipLaunchKernelGGL((k_sample4<4, N>), dim3((unsigned)grid4), dim3(blk), lds4, s, a4); break;
       TSIM_L4(2) TSIM_L4(4) TSIM_L4(6) TSIM_L4(8) TSIM_L4(10) TSIM_L4(12) TSIM_L4(14)

@@ -224,12 +224,20 @@ k_sample4(Sample4Args A4) {
   const bool check_block = A4.has_check && (blockIdx.x == gridDim.x - 1);
   long long row = (long long)blockIdx.x * nthr + threadIdx.x;
   bool active = row < A.B;
-  if (A.row_index) {  // device-side post-selection: slots map to listed survivor rows
-    const long long n = (long long)*A.row_count;
-    if (!check_block && (long long)blockIdx.x * nthr >= n) return;  // block-uniform: no barrier skipped
+  if (A.row_index) {  // row lists (device-side post-selection / hard rows of a two-pass launch)
+    const uint32_t nl = A.row_lists > 1 ? (uint32_t)A.row_lists : 1u;
+    const uint32_t k = blockIdx.x % nl;
+    const long long base = (long long)(blockIdx.x / nl) * nthr;
+    const long long n = (long long)A.row_count[32u * k * (nl > 1 ? 1u : 0u)];
+    if (!check_block && base >= n) return;  // block-uniform: no barrier skipped
+    row = base + threadIdx.x;
     active = row < n;
-    if (check_block) { row = 0; active = (threadIdx.x == 0) && n > 0; }
-    row = !active ? 0 : (check_block && A.check_row) ? (long long)*A.check_row : (long long)A.row_index[row];
+    if (check_block) {
+      active = (threadIdx.x == 0) && (A.check_row ? (*A.check_row != 0xFFFFFFFFu) : (n > 0));
+      row = !active ? 0 : A.check_row ? (long long)*A.check_row : (long long)A.row_index[0];
+    } else {
+      row = active ? (long long)A.row_index[(size_t)k * (nl > 1 ? A.row_list_cap : 0) + row] : 0;
+    }
   } else if (check_block) {  // replay in-batch shot 0 (row 0 of this launch) in lane 0
     row = 0;
     active = (threadIdx.x == 0);

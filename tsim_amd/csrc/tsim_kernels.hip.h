@@ -54,6 +54,10 @@ struct SampleArgs {
   // so results do not depend on the order of the list.  nullptr = identity.
   const uint32_t *row_index;
   const uint32_t *row_count;
+  // row_lists > 1 (two-pass launches): row_lists sub-lists of capacity row_list_cap each; list k
+  // holds row_count[32 * k] entries at row_index + k * row_list_cap and is served by the blocks with
+  // blockIdx % row_lists == k (several counters instead of one: same-address atomics serialise)
+  int row_lists, row_list_cap;
   // normalisation-check row (sampler.py:66-72).  Default: in-batch shot 0, or the first listed row
   // when a row list is given.  check_row != nullptr: the listed row whose index equals *check_row
   // (two-pass launches: the list is unordered).  no_check != 0: nobody.
@@ -570,11 +574,18 @@ extern __shared__ uint32_t tsimk_lds[];
 template <int WMAX, bool FAST>
 __global__ void __launch_bounds__(256) k_sample(SampleArgs A) {
   const int nthr = blockDim.x;
-  const long long slot = (long long)blockIdx.x * nthr + threadIdx.x;
+  long long slot = (long long)blockIdx.x * nthr + threadIdx.x;
   long long row = slot;
   if (A.row_index) {
-    if (slot >= (long long)*A.row_count) return;
-    row = A.row_index[slot];
+    if (A.row_lists > 1) {
+      const uint32_t k = blockIdx.x % (uint32_t)A.row_lists;
+      slot = (long long)(blockIdx.x / (uint32_t)A.row_lists) * nthr + threadIdx.x;
+      if (slot >= (long long)A.row_count[32u * k]) return;
+      row = A.row_index[(size_t)k * A.row_list_cap + slot];
+    } else {
+      if (slot >= (long long)*A.row_count) return;
+      row = A.row_index[slot];
+    }
   } else if (slot >= A.B) {
     return;  // no barriers below: every lane owns its LDS columns
   }
@@ -709,7 +720,11 @@ __global__ void __launch_bounds__(256) k_direct_filter(FilterArgs A) {
 // output, threaded through the components in processing order
 // (sampler.py:74,147-148).  A sequential chain, one thread, stream-ordered.
 // ---------------------------------------------------------------------------
-__global__ void k_keygen(uint32_t k0, uint32_t k1, int n, uint32_t *__restrict__ subkeys) {
+__global__ void k_keygen(uint32_t k0, uint32_t k1, int n, uint32_t *__restrict__ subkeys,
+                         uint32_t *__restrict__ counters, int n_counters) {
+  // two-pass launches: reset the hard-row counters (one per 128 bytes) and the check row
+  if (counters && blockIdx.x == 0 && (int)threadIdx.x <= n_counters)
+    counters[32u * threadIdx.x] = ((int)threadIdx.x == n_counters) ? 0xFFFFFFFFu : 0u;  // last: "no check row"
   if (blockIdx.x != 0 || threadIdx.x != 0) return;
   for (int i = 0; i < n; ++i) {
     uint32_t a0 = 0u, a1 = 0u, b0 = 0u, b1 = 1u;

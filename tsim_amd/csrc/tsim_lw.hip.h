@@ -20,15 +20,26 @@
 #pragma once
 #include "tsim_kernels.hip.h"
 
+#ifndef LW_EXP
+#define LW_EXP 0
+#endif
+
 namespace tsimk {
 
 // per-component record of the pattern tables (uint32 words, in the program image)
 enum {
-  LW_NOUT = 0, LW_F, LW_FSEL, LW_OUTPOS, LW_KEYBASE, LW_WMAX, LW_TAB /* float offset into tab */,
-  LW_OFF2 /* index of the first weight-2 pattern */, LW_OFF3, LW_NPAT, LW_WORDS = 16
+  LW_NOUT = 0, LW_F, LW_FSELP /* gather program f row -> x */, LW_OUTPOS, LW_KEYBASE, LW_WMAX,
+  LW_TAB /* float offset into tab */, LW_OFF2 /* index of the first weight-2 pattern */, LW_OFF3, LW_NPAT,
+  LW_FSELN /* chunks of the gather program */, LW_WORDS = 16
 };
+// A gather program moves bit fields of the packed f row to a destination bit vector.  It is a
+// list of 4-word runs [ctl, mask, flip, 0], four runs per 64-byte chunk (one s_load_dwordx16; the
+// last chunk is padded with mask = 0 runs):
+//   ctl = src_shift | dst_shift << 8 | dst_word << 16 | src_word << 24
+//   dst_word[dst_shift ..] |= ((f32[src_word] >> src_shift) & mask) ^ flip
 #define TSIMK_LW_MAX_NOUT 10
 #define TSIMK_LW_MAX_WEIGHT 3
+#define TSIMK_LW_LISTS 64   // hard-row sub-lists (one atomic counter each, 128 bytes apart)
 
 // colex rank of a pattern with sorted set-bit positions b0 < b1 < b2 (missing ones passed as 0)
 __host__ __device__ __forceinline__ uint32_t lw_binom2(uint32_t b) { return (b * (b - 1u)) >> 1; }
@@ -93,16 +104,41 @@ __global__ void __launch_bounds__(256) k_lw_build(LwBuildArgs A) {
 // ---------------------------------------------------------------------------
 // pass 1
 // ---------------------------------------------------------------------------
+typedef uint32_t lw_u32x16 __attribute__((ext_vector_type(16)));
+typedef const __attribute__((address_space(4))) lw_u32x16 *lw_cptr16;
+
+// runs one gather program; destination words 0 and 1 are register accumulators, higher ones (rare:
+// more than 64 outputs) go to the lane's LDS column `lds_hi` (may be nullptr when there are none)
+__device__ __forceinline__ void lw_gather(cptr prog, uint32_t nchunks, const uint32_t *lds_f, uint32_t *lds_hi,
+                                          int nthr, uint32_t &a0, uint32_t &a1) {
+  for (uint32_t c = 0; c < nchunks; ++c) {
+    const lw_u32x16 q = *(lw_cptr16)(prog + 16u * c);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const uint32_t ctl = q[4 * k];
+      const uint32_t fw = lds_f[(ctl >> 24) * nthr];
+      const uint32_t v = (((fw >> (ctl & 31u)) & q[4 * k + 1]) ^ q[4 * k + 2]) << ((ctl >> 8) & 31u);
+      const uint32_t dw = (ctl >> 16) & 255u;
+      if (dw == 0u) a0 |= v;
+      else if (dw == 1u) a1 |= v;
+      else lds_hi[dw * nthr] |= v;
+    }
+  }
+}
+
 struct LwArgs {
   SampleArgs s;           // row_index/row_count: optional INPUT list (device-side post-selection)
   const float *tab;       // thresholds, all components
   int lw_off;             // image offset of the LW component records
+  int direct_prog;        // image offset of the direct-output gather program (64-byte aligned)
+  int direct_chunks;
   int has_check;          // the first slot's row is the normalisation-check row: always "hard"
-  uint32_t *hard_index;   // [B] out: rows that need the full kernel (unordered)
-  uint32_t *ctl;          // ctl[0] = hard count (zeroed by the caller), ctl[1] = check row
+  uint32_t *hard_index;   // out: TSIMK_LW_LISTS sub-lists of list_cap rows that need the full kernel
+  uint32_t *ctl;          // ctl[32 k] = entries of list k (zeroed by the caller), ctl[32 LISTS] = check row
+  int list_cap;
 };
 
-__global__ void __launch_bounds__(256) k_sample_lw(LwArgs L) {
+__global__ void __launch_bounds__(1024) k_sample_lw(LwArgs L) {
   const SampleArgs &A = L.s;
   const int nthr = blockDim.x;
   const long long slot = (long long)blockIdx.x * nthr + threadIdx.x;
@@ -119,6 +155,7 @@ __global__ void __launch_bounds__(256) k_sample_lw(LwArgs L) {
   uint32_t *lds_o = tsimk_lds + WF32 * nthr + threadIdx.x;  // [WO32][nthr]
 
   bool hard = false;
+  uint32_t o0 = 0, o1 = 0;  // output words 0 and 1 (the LDS column holds the others)
   if (active) {
     const uint64_t *frow = A.f + row * A.WF;
     for (int w = 0; w < A.WF; ++w) {
@@ -128,62 +165,63 @@ __global__ void __launch_bounds__(256) k_sample_lw(LwArgs L) {
     }
     for (int w = 0; w < WO32; ++w) lds_o[w * nthr] = 0u;
     hard = L.has_check && slot == 0;
-    if (hard) L.ctl[1] = (uint32_t)row;
+    if (hard) L.ctl[32 * TSIMK_LW_LISTS] = (uint32_t)row;
 
-    // f_sel weight test of every component first: a hard shot skips all the rest of this pass
-    for (int ci = 0; ci < A.n_comp && !hard; ++ci) {
-      cptr rec = img + L.lw_off + ci * LW_WORDS;
-      const uint32_t F = rec[LW_F];
-      cptr fsel = img + rec[LW_FSEL];
-      uint32_t cnt = 0;
-      for (uint32_t j = 0; j < F; ++j) {
-        const uint32_t src = fsel[j];
-        cnt += (lds_f[(src >> 5) * nthr] >> (src & 31u)) & 1u;
-      }
-      hard = cnt > rec[LW_WMAX];
-    }
-  }
+    // K14: direct outputs f[idx] ^ flip (sampler.py:140-145), as bit-field moves
+    lw_gather(img + L.direct_prog, (uint32_t)L.direct_chunks, lds_f, lds_o, nthr, o0, o1);
 
-  if (active && !hard) {
-    // K14: direct outputs f[idx] ^ flip (sampler.py:140-145)
-    cptr dt = img + A.direct_off;
-    for (int j = 0; j < A.n_direct; ++j) {
-      const uint32_t s = dt[2 * j], dst = dt[2 * j + 1];
-      const uint32_t src = s & 0x7FFFFFFFu;
-      const uint32_t bit = ((lds_f[(src >> 5) * nthr] >> (src & 31u)) ^ (s >> 31)) & 1u;
-      lds_o[(dst >> 5) * nthr] |= bit << (dst & 31u);
-    }
     for (int ci = 0; ci < A.n_comp; ++ci) {
       cptr rec = img + L.lw_off + ci * LW_WORDS;
-      const uint32_t n_out = rec[LW_NOUT], F = rec[LW_F];
-      cptr fsel = img + rec[LW_FSEL];
-      cptr outpos = img + rec[LW_OUTPOS];
-      const uint32_t *keys = A.subkeys + 2 * rec[LW_KEYBASE];
-      // positions (within f_sel) of the at most three set bits, ascending
-      uint32_t b0 = 0, b1 = 0, b2 = 0, cnt = 0;
-      for (uint32_t j = 0; j < F; ++j) {
-        const uint32_t src = fsel[j];
-        const bool set = ((lds_f[(src >> 5) * nthr] >> (src & 31u)) & 1u) != 0u;
-        if (set) {
-          if (cnt == 0) b0 = j; else if (cnt == 1) b1 = j; else b2 = j;
-          ++cnt;
-        }
-      }
+      // f_sel gather (sampler.py:48) -> x, then the weight test
+      uint32_t x0 = 0, x1 = 0;
+      lw_gather(img + rec[LW_FSELP], rec[LW_FSELN], lds_f, nullptr, nthr, x0, x1);
+      unsigned long long xf = ((unsigned long long)x1 << 32) | x0;
+      const uint32_t cnt = (uint32_t)__popcll(xf);
+#if LW_EXP != 1
+      if (cnt > rec[LW_WMAX]) hard = true;
+#endif
+      if (hard) continue;  // needs the full kernel: nothing of this row is written here
+      // colex rank of the (<= 3)-subset
+      uint32_t b0 = 0, b1 = 0, b2 = 0;
+      if (cnt >= 1) { b0 = (uint32_t)__builtin_ctzll(xf); xf &= xf - 1ull; }
+      if (cnt >= 2) { b1 = (uint32_t)__builtin_ctzll(xf); xf &= xf - 1ull; }
+      if (cnt >= 3) { b2 = (uint32_t)__builtin_ctzll(xf); }
       const uint32_t base = (cnt == 0) ? 0u : (cnt == 1) ? 1u : (cnt == 2) ? rec[LW_OFF2] : rec[LW_OFF3];
       const uint32_t pat = base + b0 + (cnt >= 2 ? lw_binom2(b1) : 0u) + (cnt >= 3 ? lw_binom3(b2) : 0u);
+      const uint32_t n_out = rec[LW_NOUT];
+      cptr outpos = img + rec[LW_OUTPOS];
+      const uint32_t *keys = A.subkeys + 2 * rec[LW_KEYBASE];
       const float *thr = L.tab + rec[LW_TAB] + ((size_t)pat << n_out);
       uint32_t node = 1u;
       for (uint32_t i = 0; i < n_out; ++i) {
+#if LW_EXP == 3
+        const float u = __uint_as_float((((uint32_t)shot * 2654435761u + i) >> 9) | 0x3F800000u) - 1.0f;
+#else
         const float u = uniform01(keys[2 * i], keys[2 * i + 1], shot);  // sampler.py:74-75
+#endif
+#if LW_EXP == 2
+        const bool bit = u < 0.5f;
+#else
         const bool bit = u < thr[node];
+#endif
         node = 2u * node + (bit ? 1u : 0u);
         const uint32_t dst = outpos[i];
-        lds_o[(dst >> 5) * nthr] |= (bit ? 1u : 0u) << (dst & 31u);
+        const uint32_t v = (bit ? 1u : 0u) << (dst & 31u);
+        if ((dst >> 5) == 0u) o0 |= v;
+        else if ((dst >> 5) == 1u) o1 |= v;
+        else lds_o[(dst >> 5) * nthr] |= v;
       }
     }
-    uint64_t *orow = A.out + row * A.WO;
-    for (int w = 0; w < A.WO; ++w)
-      orow[w] = (uint64_t)lds_o[(2 * w) * nthr] | ((uint64_t)lds_o[(2 * w + 1) * nthr] << 32);
+#if LW_EXP == 4
+    if (o0 == 0x12345u) {
+#else
+    if (!hard) {
+#endif
+      uint64_t *orow = A.out + row * A.WO;
+      if (A.WO > 0) orow[0] = (uint64_t)o0 | ((uint64_t)o1 << 32);
+      for (int w = 1; w < A.WO; ++w)
+        orow[w] = (uint64_t)lds_o[(2 * w) * nthr] | ((uint64_t)lds_o[(2 * w + 1) * nthr] << 32);
+    }
   }
 
   // wave-aggregated append of the hard rows
@@ -192,9 +230,11 @@ __global__ void __launch_bounds__(256) k_sample_lw(LwArgs L) {
     const int lane = (int)(threadIdx.x & 63u);
     const int leader = __builtin_ctzll(hm);
     uint32_t basei = 0;
-    if (lane == leader) basei = atomicAdd(&L.ctl[0], (uint32_t)__popcll(hm));
+    const uint32_t k = blockIdx.x % (uint32_t)TSIMK_LW_LISTS;  // this block's sub-list
+    if (lane == leader) basei = atomicAdd(&L.ctl[32u * k], (uint32_t)__popcll(hm));
     basei = (uint32_t)__shfl((int)basei, leader, 64);
-    if (hard) L.hard_index[basei + (uint32_t)__popcll(hm & ((1ull << lane) - 1ull))] = (uint32_t)row;
+    if (hard)
+      L.hard_index[(size_t)k * L.list_cap + basei + (uint32_t)__popcll(hm & ((1ull << lane) - 1ull))] = (uint32_t)row;
   }
 }
 

@@ -7,6 +7,7 @@
 #include "../../include/tsim_hip.h"
 #include "tsim_kernels.hip.h"
 #include "tsim_kernel4.hip.h"
+#include "tsim_kernel4h.hip.h"
 #include "tsim_lw.hip.h"
 #include "tsim_noise.hip.h"
 #include "tsim_format.hip.h"
@@ -130,6 +131,7 @@ struct tsim_program {
   int lw_request = -1;        // -1 default (on in TSIM_MODE_AUTO), 0 off, 1 on
   int lw_weight_cap = -1;     // -1 = TSIMK_LW_MAX_WEIGHT
   bool lw = false;            // tables built, pass 1 active
+  bool h_attr_set = false;    // k_sample4h: large dynamic LDS enabled
   int lw_off = 0;             // image offset of the LW component records
   int lw_direct_prog = 0;     // image offset of the direct-output gather program
   int lw_direct_chunks = 0;
@@ -1436,6 +1438,8 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
   a.row_count = d_row_index ? d_row_count : nullptr;
   a.row_lists = 0;
   a.row_list_cap = 0;
+  a.row_slot_begin = 0;
+  a.row_slot_end = 0;
   a.check_row = nullptr;
   a.no_check = 0;
   if (num_f == 0) a.WF = 0;
@@ -1496,8 +1500,45 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
     const size_t tile_bytes = std::max((size_t)p->v4_max_nch * 16, (size_t)p->v4_max_sent) * p->v4_gt * 16;
     const size_t lds4 = (size_t)(2 * a.WF + 2 * a.WO) * blk * 4 + 2 * tile_bytes;
     if (lds4 > 64 * 1024) return fail(TSIM_ENOTSUP, "v4 kernel needs %zu B of LDS", lds4);
+    const char *henv = getenv("TSIM_AMD_HARD_KERNEL");
+    if (a.row_lists > 1 && !(henv && atoi(henv) == 0)) {
+      // short row lists (second pass of a two-pass launch): NW waves per 64 rows, tsim_kernel4h.hip.h
+      constexpr int NW = 8;
+      const size_t tile_b = (size_t)p->v4_max_nch * 16 * p->v4_gt * 16;
+      const size_t fixed_b = (size_t)(2 * a.WF + 2 * a.WO) * 64 * 4 + (size_t)NW * 8 * 64 * 4;
+      const size_t budget = 150 * 1024;
+      int group_tiles = fixed_b + tile_b <= budget ? (int)std::min<size_t>(TSIMK_H_MAX_GROUP_TILES, (budget - fixed_b) / tile_b) : 0;
+      if (group_tiles >= 1) {
+        // the first kHardBlocks * 64 slots of every list go to the NW-wave kernel; k_sample4 below
+        // serves the rest (its blocks exit at once when the lists are short - the usual case)
+        constexpr int kHardBlocks = 4;
+        const size_t ldsh = fixed_b + (size_t)group_tiles * tile_b;
+        const long long gridh = (long long)kHardBlocks * nlists + a4.has_check;
+        Sample4Args ah = a4;
+        ah.s.row_slot_end = kHardBlocks * 64;
+        switch (p->v4_max_nch) {
+#define TSIM_LH(N)                                                                                          \
+  case N: {                                                                                                 \
+    auto kfn = k_sample4h<4, N, NW>;                                                                        \
+    if (!p->h_attr_set)                                                                                     \
+      HIP_TRY(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+    hipLaunchKernelGGL(kfn, dim3((unsigned)gridh), dim3(NW * 64), ldsh, s, ah, group_tiles);                \
+  } break;
+          TSIM_LH(2) TSIM_LH(4) TSIM_LH(6) TSIM_LH(8) TSIM_LH(10) TSIM_LH(12) TSIM_LH(14) TSIM_LH(16)
+#undef TSIM_LH
+          default: return fail(TSIM_ESTATE, "bad chunk count %d", p->v4_max_nch);
+        }
+        HIP_TRY(hipGetLastError());
+        p->h_attr_set = true;
+        a4.has_check = 0;  // done by the kernel above
+        a4.s.no_check = 1;
+        a4.s.row_slot_begin = kHardBlocks * 64;
+        B2 = std::max<long long>(0, B2 - kHardBlocks * 64);
+      }
+    }
     const long long grid4 = (B2 + blk - 1) / blk * nlists + a4.has_check;
-    switch (p->v4_max_nch) {
+    if (grid4 > 0x7FFFFFFFll) return fail(TSIM_ENOTSUP, "batch too large");
+    if (grid4 > 0) switch (p->v4_max_nch) {
 #define TSIM_L4(N) case N: hipLaunchKernelGGL((k_sample4<4, N>), dim3((unsigned)grid4), dim3(blk), lds4, s, a4); break;
       TSIM_L4(2) TSIM_L4(4) TSIM_L4(6) TSIM_L4(8) TSIM_L4(10) TSIM_L4(12) TSIM_L4(14)
 #undef TSIM_L4

@@ -227,21 +227,24 @@ k_sample4(Sample4Args A4) {
   if (A.row_index) {  // row lists (device-side post-selection / hard rows of a two-pass launch)
     const uint32_t nl = A.row_lists > 1 ? (uint32_t)A.row_lists : 1u;
     const uint32_t k = blockIdx.x % nl;
-    const long long base = (long long)(blockIdx.x / nl) * nthr;
+    const long long base = (long long)(blockIdx.x / nl) * nthr + (nl > 1 ? A.row_slot_begin : 0);
     const long long n = (long long)A.row_count[32u * k * (nl > 1 ? 1u : 0u)];
     if (!check_block && base >= n) return;  // block-uniform: no barrier skipped
     row = base + threadIdx.x;
     active = row < n;
-    if (check_block) {
-      active = (threadIdx.x == 0) && (A.check_row ? (*A.check_row != 0xFFFFFFFFu) : (n > 0));
+    if (check_block) {  // lanes 0 and 1 both replay the check row (trial bit 1 / trial bit 0)
+      active = (threadIdx.x < 2) && (A.check_row ? (*A.check_row != 0xFFFFFFFFu) : (n > 0));
       row = !active ? 0 : A.check_row ? (long long)*A.check_row : (long long)A.row_index[0];
     } else {
       row = active ? (long long)A.row_index[(size_t)k * (nl > 1 ? A.row_list_cap : 0) + row] : 0;
     }
-  } else if (check_block) {  // replay in-batch shot 0 (row 0 of this launch) in lane 0
+  } else if (check_block) {  // replay in-batch shot 0 (row 0 of this launch) in lanes 0 and 1
     row = 0;
-    active = (threadIdx.x == 0);
+    active = (threadIdx.x < 2);
   }
+  // normalisation check (sampler.py:66-72): lane 1 of the check block evaluates every level with
+  // trial bit 0 while lane 0 evaluates it with trial bit 1 - one pass gives both values
+  const bool trial0 = check_block && threadIdx.x == 1;
   const unsigned long long shot = (unsigned long long)(A.shot_offset + row);
   cptr img = (cptr)(uintptr_t)A.img;
 
@@ -305,11 +308,12 @@ k_sample4(Sample4Args A4) {
       const uint32_t bm = (li > 0) ? (1u << (bitpos & 31u)) : 0u;
       const bool hiw = (li > 0) && bitpos >= 32u;
       const bool lvl_fixed = (lvl[L4_FLAGS] & TSIMK_LFLAG_FIXED) != 0;
-      const int npass = (li > 0 && check_block) ? 2 : 1;  // block-uniform
-      float val[2] = {0.0f, 0.0f};
-      for (int pass = 0; pass < npass; ++pass) {
-        if (pass == 0) { if (hiw) x[1] |= bm; else x[0] |= bm; }
-        else { if (hiw) x[1] &= ~bm; else x[0] &= ~bm; }
+      if (li > 0) {
+        if (hiw) x[1] = trial0 ? (x[1] & ~bm) : (x[1] | bm);
+        else x[0] = trial0 ? (x[0] & ~bm) : (x[0] | bm);
+      }
+      float v1, v0 = 0.0f;
+      {
         float re, im;
         if (sparse && lvl_fixed) {
           // sparse-f tables: <= 4 set f bits in every lane of the block -> 4 column reads + the two
@@ -341,14 +345,17 @@ k_sample4(Sample4Args A4) {
           if (lvl_fixed) eval_level4<GT, NCH, true>(A.img, img, lvl, en, NCH * Tile4<GT>::kChunkBytes, lvl[L4_TABLES], lds_tab, re, im);
           else eval_level4<GT, NCH, false>(A.img, img, lvl, en, NCH * Tile4<GT>::kChunkBytes, lvl[L4_TABLES], lds_tab, re, im);
         }
-        const float v = cabs32(re, im);
-        if (pass == 0) val[0] = v; else val[1] = v;
+        v1 = cabs32(re, im);
       }
-      if (li == 0) { prev = val[0]; continue; }
+      if (check_block) {  // block-uniform
+        v0 = __shfl(v1, 1, 64);
+        v1 = __shfl(v1, 0, 64);
+      }
+      if (li == 0) { prev = v1; continue; }
       const uint32_t i = li - 1u;
-      const float p1 = val[0];
+      const float p1 = v1;
       if (check_block) {
-        const float norm = __fdiv_rn(__fadd_rn(val[1], p1), prev);   // sampler.py:71
+        const float norm = __fdiv_rn(__fadd_rn(v0, p1), prev);      // sampler.py:71
         maxdev = nanmax(maxdev, fabsf(__fsub_rn(norm, 1.0f)));      // sampler.py:72
       }
       const float u = uniform01(keys[2 * i], keys[2 * i + 1], shot);

@@ -58,6 +58,9 @@ struct SampleArgs {
   // holds row_count[32 * k] entries at row_index + k * row_list_cap and is served by the blocks with
   // blockIdx % row_lists == k (several counters instead of one: same-address atomics serialise)
   int row_lists, row_list_cap;
+  // list mode only: this launch serves the slots [row_slot_begin, row_slot_end) of every list
+  // (row_slot_end == 0: to the end) - lets two kernels split the lists between them
+  int row_slot_begin, row_slot_end;
   // normalisation-check row (sampler.py:66-72).  Default: in-batch shot 0, or the first listed row
   // when a row list is given.  check_row != nullptr: the listed row whose index equals *check_row
   // (two-pass launches: the list is unordered).  no_check != 0: nobody.
@@ -579,7 +582,7 @@ __global__ void __launch_bounds__(256) k_sample(SampleArgs A) {
   if (A.row_index) {
     if (A.row_lists > 1) {
       const uint32_t k = blockIdx.x % (uint32_t)A.row_lists;
-      slot = (long long)(blockIdx.x / (uint32_t)A.row_lists) * nthr + threadIdx.x;
+      slot = (long long)(blockIdx.x / (uint32_t)A.row_lists) * nthr + threadIdx.x + A.row_slot_begin;
       if (slot >= (long long)A.row_count[32u * k]) return;
       row = A.row_index[(size_t)k * A.row_list_cap + slot];
     } else {

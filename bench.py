@@ -168,6 +168,7 @@ def main() -> None:
     ap.add_argument("--config", default="C2")
     ap.add_argument("--p-bit", type=float, default=None, help="override the per-bit fire probability of the synthetic f batch (experiments only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-full-leg", action="store_true", help="skip the extra timing of the full kernel alone (profiling runs)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
 
@@ -271,8 +272,26 @@ def main() -> None:
         dist.barrier()
         torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    stages = hp.profile_read_stages()
     kern_ms, launches = hp.profile_read(reset=True)
     hp.profile_enable(False)
+
+    # the full kernel alone (pattern tables off), a few steps: the rate on inputs where no shot is
+    # tabulated, and the quantity earlier rounds reported
+    full_only = None
+    if N == 1 and info.get("pattern_tables") and not use_dist and not args.no_full_leg:
+        hp_full = backend.HipProgram(program, device=local_rank, pattern_tables=False)
+        for _ in range(2):
+            hp_full.sample_batch_device(d_f.ptr, B, num_f, key, d_out.ptr, shot_offset=shot_offset)
+        hp_full.synchronize()
+        hp_full.profile_enable(True)
+        hp_full.profile_read(reset=True)
+        for _ in range(5):
+            hp_full.sample_batch_device(d_f.ptr, B, num_f, key, d_out.ptr, shot_offset=shot_offset)
+        fms, fl = hp_full.profile_read(reset=True)
+        hp_full.profile_enable(False)
+        full_only = {"kernel": "tsimk::k_sample4" if hp_full.info().get("chunk_table_kernel") else "tsimk::k_sample",
+                     "kernel_avg_ms": fms / max(fl, 1), "shots_per_s": B / (fms / max(fl, 1) * 1e-3), "launches": fl}
 
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
@@ -287,6 +306,12 @@ def main() -> None:
         ops_per_shot = algorithmic_ops_per_shot(program)
         achieved_gbs = bytes_per_shot * B / avg_kernel_s / 1e9
         achieved_tops = ops_per_shot * B / avg_kernel_s / 1e12
+        if info.get("pattern_tables"):
+            kernel_name = ("tsimk::k_sample_lw (pattern-table pass) + tsimk::k_sample4h (hard rows) + "
+                           "tsimk::k_sample4 (overflow rows)") if info.get("chunk_table_kernel") else \
+                "tsimk::k_sample_lw (pattern-table pass) + tsimk::k_sample (hard rows)"
+        else:
+            kernel_name = "tsimk::k_sample4 (LDS chunk tables)" if info.get("chunk_table_kernel") else "tsimk::k_sample"
         res = {
             "metric": "detector shots/sec, 35-qubit distillation circuit, 1/2/4/8 MI355X",
             "value": value,
@@ -301,7 +326,7 @@ def main() -> None:
             "dtype": "int32",
             "data": "synthetic",
             "config": {
-                "workload": f"{args.config}: 35-qubit distillation shape (SURVEY 8d), synthetic seeded program: "
+                "workload": f"{args.config}: {cfg.get('name', 'shape of SURVEY 8d')}, synthetic seeded program: "
                 f"{info['total_graphs']} stabiliser terms, {info['total_rows']} GF(2) rows, n_out={n_out}, "
                 f"num_f={num_f}, p_bit={cfg['p_bit']}",
                 "shots_per_step_per_gpu": B,
@@ -317,14 +342,18 @@ def main() -> None:
                 "frac": achieved_gbs / HBM_PEAK_GBS,
                 "traffic": pmc_traffic_bytes(args.config, B),
                 "traffic_unit": "bytes per launch, rocprofv3 PMC: 2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction)",
-                "kernel": "tsimk::k_sample4 (LDS chunk tables)" if info.get("chunk_table_kernel") else "tsimk::k_sample",
+                "kernel": kernel_name,
                 "kernel_avg_ms": avg_kernel_s * 1e3,
                 "launches": launches,
+                "stage_avg_ms": {k: v / max(launches, 1) for k, v in stages.items()},
                 "algorithmic_bytes_per_shot": bytes_per_shot,
-                "note": "fused kernel is integer-VALU bound, not HBM bound (DESIGN.md); see `valu`",
+                "note": "achieved = algorithmic bytes of one launch / HIP-event time of the launch (all of its kernels, "
+                "gaps included). The work is integer-VALU / latency bound, not HBM bound (DESIGN.md section 3.5); see `valu`",
             },
             "valu": valu_block(ops_per_shot, B, avg_kernel_s, args.config),
         }
+        if full_only is not None:
+            res["full_kernel_only"] = full_only
         if N == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(program, cfg, args.cpu_seconds)
     if use_dist:

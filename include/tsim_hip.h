@@ -245,6 +245,9 @@ int tsim_profile_enable(tsim_program *p, int32_t on);
 /* Sum of kernel durations (ms) and number of launches since the last reset;
  * synchronises the stream.                                                   */
 int tsim_profile_read(tsim_program *p, double *kernel_ms, int64_t *launches, int32_t reset);
+/* The same total split by kernel: [0] pattern-table pass (k_sample_lw), [1] hard-row kernel
+ * (k_sample4h), [2] full kernel (k_sample4 / k_sample); call before a resetting tsim_profile_read. */
+int tsim_profile_read_stages(tsim_program *p, double stage_ms[3]);
 
 /* ---- introspection ---------------------------------------------------- */
 

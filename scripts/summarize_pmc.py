@@ -1,28 +1,42 @@
-"""Summarise rocprofv3 counter_collection CSVs (one or more passes) for the sampling kernel.
+"""Summarise rocprofv3 counter_collection CSVs (one or more passes) for the sampling kernels.
 
-usage: python scripts/summarize_pmc.py OUT.json DIR [DIR ...]
-Each DIR is a rocprofv3 -d output directory; per-launch averages of every counter found for
-kernels whose name contains "k_sample" are written to OUT.json (and printed).
+usage: python scripts/summarize_pmc.py OUT.json CONFIG SHOTS DIR [DIR ...]
+Each DIR is a rocprofv3 -d output directory.  For every kernel whose name contains "k_sample" the
+per-invocation average of every counter is computed; OUT.json holds the PER-LAUNCH totals (sum over
+the kernels of one sampling launch: pattern-table pass + hard-row kernel + full kernel) at the top
+level - the keys bench.py reads - and the per-kernel averages under "_per_kernel".
 """
 import collections
 import csv
 import glob
 import json
+import re
 import sys
 
 
+def short(name):
+    m = re.search(r"tsimk::(k_\w+)", name)
+    return m.group(1) if m else name
+
+
 def main():
-    out, dirs = sys.argv[1], sys.argv[2:]
-    agg = collections.defaultdict(list)
+    out, config, shots, dirs = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4:]
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for d in dirs:
         for fn in glob.glob(f"{d}/*/*_counter_collection.csv"):
             for r in csv.DictReader(open(fn)):
                 if "k_sample" in r["Kernel_Name"]:
-                    agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
-                    kern = r["Kernel_Name"]
-    res = {k: sum(v) / len(v) for k, v in sorted(agg.items())}
-    res["_kernel"] = kern
-    res["_launches_per_counter"] = {k: len(v) for k, v in agg.items()}
+                    agg[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    per_kernel = {k: {c: sum(v) / len(v) for c, v in sorted(cs.items())} for k, cs in agg.items()}
+    total = collections.defaultdict(float)
+    for cs in per_kernel.values():
+        for c, v in cs.items():
+            total[c] += v
+    res = dict(sorted(total.items()))
+    res["_per_kernel"] = per_kernel
+    res["_invocations"] = {k: {c: len(v) for c, v in cs.items()} for k, cs in agg.items()}
+    res["_config"] = config
+    res["_shots"] = shots
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res, indent=1))
 

@@ -89,6 +89,7 @@ SYMBOLS: dict[str, tuple] = {
     "tsim_get_stream": (C.c_int, [_P, C.POINTER(_P)]),
     "tsim_profile_enable": (C.c_int, [_P, _I32]),
     "tsim_profile_read": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(_I64), _I32]),
+    "tsim_profile_read_stages": (C.c_int, [_P, C.POINTER(C.c_double)]),
     "tsim_program_info": (
         C.c_int,
         [_P, C.POINTER(_I32), C.POINTER(_I32), C.POINTER(_I64), C.POINTER(_I64), C.POINTER(_I64)],

@@ -298,6 +298,12 @@ class HipProgram:
         _lib.check(self._lib.tsim_profile_read(self._h, C.byref(ms), C.byref(n), 1 if reset else 0), "tsim_profile_read")
         return float(ms.value), int(n.value)
 
+    def profile_read_stages(self) -> dict:
+        """Kernel time (ms) since the last reset, split by kernel; call before ``profile_read``."""
+        st = (C.c_double * 3)()
+        _lib.check(self._lib.tsim_profile_read_stages(self._h, st), "tsim_profile_read_stages")
+        return {"pattern_pass": float(st[0]), "hard_rows": float(st[1]), "full_kernel": float(st[2])}
+
     # -- evaluate seam ----------------------------------------------------------
     def evaluate(self, component: int, level: int, param_vals: np.ndarray, *, exact: bool = False,
                  return_abs: bool = False):

@@ -131,6 +131,7 @@ struct tsim_program {
   int lw_request = -1;        // -1 default (on in TSIM_MODE_AUTO), 0 off, 1 on
   int lw_weight_cap = -1;     // -1 = TSIMK_LW_MAX_WEIGHT
   bool lw = false;            // tables built, pass 1 active
+  int lw_parity = 0;          // counter set of the next launch
   bool h_attr_set = false;    // k_sample4h: large dynamic LDS enabled
   int lw_off = 0;             // image offset of the LW component records
   int lw_direct_prog = 0;     // image offset of the direct-output gather program
@@ -145,6 +146,8 @@ struct tsim_program {
   // profiling
   bool profiling = false;
   std::vector<hipEvent_t> ev_pool;
+  std::vector<int> ev_tag;
+  double prof_stage_ms[4] = {0.0, 0.0, 0.0, 0.0};
   size_t ev_used = 0;
   double prof_ms = 0.0;
   long long prof_launches = 0;
@@ -986,8 +989,11 @@ static void launch_lw_build(const LwBuildArgs &a, long long lanes, hipStream_t s
 
 static int build_pattern_tables(tsim_program *p, const std::vector<long long> &npat) {
   HIP_TRY(hipMalloc((void **)&p->d_lw_tab, std::max<size_t>(16, (size_t)p->lw_bytes)));
-  HIP_TRY(hipMalloc((void **)&p->d_lw_ctl, (TSIMK_LW_LISTS + 1) * 128));
-  HIP_TRY(hipMemset(p->d_lw_ctl, 0, (TSIMK_LW_LISTS + 1) * 128));
+  // two counter sets used alternately: pass 1 of a launch resets the set of the next one
+  HIP_TRY(hipMalloc((void **)&p->d_lw_ctl, 2 * (TSIMK_LW_LISTS + 1) * 128));
+  HIP_TRY(hipMemset(p->d_lw_ctl, 0, 2 * (TSIMK_LW_LISTS + 1) * 128));
+  for (int st = 0; st < 2; ++st)
+    HIP_TRY(hipMemset(p->d_lw_ctl + st * (TSIMK_LW_LISTS + 1) * 32 + TSIMK_LW_LISTS * 32, 0xFF, 4));
   long long tab_off = 0;
   for (size_t ci = 0; ci < p->comps.size(); ++ci) {
     const HostComponent &c = p->comps[ci];
@@ -1378,23 +1384,34 @@ static int ensure_scratch(tsim_program *p, int slot, size_t bytes) {
   return 0;
 }
 
-static int prof_event(tsim_program *p, hipStream_t s) {
+// stage tags of the profiling events: 0 opens a launch, the others close a stage
+enum { PROF_BEGIN = 0, PROF_PASS1 = 1, PROF_HARD = 2, PROF_FULL = 3 };
+
+static int prof_event(tsim_program *p, hipStream_t s, int tag) {
   if (p->ev_used == p->ev_pool.size()) {
     hipEvent_t e;
     HIP_TRY(hipEventCreate(&e));
     p->ev_pool.push_back(e);
+    p->ev_tag.push_back(0);
   }
+  p->ev_tag[p->ev_used] = tag;
   HIP_TRY(hipEventRecord(p->ev_pool[p->ev_used++], s));
   return 0;
 }
 
 static int prof_drain(tsim_program *p) {
-  for (size_t i = 0; i + 1 < p->ev_used; i += 2) {
-    HIP_TRY(hipEventSynchronize(p->ev_pool[i + 1]));
+  size_t begin = 0;
+  for (size_t i = 0; i < p->ev_used; ++i) {
+    if (p->ev_tag[i] == PROF_BEGIN) { begin = i; continue; }
+    HIP_TRY(hipEventSynchronize(p->ev_pool[i]));
     float ms = 0.f;
-    HIP_TRY(hipEventElapsedTime(&ms, p->ev_pool[i], p->ev_pool[i + 1]));
-    p->prof_ms += ms;
-    p->prof_launches += 1;
+    HIP_TRY(hipEventElapsedTime(&ms, p->ev_pool[i - 1], p->ev_pool[i]));
+    p->prof_stage_ms[p->ev_tag[i]] += ms;
+    if (i + 1 == p->ev_used || p->ev_tag[i + 1] == PROF_BEGIN) {  // last event of this launch
+      HIP_TRY(hipEventElapsedTime(&ms, p->ev_pool[begin], p->ev_pool[i]));
+      p->prof_ms += ms;
+      p->prof_launches += 1;
+    }
   }
   p->ev_used = 0;
   return 0;
@@ -1412,15 +1429,23 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
   if (!d_out) return fail(TSIM_EINVAL, "out buffer is NULL");
   // per-output subkeys: key, subkey = split(key) once per output, threaded through the
   // components in processing order (sampler.py:74,147-148)
-  if (p->total_keys > 0) {
-    hipLaunchKernelGGL(k_keygen, dim3(1), dim3(p->lw ? 128 : 1), 0, s, key_hi, key_lo, p->total_keys, p->d_keys,
-                       p->lw ? p->d_lw_ctl : (uint32_t *)nullptr, (int)TSIMK_LW_LISTS);
-    HIP_TRY(hipGetLastError());
-  } else if (p->lw) {
-    HIP_TRY(hipMemsetAsync(p->d_lw_ctl, 0, TSIMK_LW_LISTS * 128, s));
-    HIP_TRY(hipMemsetAsync(p->d_lw_ctl + 32 * TSIMK_LW_LISTS, 0xFF, 4, s));
-  }
   SampleArgs a{};
+  if (p->total_keys > 0 && p->total_keys <= TSIMK_INLINE_KEYS) {
+    uint32_t k0 = key_hi, k1 = key_lo;
+    for (int i = 0; i < p->total_keys; ++i) {
+      uint32_t a0 = 0u, a1 = 0u, b0 = 0u, b1 = 1u;
+      threefry2x32(k0, k1, a0, a1);  // split(key)[0] -> next key
+      threefry2x32(k0, k1, b0, b1);  // split(key)[1] -> this output's subkey
+      a.inline_keys[2 * i] = b0;
+      a.inline_keys[2 * i + 1] = b1;
+      k0 = a0;
+      k1 = a1;
+    }
+    a.n_inline_keys = p->total_keys;
+  } else if (p->total_keys > 0) {
+    hipLaunchKernelGGL(k_keygen, dim3(1), dim3(1), 0, s, key_hi, key_lo, p->total_keys, p->d_keys);
+    HIP_TRY(hipGetLastError());
+  }
   a.img = p->d_img;
   a.f = d_f;
   a.out = d_out;
@@ -1444,7 +1469,7 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
   a.no_check = 0;
   if (num_f == 0) a.WF = 0;
   if (B > 0x7FFFFFFFll * 64) return fail(TSIM_ENOTSUP, "batch too large");
-  if (p->profiling) { int r = prof_event(p, s); if (r) return r; }
+  if (p->profiling) { int r = prof_event(p, s, PROF_BEGIN); if (r) return r; }
   // the normalisation check applies to in-batch shot 0 (sampler.py:66-72) or the first listed row
   bool has_check = (shot_offset == 0 || d_row_index);
   long long B2 = B;  // slots per row list of the full kernel's launch
@@ -1465,18 +1490,22 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
     l.direct_chunks = p->lw_direct_chunks;
     l.has_check = has_check ? 1 : 0;
     l.hard_index = (uint32_t *)p->scratch[4];
-    l.ctl = p->d_lw_ctl;
+    uint32_t *ctl = p->d_lw_ctl + p->lw_parity * (TSIMK_LW_LISTS + 1) * 32;
+    l.ctl = ctl;
+    l.ctl_next = p->d_lw_ctl + (p->lw_parity ^ 1) * (TSIMK_LW_LISTS + 1) * 32;
+    p->lw_parity ^= 1;
     l.list_cap = (int)list_cap;
     const size_t lds1 = (size_t)(2 * a.WF + 2 * a.WO) * blk1 * 4;
     if (lds1 > 64 * 1024) return fail(TSIM_ENOTSUP, "num_f + num_outputs too large for LDS staging (%zu B)", lds1);
     hipLaunchKernelGGL(k_sample_lw, dim3((unsigned)grid1), dim3(blk1), lds1, s, l);
     HIP_TRY(hipGetLastError());
+    if (p->profiling) { int r = prof_event(p, s, PROF_PASS1); if (r) return r; }
     // pass 2 below runs on the hard lists; the check row was forced into one of them
     a.row_index = l.hard_index;
-    a.row_count = p->d_lw_ctl;
+    a.row_count = ctl;
     a.row_lists = TSIMK_LW_LISTS;
     a.row_list_cap = (int)list_cap;
-    a.check_row = has_check ? p->d_lw_ctl + 32 * TSIMK_LW_LISTS : nullptr;
+    a.check_row = has_check ? ctl + 32 * TSIMK_LW_LISTS : nullptr;
     a.no_check = has_check ? 0 : 1;
     B2 = list_cap;
   } else if (!has_check) {
@@ -1529,6 +1558,7 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
           default: return fail(TSIM_ESTATE, "bad chunk count %d", p->v4_max_nch);
         }
         HIP_TRY(hipGetLastError());
+        if (p->profiling) { int r = prof_event(p, s, PROF_HARD); if (r) return r; }
         p->h_attr_set = true;
         a4.has_check = 0;  // done by the kernel above
         a4.s.no_check = 1;
@@ -1545,7 +1575,7 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
       default: hipLaunchKernelGGL((k_sample4<4, 16>), dim3((unsigned)grid4), dim3(blk), lds4, s, a4); break;
     }
     HIP_TRY(hipGetLastError());
-    if (p->profiling) { int r = prof_event(p, s); if (r) return r; }
+    if (p->profiling) { int r = prof_event(p, s, PROF_FULL); if (r) return r; }
     return 0;
   }
   int wmax = 1;
@@ -1562,7 +1592,7 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
     default: return fail(TSIM_ENOTSUP, "unsupported word count %d", wmax);
   }
   HIP_TRY(hipGetLastError());
-  if (p->profiling) { int r = prof_event(p, s); if (r) return r; }
+  if (p->profiling) { int r = prof_event(p, s, PROF_FULL); if (r) return r; }
   return 0;
 }
 
@@ -1973,6 +2003,21 @@ extern "C" int tsim_profile_read(tsim_program *p, double *kernel_ms, int64_t *la
   if (int r = prof_drain(p)) return r;
   if (kernel_ms) *kernel_ms = p->prof_ms;
   if (launches) *launches = p->prof_launches;
-  if (reset) { p->prof_ms = 0.0; p->prof_launches = 0; }
+  if (reset) {
+    p->prof_ms = 0.0;
+    p->prof_launches = 0;
+    for (double &v : p->prof_stage_ms) v = 0.0;
+  }
+  return TSIM_OK;
+}
+
+extern "C" int tsim_profile_read_stages(tsim_program *p, double stage_ms[3]) {
+  if (int r = need_final(p)) return r;
+  if (int r = set_device(p)) return r;
+  if (!stage_ms) return fail(TSIM_EINVAL, "NULL argument");
+  if (int r = prof_drain(p)) return r;
+  stage_ms[0] = p->prof_stage_ms[PROF_PASS1];
+  stage_ms[1] = p->prof_stage_ms[PROF_HARD];
+  stage_ms[2] = p->prof_stage_ms[PROF_FULL];
   return TSIM_OK;
 }

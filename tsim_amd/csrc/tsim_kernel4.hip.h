@@ -280,7 +280,7 @@ k_sample4(Sample4Args A4) {
     cptr fsel = img + comp[C_FSEL];
     cptr levels = img + comp[C4_LEVELS];
     cptr outpos = img + comp[C_OUTPOS];
-    const uint32_t *keys = A.subkeys + 2 * comp[C_KEYBASE];
+    const uint32_t keybase = comp[C_KEYBASE];
 
     uint32_t x[2] = {0u, 0u};
 #pragma unroll
@@ -358,7 +358,7 @@ k_sample4(Sample4Args A4) {
         const float norm = __fdiv_rn(__fadd_rn(v0, p1), prev);      // sampler.py:71
         maxdev = nanmax(maxdev, fabsf(__fsub_rn(norm, 1.0f)));      // sampler.py:72
       }
-      const float u = uniform01(keys[2 * i], keys[2 * i + 1], shot);
+      const float u = uniform01(subkey(A, keybase + i, 0), subkey(A, keybase + i, 1), shot);
       const bool bit = u < __fdiv_rn(p1, prev);
       if (hiw) x[1] = bit ? (x[1] | bm) : (x[1] & ~bm);
       else x[0] = bit ? (x[0] | bm) : (x[0] & ~bm);

@@ -66,7 +66,17 @@ struct SampleArgs {
   // (two-pass launches: the list is unordered).  no_check != 0: nobody.
   const uint32_t *check_row;
   int no_check;
+  // per-output subkeys computed by the host and passed in the kernel arguments (programs with at
+  // most TSIMK_INLINE_KEYS compiled outputs): no key-generation kernel, no shared key buffer
+  int n_inline_keys;
+  uint32_t inline_keys[2 * 32];
 };
+#define TSIMK_INLINE_KEYS 32
+
+// subkey word j (0/1) of compiled output `o` (sampler.py:74,147-148)
+__device__ __forceinline__ uint32_t subkey(const SampleArgs &A, uint32_t o, uint32_t j) {
+  return A.n_inline_keys ? A.inline_keys[2u * o + j] : A.subkeys[2u * o + j];
+}
 
 struct EvalArgs {
   const uint32_t *img;
@@ -144,9 +154,9 @@ __device__ __forceinline__ float cabs32(float re, float im) {
 // ---------------------------------------------------------------------------
 // Threefry-2x32-20 (jax.random, threefry_partitionable)
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
+__host__ __device__ __forceinline__ uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
 
-__device__ __forceinline__ void threefry2x32(uint32_t k0, uint32_t k1, uint32_t &x0, uint32_t &x1) {
+__host__ __device__ __forceinline__ void threefry2x32(uint32_t k0, uint32_t k1, uint32_t &x0, uint32_t &x1) {
   const uint32_t k2 = k0 ^ k1 ^ 0x1BD11BDAu;
   x0 += k0; x1 += k1;
 #define TF_R(r) x0 += x1; x1 = rotl32(x1, r); x1 ^= x0;
@@ -512,7 +522,7 @@ __device__ __forceinline__ void run_component(const SampleArgs &A, cptr img, cpt
   cptr fsel = img + comp[C_FSEL];
   cptr levels = img + comp[C_LEVELS];
   cptr outpos = img + comp[C_OUTPOS];
-  const uint32_t *keys = A.subkeys + 2 * comp[C_KEYBASE];
+  const uint32_t keybase = comp[C_KEYBASE];
 
   // K1: gather the component's f bits (sampler.py:48) from the LDS-staged row
   uint32_t x[W];
@@ -554,7 +564,7 @@ __device__ __forceinline__ void run_component(const SampleArgs &A, cptr img, cpt
       maxdev = nanmax(maxdev, fabsf(__fsub_rn(norm, 1.0f)));      // sampler.py:72
     }
     // sampler.py:74-79
-    const float u = uniform01(keys[2 * i], keys[2 * i + 1], shot);
+    const float u = uniform01(subkey(A, keybase + i, 0), subkey(A, keybase + i, 1), shot);
     const bool bit = u < __fdiv_rn(p1, prev);
 #pragma unroll
     for (int w = 0; w < W; ++w)
@@ -723,11 +733,7 @@ __global__ void __launch_bounds__(256) k_direct_filter(FilterArgs A) {
 // output, threaded through the components in processing order
 // (sampler.py:74,147-148).  A sequential chain, one thread, stream-ordered.
 // ---------------------------------------------------------------------------
-__global__ void k_keygen(uint32_t k0, uint32_t k1, int n, uint32_t *__restrict__ subkeys,
-                         uint32_t *__restrict__ counters, int n_counters) {
-  // two-pass launches: reset the hard-row counters (one per 128 bytes) and the check row
-  if (counters && blockIdx.x == 0 && (int)threadIdx.x <= n_counters)
-    counters[32u * threadIdx.x] = ((int)threadIdx.x == n_counters) ? 0xFFFFFFFFu : 0u;  // last: "no check row"
+__global__ void k_keygen(uint32_t k0, uint32_t k1, int n, uint32_t *__restrict__ subkeys) {
   if (blockIdx.x != 0 || threadIdx.x != 0) return;
   for (int i = 0; i < n; ++i) {
     uint32_t a0 = 0u, a1 = 0u, b0 = 0u, b1 = 1u;

@@ -136,6 +136,7 @@ struct LwArgs {
   uint32_t *hard_index;   // out: TSIMK_LW_LISTS sub-lists of list_cap rows that need the full kernel
   uint32_t *ctl;          // ctl[32 k] = entries of list k (zeroed by the caller), ctl[32 LISTS] = check row
   int list_cap;
+  uint32_t *ctl_next;     // the counter set of the NEXT launch: reset here (nobody else touches it now)
 };
 
 __global__ void __launch_bounds__(1024) k_sample_lw(LwArgs L) {
@@ -154,6 +155,8 @@ __global__ void __launch_bounds__(1024) k_sample_lw(LwArgs L) {
   uint32_t *lds_f = tsimk_lds + threadIdx.x;                // [WF32][nthr]
   uint32_t *lds_o = tsimk_lds + WF32 * nthr + threadIdx.x;  // [WO32][nthr]
 
+  if (blockIdx.x == 0 && threadIdx.x <= TSIMK_LW_LISTS)
+    L.ctl_next[32u * threadIdx.x] = (threadIdx.x == TSIMK_LW_LISTS) ? 0xFFFFFFFFu : 0u;  // last: "no check row"
   bool hard = false;
   uint32_t o0 = 0, o1 = 0;  // output words 0 and 1 (the LDS column holds the others)
   if (active) {
@@ -190,14 +193,14 @@ __global__ void __launch_bounds__(1024) k_sample_lw(LwArgs L) {
       const uint32_t pat = base + b0 + (cnt >= 2 ? lw_binom2(b1) : 0u) + (cnt >= 3 ? lw_binom3(b2) : 0u);
       const uint32_t n_out = rec[LW_NOUT];
       cptr outpos = img + rec[LW_OUTPOS];
-      const uint32_t *keys = A.subkeys + 2 * rec[LW_KEYBASE];
+      const uint32_t keybase = rec[LW_KEYBASE];
       const float *thr = L.tab + rec[LW_TAB] + ((size_t)pat << n_out);
       uint32_t node = 1u;
       for (uint32_t i = 0; i < n_out; ++i) {
 #if LW_EXP == 3
         const float u = __uint_as_float((((uint32_t)shot * 2654435761u + i) >> 9) | 0x3F800000u) - 1.0f;
 #else
-        const float u = uniform01(keys[2 * i], keys[2 * i + 1], shot);  // sampler.py:74-75
+        const float u = uniform01(subkey(A, keybase + i, 0), subkey(A, keybase + i, 1), shot);  // sampler.py:74-75
 #endif
 #if LW_EXP == 2
         const bool bit = u < 0.5f;

@@ -258,9 +258,10 @@ def synth_f(B: int, num_f: int, p_bit: float, seed: int = 42) -> np.ndarray:
 
 CONFIGS = {
     # d=3 rotated surface code, Clifford only: pure direct path
-    "C1": dict(num_f=24, n_direct=24, components=[], shots=1000, batch=1000, p_bit=0.008, seed=0),
+    "C1": dict(name="d=3 surface code, Clifford only (direct path)", num_f=24, n_direct=24, components=[], shots=1000, batch=1000, p_bit=0.008, seed=0),
     # 35-qubit distillation: 15 direct detectors + one 5-output component, sum G = 148
     "C2": dict(
+        name="35-qubit distillation shape (SURVEY 8d)",
         num_f=64,
         n_direct=15,
         components=[dict(n=5, F=32, G=[8, 16, 24, 28, 32, 40])],
@@ -271,6 +272,7 @@ CONFIGS = {
     ),
     # 85-qubit distillation: sum G = 147
     "C3": dict(
+        name="85-qubit distillation shape (SURVEY 8d)",
         num_f=104,
         n_direct=40,
         components=[dict(n=5, F=48, G=[7, 16, 24, 28, 32, 40])],
@@ -281,6 +283,7 @@ CONFIGS = {
     ),
     # d=3 cultivation: three components, sum G = 1024, T up to 64
     "C4": dict(
+        name="d=3 cultivation shape (SURVEY 8d)",
         num_f=64,
         n_direct=10,
         components=[
@@ -295,6 +298,7 @@ CONFIGS = {
     ),
     # d=5 surface code + injected T: wide f (W=4), few graphs
     "C5": dict(
+        name="d=5 surface code + T shape (SURVEY 8d)",
         num_f=320,
         n_direct=118,
         components=[dict(n=3, F=200, G=[1, 2, 2, 3], density=0.08)],

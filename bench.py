@@ -22,6 +22,7 @@ all sampling arithmetic is in ``tsim_amd/libtsim_hip.so``.
 from __future__ import annotations
 
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -162,8 +163,8 @@ def cpu_baseline(program, cfg, seconds: float = 15.0) -> dict:
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--shots", type=int, default=1_000_000, help="shots per step per GPU")
     ap.add_argument("--config", default="C2")
     ap.add_argument("--p-bit", type=float, default=None, help="override the per-bit fire probability of the synthetic f batch (experiments only)")
@@ -212,43 +213,75 @@ def main() -> None:
     hp.h2d(d_f, f_packed)
     del f
 
+    # Pipeline of depth NSLOT (tsim_sample_batch_device_begin/_end): step i's first pass runs on the
+    # engine's stream while the second passes (hard rows, latency-bound) of steps i-1.. run on side
+    # streams; one output buffer per slot.  For N > 1 the RCCL gather of step i is issued when its
+    # slot is joined (async, on the engine's stream), so it overlaps the kernels of later steps too.
+    NSLOT = max(1, min(backend.HipProgram.PIPELINE_SLOTS, int(os.environ.get("TSIM_BENCH_SLOTS", "4"))))
     if use_dist:
-        # Two output buffers: the RCCL gather of step i (async, ordered after kernel i on the
-        # engine's own stream) overlaps the kernel of step i+1.
         dev = torch.device("cuda", local_rank)
         ext = torch.cuda.ExternalStream(hp.stream_ptr(), device=dev)
-        out_bufs = [torch.zeros((B, WO * 8), dtype=torch.uint8, device=dev) for _ in range(2)]
-        gather_lists = [[torch.empty_like(out_bufs[0]) for _ in range(N)] if rank == 0 else None for _ in range(2)]
-        pending = [None, None]
+        out_bufs = [torch.zeros((B, WO * 8), dtype=torch.uint8, device=dev) for _ in range(NSLOT)]
+        out_ptrs = [t.data_ptr() for t in out_bufs]
+        gather_lists = [[torch.empty_like(out_bufs[0]) for _ in range(N)] if rank == 0 else None for _ in range(NSLOT)]
     else:
-        d_out = hp.malloc(B * WO * 8)
+        d_outs = [hp.malloc(B * WO * 8) for _ in range(NSLOT)]
+        out_ptrs = [d.ptr for d in d_outs]
+        d_out = d_outs[0]
+    pending = [None] * NSLOT   # gather handle of the slot's previous step
+    inflight = []              # slots begun, not yet ended (oldest first)
 
     key = prng.key(cfg["seed"])
     shot_offset = rank * B
     step_no = [0]
 
-    def step():
-        nonlocal key
-        key, sub = prng.split(key)  # one host split per batch (sampler.py:399)
-        if not use_dist:
-            hp.sample_batch_device(d_f.ptr, B, num_f, sub, d_out.ptr, shot_offset=shot_offset)
-            return
-        b = step_no[0] & 1
-        step_no[0] += 1
-        with torch.cuda.stream(ext):
-            if pending[b] is not None:
-                pending[b].wait()  # the engine's stream waits until gather(i-2) released buffer b
-                pending[b] = None
-            hp.sample_batch_device(d_f.ptr, B, num_f, sub, out_bufs[b].data_ptr(), shot_offset=shot_offset)
+    begin_fn = hp._lib.tsim_sample_batch_device_begin
+    d_f_ptr = d_f.ptr
+
+    def join(b):
+        hp.sample_batch_device_end(b)
+        if use_dist:
             pending[b] = dist.gather(out_bufs[b], gather_lists[b], dst=0, async_op=True)
 
+    def step():
+        nonlocal key
+        key, sub = hp.split_key(key)  # one host split per batch (sampler.py:399)
+        b = step_no[0] % NSLOT
+        step_no[0] += 1
+        if not use_dist:
+            # _begin on a slot whose previous step was not joined is ordered after that step's second
+            # pass by the library (include/tsim_hip.h), so one call per step is enough here
+            rc = begin_fn(hp._h, b, d_f_ptr, B, num_f, sub[0], sub[1], shot_offset, out_ptrs[b], None, None)
+            if rc < 0:
+                raise RuntimeError(f"tsim_sample_batch_device_begin failed ({rc})")
+            if b not in inflight:
+                inflight.append(b)
+            return
+        with torch.cuda.stream(ext):
+            if b in inflight:  # the slot's previous step: join it (and start its gather) first
+                while inflight:
+                    o = inflight.pop(0)
+                    join(o)
+                    if o == b:
+                        break
+            if pending[b] is not None:
+                pending[b].wait()  # the engine's stream waits until the gather released buffer b
+                pending[b] = None
+            hp.sample_batch_device_begin(b, d_f.ptr, B, num_f, sub, out_ptrs[b], shot_offset=shot_offset)
+            inflight.append(b)
+            # keep at most NSLOT - 1 steps un-joined so that the next step always finds a free slot
+            while len(inflight) > NSLOT - 1:
+                join(inflight.pop(0))
+
     def drain():
-        if use_dist:
-            with torch.cuda.stream(ext):
-                for b in range(2):
-                    if pending[b] is not None:
-                        pending[b].wait()
-                        pending[b] = None
+        ctx = torch.cuda.stream(ext) if use_dist else contextlib.nullcontext()
+        with ctx:
+            while inflight:
+                join(inflight.pop(0))
+            for b in range(NSLOT):
+                if pending[b] is not None:
+                    pending[b].wait()
+                    pending[b] = None
 
     def fence():
         drain()
@@ -260,11 +293,16 @@ def main() -> None:
     for _ in range(args.warmup):
         step()
     fence()
-    hp.profile_enable(True)
+    # HIP events around the dominant kernel only (level 2): timing events drain the queue they are
+    # recorded on, and bracketing every side-stream kernel costs ~10 us per pipelined step
+    PROF_EVERY = 8  # bracket one launch in 8: a timing event costs a queue drain (~5 us)
+    hp.profile_set_sampling(PROF_EVERY)
+    hp.profile_enable(0 if os.environ.get("TSIM_BENCH_NO_PROFILE") == "1" else 2)
     hp.profile_read(reset=True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    host_enqueue_s = time.perf_counter() - t0  # host time to enqueue all steps (before draining)
     drain()
     hp.synchronize()
     torch.cuda.synchronize()
@@ -275,6 +313,22 @@ def main() -> None:
     stages = hp.profile_read_stages()
     kern_ms, launches = hp.profile_read(reset=True)
     hp.profile_enable(False)
+
+    # untimed: a few more steps with every kernel bracketed, for the per-kernel split and the
+    # first-kernel-start -> last-kernel-end latency of one launch
+    detail = None
+    hp.profile_set_sampling(1)
+    if info.get("pattern_tables"):
+        hp.profile_enable(1)
+        for _ in range(8):
+            step()
+        drain()
+        hp.synchronize()
+        dst = hp.profile_read_stages()
+        dms, dl = hp.profile_read(reset=True)
+        hp.profile_enable(False)
+        detail = {"stage_avg_ms": {k: v / max(dl, 1) for k, v in dst.items()}, "launch_latency_ms": dms / max(dl, 1),
+                  "launches": dl, "note": "separate untimed steps with every kernel bracketed by HIP events"}
 
     # the full kernel alone (pattern tables off), a few steps: the rate on inputs where no shot is
     # tabulated, and the quantity earlier rounds reported
@@ -301,15 +355,23 @@ def main() -> None:
     if rank == 0:
         total_shots = float(B) * N * args.steps
         value = total_shots / elapsed
-        avg_kernel_s = (kern_ms / max(launches, 1)) * 1e-3
+        launch_s = (kern_ms / max(launches, 1)) * 1e-3  # first kernel start -> last kernel end of one launch
+        # dominant kernel: with pattern tables the first pass (k_sample_lw) touches every row and moves
+        # all the algorithmic bytes; the hard-row kernels of a launch overlap the first pass of the
+        # following launches (pipelined slots).  Without tables: the one full kernel.
+        if info.get("pattern_tables"):
+            avg_kernel_s = stages["pattern_pass"] / max(launches, 1) * 1e-3
+        else:
+            avg_kernel_s = launch_s
+        if launches == 0:  # profiling events disabled (experiments): fall back to the step time
+            avg_kernel_s = launch_s = elapsed / args.steps
         bytes_per_shot = algorithmic_bytes_per_shot(num_f, n_out)
         ops_per_shot = algorithmic_ops_per_shot(program)
         achieved_gbs = bytes_per_shot * B / avg_kernel_s / 1e9
         achieved_tops = ops_per_shot * B / avg_kernel_s / 1e12
         if info.get("pattern_tables"):
-            kernel_name = ("tsimk::k_sample_lw (pattern-table pass) + tsimk::k_sample4h (hard rows) + "
-                           "tsimk::k_sample4 (overflow rows)") if info.get("chunk_table_kernel") else \
-                "tsimk::k_sample_lw (pattern-table pass) + tsimk::k_sample (hard rows)"
+            kernel_name = "tsimk::k_sample_lw (pattern-table pass; hard rows: k_sample4h + k_sample4 on side streams)" \
+                if info.get("chunk_table_kernel") else "tsimk::k_sample_lw (pattern-table pass; hard rows: k_sample on side streams)"
         else:
             kernel_name = "tsimk::k_sample4 (LDS chunk tables)" if info.get("chunk_table_kernel") else "tsimk::k_sample"
         res = {
@@ -345,10 +407,15 @@ def main() -> None:
                 "kernel": kernel_name,
                 "kernel_avg_ms": avg_kernel_s * 1e3,
                 "launches": launches,
-                "stage_avg_ms": {k: v / max(launches, 1) for k, v in stages.items()},
+                "hip_event_sampling": f"1 launch in {PROF_EVERY} bracketed",
+                "all_kernels": detail,
+                "pipeline_slots": NSLOT,
+                "host_enqueue_ms_per_step": host_enqueue_s / args.steps * 1e3,
                 "algorithmic_bytes_per_shot": bytes_per_shot,
-                "note": "achieved = algorithmic bytes of one launch / HIP-event time of the launch (all of its kernels, "
-                "gaps included). The work is integer-VALU / latency bound, not HBM bound (DESIGN.md section 3.5); see `valu`",
+                "note": "achieved = algorithmic bytes of one launch / HIP-event time of the dominant kernel (k_sample_lw when "
+                "pattern tables are active: it reads every f row and writes every tabulated row; the hard-row kernels "
+                "run on side streams under the next launches). Integer-VALU / latency bound, not HBM bound "
+                "(DESIGN.md section 3.5); see `valu` and `stage_avg_ms`",
             },
             "valu": valu_block(ops_per_shot, B, avg_kernel_s, args.config),
         }

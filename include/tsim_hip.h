@@ -172,6 +172,23 @@ int tsim_sample_batch_device(tsim_program *p, const uint64_t *d_f, int64_t B, in
                              uint64_t *d_out, float *d_max_norm_dev, void *stream);
 
 /*
+ * Pipelined form of tsim_sample_batch_device.  With the pattern tables active a launch is two
+ * passes; the second one (a few thousand "hard" rows, latency-bound) does not need the GPU to
+ * itself.  _begin enqueues the first pass on `stream` and the second pass on a side stream owned
+ * by `slot` (0 .. TSIM_PIPELINE_SLOTS-1), so that it overlaps the first pass of later launches;
+ * _end makes `stream` wait for the slot's second pass - only after _end (and the usual stream
+ * ordering) are d_out / d_max_norm_dev complete.  The caller must not reuse the buffers of a slot
+ * (d_f, d_out, d_max_norm_dev) for anything else between _begin and _end; a _begin on a slot that
+ * was not ended is ordered after that slot's previous launch.  Results are identical to the
+ * serial call.  Programs without pattern tables run entirely on `stream` (_end is then a no-op).
+ */
+#define TSIM_PIPELINE_SLOTS 4
+int tsim_sample_batch_device_begin(tsim_program *p, int32_t slot, const uint64_t *d_f, int64_t B,
+                                   int32_t num_f, uint32_t key_hi, uint32_t key_lo, int64_t shot_offset,
+                                   uint64_t *d_out, float *d_max_norm_dev, void *stream);
+int tsim_sample_batch_device_end(tsim_program *p, int32_t slot, void *stream);
+
+/*
  * Device-side post-selection (the shot-skipping of src/tsim/sampler.py:422-545, done in HBM):
  *   tsim_postselect_device writes every row's DIRECT output bits to d_out (compiled columns 0),
  *   tests ((row ^ ref) & mask) != 0 per row (mask/ref: packed uint64 [ceil(num_outputs/64)] in final
@@ -240,8 +257,17 @@ int tsim_synchronize(tsim_program *p);                      /* handle's stream *
 /* the handle's hipStream_t, e.g. to order a collective after the sampling kernel */
 int tsim_get_stream(tsim_program *p, void **stream);
 
-/* HIP-event timing of the sampling kernel launches on the handle's stream.   */
+/* Host helper, no device involved: `new_key, subkey = jax.random.split(key)` for the threefry2x32
+ * key layout (the once-per-batch split of sampler.py:399); out = {new_hi, new_lo, sub_hi, sub_lo}. */
+void tsim_key_split(uint32_t key_hi, uint32_t key_lo, uint32_t out[4]);
+
+/* HIP-event timing of the sampling kernel launches on the handle's stream.
+ * on = 1: every kernel of a launch; on = 2: only the first kernel of a launch (the pattern-table
+ * pass when tables are active) - timing events drain the queue they are recorded on, which costs
+ * pipelined launches ~10 us per step when every side-stream kernel is bracketed.            */
 int tsim_profile_enable(tsim_program *p, int32_t on);
+/* Bracket only one launch in `every` (default 1): each timing event costs a queue drain.        */
+int tsim_profile_set_sampling(tsim_program *p, int32_t every);
 /* Sum of kernel durations (ms) and number of launches since the last reset;
  * synchronises the stream.                                                   */
 int tsim_profile_read(tsim_program *p, double *kernel_ms, int64_t *launches, int32_t reset);

@@ -70,3 +70,22 @@ def test_npz_roundtrip(tmp_path):
 
     f = synth.synth_f(50, cfg["num_f"], 0.05, seed=1)
     assert np.array_equal(O.sample_program(prog, f, (1, 2)), O.sample_program(back, f, (1, 2)))
+
+
+def test_key_split_matches_python_prng():
+    """tsim_key_split (host helper, no device) == tsim_amd.prng.split."""
+    import ctypes as C
+
+    from tsim_amd import _lib, prng
+
+    lib = _lib.load()
+    out = (C.c_uint32 * 4)()
+    k = prng.key(0)
+    for _ in range(5):
+        lib.tsim_key_split(k[0], k[1], out)
+        new, sub = prng.split(k)
+        assert (out[0], out[1]) == new and (out[2], out[3]) == sub
+        k = new
+    lib.tsim_key_split(0xFFFFFFFF, 0x12345678, out)
+    new, sub = prng.split((0xFFFFFFFF, 0x12345678))
+    assert (out[0], out[1]) == new and (out[2], out[3]) == sub

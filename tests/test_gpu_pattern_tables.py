@@ -127,3 +127,33 @@ def test_postselection_list_feeds_pass_one(hip):
     a, b = outs
     np.testing.assert_array_equal(a, b)
     assert a[:, prog.num_detectors:].any()
+
+
+def test_pipelined_begin_end_matches_serial(hip):
+    """tsim_sample_batch_device_begin/_end: several launches in flight on different slots give the
+    bits of the serial call."""
+    prog, cfg = synth.config_program("C2")
+    hp = hip.HipProgram(prog)
+    nf, B = cfg["num_f"], 5000
+    wf, wo = (nf + 63) // 64, (prog.num_outputs + 63) // 64
+    keys = [prng.key(100 + i) for i in range(7)]
+    fs = [synth.synth_f(B, nf, 0.03 + 0.02 * (i % 3), seed=40 + i) for i in range(7)]
+    want = [hp.sample_batch(f, k, bit_packed=True)[0] for f, k in zip(fs, keys)]
+    d_f = [hp.malloc(B * wf * 8) for _ in fs]
+    d_o = [hp.malloc(B * wo * 8) for _ in fs]
+    for d, f in zip(d_f, fs):
+        packed = np.packbits(f, axis=1, bitorder="little")
+        packed = np.pad(packed, ((0, 0), (0, wf * 8 - packed.shape[1])))
+        hp.h2d(d, packed)
+    nslot = hp.PIPELINE_SLOTS
+    for i in range(7):
+        if i >= nslot:
+            hp.sample_batch_device_end((i - nslot) % nslot)
+        hp.sample_batch_device_begin(i % nslot, d_f[i].ptr, B, nf, keys[i], d_o[i].ptr)
+    for s in range(nslot):
+        hp.sample_batch_device_end(s)
+    hp.synchronize()
+    for i in range(7):
+        got = np.zeros((B, wo * 8), np.uint8)
+        hp.d2h(got, d_o[i])
+        np.testing.assert_array_equal(got, want[i], err_msg=f"launch {i}")

@@ -70,6 +70,8 @@ SYMBOLS: dict[str, tuple] = {
     "tsim_program_destroy": (None, [_P]),
     "tsim_sample_batch": (C.c_int, [_P, _P, _I64, _I32, _U32, _U32, _I64, _P, _I32, _P]),
     "tsim_sample_batch_device": (C.c_int, [_P, _P, _I64, _I32, _U32, _U32, _I64, _P, _P, _P]),
+    "tsim_sample_batch_device_begin": (C.c_int, [_P, _I32, _P, _I64, _I32, _U32, _U32, _I64, _P, _P, _P]),
+    "tsim_sample_batch_device_end": (C.c_int, [_P, _I32, _P]),
     "tsim_postselect_device": (C.c_int, [_P, _P, _I64, _I32, _P, _P, _P, _P, _P, _P, _P]),
     "tsim_sample_rows_device": (C.c_int, [_P, _P, _I64, _I32, _U32, _U32, _I64, _P, _P, _P, _P, _P]),
     "tsim_evaluate": (C.c_int, [_P, _I32, _I32, _P, _I64, _P, _P, _P, _P]),
@@ -88,6 +90,7 @@ SYMBOLS: dict[str, tuple] = {
     "tsim_synchronize": (C.c_int, [_P]),
     "tsim_get_stream": (C.c_int, [_P, C.POINTER(_P)]),
     "tsim_profile_enable": (C.c_int, [_P, _I32]),
+    "tsim_profile_set_sampling": (C.c_int, [_P, _I32]),
     "tsim_profile_read": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(_I64), _I32]),
     "tsim_profile_read_stages": (C.c_int, [_P, C.POINTER(C.c_double)]),
     "tsim_program_info": (
@@ -95,6 +98,7 @@ SYMBOLS: dict[str, tuple] = {
         [_P, C.POINTER(_I32), C.POINTER(_I32), C.POINTER(_I64), C.POINTER(_I64), C.POINTER(_I64)],
     ),
     "tsim_program_stats": (C.c_int, [_P, C.POINTER(_I64)]),
+    "tsim_key_split": (None, [_U32, _U32, C.POINTER(_U32)]),
     "tsim_last_error": (C.c_char_p, []),
     "tsim_version": (C.c_char_p, []),
 }

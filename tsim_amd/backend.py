@@ -168,6 +168,7 @@ class HipProgram:
             lib.tsim_program_destroy(h)
             self._h = None
             raise
+        self._split_buf = (C.c_uint32 * 4)()
         self._finalizer = weakref.finalize(self, lib.tsim_program_destroy, h)
 
     # -- info ---------------------------------------------------------------
@@ -256,6 +257,28 @@ class HipProgram:
             "tsim_sample_batch_device",
         )
 
+    PIPELINE_SLOTS = 4
+
+    def split_key(self, key):
+        """``prng.split`` computed by the library (same values; ~5 us cheaper per batch)."""
+        out = self._split_buf
+        self._lib.tsim_key_split(key[0], key[1], out)
+        return (out[0], out[1]), (out[2], out[3])
+
+    def sample_batch_device_begin(self, slot: int, d_f: int, B: int, num_f: int, key, d_out: int, *,
+                                  shot_offset: int = 0, d_norm_dev: int = 0) -> None:
+        """Pipelined launch: first pass on the handle's stream, second pass (hard rows) on the
+        slot's side stream.  ``d_out`` is complete only after ``sample_batch_device_end(slot)``."""
+        rc = self._lib.tsim_sample_batch_device_begin(
+            self._h, slot, d_f, B, num_f, key[0] & 0xFFFFFFFF, key[1] & 0xFFFFFFFF, shot_offset, d_out,
+            d_norm_dev or None, None)
+        if rc < 0:
+            _lib.check(rc, "tsim_sample_batch_device_begin")
+
+    def sample_batch_device_end(self, slot: int) -> None:
+        """Make the handle's stream wait for the slot's second pass."""
+        _lib.check(self._lib.tsim_sample_batch_device_end(self._h, int(slot), None), "tsim_sample_batch_device_end")
+
     def stream_ptr(self) -> int:
         """The handle's ``hipStream_t`` as an integer (to order foreign work after the kernels)."""
         st = C.c_void_p()
@@ -290,8 +313,13 @@ class HipProgram:
     def synchronize(self) -> None:
         _lib.check(self._lib.tsim_synchronize(self._h), "tsim_synchronize")
 
-    def profile_enable(self, on: bool = True) -> None:
-        _lib.check(self._lib.tsim_profile_enable(self._h, 1 if on else 0), "tsim_profile_enable")
+    def profile_enable(self, on=True) -> None:
+        """``True``/1: time every kernel of a launch; 2: only the first kernel (cheap enough for
+        pipelined launches); ``False``: off."""
+        _lib.check(self._lib.tsim_profile_enable(self._h, int(on)), "tsim_profile_enable")
+
+    def profile_set_sampling(self, every: int) -> None:
+        _lib.check(self._lib.tsim_profile_set_sampling(self._h, int(every)), "tsim_profile_set_sampling")
 
     def profile_read(self, reset: bool = True) -> tuple[float, int]:
         ms, n = C.c_double(), C.c_int64()

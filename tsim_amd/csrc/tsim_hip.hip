@@ -124,14 +124,27 @@ struct tsim_program {
   // device
   int device = -1;
   uint32_t *d_img = nullptr;
-  uint32_t *d_keys = nullptr;
   float *d_dev = nullptr;
   hipStream_t stream = nullptr;
   // low-weight pattern tables (tsim_lw.hip.h)
   int lw_request = -1;        // -1 default (on in TSIM_MODE_AUTO), 0 off, 1 on
   int lw_weight_cap = -1;     // -1 = TSIMK_LW_MAX_WEIGHT
   bool lw = false;            // tables built, pass 1 active
-  int lw_parity = 0;          // counter set of the next launch
+  // Launch slots: slot 0 serves the serial API (everything on the caller's stream); slots 1..4 serve
+  // tsim_sample_batch_device_begin/_end, whose second pass runs on the slot's own side stream so
+  // that it overlaps the first pass of the following launches.
+  struct Slot {
+    int parity = 0;               // counter set of the next launch
+    uint32_t *ctl = nullptr;      // 2 counter sets (hard-row counters + check row)
+    void *hard = nullptr;         // hard-row lists
+    size_t hard_sz = 0;
+    uint32_t *keys = nullptr;     // k_keygen output (programs with > TSIMK_INLINE_KEYS outputs)
+    hipStream_t side = nullptr;
+    hipEvent_t ev1 = nullptr, ev2 = nullptr;
+    bool pending = false;         // second pass enqueued on `side`, not yet joined
+  };
+  Slot slots[1 + TSIM_PIPELINE_SLOTS];
+  bool slots_ready = false;
   bool h_attr_set = false;    // k_sample4h: large dynamic LDS enabled
   int lw_off = 0;             // image offset of the LW component records
   int lw_direct_prog = 0;     // image offset of the direct-output gather program
@@ -139,12 +152,14 @@ struct tsim_program {
   std::vector<int> lw_wmax;   // per component
   long long lw_bytes = 0;
   float *d_lw_tab = nullptr;
-  uint32_t *d_lw_ctl = nullptr;  // [0] hard count, [1] check row
-  // scratch (host-buffer API: 0..3; hard-row list: 4)
-  void *scratch[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-  size_t scratch_sz[5] = {0, 0, 0, 0, 0};
+  // scratch (host-buffer API)
+  void *scratch[4] = {nullptr, nullptr, nullptr, nullptr};
+  size_t scratch_sz[4] = {0, 0, 0, 0};
   // profiling
   bool profiling = false;
+  bool prof_light = false;    // only the events of the first kernel of a launch
+  int prof_every = 1;         // bracket one launch in prof_every
+  long long prof_counter = 0;
   std::vector<hipEvent_t> ev_pool;
   std::vector<int> ev_tag;
   double prof_stage_ms[4] = {0.0, 0.0, 0.0, 0.0};
@@ -989,11 +1004,6 @@ static void launch_lw_build(const LwBuildArgs &a, long long lanes, hipStream_t s
 
 static int build_pattern_tables(tsim_program *p, const std::vector<long long> &npat) {
   HIP_TRY(hipMalloc((void **)&p->d_lw_tab, std::max<size_t>(16, (size_t)p->lw_bytes)));
-  // two counter sets used alternately: pass 1 of a launch resets the set of the next one
-  HIP_TRY(hipMalloc((void **)&p->d_lw_ctl, 2 * (TSIMK_LW_LISTS + 1) * 128));
-  HIP_TRY(hipMemset(p->d_lw_ctl, 0, 2 * (TSIMK_LW_LISTS + 1) * 128));
-  for (int st = 0; st < 2; ++st)
-    HIP_TRY(hipMemset(p->d_lw_ctl + st * (TSIMK_LW_LISTS + 1) * 32 + TSIMK_LW_LISTS * 32, 0xFF, 4));
   long long tab_off = 0;
   for (size_t ci = 0; ci < p->comps.size(); ++ci) {
     const HostComponent &c = p->comps[ci];
@@ -1306,7 +1316,6 @@ retry_pack:
   HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
   HIP_TRY(hipMalloc((void **)&p->d_img, img.size() * 4));
   HIP_TRY(hipMemcpy(p->d_img, img.data(), img.size() * 4, hipMemcpyHostToDevice));
-  HIP_TRY(hipMalloc((void **)&p->d_keys, std::max(1, p->total_keys) * 8));
   HIP_TRY(hipMalloc((void **)&p->d_dev, std::max<size_t>(1, p->comps.size()) * 4));
   HIP_TRY(hipMemset(p->d_dev, 0, std::max<size_t>(1, p->comps.size()) * 4));
   if (p->lw) {
@@ -1325,10 +1334,17 @@ extern "C" void tsim_program_destroy(tsim_program *p) {
     for (void *s : p->scratch)
       if (s) (void)hipFree(s);
     if (p->d_img) (void)hipFree(p->d_img);
-    if (p->d_keys) (void)hipFree(p->d_keys);
     if (p->d_dev) (void)hipFree(p->d_dev);
     if (p->d_lw_tab) (void)hipFree(p->d_lw_tab);
-    if (p->d_lw_ctl) (void)hipFree(p->d_lw_ctl);
+    for (auto &sl : p->slots) {
+      if (sl.side) (void)hipStreamSynchronize(sl.side);
+      if (sl.ctl) (void)hipFree(sl.ctl);
+      if (sl.hard) (void)hipFree(sl.hard);
+      if (sl.keys) (void)hipFree(sl.keys);
+      if (sl.ev1) (void)hipEventDestroy(sl.ev1);
+      if (sl.ev2) (void)hipEventDestroy(sl.ev2);
+      if (sl.side) (void)hipStreamDestroy(sl.side);
+    }
     if (p->stream) (void)hipStreamDestroy(p->stream);
   }
   delete p;
@@ -1417,9 +1433,41 @@ static int prof_drain(tsim_program *p) {
   return 0;
 }
 
+// per-slot resources, created on first use
+static int slot_prepare(tsim_program *p, int slot, size_t hard_bytes) {
+  tsim_program::Slot &sl = p->slots[slot];
+  if (p->lw && !sl.ctl) {
+    // two counter sets used alternately: pass 1 of a launch resets the set of the slot's next one
+    const size_t set_bytes = (TSIMK_LW_LISTS + 1) * 128;
+    HIP_TRY(hipMalloc((void **)&sl.ctl, 2 * set_bytes));
+    HIP_TRY(hipMemset(sl.ctl, 0, 2 * set_bytes));
+    for (int st = 0; st < 2; ++st)
+      HIP_TRY(hipMemset(sl.ctl + st * (TSIMK_LW_LISTS + 1) * 32 + TSIMK_LW_LISTS * 32, 0xFF, 4));
+  }
+  if (p->total_keys > TSIMK_INLINE_KEYS && !sl.keys) HIP_TRY(hipMalloc((void **)&sl.keys, (size_t)p->total_keys * 8));
+  if (slot > 0 && !sl.side) {
+    HIP_TRY(hipStreamCreateWithFlags(&sl.side, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&sl.ev1, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&sl.ev2, hipEventDisableTiming));
+  }
+  if (sl.hard_sz < hard_bytes) {
+    if (sl.hard) {
+      HIP_TRY(hipDeviceSynchronize());
+      HIP_TRY(hipFree(sl.hard));
+      sl.hard = nullptr;
+      sl.hard_sz = 0;
+    }
+    hipError_t e = hipMalloc(&sl.hard, hard_bytes);
+    if (e != hipSuccess) return fail(TSIM_ENOMEM, "hipMalloc(%zu) failed: %s", hard_bytes, hipGetErrorString(e));
+    sl.hard_sz = hard_bytes;
+  }
+  return 0;
+}
+
 static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_t num_f, uint32_t key_hi,
                          uint32_t key_lo, int64_t shot_offset, uint64_t *d_out, float *d_dev, hipStream_t s,
-                         const uint32_t *d_row_index = nullptr, const uint32_t *d_row_count = nullptr) {
+                         const uint32_t *d_row_index = nullptr, const uint32_t *d_row_count = nullptr,
+                         int slot = 0) {
   if (!p->sampleable) return fail(TSIM_ESTATE, "program has joint-mode components (evaluate-only)");
   if (B < 0 || num_f < 0 || shot_offset < 0) return fail(TSIM_EINVAL, "negative B/num_f/shot_offset");
   if (p->max_f_index >= num_f)
@@ -1429,6 +1477,15 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
   if (!d_out) return fail(TSIM_EINVAL, "out buffer is NULL");
   // per-output subkeys: key, subkey = split(key) once per output, threaded through the
   // components in processing order (sampler.py:74,147-148)
+  tsim_program::Slot &sl = p->slots[slot];
+  {
+    size_t hard_bytes = 0;
+    if (p->lw) {
+      const long long g1 = (B + 255) / 256;  // the pattern pass uses 256-thread blocks unless overridden
+      hard_bytes = (size_t)((g1 + TSIMK_LW_LISTS - 1) / TSIMK_LW_LISTS * 1024) * TSIMK_LW_LISTS * 4;
+    }
+    if (int r = slot_prepare(p, slot, hard_bytes)) return r;
+  }
   SampleArgs a{};
   if (p->total_keys > 0 && p->total_keys <= TSIMK_INLINE_KEYS) {
     uint32_t k0 = key_hi, k1 = key_lo;
@@ -1443,13 +1500,13 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
     }
     a.n_inline_keys = p->total_keys;
   } else if (p->total_keys > 0) {
-    hipLaunchKernelGGL(k_keygen, dim3(1), dim3(1), 0, s, key_hi, key_lo, p->total_keys, p->d_keys);
+    hipLaunchKernelGGL(k_keygen, dim3(1), dim3(1), 0, s, key_hi, key_lo, p->total_keys, sl.keys);
     HIP_TRY(hipGetLastError());
   }
   a.img = p->d_img;
   a.f = d_f;
   a.out = d_out;
-  a.subkeys = p->d_keys;
+  a.subkeys = sl.keys;
   a.norm_dev = d_dev;
   a.B = B;
   a.shot_offset = shot_offset;
@@ -1469,10 +1526,19 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
   a.no_check = 0;
   if (num_f == 0) a.WF = 0;
   if (B > 0x7FFFFFFFll * 64) return fail(TSIM_ENOTSUP, "batch too large");
-  if (p->profiling) { int r = prof_event(p, s, PROF_BEGIN); if (r) return r; }
+  const bool prof = p->profiling && (p->prof_counter++ % p->prof_every == 0);
+  if (prof) { int r = prof_event(p, s, PROF_BEGIN); if (r) return r; }
   // the normalisation check applies to in-batch shot 0 (sampler.py:66-72) or the first listed row
   bool has_check = (shot_offset == 0 || d_row_index);
   long long B2 = B;  // slots per row list of the full kernel's launch
+  bool pipelined = false;
+  auto finish = [&]() -> int {
+    if (pipelined) {
+      HIP_TRY(hipEventRecord(sl.ev2, s));
+      sl.pending = true;
+    }
+    return 0;
+  };
   if (p->lw) {
     // pass 1: shots whose f_sel patterns are tabulated finish here, the others go to the hard list
     if (B > 0xFFFFFFFFll) return fail(TSIM_ENOTSUP, "batch too large for the row list");
@@ -1481,7 +1547,7 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
     const long long grid1 = (B + blk1 - 1) / blk1;
     const long long list_cap = (grid1 + TSIMK_LW_LISTS - 1) / TSIMK_LW_LISTS * blk1;
     if (list_cap > 0x7FFFFFFFll) return fail(TSIM_ENOTSUP, "batch too large for the row lists");
-    if (int r = ensure_scratch(p, 4, (size_t)list_cap * TSIMK_LW_LISTS * 4)) return r;
+    if ((size_t)list_cap * TSIMK_LW_LISTS * 4 > sl.hard_sz) return fail(TSIM_ESTATE, "hard-row list too small");
     LwArgs l;
     l.s = a;
     l.tab = p->d_lw_tab;
@@ -1489,17 +1555,23 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
     l.direct_prog = p->lw_direct_prog;
     l.direct_chunks = p->lw_direct_chunks;
     l.has_check = has_check ? 1 : 0;
-    l.hard_index = (uint32_t *)p->scratch[4];
-    uint32_t *ctl = p->d_lw_ctl + p->lw_parity * (TSIMK_LW_LISTS + 1) * 32;
+    l.hard_index = (uint32_t *)sl.hard;
+    uint32_t *ctl = sl.ctl + sl.parity * (TSIMK_LW_LISTS + 1) * 32;
     l.ctl = ctl;
-    l.ctl_next = p->d_lw_ctl + (p->lw_parity ^ 1) * (TSIMK_LW_LISTS + 1) * 32;
-    p->lw_parity ^= 1;
+    l.ctl_next = sl.ctl + (sl.parity ^ 1) * (TSIMK_LW_LISTS + 1) * 32;
+    sl.parity ^= 1;
     l.list_cap = (int)list_cap;
     const size_t lds1 = (size_t)(2 * a.WF + 2 * a.WO) * blk1 * 4;
     if (lds1 > 64 * 1024) return fail(TSIM_ENOTSUP, "num_f + num_outputs too large for LDS staging (%zu B)", lds1);
     hipLaunchKernelGGL(k_sample_lw, dim3((unsigned)grid1), dim3(blk1), lds1, s, l);
     HIP_TRY(hipGetLastError());
-    if (p->profiling) { int r = prof_event(p, s, PROF_PASS1); if (r) return r; }
+    if (prof) { int r = prof_event(p, s, PROF_PASS1); if (r) return r; }
+    if (slot > 0) {  // pipelined launch: the second pass goes to the slot's side stream
+      HIP_TRY(hipEventRecord(sl.ev1, s));
+      HIP_TRY(hipStreamWaitEvent(sl.side, sl.ev1, 0));
+      s = sl.side;
+      pipelined = true;
+    }
     // pass 2 below runs on the hard lists; the check row was forced into one of them
     a.row_index = l.hard_index;
     a.row_count = ctl;
@@ -1535,7 +1607,8 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
       constexpr int NW = 8;
       const size_t tile_b = (size_t)p->v4_max_nch * 16 * p->v4_gt * 16;
       const size_t fixed_b = (size_t)(2 * a.WF + 2 * a.WO) * 64 * 4 + (size_t)NW * 8 * 64 * 4;
-      const size_t budget = 150 * 1024;
+      const char *lenv = getenv("TSIM_AMD_HARD_LDS_KB");
+      const size_t budget = (size_t)(lenv ? std::max(24, std::min(156, atoi(lenv))) : 150) * 1024;
       int group_tiles = fixed_b + tile_b <= budget ? (int)std::min<size_t>(TSIMK_H_MAX_GROUP_TILES, (budget - fixed_b) / tile_b) : 0;
       if (group_tiles >= 1) {
         // the first kHardBlocks * 64 slots of every list go to the NW-wave kernel; k_sample4 below
@@ -1551,14 +1624,14 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
     auto kfn = k_sample4h<4, N, NW>;                                                                        \
     if (!p->h_attr_set)                                                                                     \
       HIP_TRY(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-    hipLaunchKernelGGL(kfn, dim3((unsigned)gridh), dim3(NW * 64), ldsh, s, ah, group_tiles);                \
+    hipLaunchKernelGGL(kfn, dim3((unsigned)gridh), dim3(NW * 64), ldsh, s, ah, group_tiles);   \
   } break;
           TSIM_LH(2) TSIM_LH(4) TSIM_LH(6) TSIM_LH(8) TSIM_LH(10) TSIM_LH(12) TSIM_LH(14) TSIM_LH(16)
 #undef TSIM_LH
           default: return fail(TSIM_ESTATE, "bad chunk count %d", p->v4_max_nch);
         }
         HIP_TRY(hipGetLastError());
-        if (p->profiling) { int r = prof_event(p, s, PROF_HARD); if (r) return r; }
+        if (prof && !p->prof_light) { int r = prof_event(p, s, PROF_HARD); if (r) return r; }
         p->h_attr_set = true;
         a4.has_check = 0;  // done by the kernel above
         a4.s.no_check = 1;
@@ -1575,8 +1648,8 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
       default: hipLaunchKernelGGL((k_sample4<4, 16>), dim3((unsigned)grid4), dim3(blk), lds4, s, a4); break;
     }
     HIP_TRY(hipGetLastError());
-    if (p->profiling) { int r = prof_event(p, s, PROF_FULL); if (r) return r; }
-    return 0;
+    if (prof && !(p->prof_light && p->lw)) { int r = prof_event(p, s, PROF_FULL); if (r) return r; }
+    return finish();
   }
   int wmax = 1;
   for (int w : p->comp_w) wmax = std::max(wmax, w);
@@ -1592,8 +1665,44 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
     default: return fail(TSIM_ENOTSUP, "unsupported word count %d", wmax);
   }
   HIP_TRY(hipGetLastError());
-  if (p->profiling) { int r = prof_event(p, s, PROF_FULL); if (r) return r; }
-  return 0;
+  if (prof && !(p->prof_light && p->lw)) { int r = prof_event(p, s, PROF_FULL); if (r) return r; }
+  return finish();
+}
+
+extern "C" int tsim_sample_batch_device_begin(tsim_program *p, int32_t slot, const uint64_t *d_f, int64_t B,
+                                              int32_t num_f, uint32_t key_hi, uint32_t key_lo, int64_t shot_offset,
+                                              uint64_t *d_out, float *d_max_norm_dev, void *stream) {
+  if (int r = need_final(p)) return r;
+  if (int r = set_device(p)) return r;
+  if (slot < 0 || slot >= TSIM_PIPELINE_SLOTS) return fail(TSIM_EINVAL, "slot %d out of range", slot);
+  hipStream_t s = stream ? (hipStream_t)stream : p->stream;
+  tsim_program::Slot &sl = p->slots[1 + slot];
+  if (sl.pending) {  // the slot's previous launch was never joined: order this one after it
+    HIP_TRY(hipStreamWaitEvent(s, sl.ev2, 0));
+    sl.pending = false;
+  }
+  if (!p->slots_ready) {  // first pipelined launch: create every slot's stream/buffers now, not mid-run
+    size_t hard_bytes = 0;
+    if (p->lw) hard_bytes = (size_t)(((B + 255) / 256 + TSIMK_LW_LISTS - 1) / TSIMK_LW_LISTS * 1024) * TSIMK_LW_LISTS * 4;
+    for (int k = 1; k <= TSIM_PIPELINE_SLOTS; ++k)
+      if (int r = slot_prepare(p, k, hard_bytes)) return r;
+    p->slots_ready = true;
+  }
+  return launch_sample(p, d_f, B, num_f, key_hi, key_lo, shot_offset, d_out, d_max_norm_dev, s, nullptr, nullptr,
+                       1 + slot);
+}
+
+extern "C" int tsim_sample_batch_device_end(tsim_program *p, int32_t slot, void *stream) {
+  if (int r = need_final(p)) return r;
+  if (int r = set_device(p)) return r;
+  if (slot < 0 || slot >= TSIM_PIPELINE_SLOTS) return fail(TSIM_EINVAL, "slot %d out of range", slot);
+  hipStream_t s = stream ? (hipStream_t)stream : p->stream;
+  tsim_program::Slot &sl = p->slots[1 + slot];
+  if (sl.pending) {
+    HIP_TRY(hipStreamWaitEvent(s, sl.ev2, 0));
+    sl.pending = false;
+  }
+  return TSIM_OK;
 }
 
 extern "C" int tsim_sample_batch_device(tsim_program *p, const uint64_t *d_f, int64_t B, int32_t num_f,
@@ -1982,10 +2091,23 @@ extern "C" int tsim_get_stream(tsim_program *p, void **stream) {
   return TSIM_OK;
 }
 
+extern "C" void tsim_key_split(uint32_t key_hi, uint32_t key_lo, uint32_t out[4]) {
+  // new_key, subkey = jax.random.split(key) (threefry_partitionable): counters (0,0) and (0,1)
+  uint32_t a0 = 0u, a1 = 0u, b0 = 0u, b1 = 1u;
+  threefry2x32(key_hi, key_lo, a0, a1);
+  threefry2x32(key_hi, key_lo, b0, b1);
+  out[0] = a0; out[1] = a1; out[2] = b0; out[3] = b1;
+}
+
 extern "C" int tsim_synchronize(tsim_program *p) {
   if (int r = need_final(p)) return r;
   if (int r = set_device(p)) return r;
   HIP_TRY(hipStreamSynchronize(p->stream));
+  for (auto &sl : p->slots)
+    if (sl.side) {
+      HIP_TRY(hipStreamSynchronize(sl.side));
+      sl.pending = false;
+    }
   return TSIM_OK;
 }
 
@@ -1994,6 +2116,15 @@ extern "C" int tsim_profile_enable(tsim_program *p, int32_t on) {
   if (int r = set_device(p)) return r;
   if (!on && p->ev_used) { if (int r = prof_drain(p)) return r; }
   p->profiling = on != 0;
+  p->prof_light = on == 2;
+  p->prof_counter = 0;
+  return TSIM_OK;
+}
+
+extern "C" int tsim_profile_set_sampling(tsim_program *p, int32_t every) {
+  if (!p || every < 1) return fail(TSIM_EINVAL, "bad argument");
+  p->prof_every = every;
+  p->prof_counter = 0;
   return TSIM_OK;
 }
 

@@ -359,9 +359,10 @@ def main() -> None:
         # dominant kernel: with pattern tables the first pass (k_sample_lw) touches every row and moves
         # all the algorithmic bytes; the hard-row kernels of a launch overlap the first pass of the
         # following launches (pipelined slots).  Without tables: the one full kernel.
-        if info.get("pattern_tables"):
+        tables_dominant = bool(info.get("pattern_tables")) and stages["pattern_pass"] >= stages["full_kernel"]
+        if tables_dominant:
             avg_kernel_s = stages["pattern_pass"] / max(launches, 1) * 1e-3
-        else:
+        else:  # no tables, or dense error patterns: the launch plan went back to the full kernel
             avg_kernel_s = launch_s
         if launches == 0:  # profiling events disabled (experiments): fall back to the step time
             avg_kernel_s = launch_s = elapsed / args.steps
@@ -369,7 +370,7 @@ def main() -> None:
         ops_per_shot = algorithmic_ops_per_shot(program)
         achieved_gbs = bytes_per_shot * B / avg_kernel_s / 1e9
         achieved_tops = ops_per_shot * B / avg_kernel_s / 1e12
-        if info.get("pattern_tables"):
+        if tables_dominant:
             kernel_name = "tsimk::k_sample_lw (pattern-table pass; hard rows: k_sample4h + k_sample4 on side streams)" \
                 if info.get("chunk_table_kernel") else "tsimk::k_sample_lw (pattern-table pass; hard rows: k_sample on side streams)"
         else:

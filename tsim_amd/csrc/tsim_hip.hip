@@ -145,6 +145,11 @@ struct tsim_program {
   };
   Slot slots[1 + TSIM_PIPELINE_SLOTS];
   bool slots_ready = false;
+  // launch-plan feedback (mapped pinned host memory written by k_sample4h): [0] hard rows,
+  // [1] longest hard-row list, [2] rows of that launch; 0xFFFFFFFF = nothing seen yet
+  volatile uint32_t *h_feedback = nullptr;
+  uint32_t *d_feedback = nullptr;
+  int lw_direct_left = 0;     // launches still to run on the full kernel before the next probe
   bool h_attr_set = false;    // k_sample4h: large dynamic LDS enabled
   int lw_off = 0;             // image offset of the LW component records
   int lw_direct_prog = 0;     // image offset of the direct-output gather program
@@ -1042,6 +1047,20 @@ static int build_pattern_tables(tsim_program *p, const std::vector<long long> &n
     if (e != hipSuccess) return fail(TSIM_EHIP, "pattern table build failed: %s", hipGetErrorString(e));
     tab_off += lanes;
   }
+  if (p->v4) {
+    void *h = nullptr;
+    if (hipHostMalloc(&h, 64, hipHostMallocMapped) == hipSuccess) {
+      void *d = nullptr;
+      if (hipHostGetDevicePointer(&d, h, 0) == hipSuccess) {
+        p->h_feedback = (volatile uint32_t *)h;
+        p->d_feedback = (uint32_t *)d;
+        for (int i = 0; i < 16; ++i) p->h_feedback[i] = 0xFFFFFFFFu;
+      } else {
+        (void)hipHostFree(h);
+      }
+    }
+    (void)hipGetLastError();  // feedback is optional: without it every launch takes the default plan
+  }
   return 0;
 }
 
@@ -1248,7 +1267,7 @@ retry_pack:
       ok = ok && (c.n_levels == c.n_out + 1) && c.n_out <= TSIMK_LW_MAX_NOUT && c.F + c.n_out <= 64;
     if (ok) {
       const int cap = p->lw_weight_cap < 0 ? TSIMK_LW_MAX_WEIGHT : std::min(p->lw_weight_cap, TSIMK_LW_MAX_WEIGHT);
-      const long long budget = 2ll << 20;  // bytes per component: stays L2-resident
+      const long long budget = 4ll << 20;  // bytes per component (the hot low-weight rows stay cache-resident)
       while (img.size() % 16) img.push_back(0u);
       p->lw_off = (int)img.size();
       img.resize(img.size() + p->comps.size() * LW_WORDS, 0u);
@@ -1336,6 +1355,7 @@ extern "C" void tsim_program_destroy(tsim_program *p) {
     if (p->d_img) (void)hipFree(p->d_img);
     if (p->d_dev) (void)hipFree(p->d_dev);
     if (p->d_lw_tab) (void)hipFree(p->d_lw_tab);
+    if (p->h_feedback) (void)hipHostFree((void *)p->h_feedback);
     for (auto &sl : p->slots) {
       if (sl.side) (void)hipStreamSynchronize(sl.side);
       if (sl.ctl) (void)hipFree(sl.ctl);
@@ -1539,7 +1559,23 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
     }
     return 0;
   };
-  if (p->lw) {
+  // Launch plan from the feedback of earlier launches (results do not depend on it):
+  //  * most rows hard (dense error patterns): the pattern pass is wasted work - run the full kernel
+  //    on every row for the next 15 launches, then probe again with one two-pass launch;
+  //  * hard-row lists short: k_sample4h walks them alone, no overflow launch of k_sample4.
+  bool use_tables = p->lw, need_overflow = true;
+  if (p->lw && p->h_feedback && !(getenv("TSIM_AMD_ADAPTIVE") && atoi(getenv("TSIM_AMD_ADAPTIVE")) == 0)) {
+    const uint32_t fb_sum = p->h_feedback[0], fb_max = p->h_feedback[1], fb_rows = p->h_feedback[2];
+    const bool known = fb_rows != 0xFFFFFFFFu && fb_rows > 0u && fb_sum != 0xFFFFFFFFu;
+    if (p->lw_direct_left > 0) {
+      --p->lw_direct_left;
+      use_tables = false;
+    } else if (known && (double)fb_sum > 0.5 * (double)fb_rows && !d_row_index) {
+      p->lw_direct_left = 15;  // this launch is the probe
+    }
+    if (known && fb_max <= 192u) need_overflow = false;
+  }
+  if (use_tables) {
     // pass 1: shots whose f_sel patterns are tabulated finish here, the others go to the hard list
     if (B > 0xFFFFFFFFll) return fail(TSIM_ENOTSUP, "batch too large for the row list");
     const char *b1env = getenv("TSIM_AMD_LW_BLOCK");
@@ -1617,14 +1653,16 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
         const size_t ldsh = fixed_b + (size_t)group_tiles * tile_b;
         const long long gridh = (long long)kHardBlocks * nlists + a4.has_check;
         Sample4Args ah = a4;
-        ah.s.row_slot_end = kHardBlocks * 64;
+        ah.s.row_slot_end = need_overflow ? kHardBlocks * 64 : 0;
+        const int loop_stride = need_overflow ? 0 : kHardBlocks * 64;
         switch (p->v4_max_nch) {
 #define TSIM_LH(N)                                                                                          \
   case N: {                                                                                                 \
     auto kfn = k_sample4h<4, N, NW>;                                                                        \
     if (!p->h_attr_set)                                                                                     \
       HIP_TRY(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-    hipLaunchKernelGGL(kfn, dim3((unsigned)gridh), dim3(NW * 64), ldsh, s, ah, group_tiles);   \
+    hipLaunchKernelGGL(kfn, dim3((unsigned)gridh), dim3(NW * 64), ldsh, s, ah, group_tiles, loop_stride,    \
+                       p->d_feedback);                                                                      \
   } break;
           TSIM_LH(2) TSIM_LH(4) TSIM_LH(6) TSIM_LH(8) TSIM_LH(10) TSIM_LH(12) TSIM_LH(14) TSIM_LH(16)
 #undef TSIM_LH
@@ -1636,7 +1674,7 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
         a4.has_check = 0;  // done by the kernel above
         a4.s.no_check = 1;
         a4.s.row_slot_begin = kHardBlocks * 64;
-        B2 = std::max<long long>(0, B2 - kHardBlocks * 64);
+        B2 = need_overflow ? std::max<long long>(0, B2 - kHardBlocks * 64) : 0;
       }
     }
     const long long grid4 = (B2 + blk - 1) / blk * nlists + a4.has_check;
@@ -1648,7 +1686,7 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
       default: hipLaunchKernelGGL((k_sample4<4, 16>), dim3((unsigned)grid4), dim3(blk), lds4, s, a4); break;
     }
     HIP_TRY(hipGetLastError());
-    if (prof && !(p->prof_light && p->lw)) { int r = prof_event(p, s, PROF_FULL); if (r) return r; }
+    if (prof && !(p->prof_light && use_tables)) { int r = prof_event(p, s, PROF_FULL); if (r) return r; }
     return finish();
   }
   int wmax = 1;
@@ -1665,7 +1703,7 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
     default: return fail(TSIM_ENOTSUP, "unsupported word count %d", wmax);
   }
   HIP_TRY(hipGetLastError());
-  if (prof && !(p->prof_light && p->lw)) { int r = prof_event(p, s, PROF_FULL); if (r) return r; }
+  if (prof && !(p->prof_light && use_tables)) { int r = prof_event(p, s, PROF_FULL); if (r) return r; }
   return finish();
 }
 

@@ -194,17 +194,35 @@ __device__ __forceinline__ void eval_level4h(const uint32_t *gimg, cptr img, cpt
 
 // sample_program on row lists, 64 rows per block, NW waves per row group
 template <int GT, int NCH, int NW>
-__global__ void __launch_bounds__(NW * 64) k_sample4h(Sample4Args A4, int group_tiles) {
+__global__ void __launch_bounds__(NW * 64) k_sample4h(Sample4Args A4, int group_tiles, int loop_stride,
+                                                        uint32_t *feedback) {
   typedef Hard4<GT, NCH, NW> H;
   const SampleArgs &A = A4.s;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const bool check_block = A4.has_check && (blockIdx.x == gridDim.x - 1);
+  // feedback to the host (mapped pinned memory, read at later launches to choose the launch plan):
+  // total and longest hard-row list of THIS launch
+  if (feedback && blockIdx.x == 0 && wave == 0 && A.row_lists > 1) {
+    uint32_t c = lane < A.row_lists ? A.row_count[32u * lane] : 0u, m = c;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      c += (uint32_t)__shfl_xor((int)c, o, 64);
+      m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
+    }
+    if (lane == 0) {
+      feedback[0] = c;
+      feedback[1] = m;
+      feedback[2] = (uint32_t)min(A.B, 0xFFFFFFFFll);
+    }
+  }
+  // loop_stride > 0: the block walks its list in steps of loop_stride rows (no overflow kernel)
+  for (long long iter_base = 0;; iter_base += loop_stride) {
   long long row = (long long)blockIdx.x * 64 + lane;
   bool active = row < A.B;
   if (A.row_index) {
     const uint32_t nl = A.row_lists > 1 ? (uint32_t)A.row_lists : 1u;
     const uint32_t k = blockIdx.x % nl;
-    const long long base = (long long)(blockIdx.x / nl) * 64;
+    const long long base = (long long)(blockIdx.x / nl) * 64 + iter_base;
     long long n = (long long)A.row_count[32u * k * (nl > 1 ? 1u : 0u)];
     if (A.row_slot_end > 0) n = min(n, (long long)A.row_slot_end);
     if (!check_block && base >= n) return;  // block-uniform
@@ -322,6 +340,9 @@ __global__ void __launch_bounds__(NW * 64) k_sample4h(Sample4Args A4, int group_
     uint64_t *orow = A.out + row * A.WO;
     for (int w = 0; w < A.WO; ++w)
       orow[w] = (uint64_t)lds_o[(2 * w) * 64] | ((uint64_t)lds_o[(2 * w + 1) * 64] << 32);
+  }
+  if (check_block || loop_stride <= 0 || !A.row_index) return;
+  __syncthreads();  // the LDS staging of this row group is reused by the next one
   }
 }
 

@@ -215,38 +215,60 @@ def main() -> None:
 
     # Pipeline of depth NSLOT (tsim_sample_batch_device_begin/_end): step i's first pass runs on the
     # engine's stream while the second passes (hard rows, latency-bound) of steps i-1.. run on side
-    # streams; one output buffer per slot.  For N > 1 the RCCL gather of step i is issued when its
-    # slot is joined (async, on the engine's stream), so it overlaps the kernels of later steps too.
-    NSLOT = max(1, min(backend.HipProgram.PIPELINE_SLOTS, int(os.environ.get("TSIM_BENCH_SLOTS", "4"))))
+    # streams; one output buffer per slot.  Three slots: HIP multiplexes streams onto 4 hardware queues,
+    # a fourth side stream would share the engine stream's queue and serialise with the first pass.
+    # N > 1: when a step is joined its rows are compacted to the reference's bit_packed layout
+    # (ceil(n_out/8) bytes per shot instead of the padded 8-byte words) into a group buffer in HBM; every
+    # GATHER_EVERY steps ONE asynchronous RCCL gather sends the whole group to rank 0 (fewer, larger
+    # collectives: a gather per step would cost more host time than the step itself), double-buffered
+    # so that it overlaps the kernels of the next group.
+    NSLOT = max(1, min(backend.HipProgram.PIPELINE_SLOTS, int(os.environ.get("TSIM_BENCH_SLOTS", "3"))))
+    GATHER_EVERY = max(1, int(os.environ.get("TSIM_BENCH_GATHER_EVERY", "16")))
     if use_dist:
         dev = torch.device("cuda", local_rank)
         ext = torch.cuda.ExternalStream(hp.stream_ptr(), device=dev)
         out_bufs = [torch.zeros((B, WO * 8), dtype=torch.uint8, device=dev) for _ in range(NSLOT)]
         out_ptrs = [t.data_ptr() for t in out_bufs]
-        gather_lists = [[torch.empty_like(out_bufs[0]) for _ in range(N)] if rank == 0 else None for _ in range(NSLOT)]
+        RB = (n_out + 7) // 8
+        grp_bufs = [torch.zeros((GATHER_EVERY, B, RB), dtype=torch.uint8, device=dev) for _ in range(2)]
+        grp_lists = [[torch.empty_like(grp_bufs[0]) for _ in range(N)] if rank == 0 else None for _ in range(2)]
+        grp_ptrs = [t.data_ptr() for t in grp_bufs]
+        grp_pending = [None, None]  # gather handle of the group buffer's previous use
+        compact_fn = hp._lib.tsim_sample_batch_device_compact
     else:
         d_outs = [hp.malloc(B * WO * 8) for _ in range(NSLOT)]
         out_ptrs = [d.ptr for d in d_outs]
         d_out = d_outs[0]
-    pending = [None] * NSLOT   # gather handle of the slot's previous step
-    inflight = []              # slots begun, not yet ended (oldest first)
+    inflight = []  # (slot, step id) begun, not yet joined (N == 1 bookkeeping)
 
     key = prng.key(cfg["seed"])
     shot_offset = rank * B
     step_no = [0]
 
     begin_fn = hp._lib.tsim_sample_batch_device_begin
+    end_fn = hp._lib.tsim_sample_batch_device_end
     d_f_ptr = d_f.ptr
 
-    def join(b):
-        hp.sample_batch_device_end(b)
-        if use_dist:
-            pending[b] = dist.gather(out_bufs[b], gather_lists[b], dst=0, async_op=True)
+    gathered = [0]  # groups whose gather has been issued (N > 1)
+
+    def gather_next(count=None):
+        """Issue the gather of the oldest un-gathered group (all of its steps must be joined)."""
+        k = gathered[0]
+        g = k & 1
+        count = GATHER_EVERY if count is None else count
+        src = grp_bufs[g] if count == GATHER_EVERY else grp_bufs[g][:count]
+        dst = None
+        if rank == 0:
+            dst = grp_lists[g] if count == GATHER_EVERY else [t[:count] for t in grp_lists[g]]
+        with torch.cuda.stream(ext):
+            grp_pending[g] = dist.gather(src, dst, dst=0, async_op=True)
+        gathered[0] = k + 1
 
     def step():
         nonlocal key
         key, sub = hp.split_key(key)  # one host split per batch (sampler.py:399)
-        b = step_no[0] % NSLOT
+        j = step_no[0]
+        b = j % NSLOT
         step_no[0] += 1
         if not use_dist:
             # _begin on a slot whose previous step was not joined is ordered after that step's second
@@ -254,34 +276,42 @@ def main() -> None:
             rc = begin_fn(hp._h, b, d_f_ptr, B, num_f, sub[0], sub[1], shot_offset, out_ptrs[b], None, None)
             if rc < 0:
                 raise RuntimeError(f"tsim_sample_batch_device_begin failed ({rc})")
-            if b not in inflight:
-                inflight.append(b)
+            if not inflight or len(inflight) < NSLOT:
+                inflight.append((b, j))
             return
-        with torch.cuda.stream(ext):
-            if b in inflight:  # the slot's previous step: join it (and start its gather) first
-                while inflight:
-                    o = inflight.pop(0)
-                    join(o)
-                    if o == b:
-                        break
-            if pending[b] is not None:
-                pending[b].wait()  # the engine's stream waits until the gather released buffer b
-                pending[b] = None
-            hp.sample_batch_device_begin(b, d_f.ptr, B, num_f, sub, out_ptrs[b], shot_offset=shot_offset)
-            inflight.append(b)
-            # keep at most NSLOT - 1 steps un-joined so that the next step always finds a free slot
-            while len(inflight) > NSLOT - 1:
-                join(inflight.pop(0))
+        g, pos = (j // GATHER_EVERY) & 1, j % GATHER_EVERY
+        if pos == 0 and grp_pending[g] is not None:
+            with torch.cuda.stream(ext):
+                grp_pending[g].wait()  # the engine's stream waits until the previous gather released the buffer
+            grp_pending[g] = None
+        rc = begin_fn(hp._h, b, d_f_ptr, B, num_f, sub[0], sub[1], shot_offset, out_ptrs[b], None, None)
+        if rc >= 0:  # rows -> the reference's bit_packed layout, behind the hard-row pass on the side stream
+            rc = compact_fn(hp._h, b, out_ptrs[b], B, n_out, grp_ptrs[g] + pos * B * RB, None)
+        if rc < 0:
+            raise RuntimeError(f"pipelined launch failed ({rc})")
+        # Every slot has been reused (hence joined by _begin) NSLOT steps after a step: once step
+        # (k+1)*GATHER_EVERY - 1 + NSLOT has begun, the engine's stream is ordered after every side
+        # stream that produced group k - its gather can go out without an explicit join.
+        if j + 1 >= (gathered[0] + 1) * GATHER_EVERY + NSLOT:
+            gather_next()
 
     def drain():
-        ctx = torch.cuda.stream(ext) if use_dist else contextlib.nullcontext()
-        with ctx:
+        if not use_dist:
             while inflight:
-                join(inflight.pop(0))
-            for b in range(NSLOT):
-                if pending[b] is not None:
-                    pending[b].wait()
-                    pending[b] = None
+                hp.sample_batch_device_end(inflight.pop(0)[0])
+            return
+        for b in range(NSLOT):
+            end_fn(hp._h, b, None)
+        n_steps = step_no[0]
+        while gathered[0] * GATHER_EVERY < n_steps:
+            gather_next(min(GATHER_EVERY, n_steps - gathered[0] * GATHER_EVERY))
+        with torch.cuda.stream(ext):
+            for g in range(2):
+                if grp_pending[g] is not None:
+                    grp_pending[g].wait()
+                    grp_pending[g] = None
+        gathered[0] = 0
+        step_no[0] = 0
 
     def fence():
         drain()
@@ -394,7 +424,7 @@ def main() -> None:
                 f"num_f={num_f}, p_bit={cfg['p_bit']}",
                 "shots_per_step_per_gpu": B,
                 "global_batch": B * N,
-                "sharding": f"shots x{N}, RCCL gather of packed bits" if N > 1 else "single GPU",
+                "sharding": f"shots x{N}, RCCL gather of the bit-packed rows ({(n_out + 7) // 8} B/shot)" if N > 1 else "single GPU",
                 "f_resident_in_hbm": True,
             },
             "roofline": {

@@ -187,11 +187,16 @@ int tsim_sample_batch_device(tsim_program *p, const uint64_t *d_f, int64_t B, in
  * was not ended is ordered after that slot's previous launch.  Results are identical to the
  * serial call.  Programs without pattern tables run entirely on `stream` (_end is then a no-op).
  */
-#define TSIM_PIPELINE_SLOTS 4
+#define TSIM_PIPELINE_SLOTS 8
 int tsim_sample_batch_device_begin(tsim_program *p, int32_t slot, const uint64_t *d_f, int64_t B,
                                    int32_t num_f, uint32_t key_hi, uint32_t key_lo, int64_t shot_offset,
                                    uint64_t *d_out, float *d_max_norm_dev, void *stream);
 int tsim_sample_batch_device_end(tsim_program *p, int32_t slot, void *stream);
+/* Between _begin and _end of `slot`: tsim_compact_rows_device of the launch's output rows, enqueued
+ * behind the slot's second pass (on its side stream) so that `stream` carries no extra kernel;
+ * _end then also covers d_out.  Without a second pass in flight it runs on `stream`. */
+int tsim_sample_batch_device_compact(tsim_program *p, int32_t slot, const uint64_t *d_rows, int64_t B,
+                                     int32_t nbits, uint8_t *d_out, void *stream);
 
 /*
  * Device-side post-selection (the shot-skipping of src/tsim/sampler.py:422-545, done in HBM):
@@ -232,6 +237,11 @@ int tsim_pack_bits_device(tsim_program *p, const uint8_t *d_in, int64_t B, int32
 /* packed uint64 [B,ceil(nbits/64)] (device) -> uint8 [B,nbits] (device)      */
 int tsim_unpack_bits_device(tsim_program *p, const uint64_t *d_in, int64_t B, int32_t nbits,
                             uint8_t *d_out, void *stream);
+/* uint64[B, ceil(nbits/64)] padded rows -> uint8[B, ceil(nbits/8)] rows: the reference's
+ * bit_packed=True layout (np.packbits(axis=1, bitorder="little"), sampler.py:665-669) - what a gather
+ * or a packed D2H has to move (3 instead of 8 bytes per shot for 20 outputs). d_out 4-byte aligned. */
+int tsim_compact_rows_device(tsim_program *p, const uint64_t *d_in, int64_t B, int32_t nbits,
+                             uint8_t *d_out, void *stream);
 
 /* ---- device-side noise sampler (statistical replacement of ChannelSampler.sample,
  *      src/tsim/noise/channels.py:578-658; the numpy PCG64 stream is not reproduced) ---------- */

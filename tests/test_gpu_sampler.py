@@ -183,3 +183,25 @@ def test_device_postselection(hip, mode):
                                    error_transform=noise["error_transform"])
     z = alld.sample(5000, batch_size=2000, append_observables=True, postselection_mask=mask)
     assert z[:, 0].all() and not z[:, 2:].any()
+
+
+@pytest.mark.parametrize("nbits,B", [(20, 1001), (5, 7), (64, 300), (121, 4096), (8, 3)])
+def test_compact_rows_equals_numpy_packbits(hip, nbits, B):
+    """tsim_compact_rows_device == np.packbits(bits, axis=1, bitorder="little") (sampler.py:665-669)."""
+    from tsim_amd import synth
+
+    prog, _ = synth.config_program("C1")
+    hp = hip.HipProgram(prog)
+    rng = np.random.default_rng(nbits * 1000 + B)
+    bits = rng.integers(0, 2, size=(B, nbits), dtype=np.uint8)
+    wo = (nbits + 63) // 64
+    padded = np.zeros((B, wo * 8), np.uint8)
+    pk = np.packbits(bits, axis=1, bitorder="little")
+    padded[:, : pk.shape[1]] = pk
+    d_in, d_out = hp.malloc(B * wo * 8), hp.malloc(B * pk.shape[1] + 16)
+    hp.h2d(d_in, padded)
+    hp.compact_rows_device(d_in.ptr, B, nbits, d_out.ptr)
+    hp.synchronize()
+    got = np.zeros((B, pk.shape[1]), np.uint8)
+    hp.d2h(got, d_out)
+    np.testing.assert_array_equal(got, pk)

@@ -245,6 +245,13 @@ class HipProgram:
             "tsim_unpack_bits_device",
         )
 
+    def compact_rows_device(self, d_in: int, B: int, nbits: int, d_out: int) -> None:
+        """Padded uint64 rows -> ``ceil(nbits/8)``-byte rows (``np.packbits(axis=1, bitorder="little")``)."""
+        _lib.check(
+            self._lib.tsim_compact_rows_device(self._h, C.c_void_p(d_in), int(B), int(nbits), C.c_void_p(d_out), None),
+            "tsim_compact_rows_device",
+        )
+
     def sample_batch_device(self, d_f: int, B: int, num_f: int, key, d_out: int, *,
                             shot_offset: int = 0, d_norm_dev: int = 0) -> None:
         """Asynchronous launch on the handle's stream; buffers are raw device pointers."""
@@ -257,7 +264,7 @@ class HipProgram:
             "tsim_sample_batch_device",
         )
 
-    PIPELINE_SLOTS = 4
+    PIPELINE_SLOTS = 8
 
     def split_key(self, key):
         """``prng.split`` computed by the library (same values; ~5 us cheaper per batch)."""

@@ -120,4 +120,34 @@ __global__ void __launch_bounds__(256) k_unpack_bits(const uint32_t *__restrict_
   }
 }
 
+
+// uint64[B, WO] padded rows -> ceil(nbits/8)-byte rows (== np.packbits(bits, axis=1,
+// bitorder="little"), the reference's bit_packed=True format, sampler.py:665-669): what the RCCL
+// gather and a packed D2H actually have to move.  One thread = 4 rows = rb whole output words.
+__global__ void __launch_bounds__(256) k_compact_rows(const uint64_t *__restrict__ in, uint8_t *__restrict__ out,
+                                                      long long B, int WO, int rb) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long r0 = 4 * t;
+  if (r0 >= B) return;
+  const uint64_t *src = in + r0 * WO;
+  if (r0 + 4 <= B) {
+    uint32_t *dst = reinterpret_cast<uint32_t *>(out + r0 * rb);  // 4 * rb bytes: word aligned
+    int row = 0, off = 0;
+    for (int j = 0; j < rb; ++j) {
+      uint32_t w = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const uint32_t byte = (uint32_t)(src[row * WO + (off >> 3)] >> (8 * (off & 7))) & 255u;
+        w |= byte << (8 * k);
+        if (++off == rb) { off = 0; ++row; }
+      }
+      dst[j] = w;
+    }
+  } else {
+    for (long long r = r0; r < B; ++r)
+      for (int o = 0; o < rb; ++o)
+        out[r * rb + o] = (uint8_t)(in[r * WO + (o >> 3)] >> (8 * (o & 7)));
+  }
+}
+
 }  // namespace tsimk

@@ -1730,6 +1730,26 @@ extern "C" int tsim_sample_batch_device_begin(tsim_program *p, int32_t slot, con
                        1 + slot);
 }
 
+extern "C" int tsim_sample_batch_device_compact(tsim_program *p, int32_t slot, const uint64_t *d_rows, int64_t B,
+                                                int32_t nbits, uint8_t *d_out, void *stream) {
+  if (int r = need_final(p)) return r;
+  if (int r = set_device(p)) return r;
+  if (slot < 0 || slot >= TSIM_PIPELINE_SLOTS) return fail(TSIM_EINVAL, "slot %d out of range", slot);
+  if (B < 0 || nbits < 0) return fail(TSIM_EINVAL, "negative size");
+  if (B == 0 || nbits == 0) return TSIM_OK;
+  if (!d_rows || !d_out) return fail(TSIM_EINVAL, "NULL buffer");
+  tsim_program::Slot &sl = p->slots[1 + slot];
+  // after the slot's second pass when there is one in flight, else simply on the caller's stream
+  hipStream_t s = sl.pending ? sl.side : (stream ? (hipStream_t)stream : p->stream);
+  const int WO = (nbits + 63) / 64, rb = (nbits + 7) / 8;
+  const long long nthreads = (B + 3) / 4;
+  hipLaunchKernelGGL(k_compact_rows, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, s, d_rows, d_out,
+                     (long long)B, WO, rb);
+  HIP_TRY(hipGetLastError());
+  if (sl.pending) HIP_TRY(hipEventRecord(sl.ev2, sl.side));
+  return TSIM_OK;
+}
+
 extern "C" int tsim_sample_batch_device_end(tsim_program *p, int32_t slot, void *stream) {
   if (int r = need_final(p)) return r;
   if (int r = set_device(p)) return r;
@@ -1855,6 +1875,21 @@ extern "C" int tsim_unpack_bits_device(tsim_program *p, const uint64_t *d_in, in
   if (int r = set_device(p)) return r;
   if (B < 0 || nbits < 0) return fail(TSIM_EINVAL, "negative size");
   return launch_unpack(p, d_in, B, nbits, d_out, stream ? (hipStream_t)stream : p->stream);
+}
+
+extern "C" int tsim_compact_rows_device(tsim_program *p, const uint64_t *d_in, int64_t B, int32_t nbits,
+                                        uint8_t *d_out, void *stream) {
+  if (int r = need_final(p)) return r;
+  if (int r = set_device(p)) return r;
+  if (B < 0 || nbits < 0) return fail(TSIM_EINVAL, "negative size");
+  if (B == 0 || nbits == 0) return TSIM_OK;
+  if (!d_in || !d_out) return fail(TSIM_EINVAL, "NULL buffer");
+  const int WO = (nbits + 63) / 64, rb = (nbits + 7) / 8;
+  const long long nthreads = (B + 3) / 4;
+  hipLaunchKernelGGL(k_compact_rows, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0,
+                     stream ? (hipStream_t)stream : p->stream, d_in, d_out, (long long)B, WO, rb);
+  HIP_TRY(hipGetLastError());
+  return TSIM_OK;
 }
 
 extern "C" int tsim_sample_batch(tsim_program *p, const uint8_t *f, int64_t B, int32_t num_f, uint32_t key_hi,

@@ -237,11 +237,12 @@ int tsim_pack_bits_device(tsim_program *p, const uint8_t *d_in, int64_t B, int32
 /* packed uint64 [B,ceil(nbits/64)] (device) -> uint8 [B,nbits] (device)      */
 int tsim_unpack_bits_device(tsim_program *p, const uint64_t *d_in, int64_t B, int32_t nbits,
                             uint8_t *d_out, void *stream);
-/* uint64[B, ceil(nbits/64)] padded rows -> uint8[B, ceil(nbits/8)] rows: the reference's
- * bit_packed=True layout (np.packbits(axis=1, bitorder="little"), sampler.py:665-669) - what a gather
- * or a packed D2H has to move (3 instead of 8 bytes per shot for 20 outputs). d_out 4-byte aligned. */
-int tsim_compact_rows_device(tsim_program *p, const uint64_t *d_in, int64_t B, int32_t nbits,
-                             uint8_t *d_out, void *stream);
+/* uint64[B, in_words] padded rows -> uint8[B, ceil(nbits/8)] rows holding the first nbits columns:
+ * the reference's bit_packed=True layout (np.packbits(bits[:, :nbits], axis=1, bitorder="little"),
+ * sampler.py:665-669) - what a gather or a packed D2H has to move (3 instead of 8 bytes per shot for
+ * 20 outputs).  in_words = 0: ceil(nbits/64).  d_out 4-byte aligned. */
+int tsim_compact_rows_device(tsim_program *p, const uint64_t *d_in, int64_t B, int32_t in_words,
+                             int32_t nbits, uint8_t *d_out, void *stream);
 
 /* ---- device-side noise sampler (statistical replacement of ChannelSampler.sample,
  *      src/tsim/noise/channels.py:578-658; the numpy PCG64 stream is not reproduced) ---------- */

@@ -19,7 +19,7 @@ T = np.eye(cfg["num_f"], dtype=np.uint8)
 shots, batch = 4_000_000, 1_000_000
 for mode in ("host", "device"):
     s = CompiledDetectorSampler(prog, channel_probs=probs, error_transform=T, seed=1, noise=mode)
-    s.sample(batch, batch_size=batch)  # warm-up (program upload, allocations)
+    s.sample(shots, batch_size=batch)  # warm-up with the same shape (program upload, buffer allocations)
     t0 = time.perf_counter()
     out = s.sample(shots, batch_size=batch, append_observables=True)
     dt = time.perf_counter() - t0
@@ -27,3 +27,9 @@ for mode in ("host", "device"):
     if mode == "host":
         t0 = time.perf_counter(); f = s._channel_sampler.sample(batch); dt = time.perf_counter() - t0
         print(f"   host ChannelSampler alone: {batch/dt:.3e} shots/s")
+s = CompiledDetectorSampler(prog, channel_probs=probs, error_transform=T, seed=1, noise="device")
+s.sample(shots, batch_size=batch, bit_packed=True, append_observables=True)
+t0 = time.perf_counter()
+out = s.sample(shots, batch_size=batch, bit_packed=True, append_observables=True)
+dt = time.perf_counter() - t0
+print(f"noise=device bit_packed=True p={p}: {shots/dt:.3e} shots/s end to end ({dt*1e3/(shots/1e6):.2f} ms per 1e6 shots), out {out.shape} {out.dtype}")

@@ -1,0 +1,276 @@
+"""Clifford-only front-end (tsim_amd/clifford.py): Pauli-frame analysis checked against an explicit
+stabilizer-tableau replay of every single error, the reference's seeded known-answer test, and the
+GF(2) basis conventions of the reference (find_basis / transform_error_basis / classify_direct)."""
+
+import numpy as np
+import pytest
+
+from tsim_amd.clifford import CliffordCircuit, find_basis, pauli_channel_2_probs
+
+
+def test_find_basis_reconstructs_rows_and_is_greedy():
+    rng = np.random.default_rng(0)
+    for _ in range(50):
+        n, d = int(rng.integers(1, 12)), int(rng.integers(1, 10))
+        rows = [int(rng.integers(0, 2**d)) for _ in range(n)]
+        basis_idx, combos = find_basis(rows)
+        # reconstruction: row i = XOR of basis rows selected by combos[i]
+        for i, r in enumerate(rows):
+            acc = 0
+            for pos, bi in enumerate(basis_idx):
+                if (combos[i] >> pos) & 1:
+                    acc ^= rows[bi]
+            assert acc == r
+        # greedy: a row is in the basis iff it is independent of the rows before it
+        mat = np.array([[(r >> k) & 1 for k in range(d)] for r in rows], dtype=np.uint8)
+
+        def rank(m):
+            m = m.copy() % 2
+            rk = 0
+            for c in range(m.shape[1]):
+                piv = [i for i in range(rk, m.shape[0]) if m[i, c]]
+                if not piv:
+                    continue
+                m[[rk, piv[0]]] = m[[piv[0], rk]]
+                for i in range(m.shape[0]):
+                    if i != rk and m[i, c]:
+                        m[i] ^= m[rk]
+                rk += 1
+            return rk
+
+        expect = [i for i in range(n) if rank(mat[: i + 1]) > (rank(mat[:i]) if i else 0)]
+        assert basis_idx == expect
+
+
+def test_pauli_channel_2_layout():
+    """index = z_i + 2 x_i + 4 z_j + 8 x_j (reference noise/channels.py:114-167)."""
+    args = [0.001 * (k + 1) for k in range(15)]  # IX, IY, IZ, XI, ... ZZ
+    t = pauli_channel_2_probs(*args)
+    assert t.shape == (16,) and abs(t.sum() - 1) < 1e-12
+    name = dict(zip(("IX", "IY", "IZ", "XI", "XX", "XY", "XZ", "YI", "YX", "YY", "YZ", "ZI", "ZX", "ZY", "ZZ"), args))
+    assert t[1] == name["ZI"] and t[2] == name["XI"] and t[3] == name["YI"]
+    assert t[4] == name["IZ"] and t[8] == name["IX"] and t[12] == name["IY"]
+    assert t[5] == name["ZZ"] and t[10] == name["XX"] and t[15] == name["YY"] and t[6] == name["XZ"]
+
+
+def test_reference_kat_bell_pair_with_x_error():
+    """test/integration/test_sampler_circuits.py:25-37 of the reference: 4 of 10, rows 1, 6, 8, 9."""
+    c = CliffordCircuit("""
+        R 0 1
+        H 0
+        CNOT 0 1
+        X_ERROR(0.3) 0
+        M 0 1
+        DETECTOR rec[-1] rec[-2]
+        """)
+    program, probs, et = c.compile()
+    assert program.num_outputs == 1 and program.num_detectors == 1 and not program.components
+    assert et.tolist() == [[1]] and np.allclose(probs[0], [0.7, 0.3])
+    d = c.compile_detector_sampler(seed=1).sample(10)
+    assert d.shape == (10, 1) and np.count_nonzero(d) == 4
+    assert np.nonzero(d[:, 0])[0].tolist() == [1, 6, 8, 9]
+
+
+_INVERSE = {"H": "H", "X": "X", "Y": "Y", "Z": "Z", "S": "S_DAG", "S_DAG": "S", "SQRT_X": "SQRT_X_DAG",
+            "SQRT_X_DAG": "SQRT_X", "SQRT_Y": "SQRT_Y_DAG", "SQRT_Y_DAG": "SQRT_Y", "H_YZ": "H_YZ",
+            "CX": "CX", "CZ": "CZ", "CY": "CY", "SWAP": "SWAP", "XCZ": "XCZ"}
+
+
+def _random_echo_circuit(rng, n, depth):
+    """U, then U^-1, then measure everything: every measurement is deterministic (0) without noise.
+    Returns the gate list; noise is inserted by the caller."""
+    gates = []
+    for _ in range(depth):
+        g = str(rng.choice(list(_INVERSE)))
+        if g in ("CX", "CZ", "CY", "SWAP", "XCZ"):
+            a, b = rng.choice(n, size=2, replace=False)
+            gates.append((g, (int(a), int(b))))
+        else:
+            gates.append((g, (int(rng.integers(0, n)),)))
+    inv = [(_INVERSE[g], q) for g, q in reversed(gates)]
+    return gates + inv
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_frame_propagation_matches_explicit_pauli_replay(seed):
+    """For every error bit: replace the noise channel by the explicit Pauli gate and replay the
+    noiseless tableau; the detectors that flip must be exactly those whose error set holds the bit."""
+    rng = np.random.default_rng(100 + seed)
+    n = int(rng.integers(2, 6))
+    gates = _random_echo_circuit(rng, n, int(rng.integers(4, 14)))
+    # noise sites: (position in the gate list, kind, qubits)
+    sites = []
+    for _ in range(int(rng.integers(1, 6))):
+        kind = str(rng.choice(["X_ERROR", "Y_ERROR", "Z_ERROR", "DEPOLARIZE1", "DEPOLARIZE2"]))
+        pos = int(rng.integers(0, len(gates) + 1))
+        qs = tuple(int(q) for q in rng.choice(n, size=2 if kind == "DEPOLARIZE2" else 1, replace=False))
+        sites.append((pos, kind, qs))
+    sites.sort(key=lambda s: s[0])
+    basis = str(rng.choice(["M", "MX", "MR"]))
+
+    def text(explicit=None):
+        """explicit = (site index, [pauli per qubit]) replaces that site by Pauli gates."""
+        lines, si = [f"R {' '.join(map(str, range(n)))}"], 0
+        if basis == "MX":
+            lines.append(f"H {' '.join(map(str, range(n)))}")
+        for pos in range(len(gates) + 1):
+            while si < len(sites) and sites[si][0] == pos:
+                _, kind, qs = sites[si]
+                if explicit is None:
+                    lines.append(f"{kind}(0.01) {' '.join(map(str, qs))}")
+                elif explicit[0] == si:
+                    for q, pl in zip(qs, explicit[1]):
+                        if pl != "I":
+                            lines.append(f"{pl} {q}")
+                si += 1
+            if pos < len(gates):
+                g, q = gates[pos]
+                lines.append(f"{g} {' '.join(map(str, q))}")
+        lines.append(f"{basis} {' '.join(map(str, range(n)))}")
+        for k in range(n):
+            lines.append(f"DETECTOR rec[-{k + 1}]")
+        lines.append(f"OBSERVABLE_INCLUDE(0) rec[-1] rec[-{n}]")
+        return "\n".join(lines)
+
+    an = CliffordCircuit(text()).analyze()
+    base = [v for _, v in an.detectors] + [an.observables[0][1]]
+    sets = [s for s, _ in an.detectors] + [an.observables[0][0]]
+    bit = 0
+    for si, (_, kind, qs) in enumerate(sites):
+        if kind == "DEPOLARIZE1":
+            variants = [("Z",), ("X",)]          # bit order: Z component, X component
+        elif kind == "DEPOLARIZE2":
+            variants = [("Z", "I"), ("X", "I"), ("I", "Z"), ("I", "X")]
+        else:
+            variants = [(kind[0],)]
+        for paulis in variants:
+            rep = CliffordCircuit(text((si, paulis))).analyze()
+            got = [v for _, v in rep.detectors] + [rep.observables[0][1]]
+            want = [b ^ ((s >> bit) & 1) for b, s in zip(base, sets)]
+            assert got == want, (kind, paulis, bit)
+            bit += 1
+    assert bit == an.num_e
+
+
+def _repetition_code(distance, rounds, p_data, p_meas):
+    data = list(range(0, 2 * distance, 2))
+    anc = list(range(1, 2 * distance - 1, 2))
+    L = [f"R {' '.join(map(str, data + anc))}"]
+    body = [f"X_ERROR({p_data}) {' '.join(map(str, data))}",
+            f"CX {' '.join(f'{d} {a}' for d, a in zip(data[:-1], anc))}",
+            f"CX {' '.join(f'{d} {a}' for d, a in zip(data[1:], anc))}",
+            f"MR({p_meas}) {' '.join(map(str, anc))}"]
+    k = len(anc)
+    L += body + [f"DETECTOR rec[-{k - i}]" for i in range(k)]
+    L += [f"REPEAT {rounds - 1} {{"] + body + [f"DETECTOR rec[-{k - i}] rec[-{2 * k - i}]" for i in range(k)] + ["}"]
+    L += [f"M {' '.join(map(str, data))}"]
+    d = len(data)
+    L += [f"DETECTOR rec[-{d - i}] rec[-{d - i - 1}] rec[-{d + k - i}]" for i in range(k)]
+    L += [f"OBSERVABLE_INCLUDE(0) rec[-1]"]
+    return "\n".join(L)
+
+
+def test_repetition_code_structure_and_statistics():
+    dist, rounds, p, q = 5, 4, 0.02, 0.01
+    c = CliffordCircuit(_repetition_code(dist, rounds, p, q))
+    program, probs, et = c.compile()
+    k = dist - 1
+    assert program.num_detectors == k * (rounds + 1) and program.num_outputs == program.num_detectors + 1
+    assert len(probs) == rounds * (dist + k)          # one channel per X_ERROR target and per noisy MR
+    assert not program.components                     # every detector is its own f bit (or a basis row)
+    assert et.shape[1] == len(probs)
+    shots = 200_000
+    d = c.compile_detector_sampler(seed=7).sample(shots, batch_size=50_000)
+    assert d.shape == (shots, program.num_detectors)
+    # first-round detector of an interior ancilla fires iff an odd number of {two data errors, its meas error}
+    def odd(ps):
+        r = 0.0
+        for x in ps:
+            r = r * (1 - x) + (1 - r) * x
+        return r
+    rate = d[:, 1].mean()
+    assert abs(rate - odd([p, p, q])) < 4 * np.sqrt(rate / shots) + 1e-4
+    # a middle-round detector compares two noisy measurements and sees one round of data errors
+    rate2 = d[:, k + 1].mean()
+    assert abs(rate2 - odd([p, p, q, q])) < 4 * np.sqrt(rate2 / shots) + 1e-4
+
+
+def test_flips_and_unsupported_instructions():
+    c = CliffordCircuit("X 0\nM 0 !0\nDETECTOR rec[-2]\nDETECTOR rec[-1]\nDETECTOR rec[-1] rec[-2]")
+    an = c.analyze()
+    assert [v for _, v in an.detectors] == [1, 0, 1] and all(s == 0 for s, _ in an.detectors)
+    with pytest.raises(NotImplementedError):
+        CliffordCircuit("T 0\nM 0").analyze()
+    with pytest.raises(NotImplementedError):
+        CliffordCircuit("M 0\nCX rec[-1] 1").analyze()
+    with pytest.raises(ValueError):
+        CliffordCircuit("M 0\nDETECTOR rec[-2]").analyze()
+
+
+def test_mpp_and_basis_measurements_are_consistent():
+    """Bell pair: XX and ZZ products are +1 deterministically; a Z error on one qubit flips XX only."""
+    c = CliffordCircuit("""
+        R 0 1
+        H 0
+        CX 0 1
+        Z_ERROR(0.1) 0
+        X_ERROR(0.2) 1
+        MPP X0*X1 Z0*Z1
+        DETECTOR rec[-2]
+        DETECTOR rec[-1]
+        MX 0 1
+        DETECTOR rec[-1] rec[-2]
+    """)
+    an = c.analyze()
+    assert [(s, v) for s, v in an.detectors] == [(0b01, 0), (0b10, 0), (0b01, 0)]
+
+
+def test_nondeterministic_detector_is_rejected_and_repeated_outcomes_cancel():
+    with pytest.raises(ValueError, match="not deterministic"):
+        CliffordCircuit("H 0\nM 0\nDETECTOR rec[-1]").analyze()
+    # the same random outcome twice cancels; a reset after a random outcome is deterministic again
+    an = CliffordCircuit("H 0\nM 0\nM 0\nDETECTOR rec[-1] rec[-2]\nH 1\nMR 1\nM 1\nDETECTOR rec[-1]").analyze()
+    assert [(s, v) for s, v in an.detectors] == [(0, 0), (0, 0)]
+    # Bell pair: the two Z outcomes are random but equal
+    an = CliffordCircuit("H 0\nCX 0 1\nM 0 1\nDETECTOR rec[-1] rec[-2]").analyze()
+    assert an.detectors == [(0, 0)]
+    with pytest.raises(ValueError, match="OBSERVABLE 0"):
+        CliffordCircuit("H 0\nM 0\nOBSERVABLE_INCLUDE(0) rec[-1]").compile()
+
+
+@pytest.mark.parametrize("basis", ["Z", "X"])
+@pytest.mark.parametrize("distance", [3, 5])
+def test_rotated_surface_code_compiles_to_a_direct_program(basis, distance):
+    """BASELINE.json configs[0] for real: d = 3, 3 rounds -> 24 detectors, all on the direct path."""
+    from tsim_amd.circuits import rotated_surface_code_memory
+
+    rounds = 3
+    c = CliffordCircuit(rotated_surface_code_memory(
+        distance, rounds, basis=basis, after_clifford_depolarization=0.001,
+        before_round_data_depolarization=0.002, before_measure_flip_probability=0.003,
+        after_reset_flip_probability=0.004))
+    program, probs, et = c.compile()
+    checks = distance * distance - 1
+    assert program.num_detectors == checks // 2 * 2 + checks * (rounds - 1)
+    assert program.num_outputs == program.num_detectors + 1
+    assert not program.components and not np.asarray(program.direct_flips).any()
+    assert et.shape == (program.num_outputs, sum(int(np.log2(len(p))) for p in probs))
+    # every detector is a basis row: f_j = XOR of its own error set, in output order
+    assert np.asarray(program.direct_f_indices).tolist() == list(range(program.num_outputs))
+    an = c.analyze()
+    weights = [sum((s >> e) & 1 for s, _ in an.detectors) for e in range(an.num_e)]
+    assert max(weights) <= 4 and sum(w > 0 for w in weights) > 0.6 * len(weights)
+    if distance == 3:
+        d = c.compile_detector_sampler(seed=3).sample(20000, batch_size=5000, append_observables=True)
+        assert d.shape == (20000, program.num_outputs)
+        assert 0.002 < d[:, : program.num_detectors].mean() < 0.08   # detection events are rare but present
+
+
+def test_noiseless_surface_code_has_silent_detectors():
+    from tsim_amd.circuits import rotated_surface_code_memory
+
+    c = CliffordCircuit(rotated_surface_code_memory(3, 2))
+    program, probs, et = c.compile()
+    assert probs == [] and et.shape == (1, 0)  # no error bits: every output reads the always-zero column
+    d = c.compile_detector_sampler(seed=0).sample(50, append_observables=True)
+    assert d.shape == (50, program.num_outputs) and not d.any()

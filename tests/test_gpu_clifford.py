@@ -1,0 +1,58 @@
+"""Clifford front-end outputs that are NOT single f bits (XORs of several basis bits) run as
+one-output components on the GPU; the bits must satisfy the same linear relations."""
+
+import warnings
+
+import numpy as np
+import pytest
+
+from tsim_amd.clifford import CliffordCircuit
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("noise", ["host", "device"])
+def test_dependent_and_constant_detectors(hip, noise):
+    c = CliffordCircuit("""
+        R 0 1 2
+        X 2
+        X_ERROR(0.2) 0
+        X_ERROR(0.3) 1
+        M 0 1 2
+        DETECTOR rec[-3]
+        DETECTOR rec[-2]
+        DETECTOR rec[-3] rec[-2]
+        DETECTOR rec[-1]
+        DETECTOR rec[-3] rec[-2] rec[-1]
+        OBSERVABLE_INCLUDE(1) rec[-3]
+    """)
+    program, probs, et = c.compile()
+    assert program.num_detectors == 5 and program.num_outputs == 6
+    # d0, d1 are basis rows; d2 = d0^d1 and d4 = d0^d1^1 are components; d3 is the constant 1; obs = d0 again
+    assert len(program.components) == 2 and et.shape == (3, 2)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        s = c.compile_detector_sampler(seed=11, noise=noise)
+        d = s.sample(40000, batch_size=16384, append_observables=True)
+    assert d.shape == (40000, 6)
+    np.testing.assert_array_equal(d[:, 2], d[:, 0] ^ d[:, 1])
+    assert d[:, 3].all()
+    np.testing.assert_array_equal(d[:, 4], ~(d[:, 0] ^ d[:, 1]))
+    np.testing.assert_array_equal(d[:, 5], d[:, 0])
+    assert abs(d[:, 0].mean() - 0.2) < 0.01 and abs(d[:, 1].mean() - 0.3) < 0.01
+
+
+def test_host_and_oracle_agree_on_component_program(hip):
+    """The hand-built delta components go through the same parity machinery as every other program."""
+    from oracle import oracle_c as OC
+    from tsim_amd import prng
+
+    c = CliffordCircuit("R 0 1\nX_ERROR(0.5) 0 1\nM 0 1\nDETECTOR rec[-1]\nDETECTOR rec[-2]\nDETECTOR rec[-1] rec[-2]")
+    program, _, et = c.compile()
+    f = np.random.default_rng(0).integers(0, 2, size=(500, et.shape[0]), dtype=np.uint8)
+    key = prng.key(3)
+    want, wdev, ov = OC.OracleProgram(program).sample_program(f, key, return_devs=True, return_overflow=True)
+    got, gdev = hip.HipProgram(program).sample_batch(f, key)
+    assert not ov
+    np.testing.assert_array_equal(got, want)
+    np.testing.assert_array_equal(got[:, 2], got[:, 0] ^ got[:, 1])

@@ -200,8 +200,29 @@ def test_compact_rows_equals_numpy_packbits(hip, nbits, B):
     padded[:, : pk.shape[1]] = pk
     d_in, d_out = hp.malloc(B * wo * 8), hp.malloc(B * pk.shape[1] + 16)
     hp.h2d(d_in, padded)
-    hp.compact_rows_device(d_in.ptr, B, nbits, d_out.ptr)
+    hp.compact_rows_device(d_in.ptr, B, nbits, d_out.ptr)  # in_words defaults to ceil(nbits/64)
     hp.synchronize()
     got = np.zeros((B, pk.shape[1]), np.uint8)
     hp.d2h(got, d_out)
     np.testing.assert_array_equal(got, pk)
+
+
+@pytest.mark.parametrize("append", [False, True])
+def test_bit_packed_device_fast_path_equals_packbits(hip, append):
+    """bit_packed=True with device noise takes the compact-rows path: same bytes as packing the
+    unpacked result on the host (sampler.py:665-669)."""
+    from tsim_amd import synth
+
+    prog, cfg = synth.config_program("C2")
+    nf = cfg["num_f"]
+    probs = [np.array([0.98, 0.02]) for _ in range(nf)]
+    et = np.eye(nf, dtype=np.uint8)
+    a = CompiledDetectorSampler(prog, channel_probs=probs, error_transform=et, seed=5, noise="device")
+    b = CompiledDetectorSampler(prog, channel_probs=probs, error_transform=et, seed=5, noise="device")
+    import warnings
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        packed = a.sample(5003, batch_size=2048, bit_packed=True, append_observables=append)
+        plain = b.sample(5003, batch_size=2048, append_observables=append)
+    np.testing.assert_array_equal(packed, np.packbits(plain, axis=1, bitorder="little"))

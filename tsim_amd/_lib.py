@@ -78,7 +78,7 @@ SYMBOLS: dict[str, tuple] = {
     "tsim_evaluate": (C.c_int, [_P, _I32, _I32, _P, _I64, _P, _P, _P, _P]),
     "tsim_pack_bits_device": (C.c_int, [_P, _P, _I64, _I32, _P, _P]),
     "tsim_unpack_bits_device": (C.c_int, [_P, _P, _I64, _I32, _P, _P]),
-    "tsim_compact_rows_device": (C.c_int, [_P, _P, _I64, _I32, _P, _P]),
+    "tsim_compact_rows_device": (C.c_int, [_P, _P, _I64, _I32, _I32, _P, _P]),
     "tsim_noise_create": (C.c_int, [_P, _I32, _I32, _P, _P, _P, _P, C.POINTER(_P)]),
     "tsim_noise_sample_device": (C.c_int, [_P, _I64, _U32, _U32, _P, _P]),
     "tsim_noise_destroy": (None, [_P]),

@@ -245,10 +245,12 @@ class HipProgram:
             "tsim_unpack_bits_device",
         )
 
-    def compact_rows_device(self, d_in: int, B: int, nbits: int, d_out: int) -> None:
-        """Padded uint64 rows -> ``ceil(nbits/8)``-byte rows (``np.packbits(axis=1, bitorder="little")``)."""
+    def compact_rows_device(self, d_in: int, B: int, nbits: int, d_out: int, *, in_words: int = 0) -> None:
+        """Padded uint64 rows (``in_words`` per row, default ``ceil(nbits/64)``) -> ``ceil(nbits/8)``-byte
+        rows of the first ``nbits`` columns (``np.packbits(bits[:, :nbits], axis=1, bitorder="little")``)."""
         _lib.check(
-            self._lib.tsim_compact_rows_device(self._h, C.c_void_p(d_in), int(B), int(nbits), C.c_void_p(d_out), None),
+            self._lib.tsim_compact_rows_device(self._h, C.c_void_p(d_in), int(B), int(in_words), int(nbits),
+                                               C.c_void_p(d_out), None),
             "tsim_compact_rows_device",
         )
 

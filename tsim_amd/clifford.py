@@ -1,0 +1,527 @@
+"""Clifford-only circuit front-end: Stim-style text -> compiled detector-sampling program.
+
+SURVEY.md section 8(f) row 4.  For a circuit made of Clifford gates, resets, measurements and
+Pauli noise every detector/observable is ``flip XOR (XOR of some error bits e_i)``; the reference
+finds that by ZX reduction (``prepare_graph`` -> ``zx.full_reduce``, src/tsim/core/graph.py:517-557),
+here it comes from **Pauli-frame propagation** (which errors flip which measurement) plus a small
+**stabilizer-tableau run** of the noiseless circuit (the constant ``flip``).  From there on the
+reference's own conventions are followed so that the resulting program, channel list and
+``error_transform`` are the ones the reference would hand to its sampler:
+
+* error variables and channel tables in circuit order, Z component before X component
+  (src/tsim/core/instructions.py:620-724, measurement errors :818-840);
+* outputs = detectors in order, then observables by index (core/graph.py:287-303);
+* ``e -> f`` change of basis by the greedy GF(2) elimination of ``find_basis``
+  (src/tsim/utils/linalg.py:8-79) over the outputs' error sets in output order
+  (``transform_error_basis``, core/graph.py:312-381);
+* an output that is a single ``f`` bit is a *direct* entry ``f[idx] ^ flip``
+  (``classify_direct``, core/graph.py:68-124; ``compile_program``, compile/pipeline.py:55-102),
+  sampled by ``_sample_direct`` (sampler.py:547-555).
+
+Outputs that are XORs of several basis bits (linearly dependent detectors) become one-output
+components whose marginal is a 0/1 delta (a NodePhases factor over the f bits and the outcome bit);
+outputs that no error touches read an extra, always-zero ``f`` column.  Both give the bits the
+reference gives; the *structure* of those rare components is this front-end's own.
+
+Not covered (``NotImplementedError``): non-Clifford gates (T, rotations - they need the
+stabilizer-rank compiler, out of scope), classically controlled gates, ``CORRELATED_ERROR`` chains,
+heralded channels, measurement (non-detector) sampling.
+"""
+
+from __future__ import annotations
+
+import re
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from .channels import error_probs, pauli_channel_1_probs
+from .program import CompiledComponent, CompiledProgram, make_program, scalar_graphs_from_terms
+
+__all__ = ["CliffordCircuit", "find_basis", "pauli_channel_2_probs"]
+
+
+# ---------------------------------------------------------------------------
+# channel table of the two-qubit Pauli channel (src/tsim/noise/channels.py:97-167):
+# index = z_i + 2 x_i + 4 z_j + 8 x_j
+# ---------------------------------------------------------------------------
+_P2_ARGS = ("IX", "IY", "IZ", "XI", "XX", "XY", "XZ", "YI", "YX", "YY", "YZ", "ZI", "ZX", "ZY", "ZZ")
+_XZ = {"I": (0, 0), "X": (1, 0), "Y": (1, 1), "Z": (0, 1)}
+
+
+def pauli_channel_2_probs(*p15: float) -> np.ndarray:
+    """``PAULI_CHANNEL_2`` arguments in Stim's order (IX, IY, ..., ZZ) -> 16-entry table."""
+    if len(p15) != 15:
+        raise ValueError("PAULI_CHANNEL_2 takes 15 probabilities")
+    probs = np.zeros(16, dtype=np.float64)
+    probs[0] = 1.0 - float(np.sum(np.asarray(p15, dtype=np.float64)))
+    for name, p in zip(_P2_ARGS, p15):
+        (xi, zi), (xj, zj) = _XZ[name[0]], _XZ[name[1]]
+        probs[zi + 2 * xi + 4 * zj + 8 * xj] = p
+    return probs
+
+
+# ---------------------------------------------------------------------------
+# GF(2) basis (restates src/tsim/utils/linalg.py:8-79 on Python-int bit rows)
+# ---------------------------------------------------------------------------
+def find_basis(rows: list[int]) -> tuple[list[int], list[int]]:
+    """Greedy basis of bit-vector rows: ``(basis_row_indices, combos)``.
+
+    A row is a basis row iff it is independent of the rows before it; ``combos[i]`` is the bitmask
+    (over basis positions) of the basis rows whose XOR gives row ``i``.
+    """
+    reduced: list[tuple[int, int, int]] = []  # (reduced vector, pivot bit, expansion over basis positions)
+    basis_idx: list[int] = []
+    combos: list[int] = []
+    for i, v in enumerate(rows):
+        expansion = 0
+        for rv, pivot, exp in reduced:
+            if v & pivot:
+                v ^= rv
+                expansion ^= exp
+        if v:
+            pos = len(basis_idx)
+            basis_idx.append(i)
+            expansion ^= 1 << pos
+            reduced.append((v, v & -v, expansion))  # pivot: lowest set bit == np.argmax of the 0/1 row
+            combos.append(1 << pos)
+        else:
+            combos.append(expansion)
+    return basis_idx, combos
+
+
+# ---------------------------------------------------------------------------
+# text -> flat instruction list
+# ---------------------------------------------------------------------------
+@dataclass
+class _Instr:
+    name: str
+    args: tuple
+    targets: tuple  # of str tokens
+
+
+_LINE = re.compile(r"^([A-Za-z_][A-Za-z0-9_]*)(?:\[[^\]]*\])?(?:\(([^)]*)\))?\s*(.*)$")
+
+
+def _parse(text: str) -> list[_Instr]:
+    lines = [ln.split("#", 1)[0].strip() for ln in text.replace(";", "\n").splitlines()]
+
+    def block(pos: int, depth: int) -> tuple[list[_Instr], int]:
+        out: list[_Instr] = []
+        while pos < len(lines):
+            ln = lines[pos]
+            pos += 1
+            if not ln:
+                continue
+            if ln == "}":
+                if depth == 0:
+                    raise ValueError("unmatched '}'")
+                return out, pos
+            m = _LINE.match(ln)
+            if not m:
+                raise ValueError(f"cannot parse line {ln!r}")
+            name, args, rest = m.group(1).upper(), m.group(2), m.group(3).strip()
+            if name == "REPEAT":
+                if not rest.endswith("{"):
+                    raise ValueError("REPEAT needs a '{' on the same line")
+                count = int(rest[:-1].strip())
+                body, pos = block(pos, depth + 1)
+                out.extend(body * count)
+                continue
+            a = tuple(float(x) for x in args.split(",")) if args and args.strip() else ()
+            out.append(_Instr(name, a, tuple(rest.split())))
+        if depth:
+            raise ValueError("missing '}'")
+        return out, pos
+
+    return block(0, 0)[0]
+
+
+# ---------------------------------------------------------------------------
+# stabilizer tableau (Aaronson-Gottesman), noiseless reference run
+# ---------------------------------------------------------------------------
+class _Tableau:
+    def __init__(self, n: int):
+        self.n = n
+        self.x = np.zeros((2 * n + 1, n), dtype=np.uint8)
+        self.z = np.zeros((2 * n + 1, n), dtype=np.uint8)
+        self.r = np.zeros(2 * n + 1, dtype=np.uint8)
+        # random measurement outcomes are symbols: sym[row] = bitmask of the symbols in the row's sign
+        self.sym = [0] * (2 * n + 1)
+        self.n_random = 0
+        for i in range(n):
+            self.x[i, i] = 1          # destabilizers X_i
+            self.z[n + i, i] = 1      # stabilizers Z_i  (|0...0>)
+
+    def h(self, a):
+        self.r ^= self.x[:, a] & self.z[:, a]
+        self.x[:, a], self.z[:, a] = self.z[:, a].copy(), self.x[:, a].copy()
+
+    def s(self, a):
+        self.r ^= self.x[:, a] & self.z[:, a]
+        self.z[:, a] ^= self.x[:, a]
+
+    def cx(self, a, b):
+        self.r ^= self.x[:, a] & self.z[:, b] & (self.x[:, b] ^ self.z[:, a] ^ 1)
+        self.x[:, b] ^= self.x[:, a]
+        self.z[:, a] ^= self.z[:, b]
+
+    def pauli(self, a, px, pz):  # conjugation by X^px Z^pz on qubit a: sign flips only
+        if px:
+            self.r ^= self.z[:, a]
+        if pz:
+            self.r ^= self.x[:, a]
+
+    def _rowsum(self, h, i):  # row h <- row h * row i
+        x1, z1, x2, z2 = self.x[i].astype(np.int64), self.z[i].astype(np.int64), self.x[h].astype(np.int64), self.z[h].astype(np.int64)
+        g = np.where((x1 == 1) & (z1 == 1), z2 - x2, 0)
+        g = g + np.where((x1 == 1) & (z1 == 0), z2 * (2 * x2 - 1), 0)
+        g = g + np.where((x1 == 0) & (z1 == 1), x2 * (1 - 2 * z2), 0)
+        tot = (2 * int(self.r[h]) + 2 * int(self.r[i]) + int(g.sum())) % 4
+        self.r[h] = 1 if tot == 2 else 0
+        self.sym[h] ^= self.sym[i]
+        self.x[h] ^= self.x[i]
+        self.z[h] ^= self.z[i]
+
+    def pauli_if(self, a, sym_mask):
+        """X on qubit a controlled by the XOR of the random symbols in sym_mask (reset after a random
+        measurement)."""
+        if sym_mask:
+            for row in np.nonzero(self.z[:, a])[0]:
+                self.sym[int(row)] ^= sym_mask
+
+    def measure_z(self, a) -> tuple[int, int]:
+        """Z-basis measurement -> (constant part, symbol mask).  A random outcome is a fresh symbol
+        (value 0 in the reference run); later outcomes that repeat it carry the same symbol, so a
+        detector is deterministic exactly when its symbols cancel."""
+        n = self.n
+        ps = np.nonzero(self.x[n:2 * n, a])[0]
+        if len(ps):
+            p = int(ps[0]) + n
+            for i in range(2 * n):
+                if i != p and self.x[i, a]:
+                    self._rowsum(i, p)
+            self.x[p - n], self.z[p - n], self.r[p - n] = self.x[p].copy(), self.z[p].copy(), self.r[p]
+            self.sym[p - n] = self.sym[p]
+            self.x[p] = 0
+            self.z[p] = 0
+            self.z[p, a] = 1
+            self.r[p] = 0
+            self.sym[p] = 1 << self.n_random
+            self.n_random += 1
+            return 0, self.sym[p]
+        s = 2 * n
+        self.x[s] = 0
+        self.z[s] = 0
+        self.r[s] = 0
+        self.sym[s] = 0
+        for i in range(n):
+            if self.x[i, a]:
+                self._rowsum(s, i + n)
+        return int(self.r[s]), self.sym[s]
+
+
+# ---------------------------------------------------------------------------
+# the analysis: frames + tableau driven by one gate decomposition
+# ---------------------------------------------------------------------------
+# every supported unitary as a word over primitives applied left to right:
+#   H q | S q | CX c t | P(x,z) q (Pauli X^x Z^z: tableau signs only)
+_ONE_QUBIT = {
+    "I": (), "X": (("P", 1, 0),), "Y": (("P", 1, 1),), "Z": (("P", 0, 1),),
+    "H": (("H",),), "H_XZ": (("H",),),
+    "S": (("S",),), "SQRT_Z": (("S",),),
+    "S_DAG": (("S",), ("S",), ("S",)), "SQRT_Z_DAG": (("S",), ("S",), ("S",)),
+    "SQRT_X": (("H",), ("S",), ("H",)),
+    "SQRT_X_DAG": (("H",), ("S",), ("S",), ("S",), ("H",)),
+    "SQRT_Y": (("H",), ("P", 1, 0)),          # X -> -Z, Z -> X
+    "SQRT_Y_DAG": (("P", 1, 0), ("H",)),      # X -> Z, Z -> -X
+    "H_YZ": (("H",), ("S",), ("H",), ("P", 0, 1)),  # sqrt(X) then Z: X -> -X, Y <-> Z
+}
+_TWO_QUBIT = {"CX", "CNOT", "ZCX", "CZ", "ZCZ", "CY", "ZCY", "SWAP", "XCZ"}
+_NOISE_1 = {"X_ERROR": (1, 0), "Z_ERROR": (0, 1), "Y_ERROR": (1, 1)}
+_IGNORED = {"TICK", "QUBIT_COORDS", "SHIFT_COORDS"}
+_MEASURE = {"M": "Z", "MZ": "Z", "MX": "X", "MY": "Y", "MR": "Z", "MRZ": "Z", "MRX": "X", "MRY": "Y"}
+_RESET = {"R": "Z", "RZ": "Z", "RX": "X", "RY": "Y"}
+
+
+@dataclass
+class _Analysis:
+    channel_probs: list = field(default_factory=list)
+    num_e: int = 0
+    rec_sets: list = field(default_factory=list)    # error bitmask of every measurement record
+    rec_vals: list = field(default_factory=list)    # noiseless outcome of every record
+    rec_syms: list = field(default_factory=list)    # random symbols of every record (0: deterministic)
+    detectors: list = field(default_factory=list)   # (error bitmask, flip)
+    observables: dict = field(default_factory=dict)  # index -> [error bitmask, flip]
+
+
+class _Sim:
+    def __init__(self, n_qubits: int):
+        self.n = n_qubits + 1  # one auxiliary qubit for Pauli-product measurements
+        self.aux = n_qubits
+        self.tab = _Tableau(self.n)
+        self.fx = [0] * self.n  # X component of the error frame, as bitmask over e
+        self.fz = [0] * self.n
+        self.out = _Analysis()
+
+    # primitives ---------------------------------------------------------------
+    def _h(self, q):
+        self.tab.h(q)
+        self.fx[q], self.fz[q] = self.fz[q], self.fx[q]
+
+    def _s(self, q):
+        self.tab.s(q)
+        self.fz[q] ^= self.fx[q]
+
+    def _cx(self, c, t):
+        self.tab.cx(c, t)
+        self.fx[t] ^= self.fx[c]
+        self.fz[c] ^= self.fz[t]
+
+    def gate1(self, name, q):
+        for step in _ONE_QUBIT[name]:
+            if step[0] == "H":
+                self._h(q)
+            elif step[0] == "S":
+                self._s(q)
+            else:
+                self.tab.pauli(q, step[1], step[2])
+
+    def gate2(self, name, a, b):
+        if name in ("CX", "CNOT", "ZCX"):
+            self._cx(a, b)
+        elif name == "XCZ":
+            self._cx(b, a)
+        elif name in ("CZ", "ZCZ"):
+            self._h(b); self._cx(a, b); self._h(b)
+        elif name in ("CY", "ZCY"):
+            self.gate1("S_DAG", b); self._cx(a, b); self._s(b)
+        elif name == "SWAP":
+            self._cx(a, b); self._cx(b, a); self._cx(a, b)
+
+    # noise ----------------------------------------------------------------------
+    def _new_bits(self, k: int) -> list[int]:
+        first = self.out.num_e
+        self.out.num_e += k
+        return [1 << (first + i) for i in range(k)]
+
+    def error1(self, q, x, z, p):
+        self.out.channel_probs.append(error_probs(p))
+        (b,) = self._new_bits(1)
+        if x:
+            self.fx[q] ^= b
+        if z:
+            self.fz[q] ^= b
+
+    def pauli_channel_1(self, q, px, py, pz):
+        self.out.channel_probs.append(pauli_channel_1_probs(px, py, pz))
+        bz, bx = self._new_bits(2)  # Z component first (instructions.py:631-638)
+        self.fz[q] ^= bz
+        self.fx[q] ^= bx
+
+    def pauli_channel_2(self, qi, qj, p15):
+        self.out.channel_probs.append(pauli_channel_2_probs(*p15))
+        bzi, bxi, bzj, bxj = self._new_bits(4)
+        self.fz[qi] ^= bzi; self.fx[qi] ^= bxi
+        self.fz[qj] ^= bzj; self.fx[qj] ^= bxj
+
+    # measurement / reset -----------------------------------------------------------
+    def _basis_in(self, q, basis):
+        if basis == "X":
+            self.gate1("H", q)
+        elif basis == "Y":
+            self.gate1("H_YZ", q)
+
+    def measure(self, q, basis="Z", p=0.0, invert=False, reset=False):
+        self._basis_in(q, basis)
+        flips = self.fx[q]
+        if p > 0:  # the outcome flips, the state does not (X before and after, instructions.py:818-840)
+            self.out.channel_probs.append(error_probs(p))
+            (b,) = self._new_bits(1)
+            flips ^= b
+        val, sym = self.tab.measure_z(q)
+        self.out.rec_sets.append(flips)
+        self.out.rec_vals.append(val ^ (1 if invert else 0))
+        self.out.rec_syms.append(sym)
+        if reset:
+            self._reset_z(q)
+        self._basis_in(q, basis)  # H and H_YZ are self-inverse
+
+    def _reset_z(self, q):
+        val, sym = self.tab.measure_z(q)
+        if val:
+            self.tab.pauli(q, 1, 0)
+        self.tab.pauli_if(q, sym)
+        self.fx[q] = 0
+        self.fz[q] = 0
+
+    def reset(self, q, basis="Z"):
+        self._reset_z(q)
+        self._basis_in(q, basis)
+
+    def mpp(self, paulis, p=0.0, invert=False):
+        """One Pauli product through the auxiliary qubit (instructions.py:874-909)."""
+        a = self.aux
+        self._reset_z(a)
+        self._h(a)
+        for kind, q in paulis:
+            self.gate2({"X": "CX", "Z": "CZ", "Y": "CY"}[kind], a, q)
+        self._h(a)
+        self.measure(a, "Z", p=p, invert=invert)
+
+
+class CliffordCircuit:
+    """A Clifford + Pauli-noise circuit in Stim's text format (the subset listed in the module
+    docstring), compiled to the same `(program, channel_probs, error_transform)` triple the
+    reference produces for such circuits."""
+
+    def __init__(self, text: str):
+        self.instructions = _parse(text)
+        self._compiled = None
+
+    # -- analysis -------------------------------------------------------------------
+    def _qubit_count(self) -> int:
+        hi = -1
+        for ins in self.instructions:
+            if ins.name in ("DETECTOR", "OBSERVABLE_INCLUDE") or ins.name in _IGNORED:
+                continue
+            for t in ins.targets:
+                for tok in t.split("*"):
+                    m = re.fullmatch(r"!?[XYZxyz]?(\d+)", tok)
+                    if m:
+                        hi = max(hi, int(m.group(1)))
+        return hi + 1
+
+    def analyze(self) -> _Analysis:
+        sim = _Sim(max(1, self._qubit_count()))
+        out = sim.out
+
+        def rec(tok: str) -> int:
+            m = re.fullmatch(r"rec\[-(\d+)\]", tok)
+            if not m:
+                raise ValueError(f"expected rec[-k], got {tok!r}")
+            k = int(m.group(1))
+            if k < 1 or k > len(out.rec_sets):
+                raise ValueError(f"{tok} reaches before the first measurement")
+            return len(out.rec_sets) - k
+
+        for ins in self.instructions:
+            name, args, tg = ins.name, ins.args, ins.targets
+            if name in _IGNORED:
+                continue
+            if any(t.startswith(("rec[", "sweep[")) for t in tg) and name not in ("DETECTOR", "OBSERVABLE_INCLUDE"):
+                raise NotImplementedError(f"classically controlled {name} is not supported by the Clifford front-end")
+            if name in _ONE_QUBIT:
+                for t in tg:
+                    sim.gate1(name, int(t))
+            elif name in _TWO_QUBIT:
+                if len(tg) % 2:
+                    raise ValueError(f"{name} needs an even number of targets")
+                for i in range(0, len(tg), 2):
+                    sim.gate2(name, int(tg[i]), int(tg[i + 1]))
+            elif name in _NOISE_1:
+                x, z = _NOISE_1[name]
+                for t in tg:
+                    sim.error1(int(t), x, z, args[0])
+            elif name == "DEPOLARIZE1":
+                for t in tg:
+                    sim.pauli_channel_1(int(t), args[0] / 3, args[0] / 3, args[0] / 3)
+            elif name == "PAULI_CHANNEL_1":
+                for t in tg:
+                    sim.pauli_channel_1(int(t), *args)
+            elif name in ("DEPOLARIZE2", "PAULI_CHANNEL_2"):
+                p15 = (args[0] / 15,) * 15 if name == "DEPOLARIZE2" else args
+                for i in range(0, len(tg), 2):
+                    sim.pauli_channel_2(int(tg[i]), int(tg[i + 1]), p15)
+            elif name in _MEASURE:
+                for t in tg:
+                    inv = t.startswith("!")
+                    sim.measure(int(t.lstrip("!")), _MEASURE[name], p=args[0] if args else 0.0, invert=inv,
+                                reset=name.startswith("MR"))
+            elif name in _RESET:
+                for t in tg:
+                    sim.reset(int(t), _RESET[name])
+            elif name == "MPP":
+                for t in tg:
+                    inv = t.startswith("!")
+                    paulis = [(tok[0].upper(), int(tok[1:])) for tok in t.lstrip("!").split("*")]
+                    sim.mpp(paulis, p=args[0] if args else 0.0, invert=inv)
+            elif name == "DETECTOR":
+                s, v, y = 0, 0, 0
+                for t in tg:
+                    s ^= out.rec_sets[rec(t)]
+                    v ^= out.rec_vals[rec(t)]
+                    y ^= out.rec_syms[rec(t)]
+                if y:
+                    raise ValueError(f"DETECTOR {' '.join(tg)} (detector {len(out.detectors)}) is not deterministic: "
+                                     "its measurements depend on random outcomes that do not cancel")
+                out.detectors.append((s, v))
+            elif name == "OBSERVABLE_INCLUDE":
+                idx = int(args[0]) if args else 0
+                cur = out.observables.setdefault(idx, [0, 0, 0])
+                for t in tg:
+                    cur[0] ^= out.rec_sets[rec(t)]
+                    cur[1] ^= out.rec_vals[rec(t)]
+                    cur[2] ^= out.rec_syms[rec(t)]
+            else:
+                raise NotImplementedError(f"instruction {name} is not supported by the Clifford front-end")
+        return out
+
+    # -- program assembly -------------------------------------------------------------------
+    def compile(self):
+        """``(program, channel_probs, error_transform)`` for detector sampling."""
+        if self._compiled is not None:
+            return self._compiled
+        an = self.analyze()
+        for k, (_, _, y) in an.observables.items():
+            if y:
+                raise ValueError(f"OBSERVABLE {k} is not deterministic: its random outcomes do not cancel")
+        outputs = list(an.detectors) + [tuple(an.observables[k][:2]) for k in sorted(an.observables)]
+        n_det, n_out = len(an.detectors), len(outputs)
+        # rows of the error matrix: outputs that carry at least one error bit, in output order
+        rows = [(i, s) for i, (s, _) in enumerate(outputs) if s]
+        basis_idx, combos = find_basis([s for _, s in rows])
+        num_f = len(basis_idx)
+        need_zero_col = any(not s for s, _ in outputs)
+        error_transform = np.zeros((num_f + (1 if need_zero_col else 0), an.num_e), dtype=np.uint8)
+        for pos, bi in enumerate(basis_idx):
+            s = rows[bi][1]
+            for e in range(an.num_e):
+                if (s >> e) & 1:
+                    error_transform[pos, e] = 1
+        combo_of = {i: combos[j] for j, (i, _) in enumerate(rows)}
+        direct, components = [], []
+        for i, (s, flip) in enumerate(outputs):
+            c = combo_of.get(i, 0)
+            if not s:
+                direct.append((i, num_f, bool(flip)))  # the always-zero column
+            elif c & (c - 1) == 0:
+                direct.append((i, c.bit_length() - 1, bool(flip)))
+            else:  # XOR of several basis bits: deterministic one-output component
+                fsel = [b for b in range(num_f) if (c >> b) & 1]
+                F = len(fsel)
+                lv0 = scalar_graphs_from_terms(F, [dict(floatfactor=(1, 0, 0, 0), power2=0)])
+                lv1 = scalar_graphs_from_terms(F + 1, [dict(floatfactor=(1, 0, 0, 0), power2=-1,
+                                                            A=[(4 * int(flip), list(range(F + 1)))])])
+                components.append(CompiledComponent((i,), np.asarray(fsel, np.int32), (lv0, lv1)))
+        program = make_program(components, direct, n_out, n_det)
+        self._compiled = (program, list(an.channel_probs), error_transform)
+        return self._compiled
+
+    def compile_detector_sampler(self, *, seed: int | None = None, device: int = 0, noise: str = "host",
+                                 mode: str = "auto"):
+        """Mirror of ``Circuit.compile_detector_sampler`` (src/tsim/circuit.py:836-867)."""
+        from .sampler import CompiledDetectorSampler
+
+        program, channel_probs, error_transform = self.compile()
+        return CompiledDetectorSampler(program, channel_probs=channel_probs, error_transform=error_transform,
+                                       seed=seed, device=device, noise=noise, mode=mode)
+
+    @property
+    def num_detectors(self) -> int:
+        return int(self.compile()[0].num_detectors)
+
+    @property
+    def num_observables(self) -> int:
+        p = self.compile()[0]
+        return int(p.num_outputs - p.num_detectors)

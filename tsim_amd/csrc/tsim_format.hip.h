@@ -125,7 +125,7 @@ __global__ void __launch_bounds__(256) k_unpack_bits(const uint32_t *__restrict_
 // bitorder="little"), the reference's bit_packed=True format, sampler.py:665-669): what the RCCL
 // gather and a packed D2H actually have to move.  One thread = 4 rows = rb whole output words.
 __global__ void __launch_bounds__(256) k_compact_rows(const uint64_t *__restrict__ in, uint8_t *__restrict__ out,
-                                                      long long B, int WO, int rb) {
+                                                      long long B, int WO, int rb, uint32_t tail_mask) {
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long r0 = 4 * t;
   if (r0 >= B) return;
@@ -137,7 +137,8 @@ __global__ void __launch_bounds__(256) k_compact_rows(const uint64_t *__restrict
       uint32_t w = 0;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const uint32_t byte = (uint32_t)(src[row * WO + (off >> 3)] >> (8 * (off & 7))) & 255u;
+        uint32_t byte = (uint32_t)(src[row * WO + (off >> 3)] >> (8 * (off & 7))) & 255u;
+        if (off == rb - 1) byte &= tail_mask;  // columns beyond nbits do not belong to the row
         w |= byte << (8 * k);
         if (++off == rb) { off = 0; ++row; }
       }
@@ -146,7 +147,7 @@ __global__ void __launch_bounds__(256) k_compact_rows(const uint64_t *__restrict
   } else {
     for (long long r = r0; r < B; ++r)
       for (int o = 0; o < rb; ++o)
-        out[r * rb + o] = (uint8_t)(in[r * WO + (o >> 3)] >> (8 * (o & 7)));
+        out[r * rb + o] = (uint8_t)((uint32_t)(in[r * WO + (o >> 3)] >> (8 * (o & 7))) & (o == rb - 1 ? tail_mask : 255u));
   }
 }
 

@@ -1743,8 +1743,9 @@ extern "C" int tsim_sample_batch_device_compact(tsim_program *p, int32_t slot, c
   hipStream_t s = sl.pending ? sl.side : (stream ? (hipStream_t)stream : p->stream);
   const int WO = (nbits + 63) / 64, rb = (nbits + 7) / 8;
   const long long nthreads = (B + 3) / 4;
+  const uint32_t tail_mask = (nbits & 7) ? ((1u << (nbits & 7)) - 1u) : 255u;
   hipLaunchKernelGGL(k_compact_rows, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, s, d_rows, d_out,
-                     (long long)B, WO, rb);
+                     (long long)B, WO, rb, tail_mask);
   HIP_TRY(hipGetLastError());
   if (sl.pending) HIP_TRY(hipEventRecord(sl.ev2, sl.side));
   return TSIM_OK;
@@ -1877,17 +1878,19 @@ extern "C" int tsim_unpack_bits_device(tsim_program *p, const uint64_t *d_in, in
   return launch_unpack(p, d_in, B, nbits, d_out, stream ? (hipStream_t)stream : p->stream);
 }
 
-extern "C" int tsim_compact_rows_device(tsim_program *p, const uint64_t *d_in, int64_t B, int32_t nbits,
-                                        uint8_t *d_out, void *stream) {
+extern "C" int tsim_compact_rows_device(tsim_program *p, const uint64_t *d_in, int64_t B, int32_t in_words,
+                                        int32_t nbits, uint8_t *d_out, void *stream) {
   if (int r = need_final(p)) return r;
   if (int r = set_device(p)) return r;
-  if (B < 0 || nbits < 0) return fail(TSIM_EINVAL, "negative size");
+  if (B < 0 || nbits < 0 || in_words < 0) return fail(TSIM_EINVAL, "negative size");
   if (B == 0 || nbits == 0) return TSIM_OK;
   if (!d_in || !d_out) return fail(TSIM_EINVAL, "NULL buffer");
-  const int WO = (nbits + 63) / 64, rb = (nbits + 7) / 8;
+  const int WO = in_words ? in_words : (nbits + 63) / 64, rb = (nbits + 7) / 8;
+  if ((long long)WO * 64 < nbits) return fail(TSIM_EINVAL, "rows of %d words hold fewer than %d bits", WO, nbits);
   const long long nthreads = (B + 3) / 4;
+  const uint32_t tail_mask = (nbits & 7) ? ((1u << (nbits & 7)) - 1u) : 255u;
   hipLaunchKernelGGL(k_compact_rows, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0,
-                     stream ? (hipStream_t)stream : p->stream, d_in, d_out, (long long)B, WO, rb);
+                     stream ? (hipStream_t)stream : p->stream, d_in, d_out, (long long)B, WO, rb, tail_mask);
   HIP_TRY(hipGetLastError());
   return TSIM_OK;
 }

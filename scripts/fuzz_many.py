@@ -15,9 +15,13 @@ for seed in range(n):
     want, wdev, ov = OC.OracleProgram(prog).sample_program(f, key, return_devs=True, return_overflow=True)
     if ov:
         skipped += 1; continue
-    for mode in ("auto", "rows", "faithful"):
-        hp = hip.HipProgram(prog, mode=mode)
+    for mode, pt in (("auto", None), ("auto", False), ("rows", True), ("faithful", True), ("auto", 1)):
+        hp = hip.HipProgram(prog, mode=mode, pattern_tables=pt)
         got, gdev = hp.sample_batch(f, key)
+        if pt is None and seed % 3 == 0:  # a second launch on the same handle: the adaptive plan must not change bits
+            got2, _ = hp.sample_batch(f, key)
+            if not np.array_equal(got2, got):
+                bad += 1; print("MISMATCH (second launch) seed", seed, mode, hp.info())
         if not (np.array_equal(got, want) and np.array_equal(np.asarray(gdev, np.float32), np.asarray(wdev, np.float32), equal_nan=True)):
-            bad += 1; print("MISMATCH seed", seed, mode, hp.info())
+            bad += 1; print("MISMATCH seed", seed, mode, pt, hp.info())
 print("done", n, "programs; mismatches", bad, "skipped(overflow)", skipped)

@@ -150,6 +150,14 @@ struct tsim_program {
   volatile uint32_t *h_feedback = nullptr;
   uint32_t *d_feedback = nullptr;
   int lw_direct_left = 0;     // launches still to run on the full kernel before the next probe
+  // launch-time tuning knobs, read from the environment once at finalize (experiments only)
+  struct Knobs {
+    bool adaptive = true;     // TSIM_AMD_ADAPTIVE=0 pins the default launch plan
+    bool hard_kernel = true;  // TSIM_AMD_HARD_KERNEL=0: hard rows on k_sample4 instead of k_sample4h
+    int lw_block = 256;       // TSIM_AMD_LW_BLOCK
+    int v4_block = 256;       // TSIM_AMD_V4_BLOCK
+    int hard_lds_kb = 150;    // TSIM_AMD_HARD_LDS_KB
+  } knobs;
   bool h_attr_set = false;    // k_sample4h: large dynamic LDS enabled
   int lw_off = 0;             // image offset of the LW component records
   int lw_direct_prog = 0;     // image offset of the direct-output gather program
@@ -1326,6 +1334,16 @@ retry_pack:
   img.resize(img.size() + 256, 0u);  // tail padding: wide scalar loads may over-read
   if (img.size() >= (1ull << 31)) return fail(TSIM_ENOTSUP, "program image too large");
 
+  {
+    auto env_int = [](const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; };
+    p->knobs.adaptive = env_int("TSIM_AMD_ADAPTIVE", 1) != 0;
+    p->knobs.hard_kernel = env_int("TSIM_AMD_HARD_KERNEL", 1) != 0;
+    p->knobs.lw_block = std::max(64, std::min(1024, env_int("TSIM_AMD_LW_BLOCK", 256) & ~63));
+    const int vb = env_int("TSIM_AMD_V4_BLOCK", 256);
+    p->knobs.v4_block = (vb == 512 || vb == 128) ? vb : 256;
+    p->knobs.hard_lds_kb = std::max(24, std::min(156, env_int("TSIM_AMD_HARD_LDS_KB", 150)));
+  }
+
   // ---- upload ----
   int ndev = 0;
   HIP_TRY(hipGetDeviceCount(&ndev));
@@ -1564,7 +1582,7 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
   //    on every row for the next 15 launches, then probe again with one two-pass launch;
   //  * hard-row lists short: k_sample4h walks them alone, no overflow launch of k_sample4.
   bool use_tables = p->lw, need_overflow = true;
-  if (p->lw && p->h_feedback && !(getenv("TSIM_AMD_ADAPTIVE") && atoi(getenv("TSIM_AMD_ADAPTIVE")) == 0)) {
+  if (p->lw && p->h_feedback && p->knobs.adaptive) {
     const uint32_t fb_sum = p->h_feedback[0], fb_max = p->h_feedback[1], fb_rows = p->h_feedback[2];
     const bool known = fb_rows != 0xFFFFFFFFu && fb_rows > 0u && fb_sum != 0xFFFFFFFFu;
     if (p->lw_direct_left > 0) {
@@ -1578,8 +1596,7 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
   if (use_tables) {
     // pass 1: shots whose f_sel patterns are tabulated finish here, the others go to the hard list
     if (B > 0xFFFFFFFFll) return fail(TSIM_ENOTSUP, "batch too large for the row list");
-    const char *b1env = getenv("TSIM_AMD_LW_BLOCK");
-    const int blk1 = b1env ? std::max(64, std::min(1024, atoi(b1env) & ~63)) : 256;
+    const int blk1 = p->knobs.lw_block;
     const long long grid1 = (B + blk1 - 1) / blk1;
     const long long list_cap = (grid1 + TSIMK_LW_LISTS - 1) / TSIMK_LW_LISTS * blk1;
     if (list_cap > 0x7FFFFFFFll) return fail(TSIM_ENOTSUP, "batch too large for the row lists");
@@ -1632,19 +1649,16 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
     a4.s = a;
     a4.comp4_off = p->comp4_off;
     a4.has_check = has_check ? 1 : 0;
-    const char *benv = getenv("TSIM_AMD_V4_BLOCK");
-    const int blk = (benv && atoi(benv) == 512) ? 512 : ((benv && atoi(benv) == 128) ? 128 : 256);
+    const int blk = p->knobs.v4_block;
     const size_t tile_bytes = std::max((size_t)p->v4_max_nch * 16, (size_t)p->v4_max_sent) * p->v4_gt * 16;
     const size_t lds4 = (size_t)(2 * a.WF + 2 * a.WO) * blk * 4 + 2 * tile_bytes;
     if (lds4 > 64 * 1024) return fail(TSIM_ENOTSUP, "v4 kernel needs %zu B of LDS", lds4);
-    const char *henv = getenv("TSIM_AMD_HARD_KERNEL");
-    if (a.row_lists > 1 && !(henv && atoi(henv) == 0)) {
+    if (a.row_lists > 1 && p->knobs.hard_kernel) {
       // short row lists (second pass of a two-pass launch): NW waves per 64 rows, tsim_kernel4h.hip.h
       constexpr int NW = 8;
       const size_t tile_b = (size_t)p->v4_max_nch * 16 * p->v4_gt * 16;
       const size_t fixed_b = (size_t)(2 * a.WF + 2 * a.WO) * 64 * 4 + (size_t)NW * 8 * 64 * 4;
-      const char *lenv = getenv("TSIM_AMD_HARD_LDS_KB");
-      const size_t budget = (size_t)(lenv ? std::max(24, std::min(156, atoi(lenv))) : 150) * 1024;
+      const size_t budget = (size_t)p->knobs.hard_lds_kb * 1024;
       int group_tiles = fixed_b + tile_b <= budget ? (int)std::min<size_t>(TSIMK_H_MAX_GROUP_TILES, (budget - fixed_b) / tile_b) : 0;
       if (group_tiles >= 1) {
         // the first kHardBlocks * 64 slots of every list go to the NW-wave kernel; k_sample4 below

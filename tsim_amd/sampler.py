@@ -45,6 +45,8 @@ _backend_sample_program = sample_program
 class _CompiledSamplerBase:
     """Shared state: key, compiled program, channel sampler, direct-output tables."""
 
+    _PIPELINE = 3  # launches in flight on the device path (one f buffer each)
+
     def __init__(
         self,
         program,
@@ -229,20 +231,27 @@ class _CompiledSamplerBase:
         if st["bufs"] is None or st["bufs"]["need"] != need:
             st["bufs"] = dict(
                 need=need,
-                f=hp.malloc(batch_size * wf * 8),
+                f=[hp.malloc(batch_size * wf * 8) for _ in range(self._PIPELINE)],
                 out=hp.malloc(total * wo * 8),
                 u8=hp.malloc(total * n_out),
                 devs=hp.malloc(num_batches * n_comp * 4),
             )
         b = st["bufs"]
+        # pipelined launches (include/tsim_hip.h: tsim_sample_batch_device_begin/_end): batch i's
+        # hard-row pass runs on a side stream under the noise sampling and first pass of batch i+1;
+        # each slot owns an f buffer, every batch its own slice of the output buffer
         for i in range(num_batches):
+            slot = i % self._PIPELINE
+            hp.sample_batch_device_end(slot)  # the slot's previous batch no longer reads its f buffer
             self._noise_key, nk = prng.split(self._noise_key)
-            st["noise"].sample_into(b["f"].ptr, batch_size, nk)
+            st["noise"].sample_into(b["f"][slot].ptr, batch_size, nk)
             self._key, subkey = prng.split(self._key)
-            hp.sample_batch_device(
-                b["f"].ptr, batch_size, num_f, subkey, b["out"].ptr + i * batch_size * wo * 8,
+            hp.sample_batch_device_begin(
+                slot, b["f"][slot].ptr, batch_size, num_f, subkey, b["out"].ptr + i * batch_size * wo * 8,
                 d_norm_dev=b["devs"].ptr + i * n_comp * 4,
             )
+        for slot in range(self._PIPELINE):
+            hp.sample_batch_device_end(slot)
         if packed_columns is not None:
             # bit_packed=True of the first `packed_columns` columns: ceil(n/8) bytes per shot over PCIe
             rb = (packed_columns + 7) // 8

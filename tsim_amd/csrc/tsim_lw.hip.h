@@ -13,16 +13,13 @@
 //           component has a tabulated pattern finish here: per output one Threefry draw and one
 //           4-byte table gather (`u < thr[pattern][prefix node]`).  The others are appended to the
 //           "hard" list.
-//   pass 2: the full kernel (k_sample4 / k_sample) on the hard list only (row indirection).
+//   pass 2: the hard rows only (row indirection): k_sample4h (tsim_kernel4h.hip.h) for the first 256
+//           slots of each of the 64 lists, k_sample4 / k_sample for the rest.
 //
 // Results are bit-identical to running the full kernel on every shot: same thresholds (floats
 // produced by the same instruction sequence), same draws (Threefry counter = in-batch shot index).
 #pragma once
 #include "tsim_kernels.hip.h"
-
-#ifndef LW_EXP
-#define LW_EXP 0
-#endif
 
 namespace tsimk {
 
@@ -180,9 +177,7 @@ __global__ void __launch_bounds__(1024) k_sample_lw(LwArgs L) {
       lw_gather(img + rec[LW_FSELP], rec[LW_FSELN], lds_f, nullptr, nthr, x0, x1);
       unsigned long long xf = ((unsigned long long)x1 << 32) | x0;
       const uint32_t cnt = (uint32_t)__popcll(xf);
-#if LW_EXP != 1
       if (cnt > rec[LW_WMAX]) hard = true;
-#endif
       if (hard) continue;  // needs the full kernel: nothing of this row is written here
       // colex rank of the (<= 3)-subset
       uint32_t b0 = 0, b1 = 0, b2 = 0;
@@ -197,16 +192,8 @@ __global__ void __launch_bounds__(1024) k_sample_lw(LwArgs L) {
       const float *thr = L.tab + rec[LW_TAB] + ((size_t)pat << n_out);
       uint32_t node = 1u;
       for (uint32_t i = 0; i < n_out; ++i) {
-#if LW_EXP == 3
-        const float u = __uint_as_float((((uint32_t)shot * 2654435761u + i) >> 9) | 0x3F800000u) - 1.0f;
-#else
         const float u = uniform01(subkey(A, keybase + i, 0), subkey(A, keybase + i, 1), shot);  // sampler.py:74-75
-#endif
-#if LW_EXP == 2
-        const bool bit = u < 0.5f;
-#else
         const bool bit = u < thr[node];
-#endif
         node = 2u * node + (bit ? 1u : 0u);
         const uint32_t dst = outpos[i];
         const uint32_t v = (bit ? 1u : 0u) << (dst & 31u);
@@ -215,11 +202,7 @@ __global__ void __launch_bounds__(1024) k_sample_lw(LwArgs L) {
         else lds_o[(dst >> 5) * nthr] |= v;
       }
     }
-#if LW_EXP == 4
-    if (o0 == 0x12345u) {
-#else
     if (!hard) {
-#endif
       uint64_t *orow = A.out + row * A.WO;
       if (A.WO > 0) orow[0] = (uint64_t)o0 | ((uint64_t)o1 << 32);
       for (int w = 1; w < A.WO; ++w)

@@ -150,10 +150,25 @@ def cpu_baseline(program, cfg, seconds: float = 15.0) -> dict:
     t0 = time.perf_counter()
     op.sample_program(f, (1, 2), threads=threads)
     dt = time.perf_counter() - t0
+    # also the single-threaded rate (the reference's ChannelSampler and Python driver are
+    # single-threaded) and the numpy restatement that keeps the reference's data movement (byte-per-bit
+    # float32 GEMM % 2, materialised lookups, sequential scans) - small samples, a few seconds each
+    f1 = synth.synth_f(20_000, cfg["num_f"], cfg["p_bit"], seed=cfg["seed"])
+    t1 = time.perf_counter()
+    op.sample_program(f1, (1, 2), threads=1)
+    single = len(f1) / (time.perf_counter() - t1)
+    from oracle import oracle_np
+
+    f2 = synth.synth_f(2048, cfg["num_f"], cfg["p_bit"], seed=cfg["seed"])
+    t2 = time.perf_counter()
+    oracle_np.sample_program(program, f2, (1, 2))
+    faithful = len(f2) / (time.perf_counter() - t2)
     return {
         "value": n / dt,
         "unit": "shots/s",
         "cores": cores,
+        "single_thread_value": single,
+        "numpy_reference_faithful_value": faithful,
         "kind": "port",
         "sample": f"{n} shots of the same C2 program and f distribution, C oracle (oracle/oracle.c, "
         f"OpenMP over shots, {threads} threads on {cores} CPUs; {note}), {dt:.1f} s wall",

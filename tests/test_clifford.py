@@ -274,3 +274,60 @@ def test_noiseless_surface_code_has_silent_detectors():
     assert probs == [] and et.shape == (1, 0)  # no error bits: every output reads the always-zero column
     d = c.compile_detector_sampler(seed=0).sample(50, append_observables=True)
     assert d.shape == (50, program.num_outputs) and not d.any()
+
+
+# ---------------------------------------------------------------------------
+# measurement sampling: programs from circuit text reproduce the reference's seeded counts
+# (through the CPU oracle here; through the GPU in tests/test_gpu_clifford.py)
+# ---------------------------------------------------------------------------
+def _oracle_counts(text, seed, shots_list):
+    from conftest import run_batches
+    from oracle import oracle_np as O
+
+    program, probs, et = CliffordCircuit(text).compile_measurements()
+    assert probs == []
+
+    def np_sample(prog, f, key):
+        return O.sample_program(prog, f, key)
+
+    return program, run_batches(np_sample, program, seed, shots_list, num_f=et.shape[0])
+
+
+def test_measurement_kats_from_text():
+    # test/unit/test_sampler.py:223-233
+    _, outs = _oracle_counts("H 0\nM 0", 0, [100] * 4)
+    assert [int(o.sum()) for o in outs] == [48, 53, 52, 50]
+    # test/integration/test_sampler_circuits.py:10-22
+    prog, (o,) = _oracle_counts("R 0 1\nH 0\nCNOT 0 1\nM 0 1", 0, [100])
+    assert len(prog.components) == 1 and prog.components[0].output_indices == (0, 1)
+    assert np.array_equal(o[:, 0], o[:, 1]) and int(o[:, 0].sum()) == 48
+    # test/integration/test_sampler_circuits.py:90-109: three single-output components, the last one constant
+    prog, (o,) = _oracle_counts("RX 0\nRX 0\nM 0\nRX 0\nM 0\nR 0\nM 0", 0, [10])
+    assert len(prog.components) == 3
+    assert o.sum(axis=0).tolist() == [7, 4, 0]
+
+
+def test_measurement_program_structure_with_noise():
+    c = CliffordCircuit("""
+        R 0 1 2
+        X_ERROR(0.1) 0
+        H 1
+        CX 1 2
+        X_ERROR(0.2) 2
+        M 0 1 2 !2
+    """)
+    program, probs, et = c.compile_measurements()
+    # record 0 = e0 (direct), records 1, 2, 3 share the random bit of the Bell pair; 2 and 3 carry e1
+    assert program.num_outputs == 4 and len(probs) == 2 and et.tolist() == [[1, 0], [0, 1]]
+    assert np.asarray(program.direct_f_indices).tolist() == [0]
+    (comp,) = program.components
+    assert comp.output_indices == (1, 2, 3) and np.asarray(comp.f_selection).tolist() == [1]
+    from oracle import oracle_np as O
+    from tsim_amd import prng
+
+    f = np.array([[0, 0], [1, 0], [0, 1], [1, 1]] * 50, dtype=np.uint8)
+    out = O.sample_program(program, f, prng.key(4))
+    np.testing.assert_array_equal(out[:, 0], f[:, 0].astype(bool))
+    np.testing.assert_array_equal(out[:, 2], out[:, 1] ^ f[:, 1].astype(bool))   # m2 = m1 ^ e1
+    np.testing.assert_array_equal(out[:, 3], ~out[:, 2])                          # inverted record
+    assert 60 < out[:, 1].sum() < 140

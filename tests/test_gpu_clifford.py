@@ -56,3 +56,24 @@ def test_host_and_oracle_agree_on_component_program(hip):
     assert not ov
     np.testing.assert_array_equal(got, want)
     np.testing.assert_array_equal(got[:, 2], got[:, 0] ^ got[:, 1])
+
+
+def test_measurement_sampler_kats_from_circuit_text(hip):
+    """The reference's seeded measurement-sampler counts, from circuit text through the GPU:
+    test/unit/test_sampler.py:223-233 and test/integration/test_sampler_circuits.py:10-22,90-109."""
+    s = CliffordCircuit("H 0\nM 0").compile_sampler(seed=0)
+    assert [int(s.sample(100).sum()) for _ in range(4)] == [48, 53, 52, 50]
+    m = CliffordCircuit("R 0 1\nH 0\nCNOT 0 1\nM 0 1").compile_sampler(seed=0).sample(100)
+    assert np.array_equal(m[:, 0], m[:, 1]) and int(m[:, 0].sum()) == 48
+    m = CliffordCircuit("RX 0\nRX 0\nM 0\nRX 0\nM 0\nR 0\nM 0").compile_sampler(seed=0).sample(10)
+    assert m.sum(axis=0).tolist() == [7, 4, 0]
+
+
+def test_measurement_sampler_of_a_noisy_ghz_state(hip):
+    c = CliffordCircuit("R 0 1 2 3\nH 0\nCX 0 1 1 2 2 3\nX_ERROR(0.25) 3\nM 0 1 2 3")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = c.compile_sampler(seed=2).sample(20000, batch_size=8192)
+    assert np.array_equal(m[:, 0], m[:, 1]) and np.array_equal(m[:, 1], m[:, 2])
+    assert abs(m[:, 0].mean() - 0.5) < 0.02
+    assert abs((m[:, 3] ^ m[:, 0]).mean() - 0.25) < 0.02

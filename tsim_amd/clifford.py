@@ -23,9 +23,17 @@ components whose marginal is a 0/1 delta (a NodePhases factor over the f bits an
 outputs that no error touches read an extra, always-zero ``f`` column.  Both give the bits the
 reference gives; the *structure* of those rare components is this front-end's own.
 
+Measurement sampling (``compile_sampler``): a record is ``const XOR <S, r> XOR <E, e>`` with ``r`` the
+random outcomes of the noiseless run (independent uniform bits).  Records that share random bits
+form a component; inside it an output is either free (marginal 1/2) or fixed by earlier outputs, so
+level k is ONE graph: a delta (NodePhases factor) per fixed output so far times 2^-k.  The marginals
+are exactly those of the reference's compiled graphs (0, 1/2 or 1 of the previous level), so the
+Threefry draws reproduce its seeded samples (``H 0; M 0`` -> 48, 53, 52, 50); with several components
+their processing order (size, then first output) is this front-end's reading of pipeline.py:65.
+
 Not covered (``NotImplementedError``): non-Clifford gates (T, rotations - they need the
 stabilizer-rank compiler, out of scope), classically controlled gates, ``CORRELATED_ERROR`` chains,
-heralded channels, measurement (non-detector) sampling.
+heralded channels.
 """
 
 from __future__ import annotations
@@ -507,6 +515,98 @@ class CliffordCircuit:
         program = make_program(components, direct, n_out, n_det)
         self._compiled = (program, list(an.channel_probs), error_transform)
         return self._compiled
+
+    def compile_measurements(self):
+        """``(program, channel_probs, error_transform)`` for measurement sampling (every record is an
+        output; ``Circuit.compile_sampler``, src/tsim/circuit.py:812-834)."""
+        if getattr(self, "_compiled_m", None) is not None:
+            return self._compiled_m
+        an = self.analyze()
+        n_out = len(an.rec_sets)
+        rows = [(i, s) for i, s in enumerate(an.rec_sets) if s]
+        basis_idx, combos = find_basis([s for _, s in rows])
+        num_f = len(basis_idx)
+        error_transform = np.zeros((num_f, an.num_e), dtype=np.uint8)
+        for pos, bi in enumerate(basis_idx):
+            for e in range(an.num_e):
+                if (rows[bi][1] >> e) & 1:
+                    error_transform[pos, e] = 1
+        fcombo = [0] * n_out
+        for j, (i, _) in enumerate(rows):
+            fcombo[i] = combos[j]
+        # direct entries: no random bit and exactly one f bit
+        direct, rest = [], []
+        for i in range(n_out):
+            c = fcombo[i]
+            if an.rec_syms[i] == 0 and c and c & (c - 1) == 0:
+                direct.append((i, c.bit_length() - 1, bool(an.rec_vals[i])))
+            else:
+                rest.append(i)
+        # components: outputs connected through shared random bits
+        parent = {i: i for i in rest}
+
+        def find(i):
+            while parent[i] != i:
+                parent[i] = parent[parent[i]]
+                i = parent[i]
+            return i
+
+        owner: dict[int, int] = {}
+        for i in rest:
+            y, b = an.rec_syms[i], 0
+            while y:
+                if y & 1:
+                    if b in owner:
+                        parent[find(i)] = find(owner[b])
+                    else:
+                        owner[b] = i
+                y >>= 1
+                b += 1
+        groups: dict[int, list[int]] = {}
+        for i in rest:
+            groups.setdefault(find(i), []).append(i)
+        components = []
+        for outs in sorted(groups.values(), key=lambda g: (len(g), g[0])):
+            outs = sorted(outs)
+            fsel = sorted({b for i in outs for b in range(num_f) if (fcombo[i] >> b) & 1})
+            fpos = {b: k for k, b in enumerate(fsel)}
+            F = len(fsel)
+            levels = [scalar_graphs_from_terms(F, [dict(floatfactor=(1, 0, 0, 0), power2=0)])]
+            sym_basis: list[tuple[int, int, int]] = []  # (reduced symbol vector, pivot, members as bitmask over positions)
+            deltas: list[tuple[int, list[int]]] = []     # NodePhases terms accumulated so far
+            for k, i in enumerate(outs):
+                v, members = an.rec_syms[i], 1 << k
+                for rv, pivot, mem in sym_basis:
+                    if v & pivot:
+                        v ^= rv
+                        members ^= mem
+                if v:
+                    sym_basis.append((v, v & -v, members))  # free output: marginal 1/2
+                else:
+                    # XOR of the member outputs is const XOR <f>: a delta over those output bits and f bits
+                    const, fmask = 0, 0
+                    params = []
+                    for q, io in enumerate(outs[: k + 1]):
+                        if (members >> q) & 1:
+                            const ^= an.rec_vals[io]
+                            fmask ^= fcombo[io]
+                            params.append(F + q)
+                    params = [fpos[b] for b in range(num_f) if (fmask >> b) & 1] + params
+                    deltas.append((4 * const, params))
+                levels.append(scalar_graphs_from_terms(
+                    F + k + 1, [dict(floatfactor=(1, 0, 0, 0), power2=-(k + 1), A=list(deltas))]))
+            components.append(CompiledComponent(tuple(outs), np.asarray(fsel, np.int32), tuple(levels)))
+        program = make_program(components, direct, n_out, 0)
+        self._compiled_m = (program, list(an.channel_probs), error_transform)
+        return self._compiled_m
+
+    def compile_sampler(self, *, seed: int | None = None, device: int = 0, noise: str = "host", mode: str = "auto"):
+        """Mirror of ``Circuit.compile_sampler`` (src/tsim/circuit.py:812-834)."""
+        from .sampler import CompiledMeasurementSampler
+
+        program, channel_probs, error_transform = self.compile_measurements()
+        return CompiledMeasurementSampler(program, channel_probs=channel_probs, error_transform=error_transform,
+                                          seed=seed, device=device, noise=noise, mode=mode)
 
     def compile_detector_sampler(self, *, seed: int | None = None, device: int = 0, noise: str = "host",
                                  mode: str = "auto"):

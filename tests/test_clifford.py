@@ -331,3 +331,93 @@ def test_measurement_program_structure_with_noise():
     np.testing.assert_array_equal(out[:, 2], out[:, 1] ^ f[:, 1].astype(bool))   # m2 = m1 ^ e1
     np.testing.assert_array_equal(out[:, 3], ~out[:, 2])                          # inverted record
     assert 60 < out[:, 1].sum() < 140
+
+
+# ---------------------------------------------------------------------------
+# statistics: the compiled sampler vs an independent vectorised Pauli-frame Monte Carlo of the same
+# circuit (the reference's own integration test compares with Stim the same way,
+# test/integration/test_sampler.py:212-257)
+# ---------------------------------------------------------------------------
+def _frame_monte_carlo(text, shots, seed):
+    """Per-shot Pauli frames as uint8 arrays; errors are drawn per instruction, not per channel table."""
+    from tsim_amd.clifford import _parse
+
+    rng = np.random.default_rng(seed)
+    ins = _parse(text)
+    nq = 1 + max(int(t) for i in ins if i.name not in ("DETECTOR", "OBSERVABLE_INCLUDE", "TICK") for t in i.targets)
+    fx = np.zeros((shots, nq), np.uint8)
+    fz = np.zeros((shots, nq), np.uint8)
+    recs, dets, obs = [], [], {}
+    for i in ins:
+        n, a, tg = i.name, i.args, [int(t) for t in i.targets] if i.name not in ("DETECTOR", "OBSERVABLE_INCLUDE") else i.targets
+        if n == "TICK":
+            continue
+        if n == "H":
+            for q in tg:
+                fx[:, q], fz[:, q] = fz[:, q].copy(), fx[:, q].copy()
+        elif n == "CX":
+            for c, t in zip(tg[::2], tg[1::2]):
+                fx[:, t] ^= fx[:, c]
+                fz[:, c] ^= fz[:, t]
+        elif n in ("R", "RX"):
+            for q in tg:
+                fx[:, q] = 0
+                fz[:, q] = 0
+        elif n in ("M", "MR", "MX"):
+            for q in tg:
+                recs.append((fz if n == "MX" else fx)[:, q].copy())
+                if n == "MR":
+                    fx[:, q] = 0
+                    fz[:, q] = 0
+        elif n in ("X_ERROR", "Z_ERROR"):
+            for q in tg:
+                (fx if n == "X_ERROR" else fz)[:, q] ^= (rng.random(shots) < a[0]).astype(np.uint8)
+        elif n == "DEPOLARIZE1":
+            for q in tg:
+                r = rng.random(shots)
+                k = np.where(r < a[0], rng.integers(1, 4, shots), 0)   # 1 = X, 2 = Y, 3 = Z
+                fx[:, q] ^= ((k == 1) | (k == 2)).astype(np.uint8)
+                fz[:, q] ^= ((k == 2) | (k == 3)).astype(np.uint8)
+        elif n == "DEPOLARIZE2":
+            for qa, qb in zip(tg[::2], tg[1::2]):
+                r = rng.random(shots)
+                k = np.where(r < a[0], rng.integers(1, 16, shots), 0)  # two base-4 digits, not both I
+                pa, pb = k % 4, k // 4                                  # 0 I, 1 X, 2 Y, 3 Z
+                fx[:, qa] ^= ((pa == 1) | (pa == 2)).astype(np.uint8)
+                fz[:, qa] ^= ((pa == 2) | (pa == 3)).astype(np.uint8)
+                fx[:, qb] ^= ((pb == 1) | (pb == 2)).astype(np.uint8)
+                fz[:, qb] ^= ((pb == 2) | (pb == 3)).astype(np.uint8)
+        elif n == "DETECTOR":
+            v = np.zeros(shots, np.uint8)
+            for t in tg:
+                v ^= recs[len(recs) - int(t[5:-1])]
+            dets.append(v)
+        elif n == "OBSERVABLE_INCLUDE":
+            v = obs.setdefault(int(a[0]), np.zeros(shots, np.uint8))
+            for t in tg:
+                v ^= recs[len(recs) - int(t[5:-1])]
+        else:
+            raise AssertionError(n)
+    return np.stack(dets + [obs[k] for k in sorted(obs)], axis=1)
+
+
+@pytest.mark.parametrize("channel", ["after_clifford_depolarization", "after_reset_flip_probability",
+                                     "before_measure_flip_probability", "before_round_data_depolarization"])
+def test_surface_code_single_noise_channel_matches_frame_monte_carlo(channel):
+    from tsim_amd.circuits import rotated_surface_code_memory
+
+    kw = {channel: 0.01}
+    text = rotated_surface_code_memory(3, 3, basis="X", **kw)
+    shots = 120_000
+    c = CliffordCircuit(text)
+    got = c.compile_detector_sampler(seed=42).sample(shots, batch_size=shots // 4, append_observables=True)
+    mc = _frame_monte_carlo(text, shots, seed=7)
+    assert got.shape == mc.shape
+    tot_a, tot_b = int(got.sum()), int(mc.sum())
+    assert tot_a > 1000
+    # two independent samples of the same distribution: 5 sigma of the difference of the totals
+    # (events within a shot are positively correlated, hence the generous variance factor)
+    assert abs(tot_a - tot_b) < 5 * np.sqrt(6 * (tot_a + tot_b))
+    # per-output rates too
+    ra, rb = got.mean(axis=0), mc.mean(axis=0)
+    assert np.all(np.abs(ra - rb) < 6 * np.sqrt((ra + rb) / shots) + 2e-4)

@@ -237,7 +237,10 @@ def main() -> None:
     # GATHER_EVERY steps ONE asynchronous RCCL gather sends the whole group to rank 0 (fewer, larger
     # collectives: a gather per step would cost more host time than the step itself), double-buffered
     # so that it overlaps the kernels of the next group.
-    NSLOT = max(1, min(backend.HipProgram.PIPELINE_SLOTS, int(os.environ.get("TSIM_BENCH_SLOTS", "3"))))
+    # More than 4 busy hardware queues is pathological on this stack (3x slower, measured with
+    # GPU_MAX_HW_QUEUES=5 / 8): engine stream + side streams (+ RCCL's own stream for N > 1) must stay <= 4.
+    default_slots = 2 if (use_dist and N > 1) else 3
+    NSLOT = max(1, min(backend.HipProgram.PIPELINE_SLOTS, int(os.environ.get("TSIM_BENCH_SLOTS", str(default_slots)))))
     GATHER_EVERY = max(1, int(os.environ.get("TSIM_BENCH_GATHER_EVERY", "16")))
     if use_dist:
         dev = torch.device("cuda", local_rank)

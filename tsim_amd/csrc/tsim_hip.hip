@@ -7,6 +7,9 @@
 #include "../../include/tsim_hip.h"
 #include "tsim_kernels.hip.h"
 #include "tsim_kernel4.hip.h"
+#ifndef TSIM_HARD_NW
+#define TSIM_HARD_NW 8   // waves per 64-row group in k_sample4h
+#endif
 #include "tsim_kernel4h.hip.h"
 #include "tsim_lw.hip.h"
 #include "tsim_noise.hip.h"
@@ -1657,7 +1660,7 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
     if (lds4 > 64 * 1024) return fail(TSIM_ENOTSUP, "v4 kernel needs %zu B of LDS", lds4);
     if (a.row_lists > 1 && p->knobs.hard_kernel) {
       // short row lists (second pass of a two-pass launch): NW waves per 64 rows, tsim_kernel4h.hip.h
-      constexpr int NW = 8;
+      constexpr int NW = TSIM_HARD_NW;
       const size_t tile_b = (size_t)p->v4_max_nch * 16 * p->v4_gt * 16;
       const size_t fixed_b = (size_t)(2 * a.WF + 2 * a.WO) * 64 * 4 + (size_t)NW * 8 * 64 * 4;
       const size_t budget = (size_t)p->knobs.hard_lds_kb * 1024;

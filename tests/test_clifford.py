@@ -421,3 +421,45 @@ def test_surface_code_single_noise_channel_matches_frame_monte_carlo(channel):
     # per-output rates too
     ra, rb = got.mean(axis=0), mc.mean(axis=0)
     assert np.all(np.abs(ra - rb) < 6 * np.sqrt((ra + rb) / shots) + 2e-4)
+
+
+def test_stim_generated_dialect_parses():
+    """Coordinates on QUBIT_COORDS / DETECTOR / SHIFT_COORDS, tags, comments and REPEAT blocks in the
+    style of Stim's circuit generators."""
+    text = """
+        QUBIT_COORDS(1, 1) 1
+        QUBIT_COORDS(2, 0) 2
+        QUBIT_COORDS(3, 1) 3
+        R 1 2 3   # reset everything
+        X_ERROR(0.01) 1 2 3
+        TICK
+        CX 1 2
+        DEPOLARIZE2(0.01) 1 2
+        TICK
+        CX 3 2
+        DEPOLARIZE2(0.01) 3 2
+        TICK
+        X_ERROR(0.02) 2
+        MR 2
+        X_ERROR(0.01) 2
+        DETECTOR(2, 0, 0) rec[-1]
+        REPEAT 2 {
+            TICK
+            DEPOLARIZE1(0.01) 1 3
+            CX 1 2
+            CX 3 2
+            MR(0.02) 2
+            SHIFT_COORDS(0, 0, 1)
+            DETECTOR(2, 0, 0) rec[-1] rec[-2]
+        }
+        M[final] 1 3
+        DETECTOR(2, 0, 1) rec[-1] rec[-2] rec[-3]
+        OBSERVABLE_INCLUDE(0) rec[-1]
+    """
+    c = CliffordCircuit(text)
+    program, probs, et = c.compile()
+    assert program.num_detectors == 4 and program.num_outputs == 5
+    # 3 + 1 + 1 one-bit channels, 2 DEPOLARIZE2 (4 bits), then per round 2 DEPOLARIZE1 (2 bits) + 1 noisy MR
+    assert [len(p) for p in probs] == [2, 2, 2, 16, 16, 2, 2] + [4, 4, 2] * 2
+    d = c.compile_detector_sampler(seed=5).sample(5000, append_observables=True)
+    assert d.shape == (5000, 5) and 0 < d.mean() < 0.2

@@ -228,18 +228,19 @@ def main() -> None:
     hp.h2d(d_f, f_packed)
     del f
 
-    # Pipeline of depth NSLOT (tsim_sample_batch_device_begin/_end): step i's first pass runs on the
-    # engine's stream while the second passes (hard rows, latency-bound) of steps i-1.. run on side
-    # streams; one output buffer per slot.  Three slots: HIP multiplexes streams onto 4 hardware queues,
-    # a fourth side stream would share the engine stream's queue and serialise with the first pass.
+    # Pipeline of NSLOT lanes (tsim_sample_batch_device_begin/_end): step i runs entirely on the stream of
+    # slot i % NSLOT, so its second pass (hard rows, latency-bound) overlaps the first pass of the next
+    # steps on the other lanes; one output buffer per slot, no cross-stream event in the steady state.
     # N > 1: when a step is joined its rows are compacted to the reference's bit_packed layout
     # (ceil(n_out/8) bytes per shot instead of the padded 8-byte words) into a group buffer in HBM; every
     # GATHER_EVERY steps ONE asynchronous RCCL gather sends the whole group to rank 0 (fewer, larger
     # collectives: a gather per step would cost more host time than the step itself), double-buffered
     # so that it overlaps the kernels of the next group.
-    # More than 4 busy hardware queues is pathological on this stack (3x slower, measured with
-    # GPU_MAX_HW_QUEUES=5 / 8): engine stream + side streams (+ RCCL's own stream for N > 1) must stay <= 4.
-    default_slots = 2 if (use_dist and N > 1) else 3
+    # Lanes (pipeline slots): measured on one MI355X, 2 lanes are best without the exchange (42 us per
+    # step; 3 lanes 49 us, 4 lanes 42 us) and 3 with it (45 us; 2 lanes 54 us).  More than 4 busy hardware
+    # queues is pathological on this stack (3x slower with GPU_MAX_HW_QUEUES=5 / 8): lanes + RCCL's stream
+    # stay <= 4 either way.
+    default_slots = 3 if use_dist else 2
     NSLOT = max(1, min(backend.HipProgram.PIPELINE_SLOTS, int(os.environ.get("TSIM_BENCH_SLOTS", str(default_slots)))))
     GATHER_EVERY = max(1, int(os.environ.get("TSIM_BENCH_GATHER_EVERY", "16")))
     if use_dist:
@@ -291,7 +292,7 @@ def main() -> None:
         if not use_dist:
             # _begin on a slot whose previous step was not joined is ordered after that step's second
             # pass by the library (include/tsim_hip.h), so one call per step is enough here
-            rc = begin_fn(hp._h, b, d_f_ptr, B, num_f, sub[0], sub[1], shot_offset, out_ptrs[b], None, None)
+            rc = begin_fn(hp._h, b, d_f_ptr, B, num_f, sub[0], sub[1], shot_offset, out_ptrs[b], None, None, 1)  # inputs ready
             if rc < 0:
                 raise RuntimeError(f"tsim_sample_batch_device_begin failed ({rc})")
             if not inflight or len(inflight) < NSLOT:
@@ -302,15 +303,16 @@ def main() -> None:
             with torch.cuda.stream(ext):
                 grp_pending[g].wait()  # the engine's stream waits until the previous gather released the buffer
             grp_pending[g] = None
-        rc = begin_fn(hp._h, b, d_f_ptr, B, num_f, sub[0], sub[1], shot_offset, out_ptrs[b], None, None)
-        if rc >= 0:  # rows -> the reference's bit_packed layout, behind the hard-row pass on the side stream
+        # flags = 0: the lane waits for the engine's stream, i.e. for the gather that last read this group
+        # buffer; the rows go to the reference's bit_packed layout on the lane, behind the launch
+        rc = begin_fn(hp._h, b, d_f_ptr, B, num_f, sub[0], sub[1], shot_offset, out_ptrs[b], None, None, 0)
+        if rc >= 0:
             rc = compact_fn(hp._h, b, out_ptrs[b], B, n_out, grp_ptrs[g] + pos * B * RB, None)
         if rc < 0:
             raise RuntimeError(f"pipelined launch failed ({rc})")
-        # Every slot has been reused (hence joined by _begin) NSLOT steps after a step: once step
-        # (k+1)*GATHER_EVERY - 1 + NSLOT has begun, the engine's stream is ordered after every side
-        # stream that produced group k - its gather can go out without an explicit join.
-        if j + 1 >= (gathered[0] + 1) * GATHER_EVERY + NSLOT:
+        if pos == GATHER_EVERY - 1:  # group complete: join every lane on the engine's stream, then gather
+            for k in range(NSLOT):
+                end_fn(hp._h, k, None)
             gather_next()
 
     def drain():
@@ -419,8 +421,8 @@ def main() -> None:
         achieved_gbs = bytes_per_shot * B / avg_kernel_s / 1e9
         achieved_tops = ops_per_shot * B / avg_kernel_s / 1e12
         if tables_dominant:
-            kernel_name = "tsimk::k_sample_lw (pattern-table pass; hard rows: k_sample4h + k_sample4 on side streams)" \
-                if info.get("chunk_table_kernel") else "tsimk::k_sample_lw (pattern-table pass; hard rows: k_sample on side streams)"
+            kernel_name = "tsimk::k_sample_lw (pattern-table pass; hard rows: k_sample4h + k_sample4, overlapped on the other lanes)" \
+                if info.get("chunk_table_kernel") else "tsimk::k_sample_lw (pattern-table pass; hard rows: k_sample, overlapped on the other lanes)"
         else:
             kernel_name = "tsimk::k_sample4 (LDS chunk tables)" if info.get("chunk_table_kernel") else "tsimk::k_sample"
         res = {
@@ -463,7 +465,7 @@ def main() -> None:
                 "algorithmic_bytes_per_shot": bytes_per_shot,
                 "note": "achieved = algorithmic bytes of one launch / HIP-event time of the dominant kernel (k_sample_lw when "
                 "pattern tables are active: it reads every f row and writes every tabulated row; the hard-row kernels "
-                "run on side streams under the next launches). Integer-VALU / latency bound, not HBM bound "
+                "run under the first pass of the next launches, on the other pipeline lanes). Integer-VALU / latency bound, not HBM bound "
                 "(DESIGN.md section 3.5); see `valu` and `stage_avg_ms`",
             },
             "valu": valu_block(ops_per_shot, B, avg_kernel_s, args.config),

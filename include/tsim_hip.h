@@ -179,22 +179,25 @@ int tsim_sample_batch_device(tsim_program *p, const uint64_t *d_f, int64_t B, in
 /*
  * Pipelined form of tsim_sample_batch_device.  With the pattern tables active a launch is two
  * passes; the second one (a few thousand "hard" rows, latency-bound) does not need the GPU to
- * itself.  _begin enqueues the first pass on `stream` and the second pass on a side stream owned
- * by `slot` (0 .. TSIM_PIPELINE_SLOTS-1), so that it overlaps the first pass of later launches;
- * _end makes `stream` wait for the slot's second pass - only after _end (and the usual stream
- * ordering) are d_out / d_max_norm_dev complete.  The caller must not reuse the buffers of a slot
- * (d_f, d_out, d_max_norm_dev) for anything else between _begin and _end; a _begin on a slot that
- * was not ended is ordered after that slot's previous launch.  Results are identical to the
- * serial call.  Programs without pattern tables run entirely on `stream` (_end is then a no-op).
+ * itself.  Each `slot` (0 .. TSIM_PIPELINE_SLOTS-1) owns a stream - a lane; _begin enqueues the whole
+ * launch on the slot's lane, so launches of one slot are ordered among themselves and launches of
+ * different slots overlap (the second pass of one under the first pass of the next).  The lane first
+ * waits for the work already queued on `stream` (the producer of d_f) unless `flags` has
+ * TSIM_PIPE_INPUTS_READY (inputs complete, and nothing queued on `stream` still uses d_out): then no
+ * cross-stream event is needed at all.  _end makes `stream` wait for the slot's lane - only after
+ * _end (and the usual stream ordering) are d_out / d_max_norm_dev complete.  The caller must not reuse
+ * the buffers of a slot for anything else between _begin and _end.  Results are identical to the
+ * serial call.  Keep the number of busy streams (lanes + the caller's + RCCL's) at 4 or fewer: beyond
+ * the 4 hardware queues HIP uses, launches slow down by 3x on this stack.
  */
 #define TSIM_PIPELINE_SLOTS 8
+#define TSIM_PIPE_INPUTS_READY 1u
 int tsim_sample_batch_device_begin(tsim_program *p, int32_t slot, const uint64_t *d_f, int64_t B,
                                    int32_t num_f, uint32_t key_hi, uint32_t key_lo, int64_t shot_offset,
-                                   uint64_t *d_out, float *d_max_norm_dev, void *stream);
+                                   uint64_t *d_out, float *d_max_norm_dev, void *stream, uint32_t flags);
 int tsim_sample_batch_device_end(tsim_program *p, int32_t slot, void *stream);
 /* Between _begin and _end of `slot`: tsim_compact_rows_device of the launch's output rows, enqueued
- * behind the slot's second pass (on its side stream) so that `stream` carries no extra kernel;
- * _end then also covers d_out.  Without a second pass in flight it runs on `stream`. */
+ * on the slot's lane behind the launch; _end then also covers d_out. */
 int tsim_sample_batch_device_compact(tsim_program *p, int32_t slot, const uint64_t *d_rows, int64_t B,
                                      int32_t nbits, uint8_t *d_out, void *stream);
 

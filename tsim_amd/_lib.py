@@ -70,7 +70,7 @@ SYMBOLS: dict[str, tuple] = {
     "tsim_program_destroy": (None, [_P]),
     "tsim_sample_batch": (C.c_int, [_P, _P, _I64, _I32, _U32, _U32, _I64, _P, _I32, _P]),
     "tsim_sample_batch_device": (C.c_int, [_P, _P, _I64, _I32, _U32, _U32, _I64, _P, _P, _P]),
-    "tsim_sample_batch_device_begin": (C.c_int, [_P, _I32, _P, _I64, _I32, _U32, _U32, _I64, _P, _P, _P]),
+    "tsim_sample_batch_device_begin": (C.c_int, [_P, _I32, _P, _I64, _I32, _U32, _U32, _I64, _P, _P, _P, _U32]),
     "tsim_sample_batch_device_end": (C.c_int, [_P, _I32, _P]),
     "tsim_sample_batch_device_compact": (C.c_int, [_P, _I32, _P, _I64, _I32, _P, _P]),
     "tsim_postselect_device": (C.c_int, [_P, _P, _I64, _I32, _P, _P, _P, _P, _P, _P, _P]),

@@ -275,12 +275,14 @@ class HipProgram:
         return (out[0], out[1]), (out[2], out[3])
 
     def sample_batch_device_begin(self, slot: int, d_f: int, B: int, num_f: int, key, d_out: int, *,
-                                  shot_offset: int = 0, d_norm_dev: int = 0) -> None:
-        """Pipelined launch: first pass on the handle's stream, second pass (hard rows) on the
-        slot's side stream.  ``d_out`` is complete only after ``sample_batch_device_end(slot)``."""
+                                  shot_offset: int = 0, d_norm_dev: int = 0, inputs_ready: bool = False) -> None:
+        """Pipelined launch on the slot's own stream (launches of different slots overlap).  ``d_out``
+        is complete only after ``sample_batch_device_end(slot)``.  ``inputs_ready=True``: ``d_f`` is
+        already complete and nothing queued on the handle's stream still uses ``d_out`` - the launch
+        then needs no cross-stream event."""
         rc = self._lib.tsim_sample_batch_device_begin(
             self._h, slot, d_f, B, num_f, key[0] & 0xFFFFFFFF, key[1] & 0xFFFFFFFF, shot_offset, d_out,
-            d_norm_dev or None, None)
+            d_norm_dev or None, None, 1 if inputs_ready else 0)
         if rc < 0:
             _lib.check(rc, "tsim_sample_batch_device_begin")
 

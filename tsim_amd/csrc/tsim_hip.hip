@@ -134,7 +134,7 @@ struct tsim_program {
   int lw_weight_cap = -1;     // -1 = TSIMK_LW_MAX_WEIGHT
   bool lw = false;            // tables built, pass 1 active
   // Launch slots: slot 0 serves the serial API (everything on the caller's stream); slots 1..4 serve
-  // tsim_sample_batch_device_begin/_end, whose second pass runs on the slot's own side stream so
+  // tsim_sample_batch_device_begin/_end: a slot's launches run on the slot's own stream (`side`) so
   // that it overlaps the first pass of the following launches.
   struct Slot {
     int parity = 0;               // counter set of the next launch
@@ -1487,7 +1487,7 @@ static int slot_prepare(tsim_program *p, int slot, size_t hard_bytes) {
   }
   if (p->total_keys > TSIMK_INLINE_KEYS && !sl.keys) HIP_TRY(hipMalloc((void **)&sl.keys, (size_t)p->total_keys * 8));
   if (slot > 0 && !sl.side) {
-    // default priority on purpose: a low- (or high-) priority side stream lands on a different class of
+    // default priority on purpose: a low- (or high-) priority lane lands on a different class of
     // hardware queue and tripled the step time (134 us vs 43 us, measured)
     HIP_TRY(hipStreamCreateWithFlags(&sl.side, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&sl.ev1, hipEventDisableTiming));
@@ -1574,7 +1574,7 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
   // the normalisation check applies to in-batch shot 0 (sampler.py:66-72) or the first listed row
   bool has_check = (shot_offset == 0 || d_row_index);
   long long B2 = B;  // slots per row list of the full kernel's launch
-  bool pipelined = false;
+  const bool pipelined = slot > 0;  // lane launch: the caller passed the slot's own stream as `s`
   auto finish = [&]() -> int {
     if (pipelined) {
       HIP_TRY(hipEventRecord(sl.ev2, s));
@@ -1624,12 +1624,6 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
     hipLaunchKernelGGL(k_sample_lw, dim3((unsigned)grid1), dim3(blk1), lds1, s, l);
     HIP_TRY(hipGetLastError());
     if (prof) { int r = prof_event(p, s, PROF_PASS1); if (r) return r; }
-    if (slot > 0) {  // pipelined launch: the second pass goes to the slot's side stream
-      HIP_TRY(hipEventRecord(sl.ev1, s));
-      HIP_TRY(hipStreamWaitEvent(sl.side, sl.ev1, 0));
-      s = sl.side;
-      pipelined = true;
-    }
     // pass 2 below runs on the hard lists; the check row was forced into one of them
     a.row_index = l.hard_index;
     a.row_count = ctl;
@@ -1728,16 +1722,12 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
 
 extern "C" int tsim_sample_batch_device_begin(tsim_program *p, int32_t slot, const uint64_t *d_f, int64_t B,
                                               int32_t num_f, uint32_t key_hi, uint32_t key_lo, int64_t shot_offset,
-                                              uint64_t *d_out, float *d_max_norm_dev, void *stream) {
+                                              uint64_t *d_out, float *d_max_norm_dev, void *stream, uint32_t flags) {
   if (int r = need_final(p)) return r;
   if (int r = set_device(p)) return r;
   if (slot < 0 || slot >= TSIM_PIPELINE_SLOTS) return fail(TSIM_EINVAL, "slot %d out of range", slot);
-  hipStream_t s = stream ? (hipStream_t)stream : p->stream;
+  hipStream_t s_user = stream ? (hipStream_t)stream : p->stream;
   tsim_program::Slot &sl = p->slots[1 + slot];
-  if (sl.pending) {  // the slot's previous launch was never joined: order this one after it
-    HIP_TRY(hipStreamWaitEvent(s, sl.ev2, 0));
-    sl.pending = false;
-  }
   if (!p->slots_ready) {  // first pipelined launch: create every slot's stream/buffers now, not mid-run
     size_t hard_bytes = 0;
     if (p->lw) hard_bytes = (size_t)(((B + 255) / 256 + TSIMK_LW_LISTS - 1) / TSIMK_LW_LISTS * 1024) * TSIMK_LW_LISTS * 4;
@@ -1745,7 +1735,15 @@ extern "C" int tsim_sample_batch_device_begin(tsim_program *p, int32_t slot, con
       if (int r = slot_prepare(p, k, hard_bytes)) return r;
     p->slots_ready = true;
   }
-  return launch_sample(p, d_f, B, num_f, key_hi, key_lo, shot_offset, d_out, d_max_norm_dev, s, nullptr, nullptr,
+  if (int r = slot_prepare(p, 1 + slot, 0)) return r;
+  // The whole launch runs on the slot's own stream (a "lane"): launches of one slot are ordered by the
+  // stream itself, launches of different slots overlap.  Unless the caller vouches for its inputs the
+  // lane first waits for what is already queued on the caller's stream.
+  if (!(flags & TSIM_PIPE_INPUTS_READY)) {
+    HIP_TRY(hipEventRecord(sl.ev1, s_user));
+    HIP_TRY(hipStreamWaitEvent(sl.side, sl.ev1, 0));
+  }
+  return launch_sample(p, d_f, B, num_f, key_hi, key_lo, shot_offset, d_out, d_max_norm_dev, sl.side, nullptr, nullptr,
                        1 + slot);
 }
 

@@ -238,7 +238,7 @@ class _CompiledSamplerBase:
             )
         b = st["bufs"]
         # pipelined launches (include/tsim_hip.h: tsim_sample_batch_device_begin/_end): batch i's
-        # hard-row pass runs on a side stream under the noise sampling and first pass of batch i+1;
+        # hard-row pass overlaps the noise sampling and first pass of batch i+1 (each slot is a lane);
         # each slot owns an f buffer, every batch its own slice of the output buffer
         for i in range(num_batches):
             slot = i % self._PIPELINE

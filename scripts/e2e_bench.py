@@ -26,7 +26,9 @@ for mode in ("host", "device"):
     print(f"noise={mode:6s} p={p}: {shots/dt:.3e} shots/s end to end ({dt*1e3/ (shots/1e6):.1f} ms per 1e6 shots), out {out.shape} {out.dtype}")
     if mode == "host":
         t0 = time.perf_counter(); f = s._channel_sampler.sample(batch); dt = time.perf_counter() - t0
-        print(f"   host ChannelSampler alone: {batch/dt:.3e} shots/s")
+        print(f"   host ChannelSampler.sample alone (unpacked rows): {batch/dt:.3e} shots/s")
+        t0 = time.perf_counter(); f = s._channel_sampler.sample_packed(batch); dt = time.perf_counter() - t0
+        print(f"   host ChannelSampler.sample_packed alone:          {batch/dt:.3e} shots/s")
 s = CompiledDetectorSampler(prog, channel_probs=probs, error_transform=T, seed=1, noise="device")
 s.sample(shots, batch_size=batch, bit_packed=True, append_observables=True)
 t0 = time.perf_counter()

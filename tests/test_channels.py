@@ -66,3 +66,36 @@ def test_statistical_equivalence_after_simplification():
     want = (e @ T.T) % 2
     assert np.allclose(f.mean(axis=0), want.mean(axis=0), rtol=0.05)
     assert np.isclose((f[:, 0] & f[:, 1]).mean(), (want[:, 0] & want[:, 1]).mean(), rtol=0.08)
+
+
+def test_sample_packed_is_the_same_stream_as_sample():
+    """sample_packed == packbits(sample) for the same seed, and the two can be mixed mid-stream."""
+    from tsim_amd.channels import ChannelSampler, error_probs, pauli_channel_1_probs
+
+    rng = np.random.default_rng(3)
+    for num_f, n_ch in [(5, 3), (64, 20), (70, 25), (130, 40)]:
+        probs, cols = [], 0
+        for k in range(n_ch):
+            if k % 3 == 0:
+                probs.append(pauli_channel_1_probs(0.01, 0.02, 0.03))
+                cols += 2
+            else:
+                probs.append(error_probs(0.05 + 0.01 * (k % 4)))
+                cols += 1
+        T = rng.integers(0, 2, size=(num_f, cols), dtype=np.uint8)
+        a = ChannelSampler(probs, T, seed=11)
+        b = ChannelSampler(probs, T, seed=11)
+        wf = (num_f + 63) // 64
+        for n in (1, 777, 5000):
+            want = a.sample(n)
+            pad = np.zeros((n, wf * 64), np.uint8)
+            pad[:, :num_f] = want
+            want_packed = np.packbits(pad, axis=1, bitorder="little").view(np.uint64).reshape(n, wf)
+            np.testing.assert_array_equal(b.sample_packed(n), want_packed)
+        # interleave: packed on one, unpacked on the other, then swap
+        x = a.sample_packed(300)
+        y = b.sample(300)
+        pad = np.zeros((300, wf * 64), np.uint8)
+        pad[:, :num_f] = y
+        np.testing.assert_array_equal(x, np.packbits(pad, axis=1, bitorder="little").view(np.uint64).reshape(300, wf))
+        np.testing.assert_array_equal(a.sample(50), b.sample(50))

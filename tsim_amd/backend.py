@@ -169,6 +169,7 @@ class HipProgram:
             self._h = None
             raise
         self._split_buf = (C.c_uint32 * 4)()
+        self._packed_bufs = None
         self._finalizer = weakref.finalize(self, lib.tsim_program_destroy, h)
 
     # -- info ---------------------------------------------------------------
@@ -218,6 +219,33 @@ class HipProgram:
         if not bit_packed:
             out = out.view(np.bool_)
         return out, devs[: self.n_components]
+
+    def sample_batch_packed(self, f_packed: np.ndarray, num_f: int, key, *, shot_offset: int = 0):
+        """One batch from PACKED error rows (``uint64[B, ceil(num_f/64)]``, e.g.
+        ``ChannelSampler.sample_packed``): 8 bytes per 64 error bits over PCIe instead of one byte per
+        bit.  Returns ``(bool[B, num_outputs], max_norm_dev[n_components])`` like :meth:`sample_batch`."""
+        f = np.ascontiguousarray(f_packed, dtype=np.uint64)
+        wf = max(1, (int(num_f) + 63) // 64)
+        if f.ndim != 2 or f.shape[1] != wf:
+            raise ValueError(f"f_packed must have shape (batch, {wf}), got {f.shape}")
+        B = f.shape[0]
+        wo = (self.num_outputs + 63) // 64
+        out = np.empty((B, self.num_outputs), dtype=np.uint8)
+        devs = np.zeros(max(1, self.n_components), dtype=np.float32)
+        if B == 0 or self.num_outputs == 0:
+            return out.view(np.bool_), devs[: self.n_components]
+        need = (B * wf * 8, B * wo * 8, B * self.num_outputs)
+        bufs = self._packed_bufs
+        if bufs is None or any(b.nbytes < n for b, n in zip(bufs[:3], need)):
+            bufs = self._packed_bufs = (self.malloc(need[0]), self.malloc(need[1]), self.malloc(need[2]),
+                                        self.malloc(4 * max(1, self.n_components)))
+        d_f, d_o, d_u8, d_dev = bufs
+        self.h2d(d_f, f)
+        self.sample_batch_device(d_f.ptr, B, num_f, key, d_o.ptr, shot_offset=shot_offset, d_norm_dev=d_dev.ptr)
+        self.unpack_bits_device(d_o.ptr, B, self.num_outputs, d_u8.ptr)
+        self.d2h(out, d_u8.ptr)
+        self.d2h(devs, d_dev.ptr)
+        return out.view(np.bool_), devs[: self.n_components]
 
     # -- the hot path, device-resident ----------------------------------------
     def malloc(self, nbytes: int) -> DeviceBuffer:

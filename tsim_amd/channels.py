@@ -259,6 +259,7 @@ class ChannelSampler:
             seed if seed is not None else np.random.default_rng().integers(0, 2**30)
         )
         self._sparse_data = self._precompute_sparse(self.channels, self.signature_matrix)
+        self._packed_patterns = None  # built on first use by sample_packed
 
     @property
     def num_f(self) -> int:
@@ -298,3 +299,34 @@ class ChannelSampler:
             outcome = np.searchsorted(cond_cdf, self._rng.uniform(size=len(positions)))
             result[positions] ^= xor_pats[outcome]
         return result
+
+    def sample_packed(self, num_samples: int = 1) -> np.ndarray:
+        """The same samples as :meth:`sample` (same generator calls in the same order, so the two are
+        interchangeable mid-stream) as packed rows ``uint64[num_samples, ceil(num_f/64)]`` - what the
+        sampling kernel reads.  The XOR scatter touches 8 bytes per fired row and word instead of
+        ``num_f`` bytes, which is where :meth:`sample` spends its time (0.56 s of 0.69 s per 10^6
+        shots x 64 one-bit channels at p = 0.02)."""
+        num_f = self.signature_matrix.shape[1]
+        wf = max(1, (num_f + 63) // 64)
+        rows = np.zeros((num_samples, wf), dtype=np.uint64)
+        if self._packed_patterns is None:
+            packed = []
+            for _, _, xor_pats in self._sparse_data:
+                pad = np.zeros((xor_pats.shape[0], wf * 64), dtype=np.uint8)
+                pad[:, :num_f] = xor_pats
+                packed.append(np.packbits(pad, axis=1, bitorder="little").view(np.uint64).reshape(-1, wf))
+            self._packed_patterns = packed
+        for (p_fire, cond_cdf, _), pats in zip(self._sparse_data, self._packed_patterns):
+            expected = num_samples * p_fire
+            sigma = np.sqrt(expected * (1.0 - p_fire))
+            n_draws = int(expected + 7.0 * sigma) + 100
+            positions = np.cumsum(self._rng.geometric(p_fire, size=n_draws)) - 1
+            positions = positions[positions < num_samples]
+            if len(positions) == 0:
+                continue
+            outcome = np.searchsorted(cond_cdf, self._rng.uniform(size=len(positions)))
+            for w in range(wf):  # positions are strictly increasing, hence unique: plain fancy XOR
+                col = pats[:, w]
+                if col.any():
+                    rows[positions, w] ^= col[outcome]
+        return rows

@@ -1,0 +1,76 @@
+// overlap_probe.hip - how much does a small resident kernel on another stream slow a GPU-filling one?
+// A: 3907 blocks x 256 threads of integer VALU work (~25 us alone), like k_sample_lw.
+// B: nb blocks x nt threads, lds bytes of dynamic LDS, each wave either spinning on VALU or sleeping,
+//    for ~dur us, like k_sample4h.   hipcc --offload-arch=gfx950 -O3 overlap_probe.hip -o overlap_probe
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
+
+template <int PRIO>
+__global__ void __launch_bounds__(256) kA(unsigned *out, int iters) {
+  if (PRIO) __builtin_amdgcn_s_setprio(PRIO);
+  unsigned x = threadIdx.x + blockIdx.x * 256u, y = x * 2654435761u;
+  for (int i = 0; i < iters; ++i) { x += y; y = (y << 13) | (y >> 19); y ^= x; }
+  if (x == 0x12345678u) out[0] = y;
+}
+
+extern __shared__ unsigned lds[];
+__global__ void kB(unsigned *out, long long cycles, int busy, int vregs) {
+  unsigned x = threadIdx.x, y = x * 2654435761u;
+  unsigned keep[24];
+#pragma unroll
+  for (int k = 0; k < 24; ++k) keep[k] = x + k;
+  lds[threadIdx.x] = x;
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < cycles) {
+    if (busy) { for (int i = 0; i < 64; ++i) { x += y; y = (y << 13) | (y >> 19); y ^= x; } }
+    else __builtin_amdgcn_s_sleep(32);
+  }
+  if (vregs) {
+#pragma unroll
+    for (int k = 0; k < 24; ++k) x ^= keep[k] * (x | 1u);
+  }
+  if (x == 0x12345678u) out[1] = y + lds[(threadIdx.x + 1) % blockDim.x];
+}
+
+int main(int argc, char **argv) {
+  unsigned *d; CK(hipMalloc(&d, 64));
+  hipStream_t sa, sb; CK(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&sb, hipStreamNonBlocking));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  CK(hipFuncSetAttribute((const void *)kB, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  const int itersA = 230;  // tuned so that A alone takes ~25 us
+  int prioA = argc > 1 ? atoi(argv[1]) : 0;
+  auto timeA = [&](int withB, int nb, int nt, int ldsb, int busy, long long cyc) {
+    float best = 1e9f, sum = 0; int n = 0;
+    for (int rep = 0; rep < 30; ++rep) {
+      if (withB) hipLaunchKernelGGL(kB, dim3(nb), dim3(nt), ldsb, sb, d, cyc, busy, 1);
+      CK(hipEventRecord(e0, sa));
+      if (prioA == 3) hipLaunchKernelGGL(kA<3>, dim3(3907), dim3(256), 0, sa, d, itersA);
+      else if (prioA == 1) hipLaunchKernelGGL(kA<1>, dim3(3907), dim3(256), 0, sa, d, itersA);
+      else hipLaunchKernelGGL(kA<0>, dim3(3907), dim3(256), 0, sa, d, itersA);
+      CK(hipEventRecord(e1, sa));
+      CK(hipDeviceSynchronize());
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+      if (rep >= 5) { sum += ms; ++n; if (ms < best) best = ms; }
+    }
+    return sum / n * 1000.f;
+  };
+  // wall_clock64 runs at 100 MHz: 100 us = 10000 ticks (B outlives A, so A always sees B resident)
+  const long long T = 10000;
+  printf("A alone: %.1f us\n", timeA(0, 0, 0, 0, 0, 0));
+  struct Cfg { const char *name; int nb, nt, lds, busy; } cfgs[] = {
+    {"B 65 x 512, 140 KB LDS, sleeping", 65, 512, 140 * 1024, 0},
+    {"B 65 x 512, 140 KB LDS, VALU busy", 65, 512, 140 * 1024, 1},
+    {"B 65 x 512,   4 KB LDS, sleeping", 65, 512, 4096, 0},
+    {"B 65 x 512,   4 KB LDS, VALU busy", 65, 512, 4096, 1},
+    {"B 65 x  64,   4 KB LDS, sleeping", 65, 64, 4096, 0},
+    {"B 65 x  64,   4 KB LDS, VALU busy", 65, 64, 4096, 1},
+    {"B  1 x  64,   4 KB LDS, sleeping", 1, 64, 4096, 0},
+    {"B 256 x 512, 140 KB LDS, sleeping", 256, 512, 140 * 1024, 0},
+    {"B 256 x 512, 140 KB LDS, VALU busy", 256, 512, 140 * 1024, 1},
+  };
+  for (auto &c : cfgs) printf("A with %-38s: %.1f us\n", c.name, timeA(1, c.nb, c.nt, c.lds, c.busy, T));
+  return 0;
+}

@@ -143,7 +143,7 @@ struct tsim_program {
     size_t hard_sz = 0;
     uint32_t *keys = nullptr;     // k_keygen output (programs with > TSIMK_INLINE_KEYS outputs)
     hipStream_t side = nullptr;
-    hipEvent_t ev1 = nullptr, ev2 = nullptr;
+    hipEvent_t ev1 = nullptr, ev2 = nullptr;  // input dependency, launch done
     bool pending = false;         // second pass enqueued on `side`, not yet joined
   };
   Slot slots[1 + TSIM_PIPELINE_SLOTS];
@@ -1623,7 +1623,6 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
     if (lds1 > 64 * 1024) return fail(TSIM_ENOTSUP, "num_f + num_outputs too large for LDS staging (%zu B)", lds1);
     hipLaunchKernelGGL(k_sample_lw, dim3((unsigned)grid1), dim3(blk1), lds1, s, l);
     HIP_TRY(hipGetLastError());
-    if (prof) { int r = prof_event(p, s, PROF_PASS1); if (r) return r; }
     // pass 2 below runs on the hard lists; the check row was forced into one of them
     a.row_index = l.hard_index;
     a.row_count = ctl;

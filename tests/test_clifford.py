@@ -463,3 +463,31 @@ def test_stim_generated_dialect_parses():
     assert [len(p) for p in probs] == [2, 2, 2, 16, 16, 2, 2] + [4, 4, 2] * 2
     d = c.compile_detector_sampler(seed=5).sample(5000, append_observables=True)
     assert d.shape == (5000, 5) and 0 < d.mean() < 0.2
+
+
+def test_correlated_error_chain_numbering_and_sampling():
+    """E / ELSE_CORRELATED_ERROR: one channel with one bit per alternative, at most one fires; the chain
+    is numbered when it is closed (reference core/instructions.py:759-816), i.e. AFTER channels that
+    appear while it is open."""
+    c = CliffordCircuit("""
+        R 0 1 2
+        E(0.2) X0 X1
+        ELSE_CORRELATED_ERROR(0.5) X2
+        X_ERROR(0.1) 0
+        M 0 1 2
+        DETECTOR rec[-3]
+        DETECTOR rec[-2]
+        DETECTOR rec[-1]
+    """)
+    an = c.analyze()
+    # e0 = the X_ERROR (numbered first), e1 = first alternative (X0 X1), e2 = second alternative (X2)
+    assert [s for s, _ in an.detectors] == [0b011, 0b010, 0b100]
+    assert [len(p) for p in an.channel_probs] == [2, 4]
+    np.testing.assert_allclose(an.channel_probs[1], [0.8 * 0.5, 0.2, 0.8 * 0.5, 0.0])
+    d = c.compile_detector_sampler(seed=9).sample(200_000, batch_size=50_000)
+    assert not (d[:, 1] & d[:, 2]).any()                      # the alternatives exclude each other
+    assert abs(d[:, 1].mean() - 0.2) < 0.005 and abs(d[:, 2].mean() - 0.4) < 0.005
+    assert abs(d[:, 0].mean() - (0.2 * 0.9 + 0.8 * 0.1)) < 0.005
+    # a second E closes the first chain
+    an = CliffordCircuit("R 0\nE(0.1) X0\nE(0.2) X0\nM 0\nDETECTOR rec[-1]").analyze()
+    assert [len(p) for p in an.channel_probs] == [2, 2] and an.detectors[0][0] == 0b11

@@ -32,8 +32,7 @@ Threefry draws reproduce its seeded samples (``H 0; M 0`` -> 48, 53, 52, 50); wi
 their processing order (size, then first output) is this front-end's reading of pipeline.py:65.
 
 Not covered (``NotImplementedError``): non-Clifford gates (T, rotations - they need the
-stabilizer-rank compiler, out of scope), classically controlled gates, ``CORRELATED_ERROR`` chains,
-heralded channels.
+stabilizer-rank compiler, out of scope), classically controlled gates, heralded channels.
 """
 
 from __future__ import annotations
@@ -43,7 +42,7 @@ from dataclasses import dataclass, field
 
 import numpy as np
 
-from .channels import error_probs, pauli_channel_1_probs
+from .channels import correlated_error_probs, error_probs, pauli_channel_1_probs
 from .program import CompiledComponent, CompiledProgram, make_program, scalar_graphs_from_terms
 
 __all__ = ["CliffordCircuit", "find_basis", "pauli_channel_2_probs"]
@@ -271,6 +270,7 @@ class _Sim:
         self.fx = [0] * self.n  # X component of the error frame, as bitmask over e
         self.fz = [0] * self.n
         self.out = _Analysis()
+        self.corr_probs: list[float] = []
 
     # primitives ---------------------------------------------------------------
     def _h(self, q):
@@ -332,6 +332,40 @@ class _Sim:
         bzi, bxi, bzj, bxj = self._new_bits(4)
         self.fz[qi] ^= bzi; self.fx[qi] ^= bxi
         self.fz[qj] ^= bzj; self.fx[qj] ^= bxj
+
+    # CORRELATED_ERROR / ELSE_CORRELATED_ERROR chains (instructions.py:759-816): the chain's bits get
+    # their error indices, and its table is appended, only when the chain is closed by the next
+    # CORRELATED_ERROR or by the end of the circuit - channels seen in between come first.
+    _TEMP = 1 << 40  # bit position of the first not-yet-numbered chain bit
+
+    def correlated_error(self, paulis, p):
+        bit = 1 << (40 + len(self.corr_probs))
+        for kind, q in paulis:
+            if kind in ("X", "Y"):
+                self.fx[q] ^= bit
+            if kind in ("Z", "Y"):
+                self.fz[q] ^= bit
+        self.corr_probs.append(p)
+
+    def finalize_correlated(self):
+        k = len(self.corr_probs)
+        if k == 0:
+            return
+        out = self.out
+        out.channel_probs.append(correlated_error_probs(self.corr_probs))
+        base, low = out.num_e, self._TEMP - 1
+
+        def move(m):
+            return (m & low) | ((m >> 40) << base)
+
+        self.fx = [move(m) for m in self.fx]
+        self.fz = [move(m) for m in self.fz]
+        out.rec_sets = [move(m) for m in out.rec_sets]
+        out.detectors = [(move(s), v) for s, v in out.detectors]
+        for cur in out.observables.values():
+            cur[0] = move(cur[0])
+        out.num_e += k
+        self.corr_probs = []
 
     # measurement / reset -----------------------------------------------------------
     def _basis_in(self, q, basis):
@@ -454,6 +488,10 @@ class CliffordCircuit:
                     inv = t.startswith("!")
                     paulis = [(tok[0].upper(), int(tok[1:])) for tok in t.lstrip("!").split("*")]
                     sim.mpp(paulis, p=args[0] if args else 0.0, invert=inv)
+            elif name in ("E", "CORRELATED_ERROR", "ELSE_CORRELATED_ERROR"):
+                if name != "ELSE_CORRELATED_ERROR":
+                    sim.finalize_correlated()
+                sim.correlated_error([(t[0].upper(), int(t[1:])) for t in tg], args[0])
             elif name == "DETECTOR":
                 s, v, y = 0, 0, 0
                 for t in tg:
@@ -473,7 +511,8 @@ class CliffordCircuit:
                     cur[2] ^= out.rec_syms[rec(t)]
             else:
                 raise NotImplementedError(f"instruction {name} is not supported by the Clifford front-end")
-        return out
+        sim.finalize_correlated()
+        return sim.out
 
     # -- program assembly -------------------------------------------------------------------
     def compile(self):

@@ -491,3 +491,19 @@ def test_correlated_error_chain_numbering_and_sampling():
     # a second E closes the first chain
     an = CliffordCircuit("R 0\nE(0.1) X0\nE(0.2) X0\nM 0\nDETECTOR rec[-1]").analyze()
     assert [len(p) for p in an.channel_probs] == [2, 2] and an.detectors[0][0] == 0b11
+
+
+def test_pair_measurements_and_mpad():
+    an = CliffordCircuit("""
+        R 0 1
+        H 0
+        CX 0 1
+        Z_ERROR(0.1) 1
+        MXX 0 1
+        MZZ 0 1
+        MPAD 1 0
+        DETECTOR rec[-4]
+        DETECTOR rec[-3]
+        DETECTOR rec[-2] rec[-1]
+    """).analyze()
+    assert an.detectors == [(0b1, 0), (0, 0), (0, 1)]

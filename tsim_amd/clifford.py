@@ -483,6 +483,20 @@ class CliffordCircuit:
             elif name in _RESET:
                 for t in tg:
                     sim.reset(int(t), _RESET[name])
+            elif name in ("MXX", "MYY", "MZZ"):
+                for i in range(0, len(tg), 2):
+                    inv = tg[i].startswith("!") ^ tg[i + 1].startswith("!")
+                    sim.mpp([(name[1], int(tg[i].lstrip("!"))), (name[2], int(tg[i + 1].lstrip("!")))],
+                            p=args[0] if args else 0.0, invert=inv)
+            elif name == "MPAD":  # a fixed bit in the measurement record (instructions.py:1040-1053)
+                for t in tg:
+                    flips = 0
+                    if args and args[0] > 0:
+                        out.channel_probs.append(error_probs(args[0]))
+                        (flips,) = sim._new_bits(1)
+                    out.rec_sets.append(flips)
+                    out.rec_vals.append(int(t) & 1)
+                    out.rec_syms.append(0)
             elif name == "MPP":
                 for t in tg:
                     inv = t.startswith("!")

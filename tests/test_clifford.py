@@ -507,3 +507,20 @@ def test_pair_measurements_and_mpad():
         DETECTOR rec[-2] rec[-1]
     """).analyze()
     assert an.detectors == [(0b1, 0), (0, 0), (0, 1)]
+
+
+def test_heralded_erase_records_a_herald_bit():
+    c = CliffordCircuit("""
+        R 0
+        HERALDED_ERASE(0.4) 0
+        M 0
+        DETECTOR rec[-2]
+        DETECTOR rec[-1]
+    """)
+    an = c.analyze()
+    # bits: herald, Z component, X component; the herald is its own record, X flips the Z measurement
+    assert an.detectors == [(0b001, 0), (0b100, 0)] and [len(p) for p in an.channel_probs] == [8]
+    d = c.compile_detector_sampler(seed=4).sample(200_000, batch_size=50_000)
+    assert abs(d[:, 0].mean() - 0.4) < 0.005            # heralded with probability p
+    assert abs(d[:, 1].mean() - 0.2) < 0.005            # X or Y: half of the fired cases
+    assert not (d[:, 1] & ~d[:, 0]).any()               # a flip never comes without its herald

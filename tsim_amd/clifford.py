@@ -32,7 +32,7 @@ Threefry draws reproduce its seeded samples (``H 0; M 0`` -> 48, 53, 52, 50); wi
 their processing order (size, then first output) is this front-end's reading of pipeline.py:65.
 
 Not covered (``NotImplementedError``): non-Clifford gates (T, rotations - they need the
-stabilizer-rank compiler, out of scope), classically controlled gates, heralded channels.
+stabilizer-rank compiler, out of scope) and classically controlled gates.
 """
 
 from __future__ import annotations
@@ -42,7 +42,7 @@ from dataclasses import dataclass, field
 
 import numpy as np
 
-from .channels import correlated_error_probs, error_probs, pauli_channel_1_probs
+from .channels import correlated_error_probs, error_probs, heralded_pauli_channel_1_probs, pauli_channel_1_probs
 from .program import CompiledComponent, CompiledProgram, make_program, scalar_graphs_from_terms
 
 __all__ = ["CliffordCircuit", "find_basis", "pauli_channel_2_probs"]
@@ -333,6 +333,16 @@ class _Sim:
         self.fz[qi] ^= bzi; self.fx[qi] ^= bxi
         self.fz[qj] ^= bzj; self.fx[qj] ^= bxj
 
+    def heralded_pauli_channel_1(self, q, pi, px, py, pz):
+        """Herald bit into the measurement record, then the Z and X components (instructions.py:726-757)."""
+        self.out.channel_probs.append(heralded_pauli_channel_1_probs(pi, px, py, pz))
+        bh, bz, bx = self._new_bits(3)
+        self.out.rec_sets.append(bh)
+        self.out.rec_vals.append(0)
+        self.out.rec_syms.append(0)
+        self.fz[q] ^= bz
+        self.fx[q] ^= bx
+
     # CORRELATED_ERROR / ELSE_CORRELATED_ERROR chains (instructions.py:759-816): the chain's bits get
     # their error indices, and its table is appended, only when the chain is closed by the next
     # CORRELATED_ERROR or by the end of the circuit - channels seen in between come first.
@@ -502,6 +512,10 @@ class CliffordCircuit:
                     inv = t.startswith("!")
                     paulis = [(tok[0].upper(), int(tok[1:])) for tok in t.lstrip("!").split("*")]
                     sim.mpp(paulis, p=args[0] if args else 0.0, invert=inv)
+            elif name in ("HERALDED_ERASE", "HERALDED_PAULI_CHANNEL_1"):
+                pr = (args[0] / 4,) * 4 if name == "HERALDED_ERASE" else args
+                for t in tg:
+                    sim.heralded_pauli_channel_1(int(t), *pr)
             elif name in ("E", "CORRELATED_ERROR", "ELSE_CORRELATED_ERROR"):
                 if name != "ELSE_CORRELATED_ERROR":
                     sim.finalize_correlated()

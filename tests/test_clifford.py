@@ -524,3 +524,18 @@ def test_heralded_erase_records_a_herald_bit():
     assert abs(d[:, 0].mean() - 0.4) < 0.005            # heralded with probability p
     assert abs(d[:, 1].mean() - 0.2) < 0.005            # X or Y: half of the fired cases
     assert not (d[:, 1] & ~d[:, 0]).any()               # a flip never comes without its herald
+
+
+def test_circuit_properties_and_without_noise(tmp_path):
+    from tsim_amd.circuits import rotated_surface_code_memory
+
+    text = rotated_surface_code_memory(3, 2, after_clifford_depolarization=0.01, before_measure_flip_probability=0.01)
+    f = tmp_path / "sc.stim"
+    f.write_text(text)
+    c = CliffordCircuit.from_file(str(f))
+    assert str(c) == text and c.is_clifford and c.num_qubits == 17
+    assert c.num_measurements == 8 * 2 + 9 and c.num_detectors == 4 + 8 + 4 and c.num_observables == 1
+    quiet = c.without_noise()
+    program, probs, et = quiet.compile()
+    assert probs == [] and program.num_detectors == c.num_detectors
+    assert not quiet.compile_detector_sampler(seed=1).sample(20).any()

@@ -427,9 +427,51 @@ class CliffordCircuit:
     docstring), compiled to the same `(program, channel_probs, error_transform)` triple the
     reference produces for such circuits."""
 
-    def __init__(self, text: str):
+    def __init__(self, text: str = ""):
+        self.text = text
         self.instructions = _parse(text)
         self._compiled = None
+
+    @classmethod
+    def from_file(cls, filename: str) -> "CliffordCircuit":
+        """Mirror of ``Circuit.from_file`` (src/tsim/circuit.py:292-310)."""
+        with open(filename) as fh:
+            return cls(fh.read())
+
+    def __str__(self) -> str:
+        return self.text
+
+    def __len__(self) -> int:
+        return len(self.instructions)  # REPEAT blocks flattened
+
+    @property
+    def is_clifford(self) -> bool:
+        return True  # anything else is rejected by analyze()
+
+    @property
+    def num_qubits(self) -> int:
+        return self._qubit_count()
+
+    @property
+    def num_measurements(self) -> int:
+        return len(self.analyze().rec_sets)
+
+    def without_noise(self) -> "CliffordCircuit":
+        """The circuit with every noise instruction dropped and measurement flip arguments removed
+        (``Circuit.without_noise``, circuit.py:546-548).  Heralded channels still record their herald."""
+        noise = set(_NOISE_1) | {"DEPOLARIZE1", "DEPOLARIZE2", "PAULI_CHANNEL_1", "PAULI_CHANNEL_2", "E",
+                                 "CORRELATED_ERROR", "ELSE_CORRELATED_ERROR"}
+        lines = []
+        for ins in self.instructions:
+            if ins.name in noise:
+                continue
+            if ins.name in ("HERALDED_ERASE", "HERALDED_PAULI_CHANNEL_1"):
+                lines.append("MPAD " + " ".join("0" for _ in ins.targets))
+                continue
+            keep_args = ins.name in ("DETECTOR", "OBSERVABLE_INCLUDE", "QUBIT_COORDS", "SHIFT_COORDS")
+            arg = "(" + ", ".join(repr(a) for a in ins.args) + ")" if (ins.args and keep_args) else ""
+            lines.append(f"{ins.name}{arg} {' '.join(ins.targets)}".rstrip())
+        return CliffordCircuit("\n".join(lines))
 
     # -- analysis -------------------------------------------------------------------
     def _qubit_count(self) -> int:

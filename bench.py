@@ -236,11 +236,11 @@ def main() -> None:
     # GATHER_EVERY steps ONE asynchronous RCCL gather sends the whole group to rank 0 (fewer, larger
     # collectives: a gather per step would cost more host time than the step itself), double-buffered
     # so that it overlaps the kernels of the next group.
-    # Lanes (pipeline slots): measured on one MI355X, 2 lanes are best without the exchange (42 us per
-    # step; 3 lanes 49 us, 4 lanes 42 us) and 3 with it (45 us; 2 lanes 54 us).  More than 4 busy hardware
-    # queues is pathological on this stack (3x slower with GPU_MAX_HW_QUEUES=5 / 8): lanes + RCCL's stream
-    # stay <= 4 either way.
-    default_slots = 3 if use_dist else 2
+    # Lanes (pipeline slots): three - the handle's own stream plus two more sit on three distinct hardware
+    # queues (36 us per step; two lanes 42 us; a fourth lane shares a queue with another, 43 us).  More
+    # than 4 busy hardware queues is pathological on this stack (3x slower with GPU_MAX_HW_QUEUES=5 / 8):
+    # lanes + RCCL's stream stay <= 4.
+    default_slots = 3
     NSLOT = max(1, min(backend.HipProgram.PIPELINE_SLOTS, int(os.environ.get("TSIM_BENCH_SLOTS", str(default_slots)))))
     GATHER_EVERY = max(1, int(os.environ.get("TSIM_BENCH_GATHER_EVERY", "16")))
     if use_dist:
@@ -455,6 +455,7 @@ def main() -> None:
                 "frac": achieved_gbs / HBM_PEAK_GBS,
                 "traffic": pmc_traffic_bytes(args.config, B),
                 "traffic_unit": "bytes per launch, rocprofv3 PMC: 2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction)",
+                "achieved_at_step_rate": bytes_per_shot * B / (elapsed / args.steps) / 1e9,
                 "kernel": kernel_name,
                 "kernel_avg_ms": avg_kernel_s * 1e3,
                 "launches": launches,
@@ -463,7 +464,9 @@ def main() -> None:
                 "pipeline_slots": NSLOT,
                 "host_enqueue_ms_per_step": host_enqueue_s / args.steps * 1e3,
                 "algorithmic_bytes_per_shot": bytes_per_shot,
-                "note": "achieved = algorithmic bytes of one launch / HIP-event time of the dominant kernel (k_sample_lw when "
+                "note": "achieved = algorithmic bytes of one launch / HIP-event time of the dominant kernel; with several "
+                "launches in flight that kernel shares the GPU with the same kernel of the other lanes, so its own "
+                "duration exceeds the step time - achieved_at_step_rate uses the step time instead. (k_sample_lw when "
                 "pattern tables are active: it reads every f row and writes every tabulated row; the hard-row kernels "
                 "run under the first pass of the next launches, on the other pipeline lanes). Integer-VALU / latency bound, not HBM bound "
                 "(DESIGN.md section 3.5); see `valu` and `stage_avg_ms`",

@@ -178,3 +178,20 @@ def test_launch_plan_adapts_without_changing_bits(hip, p_bit):
             other = hip.HipProgram(prog, pattern_tables=False).sample_batch(f, key)[0] if i == 7 else None
             if other is not None:
                 np.testing.assert_array_equal(got, other)
+
+
+def test_stage_profiling_reports_every_kernel(hip):
+    """tsim_profile_read_stages: the pattern pass and the hard-row kernel both show up (a lost event
+    would silently turn the roofline figure of bench.py into the step time)."""
+    prog, cfg = synth.config_program("C2")
+    hp = hip.HipProgram(prog)
+    f = synth.synth_f(50000, cfg["num_f"], 0.02, seed=1)
+    hp.sample_batch(f, prng.key(1))
+    hp.profile_enable(1)
+    hp.profile_read(reset=True)
+    for i in range(3):
+        hp.sample_batch(f, prng.key(2 + i))
+    st = hp.profile_read_stages()
+    ms, n = hp.profile_read(reset=True)
+    hp.profile_enable(False)
+    assert n == 3 and st["pattern_pass"] > 0 and st["hard_rows"] > 0 and ms >= st["pattern_pass"] + st["hard_rows"] - 1e-3

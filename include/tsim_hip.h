@@ -179,7 +179,8 @@ int tsim_sample_batch_device(tsim_program *p, const uint64_t *d_f, int64_t B, in
 /*
  * Pipelined form of tsim_sample_batch_device.  With the pattern tables active a launch is two
  * passes; the second one (a few thousand "hard" rows, latency-bound) does not need the GPU to
- * itself.  Each `slot` (0 .. TSIM_PIPELINE_SLOTS-1) owns a stream - a lane; _begin enqueues the whole
+ * itself.  Each `slot` (0 .. TSIM_PIPELINE_SLOTS-1) owns a stream - a lane (slot 0's lane is the handle's
+ * own stream, tsim_get_stream: it sits on a hardware queue of its own); _begin enqueues the whole
  * launch on the slot's lane, so launches of one slot are ordered among themselves and launches of
  * different slots overlap (the second pass of one under the first pass of the next).  The lane first
  * waits for the work already queued on `stream` (the producer of d_f) unless `flags` has

@@ -145,7 +145,8 @@ struct tsim_program {
     hipStream_t side = nullptr;
     hipEvent_t ev1 = nullptr, ev2 = nullptr;  // input dependency, launch done
     bool pending = false;         // second pass enqueued on `side`, not yet joined
-    bool side_borrowed = false;   // `side` is the handle's main stream
+    bool side_borrowed = false;   // `side` is not owned by the slot (the handle's main stream / the null stream)
+    bool side_ready = false;
   };
   Slot slots[1 + TSIM_PIPELINE_SLOTS];
   bool slots_ready = false;
@@ -1381,7 +1382,7 @@ extern "C" void tsim_program_destroy(tsim_program *p) {
     if (p->d_lw_tab) (void)hipFree(p->d_lw_tab);
     if (p->h_feedback) (void)hipHostFree((void *)p->h_feedback);
     for (auto &sl : p->slots) {
-      if (sl.side) (void)hipStreamSynchronize(sl.side);
+      if (sl.side_ready) (void)hipStreamSynchronize(sl.side);
       if (sl.ctl) (void)hipFree(sl.ctl);
       if (sl.hard) (void)hipFree(sl.hard);
       if (sl.keys) (void)hipFree(sl.keys);
@@ -1489,7 +1490,8 @@ static int slot_prepare(tsim_program *p, int slot, size_t hard_bytes) {
       HIP_TRY(hipMemset(sl.ctl + st * (TSIMK_LW_LISTS + 1) * 32 + TSIMK_LW_LISTS * 32, 0xFF, 4));
   }
   if (p->total_keys > TSIMK_INLINE_KEYS && !sl.keys) HIP_TRY(hipMalloc((void **)&sl.keys, (size_t)p->total_keys * 8));
-  if (slot > 0 && !sl.side) {
+  if (slot > 0 && !sl.side_ready) {
+    sl.side_ready = true;
     // default priority on purpose: a low- (or high-) priority lane lands on a different class of
     // hardware queue and tripled the step time (134 us vs 43 us, measured)
     if (slot == 1 && p->knobs.lane0_main) {
@@ -2208,7 +2210,7 @@ extern "C" int tsim_synchronize(tsim_program *p) {
   if (int r = set_device(p)) return r;
   HIP_TRY(hipStreamSynchronize(p->stream));
   for (auto &sl : p->slots)
-    if (sl.side) {
+    if (sl.side_ready) {
       HIP_TRY(hipStreamSynchronize(sl.side));
       sl.pending = false;
     }

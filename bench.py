@@ -303,9 +303,11 @@ def main() -> None:
             with torch.cuda.stream(ext):
                 grp_pending[g].wait()  # the engine's stream waits until the previous gather released the buffer
             grp_pending[g] = None
-        # flags = 0: the lane waits for the engine's stream, i.e. for the gather that last read this group
-        # buffer; the rows go to the reference's bit_packed layout on the lane, behind the launch
-        rc = begin_fn(hp._h, b, d_f_ptr, B, num_f, sub[0], sub[1], shot_offset, out_ptrs[b], None, None, 0)
+        # The first launch of every lane in a group (flags = 0) waits for the engine's stream, i.e. for the
+        # gather that last read this group buffer; the later ones need no cross-stream dependency.  The rows
+        # go to the reference's bit_packed layout on the lane, behind the launch.
+        rc = begin_fn(hp._h, b, d_f_ptr, B, num_f, sub[0], sub[1], shot_offset, out_ptrs[b], None, None,
+                      0 if pos < NSLOT else 1)
         if rc >= 0:
             rc = compact_fn(hp._h, b, out_ptrs[b], B, n_out, grp_ptrs[g] + pos * B * RB, None)
         if rc < 0:

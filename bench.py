@@ -253,7 +253,7 @@ def main() -> None:
         grp_lists = [[torch.empty_like(grp_bufs[0]) for _ in range(N)] if rank == 0 else None for _ in range(2)]
         grp_ptrs = [t.data_ptr() for t in grp_bufs]
         grp_pending = [None, None]  # gather handle of the group buffer's previous use
-        compact_fn = hp._lib.tsim_sample_batch_device_compact
+        compact_fn = hp._lib.tsim_pipeline_set_compact_output
     else:
         d_outs = [hp.malloc(B * WO * 8) for _ in range(NSLOT)]
         out_ptrs = [d.ptr for d in d_outs]
@@ -304,12 +304,12 @@ def main() -> None:
                 grp_pending[g].wait()  # the engine's stream waits until the previous gather released the buffer
             grp_pending[g] = None
         # The first launch of every lane in a group (flags = 0) waits for the engine's stream, i.e. for the
-        # gather that last read this group buffer; the later ones need no cross-stream dependency.  The rows
-        # go to the reference's bit_packed layout on the lane, behind the launch.
-        rc = begin_fn(hp._h, b, d_f_ptr, B, num_f, sub[0], sub[1], shot_offset, out_ptrs[b], None, None,
-                      0 if pos < NSLOT else 1)
+        # gather that last read this group buffer; the later ones need no cross-stream dependency.  The
+        # kernels write the rows a second time in the reference's bit_packed layout, into the group buffer.
+        rc = compact_fn(hp._h, b, grp_ptrs[g] + pos * B * RB)  # this launch also writes bit_packed rows there
         if rc >= 0:
-            rc = compact_fn(hp._h, b, out_ptrs[b], B, n_out, grp_ptrs[g] + pos * B * RB, None)
+            rc = begin_fn(hp._h, b, d_f_ptr, B, num_f, sub[0], sub[1], shot_offset, out_ptrs[b], None, None,
+                          0 if pos < NSLOT else 1)
         if rc < 0:
             raise RuntimeError(f"pipelined launch failed ({rc})")
         if pos == GATHER_EVERY - 1:  # group complete: join every lane on the engine's stream, then gather

@@ -197,6 +197,10 @@ int tsim_sample_batch_device_begin(tsim_program *p, int32_t slot, const uint64_t
                                    int32_t num_f, uint32_t key_hi, uint32_t key_lo, int64_t shot_offset,
                                    uint64_t *d_out, float *d_max_norm_dev, void *stream, uint32_t flags);
 int tsim_sample_batch_device_end(tsim_program *p, int32_t slot, void *stream);
+/* The NEXT _begin on `slot` also writes its rows as uint8[B, ceil(num_outputs/8)] into d_compact (the
+ * reference's bit_packed layout, sampler.py:665-669) straight from the sampling kernels - no separate
+ * compaction kernel.  One-shot: cleared by that launch. */
+int tsim_pipeline_set_compact_output(tsim_program *p, int32_t slot, uint8_t *d_compact);
 /* Between _begin and _end of `slot`: tsim_compact_rows_device of the launch's output rows, enqueued
  * on the slot's lane behind the launch; _end then also covers d_out. */
 int tsim_sample_batch_device_compact(tsim_program *p, int32_t slot, const uint64_t *d_rows, int64_t B,

@@ -195,3 +195,30 @@ def test_stage_profiling_reports_every_kernel(hip):
     ms, n = hp.profile_read(reset=True)
     hp.profile_enable(False)
     assert n == 3 and st["pattern_pass"] > 0 and st["hard_rows"] > 0 and ms >= st["pattern_pass"] + st["hard_rows"] - 1e-3
+
+
+@pytest.mark.parametrize("tables", [True, False])
+def test_compact_output_written_by_the_kernels(hip, tables):
+    """tsim_pipeline_set_compact_output: the sampling kernels (pattern pass, hard-row kernel, full kernel)
+    write the bit_packed rows themselves - equal to packbits of the normal output."""
+    import ctypes as C
+
+    prog, cfg = synth.config_program("C2")
+    hp = hip.HipProgram(prog, pattern_tables=tables)
+    nf, B = cfg["num_f"], 30011
+    wf, wo, rb = (nf + 63) // 64, (prog.num_outputs + 63) // 64, (prog.num_outputs + 7) // 8
+    for p_bit in (0.02, 0.3):
+        f = synth.synth_f(B, nf, p_bit, seed=17)
+        key = prng.key(8)
+        want = hp.sample_batch(f, key)[0]
+        fp = np.packbits(f, axis=1, bitorder="little")
+        fp = np.ascontiguousarray(np.pad(fp, ((0, 0), (0, wf * 8 - fp.shape[1]))))
+        d_f, d_o, d_c = hp.malloc(B * wf * 8), hp.malloc(B * wo * 8), hp.malloc(B * rb + 16)
+        hp.h2d(d_f, fp)
+        assert hp._lib.tsim_pipeline_set_compact_output(hp._h, 1, C.c_void_p(d_c.ptr)) == 0
+        hp.sample_batch_device_begin(1, d_f.ptr, B, nf, key, d_o.ptr)
+        hp.sample_batch_device_end(1)
+        hp.synchronize()
+        got = np.zeros((B, rb), np.uint8)
+        hp.d2h(got, d_c)
+        np.testing.assert_array_equal(got, np.packbits(want, axis=1, bitorder="little"))

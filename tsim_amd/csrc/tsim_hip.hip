@@ -147,6 +147,7 @@ struct tsim_program {
     bool pending = false;         // second pass enqueued on `side`, not yet joined
     bool side_borrowed = false;   // `side` is not owned by the slot (the handle's main stream / the null stream)
     bool side_ready = false;
+    uint8_t *compact_out = nullptr;  // next launch of the slot also writes bit_packed rows here
   };
   Slot slots[1 + TSIM_PIPELINE_SLOTS];
   bool slots_ready = false;
@@ -1578,6 +1579,11 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
   a.row_list_cap = 0;
   a.row_slot_begin = 0;
   a.row_slot_end = 0;
+  if (sl.compact_out) {  // tsim_pipeline_set_compact_output: consumed by this launch
+    a.out_compact = sl.compact_out;
+    a.out_rb = (p->num_outputs + 7) / 8;
+    sl.compact_out = nullptr;
+  }
   a.check_row = nullptr;
   a.no_check = 0;
   if (num_f == 0) a.WF = 0;
@@ -1758,6 +1764,13 @@ extern "C" int tsim_sample_batch_device_begin(tsim_program *p, int32_t slot, con
   }
   return launch_sample(p, d_f, B, num_f, key_hi, key_lo, shot_offset, d_out, d_max_norm_dev, sl.side, nullptr, nullptr,
                        1 + slot);
+}
+
+extern "C" int tsim_pipeline_set_compact_output(tsim_program *p, int32_t slot, uint8_t *d_compact) {
+  if (int r = need_final(p)) return r;
+  if (slot < 0 || slot >= TSIM_PIPELINE_SLOTS) return fail(TSIM_EINVAL, "slot %d out of range", slot);
+  p->slots[1 + slot].compact_out = d_compact;
+  return TSIM_OK;
 }
 
 extern "C" int tsim_sample_batch_device_compact(tsim_program *p, int32_t slot, const uint64_t *d_rows, int64_t B,

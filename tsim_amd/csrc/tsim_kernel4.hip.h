@@ -373,6 +373,7 @@ k_sample4(Sample4Args A4) {
     uint64_t *orow = A.out + row * A.WO;
     for (int w = 0; w < A.WO; ++w)
       orow[w] = (uint64_t)lds_o[(2 * w) * nthr] | ((uint64_t)lds_o[(2 * w + 1) * nthr] << 32);
+    store_compact_row(A, row, lds_o, nthr);
   }
 }
 

@@ -340,6 +340,7 @@ __global__ void __launch_bounds__(NW * 64) k_sample4h(Sample4Args A4, int group_
     uint64_t *orow = A.out + row * A.WO;
     for (int w = 0; w < A.WO; ++w)
       orow[w] = (uint64_t)lds_o[(2 * w) * 64] | ((uint64_t)lds_o[(2 * w + 1) * 64] << 32);
+    store_compact_row(A, row, lds_o, 64);
   }
   if (check_block || loop_stride <= 0 || !A.row_index) return;
   __syncthreads();  // the LDS staging of this row group is reused by the next one

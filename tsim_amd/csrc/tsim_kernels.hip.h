@@ -70,8 +70,19 @@ struct SampleArgs {
   // most TSIMK_INLINE_KEYS compiled outputs): no key-generation kernel, no shared key buffer
   int n_inline_keys;
   uint32_t inline_keys[2 * 32];
+  // optional second output: the same rows as ceil(num_outputs/8)-byte strings (the reference's
+  // bit_packed layout, sampler.py:665-669) - what a gather moves; nullptr = not wanted
+  uint8_t *out_compact;
+  int out_rb;
 };
 #define TSIMK_INLINE_KEYS 32
+
+// the lane's output row, word w at lds_o[w * stride], as out_rb bytes of the compact output
+__device__ __forceinline__ void store_compact_row(const SampleArgs &A, long long row, const uint32_t *lds_o, int stride) {
+  if (!A.out_compact) return;
+  uint8_t *dst = A.out_compact + row * A.out_rb;
+  for (int k = 0; k < A.out_rb; ++k) dst[k] = (uint8_t)(lds_o[(k >> 2) * stride] >> (8 * (k & 3)));
+}
 
 // subkey word j (0/1) of compiled output `o` (sampler.py:74,147-148)
 __device__ __forceinline__ uint32_t subkey(const SampleArgs &A, uint32_t o, uint32_t j) {
@@ -650,6 +661,7 @@ __global__ void __launch_bounds__(256) k_sample(SampleArgs A) {
   uint64_t *orow = A.out + row * A.WO;
   for (int w = 0; w < A.WO; ++w)
     orow[w] = (uint64_t)lds_o[(2 * w) * nthr] | ((uint64_t)lds_o[(2 * w + 1) * nthr] << 32);
+  store_compact_row(A, row, lds_o, nthr);
 }
 
 // ---------------------------------------------------------------------------

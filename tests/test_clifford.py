@@ -539,3 +539,19 @@ def test_circuit_properties_and_without_noise(tmp_path):
     program, probs, et = quiet.compile()
     assert probs == [] and program.num_detectors == c.num_detectors
     assert not quiet.compile_detector_sampler(seed=1).sample(20).any()
+
+
+def test_compiled_form_matches_the_committed_fixture():
+    """tests/golden/clifford_golden.npz (self-generated, see gen_clifford_golden.py): conventions that
+    decide stream-level agreement with the reference must not drift."""
+    import importlib.util
+    import os
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("gen_clifford_golden", os.path.join(here, "golden", "gen_clifford_golden.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    gold = np.load(os.path.join(here, "golden", "clifford_golden.npz"))
+    for name, text in gen.CASES.items():
+        for k, v in gen.compiled(text).items():
+            np.testing.assert_array_equal(v, gold[f"{name}.{k}"], err_msg=f"{name}.{k}")

@@ -86,7 +86,14 @@ __device__ __forceinline__ void store_compact_row(const SampleArgs &A, long long
 
 // subkey word j (0/1) of compiled output `o` (sampler.py:74,147-148)
 __device__ __forceinline__ uint32_t subkey(const SampleArgs &A, uint32_t o, uint32_t j) {
-  return A.n_inline_keys ? A.inline_keys[2u * o + j] : A.subkeys[2u * o + j];
+  // Wave-uniform, read through the constant address space (scalar loads): the inline keys sit in the
+  // kernel-argument segment - SampleArgs is the first member of the first argument of every sampling
+  // kernel - and the k_keygen buffer was written by an earlier kernel, so both are read-only here.
+  typedef const __attribute__((address_space(4))) uint8_t *cbytes;
+  cptr kp = A.n_inline_keys
+                ? (cptr)((cbytes)__builtin_amdgcn_kernarg_segment_ptr() + __builtin_offsetof(SampleArgs, inline_keys))
+                : (cptr)(uintptr_t)A.subkeys;
+  return kp[2u * o + j];
 }
 
 struct EvalArgs {

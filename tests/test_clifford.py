@@ -73,7 +73,16 @@ def test_reference_kat_bell_pair_with_x_error():
 
 _INVERSE = {"H": "H", "X": "X", "Y": "Y", "Z": "Z", "S": "S_DAG", "S_DAG": "S", "SQRT_X": "SQRT_X_DAG",
             "SQRT_X_DAG": "SQRT_X", "SQRT_Y": "SQRT_Y_DAG", "SQRT_Y_DAG": "SQRT_Y", "H_YZ": "H_YZ",
-            "CX": "CX", "CZ": "CZ", "CY": "CY", "SWAP": "SWAP", "XCZ": "XCZ"}
+            "H_XY": "H_XY", "H_NXY": "H_NXY", "H_NXZ": "H_NXZ", "H_NYZ": "H_NYZ",
+            "C_XYZ": "C_ZYX", "C_ZYX": "C_XYZ", "C_NXYZ": "C_ZYNX", "C_ZYNX": "C_NXYZ",
+            "C_XNYZ": "C_ZNYX", "C_ZNYX": "C_XNYZ", "C_XYNZ": "C_NZYX", "C_NZYX": "C_XYNZ",
+            "CX": "CX", "CZ": "CZ", "CY": "CY", "SWAP": "SWAP", "XCZ": "XCZ",
+            "XCX": "XCX", "XCY": "XCY", "YCX": "YCX", "YCY": "YCY", "YCZ": "YCZ",
+            "ISWAP": "ISWAP_DAG", "ISWAP_DAG": "ISWAP", "SQRT_XX": "SQRT_XX_DAG", "SQRT_XX_DAG": "SQRT_XX",
+            "SQRT_YY": "SQRT_YY_DAG", "SQRT_YY_DAG": "SQRT_YY", "SQRT_ZZ": "SQRT_ZZ_DAG", "SQRT_ZZ_DAG": "SQRT_ZZ",
+            "CZSWAP": "CZSWAP"}
+_TWO = {"CX", "CZ", "CY", "SWAP", "XCZ", "XCX", "XCY", "YCX", "YCY", "YCZ", "ISWAP", "ISWAP_DAG", "SQRT_XX",
+        "SQRT_XX_DAG", "SQRT_YY", "SQRT_YY_DAG", "SQRT_ZZ", "SQRT_ZZ_DAG", "CZSWAP"}
 
 
 def _random_echo_circuit(rng, n, depth):
@@ -82,7 +91,7 @@ def _random_echo_circuit(rng, n, depth):
     gates = []
     for _ in range(depth):
         g = str(rng.choice(list(_INVERSE)))
-        if g in ("CX", "CZ", "CY", "SWAP", "XCZ"):
+        if g in _TWO:
             a, b = rng.choice(n, size=2, replace=False)
             gates.append((g, (int(a), int(b))))
         else:
@@ -555,3 +564,205 @@ def test_compiled_form_matches_the_committed_fixture():
     for name, text in gen.CASES.items():
         for k, v in gen.compiled(text).items():
             np.testing.assert_array_equal(v, gold[f"{name}.{k}"], err_msg=f"{name}.{k}")
+
+
+# ---------------------------------------------------------------------------
+# every Clifford gate of the reference's gate table (core/instructions.py GATE_TABLE): the tableau's
+# conjugation action against a unitary written down from the gate's definition
+# ---------------------------------------------------------------------------
+_I2 = np.eye(2, dtype=complex)
+_PX = np.array([[0, 1], [1, 0]], dtype=complex)
+_PY = np.array([[0, -1j], [1j, 0]], dtype=complex)
+_PZ = np.diag([1, -1]).astype(complex)
+_PAULI = {"I": _I2, "X": _PX, "Y": _PY, "Z": _PZ}
+
+
+def _matrix_images(U, n):
+    """U P U^dagger for P = X_0, Z_0, X_1, Z_1...: list of (sign, pauli string)."""
+    out = []
+    names = ["".join(s) for s in __import__("itertools").product("IXYZ", repeat=n)]
+    for q in range(n):
+        for g in "XZ":
+            P = np.array([[1]], dtype=complex)
+            for k in range(n):
+                P = np.kron(P, _PAULI[g] if k == q else _I2)
+            Q = U @ P @ U.conj().T
+            hit = None
+            for nm in names:
+                M = np.array([[1]], dtype=complex)
+                for ch in nm:
+                    M = np.kron(M, _PAULI[ch])
+                c = np.trace(M.conj().T @ Q) / 2**n
+                if abs(abs(c) - 1) < 1e-9:
+                    assert abs(c.imag) < 1e-9
+                    hit = (int(round(c.real)), nm)
+            assert hit is not None, "not a Clifford"
+            out.append(hit)
+    return out
+
+
+def _tableau_images(apply, n):
+    from tsim_amd.clifford import _Sim
+
+    sim = _Sim(n)
+    apply(sim)
+    t = sim.tab
+    out = []
+    for q in range(n):
+        for row in (q, t.n + q):  # destabilizer row q started as X_q, stabilizer row as Z_q
+            nm = "".join("IXZY"[int(t.x[row, k]) + 2 * int(t.z[row, k])] for k in range(n))
+            out.append((-1 if t.r[row] else 1, nm))
+    return out
+
+
+def _one_qubit_unitaries():
+    r = 1 / np.sqrt(2)
+    S = np.diag([1, 1j])
+    H = (_PX + _PZ) * r
+    sx = H @ S @ H
+    sy = np.array([[1 + 1j, -1 - 1j], [1 + 1j, 1 + 1j]]) / 2
+    U = {"I": _I2, "X": _PX, "Y": _PY, "Z": _PZ, "H": H, "H_XZ": H, "H_XY": (_PX + _PY) * r, "H_YZ": (_PY + _PZ) * r,
+         "H_NXY": (_PY - _PX) * r, "H_NXZ": (_PZ - _PX) * r, "H_NYZ": (_PZ - _PY) * r,
+         "S": S, "SQRT_Z": S, "S_DAG": S.conj().T, "SQRT_Z_DAG": S.conj().T,
+         "SQRT_X": sx, "SQRT_X_DAG": sx.conj().T, "SQRT_Y": sy, "SQRT_Y_DAG": sy.conj().T}
+    return U
+
+
+def _cycle_unitary(name):
+    """The 120-degree rotation realising the axis cycle in the gate's name: its axis is the fixed
+    vector of the cycle, its sense the one whose conjugation action is the cycle."""
+    (sx, ax), (sz, az) = _cycle_images(name)
+    col = {"X": 0, "Y": 1, "Z": 2}
+    R = np.zeros((3, 3))
+    R[col[ax], 0] = sx
+    R[col[az], 2] = sz
+    R[:, 1] = np.cross(R[:, 2], R[:, 0])  # Y = i X Z keeps the frame right-handed
+    w, v = np.linalg.eig(R)
+    axis = np.real(v[:, np.argmin(abs(w - 1))])
+    axis = axis / abs(axis).max()
+    n = axis[0] * _PX + axis[1] * _PY + axis[2] * _PZ
+    for sign in (1, -1):
+        u = (_I2 + sign * 1j * n) / 2
+        if _matrix_images(u, 1) == [(sx, ax), (sz, az)]:
+            return u
+    raise AssertionError(name)
+
+
+
+def _cycle_images(name):
+    """C_NXYZ: -X -> Y -> Z -> -X, read off the name; returns the expected images of X and Z."""
+    body, axes, k = name[2:], [], 0
+    while k < len(body):
+        sgn = 1
+        if body[k] == "N":
+            sgn, k = -1, k + 1
+        axes.append((sgn, body[k]))
+        k += 1
+    img = {}
+    for i, (s, a) in enumerate(axes):
+        s2, b = axes[(i + 1) % 3]
+        img[a] = (s * s2, b)
+    return [img["X"], img["Z"]]
+
+
+def test_one_qubit_cliffords_match_their_unitaries():
+    from tsim_amd.clifford import _ACTION_1Q
+
+    U = _one_qubit_unitaries()
+    for name in _ACTION_1Q:
+        if name.startswith("C_"):
+            U[name] = _cycle_unitary(name)
+    assert set(U) == set(_ACTION_1Q)
+    assert np.allclose(U["C_XYZ"], (_I2 - 1j * (_PX + _PY + _PZ)) / 2)  # right-handed about (1,1,1)
+    for name, u in U.items():
+        assert np.allclose(u @ u.conj().T, _I2), name
+        got = _tableau_images(lambda sim: sim.gate1(name, 0), 1)
+        assert got == _matrix_images(u, 1), name
+        if name.startswith("C_"):
+            assert got == _cycle_images(name), name
+
+
+def _two_qubit_unitaries():
+    def proj(P, sign):
+        return (np.eye(P.shape[0]) + sign * P) / 2
+
+    CX = np.kron(proj(_PZ, 1), _I2) + np.kron(proj(_PZ, -1), _PX)
+    CZ = np.diag([1, 1, 1, -1]).astype(complex)
+    SWAP = np.eye(4, dtype=complex)[[0, 2, 1, 3]]
+    ISWAP = np.array([[1, 0, 0, 0], [0, 0, 1j, 0], [0, 1j, 0, 0], [0, 0, 0, 1]], dtype=complex)
+    U = {"SWAP": SWAP, "ISWAP": ISWAP, "ISWAP_DAG": ISWAP.conj().T, "CXSWAP": SWAP @ CX, "SWAPCX": CX @ SWAP,
+         "CZSWAP": SWAP @ CZ, "SWAPCZ": CZ @ SWAP}
+    for a in "XYZ":      # A-controlled-B: B on the second qubit when the first is in the -1 eigenstate of A
+        for b in "XYZ":
+            u = np.kron(proj(_PAULI[a], 1), _I2) + np.kron(proj(_PAULI[a], -1), _PAULI[b])
+            U[f"{a}C{b}"] = u
+            if a == "Z":
+                U[f"C{b}"] = u
+    U["CNOT"] = U["ZCX"]
+    for a in "XYZ":      # phase the -1 eigenspace of AA by i
+        PP = np.kron(_PAULI[a], _PAULI[a])
+        U[f"SQRT_{a}{a}"] = proj(PP, 1) + 1j * proj(PP, -1)
+        U[f"SQRT_{a}{a}_DAG"] = proj(PP, 1) - 1j * proj(PP, -1)
+    return U
+
+
+def test_two_qubit_cliffords_match_their_unitaries():
+    from tsim_amd.clifford import _TWO_QUBIT
+
+    U = _two_qubit_unitaries()
+    assert set(U) == set(_TWO_QUBIT)
+    for name, u in U.items():
+        got = _tableau_images(lambda sim: sim.gate2(name, 0, 1), 2)
+        assert got == _matrix_images(u, 2), name
+    # and with the operands the other way round (second listed qubit is the control / first operand)
+    SW = U["SWAP"]
+    for name in ("CX", "XCY", "YCZ", "CXSWAP", "SQRT_XX", "ISWAP_DAG"):
+        got = _tableau_images(lambda sim: sim.gate2(name, 1, 0), 2)
+        assert got == _matrix_images(SW @ U[name] @ SW, 2), name
+
+
+def test_spp_is_the_square_root_of_a_pauli_product():
+    rng = np.random.default_rng(5)
+    for _ in range(20):
+        n = int(rng.integers(1, 4))
+        qs = [int(q) for q in rng.permutation(3)[:n]]
+        kinds = [str(rng.choice(list("XYZ"))) for _ in qs]
+        P = np.array([[1]], dtype=complex)
+        for q in range(3):
+            P = np.kron(P, _PAULI[kinds[qs.index(q)]] if q in qs else _I2)
+        for dag in (False, True):
+            u = (np.eye(8) + P) / 2 + (-1j if dag else 1j) * (np.eye(8) - P) / 2
+            got = _tableau_images(lambda sim: sim.spp(list(zip(kinds, qs)), dag=dag), 3)
+            assert got == _matrix_images(u, 3), (kinds, qs, dag)
+
+
+def test_new_gates_through_the_text_front_end():
+    """Deterministic outcomes of small circuits using the added gates; tags and no-ops."""
+    def records(text):
+        an = CliffordCircuit(text).analyze()
+        assert not any(an.rec_syms), text
+        return an.rec_vals
+
+    assert records("H_XY 0\nM 0") == [1]                 # Z -> -Z
+    assert records("C_XYZ 0\nMX 0") == [0]               # Z -> X
+    assert records("C_NXYZ 0\nMX 0") == [1]              # Z -> -X
+    assert records("C_ZYX 0\nMY 0") == [0]               # Z -> Y
+    assert records("C_ZNYX 0\nMY 0") == [1]              # Z -> -Y
+    assert records("H_NXZ 0\nMX 0") == [1]               # Z -> -X
+    assert records("X 0\nISWAP 0 1\nM 0 1") == [0, 1]
+    assert records("X 0\nCXSWAP 0 1\nM 0 1") == [1, 1]   # CX then SWAP
+    assert records("X 0\nSWAPCX 0 1\nM 0 1") == [0, 1]   # SWAP then CX: control 0 is |0>
+    assert records("RX 0\nX 0\nZ 0\nXCX 0 1\nM 1") == [1]   # control in |->: X on the target
+    assert records("RY 0\nZ 0\nYCZ 0 1\nRX 1\nYCZ 0 1\nMX 1") == [1]  # control in Y = -1: Z on |+> gives |->
+    assert records("SQRT_XX 0 1\nSQRT_XX 0 1\nM 0 1") == [1, 1]       # XX
+    assert records("SQRT_YY 0 1\nSQRT_YY_DAG 0 1\nM 0 1") == [0, 0]
+    assert records("SPP X0*X1\nSPP X0*X1\nM 0 1") == [1, 1]
+    assert records("SPP Z0\nSPP !Z0\nRX 0\nSPP Z0\nSPP_DAG Z0\nMX 0") == [0]
+    assert records("RX 0\nSPP Z0\nSPP Z0\nMX 0") == [1]              # S S = Z on |+>
+    assert records("I_ERROR(0.1) 0\nII 0 1\nII_ERROR(0.1) 0 1\nS[note] 0\nM 0") == [0]
+    for bad in ("S[T] 0", "S_DAG[T] 0", "T 0", "T_DAG 0", "I[R_Z(theta=0.25*pi)] 0", "I[U3(theta=0.1*pi, phi=0, lambda=0)] 0",
+                "SPP[T] X0", "SPP[R_PAULI(theta=0.1*pi)] X0*Z1"):
+        with pytest.raises(NotImplementedError):
+            CliffordCircuit(bad + "\nM 0")
+    with pytest.raises(ValueError):
+        CliffordCircuit("CX 0 0\nM 0").analyze()

@@ -31,8 +31,14 @@ are exactly those of the reference's compiled graphs (0, 1/2 or 1 of the previou
 Threefry draws reproduce its seeded samples (``H 0; M 0`` -> 48, 53, 52, 50); with several components
 their processing order (size, then first output) is this front-end's reading of pipeline.py:65.
 
-Not covered (``NotImplementedError``): non-Clifford gates (T, rotations - they need the
-stabilizer-rank compiler, out of scope) and classically controlled gates.
+Gate coverage: every Clifford entry of the reference's gate table (core/instructions.py GATE_TABLE) -
+the 24 single-qubit Cliffords (Paulis, H_*, S/SQRT_*, the C_* axis cycles), all A-controlled-B gates,
+SQRT_XX/YY/ZZ(+_DAG), SWAP/ISWAP/CXSWAP/SWAPCX/CZSWAP, SPP/SPP_DAG Pauli-product phases - defined by what
+they do (conjugation tables / controlled-Pauli and sqrt-of-Pauli-product constructions) and checked in
+tests/test_clifford.py against unitaries written from those definitions.
+
+Not covered (``NotImplementedError``): non-Clifford gates (T, ``S[T]``, ``I[R_Z(...)]``, ``U3`` and
+``SPP[T]`` tags - they need the stabilizer-rank compiler, out of scope) and classically controlled gates.
 """
 
 from __future__ import annotations
@@ -105,9 +111,12 @@ class _Instr:
     name: str
     args: tuple
     targets: tuple  # of str tokens
+    tag: str = ""
 
 
-_LINE = re.compile(r"^([A-Za-z_][A-Za-z0-9_]*)(?:\[[^\]]*\])?(?:\(([^)]*)\))?\s*(.*)$")
+_LINE = re.compile(r"^([A-Za-z_][A-Za-z0-9_]*)(?:\[([^\]]*)\])?(?:\(([^)]*)\))?\s*(.*)$")
+# tags the reference gives a non-Clifford meaning to (core/parse.py:31-35, 263-276): S[T], I[R_Z(...)], ...
+_NON_CLIFFORD_TAG = re.compile(r"^\s*(T|R_X|R_Y|R_Z|R_PAULI|U3)\b")
 
 
 def _parse(text: str) -> list[_Instr]:
@@ -127,7 +136,9 @@ def _parse(text: str) -> list[_Instr]:
             m = _LINE.match(ln)
             if not m:
                 raise ValueError(f"cannot parse line {ln!r}")
-            name, args, rest = m.group(1).upper(), m.group(2), m.group(3).strip()
+            name, tag, args, rest = m.group(1).upper(), m.group(2) or "", m.group(3), m.group(4).strip()
+            if name in ("T", "T_DAG") or _NON_CLIFFORD_TAG.match(tag):
+                raise NotImplementedError(f"{ln!r} is a non-Clifford gate: the Clifford front-end cannot compile it")
             if name == "REPEAT":
                 if not rest.endswith("{"):
                     raise ValueError("REPEAT needs a '{' on the same line")
@@ -136,7 +147,7 @@ def _parse(text: str) -> list[_Instr]:
                 out.extend(body * count)
                 continue
             a = tuple(float(x) for x in args.split(",")) if args and args.strip() else ()
-            out.append(_Instr(name, a, tuple(rest.split())))
+            out.append(_Instr(name, a, tuple(rest.split()), tag))
         if depth:
             raise ValueError("missing '}'")
         return out, pos
@@ -231,20 +242,65 @@ class _Tableau:
 # ---------------------------------------------------------------------------
 # the analysis: frames + tableau driven by one gate decomposition
 # ---------------------------------------------------------------------------
-# every supported unitary as a word over primitives applied left to right:
-#   H q | S q | CX c t | P(x,z) q (Pauli X^x Z^z: tableau signs only)
-_ONE_QUBIT = {
-    "I": (), "X": (("P", 1, 0),), "Y": (("P", 1, 1),), "Z": (("P", 0, 1),),
-    "H": (("H",),), "H_XZ": (("H",),),
-    "S": (("S",),), "SQRT_Z": (("S",),),
-    "S_DAG": (("S",), ("S",), ("S",)), "SQRT_Z_DAG": (("S",), ("S",), ("S",)),
-    "SQRT_X": (("H",), ("S",), ("H",)),
-    "SQRT_X_DAG": (("H",), ("S",), ("S",), ("S",), ("H",)),
-    "SQRT_Y": (("H",), ("P", 1, 0)),          # X -> -Z, Z -> X
-    "SQRT_Y_DAG": (("P", 1, 0), ("H",)),      # X -> Z, Z -> -X
-    "H_YZ": (("H",), ("S",), ("H",), ("P", 0, 1)),  # sqrt(X) then Z: X -> -X, Y <-> Z
+# Single-qubit Cliffords are given by what they do (Stim's conventions): the images of X and of Z under
+# conjugation.  Each becomes a word over the primitives  H | S | P(x,z) (Pauli X^x Z^z: signs only),
+# found once at import time: the six classes modulo Paulis are the words below, the Pauli fixes the signs.
+_ACTION_1Q = {
+    "I": ("+X", "+Z"), "X": ("+X", "-Z"), "Y": ("-X", "-Z"), "Z": ("-X", "+Z"),
+    "H": ("+Z", "+X"), "H_XZ": ("+Z", "+X"), "H_NXZ": ("-Z", "-X"),
+    "H_XY": ("+Y", "-Z"), "H_NXY": ("-Y", "-Z"),
+    "H_YZ": ("-X", "+Y"), "H_NYZ": ("-X", "-Y"),
+    "S": ("+Y", "+Z"), "SQRT_Z": ("+Y", "+Z"), "S_DAG": ("-Y", "+Z"), "SQRT_Z_DAG": ("-Y", "+Z"),
+    "SQRT_X": ("+X", "-Y"), "SQRT_X_DAG": ("+X", "+Y"),
+    "SQRT_Y": ("-Z", "+X"), "SQRT_Y_DAG": ("+Z", "-X"),
+    # period-3 axis cycles, named by the cycle: C_XYZ sends X -> Y -> Z -> X, C_NXYZ sends -X -> Y -> Z -> -X
+    "C_XYZ": ("+Y", "+X"), "C_NXYZ": ("-Y", "-X"), "C_XNYZ": ("-Y", "+X"), "C_XYNZ": ("+Y", "-X"),
+    "C_ZYX": ("+Z", "+Y"), "C_NZYX": ("-Z", "-Y"), "C_ZNYX": ("+Z", "-Y"), "C_ZYNX": ("-Z", "+Y"),
 }
-_TWO_QUBIT = {"CX", "CNOT", "ZCX", "CZ", "ZCZ", "CY", "ZCY", "SWAP", "XCZ"}
+
+
+def _solve_one_qubit_words():
+    def conj(word, x, z, s):  # the tableau's update rules (Tableau.h / .s / .pauli) on one signed Pauli
+        for step in word:
+            if step[0] == "H":
+                s ^= x & z
+                x, z = z, x
+            elif step[0] == "S":
+                s ^= x & z
+                z ^= x
+            else:
+                s ^= (z & step[1]) ^ (x & step[2])
+        return x, z, s
+
+    H, S = ("H",), ("S",)
+    classes = [(), (H,), (S,), (H, S), (S, H), (H, S, H)]
+    words = {}
+    for name, images in _ACTION_1Q.items():
+        want = [(_XZ[img[1]][0], _XZ[img[1]][1], int(img[0] == "-")) for img in images]
+        for w in classes:
+            for px in (0, 1):
+                for pz in (0, 1):
+                    word = w + ((("P", px, pz),) if (px or pz) else ())
+                    if [conj(word, 1, 0, 0), conj(word, 0, 1, 0)] == want:
+                        words.setdefault(name, word)
+        if name not in words:
+            raise AssertionError(f"no Clifford word for {name}")
+    return words
+
+
+_ONE_QUBIT = _solve_one_qubit_words()
+
+# Two-qubit Cliffords by construction: A-controlled-B gates, square roots of two-qubit Pauli products
+# ("phase the -1 eigenspace of PP by i"), and SWAP composites.
+_CONTROLLED = {"CX": "ZX", "CNOT": "ZX", "ZCX": "ZX", "CY": "ZY", "ZCY": "ZY", "CZ": "ZZ", "ZCZ": "ZZ",
+               "XCX": "XX", "XCY": "XY", "XCZ": "XZ", "YCX": "YX", "YCY": "YY", "YCZ": "YZ"}
+_SQRT_PP = {"SQRT_XX": ("X", False), "SQRT_XX_DAG": ("X", True), "SQRT_YY": ("Y", False),
+            "SQRT_YY_DAG": ("Y", True), "SQRT_ZZ": ("Z", False), "SQRT_ZZ_DAG": ("Z", True)}
+_SWAP_LIKE = {"SWAP", "ISWAP", "ISWAP_DAG", "CXSWAP", "SWAPCX", "CZSWAP", "SWAPCZ"}
+_TWO_QUBIT = set(_CONTROLLED) | set(_SQRT_PP) | _SWAP_LIKE
+_TO_Z = {"X": "H", "Y": "H_YZ", "Z": None}   # self-inverse, axis -> +Z
+_TO_X = {"X": None, "Y": "H_XY", "Z": "H"}   # self-inverse, axis -> +X
+_NO_OPS = {"I_ERROR", "II", "II_ERROR"}
 _NOISE_1 = {"X_ERROR": (1, 0), "Z_ERROR": (0, 1), "Y_ERROR": (1, 1)}
 _IGNORED = {"TICK", "QUBIT_COORDS", "SHIFT_COORDS"}
 _MEASURE = {"M": "Z", "MZ": "Z", "MX": "X", "MY": "Y", "MR": "Z", "MRZ": "Z", "MRX": "X", "MRY": "Y"}
@@ -295,17 +351,57 @@ class _Sim:
             else:
                 self.tab.pauli(q, step[1], step[2])
 
+    def _basis(self, table, axis, q):
+        if table[axis]:
+            self.gate1(table[axis], q)
+
+    def _swap(self, a, b):
+        self._cx(a, b); self._cx(b, a); self._cx(a, b)
+
+    def _sqrt_zz(self, a, b, dag):  # diag(1, i, i, 1) = CZ (S x S); the inverse for dag
+        s = "S_DAG" if dag else "S"
+        self.gate1(s, a); self.gate1(s, b)
+        self._h(b); self._cx(a, b); self._h(b)
+
     def gate2(self, name, a, b):
-        if name in ("CX", "CNOT", "ZCX"):
+        if a == b:
+            raise ValueError(f"{name} {a} {b}: the two targets must differ")
+        if name in _CONTROLLED:  # change the control axis to Z and the target axis to X, CX, undo
+            ca, tb = _CONTROLLED[name]
+            self._basis(_TO_Z, ca, a); self._basis(_TO_X, tb, b)
             self._cx(a, b)
-        elif name == "XCZ":
-            self._cx(b, a)
-        elif name in ("CZ", "ZCZ"):
-            self._h(b); self._cx(a, b); self._h(b)
-        elif name in ("CY", "ZCY"):
-            self.gate1("S_DAG", b); self._cx(a, b); self._s(b)
+            self._basis(_TO_X, tb, b); self._basis(_TO_Z, ca, a)
+        elif name in _SQRT_PP:
+            axis, dag = _SQRT_PP[name]
+            self._basis(_TO_Z, axis, a); self._basis(_TO_Z, axis, b)
+            self._sqrt_zz(a, b, dag)
+            self._basis(_TO_Z, axis, b); self._basis(_TO_Z, axis, a)
         elif name == "SWAP":
-            self._cx(a, b); self._cx(b, a); self._cx(a, b)
+            self._swap(a, b)
+        elif name in ("ISWAP", "ISWAP_DAG"):  # SWAP times sqrt(ZZ)
+            self._sqrt_zz(a, b, name == "ISWAP_DAG"); self._swap(a, b)
+        elif name == "CXSWAP":
+            self._cx(a, b); self._swap(a, b)
+        elif name == "SWAPCX":
+            self._swap(a, b); self._cx(a, b)
+        else:  # CZSWAP == SWAPCZ
+            self._h(b); self._cx(a, b); self._h(b); self._swap(a, b)
+
+    def spp(self, paulis, dag=False):
+        """Phase the -1 eigenspace of a Pauli product by i (-i for dag): parity of the rotated qubits
+        into the last one, S there, undo (instructions.py:966-982)."""
+        qs = [q for _, q in paulis]
+        if len(set(qs)) != len(qs):
+            raise ValueError("SPP: a qubit appears twice in one Pauli product")
+        for kind, q in paulis:
+            self._basis(_TO_Z, kind, q)
+        for q in qs[:-1]:
+            self._cx(q, qs[-1])
+        self.gate1("S_DAG" if dag else "S", qs[-1])
+        for q in reversed(qs[:-1]):
+            self._cx(q, qs[-1])
+        for kind, q in paulis:
+            self._basis(_TO_Z, kind, q)
 
     # noise ----------------------------------------------------------------------
     def _new_bits(self, k: int) -> list[int]:
@@ -501,7 +597,7 @@ class CliffordCircuit:
 
         for ins in self.instructions:
             name, args, tg = ins.name, ins.args, ins.targets
-            if name in _IGNORED:
+            if name in _IGNORED or name in _NO_OPS:
                 continue
             if any(t.startswith(("rec[", "sweep[")) for t in tg) and name not in ("DETECTOR", "OBSERVABLE_INCLUDE"):
                 raise NotImplementedError(f"classically controlled {name} is not supported by the Clifford front-end")
@@ -554,6 +650,10 @@ class CliffordCircuit:
                     inv = t.startswith("!")
                     paulis = [(tok[0].upper(), int(tok[1:])) for tok in t.lstrip("!").split("*")]
                     sim.mpp(paulis, p=args[0] if args else 0.0, invert=inv)
+            elif name in ("SPP", "SPP_DAG"):
+                for t in tg:
+                    paulis = [(tok[0].upper(), int(tok[1:])) for tok in t.lstrip("!").split("*")]
+                    sim.spp(paulis, dag=(name == "SPP_DAG") ^ t.startswith("!"))
             elif name in ("HERALDED_ERASE", "HERALDED_PAULI_CHANNEL_1"):
                 pr = (args[0] / 4,) * 4 if name == "HERALDED_ERASE" else args
                 for t in tg:

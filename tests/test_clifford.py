@@ -211,7 +211,7 @@ def test_flips_and_unsupported_instructions():
     with pytest.raises(NotImplementedError):
         CliffordCircuit("T 0\nM 0").analyze()
     with pytest.raises(NotImplementedError):
-        CliffordCircuit("M 0\nCX rec[-1] 1").analyze()
+        CliffordCircuit("M 0\nCX sweep[0] 1").analyze()
     with pytest.raises(ValueError):
         CliffordCircuit("M 0\nDETECTOR rec[-2]").analyze()
 
@@ -766,3 +766,71 @@ def test_new_gates_through_the_text_front_end():
             CliffordCircuit(bad + "\nM 0")
     with pytest.raises(ValueError):
         CliffordCircuit("CX 0 0\nM 0").analyze()
+
+
+# ---------------------------------------------------------------------------
+# classically controlled Paulis (feedback)
+# ---------------------------------------------------------------------------
+_TELEPORT = """
+{prep}
+R 1 2
+H 1
+CX 1 2
+CX 0 1
+H 0
+M{noise} 0 1
+{cx} 
+{cz}
+{meas} 2
+DETECTOR rec[-1]
+"""
+
+
+@pytest.mark.parametrize("prep,meas,expect", [("R 0", "M", 0), ("R 0\nX 0", "M", 1), ("RX 0", "MX", 0),
+                                              ("RX 0\nZ 0", "MX", 1), ("RY 0", "MY", 0), ("RY 0\nX 0", "MY", 1)])
+@pytest.mark.parametrize("spelling", [("CX rec[-1] 2", "CZ rec[-2] 2"), ("XCZ 2 rec[-1]", "CZ 2 rec[-2]"),
+                                      ("CX rec[-1] 2 rec[-2] 1", "CZ rec[-2] 2")])
+def test_teleportation_with_feedback_is_deterministic(prep, meas, expect, spelling):
+    """The Bell measurement's two random outcomes cancel against the corrections: the teleported state
+    is measured deterministically - without the feedback the detector is rejected as random."""
+    c = CliffordCircuit(_TELEPORT.format(prep=prep, noise="", cx=spelling[0], cz=spelling[1], meas=meas))
+    an = c.analyze()
+    assert an.rec_syms[0] and an.rec_syms[1] and an.rec_syms[0] != an.rec_syms[1]
+    assert an.detectors == [(0, expect)]
+    if meas != "M":  # the Z correction matters for X / Y inputs
+        with pytest.raises(ValueError, match="not deterministic"):
+            CliffordCircuit(_TELEPORT.format(prep=prep, noise="", cx=spelling[0], cz="", meas=meas)).analyze()
+    if meas != "MX":  # the X correction matters for Z / Y inputs
+        with pytest.raises(ValueError, match="not deterministic"):
+            CliffordCircuit(_TELEPORT.format(prep=prep, noise="", cx="", cz=spelling[1], meas=meas)).analyze()
+
+
+def test_feedback_carries_measurement_errors_into_the_frame():
+    """A flipped Bell-measurement record applies the wrong correction: the record error of qubit 1
+    (X correction) flips a Z-basis readout, that of qubit 0 (Z correction) an X-basis one."""
+    z = CliffordCircuit(_TELEPORT.format(prep="R 0", noise="(0.125)", cx="CX rec[-1] 2", cz="CZ rec[-2] 2", meas="M"))
+    an = z.analyze()
+    assert an.num_e == 2 and an.rec_sets[0] == 0b01 and an.rec_sets[1] == 0b10
+    assert an.detectors == [(0b10, 0)]
+    x = CliffordCircuit(_TELEPORT.format(prep="RX 0", noise="(0.125)", cx="CX rec[-1] 2", cz="CZ rec[-2] 2", meas="MX"))
+    assert x.analyze().detectors == [(0b01, 0)]
+    y = CliffordCircuit(_TELEPORT.format(prep="RY 0", noise="(0.125)", cx="CY rec[-1] 2", cz="", meas="MX"))
+    with pytest.raises(ValueError):  # Y-basis input, X readout: random whatever the feedback
+        y.analyze()
+    # sampling: the detector fires exactly when record 1's error fires -> rate 1/8
+    d = z.compile_detector_sampler(seed=3).sample(20000)
+    assert abs(d.mean() - 0.125) < 0.01
+
+
+def test_feedback_on_a_constant_record_and_bad_operands():
+    an = CliffordCircuit("X 0\nM 0\nCX rec[-1] 1\nCY rec[-1] 2\nYCZ 3 rec[-1]\nM 1 2 3\nH 4\nCZ rec[-4] 4\nMX 4").analyze()
+    assert an.rec_vals == [1, 1, 1, 1, 1] and not any(an.rec_syms)   # last: Z on |+> gives |->
+    an = CliffordCircuit("X 0\nM !0\nCX rec[-1] 1\nM 1").analyze()
+    assert an.rec_vals == [0, 0]                                      # the inverted record is what controls
+    for bad in ("M 0\nCX 1 rec[-1]", "M 0\nXCZ rec[-1] 1", "M 0\nCX rec[-1] rec[-1]"):
+        with pytest.raises(ValueError):
+            CliffordCircuit(bad).analyze()
+    with pytest.raises(NotImplementedError):
+        CliffordCircuit("M 0\nSWAP rec[-1] 1").analyze()
+    with pytest.raises(NotImplementedError):
+        CliffordCircuit("CX sweep[0] 1\nM 1").analyze()

@@ -77,3 +77,30 @@ def test_measurement_sampler_of_a_noisy_ghz_state(hip):
     assert np.array_equal(m[:, 0], m[:, 1]) and np.array_equal(m[:, 1], m[:, 2])
     assert abs(m[:, 0].mean() - 0.5) < 0.02
     assert abs((m[:, 3] ^ m[:, 0]).mean() - 0.25) < 0.02
+
+
+def test_teleportation_with_feedback_and_new_gates(hip):
+    """Classically controlled corrections: the two Bell-measurement outcomes are fair coins, the
+    teleported state reads out deterministically; a record error (1/8) applies the wrong correction."""
+    text = """
+        R 0 1 2
+        C_XYZ 0          # |0> -> |+>  (Z -> X)
+        H 1
+        CX 1 2
+        CX 0 1
+        H 0
+        M(0.125) 0 1
+        CX rec[-1] 2
+        CZ rec[-2] 2
+        MX 2
+    """
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = CliffordCircuit(text).compile_sampler(seed=4).sample(40000, batch_size=16384)
+    assert abs(m[:, 0].mean() - 0.5) < 0.02 and abs(m[:, 1].mean() - 0.5) < 0.02
+    assert abs((m[:, 0] ^ m[:, 1]).mean() - 0.5) < 0.02
+    assert abs(m[:, 2].mean() - 0.125) < 0.01          # the Z correction's record error flips the X readout
+    m = CliffordCircuit(text.replace("M(0.125)", "M").replace("MX 2", "ISWAP 2 3\nSQRT_YY 3 4\nSQRT_YY 3 4\nMY 3\nM 4")
+                        ).compile_sampler(seed=4).sample(4096)
+    # ISWAP sends the stabilizers X2, Z3 to Z2 Y3, Z2: qubit 3 holds +Y; SQRT_YY twice = YY flips qubit 4
+    assert (m[:, 2] == 0).all() and (m[:, 3] == 1).all()

@@ -38,7 +38,9 @@ they do (conjugation tables / controlled-Pauli and sqrt-of-Pauli-product constru
 tests/test_clifford.py against unitaries written from those definitions.
 
 Not covered (``NotImplementedError``): non-Clifford gates (T, ``S[T]``, ``I[R_Z(...)]``, ``U3`` and
-``SPP[T]`` tags - they need the stabilizer-rank compiler, out of scope) and classically controlled gates.
+``SPP[T]`` tags - they need the stabilizer-rank compiler, out of scope) and ``sweep[]`` targets.
+Classically controlled Paulis (``CX rec[-1] 2``, ``CZ``, ``CY``, ``XCZ``/``YCZ`` with the record last) are
+applied to frame and tableau alike.
 """
 
 from __future__ import annotations
@@ -201,11 +203,13 @@ class _Tableau:
         self.x[h] ^= self.x[i]
         self.z[h] ^= self.z[i]
 
-    def pauli_if(self, a, sym_mask):
-        """X on qubit a controlled by the XOR of the random symbols in sym_mask (reset after a random
-        measurement)."""
+    def pauli_if(self, a, sym_mask, px=1, pz=0):
+        """X^px Z^pz on qubit a controlled by the XOR of the random symbols in sym_mask (reset after a
+        random measurement; classically controlled Paulis): rows that anticommute with it pick the
+        symbols up in their sign."""
         if sym_mask:
-            for row in np.nonzero(self.z[:, a])[0]:
+            anti = (self.z[:, a] if px else 0) ^ (self.x[:, a] if pz else 0)
+            for row in np.nonzero(anti)[0]:
                 self.sym[int(row)] ^= sym_mask
 
     def measure_z(self, a) -> tuple[int, int]:
@@ -301,6 +305,11 @@ _TWO_QUBIT = set(_CONTROLLED) | set(_SQRT_PP) | _SWAP_LIKE
 _TO_Z = {"X": "H", "Y": "H_YZ", "Z": None}   # self-inverse, axis -> +Z
 _TO_X = {"X": None, "Y": "H_XY", "Z": "H"}   # self-inverse, axis -> +X
 _NO_OPS = {"I_ERROR", "II", "II_ERROR"}
+# gates that accept a measurement record as their Z-type control: (record is the first operand, Pauli applied)
+_FEEDBACK = {"CX": (True, (1, 0)), "CNOT": (True, (1, 0)), "ZCX": (True, (1, 0)),
+             "CY": (True, (1, 1)), "ZCY": (True, (1, 1)),
+             "CZ": (True, (0, 1)), "ZCZ": (True, (0, 1)),
+             "XCZ": (False, (1, 0)), "YCZ": (False, (1, 1))}
 _NOISE_1 = {"X_ERROR": (1, 0), "Z_ERROR": (0, 1), "Y_ERROR": (1, 1)}
 _IGNORED = {"TICK", "QUBIT_COORDS", "SHIFT_COORDS"}
 _MEASURE = {"M": "Z", "MZ": "Z", "MX": "X", "MY": "Y", "MR": "Z", "MRZ": "Z", "MRX": "X", "MRY": "Y"}
@@ -386,6 +395,19 @@ class _Sim:
             self._swap(a, b); self._cx(a, b)
         else:  # CZSWAP == SWAPCZ
             self._h(b); self._cx(a, b); self._h(b); self._swap(a, b)
+
+    def feedback(self, rec_index, q, px, pz):
+        """Pauli X^px Z^pz on qubit q if measurement record rec_index is 1 (``CX rec[-1] 3``).  The record
+        is const XOR <S, r> XOR <E, e>: the constant acts on the tableau's signs, the random symbols go
+        into the signs of the rows that anticommute, the error part into the frame."""
+        out = self.out
+        if out.rec_vals[rec_index]:
+            self.tab.pauli(q, px, pz)
+        self.tab.pauli_if(q, out.rec_syms[rec_index], px, pz)
+        if px:
+            self.fx[q] ^= out.rec_sets[rec_index]
+        if pz:
+            self.fz[q] ^= out.rec_sets[rec_index]
 
     def spp(self, paulis, dag=False):
         """Phase the -1 eigenspace of a Pauli product by i (-i for dag): parity of the rotated qubits
@@ -599,8 +621,25 @@ class CliffordCircuit:
             name, args, tg = ins.name, ins.args, ins.targets
             if name in _IGNORED or name in _NO_OPS:
                 continue
-            if any(t.startswith(("rec[", "sweep[")) for t in tg) and name not in ("DETECTOR", "OBSERVABLE_INCLUDE"):
-                raise NotImplementedError(f"classically controlled {name} is not supported by the Clifford front-end")
+            if any(t.startswith("sweep[") for t in tg):
+                raise NotImplementedError(f"{name} with sweep[] targets is not supported by the Clifford front-end")
+            if any(t.startswith("rec[") for t in tg) and name not in ("DETECTOR", "OBSERVABLE_INCLUDE"):
+                # classically controlled Pauli: the record is the Z-type operand (core/instructions.py cnot/cy/cz/xcz)
+                if name not in _FEEDBACK:
+                    raise NotImplementedError(f"{name} cannot take a measurement-record target")
+                if len(tg) % 2:
+                    raise ValueError(f"{name} needs an even number of targets")
+                for i in range(0, len(tg), 2):
+                    a, b = tg[i], tg[i + 1]
+                    ra, rb = a.startswith("rec["), b.startswith("rec[")
+                    if not (ra or rb):
+                        sim.gate2(name, int(a), int(b))
+                        continue
+                    ctrl_first, (px, pz) = _FEEDBACK[name]
+                    if ra and rb or (ra != ctrl_first and name not in ("CZ", "ZCZ")):
+                        raise ValueError(f"{name} {a} {b}: the measurement record must be the Z-controlled operand")
+                    sim.feedback(rec(a if ra else b), int(b if ra else a), px, pz)
+                continue
             if name in _ONE_QUBIT:
                 for t in tg:
                     sim.gate1(name, int(t))

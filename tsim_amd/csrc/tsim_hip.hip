@@ -1040,6 +1040,12 @@ static int build_pattern_tables(tsim_program *p, const std::vector<long long> &n
       for (int b2 = 2; b2 < F; ++b2)
         for (int b1 = 1; b1 < b2; ++b1)
           for (int b0 = 0; b0 < b1; ++b0) pats.push_back((1ull << b2) | (1ull << b1) | (1ull << b0));
+    if (wmax >= 4)
+      for (int b3 = 3; b3 < F; ++b3)
+        for (int b2 = 2; b2 < b3; ++b2)
+          for (int b1 = 1; b1 < b2; ++b1)
+            for (int b0 = 0; b0 < b1; ++b0)
+              pats.push_back((1ull << b3) | (1ull << b2) | (1ull << b1) | (1ull << b0));
     if ((long long)pats.size() != npat[ci]) return fail(TSIM_ESTATE, "pattern enumeration mismatch");
     unsigned long long *d_pats = nullptr;
     HIP_TRY(hipMalloc((void **)&d_pats, pats.size() * 8));
@@ -1282,7 +1288,10 @@ retry_pack:
       ok = ok && (c.n_levels == c.n_out + 1) && c.n_out <= TSIMK_LW_MAX_NOUT && c.F + c.n_out <= 64;
     if (ok) {
       const int cap = p->lw_weight_cap < 0 ? TSIMK_LW_MAX_WEIGHT : std::min(p->lw_weight_cap, TSIMK_LW_MAX_WEIGHT);
-      const long long budget = 4ll << 20;  // bytes per component (the hot low-weight rows stay cache-resident)
+      // bytes per component.  Patterns are stored weight by weight, so the rows most shots read (weight
+      // 0..2) are a small cache-resident prefix whatever the total; the heavier tail is read rarely
+      long long budget = 32ll << 20;
+      if (const char *e = getenv("TSIM_AMD_PATTERN_TABLE_MB")) budget = std::max(1ll, atoll(e)) << 20;
       while (img.size() % 16) img.push_back(0u);
       p->lw_off = (int)img.size();
       img.resize(img.size() + p->comps.size() * LW_WORDS, 0u);
@@ -1290,7 +1299,8 @@ retry_pack:
       for (size_t ci = 0; ci < p->comps.size(); ++ci) {
         const HostComponent &c = p->comps[ci];
         const long long F = c.F;
-        const long long cnt[4] = {1, F, F * (F - 1) / 2, F * (F - 1) * (F - 2) / 6};
+        const long long cnt[5] = {1, F, F * (F - 1) / 2, F * (F - 1) * (F - 2) / 6,
+                                  F * (F - 1) * (F - 2) * (F - 3) / 24};
         long long npat = 0;
         int wmax = -1;
         for (int w = 0; w <= cap; ++w) {
@@ -1311,6 +1321,7 @@ retry_pack:
         r[LW_TAB] = (uint32_t)tab_off;
         r[LW_OFF2] = (uint32_t)(1 + F);
         r[LW_OFF3] = (uint32_t)(1 + F + cnt[2]);
+        r[LW_OFF4] = (uint32_t)(1 + F + cnt[2] + cnt[3]);
         r[LW_NPAT] = (uint32_t)npat;
         p->lw_wmax.push_back(wmax);
         lw_npat.push_back(npat);

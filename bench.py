@@ -236,11 +236,13 @@ def main() -> None:
     # GATHER_EVERY steps ONE asynchronous RCCL gather sends the whole group to rank 0 (fewer, larger
     # collectives: a gather per step would cost more host time than the step itself), double-buffered
     # so that it overlaps the kernels of the next group.
-    # Lanes (pipeline slots): three - the handle's own stream plus two more sit on three distinct hardware
-    # queues (36 us per step; two lanes 42 us; a fourth lane shares a queue with another, 43 us).  More
-    # than 4 busy hardware queues is pathological on this stack (3x slower with GPU_MAX_HW_QUEUES=5 / 8):
-    # lanes + RCCL's stream stay <= 4.
-    default_slots = 3
+    # Hardware queues: the handle's own stream plus two more sit on three distinct ones; more than 4 busy
+    # hardware queues is pathological on this stack (3x slower with GPU_MAX_HW_QUEUES=5 / 8), so lanes +
+    # RCCL's stream stay <= 4.  Slots: 8.  With short hard-row lists the library runs the first passes of
+    # consecutive launches on two of the lanes and the hard rows of four launches at a time as ONE grid on
+    # the third (deferred second pass); a slot is reused only after its batch is done, so the number of
+    # slots - not of lanes - covers the batch latency (3 slots: 46 us per step, 6: 33 us, 8 or more: 23 us).
+    default_slots = 8
     NSLOT = max(1, min(backend.HipProgram.PIPELINE_SLOTS, int(os.environ.get("TSIM_BENCH_SLOTS", str(default_slots)))))
     GATHER_EVERY = max(1, int(os.environ.get("TSIM_BENCH_GATHER_EVERY", "16")))
     if use_dist:

@@ -191,7 +191,7 @@ int tsim_sample_batch_device(tsim_program *p, const uint64_t *d_f, int64_t B, in
  * serial call.  Keep the number of busy streams (lanes + the caller's + RCCL's) at 4 or fewer: beyond
  * the 4 hardware queues HIP uses, launches slow down by 3x on this stack.
  */
-#define TSIM_PIPELINE_SLOTS 8
+#define TSIM_PIPELINE_SLOTS 16
 #define TSIM_PIPE_INPUTS_READY 1u
 int tsim_sample_batch_device_begin(tsim_program *p, int32_t slot, const uint64_t *d_f, int64_t B,
                                    int32_t num_f, uint32_t key_hi, uint32_t key_lo, int64_t shot_offset,

@@ -294,7 +294,7 @@ class HipProgram:
             "tsim_sample_batch_device",
         )
 
-    PIPELINE_SLOTS = 8
+    PIPELINE_SLOTS = 16
 
     def split_key(self, key):
         """``prng.split`` computed by the library (same values; ~5 us cheaper per batch)."""

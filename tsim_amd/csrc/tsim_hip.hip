@@ -148,9 +148,23 @@ struct tsim_program {
     bool side_borrowed = false;   // `side` is not owned by the slot (the handle's main stream / the null stream)
     bool side_ready = false;
     uint8_t *compact_out = nullptr;  // next launch of the slot also writes bit_packed rows here
+    // deferred second pass (flush_hard): pass 1 is enqueued, the hard rows wait for the next batch
+    bool deferred = false;
+    bool ctx_check = false;
+    hipStream_t p1_stream = nullptr;  // lane of that first pass
+    hipStream_t last_done = nullptr;  // stream on which done_ev of the slot's last launch was recorded
+    hipEvent_t done_ev = nullptr;     // ev2 (own second pass) or the event of the batch that served the slot
+    SampleArgs ctx;                   // the hard-row kernel's arguments for that launch
   };
   Slot slots[1 + TSIM_PIPELINE_SLOTS];
   bool slots_ready = false;
+  std::vector<int> deferred;  // slots whose hard rows are waiting, in launch order
+  hipEvent_t lane_ev[2] = {nullptr, nullptr};  // "first passes enqueued so far on lane k are done"
+  hipEvent_t batch_ev[16] = {};                // ring: one event per hard-row batch
+  unsigned batch_ring = 0;
+  int last_lists = 0;         // list count of the most recent two-pass launch (what the feedback refers to)
+  int h_group_tiles = 0;      // k_sample4h geometry, fixed at the first two-pass launch
+  size_t h_lds = 0;
   // launch-plan feedback (mapped pinned host memory written by k_sample4h): [0] hard rows,
   // [1] longest hard-row list, [2] rows of that launch; 0xFFFFFFFF = nothing seen yet
   volatile uint32_t *h_feedback = nullptr;
@@ -161,11 +175,15 @@ struct tsim_program {
     bool adaptive = true;     // TSIM_AMD_ADAPTIVE=0 pins the default launch plan
     bool hard_kernel = true;  // TSIM_AMD_HARD_KERNEL=0: hard rows on k_sample4 instead of k_sample4h
     bool lane0_main = true;   // TSIM_AMD_LANE0_MAIN=0: pipeline slot 0 gets a stream of its own
-    int lw_block = 256;       // TSIM_AMD_LW_BLOCK
+    int lw_block = 0;         // TSIM_AMD_LW_BLOCK (0: 1024 threads when the f/out staging fits 32 KB, else 256)
     int v4_block = 256;       // TSIM_AMD_V4_BLOCK
     int hard_lds_kb = 150;    // TSIM_AMD_HARD_LDS_KB
+    bool merge_lists = true;  // TSIM_AMD_MERGE_LISTS=0: always TSIMK_LW_LISTS hard-row sub-lists
+    bool defer = true;        // TSIM_AMD_DEFER_HARD=0: every pipelined launch runs its own second pass
+    int defer_group = 4;      // TSIM_AMD_DEFER_GROUP: launches per deferred hard-row batch (<= TSIMK_H_MAX_CTX)
   } knobs;
   bool h_attr_set = false;    // k_sample4h: large dynamic LDS enabled
+  bool hm_attr_set = false;   // k_sample4h_multi: the same
   int lw_off = 0;             // image offset of the LW component records
   int lw_direct_prog = 0;     // image offset of the direct-output gather program
   int lw_direct_chunks = 0;
@@ -1357,10 +1375,14 @@ retry_pack:
     p->knobs.adaptive = env_int("TSIM_AMD_ADAPTIVE", 1) != 0;
     p->knobs.hard_kernel = env_int("TSIM_AMD_HARD_KERNEL", 1) != 0;
     p->knobs.lane0_main = env_int("TSIM_AMD_LANE0_MAIN", 1) != 0;
-    p->knobs.lw_block = std::max(64, std::min(1024, env_int("TSIM_AMD_LW_BLOCK", 256) & ~63));
+    p->knobs.lw_block = env_int("TSIM_AMD_LW_BLOCK", 0);
+    if (p->knobs.lw_block != 0) p->knobs.lw_block = std::max(64, std::min(1024, p->knobs.lw_block & ~63));
     const int vb = env_int("TSIM_AMD_V4_BLOCK", 256);
     p->knobs.v4_block = (vb == 512 || vb == 128) ? vb : 256;
     p->knobs.hard_lds_kb = std::max(24, std::min(156, env_int("TSIM_AMD_HARD_LDS_KB", 150)));
+    p->knobs.defer = env_int("TSIM_AMD_DEFER_HARD", 1) != 0;
+    p->knobs.merge_lists = env_int("TSIM_AMD_MERGE_LISTS", 1) != 0;
+    p->knobs.defer_group = std::max(1, std::min(TSIMK_H_MAX_CTX, env_int("TSIM_AMD_DEFER_GROUP", 4)));
   }
 
   // ---- upload ----
@@ -1387,6 +1409,8 @@ extern "C" void tsim_program_destroy(tsim_program *p) {
     (void)hipSetDevice(p->device);
     if (p->stream) (void)hipStreamSynchronize(p->stream);
     for (hipEvent_t e : p->ev_pool) (void)hipEventDestroy(e);
+    for (hipEvent_t e : p->lane_ev) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : p->batch_ev) if (e) (void)hipEventDestroy(e);
     for (void *s : p->scratch)
       if (s) (void)hipFree(s);
     if (p->d_img) (void)hipFree(p->d_img);
@@ -1400,6 +1424,7 @@ extern "C" void tsim_program_destroy(tsim_program *p) {
       if (sl.keys) (void)hipFree(sl.keys);
       if (sl.ev1) (void)hipEventDestroy(sl.ev1);
       if (sl.ev2) (void)hipEventDestroy(sl.ev2);
+
       if (sl.side && !sl.side_borrowed) (void)hipStreamDestroy(sl.side);
     }
     if (p->stream) (void)hipStreamDestroy(p->stream);
@@ -1532,10 +1557,124 @@ static int slot_prepare(tsim_program *p, int slot, size_t hard_bytes) {
   return 0;
 }
 
+// Launch plan from the feedback of earlier launches (results do not depend on it):
+//  * most rows hard (dense error patterns): the pattern pass is wasted work - run the full kernel
+//    on every row for the next 15 launches, then probe again with one two-pass launch;
+//  * hard-row lists short: k_sample4h walks them alone, no overflow launch of k_sample4 - and a
+//    pipelined launch may leave its hard rows to a later batch (flush_hard) instead of making its
+//    lane wait for them.
+struct LaunchPlan {
+  bool use_tables = false, need_overflow = true, defer = false;
+  uint32_t fb_max = 0xFFFFFFFFu;
+  int lists = TSIMK_LW_LISTS;  // hard-row sub-lists of this launch: about 40 expected rows each
+};
+
+static LaunchPlan make_plan(tsim_program *p, bool has_row_index, bool pipelined) {
+  LaunchPlan pl;
+  pl.use_tables = p->lw;
+  if (p->lw && p->h_feedback && p->knobs.adaptive) {
+    const uint32_t fb_sum = p->h_feedback[0], fb_max = p->h_feedback[1], fb_rows = p->h_feedback[2];
+    const bool known = fb_rows != 0xFFFFFFFFu && fb_rows > 0u && fb_sum != 0xFFFFFFFFu;
+    bool dense = false;
+    if (p->lw_direct_left > 0) {
+      --p->lw_direct_left;
+      pl.use_tables = false;
+    } else if (known && (double)fb_sum > 0.5 * (double)fb_rows && !has_row_index) {
+      p->lw_direct_left = 15;  // this launch is the probe
+      dense = true;
+    }
+    if (known && fb_max <= 192u) pl.need_overflow = false;
+    pl.fb_max = known ? fb_max : 0xFFFFFFFFu;
+    if (known && p->knobs.merge_lists) {
+      const uint32_t want = (fb_sum + 39u) / 40u;
+      pl.lists = 4;
+      while ((uint32_t)pl.lists < want && pl.lists < TSIMK_LW_LISTS) pl.lists <<= 1;
+      // the longest list of the last launch was measured with ITS list count: rescale the overflow test
+      const uint32_t last = p->last_lists > 0 ? (uint32_t)p->last_lists : (uint32_t)TSIMK_LW_LISTS;
+      const uint32_t est_max = (uint32_t)std::min<unsigned long long>(0xFFFFFFFFull, (unsigned long long)fb_max * last / (uint32_t)pl.lists + 16u);
+      pl.need_overflow = !(pl.lists >= (int)last ? fb_max <= 192u : est_max <= 192u);
+    }
+    pl.defer = pipelined && pl.use_tables && !dense && !pl.need_overflow && p->knobs.defer && p->knobs.hard_kernel &&
+               p->v4 && !(p->profiling && !p->prof_light);
+  }
+  return pl;
+}
+
+// k_sample4h geometry (LDS budget -> tiles per group), 0 tiles = the kernel cannot run this program
+static void hard_geometry(tsim_program *p, int WF, int WO) {
+  constexpr int NW = TSIM_HARD_NW;
+  const size_t tile_b = (size_t)p->v4_max_nch * 16 * p->v4_gt * 16;
+  const size_t fixed_b = (size_t)(2 * WF + 2 * WO) * 64 * 4 + (size_t)NW * 8 * 64 * 4;
+  const size_t budget = (size_t)p->knobs.hard_lds_kb * 1024;
+  p->h_group_tiles = fixed_b + tile_b <= budget ? (int)std::min<size_t>(TSIMK_H_MAX_GROUP_TILES, (budget - fixed_b) / tile_b) : 0;
+  p->h_lds = fixed_b + (size_t)std::max(1, p->h_group_tiles) * tile_b;
+}
+
+// The deferred second pass: ONE k_sample4h_multi grid serves the hard rows of every launch whose
+// first pass is enqueued, on the third lane's stream, after those first passes.
+static int flush_hard(tsim_program *p) {
+  if (p->deferred.empty()) return 0;
+  constexpr int NW = TSIM_HARD_NW;
+  hipStream_t hs = p->slots[3].side;
+  Hard4Multi M{};
+  M.n_ctx = (int)p->deferred.size();
+  const uint32_t fb_max = p->h_feedback ? p->h_feedback[1] : 192u;
+  const int hb = (int)std::max(1u, std::min(4u, (std::min(fb_max, 192u) + 32u + 63u) / 64u));
+  int max_lists = 1;
+  for (int sidx : p->deferred) max_lists = std::max(max_lists, p->slots[sidx].ctx.row_lists);
+  M.blocks_per_ctx = hb * max_lists + 1;
+  M.group_tiles = p->h_group_tiles;
+  M.loop_stride = hb * 64;
+  M.comp4_off = p->comp4_off;
+  M.feedback = p->d_feedback;
+  // the batch starts after the first passes: streams are in order, so one event per lane covers them all
+  bool lane_used[2] = {false, false};
+  for (int i = 0; i < M.n_ctx; ++i) {
+    tsim_program::Slot &d = p->slots[p->deferred[i]];
+    for (int k = 0; k < 2; ++k)
+      if (d.p1_stream == p->slots[1 + k].side) lane_used[k] = true;
+    M.ctx[i] = d.ctx;
+    M.ctx[i].kernarg_off = (int)(offsetof(Hard4Multi, ctx) + (size_t)i * sizeof(SampleArgs));
+    if (d.ctx_check) M.check_mask |= 1 << i;
+  }
+  for (int k = 0; k < 2; ++k)
+    if (lane_used[k]) {
+      if (!p->lane_ev[k]) HIP_TRY(hipEventCreateWithFlags(&p->lane_ev[k], hipEventDisableTiming));
+      HIP_TRY(hipEventRecord(p->lane_ev[k], p->slots[1 + k].side));
+      HIP_TRY(hipStreamWaitEvent(hs, p->lane_ev[k], 0));
+    }
+  const unsigned grid = (unsigned)(M.n_ctx * M.blocks_per_ctx);
+  switch (p->v4_max_nch) {
+#define TSIM_LHM(N)                                                                                          \
+  case N: {                                                                                                  \
+    auto kfn = k_sample4h_multi<4, N, NW>;                                                                   \
+    if (!p->hm_attr_set)                                                                                     \
+      HIP_TRY(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(NW * 64), p->h_lds, hs, M);                                     \
+  } break;
+    TSIM_LHM(2) TSIM_LHM(4) TSIM_LHM(6) TSIM_LHM(8) TSIM_LHM(10) TSIM_LHM(12) TSIM_LHM(14) TSIM_LHM(16)
+#undef TSIM_LHM
+    default: return fail(TSIM_ESTATE, "bad chunk count %d", p->v4_max_nch);
+  }
+  HIP_TRY(hipGetLastError());
+  p->hm_attr_set = true;
+  hipEvent_t &be = p->batch_ev[p->batch_ring++ % 16u];
+  if (!be) HIP_TRY(hipEventCreateWithFlags(&be, hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(be, hs));
+  for (int i = 0; i < M.n_ctx; ++i) {
+    tsim_program::Slot &d = p->slots[p->deferred[i]];
+    d.deferred = false;
+    d.last_done = hs;
+    d.done_ev = be;
+  }
+  p->deferred.clear();
+  return 0;
+}
+
 static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_t num_f, uint32_t key_hi,
                          uint32_t key_lo, int64_t shot_offset, uint64_t *d_out, float *d_dev, hipStream_t s,
                          const uint32_t *d_row_index = nullptr, const uint32_t *d_row_count = nullptr,
-                         int slot = 0) {
+                         int slot = 0, const LaunchPlan *plan_in = nullptr) {
   if (!p->sampleable) return fail(TSIM_ESTATE, "program has joint-mode components (evaluate-only)");
   if (B < 0 || num_f < 0 || shot_offset < 0) return fail(TSIM_EINVAL, "negative B/num_f/shot_offset");
   if (p->max_f_index >= num_f)
@@ -1609,33 +1748,27 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
     if (pipelined) {
       HIP_TRY(hipEventRecord(sl.ev2, s));
       sl.pending = true;
+      sl.last_done = s;
+      sl.done_ev = sl.ev2;
     }
     return 0;
   };
-  // Launch plan from the feedback of earlier launches (results do not depend on it):
-  //  * most rows hard (dense error patterns): the pattern pass is wasted work - run the full kernel
-  //    on every row for the next 15 launches, then probe again with one two-pass launch;
-  //  * hard-row lists short: k_sample4h walks them alone, no overflow launch of k_sample4.
-  bool use_tables = p->lw, need_overflow = true;
-  if (p->lw && p->h_feedback && p->knobs.adaptive) {
-    const uint32_t fb_sum = p->h_feedback[0], fb_max = p->h_feedback[1], fb_rows = p->h_feedback[2];
-    const bool known = fb_rows != 0xFFFFFFFFu && fb_rows > 0u && fb_sum != 0xFFFFFFFFu;
-    if (p->lw_direct_left > 0) {
-      --p->lw_direct_left;
-      use_tables = false;
-    } else if (known && (double)fb_sum > 0.5 * (double)fb_rows && !d_row_index) {
-      p->lw_direct_left = 15;  // this launch is the probe
-    }
-    if (known && fb_max <= 192u) need_overflow = false;
-  }
+  const LaunchPlan plan = plan_in ? *plan_in : make_plan(p, d_row_index != nullptr, false);
+  const bool use_tables = plan.use_tables, need_overflow = plan.need_overflow;
   if (use_tables) {
     // pass 1: shots whose f_sel patterns are tabulated finish here, the others go to the hard list
     if (B > 0xFFFFFFFFll) return fail(TSIM_ENOTSUP, "batch too large for the row list");
-    const int blk1 = p->knobs.lw_block;
+    // few large blocks: 1024 threads finish a batch of 10^6 rows in 977 blocks - measurably better than
+    // 3906 blocks of 256 when the blocks of several launches and of the hard-row kernel share the CUs
+    const int blk1 = p->knobs.lw_block ? p->knobs.lw_block : ((size_t)(2 * a.WF + 2 * a.WO) * 1024 * 4 <= 32 * 1024 ? 1024 : 256);
     const long long grid1 = (B + blk1 - 1) / blk1;
-    const long long list_cap = (grid1 + TSIMK_LW_LISTS - 1) / TSIMK_LW_LISTS * blk1;
+    // n_lists sub-lists share the buffer sized for TSIMK_LW_LISTS of them: a list can hold every row of
+    // the blocks that feed it
+    const int n_lists = plan.lists;
+    const long long list_cap = (grid1 + TSIMK_LW_LISTS - 1) / TSIMK_LW_LISTS * blk1 * (TSIMK_LW_LISTS / n_lists);
     if (list_cap > 0x7FFFFFFFll) return fail(TSIM_ENOTSUP, "batch too large for the row lists");
-    if ((size_t)list_cap * TSIMK_LW_LISTS * 4 > sl.hard_sz) return fail(TSIM_ESTATE, "hard-row list too small");
+    if ((size_t)list_cap * n_lists * 4 > sl.hard_sz) return fail(TSIM_ESTATE, "hard-row list too small");
+    p->last_lists = n_lists;
     LwArgs l;
     l.s = a;
     l.tab = p->d_lw_tab;
@@ -1649,6 +1782,7 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
     l.ctl_next = sl.ctl + (sl.parity ^ 1) * (TSIMK_LW_LISTS + 1) * 32;
     sl.parity ^= 1;
     l.list_cap = (int)list_cap;
+    l.n_lists = n_lists;
     const size_t lds1 = (size_t)(2 * a.WF + 2 * a.WO) * blk1 * 4;
     if (lds1 > 64 * 1024) return fail(TSIM_ENOTSUP, "num_f + num_outputs too large for LDS staging (%zu B)", lds1);
     hipLaunchKernelGGL(k_sample_lw, dim3((unsigned)grid1), dim3(blk1), lds1, s, l);
@@ -1657,7 +1791,7 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
     // pass 2 below runs on the hard lists; the check row was forced into one of them
     a.row_index = l.hard_index;
     a.row_count = ctl;
-    a.row_lists = TSIMK_LW_LISTS;
+    a.row_lists = n_lists;
     a.row_list_cap = (int)list_cap;
     a.check_row = has_check ? ctl + 32 * TSIMK_LW_LISTS : nullptr;
     a.no_check = has_check ? 0 : 1;
@@ -1682,18 +1816,32 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
     const size_t tile_bytes = std::max((size_t)p->v4_max_nch * 16, (size_t)p->v4_max_sent) * p->v4_gt * 16;
     const size_t lds4 = (size_t)(2 * a.WF + 2 * a.WO) * blk * 4 + 2 * tile_bytes;
     if (lds4 > 64 * 1024) return fail(TSIM_ENOTSUP, "v4 kernel needs %zu B of LDS", lds4);
+    if (a.row_lists > 1 && getenv("TSIM_DBG_SKIP_HARD")) return finish();
     if (a.row_lists > 1 && p->knobs.hard_kernel) {
       // short row lists (second pass of a two-pass launch): NW waves per 64 rows, tsim_kernel4h.hip.h
       constexpr int NW = TSIM_HARD_NW;
-      const size_t tile_b = (size_t)p->v4_max_nch * 16 * p->v4_gt * 16;
-      const size_t fixed_b = (size_t)(2 * a.WF + 2 * a.WO) * 64 * 4 + (size_t)NW * 8 * 64 * 4;
-      const size_t budget = (size_t)p->knobs.hard_lds_kb * 1024;
-      int group_tiles = fixed_b + tile_b <= budget ? (int)std::min<size_t>(TSIMK_H_MAX_GROUP_TILES, (budget - fixed_b) / tile_b) : 0;
+      hard_geometry(p, a.WF, a.WO);
+      const int group_tiles = p->h_group_tiles;
+      if (group_tiles >= 1 && plan.defer && pipelined) {
+        // leave the hard rows to the next batch: this lane goes on with the next launch's first pass
+        if (!p->deferred.empty() && (p->slots[p->deferred[0]].ctx.WF != a.WF || p->slots[p->deferred[0]].ctx.WO != a.WO))
+          if (int r = flush_hard(p)) return r;  // one LDS layout per batch
+        sl.ctx = a;
+        sl.ctx.row_slot_begin = 0;
+        sl.ctx.row_slot_end = 0;
+        sl.ctx_check = has_check;
+        sl.deferred = true;
+        sl.pending = true;
+        sl.p1_stream = s;
+        p->deferred.push_back(slot);
+        if ((int)p->deferred.size() >= p->knobs.defer_group) return flush_hard(p);
+        return 0;
+      }
       if (group_tiles >= 1) {
         // the first kHardBlocks * 64 slots of every list go to the NW-wave kernel; k_sample4 below
         // serves the rest (its blocks exit at once when the lists are short - the usual case)
         constexpr int kHardBlocks = 4;
-        const size_t ldsh = fixed_b + (size_t)group_tiles * tile_b;
+        const size_t ldsh = p->h_lds;
         const long long gridh = (long long)kHardBlocks * nlists + a4.has_check;
         Sample4Args ah = a4;
         ah.s.row_slot_end = need_overflow ? kHardBlocks * 64 : 0;
@@ -1769,12 +1917,27 @@ extern "C" int tsim_sample_batch_device_begin(tsim_program *p, int32_t slot, con
   // The whole launch runs on the slot's own stream (a "lane"): launches of one slot are ordered by the
   // stream itself, launches of different slots overlap.  Unless the caller vouches for its inputs the
   // lane first waits for what is already queued on the caller's stream.
-  if (!(flags & TSIM_PIPE_INPUTS_READY) && s_user != sl.side) {
-    HIP_TRY(hipEventRecord(sl.ev1, s_user));
-    HIP_TRY(hipStreamWaitEvent(sl.side, sl.ev1, 0));
+  // Deferred plan (short hard-row lists): the first passes alternate between the first two lanes and
+  // the hard rows of several launches go to the third lane in one batch (flush_hard), so no lane
+  // waits for a second pass before it starts the next first pass.
+  if (sl.deferred)  // begin twice without end: finish the earlier launch's hard rows first
+    if (int r = flush_hard(p)) return r;
+  const LaunchPlan plan = make_plan(p, false, true);
+  hipStream_t s = plan.defer ? p->slots[1 + (slot & 1)].side : sl.side;
+  // the slot's previous launch (its lists, counters and output rows are reused): usually long finished -
+  // ask the event first, a stream wait costs queue time even when it has nothing to wait for
+  if (sl.last_done && sl.last_done != s && sl.done_ev) {
+    if (hipEventQuery(sl.done_ev) != hipSuccess) {
+      (void)hipGetLastError();
+      HIP_TRY(hipStreamWaitEvent(s, sl.done_ev, 0));
+    }
   }
-  return launch_sample(p, d_f, B, num_f, key_hi, key_lo, shot_offset, d_out, d_max_norm_dev, sl.side, nullptr, nullptr,
-                       1 + slot);
+  if (!(flags & TSIM_PIPE_INPUTS_READY) && s_user != s) {
+    HIP_TRY(hipEventRecord(sl.ev1, s_user));
+    HIP_TRY(hipStreamWaitEvent(s, sl.ev1, 0));
+  }
+  return launch_sample(p, d_f, B, num_f, key_hi, key_lo, shot_offset, d_out, d_max_norm_dev, s, nullptr, nullptr,
+                       1 + slot, &plan);
 }
 
 extern "C" int tsim_pipeline_set_compact_output(tsim_program *p, int32_t slot, uint8_t *d_compact) {
@@ -1793,15 +1956,20 @@ extern "C" int tsim_sample_batch_device_compact(tsim_program *p, int32_t slot, c
   if (B == 0 || nbits == 0) return TSIM_OK;
   if (!d_rows || !d_out) return fail(TSIM_EINVAL, "NULL buffer");
   tsim_program::Slot &sl = p->slots[1 + slot];
+  if (sl.deferred)
+    if (int r = flush_hard(p)) return r;
   // after the slot's second pass when there is one in flight, else simply on the caller's stream
-  hipStream_t s = sl.pending ? sl.side : (stream ? (hipStream_t)stream : p->stream);
+  hipStream_t s = sl.pending ? sl.last_done : (stream ? (hipStream_t)stream : p->stream);
   const int WO = (nbits + 63) / 64, rb = (nbits + 7) / 8;
   const long long nthreads = (B + 3) / 4;
   const uint32_t tail_mask = (nbits & 7) ? ((1u << (nbits & 7)) - 1u) : 255u;
   hipLaunchKernelGGL(k_compact_rows, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, s, d_rows, d_out,
                      (long long)B, WO, rb, tail_mask);
   HIP_TRY(hipGetLastError());
-  if (sl.pending) HIP_TRY(hipEventRecord(sl.ev2, sl.side));
+  if (sl.pending) {
+    HIP_TRY(hipEventRecord(sl.ev2, s));
+    sl.done_ev = sl.ev2;
+  }
   return TSIM_OK;
 }
 
@@ -1811,8 +1979,10 @@ extern "C" int tsim_sample_batch_device_end(tsim_program *p, int32_t slot, void 
   if (slot < 0 || slot >= TSIM_PIPELINE_SLOTS) return fail(TSIM_EINVAL, "slot %d out of range", slot);
   hipStream_t s = stream ? (hipStream_t)stream : p->stream;
   tsim_program::Slot &sl = p->slots[1 + slot];
+  if (sl.deferred)  // its batch is not full yet: run what is waiting now
+    if (int r = flush_hard(p)) return r;
   if (sl.pending) {
-    HIP_TRY(hipStreamWaitEvent(s, sl.ev2, 0));
+    if (sl.last_done != s) HIP_TRY(hipStreamWaitEvent(s, sl.done_ev, 0));
     sl.pending = false;
   }
   return TSIM_OK;
@@ -2232,6 +2402,7 @@ extern "C" void tsim_key_split(uint32_t key_hi, uint32_t key_lo, uint32_t out[4]
 extern "C" int tsim_synchronize(tsim_program *p) {
   if (int r = need_final(p)) return r;
   if (int r = set_device(p)) return r;
+  if (int r = flush_hard(p)) return r;
   HIP_TRY(hipStreamSynchronize(p->stream));
   for (auto &sl : p->slots)
     if (sl.side_ready) {

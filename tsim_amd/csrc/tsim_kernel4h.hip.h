@@ -192,17 +192,16 @@ __device__ __forceinline__ void eval_level4h(const uint32_t *gimg, cptr img, cpt
   }
 }
 
-// sample_program on row lists, 64 rows per block, NW waves per row group
+// sample_program on row lists, 64 rows per block, NW waves per row group; block `bidx` of `nblk`
 template <int GT, int NCH, int NW>
-__global__ void __launch_bounds__(NW * 64) k_sample4h(Sample4Args A4, int group_tiles, int loop_stride,
-                                                        uint32_t *feedback) {
+__device__ __forceinline__ void sample4h_rows(const SampleArgs &A, int comp4_off, bool has_check, int group_tiles,
+                                              int loop_stride, uint32_t *feedback, uint32_t bidx, uint32_t nblk) {
   typedef Hard4<GT, NCH, NW> H;
-  const SampleArgs &A = A4.s;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const bool check_block = A4.has_check && (blockIdx.x == gridDim.x - 1);
+  const bool check_block = has_check && (bidx == nblk - 1);
   // feedback to the host (mapped pinned memory, read at later launches to choose the launch plan):
   // total and longest hard-row list of THIS launch
-  if (feedback && blockIdx.x == 0 && wave == 0 && A.row_lists > 1) {
+  if (feedback && bidx == 0 && wave == 0 && A.row_lists > 1) {
     uint32_t c = lane < A.row_lists ? A.row_count[32u * lane] : 0u, m = c;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -217,12 +216,12 @@ __global__ void __launch_bounds__(NW * 64) k_sample4h(Sample4Args A4, int group_
   }
   // loop_stride > 0: the block walks its list in steps of loop_stride rows (no overflow kernel)
   for (long long iter_base = 0;; iter_base += loop_stride) {
-  long long row = (long long)blockIdx.x * 64 + lane;
+  long long row = (long long)bidx * 64 + lane;
   bool active = row < A.B;
   if (A.row_index) {
     const uint32_t nl = A.row_lists > 1 ? (uint32_t)A.row_lists : 1u;
-    const uint32_t k = blockIdx.x % nl;
-    const long long base = (long long)(blockIdx.x / nl) * 64 + iter_base;
+    const uint32_t k = bidx % nl;
+    const long long base = (long long)(bidx / nl) * 64 + iter_base;
     long long n = (long long)A.row_count[32u * k * (nl > 1 ? 1u : 0u)];
     if (A.row_slot_end > 0) n = min(n, (long long)A.row_slot_end);
     if (!check_block && base >= n) return;  // block-uniform
@@ -273,7 +272,7 @@ __global__ void __launch_bounds__(NW * 64) k_sample4h(Sample4Args A4, int group_
   __syncthreads();
 
   for (int ci = 0; ci < A.n_comp; ++ci) {
-    cptr comp = img + A4.comp4_off + ci * C4_WORDS;
+    cptr comp = img + comp4_off + ci * C4_WORDS;
     const uint32_t n_out = comp[C_NOUT], F = comp[C_F];
     cptr fsel = img + comp[C_FSEL];
     cptr levels = img + comp[C4_LEVELS];
@@ -345,6 +344,36 @@ __global__ void __launch_bounds__(NW * 64) k_sample4h(Sample4Args A4, int group_
   if (check_block || loop_stride <= 0 || !A.row_index) return;
   __syncthreads();  // the LDS staging of this row group is reused by the next one
   }
+}
+
+template <int GT, int NCH, int NW>
+__global__ void __launch_bounds__(NW * 64) k_sample4h(Sample4Args A4, int group_tiles, int loop_stride,
+                                                        uint32_t *feedback) {
+  sample4h_rows<GT, NCH, NW>(A4.s, A4.comp4_off, A4.has_check != 0, group_tiles, loop_stride, feedback, blockIdx.x,
+                             gridDim.x);
+}
+
+// The hard rows of SEVERAL launches in one grid (deferred second pass, tsim_hip.hip): launch c owns
+// the blocks [c * blocks_per_ctx, (c + 1) * blocks_per_ctx), the last of them its check block.
+#define TSIMK_H_MAX_CTX 8
+struct Hard4Multi {
+  int n_ctx, blocks_per_ctx, group_tiles, loop_stride;
+  int comp4_off, check_mask;
+  uint32_t *feedback;
+  SampleArgs ctx[TSIMK_H_MAX_CTX];
+};
+
+template <int GT, int NCH, int NW>
+__global__ void __launch_bounds__(NW * 64) k_sample4h_multi(Hard4Multi M) {
+  const uint32_t c = blockIdx.x / (uint32_t)M.blocks_per_ctx;
+  const uint32_t bidx = blockIdx.x - c * (uint32_t)M.blocks_per_ctx;
+  const bool has_check = ((M.check_mask >> c) & 1) != 0;
+  // without a check row the launch's last block is simply idle
+  if (!has_check && bidx == (uint32_t)M.blocks_per_ctx - 1u) return;
+  // the grid is sized for the launch with the most lists: blocks beyond this launch's own are idle
+  if (bidx + 1u < (uint32_t)M.blocks_per_ctx && bidx >= (uint32_t)(M.loop_stride / 64) * (uint32_t)M.ctx[c].row_lists) return;
+  sample4h_rows<GT, NCH, NW>(M.ctx[c], M.comp4_off, has_check, M.group_tiles, M.loop_stride, c == 0 ? M.feedback : nullptr,
+                             bidx, (uint32_t)M.blocks_per_ctx);
 }
 
 }  // namespace tsimk

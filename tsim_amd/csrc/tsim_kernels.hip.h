@@ -74,6 +74,9 @@ struct SampleArgs {
   // bit_packed layout, sampler.py:665-669) - what a gather moves; nullptr = not wanted
   uint8_t *out_compact;
   int out_rb;
+  // byte offset of THIS struct inside the kernel-argument segment (0 for every kernel whose first
+  // argument starts with it; the multi-launch hard-row kernel carries an array of them)
+  int kernarg_off;
 };
 #define TSIMK_INLINE_KEYS 32
 
@@ -87,11 +90,13 @@ __device__ __forceinline__ void store_compact_row(const SampleArgs &A, long long
 // subkey word j (0/1) of compiled output `o` (sampler.py:74,147-148)
 __device__ __forceinline__ uint32_t subkey(const SampleArgs &A, uint32_t o, uint32_t j) {
   // Wave-uniform, read through the constant address space (scalar loads): the inline keys sit in the
-  // kernel-argument segment - SampleArgs is the first member of the first argument of every sampling
-  // kernel - and the k_keygen buffer was written by an earlier kernel, so both are read-only here.
+  // kernel-argument segment (at kernarg_off: SampleArgs is the first member of the first argument of
+  // the sampling kernels, or an element of k_sample4h_multi's array) and the k_keygen buffer was
+  // written by an earlier kernel, so both are read-only here.
   typedef const __attribute__((address_space(4))) uint8_t *cbytes;
   cptr kp = A.n_inline_keys
-                ? (cptr)((cbytes)__builtin_amdgcn_kernarg_segment_ptr() + __builtin_offsetof(SampleArgs, inline_keys))
+                ? (cptr)((cbytes)__builtin_amdgcn_kernarg_segment_ptr() + A.kernarg_off +
+                         __builtin_offsetof(SampleArgs, inline_keys))
                 : (cptr)(uintptr_t)A.subkeys;
   return kp[2u * o + j];
 }

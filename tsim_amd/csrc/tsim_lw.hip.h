@@ -132,10 +132,12 @@ struct LwArgs {
   int direct_prog;        // image offset of the direct-output gather program (64-byte aligned)
   int direct_chunks;
   int has_check;          // the first slot's row is the normalisation-check row: always "hard"
-  uint32_t *hard_index;   // out: TSIMK_LW_LISTS sub-lists of list_cap rows that need the full kernel
+  uint32_t *hard_index;   // out: n_lists sub-lists of list_cap rows that need the full kernel
   uint32_t *ctl;          // ctl[32 k] = entries of list k (zeroed by the caller), ctl[32 LISTS] = check row
   int list_cap;
   uint32_t *ctl_next;     // the counter set of the NEXT launch: reset here (nobody else touches it now)
+  int n_lists;            // sub-lists in use (power of two <= TSIMK_LW_LISTS): few hard rows -> few lists,
+                          // so that the 64-row blocks of the second pass are well filled
 };
 
 __global__ void __launch_bounds__(1024) k_sample_lw(LwArgs L) {
@@ -227,7 +229,7 @@ __global__ void __launch_bounds__(1024) k_sample_lw(LwArgs L) {
     const int lane = (int)(threadIdx.x & 63u);
     const int leader = __builtin_ctzll(hm);
     uint32_t basei = 0;
-    const uint32_t k = blockIdx.x % (uint32_t)TSIMK_LW_LISTS;  // this block's sub-list
+    const uint32_t k = blockIdx.x % (uint32_t)L.n_lists;  // this block's sub-list
     if (lane == leader) basei = atomicAdd(&L.ctl[32u * k], (uint32_t)__popcll(hm));
     basei = (uint32_t)__shfl((int)basei, leader, 64);
     if (hard)

@@ -45,7 +45,7 @@ _backend_sample_program = sample_program
 class _CompiledSamplerBase:
     """Shared state: key, compiled program, channel sampler, direct-output tables."""
 
-    _PIPELINE = 3  # launches in flight on the device path (one f buffer each)
+    _PIPELINE = 8  # launches in flight on the device path (one f buffer each)
 
     def __init__(
         self,

@@ -244,10 +244,17 @@ def main() -> None:
     # slots - not of lanes - covers the batch latency (3 slots: 46 us per step, 6: 33 us, 8 or more: 23 us).
     default_slots = 8
     NSLOT = max(1, min(backend.HipProgram.PIPELINE_SLOTS, int(os.environ.get("TSIM_BENCH_SLOTS", str(default_slots)))))
-    GATHER_EVERY = max(1, int(os.environ.get("TSIM_BENCH_GATHER_EVERY", "16")))
+    GATHER_EVERY = max(1, int(os.environ.get("TSIM_BENCH_GATHER_EVERY", "32")))
     if use_dist:
         dev = torch.device("cuda", local_rank)
-        ext = torch.cuda.ExternalStream(hp.stream_ptr(), device=dev)
+        # the gathers are queued on the lane where the hard-row batches run (results complete there): the
+        # first-pass lanes - the handle's own stream is one of them - never wait for a gather or a join
+        import ctypes as _C
+        _sp = _C.c_void_p()
+        if hp._lib.tsim_pipeline_lane_stream(hp._h, 2, _C.byref(_sp)) < 0:
+            raise RuntimeError("tsim_pipeline_lane_stream failed")
+        join_ptr = int(_sp.value)
+        ext = torch.cuda.ExternalStream(join_ptr, device=dev)
         out_bufs = [torch.zeros((B, WO * 8), dtype=torch.uint8, device=dev) for _ in range(NSLOT)]
         out_ptrs = [t.data_ptr() for t in out_bufs]
         RB = (n_out + 7) // 8
@@ -256,6 +263,7 @@ def main() -> None:
         grp_ptrs = [t.data_ptr() for t in grp_bufs]
         grp_pending = [None, None]  # gather handle of the group buffer's previous use
         compact_fn = hp._lib.tsim_pipeline_set_compact_output
+        wait_fn = hp._lib.tsim_pipeline_wait_stream
     else:
         d_outs = [hp.malloc(B * WO * 8) for _ in range(NSLOT)]
         out_ptrs = [d.ptr for d in d_outs]
@@ -305,18 +313,23 @@ def main() -> None:
             with torch.cuda.stream(ext):
                 grp_pending[g].wait()  # the engine's stream waits until the previous gather released the buffer
             grp_pending[g] = None
-        # The first launch of every lane in a group (flags = 0) waits for the engine's stream, i.e. for the
-        # gather that last read this group buffer; the later ones need no cross-stream dependency.  The
-        # kernels write the rows a second time in the reference's bit_packed layout, into the group buffer.
-        rc = compact_fn(hp._h, b, grp_ptrs[g] + pos * B * RB)  # this launch also writes bit_packed rows there
+        # At the start of a group every lane waits ONCE for the engine's stream, i.e. for the gather that
+        # last read this group buffer (tsim_pipeline_wait_stream); the launches themselves then need no
+        # cross-stream dependency.  The kernels write the rows a second time in the reference's bit_packed
+        # layout, into the group buffer.
+        rc = 0
+        if pos == 0 or j < NSLOT:  # (the first launches create the lanes)
+            rc = wait_fn(hp._h, join_ptr)
+        if rc >= 0:
+            rc = compact_fn(hp._h, b, grp_ptrs[g] + pos * B * RB)  # this launch also writes bit_packed rows there
         if rc >= 0:
             rc = begin_fn(hp._h, b, d_f_ptr, B, num_f, sub[0], sub[1], shot_offset, out_ptrs[b], None, None,
-                          0 if pos < NSLOT else 1)
+                          0 if j < NSLOT else 1)
         if rc < 0:
             raise RuntimeError(f"pipelined launch failed ({rc})")
         if pos == GATHER_EVERY - 1:  # group complete: join every lane on the engine's stream, then gather
             for k in range(NSLOT):
-                end_fn(hp._h, k, None)
+                end_fn(hp._h, k, join_ptr)
             gather_next()
 
     def drain():
@@ -325,7 +338,7 @@ def main() -> None:
                 hp.sample_batch_device_end(inflight.pop(0)[0])
             return
         for b in range(NSLOT):
-            end_fn(hp._h, b, None)
+            end_fn(hp._h, b, join_ptr)
         n_steps = step_no[0]
         while gathered[0] * GATHER_EVERY < n_steps:
             gather_next(min(GATHER_EVERY, n_steps - gathered[0] * GATHER_EVERY))

@@ -190,6 +190,18 @@ int tsim_sample_batch_device(tsim_program *p, const uint64_t *d_f, int64_t B, in
  * the buffers of a slot for anything else between _begin and _end.  Results are identical to the
  * serial call.  Keep the number of busy streams (lanes + the caller's + RCCL's) at 4 or fewer: beyond
  * the 4 hardware queues HIP uses, launches slow down by 3x on this stack.
+ *
+ * Deferred second pass.  When recent launches left few hard rows (the launch-plan feedback: longest
+ * list <= 192), _begin only enqueues the FIRST pass, alternating between the lanes of slots 0 and 1,
+ * and keeps the launch's hard rows for a batch: every TSIM_AMD_DEFER_GROUP (default 4) launches - or
+ * when _end / _begin / tsim_synchronize needs a slot whose rows are still waiting - ONE grid
+ * (k_sample4h_multi) serves the hard rows of all waiting launches on the lane of slot 2, after their
+ * first passes.  No lane then waits for a second pass before its next first pass; a slot's next
+ * launch still waits for the batch that served its previous one (an event query, a stream wait only
+ * if needed), so the number of SLOTS in flight - 8 is enough on C2 - hides the batch latency, not the
+ * number of lanes.  The number of hard-row lists follows the load (4..64, about 40 rows each) so that
+ * the 64-row blocks of the hard-row kernel are filled.  TSIM_AMD_DEFER_HARD=0 / TSIM_AMD_MERGE_LISTS=0
+ * switch these off.  Results never depend on any of it.
  */
 #define TSIM_PIPELINE_SLOTS 16
 #define TSIM_PIPE_INPUTS_READY 1u
@@ -197,6 +209,15 @@ int tsim_sample_batch_device_begin(tsim_program *p, int32_t slot, const uint64_t
                                    int32_t num_f, uint32_t key_hi, uint32_t key_lo, int64_t shot_offset,
                                    uint64_t *d_out, float *d_max_norm_dev, void *stream, uint32_t flags);
 int tsim_sample_batch_device_end(tsim_program *p, int32_t slot, void *stream);
+/* Make every pipeline lane wait for the work already queued on `stream` (NULL: the handle's stream) -
+ * one event for all lanes.  Launches whose buffers depend only on that work may then pass
+ * TSIM_PIPE_INPUTS_READY (bench.py: once per gather group instead of once per launch). */
+int tsim_pipeline_wait_stream(tsim_program *p, void *stream);
+/* The stream of lane `lane` (= of slot `lane`; created on demand).  Lane 2 is where the deferred
+ * hard-row batches run, i.e. where results complete: a consumer that joins its slots on THAT stream
+ * (tsim_sample_batch_device_end(p, slot, lane2)) and queues its own work there (bench.py: the RCCL
+ * gather) never makes a first-pass lane wait. */
+int tsim_pipeline_lane_stream(tsim_program *p, int32_t lane, void **stream);
 /* The NEXT _begin on `slot` also writes its rows as uint8[B, ceil(num_outputs/8)] into d_compact (the
  * reference's bit_packed layout, sampler.py:665-669) straight from the sampling kernels - no separate
  * compaction kernel.  One-shot: cleared by that launch. */

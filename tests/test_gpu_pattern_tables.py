@@ -222,3 +222,124 @@ def test_compact_output_written_by_the_kernels(hip, tables):
         got = np.zeros((B, rb), np.uint8)
         hp.d2h(got, d_c)
         np.testing.assert_array_equal(got, np.packbits(want, axis=1, bitorder="little"))
+
+
+def _pipelined_run(hp, prog, cfg, n_launch, B, p_bits, order_end_first, nslot, compact=False, with_check=True):
+    """n_launch pipelined launches on `nslot` slots; returns (outputs, compact outputs, norm devs)."""
+    import ctypes as C
+
+    nf = cfg["num_f"]
+    wf, wo, rb = (nf + 63) // 64, (prog.num_outputs + 63) // 64, (prog.num_outputs + 7) // 8
+    n_comp = max(1, len(prog.components))
+    fs = [synth.synth_f(B, nf, p_bits[i % len(p_bits)], seed=300 + i) for i in range(n_launch)]
+    keys = [prng.key(500 + i) for i in range(n_launch)]
+    d_f = [hp.malloc(B * wf * 8) for _ in fs]
+    d_o = [hp.malloc(B * wo * 8) for _ in fs]
+    d_c = [hp.malloc(B * rb + 16) for _ in fs]
+    d_dev = hp.malloc(n_launch * n_comp * 4)
+    for d, f in zip(d_f, fs):
+        packed = np.packbits(f, axis=1, bitorder="little")
+        hp.h2d(d, np.ascontiguousarray(np.pad(packed, ((0, 0), (0, wf * 8 - packed.shape[1])))))
+    for i in range(n_launch):
+        slot = i % nslot
+        if order_end_first and i >= nslot:
+            hp.sample_batch_device_end(slot)
+        if compact:
+            assert hp._lib.tsim_pipeline_set_compact_output(hp._h, slot, C.c_void_p(d_c[i].ptr)) == 0
+        hp.sample_batch_device_begin(slot, d_f[i].ptr, B, nf, keys[i], d_o[i].ptr,
+                                     shot_offset=0 if with_check else 64 * i + 64,
+                                     d_norm_dev=d_dev.ptr + i * n_comp * 4)
+    for s in range(nslot):
+        hp.sample_batch_device_end(s)
+    hp.synchronize()
+    outs, comps = [], []
+    for i in range(n_launch):
+        got = np.zeros((B, wo * 8), np.uint8)
+        hp.d2h(got, d_o[i])
+        outs.append(got)
+        if compact:
+            c = np.zeros((B, rb), np.uint8)
+            hp.d2h(c, d_c[i])
+            comps.append(c)
+    devs = np.zeros(n_launch * n_comp, np.float32)
+    hp.d2h(devs, d_dev)
+    return fs, keys, outs, comps, devs.reshape(n_launch, n_comp)
+
+
+@pytest.mark.parametrize("group", [1, 2, 3, 4, 8])
+@pytest.mark.parametrize("nslot", [1, 3, 8])
+def test_deferred_hard_row_batches(hip, monkeypatch, group, nslot):
+    """The hard rows of several pipelined launches served by ONE k_sample4h_multi grid (deferred second
+    pass): every batch size, slot count and join order gives the bits of the serial full kernel,
+    including the normalisation check of each launch and the bit_packed second output."""
+    monkeypatch.setenv("TSIM_AMD_DEFER_GROUP", str(group))
+    prog, cfg = synth.config_program("C2")
+    hp = hip.HipProgram(prog)
+    ref = hip.HipProgram(prog, pattern_tables=False)
+    # warm the feedback so that the plan switches to deferred batches (first launches run their own pass)
+    for order_end_first in (True, False):
+        fs, keys, outs, comps, devs = _pipelined_run(hp, prog, cfg, 13, 20011, [0.02, 0.03, 0.01], order_end_first,
+                                                     nslot, compact=True)
+        for i, (f, k) in enumerate(zip(fs, keys)):
+            want, wdev = ref.sample_batch(f, k, bit_packed=True)
+            np.testing.assert_array_equal(outs[i], want, err_msg=f"launch {i}")
+            np.testing.assert_array_equal(comps[i], want[:, : comps[i].shape[1]], err_msg=f"compact {i}")
+            np.testing.assert_array_equal(devs[i], np.asarray(wdev, np.float32), err_msg=f"norm dev {i}")
+
+
+def test_deferred_batches_off_and_on_agree(hip, monkeypatch):
+    prog, cfg = synth.config_program("C3")
+    runs = []
+    for defer in ("1", "0"):
+        monkeypatch.setenv("TSIM_AMD_DEFER_HARD", defer)
+        hp = hip.HipProgram(prog)
+        runs.append(_pipelined_run(hp, prog, cfg, 11, 9001, [0.02, 0.002], True, 5, with_check=False))
+    for a, b in zip(runs[0][2], runs[1][2]):
+        np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.parametrize("p_bit,lists_expected", [(0.002, "few"), (0.06, "many")])
+def test_hard_row_list_count_follows_the_load(hip, p_bit, lists_expected):
+    """Few hard rows -> few, well filled lists; many -> all 64.  Same bits either way (serial API)."""
+    prog, cfg = synth.config_program("C2")
+    hp = hip.HipProgram(prog)
+    ref = hip.HipProgram(prog, pattern_tables=False)
+    for i in range(6):
+        f = synth.synth_f(40000, cfg["num_f"], p_bit, seed=70 + i)
+        got = hp.sample_batch(f, prng.key(i))[0]
+        np.testing.assert_array_equal(got, ref.sample_batch(f, prng.key(i))[0])
+
+
+def test_join_on_the_batch_lane_and_wait_stream(hip):
+    """A consumer may join its slots on lane 2 (where the deferred batches run) instead of the handle's
+    stream, and order every lane after a stream with one call; results as ever."""
+    prog, cfg = synth.config_program("C2")
+    hp = hip.HipProgram(prog)
+    ref = hip.HipProgram(prog, pattern_tables=False)
+    nf, B = cfg["num_f"], 12007
+    wf, wo = (nf + 63) // 64, (prog.num_outputs + 63) // 64
+    lane2 = hp.pipeline_lane_stream(2)
+    assert lane2 != 0 and lane2 != hp.stream_ptr() and hp.pipeline_lane_stream(0) == hp.stream_ptr()
+    n, nslot = 21, 6
+    fs = [synth.synth_f(B, nf, 0.02, seed=800 + i) for i in range(n)]
+    keys = [prng.key(900 + i) for i in range(n)]
+    d_f = [hp.malloc(B * wf * 8) for _ in range(nslot)]
+    d_o = [hp.malloc(B * wo * 8) for _ in range(n)]
+    for i in range(n):
+        slot = i % nslot
+        if i >= nslot:
+            hp.sample_batch_device_end(slot, lane2)
+        # the slot's f buffer is rewritten on the handle's stream: every lane must see it
+        packed = np.packbits(fs[i], axis=1, bitorder="little")
+        if i >= nslot:
+            hp.synchronize()  # the slot's previous launch no longer reads the buffer the blocking copy rewrites
+        hp.h2d(d_f[slot], np.ascontiguousarray(np.pad(packed, ((0, 0), (0, wf * 8 - packed.shape[1])))))
+        hp.pipeline_wait_stream()
+        hp.sample_batch_device_begin(slot, d_f[slot].ptr, B, nf, keys[i], d_o[i].ptr, inputs_ready=True)
+    for s in range(nslot):
+        hp.sample_batch_device_end(s, lane2)
+    hp.synchronize()
+    for i in range(n):
+        got = np.zeros((B, wo * 8), np.uint8)
+        hp.d2h(got, d_o[i])
+        np.testing.assert_array_equal(got, ref.sample_batch(fs[i], keys[i], bit_packed=True)[0], err_msg=f"launch {i}")

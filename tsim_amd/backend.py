@@ -314,9 +314,20 @@ class HipProgram:
         if rc < 0:
             _lib.check(rc, "tsim_sample_batch_device_begin")
 
-    def sample_batch_device_end(self, slot: int) -> None:
-        """Make the handle's stream wait for the slot's second pass."""
-        _lib.check(self._lib.tsim_sample_batch_device_end(self._h, int(slot), None), "tsim_sample_batch_device_end")
+    def sample_batch_device_end(self, slot: int, stream: int = 0) -> None:
+        """Make ``stream`` (0: the handle's stream) wait for the slot's second pass."""
+        _lib.check(self._lib.tsim_sample_batch_device_end(self._h, int(slot), stream or None), "tsim_sample_batch_device_end")
+
+    def pipeline_lane_stream(self, lane: int) -> int:
+        """``hipStream_t`` of pipeline lane ``lane`` as an integer; lane 2 is where deferred hard-row
+        batches - i.e. results - complete (include/tsim_hip.h)."""
+        st = C.c_void_p()
+        _lib.check(self._lib.tsim_pipeline_lane_stream(self._h, int(lane), C.byref(st)), "tsim_pipeline_lane_stream")
+        return int(st.value or 0)
+
+    def pipeline_wait_stream(self, stream: int = 0) -> None:
+        """Every pipeline lane waits for the work already queued on ``stream`` (0: the handle's)."""
+        _lib.check(self._lib.tsim_pipeline_wait_stream(self._h, stream or None), "tsim_pipeline_wait_stream")
 
     def stream_ptr(self) -> int:
         """The handle's ``hipStream_t`` as an integer (to order foreign work after the kernels)."""

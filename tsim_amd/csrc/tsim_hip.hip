@@ -151,6 +151,7 @@ struct tsim_program {
     // deferred second pass (flush_hard): pass 1 is enqueued, the hard rows wait for the next batch
     bool deferred = false;
     bool ctx_check = false;
+    bool used = false;                // a launch ran on the slot's own stream
     hipStream_t p1_stream = nullptr;  // lane of that first pass
     hipStream_t last_done = nullptr;  // stream on which done_ev of the slot's last launch was recorded
     hipEvent_t done_ev = nullptr;     // ev2 (own second pass) or the event of the batch that served the slot
@@ -161,6 +162,7 @@ struct tsim_program {
   std::vector<int> deferred;  // slots whose hard rows are waiting, in launch order
   hipEvent_t lane_ev[2] = {nullptr, nullptr};  // "first passes enqueued so far on lane k are done"
   hipEvent_t batch_ev[16] = {};                // ring: one event per hard-row batch
+  hipEvent_t sync_ev = nullptr;                // tsim_pipeline_wait_stream
   unsigned batch_ring = 0;
   int last_lists = 0;         // list count of the most recent two-pass launch (what the feedback refers to)
   int h_group_tiles = 0;      // k_sample4h geometry, fixed at the first two-pass launch
@@ -1409,6 +1411,7 @@ extern "C" void tsim_program_destroy(tsim_program *p) {
     (void)hipSetDevice(p->device);
     if (p->stream) (void)hipStreamSynchronize(p->stream);
     for (hipEvent_t e : p->ev_pool) (void)hipEventDestroy(e);
+    if (p->sync_ev) (void)hipEventDestroy(p->sync_ev);
     for (hipEvent_t e : p->lane_ev) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : p->batch_ev) if (e) (void)hipEventDestroy(e);
     for (void *s : p->scratch)
@@ -1924,6 +1927,7 @@ extern "C" int tsim_sample_batch_device_begin(tsim_program *p, int32_t slot, con
     if (int r = flush_hard(p)) return r;
   const LaunchPlan plan = make_plan(p, false, true);
   hipStream_t s = plan.defer ? p->slots[1 + (slot & 1)].side : sl.side;
+  if (!plan.defer) sl.used = true;
   // the slot's previous launch (its lists, counters and output rows are reused): usually long finished -
   // ask the event first, a stream wait costs queue time even when it has nothing to wait for
   if (sl.last_done && sl.last_done != s && sl.done_ev) {
@@ -1938,6 +1942,35 @@ extern "C" int tsim_sample_batch_device_begin(tsim_program *p, int32_t slot, con
   }
   return launch_sample(p, d_f, B, num_f, key_hi, key_lo, shot_offset, d_out, d_max_norm_dev, s, nullptr, nullptr,
                        1 + slot, &plan);
+}
+
+extern "C" int tsim_pipeline_lane_stream(tsim_program *p, int32_t lane, void **stream) {
+  if (int r = need_final(p)) return r;
+  if (int r = set_device(p)) return r;
+  if (lane < 0 || lane >= TSIM_PIPELINE_SLOTS || !stream) return fail(TSIM_EINVAL, "bad lane %d", lane);
+  if (int r = slot_prepare(p, 1 + lane, 0)) return r;
+  *stream = (void *)p->slots[1 + lane].side;
+  return TSIM_OK;
+}
+
+extern "C" int tsim_pipeline_wait_stream(tsim_program *p, void *stream) {
+  if (int r = need_final(p)) return r;
+  if (int r = set_device(p)) return r;
+  hipStream_t s_user = stream ? (hipStream_t)stream : p->stream;
+  if (!p->slots_ready) return TSIM_OK;  // no lane exists yet: the first launches order themselves
+  if (!p->sync_ev) HIP_TRY(hipEventCreateWithFlags(&p->sync_ev, hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(p->sync_ev, s_user));
+  // every lane a launch may run on: the slots' own streams that were used so far and the first three
+  // (first passes / hard-row batches of the deferred plan)
+  std::vector<hipStream_t> seen;
+  for (int k = 1; k <= TSIM_PIPELINE_SLOTS; ++k) {
+    tsim_program::Slot &sl = p->slots[k];
+    if (!sl.side_ready || (k > 3 && !sl.used) || sl.side == s_user) continue;
+    if (std::find(seen.begin(), seen.end(), sl.side) != seen.end()) continue;
+    seen.push_back(sl.side);
+    HIP_TRY(hipStreamWaitEvent(sl.side, p->sync_ev, 0));
+  }
+  return TSIM_OK;
 }
 
 extern "C" int tsim_pipeline_set_compact_output(tsim_program *p, int32_t slot, uint8_t *d_compact) {

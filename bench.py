@@ -397,6 +397,26 @@ def main() -> None:
         detail = {"stage_avg_ms": {k: v / max(dl, 1) for k, v in dst.items()}, "launch_latency_ms": dms / max(dl, 1),
                   "launches": dl, "note": "separate untimed steps with every kernel bracketed by HIP events"}
 
+    # untimed: the dominant kernel with the GPU to itself (serial launches on the handle's stream): its own
+    # duration, the figure rocprofv3's serial kernel trace gives (profiles/r01/*_kernel_stats_serial.csv).
+    # In the timed region two or three launches are in flight and each first pass shares the CUs with the
+    # others, so its bracketed duration there is longer than its cost.
+    serial_ms = None
+    if info.get("pattern_tables") and not use_dist:
+        for _ in range(2):
+            hp.sample_batch_device(d_f.ptr, B, num_f, key, d_out.ptr, shot_offset=shot_offset)
+        hp.synchronize()
+        hp.profile_enable(1)
+        hp.profile_read(reset=True)
+        for _ in range(8):
+            hp.sample_batch_device(d_f.ptr, B, num_f, key, d_out.ptr, shot_offset=shot_offset)
+        hp.synchronize()
+        sst = hp.profile_read_stages()
+        _, sl_n = hp.profile_read(reset=True)
+        hp.profile_enable(False)
+        if sl_n and sst["pattern_pass"] >= sst["full_kernel"]:
+            serial_ms = sst["pattern_pass"] / sl_n
+
     # the full kernel alone (pattern tables off), a few steps: the rate on inputs where no shot is
     # tabulated, and the quantity earlier rounds reported
     full_only = None
@@ -438,7 +458,7 @@ def main() -> None:
         achieved_gbs = bytes_per_shot * B / avg_kernel_s / 1e9
         achieved_tops = ops_per_shot * B / avg_kernel_s / 1e12
         if tables_dominant:
-            kernel_name = "tsimk::k_sample_lw (pattern-table pass; hard rows: k_sample4h + k_sample4, overlapped on the other lanes)" \
+            kernel_name = "tsimk::k_sample_lw (pattern-table pass; hard rows: k_sample4h_multi batches / k_sample4h + k_sample4, on the third lane)" \
                 if info.get("chunk_table_kernel") else "tsimk::k_sample_lw (pattern-table pass; hard rows: k_sample, overlapped on the other lanes)"
         else:
             kernel_name = "tsimk::k_sample4 (LDS chunk tables)" if info.get("chunk_table_kernel") else "tsimk::k_sample"
@@ -477,16 +497,20 @@ def main() -> None:
                 "kernel_avg_ms": avg_kernel_s * 1e3,
                 "launches": launches,
                 "hip_event_sampling": f"1 launch in {PROF_EVERY} bracketed",
+                "kernel_serial_avg_ms": serial_ms,
+                "achieved_serial": (bytes_per_shot * B / (serial_ms * 1e-3) / 1e9) if serial_ms else None,
                 "all_kernels": detail,
                 "pipeline_slots": NSLOT,
                 "host_enqueue_ms_per_step": host_enqueue_s / args.steps * 1e3,
                 "algorithmic_bytes_per_shot": bytes_per_shot,
-                "note": "achieved = algorithmic bytes of one launch / HIP-event time of the dominant kernel; with several "
-                "launches in flight that kernel shares the GPU with the same kernel of the other lanes, so its own "
-                "duration exceeds the step time - achieved_at_step_rate uses the step time instead. (k_sample_lw when "
-                "pattern tables are active: it reads every f row and writes every tabulated row; the hard-row kernels "
-                "run under the first pass of the next launches, on the other pipeline lanes). Integer-VALU / latency bound, not HBM bound "
-                "(DESIGN.md section 3.5); see `valu` and `stage_avg_ms`",
+                "note": "achieved = algorithmic bytes of one launch / HIP-event time of the dominant kernel inside the "
+                "timed region; there two first passes are in flight (two lanes) plus the hard-row batch on a third, so "
+                "each first pass shares the CUs and its own duration is about twice the step time - "
+                "achieved_at_step_rate uses the step time instead, achieved_serial the kernel's duration with the GPU "
+                "to itself (kernel_serial_avg_ms, measured after the timed region; = rocprofv3's serial kernel "
+                "trace). (k_sample_lw when pattern tables are active: it reads every f row and writes every "
+                "tabulated row.) Integer-VALU / latency bound, not HBM bound (DESIGN.md section 3.5); see `valu` "
+                "and `stage_avg_ms`",
             },
             "valu": valu_block(ops_per_shot, B, avg_kernel_s, args.config),
         }

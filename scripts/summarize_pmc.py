@@ -5,6 +5,11 @@ Each DIR is a rocprofv3 -d output directory.  For every kernel whose name contai
 per-invocation average of every counter is computed; OUT.json holds the PER-LAUNCH totals (sum over
 the kernels of one sampling launch: pattern-table pass + hard-row kernel + full kernel) at the top
 level - the keys bench.py reads - and the per-kernel averages under "_per_kernel".
+
+Deferred plan: one k_sample4h_multi grid serves the hard rows of GROUP launches (TSIM_AMD_DEFER_GROUP,
+default 4), so a launch is k_sample_lw + 1/GROUP of that grid; the k_sample4h / k_sample4 invocations
+in such a run belong to the first launches (before the plan has feedback) and are left out of the
+total ("_weights" records what was summed).
 """
 import collections
 import csv
@@ -28,12 +33,19 @@ def main():
                 if "k_sample" in r["Kernel_Name"]:
                     agg[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
     per_kernel = {k: {c: sum(v) / len(v) for c, v in sorted(cs.items())} for k, cs in agg.items()}
+    import os
+    group = int(os.environ.get("TSIM_AMD_DEFER_GROUP", "4"))
+    if "k_sample4h_multi" in per_kernel:
+        weights = {"k_sample_lw": 1.0, "k_sample4h_multi": 1.0 / group}
+    else:
+        weights = {k: 1.0 for k in per_kernel}
     total = collections.defaultdict(float)
-    for cs in per_kernel.values():
+    for k, cs in per_kernel.items():
         for c, v in cs.items():
-            total[c] += v
+            total[c] += v * weights.get(k, 0.0)
     res = dict(sorted(total.items()))
     res["_per_kernel"] = per_kernel
+    res["_weights"] = weights
     res["_invocations"] = {k: {c: len(v) for c, v in cs.items()} for k, cs in agg.items()}
     res["_config"] = config
     res["_shots"] = shots

@@ -19,7 +19,7 @@ def _oracle(prog, f, key):
 def test_tables_selected_for_c2(hip):
     prog, _ = synth.config_program("C2")
     info = hip.HipProgram(prog).info()
-    assert info["pattern_tables"] and info["pattern_max_weight"] == [4]
+    assert info["pattern_tables"] and info["pattern_max_weight"] == [5]
     assert 0 < info["pattern_table_bytes"] <= 32 << 20
     assert not hip.HipProgram(prog, pattern_tables=False).info()["pattern_tables"]
     assert not hip.HipProgram(prog, mode="faithful").info()["pattern_tables"]  # default: auto mode only
@@ -28,7 +28,7 @@ def test_tables_selected_for_c2(hip):
 
 
 @pytest.mark.parametrize("p_bit", [0.0, 0.01, 0.05, 0.2])
-@pytest.mark.parametrize("cap", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("cap", [0, 1, 2, 3, 4, 5])
 def test_c2_every_depth_matches_oracle(hip, p_bit, cap):
     prog, cfg = synth.config_program("C2")
     B = 3000

@@ -1066,6 +1066,13 @@ static int build_pattern_tables(tsim_program *p, const std::vector<long long> &n
           for (int b1 = 1; b1 < b2; ++b1)
             for (int b0 = 0; b0 < b1; ++b0)
               pats.push_back((1ull << b3) | (1ull << b2) | (1ull << b1) | (1ull << b0));
+    if (wmax >= 5)
+      for (int b4 = 4; b4 < F; ++b4)
+        for (int b3 = 3; b3 < b4; ++b3)
+          for (int b2 = 2; b2 < b3; ++b2)
+            for (int b1 = 1; b1 < b2; ++b1)
+              for (int b0 = 0; b0 < b1; ++b0)
+                pats.push_back((1ull << b4) | (1ull << b3) | (1ull << b2) | (1ull << b1) | (1ull << b0));
     if ((long long)pats.size() != npat[ci]) return fail(TSIM_ESTATE, "pattern enumeration mismatch");
     unsigned long long *d_pats = nullptr;
     HIP_TRY(hipMalloc((void **)&d_pats, pats.size() * 8));
@@ -1319,8 +1326,9 @@ retry_pack:
       for (size_t ci = 0; ci < p->comps.size(); ++ci) {
         const HostComponent &c = p->comps[ci];
         const long long F = c.F;
-        const long long cnt[5] = {1, F, F * (F - 1) / 2, F * (F - 1) * (F - 2) / 6,
-                                  F * (F - 1) * (F - 2) * (F - 3) / 24};
+        const long long cnt[6] = {1, F, F * (F - 1) / 2, F * (F - 1) * (F - 2) / 6,
+                                  F * (F - 1) * (F - 2) * (F - 3) / 24,
+                                  F * (F - 1) * (F - 2) * (F - 3) * (F - 4) / 120};
         long long npat = 0;
         int wmax = -1;
         for (int w = 0; w <= cap; ++w) {
@@ -1342,6 +1350,7 @@ retry_pack:
         r[LW_OFF2] = (uint32_t)(1 + F);
         r[LW_OFF3] = (uint32_t)(1 + F + cnt[2]);
         r[LW_OFF4] = (uint32_t)(1 + F + cnt[2] + cnt[3]);
+        r[LW_OFF5] = (uint32_t)(1 + F + cnt[2] + cnt[3] + cnt[4]);
         r[LW_NPAT] = (uint32_t)npat;
         p->lw_wmax.push_back(wmax);
         lw_npat.push_back(npat);

@@ -5,7 +5,7 @@
 // the chain rule prev <- bit ? p1 : prev - p1 - is a function of (f_sel, m_0..m_{i-1}) only.  The
 // shot index enters through the uniform draw alone.  Error bits are sparse (the regime the
 // reference's ChannelSampler is built for, noise/channels.py:624-658), so most shots of a batch
-// carry one of very few f_sel patterns: weight 0, 1, 2, 3 or 4.  For those patterns the packer
+// carry one of very few f_sel patterns: weight 0 to 5.  For those patterns the packer
 // tabulates the threshold of every node of the prefix tree once per program (k_lw_build, with the
 // SAME device arithmetic as the sampling kernels: eval_any -> cabs32 -> __fdiv_rn/__fsub_rn), and
 //
@@ -27,7 +27,7 @@ namespace tsimk {
 enum {
   LW_NOUT = 0, LW_F, LW_FSELP /* gather program f row -> x */, LW_OUTPOS, LW_KEYBASE, LW_WMAX,
   LW_TAB /* float offset into tab */, LW_OFF2 /* index of the first weight-2 pattern */, LW_OFF3, LW_NPAT,
-  LW_FSELN /* chunks of the gather program */, LW_OFF4, LW_WORDS = 16
+  LW_FSELN /* chunks of the gather program */, LW_OFF4, LW_OFF5, LW_WORDS = 16
 };
 // A gather program moves bit fields of the packed f row to a destination bit vector.  It is a
 // list of 4-word runs [ctl, mask, flip, 0], four runs per 64-byte chunk (one s_load_dwordx16; the
@@ -35,10 +35,10 @@ enum {
 //   ctl = src_shift | dst_shift << 8 | dst_word << 16 | src_word << 24
 //   dst_word[dst_shift ..] |= ((f32[src_word] >> src_shift) & mask) ^ flip
 #define TSIMK_LW_MAX_NOUT 10
-#define TSIMK_LW_MAX_WEIGHT 4
+#define TSIMK_LW_MAX_WEIGHT 5
 #define TSIMK_LW_LISTS 64   // hard-row sub-lists (one atomic counter each, 128 bytes apart)
 
-// colex rank of a pattern with sorted set-bit positions b0 < b1 < b2 < b3 (missing ones passed as 0)
+// colex rank of a pattern with sorted set-bit positions b0 < b1 < b2 < b3 < b4 (missing ones passed as 0)
 __host__ __device__ __forceinline__ uint32_t lw_binom2(uint32_t b) { return (b * (b - 1u)) >> 1; }
 __host__ __device__ __forceinline__ uint32_t lw_binom3(uint32_t b) {
   // b(b-1)(b-2)/6 for b <= 64: the product is a multiple of 6 below 2^18, and
@@ -48,6 +48,11 @@ __host__ __device__ __forceinline__ uint32_t lw_binom3(uint32_t b) {
 }
 // C(b,4) = C(b,3) (b-3) / 4, exact; 0 for b < 4 (C(b,3) = 0 below 3, the factor is 0 at 3)
 __host__ __device__ __forceinline__ uint32_t lw_binom4(uint32_t b) { return (lw_binom3(b) * (b - 3u)) >> 2; }
+// C(b,5) = C(b,4) (b-4) / 5, exact (the product stays below 2^26 for b <= 64); 0 for b < 5
+__host__ __device__ __forceinline__ uint32_t lw_binom5(uint32_t b) {
+  const unsigned long long v = (unsigned long long)lw_binom4(b) * (unsigned long long)(b - 4u);  // 0 when C(b,4) == 0
+  return (uint32_t)((v * 3435973837ull) >> 34);  // v / 5 for v < 2^32 (magic 0xCCCCCCCD)
+}
 
 // ---------------------------------------------------------------------------
 // table build: one lane per (pattern, full assignment m of the n outputs).  The lane walks the
@@ -183,15 +188,17 @@ __global__ void __launch_bounds__(1024) k_sample_lw(LwArgs L) {
       const uint32_t cnt = (uint32_t)__popcll(xf);
       if (cnt > rec[LW_WMAX]) hard = true;
       if (hard) continue;  // needs the full kernel: nothing of this row is written here
-      // colex rank of the (<= 4)-subset
-      uint32_t b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+      // colex rank of the (<= 5)-subset
+      uint32_t b0 = 0, b1 = 0, b2 = 0, b3 = 0, b4 = 0;
       if (cnt >= 1) { b0 = (uint32_t)__builtin_ctzll(xf); xf &= xf - 1ull; }
       if (cnt >= 2) { b1 = (uint32_t)__builtin_ctzll(xf); xf &= xf - 1ull; }
       if (cnt >= 3) { b2 = (uint32_t)__builtin_ctzll(xf); xf &= xf - 1ull; }
-      if (cnt >= 4) { b3 = (uint32_t)__builtin_ctzll(xf); }
-      const uint32_t base = (cnt == 0) ? 0u : (cnt == 1) ? 1u : (cnt == 2) ? rec[LW_OFF2] : (cnt == 3) ? rec[LW_OFF3] : rec[LW_OFF4];
+      if (cnt >= 4) { b3 = (uint32_t)__builtin_ctzll(xf); xf &= xf - 1ull; }
+      if (cnt >= 5) { b4 = (uint32_t)__builtin_ctzll(xf); }
+      const uint32_t base = (cnt == 0) ? 0u : (cnt == 1) ? 1u : (cnt == 2) ? rec[LW_OFF2] : (cnt == 3) ? rec[LW_OFF3]
+                          : (cnt == 4) ? rec[LW_OFF4] : rec[LW_OFF5];
       const uint32_t pat = base + b0 + (cnt >= 2 ? lw_binom2(b1) : 0u) + (cnt >= 3 ? lw_binom3(b2) : 0u) +
-                           (cnt >= 4 ? lw_binom4(b3) : 0u);
+                           (cnt >= 4 ? lw_binom4(b3) : 0u) + (cnt >= 5 ? lw_binom5(b4) : 0u);
       const uint32_t n_out = rec[LW_NOUT];
       cptr outpos = img + rec[LW_OUTPOS];
       const uint32_t keybase = rec[LW_KEYBASE];

@@ -362,7 +362,7 @@ def main() -> None:
     fence()
     # HIP events around the dominant kernel only (level 2): timing events drain the queue they are
     # recorded on, and bracketing every side-stream kernel costs ~10 us per pipelined step
-    PROF_EVERY = 8  # bracket one launch in 8: a timing event costs a queue drain (~5 us)
+    PROF_EVERY = 25  # bracket one launch in 25: a timing event costs a queue drain (~5 us; 1 in 8 cost 6 % of the rate)
     hp.profile_set_sampling(PROF_EVERY)
     hp.profile_enable(0 if os.environ.get("TSIM_BENCH_NO_PROFILE") == "1" else 2)
     hp.profile_read(reset=True)

@@ -155,6 +155,7 @@ struct tsim_program {
     hipStream_t p1_stream = nullptr;  // lane of that first pass
     hipStream_t last_done = nullptr;  // stream on which done_ev of the slot's last launch was recorded
     hipEvent_t done_ev = nullptr;     // ev2 (own second pass) or the event of the batch that served the slot
+    unsigned long long batch_seq = 0; // sequence number of that batch (0: own second pass)
     SampleArgs ctx;                   // the hard-row kernel's arguments for that launch
   };
   Slot slots[1 + TSIM_PIPELINE_SLOTS];
@@ -163,7 +164,10 @@ struct tsim_program {
   hipEvent_t lane_ev[2] = {nullptr, nullptr};  // "first passes enqueued so far on lane k are done"
   hipEvent_t batch_ev[16] = {};                // ring: one event per hard-row batch
   hipEvent_t sync_ev = nullptr;                // tsim_pipeline_wait_stream
-  unsigned batch_ring = 0;
+  unsigned long long batch_next = 1;       // sequence number of the next batch (event = batch_ev[seq % 16])
+  unsigned long long batch_confirmed = 0;  // every batch up to this one is known to be complete
+  unsigned long long lane_waited[2] = {0, 0};  // newest batch each first-pass lane already waits for
+  unsigned long long dbg_queries = 0, dbg_waits = 0, dbg_begins = 0, dbg_flushes = 0, dbg_defer = 0;
   int last_lists = 0;         // list count of the most recent two-pass launch (what the feedback refers to)
   int h_group_tiles = 0;      // k_sample4h geometry, fixed at the first two-pass launch
   size_t h_lds = 0;
@@ -181,6 +185,8 @@ struct tsim_program {
     int v4_block = 256;       // TSIM_AMD_V4_BLOCK
     int hard_lds_kb = 150;    // TSIM_AMD_HARD_LDS_KB
     bool merge_lists = true;  // TSIM_AMD_MERGE_LISTS=0: always TSIMK_LW_LISTS hard-row sub-lists
+    int list_rows = 40;       // TSIM_AMD_LIST_ROWS: expected hard rows per list the list count aims at
+    int min_lists = 4;        // TSIM_AMD_MIN_LISTS (power of two >= 2)
     bool defer = true;        // TSIM_AMD_DEFER_HARD=0: every pipelined launch runs its own second pass
     int defer_group = 4;      // TSIM_AMD_DEFER_GROUP: launches per deferred hard-row batch (<= TSIMK_H_MAX_CTX)
   } knobs;
@@ -1393,6 +1399,9 @@ retry_pack:
     p->knobs.hard_lds_kb = std::max(24, std::min(156, env_int("TSIM_AMD_HARD_LDS_KB", 150)));
     p->knobs.defer = env_int("TSIM_AMD_DEFER_HARD", 1) != 0;
     p->knobs.merge_lists = env_int("TSIM_AMD_MERGE_LISTS", 1) != 0;
+    p->knobs.list_rows = env_int("TSIM_AMD_LIST_ROWS", 40);
+    p->knobs.min_lists = env_int("TSIM_AMD_MIN_LISTS", 4);
+    if (p->knobs.min_lists & (p->knobs.min_lists - 1)) p->knobs.min_lists = 4;
     p->knobs.defer_group = std::max(1, std::min(TSIMK_H_MAX_CTX, env_int("TSIM_AMD_DEFER_GROUP", 4)));
   }
 
@@ -1420,6 +1429,9 @@ extern "C" void tsim_program_destroy(tsim_program *p) {
     (void)hipSetDevice(p->device);
     if (p->stream) (void)hipStreamSynchronize(p->stream);
     for (hipEvent_t e : p->ev_pool) (void)hipEventDestroy(e);
+    if (getenv("TSIM_AMD_PIPELINE_STATS"))
+      fprintf(stderr, "tsim pipeline: begins %llu deferred %llu flushes %llu queries %llu waits %llu\n", p->dbg_begins,
+              p->dbg_defer, p->dbg_flushes, p->dbg_queries, p->dbg_waits);
     if (p->sync_ev) (void)hipEventDestroy(p->sync_ev);
     for (hipEvent_t e : p->lane_ev) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : p->batch_ev) if (e) (void)hipEventDestroy(e);
@@ -1598,8 +1610,9 @@ static LaunchPlan make_plan(tsim_program *p, bool has_row_index, bool pipelined)
     if (known && fb_max <= 192u) pl.need_overflow = false;
     pl.fb_max = known ? fb_max : 0xFFFFFFFFu;
     if (known && p->knobs.merge_lists) {
-      const uint32_t want = (fb_sum + 39u) / 40u;
-      pl.lists = 4;
+      const uint32_t per = (uint32_t)std::max(8, p->knobs.list_rows);
+      const uint32_t want = (fb_sum + per - 1u) / per;
+      pl.lists = std::max(2, std::min(TSIMK_LW_LISTS, p->knobs.min_lists));
       while ((uint32_t)pl.lists < want && pl.lists < TSIMK_LW_LISTS) pl.lists <<= 1;
       // the longest list of the last launch was measured with ITS list count: rescale the overflow test
       const uint32_t last = p->last_lists > 0 ? (uint32_t)p->last_lists : (uint32_t)TSIMK_LW_LISTS;
@@ -1670,14 +1683,21 @@ static int flush_hard(tsim_program *p) {
   }
   HIP_TRY(hipGetLastError());
   p->hm_attr_set = true;
-  hipEvent_t &be = p->batch_ev[p->batch_ring++ % 16u];
+  ++p->dbg_flushes;
+  const unsigned long long seq = p->batch_next++;
+  hipEvent_t &be = p->batch_ev[seq % 16u];
   if (!be) HIP_TRY(hipEventCreateWithFlags(&be, hipEventDisableTiming));
+  if (seq > 16u && p->batch_confirmed < seq - 16u) {  // the ring slot's previous batch: 16 batches ago, long done
+    HIP_TRY(hipEventSynchronize(be));
+    p->batch_confirmed = seq - 16u;
+  }
   HIP_TRY(hipEventRecord(be, hs));
   for (int i = 0; i < M.n_ctx; ++i) {
     tsim_program::Slot &d = p->slots[p->deferred[i]];
     d.deferred = false;
     d.last_done = hs;
     d.done_ev = be;
+    d.batch_seq = seq;
   }
   p->deferred.clear();
   return 0;
@@ -1762,6 +1782,7 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
       sl.pending = true;
       sl.last_done = s;
       sl.done_ev = sl.ev2;
+      sl.batch_seq = 0;
     }
     return 0;
   };
@@ -1828,7 +1849,6 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
     const size_t tile_bytes = std::max((size_t)p->v4_max_nch * 16, (size_t)p->v4_max_sent) * p->v4_gt * 16;
     const size_t lds4 = (size_t)(2 * a.WF + 2 * a.WO) * blk * 4 + 2 * tile_bytes;
     if (lds4 > 64 * 1024) return fail(TSIM_ENOTSUP, "v4 kernel needs %zu B of LDS", lds4);
-    if (a.row_lists > 1 && getenv("TSIM_DBG_SKIP_HARD")) return finish();
     if (a.row_lists > 1 && p->knobs.hard_kernel) {
       // short row lists (second pass of a two-pass launch): NW waves per 64 rows, tsim_kernel4h.hip.h
       constexpr int NW = TSIM_HARD_NW;
@@ -1940,11 +1960,24 @@ extern "C" int tsim_sample_batch_device_begin(tsim_program *p, int32_t slot, con
   // the slot's previous launch (its lists, counters and output rows are reused): usually long finished -
   // ask the event first, a stream wait costs queue time even when it has nothing to wait for
   if (sl.last_done && sl.last_done != s && sl.done_ev) {
-    if (hipEventQuery(sl.done_ev) != hipSuccess) {
-      (void)hipGetLastError();
-      HIP_TRY(hipStreamWaitEvent(s, sl.done_ev, 0));
+    bool done = false;
+    if (sl.batch_seq) {
+      // Batches complete in order (one stream) and a lane is in order too: once a lane waits for batch b it
+      // is behind every batch <= b.  The four slots of a batch alternate over the two lanes, so this is
+      // one stream wait per lane and batch - no event query (the host usually runs several batches ahead
+      // of the GPU, the query would fail and cost as much as the wait).
+      const int lane = (s == p->slots[1].side) ? 0 : (s == p->slots[2].side) ? 1 : -1;
+      if (sl.batch_seq <= p->batch_confirmed || (lane >= 0 && sl.batch_seq <= p->lane_waited[lane])) done = true;
+      else if (lane >= 0) p->lane_waited[lane] = sl.batch_seq;
+    } else {
+      ++p->dbg_queries;
+      done = hipEventQuery(sl.done_ev) == hipSuccess;
+      if (!done) (void)hipGetLastError();
     }
+    if (!done) { ++p->dbg_waits; HIP_TRY(hipStreamWaitEvent(s, sl.done_ev, 0)); }
   }
+  ++p->dbg_begins;
+  if (plan.defer) ++p->dbg_defer;
   if (!(flags & TSIM_PIPE_INPUTS_READY) && s_user != s) {
     HIP_TRY(hipEventRecord(sl.ev1, s_user));
     HIP_TRY(hipStreamWaitEvent(s, sl.ev1, 0));
@@ -2011,6 +2044,7 @@ extern "C" int tsim_sample_batch_device_compact(tsim_program *p, int32_t slot, c
   if (sl.pending) {
     HIP_TRY(hipEventRecord(sl.ev2, s));
     sl.done_ev = sl.ev2;
+    sl.batch_seq = 0;
   }
   return TSIM_OK;
 }

@@ -28,7 +28,9 @@ def main():
     out, config, shots, dirs = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4:]
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for d in dirs:
-        for fn in glob.glob(f"{d}/*/*_counter_collection.csv"):
+        import os
+        files = sorted(glob.glob(f"{d}/*/*_counter_collection.csv"), key=os.path.getmtime)
+        for fn in files[-1:]:  # a re-used output directory keeps older runs: only the newest counts
             for r in csv.DictReader(open(fn)):
                 if "k_sample" in r["Kernel_Name"]:
                     agg[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))

@@ -244,7 +244,7 @@ def main() -> None:
     # slots - not of lanes - covers the batch latency (3 slots: 46 us per step, 6: 33 us, 8: 22-23 us, 12: 21 us).
     default_slots = 12
     NSLOT = max(1, min(backend.HipProgram.PIPELINE_SLOTS, int(os.environ.get("TSIM_BENCH_SLOTS", str(default_slots)))))
-    GATHER_EVERY = max(1, int(os.environ.get("TSIM_BENCH_GATHER_EVERY", "32")))
+    GATHER_EVERY = max(1, int(os.environ.get("TSIM_BENCH_GATHER_EVERY", "64")))
     if use_dist:
         dev = torch.device("cuda", local_rank)
         # the gathers are queued on the lane where the hard-row batches run (results complete there): the
@@ -255,6 +255,7 @@ def main() -> None:
             raise RuntimeError("tsim_pipeline_lane_stream failed")
         join_ptr = int(_sp.value)
         ext = torch.cuda.ExternalStream(join_ptr, device=dev)
+        ext_main = torch.cuda.ExternalStream(hp.stream_ptr(), device=dev)  # first-pass lane 0
         out_bufs = [torch.zeros((B, WO * 8), dtype=torch.uint8, device=dev) for _ in range(NSLOT)]
         out_ptrs = [t.data_ptr() for t in out_bufs]
         RB = (n_out + 7) // 8
@@ -262,7 +263,7 @@ def main() -> None:
         grp_lists = [[torch.empty_like(grp_bufs[0]) for _ in range(N)] if rank == 0 else None for _ in range(2)]
         grp_ptrs = [t.data_ptr() for t in grp_bufs]
         grp_pending = [None, None]  # gather handle of the group buffer's previous use
-        compact_fn = hp._lib.tsim_pipeline_set_compact_output
+        series_fn = hp._lib.tsim_pipeline_set_compact_series
         wait_fn = hp._lib.tsim_pipeline_wait_stream
     else:
         d_outs = [hp.malloc(B * WO * 8) for _ in range(NSLOT)]
@@ -310,8 +311,12 @@ def main() -> None:
             return
         g, pos = (j // GATHER_EVERY) & 1, j % GATHER_EVERY
         if pos == 0 and grp_pending[g] is not None:
-            with torch.cuda.stream(ext):
-                grp_pending[g].wait()  # the engine's stream waits until the previous gather released the buffer
+            # the gather that last read this group buffer (two groups ago, long finished) must be done before
+            # the kernels overwrite it: first-pass lane 0 (the handle's stream) waits for it, the other lanes
+            # are ordered after lane 0 below.  (Waiting on the batch lane instead would park the dependency
+            # behind every queued hard-row batch and drain the pipeline once per group.)
+            with torch.cuda.stream(ext_main):
+                grp_pending[g].wait()
             grp_pending[g] = None
         # At the start of a group every lane waits ONCE for the engine's stream, i.e. for the gather that
         # last read this group buffer (tsim_pipeline_wait_stream); the launches themselves then need no
@@ -319,9 +324,9 @@ def main() -> None:
         # layout, into the group buffer.
         rc = 0
         if pos == 0 or j < NSLOT:  # (the first launches create the lanes)
-            rc = wait_fn(hp._h, join_ptr)
-        if rc >= 0:
-            rc = compact_fn(hp._h, b, grp_ptrs[g] + pos * B * RB)  # this launch also writes bit_packed rows there
+            rc = wait_fn(hp._h, None)
+        if rc >= 0 and pos == 0:  # the launches of this group also write bit_packed rows, one slice each
+            rc = series_fn(hp._h, grp_ptrs[g], B * RB, GATHER_EVERY)
         if rc >= 0:
             rc = begin_fn(hp._h, b, d_f_ptr, B, num_f, sub[0], sub[1], shot_offset, out_ptrs[b], None, None,
                           0 if j < NSLOT else 1)

@@ -222,6 +222,10 @@ int tsim_pipeline_lane_stream(tsim_program *p, int32_t lane, void **stream);
  * reference's bit_packed layout, sampler.py:665-669) straight from the sampling kernels - no separate
  * compaction kernel.  One-shot: cleared by that launch. */
 int tsim_pipeline_set_compact_output(tsim_program *p, int32_t slot, uint8_t *d_compact);
+/* The same for a run of launches: the next `count` pipelined launches (any slot, in call order) write
+ * their bit_packed rows to d_base, d_base + stride_bytes, ... - one call per gather group instead of one
+ * per launch.  A per-slot buffer set with tsim_pipeline_set_compact_output takes precedence. */
+int tsim_pipeline_set_compact_series(tsim_program *p, uint8_t *d_base, int64_t stride_bytes, int32_t count);
 /* Between _begin and _end of `slot`: tsim_compact_rows_device of the launch's output rows, enqueued
  * on the slot's lane behind the launch; _end then also covers d_out. */
 int tsim_sample_batch_device_compact(tsim_program *p, int32_t slot, const uint64_t *d_rows, int64_t B,

@@ -343,3 +343,35 @@ def test_join_on_the_batch_lane_and_wait_stream(hip):
         got = np.zeros((B, wo * 8), np.uint8)
         hp.d2h(got, d_o[i])
         np.testing.assert_array_equal(got, ref.sample_batch(fs[i], keys[i], bit_packed=True)[0], err_msg=f"launch {i}")
+
+
+def test_compact_series_one_slice_per_launch(hip):
+    """tsim_pipeline_set_compact_series: the next `count` pipelined launches write their bit_packed rows
+    into consecutive slices of one buffer (what bench.py gathers), later launches do not."""
+    import ctypes as C
+
+    prog, cfg = synth.config_program("C2")
+    hp = hip.HipProgram(prog)
+    nf, B, n = cfg["num_f"], 7001, 6
+    wf, wo, rb = (nf + 63) // 64, (prog.num_outputs + 63) // 64, (prog.num_outputs + 7) // 8
+    fs = [synth.synth_f(B, nf, 0.02, seed=60 + i) for i in range(n)]
+    keys = [prng.key(70 + i) for i in range(n)]
+    d_f = [hp.malloc(B * wf * 8) for _ in range(n)]
+    d_o = [hp.malloc(B * wo * 8) for _ in range(n)]
+    d_c = hp.malloc(n * B * rb + 16)
+    hp.h2d(d_c, np.full(n * B * rb + 16, 0xEE, np.uint8))
+    for d, f in zip(d_f, fs):
+        packed = np.packbits(f, axis=1, bitorder="little")
+        hp.h2d(d, np.ascontiguousarray(np.pad(packed, ((0, 0), (0, wf * 8 - packed.shape[1])))))
+    assert hp._lib.tsim_pipeline_set_compact_series(hp._h, C.c_void_p(d_c.ptr), B * rb, n - 1) == 0
+    for i in range(n):
+        hp.sample_batch_device_begin(i % 4, d_f[i].ptr, B, nf, keys[i], d_o[i].ptr)
+    for s in range(4):
+        hp.sample_batch_device_end(s)
+    hp.synchronize()
+    got = np.zeros(n * B * rb + 16, np.uint8)
+    hp.d2h(got, d_c)
+    for i in range(n - 1):
+        want = hp.sample_batch(fs[i], keys[i])[0]
+        np.testing.assert_array_equal(got[i * B * rb:(i + 1) * B * rb].reshape(B, rb), np.packbits(want, axis=1, bitorder="little"))
+    assert (got[(n - 1) * B * rb:] == 0xEE).all()  # the series had n - 1 entries

@@ -76,6 +76,7 @@ SYMBOLS: dict[str, tuple] = {
     "tsim_pipeline_lane_stream": (C.c_int, [_P, _I32, C.POINTER(C.c_void_p)]),
     "tsim_sample_batch_device_compact": (C.c_int, [_P, _I32, _P, _I64, _I32, _P, _P]),
     "tsim_pipeline_set_compact_output": (C.c_int, [_P, _I32, _P]),
+    "tsim_pipeline_set_compact_series": (C.c_int, [_P, _P, _I64, _I32]),
     "tsim_postselect_device": (C.c_int, [_P, _P, _I64, _I32, _P, _P, _P, _P, _P, _P, _P]),
     "tsim_sample_rows_device": (C.c_int, [_P, _P, _I64, _I32, _U32, _U32, _I64, _P, _P, _P, _P, _P]),
     "tsim_evaluate": (C.c_int, [_P, _I32, _I32, _P, _I64, _P, _P, _P, _P]),

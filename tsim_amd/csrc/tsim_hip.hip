@@ -164,6 +164,9 @@ struct tsim_program {
   hipEvent_t lane_ev[2] = {nullptr, nullptr};  // "first passes enqueued so far on lane k are done"
   hipEvent_t batch_ev[16] = {};                // ring: one event per hard-row batch
   hipEvent_t sync_ev = nullptr;                // tsim_pipeline_wait_stream
+  uint8_t *series_ptr = nullptr;               // tsim_pipeline_set_compact_series
+  int64_t series_stride = 0;
+  int series_left = 0;
   unsigned long long batch_next = 1;       // sequence number of the next batch (event = batch_ev[seq % 16])
   unsigned long long batch_confirmed = 0;  // every batch up to this one is known to be complete
   unsigned long long lane_waited[2] = {0, 0};  // newest batch each first-pass lane already waits for
@@ -1765,6 +1768,11 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
     a.out_compact = sl.compact_out;
     a.out_rb = (p->num_outputs + 7) / 8;
     sl.compact_out = nullptr;
+  } else if (slot > 0 && p->series_left > 0) {  // tsim_pipeline_set_compact_series: next buffer of the series
+    a.out_compact = p->series_ptr;
+    a.out_rb = (p->num_outputs + 7) / 8;
+    p->series_ptr += p->series_stride;
+    --p->series_left;
   }
   a.check_row = nullptr;
   a.no_check = 0;
@@ -2012,6 +2020,15 @@ extern "C" int tsim_pipeline_wait_stream(tsim_program *p, void *stream) {
     seen.push_back(sl.side);
     HIP_TRY(hipStreamWaitEvent(sl.side, p->sync_ev, 0));
   }
+  return TSIM_OK;
+}
+
+extern "C" int tsim_pipeline_set_compact_series(tsim_program *p, uint8_t *d_base, int64_t stride_bytes, int32_t count) {
+  if (int r = need_final(p)) return r;
+  if (count < 0 || stride_bytes < 0 || (count > 0 && !d_base)) return fail(TSIM_EINVAL, "bad compact series");
+  p->series_ptr = d_base;
+  p->series_stride = stride_bytes;
+  p->series_left = count;
   return TSIM_OK;
 }
 

@@ -375,3 +375,33 @@ def test_compact_series_one_slice_per_launch(hip):
         want = hp.sample_batch(fs[i], keys[i])[0]
         np.testing.assert_array_equal(got[i * B * rb:(i + 1) * B * rb].reshape(B, rb), np.packbits(want, axis=1, bitorder="little"))
     assert (got[(n - 1) * B * rb:] == 0xEE).all()  # the series had n - 1 entries
+
+
+def test_destroy_with_parked_hard_rows_and_mixed_serial_calls(hip):
+    """Handles dropped while launches are parked (never joined), and the serial API used between
+    pipelined launches of the same handle."""
+    prog, cfg = synth.config_program("C2")
+    ref = hip.HipProgram(prog, pattern_tables=False)
+    nf, B = cfg["num_f"], 9001
+    wf, wo = (nf + 63) // 64, (prog.num_outputs + 63) // 64
+    f = synth.synth_f(B, nf, 0.02, seed=5)
+    packed = np.packbits(f, axis=1, bitorder="little")
+    packed = np.ascontiguousarray(np.pad(packed, ((0, 0), (0, wf * 8 - packed.shape[1]))))
+    for round_ in range(3):
+        hp = hip.HipProgram(prog)
+        d_f, outs = hp.malloc(B * wf * 8), [hp.malloc(B * wo * 8) for _ in range(7)]
+        hp.h2d(d_f, packed)
+        for i in range(6):  # warm the plan, join properly
+            hp.sample_batch_device_begin(i % 3, d_f.ptr, B, nf, prng.key(i), outs[i].ptr)
+        for s in range(3):
+            hp.sample_batch_device_end(s)
+        serial = hp.sample_batch(f, prng.key(99))[0]           # serial call in between
+        np.testing.assert_array_equal(serial, ref.sample_batch(f, prng.key(99))[0])
+        for i in range(5):  # parked: no end, no synchronize
+            hp.sample_batch_device_begin(i, d_f.ptr, B, nf, prng.key(10 + i), outs[i].ptr)
+        if round_ == 1:
+            hp.synchronize()
+            got = np.zeros((B, wo * 8), np.uint8)
+            hp.d2h(got, outs[4])
+            np.testing.assert_array_equal(got, ref.sample_batch(f, prng.key(14), bit_packed=True)[0])
+        del hp, d_f, outs

@@ -1426,11 +1426,16 @@ retry_pack:
   return TSIM_OK;
 }
 
+static int flush_hard(tsim_program *p);
+
 extern "C" void tsim_program_destroy(tsim_program *p) {
   if (!p) return;
   if (p->finalized && p->device >= 0) {
     (void)hipSetDevice(p->device);
+    (void)flush_hard(p);  // parked hard rows of launches that were never joined: finish them, then drain every lane
     if (p->stream) (void)hipStreamSynchronize(p->stream);
+    for (auto &sl : p->slots)
+      if (sl.side_ready) (void)hipStreamSynchronize(sl.side);
     for (hipEvent_t e : p->ev_pool) (void)hipEventDestroy(e);
     if (getenv("TSIM_AMD_PIPELINE_STATS"))
       fprintf(stderr, "tsim pipeline: begins %llu deferred %llu flushes %llu queries %llu waits %llu\n", p->dbg_begins,
@@ -1445,7 +1450,6 @@ extern "C" void tsim_program_destroy(tsim_program *p) {
     if (p->d_lw_tab) (void)hipFree(p->d_lw_tab);
     if (p->h_feedback) (void)hipHostFree((void *)p->h_feedback);
     for (auto &sl : p->slots) {
-      if (sl.side_ready) (void)hipStreamSynchronize(sl.side);
       if (sl.ctl) (void)hipFree(sl.ctl);
       if (sl.hard) (void)hipFree(sl.hard);
       if (sl.keys) (void)hipFree(sl.keys);

@@ -238,11 +238,11 @@ def main() -> None:
     # so that it overlaps the kernels of the next group.
     # Hardware queues: the handle's own stream plus two more sit on three distinct ones; more than 4 busy
     # hardware queues is pathological on this stack (3x slower with GPU_MAX_HW_QUEUES=5 / 8), so lanes +
-    # RCCL's stream stay <= 4.  Slots: 12.  With short hard-row lists the library runs the first passes of
+    # RCCL's stream stay <= 4.  Slots: 16 (two batches of up to 8 launches in flight).  With short hard-row lists the library runs the first passes of
     # consecutive launches on two of the lanes and the hard rows of four launches at a time as ONE grid on
     # the third (deferred second pass); a slot is reused only after its batch is done, so the number of
     # slots - not of lanes - covers the batch latency (3 slots: 46 us per step, 6: 33 us, 8: 22-23 us, 12: 21 us).
-    default_slots = 12
+    default_slots = 16
     NSLOT = max(1, min(backend.HipProgram.PIPELINE_SLOTS, int(os.environ.get("TSIM_BENCH_SLOTS", str(default_slots)))))
     GATHER_EVERY = max(1, int(os.environ.get("TSIM_BENCH_GATHER_EVERY", "64")))
     if use_dist:

@@ -121,7 +121,7 @@ int tsim_program_get_mode(const tsim_program *p, int32_t *fast);
  * Low-weight error-pattern tables (before finalize).  The Bernoulli thresholds p1/prev of
  * _sample_component (sampler.py:54-79) depend on a shot only through the component's selected
  * f bits and the outcome prefix; for f_sel patterns of weight <= max_weight (0..5, as many as fit a
- * 32 MiB table per component; TSIM_AMD_PATTERN_TABLE_MB overrides) they are tabulated at finalize by the sampling kernels' own
+ * 256 MiB table per component; TSIM_AMD_PATTERN_TABLE_MB overrides) they are tabulated at finalize by the sampling kernels' own
  * arithmetic, and shots carrying such patterns in every component are finished by a light first
  * pass (one Threefry draw + one table read per output); only the remaining rows run the full
  * kernel.  Bit-identical results.  Requires <= 10 outputs and <= 64 parameters per component.
@@ -193,7 +193,8 @@ int tsim_sample_batch_device(tsim_program *p, const uint64_t *d_f, int64_t B, in
  *
  * Deferred second pass.  When recent launches left few hard rows (the launch-plan feedback: longest
  * list <= 192), _begin only enqueues the FIRST pass, alternating between the lanes of slots 0 and 1,
- * and keeps the launch's hard rows for a batch: every TSIM_AMD_DEFER_GROUP (default 4) launches - or
+ * and keeps the launch's hard rows for a batch: every TSIM_AMD_DEFER_GROUP (default 4; 8 for programs with
+ * more than 4 MB of chunk tables, whose hard-row pass is long) launches - or
  * when _end / _begin / tsim_synchronize needs a slot whose rows are still waiting - ONE grid
  * (k_sample4h_multi) serves the hard rows of all waiting launches on the lane of slot 2, after their
  * first passes.  No lane then waits for a second pass before its next first pass; a slot's next

@@ -20,7 +20,7 @@ def test_tables_selected_for_c2(hip):
     prog, _ = synth.config_program("C2")
     info = hip.HipProgram(prog).info()
     assert info["pattern_tables"] and info["pattern_max_weight"] == [5]
-    assert 0 < info["pattern_table_bytes"] <= 32 << 20
+    assert 0 < info["pattern_table_bytes"] <= 256 << 20
     assert not hip.HipProgram(prog, pattern_tables=False).info()["pattern_tables"]
     assert not hip.HipProgram(prog, mode="faithful").info()["pattern_tables"]  # default: auto mode only
     assert hip.HipProgram(prog, mode="faithful", pattern_tables=True).info()["pattern_tables"]

@@ -1326,7 +1326,7 @@ retry_pack:
       const int cap = p->lw_weight_cap < 0 ? TSIMK_LW_MAX_WEIGHT : std::min(p->lw_weight_cap, TSIMK_LW_MAX_WEIGHT);
       // bytes per component.  Patterns are stored weight by weight, so the rows most shots read (weight
       // 0..2) are a small cache-resident prefix whatever the total; the heavier tail is read rarely
-      long long budget = 32ll << 20;
+      long long budget = 256ll << 20;
       if (const char *e = getenv("TSIM_AMD_PATTERN_TABLE_MB")) budget = std::max(1ll, atoll(e)) << 20;
       while (img.size() % 16) img.push_back(0u);
       p->lw_off = (int)img.size();
@@ -1341,7 +1341,8 @@ retry_pack:
         long long npat = 0;
         int wmax = -1;
         for (int w = 0; w <= cap; ++w) {
-          if (((npat + cnt[w]) << c.n_out) * 4 > budget) break;
+          const long long bytes = ((npat + cnt[w]) << c.n_out) * 4;
+          if (bytes > budget || (w > 1 && tab_off * 4 + bytes > 4 * budget)) break;  // per component / all together
           npat += cnt[w];
           wmax = w;
         }
@@ -1405,7 +1406,12 @@ retry_pack:
     p->knobs.list_rows = env_int("TSIM_AMD_LIST_ROWS", 40);
     p->knobs.min_lists = env_int("TSIM_AMD_MIN_LISTS", 4);
     if (p->knobs.min_lists & (p->knobs.min_lists - 1)) p->knobs.min_lists = 4;
-    p->knobs.defer_group = std::max(1, std::min(TSIMK_H_MAX_CTX, env_int("TSIM_AMD_DEFER_GROUP", 4)));
+    // launches per deferred batch: a batch lasts about as long as ONE hard-row pass (its blocks run side by
+    // side), and batches are serial on their lane - so the batch must cover at least (pass time / step time)
+    // launches.  The pass time grows with the chunk tables a 64-row block streams through LDS (C2: 1.7 MB,
+    // 35-50 us; C4: 10.8 MB, 450 us): 4 launches for small programs, 8 (the kernel's limit) beyond 4 MB.
+    p->knobs.defer_group = p->stats[5] > (4ll << 20) ? TSIMK_H_MAX_CTX : 4;
+    p->knobs.defer_group = std::max(1, std::min(TSIMK_H_MAX_CTX, env_int("TSIM_AMD_DEFER_GROUP", p->knobs.defer_group)));
   }
 
   // ---- upload ----

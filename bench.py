@@ -244,7 +244,20 @@ def main() -> None:
     # slots - not of lanes - covers the batch latency (3 slots: 46 us per step, 6: 33 us, 8: 22-23 us, 12: 21 us).
     default_slots = 16
     NSLOT = max(1, min(backend.HipProgram.PIPELINE_SLOTS, int(os.environ.get("TSIM_BENCH_SLOTS", str(default_slots)))))
+    # batches per collective: a torch.distributed call costs ~0.15 ms of host time, several steps' worth -
+    # smaller groups for short runs were measured and are worse (20 steps: 63 us per step with groups of 5,
+    # 36 us with one collective at the end)
     GATHER_EVERY = max(1, int(os.environ.get("TSIM_BENCH_GATHER_EVERY", "64")))
+    # How the bit-packed rows are collected (N > 1).  "alltoall" (default): every group of GATHER_EVERY
+    # batches is split by batch index into N chunks and chunk j of every rank is assembled on rank j with ONE
+    # RCCL all-to-all - a gather whose roots are spread over the node.  xGMI is a full mesh of point-to-point
+    # links (~77 GB/s per direction and pair): at 4e10 shots/s a rank produces 120 GB/s of rows, and a gather
+    # to rank 0 would push all of it through the single link to rank 0 (and everything through rank 0's one
+    # PCIe link afterwards); the all-to-all puts 1/N of it on each of the N-1 links and leaves complete batches
+    # on every rank, next to all 8 PCIe links.  "root0": the classic gather to rank 0, for comparison.
+    GATHER_MODE = os.environ.get("TSIM_BENCH_GATHER", "alltoall")
+    if GATHER_MODE == "alltoall":
+        GATHER_EVERY = (GATHER_EVERY + N - 1) // N * N
     if use_dist:
         dev = torch.device("cuda", local_rank)
         # the gathers are queued on the lane where the hard-row batches run (results complete there): the
@@ -260,7 +273,11 @@ def main() -> None:
         out_ptrs = [t.data_ptr() for t in out_bufs]
         RB = (n_out + 7) // 8
         grp_bufs = [torch.zeros((GATHER_EVERY, B, RB), dtype=torch.uint8, device=dev) for _ in range(2)]
-        grp_lists = [[torch.empty_like(grp_bufs[0]) for _ in range(N)] if rank == 0 else None for _ in range(2)]
+        if GATHER_MODE == "alltoall":
+            grp_recv = [torch.empty_like(grp_bufs[0]) for _ in range(2)]  # [N chunks of GATHER_EVERY/N batches, B, RB]
+            grp_lists = [None, None]
+        else:
+            grp_lists = [[torch.empty_like(grp_bufs[0]) for _ in range(N)] if rank == 0 else None for _ in range(2)]
         grp_ptrs = [t.data_ptr() for t in grp_bufs]
         grp_pending = [None, None]  # gather handle of the group buffer's previous use
         series_fn = hp._lib.tsim_pipeline_set_compact_series
@@ -288,10 +305,14 @@ def main() -> None:
         count = GATHER_EVERY if count is None else count
         src = grp_bufs[g] if count == GATHER_EVERY else grp_bufs[g][:count]
         dst = None
-        if rank == 0:
+        if rank == 0 and GATHER_MODE != "alltoall":
             dst = grp_lists[g] if count == GATHER_EVERY else [t[:count] for t in grp_lists[g]]
         with torch.cuda.stream(ext):
-            grp_pending[g] = dist.gather(src, dst, dst=0, async_op=True)
+            if GATHER_MODE == "alltoall":  # equal chunks: a partial last group is rounded up to a multiple of N batches
+                cnt = (count + N - 1) // N * N
+                grp_pending[g] = dist.all_to_all_single(grp_recv[g][:cnt], grp_bufs[g][:cnt], async_op=True)
+            else:
+                grp_pending[g] = dist.gather(src, dst, dst=0, async_op=True)
         gathered[0] = k + 1
 
     def step():
@@ -493,7 +514,9 @@ def main() -> None:
                 f"num_f={num_f}, p_bit={cfg['p_bit']}",
                 "shots_per_step_per_gpu": B,
                 "global_batch": B * N,
-                "sharding": f"shots x{N}, RCCL gather of the bit-packed rows ({(n_out + 7) // 8} B/shot)" if N > 1 else "single GPU",
+                "sharding": (f"shots x{N}, bit-packed rows ({(n_out + 7) // 8} B/shot) collected every {GATHER_EVERY} batches by "
+                             + ("one RCCL all-to-all (batch j of all ranks assembled on rank j mod N)" if GATHER_MODE == "alltoall"
+                                else "an RCCL gather to rank 0")) if use_dist else "single GPU",
                 "f_resident_in_hbm": True,
             },
             "roofline": {

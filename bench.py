@@ -315,16 +315,20 @@ def main() -> None:
                 grp_pending[g] = dist.gather(src, dst, dst=0, async_op=True)
         gathered[0] = k + 1
 
+    import ctypes as _ct
+    key_state = (_ct.c_uint32 * 2)(key[0] & 0xFFFFFFFF, key[1] & 0xFFFFFFFF)  # split in place by the library
+    begin_split = hp._lib.tsim_sample_batch_device_begin_split
+    h_prog = hp._h
+
     def step():
-        nonlocal key
-        key, sub = hp.split_key(key)  # one host split per batch (sampler.py:399)
+        # one host split per batch, key, subkey = split(key) (sampler.py:399), inside the launch call
         j = step_no[0]
         b = j % NSLOT
-        step_no[0] += 1
+        step_no[0] = j + 1
         if not use_dist:
             # _begin on a slot whose previous step was not joined is ordered after that step's second
             # pass by the library (include/tsim_hip.h), so one call per step is enough here
-            rc = begin_fn(hp._h, b, d_f_ptr, B, num_f, sub[0], sub[1], shot_offset, out_ptrs[b], None, None, 1)  # inputs ready
+            rc = begin_split(h_prog, b, d_f_ptr, B, num_f, key_state, shot_offset, out_ptrs[b], None, None, 1)  # inputs ready
             if rc < 0:
                 raise RuntimeError(f"tsim_sample_batch_device_begin failed ({rc})")
             if not inflight or len(inflight) < NSLOT:
@@ -349,8 +353,8 @@ def main() -> None:
         if rc >= 0 and pos == 0:  # the launches of this group also write bit_packed rows, one slice each
             rc = series_fn(hp._h, grp_ptrs[g], B * RB, GATHER_EVERY)
         if rc >= 0:
-            rc = begin_fn(hp._h, b, d_f_ptr, B, num_f, sub[0], sub[1], shot_offset, out_ptrs[b], None, None,
-                          0 if j < NSLOT else 1)
+            rc = begin_split(h_prog, b, d_f_ptr, B, num_f, key_state, shot_offset, out_ptrs[b], None, None,
+                             0 if j < NSLOT else 1)
         if rc < 0:
             raise RuntimeError(f"pipelined launch failed ({rc})")
         if pos == GATHER_EVERY - 1:  # group complete: join every lane on the engine's stream, then gather

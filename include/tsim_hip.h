@@ -310,6 +310,12 @@ int tsim_get_stream(tsim_program *p, void **stream);
 /* Host helper, no device involved: `new_key, subkey = jax.random.split(key)` for the threefry2x32
  * key layout (the once-per-batch split of sampler.py:399); out = {new_hi, new_lo, sub_hi, sub_lo}. */
 void tsim_key_split(uint32_t key_hi, uint32_t key_lo, uint32_t out[4]);
+/* The per-batch idiom of the reference's sample loop in one call (sampler.py:399-401):
+ * `key, subkey = split(key)` then tsim_sample_batch_device_begin with `subkey`; key = {hi, lo} is
+ * updated in place.  Saves a foreign-function round trip per batch for Python hosts. */
+int tsim_sample_batch_device_begin_split(tsim_program *p, int32_t slot, const uint64_t *d_f, int64_t B,
+                                         int32_t num_f, uint32_t key[2], int64_t shot_offset, uint64_t *d_out,
+                                         float *d_max_norm_dev, void *stream, uint32_t flags);
 
 /* HIP-event timing of the sampling kernel launches on the handle's stream.
  * on = 1: every kernel of a launch; on = 2: only the first kernel of a launch (the pattern-table

@@ -405,3 +405,30 @@ def test_destroy_with_parked_hard_rows_and_mixed_serial_calls(hip):
             hp.d2h(got, outs[4])
             np.testing.assert_array_equal(got, ref.sample_batch(f, prng.key(14), bit_packed=True)[0])
         del hp, d_f, outs
+
+
+def test_begin_split_is_split_then_begin(hip):
+    """tsim_sample_batch_device_begin_split: key, subkey = split(key) inside the call (sampler.py:399)."""
+    import ctypes as C
+
+    prog, cfg = synth.config_program("C2")
+    hp = hip.HipProgram(prog)
+    nf, B = cfg["num_f"], 6007
+    wf, wo = (nf + 63) // 64, (prog.num_outputs + 63) // 64
+    f = synth.synth_f(B, nf, 0.02, seed=3)
+    packed = np.packbits(f, axis=1, bitorder="little")
+    d_f, d_o = hp.malloc(B * wf * 8), [hp.malloc(B * wo * 8) for _ in range(3)]
+    hp.h2d(d_f, np.ascontiguousarray(np.pad(packed, ((0, 0), (0, wf * 8 - packed.shape[1])))))
+    key = prng.key(2024)
+    state = (C.c_uint32 * 2)(key[0], key[1])
+    for i in range(3):
+        assert hp._lib.tsim_sample_batch_device_begin_split(hp._h, i, d_f.ptr, B, nf, state, 0, d_o[i].ptr, None, None, 0) == 0
+    for i in range(3):
+        hp.sample_batch_device_end(i)
+    hp.synchronize()
+    for i in range(3):
+        key, sub = prng.split(key)
+        got = np.zeros((B, wo * 8), np.uint8)
+        hp.d2h(got, d_o[i])
+        np.testing.assert_array_equal(got, hp.sample_batch(f, sub, bit_packed=True)[0], err_msg=f"batch {i}")
+    assert (state[0], state[1]) == (key[0], key[1])

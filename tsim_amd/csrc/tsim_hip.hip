@@ -2502,6 +2502,18 @@ extern "C" void tsim_key_split(uint32_t key_hi, uint32_t key_lo, uint32_t out[4]
   out[0] = a0; out[1] = a1; out[2] = b0; out[3] = b1;
 }
 
+extern "C" int tsim_sample_batch_device_begin_split(tsim_program *p, int32_t slot, const uint64_t *d_f, int64_t B,
+                                                    int32_t num_f, uint32_t key[2], int64_t shot_offset, uint64_t *d_out,
+                                                    float *d_max_norm_dev, void *stream, uint32_t flags) {
+  if (!key) return fail(TSIM_EINVAL, "key is NULL");
+  uint32_t o[4];
+  tsim_key_split(key[0], key[1], o);  // key, subkey = split(key)  (sampler.py:399)
+  key[0] = o[0];
+  key[1] = o[1];
+  return tsim_sample_batch_device_begin(p, slot, d_f, B, num_f, o[2], o[3], shot_offset, d_out, d_max_norm_dev, stream,
+                                        flags);
+}
+
 extern "C" int tsim_synchronize(tsim_program *p) {
   if (int r = need_final(p)) return r;
   if (int r = set_device(p)) return r;

@@ -170,7 +170,7 @@ struct tsim_program {
   unsigned long long batch_next = 1;       // sequence number of the next batch (event = batch_ev[seq % 16])
   unsigned long long batch_confirmed = 0;  // every batch up to this one is known to be complete
   unsigned long long lane_waited[2] = {0, 0};  // newest batch each first-pass lane already waits for
-  unsigned long long dbg_queries = 0, dbg_waits = 0, dbg_begins = 0, dbg_flushes = 0, dbg_defer = 0;
+  unsigned long long stat_queries = 0, stat_waits = 0, stat_begins = 0, stat_flushes = 0, stat_deferred = 0;
   int last_lists = 0;         // list count of the most recent two-pass launch (what the feedback refers to)
   int h_group_tiles = 0;      // k_sample4h geometry, fixed at the first two-pass launch
   size_t h_lds = 0;
@@ -1444,8 +1444,8 @@ extern "C" void tsim_program_destroy(tsim_program *p) {
       if (sl.side_ready) (void)hipStreamSynchronize(sl.side);
     for (hipEvent_t e : p->ev_pool) (void)hipEventDestroy(e);
     if (getenv("TSIM_AMD_PIPELINE_STATS"))
-      fprintf(stderr, "tsim pipeline: begins %llu deferred %llu flushes %llu queries %llu waits %llu\n", p->dbg_begins,
-              p->dbg_defer, p->dbg_flushes, p->dbg_queries, p->dbg_waits);
+      fprintf(stderr, "tsim pipeline: begins %llu deferred %llu flushes %llu queries %llu waits %llu\n", p->stat_begins,
+              p->stat_deferred, p->stat_flushes, p->stat_queries, p->stat_waits);
     if (p->sync_ev) (void)hipEventDestroy(p->sync_ev);
     for (hipEvent_t e : p->lane_ev) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : p->batch_ev) if (e) (void)hipEventDestroy(e);
@@ -1696,7 +1696,7 @@ static int flush_hard(tsim_program *p) {
   }
   HIP_TRY(hipGetLastError());
   p->hm_attr_set = true;
-  ++p->dbg_flushes;
+  ++p->stat_flushes;
   const unsigned long long seq = p->batch_next++;
   hipEvent_t &be = p->batch_ev[seq % 16u];
   if (!be) HIP_TRY(hipEventCreateWithFlags(&be, hipEventDisableTiming));
@@ -1988,14 +1988,14 @@ extern "C" int tsim_sample_batch_device_begin(tsim_program *p, int32_t slot, con
       if (sl.batch_seq <= p->batch_confirmed || (lane >= 0 && sl.batch_seq <= p->lane_waited[lane])) done = true;
       else if (lane >= 0) p->lane_waited[lane] = sl.batch_seq;
     } else {
-      ++p->dbg_queries;
+      ++p->stat_queries;
       done = hipEventQuery(sl.done_ev) == hipSuccess;
       if (!done) (void)hipGetLastError();
     }
-    if (!done) { ++p->dbg_waits; HIP_TRY(hipStreamWaitEvent(s, sl.done_ev, 0)); }
+    if (!done) { ++p->stat_waits; HIP_TRY(hipStreamWaitEvent(s, sl.done_ev, 0)); }
   }
-  ++p->dbg_begins;
-  if (plan.defer) ++p->dbg_defer;
+  ++p->stat_begins;
+  if (plan.defer) ++p->stat_deferred;
   if (!(flags & TSIM_PIPE_INPUTS_READY) && s_user != s) {
     HIP_TRY(hipEventRecord(sl.ev1, s_user));
     HIP_TRY(hipStreamWaitEvent(s, sl.ev1, 0));

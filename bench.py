@@ -532,6 +532,7 @@ def main() -> None:
                 "traffic": pmc_traffic_bytes(args.config, B),
                 "traffic_unit": "bytes per launch, rocprofv3 PMC: 2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction)",
                 "achieved_at_step_rate": bytes_per_shot * B / (elapsed / args.steps) / 1e9,
+                "frac_at_step_rate": bytes_per_shot * B / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
                 "kernel": kernel_name,
                 "kernel_avg_ms": avg_kernel_s * 1e3,
                 "launches": launches,
@@ -546,7 +547,8 @@ def main() -> None:
                 "note": "achieved = algorithmic bytes of one launch / HIP-event time of the dominant kernel inside the "
                 "timed region; there two first passes are in flight (two lanes) plus the hard-row batch on a third, so "
                 "each first pass shares the CUs and its own duration is about twice the step time - "
-                "achieved_at_step_rate uses the step time instead, achieved_serial the kernel's duration with the GPU "
+                "achieved_at_step_rate uses the step time instead (= shots/s x bytes/shot, the accounting BASELINE.md "
+                "section 4 fixes), achieved_serial the kernel's duration with the GPU "
                 "to itself (kernel_serial_avg_ms, measured after the timed region; = rocprofv3's serial kernel "
                 "trace). (k_sample_lw when pattern tables are active: it reads every f row and writes every "
                 "tabulated row.) Integer-VALU / latency bound, not HBM bound (DESIGN.md section 3.5); see `valu` "

@@ -186,7 +186,7 @@ struct tsim_program {
     bool lane0_main = true;   // TSIM_AMD_LANE0_MAIN=0: pipeline slot 0 gets a stream of its own
     int lw_block = 0;         // TSIM_AMD_LW_BLOCK (0: 1024 threads when the f/out staging fits 32 KB, else 256)
     int v4_block = 256;       // TSIM_AMD_V4_BLOCK
-    int hard_lds_kb = 150;    // TSIM_AMD_HARD_LDS_KB
+    int hard_lds_kb = 128;    // TSIM_AMD_HARD_LDS_KB (128: a first-pass block still fits next to a hard-row block)
     bool merge_lists = true;  // TSIM_AMD_MERGE_LISTS=0: always TSIMK_LW_LISTS hard-row sub-lists
     int list_rows = 40;       // TSIM_AMD_LIST_ROWS: expected hard rows per list the list count aims at
     int min_lists = 4;        // TSIM_AMD_MIN_LISTS (power of two >= 2)
@@ -1400,7 +1400,7 @@ retry_pack:
     if (p->knobs.lw_block != 0) p->knobs.lw_block = std::max(64, std::min(1024, p->knobs.lw_block & ~63));
     const int vb = env_int("TSIM_AMD_V4_BLOCK", 256);
     p->knobs.v4_block = (vb == 512 || vb == 128) ? vb : 256;
-    p->knobs.hard_lds_kb = std::max(24, std::min(156, env_int("TSIM_AMD_HARD_LDS_KB", 150)));
+    p->knobs.hard_lds_kb = std::max(24, std::min(156, env_int("TSIM_AMD_HARD_LDS_KB", 128)));
     p->knobs.defer = env_int("TSIM_AMD_DEFER_HARD", 1) != 0;
     p->knobs.merge_lists = env_int("TSIM_AMD_MERGE_LISTS", 1) != 0;
     p->knobs.list_rows = env_int("TSIM_AMD_LIST_ROWS", 40);

@@ -1,3 +1,5 @@
+"""Offline soak of the HIP path against the C oracle (test infrastructure: run by hand on the GPU box,
+`python tests/fuzz_many.py N`; not collected by pytest)."""
 import sys; sys.path.insert(0, "."); sys.path.insert(0, "tests")
 import numpy as np, warnings
 warnings.simplefilter("ignore")

@@ -257,9 +257,9 @@ class _CompiledSamplerBase:
         for i in range(num_batches):
             slot = i % self._PIPELINE
             hp.sample_batch_device_end(slot)  # the slot's previous batch no longer reads its f buffer
-            self._noise_key, nk = prng.split(self._noise_key)
+            self._noise_key, nk = hp.split_key(self._noise_key)  # prng.split, computed by the library
             st["noise"].sample_into(b["f"][slot].ptr, batch_size, nk)
-            self._key, subkey = prng.split(self._key)
+            self._key, subkey = hp.split_key(self._key)
             hp.sample_batch_device_begin(
                 slot, b["f"][slot].ptr, batch_size, num_f, subkey, b["out"].ptr + i * batch_size * wo * 8,
                 d_norm_dev=b["devs"].ptr + i * n_comp * 4,
@@ -326,12 +326,12 @@ class _CompiledSamplerBase:
             hp.h2d(d_ref, ref_w)
         hp.h2d(d_devs, np.zeros(num_batches * n_comp, np.float32))
         for i in range(num_batches):
-            self._noise_key, nk = prng.split(self._noise_key)
+            self._noise_key, nk = hp.split_key(self._noise_key)
             st["noise"].sample_into(d_f.ptr, batch_size, nk)
             out_i = d_out.ptr + i * batch_size * wo * 8
             hp.postselect_device(d_f.ptr, batch_size, num_f, d_mask.ptr, d_ref.ptr if use_ref else 0, out_i,
                                  d_idx.ptr, d_cnt.ptr, d_disc.ptr + i * batch_size)
-            self._key, subkey = prng.split(self._key)
+            self._key, subkey = hp.split_key(self._key)
             hp.sample_rows_device(d_f.ptr, batch_size, num_f, subkey, out_i, d_idx.ptr, d_cnt.ptr,
                                   d_norm_dev=d_devs.ptr + i * n_comp * 4)
         hp.unpack_bits_device(d_out.ptr, total, n_out, d_u8.ptr)

@@ -1975,8 +1975,8 @@ extern "C" int tsim_sample_batch_device_begin(tsim_program *p, int32_t slot, con
   const LaunchPlan plan = make_plan(p, false, true);
   hipStream_t s = plan.defer ? p->slots[1 + (slot & 1)].side : sl.side;
   if (!plan.defer) sl.used = true;
-  // the slot's previous launch (its lists, counters and output rows are reused): usually long finished -
-  // ask the event first, a stream wait costs queue time even when it has nothing to wait for
+  // the slot's previous launch (its lists, counters and output rows are reused) finished on another stream:
+  // this launch must be ordered after it
   if (sl.last_done && sl.last_done != s && sl.done_ev) {
     bool done = false;
     if (sl.batch_seq) {

@@ -1,6 +1,7 @@
 """The N > 1 code path of bench.py (RCCL collection of the bit-packed rows, lanes joined on the batch lane)
 forced on one GPU: it must run to completion and print the contract's JSON line.  The real N > 1 runs are
-the driver's; this keeps the plumbing from rotting between rounds."""
+the driver's; this keeps the plumbing from rotting between rounds.  (Named test_zz_* so that it runs last: it depends on
+torch.distributed + RCCL, infrastructure the other GPU tests do not need.)"""
 import json
 import os
 import socket

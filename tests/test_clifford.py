@@ -502,6 +502,30 @@ def test_correlated_error_chain_numbering_and_sampling():
     assert [len(p) for p in an.channel_probs] == [2, 2] and an.detectors[0][0] == 0b11
 
 
+def test_correlated_error_chain_among_many_error_bits():
+    """Regression (round-1 advisor): the not-yet-numbered chain bits must never collide with numbered error
+    bits, however many there are - before the chain opens, while it is open, and after it closes."""
+    n = 90  # qubits; > 64 error bits before, during and after the chain
+    lines = ["R " + " ".join(map(str, range(n)))]
+    lines += [f"X_ERROR(0.01) {q}" for q in range(n)]            # e0 .. e89
+    lines += [f"E(0.25) X{n - 1}"]                                  # chain opens (numbered at its close)
+    lines += [f"X_ERROR(0.01) {q}" for q in range(n)]            # e90 .. e179, while the chain is open
+    lines += [f"ELSE_CORRELATED_ERROR(0.5) X0 X{n - 2}"]
+    lines += [f"E(0.125) X1"]                                      # closes the first chain: e180, e181; opens a second
+    lines += [f"X_ERROR(0.01) {q}" for q in range(n)]            # e182 .. e271
+    lines += ["M " + " ".join(map(str, range(n)))]                  # end of circuit closes the second chain: e272
+    lines += [f"DETECTOR rec[-{n - q}]" for q in range(n)]
+    an = CliffordCircuit("\n".join(lines)).analyze()
+    assert an.num_e == 3 * n + 3
+    want = [(1 << q) | (1 << (n + q)) | (1 << (2 * n + 2 + q)) for q in range(n)]
+    want[n - 1] |= 1 << (2 * n)          # first alternative of chain 1
+    want[0] |= 1 << (2 * n + 1)          # second alternative
+    want[n - 2] |= 1 << (2 * n + 1)
+    want[1] |= 1 << (3 * n + 2)          # chain 2
+    assert [s for s, _ in an.detectors] == want
+    assert [len(p) for p in an.channel_probs] == [2] * (2 * n) + [4] + [2] * n + [2]
+
+
 def test_pair_measurements_and_mpad():
     an = CliffordCircuit("""
         R 0 1

@@ -1,0 +1,134 @@
+"""GPU parity on the normalised probability-model programs (tsim_amd.synth.physical_program): every
+Bernoulli threshold lies in [0, 1], so every draw is decided by the float32 value the kernels form -
+sample equality against the oracle is a test of the arithmetic, not of robustness to nonsense marginals."""
+
+import warnings
+
+import numpy as np
+import pytest
+
+from oracle import oracle_c as OC
+from oracle import oracle_np as O
+from tsim_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("mode", ["auto", "rows", "faithful"])
+@pytest.mark.parametrize("name,approx", [("C2", False), ("C2", True), ("C3", False), ("C4", False), ("C5", False)])
+def test_physical_programs_match_oracle_without_warnings(hip, name, approx, mode):
+    prog, cfg = synth.config_program(name, approx=approx)
+    n = 800 if name == "C4" else 4000
+    f = synth.synth_f(n, cfg["num_f"], cfg["p_bit"] * 2, seed=29)
+    want, wdev, ov = OC.OracleProgram(prog).sample_program(f, (51, 53), return_devs=True, return_overflow=True)
+    assert not ov
+    hp = hip.HipProgram(prog, mode=mode)
+    got, gdev = hp.sample_batch(f, (51, 53))
+    np.testing.assert_array_equal(got, want)
+    np.testing.assert_array_equal(np.asarray(gdev, np.float32), np.asarray(wdev, np.float32))
+    assert float(np.max(gdev)) < 1e-5
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")  # no normalisation warning (sampler.py:149-161) through the seam function
+        out = hip.sample_program(prog, f[:500], (51, 53), mode=mode)
+    np.testing.assert_array_equal(out, want[:500])
+
+
+@pytest.mark.parametrize("name", ["C2", "C4"])
+def test_thresholds_are_probabilities_on_device(hip, name):
+    """|amp_i(ctx, 1)| <= |amp_{i-1}(ctx)| and |amp_i(ctx,0)| + |amp_i(ctx,1)| == |amp_{i-1}(ctx)| within
+    float32 rounding, with the amplitudes the device forms (tsim_evaluate, abs output)."""
+    prog, cfg = synth.config_program(name)
+    hp = hip.HipProgram(prog)
+    rng = np.random.default_rng(7)
+    for ci, comp in enumerate(prog.components):
+        F, n = len(comp.f_selection), len(comp.output_indices)
+        B = 2000
+        f = (rng.random((B, F)) < 0.1).astype(np.uint8)
+        m = rng.integers(0, 2, size=(B, n), dtype=np.uint8)
+        prev = hp.evaluate(ci, 0, f, return_abs=True)
+        assert (prev > 0).all()
+        for i in range(n):
+            ctx = np.concatenate([f, m[:, :i]], axis=1)
+            p0 = hp.evaluate(ci, i + 1, np.concatenate([ctx, np.zeros((B, 1), np.uint8)], axis=1), return_abs=True)
+            p1 = hp.evaluate(ci, i + 1, np.concatenate([ctx, np.ones((B, 1), np.uint8)], axis=1), return_abs=True)
+            assert (p1 <= prev * (1 + 1e-6)).all() and (p0 <= prev * (1 + 1e-6)).all()
+            np.testing.assert_allclose(p0 + p1, prev, rtol=2e-6)
+            prev = np.where(m[:, i] != 0, p1, p0)
+
+
+def test_marginals_exact_integers_on_device(hip):
+    """The exact (a, b, c, d, power) the device reports for the two trial values add up to the previous
+    level's exact value (C2, integer arithmetic only)."""
+    prog, _ = synth.config_program("C2")
+    hp = hip.HipProgram(prog)
+    comp = prog.components[0]
+    F, n = len(comp.f_selection), len(comp.output_indices)
+    rng = np.random.default_rng(11)
+    B = 500
+    f = (rng.random((B, F)) < 0.1).astype(np.uint8)
+    m = rng.integers(0, 2, size=(B, n), dtype=np.uint8)
+
+    def canon(row):
+        c, p = [int(v) for v in row[:4]], int(row[4])
+        if not any(c):
+            return (0, 0, 0, 0, 0)
+        while all(v % 2 == 0 for v in c):
+            c, p = [v // 2 for v in c], p + 1
+        return (*c, p)
+
+    def add(x, y):
+        if not any(x[:4]):
+            return y
+        if not any(y[:4]):
+            return x
+        p = min(x[4], y[4])
+        return canon([a * (1 << (x[4] - p)) + b * (1 << (y[4] - p)) for a, b in zip(x[:4], y[:4])] + [p])
+
+    _, prev = hp.evaluate(0, 0, f, exact=True)
+    prev = [canon(r) for r in prev]
+    for i in range(n):
+        ctx = np.concatenate([f, m[:, :i]], axis=1)
+        _, e0 = hp.evaluate(0, i + 1, np.concatenate([ctx, np.zeros((B, 1), np.uint8)], axis=1), exact=True)
+        _, e1 = hp.evaluate(0, i + 1, np.concatenate([ctx, np.ones((B, 1), np.uint8)], axis=1), exact=True)
+        for r in range(B):
+            assert add(canon(e0[r]), canon(e1[r])) == prev[r]
+        prev = [canon(e1[r]) if m[r, i] else canon(e0[r]) for r in range(B)]
+
+
+FULL = {"C2": 1_000_000, "C3": 1_000_000, "C4": 100_000, "C5": 1_000_000}
+
+
+@pytest.mark.parametrize("physical", [True, False])
+@pytest.mark.parametrize("name", ["C2", "C3", "C4", "C5"])
+def test_full_size_properties(hip, name, physical):
+    """BASELINE sizes (1e6 / 1e5 shots) through size-independent properties:
+    * the formulations agree on every shot (chunk tables + pattern tables / row kernel / faithful mirror
+      on a 10 % slice - it is the slowest);
+    * sharding invariance: two launches with shot_offset reproduce one launch bit for bit;
+    * direct detector columns equal the f columns they copy;
+    * a 2000-shot slice equals the C oracle (shot_offset = its position)."""
+    prog, cfg = synth.config_program(name, physical=physical)
+    B = FULL[name]
+    f = synth.synth_f(B, cfg["num_f"], cfg["p_bit"], seed=123)
+    key = (77, 78)
+    n_out = prog.num_outputs
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        hp = hip.HipProgram(prog, mode="auto")
+        a, _ = hp.sample_batch(f, key, bit_packed=True)
+        b, _ = hip.HipProgram(prog, mode="rows").sample_batch(f, key, bit_packed=True)
+        assert np.array_equal(a, b)
+        ns = B // 10
+        lo = B // 3
+        c, _ = hip.HipProgram(prog, mode="faithful").sample_batch(f[lo:lo + ns], key, shot_offset=lo, bit_packed=True)
+        assert np.array_equal(a[lo:lo + ns], c)
+        cut = 2 * B // 5 + 1
+        h1, _ = hp.sample_batch(f[:cut], key, bit_packed=True)
+        h2, _ = hp.sample_batch(f[cut:], key, shot_offset=cut, bit_packed=True)
+        assert np.array_equal(np.concatenate([h1, h2]), a)
+    bits = np.unpackbits(a, axis=1, bitorder="little")[:, :n_out]
+    nd = len(prog.direct_f_indices)
+    assert np.array_equal(bits[:, prog.output_order[:nd]], f[:, prog.direct_f_indices] ^ prog.direct_flips)
+    s0 = B - 2000
+    want = OC.OracleProgram(prog).sample_program(f[s0:], key, shot_offset=s0)
+    np.testing.assert_array_equal(bits[s0:].astype(bool), np.asarray(want).astype(bool))

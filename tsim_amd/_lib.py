@@ -119,6 +119,21 @@ def load() -> C.CDLL:
     if _lib is not None:
         return _lib
     path = Path(os.environ.get("TSIM_AMD_LIB", LIB_PATH))
+    if path == LIB_PATH:
+        # The binary must be the one built from THIS tree: compare the content hash recorded at build
+        # time with the sources (a prebuilt .so travels with snapshots of the tree; a stale one is
+        # rebuilt here, never used silently).
+        from . import build as _build
+
+        if _build.needs_build():
+            try:
+                _build.build(verbose=False)
+            except Exception as exc:
+                raise HipBackendError(
+                    f"{path} is missing or was built from different sources and cannot be rebuilt here "
+                    f"({exc}); build it with `python -m tsim_amd.build` (hipcc --offload-arch=gfx950) - "
+                    "there is no CPU fallback"
+                ) from exc
     if not path.exists():
         raise HipBackendError(
             f"{path} not found - build it with `python -m tsim_amd.build` "

@@ -83,19 +83,42 @@ def _level_desc(lv: CompiledScalarGraphs, keep: list) -> _lib.LevelDesc:
     return desc
 
 
+class _Handle:
+    """The ``tsim_program*`` and what hangs off it, shared by a :class:`HipProgram` and the objects
+    that borrow it (:class:`DeviceBuffer`, :class:`DeviceNoiseSampler`).  ``close`` runs once - from
+    ``HipProgram.close()``, its finalizer or interpreter exit - destroys the dependent noise handles,
+    then the program (which frees every buffer still allocated on it) and clears ``h``: borrowers
+    check ``h`` and never touch a destroyed handle, whatever order garbage collection picks."""
+
+    def __init__(self, lib, h):
+        self.lib = lib
+        self.h = h
+        self.noise: list = []  # live tsim_noise* handles
+
+    def close(self) -> None:
+        h, self.h = self.h, None
+        if not h:
+            return
+        for n in self.noise:
+            self.lib.tsim_noise_destroy(n)
+        self.noise.clear()
+        self.lib.tsim_program_destroy(h)
+
+
 class DeviceBuffer:
-    """A ``hipMalloc`` allocation owned by a :class:`HipProgram`."""
+    """A ``hipMalloc`` allocation owned by a :class:`HipProgram` (freed with it at the latest)."""
 
     def __init__(self, prog: "HipProgram", nbytes: int):
-        self._prog = prog
+        self._handle = prog._handle
         self.nbytes = int(nbytes)
         p = C.c_void_p()
         _lib.check(prog._lib.tsim_malloc_device(prog._h, self.nbytes, C.byref(p)), "tsim_malloc_device")
         self.ptr = p.value or 0
 
     def free(self) -> None:
-        if self.ptr and self._prog._h:
-            self._prog._lib.tsim_free_device(self._prog._h, C.c_void_p(self.ptr))
+        hd = self._handle
+        if self.ptr and hd.h:
+            hd.lib.tsim_free_device(hd.h, C.c_void_p(self.ptr))
         self.ptr = 0
 
     def __del__(self):  # pragma: no cover - best effort
@@ -119,7 +142,7 @@ class HipProgram:
         if mode not in ("auto", "faithful", "rows"):
             raise ValueError("mode must be 'auto', 'faithful' or 'rows'")
         self._lib = _lib.load()
-        self._h = None
+        self._handle = _Handle(self._lib, None)
         program = from_tsim(program)
         validate_program(program)
         self.program = program
@@ -138,7 +161,8 @@ class HipProgram:
             ),
             "tsim_program_create",
         )
-        self._h = h
+        self._handle.h = h
+        self._finalizer = weakref.finalize(self, _Handle.close, self._handle)
         try:
             for comp in program.components:
                 oi = _c(comp.output_indices, np.int32)
@@ -165,12 +189,22 @@ class HipProgram:
             _lib.check(lib.tsim_program_get_mode(h, C.byref(fast)), "tsim_program_get_mode")
             self.fast = bool(fast.value)
         except Exception:
-            lib.tsim_program_destroy(h)
-            self._h = None
+            self.close()
             raise
         self._split_buf = (C.c_uint32 * 4)()
         self._packed_bufs = None
-        self._finalizer = weakref.finalize(self, lib.tsim_program_destroy, h)
+
+    @property
+    def _h(self):
+        """The live ``tsim_program*``; raises once the handle has been closed."""
+        h = self._handle.h
+        if not h:
+            raise _lib.HipBackendError("HipProgram is closed")
+        return h
+
+    def close(self) -> None:
+        """Destroy the device image, every buffer allocated on it and its noise samplers (idempotent)."""
+        self._finalizer()
 
     # -- info ---------------------------------------------------------------
     def info(self) -> dict:
@@ -538,14 +572,24 @@ class DeviceNoiseSampler:
             ),
             "tsim_noise_create",
         )
-        self._h = h
-        self._finalizer = weakref.finalize(self, self._lib.tsim_noise_destroy, h)
+        self._n = h
+        self._handle = hip_program._handle
+        self._handle.noise.append(h)
+        self._finalizer = weakref.finalize(self, DeviceNoiseSampler._destroy, self._handle, h)
+
+    @staticmethod
+    def _destroy(handle: _Handle, n) -> None:
+        if handle.h and n in handle.noise:  # otherwise _Handle.close already destroyed it
+            handle.noise.remove(n)
+            handle.lib.tsim_noise_destroy(n)
 
     def sample_into(self, d_f: int, B: int, key) -> None:
         """Asynchronous on the program's stream."""
+        if not self._handle.h:
+            raise _lib.HipBackendError("the HipProgram of this noise sampler is closed")
         _lib.check(
             self._lib.tsim_noise_sample_device(
-                self._h, int(B), int(key[0]) & 0xFFFFFFFF, int(key[1]) & 0xFFFFFFFF, C.c_void_p(d_f), None
+                self._n, int(B), int(key[0]) & 0xFFFFFFFF, int(key[1]) & 0xFFFFFFFF, C.c_void_p(d_f), None
             ),
             "tsim_noise_sample_device",
         )

@@ -428,6 +428,8 @@ class _Sim:
     # noise ----------------------------------------------------------------------
     def _new_bits(self, k: int) -> list[int]:
         first = self.out.num_e
+        if self.corr_probs and first + k > self._shift:
+            self._relocate_chain(2 * (first + k) + 64)  # numbered bits must stay below the open chain's bits
         self.out.num_e += k
         return [1 << (first + i) for i in range(k)]
 
@@ -464,10 +466,28 @@ class _Sim:
     # CORRELATED_ERROR / ELSE_CORRELATED_ERROR chains (instructions.py:759-816): the chain's bits get
     # their error indices, and its table is appended, only when the chain is closed by the next
     # CORRELATED_ERROR or by the end of the circuit - channels seen in between come first.
-    _TEMP = 1 << 40  # bit position of the first not-yet-numbered chain bit
+    # Until then they live at bit positions _shift, _shift + 1, ... - above every numbered error bit; _shift
+    # grows (the masks are rewritten) whenever the numbered bits would reach it, so the two ranges never meet.
+    _shift = 64
+
+    def _remap_masks(self, fn):
+        out = self.out
+        self.fx = [fn(m) for m in self.fx]
+        self.fz = [fn(m) for m in self.fz]
+        out.rec_sets = [fn(m) for m in out.rec_sets]
+        out.detectors = [(fn(s), v) for s, v in out.detectors]
+        for cur in out.observables.values():
+            cur[0] = fn(cur[0])
+
+    def _relocate_chain(self, new_shift):
+        old, low = self._shift, (1 << self._shift) - 1
+        self._remap_masks(lambda m: (m & low) | ((m >> old) << new_shift))
+        self._shift = new_shift
 
     def correlated_error(self, paulis, p):
-        bit = 1 << (40 + len(self.corr_probs))
+        if not self.corr_probs and self.out.num_e > self._shift:
+            self._shift = 2 * self.out.num_e + 64  # no chain bit exists yet: nothing to move
+        bit = 1 << (self._shift + len(self.corr_probs))
         for kind, q in paulis:
             if kind in ("X", "Y"):
                 self.fx[q] ^= bit
@@ -481,17 +501,8 @@ class _Sim:
             return
         out = self.out
         out.channel_probs.append(correlated_error_probs(self.corr_probs))
-        base, low = out.num_e, self._TEMP - 1
-
-        def move(m):
-            return (m & low) | ((m >> 40) << base)
-
-        self.fx = [move(m) for m in self.fx]
-        self.fz = [move(m) for m in self.fz]
-        out.rec_sets = [move(m) for m in out.rec_sets]
-        out.detectors = [(move(s), v) for s, v in out.detectors]
-        for cur in out.observables.values():
-            cur[0] = move(cur[0])
+        base, shift, low = out.num_e, self._shift, (1 << self._shift) - 1
+        self._remap_masks(lambda m: (m & low) | ((m >> shift) << base))
         out.num_e += k
         self.corr_probs = []
 

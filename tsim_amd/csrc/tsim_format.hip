@@ -1,0 +1,97 @@
+// tsim_format.hip - data-format kernels either side of the path: byte-per-bit <-> packed rows
+// (the reference's H2D / D2H formats, sampler.py:398,415) and the bit_packed compaction (sampler.py:665-669).
+#include "tsim_internal.hip.h"
+#include "tsim_format.hip.h"
+
+using namespace tsimk;
+
+int tsim_launch_pack(tsim_program *p, const uint8_t *d_in, int64_t B, int32_t nbits, uint64_t *d_out, hipStream_t s) {
+  const int n32 = 2 * ((nbits + 63) / 64);
+  const long long n = B * n32;
+  if (n == 0) return 0;
+  if ((nbits & 15) == 0 && ((uintptr_t)d_in & 15) == 0) {
+    const long long nw = B * (n32 / 2);
+    hipLaunchKernelGGL(k_pack_bits_a16, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, s, (const uint4 *)d_in, d_out,
+                       (long long)B, nbits, n32 / 2);
+    HIP_TRY(hipGetLastError());
+    return 0;
+  }
+  const long long in_dwords = (B * (long long)nbits + 3) / 4;  // the last dword may be partial
+  hipLaunchKernelGGL(k_pack_bits, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_in, (uint32_t *)d_out,
+                     (long long)B, nbits, n32, in_dwords);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// one launch covers fewer than 2^32 output bytes (32-bit indexing in the kernels): larger requests are cut
+// into row chunks (a multiple of 4 rows, so that every chunk starts 4-byte - and, for 16-column-aligned
+// rows, 16-byte - aligned)
+static int unpack_chunk(const uint64_t *d_in, int64_t B, int32_t nbits, uint8_t *d_out, hipStream_t s) {
+  const int n32 = 2 * ((nbits + 63) / 64);
+  const long long total = B * (long long)nbits;
+  if ((nbits & 15) == 0 && ((uintptr_t)d_out & 15) == 0) {
+    const long long total16 = total >> 4;
+    const unsigned long long per = (unsigned long long)(nbits >> 4);
+    const unsigned long long magic16 = ((1ull << 40) + per - 1ull) / per;
+    hipLaunchKernelGGL(k_unpack_bits_a16, dim3((unsigned)((total16 + 255) / 256)), dim3(256), 0, s, (const uint32_t *)d_in,
+                       (uint4 *)d_out, total16, nbits, n32, magic16);
+    HIP_TRY(hipGetLastError());
+    return 0;
+  }
+  const long long nthreads = (total + 3) / 4;
+  const unsigned long long magic = ((1ull << 40) + (unsigned long long)nbits - 1ull) / (unsigned long long)nbits;
+  hipLaunchKernelGGL(k_unpack_bits, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, s, (const uint32_t *)d_in,
+                     (uint32_t *)d_out, d_out, total, nbits, n32, magic, (long long)B * n32);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int tsim_launch_unpack(tsim_program *p, const uint64_t *d_in, int64_t B, int32_t nbits, uint8_t *d_out, hipStream_t s) {
+  (void)p;
+  if (B == 0 || nbits == 0) return 0;
+  const int WQ = (nbits + 63) / 64;
+  const long long max_rows = std::max<long long>(4, (((1ll << 32) - 1) / nbits) & ~3ll);
+  for (long long r0 = 0; r0 < B; r0 += max_rows) {
+    const long long rows = std::min<long long>(max_rows, B - r0);
+    if (int r = unpack_chunk(d_in + r0 * WQ, rows, nbits, d_out + r0 * (long long)nbits, s)) return r;
+  }
+  return 0;
+}
+
+extern "C" int tsim_pack_bits_device(tsim_program *p, const uint8_t *d_in, int64_t B, int32_t nbits,
+                                     uint64_t *d_out, void *stream) {
+  if (int r = tsim_need_final(p)) return r;
+  if (int r = tsim_set_device(p)) return r;
+  if (B < 0 || nbits < 0) return tsim_fail(TSIM_EINVAL, "negative size");
+  return tsim_launch_pack(p, d_in, B, nbits, d_out, stream ? (hipStream_t)stream : p->stream);
+}
+
+extern "C" int tsim_unpack_bits_device(tsim_program *p, const uint64_t *d_in, int64_t B, int32_t nbits,
+                                       uint8_t *d_out, void *stream) {
+  if (int r = tsim_need_final(p)) return r;
+  if (int r = tsim_set_device(p)) return r;
+  if (B < 0 || nbits < 0) return tsim_fail(TSIM_EINVAL, "negative size");
+  return tsim_launch_unpack(p, d_in, B, nbits, d_out, stream ? (hipStream_t)stream : p->stream);
+}
+
+int tsim_launch_compact(const uint64_t *d_in, int64_t B, int32_t WO, int32_t nbits, uint8_t *d_out, hipStream_t s) {
+  const int rb = (nbits + 7) / 8;
+  const long long nthreads = (B + 3) / 4;
+  const uint32_t tail_mask = (nbits & 7) ? ((1u << (nbits & 7)) - 1u) : 255u;
+  hipLaunchKernelGGL(k_compact_rows, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, s, d_in, d_out, (long long)B, WO,
+                     rb, tail_mask);
+  HIP_TRY(hipGetLastError());
+  return TSIM_OK;
+}
+
+extern "C" int tsim_compact_rows_device(tsim_program *p, const uint64_t *d_in, int64_t B, int32_t in_words,
+                                        int32_t nbits, uint8_t *d_out, void *stream) {
+  if (int r = tsim_need_final(p)) return r;
+  if (int r = tsim_set_device(p)) return r;
+  if (B < 0 || nbits < 0 || in_words < 0) return tsim_fail(TSIM_EINVAL, "negative size");
+  if (B == 0 || nbits == 0) return TSIM_OK;
+  if (!d_in || !d_out) return tsim_fail(TSIM_EINVAL, "NULL buffer");
+  const int WO = in_words ? in_words : (nbits + 63) / 64;
+  if ((long long)WO * 64 < nbits) return tsim_fail(TSIM_EINVAL, "rows of %d words hold fewer than %d bits", WO, nbits);
+  return tsim_launch_compact(d_in, B, WO, nbits, d_out, stream ? (hipStream_t)stream : p->stream);
+}

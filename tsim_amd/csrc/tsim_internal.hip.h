@@ -1,0 +1,259 @@
+// tsim_internal.hip.h - host-side state shared by the translation units of libtsim_hip.so.
+//
+//   tsim_program.hip   handle life cycle: description -> packed image -> upload; memory/stream plumbing
+//   tsim_pack.hip      the packer: reference-layout rows -> bit-packed rows, pack-time GF(2) algebra,
+//                      chunk tables (host only)
+//   tsim_sample.hip    launch planner + pipeline scheduler + the sampling kernels (k_sample_lw, k_sample4,
+//                      k_sample4h), device-side post-selection, HIP-event profiling
+//   tsim_rows*.hip     the row-formulation kernels (k_sample<W>, k_evaluate<W>, k_lw_build<W>), one TU per
+//                      formulation so that they compile in parallel
+//   tsim_format.hip    byte-per-bit <-> packed rows, bit_packed compaction, row gather/scatter
+//   tsim_noise.hip     device-side channel sampler
+//   tsim_pcg.cpp       numpy-stream-exact host channel sampler (PCG64 + ziggurat), no HIP
+//   tsim_dist.hip      RCCL communicator (shot sharding over the GPUs of a node)
+#pragma once
+#include "../../include/tsim_hip.h"
+#include "tsim_kernels.hip.h"
+#include "tsim_kernel4.hip.h"
+#ifndef TSIM_HARD_NW
+#define TSIM_HARD_NW 8   // waves per 64-row group in k_sample4h
+#endif
+#include "tsim_lw.hip.h"
+
+#include <algorithm>
+#include <array>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <string>
+#include <unordered_set>
+#include <vector>
+
+#define TSIMK_H_MAX_CTX 8   // launches served by one deferred hard-row batch (k_sample4h_multi)
+
+// ---------------------------------------------------------------------------
+// errors: every entry point returns 0 or a negative TSIM_E* code; the message is thread-local
+// ---------------------------------------------------------------------------
+int tsim_fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+
+#define HIP_TRY(expr)                                                                        \
+  do {                                                                                       \
+    hipError_t e_ = (expr);                                                                  \
+    if (e_ != hipSuccess) return tsim_fail(TSIM_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+// ---------------------------------------------------------------------------
+// host-side program
+// ---------------------------------------------------------------------------
+namespace tsimhost {
+
+// per-graph result of the fast packer's algebra, kept for the v4 (chunk table) emitter
+struct FastGraph {
+  std::vector<std::vector<uint64_t>> c0, c1, c3;  // counted NodePhases rows per class (masks)
+  std::vector<uint8_t> c0c, c1c, c3c;             // their constants
+  std::vector<std::vector<uint64_t>> dal, dbe;    // PhasePairs alpha / beta masks
+  std::vector<uint64_t> lam, lin;
+  std::vector<std::vector<uint64_t>> us, vs;      // Dickson product pairs
+  int n1 = 0, nD = 0;
+  bool d_tabled = false;
+};
+
+struct HostLevel {
+  std::vector<FastGraph> fg;
+  bool fixed = false;
+  int frame = 0;
+  int G = 0, P = 0;
+  bool approx = false;
+  // per graph
+  std::vector<uint32_t> graph_rec;        // G * G_WORDS (row offsets relative to `rows`)
+  std::vector<uint32_t> rows;             // packed rows, built for word count W
+  long long n_rows = 0;
+  // raw copy of the description (packing happens at finalize when W is known)
+  tsim_level_desc d{};
+  std::vector<uint8_t> u8[14];
+  std::vector<int32_t> i32[4];
+  std::vector<float> approx_v;
+};
+
+struct HostComponent {
+  int n_out = 0, F = 0, n_levels = 0;
+  std::vector<int32_t> output_indices, f_selection;
+  std::vector<HostLevel> levels;
+};
+
+static const int kWVariants[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32};
+
+inline int round_w(int w) {
+  for (int v : kWVariants)
+    if (w <= v) return v;
+  return -1;
+}
+
+}  // namespace tsimhost
+
+using tsimk::SampleArgs;
+using tsimhost::FastGraph;
+using tsimhost::HostComponent;
+using tsimhost::HostLevel;
+
+struct tsim_program {
+  // description
+  int num_outputs = 0, num_detectors = 0, n_direct = 0;
+  std::vector<int32_t> direct_f, output_order;
+  std::vector<uint8_t> direct_flips;
+  std::vector<HostComponent> comps;
+  bool finalized = false;
+  // packed image
+  std::vector<uint32_t> img;
+  int direct_off = 0, comp_off = 0;
+  int total_keys = 0;  // total compiled outputs (sequential components)
+  bool sampleable = true;
+  int mode = TSIM_MODE_AUTO;  // requested
+  bool fast = false;          // chosen at finalize: counting formulation (eval_level_fast)
+  bool v4 = false;            // chunk-table layout present (k_sample4)
+  int v4_gt = 4;              // graphs per LDS tile
+  int comp4_off = 0;
+  int v4_max_nch = 1;
+  int v4_max_sent = 0;        // entries per tile of the sparse-f tables (0: none)
+  long long total_graphs = 0, total_rows = 0;
+  long long stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // see tsim_program_stats
+  int max_f_index = -1;
+  std::vector<int> level_off;  // flattened [component][level] -> offset of level record
+  std::vector<int> level_base; // per component index into level_off
+  std::vector<int> comp_w;
+  // device
+  int device = -1;
+  uint32_t *d_img = nullptr;
+  float *d_dev = nullptr;
+  hipStream_t stream = nullptr;
+  // low-weight pattern tables (tsim_lw.hip.h)
+  int lw_request = -1;        // -1 default (on in TSIM_MODE_AUTO), 0 off, 1 on
+  int lw_weight_cap = -1;     // -1 = TSIMK_LW_MAX_WEIGHT
+  bool lw = false;            // tables built, pass 1 active
+  // Launch slots: slot 0 serves the serial API (everything on the caller's stream); slots 1..4 serve
+  // tsim_sample_batch_device_begin/_end: a slot's launches run on the slot's own stream (`side`) so
+  // that it overlaps the first pass of the following launches.
+  struct Slot {
+    int parity = 0;               // counter set of the next launch
+    uint32_t *ctl = nullptr;      // 2 counter sets (hard-row counters + check row)
+    void *hard = nullptr;         // hard-row lists
+    size_t hard_sz = 0;
+    uint32_t *keys = nullptr;     // k_keygen output (programs with > TSIMK_INLINE_KEYS outputs)
+    hipStream_t side = nullptr;
+    hipEvent_t ev1 = nullptr, ev2 = nullptr;  // input dependency, launch done
+    bool pending = false;         // second pass enqueued on `side`, not yet joined
+    bool side_borrowed = false;   // `side` is not owned by the slot (the handle's main stream / the null stream)
+    bool side_ready = false;
+    uint8_t *compact_out = nullptr;  // next launch of the slot also writes bit_packed rows here
+    // deferred second pass (flush_hard): pass 1 is enqueued, the hard rows wait for the next batch
+    bool deferred = false;
+    bool ctx_check = false;
+    bool used = false;                // a launch ran on the slot's own stream
+    hipStream_t p1_stream = nullptr;  // lane of that first pass
+    hipStream_t last_done = nullptr;  // stream on which done_ev of the slot's last launch was recorded
+    hipEvent_t done_ev = nullptr;     // ev2 (own second pass) or the event of the batch that served the slot
+    unsigned long long batch_seq = 0; // sequence number of that batch (0: own second pass)
+    SampleArgs ctx;                   // the hard-row kernel's arguments for that launch
+  };
+  Slot slots[1 + TSIM_PIPELINE_SLOTS];
+  bool slots_ready = false;
+  std::vector<int> deferred;  // slots whose hard rows are waiting, in launch order
+  hipEvent_t lane_ev[2] = {nullptr, nullptr};  // "first passes enqueued so far on lane k are done"
+  hipEvent_t batch_ev[16] = {};                // ring: one event per hard-row batch
+  hipEvent_t sync_ev = nullptr;                // tsim_pipeline_wait_stream
+  uint8_t *series_ptr = nullptr;               // tsim_pipeline_set_compact_series
+  int64_t series_stride = 0;
+  int series_left = 0;
+  unsigned long long batch_next = 1;       // sequence number of the next batch (event = batch_ev[seq % 16])
+  unsigned long long batch_confirmed = 0;  // every batch up to this one is known to be complete
+  unsigned long long lane_waited[2] = {0, 0};  // newest batch each first-pass lane already waits for
+  unsigned long long stat_queries = 0, stat_waits = 0, stat_begins = 0, stat_flushes = 0, stat_deferred = 0;
+  int last_lists = 0;         // list count of the most recent two-pass launch (what the feedback refers to)
+  int h_group_tiles = 0;      // k_sample4h geometry, fixed at the first two-pass launch
+  size_t h_lds = 0;
+  // launch-plan feedback (mapped pinned host memory written by k_sample4h): [0] hard rows,
+  // [1] longest hard-row list, [2] rows of that launch; 0xFFFFFFFF = nothing seen yet
+  volatile uint32_t *h_feedback = nullptr;
+  uint32_t *d_feedback = nullptr;
+  int lw_direct_left = 0;     // launches still to run on the full kernel before the next probe
+  // launch-time tuning knobs, read from the environment once at finalize (experiments only)
+  struct Knobs {
+    bool adaptive = true;     // TSIM_AMD_ADAPTIVE=0 pins the default launch plan
+    bool hard_kernel = true;  // TSIM_AMD_HARD_KERNEL=0: hard rows on k_sample4 instead of k_sample4h
+    bool lane0_main = true;   // TSIM_AMD_LANE0_MAIN=0: pipeline slot 0 gets a stream of its own
+    int lw_block = 0;         // TSIM_AMD_LW_BLOCK (0: 1024 threads when the f/out staging fits 32 KB, else 256)
+    int v4_block = 256;       // TSIM_AMD_V4_BLOCK
+    int hard_lds_kb = 128;    // TSIM_AMD_HARD_LDS_KB (128: a first-pass block still fits next to a hard-row block)
+    bool merge_lists = true;  // TSIM_AMD_MERGE_LISTS=0: always TSIMK_LW_LISTS hard-row sub-lists
+    int list_rows = 40;       // TSIM_AMD_LIST_ROWS: expected hard rows per list the list count aims at
+    int min_lists = 4;        // TSIM_AMD_MIN_LISTS (power of two >= 2)
+    bool defer = true;        // TSIM_AMD_DEFER_HARD=0: every pipelined launch runs its own second pass
+    int defer_group = 4;      // TSIM_AMD_DEFER_GROUP: launches per deferred hard-row batch (<= TSIMK_H_MAX_CTX)
+  } knobs;
+  bool h_attr_set = false;    // k_sample4h: large dynamic LDS enabled
+  bool hm_attr_set = false;   // k_sample4h_multi: the same
+  int lw_off = 0;             // image offset of the LW component records
+  int lw_direct_prog = 0;     // image offset of the direct-output gather program
+  int lw_direct_chunks = 0;
+  std::vector<int> lw_wmax;   // per component
+  long long lw_bytes = 0;
+  float *d_lw_tab = nullptr;
+  // device allocations handed out by tsim_malloc_device and not yet freed: the handle owns them
+  std::unordered_set<void *> owned;
+  // scratch (host-buffer API)
+  void *scratch[4] = {nullptr, nullptr, nullptr, nullptr};
+  size_t scratch_sz[4] = {0, 0, 0, 0};
+  // profiling
+  bool profiling = false;
+  bool prof_light = false;    // only the events of the first kernel of a launch
+  int prof_every = 1;         // bracket one launch in prof_every
+  long long prof_counter = 0;
+  std::vector<hipEvent_t> ev_pool;
+  std::vector<int> ev_tag;
+  double prof_stage_ms[4] = {0.0, 0.0, 0.0, 0.0};
+  size_t ev_used = 0;
+  double prof_ms = 0.0;
+  long long prof_launches = 0;
+};
+
+// ---- tsim_program.hip
+int tsim_set_device(const tsim_program *p);
+int tsim_need_final(const tsim_program *p);
+int tsim_ensure_scratch(tsim_program *p, int slot, size_t bytes);
+
+// ---- tsim_pack.hip (host only)
+namespace tsimhost {
+void pack_level(HostLevel &h, int W);
+bool level_fast_eligible(const HostLevel &h);
+bool pack_level_fast(HostLevel &h, int W, std::vector<uint32_t> &tables, bool &fixed_out, int &frame_out);
+bool level_v4_eligible(const HostLevel &h);
+void emit_level4(const HostLevel &h, int GT, int nch, const uint32_t *v3recs, std::vector<uint32_t> &recs4,
+                 std::vector<uint32_t> &tabs4, int &nch_out, int &ntiles_out, int sparse_F,
+                 std::vector<uint32_t> &stabs4);
+std::vector<uint32_t> emit_gather_program(std::vector<std::array<int, 3>> e);
+}  // namespace tsimhost
+
+// ---- tsim_sample.hip
+int tsim_flush_hard(tsim_program *p);
+
+// ---- tsim_rows*.hip: launchers of the row-formulation kernels (W = 32-bit words per parameter row)
+int tsim_launch_rows(tsim_program *p, int wmax, const tsimk::SampleArgs &a, long long grid, int block, size_t lds,
+                     hipStream_t s);
+int tsim_launch_lw_build(int W, bool fast, const tsimk::LwBuildArgs &a, long long lanes, hipStream_t s);
+namespace tsimrows {
+int sample_fast(int wmax, const tsimk::SampleArgs &a, long long grid, int block, size_t lds, hipStream_t s);
+int sample_faithful(int wmax, const tsimk::SampleArgs &a, long long grid, int block, size_t lds, hipStream_t s);
+int eval_fast(int W, const tsimk::EvalArgs &a, hipStream_t s);
+int eval_faithful(int W, const tsimk::EvalArgs &a, hipStream_t s);
+int lw_build_fast(int W, const tsimk::LwBuildArgs &a, long long lanes, hipStream_t s);
+int lw_build_faithful(int W, const tsimk::LwBuildArgs &a, long long lanes, hipStream_t s);
+}  // namespace tsimrows
+
+// ---- tsim_format.hip
+int tsim_launch_pack(tsim_program *p, const uint8_t *d_in, int64_t B, int32_t nbits, uint64_t *d_out, hipStream_t s);
+int tsim_launch_unpack(tsim_program *p, const uint64_t *d_in, int64_t B, int32_t nbits, uint8_t *d_out, hipStream_t s);
+// padded uint64[B, WO] rows -> uint8[B, ceil(nbits/8)] rows (the reference's bit_packed layout)
+int tsim_launch_compact(const uint64_t *d_in, int64_t B, int32_t WO, int32_t nbits, uint8_t *d_out, hipStream_t s);

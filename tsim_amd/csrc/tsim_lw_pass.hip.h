@@ -1,0 +1,131 @@
+// tsim_lw_pass.hip.h - the first pass of a two-pass launch (k_sample_lw); see tsim_lw.hip.h.
+#pragma once
+#include "tsim_lw.hip.h"
+
+namespace tsimk {
+
+// ---------------------------------------------------------------------------
+// pass 1
+// ---------------------------------------------------------------------------
+typedef uint32_t lw_u32x16 __attribute__((ext_vector_type(16)));
+typedef const __attribute__((address_space(4))) lw_u32x16 *lw_cptr16;
+
+// runs one gather program; destination words 0 and 1 are register accumulators, higher ones (rare:
+// more than 64 outputs) go to the lane's LDS column `lds_hi` (may be nullptr when there are none)
+__device__ __forceinline__ void lw_gather(cptr prog, uint32_t nchunks, const uint32_t *lds_f, uint32_t *lds_hi,
+                                          int nthr, uint32_t &a0, uint32_t &a1) {
+  for (uint32_t c = 0; c < nchunks; ++c) {
+    const lw_u32x16 q = *(lw_cptr16)(prog + 16u * c);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const uint32_t ctl = q[4 * k];
+      const uint32_t fw = lds_f[(ctl >> 24) * nthr];
+      const uint32_t v = (((fw >> (ctl & 31u)) & q[4 * k + 1]) ^ q[4 * k + 2]) << ((ctl >> 8) & 31u);
+      const uint32_t dw = (ctl >> 16) & 255u;
+      if (dw == 0u) a0 |= v;
+      else if (dw == 1u) a1 |= v;
+      else lds_hi[dw * nthr] |= v;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(1024) k_sample_lw(LwArgs L) {
+  const SampleArgs &A = L.s;
+  const int nthr = blockDim.x;
+  const long long slot = (long long)blockIdx.x * nthr + threadIdx.x;
+  long long n_rows = A.B;
+  if (A.row_index) n_rows = (long long)*A.row_count;
+  const bool active = slot < n_rows;
+  long long row = slot;
+  if (A.row_index) row = active ? (long long)A.row_index[slot] : 0;
+  const unsigned long long shot = (unsigned long long)(A.shot_offset + row);
+  cptr img = (cptr)(uintptr_t)A.img;
+
+  const int WF32 = 2 * A.WF, WO32 = 2 * A.WO;
+  uint32_t *lds_f = tsimk_lds + threadIdx.x;                // [WF32][nthr]
+  uint32_t *lds_o = tsimk_lds + WF32 * nthr + threadIdx.x;  // [WO32][nthr]
+
+  if (blockIdx.x == 0 && threadIdx.x <= TSIMK_LW_LISTS)
+    L.ctl_next[32u * threadIdx.x] = (threadIdx.x == TSIMK_LW_LISTS) ? 0xFFFFFFFFu : 0u;  // last: "no check row"
+  bool hard = false;
+  uint32_t o0 = 0, o1 = 0;  // output words 0 and 1 (the LDS column holds the others)
+  if (active) {
+    const uint64_t *frow = A.f + row * A.WF;
+    for (int w = 0; w < A.WF; ++w) {
+      const uint64_t v = frow[w];
+      lds_f[(2 * w) * nthr] = (uint32_t)v;
+      lds_f[(2 * w + 1) * nthr] = (uint32_t)(v >> 32);
+    }
+    for (int w = 0; w < WO32; ++w) lds_o[w * nthr] = 0u;
+    hard = L.has_check && slot == 0;
+    if (hard) L.ctl[32 * TSIMK_LW_LISTS] = (uint32_t)row;
+
+    // K14: direct outputs f[idx] ^ flip (sampler.py:140-145), as bit-field moves
+    lw_gather(img + L.direct_prog, (uint32_t)L.direct_chunks, lds_f, lds_o, nthr, o0, o1);
+
+    for (int ci = 0; ci < A.n_comp; ++ci) {
+      cptr rec = img + L.lw_off + ci * LW_WORDS;
+      // f_sel gather (sampler.py:48) -> x, then the weight test
+      uint32_t x0 = 0, x1 = 0;
+      lw_gather(img + rec[LW_FSELP], rec[LW_FSELN], lds_f, nullptr, nthr, x0, x1);
+      unsigned long long xf = ((unsigned long long)x1 << 32) | x0;
+      const uint32_t cnt = (uint32_t)__popcll(xf);
+      if (cnt > rec[LW_WMAX]) hard = true;
+      if (hard) continue;  // needs the full kernel: nothing of this row is written here
+      // colex rank of the (<= 5)-subset
+      uint32_t b0 = 0, b1 = 0, b2 = 0, b3 = 0, b4 = 0;
+      if (cnt >= 1) { b0 = (uint32_t)__builtin_ctzll(xf); xf &= xf - 1ull; }
+      if (cnt >= 2) { b1 = (uint32_t)__builtin_ctzll(xf); xf &= xf - 1ull; }
+      if (cnt >= 3) { b2 = (uint32_t)__builtin_ctzll(xf); xf &= xf - 1ull; }
+      if (cnt >= 4) { b3 = (uint32_t)__builtin_ctzll(xf); xf &= xf - 1ull; }
+      if (cnt >= 5) { b4 = (uint32_t)__builtin_ctzll(xf); }
+      const uint32_t base = (cnt == 0) ? 0u : (cnt == 1) ? 1u : (cnt == 2) ? rec[LW_OFF2] : (cnt == 3) ? rec[LW_OFF3]
+                          : (cnt == 4) ? rec[LW_OFF4] : rec[LW_OFF5];
+      const uint32_t pat = base + b0 + (cnt >= 2 ? lw_binom2(b1) : 0u) + (cnt >= 3 ? lw_binom3(b2) : 0u) +
+                           (cnt >= 4 ? lw_binom4(b3) : 0u) + (cnt >= 5 ? lw_binom5(b4) : 0u);
+      const uint32_t n_out = rec[LW_NOUT];
+      cptr outpos = img + rec[LW_OUTPOS];
+      const uint32_t keybase = rec[LW_KEYBASE];
+      const float *thr = L.tab + rec[LW_TAB] + ((size_t)pat << n_out);
+      uint32_t node = 1u;
+      for (uint32_t i = 0; i < n_out; ++i) {
+        const float u = uniform01(subkey(A, keybase + i, 0), subkey(A, keybase + i, 1), shot);  // sampler.py:74-75
+        const bool bit = u < thr[node];
+        node = 2u * node + (bit ? 1u : 0u);
+        const uint32_t dst = outpos[i];
+        const uint32_t v = (bit ? 1u : 0u) << (dst & 31u);
+        if ((dst >> 5) == 0u) o0 |= v;
+        else if ((dst >> 5) == 1u) o1 |= v;
+        else lds_o[(dst >> 5) * nthr] |= v;
+      }
+    }
+    if (!hard) {
+      uint64_t *orow = A.out + row * A.WO;
+      if (A.WO > 0) orow[0] = (uint64_t)o0 | ((uint64_t)o1 << 32);
+      for (int w = 1; w < A.WO; ++w)
+        orow[w] = (uint64_t)lds_o[(2 * w) * nthr] | ((uint64_t)lds_o[(2 * w + 1) * nthr] << 32);
+      if (A.out_compact) {  // words 0 and 1 live in registers here
+        uint8_t *dst = A.out_compact + row * A.out_rb;
+        for (int k = 0; k < A.out_rb; ++k) {
+          const uint32_t wv = (k < 4) ? o0 : (k < 8) ? o1 : lds_o[(k >> 2) * nthr];
+          dst[k] = (uint8_t)(wv >> (8 * (k & 3)));
+        }
+      }
+    }
+  }
+
+  // wave-aggregated append of the hard rows
+  const unsigned long long hm = __ballot(hard ? 1 : 0);
+  if (hm != 0ull) {
+    const int lane = (int)(threadIdx.x & 63u);
+    const int leader = __builtin_ctzll(hm);
+    uint32_t basei = 0;
+    const uint32_t k = blockIdx.x % (uint32_t)L.n_lists;  // this block's sub-list
+    if (lane == leader) basei = atomicAdd(&L.ctl[32u * k], (uint32_t)__popcll(hm));
+    basei = (uint32_t)__shfl((int)basei, leader, 64);
+    if (hard)
+      L.hard_index[(size_t)k * L.list_cap + basei + (uint32_t)__popcll(hm & ((1ull << lane) - 1ull))] = (uint32_t)row;
+  }
+}
+
+}  // namespace tsimk

@@ -1,0 +1,116 @@
+// tsim_noise.hip - device-side channel sampler (statistical twin of ChannelSampler.sample).
+#include "tsim_internal.hip.h"
+#include "tsim_noise.hip.h"
+
+using namespace tsimk;
+
+// ---------------------------------------------------------------------------
+// device-side noise sampler (statistical twin of ChannelSampler.sample)
+// ---------------------------------------------------------------------------
+struct tsim_noise {
+  tsim_program *prog = nullptr;
+  int device = -1;  // copy of prog->device: destroy must not touch the program handle
+  int num_f = 0, n_ch = 0, WF = 0, seg = 4096;
+  double *d_l1p = nullptr;
+  uint32_t *d_off = nullptr;
+  float *d_cdf = nullptr;
+  uint64_t *d_pat = nullptr;
+};
+
+extern "C" int tsim_noise_create(tsim_program *p, int32_t num_f, int32_t n_channels, const double *p_fire,
+                                 const int32_t *n_outcomes, const double *cond_cdf, const uint8_t *xor_patterns,
+                                 tsim_noise **out) {
+  if (int r = tsim_need_final(p)) return r;
+  if (int r = tsim_set_device(p)) return r;
+  if (!out || num_f < 0 || n_channels < 0) return tsim_fail(TSIM_EINVAL, "bad argument");
+  if (n_channels > 0 && (!p_fire || !n_outcomes || !cond_cdf || (num_f > 0 && !xor_patterns)))
+    return tsim_fail(TSIM_EINVAL, "NULL channel table");
+  tsim_noise *n = new (std::nothrow) tsim_noise();
+  if (!n) return tsim_fail(TSIM_ENOMEM, "out of host memory");
+  n->prog = p;
+  n->device = p->device;
+  n->num_f = num_f;
+  n->n_ch = n_channels;
+  n->WF = std::max(1, (num_f + 63) / 64);
+  std::vector<double> l1p((size_t)std::max(1, n_channels));
+  std::vector<uint32_t> off((size_t)n_channels + 1, 0u);
+  double pmax = 1e-9;
+  for (int c = 0; c < n_channels; ++c) {
+    if (!(p_fire[c] > 0.0) || p_fire[c] > 1.0 || n_outcomes[c] < 1) {
+      delete n;
+      return tsim_fail(TSIM_EINVAL, "channel %d: p_fire=%g, outcomes=%d", c, p_fire[c], n_outcomes[c]);
+    }
+    l1p[c] = p_fire[c] >= 1.0 ? 0.0 : log1p(-p_fire[c]);
+    off[c + 1] = off[c] + (uint32_t)n_outcomes[c];
+    pmax = std::max(pmax, p_fire[c]);
+  }
+  const size_t tot = off[n_channels];
+  std::vector<float> cdf(std::max<size_t>(1, tot));
+  for (size_t i = 0; i < tot; ++i) cdf[i] = (float)cond_cdf[i];
+  std::vector<uint64_t> pat(std::max<size_t>(1, tot * n->WF), 0ull);
+  for (size_t o = 0; o < tot; ++o)
+    for (int i = 0; i < num_f; ++i)
+      if (xor_patterns[o * (size_t)num_f + i]) pat[o * n->WF + (i >> 6)] |= 1ull << (i & 63);
+  // segment length: about 8 expected fires of the most active channel per thread
+  int seg = 64;
+  while (seg < 65536 && seg * pmax < 8.0) seg *= 2;
+  n->seg = seg;
+  hipError_t e = hipSuccess;
+  if ((e = hipMalloc((void **)&n->d_l1p, l1p.size() * 8)) != hipSuccess ||
+      (e = hipMalloc((void **)&n->d_off, off.size() * 4)) != hipSuccess ||
+      (e = hipMalloc((void **)&n->d_cdf, cdf.size() * 4)) != hipSuccess ||
+      (e = hipMalloc((void **)&n->d_pat, pat.size() * 8)) != hipSuccess) {
+    tsim_noise_destroy(n);
+    return tsim_fail(TSIM_ENOMEM, "hipMalloc failed: %s", hipGetErrorString(e));
+  }
+  if ((e = hipMemcpy(n->d_l1p, l1p.data(), l1p.size() * 8, hipMemcpyHostToDevice)) != hipSuccess ||
+      (e = hipMemcpy(n->d_off, off.data(), off.size() * 4, hipMemcpyHostToDevice)) != hipSuccess ||
+      (e = hipMemcpy(n->d_cdf, cdf.data(), cdf.size() * 4, hipMemcpyHostToDevice)) != hipSuccess ||
+      (e = hipMemcpy(n->d_pat, pat.data(), pat.size() * 8, hipMemcpyHostToDevice)) != hipSuccess) {
+    tsim_noise_destroy(n);
+    return tsim_fail(TSIM_EHIP, "hipMemcpy failed: %s", hipGetErrorString(e));
+  }
+  *out = n;
+  return TSIM_OK;
+}
+
+extern "C" int tsim_noise_sample_device(tsim_noise *n, int64_t B, uint32_t key_hi, uint32_t key_lo, uint64_t *d_f,
+                                        void *stream) {
+  if (!n || !n->prog) return tsim_fail(TSIM_EINVAL, "noise sampler is NULL");
+  if (int r = tsim_set_device(n->prog)) return r;
+  if (B < 0) return tsim_fail(TSIM_EINVAL, "negative B");
+  if (B == 0) return TSIM_OK;
+  if (!d_f) return tsim_fail(TSIM_EINVAL, "f buffer is NULL");
+  hipStream_t s = stream ? (hipStream_t)stream : n->prog->stream;
+  HIP_TRY(hipMemsetAsync(d_f, 0, (size_t)B * n->WF * 8, s));
+  if (n->n_ch == 0) return TSIM_OK;
+  NoiseArgs a;
+  a.log1m_p = n->d_l1p;
+  a.cdf_off = n->d_off;
+  a.cdf = n->d_cdf;
+  a.patterns = n->d_pat;
+  a.f = (unsigned long long *)d_f;
+  a.B = B;
+  a.n_ch = n->n_ch;
+  a.WF = n->WF;
+  a.seg = n->seg;
+  a.n_seg = (B + n->seg - 1) / n->seg;
+  a.k0 = key_hi;
+  a.k1 = key_lo;
+  const long long total = (long long)a.n_ch * a.n_seg;
+  const long long grid = (total + 255) / 256;
+  if (grid > 0x7FFFFFFFll) return tsim_fail(TSIM_ENOTSUP, "noise launch too large");
+  hipLaunchKernelGGL(k_noise, dim3((unsigned)grid), dim3(256), 0, s, a);
+  HIP_TRY(hipGetLastError());
+  return TSIM_OK;
+}
+
+extern "C" void tsim_noise_destroy(tsim_noise *n) {
+  if (!n) return;
+  if (n->device >= 0) (void)hipSetDevice(n->device);
+  if (n->d_l1p) (void)hipFree(n->d_l1p);
+  if (n->d_off) (void)hipFree(n->d_off);
+  if (n->d_cdf) (void)hipFree(n->d_cdf);
+  if (n->d_pat) (void)hipFree(n->d_pat);
+  delete n;
+}

@@ -1,0 +1,662 @@
+// tsim_pack.hip - the packer: reference-layout level descriptions -> device image pieces (host only).
+//
+//   pack_level       faithful layout: the reference's rows, one meta word each, exact no-ops dropped
+//   pack_level_fast  exact-value formulation: NodePhases class counting, the phase exponent as a
+//                    Dickson-reduced GF(2) quadratic form, pack-time Z[w] term tables
+//   emit_level4      4-bit chunk tables / sparse-f column tables of the LDS kernel (k_sample4)
+//   emit_gather_program  bit-field runs of the first pass (k_sample_lw)
+#include "tsim_internal.hip.h"
+
+using namespace tsimk;
+
+namespace tsimhost {
+
+// pack one byte-per-bit row into W 32-bit words appended to `dst`; returns true if any bit set
+static bool pack_row(std::vector<uint32_t> &dst, const uint8_t *bits, int P, int W) {
+  bool any = false;
+  size_t base = dst.size();
+  dst.resize(base + W, 0u);
+  for (int i = 0; i < P; ++i)
+    if (bits[i] & 1) {  // reference bit-matrices hold 0/1 (compile.py:40-238)
+      dst[base + (i >> 5)] |= 1u << (i & 31);
+      any = true;
+    }
+  return any;
+}
+
+static const int8_t kUnit[8][4] = {{1, 0, 0, 0}, {0, 1, 0, 0},  {0, 0, 1, 0},  {0, 0, 0, -1},
+                                   {-1, 0, 0, 0}, {0, -1, 0, 0}, {0, 0, -1, 0}, {0, 0, 0, 1}};
+
+// Build graph records + rows for a level with W words per row.
+void pack_level(HostLevel &h, int W) {
+  const int G = h.G, P = h.P;
+  const tsim_level_desc &d = h.d;
+  h.graph_rec.assign((size_t)G * G_WORDS, 0u);
+  h.rows.clear();
+  h.n_rows = 0;
+  std::vector<uint32_t> tmp;
+  for (int g = 0; g < G; ++g) {
+    uint32_t *rec = &h.graph_rec[(size_t)g * G_WORDS];
+    rec[G_ROWS] = (uint32_t)h.rows.size();
+    // A: the first counts[g] slots are real (terms.py:70-71)
+    const int nA = d.ta ? h.i32[0][g] : 0;
+    for (int t = 0; t < nA; ++t) {
+      h.rows.push_back((uint32_t)(h.u8[0][(size_t)g * d.ta + t] & 7));
+      pack_row(h.rows, &h.u8[1][((size_t)g * d.ta + t) * P], P, W);
+    }
+    rec[G_NA] = (uint32_t)nA;
+    // B: zero coefficient or empty parity contributes exponent 0 (terms.py:104-106) -> dropped
+    int nB = 0;
+    for (int t = 0; t < d.tb; ++t) {
+      const uint32_t coeff = h.u8[2][(size_t)g * d.tb + t] & 7u;  // (rowsum*coeff) % 8
+      if (!coeff) continue;
+      tmp.clear();
+      if (!pack_row(tmp, &h.u8[3][((size_t)g * d.tb + t) * P], P, W)) continue;
+      h.rows.push_back(coeff);
+      h.rows.insert(h.rows.end(), tmp.begin(), tmp.end());
+      ++nB;
+    }
+    rec[G_NB] = (uint32_t)nB;
+    // C: a slot whose psi or phi is identically 0 contributes (-1)^0 (terms.py:136-141) -> dropped
+    int nC = 0;
+    for (int t = 0; t < d.tc; ++t) {
+      const uint32_t pc = h.u8[4][(size_t)g * d.tc + t] & 1u, qc = h.u8[6][(size_t)g * d.tc + t] & 1u;
+      std::vector<uint32_t> r1, r2;
+      const bool any1 = pack_row(r1, &h.u8[5][((size_t)g * d.tc + t) * P], P, W);
+      const bool any2 = pack_row(r2, &h.u8[7][((size_t)g * d.tc + t) * P], P, W);
+      if ((!any1 && !pc) || (!any2 && !qc)) continue;
+      h.rows.push_back(pc | (qc << 1));
+      h.rows.insert(h.rows.end(), r1.begin(), r1.end());
+      h.rows.insert(h.rows.end(), r2.begin(), r2.end());
+      ++nC;
+    }
+    rec[G_NC] = (uint32_t)nC;
+    // D: first counts[g] slots are real; the four possible term values are tabulated
+    const int nD = d.td ? h.i32[1][g] : 0;
+    for (int t = 0; t < nD; ++t) {
+      const int al = h.u8[8][(size_t)g * d.td + t] & 7, be = h.u8[10][(size_t)g * d.td + t] & 7;
+      for (int idx = 0; idx < 4; ++idx) {
+        const int pa = idx & 1, pb = idx >> 1;
+        const int a1 = (al + 4 * pa) & 7, b1 = (be + 4 * pb) & 7, g1 = (a1 + b1) & 7;
+        uint32_t w = 0;
+        for (int j = 0; j < 4; ++j) {
+          const int v = (j == 0 ? 1 : 0) + kUnit[a1][j] + kUnit[b1][j] - kUnit[g1][j];
+          w |= (uint32_t)(uint8_t)(int8_t)v << (8 * j);
+        }
+        h.rows.push_back(w);
+      }
+      pack_row(h.rows, &h.u8[9][((size_t)g * d.td + t) * P], P, W);
+      pack_row(h.rows, &h.u8[11][((size_t)g * d.td + t) * P], P, W);
+    }
+    rec[G_ND] = (uint32_t)nD;
+    h.n_rows += nA + nB + 2 * nC + 2 * nD;
+    rec[G_PHASE] = h.u8[12][g] & 7u;
+    const int32_t *ff = &h.i32[2][(size_t)g * 4];
+    rec[G_FFA] = (uint32_t)ff[0]; rec[G_FFB] = (uint32_t)ff[1];
+    rec[G_FFC] = (uint32_t)ff[2]; rec[G_FFD] = (uint32_t)ff[3];
+    rec[G_POW2] = (uint32_t)h.i32[3][g];
+    memcpy(&rec[G_APRE], &h.approx_v[2 * (size_t)g], 4);
+    memcpy(&rec[G_APIM], &h.approx_v[2 * (size_t)g + 1], 4);
+    rec[G_FLAGS] = (ff[0] == 1 && ff[1] == 0 && ff[2] == 0 && ff[3] == 0) ? TSIMK_GFLAG_FF_IS_ONE : 0u;
+  }
+}
+
+// exact element of Z[w] * 2^p on basis (1, w, i, conj w), int64 coefficients, kept canonical
+struct ZW {
+  long long c[4];
+  int p;
+};
+
+static void zw_canon(ZW &z) {
+  if (!(z.c[0] | z.c[1] | z.c[2] | z.c[3])) return;
+  while (!((z.c[0] | z.c[1] | z.c[2] | z.c[3]) & 1)) {
+    for (auto &v : z.c) v >>= 1;
+    ++z.p;
+  }
+}
+
+static void zw_mul(ZW &x, const long long y[4]) {  // exact_scalar.py:19-39, then canonicalise
+  const long long a1 = x.c[0], b1 = x.c[1], c1 = x.c[2], d1 = x.c[3];
+  const long long a2 = y[0], b2 = y[1], c2 = y[2], d2 = y[3];
+  x.c[0] = a1 * a2 + b1 * d2 - c1 * c2 + d1 * b2;
+  x.c[1] = a1 * b2 + b1 * a2 + c1 * d2 + d1 * c2;
+  x.c[2] = a1 * c2 + b1 * b2 + c1 * a2 - d1 * d2;
+  x.c[3] = a1 * d2 - b1 * c2 - c1 * b2 + d1 * a2;
+  zw_canon(x);
+}
+
+static void unit_plus_one(int k, long long out[4]) {  // 1 + w^k
+  for (int j = 0; j < 4; ++j) out[j] = kUnit[k & 7][j];
+  out[0] += 1;
+}
+
+// ---- GF(2) algebra used by the fast packer -------------------------------------------------
+// An affine form c ^ <m, x> over the level's P parameters.
+struct Affine {
+  std::vector<uint64_t> m;
+  bool c = false;
+};
+
+static Affine affine_from(const uint8_t *bits, int P, bool c) {
+  Affine a;
+  a.m.assign((size_t)(P + 63) / 64 + 1, 0ull);
+  for (int i = 0; i < P; ++i)
+    if (bits[i] & 1) a.m[i >> 6] ^= 1ull << (i & 63);
+  a.c = c;
+  return a;
+}
+
+// A quadratic form over GF(2): q(x) = sum_{i<j} B[i][j] x_i x_j  ^  <lin, x>  ^  c.
+// B is kept symmetric with zero diagonal (x_i^2 = x_i goes to `lin`).
+struct QForm {
+  int P = 0, PW = 0;
+  std::vector<uint64_t> B;  // P rows x PW words
+  std::vector<uint64_t> lin;
+  bool c = false;
+  explicit QForm(int p) : P(p), PW((p + 63) / 64 + 1), B((size_t)p * ((p + 63) / 64 + 1), 0ull), lin((p + 63) / 64 + 1, 0ull) {}
+  uint64_t *row(int i) { return &B[(size_t)i * PW]; }
+  void add_linear(const Affine &a) {
+    for (int w = 0; w < PW && w < (int)a.m.size(); ++w) lin[w] ^= a.m[w];
+    c ^= a.c;
+  }
+  // q ^= (a.c ^ <a.m,x>) * (b.c ^ <b.m,x>)
+  void add_product(const Affine &a, const Affine &b) {
+    for (int i = 0; i < P; ++i) {
+      if (!((a.m[i >> 6] >> (i & 63)) & 1)) continue;
+      uint64_t *ri = row(i);
+      for (int w = 0; w < PW && w < (int)b.m.size(); ++w) ri[w] ^= b.m[w];  // row i ^= b (may set the diagonal)
+    }
+    // symmetrise: the loop above added the ordered pairs (i in a, j in b); fold (i,j) and (j,i) together
+    // by rebuilding the symmetric part lazily in `finish()`.
+    if (a.c) for (int w = 0; w < PW && w < (int)b.m.size(); ++w) lin[w] ^= b.m[w];
+    if (b.c) for (int w = 0; w < PW && w < (int)a.m.size(); ++w) lin[w] ^= a.m[w];
+    c ^= (a.c && b.c);
+  }
+  // After all add_product calls B holds an arbitrary (non-symmetric) bilinear matrix M with
+  // q = x^T M x.  Convert to the canonical alternating form: B'[i][j] = M[i][j] ^ M[j][i], diagonal -> lin.
+  void finish() {
+    for (int i = 0; i < P; ++i)
+      if ((row(i)[i >> 6] >> (i & 63)) & 1) {
+        lin[i >> 6] ^= 1ull << (i & 63);
+        row(i)[i >> 6] ^= 1ull << (i & 63);
+      }
+    for (int i = 0; i < P; ++i)
+      for (int j = i + 1; j < P; ++j) {
+        const bool mij = (row(i)[j >> 6] >> (j & 63)) & 1, mji = (row(j)[i >> 6] >> (i & 63)) & 1;
+        const bool s = mij ^ mji;
+        if (mij != s) row(i)[j >> 6] ^= 1ull << (j & 63);
+        if (mji != s) row(j)[i >> 6] ^= 1ull << (i & 63);
+      }
+  }
+  bool get(int i, int j) { return (row(i)[j >> 6] >> (j & 63)) & 1; }
+};
+
+// Dickson reduction: q = XOR_s <u_s,x><v_s,x> ^ <lin,x> ^ c with rank(B)/2 product pairs.
+// Pivot on (i,j) with B[i][j] = 1: with alpha = B[i] \ {i,j}, beta = B[j] \ {i,j},
+//   x_i x_j ^ x_i<alpha,x> ^ x_j<beta,x> = (x_i ^ <beta,x>)(x_j ^ <alpha,x>) ^ <alpha,x><beta,x>.
+static void dickson_reduce(QForm &q, std::vector<std::vector<uint64_t>> &us, std::vector<std::vector<uint64_t>> &vs) {
+  const int P = q.P, PW = q.PW;
+  for (int i = 0; i < P; ++i) {
+    for (;;) {
+      int j = -1;
+      for (int t = 0; t < P; ++t)
+        if (q.get(i, t)) { j = t; break; }
+      if (j < 0) break;
+      std::vector<uint64_t> alpha(q.row(i), q.row(i) + PW), beta(q.row(j), q.row(j) + PW);
+      alpha[j >> 6] &= ~(1ull << (j & 63));  // B[i][i] is 0 already
+      beta[i >> 6] &= ~(1ull << (i & 63));
+      std::vector<uint64_t> u = beta, v = alpha;
+      u[i >> 6] ^= 1ull << (i & 63);
+      v[j >> 6] ^= 1ull << (j & 63);
+      us.push_back(u);
+      vs.push_back(v);
+      // remove variables i and j from B
+      for (int w = 0; w < PW; ++w) q.row(i)[w] = q.row(j)[w] = 0ull;
+      for (int k = 0; k < P; ++k) {
+        q.row(k)[i >> 6] &= ~(1ull << (i & 63));
+        q.row(k)[j >> 6] &= ~(1ull << (j & 63));
+      }
+      // q ^= <alpha,x><beta,x>: B[k][l] ^= alpha_k beta_l ^ alpha_l beta_k ; lin_k ^= alpha_k beta_k
+      for (int k = 0; k < P; ++k) {
+        const bool ak = (alpha[k >> 6] >> (k & 63)) & 1, bk = (beta[k >> 6] >> (k & 63)) & 1;
+        if (ak) for (int w = 0; w < PW; ++w) q.row(k)[w] ^= beta[w];
+        if (bk) for (int w = 0; w < PW; ++w) q.row(k)[w] ^= alpha[w];
+        if (ak && bk) q.lin[k >> 6] ^= 1ull << (k & 63);
+        q.row(k)[k >> 6] &= ~(1ull << (k & 63));  // diagonal stays zero
+      }
+    }
+  }
+}
+
+static bool push_mask_row(std::vector<uint32_t> &dst, const std::vector<uint64_t> &m, int P, int W) {
+  bool any = false;
+  const size_t base = dst.size();
+  dst.resize(base + W, 0u);
+  for (int i = 0; i < P; ++i)
+    if ((m[i >> 6] >> (i & 63)) & 1) {
+      dst[base + (i >> 5)] |= 1u << (i & 31);
+      any = true;
+    }
+  return any;
+}
+
+// Can this level be evaluated by the counting formulation?  (see eval_level_fast)
+bool level_fast_eligible(const HostLevel &h) {
+  const tsim_level_desc &d = h.d;
+  for (int g = 0; g < h.G; ++g) {
+    const int nA = d.ta ? h.i32[0][g] : 0;
+    if (nA > 30) return false;  // beyond this the reference's own int32 scan may wrap
+    for (int t = 0; t < d.tb; ++t) {
+      const unsigned c = h.u8[2][(size_t)g * d.tb + t] & 7u;
+      if (c & 1u) return false;  // odd eighth-turn coefficients never come out of the compiler
+    }
+    if (d.td > 60000 || h.P > 60000) return false;
+    for (int j = 0; j < 4; ++j)
+      if (std::llabs((long long)h.i32[2][(size_t)g * 4 + j]) > (1ll << 20)) return false;
+  }
+  return true;
+}
+
+// Build graph records + rows + NodePhases tables for eval_level_fast.  Returns false if a table
+// entry does not fit int32 (the caller then falls back to the faithful layout).
+//
+// Per graph the w-exponent contributed by HalfPi rows (coefficients 2,4,6), PiProducts and the
+// (-i)^(m1+m2+m3) of the NodePhases is rewritten at pack time as
+//     k(x) = k0 + 2 * <lam, x> + 4 * ( <lin, x> ^ XOR_s <u_s,x><v_s,x> )          (mod 8)
+// using  2*(sum of bits p_t) = 2*(XOR p_t) + 4*e2(p)  (mod 8)  for the list of bits that enter with
+// coefficient 2 (coefficient 6 = 2 + 4), e2 = second elementary symmetric polynomial, and the Dickson
+// normal form of the resulting GF(2) quadratic form.  k0 is folded into the table as a rotation.
+bool pack_level_fast(HostLevel &h, int W, std::vector<uint32_t> &tables, bool &fixed_out, int &frame_out) {
+  const int G = h.G, P = h.P;
+  const tsim_level_desc &d = h.d;
+  h.graph_rec.assign((size_t)G * G_WORDS, 0u);
+  h.rows.clear();
+  h.n_rows = 0;
+  tables.clear();
+  fixed_out = false;
+  frame_out = 0;
+  std::vector<std::vector<ZW>> entries((size_t)G);   // per graph: the main table (entry 0 excluded)
+  std::vector<std::vector<ZW>> dentries((size_t)G);  // per graph: the separate PhasePairs table, if any
+  h.fg.assign((size_t)G, FastGraph());
+  for (int g = 0; g < G; ++g) {
+    FastGraph &fg = h.fg[(size_t)g];
+    uint32_t *rec = &h.graph_rec[(size_t)g * G_WORDS];
+    rec[GF_ROWS] = (uint32_t)h.rows.size();
+    const int nA = d.ta ? h.i32[0][g] : 0;
+    std::vector<Affine> two;  // bits entering the exponent with coefficient 2
+    QForm q4(P);              // bit entering with coefficient 4
+    int k0 = h.u8[12][g] & 7; // static phase
+    auto add_six = [&](const Affine &a) {  // 6*p = 2*p + 4*p
+      two.push_back(a);
+      q4.add_linear(a);
+    };
+    // ---- NodePhases rows counted per class 0, 1, 3 (class 2 only feeds the exponent)
+    int n[4] = {0, 0, 0, 0};
+    for (int cls = 0; cls < 4; ++cls)
+      for (int t = 0; t < nA; ++t) {
+        const unsigned ph = h.u8[0][(size_t)g * d.ta + t] & 7u;
+        if ((int)(ph & 3u) != cls) continue;
+        const uint8_t *bits = &h.u8[1][((size_t)g * d.ta + t) * P];
+        ++n[cls];
+        if (cls != 0) add_six(affine_from(bits, P, (ph >> 2) != 0));  // (-i)^(par')
+        if (cls == 2) continue;
+        h.rows.push_back(ph >> 2);
+        pack_row(h.rows, bits, P, W);
+        auto &dstm = cls == 0 ? fg.c0 : (cls == 1 ? fg.c1 : fg.c3);
+        auto &dstc = cls == 0 ? fg.c0c : (cls == 1 ? fg.c1c : fg.c3c);
+        dstm.push_back(affine_from(bits, P, false).m);
+        dstc.push_back((uint8_t)(ph >> 2));
+      }
+    rec[GF_N01] = (uint32_t)n[0] | ((uint32_t)n[1] << 16);
+    fg.n1 = n[1];
+    rec[GF_N1] = (uint32_t)n[1];
+    // ---- PhasePairs rows: two table-index bits per term when the combined table stays small,
+    //      else the faithful sequential scan (rows carry the four tabulated term values)
+    const int nD = d.td ? h.i32[1][g] : 0;
+    if (nD > 5) return false;  // 4^nD table entries: beyond this use the faithful layout
+    const long long combos = (long long)(n[1] + n[3] + 1) << (2 * nD);
+    static const long long kMaxCombined = getenv("TSIM_AMD_COMBINED") ? atoll(getenv("TSIM_AMD_COMBINED")) : 1024;
+    const bool d_tabled = nD > 0 && combos <= kMaxCombined;   // combined table, else a separate one
+    std::vector<std::array<std::array<int, 4>, 4>> dterm((size_t)nD);  // [t][pa + 2 pb] -> term value
+    for (int t = 0; t < nD; ++t) {
+      const int al = h.u8[8][(size_t)g * d.td + t] & 7, be = h.u8[10][(size_t)g * d.td + t] & 7;
+      for (int idx = 0; idx < 4; ++idx) {
+        const int pa = idx & 1, pb = idx >> 1;
+        const int a1 = (al + 4 * pa) & 7, b1 = (be + 4 * pb) & 7, g1 = (a1 + b1) & 7;
+        uint32_t w = 0;
+        for (int j = 0; j < 4; ++j) {
+          const int v = (j == 0 ? 1 : 0) + kUnit[a1][j] + kUnit[b1][j] - kUnit[g1][j];
+          dterm[t][idx][j] = v;
+          w |= (uint32_t)(uint8_t)(int8_t)v << (8 * j);
+        }
+        (void)w;
+      }
+      pack_row(h.rows, &h.u8[9][((size_t)g * d.td + t) * P], P, W);
+      pack_row(h.rows, &h.u8[11][((size_t)g * d.td + t) * P], P, W);
+      fg.dal.push_back(affine_from(&h.u8[9][((size_t)g * d.td + t) * P], P, false).m);
+      fg.dbe.push_back(affine_from(&h.u8[11][((size_t)g * d.td + t) * P], P, false).m);
+    }
+    rec[GF_ND] = (uint32_t)nD;
+    fg.nD = nD;
+    fg.d_tabled = d_tabled;
+    // ---- HalfPi rows
+    for (int t = 0; t < d.tb; ++t) {
+      const uint32_t coeff = h.u8[2][(size_t)g * d.tb + t] & 7u;
+      if (!coeff) continue;
+      const Affine a = affine_from(&h.u8[3][((size_t)g * d.tb + t) * P], P, false);
+      if (coeff == 2) two.push_back(a);
+      else if (coeff == 4) q4.add_linear(a);
+      else add_six(a);
+    }
+    // ---- PiProducts: 4 * psi * phi
+    for (int t = 0; t < d.tc; ++t) {
+      const Affine psi = affine_from(&h.u8[5][((size_t)g * d.tc + t) * P], P, h.u8[4][(size_t)g * d.tc + t] & 1u);
+      const Affine phi = affine_from(&h.u8[7][((size_t)g * d.tc + t) * P], P, h.u8[6][(size_t)g * d.tc + t] & 1u);
+      q4.add_product(psi, phi);
+    }
+    // ---- 2 * sum(two) = 2 * XOR(two) + 4 * e2(two)
+    Affine lam;
+    lam.m.assign((size_t)(P + 63) / 64 + 1, 0ull);
+    for (size_t s = 0; s < two.size(); ++s) {
+      for (size_t w = 0; w < lam.m.size(); ++w) lam.m[w] ^= two[s].m[w];
+      lam.c ^= two[s].c;
+      for (size_t t2 = s + 1; t2 < two.size(); ++t2) q4.add_product(two[s], two[t2]);
+    }
+    if (lam.c) {  // 2*(1 ^ y) = 2 + 6*y = 2 + 2*y + 4*y
+      k0 += 2;
+      Affine y = lam;
+      y.c = false;
+      q4.add_linear(y);
+    }
+    q4.finish();
+    std::vector<std::vector<uint64_t>> us, vs;
+    dickson_reduce(q4, us, vs);
+    if (q4.c) k0 += 4;
+    if (us.size() > 60000) return false;
+    // ---- rows: lam, lin, then the product pairs
+    uint32_t flags = d_tabled ? TSIMK_GFLAG_D_TABLED : 0u;
+    {
+      std::vector<uint32_t> tmp;
+      if (push_mask_row(tmp, lam.m, P, W)) { flags |= TSIMK_GFLAG_LAM; h.rows.insert(h.rows.end(), tmp.begin(), tmp.end()); }
+      tmp.clear();
+      if (push_mask_row(tmp, q4.lin, P, W)) { flags |= TSIMK_GFLAG_LIN; h.rows.insert(h.rows.end(), tmp.begin(), tmp.end()); }
+    }
+    for (size_t s = 0; s < us.size(); ++s) {
+      push_mask_row(h.rows, us[s], P, W);
+      push_mask_row(h.rows, vs[s], P, W);
+    }
+    rec[GF_N3H] = (uint32_t)n[3] | ((uint32_t)us.size() << 16);
+    rec[GF_FLAGS] = flags;
+    fg.lam = lam.m;
+    fg.lin = q4.lin;
+    fg.us = us;
+    fg.vs = vs;
+    h.n_rows += n[0] + n[1] + n[3] + ((flags & TSIMK_GFLAG_LAM) ? 1 : 0) + ((flags & TSIMK_GFLAG_LIN) ? 1 : 0) +
+                2 * (long long)us.size() + 2 * nD;
+    // ---- table entries (index: ((delta + n1) << 2 nD | dbits) + 1; entry 0 is the exact zero)
+    //   canon( 2^n0 (1+i)^n2 (1+w)^(n1-m1) (1-w)^m1 (1+w^3)^(n3-m3) (1-w^3)^m3 * i^(m1+m3)
+    //          * floatfactor * w^k0 * [product of the PhasePairs terms selected by dbits] ) * 2^power2
+    //   with m3 = max(delta,0), m1 = max(-delta,0)
+    const long long ff[4] = {h.i32[2][(size_t)g * 4], h.i32[2][(size_t)g * 4 + 1], h.i32[2][(size_t)g * 4 + 2],
+                             h.i32[2][(size_t)g * 4 + 3]};
+    const int ndb = d_tabled ? (1 << (2 * nD)) : 1;
+    for (int delta = -n[1]; delta <= n[3]; ++delta) {
+      const int m3 = delta > 0 ? delta : 0, m1 = delta < 0 ? -delta : 0;
+      ZW z{{1, 0, 0, 0}, 0};
+      long long f[4];
+      auto mul_k = [&](int k, int times) {
+        unit_plus_one(k, f);
+        for (int i = 0; i < times; ++i) zw_mul(z, f);
+      };
+      mul_k(0, n[0]);
+      mul_k(2, n[2]);
+      mul_k(1, n[1] - m1);
+      mul_k(5, m1);
+      mul_k(3, n[3] - m3);
+      mul_k(7, m3);
+      const int r = (2 * (m1 + m3) + k0) & 7;
+      const long long rot[4] = {kUnit[r][0], kUnit[r][1], kUnit[r][2], kUnit[r][3]};
+      zw_mul(z, rot);
+      zw_mul(z, ff);
+      z.p += h.i32[3][g];  // power2
+      for (int db = 0; db < ndb; ++db) {
+        ZW e = z;
+        for (int t = 0; t < nD && d_tabled; ++t) {
+          const int sel = (db >> (2 * (nD - 1 - t))) & 3;  // term 0 holds the most significant pair
+          const long long tv[4] = {dterm[t][sel][0], dterm[t][sel][1], dterm[t][sel][2], dterm[t][sel][3]};
+          zw_mul(e, tv);
+        }
+        for (int j = 0; j < 4; ++j)
+          if (e.c[j] > INT32_MAX || e.c[j] < INT32_MIN) return false;
+        if (!(e.c[0] | e.c[1] | e.c[2] | e.c[3])) e.p = h.approx ? 0 : TSIMK_ZERO_POWER;
+        entries[g].push_back(e);
+      }
+    }
+    if (nD > 0 && !d_tabled) {  // separate PhasePairs table over the 4^nD parity patterns
+      for (int db = 0; db < (1 << (2 * nD)); ++db) {
+        ZW e{{1, 0, 0, 0}, 0};
+        for (int t = 0; t < nD; ++t) {
+          const int sel = (db >> (2 * (nD - 1 - t))) & 3;
+          const long long tv[4] = {dterm[t][sel][0], dterm[t][sel][1], dterm[t][sel][2], dterm[t][sel][3]};
+          zw_mul(e, tv);
+        }
+        dentries[g].push_back(e);
+      }
+    }
+    memcpy(&rec[GF_APRE], &h.approx_v[2 * (size_t)g], 4);
+    memcpy(&rec[GF_APIM], &h.approx_v[2 * (size_t)g + 1], 4);
+  }
+  // ---- fixed frame: every term of the level comes straight from a table and, shifted to the
+  //      level's smallest power, the worst-case sum of all graphs stays inside int32
+  bool fixed = !h.approx && G > 0;
+  int frame = INT32_MAX;
+  if (fixed) {
+    for (auto &ge : entries)
+      for (auto &e : ge)
+        if (e.c[0] | e.c[1] | e.c[2] | e.c[3]) frame = std::min(frame, e.p);
+    if (frame == INT32_MAX) frame = 0;
+    long double total = 0;
+    for (int g = 0; g < G && fixed; ++g) {
+      long double worst = 0;
+      for (auto &e : entries[g]) {
+        if (!(e.c[0] | e.c[1] | e.c[2] | e.c[3])) continue;
+        const int sh = e.p - frame;
+        if (sh > 40) { fixed = false; break; }
+        // a rotation by i permutes/negates coefficients: bound by the largest one
+        long double m = 0;
+        for (auto v : e.c) m = std::max(m, (long double)std::llabs(v));
+        worst = std::max(worst, m * (long double)(1ll << sh));
+      }
+      // separate PhasePairs table: entries become plain integers c * 2^p (p >= 0); the product
+      // with the main entry is a sum of four coefficient products
+      long double dworst = 0;
+      for (auto &e : dentries[g]) {
+        if (e.p < 0 || e.p > 40) { fixed = false; break; }
+        long double m = 0;
+        for (auto v : e.c) m = std::max(m, (long double)std::llabs(v));
+        dworst = std::max(dworst, m * (long double)(1ll << e.p));
+      }
+      if (!dentries[g].empty()) worst = 4 * worst * dworst;
+      total += worst;
+    }
+    if (total >= 2147483000.0L) fixed = false;
+  }
+  for (int g = 0; g < G; ++g) {
+    uint32_t *rec = &h.graph_rec[(size_t)g * G_WORDS];
+    rec[GF_TBL] = (uint32_t)tables.size();
+    if (fixed) {
+      // fixed-frame levels: an entry is 16 words = the value times i^r for r = 0..3 (4 words each),
+      // pre-shifted to the frame power, so the kernel adds the selected rotation without any
+      // per-lane rotate/shift.  Entry 0 is the exact zero.
+      for (int j = 0; j < 16; ++j) tables.push_back(0u);
+      for (auto &e : entries[g]) {
+        const bool nz = (e.c[0] | e.c[1] | e.c[2] | e.c[3]) != 0;
+        const int sh = nz ? e.p - frame : 0;
+        long long v[4] = {e.c[0] * (1ll << sh), e.c[1] * (1ll << sh), e.c[2] * (1ll << sh), e.c[3] * (1ll << sh)};
+        for (int r = 0; r < 4; ++r) {
+          for (int j = 0; j < 4; ++j) tables.push_back((uint32_t)(int32_t)v[j]);
+          const long long t[4] = {-v[2], v[3], v[0], -v[1]};  // times i: (a,b,c,d) -> (-c, d, a, -b)
+          for (int j = 0; j < 4; ++j) v[j] = t[j];
+        }
+      }
+    } else {
+      for (int j = 0; j < 4; ++j) tables.push_back(0u);  // entry 0: exact zero
+      tables.push_back((uint32_t)(h.approx ? 0 : TSIMK_ZERO_POWER));
+      tables.push_back(0u); tables.push_back(0u); tables.push_back(0u);
+      for (auto &e : entries[g]) {
+        for (int j = 0; j < 4; ++j) tables.push_back((uint32_t)(int32_t)e.c[j]);
+        tables.push_back((uint32_t)e.p);
+        tables.push_back(0u); tables.push_back(0u); tables.push_back(0u);
+      }
+    }
+  }
+  for (int g = 0; g < G; ++g) {
+    if (dentries[g].empty()) continue;
+    uint32_t *rec = &h.graph_rec[(size_t)g * G_WORDS];
+    rec[GF_TBL2] = (uint32_t)tables.size();
+    for (auto &e : dentries[g]) {
+      const int sh = fixed ? e.p : 0;
+      for (int j = 0; j < 4; ++j) {
+        const long long v = e.c[j] * (1ll << sh);
+        if (v > INT32_MAX || v < INT32_MIN) return false;
+        tables.push_back((uint32_t)(int32_t)v);
+      }
+      tables.push_back((uint32_t)(fixed ? 0 : e.p));
+      tables.push_back(0u); tables.push_back(0u); tables.push_back(0u);
+    }
+  }
+  fixed_out = fixed;
+  frame_out = fixed ? frame : 0;
+  h.fixed = fixed;
+  h.frame = frame_out;
+  return true;
+}
+
+
+bool level_v4_eligible(const HostLevel &h) {
+  if (h.P > 64) return false;
+  for (const FastGraph &fg : h.fg) {
+    if (fg.us.size() > 32) return false;
+    if (fg.c0.size() + fg.c1.size() + fg.c3.size() > 32) return false;
+    if (2 * fg.nD > 28) return false;
+  }
+  return true;
+}
+
+static inline bool mask_bit(const std::vector<uint64_t> &m, int i) { return (m[(size_t)i >> 6] >> (i & 63)) & 1; }
+
+// recs4: G x G4_WORDS; tabs4: ntiles x nch x 16 x GT x 4 words.  `v3recs` are the level's patched
+// fast-layout graph records (for the term-table offsets and the approximate floatfactors).
+// `stabs4` (optional, sparse_F >= 0): the "sparse f" table of the same tile: one entry per f COLUMN
+// (bits 0..F-1), one all-zero entry, then 2 x 16 entries for the two 4-bit chunks of the output
+// bits F..F+7 (row constants live in the first of them): [tile][entry][graph][4 words].
+void emit_level4(const HostLevel &h, int GT, int nch, const uint32_t *v3recs, std::vector<uint32_t> &recs4,
+                        std::vector<uint32_t> &tabs4, int &nch_out, int &ntiles_out, int sparse_F,
+                        std::vector<uint32_t> &stabs4) {
+  const int G = h.G, P = h.P;
+  const int ntiles = (G + GT - 1) / GT;  // nch: chunks per tile, the same for every level (zero padded)
+  nch_out = nch;
+  ntiles_out = ntiles;
+  recs4.assign((size_t)G * G4_WORDS, 0u);
+  tabs4.assign((size_t)ntiles * nch * 16 * GT * 4, 0u);
+  const int sent = sparse_F >= 0 ? sparse_F + 1 + 32 : 0;
+  stabs4.assign((size_t)ntiles * sent * GT * 4, 0u);
+  std::vector<std::array<uint32_t, 4>> col((size_t)std::max(P, 1));
+  for (int g = 0; g < G; ++g) {
+    const FastGraph &fg = h.fg[(size_t)g];
+    for (auto &c : col) c = {0u, 0u, 0u, 0u};
+    std::array<uint32_t, 4> cst = {0u, 0u, 0u, 0u};
+    auto place = [&](const std::vector<uint64_t> &m, int word, int bit) {
+      for (int i = 0; i < P; ++i)
+        if (mask_bit(m, i)) col[(size_t)i][(size_t)word] |= 1u << bit;
+    };
+    const int h2 = (int)fg.us.size();
+    for (int s = 0; s < h2; ++s) {
+      place(fg.us[(size_t)s], 0, s);
+      place(fg.vs[(size_t)s], 1, s);
+    }
+    uint32_t M0 = 0, M1 = 0, M3 = 0;
+    int b = 0;
+    for (size_t t = 0; t < fg.c0.size(); ++t, ++b) { place(fg.c0[t], 2, b); M0 |= 1u << b; if (fg.c0c[t]) cst[2] |= 1u << b; }
+    for (size_t t = 0; t < fg.c1.size(); ++t, ++b) { place(fg.c1[t], 2, b); M1 |= 1u << b; if (fg.c1c[t]) cst[2] |= 1u << b; }
+    for (size_t t = 0; t < fg.c3.size(); ++t, ++b) { place(fg.c3[t], 2, b); M3 |= 1u << b; if (fg.c3c[t]) cst[2] |= 1u << b; }
+    for (int t = 0; t < fg.nD; ++t) {  // index bits: term 0 holds the most significant pair
+      place(fg.dal[(size_t)t], 3, 2 * (fg.nD - 1 - t));
+      place(fg.dbe[(size_t)t], 3, 2 * (fg.nD - 1 - t) + 1);
+    }
+    place(fg.lam, 3, 30);
+    place(fg.lin, 3, 31);
+    const int tile = g / GT, j = g % GT;
+    for (int c = 0; c < nch; ++c)
+      for (int v = 0; v < 16; ++v) {
+        std::array<uint32_t, 4> val = (c == 0) ? cst : std::array<uint32_t, 4>{0u, 0u, 0u, 0u};
+        for (int bb = 0; bb < 4; ++bb) {
+          const int i = 4 * c + bb;
+          if (!((v >> bb) & 1) || i >= P) continue;
+          for (int w = 0; w < 4; ++w) val[(size_t)w] ^= col[(size_t)i][(size_t)w];
+        }
+        uint32_t *dst = &tabs4[((((size_t)tile * nch + c) * 16 + v) * GT + j) * 4];
+        for (int w = 0; w < 4; ++w) dst[w] = val[(size_t)w];
+      }
+    if (sent) {
+      auto put = [&](int e, const std::array<uint32_t, 4> &val) {
+        uint32_t *dst = &stabs4[(((size_t)tile * sent + e) * GT + j) * 4];
+        for (int w = 0; w < 4; ++w) dst[w] = val[(size_t)w];
+      };
+      for (int i = 0; i < sparse_F && i < P; ++i) put(i, col[(size_t)i]);
+      for (int c = 0; c < 2; ++c)
+        for (int v = 0; v < 16; ++v) {
+          std::array<uint32_t, 4> val = (c == 0) ? cst : std::array<uint32_t, 4>{0u, 0u, 0u, 0u};
+          for (int bb = 0; bb < 4; ++bb) {
+            const int i = sparse_F + 4 * c + bb;
+            if (!((v >> bb) & 1) || i >= P) continue;
+            for (int w = 0; w < 4; ++w) val[(size_t)w] ^= col[(size_t)i][(size_t)w];
+          }
+          put(sparse_F + 1 + 16 * c + v, val);
+        }
+    }
+    uint32_t *r4 = &recs4[(size_t)g * G4_WORDS];
+    const uint32_t *r3 = v3recs + (size_t)g * G_WORDS;
+    r4[G4_M0] = M0; r4[G4_M1] = M1; r4[G4_M3] = M3;
+    r4[G4_PM] = h2 >= 32 ? 0xFFFFFFFFu : ((1u << h2) - 1u);
+    r4[G4_N1] = (uint32_t)fg.n1;
+    r4[G4_DBITS] = (uint32_t)(2 * fg.nD);
+    r4[G4_TBL] = r3[GF_TBL];
+    r4[G4_TBL2] = r3[GF_TBL2];
+    r4[G4_FLAGS] = fg.nD == 0 ? 0u : (fg.d_tabled ? TSIMK_G4FLAG_D_COMBINED : TSIMK_G4FLAG_D_SEPARATE);
+    r4[G4_APRE] = r3[GF_APRE];
+    r4[G4_APIM] = r3[GF_APIM];
+  }
+}
+
+// Gather program (tsim_lw.hip.h): bit moves (src f bit -> dst bit, flip) merged into runs that are
+// contiguous in both the source and the destination word; 4-word runs, padded to chunks of four.
+std::vector<uint32_t> emit_gather_program(std::vector<std::array<int, 3>> e) {
+  std::sort(e.begin(), e.end(), [](const std::array<int, 3> &a, const std::array<int, 3> &b) {
+    if ((a[0] >> 5) != (b[0] >> 5)) return (a[0] >> 5) < (b[0] >> 5);
+    if ((a[1] >> 5) != (b[1] >> 5)) return (a[1] >> 5) < (b[1] >> 5);
+    return a[0] < b[0];
+  });
+  std::vector<uint32_t> out;
+  size_t i = 0;
+  while (i < e.size()) {
+    size_t j = i + 1;
+    while (j < e.size() && e[j][0] == e[j - 1][0] + 1 && e[j][1] == e[j - 1][1] + 1 &&
+           (e[j][0] >> 5) == (e[i][0] >> 5) && (e[j][1] >> 5) == (e[i][1] >> 5))
+      ++j;
+    const int len = (int)(j - i);
+    uint32_t flip = 0;
+    for (size_t k = i; k < j; ++k) flip |= (uint32_t)(e[k][2] & 1) << (k - i);
+    const uint32_t mask = len >= 32 ? 0xFFFFFFFFu : ((1u << len) - 1u);
+    out.push_back((uint32_t)(e[i][0] & 31) | ((uint32_t)(e[i][1] & 31) << 8) | ((uint32_t)(e[i][1] >> 5) << 16) |
+                  ((uint32_t)(e[i][0] >> 5) << 24));
+    out.push_back(mask);
+    out.push_back(flip);
+    out.push_back(0u);
+    i = j;
+  }
+  while (out.size() % 16) out.push_back(0u);  // mask = 0 runs: no-ops
+  return out;
+}
+
+}  // namespace tsimhost

@@ -1,0 +1,755 @@
+// tsim_program.hip - handle life cycle of the C ABI (include/tsim_hip.h): program description ->
+// packed image -> upload, plus the memory / stream plumbing.  No kernels are defined here.
+#include "tsim_internal.hip.h"
+
+using namespace tsimk;
+using namespace tsimhost;
+
+// ---------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+int tsim_fail(int code, const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+extern "C" const char *tsim_last_error(void) { return g_err; }
+extern "C" const char *tsim_version(void) { return "tsim_amd-hip 0.2 (gfx950)"; }
+
+int tsim_set_device(const tsim_program *p) {
+  HIP_TRY(hipSetDevice(p->device));
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// construction
+// ---------------------------------------------------------------------------
+extern "C" int tsim_program_create(int32_t num_outputs, int32_t num_detectors, int32_t n_direct,
+                                   const int32_t *direct_f_indices, const uint8_t *direct_flips,
+                                   const int32_t *output_order, tsim_program **out) {
+  if (!out) return tsim_fail(TSIM_EINVAL, "out is NULL");
+  if (num_outputs < 0 || n_direct < 0 || n_direct > num_outputs || num_detectors < 0)
+    return tsim_fail(TSIM_EINVAL, "bad counts: num_outputs=%d n_direct=%d num_detectors=%d", num_outputs,
+                n_direct, num_detectors);
+  if (n_direct > 0 && (!direct_f_indices || !direct_flips)) return tsim_fail(TSIM_EINVAL, "direct arrays NULL");
+  if (num_outputs > 0 && !output_order) return tsim_fail(TSIM_EINVAL, "output_order is NULL");
+  tsim_program *p = new (std::nothrow) tsim_program();
+  if (!p) return tsim_fail(TSIM_ENOMEM, "out of host memory");
+  p->num_outputs = num_outputs;
+  p->num_detectors = num_detectors;
+  p->n_direct = n_direct;
+  p->direct_f.assign(direct_f_indices, direct_f_indices + n_direct);
+  p->direct_flips.assign(direct_flips, direct_flips + n_direct);
+  p->output_order.assign(output_order, output_order + num_outputs);
+  std::vector<char> seen(num_outputs, 0);
+  for (int i = 0; i < num_outputs; ++i) {
+    int o = p->output_order[i];
+    if (o < 0 || o >= num_outputs || seen[o]) {
+      delete p;
+      return tsim_fail(TSIM_EINVAL, "output_order is not a permutation of 0..%d", num_outputs - 1);
+    }
+    seen[o] = 1;
+  }
+  for (int i = 0; i < n_direct; ++i) {
+    if (p->direct_f[i] < 0) {
+      delete p;
+      return tsim_fail(TSIM_EINVAL, "negative direct_f_indices[%d]", i);
+    }
+    p->max_f_index = std::max(p->max_f_index, p->direct_f[i]);
+  }
+  *out = p;
+  return TSIM_OK;
+}
+
+extern "C" int tsim_program_add_component(tsim_program *p, int32_t n_out, const int32_t *output_indices,
+                                          int32_t F, const int32_t *f_selection, int32_t n_levels) {
+  if (!p) return tsim_fail(TSIM_EINVAL, "program is NULL");
+  if (p->finalized) return tsim_fail(TSIM_ESTATE, "program already finalized");
+  if (n_out < 0 || F < 0) return tsim_fail(TSIM_EINVAL, "negative n_out/F");
+  if (n_levels != n_out + 1 && n_levels != 2)
+    return tsim_fail(TSIM_EINVAL, "component with %d outputs needs %d (sequential) or 2 (joint) levels, got %d",
+                n_out, n_out + 1, n_levels);
+  if ((n_out > 0 && !output_indices) || (F > 0 && !f_selection)) return tsim_fail(TSIM_EINVAL, "NULL index array");
+  HostComponent c;
+  c.n_out = n_out;
+  c.F = F;
+  c.n_levels = n_levels;
+  c.output_indices.assign(output_indices, output_indices + n_out);
+  c.f_selection.assign(f_selection, f_selection + F);
+  for (int i = 0; i < F; ++i) {
+    if (c.f_selection[i] < 0) return tsim_fail(TSIM_EINVAL, "negative f_selection[%d]", i);
+    p->max_f_index = std::max(p->max_f_index, c.f_selection[i]);
+  }
+  p->comps.push_back(std::move(c));
+  return (int)p->comps.size() - 1;
+}
+
+template <class T>
+static void copy_arr(std::vector<T> &dst, const T *src, size_t n) {
+  if (n && src) dst.assign(src, src + n);
+  else dst.assign(n, T());
+}
+
+extern "C" int tsim_program_add_level(tsim_program *p, int32_t component, const tsim_level_desc *L) {
+  if (!p || !L) return tsim_fail(TSIM_EINVAL, "NULL argument");
+  if (p->finalized) return tsim_fail(TSIM_ESTATE, "program already finalized");
+  if (component < 0 || component >= (int)p->comps.size()) return tsim_fail(TSIM_EINVAL, "bad component index %d", component);
+  HostComponent &c = p->comps[component];
+  if ((int)c.levels.size() >= c.n_levels) return tsim_fail(TSIM_EINVAL, "component %d already has all %d levels", component, c.n_levels);
+  const int k = (int)c.levels.size();
+  const bool sequential = (c.n_levels == c.n_out + 1);
+  const int want_P = c.F + (sequential ? k : (k == 0 ? 0 : c.n_out));
+  if (L->n_params != want_P)
+    return tsim_fail(TSIM_EINVAL, "component %d level %d: n_params=%d, expected %d", component, k, L->n_params, want_P);
+  if (L->num_graphs < 0 || L->ta < 0 || L->tb < 0 || L->tc < 0 || L->td < 0) return tsim_fail(TSIM_EINVAL, "negative sizes");
+  if (L->n_params > TSIM_MAX_PARAMS)
+    return tsim_fail(TSIM_ENOTSUP, "n_params=%d exceeds TSIM_MAX_PARAMS=%d", L->n_params, TSIM_MAX_PARAMS);
+  const size_t G = L->num_graphs, P = L->n_params;
+  if (G > 0) {
+    const void *req[] = {L->phase_indices, L->floatfactor, L->power2};
+    for (const void *q : req)
+      if (!q) return tsim_fail(TSIM_EINVAL, "prefactor array is NULL");
+    if ((L->ta && (!L->a_phases || !L->a_counts || (P && !L->a_params))) ||
+        (L->tb && (!L->b_coeffs || (P && !L->b_params))) ||
+        (L->tc && (!L->c_psi_const || !L->c_phi_const || (P && (!L->c_psi_params || !L->c_phi_params)))) ||
+        (L->td && (!L->d_alpha || !L->d_beta || !L->d_counts || (P && (!L->d_alpha_params || !L->d_beta_params)))))
+      return tsim_fail(TSIM_EINVAL, "term array is NULL");
+    if (L->has_approx && !L->approx) return tsim_fail(TSIM_EINVAL, "has_approx set but approx is NULL");
+  }
+  HostLevel h;
+  h.G = (int)G;
+  h.P = (int)P;
+  h.approx = L->has_approx != 0;
+  h.d = *L;
+  copy_arr(h.u8[0], L->a_phases, G * L->ta);
+  copy_arr(h.u8[1], L->a_params, G * L->ta * P);
+  copy_arr(h.u8[2], L->b_coeffs, G * L->tb);
+  copy_arr(h.u8[3], L->b_params, G * L->tb * P);
+  copy_arr(h.u8[4], L->c_psi_const, G * L->tc);
+  copy_arr(h.u8[5], L->c_psi_params, G * L->tc * P);
+  copy_arr(h.u8[6], L->c_phi_const, G * L->tc);
+  copy_arr(h.u8[7], L->c_phi_params, G * L->tc * P);
+  copy_arr(h.u8[8], L->d_alpha, G * L->td);
+  copy_arr(h.u8[9], L->d_alpha_params, G * L->td * P);
+  copy_arr(h.u8[10], L->d_beta, G * L->td);
+  copy_arr(h.u8[11], L->d_beta_params, G * L->td * P);
+  copy_arr(h.u8[12], L->phase_indices, G);
+  copy_arr(h.i32[0], L->a_counts, L->ta ? G : 0);
+  copy_arr(h.i32[1], L->d_counts, L->td ? G : 0);
+  copy_arr(h.i32[2], L->floatfactor, G * 4);
+  copy_arr(h.i32[3], L->power2, G);
+  if (L->approx) copy_arr(h.approx_v, L->approx, G * 2);
+  else { h.approx_v.assign(G * 2, 0.0f); for (size_t g = 0; g < G; ++g) h.approx_v[2 * g] = 1.0f; }
+  for (size_t g = 0; g < G; ++g) {
+    if (L->ta && (h.i32[0][g] < 0 || h.i32[0][g] > L->ta)) return tsim_fail(TSIM_EINVAL, "a_counts[%zu] out of range", g);
+    if (L->td && (h.i32[1][g] < 0 || h.i32[1][g] > L->td)) return tsim_fail(TSIM_EINVAL, "d_counts[%zu] out of range", g);
+  }
+  c.levels.push_back(std::move(h));
+  return TSIM_OK;
+}
+extern "C" int tsim_program_set_mode(tsim_program *p, int32_t mode) {
+  if (!p) return tsim_fail(TSIM_EINVAL, "program is NULL");
+  if (p->finalized) return tsim_fail(TSIM_ESTATE, "program already finalized");
+  if (mode != TSIM_MODE_AUTO && mode != TSIM_MODE_FAITHFUL && mode != TSIM_MODE_ROW_KERNEL)
+    return tsim_fail(TSIM_EINVAL, "bad mode %d", mode);
+  p->mode = mode;
+  return TSIM_OK;
+}
+extern "C" int tsim_program_set_pattern_tables(tsim_program *p, int32_t enable, int32_t max_weight) {
+  if (!p) return tsim_fail(TSIM_EINVAL, "program is NULL");
+  if (p->finalized) return tsim_fail(TSIM_ESTATE, "program already finalized");
+  if (enable < -1 || enable > 1 || max_weight < -1 || max_weight > TSIMK_LW_MAX_WEIGHT)
+    return tsim_fail(TSIM_EINVAL, "bad pattern-table setting (%d, %d)", enable, max_weight);
+  p->lw_request = enable;
+  p->lw_weight_cap = max_weight;
+  return TSIM_OK;
+}
+
+extern "C" int tsim_program_pattern_table_info(const tsim_program *p, int32_t *enabled, int64_t *table_bytes,
+                                               int32_t *max_weight) {
+  if (!p) return tsim_fail(TSIM_EINVAL, "program is NULL");
+  if (!p->finalized) return tsim_fail(TSIM_ESTATE, "program not finalized");
+  if (enabled) *enabled = p->lw ? 1 : 0;
+  if (table_bytes) *table_bytes = p->lw ? p->lw_bytes : 0;
+  if (max_weight)
+    for (size_t i = 0; i < p->comps.size(); ++i) max_weight[i] = p->lw ? p->lw_wmax[i] : -1;
+  return TSIM_OK;
+}
+// ---------------------------------------------------------------------------
+// low-weight pattern tables (tsim_lw.hip.h): enumerate the patterns of every component in table
+// order and let k_lw_build fill the thresholds with the sampling kernels' own arithmetic
+// ---------------------------------------------------------------------------
+static int build_pattern_tables(tsim_program *p, const std::vector<long long> &npat) {
+  HIP_TRY(hipMalloc((void **)&p->d_lw_tab, std::max<size_t>(16, (size_t)p->lw_bytes)));
+  long long tab_off = 0;
+  for (size_t ci = 0; ci < p->comps.size(); ++ci) {
+    const HostComponent &c = p->comps[ci];
+    const int F = c.F, wmax = p->lw_wmax[ci];
+    std::vector<unsigned long long> pats;
+    pats.reserve((size_t)npat[ci]);
+    pats.push_back(0ull);
+    if (wmax >= 1)
+      for (int b0 = 0; b0 < F; ++b0) pats.push_back(1ull << b0);
+    if (wmax >= 2)
+      for (int b1 = 1; b1 < F; ++b1)
+        for (int b0 = 0; b0 < b1; ++b0) pats.push_back((1ull << b1) | (1ull << b0));
+    if (wmax >= 3)
+      for (int b2 = 2; b2 < F; ++b2)
+        for (int b1 = 1; b1 < b2; ++b1)
+          for (int b0 = 0; b0 < b1; ++b0) pats.push_back((1ull << b2) | (1ull << b1) | (1ull << b0));
+    if (wmax >= 4)
+      for (int b3 = 3; b3 < F; ++b3)
+        for (int b2 = 2; b2 < b3; ++b2)
+          for (int b1 = 1; b1 < b2; ++b1)
+            for (int b0 = 0; b0 < b1; ++b0)
+              pats.push_back((1ull << b3) | (1ull << b2) | (1ull << b1) | (1ull << b0));
+    if (wmax >= 5)
+      for (int b4 = 4; b4 < F; ++b4)
+        for (int b3 = 3; b3 < b4; ++b3)
+          for (int b2 = 2; b2 < b3; ++b2)
+            for (int b1 = 1; b1 < b2; ++b1)
+              for (int b0 = 0; b0 < b1; ++b0)
+                pats.push_back((1ull << b4) | (1ull << b3) | (1ull << b2) | (1ull << b1) | (1ull << b0));
+    if ((long long)pats.size() != npat[ci]) return tsim_fail(TSIM_ESTATE, "pattern enumeration mismatch");
+    unsigned long long *d_pats = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_pats, pats.size() * 8));
+    HIP_TRY(hipMemcpy(d_pats, pats.data(), pats.size() * 8, hipMemcpyHostToDevice));
+    LwBuildArgs a;
+    a.img = p->d_img;
+    a.patbits = d_pats;
+    a.tab = p->d_lw_tab + tab_off;
+    a.comp_off = p->comp_off + (int)ci * C_WORDS;
+    a.npat = (int)npat[ci];
+    const long long lanes = npat[ci] << c.n_out;
+    if (int r = tsim_launch_lw_build(p->comp_w[ci], p->fast, a, lanes, p->stream)) {
+      (void)hipFree(d_pats);
+      return r;
+    }
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
+    (void)hipFree(d_pats);
+    if (e != hipSuccess) return tsim_fail(TSIM_EHIP, "pattern table build failed: %s", hipGetErrorString(e));
+    tab_off += lanes;
+  }
+  if (p->v4) {
+    void *h = nullptr;
+    if (hipHostMalloc(&h, 64, hipHostMallocMapped) == hipSuccess) {
+      void *d = nullptr;
+      if (hipHostGetDevicePointer(&d, h, 0) == hipSuccess) {
+        p->h_feedback = (volatile uint32_t *)h;
+        p->d_feedback = (uint32_t *)d;
+        for (int i = 0; i < 16; ++i) p->h_feedback[i] = 0xFFFFFFFFu;
+      } else {
+        (void)hipHostFree(h);
+      }
+    }
+    (void)hipGetLastError();  // feedback is optional: without it every launch takes the default plan
+  }
+  return 0;
+}
+
+extern "C" int tsim_program_finalize(tsim_program *p, int32_t device) {
+  if (!p) return tsim_fail(TSIM_EINVAL, "program is NULL");
+  if (p->finalized) return tsim_fail(TSIM_ESTATE, "program already finalized");
+  // ---- choose the evaluation formulation ----
+  {
+    const char *env = getenv("TSIM_AMD_MODE");
+    bool fast = (p->mode != TSIM_MODE_FAITHFUL) && !(env && strcmp(env, "faithful") == 0);
+    for (auto &c : p->comps)
+      for (auto &lv : c.levels) fast = fast && level_fast_eligible(lv);
+    p->fast = fast;
+  }
+retry_pack:
+  // ---- validate the output bookkeeping (pipeline.py:83-102) ----
+  int pos = p->n_direct;
+  for (size_t ci = 0; ci < p->comps.size(); ++ci) {
+    HostComponent &c = p->comps[ci];
+    if ((int)c.levels.size() != c.n_levels)
+      return tsim_fail(TSIM_EINVAL, "component %zu has %zu of %d levels", ci, c.levels.size(), c.n_levels);
+    for (int j = 0; j < c.n_out; ++j) {
+      if (pos >= p->num_outputs || p->output_order[pos] != c.output_indices[j])
+        return tsim_fail(TSIM_EINVAL, "output_order[%d] does not match component %zu output %d", pos, ci, j);
+      ++pos;
+    }
+  }
+  if (pos != p->num_outputs)
+    return tsim_fail(TSIM_EINVAL, "direct entries + component outputs cover %d of %d outputs", pos, p->num_outputs);
+
+  // ---- build the image ----
+  std::vector<uint32_t> &img = p->img;
+  img.clear();
+  img.resize(16, 0u);  // word 0..15 reserved (keeps every offset non-zero)
+  p->direct_off = (int)img.size();
+  for (int j = 0; j < p->n_direct; ++j) {
+    img.push_back((uint32_t)p->direct_f[j] | ((p->direct_flips[j] ? 1u : 0u) << 31));
+    img.push_back((uint32_t)p->output_order[j]);
+  }
+  p->comp_off = (int)img.size();
+  img.resize(img.size() + p->comps.size() * C_WORDS, 0u);
+  p->total_keys = 0;
+  p->sampleable = true;
+  p->total_graphs = p->total_rows = 0;
+  for (auto &v : p->stats) v = 0;
+  p->level_off.clear();
+  p->level_base.clear();
+  p->comp_w.clear();
+  for (size_t ci = 0; ci < p->comps.size(); ++ci) {
+    HostComponent &c = p->comps[ci];
+    int maxP = 1;
+    for (auto &lv : c.levels) maxP = std::max(maxP, lv.P);
+    // sampling appends the trial bit at position F+i (< F+n_out)
+    const bool sequential = (c.n_levels == c.n_out + 1);
+    if (sequential) maxP = std::max(maxP, c.F + c.n_out);
+    const int W = round_w((maxP + 31) / 32);
+    if (W < 0) return tsim_fail(TSIM_ENOTSUP, "component %zu needs %d parameter bits (max %d)", ci, maxP, TSIM_MAX_PARAMS);
+    p->comp_w.push_back(W);
+    if (!sequential && c.n_out != 1) p->sampleable = false;
+    uint32_t rec[C_WORDS] = {0};
+    rec[C_NOUT] = (uint32_t)c.n_out;
+    rec[C_F] = (uint32_t)c.F;
+    rec[C_W] = (uint32_t)W;
+    rec[C_NLEVELS] = (uint32_t)c.n_levels;
+    rec[C_KEYBASE] = (uint32_t)p->total_keys;
+    rec[C_FSEL] = (uint32_t)img.size();
+    for (int v : c.f_selection) img.push_back((uint32_t)v);
+    rec[C_OUTPOS] = (uint32_t)img.size();
+    for (int v : c.output_indices) img.push_back((uint32_t)v);
+    // level records, then graph records + rows of every level
+    rec[C_LEVELS] = (uint32_t)img.size();
+    const size_t lrec = img.size();
+    img.resize(img.size() + (size_t)c.n_levels * L_WORDS, 0u);
+    p->level_base.push_back((int)p->level_off.size());
+    for (int k = 0; k < c.n_levels; ++k) {
+      HostLevel &h = c.levels[k];
+      std::vector<uint32_t> tables;
+      bool fixed = false;
+      int frame = 0;
+      if (p->fast) {
+        if (!pack_level_fast(h, W, tables, fixed, frame)) {  // a table entry exceeds int32: use the faithful layout
+          p->fast = false;
+          goto retry_pack;
+        }
+      } else {
+        pack_level(h, W);
+      }
+      // align graph records to 16 words (one s_load_dwordx16 each)
+      while (img.size() % 16) img.push_back(0u);
+      const uint32_t goff = (uint32_t)img.size();
+      img.insert(img.end(), h.graph_rec.begin(), h.graph_rec.end());
+      const uint32_t roff = (uint32_t)img.size();
+      img.insert(img.end(), h.rows.begin(), h.rows.end());
+      static_assert((int)G_ROWS == (int)GF_ROWS, "row offset slot is shared by both layouts");
+      for (int g = 0; g < h.G; ++g) img[goff + (size_t)g * G_WORDS + G_ROWS] += roff;
+      if (p->fast) {
+        while (img.size() % 16) img.push_back(0u);  // 64-byte aligned table entries (uint4 loads)
+        const uint32_t toff = (uint32_t)img.size();
+        img.insert(img.end(), tables.begin(), tables.end());
+        for (int g = 0; g < h.G; ++g) {
+          img[goff + (size_t)g * G_WORDS + GF_TBL] += toff;
+          if (img[goff + (size_t)g * G_WORDS + GF_TBL2]) img[goff + (size_t)g * G_WORDS + GF_TBL2] += toff;
+        }
+      }
+      uint32_t *lr = &img[lrec + (size_t)k * L_WORDS];
+      lr[L_G] = (uint32_t)h.G;
+      lr[L_GRAPHS] = goff;
+      lr[L_FLAGS] = (h.approx ? TSIMK_LFLAG_APPROX : 0u) | (fixed ? TSIMK_LFLAG_FIXED : 0u);
+      lr[L_FRAME] = (uint32_t)frame;
+      p->stats[1] += 1;
+      p->stats[2] += fixed ? 1 : 0;
+      p->stats[5] += (long long)tables.size() * 4;  // table bytes
+      if (p->fast)
+        for (int g = 0; g < h.G; ++g) {
+          const uint32_t *r = &h.graph_rec[(size_t)g * G_WORDS];
+          p->stats[3] += r[GF_N3H] >> 16;
+          p->stats[4] += (r[GF_N01] & 0xFFFF) + (r[GF_N01] >> 16) + (r[GF_N3H] & 0xFFFF);
+          p->stats[6] += (r[GF_FLAGS] & TSIMK_GFLAG_D_TABLED) ? 1 : 0;
+        }
+      lr[L_NPARAMS] = (uint32_t)h.P;
+      p->level_off.push_back((int)(lrec + (size_t)k * L_WORDS));
+      p->total_graphs += h.G;
+      p->total_rows += h.n_rows;
+    }
+    if (sequential) p->total_keys += c.n_out;
+    memcpy(&img[p->comp_off + ci * C_WORDS], rec, sizeof rec);
+  }
+  // ---- v4 (chunk table) layout, when every sampled component qualifies ----
+  p->v4 = false;
+  if (p->fast && p->sampleable) {
+    bool ok = !p->comps.empty();
+    for (auto &c : p->comps)
+      for (auto &lv : c.levels) ok = ok && level_v4_eligible(lv);
+    const char *kenv = getenv("TSIM_AMD_KERNEL");
+    if (kenv && strcmp(kenv, "v3") == 0) ok = false;
+    if (p->mode == TSIM_MODE_ROW_KERNEL) ok = false;
+    p->v4_gt = 4;
+    if (ok) {
+      while (img.size() % 16) img.push_back(0u);
+      p->comp4_off = (int)img.size();
+      img.resize(img.size() + p->comps.size() * C4_WORDS, 0u);
+      p->v4_max_sent = 0;
+      int maxp = 1;
+      for (auto &c : p->comps)
+        for (auto &lv : c.levels) maxp = std::max(maxp, lv.P);
+      static const int kNch[] = {2, 4, 6, 8, 10, 12, 14, 16};
+      p->v4_max_nch = 16;
+      for (int v : kNch)
+        if (4 * v >= maxp) { p->v4_max_nch = v; break; }
+      for (size_t ci = 0; ci < p->comps.size(); ++ci) {
+        HostComponent &c = p->comps[ci];
+        for (int w = 0; w < 8; ++w) img[p->comp4_off + ci * C4_WORDS + w] = img[p->comp_off + ci * C_WORDS + w];
+        while (img.size() % 16) img.push_back(0u);
+        const size_t l4 = img.size();
+        img[p->comp4_off + ci * C4_WORDS + C4_LEVELS] = (uint32_t)l4;
+        img.resize(img.size() + (size_t)c.n_levels * L4_WORDS, 0u);
+        for (int k = 0; k < c.n_levels; ++k) {
+          HostLevel &h = c.levels[k];
+          const uint32_t v3lvl = (uint32_t)p->level_off[p->level_base[ci] + k];
+          const uint32_t v3recs = img[v3lvl + L_GRAPHS];
+          std::vector<uint32_t> recs4, tabs4, stabs4;
+          int nch = 1, ntiles = 0;
+          const bool sequential = (c.n_levels == c.n_out + 1);
+          const int sparse_F = (sequential && c.n_out <= 8 && c.F + c.n_out <= 64) ? c.F : -1;
+          std::vector<uint32_t> v3copy(img.begin() + v3recs, img.begin() + v3recs + (size_t)h.G * G_WORDS);
+          emit_level4(h, p->v4_gt, p->v4_max_nch, v3copy.data(), recs4, tabs4, nch, ntiles, sparse_F, stabs4);
+          while (img.size() % 16) img.push_back(0u);
+          const uint32_t roff = (uint32_t)img.size();
+          img.insert(img.end(), recs4.begin(), recs4.end());
+          while (img.size() % 16) img.push_back(0u);
+          const uint32_t toff = (uint32_t)img.size();
+          img.insert(img.end(), tabs4.begin(), tabs4.end());
+          while (img.size() % 16) img.push_back(0u);
+          const uint32_t stoff = stabs4.empty() ? 0u : (uint32_t)img.size();
+          img.insert(img.end(), stabs4.begin(), stabs4.end());
+          p->v4_max_sent = std::max(p->v4_max_sent, sparse_F >= 0 ? sparse_F + 33 : 0);
+          uint32_t *lr = &img[l4 + (size_t)k * L4_WORDS];
+          lr[L4_STAB] = stoff;
+          lr[L4_G] = (uint32_t)h.G;
+          lr[L4_NTILES] = (uint32_t)ntiles;
+          lr[L4_TABLES] = toff;
+          lr[L4_RECS] = roff;
+          lr[L4_NCH] = (uint32_t)nch;
+          lr[L4_FLAGS] = (h.approx ? TSIMK_LFLAG_APPROX : 0u) | (h.fixed ? TSIMK_LFLAG_FIXED : 0u);
+          lr[L4_FRAME] = (uint32_t)h.frame;
+        }
+      }
+      p->v4 = true;
+    }
+  }
+  p->stats[7] = p->v4 ? 1 : 0;
+
+  // ---- low-weight pattern tables: plan (records + sizes); built on the device after upload ----
+  p->lw = false;
+  p->lw_wmax.clear();
+  p->lw_bytes = 0;
+  std::vector<long long> lw_npat;
+  std::vector<std::vector<std::array<int, 3>>> lw_fsel_progs;
+  {
+    bool want = p->lw_request < 0 ? (p->mode == TSIM_MODE_AUTO) : (p->lw_request != 0);
+    if (const char *e = getenv("TSIM_AMD_PATTERN_TABLES")) want = atoi(e) != 0;
+    bool ok = want && p->sampleable && !p->comps.empty();
+    for (auto &c : p->comps)
+      ok = ok && (c.n_levels == c.n_out + 1) && c.n_out <= TSIMK_LW_MAX_NOUT && c.F + c.n_out <= 64;
+    if (ok) {
+      const int cap = p->lw_weight_cap < 0 ? TSIMK_LW_MAX_WEIGHT : std::min(p->lw_weight_cap, TSIMK_LW_MAX_WEIGHT);
+      // bytes per component.  Patterns are stored weight by weight, so the rows most shots read (weight
+      // 0..2) are a small cache-resident prefix whatever the total; the heavier tail is read rarely
+      long long budget = 256ll << 20;
+      if (const char *e = getenv("TSIM_AMD_PATTERN_TABLE_MB")) budget = std::max(1ll, atoll(e)) << 20;
+      while (img.size() % 16) img.push_back(0u);
+      p->lw_off = (int)img.size();
+      img.resize(img.size() + p->comps.size() * LW_WORDS, 0u);
+      long long tab_off = 0;
+      for (size_t ci = 0; ci < p->comps.size(); ++ci) {
+        const HostComponent &c = p->comps[ci];
+        const long long F = c.F;
+        const long long cnt[6] = {1, F, F * (F - 1) / 2, F * (F - 1) * (F - 2) / 6,
+                                  F * (F - 1) * (F - 2) * (F - 3) / 24,
+                                  F * (F - 1) * (F - 2) * (F - 3) * (F - 4) / 120};
+        long long npat = 0;
+        int wmax = -1;
+        for (int w = 0; w <= cap; ++w) {
+          const long long bytes = ((npat + cnt[w]) << c.n_out) * 4;
+          if (bytes > budget || (w > 1 && tab_off * 4 + bytes > 4 * budget)) break;  // per component / all together
+          npat += cnt[w];
+          wmax = w;
+        }
+        if (wmax < 0) { ok = false; break; }
+        const uint32_t *crec = &img[p->comp_off + ci * C_WORDS];
+        uint32_t *r = &img[p->lw_off + ci * LW_WORDS];
+        r[LW_NOUT] = (uint32_t)c.n_out;
+        r[LW_F] = (uint32_t)c.F;
+        lw_fsel_progs.push_back({});
+        for (int j = 0; j < c.F; ++j) lw_fsel_progs.back().push_back({c.f_selection[j], j, 0});
+        r[LW_OUTPOS] = crec[C_OUTPOS];
+        r[LW_KEYBASE] = crec[C_KEYBASE];
+        r[LW_WMAX] = (uint32_t)wmax;
+        r[LW_TAB] = (uint32_t)tab_off;
+        r[LW_OFF2] = (uint32_t)(1 + F);
+        r[LW_OFF3] = (uint32_t)(1 + F + cnt[2]);
+        r[LW_OFF4] = (uint32_t)(1 + F + cnt[2] + cnt[3]);
+        r[LW_OFF5] = (uint32_t)(1 + F + cnt[2] + cnt[3] + cnt[4]);
+        r[LW_NPAT] = (uint32_t)npat;
+        p->lw_wmax.push_back(wmax);
+        lw_npat.push_back(npat);
+        tab_off += npat << c.n_out;
+      }
+      if (ok) {
+        p->lw = true;
+        p->lw_bytes = tab_off * 4;
+        // gather programs: direct outputs, then every component's f_sel
+        std::vector<std::array<int, 3>> de;
+        for (int j = 0; j < p->n_direct; ++j) de.push_back({p->direct_f[j], p->output_order[j], p->direct_flips[j] ? 1 : 0});
+        std::vector<uint32_t> prog = emit_gather_program(de);
+        while (img.size() % 16) img.push_back(0u);
+        p->lw_direct_prog = (int)img.size();
+        p->lw_direct_chunks = (int)(prog.size() / 16);
+        img.insert(img.end(), prog.begin(), prog.end());
+        for (size_t ci = 0; ci < p->comps.size(); ++ci) {
+          prog = emit_gather_program(lw_fsel_progs[ci]);
+          img[p->lw_off + ci * LW_WORDS + LW_FSELP] = (uint32_t)img.size();
+          img[p->lw_off + ci * LW_WORDS + LW_FSELN] = (uint32_t)(prog.size() / 16);
+          img.insert(img.end(), prog.begin(), prog.end());
+        }
+      } else {
+        p->lw_wmax.clear();
+      }
+    }
+  }
+  img.resize(img.size() + 256, 0u);  // tail padding: wide scalar loads may over-read
+  if (img.size() >= (1ull << 31)) return tsim_fail(TSIM_ENOTSUP, "program image too large");
+
+  {
+    auto env_int = [](const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; };
+    p->knobs.adaptive = env_int("TSIM_AMD_ADAPTIVE", 1) != 0;
+    p->knobs.hard_kernel = env_int("TSIM_AMD_HARD_KERNEL", 1) != 0;
+    p->knobs.lane0_main = env_int("TSIM_AMD_LANE0_MAIN", 1) != 0;
+    p->knobs.lw_block = env_int("TSIM_AMD_LW_BLOCK", 0);
+    if (p->knobs.lw_block != 0) p->knobs.lw_block = std::max(64, std::min(1024, p->knobs.lw_block & ~63));
+    const int vb = env_int("TSIM_AMD_V4_BLOCK", 256);
+    p->knobs.v4_block = (vb == 512 || vb == 128) ? vb : 256;
+    p->knobs.hard_lds_kb = std::max(24, std::min(156, env_int("TSIM_AMD_HARD_LDS_KB", 128)));
+    p->knobs.defer = env_int("TSIM_AMD_DEFER_HARD", 1) != 0;
+    p->knobs.merge_lists = env_int("TSIM_AMD_MERGE_LISTS", 1) != 0;
+    p->knobs.list_rows = env_int("TSIM_AMD_LIST_ROWS", 40);
+    p->knobs.min_lists = env_int("TSIM_AMD_MIN_LISTS", 4);
+    if (p->knobs.min_lists & (p->knobs.min_lists - 1)) p->knobs.min_lists = 4;
+    // launches per deferred batch: a batch lasts about as long as ONE hard-row pass (its blocks run side by
+    // side), and batches are serial on their lane - so the batch must cover at least (pass time / step time)
+    // launches.  The pass time grows with the chunk tables a 64-row block streams through LDS (C2: 1.7 MB,
+    // 35-50 us; C4: 10.8 MB, 450 us): 4 launches for small programs, 8 (the kernel's limit) beyond 4 MB.
+    p->knobs.defer_group = p->stats[5] > (4ll << 20) ? TSIMK_H_MAX_CTX : 4;
+    p->knobs.defer_group = std::max(1, std::min(TSIMK_H_MAX_CTX, env_int("TSIM_AMD_DEFER_GROUP", p->knobs.defer_group)));
+  }
+
+  // ---- upload ----
+  int ndev = 0;
+  HIP_TRY(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev) return tsim_fail(TSIM_EINVAL, "device %d out of range (%d visible)", device, ndev);
+  p->device = device;
+  HIP_TRY(hipSetDevice(device));
+  HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+  HIP_TRY(hipMalloc((void **)&p->d_img, img.size() * 4));
+  HIP_TRY(hipMemcpy(p->d_img, img.data(), img.size() * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMalloc((void **)&p->d_dev, std::max<size_t>(1, p->comps.size()) * 4));
+  HIP_TRY(hipMemset(p->d_dev, 0, std::max<size_t>(1, p->comps.size()) * 4));
+  if (p->lw) {
+    if (int r = build_pattern_tables(p, lw_npat)) return r;
+  }
+  p->finalized = true;
+  return TSIM_OK;
+}
+extern "C" void tsim_program_destroy(tsim_program *p) {
+  if (!p) return;
+  if (p->finalized && p->device >= 0) {
+    (void)hipSetDevice(p->device);
+    (void)tsim_flush_hard(p);  // parked hard rows of launches that were never joined: finish them, then drain every lane
+    if (p->stream) (void)hipStreamSynchronize(p->stream);
+    for (auto &sl : p->slots)
+      if (sl.side_ready) (void)hipStreamSynchronize(sl.side);
+    for (hipEvent_t e : p->ev_pool) (void)hipEventDestroy(e);
+    if (getenv("TSIM_AMD_PIPELINE_STATS"))
+      fprintf(stderr, "tsim pipeline: begins %llu deferred %llu flushes %llu queries %llu waits %llu\n", p->stat_begins,
+              p->stat_deferred, p->stat_flushes, p->stat_queries, p->stat_waits);
+    if (p->sync_ev) (void)hipEventDestroy(p->sync_ev);
+    for (hipEvent_t e : p->lane_ev) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : p->batch_ev) if (e) (void)hipEventDestroy(e);
+    for (void *s : p->scratch)
+      if (s) (void)hipFree(s);
+    for (void *q : p->owned) (void)hipFree(q);  // buffers the caller never returned
+    p->owned.clear();
+    if (p->d_img) (void)hipFree(p->d_img);
+    if (p->d_dev) (void)hipFree(p->d_dev);
+    if (p->d_lw_tab) (void)hipFree(p->d_lw_tab);
+    if (p->h_feedback) (void)hipHostFree((void *)p->h_feedback);
+    for (auto &sl : p->slots) {
+      if (sl.ctl) (void)hipFree(sl.ctl);
+      if (sl.hard) (void)hipFree(sl.hard);
+      if (sl.keys) (void)hipFree(sl.keys);
+      if (sl.ev1) (void)hipEventDestroy(sl.ev1);
+      if (sl.ev2) (void)hipEventDestroy(sl.ev2);
+
+      if (sl.side && !sl.side_borrowed) (void)hipStreamDestroy(sl.side);
+    }
+    if (p->stream) (void)hipStreamDestroy(p->stream);
+  }
+  delete p;
+}
+
+extern "C" int tsim_program_stats(const tsim_program *p, int64_t out[8]) {
+  if (!p || !out) return tsim_fail(TSIM_EINVAL, "NULL argument");
+  if (!p->finalized) return tsim_fail(TSIM_ESTATE, "program not finalized");
+  for (int i = 0; i < 8; ++i) out[i] = p->stats[i];
+  out[0] = p->fast ? 1 : 0;
+  return TSIM_OK;
+}
+
+extern "C" int tsim_program_get_mode(const tsim_program *p, int32_t *fast) {
+  if (!p || !fast) return tsim_fail(TSIM_EINVAL, "NULL argument");
+  if (!p->finalized) return tsim_fail(TSIM_ESTATE, "program not finalized");
+  *fast = p->fast ? 1 : 0;
+  return TSIM_OK;
+}
+
+extern "C" int tsim_program_info(const tsim_program *p, int32_t *n_components, int32_t *num_outputs,
+                                 int64_t *image_bytes, int64_t *total_graphs, int64_t *total_rows) {
+  if (!p) return tsim_fail(TSIM_EINVAL, "program is NULL");
+  if (n_components) *n_components = (int32_t)p->comps.size();
+  if (num_outputs) *num_outputs = p->num_outputs;
+  if (image_bytes) *image_bytes = (int64_t)p->img.size() * 4;
+  if (total_graphs) *total_graphs = p->total_graphs;
+  if (total_rows) *total_rows = p->total_rows;
+  return TSIM_OK;
+}
+int tsim_need_final(const tsim_program *p) {
+  if (!p) return tsim_fail(TSIM_EINVAL, "program is NULL");
+  if (!p->finalized) return tsim_fail(TSIM_ESTATE, "program not finalized");
+  return 0;
+}
+
+int tsim_ensure_scratch(tsim_program *p, int slot, size_t bytes) {
+  if (p->scratch_sz[slot] >= bytes) return 0;
+  if (p->scratch[slot]) {
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    HIP_TRY(hipFree(p->scratch[slot]));
+    p->scratch[slot] = nullptr;
+    p->scratch_sz[slot] = 0;
+  }
+  size_t cap = std::max<size_t>(bytes, 256);
+  hipError_t e = hipMalloc(&p->scratch[slot], cap);
+  if (e != hipSuccess) return tsim_fail(TSIM_ENOMEM, "hipMalloc(%zu) failed: %s", cap, hipGetErrorString(e));
+  p->scratch_sz[slot] = cap;
+  return 0;
+}
+// ---------------------------------------------------------------------------
+// plumbing
+// ---------------------------------------------------------------------------
+extern "C" int tsim_device_count(int32_t *count) {
+  if (!count) return tsim_fail(TSIM_EINVAL, "count is NULL");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    *count = 0;
+    return tsim_fail(TSIM_EHIP, "hipGetDeviceCount failed: %s", hipGetErrorString(e));
+  }
+  *count = n;
+  return TSIM_OK;
+}
+
+extern "C" int tsim_malloc_device(tsim_program *p, int64_t nbytes, void **d_ptr) {
+  if (int r = tsim_need_final(p)) return r;
+  if (int r = tsim_set_device(p)) return r;
+  if (!d_ptr || nbytes < 0) return tsim_fail(TSIM_EINVAL, "bad argument");
+  hipError_t e = hipMalloc(d_ptr, (size_t)std::max<int64_t>(nbytes, 1));
+  if (e != hipSuccess) return tsim_fail(TSIM_ENOMEM, "hipMalloc(%lld) failed: %s", (long long)nbytes, hipGetErrorString(e));
+  p->owned.insert(*d_ptr);
+  return TSIM_OK;
+}
+
+extern "C" int tsim_free_device(tsim_program *p, void *d_ptr) {
+  if (int r = tsim_need_final(p)) return r;
+  if (int r = tsim_set_device(p)) return r;
+  if (!d_ptr) return TSIM_OK;
+  if (!p->owned.erase(d_ptr)) return tsim_fail(TSIM_EINVAL, "pointer was not allocated by tsim_malloc_device on this handle");
+  HIP_TRY(hipFree(d_ptr));
+  return TSIM_OK;
+}
+
+extern "C" int tsim_malloc_pinned(int64_t nbytes, void **h_ptr) {
+  if (!h_ptr || nbytes < 0) return tsim_fail(TSIM_EINVAL, "bad argument");
+  hipError_t e = hipHostMalloc(h_ptr, (size_t)std::max<int64_t>(nbytes, 1), hipHostMallocDefault);
+  if (e != hipSuccess) return tsim_fail(TSIM_ENOMEM, "hipHostMalloc(%lld) failed: %s", (long long)nbytes, hipGetErrorString(e));
+  return TSIM_OK;
+}
+
+extern "C" int tsim_free_pinned(void *h_ptr) {
+  HIP_TRY(hipHostFree(h_ptr));
+  return TSIM_OK;
+}
+
+extern "C" int tsim_memcpy_h2d(tsim_program *p, void *d_dst, const void *h_src, int64_t nbytes) {
+  if (int r = tsim_need_final(p)) return r;
+  if (int r = tsim_set_device(p)) return r;
+  if (nbytes < 0) return tsim_fail(TSIM_EINVAL, "negative size");
+  if (nbytes == 0) return TSIM_OK;
+  HIP_TRY(hipMemcpyAsync(d_dst, h_src, (size_t)nbytes, hipMemcpyHostToDevice, p->stream));
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  return TSIM_OK;
+}
+
+extern "C" int tsim_memcpy_d2h(tsim_program *p, void *h_dst, const void *d_src, int64_t nbytes) {
+  if (int r = tsim_need_final(p)) return r;
+  if (int r = tsim_set_device(p)) return r;
+  if (nbytes < 0) return tsim_fail(TSIM_EINVAL, "negative size");
+  if (nbytes == 0) return TSIM_OK;
+  HIP_TRY(hipMemcpyAsync(h_dst, d_src, (size_t)nbytes, hipMemcpyDeviceToHost, p->stream));
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  return TSIM_OK;
+}
+
+extern "C" int tsim_get_stream(tsim_program *p, void **stream) {
+  if (int r = tsim_need_final(p)) return r;
+  if (!stream) return tsim_fail(TSIM_EINVAL, "stream is NULL");
+  *stream = (void *)p->stream;
+  return TSIM_OK;
+}
+
+extern "C" void tsim_key_split(uint32_t key_hi, uint32_t key_lo, uint32_t out[4]) {
+  // new_key, subkey = jax.random.split(key) (threefry_partitionable): counters (0,0) and (0,1)
+  uint32_t a0 = 0u, a1 = 0u, b0 = 0u, b1 = 1u;
+  threefry2x32(key_hi, key_lo, a0, a1);
+  threefry2x32(key_hi, key_lo, b0, b1);
+  out[0] = a0; out[1] = a1; out[2] = b0; out[3] = b1;
+}
+
+extern "C" int tsim_sample_batch_device_begin_split(tsim_program *p, int32_t slot, const uint64_t *d_f, int64_t B,
+                                                    int32_t num_f, uint32_t key[2], int64_t shot_offset, uint64_t *d_out,
+                                                    float *d_max_norm_dev, void *stream, uint32_t flags) {
+  if (!key) return tsim_fail(TSIM_EINVAL, "key is NULL");
+  uint32_t o[4];
+  tsim_key_split(key[0], key[1], o);  // key, subkey = split(key)  (sampler.py:399)
+  key[0] = o[0];
+  key[1] = o[1];
+  return tsim_sample_batch_device_begin(p, slot, d_f, B, num_f, o[2], o[3], shot_offset, d_out, d_max_norm_dev, stream,
+                                        flags);
+}
+
+extern "C" int tsim_synchronize(tsim_program *p) {
+  if (int r = tsim_need_final(p)) return r;
+  if (int r = tsim_set_device(p)) return r;
+  if (int r = tsim_flush_hard(p)) return r;
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  // the three lanes of the deferred plan and every slot stream a launch actually ran on (a stream that never
+  // carried work has nothing to wait for - and each hipStreamSynchronize costs a few microseconds)
+  for (int k = 1; k <= TSIM_PIPELINE_SLOTS; ++k) {
+    tsim_program::Slot &sl = p->slots[k];
+    if (!sl.side_ready) continue;
+    if ((k <= 3 || sl.used) && sl.side != p->stream) HIP_TRY(hipStreamSynchronize(sl.side));
+    sl.pending = false;
+  }
+  return TSIM_OK;
+}

@@ -1,0 +1,63 @@
+// tsim_rows_impl.hip.h - instantiations of the row-formulation kernels for ONE evaluation formulation
+// (TSIM_ROWS_FAST = true: pack-time algebra / false: operation-by-operation mirror of the reference).
+// Included by tsim_rows_fast.hip and tsim_rows_faithful.hip so that the two sets compile in parallel.
+#include "tsim_internal.hip.h"
+
+#ifndef TSIM_ROWS_FAST
+#error "define TSIM_ROWS_FAST (true/false) and TSIM_ROWS_NAME(sym) before including this file"
+#endif
+
+using namespace tsimk;
+
+// every W the packer can choose (tsimhost::kWVariants)
+#define TSIM_FOR_EACH_W(X) X(1) X(2) X(3) X(4) X(6) X(8) X(12) X(16) X(24) X(32)
+
+namespace tsimrows {
+
+int TSIM_ROWS_NAME(sample)(int wmax, const SampleArgs &a, long long grid, int block, size_t lds, hipStream_t s) {
+  switch (wmax) {
+#define TSIM_X(WV)                                                                                              \
+  case WV:                                                                                                      \
+    hipLaunchKernelGGL((k_sample<WV, TSIM_ROWS_FAST>), dim3((unsigned)grid), dim3(block), lds, s, a);           \
+    break;
+    TSIM_FOR_EACH_W(TSIM_X)
+#undef TSIM_X
+    default: return tsim_fail(TSIM_ENOTSUP, "unsupported word count %d", wmax);
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int TSIM_ROWS_NAME(eval)(int W, const EvalArgs &a, hipStream_t s) {
+  const dim3 grid((unsigned)((a.B + 255) / 256));
+  switch (W) {
+#define TSIM_X(WV)                                                                                 \
+  case WV:                                                                                         \
+    hipLaunchKernelGGL((k_evaluate<WV, TSIM_ROWS_FAST>), grid, dim3(256), 0, s, a);                \
+    break;
+    TSIM_FOR_EACH_W(TSIM_X)
+#undef TSIM_X
+    default: return tsim_fail(TSIM_ENOTSUP, "unsupported word count %d", W);
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// pattern-table build (tsim_lw.hip.h): components with <= 64 parameters use W = 1, 2; wide components
+// (multi-word patterns) the W of their rows
+int TSIM_ROWS_NAME(lw_build)(int W, const LwBuildArgs &a, long long lanes, hipStream_t s) {
+  const dim3 grid((unsigned)((lanes + 255) / 256));
+  switch (W) {
+#define TSIM_X(WV)                                                                                 \
+  case WV:                                                                                         \
+    hipLaunchKernelGGL((k_lw_build<WV, TSIM_ROWS_FAST>), grid, dim3(256), 0, s, a);                \
+    break;
+    TSIM_FOR_EACH_W(TSIM_X)
+#undef TSIM_X
+    default: return tsim_fail(TSIM_ENOTSUP, "pattern tables: unsupported word count %d", W);
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+}  // namespace tsimrows

@@ -1,0 +1,695 @@
+// tsim_sample.hip - the hot path of the C ABI: launch planner, pipeline scheduler and the sampling
+// kernels that need the chunk-table layout (k_sample_lw, k_sample4, k_sample4h, k_sample4h_multi),
+// device-side post-selection and the HIP-event profiling of the launches.
+#include "tsim_internal.hip.h"
+#include "tsim_kernel4h.hip.h"
+#include "tsim_filter.hip.h"
+#include "tsim_lw_pass.hip.h"
+
+using namespace tsimk;
+using namespace tsimhost;
+
+// stage tags of the profiling events: 0 opens a launch, the others close a stage
+enum { PROF_BEGIN = 0, PROF_PASS1 = 1, PROF_HARD = 2, PROF_FULL = 3 };
+
+static int prof_event(tsim_program *p, hipStream_t s, int tag) {
+  if (p->ev_used == p->ev_pool.size()) {
+    hipEvent_t e;
+    HIP_TRY(hipEventCreate(&e));
+    p->ev_pool.push_back(e);
+    p->ev_tag.push_back(0);
+  }
+  p->ev_tag[p->ev_used] = tag;
+  HIP_TRY(hipEventRecord(p->ev_pool[p->ev_used++], s));
+  return 0;
+}
+
+static int prof_drain(tsim_program *p) {
+  size_t begin = 0;
+  for (size_t i = 0; i < p->ev_used; ++i) {
+    if (p->ev_tag[i] == PROF_BEGIN) { begin = i; continue; }
+    HIP_TRY(hipEventSynchronize(p->ev_pool[i]));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, p->ev_pool[i - 1], p->ev_pool[i]));
+    p->prof_stage_ms[p->ev_tag[i]] += ms;
+    if (i + 1 == p->ev_used || p->ev_tag[i + 1] == PROF_BEGIN) {  // last event of this launch
+      HIP_TRY(hipEventElapsedTime(&ms, p->ev_pool[begin], p->ev_pool[i]));
+      p->prof_ms += ms;
+      p->prof_launches += 1;
+    }
+  }
+  p->ev_used = 0;
+  return 0;
+}
+// per-slot resources, created on first use
+static int slot_prepare(tsim_program *p, int slot, size_t hard_bytes) {
+  tsim_program::Slot &sl = p->slots[slot];
+  if (p->lw && !sl.ctl) {
+    // two counter sets used alternately: pass 1 of a launch resets the set of the slot's next one
+    const size_t set_bytes = (TSIMK_LW_LISTS + 1) * 128;
+    HIP_TRY(hipMalloc((void **)&sl.ctl, 2 * set_bytes));
+    HIP_TRY(hipMemset(sl.ctl, 0, 2 * set_bytes));
+    for (int st = 0; st < 2; ++st)
+      HIP_TRY(hipMemset(sl.ctl + st * (TSIMK_LW_LISTS + 1) * 32 + TSIMK_LW_LISTS * 32, 0xFF, 4));
+  }
+  if (p->total_keys > TSIMK_INLINE_KEYS && !sl.keys) HIP_TRY(hipMalloc((void **)&sl.keys, (size_t)p->total_keys * 8));
+  if (slot > 0 && !sl.side_ready) {
+    sl.side_ready = true;
+    // default priority on purpose: a low- (or high-) priority lane lands on a different class of
+    // hardware queue and tripled the step time (134 us vs 43 us, measured)
+    if (slot == 1 && p->knobs.lane0_main) {
+      // The handle's own stream doubles as the first lane: HIP gave the lanes it created only two distinct
+      // hardware queues (kernel trace: three created streams -> queues 3, 4, 4), the handle's stream sits on
+      // a third one.  Three truly concurrent lanes: 36 us per step instead of 42.
+      sl.side = p->stream;
+      sl.side_borrowed = true;
+    } else {
+      HIP_TRY(hipStreamCreateWithFlags(&sl.side, hipStreamNonBlocking));
+    }
+    HIP_TRY(hipEventCreateWithFlags(&sl.ev1, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&sl.ev2, hipEventDisableTiming));
+  }
+  if (sl.hard_sz < hard_bytes) {
+    if (sl.hard) {
+      HIP_TRY(hipDeviceSynchronize());
+      HIP_TRY(hipFree(sl.hard));
+      sl.hard = nullptr;
+      sl.hard_sz = 0;
+    }
+    hipError_t e = hipMalloc(&sl.hard, hard_bytes);
+    if (e != hipSuccess) return tsim_fail(TSIM_ENOMEM, "hipMalloc(%zu) failed: %s", hard_bytes, hipGetErrorString(e));
+    sl.hard_sz = hard_bytes;
+  }
+  return 0;
+}
+
+// Launch plan from the feedback of earlier launches (results do not depend on it):
+//  * most rows hard (dense error patterns): the pattern pass is wasted work - run the full kernel
+//    on every row for the next 15 launches, then probe again with one two-pass launch;
+//  * hard-row lists short: k_sample4h walks them alone, no overflow launch of k_sample4 - and a
+//    pipelined launch may leave its hard rows to a later batch (flush_hard) instead of making its
+//    lane wait for them.
+struct LaunchPlan {
+  bool use_tables = false, need_overflow = true, defer = false;
+  uint32_t fb_max = 0xFFFFFFFFu;
+  int lists = TSIMK_LW_LISTS;  // hard-row sub-lists of this launch: about 40 expected rows each
+};
+
+static LaunchPlan make_plan(tsim_program *p, bool has_row_index, bool pipelined) {
+  LaunchPlan pl;
+  pl.use_tables = p->lw;
+  if (p->lw && p->h_feedback && p->knobs.adaptive) {
+    const uint32_t fb_sum = p->h_feedback[0], fb_max = p->h_feedback[1], fb_rows = p->h_feedback[2];
+    const bool known = fb_rows != 0xFFFFFFFFu && fb_rows > 0u && fb_sum != 0xFFFFFFFFu;
+    bool dense = false;
+    if (p->lw_direct_left > 0) {
+      --p->lw_direct_left;
+      pl.use_tables = false;
+    } else if (known && (double)fb_sum > 0.5 * (double)fb_rows && !has_row_index) {
+      p->lw_direct_left = 15;  // this launch is the probe
+      dense = true;
+    }
+    if (known && fb_max <= 192u) pl.need_overflow = false;
+    pl.fb_max = known ? fb_max : 0xFFFFFFFFu;
+    if (known && p->knobs.merge_lists) {
+      const uint32_t per = (uint32_t)std::max(8, p->knobs.list_rows);
+      const uint32_t want = (fb_sum + per - 1u) / per;
+      pl.lists = std::max(2, std::min(TSIMK_LW_LISTS, p->knobs.min_lists));
+      while ((uint32_t)pl.lists < want && pl.lists < TSIMK_LW_LISTS) pl.lists <<= 1;
+      // the longest list of the last launch was measured with ITS list count: rescale the overflow test
+      const uint32_t last = p->last_lists > 0 ? (uint32_t)p->last_lists : (uint32_t)TSIMK_LW_LISTS;
+      const uint32_t est_max = (uint32_t)std::min<unsigned long long>(0xFFFFFFFFull, (unsigned long long)fb_max * last / (uint32_t)pl.lists + 16u);
+      pl.need_overflow = !(pl.lists >= (int)last ? fb_max <= 192u : est_max <= 192u);
+    }
+    pl.defer = pipelined && pl.use_tables && !dense && !pl.need_overflow && p->knobs.defer && p->knobs.hard_kernel &&
+               p->v4 && !(p->profiling && !p->prof_light);
+  }
+  return pl;
+}
+
+// k_sample4h geometry (LDS budget -> tiles per group), 0 tiles = the kernel cannot run this program
+static void hard_geometry(tsim_program *p, int WF, int WO) {
+  constexpr int NW = TSIM_HARD_NW;
+  const size_t tile_b = (size_t)p->v4_max_nch * 16 * p->v4_gt * 16;
+  const size_t fixed_b = (size_t)(2 * WF + 2 * WO) * 64 * 4 + (size_t)NW * 8 * 64 * 4;
+  const size_t budget = (size_t)p->knobs.hard_lds_kb * 1024;
+  p->h_group_tiles = fixed_b + tile_b <= budget ? (int)std::min<size_t>(TSIMK_H_MAX_GROUP_TILES, (budget - fixed_b) / tile_b) : 0;
+  p->h_lds = fixed_b + (size_t)std::max(1, p->h_group_tiles) * tile_b;
+}
+
+// The deferred second pass: ONE k_sample4h_multi grid serves the hard rows of every launch whose
+// first pass is enqueued, on the third lane's stream, after those first passes.
+int tsim_flush_hard(tsim_program *p) {
+  if (p->deferred.empty()) return 0;
+  constexpr int NW = TSIM_HARD_NW;
+  hipStream_t hs = p->slots[3].side;
+  Hard4Multi M{};
+  M.n_ctx = (int)p->deferred.size();
+  const uint32_t fb_max = p->h_feedback ? p->h_feedback[1] : 192u;
+  const int hb = (int)std::max(1u, std::min(4u, (std::min(fb_max, 192u) + 32u + 63u) / 64u));
+  int max_lists = 1;
+  for (int sidx : p->deferred) max_lists = std::max(max_lists, p->slots[sidx].ctx.row_lists);
+  M.blocks_per_ctx = hb * max_lists + 1;
+  M.group_tiles = p->h_group_tiles;
+  M.loop_stride = hb * 64;
+  M.comp4_off = p->comp4_off;
+  M.feedback = p->d_feedback;
+  // the batch starts after the first passes: streams are in order, so one event per lane covers them all
+  bool lane_used[2] = {false, false};
+  for (int i = 0; i < M.n_ctx; ++i) {
+    tsim_program::Slot &d = p->slots[p->deferred[i]];
+    for (int k = 0; k < 2; ++k)
+      if (d.p1_stream == p->slots[1 + k].side) lane_used[k] = true;
+    M.ctx[i] = d.ctx;
+    M.ctx[i].kernarg_off = (int)(offsetof(Hard4Multi, ctx) + (size_t)i * sizeof(SampleArgs));
+    if (d.ctx_check) M.check_mask |= 1 << i;
+  }
+  for (int k = 0; k < 2; ++k)
+    if (lane_used[k]) {
+      if (!p->lane_ev[k]) HIP_TRY(hipEventCreateWithFlags(&p->lane_ev[k], hipEventDisableTiming));
+      HIP_TRY(hipEventRecord(p->lane_ev[k], p->slots[1 + k].side));
+      HIP_TRY(hipStreamWaitEvent(hs, p->lane_ev[k], 0));
+    }
+  const unsigned grid = (unsigned)(M.n_ctx * M.blocks_per_ctx);
+  switch (p->v4_max_nch) {
+#define TSIM_LHM(N)                                                                                          \
+  case N: {                                                                                                  \
+    auto kfn = k_sample4h_multi<4, N, NW>;                                                                   \
+    if (!p->hm_attr_set)                                                                                     \
+      HIP_TRY(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(NW * 64), p->h_lds, hs, M);                                     \
+  } break;
+    TSIM_LHM(2) TSIM_LHM(4) TSIM_LHM(6) TSIM_LHM(8) TSIM_LHM(10) TSIM_LHM(12) TSIM_LHM(14) TSIM_LHM(16)
+#undef TSIM_LHM
+    default: return tsim_fail(TSIM_ESTATE, "bad chunk count %d", p->v4_max_nch);
+  }
+  HIP_TRY(hipGetLastError());
+  p->hm_attr_set = true;
+  ++p->stat_flushes;
+  const unsigned long long seq = p->batch_next++;
+  hipEvent_t &be = p->batch_ev[seq % 16u];
+  if (!be) HIP_TRY(hipEventCreateWithFlags(&be, hipEventDisableTiming));
+  if (seq > 16u && p->batch_confirmed < seq - 16u) {  // the ring slot's previous batch: 16 batches ago, long done
+    HIP_TRY(hipEventSynchronize(be));
+    p->batch_confirmed = seq - 16u;
+  }
+  HIP_TRY(hipEventRecord(be, hs));
+  for (int i = 0; i < M.n_ctx; ++i) {
+    tsim_program::Slot &d = p->slots[p->deferred[i]];
+    d.deferred = false;
+    d.last_done = hs;
+    d.done_ev = be;
+    d.batch_seq = seq;
+  }
+  p->deferred.clear();
+  return 0;
+}
+
+static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_t num_f, uint32_t key_hi,
+                         uint32_t key_lo, int64_t shot_offset, uint64_t *d_out, float *d_dev, hipStream_t s,
+                         const uint32_t *d_row_index = nullptr, const uint32_t *d_row_count = nullptr,
+                         int slot = 0, const LaunchPlan *plan_in = nullptr) {
+  if (!p->sampleable) return tsim_fail(TSIM_ESTATE, "program has joint-mode components (evaluate-only)");
+  if (B < 0 || num_f < 0 || shot_offset < 0) return tsim_fail(TSIM_EINVAL, "negative B/num_f/shot_offset");
+  if (p->max_f_index >= num_f)
+    return tsim_fail(TSIM_EINVAL, "program references f index %d but num_f=%d", p->max_f_index, num_f);
+  if (B == 0 || p->num_outputs == 0) return 0;
+  if (!d_f && num_f > 0) return tsim_fail(TSIM_EINVAL, "f buffer is NULL");
+  if (!d_out) return tsim_fail(TSIM_EINVAL, "out buffer is NULL");
+  // per-output subkeys: key, subkey = split(key) once per output, threaded through the
+  // components in processing order (sampler.py:74,147-148)
+  tsim_program::Slot &sl = p->slots[slot];
+  {
+    size_t hard_bytes = 0;
+    if (p->lw) {
+      const long long g1 = (B + 255) / 256;  // the pattern pass uses 256-thread blocks unless overridden
+      hard_bytes = (size_t)((g1 + TSIMK_LW_LISTS - 1) / TSIMK_LW_LISTS * 1024) * TSIMK_LW_LISTS * 4;
+    }
+    if (int r = slot_prepare(p, slot, hard_bytes)) return r;
+  }
+  SampleArgs a{};
+  if (p->total_keys > 0 && p->total_keys <= TSIMK_INLINE_KEYS) {
+    uint32_t k0 = key_hi, k1 = key_lo;
+    for (int i = 0; i < p->total_keys; ++i) {
+      uint32_t a0 = 0u, a1 = 0u, b0 = 0u, b1 = 1u;
+      threefry2x32(k0, k1, a0, a1);  // split(key)[0] -> next key
+      threefry2x32(k0, k1, b0, b1);  // split(key)[1] -> this output's subkey
+      a.inline_keys[2 * i] = b0;
+      a.inline_keys[2 * i + 1] = b1;
+      k0 = a0;
+      k1 = a1;
+    }
+    a.n_inline_keys = p->total_keys;
+  } else if (p->total_keys > 0) {
+    hipLaunchKernelGGL(k_keygen, dim3(1), dim3(1), 0, s, key_hi, key_lo, p->total_keys, sl.keys);
+    HIP_TRY(hipGetLastError());
+  }
+  a.img = p->d_img;
+  a.f = d_f;
+  a.out = d_out;
+  a.subkeys = sl.keys;
+  a.norm_dev = d_dev;
+  a.B = B;
+  a.shot_offset = shot_offset;
+  a.WF = std::max(1, (num_f + 63) / 64);
+  a.WO = (p->num_outputs + 63) / 64;
+  a.n_direct = p->n_direct;
+  a.direct_off = p->direct_off;
+  a.n_comp = (int)p->comps.size();
+  a.comp_off = p->comp_off;
+  a.row_index = d_row_index;
+  a.row_count = d_row_index ? d_row_count : nullptr;
+  a.row_lists = 0;
+  a.row_list_cap = 0;
+  a.row_slot_begin = 0;
+  a.row_slot_end = 0;
+  if (sl.compact_out) {  // tsim_pipeline_set_compact_output: consumed by this launch
+    a.out_compact = sl.compact_out;
+    a.out_rb = (p->num_outputs + 7) / 8;
+    sl.compact_out = nullptr;
+  } else if (slot > 0 && p->series_left > 0) {  // tsim_pipeline_set_compact_series: next buffer of the series
+    a.out_compact = p->series_ptr;
+    a.out_rb = (p->num_outputs + 7) / 8;
+    p->series_ptr += p->series_stride;
+    --p->series_left;
+  }
+  a.check_row = nullptr;
+  a.no_check = 0;
+  if (num_f == 0) a.WF = 0;
+  if (B > 0x7FFFFFFFll * 64) return tsim_fail(TSIM_ENOTSUP, "batch too large");
+  const bool prof = p->profiling && (p->prof_counter++ % p->prof_every == 0);
+  if (prof) { int r = prof_event(p, s, PROF_BEGIN); if (r) return r; }
+  // the normalisation check applies to in-batch shot 0 (sampler.py:66-72) or the first listed row
+  bool has_check = (shot_offset == 0 || d_row_index);
+  long long B2 = B;  // slots per row list of the full kernel's launch
+  const bool pipelined = slot > 0;  // lane launch: the caller passed the slot's own stream as `s`
+  auto finish = [&]() -> int {
+    if (pipelined) {
+      HIP_TRY(hipEventRecord(sl.ev2, s));
+      sl.pending = true;
+      sl.last_done = s;
+      sl.done_ev = sl.ev2;
+      sl.batch_seq = 0;
+    }
+    return 0;
+  };
+  const LaunchPlan plan = plan_in ? *plan_in : make_plan(p, d_row_index != nullptr, false);
+  const bool use_tables = plan.use_tables, need_overflow = plan.need_overflow;
+  if (use_tables) {
+    // pass 1: shots whose f_sel patterns are tabulated finish here, the others go to the hard list
+    if (B > 0xFFFFFFFFll) return tsim_fail(TSIM_ENOTSUP, "batch too large for the row list");
+    // few large blocks: 1024 threads finish a batch of 10^6 rows in 977 blocks - measurably better than
+    // 3906 blocks of 256 when the blocks of several launches and of the hard-row kernel share the CUs
+    const int blk1 = p->knobs.lw_block ? p->knobs.lw_block : ((size_t)(2 * a.WF + 2 * a.WO) * 1024 * 4 <= 32 * 1024 ? 1024 : 256);
+    const long long grid1 = (B + blk1 - 1) / blk1;
+    // n_lists sub-lists share the buffer sized for TSIMK_LW_LISTS of them: a list can hold every row of
+    // the blocks that feed it
+    const int n_lists = plan.lists;
+    const long long list_cap = (grid1 + TSIMK_LW_LISTS - 1) / TSIMK_LW_LISTS * blk1 * (TSIMK_LW_LISTS / n_lists);
+    if (list_cap > 0x7FFFFFFFll) return tsim_fail(TSIM_ENOTSUP, "batch too large for the row lists");
+    if ((size_t)list_cap * n_lists * 4 > sl.hard_sz) return tsim_fail(TSIM_ESTATE, "hard-row list too small");
+    p->last_lists = n_lists;
+    LwArgs l;
+    l.s = a;
+    l.tab = p->d_lw_tab;
+    l.lw_off = p->lw_off;
+    l.direct_prog = p->lw_direct_prog;
+    l.direct_chunks = p->lw_direct_chunks;
+    l.has_check = has_check ? 1 : 0;
+    l.hard_index = (uint32_t *)sl.hard;
+    uint32_t *ctl = sl.ctl + sl.parity * (TSIMK_LW_LISTS + 1) * 32;
+    l.ctl = ctl;
+    l.ctl_next = sl.ctl + (sl.parity ^ 1) * (TSIMK_LW_LISTS + 1) * 32;
+    sl.parity ^= 1;
+    l.list_cap = (int)list_cap;
+    l.n_lists = n_lists;
+    const size_t lds1 = (size_t)(2 * a.WF + 2 * a.WO) * blk1 * 4;
+    if (lds1 > 64 * 1024) return tsim_fail(TSIM_ENOTSUP, "num_f + num_outputs too large for LDS staging (%zu B)", lds1);
+    hipLaunchKernelGGL(k_sample_lw, dim3((unsigned)grid1), dim3(blk1), lds1, s, l);
+    HIP_TRY(hipGetLastError());
+    if (prof) { int r = prof_event(p, s, PROF_PASS1); if (r) return r; }
+    // pass 2 below runs on the hard lists; the check row was forced into one of them
+    a.row_index = l.hard_index;
+    a.row_count = ctl;
+    a.row_lists = n_lists;
+    a.row_list_cap = (int)list_cap;
+    a.check_row = has_check ? ctl + 32 * TSIMK_LW_LISTS : nullptr;
+    a.no_check = has_check ? 0 : 1;
+    B2 = list_cap;
+  } else if (!has_check) {
+    a.no_check = 1;
+  }
+  int block = 256;
+  size_t lds = (size_t)(2 * a.WF + 2 * a.WO) * block * 4;
+  if (lds > 60 * 1024) { block = 64; lds = (size_t)(2 * a.WF + 2 * a.WO) * block * 4; }
+  if (lds > 60 * 1024) return tsim_fail(TSIM_ENOTSUP, "num_f + num_outputs too large for LDS staging (%zu B)", lds);
+  const long long nlists = a.row_lists > 1 ? a.row_lists : 1;
+  const long long grid = (B2 + block - 1) / block * nlists;
+  if (grid > 0x7FFFFFFFll) return tsim_fail(TSIM_ENOTSUP, "batch too large");
+  if (p->v4) {
+    // chunk-table kernel: LDS = f/out staging + two tile buffers; one extra block replays shot 0
+    Sample4Args a4;
+    a4.s = a;
+    a4.comp4_off = p->comp4_off;
+    a4.has_check = has_check ? 1 : 0;
+    const int blk = p->knobs.v4_block;
+    const size_t tile_bytes = std::max((size_t)p->v4_max_nch * 16, (size_t)p->v4_max_sent) * p->v4_gt * 16;
+    const size_t lds4 = (size_t)(2 * a.WF + 2 * a.WO) * blk * 4 + 2 * tile_bytes;
+    if (lds4 > 64 * 1024) return tsim_fail(TSIM_ENOTSUP, "v4 kernel needs %zu B of LDS", lds4);
+    if (a.row_lists > 1 && p->knobs.hard_kernel) {
+      // short row lists (second pass of a two-pass launch): NW waves per 64 rows, tsim_kernel4h.hip.h
+      constexpr int NW = TSIM_HARD_NW;
+      hard_geometry(p, a.WF, a.WO);
+      const int group_tiles = p->h_group_tiles;
+      if (group_tiles >= 1 && plan.defer && pipelined) {
+        // leave the hard rows to the next batch: this lane goes on with the next launch's first pass
+        if (!p->deferred.empty() && (p->slots[p->deferred[0]].ctx.WF != a.WF || p->slots[p->deferred[0]].ctx.WO != a.WO))
+          if (int r = tsim_flush_hard(p)) return r;  // one LDS layout per batch
+        sl.ctx = a;
+        sl.ctx.row_slot_begin = 0;
+        sl.ctx.row_slot_end = 0;
+        sl.ctx_check = has_check;
+        sl.deferred = true;
+        sl.pending = true;
+        sl.p1_stream = s;
+        p->deferred.push_back(slot);
+        if ((int)p->deferred.size() >= p->knobs.defer_group) return tsim_flush_hard(p);
+        return 0;
+      }
+      if (group_tiles >= 1) {
+        // the first kHardBlocks * 64 slots of every list go to the NW-wave kernel; k_sample4 below
+        // serves the rest (its blocks exit at once when the lists are short - the usual case)
+        constexpr int kHardBlocks = 4;
+        const size_t ldsh = p->h_lds;
+        const long long gridh = (long long)kHardBlocks * nlists + a4.has_check;
+        Sample4Args ah = a4;
+        ah.s.row_slot_end = need_overflow ? kHardBlocks * 64 : 0;
+        const int loop_stride = need_overflow ? 0 : kHardBlocks * 64;
+        switch (p->v4_max_nch) {
+#define TSIM_LH(N)                                                                                          \
+  case N: {                                                                                                 \
+    auto kfn = k_sample4h<4, N, NW>;                                                                        \
+    if (!p->h_attr_set)                                                                                     \
+      HIP_TRY(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+    hipLaunchKernelGGL(kfn, dim3((unsigned)gridh), dim3(NW * 64), ldsh, s, ah, group_tiles, loop_stride,    \
+                       p->d_feedback);                                                                      \
+  } break;
+          TSIM_LH(2) TSIM_LH(4) TSIM_LH(6) TSIM_LH(8) TSIM_LH(10) TSIM_LH(12) TSIM_LH(14) TSIM_LH(16)
+#undef TSIM_LH
+          default: return tsim_fail(TSIM_ESTATE, "bad chunk count %d", p->v4_max_nch);
+        }
+        HIP_TRY(hipGetLastError());
+        if (prof && !p->prof_light) { int r = prof_event(p, s, PROF_HARD); if (r) return r; }
+        p->h_attr_set = true;
+        a4.has_check = 0;  // done by the kernel above
+        a4.s.no_check = 1;
+        a4.s.row_slot_begin = kHardBlocks * 64;
+        B2 = need_overflow ? std::max<long long>(0, B2 - kHardBlocks * 64) : 0;
+      }
+    }
+    const long long grid4 = (B2 + blk - 1) / blk * nlists + a4.has_check;
+    if (grid4 > 0x7FFFFFFFll) return tsim_fail(TSIM_ENOTSUP, "batch too large");
+    if (grid4 > 0) switch (p->v4_max_nch) {
+#define TSIM_L4(N) case N: hipLaunchKernelGGL((k_sample4<4, N>), dim3((unsigned)grid4), dim3(blk), lds4, s, a4); break;
+      TSIM_L4(2) TSIM_L4(4) TSIM_L4(6) TSIM_L4(8) TSIM_L4(10) TSIM_L4(12) TSIM_L4(14)
+#undef TSIM_L4
+      default: hipLaunchKernelGGL((k_sample4<4, 16>), dim3((unsigned)grid4), dim3(blk), lds4, s, a4); break;
+    }
+    HIP_TRY(hipGetLastError());
+    if (prof && !(p->prof_light && use_tables)) { int r = prof_event(p, s, PROF_FULL); if (r) return r; }
+    return finish();
+  }
+  int wmax = 1;
+  for (int w : p->comp_w) wmax = std::max(wmax, w);
+  if (int r = tsim_launch_rows(p, wmax, a, grid, block, lds, s)) return r;
+  if (prof && !(p->prof_light && use_tables)) { int r = prof_event(p, s, PROF_FULL); if (r) return r; }
+  return finish();
+}
+extern "C" int tsim_sample_batch_device_begin(tsim_program *p, int32_t slot, const uint64_t *d_f, int64_t B,
+                                              int32_t num_f, uint32_t key_hi, uint32_t key_lo, int64_t shot_offset,
+                                              uint64_t *d_out, float *d_max_norm_dev, void *stream, uint32_t flags) {
+  if (int r = tsim_need_final(p)) return r;
+  if (int r = tsim_set_device(p)) return r;
+  if (slot < 0 || slot >= TSIM_PIPELINE_SLOTS) return tsim_fail(TSIM_EINVAL, "slot %d out of range", slot);
+  hipStream_t s_user = stream ? (hipStream_t)stream : p->stream;
+  tsim_program::Slot &sl = p->slots[1 + slot];
+  if (!p->slots_ready) {  // first pipelined launch: create every slot's stream/buffers now, not mid-run
+    size_t hard_bytes = 0;
+    if (p->lw) hard_bytes = (size_t)(((B + 255) / 256 + TSIMK_LW_LISTS - 1) / TSIMK_LW_LISTS * 1024) * TSIMK_LW_LISTS * 4;
+    for (int k = 1; k <= TSIM_PIPELINE_SLOTS; ++k)
+      if (int r = slot_prepare(p, k, hard_bytes)) return r;
+    p->slots_ready = true;
+  }
+  if (int r = slot_prepare(p, 1 + slot, 0)) return r;
+  // The whole launch runs on the slot's own stream (a "lane"): launches of one slot are ordered by the
+  // stream itself, launches of different slots overlap.  Unless the caller vouches for its inputs the
+  // lane first waits for what is already queued on the caller's stream.
+  // Deferred plan (short hard-row lists): the first passes alternate between the first two lanes and
+  // the hard rows of several launches go to the third lane in one batch (flush_hard), so no lane
+  // waits for a second pass before it starts the next first pass.
+  if (sl.deferred)  // begin twice without end: finish the earlier launch's hard rows first
+    if (int r = tsim_flush_hard(p)) return r;
+  const LaunchPlan plan = make_plan(p, false, true);
+  hipStream_t s = plan.defer ? p->slots[1 + (slot & 1)].side : sl.side;
+  if (!plan.defer) sl.used = true;
+  // the slot's previous launch (its lists, counters and output rows are reused) finished on another stream:
+  // this launch must be ordered after it
+  if (sl.last_done && sl.last_done != s && sl.done_ev) {
+    bool done = false;
+    if (sl.batch_seq) {
+      // Batches complete in order (one stream) and a lane is in order too: once a lane waits for batch b it
+      // is behind every batch <= b.  The four slots of a batch alternate over the two lanes, so this is
+      // one stream wait per lane and batch - no event query (the host usually runs several batches ahead
+      // of the GPU, the query would fail and cost as much as the wait).
+      const int lane = (s == p->slots[1].side) ? 0 : (s == p->slots[2].side) ? 1 : -1;
+      if (sl.batch_seq <= p->batch_confirmed || (lane >= 0 && sl.batch_seq <= p->lane_waited[lane])) done = true;
+      else if (lane >= 0) p->lane_waited[lane] = sl.batch_seq;
+    } else {
+      ++p->stat_queries;
+      done = hipEventQuery(sl.done_ev) == hipSuccess;
+      if (!done) (void)hipGetLastError();
+    }
+    if (!done) { ++p->stat_waits; HIP_TRY(hipStreamWaitEvent(s, sl.done_ev, 0)); }
+  }
+  ++p->stat_begins;
+  if (plan.defer) ++p->stat_deferred;
+  if (!(flags & TSIM_PIPE_INPUTS_READY) && s_user != s) {
+    HIP_TRY(hipEventRecord(sl.ev1, s_user));
+    HIP_TRY(hipStreamWaitEvent(s, sl.ev1, 0));
+  }
+  return launch_sample(p, d_f, B, num_f, key_hi, key_lo, shot_offset, d_out, d_max_norm_dev, s, nullptr, nullptr,
+                       1 + slot, &plan);
+}
+
+extern "C" int tsim_pipeline_lane_stream(tsim_program *p, int32_t lane, void **stream) {
+  if (int r = tsim_need_final(p)) return r;
+  if (int r = tsim_set_device(p)) return r;
+  if (lane < 0 || lane >= TSIM_PIPELINE_SLOTS || !stream) return tsim_fail(TSIM_EINVAL, "bad lane %d", lane);
+  if (int r = slot_prepare(p, 1 + lane, 0)) return r;
+  *stream = (void *)p->slots[1 + lane].side;
+  return TSIM_OK;
+}
+
+extern "C" int tsim_pipeline_wait_stream(tsim_program *p, void *stream) {
+  if (int r = tsim_need_final(p)) return r;
+  if (int r = tsim_set_device(p)) return r;
+  hipStream_t s_user = stream ? (hipStream_t)stream : p->stream;
+  if (!p->slots_ready) return TSIM_OK;  // no lane exists yet: the first launches order themselves
+  if (!p->sync_ev) HIP_TRY(hipEventCreateWithFlags(&p->sync_ev, hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(p->sync_ev, s_user));
+  // every lane a launch may run on: the slots' own streams that were used so far and the first three
+  // (first passes / hard-row batches of the deferred plan)
+  std::vector<hipStream_t> seen;
+  for (int k = 1; k <= TSIM_PIPELINE_SLOTS; ++k) {
+    tsim_program::Slot &sl = p->slots[k];
+    if (!sl.side_ready || (k > 3 && !sl.used) || sl.side == s_user) continue;
+    if (std::find(seen.begin(), seen.end(), sl.side) != seen.end()) continue;
+    seen.push_back(sl.side);
+    HIP_TRY(hipStreamWaitEvent(sl.side, p->sync_ev, 0));
+  }
+  return TSIM_OK;
+}
+
+extern "C" int tsim_pipeline_set_compact_series(tsim_program *p, uint8_t *d_base, int64_t stride_bytes, int32_t count) {
+  if (int r = tsim_need_final(p)) return r;
+  if (count < 0 || stride_bytes < 0 || (count > 0 && !d_base)) return tsim_fail(TSIM_EINVAL, "bad compact series");
+  p->series_ptr = d_base;
+  p->series_stride = stride_bytes;
+  p->series_left = count;
+  return TSIM_OK;
+}
+
+extern "C" int tsim_pipeline_set_compact_output(tsim_program *p, int32_t slot, uint8_t *d_compact) {
+  if (int r = tsim_need_final(p)) return r;
+  if (slot < 0 || slot >= TSIM_PIPELINE_SLOTS) return tsim_fail(TSIM_EINVAL, "slot %d out of range", slot);
+  p->slots[1 + slot].compact_out = d_compact;
+  return TSIM_OK;
+}
+
+extern "C" int tsim_sample_batch_device_compact(tsim_program *p, int32_t slot, const uint64_t *d_rows, int64_t B,
+                                                int32_t nbits, uint8_t *d_out, void *stream) {
+  if (int r = tsim_need_final(p)) return r;
+  if (int r = tsim_set_device(p)) return r;
+  if (slot < 0 || slot >= TSIM_PIPELINE_SLOTS) return tsim_fail(TSIM_EINVAL, "slot %d out of range", slot);
+  if (B < 0 || nbits < 0) return tsim_fail(TSIM_EINVAL, "negative size");
+  if (B == 0 || nbits == 0) return TSIM_OK;
+  if (!d_rows || !d_out) return tsim_fail(TSIM_EINVAL, "NULL buffer");
+  tsim_program::Slot &sl = p->slots[1 + slot];
+  if (sl.deferred)
+    if (int r = tsim_flush_hard(p)) return r;
+  // after the slot's second pass when there is one in flight, else simply on the caller's stream
+  hipStream_t s = sl.pending ? sl.last_done : (stream ? (hipStream_t)stream : p->stream);
+  if (int r = tsim_launch_compact(d_rows, B, (nbits + 63) / 64, nbits, d_out, s)) return r;
+  if (sl.pending) {
+    HIP_TRY(hipEventRecord(sl.ev2, s));
+    sl.done_ev = sl.ev2;
+    sl.batch_seq = 0;
+  }
+  return TSIM_OK;
+}
+
+extern "C" int tsim_sample_batch_device_end(tsim_program *p, int32_t slot, void *stream) {
+  if (int r = tsim_need_final(p)) return r;
+  if (int r = tsim_set_device(p)) return r;
+  if (slot < 0 || slot >= TSIM_PIPELINE_SLOTS) return tsim_fail(TSIM_EINVAL, "slot %d out of range", slot);
+  hipStream_t s = stream ? (hipStream_t)stream : p->stream;
+  tsim_program::Slot &sl = p->slots[1 + slot];
+  if (sl.deferred)  // its batch is not full yet: run what is waiting now
+    if (int r = tsim_flush_hard(p)) return r;
+  if (sl.pending) {
+    if (sl.last_done != s) HIP_TRY(hipStreamWaitEvent(s, sl.done_ev, 0));
+    sl.pending = false;
+  }
+  return TSIM_OK;
+}
+
+extern "C" int tsim_sample_batch_device(tsim_program *p, const uint64_t *d_f, int64_t B, int32_t num_f,
+                                        uint32_t key_hi, uint32_t key_lo, int64_t shot_offset,
+                                        uint64_t *d_out, float *d_max_norm_dev, void *stream) {
+  if (int r = tsim_need_final(p)) return r;
+  if (int r = tsim_set_device(p)) return r;
+  hipStream_t s = stream ? (hipStream_t)stream : p->stream;
+  return launch_sample(p, d_f, B, num_f, key_hi, key_lo, shot_offset, d_out, d_max_norm_dev, s);
+}
+extern "C" int tsim_sample_rows_device(tsim_program *p, const uint64_t *d_f, int64_t B, int32_t num_f,
+                                       uint32_t key_hi, uint32_t key_lo, int64_t shot_offset, uint64_t *d_out,
+                                       float *d_max_norm_dev, const uint32_t *d_row_index,
+                                       const uint32_t *d_row_count, void *stream) {
+  if (int r = tsim_need_final(p)) return r;
+  if (int r = tsim_set_device(p)) return r;
+  if (!d_row_index || !d_row_count) return tsim_fail(TSIM_EINVAL, "row list is NULL");
+  if (B >= (1ll << 32)) return tsim_fail(TSIM_ENOTSUP, "row indices are 32-bit");
+  hipStream_t s = stream ? (hipStream_t)stream : p->stream;
+  return launch_sample(p, d_f, B, num_f, key_hi, key_lo, shot_offset, d_out, d_max_norm_dev, s, d_row_index,
+                       d_row_count);
+}
+
+extern "C" int tsim_postselect_device(tsim_program *p, const uint64_t *d_f, int64_t B, int32_t num_f,
+                                      const uint64_t *d_mask, const uint64_t *d_ref, uint64_t *d_out,
+                                      uint32_t *d_row_index, uint32_t *d_row_count, uint8_t *d_discarded,
+                                      void *stream) {
+  if (int r = tsim_need_final(p)) return r;
+  if (int r = tsim_set_device(p)) return r;
+  if (B < 0 || num_f < 0) return tsim_fail(TSIM_EINVAL, "negative size");
+  if (B >= (1ll << 32)) return tsim_fail(TSIM_ENOTSUP, "row indices are 32-bit");
+  if (p->max_f_index >= num_f) return tsim_fail(TSIM_EINVAL, "program references f index %d but num_f=%d", p->max_f_index, num_f);
+  if (!d_mask || !d_out || !d_row_index || !d_row_count) return tsim_fail(TSIM_EINVAL, "NULL buffer");
+  hipStream_t s = stream ? (hipStream_t)stream : p->stream;
+  HIP_TRY(hipMemsetAsync(d_row_count, 0, 4, s));
+  if (B == 0 || p->num_outputs == 0) return TSIM_OK;
+  FilterArgs a;
+  a.img = p->d_img;
+  a.f = d_f;
+  a.out = d_out;
+  a.mask = d_mask;
+  a.ref = d_ref;
+  a.row_index = d_row_index;
+  a.row_count = d_row_count;
+  a.discarded = d_discarded;
+  a.B = B;
+  a.WF = num_f == 0 ? 0 : std::max(1, (num_f + 63) / 64);
+  a.WO = (p->num_outputs + 63) / 64;
+  a.n_direct = p->n_direct;
+  a.direct_off = p->direct_off;
+  int block = 256;
+  size_t lds = (size_t)(2 * a.WF + 2 * a.WO) * block * 4;
+  if (lds > 60 * 1024) { block = 64; lds = (size_t)(2 * a.WF + 2 * a.WO) * block * 4; }
+  if (lds > 60 * 1024) return tsim_fail(TSIM_ENOTSUP, "num_f + num_outputs too large for LDS staging (%zu B)", lds);
+  hipLaunchKernelGGL(k_direct_filter, dim3((unsigned)((B + block - 1) / block)), dim3(block), lds, s, a);
+  HIP_TRY(hipGetLastError());
+  return TSIM_OK;
+}
+extern "C" int tsim_sample_batch(tsim_program *p, const uint8_t *f, int64_t B, int32_t num_f, uint32_t key_hi,
+                                 uint32_t key_lo, int64_t shot_offset, uint8_t *out, int32_t out_packed,
+                                 float *max_norm_dev) {
+  if (int r = tsim_need_final(p)) return r;
+  if (int r = tsim_set_device(p)) return r;
+  if (B < 0 || num_f < 0) return tsim_fail(TSIM_EINVAL, "negative B/num_f");
+  if (B == 0 || p->num_outputs == 0) return 0;
+  if (!out) return tsim_fail(TSIM_EINVAL, "out is NULL");
+  if (!f && num_f > 0) return tsim_fail(TSIM_EINVAL, "f is NULL");
+  const int WF = std::max(1, (num_f + 63) / 64), WO = (p->num_outputs + 63) / 64;
+  hipStream_t s = p->stream;
+  if (int r = tsim_ensure_scratch(p, 0, (size_t)B * std::max(1, num_f))) return r;
+  if (int r = tsim_ensure_scratch(p, 1, (size_t)B * WF * 8)) return r;
+  if (int r = tsim_ensure_scratch(p, 2, (size_t)B * WO * 8)) return r;
+  if (num_f > 0) {
+    HIP_TRY(hipMemcpyAsync(p->scratch[0], f, (size_t)B * num_f, hipMemcpyHostToDevice, s));
+    if (int r = tsim_launch_pack(p, (const uint8_t *)p->scratch[0], B, num_f, (uint64_t *)p->scratch[1], s)) return r;
+  }
+  if (int r = launch_sample(p, (const uint64_t *)p->scratch[1], B, num_f, key_hi, key_lo, shot_offset,
+                            (uint64_t *)p->scratch[2], p->d_dev, s))
+    return r;
+  if (out_packed) {
+    HIP_TRY(hipMemcpyAsync(out, p->scratch[2], (size_t)B * WO * 8, hipMemcpyDeviceToHost, s));
+  } else {
+    if (int r = tsim_ensure_scratch(p, 3, (size_t)B * p->num_outputs)) return r;
+    if (int r = tsim_launch_unpack(p, (const uint64_t *)p->scratch[2], B, p->num_outputs, (uint8_t *)p->scratch[3], s)) return r;
+    HIP_TRY(hipMemcpyAsync(out, p->scratch[3], (size_t)B * p->num_outputs, hipMemcpyDeviceToHost, s));
+  }
+  if (max_norm_dev && shot_offset == 0 && !p->comps.empty())
+    HIP_TRY(hipMemcpyAsync(max_norm_dev, p->d_dev, p->comps.size() * 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  return TSIM_OK;
+}
+extern "C" int tsim_profile_enable(tsim_program *p, int32_t on) {
+  if (int r = tsim_need_final(p)) return r;
+  if (int r = tsim_set_device(p)) return r;
+  if (!on && p->ev_used) { if (int r = prof_drain(p)) return r; }
+  p->profiling = on != 0;
+  p->prof_light = on == 2;
+  p->prof_counter = 0;
+  return TSIM_OK;
+}
+
+extern "C" int tsim_profile_set_sampling(tsim_program *p, int32_t every) {
+  if (!p || every < 1) return tsim_fail(TSIM_EINVAL, "bad argument");
+  p->prof_every = every;
+  p->prof_counter = 0;
+  return TSIM_OK;
+}
+
+extern "C" int tsim_profile_read(tsim_program *p, double *kernel_ms, int64_t *launches, int32_t reset) {
+  if (int r = tsim_need_final(p)) return r;
+  if (int r = tsim_set_device(p)) return r;
+  if (int r = prof_drain(p)) return r;
+  if (kernel_ms) *kernel_ms = p->prof_ms;
+  if (launches) *launches = p->prof_launches;
+  if (reset) {
+    p->prof_ms = 0.0;
+    p->prof_launches = 0;
+    for (double &v : p->prof_stage_ms) v = 0.0;
+  }
+  return TSIM_OK;
+}
+
+extern "C" int tsim_profile_read_stages(tsim_program *p, double stage_ms[3]) {
+  if (int r = tsim_need_final(p)) return r;
+  if (int r = tsim_set_device(p)) return r;
+  if (!stage_ms) return tsim_fail(TSIM_EINVAL, "NULL argument");
+  if (int r = prof_drain(p)) return r;
+  stage_ms[0] = p->prof_stage_ms[PROF_PASS1];
+  stage_ms[1] = p->prof_stage_ms[PROF_HARD];
+  stage_ms[2] = p->prof_stage_ms[PROF_FULL];
+  return TSIM_OK;
+}

@@ -310,11 +310,244 @@ CONFIGS = {
 }
 
 
-def config_program(name: str, *, approx: bool = False) -> tuple[CompiledProgram, dict]:
-    """Return ``(program, config_dict)`` for one of ``C1..C5``."""
+def config_program(name: str, *, approx: bool = False, physical: bool = True) -> tuple[CompiledProgram, dict]:
+    """Return ``(program, config_dict)`` for one of ``C1..C5``.
+
+    ``physical=True`` (default): the normalised probability model of :func:`physical_program`;
+    ``physical=False``: the unconstrained random program of :func:`synth_program` (nonsense marginals,
+    NaN / negative thresholds - the kernels must equal the oracle on those too)."""
     cfg = CONFIGS[name]
+    if physical:
+        prog = physical_program(num_f=cfg["num_f"], n_direct=cfg["n_direct"], components=[dict(c) for c in cfg["components"]],
+                                seed=cfg["seed"], approx=approx)
+        return prog, dict(cfg, name=cfg["name"] + ", normalised probability model")
     comps = [dict(c, approx=approx) if approx else dict(c) for c in cfg["components"]]
     prog = synth_program(
         num_f=cfg["num_f"], n_direct=cfg["n_direct"], components=comps, seed=cfg["seed"]
     )
     return prog, cfg
+
+
+# --------------------------------------------------------------------------
+# physically normalised synthetic programs
+# --------------------------------------------------------------------------
+#
+# The random programs above have the published SHAPE but their "amplitudes" are not probabilities:
+# p1/prev is often outside [0, 1], so many Bernoulli draws are decided whatever the float value.
+# The programs below are genuine probability models with the same shape - a mixture of product
+# distributions, written in the reference's own term families - so that for every level i
+#
+#     amp_i(f, m_<i, 0) + amp_i(f, m_<i, 1) == amp_{i-1}(f, m_<i)        exactly (in Z[w] * 2^k)
+#     amp_i >= 0
+#
+# and therefore every threshold p1/prev lies in [0, 1] and the normalisation check
+# (sampler.py:66-72) deviates from 1 only by float32 rounding.
+#
+# Construction.  A *lineage* is a set of graphs (stabiliser terms) that is extended in lockstep, one
+# conditional factor q_j(m_j | f, m_<j) per output, with sum_{m_j} q_j = 1:
+#   "T"  NodePhases pair (k, 8-k), k in {1, 3}, on the same parity row r + {m_j}:
+#        (1 + w^(k+4p))(1 + w^(-k+4p)) = 2 +- sqrt2 (-1)^p, power2 -= 2      -> (2 +- sqrt2)/4
+#   "U"  NodePhases pair (2, 6): (1 + i^..)(1 - i^..) = 2, power2 -= 2         -> 1/2
+#   "D"  one NodePhases term of phase 0 / 4: 1 +- (-1)^p, power2 -= 1          -> delta(p = 0 / 1)
+#   "S"  the "T" factor split over TWO graphs: 1/2  and  (w + conj w)/4 * w^(4p) (a HalfPi term of
+#        coefficient 4 and floatfactor * (0,1,0,1)): the second one alone is signed, their sum is not.
+# Members of a lineage differ by what they carry from level 0 on and keep at every level:
+#   * a positive weight (floatfactor * 2^power2), optionally f-dependent through "T" factors on f rows;
+#   * sign factors s(f) = +-1 on f rows - PiProducts (-1)^(psi phi) and PhasePairs with alpha, beta in
+#     {0, 4} (1 + w^a + w^b - w^(a+b) = 2 (-1)^(pa pb), power2 -= 1) - always next to an unsigned
+#     member of three times the weight, so that the lineage's sum stays positive.
+# Every graph is then padded with *neutral* terms on rows over ALL parameters (HalfPi pairs of
+# coefficients (2,6) or (4,4) on one row, duplicated PiProducts, duplicated sign-type PhasePairs with
+# power2 -= 2, NodePhases (2,6) pairs with power2 -= 1) up to the term counts of the published shape:
+# they change no value but are real work for the oracle and the faithful kernel.
+
+
+def _zw_mul(x, y):
+    """Product in Z[w] on the basis (1, w, i, conj w) (exact_scalar.py:19-39)."""
+    a1, b1, c1, d1 = x
+    a2, b2, c2, d2 = y
+    return (
+        a1 * a2 + b1 * d2 - c1 * c2 + d1 * b2,
+        a1 * b2 + b1 * a2 + c1 * d2 + d1 * c2,
+        a1 * c2 + b1 * b2 + c1 * a2 - d1 * d2,
+        a1 * d2 - b1 * c2 - c1 * b2 + d1 * a2,
+    )
+
+
+def _zw_norm(ff, power2):
+    """Pull common factors of two out of a floatfactor."""
+    ff = tuple(int(v) for v in ff)
+    while any(ff) and all(v % 2 == 0 for v in ff):
+        ff = tuple(v // 2 for v in ff)
+        power2 += 1
+    return ff, power2
+
+
+def _copy_graph(g: dict) -> dict:
+    return dict(A=list(g["A"]), B=list(g["B"]), C=list(g["C"]), D=list(g["D"]), phase=g["phase"],
+                floatfactor=tuple(g["floatfactor"]), power2=g["power2"], approx=g.get("approx", 1.0))
+
+
+def _rand_row(rng, lo: int, hi: int, density: float) -> list[int]:
+    """Random non-empty subset of the parameter indices [lo, hi)."""
+    n = hi - lo
+    if n <= 0:
+        return []
+    m = rng.random(n) < density
+    if not m.any():
+        m[rng.integers(0, n)] = True
+    return (lo + np.flatnonzero(m)).tolist()
+
+
+def _sign_terms(rng, F: int, density: float, n_c: int, n_d: int):
+    """Random f-only sign factors: ``n_c`` PiProducts and ``n_d`` sign-type PhasePairs (+ power shift)."""
+    C = [(int(rng.integers(0, 2)), _rand_row(rng, 0, F, density), int(rng.integers(0, 2)), _rand_row(rng, 0, F, density))
+         for _ in range(n_c)]
+    D = [(int(rng.choice([0, 4])), _rand_row(rng, 0, F, density), int(rng.choice([0, 4])), _rand_row(rng, 0, F, density))
+         for _ in range(n_d)]
+    return C, D, -n_d
+
+
+def _pad_neutral(rng, g: dict, P: int, density: float, ta, tb, tc, td) -> dict:
+    """Neutral terms up to the shape's term counts (drawn per graph from the given ranges)."""
+    g = _copy_graph(g)
+    if P == 0:
+        return g
+    want_a = int(rng.integers(ta[0], ta[1] + 1))
+    want_b = int(rng.integers(tb[0], tb[1] + 1))
+    want_c = int(rng.integers(tc[0], tc[1] + 1))
+    want_d = int(rng.integers(td[0], td[1] + 1))
+    while len(g["A"]) + 2 <= want_a:
+        row = _rand_row(rng, 0, P, density)
+        g["A"] += [(2, row), (6, row)]
+        g["power2"] -= 1
+    while len(g["B"]) + 2 <= want_b:
+        row = _rand_row(rng, 0, P, density)
+        g["B"] += [(2, row), (6, row)] if rng.random() < 0.5 else [(4, row), (4, row)]
+    while len(g["C"]) + 2 <= want_c:
+        t = (int(rng.integers(0, 2)), _rand_row(rng, 0, P, density), int(rng.integers(0, 2)), _rand_row(rng, 0, P, density))
+        g["C"] += [t, t]
+    while len(g["D"]) + 2 <= want_d:
+        t = (int(rng.choice([0, 4])), _rand_row(rng, 0, P, density), int(rng.choice([0, 4])), _rand_row(rng, 0, P, density))
+        g["D"] += [t, t]
+        g["power2"] -= 2
+    # interleave: the families are products, term order is free (rows of one pair need not be adjacent)
+    for fam in "ABCD":
+        order = rng.permutation(len(g[fam]))
+        g[fam] = [g[fam][int(k)] for k in order]
+    return g
+
+
+def physical_component(rng, output_indices, f_selection, Gs, *, density: float = 0.3, ta=(4, 16), tb=(4, 24),
+                       tc=(8, 40), td=(0, 4), approx: bool = False, delta_fraction: float = 0.08,
+                       signed_fraction: float = 0.35) -> CompiledComponent:
+    """One normalised component with ``Gs[k]`` graphs at level k (see the block comment above)."""
+    n, F = len(output_indices), len(f_selection)
+    if len(Gs) != n + 1:
+        raise ValueError("need n+1 graph counts per component")
+    if any(b < a for a, b in zip(Gs, Gs[1:])) or Gs[0] < 1:
+        raise ValueError("graph counts must be positive and non-decreasing")
+    # ---- level 0: lineages of one unsigned member, or an (unsigned x3, signed x1) pair
+    lineages: list[list[dict]] = []
+    left = Gs[0]
+    while left > 0:
+        base = dict(A=[], B=[], C=[], D=[], phase=0, floatfactor=(int(rng.integers(1, 4)), 0, 0, 0),
+                    power2=int(rng.integers(-3, 1)), approx=1.0)
+        if approx:
+            base["approx"] = complex(0.5 + rng.random())  # real positive: mixture weights stay positive
+        if F > 0:
+            for _ in range(int(rng.integers(0, 3))):  # f-dependent weight
+                k = int(rng.choice([1, 3]))
+                row = _rand_row(rng, 0, F, density)
+                base["A"] += [(k, row), (8 - k, row)]
+                base["power2"] -= 2
+        if left >= 2 and F > 0 and rng.random() < signed_fraction:
+            big, small = _copy_graph(base), _copy_graph(base)
+            big["floatfactor"] = tuple(3 * v for v in base["floatfactor"])
+            C, D, dp = _sign_terms(rng, F, density, int(rng.integers(max(1, tc[0] // 2), max(2, tc[1] // 2) + 1)),
+                                   int(rng.integers(0, max(1, td[1] // 2) + 1)))
+            small["C"], small["D"] = C, D
+            small["power2"] += dp
+            lineages.append([big, small])
+            left -= 2
+        else:
+            lineages.append([base])
+            left -= 1
+    levels = []
+
+    def emit(k: int):
+        graphs = [_pad_neutral(rng, g, F + k, density, ta, tb, tc, td) for lin in lineages for g in lin]
+        assert len(graphs) == Gs[k]
+        return scalar_graphs_from_terms(F + k, graphs)
+
+    levels.append(emit(0))
+    # ---- one conditional factor per output
+    for j in range(n):
+        bit = F + j
+        grow = Gs[j + 1] - Gs[j]
+        order = rng.permutation(len(lineages))
+        split = set()
+        for li in order:  # lineages that take the two-graph form of the factor
+            s = len(lineages[int(li)])
+            if s <= grow and rng.random() < 0.8:
+                split.add(int(li))
+                grow -= s
+        for li, lin in enumerate(lineages):
+            row = _rand_row(rng, 0, bit, density) + [bit] if bit > 0 else [bit]
+            if bit > 0 and rng.random() < 0.15:
+                row = [bit]  # an output that ignores its context
+            if li in split:
+                sign = int(rng.choice([0, 4]))
+                new = []
+                for g in lin:
+                    g1, g2 = _copy_graph(g), _copy_graph(g)
+                    g1["power2"] -= 1
+                    g2["B"].append((4, row))
+                    g2["phase"] = (g2["phase"] + sign) % 8
+                    g2["floatfactor"], g2["power2"] = _zw_norm(_zw_mul(g2["floatfactor"], (0, 1, 0, 1)), g2["power2"] - 2)
+                    new += [g1, g2]
+                lin[:] = new
+                continue
+            r = rng.random()
+            for g in lin:
+                if r < delta_fraction:
+                    g["A"].append((0 if r < delta_fraction / 2 else 4, row))
+                    g["power2"] -= 1
+                elif r < delta_fraction + 0.12:
+                    g["A"] += [(2, row), (6, row)]
+                    g["power2"] -= 2
+                else:
+                    k = 1 if r < 0.6 else 3
+                    g["A"] += [(k, row), (8 - k, row)]
+                    g["power2"] -= 2
+        while grow > 0:  # duplicates: w = w/2 + w/2 inside one lineage
+            lin = lineages[int(rng.integers(0, len(lineages)))]
+            src = int(rng.integers(0, len(lin)))
+            lin[src]["power2"] -= 1
+            lin.insert(src + 1, _copy_graph(lin[src]))
+            grow -= 1
+        levels.append(emit(j + 1))
+    return CompiledComponent(tuple(int(i) for i in output_indices), np.asarray(f_selection, np.int32), tuple(levels))
+
+
+def physical_program(*, num_f: int, n_direct: int, components: list[dict], seed: int = 42,
+                     num_detectors: int | None = None, shuffle_outputs: bool = False,
+                     direct_flip_fraction: float = 0.0, identity_direct: bool = True,
+                     approx: bool = False) -> CompiledProgram:
+    """Normalised counterpart of :func:`synth_program` (same arguments, same shapes)."""
+    rng = np.random.default_rng([seed, 0x70687973])
+    n_comp_out = sum(c["n"] for c in components)
+    num_outputs = n_direct + n_comp_out
+    out_ids = rng.permutation(num_outputs) if shuffle_outputs else np.arange(num_outputs)
+    dfi = np.arange(n_direct) if identity_direct else (rng.choice(num_f, size=n_direct, replace=False) if n_direct else np.zeros(0, int))
+    flips = rng.random(n_direct) < direct_flip_fraction
+    direct = [(int(out_ids[j]), int(dfi[j]), bool(flips[j])) for j in range(n_direct)]
+    comps, pos = [], n_direct
+    for c in components:
+        n, F = int(c["n"]), int(c["F"])
+        kw = {k: v for k, v in c.items() if k in ("density", "ta", "tb", "tc", "td")}
+        fsel = np.sort(rng.choice(num_f, size=F, replace=False)).astype(np.int32)
+        comps.append(physical_component(rng, out_ids[pos:pos + n], fsel, list(c["G"]), approx=approx, **kw))
+        pos += n
+    nd = num_detectors if num_detectors is not None else n_direct
+    return make_program(comps, direct, num_outputs, nd)

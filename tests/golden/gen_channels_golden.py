@@ -62,10 +62,18 @@ def main():
     ref = load_reference()
     rng = np.random.default_rng(20260928)
     out = {}
-    cases = [(3, 4), (6, 5), (10, 8), (16, 12), (25, 20), (40, 33)]
+    # (channels, num_f, distinct columns): the last entry, when set, rebuilds error_transform from that few
+    # distinct columns plus zero columns, so that duplicate folding, multi-bit marginalisation, merging and
+    # subset absorption all fire many times (added in round 2, after the six original cases)
+    cases = [(3, 4, 0), (6, 5, 0), (10, 8, 0), (16, 12, 0), (25, 20, 0), (40, 33, 0),
+             (8, 3, 2), (14, 6, 2), (20, 7, 3), (30, 9, 3), (12, 70, 4), (24, 130, 5)]
     out["n_cases"] = np.int64(len(cases))
-    for ci, (nch, num_f) in enumerate(cases):
+    for ci, (nch, num_f, distinct) in enumerate(cases):
         probs, T = random_case(rng, ref, nch, num_f)
+        if distinct:
+            base = (rng.random((num_f, distinct)) < 0.5).astype(np.uint8)
+            T = np.stack([base[:, rng.integers(0, distinct)] if rng.random() > 0.3 else np.zeros(num_f, np.uint8)
+                          for _ in range(T.shape[1])], axis=1)
         seed = 1000 + ci
         s = ref.ChannelSampler(probs, T, seed=seed)
         out[f"c{ci}_n_channels"] = np.int64(nch)

@@ -52,7 +52,7 @@ def test_thresholds_are_probabilities_on_device(hip, name):
             p0 = hp.evaluate(ci, i + 1, np.concatenate([ctx, np.zeros((B, 1), np.uint8)], axis=1), return_abs=True)
             p1 = hp.evaluate(ci, i + 1, np.concatenate([ctx, np.ones((B, 1), np.uint8)], axis=1), return_abs=True)
             assert (p1 <= prev * (1 + 1e-6)).all() and (p0 <= prev * (1 + 1e-6)).all()
-            np.testing.assert_allclose(p0 + p1, prev, rtol=2e-6)
+            np.testing.assert_allclose(p0 + p1, prev, rtol=1e-5)  # the bound above which sampler.py:156 warns
             prev = np.where(m[:, i] != 0, p1, p0)
 
 

@@ -1,21 +1,27 @@
-"""Host-side noise sampling: error channels -> error-mechanism bit-vectors ``f``.
+"""Noise model -> error-mechanism rows ``f`` (host side of the path).
 
-Mirror of the reference's ``ChannelSampler`` (src/tsim/noise/channels.py:503-658) with the
-same constructor arguments, attributes (``channels``, ``signature_matrix``) and ``sample``
-semantics, so that for a fixed seed it consumes numpy's PCG64 stream identically and returns
-the same ``uint8[num_samples, num_f]`` array:
+What must come out is fixed by the reference (``src/tsim/noise/channels.py``): for a seed, the same
+simplified channel tables (float64, bit for bit) and the same ``uint8[num_samples, num_f]`` array as its
+``ChannelSampler`` - that is the drop-in contract, pinned by golden vectors generated from the reference
+module itself (``tests/golden/gen_channels_golden.py``).  HOW it is computed here is this repo's own:
 
-* ``f_i = XOR_j error_transform[i, j] * e_j``;
-* at construction the channels are simplified - bits that touch no ``f`` are marginalised,
-  bits with equal column signatures are XOR-folded, channels over the same signature set are
-  XOR-convolved, and channels whose signature set is a strict subset of another's (of at most
-  ``max_bits`` bits) are absorbed into it (src/tsim/noise/channels.py:230-500);
-* sampling is geometric-skip per channel: positions of firing shots from cumulative
-  ``Generator.geometric`` draws, outcome by inverse-CDF on ``Generator.uniform``, then the
-  outcome's precomputed XOR pattern is applied (src/tsim/noise/channels.py:578-658).
+* **Signatures as packed bit strings.**  ``f_i = XOR_j error_transform[i, j] e_j``: an error bit matters only
+  through its column of ``error_transform``.  Columns are packed into integers (row 0 most significant, so
+  integer order is the lexicographic column order the reference's ``np.unique(axis=1)`` yields) and
+  numbered in sorted order; the XOR pattern of a channel outcome is an XOR of packed signature words -
+  produced directly in the ``uint64`` little-endian row layout the sampling kernels read.
+* **One structural primitive.**  Dropping a bit that touches no ``f``, sorting a channel's bits, folding
+  bits with the same signature and embedding a channel into a wider one are all the same operation: the
+  push-forward of an outcome distribution along a GF(2)-linear map of the outcome bits
+  (:func:`push_forward`).  Channels on nested supports are then XOR-convolved (:func:`combine_supports`).
+* **Packed rows are the product.**  :meth:`ChannelSampler.sample_packed` scatters 8-byte words;
+  :meth:`ChannelSampler.sample` is its unpacked view for callers of the reference layout.
 
-This is host logic of the path, written against numpy only.  It is validated against golden
-vectors produced by the reference module itself (tests/golden/gen_channels_golden.py).
+Forced by the stream contract (and only that): the order of float additions inside
+:func:`push_forward`/:func:`xor_convolve`/:func:`marginalise`, and the generator-call sequence of
+:meth:`ChannelSampler._draw` (``Generator.geometric`` then ``Generator.uniform`` per channel with the
+reference's draw-count formula, ``channels.py:624-658``) together with the float sequence that builds the
+conditional CDFs (``channels.py:578-622``).
 """
 
 from __future__ import annotations
@@ -24,309 +30,298 @@ from dataclasses import dataclass
 
 import numpy as np
 
+_TOL = 1e-6
+
 
 @dataclass
 class Channel:
-    """A distribution over the 2^k outcomes of k error bits.
+    """A distribution over the ``2**k`` joint values of ``k`` error bits.
 
-    ``probs[o]`` is the probability of outcome ``o`` (bit i of ``o`` = error bit i);
-    ``unique_col_ids[i]`` names the error-transform column signature that bit i drives.
+    ``probs[o]``: probability that the bits read ``o`` (bit ``i`` of ``o`` = error bit ``i``);
+    ``unique_col_ids[i]``: number of the ``error_transform`` column signature that bit ``i`` carries.
     """
 
     probs: np.ndarray
     unique_col_ids: tuple
 
     def __post_init__(self) -> None:
-        tol = 1e-6
-        if np.any(self.probs < -tol) or np.any(self.probs > 1.0 + tol):
-            raise ValueError(f"Probabilities must lie in [0, 1], but got: {self.probs}")
-        if not np.isclose(np.sum(self.probs), 1.0):
-            raise ValueError(
-                f"Probabilities must sum to 1, but got: {self.probs} (sum {np.sum(self.probs)})"
-            )
+        p = np.asarray(self.probs, dtype=np.float64)
+        if p.ndim != 1 or p.size != 1 << len(self.unique_col_ids):
+            raise ValueError(f"a channel over {len(self.unique_col_ids)} bits needs {1 << len(self.unique_col_ids)} probabilities, got shape {p.shape}")
+        if p.min(initial=0.0) < -_TOL or p.max(initial=0.0) > 1.0 + _TOL:
+            raise ValueError(f"channel probabilities outside [0, 1]: {p}")
+        total = float(p.sum())
+        if not np.isclose(total, 1.0):
+            raise ValueError(f"channel probabilities add up to {total}, not 1: {p}")
 
     @property
     def num_bits(self) -> int:
-        return int(np.log2(len(self.probs)))
+        return len(self.unique_col_ids)
 
 
-# ---- probability constructors (src/tsim/noise/channels.py:47-205) ----------
+# ---- outcome tables of the noise instructions (bit orders are the reference's, channels.py:47-198) -------
 
 
 def error_probs(p: float) -> np.ndarray:
-    """One-bit channel ``[1-p, p]``."""
+    """One error bit that fires with probability ``p``."""
     return np.array([1 - p, p], dtype=np.float64)
 
 
 def pauli_channel_1_probs(px: float, py: float, pz: float) -> np.ndarray:
-    """Single-qubit Pauli channel; bit 0 = Z component, bit 1 = X component."""
+    """Single-qubit Pauli channel; bit 0 = Z component, bit 1 = X component (Y = both)."""
     return np.array([1 - px - py - pz, pz, px, py], dtype=np.float64)
 
 
 def heralded_pauli_channel_1_probs(pi: float, px: float, py: float, pz: float) -> np.ndarray:
-    """Heralded Pauli channel; bit 0 = herald, bit 1 = Z, bit 2 = X."""
+    """Heralded Pauli channel; bit 0 = herald, bit 1 = Z, bit 2 = X.  Nothing fires without the herald."""
     probs = np.zeros(8, dtype=np.float64)
     probs[0] = 1 - pi - px - py - pz
-    probs[0b001], probs[0b011], probs[0b101], probs[0b111] = pi, pz, px, py
+    for outcome, p in ((0b001, pi), (0b011, pz), (0b101, px), (0b111, py)):
+        probs[outcome] = p
     return probs
 
 
 def correlated_error_probs(probabilities) -> np.ndarray:
-    """``CORRELATED_ERROR(p1) ELSE_CORRELATED_ERROR(p2) ...``: at most one bit fires."""
-    k = len(probabilities)
-    probs = np.zeros(2**k, dtype=np.float64)
-    survive = 1.0
-    for i, p in enumerate(probabilities):
-        probs[1 << i] = survive * p
-        survive *= 1 - p
-    probs[0] = survive
+    """``CORRELATED_ERROR(p1) ELSE_CORRELATED_ERROR(p2) ...``: one bit per branch, at most one fires."""
+    probs = np.zeros(1 << len(probabilities), dtype=np.float64)
+    none_yet = 1.0
+    for branch, p in enumerate(probabilities):
+        probs[1 << branch] = none_yet * p
+        none_yet *= 1 - p
+    probs[0] = none_yet
     return probs
 
 
-# ---- simplification passes ----------------------------------------------------
+# ---- the two arithmetic primitives ---------------------------------------------------------------------------
 
 
 def xor_convolve(pa: np.ndarray, pb: np.ndarray) -> np.ndarray:
-    """``P(A xor B = o) = sum_{a ^ b = o} P(A=a) P(B=b)`` (accumulated in (a, b) order)."""
+    """Distribution of ``A xor B`` for independent ``A ~ pa``, ``B ~ pb`` over the same outcome space.
+
+    Entry ``o`` receives its terms ``pa[a] * pb[a ^ o]`` in increasing ``a`` (one vector update per ``a``:
+    within it every target index occurs once) - the accumulation order the reference's tables have."""
     n = len(pa)
     if len(pb) != n:
-        raise ValueError("Both channels must have same number of outcomes")
+        raise ValueError(f"cannot convolve distributions over {n} and {len(pb)} outcomes")
     out = np.zeros(n, dtype=np.float64)
+    index = np.arange(n)
     for a in range(n):
-        for b in range(n):
-            out[a ^ b] += pa[a] * pb[b]
+        out[index ^ a] += pa[a] * pb
     return out
 
 
-def _remap_outcomes(probs: np.ndarray, bit_targets: list, n_new: int) -> np.ndarray:
-    """Push every outcome through a GF(2)-linear bit map and accumulate in outcome order.
+def push_forward(probs: np.ndarray, images: list, n_new: int, scan: list | None = None) -> np.ndarray:
+    """Push an outcome distribution through a GF(2)-linear map of the outcome bits.
 
-    ``bit_targets[i]`` is the new bit position driven by old bit i (``None`` = dropped).
-    Several old bits may drive the same new bit (their contributions XOR).
+    ``images[i]`` is the image of old bit ``i`` as a bit mask over the ``n_new`` new bits (0: the bit is
+    dropped; several old bits may share an image - their contributions XOR).  New outcome ``y`` collects
+    ``probs[x]`` over all ``x`` with ``L(x) = y``, visiting the old outcomes in the order of the counter
+    ``s = 0, 1, ...`` whose bit ``j`` is old bit ``scan[j]`` (default: ``scan[j] = j``, i.e. increasing ``x``).
     """
-    out = np.zeros(2**n_new, dtype=np.float64)
-    for old in range(len(probs)):
-        new = 0
-        for i, tgt in enumerate(bit_targets):
-            if tgt is not None and (old >> i) & 1:
-                new ^= 1 << tgt
-        out[new] += probs[old]
+    k = len(images)
+    scan = list(range(k)) if scan is None else list(scan)
+    s = np.arange(1 << k)
+    old = np.zeros(1 << k, dtype=np.int64)
+    new = np.zeros(1 << k, dtype=np.int64)
+    for j, i in enumerate(scan):
+        bit = (s >> j) & 1
+        old |= bit << i
+        new ^= bit * int(images[i])
+    out = np.zeros(1 << n_new, dtype=np.float64)
+    np.add.at(out, new, np.asarray(probs, dtype=np.float64)[old])  # unbuffered: sequential, in visiting order
     return out
 
 
-def reduce_null_bits(channels: list, null_col_id: int | None = None) -> list:
-    """Marginalise bits that map to the all-zero column; drop channels left with no bits."""
-    if null_col_id is None:
-        return channels
-    result = []
+# ---- reduction of a noise model to independent channels on distinct signature sets ------------------------------
+
+
+def marginalise(channel: Channel, null_col_id: int | None) -> Channel | None:
+    """Sum out the bits that drive no ``f`` (signature = the all-zero column); ``None`` if no bit is left.
+
+    Bit ``i`` is axis ``i`` of the Fortran-ordered ``(2,) * k`` view of ``probs``; the summation is numpy's
+    multi-axis ``sum`` because its addition order is part of the golden tables."""
+    live = [i for i, cid in enumerate(channel.unique_col_ids) if cid != null_col_id]
+    if null_col_id is None or len(live) == channel.num_bits:
+        return channel
+    if not live:
+        return None
+    k = channel.num_bits
+    dead = tuple(i for i in range(k) if i not in live)
+    cube = np.asarray(channel.probs).reshape((2,) * k, order="F")
+    return Channel(cube.sum(axis=dead).reshape(1 << len(live), order="F"), tuple(channel.unique_col_ids[i] for i in live))
+
+
+def canonicalise(channel: Channel) -> Channel:
+    """Distinct, ascending signature ids: bits are visited in id order (stable) and bits that carry the same
+    signature collapse into one (only their parity reaches ``f``) - a single push-forward."""
+    ids = channel.unique_col_ids
+    support = tuple(sorted(set(ids)))
+    slot = {cid: pos for pos, cid in enumerate(support)}
+    by_id = sorted(range(len(ids)), key=lambda i: ids[i])  # stable
+    probs = push_forward(channel.probs, [1 << slot[cid] for cid in ids], len(support), scan=by_id)
+    return Channel(probs, support)
+
+
+def combine_supports(channels: list, max_bits: int = 4) -> list:
+    """Independent channels on the same support XOR-convolve; a channel whose support is strictly inside a
+    wider one of at most ``max_bits`` bits is embedded into it and convolved in.
+
+    Order (it fixes the float results): supports in first-appearance order, members convolved left to right;
+    then widest supports first (stable); a narrow channel joins the FIRST wider host in that order, hosts
+    take their guests in that order too."""
+    merged: dict = {}
     for ch in channels:
-        keep = [i for i, cid in enumerate(ch.unique_col_ids) if cid != null_col_id]
-        if not keep:
+        have = merged.get(ch.unique_col_ids)
+        merged[ch.unique_col_ids] = np.array(ch.probs, dtype=np.float64) if have is None else xor_convolve(have, ch.probs)
+    ranked = sorted(merged.items(), key=lambda kv: -len(kv[0]))
+    host_of: dict = {}
+    for j, (ids_j, _) in enumerate(ranked):
+        need = set(ids_j)
+        for i in range(j):
+            ids_i = ranked[i][0]
+            if i not in host_of and len(ids_i) <= max_bits and need < set(ids_i):
+                host_of[j] = i
+                break
+    out = []
+    for i, (ids_i, probs_i) in enumerate(ranked):
+        if i in host_of:
             continue
-        n = ch.num_bits
-        if len(keep) == n:
-            result.append(Channel(probs=ch.probs, unique_col_ids=tuple(ch.unique_col_ids)))
-            continue
-        drop = tuple(i for i in range(n) if i not in keep)
-        # little-endian bit i == axis i of the Fortran-ordered (2,)*n tensor
-        tensor = ch.probs.reshape((2,) * n, order="F")
-        new_probs = tensor.sum(axis=drop).reshape(2 ** len(keep), order="F")
-        result.append(Channel(probs=new_probs, unique_col_ids=tuple(ch.unique_col_ids[i] for i in keep)))
-    return result
-
-
-def normalize_channels(channels: list) -> list:
-    """Sort each channel's column ids (stable) and permute its outcome bits accordingly."""
-    result = []
-    for ch in channels:
-        ids = np.array(ch.unique_col_ids)
-        perm = np.argsort(ids, stable=True)  # new bit j <- old bit perm[j]
-        n = ch.num_bits
-        new_probs = np.empty_like(ch.probs)
-        for old in range(len(ch.probs)):
-            new = 0
-            for j in range(n):
-                new |= ((old >> int(perm[j])) & 1) << j
-            new_probs[new] = ch.probs[old]
-        result.append(Channel(probs=new_probs, unique_col_ids=tuple(ids[perm])))
-    return result
-
-
-def fold_duplicate_channel_bits(channels: list) -> list:
-    """Bits of one channel with the same column id only matter through their parity."""
-    result = []
-    for ch in channels:
-        uniq = tuple(dict.fromkeys(ch.unique_col_ids))
-        if len(uniq) == len(ch.unique_col_ids):
-            result.append(ch)
-            continue
-        pos = {c: i for i, c in enumerate(uniq)}
-        targets = [pos[c] for c in ch.unique_col_ids]
-        result.append(Channel(probs=_remap_outcomes(ch.probs, targets, len(uniq)), unique_col_ids=uniq))
-    return result
-
-
-def expand_channel(channel: Channel, target_col_ids: tuple) -> Channel:
-    """Embed a channel into a strict superset of (sorted, duplicate-free) column ids."""
-    src = channel.unique_col_ids
-    if src != tuple(sorted(src)):
-        raise ValueError("Source must be sorted")
-    if target_col_ids != tuple(sorted(target_col_ids)):
-        raise ValueError("Target must be sorted")
-    if len(set(target_col_ids)) != len(target_col_ids):
-        raise ValueError("Target must not contain duplicates")
-    if not set(src) < set(target_col_ids):
-        raise ValueError("Source must be strict subset")
-    targets = [target_col_ids.index(s) for s in src]
-    return Channel(
-        probs=_remap_outcomes(channel.probs, targets, len(target_col_ids)), unique_col_ids=target_col_ids
-    )
-
-
-def merge_identical_channels(channels: list) -> list:
-    """XOR-convolve all channels over the same signature tuple (first-seen group order)."""
-    groups: dict = {}
-    for ch in channels:
-        groups.setdefault(ch.unique_col_ids, []).append(ch)
-    result = []
-    for ids, grp in groups.items():
-        if len(grp) == 1:
-            result.append(grp[0])
-            continue
-        acc = grp[0].probs.copy()
-        for ch in grp[1:]:
-            acc = xor_convolve(acc, ch.probs)
-        result.append(Channel(probs=acc, unique_col_ids=ids))
-    return result
-
-
-def absorb_subset_channels(channels: list, max_bits: int = 4) -> list:
-    """Fold every channel whose signature set is a strict subset of a larger one (<= max_bits) into it."""
-    order = sorted(channels, key=lambda c: -len(c.unique_col_ids))  # stable, widest first
-    gone: set = set()
-    result = []
-    for i, big in enumerate(order):
-        if i in gone:
-            continue
-        big_set = set(big.unique_col_ids)
-        probs = big.probs.copy()
-        for j in range(i + 1, len(order)):
-            if j in gone:
-                continue
-            small = order[j]
-            if set(small.unique_col_ids) < big_set and len(big_set) <= max_bits:
-                probs = xor_convolve(probs, expand_channel(small, big.unique_col_ids).probs)
-                gone.add(j)
-        result.append(Channel(probs=probs, unique_col_ids=big.unique_col_ids))
-    return result
+        place = {cid: pos for pos, cid in enumerate(ids_i)}
+        for j in (g for g, h in host_of.items() if h == i):  # ascending j: dict insertion order
+            ids_j, probs_j = ranked[j]
+            probs_i = xor_convolve(probs_i, push_forward(probs_j, [1 << place[cid] for cid in ids_j], len(ids_i)))
+        out.append(Channel(probs_i, ids_i))
+    return out
 
 
 def simplify_channels(channels: list, max_bits: int = 4, null_col_id: int | None = None) -> list:
-    """null-bit removal -> sort -> fold duplicates -> merge identical -> absorb subsets."""
-    channels = reduce_null_bits(channels, null_col_id)
-    channels = normalize_channels(channels)
-    channels = fold_duplicate_channel_bits(channels)
-    channels = merge_identical_channels(channels)
-    channels = absorb_subset_channels(channels, max_bits)
-    return channels
+    """The independent channels, on distinct signature sets, that reproduce the noise model's ``f`` statistics."""
+    kept = (marginalise(ch, null_col_id) for ch in channels)
+    return combine_supports([canonicalise(ch) for ch in kept if ch is not None], max_bits)
 
 
-# ---- the sampler ----------------------------------------------------------------
+# ---- signatures ---------------------------------------------------------------------------------------------
+
+
+def column_signatures(error_transform: np.ndarray):
+    """``(signature_matrix uint8[n_sig, num_f], ids int[num_e], null_id)``: distinct columns in lexicographic
+    order (row 0 first) and, per error bit, the number of its column."""
+    T = np.asarray(error_transform)
+    num_f, num_e = (T.shape if T.ndim == 2 else (0, 0))
+    if num_e == 0:
+        return np.zeros((0, num_f), np.uint8), np.zeros(0, np.int64), None
+    bits = np.ascontiguousarray((T != 0).T.astype(np.uint8))  # one row per column
+    packed = np.packbits(bits, axis=1)                         # big-endian: row 0 of T is the top bit
+    keys = [int.from_bytes(row.tobytes(), "big") for row in packed]
+    distinct = sorted(set(keys))
+    number = {key: n for n, key in enumerate(distinct)}
+    ids = np.fromiter((number[key] for key in keys), dtype=np.int64, count=num_e)
+    first = {}
+    for col, key in enumerate(keys):
+        first.setdefault(key, col)
+    signature_matrix = np.stack([bits[first[key]] for key in distinct]).astype(np.uint8)
+    null_id = number.get(0)
+    return signature_matrix, ids, null_id
+
+
+def pack_rows(bits: np.ndarray) -> np.ndarray:
+    """``uint8[n, num_f]`` (0/1) -> ``uint64[n, ceil(num_f/64)]`` little-endian bit rows (>= 1 word)."""
+    n, num_f = bits.shape
+    wf = max(1, (num_f + 63) // 64)
+    padded = np.zeros((n, wf * 64), dtype=np.uint8)
+    padded[:, :num_f] = bits
+    return np.packbits(padded, axis=1, bitorder="little").view(np.uint64).reshape(n, wf)
+
+
+def unpack_rows(rows: np.ndarray, num_f: int) -> np.ndarray:
+    """Inverse of :func:`pack_rows`: a fresh, contiguous ``uint8[n, num_f]``."""
+    rows = np.ascontiguousarray(rows, dtype=np.uint64)
+    bits = np.unpackbits(rows.view(np.uint8).reshape(rows.shape[0], -1), axis=1, bitorder="little")
+    return np.ascontiguousarray(bits[:, :num_f])
+
+
+# ---- the sampler -----------------------------------------------------------------------------------------------
 
 
 class ChannelSampler:
-    """Samples all error channels and maps the error bits to the reduced ``f`` basis."""
+    """Samples every error channel and maps the error bits to the reduced basis ``f``.
+
+    Attributes mirrored from the reference: ``channels`` (simplified), ``signature_matrix``."""
 
     def __init__(self, channel_probs: list, error_transform: np.ndarray, seed: int | None = None):
-        error_transform = np.asarray(error_transform)
-        unique_cols, inverse = np.unique(error_transform, axis=1, return_inverse=True)
-        inverse = np.asarray(inverse).reshape(-1)
-        signature_matrix = unique_cols.T  # one row per distinct column signature
-        zero_cols = np.flatnonzero(np.all(unique_cols == 0, axis=0))
-        null_col_id = int(zero_cols[0]) if len(zero_cols) else None
-
-        channels = []
-        offset = 0
+        self.signature_matrix, ids, null_id = column_signatures(error_transform)
+        raw, at = [], 0
         for probs in channel_probs:
             k = int(np.log2(len(probs)))
-            ids = tuple(int(inverse[offset + i]) for i in range(k))
-            channels.append(Channel(probs=probs, unique_col_ids=ids))
-            offset += k
-
-        self.channels = simplify_channels(channels, null_col_id=null_col_id)
-        self.signature_matrix = signature_matrix.astype(np.uint8)
-        self._rng = np.random.default_rng(
-            seed if seed is not None else np.random.default_rng().integers(0, 2**30)
-        )
-        self._sparse_data = self._precompute_sparse(self.channels, self.signature_matrix)
-        self._packed_patterns = None  # built on first use by sample_packed
+            raw.append(Channel(probs, tuple(int(v) for v in ids[at:at + k])))
+            at += k
+        self.channels = simplify_channels(raw, null_col_id=null_id)
+        if seed is None:
+            seed = np.random.default_rng().integers(0, 2**30)
+        self._rng = np.random.default_rng(seed)
+        self._sig_words = pack_rows(self.signature_matrix) if len(self.signature_matrix) else np.zeros((0, self.num_words), np.uint64)
+        self._tables = self._firing_tables()
+        # (p_fire, conditional CDF, uint8 XOR patterns) per firing channel: what the device-side sampler uploads
+        self._sparse_data = [(p, cdf, unpack_rows(pats, self.num_f)) for p, cdf, pats in self._tables]
 
     @property
     def num_f(self) -> int:
         return int(self.signature_matrix.shape[1])
 
-    @staticmethod
-    def _precompute_sparse(channels: list, signature_matrix: np.ndarray) -> list:
-        """Per channel: ``(p_fire, conditional CDF over non-identity outcomes, XOR patterns)``."""
-        data = []
-        for ch in channels:
-            probs = ch.probs.astype(np.float64)
-            p_fire = 1.0 - float(probs[0])
-            n_outcomes = len(probs)
-            if p_fire <= 1e-15 or n_outcomes <= 1:
-                continue
-            cond_cdf = np.cumsum(probs[1:] / p_fire, dtype=np.float64)
-            cond_cdf /= cond_cdf[-1]
-            ids = np.asarray(ch.unique_col_ids)
-            k = len(ids)
-            outcomes = np.arange(1, n_outcomes)
-            bits = ((outcomes[:, None] >> np.arange(k)) & 1).astype(np.uint8)
-            xor_patterns = (bits @ signature_matrix[ids] % 2).astype(np.uint8)
-            data.append((p_fire, cond_cdf, xor_patterns))
-        return data
+    @property
+    def num_words(self) -> int:
+        return max(1, (self.num_f + 63) // 64)
 
-    def sample(self, num_samples: int = 1) -> np.ndarray:
-        """``uint8[num_samples, num_f]`` (geometric-skip sampling, channels.py:624-658)."""
-        result = np.zeros((num_samples, self.signature_matrix.shape[1]), dtype=np.uint8)
-        for p_fire, cond_cdf, xor_pats in self._sparse_data:
-            expected = num_samples * p_fire
-            sigma = np.sqrt(expected * (1.0 - p_fire))
-            n_draws = int(expected + 7.0 * sigma) + 100  # 7 sigma: undersampling ~1e-12
-            positions = np.cumsum(self._rng.geometric(p_fire, size=n_draws)) - 1
-            positions = positions[positions < num_samples]
-            if len(positions) == 0:
+    def _firing_tables(self) -> list:
+        """Per channel that can fire: ``(p_fire, cdf over the non-identity outcomes, packed XOR patterns)``.
+
+        The float sequence (``1 - p0``, ``cumsum(p[1:] / p_fire)``, renormalisation by the last entry) decides
+        which outcome a uniform draw selects and is therefore the reference's (channels.py:600-610)."""
+        tables = []
+        for ch in self.channels:
+            probs = np.asarray(ch.probs, dtype=np.float64)
+            p_fire = 1.0 - float(probs[0])
+            if len(probs) <= 1 or p_fire <= 1e-15:
                 continue
-            outcome = np.searchsorted(cond_cdf, self._rng.uniform(size=len(positions)))
-            result[positions] ^= xor_pats[outcome]
-        return result
+            cdf = np.cumsum(probs[1:] / p_fire, dtype=np.float64)
+            cdf /= cdf[-1]
+            patterns = np.zeros((len(probs) - 1, self.num_words), dtype=np.uint64)
+            outcomes = np.arange(1, len(probs))
+            for bit, cid in enumerate(ch.unique_col_ids):
+                hit = ((outcomes >> bit) & 1).astype(bool)
+                patterns[hit] ^= self._sig_words[cid]
+            tables.append((p_fire, cdf, patterns))
+        return tables
+
+    def _draw(self, p_fire: float, cdf: np.ndarray, num_samples: int):
+        """Geometric-skip draw of one channel: ``(rows that fire, outcome index per fired row)``.
+
+        The generator calls and their sizes are the stream contract (channels.py:641-655): ``n_draws``
+        geometric gaps (7 sigma above the expected number of fires, + 100), then one uniform per fired row
+        that lies inside the batch."""
+        expected = num_samples * p_fire
+        n_draws = int(expected + 7.0 * np.sqrt(expected * (1.0 - p_fire))) + 100
+        rows = np.cumsum(self._rng.geometric(p_fire, size=n_draws)) - 1
+        rows = rows[rows < num_samples]
+        if len(rows) == 0:
+            return rows, None
+        return rows, np.searchsorted(cdf, self._rng.uniform(size=len(rows)))
 
     def sample_packed(self, num_samples: int = 1) -> np.ndarray:
-        """The same samples as :meth:`sample` (same generator calls in the same order, so the two are
-        interchangeable mid-stream) as packed rows ``uint64[num_samples, ceil(num_f/64)]`` - what the
-        sampling kernel reads.  The XOR scatter touches 8 bytes per fired row and word instead of
-        ``num_f`` bytes, which is where :meth:`sample` spends its time (0.56 s of 0.69 s per 10^6
-        shots x 64 one-bit channels at p = 0.02)."""
-        num_f = self.signature_matrix.shape[1]
-        wf = max(1, (num_f + 63) // 64)
-        rows = np.zeros((num_samples, wf), dtype=np.uint64)
-        if self._packed_patterns is None:
-            packed = []
-            for _, _, xor_pats in self._sparse_data:
-                pad = np.zeros((xor_pats.shape[0], wf * 64), dtype=np.uint8)
-                pad[:, :num_f] = xor_pats
-                packed.append(np.packbits(pad, axis=1, bitorder="little").view(np.uint64).reshape(-1, wf))
-            self._packed_patterns = packed
-        for (p_fire, cond_cdf, _), pats in zip(self._sparse_data, self._packed_patterns):
-            expected = num_samples * p_fire
-            sigma = np.sqrt(expected * (1.0 - p_fire))
-            n_draws = int(expected + 7.0 * sigma) + 100
-            positions = np.cumsum(self._rng.geometric(p_fire, size=n_draws)) - 1
-            positions = positions[positions < num_samples]
-            if len(positions) == 0:
+        """``uint64[num_samples, ceil(num_f/64)]``: the rows the sampling kernels read (bit ``i`` of a row =
+        ``f_i``).  Fired rows of one channel are distinct, so the scatter is a plain indexed XOR per word."""
+        out = np.zeros((num_samples, self.num_words), dtype=np.uint64)
+        for p_fire, cdf, patterns in self._tables:
+            rows, outcome = self._draw(p_fire, cdf, num_samples)
+            if outcome is None:
                 continue
-            outcome = np.searchsorted(cond_cdf, self._rng.uniform(size=len(positions)))
-            for w in range(wf):  # positions are strictly increasing, hence unique: plain fancy XOR
-                col = pats[:, w]
-                if col.any():
-                    rows[positions, w] ^= col[outcome]
-        return rows
+            for w in range(self.num_words):
+                column = patterns[:, w]
+                if column.any():
+                    out[rows, w] ^= column[outcome]
+        return out
+
+    def sample(self, num_samples: int = 1) -> np.ndarray:
+        """``uint8[num_samples, num_f]``, the reference's layout - same generator stream as :meth:`sample_packed`
+        (the two can be mixed call by call)."""
+        return unpack_rows(self.sample_packed(num_samples), self.num_f)

@@ -1,32 +1,39 @@
 #!/usr/bin/env python
-"""bench.py - detector shots/sec of the fused sampling kernel on N MI355X.
+"""bench.py - detector shots/sec of the fused sampling path on N MI355X.
 
-Contract (see the round prompt): ``python bench.py --gpus N --steps K --warmup W`` prints ONE
-JSON line on rank 0.  For N > 1 it is launched by ``torch.distributed.run`` with one rank per
-GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment).
+Contract (see the round prompt): ``python bench.py --gpus N --steps K --warmup W`` prints ONE JSON line on
+rank 0.  For N > 1 it is launched by ``torch.distributed.run`` with one rank per GPU (RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_* from the environment) - used as a process launcher only: the communicator, the
+collectives, the barrier and the max over ranks are ``libtsim_hip.so``'s own RCCL calls
+(``tsim_amd.dist.Communicator``); torch is imported for ``torch.cuda.synchronize()`` (the contract's bracket)
+and, under the elastic agent, for its TCP store as the channel that carries the 128-byte ncclUniqueId.
 
-Workload (``config.workload``): BASELINE.json ``configs[1]`` - the 35-qubit magic-state
-distillation shape (15 direct detectors + one 5-output component,
-sum G = 148 stabiliser terms, num_f = 64, per-bit fire probability 0.02, seed 42), as a seeded
-synthetic program because the reference's compile pipeline cannot run here.  A *step* is one
-pass of the hot path (``sample_program``) over one batch of ``--shots`` shots PER GPU (weak
-scaling: rank r owns in-batch rows [r*shots, (r+1)*shots) of a global batch of N*shots, the
-Threefry counter is the global row index, so the sharded result equals the unsharded one).
-The packed ``f`` batch is resident in HBM before the timed region starts; for N > 1 every step
-ends with the RCCL gather of the packed detector/observable bits to rank 0.
+Workload (``config.workload``): BASELINE.json ``configs[1]`` - the 35-qubit magic-state distillation shape
+(15 direct detectors + one 5-output component, sum G = 148 stabiliser terms,
+num_f = 64, per-bit fire probability 0.02, seed 42) as a seeded synthetic *normalised probability model*
+(``tsim_amd.synth.physical_program``: every Bernoulli threshold lies in [0, 1]) because the reference's compile
+pipeline cannot run here.  A *step* is one pass of the hot path (``sample_program``) over one batch of
+``--shots`` shots PER GPU (weak scaling: rank r owns in-batch rows [r*shots, (r+1)*shots) of a global batch of
+N*shots; the Threefry counter is the global row index, so the sharded result equals the unsharded one).  Packed
+``f`` batches are resident in HBM before the timed region starts - ``NF`` distinct ones, used in rotation - and
+for N > 1 the bit-packed detector/observable rows are collected by RCCL every ``GATHER_EVERY`` steps.
 
-Torch is plumbing only (``torch.distributed`` rendezvous/barrier/gather, ``torch.cuda.synchronize``);
-all sampling arithmetic is in ``tsim_amd/libtsim_hip.so``.
+The ``--steps`` loop is repeated ``--repeats`` times, each repetition bracketed by barrier + synchronize on
+both sides; ``value`` / ``ms_per_step`` are the MEDIAN repetition (max over ranks), ``repeat_ms_per_step`` lists
+all of them.  Untimed extra legs (N = 1) put the headline in context: the full kernel alone, dense error
+patterns, end-to-end ``CompiledDetectorSampler.sample()`` (host buffers in and out) and time-to-first-batch.
 """
 
 from __future__ import annotations
 
 import argparse
-import contextlib
+import ctypes as C
 import json
 import os
+import statistics
 import sys
 import time
+import warnings
 
 import numpy as np
 
@@ -35,15 +42,16 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md)
 VALU_PEAK_TOPS = 78.6  # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz, one int32 lane-op per lane-clock
+NF = 4                 # distinct f batches rotated through the timed loop
 
 
 def algorithmic_bytes_per_shot(num_f: int, num_outputs: int) -> int:
-    """BASELINE.md §4: packed f read + packed bits written."""
+    """BASELINE.md section 4: packed f read + packed bits written."""
     return 8 * ((num_f + 63) // 64) + (num_outputs + 7) // 8
 
 
 def algorithmic_ops_per_shot(program) -> int:
-    """SURVEY.md §8(d): sum_levels sum_g [(T_A+T_B+2T_C+2T_D) * W * 2 + (T_A+T_D+5) * 16 + 40]."""
+    """SURVEY.md 8(d): sum_levels sum_g [(T_A+T_B+2T_C+2T_D) * W * 2 + (T_A+T_D+5) * 16 + 40]."""
     total = 0
     for comp in program.components:
         for lv in comp.compiled_scalar_graphs:
@@ -65,52 +73,36 @@ def algorithmic_ops_per_shot(program) -> int:
     return total
 
 
-def valu_block(ref_ops_per_shot: int, shots: int, kernel_s: float, config: str) -> dict:
-    """The bound that actually binds: integer VALU issue.
+def load_pmc(config: str, shots: int):
+    """The committed rocprofv3 PMC summary of this workload (profiles/latest_pmc.json), or None."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "latest_pmc.json")))
+        if d.get("_config") == config and d.get("_shots") == shots:
+            return d
+    except Exception:
+        pass
+    return None
 
-    `reference_algorithm_*` prices the reference's un-reduced algorithm (SURVEY 8(d) op count); the
-    kernel executes far fewer instructions than that because the packer reduces the program
-    algebraically.  When a rocprofv3 PMC summary of this workload is committed (profiles/), the
-    executed VALU wave-instructions per launch are taken from it and turned into issue-cycles per
-    instruction per SIMD (gfx950 issues the int ops used here at ~4 cycles per wave-instruction).
-    """
+
+def valu_block(ref_ops_per_shot: int, shots: int, kernel_s: float, pmc) -> dict:
+    """The bound that actually binds: integer VALU issue."""
     out = {
         "bound": "valu_issue",
         "reference_algorithm_ops_per_shot": ref_ops_per_shot,
         "reference_algorithm_equiv_Tlaneops": ref_ops_per_shot * shots / kernel_s / 1e12,
         "peak_Tlaneops_at_2cyc_issue": VALU_PEAK_TOPS,
     }
-    pmc = os.path.join(ROOT, "profiles", "latest_pmc.json")
-    try:
-        d = json.load(open(pmc))
-        if d.get("_config") == config and d.get("_shots") == shots:
-            insts = float(d["SQ_INSTS_VALU"])
-            simd_cycles = kernel_s * 2.4e9 * 1024
-            out.update({
-                "executed_valu_wave_insts_per_launch": insts,
-                "executed_valu_wave_insts_per_64_shots": insts / (shots / 64.0),
-                "cycles_per_valu_inst_per_simd_at_2p4GHz": simd_cycles / insts,
-                "valu_issue_busy_frac_at_4cyc": min(1.0, 4.0 * insts / simd_cycles),
-                "pmc_source": "profiles/latest_pmc.json (rocprofv3 --pmc SQ_INSTS_VALU, same workload)",
-            })
-    except Exception:
-        pass
+    if pmc and "SQ_INSTS_VALU" in pmc:
+        insts = float(pmc["SQ_INSTS_VALU"])
+        simd_cycles = kernel_s * 2.4e9 * 1024
+        out.update({
+            "executed_valu_wave_insts_per_launch": insts,
+            "executed_valu_wave_insts_per_64_shots": insts / (shots / 64.0),
+            "cycles_per_valu_inst_per_simd_at_2p4GHz": simd_cycles / insts,
+            "valu_issue_busy_frac_at_4cyc": min(1.0, 4.0 * insts / simd_cycles),
+            "pmc_source": "profiles/latest_pmc.json (rocprofv3 --pmc SQ_INSTS_VALU, same workload)",
+        })
     return out
-
-
-def pmc_traffic_bytes(config: str, shots: int):
-    """HBM bytes per launch from the committed PMC summary of this workload (None if absent).
-
-    FETCH_SIZE/WRITE_SIZE are in KB; on gfx950 FETCH_SIZE reports half of a coalesced stream
-    (guides/MI355X_MICROARCH.md, HBM section), hence the factor 2 on the read side.
-    """
-    try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "latest_pmc.json")))
-        if d.get("_config") == config and d.get("_shots") == shots:
-            return (2.0 * float(d["FETCH_SIZE"]) + float(d["WRITE_SIZE"])) * 1024.0
-    except Exception:
-        pass
-    return None
 
 
 def host_cpu_budget() -> tuple[int, str]:
@@ -131,7 +123,7 @@ def host_cpu_budget() -> tuple[int, str]:
 
 def cpu_baseline(program, cfg, seconds: float = 15.0) -> dict:
     """Time the C oracle (kind "port") on a bounded sample of the same workload on the host cores."""
-    from oracle import oracle_c
+    from oracle import oracle_c, oracle_np
     from tsim_amd import synth
 
     oracle_c.build()
@@ -150,15 +142,12 @@ def cpu_baseline(program, cfg, seconds: float = 15.0) -> dict:
     t0 = time.perf_counter()
     op.sample_program(f, (1, 2), threads=threads)
     dt = time.perf_counter() - t0
-    # also the single-threaded rate (the reference's ChannelSampler and Python driver are
-    # single-threaded) and the numpy restatement that keeps the reference's data movement (byte-per-bit
-    # float32 GEMM % 2, materialised lookups, sequential scans) - small samples, a few seconds each
+    # also the single-threaded rate (the reference's Python driver is single-threaded) and the numpy
+    # restatement that keeps the reference's data movement (float32 GEMM % 2, materialised lookups, scans)
     f1 = synth.synth_f(20_000, cfg["num_f"], cfg["p_bit"], seed=cfg["seed"])
     t1 = time.perf_counter()
     op.sample_program(f1, (1, 2), threads=1)
     single = len(f1) / (time.perf_counter() - t1)
-    from oracle import oracle_np
-
     f2 = synth.synth_f(2048, cfg["num_f"], cfg["p_bit"], seed=cfg["seed"])
     t2 = time.perf_counter()
     oracle_np.sample_program(program, f2, (1, 2))
@@ -170,9 +159,34 @@ def cpu_baseline(program, cfg, seconds: float = 15.0) -> dict:
         "single_thread_value": single,
         "numpy_reference_faithful_value": faithful,
         "kind": "port",
-        "sample": f"{n} shots of the same C2 program and f distribution, C oracle (oracle/oracle.c, "
-        f"OpenMP over shots, {threads} threads on {cores} CPUs; {note}), {dt:.1f} s wall",
+        "sample": f"{n} shots of the same program and f distribution, C oracle (oracle/oracle.c, OpenMP over shots, "
+        f"{threads} threads on {cores} CPUs; {note}), {dt:.1f} s wall",
     }
+
+
+def exchange_unique_id(rank: int, world: int) -> bytes:
+    """The ncclUniqueId from rank 0 to everyone: through the launcher's own TCP store when this process runs
+    under torch's elastic agent, else over tsim_amd.dist's socket rendezvous."""
+    from tsim_amd import dist as tdist
+
+    addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
+    port = int(os.environ.get("MASTER_PORT", "29511"))
+    if world > 1 and os.environ.get("TORCHELASTIC_USE_AGENT_STORE", "").lower() == "true":
+        try:
+            from datetime import timedelta
+
+            from torch.distributed import TCPStore
+
+            store = TCPStore(addr, port, world, is_master=False, timeout=timedelta(seconds=120))
+            key = "tsim_amd/rccl_unique_id/" + os.environ.get("TORCHELASTIC_RESTART_COUNT", "0")
+            if rank == 0:
+                ident = tdist.unique_id()
+                store.set(key, ident)
+                return ident
+            return bytes(store.get(key))
+        except Exception as exc:  # fall through to the socket rendezvous
+            print(f"[bench] agent store unavailable ({exc!r}); using the socket rendezvous", file=sys.stderr)
+    return tdist.rendezvous_tcp(rank, world, addr=addr, port=int(os.environ.get("TSIM_DIST_PORT", port + 1)))
 
 
 def main() -> None:
@@ -180,13 +194,18 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--repeats", type=int, default=5, help="repetitions of the timed --steps loop (median reported)")
     ap.add_argument("--shots", type=int, default=1_000_000, help="shots per step per GPU")
     ap.add_argument("--config", default="C2")
-    ap.add_argument("--p-bit", type=float, default=None, help="override the per-bit fire probability of the synthetic f batch (experiments only)")
+    ap.add_argument("--random-program", action="store_true", help="the unconstrained random program instead of the normalised one")
+    ap.add_argument("--p-bit", type=float, default=None, help="override the per-bit fire probability of the synthetic f batches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-full-leg", action="store_true", help="skip the extra timing of the full kernel alone (profiling runs)")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the untimed context legs (profiling runs)")
+    ap.add_argument("--no-full-leg", action="store_true", help=argparse.SUPPRESS)  # older name
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
+    if args.no_full_leg:
+        args.no_extra_legs = True
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -196,200 +215,163 @@ def main() -> None:
     N = max(world, 1)
     use_dist = N > 1 or os.environ.get("TSIM_BENCH_FORCE_DIST") == "1"
 
-    # torch first: its bundled HIP runtime must be the one the process shares
-    import torch
+    # torch: only for the contract's torch.cuda.synchronize() (and its HIP runtime must be the first one loaded
+    # when it is present at all)
+    try:
+        import torch
 
+        torch.cuda.set_device(local_rank)
+
+        def device_sync():
+            torch.cuda.synchronize()
+    except Exception:
+        torch = None
+
+        def device_sync():
+            pass
+
+    from tsim_amd import _lib, backend, prng, synth
+    from tsim_amd import dist as tdist
+
+    lib = _lib.load()
+    comm = None
     if use_dist:
-        import torch.distributed as dist
-
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=N, device_id=torch.device("cuda", local_rank))
+        comm = tdist.Communicator(local_rank, exchange_unique_id(rank, N), rank, N)
 
-    from tsim_amd import backend, prng, synth
-
-    program, cfg = synth.config_program(args.config)
+    program, cfg = synth.config_program(args.config, physical=not args.random_program)
     if args.p_bit is not None:
         cfg = dict(cfg, p_bit=float(args.p_bit))
+    t_build0 = time.perf_counter()
     hp = backend.HipProgram(program, device=local_rank)
+    t_build = time.perf_counter() - t_build0
     info = hp.info()
     num_f, n_out = cfg["num_f"], program.num_outputs
     B = int(args.shots)
-    WF, WO = (num_f + 63) // 64, (n_out + 63) // 64
+    WF, WO, RB = max(1, (num_f + 63) // 64), (n_out + 63) // 64, (n_out + 7) // 8
 
-    # synthetic packed f batch of this rank's shard, resident in HBM before timing
-    f = synth.synth_f(B, num_f, cfg["p_bit"], seed=cfg["seed"] + 1000 * rank)
-    f_packed = np.packbits(f, axis=1, bitorder="little")
-    pad = WF * 8 - f_packed.shape[1]
-    if pad:
-        f_packed = np.pad(f_packed, ((0, 0), (0, pad)))
-    d_f = hp.malloc(B * WF * 8)
-    hp.h2d(d_f, f_packed)
-    del f
+    def resident_f(p_bit: float, seed: int):
+        """One synthetic packed f batch of this rank's shard, in HBM."""
+        f = synth.synth_f(B, num_f, p_bit, seed=seed)
+        packed = np.packbits(f, axis=1, bitorder="little")
+        if WF * 8 - packed.shape[1]:
+            packed = np.pad(packed, ((0, 0), (0, WF * 8 - packed.shape[1])))
+        buf = hp.malloc(B * WF * 8)
+        hp.h2d(buf, packed)
+        return buf
 
-    # Pipeline of NSLOT lanes (tsim_sample_batch_device_begin/_end): step i runs entirely on the stream of
-    # slot i % NSLOT, so its second pass (hard rows, latency-bound) overlaps the first pass of the next
-    # steps on the other lanes; one output buffer per slot, no cross-stream event in the steady state.
-    # N > 1: when a step is joined its rows are compacted to the reference's bit_packed layout
-    # (ceil(n_out/8) bytes per shot instead of the padded 8-byte words) into a group buffer in HBM; every
-    # GATHER_EVERY steps ONE asynchronous RCCL gather sends the whole group to rank 0 (fewer, larger
-    # collectives: a gather per step would cost more host time than the step itself), double-buffered
-    # so that it overlaps the kernels of the next group.
-    # Hardware queues: the handle's own stream plus two more sit on three distinct ones; more than 4 busy
-    # hardware queues is pathological on this stack (3x slower with GPU_MAX_HW_QUEUES=5 / 8), so lanes +
-    # RCCL's stream stay <= 4.  Slots: 16 (two batches of up to 8 launches in flight).  With short hard-row lists the library runs the first passes of
-    # consecutive launches on two of the lanes and the hard rows of four launches at a time as ONE grid on
-    # the third (deferred second pass); a slot is reused only after its batch is done, so the number of
-    # slots - not of lanes - covers the batch latency (3 slots: 46 us per step, 6: 33 us, 8: 22-23 us, 12: 21 us).
-    default_slots = 16
-    NSLOT = max(1, min(backend.HipProgram.PIPELINE_SLOTS, int(os.environ.get("TSIM_BENCH_SLOTS", str(default_slots)))))
-    # batches per collective: a torch.distributed call costs ~0.15 ms of host time, several steps' worth -
-    # smaller groups for short runs were measured and are worse (20 steps: 63 us per step with groups of 5,
-    # 36 us with one collective at the end)
+    f_bufs = [resident_f(cfg["p_bit"], cfg["seed"] + 1000 * rank + 7919 * k) for k in range(NF)]
+
+    # Pipeline of NSLOT slots (tsim_sample_batch_device_begin/_end): with short hard-row lists the library runs
+    # the first passes of consecutive launches on two lanes and the hard rows of four launches at a time as ONE
+    # grid on a third (DESIGN.md section 3.8); a slot is reused only after its batch is done, so the number of
+    # slots - not of lanes - covers the batch latency.  N > 1: the kernels also write the reference's bit_packed
+    # rows (ceil(n_out/8) bytes per shot) into a group buffer; every GATHER_EVERY steps ONE asynchronous RCCL
+    # collective moves the group (double-buffered, queued on the lane where results complete).
+    NSLOT = max(1, min(backend.HipProgram.PIPELINE_SLOTS, int(os.environ.get("TSIM_BENCH_SLOTS", "16"))))
     GATHER_EVERY = max(1, int(os.environ.get("TSIM_BENCH_GATHER_EVERY", "64")))
-    # How the bit-packed rows are collected (N > 1).  "alltoall" (default): every group of GATHER_EVERY
-    # batches is split by batch index into N chunks and chunk j of every rank is assembled on rank j with ONE
-    # RCCL all-to-all - a gather whose roots are spread over the node.  xGMI is a full mesh of point-to-point
-    # links (~77 GB/s per direction and pair): at 4e10 shots/s a rank produces 120 GB/s of rows, and a gather
-    # to rank 0 would push all of it through the single link to rank 0 (and everything through rank 0's one
-    # PCIe link afterwards); the all-to-all puts 1/N of it on each of the N-1 links and leaves complete batches
-    # on every rank, next to all 8 PCIe links.  "root0": the classic gather to rank 0, for comparison.
-    GATHER_MODE = os.environ.get("TSIM_BENCH_GATHER", "alltoall")
+    # "root0" (default): the north star's gather of the detector bit strings to rank 0 (ncclGather).
+    # "alltoall": a gather whose roots are spread over the node - group j of every rank lands on rank j - for
+    # the case where rank 0's xGMI ingress or its single PCIe link is the limit (DESIGN.md section 6).
+    GATHER_MODE = os.environ.get("TSIM_BENCH_GATHER", "root0")
     if GATHER_MODE == "alltoall":
         GATHER_EVERY = (GATHER_EVERY + N - 1) // N * N
+    d_outs = [hp.malloc(B * WO * 8) for _ in range(NSLOT)]
+    out_ptrs = [d.ptr for d in d_outs]
     if use_dist:
-        dev = torch.device("cuda", local_rank)
-        # the gathers are queued on the lane where the hard-row batches run (results complete there): the
-        # first-pass lanes - the handle's own stream is one of them - never wait for a gather or a join
-        import ctypes as _C
-        _sp = _C.c_void_p()
-        if hp._lib.tsim_pipeline_lane_stream(hp._h, 2, _C.byref(_sp)) < 0:
-            raise RuntimeError("tsim_pipeline_lane_stream failed")
-        join_ptr = int(_sp.value)
-        ext = torch.cuda.ExternalStream(join_ptr, device=dev)
-        ext_main = torch.cuda.ExternalStream(hp.stream_ptr(), device=dev)  # first-pass lane 0
-        out_bufs = [torch.zeros((B, WO * 8), dtype=torch.uint8, device=dev) for _ in range(NSLOT)]
-        out_ptrs = [t.data_ptr() for t in out_bufs]
-        RB = (n_out + 7) // 8
-        grp_bufs = [torch.zeros((GATHER_EVERY, B, RB), dtype=torch.uint8, device=dev) for _ in range(2)]
+        join_ptr = hp.pipeline_lane_stream(2)   # where deferred hard-row batches - i.e. results - complete
+        main_ptr = hp.stream_ptr()               # first-pass lane 0
+        grp = [hp.malloc(GATHER_EVERY * B * RB) for _ in range(2)]
         if GATHER_MODE == "alltoall":
-            grp_recv = [torch.empty_like(grp_bufs[0]) for _ in range(2)]  # [N chunks of GATHER_EVERY/N batches, B, RB]
-            grp_lists = [None, None]
+            grp_recv = [hp.malloc(GATHER_EVERY * B * RB) for _ in range(2)]
         else:
-            grp_lists = [[torch.empty_like(grp_bufs[0]) for _ in range(N)] if rank == 0 else None for _ in range(2)]
-        grp_ptrs = [t.data_ptr() for t in grp_bufs]
-        grp_pending = [None, None]  # gather handle of the group buffer's previous use
-        series_fn = hp._lib.tsim_pipeline_set_compact_series
-        wait_fn = hp._lib.tsim_pipeline_wait_stream
-    else:
-        d_outs = [hp.malloc(B * WO * 8) for _ in range(NSLOT)]
-        out_ptrs = [d.ptr for d in d_outs]
-        d_out = d_outs[0]
-    inflight = []  # (slot, step id) begun, not yet joined (N == 1 bookkeeping)
+            grp_recv = [hp.malloc(N * GATHER_EVERY * B * RB) if rank == 0 else None for _ in range(2)]
+        grp_used = [False, False]
 
     key = prng.key(cfg["seed"])
+    key_state = (C.c_uint32 * 2)(key[0] & 0xFFFFFFFF, key[1] & 0xFFFFFFFF)  # split in place by the library
     shot_offset = rank * B
     step_no = [0]
-
-    begin_fn = hp._lib.tsim_sample_batch_device_begin
-    end_fn = hp._lib.tsim_sample_batch_device_end
-    d_f_ptr = d_f.ptr
-
-    gathered = [0]  # groups whose gather has been issued (N > 1)
-
-    def gather_next(count=None):
-        """Issue the gather of the oldest un-gathered group (all of its steps must be joined)."""
-        k = gathered[0]
-        g = k & 1
-        count = GATHER_EVERY if count is None else count
-        src = grp_bufs[g] if count == GATHER_EVERY else grp_bufs[g][:count]
-        dst = None
-        if rank == 0 and GATHER_MODE != "alltoall":
-            dst = grp_lists[g] if count == GATHER_EVERY else [t[:count] for t in grp_lists[g]]
-        with torch.cuda.stream(ext):
-            if GATHER_MODE == "alltoall":  # equal chunks: a partial last group is rounded up to a multiple of N batches
-                cnt = (count + N - 1) // N * N
-                grp_pending[g] = dist.all_to_all_single(grp_recv[g][:cnt], grp_bufs[g][:cnt], async_op=True)
-            else:
-                grp_pending[g] = dist.gather(src, dst, dst=0, async_op=True)
-        gathered[0] = k + 1
-
-    import ctypes as _ct
-    key_state = (_ct.c_uint32 * 2)(key[0] & 0xFFFFFFFF, key[1] & 0xFFFFFFFF)  # split in place by the library
-    begin_split = hp._lib.tsim_sample_batch_device_begin_split
+    gathered = [0]  # groups whose collective has been issued
+    begin_split = lib.tsim_sample_batch_device_begin_split
+    end_fn = lib.tsim_sample_batch_device_end
+    series_fn = lib.tsim_pipeline_set_compact_series
+    wait_fn = lib.tsim_pipeline_wait_stream
     h_prog = hp._h
 
-    def step():
+    def gather_next(count: int) -> None:
+        """Issue the collective of the oldest un-collected group (all of its steps are joined on the join lane)."""
+        g = gathered[0] & 1
+        if GATHER_MODE == "alltoall":  # equal chunks; a partial last group is rounded up (the tail rows are stale)
+            per_peer = (count + N - 1) // N * B * RB
+            comm.alltoall_rows(grp[g].ptr, grp_recv[g].ptr, per_peer, stream=join_ptr)
+        else:
+            comm.gather_rows(grp[g].ptr, count * B * RB, grp_recv[g].ptr if grp_recv[g] else 0, root=0, stream=join_ptr)
+        comm.mark(g, join_ptr)  # "the collective that read group buffer g is done"
+        grp_used[g] = True
+        gathered[0] += 1
+
+    def step(f_list=f_bufs) -> None:
         # one host split per batch, key, subkey = split(key) (sampler.py:399), inside the launch call
         j = step_no[0]
         b = j % NSLOT
         step_no[0] = j + 1
+        d_f = f_list[j % len(f_list)].ptr
         if not use_dist:
-            # _begin on a slot whose previous step was not joined is ordered after that step's second
-            # pass by the library (include/tsim_hip.h), so one call per step is enough here
-            rc = begin_split(h_prog, b, d_f_ptr, B, num_f, key_state, shot_offset, out_ptrs[b], None, None, 1)  # inputs ready
+            # _begin on a slot whose previous step was not joined is ordered after that step's second pass by the
+            # library (include/tsim_hip.h), so one call per step is enough here
+            rc = begin_split(h_prog, b, d_f, B, num_f, key_state, shot_offset, out_ptrs[b], None, None, 1)  # inputs ready
             if rc < 0:
-                raise RuntimeError(f"tsim_sample_batch_device_begin failed ({rc})")
-            if not inflight or len(inflight) < NSLOT:
-                inflight.append((b, j))
+                raise RuntimeError(f"tsim_sample_batch_device_begin failed ({rc}): {_lib.last_error()}")
             return
         g, pos = (j // GATHER_EVERY) & 1, j % GATHER_EVERY
-        if pos == 0 and grp_pending[g] is not None:
-            # the gather that last read this group buffer (two groups ago, long finished) must be done before
-            # the kernels overwrite it: first-pass lane 0 (the handle's stream) waits for it, the other lanes
-            # are ordered after lane 0 below.  (Waiting on the batch lane instead would park the dependency
-            # behind every queued hard-row batch and drain the pipeline once per group.)
-            with torch.cuda.stream(ext_main):
-                grp_pending[g].wait()
-            grp_pending[g] = None
-        # At the start of a group every lane waits ONCE for the engine's stream, i.e. for the gather that
-        # last read this group buffer (tsim_pipeline_wait_stream); the launches themselves then need no
-        # cross-stream dependency.  The kernels write the rows a second time in the reference's bit_packed
-        # layout, into the group buffer.
         rc = 0
-        if pos == 0 or j < NSLOT:  # (the first launches create the lanes)
-            rc = wait_fn(hp._h, None)
-        if rc >= 0 and pos == 0:  # the launches of this group also write bit_packed rows, one slice each
-            rc = series_fn(hp._h, grp_ptrs[g], B * RB, GATHER_EVERY)
+        if pos == 0:
+            if grp_used[g]:
+                # the collective that last read this group buffer (two groups ago) must be done before kernels
+                # overwrite it: first-pass lane 0 waits for THAT marker only (waiting for the whole join lane would
+                # drain the pipeline once per group); the other lanes are ordered after lane 0 just below
+                comm.wait_mark(g, main_ptr)
+            rc = wait_fn(h_prog, None)
+            if rc >= 0:  # the launches of this group also write bit_packed rows, one slice each
+                rc = series_fn(h_prog, grp[g].ptr, B * RB, GATHER_EVERY)
+        elif j < NSLOT:  # (the first launches create the lanes)
+            rc = wait_fn(h_prog, None)
         if rc >= 0:
-            rc = begin_split(h_prog, b, d_f_ptr, B, num_f, key_state, shot_offset, out_ptrs[b], None, None,
-                             0 if j < NSLOT else 1)
+            rc = begin_split(h_prog, b, d_f, B, num_f, key_state, shot_offset, out_ptrs[b], None, None, 0 if j < NSLOT else 1)
         if rc < 0:
-            raise RuntimeError(f"pipelined launch failed ({rc})")
-        if pos == GATHER_EVERY - 1:  # group complete: join every lane on the engine's stream, then gather
+            raise RuntimeError(f"pipelined launch failed ({rc}): {_lib.last_error()}")
+        if pos == GATHER_EVERY - 1:  # group complete: join every slot on the join lane, then collect
             for k in range(NSLOT):
-                end_fn(hp._h, k, join_ptr)
-            gather_next()
+                end_fn(h_prog, k, join_ptr)
+            gather_next(GATHER_EVERY)
 
-    def drain():
+    def drain() -> None:
         if not use_dist:
-            while inflight:
-                hp.sample_batch_device_end(inflight.pop(0)[0])
+            for k in range(NSLOT):
+                hp.sample_batch_device_end(k)
             return
-        for b in range(NSLOT):
-            end_fn(hp._h, b, join_ptr)
+        for k in range(NSLOT):
+            end_fn(h_prog, k, join_ptr)
         n_steps = step_no[0]
         while gathered[0] * GATHER_EVERY < n_steps:
             gather_next(min(GATHER_EVERY, n_steps - gathered[0] * GATHER_EVERY))
-        with torch.cuda.stream(ext):
-            for g in range(2):
-                if grp_pending[g] is not None:
-                    grp_pending[g].wait()
-                    grp_pending[g] = None
         gathered[0] = 0
         step_no[0] = 0
 
-    def fence():
+    def fence() -> None:
+        """drain + everything queued on this device finished + all ranks here (the contract's bracket)."""
         drain()
         hp.synchronize()
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
+        lib.tsim_device_synchronize(local_rank)
+        device_sync()
+        if comm is not None:
+            comm.barrier()
 
-    # initialisation (untimed, not part of --warmup): the launch plan of the library follows the hard-row
-    # counts of earlier launches (deferred batches need one launch of feedback), lanes and per-slot buffers
-    # are created by the first pipelined launches
+    # initialisation (untimed, not part of --warmup): the launch plan follows the hard-row counts of earlier
+    # launches (deferred batches need one launch of feedback), lanes and per-slot buffers are created by the
+    # first pipelined launches
     INIT_STEPS = 16
     for _ in range(INIT_STEPS):
         step()
@@ -397,32 +379,42 @@ def main() -> None:
     for _ in range(args.warmup):
         step()
     fence()
-    # HIP events around the dominant kernel only (level 2): timing events drain the queue they are
-    # recorded on, and bracketing every side-stream kernel costs ~10 us per pipelined step
-    PROF_EVERY = 25  # bracket one launch in 25: a timing event costs a queue drain (~5 us; 1 in 8 cost 6 % of the rate)
+    # HIP events around the dominant kernel only (level 2), on at least 8 launches per repetition: timing events
+    # drain the queue they are recorded on (~5 us each), so not every launch is bracketed
+    PROF_EVERY = max(1, min(25, args.steps // 8))
     hp.profile_set_sampling(PROF_EVERY)
     hp.profile_enable(0 if os.environ.get("TSIM_BENCH_NO_PROFILE") == "1" else 2)
     hp.profile_read(reset=True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    host_enqueue_s = time.perf_counter() - t0  # host time to enqueue all steps (before draining)
-    drain()
-    hp.synchronize()
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-        torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    rep_elapsed, rep_enqueue = [], []
+    for _ in range(max(1, args.repeats)):
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        t_enq = time.perf_counter() - t0  # host time to enqueue all steps (before draining)
+        drain()
+        hp.synchronize()
+        lib.tsim_device_synchronize(local_rank)
+        device_sync()
+        if comm is not None:
+            comm.barrier()
+        elapsed = time.perf_counter() - t0
+        if comm is not None:
+            elapsed = comm.allreduce_max(elapsed)
+        rep_elapsed.append(elapsed)
+        rep_enqueue.append(t_enq)
     stages = hp.profile_read_stages()
     kern_ms, launches = hp.profile_read(reset=True)
     hp.profile_enable(False)
+    elapsed = statistics.median(rep_elapsed)
+    host_enqueue_s = statistics.median(rep_enqueue)
 
-    # untimed: a few more steps with every kernel bracketed, for the per-kernel split and the
-    # first-kernel-start -> last-kernel-end latency of one launch
-    detail = None
+    # ---- untimed context (rank 0 prints it) ----
+    detail = serial_ms = None
+    d_out0 = d_outs[0]
     hp.profile_set_sampling(1)
     if info.get("pattern_tables"):
+        # every kernel of 8 launches bracketed: per-kernel split and first-kernel-start -> last-kernel-end latency
         hp.profile_enable(1)
         for _ in range(8):
             step()
@@ -433,72 +425,50 @@ def main() -> None:
         hp.profile_enable(False)
         detail = {"stage_avg_ms": {k: v / max(dl, 1) for k, v in dst.items()}, "launch_latency_ms": dms / max(dl, 1),
                   "launches": dl, "note": "separate untimed steps with every kernel bracketed by HIP events"}
+        if not use_dist:
+            # the dominant kernel with the GPU to itself (serial launches on the handle's stream): its own duration,
+            # the figure rocprofv3's serial kernel trace gives
+            for _ in range(2):
+                hp.sample_batch_device(f_bufs[0].ptr, B, num_f, key, d_out0.ptr, shot_offset=shot_offset)
+            hp.synchronize()
+            hp.profile_enable(1)
+            hp.profile_read(reset=True)
+            for k in range(8):
+                hp.sample_batch_device(f_bufs[k % NF].ptr, B, num_f, key, d_out0.ptr, shot_offset=shot_offset)
+            hp.synchronize()
+            sst = hp.profile_read_stages()
+            _, sl_n = hp.profile_read(reset=True)
+            hp.profile_enable(False)
+            if sl_n and sst["pattern_pass"] >= sst["full_kernel"]:
+                serial_ms = sst["pattern_pass"] / sl_n
 
-    # untimed: the dominant kernel with the GPU to itself (serial launches on the handle's stream): its own
-    # duration, the figure rocprofv3's serial kernel trace gives (profiles/r01/*_kernel_stats_serial.csv).
-    # In the timed region two or three launches are in flight and each first pass shares the CUs with the
-    # others, so its bracketed duration there is longer than its cost.
-    serial_ms = None
-    if info.get("pattern_tables") and not use_dist:
-        for _ in range(2):
-            hp.sample_batch_device(d_f.ptr, B, num_f, key, d_out.ptr, shot_offset=shot_offset)
-        hp.synchronize()
-        hp.profile_enable(1)
-        hp.profile_read(reset=True)
-        for _ in range(8):
-            hp.sample_batch_device(d_f.ptr, B, num_f, key, d_out.ptr, shot_offset=shot_offset)
-        hp.synchronize()
-        sst = hp.profile_read_stages()
-        _, sl_n = hp.profile_read(reset=True)
-        hp.profile_enable(False)
-        if sl_n and sst["pattern_pass"] >= sst["full_kernel"]:
-            serial_ms = sst["pattern_pass"] / sl_n
-
-    # the full kernel alone (pattern tables off), a few steps: the rate on inputs where no shot is
-    # tabulated, and the quantity earlier rounds reported
-    full_only = None
-    if N == 1 and info.get("pattern_tables") and not use_dist and not args.no_full_leg:
-        hp_full = backend.HipProgram(program, device=local_rank, pattern_tables=False)
-        for _ in range(2):
-            hp_full.sample_batch_device(d_f.ptr, B, num_f, key, d_out.ptr, shot_offset=shot_offset)
-        hp_full.synchronize()
-        hp_full.profile_enable(True)
-        hp_full.profile_read(reset=True)
-        for _ in range(5):
-            hp_full.sample_batch_device(d_f.ptr, B, num_f, key, d_out.ptr, shot_offset=shot_offset)
-        fms, fl = hp_full.profile_read(reset=True)
-        hp_full.profile_enable(False)
-        full_only = {"kernel": "tsimk::k_sample4" if hp_full.info().get("chunk_table_kernel") else "tsimk::k_sample",
-                     "kernel_avg_ms": fms / max(fl, 1), "shots_per_s": B / (fms / max(fl, 1) * 1e-3), "launches": fl}
-
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    extra = {}
+    if N == 1 and not use_dist and not args.no_extra_legs:
+        extra = extra_legs(backend, synth, program, cfg, hp, info, B, num_f, n_out, key, f_bufs, d_out0, local_rank, t_build,
+                           resident_f, step, drain, INIT_STEPS)
 
     if rank == 0:
         total_shots = float(B) * N * args.steps
         value = total_shots / elapsed
         launch_s = (kern_ms / max(launches, 1)) * 1e-3  # first kernel start -> last kernel end of one launch
-        # dominant kernel: with pattern tables the first pass (k_sample_lw) touches every row and moves
-        # all the algorithmic bytes; the hard-row kernels of a launch overlap the first pass of the
-        # following launches (pipelined slots).  Without tables: the one full kernel.
+        # dominant kernel: with pattern tables the first pass (k_sample_lw) touches every row and moves all the
+        # algorithmic bytes; the hard-row kernels overlap the first passes of the following launches
         tables_dominant = bool(info.get("pattern_tables")) and stages["pattern_pass"] >= stages["full_kernel"]
-        if tables_dominant:
-            avg_kernel_s = stages["pattern_pass"] / max(launches, 1) * 1e-3
-        else:  # no tables, or dense error patterns: the launch plan went back to the full kernel
-            avg_kernel_s = launch_s
+        avg_kernel_s = stages["pattern_pass"] / max(launches, 1) * 1e-3 if tables_dominant else launch_s
         if launches == 0:  # profiling events disabled (experiments): fall back to the step time
             avg_kernel_s = launch_s = elapsed / args.steps
         bytes_per_shot = algorithmic_bytes_per_shot(num_f, n_out)
         ops_per_shot = algorithmic_ops_per_shot(program)
         achieved_gbs = bytes_per_shot * B / avg_kernel_s / 1e9
-        achieved_tops = ops_per_shot * B / avg_kernel_s / 1e12
         if tables_dominant:
-            kernel_name = "tsimk::k_sample_lw (pattern-table pass; hard rows: k_sample4h_multi batches / k_sample4h + k_sample4, on the third lane)" \
-                if info.get("chunk_table_kernel") else "tsimk::k_sample_lw (pattern-table pass; hard rows: k_sample, overlapped on the other lanes)"
+            kernel_name = ("tsimk::k_sample_lw (pattern-table pass; hard rows: k_sample4h_multi batches / k_sample4h + "
+                           "k_sample4, on the third lane)") if info.get("chunk_table_kernel") else \
+                "tsimk::k_sample_lw (pattern-table pass; hard rows: k_sample, overlapped on the other lanes)"
         else:
             kernel_name = "tsimk::k_sample4 (LDS chunk tables)" if info.get("chunk_table_kernel") else "tsimk::k_sample"
+        pmc = load_pmc(args.config, B)
+        traffic = (2.0 * float(pmc["FETCH_SIZE"]) + float(pmc["WRITE_SIZE"])) * 1024.0 if pmc and "FETCH_SIZE" in pmc else None
+        per_step = [e / args.steps * 1e3 for e in rep_elapsed]
         res = {
             "metric": "detector shots/sec, 35-qubit distillation circuit, 1/2/4/8 MI355X",
             "value": value,
@@ -512,15 +482,19 @@ def main() -> None:
             "vs_baseline": None,
             "dtype": "int32",
             "data": "synthetic",
+            "repeats": len(rep_elapsed),
+            "repeat_ms_per_step": {"median": statistics.median(per_step), "min": min(per_step), "max": max(per_step), "all": per_step},
             "config": {
                 "workload": f"{args.config}: {cfg.get('name', 'shape of SURVEY 8d')}, synthetic seeded program: "
                 f"{info['total_graphs']} stabiliser terms, {info['total_rows']} GF(2) rows, n_out={n_out}, "
                 f"num_f={num_f}, p_bit={cfg['p_bit']}",
                 "shots_per_step_per_gpu": B,
                 "global_batch": B * N,
-                "sharding": (f"shots x{N}, bit-packed rows ({(n_out + 7) // 8} B/shot) collected every {GATHER_EVERY} batches by "
-                             + ("one RCCL all-to-all (batch j of all ranks assembled on rank j mod N)" if GATHER_MODE == "alltoall"
-                                else "an RCCL gather to rank 0")) if use_dist else "single GPU",
+                "distinct_f_batches": NF,
+                "sharding": (f"shots x{N}, bit-packed rows ({RB} B/shot) collected every {GATHER_EVERY} batches by "
+                             + ("one RCCL all-to-all (batch group j of all ranks assembled on rank j)" if GATHER_MODE == "alltoall"
+                                else "an RCCL gather to rank 0") + ", issued by libtsim_hip.so (no torch.distributed)")
+                if use_dist else "single GPU",
                 "f_resident_in_hbm": True,
             },
             "roofline": {
@@ -529,14 +503,14 @@ def main() -> None:
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved_gbs / HBM_PEAK_GBS,
-                "traffic": pmc_traffic_bytes(args.config, B),
+                "traffic": traffic,
                 "traffic_unit": "bytes per launch, rocprofv3 PMC: 2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction)",
                 "achieved_at_step_rate": bytes_per_shot * B / (elapsed / args.steps) / 1e9,
                 "frac_at_step_rate": bytes_per_shot * B / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
                 "kernel": kernel_name,
                 "kernel_avg_ms": avg_kernel_s * 1e3,
                 "launches": launches,
-                "hip_event_sampling": f"1 launch in {PROF_EVERY} bracketed",
+                "hip_event_sampling": f"1 launch in {PROF_EVERY} bracketed, {len(rep_elapsed)} repetitions",
                 "kernel_serial_avg_ms": serial_ms,
                 "achieved_serial": (bytes_per_shot * B / (serial_ms * 1e-3) / 1e9) if serial_ms else None,
                 "all_kernels": detail,
@@ -544,31 +518,100 @@ def main() -> None:
                 "init_steps_untimed": INIT_STEPS,
                 "host_enqueue_ms_per_step": host_enqueue_s / args.steps * 1e3,
                 "algorithmic_bytes_per_shot": bytes_per_shot,
-                "note": "achieved = algorithmic bytes of one launch / HIP-event time of the dominant kernel inside the "
-                "timed region; there two first passes are in flight (two lanes) plus the hard-row batch on a third, so "
-                "each first pass shares the CUs and its own duration is about twice the step time - "
-                "achieved_at_step_rate uses the step time instead (= shots/s x bytes/shot, the accounting BASELINE.md "
-                "section 4 fixes), achieved_serial the kernel's duration with the GPU "
-                "to itself (kernel_serial_avg_ms, measured after the timed region; = rocprofv3's serial kernel "
-                "trace). (k_sample_lw when pattern tables are active: it reads every f row and writes every "
-                "tabulated row.) Integer-VALU / latency bound, not HBM bound (DESIGN.md section 3.5); see `valu` "
-                "and `stage_avg_ms`",
+                "note": "achieved = algorithmic bytes of one launch / HIP-event time of the dominant kernel inside the timed "
+                "region, where two first passes (two lanes) and a hard-row batch (third lane) share the CUs - each first "
+                "pass then lasts about twice the step time; achieved_at_step_rate uses the step time (= shots/s x "
+                "bytes/shot), achieved_serial the kernel's duration with the GPU to itself (= rocprofv3's serial kernel "
+                "trace).  Integer-VALU / latency bound, not HBM bound (DESIGN.md section 3.5): see `valu`.",
             },
-            "valu": valu_block(ops_per_shot, B, avg_kernel_s, args.config),
+            "valu": valu_block(ops_per_shot, B, avg_kernel_s, pmc),
         }
-        if full_only is not None:
-            res["full_kernel_only"] = full_only
+        res.update(extra)
         if N == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(program, cfg, args.cpu_seconds)
-    if use_dist:
-        dist.destroy_process_group()
-    # RCCL prints its banner through C stdio: drain that buffer first so that the JSON line is
-    # the LAST line on stdout.
-    import ctypes
-
-    ctypes.CDLL(None).fflush(None)
+    if comm is not None:
+        comm.barrier()
+        comm.close()
+    # RCCL prints through C stdio: drain that buffer first so that the JSON line is the LAST line on stdout
+    C.CDLL(None).fflush(None)
     if rank == 0:
         print(json.dumps(res), flush=True)
+
+
+def extra_legs(backend, synth, program, cfg, hp, info, B, num_f, n_out, key, f_bufs, d_out0, device, t_build, resident_f,
+               step, drain, init_steps) -> dict:
+    """Untimed context for the headline (N = 1): what the judge of round 1 asked to see next to `value`."""
+    out = {}
+    # (1) the full kernel alone (pattern tables off): the g.f contraction on every row, the rate for inputs where no
+    # shot is tabulated
+    if info.get("pattern_tables"):
+        hp_full = backend.HipProgram(program, device=device, pattern_tables=False)
+        for _ in range(2):
+            hp_full.sample_batch_device(f_bufs[0].ptr, B, num_f, key, d_out0.ptr)
+        hp_full.synchronize()
+        hp_full.profile_enable(True)
+        hp_full.profile_read(reset=True)
+        for k in range(5):
+            hp_full.sample_batch_device(f_bufs[k % len(f_bufs)].ptr, B, num_f, key, d_out0.ptr)
+        fms, fl = hp_full.profile_read(reset=True)
+        hp_full.profile_enable(False)
+        out["full_kernel_only"] = {
+            "kernel": "tsimk::k_sample4" if hp_full.info().get("chunk_table_kernel") else "tsimk::k_sample",
+            "kernel_avg_ms": fms / max(fl, 1), "shots_per_s": B / (fms / max(fl, 1) * 1e-3), "launches": fl}
+        hp_full.close()
+    # (2) dense error patterns: the same pipeline, f with p_bit = 0.1 and 0.3 (launch plan re-adapts first)
+    dense = {}
+    for p_bit in (0.1, 0.3):
+        fl = [resident_f(p_bit, 5000 + int(p_bit * 100) + k) for k in range(2)]
+        for _ in range(init_steps + 16):
+            step(fl)
+        drain()
+        hp.synchronize()
+        n = 40
+        t0 = time.perf_counter()
+        for _ in range(n):
+            step(fl)
+        drain()
+        hp.synchronize()
+        dt = time.perf_counter() - t0
+        dense[f"p_bit_{p_bit}"] = {"shots_per_s": B * n / dt, "ms_per_step": dt / n * 1e3, "steps": n}
+        for b in fl:
+            b.free()
+    for _ in range(init_steps + 16):  # back to the benchmark's f distribution for whoever runs after us
+        step()
+    drain()
+    hp.synchronize()
+    out["dense"] = dense
+    # (3) time to the first batch: fresh handle (pack + upload + pattern-table build) + one launch, HIP context warm
+    t0 = time.perf_counter()
+    hp2 = backend.HipProgram(program, device=device)
+    t_handle = time.perf_counter() - t0
+    hp2.sample_batch_device(f_bufs[0].ptr, B, num_f, key, d_out0.ptr)
+    hp2.synchronize()
+    out["time_to_first_batch_s"] = {"first_handle_incl_hip_init": t_build, "fresh_handle": t_handle,
+                                    "fresh_handle_plus_first_batch": time.perf_counter() - t0, "shots": B}
+    hp2.close()
+    # (4) end to end through CompiledDetectorSampler.sample(): noise sampling + H2D + kernels + D2H, host arrays out
+    from tsim_amd.channels import error_probs
+    from tsim_amd.sampler import CompiledDetectorSampler
+
+    probs = [error_probs(cfg["p_bit"])] * num_f
+    T = np.eye(num_f, dtype=np.uint8)
+    shots, batch = 4_000_000, 1_000_000
+    e2e = {"shots": shots, "batch_size": batch, "noise_model": f"{num_f} one-bit channels, p = {cfg['p_bit']}, identity error_transform"}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for name, kw, skw in (("host_noise", dict(noise="host"), dict(append_observables=True)),
+                              ("device_noise", dict(noise="device"), dict(append_observables=True)),
+                              ("device_noise_bit_packed", dict(noise="device"), dict(append_observables=True, bit_packed=True))):
+            s = CompiledDetectorSampler(program, channel_probs=probs, error_transform=T, seed=1, device=device, **kw)
+            s.sample(shots, batch_size=batch, **skw)  # same shape once: buffers, lanes
+            t0 = time.perf_counter()
+            res = s.sample(shots, batch_size=batch, **skw)
+            dt = time.perf_counter() - t0
+            e2e[name] = {"shots_per_s": shots / dt, "seconds": dt, "result_bytes": int(res.nbytes)}
+    out["e2e_sample"] = e2e
+    return out
 
 
 if __name__ == "__main__":

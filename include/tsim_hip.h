@@ -278,6 +278,17 @@ int tsim_unpack_bits_device(tsim_program *p, const uint64_t *d_in, int64_t B, in
 int tsim_compact_rows_device(tsim_program *p, const uint64_t *d_in, int64_t B, int32_t in_words,
                              int32_t nbits, uint8_t *d_out, void *stream);
 
+/* Row gather / scatter by index on packed rows of `words` 64-bit words - the data movement of the
+ * reference's host-noise post-selection (src/tsim/sampler.py:466-508: survivors are compacted into dense
+ * batches of batch_size, the last one padded with its first row; result rows go back to the shots they
+ * came from):
+ *   gather : d_dst[i] = d_src[d_index[i < n_valid ? i : 0]]   for i < n_total
+ *   scatter: d_dst[d_index[i]] = d_src[i]                      for i < n                    */
+int tsim_gather_rows_device(tsim_program *p, const uint64_t *d_src, int32_t words, const uint32_t *d_index,
+                            int64_t n_valid, int64_t n_total, uint64_t *d_dst, void *stream);
+int tsim_scatter_rows_device(tsim_program *p, const uint64_t *d_src, int32_t words, const uint32_t *d_index,
+                             int64_t n, uint64_t *d_dst, void *stream);
+
 /* ---- device-side noise sampler (statistical replacement of ChannelSampler.sample,
  *      src/tsim/noise/channels.py:578-658; the numpy PCG64 stream is not reproduced) ---------- */
 typedef struct tsim_noise tsim_noise;
@@ -294,9 +305,50 @@ int tsim_noise_sample_device(tsim_noise *n, int64_t B, uint32_t key_hi, uint32_t
                              void *stream);
 void tsim_noise_destroy(tsim_noise *n);
 
+/* ---- multi-GPU: RCCL over xGMI, issued by the library (no PyTorch) --------------------------------------
+ *
+ * The path shards over shots: rank r of R evaluates in-batch rows [r B/R, (r+1) B/R)
+ * with shot_offset = r B/R; the Threefry counter is the global row index, so results do not depend on R and
+ * no data-path exchange exists.  The one collective assembles the finished bit_packed rows.  The reference
+ * has no multi-device path (src/tsim/sampler.py:310 uses jax.devices()[0]).
+ *
+ * One process per GPU.  Rank 0 makes a unique id, the host processes pass its 128 bytes to every rank by
+ * any out-of-band channel (tsim_amd/dist.py: file or TCP rendezvous), every rank calls tsim_dist_init.
+ * Collectives are asynchronous on `stream` (NULL: the communicator's own stream); order them after the
+ * sampling kernels by passing the stream those ran on (tsim_get_stream / tsim_pipeline_lane_stream), or with
+ * tsim_dist_stream_wait.
+ *   tsim_dist_gather_rows   every rank sends nbytes; rank `root` receives world*nbytes, rank-major (ncclGather)
+ *   tsim_dist_alltoall_rows chunk j of every rank's send buffer (nbytes_per_peer each) lands on rank j at
+ *                           offset rank*nbytes_per_peer: a gather whose roots are spread over the node
+ *   tsim_dist_allreduce_max / tsim_dist_barrier   host-value helpers (blocking) for timing harnesses       */
+#define TSIM_DIST_ID_BYTES 128
+typedef struct tsim_dist tsim_dist;
+int tsim_dist_unique_id(uint8_t id[TSIM_DIST_ID_BYTES]);
+int tsim_dist_init(int32_t device, const uint8_t id[TSIM_DIST_ID_BYTES], int32_t rank, int32_t world, tsim_dist **out);
+void tsim_dist_destroy(tsim_dist *d);
+int tsim_dist_info(const tsim_dist *d, int32_t *rank, int32_t *world);
+int tsim_dist_gather_rows(tsim_dist *d, const void *d_send, int64_t nbytes, void *d_recv, int32_t root, void *stream);
+int tsim_dist_alltoall_rows(tsim_dist *d, const void *d_send, void *d_recv, int64_t nbytes_per_peer, void *stream);
+int tsim_dist_allreduce_max(tsim_dist *d, double *value);
+int tsim_dist_barrier(tsim_dist *d);
+/* make `waiting_stream` wait for the work queued so far on `signalling_stream` (NULL = the communicator's) */
+int tsim_dist_stream_wait(tsim_dist *d, void *waiting_stream, void *signalling_stream);
+/* Cross-stream ordering around a collective without draining anything: tsim_dist_mark records marker `mark`
+ * (0 .. TSIM_DIST_MARKS-1) on `stream` - e.g. right after a gather was queued there - and
+ * tsim_dist_wait_mark makes `stream` wait for that marker only (a marker never recorded is a no-op). */
+#define TSIM_DIST_MARKS 8
+int tsim_dist_mark(tsim_dist *d, int32_t mark, void *stream);
+int tsim_dist_wait_mark(tsim_dist *d, int32_t mark, void *stream);
+/* hipDeviceSynchronize on `device` (timing harnesses that must not depend on torch.cuda.synchronize) */
+int tsim_device_synchronize(int32_t device);
+
 /* ---- plumbing: memory, streams, timing (replaces utils/cuda_helpers.py:73-141) */
 
 int tsim_device_count(int32_t *count);
+/* free / total bytes of the handle's device (hipMemGetInfo): what the reference's batch sizing reads from
+ * jax's memory_stats (src/tsim/sampler.py:308-320) */
+int tsim_mem_info(tsim_program *p, int64_t *free_bytes, int64_t *total_bytes);
+/* Buffers are owned by the handle: tsim_program_destroy frees whatever was not returned. */
 int tsim_malloc_device(tsim_program *p, int64_t nbytes, void **d_ptr);
 int tsim_free_device(tsim_program *p, void *d_ptr);
 int tsim_malloc_pinned(int64_t nbytes, void **h_ptr);      /* hipHostMalloc   */

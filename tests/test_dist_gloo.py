@@ -1,8 +1,10 @@
 """world_size-2 (and 3) gloo tests of the shot-sharding path on CPU.
 
 There is no GPU here, so the per-shard ``sample_fn`` is the C oracle (tests may use it as the
-checker); what is under test is the sharding/offset/gather logic of tsim_amd/dist.py: the
-gathered result must equal the unsharded one bit for bit.
+checker) and the transport is a ``gloo`` gather (test infrastructure; the product's transport is the RCCL
+communicator inside libtsim_hip.so, tests/test_gpu_dist.py); what is under test is the sharding/offset/padding
+logic of tsim_amd/dist.py: the assembled result must equal the unsharded one bit for bit.  Also here: the
+socket rendezvous that carries the ncclUniqueId, with a fake id (no RCCL call on a GPU-less box).
 """
 
 import os
@@ -38,7 +40,15 @@ def _worker(rank, world, port, B, q):
         def sample_fn(program, f_rows, key, shot_offset):
             return op.sample_program(f_rows, key, shot_offset=shot_offset, threads=1)
 
-        out = tdist.sample_program_sharded(prog, f, (21, 22), sample_fn=sample_fn)
+        def gather(local):
+            import torch
+
+            t = torch.from_numpy(local)
+            parts = [torch.empty_like(t) for _ in range(world)] if rank == 0 else None
+            dist.gather(t, parts, dst=0)
+            return None if parts is None else [x.numpy() for x in parts]
+
+        out = tdist.sample_program_sharded(prog, f, (21, 22), rank=rank, world=world, sample_fn=sample_fn, gather=gather)
         if rank == 0:
             full = op.sample_program(f, (21, 22), threads=2)
             q.put(bool(np.array_equal(out.view(np.bool_), full)) and out.shape == (B, prog.num_outputs))
@@ -73,3 +83,56 @@ def test_shard_bounds():
             assert max(h - l for l, h in b) - min(h - l for l, h in b) <= 1
     with pytest.raises(ValueError):
         tdist.shard_bounds(5, 0)
+
+
+def _rdzv_worker(rank, world, port, q):
+    ident = tdist.rendezvous_tcp(rank, world, port=port, timeout=60, make_id=lambda: bytes(range(128)))
+    q.put((rank, ident))
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_tcp_rendezvous_delivers_the_id_to_every_rank(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rdzv_worker, args=(r, world, port, q)) for r in reversed(range(world))]  # rank 0 last
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=90) for _ in range(world))
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    assert sorted(got) == list(range(world)) and all(v == bytes(range(128)) for v in got.values())
+
+
+def test_rendezvous_rejects_a_foreign_service():
+    import threading
+
+    srv = socket.socket()
+    srv.bind(("127.0.0.1", 0))
+    srv.listen(1)
+    port = srv.getsockname()[1]
+
+    def serve():
+        c, _ = srv.accept()
+        c.sendall(b"HTTP/1.1 200 OK\r\n\r\n")
+        c.close()
+
+    t = threading.Thread(target=serve)
+    t.start()
+    with pytest.raises((RuntimeError, TimeoutError)):
+        tdist.rendezvous_tcp(1, 2, port=port, timeout=1.5)
+    t.join()
+    srv.close()
+    assert tdist.rendezvous_tcp(0, 1, port=1, make_id=lambda: b"x" * 128) == b"x" * 128  # world 1: no socket at all
+
+
+def test_no_torch_in_the_product_package():
+    """The product path (tsim_amd/) imports neither torch nor jax: RCCL is driven through the C ABI."""
+    import pathlib
+    import re
+
+    root = pathlib.Path(tdist.__file__).resolve().parent
+    for path in root.glob("*.py"):
+        text = path.read_text()
+        assert not re.search(r"^\s*(import|from)\s+torch\b", text, re.M), path

@@ -1,7 +1,7 @@
-"""The N > 1 code path of bench.py (RCCL collection of the bit-packed rows, lanes joined on the batch lane)
-forced on one GPU: it must run to completion and print the contract's JSON line.  The real N > 1 runs are
-the driver's; this keeps the plumbing from rotting between rounds.  (Named test_zz_* so that it runs last: it depends on
-torch.distributed + RCCL, infrastructure the other GPU tests do not need.)"""
+"""The N > 1 code path of bench.py (RCCL collection of the bit-packed rows through libtsim_hip.so's own
+communicator, lanes joined on the batch lane) forced on one GPU: it must run to completion and print the
+contract's JSON line.  The real N > 1 runs are the driver's; this keeps the plumbing from rotting between
+rounds.  (Named test_zz_* so that it runs last: a subprocess with its own HIP context.)"""
 import json
 import os
 import socket
@@ -30,11 +30,10 @@ def test_bench_distributed_path_on_one_gpu(hip, mode):
         r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     except subprocess.TimeoutExpired:
         pytest.fail("bench.py (forced distributed path) did not finish in 15 minutes")
-    if r.returncode != 0 and ("ProcessGroupNCCL" in r.stderr or "init_process_group" in r.stderr or "No module named 'torch'" in r.stderr):
-        pytest.skip("torch.distributed / RCCL not usable in this environment: " + r.stderr[-300:])
     assert r.returncode == 0, r.stderr[-2000:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 1 and d["steps"] == 21 and d["value"] > 0 and d["scaling"] == "weak"
     assert ("all-to-all" in d["config"]["sharding"]) == (mode == "alltoall")
-    assert d["roofline"]["achieved"] > 0 and d["roofline"]["launches"] >= 1
+    assert d["roofline"]["achieved"] > 0 and d["roofline"]["launches"] >= 8
+    assert "no torch.distributed" in d["config"]["sharding"] and d["repeats"] >= 1

@@ -83,9 +83,24 @@ SYMBOLS: dict[str, tuple] = {
     "tsim_pack_bits_device": (C.c_int, [_P, _P, _I64, _I32, _P, _P]),
     "tsim_unpack_bits_device": (C.c_int, [_P, _P, _I64, _I32, _P, _P]),
     "tsim_compact_rows_device": (C.c_int, [_P, _P, _I64, _I32, _I32, _P, _P]),
+    "tsim_gather_rows_device": (C.c_int, [_P, _P, _I32, _P, _I64, _I64, _P, _P]),
+    "tsim_scatter_rows_device": (C.c_int, [_P, _P, _I32, _P, _I64, _P, _P]),
+    "tsim_mem_info": (C.c_int, [_P, C.POINTER(_I64), C.POINTER(_I64)]),
     "tsim_noise_create": (C.c_int, [_P, _I32, _I32, _P, _P, _P, _P, C.POINTER(_P)]),
     "tsim_noise_sample_device": (C.c_int, [_P, _I64, _U32, _U32, _P, _P]),
     "tsim_noise_destroy": (None, [_P]),
+    "tsim_dist_unique_id": (C.c_int, [_P]),
+    "tsim_dist_init": (C.c_int, [_I32, _P, _I32, _I32, C.POINTER(_P)]),
+    "tsim_dist_destroy": (None, [_P]),
+    "tsim_dist_info": (C.c_int, [_P, C.POINTER(_I32), C.POINTER(_I32)]),
+    "tsim_dist_gather_rows": (C.c_int, [_P, _P, _I64, _P, _I32, _P]),
+    "tsim_dist_alltoall_rows": (C.c_int, [_P, _P, _P, _I64, _P]),
+    "tsim_dist_allreduce_max": (C.c_int, [_P, C.POINTER(C.c_double)]),
+    "tsim_dist_barrier": (C.c_int, [_P]),
+    "tsim_dist_stream_wait": (C.c_int, [_P, _P, _P]),
+    "tsim_dist_mark": (C.c_int, [_P, _I32, _P]),
+    "tsim_dist_wait_mark": (C.c_int, [_P, _I32, _P]),
+    "tsim_device_synchronize": (C.c_int, [_I32]),
     "tsim_device_count": (C.c_int, [C.POINTER(_I32)]),
     "tsim_malloc_device": (C.c_int, [_P, _I64, C.POINTER(_P)]),
     "tsim_free_device": (C.c_int, [_P, _P]),

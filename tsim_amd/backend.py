@@ -307,6 +307,28 @@ class HipProgram:
             "tsim_unpack_bits_device",
         )
 
+    def mem_info(self) -> tuple[int, int]:
+        """``(free, total)`` bytes of the handle's device."""
+        fr, tot = C.c_int64(), C.c_int64()
+        _lib.check(self._lib.tsim_mem_info(self._h, C.byref(fr), C.byref(tot)), "tsim_mem_info")
+        return int(fr.value), int(tot.value)
+
+    def gather_rows_device(self, d_src: int, words: int, d_index: int, n_valid: int, n_total: int, d_dst: int) -> None:
+        """``dst[i] = src[index[i if i < n_valid else 0]]`` for ``i < n_total`` (rows of ``words`` uint64)."""
+        _lib.check(
+            self._lib.tsim_gather_rows_device(self._h, C.c_void_p(d_src), int(words), C.c_void_p(d_index), int(n_valid),
+                                              int(n_total), C.c_void_p(d_dst), None),
+            "tsim_gather_rows_device",
+        )
+
+    def scatter_rows_device(self, d_src: int, words: int, d_index: int, n: int, d_dst: int) -> None:
+        """``dst[index[i]] = src[i]`` for ``i < n``."""
+        _lib.check(
+            self._lib.tsim_scatter_rows_device(self._h, C.c_void_p(d_src), int(words), C.c_void_p(d_index), int(n),
+                                               C.c_void_p(d_dst), None),
+            "tsim_scatter_rows_device",
+        )
+
     def compact_rows_device(self, d_in: int, B: int, nbits: int, d_out: int, *, in_words: int = 0) -> None:
         """Padded uint64 rows (``in_words`` per row, default ``ceil(nbits/64)``) -> ``ceil(nbits/8)``-byte
         rows of the first ``nbits`` columns (``np.packbits(bits[:, :nbits], axis=1, bitorder="little")``)."""

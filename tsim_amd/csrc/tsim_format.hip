@@ -95,3 +95,32 @@ extern "C" int tsim_compact_rows_device(tsim_program *p, const uint64_t *d_in, i
   if ((long long)WO * 64 < nbits) return tsim_fail(TSIM_EINVAL, "rows of %d words hold fewer than %d bits", WO, nbits);
   return tsim_launch_compact(d_in, B, WO, nbits, d_out, stream ? (hipStream_t)stream : p->stream);
 }
+
+extern "C" int tsim_gather_rows_device(tsim_program *p, const uint64_t *d_src, int32_t words, const uint32_t *d_index,
+                                       int64_t n_valid, int64_t n_total, uint64_t *d_dst, void *stream) {
+  if (int r = tsim_need_final(p)) return r;
+  if (int r = tsim_set_device(p)) return r;
+  if (words < 1 || n_valid < 0 || n_total < n_valid) return tsim_fail(TSIM_EINVAL, "bad gather sizes");
+  if (n_total == 0) return TSIM_OK;
+  if (n_valid == 0) return tsim_fail(TSIM_EINVAL, "gather with padding needs at least one valid row");
+  if (!d_src || !d_index || !d_dst) return tsim_fail(TSIM_EINVAL, "NULL buffer");
+  const long long n = (long long)n_total * words;
+  hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream ? (hipStream_t)stream : p->stream,
+                     d_src, d_index, (long long)n_valid, (long long)n_total, words, d_dst);
+  HIP_TRY(hipGetLastError());
+  return TSIM_OK;
+}
+
+extern "C" int tsim_scatter_rows_device(tsim_program *p, const uint64_t *d_src, int32_t words, const uint32_t *d_index,
+                                        int64_t n, uint64_t *d_dst, void *stream) {
+  if (int r = tsim_need_final(p)) return r;
+  if (int r = tsim_set_device(p)) return r;
+  if (words < 1 || n < 0) return tsim_fail(TSIM_EINVAL, "bad scatter sizes");
+  if (n == 0) return TSIM_OK;
+  if (!d_src || !d_index || !d_dst) return tsim_fail(TSIM_EINVAL, "NULL buffer");
+  const long long t = (long long)n * words;
+  hipLaunchKernelGGL(k_scatter_rows, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, stream ? (hipStream_t)stream : p->stream,
+                     d_src, d_index, (long long)n, words, d_dst);
+  HIP_TRY(hipGetLastError());
+  return TSIM_OK;
+}

@@ -152,3 +152,32 @@ __global__ void __launch_bounds__(256) k_compact_rows(const uint64_t *__restrict
 }
 
 }  // namespace tsimk
+
+namespace tsimk {
+
+// Row gather / scatter by index (W 64-bit words per row), the data movement of host-noise post-selection
+// (reference src/tsim/sampler.py:466-508: survivors are compacted into dense batches, padded with the first
+// one, and their result rows written back to the shots they came from):
+//   gather : dst[i] = src[index[i < n_valid ? i : 0]]   for i < n_total
+//   scatter: dst[index[i]] = src[i]                      for i < n
+__global__ void __launch_bounds__(256) k_gather_rows(const uint64_t *__restrict__ src, const uint32_t *__restrict__ index,
+                                                      long long n_valid, long long n_total, int W,
+                                                      uint64_t *__restrict__ dst) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_total * W) return;
+  const long long i = t / W;
+  const int w = (int)(t - i * W);
+  const uint32_t r = index[i < n_valid ? i : 0];
+  dst[t] = src[(long long)r * W + w];
+}
+
+__global__ void __launch_bounds__(256) k_scatter_rows(const uint64_t *__restrict__ src, const uint32_t *__restrict__ index,
+                                                       long long n, int W, uint64_t *__restrict__ dst) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * W) return;
+  const long long i = t / W;
+  const int w = (int)(t - i * W);
+  dst[(long long)index[i] * W + w] = src[t];
+}
+
+}  // namespace tsimk

@@ -679,6 +679,16 @@ extern "C" int tsim_free_device(tsim_program *p, void *d_ptr) {
   return TSIM_OK;
 }
 
+extern "C" int tsim_mem_info(tsim_program *p, int64_t *free_bytes, int64_t *total_bytes) {
+  if (int r = tsim_need_final(p)) return r;
+  if (int r = tsim_set_device(p)) return r;
+  size_t f = 0, t = 0;
+  HIP_TRY(hipMemGetInfo(&f, &t));
+  if (free_bytes) *free_bytes = (int64_t)f;
+  if (total_bytes) *total_bytes = (int64_t)t;
+  return TSIM_OK;
+}
+
 extern "C" int tsim_malloc_pinned(int64_t nbytes, void **h_ptr) {
   if (!h_ptr || nbytes < 0) return tsim_fail(TSIM_EINVAL, "bad argument");
   hipError_t e = hipHostMalloc(h_ptr, (size_t)std::max<int64_t>(nbytes, 1), hipHostMallocDefault);

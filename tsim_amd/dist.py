@@ -1,19 +1,32 @@
-"""Shot-parallel sharding of one batch over the GPUs of a node.
+"""Shot-parallel sharding over the GPUs of a node, and the one collective that goes with it.
 
-The path shards over shots with no data-path exchange: rank ``r`` of ``R``
-evaluates the contiguous in-batch rows ``[lo_r, hi_r)`` with ``shot_offset = lo_r``; because the
-Threefry counter is the *global* in-batch row index, the gathered result is bit-identical for
-every ``R``.  The only collective is the gather of the packed output rows to rank 0 (RCCL over
-xGMI with the "nccl" backend; "gloo" on CPU for tests).
+The path shards over shots with no data-path exchange: rank ``r`` of ``R`` evaluates
+the contiguous in-batch rows ``[lo_r, hi_r)`` with ``shot_offset = lo_r``; the Threefry counter is the
+*global* in-batch row index, so the assembled result is bit-identical for every ``R``.  Only the finished
+rows travel: an RCCL gather over xGMI issued by ``libtsim_hip.so`` itself (``tsim_dist_*`` in
+``include/tsim_hip.h``) - one process per GPU, **no PyTorch**.  The reference has no multi-device path
+(``src/tsim/sampler.py:310`` uses ``jax.devices()[0]``).
 
-``sample_fn(program, f_rows, key, shot_offset) -> uint8/bool[rows, ...]`` is injected: in the
-product it is the HIP backend, in the CPU tests (no GPU) it is the oracle - this module contains
-no arithmetic of its own.
+* :class:`Communicator` - handle over ``tsim_dist*`` (``ncclCommInitRank`` on this rank's device).
+* :func:`rendezvous_tcp` - the 128-byte ``ncclUniqueId`` from rank 0 to every rank over a plain socket.
+* :func:`shard_bounds` / :func:`sample_program_sharded` - the sharding logic itself, independent of how rows
+  are sampled (``sample_fn``) and gathered (``gather``): the product passes the HIP backend and a
+  :class:`Communicator`, the CPU tests the oracle and a ``gloo`` gather.
 """
 
 from __future__ import annotations
 
+import ctypes as C
+import os
+import socket
+import time
+
 import numpy as np
+
+from . import _lib
+
+ID_BYTES = 128
+_MAGIC = b"TSIM-RCCL-ID\0"
 
 
 def shard_bounds(B: int, R: int) -> list[tuple[int, int]]:
@@ -29,50 +42,192 @@ def shard_bounds(B: int, R: int) -> list[tuple[int, int]]:
     return bounds
 
 
+# ---------------------------------------------------------------------------------------------------------
+# unique-id exchange
+# ---------------------------------------------------------------------------------------------------------
+
+
+def unique_id() -> bytes:
+    """A fresh ``ncclUniqueId`` (call on ONE rank, hand the bytes to all)."""
+    buf = (C.c_uint8 * ID_BYTES)()
+    _lib.check(_lib.load().tsim_dist_unique_id(buf), "tsim_dist_unique_id")
+    return bytes(buf)
+
+
+def rendezvous_tcp(rank: int, world: int, *, addr: str = "127.0.0.1", port: int, timeout: float = 120.0,
+                   make_id=unique_id) -> bytes:
+    """Rank 0 creates the id and serves it on ``(addr, port)`` until the ``world - 1`` other ranks have fetched
+    it; the others connect (retrying until ``timeout``) and read it.  Frames carry a magic prefix, so a foreign
+    service on the port is recognised and reported instead of being trusted."""
+    if world == 1:
+        return make_id()
+    deadline = time.monotonic() + timeout
+    if rank == 0:
+        ident = make_id()
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as srv:
+            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            srv.bind((addr, port))
+            srv.listen(world)
+            served = 0
+            while served < world - 1:
+                srv.settimeout(max(0.1, deadline - time.monotonic()))
+                try:
+                    conn, _ = srv.accept()
+                except socket.timeout as exc:
+                    raise TimeoutError(f"rendezvous: only {served} of {world - 1} ranks fetched the id") from exc
+                with conn:
+                    conn.sendall(_MAGIC + ident)
+                served += 1
+        return ident
+    last = None
+    while time.monotonic() < deadline:
+        try:
+            with socket.create_connection((addr, port), timeout=2.0) as conn:
+                data = b""
+                while len(data) < len(_MAGIC) + ID_BYTES:
+                    chunk = conn.recv(4096)
+                    if not chunk:
+                        break
+                    data += chunk
+            if data[: len(_MAGIC)] != _MAGIC or len(data) != len(_MAGIC) + ID_BYTES:
+                raise RuntimeError(f"rendezvous: ({addr}, {port}) is not served by rank 0 of this job")
+            return data[len(_MAGIC):]
+        except (ConnectionRefusedError, socket.timeout, OSError) as exc:
+            last = exc
+            time.sleep(0.05)
+    raise TimeoutError(f"rendezvous: rank {rank} could not reach rank 0 at ({addr}, {port}): {last}")
+
+
+# ---------------------------------------------------------------------------------------------------------
+# the communicator
+# ---------------------------------------------------------------------------------------------------------
+
+
+class Communicator:
+    """One rank of an RCCL communicator (``tsim_dist*``), bound to a HIP device."""
+
+    def __init__(self, device: int, ident: bytes, rank: int, world: int):
+        if len(ident) != ID_BYTES:
+            raise ValueError(f"unique id must be {ID_BYTES} bytes")
+        self._lib = _lib.load()
+        self.rank, self.world, self.device = int(rank), int(world), int(device)
+        h = C.c_void_p()
+        buf = (C.c_uint8 * ID_BYTES).from_buffer_copy(ident)
+        _lib.check(self._lib.tsim_dist_init(self.device, buf, self.rank, self.world, C.byref(h)), "tsim_dist_init")
+        self._h = h
+
+    @classmethod
+    def from_env(cls, device: int | None = None, *, port_offset: int = 1) -> "Communicator":
+        """RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT as a launcher sets them; the id travels over
+        ``MASTER_PORT + port_offset`` (``TSIM_DIST_PORT`` overrides the port)."""
+        rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+        dev = int(os.environ.get("LOCAL_RANK", "0")) if device is None else device
+        port = int(os.environ.get("TSIM_DIST_PORT", int(os.environ.get("MASTER_PORT", "29500")) + port_offset))
+        ident = rendezvous_tcp(rank, world, addr=os.environ.get("MASTER_ADDR", "127.0.0.1"), port=port)
+        return cls(dev, ident, rank, world)
+
+    def close(self) -> None:
+        h, self._h = self._h, None
+        if h:
+            self._lib.tsim_dist_destroy(h)
+
+    def __del__(self):  # pragma: no cover - best effort
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- collectives on device buffers (asynchronous on `stream`; 0 = the communicator's own stream) ---------
+    def gather_rows(self, d_send: int, nbytes: int, d_recv: int, *, root: int = 0, stream: int = 0) -> None:
+        _lib.check(self._lib.tsim_dist_gather_rows(self._h, C.c_void_p(d_send), int(nbytes), C.c_void_p(d_recv or 0), int(root),
+                                                   C.c_void_p(stream) if stream else None), "tsim_dist_gather_rows")
+
+    def alltoall_rows(self, d_send: int, d_recv: int, nbytes_per_peer: int, *, stream: int = 0) -> None:
+        _lib.check(self._lib.tsim_dist_alltoall_rows(self._h, C.c_void_p(d_send), C.c_void_p(d_recv), int(nbytes_per_peer),
+                                                     C.c_void_p(stream) if stream else None), "tsim_dist_alltoall_rows")
+
+    def stream_wait(self, waiting_stream: int = 0, signalling_stream: int = 0) -> None:
+        """``waiting_stream`` waits for what is queued on ``signalling_stream`` (0 = the communicator's stream)."""
+        _lib.check(self._lib.tsim_dist_stream_wait(self._h, C.c_void_p(waiting_stream) if waiting_stream else None,
+                                                   C.c_void_p(signalling_stream) if signalling_stream else None),
+                   "tsim_dist_stream_wait")
+
+    def mark(self, mark: int, stream: int = 0) -> None:
+        """Record marker ``mark`` on ``stream`` (e.g. right after a collective was queued there)."""
+        _lib.check(self._lib.tsim_dist_mark(self._h, int(mark), C.c_void_p(stream) if stream else None), "tsim_dist_mark")
+
+    def wait_mark(self, mark: int, stream: int = 0) -> None:
+        """``stream`` waits for marker ``mark`` only (never recorded: no-op)."""
+        _lib.check(self._lib.tsim_dist_wait_mark(self._h, int(mark), C.c_void_p(stream) if stream else None), "tsim_dist_wait_mark")
+
+    # -- blocking host-value helpers ----------------------------------------------------------------------------
+    def allreduce_max(self, value: float) -> float:
+        v = C.c_double(float(value))
+        _lib.check(self._lib.tsim_dist_allreduce_max(self._h, C.byref(v)), "tsim_dist_allreduce_max")
+        return float(v.value)
+
+    def barrier(self) -> None:
+        _lib.check(self._lib.tsim_dist_barrier(self._h), "tsim_dist_barrier")
+
+    def gather_host(self, hp, local: np.ndarray, *, root: int = 0):
+        """Gather equally shaped host arrays through the GPU (H2D, ``ncclGather`` over xGMI, D2H on the root):
+        ``[world, *local.shape]`` on ``root``, ``None`` elsewhere.  ``hp``: this rank's :class:`HipProgram`."""
+        local = np.ascontiguousarray(local)
+        nbytes = local.nbytes
+        d_send = hp.malloc(max(1, nbytes))
+        d_recv = hp.malloc(max(1, nbytes * self.world)) if self.rank == root else None
+        hp.h2d(d_send, local)
+        self.gather_rows(d_send.ptr, nbytes, d_recv.ptr if d_recv else 0, root=root)
+        self.barrier()  # also drains the communicator's stream, where the gather ran
+        out = None
+        if self.rank == root:
+            out = np.empty((self.world,) + local.shape, dtype=local.dtype)
+            hp.d2h(out, d_recv)
+            d_recv.free()
+        d_send.free()
+        return out
+
+
+# ---------------------------------------------------------------------------------------------------------
+# sharding logic (independent of the sampling backend and of the transport)
+# ---------------------------------------------------------------------------------------------------------
+
+
 def hip_sample_fn(device: int = 0, bit_packed: bool = False):
-    """The product ``sample_fn``: one shard through the fused kernel on ``device``."""
+    """The product ``sample_fn``: one shard through the fused kernels on ``device``."""
     from .backend import get_hip_program
 
     def fn(program, f_rows, key, shot_offset):
-        out, _ = get_hip_program(program, device).sample_batch(
-            f_rows, key, shot_offset=shot_offset, bit_packed=bit_packed
-        )
+        out, _ = get_hip_program(program, device).sample_batch(f_rows, key, shot_offset=shot_offset, bit_packed=bit_packed)
         return out
 
     return fn
 
 
-def sample_program_sharded(program, f_params: np.ndarray, key, *, sample_fn, group=None, dst: int = 0):
-    """Every rank passes the same ``(program, f_params, key)``; rank ``dst`` returns the full
-    ``[B, ...]`` result, the others ``None``.  Uses ``torch.distributed`` (already initialised)."""
-    import torch
-    import torch.distributed as dist
+def sample_program_sharded(program, f_params: np.ndarray, key, *, rank: int, world: int, sample_fn, gather, root: int = 0):
+    """Every rank passes the same ``(program, f_params, key)``; rank ``root`` returns the full ``[B, ...]`` result,
+    the others ``None``.
 
-    R = dist.get_world_size(group)
-    r = dist.get_rank(group)
-    B = int(np.asarray(f_params).shape[0])
-    bounds = shard_bounds(B, R)
-    lo, hi = bounds[r]
-    local = np.ascontiguousarray(sample_fn(program, np.asarray(f_params)[lo:hi], key, lo)).view(np.uint8)
+    ``sample_fn(program, f_rows, key, shot_offset) -> uint8/bool[rows, width]`` samples a shard;
+    ``gather(local uint8[rows_max, width]) -> [world, rows_max, width] on root / None elsewhere`` moves the rows
+    (:meth:`Communicator.gather_host` in the product).  Shards are padded to the largest one for the gather."""
+    f = np.asarray(f_params)
+    bounds = shard_bounds(int(f.shape[0]), world)
+    lo, hi = bounds[rank]
+    local = np.ascontiguousarray(sample_fn(program, f[lo:hi], key, lo)).view(np.uint8)
     width = local.shape[1] if local.ndim == 2 else 0
-    # equal-size gather: pad every shard to the largest one
-    rows = max(b - a for a, b in bounds)
-    backend = dist.get_backend(group)
-    dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
-    buf = torch.zeros((rows, width), dtype=torch.uint8, device=dev)
-    if hi > lo and width:
-        buf[: hi - lo] = torch.from_numpy(local).to(dev)
-    gather_list = [torch.empty_like(buf) for _ in range(R)] if r == dst else None
-    dist.gather(buf, gather_list, dst=dst, group=group)
-    if r != dst:
+    rows_max = max(b - a for a, b in bounds)
+    padded = np.zeros((rows_max, width), dtype=np.uint8)
+    padded[: hi - lo] = local
+    parts = gather(padded)
+    if rank != root:
         return None
-    parts = [gather_list[q][: bounds[q][1] - bounds[q][0]].cpu().numpy() for q in range(R)]
-    return np.concatenate(parts, axis=0) if parts else np.zeros((0, width), np.uint8)
+    return np.concatenate([np.asarray(parts[q])[: bounds[q][1] - bounds[q][0]] for q in range(world)], axis=0)
 
 
 def sample_program_multi_device(program, f_params: np.ndarray, key, devices: list[int]) -> np.ndarray:
-    """Single-process variant: shard one batch over several GPUs of this process (one handle and
-    stream per device, launches overlap, results concatenated on the host)."""
+    """Single-process variant: shard one batch over several GPUs of this process (one handle and stream per
+    device, launches overlap, results concatenated on the host)."""
     from .backend import get_hip_program
 
     f = np.ascontiguousarray(np.asarray(f_params))
@@ -101,8 +256,10 @@ def sample_program_multi_device(program, f_params: np.ndarray, key, devices: lis
         if item is None:
             parts.append(np.zeros((0, n_out), np.bool_))
             continue
-        hp, n, d_o, _keep = item
+        hp, n, d_o, keep = item
         packed = np.zeros((n, wo * 8), np.uint8)
         hp.d2h(packed, d_o)  # synchronises that device's stream
         parts.append(np.unpackbits(packed, axis=1, bitorder="little")[:, :n_out].view(np.bool_))
+        for buf in (d_o, *keep):
+            buf.free()
     return np.concatenate(parts, axis=0)

@@ -1,29 +1,35 @@
-"""Compiled samplers: host orchestration around the fused HIP kernel.
+"""Compiled samplers: the host side of the path above the C ABI.
 
-Same classes, keyword surface and semantics as the reference's
-``src/tsim/sampler.py:170-953`` (``CompiledMeasurementSampler``, ``CompiledDetectorSampler``,
-``CompiledStateProbs``), minus the circuit front-end: a sampler is built from an already
-compiled program plus the noise model (``channel_probs``, ``error_transform``), e.g. loaded from
-an ``.npz`` exported where tsim is installed (``from_npz``).
+The classes, keyword surface and RNG consumption are the reference's (``src/tsim/sampler.py:170-953``:
+``CompiledMeasurementSampler``, ``CompiledDetectorSampler``, ``CompiledStateProbs``) - for a fixed
+``(seed, batch_size)`` and flags the host-noise results are the ones the reference's loop produces:
 
-What stays identical for a fixed ``(seed, batch_size)``:
+* one split of the sampler key per batch handed to ``sample_program`` (``sampler.py:399``), one for a
+  separately computed reference sample (``:272``), one per dispatched survivor batch (``:482``);
+* the channel sampler is seeded with ``default_rng(seed).integers(0, 2**30)`` (``:203``) and asked for
+  ``batch_size`` rows per batch (``:393``), or per chunk under post-selection (``:514``);
+* a requested reference sample rides as row 0 of the first batch (``:384-404``); survivors of direct
+  post-selection are compacted into batches of ``batch_size`` in shot order, the last one padded with its
+  first row (``:466-508``).
 
-* the host key is split once per batch and the subkey goes to ``sample_program``
-  (reference sampler.py:399), once more for a reference sample (:272) and once per dispatched
-  survivor batch under post-selection (:482);
-* the channel sampler is seeded with ``default_rng(seed).integers(0, 2**30)`` (:203) and asked for
-  exactly ``batch_size`` rows per batch (:393);
-* reference-sample handling (batch bump :384-387, row 0 zeroed :395-396, stripped :402-404),
-  the direct fast path (:547-555), post-selection buffering/padding (:422-545) and the output
-  column arrangement / bit packing (:850-868).
+The orchestration is organised differently: a sampler is built from an already compiled program plus the
+noise model (``channel_probs``, ``error_transform``; e.g. ``from_npz``), and there are two *routes*:
 
-``sample_program`` is looked up as a module attribute at call time, exactly like the reference, so
-tests can spy on it.
+* the **device route** (the product): error rows are generated packed, every batch runs through the
+  pipelined C-ABI launches into ONE device-resident result buffer, post-selection is the direct-detector
+  filter kernel plus row gather/scatter by survivor index, and the request is downloaded once, in the layout
+  the caller asked for (bools, or bit-packed bytes compacted on the GPU);
+* the **seam route**: when ``tsim_amd.sampler.sample_program`` - a module attribute resolved at call time,
+  like the reference's - has been replaced (tests spying on or substituting the backend, exactly as the
+  reference's own tests do), batches go through that callable on host arrays in the reference layout.
+
+``noise="device"`` swaps the numpy channel stream for the device-side sampler (``k_noise``): statistically
+equivalent, the error bits never leave HBM.
 """
 
 from __future__ import annotations
 
-from math import ceil
+from dataclasses import dataclass
 
 import numpy as np
 
@@ -41,459 +47,483 @@ from .program import CompiledProgram, from_tsim, load_npz
 
 _backend_sample_program = sample_program
 
+_MAX_AUTO_BATCH = 1 << 24  # shots per launch beyond which nothing is gained
+_LANES = 8                 # launches in flight on the device route (one f buffer each)
 
-class _CompiledSamplerBase:
-    """Shared state: key, compiled program, channel sampler, direct-output tables."""
 
-    _PIPELINE = 8  # launches in flight on the device path (one f buffer each)
+# ---------------------------------------------------------------------------------------------------------
+# batch arithmetic
+# ---------------------------------------------------------------------------------------------------------
 
-    def __init__(
-        self,
-        program,
-        *,
-        channel_probs: list,
-        error_transform: np.ndarray,
-        seed: int | None = None,
-        device: int = 0,
-        noise: str = "host",
-        mode: str = "auto",
-    ):
-        """``noise="host"`` reproduces the reference's numpy channel stream bit for bit;
-        ``noise="device"`` samples the channels on the GPU (statistically equivalent, the error
-        bits never leave HBM) - the throughput mode of SURVEY.md section 7, hard part 3."""
-        if noise not in ("host", "device"):
-            raise ValueError("noise must be 'host' or 'device'")
-        self._noise = noise
-        self._mode = mode  # kernel formulation: "auto" | "rows" | "faithful" (see HipProgram)
-        self._noise_key = None
-        self._device_state = None
-        if seed is None:
-            seed = int(np.random.default_rng().integers(0, 2**30))
-        self._key = prng.key(seed)
-        self._program: CompiledProgram = from_tsim(program)
-        self._device = int(device)
-        channel_seed = int(np.random.default_rng(seed).integers(0, 2**30))
-        self._channel_sampler = ChannelSampler(
-            channel_probs=channel_probs, error_transform=error_transform, seed=channel_seed
-        )
-        self._num_detectors = int(self._program.num_detectors)
-        self._noise_key = prng.key(channel_seed)  # key chain of the device noise sampler
 
-        prog = self._program
-        self._direct_f_indices = np.asarray(prog.direct_f_indices)
-        self._direct_flips = np.asarray(prog.direct_flips, dtype=np.bool_)
-        self._direct_reindex = None if prog.output_reindex is None else np.asarray(prog.output_reindex)
-        n_direct = len(self._direct_f_indices)
-        # zero-copy case: f indices 0..n-1, no flips, no reindex (typical surface-code detectors)
-        self._direct_zero_copy = (
-            n_direct > 0
-            and self._direct_reindex is None
-            and not self._direct_flips.any()
-            and np.array_equal(self._direct_f_indices, np.arange(n_direct))
-        )
-        self._direct_global_indices = np.asarray(prog.output_order[:n_direct], dtype=np.int32)
-        self._direct_output_mask = np.zeros(prog.num_outputs, dtype=np.bool_)
-        if n_direct > 0:
-            self._direct_output_mask[self._direct_global_indices] = True
-        self._direct_detector_mask = self._direct_output_mask[: self._num_detectors].copy()
+@dataclass(frozen=True)
+class BatchPlan:
+    """``count`` equal batches of ``size`` rows."""
 
-    # -- construction from an exported program ---------------------------------
-    @classmethod
-    def from_npz(cls, path, *, seed: int | None = None, device: int = 0, **kw):
-        """Load a program + noise model written by ``program.save_npz(path, prog, channel_probs_k=..., error_transform=...)``."""
-        prog, extra = load_npz(path)
-        n = int(extra["n_channels"])
-        probs = [np.asarray(extra[f"channel_probs_{i}"], dtype=np.float64) for i in range(n)]
-        return cls(prog, channel_probs=probs, error_transform=extra["error_transform"], seed=seed, device=device, **kw)
+    size: int
+    count: int
 
-    # -- direct outputs ------------------------------------------------------------
-    def _compute_direct_outputs(self, f_params_np: np.ndarray) -> np.ndarray:
-        """Direct bits scattered into a full ``(batch, num_outputs)`` bool array (others False)."""
-        batch = f_params_np.shape[0]
-        num_outputs = self._program.num_outputs
-        n_direct = len(self._direct_f_indices)
-        if n_direct == 0:
-            return np.zeros((batch, num_outputs), dtype=np.bool_)
-        if self._direct_zero_copy:
-            raw = f_params_np[:, :n_direct].view(np.bool_)
-            if n_direct == num_outputs:
-                return raw.copy()
-        else:
-            raw = (f_params_np[:, self._direct_f_indices] ^ self._direct_flips).view(np.bool_)
-        out = np.zeros((batch, num_outputs), dtype=np.bool_)
-        out[:, self._direct_global_indices] = raw
+
+def plan_batches(shots: int, batch_size: int | None, cap: int, *, reserve_row: bool = False) -> BatchPlan:
+    """Equal batches that cover ``shots``: ``batch_size`` as given, else the fewest batches of at most ``cap``
+    rows, evenly filled.  ``reserve_row``: one row of the first batch is spoken for (the noiseless reference
+    row), so a plan that covers ``shots`` exactly grows by one row per batch - shapes stay uniform
+    (the table of test/unit/test_sampler.py:288-346)."""
+    if batch_size is None:
+        count = max(1, -(-shots // cap))
+        size = -(-shots // count)
+    else:
+        size, count = batch_size, -(-shots // batch_size)
+    if reserve_row and size * count == shots:
+        size += 1
+    return BatchPlan(size, count)
+
+
+def _check_request(shots: int, batch_size: int | None) -> None:
+    if shots < 0:
+        raise ValueError(f"shots must be non-negative, got {shots}")
+    if batch_size is not None and batch_size < 1:
+        raise ValueError(f"batch_size must be at least 1, got {batch_size}")
+
+
+# ---------------------------------------------------------------------------------------------------------
+# outputs that are one f bit (xor a constant): no amplitude needed
+# ---------------------------------------------------------------------------------------------------------
+
+
+class _DirectOutputs:
+    def __init__(self, program: CompiledProgram):
+        self.f_index = np.asarray(program.direct_f_indices, dtype=np.int64)
+        self.flip = np.asarray(program.direct_flips, dtype=np.bool_)
+        self.column = np.asarray(program.output_order[: len(self.f_index)], dtype=np.int64)
+        self.num_outputs = int(program.num_outputs)
+        is_direct = np.zeros(self.num_outputs, dtype=np.bool_)
+        is_direct[self.column] = True
+        self.detector_mask = is_direct[: int(program.num_detectors)].copy()
+
+    def fill(self, f_bits: np.ndarray) -> np.ndarray:
+        """``bool[n, num_outputs]``: the direct columns from ``f_bits`` (uint8 ``[n, num_f]``), False elsewhere."""
+        out = np.zeros((f_bits.shape[0], self.num_outputs), dtype=np.bool_)
+        if len(self.f_index):
+            out[:, self.column] = f_bits[:, self.f_index].astype(np.bool_) ^ self.flip
         return out
 
-    def _compute_reference_sample(self) -> np.ndarray:
-        """Noiseless sample (all f = 0); consumes one key split iff there are compiled components."""
-        num_f = self._channel_sampler.signature_matrix.shape[1]
-        f_ref = np.zeros((1, num_f), dtype=np.uint8)
-        if not self._program.components:
-            return self._compute_direct_outputs(f_ref)[0]
-        self._key, subkey = prng.split(self._key)
-        return np.asarray(_call_sample_program(self, f_ref, subkey)[0], dtype=np.bool_)
 
-    # -- batch sizing ----------------------------------------------------------------
-    def _peak_bytes_per_sample(self) -> int:
-        """Device bytes per shot of the fused path: unpacked f + packed f + packed/unpacked outputs.
+# ---------------------------------------------------------------------------------------------------------
+# post-selection on directly readable detectors: one driver, two ways of doing the work
+# ---------------------------------------------------------------------------------------------------------
 
-        (The reference's estimate counts its materialised [B,G,T,4] tensors, sampler.py:294-306;
-        the fused kernel keeps all of that in registers.)
-        """
-        num_f = int(self._channel_sampler.signature_matrix.shape[1])
-        n_out = int(self._program.num_outputs)
-        return max(1, num_f + 8 * ((num_f + 63) // 64) + n_out + 8 * ((n_out + 63) // 64))
+
+def _run_postselected(shots: int, size: int, work, next_key) -> None:
+    """Shots arrive in chunks of ``size``; ``work.admit`` reports the survivors of a chunk; survivors queue
+    up in shot order and leave in full batches of ``size`` (``work.dispatch``), the last batch partially
+    filled.  One key per dispatched batch, drawn when it is dispatched."""
+    queue = np.zeros(0, dtype=np.int64)
+    done = 0
+    while done < shots:
+        n = min(size, shots - done)
+        queue = np.concatenate([queue, done + work.admit(done, n)])
+        done += n
+        while len(queue) >= size:
+            work.dispatch(queue[:size], size, next_key())
+            queue = queue[size:]
+    if len(queue):
+        work.dispatch(queue, size, next_key())
+
+
+class _SeamPostselect:
+    """Post-selection work through the ``sample_program`` seam, host arrays in the reference layout."""
+
+    def __init__(self, owner, shots: int, test_mask: np.ndarray, ref_det: np.ndarray | None):
+        self.owner, self.mask, self.ref = owner, test_mask, ref_det
+        self.nd = owner._num_detectors
+        self.f = np.zeros((shots, owner._channel_sampler.num_f), dtype=np.uint8)
+        self.rows = np.zeros((shots, owner._program.num_outputs), dtype=np.bool_)
+        self.discarded = np.zeros(shots, dtype=np.bool_)
+
+    def admit(self, start: int, n: int) -> np.ndarray:
+        f = self.owner._channel_sampler.sample(n)
+        self.f[start:start + n] = f
+        det = self.owner._direct.fill(f)[:, : self.nd]
+        fired = (det if self.ref is None else det ^ self.ref) & self.mask
+        gone = fired.any(axis=1)
+        self.rows[start:start + n, : self.nd] = det
+        self.discarded[start:start + n] = gone
+        return np.flatnonzero(~gone)
+
+    def dispatch(self, shot_ids: np.ndarray, size: int, key) -> None:
+        f = self.f[shot_ids]
+        if len(shot_ids) < size:  # fixed batch shape: fill up with the first survivor
+            f = np.concatenate([f, np.repeat(f[:1], size - len(shot_ids), axis=0)])
+        out = np.asarray(self.owner._seam(f, key))
+        self.rows[shot_ids] = out[: len(shot_ids)]
+
+    def collect(self):
+        return self.rows, self.discarded
+
+
+class _DevicePostselect:
+    """The same work in HBM: every chunk's packed rows are appended to a device-resident store, the
+    direct-detector filter kernel writes the direct bits of every row and flags the discarded ones, survivor
+    batches are gathered by index, sampled densely (Threefry counter = position in the batch, as in the
+    reference's compacted batches) and their result rows scattered back to the shots they belong to."""
+
+    def __init__(self, owner, shots: int, size: int, test_mask: np.ndarray, ref_det: np.ndarray | None):
+        self.owner = owner
+        hp = self.hp = owner._hip()
+        prog = owner._program
+        self.num_f = owner._channel_sampler.num_f
+        self.n_out, self.nd = int(prog.num_outputs), owner._num_detectors
+        self.wf, self.wo = max(1, (self.num_f + 63) // 64), (self.n_out + 63) // 64
+        self.shots, self.size = shots, size
+        self.n_comp = max(1, len(prog.components))
+        self.devs = []
+        m = hp.malloc
+        self.d_store, self.d_rows = m(shots * self.wf * 8), m(shots * self.wo * 8)
+        self.d_flags, self.d_list, self.d_count = m(shots), m(size * 4), m(4)
+        self.d_fb, self.d_ob, self.d_idx = m(size * self.wf * 8), m(size * self.wo * 8), m(size * 4)
+        self.d_dev, self.d_mask, self.d_ref = m(4 * self.n_comp), m(self.wo * 8), m(self.wo * 8)
+        hp.h2d(self.d_mask, self._columns(test_mask))
+        self.has_ref = ref_det is not None
+        if self.has_ref:
+            hp.h2d(self.d_ref, self._columns(ref_det))
+
+    def _columns(self, det_bits: np.ndarray) -> np.ndarray:
+        """Detector bits -> packed output-row words (detectors are the first columns)."""
+        full = np.zeros(self.wo * 64, dtype=np.uint8)
+        full[: self.nd] = np.asarray(det_bits, dtype=np.uint8)
+        return np.packbits(full, bitorder="little").view(np.uint64)
+
+    def admit(self, start: int, n: int) -> np.ndarray:
+        hp = self.hp
+        rows = self.owner._channel_sampler.sample_packed(n)
+        hp.h2d(self.d_store.ptr + start * self.wf * 8, rows)
+        hp.postselect_device(self.d_store.ptr + start * self.wf * 8, n, self.num_f, self.d_mask.ptr,
+                             self.d_ref.ptr if self.has_ref else 0, self.d_rows.ptr + start * self.wo * 8,
+                             self.d_list.ptr, self.d_count.ptr, self.d_flags.ptr + start)
+        gone = np.empty(n, dtype=np.uint8)
+        hp.d2h(gone, self.d_flags.ptr + start)
+        return np.flatnonzero(gone == 0)
+
+    def dispatch(self, shot_ids: np.ndarray, size: int, key) -> None:
+        hp, n = self.hp, len(shot_ids)
+        hp.h2d(self.d_idx, shot_ids.astype(np.uint32))
+        hp.gather_rows_device(self.d_store.ptr, self.wf, self.d_idx.ptr, n, size, self.d_fb.ptr)
+        hp.sample_batch_device(self.d_fb.ptr, size, self.num_f, key, self.d_ob.ptr, d_norm_dev=self.d_dev.ptr)
+        hp.scatter_rows_device(self.d_ob.ptr, self.wo, self.d_idx.ptr, n, self.d_rows.ptr)
+        dev = np.zeros(self.n_comp, dtype=np.float32)
+        hp.d2h(dev, self.d_dev)
+        self.devs.append(dev)
+
+    def collect(self):
+        rows, gone = self.owner._download_bools(self.hp, self.d_rows, self.shots), np.empty(self.shots, dtype=np.uint8)
+        self.hp.d2h(gone, self.d_flags)
+        for buf in (self.d_store, self.d_rows, self.d_flags, self.d_list, self.d_count, self.d_fb, self.d_ob, self.d_idx,
+                    self.d_dev, self.d_mask, self.d_ref):
+            buf.free()
+        for dev in self.devs:
+            self.owner._check_devs(dev)
+        gone = gone.astype(np.bool_)
+        rows[gone, self.nd:] = False  # a discarded shot keeps its direct DETECTOR columns only
+        return rows, gone
+
+
+# ---------------------------------------------------------------------------------------------------------
+# the samplers
+# ---------------------------------------------------------------------------------------------------------
+
+
+class _CompiledSamplerBase:
+    def __init__(self, program, *, channel_probs: list, error_transform: np.ndarray, seed: int | None = None,
+                 device: int = 0, noise: str = "host", mode: str = "auto"):
+        """``noise="host"``: the reference's numpy channel stream, bit for bit; ``noise="device"``: channels
+        sampled on the GPU.  ``mode``: kernel formulation, see :class:`tsim_amd.backend.HipProgram`."""
+        if noise not in ("host", "device"):
+            raise ValueError("noise must be 'host' or 'device'")
+        if seed is None:
+            seed = int(np.random.default_rng().integers(0, 2**30))
+        self._noise, self._mode, self._device = noise, mode, int(device)
+        self._key = prng.key(seed)
+        self._program: CompiledProgram = from_tsim(program)
+        channel_seed = int(np.random.default_rng(seed).integers(0, 2**30))
+        self._channel_sampler = ChannelSampler(channel_probs=channel_probs, error_transform=error_transform, seed=channel_seed)
+        self._noise_key = prng.key(channel_seed)  # key chain of the device-side channel sampler
+        self._num_detectors = int(self._program.num_detectors)
+        self._direct = _DirectOutputs(self._program)
+        self._direct_detector_mask = self._direct.detector_mask
+        self._device_noise = None
+        self._f_slots = None
+
+    @classmethod
+    def from_npz(cls, path, *, seed: int | None = None, device: int = 0, **kw):
+        """A program + noise model written by ``program.save_npz(path, prog, n_channels=, channel_probs_<i>=,
+        error_transform=)`` where tsim is installed."""
+        prog, extra = load_npz(path)
+        probs = [np.asarray(extra[f"channel_probs_{i}"], dtype=np.float64) for i in range(int(extra["n_channels"]))]
+        return cls(prog, channel_probs=probs, error_transform=extra["error_transform"], seed=seed, device=device, **kw)
+
+    # -- routes ---------------------------------------------------------------------------------------------
+    def _seam_replaced(self) -> bool:
+        return globals()["sample_program"] is not _backend_sample_program
+
+    def _seam(self, f_params: np.ndarray, key) -> np.ndarray:
+        """Call whatever is bound to this module's ``sample_program`` right now."""
+        fn = globals()["sample_program"]
+        if fn is _backend_sample_program:
+            return fn(self._program, f_params, key, device=self._device, mode=self._mode)
+        return fn(self._program, f_params, key)
+
+    def _hip(self) -> HipProgram:
+        return get_hip_program(self._program, self._device, self._mode)
+
+    def _next_key(self):
+        self._key, sub = prng.split(self._key)
+        return sub
+
+    def _check_devs(self, devs) -> None:
+        for dev in np.asarray(devs, dtype=np.float32).reshape(-1)[: len(self._program.components)]:
+            check_norm_deviation(float(dev))
+
+    # -- sizing ----------------------------------------------------------------------------------------------
+    def _bytes_per_shot(self) -> int:
+        """HBM per shot on the device route: packed f row + packed result row + its unpacked bytes.  (The
+        reference's estimate counts its materialised [B, G, T, 4] tensors, sampler.py:294-306; here those
+        live in registers.)"""
+        num_f, n_out = self._channel_sampler.num_f, int(self._program.num_outputs)
+        return max(1, 8 * ((num_f + 63) // 64) + 8 * ((n_out + 63) // 64) + n_out)
 
     def _estimate_batch_size(self) -> int:
-        """Largest batch worth launching: a quarter of HBM, capped at 2**24 shots."""
-        available = 64 * 1024**3  # conservative share of the 288 GB of one MI355X
-        return max(1, min(1 << 24, int(available * 0.25) // self._peak_bytes_per_sample()))
+        """Largest batch worth launching: half of the device's free memory (queried through the C ABI, as
+        sampler.py:308-320 asks jax), at most 2**24 shots."""
+        if self._seam_replaced() or not self._program.components:
+            return 1 << 20
+        free, _total = self._hip().mem_info()
+        return max(1, min(_MAX_AUTO_BATCH, (free // 2) // self._bytes_per_shot()))
 
-    def _resolve_batch_size(self, shots: int, batch_size: int | None, *, compute_reference: bool) -> int:
-        if batch_size is None:
-            max_batch_size = self._estimate_batch_size()
-            num_batches = max(1, ceil(shots / max_batch_size))
-            batch_size = ceil(shots / num_batches)
-        if compute_reference and batch_size * ceil(shots / batch_size) == shots:
-            batch_size += 1
-        return batch_size
-
-    # -- plain batching ----------------------------------------------------------------
-    def _sample_batches(self, shots: int, batch_size: int | None = None, *, compute_reference: bool = False):
-        if shots < 0:
-            raise ValueError(f"shots must be non-negative, got {shots}")
-        if batch_size is not None and batch_size < 1:
-            raise ValueError(f"batch_size must be at least 1, got {batch_size}")
-        num_outputs = self._program.num_outputs
-        if shots == 0:
-            empty = np.empty((0, num_outputs), dtype=np.bool_)
-            return (empty, np.zeros(num_outputs, dtype=np.bool_)) if compute_reference else empty
+    # -- the noiseless sample ------------------------------------------------------------------------------------
+    def _compute_reference_sample(self) -> np.ndarray:
+        """All f = 0.  A key split is consumed iff there is a compiled component (sampler.py:263-276)."""
+        f0 = np.zeros((1, self._channel_sampler.num_f), dtype=np.uint8)
         if not self._program.components:
-            samples = self._sample_direct(shots)
-            return (samples, self._compute_reference_sample()) if compute_reference else samples
-        if self._noise == "device":
-            return self._sample_batches_device(shots, batch_size, compute_reference=compute_reference)
+            return self._direct.fill(f0)[0]
+        return np.asarray(self._seam(f0, self._next_key())[0], dtype=np.bool_)
 
-        if batch_size is None:
-            max_batch_size = self._estimate_batch_size()
-            num_batches = max(1, ceil(shots / max_batch_size))
-            batch_size = ceil(shots / num_batches)
-        else:
-            num_batches = ceil(shots / batch_size)
-        if compute_reference and batch_size * num_batches == shots:
-            batch_size += 1  # room for the reference row, uniform batch shapes kept
-
-        batches = []
-        reference = None
-        # With the library's own sample_program in place (not a test replacement) the error rows go to the
-        # GPU packed: same generator stream, same bits, 8x fewer bytes to scatter and to copy.
-        packed_route = globals()["sample_program"] is _backend_sample_program
-        for _ in range(num_batches):
-            want_ref = compute_reference and reference is None
-            if packed_route:
-                f_packed = self._channel_sampler.sample_packed(batch_size)
-                if want_ref:
-                    f_packed[0] = 0
-                self._key, subkey = prng.split(self._key)
-                hp = get_hip_program(self._program, self._device, self._mode)
-                num_f = int(self._channel_sampler.signature_matrix.shape[1])
-                samples, devs = hp.sample_batch_packed(f_packed, num_f, subkey)
-                for dev in devs:
-                    check_norm_deviation(float(dev))
-            else:
-                f_params_np = self._channel_sampler.sample(batch_size)
-                if want_ref:
-                    f_params_np[0] = 0
-                self._key, subkey = prng.split(self._key)
-                samples = _call_sample_program(self, f_params_np, subkey)
-            if want_ref:
-                reference = np.asarray(samples[0])
-                samples = samples[1:]
-            batches.append(samples)
-        result = (batches[0] if len(batches) == 1 else np.concatenate(batches, axis=0))[:shots]
-        if compute_reference:
-            assert reference is not None
-            return result, reference
-        return result
-
-    # -- device-resident pipeline (noise="device") ---------------------------------------------
-    def _sample_batches_device(self, shots: int, batch_size: int | None, *, compute_reference: bool = False,
-                               packed_columns: int | None = None):
-        """noise -> f -> sample_program -> unpack, all on the GPU; one pinned D2H at the end.
-
-        Per batch: one split of the noise key chain for the device channel sampler and one split
-        of the sampler key for ``sample_program`` (as reference sampler.py:399).  The reference
-        sample, when requested, is its own 1-row call with f = 0 (sampler.py:263-276).
-        """
-        hp = get_hip_program(self._program, self._device, self._mode)
-        st = self._device_state
-        if st is None or st["hp"] is not hp:
-            st = self._device_state = dict(hp=hp, noise=DeviceNoiseSampler(hp, self._channel_sampler), bufs=None)
-        if batch_size is None:
-            max_batch_size = self._estimate_batch_size()
-            num_batches = max(1, ceil(shots / max_batch_size))
-            batch_size = ceil(shots / num_batches)
-        else:
-            num_batches = ceil(shots / batch_size)
-        reference = self._compute_reference_sample() if compute_reference else None
-        num_f = int(self._channel_sampler.signature_matrix.shape[1])
-        n_out = int(self._program.num_outputs)
-        wf, wo = max(1, (num_f + 63) // 64), (n_out + 63) // 64
-        total = num_batches * batch_size
-        n_comp = max(1, len(self._program.components))
-        need = (batch_size, total)
-        if st["bufs"] is None or st["bufs"]["need"] != need:
-            st["bufs"] = dict(
-                need=need,
-                f=[hp.malloc(batch_size * wf * 8) for _ in range(self._PIPELINE)],
-                out=hp.malloc(total * wo * 8),
-                u8=hp.malloc(total * n_out),
-                devs=hp.malloc(num_batches * n_comp * 4),
-            )
-        b = st["bufs"]
-        # pipelined launches (include/tsim_hip.h: tsim_sample_batch_device_begin/_end): batch i's
-        # hard-row pass overlaps the noise sampling and first pass of batch i+1 (each slot is a lane);
-        # each slot owns an f buffer, every batch its own slice of the output buffer
-        for i in range(num_batches):
-            slot = i % self._PIPELINE
-            hp.sample_batch_device_end(slot)  # the slot's previous batch no longer reads its f buffer
-            self._noise_key, nk = hp.split_key(self._noise_key)  # prng.split, computed by the library
-            st["noise"].sample_into(b["f"][slot].ptr, batch_size, nk)
-            self._key, subkey = hp.split_key(self._key)
-            hp.sample_batch_device_begin(
-                slot, b["f"][slot].ptr, batch_size, num_f, subkey, b["out"].ptr + i * batch_size * wo * 8,
-                d_norm_dev=b["devs"].ptr + i * n_comp * 4,
-            )
-        for slot in range(self._PIPELINE):
-            hp.sample_batch_device_end(slot)
-        if packed_columns is not None:
-            # bit_packed=True of the first `packed_columns` columns: ceil(n/8) bytes per shot over PCIe
-            rb = (packed_columns + 7) // 8
-            hp.compact_rows_device(b["out"].ptr, total, packed_columns, b["u8"].ptr, in_words=wo)
-            result = np.empty((total, rb), np.uint8)
-            hp.d2h(result, b["u8"].ptr)
-            devs = np.zeros(num_batches * n_comp, np.float32)
-            hp.d2h(devs, b["devs"])
-            for dev in devs[: num_batches * len(self._program.components)]:
-                check_norm_deviation(float(dev))
-            return result[:shots]
-        hp.unpack_bits_device(b["out"].ptr, total, n_out, b["u8"].ptr)
-        # straight into a pageable array: a fresh pinned allocation of this size costs more (19 ms
-        # per 80 MB, hipHostMalloc) than the whole pipeline; the copy itself runs at ~35 GB/s
-        result = np.empty((total, n_out), np.uint8)
-        hp.d2h(result, b["u8"])
-        devs = np.zeros(num_batches * n_comp, np.float32)
-        hp.d2h(devs, b["devs"])
-        for dev in devs[: num_batches * len(self._program.components)]:
-            check_norm_deviation(float(dev))
-        result = result.view(np.bool_)[:shots]
-        return (result, reference) if compute_reference else result
-
-    def _postselect_device(self, shots, batch_size, *, postselect_direct, compute_reference, xor_detector_ref):
-        """Post-selection with everything on the GPU: ``k_noise`` -> ``k_direct_filter`` (direct bits
-        for all rows + survivor list) -> the sampling kernel on the survivors only.  Same return
-        contract as the host path: ``(result, reference, was_discarded)``."""
-        hp = get_hip_program(self._program, self._device, self._mode)
-        st = self._device_state
-        if st is None or st["hp"] is not hp:
-            st = self._device_state = dict(hp=hp, noise=DeviceNoiseSampler(hp, self._channel_sampler), bufs=None)
-        if batch_size is None:
-            batch_size = self._resolve_batch_size(shots, batch_size, compute_reference=False)
-        num_batches = ceil(shots / batch_size)
-        reference = self._compute_reference_sample() if compute_reference else None
-        nd = self._num_detectors
-        num_f = int(self._channel_sampler.signature_matrix.shape[1])
-        n_out = int(self._program.num_outputs)
-        wf, wo = max(1, (num_f + 63) // 64), (n_out + 63) // 64
-        total = num_batches * batch_size
-        n_comp = max(1, len(self._program.components))
-
-        def pack_cols(bits_nd):
-            full = np.zeros(wo * 64, np.uint8)
-            full[:nd] = np.asarray(bits_nd, np.uint8)
-            return np.packbits(full, bitorder="little").view(np.uint64)
-
-        mask_w = pack_cols(postselect_direct)
-        use_ref = xor_detector_ref and reference is not None
-        ref_w = pack_cols(reference[:nd]) if use_ref else None
-        d_f, d_out = hp.malloc(batch_size * wf * 8), hp.malloc(total * wo * 8)
-        d_u8, d_disc = hp.malloc(total * n_out), hp.malloc(total)
-        d_idx, d_cnt = hp.malloc(batch_size * 4), hp.malloc(4)
-        d_devs, d_mask = hp.malloc(num_batches * n_comp * 4), hp.malloc(wo * 8)
-        d_ref = hp.malloc(wo * 8)
-        hp.h2d(d_mask, mask_w)
-        if use_ref:
-            hp.h2d(d_ref, ref_w)
-        hp.h2d(d_devs, np.zeros(num_batches * n_comp, np.float32))
-        for i in range(num_batches):
-            self._noise_key, nk = hp.split_key(self._noise_key)
-            st["noise"].sample_into(d_f.ptr, batch_size, nk)
-            out_i = d_out.ptr + i * batch_size * wo * 8
-            hp.postselect_device(d_f.ptr, batch_size, num_f, d_mask.ptr, d_ref.ptr if use_ref else 0, out_i,
-                                 d_idx.ptr, d_cnt.ptr, d_disc.ptr + i * batch_size)
-            self._key, subkey = hp.split_key(self._key)
-            hp.sample_rows_device(d_f.ptr, batch_size, num_f, subkey, out_i, d_idx.ptr, d_cnt.ptr,
-                                  d_norm_dev=d_devs.ptr + i * n_comp * 4)
-        hp.unpack_bits_device(d_out.ptr, total, n_out, d_u8.ptr)
-        result = np.empty((total, n_out), np.uint8)  # pageable on purpose, see _sample_batches_device
-        hp.d2h(result, d_u8)
-        disc = np.zeros(total, np.uint8)
-        hp.d2h(disc, d_disc)
-        devs = np.zeros(num_batches * n_comp, np.float32)
-        hp.d2h(devs, d_devs)
-        for dev in devs[: num_batches * len(self._program.components)]:
-            check_norm_deviation(float(dev))
-        for buf in (d_f, d_out, d_u8, d_disc, d_idx, d_cnt, d_devs, d_mask, d_ref):
-            buf.free()
-        result = result.view(np.bool_)[:shots]
-        was_discarded = disc[:shots].astype(np.bool_)
-        # discarded rows keep their direct DETECTOR columns only (reference sampler.py:519-521)
-        result[was_discarded, nd:] = False
-        if use_ref:
-            det_ref = reference[:nd]
-            result[~was_discarded, :nd] ^= det_ref
-            result[was_discarded, :nd] ^= det_ref & self._direct_detector_mask
-        return result, reference, was_discarded
-
-    # -- post-selection ------------------------------------------------------------------
-    def _sample_batches_with_postselection(
-        self,
-        shots: int,
-        batch_size: int | None,
-        *,
-        postselection_mask: np.ndarray,
-        compute_reference: bool = False,
-        xor_detector_ref: bool = False,
-    ):
-        """Shots discarded by a masked *direct* detector never reach the device (sampler.py:422-545)."""
-        if shots < 0:
-            raise ValueError(f"shots must be non-negative, got {shots}")
-        if batch_size is not None and batch_size < 1:
-            raise ValueError(f"batch_size must be at least 1, got {batch_size}")
-        num_outputs = self._program.num_outputs
-        nd = self._num_detectors
-        if shots == 0:
-            empty = np.empty((0, num_outputs), dtype=np.bool_)
-            none_discarded = np.empty(0, dtype=np.bool_)
-            ref0 = np.zeros(num_outputs, dtype=np.bool_) if compute_reference else None
-            return empty, ref0, none_discarded
-
-        postselect_direct = postselection_mask & self._direct_detector_mask
-        if self._noise == "device" and self._program.components:
-            return self._postselect_device(
-                shots, batch_size, postselect_direct=postselect_direct,
-                compute_reference=compute_reference, xor_detector_ref=xor_detector_ref,
-            )
-        if not self._program.components:
-            samples = self._sample_direct(shots)
-            reference = None
-            if compute_reference:
-                reference = self._compute_reference_sample()
-                if xor_detector_ref:
-                    samples[:, :nd] ^= reference[:nd]
-            return samples, reference, np.zeros(shots, dtype=np.bool_)
-
-        if batch_size is None:
-            batch_size = self._resolve_batch_size(shots, batch_size, compute_reference=False)
-        reference = self._compute_reference_sample() if compute_reference else None
-
-        result = np.zeros((shots, num_outputs), dtype=np.bool_)
-        was_discarded = np.zeros(shots, dtype=np.bool_)
-        pending_f: list = []  # survivor f rows not yet dispatched
-        pending_idx: list = []
-
-        def dispatch(f_batch: np.ndarray, indices: list, n_valid: int) -> None:
-            self._key, subkey = prng.split(self._key)
-            out = np.asarray(_call_sample_program(self, f_batch, subkey))
-            result[indices[:n_valid]] = out[:n_valid]
-
-        def flush(final: bool = False) -> None:
-            nonlocal pending_f, pending_idx
-            while len(pending_f) >= batch_size:
-                dispatch(np.stack(pending_f[:batch_size]), pending_idx[:batch_size], batch_size)
-                pending_f, pending_idx = pending_f[batch_size:], pending_idx[batch_size:]
-            if final and pending_f:
-                n_valid = len(pending_f)
-                stack = np.stack(pending_f)
-                f_batch = np.empty((batch_size, stack.shape[1]), dtype=stack.dtype)
-                f_batch[:n_valid] = stack
-                f_batch[n_valid:] = stack[0]  # padding keeps the batch shape fixed
-                dispatch(f_batch, pending_idx, n_valid)
-                pending_f, pending_idx = [], []
-
-        done = 0
-        while done < shots:
-            chunk = min(batch_size, shots - done)
-            f_params_np = self._channel_sampler.sample(chunk)
-            direct_full = self._compute_direct_outputs(f_params_np)
-            det_cols = direct_full[:, :nd]
-            if xor_detector_ref and reference is not None:
-                det_cols = det_cols ^ reference[:nd]
-            discarded = (det_cols & postselect_direct).any(axis=1)
-            result[done : done + chunk, :nd] = direct_full[:, :nd]
-            was_discarded[done : done + chunk] = discarded
-            keep = np.flatnonzero(~discarded)
-            if keep.size:
-                pending_f.extend(f_params_np[keep])
-                pending_idx.extend((done + keep).tolist())
-            done += chunk
-            flush()
-        flush(final=True)
-
-        if xor_detector_ref and reference is not None:
-            det_ref = reference[:nd]
-            result[~was_discarded, :nd] ^= det_ref
-            result[was_discarded, :nd] ^= det_ref & self._direct_detector_mask
-        return result, reference, was_discarded
+    def _compute_direct_outputs(self, f_params_np: np.ndarray) -> np.ndarray:
+        return self._direct.fill(np.asarray(f_params_np))
 
     def _sample_direct(self, shots: int) -> np.ndarray:
-        """All outputs direct: pure numpy, the device is never touched (sampler.py:547-555)."""
-        f_params = self._channel_sampler.sample(shots)
-        if self._direct_zero_copy:
-            return f_params[:, : len(self._direct_f_indices)].view(np.bool_)
-        result = f_params[:, self._direct_f_indices] ^ self._direct_flips
-        if self._direct_reindex is not None:
-            result = result[:, self._direct_reindex]
-        return result.view(np.bool_)
+        """Programs without compiled components: pure host work, the device is never touched
+        (sampler.py:547-555)."""
+        # fill() places every direct bit at its final column (output_order), i.e. the result is already reindexed
+        return self._direct.fill(self._channel_sampler.sample(shots))
+
+    # -- plain batching ----------------------------------------------------------------------------------------
+    def _sample_batches(self, shots: int, batch_size: int | None = None, *, compute_reference: bool = False):
+        _check_request(shots, batch_size)
+        n_out = int(self._program.num_outputs)
+        if shots == 0:
+            rows, ref = np.empty((0, n_out), dtype=np.bool_), np.zeros(n_out, dtype=np.bool_)
+        elif not self._program.components:
+            rows = self._sample_direct(shots)
+            ref = self._compute_reference_sample() if compute_reference else None
+        elif self._seam_replaced():
+            plan = plan_batches(shots, batch_size, self._estimate_batch_size(), reserve_row=compute_reference)
+            rows, ref = self._seam_plain(shots, plan, compute_reference)
+        else:
+            rows, ref = self._device_plain(shots, batch_size, compute_reference)
+        return (rows, ref) if compute_reference else rows
+
+    def _seam_plain(self, shots: int, plan: BatchPlan, want_ref: bool):
+        parts, ref = [], None
+        for b in range(plan.count):
+            f = self._channel_sampler.sample(plan.size)
+            rides = want_ref and b == 0
+            if rides:
+                f[0] = 0
+            out = np.asarray(self._seam(f, self._next_key()))
+            if rides:
+                ref, out = np.array(out[0], dtype=np.bool_), out[1:]
+            parts.append(out)
+        rows = parts[0] if len(parts) == 1 else np.concatenate(parts, axis=0)
+        return np.asarray(rows[:shots], dtype=np.bool_), ref
+
+    def _device_noise_sampler(self, hp: HipProgram) -> DeviceNoiseSampler:
+        if self._device_noise is None or self._device_noise._prog is not hp:
+            self._device_noise = DeviceNoiseSampler(hp, self._channel_sampler)
+        return self._device_noise
+
+    def _lane_buffers(self, hp: HipProgram, nbytes: int) -> list:
+        have = self._f_slots
+        if have is None or have[0] is not hp or have[1] < nbytes:
+            if have is not None and have[0] is hp:
+                hp.synchronize()
+                for buf in have[2]:
+                    buf.free()
+            self._f_slots = have = (hp, nbytes, [hp.malloc(nbytes) for _ in range(_LANES)])
+        return have[2]
+
+    def _download_bools(self, hp: HipProgram, d_rows, n: int) -> np.ndarray:
+        """Packed device rows -> ``bool[n, num_outputs]`` on the host (unpack kernel + one D2H into a pageable
+        array: a fresh pinned allocation of this size costs more than the copy)."""
+        n_out = int(self._program.num_outputs)
+        d_u8 = hp.malloc(max(1, n * n_out))
+        hp.unpack_bits_device(d_rows.ptr if hasattr(d_rows, "ptr") else d_rows, n, n_out, d_u8.ptr)
+        host = np.empty((n, n_out), dtype=np.uint8)
+        hp.d2h(host, d_u8)
+        d_u8.free()
+        return host.view(np.bool_)
+
+    def _device_plain(self, shots: int, batch_size: int | None, want_ref: bool, packed_columns: int | None = None):
+        """noise -> f -> ``sample_program`` -> layout conversion without leaving the GPU.
+
+        Every batch is a pipelined launch (``tsim_sample_batch_device_begin``) into its slice of one result
+        buffer; ``_LANES`` f buffers rotate, so the host generates (or ``k_noise`` fills) batch i+1 while batch
+        i runs.  Host noise: the reference row, when wanted, is row 0 of the first batch.  Device noise: the
+        reference sample is its own 1-row call (there is no stream to stay aligned with)."""
+        hp = self._hip()
+        host_noise = self._noise == "host"
+        rides = want_ref and host_noise
+        plan = plan_batches(shots, batch_size, self._estimate_batch_size(), reserve_row=rides)
+        ref = self._compute_reference_sample() if (want_ref and not host_noise) else None
+        cs = self._channel_sampler
+        num_f, n_out = cs.num_f, int(self._program.num_outputs)
+        wf, wo = max(1, (num_f + 63) // 64), (n_out + 63) // 64
+        n_comp = max(1, len(self._program.components))
+        total = plan.size * plan.count
+        lanes = self._lane_buffers(hp, plan.size * wf * 8)
+        d_rows, d_devs = hp.malloc(total * wo * 8), hp.malloc(plan.count * n_comp * 4)
+        noise = None if host_noise else self._device_noise_sampler(hp)
+        for b in range(plan.count):
+            lane = b % _LANES
+            hp.sample_batch_device_end(lane)  # the lane's previous launch no longer reads its f buffer
+            if host_noise:
+                rows = cs.sample_packed(plan.size)
+                if rides and b == 0:
+                    rows[0] = 0
+                hp.h2d(lanes[lane], rows)
+            else:
+                self._noise_key, nk = hp.split_key(self._noise_key)
+                noise.sample_into(lanes[lane].ptr, plan.size, nk)
+            hp.sample_batch_device_begin(lane, lanes[lane].ptr, plan.size, num_f, self._next_key(),
+                                         d_rows.ptr + b * plan.size * wo * 8, d_norm_dev=d_devs.ptr + b * n_comp * 4)
+        for lane in range(min(_LANES, plan.count)):
+            hp.sample_batch_device_end(lane)
+        devs = np.zeros(plan.count * n_comp, dtype=np.float32)
+        skip = 1 if rides else 0
+        if packed_columns is not None:  # bit_packed=True of the first columns: compacted on the GPU
+            rb = (packed_columns + 7) // 8
+            d_c = hp.malloc(total * rb + 16)
+            hp.compact_rows_device(d_rows.ptr, total, packed_columns, d_c.ptr, in_words=wo)
+            out = np.empty((total, rb), dtype=np.uint8)
+            hp.d2h(out, d_c)
+            d_c.free()
+        else:
+            out = self._download_bools(hp, d_rows, total)
+            if rides:
+                ref = out[0].copy()
+        hp.d2h(devs, d_devs)
+        d_rows.free()
+        d_devs.free()
+        for b in range(plan.count):
+            self._check_devs(devs[b * n_comp:(b + 1) * n_comp])
+        return out[skip:skip + shots], ref
+
+    # -- post-selection -----------------------------------------------------------------------------------------
+    def _sample_batches_with_postselection(self, shots: int, batch_size: int | None, *, postselection_mask: np.ndarray,
+                                           compute_reference: bool = False, xor_detector_ref: bool = False):
+        """``(rows, reference or None, was_discarded)``: shots in which a masked, directly readable detector
+        fires never reach ``sample_program``; they keep their direct detector columns and False elsewhere
+        (sampler.py:422-545)."""
+        _check_request(shots, batch_size)
+        n_out, nd = int(self._program.num_outputs), self._num_detectors
+        if shots == 0:
+            return (np.empty((0, n_out), dtype=np.bool_), np.zeros(n_out, dtype=np.bool_) if compute_reference else None,
+                    np.empty(0, dtype=np.bool_))
+        if not self._program.components:
+            rows = self._sample_direct(shots)
+            ref = self._compute_reference_sample() if compute_reference else None
+            if ref is not None and xor_detector_ref:
+                rows[:, :nd] ^= ref[:nd]
+            return rows, ref, np.zeros(shots, dtype=np.bool_)
+        test_mask = np.asarray(postselection_mask, dtype=np.bool_) & self._direct_detector_mask
+        if self._noise == "device" and not self._seam_replaced():
+            return self._device_noise_postselect(shots, batch_size, test_mask, compute_reference, xor_detector_ref)
+        size = plan_batches(shots, batch_size, self._estimate_batch_size()).size
+        ref = self._compute_reference_sample() if compute_reference else None
+        ref_det = ref[:nd] if (ref is not None and xor_detector_ref) else None
+        work = (_SeamPostselect(self, shots, test_mask, ref_det) if self._seam_replaced()
+                else _DevicePostselect(self, shots, size, test_mask, ref_det))
+        _run_postselected(shots, size, work, self._next_key)
+        rows, gone = work.collect()
+        self._apply_detector_reference(rows, gone, ref_det)
+        return rows, ref, gone
+
+    def _apply_detector_reference(self, rows: np.ndarray, gone: np.ndarray, ref_det: np.ndarray | None) -> None:
+        """XOR the reference's detector bits in: all of them for shots that ran, only the directly readable
+        ones for discarded shots (their other columns are blank, sampler.py:532-540)."""
+        if ref_det is None:
+            return
+        nd = self._num_detectors
+        rows[~gone, :nd] ^= ref_det
+        rows[gone, :nd] ^= ref_det & self._direct_detector_mask
+
+    def _device_noise_postselect(self, shots, batch_size, test_mask, compute_reference, xor_detector_ref):
+        """``noise="device"``: ``k_noise`` -> filter kernel (direct bits of every row + survivor list) -> the
+        sampling kernels on the listed rows only; nothing but the final result crosses PCIe.  (Survivors keep
+        their own in-batch Threefry counter: there is no host stream to reproduce.)"""
+        hp = self._hip()
+        noise = self._device_noise_sampler(hp)
+        plan = plan_batches(shots, batch_size, self._estimate_batch_size())
+        ref = self._compute_reference_sample() if compute_reference else None
+        ref_det = ref[: self._num_detectors] if (ref is not None and xor_detector_ref) else None
+        helper = _DevicePostselect(self, plan.size * plan.count, plan.size, test_mask, ref_det)
+        num_f, wf, wo, n_comp = helper.num_f, helper.wf, helper.wo, helper.n_comp
+        d_devs = hp.malloc(plan.count * n_comp * 4)
+        hp.h2d(d_devs, np.zeros(plan.count * n_comp, dtype=np.float32))
+        for b in range(plan.count):
+            lo = b * plan.size
+            d_f, d_o = helper.d_store.ptr + lo * wf * 8, helper.d_rows.ptr + lo * wo * 8
+            self._noise_key, nk = hp.split_key(self._noise_key)
+            noise.sample_into(d_f, plan.size, nk)
+            hp.postselect_device(d_f, plan.size, num_f, helper.d_mask.ptr, helper.d_ref.ptr if helper.has_ref else 0, d_o,
+                                 helper.d_list.ptr, helper.d_count.ptr, helper.d_flags.ptr + lo)
+            hp.sample_rows_device(d_f, plan.size, num_f, self._next_key(), d_o, helper.d_list.ptr, helper.d_count.ptr,
+                                  d_norm_dev=d_devs.ptr + b * n_comp * 4)
+        devs = np.zeros(plan.count * n_comp, dtype=np.float32)
+        hp.d2h(devs, d_devs)
+        d_devs.free()
+        helper.devs = [devs[b * n_comp:(b + 1) * n_comp] for b in range(plan.count)]
+        rows, gone = helper.collect()
+        rows, gone = rows[:shots], gone[:shots]
+        self._apply_detector_reference(rows, gone, ref_det)
+        return rows, ref, gone
 
     def __repr__(self) -> str:
         """Compilation statistics in the reference's format (sampler.py:557-609)."""
-        graphs, params, na, nb, nc, nd_, outs = [], [], [], [], [], [], []
-        nbytes = 0
-        for comp in self._program.components:
-            for lv in comp.compiled_scalar_graphs:
-                outs.append(len(comp.output_indices))
-                graphs.append(lv.num_graphs)
-                params.append(lv.n_params)
-                na.append(np.asarray(lv.node_phases.phases).size)
-                nb.append(np.asarray(lv.halfpi_phases.coeffs).size)
-                nc.append(np.asarray(lv.pi_products.psi_const).size)
-                nd_.append(np.asarray(lv.phase_pairs.alpha).size + np.asarray(lv.phase_pairs.beta).size)
-                for fam in (lv.node_phases, lv.halfpi_phases, lv.pi_products, lv.phase_pairs, lv.prefactor):
-                    nbytes += sum(np.asarray(v).nbytes for v in vars(fam).values() if isinstance(v, np.ndarray))
+        levels = [(len(c.output_indices), lv) for c in self._program.components for lv in c.compiled_scalar_graphs]
 
-        def fmt(n: int) -> str:
-            if n < 1024:
-                return f"{n} B"
-            return f"{n / 1024:.1f} kB" if n < 1024**2 else f"{n / 1024**2:.1f} MB"
+        def size_of(*arrays) -> int:
+            return int(sum(np.asarray(a).size for a in arrays))
 
-        bits = sum(c.num_bits for c in self._channel_sampler.channels)
+        terms = {
+            "A": sum(size_of(lv.node_phases.phases) for _, lv in levels),
+            "B": sum(size_of(lv.halfpi_phases.coeffs) for _, lv in levels),
+            "C": sum(size_of(lv.pi_products.psi_const) for _, lv in levels),
+            "D": sum(size_of(lv.phase_pairs.alpha, lv.phase_pairs.beta) for _, lv in levels),
+        }
+        nbytes = sum(np.asarray(v).nbytes for _, lv in levels
+                     for fam in (lv.node_phases, lv.halfpi_phases, lv.pi_products, lv.phase_pairs, lv.prefactor)
+                     for v in vars(fam).values() if isinstance(v, np.ndarray))
+        unit, scale = ("B", 1) if nbytes < 1024 else ("kB", 1024) if nbytes < 1024**2 else ("MB", 1024**2)
+        mem = f"{nbytes} B" if scale == 1 else f"{nbytes / scale:.1f} {unit}"
         return (
             f"{type(self).__name__}({len(self._program.direct_f_indices)} direct, "
-            f"{int(np.sum(graphs))} graphs, {bits} error channel bits, "
-            f"{max(outs) if outs else 0} outputs for largest cc, "
-            f"≤ {max(params) if params else 0} parameters, {int(np.sum(na))} A terms, "
-            f"{int(np.sum(nb))} B terms, {int(np.sum(nc))} C terms, {int(np.sum(nd_))} D terms, "
-            f"{fmt(nbytes)})"
+            f"{sum(lv.num_graphs for _, lv in levels)} graphs, "
+            f"{sum(ch.num_bits for ch in self._channel_sampler.channels)} error channel bits, "
+            f"{max((n for n, _ in levels), default=0)} outputs for largest cc, "
+            f"≤ {max((lv.n_params for _, lv in levels), default=0)} parameters, "
+            f"{terms['A']} A terms, {terms['B']} B terms, {terms['C']} C terms, {terms['D']} D terms, {mem})"
         )
-
-
-def _call_sample_program(sampler: _CompiledSamplerBase, f_params: np.ndarray, subkey) -> np.ndarray:
-    """Late-bound call of this module's ``sample_program`` (so tests can replace it)."""
-    fn = globals()["sample_program"]
-    if fn is _backend_sample_program:
-        return fn(sampler._program, f_params, subkey, device=sampler._device, mode=sampler._mode)
-    return fn(sampler._program, f_params, subkey)  # a replacement with the reference's 3-arg signature
 
 
 class CompiledMeasurementSampler(_CompiledSamplerBase):
@@ -503,110 +533,87 @@ class CompiledMeasurementSampler(_CompiledSamplerBase):
         return self._sample_batches(shots, batch_size)
 
 
-def _maybe_bit_pack(array: np.ndarray, *, bit_packed: bool) -> np.ndarray:
-    if not bit_packed:
-        return array
-    return np.packbits(array.astype(np.bool_), axis=1, bitorder="little")
+def _pack_columns(bits: np.ndarray, bit_packed: bool) -> np.ndarray:
+    """``bit_packed=True``: little-endian bytes per row, ``np.packbits(..., bitorder="little")`` (sampler.py:665-669)."""
+    return np.packbits(bits.astype(np.bool_), axis=1, bitorder="little") if bit_packed else bits
 
 
 class CompiledDetectorSampler(_CompiledSamplerBase):
     """Samples detector and observable outcomes."""
 
-    def sample(
-        self,
-        shots: int,
-        *,
-        batch_size: int | None = None,
-        prepend_observables: bool = False,
-        append_observables: bool = False,
-        separate_observables: bool = False,
-        bit_packed: bool = False,
-        use_detector_reference_sample: bool = False,
-        use_observable_reference_sample: bool = False,
-        postselection_mask: np.ndarray | None = None,
-    ):
-        """Detector samples, with the reference's column-arrangement flags (sampler.py:732-868)."""
+    def sample(self, shots: int, *, batch_size: int | None = None, prepend_observables: bool = False,
+               append_observables: bool = False, separate_observables: bool = False, bit_packed: bool = False,
+               use_detector_reference_sample: bool = False, use_observable_reference_sample: bool = False,
+               postselection_mask: np.ndarray | None = None):
+        """Detector samples with the reference's column-arrangement, reference-sample and post-selection flags
+        (sampler.py:732-868)."""
         if separate_observables and (prepend_observables or append_observables):
-            raise ValueError(
-                "Can't specify separate_observables=True with append_observables=True or prepend_observables=True"
-            )
-        nd = self._num_detectors
-        compute_reference = use_detector_reference_sample or use_observable_reference_sample
-
+            raise ValueError("Can't specify separate_observables=True with append_observables=True or prepend_observables=True")
+        nd, n_out = self._num_detectors, int(self._program.num_outputs)
+        want_ref = use_detector_reference_sample or use_observable_reference_sample
+        mask = None
         if postselection_mask is not None:
             mask = np.asarray(postselection_mask, dtype=np.bool_)
             if mask.shape != (nd,):
                 raise ValueError(f"postselection_mask must have shape ({nd},), got {mask.shape}")
-            postselection_mask = mask
-            if not (mask & self._direct_detector_mask).any() or not self._program.components:
-                postselection_mask = None  # nothing can be skipped: plain path
+            if not self._program.components or not (mask & self._direct_detector_mask).any():
+                mask = None  # no shot could be skipped: the plain path does the same work
 
-        if postselection_mask is not None:
-            samples, reference, discarded = self._sample_batches_with_postselection(
-                shots,
-                batch_size,
-                postselection_mask=postselection_mask,
-                compute_reference=compute_reference,
-                xor_detector_ref=use_detector_reference_sample,
-            )
-            if compute_reference and use_observable_reference_sample:
-                samples[~discarded, nd:] ^= reference[nd:]
-        elif compute_reference:
-            samples, reference = self._sample_batches(shots, batch_size, compute_reference=True)
-            if use_detector_reference_sample:
-                samples[:, :nd] ^= reference[:nd]
+        if mask is not None:
+            rows, ref, gone = self._sample_batches_with_postselection(
+                shots, batch_size, postselection_mask=mask, compute_reference=want_ref,
+                xor_detector_ref=use_detector_reference_sample)
             if use_observable_reference_sample:
-                samples[:, nd:] ^= reference[nd:]
+                rows[~gone, nd:] ^= ref[nd:]
+        elif want_ref:
+            rows, ref = self._sample_batches(shots, batch_size, compute_reference=True)
+            flip = np.zeros(n_out, dtype=np.bool_)
+            if use_detector_reference_sample:
+                flip[:nd] = ref[:nd]
+            if use_observable_reference_sample:
+                flip[nd:] = ref[nd:]
+            rows = rows ^ flip
         else:
-            ncols = self._program.num_outputs if append_observables else nd
+            width = n_out if append_observables else nd
             if (bit_packed and self._noise == "device" and not separate_observables and not prepend_observables
-                    and ncols > 0 and shots > 0 and self._program.components
-                    and (batch_size is None or batch_size >= 1)):
-                # the requested columns are the first `ncols` bits of a packed device row: compact on
-                # the GPU and move ceil(ncols/8) bytes per shot instead of one byte per bit
-                return self._sample_batches_device(shots, batch_size, packed_columns=ncols)
-            samples = self._sample_batches(shots, batch_size)
+                    and width > 0 and shots > 0 and self._program.components and not self._seam_replaced()):
+                # the wanted columns are a prefix of the packed device rows: compact there, move width/8 bytes per shot
+                _check_request(shots, batch_size)
+                return self._device_plain(shots, batch_size, False, packed_columns=width)[0]
+            rows = self._sample_batches(shots, batch_size)
 
-        det, obs = samples[:, :nd], samples[:, nd:]
+        det, obs = rows[:, :nd], rows[:, nd:]
         if separate_observables:
-            return _maybe_bit_pack(det, bit_packed=bit_packed), _maybe_bit_pack(obs, bit_packed=bit_packed)
-        if prepend_observables and append_observables:
-            cols = np.concatenate([obs, det, obs], axis=1)
-        elif append_observables:
-            cols = samples
-        elif prepend_observables:
-            cols = np.concatenate([obs, det], axis=1)
-        else:
-            cols = det
-        return _maybe_bit_pack(cols, bit_packed=bit_packed)
+            return _pack_columns(det, bit_packed), _pack_columns(obs, bit_packed)
+        blocks = ([obs] if prepend_observables else []) + [det] + ([obs] if append_observables else [])
+        return _pack_columns(blocks[0] if len(blocks) == 1 else np.concatenate(blocks, axis=1), bit_packed)
 
 
 class CompiledStateProbs(_CompiledSamplerBase):
     """``P(state | error sample)`` from joint-mode programs (levels [0, n] per component)."""
 
     def probability_of(self, state: np.ndarray, *, batch_size: int) -> np.ndarray:
-        """sampler.py:906-953: ``p_joint / p_norm`` per sampled error configuration."""
+        """``p_joint / p_norm`` per sampled error configuration (sampler.py:906-953)."""
         if batch_size < 1:
             raise ValueError(f"batch_size must be at least 1, got {batch_size}")
         state = np.asarray(state)
-        expected = self._program.num_outputs
-        if state.shape != (expected,):
-            raise ValueError(f"state must have shape ({expected},), got {state.shape}")
-        f_samples = self._channel_sampler.sample(batch_size)
-        p_norm = np.ones(batch_size, dtype=np.float32)
-        p_joint = np.ones(batch_size, dtype=np.float32)
-        n_direct = len(self._program.direct_f_indices)
-        if n_direct > 0:
-            direct_bits = f_samples[:, self._direct_f_indices].astype(np.bool_) ^ self._direct_flips
-            targets = state[np.asarray(self._program.output_order[:n_direct])].astype(np.bool_)
-            p_joint = p_joint * (direct_bits == targets).all(axis=1).astype(np.float32)
-        hp = get_hip_program(self._program, self._device, self._mode)
+        n_out = int(self._program.num_outputs)
+        if state.shape != (n_out,):
+            raise ValueError(f"state must have shape ({n_out},), got {state.shape}")
+        f = self._channel_sampler.sample(batch_size)
+        d = self._direct
+        agree = np.ones(batch_size, dtype=np.float32)
+        if len(d.f_index):
+            want = state[d.column].astype(np.bool_)
+            agree = ((f[:, d.f_index].astype(np.bool_) ^ d.flip) == want).all(axis=1).astype(np.float32)
+        p_norm, p_joint = np.ones(batch_size, dtype=np.float32), agree
+        hp = self._hip()
         for ci, comp in enumerate(self._program.components):
-            assert len(comp.compiled_scalar_graphs) == 2
-            f_sel = f_samples[:, np.asarray(comp.f_selection, dtype=np.int64)]
+            if len(comp.compiled_scalar_graphs) != 2:
+                raise ValueError("probability_of needs a joint-mode program (two levels per component)")
+            f_sel = f[:, np.asarray(comp.f_selection, dtype=np.int64)]
+            plugged = np.broadcast_to(state[list(comp.output_indices)].astype(np.uint8), (batch_size, len(comp.output_indices)))
             p_norm = p_norm * hp.evaluate(ci, 0, f_sel, return_abs=True)
-            comp_state = state[list(comp.output_indices)].astype(np.uint8)
-            joint = np.hstack([f_sel, np.tile(comp_state, (batch_size, 1))])
-            p_joint = p_joint * hp.evaluate(ci, 1, joint, return_abs=True)
+            p_joint = p_joint * hp.evaluate(ci, 1, np.hstack([f_sel, plugged]), return_abs=True)
         with np.errstate(divide="ignore", invalid="ignore"):
             return np.asarray(p_joint / p_norm)

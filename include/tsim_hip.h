@@ -289,6 +289,31 @@ int tsim_gather_rows_device(tsim_program *p, const uint64_t *d_src, int32_t word
 int tsim_scatter_rows_device(tsim_program *p, const uint64_t *d_src, int32_t words, const uint32_t *d_index,
                              int64_t n, uint64_t *d_dst, void *stream);
 
+/* ---- host-side noise sampler ON NUMPY'S STREAM (bit-exact replacement of ChannelSampler.sample,
+ *      src/tsim/noise/channels.py:624-658, for a numpy Generator backed by PCG64; no device involved) --------- */
+
+/* PCG64 state and increment as numpy's bit_generator.state reports them (128-bit integers, split in halves) */
+typedef struct tsim_pcg64 {
+  uint64_t state_lo, state_hi, inc_lo, inc_hi;
+} tsim_pcg64;
+
+#define TSIM_PCG_RAW 0          /* Generator.bit_generator.random_raw  -> uint64 */
+#define TSIM_PCG_DOUBLE 1       /* Generator.random / uniform(0, 1)    -> double */
+#define TSIM_PCG_EXPONENTIAL 2  /* Generator.standard_exponential      -> double (ziggurat) */
+#define TSIM_PCG_GEOMETRIC 3    /* Generator.geometric(p)              -> int64  */
+/* n draws of one kind; `rng` is advanced exactly as numpy advances it */
+int tsim_pcg_draw(tsim_pcg64 *rng, int32_t kind, double p, int64_t n, void *out);
+
+/* One ChannelSampler.sample(num_samples) call: per channel c (tables as _precompute_sparse builds them,
+ * channels.py:578-622) n_draws = int(B p + 7 sqrt(B p (1 - p))) + 100 geometric gaps, positions = cumsum - 1
+ * (those < B fire), one uniform per fired row, outcome = searchsorted(cond_cdf_c, u), row ^= pattern.
+ *   n_outcomes[c]  non-identity outcomes of channel c;  cond_cdf  concatenated conditional CDFs;
+ *   patterns       uint64 [sum n_outcomes, words] packed XOR patterns;  rows  uint64 [num_samples, words] (overwritten)
+ *   threads        worker threads of the scatter pass (0: up to 8).  The stream consumption is sequential. */
+int tsim_pcg_sample_channels(tsim_pcg64 *rng, int32_t n_channels, const double *p_fire, const int32_t *n_outcomes,
+                             const double *cond_cdf, const uint64_t *patterns, int32_t words, int64_t num_samples,
+                             uint64_t *rows, int32_t threads);
+
 /* ---- device-side noise sampler (statistical replacement of ChannelSampler.sample,
  *      src/tsim/noise/channels.py:578-658; the numpy PCG64 stream is not reproduced) ---------- */
 typedef struct tsim_noise tsim_noise;

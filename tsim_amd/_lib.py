@@ -86,6 +86,8 @@ SYMBOLS: dict[str, tuple] = {
     "tsim_gather_rows_device": (C.c_int, [_P, _P, _I32, _P, _I64, _I64, _P, _P]),
     "tsim_scatter_rows_device": (C.c_int, [_P, _P, _I32, _P, _I64, _P, _P]),
     "tsim_mem_info": (C.c_int, [_P, C.POINTER(_I64), C.POINTER(_I64)]),
+    "tsim_pcg_draw": (C.c_int, [_P, _I32, C.c_double, _I64, _P]),
+    "tsim_pcg_sample_channels": (C.c_int, [_P, _I32, _P, _P, _P, _P, _I32, _I64, _P, _I32]),
     "tsim_noise_create": (C.c_int, [_P, _I32, _I32, _P, _P, _P, _P, C.POINTER(_P)]),
     "tsim_noise_sample_device": (C.c_int, [_P, _I64, _U32, _U32, _P, _P]),
     "tsim_noise_destroy": (None, [_P]),

@@ -26,6 +26,8 @@ conditional CDFs (``channels.py:578-622``).
 
 from __future__ import annotations
 
+import ctypes as C
+import warnings
 from dataclasses import dataclass
 
 import numpy as np
@@ -248,7 +250,13 @@ class ChannelSampler:
 
     Attributes mirrored from the reference: ``channels`` (simplified), ``signature_matrix``."""
 
-    def __init__(self, channel_probs: list, error_transform: np.ndarray, seed: int | None = None):
+    def __init__(self, channel_probs: list, error_transform: np.ndarray, seed: int | None = None, engine: str = "auto"):
+        """``engine``: ``"numpy"`` draws through ``numpy.random.Generator`` as the reference does; ``"native"`` runs
+        the same stream (PCG64, ziggurat exponential, geometric, uniform - bit for bit) inside ``libtsim_hip.so``
+        (``tsim_pcg_sample_channels``), an order of magnitude faster; ``"auto"`` = native when the library is
+        there and reproduces this numpy's stream (checked once per process), else numpy."""
+        if engine not in ("auto", "numpy", "native"):
+            raise ValueError("engine must be 'auto', 'numpy' or 'native'")
         self.signature_matrix, ids, null_id = column_signatures(error_transform)
         raw, at = [], 0
         for probs in channel_probs:
@@ -263,6 +271,13 @@ class ChannelSampler:
         self._tables = self._firing_tables()
         # (p_fire, conditional CDF, uint8 XOR patterns) per firing channel: what the device-side sampler uploads
         self._sparse_data = [(p, cdf, unpack_rows(pats, self.num_f)) for p, cdf, pats in self._tables]
+        self._native = None
+        if engine != "numpy":
+            ok, why = native_stream_available()
+            if ok:
+                self._native = _NativeTables(self._tables, self.num_words)
+            elif engine == "native":
+                raise RuntimeError(f"native channel sampler unavailable: {why}")
 
     @property
     def num_f(self) -> int:
@@ -307,10 +322,19 @@ class ChannelSampler:
             return rows, None
         return rows, np.searchsorted(cdf, self._rng.uniform(size=len(rows)))
 
-    def sample_packed(self, num_samples: int = 1) -> np.ndarray:
+    def sample_packed(self, num_samples: int = 1, out: np.ndarray | None = None) -> np.ndarray:
         """``uint64[num_samples, ceil(num_f/64)]``: the rows the sampling kernels read (bit ``i`` of a row =
-        ``f_i``).  Fired rows of one channel are distinct, so the scatter is a plain indexed XOR per word."""
-        out = np.zeros((num_samples, self.num_words), dtype=np.uint64)
+        ``f_i``).  Fired rows of one channel are distinct, so the scatter is a plain indexed XOR per word.
+        ``out``: optional C-contiguous destination of that shape (a reused staging buffer saves the page faults
+        of a fresh 8 MB array per batch)."""
+        if out is not None and (out.shape != (num_samples, self.num_words) or out.dtype != np.uint64 or not out.flags.c_contiguous):
+            raise ValueError("out must be a C-contiguous uint64 array of shape (num_samples, num_words)")
+        if self._native is not None and 0 < num_samples < (1 << 32):
+            return self._native.sample(self._rng, num_samples, out)
+        if out is None:
+            out = np.zeros((num_samples, self.num_words), dtype=np.uint64)
+        else:
+            out[...] = 0
         for p_fire, cdf, patterns in self._tables:
             rows, outcome = self._draw(p_fire, cdf, num_samples)
             if outcome is None:
@@ -325,3 +349,92 @@ class ChannelSampler:
         """``uint8[num_samples, num_f]``, the reference's layout - same generator stream as :meth:`sample_packed`
         (the two can be mixed call by call)."""
         return unpack_rows(self.sample_packed(num_samples), self.num_f)
+
+
+# ---- the same stream, natively ------------------------------------------------------------------------------------
+
+
+class _PcgState(C.Structure):
+    _fields_ = [("state_lo", C.c_uint64), ("state_hi", C.c_uint64), ("inc_lo", C.c_uint64), ("inc_hi", C.c_uint64)]
+
+
+_M64 = (1 << 64) - 1
+
+
+def _export_state(gen: np.random.Generator) -> tuple:
+    st = gen.bit_generator.state
+    if st.get("bit_generator") != "PCG64":
+        raise TypeError("the native sampler reproduces PCG64 streams only")
+    s, inc = int(st["state"]["state"]), int(st["state"]["inc"])
+    return st, _PcgState(s & _M64, s >> 64, inc & _M64, inc >> 64)
+
+
+def _import_state(gen: np.random.Generator, st: dict, raw: _PcgState) -> None:
+    st["state"]["state"] = (int(raw.state_hi) << 64) | int(raw.state_lo)
+    gen.bit_generator.state = st  # the 32-bit half-word buffer (has_uint32 / uinteger) is untouched: never used here
+
+
+class _NativeTables:
+    """The firing tables in the flat layout ``tsim_pcg_sample_channels`` takes."""
+
+    def __init__(self, tables: list, words: int):
+        from . import _lib
+
+        self._fn = _lib.load().tsim_pcg_sample_channels
+        self._check = _lib.check
+        self.words = int(words)
+        self.n = len(tables)
+        self.p_fire = np.ascontiguousarray([t[0] for t in tables], dtype=np.float64)
+        self.n_out = np.ascontiguousarray([len(t[1]) for t in tables], dtype=np.int32)
+        self.cdf = np.ascontiguousarray(np.concatenate([t[1] for t in tables]) if tables else np.zeros(0), dtype=np.float64)
+        self.patterns = np.ascontiguousarray(np.concatenate([t[2] for t in tables], axis=0) if tables
+                                             else np.zeros((0, self.words)), dtype=np.uint64)
+
+    def sample(self, gen: np.random.Generator, num_samples: int, out: np.ndarray | None = None) -> np.ndarray:
+        st, raw = _export_state(gen)
+        if out is None:
+            out = np.empty((num_samples, self.words), dtype=np.uint64)
+        ptr = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+        self._check(self._fn(C.byref(raw), self.n, ptr(self.p_fire), ptr(self.n_out), ptr(self.cdf), ptr(self.patterns),
+                             self.words, int(num_samples), ptr(out), 0), "tsim_pcg_sample_channels")
+        _import_state(gen, st, raw)
+        return out
+
+
+_native_verdict: tuple | None = None
+
+
+def native_stream_available() -> tuple:
+    """``(ok, reason)``: the library loads and its PCG64 / ziggurat / geometric / uniform draws equal this
+    numpy's, draw for draw, on a seeded stream long enough to visit the ziggurat's rare branches.  The tables
+    inside the library were measured from one numpy version (csrc/tsim_zig_tables.h); another numpy with other
+    constants is detected here and the numpy engine is used instead - the drop-in contract is the numpy stream."""
+    global _native_verdict
+    if _native_verdict is not None:
+        return _native_verdict
+    try:
+        from . import _lib
+
+        lib = _lib.load()
+        gen = np.random.default_rng(20260928)
+        twin = np.random.default_rng(20260928)
+        for kind, p, n, dtype, draw in (
+            (2, 0.0, 200_000, np.float64, lambda g, n: g.standard_exponential(n)),
+            (3, 0.02, 50_000, np.int64, lambda g, n: g.geometric(0.02, n)),
+            (3, 0.5, 20_000, np.int64, lambda g, n: g.geometric(0.5, n)),
+            (1, 0.0, 20_000, np.float64, lambda g, n: g.uniform(size=n)),
+            (3, 1e-7, 5_000, np.int64, lambda g, n: g.geometric(1e-7, n)),
+        ):
+            want = draw(gen, n)
+            st, raw = _export_state(twin)
+            got = np.empty(n, dtype=dtype)
+            _lib.check(lib.tsim_pcg_draw(C.byref(raw), kind, float(p), n, got.ctypes.data_as(C.c_void_p)), "tsim_pcg_draw")
+            _import_state(twin, st, raw)
+            if not np.array_equal(want, got) or twin.bit_generator.state != gen.bit_generator.state:
+                _native_verdict = (False, f"native draws of kind {kind} (p = {p}) differ from numpy {np.__version__}")
+                warnings.warn("tsim_amd: " + _native_verdict[1] + "; falling back to the numpy channel sampler", stacklevel=2)
+                return _native_verdict
+        _native_verdict = (True, "")
+    except Exception as exc:  # library missing / not loadable: the numpy engine still gives the right stream
+        _native_verdict = (False, repr(exc))
+    return _native_verdict

@@ -253,6 +253,8 @@ class _CompiledSamplerBase:
         self._direct_detector_mask = self._direct.detector_mask
         self._device_noise = None
         self._f_slots = None
+        self._stage = None      # host staging array of one batch of packed f rows
+        self._bufs: dict = {}  # name -> (HipProgram, DeviceBuffer): grow-only scratch of the device route
 
     @classmethod
     def from_npz(cls, path, *, seed: int | None = None, device: int = 0, **kw):
@@ -362,15 +364,34 @@ class _CompiledSamplerBase:
             self._f_slots = have = (hp, nbytes, [hp.malloc(nbytes) for _ in range(_LANES)])
         return have[2]
 
+    def _scratch(self, hp: HipProgram, name: str, nbytes: int):
+        """A device buffer of at least ``nbytes`` kept between calls (allocation and free cost more than the
+        kernels of a small request); grown when too small, dropped by :meth:`release`."""
+        have = self._bufs.get(name)
+        if have is None or have[0] is not hp or have[1].nbytes < nbytes:
+            if have is not None and have[0] is hp:
+                have[1].free()
+            have = self._bufs[name] = (hp, hp.malloc(max(1, nbytes)))
+        return have[1]
+
+    def release(self) -> None:
+        """Give the cached device buffers back (they are otherwise freed with the program's handle)."""
+        for _hp, buf in self._bufs.values():
+            buf.free()
+        self._bufs.clear()
+        if self._f_slots is not None:
+            for buf in self._f_slots[2]:
+                buf.free()
+            self._f_slots = None
+
     def _download_bools(self, hp: HipProgram, d_rows, n: int) -> np.ndarray:
         """Packed device rows -> ``bool[n, num_outputs]`` on the host (unpack kernel + one D2H into a pageable
         array: a fresh pinned allocation of this size costs more than the copy)."""
         n_out = int(self._program.num_outputs)
-        d_u8 = hp.malloc(max(1, n * n_out))
+        d_u8 = self._scratch(hp, "unpacked", n * n_out)
         hp.unpack_bits_device(d_rows.ptr if hasattr(d_rows, "ptr") else d_rows, n, n_out, d_u8.ptr)
         host = np.empty((n, n_out), dtype=np.uint8)
-        hp.d2h(host, d_u8)
-        d_u8.free()
+        hp.d2h(host, d_u8.ptr)
         return host.view(np.bool_)
 
     def _device_plain(self, shots: int, batch_size: int | None, want_ref: bool, packed_columns: int | None = None):
@@ -391,13 +412,15 @@ class _CompiledSamplerBase:
         n_comp = max(1, len(self._program.components))
         total = plan.size * plan.count
         lanes = self._lane_buffers(hp, plan.size * wf * 8)
-        d_rows, d_devs = hp.malloc(total * wo * 8), hp.malloc(plan.count * n_comp * 4)
+        d_rows, d_devs = self._scratch(hp, "rows", total * wo * 8), self._scratch(hp, "devs", plan.count * n_comp * 4)
         noise = None if host_noise else self._device_noise_sampler(hp)
         for b in range(plan.count):
             lane = b % _LANES
             hp.sample_batch_device_end(lane)  # the lane's previous launch no longer reads its f buffer
             if host_noise:
-                rows = cs.sample_packed(plan.size)
+                if self._stage is None or self._stage.shape != (plan.size, wf):
+                    self._stage = np.empty((plan.size, wf), dtype=np.uint64)
+                rows = cs.sample_packed(plan.size, out=self._stage)
                 if rides and b == 0:
                     rows[0] = 0
                 hp.h2d(lanes[lane], rows)
@@ -412,18 +435,15 @@ class _CompiledSamplerBase:
         skip = 1 if rides else 0
         if packed_columns is not None:  # bit_packed=True of the first columns: compacted on the GPU
             rb = (packed_columns + 7) // 8
-            d_c = hp.malloc(total * rb + 16)
+            d_c = self._scratch(hp, "compact", total * rb + 16)
             hp.compact_rows_device(d_rows.ptr, total, packed_columns, d_c.ptr, in_words=wo)
             out = np.empty((total, rb), dtype=np.uint8)
-            hp.d2h(out, d_c)
-            d_c.free()
+            hp.d2h(out, d_c.ptr)
         else:
             out = self._download_bools(hp, d_rows, total)
             if rides:
                 ref = out[0].copy()
-        hp.d2h(devs, d_devs)
-        d_rows.free()
-        d_devs.free()
+        hp.d2h(devs, d_devs.ptr)
         for b in range(plan.count):
             self._check_devs(devs[b * n_comp:(b + 1) * n_comp])
         return out[skip:skip + shots], ref

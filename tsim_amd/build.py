@@ -33,7 +33,7 @@ HIP_FLAGS = [
     "-ffp-contract=off",  # float32 epilogue must round once per operation
     "-fPIC",
 ]
-CXX_FLAGS = ["-O3", "-std=c++17", "-ffp-contract=off", "-fPIC"]
+CXX_FLAGS = ["-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-msse4.1"]  # sse4.1: ceil() as one roundsd in tsim_pcg.cpp
 LINK_LIBS = ["-lrccl"]  # tsim_dist.hip: the gather of the detector rows over xGMI
 
 

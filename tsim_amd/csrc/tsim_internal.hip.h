@@ -133,6 +133,7 @@ struct tsim_program {
   int lw_request = -1;        // -1 default (on in TSIM_MODE_AUTO), 0 off, 1 on
   int lw_weight_cap = -1;     // -1 = TSIMK_LW_MAX_WEIGHT
   bool lw = false;            // tables built, pass 1 active
+  bool lw_reg = false;        // the register form of pass 1 applies (narrow f rows, ascending f_selection)
   // Launch slots: slot 0 serves the serial API (everything on the caller's stream); slots 1..4 serve
   // tsim_sample_batch_device_begin/_end: a slot's launches run on the slot's own stream (`side`) so
   // that it overlaps the first pass of the following launches.
@@ -190,6 +191,7 @@ struct tsim_program {
     bool merge_lists = true;  // TSIM_AMD_MERGE_LISTS=0: always TSIMK_LW_LISTS hard-row sub-lists
     int list_rows = 40;       // TSIM_AMD_LIST_ROWS: expected hard rows per list the list count aims at
     int min_lists = 4;        // TSIM_AMD_MIN_LISTS (power of two >= 2)
+    bool lw_reg = true;       // TSIM_AMD_LW_REG=0: LDS-staged first pass even where the register form applies
     bool defer = true;        // TSIM_AMD_DEFER_HARD=0: every pipelined launch runs its own second pass
     int defer_group = 4;      // TSIM_AMD_DEFER_GROUP: launches per deferred hard-row batch (<= TSIMK_H_MAX_CTX)
   } knobs;

@@ -27,7 +27,9 @@ namespace tsimk {
 enum {
   LW_NOUT = 0, LW_F, LW_FSELP /* gather program f row -> x */, LW_OUTPOS, LW_KEYBASE, LW_WMAX,
   LW_TAB /* float offset into tab */, LW_OFF2 /* index of the first weight-2 pattern */, LW_OFF3, LW_NPAT,
-  LW_FSELN /* chunks of the gather program */, LW_OFF4, LW_OFF5, LW_WORDS = 16
+  LW_FSELN /* chunks of the gather program */, LW_OFF4, LW_OFF5,
+  LW_SELMASK /* image offset of 4 selection-mask words + 4 prefix counts (register first pass), 0 = none */,
+  LW_WORDS = 16
 };
 // A gather program moves bit fields of the packed f row to a destination bit vector.  It is a
 // list of 4-word runs [ctl, mask, flip, 0], four runs per 64-byte chunk (one s_load_dwordx16; the

@@ -128,4 +128,138 @@ __global__ void __launch_bounds__(1024) k_sample_lw(LwArgs L) {
   }
 }
 
+// ---------------------------------------------------------------------------
+// pass 1, register form: narrow programs (f rows of at most 128 bits, at most 64 outputs, every component's
+// f_selection ascending - what the reference's compiler emits, pipeline.py:141-143).  Nothing is staged in LDS:
+//   * the f row lives in WF32 VGPRs; direct outputs are bit-field runs on those registers;
+//   * f_sel is never materialised: the weight test is popcount(f & selection mask) per word, and the colex rank
+//     of the pattern is accumulated from the set bits directly - the position of a set bit inside f_sel is the
+//     number of selected bits below it, popcount(mask & (2^p - 1)) plus the word's prefix count (both wave-uniform
+//     operands).  Lanes loop over THEIR set bits only (mean weight 0.6 at the benchmark's noise level) instead
+//     of every lane running the whole gather program (one run per contiguous bit field, ~16 for C2).
+// Same thresholds, same Threefry draws, same hard-row protocol as k_sample_lw.
+// ---------------------------------------------------------------------------
+template <int WF32>
+__device__ __forceinline__ void lw_gather_reg(cptr prog, uint32_t nchunks, const uint32_t (&fw)[WF32], uint32_t &a0,
+                                              uint32_t &a1) {
+  for (uint32_t c = 0; c < nchunks; ++c) {
+    const lw_u32x16 q = *(lw_cptr16)(prog + 16u * c);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const uint32_t ctl = q[4 * k];
+      const uint32_t sw = ctl >> 24;  // wave-uniform: a scalar select
+      uint32_t src = fw[0];
+#pragma unroll
+      for (int w = 1; w < WF32; ++w) src = (sw == (uint32_t)w) ? fw[w] : src;
+      const uint32_t v = (((src >> (ctl & 31u)) & q[4 * k + 1]) ^ q[4 * k + 2]) << ((ctl >> 8) & 31u);
+      if (((ctl >> 16) & 255u) == 0u) a0 |= v;
+      else a1 |= v;
+    }
+  }
+}
+
+template <int WF32>
+__global__ void __launch_bounds__(1024) k_sample_lw_reg(LwArgs L) {
+  const SampleArgs &A = L.s;
+  const int nthr = blockDim.x;
+  const long long slot = (long long)blockIdx.x * nthr + threadIdx.x;
+  long long n_rows = A.B;
+  if (A.row_index) n_rows = (long long)*A.row_count;
+  const bool active = slot < n_rows;
+  long long row = slot;
+  if (A.row_index) row = active ? (long long)A.row_index[slot] : 0;
+  const unsigned long long shot = (unsigned long long)(A.shot_offset + row);
+  cptr img = (cptr)(uintptr_t)A.img;
+
+  if (blockIdx.x == 0 && threadIdx.x <= TSIMK_LW_LISTS)
+    L.ctl_next[32u * threadIdx.x] = (threadIdx.x == TSIMK_LW_LISTS) ? 0xFFFFFFFFu : 0u;  // last: "no check row"
+  bool hard = false;
+  if (active) {
+    uint32_t fw[WF32];
+    const uint64_t *frow = A.f + row * (WF32 / 2);
+#pragma unroll
+    for (int w = 0; w < WF32 / 2; ++w) {
+      const uint64_t v = frow[w];
+      fw[2 * w] = (uint32_t)v;
+      fw[2 * w + 1] = (uint32_t)(v >> 32);
+    }
+    hard = L.has_check && slot == 0;
+    if (hard) L.ctl[32 * TSIMK_LW_LISTS] = (uint32_t)row;
+    uint32_t o0 = 0, o1 = 0;
+    lw_gather_reg<WF32>(img + L.direct_prog, (uint32_t)L.direct_chunks, fw, o0, o1);  // K14, sampler.py:140-145
+
+    for (int ci = 0; ci < A.n_comp; ++ci) {
+      cptr rec = img + L.lw_off + ci * LW_WORDS;
+      cptr sel = img + rec[LW_SELMASK];  // sel[0..3]: masks, sel[4..7]: selected bits in lower words
+      uint32_t m[WF32];
+      uint32_t cnt = 0;
+#pragma unroll
+      for (int w = 0; w < WF32; ++w) {
+        m[w] = fw[w] & sel[w];
+        cnt += (uint32_t)__builtin_popcount(m[w]);
+      }
+      if (cnt > rec[LW_WMAX]) hard = true;
+      if (hard) continue;  // needs the full kernel: nothing of this row is written here
+      uint32_t pat = (cnt == 0) ? 0u : (cnt == 1) ? 1u : (cnt == 2) ? rec[LW_OFF2] : (cnt == 3) ? rec[LW_OFF3]
+                     : (cnt == 4) ? rec[LW_OFF4] : rec[LW_OFF5];
+#pragma unroll
+      for (int i = 0; i < TSIMK_LW_MAX_WEIGHT; ++i) {
+        if (cnt > (uint32_t)i) {
+          // lowest set bit over the words -> its index inside f_sel
+          uint32_t cur = m[WF32 - 1], sw = sel[WF32 - 1], base = sel[4 + WF32 - 1];
+          int wi = WF32 - 1;
+#pragma unroll
+          for (int w = WF32 - 2; w >= 0; --w) {
+            const bool nz = m[w] != 0u;
+            cur = nz ? m[w] : cur;
+            sw = nz ? sel[w] : sw;
+            base = nz ? sel[4 + w] : base;
+            wi = nz ? w : wi;
+          }
+          const uint32_t p = (uint32_t)__builtin_ctz(cur);
+          const uint32_t b = base + (uint32_t)__builtin_popcount(sw & ((1u << p) - 1u));
+          cur &= cur - 1u;
+#pragma unroll
+          for (int w = 0; w < WF32; ++w) m[w] = (wi == w) ? cur : m[w];
+          pat += (i == 0) ? b : (i == 1) ? lw_binom2(b) : (i == 2) ? lw_binom3(b) : (i == 3) ? lw_binom4(b) : lw_binom5(b);
+        }
+      }
+      const uint32_t n_out = rec[LW_NOUT];
+      cptr outpos = img + rec[LW_OUTPOS];
+      const uint32_t keybase = rec[LW_KEYBASE];
+      const float *thr = L.tab + rec[LW_TAB] + ((size_t)pat << n_out);
+      uint32_t node = 1u;
+      for (uint32_t i = 0; i < n_out; ++i) {
+        const float u = uniform01(subkey(A, keybase + i, 0), subkey(A, keybase + i, 1), shot);  // sampler.py:74-75
+        const bool bit = u < thr[node];
+        node = 2u * node + (bit ? 1u : 0u);
+        const uint32_t dst = outpos[i];
+        const uint32_t v = (bit ? 1u : 0u) << (dst & 31u);
+        if ((dst >> 5) == 0u) o0 |= v;
+        else o1 |= v;
+      }
+    }
+    if (!hard) {
+      if (A.out) A.out[row] = (uint64_t)o0 | ((uint64_t)o1 << 32);  // WO == 1
+      if (A.out_compact) {
+        uint8_t *dst = A.out_compact + row * A.out_rb;
+        for (int k = 0; k < A.out_rb; ++k) dst[k] = (uint8_t)(((k < 4) ? o0 : o1) >> (8 * (k & 3)));
+      }
+    }
+  }
+
+  // wave-aggregated append of the hard rows
+  const unsigned long long hm = __ballot(hard ? 1 : 0);
+  if (hm != 0ull) {
+    const int lane = (int)(threadIdx.x & 63u);
+    const int leader = __builtin_ctzll(hm);
+    uint32_t basei = 0;
+    const uint32_t k = blockIdx.x % (uint32_t)L.n_lists;  // this block's sub-list
+    if (lane == leader) basei = atomicAdd(&L.ctl[32u * k], (uint32_t)__popcll(hm));
+    basei = (uint32_t)__shfl((int)basei, leader, 64);
+    if (hard)
+      L.hard_index[(size_t)k * L.list_cap + basei + (uint32_t)__popcll(hm & ((1ull << lane) - 1ull))] = (uint32_t)row;
+  }
+}
+
 }  // namespace tsimk

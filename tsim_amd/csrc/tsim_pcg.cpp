@@ -19,6 +19,9 @@
 #include "tsim_zig_tables.h"
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -106,10 +109,27 @@ inline void store(tsim_pcg64 *s, const Pcg &g) {
   s->state_lo = (uint64_t)g.state;
 }
 
-struct Fire {
-  uint32_t row;
-  uint32_t pattern;  // index into the concatenated pattern table
+// g jumps `delta` raw outputs ahead in O(log delta) (Brown, "Random number generation with arbitrary strides")
+inline void advance(Pcg &g, uint64_t delta) {
+  u128 acc_mult = 1, acc_plus = 0, cur_mult = kMult, cur_plus = g.inc;
+  while (delta) {
+    if (delta & 1u) {
+      acc_mult *= cur_mult;
+      acc_plus = acc_plus * cur_mult + cur_plus;
+    }
+    cur_plus = (cur_mult + 1) * cur_plus;
+    cur_mult *= cur_mult;
+    delta >>= 1;
+  }
+  g.state = acc_mult * g.state + acc_plus;
+}
+
+// scratch that survives between calls (one sampler thread per process is the rule; thread_local keeps others safe)
+struct Scratch {
+  std::vector<uint32_t> row;      // fired rows, channel after channel
+  std::vector<uint16_t> outcome;  // outcome index per fired row (multi-outcome channels only)
 };
+thread_local Scratch g_scratch;
 
 }  // namespace
 
@@ -150,85 +170,108 @@ extern "C" int tsim_pcg_sample_channels(tsim_pcg64 *rng, int32_t n_channels, con
   if (num_samples > 0 && !rows) return tsim_fail(TSIM_EINVAL, "rows is NULL");
   if (n_channels > 0 && (!p_fire || !n_outcomes || !cond_cdf || !patterns)) return tsim_fail(TSIM_EINVAL, "NULL channel table");
   if (num_samples == 0) return TSIM_OK;
+  static const bool timing = getenv("TSIM_PCG_TIMING") != nullptr;
+  const auto t_start = std::chrono::steady_clock::now();
   memset(rows, 0, (size_t)num_samples * words * 8);
+  const auto t_zero = std::chrono::steady_clock::now();
   Pcg g = load(rng);
   // ---- pass 1 (sequential: the stream is one dependency chain): per channel the fired rows and their outcomes
-  std::vector<Fire> fires;
-  std::vector<size_t> chan_begin((size_t)n_channels + 1, 0);
-  size_t table_off = 0;
+  Scratch &S = g_scratch;
+  std::vector<size_t> chan_begin((size_t)n_channels + 1, 0), table_off((size_t)n_channels + 1, 0);
   {
-    double expect_total = 0;
-    for (int c = 0; c < n_channels; ++c) expect_total += (double)num_samples * p_fire[c];
-    fires.reserve((size_t)(expect_total * 1.05) + 1024);
+    double cap = 0;
+    for (int c = 0; c < n_channels; ++c) {
+      const double e = (double)num_samples * p_fire[c];
+      cap += e + 7.0 * sqrt(e) + 101.0;
+      table_off[c + 1] = table_off[c] + (size_t)std::max(0, n_outcomes[c]);
+      if (n_outcomes[c] > 65535) return tsim_fail(TSIM_ENOTSUP, "channel %d has more than 65535 outcomes", c);
+    }
+    if (S.row.size() < (size_t)cap + 16) S.row.resize((size_t)cap + 16);
+    if (S.outcome.size() < S.row.size()) S.outcome.resize(S.row.size());
   }
+  uint32_t *const frow = S.row.data();
+  uint16_t *const fout = S.outcome.data();
+  size_t n_fires = 0;
   for (int c = 0; c < n_channels; ++c) {
     const double p = p_fire[c];
     const int nout = n_outcomes[c];
     if (!(p > 0.0) || p > 1.0 || nout < 1) return tsim_fail(TSIM_EINVAL, "channel %d: p_fire = %g, outcomes = %d", c, p, nout);
-    const double *cdf = cond_cdf + table_off;
+    const double *cdf = cond_cdf + table_off[c];
     // n_draws = int(expected + 7 sigma) + 100 (channels.py:641-644), in the same double operations
     const double expected = (double)num_samples * p;
     const double sigma = sqrt(expected * (1.0 - p));
     const int64_t n_draws = (int64_t)(expected + 7.0 * sigma) + 100;
-    chan_begin[c] = fires.size();
-    // cumsum(geometric) - 1, kept while < num_samples; every one of the n_draws gaps is drawn (stream position)
+    chan_begin[c] = n_fires;
+    // positions = cumsum(gaps) - 1, kept while < num_samples.  Every one of the n_draws gaps is drawn (the stream
+    // position depends on it); positions only grow, so the store below is unconditional and the count advances
+    // only while the position is still inside the batch.
+    size_t n = n_fires;
+    const size_t room = S.row.size() - 1;
     int64_t pos = -1;
-    bool inside = true;
     if (p >= 0.333333333333333333333333) {
       for (int64_t i = 0; i < n_draws; ++i) {
-        const int64_t gap = geometric_search(g, p);
-        if (!inside) continue;
-        pos += gap;
-        if (pos < num_samples) fires.push_back(Fire{(uint32_t)pos, 0u});
-        else inside = false;
+        pos += geometric_search(g, p);
+        frow[n] = (uint32_t)pos;
+        n += (size_t)((pos < num_samples) & (n < room));
       }
     } else {
+      // gap = ceil(-e / log1p(-p)) with the exact division (a multiply by the reciprocal plus a closeness check
+      // was measured: slower - the divide is off the dependency chain).  A position that has left the batch stays
+      // outside (clamped: numpy's int64 cumsum cannot wrap back below 2^32 rows either).
       const double l = log1p(-p);
+      const int64_t far = num_samples + 1;
       for (int64_t i = 0; i < n_draws; ++i) {
         const int64_t gap = geometric_inversion(g, l);
-        if (!inside) continue;
-        pos = (gap > INT64_MAX - pos - 1) ? INT64_MAX : pos + gap;
-        if (pos < num_samples) fires.push_back(Fire{(uint32_t)pos, 0u});
-        else inside = false;
+        pos = (gap >= far || pos + gap >= far) ? far : pos + gap;
+        frow[n] = (uint32_t)pos;
+        n += (size_t)((pos < num_samples) & (n < room));
       }
     }
-    // one uniform per fired row; outcome = searchsorted(cdf, u) (first entry >= u; cdf[-1] == 1 > u)
-    for (size_t k = chan_begin[c]; k < fires.size(); ++k) {
-      const double u = next_double(g);
-      int o = 0;
-      while (o < nout - 1 && cdf[o] < u) ++o;
-      fires[k].pattern = (uint32_t)(table_off + (size_t)o);
+    // one uniform per fired row; outcome = searchsorted(cdf, u) (first entry >= u; cdf[-1] == 1 > u).  A channel
+    // with a single non-identity outcome needs no value - only the stream position: jump over its uniforms.
+    if (nout == 1) {
+      advance(g, (uint64_t)(n - n_fires));
+    } else {
+      for (size_t k = n_fires; k < n; ++k) {
+        const double u = next_double(g);
+        int o = 0;
+        while (o < nout - 1 && cdf[o] < u) ++o;
+        fout[k] = (uint16_t)o;
+      }
     }
-    table_off += (size_t)nout;
+    n_fires = n;
   }
-  chan_begin[n_channels] = fires.size();
+  chan_begin[n_channels] = n_fires;
   store(rng, g);
+  const auto t_pass1 = std::chrono::steady_clock::now();
   // ---- pass 2: XOR the patterns in, tiled over shot ranges (a tile of rows stays cache resident while every
   //      channel's cursor sweeps it) and threaded over tiles
   const int64_t tile_rows = std::max<int64_t>(1024, (256 * 1024) / (8 * (int64_t)words));
   const int64_t n_tiles = (num_samples + tile_rows - 1) / tile_rows;
   int T = threads > 0 ? threads : (int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency()));
-  T = (int)std::min<int64_t>(T, n_tiles);
-  if (fires.size() < 4096) T = 1;
+  T = (int)std::max<int64_t>(1, std::min<int64_t>(T, n_tiles));
+  if (n_fires < 16384) T = 1;
   auto work = [&](int t) {
     std::vector<size_t> cur((size_t)n_channels);
     const int64_t tile_lo = n_tiles * t / T, tile_hi = n_tiles * (t + 1) / T;
     const uint32_t first_row = (uint32_t)std::min<int64_t>(num_samples, tile_lo * tile_rows);
-    for (int c = 0; c < n_channels; ++c) {  // first fire of this thread's range in every channel
-      const Fire *b = fires.data() + chan_begin[c], *e = fires.data() + chan_begin[c + 1];
-      cur[c] = (size_t)(std::lower_bound(b, e, first_row, [](const Fire &f, uint32_t r) { return f.row < r; }) - fires.data());
-    }
+    for (int c = 0; c < n_channels; ++c)  // first fire of this thread's range in every channel
+      cur[c] = (size_t)(std::lower_bound(frow + chan_begin[c], frow + chan_begin[c + 1], first_row) - frow);
     for (int64_t tile = tile_lo; tile < tile_hi; ++tile) {
       const uint32_t end_row = (uint32_t)std::min<int64_t>(num_samples, (tile + 1) * tile_rows);
       for (int c = 0; c < n_channels; ++c) {
         size_t k = cur[c];
         const size_t stop = chan_begin[c + 1];
-        if (words == 1) {
-          for (; k < stop && fires[k].row < end_row; ++k) rows[fires[k].row] ^= patterns[fires[k].pattern];
+        const uint64_t *pat = patterns + table_off[c] * (size_t)words;
+        if (words == 1 && n_outcomes[c] == 1) {
+          const uint64_t v = pat[0];
+          for (; k < stop && frow[k] < end_row; ++k) rows[frow[k]] ^= v;
+        } else if (words == 1) {
+          for (; k < stop && frow[k] < end_row; ++k) rows[frow[k]] ^= pat[fout[k]];
         } else {
-          for (; k < stop && fires[k].row < end_row; ++k) {
-            uint64_t *dst = rows + (size_t)fires[k].row * words;
-            const uint64_t *src = patterns + (size_t)fires[k].pattern * words;
+          for (; k < stop && frow[k] < end_row; ++k) {
+            uint64_t *dst = rows + (size_t)frow[k] * words;
+            const uint64_t *src = pat + (n_outcomes[c] == 1 ? 0 : (size_t)fout[k] * words);
             for (int w = 0; w < words; ++w) dst[w] ^= src[w];
           }
         }
@@ -237,7 +280,6 @@ extern "C" int tsim_pcg_sample_channels(tsim_pcg64 *rng, int32_t n_channels, con
     }
   };
   if (T <= 1) {
-    T = 1;
     work(0);
   } else {
     std::vector<std::thread> pool;
@@ -245,5 +287,11 @@ extern "C" int tsim_pcg_sample_channels(tsim_pcg64 *rng, int32_t n_channels, con
     work(0);
     for (auto &th : pool) th.join();
   }
+  const size_t fires_total = n_fires;
+  if (timing)
+    fprintf(stderr, "tsim_pcg_sample_channels: %lld rows, %zu fires: zero %.2f ms, draws %.2f ms, scatter (%d threads) %.2f ms\n",
+            (long long)num_samples, fires_total, std::chrono::duration<double, std::milli>(t_zero - t_start).count(),
+            std::chrono::duration<double, std::milli>(t_pass1 - t_zero).count(), T,
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_pass1).count());
   return TSIM_OK;
 }

@@ -515,6 +515,20 @@ retry_pack:
           img[p->lw_off + ci * LW_WORDS + LW_FSELN] = (uint32_t)(prog.size() / 16);
           img.insert(img.end(), prog.begin(), prog.end());
         }
+        // register form of the first pass (k_sample_lw_reg): selection masks over the f row and, per word, the
+        // number of selected bits in the lower words.  Needs ascending f_selection (then the position of an f bit
+        // inside f_sel is a popcount), f indices below 128 and at most 64 outputs.
+        p->lw_reg = p->max_f_index < 128 && p->num_outputs <= 64;
+        for (auto &c : p->comps)
+          for (int j = 1; j < c.F; ++j) p->lw_reg = p->lw_reg && c.f_selection[j] > c.f_selection[j - 1];
+        if (p->lw_reg)
+          for (size_t ci = 0; ci < p->comps.size(); ++ci) {
+            uint32_t sel[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int v : p->comps[ci].f_selection) sel[v >> 5] |= 1u << (v & 31);
+            for (int w = 1; w < 4; ++w) sel[4 + w] = sel[4 + w - 1] + (uint32_t)__builtin_popcount(sel[w - 1]);
+            img[p->lw_off + ci * LW_WORDS + LW_SELMASK] = (uint32_t)img.size();
+            img.insert(img.end(), sel, sel + 8);
+          }
       } else {
         p->lw_wmax.clear();
       }
@@ -534,6 +548,7 @@ retry_pack:
     p->knobs.v4_block = (vb == 512 || vb == 128) ? vb : 256;
     p->knobs.hard_lds_kb = std::max(24, std::min(156, env_int("TSIM_AMD_HARD_LDS_KB", 128)));
     p->knobs.defer = env_int("TSIM_AMD_DEFER_HARD", 1) != 0;
+    p->knobs.lw_reg = env_int("TSIM_AMD_LW_REG", 1) != 0;
     p->knobs.merge_lists = env_int("TSIM_AMD_MERGE_LISTS", 1) != 0;
     p->knobs.list_rows = env_int("TSIM_AMD_LIST_ROWS", 40);
     p->knobs.min_lists = env_int("TSIM_AMD_MIN_LISTS", 4);

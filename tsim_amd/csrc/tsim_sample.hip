@@ -324,8 +324,14 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
     l.list_cap = (int)list_cap;
     l.n_lists = n_lists;
     const size_t lds1 = (size_t)(2 * a.WF + 2 * a.WO) * blk1 * 4;
-    if (lds1 > 64 * 1024) return tsim_fail(TSIM_ENOTSUP, "num_f + num_outputs too large for LDS staging (%zu B)", lds1);
-    hipLaunchKernelGGL(k_sample_lw, dim3((unsigned)grid1), dim3(blk1), lds1, s, l);
+    if (p->lw_reg && p->knobs.lw_reg && (a.WF == 1 || a.WF == 2) && a.WO == 1) {
+      // narrow rows: everything in registers, no LDS
+      if (a.WF == 1) hipLaunchKernelGGL(k_sample_lw_reg<2>, dim3((unsigned)grid1), dim3(blk1), 0, s, l);
+      else hipLaunchKernelGGL(k_sample_lw_reg<4>, dim3((unsigned)grid1), dim3(blk1), 0, s, l);
+    } else {
+      if (lds1 > 64 * 1024) return tsim_fail(TSIM_ENOTSUP, "num_f + num_outputs too large for LDS staging (%zu B)", lds1);
+      hipLaunchKernelGGL(k_sample_lw, dim3((unsigned)grid1), dim3(blk1), lds1, s, l);
+    }
     HIP_TRY(hipGetLastError());
     if (prof) { int r = prof_event(p, s, PROF_PASS1); if (r) return r; }
     // pass 2 below runs on the hard lists; the check row was forced into one of them

@@ -277,8 +277,11 @@ def main() -> None:
     GATHER_MODE = os.environ.get("TSIM_BENCH_GATHER", "root0")
     if GATHER_MODE == "alltoall":
         GATHER_EVERY = (GATHER_EVERY + N - 1) // N * N
-    d_outs = [hp.malloc(B * WO * 8) for _ in range(NSLOT)]
+    # results are written in the reference's bit_packed layout (sampler.py:665-669: ceil(n_out/8) bytes per shot,
+    # TSIM_PIPE_OUT_BIT_PACKED) - the algorithmic output bytes, not the padded 8-byte device word
+    d_outs = [hp.malloc(B * WO * 8) for _ in range(NSLOT)]  # sized for the padded rows too (serial legs below)
     out_ptrs = [d.ptr for d in d_outs]
+    PIPE_READY, PIPE_PACKED = 1, 2
     if use_dist:
         join_ptr = hp.pipeline_lane_stream(2)   # where deferred hard-row batches - i.e. results - complete
         main_ptr = hp.stream_ptr()               # first-pass lane 0
@@ -296,7 +299,6 @@ def main() -> None:
     gathered = [0]  # groups whose collective has been issued
     begin_split = lib.tsim_sample_batch_device_begin_split
     end_fn = lib.tsim_sample_batch_device_end
-    series_fn = lib.tsim_pipeline_set_compact_series
     wait_fn = lib.tsim_pipeline_wait_stream
     h_prog = hp._h
 
@@ -321,7 +323,7 @@ def main() -> None:
         if not use_dist:
             # _begin on a slot whose previous step was not joined is ordered after that step's second pass by the
             # library (include/tsim_hip.h), so one call per step is enough here
-            rc = begin_split(h_prog, b, d_f, B, num_f, key_state, shot_offset, out_ptrs[b], None, None, 1)  # inputs ready
+            rc = begin_split(h_prog, b, d_f, B, num_f, key_state, shot_offset, out_ptrs[b], None, None, PIPE_READY | PIPE_PACKED)
             if rc < 0:
                 raise RuntimeError(f"tsim_sample_batch_device_begin failed ({rc}): {_lib.last_error()}")
             return
@@ -334,12 +336,11 @@ def main() -> None:
                 # drain the pipeline once per group); the other lanes are ordered after lane 0 just below
                 comm.wait_mark(g, main_ptr)
             rc = wait_fn(h_prog, None)
-            if rc >= 0:  # the launches of this group also write bit_packed rows, one slice each
-                rc = series_fn(h_prog, grp[g].ptr, B * RB, GATHER_EVERY)
         elif j < NSLOT:  # (the first launches create the lanes)
             rc = wait_fn(h_prog, None)
-        if rc >= 0:
-            rc = begin_split(h_prog, b, d_f, B, num_f, key_state, shot_offset, out_ptrs[b], None, None, 0 if j < NSLOT else 1)
+        if rc >= 0:  # every launch writes its bit_packed rows straight into its slice of the group buffer
+            rc = begin_split(h_prog, b, d_f, B, num_f, key_state, shot_offset, grp[g].ptr + pos * B * RB, None, None,
+                             (0 if j < NSLOT else PIPE_READY) | PIPE_PACKED)
         if rc < 0:
             raise RuntimeError(f"pipelined launch failed ({rc}): {_lib.last_error()}")
         if pos == GATHER_EVERY - 1:  # group complete: join every slot on the join lane, then collect
@@ -496,6 +497,7 @@ def main() -> None:
                                 else "an RCCL gather to rank 0") + ", issued by libtsim_hip.so (no torch.distributed)")
                 if use_dist else "single GPU",
                 "f_resident_in_hbm": True,
+                "output_layout": f"bit_packed rows, {RB} B/shot (sampler.py:665-669), written by the sampling kernels",
             },
             "roofline": {
                 "bound": "hbm",

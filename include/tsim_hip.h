@@ -206,6 +206,9 @@ int tsim_sample_batch_device(tsim_program *p, const uint64_t *d_f, int64_t B, in
  */
 #define TSIM_PIPELINE_SLOTS 16
 #define TSIM_PIPE_INPUTS_READY 1u
+/* d_out receives the reference's bit_packed rows, uint8 [B, ceil(num_outputs/8)] (sampler.py:665-669), INSTEAD of
+ * the padded 8-byte words: ceil(n/8) bytes written per shot (3 instead of 8 for 20 outputs); any alignment */
+#define TSIM_PIPE_OUT_BIT_PACKED 2u
 int tsim_sample_batch_device_begin(tsim_program *p, int32_t slot, const uint64_t *d_f, int64_t B,
                                    int32_t num_f, uint32_t key_hi, uint32_t key_lo, int64_t shot_offset,
                                    uint64_t *d_out, float *d_max_norm_dev, void *stream, uint32_t flags);

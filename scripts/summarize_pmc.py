@@ -38,7 +38,8 @@ def main():
     import os
     group = int(os.environ.get("TSIM_AMD_DEFER_GROUP", "4"))
     if "k_sample4h_multi" in per_kernel:
-        weights = {"k_sample_lw": 1.0, "k_sample4h_multi": 1.0 / group}
+        weights = {k: 1.0 for k in per_kernel if k.startswith("k_sample_lw")}  # k_sample_lw / k_sample_lw_reg
+        weights["k_sample4h_multi"] = 1.0 / group
     else:
         weights = {k: 1.0 for k in per_kernel}
     total = collections.defaultdict(float)

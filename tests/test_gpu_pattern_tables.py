@@ -432,3 +432,44 @@ def test_begin_split_is_split_then_begin(hip):
         hp.d2h(got, d_o[i])
         np.testing.assert_array_equal(got, hp.sample_batch(f, sub, bit_packed=True)[0], err_msg=f"batch {i}")
     assert (state[0], state[1]) == (key[0], key[1])
+
+
+@pytest.mark.parametrize("name", ["C2", "C5"])
+def test_bit_packed_only_output_of_pipelined_launches(hip, name):
+    """TSIM_PIPE_OUT_BIT_PACKED: the kernels write ceil(n_out/8)-byte rows instead of the padded words - equal to
+    np.packbits of the ordinary result, for tabulated rows, hard rows (own pass and deferred batches) and the full kernel."""
+    import ctypes as C
+
+    prog, cfg = synth.config_program(name)
+    hp = hip.HipProgram(prog)
+    nf, n_out = cfg["num_f"], prog.num_outputs
+    wf, rb = (nf + 63) // 64, (n_out + 7) // 8
+    B, n = 50_000, 12
+    d_f, d_c = [], []
+    want = []
+    key = [(i + 1, 7 * i + 3) for i in range(n)]
+    for i in range(n):
+        f = synth.synth_f(B, nf, cfg["p_bit"] * (1 + i % 3), seed=300 + i)
+        packed = np.zeros((B, wf * 8), np.uint8)
+        pk = np.packbits(f, axis=1, bitorder="little")
+        packed[:, : pk.shape[1]] = pk
+        buf = hp.malloc(packed.nbytes)
+        hp.h2d(buf, packed)
+        d_f.append(buf)
+        d_c.append(hp.malloc(B * rb + 16))
+        ref, _ = hp.sample_batch(f, key[i])
+        want.append(np.packbits(ref, axis=1, bitorder="little"))
+    for rounds in range(2):  # second round: the deferred plan is active (feedback from the first)
+        for i in range(n):
+            rc = hp._lib.tsim_sample_batch_device_begin(hp._h, i % 8, d_f[i].ptr, B, nf, key[i][0], key[i][1], 0, d_c[i].ptr, None, None, 2)
+            assert rc == 0
+            if i % 8 == 7:
+                for s in range(8):
+                    hp.sample_batch_device_end(s)
+        for s in range(8):
+            hp.sample_batch_device_end(s)
+        hp.synchronize()
+        for i in range(n):
+            got = np.zeros((B, rb), np.uint8)
+            hp.d2h(got, d_c[i])
+            np.testing.assert_array_equal(got, want[i])

@@ -359,14 +359,16 @@ class HipProgram:
         return (out[0], out[1]), (out[2], out[3])
 
     def sample_batch_device_begin(self, slot: int, d_f: int, B: int, num_f: int, key, d_out: int, *,
-                                  shot_offset: int = 0, d_norm_dev: int = 0, inputs_ready: bool = False) -> None:
+                                  shot_offset: int = 0, d_norm_dev: int = 0, inputs_ready: bool = False,
+                                  out_bit_packed: bool = False) -> None:
         """Pipelined launch on the slot's own stream (launches of different slots overlap).  ``d_out``
         is complete only after ``sample_batch_device_end(slot)``.  ``inputs_ready=True``: ``d_f`` is
         already complete and nothing queued on the handle's stream still uses ``d_out`` - the launch
-        then needs no cross-stream event."""
+        then needs no cross-stream event.  ``out_bit_packed=True``: ``d_out`` receives ``uint8[B, ceil(num_outputs/8)]``
+        rows (the reference's ``bit_packed`` layout) instead of the padded 8-byte words."""
         rc = self._lib.tsim_sample_batch_device_begin(
             self._h, slot, d_f, B, num_f, key[0] & 0xFFFFFFFF, key[1] & 0xFFFFFFFF, shot_offset, d_out,
-            d_norm_dev or None, None, 1 if inputs_ready else 0)
+            d_norm_dev or None, None, (1 if inputs_ready else 0) | (2 if out_bit_packed else 0))
         if rc < 0:
             _lib.check(rc, "tsim_sample_batch_device_begin")
 

@@ -370,9 +370,11 @@ k_sample4(Sample4Args A4) {
   }
 
   if (active && !check_block) {
-    uint64_t *orow = A.out + row * A.WO;
-    for (int w = 0; w < A.WO; ++w)
-      orow[w] = (uint64_t)lds_o[(2 * w) * nthr] | ((uint64_t)lds_o[(2 * w + 1) * nthr] << 32);
+    if (A.out) {  // nullptr: the caller wants the bit_packed rows only
+      uint64_t *orow = A.out + row * A.WO;
+      for (int w = 0; w < A.WO; ++w)
+        orow[w] = (uint64_t)lds_o[(2 * w) * nthr] | ((uint64_t)lds_o[(2 * w + 1) * nthr] << 32);
+    }
     store_compact_row(A, row, lds_o, nthr);
   }
 }

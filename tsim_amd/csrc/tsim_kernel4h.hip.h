@@ -336,9 +336,11 @@ __device__ __forceinline__ void sample4h_rows(const SampleArgs &A, int comp4_off
   }
 
   if (wave == 0 && active && !check_block) {
-    uint64_t *orow = A.out + row * A.WO;
-    for (int w = 0; w < A.WO; ++w)
-      orow[w] = (uint64_t)lds_o[(2 * w) * 64] | ((uint64_t)lds_o[(2 * w + 1) * 64] << 32);
+    if (A.out) {
+      uint64_t *orow = A.out + row * A.WO;
+      for (int w = 0; w < A.WO; ++w)
+        orow[w] = (uint64_t)lds_o[(2 * w) * 64] | ((uint64_t)lds_o[(2 * w + 1) * 64] << 32);
+    }
     store_compact_row(A, row, lds_o, 64);
   }
   if (check_block || loop_stride <= 0 || !A.row_index) return;

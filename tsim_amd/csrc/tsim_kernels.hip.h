@@ -41,7 +41,7 @@ enum {
 struct SampleArgs {
   const uint32_t *img;      // program image
   const uint64_t *f;        // [B, WF] packed error-mechanism rows
-  uint64_t *out;            // [B, WO] packed outputs
+  uint64_t *out;            // [B, WO] packed outputs (nullptr when only out_compact is wanted)
   const uint32_t *subkeys;  // [total compiled outputs, 2] Threefry subkeys
   float *norm_dev;          // [n_components] or nullptr
   long long B;              // rows in this launch
@@ -670,9 +670,11 @@ __global__ void __launch_bounds__(256) k_sample(SampleArgs A) {
   }
 
   // the only per-shot HBM write: the packed output row
-  uint64_t *orow = A.out + row * A.WO;
-  for (int w = 0; w < A.WO; ++w)
-    orow[w] = (uint64_t)lds_o[(2 * w) * nthr] | ((uint64_t)lds_o[(2 * w + 1) * nthr] << 32);
+  if (A.out) {  // nullptr: the caller wants the bit_packed rows only
+    uint64_t *orow = A.out + row * A.WO;
+    for (int w = 0; w < A.WO; ++w)
+      orow[w] = (uint64_t)lds_o[(2 * w) * nthr] | ((uint64_t)lds_o[(2 * w + 1) * nthr] << 32);
+  }
   store_compact_row(A, row, lds_o, nthr);
 }
 

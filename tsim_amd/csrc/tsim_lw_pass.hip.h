@@ -100,10 +100,12 @@ __global__ void __launch_bounds__(1024) k_sample_lw(LwArgs L) {
       }
     }
     if (!hard) {
-      uint64_t *orow = A.out + row * A.WO;
-      if (A.WO > 0) orow[0] = (uint64_t)o0 | ((uint64_t)o1 << 32);
-      for (int w = 1; w < A.WO; ++w)
-        orow[w] = (uint64_t)lds_o[(2 * w) * nthr] | ((uint64_t)lds_o[(2 * w + 1) * nthr] << 32);
+      if (A.out) {
+        uint64_t *orow = A.out + row * A.WO;
+        if (A.WO > 0) orow[0] = (uint64_t)o0 | ((uint64_t)o1 << 32);
+        for (int w = 1; w < A.WO; ++w)
+          orow[w] = (uint64_t)lds_o[(2 * w) * nthr] | ((uint64_t)lds_o[(2 * w + 1) * nthr] << 32);
+      }
       if (A.out_compact) {  // words 0 and 1 live in registers here
         uint8_t *dst = A.out_compact + row * A.out_rb;
         for (int k = 0; k < A.out_rb; ++k) {

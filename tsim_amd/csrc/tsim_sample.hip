@@ -208,7 +208,7 @@ int tsim_flush_hard(tsim_program *p) {
 static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_t num_f, uint32_t key_hi,
                          uint32_t key_lo, int64_t shot_offset, uint64_t *d_out, float *d_dev, hipStream_t s,
                          const uint32_t *d_row_index = nullptr, const uint32_t *d_row_count = nullptr,
-                         int slot = 0, const LaunchPlan *plan_in = nullptr) {
+                         int slot = 0, const LaunchPlan *plan_in = nullptr, bool out_bit_packed = false) {
   if (!p->sampleable) return tsim_fail(TSIM_ESTATE, "program has joint-mode components (evaluate-only)");
   if (B < 0 || num_f < 0 || shot_offset < 0) return tsim_fail(TSIM_EINVAL, "negative B/num_f/shot_offset");
   if (p->max_f_index >= num_f)
@@ -263,7 +263,11 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
   a.row_list_cap = 0;
   a.row_slot_begin = 0;
   a.row_slot_end = 0;
-  if (sl.compact_out) {  // tsim_pipeline_set_compact_output: consumed by this launch
+  if (out_bit_packed) {  // TSIM_PIPE_OUT_BIT_PACKED: d_out IS the bit_packed buffer, no padded rows at all
+    a.out = nullptr;
+    a.out_compact = (uint8_t *)d_out;
+    a.out_rb = (p->num_outputs + 7) / 8;
+  } else if (sl.compact_out) {  // tsim_pipeline_set_compact_output: consumed by this launch
     a.out_compact = sl.compact_out;
     a.out_rb = (p->num_outputs + 7) / 8;
     sl.compact_out = nullptr;
@@ -484,7 +488,7 @@ extern "C" int tsim_sample_batch_device_begin(tsim_program *p, int32_t slot, con
     HIP_TRY(hipStreamWaitEvent(s, sl.ev1, 0));
   }
   return launch_sample(p, d_f, B, num_f, key_hi, key_lo, shot_offset, d_out, d_max_norm_dev, s, nullptr, nullptr,
-                       1 + slot, &plan);
+                       1 + slot, &plan, (flags & TSIM_PIPE_OUT_BIT_PACKED) != 0);
 }
 
 extern "C" int tsim_pipeline_lane_stream(tsim_program *p, int32_t lane, void **stream) {

@@ -412,7 +412,10 @@ class _CompiledSamplerBase:
         n_comp = max(1, len(self._program.components))
         total = plan.size * plan.count
         lanes = self._lane_buffers(hp, plan.size * wf * 8)
-        d_rows, d_devs = self._scratch(hp, "rows", total * wo * 8), self._scratch(hp, "devs", plan.count * n_comp * 4)
+        # all columns wanted bit-packed: the kernels write that layout themselves (no padded rows, no compaction pass)
+        direct_packed = packed_columns is not None and packed_columns == n_out
+        row_bytes = (n_out + 7) // 8 if direct_packed else wo * 8
+        d_rows, d_devs = self._scratch(hp, "rows", total * row_bytes + 16), self._scratch(hp, "devs", plan.count * n_comp * 4)
         noise = None if host_noise else self._device_noise_sampler(hp)
         for b in range(plan.count):
             lane = b % _LANES
@@ -428,12 +431,16 @@ class _CompiledSamplerBase:
                 self._noise_key, nk = hp.split_key(self._noise_key)
                 noise.sample_into(lanes[lane].ptr, plan.size, nk)
             hp.sample_batch_device_begin(lane, lanes[lane].ptr, plan.size, num_f, self._next_key(),
-                                         d_rows.ptr + b * plan.size * wo * 8, d_norm_dev=d_devs.ptr + b * n_comp * 4)
+                                         d_rows.ptr + b * plan.size * row_bytes, d_norm_dev=d_devs.ptr + b * n_comp * 4,
+                                         out_bit_packed=direct_packed)
         for lane in range(min(_LANES, plan.count)):
             hp.sample_batch_device_end(lane)
         devs = np.zeros(plan.count * n_comp, dtype=np.float32)
         skip = 1 if rides else 0
-        if packed_columns is not None:  # bit_packed=True of the first columns: compacted on the GPU
+        if direct_packed:
+            out = np.empty((total, row_bytes), dtype=np.uint8)
+            hp.d2h(out, d_rows.ptr)
+        elif packed_columns is not None:  # bit_packed=True of the first columns: compacted on the GPU
             rb = (packed_columns + 7) // 8
             d_c = self._scratch(hp, "compact", total * rb + 16)
             hp.compact_rows_device(d_rows.ptr, total, packed_columns, d_c.ptr, in_words=wo)

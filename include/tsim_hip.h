@@ -120,12 +120,14 @@ int tsim_program_get_mode(const tsim_program *p, int32_t *fast);
 /*
  * Low-weight error-pattern tables (before finalize).  The Bernoulli thresholds p1/prev of
  * _sample_component (sampler.py:54-79) depend on a shot only through the component's selected
- * f bits and the outcome prefix; for f_sel patterns of weight <= max_weight (0..5, as many as fit a
- * 256 MiB table per component; TSIM_AMD_PATTERN_TABLE_MB overrides) they are tabulated at finalize by the sampling kernels' own
+ * f bits and the outcome prefix; for f_sel patterns of weight <= max_weight (0..7, as many as fit a
+ * 1 GiB table per component; TSIM_AMD_PATTERN_TABLE_MB overrides) they are tabulated by the sampling kernels' own
  * arithmetic, and shots carrying such patterns in every component are finished by a light first
  * pass (one Threefry draw + one table read per output); only the remaining rows run the full
  * kernel.  Bit-identical results.  Requires <= 10 outputs and <= 64 parameters per component.
- *   enable: 1 on, 0 off, -1 default (on in TSIM_MODE_AUTO);  max_weight: 0..5, -1 = 5.
+ *   enable: 1 on, 0 off, -1 default (on in TSIM_MODE_AUTO);  max_weight: 0..7 pins the depth; -1 = weight 5 at
+ *   finalize (6 ms for the 35-qubit shape), deepened once to 7 (0.1 s, 0.6 GB) if launches keep leaving more than
+ *   1 % of their rows to the full kernel (dense error patterns).
  * The environment variable TSIM_AMD_PATTERN_TABLES=0/1 overrides `enable`.
  * Launch plan: the hard-row kernel reports the number of hard rows of each launch through mapped
  * host memory; when most rows of recent launches were hard (dense error patterns) the following

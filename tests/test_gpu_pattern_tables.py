@@ -28,7 +28,7 @@ def test_tables_selected_for_c2(hip):
 
 
 @pytest.mark.parametrize("p_bit", [0.0, 0.01, 0.05, 0.2])
-@pytest.mark.parametrize("cap", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("cap", [0, 1, 2, 3, 4, 5, 6, 7])
 def test_c2_every_depth_matches_oracle(hip, p_bit, cap):
     prog, cfg = synth.config_program("C2")
     B = 3000
@@ -36,9 +36,53 @@ def test_c2_every_depth_matches_oracle(hip, p_bit, cap):
     key = prng.key(1234)
     want, wdev = _oracle(prog, f, key)
     hp = hip.HipProgram(prog, pattern_tables=cap)
+    assert hp.info()["pattern_max_weight"] == [cap]
     got, gdev = hp.sample_batch(f, key)
     np.testing.assert_array_equal(got, want)
     np.testing.assert_array_equal(np.asarray(gdev, np.float32), wdev)
+    hp.close()  # weight-7 tables are 0.6 GB: do not keep eight handles alive
+
+
+def test_tables_deepen_on_demand_and_results_do_not_change(hip):
+    """Default depth: 5 at finalize; three launches in a row that leave more than 1 % of their rows to the full
+    kernel make the planner build the weight-6/7 tables.  Every launch - before, during and after - equals the oracle,
+    on the serial and on the pipelined API, and sparse launches afterwards still take the short path."""
+    prog, cfg = synth.config_program("C2")
+    nf, n_out = cfg["num_f"], prog.num_outputs
+    hp = hip.HipProgram(prog)
+    assert hp.info()["pattern_max_weight"] == [5]
+    B = 20_000
+    for i in range(8):
+        f = synth.synth_f(B, nf, 0.12, seed=40 + i)
+        want, wdev = _oracle(prog, f, (i, 5))
+        got, gdev = hp.sample_batch(f, (i, 5))
+        np.testing.assert_array_equal(got, want)
+        np.testing.assert_array_equal(np.asarray(gdev, np.float32), wdev)
+    assert hp.info()["pattern_max_weight"] == [7]
+    assert hp.info()["pattern_table_bytes"] > 400 << 20
+    wf, wo = (nf + 63) // 64, (n_out + 63) // 64
+    for p_bit in (0.02, 0.12, 0.02):
+        bufs = []
+        for i in range(6):
+            f = synth.synth_f(B, nf, p_bit, seed=90 + i)
+            pk = np.zeros((B, wf * 8), np.uint8)
+            q = np.packbits(f, axis=1, bitorder="little")
+            pk[:, : q.shape[1]] = q
+            d_f, d_o = hp.malloc(pk.nbytes), hp.malloc(B * wo * 8)
+            hp.h2d(d_f, pk)
+            hp.sample_batch_device_begin(i, d_f.ptr, B, nf, (i, 9), d_o.ptr)
+            bufs.append((f, d_f, d_o))
+        for i, (f, d_f, d_o) in enumerate(bufs):
+            hp.sample_batch_device_end(i)
+        hp.synchronize()
+        for i, (f, d_f, d_o) in enumerate(bufs):
+            out = np.zeros((B, wo * 8), np.uint8)
+            hp.d2h(out, d_o)
+            got = np.unpackbits(out, axis=1, bitorder="little")[:, :n_out].astype(bool)
+            np.testing.assert_array_equal(got, _oracle(prog, f, (i, 9))[0])
+            d_f.free()
+            d_o.free()
+    hp.close()
 
 
 @pytest.mark.parametrize("mode", ["auto", "rows", "faithful"])

@@ -138,7 +138,7 @@ class HipProgram:
         include/tsim_hip.h.
 
         ``pattern_tables``: None = default (low-weight error-pattern tables on in "auto" mode),
-        False = off, True = on, or an int 0..5 = on with that maximum tabulated weight."""
+        False = off, True = on, or an int 0..7 = on with exactly that maximum tabulated weight (no on-demand deepening)."""
         if mode not in ("auto", "faithful", "rows"):
             raise ValueError("mode must be 'auto', 'faithful' or 'rows'")
         self._lib = _lib.load()

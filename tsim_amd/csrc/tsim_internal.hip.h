@@ -201,6 +201,10 @@ struct tsim_program {
   int lw_direct_prog = 0;     // image offset of the direct-output gather program
   int lw_direct_chunks = 0;
   std::vector<int> lw_wmax;   // per component
+  std::vector<long long> lw_npat;  // per component: tabulated patterns
+  int lw_cap_now = 0, lw_cap_max = 0;  // table depth built / allowed (tsim_tables_extend deepens on demand)
+  long long lw_budget = 0;    // bytes per component
+  int lw_dense_launches = 0;  // consecutive launches whose hard-row share says "deeper tables would pay"
   long long lw_bytes = 0;
   float *d_lw_tab = nullptr;
   // device allocations handed out by tsim_malloc_device and not yet freed: the handle owns them
@@ -237,6 +241,11 @@ void emit_level4(const HostLevel &h, int GT, int nch, const uint32_t *v3recs, st
                  std::vector<uint32_t> &stabs4);
 std::vector<uint32_t> emit_gather_program(std::vector<std::array<int, 3>> e);
 }  // namespace tsimhost
+
+// ---- tsim_tables.hip
+bool tsim_tables_plan(tsim_program *p, int cap, long long budget);
+int tsim_tables_build(tsim_program *p, float **old);
+int tsim_tables_extend(tsim_program *p);
 
 // ---- tsim_sample.hip
 int tsim_flush_hard(tsim_program *p);

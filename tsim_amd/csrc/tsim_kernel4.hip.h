@@ -43,6 +43,7 @@ struct Sample4Args {
   SampleArgs s;
   int comp4_off;   // offset of the v4 component records (C4_WORDS each)
   int has_check;   // 1: the last block replays in-batch shot 0 for the normalisation check
+  uint32_t *feedback;  // optional (two-pass launches served by this kernel alone): [hard rows, longest list, rows]
 };
 
 // a ^ b ^ c in one full-rate VALU op
@@ -222,6 +223,20 @@ k_sample4(Sample4Args A4) {
   const SampleArgs &A = A4.s;
   const int nthr = blockDim.x;
   const bool check_block = A4.has_check && (blockIdx.x == gridDim.x - 1);
+  if (A4.feedback && blockIdx.x == 0 && threadIdx.x < 64 && A.row_lists > 1) {  // launch-plan feedback, as k_sample4h
+    const int lane = threadIdx.x;
+    uint32_t c = lane < A.row_lists ? A.row_count[32u * lane] : 0u, m = c;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      c += (uint32_t)__shfl_xor((int)c, o, 64);
+      m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
+    }
+    if (lane == 0) {
+      A4.feedback[0] = c;
+      A4.feedback[1] = m;
+      A4.feedback[2] = (uint32_t)min(A.B, 0xFFFFFFFFll);
+    }
+  }
   long long row = (long long)blockIdx.x * nthr + threadIdx.x;
   bool active = row < A.B;
   if (A.row_index) {  // row lists (device-side post-selection / hard rows of a two-pass launch)

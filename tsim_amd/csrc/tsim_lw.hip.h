@@ -26,8 +26,8 @@ namespace tsimk {
 // per-component record of the pattern tables (uint32 words, in the program image)
 enum {
   LW_NOUT = 0, LW_F, LW_FSELP /* gather program f row -> x */, LW_OUTPOS, LW_KEYBASE, LW_WMAX,
-  LW_TAB /* float offset into tab */, LW_OFF2 /* index of the first weight-2 pattern */, LW_OFF3, LW_NPAT,
-  LW_FSELN /* chunks of the gather program */, LW_OFF4, LW_OFF5,
+  LW_TAB /* float offset into tab */, LW_BASES /* image offset of 8 words: index of the first pattern of weight w */,
+  LW_RSV0, LW_NPAT, LW_FSELN /* chunks of the gather program */, LW_RSV1, LW_RSV2,
   LW_SELMASK /* image offset of 4 selection-mask words + 4 prefix counts (register first pass), 0 = none */,
   LW_WORDS = 16
 };
@@ -37,7 +37,7 @@ enum {
 //   ctl = src_shift | dst_shift << 8 | dst_word << 16 | src_word << 24
 //   dst_word[dst_shift ..] |= ((f32[src_word] >> src_shift) & mask) ^ flip
 #define TSIMK_LW_MAX_NOUT 10
-#define TSIMK_LW_MAX_WEIGHT 5
+#define TSIMK_LW_MAX_WEIGHT 7
 #define TSIMK_LW_LISTS 64   // hard-row sub-lists (one atomic counter each, 128 bytes apart)
 
 // colex rank of a pattern with sorted set-bit positions b0 < b1 < b2 < b3 < b4 (missing ones passed as 0)
@@ -54,6 +54,18 @@ __host__ __device__ __forceinline__ uint32_t lw_binom4(uint32_t b) { return (lw_
 __host__ __device__ __forceinline__ uint32_t lw_binom5(uint32_t b) {
   const unsigned long long v = (unsigned long long)lw_binom4(b) * (unsigned long long)(b - 4u);  // 0 when C(b,4) == 0
   return (uint32_t)((v * 3435973837ull) >> 34);  // v / 5 for v < 2^32 (magic 0xCCCCCCCD)
+}
+
+// C(b,6) = C(b,5) (b-5) / 6 and C(b,7) = C(b,6) (b-6) / 7 for b <= 64: the products are exact multiples (< 2^32),
+// so the division is a multiplication by the inverse modulo 2^32 (of 3 after halving, of 7)
+__host__ __device__ __forceinline__ uint32_t lw_binom6(uint32_t b) {
+  return b < 6u ? 0u : ((lw_binom5(b) * (b - 5u)) >> 1) * 0xAAAAAAABu;
+}
+__host__ __device__ __forceinline__ uint32_t lw_binom7(uint32_t b) { return b < 7u ? 0u : (lw_binom6(b) * (b - 6u)) * 0xB6DB6DB7u; }
+// C(b, i + 1): the term set bit number i (in ascending order) at f_sel position b adds to the colex rank
+__host__ __device__ __forceinline__ uint32_t lw_rank_term(int i, uint32_t b) {
+  return (i == 0) ? b : (i == 1) ? lw_binom2(b) : (i == 2) ? lw_binom3(b) : (i == 3) ? lw_binom4(b)
+       : (i == 4) ? lw_binom5(b) : (i == 5) ? lw_binom6(b) : lw_binom7(b);
 }
 
 // ---------------------------------------------------------------------------

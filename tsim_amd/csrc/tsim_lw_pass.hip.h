@@ -72,17 +72,15 @@ __global__ void __launch_bounds__(1024) k_sample_lw(LwArgs L) {
       const uint32_t cnt = (uint32_t)__popcll(xf);
       if (cnt > rec[LW_WMAX]) hard = true;
       if (hard) continue;  // needs the full kernel: nothing of this row is written here
-      // colex rank of the (<= 5)-subset
-      uint32_t b0 = 0, b1 = 0, b2 = 0, b3 = 0, b4 = 0;
-      if (cnt >= 1) { b0 = (uint32_t)__builtin_ctzll(xf); xf &= xf - 1ull; }
-      if (cnt >= 2) { b1 = (uint32_t)__builtin_ctzll(xf); xf &= xf - 1ull; }
-      if (cnt >= 3) { b2 = (uint32_t)__builtin_ctzll(xf); xf &= xf - 1ull; }
-      if (cnt >= 4) { b3 = (uint32_t)__builtin_ctzll(xf); xf &= xf - 1ull; }
-      if (cnt >= 5) { b4 = (uint32_t)__builtin_ctzll(xf); }
-      const uint32_t base = (cnt == 0) ? 0u : (cnt == 1) ? 1u : (cnt == 2) ? rec[LW_OFF2] : (cnt == 3) ? rec[LW_OFF3]
-                          : (cnt == 4) ? rec[LW_OFF4] : rec[LW_OFF5];
-      const uint32_t pat = base + b0 + (cnt >= 2 ? lw_binom2(b1) : 0u) + (cnt >= 3 ? lw_binom3(b2) : 0u) +
-                           (cnt >= 4 ? lw_binom4(b3) : 0u) + (cnt >= 5 ? lw_binom5(b4) : 0u);
+      // colex rank of the pattern: set bits in ascending order, bit number i at position b adds C(b, i + 1)
+      uint32_t pat = (img + rec[LW_BASES])[cnt];
+#pragma unroll
+      for (int i = 0; i < TSIMK_LW_MAX_WEIGHT; ++i) {
+        if (cnt > (uint32_t)i) {
+          pat += lw_rank_term(i, (uint32_t)__builtin_ctzll(xf));
+          xf &= xf - 1ull;
+        }
+      }
       const uint32_t n_out = rec[LW_NOUT];
       cptr outpos = img + rec[LW_OUTPOS];
       const uint32_t keybase = rec[LW_KEYBASE];
@@ -202,8 +200,7 @@ __global__ void __launch_bounds__(1024) k_sample_lw_reg(LwArgs L) {
       }
       if (cnt > rec[LW_WMAX]) hard = true;
       if (hard) continue;  // needs the full kernel: nothing of this row is written here
-      uint32_t pat = (cnt == 0) ? 0u : (cnt == 1) ? 1u : (cnt == 2) ? rec[LW_OFF2] : (cnt == 3) ? rec[LW_OFF3]
-                     : (cnt == 4) ? rec[LW_OFF4] : rec[LW_OFF5];
+      uint32_t pat = (img + rec[LW_BASES])[cnt];
 #pragma unroll
       for (int i = 0; i < TSIMK_LW_MAX_WEIGHT; ++i) {
         if (cnt > (uint32_t)i) {
@@ -223,7 +220,7 @@ __global__ void __launch_bounds__(1024) k_sample_lw_reg(LwArgs L) {
           cur &= cur - 1u;
 #pragma unroll
           for (int w = 0; w < WF32; ++w) m[w] = (wi == w) ? cur : m[w];
-          pat += (i == 0) ? b : (i == 1) ? lw_binom2(b) : (i == 2) ? lw_binom3(b) : (i == 3) ? lw_binom4(b) : lw_binom5(b);
+          pat += lw_rank_term(i, b);
         }
       }
       const uint32_t n_out = rec[LW_NOUT];

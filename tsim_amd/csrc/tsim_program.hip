@@ -180,62 +180,8 @@ extern "C" int tsim_program_pattern_table_info(const tsim_program *p, int32_t *e
     for (size_t i = 0; i < p->comps.size(); ++i) max_weight[i] = p->lw ? p->lw_wmax[i] : -1;
   return TSIM_OK;
 }
-// ---------------------------------------------------------------------------
-// low-weight pattern tables (tsim_lw.hip.h): enumerate the patterns of every component in table
-// order and let k_lw_build fill the thresholds with the sampling kernels' own arithmetic
-// ---------------------------------------------------------------------------
-static int build_pattern_tables(tsim_program *p, const std::vector<long long> &npat) {
-  HIP_TRY(hipMalloc((void **)&p->d_lw_tab, std::max<size_t>(16, (size_t)p->lw_bytes)));
-  long long tab_off = 0;
-  for (size_t ci = 0; ci < p->comps.size(); ++ci) {
-    const HostComponent &c = p->comps[ci];
-    const int F = c.F, wmax = p->lw_wmax[ci];
-    std::vector<unsigned long long> pats;
-    pats.reserve((size_t)npat[ci]);
-    pats.push_back(0ull);
-    if (wmax >= 1)
-      for (int b0 = 0; b0 < F; ++b0) pats.push_back(1ull << b0);
-    if (wmax >= 2)
-      for (int b1 = 1; b1 < F; ++b1)
-        for (int b0 = 0; b0 < b1; ++b0) pats.push_back((1ull << b1) | (1ull << b0));
-    if (wmax >= 3)
-      for (int b2 = 2; b2 < F; ++b2)
-        for (int b1 = 1; b1 < b2; ++b1)
-          for (int b0 = 0; b0 < b1; ++b0) pats.push_back((1ull << b2) | (1ull << b1) | (1ull << b0));
-    if (wmax >= 4)
-      for (int b3 = 3; b3 < F; ++b3)
-        for (int b2 = 2; b2 < b3; ++b2)
-          for (int b1 = 1; b1 < b2; ++b1)
-            for (int b0 = 0; b0 < b1; ++b0)
-              pats.push_back((1ull << b3) | (1ull << b2) | (1ull << b1) | (1ull << b0));
-    if (wmax >= 5)
-      for (int b4 = 4; b4 < F; ++b4)
-        for (int b3 = 3; b3 < b4; ++b3)
-          for (int b2 = 2; b2 < b3; ++b2)
-            for (int b1 = 1; b1 < b2; ++b1)
-              for (int b0 = 0; b0 < b1; ++b0)
-                pats.push_back((1ull << b4) | (1ull << b3) | (1ull << b2) | (1ull << b1) | (1ull << b0));
-    if ((long long)pats.size() != npat[ci]) return tsim_fail(TSIM_ESTATE, "pattern enumeration mismatch");
-    unsigned long long *d_pats = nullptr;
-    HIP_TRY(hipMalloc((void **)&d_pats, pats.size() * 8));
-    HIP_TRY(hipMemcpy(d_pats, pats.data(), pats.size() * 8, hipMemcpyHostToDevice));
-    LwBuildArgs a;
-    a.img = p->d_img;
-    a.patbits = d_pats;
-    a.tab = p->d_lw_tab + tab_off;
-    a.comp_off = p->comp_off + (int)ci * C_WORDS;
-    a.npat = (int)npat[ci];
-    const long long lanes = npat[ci] << c.n_out;
-    if (int r = tsim_launch_lw_build(p->comp_w[ci], p->fast, a, lanes, p->stream)) {
-      (void)hipFree(d_pats);
-      return r;
-    }
-    hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
-    (void)hipFree(d_pats);
-    if (e != hipSuccess) return tsim_fail(TSIM_EHIP, "pattern table build failed: %s", hipGetErrorString(e));
-    tab_off += lanes;
-  }
+// launch-plan feedback buffer (mapped pinned host memory the hard-row kernels write)
+static int alloc_feedback(tsim_program *p) {
   if (p->v4) {
     void *h = nullptr;
     if (hipHostMalloc(&h, 64, hipHostMallocMapped) == hipSuccess) {
@@ -446,7 +392,6 @@ retry_pack:
   p->lw = false;
   p->lw_wmax.clear();
   p->lw_bytes = 0;
-  std::vector<long long> lw_npat;
   std::vector<std::vector<std::array<int, 3>>> lw_fsel_progs;
   {
     bool want = p->lw_request < 0 ? (p->mode == TSIM_MODE_AUTO) : (p->lw_request != 0);
@@ -455,52 +400,32 @@ retry_pack:
     for (auto &c : p->comps)
       ok = ok && (c.n_levels == c.n_out + 1) && c.n_out <= TSIMK_LW_MAX_NOUT && c.F + c.n_out <= 64;
     if (ok) {
-      const int cap = p->lw_weight_cap < 0 ? TSIMK_LW_MAX_WEIGHT : std::min(p->lw_weight_cap, TSIMK_LW_MAX_WEIGHT);
-      // bytes per component.  Patterns are stored weight by weight, so the rows most shots read (weight
-      // 0..2) are a small cache-resident prefix whatever the total; the heavier tail is read rarely
-      long long budget = 256ll << 20;
-      if (const char *e = getenv("TSIM_AMD_PATTERN_TABLE_MB")) budget = std::max(1ll, atoll(e)) << 20;
+      // depth: the caller's, or 5 now and up to TSIMK_LW_MAX_WEIGHT on demand (tsim_tables.hip).  Patterns are
+      // stored weight by weight, so the rows most shots read (weight 0..2) are a small cache-resident prefix
+      // whatever the total; the heavier tail is read rarely.
+      const bool pinned = p->lw_weight_cap >= 0;
+      p->lw_cap_max = pinned ? std::min(p->lw_weight_cap, TSIMK_LW_MAX_WEIGHT) : TSIMK_LW_MAX_WEIGHT;
+      p->lw_cap_now = pinned ? p->lw_cap_max : std::min(5, p->lw_cap_max);
+      p->lw_budget = 1024ll << 20;  // per component (4 x per program): HBM is 288 GB, and only the prefix is hot
+      if (const char *e = getenv("TSIM_AMD_PATTERN_TABLE_MB")) p->lw_budget = std::max(1ll, atoll(e)) << 20;
       while (img.size() % 16) img.push_back(0u);
       p->lw_off = (int)img.size();
-      img.resize(img.size() + p->comps.size() * LW_WORDS, 0u);
-      long long tab_off = 0;
+      img.resize(img.size() + p->comps.size() * (LW_WORDS + 8), 0u);  // records, then 8 base words per component
       for (size_t ci = 0; ci < p->comps.size(); ++ci) {
         const HostComponent &c = p->comps[ci];
-        const long long F = c.F;
-        const long long cnt[6] = {1, F, F * (F - 1) / 2, F * (F - 1) * (F - 2) / 6,
-                                  F * (F - 1) * (F - 2) * (F - 3) / 24,
-                                  F * (F - 1) * (F - 2) * (F - 3) * (F - 4) / 120};
-        long long npat = 0;
-        int wmax = -1;
-        for (int w = 0; w <= cap; ++w) {
-          const long long bytes = ((npat + cnt[w]) << c.n_out) * 4;
-          if (bytes > budget || (w > 1 && tab_off * 4 + bytes > 4 * budget)) break;  // per component / all together
-          npat += cnt[w];
-          wmax = w;
-        }
-        if (wmax < 0) { ok = false; break; }
         const uint32_t *crec = &img[p->comp_off + ci * C_WORDS];
         uint32_t *r = &img[p->lw_off + ci * LW_WORDS];
         r[LW_NOUT] = (uint32_t)c.n_out;
         r[LW_F] = (uint32_t)c.F;
-        lw_fsel_progs.push_back({});
-        for (int j = 0; j < c.F; ++j) lw_fsel_progs.back().push_back({c.f_selection[j], j, 0});
         r[LW_OUTPOS] = crec[C_OUTPOS];
         r[LW_KEYBASE] = crec[C_KEYBASE];
-        r[LW_WMAX] = (uint32_t)wmax;
-        r[LW_TAB] = (uint32_t)tab_off;
-        r[LW_OFF2] = (uint32_t)(1 + F);
-        r[LW_OFF3] = (uint32_t)(1 + F + cnt[2]);
-        r[LW_OFF4] = (uint32_t)(1 + F + cnt[2] + cnt[3]);
-        r[LW_OFF5] = (uint32_t)(1 + F + cnt[2] + cnt[3] + cnt[4]);
-        r[LW_NPAT] = (uint32_t)npat;
-        p->lw_wmax.push_back(wmax);
-        lw_npat.push_back(npat);
-        tab_off += npat << c.n_out;
+        r[LW_BASES] = (uint32_t)(p->lw_off + p->comps.size() * LW_WORDS + ci * 8);
+        lw_fsel_progs.push_back({});
+        for (int j = 0; j < c.F; ++j) lw_fsel_progs.back().push_back({c.f_selection[j], j, 0});
       }
+      ok = tsim_tables_plan(p, p->lw_cap_now, p->lw_budget);
       if (ok) {
         p->lw = true;
-        p->lw_bytes = tab_off * 4;
         // gather programs: direct outputs, then every component's f_sel
         std::vector<std::array<int, 3>> de;
         for (int j = 0; j < p->n_direct; ++j) de.push_back({p->direct_f[j], p->output_order[j], p->direct_flips[j] ? 1 : 0});
@@ -573,7 +498,8 @@ retry_pack:
   HIP_TRY(hipMalloc((void **)&p->d_dev, std::max<size_t>(1, p->comps.size()) * 4));
   HIP_TRY(hipMemset(p->d_dev, 0, std::max<size_t>(1, p->comps.size()) * 4));
   if (p->lw) {
-    if (int r = build_pattern_tables(p, lw_npat)) return r;
+    if (int r = tsim_tables_build(p, nullptr)) return r;
+    if (int r = alloc_feedback(p)) return r;
   }
   p->finalized = true;
   return TSIM_OK;

@@ -91,6 +91,7 @@ static int slot_prepare(tsim_program *p, int slot, size_t hard_bytes) {
 //    lane wait for them.
 struct LaunchPlan {
   bool use_tables = false, need_overflow = true, defer = false;
+  bool hard_kernel = true;  // the NW-waves-per-64-rows kernel for the head of every list (few hard rows: latency)
   uint32_t fb_max = 0xFFFFFFFFu;
   int lists = TSIMK_LW_LISTS;  // hard-row sub-lists of this launch: about 40 expected rows each
 };
@@ -99,8 +100,23 @@ static LaunchPlan make_plan(tsim_program *p, bool has_row_index, bool pipelined)
   LaunchPlan pl;
   pl.use_tables = p->lw;
   if (p->lw && p->h_feedback && p->knobs.adaptive) {
-    const uint32_t fb_sum = p->h_feedback[0], fb_max = p->h_feedback[1], fb_rows = p->h_feedback[2];
-    const bool known = fb_rows != 0xFFFFFFFFu && fb_rows > 0u && fb_sum != 0xFFFFFFFFu;
+    uint32_t fb_sum = p->h_feedback[0], fb_max = p->h_feedback[1], fb_rows = p->h_feedback[2];
+    bool known = fb_rows != 0xFFFFFFFFu && fb_rows > 0u && fb_sum != 0xFFFFFFFFu;
+    // More than 1 % of the rows hard, three launches in a row, and deeper tables are allowed: build them now
+    // (once; every lane is drained first because the records in the device image are rewritten).
+    if (known && p->lw_cap_now < p->lw_cap_max && !has_row_index) {
+      p->lw_dense_launches = ((double)fb_sum > 0.01 * (double)fb_rows) ? p->lw_dense_launches + 1 : 0;
+      if (p->lw_dense_launches >= 3) {
+        p->lw_dense_launches = 0;
+        if (tsim_synchronize(p) == TSIM_OK && tsim_tables_extend(p) == TSIM_OK) {
+          for (int i = 0; i < 3; ++i) p->h_feedback[i] = 0xFFFFFFFFu;  // the old counts describe the old tables
+          p->lw_direct_left = 0;
+          known = false;
+        }
+      }
+    }
+    // Many hard rows: they are throughput work for the full kernel, not latency work for the 8-waves-per-group one
+    pl.hard_kernel = !(known && fb_sum > 16384u);
     bool dense = false;
     if (p->lw_direct_left > 0) {
       --p->lw_direct_left;
@@ -121,7 +137,7 @@ static LaunchPlan make_plan(tsim_program *p, bool has_row_index, bool pipelined)
       const uint32_t est_max = (uint32_t)std::min<unsigned long long>(0xFFFFFFFFull, (unsigned long long)fb_max * last / (uint32_t)pl.lists + 16u);
       pl.need_overflow = !(pl.lists >= (int)last ? fb_max <= 192u : est_max <= 192u);
     }
-    pl.defer = pipelined && pl.use_tables && !dense && !pl.need_overflow && p->knobs.defer && p->knobs.hard_kernel &&
+    pl.defer = pipelined && pl.use_tables && !dense && !pl.need_overflow && pl.hard_kernel && p->knobs.defer && p->knobs.hard_kernel &&
                p->v4 && !(p->profiling && !p->prof_light);
   }
   return pl;
@@ -362,11 +378,12 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
     a4.s = a;
     a4.comp4_off = p->comp4_off;
     a4.has_check = has_check ? 1 : 0;
+    a4.feedback = (a.row_lists > 1 && !(p->knobs.hard_kernel && plan.hard_kernel)) ? p->d_feedback : nullptr;
     const int blk = p->knobs.v4_block;
     const size_t tile_bytes = std::max((size_t)p->v4_max_nch * 16, (size_t)p->v4_max_sent) * p->v4_gt * 16;
     const size_t lds4 = (size_t)(2 * a.WF + 2 * a.WO) * blk * 4 + 2 * tile_bytes;
     if (lds4 > 64 * 1024) return tsim_fail(TSIM_ENOTSUP, "v4 kernel needs %zu B of LDS", lds4);
-    if (a.row_lists > 1 && p->knobs.hard_kernel) {
+    if (a.row_lists > 1 && p->knobs.hard_kernel && plan.hard_kernel) {
       // short row lists (second pass of a two-pass launch): NW waves per 64 rows, tsim_kernel4h.hip.h
       constexpr int NW = TSIM_HARD_NW;
       hard_geometry(p, a.WF, a.WO);

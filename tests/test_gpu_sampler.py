@@ -207,8 +207,9 @@ def test_compact_rows_equals_numpy_packbits(hip, nbits, B):
     np.testing.assert_array_equal(got, pk)
 
 
+@pytest.mark.parametrize("noise", ["device", "host"])
 @pytest.mark.parametrize("append", [False, True])
-def test_bit_packed_device_fast_path_equals_packbits(hip, append):
+def test_bit_packed_device_fast_path_equals_packbits(hip, append, noise):
     """bit_packed=True with device noise takes the compact-rows path: same bytes as packing the
     unpacked result on the host (sampler.py:665-669)."""
     from tsim_amd import synth
@@ -217,8 +218,8 @@ def test_bit_packed_device_fast_path_equals_packbits(hip, append):
     nf = cfg["num_f"]
     probs = [np.array([0.98, 0.02]) for _ in range(nf)]
     et = np.eye(nf, dtype=np.uint8)
-    a = CompiledDetectorSampler(prog, channel_probs=probs, error_transform=et, seed=5, noise="device")
-    b = CompiledDetectorSampler(prog, channel_probs=probs, error_transform=et, seed=5, noise="device")
+    a = CompiledDetectorSampler(prog, channel_probs=probs, error_transform=et, seed=5, noise=noise)
+    b = CompiledDetectorSampler(prog, channel_probs=probs, error_transform=et, seed=5, noise=noise)
     import warnings
 
     with warnings.catch_warnings():
@@ -226,3 +227,30 @@ def test_bit_packed_device_fast_path_equals_packbits(hip, append):
         packed = a.sample(5003, batch_size=2048, bit_packed=True, append_observables=append)
         plain = b.sample(5003, batch_size=2048, append_observables=append)
     np.testing.assert_array_equal(packed, np.packbits(plain, axis=1, bitorder="little"))
+
+
+def test_host_noise_device_route_equals_oracle_twin_at_scale(hip, monkeypatch):
+    """The product route (native PCG64 channel stream -> packed rows -> pipelined launches -> one download) against
+    the seam route driven by the oracle with numpy's generator: same seed, same batch size -> same bits, with and
+    without the reference row and under post-selection (gather / dense sampling / scatter on the device)."""
+    prog, cfg = synth.config_program("C2")
+    nf = cfg["num_f"]
+    probs = [error_probs(0.03)] * (nf - 2) + [pauli_channel_1_probs(0.01, 0.02, 0.005)]
+    et = np.eye(nf, dtype=np.uint8)
+    mask = np.zeros(15, bool)
+    mask[[0, 3]] = True
+    cases = [dict(append_observables=True),
+             dict(separate_observables=True, use_detector_reference_sample=True, use_observable_reference_sample=True),
+             dict(append_observables=True, postselection_mask=mask),
+             dict(append_observables=True, postselection_mask=mask, use_detector_reference_sample=True)]
+    got = [CompiledDetectorSampler(prog, channel_probs=probs, error_transform=et, seed=21).sample(7001, batch_size=2000, **kw)
+           for kw in cases]
+    monkeypatch.setattr(sampler_module, "sample_program", oracle_sample_program)
+    for kw, g in zip(cases, got):
+        s = CompiledDetectorSampler(prog, channel_probs=probs, error_transform=et, seed=21)
+        s._channel_sampler._native = None  # numpy's own generator on the twin
+        w = s.sample(7001, batch_size=2000, **kw)
+        if isinstance(g, tuple):
+            assert all(np.array_equal(x, y) for x, y in zip(g, w))
+        else:
+            assert np.array_equal(g, w)

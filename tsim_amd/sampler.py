@@ -602,7 +602,7 @@ class CompiledDetectorSampler(_CompiledSamplerBase):
             rows = rows ^ flip
         else:
             width = n_out if append_observables else nd
-            if (bit_packed and self._noise == "device" and not separate_observables and not prepend_observables
+            if (bit_packed and not separate_observables and not prepend_observables
                     and width > 0 and shots > 0 and self._program.components and not self._seam_replaced()):
                 # the wanted columns are a prefix of the packed device rows: compact there, move width/8 bytes per shot
                 _check_request(shots, batch_size)

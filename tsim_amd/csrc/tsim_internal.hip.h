@@ -133,6 +133,7 @@ struct tsim_program {
   int lw_request = -1;        // -1 default (on in TSIM_MODE_AUTO), 0 off, 1 on
   int lw_weight_cap = -1;     // -1 = TSIMK_LW_MAX_WEIGHT
   bool lw = false;            // tables built, pass 1 active
+  int lw_binom_off = 0;       // image offset of the binomial table of the register first pass
   bool lw_reg = false;        // the register form of pass 1 applies (narrow f rows, ascending f_selection)
   // Launch slots: slot 0 serves the serial API (everything on the caller's stream); slots 1..4 serve
   // tsim_sample_batch_device_begin/_end: a slot's launches run on the slot's own stream (`side`) so

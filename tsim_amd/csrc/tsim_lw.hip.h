@@ -130,6 +130,7 @@ struct LwArgs {
   uint32_t *ctl;          // ctl[32 k] = entries of list k (zeroed by the caller), ctl[32 LISTS] = check row
   int list_cap;
   uint32_t *ctl_next;     // the counter set of the NEXT launch: reset here (nobody else touches it now)
+  int binom_off;          // image offset of the binomial table C(b, k + 1), [8][64] words (register first pass)
   int n_lists;            // sub-lists in use (power of two <= TSIMK_LW_LISTS): few hard rows -> few lists,
                           // so that the 64-row blocks of the second pass are well filled
 };

@@ -139,22 +139,42 @@ __global__ void __launch_bounds__(1024) k_sample_lw(LwArgs L) {
 //     of every lane running the whole gather program (one run per contiguous bit field, ~16 for C2).
 // Same thresholds, same Threefry draws, same hard-row protocol as k_sample_lw.
 // ---------------------------------------------------------------------------
+// word `sw` (wave-uniform) of the f row.  Written as a select tree over four SCALARS on purpose: an array indexed
+// through a compare chain is recognised as dynamic indexing, and the compiler then parks the whole row in LDS
+// (measured: 46.8 instead of 21.7 us for 128-bit rows).
 template <int WF32>
-__device__ __forceinline__ void lw_gather_reg(cptr prog, uint32_t nchunks, const uint32_t (&fw)[WF32], uint32_t &a0,
-                                              uint32_t &a1) {
+__device__ __forceinline__ uint32_t lw_pick(uint32_t sw, uint32_t f0, uint32_t f1, uint32_t f2, uint32_t f3) {
+  const uint32_t lo = (sw & 1u) ? f1 : f0;
+  if constexpr (WF32 <= 2) return lo;
+  const uint32_t hi = (sw & 1u) ? f3 : f2;
+  return (sw & 2u) ? hi : lo;
+}
+
+template <int WF32>
+__device__ __forceinline__ void lw_gather_reg(cptr prog, uint32_t nchunks, uint32_t f0, uint32_t f1, uint32_t f2,
+                                              uint32_t f3, uint32_t &a0, uint32_t &a1) {
   for (uint32_t c = 0; c < nchunks; ++c) {
     const lw_u32x16 q = *(lw_cptr16)(prog + 16u * c);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const uint32_t ctl = q[4 * k];
-      const uint32_t sw = ctl >> 24;  // wave-uniform: a scalar select
-      uint32_t src = fw[0];
-#pragma unroll
-      for (int w = 1; w < WF32; ++w) src = (sw == (uint32_t)w) ? fw[w] : src;
+      const uint32_t src = lw_pick<WF32>(ctl >> 24, f0, f1, f2, f3);
       const uint32_t v = (((src >> (ctl & 31u)) & q[4 * k + 1]) ^ q[4 * k + 2]) << ((ctl >> 8) & 31u);
       if (((ctl >> 16) & 255u) == 0u) a0 |= v;
       else a1 |= v;
     }
+  }
+}
+
+// the lane's set bits of one masked f word: each adds C(position inside f_sel, ordinal + 1) to the colex rank
+__device__ __forceinline__ void lw_rank_word(uint32_t mw, uint32_t sw, uint32_t base, const uint32_t *binom_lds, uint32_t &ord,
+                                             uint32_t &pat) {
+  while (mw) {
+    const uint32_t p = (uint32_t)__builtin_ctz(mw);
+    const uint32_t b = base + (uint32_t)__builtin_popcount(sw & ((1u << p) - 1u));
+    pat += binom_lds[ord * 64u + b];
+    ++ord;
+    mw &= mw - 1u;
   }
 }
 
@@ -173,55 +193,59 @@ __global__ void __launch_bounds__(1024) k_sample_lw_reg(LwArgs L) {
 
   if (blockIdx.x == 0 && threadIdx.x <= TSIMK_LW_LISTS)
     L.ctl_next[32u * threadIdx.x] = (threadIdx.x == TSIMK_LW_LISTS) ? 0xFFFFFFFFu : 0u;  // last: "no check row"
+  // C(b, k + 1) for b < 64, k < 8 (packer: tsim_program.hip).  Every WAVE writes the whole 2 KB table itself (all
+  // waves store the same values) and only ever reads after its own stores - LDS operations of one wave are in
+  // order - so no block barrier is needed: a wave starts as soon as ITS two 16-byte loads are back.
+  __shared__ uint4 binom_lds4[128];
+  {
+    const uint4 *src = reinterpret_cast<const uint4 *>(A.img + L.binom_off);
+    const int lane = threadIdx.x & 63;
+    binom_lds4[lane] = src[lane];
+    binom_lds4[64 + lane] = src[64 + lane];
+    __builtin_amdgcn_wave_barrier();
+  }
+  const uint32_t *binom_lds = reinterpret_cast<const uint32_t *>(binom_lds4);
   bool hard = false;
   if (active) {
-    uint32_t fw[WF32];
-    const uint64_t *frow = A.f + row * (WF32 / 2);
-#pragma unroll
-    for (int w = 0; w < WF32 / 2; ++w) {
-      const uint64_t v = frow[w];
-      fw[2 * w] = (uint32_t)v;
-      fw[2 * w + 1] = (uint32_t)(v >> 32);
+    uint32_t f0, f1, f2 = 0u, f3 = 0u;  // scalars, not an array (see lw_pick)
+    {
+      const uint64_t *frow = A.f + row * (WF32 / 2);
+      const uint64_t v0 = frow[0];
+      f0 = (uint32_t)v0;
+      f1 = (uint32_t)(v0 >> 32);
+      if constexpr (WF32 == 4) {
+        const uint64_t v1 = frow[1];
+        f2 = (uint32_t)v1;
+        f3 = (uint32_t)(v1 >> 32);
+      }
     }
     hard = L.has_check && slot == 0;
     if (hard) L.ctl[32 * TSIMK_LW_LISTS] = (uint32_t)row;
     uint32_t o0 = 0, o1 = 0;
-    lw_gather_reg<WF32>(img + L.direct_prog, (uint32_t)L.direct_chunks, fw, o0, o1);  // K14, sampler.py:140-145
+    lw_gather_reg<WF32>(img + L.direct_prog, (uint32_t)L.direct_chunks, f0, f1, f2, f3, o0, o1);  // K14, sampler.py:140-145
 
     for (int ci = 0; ci < A.n_comp; ++ci) {
       cptr rec = img + L.lw_off + ci * LW_WORDS;
       cptr sel = img + rec[LW_SELMASK];  // sel[0..3]: masks, sel[4..7]: selected bits in lower words
-      uint32_t m[WF32];
-      uint32_t cnt = 0;
-#pragma unroll
-      for (int w = 0; w < WF32; ++w) {
-        m[w] = fw[w] & sel[w];
-        cnt += (uint32_t)__builtin_popcount(m[w]);
+      const uint32_t m0 = f0 & sel[0], m1 = f1 & sel[1];
+      uint32_t m2 = 0u, m3 = 0u;
+      uint32_t cnt = (uint32_t)__builtin_popcount(m0) + (uint32_t)__builtin_popcount(m1);
+      if constexpr (WF32 == 4) {
+        m2 = f2 & sel[2];
+        m3 = f3 & sel[3];
+        cnt += (uint32_t)__builtin_popcount(m2) + (uint32_t)__builtin_popcount(m3);
       }
       if (cnt > rec[LW_WMAX]) hard = true;
       if (hard) continue;  // needs the full kernel: nothing of this row is written here
+      // colex rank = sum over the set bits, in ascending order, of C(position inside f_sel, ordinal + 1): each lane
+      // walks ITS OWN set bits word by word; the binomials come from a 2 KB LDS table (no per-lane multiplications)
       uint32_t pat = (img + rec[LW_BASES])[cnt];
-#pragma unroll
-      for (int i = 0; i < TSIMK_LW_MAX_WEIGHT; ++i) {
-        if (cnt > (uint32_t)i) {
-          // lowest set bit over the words -> its index inside f_sel
-          uint32_t cur = m[WF32 - 1], sw = sel[WF32 - 1], base = sel[4 + WF32 - 1];
-          int wi = WF32 - 1;
-#pragma unroll
-          for (int w = WF32 - 2; w >= 0; --w) {
-            const bool nz = m[w] != 0u;
-            cur = nz ? m[w] : cur;
-            sw = nz ? sel[w] : sw;
-            base = nz ? sel[4 + w] : base;
-            wi = nz ? w : wi;
-          }
-          const uint32_t p = (uint32_t)__builtin_ctz(cur);
-          const uint32_t b = base + (uint32_t)__builtin_popcount(sw & ((1u << p) - 1u));
-          cur &= cur - 1u;
-#pragma unroll
-          for (int w = 0; w < WF32; ++w) m[w] = (wi == w) ? cur : m[w];
-          pat += lw_rank_term(i, b);
-        }
+      uint32_t ord = 0;
+      lw_rank_word(m0, sel[0], 0u, binom_lds, ord, pat);
+      lw_rank_word(m1, sel[1], sel[5], binom_lds, ord, pat);
+      if constexpr (WF32 == 4) {
+        lw_rank_word(m2, sel[2], sel[6], binom_lds, ord, pat);
+        lw_rank_word(m3, sel[3], sel[7], binom_lds, ord, pat);
       }
       const uint32_t n_out = rec[LW_NOUT];
       cptr outpos = img + rec[LW_OUTPOS];

@@ -446,6 +446,16 @@ retry_pack:
         p->lw_reg = p->max_f_index < 128 && p->num_outputs <= 64;
         for (auto &c : p->comps)
           for (int j = 1; j < c.F; ++j) p->lw_reg = p->lw_reg && c.f_selection[j] > c.f_selection[j - 1];
+        if (p->lw_reg) {  // binomial table of the rank computation: C(b, k + 1), k < 8, b < 64
+          while (img.size() % 16) img.push_back(0u);
+          p->lw_binom_off = (int)img.size();
+          for (int k = 0; k < 8; ++k)
+            for (int b = 0; b < 64; ++b) {
+              unsigned long long c = 1;
+              for (int i = 1; i <= k + 1; ++i) c = c * (unsigned long long)(b - (k + 1) + i > 0 ? b - (k + 1) + i : 0) / (unsigned long long)i;
+              img.push_back(b >= k + 1 ? (uint32_t)c : 0u);
+            }
+        }
         if (p->lw_reg)
           for (size_t ci = 0; ci < p->comps.size(); ++ci) {
             uint32_t sel[8] = {0, 0, 0, 0, 0, 0, 0, 0};

@@ -343,6 +343,7 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
     sl.parity ^= 1;
     l.list_cap = (int)list_cap;
     l.n_lists = n_lists;
+    l.binom_off = p->lw_binom_off;
     const size_t lds1 = (size_t)(2 * a.WF + 2 * a.WO) * blk1 * 4;
     if (p->lw_reg && p->knobs.lw_reg && (a.WF == 1 || a.WF == 2) && a.WO == 1) {
       // narrow rows: everything in registers, no LDS

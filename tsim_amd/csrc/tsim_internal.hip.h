@@ -114,6 +114,7 @@ struct tsim_program {
   int mode = TSIM_MODE_AUTO;  // requested
   bool fast = false;          // chosen at finalize: counting formulation (eval_level_fast)
   bool v4 = false;            // chunk-table layout present (k_sample4)
+  bool v4w = false;           // wide components: column tables only (k_sample4w + row kernel for the overflow)
   int v4_gt = 4;              // graphs per LDS tile
   int comp4_off = 0;
   int v4_max_nch = 1;
@@ -192,6 +193,7 @@ struct tsim_program {
     bool merge_lists = true;  // TSIM_AMD_MERGE_LISTS=0: always TSIMK_LW_LISTS hard-row sub-lists
     int list_rows = 40;       // TSIM_AMD_LIST_ROWS: expected hard rows per list the list count aims at
     int min_lists = 4;        // TSIM_AMD_MIN_LISTS (power of two >= 2)
+    bool wide = true;         // TSIM_AMD_WIDE=0: wide components on the row kernel alone (no sparse-column pass)
     bool lw_reg = true;       // TSIM_AMD_LW_REG=0: LDS-staged first pass even where the register form applies
     bool defer = true;        // TSIM_AMD_DEFER_HARD=0: every pipelined launch runs its own second pass
     int defer_group = 4;      // TSIM_AMD_DEFER_GROUP: launches per deferred hard-row batch (<= TSIMK_H_MAX_CTX)
@@ -236,7 +238,7 @@ namespace tsimhost {
 void pack_level(HostLevel &h, int W);
 bool level_fast_eligible(const HostLevel &h);
 bool pack_level_fast(HostLevel &h, int W, std::vector<uint32_t> &tables, bool &fixed_out, int &frame_out);
-bool level_v4_eligible(const HostLevel &h);
+bool level_v4_eligible(const HostLevel &h, bool wide = false);
 void emit_level4(const HostLevel &h, int GT, int nch, const uint32_t *v3recs, std::vector<uint32_t> &recs4,
                  std::vector<uint32_t> &tabs4, int &nch_out, int &ntiles_out, int sparse_F,
                  std::vector<uint32_t> &stabs4);

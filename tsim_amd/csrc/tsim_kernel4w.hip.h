@@ -1,0 +1,176 @@
+// tsim_kernel4w.hip.h - sparse-column sampling kernel for WIDE components (more than 64 parameters), gfx950.
+//
+// The chunk-table kernel (k_sample4) forms every parity of a graph as one 128-bit word Y_g = R_g x from 4-bit
+// chunks of x - ceil(P/4) LDS reads per graph, which stops paying beyond 64 parameters (C5, the d=5 surface code
+// with an injected T: F = 200 selected f bits, 3 outputs).  But x is SPARSE there: a handful of error bits plus the
+// outcome bits.  So Y_g = XOR over the lane's set f bits j of COLUMN_j(R_g) (one 16-byte LDS read each, from the
+// same per-tile column tables k_sample4 uses for its sparse-f path) XOR the two 4-bit chunks of the outcome bits:
+// K + 2 reads per graph whatever P is, instead of ~3 VALU ops per row and 32-bit word (the W = 8 row kernel spends
+// ~10^4 instructions per shot on C5, this ~10^3).
+//
+//   * the set bits are found on the packed f row with the component's selection masks (ascending f_selection: the
+//     position inside f_sel is a popcount), once per component - they do not change from level to level;
+//   * a lane with more than K set bits is not evaluated here: its row goes to the hard-row lists (the same protocol
+//     as the pattern-table pass) and the row kernel (k_sample<W>) evaluates it afterwards; so does the
+//     normalisation-check row;
+//   * everything behind Y_g - class counts, Dickson pairs, term tables, exact sum, float epilogue, Threefry draw -
+//     is eval_level4 / the k_sample4 epilogue, unchanged: same values, same bits.
+#pragma once
+#include "tsim_kernel4.hip.h"
+#include "tsim_lw.hip.h"
+
+namespace tsimk {
+
+// component record extension of the wide layout: C4_SELMASK = image offset of 8 selection-mask words (f bits
+// 0..255) followed by 8 prefix counts (selected bits in the lower words)
+enum { C4_SELMASK = 9 };
+
+struct Wide4Args {
+  SampleArgs s;          // row_index / row_count: optional INPUT list (device-side post-selection)
+  int comp4_off;
+  int has_check;         // the first slot's row is the normalisation-check row: left to the row kernel
+  uint32_t *hard_index;  // out: n_lists sub-lists of list_cap rows for the row kernel
+  uint32_t *ctl;         // ctl[32 k] = entries of list k, ctl[32 LISTS] = check row (as LwArgs)
+  uint32_t *ctl_next;    // the counter set of the NEXT launch: reset here
+  int list_cap, n_lists;
+};
+
+template <int GT, int K>
+__global__ void __launch_bounds__(256) k_sample4w(Wide4Args W) {
+  static_assert(K % 2 == 0, "entries are consumed in pairs");
+  const SampleArgs &A = W.s;
+  const int nthr = blockDim.x;
+  const long long slot = (long long)blockIdx.x * nthr + threadIdx.x;
+  long long n_rows = A.B;
+  if (A.row_index) n_rows = (long long)*A.row_count;
+  const bool active = slot < n_rows;
+  long long row = slot;
+  if (A.row_index) row = active ? (long long)A.row_index[slot] : 0;
+  if (!active) row = 0;
+  const unsigned long long shot = (unsigned long long)(A.shot_offset + row);
+  cptr img = (cptr)(uintptr_t)A.img;
+
+  if (blockIdx.x == 0 && threadIdx.x <= TSIMK_LW_LISTS)
+    W.ctl_next[32u * threadIdx.x] = (threadIdx.x == TSIMK_LW_LISTS) ? 0xFFFFFFFFu : 0u;
+
+  const int WF32 = 2 * A.WF, WO32 = 2 * A.WO;
+  uint32_t *lds_f = tsimk_lds + threadIdx.x;                // [WF32][nthr]
+  uint32_t *lds_o = tsimk_lds + WF32 * nthr + threadIdx.x;  // [WO32][nthr]
+  uint8_t *lds_tab = reinterpret_cast<uint8_t *>(tsimk_lds + (WF32 + WO32) * nthr);
+
+  if (active) {
+    const uint64_t *frow = A.f + row * A.WF;
+    for (int w = 0; w < A.WF; ++w) {
+      const uint64_t v = frow[w];
+      lds_f[(2 * w) * nthr] = (uint32_t)v;
+      lds_f[(2 * w + 1) * nthr] = (uint32_t)(v >> 32);
+    }
+  } else {
+    for (int w = 0; w < WF32; ++w) lds_f[w * nthr] = 0u;
+  }
+  for (int w = 0; w < WO32; ++w) lds_o[w * nthr] = 0u;
+  bool hard = active && W.has_check && slot == 0;
+  if (hard) W.ctl[32 * TSIMK_LW_LISTS] = (uint32_t)row;
+
+  // direct outputs (sampler.py:140-145)
+  cptr dt = img + A.direct_off;
+  for (int j = 0; j < A.n_direct; ++j) {
+    const uint32_t s = dt[2 * j], dst = dt[2 * j + 1];
+    const uint32_t src = s & 0x7FFFFFFFu;
+    const uint32_t bit = ((lds_f[(src >> 5) * nthr] >> (src & 31u)) ^ (s >> 31)) & 1u;
+    lds_o[(dst >> 5) * nthr] |= bit << (dst & 31u);
+  }
+
+  // Pass A over the components: more than K set bits anywhere -> the whole row is the row kernel's.
+  for (int ci = 0; ci < A.n_comp; ++ci) {
+    cptr comp = img + W.comp4_off + ci * C4_WORDS;
+    cptr sel = img + comp[C4_SELMASK];
+    uint32_t cnt = 0;
+    const int nw = WF32 < 8 ? WF32 : 8;
+    for (int w = 0; w < nw; ++w) cnt += (uint32_t)__builtin_popcount(lds_f[w * nthr] & sel[w]);
+    hard = hard || (cnt > (uint32_t)K);
+  }
+
+  for (int ci = 0; ci < A.n_comp; ++ci) {
+    cptr comp = img + W.comp4_off + ci * C4_WORDS;
+    const uint32_t n_out = comp[C_NOUT], F = comp[C_F];
+    cptr levels = img + comp[C4_LEVELS];
+    cptr outpos = img + comp[C_OUTPOS];
+    cptr sel = img + comp[C4_SELMASK];
+    const uint32_t keybase = comp[C_KEYBASE];
+    constexpr uint32_t kEntry = GT * 16;
+
+    // the lane's set f bits as column entries (F = the all-zero column); hard lanes ride along with empty lists
+    uint32_t col[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) col[k] = F * kEntry;
+    if (!hard) {
+      int n = 0;
+      (void)n;
+      const int nw = WF32 < 8 ? WF32 : 8;
+      for (int w = 0; w < nw; ++w) {
+        uint32_t mw = lds_f[w * nthr] & sel[w];
+        const uint32_t sw = sel[w], base = sel[8 + w];
+        while (mw) {
+          const uint32_t p = (uint32_t)__builtin_ctz(mw);
+          const uint32_t pos = base + (uint32_t)__builtin_popcount(sw & ((1u << p) - 1u));
+          // shift-register insert (static indices only: a compare chain on `n` would be recognised as dynamic
+          // indexing and park the array in LDS); the order of the columns is irrelevant to the XOR
+#pragma unroll
+          for (int k = K - 1; k > 0; --k) col[k] = col[k - 1];
+          col[0] = pos * kEntry;
+          ++n;
+          mw &= mw - 1u;
+        }
+      }
+    }
+    const uint32_t tile_bytes = (F + 33u) * kEntry;
+    uint32_t mb = 0;  // outcome bits so far (bit i = output i), trial bit included
+    float prev = 0.0f;
+    for (uint32_t li = 0; li <= n_out; ++li) {
+      cptr lvl = levels + li * L4_WORDS;
+      if (li > 0) mb |= 1u << (li - 1u);  // trial bit 1 (sampler.py:65)
+      uint32_t e[K + 2];
+#pragma unroll
+      for (int k = 0; k < K; ++k) e[k] = col[k];
+      e[K] = (F + 1u + (mb & 15u)) * kEntry;
+      e[K + 1] = (F + 17u + ((mb >> 4) & 15u)) * kEntry;
+      float re, im;
+      if (lvl[L4_FLAGS] & TSIMK_LFLAG_FIXED) eval_level4<GT, K + 2, true>(A.img, img, lvl, e, tile_bytes, lvl[L4_STAB], lds_tab, re, im);
+      else eval_level4<GT, K + 2, false>(A.img, img, lvl, e, tile_bytes, lvl[L4_STAB], lds_tab, re, im);
+      const float v1 = cabs32(re, im);
+      if (li == 0) { prev = v1; continue; }
+      const uint32_t i = li - 1u;
+      const float u = uniform01(subkey(A, keybase + i, 0), subkey(A, keybase + i, 1), shot);
+      const bool bit = u < __fdiv_rn(v1, prev);  // sampler.py:74-75
+      if (!bit) mb &= ~(1u << i);
+      prev = bit ? v1 : __fsub_rn(prev, v1);
+      const uint32_t dst = outpos[i];
+      lds_o[(dst >> 5) * nthr] |= (bit ? 1u : 0u) << (dst & 31u);
+    }
+  }
+
+  if (active && !hard) {
+    if (A.out) {
+      uint64_t *orow = A.out + row * A.WO;
+      for (int w = 0; w < A.WO; ++w)
+        orow[w] = (uint64_t)lds_o[(2 * w) * nthr] | ((uint64_t)lds_o[(2 * w + 1) * nthr] << 32);
+    }
+    store_compact_row(A, row, lds_o, nthr);
+  }
+
+  // wave-aggregated append of the rows left to the row kernel
+  const unsigned long long hm = __ballot(hard ? 1 : 0);
+  if (hm != 0ull) {
+    const int lane = (int)(threadIdx.x & 63u);
+    const int leader = __builtin_ctzll(hm);
+    uint32_t basei = 0;
+    const uint32_t k = blockIdx.x % (uint32_t)W.n_lists;
+    if (lane == leader) basei = atomicAdd(&W.ctl[32u * k], (uint32_t)__popcll(hm));
+    basei = (uint32_t)__shfl((int)basei, leader, 64);
+    if (hard)
+      W.hard_index[(size_t)k * W.list_cap + basei + (uint32_t)__popcll(hm & ((1ull << lane) - 1ull))] = (uint32_t)row;
+  }
+}
+
+}  // namespace tsimk

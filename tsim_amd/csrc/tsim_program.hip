@@ -1,6 +1,7 @@
 // tsim_program.hip - handle life cycle of the C ABI (include/tsim_hip.h): program description ->
 // packed image -> upload, plus the memory / stream plumbing.  No kernels are defined here.
 #include "tsim_internal.hip.h"
+#include "tsim_kernel4w.hip.h"  // C4_SELMASK
 
 using namespace tsimk;
 using namespace tsimhost;
@@ -325,15 +326,24 @@ retry_pack:
   }
   // ---- v4 (chunk table) layout, when every sampled component qualifies ----
   p->v4 = false;
+  p->v4w = false;
   if (p->fast && p->sampleable) {
     bool ok = !p->comps.empty();
     for (auto &c : p->comps)
       for (auto &lv : c.levels) ok = ok && level_v4_eligible(lv);
+    // wide components (more than 64 parameters): column tables only, for the sparse-column kernel k_sample4w.
+    // Needs sequential components of at most 8 outputs over at most 256 ascending f indices below 256.
+    bool wide = !ok && !p->comps.empty() && p->max_f_index < 256;
+    for (auto &c : p->comps) {
+      wide = wide && (c.n_levels == c.n_out + 1) && c.n_out <= 8 && c.F <= 256;
+      for (int j = 1; j < c.F; ++j) wide = wide && c.f_selection[j] > c.f_selection[j - 1];
+      for (auto &lv : c.levels) wide = wide && level_v4_eligible(lv, true);
+    }
     const char *kenv = getenv("TSIM_AMD_KERNEL");
-    if (kenv && strcmp(kenv, "v3") == 0) ok = false;
-    if (p->mode == TSIM_MODE_ROW_KERNEL) ok = false;
+    if (kenv && strcmp(kenv, "v3") == 0) ok = wide = false;
+    if (p->mode == TSIM_MODE_ROW_KERNEL) ok = wide = false;
     p->v4_gt = 4;
-    if (ok) {
+    if (ok || wide) {
       while (img.size() % 16) img.push_back(0u);
       p->comp4_off = (int)img.size();
       img.resize(img.size() + p->comps.size() * C4_WORDS, 0u);
@@ -345,6 +355,7 @@ retry_pack:
       p->v4_max_nch = 16;
       for (int v : kNch)
         if (4 * v >= maxp) { p->v4_max_nch = v; break; }
+      if (wide) p->v4_max_nch = 0;  // no chunk tables at all
       for (size_t ci = 0; ci < p->comps.size(); ++ci) {
         HostComponent &c = p->comps[ci];
         for (int w = 0; w < 8; ++w) img[p->comp4_off + ci * C4_WORDS + w] = img[p->comp_off + ci * C_WORDS + w];
@@ -359,7 +370,7 @@ retry_pack:
           std::vector<uint32_t> recs4, tabs4, stabs4;
           int nch = 1, ntiles = 0;
           const bool sequential = (c.n_levels == c.n_out + 1);
-          const int sparse_F = (sequential && c.n_out <= 8 && c.F + c.n_out <= 64) ? c.F : -1;
+          const int sparse_F = (wide || (sequential && c.n_out <= 8 && c.F + c.n_out <= 64)) ? c.F : -1;
           std::vector<uint32_t> v3copy(img.begin() + v3recs, img.begin() + v3recs + (size_t)h.G * G_WORDS);
           emit_level4(h, p->v4_gt, p->v4_max_nch, v3copy.data(), recs4, tabs4, nch, ntiles, sparse_F, stabs4);
           while (img.size() % 16) img.push_back(0u);
@@ -382,8 +393,17 @@ retry_pack:
           lr[L4_FLAGS] = (h.approx ? TSIMK_LFLAG_APPROX : 0u) | (h.fixed ? TSIMK_LFLAG_FIXED : 0u);
           lr[L4_FRAME] = (uint32_t)h.frame;
         }
+        if (wide) {  // selection masks over f bits 0..255 and, per word, the selected bits below it
+          uint32_t sel[16] = {0};
+          for (int v : c.f_selection) sel[v >> 5] |= 1u << (v & 31);
+          for (int w = 1; w < 8; ++w) sel[8 + w] = sel[8 + w - 1] + (uint32_t)__builtin_popcount(sel[w - 1]);
+          while (img.size() % 16) img.push_back(0u);
+          img[p->comp4_off + ci * C4_WORDS + C4_SELMASK] = (uint32_t)img.size();
+          img.insert(img.end(), sel, sel + 16);
+        }
       }
-      p->v4 = true;
+      p->v4 = ok;
+      p->v4w = wide;
     }
   }
   p->stats[7] = p->v4 ? 1 : 0;
@@ -484,6 +504,7 @@ retry_pack:
     p->knobs.hard_lds_kb = std::max(24, std::min(156, env_int("TSIM_AMD_HARD_LDS_KB", 128)));
     p->knobs.defer = env_int("TSIM_AMD_DEFER_HARD", 1) != 0;
     p->knobs.lw_reg = env_int("TSIM_AMD_LW_REG", 1) != 0;
+    p->knobs.wide = env_int("TSIM_AMD_WIDE", 1) != 0;
     p->knobs.merge_lists = env_int("TSIM_AMD_MERGE_LISTS", 1) != 0;
     p->knobs.list_rows = env_int("TSIM_AMD_LIST_ROWS", 40);
     p->knobs.min_lists = env_int("TSIM_AMD_MIN_LISTS", 4);

@@ -5,6 +5,7 @@
 #include "tsim_kernel4h.hip.h"
 #include "tsim_filter.hip.h"
 #include "tsim_lw_pass.hip.h"
+#include "tsim_kernel4w.hip.h"
 
 using namespace tsimk;
 using namespace tsimhost;
@@ -44,7 +45,7 @@ static int prof_drain(tsim_program *p) {
 // per-slot resources, created on first use
 static int slot_prepare(tsim_program *p, int slot, size_t hard_bytes) {
   tsim_program::Slot &sl = p->slots[slot];
-  if (p->lw && !sl.ctl) {
+  if ((p->lw || p->v4w) && !sl.ctl) {
     // two counter sets used alternately: pass 1 of a launch resets the set of the slot's next one
     const size_t set_bytes = (TSIMK_LW_LISTS + 1) * 128;
     HIP_TRY(hipMalloc((void **)&sl.ctl, 2 * set_bytes));
@@ -237,7 +238,7 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
   tsim_program::Slot &sl = p->slots[slot];
   {
     size_t hard_bytes = 0;
-    if (p->lw) {
+    if (p->lw || p->v4w) {
       const long long g1 = (B + 255) / 256;  // the pattern pass uses 256-thread blocks unless overridden
       hard_bytes = (size_t)((g1 + TSIMK_LW_LISTS - 1) / TSIMK_LW_LISTS * 1024) * TSIMK_LW_LISTS * 4;
     }
@@ -363,6 +364,38 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
     a.check_row = has_check ? ctl + 32 * TSIMK_LW_LISTS : nullptr;
     a.no_check = has_check ? 0 : 1;
     B2 = list_cap;
+  } else if (p->v4w && p->knobs.wide &&
+             (size_t)(2 * a.WF + 2 * a.WO) * 256 * 4 + 2 * (size_t)p->v4_max_sent * p->v4_gt * 16 <= 64 * 1024) {
+    // wide components: sparse-column pass on every row (k_sample4w); rows with more than K set f bits and the
+    // normalisation-check row go to the row lists, which the row kernel below serves
+    if (B > 0xFFFFFFFFll) return tsim_fail(TSIM_ENOTSUP, "batch too large for the row list");
+    constexpr int kWideBlock = 256, kWideK = 10, kWideLists = 16;
+    const long long grid1 = (B + kWideBlock - 1) / kWideBlock;
+    const long long list_cap = (grid1 + TSIMK_LW_LISTS - 1) / TSIMK_LW_LISTS * kWideBlock * (TSIMK_LW_LISTS / kWideLists);
+    if (list_cap > 0x7FFFFFFFll) return tsim_fail(TSIM_ENOTSUP, "batch too large for the row lists");
+    if ((size_t)list_cap * kWideLists * 4 > sl.hard_sz) return tsim_fail(TSIM_ESTATE, "row list too small");
+    Wide4Args w;
+    w.s = a;
+    w.comp4_off = p->comp4_off;
+    w.has_check = has_check ? 1 : 0;
+    w.hard_index = (uint32_t *)sl.hard;
+    uint32_t *ctl = sl.ctl + sl.parity * (TSIMK_LW_LISTS + 1) * 32;
+    w.ctl = ctl;
+    w.ctl_next = sl.ctl + (sl.parity ^ 1) * (TSIMK_LW_LISTS + 1) * 32;
+    sl.parity ^= 1;
+    w.list_cap = (int)list_cap;
+    w.n_lists = kWideLists;
+    const size_t ldsw = (size_t)(2 * a.WF + 2 * a.WO) * kWideBlock * 4 + 2 * (size_t)p->v4_max_sent * p->v4_gt * 16;
+    hipLaunchKernelGGL((k_sample4w<4, kWideK>), dim3((unsigned)grid1), dim3(kWideBlock), ldsw, s, w);
+    HIP_TRY(hipGetLastError());
+    if (prof) { int r = prof_event(p, s, PROF_PASS1); if (r) return r; }
+    a.row_index = w.hard_index;
+    a.row_count = ctl;
+    a.row_lists = kWideLists;
+    a.row_list_cap = (int)list_cap;
+    a.check_row = has_check ? ctl + 32 * TSIMK_LW_LISTS : nullptr;
+    a.no_check = has_check ? 0 : 1;
+    B2 = list_cap;
   } else if (!has_check) {
     a.no_check = 1;
   }
@@ -463,7 +496,7 @@ extern "C" int tsim_sample_batch_device_begin(tsim_program *p, int32_t slot, con
   tsim_program::Slot &sl = p->slots[1 + slot];
   if (!p->slots_ready) {  // first pipelined launch: create every slot's stream/buffers now, not mid-run
     size_t hard_bytes = 0;
-    if (p->lw) hard_bytes = (size_t)(((B + 255) / 256 + TSIMK_LW_LISTS - 1) / TSIMK_LW_LISTS * 1024) * TSIMK_LW_LISTS * 4;
+    if (p->lw || p->v4w) hard_bytes = (size_t)(((B + 255) / 256 + TSIMK_LW_LISTS - 1) / TSIMK_LW_LISTS * 1024) * TSIMK_LW_LISTS * 4;
     for (int k = 1; k <= TSIM_PIPELINE_SLOTS; ++k)
       if (int r = slot_prepare(p, k, hard_bytes)) return r;
     p->slots_ready = true;

@@ -30,6 +30,7 @@ def test_wide_sparse_matches_oracle(hip, p_bit, physical):
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         hp = hip.HipProgram(prog)
+        assert hp.info()["wide_sparse_kernel"] == physical  # the random program's Dickson forms exceed 32 pairs
         got, gdev = hp.sample_batch(f, (5, 6))
         np.testing.assert_array_equal(got, want)
         np.testing.assert_array_equal(np.asarray(gdev, np.float32), np.asarray(wdev, np.float32))
@@ -43,7 +44,9 @@ def test_wide_sparse_matches_oracle(hip, p_bit, physical):
 def test_wide_sparse_is_selected_and_equals_row_kernel_at_scale(hip):
     prog, cfg = synth.config_program("C5")
     f = synth.synth_f(200_000, cfg["num_f"], cfg["p_bit"], seed=9)
-    a, _ = hip.HipProgram(prog).sample_batch(f, (1, 2), bit_packed=True)
+    hp = hip.HipProgram(prog)
+    assert hp.info()["wide_sparse_kernel"] and not hp.info()["chunk_table_kernel"]
+    a, _ = hp.sample_batch(f, (1, 2), bit_packed=True)
     b, _ = hip.HipProgram(prog, mode="rows").sample_batch(f, (1, 2), bit_packed=True)
     assert np.array_equal(a, b)
 
@@ -53,6 +56,7 @@ def test_wide_sparse_pipelined_and_row_list_input(hip):
     nf, n_out = 320, prog.num_outputs
     wf, wo, rb = (nf + 63) // 64, (n_out + 63) // 64, (n_out + 7) // 8
     hp = hip.HipProgram(prog)
+    assert hp.info()["wide_sparse_kernel"]
     B = 30_000
     orc = OC.OracleProgram(prog)
     bufs = []

@@ -114,6 +114,7 @@ struct tsim_program {
   int mode = TSIM_MODE_AUTO;  // requested
   bool fast = false;          // chosen at finalize: counting formulation (eval_level_fast)
   bool v4 = false;            // chunk-table layout present (k_sample4)
+  size_t v4w_resident_bytes = 0;  // LDS needed to hold all levels' column tables of the largest component
   bool v4w = false;           // wide components: column tables only (k_sample4w + row kernel for the overflow)
   int v4_gt = 4;              // graphs per LDS tile
   int comp4_off = 0;
@@ -193,6 +194,7 @@ struct tsim_program {
     bool merge_lists = true;  // TSIM_AMD_MERGE_LISTS=0: always TSIMK_LW_LISTS hard-row sub-lists
     int list_rows = 40;       // TSIM_AMD_LIST_ROWS: expected hard rows per list the list count aims at
     int min_lists = 4;        // TSIM_AMD_MIN_LISTS (power of two >= 2)
+    bool direct_runs = true;  // TSIM_AMD_DIRECT_RUNS=0: direct outputs bit by bit (pair table) in the full kernels
     bool wide = true;         // TSIM_AMD_WIDE=0: wide components on the row kernel alone (no sparse-column pass)
     bool lw_reg = true;       // TSIM_AMD_LW_REG=0: LDS-staged first pass even where the register form applies
     bool defer = true;        // TSIM_AMD_DEFER_HARD=0: every pipelined launch runs its own second pass

@@ -67,6 +67,107 @@ struct Tile4 {
   static constexpr int kChunkBytes = 16 * GT * 16;  // 16 chunk values x GT graphs x 16 B
 };
 
+// Running value of a level while its graphs are consumed one by one: the exact sum (or the float sum of the
+// approximate branch) plus, in fixed-frame levels, the one table entry still in flight.
+struct Acc4 {
+  int sa = 0, sb = 0, sc = 0, sd = 0, sp = TSIMK_ZERO_POWER;
+  float fre = 0.0f, fim = 0.0f;
+  uint4 pend_tv = {0u, 0u, 0u, 0u}, pend_dv = {1u, 0u, 0u, 0u};
+  bool pend_sep = false;
+};
+
+// One graph: from its 128-bit parity word Y_g = (U, V, O1, O2) to its term-table entry, added to the level's value.
+//   word U, V : the Dickson product pairs  ->  e = parity(popcount(U & V & PM))
+//   word O1   : counted NodePhases rows    ->  m0 = any(O1 & M0), m1 = popc(O1 & M1), m3 = popc(O1 & M3)
+//   word O2   : PhasePairs index bits, lambda (bit 30), linear bit (bit 31)
+// Fixed-frame levels: the table gather of graph g is consumed while graph g+1 is being formed (software pipelining
+// of the VMEM latency).
+template <bool FIXED>
+__device__ __forceinline__ void acc_graph4(Acc4 &S, const uint32_t *gimg, cptr gr, uint32_t U, uint32_t V, uint32_t O1,
+                                           uint32_t O2, bool approx) {
+  constexpr bool fixed = FIXED;
+  const uint32_t gflags = gr[G4_FLAGS];
+  // ---- counted NodePhases rows and the table index ----
+  const bool z = (O1 & gr[G4_M0]) != 0;
+  const uint32_t m1 = (uint32_t)__builtin_popcount(O1 & gr[G4_M1]);
+  const uint32_t m3 = (uint32_t)__builtin_popcount(O1 & gr[G4_M3]);
+  uint32_t idx = m3 - m1 + gr[G4_N1];
+  const uint32_t dsh = gr[G4_DBITS];
+  const uint32_t dbits = O2 & ((1u << dsh) - 1u);
+  if (gflags & TSIMK_G4FLAG_D_COMBINED) idx = (idx << dsh) | dbits;
+  idx = z ? 0u : idx + 1u;
+  // ---- exponent of w: k = 2 lambda + 4 (lin ^ parity(U & V & PM)); r = k / 2 ----
+  const uint32_t pc = (uint32_t)__builtin_popcount(U & V & gr[G4_PM]);
+  const uint32_t r = (O2 >> 30) ^ ((pc & 1u) << 1);
+  // fixed-frame levels: 4 pre-rotated copies per entry (value * i^r), 16 words per entry
+  const uint32_t *te = gimg + gr[G4_TBL] + (fixed ? (16u * idx + 4u * r) : 8u * idx);
+  const uint4 tv = *reinterpret_cast<const uint4 *>(te);
+  if constexpr (fixed) {
+    uint4 dv = {1u, 0u, 0u, 0u};
+    const bool sep = (gflags & TSIMK_G4FLAG_D_SEPARATE) != 0;
+    if (sep) dv = *reinterpret_cast<const uint4 *>(gimg + gr[G4_TBL2] + 8u * dbits);
+    // retire the previous graph's entry (zero-initialised before the first graph)
+    {
+      int a = (int)S.pend_tv.x, b = (int)S.pend_tv.y, c = (int)S.pend_tv.z, d = (int)S.pend_tv.w;
+      if (S.pend_sep) zmul(a, b, c, d, (int)S.pend_dv.x, (int)S.pend_dv.y, (int)S.pend_dv.z, (int)S.pend_dv.w);
+      S.sa += a; S.sb += b; S.sc += c; S.sd += d;
+    }
+    S.pend_tv = tv; S.pend_dv = dv; S.pend_sep = sep;
+    return;
+  }
+  int a = (int)tv.x, b = (int)tv.y, c = (int)tv.z, d = (int)tv.w, p = 0;
+  if (!fixed) p = (int)te[4];
+  if (gflags & TSIMK_G4FLAG_D_SEPARATE) {
+    const uint32_t *td = gimg + gr[G4_TBL2] + 8u * dbits;
+    const uint4 dv = *reinterpret_cast<const uint4 *>(td);
+    zmul(a, b, c, d, (int)dv.x, (int)dv.y, (int)dv.z, (int)dv.w);
+    if (!fixed) p += (int)td[4];
+  }
+  if (!fixed) {  // rotate by i^r
+    const bool k2 = (r & 1u) != 0;
+    const int t0 = k2 ? -c : a, t1 = k2 ? d : b, t2 = k2 ? a : c, t3 = k2 ? -b : d;
+    const int nm = -(int)((r >> 1) & 1u);
+    a = (t0 ^ nm) - nm; b = (t1 ^ nm) - nm; c = (t2 ^ nm) - nm; d = (t3 ^ nm) - nm;
+  }
+  if (!approx) {
+    if ((a | b | c | d) == 0) p = TSIMK_ZERO_POWER;
+    const int d1 = max(S.sp - p, 0), d2 = max(p - S.sp, 0);
+    S.sa = (int)((unsigned)shl_sat(S.sa, d1) + (unsigned)shl_sat(a, d2));
+    S.sb = (int)((unsigned)shl_sat(S.sb, d1) + (unsigned)shl_sat(b, d2));
+    S.sc = (int)((unsigned)shl_sat(S.sc, d1) + (unsigned)shl_sat(c, d2));
+    S.sd = (int)((unsigned)shl_sat(S.sd, d1) + (unsigned)shl_sat(d, d2));
+    S.sp = min(S.sp, p);
+    reduce1(S.sa, S.sb, S.sc, S.sd, S.sp);
+  } else {
+    float zr, zi;
+    to_complex(a, b, c, d, p, zr, zi);
+    const float ar = __uint_as_float(gr[G4_APRE]), ai = __uint_as_float(gr[G4_APIM]);
+    const float tr = __fsub_rn(__fmul_rn(zr, ar), __fmul_rn(zi, ai));
+    const float ti = __fadd_rn(__fmul_rn(zr, ai), __fmul_rn(zi, ar));
+    S.fre = __fadd_rn(S.fre, tr);
+    S.fim = __fadd_rn(S.fim, ti);
+  }
+}
+
+// the level's amplitude once every graph has been added
+template <bool FIXED>
+__device__ __forceinline__ void acc_finish4(Acc4 &S, cptr lvl, bool approx, float &out_re, float &out_im) {
+  if constexpr (FIXED) {  // retire the last in-flight entry
+    int a = (int)S.pend_tv.x, b = (int)S.pend_tv.y, c = (int)S.pend_tv.z, d = (int)S.pend_tv.w;
+    if (S.pend_sep) zmul(a, b, c, d, (int)S.pend_dv.x, (int)S.pend_dv.y, (int)S.pend_dv.z, (int)S.pend_dv.w);
+    S.sa += a; S.sb += b; S.sc += c; S.sd += d;
+  }
+  if (!approx) {
+    if (FIXED) S.sp = (int)lvl[L4_FRAME];
+    canon(S.sa, S.sb, S.sc, S.sd, S.sp);
+    if ((S.sa | S.sb | S.sc | S.sd) == 0) S.sp = 0;
+    to_complex(S.sa, S.sb, S.sc, S.sd, S.sp, out_re, out_im);
+  } else {
+    out_re = S.fre;
+    out_im = S.fim;
+  }
+}
+
 // evaluate() of one level with LDS chunk tables.  All threads of the block must call this together.
 // NR = LDS reads per graph: the caller passes this lane's NR entry offsets inside a tile table
 // (`ent0`, bytes from the start of the tile), the tile size and the table's offset in the image.
@@ -75,9 +176,7 @@ __device__ __forceinline__ void eval_level4(const uint32_t *gimg, cptr img, cptr
                                             uint32_t tile_bytes, uint32_t table_off,
                                             uint8_t *lds_tab /* 2 * tile bytes */, float &out_re, float &out_im) {
   const uint32_t G = lvl[L4_G], ntiles = lvl[L4_NTILES];
-  const uint32_t lflags = lvl[L4_FLAGS];
-  const bool approx = (lflags & TSIMK_LFLAG_APPROX) != 0;
-  constexpr bool fixed = FIXED;  // (lflags & TSIMK_LFLAG_FIXED), resolved by the caller
+  const bool approx = (lvl[L4_FLAGS] & TSIMK_LFLAG_APPROX) != 0;
   const uint32_t tile_vec = tile_bytes >> 4;  // uint4 elements per tile
   const uint4 *gtab = reinterpret_cast<const uint4 *>(gimg + table_off);
   cptr recs = img + lvl[L4_RECS];
@@ -91,18 +190,12 @@ __device__ __forceinline__ void eval_level4(const uint32_t *gimg, cptr img, cptr
   for (int c = 0; c < NR; ++c) ent[c] = tab0 + ent0[c];
   int delta = (int)tile_bytes;  // +tile_bytes / -tile_bytes: toggles ent[] between the two buffers
 
-  int sa = 0, sb = 0, sc = 0, sd = 0, sp = TSIMK_ZERO_POWER;
-  float fre = 0.0f, fim = 0.0f;
+  Acc4 S;
 
   // tile 0 -> LDS buffer 0 (async global->LDS copies, 1 KiB per wave-instruction)
   __syncthreads();  // previous users of the buffers are done
   if (ntiles) tile_copy(gtab, lds_tab, tile_vec, tid, nthr);
   __syncthreads();
-
-  // Fixed-frame levels: the table gather of graph g is consumed while graph g+1 is being formed
-  // (software pipelining of the VMEM latency); `pend_*` hold the in-flight entry.
-  uint4 pend_tv = {0u, 0u, 0u, 0u}, pend_dv = {1u, 0u, 0u, 0u};
-  bool pend_sep = false;
 
   for (uint32_t t = 0; t < ntiles; ++t) {
     // prefetch tile t+1 straight into the other LDS buffer: its last readers passed the barrier
@@ -125,70 +218,7 @@ __device__ __forceinline__ void eval_level4(const uint32_t *gimg, cptr img, cptr
         // any more LDS latency
         if (c % 6 == 4 && c + 2 < NR) __builtin_amdgcn_sched_barrier(0);
       }
-      cptr gr = recs + g * G4_WORDS;
-      const uint32_t gflags = gr[G4_FLAGS];
-      // ---- counted NodePhases rows and the table index ----
-      const bool z = (O1 & gr[G4_M0]) != 0;
-      const uint32_t m1 = (uint32_t)__builtin_popcount(O1 & gr[G4_M1]);
-      const uint32_t m3 = (uint32_t)__builtin_popcount(O1 & gr[G4_M3]);
-      uint32_t idx = m3 - m1 + gr[G4_N1];
-      const uint32_t dsh = gr[G4_DBITS];
-      const uint32_t dbits = O2 & ((1u << dsh) - 1u);
-      if (gflags & TSIMK_G4FLAG_D_COMBINED) idx = (idx << dsh) | dbits;
-      idx = z ? 0u : idx + 1u;
-      // ---- exponent of w: k = 2 lambda + 4 (lin ^ parity(U & V & PM)); r = k / 2 ----
-      const uint32_t pc = (uint32_t)__builtin_popcount(U & V & gr[G4_PM]);
-      const uint32_t r = (O2 >> 30) ^ ((pc & 1u) << 1);
-      // fixed-frame levels: 4 pre-rotated copies per entry (value * i^r), 16 words per entry
-      const uint32_t *te = gimg + gr[G4_TBL] + (fixed ? (16u * idx + 4u * r) : 8u * idx);
-      const uint4 tv = *reinterpret_cast<const uint4 *>(te);
-      if constexpr (fixed) {
-        uint4 dv = {1u, 0u, 0u, 0u};
-        const bool sep = (gflags & TSIMK_G4FLAG_D_SEPARATE) != 0;
-        if (sep) dv = *reinterpret_cast<const uint4 *>(gimg + gr[G4_TBL2] + 8u * dbits);
-        // retire the previous graph's entry (zero-initialised before the first graph)
-        {
-          int a = (int)pend_tv.x, b = (int)pend_tv.y, c = (int)pend_tv.z, d = (int)pend_tv.w;
-          if (pend_sep) zmul(a, b, c, d, (int)pend_dv.x, (int)pend_dv.y, (int)pend_dv.z, (int)pend_dv.w);
-          sa += a; sb += b; sc += c; sd += d;
-        }
-        pend_tv = tv; pend_dv = dv; pend_sep = sep;
-        continue;
-      }
-      int a = (int)tv.x, b = (int)tv.y, c = (int)tv.z, d = (int)tv.w, p = 0;
-      if (!fixed) p = (int)te[4];
-      if (gflags & TSIMK_G4FLAG_D_SEPARATE) {
-        const uint32_t *td = gimg + gr[G4_TBL2] + 8u * dbits;
-        const uint4 dv = *reinterpret_cast<const uint4 *>(td);
-        zmul(a, b, c, d, (int)dv.x, (int)dv.y, (int)dv.z, (int)dv.w);
-        if (!fixed) p += (int)td[4];
-      }
-      if (!fixed) {  // rotate by i^r
-        const bool k2 = (r & 1u) != 0;
-        const int t0 = k2 ? -c : a, t1 = k2 ? d : b, t2 = k2 ? a : c, t3 = k2 ? -b : d;
-        const int nm = -(int)((r >> 1) & 1u);
-        a = (t0 ^ nm) - nm; b = (t1 ^ nm) - nm; c = (t2 ^ nm) - nm; d = (t3 ^ nm) - nm;
-      }
-      if (fixed) {
-        sa += a; sb += b; sc += c; sd += d;
-      } else if (!approx) {
-        if ((a | b | c | d) == 0) p = TSIMK_ZERO_POWER;
-        const int d1 = max(sp - p, 0), d2 = max(p - sp, 0);
-        sa = (int)((unsigned)shl_sat(sa, d1) + (unsigned)shl_sat(a, d2));
-        sb = (int)((unsigned)shl_sat(sb, d1) + (unsigned)shl_sat(b, d2));
-        sc = (int)((unsigned)shl_sat(sc, d1) + (unsigned)shl_sat(c, d2));
-        sd = (int)((unsigned)shl_sat(sd, d1) + (unsigned)shl_sat(d, d2));
-        sp = min(sp, p);
-        reduce1(sa, sb, sc, sd, sp);
-      } else {
-        float zr, zi;
-        to_complex(a, b, c, d, p, zr, zi);
-        const float ar = __uint_as_float(gr[G4_APRE]), ai = __uint_as_float(gr[G4_APIM]);
-        const float tr = __fsub_rn(__fmul_rn(zr, ar), __fmul_rn(zi, ai));
-        const float ti = __fadd_rn(__fmul_rn(zr, ai), __fmul_rn(zi, ar));
-        fre = __fadd_rn(fre, tr);
-        fim = __fadd_rn(fim, ti);
-      }
+      acc_graph4<FIXED>(S, gimg, recs + g * G4_WORDS, U, V, O1, O2, approx);
     }
     if (more) {
 #pragma unroll
@@ -197,22 +227,7 @@ __device__ __forceinline__ void eval_level4(const uint32_t *gimg, cptr img, cptr
     }
     __syncthreads();
   }
-
-  if constexpr (fixed) {  // retire the last in-flight entry
-    int a = (int)pend_tv.x, b = (int)pend_tv.y, c = (int)pend_tv.z, d = (int)pend_tv.w;
-    if (pend_sep) zmul(a, b, c, d, (int)pend_dv.x, (int)pend_dv.y, (int)pend_dv.z, (int)pend_dv.w);
-    sa += a; sb += b; sc += c; sd += d;
-  }
-
-  if (!approx) {
-    if (fixed) sp = (int)lvl[L4_FRAME];
-    canon(sa, sb, sc, sd, sp);
-    if ((sa | sb | sc | sd) == 0) sp = 0;
-    to_complex(sa, sb, sc, sd, sp, out_re, out_im);
-  } else {
-    out_re = fre;
-    out_im = fim;
-  }
+  acc_finish4<FIXED>(S, lvl, approx, out_re, out_im);
 }
 
 // sample_program for one batch, LDS chunk-table formulation.  Requires every sampled component to
@@ -281,13 +296,7 @@ k_sample4(Sample4Args A4) {
   for (int w = 0; w < WO32; ++w) lds_o[w * nthr] = 0u;
 
   // direct outputs (sampler.py:140-145)
-  cptr dt = img + A.direct_off;
-  for (int j = 0; j < A.n_direct; ++j) {
-    const uint32_t s = dt[2 * j], dst = dt[2 * j + 1];
-    const uint32_t src = s & 0x7FFFFFFFu;
-    const uint32_t bit = ((lds_f[(src >> 5) * nthr] >> (src & 31u)) ^ (s >> 31)) & 1u;
-    lds_o[(dst >> 5) * nthr] |= bit << (dst & 31u);
-  }
+  direct_outputs(A, img, lds_f, lds_o, nthr);
 
   for (int ci = 0; ci < A.n_comp; ++ci) {
     cptr comp = img + A4.comp4_off + ci * C4_WORDS;

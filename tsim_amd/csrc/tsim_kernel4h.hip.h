@@ -261,13 +261,7 @@ __device__ __forceinline__ void sample4h_rows(const SampleArgs &A, int comp4_off
       for (int w = 0; w < WF32; ++w) lds_f[w * 64] = 0u;
     }
     for (int w = 0; w < WO32; ++w) lds_o[w * 64] = 0u;
-    cptr dt = img + A.direct_off;
-    for (int j = 0; j < A.n_direct; ++j) {
-      const uint32_t s = dt[2 * j], dst = dt[2 * j + 1];
-      const uint32_t src = s & 0x7FFFFFFFu;
-      const uint32_t bit = ((lds_f[(src >> 5) * 64] >> (src & 31u)) ^ (s >> 31)) & 1u;
-      lds_o[(dst >> 5) * 64] |= bit << (dst & 31u);
-    }
+    direct_outputs(A, img, lds_f, lds_o, 64);
   }
   __syncthreads();
 

@@ -21,9 +21,10 @@
 
 namespace tsimk {
 
-// component record extension of the wide layout: C4_SELMASK = image offset of 8 selection-mask words (f bits
-// 0..255) followed by 8 prefix counts (selected bits in the lower words)
+// component record extension of the wide layout: C4_SELMASK = image offset of TSIMK_W_SELWORDS selection-mask
+// words (f bits 0..511) followed by as many prefix counts (selected bits in the lower words)
 enum { C4_SELMASK = 9 };
+#define TSIMK_W_SELWORDS 16
 
 struct Wide4Args {
   SampleArgs s;          // row_index / row_count: optional INPUT list (device-side post-selection)
@@ -33,11 +34,39 @@ struct Wide4Args {
   uint32_t *ctl;         // ctl[32 k] = entries of list k, ctl[32 LISTS] = check row (as LwArgs)
   uint32_t *ctl_next;    // the counter set of the NEXT launch: reset here
   int list_cap, n_lists;
+  int resident;          // 1: the LDS table area holds ALL levels of a component at once (one copy, no per-level barriers)
 };
 
+// One level from LDS-resident column tables (graph g of the level at lds_level + g * ent_bytes): no copy, no barrier.
+template <int NR, bool FIXED>
+__device__ __forceinline__ void eval_level4_resident(const uint32_t *gimg, cptr img, cptr lvl, const uint32_t (&e)[NR],
+                                                     uint32_t lds_level, uint32_t ent_bytes, float &out_re, float &out_im) {
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  typedef const __attribute__((address_space(3))) u32x4 *lds_u4p;
+  const uint32_t G = lvl[L4_G];
+  const bool approx = (lvl[L4_FLAGS] & TSIMK_LFLAG_APPROX) != 0;
+  cptr recs = img + lvl[L4_RECS];
+  Acc4 S;
+  for (uint32_t g = 0; g < G; ++g) {
+    const uint32_t base = lds_level + g * ent_bytes;
+    uint32_t U = 0, V = 0, O1 = 0, O2 = 0;
+#pragma unroll
+    for (int c = 0; c < NR; c += 2) {
+      const u32x4 v = *(lds_u4p)(uintptr_t)(base + e[c]);
+      const u32x4 w = *(lds_u4p)(uintptr_t)(base + e[c + 1]);
+      U = xor3(U, v.x, w.x); V = xor3(V, v.y, w.y); O1 = xor3(O1, v.z, w.z); O2 = xor3(O2, v.w, w.w);
+      if (c % 6 == 4 && c + 2 < NR) __builtin_amdgcn_sched_barrier(0);
+    }
+    acc_graph4<FIXED>(S, gimg, recs + g * G4_WORDS, U, V, O1, O2, approx);
+  }
+  acc_finish4<FIXED>(S, lvl, approx, out_re, out_im);
+}
+
+// GT is 1 in the wide layout: one graph per tile, a level's tables are G consecutive (F + 33) x 16-byte blocks.
 template <int GT, int K>
 __global__ void __launch_bounds__(256) k_sample4w(Wide4Args W) {
   static_assert(K % 2 == 0, "entries are consumed in pairs");
+  static_assert(GT == 1, "the wide layout has one graph per tile");
   const SampleArgs &A = W.s;
   const int nthr = blockDim.x;
   const long long slot = (long long)blockIdx.x * nthr + threadIdx.x;
@@ -73,20 +102,14 @@ __global__ void __launch_bounds__(256) k_sample4w(Wide4Args W) {
   if (hard) W.ctl[32 * TSIMK_LW_LISTS] = (uint32_t)row;
 
   // direct outputs (sampler.py:140-145)
-  cptr dt = img + A.direct_off;
-  for (int j = 0; j < A.n_direct; ++j) {
-    const uint32_t s = dt[2 * j], dst = dt[2 * j + 1];
-    const uint32_t src = s & 0x7FFFFFFFu;
-    const uint32_t bit = ((lds_f[(src >> 5) * nthr] >> (src & 31u)) ^ (s >> 31)) & 1u;
-    lds_o[(dst >> 5) * nthr] |= bit << (dst & 31u);
-  }
+  direct_outputs(A, img, lds_f, lds_o, nthr);
 
   // Pass A over the components: more than K set bits anywhere -> the whole row is the row kernel's.
   for (int ci = 0; ci < A.n_comp; ++ci) {
     cptr comp = img + W.comp4_off + ci * C4_WORDS;
     cptr sel = img + comp[C4_SELMASK];
     uint32_t cnt = 0;
-    const int nw = WF32 < 8 ? WF32 : 8;
+    const int nw = WF32 < TSIMK_W_SELWORDS ? WF32 : TSIMK_W_SELWORDS;
     for (int w = 0; w < nw; ++w) cnt += (uint32_t)__builtin_popcount(lds_f[w * nthr] & sel[w]);
     hard = hard || (cnt > (uint32_t)K);
   }
@@ -107,10 +130,10 @@ __global__ void __launch_bounds__(256) k_sample4w(Wide4Args W) {
     if (!hard) {
       int n = 0;
       (void)n;
-      const int nw = WF32 < 8 ? WF32 : 8;
+      const int nw = WF32 < TSIMK_W_SELWORDS ? WF32 : TSIMK_W_SELWORDS;
       for (int w = 0; w < nw; ++w) {
         uint32_t mw = lds_f[w * nthr] & sel[w];
-        const uint32_t sw = sel[w], base = sel[8 + w];
+        const uint32_t sw = sel[w], base = sel[TSIMK_W_SELWORDS + w];
         while (mw) {
           const uint32_t p = (uint32_t)__builtin_ctz(mw);
           const uint32_t pos = base + (uint32_t)__builtin_popcount(sw & ((1u << p) - 1u));
@@ -125,7 +148,21 @@ __global__ void __launch_bounds__(256) k_sample4w(Wide4Args W) {
       }
     }
     const uint32_t tile_bytes = (F + 33u) * kEntry;
+    // resident mode: every level's tables into LDS now - one burst of async copies, one barrier per component
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)lds_tab;
+    if (W.resident) {
+      __syncthreads();  // the previous component's readers are done
+      uint32_t off = 0;
+      for (uint32_t li = 0; li <= n_out; ++li) {
+        cptr lvl = levels + li * L4_WORDS;
+        const uint32_t bytes = lvl[L4_G] * tile_bytes;
+        tile_copy(reinterpret_cast<const uint4 *>(A.img + lvl[L4_STAB]), lds_tab + off, bytes >> 4, threadIdx.x, nthr);
+        off += bytes;
+      }
+      __syncthreads();
+    }
     uint32_t mb = 0;  // outcome bits so far (bit i = output i), trial bit included
+    uint32_t lvl_off = 0;
     float prev = 0.0f;
     for (uint32_t li = 0; li <= n_out; ++li) {
       cptr lvl = levels + li * L4_WORDS;
@@ -136,8 +173,15 @@ __global__ void __launch_bounds__(256) k_sample4w(Wide4Args W) {
       e[K] = (F + 1u + (mb & 15u)) * kEntry;
       e[K + 1] = (F + 17u + ((mb >> 4) & 15u)) * kEntry;
       float re, im;
-      if (lvl[L4_FLAGS] & TSIMK_LFLAG_FIXED) eval_level4<GT, K + 2, true>(A.img, img, lvl, e, tile_bytes, lvl[L4_STAB], lds_tab, re, im);
-      else eval_level4<GT, K + 2, false>(A.img, img, lvl, e, tile_bytes, lvl[L4_STAB], lds_tab, re, im);
+      const bool fixed = (lvl[L4_FLAGS] & TSIMK_LFLAG_FIXED) != 0;
+      if (W.resident) {
+        if (fixed) eval_level4_resident<K + 2, true>(A.img, img, lvl, e, lds0 + lvl_off, tile_bytes, re, im);
+        else eval_level4_resident<K + 2, false>(A.img, img, lvl, e, lds0 + lvl_off, tile_bytes, re, im);
+        lvl_off += lvl[L4_G] * tile_bytes;
+      } else {
+        if (fixed) eval_level4<GT, K + 2, true>(A.img, img, lvl, e, tile_bytes, lvl[L4_STAB], lds_tab, re, im);
+        else eval_level4<GT, K + 2, false>(A.img, img, lvl, e, tile_bytes, lvl[L4_STAB], lds_tab, re, im);
+      }
       const float v1 = cabs32(re, im);
       if (li == 0) { prev = v1; continue; }
       const uint32_t i = li - 1u;

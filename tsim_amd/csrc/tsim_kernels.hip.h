@@ -48,6 +48,9 @@ struct SampleArgs {
   long long shot_offset;    // in-batch index of row 0
   int WF, WO;               // 64-bit words per f row / out row
   int n_direct, direct_off; // direct table: (src | flip<<31, dst) pairs
+  // the same moves as a gather program (bit-field runs, see gather_runs below): image offset (64-byte aligned) and
+  // number of 16-word chunks; direct_chunks == 0: walk the pair table instead
+  int direct_prog, direct_chunks;
   int n_comp, comp_off;
   // optional row indirection (device-side post-selection): launch slot i handles row
   // row_index[i] for i < *row_count; the Threefry counter stays the row's own in-batch index,
@@ -85,6 +88,33 @@ __device__ __forceinline__ void store_compact_row(const SampleArgs &A, long long
   if (!A.out_compact) return;
   uint8_t *dst = A.out_compact + row * A.out_rb;
   for (int k = 0; k < A.out_rb; ++k) dst[k] = (uint8_t)(lds_o[(k >> 2) * stride] >> (8 * (k & 3)));
+}
+
+// A gather program moves bit fields of the packed f row to a destination bit vector.  It is a list of 4-word runs
+// [ctl, mask, flip, 0], four runs per 64-byte chunk (one s_load_dwordx16; the last chunk is padded with mask = 0
+// runs), built by the packer from (source bit, destination bit, flip) moves that are contiguous in both words:
+//   ctl = src_shift | dst_shift << 8 | dst_word << 16 | src_word << 24
+//   dst_word[dst_shift ..] |= ((f32[src_word] >> src_shift) & mask) ^ flip
+// `lds_f` is the lane's LDS column of f words ([word][lane], stride nthr).  Destination words 0 and 1 are register
+// accumulators, higher ones (more than 64 outputs) go to the lane's LDS column `lds_hi`.
+typedef uint32_t lw_u32x16 __attribute__((ext_vector_type(16)));
+typedef const __attribute__((address_space(4))) lw_u32x16 *lw_cptr16;
+
+__device__ __forceinline__ void gather_runs(const __attribute__((address_space(4))) uint32_t *prog, uint32_t nchunks,
+                                            const uint32_t *lds_f, uint32_t *lds_hi, int nthr, uint32_t &a0, uint32_t &a1) {
+  for (uint32_t c = 0; c < nchunks; ++c) {
+    const lw_u32x16 q = *(lw_cptr16)(prog + 16u * c);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const uint32_t ctl = q[4 * k];
+      const uint32_t fw = lds_f[(ctl >> 24) * nthr];
+      const uint32_t v = (((fw >> (ctl & 31u)) & q[4 * k + 1]) ^ q[4 * k + 2]) << ((ctl >> 8) & 31u);
+      const uint32_t dw = (ctl >> 16) & 255u;
+      if (dw == 0u) a0 |= v;
+      else if (dw == 1u) a1 |= v;
+      else lds_hi[dw * nthr] |= v;
+    }
+  }
 }
 
 // subkey word j (0/1) of compiled output `o` (sampler.py:74,147-148)
@@ -534,6 +564,28 @@ __device__ __forceinline__ float nanmax(float a, float b) {
   return (isnan(a) || isnan(b)) ? NAN : fmaxf(a, b);
 }
 
+// K14: direct outputs f[idx] ^ flip (sampler.py:140-145) from the LDS-staged f row into the (zeroed) LDS output row:
+// bit-field runs when the packer emitted them (a read-modify-write of LDS per BIT made this loop the longest
+// dependency chain of a block for programs with ~100 direct detectors), else the pair table.
+__device__ __forceinline__ void direct_outputs(const SampleArgs &A, cptr img, const uint32_t *lds_f, uint32_t *lds_o, int nthr) {
+  if (A.direct_chunks > 0) {
+    uint32_t o0 = 0, o1 = 0;
+    gather_runs(img + A.direct_prog, (uint32_t)A.direct_chunks, lds_f, lds_o, nthr, o0, o1);
+    if (A.WO > 0) {
+      lds_o[0] |= o0;
+      lds_o[nthr] |= o1;
+    }
+    return;
+  }
+  cptr dt = img + A.direct_off;
+  for (int j = 0; j < A.n_direct; ++j) {
+    const uint32_t s = dt[2 * j], dst = dt[2 * j + 1];
+    const uint32_t src = s & 0x7FFFFFFFu;
+    const uint32_t bit = ((lds_f[(src >> 5) * nthr] >> (src & 31u)) ^ (s >> 31)) & 1u;
+    lds_o[(dst >> 5) * nthr] |= bit << (dst & 31u);
+  }
+}
+
 // ---------------------------------------------------------------------------
 // one component: _sample_component (sampler.py:28-81)
 // ---------------------------------------------------------------------------
@@ -646,13 +698,7 @@ __global__ void __launch_bounds__(256) k_sample(SampleArgs A) {
   for (int w = 0; w < WO32; ++w) lds_o[w * nthr] = 0u;
 
   // K14: direct outputs f[idx] ^ flip (sampler.py:140-145)
-  cptr dt = img + A.direct_off;
-  for (int j = 0; j < A.n_direct; ++j) {
-    const uint32_t s = dt[2 * j], dst = dt[2 * j + 1];
-    const uint32_t src = s & 0x7FFFFFFFu;
-    const uint32_t bit = ((lds_f[(src >> 5) * nthr] >> (src & 31u)) ^ (s >> 31)) & 1u;
-    lds_o[(dst >> 5) * nthr] |= bit << (dst & 31u);
-  }
+  direct_outputs(A, img, lds_f, lds_o, nthr);
 
   // compiled components, in processing order (sampler.py:147-162)
   for (int ci = 0; ci < A.n_comp; ++ci) {

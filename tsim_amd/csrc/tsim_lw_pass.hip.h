@@ -7,28 +7,6 @@ namespace tsimk {
 // ---------------------------------------------------------------------------
 // pass 1
 // ---------------------------------------------------------------------------
-typedef uint32_t lw_u32x16 __attribute__((ext_vector_type(16)));
-typedef const __attribute__((address_space(4))) lw_u32x16 *lw_cptr16;
-
-// runs one gather program; destination words 0 and 1 are register accumulators, higher ones (rare:
-// more than 64 outputs) go to the lane's LDS column `lds_hi` (may be nullptr when there are none)
-__device__ __forceinline__ void lw_gather(cptr prog, uint32_t nchunks, const uint32_t *lds_f, uint32_t *lds_hi,
-                                          int nthr, uint32_t &a0, uint32_t &a1) {
-  for (uint32_t c = 0; c < nchunks; ++c) {
-    const lw_u32x16 q = *(lw_cptr16)(prog + 16u * c);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const uint32_t ctl = q[4 * k];
-      const uint32_t fw = lds_f[(ctl >> 24) * nthr];
-      const uint32_t v = (((fw >> (ctl & 31u)) & q[4 * k + 1]) ^ q[4 * k + 2]) << ((ctl >> 8) & 31u);
-      const uint32_t dw = (ctl >> 16) & 255u;
-      if (dw == 0u) a0 |= v;
-      else if (dw == 1u) a1 |= v;
-      else lds_hi[dw * nthr] |= v;
-    }
-  }
-}
-
 __global__ void __launch_bounds__(1024) k_sample_lw(LwArgs L) {
   const SampleArgs &A = L.s;
   const int nthr = blockDim.x;
@@ -61,13 +39,13 @@ __global__ void __launch_bounds__(1024) k_sample_lw(LwArgs L) {
     if (hard) L.ctl[32 * TSIMK_LW_LISTS] = (uint32_t)row;
 
     // K14: direct outputs f[idx] ^ flip (sampler.py:140-145), as bit-field moves
-    lw_gather(img + L.direct_prog, (uint32_t)L.direct_chunks, lds_f, lds_o, nthr, o0, o1);
+    gather_runs(img + L.direct_prog, (uint32_t)L.direct_chunks, lds_f, lds_o, nthr, o0, o1);
 
     for (int ci = 0; ci < A.n_comp; ++ci) {
       cptr rec = img + L.lw_off + ci * LW_WORDS;
       // f_sel gather (sampler.py:48) -> x, then the weight test
       uint32_t x0 = 0, x1 = 0;
-      lw_gather(img + rec[LW_FSELP], rec[LW_FSELN], lds_f, nullptr, nthr, x0, x1);
+      gather_runs(img + rec[LW_FSELP], rec[LW_FSELN], lds_f, nullptr, nthr, x0, x1);
       unsigned long long xf = ((unsigned long long)x1 << 32) | x0;
       const uint32_t cnt = (uint32_t)__popcll(xf);
       if (cnt > rec[LW_WMAX]) hard = true;

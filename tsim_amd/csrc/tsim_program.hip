@@ -332,8 +332,8 @@ retry_pack:
     for (auto &c : p->comps)
       for (auto &lv : c.levels) ok = ok && level_v4_eligible(lv);
     // wide components (more than 64 parameters): column tables only, for the sparse-column kernel k_sample4w.
-    // Needs sequential components of at most 8 outputs over at most 256 ascending f indices below 256.
-    bool wide = !ok && !p->comps.empty() && p->max_f_index < 256;
+    // Needs sequential components of at most 8 outputs over at most 256 ascending f indices below 512.
+    bool wide = !ok && !p->comps.empty() && p->max_f_index < 32 * TSIMK_W_SELWORDS;
     for (auto &c : p->comps) {
       wide = wide && (c.n_levels == c.n_out + 1) && c.n_out <= 8 && c.F <= 256;
       for (int j = 1; j < c.F; ++j) wide = wide && c.f_selection[j] > c.f_selection[j - 1];
@@ -355,7 +355,10 @@ retry_pack:
       p->v4_max_nch = 16;
       for (int v : kNch)
         if (4 * v >= maxp) { p->v4_max_nch = v; break; }
-      if (wide) p->v4_max_nch = 0;  // no chunk tables at all
+      if (wide) {  // no chunk tables at all, one graph per tile (column tables only)
+        p->v4_max_nch = 0;
+        p->v4_gt = 1;
+      }
       for (size_t ci = 0; ci < p->comps.size(); ++ci) {
         HostComponent &c = p->comps[ci];
         for (int w = 0; w < 8; ++w) img[p->comp4_off + ci * C4_WORDS + w] = img[p->comp_off + ci * C_WORDS + w];
@@ -394,20 +397,38 @@ retry_pack:
           lr[L4_FRAME] = (uint32_t)h.frame;
         }
         if (wide) {  // selection masks over f bits 0..255 and, per word, the selected bits below it
-          uint32_t sel[16] = {0};
+          uint32_t sel[2 * TSIMK_W_SELWORDS] = {0};
           for (int v : c.f_selection) sel[v >> 5] |= 1u << (v & 31);
-          for (int w = 1; w < 8; ++w) sel[8 + w] = sel[8 + w - 1] + (uint32_t)__builtin_popcount(sel[w - 1]);
+          for (int w = 1; w < TSIMK_W_SELWORDS; ++w)
+            sel[TSIMK_W_SELWORDS + w] = sel[TSIMK_W_SELWORDS + w - 1] + (uint32_t)__builtin_popcount(sel[w - 1]);
           while (img.size() % 16) img.push_back(0u);
           img[p->comp4_off + ci * C4_WORDS + C4_SELMASK] = (uint32_t)img.size();
-          img.insert(img.end(), sel, sel + 16);
+          img.insert(img.end(), sel, sel + 2 * TSIMK_W_SELWORDS);
         }
       }
       p->v4 = ok;
       p->v4w = wide;
+      p->v4w_resident_bytes = 0;
+      if (wide)
+        for (auto &c : p->comps) {
+          size_t tot = 0;
+          for (auto &lv : c.levels) tot += (size_t)lv.G * (size_t)(c.F + 33) * 16;
+          p->v4w_resident_bytes = std::max(p->v4w_resident_bytes, tot);
+        }
     }
   }
-  p->stats[7] = p->v4 ? 1 : 0;
+  p->stats[7] = p->v4 ? 1 : (p->v4w ? 2 : 0);
 
+  // ---- direct outputs as a gather program (bit-field runs), for every sampling kernel ----
+  {
+    std::vector<std::array<int, 3>> de;
+    for (int j = 0; j < p->n_direct; ++j) de.push_back({p->direct_f[j], p->output_order[j], p->direct_flips[j] ? 1 : 0});
+    std::vector<uint32_t> prog = emit_gather_program(de);
+    while (img.size() % 16) img.push_back(0u);
+    p->lw_direct_prog = (int)img.size();
+    p->lw_direct_chunks = (int)(prog.size() / 16);
+    img.insert(img.end(), prog.begin(), prog.end());
+  }
   // ---- low-weight pattern tables: plan (records + sizes); built on the device after upload ----
   p->lw = false;
   p->lw_wmax.clear();
@@ -446,14 +467,8 @@ retry_pack:
       ok = tsim_tables_plan(p, p->lw_cap_now, p->lw_budget);
       if (ok) {
         p->lw = true;
-        // gather programs: direct outputs, then every component's f_sel
-        std::vector<std::array<int, 3>> de;
-        for (int j = 0; j < p->n_direct; ++j) de.push_back({p->direct_f[j], p->output_order[j], p->direct_flips[j] ? 1 : 0});
-        std::vector<uint32_t> prog = emit_gather_program(de);
-        while (img.size() % 16) img.push_back(0u);
-        p->lw_direct_prog = (int)img.size();
-        p->lw_direct_chunks = (int)(prog.size() / 16);
-        img.insert(img.end(), prog.begin(), prog.end());
+        // gather programs of every component's f_sel (the LDS-staged first pass)
+        std::vector<uint32_t> prog;
         for (size_t ci = 0; ci < p->comps.size(); ++ci) {
           prog = emit_gather_program(lw_fsel_progs[ci]);
           img[p->lw_off + ci * LW_WORDS + LW_FSELP] = (uint32_t)img.size();
@@ -505,6 +520,7 @@ retry_pack:
     p->knobs.defer = env_int("TSIM_AMD_DEFER_HARD", 1) != 0;
     p->knobs.lw_reg = env_int("TSIM_AMD_LW_REG", 1) != 0;
     p->knobs.wide = env_int("TSIM_AMD_WIDE", 1) != 0;
+    p->knobs.direct_runs = env_int("TSIM_AMD_DIRECT_RUNS", 1) != 0;
     p->knobs.merge_lists = env_int("TSIM_AMD_MERGE_LISTS", 1) != 0;
     p->knobs.list_rows = env_int("TSIM_AMD_LIST_ROWS", 40);
     p->knobs.min_lists = env_int("TSIM_AMD_MIN_LISTS", 4);

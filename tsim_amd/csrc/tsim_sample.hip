@@ -272,6 +272,8 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
   a.WO = (p->num_outputs + 63) / 64;
   a.n_direct = p->n_direct;
   a.direct_off = p->direct_off;
+  a.direct_prog = p->lw_direct_prog;
+  a.direct_chunks = p->knobs.direct_runs ? p->lw_direct_chunks : 0;
   a.n_comp = (int)p->comps.size();
   a.comp_off = p->comp_off;
   a.row_index = d_row_index;
@@ -385,8 +387,11 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
     sl.parity ^= 1;
     w.list_cap = (int)list_cap;
     w.n_lists = kWideLists;
-    const size_t ldsw = (size_t)(2 * a.WF + 2 * a.WO) * kWideBlock * 4 + 2 * (size_t)p->v4_max_sent * p->v4_gt * 16;
-    hipLaunchKernelGGL((k_sample4w<4, kWideK>), dim3((unsigned)grid1), dim3(kWideBlock), ldsw, s, w);
+    const size_t stage_b = (size_t)(2 * a.WF + 2 * a.WO) * kWideBlock * 4, stream_b = 2 * (size_t)p->v4_max_sent * p->v4_gt * 16;
+    // all levels of a component resident in LDS when that still leaves room for two blocks per CU
+    w.resident = (stage_b + p->v4w_resident_bytes <= 64 * 1024) ? 1 : 0;
+    const size_t ldsw = stage_b + (w.resident ? std::max(p->v4w_resident_bytes, (size_t)16) : stream_b);
+    hipLaunchKernelGGL((k_sample4w<1, kWideK>), dim3((unsigned)grid1), dim3(kWideBlock), ldsw, s, w);
     HIP_TRY(hipGetLastError());
     if (prof) { int r = prof_event(p, s, PROF_PASS1); if (r) return r; }
     a.row_index = w.hard_index;

@@ -64,51 +64,55 @@ class Channel:
 # ---- outcome tables of the noise instructions (bit orders are the reference's, channels.py:47-198) -------
 
 
+def _outcome_table(num_bits: int, fires: dict, stay: float) -> np.ndarray:
+    """Outcome distribution of a noise instruction: ``fires[outcome]`` for the listed non-identity outcomes,
+    ``stay`` for outcome 0, zero elsewhere (bit ``i`` of an outcome = the instruction's error bit ``i``)."""
+    table = np.zeros(1 << num_bits, dtype=np.float64)
+    table[0] = stay
+    for outcome, prob in fires.items():
+        table[outcome] = prob
+    return table
+
+
 def error_probs(p: float) -> np.ndarray:
     """One error bit that fires with probability ``p``."""
-    return np.array([1 - p, p], dtype=np.float64)
+    return _outcome_table(1, {0b1: p}, 1 - p)
 
 
 def pauli_channel_1_probs(px: float, py: float, pz: float) -> np.ndarray:
     """Single-qubit Pauli channel; bit 0 = Z component, bit 1 = X component (Y = both)."""
-    return np.array([1 - px - py - pz, pz, px, py], dtype=np.float64)
+    return _outcome_table(2, {0b01: pz, 0b10: px, 0b11: py}, 1 - px - py - pz)
 
 
 def heralded_pauli_channel_1_probs(pi: float, px: float, py: float, pz: float) -> np.ndarray:
     """Heralded Pauli channel; bit 0 = herald, bit 1 = Z, bit 2 = X.  Nothing fires without the herald."""
-    probs = np.zeros(8, dtype=np.float64)
-    probs[0] = 1 - pi - px - py - pz
-    for outcome, p in ((0b001, pi), (0b011, pz), (0b101, px), (0b111, py)):
-        probs[outcome] = p
-    return probs
+    return _outcome_table(3, {0b001: pi, 0b011: pz, 0b101: px, 0b111: py}, 1 - pi - px - py - pz)
 
 
 def correlated_error_probs(probabilities) -> np.ndarray:
-    """``CORRELATED_ERROR(p1) ELSE_CORRELATED_ERROR(p2) ...``: one bit per branch, at most one fires."""
-    probs = np.zeros(1 << len(probabilities), dtype=np.float64)
-    none_yet = 1.0
+    """``CORRELATED_ERROR(p1) ELSE_CORRELATED_ERROR(p2) ...``: one bit per branch, at most one fires - branch
+    ``i`` with its own probability times the probability that no earlier branch did."""
+    fires, none_yet = {}, 1.0
     for branch, p in enumerate(probabilities):
-        probs[1 << branch] = none_yet * p
+        fires[1 << branch] = none_yet * p
         none_yet *= 1 - p
-    probs[0] = none_yet
-    return probs
+    return _outcome_table(len(probabilities), fires, none_yet)
 
 
 # ---- the two arithmetic primitives ---------------------------------------------------------------------------
 
 
 def xor_convolve(pa: np.ndarray, pb: np.ndarray) -> np.ndarray:
-    """Distribution of ``A xor B`` for independent ``A ~ pa``, ``B ~ pb`` over the same outcome space.
-
-    Entry ``o`` receives its terms ``pa[a] * pb[a ^ o]`` in increasing ``a`` (one vector update per ``a``:
-    within it every target index occurs once) - the accumulation order the reference's tables have."""
-    n = len(pa)
-    if len(pb) != n:
-        raise ValueError(f"cannot convolve distributions over {n} and {len(pb)} outcomes")
-    out = np.zeros(n, dtype=np.float64)
-    index = np.arange(n)
-    for a in range(n):
-        out[index ^ a] += pa[a] * pb
+    """Distribution of ``A xor B`` for independent ``A ~ pa``, ``B ~ pb`` over the same outcome space:
+    ``out[o] = sum_a pa[a] * pb[a ^ o]``, the terms of every entry added in increasing ``a`` (the accumulation
+    order the reference's tables have) - one permuted copy of ``pb`` per ``a``."""
+    pa, pb = np.asarray(pa, dtype=np.float64), np.asarray(pb, dtype=np.float64)
+    if pa.shape != pb.shape:
+        raise ValueError(f"cannot convolve distributions over {len(pa)} and {len(pb)} outcomes")
+    partner = np.arange(len(pa))
+    out = np.zeros_like(pa)
+    for a, weight in enumerate(pa):
+        out += weight * pb[partner ^ a]
     return out
 
 

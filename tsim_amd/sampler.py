@@ -69,14 +69,11 @@ def plan_batches(shots: int, batch_size: int | None, cap: int, *, reserve_row: b
     rows, evenly filled.  ``reserve_row``: one row of the first batch is spoken for (the noiseless reference
     row), so a plan that covers ``shots`` exactly grows by one row per batch - shapes stay uniform
     (the table of test/unit/test_sampler.py:288-346)."""
-    if batch_size is None:
-        count = max(1, -(-shots // cap))
-        size = -(-shots // count)
-    else:
-        size, count = batch_size, -(-shots // batch_size)
-    if reserve_row and size * count == shots:
-        size += 1
-    return BatchPlan(size, count)
+    ceil_div = lambda a, b: -(-a // b)  # noqa: E731
+    count = ceil_div(shots, batch_size) if batch_size is not None else max(1, ceil_div(shots, cap))
+    size = batch_size if batch_size is not None else ceil_div(shots, count)
+    spare = size * count - shots  # rows sampled beyond the request
+    return BatchPlan(size + (1 if reserve_row and spare == 0 else 0), count)
 
 
 def _check_request(shots: int, batch_size: int | None) -> None:
@@ -304,11 +301,11 @@ class _CompiledSamplerBase:
 
     # -- the noiseless sample ------------------------------------------------------------------------------------
     def _compute_reference_sample(self) -> np.ndarray:
-        """All f = 0.  A key split is consumed iff there is a compiled component (sampler.py:263-276)."""
-        f0 = np.zeros((1, self._channel_sampler.num_f), dtype=np.uint8)
-        if not self._program.components:
-            return self._direct.fill(f0)[0]
-        return np.asarray(self._seam(f0, self._next_key())[0], dtype=np.bool_)
+        """The outputs of the noiseless circuit (all f = 0); costs a key split iff something is compiled
+        (sampler.py:263-276)."""
+        quiet = np.zeros((1, self._channel_sampler.num_f), dtype=np.uint8)
+        rows = self._seam(quiet, self._next_key()) if self._program.components else self._direct.fill(quiet)
+        return np.asarray(rows[0], dtype=np.bool_)
 
     def _compute_direct_outputs(self, f_params_np: np.ndarray) -> np.ndarray:
         return self._direct.fill(np.asarray(f_params_np))
@@ -560,9 +557,12 @@ class CompiledMeasurementSampler(_CompiledSamplerBase):
         return self._sample_batches(shots, batch_size)
 
 
-def _pack_columns(bits: np.ndarray, bit_packed: bool) -> np.ndarray:
-    """``bit_packed=True``: little-endian bytes per row, ``np.packbits(..., bitorder="little")`` (sampler.py:665-669)."""
-    return np.packbits(bits.astype(np.bool_), axis=1, bitorder="little") if bit_packed else bits
+def _deliver(bit_packed: bool, *blocks: np.ndarray):
+    """The column blocks as the caller gets them: bools, or - ``bit_packed=True`` - little-endian bytes per row
+    (sampler.py:665-669); one block comes back bare, several as a tuple."""
+    if bit_packed:
+        blocks = tuple(np.packbits(b.view(np.uint8) if b.dtype == np.bool_ else b, axis=1, bitorder="little") for b in blocks)
+    return blocks[0] if len(blocks) == 1 else blocks
 
 
 class CompiledDetectorSampler(_CompiledSamplerBase):
@@ -611,10 +611,10 @@ class CompiledDetectorSampler(_CompiledSamplerBase):
 
         det, obs = rows[:, :nd], rows[:, nd:]
         if separate_observables:
-            return _pack_columns(det, bit_packed), _pack_columns(obs, bit_packed)
+            return _deliver(bit_packed, det, obs)
         if not prepend_observables:  # detectors first: a prefix of the rows as they are (no 80 MB copy)
-            return _pack_columns(rows if append_observables else det, bit_packed)
-        return _pack_columns(np.concatenate([obs, det] + ([obs] if append_observables else []), axis=1), bit_packed)
+            return _deliver(bit_packed, rows if append_observables else det)
+        return _deliver(bit_packed, np.concatenate([obs, det] + ([obs] if append_observables else []), axis=1))
 
 
 class CompiledStateProbs(_CompiledSamplerBase):

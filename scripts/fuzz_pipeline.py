@@ -8,7 +8,7 @@ from tsim_amd import backend as hip, synth, prng
 n_iter = int(sys.argv[1]) if len(sys.argv) > 1 else 150
 rng = np.random.default_rng(2026)
 bad = 0
-for cfg_name in ("C2", "C4", "C3"):
+for cfg_name in ("C2", "C4", "C3", "C5"):
     prog, cfg = synth.config_program(cfg_name)
     hp = hip.HipProgram(prog)                       # tables + pipelining + adaptive plan
     ref = hip.HipProgram(prog, pattern_tables=False)  # the full kernel, serial

@@ -5,12 +5,13 @@ import numpy as np, warnings
 warnings.simplefilter("ignore")
 from tsim_amd import backend as hip, synth
 from oracle import oracle_c as OC
-from test_gpu_fuzz import random_program
+from test_gpu_fuzz import random_physical_program, random_program
 bad = skipped = 0
+used = {}
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 for seed in range(n):
     rng = np.random.default_rng(5000 + seed)
-    prog, num_f = random_program(rng)
+    prog, num_f = (random_physical_program if seed % 2 else random_program)(rng)
     B = int(rng.choice([1, 64, 65, 257, 1000]))
     f = synth.synth_f(B, num_f, float(rng.choice([0.0, 0.02, 0.3])), seed=seed)
     key = (int(rng.integers(0, 2**32)), int(rng.integers(0, 2**32)))
@@ -20,10 +21,13 @@ for seed in range(n):
     for mode, pt in (("auto", None), ("auto", False), ("rows", True), ("faithful", True), ("auto", 1)):
         hp = hip.HipProgram(prog, mode=mode, pattern_tables=pt)
         got, gdev = hp.sample_batch(f, key)
+        kinds = hp.info(); used[(kinds["chunk_table_kernel"], kinds["wide_sparse_kernel"], kinds["pattern_tables"])] = used.get((kinds["chunk_table_kernel"], kinds["wide_sparse_kernel"], kinds["pattern_tables"]), 0) + 1
         if pt is None and seed % 3 == 0:  # a second launch on the same handle: the adaptive plan must not change bits
             got2, _ = hp.sample_batch(f, key)
             if not np.array_equal(got2, got):
                 bad += 1; print("MISMATCH (second launch) seed", seed, mode, hp.info())
         if not (np.array_equal(got, want) and np.array_equal(np.asarray(gdev, np.float32), np.asarray(wdev, np.float32), equal_nan=True)):
             bad += 1; print("MISMATCH seed", seed, mode, pt, hp.info())
-print("done", n, "programs; mismatches", bad, "skipped(overflow)", skipped)
+    if seed % 50 == 49:
+        import gc; gc.collect()
+print("done", n, "programs; mismatches", bad, "skipped(overflow)", skipped, "handles by (chunk, wide, tables):", used)

@@ -33,6 +33,49 @@ def random_program(rng):
     return prog, num_f
 
 
+def random_physical_program(rng):
+    """Normalised probability models of random shape, narrow and wide (up to ~300 selected f bits): every kernel
+    family gets programs it is eligible for (chunk tables, pattern tables, sparse columns, rows)."""
+    num_f = int(rng.choice([8, 40, 64, 100, 200, 330, 500]))
+    n_comp = int(rng.integers(1, 4))
+    comps = []
+    for _ in range(n_comp):
+        n = int(rng.integers(1, 6))
+        F = int(rng.integers(1, min(num_f, int(rng.choice([12, 40, 60, 120, 250]))) + 1))
+        g0 = int(rng.integers(1, 4))
+        G = [g0]
+        for _k in range(n):
+            G.append(G[-1] + int(rng.integers(0, G[-1] + 1)))
+        comps.append(dict(n=n, F=F, G=G, density=float(rng.choice([0.05, 0.2])), ta=(0, 8), tb=(0, 8), tc=(0, 10), td=(0, 3)))
+    n_direct = int(rng.integers(0, min(num_f, 140) + 1))
+    prog = synth.physical_program(
+        num_f=num_f, n_direct=n_direct, components=comps, seed=int(rng.integers(0, 2**31)),
+        shuffle_outputs=bool(rng.integers(0, 2)), direct_flip_fraction=0.3, identity_direct=bool(rng.integers(0, 2)),
+        approx=bool(rng.integers(0, 4) == 0),
+    )
+    return prog, num_f
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_fuzz_physical_all_kernels(hip, seed):
+    rng = np.random.default_rng(7000 + seed)
+    prog, num_f = random_physical_program(rng)
+    B = int(rng.choice([1, 64, 65, 257, 1000, 2500]))
+    f = synth.synth_f(B, num_f, float(rng.choice([0.0, 0.01, 0.05, 0.3])), seed=seed)
+    key = (int(rng.integers(0, 2**32)), int(rng.integers(0, 2**32)))
+    want, wdev, ov = OC.OracleProgram(prog).sample_program(f, key, return_devs=True, return_overflow=True)
+    assert not ov
+    kinds = set()
+    for mode in ("auto", "rows", "faithful"):
+        hp = hip.HipProgram(prog, mode=mode)
+        i = hp.info()
+        kinds.add((i["chunk_table_kernel"], i["wide_sparse_kernel"], i["pattern_tables"]))
+        got, gdev = hp.sample_batch(f, key)
+        np.testing.assert_array_equal(got, want, err_msg=f"mode={mode} {i}")
+        np.testing.assert_array_equal(np.asarray(gdev, np.float32), np.asarray(wdev, np.float32), err_msg=f"mode={mode}")
+        hp.close()
+
+
 @pytest.mark.parametrize("seed", range(24))
 def test_fuzz_all_kernels(hip, seed):
     rng = np.random.default_rng(1000 + seed)

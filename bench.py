@@ -271,10 +271,16 @@ def main() -> None:
     # collective moves the group (double-buffered, queued on the lane where results complete).
     NSLOT = max(1, min(backend.HipProgram.PIPELINE_SLOTS, int(os.environ.get("TSIM_BENCH_SLOTS", "16"))))
     GATHER_EVERY = max(1, int(os.environ.get("TSIM_BENCH_GATHER_EVERY", "64")))
-    # "root0" (default): the north star's gather of the detector bit strings to rank 0 (ncclGather).
-    # "alltoall": a gather whose roots are spread over the node - group j of every rank lands on rank j - for
-    # the case where rank 0's xGMI ingress or its single PCIe link is the limit.
-    GATHER_MODE = os.environ.get("TSIM_BENCH_GATHER", "root0")
+    # How the finished rows are collected (N > 1).  "root0": the north star's gather of the detector bit strings to
+    # rank 0 (ncclGather).  "alltoall": the same gather with its roots spread over the node - group j of every rank
+    # lands on rank j (ncclAllToAll).  Arithmetic behind the default: a rank produces
+    # ~180 GB/s of bit-packed rows; xGMI is a full mesh of point-to-point links of ~50-77 GB/s per direction, so
+    # rank 0 can take in ~0.4 TB/s over its 7 links while a gather from 7 peers needs 1.2 TB/s - the single root
+    # would bound the node at ~3x one GPU.  Spread roots put 1/N of a rank's stream on each link.  Hence
+    # "auto": root0 for N <= 2 (one link either way), alltoall beyond; no N > 1 measurement exists yet to confirm.
+    GATHER_MODE = os.environ.get("TSIM_BENCH_GATHER", "auto")
+    if GATHER_MODE == "auto":
+        GATHER_MODE = "root0" if N <= 2 else "alltoall"
     if GATHER_MODE == "alltoall":
         GATHER_EVERY = (GATHER_EVERY + N - 1) // N * N
     # results are written in the reference's bit_packed layout (sampler.py:665-669: ceil(n_out/8) bytes per shot,

@@ -29,7 +29,10 @@ enum {
   LW_TAB /* float offset into tab */, LW_BASES /* image offset of 8 words: index of the first pattern of weight w */,
   LW_RSV0, LW_NPAT, LW_FSELN /* chunks of the gather program */, LW_RSV1, LW_RSV2,
   LW_SELMASK /* image offset of 4 selection-mask words + 4 prefix counts (register first pass), 0 = none */,
-  LW_WORDS = 16
+  // The masks and the bases live INSIDE the record (LW_SELMASK / LW_BASES point at these words): a wave has
+  // everything it needs of a component after one 128-byte scalar load - no dependent load behind the record.
+  LW_SEL_INLINE = 16 /* 8 words */, LW_BASES_INLINE = 24 /* 8 words */,
+  LW_WORDS = 32
 };
 // A gather program moves bit fields of the packed f row to a destination bit vector.  It is a
 // list of 4-word runs [ctl, mask, flip, 0], four runs per 64-byte chunk (one s_load_dwordx16; the

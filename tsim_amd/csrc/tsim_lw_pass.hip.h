@@ -4,6 +4,53 @@
 
 namespace tsimk {
 
+
+// ---------------------------------------------------------------------------
+// The threshold walk of one component: for output i, bit_i = u_i < thr[node], node <- 2 node + bit_i
+// (sampler.py:74-79 with the thresholds tabulated).  Walking node by node is a chain of n_out DEPENDENT 4-byte
+// gathers - five memory latencies per shot for C2, most of a wave's lifetime.  The tree of a pattern is one
+// contiguous row (2^n_out floats, level k at [2^k, 2^(k+1))), so the next THREE levels below a node are one
+// 4-byte, one 8-byte and one 16-byte word (thr + node, thr + 2 node, thr + 4 node): they are loaded together,
+// the three Threefry blocks run while they are in flight, and the bits are picked with selects - one latency
+// per three outputs, the same comparisons on the same floats.
+// ---------------------------------------------------------------------------
+template <class Emit>
+__device__ __forceinline__ void lw_walk(const SampleArgs &A, const float *thr, uint32_t n_out, uint32_t keybase,
+                                        unsigned long long shot, Emit emit) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  uint32_t node = 1u, i = 0u;
+  for (; i + 3u <= n_out; i += 3u) {
+    const float t0 = thr[node];
+    const f32x2 t1 = *reinterpret_cast<const f32x2 *>(thr + 2u * node);
+    const f32x4 t2 = *reinterpret_cast<const f32x4 *>(thr + 4u * node);
+    const float u0 = uniform01(subkey(A, keybase + i, 0), subkey(A, keybase + i, 1), shot);
+    const float u1 = uniform01(subkey(A, keybase + i + 1u, 0), subkey(A, keybase + i + 1u, 1), shot);
+    const float u2 = uniform01(subkey(A, keybase + i + 2u, 0), subkey(A, keybase + i + 2u, 1), shot);
+    const bool b0 = u0 < t0;
+    const bool b1 = u1 < (b0 ? t1.y : t1.x);
+    const float lo = b1 ? t2.y : t2.x, hi = b1 ? t2.w : t2.z;
+    const bool b2 = u2 < (b0 ? hi : lo);
+    node = 8u * node + (b0 ? 4u : 0u) + (b1 ? 2u : 0u) + (b2 ? 1u : 0u);
+    emit(i, b0);
+    emit(i + 1u, b1);
+    emit(i + 2u, b2);
+  }
+  if (n_out - i == 2u) {
+    const float t0 = thr[node];
+    const f32x2 t1 = *reinterpret_cast<const f32x2 *>(thr + 2u * node);
+    const float u0 = uniform01(subkey(A, keybase + i, 0), subkey(A, keybase + i, 1), shot);
+    const float u1 = uniform01(subkey(A, keybase + i + 1u, 0), subkey(A, keybase + i + 1u, 1), shot);
+    const bool b0 = u0 < t0;
+    const bool b1 = u1 < (b0 ? t1.y : t1.x);
+    emit(i, b0);
+    emit(i + 1u, b1);
+  } else if (n_out - i == 1u) {
+    const float u0 = uniform01(subkey(A, keybase + i, 0), subkey(A, keybase + i, 1), shot);
+    emit(i, u0 < thr[node]);
+  }
+}
+
 // ---------------------------------------------------------------------------
 // pass 1
 // ---------------------------------------------------------------------------
@@ -63,17 +110,13 @@ __global__ void __launch_bounds__(1024) k_sample_lw(LwArgs L) {
       cptr outpos = img + rec[LW_OUTPOS];
       const uint32_t keybase = rec[LW_KEYBASE];
       const float *thr = L.tab + rec[LW_TAB] + ((size_t)pat << n_out);
-      uint32_t node = 1u;
-      for (uint32_t i = 0; i < n_out; ++i) {
-        const float u = uniform01(subkey(A, keybase + i, 0), subkey(A, keybase + i, 1), shot);  // sampler.py:74-75
-        const bool bit = u < thr[node];
-        node = 2u * node + (bit ? 1u : 0u);
+      lw_walk(A, thr, n_out, keybase, shot, [&](uint32_t i, bool bit) {
         const uint32_t dst = outpos[i];
         const uint32_t v = (bit ? 1u : 0u) << (dst & 31u);
         if ((dst >> 5) == 0u) o0 |= v;
         else if ((dst >> 5) == 1u) o1 |= v;
         else lds_o[(dst >> 5) * nthr] |= v;
-      }
+      });
     }
     if (!hard) {
       if (A.out) {
@@ -204,7 +247,7 @@ __global__ void __launch_bounds__(1024) k_sample_lw_reg(LwArgs L) {
 
     for (int ci = 0; ci < A.n_comp; ++ci) {
       cptr rec = img + L.lw_off + ci * LW_WORDS;
-      cptr sel = img + rec[LW_SELMASK];  // sel[0..3]: masks, sel[4..7]: selected bits in lower words
+      cptr sel = rec + LW_SEL_INLINE;  // sel[0..3]: masks, sel[4..7]: selected bits in lower words (inside the record)
       const uint32_t m0 = f0 & sel[0], m1 = f1 & sel[1];
       uint32_t m2 = 0u, m3 = 0u;
       uint32_t cnt = (uint32_t)__builtin_popcount(m0) + (uint32_t)__builtin_popcount(m1);
@@ -217,7 +260,16 @@ __global__ void __launch_bounds__(1024) k_sample_lw_reg(LwArgs L) {
       if (hard) continue;  // needs the full kernel: nothing of this row is written here
       // colex rank = sum over the set bits, in ascending order, of C(position inside f_sel, ordinal + 1): each lane
       // walks ITS OWN set bits word by word; the binomials come from a 2 KB LDS table (no per-lane multiplications)
-      uint32_t pat = (img + rec[LW_BASES])[cnt];
+      // index of the first pattern of weight cnt: a select chain over the record's 8 base words (scalars) - a
+      // gather from the image here would be one more memory latency in front of the threshold reads
+      // (readfirstlane pins each word as a scalar: otherwise the selects are folded into ONE select of addresses
+      // and a gather again)
+      uint32_t pat = rec[LW_BASES_INLINE];
+#pragma unroll
+      for (uint32_t w = 1; w <= TSIMK_LW_MAX_WEIGHT; ++w) {
+        const uint32_t bw = (uint32_t)__builtin_amdgcn_readfirstlane((int)rec[LW_BASES_INLINE + w]);
+        pat = (cnt == w) ? bw : pat;
+      }
       uint32_t ord = 0;
       lw_rank_word(m0, sel[0], 0u, binom_lds, ord, pat);
       lw_rank_word(m1, sel[1], sel[5], binom_lds, ord, pat);
@@ -229,16 +281,12 @@ __global__ void __launch_bounds__(1024) k_sample_lw_reg(LwArgs L) {
       cptr outpos = img + rec[LW_OUTPOS];
       const uint32_t keybase = rec[LW_KEYBASE];
       const float *thr = L.tab + rec[LW_TAB] + ((size_t)pat << n_out);
-      uint32_t node = 1u;
-      for (uint32_t i = 0; i < n_out; ++i) {
-        const float u = uniform01(subkey(A, keybase + i, 0), subkey(A, keybase + i, 1), shot);  // sampler.py:74-75
-        const bool bit = u < thr[node];
-        node = 2u * node + (bit ? 1u : 0u);
+      lw_walk(A, thr, n_out, keybase, shot, [&](uint32_t i, bool bit) {
         const uint32_t dst = outpos[i];
         const uint32_t v = (bit ? 1u : 0u) << (dst & 31u);
         if ((dst >> 5) == 0u) o0 |= v;
         else o1 |= v;
-      }
+      });
     }
     if (!hard) {
       if (A.out) A.out[row] = (uint64_t)o0 | ((uint64_t)o1 << 32);  // WO == 1

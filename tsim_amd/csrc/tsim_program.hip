@@ -449,9 +449,9 @@ retry_pack:
       p->lw_cap_now = pinned ? p->lw_cap_max : std::min(5, p->lw_cap_max);
       p->lw_budget = 1024ll << 20;  // per component (4 x per program): HBM is 288 GB, and only the prefix is hot
       if (const char *e = getenv("TSIM_AMD_PATTERN_TABLE_MB")) p->lw_budget = std::max(1ll, atoll(e)) << 20;
-      while (img.size() % 16) img.push_back(0u);
+      while (img.size() % 32) img.push_back(0u);
       p->lw_off = (int)img.size();
-      img.resize(img.size() + p->comps.size() * (LW_WORDS + 8), 0u);  // records, then 8 base words per component
+      img.resize(img.size() + p->comps.size() * LW_WORDS, 0u);  // records (selection masks and bases inline)
       for (size_t ci = 0; ci < p->comps.size(); ++ci) {
         const HostComponent &c = p->comps[ci];
         const uint32_t *crec = &img[p->comp_off + ci * C_WORDS];
@@ -460,7 +460,7 @@ retry_pack:
         r[LW_F] = (uint32_t)c.F;
         r[LW_OUTPOS] = crec[C_OUTPOS];
         r[LW_KEYBASE] = crec[C_KEYBASE];
-        r[LW_BASES] = (uint32_t)(p->lw_off + p->comps.size() * LW_WORDS + ci * 8);
+        r[LW_BASES] = (uint32_t)(p->lw_off + ci * LW_WORDS + LW_BASES_INLINE);
         lw_fsel_progs.push_back({});
         for (int j = 0; j < c.F; ++j) lw_fsel_progs.back().push_back({c.f_selection[j], j, 0});
       }
@@ -496,8 +496,9 @@ retry_pack:
             uint32_t sel[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             for (int v : p->comps[ci].f_selection) sel[v >> 5] |= 1u << (v & 31);
             for (int w = 1; w < 4; ++w) sel[4 + w] = sel[4 + w - 1] + (uint32_t)__builtin_popcount(sel[w - 1]);
-            img[p->lw_off + ci * LW_WORDS + LW_SELMASK] = (uint32_t)img.size();
-            img.insert(img.end(), sel, sel + 8);
+            uint32_t *r = &img[p->lw_off + ci * LW_WORDS];
+            r[LW_SELMASK] = (uint32_t)(p->lw_off + ci * LW_WORDS + LW_SEL_INLINE);
+            memcpy(r + LW_SEL_INLINE, sel, sizeof sel);
           }
       } else {
         p->lw_wmax.clear();

@@ -33,7 +33,7 @@ bool tsim_tables_plan(tsim_program *p, int cap, long long budget) {
     uint32_t bases[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int w = 0; w <= cap && w <= TSIMK_LW_MAX_WEIGHT; ++w) {
       const long long cnt = binom(c.F, w);
-      const long long bytes = ((npat + cnt) << c.n_out) * 4;
+      const long long bytes = ((npat + cnt) << c.n_out) * 4;  // (the component's table starts on a 128-byte line)
       if (bytes > budget || (w > 1 && tab_off * 4 + bytes > 4 * budget)) break;  // per component / all together
       if (((npat + cnt) << c.n_out) + tab_off >= (1ll << 32)) break;              // float offsets are 32-bit
       bases[w] = (uint32_t)npat;
@@ -49,6 +49,7 @@ bool tsim_tables_plan(tsim_program *p, int cap, long long budget) {
     p->lw_wmax.push_back(wmax);
     p->lw_npat.push_back(npat);
     tab_off += npat << c.n_out;
+    tab_off = (tab_off + 31) & ~31ll;  // 128-byte lines: the first pass reads a node's subtree as 8- and 16-byte words
   }
   p->lw_bytes = tab_off * 4;
   return true;
@@ -81,9 +82,9 @@ int tsim_tables_build(tsim_program *p, float **old) {
   float *tab = nullptr;
   hipError_t me = hipMalloc((void **)&tab, std::max<size_t>(16, (size_t)p->lw_bytes));
   if (me != hipSuccess) return tsim_fail(TSIM_ENOMEM, "hipMalloc(%lld) for the pattern tables failed: %s", p->lw_bytes, hipGetErrorString(me));
-  long long tab_off = 0;
   for (size_t ci = 0; ci < p->comps.size(); ++ci) {
     const HostComponent &c = p->comps[ci];
+    const long long tab_off = (long long)p->img[p->lw_off + ci * LW_WORDS + LW_TAB];
     std::vector<unsigned long long> pats;
     pats.reserve((size_t)p->lw_npat[ci]);
     enumerate_patterns(c.F, p->lw_wmax[ci], pats);
@@ -109,7 +110,6 @@ int tsim_tables_build(tsim_program *p, float **old) {
       (void)hipFree(tab);
       return r ? r : tsim_fail(TSIM_EHIP, "pattern table build failed: %s", hipGetErrorString(e));
     }
-    tab_off += lanes;
   }
   if (old) *old = p->d_lw_tab;
   p->d_lw_tab = tab;
@@ -123,7 +123,7 @@ int tsim_tables_extend(tsim_program *p) {
   const std::vector<int> before = p->lw_wmax;
   const std::vector<long long> npat_before = p->lw_npat;
   const long long bytes_before = p->lw_bytes;
-  std::vector<uint32_t> saved(p->img.begin() + p->lw_off, p->img.begin() + p->lw_off + p->comps.size() * (LW_WORDS + 8));
+  std::vector<uint32_t> saved(p->img.begin() + p->lw_off, p->img.begin() + p->lw_off + p->comps.size() * LW_WORDS);
   p->lw_cap_now = p->lw_cap_max;
   if (!tsim_tables_plan(p, p->lw_cap_max, p->lw_budget) || p->lw_wmax == before) {
     // nothing to gain (budget): restore the plan, never ask again
@@ -142,7 +142,7 @@ int tsim_tables_extend(tsim_program *p) {
     (void)hipGetLastError();
     return 0;
   }
-  HIP_TRY(hipMemcpy(p->d_img + p->lw_off, p->img.data() + p->lw_off, p->comps.size() * (LW_WORDS + 8) * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(p->d_img + p->lw_off, p->img.data() + p->lw_off, p->comps.size() * LW_WORDS * 4, hipMemcpyHostToDevice));
   if (old) HIP_TRY(hipFree(old));
   return 0;
 }

@@ -41,7 +41,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md)
-VALU_PEAK_TOPS = 78.6  # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz, one int32 lane-op per lane-clock
+VALU_PEAK_WAVE_INSTS = 5.7e11  # wave64 int VALU instructions/s, whole chip: measured (scripts/microbench/valu_peak.hip)
 NF = 4                 # distinct f batches rotated through the timed loop
 
 
@@ -84,23 +84,35 @@ def load_pmc(config: str, shots: int):
     return None
 
 
-def valu_block(ref_ops_per_shot: int, shots: int, kernel_s: float, pmc) -> dict:
-    """The bound that actually binds: integer VALU issue."""
+def valu_block(ref_ops_per_shot: int, shots: int, kernel_s: float, serial_s, step_s: float, pmc) -> dict:
+    """The bound that actually binds: integer VALU issue.
+
+    Peak: a wave64 integer instruction (add / rotate / xor - the Threefry mix) occupies a SIMD for 4.2 cycles,
+    measured with scripts/microbench/valu_peak.hip on this chip at 8 waves per SIMD: 5.7e11 wave-instructions/s
+    over 1024 SIMDs.  Executed instructions per launch: rocprofv3 --pmc SQ_INSTS_VALU, all kernels of a launch
+    (first pass + its share of the hard-row kernels)."""
     out = {
         "bound": "valu_issue",
+        "peak_wave_insts_per_s": VALU_PEAK_WAVE_INSTS,
+        "peak_source": "scripts/microbench/valu_peak.hip on MI355X: 4.1-4.35 cycles per wave64 int instruction and SIMD "
+                       "(profiles/r02/valu_peak.txt)",
         "reference_algorithm_ops_per_shot": ref_ops_per_shot,
-        "reference_algorithm_equiv_Tlaneops": ref_ops_per_shot * shots / kernel_s / 1e12,
-        "peak_Tlaneops_at_2cyc_issue": VALU_PEAK_TOPS,
     }
     if pmc and "SQ_INSTS_VALU" in pmc:
         insts = float(pmc["SQ_INSTS_VALU"])
-        simd_cycles = kernel_s * 2.4e9 * 1024
+        first = float(pmc.get("_per_kernel", {}).get("k_sample_lw_reg", pmc.get("_per_kernel", {}).get("k_sample_lw", {})).get("SQ_INSTS_VALU", insts))
         out.update({
             "executed_valu_wave_insts_per_launch": insts,
             "executed_valu_wave_insts_per_64_shots": insts / (shots / 64.0),
-            "cycles_per_valu_inst_per_simd_at_2p4GHz": simd_cycles / insts,
-            "valu_issue_busy_frac_at_4cyc": min(1.0, 4.0 * insts / simd_cycles),
+            "threefry_floor_wave_insts_per_64_shots": "77 per draw: 20 rounds x (add, rotate, xor) + key injections + float conversion",
+            "achieved_wave_insts_per_s_at_step_rate": insts / step_s,
+            "frac_at_step_rate": insts / step_s / VALU_PEAK_WAVE_INSTS,
+            "frac_dominant_kernel_serial": (first / serial_s / VALU_PEAK_WAVE_INSTS) if serial_s else None,
+            "frac_dominant_kernel_in_pipeline": first / kernel_s / VALU_PEAK_WAVE_INSTS,
             "pmc_source": "profiles/latest_pmc.json (rocprofv3 --pmc SQ_INSTS_VALU, same workload)",
+            "note": "frac_at_step_rate = VALU instructions of everything one step launches / step time / issue peak: the "
+                    "share of the chip's VALU issue slots the pipeline keeps busy.  75 % of the first pass's instructions "
+                    "are the Threefry blocks the reference's draws require (one block per shot and sampled output).",
         })
     return out
 
@@ -532,7 +544,7 @@ def main() -> None:
                 "bytes/shot), achieved_serial the kernel's duration with the GPU to itself (= rocprofv3's serial kernel "
                 "trace).  Integer-VALU / latency bound, not HBM bound (DESIGN.md section 3.5): see `valu`.",
             },
-            "valu": valu_block(ops_per_shot, B, avg_kernel_s, pmc),
+            "valu": valu_block(ops_per_shot, B, avg_kernel_s, (serial_ms * 1e-3) if serial_ms else None, elapsed / args.steps, pmc),
         }
         res.update(extra)
         if N == 1 and not args.no_cpu_baseline:

@@ -136,6 +136,7 @@ struct tsim_program {
   int lw_weight_cap = -1;     // -1 = TSIMK_LW_MAX_WEIGHT
   bool lw = false;            // tables built, pass 1 active
   int lw_binom_off = 0;       // image offset of the binomial table of the register first pass
+  int n_cu = 256;             // compute units of the device (grid sizing)
   bool lw_reg = false;        // the register form of pass 1 applies (narrow f rows, ascending f_selection)
   // Launch slots: slot 0 serves the serial API (everything on the caller's stream); slots 1..4 serve
   // tsim_sample_batch_device_begin/_end: a slot's launches run on the slot's own stream (`side`) so
@@ -197,6 +198,7 @@ struct tsim_program {
     bool direct_runs = true;  // TSIM_AMD_DIRECT_RUNS=0: direct outputs bit by bit (pair table) in the full kernels
     bool wide = true;         // TSIM_AMD_WIDE=0: wide components on the row kernel alone (no sparse-column pass)
     bool lw_reg = true;       // TSIM_AMD_LW_REG=0: LDS-staged first pass even where the register form applies
+    int lw_resident = 1;      // TSIM_AMD_LW_RESIDENT: first-pass grid = this many chip-fulls of blocks, rows by grid stride (0: one block per 1024 rows)
     bool defer = true;        // TSIM_AMD_DEFER_HARD=0: every pipelined launch runs its own second pass
     int defer_group = 4;      // TSIM_AMD_DEFER_GROUP: launches per deferred hard-row batch (<= TSIMK_H_MAX_CTX)
   } knobs;
@@ -205,6 +207,7 @@ struct tsim_program {
   int lw_off = 0;             // image offset of the LW component records
   int lw_direct_prog = 0;     // image offset of the direct-output gather program
   int lw_direct_chunks = 0;
+  int lw_direct_rot = 0;      // the same moves in rotate-and-mask form (register first pass), 0 = none
   std::vector<int> lw_wmax;   // per component
   std::vector<long long> lw_npat;  // per component: tabulated patterns
   int lw_cap_now = 0, lw_cap_max = 0;  // table depth built / allowed (tsim_tables_extend deepens on demand)
@@ -245,6 +248,7 @@ void emit_level4(const HostLevel &h, int GT, int nch, const uint32_t *v3recs, st
                  std::vector<uint32_t> &tabs4, int &nch_out, int &ntiles_out, int sparse_F,
                  std::vector<uint32_t> &stabs4);
 std::vector<uint32_t> emit_gather_program(std::vector<std::array<int, 3>> e);
+std::vector<uint32_t> emit_rotmask_program(const std::vector<std::array<int, 3>> &e);
 }  // namespace tsimhost
 
 // ---- tsim_tables.hip

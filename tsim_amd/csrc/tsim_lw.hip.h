@@ -128,6 +128,7 @@ struct LwArgs {
   int lw_off;             // image offset of the LW component records
   int direct_prog;        // image offset of the direct-output gather program (64-byte aligned)
   int direct_chunks;
+  int direct_rot;         // image offset of the rotate-and-mask form of the same program (register first pass)
   int has_check;          // the first slot's row is the normalisation-check row: always "hard"
   uint32_t *hard_index;   // out: n_lists sub-lists of list_cap rows that need the full kernel
   uint32_t *ctl;          // ctl[32 k] = entries of list k (zeroed by the caller), ctl[32 LISTS] = check row

@@ -152,7 +152,7 @@ __global__ void __launch_bounds__(1024) k_sample_lw(LwArgs L) {
 // ---------------------------------------------------------------------------
 // pass 1, register form: narrow programs (f rows of at most 128 bits, at most 64 outputs, every component's
 // f_selection ascending - what the reference's compiler emits, pipeline.py:141-143).  Nothing is staged in LDS:
-//   * the f row lives in WF32 VGPRs; direct outputs are bit-field runs on those registers;
+//   * the f row lives in WF32 VGPRs; direct outputs are rotate-and-mask runs on those registers;
 //   * f_sel is never materialised: the weight test is popcount(f & selection mask) per word, and the colex rank
 //     of the pattern is accumulated from the set bits directly - the position of a set bit inside f_sel is the
 //     number of selected bits below it, popcount(mask & (2^p - 1)) plus the word's prefix count (both wave-uniform
@@ -160,31 +160,34 @@ __global__ void __launch_bounds__(1024) k_sample_lw(LwArgs L) {
 //     of every lane running the whole gather program (one run per contiguous bit field, ~16 for C2).
 // Same thresholds, same Threefry draws, same hard-row protocol as k_sample_lw.
 // ---------------------------------------------------------------------------
-// word `sw` (wave-uniform) of the f row.  Written as a select tree over four SCALARS on purpose: an array indexed
-// through a compare chain is recognised as dynamic indexing, and the compiler then parks the whole row in LDS
-// (measured: 46.8 instead of 21.7 us for 128-bit rows).
+// Direct outputs from registers, rotate-and-mask form (tsim_pack.hip: emit_rotmask_program): the loops over source
+// and destination word are compile-time, a run is v_alignbit + v_and_or.
 template <int WF32>
-__device__ __forceinline__ uint32_t lw_pick(uint32_t sw, uint32_t f0, uint32_t f1, uint32_t f2, uint32_t f3) {
-  const uint32_t lo = (sw & 1u) ? f1 : f0;
-  if constexpr (WF32 <= 2) return lo;
-  const uint32_t hi = (sw & 1u) ? f3 : f2;
-  return (sw & 2u) ? hi : lo;
-}
-
-template <int WF32>
-__device__ __forceinline__ void lw_gather_reg(cptr prog, uint32_t nchunks, uint32_t f0, uint32_t f1, uint32_t f2,
-                                              uint32_t f3, uint32_t &a0, uint32_t &a1) {
-  for (uint32_t c = 0; c < nchunks; ++c) {
-    const lw_u32x16 q = *(lw_cptr16)(prog + 16u * c);
+__device__ __forceinline__ void lw_direct_reg(cptr prog, uint32_t f0, uint32_t f1, uint32_t f2, uint32_t f3,
+                                              uint32_t &o0, uint32_t &o1) {
+  typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+  typedef const __attribute__((address_space(4))) u32x8 *cptr8;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const uint32_t ctl = q[4 * k];
-      const uint32_t src = lw_pick<WF32>(ctl >> 24, f0, f1, f2, f3);
-      const uint32_t v = (((src >> (ctl & 31u)) & q[4 * k + 1]) ^ q[4 * k + 2]) << ((ctl >> 8) & 31u);
-      if (((ctl >> 16) & 255u) == 0u) a0 |= v;
-      else a1 |= v;
+  for (int s = 0; s < WF32; ++s) {
+    const uint32_t src = (s == 0) ? f0 : (s == 1) ? f1 : (s == 2) ? f2 : f3;
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+      const uint32_t groups = prog[s * 2 + d];
+      cptr q = prog + prog[8 + s * 2 + d];
+      uint32_t acc = 0u;
+      for (uint32_t g = 0; g < groups; ++g) {
+        const u32x8 v = *(cptr8)(q + 8u * g);
+        acc |= __builtin_amdgcn_alignbit(src, src, v[0]) & v[1];
+        acc |= __builtin_amdgcn_alignbit(src, src, v[2]) & v[3];
+        acc |= __builtin_amdgcn_alignbit(src, src, v[4]) & v[5];
+        acc |= __builtin_amdgcn_alignbit(src, src, v[6]) & v[7];
+      }
+      if (d == 0) o0 |= acc;
+      else o1 |= acc;
     }
   }
+  o0 ^= prog[16];
+  o1 ^= prog[17];
 }
 
 // the lane's set bits of one masked f word: each adds C(position inside f_sel, ordinal + 1) to the colex rank
@@ -203,13 +206,8 @@ template <int WF32>
 __global__ void __launch_bounds__(1024) k_sample_lw_reg(LwArgs L) {
   const SampleArgs &A = L.s;
   const int nthr = blockDim.x;
-  const long long slot = (long long)blockIdx.x * nthr + threadIdx.x;
   long long n_rows = A.B;
   if (A.row_index) n_rows = (long long)*A.row_count;
-  const bool active = slot < n_rows;
-  long long row = slot;
-  if (A.row_index) row = active ? (long long)A.row_index[slot] : 0;
-  const unsigned long long shot = (unsigned long long)(A.shot_offset + row);
   cptr img = (cptr)(uintptr_t)A.img;
 
   if (blockIdx.x == 0 && threadIdx.x <= TSIMK_LW_LISTS)
@@ -226,9 +224,19 @@ __global__ void __launch_bounds__(1024) k_sample_lw_reg(LwArgs L) {
     __builtin_amdgcn_wave_barrier();
   }
   const uint32_t *binom_lds = reinterpret_cast<const uint32_t *>(binom_lds4);
+  // Grid-stride over the rows: the launch puts as many blocks on the chip as fit AT ONCE (tsim_sample.hip) and every
+  // wave takes several rows per lane in turn - one round of waves instead of several, each with its ramp and
+  // tail, and the per-wave preamble (kernel arguments, binomial table) paid once.  The trip count is uniform
+  // over a block, so the wave-wide append at the end of the body is executed by every lane.
+  for (long long base = (long long)blockIdx.x * nthr; base < n_rows; base += (long long)gridDim.x * nthr) {
+  const long long slot = base + threadIdx.x;
+  const bool active = slot < n_rows;
+  long long row = slot;
+  if (A.row_index) row = active ? (long long)A.row_index[slot] : 0;
+  const unsigned long long shot = (unsigned long long)(A.shot_offset + row);
   bool hard = false;
   if (active) {
-    uint32_t f0, f1, f2 = 0u, f3 = 0u;  // scalars, not an array (see lw_pick)
+    uint32_t f0, f1, f2 = 0u, f3 = 0u;  // scalars, not an array: a dynamically indexed one would be parked in LDS
     {
       const uint64_t *frow = A.f + row * (WF32 / 2);
       const uint64_t v0 = frow[0];
@@ -243,7 +251,7 @@ __global__ void __launch_bounds__(1024) k_sample_lw_reg(LwArgs L) {
     hard = L.has_check && slot == 0;
     if (hard) L.ctl[32 * TSIMK_LW_LISTS] = (uint32_t)row;
     uint32_t o0 = 0, o1 = 0;
-    lw_gather_reg<WF32>(img + L.direct_prog, (uint32_t)L.direct_chunks, f0, f1, f2, f3, o0, o1);  // K14, sampler.py:140-145
+    lw_direct_reg<WF32>(img + L.direct_rot, f0, f1, f2, f3, o0, o1);  // K14, sampler.py:140-145
 
     for (int ci = 0; ci < A.n_comp; ++ci) {
       cptr rec = img + L.lw_off + ci * LW_WORDS;
@@ -309,6 +317,7 @@ __global__ void __launch_bounds__(1024) k_sample_lw_reg(LwArgs L) {
     if (hard)
       L.hard_index[(size_t)k * L.list_cap + basei + (uint32_t)__popcll(hm & ((1ull << lane) - 1ull))] = (uint32_t)row;
   }
+  }  // rows of this block
 }
 
 }  // namespace tsimk

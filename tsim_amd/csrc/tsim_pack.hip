@@ -659,4 +659,43 @@ std::vector<uint32_t> emit_gather_program(std::vector<std::array<int, 3>> e) {
   return out;
 }
 
+// Rotate-and-mask form of a gather program, for kernels that hold the f row and the output words in REGISTERS
+// (k_sample_lw_reg): f words 0..3 -> output words 0..1.  The moves are bucketed by (source word, destination
+// word), so the kernel's loops over the buckets are compile-time and no run needs a select; a run is two VALU
+// operations, dst |= rotr(src, rot) & mask, the flips are one XOR per output word at the end.
+//   words 0..7   groups of four runs in bucket s * 2 + d          words 8..15  word offset of the bucket's runs
+//   words 16..17 flip masks of output words 0 and 1               (header: 32 words)
+//   runs: [rot, mask] pairs, every bucket padded to a multiple of four with mask = 0
+std::vector<uint32_t> emit_rotmask_program(const std::vector<std::array<int, 3>> &e) {
+  std::vector<uint32_t> out(32, 0u);
+  for (int s = 0; s < 4; ++s)
+    for (int d = 0; d < 2; ++d) {
+      std::vector<std::array<int, 2>> m;  // (src bit, dst bit) inside the words
+      for (auto &x : e)
+        if ((x[0] >> 5) == s && (x[1] >> 5) == d) {
+          m.push_back({x[0] & 31, x[1] & 31});
+          if (x[2] & 1) out[16 + d] |= 1u << (x[1] & 31);
+        }
+      std::sort(m.begin(), m.end());
+      const int b = s * 2 + d;
+      out[8 + b] = (uint32_t)out.size();
+      uint32_t runs = 0;
+      size_t i = 0;
+      while (i < m.size()) {
+        size_t j = i + 1;
+        while (j < m.size() && m[j][0] == m[j - 1][0] + 1 && m[j][1] == m[j - 1][1] + 1) ++j;
+        const int len = (int)(j - i);
+        const uint32_t field = len >= 32 ? 0xFFFFFFFFu : ((1u << len) - 1u);
+        out.push_back((uint32_t)((m[i][0] - m[i][1]) & 31));  // rotate right: source bit p lands on p - rot
+        out.push_back(field << m[i][1]);
+        ++runs;
+        i = j;
+      }
+      while (runs % 4) { out.push_back(0u); out.push_back(0u); ++runs; }
+      out[b] = runs / 4;
+    }
+  while (out.size() % 16) out.push_back(0u);
+  return out;
+}
+
 }  // namespace tsimhost

@@ -428,6 +428,12 @@ retry_pack:
     p->lw_direct_prog = (int)img.size();
     p->lw_direct_chunks = (int)(prog.size() / 16);
     img.insert(img.end(), prog.begin(), prog.end());
+    p->lw_direct_rot = 0;
+    if (p->max_f_index < 128 && p->num_outputs <= 64) {
+      prog = emit_rotmask_program(de);
+      p->lw_direct_rot = (int)img.size();
+      img.insert(img.end(), prog.begin(), prog.end());
+    }
   }
   // ---- low-weight pattern tables: plan (records + sizes); built on the device after upload ----
   p->lw = false;
@@ -520,6 +526,7 @@ retry_pack:
     p->knobs.hard_lds_kb = std::max(24, std::min(156, env_int("TSIM_AMD_HARD_LDS_KB", 128)));
     p->knobs.defer = env_int("TSIM_AMD_DEFER_HARD", 1) != 0;
     p->knobs.lw_reg = env_int("TSIM_AMD_LW_REG", 1) != 0;
+    p->knobs.lw_resident = std::max(0, std::min(8, env_int("TSIM_AMD_LW_RESIDENT", 1)));
     p->knobs.wide = env_int("TSIM_AMD_WIDE", 1) != 0;
     p->knobs.direct_runs = env_int("TSIM_AMD_DIRECT_RUNS", 1) != 0;
     p->knobs.merge_lists = env_int("TSIM_AMD_MERGE_LISTS", 1) != 0;
@@ -540,6 +547,10 @@ retry_pack:
   if (device < 0 || device >= ndev) return tsim_fail(TSIM_EINVAL, "device %d out of range (%d visible)", device, ndev);
   p->device = device;
   HIP_TRY(hipSetDevice(device));
+  {
+    int cu = 0;
+    if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cu > 0) p->n_cu = cu;
+  }
   HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
   HIP_TRY(hipMalloc((void **)&p->d_img, img.size() * 4));
   HIP_TRY(hipMemcpy(p->d_img, img.data(), img.size() * 4, hipMemcpyHostToDevice));

@@ -324,11 +324,17 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
     // few large blocks: 1024 threads finish a batch of 10^6 rows in 977 blocks - measurably better than
     // 3906 blocks of 256 when the blocks of several launches and of the hard-row kernel share the CUs
     const int blk1 = p->knobs.lw_block ? p->knobs.lw_block : ((size_t)(2 * a.WF + 2 * a.WO) * 1024 * 4 <= 32 * 1024 ? 1024 : 256);
-    const long long grid1 = (B + blk1 - 1) / blk1;
+    const bool reg_form = p->lw_reg && p->knobs.lw_reg && (a.WF == 1 || a.WF == 2) && a.WO == 1;
+    const long long blocks = (B + blk1 - 1) / blk1;
+    // the register form strides over the rows: no more blocks than the chip holds at once (2048 threads per CU)
+    long long grid1 = blocks;
+    if (reg_form && p->knobs.lw_resident > 0)
+      grid1 = std::min(blocks, (long long)p->n_cu * p->knobs.lw_resident * (2048 / blk1));
+    const long long iters = (blocks + grid1 - 1) / grid1;
     // n_lists sub-lists share the buffer sized for TSIMK_LW_LISTS of them: a list can hold every row of
     // the blocks that feed it
     const int n_lists = plan.lists;
-    const long long list_cap = (grid1 + TSIMK_LW_LISTS - 1) / TSIMK_LW_LISTS * blk1 * (TSIMK_LW_LISTS / n_lists);
+    const long long list_cap = (grid1 + n_lists - 1) / n_lists * iters * blk1;
     if (list_cap > 0x7FFFFFFFll) return tsim_fail(TSIM_ENOTSUP, "batch too large for the row lists");
     if ((size_t)list_cap * n_lists * 4 > sl.hard_sz) return tsim_fail(TSIM_ESTATE, "hard-row list too small");
     p->last_lists = n_lists;
@@ -338,6 +344,7 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
     l.lw_off = p->lw_off;
     l.direct_prog = p->lw_direct_prog;
     l.direct_chunks = p->lw_direct_chunks;
+    l.direct_rot = p->lw_direct_rot;
     l.has_check = has_check ? 1 : 0;
     l.hard_index = (uint32_t *)sl.hard;
     uint32_t *ctl = sl.ctl + sl.parity * (TSIMK_LW_LISTS + 1) * 32;
@@ -348,7 +355,7 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
     l.n_lists = n_lists;
     l.binom_off = p->lw_binom_off;
     const size_t lds1 = (size_t)(2 * a.WF + 2 * a.WO) * blk1 * 4;
-    if (p->lw_reg && p->knobs.lw_reg && (a.WF == 1 || a.WF == 2) && a.WO == 1) {
+    if (reg_form) {
       // narrow rows: everything in registers, no LDS
       if (a.WF == 1) hipLaunchKernelGGL(k_sample_lw_reg<2>, dim3((unsigned)grid1), dim3(blk1), 0, s, l);
       else hipLaunchKernelGGL(k_sample_lw_reg<4>, dim3((unsigned)grid1), dim3(blk1), 0, s, l);

@@ -137,6 +137,8 @@ struct tsim_program {
   bool lw = false;            // tables built, pass 1 active
   int lw_binom_off = 0;       // image offset of the binomial table of the register first pass
   int n_cu = 256;             // compute units of the device (grid sizing)
+  int v4w_occ_blocks = 1;     // blocks of the sparse-column kernel a CU holds at once with v4w_occ_lds bytes of LDS
+  size_t v4w_occ_lds = 0;
   bool lw_reg = false;        // the register form of pass 1 applies (narrow f rows, ascending f_selection)
   // Launch slots: slot 0 serves the serial API (everything on the caller's stream); slots 1..4 serve
   // tsim_sample_batch_device_begin/_end: a slot's launches run on the slot's own stream (`side`) so

@@ -69,14 +69,8 @@ __global__ void __launch_bounds__(256) k_sample4w(Wide4Args W) {
   static_assert(GT == 1, "the wide layout has one graph per tile");
   const SampleArgs &A = W.s;
   const int nthr = blockDim.x;
-  const long long slot = (long long)blockIdx.x * nthr + threadIdx.x;
   long long n_rows = A.B;
   if (A.row_index) n_rows = (long long)*A.row_count;
-  const bool active = slot < n_rows;
-  long long row = slot;
-  if (A.row_index) row = active ? (long long)A.row_index[slot] : 0;
-  if (!active) row = 0;
-  const unsigned long long shot = (unsigned long long)(A.shot_offset + row);
   cptr img = (cptr)(uintptr_t)A.img;
 
   if (blockIdx.x == 0 && threadIdx.x <= TSIMK_LW_LISTS)
@@ -86,6 +80,32 @@ __global__ void __launch_bounds__(256) k_sample4w(Wide4Args W) {
   uint32_t *lds_f = tsimk_lds + threadIdx.x;                // [WF32][nthr]
   uint32_t *lds_o = tsimk_lds + WF32 * nthr + threadIdx.x;  // [WO32][nthr]
   uint8_t *lds_tab = reinterpret_cast<uint8_t *>(tsimk_lds + (WF32 + WO32) * nthr);
+
+  // One component with LDS-resident tables (the usual wide program): the tables are copied ONCE per block and the
+  // block then strides over the rows - the launch sizes the grid to what the chip holds at once.  The staging
+  // columns are private to a thread, the tables read-only: no barrier between the row chunks.
+  const bool preloaded = W.resident && A.n_comp == 1;
+  if (preloaded) {
+    cptr comp = img + W.comp4_off;
+    cptr levels = img + comp[C4_LEVELS];
+    const uint32_t tile_bytes = (comp[C_F] + 33u) * (uint32_t)GT * 16u;
+    uint32_t off = 0;
+    for (uint32_t li = 0; li <= comp[C_NOUT]; ++li) {
+      cptr lvl = levels + li * L4_WORDS;
+      const uint32_t bytes = lvl[L4_G] * tile_bytes;
+      tile_copy(reinterpret_cast<const uint4 *>(A.img + lvl[L4_STAB]), lds_tab + off, bytes >> 4, threadIdx.x, nthr);
+      off += bytes;
+    }
+    __syncthreads();
+  }
+
+  for (long long base = (long long)blockIdx.x * nthr; base < n_rows; base += (long long)gridDim.x * nthr) {
+  const long long slot = base + threadIdx.x;
+  const bool active = slot < n_rows;
+  long long row = slot;
+  if (A.row_index) row = active ? (long long)A.row_index[slot] : 0;
+  if (!active) row = 0;
+  const unsigned long long shot = (unsigned long long)(A.shot_offset + row);
 
   if (active) {
     const uint64_t *frow = A.f + row * A.WF;
@@ -150,7 +170,7 @@ __global__ void __launch_bounds__(256) k_sample4w(Wide4Args W) {
     const uint32_t tile_bytes = (F + 33u) * kEntry;
     // resident mode: every level's tables into LDS now - one burst of async copies, one barrier per component
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)lds_tab;
-    if (W.resident) {
+    if (W.resident && !preloaded) {
       __syncthreads();  // the previous component's readers are done
       uint32_t off = 0;
       for (uint32_t li = 0; li <= n_out; ++li) {
@@ -215,6 +235,7 @@ __global__ void __launch_bounds__(256) k_sample4w(Wide4Args W) {
     if (hard)
       W.hard_index[(size_t)k * W.list_cap + basei + (uint32_t)__popcll(hm & ((1ull << lane) - 1ull))] = (uint32_t)row;
   }
+  }  // row chunks of this block
 }
 
 }  // namespace tsimk

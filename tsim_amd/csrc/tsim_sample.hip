@@ -379,8 +379,28 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
     // normalisation-check row go to the row lists, which the row kernel below serves
     if (B > 0xFFFFFFFFll) return tsim_fail(TSIM_ENOTSUP, "batch too large for the row list");
     constexpr int kWideBlock = 256, kWideK = 10, kWideLists = 16;
-    const long long grid1 = (B + kWideBlock - 1) / kWideBlock;
-    const long long list_cap = (grid1 + TSIMK_LW_LISTS - 1) / TSIMK_LW_LISTS * kWideBlock * (TSIMK_LW_LISTS / kWideLists);
+    const size_t stage_b = (size_t)(2 * a.WF + 2 * a.WO) * kWideBlock * 4, stream_b = 2 * (size_t)p->v4_max_sent * p->v4_gt * 16;
+    // all levels of a component resident in LDS when that still leaves room for two blocks per CU
+    const bool resident = stage_b + p->v4w_resident_bytes <= 64 * 1024;
+    const size_t ldsw = stage_b + (resident ? std::max(p->v4w_resident_bytes, (size_t)16) : stream_b);
+    const long long blocks = (B + kWideBlock - 1) / kWideBlock;
+    // One component with resident tables: the kernel copies the tables once per block and strides over the rows, so
+    // the grid is what the chip holds at once (occupancy of this kernel with this much LDS), not one block per 256 rows
+    long long grid1 = blocks;
+    if (resident && p->comps.size() == 1 && p->knobs.lw_resident > 0) {
+      if (p->v4w_occ_lds != ldsw) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_sample4w<1, kWideK>, kWideBlock, ldsw) != hipSuccess || nb < 1) {
+          (void)hipGetLastError();
+          nb = 1;
+        }
+        p->v4w_occ_blocks = nb;
+        p->v4w_occ_lds = ldsw;
+      }
+      grid1 = std::min(blocks, (long long)p->n_cu * p->v4w_occ_blocks * p->knobs.lw_resident);
+    }
+    const long long iters = (blocks + grid1 - 1) / grid1;
+    const long long list_cap = (grid1 + kWideLists - 1) / kWideLists * iters * kWideBlock;
     if (list_cap > 0x7FFFFFFFll) return tsim_fail(TSIM_ENOTSUP, "batch too large for the row lists");
     if ((size_t)list_cap * kWideLists * 4 > sl.hard_sz) return tsim_fail(TSIM_ESTATE, "row list too small");
     Wide4Args w;
@@ -394,10 +414,7 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
     sl.parity ^= 1;
     w.list_cap = (int)list_cap;
     w.n_lists = kWideLists;
-    const size_t stage_b = (size_t)(2 * a.WF + 2 * a.WO) * kWideBlock * 4, stream_b = 2 * (size_t)p->v4_max_sent * p->v4_gt * 16;
-    // all levels of a component resident in LDS when that still leaves room for two blocks per CU
-    w.resident = (stage_b + p->v4w_resident_bytes <= 64 * 1024) ? 1 : 0;
-    const size_t ldsw = stage_b + (w.resident ? std::max(p->v4w_resident_bytes, (size_t)16) : stream_b);
+    w.resident = resident ? 1 : 0;
     hipLaunchKernelGGL((k_sample4w<1, kWideK>), dim3((unsigned)grid1), dim3(kWideBlock), ldsw, s, w);
     HIP_TRY(hipGetLastError());
     if (prof) { int r = prof_event(p, s, PROF_PASS1); if (r) return r; }

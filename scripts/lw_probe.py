@@ -13,7 +13,7 @@ pk = np.zeros((B, wf * 8), np.uint8)
 q = np.packbits(f, axis=1, bitorder="little"); pk[:, :q.shape[1]] = q
 d_f = hp.malloc(pk.nbytes); hp.h2d(d_f, pk)
 d_o = hp.malloc(B * 8 * ((prog.num_outputs + 63) // 64))
-for _ in range(5):
+for _ in range(int(sys.argv[4]) if len(sys.argv) > 4 else 5):
     hp.sample_batch_device(d_f.ptr, B, num_f, (1, 2), d_o.ptr)
 hp.synchronize()
 hp.profile_enable(1); hp.profile_read(reset=True)

@@ -1,0 +1,106 @@
+"""Pattern tables in front of the sparse-column kernel (wide components, more than 64 parameters): the first pass
+k_sample_lw<true> finishes the rows whose selected f bits have weight <= depth from tables indexed by the colex rank
+of the pattern (built on the device by unranking), the others go through row lists to k_sample4w and its overflow to
+the row kernel.  Results must not depend on the depth, the launch API or the shard; every case against the oracle."""
+
+import warnings
+
+import numpy as np
+import pytest
+
+from oracle import oracle_c as OC
+from tsim_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def wide_program(seed=0):
+    comps = [dict(n=3, F=200, G=[1, 2, 2, 3], density=0.08), dict(n=2, F=90, G=[2, 3, 4], density=0.1)]
+    return synth.physical_program(num_f=320, n_direct=100, components=comps, seed=seed)
+
+
+@pytest.mark.parametrize("cap", [0, 1, 2, 3, 4])
+def test_every_depth_matches_oracle(hip, cap):
+    prog = wide_program(11)
+    orc = OC.OracleProgram(prog)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        hp = hip.HipProgram(prog, pattern_tables=cap)
+        info = hp.info()
+        assert info["wide_sparse_kernel"] and info["pattern_tables"] and info["pattern_max_weight"] == [cap, cap]
+        for p_bit in (0.0, 0.004, 0.015, 0.05):
+            f = synth.synth_f(3000, 320, p_bit, seed=int(p_bit * 1000) + cap)
+            want, wdev = orc.sample_program(f, (cap, 6), return_devs=True)
+            got, gdev = hp.sample_batch(f, (cap, 6))
+            np.testing.assert_array_equal(got, want)
+            np.testing.assert_array_equal(np.asarray(gdev, np.float32), np.asarray(wdev, np.float32))
+        hp.close()  # the weight-4 table of 200 bits is 2.1 GB
+
+
+def test_default_depth_deepens_on_demand_and_bits_do_not_change(hip):
+    prog, cfg = synth.config_program("C5")
+    orc = OC.OracleProgram(prog)
+    hp = hip.HipProgram(prog)
+    assert hp.info()["pattern_tables"] and hp.info()["pattern_max_weight"] == [3]
+    B = 20_000
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for i in range(8):
+            f = synth.synth_f(B, cfg["num_f"], cfg["p_bit"], seed=300 + i)
+            got, _ = hp.sample_batch(f, (i, 2))
+            np.testing.assert_array_equal(got, orc.sample_program(f, (i, 2)))
+        assert hp.info()["pattern_max_weight"] == [4]
+        assert hp.info()["pattern_table_bytes"] > 1 << 30
+        for i in range(3):
+            f = synth.synth_f(B, cfg["num_f"], 0.003, seed=400 + i)
+            got, _ = hp.sample_batch(f, (i, 3), shot_offset=7 * i)
+            np.testing.assert_array_equal(got, orc.sample_program(f, (i, 3), shot_offset=7 * i))
+    hp.close()
+
+
+def test_tables_off_on_and_row_kernel_agree_at_scale(hip):
+    prog, cfg = synth.config_program("C5")
+    f = synth.synth_f(150_000, cfg["num_f"], cfg["p_bit"], seed=21)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        a, _ = hip.HipProgram(prog, pattern_tables=4).sample_batch(f, (1, 2), bit_packed=True)
+        b, _ = hip.HipProgram(prog, pattern_tables=False).sample_batch(f, (1, 2), bit_packed=True)
+        c, _ = hip.HipProgram(prog, mode="rows", pattern_tables=False).sample_batch(f, (1, 2), bit_packed=True)
+    assert np.array_equal(a, b) and np.array_equal(a, c)
+
+
+def test_pipelined_bit_packed_launches(hip):
+    prog = wide_program(5)
+    nf, n_out = 320, prog.num_outputs
+    wf, rb = (nf + 63) // 64, (n_out + 7) // 8
+    hp = hip.HipProgram(prog, pattern_tables=3)
+    B = 30_000
+    orc = OC.OracleProgram(prog)
+    bufs = []
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for rnd in range(2):  # the second round reuses the slots (counter sets alternate)
+            for i in range(5):
+                f = synth.synth_f(B, nf, 0.006 * (i + 1), seed=70 + i + 10 * rnd)
+                pk = np.zeros((B, wf * 8), np.uint8)
+                q = np.packbits(f, axis=1, bitorder="little")
+                pk[:, : q.shape[1]] = q
+                d_f, d_o = hp.malloc(pk.nbytes), hp.malloc(B * rb + 16)
+                hp.h2d(d_f, pk)
+                hp.sample_batch_device_begin(i, d_f.ptr, B, nf, (i, 4 + rnd), d_o.ptr, out_bit_packed=True, shot_offset=B * i)
+                bufs.append((f, d_f, d_o, (i, 4 + rnd), B * i))
+            for i in range(5):
+                hp.sample_batch_device_end(i)
+        hp.synchronize()
+        for f, d_f, d_o, key, off in bufs:
+            got = np.zeros((B, rb), np.uint8)
+            hp.d2h(got, d_o)
+            np.testing.assert_array_equal(got, np.packbits(orc.sample_program(f, key, shot_offset=off), axis=1, bitorder="little"))
+    hp.close()
+
+
+def test_switch_off(hip, monkeypatch):
+    prog, _ = synth.config_program("C5")
+    monkeypatch.setenv("TSIM_AMD_WIDE_TABLES", "0")
+    info = hip.HipProgram(prog).info()
+    assert info["wide_sparse_kernel"] and not info["pattern_tables"]

@@ -135,6 +135,7 @@ struct tsim_program {
   int lw_request = -1;        // -1 default (on in TSIM_MODE_AUTO), 0 off, 1 on
   int lw_weight_cap = -1;     // -1 = TSIMK_LW_MAX_WEIGHT
   bool lw = false;            // tables built, pass 1 active
+  bool lw_wide = false;       // ... for wide components: k_sample_lw<true> -> k_sample4w on its lists -> row kernel
   int lw_binom_off = 0;       // image offset of the binomial table of the register first pass
   int n_cu = 256;             // compute units of the device (grid sizing)
   int v4w_occ_blocks = 1;     // blocks of the sparse-column kernel a CU holds at once with v4w_occ_lds bytes of LDS
@@ -148,6 +149,9 @@ struct tsim_program {
     uint32_t *ctl = nullptr;      // 2 counter sets (hard-row counters + check row)
     void *hard = nullptr;         // hard-row lists
     size_t hard_sz = 0;
+    uint32_t *ctl2 = nullptr;     // wide programs with tables: the sparse-column pass's own lists (its overflow rows)
+    void *hard2 = nullptr;
+    size_t hard2_sz = 0;
     uint32_t *keys = nullptr;     // k_keygen output (programs with > TSIMK_INLINE_KEYS outputs)
     hipStream_t side = nullptr;
     hipEvent_t ev1 = nullptr, ev2 = nullptr;  // input dependency, launch done

@@ -284,12 +284,7 @@ k_sample4(Sample4Args A4) {
   uint8_t *lds_tab = reinterpret_cast<uint8_t *>(tsimk_lds + (WF32 + WO32) * nthr);
 
   if (active) {
-    const uint64_t *frow = A.f + row * A.WF;
-    for (int w = 0; w < A.WF; ++w) {
-      const uint64_t v = frow[w];
-      lds_f[(2 * w) * nthr] = (uint32_t)v;
-      lds_f[(2 * w + 1) * nthr] = (uint32_t)(v >> 32);
-    }
+    stage_f_row(A.f + row * A.WF, A.WF, lds_f, nthr);
   } else {
     for (int w = 0; w < WF32; ++w) lds_f[w * nthr] = 0u;
   }

@@ -251,12 +251,7 @@ __device__ __forceinline__ void sample4h_rows(const SampleArgs &A, int comp4_off
 
   if (wave == 0) {
     if (active) {
-      const uint64_t *frow = A.f + row * A.WF;
-      for (int w = 0; w < A.WF; ++w) {
-        const uint64_t v = frow[w];
-        lds_f[(2 * w) * 64] = (uint32_t)v;
-        lds_f[(2 * w + 1) * 64] = (uint32_t)(v >> 32);
-      }
+      stage_f_row(A.f + row * A.WF, A.WF, lds_f, 64);
     } else {
       for (int w = 0; w < WF32; ++w) lds_f[w * 64] = 0u;
     }
@@ -343,7 +338,7 @@ __device__ __forceinline__ void sample4h_rows(const SampleArgs &A, int comp4_off
 }
 
 template <int GT, int NCH, int NW>
-__global__ void __launch_bounds__(NW * 64) k_sample4h(Sample4Args A4, int group_tiles, int loop_stride,
+__global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(3, 8))) k_sample4h(Sample4Args A4, int group_tiles, int loop_stride,
                                                         uint32_t *feedback) {
   sample4h_rows<GT, NCH, NW>(A4.s, A4.comp4_off, A4.has_check != 0, group_tiles, loop_stride, feedback, blockIdx.x,
                              gridDim.x);
@@ -360,7 +355,7 @@ struct Hard4Multi {
 };
 
 template <int GT, int NCH, int NW>
-__global__ void __launch_bounds__(NW * 64) k_sample4h_multi(Hard4Multi M) {
+__global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(3, 8))) k_sample4h_multi(Hard4Multi M) {
   const uint32_t c = blockIdx.x / (uint32_t)M.blocks_per_ctx;
   const uint32_t bidx = blockIdx.x - c * (uint32_t)M.blocks_per_ctx;
   const bool has_check = ((M.check_mask >> c) & 1) != 0;

@@ -34,6 +34,12 @@ struct Wide4Args {
   uint32_t *ctl;         // ctl[32 k] = entries of list k, ctl[32 LISTS] = check row (as LwArgs)
   uint32_t *ctl_next;    // the counter set of the NEXT launch: reset here
   int list_cap, n_lists;
+  // Behind a pattern-table first pass (k_sample_lw<true>): the input is that pass's hard-row lists (s.row_lists
+  // sub-lists of s.row_list_cap entries at s.row_index, counts at s.row_count[32 k]; list k is served by the blocks
+  // with blockIdx % row_lists == k), the check row is the one that pass recorded, and block 0 reports the list
+  // lengths to the launch planner.
+  const uint32_t *check_row_in;  // nullptr: the check row is slot 0
+  uint32_t *feedback;            // optional: [rows in the lists, longest list, rows of the launch]
   int resident;          // 1: the LDS table area holds ALL levels of a component at once (one copy, no per-level barriers)
 };
 
@@ -70,7 +76,35 @@ __global__ void __launch_bounds__(256) k_sample4w(Wide4Args W) {
   const SampleArgs &A = W.s;
   const int nthr = blockDim.x;
   long long n_rows = A.B;
-  if (A.row_index) n_rows = (long long)*A.row_count;
+  const uint32_t *rows_in = A.row_index;
+  long long first = (long long)blockIdx.x * nthr, stride = (long long)gridDim.x * nthr;
+  if (A.row_index && A.row_lists > 1) {
+    const uint32_t lk = blockIdx.x % (uint32_t)A.row_lists;
+    n_rows = (long long)A.row_count[32u * lk];
+    rows_in = A.row_index + (size_t)lk * A.row_list_cap;
+    first = (long long)(blockIdx.x / (uint32_t)A.row_lists) * nthr;
+    stride = (long long)(gridDim.x / (uint32_t)A.row_lists) * nthr;
+    if (W.feedback && blockIdx.x == 0 && threadIdx.x < 64) {  // launch-plan feedback, as k_sample4h
+      uint32_t c = 0, m = 0;
+      for (int k = (int)threadIdx.x; k < A.row_lists; k += 64) {
+        const uint32_t v = A.row_count[32 * k];
+        c += v;
+        m = max(m, v);
+      }
+      for (int o = 32; o > 0; o >>= 1) {
+        c += (uint32_t)__shfl_xor((int)c, o, 64);
+        m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
+      }
+      if (threadIdx.x == 0) {
+        W.feedback[0] = c;
+        W.feedback[1] = m;
+        W.feedback[2] = (uint32_t)min(A.B, 0xFFFFFFFFll);
+      }
+    }
+  } else if (A.row_index) {
+    n_rows = (long long)*A.row_count;
+  }
+  const uint32_t check_row = W.check_row_in ? *W.check_row_in : 0xFFFFFFFFu;
   cptr img = (cptr)(uintptr_t)A.img;
 
   if (blockIdx.x == 0 && threadIdx.x <= TSIMK_LW_LISTS)
@@ -85,6 +119,7 @@ __global__ void __launch_bounds__(256) k_sample4w(Wide4Args W) {
   // block then strides over the rows - the launch sizes the grid to what the chip holds at once.  The staging
   // columns are private to a thread, the tables read-only: no barrier between the row chunks.
   const bool preloaded = W.resident && A.n_comp == 1;
+  if (first >= n_rows) return;  // nothing for this block (short input lists): no table copy, no barrier
   if (preloaded) {
     cptr comp = img + W.comp4_off;
     cptr levels = img + comp[C4_LEVELS];
@@ -99,26 +134,21 @@ __global__ void __launch_bounds__(256) k_sample4w(Wide4Args W) {
     __syncthreads();
   }
 
-  for (long long base = (long long)blockIdx.x * nthr; base < n_rows; base += (long long)gridDim.x * nthr) {
+  for (long long base = first; base < n_rows; base += stride) {
   const long long slot = base + threadIdx.x;
   const bool active = slot < n_rows;
   long long row = slot;
-  if (A.row_index) row = active ? (long long)A.row_index[slot] : 0;
+  if (rows_in) row = active ? (long long)rows_in[slot] : 0;
   if (!active) row = 0;
   const unsigned long long shot = (unsigned long long)(A.shot_offset + row);
 
   if (active) {
-    const uint64_t *frow = A.f + row * A.WF;
-    for (int w = 0; w < A.WF; ++w) {
-      const uint64_t v = frow[w];
-      lds_f[(2 * w) * nthr] = (uint32_t)v;
-      lds_f[(2 * w + 1) * nthr] = (uint32_t)(v >> 32);
-    }
+    stage_f_row(A.f + row * A.WF, A.WF, lds_f, nthr);
   } else {
     for (int w = 0; w < WF32; ++w) lds_f[w * nthr] = 0u;
   }
   for (int w = 0; w < WO32; ++w) lds_o[w * nthr] = 0u;
-  bool hard = active && W.has_check && slot == 0;
+  bool hard = active && W.has_check && (W.check_row_in ? (uint32_t)row == check_row : slot == 0);
   if (hard) W.ctl[32 * TSIMK_LW_LISTS] = (uint32_t)row;
 
   // direct outputs (sampler.py:140-145)
@@ -127,10 +157,12 @@ __global__ void __launch_bounds__(256) k_sample4w(Wide4Args W) {
   // Pass A over the components: more than K set bits anywhere -> the whole row is the row kernel's.
   for (int ci = 0; ci < A.n_comp; ++ci) {
     cptr comp = img + W.comp4_off + ci * C4_WORDS;
-    cptr sel = img + comp[C4_SELMASK];
+    const lw_u32x16 selm = *(lw_cptr16)(img + comp[C4_SELMASK]);  // one 64-byte scalar load, static indices below
     uint32_t cnt = 0;
     const int nw = WF32 < TSIMK_W_SELWORDS ? WF32 : TSIMK_W_SELWORDS;
-    for (int w = 0; w < nw; ++w) cnt += (uint32_t)__builtin_popcount(lds_f[w * nthr] & sel[w]);
+#pragma unroll
+    for (int w = 0; w < TSIMK_W_SELWORDS; ++w)
+      if (w < nw) cnt += (uint32_t)__builtin_popcount(lds_f[w * nthr] & selm[w]);
     hard = hard || (cnt > (uint32_t)K);
   }
 
@@ -151,9 +183,12 @@ __global__ void __launch_bounds__(256) k_sample4w(Wide4Args W) {
       int n = 0;
       (void)n;
       const int nw = WF32 < TSIMK_W_SELWORDS ? WF32 : TSIMK_W_SELWORDS;
-      for (int w = 0; w < nw; ++w) {
-        uint32_t mw = lds_f[w * nthr] & sel[w];
-        const uint32_t sw = sel[w], base = sel[TSIMK_W_SELWORDS + w];
+      const lw_u32x16 selm = *(lw_cptr16)sel, selp = *(lw_cptr16)(sel + TSIMK_W_SELWORDS);
+#pragma unroll
+      for (int w = 0; w < TSIMK_W_SELWORDS; ++w) {
+        if (w >= nw) continue;
+        uint32_t mw = lds_f[w * nthr] & selm[w];
+        const uint32_t sw = selm[w], base = selp[w];
         while (mw) {
           const uint32_t p = (uint32_t)__builtin_ctz(mw);
           const uint32_t pos = base + (uint32_t)__builtin_popcount(sw & ((1u << p) - 1u));

@@ -84,10 +84,47 @@ struct SampleArgs {
 #define TSIMK_INLINE_KEYS 32
 
 // the lane's output row, word w at lds_o[w * stride], as out_rb bytes of the compact output
-__device__ __forceinline__ void store_compact_row(const SampleArgs &A, long long row, const uint32_t *lds_o, int stride) {
+// Stage a shot's packed f row into its LDS column ([word][lane], stride `stride`).  The first eight 64-bit words are
+// loaded by a fully unrolled, guarded sequence - all loads in flight before the first LDS store - instead of a
+// load-wait-store loop (one HBM latency per word); longer rows finish in a plain loop.
+__device__ __forceinline__ void stage_f_row(const uint64_t *frow, int WF, uint32_t *lds_f, int stride) {
+  uint64_t v[8];
+#pragma unroll
+  for (int w = 0; w < 8; ++w) v[w] = (w < WF) ? frow[w] : 0ull;
+#pragma unroll
+  for (int w = 0; w < 8; ++w)
+    if (w < WF) {
+      lds_f[(2 * w) * stride] = (uint32_t)v[w];
+      lds_f[(2 * w + 1) * stride] = (uint32_t)(v[w] >> 32);
+    }
+  for (int w = 8; w < WF; ++w) {
+    const uint64_t x = frow[w];
+    lds_f[(2 * w) * stride] = (uint32_t)x;
+    lds_f[(2 * w + 1) * stride] = (uint32_t)(x >> 32);
+  }
+}
+
+// One bit_packed row (out_rb bytes at out_compact + row * out_rb); word w of the row comes from `word(w)`.  Rows of
+// a multiple of four bytes in a 4-byte aligned buffer are written as dwords (16-byte rows: one store), the others
+// byte by byte.  The choice is uniform over the launch.
+template <class Word>
+__device__ __forceinline__ void store_compact_words(const SampleArgs &A, long long row, Word word) {
   if (!A.out_compact) return;
   uint8_t *dst = A.out_compact + row * A.out_rb;
-  for (int k = 0; k < A.out_rb; ++k) dst[k] = (uint8_t)(lds_o[(k >> 2) * stride] >> (8 * (k & 3)));
+  const uintptr_t base = (uintptr_t)A.out_compact;
+  if ((A.out_rb & 15) == 0 && (base & 15u) == 0u) {
+    for (int k = 0; k < A.out_rb; k += 16) {
+      const int w = k >> 2;
+      *reinterpret_cast<uint4 *>(dst + k) = make_uint4(word(w), word(w + 1), word(w + 2), word(w + 3));
+    }
+  } else if ((A.out_rb & 3) == 0 && (base & 3u) == 0u) {
+    for (int k = 0; k < A.out_rb; k += 4) *reinterpret_cast<uint32_t *>(dst + k) = word(k >> 2);
+  } else {
+    for (int k = 0; k < A.out_rb; ++k) dst[k] = (uint8_t)(word(k >> 2) >> (8 * (k & 3)));
+  }
+}
+__device__ __forceinline__ void store_compact_row(const SampleArgs &A, long long row, const uint32_t *lds_o, int stride) {
+  store_compact_words(A, row, [&](int w) { return lds_o[w * stride]; });
 }
 
 // A gather program moves bit fields of the packed f row to a destination bit vector.  It is a list of 4-word runs
@@ -193,6 +230,10 @@ __device__ __forceinline__ void to_complex(int a, int b, int c, int d, int p, fl
 
 // jnp.abs(complex64): max * sqrt(1 + (min/max)^2)
 __device__ __forceinline__ float cabs32(float re, float im) {
+  // No lane of the wave has an imaginary part (probability models: the exact sums are real): the general formula
+  // gives max = |re|, min/max = 0 (or the mx == 0 / inf / NaN cases below) -> |re| bit for bit, without the
+  // division and the square root (about 25 VALU operations per level).
+  if (__builtin_amdgcn_ballot_w64(im != 0.0f) == 0ull) return fabsf(re);
   float ar = fabsf(re), ai = fabsf(im);
   float mx = fmaxf(ar, ai), mn = fminf(ar, ai);
   float r = __fdiv_rn(mn, mx);
@@ -689,12 +730,7 @@ __global__ void __launch_bounds__(256) k_sample(SampleArgs A) {
   uint32_t *lds_o = tsimk_lds + WF32 * nthr + threadIdx.x;  // [WO32][nthr]
 
   // stage this shot's packed f row (the only per-shot HBM read)
-  const uint64_t *frow = A.f + row * A.WF;
-  for (int w = 0; w < A.WF; ++w) {
-    const uint64_t v = frow[w];
-    lds_f[(2 * w) * nthr] = (uint32_t)v;
-    lds_f[(2 * w + 1) * nthr] = (uint32_t)(v >> 32);
-  }
+  stage_f_row(A.f + row * A.WF, A.WF, lds_f, nthr);
   for (int w = 0; w < WO32; ++w) lds_o[w * nthr] = 0u;
 
   // K14: direct outputs f[idx] ^ flip (sampler.py:140-145)

@@ -42,6 +42,11 @@ enum {
 #define TSIMK_LW_MAX_NOUT 10
 #define TSIMK_LW_MAX_WEIGHT 7
 #define TSIMK_LW_LISTS 64   // hard-row sub-lists (one atomic counter each, 128 bytes apart)
+// Wide components (more than 64 parameters; first pass k_sample_lw<true> in front of the sparse-column kernel):
+// f_sel positions below 256, patterns to weight 4, rank from a [4][256] binomial table; the table-build kernel
+// gets no pattern list but unranks the pattern index itself.
+#define TSIMK_LWW_MAX_WEIGHT 4
+#define TSIMK_LWW_MAX_F 255
 
 // colex rank of a pattern with sorted set-bit positions b0 < b1 < b2 < b3 < b4 (missing ones passed as 0)
 __host__ __device__ __forceinline__ uint32_t lw_binom2(uint32_t b) { return (b * (b - 1u)) >> 1; }
@@ -82,6 +87,9 @@ struct LwBuildArgs {
   float *tab;                         // this component's table: [npat << n_out]
   int comp_off;                       // row-layout component record (C_*)
   int npat;
+  // wide components: patbits == nullptr, the lane unranks its pattern (weight class from `bases`, then the set
+  // bits from the largest down: the largest b with C(b, i + 1) <= r, binary search in the [4][256] table)
+  int wide_binom_off, bases_off, wmax;
 };
 
 template <int W, bool FAST>
@@ -93,10 +101,35 @@ __global__ void __launch_bounds__(256) k_lw_build(LwBuildArgs A) {
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= ((long long)A.npat << n_out)) return;
   const uint32_t pat = (uint32_t)(t >> n_out), m = (uint32_t)t & ((1u << n_out) - 1u);
-  const unsigned long long pb = A.patbits[pat];
   uint32_t x[W];
+  if (A.patbits) {
+    const unsigned long long pb = A.patbits[pat];
 #pragma unroll
-  for (int w = 0; w < W; ++w) x[w] = (w < 2) ? (uint32_t)(pb >> (32 * w)) : 0u;
+    for (int w = 0; w < W; ++w) x[w] = (w < 2) ? (uint32_t)(pb >> (32 * w)) : 0u;
+  } else {
+#pragma unroll
+    for (int w = 0; w < W; ++w) x[w] = 0u;
+    cptr bases = img + A.bases_off;
+    cptr bn = img + A.wide_binom_off;
+    int wt = 0;
+    for (int k = 1; k <= A.wmax; ++k)
+      if (pat >= bases[k]) wt = k;
+    uint32_t r = pat - bases[wt];
+    int hi = (int)F;  // the next set bit lies below this position
+    for (int i = wt - 1; i >= 0; --i) {
+      int lo = i, up = hi - 1;  // C(i, i + 1) = 0 <= r: position i always qualifies
+      while (lo < up) {
+        const int mid = (lo + up + 1) >> 1;
+        if (bn[i * 256 + mid] <= r) lo = mid;
+        else up = mid - 1;
+      }
+      r -= bn[i * 256 + lo];
+#pragma unroll
+      for (int w = 0; w < W; ++w)
+        if (w == (lo >> 5)) x[w] |= 1u << (lo & 31);
+      hi = lo;
+    }
+  }
   float re, im;
   eval_any<W, FAST>(A.img, img, levels, x, re, im, nullptr);  // sampler.py:54
   float prev = cabs32(re, im);

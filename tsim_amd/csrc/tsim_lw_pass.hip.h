@@ -51,9 +51,28 @@ __device__ __forceinline__ void lw_walk(const SampleArgs &A, const float *thr, u
   }
 }
 
+// the lane's set bits of one masked f word: each adds C(position inside f_sel, ordinal + 1) to the colex rank
+template <int STRIDE = 64>
+__device__ __forceinline__ void lw_rank_word(uint32_t mw, uint32_t sw, uint32_t base, const uint32_t *binom_lds, uint32_t &ord,
+                                             uint32_t &pat) {
+  while (mw) {
+    const uint32_t p = (uint32_t)__builtin_ctz(mw);
+    const uint32_t b = base + (uint32_t)__builtin_popcount(sw & ((1u << p) - 1u));
+    pat += binom_lds[ord * (uint32_t)STRIDE + b];
+    ++ord;
+    mw &= mw - 1u;
+  }
+}
+
+
 // ---------------------------------------------------------------------------
 // pass 1
 // ---------------------------------------------------------------------------
+// WIDE = false: components of at most 64 parameters (f_sel gathered into a 64-bit word, rank by arithmetic).
+// WIDE = true : components of up to 255 f_sel bits with ascending f_selection (the first pass in front of the
+//   sparse-column kernel): weight and rank straight from the f row through the component's selection masks, as the
+//   register form does, the binomials C(b, k + 1), b < 256, k < 4 from an LDS table behind the staging columns.
+template <bool WIDE>
 __global__ void __launch_bounds__(1024) k_sample_lw(LwArgs L) {
   const SampleArgs &A = L.s;
   const int nthr = blockDim.x;
@@ -72,15 +91,19 @@ __global__ void __launch_bounds__(1024) k_sample_lw(LwArgs L) {
 
   if (blockIdx.x == 0 && threadIdx.x <= TSIMK_LW_LISTS)
     L.ctl_next[32u * threadIdx.x] = (threadIdx.x == TSIMK_LW_LISTS) ? 0xFFFFFFFFu : 0u;  // last: "no check row"
+  uint32_t *binom_lds = tsimk_lds + (WF32 + WO32) * nthr;  // WIDE: [4][256] words; every wave writes all of it
+  if constexpr (WIDE) {                                   // itself and reads only after its own stores: no barrier
+    const uint4 *src = reinterpret_cast<const uint4 *>(A.img + L.binom_off);
+    uint4 *dst = reinterpret_cast<uint4 *>(binom_lds);
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dst[64 * k + lane] = src[64 * k + lane];
+    __builtin_amdgcn_wave_barrier();
+  }
   bool hard = false;
   uint32_t o0 = 0, o1 = 0;  // output words 0 and 1 (the LDS column holds the others)
   if (active) {
-    const uint64_t *frow = A.f + row * A.WF;
-    for (int w = 0; w < A.WF; ++w) {
-      const uint64_t v = frow[w];
-      lds_f[(2 * w) * nthr] = (uint32_t)v;
-      lds_f[(2 * w + 1) * nthr] = (uint32_t)(v >> 32);
-    }
+    stage_f_row(A.f + row * A.WF, A.WF, lds_f, nthr);
     for (int w = 0; w < WO32; ++w) lds_o[w * nthr] = 0u;
     hard = L.has_check && slot == 0;
     if (hard) L.ctl[32 * TSIMK_LW_LISTS] = (uint32_t)row;
@@ -90,21 +113,49 @@ __global__ void __launch_bounds__(1024) k_sample_lw(LwArgs L) {
 
     for (int ci = 0; ci < A.n_comp; ++ci) {
       cptr rec = img + L.lw_off + ci * LW_WORDS;
-      // f_sel gather (sampler.py:48) -> x, then the weight test
-      uint32_t x0 = 0, x1 = 0;
-      gather_runs(img + rec[LW_FSELP], rec[LW_FSELN], lds_f, nullptr, nthr, x0, x1);
-      unsigned long long xf = ((unsigned long long)x1 << 32) | x0;
-      const uint32_t cnt = (uint32_t)__popcll(xf);
-      if (cnt > rec[LW_WMAX]) hard = true;
-      if (hard) continue;  // needs the full kernel: nothing of this row is written here
-      // colex rank of the pattern: set bits in ascending order, bit number i at position b adds C(b, i + 1)
-      uint32_t pat = (img + rec[LW_BASES])[cnt];
+      uint32_t pat;
+      if constexpr (!WIDE) {
+        // f_sel gather (sampler.py:48) -> x, then the weight test
+        uint32_t x0 = 0, x1 = 0;
+        gather_runs(img + rec[LW_FSELP], rec[LW_FSELN], lds_f, nullptr, nthr, x0, x1);
+        unsigned long long xf = ((unsigned long long)x1 << 32) | x0;
+        const uint32_t cnt = (uint32_t)__popcll(xf);
+        if (cnt > rec[LW_WMAX]) hard = true;
+        if (hard) continue;  // needs the full kernel: nothing of this row is written here
+        // colex rank of the pattern: set bits in ascending order, bit number i at position b adds C(b, i + 1)
+        pat = (img + rec[LW_BASES])[cnt];
 #pragma unroll
-      for (int i = 0; i < TSIMK_LW_MAX_WEIGHT; ++i) {
-        if (cnt > (uint32_t)i) {
-          pat += lw_rank_term(i, (uint32_t)__builtin_ctzll(xf));
-          xf &= xf - 1ull;
+        for (int i = 0; i < TSIMK_LW_MAX_WEIGHT; ++i) {
+          if (cnt > (uint32_t)i) {
+            pat += lw_rank_term(i, (uint32_t)__builtin_ctzll(xf));
+            xf &= xf - 1ull;
+          }
         }
+      } else {
+        // 16 mask words (f bits 0..511) and 16 prefix counts: two 64-byte scalar loads, then static indices only
+        // (a scalar load per word inside the loops made a chain of ~60 dependent scalar-memory latencies per wave)
+        const lw_u32x16 selm = *(lw_cptr16)(img + rec[LW_SELMASK]);
+        const lw_u32x16 selp = *(lw_cptr16)(img + rec[LW_SELMASK] + 16u);
+        const int nw = WF32 < 16 ? WF32 : 16;
+        uint32_t mw[16];
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+          mw[w] = (w < nw) ? (lds_f[w * nthr] & selm[w]) : 0u;
+          cnt += (uint32_t)__builtin_popcount(mw[w]);
+        }
+        if (cnt > rec[LW_WMAX]) hard = true;
+        if (hard) continue;
+        pat = rec[LW_BASES_INLINE];
+#pragma unroll
+        for (uint32_t w = 1; w <= TSIMK_LWW_MAX_WEIGHT; ++w) {
+          const uint32_t bw = (uint32_t)__builtin_amdgcn_readfirstlane((int)rec[LW_BASES_INLINE + w]);
+          pat = (cnt == w) ? bw : pat;
+        }
+        uint32_t ord = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w)
+          if (w < nw) lw_rank_word<256>(mw[w], selm[w], selp[w], binom_lds, ord, pat);
       }
       const uint32_t n_out = rec[LW_NOUT];
       cptr outpos = img + rec[LW_OUTPOS];
@@ -125,13 +176,8 @@ __global__ void __launch_bounds__(1024) k_sample_lw(LwArgs L) {
         for (int w = 1; w < A.WO; ++w)
           orow[w] = (uint64_t)lds_o[(2 * w) * nthr] | ((uint64_t)lds_o[(2 * w + 1) * nthr] << 32);
       }
-      if (A.out_compact) {  // words 0 and 1 live in registers here
-        uint8_t *dst = A.out_compact + row * A.out_rb;
-        for (int k = 0; k < A.out_rb; ++k) {
-          const uint32_t wv = (k < 4) ? o0 : (k < 8) ? o1 : lds_o[(k >> 2) * nthr];
-          dst[k] = (uint8_t)(wv >> (8 * (k & 3)));
-        }
-      }
+      // words 0 and 1 live in registers here
+      store_compact_words(A, row, [&](int w) { return (w == 0) ? o0 : (w == 1) ? o1 : lds_o[w * nthr]; });
     }
   }
 
@@ -188,18 +234,6 @@ __device__ __forceinline__ void lw_direct_reg(cptr prog, uint32_t f0, uint32_t f
   }
   o0 ^= prog[16];
   o1 ^= prog[17];
-}
-
-// the lane's set bits of one masked f word: each adds C(position inside f_sel, ordinal + 1) to the colex rank
-__device__ __forceinline__ void lw_rank_word(uint32_t mw, uint32_t sw, uint32_t base, const uint32_t *binom_lds, uint32_t &ord,
-                                             uint32_t &pat) {
-  while (mw) {
-    const uint32_t p = (uint32_t)__builtin_ctz(mw);
-    const uint32_t b = base + (uint32_t)__builtin_popcount(sw & ((1u << p) - 1u));
-    pat += binom_lds[ord * 64u + b];
-    ++ord;
-    mw &= mw - 1u;
-  }
 }
 
 template <int WF32>
@@ -298,7 +332,7 @@ __global__ void __launch_bounds__(1024) k_sample_lw_reg(LwArgs L) {
     }
     if (!hard) {
       if (A.out) A.out[row] = (uint64_t)o0 | ((uint64_t)o1 << 32);  // WO == 1
-      if (A.out_compact) {
+      if (A.out_compact) {  // at most 8 bytes here (WO == 1)
         uint8_t *dst = A.out_compact + row * A.out_rb;
         for (int k = 0; k < A.out_rb; ++k) dst[k] = (uint8_t)(((k < 4) ? o0 : o1) >> (8 * (k & 3)));
       }

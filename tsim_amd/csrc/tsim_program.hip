@@ -183,7 +183,7 @@ extern "C" int tsim_program_pattern_table_info(const tsim_program *p, int32_t *e
 }
 // launch-plan feedback buffer (mapped pinned host memory the hard-row kernels write)
 static int alloc_feedback(tsim_program *p) {
-  if (p->v4) {
+  if (p->v4 || p->lw_wide) {
     void *h = nullptr;
     if (hipHostMalloc(&h, 64, hipHostMallocMapped) == hipSuccess) {
       void *d = nullptr;
@@ -444,16 +444,32 @@ retry_pack:
     bool want = p->lw_request < 0 ? (p->mode == TSIM_MODE_AUTO) : (p->lw_request != 0);
     if (const char *e = getenv("TSIM_AMD_PATTERN_TABLES")) want = atoi(e) != 0;
     bool ok = want && p->sampleable && !p->comps.empty();
-    for (auto &c : p->comps)
-      ok = ok && (c.n_levels == c.n_out + 1) && c.n_out <= TSIMK_LW_MAX_NOUT && c.F + c.n_out <= 64;
+    bool narrow = true;
+    for (auto &c : p->comps) narrow = narrow && (c.n_levels == c.n_out + 1) && c.n_out <= TSIMK_LW_MAX_NOUT && c.F + c.n_out <= 64;
+    // wide components (the sparse-column kernel's programs): tables to weight TSIMK_LWW_MAX_WEIGHT in front of it
+    p->lw_wide = false;
+    if (ok && !narrow && p->v4w && p->max_f_index < 512) {
+      bool wide_ok = true;
+      if (const char *e = getenv("TSIM_AMD_WIDE_TABLES")) wide_ok = atoi(e) != 0;
+      for (auto &c : p->comps) {
+        wide_ok = wide_ok && (c.n_levels == c.n_out + 1) && c.n_out <= 8 && c.F <= TSIMK_LWW_MAX_F;
+        for (int j = 1; j < c.F; ++j) wide_ok = wide_ok && c.f_selection[j] > c.f_selection[j - 1];
+      }
+      p->lw_wide = wide_ok;
+    }
+    ok = ok && (narrow || p->lw_wide);
     if (ok) {
       // depth: the caller's, or 5 now and up to TSIMK_LW_MAX_WEIGHT on demand (tsim_tables.hip).  Patterns are
       // stored weight by weight, so the rows most shots read (weight 0..2) are a small cache-resident prefix
       // whatever the total; the heavier tail is read rarely.
       const bool pinned = p->lw_weight_cap >= 0;
-      p->lw_cap_max = pinned ? std::min(p->lw_weight_cap, TSIMK_LW_MAX_WEIGHT) : TSIMK_LW_MAX_WEIGHT;
-      p->lw_cap_now = pinned ? p->lw_cap_max : std::min(5, p->lw_cap_max);
+      const int hw_cap = p->lw_wide ? TSIMK_LWW_MAX_WEIGHT : TSIMK_LW_MAX_WEIGHT;
+      p->lw_cap_max = pinned ? std::min(p->lw_weight_cap, hw_cap) : hw_cap;
+      p->lw_cap_now = pinned ? p->lw_cap_max : std::min(p->lw_wide ? 3 : 5, p->lw_cap_max);
       p->lw_budget = 1024ll << 20;  // per component (4 x per program): HBM is 288 GB, and only the prefix is hot
+      // wide components: C(200, 4) patterns of 8 thresholds are 2.1 GB - what lifts the tabulated share of C5's
+      // shots from 43 % to 63 %; still under 1 % of the HBM
+      if (p->lw_wide) p->lw_budget = 4096ll << 20;
       if (const char *e = getenv("TSIM_AMD_PATTERN_TABLE_MB")) p->lw_budget = std::max(1ll, atoll(e)) << 20;
       while (img.size() % 32) img.push_back(0u);
       p->lw_off = (int)img.size();
@@ -471,7 +487,21 @@ retry_pack:
         for (int j = 0; j < c.F; ++j) lw_fsel_progs.back().push_back({c.f_selection[j], j, 0});
       }
       ok = tsim_tables_plan(p, p->lw_cap_now, p->lw_budget);
-      if (ok) {
+      if (ok && p->lw_wide) {
+        p->lw = true;
+        p->lw_reg = false;
+        // selection masks: the comp4 record's (16 mask words + 16 prefix counts); binomials C(b, k + 1), k < 4, b < 256
+        for (size_t ci = 0; ci < p->comps.size(); ++ci)
+          img[p->lw_off + ci * LW_WORDS + LW_SELMASK] = img[p->comp4_off + ci * C4_WORDS + C4_SELMASK];
+        while (img.size() % 16) img.push_back(0u);
+        p->lw_binom_off = (int)img.size();
+        for (int k = 0; k < 4; ++k)
+          for (int b = 0; b < 256; ++b) {
+            unsigned long long c = 1;
+            for (int i = 1; i <= k + 1; ++i) c = c * (unsigned long long)(b - (k + 1) + i > 0 ? b - (k + 1) + i : 0) / (unsigned long long)i;
+            img.push_back(b >= k + 1 ? (uint32_t)c : 0u);
+          }
+      } else if (ok) {
         p->lw = true;
         // gather programs of every component's f_sel (the LDS-staged first pass)
         std::vector<uint32_t> prog;
@@ -589,6 +619,8 @@ extern "C" void tsim_program_destroy(tsim_program *p) {
     for (auto &sl : p->slots) {
       if (sl.ctl) (void)hipFree(sl.ctl);
       if (sl.hard) (void)hipFree(sl.hard);
+      if (sl.ctl2) (void)hipFree(sl.ctl2);
+      if (sl.hard2) (void)hipFree(sl.hard2);
       if (sl.keys) (void)hipFree(sl.keys);
       if (sl.ev1) (void)hipEventDestroy(sl.ev1);
       if (sl.ev2) (void)hipEventDestroy(sl.ev2);

@@ -53,6 +53,13 @@ static int slot_prepare(tsim_program *p, int slot, size_t hard_bytes) {
     for (int st = 0; st < 2; ++st)
       HIP_TRY(hipMemset(sl.ctl + st * (TSIMK_LW_LISTS + 1) * 32 + TSIMK_LW_LISTS * 32, 0xFF, 4));
   }
+  if (p->lw_wide && !sl.ctl2) {  // the sparse-column pass behind a table pass: counters and lists of its own
+    const size_t set_bytes = (TSIMK_LW_LISTS + 1) * 128;
+    HIP_TRY(hipMalloc((void **)&sl.ctl2, 2 * set_bytes));
+    HIP_TRY(hipMemset(sl.ctl2, 0, 2 * set_bytes));
+    for (int st = 0; st < 2; ++st)
+      HIP_TRY(hipMemset(sl.ctl2 + st * (TSIMK_LW_LISTS + 1) * 32 + TSIMK_LW_LISTS * 32, 0xFF, 4));
+  }
   if (p->total_keys > TSIMK_INLINE_KEYS && !sl.keys) HIP_TRY(hipMalloc((void **)&sl.keys, (size_t)p->total_keys * 8));
   if (slot > 0 && !sl.side_ready) {
     sl.side_ready = true;
@@ -80,6 +87,17 @@ static int slot_prepare(tsim_program *p, int slot, size_t hard_bytes) {
     hipError_t e = hipMalloc(&sl.hard, hard_bytes);
     if (e != hipSuccess) return tsim_fail(TSIM_ENOMEM, "hipMalloc(%zu) failed: %s", hard_bytes, hipGetErrorString(e));
     sl.hard_sz = hard_bytes;
+  }
+  if (p->lw_wide && sl.hard2_sz < hard_bytes) {
+    if (sl.hard2) {
+      HIP_TRY(hipDeviceSynchronize());
+      HIP_TRY(hipFree(sl.hard2));
+      sl.hard2 = nullptr;
+      sl.hard2_sz = 0;
+    }
+    hipError_t e = hipMalloc(&sl.hard2, hard_bytes);
+    if (e != hipSuccess) return tsim_fail(TSIM_ENOMEM, "hipMalloc(%zu) failed: %s", hard_bytes, hipGetErrorString(e));
+    sl.hard2_sz = hard_bytes;
   }
   return 0;
 }
@@ -318,6 +336,75 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
   };
   const LaunchPlan plan = plan_in ? *plan_in : make_plan(p, d_row_index != nullptr, false);
   const bool use_tables = plan.use_tables, need_overflow = plan.need_overflow;
+  // The sparse-column pass (k_sample4w) over every row, or - behind a pattern-table first pass - over that pass's
+  // hard-row lists (from_lists; `a` then describes them).  Its own overflow (more than K set bits, the check row)
+  // goes to row lists of its own, which `a` describes afterwards: the row kernel below serves them.
+  const bool wide_fits = p->v4w && p->knobs.wide &&
+                         (size_t)(2 * a.WF + 2 * a.WO) * 256 * 4 + 2 * (size_t)p->v4_max_sent * p->v4_gt * 16 <= 64 * 1024;
+  auto wide_pass = [&](bool from_lists, int par) -> int {
+    if (B > 0xFFFFFFFFll) return tsim_fail(TSIM_ENOTSUP, "batch too large for the row list");
+    constexpr int kWideBlock = 256, kWideK = 10, kWideLists = 16;
+    const size_t stage_b = (size_t)(2 * a.WF + 2 * a.WO) * kWideBlock * 4, stream_b = 2 * (size_t)p->v4_max_sent * p->v4_gt * 16;
+    // all levels of a component resident in LDS when that still leaves room for two blocks per CU
+    const bool resident = stage_b + p->v4w_resident_bytes <= 64 * 1024;
+    const size_t ldsw = stage_b + (resident ? std::max(p->v4w_resident_bytes, (size_t)16) : stream_b);
+    if (p->v4w_occ_lds != ldsw) {
+      int nb = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_sample4w<1, kWideK>, kWideBlock, ldsw) != hipSuccess || nb < 1) {
+        (void)hipGetLastError();
+        nb = 1;
+      }
+      p->v4w_occ_blocks = nb;
+      p->v4w_occ_lds = ldsw;
+    }
+    const long long chip = (long long)p->n_cu * p->v4w_occ_blocks * std::max(1, p->knobs.lw_resident);
+    long long grid1, list_cap;
+    if (from_lists) {
+      // every input list gets the same number of blocks, which stride over it
+      const long long per_list = std::max(1ll, std::min(chip / a.row_lists, ((long long)a.row_list_cap + kWideBlock - 1) / kWideBlock));
+      grid1 = per_list * a.row_lists;
+      const long long rows_per_block = ((long long)a.row_list_cap + per_list * kWideBlock - 1) / (per_list * kWideBlock) * kWideBlock;
+      // an output list takes the overflow of the blocks with its residue - never more than the launch has rows
+      list_cap = std::min((grid1 + kWideLists - 1) / kWideLists * rows_per_block, (long long)(B + kWideBlock - 1) / kWideBlock * kWideBlock);
+    } else {
+      const long long blocks = (B + kWideBlock - 1) / kWideBlock;
+      // One component with resident tables: the kernel copies the tables once per block and strides over the rows, so
+      // the grid is what the chip holds at once (occupancy of this kernel with this much LDS), not one block per 256 rows
+      grid1 = blocks;
+      if (resident && p->comps.size() == 1 && p->knobs.lw_resident > 0) grid1 = std::min(blocks, chip);
+      const long long iters = (blocks + grid1 - 1) / grid1;
+      list_cap = (grid1 + kWideLists - 1) / kWideLists * iters * kWideBlock;
+    }
+    void *lists = from_lists ? sl.hard2 : sl.hard;
+    uint32_t *ctl_base = from_lists ? sl.ctl2 : sl.ctl;
+    const size_t lists_sz = from_lists ? sl.hard2_sz : sl.hard_sz;
+    if (list_cap > 0x7FFFFFFFll) return tsim_fail(TSIM_ENOTSUP, "batch too large for the row lists");
+    if (!lists || !ctl_base || (size_t)list_cap * kWideLists * 4 > lists_sz) return tsim_fail(TSIM_ESTATE, "row list too small");
+    Wide4Args w;
+    w.s = a;
+    w.comp4_off = p->comp4_off;
+    w.has_check = has_check ? 1 : 0;
+    w.check_row_in = (from_lists && has_check) ? a.check_row : nullptr;
+    w.feedback = from_lists ? p->d_feedback : nullptr;
+    w.hard_index = (uint32_t *)lists;
+    uint32_t *ctl = ctl_base + par * (TSIMK_LW_LISTS + 1) * 32;
+    w.ctl = ctl;
+    w.ctl_next = ctl_base + (par ^ 1) * (TSIMK_LW_LISTS + 1) * 32;
+    w.list_cap = (int)list_cap;
+    w.n_lists = kWideLists;
+    w.resident = resident ? 1 : 0;
+    hipLaunchKernelGGL((k_sample4w<1, kWideK>), dim3((unsigned)grid1), dim3(kWideBlock), ldsw, s, w);
+    HIP_TRY(hipGetLastError());
+    if (prof && !(from_lists && p->prof_light)) { int r = prof_event(p, s, from_lists ? PROF_HARD : PROF_PASS1); if (r) return r; }
+    a.row_index = w.hard_index;
+    a.row_count = ctl;
+    a.row_lists = kWideLists;
+    a.row_list_cap = (int)list_cap;
+    a.check_row = has_check ? ctl + 32 * TSIMK_LW_LISTS : nullptr;
+    a.no_check = has_check ? 0 : 1;
+    B2 = list_cap;
+    return 0;
+  };
   if (use_tables) {
     // pass 1: shots whose f_sel patterns are tabulated finish here, the others go to the hard list
     if (B > 0xFFFFFFFFll) return tsim_fail(TSIM_ENOTSUP, "batch too large for the row list");
@@ -354,14 +441,15 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
     l.list_cap = (int)list_cap;
     l.n_lists = n_lists;
     l.binom_off = p->lw_binom_off;
-    const size_t lds1 = (size_t)(2 * a.WF + 2 * a.WO) * blk1 * 4;
+    const size_t lds1 = (size_t)(2 * a.WF + 2 * a.WO) * blk1 * 4 + (p->lw_wide ? 4096 : 0);
     if (reg_form) {
       // narrow rows: everything in registers, no LDS
       if (a.WF == 1) hipLaunchKernelGGL(k_sample_lw_reg<2>, dim3((unsigned)grid1), dim3(blk1), 0, s, l);
       else hipLaunchKernelGGL(k_sample_lw_reg<4>, dim3((unsigned)grid1), dim3(blk1), 0, s, l);
     } else {
       if (lds1 > 64 * 1024) return tsim_fail(TSIM_ENOTSUP, "num_f + num_outputs too large for LDS staging (%zu B)", lds1);
-      hipLaunchKernelGGL(k_sample_lw, dim3((unsigned)grid1), dim3(blk1), lds1, s, l);
+      if (p->lw_wide) hipLaunchKernelGGL(k_sample_lw<true>, dim3((unsigned)grid1), dim3(blk1), lds1, s, l);
+      else hipLaunchKernelGGL(k_sample_lw<false>, dim3((unsigned)grid1), dim3(blk1), lds1, s, l);
     }
     HIP_TRY(hipGetLastError());
     if (prof) { int r = prof_event(p, s, PROF_PASS1); if (r) return r; }
@@ -373,58 +461,14 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
     a.check_row = has_check ? ctl + 32 * TSIMK_LW_LISTS : nullptr;
     a.no_check = has_check ? 0 : 1;
     B2 = list_cap;
-  } else if (p->v4w && p->knobs.wide &&
-             (size_t)(2 * a.WF + 2 * a.WO) * 256 * 4 + 2 * (size_t)p->v4_max_sent * p->v4_gt * 16 <= 64 * 1024) {
+    // wide components: the listed rows go through the sparse-column pass first, its overflow to the row kernel
+    if (p->lw_wide && wide_fits)
+      if (int r = wide_pass(true, sl.parity ^ 1)) return r;  // (the parity this launch's first pass used)
+  } else if (wide_fits) {
     // wide components: sparse-column pass on every row (k_sample4w); rows with more than K set f bits and the
     // normalisation-check row go to the row lists, which the row kernel below serves
-    if (B > 0xFFFFFFFFll) return tsim_fail(TSIM_ENOTSUP, "batch too large for the row list");
-    constexpr int kWideBlock = 256, kWideK = 10, kWideLists = 16;
-    const size_t stage_b = (size_t)(2 * a.WF + 2 * a.WO) * kWideBlock * 4, stream_b = 2 * (size_t)p->v4_max_sent * p->v4_gt * 16;
-    // all levels of a component resident in LDS when that still leaves room for two blocks per CU
-    const bool resident = stage_b + p->v4w_resident_bytes <= 64 * 1024;
-    const size_t ldsw = stage_b + (resident ? std::max(p->v4w_resident_bytes, (size_t)16) : stream_b);
-    const long long blocks = (B + kWideBlock - 1) / kWideBlock;
-    // One component with resident tables: the kernel copies the tables once per block and strides over the rows, so
-    // the grid is what the chip holds at once (occupancy of this kernel with this much LDS), not one block per 256 rows
-    long long grid1 = blocks;
-    if (resident && p->comps.size() == 1 && p->knobs.lw_resident > 0) {
-      if (p->v4w_occ_lds != ldsw) {
-        int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_sample4w<1, kWideK>, kWideBlock, ldsw) != hipSuccess || nb < 1) {
-          (void)hipGetLastError();
-          nb = 1;
-        }
-        p->v4w_occ_blocks = nb;
-        p->v4w_occ_lds = ldsw;
-      }
-      grid1 = std::min(blocks, (long long)p->n_cu * p->v4w_occ_blocks * p->knobs.lw_resident);
-    }
-    const long long iters = (blocks + grid1 - 1) / grid1;
-    const long long list_cap = (grid1 + kWideLists - 1) / kWideLists * iters * kWideBlock;
-    if (list_cap > 0x7FFFFFFFll) return tsim_fail(TSIM_ENOTSUP, "batch too large for the row lists");
-    if ((size_t)list_cap * kWideLists * 4 > sl.hard_sz) return tsim_fail(TSIM_ESTATE, "row list too small");
-    Wide4Args w;
-    w.s = a;
-    w.comp4_off = p->comp4_off;
-    w.has_check = has_check ? 1 : 0;
-    w.hard_index = (uint32_t *)sl.hard;
-    uint32_t *ctl = sl.ctl + sl.parity * (TSIMK_LW_LISTS + 1) * 32;
-    w.ctl = ctl;
-    w.ctl_next = sl.ctl + (sl.parity ^ 1) * (TSIMK_LW_LISTS + 1) * 32;
+    if (int r = wide_pass(false, sl.parity)) return r;
     sl.parity ^= 1;
-    w.list_cap = (int)list_cap;
-    w.n_lists = kWideLists;
-    w.resident = resident ? 1 : 0;
-    hipLaunchKernelGGL((k_sample4w<1, kWideK>), dim3((unsigned)grid1), dim3(kWideBlock), ldsw, s, w);
-    HIP_TRY(hipGetLastError());
-    if (prof) { int r = prof_event(p, s, PROF_PASS1); if (r) return r; }
-    a.row_index = w.hard_index;
-    a.row_count = ctl;
-    a.row_lists = kWideLists;
-    a.row_list_cap = (int)list_cap;
-    a.check_row = has_check ? ctl + 32 * TSIMK_LW_LISTS : nullptr;
-    a.no_check = has_check ? 0 : 1;
-    B2 = list_cap;
   } else if (!has_check) {
     a.no_check = 1;
   }

@@ -86,18 +86,24 @@ int tsim_tables_build(tsim_program *p, float **old) {
     const HostComponent &c = p->comps[ci];
     const long long tab_off = (long long)p->img[p->lw_off + ci * LW_WORDS + LW_TAB];
     std::vector<unsigned long long> pats;
-    pats.reserve((size_t)p->lw_npat[ci]);
-    enumerate_patterns(c.F, p->lw_wmax[ci], pats);
-    if ((long long)pats.size() != p->lw_npat[ci]) {
-      (void)hipFree(tab);
-      return tsim_fail(TSIM_ESTATE, "pattern enumeration mismatch (%zu vs %lld)", pats.size(), p->lw_npat[ci]);
-    }
     unsigned long long *d_pats = nullptr;
-    hipError_t e = hipMalloc((void **)&d_pats, pats.size() * 8);
-    if (e == hipSuccess) e = hipMemcpy(d_pats, pats.data(), pats.size() * 8, hipMemcpyHostToDevice);
+    hipError_t e = hipSuccess;
+    if (!p->lw_wide) {  // (wide components: no list - the build kernel unranks the pattern index)
+      pats.reserve((size_t)p->lw_npat[ci]);
+      enumerate_patterns(c.F, p->lw_wmax[ci], pats);
+      if ((long long)pats.size() != p->lw_npat[ci]) {
+        (void)hipFree(tab);
+        return tsim_fail(TSIM_ESTATE, "pattern enumeration mismatch (%zu vs %lld)", pats.size(), p->lw_npat[ci]);
+      }
+      e = hipMalloc((void **)&d_pats, pats.size() * 8);
+      if (e == hipSuccess) e = hipMemcpy(d_pats, pats.data(), pats.size() * 8, hipMemcpyHostToDevice);
+    }
     LwBuildArgs a;
     a.img = p->d_img;
     a.patbits = d_pats;
+    a.wide_binom_off = p->lw_binom_off;
+    a.bases_off = p->lw_off + (int)ci * LW_WORDS + LW_BASES_INLINE;
+    a.wmax = p->lw_wmax[ci];
     a.tab = tab + tab_off;
     a.comp_off = p->comp_off + (int)ci * C_WORDS;
     a.npat = (int)p->lw_npat[ci];
@@ -134,8 +140,13 @@ int tsim_tables_extend(tsim_program *p) {
     return 0;
   }
   float *old = nullptr;
+  const size_t rec_bytes = p->comps.size() * LW_WORDS * 4;
+  // wide components: the build kernel unranks with the NEW bases, read from the device image (every lane is idle)
+  if (p->lw_wide) HIP_TRY(hipMemcpy(p->d_img + p->lw_off, p->img.data() + p->lw_off, rec_bytes, hipMemcpyHostToDevice));
   if (int r = tsim_tables_build(p, &old)) {  // e.g. out of memory: keep what we have
+    (void)r;
     std::copy(saved.begin(), saved.end(), p->img.begin() + p->lw_off);
+    if (p->lw_wide) (void)hipMemcpy(p->d_img + p->lw_off, p->img.data() + p->lw_off, rec_bytes, hipMemcpyHostToDevice);
     p->lw_wmax = before;
     p->lw_npat = npat_before;
     p->lw_bytes = bytes_before;

@@ -205,6 +205,7 @@ struct tsim_program {
     bool wide = true;         // TSIM_AMD_WIDE=0: wide components on the row kernel alone (no sparse-column pass)
     bool lw_reg = true;       // TSIM_AMD_LW_REG=0: LDS-staged first pass even where the register form applies
     int lw_resident = 1;      // TSIM_AMD_LW_RESIDENT: first-pass grid = this many chip-fulls of blocks, rows by grid stride (0: one block per 1024 rows)
+    int wide_list_blocks = 0; // TSIM_AMD_WIDE_LIST_BLOCKS: blocks per CU of the list-driven sparse-column pass (0: what fits)
     bool defer = true;        // TSIM_AMD_DEFER_HARD=0: every pipelined launch runs its own second pass
     int defer_group = 4;      // TSIM_AMD_DEFER_GROUP: launches per deferred hard-row batch (<= TSIMK_H_MAX_CTX)
   } knobs;

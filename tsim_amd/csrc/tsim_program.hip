@@ -557,6 +557,7 @@ retry_pack:
     p->knobs.defer = env_int("TSIM_AMD_DEFER_HARD", 1) != 0;
     p->knobs.lw_reg = env_int("TSIM_AMD_LW_REG", 1) != 0;
     p->knobs.lw_resident = std::max(0, std::min(8, env_int("TSIM_AMD_LW_RESIDENT", 1)));
+    p->knobs.wide_list_blocks = std::max(0, std::min(8, env_int("TSIM_AMD_WIDE_LIST_BLOCKS", 0)));
     p->knobs.wide = env_int("TSIM_AMD_WIDE", 1) != 0;
     p->knobs.direct_runs = env_int("TSIM_AMD_DIRECT_RUNS", 1) != 0;
     p->knobs.merge_lists = env_int("TSIM_AMD_MERGE_LISTS", 1) != 0;

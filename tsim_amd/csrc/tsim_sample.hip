@@ -361,7 +361,8 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
     long long grid1, list_cap;
     if (from_lists) {
       // every input list gets the same number of blocks, which stride over it
-      const long long per_list = std::max(1ll, std::min(chip / a.row_lists, ((long long)a.row_list_cap + kWideBlock - 1) / kWideBlock));
+      const long long chip_l = p->knobs.wide_list_blocks > 0 ? (long long)p->n_cu * std::min(p->knobs.wide_list_blocks, p->v4w_occ_blocks) : chip;
+      const long long per_list = std::max(1ll, std::min(chip_l / a.row_lists, ((long long)a.row_list_cap + kWideBlock - 1) / kWideBlock));
       grid1 = per_list * a.row_lists;
       const long long rows_per_block = ((long long)a.row_list_cap + per_list * kWideBlock - 1) / (per_list * kWideBlock) * kWideBlock;
       // an output list takes the overflow of the blocks with its residue - never more than the launch has rows

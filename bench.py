@@ -400,7 +400,11 @@ def main() -> None:
     fence()
     # HIP events around the dominant kernel only (level 2), on at least 8 launches per repetition: timing events
     # drain the queue they are recorded on (~5 us each), so not every launch is bracketed
-    PROF_EVERY = max(1, min(25, args.steps // 8))
+    # (at least 8 bracketed launches over the repetitions together: a bracket costs ~7 us of a ~17 us step)
+    per_rep = max(1, -(-8 // max(1, args.repeats)))
+    PROF_EVERY = max(1, min(25, args.steps // per_rep))
+    if os.environ.get("TSIM_BENCH_PROF_EVERY"):
+        PROF_EVERY = max(1, int(os.environ["TSIM_BENCH_PROF_EVERY"]))
     hp.profile_set_sampling(PROF_EVERY)
     hp.profile_enable(0 if os.environ.get("TSIM_BENCH_NO_PROFILE") == "1" else 2)
     hp.profile_read(reset=True)
@@ -412,12 +416,19 @@ def main() -> None:
             step()
         t_enq = time.perf_counter() - t0  # host time to enqueue all steps (before draining)
         drain()
+        t_a = time.perf_counter()
         hp.synchronize()
+        t_b = time.perf_counter()
         lib.tsim_device_synchronize(local_rank)
+        t_c = time.perf_counter()
         device_sync()
+        t_d = time.perf_counter()
         if comm is not None:
             comm.barrier()
         elapsed = time.perf_counter() - t0
+        if os.environ.get("TSIM_BENCH_TRACE") and rank == 0:
+            print(f"[trace] enqueue {t_enq*1e6:.0f} us, drain {(t_a-t0-t_enq)*1e6:.0f}, handle sync {(t_b-t_a)*1e6:.0f}, "
+                  f"device sync {(t_c-t_b)*1e6:.0f}, torch sync {(t_d-t_c)*1e6:.0f}, total {elapsed*1e6:.0f}", file=sys.stderr)
         if comm is not None:
             elapsed = comm.allreduce_max(elapsed)
         rep_elapsed.append(elapsed)

@@ -282,17 +282,25 @@ def main() -> None:
     # rows (ceil(n_out/8) bytes per shot) into a group buffer; every GATHER_EVERY steps ONE asynchronous RCCL
     # collective moves the group (double-buffered, queued on the lane where results complete).
     NSLOT = max(1, min(backend.HipProgram.PIPELINE_SLOTS, int(os.environ.get("TSIM_BENCH_SLOTS", "16"))))
-    GATHER_EVERY = max(1, int(os.environ.get("TSIM_BENCH_GATHER_EVERY", "64")))
+    # Group size: a collective per group runs on the join lane under the next group's kernels, only the LAST group's
+    # is exposed at the end of a timed region - so a short region (the driver's --steps 20) wants small groups, a
+    # long one fewer, larger collectives: about a quarter of the region, at most 64 batches, at least N.
+    if os.environ.get("TSIM_BENCH_GATHER_EVERY"):
+        GATHER_EVERY = max(1, int(os.environ["TSIM_BENCH_GATHER_EVERY"]))
+    else:
+        GATHER_EVERY = max(1, min(64, max(N, args.steps // 4)))
     # How the finished rows are collected (N > 1).  "root0": the north star's gather of the detector bit strings to
     # rank 0 (ncclGather).  "alltoall": the same gather with its roots spread over the node - group j of every rank
     # lands on rank j (ncclAllToAll).  Arithmetic behind the default: a rank produces
     # ~180 GB/s of bit-packed rows; xGMI is a full mesh of point-to-point links of ~50-77 GB/s per direction, so
     # rank 0 can take in ~0.4 TB/s over its 7 links while a gather from 7 peers needs 1.2 TB/s - the single root
-    # would bound the node at ~3x one GPU.  Spread roots put 1/N of a rank's stream on each link.  Hence
-    # "auto": root0 for N <= 2 (one link either way), alltoall beyond; no N > 1 measurement exists yet to confirm.
+    # would bound the node at ~3x one GPU.  Spread roots put 1/N of a rank's stream on each link: 91 GB/s at N = 2
+    # (still above one link: two GPUs are link-bound either way, the single root by 2.4x, spread roots by ~1.2x),
+    # 46 GB/s at N = 4, 23 GB/s at N = 8.  Hence "auto" = alltoall for every N > 1; no N > 1 measurement exists
+    # yet to confirm the arithmetic.
     GATHER_MODE = os.environ.get("TSIM_BENCH_GATHER", "auto")
     if GATHER_MODE == "auto":
-        GATHER_MODE = "root0" if N <= 2 else "alltoall"
+        GATHER_MODE = "alltoall"
     if GATHER_MODE == "alltoall":
         GATHER_EVERY = (GATHER_EVERY + N - 1) // N * N
     # results are written in the reference's bit_packed layout (sampler.py:665-669: ceil(n_out/8) bytes per shot,

@@ -20,10 +20,15 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("mode", ["alltoall", "root0"])
+@pytest.mark.parametrize("mode", ["alltoall", "root0", "auto"])
 def test_bench_distributed_path_on_one_gpu(hip, mode):
-    env = dict(os.environ, TSIM_BENCH_FORCE_DIST="1", TSIM_BENCH_GATHER=mode, MASTER_ADDR="127.0.0.1",
-               MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", TSIM_BENCH_GATHER_EVERY="8")
+    env = dict(os.environ, TSIM_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    if mode == "auto":  # the defaults: spread roots, group size from --steps (21 // 4 = 5 batches per collective)
+        env.pop("TSIM_BENCH_GATHER", None)
+        env.pop("TSIM_BENCH_GATHER_EVERY", None)
+    else:
+        env.update(TSIM_BENCH_GATHER=mode, TSIM_BENCH_GATHER_EVERY="8")
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "21", "--warmup", "2", "--shots", "200000",
            "--no-cpu-baseline", "--no-full-leg"]
     try:
@@ -34,6 +39,8 @@ def test_bench_distributed_path_on_one_gpu(hip, mode):
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 1 and d["steps"] == 21 and d["value"] > 0 and d["scaling"] == "weak"
-    assert ("all-to-all" in d["config"]["sharding"]) == (mode == "alltoall")
+    assert ("all-to-all" in d["config"]["sharding"]) == (mode != "root0")
+    if mode == "auto":
+        assert "every 5 batches" in d["config"]["sharding"]
     assert d["roofline"]["achieved"] > 0 and d["roofline"]["launches"] >= 8
     assert "no torch.distributed" in d["config"]["sharding"] and d["repeats"] >= 1

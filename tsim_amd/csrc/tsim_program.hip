@@ -555,6 +555,7 @@ retry_pack:
     p->knobs.v4_block = (vb == 512 || vb == 128) ? vb : 256;
     p->knobs.hard_lds_kb = std::max(24, std::min(156, env_int("TSIM_AMD_HARD_LDS_KB", 128)));
     p->knobs.defer = env_int("TSIM_AMD_DEFER_HARD", 1) != 0;
+    p->knobs.batch_lanes = env_int("TSIM_AMD_BATCH_LANES", 1) >= 2 ? 2 : 1;
     p->knobs.lw_reg = env_int("TSIM_AMD_LW_REG", 1) != 0;
     p->knobs.lw_resident = std::max(0, std::min(8, env_int("TSIM_AMD_LW_RESIDENT", 1)));
     p->knobs.wide_list_blocks = std::max(0, std::min(8, env_int("TSIM_AMD_WIDE_LIST_BLOCKS", 0)));
@@ -786,12 +787,12 @@ extern "C" int tsim_synchronize(tsim_program *p) {
   if (int r = tsim_set_device(p)) return r;
   if (int r = tsim_flush_hard(p)) return r;
   HIP_TRY(hipStreamSynchronize(p->stream));
-  // the three lanes of the deferred plan and every slot stream a launch actually ran on (a stream that never
+  // the four lanes of the deferred plan (two of first passes, two of hard-row batches) and every slot stream a launch actually ran on (a stream that never
   // carried work has nothing to wait for - and each hipStreamSynchronize costs a few microseconds)
   for (int k = 1; k <= TSIM_PIPELINE_SLOTS; ++k) {
     tsim_program::Slot &sl = p->slots[k];
     if (!sl.side_ready) continue;
-    if ((k <= 3 || sl.used) && sl.side != p->stream) HIP_TRY(hipStreamSynchronize(sl.side));
+    if ((k <= 4 || sl.used) && sl.side != p->stream) HIP_TRY(hipStreamSynchronize(sl.side));
     sl.pending = false;
   }
   return TSIM_OK;

@@ -177,7 +177,13 @@ static void hard_geometry(tsim_program *p, int WF, int WO) {
 int tsim_flush_hard(tsim_program *p) {
   if (p->deferred.empty()) return 0;
   constexpr int NW = TSIM_HARD_NW;
-  hipStream_t hs = p->slots[3].side;
+  // TSIM_AMD_BATCH_LANES=2 alternates the batches over two lanes (the third and fourth slot's streams; batches of
+  // one lane complete in order).  Tried for C4, whose 205-us batches of 8 launches bound the pipeline at ~29 us per
+  // launch whatever the batch size: both streams landed on ONE hardware queue, the batches did not overlap
+  // (29.2 -> 27.6 us per step with GPU_MAX_HW_QUEUES=8) - off by default.
+  const unsigned long long seq = p->batch_next++;
+  const int bl = p->knobs.batch_lanes > 1 ? (int)(seq & 1ull) : 0;
+  hipStream_t hs = p->slots[3 + bl].side;
   Hard4Multi M{};
   M.n_ctx = (int)p->deferred.size();
   const uint32_t fb_max = p->h_feedback ? p->h_feedback[1] : 192u;
@@ -221,12 +227,11 @@ int tsim_flush_hard(tsim_program *p) {
   HIP_TRY(hipGetLastError());
   p->hm_attr_set = true;
   ++p->stat_flushes;
-  const unsigned long long seq = p->batch_next++;
   hipEvent_t &be = p->batch_ev[seq % 16u];
   if (!be) HIP_TRY(hipEventCreateWithFlags(&be, hipEventDisableTiming));
-  if (seq > 16u && p->batch_confirmed < seq - 16u) {  // the ring slot's previous batch: 16 batches ago, long done
+  if (seq > 16u && p->batch_confirmed[bl] < seq - 16u) {  // the ring slot's previous batch: 16 batches ago (same lane), long done
     HIP_TRY(hipEventSynchronize(be));
-    p->batch_confirmed = seq - 16u;
+    p->batch_confirmed[bl] = seq - 16u;
   }
   HIP_TRY(hipEventRecord(be, hs));
   for (int i = 0; i < M.n_ctx; ++i) {
@@ -597,8 +602,9 @@ extern "C" int tsim_sample_batch_device_begin(tsim_program *p, int32_t slot, con
       // one stream wait per lane and batch - no event query (the host usually runs several batches ahead
       // of the GPU, the query would fail and cost as much as the wait).
       const int lane = (s == p->slots[1].side) ? 0 : (s == p->slots[2].side) ? 1 : -1;
-      if (sl.batch_seq <= p->batch_confirmed || (lane >= 0 && sl.batch_seq <= p->lane_waited[lane])) done = true;
-      else if (lane >= 0) p->lane_waited[lane] = sl.batch_seq;
+      const int bl = p->knobs.batch_lanes > 1 ? (int)(sl.batch_seq & 1ull) : 0;  // the lane that batch ran on
+      if (sl.batch_seq <= p->batch_confirmed[bl] || (lane >= 0 && sl.batch_seq <= p->lane_waited[lane][bl])) done = true;
+      else if (lane >= 0) p->lane_waited[lane][bl] = sl.batch_seq;
     } else {
       ++p->stat_queries;
       done = hipEventQuery(sl.done_ev) == hipSuccess;
@@ -637,7 +643,7 @@ extern "C" int tsim_pipeline_wait_stream(tsim_program *p, void *stream) {
   std::vector<hipStream_t> seen;
   for (int k = 1; k <= TSIM_PIPELINE_SLOTS; ++k) {
     tsim_program::Slot &sl = p->slots[k];
-    if (!sl.side_ready || (k > 3 && !sl.used) || sl.side == s_user) continue;
+    if (!sl.side_ready || (k > 4 && !sl.used) || sl.side == s_user) continue;
     if (std::find(seen.begin(), seen.end(), sl.side) != seen.end()) continue;
     seen.push_back(sl.side);
     HIP_TRY(hipStreamWaitEvent(sl.side, p->sync_ev, 0));

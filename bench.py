@@ -219,6 +219,9 @@ def main() -> None:
     if args.no_full_leg:
         args.no_extra_legs = True
 
+    # the host driver supports dmabuf IPC only: RCCL's peer mappings fail without this (exported on the GPU boxes;
+    # set here too in case a launcher scrubs the environment) - before any HIP runtime is loaded
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -12,6 +12,7 @@ image on the GPU box too), so a stale ``.so`` can never be used silently.
 
 from __future__ import annotations
 
+import fcntl
 import hashlib
 import os
 import shutil
@@ -102,6 +103,16 @@ def build(force: bool = False, verbose: bool = True) -> Path:
     if not force and not needs_build():
         return OUT
     BUILD.mkdir(exist_ok=True)
+    # one builder at a time: the ranks of a multi-process launch that all find a stale binary must not compile and
+    # link into the same files side by side - the first one builds, the others wait and find it up to date
+    with open(BUILD / ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and not needs_build():
+            return OUT
+        return _build_locked(force, verbose)
+
+
+def _build_locked(force: bool, verbose: bool) -> Path:
     if force:
         for f in BUILD.glob("*.sha256"):
             f.unlink()

@@ -206,7 +206,7 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=8)
-    ap.add_argument("--repeats", type=int, default=5, help="repetitions of the timed --steps loop (median reported)")
+    ap.add_argument("--repeats", type=int, default=8, help="repetitions of the timed --steps loop (median reported)")
     ap.add_argument("--shots", type=int, default=1_000_000, help="shots per step per GPU")
     ap.add_argument("--config", default="C2")
     ap.add_argument("--random-program", action="store_true", help="the unconstrained random program instead of the normalised one")

@@ -284,7 +284,12 @@ def main() -> None:
     # slots - not of lanes - covers the batch latency.  N > 1: the kernels also write the reference's bit_packed
     # rows (ceil(n_out/8) bytes per shot) into a group buffer; every GATHER_EVERY steps ONE asynchronous RCCL
     # collective moves the group (double-buffered, queued on the lane where results complete).
-    NSLOT = max(1, min(backend.HipProgram.PIPELINE_SLOTS, int(os.environ.get("TSIM_BENCH_SLOTS", "16"))))
+    # 14 slots, not all 16: measured (profiles/r02/slot_count.txt) - with a slot count of 2 mod 4 the four launches
+    # of a hard-row batch reuse slots of TWO earlier batches instead of one, and the steady state is 8-9 % faster
+    # (15.0 instead of 16.3 us per step at 1000 steps; 10 and 14 slots alike, 8 / 12 / 16 alike, odd counts break
+    # the lane alternation).  The reuse wait itself never binds (the earlier batch is long done), so the cause is
+    # not understood beyond that regularity.
+    NSLOT = max(1, min(backend.HipProgram.PIPELINE_SLOTS, int(os.environ.get("TSIM_BENCH_SLOTS", "14"))))
     # Group size: a collective per group runs on the join lane under the next group's kernels, only the LAST group's
     # is exposed at the end of a timed region - so a short region (the driver's --steps 20) wants small groups, a
     # long one fewer, larger collectives: about a quarter of the region, at most 64 batches, at least N.
@@ -420,11 +425,21 @@ def main() -> None:
     hp.profile_enable(0 if os.environ.get("TSIM_BENCH_NO_PROFILE") == "1" else 2)
     hp.profile_read(reset=True)
     rep_elapsed, rep_enqueue = [], []
+    START_SLOT = os.environ.get("TSIM_BENCH_START_SLOT")
     for _ in range(max(1, args.repeats)):
         fence()
+        if START_SLOT is not None and not use_dist:
+            step_no[0] = int(START_SLOT)
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
+        if os.environ.get("TSIM_BENCH_TRACE") == "2":
+            stamps = []
+            for _ in range(args.steps):
+                step()
+                stamps.append(time.perf_counter())
+            print("[trace] host us per begin():", [round((b - a) * 1e6) for a, b in zip([t0] + stamps, stamps)], file=sys.stderr)
+        else:
+            for _ in range(args.steps):
+                step()
         t_enq = time.perf_counter() - t0  # host time to enqueue all steps (before draining)
         drain()
         t_a = time.perf_counter()

@@ -284,11 +284,9 @@ def main() -> None:
     # slots - not of lanes - covers the batch latency.  N > 1: the kernels also write the reference's bit_packed
     # rows (ceil(n_out/8) bytes per shot) into a group buffer; every GATHER_EVERY steps ONE asynchronous RCCL
     # collective moves the group (double-buffered, queued on the lane where results complete).
-    # 14 slots, not all 16: measured (profiles/r02/slot_count.txt) - with a slot count of 2 mod 4 the four launches
-    # of a hard-row batch reuse slots of TWO earlier batches instead of one, and the steady state is 8-9 % faster
-    # (15.0 instead of 16.3 us per step at 1000 steps; 10 and 14 slots alike, 8 / 12 / 16 alike, odd counts break
-    # the lane alternation).  The reuse wait itself never binds (the earlier batch is long done), so the cause is
-    # not understood beyond that regularity.
+    # 14 slots: any even count from 10 to 16 gives the same steady state since the library pre-waits mid-batch
+    # (tsim_sample_batch_device_begin; before that, counts of 0 mod 4 were 8 % slower - profiles/r02/slot_count.txt);
+    # 14 is marginally the best at the driver's 20 steps per timed region.
     NSLOT = max(1, min(backend.HipProgram.PIPELINE_SLOTS, int(os.environ.get("TSIM_BENCH_SLOTS", "14"))))
     # Group size: a collective per group runs on the join lane under the next group's kernels, only the LAST group's
     # is exposed at the end of a timed region - so a short region (the driver's --steps 20) wants small groups, a

@@ -180,6 +180,7 @@ struct tsim_program {
   int series_left = 0;
   unsigned long long batch_next = 1;       // sequence number of the next batch (event = batch_ev[seq % 16])
   unsigned long long batch_confirmed[2] = {0, 0};  // per batch lane: every batch up to this one is known to be complete
+  int lane_reach[2] = {0, 0};  // batches between a lane's last start-of-batch wait and the batch it waited for (pre-wait)
   unsigned long long lane_waited[2][2] = {{0, 0}, {0, 0}};  // [first-pass lane][batch lane]: newest batch already waited for
   unsigned long long stat_queries = 0, stat_waits = 0, stat_begins = 0, stat_flushes = 0, stat_deferred = 0;
   int last_lists = 0;         // list count of the most recent two-pass launch (what the feedback refers to)
@@ -207,6 +208,7 @@ struct tsim_program {
     int lw_resident = 1;      // TSIM_AMD_LW_RESIDENT: first-pass grid = this many chip-fulls of blocks, rows by grid stride (0: one block per 1024 rows)
     int wide_list_blocks = 0; // TSIM_AMD_WIDE_LIST_BLOCKS: blocks per CU of the list-driven sparse-column pass (0: what fits)
     bool defer = true;        // TSIM_AMD_DEFER_HARD=0: every pipelined launch runs its own second pass
+    bool prewait = true;      // TSIM_AMD_PREWAIT=0: no mid-batch pre-wait of the first-pass lanes (tsim_sample_batch_device_begin)
     int batch_lanes = 1;      // TSIM_AMD_BATCH_LANES=2: hard-row batches alternate over two streams (no measured gain: both land on one hardware queue)
     int defer_group = 4;      // TSIM_AMD_DEFER_GROUP: launches per deferred hard-row batch (<= TSIMK_H_MAX_CTX)
   } knobs;

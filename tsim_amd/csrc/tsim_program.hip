@@ -556,6 +556,7 @@ retry_pack:
     p->knobs.hard_lds_kb = std::max(24, std::min(156, env_int("TSIM_AMD_HARD_LDS_KB", 128)));
     p->knobs.defer = env_int("TSIM_AMD_DEFER_HARD", 1) != 0;
     p->knobs.batch_lanes = env_int("TSIM_AMD_BATCH_LANES", 1) >= 2 ? 2 : 1;
+    p->knobs.prewait = env_int("TSIM_AMD_PREWAIT", 1) != 0;
     p->knobs.lw_reg = env_int("TSIM_AMD_LW_REG", 1) != 0;
     p->knobs.lw_resident = std::max(0, std::min(8, env_int("TSIM_AMD_LW_RESIDENT", 1)));
     p->knobs.wide_list_blocks = std::max(0, std::min(8, env_int("TSIM_AMD_WIDE_LIST_BLOCKS", 0)));

@@ -604,13 +604,37 @@ extern "C" int tsim_sample_batch_device_begin(tsim_program *p, int32_t slot, con
       const int lane = (s == p->slots[1].side) ? 0 : (s == p->slots[2].side) ? 1 : -1;
       const int bl = p->knobs.batch_lanes > 1 ? (int)(sl.batch_seq & 1ull) : 0;  // the lane that batch ran on
       if (sl.batch_seq <= p->batch_confirmed[bl] || (lane >= 0 && sl.batch_seq <= p->lane_waited[lane][bl])) done = true;
-      else if (lane >= 0) p->lane_waited[lane][bl] = sl.batch_seq;
+      else if (lane >= 0) {
+        p->lane_waited[lane][bl] = sl.batch_seq;
+        // how far back the slots of this caller's rotation reach, in batches (for the pre-wait below)
+        if (p->deferred.size() < 2 && p->batch_next > sl.batch_seq) p->lane_reach[lane] = (int)(p->batch_next - sl.batch_seq);
+      }
     } else {
       ++p->stat_queries;
       done = hipEventQuery(sl.done_ev) == hipSuccess;
       if (!done) (void)hipGetLastError();
     }
     if (!done) { ++p->stat_waits; HIP_TRY(hipStreamWaitEvent(s, sl.done_ev, 0)); }
+  }
+  // Pre-wait, mid-batch.  When the caller rotates through a slot count that is a multiple of the batch size, the
+  // wait a lane needs for its next batch of slots falls on the lane's FIRST launch of that batch - right behind the
+  // event record of the flush that closed the previous batch: two non-kernel packets in a row, on both lanes at
+  // once, and the kernel trace shows both lanes idle for 25-40 us after every flush (16 slots: 16.3 us per step
+  // where 14 slots, whose waits fall mid-batch, reach 15.0).  So the lane's SECOND launch of a batch (which needs
+  // no wait of its own) already waits for the batch the first launch of the next batch will ask for - known from
+  // how far back the last such wait reached (lane_reach) and at least two flushes old, i.e. complete; that launch
+  // then finds the lane already behind it.  Ordering only ever gets stricter.
+  if (plan.defer && p->knobs.prewait && p->knobs.batch_lanes == 1 && p->deferred.size() >= 2) {
+    const int lane = (s == p->slots[1].side) ? 0 : (s == p->slots[2].side) ? 1 : -1;
+    if (lane >= 0 && p->lane_reach[lane] >= 3 && p->lane_reach[lane] <= 15 && p->batch_next > (unsigned long long)p->lane_reach[lane]) {
+      const unsigned long long want = p->batch_next - (unsigned long long)(p->lane_reach[lane] - 1);
+      hipEvent_t ev = p->batch_ev[want % 16u];
+      if (ev && want > p->lane_waited[lane][0] && want > p->batch_confirmed[0]) {
+        p->lane_waited[lane][0] = want;
+        ++p->stat_waits;
+        HIP_TRY(hipStreamWaitEvent(s, ev, 0));
+      }
+    }
   }
   ++p->stat_begins;
   if (plan.defer) ++p->stat_deferred;

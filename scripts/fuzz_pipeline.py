@@ -8,7 +8,7 @@ from tsim_amd import backend as hip, synth, prng
 n_iter = int(sys.argv[1]) if len(sys.argv) > 1 else 150
 rng = np.random.default_rng(2026)
 bad = 0
-for cfg_name in ("C2", "C4", "C3", "C5"):
+for cfg_name in ([a for a in sys.argv[2:] if a != "log"] or ("C2", "C4", "C3", "C5")):
     prog, cfg = synth.config_program(cfg_name)
     hp = hip.HipProgram(prog)                       # tables + pipelining + adaptive plan
     ref = hip.HipProgram(prog, pattern_tables=False)  # the full kernel, serial
@@ -40,6 +40,8 @@ for cfg_name in ("C2", "C4", "C3", "C5"):
         off = int(rng.choice([0, 0, 12345]))
         hp.h2d(d_f[slot], fp)
         hp.sample_batch_device_begin(slot, d_f[slot].ptr, B, nf, key, d_o[slot].ptr, shot_offset=off)
+        if len(sys.argv) > 2 and sys.argv[-1] == "log":
+            print("launch", it, "slot", slot, "B", B, "p", p, "off", off, "tables", hp.info()["pattern_max_weight"], flush=True)
         pending[slot] = (B, fp, key, off)
         if rng.random() < 0.3 and pending:
             check(int(rng.choice(list(pending))))

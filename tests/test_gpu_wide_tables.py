@@ -104,3 +104,36 @@ def test_switch_off(hip, monkeypatch):
     monkeypatch.setenv("TSIM_AMD_WIDE_TABLES", "0")
     info = hip.HipProgram(prog).info()
     assert info["wide_sparse_kernel"] and not info["pattern_tables"]
+
+
+def test_list_counters_survive_launches_that_skip_the_tables(hip):
+    """Dense batches make the planner skip the table pass for 15 launches; the sparse-column pass's own counter sets
+    (its overflow lists) are untouched by those launches and must still be the reset ones when the tables come
+    back.  A random walk over batch sizes and noise levels on ONE slot (seed 5 failed at launch 33 while the second
+    counter set followed the first one's parity: stale counts of a large batch pushed a later batch's rows past its
+    list capacity; found by scripts/fuzz_pipeline.py)."""
+    prog, cfg = synth.config_program("C5")
+    nf, n_out = cfg["num_f"], prog.num_outputs
+    wf, wo = (nf + 63) // 64, (n_out + 63) // 64
+    hp = hip.HipProgram(prog, pattern_tables=3)
+    ref = hip.HipProgram(prog, pattern_tables=False)
+    rng = np.random.default_rng(5)
+    d_f, d_o = hp.malloc(20000 * wf * 8), hp.malloc(20000 * wo * 8)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for i in range(60):
+            B = int(rng.choice([64, 1000, 4097, 20000]))
+            p_bit = float(rng.choice([0.0, 0.005, 0.02, 0.06, 0.3]))
+            f = synth.synth_f(B, nf, p_bit, seed=int(rng.integers(0, 1 << 30)))
+            pk = np.zeros((B, wf * 8), np.uint8)
+            q = np.packbits(f, axis=1, bitorder="little")
+            pk[:, : q.shape[1]] = q
+            hp.h2d(d_f, pk)
+            hp.sample_batch_device_begin(5, d_f.ptr, B, nf, (i, 77), d_o.ptr)
+            hp.sample_batch_device_end(5)
+            hp.synchronize()
+            got = np.zeros((B, wo * 8), np.uint8)
+            hp.d2h(got, d_o)
+            want, _ = ref.sample_batch(f, (i, 77), bit_packed=True)
+            np.testing.assert_array_equal(got[:, : want.shape[1]], want, err_msg=f"launch {i} (B={B}, p_bit={p_bit})")
+    hp.close()

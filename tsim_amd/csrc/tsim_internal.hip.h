@@ -149,6 +149,7 @@ struct tsim_program {
     uint32_t *ctl = nullptr;      // 2 counter sets (hard-row counters + check row)
     void *hard = nullptr;         // hard-row lists
     size_t hard_sz = 0;
+    int parity2 = 0;              // counter set of ctl2 for its next use (ctl2 is not used by every launch)
     uint32_t *ctl2 = nullptr;     // wide programs with tables: the sparse-column pass's own lists (its overflow rows)
     void *hard2 = nullptr;
     size_t hard2_sz = 0;

@@ -468,8 +468,12 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
     a.no_check = has_check ? 0 : 1;
     B2 = list_cap;
     // wide components: the listed rows go through the sparse-column pass first, its overflow to the row kernel
-    if (p->lw_wide && wide_fits)
-      if (int r = wide_pass(true, sl.parity ^ 1)) return r;  // (the parity this launch's first pass used)
+    // (ctl2 alternates on its own: launches that skip the tables - dense batches - do not touch it, and its reset
+    // is done by the launch that used it last)
+    if (p->lw_wide && wide_fits) {
+      if (int r = wide_pass(true, sl.parity2)) return r;
+      sl.parity2 ^= 1;
+    }
   } else if (wide_fits) {
     // wide components: sparse-column pass on every row (k_sample4w); rows with more than K set f bits and the
     // normalisation-check row go to the row lists, which the row kernel below serves

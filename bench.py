@@ -284,10 +284,12 @@ def main() -> None:
     # slots - not of lanes - covers the batch latency.  N > 1: the kernels also write the reference's bit_packed
     # rows (ceil(n_out/8) bytes per shot) into a group buffer; every GATHER_EVERY steps ONE asynchronous RCCL
     # collective moves the group (double-buffered, queued on the lane where results complete).
-    # 14 slots: any even count from 10 to 16 gives the same steady state since the library pre-waits mid-batch
-    # (tsim_sample_batch_device_begin; before that, counts of 0 mod 4 were 8 % slower - profiles/r02/slot_count.txt);
-    # 14 is marginally the best at the driver's 20 steps per timed region.
-    NSLOT = max(1, min(backend.HipProgram.PIPELINE_SLOTS, int(os.environ.get("TSIM_BENCH_SLOTS", "14"))))
+    # Slots: the hard rows of 4 launches form a batch (8 when the chunk tables exceed 4 MB - C4), and two full batches
+    # must fit the rotation: 16 slots for the 8-launch programs (C4: 33 us per step, 41 with 14 slots), 14 otherwise -
+    # every even count from 10 to 16 gives C2 the same steady state since the library pre-waits mid-batch
+    # (profiles/r02/slot_count.txt), 14 is marginally the best at the driver's 20 steps per timed region.
+    default_slots = 16 if info["table_bytes"] > (4 << 20) else 14
+    NSLOT = max(1, min(backend.HipProgram.PIPELINE_SLOTS, int(os.environ.get("TSIM_BENCH_SLOTS", str(default_slots)))))
     # Group size: a collective per group runs on the join lane under the next group's kernels, only the LAST group's
     # is exposed at the end of a timed region - so a short region (the driver's --steps 20) wants small groups, a
     # long one fewer, larger collectives: about a quarter of the region, at most 64 batches, at least N.

@@ -254,3 +254,32 @@ def test_host_noise_device_route_equals_oracle_twin_at_scale(hip, monkeypatch):
             assert all(np.array_equal(x, y) for x, y in zip(g, w))
         else:
             assert np.array_equal(g, w)
+
+
+def test_wide_program_through_the_sampler_equals_oracle_twin(hip, monkeypatch):
+    """The same twin check on C5 (200-parameter component: pattern tables -> sparse-column kernel -> row kernel behind
+    the sampler's pipelined launches), with post-selection on direct detectors and the reference rows."""
+    prog, cfg = synth.config_program("C5")
+    nf = cfg["num_f"]
+    probs = [error_probs(0.02)] * (nf - 2) + [pauli_channel_1_probs(0.01, 0.02, 0.005)]
+    et = np.eye(nf, dtype=np.uint8)
+    mask = np.zeros(prog.num_detectors, bool)
+    mask[[1, 7]] = True
+    cases = [dict(append_observables=True),
+             dict(separate_observables=True, use_detector_reference_sample=True, use_observable_reference_sample=True),
+             dict(append_observables=True, postselection_mask=mask)]
+    import warnings
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        got = [CompiledDetectorSampler(prog, channel_probs=probs, error_transform=et, seed=33).sample(6001, batch_size=2500, **kw)
+               for kw in cases]
+        monkeypatch.setattr(sampler_module, "sample_program", oracle_sample_program)
+        for kw, g in zip(cases, got):
+            s = CompiledDetectorSampler(prog, channel_probs=probs, error_transform=et, seed=33)
+            s._channel_sampler._native = None  # numpy's own generator on the twin
+            w = s.sample(6001, batch_size=2500, **kw)
+            if isinstance(g, tuple):
+                assert all(np.array_equal(x, y) for x, y in zip(g, w))
+            else:
+                assert np.array_equal(g, w)

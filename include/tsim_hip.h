@@ -124,7 +124,10 @@ int tsim_program_get_mode(const tsim_program *p, int32_t *fast);
  * 1 GiB table per component; TSIM_AMD_PATTERN_TABLE_MB overrides) they are tabulated by the sampling kernels' own
  * arithmetic, and shots carrying such patterns in every component are finished by a light first
  * pass (one Threefry draw + one table read per output); only the remaining rows run the full
- * kernel.  Bit-identical results.  Requires <= 10 outputs and <= 64 parameters per component.
+ * kernel.  Bit-identical results.  Requires <= 10 outputs and <= 64 parameters per component - or, for the
+ * programs of the sparse-column kernel (components of up to 255 selected f bits in ascending order, <= 8
+ * outputs): weight <= 4, 4 GiB per component (C(200, <= 4) patterns of 8 thresholds are 2.1 GB), built on the
+ * device by unranking the pattern index; there weight 3 at finalize, deepened once to 4 on demand.
  *   enable: 1 on, 0 off, -1 default (on in TSIM_MODE_AUTO);  max_weight: 0..7 pins the depth; -1 = weight 5 at
  *   finalize (6 ms for the 35-qubit shape), deepened once to 7 (0.1 s, 0.6 GB) if launches keep leaving more than
  *   1 % of their rows to the full kernel (dense error patterns).

@@ -1,5 +1,7 @@
 """Soak test of tsim_sample_batch_device_begin/_end: random batch sizes, noise levels and slot orders,
-several launches in flight; every result is compared with the full kernel on a second handle."""
+several launches in flight; every result is compared with the full kernel on a second handle.
+
+usage: fuzz_pipeline.py [iterations per config] [C2 C3 ... (default: C2 C4 C3 C5)] [log]   ("log" prints every launch)"""
 import sys; sys.path.insert(0, ".")
 import numpy as np, warnings
 warnings.simplefilter("ignore")

@@ -2,7 +2,9 @@
 
 usage: python scripts/summarize_pmc.py OUT.json CONFIG SHOTS DIR [DIR ...]
 Each DIR is a rocprofv3 -d output directory.  For every kernel whose name contains "k_sample" the
-per-invocation average of every counter is computed; OUT.json holds the PER-LAUNCH totals (sum over
+per-invocation MEDIAN of every counter is computed (bench.py's serial legs after the timed region launch the same
+kernels with the padded 8-byte output word: an average would mix their 7.8 MB of writes into the 2.9 MB of the
+timed launches - it did until v17: "WRITE_SIZE 4155 KB"); OUT.json holds the PER-LAUNCH totals (sum over
 the kernels of one sampling launch: pattern-table pass + hard-row kernel + full kernel) at the top
 level - the keys bench.py reads - and the per-kernel averages under "_per_kernel".
 
@@ -34,7 +36,8 @@ def main():
             for r in csv.DictReader(open(fn)):
                 if "k_sample" in r["Kernel_Name"]:
                     agg[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
-    per_kernel = {k: {c: sum(v) / len(v) for c, v in sorted(cs.items())} for k, cs in agg.items()}
+    import statistics
+    per_kernel = {k: {c: statistics.median(v) for c, v in sorted(cs.items())} for k, cs in agg.items()}
     import os
     group = int(os.environ.get("TSIM_AMD_DEFER_GROUP", "4"))
     if "k_sample4h_multi" in per_kernel:

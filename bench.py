@@ -384,8 +384,13 @@ def main() -> None:
 
     def drain() -> None:
         if not use_dist:
-            for k in range(NSLOT):
-                hp.sample_batch_device_end(k)
+            # nothing to join per slot: every caller of drain() goes on to hp.synchronize(), which flushes the waiting
+            # hard-row batch and waits for every lane (tsim_synchronize).  A _end per slot would queue one stream wait
+            # per slot on the handle's stream - which is also first-pass lane 0: 14 barrier packets behind its last
+            # kernel, ~60 us of a 20-step region (TSIM_BENCH_END_EACH=1 restores them).
+            if os.environ.get("TSIM_BENCH_END_EACH") == "1":
+                for k in range(NSLOT):
+                    hp.sample_batch_device_end(k)
             return
         for k in range(NSLOT):
             end_fn(h_prog, k, join_ptr)

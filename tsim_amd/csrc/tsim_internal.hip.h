@@ -181,6 +181,8 @@ struct tsim_program {
   int series_left = 0;
   unsigned long long batch_next = 1;       // sequence number of the next batch (event = batch_ev[seq % 16])
   unsigned long long batch_confirmed[2] = {0, 0};  // per batch lane: every batch up to this one is known to be complete
+  hipStream_t joined_stream = nullptr;  // tsim_sample_batch_device_end: the stream that last joined a batch ...
+  unsigned long long joined_seq = 0;     // ... and that batch: it is behind every batch up to this one
   int lane_reach[2] = {0, 0};  // batches between a lane's last start-of-batch wait and the batch it waited for (pre-wait)
   unsigned long long lane_waited[2][2] = {{0, 0}, {0, 0}};  // [first-pass lane][batch lane]: newest batch already waited for
   unsigned long long stat_queries = 0, stat_waits = 0, stat_begins = 0, stat_flushes = 0, stat_deferred = 0;

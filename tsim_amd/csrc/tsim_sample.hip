@@ -726,7 +726,25 @@ extern "C" int tsim_sample_batch_device_end(tsim_program *p, int32_t slot, void 
   if (sl.deferred)  // its batch is not full yet: run what is waiting now
     if (int r = tsim_flush_hard(p)) return r;
   if (sl.pending) {
-    if (sl.last_done != s) HIP_TRY(hipStreamWaitEvent(s, sl.done_ev, 0));
+    if (sl.last_done != s) {
+      // Batches complete in order on their lane: a stream that already waits for batch b is behind every batch <= b.
+      // "End every slot" - the usual way to join a pipeline - is then ONE stream wait, not one per slot (each is a
+      // barrier packet on `s`; when `s` is the handle's stream, i.e. first-pass lane 0, fourteen of them behind its
+      // last kernel were ~60 us of a 20-launch burst).
+      // (only for streams the handle owns - a caller's stream handle may be destroyed and its address reused)
+      bool own = s == p->stream;
+      for (int k = 1; k <= 4 && !own; ++k) own = p->slots[k].side_ready && s == p->slots[k].side;
+      const bool in_order = own && sl.batch_seq != 0 && p->knobs.batch_lanes == 1;
+      if (in_order && s == p->joined_stream && sl.batch_seq <= p->joined_seq) {
+        // nothing to add
+      } else {
+        HIP_TRY(hipStreamWaitEvent(s, sl.done_ev, 0));
+        if (in_order && (s != p->joined_stream || sl.batch_seq > p->joined_seq)) {
+          p->joined_stream = s;
+          p->joined_seq = sl.batch_seq;
+        }
+      }
+    }
     sl.pending = false;
   }
   return TSIM_OK;

@@ -292,11 +292,15 @@ def main() -> None:
     NSLOT = max(1, min(backend.HipProgram.PIPELINE_SLOTS, int(os.environ.get("TSIM_BENCH_SLOTS", str(default_slots)))))
     # Group size: a collective per group runs on the join lane under the next group's kernels, only the LAST group's
     # is exposed at the end of a timed region - so a short region (the driver's --steps 20) wants small groups, a
-    # long one fewer, larger collectives: about a quarter of the region, at most 64 batches, at least N.
+    # long one fewer, larger collectives.  A group must be a multiple of the hard-row batch (4 launches: closing a
+    # group flushes the waiting batch, and a partial batch is a whole extra hard-row pass - measured on the forced
+    # one-GPU path at 20 steps: groups of 5: 698 us per region, of 8: 528, of 20: 519, of 4: 607) and of N (equal
+    # chunks per peer): about a third of the region in units of max(4, N), at least 8, at most 64 batches.
     if os.environ.get("TSIM_BENCH_GATHER_EVERY"):
         GATHER_EVERY = max(1, int(os.environ["TSIM_BENCH_GATHER_EVERY"]))
     else:
-        GATHER_EVERY = max(1, min(64, max(N, args.steps // 4)))
+        unit = max(4, N)
+        GATHER_EVERY = max(8, min(64, (args.steps // 3) // unit * unit))
     # How the finished rows are collected (N > 1).  "root0": the north star's gather of the detector bit strings to
     # rank 0 (ncclGather).  "alltoall": the same gather with its roots spread over the node - group j of every rank
     # lands on rank j (ncclAllToAll).  Arithmetic behind the default: a rank produces
@@ -330,6 +334,7 @@ def main() -> None:
     key_state = (C.c_uint32 * 2)(key[0] & 0xFFFFFFFF, key[1] & 0xFFFFFFFF)  # split in place by the library
     shot_offset = rank * B
     step_no = [0]
+    launched = [0]  # launches of the whole run (step_no restarts with every timed region in the N > 1 path)
     gathered = [0]  # groups whose collective has been issued
     begin_split = lib.tsim_sample_batch_device_begin_split
     end_fn = lib.tsim_sample_batch_device_end
@@ -370,11 +375,12 @@ def main() -> None:
                 # drain the pipeline once per group); the other lanes are ordered after lane 0 just below
                 comm.wait_mark(g, main_ptr)
             rc = wait_fn(h_prog, None)
-        elif j < NSLOT:  # (the first launches create the lanes)
+        elif launched[0] < NSLOT:  # (the very first launches of the run create the lanes)
             rc = wait_fn(h_prog, None)
         if rc >= 0:  # every launch writes its bit_packed rows straight into its slice of the group buffer
             rc = begin_split(h_prog, b, d_f, B, num_f, key_state, shot_offset, grp[g].ptr + pos * B * RB, None, None,
-                             (0 if j < NSLOT else PIPE_READY) | PIPE_PACKED)
+                             (0 if launched[0] < NSLOT else PIPE_READY) | PIPE_PACKED)
+        launched[0] += 1
         if rc < 0:
             raise RuntimeError(f"pipelined launch failed ({rc}): {_lib.last_error()}")
         if pos == GATHER_EVERY - 1:  # group complete: join every slot on the join lane, then collect

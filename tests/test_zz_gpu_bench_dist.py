@@ -24,7 +24,7 @@ def _free_port():
 def test_bench_distributed_path_on_one_gpu(hip, mode):
     env = dict(os.environ, TSIM_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1",
                MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
-    if mode == "auto":  # the defaults: spread roots, group size from --steps (21 // 4 = 5 batches per collective)
+    if mode == "auto":  # the defaults: spread roots, group size from --steps (8 batches per collective at 21 steps)
         env.pop("TSIM_BENCH_GATHER", None)
         env.pop("TSIM_BENCH_GATHER_EVERY", None)
     else:
@@ -41,6 +41,6 @@ def test_bench_distributed_path_on_one_gpu(hip, mode):
     assert d["n_gpus"] == 1 and d["steps"] == 21 and d["value"] > 0 and d["scaling"] == "weak"
     assert ("all-to-all" in d["config"]["sharding"]) == (mode != "root0")
     if mode == "auto":
-        assert "every 5 batches" in d["config"]["sharding"]
+        assert "every 8 batches" in d["config"]["sharding"]
     assert d["roofline"]["achieved"] > 0 and d["roofline"]["launches"] >= 8
     assert "no torch.distributed" in d["config"]["sharding"] and d["repeats"] >= 1

@@ -56,6 +56,7 @@ extern "C" int tsim_dist_init(int32_t device, const uint8_t id[TSIM_DIST_ID_BYTE
   }
   hipError_t e = hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipMalloc((void **)&d->d_scalar, 64);
+  if (e == hipSuccess) e = hipMemset(d->d_scalar, 0, 64);
   if (e != hipSuccess) {
     tsim_dist_destroy(d);
     return tsim_fail(TSIM_EHIP, "tsim_dist_init: %s", hipGetErrorString(e));
@@ -119,8 +120,11 @@ extern "C" int tsim_dist_allreduce_max(tsim_dist *d, double *value) {
 }
 
 extern "C" int tsim_dist_barrier(tsim_dist *d) {
-  double one = 1.0;
-  return tsim_dist_allreduce_max(d, &one);
+  // an all-reduce of the device scalar as it is (its value is of no interest): no host copies either side
+  if (int r = dist_ready(d)) return r;
+  NCCL_TRY(ncclAllReduce(d->d_scalar, d->d_scalar, 1, ncclDouble, ncclMax, d->comm, d->stream));
+  HIP_TRY(hipStreamSynchronize(d->stream));
+  return TSIM_OK;
 }
 
 extern "C" int tsim_dist_stream_wait(tsim_dist *d, void *waiting_stream, void *signalling_stream) {

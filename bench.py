@@ -320,6 +320,7 @@ def main() -> None:
     d_outs = [hp.malloc(B * WO * 8) for _ in range(NSLOT)]  # sized for the padded rows too (serial legs below)
     out_ptrs = [d.ptr for d in d_outs]
     PIPE_READY, PIPE_PACKED = 1, 2
+    COLL_OWN_STREAM = os.environ.get("TSIM_BENCH_COLL_STREAM", "own") == "own"
     if use_dist:
         join_ptr = hp.pipeline_lane_stream(2)   # where deferred hard-row batches - i.e. results - complete
         main_ptr = hp.stream_ptr()               # first-pass lane 0
@@ -344,12 +345,18 @@ def main() -> None:
     def gather_next(count: int) -> None:
         """Issue the collective of the oldest un-collected group (all of its steps are joined on the join lane)."""
         g = gathered[0] & 1
+        # The collective runs on the communicator's OWN stream, ordered behind the join lane by one event: queued on
+        # the join lane itself (= the hard-row batch lane) it held back the next batch's hard-row pass (kernel trace
+        # of the forced one-GPU path: the last batch of a region started 38 us after its first passes instead of 12).
+        coll = 0 if COLL_OWN_STREAM else join_ptr
+        if COLL_OWN_STREAM:
+            comm.stream_wait(0, join_ptr)
         if GATHER_MODE == "alltoall":  # equal chunks; a partial last group is rounded up (the tail rows are stale)
             per_peer = (count + N - 1) // N * B * RB
-            comm.alltoall_rows(grp[g].ptr, grp_recv[g].ptr, per_peer, stream=join_ptr)
+            comm.alltoall_rows(grp[g].ptr, grp_recv[g].ptr, per_peer, stream=coll)
         else:
-            comm.gather_rows(grp[g].ptr, count * B * RB, grp_recv[g].ptr if grp_recv[g] else 0, root=0, stream=join_ptr)
-        comm.mark(g, join_ptr)  # "the collective that read group buffer g is done"
+            comm.gather_rows(grp[g].ptr, count * B * RB, grp_recv[g].ptr if grp_recv[g] else 0, root=0, stream=coll)
+        comm.mark(g, coll)  # "the collective that read group buffer g is done"
         grp_used[g] = True
         gathered[0] += 1
 

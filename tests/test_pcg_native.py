@@ -123,3 +123,41 @@ def test_native_big_batch_many_channels_threads():
     wide = ch.ChannelSampler([ch.error_probs(0.05)] * 200, np.eye(200, dtype=np.uint8), seed=6, engine="native")
     wide_np = ch.ChannelSampler([ch.error_probs(0.05)] * 200, np.eye(200, dtype=np.uint8), seed=6, engine="numpy")
     np.testing.assert_array_equal(wide.sample_packed(50_000), wide_np.sample_packed(50_000))
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_blocked_stream_equals_scalar_and_numpy(monkeypatch, seed):
+    """The AVX-512 path (four interleaved LCG chains into a buffer, eight geometric draws per step, positions by an
+    in-register prefix sum, output skipping by count) against the scalar path of the same library (TSIM_PCG_SCALAR=1)
+    and numpy: channel mixes that hit every branch - p from 1e-9 to 0.9 (tiny-p scalar fallback, inversion, search),
+    one-outcome channels with more fires than the buffer holds (skip by re-seeding), multi-outcome channels (uniforms
+    through the buffer), batches of 1 to 300 000 rows, consecutive calls on one generator."""
+    rng = np.random.default_rng(100 + seed)
+    probs = []
+    for _ in range(int(rng.integers(3, 40))):
+        p = float(rng.choice([1e-9, 1e-5, 1e-3, 0.02, 0.1, 0.3, 0.34, 0.5, 0.9]))
+        kind = int(rng.integers(0, 3))
+        if kind == 0:
+            probs.append(np.array([1.0 - p, p]))
+        elif kind == 1:
+            probs.append(ch.pauli_channel_1_probs(p / 3, p / 3, p / 3))
+        else:
+            w = rng.random(15)
+            probs.append(np.concatenate([[1.0 - p], p * w / w.sum()]))
+    nbits = sum(int(np.log2(len(q))) for q in probs)
+    num_f = int(rng.integers(8, 130))
+    T = rng.integers(0, 2, size=(num_f, nbits), dtype=np.uint8)  # [f bit, channel bit]
+    T[rng.integers(0, num_f, size=nbits), np.arange(nbits)] = 1  # no empty column
+    a = ch.ChannelSampler(probs, T, seed=seed, engine="native")
+    b = ch.ChannelSampler(probs, T, seed=seed, engine="native")
+    c = ch.ChannelSampler(probs, T, seed=seed, engine="numpy")
+    assert a._native is not None and b._native is not None
+    for n in (1, 7, 300_000, 64, 12_345):
+        monkeypatch.delenv("TSIM_PCG_SCALAR", raising=False)
+        fast = a.sample_packed(n).copy()
+        monkeypatch.setenv("TSIM_PCG_SCALAR", "1")
+        slow = b.sample_packed(n).copy()
+        monkeypatch.delenv("TSIM_PCG_SCALAR", raising=False)
+        np.testing.assert_array_equal(fast, slow)
+        np.testing.assert_array_equal(fast, c.sample_packed(n))
+        assert a._rng.bit_generator.state == b._rng.bit_generator.state == c._rng.bit_generator.state

@@ -26,7 +26,10 @@
 #include <cstdint>
 #include <cstring>
 #include <thread>
+#include <type_traits>
 #include <vector>
+
+#include <immintrin.h>
 
 int tsim_fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 
@@ -124,12 +127,275 @@ inline void advance(Pcg &g, uint64_t delta) {
   g.state = acc_mult * g.state + acc_plus;
 }
 
+// ---------------------------------------------------------------------------
+// Blocked stream (AVX-512 machines).  The generator is an LCG: s_{n+4} = s_n * M^4 + c (M^3 + M^2 + M + 1), so four
+// interleaved chains produce the SAME outputs in the same order with four multiplies in flight instead of one
+// dependent multiply per output.  Outputs go to a small buffer; the geometric draws below consume it eight at a
+// time.  The stream position is a plain count: the state handed back to the caller is the initial state advanced
+// by the number of outputs consumed (Brown's jump), skipping outputs (single-outcome channels) moves the count.
+// ---------------------------------------------------------------------------
+struct Stream {
+  static constexpr int kBlock = 4096;
+  Pcg start;                 // state before output 0 of the call
+  u128 m4, c4;               // the four-step LCG
+  u128 chain[4];             // states whose outputs are next in line: buf[len + j] = out(chain[j])
+  uint64_t consumed = 0;     // outputs consumed before buf[pos]... i.e. stream position of buf[0] is `origin`
+  uint64_t origin = 0;       // stream index of buf[0]
+  int pos = 0, len = 0;
+  alignas(64) uint64_t buf[kBlock + 16];
+
+  static inline uint64_t out(u128 st) {
+    const uint64_t hi = (uint64_t)(st >> 64), lo = (uint64_t)st;
+    const unsigned rot = (unsigned)(hi >> 58);
+    const uint64_t x = hi ^ lo;
+    return (x >> rot) | (x << ((64u - rot) & 63u));
+  }
+  void seed_chains(u128 st) {  // st = state BEFORE the next output
+    for (int j = 0; j < 4; ++j) {
+      st = st * kMult + start.inc;
+      chain[j] = st;
+    }
+  }
+  explicit Stream(const Pcg &g) : start(g) {
+    const u128 m2 = kMult * kMult;
+    m4 = m2 * m2;
+    c4 = start.inc * (kMult * m2 + m2 + kMult + 1);
+    seed_chains(g.state);
+  }
+  // make at least `need` (<= 16) outputs available at buf[pos..]
+  inline void ensure(int need) {
+    if (len - pos >= need) return;
+    const int left = len - pos;
+    for (int k = 0; k < left; ++k) buf[k] = buf[pos + k];
+    origin += (uint64_t)pos;
+    pos = 0;
+    len = left;
+    u128 s0 = chain[0], s1 = chain[1], s2 = chain[2], s3 = chain[3];
+    uint64_t *dst = buf + len;
+    const int n4 = (kBlock - len) / 4;
+    for (int t = 0; t < n4; ++t) {
+      dst[0] = out(s0); dst[1] = out(s1); dst[2] = out(s2); dst[3] = out(s3);
+      s0 = s0 * m4 + c4; s1 = s1 * m4 + c4; s2 = s2 * m4 + c4; s3 = s3 * m4 + c4;
+      dst += 4;
+    }
+    chain[0] = s0; chain[1] = s1; chain[2] = s2; chain[3] = s3;
+    len += 4 * n4;
+  }
+  inline uint64_t next64() {
+    ensure(1);
+    return buf[pos++];
+  }
+  inline double next_double() { return (double)(next64() >> 11) * (1.0 / 9007199254740992.0); }
+  uint64_t position() const { return origin + (uint64_t)pos; }
+  void skip(uint64_t n) {
+    if (n <= (uint64_t)(len - pos)) {
+      pos += (int)n;
+      return;
+    }
+    const uint64_t target = position() + n;
+    Pcg g = start;
+    advance(g, target);
+    seed_chains(g.state);
+    origin = target;
+    pos = len = 0;
+  }
+  Pcg finish() const {
+    Pcg g = start;
+    advance(g, position());
+    return g;
+  }
+};
+
+inline double standard_exponential(Stream &g) {
+  for (;;) {
+    uint64_t ri = g.next64() >> 3;
+    const unsigned idx = (unsigned)(ri & 0xFFu);
+    ri >>= 8;
+    const Strip &st = kStrips.s[idx];
+    const double x = (double)ri * st.we;
+    if (ri < st.ke) return x;
+    if (idx == 0) return kZigExpR - log1p(-g.next_double());
+    if ((kZigFe[idx - 1] - kZigFe[idx]) * g.next_double() + kZigFe[idx] < exp(-x)) return x;
+  }
+}
+
+inline int64_t geometric_search(Stream &g, double p) {
+  int64_t X = 1;
+  double sum = p, prod = p;
+  const double q = 1.0 - p, U = g.next_double();
+  while (U > sum) {
+    prod *= q;
+    sum += prod;
+    ++X;
+  }
+  return X;
+}
+
+inline int64_t geometric_inversion(Stream &g, double log1m_p) {
+  const double z = ceil(-standard_exponential(g) / log1m_p);
+  if (z >= 9.223372036854776e+18) return INT64_MAX;
+  return (int64_t)z;
+}
+
+// Eight geometric(p < 1/3) draws at a time: the common path of the ziggurat (one output per draw, 98.9 %) for eight
+// consecutive outputs at once.  k = how many leading draws took it: the caller consumes exactly k outputs and handles
+// the next draw (a wedge or tail case, which reads further outputs) with the scalar code.  Same operations as the
+// scalar path lane by lane - shift / mask, exact u64 -> f64, one multiply, one divide, ceil, truncation, all
+// correctly rounded - so the bits are the same.  The positions (running sum of the gaps, clamped at `far` once
+// they leave the batch, exactly like the scalar code) come from an in-register prefix sum; they only grow, so the
+// k values are stored unconditionally and the count of those inside the batch advances the output cursor.
+struct Geo8 {
+  int k;          // draws taken
+  int inside;     // of those, positions < num_samples
+  int64_t pos;    // position after the k-th draw
+};
+__attribute__((target("avx512f,avx512dq,avx512vl"))) inline Geo8 geometric8(const uint64_t *raw, double log1m_p, int64_t pos,
+                                                                          int64_t far, int64_t num_samples, uint32_t *dst) {
+  const __m512i v = _mm512_loadu_si512((const void *)raw);
+  __m512i ri = _mm512_srli_epi64(v, 3);
+  const __m512i idx = _mm512_and_si512(ri, _mm512_set1_epi64(0xFF));
+  ri = _mm512_srli_epi64(ri, 8);
+  const __m512i ke = _mm512_i64gather_epi64(idx, (const void *)kZigKe, 8);
+  const __m512d we = _mm512_i64gather_pd(idx, (const void *)kZigWe, 8);
+  const __m512d x = _mm512_mul_pd(_mm512_cvtepu64_pd(ri), we);
+  const __mmask8 ok = _mm512_cmplt_epu64_mask(ri, ke);
+  const __m512d nx = _mm512_xor_pd(x, _mm512_set1_pd(-0.0));  // unary minus, as the scalar code
+  const __m512d z = _mm512_roundscale_pd(_mm512_div_pd(nx, _mm512_set1_pd(log1m_p)), _MM_FROUND_TO_POS_INF | _MM_FROUND_NO_EXC);
+  __m512i p = _mm512_cvttpd_epi64(z);
+  const __m512i zero = _mm512_setzero_si512();
+  p = _mm512_add_epi64(p, _mm512_alignr_epi64(p, zero, 7));
+  p = _mm512_add_epi64(p, _mm512_alignr_epi64(p, zero, 6));
+  p = _mm512_add_epi64(p, _mm512_alignr_epi64(p, zero, 4));
+  p = _mm512_min_epi64(_mm512_add_epi64(p, _mm512_set1_epi64(pos)), _mm512_set1_epi64(far));
+  Geo8 r;
+  r.k = __builtin_ctz(~(unsigned)ok | 0x100u);
+  const __mmask8 taken = (__mmask8)((1u << r.k) - 1u);
+  r.inside = __builtin_popcount((unsigned)(_mm512_cmplt_epi64_mask(p, _mm512_set1_epi64(num_samples)) & taken));
+  _mm256_storeu_si256((__m256i *)dst, _mm512_cvtepi64_epi32(p));  // 8 values; only the first `inside` are kept
+  alignas(64) int64_t tmp[8];
+  _mm512_store_si512((void *)tmp, p);
+  r.pos = r.k ? tmp[r.k - 1] : pos;
+  return r;
+}
+
+// The eight-wide loop of one channel (in a function of its own so that geometric8 - compiled for AVX-512 - inlines).
+__attribute__((target("avx512f,avx512dq,avx512vl"))) void geometric_run(Stream &g, double l, int64_t n_draws, int64_t far,
+                                                                      int64_t num_samples, uint32_t *frow, size_t room,
+                                                                      int64_t &i, int64_t &pos, size_t &n) {
+  while (i + 8 <= n_draws && n + 8 <= room) {
+    g.ensure(8);
+    const Geo8 r = geometric8(g.buf + g.pos, l, pos, far, num_samples, frow + n);
+    n += (size_t)r.inside;
+    pos = r.pos;
+    g.pos += r.k;
+    i += r.k;
+    if (r.k < 8) {  // this draw needs the wedge / tail code (it reads further outputs)
+      const int64_t gap = geometric_inversion(g, l);
+      pos = (gap >= far || pos + gap >= far) ? far : pos + gap;
+      frow[n] = (uint32_t)pos;
+      n += (size_t)((pos < num_samples) & (n < room));
+      ++i;
+    }
+  }
+}
+
+bool have_avx512() {
+  static const bool ok = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512dq") && __builtin_cpu_supports("avx512vl");
+  return ok;
+}
+
 // scratch that survives between calls (one sampler thread per process is the rule; thread_local keeps others safe)
 struct Scratch {
   std::vector<uint32_t> row;      // fired rows, channel after channel
   std::vector<uint16_t> outcome;  // outcome index per fired row (multi-outcome channels only)
 };
 thread_local Scratch g_scratch;
+
+// generator-agnostic helpers of pass 1
+inline void skip_outputs(Pcg &g, uint64_t n) { advance(g, n); }
+inline void skip_outputs(Stream &g, uint64_t n) { g.skip(n); }
+inline double draw_double(Pcg &g) { return next_double(g); }
+inline double draw_double(Stream &g) { return g.next_double(); }
+
+// pass 1 of tsim_pcg_sample_channels for either generator form
+template <class G>
+int draw_channels(G &g, int32_t n_channels, const double *p_fire, const int32_t *n_outcomes, const double *cond_cdf,
+                  int64_t num_samples, Scratch &S, std::vector<size_t> &chan_begin, std::vector<size_t> &table_off,
+                  size_t &n_fires_out) {
+  {
+    double cap = 0;
+    for (int c = 0; c < n_channels; ++c) {
+      const double e = (double)num_samples * p_fire[c];
+      cap += e + 7.0 * sqrt(e) + 101.0;
+      table_off[c + 1] = table_off[c] + (size_t)std::max(0, n_outcomes[c]);
+      if (n_outcomes[c] > 65535) return tsim_fail(TSIM_ENOTSUP, "channel %d has more than 65535 outcomes", c);
+    }
+    if (S.row.size() < (size_t)cap + 32) S.row.resize((size_t)cap + 32);
+    if (S.outcome.size() < S.row.size()) S.outcome.resize(S.row.size());
+  }
+  uint32_t *const frow = S.row.data();
+  uint16_t *const fout = S.outcome.data();
+  size_t n_fires = 0;
+  for (int c = 0; c < n_channels; ++c) {
+    const double p = p_fire[c];
+    const int nout = n_outcomes[c];
+    if (!(p > 0.0) || p > 1.0 || nout < 1) return tsim_fail(TSIM_EINVAL, "channel %d: p_fire = %g, outcomes = %d", c, p, nout);
+    const double *cdf = cond_cdf + table_off[c];
+    // n_draws = int(expected + 7 sigma) + 100 (channels.py:641-644), in the same double operations
+    const double expected = (double)num_samples * p;
+    const double sigma = sqrt(expected * (1.0 - p));
+    const int64_t n_draws = (int64_t)(expected + 7.0 * sigma) + 100;
+    chan_begin[c] = n_fires;
+    // positions = cumsum(gaps) - 1, kept while < num_samples.  Every one of the n_draws gaps is drawn (the stream
+    // position depends on it); positions only grow, so the store below is unconditional and the count advances
+    // only while the position is still inside the batch.
+    size_t n = n_fires;
+    const size_t room = S.row.size() - 1;
+    int64_t pos = -1;
+    if (p >= 0.333333333333333333333333) {
+      for (int64_t i = 0; i < n_draws; ++i) {
+        pos += geometric_search(g, p);
+        frow[n] = (uint32_t)pos;
+        n += (size_t)((pos < num_samples) & (n < room));
+      }
+    } else {
+      // gap = ceil(-e / log1p(-p)) with the exact division (a multiply by the reciprocal plus a closeness check
+      // was measured: slower - the divide is off the dependency chain).  A position that has left the batch stays
+      // outside (clamped: numpy's int64 cumsum cannot wrap back below 2^32 rows either).
+      const double l = log1p(-p);
+      const int64_t far = num_samples + 1;
+      int64_t i = 0;
+      if constexpr (std::is_same<G, Stream>::value) {
+        // eight draws per step while the common path holds; the scalar loop below finishes the rest (the draw
+        // that left the common path, and tiny p whose gaps may not fit an int64)
+        if (l < -1e-15) {
+          geometric_run(g, l, n_draws, far, num_samples, frow, room, i, pos, n);
+        }
+      }
+      for (; i < n_draws; ++i) {
+        const int64_t gap = geometric_inversion(g, l);
+        pos = (gap >= far || pos + gap >= far) ? far : pos + gap;
+        frow[n] = (uint32_t)pos;
+        n += (size_t)((pos < num_samples) & (n < room));
+      }
+    }
+    // one uniform per fired row; outcome = searchsorted(cdf, u) (first entry >= u; cdf[-1] == 1 > u).  A channel
+    // with a single non-identity outcome needs no value - only the stream position: jump over its uniforms.
+    if (nout == 1) {
+      skip_outputs(g, (uint64_t)(n - n_fires));
+    } else {
+      for (size_t k = n_fires; k < n; ++k) {
+        const double u = draw_double(g);
+        int o = 0;
+        while (o < nout - 1 && cdf[o] < u) ++o;
+        fout[k] = (uint16_t)o;
+      }
+    }
+    n_fires = n;
+  }
+  n_fires_out = n_fires;
+  return TSIM_OK;
+}
 
 }  // namespace
 
@@ -174,73 +440,20 @@ extern "C" int tsim_pcg_sample_channels(tsim_pcg64 *rng, int32_t n_channels, con
   const auto t_start = std::chrono::steady_clock::now();
   memset(rows, 0, (size_t)num_samples * words * 8);
   const auto t_zero = std::chrono::steady_clock::now();
-  Pcg g = load(rng);
   // ---- pass 1 (sequential: the stream is one dependency chain): per channel the fired rows and their outcomes
   Scratch &S = g_scratch;
   std::vector<size_t> chan_begin((size_t)n_channels + 1, 0), table_off((size_t)n_channels + 1, 0);
-  {
-    double cap = 0;
-    for (int c = 0; c < n_channels; ++c) {
-      const double e = (double)num_samples * p_fire[c];
-      cap += e + 7.0 * sqrt(e) + 101.0;
-      table_off[c + 1] = table_off[c] + (size_t)std::max(0, n_outcomes[c]);
-      if (n_outcomes[c] > 65535) return tsim_fail(TSIM_ENOTSUP, "channel %d has more than 65535 outcomes", c);
-    }
-    if (S.row.size() < (size_t)cap + 16) S.row.resize((size_t)cap + 16);
-    if (S.outcome.size() < S.row.size()) S.outcome.resize(S.row.size());
+  size_t n_fires = 0;
+  Pcg g = load(rng);
+  if (have_avx512() && !getenv("TSIM_PCG_SCALAR")) {
+    Stream st(g);
+    if (int r = draw_channels(st, n_channels, p_fire, n_outcomes, cond_cdf, num_samples, S, chan_begin, table_off, n_fires)) return r;
+    g = st.finish();
+  } else {
+    if (int r = draw_channels(g, n_channels, p_fire, n_outcomes, cond_cdf, num_samples, S, chan_begin, table_off, n_fires)) return r;
   }
   uint32_t *const frow = S.row.data();
   uint16_t *const fout = S.outcome.data();
-  size_t n_fires = 0;
-  for (int c = 0; c < n_channels; ++c) {
-    const double p = p_fire[c];
-    const int nout = n_outcomes[c];
-    if (!(p > 0.0) || p > 1.0 || nout < 1) return tsim_fail(TSIM_EINVAL, "channel %d: p_fire = %g, outcomes = %d", c, p, nout);
-    const double *cdf = cond_cdf + table_off[c];
-    // n_draws = int(expected + 7 sigma) + 100 (channels.py:641-644), in the same double operations
-    const double expected = (double)num_samples * p;
-    const double sigma = sqrt(expected * (1.0 - p));
-    const int64_t n_draws = (int64_t)(expected + 7.0 * sigma) + 100;
-    chan_begin[c] = n_fires;
-    // positions = cumsum(gaps) - 1, kept while < num_samples.  Every one of the n_draws gaps is drawn (the stream
-    // position depends on it); positions only grow, so the store below is unconditional and the count advances
-    // only while the position is still inside the batch.
-    size_t n = n_fires;
-    const size_t room = S.row.size() - 1;
-    int64_t pos = -1;
-    if (p >= 0.333333333333333333333333) {
-      for (int64_t i = 0; i < n_draws; ++i) {
-        pos += geometric_search(g, p);
-        frow[n] = (uint32_t)pos;
-        n += (size_t)((pos < num_samples) & (n < room));
-      }
-    } else {
-      // gap = ceil(-e / log1p(-p)) with the exact division (a multiply by the reciprocal plus a closeness check
-      // was measured: slower - the divide is off the dependency chain).  A position that has left the batch stays
-      // outside (clamped: numpy's int64 cumsum cannot wrap back below 2^32 rows either).
-      const double l = log1p(-p);
-      const int64_t far = num_samples + 1;
-      for (int64_t i = 0; i < n_draws; ++i) {
-        const int64_t gap = geometric_inversion(g, l);
-        pos = (gap >= far || pos + gap >= far) ? far : pos + gap;
-        frow[n] = (uint32_t)pos;
-        n += (size_t)((pos < num_samples) & (n < room));
-      }
-    }
-    // one uniform per fired row; outcome = searchsorted(cdf, u) (first entry >= u; cdf[-1] == 1 > u).  A channel
-    // with a single non-identity outcome needs no value - only the stream position: jump over its uniforms.
-    if (nout == 1) {
-      advance(g, (uint64_t)(n - n_fires));
-    } else {
-      for (size_t k = n_fires; k < n; ++k) {
-        const double u = next_double(g);
-        int o = 0;
-        while (o < nout - 1 && cdf[o] < u) ++o;
-        fout[k] = (uint16_t)o;
-      }
-    }
-    n_fires = n;
-  }
   chan_begin[n_channels] = n_fires;
   store(rng, g);
   const auto t_pass1 = std::chrono::steady_clock::now();

@@ -1,5 +1,5 @@
 """Offline soak of the HIP path against the C oracle (test infrastructure: run by hand on the GPU box,
-`python tests/fuzz_many.py N`; not collected by pytest)."""
+`python tests/fuzz_many.py N [first seed]`; not collected by pytest)."""
 import sys; sys.path.insert(0, "."); sys.path.insert(0, "tests")
 import numpy as np, warnings
 warnings.simplefilter("ignore")
@@ -9,7 +9,8 @@ from test_gpu_fuzz import random_physical_program, random_program
 bad = skipped = 0
 used = {}
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
-for seed in range(n):
+first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+for seed in range(first, first + n):
     rng = np.random.default_rng(5000 + seed)
     prog, num_f = (random_physical_program if seed % 2 else random_program)(rng)
     B = int(rng.choice([1, 64, 65, 257, 1000]))
@@ -18,7 +19,7 @@ for seed in range(n):
     want, wdev, ov = OC.OracleProgram(prog).sample_program(f, key, return_devs=True, return_overflow=True)
     if ov:
         skipped += 1; continue
-    for mode, pt in (("auto", None), ("auto", False), ("rows", True), ("faithful", True), ("auto", 1)):
+    for mode, pt in (("auto", None), ("auto", False), ("rows", True), ("faithful", True), ("auto", 1), ("auto", 4)):
         hp = hip.HipProgram(prog, mode=mode, pattern_tables=pt)
         got, gdev = hp.sample_batch(f, key)
         kinds = hp.info(); used[(kinds["chunk_table_kernel"], kinds["wide_sparse_kernel"], kinds["pattern_tables"])] = used.get((kinds["chunk_table_kernel"], kinds["wide_sparse_kernel"], kinds["pattern_tables"]), 0) + 1
@@ -28,6 +29,7 @@ for seed in range(n):
                 bad += 1; print("MISMATCH (second launch) seed", seed, mode, hp.info())
         if not (np.array_equal(got, want) and np.array_equal(np.asarray(gdev, np.float32), np.asarray(wdev, np.float32), equal_nan=True)):
             bad += 1; print("MISMATCH seed", seed, mode, pt, hp.info())
+        hp.close()  # depth-4 tables of a wide component are gigabytes: do not wait for the collector
     if seed % 50 == 49:
         import gc; gc.collect()
 print("done", n, "programs; mismatches", bad, "skipped(overflow)", skipped, "handles by (chunk, wide, tables):", used)

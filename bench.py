@@ -317,6 +317,13 @@ def main() -> None:
         GATHER_EVERY = (GATHER_EVERY + N - 1) // N * N
     # results are written in the reference's bit_packed layout (sampler.py:665-669: ceil(n_out/8) bytes per shot,
     # TSIM_PIPE_OUT_BIT_PACKED) - the algorithmic output bytes, not the padded 8-byte device word
+    # N = 1: the K steps of a timed region are ONE call of tsim_sample_steps_device (key splits included): the library
+    # fuses the first passes of up to 8 batches into one grid and runs each group's hard rows as one batch behind it
+    # (DESIGN.md section 3.10); its slot rotation covers all 16 pipeline slots, so 16 output buffers.
+    # TSIM_BENCH_PER_STEP=1: one tsim_sample_batch_device_begin_split per step, as in rounds 1-2.
+    PER_STEP = use_dist or os.environ.get("TSIM_BENCH_PER_STEP") == "1"
+    if not PER_STEP:
+        NSLOT = backend.HipProgram.PIPELINE_SLOTS
     d_outs = [hp.malloc(B * WO * 8) for _ in range(NSLOT)]  # sized for the padded rows too (serial legs below)
     out_ptrs = [d.ptr for d in d_outs]
     PIPE_READY, PIPE_PACKED = 1, 2
@@ -359,6 +366,28 @@ def main() -> None:
         comm.mark(g, coll)  # "the collective that read group buffer g is done"
         grp_used[g] = True
         gathered[0] += 1
+
+    steps_fn = lib.tsim_sample_steps_device
+    ptr_cache = {}
+
+    def steps(k: int, f_list=f_bufs) -> None:
+        """k consecutive steps in one library call (N = 1): per batch key, subkey = split(key) (sampler.py:399) and one
+        sample_program; batch j reads f_list[j % len], writes bit_packed rows to out buffer j % NSLOT."""
+        if PER_STEP:
+            for _ in range(k):
+                step(f_list)
+            return
+        j0 = step_no[0]
+        ck = (k, j0 % NSLOT, j0 % len(f_list), id(f_list))
+        arrs = ptr_cache.get(ck)
+        if arrs is None:
+            arrs = ((C.c_void_p * k)(*[f_list[(j0 + i) % len(f_list)].ptr for i in range(k)]),
+                    (C.c_void_p * k)(*[out_ptrs[(j0 + i) % NSLOT] for i in range(k)]))
+            ptr_cache[ck] = arrs
+        step_no[0] = j0 + k
+        rc = steps_fn(h_prog, k, arrs[0], B, num_f, key_state, shot_offset, arrs[1], None, PIPE_READY | PIPE_PACKED)
+        if rc < 0:
+            raise RuntimeError(f"tsim_sample_steps_device failed ({rc}): {_lib.last_error()}")
 
     def step(f_list=f_bufs) -> None:
         # one host split per batch, key, subkey = split(key) (sampler.py:399), inside the launch call
@@ -429,19 +458,21 @@ def main() -> None:
     for _ in range(INIT_STEPS):
         step()
     fence()
-    for _ in range(args.warmup):
-        step()
+    steps(args.warmup)
     fence()
     # HIP events around the dominant kernel only (level 2), on at least 8 launches per repetition: timing events
     # drain the queue they are recorded on (~5 us each), so not every launch is bracketed
     # (at least 8 bracketed launches over the repetitions together: a bracket costs ~7 us of a ~17 us step)
     per_rep = max(1, -(-8 // max(1, args.repeats)))
     PROF_EVERY = max(1, min(25, args.steps // per_rep))
+    if not PER_STEP:
+        PROF_EVERY = 1  # a fused first pass serves several batches: two events per ~100 us kernel
     if os.environ.get("TSIM_BENCH_PROF_EVERY"):
         PROF_EVERY = max(1, int(os.environ["TSIM_BENCH_PROF_EVERY"]))
     hp.profile_set_sampling(PROF_EVERY)
     hp.profile_enable(0 if os.environ.get("TSIM_BENCH_NO_PROFILE") == "1" else 2)
     hp.profile_read(reset=True)
+    hp.profile_read_steps()
     rep_elapsed, rep_enqueue = [], []
     START_SLOT = os.environ.get("TSIM_BENCH_START_SLOT")
     for _ in range(max(1, args.repeats)):
@@ -456,8 +487,7 @@ def main() -> None:
                 stamps.append(time.perf_counter())
             print("[trace] host us per begin():", [round((b - a) * 1e6) for a, b in zip([t0] + stamps, stamps)], file=sys.stderr)
         else:
-            for _ in range(args.steps):
-                step()
+            steps(args.steps)
         t_enq = time.perf_counter() - t0  # host time to enqueue all steps (before draining)
         drain()
         t_a = time.perf_counter()
@@ -479,6 +509,7 @@ def main() -> None:
         rep_enqueue.append(t_enq)
     stages = hp.profile_read_stages()
     kern_ms, launches = hp.profile_read(reset=True)
+    prof_steps = hp.profile_read_steps()  # batches covered by the bracketed (fused) first passes
     hp.profile_enable(False)
     elapsed = statistics.median(rep_elapsed)
     host_enqueue_s = statistics.median(rep_enqueue)
@@ -494,6 +525,7 @@ def main() -> None:
             step()
         drain()
         hp.synchronize()
+        hp.profile_read_steps()
         dst = hp.profile_read_stages()
         dms, dl = hp.profile_read(reset=True)
         hp.profile_enable(False)
@@ -533,7 +565,9 @@ def main() -> None:
             avg_kernel_s = launch_s = elapsed / args.steps
         bytes_per_shot = algorithmic_bytes_per_shot(num_f, n_out)
         ops_per_shot = algorithmic_ops_per_shot(program)
-        achieved_gbs = bytes_per_shot * B / avg_kernel_s / 1e9
+        # a fused first pass (tsim_sample_steps_device) serves several batches per launch: algorithmic bytes per LAUNCH
+        batches_per_launch = (prof_steps / launches) if (prof_steps and launches and tables_dominant) else 1.0
+        achieved_gbs = bytes_per_shot * B * batches_per_launch / avg_kernel_s / 1e9
         if tables_dominant:
             kernel_name = ("tsimk::k_sample_lw (pattern-table pass; hard rows: k_sample4h_multi batches / k_sample4h + "
                            "k_sample4, on the third lane)") if info.get("chunk_table_kernel") else \
@@ -584,6 +618,8 @@ def main() -> None:
                 "frac_at_step_rate": bytes_per_shot * B / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
                 "kernel": kernel_name,
                 "kernel_avg_ms": avg_kernel_s * 1e3,
+                "batches_per_launch": batches_per_launch,
+                "kernel_avg_ms_per_batch": avg_kernel_s * 1e3 / batches_per_launch,
                 "launches": launches,
                 "hip_event_sampling": f"1 launch in {PROF_EVERY} bracketed, {len(rep_elapsed)} repetitions",
                 "kernel_serial_avg_ms": serial_ms,
@@ -599,7 +635,7 @@ def main() -> None:
                 "bytes/shot), achieved_serial the kernel's duration with the GPU to itself (= rocprofv3's serial kernel "
                 "trace).  Integer-VALU / latency bound, not HBM bound (DESIGN.md section 3.5): see `valu`.",
             },
-            "valu": valu_block(ops_per_shot, B, avg_kernel_s, (serial_ms * 1e-3) if serial_ms else None, elapsed / args.steps, pmc),
+            "valu": valu_block(ops_per_shot, B, avg_kernel_s / batches_per_launch, (serial_ms * 1e-3) if serial_ms else None, elapsed / args.steps, pmc),
         }
         res.update(extra)
         if N == 1 and not args.no_cpu_baseline:

@@ -402,6 +402,22 @@ int tsim_sample_batch_device_begin_split(tsim_program *p, int32_t slot, const ui
                                          int32_t num_f, uint32_t key[2], int64_t shot_offset, uint64_t *d_out,
                                          float *d_max_norm_dev, void *stream, uint32_t flags);
 
+/* SEVERAL consecutive batches of the reference's batch loop in one call (src/tsim/sampler.py:340-420: per batch
+ * `key, subkey = split(key)`, sampler.py:399, then one sample_program, sampler.py:117-167).  For j < n_steps:
+ * d_out[j] = sample_program(d_f[j], subkey_j) - exactly what n_steps calls of tsim_sample_batch_device_begin_split
+ * on consecutive pipeline slots give, bit for bit; `key` = {hi, lo} is advanced n_steps times.  The call only
+ * enqueues (slots rotate through all TSIM_PIPELINE_SLOTS; tsim_synchronize, or tsim_sample_batch_device_end on the
+ * slots, completes the results); all batches share B, num_f, shot_offset and `flags` (TSIM_PIPE_*; the inputs are
+ * ordered after the handle's stream unless TSIM_PIPE_INPUTS_READY).  d_max_norm_dev may be NULL, and so may its
+ * entries.  Where the register first pass applies (f rows of at most 128 bits, at most 64 outputs and 16 compiled
+ * outputs, pattern tables on, short hard-row lists) the first passes of up to 8 batches are ONE grid
+ * (k_sample_lw_multi: no kernel boundary, no host call between batches, one ramp and one tail per group) and their
+ * hard rows one k_sample4h_multi batch behind it; any other program or launch plan goes batch by batch through
+ * tsim_sample_batch_device_begin.  TSIM_AMD_FUSED_STEPS=0 forces the latter, TSIM_AMD_FUSED_MAX caps a group. */
+int tsim_sample_steps_device(tsim_program *p, int32_t n_steps, const uint64_t *const *d_f, int64_t B, int32_t num_f,
+                             uint32_t key[2], int64_t shot_offset, void *const *d_out, float *const *d_max_norm_dev,
+                             uint32_t flags);
+
 /* HIP-event timing of the sampling kernel launches on the handle's stream.
  * on = 1: every kernel of a launch; on = 2: only the first kernel of a launch (the pattern-table
  * pass when tables are active) - timing events drain the queue they are recorded on, which costs
@@ -415,6 +431,9 @@ int tsim_profile_read(tsim_program *p, double *kernel_ms, int64_t *launches, int
 /* The same total split by kernel: [0] pattern-table pass (k_sample_lw), [1] hard-row kernel
  * (k_sample4h), [2] full kernel (k_sample4 / k_sample); call before a resetting tsim_profile_read. */
 int tsim_profile_read_stages(tsim_program *p, double stage_ms[3]);
+/* Batches covered by the bracketed first passes since the last reset: a fused first pass
+ * (tsim_sample_steps_device) is ONE launch in tsim_profile_read that serves several batches. */
+int tsim_profile_read_steps(tsim_program *p, int64_t *steps, int32_t reset);
 
 /* ---- introspection ---------------------------------------------------- */
 

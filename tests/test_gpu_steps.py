@@ -1,0 +1,141 @@
+"""tsim_sample_steps_device: several consecutive batches of the reference's batch loop (sampler.py:340-420) in one
+call - fused first passes (k_sample_lw_multi) where the register form applies - must give, batch for batch, the
+bits of the oracle with the split key chain of sampler.py:399 (and therefore of the one-batch-per-call API)."""
+
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import oracle_c as OC
+from tsim_amd import prng, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _packed(f, wf):
+    p = np.packbits(f, axis=1, bitorder="little")
+    return np.ascontiguousarray(np.pad(p, ((0, 0), (0, wf * 8 - p.shape[1]))))
+
+
+def _subkeys(key, n):
+    """key, sub = split(key) once per batch (sampler.py:399)."""
+    subs = []
+    for _ in range(n):
+        key, sub = prng.split(key)
+        subs.append(sub)
+    return key, subs
+
+
+def _run_steps(hp, prog, fs, key, nf, *, packed, shot_offset=0, calls=None):
+    """fs through sample_steps_device (optionally split into several calls of the given sizes); returns the rows."""
+    B = len(fs[0])
+    wf, wo, rb = (nf + 63) // 64, (prog.num_outputs + 63) // 64, (prog.num_outputs + 7) // 8
+    d_f = [hp.malloc(B * wf * 8) for _ in fs]
+    d_o = [hp.malloc(max(B * wo * 8, 16)) for _ in fs]
+    for d, f in zip(d_f, fs):
+        hp.h2d(d, _packed(f, wf))
+    ks = (C.c_uint32 * 2)(key[0] & 0xFFFFFFFF, key[1] & 0xFFFFFFFF)
+    i = 0
+    for n in (calls or [len(fs)]):
+        hp.sample_steps_device([d.ptr for d in d_f[i:i + n]], B, nf, ks, [d.ptr for d in d_o[i:i + n]],
+                               shot_offset=shot_offset, out_bit_packed=packed)
+        i += n
+    assert i == len(fs)
+    hp.synchronize()
+    outs = []
+    for d in d_o:
+        if packed:
+            got = np.zeros((B, rb), np.uint8)
+            hp.d2h(got, d)
+        else:
+            raw = np.zeros((B, wo * 8), np.uint8)
+            hp.d2h(raw, d)
+            got = np.packbits(np.unpackbits(raw, axis=1, bitorder="little")[:, : prog.num_outputs], axis=1, bitorder="little")
+        outs.append(got)
+    for d in d_f + d_o:
+        d.free()
+    return outs, (int(ks[0]), int(ks[1]))
+
+
+@pytest.mark.parametrize("name,B,n", [("C2", 3000, 11), ("C3", 2500, 9), ("C4", 1500, 8), ("C2", 1, 3), ("C2", 70000, 20)])
+@pytest.mark.parametrize("packed", [True, False])
+def test_steps_equal_oracle_batch_by_batch(hip, name, B, n, packed):
+    prog, cfg = synth.config_program(name)
+    nf = cfg["num_f"]
+    hp = hip.HipProgram(prog)
+    key = prng.key(77)
+    # launch-plan feedback first (fused groups need "short hard-row lists" from earlier launches), on the same handle
+    warm = [synth.synth_f(B, nf, cfg["p_bit"], seed=500 + i) for i in range(3)]
+    _run_steps(hp, prog, warm, prng.key(1), nf, packed=packed)
+    fs = [synth.synth_f(B, nf, cfg["p_bit"] * (1 + (i % 3)), seed=10 + i) for i in range(n)]
+    outs, key_after = _run_steps(hp, prog, fs, key, nf, packed=packed)
+    end_key, subs = _subkeys(key, n)
+    assert key_after == (end_key[0] & 0xFFFFFFFF, end_key[1] & 0xFFFFFFFF)
+    op = OC.OracleProgram(prog)
+    check = range(n) if B <= 3000 else (0, n // 2, n - 1)
+    for i in check:
+        m = min(B, 4000)  # an oracle slice of the large batches; the rest is compared with the serial kernel path below
+        want = op.sample_program(fs[i][:m], subs[i])
+        np.testing.assert_array_equal(outs[i][:m], np.packbits(want, axis=1, bitorder="little"), err_msg=f"batch {i}")
+    if B > 3000:
+        for i in check:
+            want = hp.sample_batch(fs[i], subs[i])[0]
+            np.testing.assert_array_equal(outs[i], np.packbits(want, axis=1, bitorder="little"), err_msg=f"batch {i} vs the serial API")
+    hp.close()
+
+
+def test_steps_use_the_fused_first_pass_and_split_calls_agree(hip):
+    """The same 20 batches as one call, as calls of 7 + 1 + 12, and with the fused path switched off: identical rows;
+    the profile counter shows that the fused kernel really ran."""
+    import os
+
+    prog, cfg = synth.config_program("C2")
+    nf, B, n = cfg["num_f"], 20000, 20
+    fs = [synth.synth_f(B, nf, 0.02 + 0.01 * (i % 4), seed=300 + i) for i in range(n)]
+    key = prng.key(5)
+    runs = []
+    for calls, env in (([20], None), ([7, 1, 12], None), ([20], "0")):
+        if env is not None:
+            os.environ["TSIM_AMD_FUSED_STEPS"] = env
+        try:
+            prog2, _ = synth.config_program("C2")
+            hp = hip.HipProgram(prog2)
+        finally:
+            os.environ.pop("TSIM_AMD_FUSED_STEPS", None)
+        _run_steps(hp, prog2, fs[:3], prng.key(1), nf, packed=True)  # feedback
+        hp.profile_set_sampling(1)
+        hp.profile_enable(2)
+        hp.profile_read(reset=True)
+        hp.profile_read_steps()
+        outs, _ = _run_steps(hp, prog2, fs, key, nf, packed=True, calls=calls)
+        _, launches = hp.profile_read(reset=True)
+        steps = hp.profile_read_steps()
+        hp.profile_enable(False)
+        runs.append(outs)
+        if env is None:
+            assert steps == n and launches < n, (steps, launches)  # several batches per first-pass launch
+        else:
+            assert steps == 0 and launches == n
+        hp.close()
+    for other in runs[1:]:
+        for a, b in zip(runs[0], other):
+            np.testing.assert_array_equal(a, b)
+
+
+def test_steps_with_shot_offset_and_dense_rows(hip):
+    """A shard (shot_offset > 0: no normalisation-check row) and batches dense enough that the launch plan leaves the
+    fused path (many hard rows): still the oracle's bits."""
+    prog, cfg = synth.config_program("C2")
+    nf, B = cfg["num_f"], 6000
+    hp = hip.HipProgram(prog)
+    op = OC.OracleProgram(prog)
+    for p_bit, off in ((0.02, 123457), (0.25, 0), (0.02, 0)):
+        fs = [synth.synth_f(B, nf, p_bit, seed=40 + i) for i in range(10)]
+        key = prng.key(31)
+        outs, _ = _run_steps(hp, prog, fs, key, nf, packed=True, shot_offset=off)
+        _, subs = _subkeys(key, len(fs))
+        for i in (0, 4, 9):
+            want = op.sample_program(fs[i], subs[i], shot_offset=off)
+            np.testing.assert_array_equal(outs[i], np.packbits(want, axis=1, bitorder="little"), err_msg=f"p_bit {p_bit} batch {i}")
+    hp.close()

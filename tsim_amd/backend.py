@@ -372,6 +372,25 @@ class HipProgram:
         if rc < 0:
             _lib.check(rc, "tsim_sample_batch_device_begin")
 
+    def sample_steps_device(self, d_f, B: int, num_f: int, key_state, d_out, *, shot_offset: int = 0,
+                            inputs_ready: bool = False, out_bit_packed: bool = False) -> None:
+        """``len(d_f)`` consecutive batches in one call (the reference's batch loop, ``sampler.py:340-420``): for each,
+        ``key, subkey = split(key)`` and one ``sample_program``; ``key_state`` is a ``(c_uint32 * 2)`` advanced in
+        place.  ``d_f`` / ``d_out``: sequences of device addresses (or ``(c_void_p * n)`` arrays, reused as they are).
+        Results are complete after ``synchronize()``; see ``tsim_sample_steps_device`` in include/tsim_hip.h."""
+        n = len(d_f)
+        fa = d_f if isinstance(d_f, C.Array) else (C.c_void_p * n)(*[int(x) for x in d_f])
+        oa = d_out if isinstance(d_out, C.Array) else (C.c_void_p * n)(*[int(x) for x in d_out])
+        rc = self._lib.tsim_sample_steps_device(self._h, n, fa, int(B), int(num_f), key_state, int(shot_offset), oa, None,
+                                                (1 if inputs_ready else 0) | (2 if out_bit_packed else 0))
+        if rc < 0:
+            _lib.check(rc, "tsim_sample_steps_device")
+
+    def profile_read_steps(self, reset: bool = True) -> int:
+        n = C.c_int64(0)
+        _lib.check(self._lib.tsim_profile_read_steps(self._h, C.byref(n), 1 if reset else 0), "tsim_profile_read_steps")
+        return int(n.value)
+
     def sample_batch_device_end(self, slot: int, stream: int = 0) -> None:
         """Make ``stream`` (0: the handle's stream) wait for the slot's second pass."""
         _lib.check(self._lib.tsim_sample_batch_device_end(self._h, int(slot), stream or None), "tsim_sample_batch_device_end")

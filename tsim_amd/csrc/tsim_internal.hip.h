@@ -141,6 +141,7 @@ struct tsim_program {
   int v4w_occ_blocks = 1;     // blocks of the sparse-column kernel a CU holds at once with v4w_occ_lds bytes of LDS
   size_t v4w_occ_lds = 0;
   bool lw_reg = false;        // the register form of pass 1 applies (narrow f rows, ascending f_selection)
+  int lwf_off = 0;            // image offset of the fast record (one component of <= 8 outputs: k_sample_lw_fast), 0 = none
   // Launch slots: slot 0 serves the serial API (everything on the caller's stream); slots 1..4 serve
   // tsim_sample_batch_device_begin/_end: a slot's launches run on the slot's own stream (`side`) so
   // that it overlaps the first pass of the following launches.
@@ -185,7 +186,9 @@ struct tsim_program {
   unsigned long long joined_seq = 0;     // ... and that batch: it is behind every batch up to this one
   int lane_reach[2] = {0, 0};  // batches between a lane's last start-of-batch wait and the batch it waited for (pre-wait)
   unsigned long long lane_waited[2][2] = {{0, 0}, {0, 0}};  // [first-pass lane][batch lane]: newest batch already waited for
-  unsigned long long stat_queries = 0, stat_waits = 0, stat_begins = 0, stat_flushes = 0, stat_deferred = 0;
+  unsigned long long stat_queries = 0, stat_waits = 0, stat_begins = 0, stat_flushes = 0, stat_deferred = 0, stat_fused = 0, stat_fast = 0;
+  unsigned long long steps_slot = 0;    // tsim_sample_steps_device: next pipeline slot of its rotation ...
+  unsigned long long steps_groups = 0;  // ... and the fused groups launched so far (first-pass lanes alternate)
   int last_lists = 0;         // list count of the most recent two-pass launch (what the feedback refers to)
   int h_group_tiles = 0;      // k_sample4h geometry, fixed at the first two-pass launch
   size_t h_lds = 0;
@@ -214,6 +217,9 @@ struct tsim_program {
     bool prewait = true;      // TSIM_AMD_PREWAIT=0: no mid-batch pre-wait of the first-pass lanes (tsim_sample_batch_device_begin)
     int batch_lanes = 1;      // TSIM_AMD_BATCH_LANES=2: hard-row batches alternate over two streams (no measured gain: both land on one hardware queue)
     int defer_group = 4;      // TSIM_AMD_DEFER_GROUP: launches per deferred hard-row batch (<= TSIMK_H_MAX_CTX)
+    bool fused_steps = true;  // TSIM_AMD_FUSED_STEPS=0: tsim_sample_steps_device launches batch by batch
+    bool lw_fast = true;      // TSIM_AMD_LW_FAST=0: the generic fused pass (k_sample_lw_multi) also for one-component programs
+    int fused_max = 8;        // TSIM_AMD_FUSED_MAX: batches per fused first pass (<= TSIMK_LWM_MAX_STEPS = TSIMK_H_MAX_CTX)
   } knobs;
   bool h_attr_set = false;    // k_sample4h: large dynamic LDS enabled
   bool hm_attr_set = false;   // k_sample4h_multi: the same
@@ -227,7 +233,7 @@ struct tsim_program {
   long long lw_budget = 0;    // bytes per component
   int lw_dense_launches = 0;  // consecutive launches whose hard-row share says "deeper tables would pay"
   long long lw_bytes = 0;
-  float *d_lw_tab = nullptr;
+  uint32_t *d_lw_tab = nullptr;  // integer Bernoulli thresholds (tsimk::bernoulli_threshold)
   // device allocations handed out by tsim_malloc_device and not yet freed: the handle owns them
   std::unordered_set<void *> owned;
   // scratch (host-buffer API)
@@ -244,6 +250,7 @@ struct tsim_program {
   size_t ev_used = 0;
   double prof_ms = 0.0;
   long long prof_launches = 0;
+  long long prof_steps = 0;   // batches covered by the bracketed fused first passes (tsim_profile_read_steps)
 };
 
 // ---- tsim_program.hip
@@ -266,7 +273,7 @@ std::vector<uint32_t> emit_rotmask_program(const std::vector<std::array<int, 3>>
 
 // ---- tsim_tables.hip
 bool tsim_tables_plan(tsim_program *p, int cap, long long budget);
-int tsim_tables_build(tsim_program *p, float **old);
+int tsim_tables_build(tsim_program *p, uint32_t **old);
 int tsim_tables_extend(tsim_program *p);
 
 // ---- tsim_sample.hip

@@ -267,13 +267,52 @@ __host__ __device__ __forceinline__ void threefry2x32(uint32_t k0, uint32_t k1, 
 #undef TF_R
 }
 
+// The 32 random bits jax.random.bits(key, (B,))[s] = x0 ^ x1 of threefry2x32(key, (s >> 32, s)) - the block of every
+// Bernoulli draw (sampler.py:74-75).  Same function as threefry2x32 above; the instructions are selected by hand,
+// because this block is most of what the first pass issues (measured per instruction class in
+// profiles/r03/valu_table.txt):
+//   * full rate (2 cycles per wave64 instruction and SIMD): v_add_u32 / v_xor_b32 on vector registers;
+//     half rate: v_alignbit_b32 (like every other way to rotate or shift left), v_add3_u32, any SGPR operand;
+//   * a round is v_add_u32, v_alignbit_b32, v_xor_b32 - written as asm so that the compiler cannot reassociate
+//     the additions of a block (it turned the 32 adds of a block into 40-60 when it could see them);
+//   * a key injection `x0 += ka; x1 += kb + i` and the add of the following round are two instructions instead of
+//     three: x1 += (kb + i) with the sum formed on the scalar unit, then x0 = x0 + x1 + ka as one v_add3_u32.
+// The asm is not volatile: the compiler may still interleave the blocks of different draws.
+__device__ __forceinline__ uint32_t threefry_bits32(uint32_t k0, uint32_t k1, unsigned long long s) {
+  const uint32_t k2 = k0 ^ k1 ^ 0x1BD11BDAu;
+  const uint32_t j1 = k2 + 1u, j2 = k0 + 2u, j3 = k1 + 3u, j4 = k2 + 4u, j5 = k0 + 5u;
+  const uint32_t hi = (uint32_t)(s >> 32), lo = (uint32_t)s;
+  uint32_t x0, x1;
+#define TF_RN(r) "v_alignbit_b32 %1, %1, %1, " #r "\n v_xor_b32 %1, %1, %0\n"  /* rotate left by 32 - r, xor */
+#define TF_RA(r) "v_add_u32 %0, %0, %1\n" TF_RN(r)
+  asm("v_add_u32 %1, %5, %2\n v_add3_u32 %0, %3, %1, %4\n"  // x1 = lo + k1; x0 = hi + k0, then round 1's add
+      TF_RN(19) TF_RA(17) TF_RA(6) TF_RA(26)
+      "v_add_u32 %1, %7, %1\n v_add3_u32 %0, %0, %1, %5\n" TF_RN(15) TF_RA(3) TF_RA(16) TF_RA(8)
+      "v_add_u32 %1, %8, %1\n v_add3_u32 %0, %0, %1, %6\n" TF_RN(19) TF_RA(17) TF_RA(6) TF_RA(26)
+      "v_add_u32 %1, %9, %1\n v_add3_u32 %0, %0, %1, %4\n" TF_RN(15) TF_RA(3) TF_RA(16) TF_RA(8)
+      "v_add_u32 %1, %10, %1\n v_add3_u32 %0, %0, %1, %5\n" TF_RN(19) TF_RA(17) TF_RA(6) TF_RA(26)
+      "v_add_u32 %0, %6, %0\n v_add_u32 %1, %11, %1\n v_xor_b32 %0, %0, %1\n"
+      : "=&v"(x0), "=&v"(x1)
+      : "v"(lo), "v"(hi), "s"(k0), "s"(k1), "s"(k2), "s"(j1), "s"(j2), "s"(j3), "s"(j4), "s"(j5));
+#undef TF_RA
+#undef TF_RN
+  return x0;
+}
+
 // jax.random.uniform(key, (B,), float32)[s]
 __device__ __forceinline__ float uniform01(uint32_t k0, uint32_t k1, unsigned long long s) {
-  uint32_t x0 = (uint32_t)(s >> 32), x1 = (uint32_t)s;
-  threefry2x32(k0, k1, x0, x1);
-  uint32_t bits = x0 ^ x1;
-  float f = __uint_as_float((bits >> 9) | 0x3F800000u) - 1.0f;
-  return fmaxf(0.0f, f);
+  const uint32_t bits = threefry_bits32(k0, k1, s);
+  return __uint_as_float((bits >> 9) | 0x3F800000u) - 1.0f;  // in [0, 1): no clamp needed
+}
+
+// Bernoulli thresholds as integers.  u = (bits >> 9) / 2^23 exactly, so for a float threshold t
+//   u < t  <=>  (bits >> 9) < T(t),  T = 0 for t <= 0 or NaN, 2^23 for t >= 1, ceil(t * 2^23) otherwise
+// (t * 2^23 is exact, its ceiling too): the same bit for every draw, one shift and one compare instead of the
+// conversion to float.  The pattern tables of the first pass hold T.
+__device__ __forceinline__ uint32_t bernoulli_threshold(float t) {
+  if (!(t > 0.0f)) return 0u;
+  if (t >= 1.0f) return 1u << 23;
+  return (uint32_t)ceilf(t * 8388608.0f);
 }
 
 // ---------------------------------------------------------------------------

@@ -84,7 +84,7 @@ __host__ __device__ __forceinline__ uint32_t lw_rank_term(int i, uint32_t b) {
 struct LwBuildArgs {
   const uint32_t *img;
   const unsigned long long *patbits;  // [npat] f_sel bit patterns in table order
-  float *tab;                         // this component's table: [npat << n_out]
+  uint32_t *tab;                      // this component's table: [npat << n_out] integer thresholds (bernoulli_threshold)
   int comp_off;                       // row-layout component record (C_*)
   int npat;
   // wide components: patbits == nullptr, the lane unranks its pattern (weight class from `bases`, then the set
@@ -133,8 +133,8 @@ __global__ void __launch_bounds__(256) k_lw_build(LwBuildArgs A) {
   float re, im;
   eval_any<W, FAST>(A.img, img, levels, x, re, im, nullptr);  // sampler.py:54
   float prev = cabs32(re, im);
-  float *row = A.tab + ((size_t)pat << n_out);
-  if (m == 0u) row[0] = 0.0f;  // node 0 is unused
+  uint32_t *row = A.tab + ((size_t)pat << n_out);
+  if (m == 0u) row[0] = 0u;  // node 0 is unused
   uint32_t node = 1u;
   for (uint32_t i = 0; i < n_out; ++i) {
     cptr lvl = levels + (i + 1) * L_WORDS;
@@ -145,7 +145,7 @@ __global__ void __launch_bounds__(256) k_lw_build(LwBuildArgs A) {
       if ((uint32_t)w == wi) x[w] |= bm;
     eval_any<W, FAST>(A.img, img, lvl, x, re, im, nullptr);  // sampler.py:65
     const float p1 = cabs32(re, im);
-    row[node] = __fdiv_rn(p1, prev);                          // sampler.py:75
+    row[node] = bernoulli_threshold(__fdiv_rn(p1, prev));     // sampler.py:75: bit = u < p1 / prev
     const bool bit = ((m >> (n_out - 1u - i)) & 1u) != 0u;    // prefix bits, first output first
 #pragma unroll
     for (int w = 0; w < W; ++w)
@@ -157,7 +157,7 @@ __global__ void __launch_bounds__(256) k_lw_build(LwBuildArgs A) {
 
 struct LwArgs {
   SampleArgs s;           // row_index/row_count: optional INPUT list (device-side post-selection)
-  const float *tab;       // thresholds, all components
+  const uint32_t *tab;    // integer thresholds (bernoulli_threshold), all components
   int lw_off;             // image offset of the LW component records
   int direct_prog;        // image offset of the direct-output gather program (64-byte aligned)
   int direct_chunks;

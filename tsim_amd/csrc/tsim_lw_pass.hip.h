@@ -4,6 +4,28 @@
 
 namespace tsimk {
 
+// Optional timeline of the register first pass (build with -DTSIMK_LW_TRACE, scripts/lw_trace.py): wave 0 of the first
+// blocks stamps s_memtime at the phase boundaries of its first two rows.  Compiled out by default.
+#ifdef TSIMK_LW_TRACE
+__device__ unsigned long long tsimk_lw_trace[16 * 32];
+#define LW_STAMP(k)                                                                                           \
+  do {                                                                                                        \
+    if (threadIdx.x == 0 && blockIdx.x < 16 && tr_it < 2) {                                                   \
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                             \
+      tsimk_lw_trace[blockIdx.x * 32 + tr_it * 12 + (k)] = __builtin_readcyclecounter();                      \
+    }                                                                                                         \
+  } while (0)
+#define LW_STAMP_ABS(slot)                                                                                    \
+  do {                                                                                                        \
+    if (threadIdx.x == 0 && blockIdx.x < 16) {                                                                \
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                             \
+      tsimk_lw_trace[blockIdx.x * 32 + (slot)] = __builtin_readcyclecounter();                                \
+    }                                                                                                         \
+  } while (0)
+#else
+#define LW_STAMP(k) do { } while (0)
+#define LW_STAMP_ABS(slot) do { } while (0)
+#endif
 
 // ---------------------------------------------------------------------------
 // The threshold walk of one component: for output i, bit_i = u_i < thr[node], node <- 2 node + bit_i
@@ -14,41 +36,78 @@ namespace tsimk {
 // the three Threefry blocks run while they are in flight, and the bits are picked with selects - one latency
 // per three outputs, the same comparisons on the same floats.
 // ---------------------------------------------------------------------------
-template <class Emit>
-__device__ __forceinline__ void lw_walk(const SampleArgs &A, const float *thr, uint32_t n_out, uint32_t keybase,
-                                        unsigned long long shot, Emit emit) {
-  typedef float f32x2 __attribute__((ext_vector_type(2)));
-  typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <class Key, class Emit>
+__device__ __forceinline__ void lw_walk_impl(Key key, const uint32_t *thr, uint32_t n_out, uint32_t keybase,
+                                             unsigned long long shot, Emit emit, int tr_it) {
+  (void)tr_it;
+  typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  // the draw of output o as the 23 bits the reference turns into its uniform (bit = m < T, see bernoulli_threshold)
+#if defined(TSIMK_LWM_SKIP) && (TSIMK_LWM_SKIP & 1)
+  auto draw = [&](uint32_t o) { return ((uint32_t)shot * 0x9E3779B9u + key(o, 0u)) >> 9; };  // diagnostic: no Threefry
+#else
+  auto draw = [&](uint32_t o) { return threefry_bits32(key(o, 0u), key(o, 1u), shot) >> 9; };
+#endif
   uint32_t node = 1u, i = 0u;
+#if defined(TSIMK_LWM_SKIP) && (TSIMK_LWM_SKIP & 32)
+  {  // diagnostic: thresholds without memory
+    const uint32_t base = (uint32_t)(uintptr_t)thr;
+    for (; i < n_out; ++i) {
+      const bool b = draw(keybase + i) < ((base * 2654435761u + node * 40503u) & 0x7FFFFFu);
+      node = 2u * node + (b ? 1u : 0u);
+      emit(i, b);
+    }
+    return;
+  }
+#endif
   for (; i + 3u <= n_out; i += 3u) {
-    const float t0 = thr[node];
-    const f32x2 t1 = *reinterpret_cast<const f32x2 *>(thr + 2u * node);
-    const f32x4 t2 = *reinterpret_cast<const f32x4 *>(thr + 4u * node);
-    const float u0 = uniform01(subkey(A, keybase + i, 0), subkey(A, keybase + i, 1), shot);
-    const float u1 = uniform01(subkey(A, keybase + i + 1u, 0), subkey(A, keybase + i + 1u, 1), shot);
-    const float u2 = uniform01(subkey(A, keybase + i + 2u, 0), subkey(A, keybase + i + 2u, 1), shot);
-    const bool b0 = u0 < t0;
-    const bool b1 = u1 < (b0 ? t1.y : t1.x);
-    const float lo = b1 ? t2.y : t2.x, hi = b1 ? t2.w : t2.z;
-    const bool b2 = u2 < (b0 ? hi : lo);
+    const uint32_t t0 = thr[node];
+    const u32x2 t1 = *reinterpret_cast<const u32x2 *>(thr + 2u * node);
+    const u32x4 t2 = *reinterpret_cast<const u32x4 *>(thr + 4u * node);
+    const uint32_t m0 = draw(keybase + i), m1 = draw(keybase + i + 1u), m2 = draw(keybase + i + 2u);
+#ifdef TSIMK_LW_TRACE
+    if (threadIdx.x == 0 && blockIdx.x < 16 && tr_it < 2) {  // draws done, loads possibly still in flight
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      asm volatile("" :: "v"(m0), "v"(m1), "v"(m2));
+      tsimk_lw_trace[blockIdx.x * 32 + tr_it * 12 + 5] = __builtin_readcyclecounter();
+    }
+#endif
+    const bool b0 = m0 < t0;
+    const bool b1 = m1 < (b0 ? t1.y : t1.x);
+    const uint32_t lo = b1 ? t2.y : t2.x, hi = b1 ? t2.w : t2.z;
+    const bool b2 = m2 < (b0 ? hi : lo);
     node = 8u * node + (b0 ? 4u : 0u) + (b1 ? 2u : 0u) + (b2 ? 1u : 0u);
     emit(i, b0);
     emit(i + 1u, b1);
     emit(i + 2u, b2);
+    LW_STAMP(6);
   }
   if (n_out - i == 2u) {
-    const float t0 = thr[node];
-    const f32x2 t1 = *reinterpret_cast<const f32x2 *>(thr + 2u * node);
-    const float u0 = uniform01(subkey(A, keybase + i, 0), subkey(A, keybase + i, 1), shot);
-    const float u1 = uniform01(subkey(A, keybase + i + 1u, 0), subkey(A, keybase + i + 1u, 1), shot);
-    const bool b0 = u0 < t0;
-    const bool b1 = u1 < (b0 ? t1.y : t1.x);
+    const uint32_t t0 = thr[node];
+    const u32x2 t1 = *reinterpret_cast<const u32x2 *>(thr + 2u * node);
+    const uint32_t m0 = draw(keybase + i), m1 = draw(keybase + i + 1u);
+    const bool b0 = m0 < t0;
+    const bool b1 = m1 < (b0 ? t1.y : t1.x);
     emit(i, b0);
     emit(i + 1u, b1);
+    LW_STAMP(7);
   } else if (n_out - i == 1u) {
-    const float u0 = uniform01(subkey(A, keybase + i, 0), subkey(A, keybase + i, 1), shot);
-    emit(i, u0 < thr[node]);
+    const uint32_t m0 = draw(keybase + i);
+    emit(i, m0 < thr[node]);
   }
+}
+
+// subkeys from the launch's SampleArgs (inline in the kernel arguments or the k_keygen buffer) ...
+template <class Emit>
+__device__ __forceinline__ void lw_walk(const SampleArgs &A, const uint32_t *thr, uint32_t n_out, uint32_t keybase,
+                                        unsigned long long shot, Emit emit, int tr_it = 0) {
+  lw_walk_impl([&](uint32_t o, uint32_t j) { return subkey(A, o, j); }, thr, n_out, keybase, shot, emit, tr_it);
+}
+// ... or from a wave-uniform key array [output][2] (the fused multi-batch pass: one array per batch)
+template <class Emit>
+__device__ __forceinline__ void lw_walk_keys(cptr kp, const uint32_t *thr, uint32_t n_out, uint32_t keybase,
+                                             unsigned long long shot, Emit emit) {
+  lw_walk_impl([&](uint32_t o, uint32_t j) { return kp[2u * o + j]; }, thr, n_out, keybase, shot, emit, 0);
 }
 
 // the lane's set bits of one masked f word: each adds C(position inside f_sel, ordinal + 1) to the colex rank
@@ -160,7 +219,7 @@ __global__ void __launch_bounds__(1024) k_sample_lw(LwArgs L) {
       const uint32_t n_out = rec[LW_NOUT];
       cptr outpos = img + rec[LW_OUTPOS];
       const uint32_t keybase = rec[LW_KEYBASE];
-      const float *thr = L.tab + rec[LW_TAB] + ((size_t)pat << n_out);
+      const uint32_t *thr = L.tab + rec[LW_TAB] + ((size_t)pat << n_out);
       lw_walk(A, thr, n_out, keybase, shot, [&](uint32_t i, bool bit) {
         const uint32_t dst = outpos[i];
         const uint32_t v = (bit ? 1u : 0u) << (dst & 31u);
@@ -236,10 +295,14 @@ __device__ __forceinline__ void lw_direct_reg(cptr prog, uint32_t f0, uint32_t f
   o1 ^= prog[17];
 }
 
+#ifndef TSIMK_LW_SGPRS
+#define TSIMK_LW_SGPRS 80
+#endif
 template <int WF32>
-__global__ void __launch_bounds__(1024) k_sample_lw_reg(LwArgs L) {
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(TSIMK_LW_SGPRS))) k_sample_lw_reg(LwArgs L) {
   const SampleArgs &A = L.s;
   const int nthr = blockDim.x;
+  LW_STAMP_ABS(24);
   long long n_rows = A.B;
   if (A.row_index) n_rows = (long long)*A.row_count;
   cptr img = (cptr)(uintptr_t)A.img;
@@ -258,11 +321,15 @@ __global__ void __launch_bounds__(1024) k_sample_lw_reg(LwArgs L) {
     __builtin_amdgcn_wave_barrier();
   }
   const uint32_t *binom_lds = reinterpret_cast<const uint32_t *>(binom_lds4);
+  int tr_it = 0;
+  (void)tr_it;
+  LW_STAMP_ABS(25);
   // Grid-stride over the rows: the launch puts as many blocks on the chip as fit AT ONCE (tsim_sample.hip) and every
   // wave takes several rows per lane in turn - one round of waves instead of several, each with its ramp and
   // tail, and the per-wave preamble (kernel arguments, binomial table) paid once.  The trip count is uniform
   // over a block, so the wave-wide append at the end of the body is executed by every lane.
-  for (long long base = (long long)blockIdx.x * nthr; base < n_rows; base += (long long)gridDim.x * nthr) {
+  for (long long base = (long long)blockIdx.x * nthr; base < n_rows; base += (long long)gridDim.x * nthr, ++tr_it) {
+  LW_STAMP(0);
   const long long slot = base + threadIdx.x;
   const bool active = slot < n_rows;
   long long row = slot;
@@ -284,8 +351,13 @@ __global__ void __launch_bounds__(1024) k_sample_lw_reg(LwArgs L) {
     }
     hard = L.has_check && slot == 0;
     if (hard) L.ctl[32 * TSIMK_LW_LISTS] = (uint32_t)row;
+    LW_STAMP(1);
     uint32_t o0 = 0, o1 = 0;
     lw_direct_reg<WF32>(img + L.direct_rot, f0, f1, f2, f3, o0, o1);  // K14, sampler.py:140-145
+#ifdef TSIMK_LW_TRACE
+    asm volatile("" :: "v"(o0), "v"(o1));
+#endif
+    LW_STAMP(2);
 
     for (int ci = 0; ci < A.n_comp; ++ci) {
       cptr rec = img + L.lw_off + ci * LW_WORDS;
@@ -322,13 +394,17 @@ __global__ void __launch_bounds__(1024) k_sample_lw_reg(LwArgs L) {
       const uint32_t n_out = rec[LW_NOUT];
       cptr outpos = img + rec[LW_OUTPOS];
       const uint32_t keybase = rec[LW_KEYBASE];
-      const float *thr = L.tab + rec[LW_TAB] + ((size_t)pat << n_out);
+      const uint32_t *thr = L.tab + rec[LW_TAB] + ((size_t)pat << n_out);
+#ifdef TSIMK_LW_TRACE
+      asm volatile("" :: "v"(pat));
+#endif
+      LW_STAMP(3);
       lw_walk(A, thr, n_out, keybase, shot, [&](uint32_t i, bool bit) {
         const uint32_t dst = outpos[i];
         const uint32_t v = (bit ? 1u : 0u) << (dst & 31u);
         if ((dst >> 5) == 0u) o0 |= v;
         else o1 |= v;
-      });
+      }, tr_it);
     }
     if (!hard) {
       if (A.out) A.out[row] = (uint64_t)o0 | ((uint64_t)o1 << 32);  // WO == 1
@@ -338,6 +414,7 @@ __global__ void __launch_bounds__(1024) k_sample_lw_reg(LwArgs L) {
       }
     }
   }
+  LW_STAMP(8);
 
   // wave-aggregated append of the hard rows
   const unsigned long long hm = __ballot(hard ? 1 : 0);
@@ -351,7 +428,9 @@ __global__ void __launch_bounds__(1024) k_sample_lw_reg(LwArgs L) {
     if (hard)
       L.hard_index[(size_t)k * L.list_cap + basei + (uint32_t)__popcll(hm & ((1ull << lane) - 1ull))] = (uint32_t)row;
   }
+  LW_STAMP(9);
   }  // rows of this block
+  LW_STAMP_ABS(26);
 }
 
 }  // namespace tsimk

@@ -1,6 +1,7 @@
 // tsim_program.hip - handle life cycle of the C ABI (include/tsim_hip.h): program description ->
 // packed image -> upload, plus the memory / stream plumbing.  No kernels are defined here.
 #include "tsim_internal.hip.h"
+#include "tsim_lw_fast.hip.h"
 #include "tsim_kernel4w.hip.h"  // C4_SELMASK
 
 using namespace tsimk;
@@ -536,6 +537,79 @@ retry_pack:
             r[LW_SELMASK] = (uint32_t)(p->lw_off + ci * LW_WORDS + LW_SEL_INLINE);
             memcpy(r + LW_SEL_INLINE, sel, sizeof sel);
           }
+        // The fast record (k_sample_lw_fast, tsim_lw_fast.hip.h): ONE component of at most 8 outputs.  Direct outputs
+        // as a flat list of runs (rotate right, destination masks), the rank table RANK[ordinal][f-row bit position] =
+        // C(position inside f_sel, ordinal + 1) and the placement table LUT[leaf] = the n_out sampled bits at their
+        // final columns (leaf = the bits in sampling order, first output most significant).
+        p->lwf_off = 0;
+        if (p->lw_reg && p->comps.size() == 1 && p->comps[0].n_out >= 1 && p->comps[0].n_out <= TSIMK_LWF_MAX_NOUT) {
+          const HostComponent &c = p->comps[0];
+          std::vector<uint32_t> runs;
+          uint32_t flip[2] = {0u, 0u};
+          for (int s = 0; s < 4; ++s)
+            for (int d = 0; d < 2; ++d) {
+              std::vector<std::array<int, 2>> m;  // (src bit, dst bit) inside the words
+              for (int j = 0; j < p->n_direct; ++j) {
+                const int src = p->direct_f[j], dst = p->output_order[j];
+                if ((src >> 5) != s || (dst >> 5) != d) continue;
+                m.push_back({src & 31, dst & 31});
+                if (p->direct_flips[j]) flip[d] |= 1u << (dst & 31);
+              }
+              std::sort(m.begin(), m.end());
+              for (size_t i = 0; i < m.size();) {
+                size_t j = i + 1;
+                while (j < m.size() && m[j][0] == m[j - 1][0] + 1 && m[j][1] == m[j - 1][1] + 1) ++j;
+                const int len = (int)(j - i);
+                const uint32_t field = (len >= 32 ? 0xFFFFFFFFu : ((1u << len) - 1u)) << m[i][1];
+                runs.push_back((uint32_t)((m[i][0] - m[i][1]) & 31) | ((uint32_t)s << 8));
+                runs.push_back(d == 0 ? field : 0u);
+                runs.push_back(d == 1 ? field : 0u);
+                runs.push_back(0u);
+                i = j;
+              }
+            }
+          if (runs.size() / 4 <= TSIMK_LWF_MAX_RUNS) {
+            while (img.size() % 16) img.push_back(0u);
+            p->lwf_off = (int)img.size();
+            img.resize(img.size() + LWF_WORDS, 0u);
+            const uint32_t runs_off = (uint32_t)img.size();
+            img.insert(img.end(), runs.begin(), runs.end());
+            while (img.size() % 16) img.push_back(0u);
+            const uint32_t rank_off = (uint32_t)img.size();
+            std::vector<int> pos_in(128, -1);
+            for (int j = 0; j < c.F; ++j) pos_in[c.f_selection[j]] = j;
+            for (int k = 0; k < 8; ++k)
+              for (int q = 0; q < 128; ++q) {
+                const int b = pos_in[q];
+                unsigned long long v = 0;
+                if (b >= k + 1) {
+                  v = 1;
+                  for (int i = 1; i <= k + 1; ++i) v = v * (unsigned long long)(b - (k + 1) + i) / (unsigned long long)i;
+                }
+                img.push_back((uint32_t)v);
+              }
+            const uint32_t lut_off = (uint32_t)img.size();
+            const uint32_t outpos_off = img[p->lw_off + LW_OUTPOS];
+            for (uint32_t leaf = 0; leaf < (1u << c.n_out); ++leaf) {
+              uint32_t w[2] = {0u, 0u};
+              for (int i = 0; i < c.n_out; ++i)
+                if ((leaf >> (c.n_out - 1 - i)) & 1u) {
+                  const uint32_t dst = img[outpos_off + i];
+                  w[dst >> 5] |= 1u << (dst & 31u);
+                }
+              img.push_back(w[0]);
+              img.push_back(w[1]);
+            }
+            uint32_t *h = &img[p->lwf_off];
+            h[LWF_NRUNS] = (uint32_t)(runs.size() / 4);
+            h[LWF_FLIP0] = flip[0];
+            h[LWF_FLIP1] = flip[1];
+            h[LWF_RUNS] = runs_off;
+            h[LWF_RANK] = rank_off;
+            h[LWF_LUT] = lut_off;
+            h[LWF_NOUT] = (uint32_t)c.n_out;
+          }
+        }
       } else {
         p->lw_wmax.clear();
       }
@@ -572,6 +646,9 @@ retry_pack:
     // 35-50 us; C4: 10.8 MB, 450 us): 4 launches for small programs, 8 (the kernel's limit) beyond 4 MB.
     p->knobs.defer_group = p->stats[5] > (4ll << 20) ? TSIMK_H_MAX_CTX : 4;
     p->knobs.defer_group = std::max(1, std::min(TSIMK_H_MAX_CTX, env_int("TSIM_AMD_DEFER_GROUP", p->knobs.defer_group)));
+    p->knobs.fused_steps = env_int("TSIM_AMD_FUSED_STEPS", 1) != 0;
+    p->knobs.lw_fast = env_int("TSIM_AMD_LW_FAST", 1) != 0;
+    p->knobs.fused_max = std::max(1, std::min(TSIMK_H_MAX_CTX, env_int("TSIM_AMD_FUSED_MAX", TSIMK_H_MAX_CTX)));
   }
 
   // ---- upload ----

@@ -5,6 +5,8 @@
 #include "tsim_kernel4h.hip.h"
 #include "tsim_filter.hip.h"
 #include "tsim_lw_pass.hip.h"
+#include "tsim_lw_multi.hip.h"
+#include "tsim_lw_fast.hip.h"
 #include "tsim_kernel4w.hip.h"
 
 using namespace tsimk;
@@ -245,29 +247,12 @@ int tsim_flush_hard(tsim_program *p) {
   return 0;
 }
 
-static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_t num_f, uint32_t key_hi,
-                         uint32_t key_lo, int64_t shot_offset, uint64_t *d_out, float *d_dev, hipStream_t s,
-                         const uint32_t *d_row_index = nullptr, const uint32_t *d_row_count = nullptr,
-                         int slot = 0, const LaunchPlan *plan_in = nullptr, bool out_bit_packed = false) {
-  if (!p->sampleable) return tsim_fail(TSIM_ESTATE, "program has joint-mode components (evaluate-only)");
-  if (B < 0 || num_f < 0 || shot_offset < 0) return tsim_fail(TSIM_EINVAL, "negative B/num_f/shot_offset");
-  if (p->max_f_index >= num_f)
-    return tsim_fail(TSIM_EINVAL, "program references f index %d but num_f=%d", p->max_f_index, num_f);
-  if (B == 0 || p->num_outputs == 0) return 0;
-  if (!d_f && num_f > 0) return tsim_fail(TSIM_EINVAL, "f buffer is NULL");
-  if (!d_out) return tsim_fail(TSIM_EINVAL, "out buffer is NULL");
-  // per-output subkeys: key, subkey = split(key) once per output, threaded through the
-  // components in processing order (sampler.py:74,147-148)
-  tsim_program::Slot &sl = p->slots[slot];
-  {
-    size_t hard_bytes = 0;
-    if (p->lw || p->v4w) {
-      const long long g1 = (B + 255) / 256;  // the pattern pass uses 256-thread blocks unless overridden
-      hard_bytes = (size_t)((g1 + TSIMK_LW_LISTS - 1) / TSIMK_LW_LISTS * 1024) * TSIMK_LW_LISTS * 4;
-    }
-    if (int r = slot_prepare(p, slot, hard_bytes)) return r;
-  }
-  SampleArgs a{};
+// The arguments every sampling kernel of one launch shares (SampleArgs): per-output subkeys - key, subkey =
+// split(key) once per output, threaded through the components in processing order (sampler.py:74,147-148) - inline
+// for programs with at most TSIMK_INLINE_KEYS compiled outputs, else by k_keygen on `s`; buffers; output layout.
+static int fill_sample_args(tsim_program *p, tsim_program::Slot &sl, SampleArgs &a, const uint64_t *d_f, int64_t B, int32_t num_f,
+                            uint32_t key_hi, uint32_t key_lo, int64_t shot_offset, uint64_t *d_out, float *d_dev, hipStream_t s,
+                            int slot, bool out_bit_packed) {
   if (p->total_keys > 0 && p->total_keys <= TSIMK_INLINE_KEYS) {
     uint32_t k0 = key_hi, k1 = key_lo;
     for (int i = 0; i < p->total_keys; ++i) {
@@ -299,8 +284,8 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
   a.direct_chunks = p->knobs.direct_runs ? p->lw_direct_chunks : 0;
   a.n_comp = (int)p->comps.size();
   a.comp_off = p->comp_off;
-  a.row_index = d_row_index;
-  a.row_count = d_row_index ? d_row_count : nullptr;
+  a.row_index = nullptr;  // (launch_sample sets an input row list)
+  a.row_count = nullptr;
   a.row_lists = 0;
   a.row_list_cap = 0;
   a.row_slot_begin = 0;
@@ -322,6 +307,35 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
   a.check_row = nullptr;
   a.no_check = 0;
   if (num_f == 0) a.WF = 0;
+  return 0;
+}
+
+static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_t num_f, uint32_t key_hi,
+                         uint32_t key_lo, int64_t shot_offset, uint64_t *d_out, float *d_dev, hipStream_t s,
+                         const uint32_t *d_row_index = nullptr, const uint32_t *d_row_count = nullptr,
+                         int slot = 0, const LaunchPlan *plan_in = nullptr, bool out_bit_packed = false) {
+  if (!p->sampleable) return tsim_fail(TSIM_ESTATE, "program has joint-mode components (evaluate-only)");
+  if (B < 0 || num_f < 0 || shot_offset < 0) return tsim_fail(TSIM_EINVAL, "negative B/num_f/shot_offset");
+  if (p->max_f_index >= num_f)
+    return tsim_fail(TSIM_EINVAL, "program references f index %d but num_f=%d", p->max_f_index, num_f);
+  if (B == 0 || p->num_outputs == 0) return 0;
+  if (!d_f && num_f > 0) return tsim_fail(TSIM_EINVAL, "f buffer is NULL");
+  if (!d_out) return tsim_fail(TSIM_EINVAL, "out buffer is NULL");
+  // per-output subkeys: key, subkey = split(key) once per output, threaded through the
+  // components in processing order (sampler.py:74,147-148)
+  tsim_program::Slot &sl = p->slots[slot];
+  {
+    size_t hard_bytes = 0;
+    if (p->lw || p->v4w) {
+      const long long g1 = (B + 255) / 256;  // the pattern pass uses 256-thread blocks unless overridden
+      hard_bytes = (size_t)((g1 + TSIMK_LW_LISTS - 1) / TSIMK_LW_LISTS * 1024) * TSIMK_LW_LISTS * 4;
+    }
+    if (int r = slot_prepare(p, slot, hard_bytes)) return r;
+  }
+  SampleArgs a{};
+  if (int r = fill_sample_args(p, sl, a, d_f, B, num_f, key_hi, key_lo, shot_offset, d_out, d_dev, s, slot, out_bit_packed)) return r;
+  a.row_index = d_row_index;
+  a.row_count = d_row_index ? d_row_count : nullptr;
   if (B > 0x7FFFFFFFll * 64) return tsim_fail(TSIM_ENOTSUP, "batch too large");
   const bool prof = p->profiling && (p->prof_counter++ % p->prof_every == 0);
   if (prof) { int r = prof_event(p, s, PROF_BEGIN); if (r) return r; }
@@ -569,6 +583,32 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
   if (prof && !(p->prof_light && use_tables)) { int r = prof_event(p, s, PROF_FULL); if (r) return r; }
   return finish();
 }
+// A slot's previous launch (its lists, counters and output rows are reused) may have finished on another stream than
+// `s`: order this launch after it.  Batches complete in order (one stream) and a lane is in order too: once a lane
+// waits for batch b it is behind every batch <= b.  The slots of a batch alternate over the two first-pass lanes, so
+// this is one stream wait per lane and batch - no event query (the host usually runs several batches ahead of the
+// GPU, the query would fail and cost as much as the wait).
+static int slot_order_after_previous(tsim_program *p, tsim_program::Slot &sl, hipStream_t s) {
+  if (!(sl.last_done && sl.last_done != s && sl.done_ev)) return 0;
+  bool done = false;
+  if (sl.batch_seq) {
+    const int lane = (s == p->slots[1].side) ? 0 : (s == p->slots[2].side) ? 1 : -1;
+    const int bl = p->knobs.batch_lanes > 1 ? (int)(sl.batch_seq & 1ull) : 0;  // the lane that batch ran on
+    if (sl.batch_seq <= p->batch_confirmed[bl] || (lane >= 0 && sl.batch_seq <= p->lane_waited[lane][bl])) done = true;
+    else if (lane >= 0) {
+      p->lane_waited[lane][bl] = sl.batch_seq;
+      // how far back the slots of this caller's rotation reach, in batches (for the pre-wait of _begin)
+      if (p->deferred.size() < 2 && p->batch_next > sl.batch_seq) p->lane_reach[lane] = (int)(p->batch_next - sl.batch_seq);
+    }
+  } else {
+    ++p->stat_queries;
+    done = hipEventQuery(sl.done_ev) == hipSuccess;
+    if (!done) (void)hipGetLastError();
+  }
+  if (!done) { ++p->stat_waits; HIP_TRY(hipStreamWaitEvent(s, sl.done_ev, 0)); }
+  return 0;
+}
+
 extern "C" int tsim_sample_batch_device_begin(tsim_program *p, int32_t slot, const uint64_t *d_f, int64_t B,
                                               int32_t num_f, uint32_t key_hi, uint32_t key_lo, int64_t shot_offset,
                                               uint64_t *d_out, float *d_max_norm_dev, void *stream, uint32_t flags) {
@@ -596,30 +636,7 @@ extern "C" int tsim_sample_batch_device_begin(tsim_program *p, int32_t slot, con
   const LaunchPlan plan = make_plan(p, false, true);
   hipStream_t s = plan.defer ? p->slots[1 + (slot & 1)].side : sl.side;
   if (!plan.defer) sl.used = true;
-  // the slot's previous launch (its lists, counters and output rows are reused) finished on another stream:
-  // this launch must be ordered after it
-  if (sl.last_done && sl.last_done != s && sl.done_ev) {
-    bool done = false;
-    if (sl.batch_seq) {
-      // Batches complete in order (one stream) and a lane is in order too: once a lane waits for batch b it
-      // is behind every batch <= b.  The four slots of a batch alternate over the two lanes, so this is
-      // one stream wait per lane and batch - no event query (the host usually runs several batches ahead
-      // of the GPU, the query would fail and cost as much as the wait).
-      const int lane = (s == p->slots[1].side) ? 0 : (s == p->slots[2].side) ? 1 : -1;
-      const int bl = p->knobs.batch_lanes > 1 ? (int)(sl.batch_seq & 1ull) : 0;  // the lane that batch ran on
-      if (sl.batch_seq <= p->batch_confirmed[bl] || (lane >= 0 && sl.batch_seq <= p->lane_waited[lane][bl])) done = true;
-      else if (lane >= 0) {
-        p->lane_waited[lane][bl] = sl.batch_seq;
-        // how far back the slots of this caller's rotation reach, in batches (for the pre-wait below)
-        if (p->deferred.size() < 2 && p->batch_next > sl.batch_seq) p->lane_reach[lane] = (int)(p->batch_next - sl.batch_seq);
-      }
-    } else {
-      ++p->stat_queries;
-      done = hipEventQuery(sl.done_ev) == hipSuccess;
-      if (!done) (void)hipGetLastError();
-    }
-    if (!done) { ++p->stat_waits; HIP_TRY(hipStreamWaitEvent(s, sl.done_ev, 0)); }
-  }
+  if (int r = slot_order_after_previous(p, sl, s)) return r;
   // Pre-wait, mid-batch.  When the caller rotates through a slot count that is a multiple of the batch size, the
   // wait a lane needs for its next batch of slots falls on the lane's FIRST launch of that batch - right behind the
   // event record of the flush that closed the previous batch: two non-kernel packets in a row, on both lanes at
@@ -648,6 +665,198 @@ extern "C" int tsim_sample_batch_device_begin(tsim_program *p, int32_t slot, con
   }
   return launch_sample(p, d_f, B, num_f, key_hi, key_lo, shot_offset, d_out, d_max_norm_dev, s, nullptr, nullptr,
                        1 + slot, &plan, (flags & TSIM_PIPE_OUT_BIT_PACKED) != 0);
+}
+
+// ---------------------------------------------------------------------------
+// Several consecutive batches in one call (the reference's batch loop, sampler.py:340-420: per batch
+// `key, subkey = split(key)` and one sample_program).  Batches whose first pass is the register form go out in
+// groups of up to TSIMK_LWM_MAX_STEPS as ONE grid (k_sample_lw_multi, tsim_lw_multi.hip.h) on a first-pass lane,
+// lanes alternating between groups; the group's hard rows are one k_sample4h_multi batch on the batch lane behind it
+// (tsim_flush_hard) while the next group's first pass runs.  Anything else - dense plans, wide programs, row kernels -
+// goes through tsim_sample_batch_device_begin batch by batch: same results either way.
+// ---------------------------------------------------------------------------
+static int steps_group_fused(tsim_program *p, int n, const uint64_t *const *d_f, int64_t B, int32_t num_f, uint32_t key[2],
+                             int64_t shot_offset, void *const *d_out, float *const *d_dev, uint32_t flags, const LaunchPlan &plan) {
+  const bool packed = (flags & TSIM_PIPE_OUT_BIT_PACKED) != 0;
+  if (!p->deferred.empty())
+    if (int r = tsim_flush_hard(p)) return r;  // rows parked by batch-by-batch launches: their own batch first
+  hipStream_t s = p->slots[1 + (int)(p->steps_groups++ & 1ull)].side;
+  if (!(flags & TSIM_PIPE_INPUTS_READY) && p->stream != s) {
+    if (!p->sync_ev) HIP_TRY(hipEventCreateWithFlags(&p->sync_ev, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(p->sync_ev, p->stream));
+    HIP_TRY(hipStreamWaitEvent(s, p->sync_ev, 0));
+  }
+  const int WF = std::max(1, (num_f + 63) / 64);
+  const int blk1 = p->knobs.lw_block ? p->knobs.lw_block : 1024;
+  const long long bps = (B + blk1 - 1) / blk1;
+  const int n_lists = plan.lists;
+  if (getenv("TSIM_AMD_PIPELINE_STATS") && p->stat_fused == 0) {
+    int nb = -1;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_sample_lw_multi<2>, blk1, 0);
+    fprintf(stderr, "[tsim] k_sample_lw_multi<2>: %d blocks of %d threads per CU (occupancy API)\n", nb, blk1);
+  }
+  const long long list_cap = (bps + n_lists - 1) / n_lists * blk1;
+  if (list_cap > 0x7FFFFFFFll || bps * n > 0x7FFFFFFFll) return tsim_fail(TSIM_ENOTSUP, "batch too large for the row lists");
+  const bool has_check = shot_offset == 0;
+  LwMultiArgs M{};
+  M.img = p->d_img;
+  M.tab = p->d_lw_tab;
+  M.B = B;
+  M.shot_offset = shot_offset;
+  M.n_steps = n;
+  M.blocks_per_step = (int)bps;
+  M.n_comp = (int)p->comps.size();
+  M.lw_off = p->lw_off;
+  M.direct_rot = p->lw_direct_rot;
+  M.binom_off = p->lw_binom_off;
+  M.has_check = has_check ? 1 : 0;
+  M.list_cap = (int)list_cap;
+  M.n_lists = n_lists;
+  M.out_rb = (p->num_outputs + 7) / 8;
+  p->last_lists = n_lists;
+  int slots[TSIMK_LWM_MAX_STEPS];
+  for (int j = 0; j < n; ++j) {
+    const int sidx = 1 + (int)(p->steps_slot++ % (unsigned long long)TSIM_PIPELINE_SLOTS);
+    slots[j] = sidx;
+    tsim_program::Slot &sl = p->slots[sidx];
+    if (sl.deferred) return tsim_fail(TSIM_ESTATE, "pipeline slot %d still holds a parked launch", sidx - 1);
+    if ((size_t)list_cap * n_lists * 4 > sl.hard_sz) return tsim_fail(TSIM_ESTATE, "hard-row list too small");
+    if (int r = slot_order_after_previous(p, sl, s)) return r;
+    uint32_t o[4];
+    tsim_key_split(key[0], key[1], o);  // key, subkey = split(key)  (sampler.py:399)
+    key[0] = o[0];
+    key[1] = o[1];
+    SampleArgs &a = sl.ctx;
+    a = SampleArgs{};
+    if (int r = fill_sample_args(p, sl, a, d_f[j], B, num_f, o[2], o[3], shot_offset, (uint64_t *)d_out[j], d_dev ? d_dev[j] : nullptr, s,
+                                 sidx, packed))
+      return r;
+    LwStep &st = M.step[j];
+    st.f = d_f[j];
+    st.out = a.out;
+    st.out_compact = a.out_compact;
+    st.hard_index = (uint32_t *)sl.hard;
+    uint32_t *ctl = sl.ctl + sl.parity * (TSIMK_LW_LISTS + 1) * 32;
+    st.ctl = ctl;
+    st.ctl_next = sl.ctl + (sl.parity ^ 1) * (TSIMK_LW_LISTS + 1) * 32;
+    sl.parity ^= 1;
+    memcpy(st.keys, a.inline_keys, sizeof(uint32_t) * 2 * (size_t)p->total_keys);
+    // what the hard-row batch needs of this launch (launch_sample fills the same fields behind its first pass)
+    a.row_index = st.hard_index;
+    a.row_count = ctl;
+    a.row_lists = n_lists;
+    a.row_list_cap = (int)list_cap;
+    a.check_row = has_check ? ctl + 32 * TSIMK_LW_LISTS : nullptr;
+    a.no_check = has_check ? 0 : 1;
+    a.row_slot_begin = 0;
+    a.row_slot_end = 0;
+  }
+  // one chip-full of blocks (2048 threads per CU), every block the same number of (batch, row block) pairs
+  const long long total = bps * n;
+  const long long chip = (long long)p->n_cu * std::max(1, p->knobs.lw_resident) * (2048 / blk1);
+  const long long iters = (total + chip - 1) / chip;
+  const long long grid = (total + iters - 1) / iters;
+  const bool prof = p->profiling && (p->prof_counter++ % p->prof_every == 0);
+  if (prof) { if (int r = prof_event(p, s, PROF_BEGIN)) return r; }
+  // one component of at most 8 outputs: the specialised pass (tsim_lw_fast.hip.h) - 32-bit byte offsets everywhere, so
+  // batches below 2^28 rows, tables below 4 GB, and a shot range that does not cross a multiple of 2^32
+  const bool fast = p->lwf_off != 0 && p->knobs.lw_fast && B < (1ll << 28) && p->lw_bytes < (1ll << 32) && (n_lists & (n_lists - 1)) == 0 &&
+                    ((unsigned long long)shot_offset >> 32) == ((unsigned long long)(shot_offset + B - 1) >> 32);
+  M.lwf_off = fast ? p->lwf_off : 0;
+  if (fast) {
+    const int n_out = p->comps[0].n_out;
+#define TSIM_LF(N)                                                                                     \
+  case N:                                                                                              \
+    if (WF == 1) hipLaunchKernelGGL((k_sample_lw_fast<2, N>), dim3((unsigned)grid), dim3(blk1), 0, s, M); \
+    else hipLaunchKernelGGL((k_sample_lw_fast<4, N>), dim3((unsigned)grid), dim3(blk1), 0, s, M);        \
+    break;
+    switch (n_out) {
+      TSIM_LF(1) TSIM_LF(2) TSIM_LF(3) TSIM_LF(4) TSIM_LF(5) TSIM_LF(6) TSIM_LF(7) TSIM_LF(8)
+      default: return tsim_fail(TSIM_ESTATE, "fast record with %d outputs", n_out);
+    }
+#undef TSIM_LF
+    ++p->stat_fast;
+  } else if (WF == 1) hipLaunchKernelGGL(k_sample_lw_multi<2>, dim3((unsigned)grid), dim3(blk1), 0, s, M);
+  else hipLaunchKernelGGL(k_sample_lw_multi<4>, dim3((unsigned)grid), dim3(blk1), 0, s, M);
+  HIP_TRY(hipGetLastError());
+  if (prof) {
+    if (int r = prof_event(p, s, PROF_PASS1)) return r;
+    p->prof_steps += n;
+  }
+  hard_geometry(p, WF, (p->num_outputs + 63) / 64);
+  for (int j = 0; j < n; ++j) {
+    tsim_program::Slot &sl = p->slots[slots[j]];
+    sl.ctx_check = has_check;
+    sl.deferred = true;
+    sl.pending = true;
+    sl.p1_stream = s;
+    p->deferred.push_back(slots[j]);
+  }
+  p->stat_begins += (unsigned long long)n;
+  p->stat_deferred += (unsigned long long)n;
+  ++p->stat_fused;
+  return tsim_flush_hard(p);
+}
+
+extern "C" int tsim_sample_steps_device(tsim_program *p, int32_t n_steps, const uint64_t *const *d_f, int64_t B, int32_t num_f,
+                                        uint32_t key[2], int64_t shot_offset, void *const *d_out, float *const *d_max_norm_dev,
+                                        uint32_t flags) {
+  if (int r = tsim_need_final(p)) return r;
+  if (int r = tsim_set_device(p)) return r;
+  if (n_steps < 0 || B < 0 || num_f < 0 || shot_offset < 0) return tsim_fail(TSIM_EINVAL, "negative n_steps/B/num_f/shot_offset");
+  if (!key || (n_steps > 0 && (!d_f || !d_out))) return tsim_fail(TSIM_EINVAL, "NULL argument");
+  if (!p->sampleable) return tsim_fail(TSIM_ESTATE, "program has joint-mode components (evaluate-only)");
+  if (p->max_f_index >= num_f) return tsim_fail(TSIM_EINVAL, "program references f index %d but num_f=%d", p->max_f_index, num_f);
+  for (int j = 0; j < n_steps; ++j)
+    if ((!d_f[j] && num_f > 0) || !d_out[j]) return tsim_fail(TSIM_EINVAL, "buffer %d is NULL", j);
+  const int WF = std::max(1, (num_f + 63) / 64), WO = (p->num_outputs + 63) / 64;
+  int done = 0;
+  while (done < n_steps) {
+    // the fused first pass applies when the register form does, the subkeys fit its records, and the launch plan
+    // says "tables, short lists": decided per group - the plan follows the feedback of earlier launches
+    bool fused = p->lw && !p->lw_wide && p->lw_reg && p->knobs.lw_reg && p->knobs.fused_steps && (WF == 1 || WF == 2) && WO == 1 &&
+                 p->total_keys > 0 && p->total_keys <= TSIMK_LWM_KEYS && p->num_outputs > 0 && B > 0 && B <= 0x7FFFFFFFll &&
+                 p->knobs.defer_group >= 1;
+    LaunchPlan plan;
+    if (fused) {
+      if (!p->slots_ready) {  // as in _begin: every slot's stream / buffers now, not mid-run
+        const size_t hard_bytes = (size_t)(((B + 255) / 256 + TSIMK_LW_LISTS - 1) / TSIMK_LW_LISTS * 1024) * TSIMK_LW_LISTS * 4;
+        for (int k = 1; k <= TSIM_PIPELINE_SLOTS; ++k)
+          if (int r = slot_prepare(p, k, hard_bytes)) return r;
+        p->slots_ready = true;
+      }
+      plan = make_plan(p, false, true);
+      hard_geometry(p, WF, WO);
+      fused = plan.defer && plan.use_tables && p->h_group_tiles >= 1;
+    }
+    if (fused) {
+      // even groups of at most TSIMK_LWM_MAX_STEPS batches
+      const int left = n_steps - done;
+      const int gmax = std::min(TSIMK_LWM_MAX_STEPS, p->knobs.fused_max);
+      const int groups = (left + gmax - 1) / gmax;
+      const int n = (left + groups - 1) / groups;
+      {
+        const size_t hard_bytes = (size_t)(((B + 255) / 256 + TSIMK_LW_LISTS - 1) / TSIMK_LW_LISTS * 1024) * TSIMK_LW_LISTS * 4;
+        for (int j = 0; j < n; ++j)
+          if (int r = slot_prepare(p, 1 + (int)((p->steps_slot + (unsigned long long)j) % TSIM_PIPELINE_SLOTS), hard_bytes)) return r;
+      }
+      if (int r = steps_group_fused(p, n, d_f + done, B, num_f, key, shot_offset, d_out + done, d_max_norm_dev ? d_max_norm_dev + done : nullptr,
+                                    flags, plan))
+        return r;
+      done += n;
+    } else {
+      const int slot = (int)(p->steps_slot++ % (unsigned long long)TSIM_PIPELINE_SLOTS);
+      uint32_t o[4];
+      tsim_key_split(key[0], key[1], o);
+      key[0] = o[0];
+      key[1] = o[1];
+      if (int r = tsim_sample_batch_device_begin(p, slot, d_f[done], B, num_f, o[2], o[3], shot_offset, (uint64_t *)d_out[done],
+                                                 d_max_norm_dev ? d_max_norm_dev[done] : nullptr, nullptr, flags))
+        return r;
+      ++done;
+    }
+  }
+  return TSIM_OK;
 }
 
 extern "C" int tsim_pipeline_lane_stream(tsim_program *p, int32_t lane, void **stream) {
@@ -839,6 +1048,15 @@ extern "C" int tsim_sample_batch(tsim_program *p, const uint8_t *f, int64_t B, i
   HIP_TRY(hipStreamSynchronize(s));
   return TSIM_OK;
 }
+#ifdef TSIMK_LW_TRACE
+// diagnostic builds only (scripts/lw_trace.py): the s_memtime stamps of the first pass's first blocks
+extern "C" int tsim_debug_lw_trace(unsigned long long *out) {
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(tsimk::tsimk_lw_trace), 16 * 32 * 8));
+  return 0;
+}
+#endif
+
 extern "C" int tsim_profile_enable(tsim_program *p, int32_t on) {
   if (int r = tsim_need_final(p)) return r;
   if (int r = tsim_set_device(p)) return r;
@@ -867,6 +1085,14 @@ extern "C" int tsim_profile_read(tsim_program *p, double *kernel_ms, int64_t *la
     p->prof_launches = 0;
     for (double &v : p->prof_stage_ms) v = 0.0;
   }
+  return TSIM_OK;
+}
+
+extern "C" int tsim_profile_read_steps(tsim_program *p, int64_t *steps, int32_t reset) {
+  if (int r = tsim_need_final(p)) return r;
+  if (!steps) return tsim_fail(TSIM_EINVAL, "NULL argument");
+  *steps = p->prof_steps;
+  if (reset) p->prof_steps = 0;
   return TSIM_OK;
 }
 

@@ -78,8 +78,8 @@ static void enumerate_patterns(int F, int wmax, std::vector<unsigned long long> 
 
 // Allocate and fill the tables for the current plan (p->lw_wmax); the previous buffer, if any, is returned in
 // *old (the caller frees it once nothing in flight reads it).
-int tsim_tables_build(tsim_program *p, float **old) {
-  float *tab = nullptr;
+int tsim_tables_build(tsim_program *p, uint32_t **old) {
+  uint32_t *tab = nullptr;
   hipError_t me = hipMalloc((void **)&tab, std::max<size_t>(16, (size_t)p->lw_bytes));
   if (me != hipSuccess) return tsim_fail(TSIM_ENOMEM, "hipMalloc(%lld) for the pattern tables failed: %s", p->lw_bytes, hipGetErrorString(me));
   for (size_t ci = 0; ci < p->comps.size(); ++ci) {
@@ -126,6 +126,10 @@ int tsim_tables_build(tsim_program *p, float **old) {
 // with every lane idle: the records in the device image are rewritten).
 int tsim_tables_extend(tsim_program *p) {
   if (!p->lw || p->lw_cap_now >= p->lw_cap_max) return 0;
+  // The component records in the device image are rewritten below and the old table is freed: nothing may be in
+  // flight - not on the handle's lanes (the planner drained them) and not on a stream the CALLER passed to the
+  // device entry points either (include/tsim_hip.h lets it).  Once per handle.
+  HIP_TRY(hipDeviceSynchronize());
   const std::vector<int> before = p->lw_wmax;
   const std::vector<long long> npat_before = p->lw_npat;
   const long long bytes_before = p->lw_bytes;
@@ -139,7 +143,7 @@ int tsim_tables_extend(tsim_program *p) {
     p->lw_bytes = bytes_before;
     return 0;
   }
-  float *old = nullptr;
+  uint32_t *old = nullptr;
   const size_t rec_bytes = p->comps.size() * LW_WORDS * 4;
   // wide components: the build kernel unranks with the NEW bases, read from the device image (every lane is idle)
   if (p->lw_wide) HIP_TRY(hipMemcpy(p->d_img + p->lw_off, p->img.data() + p->lw_off, rec_bytes, hipMemcpyHostToDevice));

@@ -41,7 +41,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md)
-VALU_PEAK_WAVE_INSTS = 5.7e11  # wave64 int VALU instructions/s, whole chip: measured (scripts/microbench/valu_peak.hip)
+# Vector-ALU issue, whole chip (1024 SIMDs).  The guide's figure: a wave64 instruction issues over 2 cycles at 2.4 GHz.
+VALU_ISSUE_PEAK = 1024 * 2.4e9 / 2.0  # 1.23e12 wave64 instructions/s
+# Measured on this chip per instruction class (scripts/microbench/valu_table.hip -> profiles/r03/valu_table.txt):
+# full-rate instructions 2.4 cycles at the 1.9-2.1 GHz the chip sustains under them (8.2-8.5e11/s), half-rate ones -
+# v_alignbit, v_lshlrev, v_add3, v_cndmask, v_cmp, v_bcnt, every instruction with an SGPR operand - 4.3 cycles at
+# 2.3-2.4 GHz (5.5-5.8e11/s); one Threefry-2x32-20 block = 75 such instructions, best of ten instruction selections:
+# 5.8e11 blocks/s (scripts/microbench/threefry_block.hip -> profiles/r03/threefry_block.txt).
+THREEFRY_BLOCKS_PER_S = 5.8e11
 NF = 4                 # distinct f batches rotated through the timed loop
 
 
@@ -84,36 +91,61 @@ def load_pmc(config: str, shots: int):
     return None
 
 
-def valu_block(ref_ops_per_shot: int, shots: int, kernel_s: float, serial_s, step_s: float, pmc) -> dict:
-    """The bound that actually binds: integer VALU issue.
+def load_isa_classes():
+    """The committed instruction-class census of the first pass's row loop (scripts/isa_classes.py), or None."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "r03", "first_pass_isa.json")))
+    except Exception:
+        return None
 
-    Peak: a wave64 integer instruction (add / rotate / xor - the Threefry mix) occupies a SIMD for 4.2 cycles,
-    measured with scripts/microbench/valu_peak.hip on this chip at 8 waves per SIMD: 5.7e11 wave-instructions/s
-    over 1024 SIMDs.  Executed instructions per launch: rocprofv3 --pmc SQ_INSTS_VALU, all kernels of a launch
-    (first pass + its share of the hard-row kernels)."""
+
+def valu_block(ref_ops_per_shot: int, shots: int, n_draws: int, kernel_s_per_batch: float, serial_s, step_s: float, pmc, fast_path: bool) -> dict:
+    """The bound that actually binds the first pass: vector-ALU issue.
+
+    Three yardsticks, from loose to tight: (1) the guide's issue peak - one wave64 instruction per 2 cycles and SIMD,
+    1.23e12/s; (2) the op-class-weighted bound - the kernel's own loop body (profiles/r03/first_pass_isa.json) priced
+    with the issue cost MEASURED per instruction class; (3) the Threefry floor - the draws the reference's RNG stream
+    prescribes (one Threefry-2x32-20 block per shot and sampled output, sampler.py:74-75) at the best block rate any
+    instruction selection reached on this chip."""
+    isa = load_isa_classes() if fast_path else None
     out = {
         "bound": "valu_issue",
-        "peak_wave_insts_per_s": VALU_PEAK_WAVE_INSTS,
-        "peak_source": "scripts/microbench/valu_peak.hip on MI355X: 4.1-4.35 cycles per wave64 int instruction and SIMD "
-                       "(profiles/r02/valu_peak.txt)",
+        "issue_peak_wave_insts_per_s": VALU_ISSUE_PEAK,
+        "issue_peak_source": "MI355X_MICROARCH.md: wave64 VALU instruction = 2 cycles per SIMD, 1024 SIMDs x 2.4 GHz",
         "reference_algorithm_ops_per_shot": ref_ops_per_shot,
+        "threefry_floor_us_per_batch": n_draws * shots / THREEFRY_BLOCKS_PER_S * 1e6,
+        "threefry_floor_source": "scripts/microbench/threefry_block.hip: 5.8e11 blocks/s, the best of ten instruction "
+                                 "selections (profiles/r03/threefry_block.txt); one block per shot and compiled output",
+        "frac_of_threefry_floor_in_pipeline": n_draws * shots / THREEFRY_BLOCKS_PER_S / kernel_s_per_batch,
+        "frac_of_threefry_floor_at_step_rate": n_draws * shots / THREEFRY_BLOCKS_PER_S / step_s,
     }
+    if isa:
+        wi = isa["wave_instructions_per_1e6_shots"]
+        insts = wi["valu"] * shots / 1e6
+        bound_s = isa["us_per_1e6_shots_at_2.3GHz"]["valu"] * 1e-6 * shots / 1e6
+        out.update({
+            "loop_body_valu_wave_insts_per_launch_of_one_batch": insts,
+            "loop_body_classes": isa["classes"],
+            "frac_of_issue_peak_at_step_rate": insts / step_s / VALU_ISSUE_PEAK,
+            "frac_of_issue_peak_in_pipeline": insts / kernel_s_per_batch / VALU_ISSUE_PEAK,
+            "op_class_bound_us_per_batch": bound_s * 1e6,
+            "frac_of_op_class_bound_at_step_rate": bound_s / step_s,
+            "frac_of_op_class_bound_in_pipeline": bound_s / kernel_s_per_batch,
+            "frac_of_op_class_bound_serial": (bound_s / serial_s) if serial_s else None,
+            "op_class_source": "profiles/r03/first_pass_isa.json: static census of k_sample_lw_fast's row loop x measured cycles "
+                               "per class (full 2.4, half 4.3; profiles/r03/valu_table.txt), 15.26 wave-rows per SIMD, 2.3 GHz",
+        })
     if pmc and "SQ_INSTS_VALU" in pmc:
         insts = float(pmc["SQ_INSTS_VALU"])
-        first = float(pmc.get("_per_kernel", {}).get("k_sample_lw_reg", pmc.get("_per_kernel", {}).get("k_sample_lw", {})).get("SQ_INSTS_VALU", insts))
         out.update({
-            "executed_valu_wave_insts_per_launch": insts,
-            "executed_valu_wave_insts_per_64_shots": insts / (shots / 64.0),
-            "threefry_floor_wave_insts_per_64_shots": "77 per draw: 20 rounds x (add, rotate, xor) + key injections + float conversion",
-            "achieved_wave_insts_per_s_at_step_rate": insts / step_s,
-            "frac_at_step_rate": insts / step_s / VALU_PEAK_WAVE_INSTS,
-            "frac_dominant_kernel_serial": (first / serial_s / VALU_PEAK_WAVE_INSTS) if serial_s else None,
-            "frac_dominant_kernel_in_pipeline": first / kernel_s / VALU_PEAK_WAVE_INSTS,
+            "executed_valu_wave_insts_per_batch": insts,
+            "executed_frac_of_issue_peak_at_step_rate": insts / step_s / VALU_ISSUE_PEAK,
             "pmc_source": "profiles/latest_pmc.json (rocprofv3 --pmc SQ_INSTS_VALU, same workload)",
-            "note": "frac_at_step_rate = VALU instructions of everything one step launches / step time / issue peak: the "
-                    "share of the chip's VALU issue slots the pipeline keeps busy.  75 % of the first pass's instructions "
-                    "are the Threefry blocks the reference's draws require (one block per shot and sampled output).",
         })
+    out["note"] = ("frac_of_issue_peak = vector instructions / time / 1.23e12: what the guide's peak would allow; the op-class "
+                   "bound prices the SAME instructions with the rates this chip sustains (half of them are half-rate: rotates, "
+                   "selects, SGPR operands); the Threefry floor is what the prescribed draws alone cost.  *_in_pipeline uses the "
+                   "first pass's own HIP-event duration per batch inside the timed region, *_at_step_rate the step time.")
     return out
 
 
@@ -171,6 +203,11 @@ def cpu_baseline(program, cfg, seconds: float = 15.0) -> dict:
         "single_thread_value": single,
         "numpy_reference_faithful_value": faithful,
         "kind": "port",
+        "note": "the repo's own C restatement of the reference algorithm (packed popcount rows, OpenMP over shots) - NOT the "
+                "reference's JAX-on-CPU path, which cannot run in this image (no jax/equinox); numpy_reference_faithful_value keeps "
+                "the reference's data movement (float32 GEMM % 2, materialised lookups, scans) and is 250x slower than this port; "
+                "the reference's only published CPU figure for this circuit is 2.8e5 shots/s on unstated hardware (BASELINE.md): "
+                "a '>= 10x the reference CPU path' claim can only be made against that number",
         "sample": f"{n} shots of the same program and f distribution, C oracle (oracle/oracle.c, OpenMP over shots, "
         f"{threads} threads on {cores} CPUs; {note}), {dt:.1f} s wall",
     }
@@ -201,6 +238,35 @@ def exchange_unique_id(rank: int, world: int) -> bytes:
     return tdist.rendezvous_tcp(rank, world, addr=addr, port=int(os.environ.get("TSIM_DIST_PORT", port + 1)))
 
 
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: spawn the N ranks here - one process per GPU, rank r on device r,
+    rendezvous over tsim_amd.dist's own socket protocol (no torch.distributed) - and relay rank 0's line."""
+    import socket
+    import subprocess
+
+    def free_port() -> int:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            return sk.getsockname()[1]
+
+    port, dport = free_port(), free_port()
+    launch_only = os.environ.get("TSIM_BENCH_LAUNCH_ONLY") == "1"
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   TSIM_DIST_PORT=str(dport))
+        env.pop("TORCHELASTIC_USE_AGENT_STORE", None)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if (r == 0 or launch_only) else subprocess.DEVNULL))
+    outs = [p.communicate()[0] if p.stdout else (p.wait() and b"") for p in procs]
+    rc = max(abs(p.returncode or 0) for p in procs)
+    for o in outs:
+        if o:
+            sys.stdout.write(o.decode("utf-8", "replace"))
+    sys.stdout.flush()
+    return rc
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -211,6 +277,13 @@ def main() -> None:
     ap.add_argument("--config", default="C2")
     ap.add_argument("--random-program", action="store_true", help="the unconstrained random program instead of the normalised one")
     ap.add_argument("--p-bit", type=float, default=None, help="override the per-bit fire probability of the synthetic f batches")
+    ap.add_argument("--approx", action="store_true", help="has_approximate_floatfactors=True in every level (compile/evaluate.py:56-59: "
+                    "the float32 sum branch the real distillation circuits take, SURVEY section 7 hard part 2) as the headline workload")
+    ap.add_argument("--live-padding", action="store_true", help="term counts of the shape reached with terms the packer cannot cancel")
+    ap.add_argument("--program", default=None, help="a compiled program exported where tsim is installed "
+                    "(scripts/export_from_tsim.py -> .npz) instead of the synthetic shape")
+    ap.add_argument("--num-f", type=int, default=None, help="with --program: width of the synthetic f batches (default: from the file, "
+                    "else the largest f index + 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the untimed context legs (profiling runs)")
     ap.add_argument("--no-full-leg", action="store_true", help=argparse.SUPPRESS)  # older name
@@ -222,12 +295,26 @@ def main() -> None:
     # the host driver supports dmabuf IPC only: RCCL's peer mappings fail without this (exported on the GPU boxes;
     # set here too in case a launcher scrubs the environment) - before any HIP runtime is loaded
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher: spawn the N ranks ourselves (one process per GPU, tsim_amd.dist's socket rendezvous, no torch)
+        raise SystemExit(self_launch(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:  # never print a line whose n_gpus is not what was asked for
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     N = max(world, 1)
+    if os.environ.get("TSIM_BENCH_LAUNCH_ONLY") == "1":
+        # launcher check (tests/test_dist_gloo.py, no GPU needed): every rank reaches the point where the communicator
+        # would be created, with the same 128 bytes in hand
+        import hashlib
+        from tsim_amd import dist as tdist0
+
+        ident = tdist0.rendezvous_tcp(rank, N, addr=os.environ.get("MASTER_ADDR", "127.0.0.1"),
+                                      port=int(os.environ.get("TSIM_DIST_PORT", int(os.environ.get("MASTER_PORT", "29511")) + 1)),
+                                      timeout=60, make_id=lambda: bytes((7 * i + 3) % 256 for i in range(128)))
+        print(json.dumps({"launch_only": True, "rank": rank, "world": N, "local_rank": local_rank, "id_sha": hashlib.sha256(ident).hexdigest()[:16]}), flush=True)
+        return
     use_dist = N > 1 or os.environ.get("TSIM_BENCH_FORCE_DIST") == "1"
 
     # torch: only for the contract's torch.cuda.synchronize() (and its HIP runtime must be the first one loaded
@@ -255,7 +342,18 @@ def main() -> None:
         os.environ.setdefault("MASTER_PORT", "29511")
         comm = tdist.Communicator(local_rank, exchange_unique_id(rank, N), rank, N)
 
-    program, cfg = synth.config_program(args.config, physical=not args.random_program)
+    if args.program:
+        from tsim_amd import program as tprog
+
+        program, extra_arrays = tprog.load_npz(args.program)
+        tprog.validate_program(program)
+        need_f = 1 + max([int(np.max(program.direct_f_indices, initial=-1))] + [int(np.max(c.f_selection, initial=-1)) for c in program.components])
+        nf_file = int(extra_arrays["num_f"]) if "num_f" in extra_arrays else need_f
+        cfg = dict(name=f"exported program {os.path.basename(args.program)}", num_f=int(args.num_f or max(nf_file, need_f)), p_bit=0.02, seed=42)
+        args.config = os.path.basename(args.program)
+    else:
+        program, cfg = synth.config_program(args.config, physical=not args.random_program, approx=args.approx,
+                                            **({"live_padding": True} if args.live_padding else {}))
     if args.p_bit is not None:
         cfg = dict(cfg, p_bit=float(args.p_bit))
     t_build0 = time.perf_counter()
@@ -310,9 +408,11 @@ def main() -> None:
     # (still above one link: two GPUs are link-bound either way, the single root by 2.4x, spread roots by ~1.2x),
     # 46 GB/s at N = 4, 23 GB/s at N = 8.  Hence "auto" = alltoall for every N > 1; no N > 1 measurement exists
     # yet to confirm the arithmetic.
-    GATHER_MODE = os.environ.get("TSIM_BENCH_GATHER", "auto")
+    # Default: "root0" - the north star's collective; "alltoall" is the hypothesis above, to be chosen by the first N > 1
+    # measurement (TSIM_BENCH_GATHER=alltoall), not by arithmetic.
+    GATHER_MODE = os.environ.get("TSIM_BENCH_GATHER", "root0")
     if GATHER_MODE == "auto":
-        GATHER_MODE = "alltoall"
+        GATHER_MODE = "root0"
     if GATHER_MODE == "alltoall":
         GATHER_EVERY = (GATHER_EVERY + N - 1) // N * N
     # results are written in the reference's bit_packed layout (sampler.py:665-669: ceil(n_out/8) bytes per shot,
@@ -321,7 +421,7 @@ def main() -> None:
     # fuses the first passes of up to 8 batches into one grid and runs each group's hard rows as one batch behind it
     # (DESIGN.md section 3.10); its slot rotation covers all 16 pipeline slots, so 16 output buffers.
     # TSIM_BENCH_PER_STEP=1: one tsim_sample_batch_device_begin_split per step, as in rounds 1-2.
-    PER_STEP = use_dist or os.environ.get("TSIM_BENCH_PER_STEP") == "1"
+    PER_STEP = os.environ.get("TSIM_BENCH_PER_STEP") == "1"
     if not PER_STEP:
         NSLOT = backend.HipProgram.PIPELINE_SLOTS
     d_outs = [hp.malloc(B * WO * 8) for _ in range(NSLOT)]  # sized for the padded rows too (serial legs below)
@@ -332,8 +432,8 @@ def main() -> None:
         join_ptr = hp.pipeline_lane_stream(2)   # where deferred hard-row batches - i.e. results - complete
         main_ptr = hp.stream_ptr()               # first-pass lane 0
         grp = [hp.malloc(GATHER_EVERY * B * RB) for _ in range(2)]
-        if GATHER_MODE == "alltoall":
-            grp_recv = [hp.malloc(GATHER_EVERY * B * RB) for _ in range(2)]
+        if GATHER_MODE == "alltoall":  # (rank 0 also takes the gather of a partial last group: N senders)
+            grp_recv = [hp.malloc((N if rank == 0 else 1) * GATHER_EVERY * B * RB) for _ in range(2)]
         else:
             grp_recv = [hp.malloc(N * GATHER_EVERY * B * RB) if rank == 0 else None for _ in range(2)]
         grp_used = [False, False]
@@ -358,11 +458,11 @@ def main() -> None:
         coll = 0 if COLL_OWN_STREAM else join_ptr
         if COLL_OWN_STREAM:
             comm.stream_wait(0, join_ptr)
-        if GATHER_MODE == "alltoall":  # equal chunks; a partial last group is rounded up (the tail rows are stale)
-            per_peer = (count + N - 1) // N * B * RB
-            comm.alltoall_rows(grp[g].ptr, grp_recv[g].ptr, per_peer, stream=coll)
-        else:
+        if GATHER_MODE == "alltoall" and count % N == 0:  # equal chunks: batches [j * count/N, (j+1) * count/N) land on rank j
+            comm.alltoall_rows(grp[g].ptr, grp_recv[g].ptr, count // N * B * RB, stream=coll)
+        else:  # the gather to rank 0, exactly `count` batches - also what a partial last group of the all-to-all mode takes
             comm.gather_rows(grp[g].ptr, count * B * RB, grp_recv[g].ptr if grp_recv[g] else 0, root=0, stream=coll)
+        last_collective[0] = (g, count, "alltoall" if (GATHER_MODE == "alltoall" and count % N == 0) else "root0")
         comm.mark(g, coll)  # "the collective that read group buffer g is done"
         grp_used[g] = True
         gathered[0] += 1
@@ -370,12 +470,50 @@ def main() -> None:
     steps_fn = lib.tsim_sample_steps_device
     ptr_cache = {}
 
+    last_collective = [None]
+
+    def dist_steps(k: int, f_list) -> None:
+        """N > 1: the same library call per piece of a gather group; every batch writes its bit_packed rows straight into
+        its slice of the group buffer, a complete group is joined on the join lane and collected."""
+        done = 0
+        while done < k:
+            j = step_no[0]
+            g, pos = (j // GATHER_EVERY) & 1, j % GATHER_EVERY
+            n = min(k - done, GATHER_EVERY - pos)
+            rc = 0
+            if pos == 0:
+                if grp_used[g]:
+                    # the collective that last read this group buffer (two groups ago) must be done before kernels
+                    # overwrite it: first-pass lane 0 waits for THAT marker only (waiting for the whole join lane would
+                    # drain the pipeline once per group); the other lanes are ordered after lane 0 just below
+                    comm.wait_mark(g, main_ptr)
+                rc = wait_fn(h_prog, None)
+            elif launched[0] < NSLOT:  # (the very first launches of the run create the lanes)
+                rc = wait_fn(h_prog, None)
+            if rc >= 0:
+                fa = (C.c_void_p * n)(*[f_list[(j + i) % len(f_list)].ptr for i in range(n)])
+                oa = (C.c_void_p * n)(*[grp[g].ptr + (pos + i) * B * RB for i in range(n)])
+                rc = steps_fn(h_prog, n, fa, B, num_f, key_state, shot_offset, oa, None,
+                              (0 if launched[0] < NSLOT else PIPE_READY) | PIPE_PACKED)
+            if rc < 0:
+                raise RuntimeError(f"pipelined launch failed ({rc}): {_lib.last_error()}")
+            launched[0] += n
+            step_no[0] = j + n
+            done += n
+            if pos + n == GATHER_EVERY:  # group complete: join every slot on the join lane, then collect
+                for q in range(backend.HipProgram.PIPELINE_SLOTS):
+                    end_fn(h_prog, q, join_ptr)
+                gather_next(GATHER_EVERY)
+
     def steps(k: int, f_list=f_bufs) -> None:
         """k consecutive steps in one library call (N = 1): per batch key, subkey = split(key) (sampler.py:399) and one
         sample_program; batch j reads f_list[j % len], writes bit_packed rows to out buffer j % NSLOT."""
         if PER_STEP:
             for _ in range(k):
                 step(f_list)
+            return
+        if use_dist:
+            dist_steps(k, f_list)
             return
         j0 = step_no[0]
         ck = (k, j0 % NSLOT, j0 % len(f_list), id(f_list))
@@ -434,7 +572,7 @@ def main() -> None:
                 for k in range(NSLOT):
                     hp.sample_batch_device_end(k)
             return
-        for k in range(NSLOT):
+        for k in range(backend.HipProgram.PIPELINE_SLOTS):
             end_fn(h_prog, k, join_ptr)
         n_steps = step_no[0]
         while gathered[0] * GATHER_EVERY < n_steps:
@@ -455,11 +593,19 @@ def main() -> None:
     # launches (deferred batches need one launch of feedback), lanes and per-slot buffers are created by the
     # first pipelined launches
     INIT_STEPS = 16
-    for _ in range(INIT_STEPS):
-        step()
+    if PER_STEP:
+        for _ in range(INIT_STEPS):
+            step()
+    else:
+        for _ in range(INIT_STEPS // 4):  # small calls: the launch plan needs the feedback of earlier launches
+            steps(4)
     fence()
     steps(args.warmup)
     fence()
+    verify = None
+    if use_dist and os.environ.get("TSIM_BENCH_VERIFY") == "1":
+        verify = verify_collected(backend, prng, synth, program, cfg, hp, comm, lib, rank, N, B, num_f, n_out, RB, local_rank,
+                                  key_state, steps, drain, fence, grp_recv, last_collective, GATHER_EVERY, NF)
     # HIP events around the dominant kernel only (level 2), on at least 8 launches per repetition: timing events
     # drain the queue they are recorded on (~5 us each), so not every launch is bracketed
     # (at least 8 bracketed launches over the repetitions together: a bracket costs ~7 us of a ~17 us step)
@@ -551,7 +697,7 @@ def main() -> None:
     extra = {}
     if N == 1 and not use_dist and not args.no_extra_legs:
         extra = extra_legs(backend, synth, program, cfg, hp, info, B, num_f, n_out, key, f_bufs, d_out0, local_rank, t_build,
-                           resident_f, step, drain, INIT_STEPS)
+                           resident_f, steps, drain, INIT_STEPS, args)
 
     if rank == 0:
         total_shots = float(B) * N * args.steps
@@ -568,7 +714,11 @@ def main() -> None:
         # a fused first pass (tsim_sample_steps_device) serves several batches per launch: algorithmic bytes per LAUNCH
         batches_per_launch = (prof_steps / launches) if (prof_steps and launches and tables_dominant) else 1.0
         achieved_gbs = bytes_per_shot * B * batches_per_launch / avg_kernel_s / 1e9
-        if tables_dominant:
+        fast_path = len(program.components) == 1 and len(program.components[0].output_indices) <= 8 and not PER_STEP
+        if tables_dominant and batches_per_launch > 1.0:
+            kernel_name = ("tsimk::k_sample_lw_fast" if fast_path else "tsimk::k_sample_lw_multi") + \
+                f" (fused pattern-table pass over {batches_per_launch:.1f} batches per launch; hard rows: one k_sample4h_multi batch per group, on the third lane)"
+        elif tables_dominant:
             kernel_name = ("tsimk::k_sample_lw (pattern-table pass; hard rows: k_sample4h_multi batches / k_sample4h + "
                            "k_sample4, on the third lane)") if info.get("chunk_table_kernel") else \
                 "tsimk::k_sample_lw (pattern-table pass; hard rows: k_sample, overlapped on the other lanes)"
@@ -603,6 +753,8 @@ def main() -> None:
                              + ("one RCCL all-to-all (batch group j of all ranks assembled on rank j)" if GATHER_MODE == "alltoall"
                                 else "an RCCL gather to rank 0") + ", issued by libtsim_hip.so (no torch.distributed)")
                 if use_dist else "single GPU",
+                "steps_per_library_call": "all --steps in one tsim_sample_steps_device call (first passes fused in groups of <= 8 batches)"
+                if not PER_STEP else "one tsim_sample_batch_device_begin_split per step",
                 "f_resident_in_hbm": True,
                 "output_layout": f"bit_packed rows, {RB} B/shot (sampler.py:665-669), written by the sampling kernels",
             },
@@ -635,8 +787,15 @@ def main() -> None:
                 "bytes/shot), achieved_serial the kernel's duration with the GPU to itself (= rocprofv3's serial kernel "
                 "trace).  Integer-VALU / latency bound, not HBM bound (DESIGN.md section 3.5): see `valu`.",
             },
-            "valu": valu_block(ops_per_shot, B, avg_kernel_s / batches_per_launch, (serial_ms * 1e-3) if serial_ms else None, elapsed / args.steps, pmc),
+            "valu": valu_block(ops_per_shot, B, sum(len(c.output_indices) for c in program.components), avg_kernel_s / batches_per_launch,
+                               (serial_ms * 1e-3) if serial_ms else None, elapsed / args.steps, pmc,
+                               fast_path=(len(program.components) == 1 and len(program.components[0].output_indices) <= 8 and not PER_STEP)),
         }
+        if verify is not None:
+            res["verify"] = verify
+        if args.approx or args.live_padding or args.program:
+            res["config"]["variant"] = ("approximate floatfactors (compile/evaluate.py:56-59) " if args.approx else "") + \
+                ("live padding " if args.live_padding else "") + (f"exported program {args.program}" if args.program else "")
         res.update(extra)
         if N == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(program, cfg, args.cpu_seconds)
@@ -649,47 +808,166 @@ def main() -> None:
         print(json.dumps(res), flush=True)
 
 
+def verify_collected(backend, prng, synth, program, cfg, hp, comm, lib, rank, N, B, num_f, n_out, RB, device, key_state, steps, drain,
+                     fence, grp_recv, last_collective, GATHER_EVERY, NF) -> dict:
+    """TSIM_BENCH_VERIFY=1 (untimed): what the collectives delivered, byte for byte.  One complete gather group and one
+    PARTIAL group (exact count: no stale tail) go through the benchmark's own path; every rank that received rows
+    regenerates the senders' f batches from their seeds and recomputes the rows with the full kernel (pattern tables
+    off: another code path) under the same subkeys and shot offsets."""
+    WF = max(1, (num_f + 63) // 64)
+    hp_ref = backend.HipProgram(program, device=device, pattern_tables=False)
+    d_f, d_o = hp_ref.malloc(B * WF * 8), hp_ref.malloc(B * 8 * ((n_out + 63) // 64))
+    checked, bad = 0, []
+
+    def reference_rows(sender: int, batch_no: int, sub):
+        f = synth.synth_f(B, num_f, cfg["p_bit"], seed=cfg["seed"] + 1000 * sender + 7919 * (batch_no % NF))
+        packed = np.packbits(f, axis=1, bitorder="little")
+        if WF * 8 - packed.shape[1]:
+            packed = np.pad(packed, ((0, 0), (0, WF * 8 - packed.shape[1])))
+        hp_ref.h2d(d_f, np.ascontiguousarray(packed))
+        hp_ref.sample_batch_device(d_f.ptr, B, num_f, sub, d_o.ptr, shot_offset=sender * B)
+        hp_ref.synchronize()
+        raw = np.zeros((B, 8 * ((n_out + 63) // 64)), np.uint8)
+        hp_ref.d2h(raw, d_o)
+        return np.ascontiguousarray(raw[:, :RB])
+
+    for count in (GATHER_EVERY, max(1, GATHER_EVERY - 3)):
+        fence()
+        key = (int(key_state[0]), int(key_state[1]))
+        subs = []
+        for _ in range(count):
+            key, sub = prng.split(key)
+            subs.append(sub)
+        steps(count)
+        drain()  # a partial group is collected here
+        fence()
+        g, cnt, mode = last_collective[0]
+        assert cnt == count, (cnt, count)
+        if mode == "root0":
+            if rank == 0:
+                got = np.zeros((N, count, B, RB), np.uint8)
+                hp.d2h(got, grp_recv[g])
+                for sender in range(N):
+                    for b in range(count):
+                        checked += 1
+                        if not np.array_equal(got[sender, b], reference_rows(sender, b, subs[b])):
+                            bad.append((count, sender, b))
+        else:
+            per = count // N
+            got = np.zeros((N, per, B, RB), np.uint8)
+            hp.d2h(got, grp_recv[g])
+            for sender in range(N):
+                for b in range(per):
+                    checked += 1
+                    if not np.array_equal(got[sender, b], reference_rows(sender, rank * per + b, subs[rank * per + b])):
+                        bad.append((count, sender, rank * per + b))
+    hp_ref.close()
+    n_bad = comm.allreduce_max(float(len(bad)))
+    if n_bad:
+        raise SystemExit(f"TSIM_BENCH_VERIFY: rank {rank}: {len(bad)} collected batches differ from the serial full-kernel rows: {bad[:8]}")
+    return {"ok": True, "batches_checked_on_rank0": checked, "groups": [GATHER_EVERY, max(1, GATHER_EVERY - 3)],
+            "against": "full kernel (pattern tables off), same subkeys and shot offsets, f regenerated from the senders' seeds"}
+
+
+def full_kernel_leg(backend, program, device, f_bufs, B, num_f, key, d_out0) -> dict:
+    """The full kernel alone (pattern tables off): the g.f contraction on EVERY row - the rate for inputs where no shot
+    is tabulated, with the HBM and vector-issue figures of that kernel."""
+    hp_full = backend.HipProgram(program, device=device, pattern_tables=False)
+    fi = hp_full.info()
+    for _ in range(2):
+        hp_full.sample_batch_device(f_bufs[0].ptr, B, num_f, key, d_out0.ptr)
+    hp_full.synchronize()
+    hp_full.profile_enable(True)
+    hp_full.profile_read(reset=True)
+    for k in range(5):
+        hp_full.sample_batch_device(f_bufs[k % len(f_bufs)].ptr, B, num_f, key, d_out0.ptr)
+    fms, fl = hp_full.profile_read(reset=True)
+    hp_full.profile_enable(False)
+    hp_full.close()
+    t = fms / max(fl, 1) * 1e-3
+    bytes_per_shot = algorithmic_bytes_per_shot(num_f, program.num_outputs)
+    # executed vector instructions of this kernel on the benchmark shape: rocprofv3 SQ_INSTS_VALU (profiles/r01/v5_pmc.json,
+    # same kernel, same shape: 1.52e8 per 10^6 shots = 9.7k per 64 shots)
+    insts = 1.52e8 * B / 1e6
+    return {
+        "kernel": "tsimk::k_sample4 (LDS chunk tables)" if fi.get("chunk_table_kernel") else "tsimk::k_sample",
+        "kernel_avg_ms": t * 1e3, "shots_per_s": B / t, "launches": fl, "total_rows": fi["total_rows"], "table_bytes": fi["table_bytes"],
+        "roofline": {"bound": "hbm", "achieved": bytes_per_shot * B / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": bytes_per_shot * B / t / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_shot": bytes_per_shot},
+        "valu": {"bound": "valu_issue", "executed_valu_wave_insts_per_launch": insts, "issue_peak_wave_insts_per_s": VALU_ISSUE_PEAK,
+                 "frac_of_issue_peak": insts / t / VALU_ISSUE_PEAK,
+                 "pmc_source": "profiles/r01/v5_pmc.json (rocprofv3 SQ_INSTS_VALU of k_sample4 on the C2 shape; scaled to this batch)"},
+    }
+
+
 def extra_legs(backend, synth, program, cfg, hp, info, B, num_f, n_out, key, f_bufs, d_out0, device, t_build, resident_f,
-               step, drain, init_steps) -> dict:
-    """Untimed context for the headline (N = 1): what the judge of round 1 asked to see next to `value`."""
+               steps, drain, init_steps, args) -> dict:
+    """Untimed context for the headline (N = 1): what the judges of rounds 1-2 asked to see next to `value`."""
     out = {}
-    # (1) the full kernel alone (pattern tables off): the g.f contraction on every row, the rate for inputs where no
-    # shot is tabulated
+
+    def pipelined_rate(hpx, f_list, n=48):
+        """Short pipelined run of another handle through the steps API (feedback first)."""
+        ks = (C.c_uint32 * 2)(1, 2)
+        outs = [hpx.malloc(B * 8) for _ in range(16)]
+        j = [0]
+
+        def go(k):
+            hpx.sample_steps_device([f_list[(j[0] + i) % len(f_list)].ptr for i in range(k)], B, num_f, ks,
+                                    [outs[(j[0] + i) % 16].ptr for i in range(k)], inputs_ready=True, out_bit_packed=True)
+            j[0] += k
+
+        for _ in range(4):
+            go(4)
+        hpx.synchronize()
+        t0 = time.perf_counter()
+        go(n)
+        hpx.synchronize()
+        dt = time.perf_counter() - t0
+        for o in outs:
+            o.free()
+        return {"shots_per_s": B * n / dt, "ms_per_step": dt / n * 1e3, "steps": n}
+
+    # (1) the full kernel alone
     if info.get("pattern_tables"):
-        hp_full = backend.HipProgram(program, device=device, pattern_tables=False)
-        for _ in range(2):
-            hp_full.sample_batch_device(f_bufs[0].ptr, B, num_f, key, d_out0.ptr)
-        hp_full.synchronize()
-        hp_full.profile_enable(True)
-        hp_full.profile_read(reset=True)
-        for k in range(5):
-            hp_full.sample_batch_device(f_bufs[k % len(f_bufs)].ptr, B, num_f, key, d_out0.ptr)
-        fms, fl = hp_full.profile_read(reset=True)
-        hp_full.profile_enable(False)
-        out["full_kernel_only"] = {
-            "kernel": "tsimk::k_sample4" if hp_full.info().get("chunk_table_kernel") else "tsimk::k_sample",
-            "kernel_avg_ms": fms / max(fl, 1), "shots_per_s": B / (fms / max(fl, 1) * 1e-3), "launches": fl}
-        hp_full.close()
+        out["full_kernel_only"] = full_kernel_leg(backend, program, device, f_bufs, B, num_f, key, d_out0)
+    # (1b) what the real circuits would run (SURVEY section 7 hard part 2, section 8(d) "two variants"): the same shape with
+    # has_approximate_floatfactors = True (compile/evaluate.py:56-59: float32 sum over the graphs) - pipeline and full kernel;
+    # and with padding terms the packer's algebra cannot cancel (tsim_amd.synth: live_padding) - complex amplitudes, full-rank
+    # quadratic forms, 3x the GF(2) rows
+    if not args.program and not args.random_program and args.config in ("C2", "C3", "C4"):
+        variants = {}
+        for vname, kw in (("approx_floatfactors", dict(approx=True)), ("live_padding", dict(live_padding=True)),
+                          ("live_padding_approx", dict(live_padding=True, approx=True))):
+            if (vname == "approx_floatfactors" and args.approx and not args.live_padding) or (vname == "live_padding" and args.live_padding and not args.approx):
+                continue  # that IS the headline
+            pv, _ = synth.config_program(args.config, **kw)
+            hv = backend.HipProgram(pv, device=device)
+            iv = hv.info()
+            leg = {"total_rows": iv["total_rows"], "table_bytes": iv["table_bytes"], "pipelined": pipelined_rate(hv, f_bufs)}
+            hv.close()
+            fk = full_kernel_leg(backend, pv, device, f_bufs, B, num_f, key, d_out0)
+            leg["full_kernel_only"] = {k: fk[k] for k in ("kernel", "kernel_avg_ms", "shots_per_s")}
+            variants[vname] = leg
+        out["variants"] = variants
     # (2) dense error patterns: the same pipeline, f with p_bit = 0.1 and 0.3 (launch plan re-adapts first)
     dense = {}
     for p_bit in (0.1, 0.3):
         fl = [resident_f(p_bit, 5000 + int(p_bit * 100) + k) for k in range(2)]
-        for _ in range(init_steps + 16):
-            step(fl)
+        for _ in range((init_steps + 16) // 4):
+            steps(4, fl)
         drain()
         hp.synchronize()
         n = 40
         t0 = time.perf_counter()
-        for _ in range(n):
-            step(fl)
+        steps(n, fl)
         drain()
         hp.synchronize()
         dt = time.perf_counter() - t0
         dense[f"p_bit_{p_bit}"] = {"shots_per_s": B * n / dt, "ms_per_step": dt / n * 1e3, "steps": n}
         for b in fl:
             b.free()
-    for _ in range(init_steps + 16):  # back to the benchmark's f distribution for whoever runs after us
-        step()
+    for _ in range((init_steps + 16) // 4):  # back to the benchmark's f distribution for whoever runs after us
+        steps(4)
     drain()
     hp.synchronize()
     out["dense"] = dense
@@ -702,29 +980,41 @@ def extra_legs(backend, synth, program, cfg, hp, info, B, num_f, n_out, key, f_b
     out["time_to_first_batch_s"] = {"first_handle_incl_hip_init": t_build, "fresh_handle": t_handle,
                                     "fresh_handle_plus_first_batch": time.perf_counter() - t0, "shots": B}
     hp2.close()
-    # (4) end to end through CompiledDetectorSampler.sample(): noise sampling + H2D + kernels + D2H, host arrays out
+    # (4) end to end through CompiledDetectorSampler.sample(): noise sampling + H2D + kernels + D2H, host arrays out.
+    # Two noise models: the stress case of rounds 1-2 (one channel per f bit at the benchmark's p_bit) and a BASELINE-style
+    # one (p = 1e-3 per mechanism, 20 mechanisms per f bit through a random error_transform: about the same f density).
     from tsim_amd.channels import error_probs
     from tsim_amd.sampler import CompiledDetectorSampler
 
-    probs = [error_probs(cfg["p_bit"])] * num_f
-    T = np.eye(num_f, dtype=np.uint8)
     shots, batch = 4_000_000, 1_000_000
-    e2e = {"shots": shots, "batch_size": batch, "noise_model": f"{num_f} one-bit channels, p = {cfg['p_bit']}, identity error_transform",
+    rng = np.random.default_rng(7)
+    n_mech = 20 * num_f
+    T_mech = np.zeros((num_f, n_mech), dtype=np.uint8)
+    T_mech[rng.integers(0, num_f, size=n_mech), np.arange(n_mech)] = 1
+    models = {
+        "p_bit": ([error_probs(cfg["p_bit"])] * num_f, np.eye(num_f, dtype=np.uint8), f"{num_f} one-bit channels, p = {cfg['p_bit']}, identity error_transform"),
+        "p1e-3": ([error_probs(1e-3)] * n_mech, T_mech, f"{n_mech} one-bit channels at p = 1e-3 (BASELINE configs' noise level), each feeding one of the "
+                  f"{num_f} f bits (about 20 mechanisms per bit)"),
+    }
+    e2e = {"shots": shots, "batch_size": batch,
            "note": "host_noise*: the reference's numpy/PCG64 channel stream reproduced bit for bit by the native sampler "
                    "(tsim_pcg_sample_channels); device_noise*: k_noise (statistically equivalent, f never leaves HBM); "
                    "*_bit_packed: 3 B/shot over PCIe instead of 20"}
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        for name, kw, skw in (("host_noise", dict(noise="host"), dict(append_observables=True)),
-                              ("host_noise_bit_packed", dict(noise="host"), dict(append_observables=True, bit_packed=True)),
-                              ("device_noise", dict(noise="device"), dict(append_observables=True)),
-                              ("device_noise_bit_packed", dict(noise="device"), dict(append_observables=True, bit_packed=True))):
-            s = CompiledDetectorSampler(program, channel_probs=probs, error_transform=T, seed=1, device=device, **kw)
-            s.sample(shots, batch_size=batch, **skw)  # same shape once: buffers, lanes
-            t0 = time.perf_counter()
-            res = s.sample(shots, batch_size=batch, **skw)
-            dt = time.perf_counter() - t0
-            e2e[name] = {"shots_per_s": shots / dt, "seconds": dt, "result_bytes": int(res.nbytes)}
+        for mname, (probs, T, desc) in models.items():
+            leg = {"noise_model": desc}
+            for name, kw, skw in (("host_noise", dict(noise="host"), dict(append_observables=True)),
+                                  ("host_noise_bit_packed", dict(noise="host"), dict(append_observables=True, bit_packed=True)),
+                                  ("device_noise", dict(noise="device"), dict(append_observables=True)),
+                                  ("device_noise_bit_packed", dict(noise="device"), dict(append_observables=True, bit_packed=True))):
+                s = CompiledDetectorSampler(program, channel_probs=probs, error_transform=T, seed=1, device=device, **kw)
+                s.sample(shots, batch_size=batch, **skw)  # same shape once: buffers, lanes
+                t0 = time.perf_counter()
+                res = s.sample(shots, batch_size=batch, **skw)
+                dt = time.perf_counter() - t0
+                leg[name] = {"shots_per_s": shots / dt, "seconds": dt, "result_bytes": int(res.nbytes)}
+            e2e[mname] = leg
     out["e2e_sample"] = e2e
     return out
 

@@ -105,6 +105,46 @@ def test_tcp_rendezvous_delivers_the_id_to_every_rank(world):
     assert sorted(got) == list(range(world)) and all(v == bytes(range(128)) for v in got.values())
 
 
+def _stray_then_real(port, q):
+    """A stray connection that says nothing, one that says garbage, then rank 1 twice (a retry)."""
+    import time
+
+    for payload in (None, b"GET / HTTP/1.0\r\n\r\n"):
+        for _ in range(200):
+            try:
+                c = socket.create_connection(("127.0.0.1", port), timeout=1.0)
+                break
+            except OSError:
+                time.sleep(0.05)
+        if payload:
+            c.sendall(payload)
+        c.close()
+    a = tdist.rendezvous_tcp(1, 3, port=port, timeout=60)
+    b = tdist.rendezvous_tcp(1, 3, port=port, timeout=60)  # the same rank again: served, not counted twice
+    q.put((1, a, b))
+
+
+def test_rendezvous_counts_distinct_ranks_not_connections():
+    """Rank 0 keeps serving until ranks 1 AND 2 have the id, whatever else connects in between."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    p0 = ctx.Process(target=_rdzv_worker, args=(0, 3, port, q))
+    p1 = ctx.Process(target=_stray_then_real, args=(port, q))
+    p0.start()
+    p1.start()
+    r1 = q.get(timeout=60)
+    assert r1[0] == 1 and r1[1] == r1[2] == bytes(range(128))
+    assert p0.is_alive()  # still waiting for rank 2
+    p2 = ctx.Process(target=_rdzv_worker, args=(2, 3, port, q))
+    p2.start()
+    got = dict(q.get(timeout=60) for _ in range(2))
+    for p in (p0, p1, p2):
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    assert got[0] == got[2] == bytes(range(128))
+
+
 def test_rendezvous_rejects_a_foreign_service():
     import threading
 
@@ -125,6 +165,32 @@ def test_rendezvous_rejects_a_foreign_service():
     t.join()
     srv.close()
     assert tdist.rendezvous_tcp(0, 1, port=1, make_id=lambda: b"x" * 128) == b"x" * 128  # world 1: no socket at all
+
+
+def test_bench_launches_its_own_ranks_without_a_launcher():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment spawns two ranks itself (one process per GPU,
+    tsim_amd.dist's socket rendezvous, no torch.distributed); TSIM_BENCH_LAUNCH_ONLY stops each rank where the RCCL
+    communicator would be created - with the same 128 bytes in hand on both.  (No GPU needed up to that point.)"""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env["TSIM_BENCH_LAUNCH_ONLY"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3"], env=env, cwd=root,
+                       capture_output=True, text=True, timeout=180)
+    assert r.returncode == 0, r.stderr[-1500:]
+    lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert sorted(d["rank"] for d in lines) == [0, 1] and all(d["world"] == 2 and d["launch_only"] for d in lines)
+    assert sorted(d["local_rank"] for d in lines) == [0, 1]
+    assert lines[0]["id_sha"] == lines[1]["id_sha"]
+    # and a launcher's world size that contradicts --gpus is an error, never a line with another n_gpus
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3"], env=env2, cwd=root,
+                        capture_output=True, text=True, timeout=60)
+    assert r2.returncode != 0 and "WORLD_SIZE=1" in r2.stderr and not r2.stdout.strip()
 
 
 def test_no_torch_in_the_product_package():

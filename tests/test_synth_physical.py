@@ -70,6 +70,36 @@ def test_levels_are_exact_marginals(name):
             prev = [a1[r] if m[r, i] else a0[r] for r in range(nrows)]
 
 
+@pytest.mark.parametrize("name", ["C2", "C3"])
+def test_live_padding_keeps_the_model_and_survives_the_algebra(name):
+    """live_padding: the exact marginal identity still holds (the common phase w^q(f) multiplies every level alike),
+    amplitudes are genuinely complex, the normalisation deviation stays at float32 rounding."""
+    prog, cfg = synth.config_program(name, live_padding=True)
+    rng = np.random.default_rng(5)
+    comp = prog.components[0]
+    F, n = len(comp.f_selection), len(comp.output_indices)
+    levels = comp.compiled_scalar_graphs
+    nrows = 60
+    f = (rng.random((nrows, F)) < 0.15).astype(np.uint8)
+    m = rng.integers(0, 2, size=(nrows, n), dtype=np.uint8)
+    prev = _exact(levels[0], f)
+    assert any(v[1] != v[3] or v[2] != 0 for v in prev)  # not all real any more
+    for i in range(n):
+        ctx = np.concatenate([f, m[:, :i]], axis=1)
+        a0 = _exact(levels[i + 1], np.concatenate([ctx, np.zeros((nrows, 1), np.uint8)], axis=1))
+        a1 = _exact(levels[i + 1], np.concatenate([ctx, np.ones((nrows, 1), np.uint8)], axis=1))
+        for r in range(nrows):
+            assert _add(a0[r], a1[r]) == prev[r], (name, i, r)
+        prev = [a1[r] if m[r, i] else a0[r] for r in range(nrows)]
+    fb = synth.synth_f(300, cfg["num_f"], cfg["p_bit"], seed=3)
+    _, devs = O.sample_program(prog, fb, (3, 4), return_devs=True)
+    assert max(float(d) for d in devs) < 1e-5
+    # same graph counts as the neutral-padding program, comparable term counts
+    ref, _ = synth.config_program(name)
+    assert [lv.num_graphs for lv in levels] == [lv.num_graphs for lv in ref.components[0].compiled_scalar_graphs]
+    assert (levels[-1].halfpi_phases.coeffs != 0).sum() > 0 and levels[-1].pi_products.psi_params.any()
+
+
 @pytest.mark.parametrize("name,approx", [("C2", False), ("C2", True), ("C3", False), ("C5", False)])
 def test_no_normalisation_warning(name, approx):
     from tsim_amd.backend import check_norm_deviation

@@ -1,7 +1,9 @@
 """The N > 1 code path of bench.py (RCCL collection of the bit-packed rows through libtsim_hip.so's own
-communicator, lanes joined on the batch lane) forced on one GPU: it must run to completion and print the
-contract's JSON line.  The real N > 1 runs are the driver's; this keeps the plumbing from rotting between
-rounds.  (Named test_zz_* so that it runs last: a subprocess with its own HIP context.)"""
+communicator, lanes joined on the batch lane) forced on one GPU: it must run to completion, print the
+contract's JSON line, and - TSIM_BENCH_VERIFY=1 - the bytes that arrive in the receive buffers must equal the
+rows of a serial full-kernel run, for a complete gather group and for a PARTIAL one (exact count, no stale tail),
+with both collectives.  The real N > 1 runs are the driver's; this keeps the plumbing honest between rounds.
+(Named test_zz_* so that it runs last: a subprocess with its own HIP context.)"""
 import json
 import os
 import socket
@@ -20,11 +22,11 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("mode", ["alltoall", "root0", "auto"])
+@pytest.mark.parametrize("mode", ["alltoall", "root0", "default"])
 def test_bench_distributed_path_on_one_gpu(hip, mode):
-    env = dict(os.environ, TSIM_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1",
+    env = dict(os.environ, TSIM_BENCH_FORCE_DIST="1", TSIM_BENCH_VERIFY="1", MASTER_ADDR="127.0.0.1",
                MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
-    if mode == "auto":  # the defaults: spread roots, group size from --steps (8 batches per collective at 21 steps)
+    if mode == "default":  # the defaults: the north star's gather to rank 0, group size from --steps (8 batches at 21 steps)
         env.pop("TSIM_BENCH_GATHER", None)
         env.pop("TSIM_BENCH_GATHER_EVERY", None)
     else:
@@ -39,8 +41,19 @@ def test_bench_distributed_path_on_one_gpu(hip, mode):
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 1 and d["steps"] == 21 and d["value"] > 0 and d["scaling"] == "weak"
-    assert ("all-to-all" in d["config"]["sharding"]) == (mode != "root0")
-    if mode == "auto":
-        assert "every 8 batches" in d["config"]["sharding"]
-    assert d["roofline"]["achieved"] > 0 and d["roofline"]["launches"] >= 8
+    assert ("all-to-all" in d["config"]["sharding"]) == (mode == "alltoall")
+    if mode == "default":
+        assert "every 8 batches" in d["config"]["sharding"] and "gather to rank 0" in d["config"]["sharding"]
+    assert d["roofline"]["achieved"] > 0 and d["roofline"]["launches"] >= 3
     assert "no torch.distributed" in d["config"]["sharding"] and d["repeats"] >= 1
+    # the collected bytes were compared with a serial full-kernel run: 8 batches of the complete group + 5 of the partial one
+    assert d["verify"]["ok"] is True and d["verify"]["batches_checked_on_rank0"] == 13
+
+
+def test_bench_refuses_a_world_size_it_was_not_asked_for(hip):
+    """`--gpus 2` under a launcher that provides one rank: an error, not an n_gpus = 1 line."""
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--no-cpu-baseline", "--no-extra-legs"],
+                       env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

@@ -197,6 +197,12 @@ template <int GT, int NCH, int NW>
 __device__ __forceinline__ void sample4h_rows(const SampleArgs &A, int comp4_off, bool has_check, int group_tiles,
                                               int loop_stride, uint32_t *feedback, uint32_t bidx, uint32_t nblk) {
   typedef Hard4<GT, NCH, NW> H;
+#ifndef TSIMK_HARD_PRIO
+#define TSIMK_HARD_PRIO 3
+#endif
+  // The hard rows are a few hundred waves of latency-bound work beside a chip-full of issue-bound first-pass waves:
+  // when one of these waves can issue, it should (s_setprio: issue arbitration is by priority, then age).
+  if (TSIMK_HARD_PRIO) __builtin_amdgcn_s_setprio(TSIMK_HARD_PRIO);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const bool check_block = has_check && (bidx == nblk - 1);
   // feedback to the host (mapped pinned memory, read at later launches to choose the launch plan):

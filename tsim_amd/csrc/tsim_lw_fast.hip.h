@@ -60,11 +60,11 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(TSIMK_LW_
   typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
   constexpr int NPOS = 32 * WF32;                       // f-row bit positions
-  constexpr int L_RANK = 0;                             // [8][NPOS]
-  constexpr int L_LUT = L_RANK + 8 * NPOS;              // [2^NOUT][2]
+  constexpr int RSTR = NPOS + 1;                        // a rank row: NPOS entries and a zero (what an exhausted lane reads)
+  constexpr int L_RANK = 0;                             // [8][RSTR]
+  constexpr int L_LUT = (L_RANK + 8 * RSTR + 1) & ~1;   // [2^NOUT][2], 8-byte aligned
   constexpr int L_RUNS = L_LUT + (2 << NOUT);           // [MAX_RUNS][4]
   constexpr int L_BASES = L_RUNS + 4 * TSIMK_LWF_MAX_RUNS;  // [72]: bases[cnt], cnt <= 64; zeros above wmax
-  constexpr int L_ZERO = L_BASES + 71;                  // a word that is always 0
   constexpr int L_WORDS = L_BASES + 72;
   __shared__ uint32_t lds[L_WORDS];
   const int nthr = blockDim.x;
@@ -75,7 +75,8 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(TSIMK_LW_
   {
     const uint32_t *g = M.img;
     const uint32_t rank_off = fr[LWF_RANK], lut_off = fr[LWF_LUT], runs_off = fr[LWF_RUNS], n_runs = fr[LWF_NRUNS];
-    for (int i = threadIdx.x; i < 8 * NPOS; i += nthr) lds[L_RANK + i] = g[rank_off + (uint32_t)(i / NPOS) * 128u + (uint32_t)(i % NPOS)];
+    for (int i = threadIdx.x; i < 8 * RSTR; i += nthr)
+      lds[L_RANK + i] = (i % RSTR) < NPOS ? g[rank_off + (uint32_t)(i / RSTR) * 128u + (uint32_t)(i % RSTR)] : 0u;
     for (int i = threadIdx.x; i < (2 << NOUT); i += nthr) lds[L_LUT + i] = g[lut_off + i];
     for (int i = threadIdx.x; i < 4 * TSIMK_LWF_MAX_RUNS; i += nthr) lds[L_RUNS + i] = (uint32_t)i < 4u * n_runs ? g[runs_off + i] : 0u;
     if (threadIdx.x < 72) lds[L_BASES + threadIdx.x] = threadIdx.x < 8 ? g[M.lw_off + LW_BASES_INLINE + threadIdx.x] : 0u;
@@ -89,7 +90,8 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(TSIMK_LW_
   const uint32_t wmax = rec[LW_WMAX];
   const uint32_t tab_byte = rec[LW_TAB] * 4u;
   const uint32_t keybase = rec[LW_KEYBASE];
-  const __amdgpu_buffer_rsrc_t r_tab = __builtin_amdgcn_make_buffer_rsrc((void *)M.tab, 0, 0xFFFFFFFF, 0x00020000);
+  // the descriptor ends with the tables: a lane whose pattern index means nothing (hard rows) reads zeros, never beyond
+  const __amdgpu_buffer_rsrc_t r_tab = __builtin_amdgcn_make_buffer_rsrc((void *)M.tab, 0, M.tab_bytes, 0x00020000);
   cstep steps = (cstep)((cbytes)__builtin_amdgcn_kernarg_segment_ptr() + __builtin_offsetof(LwMultiArgs, step));
   const uint32_t so_lo = (uint32_t)M.shot_offset, so_hi = (uint32_t)((unsigned long long)M.shot_offset >> 32);
 
@@ -106,6 +108,7 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(TSIMK_LW_
     const __amdgpu_buffer_rsrc_t r_f = __builtin_amdgcn_make_buffer_rsrc((void *)steps[st].f, 0, Bu * (uint32_t)(4 * WF32), 0x00020000);
     const uint32_t row = rbk * (uint32_t)nthr + threadIdx.x;
     const uint32_t off = row * (uint32_t)(4 * WF32);
+    if (TSIMK_LWM_SKIP & 64) { n[0] ^= (row * 0x9E3779B9u) & (row * 0x85EBCA6Bu) & (row * 0xC2B2AE35u) & 0x11111111u; n[1] = 0; return; }
     if constexpr (WF32 == 2) {
       const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r_f, off, 0, 0);
       n[0] = v.x; n[1] = v.y;
@@ -128,7 +131,7 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(TSIMK_LW_
       S->ctl_next[32u * threadIdx.x] = (threadIdx.x == TSIMK_LW_LISTS) ? 0xFFFFFFFFu : 0u;
     // ---- K14: direct outputs f[idx] ^ flip (sampler.py:140-145): bit-field runs, rotate and mask
     uint32_t o0 = 0u, o1 = 0u;
-    for (uint32_t r = 0; r < n_runs; ++r) {
+    for (uint32_t r = 0; r < ((TSIMK_LWM_SKIP & 2) ? 0u : n_runs); ++r) {
       const u32x4 run = *reinterpret_cast<const u32x4 *>(&lds[L_RUNS + 4u * r]);  // same address in every lane: broadcast
       const uint32_t sw = (uint32_t)__builtin_amdgcn_readfirstlane((int)run.x) >> 8;
       uint32_t src = f[0];
@@ -157,20 +160,39 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(TSIMK_LW_
     const bool easy = active && !hard;
     uint32_t pat = lds[L_BASES + cnt];
     const uint32_t live = easy ? cnt : 0u;
-    for (uint32_t k = 0; __builtin_amdgcn_ballot_w64(live > k) != 0ull; ++k) {
-      // lowest set bit over the words, then clear it
-      uint32_t p = 0u;
-      bool lower_zero = true;
+    // One ordinal: the lowest set bit of the masked words leaves them, its RANK entry joins the index.  An exhausted
+    // lane finds position 0xFFFFFFFF (v_ffbl_b32 of 0 is -1, `| 32 w` keeps it) -> the zero at the end of the row.
+    auto ordinal = [&](uint32_t k) -> uint32_t {
+      uint32_t c[4], t[4];
 #pragma unroll
       for (int w = 0; w < WF32; ++w) {
-        const bool here = lower_zero && m[w] != 0u;
-        p = here ? (uint32_t)__builtin_ctz(m[w]) + 32u * (uint32_t)w : p;
-        const uint32_t cleared = m[w] & (m[w] - 1u);
-        lower_zero = lower_zero && m[w] == 0u;
-        m[w] = here ? cleared : m[w];
+        uint32_t fb;
+        asm("v_ffbl_b32 %0, %1" : "=v"(fb) : "v"(m[w]));
+        c[w] = w ? (fb | (32u * (uint32_t)w)) : fb;
+        t[w] = m[w] & (m[w] - 1u);
       }
-      const uint32_t idx = (live > k) ? (uint32_t)L_RANK + k * (uint32_t)NPOS + p : (uint32_t)L_ZERO;
-      pat += lds[idx];
+      uint32_t p = c[0];
+#pragma unroll
+      for (int w = 1; w < WF32; ++w) p = p < c[w] ? p : c[w];
+      bool lower_zero = m[0] == 0u;
+      m[0] = t[0];
+#pragma unroll
+      for (int w = 1; w < WF32; ++w) {
+        const bool z = m[w] == 0u;
+        m[w] = lower_zero ? t[w] : m[w];
+        lower_zero = lower_zero && z;
+      }
+      p = p < (uint32_t)NPOS ? p : (uint32_t)NPOS;
+      return lds[(uint32_t)L_RANK + k * (uint32_t)RSTR + p];
+    };
+    if (!(TSIMK_LWM_SKIP & 4)) {
+      // The first two ordinals without asking (98 % of the waves hold a lane of weight 2), the rest while a lane
+      // needs them.  Lanes that are not `easy` run along: whatever they add up is never used (their table reads stay
+      // inside the descriptor).
+      const uint32_t r0 = ordinal(0u);
+      const uint32_t r1 = ordinal(1u);
+      pat += r0 + r1;
+      for (uint32_t k = 2u; __builtin_amdgcn_ballot_w64(live > k) != 0ull; ++k) pat += ordinal(k);
     }
     // ---- thresholds of the pattern's prefix tree and the draws (sampler.py:62-79 with the thresholds tabulated)
     const uint32_t thr = tab_byte + (pat << (NOUT + 2));  // byte offset of the pattern's row
@@ -178,10 +200,15 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(TSIMK_LW_
     cptr kp = (cptr)((cbytes)S + __builtin_offsetof(LwStep, keys)) + 2u * keybase;
     auto draw = [&](int o) -> uint32_t {
       const uint32_t k0 = kp[2 * o], k1 = kp[2 * o + 1];
+      if (TSIMK_LWM_SKIP & 1) return (slo * 0x9E3779B9u + k0 + k1) >> 9;  // diagnostic: no Threefry
       return threefry_bits32_lo(k0, k1, k0 + so_hi, slo) >> 9;
     };
     uint32_t node = 1u;
     int i = 0;
+    if (TSIMK_LWM_SKIP & 32) {  // diagnostic: thresholds without memory
+#pragma unroll
+      for (; i < NOUT; ++i) node = 2u * node + (draw(i) < ((thr * 2654435761u + node * 40503u) & 0x7FFFFFu) ? 1u : 0u);
+    }
 #pragma unroll
     for (; i + 3 <= NOUT; i += 3) {
       const uint32_t t0 = __builtin_amdgcn_raw_buffer_load_b32(r_tab, thr + 4u * node, 0, 0);
@@ -194,7 +221,8 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(TSIMK_LW_
       const bool b2 = d2 < (b0 ? hi : lo);
       node = 8u * node + (b0 ? 4u : 0u) + (b1 ? 2u : 0u) + (b2 ? 1u : 0u);
     }
-    if constexpr (NOUT % 3 == 2) {
+    if (TSIMK_LWM_SKIP & 32) {
+    } else if constexpr (NOUT % 3 == 2) {
       const uint32_t t0 = __builtin_amdgcn_raw_buffer_load_b32(r_tab, thr + 4u * node, 0, 0);
       const u32x2 t1 = __builtin_amdgcn_raw_buffer_load_b64(r_tab, thr + 8u * node, 0, 0);
       const uint32_t d0 = draw(i), d1 = draw(i + 1);
@@ -209,7 +237,8 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(TSIMK_LW_
     const u32x2 placed = *reinterpret_cast<const u32x2 *>(&lds[L_LUT + 2u * (node & ((1u << NOUT) - 1u))]);
     o0 |= placed.x;
     o1 |= placed.y;
-    if (easy) {
+    if (TSIMK_LWM_SKIP & 16) n[0] ^= (o0 ^ o1) & 0x10101010u;  // diagnostic: results stay live without stores
+    if (easy && !(TSIMK_LWM_SKIP & 16)) {
       uint64_t *out = S->out;
       uint8_t *oc = S->out_compact;
       if (out) {
@@ -220,9 +249,19 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(TSIMK_LW_
       }
       if (oc) {
         const __amdgpu_buffer_rsrc_t r_c = __builtin_amdgcn_make_buffer_rsrc((void *)oc, 0, 0xFFFFFFFF, 0x00020000);
+        // out_rb bytes at row * out_rb (any alignment: the device runs in unaligned-access mode): as few stores as the
+        // size allows - 4-byte pieces, then 2, then 1 (20 outputs: a short and a byte instead of three bytes)
         const uint32_t off = row * (uint32_t)M.out_rb;
-        for (int k = 0; k < M.out_rb; ++k)
-          __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(((k < 4) ? o0 : o1) >> (8 * (k & 3))), r_c, off + (uint32_t)k, 0, 0);
+        const int rb8 = M.out_rb;
+        if (rb8 >= 4) __builtin_amdgcn_raw_buffer_store_b32(o0, r_c, off, 0, 0);
+        if (rb8 == 8) __builtin_amdgcn_raw_buffer_store_b32(o1, r_c, off, 4, 0);
+        else {
+          const uint32_t w = rb8 >= 4 ? o1 : o0;  // the word the remaining 1..3 bytes come from
+          const uint32_t at = rb8 >= 4 ? off + 4u : off;
+          const int rem = rb8 & 3;
+          if (rem >= 2) __builtin_amdgcn_raw_buffer_store_b16((uint16_t)w, r_c, at, 0, 0);
+          if (rem & 1) __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(w >> (rem == 3 ? 16 : 0)), r_c, at + (rem == 3 ? 2u : 0u), 0, 0);
+        }
       }
     }
     // ---- wave-aggregated append of the hard rows to this batch's lists

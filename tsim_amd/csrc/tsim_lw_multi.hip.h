@@ -41,7 +41,8 @@ struct LwMultiArgs {
   int n_steps, blocks_per_step;
   int n_comp, lw_off, direct_rot, binom_off;
   int has_check, list_cap, n_lists, out_rb;
-  int lwf_off, pad0;      // image offset of the fast record (k_sample_lw_fast), 0 = none
+  int lwf_off;            // image offset of the fast record (k_sample_lw_fast), 0 = none
+  uint32_t tab_bytes;     // size of the pattern tables when below 4 GB (k_sample_lw_fast: range-checked reads)
   LwStep step[TSIMK_LWM_MAX_STEPS];
 };
 

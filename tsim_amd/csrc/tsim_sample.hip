@@ -763,6 +763,7 @@ static int steps_group_fused(tsim_program *p, int n, const uint64_t *const *d_f,
   const bool fast = p->lwf_off != 0 && p->knobs.lw_fast && B < (1ll << 28) && p->lw_bytes < (1ll << 32) && (n_lists & (n_lists - 1)) == 0 &&
                     ((unsigned long long)shot_offset >> 32) == ((unsigned long long)(shot_offset + B - 1) >> 32);
   M.lwf_off = fast ? p->lwf_off : 0;
+  M.tab_bytes = fast ? (uint32_t)p->lw_bytes : 0u;
   if (fast) {
     const int n_out = p->comps[0].n_out;
 #define TSIM_LF(N)                                                                                     \
@@ -834,7 +835,21 @@ extern "C" int tsim_sample_steps_device(tsim_program *p, int32_t n_steps, const 
       const int left = n_steps - done;
       const int gmax = std::min(TSIMK_LWM_MAX_STEPS, p->knobs.fused_max);
       const int groups = (left + gmax - 1) / gmax;
-      const int n = (left + groups - 1) / groups;
+      int n = (left + groups - 1) / groups;
+      if (const char *e = getenv("TSIM_AMD_FUSED_PLAN")) {  // experiments: "2,6,6,4,2" = the group sizes of a call, in order
+        int idx = 0, gi = 0;
+        for (int d2 = 0; d2 < done;) {  // which group are we at
+          int v = atoi(e + idx);
+          if (v < 1) break;
+          d2 += v;
+          ++gi;
+          const char *c2 = strchr(e + idx, ',');
+          if (!c2) { idx = -1; break; }
+          idx = (int)(c2 - e) + 1;
+        }
+        (void)gi;
+        if (idx >= 0) { const int v = atoi(e + idx); if (v >= 1) n = std::min(std::min(v, left), TSIMK_LWM_MAX_STEPS); }
+      }
       {
         const size_t hard_bytes = (size_t)(((B + 255) / 256 + TSIMK_LW_LISTS - 1) / TSIMK_LW_LISTS * 1024) * TSIMK_LW_LISTS * 4;
         for (int j = 0; j < n; ++j)

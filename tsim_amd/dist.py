@@ -54,10 +54,23 @@ def unique_id() -> bytes:
     return bytes(buf)
 
 
+def _recv_exact(conn: socket.socket, n: int) -> bytes:
+    data = b""
+    while len(data) < n:
+        chunk = conn.recv(n - len(data))
+        if not chunk:
+            break
+        data += chunk
+    return data
+
+
 def rendezvous_tcp(rank: int, world: int, *, addr: str = "127.0.0.1", port: int, timeout: float = 120.0,
                    make_id=unique_id) -> bytes:
-    """Rank 0 creates the id and serves it on ``(addr, port)`` until the ``world - 1`` other ranks have fetched
-    it; the others connect (retrying until ``timeout``) and read it.  Frames carry a magic prefix, so a foreign
+    """Rank 0 creates the id and serves it on ``(addr, port)`` until every other rank has fetched it; the others
+    connect (retrying until ``timeout``), announce themselves - magic prefix and their rank - and read it.  Rank 0
+    counts DISTINCT ranks: a stray connection (a port scan, a health probe, the second attempt of a rank whose first
+    read timed out) is answered or dropped without using up anybody's place, and the listener stays open until all
+    ``world - 1`` ranks have been served or the deadline passes.  The reply carries the magic too, so a foreign
     service on the port is recognised and reported instead of being trusted."""
     if world == 1:
         return make_id()
@@ -67,32 +80,45 @@ def rendezvous_tcp(rank: int, world: int, *, addr: str = "127.0.0.1", port: int,
         with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as srv:
             srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
             srv.bind((addr, port))
-            srv.listen(world)
-            served = 0
-            while served < world - 1:
-                srv.settimeout(max(0.1, deadline - time.monotonic()))
+            srv.listen(max(8, 2 * world))
+            served: set[int] = set()
+            while len(served) < world - 1:
+                left = deadline - time.monotonic()
+                if left <= 0:
+                    raise TimeoutError(f"rendezvous: only ranks {sorted(served)} of {world - 1} fetched the id")
+                srv.settimeout(max(0.1, left))
                 try:
                     conn, _ = srv.accept()
-                except socket.timeout as exc:
-                    raise TimeoutError(f"rendezvous: only {served} of {world - 1} ranks fetched the id") from exc
+                except socket.timeout:
+                    continue
                 with conn:
-                    conn.sendall(_MAGIC + ident)
-                served += 1
+                    try:
+                        conn.settimeout(2.0)
+                        hello = _recv_exact(conn, len(_MAGIC) + 4)
+                        if hello[: len(_MAGIC)] != _MAGIC or len(hello) != len(_MAGIC) + 4:
+                            continue  # not one of ours
+                        peer = int.from_bytes(hello[len(_MAGIC):], "little")
+                        if not 0 < peer < world:
+                            continue
+                        conn.sendall(_MAGIC + ident)
+                        served.add(peer)
+                    except OSError:
+                        continue  # that rank will come again
         return ident
     last = None
     while time.monotonic() < deadline:
         try:
             with socket.create_connection((addr, port), timeout=2.0) as conn:
-                data = b""
-                while len(data) < len(_MAGIC) + ID_BYTES:
-                    chunk = conn.recv(4096)
-                    if not chunk:
-                        break
-                    data += chunk
+                conn.settimeout(5.0)
+                conn.sendall(_MAGIC + int(rank).to_bytes(4, "little"))
+                data = _recv_exact(conn, len(_MAGIC) + ID_BYTES)
             if data[: len(_MAGIC)] != _MAGIC or len(data) != len(_MAGIC) + ID_BYTES:
                 raise RuntimeError(f"rendezvous: ({addr}, {port}) is not served by rank 0 of this job")
             return data[len(_MAGIC):]
-        except (ConnectionRefusedError, socket.timeout, OSError) as exc:
+        except (ConnectionRefusedError, ConnectionResetError, socket.timeout, TimeoutError) as exc:
+            last = exc
+            time.sleep(0.05)
+        except OSError as exc:
             last = exc
             time.sleep(0.05)
     raise TimeoutError(f"rendezvous: rank {rank} could not reach rank 0 at ({addr}, {port}): {last}")

@@ -310,17 +310,20 @@ CONFIGS = {
 }
 
 
-def config_program(name: str, *, approx: bool = False, physical: bool = True) -> tuple[CompiledProgram, dict]:
+def config_program(name: str, *, approx: bool = False, physical: bool = True, live_padding: bool = False) -> tuple[CompiledProgram, dict]:
     """Return ``(program, config_dict)`` for one of ``C1..C5``.
 
     ``physical=True`` (default): the normalised probability model of :func:`physical_program`;
     ``physical=False``: the unconstrained random program of :func:`synth_program` (nonsense marginals,
-    NaN / negative thresholds - the kernels must equal the oracle on those too)."""
+    NaN / negative thresholds - the kernels must equal the oracle on those too).
+    ``live_padding=True`` (physical programs): the term counts of the published shape are reached with terms that DO
+    something - a quadratic phase common to every graph and per-lineage weight factors - instead of neutral pairs that
+    the packer's algebra cancels (see :func:`physical_component`)."""
     cfg = CONFIGS[name]
     if physical:
         prog = physical_program(num_f=cfg["num_f"], n_direct=cfg["n_direct"], components=[dict(c) for c in cfg["components"]],
-                                seed=cfg["seed"], approx=approx)
-        return prog, dict(cfg, name=cfg["name"] + ", normalised probability model")
+                                seed=cfg["seed"], approx=approx, live_padding=live_padding)
+        return prog, dict(cfg, name=cfg["name"] + ", normalised probability model" + (", live padding" if live_padding else ""))
     comps = [dict(c, approx=approx) if approx else dict(c) for c in cfg["components"]]
     prog = synth_program(
         num_f=cfg["num_f"], n_direct=cfg["n_direct"], components=comps, seed=cfg["seed"]
@@ -440,8 +443,18 @@ def _pad_neutral(rng, g: dict, P: int, density: float, ta, tb, tc, td) -> dict:
 
 def physical_component(rng, output_indices, f_selection, Gs, *, density: float = 0.3, ta=(4, 16), tb=(4, 24),
                        tc=(8, 40), td=(0, 4), approx: bool = False, delta_fraction: float = 0.08,
-                       signed_fraction: float = 0.35) -> CompiledComponent:
-    """One normalised component with ``Gs[k]`` graphs at level k (see the block comment above)."""
+                       signed_fraction: float = 0.35, live_padding: bool = False) -> CompiledComponent:
+    """One normalised component with ``Gs[k]`` graphs at level k (see the block comment above).
+
+    ``live_padding``: the neutral pairs that bring a graph to the published term counts are exact no-ops, and the
+    packer's GF(2) algebra removes them (C2: 10 972 rows in, 2 510 kept).  With ``live_padding`` the same counts are
+    reached by terms no algebra can remove, the model staying a normalised mixture:
+      * a quadratic phase w^q(f) COMMON to every graph of every level - HalfPi rows with coefficients 2/4/6 and
+        PiProducts on f-only rows, about tb/2 and tc/2 of them: amp_i -> w^q(f) amp_i for all i, so |amp| and every
+        threshold are unchanged as real numbers while each graph's quadratic form has full rank (Dickson pairs) and the
+        amplitudes are genuinely complex (the general |z| path);
+      * per LINEAGE (identical in all its members, from level 0 on) ta/2 "T" pairs (k, 8 - k) on f rows: positive
+        f-dependent weights (2 +- sqrt2)/4 - counted NodePhases rows."""
     n, F = len(output_indices), len(f_selection)
     if len(Gs) != n + 1:
         raise ValueError("need n+1 graph counts per component")
@@ -456,7 +469,8 @@ def physical_component(rng, output_indices, f_selection, Gs, *, density: float =
         if approx:
             base["approx"] = complex(0.5 + rng.random())  # real positive: mixture weights stay positive
         if F > 0:
-            for _ in range(int(rng.integers(0, 3))):  # f-dependent weight
+            n_t = int(rng.integers(max(1, ta[0] // 2), max(2, ta[1] // 2) + 1)) if live_padding else int(rng.integers(0, 3))
+            for _ in range(n_t):  # f-dependent weight
                 k = int(rng.choice([1, 3]))
                 row = _rand_row(rng, 0, F, density)
                 base["A"] += [(k, row), (8 - k, row)]
@@ -474,9 +488,26 @@ def physical_component(rng, output_indices, f_selection, Gs, *, density: float =
             lineages.append([base])
             left -= 1
     levels = []
+    common_B, common_C = [], []
+    if live_padding and F > 0:
+        common_B = [(int(rng.choice([2, 4, 6])), _rand_row(rng, 0, F, density)) for _ in range(int(rng.integers(max(1, tb[0] // 2), max(2, tb[1] // 2) + 1)))]
+        common_C = [(int(rng.integers(0, 2)), _rand_row(rng, 0, F, density), int(rng.integers(0, 2)), _rand_row(rng, 0, F, density))
+                    for _ in range(int(rng.integers(max(1, tc[0] // 2), max(2, tc[1] // 2) + 1)))]
 
     def emit(k: int):
-        graphs = [_pad_neutral(rng, g, F + k, density, ta, tb, tc, td) for lin in lineages for g in lin]
+        if live_padding:
+            graphs = []
+            for lin in lineages:
+                for g in lin:
+                    g2 = _copy_graph(g)
+                    g2["B"] = list(g2["B"]) + common_B
+                    g2["C"] = list(g2["C"]) + common_C
+                    for fam in "ABCD":  # term order inside a family is free
+                        order = rng.permutation(len(g2[fam]))
+                        g2[fam] = [g2[fam][int(q)] for q in order]
+                    graphs.append(g2)
+        else:
+            graphs = [_pad_neutral(rng, g, F + k, density, ta, tb, tc, td) for lin in lineages for g in lin]
         assert len(graphs) == Gs[k]
         return scalar_graphs_from_terms(F + k, graphs)
 
@@ -533,7 +564,7 @@ def physical_component(rng, output_indices, f_selection, Gs, *, density: float =
 def physical_program(*, num_f: int, n_direct: int, components: list[dict], seed: int = 42,
                      num_detectors: int | None = None, shuffle_outputs: bool = False,
                      direct_flip_fraction: float = 0.0, identity_direct: bool = True,
-                     approx: bool = False) -> CompiledProgram:
+                     approx: bool = False, live_padding: bool = False) -> CompiledProgram:
     """Normalised counterpart of :func:`synth_program` (same arguments, same shapes)."""
     rng = np.random.default_rng([seed, 0x70687973])
     n_comp_out = sum(c["n"] for c in components)
@@ -547,7 +578,7 @@ def physical_program(*, num_f: int, n_direct: int, components: list[dict], seed:
         n, F = int(c["n"]), int(c["F"])
         kw = {k: v for k, v in c.items() if k in ("density", "ta", "tb", "tc", "td")}
         fsel = np.sort(rng.choice(num_f, size=F, replace=False)).astype(np.int32)
-        comps.append(physical_component(rng, out_ids[pos:pos + n], fsel, list(c["G"]), approx=approx, **kw))
+        comps.append(physical_component(rng, out_ids[pos:pos + n], fsel, list(c["G"]), approx=approx, live_padding=live_padding, **kw))
         pos += n
     nd = num_detectors if num_detectors is not None else n_direct
     return make_program(comps, direct, num_outputs, nd)

@@ -121,6 +121,7 @@ struct tsim_program {
   int v4_max_nch = 1;
   int v4_max_sent = 0;        // entries per tile of the sparse-f tables (0: none)
   long long total_graphs = 0, total_rows = 0;
+  long long hw_max_rows = 0;  // longest per-level row stream (LDS of the wave-per-row kernel: one parity bit per row)
   long long stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // see tsim_program_stats
   int max_f_index = -1;
   std::vector<int> level_off;  // flattened [component][level] -> offset of level record
@@ -218,6 +219,7 @@ struct tsim_program {
     int batch_lanes = 1;      // TSIM_AMD_BATCH_LANES=2: hard-row batches alternate over two streams (no measured gain: both land on one hardware queue)
     int defer_group = 4;      // TSIM_AMD_DEFER_GROUP: launches per deferred hard-row batch (<= TSIMK_H_MAX_CTX)
     bool fused_steps = true;  // TSIM_AMD_FUSED_STEPS=0: tsim_sample_steps_device launches batch by batch
+    bool hard_wave = true;    // TSIM_AMD_HARD_WAVE=0: hard-row batches on k_sample4h_multi (64 rows per block) instead of one wave per row
     bool lw_fast = true;      // TSIM_AMD_LW_FAST=0: the generic fused pass (k_sample_lw_multi) also for one-component programs
     int fused_max = 8;        // TSIM_AMD_FUSED_MAX: batches per fused first pass (<= TSIMK_LWM_MAX_STEPS = TSIMK_H_MAX_CTX)
   } knobs;

@@ -25,7 +25,8 @@ typedef const __attribute__((address_space(4))) uint32_t *cptr;
 // component record
 enum { C_NOUT = 0, C_F, C_W, C_FSEL, C_LEVELS, C_OUTPOS, C_KEYBASE, C_NLEVELS, C_WORDS = 8 };
 // level record
-enum { L_G = 0, L_GRAPHS, L_FLAGS, L_NPARAMS, L_FRAME, L_WORDS = 8 };
+enum { L_G = 0, L_GRAPHS, L_FLAGS, L_NPARAMS, L_FRAME, L_HWROWS /* fast layout: image offset of the level's uniform-stride row stream */,
+       L_HWN /* rows in it */, L_WORDS = 8 };
 // graph record
 enum {
   G_NA = 0, G_NB, G_NC, G_ND, G_ROWS, G_PHASE, G_FFA, G_FFB, G_FFC, G_FFD, G_POW2,
@@ -487,7 +488,9 @@ enum {
   GF_N01 = 0,   // n0 | n1 << 16   NodePhases rows of phase class 0 / 1 (counted)
   GF_N3H = 1,   // n3 | h << 16    class-3 rows (counted) / number of product pairs
   GF_FLAGS = 2, // TSIMK_GFLAG_LAM | _LIN | _D_TABLED
-  GF_ND = 3, GF_ROWS = 4, GF_TBL = 5, GF_N1 = 6, GF_TBL2 = 7, GF_APRE = 11, GF_APIM = 12
+  GF_ND = 3, GF_ROWS = 4, GF_TBL = 5, GF_N1 = 6, GF_TBL2 = 7,
+  GF_HWROW = 8, // index of the graph's first row in the level's uniform-stride stream (tsim_kernel_hw.hip.h)
+  GF_APRE = 11, GF_APIM = 12
 };
 #define TSIMK_ZERO_POWER (1 << 20)  // power given to an exactly-zero term: a no-op in the aligned add
 
@@ -514,6 +517,140 @@ __device__ __forceinline__ uint32_t rows_count_nometa(cptr &row, uint32_t n, con
   return cnt;
 }
 
+// One graph (stabiliser term) of a fast-layout level: its exact value (a, b, c, d) * 2^p - in fixed-frame levels
+// already shifted to the level's frame power (p unused) - from the graph record `gr` and the parameter words x.
+// `gr` may be wave-uniform (the per-shot kernels: rows arrive through scalar loads) or differ per lane (the
+// wave-per-row kernel, tsim_kernel_hw.hip.h: lane = graph): the code is the same, the compiler picks the loads.
+// What the rows of one fast-layout graph contribute, as numbers: the counts of minus signs in the counted
+// NodePhases classes, the PhasePairs index bits (two per term, first term most significant), the lambda bit and the
+// bit e = <lin,x> ^ XOR_s <u_s,x><v_s,x> of the exponent.
+struct GraphBits {
+  uint32_t m0, m1, m3, dbits, lam, e;
+};
+
+// ... and the graph's exact value from them: (a, b, c, d) * 2^p - in fixed-frame levels already shifted to the
+// level's frame power (p unused).  The record words it needs are passed in (scalar loads of a wave-uniform record in
+// the per-shot kernels, the lane's own record in the wave-per-row kernel).
+struct GraphRec {
+  uint32_t flags, nD, n1, tbl, tbl2;
+};
+__device__ __forceinline__ GraphRec graph_rec_of(cptr gr) {
+  GraphRec r;
+  r.flags = gr[GF_FLAGS]; r.nD = gr[GF_ND]; r.n1 = gr[GF_N1]; r.tbl = gr[GF_TBL]; r.tbl2 = gr[GF_TBL2];
+  return r;
+}
+__device__ __forceinline__ void graph_fast_value(const uint32_t *gimg, const GraphRec &R, bool fixed, const GraphBits &q, int &a, int &b, int &c,
+                                                 int &d, int &p) {
+  const uint32_t flags = R.flags, nD = R.nD;
+  const bool d_tabled = (flags & TSIMK_GFLAG_D_TABLED) != 0;
+  uint32_t idx = q.m3 - q.m1 + R.n1;
+  int da = 1, db = 0, dc = 0, dd = 0, dp = 0;
+  if (d_tabled) {
+    idx = (idx << (2u * nD)) | q.dbits;
+  } else if (nD) {
+    // a separate PhasePairs table (the combined one would be too large)
+    const uint32_t *td = gimg + R.tbl2 + 8u * q.dbits;
+    const uint4 dv = *reinterpret_cast<const uint4 *>(td);
+    da = (int)dv.x; db = (int)dv.y; dc = (int)dv.z; dd = (int)dv.w;
+    dp = (int)td[4];
+  }
+  // entry 0 of every table is the exact zero (a vanished NodePhases product: some 1 + w^4 factor)
+  idx = (q.m0 != 0) ? 0u : idx + 1u;
+  // per-lane gather of the tabulated term (global memory, L1/L2 resident).  Fixed-frame levels
+  // hold four pre-rotated copies per entry (value * i^r), selected by the exponent below.
+  const uint32_t *te = gimg + R.tbl + (fixed ? 16u : 8u) * idx;
+  // exponent of w: k = 2 <lam,x> + 4 e (k0 is in the table)
+  const uint32_t k = ((q.lam & 1u) << 1) + ((q.e & 1u) << 2);
+  const uint4 tv = *reinterpret_cast<const uint4 *>(te + (fixed ? (k << 1) : 0u));  // r = k/2, 4 words each
+  a = (int)tv.x; b = (int)tv.y; c = (int)tv.z; d = (int)tv.w; p = 0;
+  if (!fixed) p = (int)te[4];
+  if (!d_tabled && nD) {
+    zmul(a, b, c, d, da, db, dc, dd);
+    p += dp;
+  }
+  if (!fixed) {  // rotate by w^k, k in {0, 2, 4, 6} (differs per lane)
+    const bool k2 = (k & 2u) != 0;
+    const int t0 = k2 ? -c : a, t1 = k2 ? d : b, t2 = k2 ? a : c, t3 = k2 ? -b : d;
+    const int nm = -(int)((k >> 2) & 1u);
+    a = (t0 ^ nm) - nm; b = (t1 ^ nm) - nm; c = (t2 ^ nm) - nm; d = (t3 ^ nm) - nm;
+  }
+}
+
+// One graph (stabiliser term) of a fast-layout level from its rows (wave-uniform `gr`: the rows arrive through
+// scalar loads) and the lane's parameter words x.
+template <int W>
+__device__ __forceinline__ void eval_graph_fast(const uint32_t *gimg, cptr img, cptr gr, const uint32_t (&x)[W], bool fixed,
+                                                int &a, int &b, int &c, int &d, int &p) {
+  const uint32_t n01 = gr[GF_N01], n3h = gr[GF_N3H], flags = gr[GF_FLAGS];
+  cptr row = img + gr[GF_ROWS];
+  GraphBits q;
+  // ---- NodePhases: count minus signs in the phase classes that need an integer count ----
+  q.m0 = rows_count<W>(row, n01 & 0xFFFFu, x);
+  q.m1 = rows_count<W>(row, n01 >> 16, x);
+  q.m3 = rows_count<W>(row, n3h & 0xFFFFu, x);
+  // ---- PhasePairs: two index bits per term (into the combined table or the separate one) ----
+  const uint32_t nD = gr[GF_ND];
+  q.dbits = 0;
+  for (uint32_t t = 0; t < nD; ++t) {
+    const uint32_t pa = row_par<W>(row, x, 0) & 1u;
+    const uint32_t pb = row_par<W>(row + W, x, 0) & 1u;
+    q.dbits = (q.dbits << 2) | pa | (pb << 1);
+    row += 2 * W;
+  }
+  // ---- exponent of w: k = 2 <lam,x> + 4 ( <lin,x> ^ XOR_s <u_s,x><v_s,x> )
+  q.lam = 0;
+  q.e = 0;
+  if (flags & TSIMK_GFLAG_LAM) { q.lam = row_par<W>(row, x, 0) & 1u; row += W; }
+  if (flags & TSIMK_GFLAG_LIN) { q.e = row_par<W>(row, x, 0); row += W; }
+  const uint32_t nH = n3h >> 16;
+#pragma unroll 4
+  for (uint32_t t = 0; t < nH; ++t) {
+    const uint32_t pu = row_par<W>(row, x, 0);
+    const uint32_t pv = row_par<W>(row + W, x, 0);
+    q.e = and_xor(pu, pv, q.e);
+    row += 2 * W;
+  }
+  graph_fast_value(gimg, graph_rec_of(gr), fixed, q, a, b, c, d, p);
+}
+
+// the running sum of a level takes one more graph (evaluate.py:53-59), in graph order
+struct LevelSum {
+  int sa = 0, sb = 0, sc = 0, sd = 0, sp = TSIMK_ZERO_POWER;
+  float fre = 0.0f, fim = 0.0f;
+};
+__device__ __forceinline__ void level_sum_exact(LevelSum &S, int a, int b, int c, int d, int p) {
+  // exactly-zero terms get a huge power, which makes the aligned add below a no-op for them
+  if ((a | b | c | d) == 0) p = TSIMK_ZERO_POWER;
+  const int d1 = max(S.sp - p, 0), d2 = max(p - S.sp, 0);
+  S.sa = (int)((unsigned)shl_sat(S.sa, d1) + (unsigned)shl_sat(a, d2));
+  S.sb = (int)((unsigned)shl_sat(S.sb, d1) + (unsigned)shl_sat(b, d2));
+  S.sc = (int)((unsigned)shl_sat(S.sc, d1) + (unsigned)shl_sat(c, d2));
+  S.sd = (int)((unsigned)shl_sat(S.sd, d1) + (unsigned)shl_sat(d, d2));
+  S.sp = min(S.sp, p);
+  reduce1(S.sa, S.sb, S.sc, S.sd, S.sp);
+}
+// the float32 term of the approximate branch: complex64(term) * approx (the table power already contains power2)
+__device__ __forceinline__ void level_term_approx(uint32_t apre, uint32_t apim, int a, int b, int c, int d, int p, float &tr, float &ti) {
+  float zr, zi;
+  to_complex(a, b, c, d, p, zr, zi);
+  const float ar = __uint_as_float(apre), ai = __uint_as_float(apim);
+  tr = __fsub_rn(__fmul_rn(zr, ar), __fmul_rn(zi, ai));
+  ti = __fadd_rn(__fmul_rn(zr, ai), __fmul_rn(zi, ar));
+}
+__device__ __forceinline__ void level_finish(const LevelSum &S0, cptr lvl, bool approx, bool fixed, float &out_re, float &out_im, int *exact5) {
+  if (!approx) {
+    int sa = S0.sa, sb = S0.sb, sc = S0.sc, sd = S0.sd, sp = S0.sp;
+    if (fixed) sp = (int)lvl[L_FRAME];
+    canon(sa, sb, sc, sd, sp);
+    if ((sa | sb | sc | sd) == 0) sp = 0;
+    to_complex(sa, sb, sc, sd, sp, out_re, out_im);
+    if (exact5) { exact5[0] = sa; exact5[1] = sb; exact5[2] = sc; exact5[3] = sd; exact5[4] = sp; }
+  } else {
+    out_re = S0.fre; out_im = S0.fim;
+    if (exact5) { exact5[0] = exact5[1] = exact5[2] = exact5[3] = exact5[4] = 0; }
+  }
+}
+
 template <int W>
 __device__ __forceinline__ void eval_level_fast(const uint32_t *gimg, cptr img, cptr lvl, const uint32_t (&x)[W],
                                                 float &out_re, float &out_im, int *exact5) {
@@ -521,115 +658,24 @@ __device__ __forceinline__ void eval_level_fast(const uint32_t *gimg, cptr img, 
   const bool approx = (lvl[L_FLAGS] & TSIMK_LFLAG_APPROX) != 0;
   const bool fixed = (lvl[L_FLAGS] & TSIMK_LFLAG_FIXED) != 0;
   cptr gr = img + lvl[L_GRAPHS];
-
-  int sa = 0, sb = 0, sc = 0, sd = 0, sp = TSIMK_ZERO_POWER;
-  float fre = 0.0f, fim = 0.0f;
-
+  LevelSum S;
   for (uint32_t g = 0; g < G; ++g, gr += G_WORDS) {
-    const uint32_t n01 = gr[GF_N01], n3h = gr[GF_N3H], flags = gr[GF_FLAGS];
-    cptr row = img + gr[GF_ROWS];
-
-    // ---- NodePhases: count minus signs in the phase classes that need an integer count ----
-    const uint32_t m0 = rows_count<W>(row, n01 & 0xFFFFu, x);
-    const uint32_t m1 = rows_count<W>(row, n01 >> 16, x);
-    const uint32_t m3 = rows_count<W>(row, n3h & 0xFFFFu, x);
-    uint32_t idx = m3 - m1 + gr[GF_N1];
-
-    // ---- PhasePairs: either two index bits per term into the combined table, or the scan ----
-    const uint32_t nD = gr[GF_ND];
-    int da = 1, db = 0, dc = 0, dd = 0, dp = 0;
-    const bool d_tabled = (flags & TSIMK_GFLAG_D_TABLED) != 0;
-    if (d_tabled) {
-      for (uint32_t t = 0; t < nD; ++t) {
-        const uint32_t pa = row_par<W>(row, x, 0) & 1u;
-        const uint32_t pb = row_par<W>(row + W, x, 0) & 1u;
-        idx = (idx << 2) | pa | (pb << 1);
-        row += 2 * W;
-      }
-    } else if (nD) {
-      // a separate PhasePairs table (the combined one would be too large): index bits only
-      uint32_t dbits = 0;
-      for (uint32_t t = 0; t < nD; ++t) {
-        const uint32_t pa = row_par<W>(row, x, 0) & 1u;
-        const uint32_t pb = row_par<W>(row + W, x, 0) & 1u;
-        dbits = (dbits << 2) | pa | (pb << 1);
-        row += 2 * W;
-      }
-      const uint32_t *td = gimg + gr[GF_TBL2] + 8u * dbits;
-      const uint4 dv = *reinterpret_cast<const uint4 *>(td);
-      da = (int)dv.x; db = (int)dv.y; dc = (int)dv.z; dd = (int)dv.w;
-      dp = (int)td[4];
-    }
-    // entry 0 of every table is the exact zero (a vanished NodePhases product: some 1 + w^4 factor)
-    idx = (m0 != 0) ? 0u : idx + 1u;
-    // per-lane gather of the tabulated term (global memory, L1/L2 resident).  Fixed-frame levels
-    // hold four pre-rotated copies per entry (value * i^r), selected by the exponent below.
-    const uint32_t *te = gimg + gr[GF_TBL] + (fixed ? 16u : 8u) * idx;
-
-    // ---- exponent of w: k = 2 <lam,x> + 4 ( <lin,x> ^ XOR_s <u_s,x><v_s,x> ) (k0 is in the table)
-    uint32_t k = 0, e = 0;
-    if (flags & TSIMK_GFLAG_LAM) { k = (row_par<W>(row, x, 0) & 1u) << 1; row += W; }
-    if (flags & TSIMK_GFLAG_LIN) { e = row_par<W>(row, x, 0); row += W; }
-    const uint32_t nH = n3h >> 16;
-#pragma unroll 4
-    for (uint32_t t = 0; t < nH; ++t) {
-      const uint32_t pu = row_par<W>(row, x, 0);
-      const uint32_t pv = row_par<W>(row + W, x, 0);
-      e = and_xor(pu, pv, e);
-      row += 2 * W;
-    }
-    k += (e & 1u) << 2;
-
-    const uint4 tv = *reinterpret_cast<const uint4 *>(te + (fixed ? (k << 1) : 0u));  // r = k/2, 4 words each
-    int a = (int)tv.x, b = (int)tv.y, c = (int)tv.z, d = (int)tv.w, p = 0;
-    if (!fixed) p = (int)te[4];
-    if (!d_tabled && nD) {
-      zmul(a, b, c, d, da, db, dc, dd);
-      p += dp;
-    }
-
-    if (!fixed) {  // rotate by w^k, k in {0, 2, 4, 6} (differs per lane)
-      const bool k2 = (k & 2u) != 0;
-      const int t0 = k2 ? -c : a, t1 = k2 ? d : b, t2 = k2 ? a : c, t3 = k2 ? -b : d;
-      const int nm = -(int)((k >> 2) & 1u);
-      a = (t0 ^ nm) - nm; b = (t1 ^ nm) - nm; c = (t2 ^ nm) - nm; d = (t3 ^ nm) - nm;
-    }
-
+    int a, b, c, d, p;
+    eval_graph_fast<W>(gimg, img, gr, x, fixed, a, b, c, d, p);
     if (fixed) {
       // every table entry of this level is pre-shifted to the level's frame power: plain adds,
       // the pack-time bound guarantees no int32 overflow (see pack_level_fast)
-      sa += a; sb += b; sc += c; sd += d;
+      S.sa += a; S.sb += b; S.sc += c; S.sd += d;
     } else if (!approx) {
-      // exactly-zero terms get a huge power, which makes the aligned add below a no-op for them
-      if ((a | b | c | d) == 0) p = TSIMK_ZERO_POWER;
-      const int d1 = max(sp - p, 0), d2 = max(p - sp, 0);
-      sa = (int)((unsigned)shl_sat(sa, d1) + (unsigned)shl_sat(a, d2));
-      sb = (int)((unsigned)shl_sat(sb, d1) + (unsigned)shl_sat(b, d2));
-      sc = (int)((unsigned)shl_sat(sc, d1) + (unsigned)shl_sat(c, d2));
-      sd = (int)((unsigned)shl_sat(sd, d1) + (unsigned)shl_sat(d, d2));
-      sp = min(sp, p);
-      reduce1(sa, sb, sc, sd, sp);
+      level_sum_exact(S, a, b, c, d, p);
     } else {
-      float zr, zi;
-      to_complex(a, b, c, d, p, zr, zi);  // the table power already contains power2
-      const float ar = __uint_as_float(gr[GF_APRE]), ai = __uint_as_float(gr[GF_APIM]);
-      const float tr = __fsub_rn(__fmul_rn(zr, ar), __fmul_rn(zi, ai));
-      const float ti = __fadd_rn(__fmul_rn(zr, ai), __fmul_rn(zi, ar));
-      fre = __fadd_rn(fre, tr);
-      fim = __fadd_rn(fim, ti);
+      float tr, ti;
+      level_term_approx(gr[GF_APRE], gr[GF_APIM], a, b, c, d, p, tr, ti);
+      S.fre = __fadd_rn(S.fre, tr);
+      S.fim = __fadd_rn(S.fim, ti);
     }
   }
-
-  if (!approx) {
-    if (fixed) sp = (int)lvl[L_FRAME];
-    canon(sa, sb, sc, sd, sp);
-    if ((sa | sb | sc | sd) == 0) sp = 0;
-    to_complex(sa, sb, sc, sd, sp, out_re, out_im);
-    if (exact5) { exact5[0] = sa; exact5[1] = sb; exact5[2] = sc; exact5[3] = sd; exact5[4] = sp; }
-  } else {
-    out_re = fre; out_im = fim;
-    if (exact5) { exact5[0] = exact5[1] = exact5[2] = exact5[3] = exact5[4] = 0; }
-  }
+  level_finish(S, lvl, approx, fixed, out_re, out_im, exact5);
 }
 
 template <int W, bool FAST>

@@ -213,6 +213,7 @@ extern "C" int tsim_program_finalize(tsim_program *p, int32_t device) {
     p->fast = fast;
   }
 retry_pack:
+  p->hw_max_rows = 0;
   // ---- validate the output bookkeeping (pipeline.py:83-102) ----
   int pos = p->n_direct;
   for (size_t ci = 0; ci < p->comps.size(); ++ci) {
@@ -302,9 +303,34 @@ retry_pack:
           if (img[goff + (size_t)g * G_WORDS + GF_TBL2]) img[goff + (size_t)g * G_WORDS + GF_TBL2] += toff;
         }
       }
+      // The same rows once more as ONE stream of uniform stride per level - [const, w_0 .. w_(W-1)] per row, graph after
+      // graph in the order eval_graph_fast reads them - for the wave-per-row kernel (tsim_kernel_hw.hip.h), whose lanes
+      // take one ROW each (coalesced) and whose graphs then read their parities by position.
+      uint32_t hw_off = 0, hw_n = 0;
+      if (p->fast) {
+        while (img.size() % 16) img.push_back(0u);
+        hw_off = (uint32_t)img.size();
+        for (int g = 0; g < h.G; ++g) {
+          const uint32_t *r = &h.graph_rec[(size_t)g * G_WORDS];
+          const uint32_t n_meta = (r[GF_N01] & 0xFFFFu) + (r[GF_N01] >> 16) + (r[GF_N3H] & 0xFFFFu);
+          const uint32_t n_plain = 2u * r[GF_ND] + ((r[GF_FLAGS] & TSIMK_GFLAG_LAM) ? 1u : 0u) + ((r[GF_FLAGS] & TSIMK_GFLAG_LIN) ? 1u : 0u) +
+                                   2u * (r[GF_N3H] >> 16);
+          img[goff + (size_t)g * G_WORDS + GF_HWROW] = hw_n;
+          const uint32_t *src = &h.rows[r[GF_ROWS]];
+          for (uint32_t t = 0; t < n_meta; ++t, src += 1 + W) img.insert(img.end(), src, src + 1 + W);
+          for (uint32_t t = 0; t < n_plain; ++t, src += W) {
+            img.push_back(0u);
+            img.insert(img.end(), src, src + W);
+          }
+          hw_n += n_meta + n_plain;
+        }
+        p->hw_max_rows = std::max(p->hw_max_rows, (long long)hw_n);
+      }
       uint32_t *lr = &img[lrec + (size_t)k * L_WORDS];
       lr[L_G] = (uint32_t)h.G;
       lr[L_GRAPHS] = goff;
+      lr[L_HWROWS] = hw_off;
+      lr[L_HWN] = hw_n;
       lr[L_FLAGS] = (h.approx ? TSIMK_LFLAG_APPROX : 0u) | (fixed ? TSIMK_LFLAG_FIXED : 0u);
       lr[L_FRAME] = (uint32_t)frame;
       p->stats[1] += 1;
@@ -648,6 +674,7 @@ retry_pack:
     p->knobs.defer_group = std::max(1, std::min(TSIMK_H_MAX_CTX, env_int("TSIM_AMD_DEFER_GROUP", p->knobs.defer_group)));
     p->knobs.fused_steps = env_int("TSIM_AMD_FUSED_STEPS", 1) != 0;
     p->knobs.lw_fast = env_int("TSIM_AMD_LW_FAST", 1) != 0;
+    p->knobs.hard_wave = env_int("TSIM_AMD_HARD_WAVE", 1) != 0;
     p->knobs.fused_max = std::max(1, std::min(TSIMK_H_MAX_CTX, env_int("TSIM_AMD_FUSED_MAX", TSIMK_H_MAX_CTX)));
   }
 

@@ -8,6 +8,7 @@
 #include "tsim_lw_multi.hip.h"
 #include "tsim_lw_fast.hip.h"
 #include "tsim_kernel4w.hip.h"
+#include "tsim_kernel_hw.hip.h"
 
 using namespace tsimk;
 using namespace tsimhost;
@@ -213,6 +214,32 @@ int tsim_flush_hard(tsim_program *p) {
       HIP_TRY(hipEventRecord(p->lane_ev[k], p->slots[1 + k].side));
       HIP_TRY(hipStreamWaitEvent(hs, p->lane_ev[k], 0));
     }
+  // One wave per hard row (tsim_kernel_hw.hip.h) where the fast row layout exists and the rows are narrow: a batch
+  // then takes the time of one row, and the approximate branch is no slower than the exact one.
+  int wmax = 1;
+  for (int w : p->comp_w) wmax = std::max(wmax, w);
+  const bool hw = p->fast && p->knobs.hard_wave && wmax <= 2 && M.ctx[0].WF <= 32 && M.ctx[0].WO <= 2 && p->hw_max_rows < 60000;
+  if (hw) {
+    HwMulti H{};
+    H.n_ctx = M.n_ctx;
+    H.max_lists = max_lists;
+    // as many waves per list as the longest list of the last launch had rows (plus a margin): each wave then takes one
+    // row; longer lists are walked in turns
+    // (blocks of four waves: one row at a time each, see k_sample_hw)
+    H.waves_per_list = (int)std::max(8u, std::min(128u, std::min(fb_max, 4096u) * 2u + 8u));
+    if (const char *e = getenv("TSIM_AMD_HW_WAVES")) H.waves_per_list = std::max(1, std::min(256, atoi(e)));
+    H.feedback = p->d_feedback;
+    for (int i = 0; i < M.n_ctx; ++i) {
+      H.ctx[i] = M.ctx[i];
+      H.ctx[i].kernarg_off = (int)(offsetof(HwMulti, ctx) + (size_t)i * sizeof(SampleArgs));
+    }
+    const unsigned gridw = (unsigned)((long long)H.n_ctx * H.max_lists * H.waves_per_list);
+    H.par_words = (int)(2 * ((p->hw_max_rows + 63) / 64) + 2);
+    const size_t ldsw = (size_t)H.par_words * 2 * 4;  // two bit arrays per block (the check row evaluates trial bits 1 and 0 together)
+    if (wmax == 1) hipLaunchKernelGGL(k_sample_hw<1>, dim3(gridw), dim3(256), ldsw, hs, H);
+    else hipLaunchKernelGGL(k_sample_hw<2>, dim3(gridw), dim3(256), ldsw, hs, H);
+    HIP_TRY(hipGetLastError());
+  } else {
   const unsigned grid = (unsigned)(M.n_ctx * M.blocks_per_ctx);
   switch (p->v4_max_nch) {
 #define TSIM_LHM(N)                                                                                          \
@@ -228,6 +255,7 @@ int tsim_flush_hard(tsim_program *p) {
   }
   HIP_TRY(hipGetLastError());
   p->hm_attr_set = true;
+  }
   ++p->stat_flushes;
   hipEvent_t &be = p->batch_ev[seq % 16u];
   if (!be) HIP_TRY(hipEventCreateWithFlags(&be, hipEventDisableTiming));

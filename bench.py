@@ -1009,11 +1009,17 @@ def extra_legs(backend, synth, program, cfg, hp, info, B, num_f, n_out, key, f_b
                                   ("device_noise", dict(noise="device"), dict(append_observables=True)),
                                   ("device_noise_bit_packed", dict(noise="device"), dict(append_observables=True, bit_packed=True))):
                 s = CompiledDetectorSampler(program, channel_probs=probs, error_transform=T, seed=1, device=device, **kw)
-                s.sample(shots, batch_size=batch, **skw)  # same shape once: buffers, lanes
-                t0 = time.perf_counter()
-                res = s.sample(shots, batch_size=batch, **skw)
-                dt = time.perf_counter() - t0
-                leg[name] = {"shots_per_s": shots / dt, "seconds": dt, "result_bytes": int(res.nbytes)}
+                n_sh = shots * (4 if kw["noise"] == "device" else 1)  # 16 batches for the device route: its pipeline is three stages deep
+                for _ in range(2):  # same shape twice: buffers and lanes, then the launch plan's kernels (first launches load code)
+                    s.sample(n_sh, batch_size=batch, **skw)
+                dts = []
+                for _ in range(3):
+                    t0 = time.perf_counter()
+                    res = s.sample(n_sh, batch_size=batch, **skw)
+                    dts.append(time.perf_counter() - t0)
+                dt = statistics.median(dts)
+                leg[name] = {"shots_per_s": n_sh / dt, "seconds": dt, "shots": n_sh, "result_bytes": int(res.nbytes)}
+                s.release()
             e2e[mname] = leg
     out["e2e_sample"] = e2e
     return out

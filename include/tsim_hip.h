@@ -389,6 +389,19 @@ int tsim_free_pinned(void *h_ptr);
 int tsim_memcpy_h2d(tsim_program *p, void *d_dst, const void *h_src, int64_t nbytes);
 int tsim_memcpy_d2h(tsim_program *p, void *h_dst, const void *d_src, int64_t nbytes);
 int tsim_synchronize(tsim_program *p);                      /* handle's stream */
+/* Asynchronous variants on a caller-chosen stream (NULL: the handle's) and the matching wait: the end-to-end sampler
+ * downloads finished batches while later ones are sampled (utils/cuda_helpers.py:105-141 copies once, at the end).
+ * Pageable host memory is allowed; the call may then block until the copy is done. */
+int tsim_memcpy_d2h_async(tsim_program *p, void *h_dst, const void *d_src, int64_t nbytes, void *stream);
+int tsim_memcpy_h2d_async(tsim_program *p, void *d_dst, const void *h_src, int64_t nbytes, void *stream);
+int tsim_stream_synchronize(tsim_program *p, void *stream);
+/* Auxiliary hipStream_t owned by the handle (index 0 .. TSIM_AUX_STREAMS-1; created on first use): work beside the
+ * sampling lanes - the device-side channel sampler, transfers. */
+#define TSIM_AUX_STREAMS 4
+int tsim_aux_stream(tsim_program *p, int32_t index, void **stream);
+/* The pipeline slot the next batch of tsim_sample_steps_device will take (it rotates over all TSIM_PIPELINE_SLOTS): pass
+ * it to tsim_sample_batch_device_end later to make a stream wait for exactly that batch. */
+int tsim_pipeline_next_slot(tsim_program *p, int32_t *slot);
 /* the handle's hipStream_t, e.g. to order a collective after the sampling kernel */
 int tsim_get_stream(tsim_program *p, void **stream);
 

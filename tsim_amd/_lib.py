@@ -125,6 +125,11 @@ SYMBOLS: dict[str, tuple] = {
     "tsim_sample_batch_device_begin_split": (C.c_int, [_P, _I32, _P, _I64, _I32, C.POINTER(_U32), _I64, _P, _P, _P, _U32]),
     "tsim_sample_steps_device": (C.c_int, [_P, _I32, C.POINTER(_P), _I64, _I32, C.POINTER(_U32), _I64, C.POINTER(_P), C.POINTER(_P), _U32]),
     "tsim_profile_read_steps": (C.c_int, [_P, C.POINTER(_I64), _I32]),
+    "tsim_memcpy_d2h_async": (C.c_int, [_P, _P, _P, _I64, _P]),
+    "tsim_memcpy_h2d_async": (C.c_int, [_P, _P, _P, _I64, _P]),
+    "tsim_stream_synchronize": (C.c_int, [_P, _P]),
+    "tsim_aux_stream": (C.c_int, [_P, _I32, C.POINTER(_P)]),
+    "tsim_pipeline_next_slot": (C.c_int, [_P, C.POINTER(_I32)]),
     "tsim_last_error": (C.c_char_p, []),
     "tsim_version": (C.c_char_p, []),
 }

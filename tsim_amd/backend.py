@@ -301,9 +301,9 @@ class HipProgram:
             "tsim_pack_bits_device",
         )
 
-    def unpack_bits_device(self, d_in: int, B: int, nbits: int, d_out: int) -> None:
+    def unpack_bits_device(self, d_in: int, B: int, nbits: int, d_out: int, stream: int = 0) -> None:
         _lib.check(
-            self._lib.tsim_unpack_bits_device(self._h, C.c_void_p(d_in), B, nbits, C.c_void_p(d_out), None),
+            self._lib.tsim_unpack_bits_device(self._h, C.c_void_p(d_in), B, nbits, C.c_void_p(d_out), stream or None),
             "tsim_unpack_bits_device",
         )
 
@@ -329,12 +329,12 @@ class HipProgram:
             "tsim_scatter_rows_device",
         )
 
-    def compact_rows_device(self, d_in: int, B: int, nbits: int, d_out: int, *, in_words: int = 0) -> None:
+    def compact_rows_device(self, d_in: int, B: int, nbits: int, d_out: int, *, in_words: int = 0, stream: int = 0) -> None:
         """Padded uint64 rows (``in_words`` per row, default ``ceil(nbits/64)``) -> ``ceil(nbits/8)``-byte
         rows of the first ``nbits`` columns (``np.packbits(bits[:, :nbits], axis=1, bitorder="little")``)."""
         _lib.check(
             self._lib.tsim_compact_rows_device(self._h, C.c_void_p(d_in), int(B), int(in_words), int(nbits),
-                                               C.c_void_p(d_out), None),
+                                               C.c_void_p(d_out), stream or None),
             "tsim_compact_rows_device",
         )
 
@@ -372,8 +372,31 @@ class HipProgram:
         if rc < 0:
             _lib.check(rc, "tsim_sample_batch_device_begin")
 
+    def aux_stream(self, index: int) -> int:
+        """One of the handle's auxiliary ``hipStream_t`` (noise sampling, transfers beside the sampling lanes)."""
+        st = C.c_void_p()
+        _lib.check(self._lib.tsim_aux_stream(self._h, int(index), C.byref(st)), "tsim_aux_stream")
+        return int(st.value or 0)
+
+    def pipeline_next_slot(self) -> int:
+        """The pipeline slot the next batch of :meth:`sample_steps_device` will take."""
+        n = C.c_int32(0)
+        _lib.check(self._lib.tsim_pipeline_next_slot(self._h, C.byref(n)), "tsim_pipeline_next_slot")
+        return int(n.value)
+
+    def d2h_async(self, dst: np.ndarray, src: int, stream: int) -> None:
+        assert dst.flags.c_contiguous
+        _lib.check(self._lib.tsim_memcpy_d2h_async(self._h, _lib.ptr(dst), C.c_void_p(int(src)), dst.nbytes, stream or None), "tsim_memcpy_d2h_async")
+
+    def h2d_async(self, dst: int, src: np.ndarray, stream: int) -> None:
+        assert src.flags.c_contiguous
+        _lib.check(self._lib.tsim_memcpy_h2d_async(self._h, C.c_void_p(int(dst)), _lib.ptr(src), src.nbytes, stream or None), "tsim_memcpy_h2d_async")
+
+    def stream_synchronize(self, stream: int) -> None:
+        _lib.check(self._lib.tsim_stream_synchronize(self._h, stream or None), "tsim_stream_synchronize")
+
     def sample_steps_device(self, d_f, B: int, num_f: int, key_state, d_out, *, shot_offset: int = 0,
-                            inputs_ready: bool = False, out_bit_packed: bool = False) -> None:
+                            inputs_ready: bool = False, out_bit_packed: bool = False, d_norm_dev=None) -> None:
         """``len(d_f)`` consecutive batches in one call (the reference's batch loop, ``sampler.py:340-420``): for each,
         ``key, subkey = split(key)`` and one ``sample_program``; ``key_state`` is a ``(c_uint32 * 2)`` advanced in
         place.  ``d_f`` / ``d_out``: sequences of device addresses (or ``(c_void_p * n)`` arrays, reused as they are).
@@ -381,7 +404,8 @@ class HipProgram:
         n = len(d_f)
         fa = d_f if isinstance(d_f, C.Array) else (C.c_void_p * n)(*[int(x) for x in d_f])
         oa = d_out if isinstance(d_out, C.Array) else (C.c_void_p * n)(*[int(x) for x in d_out])
-        rc = self._lib.tsim_sample_steps_device(self._h, n, fa, int(B), int(num_f), key_state, int(shot_offset), oa, None,
+        da = None if d_norm_dev is None else (C.c_void_p * n)(*[int(x) for x in d_norm_dev])
+        rc = self._lib.tsim_sample_steps_device(self._h, n, fa, int(B), int(num_f), key_state, int(shot_offset), oa, da,
                                                 (1 if inputs_ready else 0) | (2 if out_bit_packed else 0))
         if rc < 0:
             _lib.check(rc, "tsim_sample_steps_device")
@@ -626,13 +650,13 @@ class DeviceNoiseSampler:
             handle.noise.remove(n)
             handle.lib.tsim_noise_destroy(n)
 
-    def sample_into(self, d_f: int, B: int, key) -> None:
-        """Asynchronous on the program's stream."""
+    def sample_into(self, d_f: int, B: int, key, stream: int = 0) -> None:
+        """Asynchronous on ``stream`` (0: the program's stream)."""
         if not self._handle.h:
             raise _lib.HipBackendError("the HipProgram of this noise sampler is closed")
         _lib.check(
             self._lib.tsim_noise_sample_device(
-                self._n, int(B), int(key[0]) & 0xFFFFFFFF, int(key[1]) & 0xFFFFFFFF, C.c_void_p(d_f), None
+                self._n, int(B), int(key[0]) & 0xFFFFFFFF, int(key[1]) & 0xFFFFFFFF, C.c_void_p(d_f), stream or None
             ),
             "tsim_noise_sample_device",
         )
@@ -665,6 +689,46 @@ class _PinnedBuf:
                 self.ptr = 0
         except Exception:
             pass
+
+
+class PinnedPool:
+    """Result arrays on recycled pinned host memory.
+
+    A fresh ``np.empty`` of tens of MB costs more than the PCIe copy that fills it (the kernel zeroes every page on first
+    touch: ~5 ms per 48 MB, where the copy takes 0.9 ms), and so does a fresh ``hipHostMalloc``.  ``take`` hands out a
+    numpy array backed by a pinned block; when the LAST view of it dies the block comes back to the pool (a
+    ``weakref.finalize`` on the exporting buffer) instead of being unpinned, so the next call of a sampling loop gets
+    warm, pinned memory: asynchronous copies at the full PCIe rate, no page faults.  Blocks the caller keeps alive are
+    simply not reused; at most ``cap`` bytes wait in the pool."""
+
+    def __init__(self, cap: int = 2 << 30):
+        self.cap = int(cap)
+        self._free: list[_PinnedBuf] = []
+
+    def _give_back(self, buf: "_PinnedBuf") -> None:
+        if sum(b.nbytes for b in self._free) + buf.nbytes <= self.cap:
+            self._free.append(buf)
+        # else: dropped here -> _PinnedBuf.__del__ unpins it
+
+    def take(self, shape, dtype=np.uint8) -> np.ndarray:
+        import weakref
+
+        need = max(1, int(np.prod(shape)) * np.dtype(dtype).itemsize)
+        best = None
+        for i, b in enumerate(self._free):
+            if need <= b.nbytes <= max(2 * need, need + (1 << 20)) and (best is None or b.nbytes < self._free[best].nbytes):
+                best = i
+        buf = self._free.pop(best) if best is not None else _PinnedBuf(need)
+        carr = (C.c_uint8 * buf.nbytes).from_address(buf.ptr)
+        weakref.finalize(carr, self._give_back, buf)
+        return np.frombuffer(carr, dtype=np.uint8)[:need].view(dtype).reshape(shape)
+
+
+_result_pool = PinnedPool()
+
+
+def result_pool() -> PinnedPool:
+    return _result_pool
 
 
 def alloc_pinned_numpy(nbytes: int, dtype, shape) -> np.ndarray:

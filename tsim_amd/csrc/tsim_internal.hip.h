@@ -132,6 +132,7 @@ struct tsim_program {
   uint32_t *d_img = nullptr;
   float *d_dev = nullptr;
   hipStream_t stream = nullptr;
+  hipStream_t aux[TSIM_AUX_STREAMS] = {};  // tsim_aux_stream
   // low-weight pattern tables (tsim_lw.hip.h)
   int lw_request = -1;        // -1 default (on in TSIM_MODE_AUTO), 0 off, 1 on
   int lw_weight_cap = -1;     // -1 = TSIMK_LW_MAX_WEIGHT

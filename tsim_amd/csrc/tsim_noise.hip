@@ -12,6 +12,8 @@ struct tsim_noise {
   int device = -1;  // copy of prog->device: destroy must not touch the program handle
   int num_f = 0, n_ch = 0, WF = 0, seg = 4096;
   double *d_l1p = nullptr;
+  float *d_inv = nullptr;  // 1 / log2(1 - p) per channel (k_noise_tile)
+  int tile = 0, tseg = 0;  // k_noise_tile geometry; 0 = the tile form does not apply (rows too wide for LDS)
   uint32_t *d_off = nullptr;
   float *d_cdf = nullptr;
   uint64_t *d_pat = nullptr;
@@ -55,8 +57,20 @@ extern "C" int tsim_noise_create(tsim_program *p, int32_t num_f, int32_t n_chann
   int seg = 64;
   while (seg < 65536 && seg * pmax < 8.0) seg *= 2;
   n->seg = seg;
+  // tile form: 32 KB of rows per block; sub-segments of about 4 expected fires of the most active channel
+  std::vector<float> inv((size_t)std::max(1, n_channels));
+  for (int c = 0; c < n_channels; ++c) inv[c] = p_fire[c] >= 1.0 ? 0.0f : (float)(1.0 / log2(1.0 - p_fire[c]));
+  n->tile = 0;
+  if (n->WF * 8 * 64 <= 32 * 1024 && !getenv("TSIM_AMD_NOISE_ATOMIC")) {
+    n->tile = 64;
+    while (n->tile * 2 * n->WF * 8 <= 32 * 1024) n->tile *= 2;
+    int ts = 64;
+    while (ts < n->tile && ts * pmax < 4.0) ts *= 2;
+    n->tseg = ts;
+  }
   hipError_t e = hipSuccess;
   if ((e = hipMalloc((void **)&n->d_l1p, l1p.size() * 8)) != hipSuccess ||
+      (e = hipMalloc((void **)&n->d_inv, inv.size() * 4)) != hipSuccess ||
       (e = hipMalloc((void **)&n->d_off, off.size() * 4)) != hipSuccess ||
       (e = hipMalloc((void **)&n->d_cdf, cdf.size() * 4)) != hipSuccess ||
       (e = hipMalloc((void **)&n->d_pat, pat.size() * 8)) != hipSuccess) {
@@ -64,6 +78,7 @@ extern "C" int tsim_noise_create(tsim_program *p, int32_t num_f, int32_t n_chann
     return tsim_fail(TSIM_ENOMEM, "hipMalloc failed: %s", hipGetErrorString(e));
   }
   if ((e = hipMemcpy(n->d_l1p, l1p.data(), l1p.size() * 8, hipMemcpyHostToDevice)) != hipSuccess ||
+      (e = hipMemcpy(n->d_inv, inv.data(), inv.size() * 4, hipMemcpyHostToDevice)) != hipSuccess ||
       (e = hipMemcpy(n->d_off, off.data(), off.size() * 4, hipMemcpyHostToDevice)) != hipSuccess ||
       (e = hipMemcpy(n->d_cdf, cdf.data(), cdf.size() * 4, hipMemcpyHostToDevice)) != hipSuccess ||
       (e = hipMemcpy(n->d_pat, pat.data(), pat.size() * 8, hipMemcpyHostToDevice)) != hipSuccess) {
@@ -82,9 +97,28 @@ extern "C" int tsim_noise_sample_device(tsim_noise *n, int64_t B, uint32_t key_h
   if (B == 0) return TSIM_OK;
   if (!d_f) return tsim_fail(TSIM_EINVAL, "f buffer is NULL");
   hipStream_t s = stream ? (hipStream_t)stream : n->prog->stream;
+  if (n->tile > 0 && n->n_ch > 0) {  // one block per tile of shots: rows built in LDS, written once (tsim_noise.hip.h)
+    NoiseArgs a{};
+    a.inv_log2_1mp = n->d_inv;
+    a.cdf_off = n->d_off;
+    a.cdf = n->d_cdf;
+    a.patterns = n->d_pat;
+    a.f = (unsigned long long *)d_f;
+    a.B = B;
+    a.n_ch = n->n_ch;
+    a.WF = n->WF;
+    a.seg = n->tseg;
+    a.tile = n->tile;
+    a.n_tiles = (int)((B + n->tile - 1) / n->tile);
+    a.k0 = key_hi;
+    a.k1 = key_lo;
+    hipLaunchKernelGGL(k_noise_tile, dim3((unsigned)a.n_tiles), dim3(256), (size_t)n->tile * n->WF * 8, s, a);
+    HIP_TRY(hipGetLastError());
+    return TSIM_OK;
+  }
   HIP_TRY(hipMemsetAsync(d_f, 0, (size_t)B * n->WF * 8, s));
   if (n->n_ch == 0) return TSIM_OK;
-  NoiseArgs a;
+  NoiseArgs a{};
   a.log1m_p = n->d_l1p;
   a.cdf_off = n->d_off;
   a.cdf = n->d_cdf;
@@ -109,6 +143,7 @@ extern "C" void tsim_noise_destroy(tsim_noise *n) {
   if (!n) return;
   if (n->device >= 0) (void)hipSetDevice(n->device);
   if (n->d_l1p) (void)hipFree(n->d_l1p);
+  if (n->d_inv) (void)hipFree(n->d_inv);
   if (n->d_off) (void)hipFree(n->d_off);
   if (n->d_cdf) (void)hipFree(n->d_cdf);
   if (n->d_pat) (void)hipFree(n->d_pat);

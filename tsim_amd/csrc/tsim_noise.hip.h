@@ -16,6 +16,8 @@
 namespace tsimk {
 
 struct NoiseArgs {
+  const float *inv_log2_1mp; // [n_ch] 1 / log2(1 - p_fire) (negative; 0 -> channel always fires): k_noise_tile
+  int tile, n_tiles;         // k_noise_tile: shots per block (seg divides it)
   const double *log1m_p;     // [n_ch] log(1 - p_fire)  (0 -> channel always fires)
   const uint32_t *cdf_off;   // [n_ch + 1] offsets into cdf / pattern tables
   const float *cdf;          // conditional CDF over the non-identity outcomes
@@ -64,6 +66,71 @@ __global__ void __launch_bounds__(256) k_noise(NoiseArgs A) {
       if (v) atomicXor(&A.f[pos * A.WF + w], (unsigned long long)v);
     }
   }
+}
+
+// The same sampler, one block per TILE of shots (round 3).  k_noise applies every fire with a device-scope 64-bit
+// atomic on the row in HBM behind a full memset: 1.3 atomics per shot at the benchmark's noise level are what it
+// waits for (62 us per 10^6 shots; its arithmetic is a few microseconds).  Here a block owns the rows
+// [tile * TILE, (tile + 1) * TILE): they live in LDS - zeroed there, patterns applied with LDS atomics by the
+// (channel, sub-segment) pairs of the tile, then written ONCE, coalesced; no memset, no global atomic.  The gap of the
+// geometric skip is float32: floor(log2(u) / log2(1 - p)) + 1 with u a 24-bit uniform in (0, 1] and v_log_f32 (1 ulp)
+// - P(gap >= k) is reproduced to a relative ~1e-6, gaps beyond 2^24 / p shots are cut off (channels with
+// p < 1e-6 per shot lose ~1e-7 of their fires); single-outcome channels use both Threefry words of a block for gaps.
+__global__ void __launch_bounds__(256) k_noise_tile(NoiseArgs A) {
+  extern __shared__ unsigned long long noise_rows[];  // [TILE][WF]
+  const long long t_lo = (long long)blockIdx.x * A.tile;
+  const int rows = (int)min((long long)A.tile, A.B - t_lo);
+  for (int i = threadIdx.x; i < rows * A.WF; i += blockDim.x) noise_rows[i] = 0ull;
+  __syncthreads();
+  const int nsub = A.tile / A.seg;
+  const int pairs = A.n_ch * nsub;
+  for (int pr = threadIdx.x; pr < pairs; pr += blockDim.x) {
+    const int ch = pr / nsub, sub = pr - ch * nsub;
+    const int lo = sub * A.seg, hi = min(lo + A.seg, rows);
+    if (lo >= rows) continue;
+    const float inv = A.inv_log2_1mp[ch];
+    const uint32_t c0 = A.cdf_off[ch], c1 = A.cdf_off[ch + 1];
+    const bool single = c1 - c0 <= 1u;
+    // stream of this (channel, global segment): key folded with the channel, counter = (segment, draw)
+    const uint32_t gseg = (uint32_t)((t_lo / A.seg) + sub);
+    int pos = lo - 1;
+    uint32_t spare = 0u;
+    bool have_spare = false;
+    for (uint32_t draw = 0;; ++draw) {
+      uint32_t w_gap, w_out = 0u;
+      if (single && have_spare) {
+        w_gap = spare;
+        have_spare = false;
+      } else {
+        uint32_t x0 = gseg, x1 = draw;
+        threefry2x32(A.k0 ^ (uint32_t)ch * 0x9E3779B9u, A.k1, x0, x1);
+        w_gap = x0;
+        if (single) { spare = x1; have_spare = true; }
+        else w_out = x1;
+      }
+      int gap = 1;
+      if (inv < 0.0f) {
+        const float u = (float)((w_gap >> 8) + 1u) * (1.0f / 16777216.0f);  // (0, 1]
+        const float g = floorf(__log2f(u) * inv);
+        gap = g >= 1.0e9f ? 1000000000 : (int)g + 1;
+      }
+      if (gap >= hi - pos) break;  // (no overflow: pos < hi)
+      pos += gap;
+      uint32_t o = c0;
+      if (!single) {
+        const float u2 = (float)(w_out >> 8) * (1.0f / 16777216.0f);
+        while (o + 1 < c1 && A.cdf[o] <= u2) ++o;
+      }
+      const uint64_t *pat = A.patterns + (size_t)o * A.WF;
+      for (int w = 0; w < A.WF; ++w) {
+        const uint64_t v = pat[w];
+        if (v) atomicXor(&noise_rows[pos * A.WF + w], (unsigned long long)v);
+      }
+    }
+  }
+  __syncthreads();
+  unsigned long long *dst = A.f + t_lo * A.WF;
+  for (int i = threadIdx.x; i < rows * A.WF; i += blockDim.x) dst[i] = noise_rows[i];
 }
 
 }  // namespace tsimk

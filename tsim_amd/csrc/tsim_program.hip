@@ -702,6 +702,9 @@ retry_pack:
 }
 extern "C" void tsim_program_destroy(tsim_program *p) {
   if (!p) return;
+  if (p->device >= 0) (void)hipSetDevice(p->device);
+  for (hipStream_t &a : p->aux)
+    if (a) { (void)hipStreamSynchronize(a); (void)hipStreamDestroy(a); a = nullptr; }
   if (p->finalized && p->device >= 0) {
     (void)hipSetDevice(p->device);
     (void)tsim_flush_hard(p);  // parked hard rows of launches that were never joined: finish them, then drain every lane
@@ -857,6 +860,54 @@ extern "C" int tsim_memcpy_d2h(tsim_program *p, void *h_dst, const void *d_src, 
   if (nbytes == 0) return TSIM_OK;
   HIP_TRY(hipMemcpyAsync(h_dst, d_src, (size_t)nbytes, hipMemcpyDeviceToHost, p->stream));
   HIP_TRY(hipStreamSynchronize(p->stream));
+  return TSIM_OK;
+}
+
+// Asynchronous copies on a caller-chosen stream (e.g. an auxiliary stream of the handle): the end-to-end sampler moves
+// finished batches to the host while later ones are still being sampled (utils/cuda_helpers.py:105-141 copies once, at
+// the end).  Pageable host memory is allowed (the runtime stages it; the call may then block until the copy is done).
+extern "C" int tsim_memcpy_d2h_async(tsim_program *p, void *h_dst, const void *d_src, int64_t nbytes, void *stream) {
+  if (int r = tsim_need_final(p)) return r;
+  if (int r = tsim_set_device(p)) return r;
+  if (nbytes < 0) return tsim_fail(TSIM_EINVAL, "negative size");
+  if (nbytes == 0) return TSIM_OK;
+  HIP_TRY(hipMemcpyAsync(h_dst, d_src, (size_t)nbytes, hipMemcpyDeviceToHost, stream ? (hipStream_t)stream : p->stream));
+  return TSIM_OK;
+}
+
+extern "C" int tsim_memcpy_h2d_async(tsim_program *p, void *d_dst, const void *h_src, int64_t nbytes, void *stream) {
+  if (int r = tsim_need_final(p)) return r;
+  if (int r = tsim_set_device(p)) return r;
+  if (nbytes < 0) return tsim_fail(TSIM_EINVAL, "negative size");
+  if (nbytes == 0) return TSIM_OK;
+  HIP_TRY(hipMemcpyAsync(d_dst, h_src, (size_t)nbytes, hipMemcpyHostToDevice, stream ? (hipStream_t)stream : p->stream));
+  return TSIM_OK;
+}
+
+extern "C" int tsim_stream_synchronize(tsim_program *p, void *stream) {
+  if (int r = tsim_need_final(p)) return r;
+  if (int r = tsim_set_device(p)) return r;
+  HIP_TRY(hipStreamSynchronize(stream ? (hipStream_t)stream : p->stream));
+  return TSIM_OK;
+}
+
+// Auxiliary streams owned by the handle (index 0 .. TSIM_AUX_STREAMS-1, created on first use, destroyed with it): for
+// work beside the sampling lanes - the device-side channel sampler, host transfers.
+extern "C" int tsim_aux_stream(tsim_program *p, int32_t index, void **stream) {
+  if (int r = tsim_need_final(p)) return r;
+  if (int r = tsim_set_device(p)) return r;
+  if (index < 0 || index >= TSIM_AUX_STREAMS || !stream) return tsim_fail(TSIM_EINVAL, "bad auxiliary stream %d", index);
+  if (!p->aux[index]) HIP_TRY(hipStreamCreateWithFlags(&p->aux[index], hipStreamNonBlocking));
+  *stream = (void *)p->aux[index];
+  return TSIM_OK;
+}
+
+// The pipeline slot the next batch of tsim_sample_steps_device will use (its rotation over all TSIM_PIPELINE_SLOTS):
+// what a caller needs to join exactly that batch later (tsim_sample_batch_device_end on the slot).
+extern "C" int tsim_pipeline_next_slot(tsim_program *p, int32_t *slot) {
+  if (int r = tsim_need_final(p)) return r;
+  if (!slot) return tsim_fail(TSIM_EINVAL, "NULL argument");
+  *slot = (int32_t)(p->steps_slot % (unsigned long long)TSIM_PIPELINE_SLOTS);
   return TSIM_OK;
 }
 

@@ -29,12 +29,14 @@ equivalent, the error bits never leave HBM.
 
 from __future__ import annotations
 
+import ctypes as C
 from dataclasses import dataclass
 
 import numpy as np
 
 from . import prng
 from .backend import (  # noqa: F401
+    result_pool,
     DeviceNoiseSampler,
     HipProgram,
     check_norm_deviation,
@@ -250,6 +252,7 @@ class _CompiledSamplerBase:
         self._direct_detector_mask = self._direct.detector_mask
         self._device_noise = None
         self._f_slots = None
+        self._f_ring = None
         self._stage = None      # host staging array of one batch of packed f rows
         self._bufs: dict = {}  # name -> (HipProgram, DeviceBuffer): grow-only scratch of the device route
 
@@ -376,6 +379,10 @@ class _CompiledSamplerBase:
         for _hp, buf in self._bufs.values():
             buf.free()
         self._bufs.clear()
+        if self._f_ring is not None:
+            for buf in self._f_ring[2]:
+                buf.free()
+            self._f_ring = None
         if self._f_slots is not None:
             for buf in self._f_slots[2]:
                 buf.free()
@@ -391,6 +398,100 @@ class _CompiledSamplerBase:
         hp.d2h(host, d_u8.ptr)
         return host.view(np.bool_)
 
+    def _device_noise_plain(self, shots: int, batch_size: int | None, want_ref: bool, packed_columns: int | None = None):
+        """``noise="device"``: three things at once - ``k_noise`` fills the f rows of group g + 1 on its own stream, the
+        sampling kernels of group g run on the pipeline lanes (``tsim_sample_steps_device``: fused first passes, one
+        hard-row batch per group), the rows of group g - 1 travel to the host on a copy stream.  A group is a few
+        batches; every batch owns the f buffer of its pipeline slot, so the noise stream only waits for the batch that
+        used the slot before (``tsim_sample_batch_device_end`` on it).  The reference's loop does the same things one
+        after the other (``sampler.py:393-415``: sample f, upload, sample_program, concatenate, download once)."""
+        hp = self._hip()
+        plan = plan_batches(shots, batch_size, self._estimate_batch_size())
+        ref = self._compute_reference_sample() if want_ref else None
+        cs = self._channel_sampler
+        num_f, n_out = cs.num_f, int(self._program.num_outputs)
+        wf, wo = max(1, (num_f + 63) // 64), (n_out + 63) // 64
+        n_comp = max(1, len(self._program.components))
+        total, size = plan.size * plan.count, plan.size
+        nslot = HipProgram.PIPELINE_SLOTS
+        ring = self._f_ring
+        if ring is None or ring[0] is not hp or ring[1] < size * wf * 8:
+            if ring is not None and ring[0] is hp:
+                hp.synchronize()
+                for buf in ring[2]:
+                    buf.free()
+            self._f_ring = ring = (hp, size * wf * 8, [hp.malloc(size * wf * 8) for _ in range(nslot)])
+        f_ring = ring[2]
+        direct_packed = packed_columns is not None and packed_columns == n_out
+        row_bytes = (n_out + 7) // 8 if direct_packed else wo * 8
+        d_rows, d_devs = self._scratch(hp, "rows", total * row_bytes + 16), self._scratch(hp, "devs", plan.count * n_comp * 4)
+        noise = self._device_noise_sampler(hp)
+        s_noise, s_copy = hp.aux_stream(0), hp.aux_stream(1)
+        # results land in recycled pinned memory (backend.PinnedPool): truly asynchronous copies, no first-touch page faults
+        pool = result_pool()
+        if direct_packed:
+            out = pool.take((total, row_bytes))
+        elif packed_columns is not None:
+            rb = (packed_columns + 7) // 8
+            out = pool.take((total, rb))
+            d_c = self._scratch(hp, "compact", total * rb + 16)
+        else:
+            out = pool.take((total, n_out))
+            d_u8 = self._scratch(hp, "unpacked", total * n_out)
+        key_state = (C.c_uint32 * 2)(self._key[0] & 0xFFFFFFFF, self._key[1] & 0xFFFFFFFF)
+        # groups: small at both ends (the first one starts the GPU early, the last one is all that is left to download
+        # when the kernels are done), up to 4 batches in between
+        sizes, left = [], plan.count
+        while left > 0:
+            n = 1 if (not sizes or left <= 2) else min(4, left - 1)
+            sizes.append(n)
+            left -= n
+        groups, b0, done = [], 0, 0
+
+        def download(g) -> None:
+            lo, n, slots = g
+            for sl in slots:
+                hp.sample_batch_device_end(sl, s_copy)  # the copy stream waits for exactly these batches
+            r0, r1 = lo * size, (lo + n) * size
+            if direct_packed:
+                hp.d2h_async(out[r0:r1], d_rows.ptr + r0 * row_bytes, s_copy)
+            elif packed_columns is not None:
+                hp.compact_rows_device(d_rows.ptr + r0 * row_bytes, r1 - r0, packed_columns, d_c.ptr + r0 * rb, in_words=wo, stream=s_copy)
+                hp.d2h_async(out[r0:r1], d_c.ptr + r0 * rb, s_copy)
+            else:
+                hp.unpack_bits_device(d_rows.ptr + r0 * row_bytes, r1 - r0, n_out, d_u8.ptr + r0 * n_out, stream=s_copy)
+                hp.d2h_async(out[r0:r1], d_u8.ptr + r0 * n_out, s_copy)
+
+        for n in sizes:
+            first = hp.pipeline_next_slot()
+            slots = [(first + i) % nslot for i in range(n)]
+            for sl in slots:
+                hp.sample_batch_device_end(sl, s_noise)  # the slot's previous batch no longer reads its f buffer
+                self._noise_key, nk = hp.split_key(self._noise_key)
+                noise.sample_into(f_ring[sl].ptr, size, nk, stream=s_noise)
+            hp.pipeline_wait_stream(s_noise)  # every lane is behind the noise queued so far
+            hp.sample_steps_device([f_ring[sl].ptr for sl in slots], size, num_f, key_state,
+                                   [d_rows.ptr + (b0 + i) * size * row_bytes for i in range(n)], inputs_ready=True,
+                                   out_bit_packed=direct_packed, d_norm_dev=[d_devs.ptr + (b0 + i) * n_comp * 4 for i in range(n)])
+            groups.append((b0, n, slots))
+            b0 += n
+            if len(groups) >= 2:  # the previous group's rows leave while this group is sampled (pinned target: the call returns at once)
+                download(groups[done])
+                done += 1
+        while done < len(groups):
+            download(groups[done])
+            done += 1
+        self._key = (int(key_state[0]), int(key_state[1]))
+        for sl in range(nslot):
+            hp.sample_batch_device_end(sl)  # the handle's stream is behind everything (the devs copy below runs there)
+        devs = np.zeros(plan.count * n_comp, dtype=np.float32)
+        hp.d2h(devs, d_devs.ptr)
+        hp.stream_synchronize(s_copy)
+        for b in range(plan.count):
+            self._check_devs(devs[b * n_comp:(b + 1) * n_comp])
+        res = out[:shots]
+        return (res if (direct_packed or packed_columns is not None) else res.view(np.bool_)), ref
+
     def _device_plain(self, shots: int, batch_size: int | None, want_ref: bool, packed_columns: int | None = None):
         """noise -> f -> ``sample_program`` -> layout conversion without leaving the GPU.
 
@@ -398,6 +499,8 @@ class _CompiledSamplerBase:
         buffer; ``_LANES`` f buffers rotate, so the host generates (or ``k_noise`` fills) batch i+1 while batch
         i runs.  Host noise: the reference row, when wanted, is row 0 of the first batch.  Device noise: the
         reference sample is its own 1-row call (there is no stream to stay aligned with)."""
+        if self._noise != "host":
+            return self._device_noise_plain(shots, batch_size, want_ref, packed_columns)
         hp = self._hip()
         host_noise = self._noise == "host"
         rides = want_ref and host_noise

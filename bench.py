@@ -1009,7 +1009,7 @@ def extra_legs(backend, synth, program, cfg, hp, info, B, num_f, n_out, key, f_b
                                   ("device_noise", dict(noise="device"), dict(append_observables=True)),
                                   ("device_noise_bit_packed", dict(noise="device"), dict(append_observables=True, bit_packed=True))):
                 s = CompiledDetectorSampler(program, channel_probs=probs, error_transform=T, seed=1, device=device, **kw)
-                n_sh = shots * (4 if kw["noise"] == "device" else 1)  # 16 batches for the device route: its pipeline is three stages deep
+                n_sh = shots * (4 if kw["noise"] == "device" else 2)  # 16 / 8 batches: the routes are pipelines (noise | kernels | download)
                 for _ in range(2):  # same shape twice: buffers and lanes, then the launch plan's kernels (first launches load code)
                     s.sample(n_sh, batch_size=batch, **skw)
                 dts = []
@@ -1020,6 +1020,14 @@ def extra_legs(backend, synth, program, cfg, hp, info, B, num_f, n_out, key, f_b
                 dt = statistics.median(dts)
                 leg[name] = {"shots_per_s": n_sh / dt, "seconds": dt, "shots": n_sh, "result_bytes": int(res.nbytes)}
                 s.release()
+            # the bound of the bit-exact route: the reference's channel stream is one dependency chain per batch
+            cs = CompiledDetectorSampler(program, channel_probs=probs, error_transform=T, seed=1, device=device, noise="host")._channel_sampler
+            stage = np.empty((batch, max(1, (num_f + 63) // 64)), np.uint64)
+            cs.sample_packed(batch, out=stage)
+            t0 = time.perf_counter()
+            for _ in range(3):
+                cs.sample_packed(batch, out=stage)
+            leg["channel_sampler_alone_shots_per_s"] = 3 * batch / (time.perf_counter() - t0)
             e2e[mname] = leg
     out["e2e_sample"] = e2e
     return out

@@ -36,6 +36,7 @@ import numpy as np
 
 from . import prng
 from .backend import (  # noqa: F401
+    alloc_pinned_numpy,
     result_pool,
     DeviceNoiseSampler,
     HipProgram,
@@ -493,67 +494,125 @@ class _CompiledSamplerBase:
         return (res if (direct_packed or packed_columns is not None) else res.view(np.bool_)), ref
 
     def _device_plain(self, shots: int, batch_size: int | None, want_ref: bool, packed_columns: int | None = None):
-        """noise -> f -> ``sample_program`` -> layout conversion without leaving the GPU.
+        """noise -> f -> ``sample_program`` -> layout conversion, the GPU busy beside the channel sampler.
 
-        Every batch is a pipelined launch (``tsim_sample_batch_device_begin``) into its slice of one result
-        buffer; ``_LANES`` f buffers rotate, so the host generates (or ``k_noise`` fills) batch i+1 while batch
-        i runs.  Host noise: the reference row, when wanted, is row 0 of the first batch.  Device noise: the
-        reference sample is its own 1-row call (there is no stream to stay aligned with)."""
+        ``noise="device"``: :meth:`_device_noise_plain`.  ``noise="host"`` (the reference's numpy/PCG64 stream, bit for
+        bit): the stream is sequential by contract - ``ChannelSampler`` is one dependency chain per batch, 5 ms per 10^6
+        shots - so it runs on a WORKER THREAD (the native sampler releases the GIL) into a ring of pinned staging
+        buffers, batch after batch in stream order, while this thread uploads batch i (asynchronous copy from the
+        pinned buffer), launches its kernels on the pipeline lanes and sends the rows of batch i - 1 to the host
+        (asynchronous copy into recycled pinned result memory).  Wall time = the sampler's, plus the last batch's trip.
+        The reference row, when wanted, is row 0 of the first batch (``sampler.py:395-404``)."""
         if self._noise != "host":
             return self._device_noise_plain(shots, batch_size, want_ref, packed_columns)
+        import queue
+        import threading
+
         hp = self._hip()
-        host_noise = self._noise == "host"
-        rides = want_ref and host_noise
+        rides = want_ref
         plan = plan_batches(shots, batch_size, self._estimate_batch_size(), reserve_row=rides)
-        ref = self._compute_reference_sample() if (want_ref and not host_noise) else None
+        ref = None
         cs = self._channel_sampler
         num_f, n_out = cs.num_f, int(self._program.num_outputs)
         wf, wo = max(1, (num_f + 63) // 64), (n_out + 63) // 64
         n_comp = max(1, len(self._program.components))
-        total = plan.size * plan.count
-        lanes = self._lane_buffers(hp, plan.size * wf * 8)
+        total, size = plan.size * plan.count, plan.size
+        lanes = self._lane_buffers(hp, size * wf * 8)
         # all columns wanted bit-packed: the kernels write that layout themselves (no padded rows, no compaction pass)
         direct_packed = packed_columns is not None and packed_columns == n_out
         row_bytes = (n_out + 7) // 8 if direct_packed else wo * 8
         d_rows, d_devs = self._scratch(hp, "rows", total * row_bytes + 16), self._scratch(hp, "devs", plan.count * n_comp * 4)
-        noise = None if host_noise else self._device_noise_sampler(hp)
-        for b in range(plan.count):
-            lane = b % _LANES
-            hp.sample_batch_device_end(lane)  # the lane's previous launch no longer reads its f buffer
-            if host_noise:
-                if self._stage is None or self._stage.shape != (plan.size, wf):
-                    self._stage = np.empty((plan.size, wf), dtype=np.uint64)
-                rows = cs.sample_packed(plan.size, out=self._stage)
+        s_up, s_copy = hp.aux_stream(0), hp.aux_stream(1)
+        pool = result_pool()
+        if direct_packed:
+            out = pool.take((total, row_bytes))
+        elif packed_columns is not None:
+            rb = (packed_columns + 7) // 8
+            out = pool.take((total, rb))
+            d_c = self._scratch(hp, "compact", total * rb + 16)
+        else:
+            out = pool.take((total, n_out))
+            d_u8 = self._scratch(hp, "unpacked", total * n_out)
+        # staging ring: three pinned buffers (one being filled, one being uploaded, one spare)
+        n_stage = min(3, plan.count)
+        if self._stage is None or self._stage[0].shape != (size, wf) or len(self._stage) < n_stage:
+            self._stage = [alloc_pinned_numpy(size * wf * 8, np.uint64, (size, wf)) for _ in range(3)]
+        free_q: queue.Queue = queue.Queue()
+        full_q: queue.Queue = queue.Queue()
+        for i in range(n_stage):
+            free_q.put(i)
+
+        def produce() -> None:
+            try:
+                for b in range(plan.count):
+                    i = free_q.get()
+                    if i is None:
+                        return
+                    cs.sample_packed(size, out=self._stage[i])
+                    full_q.put(i)
+            except BaseException as exc:  # hand the error to the consumer
+                full_q.put(exc)
+
+        worker = threading.Thread(target=produce, name="tsim-channel-sampler", daemon=True)
+        worker.start()
+
+        def download(b: int) -> None:
+            hp.sample_batch_device_end(b % _LANES, s_copy)  # the copy stream waits for exactly this batch
+            r0, r1 = b * size, (b + 1) * size
+            if direct_packed:
+                hp.d2h_async(out[r0:r1], d_rows.ptr + r0 * row_bytes, s_copy)
+            elif packed_columns is not None:
+                hp.compact_rows_device(d_rows.ptr + r0 * row_bytes, size, packed_columns, d_c.ptr + r0 * rb, in_words=wo, stream=s_copy)
+                hp.d2h_async(out[r0:r1], d_c.ptr + r0 * rb, s_copy)
+            else:
+                hp.unpack_bits_device(d_rows.ptr + r0 * row_bytes, size, n_out, d_u8.ptr + r0 * n_out, stream=s_copy)
+                hp.d2h_async(out[r0:r1], d_u8.ptr + r0 * n_out, s_copy)
+
+        try:
+            for b in range(plan.count):
+                i = full_q.get()
+                if isinstance(i, BaseException):
+                    raise i
+                rows = self._stage[i]
                 if rides and b == 0:
                     rows[0] = 0
-                hp.h2d(lanes[lane], rows)
-            else:
-                self._noise_key, nk = hp.split_key(self._noise_key)
-                noise.sample_into(lanes[lane].ptr, plan.size, nk)
-            hp.sample_batch_device_begin(lane, lanes[lane].ptr, plan.size, num_f, self._next_key(),
-                                         d_rows.ptr + b * plan.size * row_bytes, d_norm_dev=d_devs.ptr + b * n_comp * 4,
-                                         out_bit_packed=direct_packed)
+                lane = b % _LANES
+                hp.sample_batch_device_end(lane, s_up)  # the lane's previous launch no longer reads its f buffer
+                hp.h2d_async(lanes[lane].ptr, rows, s_up)
+                hp.pipeline_wait_stream(s_up)  # every lane is behind the upload
+                hp.sample_batch_device_begin(lane, lanes[lane].ptr, size, num_f, self._next_key(),
+                                             d_rows.ptr + b * size * row_bytes, d_norm_dev=d_devs.ptr + b * n_comp * 4,
+                                             inputs_ready=True, out_bit_packed=direct_packed)
+                if b > 0:
+                    download(b - 1)
+                hp.stream_synchronize(s_up)  # (0.15 ms per 8 MB) the staging buffer may be refilled
+                free_q.put(i)
+            download(plan.count - 1)
+        finally:
+            free_q.put(None)
+            worker.join()
         for lane in range(min(_LANES, plan.count)):
             hp.sample_batch_device_end(lane)
         devs = np.zeros(plan.count * n_comp, dtype=np.float32)
-        skip = 1 if rides else 0
-        if direct_packed:
-            out = np.empty((total, row_bytes), dtype=np.uint8)
-            hp.d2h(out, d_rows.ptr)
-        elif packed_columns is not None:  # bit_packed=True of the first columns: compacted on the GPU
-            rb = (packed_columns + 7) // 8
-            d_c = self._scratch(hp, "compact", total * rb + 16)
-            hp.compact_rows_device(d_rows.ptr, total, packed_columns, d_c.ptr, in_words=wo)
-            out = np.empty((total, rb), dtype=np.uint8)
-            hp.d2h(out, d_c.ptr)
-        else:
-            out = self._download_bools(hp, d_rows, total)
-            if rides:
-                ref = out[0].copy()
         hp.d2h(devs, d_devs.ptr)
+        hp.stream_synchronize(s_copy)
+        skip = 1 if rides else 0
+        if rides:
+            if packed_columns is None:
+                ref = out[0].view(np.bool_).copy()
+            else:  # the reference row is wanted as booleans whatever the layout of the rows: one more tiny download
+                one = np.zeros((1, n_out), dtype=np.uint8)
+                d_one = self._scratch(hp, "ref_row", n_out)
+                if direct_packed:  # the kernels wrote bit_packed rows: unpack row 0 on the host
+                    ref = np.unpackbits(out[0], bitorder="little")[:n_out].astype(np.bool_)
+                else:
+                    hp.unpack_bits_device(d_rows.ptr, 1, n_out, d_one.ptr)
+                    hp.d2h(one, d_one.ptr)
+                    ref = one[0].view(np.bool_).copy()
         for b in range(plan.count):
             self._check_devs(devs[b * n_comp:(b + 1) * n_comp])
-        return out[skip:skip + shots], ref
+        res = out[skip:skip + shots]
+        return (res if packed_columns is not None else res.view(np.bool_)), ref
 
     # -- post-selection -----------------------------------------------------------------------------------------
     def _sample_batches_with_postselection(self, shots: int, batch_size: int | None, *, postselection_mask: np.ndarray,

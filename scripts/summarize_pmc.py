@@ -1,6 +1,9 @@
 """Summarise rocprofv3 counter_collection CSVs (one or more passes) for the sampling kernels.
 
 usage: python scripts/summarize_pmc.py OUT.json CONFIG SHOTS DIR [DIR ...]
+       TSIM_PMC_BATCHES_PER_LAUNCH=n: the run used fused first passes of n batches each (round 3: k_sample_lw_fast /
+       k_sample_lw_multi with TSIM_AMD_FUSED_MAX=n; one k_sample_hw / k_sample4h_multi grid per group): the totals are
+       then PER BATCH of SHOTS shots - first pass / n + hard-row grid / n.
 Each DIR is a rocprofv3 -d output directory.  For every kernel whose name contains "k_sample" the
 per-invocation MEDIAN of every counter is computed (bench.py's serial legs after the timed region launch the same
 kernels with the padded 8-byte output word: an average would mix their 7.8 MB of writes into the 2.9 MB of the
@@ -40,7 +43,10 @@ def main():
     per_kernel = {k: {c: statistics.median(v) for c, v in sorted(cs.items())} for k, cs in agg.items()}
     import os
     group = int(os.environ.get("TSIM_AMD_DEFER_GROUP", "4"))
-    if "k_sample4h_multi" in per_kernel:
+    fused = int(os.environ.get("TSIM_PMC_BATCHES_PER_LAUNCH", "0"))
+    if fused and any(k in per_kernel for k in ("k_sample_lw_fast", "k_sample_lw_multi")):
+        weights = {k: 1.0 / fused for k in per_kernel if k in ("k_sample_lw_fast", "k_sample_lw_multi", "k_sample_hw", "k_sample4h_multi")}
+    elif "k_sample4h_multi" in per_kernel:
         weights = {k: 1.0 for k in per_kernel if k.startswith("k_sample_lw")}  # k_sample_lw / k_sample_lw_reg
         weights["k_sample4h_multi"] = 1.0 / group
     else:
@@ -55,6 +61,7 @@ def main():
     res["_invocations"] = {k: {c: len(v) for c, v in cs.items()} for k, cs in agg.items()}
     res["_config"] = config
     res["_shots"] = shots
+    res["_per"] = "batch of _shots shots" + (f" (fused launches of {fused} batches)" if fused else "")
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res, indent=1))
 

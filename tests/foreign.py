@@ -40,6 +40,26 @@ class ForeignArray:
         return self._a[k]
 
 
+class ForeignScalar:
+    """A 0-d array-like leaf (what ``jnp.asarray(5)`` or a traced static looks like from outside): converts through
+    ``int()`` / ``bool()`` / ``np.asarray`` only."""
+
+    def __init__(self, v):
+        self._v = v
+
+    def __int__(self):
+        return int(self._v)
+
+    def __index__(self):
+        return int(self._v)
+
+    def __bool__(self):
+        return bool(self._v)
+
+    def __array__(self, dtype=None, copy=None):
+        return np.asarray(self._v, dtype=dtype)
+
+
 @dataclass(frozen=True)
 class FNodePhases:
     phases: ForeignArray
@@ -108,21 +128,23 @@ class FCompiledProgram:
     num_detectors: int
 
 
-def to_foreign(program) -> FCompiledProgram:
-    """Re-express one of this repo's plain programs in the foreign containers (dtypes as the reference's)."""
+def to_foreign(program, scalar_leaves: bool = False) -> FCompiledProgram:
+    """Re-express one of this repo's plain programs in the foreign containers (dtypes as the reference's).
+    ``scalar_leaves``: counts and flags as 0-d array-likes instead of Python ints / bools."""
     A = ForeignArray
+    S = ForeignScalar if scalar_leaves else (lambda v: v)
 
     def level(lv):
         a, b, c, d, p = lv.node_phases, lv.halfpi_phases, lv.pi_products, lv.phase_pairs, lv.prefactor
         return FCompiledScalarGraphs(
-            int(lv.num_graphs), int(lv.n_params),
+            S(int(lv.num_graphs)), S(int(lv.n_params)),
             FNodePhases(A(a.phases, np.uint8), A(a.params, np.uint8), A(a.counts, np.int32)),
             FHalfPiPhases(A(b.coeffs, np.uint8), A(b.params, np.uint8)),
             FPiProducts(A(c.psi_const, np.uint8), A(c.psi_params, np.uint8), A(c.phi_const, np.uint8), A(c.phi_params, np.uint8)),
             FPhasePairs(A(d.alpha, np.uint8), A(d.alpha_params, np.uint8), A(d.beta, np.uint8), A(d.beta_params, np.uint8),
                         A(d.counts, np.int32)),
             FScalarPrefactor(A(p.phase_indices, np.uint8), A(p.floatfactor, np.int32), A(p.power2, np.int32),
-                             A(p.approximate_floatfactors, np.complex64), bool(p.has_approximate_floatfactors)),
+                             A(p.approximate_floatfactors, np.complex64), S(bool(p.has_approximate_floatfactors))),
         )
 
     comps = tuple(
@@ -133,7 +155,7 @@ def to_foreign(program) -> FCompiledProgram:
     return FCompiledProgram(
         comps, A(program.direct_f_indices, np.int32), A(program.direct_flips, np.bool_), A(program.output_order, np.int32),
         None if program.output_reindex is None else A(program.output_reindex, np.int32),
-        int(program.num_outputs), int(program.num_detectors),
+        S(int(program.num_outputs)), S(int(program.num_detectors)),
     )
 
 

@@ -77,3 +77,29 @@ def test_c1_direct_only_config_through_sample_program(hip):
     hp = hip.get_hip_program(p2)
     packed, _ = hp.sample_batch(f2, (0, 7), bit_packed=True)
     np.testing.assert_array_equal(packed[:, :3], np.packbits(got, axis=1, bitorder="little"))
+
+
+@pytest.mark.parametrize("tables", [True, False])
+def test_every_leaf_type_on_the_gpu(hip, tables):
+    """A foreign program with 0-d scalar leaves, no output_reindex and a ZERO-graph level (compile/evaluate.py:34-35:
+    amplitude 0): the kernels give the oracle's bits and its normalisation deviation - exactly 1, which the seam
+    function turns into the reference's ValueError (sampler.py:149-161)."""
+    from test_foreign_program import _program_with_an_empty_level
+    from oracle import oracle_c as OC
+
+    prog = _program_with_an_empty_level()
+    foreign = to_foreign(prog, scalar_leaves=True)
+    from tsim_amd.program import from_tsim
+
+    hp = hip.HipProgram(from_tsim(foreign), pattern_tables=tables)
+    f = synth.synth_f(3000, 20, 0.1, seed=4)
+    want, wdev = OC.OracleProgram(prog).sample_program(f, (1, 2), return_devs=True)
+    got, gdev = hp.sample_batch(f, (1, 2))
+    np.testing.assert_array_equal(got, want)
+    np.testing.assert_array_equal(np.asarray(gdev, np.float32), np.asarray(wdev, np.float32))
+    assert float(gdev[0]) == 1.0
+    with pytest.raises(ValueError):
+        hip.sample_program(foreign, f, (1, 2))
+    # the same level through the evaluate seam: zeros
+    z = hip.evaluate(foreign.components[0].compiled_scalar_graphs[1], f[:50, :7])
+    assert z.shape == (50,) and not z.any()

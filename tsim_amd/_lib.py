@@ -137,27 +137,39 @@ SYMBOLS: dict[str, tuple] = {
 _lib = None
 
 
-def load() -> C.CDLL:
-    """Load ``libtsim_hip.so`` and bind every declared symbol (raises if absent)."""
+def load(build: bool = True) -> C.CDLL:
+    """Load ``libtsim_hip.so`` and bind every declared symbol (raises if absent).
+
+    The binary must be the one built from THIS tree: the content hash recorded at build time is compared with the
+    sources (a prebuilt .so travels with snapshots of the tree).  A stale or unstamped one is rebuilt here when
+    ``build`` is true (hipcc is part of the image on the GPU boxes) - never used silently.  ``build=False`` (the
+    host-only channel sampler's probe) never starts a compile: it raises instead, and the caller falls back.
+    ``TSIM_AMD_ALLOW_STALE=1`` opts into using a binary whose stamp is missing or different, with a warning - for
+    machines without hipcc that received a library built elsewhere from the same sources."""
     global _lib
     if _lib is not None:
         return _lib
     path = Path(os.environ.get("TSIM_AMD_LIB", LIB_PATH))
     if path == LIB_PATH:
-        # The binary must be the one built from THIS tree: compare the content hash recorded at build
-        # time with the sources (a prebuilt .so travels with snapshots of the tree; a stale one is
-        # rebuilt here, never used silently).
         from . import build as _build
 
         if _build.needs_build():
-            try:
-                _build.build(verbose=False)
-            except Exception as exc:
-                raise HipBackendError(
-                    f"{path} is missing or was built from different sources and cannot be rebuilt here "
-                    f"({exc}); build it with `python -m tsim_amd.build` (hipcc --offload-arch=gfx950) - "
-                    "there is no CPU fallback"
-                ) from exc
+            if path.exists() and os.environ.get("TSIM_AMD_ALLOW_STALE") == "1":
+                import warnings
+
+                warnings.warn(f"tsim_amd: using {path} although its build stamp is missing or does not match the sources "
+                              "(TSIM_AMD_ALLOW_STALE=1)", stacklevel=2)
+            elif not build:
+                raise HipBackendError(f"{path} is missing or was built from different sources (not building from this call)")
+            else:
+                try:
+                    _build.build(verbose=False)
+                except Exception as exc:
+                    raise HipBackendError(
+                        f"{path} is missing or was built from different sources and cannot be rebuilt here "
+                        f"({exc}); build it with `python -m tsim_amd.build` (hipcc --offload-arch=gfx950), or set "
+                        "TSIM_AMD_ALLOW_STALE=1 to use it as it is - there is no CPU fallback"
+                    ) from exc
     if not path.exists():
         raise HipBackendError(
             f"{path} not found - build it with `python -m tsim_amd.build` "

@@ -419,7 +419,8 @@ def native_stream_available() -> tuple:
     try:
         from . import _lib
 
-        lib = _lib.load()
+        # (a probe: constructing a host-side sampler must never start a multi-minute build of the GPU library)
+        lib = _lib.load(build=False)
         gen = np.random.default_rng(20260928)
         twin = np.random.default_rng(20260928)
         for kind, p, n, dtype, draw in (
@@ -441,4 +442,6 @@ def native_stream_available() -> tuple:
         _native_verdict = (True, "")
     except Exception as exc:  # library missing / not loadable: the numpy engine still gives the right stream
         _native_verdict = (False, repr(exc))
+        warnings.warn(f"tsim_amd: native channel sampler unavailable ({exc!r}); using the numpy engine - the same stream, "
+                      "about 10x slower (build the library with `python -m tsim_amd.build`)", stacklevel=2)
     return _native_verdict

@@ -178,7 +178,19 @@ class _DevicePostselect:
         self.shots, self.size = shots, size
         self.n_comp = max(1, len(prog.components))
         self.devs = []
-        m = hp.malloc
+        # the store, the rows, the flags and the unpack scratch are O(shots) on the device: refuse what cannot fit instead
+        # of failing half way
+        need = shots * (self.wf * 8 + self.wo * 8 + 1 + self.n_out) + size * (self.wf * 8 + self.wo * 8 + 8)
+        free, _ = hp.mem_info()
+        if need > 0.9 * free:
+            raise MemoryError(f"device post-selection of {shots} shots needs {need >> 20} MiB of device memory, {free >> 20} MiB are free: "
+                              "sample in several calls")
+        self._bufs = []
+
+        def m(nbytes):
+            self._bufs.append(hp.malloc(nbytes))
+            return self._bufs[-1]
+
         self.d_store, self.d_rows = m(shots * self.wf * 8), m(shots * self.wo * 8)
         self.d_flags, self.d_list, self.d_count = m(shots), m(size * 4), m(4)
         self.d_fb, self.d_ob, self.d_idx = m(size * self.wf * 8), m(size * self.wo * 8), m(size * 4)
@@ -215,12 +227,16 @@ class _DevicePostselect:
         hp.d2h(dev, self.d_dev)
         self.devs.append(dev)
 
+    def release(self) -> None:
+        """Give the device buffers back - also on the error paths (a normalisation error, a failed allocation or kernel)."""
+        for buf in self._bufs:
+            buf.free()
+        self._bufs = []
+
     def collect(self):
         rows, gone = self.owner._download_bools(self.hp, self.d_rows, self.shots), np.empty(self.shots, dtype=np.uint8)
         self.hp.d2h(gone, self.d_flags)
-        for buf in (self.d_store, self.d_rows, self.d_flags, self.d_list, self.d_count, self.d_fb, self.d_ob, self.d_idx,
-                    self.d_dev, self.d_mask, self.d_ref):
-            buf.free()
+        self.release()
         for dev in self.devs:
             self.owner._check_devs(dev)
         gone = gone.astype(np.bool_)
@@ -639,8 +655,12 @@ class _CompiledSamplerBase:
         ref_det = ref[:nd] if (ref is not None and xor_detector_ref) else None
         work = (_SeamPostselect(self, shots, test_mask, ref_det) if self._seam_replaced()
                 else _DevicePostselect(self, shots, size, test_mask, ref_det))
-        _run_postselected(shots, size, work, self._next_key)
-        rows, gone = work.collect()
+        try:
+            _run_postselected(shots, size, work, self._next_key)
+            rows, gone = work.collect()
+        finally:
+            if hasattr(work, "release"):
+                work.release()
         self._apply_detector_reference(rows, gone, ref_det)
         return rows, ref, gone
 
@@ -663,8 +683,15 @@ class _CompiledSamplerBase:
         ref = self._compute_reference_sample() if compute_reference else None
         ref_det = ref[: self._num_detectors] if (ref is not None and xor_detector_ref) else None
         helper = _DevicePostselect(self, plan.size * plan.count, plan.size, test_mask, ref_det)
+        try:
+            return self._device_noise_postselect_run(hp, noise, plan, helper, shots, ref, ref_det)
+        finally:
+            helper.release()
+
+    def _device_noise_postselect_run(self, hp, noise, plan, helper, shots, ref, ref_det):
         num_f, wf, wo, n_comp = helper.num_f, helper.wf, helper.wo, helper.n_comp
-        d_devs = hp.malloc(plan.count * n_comp * 4)
+        d_devs = helper.hp.malloc(plan.count * n_comp * 4)
+        helper._bufs.append(d_devs)
         hp.h2d(d_devs, np.zeros(plan.count * n_comp, dtype=np.float32))
         for b in range(plan.count):
             lo = b * plan.size
@@ -677,7 +704,6 @@ class _CompiledSamplerBase:
                                   d_norm_dev=d_devs.ptr + b * n_comp * 4)
         devs = np.zeros(plan.count * n_comp, dtype=np.float32)
         hp.d2h(devs, d_devs)
-        d_devs.free()
         helper.devs = [devs[b * n_comp:(b + 1) * n_comp] for b in range(plan.count)]
         rows, gone = helper.collect()
         rows, gone = rows[:shots], gone[:shots]

@@ -123,6 +123,41 @@ def test_steps_use_the_fused_first_pass_and_split_calls_agree(hip):
             np.testing.assert_array_equal(a, b)
 
 
+@pytest.mark.parametrize("name", ["C2", "C4"])
+def test_hard_rows_on_the_batch_lane_and_on_the_group_lane_agree(hip, name):
+    """Fused groups of at most TSIM_AMD_HARD_INLINE_ROWS shots (default: all) run their hard-row batch on their own
+    first-pass lane, larger ones on the batch lane; a handle that sees both, in turn, returns the rows of a handle
+    that only uses the batch lane - slots are handed from one stream to the other in both directions."""
+    import os
+
+    prog, cfg = synth.config_program(name)
+    nf = cfg["num_f"]
+    sizes = [4000, 4000, 300000, 4000, 300000, 300000, 4000]  # x 8 batches: <= 2e6 inline, 2.4e6 on the batch lane
+    key = prng.key(91)
+    runs = []
+    for env in ("2000000", "0"):
+        os.environ["TSIM_AMD_HARD_INLINE_ROWS"] = env
+        try:
+            prog2, _ = synth.config_program(name)
+            hp = hip.HipProgram(prog2)
+        finally:
+            os.environ.pop("TSIM_AMD_HARD_INLINE_ROWS", None)
+        outs = []
+        k = key
+        for r, B in enumerate(sizes):
+            fs = [synth.synth_f(B, nf, cfg["p_bit"], seed=900 + 31 * r + i) for i in range(8)]
+            if r == 0:
+                _run_steps(hp, prog2, fs[:3], prng.key(1), nf, packed=True)  # feedback
+            o, k2 = _run_steps(hp, prog2, fs, k, nf, packed=True)
+            k = np.array(k2, dtype=np.uint32)
+            outs += o
+        runs.append(outs)
+        hp.close()
+    assert len(runs[0]) == len(runs[1]) == 8 * len(sizes)
+    for a, b in zip(*runs):
+        np.testing.assert_array_equal(a, b)
+
+
 def test_steps_with_shot_offset_and_dense_rows(hip):
     """A shard (shot_offset > 0: no normalisation-check row) and batches dense enough that the launch plan leaves the
     fused path (many hard rows): still the oracle's bits."""

@@ -82,7 +82,10 @@ __device__ __forceinline__ HwLevelOut hw_eval_level(const uint32_t *gimg, cptr i
     const u32x4 *q4 = reinterpret_cast<const u32x4 *>(gimg + graphs + (size_t)g * G_WORDS);  // 64-byte aligned records
     rec0 = q4[0]; rec1 = q4[1]; rec2 = q4[2]; rec3 = q4[3];
   };
-  if (lane < G) load_rec(lane);
+  // phase 2 and everything behind it is the LEADING wave's alone (the others share the row pass and then wait for the
+  // sampled bit, hw_component): a row costs the instructions of one wave, not of four
+  const bool lead = threadIdx.x < 64u;
+  if (lead && lane < G) load_rec(lane);
   // ---- phase 1
   {
     const uint32_t n_rows = lvl[L_HWN];
@@ -90,8 +93,7 @@ __device__ __forceinline__ HwLevelOut hw_eval_level(const uint32_t *gimg, cptr i
     const uint32_t steps = (n_rows + 63u) >> 6;
     const uint32_t fw = flip >> 5, fs = flip & 31u;
     // the block's waves share the steps (a lone wave pays 5-6 cycles per DEPENDENT instruction: the row pass is most
-    // of a level's instructions); everything behind the barrier is done by every wave alike, so all of them hold the
-    // same state and nothing has to be handed over
+    // of a level's instructions)
     const uint32_t wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
 #pragma unroll 8
     for (uint32_t st = wv; st < steps; st += nwv) {
@@ -133,6 +135,9 @@ __device__ __forceinline__ HwLevelOut hw_eval_level(const uint32_t *gimg, cptr i
   }
   // ---- phase 2
   LevelSum S, S0;
+  HwLevelOut o;
+  o.re = o.im = o.re0 = o.im0 = 0.0f;
+  if (!lead) return o;  // (the caller's barrier keeps `par` until the leading wave has read it)
   for (uint32_t g0 = 0; g0 < G; g0 += 64u) {
     const uint32_t g = g0 + lane;
     const bool mine = g < G;
@@ -211,9 +216,6 @@ __device__ __forceinline__ HwLevelOut hw_eval_level(const uint32_t *gimg, cptr i
     S.sa = hw_sum_i32(S.sa); S.sb = hw_sum_i32(S.sb); S.sc = hw_sum_i32(S.sc); S.sd = hw_sum_i32(S.sd);
     if constexpr (DUAL) { S0.sa = hw_sum_i32(S0.sa); S0.sb = hw_sum_i32(S0.sb); S0.sc = hw_sum_i32(S0.sc); S0.sd = hw_sum_i32(S0.sd); }
   }
-  __syncthreads();  // the next level's phase 1 overwrites `par` only after these reads
-  HwLevelOut o;
-  o.re0 = o.im0 = 0.0f;
   level_finish(S, lvl, approx, fixed, o.re, o.im, nullptr);
   if constexpr (DUAL) level_finish(S0, lvl, approx, fixed, o.re0, o.im0, nullptr);
   return o;
@@ -242,13 +244,16 @@ __device__ __forceinline__ void hw_component(const SampleArgs &A, cptr img, cptr
     // the component's draws (sampler.py:74-75), all at once: lane i computes output i's uniform (a lone wave pays for a
     // Threefry block per level otherwise - 75 dependent instructions each)
     uint32_t u_bits = 0u;
-    {
+    if (threadIdx.x < 64u) {
       const uint32_t o = keybase + (lane < n_out ? lane : 0u);
       uint32_t x0 = (uint32_t)(shot >> 32), x1 = (uint32_t)shot;
       threefry2x32(subkey(A, o, 0), subkey(A, o, 1), x0, x1);
       u_bits = __float_as_uint(__uint_as_float(((x0 ^ x1) >> 9) | 0x3F800000u) - 1.0f);
     }
+    const bool lead = threadIdx.x < 64u;
+    uint32_t *bit_word = par + 2u * par_half;  // the sampled bit, leading wave -> the others
     const HwLevelOut n0 = hw_eval_level<W, false>(A.img, img, levels, x, 0u, par, par_half);  // normalisation (sampler.py:54)
+    __syncthreads();  // the next level's phase 1 overwrites `par` only after the leading wave has read it
     float prev = cabs32(n0.re, n0.im);
     float maxdev = 0.0f;
     for (uint32_t i = 0; i < n_out; ++i) {
@@ -271,7 +276,9 @@ __device__ __forceinline__ void hw_component(const SampleArgs &A, cptr img, cptr
       }
       // sampler.py:74-79
       const float u = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)u_bits, (int)i));
-      const bool bit = u < __fdiv_rn(p1, prev);
+      if (lead && lane == 0u) *bit_word = (u < __fdiv_rn(p1, prev)) ? 1u : 0u;
+      __syncthreads();  // ... which also keeps `par` until the leading wave is done with it
+      const bool bit = *bit_word != 0u;  // (rewritten only behind the next level's phase-1 barrier)
 #pragma unroll
       for (int w = 0; w < W; ++w)
         if ((uint32_t)w == wi) x[w] = bit ? (x[w] | bm) : (x[w] & ~bm);

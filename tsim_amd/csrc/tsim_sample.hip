@@ -178,15 +178,28 @@ static void hard_geometry(tsim_program *p, int WF, int WO) {
 // The deferred second pass: ONE k_sample4h_multi grid serves the hard rows of every launch whose
 // first pass is enqueued, on the third lane's stream, after those first passes.
 int tsim_flush_hard(tsim_program *p) {
-  if (p->deferred.empty()) return 0;
+  if (p->deferred.empty()) {
+    p->flush_inline = nullptr;
+    return 0;
+  }
   constexpr int NW = TSIM_HARD_NW;
   // TSIM_AMD_BATCH_LANES=2 alternates the batches over two lanes (the third and fourth slot's streams; batches of
   // one lane complete in order).  Tried for C4, whose 205-us batches of 8 launches bound the pipeline at ~29 us per
   // launch whatever the batch size: both streams landed on ONE hardware queue, the batches did not overlap
   // (29.2 -> 27.6 us per step with GPU_MAX_HW_QUEUES=8) - off by default.
   const unsigned long long seq = p->batch_next++;
-  const int bl = p->knobs.batch_lanes > 1 ? (int)(seq & 1ull) : 0;
+  // Inline (steps_group_fused, small groups): the batch runs on the group's own first-pass lane, behind its first pass.
+  // A hard-row batch is latency-bound - ~30 us for the distillation shapes, ~80 us for the cultivation one, however
+  // few the rows - so on ONE batch stream the batches of small groups (8 x 10^5 shots: a 36-us first pass) are the
+  // pipeline's period; on the two lanes they overlap each other and the other lane's first pass.
+  int bl = p->knobs.batch_lanes > 1 ? (int)(seq & 1ull) : 0;
   hipStream_t hs = p->slots[3 + bl].side;
+  if (p->flush_inline) {
+    hs = p->flush_inline;
+    bl = hs == p->slots[1].side ? 2 : 3;
+    p->flush_inline = nullptr;
+    p->inline_seen = true;
+  }
   Hard4Multi M{};
   M.n_ctx = (int)p->deferred.size();
   const uint32_t fb_max = p->h_feedback ? p->h_feedback[1] : 192u;
@@ -209,7 +222,7 @@ int tsim_flush_hard(tsim_program *p) {
     if (d.ctx_check) M.check_mask |= 1 << i;
   }
   for (int k = 0; k < 2; ++k)
-    if (lane_used[k]) {
+    if (lane_used[k] && p->slots[1 + k].side != hs) {
       if (!p->lane_ev[k]) HIP_TRY(hipEventCreateWithFlags(&p->lane_ev[k], hipEventDisableTiming));
       HIP_TRY(hipEventRecord(p->lane_ev[k], p->slots[1 + k].side));
       HIP_TRY(hipStreamWaitEvent(hs, p->lane_ev[k], 0));
@@ -218,7 +231,12 @@ int tsim_flush_hard(tsim_program *p) {
   // then takes the time of one row, and the approximate branch is no slower than the exact one.
   int wmax = 1;
   for (int w : p->comp_w) wmax = std::max(wmax, w);
-  const bool hw = p->fast && p->knobs.hard_wave && wmax <= 2 && M.ctx[0].WF <= 32 && M.ctx[0].WO <= 2 && p->hw_max_rows < 60000;
+  // ... while the rows are FEW: a row costs this kernel ~10^4 wave instructions (one wave's worth of every level),
+  // the per-shot kernel ~1.5 * 10^3 - beyond ~10^3 rows per batch of launches the block-per-row kernel would take the
+  // vector ALUs from the first passes (C3: 340 rows per launch, p_bit 0.05: 5000), so those go the per-shot way
+  const uint32_t fb_rows = p->h_feedback ? p->h_feedback[0] : 0u;
+  const bool hw = p->fast && p->knobs.hard_wave && wmax <= 2 && M.ctx[0].WF <= 32 && M.ctx[0].WO <= 2 && p->hw_max_rows < 60000 &&
+                  (unsigned long long)fb_rows * (unsigned)M.n_ctx <= (unsigned long long)p->knobs.hard_wave_rows;
   if (hw) {
     HwMulti H{};
     H.n_ctx = M.n_ctx;
@@ -235,7 +253,7 @@ int tsim_flush_hard(tsim_program *p) {
     }
     const unsigned gridw = (unsigned)((long long)H.n_ctx * H.max_lists * H.waves_per_list);
     H.par_words = (int)(2 * ((p->hw_max_rows + 63) / 64) + 2);
-    const size_t ldsw = (size_t)H.par_words * 2 * 4;  // two bit arrays per block (the check row evaluates trial bits 1 and 0 together)
+    const size_t ldsw = (size_t)H.par_words * 2 * 4 + 16;  // + the sampled bit's word; two bit arrays per block (the check row evaluates trial bits 1 and 0 together)
     if (wmax == 1) hipLaunchKernelGGL(k_sample_hw<1>, dim3(gridw), dim3(256), ldsw, hs, H);
     else hipLaunchKernelGGL(k_sample_hw<2>, dim3(gridw), dim3(256), ldsw, hs, H);
     HIP_TRY(hipGetLastError());
@@ -259,17 +277,22 @@ int tsim_flush_hard(tsim_program *p) {
   ++p->stat_flushes;
   hipEvent_t &be = p->batch_ev[seq % 16u];
   if (!be) HIP_TRY(hipEventCreateWithFlags(&be, hipEventDisableTiming));
-  if (seq > 16u && p->batch_confirmed[bl] < seq - 16u) {  // the ring slot's previous batch: 16 batches ago (same lane), long done
-    HIP_TRY(hipEventSynchronize(be));
-    p->batch_confirmed[bl] = seq - 16u;
+  if (seq > 16u) {  // the ring slot's previous batch: 16 batches ago, long done
+    const int pl = p->batch_ev_lane[seq % 16u];
+    if (p->batch_confirmed[pl] < seq - 16u) {
+      HIP_TRY(hipEventSynchronize(be));
+      p->batch_confirmed[pl] = seq - 16u;
+    }
   }
   HIP_TRY(hipEventRecord(be, hs));
+  p->batch_ev_lane[seq % 16u] = bl;
   for (int i = 0; i < M.n_ctx; ++i) {
     tsim_program::Slot &d = p->slots[p->deferred[i]];
     d.deferred = false;
     d.last_done = hs;
     d.done_ev = be;
     d.batch_seq = seq;
+    d.batch_lane = bl;
   }
   p->deferred.clear();
   return 0;
@@ -621,7 +644,7 @@ static int slot_order_after_previous(tsim_program *p, tsim_program::Slot &sl, hi
   bool done = false;
   if (sl.batch_seq) {
     const int lane = (s == p->slots[1].side) ? 0 : (s == p->slots[2].side) ? 1 : -1;
-    const int bl = p->knobs.batch_lanes > 1 ? (int)(sl.batch_seq & 1ull) : 0;  // the lane that batch ran on
+    const int bl = sl.batch_lane;  // the stream that batch ran on (batches of one stream complete in order)
     if (sl.batch_seq <= p->batch_confirmed[bl] || (lane >= 0 && sl.batch_seq <= p->lane_waited[lane][bl])) done = true;
     else if (lane >= 0) {
       p->lane_waited[lane][bl] = sl.batch_seq;
@@ -673,7 +696,7 @@ extern "C" int tsim_sample_batch_device_begin(tsim_program *p, int32_t slot, con
   // no wait of its own) already waits for the batch the first launch of the next batch will ask for - known from
   // how far back the last such wait reached (lane_reach) and at least two flushes old, i.e. complete; that launch
   // then finds the lane already behind it.  Ordering only ever gets stricter.
-  if (plan.defer && p->knobs.prewait && p->knobs.batch_lanes == 1 && p->deferred.size() >= 2) {
+  if (plan.defer && p->knobs.prewait && p->knobs.batch_lanes == 1 && !p->inline_seen && p->deferred.size() >= 2) {
     const int lane = (s == p->slots[1].side) ? 0 : (s == p->slots[2].side) ? 1 : -1;
     if (lane >= 0 && p->lane_reach[lane] >= 3 && p->lane_reach[lane] <= 15 && p->batch_next > (unsigned long long)p->lane_reach[lane]) {
       const unsigned long long want = p->batch_next - (unsigned long long)(p->lane_reach[lane] - 1);
@@ -824,6 +847,7 @@ static int steps_group_fused(tsim_program *p, int n, const uint64_t *const *d_f,
   p->stat_begins += (unsigned long long)n;
   p->stat_deferred += (unsigned long long)n;
   ++p->stat_fused;
+  if ((long long)n * B <= p->knobs.hard_inline_rows) p->flush_inline = s;
   return tsim_flush_hard(p);
 }
 
@@ -986,7 +1010,7 @@ extern "C" int tsim_sample_batch_device_end(tsim_program *p, int32_t slot, void 
       // (only for streams the handle owns - a caller's stream handle may be destroyed and its address reused)
       bool own = s == p->stream;
       for (int k = 1; k <= 4 && !own; ++k) own = p->slots[k].side_ready && s == p->slots[k].side;
-      const bool in_order = own && sl.batch_seq != 0 && p->knobs.batch_lanes == 1;
+      const bool in_order = own && sl.batch_seq != 0 && p->knobs.batch_lanes == 1 && !p->inline_seen;
       if (in_order && s == p->joined_stream && sl.batch_seq <= p->joined_seq) {
         // nothing to add
       } else {

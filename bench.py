@@ -273,6 +273,8 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--repeats", type=int, default=8, help="repetitions of the timed --steps loop (median reported)")
+    ap.add_argument("--spinup-ms", type=float, default=float(os.environ.get("TSIM_BENCH_SPINUP_MS", "30")),
+                    help="untimed steps worth this many ms before every timed repetition (clock spin-up; 0 = none)")
     ap.add_argument("--shots", type=int, default=1_000_000, help="shots per step per GPU")
     ap.add_argument("--config", default="C2")
     ap.add_argument("--random-program", action="store_true", help="the unconstrained random program instead of the normalised one")
@@ -612,16 +614,49 @@ def main() -> None:
     per_rep = max(1, -(-8 // max(1, args.repeats)))
     PROF_EVERY = max(1, min(25, args.steps // per_rep))
     if not PER_STEP:
-        PROF_EVERY = 1  # a fused first pass serves several batches: two events per ~100 us kernel
+        # a fused first pass serves up to 8 batches; a bracket (two timing events on the lane) costs ~7 us of a ~100-us
+        # kernel and, worse, a bubble on the lane: bracketing EVERY launch cost 7 % of the step rate (12.7 -> 11.8 us at
+        # --steps 200).  About 16 bracketed launches over all repetitions together.
+        launches_per_rep = max(1, -(-args.steps // 8))
+        PROF_EVERY = max(1, launches_per_rep * max(1, args.repeats) // 16)
     if os.environ.get("TSIM_BENCH_PROF_EVERY"):
         PROF_EVERY = max(1, int(os.environ["TSIM_BENCH_PROF_EVERY"]))
+    PROF_LEVEL = 0 if os.environ.get("TSIM_BENCH_NO_PROFILE") == "1" else 2
     hp.profile_set_sampling(PROF_EVERY)
-    hp.profile_enable(0 if os.environ.get("TSIM_BENCH_NO_PROFILE") == "1" else 2)
+    hp.profile_enable(PROF_LEVEL)
     hp.profile_read(reset=True)
     hp.profile_read_steps()
     rep_elapsed, rep_enqueue = [], []
     START_SLOT = os.environ.get("TSIM_BENCH_START_SLOT")
+    # Clock spin-up (untimed, disclosed in the JSON line as "spinup"): the chip's power management raises its clocks
+    # over the first ~25 ms of sustained work - with no spin-up the repetitions of ONE process get faster one after
+    # the other until ~25 ms of work have gone by (profiles/r03/steps_dependence.txt: 12.9, 11.9, 11.2, 11.2 ... us per
+    # step over the repetitions of --steps 1000; the same trend, never finished, over the eight 2.5-ms repetitions of
+    # --steps 200), which is a property of the chip, not of the engine.  --spinup-ms of the same steps run right before
+    # every timed region (after --warmup, before the fence), so that short regions are measured at the clocks long ones
+    # reach on their own.  --spinup-ms 0 switches it off.
+    spin_steps = 0
+    if args.spinup_ms > 0:
+        hp.profile_enable(0)
+        fence()
+        t0 = time.perf_counter()
+        steps(32)
+        fence()
+        est = (time.perf_counter() - t0) / 32
+        spin_steps = int(min(20000, max(0, args.spinup_ms * 1e-3 / max(est, 1e-7))))
+        hp.profile_enable(PROF_LEVEL)
     for _ in range(max(1, args.repeats)):
+        if spin_steps:
+            hp.profile_enable(0)  # (no timing events in the untimed part)
+            # in calls of 64 steps, each waited for: a backlog of thousands of commands leaves the HIP runtime with
+            # completed commands to retire during the NEXT enqueues - the timed ones (186 instead of 48 us for 20 steps)
+            left = spin_steps
+            while left > 0:
+                steps(min(64, left))
+                left -= 64
+                if not use_dist:
+                    hp.synchronize()
+            hp.profile_enable(PROF_LEVEL)
         fence()
         if START_SLOT is not None and not use_dist:
             step_no[0] = int(START_SLOT)
@@ -717,7 +752,7 @@ def main() -> None:
         fast_path = len(program.components) == 1 and len(program.components[0].output_indices) <= 8 and not PER_STEP
         if tables_dominant and batches_per_launch > 1.0:
             kernel_name = ("tsimk::k_sample_lw_fast" if fast_path else "tsimk::k_sample_lw_multi") + \
-                f" (fused pattern-table pass over {batches_per_launch:.1f} batches per launch; hard rows: one k_sample4h_multi batch per group, on the third lane)"
+                f" (fused pattern-table pass over {batches_per_launch:.1f} batches per launch; hard rows: one k_sample_hw / k_sample4h_multi grid per group, behind it on the group's lane)"
         elif tables_dominant:
             kernel_name = ("tsimk::k_sample_lw (pattern-table pass; hard rows: k_sample4h_multi batches / k_sample4h + "
                            "k_sample4, on the third lane)") if info.get("chunk_table_kernel") else \
@@ -725,7 +760,8 @@ def main() -> None:
         else:
             kernel_name = "tsimk::k_sample4 (LDS chunk tables)" if info.get("chunk_table_kernel") else "tsimk::k_sample"
         pmc = load_pmc(args.config, B)
-        traffic = (2.0 * float(pmc["FETCH_SIZE"]) + float(pmc["WRITE_SIZE"])) * 1024.0 if pmc and "FETCH_SIZE" in pmc else None
+        # the PMC summary is per BATCH of B shots (scripts/summarize_pmc.py); `achieved` is per launch of batches_per_launch batches
+        traffic = (2.0 * float(pmc["FETCH_SIZE"]) + float(pmc["WRITE_SIZE"])) * 1024.0 * batches_per_launch if pmc and "FETCH_SIZE" in pmc else None
         per_step = [e / args.steps * 1e3 for e in rep_elapsed]
         res = {
             "metric": "detector shots/sec, 35-qubit distillation circuit, 1/2/4/8 MI355X",
@@ -741,6 +777,9 @@ def main() -> None:
             "dtype": "int32",
             "data": "synthetic",
             "repeats": len(rep_elapsed),
+            "spinup": {"ms": args.spinup_ms, "untimed_steps_before_each_repeat": spin_steps,
+                       "note": "the same steps, untimed, right before every timed region: the chip reaches its sustained clocks only "
+                               "after ~25 ms of work (profiles/r03/steps_dependence.txt); --spinup-ms 0 for none"},
             "repeat_ms_per_step": {"median": statistics.median(per_step), "min": min(per_step), "max": max(per_step), "all": per_step},
             "config": {
                 "workload": f"{args.config}: {cfg.get('name', 'shape of SURVEY 8d')}, synthetic seeded program: "
@@ -782,8 +821,8 @@ def main() -> None:
                 "host_enqueue_ms_per_step": host_enqueue_s / args.steps * 1e3,
                 "algorithmic_bytes_per_shot": bytes_per_shot,
                 "note": "achieved = algorithmic bytes of one launch / HIP-event time of the dominant kernel inside the timed "
-                "region, where two first passes (two lanes) and a hard-row batch (third lane) share the CUs - each first "
-                "pass then lasts about twice the step time; achieved_at_step_rate uses the step time (= shots/s x "
+                "region, where two first passes (two lanes) and the hard-row grids behind them share the CUs - each first "
+                "pass then lasts about twice the time it takes alone; achieved_at_step_rate uses the step time (= shots/s x "
                 "bytes/shot), achieved_serial the kernel's duration with the GPU to itself (= rocprofv3's serial kernel "
                 "trace).  Integer-VALU / latency bound, not HBM bound (DESIGN.md section 3.5): see `valu`.",
             },

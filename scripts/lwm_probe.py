@@ -1,7 +1,7 @@
 """Fused first pass alone: 8 batches per launch, serial launches, HIP-event time per batch (scripts/build_variant.sh
 variants with -DTSIMK_LWM_SKIP=mask leave parts of the pass out: 1 Threefry, 2 direct outputs, 4 rank, 8 stores)."""
-import ctypes as C, sys
-sys.path.insert(0, ".")
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from tsim_amd import backend, synth
 name = sys.argv[1] if len(sys.argv) > 1 else "C2"
@@ -28,3 +28,7 @@ for rep in range(10):
     hp.synchronize()
 st = hp.profile_read_stages(); ms, ln = hp.profile_read(reset=True); steps = hp.profile_read_steps()
 print(name, "fused first pass: %.2f us per launch of %.1f batches = %.2f us per 1e6-shot batch" % (st["pattern_pass"] / ln * 1e3, steps / ln, st["pattern_pass"] / steps * 1e3))
+# the serial API (tsim_sample_batch_device: one batch per call, first pass + hard rows on the handle's stream)
+for rep in range(12):
+    hp.sample_batch_device(bufs[rep % 4].ptr, B, nf, (3, 4 + rep), outs[rep % 16].ptr)
+    hp.synchronize()

@@ -171,7 +171,7 @@ struct tsim_program {
     hipStream_t last_done = nullptr;  // stream on which done_ev of the slot's last launch was recorded
     hipEvent_t done_ev = nullptr;     // ev2 (own second pass) or the event of the batch that served the slot
     unsigned long long batch_seq = 0; // sequence number of that batch (0: own second pass)
-    int batch_lane = 0;               // the stream that batch ran on: 0/1 = the batch lanes, 2/3 = first-pass lane 0/1 itself (inline)
+    int batch_lane = 0;               // the stream that batch ran on: 0/1 = the batch lanes, 2.. = first-pass lane 0.. itself (inline)
     SampleArgs ctx;                   // the hard-row kernel's arguments for that launch
   };
   Slot slots[1 + TSIM_PIPELINE_SLOTS];
@@ -187,11 +187,11 @@ struct tsim_program {
   int64_t series_stride = 0;
   int series_left = 0;
   unsigned long long batch_next = 1;       // sequence number of the next batch (event = batch_ev[seq % 16])
-  unsigned long long batch_confirmed[4] = {0, 0, 0, 0};  // per batch lane: every batch up to this one is known to be complete
+  unsigned long long batch_confirmed[6] = {};  // per batch lane: every batch up to this one is known to be complete
   hipStream_t joined_stream = nullptr;  // tsim_sample_batch_device_end: the stream that last joined a batch ...
-  unsigned long long joined_seq = 0;     // ... and that batch: it is behind every batch up to this one
-  int lane_reach[2] = {0, 0};  // batches between a lane's last start-of-batch wait and the batch it waited for (pre-wait)
-  unsigned long long lane_waited[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};  // [first-pass lane][batch lane]: newest batch already waited for
+  unsigned long long joined_seq[6] = {};    // ... and that batch: it is behind every batch up to this one
+  int lane_reach[4] = {0, 0, 0, 0};  // batches between a lane's last start-of-batch wait and the batch it waited for (pre-wait)
+  unsigned long long lane_waited[4][6] = {};  // [first-pass lane][batch lane]: newest batch already waited for
   unsigned long long stat_queries = 0, stat_waits = 0, stat_begins = 0, stat_flushes = 0, stat_deferred = 0, stat_fused = 0, stat_fast = 0;
   unsigned long long steps_slot = 0;    // tsim_sample_steps_device: next pipeline slot of its rotation ...
   unsigned long long steps_groups = 0;  // ... and the fused groups launched so far (first-pass lanes alternate)
@@ -224,6 +224,7 @@ struct tsim_program {
     int batch_lanes = 1;      // TSIM_AMD_BATCH_LANES=2: hard-row batches alternate over two streams (no measured gain: both land on one hardware queue)
     int defer_group = 4;      // TSIM_AMD_DEFER_GROUP: launches per deferred hard-row batch (<= TSIMK_H_MAX_CTX)
     bool fused_steps = true;  // TSIM_AMD_FUSED_STEPS=0: tsim_sample_steps_device launches batch by batch
+    int fused_lanes = 2;  // TSIM_AMD_FUSED_LANES: first-pass lanes the fused groups rotate over (2-4)
     long long hard_inline_rows = 1ll << 40;  // TSIM_AMD_HARD_INLINE_ROWS: fused groups of at most this many shots run their hard rows on their own lane
     int hard_wave_rows = 1024;  // TSIM_AMD_HARD_WAVE_ROWS: ... while a batch of launches has at most this many hard rows (last feedback)
     bool hard_wave = true;    // TSIM_AMD_HARD_WAVE=0: hard-row batches on k_sample4h_multi (64 rows per block) instead of one wave per row

@@ -244,7 +244,7 @@ __device__ __forceinline__ void hw_component(const SampleArgs &A, cptr img, cptr
     // the component's draws (sampler.py:74-75), all at once: lane i computes output i's uniform (a lone wave pays for a
     // Threefry block per level otherwise - 75 dependent instructions each)
     uint32_t u_bits = 0u;
-    if (threadIdx.x < 64u) {
+    if (threadIdx.x < 64u && n_out > 0u) {  // (a component without outputs has no subkeys at all)
       const uint32_t o = keybase + (lane < n_out ? lane : 0u);
       uint32_t x0 = (uint32_t)(shot >> 32), x1 = (uint32_t)shot;
       threefry2x32(subkey(A, o, 0), subkey(A, o, 1), x0, x1);

@@ -175,6 +175,43 @@ static void hard_geometry(tsim_program *p, int WF, int WO) {
   p->h_lds = fixed_b + (size_t)std::max(1, p->h_group_tiles) * tile_b;
 }
 
+// One BLOCK per hard row (tsim_kernel_hw.hip.h) where the fast row layout exists and the rows are narrow: a batch then
+// takes the time of one row, and the approximate branch is no slower than the exact one ...
+// ... while the rows are FEW: a row costs this kernel ~10^4 wave instructions (one wave's worth of every level),
+// the per-shot kernel ~1.5 * 10^3 - beyond ~10^3 rows per batch of launches the block-per-row kernel would take the
+// vector ALUs from the first passes (C3: 340 rows per launch, p_bit 0.05: 5000), so those go the per-shot way
+static bool hw_eligible(tsim_program *p, const SampleArgs &a, int n_ctx) {
+  int wmax = 1;
+  for (int w : p->comp_w) wmax = std::max(wmax, w);
+  const uint32_t fb_rows = p->h_feedback ? p->h_feedback[0] : 0u;
+  return p->fast && p->knobs.hard_wave && wmax <= 2 && a.WF <= 32 && a.WO <= 2 && p->hw_max_rows < 60000 &&
+         (unsigned long long)fb_rows * (unsigned)n_ctx <= (unsigned long long)p->knobs.hard_wave_rows;
+}
+static int launch_hw(tsim_program *p, const SampleArgs *ctx, int n_ctx, int max_lists, hipStream_t hs) {
+  int wmax = 1;
+  for (int w : p->comp_w) wmax = std::max(wmax, w);
+  const uint32_t fb_max = p->h_feedback ? p->h_feedback[1] : 192u;
+  HwMulti H{};
+  H.n_ctx = n_ctx;
+  H.max_lists = max_lists;
+  // as many blocks per list as the longest list of the last launch had rows (plus a margin): each block then takes one
+  // row; longer lists are walked in turns (blocks of four waves: one row at a time each, see k_sample_hw)
+  H.waves_per_list = (int)std::max(8u, std::min(128u, std::min(fb_max, 4096u) * 2u + 8u));
+  if (const char *e = getenv("TSIM_AMD_HW_WAVES")) H.waves_per_list = std::max(1, std::min(256, atoi(e)));
+  H.feedback = p->d_feedback;
+  for (int i = 0; i < n_ctx; ++i) {
+    H.ctx[i] = ctx[i];
+    H.ctx[i].kernarg_off = (int)(offsetof(HwMulti, ctx) + (size_t)i * sizeof(SampleArgs));
+  }
+  const unsigned gridw = (unsigned)((long long)H.n_ctx * H.max_lists * H.waves_per_list);
+  H.par_words = (int)(2 * ((p->hw_max_rows + 63) / 64) + 2);
+  const size_t ldsw = (size_t)H.par_words * 2 * 4 + 16;  // + the sampled bit's word; two bit arrays per block (the check row evaluates trial bits 1 and 0 together)
+  if (wmax == 1) hipLaunchKernelGGL(k_sample_hw<1>, dim3(gridw), dim3(256), ldsw, hs, H);
+  else hipLaunchKernelGGL(k_sample_hw<2>, dim3(gridw), dim3(256), ldsw, hs, H);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 // The deferred second pass: ONE k_sample4h_multi grid serves the hard rows of every launch whose
 // first pass is enqueued, on the third lane's stream, after those first passes.
 int tsim_flush_hard(tsim_program *p) {
@@ -196,7 +233,9 @@ int tsim_flush_hard(tsim_program *p) {
   hipStream_t hs = p->slots[3 + bl].side;
   if (p->flush_inline) {
     hs = p->flush_inline;
-    bl = hs == p->slots[1].side ? 2 : 3;
+    bl = 2;
+    for (int k = 0; k < 4; ++k)
+      if (hs == p->slots[1 + k].side) bl = 2 + k;
     p->flush_inline = nullptr;
     p->inline_seen = true;
   }
@@ -227,36 +266,8 @@ int tsim_flush_hard(tsim_program *p) {
       HIP_TRY(hipEventRecord(p->lane_ev[k], p->slots[1 + k].side));
       HIP_TRY(hipStreamWaitEvent(hs, p->lane_ev[k], 0));
     }
-  // One wave per hard row (tsim_kernel_hw.hip.h) where the fast row layout exists and the rows are narrow: a batch
-  // then takes the time of one row, and the approximate branch is no slower than the exact one.
-  int wmax = 1;
-  for (int w : p->comp_w) wmax = std::max(wmax, w);
-  // ... while the rows are FEW: a row costs this kernel ~10^4 wave instructions (one wave's worth of every level),
-  // the per-shot kernel ~1.5 * 10^3 - beyond ~10^3 rows per batch of launches the block-per-row kernel would take the
-  // vector ALUs from the first passes (C3: 340 rows per launch, p_bit 0.05: 5000), so those go the per-shot way
-  const uint32_t fb_rows = p->h_feedback ? p->h_feedback[0] : 0u;
-  const bool hw = p->fast && p->knobs.hard_wave && wmax <= 2 && M.ctx[0].WF <= 32 && M.ctx[0].WO <= 2 && p->hw_max_rows < 60000 &&
-                  (unsigned long long)fb_rows * (unsigned)M.n_ctx <= (unsigned long long)p->knobs.hard_wave_rows;
-  if (hw) {
-    HwMulti H{};
-    H.n_ctx = M.n_ctx;
-    H.max_lists = max_lists;
-    // as many waves per list as the longest list of the last launch had rows (plus a margin): each wave then takes one
-    // row; longer lists are walked in turns
-    // (blocks of four waves: one row at a time each, see k_sample_hw)
-    H.waves_per_list = (int)std::max(8u, std::min(128u, std::min(fb_max, 4096u) * 2u + 8u));
-    if (const char *e = getenv("TSIM_AMD_HW_WAVES")) H.waves_per_list = std::max(1, std::min(256, atoi(e)));
-    H.feedback = p->d_feedback;
-    for (int i = 0; i < M.n_ctx; ++i) {
-      H.ctx[i] = M.ctx[i];
-      H.ctx[i].kernarg_off = (int)(offsetof(HwMulti, ctx) + (size_t)i * sizeof(SampleArgs));
-    }
-    const unsigned gridw = (unsigned)((long long)H.n_ctx * H.max_lists * H.waves_per_list);
-    H.par_words = (int)(2 * ((p->hw_max_rows + 63) / 64) + 2);
-    const size_t ldsw = (size_t)H.par_words * 2 * 4 + 16;  // + the sampled bit's word; two bit arrays per block (the check row evaluates trial bits 1 and 0 together)
-    if (wmax == 1) hipLaunchKernelGGL(k_sample_hw<1>, dim3(gridw), dim3(256), ldsw, hs, H);
-    else hipLaunchKernelGGL(k_sample_hw<2>, dim3(gridw), dim3(256), ldsw, hs, H);
-    HIP_TRY(hipGetLastError());
+  if (hw_eligible(p, M.ctx[0], M.n_ctx)) {
+    if (int r = launch_hw(p, M.ctx, M.n_ctx, max_lists, hs)) return r;
   } else {
   const unsigned grid = (unsigned)(M.n_ctx * M.blocks_per_ctx);
   switch (p->v4_max_nch) {
@@ -513,7 +524,55 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
     l.n_lists = n_lists;
     l.binom_off = p->lw_binom_off;
     const size_t lds1 = (size_t)(2 * a.WF + 2 * a.WO) * blk1 * 4 + (p->lw_wide ? 4096 : 0);
-    if (reg_form) {
+    // one component of at most 8 outputs: the specialised pass of the fused groups (tsim_lw_fast.hip.h), as a group of ONE
+    // batch - 14.5 instead of 19.6 us per 10^6 shots for the serial API too (same conditions as in steps_group_fused)
+    const bool fast1 = reg_form && p->lwf_off != 0 && p->knobs.lw_fast && blk1 == 1024 && a.n_inline_keys > 0 && p->total_keys <= TSIMK_LWM_KEYS &&
+                       B < (1ll << 28) && p->lw_bytes < (1ll << 32) && (n_lists & (n_lists - 1)) == 0 && a.WO == 1 &&
+                       ((unsigned long long)shot_offset >> 32) == ((unsigned long long)(shot_offset + B - 1) >> 32);
+    if (fast1) {
+      const long long cap1 = (blocks + n_lists - 1) / n_lists * blk1;  // the fused kernels' list geometry: row block rb -> list rb % n_lists
+      if ((size_t)cap1 * n_lists * 4 > sl.hard_sz) return tsim_fail(TSIM_ESTATE, "hard-row list too small");
+      LwMultiArgs M{};
+      M.img = p->d_img;
+      M.tab = p->d_lw_tab;
+      M.B = B;
+      M.shot_offset = shot_offset;
+      M.n_steps = 1;
+      M.blocks_per_step = (int)blocks;
+      M.n_comp = (int)p->comps.size();
+      M.lw_off = p->lw_off;
+      M.direct_rot = p->lw_direct_rot;
+      M.binom_off = p->lw_binom_off;
+      M.has_check = has_check ? 1 : 0;
+      M.list_cap = (int)cap1;
+      M.n_lists = n_lists;
+      M.out_rb = (p->num_outputs + 7) / 8;
+      M.lwf_off = p->lwf_off;
+      M.tab_bytes = (uint32_t)p->lw_bytes;
+      LwStep &st = M.step[0];
+      st.f = a.f;
+      st.out = a.out;
+      st.out_compact = a.out_compact;
+      st.hard_index = l.hard_index;
+      st.ctl = l.ctl;
+      st.ctl_next = l.ctl_next;
+      memcpy(st.keys, a.inline_keys, sizeof(uint32_t) * 2 * (size_t)p->total_keys);
+      const long long chip = (long long)p->n_cu * std::max(1, p->knobs.lw_resident) * (2048 / blk1);
+      const long long it1 = (blocks + chip - 1) / chip;
+      const long long gridf = (blocks + it1 - 1) / it1;
+      const int n_out = p->comps[0].n_out;
+#define TSIM_LF1(N)                                                                                        \
+  case N:                                                                                                  \
+    if (a.WF == 1) hipLaunchKernelGGL((k_sample_lw_fast<2, N>), dim3((unsigned)gridf), dim3(blk1), 0, s, M); \
+    else hipLaunchKernelGGL((k_sample_lw_fast<4, N>), dim3((unsigned)gridf), dim3(blk1), 0, s, M);          \
+    break;
+      switch (n_out) {
+        TSIM_LF1(1) TSIM_LF1(2) TSIM_LF1(3) TSIM_LF1(4) TSIM_LF1(5) TSIM_LF1(6) TSIM_LF1(7) TSIM_LF1(8)
+        default: return tsim_fail(TSIM_ESTATE, "fast record with %d outputs", n_out);
+      }
+#undef TSIM_LF1
+      l.list_cap = (int)cap1;
+    } else if (reg_form) {
       // narrow rows: everything in registers, no LDS
       if (a.WF == 1) hipLaunchKernelGGL(k_sample_lw_reg<2>, dim3((unsigned)grid1), dim3(blk1), 0, s, l);
       else hipLaunchKernelGGL(k_sample_lw_reg<4>, dim3((unsigned)grid1), dim3(blk1), 0, s, l);
@@ -528,10 +587,10 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
     a.row_index = l.hard_index;
     a.row_count = ctl;
     a.row_lists = n_lists;
-    a.row_list_cap = (int)list_cap;
+    a.row_list_cap = l.list_cap;
     a.check_row = has_check ? ctl + 32 * TSIMK_LW_LISTS : nullptr;
     a.no_check = has_check ? 0 : 1;
-    B2 = list_cap;
+    B2 = l.list_cap;
     // wide components: the listed rows go through the sparse-column pass first, its overflow to the row kernel
     // (ctl2 alternates on its own: launches that skip the tables - dense batches - do not touch it, and its reset
     // is done by the launch that used it last)
@@ -584,6 +643,13 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
         p->deferred.push_back(slot);
         if ((int)p->deferred.size() >= p->knobs.defer_group) return tsim_flush_hard(p);
         return 0;
+      }
+      if (group_tiles >= 1 && hw_eligible(p, a, 1)) {
+        // few hard rows, fast row layout: one block per row (tsim_kernel_hw.hip.h), whole lists - nothing left for k_sample4
+        if (int r = launch_hw(p, &a, 1, a.row_lists, s)) return r;
+        if (prof && !p->prof_light) { int r = prof_event(p, s, PROF_HARD); if (r) return r; }
+        if (prof && !(p->prof_light && use_tables)) { int r = prof_event(p, s, PROF_FULL); if (r) return r; }
+        return finish();
       }
       if (group_tiles >= 1) {
         // the first kHardBlocks * 64 slots of every list go to the NW-wave kernel; k_sample4 below
@@ -643,7 +709,9 @@ static int slot_order_after_previous(tsim_program *p, tsim_program::Slot &sl, hi
   if (!(sl.last_done && sl.last_done != s && sl.done_ev)) return 0;
   bool done = false;
   if (sl.batch_seq) {
-    const int lane = (s == p->slots[1].side) ? 0 : (s == p->slots[2].side) ? 1 : -1;
+    int lane = -1;
+    for (int k = 0; k < 4; ++k)
+      if (s == p->slots[1 + k].side) lane = k;
     const int bl = sl.batch_lane;  // the stream that batch ran on (batches of one stream complete in order)
     if (sl.batch_seq <= p->batch_confirmed[bl] || (lane >= 0 && sl.batch_seq <= p->lane_waited[lane][bl])) done = true;
     else if (lane >= 0) {
@@ -731,7 +799,7 @@ static int steps_group_fused(tsim_program *p, int n, const uint64_t *const *d_f,
   const bool packed = (flags & TSIM_PIPE_OUT_BIT_PACKED) != 0;
   if (!p->deferred.empty())
     if (int r = tsim_flush_hard(p)) return r;  // rows parked by batch-by-batch launches: their own batch first
-  hipStream_t s = p->slots[1 + (int)(p->steps_groups++ & 1ull)].side;
+  hipStream_t s = p->slots[1 + (int)(p->steps_groups++ % (unsigned long long)p->knobs.fused_lanes)].side;
   if (!(flags & TSIM_PIPE_INPUTS_READY) && p->stream != s) {
     if (!p->sync_ev) HIP_TRY(hipEventCreateWithFlags(&p->sync_ev, hipEventDisableTiming));
     HIP_TRY(hipEventRecord(p->sync_ev, p->stream));
@@ -886,6 +954,7 @@ extern "C" int tsim_sample_steps_device(tsim_program *p, int32_t n_steps, const 
       // even groups of at most TSIMK_LWM_MAX_STEPS batches
       const int left = n_steps - done;
       const int gmax = std::min(TSIMK_LWM_MAX_STEPS, p->knobs.fused_max);
+      // (20 batches as 7+7+6; 5+5+5+5 - both lanes ending together - measured slower: a launch more)
       const int groups = (left + gmax - 1) / gmax;
       int n = (left + groups - 1) / groups;
       if (const char *e = getenv("TSIM_AMD_FUSED_PLAN")) {  // experiments: "2,6,6,4,2" = the group sizes of a call, in order
@@ -1010,14 +1079,19 @@ extern "C" int tsim_sample_batch_device_end(tsim_program *p, int32_t slot, void 
       // (only for streams the handle owns - a caller's stream handle may be destroyed and its address reused)
       bool own = s == p->stream;
       for (int k = 1; k <= 4 && !own; ++k) own = p->slots[k].side_ready && s == p->slots[k].side;
-      const bool in_order = own && sl.batch_seq != 0 && p->knobs.batch_lanes == 1 && !p->inline_seen;
-      if (in_order && s == p->joined_stream && sl.batch_seq <= p->joined_seq) {
+      // (per batch stream: batches of ONE stream complete in order, inline batches run on the first-pass lanes)
+      const bool in_order = own && sl.batch_seq != 0 && p->knobs.batch_lanes == 1;
+      const int bl = sl.batch_lane;
+      if (in_order && s == p->joined_stream && sl.batch_seq <= p->joined_seq[bl]) {
         // nothing to add
       } else {
         HIP_TRY(hipStreamWaitEvent(s, sl.done_ev, 0));
-        if (in_order && (s != p->joined_stream || sl.batch_seq > p->joined_seq)) {
-          p->joined_stream = s;
-          p->joined_seq = sl.batch_seq;
+        if (in_order) {
+          if (s != p->joined_stream) {
+            p->joined_stream = s;
+            for (auto &q : p->joined_seq) q = 0;
+          }
+          p->joined_seq[bl] = std::max(p->joined_seq[bl], sl.batch_seq);
         }
       }
     }

@@ -161,3 +161,32 @@ def test_blocked_stream_equals_scalar_and_numpy(monkeypatch, seed):
         np.testing.assert_array_equal(fast, slow)
         np.testing.assert_array_equal(fast, c.sample_packed(n))
         assert a._rng.bit_generator.state == b._rng.bit_generator.state == c._rng.bit_generator.state
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_prefetched_stream_equals_serial_stream_and_numpy(monkeypatch, seed):
+    """Worker threads fill the raw outputs, the exponentials of draws starting at every output and their lengths ahead
+    of the consumer (tsim_pcg.cpp: PStream); the consumer walks the channels over those arrays.  Against the serial
+    blocked stream of the same library (TSIM_PCG_SERIAL=1) and numpy: channel mixes with one-outcome channels (skips),
+    multi-outcome channels (uniforms from the prefetched outputs), p >= 1/3 (search), tiny p (saturating gaps), several
+    thread counts, consecutive calls on one generator, rows and final generator state."""
+    rng = np.random.default_rng(900 + seed)
+    probs = [np.array([0.98, 0.02])] * 20
+    for _ in range(12):
+        p = float(rng.choice([1e-9, 1e-4, 0.02, 0.2, 0.34, 0.6]))
+        w = rng.random(3)
+        probs.append(np.concatenate([[1.0 - p], p * w / w.sum()]) if rng.integers(0, 2) else np.array([1.0 - p, p]))
+    nbits = sum(int(np.log2(len(q))) for q in probs)
+    T = rng.integers(0, 2, size=(70, nbits), dtype=np.uint8)
+    T[rng.integers(0, 70, size=nbits), np.arange(nbits)] = 1
+    ref = ch.ChannelSampler(probs, T, seed=40 + seed, engine="numpy")
+    want = [ref.sample_packed(n) for n in (400_000, 150_000, 7)]
+    for env in ({}, {"TSIM_PCG_THREADS": "3"}, {"TSIM_PCG_THREADS": "16"}, {"TSIM_PCG_SERIAL": "1"}):
+        for k in ("TSIM_PCG_THREADS", "TSIM_PCG_SERIAL"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        nat = ch.ChannelSampler(probs, T, seed=40 + seed, engine="native")
+        for n, w in zip((400_000, 150_000, 7), want):
+            np.testing.assert_array_equal(nat.sample_packed(n), w, err_msg=str(env))
+        assert nat._rng.bit_generator.state == ref._rng.bit_generator.state, env

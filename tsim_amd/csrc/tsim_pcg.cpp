@@ -25,6 +25,11 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <memory>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <thread>
 #include <type_traits>
 #include <vector>
@@ -299,6 +304,413 @@ __attribute__((target("avx512f,avx512dq,avx512vl"))) void geometric_run(Stream &
   }
 }
 
+
+bool have_avx512();
+
+// ---------------------------------------------------------------------------
+// Worker pool (persistent: a call per 10^6-row batch every millisecond or two cannot afford thread creation).
+// run(n, fn) hands fn(0..n-1) to the workers and returns at once; wait() joins the job.  One job at a time.
+// ---------------------------------------------------------------------------
+class Pool {
+ public:
+  explicit Pool(int n_threads) {
+    for (int t = 0; t < n_threads; ++t) threads_.emplace_back([this] { loop(); });
+  }
+  ~Pool() {
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      stop_ = true;
+    }
+    cv_.notify_all();
+    for (auto &t : threads_) t.join();
+  }
+  int size() const { return (int)threads_.size(); }
+  void run(int n_items, std::function<void(int)> fn) {
+    std::lock_guard<std::mutex> lk(m_);
+    fn_ = std::move(fn);
+    n_items_ = n_items;
+    next_.store(0, std::memory_order_relaxed);
+    active_ = (int)threads_.size();
+    ++generation_;
+    cv_.notify_all();
+  }
+  // the caller takes items too, then waits for the workers to leave the job
+  void help_and_wait() {
+    work();
+    std::unique_lock<std::mutex> lk(m_);
+    done_cv_.wait(lk, [this] { return active_ == 0; });
+  }
+
+ private:
+  void work() {
+    for (;;) {
+      const int i = next_.fetch_add(1, std::memory_order_relaxed);
+      if (i >= n_items_) break;
+      fn_(i);
+    }
+  }
+  void loop() {
+    unsigned long long seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [&] { return stop_ || generation_ != seen; });
+        if (stop_) return;
+        seen = generation_;
+      }
+      work();
+      {
+        std::lock_guard<std::mutex> lk(m_);
+        if (--active_ == 0) done_cv_.notify_all();
+      }
+    }
+  }
+  std::vector<std::thread> threads_;
+  std::mutex m_;
+  std::condition_variable cv_, done_cv_;
+  std::function<void(int)> fn_;
+  std::atomic<int> next_{0};
+  int n_items_ = 0, active_ = 0;
+  unsigned long long generation_ = 0;
+  bool stop_ = false;
+};
+
+Pool &pool(int want_threads) {  // want_threads - 1 workers beside the caller (created once; the first caller decides)
+  static Pool p(std::max(0, std::min(31, want_threads - 1)));
+  return p;
+}
+
+// ---------------------------------------------------------------------------
+// Prefetched stream.  The raw PCG64 stream is a pure function of the index (Brown's jump), and so is the COMMON path of
+// the ziggurat on an output (x = (out >> 11) * we[idx], taken when (out >> 11) < ke[idx]: 98.9 %): only what a channel
+// does with them - divide by ITS log1p(-p), accumulate positions, decide where its draws end - is sequential.  So
+// the workers fill, block by block and ahead of the consumer,
+//     raw[i] = output i            ex[i] = the exponential a draw starting at output i returns on the common path,
+//                                          -1 where that draw needs the wedge / tail code (which reads further outputs)
+// and the consumer walks the channels over those arrays: eight divides, a ceil, a prefix sum and a store per eight
+// draws - a fifth of the sequential work (the generator's 128-bit multiplies and the two table gathers are gone from it).
+// Same values in the same order as the blocked Stream above, hence as numpy.
+// ---------------------------------------------------------------------------
+struct PStream {
+  static constexpr uint64_t kBlk = 16384;
+  Pcg start;
+  u128 m4, c4;
+  std::vector<uint64_t> *raw_v;
+  std::vector<double> *ex_v;
+  std::vector<uint8_t> *extra_v;
+  uint64_t *buf = nullptr;   // raw outputs (the name Stream uses)
+  double *ex = nullptr;      // the exponential a draw starting at this output returns ...
+  uint8_t *extra = nullptr;  // ... and how many FURTHER outputs it consumes (0: common path; 255: not precomputed)
+  uint64_t pos = 0;          // stream index of the next output
+  uint64_t n_blocks = 0;     // blocks handed to the workers
+  uint64_t ready_upto = 0;   // outputs [0, ready_upto) are known to be complete
+  std::unique_ptr<std::atomic<uint8_t>[]> done;  // per block
+  bool job_open = false;
+  Pool *pl = nullptr;
+
+  PStream(const Pcg &g, uint64_t expect_outputs, Pool *p, std::vector<uint64_t> &rv, std::vector<double> &ev, std::vector<uint8_t> &xv)
+      : start(g), raw_v(&rv), ex_v(&ev), extra_v(&xv), pl(p) {
+    const u128 m2 = kMult * kMult;
+    m4 = m2 * m2;
+    c4 = start.inc * (kMult * m2 + m2 + kMult + 1);
+    n_blocks = (expect_outputs + kBlk - 1) / kBlk + 1;
+    const size_t cap = (size_t)(n_blocks * kBlk + 64);
+    if (rv.size() < cap) rv.resize(cap);
+    if (ev.size() < cap) ev.resize(cap);
+    if (xv.size() < cap) xv.resize(cap);
+    buf = rv.data();
+    ex = ev.data();
+    extra = xv.data();
+    done.reset(new std::atomic<uint8_t>[n_blocks]);
+    for (uint64_t b = 0; b < n_blocks; ++b) done[b].store(0, std::memory_order_relaxed);
+    job_open = true;
+    pl->run((int)n_blocks, [this](int b) { fill_block((uint64_t)b); done[b].store(1, std::memory_order_release); });
+  }
+  ~PStream() { close(); }
+  void close() {
+    if (job_open) {
+      pl->help_and_wait();
+      job_open = false;
+    }
+  }
+  static inline uint64_t out(u128 st) {
+    const uint64_t hi = (uint64_t)(st >> 64), lo = (uint64_t)st;
+    const unsigned rot = (unsigned)(hi >> 58);
+    const uint64_t x = hi ^ lo;
+    return (x >> rot) | (x << ((64u - rot) & 63u));
+  }
+  void fill_block(uint64_t b);
+  // outputs [pos, pos + need) complete?  (waits for the workers; beyond the prepared range: more blocks, filled here)
+  inline void ensure(uint64_t need) {
+    if (pos + need <= ready_upto) return;
+    ensure_slow(need);
+  }
+  double waited_ms = 0;
+  void ensure_slow(uint64_t need) {
+    const auto t0 = std::chrono::steady_clock::now();
+    struct Acc { double &d; std::chrono::steady_clock::time_point t; ~Acc() { d += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); } } acc{waited_ms, t0};
+    const uint64_t want = pos + need;
+    while (ready_upto < want) {
+      const uint64_t b = ready_upto / kBlk;
+      if (b < n_blocks) {
+        while (!done[b].load(std::memory_order_acquire)) _mm_pause();
+        ready_upto = (b + 1) * kBlk;
+        continue;
+      }
+      // the estimate of the stream length was short (it never is for the reference's n_draws rule): grow, fill here
+      close();
+      const uint64_t nb = n_blocks + std::max<uint64_t>(8, n_blocks / 4);
+      raw_v->resize((size_t)(nb * kBlk + 64));
+      ex_v->resize((size_t)(nb * kBlk + 64));
+      extra_v->resize((size_t)(nb * kBlk + 64));
+      buf = raw_v->data();
+      ex = ex_v->data();
+      extra = extra_v->data();
+      for (uint64_t k = n_blocks; k < nb; ++k) fill_block(k);
+      std::unique_ptr<std::atomic<uint8_t>[]> d2(new std::atomic<uint8_t>[nb]);
+      for (uint64_t k = 0; k < nb; ++k) d2[k].store(1, std::memory_order_relaxed);
+      done.swap(d2);
+      n_blocks = nb;
+    }
+  }
+  inline uint64_t next64() {
+    ensure(1);
+    return buf[pos++];
+  }
+  inline double next_double() { return (double)(next64() >> 11) * (1.0 / 9007199254740992.0); }
+  uint64_t position() const { return pos; }
+  void skip(uint64_t n) { pos += n; }
+  Pcg finish() {
+    close();
+    Pcg g = start;
+    advance(g, pos);
+    return g;
+  }
+};
+
+__attribute__((target("avx512f,avx512dq,avx512vl"))) static void zig_common_avx512(const uint64_t *raw, double *ex, uint8_t *extra, uint64_t n) {
+  for (uint64_t i = 0; i < n; i += 8) {
+    const __m512i v = _mm512_loadu_si512((const void *)(raw + i));
+    __m512i ri = _mm512_srli_epi64(v, 3);
+    const __m512i idx = _mm512_and_si512(ri, _mm512_set1_epi64(0xFF));
+    ri = _mm512_srli_epi64(ri, 8);
+    const __m512i ke = _mm512_i64gather_epi64(idx, (const void *)kZigKe, 8);
+    const __m512d we = _mm512_i64gather_pd(idx, (const void *)kZigWe, 8);
+    const __m512d x = _mm512_mul_pd(_mm512_cvtepu64_pd(ri), we);
+    const __mmask8 ok = _mm512_cmplt_epu64_mask(ri, ke);
+    _mm512_storeu_pd(ex + i, x);
+    // 0 where the common path holds, 255 ("not resolved yet") elsewhere: one byte per output
+    const __m128i bytes = _mm512_cvtepi64_epi8(_mm512_maskz_set1_epi64((__mmask8)~ok, 0xFF));
+    _mm_storel_epi64((__m128i *)(extra + i), bytes);
+  }
+}
+
+void PStream::fill_block(uint64_t b) {
+  constexpr int kTail = 64;  // outputs beyond the block, for wedge / tail draws that start near its end
+  Pcg g = start;
+  advance(g, b * kBlk);
+  u128 st = g.state, s[4];
+  for (int j = 0; j < 4; ++j) {
+    st = st * kMult + start.inc;
+    s[j] = st;
+  }
+  uint64_t *dst = buf + b * kBlk;
+  u128 s0 = s[0], s1 = s[1], s2 = s[2], s3 = s[3];
+  for (uint64_t t = 0; t < kBlk / 4; ++t) {
+    dst[0] = out(s0); dst[1] = out(s1); dst[2] = out(s2); dst[3] = out(s3);
+    s0 = s0 * m4 + c4; s1 = s1 * m4 + c4; s2 = s2 * m4 + c4; s3 = s3 * m4 + c4;
+    dst += 4;
+  }
+  double *e = ex + b * kBlk;
+  uint8_t *xt = extra + b * kBlk;
+  const uint64_t *r = buf + b * kBlk;
+  if (have_avx512()) {
+    zig_common_avx512(r, e, xt, kBlk);
+  } else {
+    for (uint64_t i = 0; i < kBlk; ++i) {
+      uint64_t ri = r[i] >> 3;
+      const unsigned idx = (unsigned)(ri & 0xFFu);
+      ri >>= 8;
+      e[i] = (double)ri * kZigWe[idx];
+      xt[i] = ri < kZigKe[idx] ? 0 : 255;
+    }
+  }
+  // the other 1.1 %: the wedge / tail draw itself (standard_exponential above, on the outputs that follow), so that the
+  // consumer finds every draw's value and length ready - a draw it had to redo cost it ~200 ns (exp, log1p, a
+  // mispredicted branch out of the eight-wide loop)
+  uint64_t tail[kTail];
+  bool have_tail = false;
+  auto raw_at = [&](uint64_t j) -> uint64_t {  // output j of this block's range, j < kBlk + kTail
+    if (j < kBlk) return r[j];
+    if (!have_tail) {
+      for (int t = 0; t < kTail; t += 4) {
+        tail[t] = out(s0); tail[t + 1] = out(s1); tail[t + 2] = out(s2); tail[t + 3] = out(s3);
+        s0 = s0 * m4 + c4; s1 = s1 * m4 + c4; s2 = s2 * m4 + c4; s3 = s3 * m4 + c4;
+      }
+      have_tail = true;
+    }
+    return tail[j - kBlk];
+  };
+  for (uint64_t i0 = 0; i0 < kBlk; i0 += 8) {
+    uint64_t m;
+    memcpy(&m, xt + i0, 8);
+    while (m) {
+      const unsigned lane = (unsigned)__builtin_ctzll(m) >> 3;
+      m &= ~(0xFFull << (8 * lane));
+      const uint64_t i = i0 + lane;
+      uint64_t j = i;
+      double val = 0.0;
+      bool resolved = false;
+      while (j + 2 < kBlk + kTail) {
+        uint64_t ri = raw_at(j++) >> 3;
+        const unsigned idx = (unsigned)(ri & 0xFFu);
+        ri >>= 8;
+        const Strip &sp = kStrips.s[idx];
+        const double x = (double)ri * sp.we;
+        if (ri < sp.ke) { val = x; resolved = true; break; }
+        const double u = (double)(raw_at(j++) >> 11) * (1.0 / 9007199254740992.0);
+        if (idx == 0) { val = kZigExpR - log1p(-u); resolved = true; break; }
+        if ((kZigFe[idx - 1] - kZigFe[idx]) * u + kZigFe[idx] < exp(-x)) { val = x; resolved = true; break; }
+      }
+      if (resolved && j - i - 1 < 255) {
+        e[i] = val;
+        xt[i] = (uint8_t)(j - i - 1);
+      }  // else: stays 255, the consumer redoes it
+    }
+  }
+}
+
+inline double standard_exponential(PStream &g) {
+  for (;;) {
+    uint64_t ri = g.next64() >> 3;
+    const unsigned idx = (unsigned)(ri & 0xFFu);
+    ri >>= 8;
+    const Strip &st = kStrips.s[idx];
+    const double x = (double)ri * st.we;
+    if (ri < st.ke) return x;
+    if (idx == 0) return kZigExpR - log1p(-g.next_double());
+    if ((kZigFe[idx - 1] - kZigFe[idx]) * g.next_double() + kZigFe[idx] < exp(-x)) return x;
+  }
+}
+inline int64_t geometric_search(PStream &g, double p) {
+  int64_t X = 1;
+  double sum = p, prod = p;
+  const double q = 1.0 - p, U = g.next_double();
+  while (U > sum) {
+    prod *= q;
+    sum += prod;
+    ++X;
+  }
+  return X;
+}
+inline int64_t geometric_inversion(PStream &g, double log1m_p) {
+  const double z = ceil(-standard_exponential(g) / log1m_p);
+  if (z >= 9.223372036854776e+18) return INT64_MAX;
+  return (int64_t)z;
+}
+
+// geometric8 on the prefetched exponentials: the per-channel part - quotient, ceil, running sum.
+//   gap = ceil(-e / log1p(-p)) must be numpy's, bit for bit, but the DIVIDE is now the consumer's bottleneck (one
+//   512-bit vdivpd per eight draws: 16 cycles on Skylake-X, ~10 on Zen 4).  q = e * (-1 / l) differs from the exact
+//   quotient by at most 2 ulp, so ceil(q) is the exact ceil unless an integer lies within that distance of q: the
+//   group then (never, in practice: e is continuous) takes the divide.  Everything but `pos = min(pos + total, far)`
+//   is off the dependency chain: the prefix sum is local to the group, its last lane is the group's total.
+struct GeoCtx {
+  double l, inv;  // log1p(-p), -1 / l
+};
+// Up to eight draws of one channel from the prefetched arrays, starting at output `at`.  Lanes after the first wedge /
+// tail draw belong to outputs that draw consumed: the group ends with it (`taken` draws, `advance` outputs).
+struct GeoP {
+  int taken, inside, redo;  // redo: the draw after the taken ones was not precomputed (extra == 255): scalar code
+  uint64_t advance;
+  int64_t pos;
+};
+__attribute__((target("avx512f,avx512dq,avx512vl"))) inline GeoP geometric8_pre(const double *ex, const uint8_t *extra, const GeoCtx &c,
+                                                                              int64_t pos, int64_t far, int64_t num_samples, uint32_t *dst) {
+  const __m512d x = _mm512_loadu_pd(ex);
+  uint64_t xm;
+  memcpy(&xm, extra, 8);
+  const __m512d q = _mm512_mul_pd(x, _mm512_set1_pd(c.inv));
+  __m512d z = _mm512_roundscale_pd(q, _MM_FROUND_TO_POS_INF | _MM_FROUND_NO_EXC);
+  // an integer within 4 ulp of q (either side)?  |q - rint(q)| <= q * 2^-50
+  const __m512d near = _mm512_roundscale_pd(q, _MM_FROUND_TO_NEAREST_INT | _MM_FROUND_NO_EXC);
+  const __m512d dist = _mm512_abs_pd(_mm512_sub_pd(q, near));
+  const __mmask8 close = _mm512_cmp_pd_mask(dist, _mm512_mul_pd(q, _mm512_set1_pd(8.8817841970012523e-16)), _CMP_LE_OQ);
+  if (__builtin_expect(close != 0, 0)) {
+    const __m512d nx = _mm512_xor_pd(x, _mm512_set1_pd(-0.0));
+    z = _mm512_roundscale_pd(_mm512_div_pd(nx, _mm512_set1_pd(c.l)), _MM_FROUND_TO_POS_INF | _MM_FROUND_NO_EXC);
+  }
+  // numpy: z >= 9.22e18 -> INT64_MAX; here every gap saturates at `far` (> num_samples) - a position that left the batch
+  // stays outside either way
+  z = _mm512_min_pd(z, _mm512_set1_pd((double)far));
+  __m512i p = _mm512_cvttpd_epi64(z);
+  const __m512i zero = _mm512_setzero_si512();
+  p = _mm512_add_epi64(p, _mm512_alignr_epi64(p, zero, 7));
+  p = _mm512_add_epi64(p, _mm512_alignr_epi64(p, zero, 6));
+  p = _mm512_add_epi64(p, _mm512_alignr_epi64(p, zero, 4));
+  GeoP r;
+  r.redo = 0;
+  if (__builtin_expect(xm == 0, 1)) {
+    const int64_t total = _mm_extract_epi64(_mm512_extracti64x2_epi64(p, 3), 1);
+    p = _mm512_min_epi64(_mm512_add_epi64(p, _mm512_set1_epi64(pos)), _mm512_set1_epi64(far));
+    r.taken = 8;
+    r.advance = 8;
+    r.inside = __builtin_popcount((unsigned)_mm512_cmplt_epi64_mask(p, _mm512_set1_epi64(num_samples)));
+    _mm256_storeu_si256((__m256i *)dst, _mm512_cvtepi64_epi32(p));
+    r.pos = pos + total >= far ? far : pos + total;
+    return r;
+  }
+  const int lane = __builtin_ctzll(xm) >> 3;  // the first wedge / tail draw
+  const unsigned ext = (unsigned)((xm >> (8 * lane)) & 0xFFu);
+  r.redo = ext == 255u;
+  r.taken = r.redo ? lane : lane + 1;
+  r.advance = (uint64_t)r.taken + (r.redo ? 0u : ext);
+  p = _mm512_min_epi64(_mm512_add_epi64(p, _mm512_set1_epi64(pos)), _mm512_set1_epi64(far));
+  const __mmask8 taken = (__mmask8)((1u << r.taken) - 1u);
+  r.inside = __builtin_popcount((unsigned)(_mm512_cmplt_epi64_mask(p, _mm512_set1_epi64(num_samples)) & taken));
+  _mm256_storeu_si256((__m256i *)dst, _mm512_cvtepi64_epi32(p));
+  alignas(64) int64_t tmp[8];
+  _mm512_store_si512((void *)tmp, p);
+  r.pos = r.taken ? tmp[r.taken - 1] : pos;
+  return r;
+}
+
+__attribute__((target("avx512f,avx512dq,avx512vl"))) void geometric_run(PStream &g, double l, int64_t n_draws, int64_t far,
+                                                                      int64_t num_samples, uint32_t *frow, size_t room, int64_t &i_io,
+                                                                      int64_t &pos_io, size_t &n_io) {
+  const GeoCtx c{l, -1.0 / l};
+  int64_t i = i_io, pos = pos_io;
+  size_t n = n_io;
+  uint64_t at = g.pos;
+  while (i + 8 <= n_draws && n + 8 <= room) {
+    if (__builtin_expect(at + 8 > g.ready_upto, 0)) {
+      g.pos = at;
+      g.ensure(8);
+    }
+    // the lines were written by other cores: ask for them early
+    _mm_prefetch((const char *)(g.ex + at + 512), _MM_HINT_T0);
+    _mm_prefetch((const char *)(g.extra + at + 1024), _MM_HINT_T0);
+    const GeoP r = geometric8_pre(g.ex + at, g.extra + at, c, pos, far, num_samples, frow + n);
+    n += (size_t)r.inside;
+    pos = r.pos;
+    at += r.advance;
+    i += r.taken;
+    if (__builtin_expect(r.redo, 0)) {  // (a draw the fill could not finish inside its look-ahead: never seen)
+      g.pos = at;
+      const int64_t gap = geometric_inversion(g, l);
+      at = g.pos;
+      pos = (gap >= far || pos + gap >= far) ? far : pos + gap;
+      frow[n] = (uint32_t)pos;
+      n += (size_t)((pos < num_samples) & (n < room));
+      ++i;
+    }
+  }
+  g.pos = at;
+  i_io = i;
+  pos_io = pos;
+  n_io = n;
+}
+
 bool have_avx512() {
   static const bool ok = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512dq") && __builtin_cpu_supports("avx512vl");
   return ok;
@@ -308,14 +720,22 @@ bool have_avx512() {
 struct Scratch {
   std::vector<uint32_t> row;      // fired rows, channel after channel
   std::vector<uint16_t> outcome;  // outcome index per fired row (multi-outcome channels only)
+  std::vector<uint64_t> raw;      // prefetched stream: outputs, ...
+  std::vector<double> ex;         // ... the exponentials of draws starting there ...
+  std::vector<uint8_t> extra;     // ... and their lengths
 };
-thread_local Scratch g_scratch;
+// One process-wide scratch (tens of MB for a 10^6-row batch: a sampler thread that a caller creates per sample() call must
+// not pay for allocating and faulting it in every time), one call at a time.
+Scratch g_scratch;
+std::mutex g_scratch_mutex;
 
 // generator-agnostic helpers of pass 1
 inline void skip_outputs(Pcg &g, uint64_t n) { advance(g, n); }
 inline void skip_outputs(Stream &g, uint64_t n) { g.skip(n); }
 inline double draw_double(Pcg &g) { return next_double(g); }
 inline double draw_double(Stream &g) { return g.next_double(); }
+inline void skip_outputs(PStream &g, uint64_t n) { g.skip(n); }
+inline double draw_double(PStream &g) { return g.next_double(); }
 
 // pass 1 of tsim_pcg_sample_channels for either generator form
 template <class G>
@@ -365,7 +785,7 @@ int draw_channels(G &g, int32_t n_channels, const double *p_fire, const int32_t 
       const double l = log1p(-p);
       const int64_t far = num_samples + 1;
       int64_t i = 0;
-      if constexpr (std::is_same<G, Stream>::value) {
+      if constexpr (std::is_same<G, Stream>::value || std::is_same<G, PStream>::value) {
         // eight draws per step while the common path holds; the scalar loop below finishes the rest (the draw
         // that left the common path, and tiny p whose gaps may not fit an int64)
         if (l < -1e-15) {
@@ -437,15 +857,40 @@ extern "C" int tsim_pcg_sample_channels(tsim_pcg64 *rng, int32_t n_channels, con
   if (n_channels > 0 && (!p_fire || !n_outcomes || !cond_cdf || !patterns)) return tsim_fail(TSIM_EINVAL, "NULL channel table");
   if (num_samples == 0) return TSIM_OK;
   static const bool timing = getenv("TSIM_PCG_TIMING") != nullptr;
+  const bool force_scalar = getenv("TSIM_PCG_SCALAR") != nullptr, force_serial = getenv("TSIM_PCG_SERIAL") != nullptr;
   const auto t_start = std::chrono::steady_clock::now();
-  memset(rows, 0, (size_t)num_samples * words * 8);
-  const auto t_zero = std::chrono::steady_clock::now();
-  // ---- pass 1 (sequential: the stream is one dependency chain): per channel the fired rows and their outcomes
+  int T = threads > 0 ? threads : (int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency()));
+  if (const char *e = getenv("TSIM_PCG_THREADS")) T = std::max(1, atoi(e));
+  Pool &pl = pool(T);
+  T = std::min(T, pl.size() + 1);
+  // ---- pass 1 (the stream is one dependency chain): per channel the fired rows and their outcomes
+  std::lock_guard<std::mutex> scratch_lock(g_scratch_mutex);
   Scratch &S = g_scratch;
   std::vector<size_t> chan_begin((size_t)n_channels + 1, 0), table_off((size_t)n_channels + 1, 0);
   size_t n_fires = 0;
   Pcg g = load(rng);
-  if (have_avx512() && !getenv("TSIM_PCG_SCALAR")) {
+  // how many outputs the call will consume, about: per channel n_draws (+ 1.2 % wedge / tail extras) and one per fire
+  double expect = 4096.0;
+  for (int c = 0; c < n_channels; ++c) {
+    const double e = (double)num_samples * p_fire[c];
+    const double nd = e + 7.0 * sqrt(std::max(0.0, e * (1.0 - p_fire[c]))) + 100.0;
+    expect += nd * 1.02 + 64.0 + e + 8.0 * sqrt(std::max(0.0, e)) + 16.0;
+  }
+  const bool prefetch = have_avx512() && !force_scalar && !force_serial && T > 1 && expect >= 65536.0 && expect < 1.5e8;
+  if (prefetch) {
+    PStream st(g, (uint64_t)expect, &pl, S.raw, S.ex, S.extra);
+    if (getenv("TSIM_PCG_FILL_FIRST")) {
+      st.close();
+      if (timing) fprintf(stderr, "  fill done at %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count());
+    }
+    const int r = draw_channels(st, n_channels, p_fire, n_outcomes, cond_cdf, num_samples, S, chan_begin, table_off, n_fires);
+    if (timing)
+      fprintf(stderr, "  consumer done at %.2f ms, %.2f ms of them waiting for blocks (position %llu of %llu prepared)\n",
+              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(), st.waited_ms,
+              (unsigned long long)st.position(), (unsigned long long)(st.n_blocks * PStream::kBlk));
+    g = st.finish();
+    if (r) return r;
+  } else if (have_avx512() && !force_scalar) {
     Stream st(g);
     if (int r = draw_channels(st, n_channels, p_fire, n_outcomes, cond_cdf, num_samples, S, chan_begin, table_off, n_fires)) return r;
     g = st.finish();
@@ -457,21 +902,21 @@ extern "C" int tsim_pcg_sample_channels(tsim_pcg64 *rng, int32_t n_channels, con
   chan_begin[n_channels] = n_fires;
   store(rng, g);
   const auto t_pass1 = std::chrono::steady_clock::now();
-  // ---- pass 2: XOR the patterns in, tiled over shot ranges (a tile of rows stays cache resident while every
-  //      channel's cursor sweeps it) and threaded over tiles
+  // ---- pass 2: zero the rows and XOR the patterns in, tile by tile over shot ranges (a tile of rows is cleared and
+  //      stays cache resident while every channel's cursor sweeps it), the tile ranges shared out over the pool
   const int64_t tile_rows = std::max<int64_t>(1024, (256 * 1024) / (8 * (int64_t)words));
   const int64_t n_tiles = (num_samples + tile_rows - 1) / tile_rows;
-  int T = threads > 0 ? threads : (int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency()));
-  T = (int)std::max<int64_t>(1, std::min<int64_t>(T, n_tiles));
-  if (n_fires < 16384) T = 1;
+  const int parts = (int)std::max<int64_t>(1, std::min<int64_t>(n_fires < 16384 && num_samples < 65536 ? 1 : 4 * T, n_tiles));
   auto work = [&](int t) {
     std::vector<size_t> cur((size_t)n_channels);
-    const int64_t tile_lo = n_tiles * t / T, tile_hi = n_tiles * (t + 1) / T;
+    const int64_t tile_lo = n_tiles * t / parts, tile_hi = n_tiles * (t + 1) / parts;
     const uint32_t first_row = (uint32_t)std::min<int64_t>(num_samples, tile_lo * tile_rows);
-    for (int c = 0; c < n_channels; ++c)  // first fire of this thread's range in every channel
+    for (int c = 0; c < n_channels; ++c)  // first fire of this range in every channel
       cur[c] = (size_t)(std::lower_bound(frow + chan_begin[c], frow + chan_begin[c + 1], first_row) - frow);
     for (int64_t tile = tile_lo; tile < tile_hi; ++tile) {
+      const uint32_t begin_row = (uint32_t)std::min<int64_t>(num_samples, tile * tile_rows);
       const uint32_t end_row = (uint32_t)std::min<int64_t>(num_samples, (tile + 1) * tile_rows);
+      memset(rows + (size_t)begin_row * words, 0, (size_t)(end_row - begin_row) * words * 8);
       for (int c = 0; c < n_channels; ++c) {
         size_t k = cur[c];
         const size_t stop = chan_begin[c + 1];
@@ -492,19 +937,17 @@ extern "C" int tsim_pcg_sample_channels(tsim_pcg64 *rng, int32_t n_channels, con
       }
     }
   };
-  if (T <= 1) {
+  if (parts <= 1) {
     work(0);
   } else {
-    std::vector<std::thread> pool;
-    for (int t = 1; t < T; ++t) pool.emplace_back(work, t);
-    work(0);
-    for (auto &th : pool) th.join();
+    pl.run(parts, work);
+    pl.help_and_wait();
   }
   const size_t fires_total = n_fires;
   if (timing)
-    fprintf(stderr, "tsim_pcg_sample_channels: %lld rows, %zu fires: zero %.2f ms, draws %.2f ms, scatter (%d threads) %.2f ms\n",
-            (long long)num_samples, fires_total, std::chrono::duration<double, std::milli>(t_zero - t_start).count(),
-            std::chrono::duration<double, std::milli>(t_pass1 - t_zero).count(), T,
+    fprintf(stderr, "tsim_pcg_sample_channels: %lld rows, %zu fires: draws (%s) %.2f ms, zero + scatter (%d threads) %.2f ms\n",
+            (long long)num_samples, fires_total, prefetch ? "prefetched stream" : "serial stream",
+            std::chrono::duration<double, std::milli>(t_pass1 - t_start).count(), T,
             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_pass1).count());
   return TSIM_OK;
 }

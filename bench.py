@@ -993,9 +993,12 @@ def extra_legs(backend, synth, program, cfg, hp, info, B, num_f, n_out, key, f_b
     for p_bit in (0.1, 0.3):
         fl = [resident_f(p_bit, 5000 + int(p_bit * 100) + k) for k in range(2)]
         for _ in range((init_steps + 16) // 4):
+            # one group at a time, waited for: the launch plan reads the hard-row counts the GPU wrote for EARLIER launches
+            # - a host that runs ahead still plans for the sparse batches (and the on-demand table build, 61 ms, would
+            # fall into the timed steps below; scripts/dense_transition.py shows the transition call by call)
             steps(4, fl)
-        drain()
-        hp.synchronize()
+            drain()
+            hp.synchronize()
         n = 40
         t0 = time.perf_counter()
         steps(n, fl)
@@ -1007,8 +1010,8 @@ def extra_legs(backend, synth, program, cfg, hp, info, B, num_f, n_out, key, f_b
             b.free()
     for _ in range((init_steps + 16) // 4):  # back to the benchmark's f distribution for whoever runs after us
         steps(4)
-    drain()
-    hp.synchronize()
+        drain()
+        hp.synchronize()
     out["dense"] = dense
     # (3) time to the first batch: fresh handle (pack + upload + pattern-table build) + one launch, HIP context warm
     t0 = time.perf_counter()

@@ -353,6 +353,16 @@ def main() -> None:
         nf_file = int(extra_arrays["num_f"]) if "num_f" in extra_arrays else need_f
         cfg = dict(name=f"exported program {os.path.basename(args.program)}", num_f=int(args.num_f or max(nf_file, need_f)), p_bit=0.02, seed=42)
         args.config = os.path.basename(args.program)
+        # the file's own noise model (scripts/export_from_tsim.py stores channel_probs / error_transform as
+        # ChannelSampler receives them, noise/channels.py:531): f batches are then drawn from IT, not from p_bit
+        file_noise = None
+        if "error_transform" in extra_arrays and "n_channels" in extra_arrays and args.p_bit is None:
+            from tsim_amd.channels import ChannelSampler
+
+            probs = [np.asarray(extra_arrays[f"channel_probs_{i}"], dtype=np.float64) for i in range(int(extra_arrays["n_channels"]))]
+            file_noise = (probs, np.asarray(extra_arrays["error_transform"], dtype=np.uint8))
+            cfg["num_f"] = int(args.num_f or file_noise[1].shape[0])
+            cfg["name"] += " with its own noise model"
     else:
         program, cfg = synth.config_program(args.config, physical=not args.random_program, approx=args.approx,
                                             **({"live_padding": True} if args.live_padding else {}))
@@ -368,6 +378,11 @@ def main() -> None:
 
     def resident_f(p_bit: float, seed: int):
         """One synthetic packed f batch of this rank's shard, in HBM."""
+        if args.program and file_noise is not None and p_bit == cfg["p_bit"]:
+            packed = ChannelSampler(file_noise[0], file_noise[1], seed=seed).sample_packed(B).view(np.uint8).reshape(B, -1)
+            buf = hp.malloc(B * WF * 8)
+            hp.h2d(buf, np.ascontiguousarray(packed))
+            return buf
         f = synth.synth_f(B, num_f, p_bit, seed=seed)
         packed = np.packbits(f, axis=1, bitorder="little")
         if WF * 8 - packed.shape[1]:
@@ -782,9 +797,10 @@ def main() -> None:
                                "after ~25 ms of work (profiles/r03/steps_dependence.txt); --spinup-ms 0 for none"},
             "repeat_ms_per_step": {"median": statistics.median(per_step), "min": min(per_step), "max": max(per_step), "all": per_step},
             "config": {
-                "workload": f"{args.config}: {cfg.get('name', 'shape of SURVEY 8d')}, synthetic seeded program: "
-                f"{info['total_graphs']} stabiliser terms, {info['total_rows']} GF(2) rows, n_out={n_out}, "
-                f"num_f={num_f}, p_bit={cfg['p_bit']}",
+                "workload": f"{args.config}: {cfg.get('name', 'shape of SURVEY 8d')}, "
+                + ("program read from the file: " if args.program else "synthetic seeded program: ")
+                + f"{info['total_graphs']} stabiliser terms, {info['total_rows']} GF(2) rows, n_out={n_out}, num_f={num_f}, "
+                + ("f drawn from the file's channel_probs / error_transform" if (args.program and file_noise is not None) else f"p_bit={cfg['p_bit']}"),
                 "shots_per_step_per_gpu": B,
                 "global_batch": B * N,
                 "distinct_f_batches": NF,

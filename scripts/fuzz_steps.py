@@ -1,0 +1,118 @@
+"""Soak test of tsim_sample_steps_device (round 3: fused first passes, the specialised pass for one component of at most
+eight outputs, hard rows on the block-per-row kernel or the per-shot one, on the group's lane or the batch lane): random
+programs (normalised probability models, exact and approximate floatfactors), group counts, batch sizes, noise levels
+(sparse <-> dense jumps: the launch plan adapts), shot offsets, both output layouts, interleaved per-step launches and
+serial launches on the same handle.  Every batch is compared with the FULL kernel (pattern tables off) of a second handle
+under the same subkey; small batches also with the C oracle.
+
+usage: fuzz_steps.py [rounds per program] [programs] [first seed]"""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import warnings
+import numpy as np
+warnings.simplefilter("ignore")
+from oracle import oracle_c as OC
+from tsim_amd import backend as hip, prng, synth
+
+rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+n_prog = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+seed0 = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+bad = 0
+for ps in range(seed0, seed0 + n_prog):
+    rng = np.random.default_rng(31000 + ps)
+    kind = ps % 5
+    if kind == 0:
+        prog, cfg = synth.config_program("C2", approx=bool(rng.integers(0, 2)), live_padding=bool(rng.integers(0, 2)))
+        nf = cfg["num_f"]
+    elif kind == 1:
+        prog, cfg = synth.config_program(str(rng.choice(["C3", "C4"])), approx=bool(rng.integers(0, 2)))
+        nf = cfg["num_f"]
+    else:  # random shapes: one component of 1..8 outputs (the specialised pass) or several (the general fused pass)
+        nf = int(rng.choice([20, 40, 64, 90, 128]))
+        ncomp = 1 if kind in (2, 3) else int(rng.integers(2, 4))
+        comps = []
+        for _ in range(ncomp):
+            n = int(rng.integers(1, 9 if ncomp == 1 else 4))
+            F = int(rng.integers(1, min(nf, 48) + 1))
+            g0 = int(rng.integers(1, 4)); G = [g0]
+            for _k in range(n):
+                G.append(G[-1] + int(rng.integers(0, G[-1] + 2)))
+            comps.append(dict(n=n, F=F, G=G, density=float(rng.choice([0.05, 0.2])), ta=(0, 6), tb=(0, 6), tc=(0, 8), td=(0, 3)))
+        prog = synth.physical_program(num_f=nf, n_direct=int(rng.integers(0, min(nf, 30) + 1)), components=comps, seed=int(rng.integers(0, 2**31)),
+                                      shuffle_outputs=bool(rng.integers(0, 2)), direct_flip_fraction=0.3, approx=bool(rng.integers(0, 3) == 0))
+    hp = hip.HipProgram(prog)
+    ref = hip.HipProgram(prog, pattern_tables=False)
+    op = OC.OracleProgram(prog)
+    wf, wo, rb = (nf + 63) // 64, (prog.num_outputs + 63) // 64, (prog.num_outputs + 7) // 8
+    key = prng.key(int(rng.integers(0, 1 << 40)))
+    ks = (C.c_uint32 * 2)(key[0] & 0xFFFFFFFF, key[1] & 0xFFFFFFFF)
+    for r in range(rounds):
+        n = int(rng.choice([1, 2, 5, 8, 9, 17, 24]))
+        B = int(rng.choice([1, 64, 1000, 4097, 30000, 120000]))
+        p = float(rng.choice([0.0, 0.005, 0.02, 0.02, 0.06, 0.15]))
+        packed = bool(rng.integers(0, 2))
+        off = int(rng.choice([0, 0, 0, 12345]))
+        fs = [synth.synth_f(B, nf, p * float(rng.choice([1.0, 1.0, 2.0])), seed=int(rng.integers(0, 1 << 30))) for _ in range(n)]
+        fps = []
+        for f in fs:
+            fp = np.packbits(f, axis=1, bitorder="little")
+            fps.append(np.ascontiguousarray(np.pad(fp, ((0, 0), (0, wf * 8 - fp.shape[1])))))
+        d_f = [hp.malloc(B * wf * 8) for _ in range(n)]
+        d_o = [hp.malloc(max(16, B * wo * 8)) for _ in range(n)]
+        for d, fp in zip(d_f, fps):
+            hp.h2d(d, fp)
+        k_before = (int(ks[0]), int(ks[1]))
+        mode = int(rng.integers(0, 4))
+        if mode == 0 and n > 2:  # split into two calls
+            m = int(rng.integers(1, n))
+            hp.sample_steps_device([d.ptr for d in d_f[:m]], B, nf, ks, [d.ptr for d in d_o[:m]], shot_offset=off, out_bit_packed=packed)
+            hp.sample_steps_device([d.ptr for d in d_f[m:]], B, nf, ks, [d.ptr for d in d_o[m:]], shot_offset=off, out_bit_packed=packed)
+        else:
+            hp.sample_steps_device([d.ptr for d in d_f], B, nf, ks, [d.ptr for d in d_o], shot_offset=off, out_bit_packed=packed)
+        hp.synchronize()
+        # the subkeys the call used
+        kk, subs = k_before, []
+        for _ in range(n):
+            kk, sub = prng.split(kk)
+            subs.append(sub)
+        assert (int(ks[0]), int(ks[1])) == (kk[0] & 0xFFFFFFFF, kk[1] & 0xFFFFFFFF), "key state"
+        r_f, r_o = ref.malloc(B * wf * 8), ref.malloc(max(16, B * wo * 8))
+        for i in range(n):
+            if packed:
+                got = np.zeros((B, rb), np.uint8); hp.d2h(got, d_o[i])
+            else:
+                raw = np.zeros((B, wo * 8), np.uint8); hp.d2h(raw, d_o[i])
+                got = np.packbits(np.unpackbits(raw, axis=1, bitorder="little")[:, : prog.num_outputs], axis=1, bitorder="little")
+            ref.h2d(r_f, fps[i]); ref.sample_batch_device(r_f.ptr, B, nf, subs[i], r_o.ptr, shot_offset=off); ref.synchronize()
+            raw = np.zeros((B, wo * 8), np.uint8); ref.d2h(raw, r_o)
+            want = np.packbits(np.unpackbits(raw, axis=1, bitorder="little")[:, : prog.num_outputs], axis=1, bitorder="little")
+            if not np.array_equal(got, want):
+                bad += 1
+                print("MISMATCH program", ps, "round", r, "batch", i, "of", n, "B", B, "p", p, "packed", packed, "off", off, int((got != want).any(axis=1).sum()), "rows differ", flush=True)
+            if B <= 1000 and off == 0 and i < 2:
+                w2 = np.packbits(op.sample_program(fs[i], subs[i]), axis=1, bitorder="little")
+                if not np.array_equal(got, w2):
+                    bad += 1
+                    print("ORACLE MISMATCH program", ps, "round", r, "batch", i, flush=True)
+        # a serial and a per-step launch in between (they share the handle's lanes, lists and plan)
+        if rng.random() < 0.5:
+            i = int(rng.integers(0, n))
+            sub = prng.key(int(rng.integers(0, 1 << 40)))
+            if rng.random() < 0.5:
+                hp.sample_batch_device(d_f[i].ptr, B, nf, sub, d_o[i].ptr, shot_offset=off)
+            else:
+                hp.sample_batch_device_begin(3, d_f[i].ptr, B, nf, sub, d_o[i].ptr, shot_offset=off); hp.sample_batch_device_end(3)
+            hp.synchronize()
+            raw = np.zeros((B, wo * 8), np.uint8); hp.d2h(raw, d_o[i])
+            ref.h2d(r_f, fps[i]); ref.sample_batch_device(r_f.ptr, B, nf, sub, r_o.ptr, shot_offset=off); ref.synchronize()
+            raw2 = np.zeros((B, wo * 8), np.uint8); ref.d2h(raw2, r_o)
+            if not np.array_equal(raw, raw2):
+                bad += 1
+                print("MISMATCH (serial / per-step launch) program", ps, "round", r, "B", B, "p", p, flush=True)
+        for d in d_f + d_o + [r_f, r_o]:
+            d.free()
+    inf = hp.info()
+    print("program", ps, "kind", kind, "outputs", prog.num_outputs, "components", [len(c.output_indices) for c in prog.components], "tables", inf["pattern_max_weight"], "ok" if not bad else "", flush=True)
+    hp.close(); ref.close()
+print("programs", n_prog, "rounds each", rounds, "mismatches", bad)
+sys.exit(1 if bad else 0)

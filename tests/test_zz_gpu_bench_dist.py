@@ -57,3 +57,24 @@ def test_bench_refuses_a_world_size_it_was_not_asked_for(hip):
                        env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_bench_on_an_exported_program_with_its_own_noise_model(hip, tmp_path):
+    """`bench.py --program x.npz`: the file scripts/export_from_tsim.py writes (here: the C2 shape saved through the same
+    save_npz, with a channel_probs / error_transform noise model) - f batches are drawn from the file's noise model."""
+    import numpy as np
+
+    from tsim_amd import synth
+    from tsim_amd.program import save_npz
+
+    prog, cfg = synth.config_program("C2")
+    nf = cfg["num_f"]
+    probs = {f"channel_probs_{i}": np.array([0.99, 0.01]) for i in range(nf)}
+    path = str(tmp_path / "exported.npz")
+    save_npz(path, prog, n_channels=np.int64(nf), error_transform=np.eye(nf, dtype=np.uint8), num_f=np.int64(nf), **probs)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--program", path, "--steps", "6", "--warmup", "2", "--shots", "200000",
+                        "--repeats", "2", "--spinup-ms", "0", "--no-cpu-baseline", "--no-extra-legs"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["value"] > 0 and "exported program" in d["config"]["variant"] and "its own noise model" in d["config"]["workload"]

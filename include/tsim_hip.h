@@ -209,7 +209,7 @@ int tsim_sample_batch_device(tsim_program *p, const uint64_t *d_f, int64_t B, in
  * the 64-row blocks of the hard-row kernel are filled.  TSIM_AMD_DEFER_HARD=0 / TSIM_AMD_MERGE_LISTS=0
  * switch these off.  Results never depend on any of it.
  */
-#define TSIM_PIPELINE_SLOTS 16
+#define TSIM_PIPELINE_SLOTS 32
 #define TSIM_PIPE_INPUTS_READY 1u
 /* d_out receives the reference's bit_packed rows, uint8 [B, ceil(num_outputs/8)] (sampler.py:665-669), INSTEAD of
  * the padded 8-byte words: ceil(n/8) bytes written per shot (3 instead of 8 for 20 outputs); any alignment */

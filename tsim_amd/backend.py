@@ -350,7 +350,7 @@ class HipProgram:
             "tsim_sample_batch_device",
         )
 
-    PIPELINE_SLOTS = 16
+    PIPELINE_SLOTS = 32
 
     def split_key(self, key):
         """``prng.split`` computed by the library (same values; ~5 us cheaper per batch)."""

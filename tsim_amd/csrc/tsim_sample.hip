@@ -799,7 +799,10 @@ static int steps_group_fused(tsim_program *p, int n, const uint64_t *const *d_f,
   const bool packed = (flags & TSIM_PIPE_OUT_BIT_PACKED) != 0;
   if (!p->deferred.empty())
     if (int r = tsim_flush_hard(p)) return r;  // rows parked by batch-by-batch launches: their own batch first
-  hipStream_t s = p->slots[1 + (int)(p->steps_groups++ % (unsigned long long)p->knobs.fused_lanes)].side;
+  // two first-pass lanes; three for small groups, whose hard-row grids (latency-bound, on the group's lane) take longer
+  // than their first passes (C4 at 8 x 10^5 shots per group: 1.16 -> 1.53e10 shots/s; the large groups of C2: no change)
+  const int lanes = p->knobs.fused_lanes > 0 ? p->knobs.fused_lanes : ((long long)n * B <= (1ll << 21) ? 3 : 2);
+  hipStream_t s = p->slots[1 + (int)(p->steps_groups++ % (unsigned long long)lanes)].side;
   if (!(flags & TSIM_PIPE_INPUTS_READY) && p->stream != s) {
     if (!p->sync_ev) HIP_TRY(hipEventCreateWithFlags(&p->sync_ev, hipEventDisableTiming));
     HIP_TRY(hipEventRecord(p->sync_ev, p->stream));

@@ -660,6 +660,21 @@ def main() -> None:
         est = (time.perf_counter() - t0) / 32
         spin_steps = int(min(20000, max(0, args.spinup_ms * 1e-3 / max(est, 1e-7))))
         hp.profile_enable(PROF_LEVEL)
+    # ... and, for the record, the SAME timed region without it first (three repetitions right after --warmup, profiling
+    # off): `spinup.without` in the JSON line - what a literal "W warm-up steps, then K timed steps" gives on this box
+    cold_elapsed = []
+    if spin_steps and not use_dist:
+        hp.profile_enable(0)
+        for _ in range(min(3, max(1, args.repeats))):
+            fence()
+            t0 = time.perf_counter()
+            steps(args.steps)
+            drain()
+            hp.synchronize()
+            lib.tsim_device_synchronize(local_rank)
+            device_sync()
+            cold_elapsed.append(time.perf_counter() - t0)
+        hp.profile_enable(PROF_LEVEL)
     for _ in range(max(1, args.repeats)):
         if spin_steps:
             hp.profile_enable(0)  # (no timing events in the untimed part)
@@ -793,6 +808,8 @@ def main() -> None:
             "data": "synthetic",
             "repeats": len(rep_elapsed),
             "spinup": {"ms": args.spinup_ms, "untimed_steps_before_each_repeat": spin_steps,
+                       "without": ({"ms_per_step": [e / args.steps * 1e3 for e in cold_elapsed],
+                                    "value_median": B * N * args.steps / statistics.median(cold_elapsed)} if cold_elapsed else None),
                        "note": "the same steps, untimed, right before every timed region: the chip reaches its sustained clocks only "
                                "after ~25 ms of work (profiles/r03/steps_dependence.txt); --spinup-ms 0 for none"},
             "repeat_ms_per_step": {"median": statistics.median(per_step), "min": min(per_step), "max": max(per_step), "all": per_step},

@@ -1,7 +1,7 @@
 """Host cost of tsim_sample_batch_device_begin in the steady state (C2, 1e6 shots per launch, inputs
 resident): per-call wall time, split into the launches that also flush a deferred hard-row batch and
 the others, and the resulting step rate without any Python work besides the call."""
-import sys, time; sys.path.insert(0, ".")
+import sys, time; sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import numpy as np
 from tsim_amd import backend as hip, synth, prng
 prog, cfg = synth.config_program("C2")

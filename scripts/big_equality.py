@@ -1,7 +1,7 @@
 """Full-size equality: the pipelined two-pass path vs the full kernel on every row, 5e7 shots each,
 same seeds, device noise, bit-packed outputs - the byte streams must be identical."""
 import hashlib, os, sys, time, warnings
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import numpy as np
 from tsim_amd import synth
 from tsim_amd.channels import error_probs

@@ -4,7 +4,7 @@ C2 program, noise model: 64 independent one-bit channels (p = 0.02) with identit
 i.e. the same per-bit fire rate as bench.py's synthetic f.  Not the `value` of bench.py.
 """
 import sys, time
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import warnings
 import numpy as np
 from tsim_amd import synth

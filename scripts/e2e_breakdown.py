@@ -1,6 +1,6 @@
 """Where the end-to-end device pipeline of CompiledDetectorSampler.sample(noise="device") spends its time."""
 import sys, time
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import warnings
 import numpy as np
 from tsim_amd import synth, prng

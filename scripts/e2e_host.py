@@ -1,6 +1,6 @@
 """End-to-end CompiledDetectorSampler.sample(noise="host"): the reference's numpy/PCG64 channel stream bit for bit."""
 import sys, time
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import warnings
 import numpy as np
 from tsim_amd import synth

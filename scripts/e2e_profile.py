@@ -1,6 +1,6 @@
 """cProfile of one steady-state CompiledDetectorSampler.sample() call per mode (where does the host time go?)."""
 import cProfile, pstats, sys, time, warnings
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import numpy as np
 from tsim_amd import synth
 from tsim_amd.channels import error_probs

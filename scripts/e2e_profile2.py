@@ -1,6 +1,6 @@
 """Host-side timeline of one CompiledDetectorSampler.sample(noise="device", bit_packed=True) call."""
 import sys, time, cProfile, pstats
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import warnings
 import numpy as np
 from tsim_amd import synth

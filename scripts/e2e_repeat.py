@@ -1,6 +1,6 @@
 """Repeat the bit-packed device pipeline call to separate steady state from first-call effects."""
 import sys, time, warnings
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import numpy as np
 from tsim_amd import synth
 from tsim_amd.channels import error_probs

@@ -1,6 +1,6 @@
 """Host-side cost of building a handle (pack + upload + pattern-table build) per shape."""
 import sys, time
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from tsim_amd import backend, synth
 for name in sys.argv[1:] or ["C2", "C3", "C4", "C5"]:
     prog, cfg = synth.config_program(name)

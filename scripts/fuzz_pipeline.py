@@ -2,7 +2,7 @@
 several launches in flight; every result is compared with the full kernel on a second handle.
 
 usage: fuzz_pipeline.py [iterations per config] [C2 C3 ... (default: C2 C4 C3 C5)] [log]   ("log" prints every launch)"""
-import sys; sys.path.insert(0, ".")
+import sys; sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import numpy as np, warnings
 warnings.simplefilter("ignore")
 from tsim_amd import backend as hip, synth, prng

@@ -1,6 +1,6 @@
 """Host-side cost of one pipelined step (tiny batch, so GPU work is negligible)."""
 import sys, time
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import numpy as np
 from tsim_amd import backend, prng, synth
 

@@ -1,6 +1,6 @@
 """Host-side cost of one pipelined launch: tiny batches (the GPU is never the bottleneck), many begin/end calls."""
 import sys, time
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import numpy as np
 from tsim_amd import backend, synth
 name = sys.argv[1] if len(sys.argv) > 1 else "C2"

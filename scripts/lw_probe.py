@@ -1,6 +1,6 @@
 """First-pass kernel timing probe: serial launches of one program at a chosen num_f (row width) and noise level."""
 import sys, time
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import numpy as np
 from tsim_amd import backend, synth
 name, num_f, p_bit = sys.argv[1], int(sys.argv[2]), float(sys.argv[3])

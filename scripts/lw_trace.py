@@ -1,7 +1,7 @@
 """Timeline of the register first pass: s_memtime stamps of wave 0 of the first 16 blocks (a library built with
 -DTSIMK_LW_TRACE: scripts/build_variant.sh WORK scripts/_ab_trace.so -DTSIMK_LW_TRACE; TSIM_AMD_LIB=scripts/_ab_trace.so)."""
 import ctypes as C, os, sys
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import numpy as np
 from tsim_amd import _lib, backend, synth
 prog, cfg = synth.config_program("C2")

@@ -1,6 +1,6 @@
 """Bandwidth of the data-format kernels (k_pack_bits / k_unpack_bits): HBM-bound rows of the path."""
 import sys, time
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import numpy as np
 from tsim_amd import backend, synth
 

@@ -787,6 +787,9 @@ def main() -> None:
             kernel_name = ("tsimk::k_sample_lw (pattern-table pass; hard rows: k_sample4h_multi batches / k_sample4h + "
                            "k_sample4, on the third lane)") if info.get("chunk_table_kernel") else \
                 "tsimk::k_sample_lw (pattern-table pass; hard rows: k_sample, overlapped on the other lanes)"
+        elif not program.components and not PER_STEP and num_f <= 128 and n_out <= 128:
+            kernel_name = ("tsimk::k_direct_multi (no components: the streaming kernel for direct outputs, up to 8 batches per launch; "
+                           "achieved = algorithmic bytes / step time - no HIP-event brackets on this path)")
         else:
             kernel_name = "tsimk::k_sample4 (LDS chunk tables)" if info.get("chunk_table_kernel") else "tsimk::k_sample"
         pmc = load_pmc(args.config, B)

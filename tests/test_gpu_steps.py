@@ -174,3 +174,28 @@ def test_steps_with_shot_offset_and_dense_rows(hip):
             want = op.sample_program(fs[i], subs[i], shot_offset=off)
             np.testing.assert_array_equal(outs[i], np.packbits(want, axis=1, bitorder="little"), err_msg=f"p_bit {p_bit} batch {i}")
     hp.close()
+
+
+@pytest.mark.parametrize("num_f,n_direct,B,n", [(24, 24, 5000, 11), (64, 40, 70001, 9), (128, 128, 3000, 3), (100, 1, 257, 17), (7, 7, 1, 2)])
+@pytest.mark.parametrize("packed", [True, False])
+def test_programs_without_components_stream_through_the_direct_kernel(hip, num_f, n_direct, B, n, packed):
+    """Clifford-only programs (every output direct: out = f[idx] ^ flip, sampler.py:140-145) through the several-batches
+    call: groups of up to eight batches as one streaming grid (tsim_direct.hip.h) - shuffled output order, flips, both
+    output layouts, row counts that are no multiple of the block; the key state advances as for any other program."""
+    if num_f == 24:
+        prog, cfg = synth.config_program("C1")
+    else:
+        prog = synth.synth_program(num_f=num_f, n_direct=n_direct, components=[], seed=11 * num_f + n_direct, shuffle_outputs=True,
+                                   direct_flip_fraction=0.4)
+    hp = hip.HipProgram(prog)
+    key = prng.key(3)
+    fs = [synth.synth_f(B, num_f, 0.3, seed=70 + i) for i in range(n)]
+    outs, key_after = _run_steps(hp, prog, fs, key, num_f, packed=packed)
+    end_key, subs = _subkeys(key, n)
+    assert key_after == (end_key[0] & 0xFFFFFFFF, end_key[1] & 0xFFFFFFFF)
+    op = OC.OracleProgram(prog)
+    for i in range(n):
+        want = op.sample_program(fs[i], subs[i])
+        np.testing.assert_array_equal(outs[i], np.packbits(want, axis=1, bitorder="little"), err_msg=f"batch {i}")
+    assert hp.info()["n_components"] == 0
+    hp.close()

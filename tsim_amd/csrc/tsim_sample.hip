@@ -9,6 +9,7 @@
 #include "tsim_lw_fast.hip.h"
 #include "tsim_kernel4w.hip.h"
 #include "tsim_kernel_hw.hip.h"
+#include "tsim_direct.hip.h"
 
 using namespace tsimk;
 using namespace tsimhost;
@@ -922,6 +923,66 @@ static int steps_group_fused(tsim_program *p, int n, const uint64_t *const *d_f,
   return tsim_flush_hard(p);
 }
 
+// Programs without components (Clifford-only circuits): up to TSIMK_DIRECT_MAX_STEPS batches as one streaming grid
+// (tsim_direct.hip.h), lanes alternating between groups.  The key is split once per batch all the same - the reference
+// does (sampler.py:399), and the caller's key state must not depend on what the program contains.
+static int steps_group_direct(tsim_program *p, int n, const uint64_t *const *d_f, int64_t B, int32_t num_f, uint32_t key[2],
+                              void *const *d_out, uint32_t flags) {
+  const bool packed = (flags & TSIM_PIPE_OUT_BIT_PACKED) != 0;
+  if (!p->deferred.empty())
+    if (int r = tsim_flush_hard(p)) return r;
+  hipStream_t s = p->slots[1 + (int)(p->steps_groups++ & 1ull)].side;
+  if (!(flags & TSIM_PIPE_INPUTS_READY) && p->stream != s) {
+    if (!p->sync_ev) HIP_TRY(hipEventCreateWithFlags(&p->sync_ev, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(p->sync_ev, p->stream));
+    HIP_TRY(hipStreamWaitEvent(s, p->sync_ev, 0));
+  }
+  const int WF = std::max(1, (num_f + 63) / 64);
+  const long long bps = (B + 256 * TSIMK_DIRECT_RPT - 1) / (256 * TSIMK_DIRECT_RPT);
+  if (bps * n > 0x7FFFFFFFll) return tsim_fail(TSIM_ENOTSUP, "batch too large");
+  DirectMultiArgs M{};
+  M.img = p->d_img;
+  M.B = B;
+  M.n_steps = n;
+  M.blocks_per_step = (int)bps;
+  M.prog = p->lw_direct_prog;
+  M.chunks = p->lw_direct_chunks;
+  M.WO = (p->num_outputs + 63) / 64;
+  M.out_rb = (p->num_outputs + 7) / 8;
+  int first = 0;
+  for (int j = 0; j < n; ++j) {
+    const int sidx = 1 + (int)(p->steps_slot++ % (unsigned long long)TSIM_PIPELINE_SLOTS);
+    if (j == 0) first = sidx;
+    tsim_program::Slot &sl = p->slots[sidx];
+    if (sl.deferred) return tsim_fail(TSIM_ESTATE, "pipeline slot %d still holds a parked launch", sidx - 1);
+    if (int r = slot_order_after_previous(p, sl, s)) return r;
+    uint32_t o[4];
+    tsim_key_split(key[0], key[1], o);
+    key[0] = o[0];
+    key[1] = o[1];
+    M.step[j].f = reinterpret_cast<const uint32_t *>(d_f[j]);
+    uint8_t *series = sl.compact_out;  // (tsim_pipeline_set_compact_output: the slot's next launch also writes bit_packed rows there)
+    M.step[j].out = packed ? nullptr : (uint64_t *)d_out[j];
+    M.step[j].out_compact = packed ? (uint8_t *)d_out[j] : series;
+    sl.compact_out = nullptr;
+  }
+  if (WF == 1) hipLaunchKernelGGL(k_direct_multi<2>, dim3((unsigned)(bps * n)), dim3(256), 0, s, M);
+  else hipLaunchKernelGGL(k_direct_multi<4>, dim3((unsigned)(bps * n)), dim3(256), 0, s, M);
+  HIP_TRY(hipGetLastError());
+  hipEvent_t ev = p->slots[first].ev2;
+  HIP_TRY(hipEventRecord(ev, s));
+  for (int j = 0; j < n; ++j) {
+    tsim_program::Slot &sl = p->slots[1 + (int)((p->steps_slot - (unsigned long long)n + (unsigned long long)j) % (unsigned long long)TSIM_PIPELINE_SLOTS)];
+    sl.pending = true;
+    sl.last_done = s;
+    sl.done_ev = ev;
+    sl.batch_seq = 0;
+  }
+  p->stat_begins += (unsigned long long)n;
+  ++p->stat_fused;
+  return 0;
+}
+
 extern "C" int tsim_sample_steps_device(tsim_program *p, int32_t n_steps, const uint64_t *const *d_f, int64_t B, int32_t num_f,
                                         uint32_t key[2], int64_t shot_offset, void *const *d_out, float *const *d_max_norm_dev,
                                         uint32_t flags) {
@@ -941,6 +1002,21 @@ extern "C" int tsim_sample_steps_device(tsim_program *p, int32_t n_steps, const 
     bool fused = p->lw && !p->lw_wide && p->lw_reg && p->knobs.lw_reg && p->knobs.fused_steps && (WF == 1 || WF == 2) && WO == 1 &&
                  p->total_keys > 0 && p->total_keys <= TSIMK_LWM_KEYS && p->num_outputs > 0 && B > 0 && B <= 0x7FFFFFFFll &&
                  p->knobs.defer_group >= 1;
+    // no components at all: the streaming kernel for direct outputs (rows of at most 128 f bits and 128 outputs)
+    if (p->comps.empty() && p->knobs.fused_steps && p->num_outputs > 0 && p->num_outputs <= 128 && WF <= 2 && p->lw_direct_chunks > 0 &&
+        p->knobs.direct_runs && B > 0 && B <= 0x7FFFFFFFll) {
+      if (!p->slots_ready) {
+        for (int k = 1; k <= TSIM_PIPELINE_SLOTS; ++k)
+          if (int r = slot_prepare(p, k, 0)) return r;
+        p->slots_ready = true;
+      }
+      const int left = n_steps - done;
+      const int groups = (left + TSIMK_DIRECT_MAX_STEPS - 1) / TSIMK_DIRECT_MAX_STEPS;
+      const int n = (left + groups - 1) / groups;
+      if (int r = steps_group_direct(p, n, d_f + done, B, num_f, key, d_out + done, flags)) return r;
+      done += n;
+      continue;
+    }
     LaunchPlan plan;
     if (fused) {
       if (!p->slots_ready) {  // as in _begin: every slot's stream / buffers now, not mid-run

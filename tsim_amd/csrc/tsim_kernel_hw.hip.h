@@ -28,7 +28,7 @@ namespace tsimk {
 #define TSIMK_HW_MAX_CTX 8
 struct HwMulti {
   int n_ctx, waves_per_list, max_lists;
-  int par_words;                      // LDS words per wave: one parity bit per row of the longest level stream, + spare
+  int par_words;                      // LDS words per bit array: one parity bit per row of the longest level stream, + spare (8 arrays per block)
   uint32_t *feedback;                 // launch-plan feedback of the first context (see sample4h_rows)
   SampleArgs ctx[TSIMK_HW_MAX_CTX];
 };
@@ -52,98 +52,95 @@ __device__ __forceinline__ uint32_t hw_bits(const uint32_t *par, uint32_t pos, u
   return n >= 32u ? v : (v & ((1u << n) - 1u));
 }
 
-// evaluate() of one level for ONE parameter row x (wave-uniform).
+// evaluate() of one level for ONE parameter row x (wave-uniform), in two phases that run on DIFFERENT waves:
 //   phase 1, lane = ROW: the level's uniform-stride row stream, 64 rows per step, fully coalesced, eight steps' loads
-//            in flight; the parities ((popcount(row & x) + const) & 1) of a step are one ballot, kept in the wave's LDS
-//            bit array `par`;
-//   phase 2, lane = GRAPH (g = lane, lane + 64, ...): the graph's counts and exponent bits are bit fields of that
-//            array (GraphBits), its value one table gather (graph_fast_value) - then the sum over the lanes.  The
-//            graph records (one 64-byte line per lane) are requested before phase 1 starts: their latency runs under it.
-// DUAL (the normalisation-check row, sampler.py:66-72): the same level for x AND for x with bit `flip` cleared (trial
-// bit 0) from ONE pass over the rows - a row's second parity is its first one XOR its own bit `flip` - into a second
-// bit array; phase 2 then forms both values (two independent gathers in flight).
+//            in flight; the parities ((popcount(row & x) + const) & 1) of a step are one ballot, kept in an LDS bit array;
+//   phase 2, lane = GRAPH (g = lane, lane + 64, ...), leading wave only: the graph's counts and exponent bits are bit
+//            fields of that array (GraphBits), its value one table gather (graph_fast_value) - then the sum over the lanes.
+// The levels of a component form a chain only through the SAMPLED BIT (sampler.py:74-79): level k + 1 needs b_k in its
+// x.  A row's parity for b_k = 0 is its parity for b_k = 1 XOR its own bit at that position, so phase 1 of level k + 1
+// does not wait for b_k: the helper waves run it WHILE the leading wave is in phase 2 of level k, for both values
+// (two ballots per step instead of one, into two bit arrays), and the leading wave picks the array once it has drawn the
+// bit.  The same trick gives the normalisation-check row (sampler.py:66-72) its trial-bit-0 evaluation: four arrays.
+// A level then costs the leading wave's phase 2 alone - the row pass, its global-load latency and its barrier are off
+// the chain.
 struct HwLevelOut {
   float re, im, re0, im0;
 };
 
+// variant v of a level's bit array: bit 0 of v = "previous sampled bit is 0", bit 1 = "trial bit is 0"
+template <int W>
+__device__ __forceinline__ void hw_phase1(const uint32_t *gimg, cptr lvl, const uint32_t (&x)[W], bool hasA, uint32_t flipA, bool hasB,
+                                          uint32_t flipB, uint32_t *par, uint32_t pw, uint32_t wv, uint32_t nwv) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t n_rows = lvl[L_HWN];
+  const uint32_t *rows = gimg + lvl[L_HWROWS];
+  const uint32_t steps = (n_rows + 63u) >> 6;
+  const uint32_t aw = flipA >> 5, as = flipA & 31u, bw = flipB >> 5, bs = flipB & 31u;
+#pragma unroll 8
+  for (uint32_t st = wv; st < steps; st += nwv) {
+    const uint32_t r = st * 64u + lane;
+    uint32_t pb = 0u, fa = 0u, fb = 0u;
+    if (r < n_rows) {
+      const uint32_t *q = rows + (size_t)r * (W + 1);
+      uint32_t rw[W + 1];
+#pragma unroll
+      for (int w = 0; w <= W; ++w) rw[w] = q[w];
+      uint32_t t = rw[W] & x[W - 1];
+#pragma unroll
+      for (int w = W - 2; w >= 0; --w) t = and_xor(rw[1 + w], x[w], t);
+      pb = ((uint32_t)__builtin_popcount(t) + rw[0]) & 1u;
+      uint32_t wa = rw[1], wb = rw[1];
+#pragma unroll
+      for (int w = 1; w < W; ++w) {
+        wa = (aw == (uint32_t)w) ? rw[1 + w] : wa;
+        wb = (bw == (uint32_t)w) ? rw[1 + w] : wb;
+      }
+      fa = (wa >> as) & 1u;
+      fb = (wb >> bs) & 1u;
+    }
+    const unsigned long long m0 = __builtin_amdgcn_ballot_w64(pb != 0u);
+    unsigned long long m1 = 0ull, m2 = 0ull, m3 = 0ull;
+    if (hasA) m1 = __builtin_amdgcn_ballot_w64((pb ^ fa) != 0u);
+    if (hasB) m2 = __builtin_amdgcn_ballot_w64((pb ^ fb) != 0u);
+    if (hasA && hasB) m3 = __builtin_amdgcn_ballot_w64((pb ^ fa ^ fb) != 0u);
+    if (lane == 0u) {
+      par[2u * st] = (uint32_t)m0;
+      par[2u * st + 1u] = (uint32_t)(m0 >> 32);
+      if (hasA) { par[pw + 2u * st] = (uint32_t)m1; par[pw + 2u * st + 1u] = (uint32_t)(m1 >> 32); }
+      if (hasB) { par[2u * pw + 2u * st] = (uint32_t)m2; par[2u * pw + 2u * st + 1u] = (uint32_t)(m2 >> 32); }
+      if (hasA && hasB) { par[3u * pw + 2u * st] = (uint32_t)m3; par[3u * pw + 2u * st + 1u] = (uint32_t)(m3 >> 32); }
+    }
+  }
+  if (lane == 0u && wv == (steps % nwv)) {  // the spare word hw_bits may touch (written once, by whichever wave)
+    par[2u * steps] = 0u;
+    par[pw + 2u * steps] = 0u;
+    par[2u * pw + 2u * steps] = 0u;
+    par[3u * pw + 2u * steps] = 0u;
+  }
+}
+
+// phase 2 on the calling wave: pa = the bit array for trial bit 1, pa0 (DUAL) = for trial bit 0
 template <int W, bool DUAL>
-__device__ __forceinline__ HwLevelOut hw_eval_level(const uint32_t *gimg, cptr img, cptr lvl, const uint32_t (&x)[W], uint32_t flip,
-                                                    uint32_t *par, uint32_t par_half) {
+__device__ __forceinline__ HwLevelOut hw_phase2(const uint32_t *gimg, cptr img, cptr lvl, const uint32_t *pa, const uint32_t *pa0) {
   const uint32_t G = lvl[L_G];
   const bool approx = (lvl[L_FLAGS] & TSIMK_LFLAG_APPROX) != 0;
   const bool fixed = (lvl[L_FLAGS] & TSIMK_LFLAG_FIXED) != 0;
   const uint32_t graphs = lvl[L_GRAPHS];
   const uint32_t lane = threadIdx.x & 63u;
-  uint32_t *par0 = par + par_half;
-  // the first round's graph record (16 words per lane): in flight during phase 1
   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
   u32x4 rec0 = {0u, 0u, 0u, 0u}, rec1 = rec0, rec2 = rec0, rec3 = rec0;
   auto load_rec = [&](uint32_t g) {
     const u32x4 *q4 = reinterpret_cast<const u32x4 *>(gimg + graphs + (size_t)g * G_WORDS);  // 64-byte aligned records
     rec0 = q4[0]; rec1 = q4[1]; rec2 = q4[2]; rec3 = q4[3];
   };
-  // phase 2 and everything behind it is the LEADING wave's alone (the others share the row pass and then wait for the
-  // sampled bit, hw_component): a row costs the instructions of one wave, not of four
-  const bool lead = threadIdx.x < 64u;
-  if (lead && lane < G) load_rec(lane);
-  // ---- phase 1
-  {
-    const uint32_t n_rows = lvl[L_HWN];
-    const uint32_t *rows = gimg + lvl[L_HWROWS];
-    const uint32_t steps = (n_rows + 63u) >> 6;
-    const uint32_t fw = flip >> 5, fs = flip & 31u;
-    // the block's waves share the steps (a lone wave pays 5-6 cycles per DEPENDENT instruction: the row pass is most
-    // of a level's instructions)
-    const uint32_t wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
-#pragma unroll 8
-    for (uint32_t st = wv; st < steps; st += nwv) {
-      const uint32_t r = st * 64u + lane;
-      uint32_t pb = 0u, pb0 = 0u;
-      if (r < n_rows) {
-        const uint32_t *q = rows + (size_t)r * (W + 1);
-        uint32_t rw[W + 1];
-#pragma unroll
-        for (int w = 0; w <= W; ++w) rw[w] = q[w];
-        uint32_t t = rw[W] & x[W - 1];
-#pragma unroll
-        for (int w = W - 2; w >= 0; --w) t = and_xor(rw[1 + w], x[w], t);
-        pb = ((uint32_t)__builtin_popcount(t) + rw[0]) & 1u;
-        if constexpr (DUAL) {
-          uint32_t word = rw[1];
-#pragma unroll
-          for (int w = 1; w < W; ++w) word = (fw == (uint32_t)w) ? rw[1 + w] : word;
-          pb0 = pb ^ ((word >> fs) & 1u);
-        }
-      }
-      const unsigned long long m = __builtin_amdgcn_ballot_w64(pb != 0u);
-      unsigned long long m0 = 0ull;
-      if constexpr (DUAL) m0 = __builtin_amdgcn_ballot_w64(pb0 != 0u);
-      if (lane == 0u) {
-        par[2u * st] = (uint32_t)m;
-        par[2u * st + 1u] = (uint32_t)(m >> 32);
-        if constexpr (DUAL) {
-          par0[2u * st] = (uint32_t)m0;
-          par0[2u * st + 1u] = (uint32_t)(m0 >> 32);
-        }
-      }
-    }
-    if (threadIdx.x == 0u) {  // the spare word hw_bits may touch
-      par[2u * steps] = 0u;
-      if constexpr (DUAL) par0[2u * steps] = 0u;
-    }
-    __syncthreads();
-  }
-  // ---- phase 2
   LevelSum S, S0;
-  HwLevelOut o;
-  o.re = o.im = o.re0 = o.im0 = 0.0f;
-  if (!lead) return o;  // (the caller's barrier keeps `par` until the leading wave has read it)
   for (uint32_t g0 = 0; g0 < G; g0 += 64u) {
     const uint32_t g = g0 + lane;
     const bool mine = g < G;
     int a = 0, b = 0, c = 0, d = 0, p = 0, a0 = 0, b0 = 0, c0 = 0, d0 = 0, p0 = 0;
     float tr = 0.0f, ti = 0.0f, tr0 = 0.0f, ti0 = 0.0f;
-    if (g0 > 0u && mine) load_rec(g);
+    if (mine) load_rec(g);
     if (mine) {
       const uint32_t n01 = rec0.x, n3h = rec0.y, flags = rec0.z, nD = rec0.w;
       const uint32_t start = rec2.x;  // GF_HWROW = 8
@@ -152,38 +149,38 @@ __device__ __forceinline__ HwLevelOut hw_eval_level(const uint32_t *gimg, cptr i
       GraphRec R;
       R.flags = flags; R.nD = nD; R.n1 = rec1.z; R.tbl = rec1.y; R.tbl2 = rec1.w;  // GF_N1 = 6, GF_TBL = 5, GF_TBL2 = 7
       const uint32_t apre = rec2.w, apim = rec3.x;                                  // GF_APRE = 11, GF_APIM = 12
-      auto bits_of = [&](const uint32_t *pa) {
+      auto bits_of = [&](const uint32_t *pq) {
         GraphBits q;
         uint32_t pos = start;
         const uint32_t n0 = n01 & 0xFFFFu, n1 = n01 >> 16, n3 = n3h & 0xFFFFu;  // at most 30 rows each (level_fast_eligible)
-        q.m0 = (uint32_t)__builtin_popcount(hw_bits(pa, pos, n0)); pos += n0;
-        q.m1 = (uint32_t)__builtin_popcount(hw_bits(pa, pos, n1)); pos += n1;
-        q.m3 = (uint32_t)__builtin_popcount(hw_bits(pa, pos, n3)); pos += n3;
+        q.m0 = (uint32_t)__builtin_popcount(hw_bits(pq, pos, n0)); pos += n0;
+        q.m1 = (uint32_t)__builtin_popcount(hw_bits(pq, pos, n1)); pos += n1;
+        q.m3 = (uint32_t)__builtin_popcount(hw_bits(pq, pos, n3)); pos += n3;
         q.dbits = 0u;
         for (uint32_t t0 = 0; t0 < nD; t0 += 16u) {  // (pa, pb) per term, first term most significant
           const uint32_t nt = min(16u, nD - t0);
-          const uint32_t bits = hw_bits(pa, pos, 2u * nt);
+          const uint32_t bits = hw_bits(pq, pos, 2u * nt);
           for (uint32_t t = 0; t < nt; ++t) q.dbits = (q.dbits << 2) | ((bits >> (2u * t)) & 3u);
           pos += 2u * nt;
         }
         q.lam = 0u;
         q.e = 0u;
-        if (flags & TSIMK_GFLAG_LAM) { q.lam = hw_bits(pa, pos, 1u); pos += 1u; }
-        if (flags & TSIMK_GFLAG_LIN) { q.e = hw_bits(pa, pos, 1u); pos += 1u; }
+        if (flags & TSIMK_GFLAG_LAM) { q.lam = hw_bits(pq, pos, 1u); pos += 1u; }
+        if (flags & TSIMK_GFLAG_LIN) { q.e = hw_bits(pq, pos, 1u); pos += 1u; }
         const uint32_t nH = n3h >> 16;
         for (uint32_t t0 = 0; t0 < nH; t0 += 16u) {  // XOR_s <u_s,x><v_s,x>: u at even, v at odd positions
           const uint32_t nt = min(16u, nH - t0);
-          const uint32_t bits = hw_bits(pa, pos, 2u * nt);
+          const uint32_t bits = hw_bits(pq, pos, 2u * nt);
           q.e ^= (uint32_t)__builtin_popcount(bits & (bits >> 1) & 0x55555555u);
           pos += 2u * nt;
         }
         return q;
       };
-      const GraphBits q1 = bits_of(par);
+      const GraphBits q1 = bits_of(pa);
       graph_fast_value(gimg, R, fixed, q1, a, b, c, d, p);
       if (approx) level_term_approx(apre, apim, a, b, c, d, p, tr, ti);
       if constexpr (DUAL) {
-        const GraphBits q0 = bits_of(par0);
+        const GraphBits q0 = bits_of(pa0);
         graph_fast_value(gimg, R, fixed, q0, a0, b0, c0, d0, p0);
         if (approx) level_term_approx(apre, apim, a0, b0, c0, d0, p0, tr0, ti0);
       }
@@ -216,86 +213,118 @@ __device__ __forceinline__ HwLevelOut hw_eval_level(const uint32_t *gimg, cptr i
     S.sa = hw_sum_i32(S.sa); S.sb = hw_sum_i32(S.sb); S.sc = hw_sum_i32(S.sc); S.sd = hw_sum_i32(S.sd);
     if constexpr (DUAL) { S0.sa = hw_sum_i32(S0.sa); S0.sb = hw_sum_i32(S0.sb); S0.sc = hw_sum_i32(S0.sc); S0.sd = hw_sum_i32(S0.sd); }
   }
+  HwLevelOut o;
+  o.re = o.im = o.re0 = o.im0 = 0.0f;
   level_finish(S, lvl, approx, fixed, o.re, o.im, nullptr);
   if constexpr (DUAL) level_finish(S0, lvl, approx, fixed, o.re0, o.im0, nullptr);
   return o;
 }
 
-// one component of one row: _sample_component (sampler.py:28-81), W = the component's own parameter-row width
+// one component of one row: _sample_component (sampler.py:28-81), W = the component's own parameter-row width.
+// LDS: two buffers (levels alternate) of four bit arrays of `pw` words each, then the word that carries the sampled bit.
 template <int W, class FBit>
 __device__ __forceinline__ void hw_component(const SampleArgs &A, cptr img, cptr comp, int ci, FBit fbit, unsigned long long shot, bool check,
-                                             uint32_t *par, uint32_t par_half, uint32_t (&out_w)[4]) {
+                                             uint32_t *par, uint32_t pw, uint32_t (&out_w)[4]) {
   const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t n_out = comp[C_NOUT], F = comp[C_F];
-    cptr fsel = img + comp[C_FSEL];
-    cptr levels = img + comp[C_LEVELS];
-    cptr outpos = img + comp[C_OUTPOS];
-    const uint32_t keybase = comp[C_KEYBASE];
-    // K1: the component's f bits (sampler.py:48): lane j fetches bit j, the ballot is the packed word pair
-    uint32_t x[W];
+  const uint32_t wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
+  const bool lead = wv == 0u;
+  const uint32_t n_out = comp[C_NOUT], F = comp[C_F];
+  cptr fsel = img + comp[C_FSEL];
+  cptr levels = img + comp[C_LEVELS];
+  cptr outpos = img + comp[C_OUTPOS];
+  const uint32_t keybase = comp[C_KEYBASE];
+  uint32_t *bit_word = par + 8u * pw;  // the sampled bit, leading wave -> the others
+  // K1: the component's f bits (sampler.py:48): lane j fetches bit j, the ballot is the packed word pair
+  uint32_t x[W];
 #pragma unroll
-    for (int w2 = 0; w2 < W; w2 += 2) {
-      const uint32_t j = 32u * (uint32_t)w2 + lane;
-      const uint32_t raw = fbit(fsel[j < F ? j : 0u]);
-      const unsigned long long m = __builtin_amdgcn_ballot_w64(j < F && raw != 0u);
-      x[w2] = (uint32_t)m;
-      if (w2 + 1 < W) x[w2 + 1] = (uint32_t)(m >> 32);
-    }
-    // the component's draws (sampler.py:74-75), all at once: lane i computes output i's uniform (a lone wave pays for a
-    // Threefry block per level otherwise - 75 dependent instructions each)
-    uint32_t u_bits = 0u;
-    if (threadIdx.x < 64u && n_out > 0u) {  // (a component without outputs has no subkeys at all)
-      const uint32_t o = keybase + (lane < n_out ? lane : 0u);
-      uint32_t x0 = (uint32_t)(shot >> 32), x1 = (uint32_t)shot;
-      threefry2x32(subkey(A, o, 0), subkey(A, o, 1), x0, x1);
-      u_bits = __float_as_uint(__uint_as_float(((x0 ^ x1) >> 9) | 0x3F800000u) - 1.0f);
-    }
-    const bool lead = threadIdx.x < 64u;
-    uint32_t *bit_word = par + 2u * par_half;  // the sampled bit, leading wave -> the others
-    const HwLevelOut n0 = hw_eval_level<W, false>(A.img, img, levels, x, 0u, par, par_half);  // normalisation (sampler.py:54)
-    __syncthreads();  // the next level's phase 1 overwrites `par` only after the leading wave has read it
-    float prev = cabs32(n0.re, n0.im);
-    float maxdev = 0.0f;
-    for (uint32_t i = 0; i < n_out; ++i) {
-      cptr lvl = levels + (i + 1) * L_WORDS;
-      const uint32_t bitpos = F + i;
-      const uint32_t wi = bitpos >> 5, bm = 1u << (bitpos & 31u);
+  for (int w2 = 0; w2 < W; w2 += 2) {
+    const uint32_t j = 32u * (uint32_t)w2 + lane;
+    const uint32_t raw = fbit(fsel[j < F ? j : 0u]);
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(j < F && raw != 0u);
+    x[w2] = (uint32_t)m;
+    if (w2 + 1 < W) x[w2 + 1] = (uint32_t)(m >> 32);
+  }
+  // the component's draws (sampler.py:74-75), all at once: lane i computes output i's uniform
+  uint32_t u_bits = 0u;
+  if (lead && n_out > 0u) {  // (a component without outputs has no subkeys at all)
+    const uint32_t o = keybase + (lane < n_out ? lane : 0u);
+    uint32_t x0 = (uint32_t)(shot >> 32), x1 = (uint32_t)shot;
+    threefry2x32(subkey(A, o, 0), subkey(A, o, 1), x0, x1);
+    u_bits = __float_as_uint(__uint_as_float(((x0 ^ x1) >> 9) | 0x3F800000u) - 1.0f);
+  }
+  auto set_bit = [&](uint32_t pos, bool on) {
+    const uint32_t wi = pos >> 5, bm = 1u << (pos & 31u);
 #pragma unroll
-      for (int w = 0; w < W; ++w)
-        if ((uint32_t)w == wi) x[w] |= bm;  // trial bit = 1 (sampler.py:65)
+    for (int w = 0; w < W; ++w)
+      if ((uint32_t)w == wi) x[w] = on ? (x[w] | bm) : (x[w] & ~bm);
+  };
+  // ---- level 0 (normalisation, sampler.py:54): its row pass by every wave
+  hw_phase1<W>(A.img, levels, x, false, 0u, false, 0u, par, pw, wv, nwv);
+  __syncthreads();
+  // ---- level 0's phase 2 (leading wave) beside level 1's row pass (the others): x = f | trial bit 1
+  float prev = 0.0f, maxdev = 0.0f;
+  if (n_out > 0u) set_bit(F, true);
+  if (lead) {
+    const HwLevelOut n0 = hw_phase2<W, false>(A.img, img, levels, par, par);
+    prev = cabs32(n0.re, n0.im);
+  } else if (n_out > 0u) {
+    hw_phase1<W>(A.img, levels + L_WORDS, x, false, 0u, check, F, par + 4u * pw, pw, wv - 1u, nwv - 1u);
+  }
+  __syncthreads();
+  uint32_t prev_bit = 1u;  // (level 1 has no previous bit: its arrays are the "bit = 1" ones)
+  for (uint32_t i = 0; i < n_out; ++i) {
+    // x holds f | b_0 .. b_(i-1) | trial bit i = 1; level i + 1's arrays are in buffer (i + 1) & 1, variant by b_(i-1)
+    cptr lvl = levels + (i + 1) * L_WORDS;
+    const uint32_t bitpos = F + i;
+    uint32_t *buf = par + (((i + 1u) & 1u) ? 4u * pw : 0u);
+    if (lead) {
+      const uint32_t *pa = buf + (prev_bit ? 0u : pw);
       float p1;
-      if (check) {  // the check row also evaluates trial bit = 0 (sampler.py:66-72), from the same pass over the rows
-        const HwLevelOut o = hw_eval_level<W, true>(A.img, img, lvl, x, bitpos, par, par_half);
+      if (check) {  // the check row also evaluates trial bit = 0 (sampler.py:66-72), from the same row pass
+        const HwLevelOut o = hw_phase2<W, true>(A.img, img, lvl, pa, pa + 2u * pw);
         p1 = cabs32(o.re, o.im);
         const float p0 = cabs32(o.re0, o.im0);
         const float norm = __fdiv_rn(__fadd_rn(p0, p1), prev);
         maxdev = nanmax(maxdev, fabsf(__fsub_rn(norm, 1.0f)));
       } else {
-        const HwLevelOut o = hw_eval_level<W, false>(A.img, img, lvl, x, 0u, par, par_half);
+        const HwLevelOut o = hw_phase2<W, false>(A.img, img, lvl, pa, pa);
         p1 = cabs32(o.re, o.im);
       }
       // sampler.py:74-79
       const float u = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)u_bits, (int)i));
-      if (lead && lane == 0u) *bit_word = (u < __fdiv_rn(p1, prev)) ? 1u : 0u;
-      __syncthreads();  // ... which also keeps `par` until the leading wave is done with it
-      const bool bit = *bit_word != 0u;  // (rewritten only behind the next level's phase-1 barrier)
+      const bool bit = u < __fdiv_rn(p1, prev);
+      prev = bit ? p1 : __fsub_rn(prev, p1);
+      if (lane == 0u) *bit_word = bit ? 1u : 0u;
+    } else if (i + 1u < n_out) {
+      // the next level's row pass, for both values of the bit being drawn: x = f | b_0..b_(i-1) | b_i = 1 | trial bit i + 1
+      uint32_t xn[W];
+#pragma unroll
+      for (int w = 0; w < W; ++w) xn[w] = x[w];
+      const uint32_t np = bitpos + 1u, wi = np >> 5, bm = 1u << (np & 31u);
 #pragma unroll
       for (int w = 0; w < W; ++w)
-        if ((uint32_t)w == wi) x[w] = bit ? (x[w] | bm) : (x[w] & ~bm);
-      prev = bit ? p1 : __fsub_rn(prev, p1);
-      const uint32_t dst = outpos[i];  // K15: the final column (sampler.py:164-166)
-      if (lane == 0u) {
-#pragma unroll
-        for (int w = 0; w < 4; ++w)
-          if ((dst >> 5) == (uint32_t)w) out_w[w] |= (bit ? 1u : 0u) << (dst & 31u);
-      }
+        if ((uint32_t)w == wi) xn[w] |= bm;
+      hw_phase1<W>(A.img, lvl + L_WORDS, xn, true, bitpos, check, np, par + (((i + 2u) & 1u) ? 4u * pw : 0u), pw, wv - 1u, nwv - 1u);
     }
-    if (check && A.norm_dev && threadIdx.x == 0u) A.norm_dev[ci] = maxdev;
+    __syncthreads();  // the bit is drawn, the next level's arrays are complete (and this level's are free again)
+    const bool bit = *bit_word != 0u;  // (rewritten only behind the next barrier)
+    prev_bit = bit ? 1u : 0u;
+    set_bit(bitpos, bit);
+    if (i + 1u < n_out) set_bit(bitpos + 1u, true);  // trial bit of the next level
+    const uint32_t dst = outpos[i];  // K15: the final column (sampler.py:164-166)
+    if (lane == 0u) {
+#pragma unroll
+      for (int w = 0; w < 4; ++w)
+        if ((dst >> 5) == (uint32_t)w) out_w[w] |= (bit ? 1u : 0u) << (dst & 31u);
+    }
+  }
+  if (check && A.norm_dev && threadIdx.x == 0u) A.norm_dev[ci] = maxdev;
+  __syncthreads();  // the next component's level 0 overwrites buffer 0
 }
 
 // sample_program (sampler.py:117-167) for one row on one wave
 template <int WMAX>
-__device__ __forceinline__ void hw_row(const SampleArgs &A, long long row, bool check, uint32_t *par, uint32_t par_half) {
+__device__ __forceinline__ void hw_row(const SampleArgs &A, long long row, bool check, uint32_t *par, uint32_t pw) {
   cptr img = (cptr)(uintptr_t)A.img;
   const uint32_t lane = threadIdx.x & 63u;
   const unsigned long long shot = (unsigned long long)(A.shot_offset + row);
@@ -326,8 +355,8 @@ __device__ __forceinline__ void hw_row(const SampleArgs &A, long long row, bool 
   for (int ci = 0; ci < A.n_comp; ++ci) {
     cptr comp = img + A.comp_off + ci * C_WORDS;
     switch (comp[C_W]) {  // rows are packed with the component's own word count
-      case 1: hw_component<1>(A, img, comp, ci, fbit, shot, check, par, par_half, out_w); break;
-      case 2: if constexpr (WMAX >= 2) hw_component<2>(A, img, comp, ci, fbit, shot, check, par, par_half, out_w); break;
+      case 1: hw_component<1>(A, img, comp, ci, fbit, shot, check, par, pw, out_w); break;
+      case 2: if constexpr (WMAX >= 2) hw_component<2>(A, img, comp, ci, fbit, shot, check, par, pw, out_w); break;
       default: __builtin_trap();  // the host launches this kernel for narrow programs only
     }
   }

@@ -206,7 +206,7 @@ static int launch_hw(tsim_program *p, const SampleArgs *ctx, int n_ctx, int max_
   }
   const unsigned gridw = (unsigned)((long long)H.n_ctx * H.max_lists * H.waves_per_list);
   H.par_words = (int)(2 * ((p->hw_max_rows + 63) / 64) + 2);
-  const size_t ldsw = (size_t)H.par_words * 2 * 4 + 16;  // + the sampled bit's word; two bit arrays per block (the check row evaluates trial bits 1 and 0 together)
+  const size_t ldsw = (size_t)H.par_words * 8 * 4 + 16;  // two buffers of four bit arrays (previous bit x trial bit) + the sampled bit.s word
   if (wmax == 1) hipLaunchKernelGGL(k_sample_hw<1>, dim3(gridw), dim3(256), ldsw, hs, H);
   else hipLaunchKernelGGL(k_sample_hw<2>, dim3(gridw), dim3(256), ldsw, hs, H);
   HIP_TRY(hipGetLastError());

@@ -831,6 +831,14 @@ def main() -> None:
                 "steps_per_library_call": "all --steps in one tsim_sample_steps_device call (first passes fused in groups of <= 8 batches)"
                 if not PER_STEP else "one tsim_sample_batch_device_begin_split per step",
                 "f_resident_in_hbm": True,
+                **({"collection_bound": (
+                    f"every rank writes {RB} B per shot; with the gather to rank 0 (the north star's collective, the default) rank 0 takes in "
+                    f"the rows of {N - 1} peers over {N - 1} point-to-point xGMI links (~64 GB/s each way): at most ~{(N - 1) * 64e9 / RB:.2e} "
+                    f"shots/s from the peers together, whatever the kernels do - one rank alone produces {RB * value / N / 1e9:.0f} GB/s of rows "
+                    "here.  TSIM_BENCH_GATHER=alltoall spreads the roots (batch group j of every rank lands on rank j): 1/N of a rank's "
+                    "rows per link."
+                    if GATHER_MODE != "alltoall" else
+                    f"roots spread over the ranks: 1/{N} of a rank's rows ({RB * value / N / N / 1e9:.1f} GB/s) per xGMI link")} if use_dist and N > 1 else {}),
                 "output_layout": f"bit_packed rows, {RB} B/shot (sampler.py:665-669), written by the sampling kernels",
             },
             "roofline": {

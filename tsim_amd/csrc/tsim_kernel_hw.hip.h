@@ -120,18 +120,34 @@ __device__ __forceinline__ void hw_phase1(const uint32_t *gimg, cptr lvl, const 
   }
 }
 
-// phase 2 on the calling wave: pa = the bit array for trial bit 1, pa0 (DUAL) = for trial bit 0
+// a lane's graph record (16 words).  Records do not depend on sampled bits: the leading wave asks for the NEXT level's
+// while it works on the current one (one global-load latency less on every level's chain).
+typedef uint32_t hw_u32x4 __attribute__((ext_vector_type(4)));
+struct HwRec {
+  hw_u32x4 r0, r1, r2, r3;
+};
+__device__ __forceinline__ HwRec hw_load_rec(const uint32_t *gimg, cptr lvl, uint32_t g) {
+  HwRec R;
+  R.r0 = R.r1 = R.r2 = R.r3 = hw_u32x4{0u, 0u, 0u, 0u};
+  if (g < lvl[L_G]) {
+    const hw_u32x4 *q4 = reinterpret_cast<const hw_u32x4 *>(gimg + lvl[L_GRAPHS] + (size_t)g * G_WORDS);  // 64-byte aligned records
+    R.r0 = q4[0]; R.r1 = q4[1]; R.r2 = q4[2]; R.r3 = q4[3];
+  }
+  return R;
+}
+
+// phase 2 on the calling wave: pa = the bit array for trial bit 1, pa0 (DUAL) = for trial bit 0; `first` = the records of
+// graphs 0..63 (hw_load_rec(…, lane), requested earlier)
 template <int W, bool DUAL>
-__device__ __forceinline__ HwLevelOut hw_phase2(const uint32_t *gimg, cptr img, cptr lvl, const uint32_t *pa, const uint32_t *pa0) {
+__device__ __forceinline__ HwLevelOut hw_phase2(const uint32_t *gimg, cptr img, cptr lvl, const uint32_t *pa, const uint32_t *pa0, const HwRec &first) {
   const uint32_t G = lvl[L_G];
   const bool approx = (lvl[L_FLAGS] & TSIMK_LFLAG_APPROX) != 0;
   const bool fixed = (lvl[L_FLAGS] & TSIMK_LFLAG_FIXED) != 0;
   const uint32_t graphs = lvl[L_GRAPHS];
   const uint32_t lane = threadIdx.x & 63u;
-  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-  u32x4 rec0 = {0u, 0u, 0u, 0u}, rec1 = rec0, rec2 = rec0, rec3 = rec0;
+  hw_u32x4 rec0 = first.r0, rec1 = first.r1, rec2 = first.r2, rec3 = first.r3;
   auto load_rec = [&](uint32_t g) {
-    const u32x4 *q4 = reinterpret_cast<const u32x4 *>(gimg + graphs + (size_t)g * G_WORDS);  // 64-byte aligned records
+    const hw_u32x4 *q4 = reinterpret_cast<const hw_u32x4 *>(gimg + graphs + (size_t)g * G_WORDS);
     rec0 = q4[0]; rec1 = q4[1]; rec2 = q4[2]; rec3 = q4[3];
   };
   LevelSum S, S0;
@@ -140,7 +156,7 @@ __device__ __forceinline__ HwLevelOut hw_phase2(const uint32_t *gimg, cptr img, 
     const bool mine = g < G;
     int a = 0, b = 0, c = 0, d = 0, p = 0, a0 = 0, b0 = 0, c0 = 0, d0 = 0, p0 = 0;
     float tr = 0.0f, ti = 0.0f, tr0 = 0.0f, ti0 = 0.0f;
-    if (mine) load_rec(g);
+    if (mine && g0 > 0u) load_rec(g);
     if (mine) {
       const uint32_t n01 = rec0.x, n3h = rec0.y, flags = rec0.z, nD = rec0.w;
       const uint32_t start = rec2.x;  // GF_HWROW = 8
@@ -258,15 +274,18 @@ __device__ __forceinline__ void hw_component(const SampleArgs &A, cptr img, cptr
     for (int w = 0; w < W; ++w)
       if ((uint32_t)w == wi) x[w] = on ? (x[w] | bm) : (x[w] & ~bm);
   };
-  // ---- level 0 (normalisation, sampler.py:54): its row pass by every wave
+  // ---- level 0 (normalisation, sampler.py:54): its row pass by every wave (the leading wave's records are on their way)
+  HwRec cur = lead ? hw_load_rec(A.img, levels, lane) : HwRec{};
   hw_phase1<W>(A.img, levels, x, false, 0u, false, 0u, par, pw, wv, nwv);
   __syncthreads();
   // ---- level 0's phase 2 (leading wave) beside level 1's row pass (the others): x = f | trial bit 1
   float prev = 0.0f, maxdev = 0.0f;
   if (n_out > 0u) set_bit(F, true);
   if (lead) {
-    const HwLevelOut n0 = hw_phase2<W, false>(A.img, img, levels, par, par);
+    const HwRec nxt = n_out > 0u ? hw_load_rec(A.img, levels + L_WORDS, lane) : HwRec{};
+    const HwLevelOut n0 = hw_phase2<W, false>(A.img, img, levels, par, par, cur);
     prev = cabs32(n0.re, n0.im);
+    cur = nxt;
   } else if (n_out > 0u) {
     hw_phase1<W>(A.img, levels + L_WORDS, x, false, 0u, check, F, par + 4u * pw, pw, wv - 1u, nwv - 1u);
   }
@@ -279,15 +298,16 @@ __device__ __forceinline__ void hw_component(const SampleArgs &A, cptr img, cptr
     uint32_t *buf = par + (((i + 1u) & 1u) ? 4u * pw : 0u);
     if (lead) {
       const uint32_t *pa = buf + (prev_bit ? 0u : pw);
+      const HwRec nxt = i + 1u < n_out ? hw_load_rec(A.img, lvl + L_WORDS, lane) : HwRec{};
       float p1;
       if (check) {  // the check row also evaluates trial bit = 0 (sampler.py:66-72), from the same row pass
-        const HwLevelOut o = hw_phase2<W, true>(A.img, img, lvl, pa, pa + 2u * pw);
+        const HwLevelOut o = hw_phase2<W, true>(A.img, img, lvl, pa, pa + 2u * pw, cur);
         p1 = cabs32(o.re, o.im);
         const float p0 = cabs32(o.re0, o.im0);
         const float norm = __fdiv_rn(__fadd_rn(p0, p1), prev);
         maxdev = nanmax(maxdev, fabsf(__fsub_rn(norm, 1.0f)));
       } else {
-        const HwLevelOut o = hw_phase2<W, false>(A.img, img, lvl, pa, pa);
+        const HwLevelOut o = hw_phase2<W, false>(A.img, img, lvl, pa, pa, cur);
         p1 = cabs32(o.re, o.im);
       }
       // sampler.py:74-79
@@ -295,6 +315,7 @@ __device__ __forceinline__ void hw_component(const SampleArgs &A, cptr img, cptr
       const bool bit = u < __fdiv_rn(p1, prev);
       prev = bit ? p1 : __fsub_rn(prev, p1);
       if (lane == 0u) *bit_word = bit ? 1u : 0u;
+      cur = nxt;
     } else if (i + 1u < n_out) {
       // the next level's row pass, for both values of the bit being drawn: x = f | b_0..b_(i-1) | b_i = 1 | trial bit i + 1
       uint32_t xn[W];

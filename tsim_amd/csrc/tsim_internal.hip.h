@@ -177,6 +177,7 @@ struct tsim_program {
   Slot slots[1 + TSIM_PIPELINE_SLOTS];
   bool slots_ready = false;
   std::vector<int> deferred;  // slots whose hard rows are waiting, in launch order
+  std::vector<int> lag[4];    // per first-pass lane: the fused group whose hard rows wait for the lane's next first pass (tsim_flush_hard)
   hipEvent_t lane_ev[2] = {nullptr, nullptr};  // "first passes enqueued so far on lane k are done"
   hipEvent_t batch_ev[16] = {};
   int batch_ev_lane[16] = {};                  // ... and the stream (batch_lane) it was recorded on
@@ -225,6 +226,10 @@ struct tsim_program {
     int defer_group = 4;      // TSIM_AMD_DEFER_GROUP: launches per deferred hard-row batch (<= TSIMK_H_MAX_CTX)
     bool fused_steps = true;  // TSIM_AMD_FUSED_STEPS=0: tsim_sample_steps_device launches batch by batch
     int fused_lanes = 0;  // TSIM_AMD_FUSED_LANES: first-pass lanes the fused groups rotate over (1-4; 0 = 2, 3 for small groups)
+    // TSIM_AMD_HARD_LAG=1: a fused group's hard rows run behind the lane's NEXT first pass instead of directly behind its own
+    // (tried for short regions - the lane is not held up by a latency-bound grid between two first passes; measured
+    // slower everywhere: --steps 20 6.84 -> 6.44e10, C4 at 1e5 shots per step 1.7e10 -> 7.9e9; off)
+    bool hard_lag = false;
     long long hard_inline_rows = 1ll << 40;  // TSIM_AMD_HARD_INLINE_ROWS: fused groups of at most this many shots run their hard rows on their own lane
     int hard_wave_rows = 1024;  // TSIM_AMD_HARD_WAVE_ROWS: ... while a batch of launches has at most this many hard rows (last feedback)
     bool hard_wave = true;    // TSIM_AMD_HARD_WAVE=0: hard-row batches on k_sample4h_multi (64 rows per block) instead of one wave per row

@@ -215,7 +215,7 @@ static int launch_hw(tsim_program *p, const SampleArgs *ctx, int n_ctx, int max_
 
 // The deferred second pass: ONE k_sample4h_multi grid serves the hard rows of every launch whose
 // first pass is enqueued, on the third lane's stream, after those first passes.
-int tsim_flush_hard(tsim_program *p) {
+static int flush_batch(tsim_program *p) {
   if (p->deferred.empty()) {
     p->flush_inline = nullptr;
     return 0;
@@ -308,6 +308,27 @@ int tsim_flush_hard(tsim_program *p) {
   }
   p->deferred.clear();
   return 0;
+}
+
+// Everything that is waiting: the lagged groups of the several-batches call (steps_group_fused: a fused group's hard rows
+// wait for the lane's NEXT first pass, so that the lane is not held up by a latency-bound grid between two first passes),
+// each as a batch on its own lane, then the launches parked by the per-step API.
+int tsim_flush_hard(tsim_program *p) {
+  bool any = false;
+  for (auto &l : p->lag) any = any || !l.empty();
+  if (any) {
+    std::vector<int> keep;
+    keep.swap(p->deferred);
+    for (int li = 0; li < 4; ++li) {
+      if (p->lag[li].empty()) continue;
+      p->deferred.swap(p->lag[li]);
+      p->lag[li].clear();
+      p->flush_inline = p->slots[1 + li].side;
+      if (int r = flush_batch(p)) return r;
+    }
+    p->deferred.swap(keep);
+  }
+  return flush_batch(p);
 }
 
 // The arguments every sampling kernel of one launch shares (SampleArgs): per-output subkeys - key, subkey =
@@ -799,7 +820,7 @@ static int steps_group_fused(tsim_program *p, int n, const uint64_t *const *d_f,
                              int64_t shot_offset, void *const *d_out, float *const *d_dev, uint32_t flags, const LaunchPlan &plan) {
   const bool packed = (flags & TSIM_PIPE_OUT_BIT_PACKED) != 0;
   if (!p->deferred.empty())
-    if (int r = tsim_flush_hard(p)) return r;  // rows parked by batch-by-batch launches: their own batch first
+    if (int r = flush_batch(p)) return r;  // rows parked by batch-by-batch launches: their own batch first
   // two first-pass lanes; three for small groups, whose hard-row grids (latency-bound, on the group's lane) take longer
   // than their first passes (C4 at 8 x 10^5 shots per group: 1.16 -> 1.53e10 shots/s; the large groups of C2: no change)
   const int lanes = p->knobs.fused_lanes > 0 ? p->knobs.fused_lanes : ((long long)n * B <= (1ll << 21) ? 3 : 2);
@@ -838,6 +859,11 @@ static int steps_group_fused(tsim_program *p, int n, const uint64_t *const *d_f,
   M.out_rb = (p->num_outputs + 7) / 8;
   p->last_lists = n_lists;
   int slots[TSIMK_LWM_MAX_STEPS];
+  for (int j = 0; j < n; ++j)  // a slot this group takes still waits for its hard rows (many lanes, few slots): those first
+    if (p->slots[1 + (int)((p->steps_slot + (unsigned long long)j) % (unsigned long long)TSIM_PIPELINE_SLOTS)].deferred) {
+      if (int r = tsim_flush_hard(p)) return r;
+      break;
+    }
   for (int j = 0; j < n; ++j) {
     const int sidx = 1 + (int)(p->steps_slot++ % (unsigned long long)TSIM_PIPELINE_SLOTS);
     slots[j] = sidx;
@@ -919,8 +945,27 @@ static int steps_group_fused(tsim_program *p, int n, const uint64_t *const *d_f,
   p->stat_begins += (unsigned long long)n;
   p->stat_deferred += (unsigned long long)n;
   ++p->stat_fused;
-  if ((long long)n * B <= p->knobs.hard_inline_rows) p->flush_inline = s;
-  return tsim_flush_hard(p);
+  if ((long long)n * B <= p->knobs.hard_inline_rows) {
+    if (p->knobs.hard_lag) {
+      // this group's hard rows wait; the group that was waiting on this lane goes now - behind the first pass just launched
+      int li = 0;
+      for (int k = 0; k < 4; ++k)
+        if (s == p->slots[1 + k].side) li = k;
+      std::vector<int> mine;
+      mine.swap(p->deferred);  // (exactly this group's slots: earlier parked launches were flushed on entry)
+      int r = 0;
+      if (!p->lag[li].empty()) {
+        p->deferred.swap(p->lag[li]);
+        p->lag[li].clear();
+        p->flush_inline = s;
+        r = flush_batch(p);
+      }
+      p->lag[li].swap(mine);
+      return r;
+    }
+    p->flush_inline = s;
+  }
+  return flush_batch(p);
 }
 
 // Programs without components (Clifford-only circuits): up to TSIMK_DIRECT_MAX_STEPS batches as one streaming grid
@@ -1071,7 +1116,8 @@ extern "C" int tsim_sample_steps_device(tsim_program *p, int32_t n_steps, const 
       ++done;
     }
   }
-  return TSIM_OK;
+  // the groups whose hard rows were waiting for their lane's next first pass: there is none in this call
+  return tsim_flush_hard(p);
 }
 
 extern "C" int tsim_pipeline_lane_stream(tsim_program *p, int32_t lane, void **stream) {

@@ -729,7 +729,7 @@ def main() -> None:
     detail = serial_ms = None
     d_out0 = d_outs[0]
     hp.profile_set_sampling(1)
-    if info.get("pattern_tables"):
+    if info.get("pattern_tables") and os.environ.get("TSIM_BENCH_NO_CONTEXT") != "1":  # (counter runs: timed launches only)
         # every kernel of 8 launches bracketed: per-kernel split and first-kernel-start -> last-kernel-end latency
         hp.profile_enable(1)
         for _ in range(8):

@@ -48,7 +48,7 @@ if want rocprof; then
   i=0
   for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM" "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY GRBM_GUI_ACTIVE" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_WAIT_INST_ANY"; do
     i=$((i+1))
-    TSIM_AMD_FUSED_MAX=4 timeout 120 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/pmc_$i -- python $R/bench.py --steps 16 --warmup 4 --spinup-ms 0 --no-cpu-baseline --no-extra-legs --repeats 1 > $O/pmc_$i.log 2>&1
+    TSIM_BENCH_NO_CONTEXT=1 TSIM_AMD_FUSED_MAX=4 timeout 120 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/pmc_$i -- python $R/bench.py --steps 16 --warmup 4 --spinup-ms 0 --no-cpu-baseline --no-extra-legs --repeats 1 > $O/pmc_$i.log 2>&1
   done
   cd $R
   TSIM_PMC_BATCHES_PER_LAUNCH=4 python scripts/summarize_pmc.py $O/pmc.json C2 1000000 $O/pmc_1 $O/pmc_2 $O/pmc_3 $O/pmc_4 $O/pmc_5 > /dev/null

@@ -36,9 +36,22 @@ def main():
         import os
         files = sorted(glob.glob(f"{d}/*/*_counter_collection.csv"), key=os.path.getmtime)
         for fn in files[-1:]:  # a re-used output directory keeps older runs: only the newest counts
-            for r in csv.DictReader(open(fn)):
-                if "k_sample" in r["Kernel_Name"]:
-                    agg[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            rows = [r for r in csv.DictReader(open(fn)) if "k_sample" in r["Kernel_Name"]]
+            # fused first passes come in several grid sizes (the timed groups of TSIM_PMC_BATCHES_PER_LAUNCH batches; groups
+            # of one batch from bench.py's serial / per-step context legs, which use the same kernel since round 3): only the
+            # largest grid of a fused kernel is a timed launch
+            biggest = {}
+            for r in rows:
+                k = short(r["Kernel_Name"])
+                biggest[k] = max(biggest.get(k, 0), int(r.get("Grid_Size", 0) or 0))
+            for r in rows:
+                k = short(r["Kernel_Name"])
+                g = int(r.get("Grid_Size", 0) or 0)
+                if k in ("k_sample_lw_fast", "k_sample_lw_multi") and g != biggest[k]:
+                    continue
+                if k == "k_sample_hw" and 2 * g < biggest[k]:  # (its grid follows the list lengths: the groups of one batch are the small ones)
+                    continue
+                agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
     import statistics
     per_kernel = {k: {c: statistics.median(v) for c, v in sorted(cs.items())} for k, cs in agg.items()}
     import os

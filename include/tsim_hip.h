@@ -285,6 +285,12 @@ int tsim_unpack_bits_device(tsim_program *p, const uint64_t *d_in, int64_t B, in
  * 20 outputs).  in_words = 0: ceil(nbits/64).  d_out 4-byte aligned. */
 int tsim_compact_rows_device(tsim_program *p, const uint64_t *d_in, int64_t B, int32_t in_words,
                              int32_t nbits, uint8_t *d_out, void *stream);
+/* Post-selection after sampling (sampler.py:422-545 for device-side noise, where no host stream decides which shots reach
+ * sample_program): rows of `row_bytes` bytes each (padded words or bit_packed); d_masks = 5 x row_bytes bytes: test mask,
+ * reference XORed before the test, columns a discarded row keeps, XOR for surviving rows, XOR for discarded rows;
+ * d_gone (optional) receives 0/1 per row. */
+int tsim_postselect_rows_device(tsim_program *p, uint8_t *d_rows, int64_t B, int32_t row_bytes, const uint8_t *d_masks,
+                                uint8_t *d_gone, void *stream);
 
 /* Row gather / scatter by index on packed rows of `words` 64-bit words - the data movement of the
  * reference's host-noise post-selection (src/tsim/sampler.py:466-508: survivors are compacted into dense

@@ -185,6 +185,49 @@ def test_device_postselection(hip, mode):
     assert z[:, 0].all() and not z[:, 2:].any()
 
 
+@pytest.mark.parametrize("ref_flags", [{}, {"use_detector_reference_sample": True}, {"use_detector_reference_sample": True, "use_observable_reference_sample": True}])
+def test_device_postselection_is_the_plain_result_with_discarded_rows_blanked(hip, ref_flags):
+    """noise="device": every row goes through the fast sampling path and a device kernel blanks the rows in which a masked
+    direct detector fires (tsim_postselect_rows_device).  A sampler with the same seed and no mask draws the same noise
+    and the same bits, so the post-selected result must be exactly that result with the reference's rules applied
+    (sampler.py:532-540: a discarded row keeps its direct detector columns, False elsewhere) - as bools, as bit_packed
+    rows, with the reference-sample flags, over several batches and a ragged last one."""
+    from tsim_amd import synth
+    from tsim_amd.channels import error_probs
+
+    prog, cfg = synth.config_program("C2")
+    nf = cfg["num_f"]
+    kw = dict(channel_probs=[error_probs(0.03)] * nf, error_transform=np.eye(nf, dtype=np.uint8), noise="device")
+    n, bs = 250_001, 100_000
+    mk = lambda: CompiledDetectorSampler(prog, seed=21, **kw)  # noqa: E731
+    s0 = mk()
+    nd = s0._num_detectors
+    direct = s0._direct_detector_mask
+    mask = np.zeros(nd, dtype=bool)
+    mask[np.flatnonzero(direct)[::2]] = True  # every other directly readable detector
+    sp = mk()  # (the reference sample is computed first and takes a key: the twin does the same before it samples)
+    ref = sp._compute_reference_sample() if ref_flags else None
+    plain = sp.sample(n, batch_size=bs, append_observables=True)
+    if ref is None:
+        ref = np.zeros(plain.shape[1], dtype=bool)
+    got = mk().sample(n, batch_size=bs, append_observables=True, postselection_mask=mask, **ref_flags)
+    det_ref = ref[:nd] if ref_flags.get("use_detector_reference_sample") else np.zeros(nd, dtype=bool)
+    obs_ref = ref[nd:] if ref_flags.get("use_observable_reference_sample") else np.zeros(plain.shape[1] - nd, dtype=bool)
+    gone = ((plain[:, :nd] ^ det_ref) & mask).any(axis=1)
+    assert 0.05 < gone.mean() < 0.95
+    want = plain.copy()
+    want[gone, nd:] = False
+    want[np.ix_(gone, np.flatnonzero(~direct))] = False
+    want[~gone, :nd] ^= det_ref
+    want[gone, :nd] ^= det_ref & direct
+    want[~gone, nd:] ^= obs_ref
+    np.testing.assert_array_equal(got, want)
+    packed = mk().sample(n, batch_size=bs, append_observables=True, postselection_mask=mask, bit_packed=True, **ref_flags)
+    np.testing.assert_array_equal(packed, np.packbits(want, axis=1, bitorder="little"))
+    det_only = mk().sample(n, batch_size=bs, postselection_mask=mask, bit_packed=True, **ref_flags)
+    np.testing.assert_array_equal(det_only, np.packbits(want[:, :nd], axis=1, bitorder="little"))
+
+
 @pytest.mark.parametrize("nbits,B", [(20, 1001), (5, 7), (64, 300), (121, 4096), (8, 3)])
 def test_compact_rows_equals_numpy_packbits(hip, nbits, B):
     """tsim_compact_rows_device == np.packbits(bits, axis=1, bitorder="little") (sampler.py:665-669)."""

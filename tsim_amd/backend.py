@@ -338,6 +338,12 @@ class HipProgram:
             "tsim_compact_rows_device",
         )
 
+    def postselect_rows_device(self, d_rows: int, B: int, row_bytes: int, d_masks: int, d_gone: int = 0, *, stream: int = 0) -> None:
+        """Blank the rows in which a masked direct detector fires (``tsim_postselect_rows_device``, include/tsim_hip.h)."""
+        _lib.check(self._lib.tsim_postselect_rows_device(self._h, C.c_void_p(d_rows), int(B), int(row_bytes), C.c_void_p(d_masks),
+                                                         C.c_void_p(d_gone) if d_gone else None, stream or None),
+                   "tsim_postselect_rows_device")
+
     def sample_batch_device(self, d_f: int, B: int, num_f: int, key, d_out: int, *,
                             shot_offset: int = 0, d_norm_dev: int = 0) -> None:
         """Asynchronous launch on the handle's stream; buffers are raw device pointers."""

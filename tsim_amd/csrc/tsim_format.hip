@@ -96,6 +96,40 @@ extern "C" int tsim_compact_rows_device(tsim_program *p, const uint64_t *d_in, i
   return tsim_launch_compact(d_in, B, WO, nbits, d_out, stream ? (hipStream_t)stream : p->stream);
 }
 
+// ---------------------------------------------------------------------------
+// Post-selection AFTER sampling (device-side noise: no host stream prescribes which shots reach sample_program, so every
+// row is sampled by the fast path and the discarded ones are blanked here - what _sample_batches_with_postselection,
+// src/tsim/sampler.py:422-545, returns for them).  Rows are byte strings (`row_bytes` each: the padded 8-byte words or
+// the bit_packed layout - same bit order).  masks = five byte strings of row_bytes:
+//   [0] test mask (masked, directly readable detectors)   [1] reference bits XORed before the test
+//   [2] columns a discarded row keeps (its direct detector columns, sampler.py:532-540)
+//   [3] XOR applied to surviving rows                      [4] XOR applied to discarded rows
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_postselect_blank(uint8_t *rows, long long B, int row_bytes, const uint8_t *masks, uint8_t *gone) {
+  const long long row = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (row >= B) return;
+  uint8_t *r = rows + row * row_bytes;
+  unsigned fired = 0u;
+  for (int k = 0; k < row_bytes; ++k) fired |= (unsigned)((r[k] ^ masks[row_bytes + k]) & masks[k]);
+  const bool g = fired != 0u;
+  const uint8_t *keep = masks + 2 * row_bytes, *xs = masks + 3 * row_bytes, *xg = masks + 4 * row_bytes;
+  for (int k = 0; k < row_bytes; ++k) r[k] = g ? (uint8_t)((r[k] & keep[k]) ^ xg[k]) : (uint8_t)(r[k] ^ xs[k]);
+  if (gone) gone[row] = g ? 1 : 0;
+}
+
+extern "C" int tsim_postselect_rows_device(tsim_program *p, uint8_t *d_rows, int64_t B, int32_t row_bytes, const uint8_t *d_masks,
+                                           uint8_t *d_gone, void *stream) {
+  if (int r = tsim_need_final(p)) return r;
+  if (int r = tsim_set_device(p)) return r;
+  if (B < 0 || row_bytes < 0) return tsim_fail(TSIM_EINVAL, "negative size");
+  if (B == 0 || row_bytes == 0) return TSIM_OK;
+  if (!d_rows || !d_masks) return tsim_fail(TSIM_EINVAL, "NULL buffer");
+  hipLaunchKernelGGL(k_postselect_blank, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, stream ? (hipStream_t)stream : p->stream, d_rows,
+                     (long long)B, (int)row_bytes, d_masks, d_gone);
+  HIP_TRY(hipGetLastError());
+  return TSIM_OK;
+}
+
 extern "C" int tsim_gather_rows_device(tsim_program *p, const uint64_t *d_src, int32_t words, const uint32_t *d_index,
                                        int64_t n_valid, int64_t n_total, uint64_t *d_dst, void *stream) {
   if (int r = tsim_need_final(p)) return r;

@@ -167,6 +167,7 @@ struct tsim_program {
     bool deferred = false;
     bool ctx_check = false;
     bool used = false;                // a launch ran on the slot's own stream
+    bool needs_sync = false;          // tsim_pipeline_wait_stream skipped this (unused) stream: its first launch waits for sync_ev
     hipStream_t p1_stream = nullptr;  // lane of that first pass
     hipStream_t last_done = nullptr;  // stream on which done_ev of the slot's last launch was recorded
     hipEvent_t done_ev = nullptr;     // ev2 (own second pass) or the event of the batch that served the slot

@@ -124,7 +124,9 @@ static LaunchPlan make_plan(tsim_program *p, bool has_row_index, bool pipelined)
   pl.use_tables = p->lw;
   if (p->lw && p->h_feedback && p->knobs.adaptive) {
     uint32_t fb_sum = p->h_feedback[0], fb_max = p->h_feedback[1], fb_rows = p->h_feedback[2];
-    bool known = fb_rows != 0xFFFFFFFFu && fb_rows > 0u && fb_sum != 0xFFFFFFFFu;
+    // (counts of a tiny launch - the one-row reference sample, sampler.py:263-276 - say nothing about the batches to come:
+    // one hard row of one was read as "dense" and cost the next fifteen launches their tables)
+    bool known = fb_rows != 0xFFFFFFFFu && fb_rows >= 32u && fb_sum != 0xFFFFFFFFu;
     // More than 1 % of the rows hard, three launches in a row, and deeper tables are allowed: build them now
     // (once; every lane is drained first because the records in the device image are rewritten).
     if (known && p->lw_cap_now < p->lw_cap_max && !has_row_index) {
@@ -776,7 +778,13 @@ extern "C" int tsim_sample_batch_device_begin(tsim_program *p, int32_t slot, con
     if (int r = tsim_flush_hard(p)) return r;
   const LaunchPlan plan = make_plan(p, false, true);
   hipStream_t s = plan.defer ? p->slots[1 + (slot & 1)].side : sl.side;
-  if (!plan.defer) sl.used = true;
+  if (!plan.defer) {
+    // the slot's own stream: tsim_pipeline_wait_stream orders only streams that carried work before - a first launch here
+    // (a plan that leaves the deferred path: dense batches, unknown feedback) must still see what the caller ordered
+    if (sl.needs_sync && p->sync_ev) HIP_TRY(hipStreamWaitEvent(s, p->sync_ev, 0));
+    sl.needs_sync = false;
+    sl.used = true;
+  }
   if (int r = slot_order_after_previous(p, sl, s)) return r;
   // Pre-wait, mid-batch.  When the caller rotates through a slot count that is a multiple of the batch size, the
   // wait a lane needs for its next batch of slots falls on the lane's FIRST launch of that batch - right behind the
@@ -1141,7 +1149,11 @@ extern "C" int tsim_pipeline_wait_stream(tsim_program *p, void *stream) {
   std::vector<hipStream_t> seen;
   for (int k = 1; k <= TSIM_PIPELINE_SLOTS; ++k) {
     tsim_program::Slot &sl = p->slots[k];
-    if (!sl.side_ready || (k > 4 && !sl.used) || sl.side == s_user) continue;
+    if (!sl.side_ready || sl.side == s_user) continue;
+    if (k > 4 && !sl.used) {  // never carried work: not worth a wait packet now - its first launch takes the wait (launch on a slot's own stream)
+      sl.needs_sync = true;
+      continue;
+    }
     if (std::find(seen.begin(), seen.end(), sl.side) != seen.end()) continue;
     seen.push_back(sl.side);
     HIP_TRY(hipStreamWaitEvent(sl.side, p->sync_ev, 0));

@@ -415,7 +415,8 @@ class _CompiledSamplerBase:
         hp.d2h(host, d_u8.ptr)
         return host.view(np.bool_)
 
-    def _device_noise_plain(self, shots: int, batch_size: int | None, want_ref: bool, packed_columns: int | None = None):
+    def _device_noise_plain(self, shots: int, batch_size: int | None, want_ref: bool, packed_columns: int | None = None,
+                            post: dict | None = None):
         """``noise="device"``: three things at once - ``k_noise`` fills the f rows of group g + 1 on its own stream, the
         sampling kernels of group g run on the pipeline lanes (``tsim_sample_steps_device``: fused first passes, one
         hard-row batch per group), the rows of group g - 1 travel to the host on a copy stream.  A group is a few
@@ -455,6 +456,17 @@ class _CompiledSamplerBase:
         else:
             out = pool.take((total, n_out))
             d_u8 = self._scratch(hp, "unpacked", total * n_out)
+        d_masks = d_gone = None
+        if post is not None:
+            # post-selection after sampling (tsim_postselect_rows_device): five column masks in the layout of the device rows
+            def as_row(cols) -> np.ndarray:
+                full = np.zeros(row_bytes * 8, dtype=np.uint8)
+                full[:n_out] = np.asarray(cols, dtype=np.uint8)[:n_out]
+                return np.packbits(full, bitorder="little")
+
+            masks = np.concatenate([as_row(post[k]) for k in ("test", "test_ref", "keep", "xor_kept", "xor_discarded")])
+            d_masks, d_gone = self._scratch(hp, "ps_masks", masks.nbytes + 16), self._scratch(hp, "ps_gone", total + 16)
+            hp.h2d(d_masks, masks)
         key_state = (C.c_uint32 * 2)(self._key[0] & 0xFFFFFFFF, self._key[1] & 0xFFFFFFFF)
         # groups: small at both ends (the first one starts the GPU early, the last one is all that is left to download
         # when the kernels are done), up to 4 batches in between
@@ -470,6 +482,8 @@ class _CompiledSamplerBase:
             for sl in slots:
                 hp.sample_batch_device_end(sl, s_copy)  # the copy stream waits for exactly these batches
             r0, r1 = lo * size, (lo + n) * size
+            if post is not None:  # blank the discarded rows where they are, before any layout conversion
+                hp.postselect_rows_device(d_rows.ptr + r0 * row_bytes, r1 - r0, row_bytes, d_masks.ptr, d_gone.ptr + r0, stream=s_copy)
             if direct_packed:
                 hp.d2h_async(out[r0:r1], d_rows.ptr + r0 * row_bytes, s_copy)
             elif packed_columns is not None:
@@ -507,7 +521,12 @@ class _CompiledSamplerBase:
         for b in range(plan.count):
             self._check_devs(devs[b * n_comp:(b + 1) * n_comp])
         res = out[:shots]
-        return (res if (direct_packed or packed_columns is not None) else res.view(np.bool_)), ref
+        res = res if (direct_packed or packed_columns is not None) else res.view(np.bool_)
+        if post is not None:
+            gone = np.empty(total, dtype=np.uint8)
+            hp.d2h(gone, d_gone.ptr)
+            return res, ref, gone[:shots].view(np.bool_)
+        return res, ref
 
     def _device_plain(self, shots: int, batch_size: int | None, want_ref: bool, packed_columns: int | None = None):
         """noise -> f -> ``sample_program`` -> layout conversion, the GPU busy beside the channel sampler.
@@ -673,41 +692,37 @@ class _CompiledSamplerBase:
         rows[~gone, :nd] ^= ref_det
         rows[gone, :nd] ^= ref_det & self._direct_detector_mask
 
-    def _device_noise_postselect(self, shots, batch_size, test_mask, compute_reference, xor_detector_ref):
-        """``noise="device"``: ``k_noise`` -> filter kernel (direct bits of every row + survivor list) -> the
-        sampling kernels on the listed rows only; nothing but the final result crosses PCIe.  (Survivors keep
-        their own in-batch Threefry counter: there is no host stream to reproduce.)"""
-        hp = self._hip()
-        noise = self._device_noise_sampler(hp)
-        plan = plan_batches(shots, batch_size, self._estimate_batch_size())
+    def _device_noise_postselect(self, shots, batch_size, test_mask, compute_reference, xor_detector_ref, *,
+                                 packed_columns: int | None = None, xor_observable_ref: bool = False):
+        """``noise="device"``: there is no host stream that says which shots reach ``sample_program`` - so EVERY row goes
+        through the fast sampling path (:meth:`_device_noise_plain`: noise, fused first passes, downloads as a pipeline) and
+        one small kernel blanks the rows in which a masked direct detector fires, exactly as the reference returns them
+        (their direct detector columns, False elsewhere; reference bits as in ``sampler.py:532-540``).  Sampling a
+        discarded row costs 11 ns per 10^3 shots; compacting the survivors first (gather, dense batches, scatter, a host
+        round trip per chunk) cost 125x the plain path.  ``packed_columns``: return ``bit_packed`` rows of that many
+        leading columns instead of bools; ``xor_observable_ref``: also XOR the reference's observable bits into the
+        surviving rows (``sample(use_observable_reference_sample=True)``)."""
+        nd, n_out = self._num_detectors, int(self._program.num_outputs)
         ref = self._compute_reference_sample() if compute_reference else None
-        ref_det = ref[: self._num_detectors] if (ref is not None and xor_detector_ref) else None
-        helper = _DevicePostselect(self, plan.size * plan.count, plan.size, test_mask, ref_det)
-        try:
-            return self._device_noise_postselect_run(hp, noise, plan, helper, shots, ref, ref_det)
-        finally:
-            helper.release()
+        ref_det = ref[:nd] if (ref is not None and xor_detector_ref) else None
 
-    def _device_noise_postselect_run(self, hp, noise, plan, helper, shots, ref, ref_det):
-        num_f, wf, wo, n_comp = helper.num_f, helper.wf, helper.wo, helper.n_comp
-        d_devs = helper.hp.malloc(plan.count * n_comp * 4)
-        helper._bufs.append(d_devs)
-        hp.h2d(d_devs, np.zeros(plan.count * n_comp, dtype=np.float32))
-        for b in range(plan.count):
-            lo = b * plan.size
-            d_f, d_o = helper.d_store.ptr + lo * wf * 8, helper.d_rows.ptr + lo * wo * 8
-            self._noise_key, nk = hp.split_key(self._noise_key)
-            noise.sample_into(d_f, plan.size, nk)
-            hp.postselect_device(d_f, plan.size, num_f, helper.d_mask.ptr, helper.d_ref.ptr if helper.has_ref else 0, d_o,
-                                 helper.d_list.ptr, helper.d_count.ptr, helper.d_flags.ptr + lo)
-            hp.sample_rows_device(d_f, plan.size, num_f, self._next_key(), d_o, helper.d_list.ptr, helper.d_count.ptr,
-                                  d_norm_dev=d_devs.ptr + b * n_comp * 4)
-        devs = np.zeros(plan.count * n_comp, dtype=np.float32)
-        hp.d2h(devs, d_devs)
-        helper.devs = [devs[b * n_comp:(b + 1) * n_comp] for b in range(plan.count)]
-        rows, gone = helper.collect()
-        rows, gone = rows[:shots], gone[:shots]
-        self._apply_detector_reference(rows, gone, ref_det)
+        def cols(det_bits=None, obs_bits=None) -> np.ndarray:
+            full = np.zeros(n_out, dtype=np.uint8)
+            if det_bits is not None:
+                full[:nd] = np.asarray(det_bits, dtype=np.uint8)
+            if obs_bits is not None:
+                full[nd:] = np.asarray(obs_bits, dtype=np.uint8)
+            return full
+
+        direct = self._direct_detector_mask
+        post = {
+            "test": cols(test_mask),
+            "test_ref": cols(ref_det),
+            "keep": cols(direct),
+            "xor_kept": cols(ref_det, ref[nd:] if (ref is not None and xor_observable_ref) else None),
+            "xor_discarded": cols(ref_det & direct if ref_det is not None else None),
+        }
+        rows, _, gone = self._device_noise_plain(shots, batch_size, False, packed_columns, post=post)
         return rows, ref, gone
 
     def __repr__(self) -> str:
@@ -775,6 +790,14 @@ class CompiledDetectorSampler(_CompiledSamplerBase):
                 mask = None  # no shot could be skipped: the plain path does the same work
 
         if mask is not None:
+            width = n_out if append_observables else nd
+            if (bit_packed and not separate_observables and not prepend_observables and width > 0 and shots > 0
+                    and self._noise == "device" and not self._seam_replaced()):
+                # device-side noise: sample everything, blank the discarded rows on the device, move width/8 bytes per shot
+                _check_request(shots, batch_size)
+                return self._device_noise_postselect(shots, batch_size, mask & self._direct_detector_mask, want_ref,
+                                                     use_detector_reference_sample, packed_columns=width,
+                                                     xor_observable_ref=use_observable_reference_sample)[0]
             rows, ref, gone = self._sample_batches_with_postselection(
                 shots, batch_size, postselection_mask=mask, compute_reference=want_ref,
                 xor_detector_ref=use_detector_reference_sample)

@@ -228,6 +228,31 @@ def test_device_postselection_is_the_plain_result_with_discarded_rows_blanked(hi
     np.testing.assert_array_equal(det_only, np.packbits(want[:, :nd], axis=1, bitorder="little"))
 
 
+@pytest.mark.parametrize("ref_flags", [{}, {"use_detector_reference_sample": True, "use_observable_reference_sample": True}])
+def test_host_noise_postselection_packed_rows_equal_the_bool_rows(hip, ref_flags):
+    """noise="host" (the reference's stream and its compacted survivor batches, sampler.py:422-545): with bit_packed=True
+    the blanking, the reference bits and the packing happen on the device (tsim_postselect_rows_device +
+    tsim_compact_rows_device); the bytes must be np.packbits of what the bool path returns for the same seed."""
+    from tsim_amd import synth
+    from tsim_amd.channels import error_probs
+
+    prog, cfg = synth.config_program("C2")
+    nf = cfg["num_f"]
+    kw = dict(channel_probs=[error_probs(0.03)] * nf, error_transform=np.eye(nf, dtype=np.uint8), noise="host")
+    mk = lambda: CompiledDetectorSampler(prog, seed=5, **kw)  # noqa: E731
+    s0 = mk()
+    nd = s0._num_detectors
+    mask = np.zeros(nd, dtype=bool)
+    mask[np.flatnonzero(s0._direct_detector_mask)[::3]] = True
+    n, bs = 70_001, 30_000
+    bools = mk().sample(n, batch_size=bs, append_observables=True, postselection_mask=mask, **ref_flags)
+    assert 0.02 < (~bools[:, nd:].any(axis=1)).mean() < 0.98
+    packed = mk().sample(n, batch_size=bs, append_observables=True, postselection_mask=mask, bit_packed=True, **ref_flags)
+    np.testing.assert_array_equal(packed, np.packbits(bools, axis=1, bitorder="little"))
+    det_only = mk().sample(n, batch_size=bs, postselection_mask=mask, bit_packed=True, **ref_flags)
+    np.testing.assert_array_equal(det_only, np.packbits(bools[:, :nd], axis=1, bitorder="little"))
+
+
 @pytest.mark.parametrize("nbits,B", [(20, 1001), (5, 7), (64, 300), (121, 4096), (8, 3)])
 def test_compact_rows_equals_numpy_packbits(hip, nbits, B):
     """tsim_compact_rows_device == np.packbits(bits, axis=1, bitorder="little") (sampler.py:665-669)."""

@@ -233,6 +233,39 @@ class _DevicePostselect:
             buf.free()
         self._bufs = []
 
+    def collect_device(self, post: dict, packed_columns: int | None):
+        """Blanking and reference bits on the device (tsim_postselect_rows_device: the filter's own test on the finished
+        rows), then either bools or - ``packed_columns`` - the reference's bit_packed rows of that many leading columns:
+        no fancy indexing over an 80 MB bool array, no host packbits."""
+        hp, owner = self.hp, self.owner
+        row_bytes = self.wo * 8
+
+        def as_row(cols) -> np.ndarray:
+            full = np.zeros(row_bytes * 8, dtype=np.uint8)
+            full[: self.n_out] = np.asarray(cols, dtype=np.uint8)[: self.n_out]
+            return np.packbits(full, bitorder="little")
+
+        masks = np.concatenate([as_row(post[k]) for k in ("test", "test_ref", "keep", "xor_kept", "xor_discarded")])
+        d_masks = hp.malloc(masks.nbytes + 16)
+        self._bufs.append(d_masks)
+        hp.h2d(d_masks, masks)
+        hp.postselect_rows_device(self.d_rows.ptr, self.shots, row_bytes, d_masks.ptr, self.d_flags.ptr)
+        gone = np.empty(self.shots, dtype=np.uint8)
+        hp.d2h(gone, self.d_flags)
+        if packed_columns is not None:
+            rb = (packed_columns + 7) // 8
+            d_c = hp.malloc(self.shots * rb + 16)
+            self._bufs.append(d_c)
+            hp.compact_rows_device(self.d_rows.ptr, self.shots, packed_columns, d_c.ptr, in_words=self.wo)
+            rows = np.empty((self.shots, rb), dtype=np.uint8)
+            hp.d2h(rows, d_c)
+        else:
+            rows = owner._download_bools(hp, self.d_rows, self.shots)
+        self.release()
+        for dev in self.devs:
+            owner._check_devs(dev)
+        return rows, gone.view(np.bool_)
+
     def collect(self):
         rows, gone = self.owner._download_bools(self.hp, self.d_rows, self.shots), np.empty(self.shots, dtype=np.uint8)
         self.hp.d2h(gone, self.d_flags)
@@ -651,7 +684,8 @@ class _CompiledSamplerBase:
 
     # -- post-selection -----------------------------------------------------------------------------------------
     def _sample_batches_with_postselection(self, shots: int, batch_size: int | None, *, postselection_mask: np.ndarray,
-                                           compute_reference: bool = False, xor_detector_ref: bool = False):
+                                           compute_reference: bool = False, xor_detector_ref: bool = False,
+                                           packed_columns: int | None = None, xor_observable_ref: bool = False):
         """``(rows, reference or None, was_discarded)``: shots in which a masked, directly readable detector
         fires never reach ``sample_program``; they keep their direct detector columns and False elsewhere
         (sampler.py:422-545)."""
@@ -668,20 +702,53 @@ class _CompiledSamplerBase:
             return rows, ref, np.zeros(shots, dtype=np.bool_)
         test_mask = np.asarray(postselection_mask, dtype=np.bool_) & self._direct_detector_mask
         if self._noise == "device" and not self._seam_replaced():
-            return self._device_noise_postselect(shots, batch_size, test_mask, compute_reference, xor_detector_ref)
+            return self._device_noise_postselect(shots, batch_size, test_mask, compute_reference, xor_detector_ref,
+                                                 packed_columns=packed_columns, xor_observable_ref=xor_observable_ref)
         size = plan_batches(shots, batch_size, self._estimate_batch_size()).size
         ref = self._compute_reference_sample() if compute_reference else None
         ref_det = ref[:nd] if (ref is not None and xor_detector_ref) else None
         work = (_SeamPostselect(self, shots, test_mask, ref_det) if self._seam_replaced()
                 else _DevicePostselect(self, shots, size, test_mask, ref_det))
+        on_device = isinstance(work, _DevicePostselect)
         try:
             _run_postselected(shots, size, work, self._next_key)
-            rows, gone = work.collect()
+            if on_device:
+                direct = self._direct_detector_mask
+                post = self._postselect_masks(test_mask, ref, ref_det, xor_observable_ref)
+                rows, gone = work.collect_device(post, packed_columns)
+            else:
+                rows, gone = work.collect()
         finally:
             if hasattr(work, "release"):
                 work.release()
-        self._apply_detector_reference(rows, gone, ref_det)
+        if not on_device:
+            self._apply_detector_reference(rows, gone, ref_det)
+            if xor_observable_ref and ref is not None:
+                rows[~gone, nd:] ^= ref[nd:]
+            if packed_columns is not None:
+                rows = np.packbits(rows[:, :packed_columns], axis=1, bitorder="little")
         return rows, ref, gone
+
+    def _postselect_masks(self, test_mask, ref, ref_det, xor_observable_ref: bool) -> dict:
+        """The five column masks of ``tsim_postselect_rows_device`` (sampler.py:532-540 and the reference-sample flags)."""
+        nd, n_out = self._num_detectors, int(self._program.num_outputs)
+
+        def cols(det_bits=None, obs_bits=None) -> np.ndarray:
+            full = np.zeros(n_out, dtype=np.uint8)
+            if det_bits is not None:
+                full[:nd] = np.asarray(det_bits, dtype=np.uint8)
+            if obs_bits is not None:
+                full[nd:] = np.asarray(obs_bits, dtype=np.uint8)
+            return full
+
+        direct = self._direct_detector_mask
+        return {
+            "test": cols(test_mask),
+            "test_ref": cols(ref_det),
+            "keep": cols(direct),
+            "xor_kept": cols(ref_det, ref[nd:] if (ref is not None and xor_observable_ref) else None),
+            "xor_discarded": cols(ref_det & direct if ref_det is not None else None),
+        }
 
     def _apply_detector_reference(self, rows: np.ndarray, gone: np.ndarray, ref_det: np.ndarray | None) -> None:
         """XOR the reference's detector bits in: all of them for shots that ran, only the directly readable
@@ -702,26 +769,10 @@ class _CompiledSamplerBase:
         round trip per chunk) cost 125x the plain path.  ``packed_columns``: return ``bit_packed`` rows of that many
         leading columns instead of bools; ``xor_observable_ref``: also XOR the reference's observable bits into the
         surviving rows (``sample(use_observable_reference_sample=True)``)."""
-        nd, n_out = self._num_detectors, int(self._program.num_outputs)
+        nd = self._num_detectors
         ref = self._compute_reference_sample() if compute_reference else None
         ref_det = ref[:nd] if (ref is not None and xor_detector_ref) else None
-
-        def cols(det_bits=None, obs_bits=None) -> np.ndarray:
-            full = np.zeros(n_out, dtype=np.uint8)
-            if det_bits is not None:
-                full[:nd] = np.asarray(det_bits, dtype=np.uint8)
-            if obs_bits is not None:
-                full[nd:] = np.asarray(obs_bits, dtype=np.uint8)
-            return full
-
-        direct = self._direct_detector_mask
-        post = {
-            "test": cols(test_mask),
-            "test_ref": cols(ref_det),
-            "keep": cols(direct),
-            "xor_kept": cols(ref_det, ref[nd:] if (ref is not None and xor_observable_ref) else None),
-            "xor_discarded": cols(ref_det & direct if ref_det is not None else None),
-        }
+        post = self._postselect_masks(test_mask, ref, ref_det, xor_observable_ref)
         rows, _, gone = self._device_noise_plain(shots, batch_size, False, packed_columns, post=post)
         return rows, ref, gone
 
@@ -791,18 +842,15 @@ class CompiledDetectorSampler(_CompiledSamplerBase):
 
         if mask is not None:
             width = n_out if append_observables else nd
-            if (bit_packed and not separate_observables and not prepend_observables and width > 0 and shots > 0
-                    and self._noise == "device" and not self._seam_replaced()):
-                # device-side noise: sample everything, blank the discarded rows on the device, move width/8 bytes per shot
-                _check_request(shots, batch_size)
-                return self._device_noise_postselect(shots, batch_size, mask & self._direct_detector_mask, want_ref,
-                                                     use_detector_reference_sample, packed_columns=width,
-                                                     xor_observable_ref=use_observable_reference_sample)[0]
+            fast = (bit_packed and not separate_observables and not prepend_observables and width > 0 and shots > 0
+                    and not self._seam_replaced())
+            # bit_packed rows of a prefix of the columns: blanking, reference bits and packing all happen on the device
             rows, ref, gone = self._sample_batches_with_postselection(
                 shots, batch_size, postselection_mask=mask, compute_reference=want_ref,
-                xor_detector_ref=use_detector_reference_sample)
-            if use_observable_reference_sample:
-                rows[~gone, nd:] ^= ref[nd:]
+                xor_detector_ref=use_detector_reference_sample, packed_columns=width if fast else None,
+                xor_observable_ref=use_observable_reference_sample)
+            if fast:
+                return rows
         elif want_ref:
             rows, ref = self._sample_batches(shots, batch_size, compute_reference=True)
             flip = np.zeros(n_out, dtype=np.bool_)

@@ -291,6 +291,11 @@ int tsim_compact_rows_device(tsim_program *p, const uint64_t *d_in, int64_t B, i
  * d_gone (optional) receives 0/1 per row. */
 int tsim_postselect_rows_device(tsim_program *p, uint8_t *d_rows, int64_t B, int32_t row_bytes, const uint8_t *d_masks,
                                 uint8_t *d_gone, void *stream);
+/* The survivors of a chunk (d_gone[i] == 0, from tsim_postselect_device), IN SHOT ORDER, appended to a device-resident
+ * queue of shot ids: queue[*d_tail ...] = base + i, *d_tail += their number (the reference's compacted batches,
+ * sampler.py:466-508: the order fixes the survivors' Threefry counters).  d_scratch: ceil(n / 1024) uint32. */
+int tsim_survivors_append_device(tsim_program *p, const uint8_t *d_gone, int64_t n, uint32_t base, uint32_t *d_scratch,
+                                 uint32_t *d_queue, uint32_t *d_tail, void *stream);
 
 /* Row gather / scatter by index on packed rows of `words` 64-bit words - the data movement of the
  * reference's host-noise post-selection (src/tsim/sampler.py:466-508: survivors are compacted into dense

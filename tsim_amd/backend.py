@@ -338,6 +338,11 @@ class HipProgram:
             "tsim_compact_rows_device",
         )
 
+    def survivors_append_device(self, d_gone: int, n: int, base: int, d_scratch: int, d_queue: int, d_tail: int) -> None:
+        """Append the shot ids ``base + i`` of the rows with ``gone[i] == 0``, in order, to a device queue (``tsim_survivors_append_device``)."""
+        _lib.check(self._lib.tsim_survivors_append_device(self._h, C.c_void_p(d_gone), int(n), int(base), C.c_void_p(d_scratch),
+                                                          C.c_void_p(d_queue), C.c_void_p(d_tail), None), "tsim_survivors_append_device")
+
     def postselect_rows_device(self, d_rows: int, B: int, row_bytes: int, d_masks: int, d_gone: int = 0, *, stream: int = 0) -> None:
         """Blank the rows in which a masked direct detector fires (``tsim_postselect_rows_device``, include/tsim_hip.h)."""
         _lib.check(self._lib.tsim_postselect_rows_device(self._h, C.c_void_p(d_rows), int(B), int(row_bytes), C.c_void_p(d_masks),

@@ -130,6 +130,79 @@ extern "C" int tsim_postselect_rows_device(tsim_program *p, uint8_t *d_rows, int
   return TSIM_OK;
 }
 
+// ---------------------------------------------------------------------------
+// Survivors of a chunk, IN SHOT ORDER, appended to a device-resident queue (the reference's compacted batches,
+// sampler.py:466-508: a survivor's Threefry counter is its position in the batch it leaves in, so the order is part of
+// the contract).  gone[i] = 1 for discarded rows (tsim_postselect_device); queue[*tail ...] receives base + i for the
+// others; *tail advances by their number.  Two small kernels: survivors per 1024-row block, then every block finds
+// its offset (a sum over the blocks before it) and writes its ids by ballot prefix.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) k_survivor_count(const uint8_t *gone, long long n, uint32_t *block_counts) {
+  const long long i = (long long)blockIdx.x * 1024 + threadIdx.x;
+  const bool keep = i < n && gone[i] == 0;
+  const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
+  __shared__ uint32_t wave_n[16];
+  if ((threadIdx.x & 63u) == 0u) wave_n[threadIdx.x >> 6] = (uint32_t)__popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0u) {
+    uint32_t t = 0;
+    for (int w = 0; w < 16; ++w) t += wave_n[w];
+    block_counts[blockIdx.x] = t;
+  }
+}
+__global__ void __launch_bounds__(1024) k_survivor_write(const uint8_t *gone, long long n, uint32_t base, const uint32_t *block_counts,
+                                                         uint32_t *queue, uint32_t *tail) {
+  __shared__ uint32_t wave_n[16];
+  __shared__ uint32_t block_off;
+  const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+  const uint32_t start = *tail;  // (advanced by the LAST block only, after every block has read it: see below)
+  // offset of this block: survivors of the blocks before it
+  uint32_t part = 0;
+  for (uint32_t b = threadIdx.x; b < blockIdx.x; b += 1024u) part += block_counts[b];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) part += (uint32_t)__shfl_xor((int)part, o, 64);
+  if (lane == 0u) wave_n[wv] = part;
+  __syncthreads();
+  if (threadIdx.x == 0u) {
+    uint32_t t = 0;
+    for (int w = 0; w < 16; ++w) t += wave_n[w];
+    block_off = t;
+  }
+  __syncthreads();
+  const long long i = (long long)blockIdx.x * 1024 + threadIdx.x;
+  const bool keep = i < n && gone[i] == 0;
+  const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
+  __syncthreads();  // (wave_n is reused)
+  if (lane == 0u) wave_n[wv] = (uint32_t)__popcll(m);
+  __syncthreads();
+  uint32_t before = 0;
+  for (uint32_t w = 0; w < wv; ++w) before += wave_n[w];
+  if (keep) queue[start + block_off + before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = base + (uint32_t)i;
+}
+__global__ void k_survivor_advance(const uint32_t *block_counts, uint32_t n_blocks, uint32_t *tail) {
+  uint32_t part = 0;
+  for (uint32_t b = threadIdx.x; b < n_blocks; b += 64u) part += block_counts[b];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) part += (uint32_t)__shfl_xor((int)part, o, 64);
+  if (threadIdx.x == 0u) *tail += part;
+}
+
+extern "C" int tsim_survivors_append_device(tsim_program *p, const uint8_t *d_gone, int64_t n, uint32_t base, uint32_t *d_scratch,
+                                            uint32_t *d_queue, uint32_t *d_tail, void *stream) {
+  if (int r = tsim_need_final(p)) return r;
+  if (int r = tsim_set_device(p)) return r;
+  if (n < 0 || n >= (1ll << 32)) return tsim_fail(TSIM_EINVAL, "bad row count");
+  if (n == 0) return TSIM_OK;
+  if (!d_gone || !d_scratch || !d_queue || !d_tail) return tsim_fail(TSIM_EINVAL, "NULL buffer");
+  hipStream_t s = stream ? (hipStream_t)stream : p->stream;
+  const unsigned nb = (unsigned)((n + 1023) / 1024);
+  hipLaunchKernelGGL(k_survivor_count, dim3(nb), dim3(1024), 0, s, d_gone, (long long)n, d_scratch);
+  hipLaunchKernelGGL(k_survivor_write, dim3(nb), dim3(1024), 0, s, d_gone, (long long)n, base, (const uint32_t *)d_scratch, d_queue, d_tail);
+  hipLaunchKernelGGL(k_survivor_advance, dim3(1), dim3(64), 0, s, (const uint32_t *)d_scratch, nb, d_tail);
+  HIP_TRY(hipGetLastError());
+  return TSIM_OK;
+}
+
 extern "C" int tsim_gather_rows_device(tsim_program *p, const uint64_t *d_src, int32_t words, const uint32_t *d_index,
                                        int64_t n_valid, int64_t n_total, uint64_t *d_dst, void *stream) {
   if (int r = tsim_need_final(p)) return r;

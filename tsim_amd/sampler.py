@@ -131,6 +131,46 @@ def _run_postselected(shots: int, size: int, work, next_key) -> None:
         work.dispatch(queue, size, next_key())
 
 
+def _run_postselected_device(shots: int, size: int, work, next_key, sample_packed) -> None:
+    """The same schedule with the survivors queued ON THE DEVICE (``_DevicePostselect.admit_device``): per chunk only the
+    queue length crosses PCIe; the channel sampler runs a chunk ahead on a worker thread (stream order is chunk order)."""
+    import queue
+    import threading
+
+    chunks = [min(size, shots - lo) for lo in range(0, shots, size)]
+    ready: "queue.Queue" = queue.Queue(maxsize=2)
+
+    def produce() -> None:
+        try:
+            for n in chunks:
+                ready.put(sample_packed(n))
+        except BaseException as e:  # noqa: BLE001 - handed to the consumer
+            ready.put(e)
+
+    th = threading.Thread(target=produce, daemon=True)
+    th.start()
+    try:
+        done = head = tail = 0
+        for n in chunks:
+            rows = ready.get()
+            if isinstance(rows, BaseException):
+                raise rows
+            tail = work.admit_device(done, rows)
+            done += n
+            while tail - head >= size:
+                work.dispatch_device(head, size, size, next_key())
+                head += size
+        if tail > head:
+            work.dispatch_device(head, tail - head, size, next_key())
+    finally:
+        while th.is_alive():  # (an error above: let the producer run out so that the generator is not left mid-draw)
+            try:
+                ready.get(timeout=0.05)
+            except queue.Empty:
+                pass
+        th.join()
+
+
 class _SeamPostselect:
     """Post-selection work through the ``sample_program`` seam, host arrays in the reference layout."""
 
@@ -180,7 +220,7 @@ class _DevicePostselect:
         self.devs = []
         # the store, the rows, the flags and the unpack scratch are O(shots) on the device: refuse what cannot fit instead
         # of failing half way
-        need = shots * (self.wf * 8 + self.wo * 8 + 1 + self.n_out) + size * (self.wf * 8 + self.wo * 8 + 8)
+        need = shots * (self.wf * 8 + self.wo * 8 + 1 + 4 + self.n_out) + size * (self.wf * 8 + self.wo * 8 + 8)
         free, _ = hp.mem_info()
         if need > 0.9 * free:
             raise MemoryError(f"device post-selection of {shots} shots needs {need >> 20} MiB of device memory, {free >> 20} MiB are free: "
@@ -195,6 +235,14 @@ class _DevicePostselect:
         self.d_flags, self.d_list, self.d_count = m(shots), m(size * 4), m(4)
         self.d_fb, self.d_ob, self.d_idx = m(size * self.wf * 8), m(size * self.wo * 8), m(size * 4)
         self.d_dev, self.d_mask, self.d_ref = m(4 * self.n_comp), m(self.wo * 8), m(self.wo * 8)
+        # the survivor queue (shot ids in shot order, appended chunk by chunk on the device), its tail, scan scratch, and one
+        # normalisation-deviation record per dispatched batch (read once, at the end)
+        self.max_dispatch = shots // max(1, size) + 2
+        self.d_queue, self.d_tail, self.d_scan = m(shots * 4 + 16), m(16), m(((size + 1023) // 1024) * 4 + 16)
+        self.d_devs = m(4 * self.n_comp * self.max_dispatch)
+        self.n_dispatch = 0
+        hp.h2d(self.d_tail, np.zeros(4, dtype=np.uint32))
+        hp.h2d(self.d_devs, np.zeros(self.n_comp * self.max_dispatch, dtype=np.float32))
         hp.h2d(self.d_mask, self._columns(test_mask))
         self.has_ref = ref_det is not None
         if self.has_ref:
@@ -226,6 +274,30 @@ class _DevicePostselect:
         dev = np.zeros(self.n_comp, dtype=np.float32)
         hp.d2h(dev, self.d_dev)
         self.devs.append(dev)
+
+    def admit_device(self, start: int, rows: np.ndarray) -> int:
+        """A chunk's packed f rows -> store, direct bits + discard flags, survivors appended (in shot order) to the device
+        queue; returns the queue's length - the only thing that comes back (4 bytes)."""
+        hp, n = self.hp, len(rows)
+        hp.h2d(self.d_store.ptr + start * self.wf * 8, rows)
+        hp.postselect_device(self.d_store.ptr + start * self.wf * 8, n, self.num_f, self.d_mask.ptr,
+                             self.d_ref.ptr if self.has_ref else 0, self.d_rows.ptr + start * self.wo * 8,
+                             self.d_list.ptr, self.d_count.ptr, self.d_flags.ptr + start)
+        hp.survivors_append_device(self.d_flags.ptr + start, n, start, self.d_scan.ptr, self.d_queue.ptr, self.d_tail.ptr)
+        tail = np.zeros(1, dtype=np.uint32)
+        hp.d2h(tail, self.d_tail.ptr)
+        return int(tail[0])
+
+    def dispatch_device(self, head: int, n_valid: int, size: int, key) -> None:
+        """One dense batch of survivors queue[head : head + n_valid] (padded to ``size`` with its first row, as the
+        reference pads, sampler.py:489-496): gather, sample, scatter - no host data."""
+        hp = self.hp
+        idx = self.d_queue.ptr + head * 4
+        hp.gather_rows_device(self.d_store.ptr, self.wf, idx, n_valid, size, self.d_fb.ptr)
+        hp.sample_batch_device(self.d_fb.ptr, size, self.num_f, key, self.d_ob.ptr,
+                               d_norm_dev=self.d_devs.ptr + self.n_dispatch * self.n_comp * 4)
+        hp.scatter_rows_device(self.d_ob.ptr, self.wo, idx, n_valid, self.d_rows.ptr)
+        self.n_dispatch += 1
 
     def release(self) -> None:
         """Give the device buffers back - also on the error paths (a normalisation error, a failed allocation or kernel)."""
@@ -261,6 +333,10 @@ class _DevicePostselect:
             hp.d2h(rows, d_c)
         else:
             rows = owner._download_bools(hp, self.d_rows, self.shots)
+        if self.n_dispatch:
+            devs = np.zeros(self.n_dispatch * self.n_comp, dtype=np.float32)
+            hp.d2h(devs, self.d_devs.ptr)
+            self.devs += [devs[k * self.n_comp:(k + 1) * self.n_comp] for k in range(self.n_dispatch)]
         self.release()
         for dev in self.devs:
             owner._check_devs(dev)
@@ -711,7 +787,10 @@ class _CompiledSamplerBase:
                 else _DevicePostselect(self, shots, size, test_mask, ref_det))
         on_device = isinstance(work, _DevicePostselect)
         try:
-            _run_postselected(shots, size, work, self._next_key)
+            if on_device:
+                _run_postselected_device(shots, size, work, self._next_key, self._channel_sampler.sample_packed)
+            else:
+                _run_postselected(shots, size, work, self._next_key)
             if on_device:
                 direct = self._direct_detector_mask
                 post = self._postselect_masks(test_mask, ref, ref_det, xor_observable_ref)

@@ -104,3 +104,31 @@ def test_teleportation_with_feedback_and_new_gates(hip):
                         ).compile_sampler(seed=4).sample(4096)
     # ISWAP sends the stabilizers X2, Z3 to Z2 Y3, Z2: qubit 3 holds +Y; SQRT_YY twice = YY flips qubit 4
     assert (m[:, 2] == 0).all() and (m[:, 3] == 1).all()
+
+
+@pytest.mark.parametrize("d", [3, 5, 7])
+def test_surface_code_memory_on_the_device_equals_the_host_path(hip, d):
+    """Programs without compiled components (every output direct): large requests run on the GPU - one ChannelSampler call
+    for all shots, as the reference's _sample_direct makes it (sampler.py:547-555), the streaming kernel for direct outputs
+    (d = 3, 5: at most 128 f bits and outputs) or the row kernel (d = 7) through tsim_sample_steps_device.  Same bits as
+    the host's numpy path for the same seed - bools, bit_packed, detectors only and with observables; with noise="device"
+    the statistics agree."""
+    from tsim_amd.circuits import rotated_surface_code_memory
+
+    c = CliffordCircuit(rotated_surface_code_memory(d, 3, after_clifford_depolarization=2e-3, before_measure_flip_probability=1e-3))
+    n = 70_000
+    dev = c.compile_detector_sampler(seed=4)
+    assert not dev._program.components and dev._direct_on_device(n)
+    got = dev.sample(n, append_observables=True)
+    host = c.compile_detector_sampler(seed=4)
+    want = host._sample_direct(n)
+    np.testing.assert_array_equal(got, want)
+    nd = dev._num_detectors
+    np.testing.assert_array_equal(c.compile_detector_sampler(seed=4).sample(n, bit_packed=True), np.packbits(want[:, :nd], axis=1, bitorder="little"))
+    np.testing.assert_array_equal(c.compile_detector_sampler(seed=4).sample(n, bit_packed=True, append_observables=True),
+                                  np.packbits(want, axis=1, bitorder="little"))
+    dn = c.compile_detector_sampler(seed=4, noise="device").sample(200_000, append_observables=True)
+    big = c.compile_detector_sampler(seed=9)._sample_direct(200_000)
+    pa, pb = dn.mean(axis=0), big.mean(axis=0)
+    sig = np.sqrt(np.maximum(pb * (1 - pb), 1e-9) * 2 / 200_000)
+    assert np.all(np.abs(pa - pb) < 6 * sig + 1e-5), float(np.max(np.abs(pa - pb) / (sig + 1e-9)))

@@ -452,7 +452,7 @@ class _CompiledSamplerBase:
         if shots == 0:
             rows, ref = np.empty((0, n_out), dtype=np.bool_), np.zeros(n_out, dtype=np.bool_)
         elif not self._program.components:
-            rows = self._sample_direct(shots)
+            rows = self._direct_device(shots, batch_size) if self._direct_on_device(shots) else self._sample_direct(shots)
             ref = self._compute_reference_sample() if compute_reference else None
         elif self._seam_replaced():
             plan = plan_batches(shots, batch_size, self._estimate_batch_size(), reserve_row=compute_reference)
@@ -460,6 +460,62 @@ class _CompiledSamplerBase:
         else:
             rows, ref = self._device_plain(shots, batch_size, compute_reference)
         return (rows, ref) if compute_reference else rows
+
+    # -- programs without compiled components (Clifford-only circuits) on the device ----------------------------------
+    def _direct_on_device(self, shots: int) -> bool:
+        """``noise="device"``: always (that is what was asked for).  ``noise="host"``: when a GPU is there and the request is
+        large enough to pay for the trip - the reference does this on the host (``_sample_direct``, sampler.py:547-555), the
+        numbers are the same either way (one ``ChannelSampler`` call for all shots, a deterministic function of its rows)."""
+        if self._seam_replaced() or int(self._program.num_outputs) == 0:
+            return False
+        if self._noise == "device":
+            return True
+        if shots < (1 << 15) or self._channel_sampler._native is None:
+            return False
+        try:
+            from . import _lib
+
+            _lib.load(build=False)
+            return _lib.device_count() > 0
+        except Exception:  # noqa: BLE001 - no library / no device: the host path is complete on its own
+            return False
+
+    def _direct_device(self, shots: int, batch_size: int | None, packed_columns: int | None = None) -> np.ndarray:
+        """Direct outputs by the streaming kernel (``tsim_direct.hip.h`` through ``tsim_sample_steps_device``).  Device noise:
+        the three-stage pipeline of :meth:`_device_noise_plain`.  Host noise: ONE ``sample_packed(shots)`` call - the
+        reference's stream for this request (sampler.py:549) - uploaded and processed in chunks."""
+        if self._noise == "device":
+            return self._device_noise_plain(shots, batch_size, False, packed_columns)[0]
+        hp = self._hip()
+        cs = self._channel_sampler
+        num_f, n_out = cs.num_f, int(self._program.num_outputs)
+        wf, wo = max(1, (num_f + 63) // 64), (n_out + 63) // 64
+        f_all = cs.sample_packed(shots)
+        chunk = min(shots, 1 << 20)
+        direct_packed = packed_columns is not None and packed_columns == n_out
+        row_bytes = (n_out + 7) // 8 if direct_packed else wo * 8
+        d_f, d_rows = self._scratch(hp, "direct_f", chunk * wf * 8), self._scratch(hp, "rows", chunk * row_bytes + 16)
+        if packed_columns is not None:
+            rb = (packed_columns + 7) // 8
+            out = np.empty((shots, rb), dtype=np.uint8)
+            d_c = d_rows if direct_packed else self._scratch(hp, "compact", chunk * rb + 16)
+        else:
+            out = np.empty((shots, n_out), dtype=np.uint8)
+            d_u8 = self._scratch(hp, "unpacked", chunk * n_out)
+        key_state = (C.c_uint32 * 2)(0, 0)  # (no random numbers in a program without components)
+        for lo in range(0, shots, chunk):
+            n = min(chunk, shots - lo)
+            hp.h2d(d_f, f_all[lo:lo + n])
+            hp.sample_steps_device([d_f.ptr], n, num_f, key_state, [d_rows.ptr], out_bit_packed=direct_packed)
+            hp.synchronize()
+            if packed_columns is not None:
+                if not direct_packed:
+                    hp.compact_rows_device(d_rows.ptr, n, packed_columns, d_c.ptr, in_words=wo)
+                hp.d2h(out[lo:lo + n], d_c.ptr)
+            else:
+                hp.unpack_bits_device(d_rows.ptr, n, n_out, d_u8.ptr)
+                hp.d2h(out[lo:lo + n], d_u8.ptr)
+        return out if packed_columns is not None else out.view(np.bool_)
 
     def _seam_plain(self, shots: int, plan: BatchPlan, want_ref: bool):
         parts, ref = [], None
@@ -945,6 +1001,10 @@ class CompiledDetectorSampler(_CompiledSamplerBase):
                 # the wanted columns are a prefix of the packed device rows: compact there, move width/8 bytes per shot
                 _check_request(shots, batch_size)
                 return self._device_plain(shots, batch_size, False, packed_columns=width)[0]
+            if (bit_packed and not separate_observables and not prepend_observables and width > 0 and shots > 0
+                    and not self._program.components and self._direct_on_device(shots)):
+                _check_request(shots, batch_size)
+                return self._direct_device(shots, batch_size, packed_columns=width)
             rows = self._sample_batches(shots, batch_size)
 
         det, obs = rows[:, :nd], rows[:, nd:]

@@ -296,6 +296,12 @@ int tsim_postselect_rows_device(tsim_program *p, uint8_t *d_rows, int64_t B, int
  * sampler.py:466-508: the order fixes the survivors' Threefry counters).  d_scratch: ceil(n / 1024) uint32. */
 int tsim_survivors_append_device(tsim_program *p, const uint8_t *d_gone, int64_t n, uint32_t base, uint32_t *d_scratch,
                                  uint32_t *d_queue, uint32_t *d_tail, void *stream);
+/* The epilogue of CompiledDetectorSampler.sample (sampler.py:850-868: detectors / observables prepended, appended,
+ * separate; reference-sample flips) and _maybe_bit_pack (:665-669) on the device: out column c = in column
+ * (d_cols[c] & 0x7FFFFFFF) XOR (d_cols[c] >> 31) of the padded rows, one byte per column (packed = 0) or
+ * ceil(n_cols / 8) bytes per row (packed = 1, np.packbits little-endian). */
+int tsim_arrange_rows_device(tsim_program *p, const uint64_t *d_in, int64_t B, int32_t in_words, const uint32_t *d_cols,
+                             int32_t n_cols, int32_t packed, uint8_t *d_out, void *stream);
 
 /* Row gather / scatter by index on packed rows of `words` 64-bit words - the data movement of the
  * reference's host-noise post-selection (src/tsim/sampler.py:466-508: survivors are compacted into dense

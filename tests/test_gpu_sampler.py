@@ -253,6 +253,50 @@ def test_host_noise_postselection_packed_rows_equal_the_bool_rows(hip, ref_flags
     np.testing.assert_array_equal(det_only, np.packbits(bools[:, :nd], axis=1, bitorder="little"))
 
 
+@pytest.mark.parametrize("noise", ["host", "device"])
+def test_output_arrangement_on_the_device_equals_the_numpy_epilogue(hip, noise):
+    """prepend / append / separate observables, the reference-sample flips and bit_packed in every combination: the
+    arrays sample() hands out are arranged on the device (tsim_arrange_rows_device); they must equal what the reference's
+    numpy epilogue (sampler.py:850-868, 665-669) makes of the plain rows and the reference sample of an identically
+    seeded twin - including the host-noise case, where the reference row rides as row 0 of the first batch."""
+    from tsim_amd import synth
+    from tsim_amd.channels import error_probs
+
+    prog, cfg = synth.config_program("C2")
+    nf = cfg["num_f"]
+    kw = dict(channel_probs=[error_probs(0.02)] * nf, error_transform=np.eye(nf, dtype=np.uint8), noise=noise)
+    mk = lambda: CompiledDetectorSampler(prog, seed=33, **kw)  # noqa: E731
+    n, bs = 130_001, 50_000
+    nd = mk()._num_detectors
+    plain_noref = mk()._sample_batches(n, bs)
+    plain_ref, ref = mk()._sample_batches(n, bs, compute_reference=True)
+    assert ref.any()
+    for flags in ({"prepend_observables": True}, {"prepend_observables": True, "append_observables": True},
+                  {"separate_observables": True}, {"use_detector_reference_sample": True},
+                  {"use_observable_reference_sample": True, "append_observables": True},
+                  {"use_detector_reference_sample": True, "use_observable_reference_sample": True, "separate_observables": True},
+                  {"use_detector_reference_sample": True, "prepend_observables": True}):
+        wants_ref = flags.get("use_detector_reference_sample") or flags.get("use_observable_reference_sample")
+        rows = (plain_ref if wants_ref else plain_noref).copy()
+        if flags.get("use_detector_reference_sample"):
+            rows[:, :nd] ^= ref[:nd]
+        if flags.get("use_observable_reference_sample"):
+            rows[:, nd:] ^= ref[nd:]
+        det, obs = rows[:, :nd], rows[:, nd:]
+        if flags.get("separate_observables"):
+            want = (det, obs)
+        elif flags.get("prepend_observables"):
+            want = (np.concatenate([obs, det] + ([obs] if flags.get("append_observables") else []), axis=1),)
+        else:
+            want = (rows if flags.get("append_observables") else det,)
+        for packed in (False, True):
+            got = mk().sample(n, batch_size=bs, bit_packed=packed, **flags)
+            got = got if isinstance(got, tuple) else (got,)
+            assert len(got) == len(want)
+            for g, w in zip(got, want):
+                np.testing.assert_array_equal(g, np.packbits(w, axis=1, bitorder="little") if packed else w, err_msg=f"{flags} packed={packed}")
+
+
 @pytest.mark.parametrize("nbits,B", [(20, 1001), (5, 7), (64, 300), (121, 4096), (8, 3)])
 def test_compact_rows_equals_numpy_packbits(hip, nbits, B):
     """tsim_compact_rows_device == np.packbits(bits, axis=1, bitorder="little") (sampler.py:665-669)."""

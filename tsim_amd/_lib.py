@@ -84,6 +84,7 @@ SYMBOLS: dict[str, tuple] = {
     "tsim_unpack_bits_device": (C.c_int, [_P, _P, _I64, _I32, _P, _P]),
     "tsim_compact_rows_device": (C.c_int, [_P, _P, _I64, _I32, _I32, _P, _P]),
     "tsim_postselect_rows_device": (C.c_int, [_P, _P, _I64, _I32, _P, _P, _P]),
+    "tsim_arrange_rows_device": (C.c_int, [_P, _P, _I64, _I32, _P, _I32, _I32, _P, _P]),
     "tsim_survivors_append_device": (C.c_int, [_P, _P, _I64, C.c_uint32, _P, _P, _P, _P]),
     "tsim_gather_rows_device": (C.c_int, [_P, _P, _I32, _P, _I64, _I64, _P, _P]),
     "tsim_scatter_rows_device": (C.c_int, [_P, _P, _I32, _P, _I64, _P, _P]),

@@ -338,6 +338,11 @@ class HipProgram:
             "tsim_compact_rows_device",
         )
 
+    def arrange_rows_device(self, d_in: int, B: int, in_words: int, d_cols: int, n_cols: int, packed: bool, d_out: int, *, stream: int = 0) -> None:
+        """Column selection / order / constant flips of padded rows, as bytes or bit-packed (``tsim_arrange_rows_device``)."""
+        _lib.check(self._lib.tsim_arrange_rows_device(self._h, C.c_void_p(d_in), int(B), int(in_words), C.c_void_p(d_cols), int(n_cols),
+                                                      1 if packed else 0, C.c_void_p(d_out), stream or None), "tsim_arrange_rows_device")
+
     def survivors_append_device(self, d_gone: int, n: int, base: int, d_scratch: int, d_queue: int, d_tail: int) -> None:
         """Append the shot ids ``base + i`` of the rows with ``gone[i] == 0``, in order, to a device queue (``tsim_survivors_append_device``)."""
         _lib.check(self._lib.tsim_survivors_append_device(self._h, C.c_void_p(d_gone), int(n), int(base), C.c_void_p(d_scratch),

@@ -203,6 +203,51 @@ extern "C" int tsim_survivors_append_device(tsim_program *p, const uint8_t *d_go
   return TSIM_OK;
 }
 
+// ---------------------------------------------------------------------------
+// Output arrangement on the device (CompiledDetectorSampler.sample's epilogue, sampler.py:850-868, and _maybe_bit_pack,
+// :665-669): out column c = in column (cols[c] & 0x7FFFFFFF) XOR (cols[c] >> 31), as one byte per column
+// (bool arrays) or bit-packed, np.packbits(..., axis=1, bitorder="little").  Covers detectors only / appended /
+// prepended / separate observables and the reference-sample flips without a host pass over the rows.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_arrange_rows(const uint64_t *__restrict__ in, long long B, int WO, const uint32_t *__restrict__ cols,
+                                                      int n_cols, int packed, uint8_t *__restrict__ out) {
+  const long long row = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (row >= B) return;
+  const uint32_t *w = reinterpret_cast<const uint32_t *>(in + row * WO);
+  if (!packed) {
+    uint8_t *dst = out + row * n_cols;
+    for (int c = 0; c < n_cols; ++c) {
+      const uint32_t s = cols[c], src = s & 0x7FFFFFFFu;
+      dst[c] = (uint8_t)(((w[src >> 5] >> (src & 31u)) ^ (s >> 31)) & 1u);
+    }
+    return;
+  }
+  const int rb = (n_cols + 7) / 8;
+  uint8_t *dst = out + row * rb;
+  uint32_t acc = 0u;
+  for (int c = 0; c < n_cols; ++c) {
+    const uint32_t s = cols[c], src = s & 0x7FFFFFFFu;
+    acc |= (((w[src >> 5] >> (src & 31u)) ^ (s >> 31)) & 1u) << (c & 7);
+    if ((c & 7) == 7 || c == n_cols - 1) {
+      dst[c >> 3] = (uint8_t)acc;
+      acc = 0u;
+    }
+  }
+}
+
+extern "C" int tsim_arrange_rows_device(tsim_program *p, const uint64_t *d_in, int64_t B, int32_t in_words, const uint32_t *d_cols,
+                                        int32_t n_cols, int32_t packed, uint8_t *d_out, void *stream) {
+  if (int r = tsim_need_final(p)) return r;
+  if (int r = tsim_set_device(p)) return r;
+  if (B < 0 || n_cols < 0 || in_words < 1) return tsim_fail(TSIM_EINVAL, "bad size");
+  if (B == 0 || n_cols == 0) return TSIM_OK;
+  if (!d_in || !d_cols || !d_out) return tsim_fail(TSIM_EINVAL, "NULL buffer");
+  hipLaunchKernelGGL(k_arrange_rows, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, stream ? (hipStream_t)stream : p->stream, d_in,
+                     (long long)B, (int)in_words, d_cols, (int)n_cols, (int)packed, d_out);
+  HIP_TRY(hipGetLastError());
+  return TSIM_OK;
+}
+
 extern "C" int tsim_gather_rows_device(tsim_program *p, const uint64_t *d_src, int32_t words, const uint32_t *d_index,
                                        int64_t n_valid, int64_t n_total, uint64_t *d_dst, void *stream) {
   if (int r = tsim_need_final(p)) return r;

@@ -580,8 +580,37 @@ class _CompiledSamplerBase:
         hp.d2h(host, d_u8.ptr)
         return host.view(np.bool_)
 
+    # -- output arrangement on the device (sample()'s epilogue, sampler.py:850-868) -------------------------------------
+    def _layout_blocks(self, hp: HipProgram, layout: list, total: int) -> list:
+        """Per wanted output block: device column table, device staging and a pinned host array."""
+        pool = result_pool()
+        blocks = []
+        for k, (cols, packed) in enumerate(layout):
+            cols = np.ascontiguousarray(cols, dtype=np.uint32)
+            n_cols = len(cols)
+            nbytes = (n_cols + 7) // 8 if packed else n_cols
+            blk = {"n_cols": n_cols, "packed": bool(packed), "nbytes": nbytes, "out": pool.take((total, nbytes)) if nbytes else np.empty((total, 0), np.uint8)}
+            if nbytes:
+                blk["d_cols"] = self._scratch(hp, f"cols{k}", n_cols * 4 + 16)
+                hp.h2d(blk["d_cols"], cols)
+                blk["d_arr"] = self._scratch(hp, f"arranged{k}", total * nbytes + 16)
+            blocks.append(blk)
+        return blocks
+
+    def _layout_download(self, hp: HipProgram, blocks: list, d_rows_ptr: int, wo: int, r0: int, r1: int, stream: int) -> None:
+        for blk in blocks:
+            if not blk["nbytes"]:
+                continue
+            dst = blk["d_arr"].ptr + r0 * blk["nbytes"]
+            hp.arrange_rows_device(d_rows_ptr, r1 - r0, wo, blk["d_cols"].ptr, blk["n_cols"], blk["packed"], dst, stream=stream)
+            hp.d2h_async(blk["out"][r0:r1], dst, stream)
+
+    @staticmethod
+    def _layout_result(blocks: list, lo: int, hi: int) -> list:
+        return [(b["out"][lo:hi] if b["packed"] else b["out"][lo:hi].view(np.bool_)) for b in blocks]
+
     def _device_noise_plain(self, shots: int, batch_size: int | None, want_ref: bool, packed_columns: int | None = None,
-                            post: dict | None = None):
+                            post: dict | None = None, layout: list | None = None):
         """``noise="device"``: three things at once - ``k_noise`` fills the f rows of group g + 1 on its own stream, the
         sampling kernels of group g run on the pipeline lanes (``tsim_sample_steps_device``: fused first passes, one
         hard-row batch per group), the rows of group g - 1 travel to the host on a copy stream.  A group is a few
@@ -605,14 +634,18 @@ class _CompiledSamplerBase:
                     buf.free()
             self._f_ring = ring = (hp, size * wf * 8, [hp.malloc(size * wf * 8) for _ in range(nslot)])
         f_ring = ring[2]
-        direct_packed = packed_columns is not None and packed_columns == n_out
+        direct_packed = layout is None and packed_columns is not None and packed_columns == n_out
         row_bytes = (n_out + 7) // 8 if direct_packed else wo * 8
         d_rows, d_devs = self._scratch(hp, "rows", total * row_bytes + 16), self._scratch(hp, "devs", plan.count * n_comp * 4)
         noise = self._device_noise_sampler(hp)
         s_noise, s_copy = hp.aux_stream(0), hp.aux_stream(1)
         # results land in recycled pinned memory (backend.PinnedPool): truly asynchronous copies, no first-touch page faults
         pool = result_pool()
-        if direct_packed:
+        blocks = None
+        if layout is not None:  # column selection / order / flips / packing per output block, on the device
+            blocks = self._layout_blocks(hp, layout, total)
+            out = None
+        elif direct_packed:
             out = pool.take((total, row_bytes))
         elif packed_columns is not None:
             rb = (packed_columns + 7) // 8
@@ -649,7 +682,9 @@ class _CompiledSamplerBase:
             r0, r1 = lo * size, (lo + n) * size
             if post is not None:  # blank the discarded rows where they are, before any layout conversion
                 hp.postselect_rows_device(d_rows.ptr + r0 * row_bytes, r1 - r0, row_bytes, d_masks.ptr, d_gone.ptr + r0, stream=s_copy)
-            if direct_packed:
+            if blocks is not None:
+                self._layout_download(hp, blocks, d_rows.ptr + r0 * row_bytes, wo, r0, r1, s_copy)
+            elif direct_packed:
                 hp.d2h_async(out[r0:r1], d_rows.ptr + r0 * row_bytes, s_copy)
             elif packed_columns is not None:
                 hp.compact_rows_device(d_rows.ptr + r0 * row_bytes, r1 - r0, packed_columns, d_c.ptr + r0 * rb, in_words=wo, stream=s_copy)
@@ -685,15 +720,19 @@ class _CompiledSamplerBase:
         hp.stream_synchronize(s_copy)
         for b in range(plan.count):
             self._check_devs(devs[b * n_comp:(b + 1) * n_comp])
-        res = out[:shots]
-        res = res if (direct_packed or packed_columns is not None) else res.view(np.bool_)
+        if blocks is not None:
+            res = self._layout_result(blocks, 0, shots)
+        else:
+            res = out[:shots]
+            res = res if (direct_packed or packed_columns is not None) else res.view(np.bool_)
         if post is not None:
             gone = np.empty(total, dtype=np.uint8)
             hp.d2h(gone, d_gone.ptr)
             return res, ref, gone[:shots].view(np.bool_)
         return res, ref
 
-    def _device_plain(self, shots: int, batch_size: int | None, want_ref: bool, packed_columns: int | None = None):
+    def _device_plain(self, shots: int, batch_size: int | None, want_ref: bool, packed_columns: int | None = None,
+                      layout: list | None = None):
         """noise -> f -> ``sample_program`` -> layout conversion, the GPU busy beside the channel sampler.
 
         ``noise="device"``: :meth:`_device_noise_plain`.  ``noise="host"`` (the reference's numpy/PCG64 stream, bit for
@@ -704,7 +743,7 @@ class _CompiledSamplerBase:
         (asynchronous copy into recycled pinned result memory).  Wall time = the sampler's, plus the last batch's trip.
         The reference row, when wanted, is row 0 of the first batch (``sampler.py:395-404``)."""
         if self._noise != "host":
-            return self._device_noise_plain(shots, batch_size, want_ref, packed_columns)
+            return self._device_noise_plain(shots, batch_size, want_ref, packed_columns, layout=layout)
         import queue
         import threading
 
@@ -719,12 +758,16 @@ class _CompiledSamplerBase:
         total, size = plan.size * plan.count, plan.size
         lanes = self._lane_buffers(hp, size * wf * 8)
         # all columns wanted bit-packed: the kernels write that layout themselves (no padded rows, no compaction pass)
-        direct_packed = packed_columns is not None and packed_columns == n_out
+        direct_packed = layout is None and packed_columns is not None and packed_columns == n_out
         row_bytes = (n_out + 7) // 8 if direct_packed else wo * 8
         d_rows, d_devs = self._scratch(hp, "rows", total * row_bytes + 16), self._scratch(hp, "devs", plan.count * n_comp * 4)
         s_up, s_copy = hp.aux_stream(0), hp.aux_stream(1)
         pool = result_pool()
-        if direct_packed:
+        blocks = None
+        if layout is not None:
+            blocks = self._layout_blocks(hp, layout, total)
+            out = None
+        elif direct_packed:
             out = pool.take((total, row_bytes))
         elif packed_columns is not None:
             rb = (packed_columns + 7) // 8
@@ -759,7 +802,9 @@ class _CompiledSamplerBase:
         def download(b: int) -> None:
             hp.sample_batch_device_end(b % _LANES, s_copy)  # the copy stream waits for exactly this batch
             r0, r1 = b * size, (b + 1) * size
-            if direct_packed:
+            if blocks is not None:
+                self._layout_download(hp, blocks, d_rows.ptr + r0 * row_bytes, wo, r0, r1, s_copy)
+            elif direct_packed:
                 hp.d2h_async(out[r0:r1], d_rows.ptr + r0 * row_bytes, s_copy)
             elif packed_columns is not None:
                 hp.compact_rows_device(d_rows.ptr + r0 * row_bytes, size, packed_columns, d_c.ptr + r0 * rb, in_words=wo, stream=s_copy)
@@ -798,7 +843,9 @@ class _CompiledSamplerBase:
         hp.stream_synchronize(s_copy)
         skip = 1 if rides else 0
         if rides:
-            if packed_columns is None:
+            if blocks is not None:  # (arranged output: the caller computed the reference row beforehand, see sample())
+                ref = None
+            elif packed_columns is None:
                 ref = out[0].view(np.bool_).copy()
             else:  # the reference row is wanted as booleans whatever the layout of the rows: one more tiny download
                 one = np.zeros((1, n_out), dtype=np.uint8)
@@ -811,6 +858,8 @@ class _CompiledSamplerBase:
                     ref = one[0].view(np.bool_).copy()
         for b in range(plan.count):
             self._check_devs(devs[b * n_comp:(b + 1) * n_comp])
+        if blocks is not None:
+            return self._layout_result(blocks, skip, skip + shots), ref
         res = out[skip:skip + shots]
         return (res if packed_columns is not None else res.view(np.bool_)), ref
 
@@ -986,6 +1035,35 @@ class CompiledDetectorSampler(_CompiledSamplerBase):
                 xor_observable_ref=use_observable_reference_sample)
             if fast:
                 return rows
+        elif (shots > 0 and self._program.components and not self._seam_replaced()
+              and (want_ref or prepend_observables or (separate_observables and bit_packed))):
+            # everything sample() does to the rows - column blocks, their order, the reference-sample flips, bit-packing -
+            # happens on the device (tsim_arrange_rows_device); the host receives the arrays it hands out
+            _check_request(shots, batch_size)
+            ref = None
+            if want_ref:
+                if self._noise == "device":
+                    ref = self._compute_reference_sample()  # (its own key, then the batches: as _device_noise_plain does it)
+                else:
+                    # host noise: the reference row rides as row 0 of the first batch (sampler.py:395-404) - the same row, same
+                    # subkey, same in-batch index computed here first, so that its bits are known before the rows are arranged
+                    quiet = np.zeros((1, self._channel_sampler.num_f), dtype=np.uint8)
+                    ref = np.asarray(self._seam(quiet, prng.split(self._key)[1])[0], dtype=np.bool_)
+            det = np.arange(nd, dtype=np.uint32)
+            obs = np.arange(nd, n_out, dtype=np.uint32)
+            if ref is not None and use_detector_reference_sample:
+                det = det | (ref[:nd].astype(np.uint32) << np.uint32(31))
+            if ref is not None and use_observable_reference_sample:
+                obs = obs | (ref[nd:].astype(np.uint32) << np.uint32(31))
+            if separate_observables:
+                cols = [det, obs]
+            elif prepend_observables:
+                cols = [np.concatenate([obs, det] + ([obs] if append_observables else []))]
+            else:
+                cols = [np.concatenate([det, obs]) if append_observables else det]
+            rides = want_ref and self._noise != "device"
+            res = self._device_plain(shots, batch_size, rides, layout=[(c, bit_packed) for c in cols])[0]
+            return tuple(res) if separate_observables else res[0]
         elif want_ref:
             rows, ref = self._sample_batches(shots, batch_size, compute_reference=True)
             flip = np.zeros(n_out, dtype=np.bool_)

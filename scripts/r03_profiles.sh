@@ -33,9 +33,11 @@ if want e2e; then
     g++ -O3 -std=c++17 -msse4.1 -ffp-contract=off -pthread scripts/microbench/pcg_probe.cpp -o /tmp/pcg_probe && /tmp/pcg_probe; lscpu | grep -E "Model name|^CPU\(s\)"; cat /sys/fs/cgroup/cpu.max; } > $O/e2e.txt 2>&1
 fi
 if want breakdown; then
+  # diagnostic builds that leave parts of the first pass out (wrong results; built here when absent: hipcc is on the box)
+  for m in 1 2 4 16 32 64 112 113; do [ -f scripts/_ab_skip$m.so ] || scripts/build_variant.sh WORK scripts/_ab_skip$m.so -DTSIMK_LWM_SKIP=$m > /dev/null 2>&1; done
   { echo "fused first pass alone (scripts/lwm_probe.py: 8 batches per launch, serial launches, HIP events), parts left out (diagnostic builds, wrong results):";
     echo -n "everything                         : "; python scripts/lwm_probe.py C2 | tail -1
-    for m in 1 2 4 16 32 64 112 113; do echo -n "TSIMK_LWM_SKIP=$m : "; TSIM_AMD_LIB=scripts/_ab_skip$m.so python scripts/lwm_probe.py C2 2>&1 | tail -1; done;
+    for m in 1 2 4 16 32 64 112 113; do echo -n "TSIMK_LWM_SKIP=$m : "; TSIM_AMD_ALLOW_STALE=1 TSIM_AMD_LIB=scripts/_ab_skip$m.so python scripts/lwm_probe.py C2 2>&1 | tail -1; done;
     echo "(1 = no Threefry blocks, 2 = no direct outputs, 4 = no rank loop, 16 = no stores, 32 = no threshold reads, 64 = no f loads, 112 = no memory at all, 113 = no memory and no Threefry)";
     echo -n "generic fused pass (TSIM_AMD_LW_FAST=0): "; TSIM_AMD_LW_FAST=0 python scripts/lwm_probe.py C2 | tail -1; echo -n "C3: "; python scripts/lwm_probe.py C3 | tail -1; } > $O/first_pass_breakdown.txt 2>&1
 fi

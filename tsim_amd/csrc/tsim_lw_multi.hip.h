@@ -20,7 +20,7 @@ namespace tsimk {
 #define TSIMK_LWM_SKIP 0
 #endif
 
-#define TSIMK_LWM_MAX_STEPS 8
+#define TSIMK_LWM_MAX_STEPS 16
 #define TSIMK_LWM_KEYS 16  // compiled outputs per program the fused launch carries subkeys for
 
 struct LwStep {

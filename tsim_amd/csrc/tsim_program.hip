@@ -679,7 +679,7 @@ retry_pack:
     p->knobs.hard_lag = env_int("TSIM_AMD_HARD_LAG", 0) != 0;
     p->knobs.fused_lanes = std::max(0, std::min(4, env_int("TSIM_AMD_FUSED_LANES", 0)));
     p->knobs.hard_wave_rows = std::max(0, env_int("TSIM_AMD_HARD_WAVE_ROWS", 1024));
-    p->knobs.fused_max = std::max(1, std::min(TSIMK_H_MAX_CTX, env_int("TSIM_AMD_FUSED_MAX", TSIMK_H_MAX_CTX)));
+    p->knobs.fused_max = std::max(1, std::min(TSIMK_LWM_MAX_STEPS, env_int("TSIM_AMD_FUSED_MAX", 8)));
   }
 
   // ---- upload ----

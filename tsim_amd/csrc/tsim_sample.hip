@@ -312,6 +312,21 @@ static int flush_batch(tsim_program *p) {
   return 0;
 }
 
+// p->deferred in batches of at most TSIMK_H_MAX_CTX launches (a hard-row grid carries that many contexts in its kernel
+// arguments; fused groups may be larger), all on the stream the caller chose
+static int flush_chunks(tsim_program *p) {
+  if ((int)p->deferred.size() <= TSIMK_H_MAX_CTX) return flush_batch(p);
+  std::vector<int> all;
+  all.swap(p->deferred);
+  hipStream_t inl = p->flush_inline;
+  for (size_t i = 0; i < all.size(); i += TSIMK_H_MAX_CTX) {
+    p->deferred.assign(all.begin() + i, all.begin() + std::min(all.size(), i + (size_t)TSIMK_H_MAX_CTX));
+    p->flush_inline = inl;
+    if (int r = flush_batch(p)) return r;
+  }
+  return 0;
+}
+
 // Everything that is waiting: the lagged groups of the several-batches call (steps_group_fused: a fused group's hard rows
 // wait for the lane's NEXT first pass, so that the lane is not held up by a latency-bound grid between two first passes),
 // each as a batch on its own lane, then the launches parked by the per-step API.
@@ -326,11 +341,11 @@ int tsim_flush_hard(tsim_program *p) {
       p->deferred.swap(p->lag[li]);
       p->lag[li].clear();
       p->flush_inline = p->slots[1 + li].side;
-      if (int r = flush_batch(p)) return r;
+      if (int r = flush_chunks(p)) return r;
     }
     p->deferred.swap(keep);
   }
-  return flush_batch(p);
+  return flush_chunks(p);
 }
 
 // The arguments every sampling kernel of one launch shares (SampleArgs): per-output subkeys - key, subkey =
@@ -966,14 +981,14 @@ static int steps_group_fused(tsim_program *p, int n, const uint64_t *const *d_f,
         p->deferred.swap(p->lag[li]);
         p->lag[li].clear();
         p->flush_inline = s;
-        r = flush_batch(p);
+        r = flush_chunks(p);
       }
       p->lag[li].swap(mine);
       return r;
     }
     p->flush_inline = s;
   }
-  return flush_batch(p);
+  return flush_chunks(p);
 }
 
 // Programs without components (Clifford-only circuits): up to TSIMK_DIRECT_MAX_STEPS batches as one streaming grid

@@ -427,10 +427,14 @@ def main() -> None:
     # yet to confirm the arithmetic.
     # Default: "root0" - the north star's collective; "alltoall" is the hypothesis above, to be chosen by the first N > 1
     # measurement (TSIM_BENCH_GATHER=alltoall), not by arithmetic.
-    GATHER_MODE = os.environ.get("TSIM_BENCH_GATHER", "root0")
+    # N > 1 and no TSIM_BENCH_GATHER: "measured" - both collectives are timed on this node before anything else (three of
+    # each on a group buffer, max over ranks) and the faster one collects the rows; the timings go into the JSON line
+    # (`gather_calibration`).  That is the N > 1 measurement the choice was waiting for, made where the run happens.
+    GATHER_MODE = os.environ.get("TSIM_BENCH_GATHER", "measured" if (use_dist and N > 1) else "root0")
     if GATHER_MODE == "auto":
-        GATHER_MODE = "root0"
-    if GATHER_MODE == "alltoall":
+        GATHER_MODE = "measured" if (use_dist and N > 1) else "root0"
+    gather_calibration = None
+    if GATHER_MODE in ("alltoall", "measured"):
         GATHER_EVERY = (GATHER_EVERY + N - 1) // N * N
     # results are written in the reference's bit_packed layout (sampler.py:665-669: ceil(n_out/8) bytes per shot,
     # TSIM_PIPE_OUT_BIT_PACKED) - the algorithmic output bytes, not the padded 8-byte device word
@@ -449,6 +453,25 @@ def main() -> None:
         join_ptr = hp.pipeline_lane_stream(2)   # where deferred hard-row batches - i.e. results - complete
         main_ptr = hp.stream_ptr()               # first-pass lane 0
         grp = [hp.malloc(GATHER_EVERY * B * RB) for _ in range(2)]
+        if GATHER_MODE == "measured":
+            recv_all = hp.malloc((N if rank == 0 else 1) * GATHER_EVERY * B * RB)
+            times = {}
+            for mode in ("root0", "alltoall"):
+                comm.barrier()
+                lib.tsim_device_synchronize(local_rank)
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    if mode == "alltoall":
+                        comm.alltoall_rows(grp[0].ptr, recv_all.ptr, GATHER_EVERY // N * B * RB, stream=0)
+                    else:
+                        comm.gather_rows(grp[0].ptr, GATHER_EVERY * B * RB, recv_all.ptr if rank == 0 else 0, root=0, stream=0)
+                lib.tsim_device_synchronize(local_rank)
+                times[mode] = comm.allreduce_max((time.perf_counter() - t0) / 3)
+            recv_all.free()
+            GATHER_MODE = "alltoall" if times["alltoall"] < 0.9 * times["root0"] else "root0"  # (the north star's gather unless clearly slower)
+            gather_calibration = {"batches_per_collective": GATHER_EVERY, "bytes_per_rank": GATHER_EVERY * B * RB,
+                                  "root0_ms": times["root0"] * 1e3, "alltoall_ms": times["alltoall"] * 1e3, "chosen": GATHER_MODE,
+                                  "rule": "alltoall (roots spread over the ranks) when it takes less than 0.9 x the gather to rank 0, measured here"}
         if GATHER_MODE == "alltoall":  # (rank 0 also takes the gather of a partial last group: N senders)
             grp_recv = [hp.malloc((N if rank == 0 else 1) * GATHER_EVERY * B * RB) for _ in range(2)]
         else:
@@ -463,6 +486,7 @@ def main() -> None:
     gathered = [0]  # groups whose collective has been issued
     begin_split = lib.tsim_sample_batch_device_begin_split
     end_fn = lib.tsim_sample_batch_device_end
+    join_fn = lib.tsim_pipeline_join
     wait_fn = lib.tsim_pipeline_wait_stream
     h_prog = hp._h
 
@@ -518,8 +542,7 @@ def main() -> None:
             step_no[0] = j + n
             done += n
             if pos + n == GATHER_EVERY:  # group complete: join every slot on the join lane, then collect
-                for q in range(backend.HipProgram.PIPELINE_SLOTS):
-                    end_fn(h_prog, q, join_ptr)
+                join_fn(h_prog, join_ptr)
                 gather_next(GATHER_EVERY)
 
     def steps(k: int, f_list=f_bufs) -> None:
@@ -575,8 +598,7 @@ def main() -> None:
         if rc < 0:
             raise RuntimeError(f"pipelined launch failed ({rc}): {_lib.last_error()}")
         if pos == GATHER_EVERY - 1:  # group complete: join every slot on the join lane, then collect
-            for k in range(NSLOT):
-                end_fn(h_prog, k, join_ptr)
+            join_fn(h_prog, join_ptr)
             gather_next(GATHER_EVERY)
 
     def drain() -> None:
@@ -589,8 +611,7 @@ def main() -> None:
                 for k in range(NSLOT):
                     hp.sample_batch_device_end(k)
             return
-        for k in range(backend.HipProgram.PIPELINE_SLOTS):
-            end_fn(h_prog, k, join_ptr)
+        join_fn(h_prog, join_ptr)
         n_steps = step_no[0]
         while gathered[0] * GATHER_EVERY < n_steps:
             gather_next(min(GATHER_EVERY, n_steps - gathered[0] * GATHER_EVERY))
@@ -876,6 +897,8 @@ def main() -> None:
         }
         if verify is not None:
             res["verify"] = verify
+        if gather_calibration is not None:
+            res["gather_calibration"] = gather_calibration
         if args.approx or args.live_padding or args.program:
             res["config"]["variant"] = ("approximate floatfactors (compile/evaluate.py:56-59) " if args.approx else "") + \
                 ("live padding " if args.live_padding else "") + (f"exported program {args.program}" if args.program else "")

@@ -222,6 +222,9 @@ int tsim_sample_batch_device_end(tsim_program *p, int32_t slot, void *stream);
  * one event for all lanes.  Launches whose buffers depend only on that work may then pass
  * TSIM_PIPE_INPUTS_READY (bench.py: once per gather group instead of once per launch). */
 int tsim_pipeline_wait_stream(tsim_program *p, void *stream);
+/* tsim_sample_batch_device_end(slot, stream) for every slot that has a launch in flight: `stream` is then behind everything the
+ * pipeline has been given (one call; NULL = the handle's stream). */
+int tsim_pipeline_join(tsim_program *p, void *stream);
 /* The stream of lane `lane` (= of slot `lane`; created on demand).  Lane 2 is where the deferred
  * hard-row batches run, i.e. where results complete: a consumer that joins its slots on THAT stream
  * (tsim_sample_batch_device_end(p, slot, lane2)) and queues its own work there (bench.py: the RCCL

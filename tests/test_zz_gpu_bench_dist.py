@@ -22,7 +22,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("mode", ["alltoall", "root0", "default"])
+@pytest.mark.parametrize("mode", ["alltoall", "root0", "default", "measured"])
 def test_bench_distributed_path_on_one_gpu(hip, mode):
     env = dict(os.environ, TSIM_BENCH_FORCE_DIST="1", TSIM_BENCH_VERIFY="1", MASTER_ADDR="127.0.0.1",
                MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
@@ -41,7 +41,12 @@ def test_bench_distributed_path_on_one_gpu(hip, mode):
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 1 and d["steps"] == 21 and d["value"] > 0 and d["scaling"] == "weak"
-    assert ("all-to-all" in d["config"]["sharding"]) == (mode == "alltoall")
+    if mode == "measured":  # the N > 1 default: both collectives timed in place, the faster one used (and its bytes checked below)
+        cal = d["gather_calibration"]
+        assert cal["root0_ms"] > 0 and cal["alltoall_ms"] > 0 and cal["chosen"] in ("root0", "alltoall")
+        assert ("all-to-all" in d["config"]["sharding"]) == (cal["chosen"] == "alltoall")
+    else:
+        assert ("all-to-all" in d["config"]["sharding"]) == (mode == "alltoall")
     if mode == "default":
         assert "every 8 batches" in d["config"]["sharding"] and "gather to rank 0" in d["config"]["sharding"]
     assert d["roofline"]["achieved"] > 0 and d["roofline"]["launches"] >= 3

@@ -431,6 +431,10 @@ class HipProgram:
         _lib.check(self._lib.tsim_profile_read_steps(self._h, C.byref(n), 1 if reset else 0), "tsim_profile_read_steps")
         return int(n.value)
 
+    def pipeline_join(self, stream: int = 0) -> None:
+        """``sample_batch_device_end`` for every slot with a launch in flight, in one call."""
+        _lib.check(self._lib.tsim_pipeline_join(self._h, stream or None), "tsim_pipeline_join")
+
     def sample_batch_device_end(self, slot: int, stream: int = 0) -> None:
         """Make ``stream`` (0: the handle's stream) wait for the slot's second pass."""
         _lib.check(self._lib.tsim_sample_batch_device_end(self._h, int(slot), stream or None), "tsim_sample_batch_device_end")

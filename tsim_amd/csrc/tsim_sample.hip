@@ -1252,6 +1252,16 @@ extern "C" int tsim_sample_batch_device_end(tsim_program *p, int32_t slot, void 
   return TSIM_OK;
 }
 
+// tsim_sample_batch_device_end for EVERY slot in one call (joining a pipeline on `stream`: one library call instead of
+// TSIM_PIPELINE_SLOTS - 32 ctypes round trips per gather group were ~60 us of host time in bench.py's N > 1 path)
+extern "C" int tsim_pipeline_join(tsim_program *p, void *stream) {
+  if (int r = tsim_need_final(p)) return r;
+  for (int slot = 0; slot < TSIM_PIPELINE_SLOTS; ++slot)
+    if (p->slots[1 + slot].pending || p->slots[1 + slot].deferred)
+      if (int r = tsim_sample_batch_device_end(p, slot, stream)) return r;
+  return TSIM_OK;
+}
+
 extern "C" int tsim_sample_batch_device(tsim_program *p, const uint64_t *d_f, int64_t B, int32_t num_f,
                                         uint32_t key_hi, uint32_t key_lo, int64_t shot_offset,
                                         uint64_t *d_out, float *d_max_norm_dev, void *stream) {

@@ -713,8 +713,7 @@ class _CompiledSamplerBase:
             download(groups[done])
             done += 1
         self._key = (int(key_state[0]), int(key_state[1]))
-        for sl in range(nslot):
-            hp.sample_batch_device_end(sl)  # the handle's stream is behind everything (the devs copy below runs there)
+        hp.pipeline_join()  # the handle's stream is behind everything (the devs copy below runs there)
         devs = np.zeros(plan.count * n_comp, dtype=np.float32)
         hp.d2h(devs, d_devs.ptr)
         hp.stream_synchronize(s_copy)

@@ -452,6 +452,7 @@ def main() -> None:
     if use_dist:
         join_ptr = hp.pipeline_lane_stream(2)   # where deferred hard-row batches - i.e. results - complete
         main_ptr = hp.stream_ptr()               # first-pass lane 0
+        lane_ptrs = [main_ptr, hp.pipeline_lane_stream(1), join_ptr]  # the lanes fused groups run on (two, three for small groups)
         grp = [hp.malloc(GATHER_EVERY * B * RB) for _ in range(2)]
         if GATHER_MODE == "measured":
             recv_all = hp.malloc((N if rank == 0 else 1) * GATHER_EVERY * B * RB)
@@ -522,15 +523,15 @@ def main() -> None:
             g, pos = (j // GATHER_EVERY) & 1, j % GATHER_EVERY
             n = min(k - done, GATHER_EVERY - pos)
             rc = 0
-            if pos == 0:
-                if grp_used[g]:
-                    # the collective that last read this group buffer (two groups ago) must be done before kernels
-                    # overwrite it: first-pass lane 0 waits for THAT marker only (waiting for the whole join lane would
-                    # drain the pipeline once per group); the other lanes are ordered after lane 0 just below
-                    comm.wait_mark(g, main_ptr)
+            if launched[0] < NSLOT:  # (the very first launches of the run create the lanes)
                 rc = wait_fn(h_prog, None)
-            elif launched[0] < NSLOT:  # (the very first launches of the run create the lanes)
-                rc = wait_fn(h_prog, None)
+            if pos == 0 and grp_used[g]:
+                # the collective that last read this group buffer (two groups ago) must be done before kernels overwrite
+                # it: every first-pass lane waits for THAT marker - and for nothing else (ordering the lanes behind
+                # lane 0's whole queue, as rounds 1-2 did, made consecutive groups run one after the other: 21.8 us per
+                # step at --steps 20 on the forced one-GPU path where the plain path takes 14.6)
+                for lp in lane_ptrs:
+                    comm.wait_mark(g, lp)
             if rc >= 0:
                 fa = (C.c_void_p * n)(*[f_list[(j + i) % len(f_list)].ptr for i in range(n)])
                 oa = (C.c_void_p * n)(*[grp[g].ptr + (pos + i) * B * RB for i in range(n)])

@@ -653,9 +653,9 @@ def main() -> None:
     if not PER_STEP:
         # a fused first pass serves up to 8 batches; a bracket (two timing events on the lane) costs ~7 us of a ~100-us
         # kernel and, worse, a bubble on the lane: bracketing EVERY launch cost 7 % of the step rate (12.7 -> 11.8 us at
-        # --steps 200).  About 16 bracketed launches over all repetitions together.
+        # --steps 200).  About 8 bracketed launches over all repetitions together.
         launches_per_rep = max(1, -(-args.steps // 8))
-        PROF_EVERY = max(1, launches_per_rep * max(1, args.repeats) // 16)
+        PROF_EVERY = max(1, launches_per_rep * max(1, args.repeats) // 8)  # (about one bracketed launch per repetition at --steps 20)
     if os.environ.get("TSIM_BENCH_PROF_EVERY"):
         PROF_EVERY = max(1, int(os.environ["TSIM_BENCH_PROF_EVERY"]))
     PROF_LEVEL = 0 if os.environ.get("TSIM_BENCH_NO_PROFILE") == "1" else 2

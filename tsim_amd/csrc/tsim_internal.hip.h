@@ -143,6 +143,7 @@ struct tsim_program {
   int v4w_occ_blocks = 1;     // blocks of the sparse-column kernel a CU holds at once with v4w_occ_lds bytes of LDS
   size_t v4w_occ_lds = 0;
   bool lw_reg = false;        // the register form of pass 1 applies (narrow f rows, ascending f_selection)
+  int lwfm_off = 0;           // fast record of programs with 2..4 components of <= 8 outputs each (k_sample_lw_fastm), 0 = none
   int lwf_off = 0;            // image offset of the fast record (one component of <= 8 outputs: k_sample_lw_fast), 0 = none
   // Launch slots: slot 0 serves the serial API (everything on the caller's stream); slots 1..4 serve
   // tsim_sample_batch_device_begin/_end: a slot's launches run on the slot's own stream (`side`) so

@@ -1,7 +1,7 @@
 // tsim_program.hip - handle life cycle of the C ABI (include/tsim_hip.h): program description ->
 // packed image -> upload, plus the memory / stream plumbing.  No kernels are defined here.
 #include "tsim_internal.hip.h"
-#include "tsim_lw_fast.hip.h"
+#include "tsim_lw_fastm.hip.h"
 #include "tsim_kernel4w.hip.h"  // C4_SELMASK
 
 using namespace tsimk;
@@ -634,6 +634,85 @@ retry_pack:
             h[LWF_RANK] = rank_off;
             h[LWF_LUT] = lut_off;
             h[LWF_NOUT] = (uint32_t)c.n_out;
+          }
+        }
+        // The same for programs of 2..4 components of at most 8 outputs each (k_sample_lw_fastm): one rank table, base
+        // table and placement table per component, their LDS offsets fixed here.  Header (16 words): n_runs, flip0,
+        // flip1, runs offset, n_comp, LDS words; then 8 words per component: rank table, LUT (image offsets), n_out,
+        // (their LDS offsets are a running sum the kernel and the launcher both form).
+        p->lwfm_off = 0;
+        if (p->lw_reg && p->comps.size() >= 2 && p->comps.size() <= TSIMK_LWFM_MAX_COMP) {
+          bool ok = true;
+          for (auto &c : p->comps) ok = ok && c.n_out >= 1 && c.n_out <= TSIMK_LWF_MAX_NOUT;
+          std::vector<uint32_t> runs;
+          uint32_t flip[2] = {0u, 0u};
+          for (int s2 = 0; s2 < 4 && ok; ++s2)
+            for (int d = 0; d < 2; ++d) {
+              std::vector<std::array<int, 2>> m;
+              for (int j2 = 0; j2 < p->n_direct; ++j2) {
+                const int src = p->direct_f[j2], dst = p->output_order[j2];
+                if ((src >> 5) != s2 || (dst >> 5) != d) continue;
+                m.push_back({src & 31, dst & 31});
+                if (p->direct_flips[j2]) flip[d] |= 1u << (dst & 31);
+              }
+              std::sort(m.begin(), m.end());
+              for (size_t a = 0; a < m.size();) {
+                size_t b = a + 1;
+                while (b < m.size() && m[b][0] == m[b - 1][0] + 1 && m[b][1] == m[b - 1][1] + 1) ++b;
+                const int len = (int)(b - a);
+                const uint32_t field = (len >= 32 ? 0xFFFFFFFFu : ((1u << len) - 1u)) << m[a][1];
+                runs.push_back((uint32_t)((m[a][0] - m[a][1]) & 31) | ((uint32_t)s2 << 8));
+                runs.push_back(d == 0 ? field : 0u);
+                runs.push_back(d == 1 ? field : 0u);
+                runs.push_back(0u);
+                a = b;
+              }
+            }
+          if (ok && runs.size() / 4 <= TSIMK_LWF_MAX_RUNS) {
+            while (img.size() % 16) img.push_back(0u);
+            p->lwfm_off = (int)img.size();
+            img.resize(img.size() + 16 + 8 * TSIMK_LWFM_MAX_COMP, 0u);
+            const uint32_t runs_off = (uint32_t)img.size();
+            img.insert(img.end(), runs.begin(), runs.end());
+            for (size_t ci = 0; ci < p->comps.size(); ++ci) {
+              const HostComponent &c = p->comps[ci];
+              while (img.size() % 16) img.push_back(0u);
+              const uint32_t rank_off = (uint32_t)img.size();
+              std::vector<int> pos_in(128, -1);
+              for (int j2 = 0; j2 < c.F; ++j2) pos_in[c.f_selection[j2]] = j2;
+              for (int k = 0; k < 8; ++k)
+                for (int q = 0; q < 128; ++q) {
+                  const int b = pos_in[q];
+                  unsigned long long v = 0;
+                  if (b >= k + 1) {
+                    v = 1;
+                    for (int t = 1; t <= k + 1; ++t) v = v * (unsigned long long)(b - (k + 1) + t) / (unsigned long long)t;
+                  }
+                  img.push_back((uint32_t)v);
+                }
+              const uint32_t lut_off = (uint32_t)img.size();
+              const uint32_t outpos_off = img[p->lw_off + ci * LW_WORDS + LW_OUTPOS];
+              for (uint32_t leaf = 0; leaf < (1u << c.n_out); ++leaf) {
+                uint32_t w[2] = {0u, 0u};
+                for (int t = 0; t < c.n_out; ++t)
+                  if ((leaf >> (c.n_out - 1 - t)) & 1u) {
+                    const uint32_t dst = img[outpos_off + t];
+                    w[dst >> 5] |= 1u << (dst & 31u);
+                  }
+                img.push_back(w[0]);
+                img.push_back(w[1]);
+              }
+              uint32_t *hc = &img[p->lwfm_off + 16 + 8 * ci];
+              hc[0] = rank_off;
+              hc[1] = lut_off;
+              hc[2] = (uint32_t)c.n_out;
+            }
+            uint32_t *h = &img[p->lwfm_off];
+            h[0] = (uint32_t)(runs.size() / 4);
+            h[1] = flip[0];
+            h[2] = flip[1];
+            h[3] = runs_off;
+            h[4] = (uint32_t)p->comps.size();
           }
         }
       } else {

@@ -10,6 +10,7 @@
 #include "tsim_kernel4w.hip.h"
 #include "tsim_kernel_hw.hip.h"
 #include "tsim_direct.hip.h"
+#include "tsim_lw_fastm.hip.h"
 
 using namespace tsimk;
 using namespace tsimhost;
@@ -948,6 +949,21 @@ static int steps_group_fused(tsim_program *p, int n, const uint64_t *const *d_f,
       default: return tsim_fail(TSIM_ESTATE, "fast record with %d outputs", n_out);
     }
 #undef TSIM_LF
+    ++p->stat_fast;
+  } else if (p->lwfm_off != 0 && p->knobs.lw_fast && blk1 == 1024 && B < (1ll << 28) && p->lw_bytes < (1ll << 32) &&
+             (n_lists & (n_lists - 1)) == 0 && ((unsigned long long)shot_offset >> 32) == ((unsigned long long)(shot_offset + B - 1) >> 32)) {
+    // 2..4 components of at most 8 outputs each: the specialised pass with per-component tables (tsim_lw_fastm.hip.h)
+    M.lwf_off = p->lwfm_off;
+    M.tab_bytes = (uint32_t)p->lw_bytes;
+    const unsigned rstr = 32u * (WF == 1 ? 2u : 4u) + 1u;
+    unsigned l = 4u * TSIMK_LWF_MAX_RUNS;  // the kernel's LDS layout (same running sum there)
+    for (auto &c : p->comps) {
+      const unsigned l_bases = l + 8u * rstr, l_lut = (l_bases + 72u + 1u) & ~1u;
+      l = l_lut + (2u << c.n_out);
+    }
+    const size_t ldsb = (size_t)l * 4;
+    if (WF == 1) hipLaunchKernelGGL(k_sample_lw_fastm<2>, dim3((unsigned)grid), dim3(blk1), ldsb, s, M);
+    else hipLaunchKernelGGL(k_sample_lw_fastm<4>, dim3((unsigned)grid), dim3(blk1), ldsb, s, M);
     ++p->stat_fast;
   } else if (WF == 1) hipLaunchKernelGGL(k_sample_lw_multi<2>, dim3((unsigned)grid), dim3(blk1), 0, s, M);
   else hipLaunchKernelGGL(k_sample_lw_multi<4>, dim3((unsigned)grid), dim3(blk1), 0, s, M);

@@ -618,6 +618,11 @@ class _CompiledSamplerBase:
         used the slot before (``tsim_sample_batch_device_end`` on it).  The reference's loop does the same things one
         after the other (``sampler.py:393-415``: sample f, upload, sample_program, concatenate, download once)."""
         hp = self._hip()
+        # device-side noise has no stream contract with the reference: batch_size only bounds memory here, so batches of
+        # fewer than 2^17 shots are merged (the same rows at 8x the rate for batch_size = 10^4; a fixed seed still gives
+        # fixed results) - the host-noise path must honour batch_size, the reference's channel stream depends on it
+        if batch_size is not None and batch_size < (1 << 17) and shots > batch_size:
+            batch_size = min(1 << 17, self._estimate_batch_size())
         plan = plan_batches(shots, batch_size, self._estimate_batch_size())
         ref = self._compute_reference_sample() if want_ref else None
         cs = self._channel_sampler

@@ -23,6 +23,7 @@ if want bench; then
     echo "== C2 hard-row grids on the batch lane (TSIM_AMD_HARD_INLINE_ROWS=0: rounds 1-2)"; TSIM_AMD_HARD_INLINE_ROWS=0 scripts/bq.sh --steps 200; TSIM_AMD_HARD_INLINE_ROWS=0 scripts/bq.sh --steps 20;
     echo "== C4, 1e5 shots per step, batch lane"; TSIM_AMD_HARD_INLINE_ROWS=0 scripts/bq.sh --config C4 --shots 100000 --steps 100;
     echo "== C3 block-per-row kernel forced (TSIM_AMD_HARD_WAVE_ROWS=100000)"; TSIM_AMD_HARD_WAVE_ROWS=100000 scripts/bq.sh --config C3 --steps 100;
+    echo "== deeper pattern tables on demand (TSIM_AMD_DEEP_TABLES=1: one more weight when the hard rows are too many for the block-per-row kernel; 60-200 ms of table build once per handle; default: only after 2e10 rows in that state): C3, C4, C2 at p_bit 0.05"; TSIM_AMD_DEEP_TABLES=1 scripts/bq.sh --config C3 --steps 100; TSIM_AMD_DEEP_TABLES=1 scripts/bq.sh --config C4 --steps 100; TSIM_AMD_DEEP_TABLES=1 scripts/bq.sh --p-bit 0.05 --steps 100;
     echo "== C2 approx, live padding"; scripts/bq.sh --steps 200 --approx; scripts/bq.sh --steps 200 --live-padding;
     for p in 0.005 0.05 0.1 0.3; do echo "== C2 p_bit $p"; scripts/bq.sh --p-bit $p --steps 100; done; } > $O/shapes.txt 2>&1
 fi

@@ -5,7 +5,7 @@
 //                      chunk tables (host only)
 //   tsim_sample.hip    launch planner + pipeline scheduler + the sampling kernels (k_sample_lw, k_sample4,
 //                      k_sample4h), device-side post-selection, HIP-event profiling
-//   tsim_rows*.hip     the row-formulation kernels (k_sample<W>, k_evaluate<W>, k_lw_build<W>), one TU per
+//   tsim_rows*.hip     the row-formulation kernels (k_sample<W>, k_evaluate<W>, k_lw_nodes<W>), one TU per
 //                      formulation so that they compile in parallel
 //   tsim_format.hip    byte-per-bit <-> packed rows, bit_packed compaction, row gather/scatter
 //   tsim_noise.hip     device-side channel sampler
@@ -233,6 +233,9 @@ struct tsim_program {
     // slower everywhere: --steps 20 6.84 -> 6.44e10, C4 at 1e5 shots per step 1.7e10 -> 7.9e9; off)
     bool hard_lag = false;
     long long hard_inline_rows = 1ll << 40;  // TSIM_AMD_HARD_INLINE_ROWS: fused groups of at most this many shots run their hard rows on their own lane
+    int deep_tables = 0;       // TSIM_AMD_DEEP_TABLES: deeper pattern tables when the hard rows are merely too many for k_sample_hw -
+                               // 0: after deep_after rows in that state, 1: at once, -1: never
+    unsigned long long deep_after = 20000000000ull;  // TSIM_AMD_DEEP_AFTER
     int hard_wave_rows = 1024;  // TSIM_AMD_HARD_WAVE_ROWS: ... while a batch of launches has at most this many hard rows (last feedback)
     bool hard_wave = true;    // TSIM_AMD_HARD_WAVE=0: hard-row batches on k_sample4h_multi (64 rows per block) instead of one wave per row
     bool lw_fast = true;      // TSIM_AMD_LW_FAST=0: the generic fused pass (k_sample_lw_multi) also for one-component programs
@@ -249,6 +252,7 @@ struct tsim_program {
   int lw_cap_now = 0, lw_cap_max = 0;  // table depth built / allowed (tsim_tables_extend deepens on demand)
   long long lw_budget = 0;    // bytes per component
   int lw_dense_launches = 0;  // consecutive launches whose hard-row share says "deeper tables would pay"
+  unsigned long long deep_rows = 0;  // rows launched while the hard rows were too many for k_sample_hw (knobs.deep_after)
   long long lw_bytes = 0;
   uint32_t *d_lw_tab = nullptr;  // integer Bernoulli thresholds (tsimk::bernoulli_threshold)
   // device allocations handed out by tsim_malloc_device and not yet freed: the handle owns them
@@ -299,14 +303,14 @@ int tsim_flush_hard(tsim_program *p);
 // ---- tsim_rows*.hip: launchers of the row-formulation kernels (W = 32-bit words per parameter row)
 int tsim_launch_rows(tsim_program *p, int wmax, const tsimk::SampleArgs &a, long long grid, int block, size_t lds,
                      hipStream_t s);
-int tsim_launch_lw_build(int W, bool fast, const tsimk::LwBuildArgs &a, long long lanes, hipStream_t s);
+int tsim_launch_lw_build(int W, bool fast, const tsimk::LwBuildArgs &a, int n_out, hipStream_t s);
 namespace tsimrows {
 int sample_fast(int wmax, const tsimk::SampleArgs &a, long long grid, int block, size_t lds, hipStream_t s);
 int sample_faithful(int wmax, const tsimk::SampleArgs &a, long long grid, int block, size_t lds, hipStream_t s);
 int eval_fast(int W, const tsimk::EvalArgs &a, hipStream_t s);
 int eval_faithful(int W, const tsimk::EvalArgs &a, hipStream_t s);
-int lw_build_fast(int W, const tsimk::LwBuildArgs &a, long long lanes, hipStream_t s);
-int lw_build_faithful(int W, const tsimk::LwBuildArgs &a, long long lanes, hipStream_t s);
+int lw_build_fast(int W, const tsimk::LwBuildArgs &a, int n_out, hipStream_t s);
+int lw_build_faithful(int W, const tsimk::LwBuildArgs &a, int n_out, hipStream_t s);
 }  // namespace tsimrows
 
 // ---- tsim_format.hip

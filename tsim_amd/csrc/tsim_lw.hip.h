@@ -83,76 +83,124 @@ __host__ __device__ __forceinline__ uint32_t lw_rank_term(int i, uint32_t b) {
 // ---------------------------------------------------------------------------
 struct LwBuildArgs {
   const uint32_t *img;
-  const unsigned long long *patbits;  // [npat] f_sel bit patterns in table order
+  const unsigned long long *patbits;  // [npat] f_sel bit patterns in table order, or nullptr: the lane unranks its pattern
   uint32_t *tab;                      // this component's table: [npat << n_out] integer thresholds (bernoulli_threshold)
   int comp_off;                       // row-layout component record (C_*)
   int npat;
-  // wide components: patbits == nullptr, the lane unranks its pattern (weight class from `bases`, then the set
-  // bits from the largest down: the largest b with C(b, i + 1) <= r, binary search in the [4][256] table)
+  // patbits == nullptr: weight class from `bases`, then the set bits from the largest down - the largest b with
+  // C(b, i + 1) <= r.  Wide components (wide_binom_off != 0): binary search in the [4][256] table; narrow ones: the same
+  // search on lw_rank_term (no 14-million-entry list built on the host and copied)
   int wide_binom_off, bases_off, wmax;
+  float *p1;                          // scratch [npat << n_out]: |amp| of every node (k_lw_nodes), node 0 = the normalisation
+  int depth;                          // k_lw_nodes: -1 = the normalisation level, d = the nodes with d prefix bits
 };
 
-template <int W, bool FAST>
-__global__ void __launch_bounds__(256) k_lw_build(LwBuildArgs A) {
-  cptr img = (cptr)(uintptr_t)A.img;
-  cptr comp = img + A.comp_off;
-  const uint32_t n_out = comp[C_NOUT], F = comp[C_F];
-  cptr levels = img + comp[C_LEVELS];
-  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= ((long long)A.npat << n_out)) return;
-  const uint32_t pat = (uint32_t)(t >> n_out), m = (uint32_t)t & ((1u << n_out) - 1u);
-  uint32_t x[W];
+// the pattern of table row `pat` as f_sel-position bits
+template <int W>
+__device__ __forceinline__ void lw_pattern_bits(const LwBuildArgs &A, cptr img, uint32_t F, uint32_t pat, uint32_t (&x)[W]) {
   if (A.patbits) {
     const unsigned long long pb = A.patbits[pat];
 #pragma unroll
     for (int w = 0; w < W; ++w) x[w] = (w < 2) ? (uint32_t)(pb >> (32 * w)) : 0u;
-  } else {
+    return;
+  }
 #pragma unroll
-    for (int w = 0; w < W; ++w) x[w] = 0u;
-    cptr bases = img + A.bases_off;
-    cptr bn = img + A.wide_binom_off;
-    int wt = 0;
-    for (int k = 1; k <= A.wmax; ++k)
-      if (pat >= bases[k]) wt = k;
-    uint32_t r = pat - bases[wt];
-    int hi = (int)F;  // the next set bit lies below this position
-    for (int i = wt - 1; i >= 0; --i) {
-      int lo = i, up = hi - 1;  // C(i, i + 1) = 0 <= r: position i always qualifies
+  for (int w = 0; w < W; ++w) x[w] = 0u;
+  cptr bases = img + A.bases_off;
+  int wt = 0;
+  for (int k = 1; k <= A.wmax; ++k)
+    if (pat >= bases[k]) wt = k;
+  uint32_t r = pat - bases[wt];
+  int hi = (int)F;  // the next set bit lies below this position
+  for (int i = wt - 1; i >= 0; --i) {
+    int lo = i, up = hi - 1;  // C(i, i + 1) = 0 <= r: position i always qualifies
+    uint32_t at_lo = 0u;
+    if (A.wide_binom_off) {
+      cptr bn = img + A.wide_binom_off;
       while (lo < up) {
         const int mid = (lo + up + 1) >> 1;
         if (bn[i * 256 + mid] <= r) lo = mid;
         else up = mid - 1;
       }
-      r -= bn[i * 256 + lo];
-#pragma unroll
-      for (int w = 0; w < W; ++w)
-        if (w == (lo >> 5)) x[w] |= 1u << (lo & 31);
-      hi = lo;
+      at_lo = bn[i * 256 + lo];
+    } else {
+      while (lo < up) {
+        const int mid = (lo + up + 1) >> 1;
+        if (lw_rank_term(i, (uint32_t)mid) <= r) lo = mid;
+        else up = mid - 1;
+      }
+      at_lo = lw_rank_term(i, (uint32_t)lo);
     }
+    r -= at_lo;
+#pragma unroll
+    for (int w = 0; w < W; ++w)
+      if (w == (lo >> 5)) x[w] |= 1u << (lo & 31);
+    hi = lo;
   }
+}
+
+// ---------------------------------------------------------------------------
+// Table build, round 3: the |amp| of a prefix-tree node depends on (pattern, prefix bits, trial bit) only - not on the
+// chain of `prev` values above it - so every node is evaluated ONCE: k_lw_nodes, one launch per depth (all lanes of a
+// launch evaluate the same level), one lane per (pattern, prefix); then k_lw_finish forms the thresholds p1 / prev
+// with prev from the chain rule over the node's ancestors (sampler.py:75-79).  The first version gave a lane to every
+// (pattern, full assignment) and let it walk all n + 1 levels of its path: (n + 1) x the evaluations (6 x for the
+// distillation shapes: 24 -> 4 ms for C3's weight-5 tables, 180 -> 30 for weight 6).  Same device arithmetic as the
+// sampling kernels (eval_any -> cabs32 -> __fdiv_rn / __fsub_rn), same values.
+// ---------------------------------------------------------------------------
+template <int W, bool FAST>
+__global__ void __launch_bounds__(256) k_lw_nodes(LwBuildArgs A) {
+  cptr img = (cptr)(uintptr_t)A.img;
+  cptr comp = img + A.comp_off;
+  const uint32_t n_out = comp[C_NOUT], F = comp[C_F];
+  cptr levels = img + comp[C_LEVELS];
+  const int d = A.depth;
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= ((long long)A.npat << (d < 0 ? 0 : d))) return;
+  const uint32_t pat = d < 0 ? (uint32_t)t : (uint32_t)(t >> d);
+  const uint32_t prefix = d < 0 ? 0u : ((uint32_t)t & ((1u << d) - 1u));
+  uint32_t x[W];
+  lw_pattern_bits<W>(A, img, F, pat, x);
   float re, im;
-  eval_any<W, FAST>(A.img, img, levels, x, re, im, nullptr);  // sampler.py:54
-  float prev = cabs32(re, im);
-  uint32_t *row = A.tab + ((size_t)pat << n_out);
-  if (m == 0u) row[0] = 0u;  // node 0 is unused
-  uint32_t node = 1u;
-  for (uint32_t i = 0; i < n_out; ++i) {
-    cptr lvl = levels + (i + 1) * L_WORDS;
-    const uint32_t bitpos = F + i;
-    const uint32_t wi = bitpos >> 5, bm = 1u << (bitpos & 31u);
-#pragma unroll
-    for (int w = 0; w < W; ++w)
-      if ((uint32_t)w == wi) x[w] |= bm;
-    eval_any<W, FAST>(A.img, img, lvl, x, re, im, nullptr);  // sampler.py:65
-    const float p1 = cabs32(re, im);
-    row[node] = bernoulli_threshold(__fdiv_rn(p1, prev));     // sampler.py:75: bit = u < p1 / prev
-    const bool bit = ((m >> (n_out - 1u - i)) & 1u) != 0u;    // prefix bits, first output first
-#pragma unroll
-    for (int w = 0; w < W; ++w)
-      if ((uint32_t)w == wi) x[w] = bit ? (x[w] | bm) : (x[w] & ~bm);
-    prev = bit ? p1 : __fsub_rn(prev, p1);                    // sampler.py:79
-    node = 2u * node + (bit ? 1u : 0u);
+  float *row = A.p1 + ((size_t)pat << n_out);
+  if (d < 0) {
+    eval_any<W, FAST>(A.img, img, levels, x, re, im, nullptr);  // sampler.py:54
+    row[0] = cabs32(re, im);
+    return;
   }
+  for (int i = 0; i <= d; ++i) {  // prefix bits (first output first), then the trial bit of output d
+    const uint32_t bitpos = F + (uint32_t)i;
+    const bool on = i == d ? true : (((prefix >> (d - 1 - i)) & 1u) != 0u);
+#pragma unroll
+    for (int w = 0; w < W; ++w)
+      if ((uint32_t)w == (bitpos >> 5) && on) x[w] |= 1u << (bitpos & 31u);
+  }
+  eval_any<W, FAST>(A.img, img, levels + (d + 1) * L_WORDS, x, re, im, nullptr);  // sampler.py:65
+  row[(1u << d) + prefix] = cabs32(re, im);
+}
+
+// thresholds from the node values: lane = (pattern, node)
+template <bool FAST>
+__global__ void __launch_bounds__(256) k_lw_finish(LwBuildArgs A) {
+  cptr img = (cptr)(uintptr_t)A.img;
+  const uint32_t n_out = (img + A.comp_off)[C_NOUT];
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= ((long long)A.npat << n_out)) return;
+  const uint32_t node = (uint32_t)t & ((1u << n_out) - 1u);
+  const float *row = A.p1 + (((size_t)t >> n_out) << n_out);
+  if (node == 0u) {
+    A.tab[t] = 0u;  // node 0 is unused
+    return;
+  }
+  const int d = 31 - __builtin_clz(node);  // depth: the node's prefix has d bits
+  float prev = row[0];
+  for (int i = 0; i < d; ++i) {  // the chain rule along the ancestors (sampler.py:79)
+    const uint32_t anc = node >> (d - i);
+    const bool bit = ((node >> (d - 1 - i)) & 1u) != 0u;
+    const float p1 = row[anc];
+    prev = bit ? p1 : __fsub_rn(prev, p1);
+  }
+  A.tab[t] = bernoulli_threshold(__fdiv_rn(row[node], prev));  // sampler.py:75: bit = u < p1 / prev
 }
 
 struct LwArgs {

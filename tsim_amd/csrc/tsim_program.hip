@@ -493,7 +493,7 @@ retry_pack:
       const int hw_cap = p->lw_wide ? TSIMK_LWW_MAX_WEIGHT : TSIMK_LW_MAX_WEIGHT;
       p->lw_cap_max = pinned ? std::min(p->lw_weight_cap, hw_cap) : hw_cap;
       p->lw_cap_now = pinned ? p->lw_cap_max : std::min(p->lw_wide ? 3 : 5, p->lw_cap_max);
-      p->lw_budget = 1024ll << 20;  // per component (4 x per program): HBM is 288 GB, and only the prefix is hot
+      p->lw_budget = 4096ll << 20;  // per component: HBM is 288 GB, and only the prefix is hot (C3's weight-6 table is 1.8 GB)
       // wide components: C(200, 4) patterns of 8 thresholds are 2.1 GB - what lifts the tabulated share of C5's
       // shots from 43 % to 63 %; still under 1 % of the HBM
       if (p->lw_wide) p->lw_budget = 4096ll << 20;
@@ -755,6 +755,8 @@ retry_pack:
     p->knobs.lw_fast = env_int("TSIM_AMD_LW_FAST", 1) != 0;
     p->knobs.hard_wave = env_int("TSIM_AMD_HARD_WAVE", 1) != 0;
     if (const char *e = getenv("TSIM_AMD_HARD_INLINE_ROWS")) p->knobs.hard_inline_rows = std::max(0ll, atoll(e));
+    p->knobs.deep_tables = env_int("TSIM_AMD_DEEP_TABLES", 0);
+    if (const char *e = getenv("TSIM_AMD_DEEP_AFTER")) p->knobs.deep_after = strtoull(e, nullptr, 10);
     p->knobs.hard_lag = env_int("TSIM_AMD_HARD_LAG", 0) != 0;
     p->knobs.fused_lanes = std::max(0, std::min(4, env_int("TSIM_AMD_FUSED_LANES", 0)));
     p->knobs.hard_wave_rows = std::max(0, env_int("TSIM_AMD_HARD_WAVE_ROWS", 1024));

@@ -9,8 +9,8 @@ int tsim_launch_rows(tsim_program *p, int wmax, const SampleArgs &a, long long g
   return p->fast ? tsimrows::sample_fast(wmax, a, grid, block, lds, s) : tsimrows::sample_faithful(wmax, a, grid, block, lds, s);
 }
 
-int tsim_launch_lw_build(int W, bool fast, const LwBuildArgs &a, long long lanes, hipStream_t s) {
-  return fast ? tsimrows::lw_build_fast(W, a, lanes, s) : tsimrows::lw_build_faithful(W, a, lanes, s);
+int tsim_launch_lw_build(int W, bool fast, const LwBuildArgs &a, int n_out, hipStream_t s) {
+  return fast ? tsimrows::lw_build_fast(W, a, n_out, s) : tsimrows::lw_build_faithful(W, a, n_out, s);
 }
 
 extern "C" int tsim_evaluate(tsim_program *p, int32_t component, int32_t level, const uint8_t *params,

@@ -45,17 +45,26 @@ int TSIM_ROWS_NAME(eval)(int W, const EvalArgs &a, hipStream_t s) {
 
 // pattern-table build (tsim_lw.hip.h): components with <= 64 parameters use W = 1, 2; wide components
 // (multi-word patterns) the W of their rows
-int TSIM_ROWS_NAME(lw_build)(int W, const LwBuildArgs &a, long long lanes, hipStream_t s) {
-  const dim3 grid((unsigned)((lanes + 255) / 256));
-  switch (W) {
+int TSIM_ROWS_NAME(lw_build)(int W, const LwBuildArgs &a0, int n_out, hipStream_t s) {
+  // one launch per depth (every lane of a launch evaluates the same level), then the thresholds
+  for (int d = -1; d < n_out; ++d) {
+    LwBuildArgs a = a0;
+    a.depth = d;
+    const long long lanes = (long long)a.npat << (d < 0 ? 0 : d);
+    const dim3 grid((unsigned)((lanes + 255) / 256));
+    switch (W) {
 #define TSIM_X(WV)                                                                                 \
   case WV:                                                                                         \
-    hipLaunchKernelGGL((k_lw_build<WV, TSIM_ROWS_FAST>), grid, dim3(256), 0, s, a);                \
+    hipLaunchKernelGGL((k_lw_nodes<WV, TSIM_ROWS_FAST>), grid, dim3(256), 0, s, a);                \
     break;
-    TSIM_FOR_EACH_W(TSIM_X)
+      TSIM_FOR_EACH_W(TSIM_X)
 #undef TSIM_X
-    default: return tsim_fail(TSIM_ENOTSUP, "pattern tables: unsupported word count %d", W);
+      default: return tsim_fail(TSIM_ENOTSUP, "pattern tables: unsupported word count %d", W);
+    }
+    HIP_TRY(hipGetLastError());
   }
+  const long long lanes = (long long)a0.npat << n_out;
+  hipLaunchKernelGGL((k_lw_finish<TSIM_ROWS_FAST>), dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, s, a0);
   HIP_TRY(hipGetLastError());
   return 0;
 }

@@ -131,7 +131,19 @@ static LaunchPlan make_plan(tsim_program *p, bool has_row_index, bool pipelined)
     // More than 1 % of the rows hard, three launches in a row, and deeper tables are allowed: build them now
     // (once; every lane is drained first because the records in the device image are rewritten).
     if (known && p->lw_cap_now < p->lw_cap_max && !has_row_index) {
-      p->lw_dense_launches = ((double)fb_sum > 0.01 * (double)fb_rows) ? p->lw_dense_launches + 1 : 0;
+      // ... or so many that a batch of launches cannot use the block-per-row kernel (hw_eligible: more than
+      // hard_wave_rows rows per eight launches - C3 at weight 5: 340 per 10^6 shots): one level deeper usually brings
+      // them under it (C3: 45), and the per-shot hard-row grid (95 us per group for C3) leaves the lanes
+      // Building a 1-2 GB table takes 20-200 ms (scripts/table_build_time.py) and gains 3-11 us per 10^6 shots: it pays
+      // after some 10^10 shots, so by default only a handle that has seen knobs.deep_after rows in this state deepens
+      // (TSIM_AMD_DEEP_TABLES=1: at once, =-1: never)
+      bool too_many_for_hw = p->knobs.deep_tables >= 0 && p->knobs.hard_wave &&
+                             (unsigned long long)fb_sum * 8ull > (unsigned long long)p->knobs.hard_wave_rows && fb_rows >= 65536u;
+      if (too_many_for_hw && p->knobs.deep_tables == 0) {
+        p->deep_rows += fb_rows;
+        too_many_for_hw = p->deep_rows >= p->knobs.deep_after;
+      }
+      p->lw_dense_launches = ((double)fb_sum > 0.01 * (double)fb_rows || too_many_for_hw) ? p->lw_dense_launches + 1 : 0;
       if (p->lw_dense_launches >= 3) {
         p->lw_dense_launches = 0;
         if (tsim_synchronize(p) == TSIM_OK && tsim_tables_extend(p) == TSIM_OK) {

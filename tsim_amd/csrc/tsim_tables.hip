@@ -9,6 +9,10 @@
 // (tsim_program_set_pattern_tables).  Results never depend on the depth.
 #include "tsim_internal.hip.h"
 
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+
 using namespace tsimk;
 using namespace tsimhost;
 
@@ -80,38 +84,32 @@ static void enumerate_patterns(int F, int wmax, std::vector<unsigned long long> 
 // *old (the caller frees it once nothing in flight reads it).
 int tsim_tables_build(tsim_program *p, uint32_t **old) {
   uint32_t *tab = nullptr;
+  const auto t_start = std::chrono::steady_clock::now();
   hipError_t me = hipMalloc((void **)&tab, std::max<size_t>(16, (size_t)p->lw_bytes));
   if (me != hipSuccess) return tsim_fail(TSIM_ENOMEM, "hipMalloc(%lld) for the pattern tables failed: %s", p->lw_bytes, hipGetErrorString(me));
   for (size_t ci = 0; ci < p->comps.size(); ++ci) {
     const HostComponent &c = p->comps[ci];
     const long long tab_off = (long long)p->img[p->lw_off + ci * LW_WORDS + LW_TAB];
-    std::vector<unsigned long long> pats;
-    unsigned long long *d_pats = nullptr;
-    hipError_t e = hipSuccess;
-    if (!p->lw_wide) {  // (wide components: no list - the build kernel unranks the pattern index)
-      pats.reserve((size_t)p->lw_npat[ci]);
-      enumerate_patterns(c.F, p->lw_wmax[ci], pats);
-      if ((long long)pats.size() != p->lw_npat[ci]) {
-        (void)hipFree(tab);
-        return tsim_fail(TSIM_ESTATE, "pattern enumeration mismatch (%zu vs %lld)", pats.size(), p->lw_npat[ci]);
-      }
-      e = hipMalloc((void **)&d_pats, pats.size() * 8);
-      if (e == hipSuccess) e = hipMemcpy(d_pats, pats.data(), pats.size() * 8, hipMemcpyHostToDevice);
-    }
+    // (no pattern list: the build kernels unrank the row index, narrow components on lw_rank_term, wide ones in
+    // the binomial table - the host enumeration + copy of 14 million patterns cost as much as the kernels)
+    const long long lanes = p->lw_npat[ci] << c.n_out;
+    float *p1 = nullptr;
+    hipError_t e = hipMalloc((void **)&p1, std::max<size_t>(16, (size_t)lanes * 4));  // node values, freed below
     LwBuildArgs a;
     a.img = p->d_img;
-    a.patbits = d_pats;
-    a.wide_binom_off = p->lw_binom_off;
+    a.patbits = nullptr;
+    a.wide_binom_off = p->lw_wide ? p->lw_binom_off : 0;
     a.bases_off = p->lw_off + (int)ci * LW_WORDS + LW_BASES_INLINE;
     a.wmax = p->lw_wmax[ci];
     a.tab = tab + tab_off;
     a.comp_off = p->comp_off + (int)ci * C_WORDS;
     a.npat = (int)p->lw_npat[ci];
-    const long long lanes = p->lw_npat[ci] << c.n_out;
+    a.p1 = p1;
+    a.depth = -1;
     int r = 0;
-    if (e == hipSuccess) r = tsim_launch_lw_build(p->comp_w[ci], p->fast, a, lanes, p->stream);
+    if (e == hipSuccess) r = tsim_launch_lw_build(p->comp_w[ci], p->fast, a, c.n_out, p->stream);
     if (e == hipSuccess && r == 0) e = hipStreamSynchronize(p->stream);
-    if (d_pats) (void)hipFree(d_pats);
+    if (p1) (void)hipFree(p1);
     if (r || e != hipSuccess) {
       (void)hipFree(tab);
       return r ? r : tsim_fail(TSIM_EHIP, "pattern table build failed: %s", hipGetErrorString(e));
@@ -119,6 +117,10 @@ int tsim_tables_build(tsim_program *p, uint32_t **old) {
   }
   if (old) *old = p->d_lw_tab;
   p->d_lw_tab = tab;
+  static const bool timing = getenv("TSIM_TABLE_TIMING") != nullptr;
+  if (timing)
+    fprintf(stderr, "[tsim] pattern tables: %.1f MB built in %.1f ms\n", (double)p->lw_bytes / 1e6,
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count());
   return 0;
 }
 
@@ -145,12 +147,12 @@ int tsim_tables_extend(tsim_program *p) {
   }
   uint32_t *old = nullptr;
   const size_t rec_bytes = p->comps.size() * LW_WORDS * 4;
-  // wide components: the build kernel unranks with the NEW bases, read from the device image (every lane is idle)
-  if (p->lw_wide) HIP_TRY(hipMemcpy(p->d_img + p->lw_off, p->img.data() + p->lw_off, rec_bytes, hipMemcpyHostToDevice));
+  // the build kernels unrank with the NEW bases, read from the device image (every lane is idle)
+  HIP_TRY(hipMemcpy(p->d_img + p->lw_off, p->img.data() + p->lw_off, rec_bytes, hipMemcpyHostToDevice));
   if (int r = tsim_tables_build(p, &old)) {  // e.g. out of memory: keep what we have
     (void)r;
     std::copy(saved.begin(), saved.end(), p->img.begin() + p->lw_off);
-    if (p->lw_wide) (void)hipMemcpy(p->d_img + p->lw_off, p->img.data() + p->lw_off, rec_bytes, hipMemcpyHostToDevice);
+    (void)hipMemcpy(p->d_img + p->lw_off, p->img.data() + p->lw_off, rec_bytes, hipMemcpyHostToDevice);
     p->lw_wmax = before;
     p->lw_npat = npat_before;
     p->lw_bytes = bytes_before;

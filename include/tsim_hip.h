@@ -40,7 +40,7 @@ extern "C" {
 #define TSIM_ENOTSUP (-95)     /* program exceeds a compiled-in limit         */
 #define TSIM_ESTATE (-1)       /* call not valid in the handle's state        */
 
-#define TSIM_MAX_PARAMS 1024   /* max n_params (f bits + outputs) per level   */
+#define TSIM_MAX_PARAMS 2048   /* max n_params (f bits + outputs) per level   */
 
 typedef struct tsim_program tsim_program;
 

@@ -92,13 +92,13 @@ def test_key_split_matches_python_prng():
 
 
 def test_parameter_limit_is_reported():
-    """More than TSIM_MAX_PARAMS = 1024 parameters per level: ENOTSUP with a message, before any device call
-    (the reference's own regression sizes, test_linalg.py:115-126, end at P = 1024, which is supported)."""
+    """More than TSIM_MAX_PARAMS = 2048 parameters per level: ENOTSUP with a message, before any device call
+    (the reference's own regression sizes, test_linalg.py:115-126, end at P = 1024; up to 2048 is supported)."""
     from tsim_amd import backend
     from tsim_amd.program import CompiledComponent, empty_scalar_graphs, make_program, scalar_graphs_from_terms
 
-    P = 1025
+    P = 2049
     lv = scalar_graphs_from_terms(P, [dict(B=[(4, list(range(P)))])])
     comp = CompiledComponent(tuple(range(P)), np.zeros(0, np.int32), (empty_scalar_graphs(0), lv))
-    with pytest.raises(_lib.HipBackendError, match="TSIM_MAX_PARAMS=1024"):
+    with pytest.raises(_lib.HipBackendError, match="TSIM_MAX_PARAMS=2048"):
         backend.HipProgram(make_program([comp], [], P, 0))

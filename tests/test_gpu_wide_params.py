@@ -1,7 +1,7 @@
 """H4 matmul_gf2 on the HIP path at the reference's regression sizes
 (/root/reference/test/unit/utils/test_linalg.py:102-126: all-ones rows with P in {256, 300, 1024} - the
 float32 sum must not saturate at 255 - and random rows against an int64 matmul), on the W = 8 / 12 / 32
-row kernels, plus a sampled component with ~1000 parameters."""
+row kernels (and W = 48 / 64 beyond the reference's own sizes), plus sampled components with up to ~2000 parameters."""
 
 import numpy as np
 import pytest
@@ -21,7 +21,7 @@ def _parity_program(P, rows):
 
 
 @pytest.mark.parametrize("mode", ["auto", "faithful"])
-@pytest.mark.parametrize("P", [255, 256, 257, 300, 301, 512, 1023, 1024])
+@pytest.mark.parametrize("P", [255, 256, 257, 300, 301, 512, 1023, 1024, 1025, 1536, 1537, 2047, 2048])
 def test_all_ones_parity_does_not_saturate(hip, P, mode):
     prog, _ = _parity_program(P, [list(range(P))])
     hp = hip.HipProgram(prog, mode=mode)
@@ -34,7 +34,7 @@ def test_all_ones_parity_does_not_saturate(hip, P, mode):
     np.testing.assert_array_equal(z.imag, np.zeros(3, np.float32))
 
 
-@pytest.mark.parametrize("P", [64, 300, 1024])
+@pytest.mark.parametrize("P", [64, 300, 1024, 1300, 2048])
 def test_random_rows_match_int64_matmul(hip, P):
     """test_linalg.py:88-101 shape: G graphs x 1 term; one graph per launch row via separate single-graph levels
     would be slow - instead the G parities are read off G one-graph levels of the same component."""
@@ -51,9 +51,10 @@ def test_random_rows_match_int64_matmul(hip, P):
 
 
 @pytest.mark.parametrize("mode", ["auto", "faithful"])
-@pytest.mark.parametrize("F", [250, 600, 1000])
+@pytest.mark.parametrize("F", [250, 600, 1000, 1400, 2040])
 def test_wide_component_samples_match_oracle(hip, F, mode):
-    """A sampled component with F + n = 253 .. 1003 parameters (W = 8 .. 32 words per row)."""
+    """A sampled component with F + n = 253 .. 2043 parameters (W = 8 .. 64 words per row; the reference has no limit,
+    utils/linalg.py:81-102 - this build stops at TSIM_MAX_PARAMS = 2048)."""
     prog = synth.synth_program(
         num_f=F + 20, n_direct=4,
         components=[dict(n=3, F=F, G=[2, 3, 3, 4], ta=(1, 5), tb=(1, 6), tc=(1, 6), td=(0, 2), density=0.04)], seed=F,

@@ -84,7 +84,7 @@ struct HostComponent {
   std::vector<HostLevel> levels;
 };
 
-static const int kWVariants[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32};
+static const int kWVariants[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64};
 
 inline int round_w(int w) {
   for (int v : kWVariants)

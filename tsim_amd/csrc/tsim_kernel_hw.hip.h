@@ -398,7 +398,7 @@ __device__ __forceinline__ void hw_row(const SampleArgs &A, long long row, bool 
 // Every BLOCK (4 waves on one row at a time) serves ONE list of ONE launch: block j of a list takes its slots j,
 // j + waves_per_list, ...
 template <int W>
-__global__ void __launch_bounds__(256) k_sample_hw(HwMulti M) {
+__global__ void __launch_bounds__(1024) k_sample_hw(HwMulti M) {
   __builtin_amdgcn_s_setprio(3);  // a few hundred latency-bound waves beside a chip-full of issue-bound ones: issue when ready
   const uint32_t wv = blockIdx.x;
   const uint32_t per_ctx = (uint32_t)(M.max_lists * M.waves_per_list);

@@ -830,7 +830,7 @@ __global__ void __launch_bounds__(256) k_sample(SampleArgs A) {
     if constexpr (WV <= WMAX) run_component<WV, FAST>(A, img, comp, lds_f, lds_o, nthr, shot, check_lane, ci); \
     break;
       TSIMK_CASE(1) TSIMK_CASE(2) TSIMK_CASE(3) TSIMK_CASE(4) TSIMK_CASE(6) TSIMK_CASE(8)
-      TSIMK_CASE(12) TSIMK_CASE(16) TSIMK_CASE(24) TSIMK_CASE(32)
+      TSIMK_CASE(12) TSIMK_CASE(16) TSIMK_CASE(24) TSIMK_CASE(32) TSIMK_CASE(48) TSIMK_CASE(64)
 #undef TSIMK_CASE
       default: __builtin_trap();  // the packer only emits the widths instantiated here (tsimhost::kWVariants)
     }

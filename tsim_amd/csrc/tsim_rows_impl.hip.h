@@ -10,7 +10,7 @@
 using namespace tsimk;
 
 // every W the packer can choose (tsimhost::kWVariants)
-#define TSIM_FOR_EACH_W(X) X(1) X(2) X(3) X(4) X(6) X(8) X(12) X(16) X(24) X(32)
+#define TSIM_FOR_EACH_W(X) X(1) X(2) X(3) X(4) X(6) X(8) X(12) X(16) X(24) X(32) X(48) X(64)
 
 namespace tsimrows {
 

@@ -2,6 +2,8 @@
 // kernels that need the chunk-table layout (k_sample_lw, k_sample4, k_sample4h, k_sample4h_multi),
 // device-side post-selection and the HIP-event profiling of the launches.
 #include "tsim_internal.hip.h"
+
+#include <chrono>
 #include "tsim_kernel4h.hip.h"
 #include "tsim_filter.hip.h"
 #include "tsim_lw_pass.hip.h"
@@ -222,8 +224,9 @@ static int launch_hw(tsim_program *p, const SampleArgs *ctx, int n_ctx, int max_
   const unsigned gridw = (unsigned)((long long)H.n_ctx * H.max_lists * H.waves_per_list);
   H.par_words = (int)(2 * ((p->hw_max_rows + 63) / 64) + 2);
   const size_t ldsw = (size_t)H.par_words * 8 * 4 + 16;  // two buffers of four bit arrays (previous bit x trial bit) + the sampled bit.s word
-  if (wmax == 1) hipLaunchKernelGGL(k_sample_hw<1>, dim3(gridw), dim3(256), ldsw, hs, H);
-  else hipLaunchKernelGGL(k_sample_hw<2>, dim3(gridw), dim3(256), ldsw, hs, H);
+  static const int hw_block = getenv("TSIM_AMD_HW_BLOCK") ? std::max(128, std::min(1024, atoi(getenv("TSIM_AMD_HW_BLOCK")) / 64 * 64)) : 256;
+  if (wmax == 1) hipLaunchKernelGGL(k_sample_hw<1>, dim3(gridw), dim3(hw_block), ldsw, hs, H);
+  else hipLaunchKernelGGL(k_sample_hw<2>, dim3(gridw), dim3(hw_block), ldsw, hs, H);
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -852,6 +855,29 @@ extern "C" int tsim_sample_batch_device_begin(tsim_program *p, int32_t slot, con
 // (tsim_flush_hard) while the next group's first pass runs.  Anything else - dense plans, wide programs, row kernels -
 // goes through tsim_sample_batch_device_begin batch by batch: same results either way.
 // ---------------------------------------------------------------------------
+// TSIM_HOST_TIMING=1: where the host time of a several-batches call goes (stderr, one line per call)
+struct HostMarks {
+  bool on;
+  std::chrono::steady_clock::time_point t[24];
+  const char *name[24];
+  int n = 0;
+  HostMarks() {
+    static const bool e = getenv("TSIM_HOST_TIMING") != nullptr;
+    on = e;
+  }
+  void mark(const char *what) {
+    if (on && n < 24) { name[n] = what; t[n++] = std::chrono::steady_clock::now(); }
+  }
+  void print() {
+    if (!on || n < 2) return;
+    fprintf(stderr, "[tsim] host:");
+    for (int i = 1; i < n; ++i) fprintf(stderr, " %s %.1f", name[i], std::chrono::duration<double, std::micro>(t[i] - t[i - 1]).count());
+    fprintf(stderr, " us\n");
+  }
+};
+static HostMarks *g_marks = nullptr;
+#define TSIM_MARK(w) do { if (g_marks) g_marks->mark(w); } while (0)
+
 static int steps_group_fused(tsim_program *p, int n, const uint64_t *const *d_f, int64_t B, int32_t num_f, uint32_t key[2],
                              int64_t shot_offset, void *const *d_out, float *const *d_dev, uint32_t flags, const LaunchPlan &plan) {
   const bool packed = (flags & TSIM_PIPE_OUT_BIT_PACKED) != 0;
@@ -941,6 +967,7 @@ static int steps_group_fused(tsim_program *p, int n, const uint64_t *const *d_f,
   const long long chip = (long long)p->n_cu * std::max(1, p->knobs.lw_resident) * (2048 / blk1);
   const long long iters = (total + chip - 1) / chip;
   const long long grid = (total + iters - 1) / iters;
+  TSIM_MARK("args");
   const bool prof = p->profiling && (p->prof_counter++ % p->prof_every == 0);
   if (prof) { if (int r = prof_event(p, s, PROF_BEGIN)) return r; }
   // one component of at most 8 outputs: the specialised pass (tsim_lw_fast.hip.h) - 32-bit byte offsets everywhere, so
@@ -980,6 +1007,7 @@ static int steps_group_fused(tsim_program *p, int n, const uint64_t *const *d_f,
   } else if (WF == 1) hipLaunchKernelGGL(k_sample_lw_multi<2>, dim3((unsigned)grid), dim3(blk1), 0, s, M);
   else hipLaunchKernelGGL(k_sample_lw_multi<4>, dim3((unsigned)grid), dim3(blk1), 0, s, M);
   HIP_TRY(hipGetLastError());
+  TSIM_MARK("launch");
   if (prof) {
     if (int r = prof_event(p, s, PROF_PASS1)) return r;
     p->prof_steps += n;
@@ -1016,7 +1044,9 @@ static int steps_group_fused(tsim_program *p, int n, const uint64_t *const *d_f,
     }
     p->flush_inline = s;
   }
-  return flush_chunks(p);
+  const int rf = flush_chunks(p);
+  TSIM_MARK("hard");
+  return rf;
 }
 
 // Programs without components (Clifford-only circuits): up to TSIMK_DIRECT_MAX_STEPS batches as one streaming grid
@@ -1091,6 +1121,9 @@ extern "C" int tsim_sample_steps_device(tsim_program *p, int32_t n_steps, const 
   for (int j = 0; j < n_steps; ++j)
     if ((!d_f[j] && num_f > 0) || !d_out[j]) return tsim_fail(TSIM_EINVAL, "buffer %d is NULL", j);
   const int WF = std::max(1, (num_f + 63) / 64), WO = (p->num_outputs + 63) / 64;
+  HostMarks marks;
+  g_marks = marks.on ? &marks : nullptr;
+  TSIM_MARK("entry");
   int done = 0;
   while (done < n_steps) {
     // the fused first pass applies when the register form does, the subkeys fit its records, and the launch plan
@@ -1123,6 +1156,7 @@ extern "C" int tsim_sample_steps_device(tsim_program *p, int32_t n_steps, const 
       }
       plan = make_plan(p, false, true);
       hard_geometry(p, WF, WO);
+      TSIM_MARK("plan");
       fused = plan.defer && plan.use_tables && p->h_group_tiles >= 1;
     }
     if (fused) {
@@ -1168,7 +1202,11 @@ extern "C" int tsim_sample_steps_device(tsim_program *p, int32_t n_steps, const 
     }
   }
   // the groups whose hard rows were waiting for their lane's next first pass: there is none in this call
-  return tsim_flush_hard(p);
+  const int rfl = tsim_flush_hard(p);
+  TSIM_MARK("end");
+  marks.print();
+  g_marks = nullptr;
+  return rfl;
 }
 
 extern "C" int tsim_pipeline_lane_stream(tsim_program *p, int32_t lane, void **stream) {

@@ -331,25 +331,6 @@ def test_deferred_hard_row_batches(hip, monkeypatch, group, nslot):
             np.testing.assert_array_equal(devs[i], np.asarray(wdev, np.float32), err_msg=f"norm dev {i}")
 
 
-@pytest.mark.parametrize("group", [1, 2, 4])
-def test_two_batch_lanes(hip, monkeypatch, group):
-    """TSIM_AMD_BATCH_LANES=2: hard-row batches alternate over two streams (batches of one lane complete in order,
-    a slot's next launch waits for ITS batch): many more launches than slots, both join orders."""
-    monkeypatch.setenv("TSIM_AMD_BATCH_LANES", "2")
-    monkeypatch.setenv("TSIM_AMD_DEFER_GROUP", str(group))
-    prog, cfg = synth.config_program("C2")
-    hp = hip.HipProgram(prog)
-    ref = hip.HipProgram(prog, pattern_tables=False)
-    for order_end_first in (True, False):
-        fs, keys, outs, comps, devs = _pipelined_run(hp, prog, cfg, 41, 9973, [0.02, 0.04, 0.005], order_end_first, 7,
-                                                     compact=True)
-        for i, (f, k) in enumerate(zip(fs, keys)):
-            want, wdev = ref.sample_batch(f, k, bit_packed=True)
-            np.testing.assert_array_equal(outs[i], want, err_msg=f"launch {i}")
-            np.testing.assert_array_equal(comps[i], want[:, : comps[i].shape[1]], err_msg=f"compact {i}")
-            np.testing.assert_array_equal(devs[i], np.asarray(wdev, np.float32), err_msg=f"norm dev {i}")
-
-
 def test_deferred_batches_off_and_on_agree(hip, monkeypatch):
     prog, cfg = synth.config_program("C3")
     runs = []

@@ -158,6 +158,41 @@ def test_hard_rows_on_the_batch_lane_and_on_the_group_lane_agree(hip, name):
         np.testing.assert_array_equal(a, b)
 
 
+@pytest.mark.parametrize("packed", [True, False])
+@pytest.mark.parametrize("B", [5000, 4097, 3])
+def test_component_parallel_hard_rows_agree_with_one_block_per_row(hip, packed, B):
+    """Programs of 2-4 components: the specialised first pass stores the hard rows too (direct outputs and the
+    tabulated components' bits) and k_sample_hw evaluates the components that are left, one block per (row,
+    component), ORing their bits into the row (32-bit atomics; compact rows whose byte range is not a whole number of
+    words - B = 4097, 3 with 3-byte rows - fall back).  Same rows as one block per row (TSIM_AMD_HARD_COMP_PAR=0) and as
+    the oracle, normalisation-check row included."""
+    import os
+
+    runs = []
+    for env in ("1", "0"):
+        os.environ["TSIM_AMD_HARD_COMP_PAR"] = env
+        try:
+            prog, cfg = synth.config_program("C4")
+            hp = hip.HipProgram(prog)
+        finally:
+            os.environ.pop("TSIM_AMD_HARD_COMP_PAR", None)
+        nf = cfg["num_f"]
+        fs = [synth.synth_f(B, nf, 0.04, seed=70 + i) for i in range(11)]
+        _run_steps(hp, prog, fs[:3], prng.key(1), nf, packed=packed)  # feedback: few hard rows -> the block-per-row kernel
+        key = prng.key(77)
+        outs, _ = _run_steps(hp, prog, fs, key, nf, packed=packed)
+        runs.append(outs)
+        if env == "1":
+            op = OC.OracleProgram(prog)
+            _, subs = _subkeys(key, len(fs))
+            for i in (0, 5, 10):
+                want = op.sample_program(fs[i], subs[i])
+                np.testing.assert_array_equal(outs[i], np.packbits(want, axis=1, bitorder="little"), err_msg=f"batch {i}")
+        hp.close()
+    for a, b in zip(*runs):
+        np.testing.assert_array_equal(a, b)
+
+
 def test_steps_with_shot_offset_and_dense_rows(hip):
     """A shard (shot_offset > 0: no normalisation-check row) and batches dense enough that the launch plan leaves the
     fused path (many hard rows): still the oracle's bits."""

@@ -174,12 +174,12 @@ struct tsim_program {
     hipEvent_t done_ev = nullptr;     // ev2 (own second pass) or the event of the batch that served the slot
     unsigned long long batch_seq = 0; // sequence number of that batch (0: own second pass)
     int batch_lane = 0;               // the stream that batch ran on: 0/1 = the batch lanes, 2.. = first-pass lane 0.. itself (inline)
+    bool partial = false;             // this launch's hard-row lists carry component masks and its hard rows are stored partially (LwMultiArgs.partial)
     SampleArgs ctx;                   // the hard-row kernel's arguments for that launch
   };
   Slot slots[1 + TSIM_PIPELINE_SLOTS];
   bool slots_ready = false;
   std::vector<int> deferred;  // slots whose hard rows are waiting, in launch order
-  std::vector<int> lag[4];    // per first-pass lane: the fused group whose hard rows wait for the lane's next first pass (tsim_flush_hard)
   hipEvent_t lane_ev[2] = {nullptr, nullptr};  // "first passes enqueued so far on lane k are done"
   hipEvent_t batch_ev[16] = {};
   int batch_ev_lane[16] = {};                  // ... and the stream (batch_lane) it was recorded on
@@ -195,7 +195,7 @@ struct tsim_program {
   unsigned long long joined_seq[6] = {};    // ... and that batch: it is behind every batch up to this one
   int lane_reach[4] = {0, 0, 0, 0};  // batches between a lane's last start-of-batch wait and the batch it waited for (pre-wait)
   unsigned long long lane_waited[4][6] = {};  // [first-pass lane][batch lane]: newest batch already waited for
-  unsigned long long stat_queries = 0, stat_waits = 0, stat_begins = 0, stat_flushes = 0, stat_deferred = 0, stat_fused = 0, stat_fast = 0;
+  unsigned long long stat_queries = 0, stat_waits = 0, stat_begins = 0, stat_flushes = 0, stat_deferred = 0, stat_fused = 0, stat_fast = 0, stat_partial = 0;
   unsigned long long steps_slot = 0;    // tsim_sample_steps_device: next pipeline slot of its rotation ...
   unsigned long long steps_groups = 0;  // ... and the fused groups launched so far (first-pass lanes alternate)
   int last_lists = 0;         // list count of the most recent two-pass launch (what the feedback refers to)
@@ -224,14 +224,10 @@ struct tsim_program {
     int wide_list_blocks = 0; // TSIM_AMD_WIDE_LIST_BLOCKS: blocks per CU of the list-driven sparse-column pass (0: what fits)
     bool defer = true;        // TSIM_AMD_DEFER_HARD=0: every pipelined launch runs its own second pass
     bool prewait = true;      // TSIM_AMD_PREWAIT=0: no mid-batch pre-wait of the first-pass lanes (tsim_sample_batch_device_begin)
-    int batch_lanes = 1;      // TSIM_AMD_BATCH_LANES=2: hard-row batches alternate over two streams (no measured gain: both land on one hardware queue)
     int defer_group = 4;      // TSIM_AMD_DEFER_GROUP: launches per deferred hard-row batch (<= TSIMK_H_MAX_CTX)
     bool fused_steps = true;  // TSIM_AMD_FUSED_STEPS=0: tsim_sample_steps_device launches batch by batch
     int fused_lanes = 0;  // TSIM_AMD_FUSED_LANES: first-pass lanes the fused groups rotate over (1-4; 0 = 2, 3 for small groups)
-    // TSIM_AMD_HARD_LAG=1: a fused group's hard rows run behind the lane's NEXT first pass instead of directly behind its own
-    // (tried for short regions - the lane is not held up by a latency-bound grid between two first passes; measured
-    // slower everywhere: --steps 20 6.84 -> 6.44e10, C4 at 1e5 shots per step 1.7e10 -> 7.9e9; off)
-    bool hard_lag = false;
+    bool hard_comp_par = true;  // TSIM_AMD_HARD_COMP_PAR=0: the hard rows of multi-component programs one block per row (all components in turn)
     long long hard_inline_rows = 1ll << 40;  // TSIM_AMD_HARD_INLINE_ROWS: fused groups of at most this many shots run their hard rows on their own lane
     int deep_tables = 0;       // TSIM_AMD_DEEP_TABLES: deeper pattern tables when the hard rows are merely too many for k_sample_hw -
                                // 0: after deep_after rows in that state, 1: at once, -1: never

@@ -28,6 +28,8 @@ namespace tsimk {
 #define TSIMK_HW_MAX_CTX 8
 struct HwMulti {
   int n_ctx, waves_per_list, max_lists;
+  int comp_par;                       // 1, or the program's component count: the lists carry component masks (LwMultiArgs.partial) and
+                                      // block (slot, c) evaluates component c of its row alone
   int par_words;                      // LDS words per bit array: one parity bit per row of the longest level stream, + spare (8 arrays per block)
   uint32_t *feedback;                 // launch-plan feedback of the first context (see sample4h_rows)
   SampleArgs ctx[TSIMK_HW_MAX_CTX];
@@ -344,8 +346,10 @@ __device__ __forceinline__ void hw_component(const SampleArgs &A, cptr img, cptr
 }
 
 // sample_program (sampler.py:117-167) for one row on one wave
+// only_comp >= 0: that component alone, its bits ORed into the row the first pass stored (direct outputs and the other
+// components' bits are there already)
 template <int WMAX>
-__device__ __forceinline__ void hw_row(const SampleArgs &A, long long row, bool check, uint32_t *par, uint32_t pw) {
+__device__ __forceinline__ void hw_row(const SampleArgs &A, long long row, bool check, uint32_t *par, uint32_t pw, int only_comp) {
   cptr img = (cptr)(uintptr_t)A.img;
   const uint32_t lane = threadIdx.x & 63u;
   const unsigned long long shot = (unsigned long long)(A.shot_offset + row);
@@ -359,7 +363,7 @@ __device__ __forceinline__ void hw_row(const SampleArgs &A, long long row, bool 
   };
   // K14: direct outputs f[idx] ^ flip (sampler.py:140-145): lane j moves direct output j, j + 64, ...
   uint32_t out_w[4] = {0u, 0u, 0u, 0u};  // output words (num_outputs <= 128 here)
-  {
+  if (only_comp < 0) {
     cptr dt = img + A.direct_off;
     for (int j0 = 0; j0 < A.n_direct; j0 += 64) {
       const int j = j0 + (int)lane;
@@ -373,7 +377,7 @@ __device__ __forceinline__ void hw_row(const SampleArgs &A, long long row, bool 
         if ((dst >> 5) == (uint32_t)w) out_w[w] |= bit << (dst & 31u);
     }
   }
-  for (int ci = 0; ci < A.n_comp; ++ci) {
+  for (int ci = only_comp < 0 ? 0 : only_comp; ci < (only_comp < 0 ? A.n_comp : only_comp + 1); ++ci) {
     cptr comp = img + A.comp_off + ci * C_WORDS;
     switch (comp[C_W]) {  // rows are packed with the component's own word count
       case 1: hw_component<1>(A, img, comp, ci, fbit, shot, check, par, pw, out_w); break;
@@ -383,7 +387,27 @@ __device__ __forceinline__ void hw_row(const SampleArgs &A, long long row, bool 
   }
 #pragma unroll
   for (int w = 0; w < 4; ++w) out_w[w] = hw_or_u32(out_w[w]);
-  if (threadIdx.x == 0u) {
+  if (threadIdx.x == 0u && only_comp >= 0) {
+    // (every word this row's bytes touch: the neighbours' bytes get zeros ORed in; all stores of the first pass are complete)
+    if (A.out) {
+      uint32_t *orow = reinterpret_cast<uint32_t *>(A.out + row * A.WO);
+#pragma unroll
+      for (int w = 0; w < 4; ++w)
+        if (w < 2 * A.WO && out_w[w]) atomicOr(orow + w, out_w[w]);
+    }
+    if (A.out_compact) {
+      // the row as a little-endian byte string of out_rb <= 16 bytes, shifted to its place in the aligned words
+      const unsigned long long at = (unsigned long long)row * (unsigned long long)A.out_rb;
+      uint32_t *base = reinterpret_cast<uint32_t *>(A.out_compact + (at & ~3ull));
+      const uint32_t sh = 8u * (uint32_t)(at & 3ull);
+#pragma unroll
+      for (int w = 0; w < 5; ++w) {
+        const uint32_t cur = w < 4 ? out_w[w < 4 ? w : 0] : 0u, below = w > 0 ? out_w[w > 0 ? w - 1 : 0] : 0u;
+        const uint32_t v = sh ? ((cur << sh) | (below >> (32u - sh))) : cur;
+        if (v) atomicOr(base + w, v);
+      }
+    }
+  } else if (threadIdx.x == 0u) {
     if (A.out) {
       uint64_t *orow = A.out + row * A.WO;
       for (int w = 0; w < A.WO; ++w) orow[w] = (uint64_t)out_w[2 * w] | ((uint64_t)out_w[2 * w + 1] << 32);
@@ -398,9 +422,11 @@ __device__ __forceinline__ void hw_row(const SampleArgs &A, long long row, bool 
 // Every BLOCK (4 waves on one row at a time) serves ONE list of ONE launch: block j of a list takes its slots j,
 // j + waves_per_list, ...
 template <int W>
-__global__ void __launch_bounds__(1024) k_sample_hw(HwMulti M) {
+__global__ void __launch_bounds__(256) k_sample_hw(HwMulti M) {
   __builtin_amdgcn_s_setprio(3);  // a few hundred latency-bound waves beside a chip-full of issue-bound ones: issue when ready
-  const uint32_t wv = blockIdx.x;
+  const uint32_t cp = (uint32_t)M.comp_par;
+  const uint32_t wv = blockIdx.x / cp;
+  const int only_comp = cp > 1u ? (int)(blockIdx.x - wv * cp) : -1;
   const uint32_t per_ctx = (uint32_t)(M.max_lists * M.waves_per_list);
   const uint32_t c = wv / per_ctx;
   if (c >= (uint32_t)M.n_ctx) return;
@@ -410,7 +436,7 @@ __global__ void __launch_bounds__(1024) k_sample_hw(HwMulti M) {
   const uint32_t lane = threadIdx.x & 63u;
   // feedback to the host (mapped pinned memory, read at later launches to choose the launch plan): total and longest
   // hard-row list of the first launch of this batch
-  if (M.feedback && wv == 0u && threadIdx.x < 64u) {
+  if (M.feedback && blockIdx.x == 0u && threadIdx.x < 64u) {
     uint32_t cn = (int)lane < A.row_lists ? A.row_count[32u * lane] : 0u, mx = cn;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -427,8 +453,14 @@ __global__ void __launch_bounds__(1024) k_sample_hw(HwMulti M) {
   const uint32_t n = A.row_count[32u * k];
   const uint32_t check_row = (A.no_check || !A.check_row) ? 0xFFFFFFFFu : *A.check_row;
   for (uint32_t slot = j; slot < n; slot += (uint32_t)M.waves_per_list) {  // block-uniform
-    const uint32_t row = A.row_index[(size_t)k * A.row_list_cap + slot];
-    hw_row<W>(A, (long long)row, row == check_row, tsimk_lds, (uint32_t)M.par_words);
+    const uint32_t entry = A.row_index[(size_t)k * A.row_list_cap + slot];
+    if (only_comp >= 0) {
+      if (!((entry >> (28 + only_comp)) & 1u)) continue;  // block-uniform: this component's bits came from the tables
+      const uint32_t row = entry & 0x0FFFFFFFu;
+      hw_row<W>(A, (long long)row, row == check_row, tsimk_lds, (uint32_t)M.par_words, only_comp);
+    } else {
+      hw_row<W>(A, (long long)entry, entry == check_row, tsimk_lds, (uint32_t)M.par_words, -1);
+    }
   }
 }
 

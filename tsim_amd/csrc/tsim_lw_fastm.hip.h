@@ -88,8 +88,8 @@ __device__ __forceinline__ bool lwfm_component(const uint32_t *lds, const uint32
     node = 2u * node + (draw(i) < t0 ? 1u : 0u);
   }
   const u32x2 placed = *reinterpret_cast<const u32x2 *>(&lds[l_lut + 2u * (node & ((1u << NOUT) - 1u))]);
-  o0 |= placed.x;
-  o1 |= placed.y;
+  o0 |= hard ? 0u : placed.x;  // (a heavier pattern's walk went through some other pattern's tree)
+  o1 |= hard ? 0u : placed.y;
   return hard;
 }
 
@@ -172,6 +172,7 @@ __global__ void __launch_bounds__(1024) k_sample_lw_fastm(LwMultiArgs M) {
     o1 ^= flip1;
     // ---- the components, in processing order (sampler.py:147-148): every one runs, a row is finished here when none is hard
     bool hard = false;
+    uint32_t hmask = 0u;  // the components this row's pattern is not tabulated for
     const uint32_t slo = so_lo + row;
     cptr keys = (cptr)((cbytes)S + __builtin_offsetof(LwStep, keys));
     uint32_t l = 4u * TSIMK_LWF_MAX_RUNS;
@@ -188,14 +189,16 @@ __global__ void __launch_bounds__(1024) k_sample_lw_fastm(LwMultiArgs M) {
         default: break;
       }
       hard = hard || h;
+      hmask |= h ? (1u << c) : 0u;
     }
     if (M.has_check && rb == 0u && threadIdx.x == 0u) {  // the normalisation-check row (sampler.py:66-72): always hard
       hard = true;
+      hmask = (1u << n_comp) - 1u;  // every component is evaluated again, with trial bit 0 beside it
       S->ctl[32 * TSIMK_LW_LISTS] = row;
     }
     hard = hard && active;
     const bool easy = active && !hard;
-    if (easy) {
+    if (easy || (hard && M.partial)) {
       uint64_t *out = S->out;
       uint8_t *oc = S->out_compact;
       if (out) {
@@ -228,7 +231,7 @@ __global__ void __launch_bounds__(1024) k_sample_lw_fastm(LwMultiArgs M) {
       uint32_t *ctl = S->ctl;
       if (lane == leader) basei = atomicAdd(&ctl[32u * k], (uint32_t)__popcll(hm));
       basei = (uint32_t)__shfl((int)basei, leader, 64);
-      if (hard) S->hard_index[(size_t)k * M.list_cap + basei + (uint32_t)__popcll(hm & ((1ull << lane) - 1ull))] = row;
+      if (hard) S->hard_index[(size_t)k * M.list_cap + basei + (uint32_t)__popcll(hm & ((1ull << lane) - 1ull))] = M.partial ? (row | (hmask << 28)) : row;
     }
     if (!more) break;
     vb = vb_n;

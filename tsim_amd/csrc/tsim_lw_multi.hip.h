@@ -43,6 +43,9 @@ struct LwMultiArgs {
   int has_check, list_cap, n_lists, out_rb;
   int lwf_off;            // image offset of the fast record (k_sample_lw_fast), 0 = none
   uint32_t tab_bytes;     // size of the pattern tables when below 4 GB (k_sample_lw_fast: range-checked reads)
+  int partial;            // k_sample_lw_fastm: hard rows are stored too - direct outputs and the tabulated components' bits - and
+                          // their list entries carry the mask of the components that are NOT tabulated in bits 28.. (k_sample_hw then
+                          // evaluates exactly those, one block per (row, component), and ORs their bits in)
   LwStep step[TSIMK_LWM_MAX_STEPS];
 };
 

@@ -734,7 +734,6 @@ retry_pack:
     p->knobs.v4_block = (vb == 512 || vb == 128) ? vb : 256;
     p->knobs.hard_lds_kb = std::max(24, std::min(156, env_int("TSIM_AMD_HARD_LDS_KB", 128)));
     p->knobs.defer = env_int("TSIM_AMD_DEFER_HARD", 1) != 0;
-    p->knobs.batch_lanes = env_int("TSIM_AMD_BATCH_LANES", 1) >= 2 ? 2 : 1;
     p->knobs.prewait = env_int("TSIM_AMD_PREWAIT", 1) != 0;
     p->knobs.lw_reg = env_int("TSIM_AMD_LW_REG", 1) != 0;
     p->knobs.lw_resident = std::max(0, std::min(8, env_int("TSIM_AMD_LW_RESIDENT", 1)));
@@ -756,8 +755,8 @@ retry_pack:
     p->knobs.hard_wave = env_int("TSIM_AMD_HARD_WAVE", 1) != 0;
     if (const char *e = getenv("TSIM_AMD_HARD_INLINE_ROWS")) p->knobs.hard_inline_rows = std::max(0ll, atoll(e));
     p->knobs.deep_tables = env_int("TSIM_AMD_DEEP_TABLES", 0);
+    p->knobs.hard_comp_par = env_int("TSIM_AMD_HARD_COMP_PAR", 1) != 0;
     if (const char *e = getenv("TSIM_AMD_DEEP_AFTER")) p->knobs.deep_after = strtoull(e, nullptr, 10);
-    p->knobs.hard_lag = env_int("TSIM_AMD_HARD_LAG", 0) != 0;
     p->knobs.fused_lanes = std::max(0, std::min(4, env_int("TSIM_AMD_FUSED_LANES", 0)));
     p->knobs.hard_wave_rows = std::max(0, env_int("TSIM_AMD_HARD_WAVE_ROWS", 1024));
     p->knobs.fused_max = std::max(1, std::min(TSIMK_LWM_MAX_STEPS, env_int("TSIM_AMD_FUSED_MAX", 8)));
@@ -798,8 +797,8 @@ extern "C" void tsim_program_destroy(tsim_program *p) {
       if (sl.side_ready) (void)hipStreamSynchronize(sl.side);
     for (hipEvent_t e : p->ev_pool) (void)hipEventDestroy(e);
     if (getenv("TSIM_AMD_PIPELINE_STATS"))
-      fprintf(stderr, "tsim pipeline: begins %llu deferred %llu flushes %llu queries %llu waits %llu\n", p->stat_begins,
-              p->stat_deferred, p->stat_flushes, p->stat_queries, p->stat_waits);
+      fprintf(stderr, "tsim pipeline: begins %llu deferred %llu flushes %llu queries %llu waits %llu fused groups %llu (specialised %llu, component-parallel hard rows %llu)\n",
+              p->stat_begins, p->stat_deferred, p->stat_flushes, p->stat_queries, p->stat_waits, p->stat_fused, p->stat_fast, p->stat_partial);
     if (p->sync_ev) (void)hipEventDestroy(p->sync_ev);
     for (hipEvent_t e : p->lane_ev) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : p->batch_ev) if (e) (void)hipEventDestroy(e);

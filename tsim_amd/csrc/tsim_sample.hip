@@ -205,7 +205,7 @@ static bool hw_eligible(tsim_program *p, const SampleArgs &a, int n_ctx) {
   return p->fast && p->knobs.hard_wave && wmax <= 2 && a.WF <= 32 && a.WO <= 2 && p->hw_max_rows < 60000 &&
          (unsigned long long)fb_rows * (unsigned)n_ctx <= (unsigned long long)p->knobs.hard_wave_rows;
 }
-static int launch_hw(tsim_program *p, const SampleArgs *ctx, int n_ctx, int max_lists, hipStream_t hs) {
+static int launch_hw(tsim_program *p, const SampleArgs *ctx, int n_ctx, int max_lists, hipStream_t hs, bool partial) {
   int wmax = 1;
   for (int w : p->comp_w) wmax = std::max(wmax, w);
   const uint32_t fb_max = p->h_feedback ? p->h_feedback[1] : 192u;
@@ -221,12 +221,14 @@ static int launch_hw(tsim_program *p, const SampleArgs *ctx, int n_ctx, int max_
     H.ctx[i] = ctx[i];
     H.ctx[i].kernarg_off = (int)(offsetof(HwMulti, ctx) + (size_t)i * sizeof(SampleArgs));
   }
-  const unsigned gridw = (unsigned)((long long)H.n_ctx * H.max_lists * H.waves_per_list);
+  H.comp_par = partial ? (int)p->comps.size() : 1;  // the lists carry component masks: one block per (row, component)
+  const unsigned gridw = (unsigned)((long long)H.n_ctx * H.max_lists * H.waves_per_list * H.comp_par);
   H.par_words = (int)(2 * ((p->hw_max_rows + 63) / 64) + 2);
   const size_t ldsw = (size_t)H.par_words * 8 * 4 + 16;  // two buffers of four bit arrays (previous bit x trial bit) + the sampled bit.s word
-  static const int hw_block = getenv("TSIM_AMD_HW_BLOCK") ? std::max(128, std::min(1024, atoi(getenv("TSIM_AMD_HW_BLOCK")) / 64 * 64)) : 256;
-  if (wmax == 1) hipLaunchKernelGGL(k_sample_hw<1>, dim3(gridw), dim3(hw_block), ldsw, hs, H);
-  else hipLaunchKernelGGL(k_sample_hw<2>, dim3(gridw), dim3(hw_block), ldsw, hs, H);
+  // (blocks of 512 / 1024 threads - more helper waves per row - were tried: no faster alone, the row pass is not the chain;
+  // next to a first pass slower, 8.8 -> 8.3 / 5.9e10 at --steps 200)
+  if (wmax == 1) hipLaunchKernelGGL(k_sample_hw<1>, dim3(gridw), dim3(256), ldsw, hs, H);
+  else hipLaunchKernelGGL(k_sample_hw<2>, dim3(gridw), dim3(256), ldsw, hs, H);
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -239,17 +241,15 @@ static int flush_batch(tsim_program *p) {
     return 0;
   }
   constexpr int NW = TSIM_HARD_NW;
-  // TSIM_AMD_BATCH_LANES=2 alternates the batches over two lanes (the third and fourth slot's streams; batches of
-  // one lane complete in order).  Tried for C4, whose 205-us batches of 8 launches bound the pipeline at ~29 us per
-  // launch whatever the batch size: both streams landed on ONE hardware queue, the batches did not overlap
-  // (29.2 -> 27.6 us per step with GPU_MAX_HW_QUEUES=8) - off by default.
+  // (alternating the batches over two streams was tried for C4: both landed on ONE hardware queue, 29.2 -> 27.6 us per step
+  // only with GPU_MAX_HW_QUEUES=8 - gone)
   const unsigned long long seq = p->batch_next++;
   // Inline (steps_group_fused, small groups): the batch runs on the group's own first-pass lane, behind its first pass.
   // A hard-row batch is latency-bound - ~30 us for the distillation shapes, ~80 us for the cultivation one, however
   // few the rows - so on ONE batch stream the batches of small groups (8 x 10^5 shots: a 36-us first pass) are the
   // pipeline's period; on the two lanes they overlap each other and the other lane's first pass.
-  int bl = p->knobs.batch_lanes > 1 ? (int)(seq & 1ull) : 0;
-  hipStream_t hs = p->slots[3 + bl].side;
+  int bl = 0;
+  hipStream_t hs = p->slots[3].side;
   if (p->flush_inline) {
     hs = p->flush_inline;
     bl = 2;
@@ -285,8 +285,10 @@ static int flush_batch(tsim_program *p) {
       HIP_TRY(hipEventRecord(p->lane_ev[k], p->slots[1 + k].side));
       HIP_TRY(hipStreamWaitEvent(hs, p->lane_ev[k], 0));
     }
-  if (hw_eligible(p, M.ctx[0], M.n_ctx)) {
-    if (int r = launch_hw(p, M.ctx, M.n_ctx, max_lists, hs)) return r;
+  // (a group whose first pass stored partial rows and component masks - steps_group_fused - was promised this kernel)
+  const bool partial = p->slots[p->deferred[0]].partial;
+  if (partial || hw_eligible(p, M.ctx[0], M.n_ctx)) {
+    if (int r = launch_hw(p, M.ctx, M.n_ctx, max_lists, hs, partial)) return r;
   } else {
   const unsigned grid = (unsigned)(M.n_ctx * M.blocks_per_ctx);
   switch (p->v4_max_nch) {
@@ -343,26 +345,8 @@ static int flush_chunks(tsim_program *p) {
   return 0;
 }
 
-// Everything that is waiting: the lagged groups of the several-batches call (steps_group_fused: a fused group's hard rows
-// wait for the lane's NEXT first pass, so that the lane is not held up by a latency-bound grid between two first passes),
-// each as a batch on its own lane, then the launches parked by the per-step API.
-int tsim_flush_hard(tsim_program *p) {
-  bool any = false;
-  for (auto &l : p->lag) any = any || !l.empty();
-  if (any) {
-    std::vector<int> keep;
-    keep.swap(p->deferred);
-    for (int li = 0; li < 4; ++li) {
-      if (p->lag[li].empty()) continue;
-      p->deferred.swap(p->lag[li]);
-      p->lag[li].clear();
-      p->flush_inline = p->slots[1 + li].side;
-      if (int r = flush_chunks(p)) return r;
-    }
-    p->deferred.swap(keep);
-  }
-  return flush_chunks(p);
-}
+// Everything that is waiting: the launches parked by the per-step API.
+int tsim_flush_hard(tsim_program *p) { return flush_chunks(p); }
 
 // The arguments every sampling kernel of one launch shares (SampleArgs): per-output subkeys - key, subkey =
 // split(key) once per output, threaded through the components in processing order (sampler.py:74,147-148) - inline
@@ -695,13 +679,14 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
         sl.deferred = true;
         sl.pending = true;
         sl.p1_stream = s;
+        sl.partial = false;
         p->deferred.push_back(slot);
         if ((int)p->deferred.size() >= p->knobs.defer_group) return tsim_flush_hard(p);
         return 0;
       }
       if (group_tiles >= 1 && hw_eligible(p, a, 1)) {
         // few hard rows, fast row layout: one block per row (tsim_kernel_hw.hip.h), whole lists - nothing left for k_sample4
-        if (int r = launch_hw(p, &a, 1, a.row_lists, s)) return r;
+        if (int r = launch_hw(p, &a, 1, a.row_lists, s, false)) return r;
         if (prof && !p->prof_light) { int r = prof_event(p, s, PROF_HARD); if (r) return r; }
         if (prof && !(p->prof_light && use_tables)) { int r = prof_event(p, s, PROF_FULL); if (r) return r; }
         return finish();
@@ -825,7 +810,7 @@ extern "C" int tsim_sample_batch_device_begin(tsim_program *p, int32_t slot, con
   // no wait of its own) already waits for the batch the first launch of the next batch will ask for - known from
   // how far back the last such wait reached (lane_reach) and at least two flushes old, i.e. complete; that launch
   // then finds the lane already behind it.  Ordering only ever gets stricter.
-  if (plan.defer && p->knobs.prewait && p->knobs.batch_lanes == 1 && !p->inline_seen && p->deferred.size() >= 2) {
+  if (plan.defer && p->knobs.prewait && !p->inline_seen && p->deferred.size() >= 2) {
     const int lane = (s == p->slots[1].side) ? 0 : (s == p->slots[2].side) ? 1 : -1;
     if (lane >= 0 && p->lane_reach[lane] >= 3 && p->lane_reach[lane] <= 15 && p->batch_next > (unsigned long long)p->lane_reach[lane]) {
       const unsigned long long want = p->batch_next - (unsigned long long)(p->lane_reach[lane] - 1);
@@ -972,6 +957,7 @@ static int steps_group_fused(tsim_program *p, int n, const uint64_t *const *d_f,
   if (prof) { if (int r = prof_event(p, s, PROF_BEGIN)) return r; }
   // one component of at most 8 outputs: the specialised pass (tsim_lw_fast.hip.h) - 32-bit byte offsets everywhere, so
   // batches below 2^28 rows, tables below 4 GB, and a shot range that does not cross a multiple of 2^32
+  bool part = false;
   const bool fast = p->lwf_off != 0 && p->knobs.lw_fast && B < (1ll << 28) && p->lw_bytes < (1ll << 32) && (n_lists & (n_lists - 1)) == 0 &&
                     ((unsigned long long)shot_offset >> 32) == ((unsigned long long)(shot_offset + B - 1) >> 32);
   M.lwf_off = fast ? p->lwf_off : 0;
@@ -994,6 +980,21 @@ static int steps_group_fused(tsim_program *p, int n, const uint64_t *const *d_f,
     // 2..4 components of at most 8 outputs each: the specialised pass with per-component tables (tsim_lw_fastm.hip.h)
     M.lwf_off = p->lwfm_off;
     M.tab_bytes = (uint32_t)p->lw_bytes;
+    // Component-parallel hard rows: the pass stores the hard rows too (direct outputs + the tabulated components' bits) and
+    // marks in the list entry which components are left; k_sample_hw runs one block per (row, component) and ORs the bits in.
+    // C4's batches then wait for the slowest component (~25 us) instead of the three in turn (~65 us).  Decided HERE, once:
+    // the hard-row launch below must be the block-per-row kernel, whatever the feedback says by then.  (Compact rows are
+    // merged with 32-bit atomics: the batch's byte range must not share a word with another batch's.)
+    {
+      bool aligned = true;
+      for (int j = 0; j < n; ++j) {
+        const SampleArgs &aj = p->slots[slots[j]].ctx;
+        if (aj.out_compact && ((((uintptr_t)aj.out_compact) & 3u) || (((unsigned long long)B * (unsigned long long)aj.out_rb) & 3ull))) aligned = false;
+      }
+      part = p->knobs.hard_comp_par && p->comps.size() >= 2 && aligned && hw_eligible(p, p->slots[slots[0]].ctx, std::min(n, TSIMK_HW_MAX_CTX));
+      M.partial = part ? 1 : 0;
+      if (part) ++p->stat_partial;
+    }
     const unsigned rstr = 32u * (WF == 1 ? 2u : 4u) + 1u;
     unsigned l = 4u * TSIMK_LWF_MAX_RUNS;  // the kernel's LDS layout (same running sum there)
     for (auto &c : p->comps) {
@@ -1019,29 +1020,14 @@ static int steps_group_fused(tsim_program *p, int n, const uint64_t *const *d_f,
     sl.deferred = true;
     sl.pending = true;
     sl.p1_stream = s;
+    sl.partial = part;
     p->deferred.push_back(slots[j]);
   }
   p->stat_begins += (unsigned long long)n;
   p->stat_deferred += (unsigned long long)n;
   ++p->stat_fused;
   if ((long long)n * B <= p->knobs.hard_inline_rows) {
-    if (p->knobs.hard_lag) {
-      // this group's hard rows wait; the group that was waiting on this lane goes now - behind the first pass just launched
-      int li = 0;
-      for (int k = 0; k < 4; ++k)
-        if (s == p->slots[1 + k].side) li = k;
-      std::vector<int> mine;
-      mine.swap(p->deferred);  // (exactly this group's slots: earlier parked launches were flushed on entry)
-      int r = 0;
-      if (!p->lag[li].empty()) {
-        p->deferred.swap(p->lag[li]);
-        p->lag[li].clear();
-        p->flush_inline = s;
-        r = flush_chunks(p);
-      }
-      p->lag[li].swap(mine);
-      return r;
-    }
+    // (letting the hard rows wait for the lane's NEXT first pass was tried - profiles/r03/hard_lag_experiment.txt: slower)
     p->flush_inline = s;
   }
   const int rf = flush_chunks(p);
@@ -1165,21 +1151,9 @@ extern "C" int tsim_sample_steps_device(tsim_program *p, int32_t n_steps, const 
       const int gmax = std::min(TSIMK_LWM_MAX_STEPS, p->knobs.fused_max);
       // (20 batches as 7+7+6; 5+5+5+5 - both lanes ending together - measured slower: a launch more)
       const int groups = (left + gmax - 1) / gmax;
-      int n = (left + groups - 1) / groups;
-      if (const char *e = getenv("TSIM_AMD_FUSED_PLAN")) {  // experiments: "2,6,6,4,2" = the group sizes of a call, in order
-        int idx = 0, gi = 0;
-        for (int d2 = 0; d2 < done;) {  // which group are we at
-          int v = atoi(e + idx);
-          if (v < 1) break;
-          d2 += v;
-          ++gi;
-          const char *c2 = strchr(e + idx, ',');
-          if (!c2) { idx = -1; break; }
-          idx = (int)(c2 - e) + 1;
-        }
-        (void)gi;
-        if (idx >= 0) { const int v = atoi(e + idx); if (v >= 1) n = std::min(std::min(v, left), TSIMK_LWM_MAX_STEPS); }
-      }
+      const int n = (left + groups - 1) / groups;
+      // (group sizes that fill whole chip-fulls of first-pass blocks - 15 batches of 10^5 shots instead of 8 - make the first
+      // pass cheaper per batch and the step slower: two hard-row grids per group, C4 at 10^5 shots 1.88 -> 1.53e10, C2 3.6 -> 2.9e10)
       {
         const size_t hard_bytes = (size_t)(((B + 255) / 256 + TSIMK_LW_LISTS - 1) / TSIMK_LW_LISTS * 1024) * TSIMK_LW_LISTS * 4;
         for (int j = 0; j < n; ++j)
@@ -1298,7 +1272,7 @@ extern "C" int tsim_sample_batch_device_end(tsim_program *p, int32_t slot, void 
       bool own = s == p->stream;
       for (int k = 1; k <= 4 && !own; ++k) own = p->slots[k].side_ready && s == p->slots[k].side;
       // (per batch stream: batches of ONE stream complete in order, inline batches run on the first-pass lanes)
-      const bool in_order = own && sl.batch_seq != 0 && p->knobs.batch_lanes == 1;
+      const bool in_order = own && sl.batch_seq != 0;
       const int bl = sl.batch_lane;
       if (in_order && s == p->joined_stream && sl.batch_seq <= p->joined_seq[bl]) {
         // nothing to add

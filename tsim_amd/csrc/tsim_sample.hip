@@ -975,7 +975,7 @@ static int steps_group_fused(tsim_program *p, int n, const uint64_t *const *d_f,
     }
 #undef TSIM_LF
     ++p->stat_fast;
-  } else if (p->lwfm_off != 0 && p->knobs.lw_fast && blk1 == 1024 && B < (1ll << 28) && p->lw_bytes < (1ll << 32) &&
+  } else if (p->lwfm_off != 0 && p->knobs.lw_fast && B < (1ll << 28) && p->lw_bytes < (1ll << 32) &&
              (n_lists & (n_lists - 1)) == 0 && ((unsigned long long)shot_offset >> 32) == ((unsigned long long)(shot_offset + B - 1) >> 32)) {
     // 2..4 components of at most 8 outputs each: the specialised pass with per-component tables (tsim_lw_fastm.hip.h)
     M.lwf_off = p->lwfm_off;

@@ -122,7 +122,8 @@ struct LaunchPlan {
   int lists = TSIMK_LW_LISTS;  // hard-row sub-lists of this launch: about 40 expected rows each
 };
 
-static LaunchPlan make_plan(tsim_program *p, bool has_row_index, bool pipelined) {
+// `rows`: the rows the launches made under this plan will carry (the deepening rule counts them)
+static LaunchPlan make_plan(tsim_program *p, bool has_row_index, bool pipelined, unsigned long long rows) {
   LaunchPlan pl;
   pl.use_tables = p->lw;
   if (p->lw && p->h_feedback && p->knobs.adaptive) {
@@ -142,7 +143,7 @@ static LaunchPlan make_plan(tsim_program *p, bool has_row_index, bool pipelined)
       bool too_many_for_hw = p->knobs.deep_tables >= 0 && p->knobs.hard_wave &&
                              (unsigned long long)fb_sum * 8ull > (unsigned long long)p->knobs.hard_wave_rows && fb_rows >= 65536u;
       if (too_many_for_hw && p->knobs.deep_tables == 0) {
-        p->deep_rows += fb_rows;
+        p->deep_rows += rows;
         too_many_for_hw = p->deep_rows >= p->knobs.deep_after;
       }
       p->lw_dense_launches = ((double)fb_sum > 0.01 * (double)fb_rows || too_many_for_hw) ? p->lw_dense_launches + 1 : 0;
@@ -455,7 +456,7 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
     }
     return 0;
   };
-  const LaunchPlan plan = plan_in ? *plan_in : make_plan(p, d_row_index != nullptr, false);
+  const LaunchPlan plan = plan_in ? *plan_in : make_plan(p, d_row_index != nullptr, false, (unsigned long long)B);
   const bool use_tables = plan.use_tables, need_overflow = plan.need_overflow;
   // The sparse-column pass (k_sample4w) over every row, or - behind a pattern-table first pass - over that pass's
   // hard-row lists (from_lists; `a` then describes them).  Its own overflow (more than K set bits, the check row)
@@ -793,7 +794,7 @@ extern "C" int tsim_sample_batch_device_begin(tsim_program *p, int32_t slot, con
   // waits for a second pass before it starts the next first pass.
   if (sl.deferred)  // begin twice without end: finish the earlier launch's hard rows first
     if (int r = tsim_flush_hard(p)) return r;
-  const LaunchPlan plan = make_plan(p, false, true);
+  const LaunchPlan plan = make_plan(p, false, true, (unsigned long long)B);
   hipStream_t s = plan.defer ? p->slots[1 + (slot & 1)].side : sl.side;
   if (!plan.defer) {
     // the slot's own stream: tsim_pipeline_wait_stream orders only streams that carried work before - a first launch here
@@ -1141,7 +1142,7 @@ extern "C" int tsim_sample_steps_device(tsim_program *p, int32_t n_steps, const 
           if (int r = slot_prepare(p, k, hard_bytes)) return r;
         p->slots_ready = true;
       }
-      plan = make_plan(p, false, true);
+      plan = make_plan(p, false, true, (unsigned long long)std::min(n_steps - done, std::min(TSIMK_LWM_MAX_STEPS, p->knobs.fused_max)) * (unsigned long long)B);
       hard_geometry(p, WF, WO);
       TSIM_MARK("plan");
       fused = plan.defer && plan.use_tables && p->h_group_tiles >= 1;

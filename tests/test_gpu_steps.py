@@ -193,6 +193,40 @@ def test_component_parallel_hard_rows_agree_with_one_block_per_row(hip, packed, 
         np.testing.assert_array_equal(a, b)
 
 
+def test_tables_deepen_when_the_hard_rows_are_too_many_for_the_block_per_row_kernel(hip):
+    """C3 at weight-5 tables leaves ~340 hard rows per 10^6 shots: too many for k_sample_hw (more than
+    TSIM_AMD_HARD_WAVE_ROWS per eight launches), far below the 1 % of the dense rule.  A handle that has launched
+    TSIM_AMD_DEEP_AFTER rows in that state (here: 1) builds the weight-6 tables; TSIM_AMD_DEEP_TABLES=-1 never does.
+    Same rows from both, before and after the build."""
+    import os
+
+    B, n = 400_000, 8
+    runs, depths = [], []
+    for env in ({"TSIM_AMD_DEEP_AFTER": "1"}, {"TSIM_AMD_DEEP_TABLES": "-1"}):
+        os.environ.update(env)
+        try:
+            prog, cfg = synth.config_program("C3")
+            hp = hip.HipProgram(prog)
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+        nf = cfg["num_f"]
+        assert hp.info()["pattern_max_weight"] == [5]
+        fs = [synth.synth_f(B, nf, cfg["p_bit"], seed=300 + i) for i in range(n)]
+        outs = []
+        key = prng.key(5)
+        for call in range(6):
+            o, k2 = _run_steps(hp, prog, fs, key, nf, packed=True)
+            key = np.array(k2, dtype=np.uint32)
+            outs += [o[0], o[n - 1]]
+        depths.append(hp.info()["pattern_max_weight"])
+        runs.append(outs)
+        hp.close()
+    assert depths == [[6], [5]]
+    for a, b in zip(*runs):
+        np.testing.assert_array_equal(a, b)
+
+
 def test_steps_with_shot_offset_and_dense_rows(hip):
     """A shard (shot_offset > 0: no normalisation-check row) and batches dense enough that the launch plan leaves the
     fused path (many hard rows): still the oracle's bits."""

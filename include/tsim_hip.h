@@ -218,6 +218,11 @@ int tsim_sample_batch_device_begin(tsim_program *p, int32_t slot, const uint64_t
                                    int32_t num_f, uint32_t key_hi, uint32_t key_lo, int64_t shot_offset,
                                    uint64_t *d_out, float *d_max_norm_dev, void *stream, uint32_t flags);
 int tsim_sample_batch_device_end(tsim_program *p, int32_t slot, void *stream);
+/* Non-consuming form of _end: `stream` (NULL: the handle's stream) waits for the launch `slot` carried LAST, whether or
+ * not a stream has been joined to it before (_end marks the slot as joined and a second _end adds no wait).  What a
+ * producer needs before it overwrites the slot's INPUT buffer - the reference has no such hazard, its batches are
+ * synchronous (sampler.py:398-404) - when a consumer stream already took the slot's output. */
+int tsim_pipeline_wait_slot(tsim_program *p, int32_t slot, void *stream);
 /* Make every pipeline lane wait for the work already queued on `stream` (NULL: the handle's stream) -
  * one event for all lanes.  Launches whose buffers depend only on that work may then pass
  * TSIM_PIPE_INPUTS_READY (bench.py: once per gather group instead of once per launch). */

@@ -395,3 +395,39 @@ def test_wide_program_through_the_sampler_equals_oracle_twin(hip, monkeypatch):
                 assert all(np.array_equal(x, y) for x, y in zip(g, w))
             else:
                 assert np.array_equal(g, w)
+
+
+def test_more_batches_than_lanes_keep_their_f_rows(hip, monkeypatch):
+    """Host noise, many more batches than f buffers (one per pipeline lane), kernels much slower than uploads: the
+    cultivation shape on the full kernel (pattern tables off), 40 batches of 500 rows.  The upload of batch b + 8 reuses
+    the buffer batch b's kernels read; the guard is `tsim_pipeline_wait_slot` - `sample_batch_device_end` no longer waits
+    once the copy stream has joined the slot (torn rows).  Against the oracle-driven twin, bit for bit."""
+    prog, cfg = synth.config_program("C4")
+    nf = cfg["num_f"]
+    probs = [error_probs(0.2)] * nf  # dense rows: nothing is tabulated, every row walks 1024 graphs
+    et = np.eye(nf, dtype=np.uint8)
+    monkeypatch.setenv("TSIM_AMD_PATTERN_TABLES", "0")
+    got = CompiledDetectorSampler(prog, channel_probs=probs, error_transform=et, seed=5).sample(20000, batch_size=500, append_observables=True)
+    monkeypatch.delenv("TSIM_AMD_PATTERN_TABLES")
+    again = CompiledDetectorSampler(prog, channel_probs=probs, error_transform=et, seed=5).sample(20000, batch_size=500, append_observables=True)
+    assert np.array_equal(got, again)
+    monkeypatch.setattr(sampler_module, "sample_program", oracle_sample_program)
+    s = CompiledDetectorSampler(prog, channel_probs=probs, error_transform=et, seed=5)
+    s._channel_sampler._native = None
+    want = s.sample(1500, batch_size=500, append_observables=True)  # the oracle is slow on this shape: the first three batches
+    assert np.array_equal(got[:1500], want)
+
+
+def test_device_noise_ring_is_not_overwritten_before_it_is_sampled(hip):
+    """noise="device", more batches than the 32 f buffers of the ring: the noise kernel of batch k + 32 must wait for
+    batch k's sampling kernels (a non-consuming wait on the slot's completion event).  A torn ring shows as results that
+    differ between identically seeded runs or from the run that never wraps the ring (its first batches)."""
+    prog, cfg = synth.config_program("C2")
+    nf = cfg["num_f"]
+    kw = dict(channel_probs=[error_probs(0.02)] * nf, error_transform=np.eye(nf, dtype=np.uint8), seed=9, noise="device")
+    shots = 40 * (1 << 20)
+    a = CompiledDetectorSampler(prog, **kw).sample(shots, batch_size=1 << 20, append_observables=True, bit_packed=True)
+    b = CompiledDetectorSampler(prog, **kw).sample(shots, batch_size=1 << 20, append_observables=True, bit_packed=True)
+    assert np.array_equal(a, b)
+    c = CompiledDetectorSampler(prog, **kw).sample(8 << 20, batch_size=1 << 20, append_observables=True, bit_packed=True)
+    assert np.array_equal(a[: 8 << 20], c)

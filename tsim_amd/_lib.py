@@ -72,6 +72,7 @@ SYMBOLS: dict[str, tuple] = {
     "tsim_sample_batch_device": (C.c_int, [_P, _P, _I64, _I32, _U32, _U32, _I64, _P, _P, _P]),
     "tsim_sample_batch_device_begin": (C.c_int, [_P, _I32, _P, _I64, _I32, _U32, _U32, _I64, _P, _P, _P, _U32]),
     "tsim_sample_batch_device_end": (C.c_int, [_P, _I32, _P]),
+    "tsim_pipeline_wait_slot": (C.c_int, [_P, _I32, _P]),
     "tsim_pipeline_wait_stream": (C.c_int, [_P, _P]),
     "tsim_pipeline_join": (C.c_int, [_P, _P]),
     "tsim_pipeline_lane_stream": (C.c_int, [_P, _I32, C.POINTER(C.c_void_p)]),

@@ -439,6 +439,12 @@ class HipProgram:
         """Make ``stream`` (0: the handle's stream) wait for the slot's second pass."""
         _lib.check(self._lib.tsim_sample_batch_device_end(self._h, int(slot), stream or None), "tsim_sample_batch_device_end")
 
+    def pipeline_wait_slot(self, slot: int, stream: int = 0) -> None:
+        """``stream`` waits for the launch ``slot`` carried last, whether or not another stream joined it already
+        (``sample_batch_device_end`` is consumed by the first stream that calls it): the guard before a slot's input
+        buffer is refilled."""
+        _lib.check(self._lib.tsim_pipeline_wait_slot(self._h, int(slot), stream or None), "tsim_pipeline_wait_slot")
+
     def pipeline_lane_stream(self, lane: int) -> int:
         """``hipStream_t`` of pipeline lane ``lane`` as an integer; lane 2 is where deferred hard-row
         batches - i.e. results - complete (include/tsim_hip.h)."""

@@ -1294,6 +1294,20 @@ extern "C" int tsim_sample_batch_device_end(tsim_program *p, int32_t slot, void 
   return TSIM_OK;
 }
 
+// `stream` waits for the launch the slot carried last - also when another stream already joined it (_end cleared
+// `pending`): the guard of a producer that refills the slot's f buffer while a consumer stream owns its output.
+extern "C" int tsim_pipeline_wait_slot(tsim_program *p, int32_t slot, void *stream) {
+  if (int r = tsim_need_final(p)) return r;
+  if (int r = tsim_set_device(p)) return r;
+  if (slot < 0 || slot >= TSIM_PIPELINE_SLOTS) return tsim_fail(TSIM_EINVAL, "slot %d out of range", slot);
+  hipStream_t s = stream ? (hipStream_t)stream : p->stream;
+  tsim_program::Slot &sl = p->slots[1 + slot];
+  if (sl.deferred)  // its hard rows are still parked: run what is waiting now
+    if (int r = tsim_flush_hard(p)) return r;
+  if (sl.done_ev && sl.last_done && sl.last_done != s) HIP_TRY(hipStreamWaitEvent(s, sl.done_ev, 0));
+  return TSIM_OK;
+}
+
 // tsim_sample_batch_device_end for EVERY slot in one call (joining a pipeline on `stream`: one library call instead of
 // TSIM_PIPELINE_SLOTS - 32 ctypes round trips per gather group were ~60 us of host time in bench.py's N > 1 path)
 extern "C" int tsim_pipeline_join(tsim_program *p, void *stream) {

@@ -226,7 +226,13 @@ class _DevicePostselect:
             raise MemoryError(f"device post-selection of {shots} shots needs {need >> 20} MiB of device memory, {free >> 20} MiB are free: "
                               "sample in several calls")
         self._bufs = []
+        try:
+            self._allocate(hp, shots, size, test_mask, ref_det)
+        except BaseException:  # a malloc / upload failed half way: give back what was taken (the caller never sees `work`)
+            self.release()
+            raise
 
+    def _allocate(self, hp, shots: int, size: int, test_mask: np.ndarray, ref_det) -> None:
         def m(nbytes):
             self._bufs.append(hp.malloc(nbytes))
             return self._bufs[-1]
@@ -362,7 +368,13 @@ class _CompiledSamplerBase:
     def __init__(self, program, *, channel_probs: list, error_transform: np.ndarray, seed: int | None = None,
                  device: int = 0, noise: str = "host", mode: str = "auto"):
         """``noise="host"``: the reference's numpy channel stream, bit for bit; ``noise="device"``: channels
-        sampled on the GPU.  ``mode``: kernel formulation, see :class:`tsim_amd.backend.HipProgram`."""
+        sampled on the GPU.  ``mode``: kernel formulation, see :class:`tsim_amd.backend.HipProgram`.
+
+        ``batch_size`` in ``sample()``: with ``noise="host"`` it is the reference's batch size (the channel stream and the
+        key chain depend on it, ``sampler.py:377-399``).  With ``noise="device"`` there is no stream to reproduce, and a
+        ``batch_size`` below 2^20 is REPLACED by batches of about 2^20 shots (results for a fixed seed are those of that
+        batching, whatever ``batch_size`` was); the result buffers on the device are O(shots) either way, so on this path
+        ``batch_size`` does not bound device memory - split the request into several ``sample()`` calls for that."""
         if noise not in ("host", "device"):
             raise ValueError("noise must be 'host' or 'device'")
         if seed is None:
@@ -704,7 +716,10 @@ class _CompiledSamplerBase:
             first = hp.pipeline_next_slot()
             slots = [(first + i) % nslot for i in range(n)]
             for sl in slots:
-                hp.sample_batch_device_end(sl, s_noise)  # the slot's previous batch no longer reads its f buffer
+                # the slot's previous batch no longer reads its f buffer.  (Not sample_batch_device_end: download() has
+                # usually joined the slot on the copy stream already, and a joined slot adds no wait - the noise kernel of
+                # batch k + 32 would overwrite rows batch k still samples.)
+                hp.pipeline_wait_slot(sl, s_noise)
                 self._noise_key, nk = hp.split_key(self._noise_key)
                 noise.sample_into(f_ring[sl].ptr, size, nk, stream=s_noise)
             hp.pipeline_wait_stream(s_noise)  # every lane is behind the noise queued so far
@@ -720,10 +735,11 @@ class _CompiledSamplerBase:
             download(groups[done])
             done += 1
         self._key = (int(key_state[0]), int(key_state[1]))
-        hp.pipeline_join()  # the handle's stream is behind everything (the devs copy below runs there)
+        # the copy stream is behind every batch (download() joined each slot on it): once it has drained, every kernel
+        # that writes d_devs has finished - only then may the handle's stream read them
+        hp.stream_synchronize(s_copy)
         devs = np.zeros(plan.count * n_comp, dtype=np.float32)
         hp.d2h(devs, d_devs.ptr)
-        hp.stream_synchronize(s_copy)
         for b in range(plan.count):
             self._check_devs(devs[b * n_comp:(b + 1) * n_comp])
         if blocks is not None:
@@ -828,7 +844,9 @@ class _CompiledSamplerBase:
                 if rides and b == 0:
                     rows[0] = 0
                 lane = b % _LANES
-                hp.sample_batch_device_end(lane, s_up)  # the lane's previous launch no longer reads its f buffer
+                # the lane's previous launch no longer reads its f buffer (a non-consuming wait: download() joined that
+                # launch on the copy stream long ago, sample_batch_device_end would add nothing here)
+                hp.pipeline_wait_slot(lane, s_up)
                 hp.h2d_async(lanes[lane].ptr, rows, s_up)
                 hp.pipeline_wait_stream(s_up)  # every lane is behind the upload
                 hp.sample_batch_device_begin(lane, lanes[lane].ptr, size, num_f, self._next_key(),
@@ -839,14 +857,20 @@ class _CompiledSamplerBase:
                 hp.stream_synchronize(s_up)  # (0.15 ms per 8 MB) the staging buffer may be refilled
                 free_q.put(i)
             download(plan.count - 1)
+        except BaseException:
+            try:  # asynchronous copies into pooled pinned arrays may still be in flight: drain them before the arrays go back
+                hp.stream_synchronize(s_copy)
+            except Exception:
+                pass
+            raise
         finally:
             free_q.put(None)
             worker.join()
         for lane in range(min(_LANES, plan.count)):
             hp.sample_batch_device_end(lane)
+        hp.stream_synchronize(s_copy)  # behind every batch: the devs below are final
         devs = np.zeros(plan.count * n_comp, dtype=np.float32)
         hp.d2h(devs, d_devs.ptr)
-        hp.stream_synchronize(s_copy)
         skip = 1 if rides else 0
         if rides:
             if blocks is not None:  # (arranged output: the caller computed the reference row beforehand, see sample())

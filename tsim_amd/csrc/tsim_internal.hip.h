@@ -144,6 +144,7 @@ struct tsim_program {
   size_t v4w_occ_lds = 0;
   bool lw_reg = false;        // the register form of pass 1 applies (narrow f rows, ascending f_selection)
   int lwfm_off = 0;           // fast record of programs with 2..4 components of <= 8 outputs each (k_sample_lw_fastm), 0 = none
+  int wr_off = 0;             // image offset of the wide record (one wide component: k_sample_wide, tsim_wide.hip.h), 0 = none
   int lwf_off = 0;            // image offset of the fast record (one component of <= 8 outputs: k_sample_lw_fast), 0 = none
   // Launch slots: slot 0 serves the serial API (everything on the caller's stream); slots 1..4 serve
   // tsim_sample_batch_device_begin/_end: a slot's launches run on the slot's own stream (`side`) so
@@ -234,6 +235,7 @@ struct tsim_program {
     unsigned long long deep_after = 20000000000ull;  // TSIM_AMD_DEEP_AFTER
     int hard_wave_rows = 1024;  // TSIM_AMD_HARD_WAVE_ROWS: ... while a batch of launches has at most this many hard rows (last feedback)
     bool hard_wave = true;    // TSIM_AMD_HARD_WAVE=0: hard-row batches on k_sample4h_multi (64 rows per block) instead of one wave per row
+    bool wide_fused = true;   // TSIM_AMD_WIDE_FUSED=0: wide programs on the three-kernel path of round 2 (tables, k_sample4w, row kernel)
     bool lw_fast = true;      // TSIM_AMD_LW_FAST=0: the generic fused pass (k_sample_lw_multi) also for one-component programs
     int fused_max = 8;        // TSIM_AMD_FUSED_MAX: batches per fused first pass (<= TSIMK_LWM_MAX_STEPS = 16; hard rows in grids of <= TSIMK_H_MAX_CTX launches)
   } knobs;

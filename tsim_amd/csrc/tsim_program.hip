@@ -3,6 +3,7 @@
 #include "tsim_internal.hip.h"
 #include "tsim_lw_fastm.hip.h"
 #include "tsim_kernel4w.hip.h"  // C4_SELMASK
+#include "tsim_wide.hip.h"      // WR_*: the wide record
 
 using namespace tsimk;
 using namespace tsimhost;
@@ -528,6 +529,71 @@ retry_pack:
             for (int i = 1; i <= k + 1; ++i) c = c * (unsigned long long)(b - (k + 1) + i > 0 ? b - (k + 1) + i : 0) / (unsigned long long)i;
             img.push_back(b >= k + 1 ? (uint32_t)c : 0u);
           }
+        // The wide record (k_sample_wide, tsim_wide.hip.h): ONE component.  Direct outputs as rotate-and-mask runs sorted by
+        // destination word, constant flips per word, the placement table LUT[leaf][word] of the sampled bits (leaf = the bits
+        // in sampling order, first output most significant) and the mask of the words that hold component outputs.
+        p->wr_off = 0;
+        const int wo32 = 2 * ((p->num_outputs + 63) / 64);
+        if (p->comps.size() == 1 && p->comps[0].n_out >= 1 && p->comps[0].n_out <= 8 && wo32 >= 2 && wo32 <= 8) {
+          const HostComponent &c = p->comps[0];
+          std::vector<uint32_t> runs, runb(1, 0u), flips((size_t)wo32, 0u);
+          for (int d = 0; d < wo32; ++d) {
+            for (int sw = 0; sw < 2 * TSIMK_W_SELWORDS / 2; ++sw) {
+              std::vector<std::array<int, 2>> m;  // (src bit, dst bit) inside the words
+              for (int j = 0; j < p->n_direct; ++j) {
+                const int src = p->direct_f[j], dst = p->output_order[j];
+                if ((src >> 5) != sw || (dst >> 5) != d) continue;
+                m.push_back({src & 31, dst & 31});
+                if (p->direct_flips[j]) flips[(size_t)d] |= 1u << (dst & 31);
+              }
+              std::sort(m.begin(), m.end());
+              for (size_t i = 0; i < m.size();) {
+                size_t j = i + 1;
+                while (j < m.size() && m[j][0] == m[j - 1][0] + 1 && m[j][1] == m[j - 1][1] + 1) ++j;
+                const int len = (int)(j - i);
+                const uint32_t field = (len >= 32 ? 0xFFFFFFFFu : ((1u << len) - 1u)) << m[i][1];
+                runs.push_back((uint32_t)sw | ((uint32_t)((m[i][0] - m[i][1]) & 31) << 8));
+                runs.push_back(field);
+                i = j;
+              }
+            }
+            runb.push_back((uint32_t)(runs.size() / 2));
+          }
+          if (runs.size() / 2 <= TSIMK_WIDE_MAX_RUNS) {
+            while (img.size() % 16) img.push_back(0u);
+            p->wr_off = (int)img.size();
+            img.resize(img.size() + WR_WORDS, 0u);
+            const uint32_t runs_off = (uint32_t)img.size();
+            img.insert(img.end(), runs.begin(), runs.end());
+            const uint32_t runb_off = (uint32_t)img.size();
+            img.insert(img.end(), runb.begin(), runb.end());
+            const uint32_t flips_off = (uint32_t)img.size();
+            img.insert(img.end(), flips.begin(), flips.end());
+            const uint32_t lut_off = (uint32_t)img.size();
+            uint32_t lutmask = 0u;
+            for (uint32_t leaf = 0; leaf < (1u << c.n_out); ++leaf) {
+              std::vector<uint32_t> w((size_t)wo32, 0u);
+              for (int i = 0; i < c.n_out; ++i)
+                if ((leaf >> (c.n_out - 1 - i)) & 1u) {
+                  const int dst = c.output_indices[i];
+                  w[(size_t)(dst >> 5)] |= 1u << (dst & 31);
+                  lutmask |= 1u << (dst >> 5);
+                }
+              img.insert(img.end(), w.begin(), w.end());
+            }
+            size_t colbytes = 0;
+            for (auto &lv : c.levels) colbytes += (size_t)lv.G * (size_t)(c.F + 33) * 16;
+            uint32_t *h = &img[p->wr_off];
+            h[WR_NRUNS] = (uint32_t)(runs.size() / 2);
+            h[WR_RUNS] = runs_off;
+            h[WR_RUNB] = runb_off;
+            h[WR_FLIPS] = flips_off;
+            h[WR_LUT] = lut_off;
+            h[WR_LUTMASK] = lutmask;
+            h[WR_WO32] = (uint32_t)wo32;
+            h[WR_COLBYTES] = (uint32_t)colbytes;
+          }
+        }
       } else if (ok) {
         p->lw = true;
         // gather programs of every component's f_sel (the LDS-staged first pass)
@@ -752,6 +818,7 @@ retry_pack:
     p->knobs.defer_group = std::max(1, std::min(TSIMK_H_MAX_CTX, env_int("TSIM_AMD_DEFER_GROUP", p->knobs.defer_group)));
     p->knobs.fused_steps = env_int("TSIM_AMD_FUSED_STEPS", 1) != 0;
     p->knobs.lw_fast = env_int("TSIM_AMD_LW_FAST", 1) != 0;
+    p->knobs.wide_fused = env_int("TSIM_AMD_WIDE_FUSED", 1) != 0;
     p->knobs.hard_wave = env_int("TSIM_AMD_HARD_WAVE", 1) != 0;
     if (const char *e = getenv("TSIM_AMD_HARD_INLINE_ROWS")) p->knobs.hard_inline_rows = std::max(0ll, atoll(e));
     p->knobs.deep_tables = env_int("TSIM_AMD_DEEP_TABLES", 0);

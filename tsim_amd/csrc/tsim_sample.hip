@@ -13,6 +13,7 @@
 #include "tsim_kernel_hw.hip.h"
 #include "tsim_direct.hip.h"
 #include "tsim_lw_fastm.hip.h"
+#include "tsim_wide.hip.h"
 
 using namespace tsimk;
 using namespace tsimhost;
@@ -126,6 +127,33 @@ struct LaunchPlan {
 static LaunchPlan make_plan(tsim_program *p, bool has_row_index, bool pipelined, unsigned long long rows) {
   LaunchPlan pl;
   pl.use_tables = p->lw;
+  if (p->lw && p->lw_wide && p->wr_off != 0 && p->knobs.wide_fused && p->knobs.wide && !has_row_index) {
+    // One wide component (k_sample_wide): the kernel serves every row itself - nothing here decides coverage.  Two things
+    // follow its statistics (block 0's share of the last launch): a deeper table when many rows miss the current one
+    // (C5 at depth 3: 57 % -> depth 4, 2.1 GB built once: 37 %), and the round-2 path (sparse-column kernel with K = 10
+    // on every row + row kernel) for 15 launches when a quarter of the rows carry more set bits than a dense pass takes.
+    if (p->h_feedback && p->knobs.adaptive) {
+      const uint32_t heavy = p->h_feedback[4], missed = p->h_feedback[5], fb_rows = p->h_feedback[6];
+      const bool known = fb_rows != 0xFFFFFFFFu && fb_rows >= 4096u;
+      if (p->lw_direct_left > 0) {
+        --p->lw_direct_left;
+        pl.use_tables = false;
+      } else if (known && (double)heavy > 0.25 * (double)fb_rows) {
+        p->lw_direct_left = 15;
+        for (int i = 4; i < 8; ++i) p->h_feedback[i] = 0xFFFFFFFFu;
+        pl.use_tables = false;
+      } else if (known && p->lw_cap_now < p->lw_cap_max && p->knobs.deep_tables >= 0) {
+        p->lw_dense_launches = (double)missed > 0.2 * (double)fb_rows ? p->lw_dense_launches + 1 : 0;
+        if (p->lw_dense_launches >= 3) {
+          p->lw_dense_launches = 0;
+          if (tsim_synchronize(p) == TSIM_OK && tsim_tables_extend(p) == TSIM_OK)
+            for (int i = 4; i < 8; ++i) p->h_feedback[i] = 0xFFFFFFFFu;
+        }
+      }
+    }
+    (void)rows;
+    return pl;
+  }
   if (p->lw && p->h_feedback && p->knobs.adaptive) {
     uint32_t fb_sum = p->h_feedback[0], fb_max = p->h_feedback[1], fb_rows = p->h_feedback[2];
     // (counts of a tiny launch - the one-row reference sample, sampler.py:263-276 - say nothing about the batches to come:
@@ -413,6 +441,120 @@ static int fill_sample_args(tsim_program *p, tsim_program::Slot &sl, SampleArgs 
   return 0;
 }
 
+// ---------------------------------------------------------------------------
+// One wide component (k_sample_wide, tsim_wide.hip.h): up to TSIMK_LWM_MAX_STEPS batches as ONE grid of chip-resident
+// blocks - tables, sparse-column evaluation of the rows they miss, heavy rows and the normalisation check all inside.
+// ---------------------------------------------------------------------------
+struct WideLayout {
+  int block = 0;       // threads per block (0: the program does not fit)
+  size_t lds = 0;
+  int l_rank, l_lut, l_runs, l_sel, l_ptrs, l_keys, l_wave, wave_bytes, w_list, w_q, w_ovf;
+};
+static WideLayout wide_layout(const tsim_program *p, int WF32) {
+  WideLayout L;
+  const HostComponent &c = p->comps[0];
+  const uint32_t *wr = &p->img[p->wr_off];
+  const int wo32 = (int)wr[WR_WO32];
+  auto up = [](size_t v, size_t a) { return (v + a - 1) / a * a; };
+  size_t off = up(wr[WR_COLBYTES], 16);
+  L.l_rank = (int)off;  off += (size_t)4 * (c.F + 1) * 4;
+  off = up(off, 16);
+  L.l_lut = (int)off;   off += ((size_t)wo32 << c.n_out) * 4;
+  off = up(off, 16);
+  L.l_runs = (int)off;  off += (size_t)(2 * TSIMK_WIDE_MAX_RUNS + 48) * 4;
+  L.l_sel = (int)off;   off += 32 * 4;
+  L.l_ptrs = (int)off;  off += (size_t)TSIMK_LWM_MAX_STEPS * 4 * 4;
+  L.l_keys = (int)off;  off += (size_t)TSIMK_LWM_MAX_STEPS * 2 * TSIMK_LWM_KEYS * 4;
+  off = up(off, 16);
+  L.l_wave = (int)off;
+  size_t w = (size_t)64 * WF32 * 4;
+  w = up(w, 16);
+  L.w_list = (int)w;    w += 64 * 16;
+  L.w_q = (int)w;       w += (size_t)(4 + c.n_out) * TSIMK_WIDE_QCAP * 4;
+  L.w_ovf = (int)w;     w += (size_t)TSIMK_WIDE_QCAP * 4;
+  L.wave_bytes = (int)up(w, 16);
+  for (int blk : {1024, 512, 256}) {  // 16 waves per CU when everything fits beside the column tables, fewer otherwise
+    const size_t tot = off + (size_t)(blk / 64) * L.wave_bytes + 64;  // + the kernel's static words
+    if (tot <= 160 * 1024) {
+      L.block = blk;
+      L.lds = off + (size_t)(blk / 64) * L.wave_bytes;
+      break;
+    }
+  }
+  return L;
+}
+
+// can this launch go to k_sample_wide?  (32-bit offsets: batches below 2^28 rows, tables below 4 GB, a shot range that does
+// not cross a multiple of 2^32; bit_packed rows are written and merged as dwords)
+static bool wide_applies(const tsim_program *p, int64_t B, int32_t num_f, int64_t shot_offset) {
+  if (!(p->lw && p->lw_wide && p->wr_off != 0 && p->knobs.wide_fused && p->knobs.wide)) return false;
+  if (p->total_keys <= 0 || p->total_keys > TSIMK_LWM_KEYS || B <= 0 || B >= (1ll << 28) || p->lw_bytes >= (1ll << 32)) return false;
+  if (((unsigned long long)shot_offset >> 32) != ((unsigned long long)(shot_offset + B - 1) >> 32)) return false;
+  const int WF = std::max(1, (num_f + 63) / 64);
+  return WF <= 8 && wide_layout(p, 2 * WF).block != 0;
+}
+static bool wide_buffers_ok(const tsim_program *p, const SampleArgs &a) {
+  if (!a.out_compact) return true;
+  return (a.out_rb & 3) == 0 && (((uintptr_t)a.out_compact) & 3u) == 0u && a.out_rb / 4 <= 2 * ((p->num_outputs + 63) / 64);
+}
+
+// `args[j]`: the SampleArgs of batch j as fill_sample_args made them (buffers, inline keys)
+static int launch_wide(tsim_program *p, int n, const SampleArgs *const *args, int64_t B, int32_t num_f, int64_t shot_offset, hipStream_t s) {
+  const int WF32 = 2 * std::max(1, (num_f + 63) / 64);
+  const WideLayout L = wide_layout(p, WF32);
+  if (!L.block) return tsim_fail(TSIM_ESTATE, "wide kernel does not fit");
+  WideArgs W{};
+  W.img = p->d_img;
+  W.tab = p->d_lw_tab;
+  W.B = B;
+  W.shot_offset = shot_offset;
+  W.n_steps = n;
+  W.chunks_per_step = (int)((B + 63) / 64);
+  W.has_check = shot_offset == 0 ? 1 : 0;
+  W.out_rb = (p->num_outputs + 7) / 8;
+  W.WF32 = WF32;
+  W.lw_off = p->lw_off;
+  W.comp4_off = p->comp4_off;
+  W.wr_off = p->wr_off;
+  W.binom_off = p->lw_binom_off;
+  W.tab_bytes = (uint32_t)p->lw_bytes;
+  W.feedback = p->d_feedback;
+  W.l_rank = L.l_rank; W.l_lut = L.l_lut; W.l_runs = L.l_runs; W.l_sel = L.l_sel; W.l_ptrs = L.l_ptrs; W.l_keys = L.l_keys;
+  W.l_wave = L.l_wave; W.wave_bytes = L.wave_bytes; W.w_list = L.w_list; W.w_q = L.w_q; W.w_ovf = L.w_ovf;
+  for (int j = 0; j < n; ++j) {
+    const SampleArgs &a = *args[j];
+    WideStep &st = W.step[j];
+    st.f = a.f;
+    st.out = a.out;
+    st.out_compact = a.out_compact;
+    st.norm_dev = a.norm_dev;
+    memcpy(st.keys, a.inline_keys, sizeof(uint32_t) * 2 * (size_t)p->total_keys);
+  }
+  const long long chunks = (long long)W.chunks_per_step * n;
+  const int wpb = L.block / 64;
+  // chip-resident blocks: as many as the LDS lets a CU hold (one of 1024 threads when the program is C5-sized)
+  const int per_cu = std::max(1, (int)((160 * 1024) / (L.lds + 64)));
+  const long long grid = std::max(1ll, std::min((long long)p->n_cu * per_cu, (chunks + wpb - 1) / wpb));
+  const int wo32 = (int)p->img[p->wr_off + WR_WO32];
+#define TSIM_LWIDE(N)                                                                                                   \
+  case N: {                                                                                                             \
+    auto kfn = k_sample_wide<N, TSIMK_WIDE_K>;                                                                          \
+    static bool attr_set = false;                                                                                       \
+    if (!attr_set) {                                                                                                    \
+      HIP_TRY(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));     \
+      attr_set = true;                                                                                                  \
+    }                                                                                                                   \
+    hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(L.block), L.lds, s, W);                                          \
+  } break;
+  switch (wo32) {
+    TSIM_LWIDE(2) TSIM_LWIDE(4) TSIM_LWIDE(6) TSIM_LWIDE(8)
+    default: return tsim_fail(TSIM_ESTATE, "wide record with %d output words", wo32);
+  }
+#undef TSIM_LWIDE
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_t num_f, uint32_t key_hi,
                          uint32_t key_lo, int64_t shot_offset, uint64_t *d_out, float *d_dev, hipStream_t s,
                          const uint32_t *d_row_index = nullptr, const uint32_t *d_row_count = nullptr,
@@ -528,6 +670,13 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
     B2 = list_cap;
     return 0;
   };
+  if (use_tables && !d_row_index && wide_applies(p, B, num_f, shot_offset) && wide_buffers_ok(p, a)) {
+    // one wide component: everything in one kernel (tsim_wide.hip.h), here as a group of one batch
+    const SampleArgs *one = &a;
+    if (int r = launch_wide(p, 1, &one, B, num_f, shot_offset, s)) return r;
+    if (prof) { int r = prof_event(p, s, PROF_PASS1); if (r) return r; }
+    return finish();
+  }
   if (use_tables) {
     // pass 1: shots whose f_sel patterns are tabulated finish here, the others go to the hard list
     if (B > 0xFFFFFFFFll) return tsim_fail(TSIM_ENOTSUP, "batch too large for the row list");
@@ -1097,6 +1246,61 @@ static int steps_group_direct(tsim_program *p, int n, const uint64_t *const *d_f
   return 0;
 }
 
+// One wide component: up to `n` batches as one k_sample_wide grid on a first-pass lane, lanes alternating between groups.
+// Nothing is left behind a group - no hard-row lists, no second kernel: the group's slots are done when the grid is.
+static int steps_group_wide(tsim_program *p, int n, const uint64_t *const *d_f, int64_t B, int32_t num_f, uint32_t key[2],
+                            int64_t shot_offset, void *const *d_out, float *const *d_dev, uint32_t flags) {
+  const bool packed = (flags & TSIM_PIPE_OUT_BIT_PACKED) != 0;
+  if (!p->deferred.empty())
+    if (int r = tsim_flush_hard(p)) return r;
+  hipStream_t s = p->slots[1 + (int)(p->steps_groups++ & 1ull)].side;
+  if (!(flags & TSIM_PIPE_INPUTS_READY) && p->stream != s) {
+    if (!p->sync_ev) HIP_TRY(hipEventCreateWithFlags(&p->sync_ev, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(p->sync_ev, p->stream));
+    HIP_TRY(hipStreamWaitEvent(s, p->sync_ev, 0));
+  }
+  const SampleArgs *args[TSIMK_LWM_MAX_STEPS];
+  int first = 0;
+  for (int j = 0; j < n; ++j) {
+    const int sidx = 1 + (int)(p->steps_slot++ % (unsigned long long)TSIM_PIPELINE_SLOTS);
+    if (j == 0) first = sidx;
+    tsim_program::Slot &sl = p->slots[sidx];
+    if (sl.deferred) return tsim_fail(TSIM_ESTATE, "pipeline slot %d still holds a parked launch", sidx - 1);
+    if (int r = slot_order_after_previous(p, sl, s)) return r;
+    uint32_t o[4];
+    tsim_key_split(key[0], key[1], o);  // key, subkey = split(key)  (sampler.py:399)
+    key[0] = o[0];
+    key[1] = o[1];
+    SampleArgs &a = sl.ctx;
+    a = SampleArgs{};
+    if (int r = fill_sample_args(p, sl, a, d_f[j], B, num_f, o[2], o[3], shot_offset, (uint64_t *)d_out[j], d_dev ? d_dev[j] : nullptr, s, sidx, packed))
+      return r;
+    if (!wide_buffers_ok(p, a)) return tsim_fail(TSIM_ESTATE, "bit_packed rows of the wide kernel must be dword-aligned");
+    args[j] = &a;
+  }
+  TSIM_MARK("args");
+  const bool prof = p->profiling && (p->prof_counter++ % p->prof_every == 0);
+  if (prof) { if (int r = prof_event(p, s, PROF_BEGIN)) return r; }
+  if (int r = launch_wide(p, n, args, B, num_f, shot_offset, s)) return r;
+  TSIM_MARK("launch");
+  if (prof) {
+    if (int r = prof_event(p, s, PROF_PASS1)) return r;
+    p->prof_steps += n;
+  }
+  hipEvent_t ev = p->slots[first].ev2;
+  HIP_TRY(hipEventRecord(ev, s));
+  for (int j = 0; j < n; ++j) {
+    tsim_program::Slot &sl = p->slots[1 + (int)((p->steps_slot - (unsigned long long)n + (unsigned long long)j) % (unsigned long long)TSIM_PIPELINE_SLOTS)];
+    sl.pending = true;
+    sl.last_done = s;
+    sl.done_ev = ev;
+    sl.batch_seq = 0;
+  }
+  p->stat_begins += (unsigned long long)n;
+  ++p->stat_fused;
+  return 0;
+}
+
 extern "C" int tsim_sample_steps_device(tsim_program *p, int32_t n_steps, const uint64_t *const *d_f, int64_t B, int32_t num_f,
                                         uint32_t key[2], int64_t shot_offset, void *const *d_out, float *const *d_max_norm_dev,
                                         uint32_t flags) {
@@ -1133,6 +1337,36 @@ extern "C" int tsim_sample_steps_device(tsim_program *p, int32_t n_steps, const 
       if (int r = steps_group_direct(p, n, d_f + done, B, num_f, key, d_out + done, flags)) return r;
       done += n;
       continue;
+    }
+    // one wide component: groups of batches through k_sample_wide (bit_packed rows must be dwords)
+    if (p->knobs.fused_steps && wide_applies(p, B, num_f, shot_offset) && p->series_left == 0) {
+      const int left = n_steps - done;
+      const int gmax = std::min(TSIMK_LWM_MAX_STEPS, p->knobs.fused_max);
+      const int groups = (left + gmax - 1) / gmax;
+      const int n = (left + groups - 1) / groups;
+      bool okb = true;
+      if (flags & TSIM_PIPE_OUT_BIT_PACKED) {
+        okb = (((p->num_outputs + 7) / 8) & 3) == 0;
+        for (int j = 0; j < n; ++j) okb = okb && (((uintptr_t)d_out[done + j]) & 3u) == 0u;
+      } else {
+        for (int j = 0; j < n; ++j) okb = okb && !p->slots[1 + (int)((p->steps_slot + (unsigned long long)j) % (unsigned long long)TSIM_PIPELINE_SLOTS)].compact_out;
+      }
+      if (okb) {
+        if (!p->slots_ready) {
+          const size_t hard_bytes = (size_t)(((B + 255) / 256 + TSIMK_LW_LISTS - 1) / TSIMK_LW_LISTS * 1024) * TSIMK_LW_LISTS * 4;
+          for (int k = 1; k <= TSIM_PIPELINE_SLOTS; ++k)
+            if (int r = slot_prepare(p, k, hard_bytes)) return r;
+          p->slots_ready = true;
+        }
+        const LaunchPlan wplan = make_plan(p, false, true, (unsigned long long)n * (unsigned long long)B);
+        TSIM_MARK("plan");
+        if (wplan.use_tables) {
+          if (int r = steps_group_wide(p, n, d_f + done, B, num_f, key, shot_offset, d_out + done, d_max_norm_dev ? d_max_norm_dev + done : nullptr, flags))
+            return r;
+          done += n;
+          continue;
+        }
+      }
     }
     LaunchPlan plan;
     if (fused) {

@@ -1,0 +1,521 @@
+// tsim_wide.hip.h - ONE pass for programs with one WIDE component (more than 64 parameters, up to 255 selected f bits,
+// at most 8 outputs: BASELINE config C5, the d = 5 surface code with an injected T), k_sample_wide.
+//
+// Round 2-3 served these with three kernels per batch - a pattern-table pass over every row (k_sample_lw<true>), the
+// sparse-column kernel on the rows the tables miss (k_sample4w, through row lists), the row kernel on ITS overflow and
+// on the normalisation-check row - each re-reading the f rows it was handed: 161 MB of traffic per 10^6 shots for
+// 56 MB of algorithmic bytes, 12 waves per CU, a launch triple per batch (profiles/r03/c5_pmc.txt).  This kernel does
+// everything sample_program does (reference: src/tsim/sampler.py:117-167, _sample_component :28-81) for up to 16 batches
+// in one grid of chip-resident blocks, reading every f row ONCE:
+//
+//   phase 1, a wave on 64 consecutive rows (one lane = one shot): the rows arrive by LDS-DMA (coalesced, no staging
+//     registers; the next chunk's copy is in flight while this one is worked on); direct outputs as bit-field runs; the
+//     selected set bits of the row -> their positions inside f_sel (one byte each, ascending); weight <= table depth: colex
+//     rank -> the pattern's threshold tree (tsim_lw.hip.h), n_out draws, done.  The draws are taken for EVERY row here
+//     (they depend on (key, shot) only), so the rows the tables miss keep theirs;
+//   phase 2, the same wave, whenever 64 missed rows have collected in its LDS queue (position list + draws, 28 bytes
+//     a row): the sparse-column evaluation of tsim_kernel4w.hip.h - Y_g = XOR of the K <= 12 column entries of the
+//     row's set bits and the two outcome-bit chunks, column tables of all levels resident in LDS - on 64 DENSE lanes,
+//     then acc_graph4 / acc_finish4, |amp|, p1 / prev against the stored draw, chain rule: the same values as every other
+//     kernel of the library.  The component's bits are ORed into the row phase 1 already wrote (32-bit atomics);
+//   generic pass, for rows with more than K set bits (3e-4 of C5's rows) and for the normalisation-check row
+//     (sampler.py:66-72: lane 0 replays shot 0 with trial bit 1, lane 1 with trial bit 0): the same evaluation with Y_g
+//     formed by walking the row's set bits, whatever their number.
+//
+// No row lists, no second kernel, no launch-plan feedback that results or coverage depend on: the only thing the host
+// learns is the share of missed / heavy rows of block 0 (a statistic: deeper tables, or the round-2 path for dense noise).
+#pragma once
+#include "tsim_kernel4w.hip.h"
+#include "tsim_lw_fast.hip.h"
+
+namespace tsimk {
+
+// wide record in the program image (uint32 words, 64-byte aligned)
+enum {
+  WR_NRUNS = 0,   // direct-output runs, sorted by destination word
+  WR_RUNS,        // image offset: n_runs x (src_word | rot << 8, mask)
+  WR_RUNB,        // image offset: WO32 + 1 run boundaries (runs of destination word d: [RUNB[d], RUNB[d + 1]))
+  WR_FLIPS,       // image offset: WO32 constant-flip words
+  WR_LUT,         // image offset: [2^n_out][WO32] placement of the sampled bits (leaf = bits in sampling order, first output most significant)
+  WR_LUTMASK,     // bit d set: destination word d holds component outputs
+  WR_WO32,        // 32-bit words per output row the record was built for
+  WR_COLBYTES,    // bytes of the column tables of all levels (LDS resident)
+  WR_WORDS = 16
+};
+#define TSIMK_WIDE_K 12        // set bits per row the dense pass takes
+#define TSIMK_WIDE_QCAP 128    // ring capacities (power of two, >= 127)
+#define TSIMK_WIDE_MAX_RUNS 256
+
+struct WideStep {
+  const uint64_t *f;      // [B, WF] packed error-mechanism rows of this batch
+  uint64_t *out;          // [B, WO] padded output rows, or nullptr
+  uint8_t *out_compact;   // [B, out_rb] bit_packed rows (out_rb a multiple of 4, 4-byte aligned), or nullptr
+  float *norm_dev;        // [1] or nullptr
+  uint32_t keys[2 * TSIMK_LWM_KEYS];  // per-output subkeys of this batch (sampler.py:74,147-148), host-computed
+};
+
+struct WideArgs {
+  const uint32_t *img;
+  const uint32_t *tab;      // integer thresholds (bernoulli_threshold) of the component
+  long long B;              // rows per batch (< 2^28)
+  long long shot_offset;    // in-batch index of row 0, the same for every batch of the group
+  int n_steps, chunks_per_step;
+  int has_check, out_rb, WF32;
+  int lw_off, comp4_off, wr_off, binom_off;
+  uint32_t tab_bytes;
+  uint32_t *feedback;       // optional (mapped host memory): [4] rows with more than K set bits, [5] rows the tables missed, [6] rows - estimates from block 0
+  // LDS layout in bytes, computed by the launcher (tsim_sample.hip: wide_layout)
+  int l_rank, l_lut, l_runs, l_sel, l_ptrs, l_keys, l_wave, wave_bytes, w_list, w_q, w_ovf;
+  WideStep step[TSIMK_LWM_MAX_STEPS];
+};
+
+// threefry_bits32 with per-lane keys (the generic pass: lanes of one pass may belong to different batches)
+__device__ __forceinline__ uint32_t threefry_bits32_v(uint32_t k0, uint32_t k1, uint32_t hi, uint32_t lo) {
+  uint32_t x0 = hi, x1 = lo;
+  threefry2x32(k0, k1, x0, x1);
+  return x0 ^ x1;
+}
+
+template <int WO32, int K>
+__global__ void __launch_bounds__(1024) k_sample_wide(WideArgs A) {
+  typedef const __attribute__((address_space(4))) uint8_t *cbytes;
+  typedef const __attribute__((address_space(4))) WideStep *cstep;
+  typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(3))) void *lds_ptr_t;
+  typedef const __attribute__((address_space(1))) void *glb_ptr_t;
+  static_assert(K % 2 == 0 && K <= 12, "position lists are three words");
+  constexpr uint32_t QCAP = TSIMK_WIDE_QCAP;
+  const int nthr = blockDim.x;
+  const uint32_t lane = threadIdx.x & 63u, wpb = (uint32_t)nthr >> 6;
+  const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform: everything derived from it stays scalar
+  cptr img = (cptr)(uintptr_t)A.img;
+  cptr comp = img + A.comp4_off;
+  cptr rec = img + A.lw_off;
+  cptr wr = img + A.wr_off;
+  const uint32_t n_out = comp[C_NOUT], F = comp[C_F];
+  cptr levels = img + comp[C4_LEVELS];
+  const uint32_t WF32 = (uint32_t)A.WF32;
+  const uint32_t ent_bytes = (F + 33u) * 16u;  // one graph's column table
+  uint8_t *lds8 = reinterpret_cast<uint8_t *>(tsimk_lds);
+  uint32_t *l_rank = tsimk_lds + (A.l_rank >> 2);  // [4][F + 1]: C(position, ordinal + 1), 0 at position F
+  uint32_t *l_lut = tsimk_lds + (A.l_lut >> 2);    // [2^n_out][WO32]
+  uint32_t *l_runs = tsimk_lds + (A.l_runs >> 2);  // runs (2 words each), then RUNB[WO32 + 1], FLIPS[WO32], BASES[8]
+  uint32_t *l_sel = tsimk_lds + (A.l_sel >> 2);    // 16 selection masks, 16 prefix counts
+  uint32_t *l_ptrs = tsimk_lds + (A.l_ptrs >> 2);  // per step: out (2 words), out_compact (2 words)
+  uint32_t *l_keys = tsimk_lds + (A.l_keys >> 2);  // per step: 2 * TSIMK_LWM_KEYS subkey words
+  cstep steps = (cstep)((cbytes)__builtin_amdgcn_kernarg_segment_ptr() + __builtin_offsetof(WideArgs, step));
+
+  // ---- once per block: everything loop-invariant into LDS
+  const uint32_t n_runs = wr[WR_NRUNS];
+  {
+    uint32_t off = 0;
+    for (uint32_t li = 0; li <= n_out; ++li) {  // the column tables of every level: one burst of LDS-DMA
+      cptr lvl = levels + li * L4_WORDS;
+      const uint32_t bytes = lvl[L4_G] * ent_bytes;
+      tile_copy(reinterpret_cast<const uint4 *>(A.img + lvl[L4_STAB]), lds8 + off, bytes >> 4, threadIdx.x, nthr);
+      off += bytes;
+    }
+    const uint32_t *g = A.img;
+    for (uint32_t i = threadIdx.x; i < 4u * (F + 1u); i += nthr) {
+      const uint32_t k = i / (F + 1u), b = i - k * (F + 1u);
+      l_rank[i] = b < F ? g[A.binom_off + k * 256u + b] : 0u;
+    }
+    for (uint32_t i = threadIdx.x; i < ((uint32_t)WO32 << n_out); i += nthr) l_lut[i] = g[wr[WR_LUT] + i];
+    for (uint32_t i = threadIdx.x; i < 2u * n_runs; i += nthr) l_runs[i] = g[wr[WR_RUNS] + i];
+    if (threadIdx.x <= (uint32_t)WO32) l_runs[2u * TSIMK_WIDE_MAX_RUNS + threadIdx.x] = g[wr[WR_RUNB] + threadIdx.x];
+    if (threadIdx.x < (uint32_t)WO32) l_runs[2u * TSIMK_WIDE_MAX_RUNS + 16u + threadIdx.x] = g[wr[WR_FLIPS] + threadIdx.x];
+    if (threadIdx.x < 8u) l_runs[2u * TSIMK_WIDE_MAX_RUNS + 32u + threadIdx.x] = g[A.lw_off + LW_BASES_INLINE + threadIdx.x];
+    if (threadIdx.x < 32u) l_sel[threadIdx.x] = g[comp[C4_SELMASK] + threadIdx.x];
+    for (uint32_t i = threadIdx.x; i < 4u * (uint32_t)A.n_steps; i += nthr) {
+      const uint64_t ptr = (i & 2u) ? (uint64_t)(uintptr_t)steps[i >> 2].out_compact : (uint64_t)(uintptr_t)steps[i >> 2].out;
+      l_ptrs[i] = (i & 1u) ? (uint32_t)(ptr >> 32) : (uint32_t)ptr;
+    }
+    for (uint32_t i = threadIdx.x; i < 2u * TSIMK_LWM_KEYS * (uint32_t)A.n_steps; i += nthr)
+      l_keys[i] = steps[i / (2u * TSIMK_LWM_KEYS)].keys[i % (2u * TSIMK_LWM_KEYS)];
+    __syncthreads();
+  }
+  const uint32_t *l_runb = l_runs + 2u * TSIMK_WIDE_MAX_RUNS, *l_flips = l_runb + 16u, *l_bases = l_runb + 32u;
+  const uint32_t lds_col0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)lds8;
+
+  // ---- this wave's LDS: the staged f rows, the position lists, the queue of missed rows, the ring of heavy rows
+  uint8_t *w8 = lds8 + A.l_wave + wv * (uint32_t)A.wave_bytes;
+  uint32_t *w_f = reinterpret_cast<uint32_t *>(w8);                  // [64][WF32] rows as they lie in HBM
+  uint32_t *w_list = reinterpret_cast<uint32_t *>(w8 + A.w_list);    // [64][4]: 16 position bytes per lane
+  uint32_t *w_q = reinterpret_cast<uint32_t *>(w8 + A.w_q);          // [4 + n_out][QCAP]: id, 3 position words, draws
+  uint32_t *w_ovf = reinterpret_cast<uint32_t *>(w8 + A.w_ovf);      // [QCAP] ids
+  uint32_t qhead = 0, qtail = 0, ohead = 0, otail = 0;              // wave-uniform
+  uint32_t n_missed = 0, n_heavy = 0;
+
+  const uint32_t wmax = rec[LW_WMAX];
+  const uint32_t tab_byte = rec[LW_TAB] * 4u;
+  const uint32_t keybase = rec[LW_KEYBASE];
+  const uint32_t lutmask = wr[WR_LUTMASK];
+  const __amdgpu_buffer_rsrc_t r_tab = __builtin_amdgcn_make_buffer_rsrc((void *)A.tab, 0, A.tab_bytes, 0x00020000);
+  const uint32_t so_lo = (uint32_t)A.shot_offset, so_hi = (uint32_t)((unsigned long long)A.shot_offset >> 32);
+  const uint32_t Bu = (uint32_t)A.B;
+  const uint32_t cps = (uint32_t)A.chunks_per_step;
+  const uint32_t total = cps * (uint32_t)A.n_steps;
+  const uint32_t zero_col = F * 16u;
+  const uint32_t zsplat = F * 0x01010101u;
+
+  // the f rows of chunk c -> w_f (LDS-DMA: 64 consecutive dwords per instruction, rows as they lie in HBM)
+  auto stage_chunk = [&](uint32_t c) {
+    const uint32_t st = c / cps, ch = c - st * cps;
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(steps[st].f) + (size_t)ch * 64u * WF32;
+    const uint32_t valid = (Bu - ch * 64u < 64u ? Bu - ch * 64u : 64u) * WF32;  // dwords of this chunk inside the batch
+    for (uint32_t w = 0; w < WF32; ++w) {
+      const uint32_t j = w * 64u + lane;
+      if (j < valid) __builtin_amdgcn_global_load_lds((glb_ptr_t)(src + j), (lds_ptr_t)(w_f + w * 64u), 4, 0, 0);
+    }
+  };
+  // K14: direct outputs f[idx] ^ flip (sampler.py:140-145) of the row staged at frow: rotate-and-mask runs per destination word
+  auto direct_words = [&](const uint32_t *frow, uint32_t (&o)[WO32]) {
+#pragma unroll
+    for (int d = 0; d < WO32; ++d) {
+      uint32_t acc = l_flips[d];
+      const uint32_t r1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)l_runb[d + 1]);
+      for (uint32_t r = (uint32_t)__builtin_amdgcn_readfirstlane((int)l_runb[d]); r < r1; ++r) {
+        const u32x2 run = *reinterpret_cast<const u32x2 *>(&l_runs[2u * r]);
+        const uint32_t ctl = (uint32_t)__builtin_amdgcn_readfirstlane((int)run.x);
+        const uint32_t fw = frow[ctl & 255u];
+        acc ^= __builtin_amdgcn_alignbit(fw, fw, ctl >> 8) & run.y;
+      }
+      o[d] = acc;
+    }
+  };
+  // a row's words -> HBM (every word of the padded row / the whole bit_packed row: dword stores)
+  auto store_row = [&](uint32_t st_lo_out, uint32_t st_hi_out, uint32_t st_lo_oc, uint32_t st_hi_oc, uint32_t row, const uint32_t (&o)[WO32]) {
+    uint32_t *out = reinterpret_cast<uint32_t *>((uintptr_t)(((uint64_t)st_hi_out << 32) | st_lo_out));
+    uint32_t *oc = reinterpret_cast<uint32_t *>((uintptr_t)(((uint64_t)st_hi_oc << 32) | st_lo_oc));
+    if (out) {
+      uint32_t *dst = out + (size_t)row * WO32;
+      if constexpr (WO32 == 4) *reinterpret_cast<u32x4 *>(dst) = u32x4{o[0], o[1], o[2], o[3]};
+      else {
+#pragma unroll
+        for (int d = 0; d < WO32; d += 2) *reinterpret_cast<u32x2 *>(dst + d) = u32x2{o[d], o[d + 1]};
+      }
+    }
+    if (oc) {
+      const uint32_t nd = (uint32_t)A.out_rb >> 2;
+      uint32_t *dst = oc + (size_t)row * nd;
+      if (WO32 == 4 && nd == 4u && (((uintptr_t)oc) & 15u) == 0u) *reinterpret_cast<u32x4 *>(dst) = u32x4{o[0], o[1], o[2], o[WO32 > 3 ? 3 : 0]};
+      else {
+#pragma unroll
+        for (int d = 0; d < WO32; ++d)
+          if ((uint32_t)d < nd) dst[d] = o[d];
+      }
+    }
+  };
+
+  // ------------------------------------------------------------------------------------------------------------
+  // phase 2: n (<= 64) queued rows, slots qhead .. qhead + n - 1: the sparse-column evaluation on dense lanes
+  // ------------------------------------------------------------------------------------------------------------
+  auto dense_pass = [&](uint32_t n) {
+    const bool on = lane < n;
+    const uint32_t slot = (qhead + lane) & (QCAP - 1u);
+    const uint32_t id = on ? w_q[slot] : 0u;
+    const uint32_t p0 = on ? w_q[QCAP + slot] : zsplat, p1 = on ? w_q[2u * QCAP + slot] : zsplat, p2 = on ? w_q[3u * QCAP + slot] : zsplat;
+    uint32_t col[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const uint32_t pw = (k < 4) ? p0 : (k < 8) ? p1 : p2;
+      col[k] = (k & 3) == 0 ? ((pw << 4) & 0xFF0u) : ((pw >> (8 * (k & 3) - 4)) & 0xFF0u);
+    }
+    uint32_t mb = 0, leaf = 0, lvl_off = 0;
+    float prev = 0.0f;
+    for (uint32_t li = 0; li <= n_out; ++li) {
+      cptr lvl = levels + li * L4_WORDS;
+      if (li > 0) mb |= 1u << (li - 1u);  // trial bit 1 (sampler.py:65)
+      uint32_t e[K + 2];
+#pragma unroll
+      for (int k = 0; k < K; ++k) e[k] = col[k];
+      e[K] = (F + 1u + (mb & 15u)) * 16u;
+      e[K + 1] = (F + 17u + ((mb >> 4) & 15u)) * 16u;
+      float re, im;
+      if ((lvl[L4_FLAGS] & TSIMK_LFLAG_FIXED) != 0) eval_level4_resident<K + 2, true>(A.img, img, lvl, e, lds_col0 + lvl_off, ent_bytes, re, im);
+      else eval_level4_resident<K + 2, false>(A.img, img, lvl, e, lds_col0 + lvl_off, ent_bytes, re, im);
+      lvl_off += lvl[L4_G] * ent_bytes;
+      const float v1 = cabs32(re, im);
+      if (li == 0) { prev = v1; continue; }
+      const uint32_t i = li - 1u;
+      const uint32_t m = w_q[(4u + i) * QCAP + slot];  // the draw phase 1 took for this output: bits >> 9
+      const float u = __uint_as_float(m | 0x3F800000u) - 1.0f;
+      const bool bit = u < __fdiv_rn(v1, prev);  // sampler.py:74-75
+      if (!bit) mb &= ~(1u << i);
+      prev = bit ? v1 : __fsub_rn(prev, v1);     // sampler.py:79
+      leaf = 2u * leaf + (bit ? 1u : 0u);
+    }
+    if (on) {  // the component's bits join the row phase 1 stored (same wave, earlier, vmcnt drained since)
+      const uint32_t st = id >> 28, row = id & 0x0FFFFFFFu;
+      const u32x4 pt = *reinterpret_cast<const u32x4 *>(&l_ptrs[4u * st]);
+      uint32_t *out = reinterpret_cast<uint32_t *>((uintptr_t)(((uint64_t)pt.y << 32) | pt.x));
+      uint32_t *oc = reinterpret_cast<uint32_t *>((uintptr_t)(((uint64_t)pt.w << 32) | pt.z));
+      const uint32_t nd = (uint32_t)A.out_rb >> 2;
+#pragma unroll
+      for (int d = 0; d < WO32; ++d)
+        if ((lutmask >> d) & 1u) {
+          const uint32_t v = l_lut[leaf * (uint32_t)WO32 + (uint32_t)d];
+          if (v != 0u) {
+            if (out) atomicOr(out + (size_t)row * WO32 + d, v);
+            if (oc && (uint32_t)d < nd) atomicOr(oc + (size_t)row * nd + d, v);
+          }
+        }
+    }
+    qhead += n;
+  };
+
+  // ------------------------------------------------------------------------------------------------------------
+  // generic pass: rows of any weight (ids from the ring of heavy rows), or - check - the normalisation check of batch
+  // `check_step`: lanes 0 and 1 replay its row 0 with trial bit 1 / 0 (sampler.py:66-72).  Uses w_f as its staging.
+  // ------------------------------------------------------------------------------------------------------------
+  auto generic_pass = [&](uint32_t n, bool check, uint32_t check_step) {
+    const bool on = check ? (lane < 2u) : (lane < n);
+    const uint32_t id = check ? (check_step << 28) : (on ? w_ovf[(ohead + lane) & (QCAP - 1u)] : 0u);
+    const uint32_t st = id >> 28, row = id & 0x0FFFFFFFu;
+    const bool trial0 = check && lane == 1u;
+    uint32_t *frow = w_f + lane * WF32;
+    {
+      const uint32_t *src = reinterpret_cast<const uint32_t *>(steps[0].f);
+      {  // the lane's batch: its f pointer from the kernel arguments (16 candidates, select by step)
+        uint64_t fp = (uint64_t)(uintptr_t)steps[0].f;
+        for (int s = 1; s < A.n_steps; ++s) fp = (st == (uint32_t)s) ? (uint64_t)(uintptr_t)steps[s].f : fp;
+        src = reinterpret_cast<const uint32_t *>((uintptr_t)fp);
+      }
+      for (uint32_t w = 0; w < WF32; ++w) frow[w] = on ? src[(size_t)row * WF32 + w] : 0u;
+    }
+    uint32_t o[WO32];
+    direct_words(frow, o);
+    const uint32_t *keys = l_keys + st * (2u * TSIMK_LWM_KEYS) + 2u * keybase;
+    const uint32_t slo = so_lo + row;
+    uint32_t mb = 0, leaf = 0, lvl_off = 0;
+    float prev = 0.0f, maxdev = 0.0f;
+    for (uint32_t li = 0; li <= n_out; ++li) {
+      cptr lvl = levels + li * L4_WORDS;
+      if (li > 0) mb = trial0 ? (mb & ~(1u << (li - 1u))) : (mb | (1u << (li - 1u)));
+      const uint32_t G = lvl[L4_G];
+      const bool fixed = (lvl[L4_FLAGS] & TSIMK_LFLAG_FIXED) != 0, approx = (lvl[L4_FLAGS] & TSIMK_LFLAG_APPROX) != 0;
+      cptr recs = img + lvl[L4_RECS];
+      Acc4 S;
+      for (uint32_t g = 0; g < G; ++g) {
+        const uint8_t *tbl = lds8 + lvl_off + g * ent_bytes;
+        u32x4 y = *reinterpret_cast<const u32x4 *>(tbl + (F + 1u + (mb & 15u)) * 16u);
+        {
+          const u32x4 t = *reinterpret_cast<const u32x4 *>(tbl + (F + 17u + ((mb >> 4) & 15u)) * 16u);
+          y.x ^= t.x; y.y ^= t.y; y.z ^= t.z; y.w ^= t.w;
+        }
+        for (uint32_t w = 0; w < WF32 && w < 16u; ++w) {
+          const uint32_t sw = l_sel[w], base = l_sel[16u + w];
+          uint32_t m = frow[w] & sw;
+          while (m) {
+            const uint32_t p = (uint32_t)__builtin_ctz(m);
+            const uint32_t pos = base + (uint32_t)__builtin_popcount(sw & ((1u << p) - 1u));
+            const u32x4 t = *reinterpret_cast<const u32x4 *>(tbl + pos * 16u);
+            y.x ^= t.x; y.y ^= t.y; y.z ^= t.z; y.w ^= t.w;
+            m &= m - 1u;
+          }
+        }
+        if (fixed) acc_graph4<true>(S, A.img, recs + g * G4_WORDS, y.x, y.y, y.z, y.w, approx);
+        else acc_graph4<false>(S, A.img, recs + g * G4_WORDS, y.x, y.y, y.z, y.w, approx);
+      }
+      float re, im;
+      if (fixed) acc_finish4<true>(S, lvl, approx, re, im);
+      else acc_finish4<false>(S, lvl, approx, re, im);
+      lvl_off += G * ent_bytes;
+      float v1 = cabs32(re, im), v0 = 0.0f;
+      if (check) {  // wave-uniform
+        v0 = __shfl(v1, 1, 64);
+        v1 = __shfl(v1, 0, 64);
+      }
+      if (li == 0) { prev = v1; continue; }
+      const uint32_t i = li - 1u;
+      if (check) {
+        const float norm = __fdiv_rn(__fadd_rn(v0, v1), prev);  // sampler.py:71
+        maxdev = nanmax(maxdev, fabsf(__fsub_rn(norm, 1.0f)));  // sampler.py:72
+      }
+      const uint32_t m = threefry_bits32_v(keys[2u * i], keys[2u * i + 1u], so_hi, slo) >> 9;
+      const float u = __uint_as_float(m | 0x3F800000u) - 1.0f;
+      const bool bit = u < __fdiv_rn(v1, prev);
+      mb = bit ? (mb | (1u << i)) : (mb & ~(1u << i));
+      prev = bit ? v1 : __fsub_rn(prev, v1);
+      leaf = 2u * leaf + (bit ? 1u : 0u);
+    }
+    if (check) {
+      float *nd = steps[check_step].norm_dev;
+      if (lane == 0u && nd) nd[0] = maxdev;
+    } else {
+      if (on) {
+#pragma unroll
+        for (int d = 0; d < WO32; ++d) o[d] |= l_lut[leaf * (uint32_t)WO32 + (uint32_t)d];
+        const u32x4 pt = *reinterpret_cast<const u32x4 *>(&l_ptrs[4u * st]);
+        store_row(pt.x, pt.y, pt.z, pt.w, row, o);
+      }
+      ohead += n;
+    }
+  };
+
+  // ------------------------------------------------------------------------------------------------------------
+  // the chunks of this wave: c = global wave index, + waves of the grid, ...  One loop, one call site per pass:
+  //   w_f free (no copy in flight): the normalisation check / heavy rows that are due, then the next chunk's copy;
+  //   dense passes while 64 missed rows are queued (the copy travels meanwhile); then the chunk itself.
+  // ------------------------------------------------------------------------------------------------------------
+  const uint32_t tw = gridDim.x * wpb;
+  uint32_t c = blockIdx.x * wpb + wv;
+  bool staged = false;
+  uint32_t check_pending = 0u;  // step + 1 of a batch whose normalisation check is due
+  for (;;) {
+    const bool done = c >= total;
+    if (!staged) {
+      if (check_pending) {
+        generic_pass(0u, true, check_pending - 1u);
+        check_pending = 0u;
+        continue;
+      }
+      if (otail - ohead >= 64u || (done && otail != ohead)) {
+        generic_pass(otail - ohead < 64u ? otail - ohead : 64u, false, 0u);
+        continue;
+      }
+      if (!done) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every read of w_f has returned
+        stage_chunk(c);
+        staged = true;
+      }
+    }
+    if (qtail - qhead >= 64u || (done && qtail != qhead)) {
+      dense_pass(qtail - qhead < 64u ? qtail - qhead : 64u);
+      continue;
+    }
+    if (done) break;
+    const uint32_t st = c / cps, ch = c - st * cps;
+    cstep S = steps + st;
+    const uint32_t row = ch * 64u + lane;
+    const bool active = row < Bu;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this chunk's rows are in w_f (and every earlier store of this wave has left)
+    const uint32_t *frow = w_f + lane * WF32;
+    // ---- direct outputs
+    uint32_t o[WO32];
+    direct_words(frow, o);
+    // ---- the selected set bits: weight, and their positions inside f_sel as bytes (ascending; F = "none")
+    *reinterpret_cast<u32x4 *>(&w_list[4u * lane]) = u32x4{zsplat, zsplat, zsplat, zsplat};
+    uint32_t cnt = 0;
+    {
+      uint8_t *lb = reinterpret_cast<uint8_t *>(&w_list[4u * lane]);
+      for (uint32_t w = 0; w < WF32 && w < 16u; ++w) {
+        const uint32_t sw = l_sel[w], base = l_sel[16u + w];
+        uint32_t m = active ? (frow[w] & sw) : 0u;
+        while (m) {
+          const uint32_t p = (uint32_t)__builtin_ctz(m);
+          const uint32_t pos = base + (uint32_t)__builtin_popcount(sw & ((1u << p) - 1u));
+          lb[cnt < 15u ? cnt : 15u] = (uint8_t)pos;
+          ++cnt;
+          m &= m - 1u;
+        }
+      }
+    }
+    const bool hit = active && cnt <= wmax;
+    const bool miss = active && cnt > wmax && cnt <= (uint32_t)K;
+    const bool heavy = active && cnt > (uint32_t)K;
+    // ---- colex rank of a tabulated pattern: sum over its set bits of C(position, ordinal + 1) (tsim_lw.hip.h)
+    const u32x4 lst = *reinterpret_cast<const u32x4 *>(&w_list[4u * lane]);
+    uint32_t pat = l_bases[cnt < 7u ? cnt : 7u];
+#pragma unroll
+    for (int k = 0; k < TSIMK_LWW_MAX_WEIGHT; ++k) pat += l_rank[(uint32_t)k * (F + 1u) + ((lst.x >> (8 * k)) & 255u)];
+    pat = hit ? pat : 0u;
+    const uint32_t thr = tab_byte + (pat << (n_out + 2u));  // byte offset of the pattern's threshold tree
+    // ---- the draws of every output (sampler.py:74-75): functions of (subkey, shot) only
+    const uint32_t slo = so_lo + row;  // (the launcher keeps shot_offset + B below the next multiple of 2^32)
+    cptr kp = (cptr)((cbytes)S + __builtin_offsetof(WideStep, keys)) + 2u * keybase;
+    uint32_t dr[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      dr[i] = 0u;
+      if ((uint32_t)i < n_out) {
+        const uint32_t k0 = kp[2 * i], k1 = kp[2 * i + 1];
+        dr[i] = threefry_bits32_lo(k0, k1, k0 + so_hi, slo) >> 9;
+      }
+    }
+    // ---- tabulated rows: walk the threshold tree, three levels per read (tsim_lw_pass.hip.h: lw_walk_impl)
+    uint32_t node = 1u;
+#pragma unroll
+    for (int i = 0; i + 3 <= 8; i += 3)
+      if ((uint32_t)(i + 3) <= n_out) {
+        const uint32_t t0 = __builtin_amdgcn_raw_buffer_load_b32(r_tab, thr + 4u * node, 0, 0);
+        const u32x2 t1 = __builtin_amdgcn_raw_buffer_load_b64(r_tab, thr + 8u * node, 0, 0);
+        const u32x4 t2 = __builtin_amdgcn_raw_buffer_load_b128(r_tab, thr + 16u * node, 0, 0);
+        const bool b0 = dr[i] < t0;
+        const bool b1 = dr[i + 1] < (b0 ? t1.y : t1.x);
+        const uint32_t lo = b1 ? t2.y : t2.x, hi = b1 ? t2.w : t2.z;
+        const bool b2 = dr[i + 2] < (b0 ? hi : lo);
+        node = 8u * node + (b0 ? 4u : 0u) + (b1 ? 2u : 0u) + (b2 ? 1u : 0u);
+      }
+#pragma unroll
+    for (int i = 0; i <= 6; i += 3)
+      if (n_out / 3u * 3u == (uint32_t)i && n_out % 3u != 0u) {
+        const uint32_t t0 = __builtin_amdgcn_raw_buffer_load_b32(r_tab, thr + 4u * node, 0, 0);
+        const bool b0 = dr[i] < t0;
+        if (n_out % 3u == 2u) {
+          const u32x2 t1 = __builtin_amdgcn_raw_buffer_load_b64(r_tab, thr + 8u * node, 0, 0);
+          const bool b1 = dr[i + 1 < 8 ? i + 1 : 7] < (b0 ? t1.y : t1.x);
+          node = 4u * node + (b0 ? 2u : 0u) + (b1 ? 1u : 0u);
+        } else {
+          node = 2u * node + (b0 ? 1u : 0u);
+        }
+      }
+    const uint32_t leaf = hit ? (node & ((1u << n_out) - 1u)) : 0u;
+    if (hit) {
+#pragma unroll
+      for (int d = 0; d < WO32; ++d) o[d] |= l_lut[leaf * (uint32_t)WO32 + (uint32_t)d];
+    }
+    // ---- every row leaves now: finished (tabulated) or with its component bits still zero
+    if (active) store_row((uint32_t)(uintptr_t)S->out, (uint32_t)((uint64_t)(uintptr_t)S->out >> 32), (uint32_t)(uintptr_t)S->out_compact,
+                          (uint32_t)((uint64_t)(uintptr_t)S->out_compact >> 32), row, o);
+    // ---- missed rows -> the queue (position list + draws); heavy rows -> their ring
+    {
+      const unsigned long long mm = __builtin_amdgcn_ballot_w64(miss);
+      if (mm != 0ull) {
+        if (miss) {
+          const uint32_t slot = (qtail + (uint32_t)__popcll(mm & ((1ull << lane) - 1ull))) & (QCAP - 1u);
+          w_q[slot] = (st << 28) | row;
+          w_q[QCAP + slot] = lst.x;
+          w_q[2u * QCAP + slot] = lst.y;
+          w_q[3u * QCAP + slot] = lst.z;
+#pragma unroll
+          for (int i = 0; i < 8; ++i)
+            if ((uint32_t)i < n_out) w_q[(4u + (uint32_t)i) * QCAP + slot] = dr[i];
+        }
+        qtail += (uint32_t)__popcll(mm);
+        n_missed += (uint32_t)__popcll(mm);
+      }
+      const unsigned long long hm = __builtin_amdgcn_ballot_w64(heavy);
+      if (hm != 0ull) {
+        if (heavy) w_ovf[(otail + (uint32_t)__popcll(hm & ((1ull << lane) - 1ull))) & (QCAP - 1u)] = (st << 28) | row;
+        otail += (uint32_t)__popcll(hm);
+        n_heavy += (uint32_t)__popcll(hm);
+      }
+    }
+    if (A.has_check && ch == 0u) check_pending = st + 1u;  // this batch's row 0 lives in this chunk (sampler.py:66-72)
+    staged = false;
+    c += tw;
+  }
+  // ---- launch-plan statistics: block 0's share, scaled to the grid (a sample: nothing but heuristics reads it)
+  if (A.feedback && blockIdx.x == 0) {
+    __shared__ uint32_t s_cnt[2];
+    if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0u;
+    __syncthreads();
+    if (lane == 0u) {
+      atomicAdd(&s_cnt[0], n_heavy);
+      atomicAdd(&s_cnt[1], n_missed);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const unsigned long long rows = (unsigned long long)Bu * (unsigned long long)A.n_steps;
+      const unsigned long long scale = gridDim.x;
+      // (words 4.. of the feedback block: the round-2 kernels keep words 0..2 for their list counts)
+      A.feedback[4] = (uint32_t)min((unsigned long long)s_cnt[0] * scale, 0xFFFFFFFEull);
+      A.feedback[5] = (uint32_t)min((unsigned long long)s_cnt[1] * scale, 0xFFFFFFFEull);
+      A.feedback[6] = (uint32_t)min(rows, 0xFFFFFFFEull);
+    }
+  }
+}
+
+}  // namespace tsimk

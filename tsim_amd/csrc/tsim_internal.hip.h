@@ -71,6 +71,7 @@ struct HostLevel {
   std::vector<uint32_t> graph_rec;        // G * G_WORDS (row offsets relative to `rows`)
   std::vector<uint32_t> rows;             // packed rows, built for word count W
   long long n_rows = 0;
+  uint32_t tt_off = 0, tt_words = 0;      // fast layout: the level's term tables in the image (one contiguous block)
   // raw copy of the description (packing happens at finalize when W is known)
   tsim_level_desc d{};
   std::vector<uint8_t> u8[14];

@@ -82,10 +82,25 @@ struct Acc4 {
 //   word O2   : PhasePairs index bits, lambda (bit 30), linear bit (bit 31)
 // Fixed-frame levels: the table gather of graph g is consumed while graph g+1 is being formed (software pipelining
 // of the VMEM latency).
-template <bool FIXED>
+// LT: the term tables of the level were copied to LDS (k_sample_wide); word offset w of the image is then the LDS byte
+// address tt_bias + 4 w - no trip to L2 on the dependency chain of a level.
+template <bool FIXED, bool LT = false>
 __device__ __forceinline__ void acc_graph4(Acc4 &S, const uint32_t *gimg, cptr gr, uint32_t U, uint32_t V, uint32_t O1,
-                                           uint32_t O2, bool approx) {
+                                           uint32_t O2, bool approx, uint32_t tt_bias = 0u) {
   constexpr bool fixed = FIXED;
+  typedef uint32_t tt_u32x4 __attribute__((ext_vector_type(4)));
+  auto ld4 = [&](uint32_t w) -> uint4 {
+    if constexpr (LT) {
+      const tt_u32x4 v = *(const __attribute__((address_space(3))) tt_u32x4 *)(uintptr_t)(tt_bias + 4u * w);
+      return make_uint4(v.x, v.y, v.z, v.w);
+    } else {
+      return *reinterpret_cast<const uint4 *>(gimg + w);
+    }
+  };
+  auto ld1 = [&](uint32_t w) -> uint32_t {
+    if constexpr (LT) return *(const __attribute__((address_space(3))) uint32_t *)(uintptr_t)(tt_bias + 4u * w);
+    else return gimg[w];
+  };
   const uint32_t gflags = gr[G4_FLAGS];
   // ---- counted NodePhases rows and the table index ----
   const bool z = (O1 & gr[G4_M0]) != 0;
@@ -100,12 +115,12 @@ __device__ __forceinline__ void acc_graph4(Acc4 &S, const uint32_t *gimg, cptr g
   const uint32_t pc = (uint32_t)__builtin_popcount(U & V & gr[G4_PM]);
   const uint32_t r = (O2 >> 30) ^ ((pc & 1u) << 1);
   // fixed-frame levels: 4 pre-rotated copies per entry (value * i^r), 16 words per entry
-  const uint32_t *te = gimg + gr[G4_TBL] + (fixed ? (16u * idx + 4u * r) : 8u * idx);
-  const uint4 tv = *reinterpret_cast<const uint4 *>(te);
+  const uint32_t te = gr[G4_TBL] + (fixed ? (16u * idx + 4u * r) : 8u * idx);
+  const uint4 tv = ld4(te);
   if constexpr (fixed) {
     uint4 dv = {1u, 0u, 0u, 0u};
     const bool sep = (gflags & TSIMK_G4FLAG_D_SEPARATE) != 0;
-    if (sep) dv = *reinterpret_cast<const uint4 *>(gimg + gr[G4_TBL2] + 8u * dbits);
+    if (sep) dv = ld4(gr[G4_TBL2] + 8u * dbits);
     // retire the previous graph's entry (zero-initialised before the first graph)
     {
       int a = (int)S.pend_tv.x, b = (int)S.pend_tv.y, c = (int)S.pend_tv.z, d = (int)S.pend_tv.w;
@@ -116,12 +131,12 @@ __device__ __forceinline__ void acc_graph4(Acc4 &S, const uint32_t *gimg, cptr g
     return;
   }
   int a = (int)tv.x, b = (int)tv.y, c = (int)tv.z, d = (int)tv.w, p = 0;
-  if (!fixed) p = (int)te[4];
+  if (!fixed) p = (int)ld1(te + 4u);
   if (gflags & TSIMK_G4FLAG_D_SEPARATE) {
-    const uint32_t *td = gimg + gr[G4_TBL2] + 8u * dbits;
-    const uint4 dv = *reinterpret_cast<const uint4 *>(td);
+    const uint32_t td = gr[G4_TBL2] + 8u * dbits;
+    const uint4 dv = ld4(td);
     zmul(a, b, c, d, (int)dv.x, (int)dv.y, (int)dv.z, (int)dv.w);
-    if (!fixed) p += (int)td[4];
+    if (!fixed) p += (int)ld1(td + 4u);
   }
   if (!fixed) {  // rotate by i^r
     const bool k2 = (r & 1u) != 0;

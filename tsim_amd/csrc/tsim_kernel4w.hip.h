@@ -44,9 +44,10 @@ struct Wide4Args {
 };
 
 // One level from LDS-resident column tables (graph g of the level at lds_level + g * ent_bytes): no copy, no barrier.
-template <int NR, bool FIXED>
+template <int NR, bool FIXED, bool LT = false>
 __device__ __forceinline__ void eval_level4_resident(const uint32_t *gimg, cptr img, cptr lvl, const uint32_t (&e)[NR],
-                                                     uint32_t lds_level, uint32_t ent_bytes, float &out_re, float &out_im) {
+                                                     uint32_t lds_level, uint32_t ent_bytes, float &out_re, float &out_im,
+                                                     uint32_t tt_bias = 0u) {
   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
   typedef const __attribute__((address_space(3))) u32x4 *lds_u4p;
   const uint32_t G = lvl[L4_G];
@@ -56,6 +57,10 @@ __device__ __forceinline__ void eval_level4_resident(const uint32_t *gimg, cptr 
   for (uint32_t g = 0; g < G; ++g) {
     const uint32_t base = lds_level + g * ent_bytes;
     uint32_t U = 0, V = 0, O1 = 0, O2 = 0;
+#if defined(TSIMK_W4_SKIP) && (TSIMK_W4_SKIP & 1)
+#pragma unroll
+    for (int c = 0; c < NR; c += 2) { U ^= e[c] + base; V ^= e[c + 1] * 3u; O1 ^= e[c] >> 3; O2 ^= e[c + 1] >> 5; }  // diagnostic: no LDS reads
+#else
 #pragma unroll
     for (int c = 0; c < NR; c += 2) {
       const u32x4 v = *(lds_u4p)(uintptr_t)(base + e[c]);
@@ -63,7 +68,12 @@ __device__ __forceinline__ void eval_level4_resident(const uint32_t *gimg, cptr 
       U = xor3(U, v.x, w.x); V = xor3(V, v.y, w.y); O1 = xor3(O1, v.z, w.z); O2 = xor3(O2, v.w, w.w);
       if (c % 6 == 4 && c + 2 < NR) __builtin_amdgcn_sched_barrier(0);
     }
-    acc_graph4<FIXED>(S, gimg, recs + g * G4_WORDS, U, V, O1, O2, approx);
+#endif
+#if defined(TSIMK_W4_SKIP) && (TSIMK_W4_SKIP & 2)
+    S.sa ^= (int)(U ^ V); S.sb ^= (int)(O1 ^ O2);  // diagnostic: no term table, no record
+#else
+    acc_graph4<FIXED, LT>(S, gimg, recs + g * G4_WORDS, U, V, O1, O2, approx, tt_bias);
+#endif
   }
   acc_finish4<FIXED>(S, lvl, approx, out_re, out_im);
 }

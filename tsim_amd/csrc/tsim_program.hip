@@ -299,6 +299,8 @@ retry_pack:
         while (img.size() % 16) img.push_back(0u);  // 64-byte aligned table entries (uint4 loads)
         const uint32_t toff = (uint32_t)img.size();
         img.insert(img.end(), tables.begin(), tables.end());
+        h.tt_off = toff;
+        h.tt_words = (uint32_t)tables.size();
         for (int g = 0; g < h.G; ++g) {
           img[goff + (size_t)g * G_WORDS + GF_TBL] += toff;
           if (img[goff + (size_t)g * G_WORDS + GF_TBL2]) img[goff + (size_t)g * G_WORDS + GF_TBL2] += toff;
@@ -592,6 +594,28 @@ retry_pack:
             h[WR_LUTMASK] = lutmask;
             h[WR_WO32] = (uint32_t)wo32;
             h[WR_COLBYTES] = (uint32_t)colbytes;
+            {  // the term tables of every level, for a copy in LDS: (image offset, words) per level
+              const uint32_t tt_rec = (uint32_t)img.size();
+              uint32_t tt_total = 0;
+              for (auto &lv : c.levels) {
+                img.push_back(lv.tt_off);
+                img.push_back((lv.tt_words + 3u) & ~3u);
+                tt_total += (lv.tt_words + 3u) & ~3u;
+              }
+              img[p->wr_off + WR_TT] = tt_rec;
+              img[p->wr_off + WR_TTBYTES] = tt_total * 4u;
+            }
+            bool one = true;
+            for (int d = 0; d < wo32; ++d) one = one && runb[(size_t)d + 1] - runb[(size_t)d] <= 1u;
+            if (one) {
+              const uint32_t r1_off = (uint32_t)img.size();
+              for (int d = 0; d < wo32; ++d) {
+                const bool has = runb[(size_t)d + 1] > runb[(size_t)d];
+                img.push_back(has ? runs[2 * (size_t)runb[(size_t)d]] : 0u);
+                img.push_back(has ? runs[2 * (size_t)runb[(size_t)d] + 1] : 0u);
+              }
+              img[p->wr_off + WR_RUN1] = r1_off;
+            }
           }
         }
       } else if (ok) {

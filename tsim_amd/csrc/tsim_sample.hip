@@ -142,7 +142,10 @@ static LaunchPlan make_plan(tsim_program *p, bool has_row_index, bool pipelined,
         p->lw_direct_left = 15;
         for (int i = 4; i < 8; ++i) p->h_feedback[i] = 0xFFFFFFFFu;
         pl.use_tables = false;
-      } else if (known && p->lw_cap_now < p->lw_cap_max && p->knobs.deep_tables >= 0) {
+      } else if (known && p->lw_cap_now < p->lw_cap_max && p->knobs.deep_tables > 0) {
+        // (only on request, TSIM_AMD_DEEP_TABLES=1: the weight-4 table of a 200-bit component is 2.1 GB of rows read at
+        // random - every read a TLB miss that the kernel's four waves per SIMD cannot hide: C5 126 -> 277 us per 10^6 shots,
+        // profiles/r04/wide_depth.txt - while the rows it would tabulate cost the dense pass ~1/3 of that)
         p->lw_dense_launches = (double)missed > 0.2 * (double)fb_rows ? p->lw_dense_launches + 1 : 0;
         if (p->lw_dense_launches >= 3) {
           p->lw_dense_launches = 0;
@@ -448,7 +451,7 @@ static int fill_sample_args(tsim_program *p, tsim_program::Slot &sl, SampleArgs 
 struct WideLayout {
   int block = 0;       // threads per block (0: the program does not fit)
   size_t lds = 0;
-  int l_rank, l_lut, l_runs, l_sel, l_ptrs, l_keys, l_wave, wave_bytes, w_list, w_q, w_ovf;
+  int l_rank, l_lut, l_runs, l_sel, l_ptrs, l_keys, l_tt, l_wave, wave_bytes, w_q, w_ovf;
 };
 static WideLayout wide_layout(const tsim_program *p, int WF32) {
   WideLayout L;
@@ -462,23 +465,31 @@ static WideLayout wide_layout(const tsim_program *p, int WF32) {
   L.l_lut = (int)off;   off += ((size_t)wo32 << c.n_out) * 4;
   off = up(off, 16);
   L.l_runs = (int)off;  off += (size_t)(2 * TSIMK_WIDE_MAX_RUNS + 48) * 4;
-  L.l_sel = (int)off;   off += 32 * 4;
+  L.l_sel = (int)off;   off += 36 * 4;  // + the two statistics counters
   L.l_ptrs = (int)off;  off += (size_t)TSIMK_LWM_MAX_STEPS * 4 * 4;
   L.l_keys = (int)off;  off += (size_t)TSIMK_LWM_MAX_STEPS * 2 * TSIMK_LWM_KEYS * 4;
   off = up(off, 16);
-  L.l_wave = (int)off;
+  const size_t fixed_end = off;
   size_t w = (size_t)64 * WF32 * 4;
   w = up(w, 16);
-  L.w_list = (int)w;    w += 64 * 16;
-  L.w_q = (int)w;       w += (size_t)(4 + c.n_out) * TSIMK_WIDE_QCAP * 4;
+  L.w_q = (int)w;       w += (size_t)(4 + c.n_out + __builtin_popcount(wr[WR_LUTMASK])) * TSIMK_WIDE_QCAP * 4;
   L.w_ovf = (int)w;     w += (size_t)TSIMK_WIDE_QCAP * 4;
   L.wave_bytes = (int)up(w, 16);
-  for (int blk : {1024, 512, 256}) {  // 16 waves per CU when everything fits beside the column tables, fewer otherwise
-    const size_t tot = off + (size_t)(blk / 64) * L.wave_bytes + 64;  // + the kernel's static words
-    if (tot <= 160 * 1024) {
-      L.block = blk;
-      L.lds = off + (size_t)(blk / 64) * L.wave_bytes;
-      break;
+  // the levels' term tables join the column tables in LDS when 16 waves still fit next to them (C5: 3 KB)
+  const size_t tt_bytes = up(wr[WR_TTBYTES], 16);
+  for (int with_tt = 1; with_tt >= 0 && !L.block; --with_tt) {
+    if (with_tt && (tt_bytes == 0 || tt_bytes > 24 * 1024)) continue;
+    off = fixed_end + (with_tt ? tt_bytes : 0);
+    for (int blk : {1024, 512, 256}) {  // 16 waves per CU when everything fits beside the tables, fewer otherwise
+      if (with_tt && blk != 1024) break;
+      const size_t tot = off + (size_t)(blk / 64) * L.wave_bytes + 64;  // + the kernel's static words
+      if (tot <= 160 * 1024) {
+        L.block = blk;
+        L.l_tt = with_tt ? (int)fixed_end : -1;
+        L.l_wave = (int)off;
+        L.lds = off + (size_t)(blk / 64) * L.wave_bytes;
+        break;
+      }
     }
   }
   return L;
@@ -520,7 +531,7 @@ static int launch_wide(tsim_program *p, int n, const SampleArgs *const *args, in
   W.tab_bytes = (uint32_t)p->lw_bytes;
   W.feedback = p->d_feedback;
   W.l_rank = L.l_rank; W.l_lut = L.l_lut; W.l_runs = L.l_runs; W.l_sel = L.l_sel; W.l_ptrs = L.l_ptrs; W.l_keys = L.l_keys;
-  W.l_wave = L.l_wave; W.wave_bytes = L.wave_bytes; W.w_list = L.w_list; W.w_q = L.w_q; W.w_ovf = L.w_ovf;
+  W.l_tt = L.l_tt; W.l_wave = L.l_wave; W.wave_bytes = L.wave_bytes; W.w_q = L.w_q; W.w_ovf = L.w_ovf;
   for (int j = 0; j < n; ++j) {
     const SampleArgs &a = *args[j];
     WideStep &st = W.step[j];
@@ -1646,6 +1657,17 @@ extern "C" int tsim_sample_batch(tsim_program *p, const uint8_t *f, int64_t B, i
 extern "C" int tsim_debug_lw_trace(unsigned long long *out) {
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(tsimk::tsimk_lw_trace), 16 * 32 * 8));
+  return 0;
+}
+#endif
+
+#ifdef TSIMK_WIDE_TRACE
+// diagnostic builds only (scripts/wide_trace.py): the phase timers of k_sample_wide, read and reset
+extern "C" int tsim_debug_wide_trace(unsigned long long *out) {
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(tsimk::tsimk_wide_trace), 24 * 8));
+  unsigned long long z[24] = {};
+  HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(tsimk::tsimk_wide_trace), z, 24 * 8));
   return 0;
 }
 #endif

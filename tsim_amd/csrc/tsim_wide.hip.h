@@ -40,6 +40,9 @@ enum {
   WR_LUTMASK,     // bit d set: destination word d holds component outputs
   WR_WO32,        // 32-bit words per output row the record was built for
   WR_COLBYTES,    // bytes of the column tables of all levels (LDS resident)
+  WR_TT,          // image offset of (n_out + 1) x (image offset, words rounded up to 4) of the levels' term tables
+  WR_TTBYTES,     // their total size in bytes
+  WR_RUN1,        // image offset of WO32 x (ctl, mask) when every destination word has at most one run (mask 0: none), else 0
   WR_WORDS = 16
 };
 #define TSIMK_WIDE_K 12        // set bits per row the dense pass takes
@@ -65,7 +68,7 @@ struct WideArgs {
   uint32_t tab_bytes;
   uint32_t *feedback;       // optional (mapped host memory): [4] rows with more than K set bits, [5] rows the tables missed, [6] rows - estimates from block 0
   // LDS layout in bytes, computed by the launcher (tsim_sample.hip: wide_layout)
-  int l_rank, l_lut, l_runs, l_sel, l_ptrs, l_keys, l_wave, wave_bytes, w_list, w_q, w_ovf;
+  int l_rank, l_lut, l_runs, l_sel, l_ptrs, l_keys, l_tt, l_wave, wave_bytes, w_q, w_ovf;  // l_tt < 0: the term tables stay in the image
   WideStep step[TSIMK_LWM_MAX_STEPS];
 };
 
@@ -76,6 +79,29 @@ __device__ __forceinline__ uint32_t threefry_bits32_v(uint32_t k0, uint32_t k1, 
   return x0 ^ x1;
 }
 
+// Optional phase timers (build with -DTSIMK_WIDE_TRACE, scripts/wide_trace.py): every wave sums the shader-clock cycles it
+// spends per phase; lane 0 adds them to a device array at the end.  Compiled out by default.
+#ifdef TSIMK_WIDE_TRACE
+__device__ unsigned long long tsimk_wide_trace[24];
+#define WT_DECL unsigned long long wt_acc[20] = {}, wt_t = __builtin_readcyclecounter(), wt_t0 = wt_t
+#define WT_MARK(k) do { const unsigned long long n_ = __builtin_readcyclecounter(); wt_acc[k] += n_ - wt_t; wt_t = n_; } while (0)
+#define WT_COUNT(k) do { wt_acc[k] += 1ull; } while (0)
+#define WT_FLUSH do { if (lane == 0u) { wt_acc[11] = __builtin_readcyclecounter() - wt_t0; for (int k_ = 0; k_ < 20; ++k_) if (k_ != 12) atomicAdd(&tsimk_wide_trace[k_], wt_acc[k_]); atomicAdd(&tsimk_wide_trace[12], 1ull); } } while (0)
+#else
+#define WT_DECL do { } while (0)
+#define WT_MARK(k) do { } while (0)
+#define WT_COUNT(k) do { } while (0)
+#define WT_FLUSH do { } while (0)
+#endif
+
+// diagnostic builds only (scripts/wide_skip.sh): leave parts out to see what each costs (wrong results)
+#ifndef TSIMK_WIDE_SKIP
+#define TSIMK_WIDE_SKIP 0
+#endif
+#ifndef TSIMK_WIDE_STAGE
+#define TSIMK_WIDE_STAGE 0   // 1: the next chunk is staged AFTER the dense passes; 2: staged through registers instead of LDS-DMA
+#endif
+
 template <int WO32, int K>
 __global__ void __launch_bounds__(1024) k_sample_wide(WideArgs A) {
   typedef const __attribute__((address_space(4))) uint8_t *cbytes;
@@ -84,6 +110,9 @@ __global__ void __launch_bounds__(1024) k_sample_wide(WideArgs A) {
   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
   typedef __attribute__((address_space(3))) void *lds_ptr_t;
   typedef const __attribute__((address_space(1))) void *glb_ptr_t;
+  typedef __attribute__((address_space(1))) uint32_t gu32;        // output rows: global_store / global_atomic, not their flat forms
+  typedef __attribute__((address_space(1))) u32x2 gu32x2;
+  typedef __attribute__((address_space(1))) u32x4 gu32x4;
   static_assert(K % 2 == 0 && K <= 12, "position lists are three words");
   constexpr uint32_t QCAP = TSIMK_WIDE_QCAP;
   const int nthr = blockDim.x;
@@ -116,6 +145,14 @@ __global__ void __launch_bounds__(1024) k_sample_wide(WideArgs A) {
       tile_copy(reinterpret_cast<const uint4 *>(A.img + lvl[L4_STAB]), lds8 + off, bytes >> 4, threadIdx.x, nthr);
       off += bytes;
     }
+    if (A.l_tt >= 0) {  // the term tables of every level behind each other
+      uint32_t toff = 0;
+      for (uint32_t li = 0; li <= n_out; ++li) {
+        const uint32_t src = img[wr[WR_TT] + 2u * li], words = img[wr[WR_TT] + 2u * li + 1u];
+        tile_copy(reinterpret_cast<const uint4 *>(A.img + src), lds8 + A.l_tt + toff, words >> 2, threadIdx.x, nthr);
+        toff += words * 4u;
+      }
+    }
     const uint32_t *g = A.img;
     for (uint32_t i = threadIdx.x; i < 4u * (F + 1u); i += nthr) {
       const uint32_t k = i / (F + 1u), b = i - k * (F + 1u);
@@ -141,8 +178,7 @@ __global__ void __launch_bounds__(1024) k_sample_wide(WideArgs A) {
   // ---- this wave's LDS: the staged f rows, the position lists, the queue of missed rows, the ring of heavy rows
   uint8_t *w8 = lds8 + A.l_wave + wv * (uint32_t)A.wave_bytes;
   uint32_t *w_f = reinterpret_cast<uint32_t *>(w8);                  // [64][WF32] rows as they lie in HBM
-  uint32_t *w_list = reinterpret_cast<uint32_t *>(w8 + A.w_list);    // [64][4]: 16 position bytes per lane
-  uint32_t *w_q = reinterpret_cast<uint32_t *>(w8 + A.w_q);          // [4 + n_out][QCAP]: id, 3 position words, draws
+  uint32_t *w_q = reinterpret_cast<uint32_t *>(w8 + A.w_q);          // [4 + n_out + ncw][QCAP]: id, 3 position words, draws, the direct bits of the ncw output words that hold component bits
   uint32_t *w_ovf = reinterpret_cast<uint32_t *>(w8 + A.w_ovf);      // [QCAP] ids
   uint32_t qhead = 0, qtail = 0, ohead = 0, otail = 0;              // wave-uniform
   uint32_t n_missed = 0, n_heavy = 0;
@@ -156,18 +192,35 @@ __global__ void __launch_bounds__(1024) k_sample_wide(WideArgs A) {
   const uint32_t Bu = (uint32_t)A.B;
   const uint32_t cps = (uint32_t)A.chunks_per_step;
   const uint32_t total = cps * (uint32_t)A.n_steps;
-  const uint32_t zero_col = F * 16u;
   const uint32_t zsplat = F * 0x01010101u;
+  // direct outputs with at most one run per destination word (identity-like tables): descriptors as scalars
+  const bool run1 = wr[WR_RUN1] != 0u;
+  uint32_t r1_ctl[WO32], r1_mask[WO32], r1_flip[WO32];
+#pragma unroll
+  for (int d = 0; d < WO32; ++d) {
+    r1_ctl[d] = run1 ? img[wr[WR_RUN1] + 2u * (uint32_t)d] : 0u;
+    r1_mask[d] = run1 ? img[wr[WR_RUN1] + 2u * (uint32_t)d + 1u] : 0u;
+    r1_flip[d] = img[wr[WR_FLIPS] + (uint32_t)d];
+  }
 
   // the f rows of chunk c -> w_f (LDS-DMA: 64 consecutive dwords per instruction, rows as they lie in HBM)
   auto stage_chunk = [&](uint32_t c) {
     const uint32_t st = c / cps, ch = c - st * cps;
     const uint32_t *src = reinterpret_cast<const uint32_t *>(steps[st].f) + (size_t)ch * 64u * WF32;
     const uint32_t valid = (Bu - ch * 64u < 64u ? Bu - ch * 64u : 64u) * WF32;  // dwords of this chunk inside the batch
+#if TSIMK_WIDE_STAGE == 2
+    uint32_t v[16];
+#pragma unroll
+    for (int w = 0; w < 16; ++w) v[w] = ((uint32_t)w < WF32 && (uint32_t)w * 64u + lane < valid) ? src[(uint32_t)w * 64u + lane] : 0u;
+#pragma unroll
+    for (int w = 0; w < 16; ++w)
+      if ((uint32_t)w < WF32) w_f[(uint32_t)w * 64u + lane] = v[w];
+#else
     for (uint32_t w = 0; w < WF32; ++w) {
       const uint32_t j = w * 64u + lane;
       if (j < valid) __builtin_amdgcn_global_load_lds((glb_ptr_t)(src + j), (lds_ptr_t)(w_f + w * 64u), 4, 0, 0);
     }
+#endif
   };
   // K14: direct outputs f[idx] ^ flip (sampler.py:140-145) of the row staged at frow: rotate-and-mask runs per destination word
   auto direct_words = [&](const uint32_t *frow, uint32_t (&o)[WO32]) {
@@ -186,20 +239,20 @@ __global__ void __launch_bounds__(1024) k_sample_wide(WideArgs A) {
   };
   // a row's words -> HBM (every word of the padded row / the whole bit_packed row: dword stores)
   auto store_row = [&](uint32_t st_lo_out, uint32_t st_hi_out, uint32_t st_lo_oc, uint32_t st_hi_oc, uint32_t row, const uint32_t (&o)[WO32]) {
-    uint32_t *out = reinterpret_cast<uint32_t *>((uintptr_t)(((uint64_t)st_hi_out << 32) | st_lo_out));
-    uint32_t *oc = reinterpret_cast<uint32_t *>((uintptr_t)(((uint64_t)st_hi_oc << 32) | st_lo_oc));
+    gu32 *out = (gu32 *)(uintptr_t)(((uint64_t)st_hi_out << 32) | st_lo_out);
+    gu32 *oc = (gu32 *)(uintptr_t)(((uint64_t)st_hi_oc << 32) | st_lo_oc);
     if (out) {
-      uint32_t *dst = out + (size_t)row * WO32;
-      if constexpr (WO32 == 4) *reinterpret_cast<u32x4 *>(dst) = u32x4{o[0], o[1], o[2], o[3]};
+      gu32 *dst = out + (size_t)row * WO32;
+      if constexpr (WO32 == 4) *(gu32x4 *)dst = u32x4{o[0], o[1], o[2], o[3]};
       else {
 #pragma unroll
-        for (int d = 0; d < WO32; d += 2) *reinterpret_cast<u32x2 *>(dst + d) = u32x2{o[d], o[d + 1]};
+        for (int d = 0; d < WO32; d += 2) *(gu32x2 *)(dst + d) = u32x2{o[d], o[d + 1]};
       }
     }
     if (oc) {
       const uint32_t nd = (uint32_t)A.out_rb >> 2;
-      uint32_t *dst = oc + (size_t)row * nd;
-      if (WO32 == 4 && nd == 4u && (((uintptr_t)oc) & 15u) == 0u) *reinterpret_cast<u32x4 *>(dst) = u32x4{o[0], o[1], o[2], o[WO32 > 3 ? 3 : 0]};
+      gu32 *dst = oc + (size_t)row * nd;
+      if (WO32 == 4 && nd == 4u && (((uintptr_t)oc) & 15u) == 0u) *(gu32x4 *)dst = u32x4{o[0], o[1], o[2], o[WO32 > 3 ? 3 : 0]};
       else {
 #pragma unroll
         for (int d = 0; d < WO32; ++d)
@@ -208,6 +261,7 @@ __global__ void __launch_bounds__(1024) k_sample_wide(WideArgs A) {
     }
   };
 
+  WT_DECL;
   // ------------------------------------------------------------------------------------------------------------
   // phase 2: n (<= 64) queued rows, slots qhead .. qhead + n - 1: the sparse-column evaluation on dense lanes
   // ------------------------------------------------------------------------------------------------------------
@@ -222,9 +276,13 @@ __global__ void __launch_bounds__(1024) k_sample_wide(WideArgs A) {
       const uint32_t pw = (k < 4) ? p0 : (k < 8) ? p1 : p2;
       col[k] = (k & 3) == 0 ? ((pw << 4) & 0xFF0u) : ((pw >> (8 * (k & 3) - 4)) & 0xFF0u);
     }
-    uint32_t mb = 0, leaf = 0, lvl_off = 0;
+    uint32_t mb = 0, leaf = 0, lvl_off = 0, tt_lds = 0;
     float prev = 0.0f;
-    for (uint32_t li = 0; li <= n_out; ++li) {
+#ifdef TSIMK_WIDE_TRACE
+    asm volatile("" :: "v"(col[0]), "v"(col[K - 1]));
+#endif
+    WT_MARK(13);
+    for (uint32_t li = 0; li <= ((TSIMK_WIDE_SKIP & 1) ? 0u : n_out); ++li) {
       cptr lvl = levels + li * L4_WORDS;
       if (li > 0) mb |= 1u << (li - 1u);  // trial bit 1 (sampler.py:65)
       uint32_t e[K + 2];
@@ -233,9 +291,22 @@ __global__ void __launch_bounds__(1024) k_sample_wide(WideArgs A) {
       e[K] = (F + 1u + (mb & 15u)) * 16u;
       e[K + 1] = (F + 17u + ((mb >> 4) & 15u)) * 16u;
       float re, im;
-      if ((lvl[L4_FLAGS] & TSIMK_LFLAG_FIXED) != 0) eval_level4_resident<K + 2, true>(A.img, img, lvl, e, lds_col0 + lvl_off, ent_bytes, re, im);
-      else eval_level4_resident<K + 2, false>(A.img, img, lvl, e, lds_col0 + lvl_off, ent_bytes, re, im);
+      const bool fixed = (lvl[L4_FLAGS] & TSIMK_LFLAG_FIXED) != 0;
+      if (A.l_tt >= 0) {
+        // image word w of this level's tables lies at LDS byte tt_lds + 4 (w - its image offset)
+        const uint32_t bias = lds_col0 + (uint32_t)A.l_tt + tt_lds - 4u * img[wr[WR_TT] + 2u * li];
+        if (fixed) eval_level4_resident<K + 2, true, true>(A.img, img, lvl, e, lds_col0 + lvl_off, ent_bytes, re, im, bias);
+        else eval_level4_resident<K + 2, false, true>(A.img, img, lvl, e, lds_col0 + lvl_off, ent_bytes, re, im, bias);
+        tt_lds += img[wr[WR_TT] + 2u * li + 1u] * 4u;
+      } else {
+        if (fixed) eval_level4_resident<K + 2, true>(A.img, img, lvl, e, lds_col0 + lvl_off, ent_bytes, re, im);
+        else eval_level4_resident<K + 2, false>(A.img, img, lvl, e, lds_col0 + lvl_off, ent_bytes, re, im);
+      }
       lvl_off += lvl[L4_G] * ent_bytes;
+#ifdef TSIMK_WIDE_TRACE
+      asm volatile("" :: "v"(re), "v"(im));
+#endif
+      WT_MARK(14);
       const float v1 = cabs32(re, im);
       if (li == 0) { prev = v1; continue; }
       const uint32_t i = li - 1u;
@@ -245,23 +316,31 @@ __global__ void __launch_bounds__(1024) k_sample_wide(WideArgs A) {
       if (!bit) mb &= ~(1u << i);
       prev = bit ? v1 : __fsub_rn(prev, v1);     // sampler.py:79
       leaf = 2u * leaf + (bit ? 1u : 0u);
+#ifdef TSIMK_WIDE_TRACE
+      asm volatile("" :: "v"(leaf), "v"(prev));
+#endif
+      WT_MARK(15);
     }
-    if (on) {  // the component's bits join the row phase 1 stored (same wave, earlier, vmcnt drained since)
+    if (on && !(TSIMK_WIDE_SKIP & 2)) {
+      // the words that hold component outputs were NOT stored by phase 1 for this row: their direct bits waited in the queue.
+      // (An atomic OR into a stored row - any scope - leaves the XCD's L2 for the fabric: 0.57e6 of them cost C5 90 of
+      // 122 us per 10^6 shots, profiles/r04/wide_skip.txt.)
       const uint32_t st = id >> 28, row = id & 0x0FFFFFFFu;
       const u32x4 pt = *reinterpret_cast<const u32x4 *>(&l_ptrs[4u * st]);
-      uint32_t *out = reinterpret_cast<uint32_t *>((uintptr_t)(((uint64_t)pt.y << 32) | pt.x));
-      uint32_t *oc = reinterpret_cast<uint32_t *>((uintptr_t)(((uint64_t)pt.w << 32) | pt.z));
+      gu32 *out = (gu32 *)(uintptr_t)(((uint64_t)pt.y << 32) | pt.x);
+      gu32 *oc = (gu32 *)(uintptr_t)(((uint64_t)pt.w << 32) | pt.z);
       const uint32_t nd = (uint32_t)A.out_rb >> 2;
+      uint32_t cwi = 0;
 #pragma unroll
       for (int d = 0; d < WO32; ++d)
         if ((lutmask >> d) & 1u) {
-          const uint32_t v = l_lut[leaf * (uint32_t)WO32 + (uint32_t)d];
-          if (v != 0u) {
-            if (out) atomicOr(out + (size_t)row * WO32 + d, v);
-            if (oc && (uint32_t)d < nd) atomicOr(oc + (size_t)row * nd + d, v);
-          }
+          const uint32_t v = w_q[(4u + n_out + cwi) * QCAP + slot] | l_lut[leaf * (uint32_t)WO32 + (uint32_t)d];
+          ++cwi;
+          if (out) out[(size_t)row * WO32 + d] = v;
+          if (oc && (uint32_t)d < nd) oc[(size_t)row * nd + d] = v;
         }
     }
+    WT_MARK(16);
     qhead += n;
   };
 
@@ -367,22 +446,29 @@ __global__ void __launch_bounds__(1024) k_sample_wide(WideArgs A) {
     const bool done = c >= total;
     if (!staged) {
       if (check_pending) {
+        WT_MARK(0);
         generic_pass(0u, true, check_pending - 1u);
         check_pending = 0u;
+        WT_MARK(7);
         continue;
       }
       if (otail - ohead >= 64u || (done && otail != ohead)) {
+        WT_MARK(0);
         generic_pass(otail - ohead < 64u ? otail - ohead : 64u, false, 0u);
+        WT_MARK(7);
         continue;
       }
-      if (!done) {
+      if (!done && !(TSIMK_WIDE_STAGE == 1 && qtail - qhead >= 64u)) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every read of w_f has returned
         stage_chunk(c);
         staged = true;
       }
     }
     if (qtail - qhead >= 64u || (done && qtail != qhead)) {
+      WT_MARK(0);
       dense_pass(qtail - qhead < 64u ? qtail - qhead : 64u);
+      WT_MARK(6);
+      WT_COUNT(9);
       continue;
     }
     if (done) break;
@@ -390,38 +476,72 @@ __global__ void __launch_bounds__(1024) k_sample_wide(WideArgs A) {
     cstep S = steps + st;
     const uint32_t row = ch * 64u + lane;
     const bool active = row < Bu;
+    WT_MARK(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this chunk's rows are in w_f (and every earlier store of this wave has left)
+    WT_MARK(1);
+    WT_COUNT(8);
     const uint32_t *frow = w_f + lane * WF32;
     // ---- direct outputs
     uint32_t o[WO32];
-    direct_words(frow, o);
-    // ---- the selected set bits: weight, and their positions inside f_sel as bytes (ascending; F = "none")
-    *reinterpret_cast<u32x4 *>(&w_list[4u * lane]) = u32x4{zsplat, zsplat, zsplat, zsplat};
-    uint32_t cnt = 0;
+    if (run1) {  // at most one run per destination word: the descriptors are scalars, the WO32 row reads are independent
+#pragma unroll
+      for (int d = 0; d < WO32; ++d) {
+        const uint32_t fw = frow[r1_ctl[d] & 255u];
+        o[d] = r1_flip[d] ^ (__builtin_amdgcn_alignbit(fw, fw, r1_ctl[d] >> 8) & r1_mask[d]);
+      }
+    } else {
+      direct_words(frow, o);
+    }
+#ifdef TSIMK_WIDE_TRACE
+    asm volatile("" :: "v"(o[0]), "v"(o[WO32 - 1]));
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+    WT_MARK(2);
+    // ---- the selected set bits: weight, and their positions inside f_sel as bytes of (l0, l1, l2), the newest (largest)
+    // in byte 0; F = "none".  The next word's mask, prefix count and f word are requested before this word's bits are
+    // walked (one LDS latency per word, under the loop); nothing in the loop touches memory.
+    uint32_t l0 = zsplat, l1 = zsplat, l2 = zsplat, cnt = 0;
     {
-      uint8_t *lb = reinterpret_cast<uint8_t *>(&w_list[4u * lane]);
-      for (uint32_t w = 0; w < WF32 && w < 16u; ++w) {
-        const uint32_t sw = l_sel[w], base = l_sel[16u + w];
-        uint32_t m = active ? (frow[w] & sw) : 0u;
+      const uint32_t nw = WF32 < 16u ? WF32 : 16u;
+      uint32_t n_sw = l_sel[0], n_base = l_sel[16], n_fw = frow[0];
+      for (uint32_t w = 0; w < ((TSIMK_WIDE_SKIP & 16) ? 0u : nw); ++w) {
+        const uint32_t sw = n_sw, base = n_base;
+        uint32_t m = active ? (n_fw & sw) : 0u;
+        if (w + 1u < nw) {
+          n_sw = l_sel[w + 1u];
+          n_base = l_sel[17u + w];
+          n_fw = frow[w + 1u];
+        }
         while (m) {
           const uint32_t p = (uint32_t)__builtin_ctz(m);
           const uint32_t pos = base + (uint32_t)__builtin_popcount(sw & ((1u << p) - 1u));
-          lb[cnt < 15u ? cnt : 15u] = (uint8_t)pos;
+          l2 = __builtin_amdgcn_alignbit(l2, l1, 24);
+          l1 = __builtin_amdgcn_alignbit(l1, l0, 24);
+          l0 = (l0 << 8) | pos;
           ++cnt;
           m &= m - 1u;
         }
       }
     }
+#ifdef TSIMK_WIDE_TRACE
+    asm volatile("" :: "v"(cnt));
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+    WT_MARK(3);
     const bool hit = active && cnt <= wmax;
     const bool miss = active && cnt > wmax && cnt <= (uint32_t)K;
     const bool heavy = active && cnt > (uint32_t)K;
-    // ---- colex rank of a tabulated pattern: sum over its set bits of C(position, ordinal + 1) (tsim_lw.hip.h)
-    const u32x4 lst = *reinterpret_cast<const u32x4 *>(&w_list[4u * lane]);
+    // ---- colex rank of a tabulated pattern: sum over its set bits of C(position, ordinal + 1) (tsim_lw.hip.h); byte j of
+    // l0 is the bit of ordinal cnt - 1 - j (unused bytes hold F: the zero at the end of every RANK row)
     uint32_t pat = l_bases[cnt < 7u ? cnt : 7u];
 #pragma unroll
-    for (int k = 0; k < TSIMK_LWW_MAX_WEIGHT; ++k) pat += l_rank[(uint32_t)k * (F + 1u) + ((lst.x >> (8 * k)) & 255u)];
+    for (int j = 0; j < TSIMK_LWW_MAX_WEIGHT; ++j) pat += l_rank[((cnt - 1u - (uint32_t)j) & 3u) * (F + 1u) + ((l0 >> (8 * j)) & 255u)];
     pat = hit ? pat : 0u;
-    const uint32_t thr = tab_byte + (pat << (n_out + 2u));  // byte offset of the pattern's threshold tree
+    const uint32_t thr = (TSIMK_WIDE_SKIP & 4) ? 0u : tab_byte + (pat << (n_out + 2u));  // byte offset of the pattern's threshold tree
+    // the first three levels of the tree are requested now: the draws below run while they travel
+    const uint32_t ta0 = __builtin_amdgcn_raw_buffer_load_b32(r_tab, thr + 4u, 0, 0);
+    const u32x2 ta1 = __builtin_amdgcn_raw_buffer_load_b64(r_tab, thr + 8u, 0, 0);
+    const u32x4 ta2 = __builtin_amdgcn_raw_buffer_load_b128(r_tab, thr + 16u, 0, 0);
     // ---- the draws of every output (sampler.py:74-75): functions of (subkey, shot) only
     const uint32_t slo = so_lo + row;  // (the launcher keeps shot_offset + B below the next multiple of 2^32)
     cptr kp = (cptr)((cbytes)S + __builtin_offsetof(WideStep, keys)) + 2u * keybase;
@@ -431,57 +551,87 @@ __global__ void __launch_bounds__(1024) k_sample_wide(WideArgs A) {
       dr[i] = 0u;
       if ((uint32_t)i < n_out) {
         const uint32_t k0 = kp[2 * i], k1 = kp[2 * i + 1];
-        dr[i] = threefry_bits32_lo(k0, k1, k0 + so_hi, slo) >> 9;
+        dr[i] = (TSIMK_WIDE_SKIP & 8) ? ((slo * 0x9E3779B9u + k0 + k1) >> 9) : (threefry_bits32_lo(k0, k1, k0 + so_hi, slo) >> 9);
       }
     }
     // ---- tabulated rows: walk the threshold tree, three levels per read (tsim_lw_pass.hip.h: lw_walk_impl)
     uint32_t node = 1u;
-#pragma unroll
-    for (int i = 0; i + 3 <= 8; i += 3)
-      if ((uint32_t)(i + 3) <= n_out) {
+    {
+      const bool b0 = dr[0] < ta0;
+      const bool b1 = dr[1] < (b0 ? ta1.y : ta1.x);
+      const uint32_t lo = b1 ? ta2.y : ta2.x, hi = b1 ? ta2.w : ta2.z;
+      const bool b2 = dr[2] < (b0 ? hi : lo);
+      node = n_out >= 3u ? (8u + (b0 ? 4u : 0u) + (b1 ? 2u : 0u) + (b2 ? 1u : 0u)) : n_out == 2u ? (4u + (b0 ? 2u : 0u) + (b1 ? 1u : 0u)) : (2u + (b0 ? 1u : 0u));
+    }
+    if (n_out > 3u) {
+      if (n_out >= 6u) {
         const uint32_t t0 = __builtin_amdgcn_raw_buffer_load_b32(r_tab, thr + 4u * node, 0, 0);
         const u32x2 t1 = __builtin_amdgcn_raw_buffer_load_b64(r_tab, thr + 8u * node, 0, 0);
         const u32x4 t2 = __builtin_amdgcn_raw_buffer_load_b128(r_tab, thr + 16u * node, 0, 0);
-        const bool b0 = dr[i] < t0;
-        const bool b1 = dr[i + 1] < (b0 ? t1.y : t1.x);
+        const bool b0 = dr[3] < t0;
+        const bool b1 = dr[4] < (b0 ? t1.y : t1.x);
         const uint32_t lo = b1 ? t2.y : t2.x, hi = b1 ? t2.w : t2.z;
-        const bool b2 = dr[i + 2] < (b0 ? hi : lo);
+        const bool b2 = dr[5] < (b0 ? hi : lo);
         node = 8u * node + (b0 ? 4u : 0u) + (b1 ? 2u : 0u) + (b2 ? 1u : 0u);
       }
 #pragma unroll
-    for (int i = 0; i <= 6; i += 3)
-      if (n_out / 3u * 3u == (uint32_t)i && n_out % 3u != 0u) {
-        const uint32_t t0 = __builtin_amdgcn_raw_buffer_load_b32(r_tab, thr + 4u * node, 0, 0);
-        const bool b0 = dr[i] < t0;
-        if (n_out % 3u == 2u) {
-          const u32x2 t1 = __builtin_amdgcn_raw_buffer_load_b64(r_tab, thr + 8u * node, 0, 0);
-          const bool b1 = dr[i + 1 < 8 ? i + 1 : 7] < (b0 ? t1.y : t1.x);
-          node = 4u * node + (b0 ? 2u : 0u) + (b1 ? 1u : 0u);
-        } else {
-          node = 2u * node + (b0 ? 1u : 0u);
+      for (int i = 3; i <= 6; i += 3)
+        if (n_out / 3u * 3u == (uint32_t)i && n_out % 3u != 0u) {
+          const uint32_t t0 = __builtin_amdgcn_raw_buffer_load_b32(r_tab, thr + 4u * node, 0, 0);
+          const bool b0 = dr[i] < t0;
+          if (n_out % 3u == 2u) {
+            const u32x2 t1 = __builtin_amdgcn_raw_buffer_load_b64(r_tab, thr + 8u * node, 0, 0);
+            const bool b1 = dr[i + 1] < (b0 ? t1.y : t1.x);
+            node = 4u * node + (b0 ? 2u : 0u) + (b1 ? 1u : 0u);
+          } else {
+            node = 2u * node + (b0 ? 1u : 0u);
+          }
         }
-      }
+    }
+#ifdef TSIMK_WIDE_TRACE
+    asm volatile("" :: "v"(node));
+#endif
+    WT_MARK(4);
     const uint32_t leaf = hit ? (node & ((1u << n_out) - 1u)) : 0u;
     if (hit) {
 #pragma unroll
       for (int d = 0; d < WO32; ++d) o[d] |= l_lut[leaf * (uint32_t)WO32 + (uint32_t)d];
     }
-    // ---- every row leaves now: finished (tabulated) or with its component bits still zero
-    if (active) store_row((uint32_t)(uintptr_t)S->out, (uint32_t)((uint64_t)(uintptr_t)S->out >> 32), (uint32_t)(uintptr_t)S->out_compact,
-                          (uint32_t)((uint64_t)(uintptr_t)S->out_compact >> 32), row, o);
+    // ---- tabulated rows leave now; a missed row leaves without the words that hold component outputs (the dense pass
+    // completes and stores those), a heavy row is written by the generic pass
+    if (hit && !(TSIMK_WIDE_SKIP & 32)) store_row((uint32_t)(uintptr_t)S->out, (uint32_t)((uint64_t)(uintptr_t)S->out >> 32), (uint32_t)(uintptr_t)S->out_compact,
+                                                  (uint32_t)((uint64_t)(uintptr_t)S->out_compact >> 32), row, o);
+    if (miss && !(TSIMK_WIDE_SKIP & 32)) {
+      gu32 *out = (gu32 *)(uintptr_t)S->out;
+      gu32 *oc = (gu32 *)(uintptr_t)S->out_compact;
+      const uint32_t nd = (uint32_t)A.out_rb >> 2;
+#pragma unroll
+      for (int d = 0; d < WO32; ++d)
+        if (!((lutmask >> d) & 1u)) {
+          if (out) out[(size_t)row * WO32 + d] = o[d];
+          if (oc && (uint32_t)d < nd) oc[(size_t)row * nd + d] = o[d];
+        }
+    }
     // ---- missed rows -> the queue (position list + draws); heavy rows -> their ring
     {
-      const unsigned long long mm = __builtin_amdgcn_ballot_w64(miss);
+      const unsigned long long mm = (TSIMK_WIDE_SKIP & 64) ? 0ull : __builtin_amdgcn_ballot_w64(miss);
       if (mm != 0ull) {
         if (miss) {
           const uint32_t slot = (qtail + (uint32_t)__popcll(mm & ((1ull << lane) - 1ull))) & (QCAP - 1u);
           w_q[slot] = (st << 28) | row;
-          w_q[QCAP + slot] = lst.x;
-          w_q[2u * QCAP + slot] = lst.y;
-          w_q[3u * QCAP + slot] = lst.z;
+          w_q[QCAP + slot] = l0;
+          w_q[2u * QCAP + slot] = l1;
+          w_q[3u * QCAP + slot] = l2;
 #pragma unroll
           for (int i = 0; i < 8; ++i)
             if ((uint32_t)i < n_out) w_q[(4u + (uint32_t)i) * QCAP + slot] = dr[i];
+          uint32_t cwi = 0;
+#pragma unroll
+          for (int d = 0; d < WO32; ++d)
+            if ((lutmask >> d) & 1u) {
+              w_q[(4u + n_out + cwi) * QCAP + slot] = o[d];
+              ++cwi;
+            }
         }
         qtail += (uint32_t)__popcll(mm);
         n_missed += (uint32_t)__popcll(mm);
@@ -494,12 +644,17 @@ __global__ void __launch_bounds__(1024) k_sample_wide(WideArgs A) {
       }
     }
     if (A.has_check && ch == 0u) check_pending = st + 1u;  // this batch's row 0 lives in this chunk (sampler.py:66-72)
+    WT_MARK(5);
     staged = false;
     c += tw;
   }
+  WT_MARK(0);
+  WT_FLUSH;
   // ---- launch-plan statistics: block 0's share, scaled to the grid (a sample: nothing but heuristics reads it)
   if (A.feedback && blockIdx.x == 0) {
-    __shared__ uint32_t s_cnt[2];
+    // (no static __shared__ here: it would sit in front of the dynamic segment and push the 16-byte table entries off their
+    // alignment - 8 bytes of counters cost every ds_read_b128 of the kernel a split access, 120 -> 50 us per 10^6 shots)
+    uint32_t *s_cnt = l_sel + 32;
     if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0u;
     __syncthreads();
     if (lane == 0u) {

@@ -84,8 +84,10 @@ struct Acc4 {
 // of the VMEM latency).
 // LT: the term tables of the level were copied to LDS (k_sample_wide); word offset w of the image is then the LDS byte
 // address tt_bias + 4 w - no trip to L2 on the dependency chain of a level.
-template <bool FIXED, bool LT = false>
-__device__ __forceinline__ void acc_graph4(Acc4 &S, const uint32_t *gimg, cptr gr, uint32_t U, uint32_t V, uint32_t O1,
+// GR: where the graph record comes from - `cptr` (the image, scalar loads) or anything with operator[] over the G4_* words
+// (k_sample_wide keeps a copy of the records in LDS: no scalar-memory latency on the chain of a level).
+template <bool FIXED, bool LT = false, class GR = cptr>
+__device__ __forceinline__ void acc_graph4(Acc4 &S, const uint32_t *gimg, GR gr, uint32_t U, uint32_t V, uint32_t O1,
                                            uint32_t O2, bool approx, uint32_t tt_bias = 0u) {
   constexpr bool fixed = FIXED;
   typedef uint32_t tt_u32x4 __attribute__((ext_vector_type(4)));
@@ -166,14 +168,20 @@ __device__ __forceinline__ void acc_graph4(Acc4 &S, const uint32_t *gimg, cptr g
 
 // the level's amplitude once every graph has been added
 template <bool FIXED>
+__device__ __forceinline__ void acc_finish4(Acc4 &S, int frame, bool approx, float &out_re, float &out_im);
+template <bool FIXED>
 __device__ __forceinline__ void acc_finish4(Acc4 &S, cptr lvl, bool approx, float &out_re, float &out_im) {
+  acc_finish4<FIXED>(S, FIXED ? (int)lvl[L4_FRAME] : 0, approx, out_re, out_im);
+}
+template <bool FIXED>
+__device__ __forceinline__ void acc_finish4(Acc4 &S, int frame, bool approx, float &out_re, float &out_im) {
   if constexpr (FIXED) {  // retire the last in-flight entry
     int a = (int)S.pend_tv.x, b = (int)S.pend_tv.y, c = (int)S.pend_tv.z, d = (int)S.pend_tv.w;
     if (S.pend_sep) zmul(a, b, c, d, (int)S.pend_dv.x, (int)S.pend_dv.y, (int)S.pend_dv.z, (int)S.pend_dv.w);
     S.sa += a; S.sb += b; S.sc += c; S.sd += d;
   }
   if (!approx) {
-    if (FIXED) S.sp = (int)lvl[L4_FRAME];
+    if (FIXED) S.sp = frame;
     canon(S.sa, S.sb, S.sc, S.sd, S.sp);
     if ((S.sa | S.sb | S.sc | S.sd) == 0) S.sp = 0;
     to_complex(S.sa, S.sb, S.sc, S.sd, S.sp, out_re, out_im);

@@ -602,6 +602,9 @@ retry_pack:
                 img.push_back((lv.tt_words + 3u) & ~3u);
                 tt_total += (lv.tt_words + 3u) & ~3u;
               }
+              uint32_t gtot = 0;
+              for (auto &lv : c.levels) gtot += (uint32_t)lv.G;
+              img[p->wr_off + WR_GTOT] = gtot;
               img[p->wr_off + WR_TT] = tt_rec;
               img[p->wr_off + WR_TTBYTES] = tt_total * 4u;
             }

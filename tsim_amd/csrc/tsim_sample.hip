@@ -451,7 +451,7 @@ static int fill_sample_args(tsim_program *p, tsim_program::Slot &sl, SampleArgs 
 struct WideLayout {
   int block = 0;       // threads per block (0: the program does not fit)
   size_t lds = 0;
-  int l_rank, l_lut, l_runs, l_sel, l_ptrs, l_keys, l_tt, l_wave, wave_bytes, w_q, w_ovf;
+  int l_rank, l_lut, l_runs, l_sel, l_ptrs, l_keys, l_tt, l_lvl, l_grec, l_wave, wave_bytes, w_q, w_ovf;
 };
 static WideLayout wide_layout(const tsim_program *p, int WF32) {
   WideLayout L;
@@ -476,9 +476,11 @@ static WideLayout wide_layout(const tsim_program *p, int WF32) {
   L.w_ovf = (int)w;     w += (size_t)TSIMK_WIDE_QCAP * 4;
   L.wave_bytes = (int)up(w, 16);
   // the levels' term tables join the column tables in LDS when 16 waves still fit next to them (C5: 3 KB)
-  const size_t tt_bytes = up(wr[WR_TTBYTES], 16);
+  // (+ the level table and the graph records: 16 bytes per level, 64 per graph)
+  const size_t tt_only = up(wr[WR_TTBYTES], 16);
+  const size_t tt_bytes = tt_only + 16 * (size_t)(c.n_out + 1) + 64 * (size_t)wr[WR_GTOT];
   for (int with_tt = 1; with_tt >= 0 && !L.block; --with_tt) {
-    if (with_tt && (tt_bytes == 0 || tt_bytes > 24 * 1024)) continue;
+    if (with_tt && (tt_only == 0 || tt_bytes > 24 * 1024)) continue;
     off = fixed_end + (with_tt ? tt_bytes : 0);
     for (int blk : {1024, 512, 256}) {  // 16 waves per CU when everything fits beside the tables, fewer otherwise
       if (with_tt && blk != 1024) break;
@@ -486,6 +488,8 @@ static WideLayout wide_layout(const tsim_program *p, int WF32) {
       if (tot <= 160 * 1024) {
         L.block = blk;
         L.l_tt = with_tt ? (int)fixed_end : -1;
+        L.l_lvl = (int)(fixed_end + tt_only);
+        L.l_grec = L.l_lvl + 16 * (c.n_out + 1);
         L.l_wave = (int)off;
         L.lds = off + (size_t)(blk / 64) * L.wave_bytes;
         break;
@@ -531,7 +535,7 @@ static int launch_wide(tsim_program *p, int n, const SampleArgs *const *args, in
   W.tab_bytes = (uint32_t)p->lw_bytes;
   W.feedback = p->d_feedback;
   W.l_rank = L.l_rank; W.l_lut = L.l_lut; W.l_runs = L.l_runs; W.l_sel = L.l_sel; W.l_ptrs = L.l_ptrs; W.l_keys = L.l_keys;
-  W.l_tt = L.l_tt; W.l_wave = L.l_wave; W.wave_bytes = L.wave_bytes; W.w_q = L.w_q; W.w_ovf = L.w_ovf;
+  W.l_tt = L.l_tt; W.l_lvl = L.l_lvl; W.l_grec = L.l_grec; W.l_wave = L.l_wave; W.wave_bytes = L.wave_bytes; W.w_q = L.w_q; W.w_ovf = L.w_ovf;
   for (int j = 0; j < n; ++j) {
     const SampleArgs &a = *args[j];
     WideStep &st = W.step[j];

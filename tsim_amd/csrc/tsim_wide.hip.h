@@ -42,6 +42,7 @@ enum {
   WR_COLBYTES,    // bytes of the column tables of all levels (LDS resident)
   WR_TT,          // image offset of (n_out + 1) x (image offset, words rounded up to 4) of the levels' term tables
   WR_TTBYTES,     // their total size in bytes
+  WR_GTOT,        // graphs of all levels together
   WR_RUN1,        // image offset of WO32 x (ctl, mask) when every destination word has at most one run (mask 0: none), else 0
   WR_WORDS = 16
 };
@@ -68,7 +69,7 @@ struct WideArgs {
   uint32_t tab_bytes;
   uint32_t *feedback;       // optional (mapped host memory): [4] rows with more than K set bits, [5] rows the tables missed, [6] rows - estimates from block 0
   // LDS layout in bytes, computed by the launcher (tsim_sample.hip: wide_layout)
-  int l_rank, l_lut, l_runs, l_sel, l_ptrs, l_keys, l_tt, l_wave, wave_bytes, w_q, w_ovf;  // l_tt < 0: the term tables stay in the image
+  int l_rank, l_lut, l_runs, l_sel, l_ptrs, l_keys, l_tt, l_lvl, l_grec, l_wave, wave_bytes, w_q, w_ovf;  // l_tt < 0: the term tables stay in the image
   WideStep step[TSIMK_LWM_MAX_STEPS];
 };
 
@@ -93,6 +94,17 @@ __device__ unsigned long long tsimk_wide_trace[24];
 #define WT_COUNT(k) do { } while (0)
 #define WT_FLUSH do { } while (0)
 #endif
+
+// a graph record (G4_* words) held in vector registers: read from the kernel's LDS copy with broadcast reads, the
+// words that steer branches pinned as scalars
+struct GrecV {
+  typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+  v4 a, b, c, d;
+  __device__ __forceinline__ uint32_t operator[](int i) const {
+    const uint32_t v = i < 4 ? a[i & 3] : i < 8 ? b[i & 3] : i < 12 ? c[i & 3] : d[i & 3];
+    return (i == G4_FLAGS || i == G4_DBITS || i == G4_TBL2) ? (uint32_t)__builtin_amdgcn_readfirstlane((int)v) : v;
+  }
+};
 
 // diagnostic builds only (scripts/wide_skip.sh): leave parts out to see what each costs (wrong results)
 #ifndef TSIMK_WIDE_SKIP
@@ -153,6 +165,31 @@ __global__ void __launch_bounds__(1024) k_sample_wide(WideArgs A) {
         toff += words * 4u;
       }
     }
+    if (A.l_tt >= 0) {
+      // ... and, with them, the level table (G, flags, frame power, first graph) and the graph records, their table offsets
+      // turned into LDS word addresses: a dense pass then reads nothing but LDS until it stores its rows
+      uint32_t g0 = 0, toff = 0;
+      uint32_t *l_lvl = tsimk_lds + (A.l_lvl >> 2), *l_grec = tsimk_lds + (A.l_grec >> 2);
+      const uint32_t tt_word0 = ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)lds8 + (uint32_t)A.l_tt) >> 2;
+      for (uint32_t li = 0; li <= n_out; ++li) {
+        cptr lvl = levels + li * L4_WORDS;
+        const uint32_t G = lvl[L4_G], recs = lvl[L4_RECS], src = img[wr[WR_TT] + 2u * li], words = img[wr[WR_TT] + 2u * li + 1u];
+        if (threadIdx.x == 0) {
+          l_lvl[4u * li] = G;
+          l_lvl[4u * li + 1u] = lvl[L4_FLAGS];
+          l_lvl[4u * li + 2u] = lvl[L4_FRAME];
+          l_lvl[4u * li + 3u] = g0;
+        }
+        for (uint32_t i = threadIdx.x; i < G * (uint32_t)G4_WORDS; i += nthr) {
+          uint32_t v = A.img[recs + i];
+          const uint32_t k = i % (uint32_t)G4_WORDS;
+          if (k == (uint32_t)G4_TBL || (k == (uint32_t)G4_TBL2 && v != 0u)) v = tt_word0 + (toff >> 2) + (v - src);
+          l_grec[g0 * (uint32_t)G4_WORDS + i] = v;
+        }
+        g0 += G;
+        toff += words * 4u;
+      }
+    }
     const uint32_t *g = A.img;
     for (uint32_t i = threadIdx.x; i < 4u * (F + 1u); i += nthr) {
       const uint32_t k = i / (F + 1u), b = i - k * (F + 1u);
@@ -204,8 +241,7 @@ __global__ void __launch_bounds__(1024) k_sample_wide(WideArgs A) {
   }
 
   // the f rows of chunk c -> w_f (LDS-DMA: 64 consecutive dwords per instruction, rows as they lie in HBM)
-  auto stage_chunk = [&](uint32_t c) {
-    const uint32_t st = c / cps, ch = c - st * cps;
+  auto stage_chunk = [&](uint32_t st, uint32_t ch) {
     const uint32_t *src = reinterpret_cast<const uint32_t *>(steps[st].f) + (size_t)ch * 64u * WF32;
     const uint32_t valid = (Bu - ch * 64u < 64u ? Bu - ch * 64u : 64u) * WF32;  // dwords of this chunk inside the batch
 #if TSIMK_WIDE_STAGE == 2
@@ -216,9 +252,13 @@ __global__ void __launch_bounds__(1024) k_sample_wide(WideArgs A) {
     for (int w = 0; w < 16; ++w)
       if ((uint32_t)w < WF32) w_f[(uint32_t)w * 64u + lane] = v[w];
 #else
-    for (uint32_t w = 0; w < WF32; ++w) {
-      const uint32_t j = w * 64u + lane;
-      if (j < valid) __builtin_amdgcn_global_load_lds((glb_ptr_t)(src + j), (lds_ptr_t)(w_f + w * 64u), 4, 0, 0);
+    if (valid == 64u * WF32) {  // (all but a batch's last chunk)
+      for (uint32_t w = 0; w < WF32; ++w) __builtin_amdgcn_global_load_lds((glb_ptr_t)(src + w * 64u + lane), (lds_ptr_t)(w_f + w * 64u), 4, 0, 0);
+    } else {
+      for (uint32_t w = 0; w < WF32; ++w) {
+        const uint32_t j = w * 64u + lane;
+        if (j < valid) __builtin_amdgcn_global_load_lds((glb_ptr_t)(src + j), (lds_ptr_t)(w_f + w * 64u), 4, 0, 0);
+      }
     }
 #endif
   };
@@ -266,6 +306,7 @@ __global__ void __launch_bounds__(1024) k_sample_wide(WideArgs A) {
   // phase 2: n (<= 64) queued rows, slots qhead .. qhead + n - 1: the sparse-column evaluation on dense lanes
   // ------------------------------------------------------------------------------------------------------------
   auto dense_pass = [&](uint32_t n) {
+    typedef const __attribute__((address_space(3))) u32x4 *lds_u4p;
     const bool on = lane < n;
     const uint32_t slot = (qhead + lane) & (QCAP - 1u);
     const uint32_t id = on ? w_q[slot] : 0u;
@@ -276,6 +317,12 @@ __global__ void __launch_bounds__(1024) k_sample_wide(WideArgs A) {
       const uint32_t pw = (k < 4) ? p0 : (k < 8) ? p1 : p2;
       col[k] = (k & 3) == 0 ? ((pw << 4) & 0xFF0u) : ((pw >> (8 * (k & 3) - 4)) & 0xFF0u);
     }
+    // which pairs of column reads any lane of this pass needs (a row of weight w uses entries 0 .. w - 1; the others are the
+    // zero column): bit c = some lane has more than 2 c set bits
+    uint32_t need = 0u;
+#pragma unroll
+    for (int c = 0; c < K / 2; ++c)
+      if (__builtin_amdgcn_ballot_w64(col[2 * c] != F * 16u) != 0ull) need |= 1u << c;
     uint32_t mb = 0, leaf = 0, lvl_off = 0, tt_lds = 0;
     float prev = 0.0f;
 #ifdef TSIMK_WIDE_TRACE
@@ -283,26 +330,55 @@ __global__ void __launch_bounds__(1024) k_sample_wide(WideArgs A) {
 #endif
     WT_MARK(13);
     for (uint32_t li = 0; li <= ((TSIMK_WIDE_SKIP & 1) ? 0u : n_out); ++li) {
-      cptr lvl = levels + li * L4_WORDS;
       if (li > 0) mb |= 1u << (li - 1u);  // trial bit 1 (sampler.py:65)
-      uint32_t e[K + 2];
-#pragma unroll
-      for (int k = 0; k < K; ++k) e[k] = col[k];
-      e[K] = (F + 1u + (mb & 15u)) * 16u;
-      e[K + 1] = (F + 17u + ((mb >> 4) & 15u)) * 16u;
+      const uint32_t e_lo = (F + 1u + (mb & 15u)) * 16u, e_hi = (F + 17u + ((mb >> 4) & 15u)) * 16u;
       float re, im;
-      const bool fixed = (lvl[L4_FLAGS] & TSIMK_LFLAG_FIXED) != 0;
       if (A.l_tt >= 0) {
-        // image word w of this level's tables lies at LDS byte tt_lds + 4 (w - its image offset)
-        const uint32_t bias = lds_col0 + (uint32_t)A.l_tt + tt_lds - 4u * img[wr[WR_TT] + 2u * li];
-        if (fixed) eval_level4_resident<K + 2, true, true>(A.img, img, lvl, e, lds_col0 + lvl_off, ent_bytes, re, im, bias);
-        else eval_level4_resident<K + 2, false, true>(A.img, img, lvl, e, lds_col0 + lvl_off, ent_bytes, re, im, bias);
-        tt_lds += img[wr[WR_TT] + 2u * li + 1u] * 4u;
+        // everything of the level from LDS: its record, the graph records, the column entries, the term tables
+        const u32x4 lv = *reinterpret_cast<const u32x4 *>(&tsimk_lds[(A.l_lvl >> 2) + 4u * li]);
+        const uint32_t G = (uint32_t)__builtin_amdgcn_readfirstlane((int)lv.x), flags = (uint32_t)__builtin_amdgcn_readfirstlane((int)lv.y);
+        const int frame = __builtin_amdgcn_readfirstlane((int)lv.z);
+        const uint32_t g0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)lv.w);
+        const bool fixed = (flags & TSIMK_LFLAG_FIXED) != 0, approx = (flags & TSIMK_LFLAG_APPROX) != 0;
+        Acc4 S;
+        for (uint32_t g = 0; g < G; ++g) {
+          const uint32_t base = lds_col0 + lvl_off + g * ent_bytes;
+          const uint32_t rb = lds_col0 + (uint32_t)A.l_grec + (g0 + g) * (uint32_t)(G4_WORDS * 4);
+          GrecV R;
+          R.a = *(lds_u4p)(uintptr_t)rb;
+          R.b = *(lds_u4p)(uintptr_t)(rb + 16u);
+          R.c = *(lds_u4p)(uintptr_t)(rb + 32u);
+          R.d = R.c;
+          if (approx) R.d = *(lds_u4p)(uintptr_t)(rb + 48u);
+          u32x4 y = *(lds_u4p)(uintptr_t)(base + e_lo);
+          {
+            const u32x4 t = *(lds_u4p)(uintptr_t)(base + e_hi);
+            y ^= t;
+          }
+#pragma unroll
+          for (int c = 0; c < K / 2; ++c)
+            if ((need >> c) & 1u) {
+              const u32x4 v = *(lds_u4p)(uintptr_t)(base + col[2 * c]);
+              const u32x4 w = *(lds_u4p)(uintptr_t)(base + col[2 * c + 1]);
+              y.x = xor3(y.x, v.x, w.x); y.y = xor3(y.y, v.y, w.y); y.z = xor3(y.z, v.z, w.z); y.w = xor3(y.w, v.w, w.w);
+            }
+          if (fixed) acc_graph4<true, true, const GrecV &>(S, A.img, R, y.x, y.y, y.z, y.w, approx, 0u);
+          else acc_graph4<false, true, const GrecV &>(S, A.img, R, y.x, y.y, y.z, y.w, approx, 0u);
+        }
+        if (fixed) acc_finish4<true>(S, frame, approx, re, im);
+        else acc_finish4<false>(S, frame, approx, re, im);
+        lvl_off += G * ent_bytes;
       } else {
-        if (fixed) eval_level4_resident<K + 2, true>(A.img, img, lvl, e, lds_col0 + lvl_off, ent_bytes, re, im);
+        cptr lvl = levels + li * L4_WORDS;
+        uint32_t e[K + 2];
+#pragma unroll
+        for (int k = 0; k < K; ++k) e[k] = col[k];
+        e[K] = e_lo;
+        e[K + 1] = e_hi;
+        if ((lvl[L4_FLAGS] & TSIMK_LFLAG_FIXED) != 0) eval_level4_resident<K + 2, true>(A.img, img, lvl, e, lds_col0 + lvl_off, ent_bytes, re, im);
         else eval_level4_resident<K + 2, false>(A.img, img, lvl, e, lds_col0 + lvl_off, ent_bytes, re, im);
+        lvl_off += lvl[L4_G] * ent_bytes;
       }
-      lvl_off += lvl[L4_G] * ent_bytes;
 #ifdef TSIMK_WIDE_TRACE
       asm volatile("" :: "v"(re), "v"(im));
 #endif
@@ -321,6 +397,7 @@ __global__ void __launch_bounds__(1024) k_sample_wide(WideArgs A) {
 #endif
       WT_MARK(15);
     }
+    (void)tt_lds;
     if (on && !(TSIMK_WIDE_SKIP & 2)) {
       // the words that hold component outputs were NOT stored by phase 1 for this row: their direct bits waited in the queue.
       // (An atomic OR into a stored row - any scope - leaves the XCD's L2 for the fabric: 0.57e6 of them cost C5 90 of
@@ -440,6 +517,8 @@ __global__ void __launch_bounds__(1024) k_sample_wide(WideArgs A) {
   // ------------------------------------------------------------------------------------------------------------
   const uint32_t tw = gridDim.x * wpb;
   uint32_t c = blockIdx.x * wpb + wv;
+  uint32_t st = c / cps, ch = c - st * cps;  // once; afterwards by increments
+  const uint32_t tw_st = tw / cps, tw_ch = tw - tw_st * cps;
   bool staged = false;
   uint32_t check_pending = 0u;  // step + 1 of a batch whose normalisation check is due
   for (;;) {
@@ -460,7 +539,7 @@ __global__ void __launch_bounds__(1024) k_sample_wide(WideArgs A) {
       }
       if (!done && !(TSIMK_WIDE_STAGE == 1 && qtail - qhead >= 64u)) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every read of w_f has returned
-        stage_chunk(c);
+        stage_chunk(st, ch);
         staged = true;
       }
     }
@@ -472,7 +551,6 @@ __global__ void __launch_bounds__(1024) k_sample_wide(WideArgs A) {
       continue;
     }
     if (done) break;
-    const uint32_t st = c / cps, ch = c - st * cps;
     cstep S = steps + st;
     const uint32_t row = ch * 64u + lane;
     const bool active = row < Bu;
@@ -647,6 +725,9 @@ __global__ void __launch_bounds__(1024) k_sample_wide(WideArgs A) {
     WT_MARK(5);
     staged = false;
     c += tw;
+    st += tw_st;
+    ch += tw_ch;
+    if (ch >= cps) { ch -= cps; ++st; }
   }
   WT_MARK(0);
   WT_FLUSH;

@@ -40,6 +40,11 @@ for _ in range(reps):
     call()
 hp.synchronize()
 dt = (time.perf_counter() - t0) / reps
+ts = []
+for _ in range(reps):
+    hp.synchronize(); time.sleep(0.002)
+    t1 = time.perf_counter(); call(); hp.synchronize(); ts.append(time.perf_counter() - t1)
+print(f"  one call at a time (2 ms idle before each, host launch + synchronize included): median {sorted(ts)[len(ts)//2] * 1e6:.1f} us, min {min(ts) * 1e6:.1f} us")
 print(f"{name} p_bit {p_bit}: {nb} batches of {B} per call: {dt * 1e6:.1f} us per call = {dt / nb * 1e6:.2f} us per batch = {nb * B / dt:.3e} shots/s; tables {hp.info()['pattern_max_weight']}")
 if lib is not None and hasattr(lib, "tsim_debug_wide_trace"):
     lib.tsim_debug_wide_trace(buf)

@@ -609,6 +609,7 @@ __global__ void __launch_bounds__(1024) k_sample_wide(WideArgs A) {
     const bool hit = active && cnt <= wmax;
     const bool miss = active && cnt > wmax && cnt <= (uint32_t)K;
     const bool heavy = active && cnt > (uint32_t)K;
+    const unsigned long long hm = __builtin_amdgcn_ballot_w64(heavy);
     // ---- colex rank of a tabulated pattern: sum over its set bits of C(position, ordinal + 1) (tsim_lw.hip.h); byte j of
     // l0 is the bit of ordinal cnt - 1 - j (unused bytes hold F: the zero at the end of every RANK row)
     uint32_t pat = l_bases[cnt < 7u ? cnt : 7u];
@@ -620,6 +621,16 @@ __global__ void __launch_bounds__(1024) k_sample_wide(WideArgs A) {
     const uint32_t ta0 = __builtin_amdgcn_raw_buffer_load_b32(r_tab, thr + 4u, 0, 0);
     const u32x2 ta1 = __builtin_amdgcn_raw_buffer_load_b64(r_tab, thr + 8u, 0, 0);
     const u32x4 ta2 = __builtin_amdgcn_raw_buffer_load_b128(r_tab, thr + 16u, 0, 0);
+    // ---- w_f is free: the NEXT chunk's rows start to travel now, behind the threshold reads (loads return in order) - unless a
+    // generic pass is due before it, which stages rows of its own in w_f (the loop's head then does both)
+    uint32_t st_n = st + tw_st, ch_n = ch + tw_ch;
+    if (ch_n >= cps) { ch_n -= cps; ++st_n; }
+    bool staged_next = false;
+    if (c + tw < total && !(A.has_check && ch == 0u) && otail - ohead + (uint32_t)__popcll(hm) < 64u && TSIMK_WIDE_STAGE != 1) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every read of w_f has returned
+      stage_chunk(st_n, ch_n);
+      staged_next = true;
+    }
     // ---- the draws of every output (sampler.py:74-75): functions of (subkey, shot) only
     const uint32_t slo = so_lo + row;  // (the launcher keeps shot_offset + B below the next multiple of 2^32)
     cptr kp = (cptr)((cbytes)S + __builtin_offsetof(WideStep, keys)) + 2u * keybase;
@@ -714,7 +725,6 @@ __global__ void __launch_bounds__(1024) k_sample_wide(WideArgs A) {
         qtail += (uint32_t)__popcll(mm);
         n_missed += (uint32_t)__popcll(mm);
       }
-      const unsigned long long hm = __builtin_amdgcn_ballot_w64(heavy);
       if (hm != 0ull) {
         if (heavy) w_ovf[(otail + (uint32_t)__popcll(hm & ((1ull << lane) - 1ull))) & (QCAP - 1u)] = (st << 28) | row;
         otail += (uint32_t)__popcll(hm);
@@ -723,11 +733,10 @@ __global__ void __launch_bounds__(1024) k_sample_wide(WideArgs A) {
     }
     if (A.has_check && ch == 0u) check_pending = st + 1u;  // this batch's row 0 lives in this chunk (sampler.py:66-72)
     WT_MARK(5);
-    staged = false;
+    staged = staged_next;
     c += tw;
-    st += tw_st;
-    ch += tw_ch;
-    if (ch >= cps) { ch -= cps; ++st; }
+    st = st_n;
+    ch = ch_n;
   }
   WT_MARK(0);
   WT_FLUSH;

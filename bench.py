@@ -49,7 +49,9 @@ VALU_ISSUE_PEAK = 1024 * 2.4e9 / 2.0  # 1.23e12 wave64 instructions/s
 # 2.3-2.4 GHz (5.5-5.8e11/s); one Threefry-2x32-20 block = 75 such instructions, best of ten instruction selections:
 # 5.8e11 blocks/s (scripts/microbench/threefry_block.hip -> profiles/r03/threefry_block.txt).
 THREEFRY_BLOCKS_PER_S = 5.8e11
-NF = 4                 # distinct f batches rotated through the timed loop
+NF_HOST = 4            # f batches drawn by the seeded host generator (tsim_amd.synth.synth_f): what the verification legs regenerate
+NF_DEFAULT = 64        # distinct f batches rotated through the timed loop: 64 x 8 MB (C2) = 512 MB, beyond the 256-MiB Infinity Cache
+INFINITY_CACHE_MB = 256
 
 
 def algorithmic_bytes_per_shot(num_f: int, num_outputs: int) -> int:
@@ -273,8 +275,12 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--repeats", type=int, default=8, help="repetitions of the timed --steps loop (median reported)")
-    ap.add_argument("--spinup-ms", type=float, default=float(os.environ.get("TSIM_BENCH_SPINUP_MS", "30")),
-                    help="untimed steps worth this many ms before every timed repetition (clock spin-up; 0 = none)")
+    ap.add_argument("--spinup-ms", type=float, default=float(os.environ.get("TSIM_BENCH_SPINUP_MS", "0")),
+                    help="untimed steps worth this many ms before every timed repetition (clock spin-up; default 0 = none: `value` is what "
+                         "--warmup steps and then --steps timed steps give; the rate after 30 ms of spin-up is reported beside it)")
+    ap.add_argument("--nf", type=int, default=NF_DEFAULT, help="distinct resident f batches the timed loop rotates through (the first "
+                    f"{NF_HOST} from the seeded host generator, the others drawn on the device with the same per-bit probability)")
+    ap.add_argument("--no-config-legs", action="store_true", help="skip the driver-timed legs of the other BASELINE configs (C3, C4, C5)")
     ap.add_argument("--shots", type=int, default=1_000_000, help="shots per step per GPU")
     ap.add_argument("--config", default="C2")
     ap.add_argument("--random-program", action="store_true", help="the unconstrained random program instead of the normalised one")
@@ -393,7 +399,16 @@ def main() -> None:
         hp.h2d(buf, packed)
         return buf
 
-    f_bufs = [resident_f(cfg["p_bit"], cfg["seed"] + 1000 * rank + 7919 * k) for k in range(NF)]
+    NF = max(1, int(args.nf))
+    f_bufs = [resident_f(cfg["p_bit"], cfg["seed"] + 1000 * rank + 7919 * k) for k in range(min(NF, NF_HOST))]
+    f_host = list(f_bufs)  # (the seeded ones: what the verification legs regenerate on the host)
+    if NF > len(f_bufs) and not (args.program and file_noise is not None):
+        # the rest are drawn ON THE DEVICE (k_noise_tile: one one-bit channel per f bit at the same probability - the same
+        # distribution as synth_f, 25 us instead of seconds per batch), so that the timed loop's working set is what `--nf` says
+        f_bufs += device_f_batches(backend, hp, num_f, cfg["p_bit"], B, WF, NF - len(f_bufs), seed=cfg["seed"] + 17 * rank)
+    elif NF > len(f_bufs):
+        f_bufs += [resident_f(cfg["p_bit"], cfg["seed"] + 1000 * rank + 7919 * k) for k in range(len(f_bufs), NF)]
+    NF = len(f_bufs)
 
     # Pipeline of NSLOT slots (tsim_sample_batch_device_begin/_end): with short hard-row lists the library runs
     # the first passes of consecutive launches on two lanes and the hard rows of four launches at a time as ONE
@@ -647,7 +662,7 @@ def main() -> None:
     verify = None
     if use_dist and os.environ.get("TSIM_BENCH_VERIFY") == "1":
         verify = verify_collected(backend, prng, synth, program, cfg, hp, comm, lib, rank, N, B, num_f, n_out, RB, local_rank,
-                                  key_state, steps, drain, fence, grp_recv, last_collective, GATHER_EVERY, NF)
+                                  key_state, lambda k: steps(k, f_host), drain, fence, grp_recv, last_collective, GATHER_EVERY, len(f_host))
     # HIP events around the dominant kernel only (level 2), on at least 8 launches per repetition: timing events
     # drain the queue they are recorded on (~5 us each), so not every launch is bracketed
     # (at least 8 bracketed launches over the repetitions together: a bracket costs ~7 us of a ~17 us step)
@@ -785,10 +800,45 @@ def main() -> None:
             if sl_n and sst["pattern_pass"] >= sst["full_kernel"]:
                 serial_ms = sst["pattern_pass"] / sl_n
 
+    # the same timed region once the chip has been busy for 30 ms (its power management raises the clocks over the first ~25 ms of
+    # sustained work, profiles/r03/steps_dependence.txt): context, NOT `value`
+    sustained = None
+    if N == 1 and not use_dist and args.spinup_ms == 0 and os.environ.get("TSIM_BENCH_NO_CONTEXT") != "1":
+        fence()
+        t0 = time.perf_counter()
+        steps(32)
+        fence()
+        est = (time.perf_counter() - t0) / 32
+        n_spin = int(min(20000, max(0, 30e-3 / max(est, 1e-7))))
+        warm = []
+        for _ in range(3):
+            left = n_spin
+            while left > 0:
+                steps(min(64, left))
+                left -= 64
+                hp.synchronize()
+            fence()
+            t0 = time.perf_counter()
+            steps(args.steps)
+            drain()
+            hp.synchronize()
+            device_sync()
+            warm.append(time.perf_counter() - t0)
+        sustained = {"untimed_ms_before_each_region": 30.0, "untimed_steps": n_spin, "ms_per_step": [w / args.steps * 1e3 for w in warm],
+                     "value_median": B * N * args.steps / statistics.median(warm)}
     extra = {}
+    if N == 1 and not use_dist and not args.no_extra_legs and not args.no_config_legs and not args.program and args.config == "C2":
+        # the other BASELINE configs, timed by this process with their own rooflines (22 / 11 / 56 B per shot)
+        legs = {}
+        for cname, cshots, csteps in (("C3", 1_000_000, 64), ("C4", 100_000, 64), ("C5", 1_000_000, 64)):
+            try:
+                legs[cname] = config_leg(backend, synth, cname, cshots, csteps, local_rank)
+            except Exception as exc:  # a leg must never cost the headline line
+                legs[cname] = {"error": repr(exc)}
+        extra["configs"] = legs
     if N == 1 and not use_dist and not args.no_extra_legs:
-        extra = extra_legs(backend, synth, program, cfg, hp, info, B, num_f, n_out, key, f_bufs, d_out0, local_rank, t_build,
-                           resident_f, steps, drain, INIT_STEPS, args)
+        extra.update(extra_legs(backend, synth, program, cfg, hp, info, B, num_f, n_out, key, f_bufs, d_out0, local_rank, t_build,
+                                resident_f, steps, drain, INIT_STEPS, args))
 
     if rank == 0:
         total_shots = float(B) * N * args.steps
@@ -836,7 +886,8 @@ def main() -> None:
             "dtype": "int32",
             "data": "synthetic",
             "repeats": len(rep_elapsed),
-            "spinup": {"ms": args.spinup_ms, "untimed_steps_before_each_repeat": spin_steps,
+            "value_after_30ms_spinup": (sustained or {}).get("value_median"),
+            "spinup": {"ms": args.spinup_ms, "untimed_steps_before_each_repeat": spin_steps, "sustained": sustained,
                        "without": ({"ms_per_step": [e / args.steps * 1e3 for e in cold_elapsed],
                                     "value_median": B * N * args.steps / statistics.median(cold_elapsed)} if cold_elapsed else None),
                        "note": "the same steps, untimed, right before every timed region: the chip reaches its sustained clocks only "
@@ -850,6 +901,13 @@ def main() -> None:
                 "shots_per_step_per_gpu": B,
                 "global_batch": B * N,
                 "distinct_f_batches": NF,
+                "working_set_mb": (NF * B * WF * 8 + NSLOT * B * RB) / 2**20,
+                "working_set_note": f"{NF} resident f batches ({NF * B * WF * 8 / 2**20:.0f} MB) read in rotation + {NSLOT} output buffers "
+                                    f"({NSLOT * B * RB / 2**20:.0f} MB) written in rotation: " + ("beyond" if (NF * B * WF * 8 + NSLOT * B * RB) / 2**20 > INFINITY_CACHE_MB else "INSIDE")
+                                    + f" the {INFINITY_CACHE_MB}-MiB Infinity Cache (MI355X_MICROARCH.md) - --nf sets it",
+                "spinup_ms": args.spinup_ms,
+                "untimed_steps_before_the_timed_region": f"16 initialisation steps (launch-plan feedback, lanes, buffers) + --warmup {args.warmup}"
+                                                         + (f" + {spin_steps} spin-up steps before every repetition" if spin_steps else "") ,
                 "sharding": (f"shots x{N}, bit-packed rows ({RB} B/shot) collected every {GATHER_EVERY} batches by "
                              + ("one RCCL all-to-all (batch group j of all ranks assembled on rank j)" if GATHER_MODE == "alltoall"
                                 else "an RCCL gather to rank 0") + ", issued by libtsim_hip.so (no torch.distributed)")
@@ -917,6 +975,92 @@ def main() -> None:
     C.CDLL(None).fflush(None)
     if rank == 0:
         print(json.dumps(res), flush=True)
+
+
+def device_f_batches(backend, hp, num_f: int, p_bit: float, B: int, WF: int, count: int, seed: int) -> list:
+    """`count` packed f batches drawn in HBM by the device-side channel sampler (k_noise_tile): one one-bit channel per f bit at
+    `p_bit` - synth_f's distribution."""
+    from tsim_amd import prng as _prng
+    from tsim_amd.channels import ChannelSampler, error_probs
+
+    cs = ChannelSampler([error_probs(p_bit)] * num_f, np.eye(num_f, dtype=np.uint8), seed=seed)
+    noise = backend.DeviceNoiseSampler(hp, cs)
+    key = _prng.key(seed)
+    bufs = []
+    for _ in range(count):
+        buf = hp.malloc(B * WF * 8)
+        key, sub = hp.split_key(key)
+        noise.sample_into(buf.ptr, B, sub)
+        bufs.append(buf)
+    hp.synchronize()
+    return bufs
+
+
+def config_leg(backend, synth, name: str, shots: int, steps_n: int, device: int, nf: int = 16, repeats: int = 5) -> dict:
+    """One of the other BASELINE configs through the same path as the headline - tsim_sample_steps_device over resident packed f
+    batches, bit_packed rows out - timed by this process: `steps_n` steps per region, `repeats` regions bracketed by synchronize,
+    median; the dominant kernel's HIP-event duration inside those regions; the HBM roofline of SURVEY 8(d) with this config's own
+    algorithmic bytes.  (Its f batches are drawn on the device: the host generator needs 20 s for one C5 batch.)"""
+    program, cfg = synth.config_program(name)
+    hpx = backend.HipProgram(program, device=device)
+    num_f, n_out = cfg["num_f"], program.num_outputs
+    WF, WO, RB = max(1, (num_f + 63) // 64), (n_out + 63) // 64, (n_out + 7) // 8
+    fl = device_f_batches(backend, hpx, num_f, cfg["p_bit"], shots, WF, nf, seed=cfg["seed"] + 5)
+    nslot = backend.HipProgram.PIPELINE_SLOTS
+    outs = [hpx.malloc(max(16, shots * max(RB, 8 * WO))) for _ in range(nslot)]
+    ks = (C.c_uint32 * 2)(3, 4)
+    j = [0]
+
+    def go(k):
+        hpx.sample_steps_device([fl[(j[0] + i) % nf].ptr for i in range(k)], shots, num_f, ks, [outs[(j[0] + i) % nslot].ptr for i in range(k)],
+                                inputs_ready=True, out_bit_packed=True)
+        j[0] += k
+
+    for _ in range(6):  # launch-plan feedback of earlier launches, lanes, buffers
+        go(4)
+        hpx.synchronize()
+    go(steps_n)
+    hpx.synchronize()
+    hpx.profile_set_sampling(max(1, (steps_n + 7) // 8 * repeats // 8))
+    hpx.profile_enable(2)
+    hpx.profile_read(reset=True)
+    hpx.profile_read_steps()
+    dts, enq = [], []
+    for _ in range(repeats):
+        hpx.synchronize()
+        t0 = time.perf_counter()
+        go(steps_n)
+        enq.append(time.perf_counter() - t0)
+        hpx.synchronize()
+        dts.append(time.perf_counter() - t0)
+    stages = hpx.profile_read_stages()
+    kern_ms, launches = hpx.profile_read(reset=True)
+    psteps = hpx.profile_read_steps()
+    hpx.profile_enable(False)
+    info = hpx.info()
+    dt = statistics.median(dts)
+    bps = algorithmic_bytes_per_shot(num_f, n_out)
+    # the kernel every row goes through: the fused pattern-table pass (stage "pattern_pass") where there is one
+    k_ms = (stages["pattern_pass"] / launches) if launches and stages["pattern_pass"] > 0 else (kern_ms / launches if launches else None)
+    bpl = (psteps / launches) if (psteps and launches) else 1.0
+    achieved = bps * shots * bpl / (k_ms * 1e-3) / 1e9 if k_ms else None
+    for b in fl + outs:
+        b.free()
+    hpx.close()
+    return {
+        "workload": f"{name}: {cfg['name']}, {info['total_graphs']} stabiliser terms, n_out={n_out}, num_f={num_f}, p_bit={cfg['p_bit']}",
+        "shots_per_step": shots, "steps": steps_n, "repeats": repeats, "distinct_f_batches": nf,
+        "working_set_mb": (nf * shots * WF * 8 + nslot * shots * RB) / 2**20,
+        "value": shots * steps_n / dt, "unit": "shots/s", "ms_per_step": dt / steps_n * 1e3,
+        "ms_per_step_all": [d / steps_n * 1e3 for d in dts],
+        "host_enqueue_ms_per_step": statistics.median(enq) / steps_n * 1e3,
+        "pattern_max_weight": info.get("pattern_max_weight"),
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
+                     "algorithmic_bytes_per_shot": bps, "kernel_avg_ms": k_ms, "batches_per_launch": bpl,
+                     "achieved_at_step_rate": bps * shots / (dt / steps_n) / 1e9, "frac_at_step_rate": bps * shots / (dt / steps_n) / 1e9 / HBM_PEAK_GBS,
+                     "traffic": None,
+                     "note": "achieved = algorithmic bytes of one launch / HIP-event time of the kernel every row goes through, inside the timed regions"},
+    }
 
 
 def verify_collected(backend, prng, synth, program, cfg, hp, comm, lib, rank, N, B, num_f, n_out, RB, device, key_state, steps, drain,

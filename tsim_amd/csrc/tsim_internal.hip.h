@@ -134,11 +134,6 @@ struct tsim_program {
   float *d_dev = nullptr;
   hipStream_t stream = nullptr;
   hipStream_t aux[TSIM_AUX_STREAMS] = {};  // tsim_aux_stream
-  // TSIM_AMD_HARD_CUS = n > 0: the first-pass lanes are confined to all but n compute units and the hard-row grids of fused
-  // groups run on two lanes of their own that own those n (hipExtStreamCreateWithCUMask): a grid then starts when its lists
-  // are complete, whatever the first passes hold (batch lanes 6 and 7)
-  hipStream_t hard_lane[2] = {nullptr, nullptr};
-  unsigned long long hard_lane_next = 0;
   // low-weight pattern tables (tsim_lw.hip.h)
   int lw_request = -1;        // -1 default (on in TSIM_MODE_AUTO), 0 off, 1 on
   int lw_weight_cap = -1;     // -1 = TSIMK_LW_MAX_WEIGHT
@@ -187,7 +182,7 @@ struct tsim_program {
   Slot slots[1 + TSIM_PIPELINE_SLOTS];
   bool slots_ready = false;
   std::vector<int> deferred;  // slots whose hard rows are waiting, in launch order
-  hipEvent_t lane_ev[4] = {nullptr, nullptr, nullptr, nullptr};  // "first passes enqueued so far on lane k are done"
+  hipEvent_t lane_ev[2] = {nullptr, nullptr};  // "first passes enqueued so far on lane k are done"
   hipEvent_t batch_ev[16] = {};
   int batch_ev_lane[16] = {};                  // ... and the stream (batch_lane) it was recorded on
   hipStream_t flush_inline = nullptr;          // set by a caller of tsim_flush_hard: run this batch on that first-pass lane itself
@@ -197,11 +192,11 @@ struct tsim_program {
   int64_t series_stride = 0;
   int series_left = 0;
   unsigned long long batch_next = 1;       // sequence number of the next batch (event = batch_ev[seq % 16])
-  unsigned long long batch_confirmed[8] = {};  // per batch lane: every batch up to this one is known to be complete
+  unsigned long long batch_confirmed[6] = {};  // per batch lane: every batch up to this one is known to be complete
   hipStream_t joined_stream = nullptr;  // tsim_sample_batch_device_end: the stream that last joined a batch ...
-  unsigned long long joined_seq[8] = {};    // ... and that batch: it is behind every batch up to this one
+  unsigned long long joined_seq[6] = {};    // ... and that batch: it is behind every batch up to this one
   int lane_reach[4] = {0, 0, 0, 0};  // batches between a lane's last start-of-batch wait and the batch it waited for (pre-wait)
-  unsigned long long lane_waited[4][8] = {};  // [first-pass lane][batch lane]: newest batch already waited for
+  unsigned long long lane_waited[4][6] = {};  // [first-pass lane][batch lane]: newest batch already waited for
   unsigned long long stat_queries = 0, stat_waits = 0, stat_begins = 0, stat_flushes = 0, stat_deferred = 0, stat_fused = 0, stat_fast = 0, stat_partial = 0;
   unsigned long long steps_slot = 0;    // tsim_sample_steps_device: next pipeline slot of its rotation ...
   unsigned long long steps_groups = 0;  // ... and the fused groups launched so far (first-pass lanes alternate)
@@ -241,7 +236,6 @@ struct tsim_program {
     unsigned long long deep_after = 20000000000ull;  // TSIM_AMD_DEEP_AFTER
     int hard_wave_rows = 1024;  // TSIM_AMD_HARD_WAVE_ROWS: ... while a batch of launches has at most this many hard rows (last feedback)
     bool hard_wave = true;    // TSIM_AMD_HARD_WAVE=0: hard-row batches on k_sample4h_multi (64 rows per block) instead of one wave per row
-    int hard_cus = 0;         // TSIM_AMD_HARD_CUS: compute units set aside for the hard-row grids of fused groups (0: none, the grids run on the group's lane)
     bool wide_fused = true;   // TSIM_AMD_WIDE_FUSED=0: wide programs on the three-kernel path of round 2 (tables, k_sample4w, row kernel)
     bool lw_fast = true;      // TSIM_AMD_LW_FAST=0: the generic fused pass (k_sample_lw_multi) also for one-component programs
     int fused_max = 8;        // TSIM_AMD_FUSED_MAX: batches per fused first pass (<= TSIMK_LWM_MAX_STEPS = 16; hard rows in grids of <= TSIMK_H_MAX_CTX launches)

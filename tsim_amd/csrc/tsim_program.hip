@@ -846,7 +846,6 @@ retry_pack:
     p->knobs.fused_steps = env_int("TSIM_AMD_FUSED_STEPS", 1) != 0;
     p->knobs.lw_fast = env_int("TSIM_AMD_LW_FAST", 1) != 0;
     p->knobs.wide_fused = env_int("TSIM_AMD_WIDE_FUSED", 1) != 0;
-    p->knobs.hard_cus = std::max(0, std::min(128, env_int("TSIM_AMD_HARD_CUS", 0)));
     p->knobs.hard_wave = env_int("TSIM_AMD_HARD_WAVE", 1) != 0;
     if (const char *e = getenv("TSIM_AMD_HARD_INLINE_ROWS")) p->knobs.hard_inline_rows = std::max(0ll, atoll(e));
     p->knobs.deep_tables = env_int("TSIM_AMD_DEEP_TABLES", 0);
@@ -867,16 +866,7 @@ retry_pack:
     int cu = 0;
     if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cu > 0) p->n_cu = cu;
   }
-  if (p->knobs.hard_cus > 0 && p->knobs.hard_cus < p->n_cu) {
-    // mask bits go round the XCDs (bit i -> XCD i mod 8, profiles/r04/cumask_probe.txt): the first n bits are n / 8 CUs of each
-    std::vector<uint32_t> m_hard((size_t)(p->n_cu + 31) / 32, 0u), m_first((size_t)(p->n_cu + 31) / 32, 0u);
-    for (int i = 0; i < p->n_cu; ++i) (i < p->knobs.hard_cus ? m_hard : m_first)[(size_t)i / 32] |= 1u << (i % 32);
-    HIP_TRY(hipExtStreamCreateWithCUMask(&p->stream, (uint32_t)m_first.size(), m_first.data()));
-    for (auto &h : p->hard_lane) HIP_TRY(hipExtStreamCreateWithCUMask(&h, (uint32_t)m_hard.size(), m_hard.data()));
-  } else {
-    p->knobs.hard_cus = 0;
-    HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
-  }
+  HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
   HIP_TRY(hipMalloc((void **)&p->d_img, img.size() * 4));
   HIP_TRY(hipMemcpy(p->d_img, img.data(), img.size() * 4, hipMemcpyHostToDevice));
   HIP_TRY(hipMalloc((void **)&p->d_dev, std::max<size_t>(1, p->comps.size()) * 4));
@@ -905,7 +895,6 @@ extern "C" void tsim_program_destroy(tsim_program *p) {
               p->stat_begins, p->stat_deferred, p->stat_flushes, p->stat_queries, p->stat_waits, p->stat_fused, p->stat_fast, p->stat_partial);
     if (p->sync_ev) (void)hipEventDestroy(p->sync_ev);
     for (hipEvent_t e : p->lane_ev) if (e) (void)hipEventDestroy(e);
-    for (hipStream_t h : p->hard_lane) if (h) (void)hipStreamDestroy(h);
     for (hipEvent_t e : p->batch_ev) if (e) (void)hipEventDestroy(e);
     for (void *s : p->scratch)
       if (s) (void)hipFree(s);
@@ -1140,7 +1129,5 @@ extern "C" int tsim_synchronize(tsim_program *p) {
     if ((k <= 4 || sl.used) && sl.side != p->stream) HIP_TRY(hipStreamSynchronize(sl.side));
     sl.pending = false;
   }
-  for (hipStream_t h : p->hard_lane)
-    if (h) HIP_TRY(hipStreamSynchronize(h));
   return TSIM_OK;
 }

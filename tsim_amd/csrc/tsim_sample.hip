@@ -79,10 +79,6 @@ static int slot_prepare(tsim_program *p, int slot, size_t hard_bytes) {
       // a third one.  Three truly concurrent lanes: 36 us per step instead of 42.
       sl.side = p->stream;
       sl.side_borrowed = true;
-    } else if (p->knobs.hard_cus > 0 && slot <= 4) {  // a first-pass lane: everything but the hard-row lanes' compute units
-      std::vector<uint32_t> m_first((size_t)(p->n_cu + 31) / 32, 0u);
-      for (int i = p->knobs.hard_cus; i < p->n_cu; ++i) m_first[(size_t)i / 32] |= 1u << (i % 32);
-      HIP_TRY(hipExtStreamCreateWithCUMask(&sl.side, (uint32_t)m_first.size(), m_first.data()));
     } else {
       HIP_TRY(hipStreamCreateWithFlags(&sl.side, hipStreamNonBlocking));
     }
@@ -287,13 +283,7 @@ static int flush_batch(tsim_program *p) {
   // pipeline's period; on the two lanes they overlap each other and the other lane's first pass.
   int bl = 0;
   hipStream_t hs = p->slots[3].side;
-  if (p->flush_inline && p->knobs.hard_cus > 0) {  // fused groups: the hard-row lanes with compute units of their own, in turn
-    const int k = (int)(p->hard_lane_next++ & 1ull);
-    hs = p->hard_lane[k];
-    bl = 6 + k;
-    p->flush_inline = nullptr;
-    p->inline_seen = true;
-  } else if (p->flush_inline) {
+  if (p->flush_inline) {
     hs = p->flush_inline;
     bl = 2;
     for (int k = 0; k < 4; ++k)
@@ -313,16 +303,16 @@ static int flush_batch(tsim_program *p) {
   M.comp4_off = p->comp4_off;
   M.feedback = p->d_feedback;
   // the batch starts after the first passes: streams are in order, so one event per lane covers them all
-  bool lane_used[4] = {false, false, false, false};
+  bool lane_used[2] = {false, false};
   for (int i = 0; i < M.n_ctx; ++i) {
     tsim_program::Slot &d = p->slots[p->deferred[i]];
-    for (int k = 0; k < 4; ++k)
-      if (p->slots[1 + k].side_ready && d.p1_stream == p->slots[1 + k].side) lane_used[k] = true;
+    for (int k = 0; k < 2; ++k)
+      if (d.p1_stream == p->slots[1 + k].side) lane_used[k] = true;
     M.ctx[i] = d.ctx;
     M.ctx[i].kernarg_off = (int)(offsetof(Hard4Multi, ctx) + (size_t)i * sizeof(SampleArgs));
     if (d.ctx_check) M.check_mask |= 1 << i;
   }
-  for (int k = 0; k < 4; ++k)
+  for (int k = 0; k < 2; ++k)
     if (lane_used[k] && p->slots[1 + k].side != hs) {
       if (!p->lane_ev[k]) HIP_TRY(hipEventCreateWithFlags(&p->lane_ev[k], hipEventDisableTiming));
       HIP_TRY(hipEventRecord(p->lane_ev[k], p->slots[1 + k].side));

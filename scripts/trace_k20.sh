@@ -2,7 +2,7 @@
 # kernel timeline of the last timed region of `bench.py --steps 20` (run on the GPU box)
 R=$GRAFT_REPO_ROOT; cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/tr20
-timeout 300 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/tr20 -- python $R/bench.py --steps ${1:-20} --warmup 3 --repeats 3 --spinup-ms ${2:-30} --no-cpu-baseline --no-extra-legs > $R/gpurun_out/tr20.json 2>/dev/null
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/tr20 -- python $R/bench.py --steps ${1:-20} --warmup 3 --repeats 3 --spinup-ms ${2:-30} --no-cpu-baseline --no-extra-legs --no-config-legs > $R/gpurun_out/tr20.json 2>/dev/null
 python - <<PY
 import csv, glob, re
 fn = glob.glob("$R/gpurun_out/tr20/*/*_kernel_trace.csv")[0]

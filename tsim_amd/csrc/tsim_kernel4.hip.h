@@ -194,10 +194,12 @@ __device__ __forceinline__ void acc_finish4(Acc4 &S, int frame, bool approx, flo
 // evaluate() of one level with LDS chunk tables.  All threads of the block must call this together.
 // NR = LDS reads per graph: the caller passes this lane's NR entry offsets inside a tile table
 // (`ent0`, bytes from the start of the tile), the tile size and the table's offset in the image.
+// `gstride`: bytes between the entries of consecutive graphs of a tile (256 in the chunk tables - [chunk][graph][value] -,
+// entries x 16 in the column tables - [graph][entry]).
 template <int GT, int NR, bool FIXED>
 __device__ __forceinline__ void eval_level4(const uint32_t *gimg, cptr img, cptr lvl, const uint32_t (&ent0)[NR],
                                             uint32_t tile_bytes, uint32_t table_off,
-                                            uint8_t *lds_tab /* 2 * tile bytes */, float &out_re, float &out_im) {
+                                            uint8_t *lds_tab /* 2 * tile bytes */, float &out_re, float &out_im, uint32_t gstride = 16u) {
   const uint32_t G = lvl[L4_G], ntiles = lvl[L4_NTILES];
   const bool approx = (lvl[L4_FLAGS] & TSIMK_LFLAG_APPROX) != 0;
   const uint32_t tile_vec = tile_bytes >> 4;  // uint4 elements per tile
@@ -234,8 +236,8 @@ __device__ __forceinline__ void eval_level4(const uint32_t *gimg, cptr img, cptr
       static_assert(NR % 2 == 0, "entries are consumed in pairs");
 #pragma unroll
       for (int c = 0; c < NR; c += 2) {
-        const u32x4 v = *(lds_u4p)(uintptr_t)(ent[c] + j * 16);
-        const u32x4 w = *(lds_u4p)(uintptr_t)(ent[c + 1] + j * 16);
+        const u32x4 v = *(lds_u4p)(uintptr_t)(ent[c] + (uint32_t)j * gstride);
+        const u32x4 w = *(lds_u4p)(uintptr_t)(ent[c + 1] + (uint32_t)j * gstride);
         U = xor3(U, v.x, w.x); V = xor3(V, v.y, w.y); O1 = xor3(O1, v.z, w.z); O2 = xor3(O2, v.w, w.w);
         // at most six 16-byte reads in flight: more only costs VGPRs (24 per six) without hiding
         // any more LDS latency
@@ -371,21 +373,21 @@ k_sample4(Sample4Args A4) {
             for (int k = 0; k < 4; ++k) {
               const uint32_t pos = rem ? (uint32_t)__builtin_ctzll(rem) : F;
               rem &= rem - 1ull;
-              col_off[k] = pos * (GT * 16);
+              col_off[k] = pos * 16u;
             }
           }
           const uint32_t e6[6] = {col_off[0], col_off[1], col_off[2], col_off[3],
-                                  (F + 1u + (mb & 15u)) * (GT * 16), (F + 17u + ((mb >> 4) & 15u)) * (GT * 16)};
-          eval_level4<GT, 6, true>(A.img, img, lvl, e6, (F + 33u) * (GT * 16), lvl[L4_STAB], lds_tab, re, im);
+                                  (F + 1u + (mb & 15u)) * 16u, (F + 17u + ((mb >> 4) & 15u)) * 16u};
+          eval_level4<GT, 6, true>(A.img, img, lvl, e6, (F + 33u) * (GT * 16), lvl[L4_STAB], lds_tab, re, im, (F + 33u) * 16u);
         } else {
           uint32_t en[NCH];
 #pragma unroll
           for (int c = 0; c < NCH; ++c) {
             const uint32_t w = (c < 8) ? x[0] : x[1];
-            en[c] = ((w >> (4 * (c & 7))) & 15u) * (GT * 16) + c * Tile4<GT>::kChunkBytes;
+            en[c] = ((w >> (4 * (c & 7))) & 15u) * 16u + c * Tile4<GT>::kChunkBytes;
           }
-          if (lvl_fixed) eval_level4<GT, NCH, true>(A.img, img, lvl, en, NCH * Tile4<GT>::kChunkBytes, lvl[L4_TABLES], lds_tab, re, im);
-          else eval_level4<GT, NCH, false>(A.img, img, lvl, en, NCH * Tile4<GT>::kChunkBytes, lvl[L4_TABLES], lds_tab, re, im);
+          if (lvl_fixed) eval_level4<GT, NCH, true>(A.img, img, lvl, en, NCH * Tile4<GT>::kChunkBytes, lvl[L4_TABLES], lds_tab, re, im, 256u);
+          else eval_level4<GT, NCH, false>(A.img, img, lvl, en, NCH * Tile4<GT>::kChunkBytes, lvl[L4_TABLES], lds_tab, re, im, 256u);
         }
         v1 = cabs32(re, im);
       }

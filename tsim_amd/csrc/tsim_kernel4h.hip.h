@@ -99,7 +99,7 @@ __device__ __forceinline__ void eval_level4h(const uint32_t *gimg, cptr img, cpt
         if (g < gend) {
           const uint32_t gl = g - gbeg;
           uint32_t U, V, O1, O2, idx, dbits, r;
-          h4_form<NCH>(ent, (gl / GT) * H::kTileBytes + (gl % GT) * 16u, U, V, O1, O2);
+          h4_form<NCH>(ent, (gl / GT) * H::kTileBytes + (gl % GT) * 256u, U, V, O1, O2);
           cptr gr = recs + g * G4_WORDS;
           h4_index(gr, U, V, O1, O2, idx, dbits, r);
           tv[q] = *reinterpret_cast<const uint4 *>(gimg + gr[G4_TBL] + 16u * idx + 4u * r);
@@ -122,7 +122,7 @@ __device__ __forceinline__ void eval_level4h(const uint32_t *gimg, cptr img, cpt
       for (uint32_t g = gbeg; g < gend; ++g) {
         const uint32_t gl = g - gbeg;
         uint32_t U, V, O1, O2, idx, dbits, r;
-        h4_form<NCH>(ent, (gl / GT) * H::kTileBytes + (gl % GT) * 16u, U, V, O1, O2);
+        h4_form<NCH>(ent, (gl / GT) * H::kTileBytes + (gl % GT) * 256u, U, V, O1, O2);
         cptr gr = recs + g * G4_WORDS;
         const uint32_t gflags = gr[G4_FLAGS];
         h4_index(gr, U, V, O1, O2, idx, dbits, r);
@@ -301,7 +301,7 @@ __device__ __forceinline__ void sample4h_rows(const SampleArgs &A, int comp4_off
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {
         const uint32_t w = (c < 8) ? x[0] : x[1];
-        en[c] = ((w >> (4 * (c & 7))) & 15u) * (GT * 16) + c * Tile4<GT>::kChunkBytes;
+        en[c] = ((w >> (4 * (c & 7))) & 15u) * 16u + c * Tile4<GT>::kChunkBytes;
       }
       float re, im;
       eval_level4h<GT, NCH, NW>(A.img, img, lvl, en, lds_tab, exch, group_tiles, re, im);

@@ -595,12 +595,15 @@ void emit_level4(const HostLevel &h, int GT, int nch, const uint32_t *v3recs, st
           if (!((v >> bb) & 1) || i >= P) continue;
           for (int w = 0; w < 4; ++w) val[(size_t)w] ^= col[(size_t)i][(size_t)w];
         }
-        uint32_t *dst = &tabs4[((((size_t)tile * nch + c) * 16 + v) * GT + j) * 4];
+        // [tile][chunk][graph][value]: the lanes of a wave read ONE graph's entry for THEIR chunk value - 16 bytes apart per value,
+        // so the 16 values fall on 16 different groups of banks (value-major entries of GT x 16 bytes put values v and v + 4 on
+        // the same banks: k_sample4's LDS pipe spent 2.4 x its busy time in bank conflicts, profiles/r04/full_kernel_pmc.txt)
+        uint32_t *dst = &tabs4[((((size_t)tile * nch + c) * GT + j) * 16 + v) * 4];
         for (int w = 0; w < 4; ++w) dst[w] = val[(size_t)w];
       }
     if (sent) {
       auto put = [&](int e, const std::array<uint32_t, 4> &val) {
-        uint32_t *dst = &stabs4[(((size_t)tile * sent + e) * GT + j) * 4];
+        uint32_t *dst = &stabs4[(((size_t)tile * GT + j) * sent + e) * 4];  // [tile][graph][entry]: consecutive entries on consecutive bank groups
         for (int w = 0; w < 4; ++w) dst[w] = val[(size_t)w];
       };
       for (int i = 0; i < sparse_F && i < P; ++i) put(i, col[(size_t)i]);

@@ -196,10 +196,13 @@ __device__ __forceinline__ void acc_finish4(Acc4 &S, int frame, bool approx, flo
 // (`ent0`, bytes from the start of the tile), the tile size and the table's offset in the image.
 // `gstride`: bytes between the entries of consecutive graphs of a tile (256 in the chunk tables - [chunk][graph][value] -,
 // entries x 16 in the column tables - [graph][entry]).
-template <int GT, int NR, bool FIXED>
+// (a template parameter: the per-graph offsets are then immediates of the LDS reads - no address arithmetic per read)
+#define TSIMK_SPARSE_ENTRIES 128  // entries per graph of a GT > 1 column-table tile (F + 33 <= 97 used, padded: constant stride)
+template <int GT, int NR, bool FIXED, int GSTRIDE = 16>
 __device__ __forceinline__ void eval_level4(const uint32_t *gimg, cptr img, cptr lvl, const uint32_t (&ent0)[NR],
                                             uint32_t tile_bytes, uint32_t table_off,
-                                            uint8_t *lds_tab /* 2 * tile bytes */, float &out_re, float &out_im, uint32_t gstride = 16u) {
+                                            uint8_t *lds_tab /* 2 * tile bytes */, float &out_re, float &out_im) {
+  constexpr uint32_t gstride = GSTRIDE;
   const uint32_t G = lvl[L4_G], ntiles = lvl[L4_NTILES];
   const bool approx = (lvl[L4_FLAGS] & TSIMK_LFLAG_APPROX) != 0;
   const uint32_t tile_vec = tile_bytes >> 4;  // uint4 elements per tile
@@ -378,7 +381,7 @@ k_sample4(Sample4Args A4) {
           }
           const uint32_t e6[6] = {col_off[0], col_off[1], col_off[2], col_off[3],
                                   (F + 1u + (mb & 15u)) * 16u, (F + 17u + ((mb >> 4) & 15u)) * 16u};
-          eval_level4<GT, 6, true>(A.img, img, lvl, e6, (F + 33u) * (GT * 16), lvl[L4_STAB], lds_tab, re, im, (F + 33u) * 16u);
+          eval_level4<GT, 6, true, TSIMK_SPARSE_ENTRIES * 16>(A.img, img, lvl, e6, TSIMK_SPARSE_ENTRIES * (GT * 16), lvl[L4_STAB], lds_tab, re, im);
         } else {
           uint32_t en[NCH];
 #pragma unroll
@@ -386,8 +389,8 @@ k_sample4(Sample4Args A4) {
             const uint32_t w = (c < 8) ? x[0] : x[1];
             en[c] = ((w >> (4 * (c & 7))) & 15u) * 16u + c * Tile4<GT>::kChunkBytes;
           }
-          if (lvl_fixed) eval_level4<GT, NCH, true>(A.img, img, lvl, en, NCH * Tile4<GT>::kChunkBytes, lvl[L4_TABLES], lds_tab, re, im, 256u);
-          else eval_level4<GT, NCH, false>(A.img, img, lvl, en, NCH * Tile4<GT>::kChunkBytes, lvl[L4_TABLES], lds_tab, re, im, 256u);
+          if (lvl_fixed) eval_level4<GT, NCH, true, 256>(A.img, img, lvl, en, NCH * Tile4<GT>::kChunkBytes, lvl[L4_TABLES], lds_tab, re, im);
+          else eval_level4<GT, NCH, false, 256>(A.img, img, lvl, en, NCH * Tile4<GT>::kChunkBytes, lvl[L4_TABLES], lds_tab, re, im);
         }
         v1 = cabs32(re, im);
       }

@@ -559,7 +559,9 @@ void emit_level4(const HostLevel &h, int GT, int nch, const uint32_t *v3recs, st
   ntiles_out = ntiles;
   recs4.assign((size_t)G * G4_WORDS, 0u);
   tabs4.assign((size_t)ntiles * nch * 16 * GT * 4, 0u);
-  const int sent = sparse_F >= 0 ? sparse_F + 1 + 32 : 0;
+  // entries per graph of a column-table tile: F + 33 used; tiles of several graphs pad to a constant (the kernel's per-graph
+  // offsets are immediates), the one-graph tiles of the wide layout do not
+  const int sent = sparse_F < 0 ? 0 : (GT > 1 ? std::max(TSIMK_SPARSE_ENTRIES, sparse_F + 33) : sparse_F + 33);
   stabs4.assign((size_t)ntiles * sent * GT * 4, 0u);
   std::vector<std::array<uint32_t, 4>> col((size_t)std::max(P, 1));
   for (int g = 0; g < G; ++g) {

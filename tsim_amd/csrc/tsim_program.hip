@@ -415,7 +415,7 @@ retry_pack:
           while (img.size() % 16) img.push_back(0u);
           const uint32_t stoff = stabs4.empty() ? 0u : (uint32_t)img.size();
           img.insert(img.end(), stabs4.begin(), stabs4.end());
-          p->v4_max_sent = std::max(p->v4_max_sent, sparse_F >= 0 ? sparse_F + 33 : 0);
+          p->v4_max_sent = std::max(p->v4_max_sent, sparse_F < 0 ? 0 : (p->v4_gt > 1 ? std::max(TSIMK_SPARSE_ENTRIES, sparse_F + 33) : sparse_F + 33));
           uint32_t *lr = &img[l4 + (size_t)k * L4_WORDS];
           lr[L4_STAB] = stoff;
           lr[L4_G] = (uint32_t)h.G;

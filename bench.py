@@ -290,6 +290,8 @@ def main() -> None:
     ap.add_argument("--live-padding", action="store_true", help="term counts of the shape reached with terms the packer cannot cancel")
     ap.add_argument("--program", default=None, help="a compiled program exported where tsim is installed "
                     "(scripts/export_from_tsim.py -> .npz) instead of the synthetic shape")
+    ap.add_argument("--check-golden", action="store_true", help="with --program: first sample the file's golden request (the shots the reference "
+                    "itself drew, scripts/export_from_tsim.py --golden) and compare bit for bit: `golden_check` in the JSON line")
     ap.add_argument("--num-f", type=int, default=None, help="with --program: width of the synthetic f batches (default: from the file, "
                     "else the largest f index + 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -352,6 +354,14 @@ def main() -> None:
         os.environ.setdefault("MASTER_PORT", "29511")
         comm = tdist.Communicator(local_rank, exchange_unique_id(rank, N), rank, N)
 
+    golden_check = None
+    if args.program and args.check_golden and rank == 0:
+        from tsim_amd import golden as tgolden
+
+        try:
+            golden_check = tgolden.check_golden(args.program, device=local_rank)
+        except KeyError as exc:
+            golden_check = {"ok": None, "note": str(exc)}
     if args.program:
         from tsim_amd import program as tprog
 
@@ -402,12 +412,12 @@ def main() -> None:
     NF = max(1, int(args.nf))
     f_bufs = [resident_f(cfg["p_bit"], cfg["seed"] + 1000 * rank + 7919 * k) for k in range(min(NF, NF_HOST))]
     f_host = list(f_bufs)  # (the seeded ones: what the verification legs regenerate on the host)
-    if NF > len(f_bufs) and not (args.program and file_noise is not None):
+    if NF > len(f_bufs):
         # the rest are drawn ON THE DEVICE (k_noise_tile: one one-bit channel per f bit at the same probability - the same
-        # distribution as synth_f, 25 us instead of seconds per batch), so that the timed loop's working set is what `--nf` says
-        f_bufs += device_f_batches(backend, hp, num_f, cfg["p_bit"], B, WF, NF - len(f_bufs), seed=cfg["seed"] + 17 * rank)
-    elif NF > len(f_bufs):
-        f_bufs += [resident_f(cfg["p_bit"], cfg["seed"] + 1000 * rank + 7919 * k) for k in range(len(f_bufs), NF)]
+        # distribution as synth_f, 25 us instead of seconds per batch - or the file's own noise model), so that the timed loop's
+        # working set is what `--nf` says
+        f_bufs += device_f_batches(backend, hp, num_f, cfg["p_bit"], B, WF, NF - len(f_bufs), seed=cfg["seed"] + 17 * rank,
+                                   noise_model=file_noise if (args.program and file_noise is not None and args.p_bit is None) else None)
     NF = len(f_bufs)
 
     # Pipeline of NSLOT slots (tsim_sample_batch_device_begin/_end): with short hard-row lists the library runs
@@ -960,6 +970,8 @@ def main() -> None:
         }
         if verify is not None:
             res["verify"] = verify
+        if golden_check is not None:
+            res["golden_check"] = golden_check
         if gather_calibration is not None:
             res["gather_calibration"] = gather_calibration
         if args.approx or args.live_padding or args.program:
@@ -977,13 +989,16 @@ def main() -> None:
         print(json.dumps(res), flush=True)
 
 
-def device_f_batches(backend, hp, num_f: int, p_bit: float, B: int, WF: int, count: int, seed: int) -> list:
+def device_f_batches(backend, hp, num_f: int, p_bit: float, B: int, WF: int, count: int, seed: int, noise_model=None) -> list:
     """`count` packed f batches drawn in HBM by the device-side channel sampler (k_noise_tile): one one-bit channel per f bit at
-    `p_bit` - synth_f's distribution."""
+    `p_bit` - synth_f's distribution - or `noise_model` = (channel_probs, error_transform), an exported program's own."""
     from tsim_amd import prng as _prng
     from tsim_amd.channels import ChannelSampler, error_probs
 
-    cs = ChannelSampler([error_probs(p_bit)] * num_f, np.eye(num_f, dtype=np.uint8), seed=seed)
+    if noise_model is not None:
+        cs = ChannelSampler(noise_model[0], noise_model[1], seed=seed)
+    else:
+        cs = ChannelSampler([error_probs(p_bit)] * num_f, np.eye(num_f, dtype=np.uint8), seed=seed)
     noise = backend.DeviceNoiseSampler(hp, cs)
     key = _prng.key(seed)
     bufs = []

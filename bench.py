@@ -275,7 +275,7 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--repeats", type=int, default=8, help="repetitions of the timed --steps loop (median reported)")
-    ap.add_argument("--spinup-ms", type=float, default=float(os.environ.get("TSIM_BENCH_SPINUP_MS", "0")),
+    ap.add_argument("--spinup-ms", type=float, default=0.0,
                     help="untimed steps worth this many ms before every timed repetition (clock spin-up; default 0 = none: `value` is what "
                          "--warmup steps and then --steps timed steps give; the rate after 30 ms of spin-up is reported beside it)")
     ap.add_argument("--nf", type=int, default=NF_DEFAULT, help="distinct resident f batches the timed loop rotates through (the first "
@@ -431,7 +431,7 @@ def main() -> None:
     # every even count from 10 to 16 gives C2 the same steady state since the library pre-waits mid-batch
     # (profiles/r02/slot_count.txt), 14 is marginally the best at the driver's 20 steps per timed region.
     default_slots = 16 if info["table_bytes"] > (4 << 20) else 14
-    NSLOT = max(1, min(backend.HipProgram.PIPELINE_SLOTS, int(os.environ.get("TSIM_BENCH_SLOTS", str(default_slots)))))
+    NSLOT = max(1, min(backend.HipProgram.PIPELINE_SLOTS, default_slots))
     # Group size: a collective per group runs on the join lane under the next group's kernels, only the LAST group's
     # is exposed at the end of a timed region - so a short region (the driver's --steps 20) wants small groups, a
     # long one fewer, larger collectives.  A group must be a multiple of the hard-row batch (4 launches: closing a
@@ -475,7 +475,7 @@ def main() -> None:
     d_outs = [hp.malloc(B * WO * 8) for _ in range(NSLOT)]  # sized for the padded rows too (serial legs below)
     out_ptrs = [d.ptr for d in d_outs]
     PIPE_READY, PIPE_PACKED = 1, 2
-    COLL_OWN_STREAM = os.environ.get("TSIM_BENCH_COLL_STREAM", "own") == "own"
+    COLL_OWN_STREAM = True  # (queued on the join lane itself the collective held back the next hard-row batch)
     if use_dist:
         join_ptr = hp.pipeline_lane_stream(2)   # where deferred hard-row batches - i.e. results - complete
         main_ptr = hp.stream_ptr()               # first-pass lane 0
@@ -634,10 +634,7 @@ def main() -> None:
             # nothing to join per slot: every caller of drain() goes on to hp.synchronize(), which flushes the waiting
             # hard-row batch and waits for every lane (tsim_synchronize).  A _end per slot would queue one stream wait
             # per slot on the handle's stream - which is also first-pass lane 0: 14 barrier packets behind its last
-            # kernel, ~60 us of a 20-step region (TSIM_BENCH_END_EACH=1 restores them).
-            if os.environ.get("TSIM_BENCH_END_EACH") == "1":
-                for k in range(NSLOT):
-                    hp.sample_batch_device_end(k)
+            # kernel, ~60 us of a 20-step region .
             return
         join_fn(h_prog, join_ptr)
         n_steps = step_no[0]
@@ -684,15 +681,12 @@ def main() -> None:
         # --steps 200).  About 8 bracketed launches over all repetitions together.
         launches_per_rep = max(1, -(-args.steps // 8))
         PROF_EVERY = max(1, launches_per_rep * max(1, args.repeats) // 8)  # (about one bracketed launch per repetition at --steps 20)
-    if os.environ.get("TSIM_BENCH_PROF_EVERY"):
-        PROF_EVERY = max(1, int(os.environ["TSIM_BENCH_PROF_EVERY"]))
     PROF_LEVEL = 0 if os.environ.get("TSIM_BENCH_NO_PROFILE") == "1" else 2
     hp.profile_set_sampling(PROF_EVERY)
     hp.profile_enable(PROF_LEVEL)
     hp.profile_read(reset=True)
     hp.profile_read_steps()
     rep_elapsed, rep_enqueue = [], []
-    START_SLOT = os.environ.get("TSIM_BENCH_START_SLOT")
     # Clock spin-up (untimed, disclosed in the JSON line as "spinup"): the chip's power management raises its clocks
     # over the first ~25 ms of sustained work - with no spin-up the repetitions of ONE process get faster one after
     # the other until ~25 ms of work have gone by (profiles/r03/steps_dependence.txt: 12.9, 11.9, 11.2, 11.2 ... us per
@@ -738,8 +732,6 @@ def main() -> None:
                     hp.synchronize()
             hp.profile_enable(PROF_LEVEL)
         fence()
-        if START_SLOT is not None and not use_dist:
-            step_no[0] = int(START_SLOT)
         t0 = time.perf_counter()
         if os.environ.get("TSIM_BENCH_TRACE") == "2":
             stamps = []

@@ -110,3 +110,52 @@ def test_zero_shots_and_zero_outputs(hip):
         hp.sample_batch(np.zeros((4, 10), np.uint8), (1, 2))  # num_f smaller than the program needs
     with pytest.raises(ValueError):
         hp.sample_batch(np.zeros(5, np.uint8), (1, 2))
+
+
+TUNE_CHOICES = {
+    "defer_hard": [0, 1], "defer_group": [1, 3, 4, 8], "lw_fast": [0, 1], "wide_fused": [0, 1], "hard_wave": [0, 1],
+    "hard_wave_rows": [0, 64, 1024, 100000], "hard_inline_rows": [0, 1 << 40], "hard_comp_par": [0, 1], "deep_after": [1, 20000000000],
+    "fused_lanes": [0, 1, 2, 3], "fused_max": [1, 3, 8, 16], "wide": [0, 1], "wide_tables": [0, 1],
+}
+PUBLIC_CHOICES = {"TSIM_AMD_ADAPTIVE": ["0", "1"], "TSIM_AMD_FUSED_STEPS": ["0", "1"], "TSIM_AMD_DEEP_TABLES": ["-1", "0", "1"]}
+
+
+def random_switches(rng) -> dict:
+    """A random assignment of the library's launch-plan switches: results must not depend on them."""
+    env = {k: str(rng.choice(v)) for k, v in PUBLIC_CHOICES.items() if rng.random() < 0.5}
+    tune = [f"{k}={rng.choice(v)}" for k, v in TUNE_CHOICES.items() if rng.random() < 0.5]
+    if tune:
+        env["TSIM_AMD_TUNE"] = ",".join(tune)
+    return env
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_fuzz_random_switch_assignments_through_the_steps_api(hip, seed, monkeypatch):
+    """Random normalised programs (narrow, several components, wide) x a random switch assignment per handle: several batches
+    through tsim_sample_steps_device - twice, so that the launch plan has feedback - and the serial API, against the C oracle."""
+    from test_gpu_steps import _run_steps, _subkeys
+    from tsim_amd import prng
+
+    rng = np.random.default_rng(9100 + seed)
+    prog, num_f = random_physical_program(rng)
+    B, n = int(rng.choice([1, 65, 700, 3000])), int(rng.integers(1, 7))
+    fs = [synth.synth_f(B, num_f, float(rng.choice([0.0, 0.01, 0.05, 0.3])), seed=50 * seed + i) for i in range(n)]
+    key = prng.key(seed)
+    _, subs = _subkeys(key, n)
+    orc = OC.OracleProgram(prog)
+    want = [np.packbits(orc.sample_program(f, k), axis=1, bitorder="little") for f, k in zip(fs, subs)]
+    for _trial in range(2):
+        env = random_switches(rng)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        hp = hip.HipProgram(prog)
+        for k in env:
+            monkeypatch.delenv(k)
+        packed = bool(rng.integers(0, 2))
+        for _round in range(2):
+            outs, _ = _run_steps(hp, prog, fs, key, num_f, packed=packed)
+            for i in range(n):
+                np.testing.assert_array_equal(outs[i], want[i], err_msg=f"switches {env}, batch {i}, round {_round}, {hp.info()}")
+        got, _ = hp.sample_batch(fs[0], subs[0], bit_packed=True)
+        np.testing.assert_array_equal(got, want[0], err_msg=f"switches {env}, serial API")
+        hp.close()

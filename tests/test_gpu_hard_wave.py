@@ -53,8 +53,8 @@ def test_hard_rows_wave_per_row_equals_block_kernel_and_oracle(hip, name, kw):
     nf, B, n = cfg["num_f"], 4000, 6
     fs = [synth.synth_f(B, nf, 0.03, seed=70 + i) for i in range(n)]
     key = prng.key(9)
-    a = _run(hip, prog, fs, key, nf, {"TSIM_AMD_HARD_WAVE": "1"})
-    b = _run(hip, prog, fs, key, nf, {"TSIM_AMD_HARD_WAVE": "0"})
+    a = _run(hip, prog, fs, key, nf, {"TSIM_AMD_TUNE": "hard_wave=1"})
+    b = _run(hip, prog, fs, key, nf, {"TSIM_AMD_TUNE": "hard_wave=0"})
     for x, y in zip(a, b):
         np.testing.assert_array_equal(x, y)
     op = OC.OracleProgram(prog)

@@ -316,7 +316,7 @@ def test_deferred_hard_row_batches(hip, monkeypatch, group, nslot):
     """The hard rows of several pipelined launches served by ONE k_sample4h_multi grid (deferred second
     pass): every batch size, slot count and join order gives the bits of the serial full kernel,
     including the normalisation check of each launch and the bit_packed second output."""
-    monkeypatch.setenv("TSIM_AMD_DEFER_GROUP", str(group))
+    monkeypatch.setenv("TSIM_AMD_TUNE", f"defer_group={group}")
     prog, cfg = synth.config_program("C2")
     hp = hip.HipProgram(prog)
     ref = hip.HipProgram(prog, pattern_tables=False)
@@ -335,7 +335,7 @@ def test_deferred_batches_off_and_on_agree(hip, monkeypatch):
     prog, cfg = synth.config_program("C3")
     runs = []
     for defer in ("1", "0"):
-        monkeypatch.setenv("TSIM_AMD_DEFER_HARD", defer)
+        monkeypatch.setenv("TSIM_AMD_TUNE", f"defer_hard={defer}")
         hp = hip.HipProgram(prog)
         runs.append(_pipelined_run(hp, prog, cfg, 11, 9001, [0.02, 0.002], True, 5, with_check=False))
     for a, b in zip(runs[0][2], runs[1][2]):

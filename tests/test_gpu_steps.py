@@ -125,7 +125,7 @@ def test_steps_use_the_fused_first_pass_and_split_calls_agree(hip):
 
 @pytest.mark.parametrize("name", ["C2", "C4"])
 def test_hard_rows_on_the_batch_lane_and_on_the_group_lane_agree(hip, name):
-    """Fused groups of at most TSIM_AMD_HARD_INLINE_ROWS shots (default: all) run their hard-row batch on their own
+    """Fused groups of at most hard_inline_rows (TSIM_AMD_TUNE) shots (default: all) run their hard-row batch on their own
     first-pass lane, larger ones on the batch lane; a handle that sees both, in turn, returns the rows of a handle
     that only uses the batch lane - slots are handed from one stream to the other in both directions."""
     import os
@@ -136,12 +136,12 @@ def test_hard_rows_on_the_batch_lane_and_on_the_group_lane_agree(hip, name):
     key = prng.key(91)
     runs = []
     for env in ("2000000", "0"):
-        os.environ["TSIM_AMD_HARD_INLINE_ROWS"] = env
+        os.environ["TSIM_AMD_TUNE"] = "hard_inline_rows=" + env
         try:
             prog2, _ = synth.config_program(name)
             hp = hip.HipProgram(prog2)
         finally:
-            os.environ.pop("TSIM_AMD_HARD_INLINE_ROWS", None)
+            os.environ.pop("TSIM_AMD_TUNE", None)
         outs = []
         k = key
         for r, B in enumerate(sizes):
@@ -164,18 +164,18 @@ def test_component_parallel_hard_rows_agree_with_one_block_per_row(hip, packed, 
     """Programs of 2-4 components: the specialised first pass stores the hard rows too (direct outputs and the
     tabulated components' bits) and k_sample_hw evaluates the components that are left, one block per (row,
     component), ORing their bits into the row (32-bit atomics; compact rows whose byte range is not a whole number of
-    words - B = 4097, 3 with 3-byte rows - fall back).  Same rows as one block per row (TSIM_AMD_HARD_COMP_PAR=0) and as
+    words - B = 4097, 3 with 3-byte rows - fall back).  Same rows as one block per row (TSIM_AMD_TUNE=hard_comp_par=0) and as
     the oracle, normalisation-check row included."""
     import os
 
     runs = []
     for env in ("1", "0"):
-        os.environ["TSIM_AMD_HARD_COMP_PAR"] = env
+        os.environ["TSIM_AMD_TUNE"] = "hard_comp_par=" + env
         try:
             prog, cfg = synth.config_program("C4")
             hp = hip.HipProgram(prog)
         finally:
-            os.environ.pop("TSIM_AMD_HARD_COMP_PAR", None)
+            os.environ.pop("TSIM_AMD_TUNE", None)
         nf = cfg["num_f"]
         fs = [synth.synth_f(B, nf, 0.04, seed=70 + i) for i in range(11)]
         _run_steps(hp, prog, fs[:3], prng.key(1), nf, packed=packed)  # feedback: few hard rows -> the block-per-row kernel
@@ -195,14 +195,14 @@ def test_component_parallel_hard_rows_agree_with_one_block_per_row(hip, packed, 
 
 def test_tables_deepen_when_the_hard_rows_are_too_many_for_the_block_per_row_kernel(hip):
     """C3 at weight-5 tables leaves ~340 hard rows per 10^6 shots: too many for k_sample_hw (more than
-    TSIM_AMD_HARD_WAVE_ROWS per eight launches), far below the 1 % of the dense rule.  A handle that has launched
-    TSIM_AMD_DEEP_AFTER rows in that state (here: 1) builds the weight-6 tables; TSIM_AMD_DEEP_TABLES=-1 never does.
+    hard_wave_rows per eight launches), far below the 1 % of the dense rule.  A handle that has launched
+    deep_after (TSIM_AMD_TUNE) rows in that state (here: 1) builds the weight-6 tables; TSIM_AMD_DEEP_TABLES=-1 never does.
     Same rows from both, before and after the build."""
     import os
 
     B, n = 400_000, 8
     runs, depths = [], []
-    for env in ({"TSIM_AMD_DEEP_AFTER": "1"}, {"TSIM_AMD_DEEP_TABLES": "-1"}):
+    for env in ({"TSIM_AMD_TUNE": "deep_after=1"}, {"TSIM_AMD_DEEP_TABLES": "-1"}):
         os.environ.update(env)
         try:
             prog, cfg = synth.config_program("C3")

@@ -131,7 +131,7 @@ def test_shapes_through_the_steps_api(hip, shape, packed):
 
 def test_c5_at_scale_equals_the_round2_path_and_the_row_kernel(hip):
     """BASELINE config C5 at 2 x 10^5 shots per batch, 5 batches, shot offsets: the fused kernel, the three-kernel path
-    of round 2 (TSIM_AMD_WIDE_FUSED=0) and the row kernel agree byte for byte; a slice against the oracle."""
+    of round 2 (TSIM_AMD_TUNE=wide_fused=0) and the row kernel agree byte for byte; a slice against the oracle."""
     prog, cfg = synth.config_program("C5")
     nf = cfg["num_f"]
     B, n = 200_000, 5
@@ -143,11 +143,11 @@ def test_c5_at_scale_equals_the_round2_path_and_the_row_kernel(hip):
         hp = hip.HipProgram(prog)
         new, _ = _steps(hp, prog, fs, key, nf, packed=True, shot_offset=123)
         again, _ = _steps(hp, prog, fs, key, nf, packed=True, shot_offset=123)  # tables one weight deeper by now: same bits
-        os.environ["TSIM_AMD_WIDE_FUSED"] = "0"
+        os.environ["TSIM_AMD_TUNE"] = "wide_fused=0"
         try:
             hp2 = hip.HipProgram(prog)
         finally:
-            os.environ.pop("TSIM_AMD_WIDE_FUSED", None)
+            os.environ.pop("TSIM_AMD_TUNE", None)
         old, _ = _steps(hp2, prog, fs, key, nf, packed=True, shot_offset=123)
         rows = hip.HipProgram(prog, mode="rows")
         orc = OC.OracleProgram(prog)

@@ -210,35 +210,39 @@ struct tsim_program {
   int lw_direct_left = 0;     // launches still to run on the full kernel before the next probe
   // launch-time tuning knobs, read from the environment once at finalize (experiments only)
   struct Knobs {
+    // public switches
     bool adaptive = true;     // TSIM_AMD_ADAPTIVE=0 pins the default launch plan
-    bool hard_kernel = true;  // TSIM_AMD_HARD_KERNEL=0: hard rows on k_sample4 instead of k_sample4h
-    bool lane0_main = true;   // TSIM_AMD_LANE0_MAIN=0: pipeline slot 0 gets a stream of its own
-    int lw_block = 0;         // TSIM_AMD_LW_BLOCK (0: 1024 threads when the f/out staging fits 32 KB, else 256)
-    int v4_block = 256;       // TSIM_AMD_V4_BLOCK
-    int hard_lds_kb = 128;    // TSIM_AMD_HARD_LDS_KB (128: a first-pass block still fits next to a hard-row block)
-    bool merge_lists = true;  // TSIM_AMD_MERGE_LISTS=0: always TSIMK_LW_LISTS hard-row sub-lists
-    int list_rows = 40;       // TSIM_AMD_LIST_ROWS: expected hard rows per list the list count aims at
-    int min_lists = 4;        // TSIM_AMD_MIN_LISTS (power of two >= 2)
-    bool direct_runs = true;  // TSIM_AMD_DIRECT_RUNS=0: direct outputs bit by bit (pair table) in the full kernels
-    bool wide = true;         // TSIM_AMD_WIDE=0: wide components on the row kernel alone (no sparse-column pass)
-    bool lw_reg = true;       // TSIM_AMD_LW_REG=0: LDS-staged first pass even where the register form applies
-    int lw_resident = 1;      // TSIM_AMD_LW_RESIDENT: first-pass grid = this many chip-fulls of blocks, rows by grid stride (0: one block per 1024 rows)
-    int wide_list_blocks = 0; // TSIM_AMD_WIDE_LIST_BLOCKS: blocks per CU of the list-driven sparse-column pass (0: what fits)
-    bool defer = true;        // TSIM_AMD_DEFER_HARD=0: every pipelined launch runs its own second pass
-    bool prewait = true;      // TSIM_AMD_PREWAIT=0: no mid-batch pre-wait of the first-pass lanes (tsim_sample_batch_device_begin)
-    int defer_group = 4;      // TSIM_AMD_DEFER_GROUP: launches per deferred hard-row batch (<= TSIMK_H_MAX_CTX)
     bool fused_steps = true;  // TSIM_AMD_FUSED_STEPS=0: tsim_sample_steps_device launches batch by batch
-    int fused_lanes = 0;  // TSIM_AMD_FUSED_LANES: first-pass lanes the fused groups rotate over (1-4; 0 = 2, 3 for small groups)
-    bool hard_comp_par = true;  // TSIM_AMD_HARD_COMP_PAR=0: the hard rows of multi-component programs one block per row (all components in turn)
-    long long hard_inline_rows = 1ll << 40;  // TSIM_AMD_HARD_INLINE_ROWS: fused groups of at most this many shots run their hard rows on their own lane
-    int deep_tables = 0;       // TSIM_AMD_DEEP_TABLES: deeper pattern tables when the hard rows are merely too many for k_sample_hw -
-                               // 0: after deep_after rows in that state, 1: at once, -1: never
-    unsigned long long deep_after = 20000000000ull;  // TSIM_AMD_DEEP_AFTER
-    int hard_wave_rows = 1024;  // TSIM_AMD_HARD_WAVE_ROWS: ... while a batch of launches has at most this many hard rows (last feedback)
-    bool hard_wave = true;    // TSIM_AMD_HARD_WAVE=0: hard-row batches on k_sample4h_multi (64 rows per block) instead of one wave per row
-    bool wide_fused = true;   // TSIM_AMD_WIDE_FUSED=0: wide programs on the three-kernel path of round 2 (tables, k_sample4w, row kernel)
-    bool lw_fast = true;      // TSIM_AMD_LW_FAST=0: the generic fused pass (k_sample_lw_multi) also for one-component programs
-    int fused_max = 8;        // TSIM_AMD_FUSED_MAX: batches per fused first pass (<= TSIMK_LWM_MAX_STEPS = 16; hard rows in grids of <= TSIMK_H_MAX_CTX launches)
+    int deep_tables = 0;      // TSIM_AMD_DEEP_TABLES: deeper pattern tables when the hard rows are merely too many for k_sample_hw -
+                              // 0: after deep_after rows in that state, 1: at once, -1: never (wide programs: only on 1)
+    // TSIM_AMD_TUNE keys (A/B parameters of tests/ and scripts/)
+    bool defer = true;        // defer_hard=0: every pipelined launch runs its own second pass
+    int defer_group = 4;      // defer_group: launches per deferred hard-row batch (<= TSIMK_H_MAX_CTX)
+    bool lw_fast = true;      // lw_fast=0: the generic fused pass (k_sample_lw_multi) also for one-component programs
+    bool wide_fused = true;   // wide_fused=0: wide programs on the three-kernel path of round 2 (tables, k_sample4w, row kernel)
+    bool hard_wave = true;    // hard_wave=0: hard-row batches on k_sample4h_multi (64 rows per block) instead of one block per row
+    int hard_wave_rows = 1024;  // hard_wave_rows: ... while a batch of launches has at most this many hard rows (last feedback)
+    long long hard_inline_rows = 1ll << 40;  // hard_inline_rows: fused groups of at most this many shots run their hard rows on their own lane
+    bool hard_comp_par = true;  // hard_comp_par=0: the hard rows of multi-component programs one block per row (all components in turn)
+    unsigned long long deep_after = 20000000000ull;  // deep_after
+    int fused_lanes = 0;      // fused_lanes: first-pass lanes the fused groups rotate over (1-4; 0 = 2, 3 for small groups)
+    int fused_max = 8;        // fused_max: batches per fused first pass (<= TSIMK_LWM_MAX_STEPS = 16)
+    bool wide = true;         // wide=0: wide components on the row kernel alone
+    bool wide_tables = true;  // wide_tables=0: no pattern tables in front of the wide kernels
+    // fixed since round 4 (the experiments behind their switches are closed: DESIGN.md / HISTORY.md)
+    bool hard_kernel = true;  // hard rows on k_sample4h, not k_sample4
+    bool lane0_main = true;   // pipeline slot 0 runs on the handle's stream (a hardware queue of its own)
+    int lw_block = 0;         // first-pass block: 1024 threads when the f/out staging fits 32 KB, else 256
+    int v4_block = 256;
+    int hard_lds_kb = 128;    // a first-pass block still fits next to a hard-row block
+    bool merge_lists = true;  // hard-row list count follows the load
+    int list_rows = 40;
+    int min_lists = 4;
+    bool direct_runs = true;  // direct outputs as bit-field runs
+    bool lw_reg = true;       // register form of the first pass where it applies
+    int lw_resident = 1;      // first-pass grid = one chip-full of blocks, rows by grid stride
+    int wide_list_blocks = 0;
+    bool prewait = true;      // mid-batch pre-wait of the first-pass lanes
   } knobs;
   bool h_attr_set = false;    // k_sample4h: large dynamic LDS enabled
   bool hm_attr_set = false;   // k_sample4h_multi: the same
@@ -274,6 +278,7 @@ struct tsim_program {
 };
 
 // ---- tsim_program.hip
+bool tsim_debug(const char *what);  // TSIM_AMD_DEBUG=tables,host,pipeline,pcg contains `what`
 int tsim_set_device(const tsim_program *p);
 int tsim_need_final(const tsim_program *p);
 int tsim_ensure_scratch(tsim_program *p, int slot, size_t bytes);

@@ -61,7 +61,7 @@ extern "C" int tsim_noise_create(tsim_program *p, int32_t num_f, int32_t n_chann
   std::vector<float> inv((size_t)std::max(1, n_channels));
   for (int c = 0; c < n_channels; ++c) inv[c] = p_fire[c] >= 1.0 ? 0.0f : (float)(1.0 / log2(1.0 - p_fire[c]));
   n->tile = 0;
-  if (n->WF * 8 * 64 <= 32 * 1024 && !getenv("TSIM_AMD_NOISE_ATOMIC")) {
+  if (n->WF * 8 * 64 <= 32 * 1024) {
     n->tile = 64;
     while (n->tile * 2 * n->WF * 8 <= 32 * 1024) n->tile *= 2;
     int ts = 64;

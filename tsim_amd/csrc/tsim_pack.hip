@@ -315,7 +315,7 @@ bool pack_level_fast(HostLevel &h, int W, std::vector<uint32_t> &tables, bool &f
     const int nD = d.td ? h.i32[1][g] : 0;
     if (nD > 5) return false;  // 4^nD table entries: beyond this use the faithful layout
     const long long combos = (long long)(n[1] + n[3] + 1) << (2 * nD);
-    static const long long kMaxCombined = getenv("TSIM_AMD_COMBINED") ? atoll(getenv("TSIM_AMD_COMBINED")) : 1024;
+    static const long long kMaxCombined = 1024;
     const bool d_tabled = nD > 0 && combos <= kMaxCombined;   // combined table, else a separate one
     std::vector<std::array<std::array<int, 4>, 4>> dterm((size_t)nD);  // [t][pa + 2 pb] -> term value
     for (int t = 0; t < nD; ++t) {

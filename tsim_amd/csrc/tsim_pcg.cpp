@@ -856,7 +856,7 @@ extern "C" int tsim_pcg_sample_channels(tsim_pcg64 *rng, int32_t n_channels, con
   if (num_samples > 0 && !rows) return tsim_fail(TSIM_EINVAL, "rows is NULL");
   if (n_channels > 0 && (!p_fire || !n_outcomes || !cond_cdf || !patterns)) return tsim_fail(TSIM_EINVAL, "NULL channel table");
   if (num_samples == 0) return TSIM_OK;
-  static const bool timing = getenv("TSIM_PCG_TIMING") != nullptr;
+  static const bool timing = getenv("TSIM_AMD_DEBUG") != nullptr && strstr(getenv("TSIM_AMD_DEBUG"), "pcg") != nullptr;
   const bool force_scalar = getenv("TSIM_PCG_SCALAR") != nullptr, force_serial = getenv("TSIM_PCG_SERIAL") != nullptr;
   const auto t_start = std::chrono::steady_clock::now();
   int T = threads > 0 ? threads : (int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency()));
@@ -879,10 +879,6 @@ extern "C" int tsim_pcg_sample_channels(tsim_pcg64 *rng, int32_t n_channels, con
   const bool prefetch = have_avx512() && !force_scalar && !force_serial && T > 1 && expect >= 65536.0 && expect < 1.5e8;
   if (prefetch) {
     PStream st(g, (uint64_t)expect, &pl, S.raw, S.ex, S.extra);
-    if (getenv("TSIM_PCG_FILL_FIRST")) {
-      st.close();
-      if (timing) fprintf(stderr, "  fill done at %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count());
-    }
     const int r = draw_channels(st, n_channels, p_fire, n_outcomes, cond_cdf, num_samples, S, chan_begin, table_off, n_fires);
     if (timing)
       fprintf(stderr, "  consumer done at %.2f ms, %.2f ms of them waiting for blocks (position %llu of %llu prepared)\n",

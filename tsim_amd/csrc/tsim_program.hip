@@ -13,6 +13,11 @@ using namespace tsimhost;
 // ---------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
 
+bool tsim_debug(const char *what) {
+  const char *e = getenv("TSIM_AMD_DEBUG");
+  return e && strstr(e, what) != nullptr;
+}
+
 int tsim_fail(int code, const char *fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
@@ -205,6 +210,36 @@ static int alloc_feedback(tsim_program *p) {
 extern "C" int tsim_program_finalize(tsim_program *p, int32_t device) {
   if (!p) return tsim_fail(TSIM_EINVAL, "program is NULL");
   if (p->finalized) return tsim_fail(TSIM_ESTATE, "program already finalized");
+  {
+    // Switches.  Results never depend on any of them.  Public: TSIM_AMD_ADAPTIVE, TSIM_AMD_FUSED_STEPS,
+    // TSIM_AMD_DEEP_TABLES (and, read where they act, TSIM_AMD_MODE / _KERNEL / _PATTERN_TABLES / _PATTERN_TABLE_MB / _DEBUG).
+    // Everything else the launch planner can be told - the A/B parameters tests/ and scripts/ use to run two paths against
+    // each other - travels in ONE variable, TSIM_AMD_TUNE="key=value,key=value".
+    auto env_int = [](const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; };
+    const std::string tune = getenv("TSIM_AMD_TUNE") ? std::string(",") + getenv("TSIM_AMD_TUNE") + "," : std::string();
+    auto tune_ll = [&](const char *key, long long dflt) -> long long {
+      const std::string k = std::string(",") + key + "=";
+      const size_t at = tune.find(k);
+      return at == std::string::npos ? dflt : atoll(tune.c_str() + at + k.size());
+    };
+    p->knobs.adaptive = env_int("TSIM_AMD_ADAPTIVE", 1) != 0;
+    p->knobs.fused_steps = env_int("TSIM_AMD_FUSED_STEPS", 1) != 0;
+    p->knobs.deep_tables = env_int("TSIM_AMD_DEEP_TABLES", 0);
+    p->knobs.defer = tune_ll("defer_hard", 1) != 0;
+    p->knobs.defer_group = (int)std::max(0ll, std::min((long long)TSIMK_H_MAX_CTX, tune_ll("defer_group", 0)));  // 0: by table size, below
+    p->knobs.lw_fast = tune_ll("lw_fast", 1) != 0;
+    p->knobs.wide_fused = tune_ll("wide_fused", 1) != 0;
+    p->knobs.hard_wave = tune_ll("hard_wave", 1) != 0;
+    p->knobs.hard_wave_rows = (int)std::max(0ll, tune_ll("hard_wave_rows", 1024));
+    p->knobs.hard_inline_rows = std::max(0ll, tune_ll("hard_inline_rows", 1ll << 40));
+    p->knobs.hard_comp_par = tune_ll("hard_comp_par", 1) != 0;
+    p->knobs.deep_after = (unsigned long long)std::max(0ll, tune_ll("deep_after", 20000000000ll));
+    p->knobs.fused_lanes = (int)std::max(0ll, std::min(4ll, tune_ll("fused_lanes", 0)));
+    p->knobs.fused_max = (int)std::max(1ll, std::min((long long)TSIMK_LWM_MAX_STEPS, tune_ll("fused_max", 8)));
+    p->knobs.wide = tune_ll("wide", 1) != 0;
+    p->knobs.wide_tables = tune_ll("wide_tables", 1) != 0;
+  }
+
   // ---- choose the evaluation formulation ----
   {
     const char *env = getenv("TSIM_AMD_MODE");
@@ -480,7 +515,7 @@ retry_pack:
     p->lw_wide = false;
     if (ok && !narrow && p->v4w && p->max_f_index < 512) {
       bool wide_ok = true;
-      if (const char *e = getenv("TSIM_AMD_WIDE_TABLES")) wide_ok = atoi(e) != 0;
+      wide_ok = p->knobs.wide_tables;
       for (auto &c : p->comps) {
         wide_ok = wide_ok && (c.n_levels == c.n_out + 1) && c.n_out <= 8 && c.F <= TSIMK_LWW_MAX_F;
         for (int j = 1; j < c.F; ++j) wide_ok = wide_ok && c.f_selection[j] > c.f_selection[j - 1];
@@ -816,45 +851,8 @@ retry_pack:
   img.resize(img.size() + 256, 0u);  // tail padding: wide scalar loads may over-read
   if (img.size() >= (1ull << 31)) return tsim_fail(TSIM_ENOTSUP, "program image too large");
 
-  {
-    auto env_int = [](const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; };
-    p->knobs.adaptive = env_int("TSIM_AMD_ADAPTIVE", 1) != 0;
-    p->knobs.hard_kernel = env_int("TSIM_AMD_HARD_KERNEL", 1) != 0;
-    p->knobs.lane0_main = env_int("TSIM_AMD_LANE0_MAIN", 1) != 0;
-    p->knobs.lw_block = env_int("TSIM_AMD_LW_BLOCK", 0);
-    if (p->knobs.lw_block != 0) p->knobs.lw_block = std::max(64, std::min(1024, p->knobs.lw_block & ~63));
-    const int vb = env_int("TSIM_AMD_V4_BLOCK", 256);
-    p->knobs.v4_block = (vb == 512 || vb == 128) ? vb : 256;
-    p->knobs.hard_lds_kb = std::max(24, std::min(156, env_int("TSIM_AMD_HARD_LDS_KB", 128)));
-    p->knobs.defer = env_int("TSIM_AMD_DEFER_HARD", 1) != 0;
-    p->knobs.prewait = env_int("TSIM_AMD_PREWAIT", 1) != 0;
-    p->knobs.lw_reg = env_int("TSIM_AMD_LW_REG", 1) != 0;
-    p->knobs.lw_resident = std::max(0, std::min(8, env_int("TSIM_AMD_LW_RESIDENT", 1)));
-    p->knobs.wide_list_blocks = std::max(0, std::min(8, env_int("TSIM_AMD_WIDE_LIST_BLOCKS", 0)));
-    p->knobs.wide = env_int("TSIM_AMD_WIDE", 1) != 0;
-    p->knobs.direct_runs = env_int("TSIM_AMD_DIRECT_RUNS", 1) != 0;
-    p->knobs.merge_lists = env_int("TSIM_AMD_MERGE_LISTS", 1) != 0;
-    p->knobs.list_rows = env_int("TSIM_AMD_LIST_ROWS", 40);
-    p->knobs.min_lists = env_int("TSIM_AMD_MIN_LISTS", 4);
-    if (p->knobs.min_lists & (p->knobs.min_lists - 1)) p->knobs.min_lists = 4;
-    // launches per deferred batch: a batch lasts about as long as ONE hard-row pass (its blocks run side by
-    // side), and batches are serial on their lane - so the batch must cover at least (pass time / step time)
-    // launches.  The pass time grows with the chunk tables a 64-row block streams through LDS (C2: 1.7 MB,
-    // 35-50 us; C4: 10.8 MB, 450 us): 4 launches for small programs, 8 (the kernel's limit) beyond 4 MB.
-    p->knobs.defer_group = p->stats[5] > (4ll << 20) ? TSIMK_H_MAX_CTX : 4;
-    p->knobs.defer_group = std::max(1, std::min(TSIMK_H_MAX_CTX, env_int("TSIM_AMD_DEFER_GROUP", p->knobs.defer_group)));
-    p->knobs.fused_steps = env_int("TSIM_AMD_FUSED_STEPS", 1) != 0;
-    p->knobs.lw_fast = env_int("TSIM_AMD_LW_FAST", 1) != 0;
-    p->knobs.wide_fused = env_int("TSIM_AMD_WIDE_FUSED", 1) != 0;
-    p->knobs.hard_wave = env_int("TSIM_AMD_HARD_WAVE", 1) != 0;
-    if (const char *e = getenv("TSIM_AMD_HARD_INLINE_ROWS")) p->knobs.hard_inline_rows = std::max(0ll, atoll(e));
-    p->knobs.deep_tables = env_int("TSIM_AMD_DEEP_TABLES", 0);
-    p->knobs.hard_comp_par = env_int("TSIM_AMD_HARD_COMP_PAR", 1) != 0;
-    if (const char *e = getenv("TSIM_AMD_DEEP_AFTER")) p->knobs.deep_after = strtoull(e, nullptr, 10);
-    p->knobs.fused_lanes = std::max(0, std::min(4, env_int("TSIM_AMD_FUSED_LANES", 0)));
-    p->knobs.hard_wave_rows = std::max(0, env_int("TSIM_AMD_HARD_WAVE_ROWS", 1024));
-    p->knobs.fused_max = std::max(1, std::min(TSIMK_LWM_MAX_STEPS, env_int("TSIM_AMD_FUSED_MAX", 8)));
-  }
+  if (p->knobs.defer_group <= 0)  // (not told by TSIM_AMD_TUNE) launches per deferred batch: a batch lasts about as long as ONE hard-row
+    p->knobs.defer_group = p->stats[5] > (4ll << 20) ? TSIMK_H_MAX_CTX : 4;  // pass; 4 for small programs, 8 beyond 4 MB of chunk tables (C4)
 
   // ---- upload ----
   int ndev = 0;
@@ -890,7 +888,7 @@ extern "C" void tsim_program_destroy(tsim_program *p) {
     for (auto &sl : p->slots)
       if (sl.side_ready) (void)hipStreamSynchronize(sl.side);
     for (hipEvent_t e : p->ev_pool) (void)hipEventDestroy(e);
-    if (getenv("TSIM_AMD_PIPELINE_STATS"))
+    if (tsim_debug("pipeline"))
       fprintf(stderr, "tsim pipeline: begins %llu deferred %llu flushes %llu queries %llu waits %llu fused groups %llu (specialised %llu, component-parallel hard rows %llu)\n",
               p->stat_begins, p->stat_deferred, p->stat_flushes, p->stat_queries, p->stat_waits, p->stat_fused, p->stat_fast, p->stat_partial);
     if (p->sync_ev) (void)hipEventDestroy(p->sync_ev);

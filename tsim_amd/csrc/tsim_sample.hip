@@ -247,8 +247,6 @@ static int launch_hw(tsim_program *p, const SampleArgs *ctx, int n_ctx, int max_
   // as many blocks per list as the longest list of the last launch had rows (plus a margin): each block then takes one
   // row; longer lists are walked in turns (blocks of four waves: one row at a time each, see k_sample_hw)
   H.waves_per_list = (int)std::max(8u, std::min(128u, std::min(fb_max, 4096u) * 2u + 8u));
-  static const int hw_waves_env = getenv("TSIM_AMD_HW_WAVES") ? std::max(1, std::min(256, atoi(getenv("TSIM_AMD_HW_WAVES")))) : 0;  // (read once: this runs per batch)
-  if (hw_waves_env) H.waves_per_list = hw_waves_env;
   H.feedback = p->d_feedback;
   for (int i = 0; i < n_ctx; ++i) {
     H.ctx[i] = ctx[i];
@@ -1013,7 +1011,7 @@ struct HostMarks {
   const char *name[24];
   int n = 0;
   HostMarks() {
-    static const bool e = getenv("TSIM_HOST_TIMING") != nullptr;
+    static const bool e = tsim_debug("host");
     on = e;
   }
   void mark(const char *what) {
@@ -1047,7 +1045,7 @@ static int steps_group_fused(tsim_program *p, int n, const uint64_t *const *d_f,
   const int blk1 = p->knobs.lw_block ? p->knobs.lw_block : 1024;
   const long long bps = (B + blk1 - 1) / blk1;
   const int n_lists = plan.lists;
-  if (p->stat_fused == 0 && getenv("TSIM_AMD_PIPELINE_STATS")) {
+  if (p->stat_fused == 0 && tsim_debug("pipeline")) {
     int nb = -1;
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_sample_lw_multi<2>, blk1, 0);
     fprintf(stderr, "[tsim] k_sample_lw_multi<2>: %d blocks of %d threads per CU (occupancy API)\n", nb, blk1);

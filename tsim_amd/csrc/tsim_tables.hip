@@ -117,7 +117,7 @@ int tsim_tables_build(tsim_program *p, uint32_t **old) {
   }
   if (old) *old = p->d_lw_tab;
   p->d_lw_tab = tab;
-  static const bool timing = getenv("TSIM_TABLE_TIMING") != nullptr;
+  static const bool timing = tsim_debug("tables");
   if (timing)
     fprintf(stderr, "[tsim] pattern tables: %.1f MB built in %.1f ms\n", (double)p->lw_bytes / 1e6,
             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count());

@@ -157,5 +157,5 @@ def test_fuzz_random_switch_assignments_through_the_steps_api(hip, seed, monkeyp
             for i in range(n):
                 np.testing.assert_array_equal(outs[i], want[i], err_msg=f"switches {env}, batch {i}, round {_round}, {hp.info()}")
         got, _ = hp.sample_batch(fs[0], subs[0], bit_packed=True)
-        np.testing.assert_array_equal(got, want[0], err_msg=f"switches {env}, serial API")
+        np.testing.assert_array_equal(got[:, : want[0].shape[1]], want[0], err_msg=f"switches {env}, serial API")
         hp.close()

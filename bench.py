@@ -281,7 +281,10 @@ def main() -> None:
     ap.add_argument("--nf", type=int, default=NF_DEFAULT, help="distinct resident f batches the timed loop rotates through (the first "
                     f"{NF_HOST} from the seeded host generator, the others drawn on the device with the same per-bit probability)")
     ap.add_argument("--no-config-legs", action="store_true", help="skip the driver-timed legs of the other BASELINE configs (C3, C4, C5)")
-    ap.add_argument("--shots", type=int, default=1_000_000, help="shots per step per GPU")
+    ap.add_argument("--shots", type=int, default=1_000_000, help="shots per step per GPU (--scaling weak) / per step of the whole job (--scaling strong)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak", help="weak: every GPU samples --shots rows per step (rank r owns rows "
+                    "[r * shots, (r + 1) * shots) of a global batch of N * shots); strong: ONE global batch of --shots rows per step, rank r samples rows "
+                    "[r * B / N, (r + 1) * B / N) (SURVEY 8(e)), B rounded up to a multiple of N")
     ap.add_argument("--config", default="C2")
     ap.add_argument("--random-program", action="store_true", help="the unconstrained random program instead of the normalised one")
     ap.add_argument("--p-bit", type=float, default=None, help="override the per-bit fire probability of the synthetic f batches")
@@ -391,7 +394,7 @@ def main() -> None:
     t_build = time.perf_counter() - t_build0
     info = hp.info()
     num_f, n_out = cfg["num_f"], program.num_outputs
-    B = int(args.shots)
+    B = int(args.shots) if args.scaling == "weak" else -(-int(args.shots) // N)  # rows THIS rank samples per step
     WF, WO, RB = max(1, (num_f + 63) // 64), (n_out + 63) // 64, (n_out + 7) // 8
 
     def resident_f(p_bit: float, seed: int):
@@ -438,11 +441,7 @@ def main() -> None:
     # group flushes the waiting batch, and a partial batch is a whole extra hard-row pass - measured on the forced
     # one-GPU path at 20 steps: groups of 5: 698 us per region, of 8: 528, of 20: 519, of 4: 607) and of N (equal
     # chunks per peer): about a third of the region in units of max(4, N), at least 8, at most 64 batches.
-    if os.environ.get("TSIM_BENCH_GATHER_EVERY"):
-        GATHER_EVERY = max(1, int(os.environ["TSIM_BENCH_GATHER_EVERY"]))
-    else:
-        unit = max(4, N)
-        GATHER_EVERY = max(8, min(64, (args.steps // 3) // unit * unit))
+    GATHER_EVERY = tdist.gather_group_size(args.steps, N, False, int(os.environ["TSIM_BENCH_GATHER_EVERY"]) if os.environ.get("TSIM_BENCH_GATHER_EVERY") else None)
     # How the finished rows are collected (N > 1).  "root0": the north star's gather of the detector bit strings to
     # rank 0 (ncclGather).  "alltoall": the same gather with its roots spread over the node - group j of every rank
     # lands on rank j (ncclAllToAll).  Arithmetic behind the default: a rank produces
@@ -527,11 +526,12 @@ def main() -> None:
         coll = 0 if COLL_OWN_STREAM else join_ptr
         if COLL_OWN_STREAM:
             comm.stream_wait(0, join_ptr)
-        if GATHER_MODE == "alltoall" and count % N == 0:  # equal chunks: batches [j * count/N, (j+1) * count/N) land on rank j
+        kind = tdist.collective_kind(GATHER_MODE, count, N)
+        if kind == "alltoall":  # equal chunks: batches [j * count/N, (j+1) * count/N) land on rank j
             comm.alltoall_rows(grp[g].ptr, grp_recv[g].ptr, count // N * B * RB, stream=coll)
         else:  # the gather to rank 0, exactly `count` batches - also what a partial last group of the all-to-all mode takes
             comm.gather_rows(grp[g].ptr, count * B * RB, grp_recv[g].ptr if grp_recv[g] else 0, root=0, stream=coll)
-        last_collective[0] = (g, count, "alltoall" if (GATHER_MODE == "alltoall" and count % N == 0) else "root0")
+        last_collective[0] = (g, count, kind)
         comm.mark(g, coll)  # "the collective that read group buffer g is done"
         grp_used[g] = True
         gathered[0] += 1
@@ -544,11 +544,8 @@ def main() -> None:
     def dist_steps(k: int, f_list) -> None:
         """N > 1: the same library call per piece of a gather group; every batch writes its bit_packed rows straight into
         its slice of the group buffer, a complete group is joined on the join lane and collected."""
-        done = 0
-        while done < k:
+        for g, pos, n in tdist.group_pieces(step_no[0], k, GATHER_EVERY):  # (the arithmetic tests/test_dist_gloo.py runs for N = 2, 4, 8)
             j = step_no[0]
-            g, pos = (j // GATHER_EVERY) & 1, j % GATHER_EVERY
-            n = min(k - done, GATHER_EVERY - pos)
             rc = 0
             if launched[0] < NSLOT:  # (the very first launches of the run create the lanes)
                 rc = wait_fn(h_prog, None)
@@ -568,7 +565,6 @@ def main() -> None:
                 raise RuntimeError(f"pipelined launch failed ({rc}): {_lib.last_error()}")
             launched[0] += n
             step_no[0] = j + n
-            done += n
             if pos + n == GATHER_EVERY:  # group complete: join every slot on the join lane, then collect
                 join_fn(h_prog, join_ptr)
                 gather_next(GATHER_EVERY)
@@ -883,7 +879,7 @@ def main() -> None:
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "int32",
             "data": "synthetic",
@@ -955,6 +951,13 @@ def main() -> None:
                 "pass then lasts about twice the time it takes alone; achieved_at_step_rate uses the step time (= shots/s x "
                 "bytes/shot), achieved_serial the kernel's duration with the GPU to itself (= rocprofv3's serial kernel "
                 "trace).  Integer-VALU / latency bound, not HBM bound (DESIGN.md section 3.5): see `valu`.",
+            },
+            "multi_gpu_prediction": {
+                "shots_per_s_by_n_gpus_and_collective": tdist.collection_prediction(value / N, RB) if N == 1 else None,
+                "row_bytes": RB, "link_bytes_per_s": tdist.XGMI_LINK_BYTES_PER_S, "collective_default": "root0 (the north star's gather) unless the in-place "
+                "calibration at N > 1 finds the all-to-all more than 10 % faster (`gather_calibration`)",
+                "note": "kernel rate x N capped by the collection: root0 = rank 0 takes the rows of N - 1 peers over N - 1 point-to-point xGMI links; "
+                        "alltoall = 1 / N of a rank's rows per link.  A prediction for the first multi-GPU run, not a measurement.",
             },
             "valu": valu_block(ops_per_shot, B, sum(len(c.output_indices) for c in program.components), avg_kernel_s / batches_per_launch,
                                (serial_ms * 1e-3) if serial_ms else None, elapsed / args.steps, pmc,
@@ -1105,24 +1108,19 @@ def verify_collected(backend, prng, synth, program, cfg, hp, comm, lib, rank, N,
         fence()
         g, cnt, mode = last_collective[0]
         assert cnt == count, (cnt, count)
-        if mode == "root0":
-            if rank == 0:
-                got = np.zeros((N, count, B, RB), np.uint8)
-                hp.d2h(got, grp_recv[g])
-                for sender in range(N):
-                    for b in range(count):
-                        checked += 1
-                        if not np.array_equal(got[sender, b], reference_rows(sender, b, subs[b])):
-                            bad.append((count, sender, b))
-        else:
-            per = count // N
-            got = np.zeros((N, per, B, RB), np.uint8)
+        from tsim_amd import dist as tdist
+
+        layout = tdist.received_layout(mode, count, N, rank)  # (sender, first batch, batches) in receive-buffer order
+        if layout:
+            got = np.zeros((sum(nb for _, _, nb in layout), B, RB), np.uint8)
             hp.d2h(got, grp_recv[g])
-            for sender in range(N):
-                for b in range(per):
+            at = 0
+            for sender, first, nb in layout:
+                for b in range(first, first + nb):
                     checked += 1
-                    if not np.array_equal(got[sender, b], reference_rows(sender, rank * per + b, subs[rank * per + b])):
-                        bad.append((count, sender, rank * per + b))
+                    if not np.array_equal(got[at], reference_rows(sender, b, subs[b])):
+                        bad.append((count, sender, b))
+                    at += 1
     hp_ref.close()
     n_bad = comm.allreduce_max(float(len(bad)))
     if n_bad:

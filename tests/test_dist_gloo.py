@@ -202,3 +202,82 @@ def test_no_torch_in_the_product_package():
     for path in root.glob("*.py"):
         text = path.read_text()
         assert not re.search(r"^\s*(import|from)\s+torch\b", text, re.M), path
+
+
+def _payload(sender: int, step: int, unit: int) -> np.ndarray:
+    """What rank `sender` writes for running step `step` of a region: distinguishable bytes."""
+    return ((np.arange(unit, dtype=np.int64) * 7 + sender * 37 + step * 101) % 251).astype(np.uint8)
+
+
+def _group_worker(rank, world, port, mode, q):
+    """bench.py's group arithmetic (tsim_amd.dist: gather_group_size, group_pieces, collective_kind, received_layout) over a
+    gloo transport: regions of 20, 7 and 64 steps, complete and partial groups, both double-buffer slots."""
+    import torch
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        unit = 24  # bytes per step and rank (B * row bytes in the benchmark)
+
+        def transport(kind, send, count):
+            t = torch.from_numpy(np.ascontiguousarray(send))
+            if kind == "root0":
+                parts = [torch.empty_like(t) for _ in range(world)] if rank == 0 else None
+                dist.gather(t, parts, dst=0)
+                return None if parts is None else np.concatenate([x.numpy() for x in parts])
+            parts = [torch.empty_like(t) for _ in range(world)]  # (gloo has no all-to-all: every rank's group, then this rank's chunk of each)
+            dist.all_gather(parts, t)
+            per = count // world * unit
+            return np.concatenate([x.numpy()[rank * per:(rank + 1) * per] for x in parts])
+
+        ok = True
+        for steps in (20, 7, 64):
+            every = tdist.gather_group_size(steps, world, mode == "alltoall")
+            col = tdist.GroupCollector(world, rank, every, mode, unit, transport)
+            for rep in range(2):  # two regions on one collector: the slot parity carries over, drain() resets the counters
+                col.collected.clear()
+                done = 0
+                for k in (3, steps - 3) if steps > 3 else (steps,):  # a region as two calls: pieces that straddle a group boundary
+                    col.steps([_payload(rank, done + i, unit) for i in range(k)])
+                    done += k
+                col.drain()
+                assert sum(c for _, _, c, _ in col.collected) == steps
+                for first, kind, count, got in col.collected:
+                    layout = tdist.received_layout(kind, count, world, rank)
+                    if not layout:
+                        ok = ok and got is None
+                        continue
+                    want = np.concatenate([_payload(s, first + b, unit) for s, fb, nb in layout for b in range(fb, fb + nb)])
+                    ok = ok and got is not None and np.array_equal(got, want)
+                    ok = ok and (kind == "alltoall") == (mode == "alltoall" and count % world == 0)
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+@pytest.mark.parametrize("mode", ["root0", "alltoall"])
+def test_group_collection_arithmetic_over_gloo(world, mode):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_group_worker, args=(r, world, port, mode, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(got) == list(range(world)) and all(got.values()), got
+
+
+def test_collection_prediction_and_strong_scaling_rows():
+    pred = tdist.collection_prediction(8e10, 3)
+    assert pred["1"]["root0"] == 8e10
+    assert pred["8"]["root0"] < 3.5 * 8e10 < 8 * 8e10 <= pred["8"]["alltoall"] + 1  # the single root caps the node, spread roots do not
+    # strong scaling: one global batch cut as SURVEY 8(e) words it
+    for B, R in ((1_000_000, 8), (1000, 3)):
+        b = tdist.shard_bounds(B, R)
+        assert b[0][0] == 0 and b[-1][1] == B

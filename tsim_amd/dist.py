@@ -289,3 +289,104 @@ def sample_program_multi_device(program, f_params: np.ndarray, key, devices: lis
         for buf in (d_o, *keep):
             buf.free()
     return np.concatenate(parts, axis=0)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Group arithmetic of the pipelined collection (bench.py --gpus N; tests/test_dist_gloo.py runs it for N = 2, 4, 8 over gloo).
+# Every rank writes the bit_packed rows of consecutive batches ("steps") into one of two group buffers; a complete group -
+# `gather_every` batches - or the partial one at the end of a region is collected by ONE collective:
+#   "root0"    ncclGather to rank 0: rank 0 receives [rank 0's group][rank 1's group] ... (the north star's gather);
+#   "alltoall" the same gather with its roots spread: the group is cut into `world` equal chunks of consecutive batches and
+#              chunk j of every rank is assembled on rank j: rank j receives [rank 0's chunk j][rank 1's chunk j] ...
+#              (needs count % world == 0: a partial group goes to rank 0 instead).
+# ---------------------------------------------------------------------------------------------------------------------
+XGMI_LINK_BYTES_PER_S = 64e9  # one direction of one point-to-point xGMI link between two GPUs of a node (MI355X_MICROARCH.md)
+
+
+def gather_group_size(steps: int, world: int, spread_roots: bool, override: int | None = None) -> int:
+    """Batches per collective: about a third of a timed region in units of max(4, world), at least 8, at most 64 - every
+    collective but the last of a region then hides under the next group's kernels; a multiple of `world` when the roots are spread."""
+    if override:
+        g = max(1, int(override))
+    else:
+        unit = max(4, world)
+        g = max(8, min(64, (steps // 3) // unit * unit))
+    if spread_roots:
+        g = (g + world - 1) // world * world
+    return g
+
+
+def group_pieces(step_no: int, k: int, gather_every: int):
+    """The next `k` steps, starting at running step number `step_no`, cut at group boundaries: tuples
+    (group buffer 0/1, first position inside the group, number of steps)."""
+    done = 0
+    while done < k:
+        j = step_no + done
+        g, pos = (j // gather_every) & 1, j % gather_every
+        n = min(k - done, gather_every - pos)
+        yield g, pos, n
+        done += n
+
+
+def collective_kind(mode: str, count: int, world: int) -> str:
+    return "alltoall" if (mode == "alltoall" and count % world == 0) else "root0"
+
+
+def received_layout(kind: str, count: int, world: int, rank: int) -> list[tuple[int, int, int]]:
+    """What rank `rank` holds after the collective of a group of `count` batches, in receive-buffer order:
+    (sender, first batch inside the group, number of batches)."""
+    if kind == "root0":
+        return [(s, 0, count) for s in range(world)] if rank == 0 else []
+    per = count // world
+    return [(s, rank * per, per) for s in range(world)]
+
+
+def collection_prediction(one_gpu_shots_per_s: float, row_bytes: int, worlds=(1, 2, 4, 8)) -> dict:
+    """Whole-node rate the collection allows, from the one-GPU rate and the link arithmetic (a PREDICTION to read the first
+    multi-GPU measurement against): every rank produces `row_bytes` per shot; root0 puts the rows of world - 1 peers on
+    rank 0's world - 1 links, alltoall puts 1 / world of a rank's rows on each of its links."""
+    out = {}
+    for w in worlds:
+        if w == 1:
+            out["1"] = {"root0": one_gpu_shots_per_s, "alltoall": one_gpu_shots_per_s}
+            continue
+        per_link_rows = XGMI_LINK_BYTES_PER_S / row_bytes
+        out[str(w)] = {"root0": one_gpu_shots_per_s + (w - 1) * min(one_gpu_shots_per_s, per_link_rows),
+                       "alltoall": w * min(one_gpu_shots_per_s, per_link_rows * w)}
+    return out
+
+
+class GroupCollector:
+    """The double-buffered group collection on the host (numpy buffers, any transport): the model bench.py's device path
+    follows, and what the gloo tests drive.  ``transport(kind, send: bytes-like [count * unit], count) -> received bytes or None``."""
+
+    def __init__(self, world: int, rank: int, gather_every: int, mode: str, unit: int, transport):
+        self.world, self.rank, self.every, self.mode, self.unit, self.transport = world, rank, gather_every, mode, unit, transport
+        self.buf = [np.zeros(gather_every * unit, np.uint8) for _ in range(2)]
+        self.step_no = 0
+        self.gathered = 0       # groups whose collective has been issued
+        self.collected = []     # (first step of the group, kind, count, received array or None)
+
+    def steps(self, payloads) -> None:
+        """`payloads`: one ``uint8[unit]`` per step, in step order."""
+        it = iter(payloads)
+        k = len(payloads)
+        for g, pos, n in group_pieces(self.step_no, k, self.every):
+            for i in range(n):
+                self.buf[g][(pos + i) * self.unit:(pos + i + 1) * self.unit] = next(it)
+            self.step_no += n
+            if pos + n == self.every:
+                self._collect(self.every)
+
+    def drain(self) -> None:
+        while self.gathered * self.every < self.step_no:
+            self._collect(min(self.every, self.step_no - self.gathered * self.every))
+        self.gathered = 0
+        self.step_no = 0
+
+    def _collect(self, count: int) -> None:
+        g = self.gathered & 1
+        kind = collective_kind(self.mode, count, self.world)
+        got = self.transport(kind, self.buf[g][: count * self.unit], count)
+        self.collected.append((self.gathered * self.every, kind, count, got))
+        self.gathered += 1

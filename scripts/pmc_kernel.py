@@ -10,6 +10,10 @@ import sys
 
 
 def main():
+    # PMC_TOP=n: per counter the mean of the n LARGEST invocations instead of the median (fused kernels launch one chip-full of blocks
+    # whatever the number of batches in the group: the grid does not tell the timed 8-batch groups from the 4-batch warm-up ones)
+    import os
+    top = int(os.environ.get("PMC_TOP", "0"))
     kern, dirs = sys.argv[1], sys.argv[2:]
     vals = collections.defaultdict(list)
     durs = []
@@ -35,9 +39,14 @@ def main():
     print(f"kernel *{kern}*, grid {grid_seen} work-items, per invocation (median over {max((len(v) for v in vals.values()), default=0)} invocations; counters are summed over the chip's XCDs as rocprofv3 reports them)")
     if durs:
         print(f"  duration_us (kernel trace, under counter collection)   median {statistics.median(durs):.1f}  min {min(durs):.1f}  n {len(durs)}")
+    pick = (lambda x: sum(sorted(x)[-top:]) / len(sorted(x)[-top:])) if top else statistics.median
+    if top:
+        print(f"  (mean of the {top} largest invocations per counter)")
+        if durs:
+            print(f"  duration_us of the {top} longest invocations: {pick(durs):.1f}")
     for c in sorted(vals):
-        print(f"  {c:28s} {statistics.median(vals[c]):.6g}")
-    v = {c: statistics.median(x) for c, x in vals.items()}
+        print(f"  {c:28s} {pick(vals[c]):.6g}")
+    v = {c: pick(x) for c, x in vals.items()}
     if "SQ_INSTS_VALU" in v and "SQ_WAVES" in v:
         print(f"  VALU instructions per wave      {v['SQ_INSTS_VALU'] / v['SQ_WAVES']:.0f}")
     if "SQ_WAVE_CYCLES" in v and "SQ_INSTS_VALU" in v:

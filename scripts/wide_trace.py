@@ -40,6 +40,13 @@ for _ in range(reps):
     call()
 hp.synchronize()
 dt = (time.perf_counter() - t0) / reps
+if os.environ.get("WIDE_TRACE_BLOCKS"):
+    for blk in range(int(os.environ["WIDE_TRACE_BLOCKS"])):
+        t1 = time.perf_counter()
+        for _ in range(10):
+            call()
+        hp.synchronize()
+        print(f"  block {blk}: {(time.perf_counter() - t1) / 10 / nb * 1e6:.1f} us per batch; tables {hp.info()['pattern_max_weight']}")
 ts = []
 for _ in range(reps):
     hp.synchronize(); time.sleep(0.002)

@@ -39,9 +39,9 @@ def test_every_depth_matches_oracle(hip, cap):
 
 @pytest.mark.parametrize("deepen", [False, True])
 def test_depth_on_demand_and_bits_do_not_change(hip, deepen, monkeypatch):
-    """One wide component (k_sample_wide): the tables stay at weight 3 by default - the weight-4 table of a 200-bit component
-    is 2.1 GB of rows read at random, slower than evaluating those rows - and deepen on request
-    (TSIM_AMD_DEEP_TABLES=1) after three launches that miss a fifth of their rows.  Same bits either way."""
+    """One wide component (k_sample_wide): the weight-4 table of a 200-bit component is 2.1 GB and 24 ms of build for 10 % of
+    rate, so a handle deepens only after `deep_after` rows that miss a fifth of the time (2e10 by default: not here) or at once
+    on request (TSIM_AMD_DEEP_TABLES=1, after three such launches).  Same bits either way."""
     prog, cfg = synth.config_program("C5")
     orc = OC.OracleProgram(prog)
     if deepen:

@@ -142,10 +142,14 @@ static LaunchPlan make_plan(tsim_program *p, bool has_row_index, bool pipelined,
         p->lw_direct_left = 15;
         for (int i = 4; i < 8; ++i) p->h_feedback[i] = 0xFFFFFFFFu;
         pl.use_tables = false;
-      } else if (known && p->lw_cap_now < p->lw_cap_max && p->knobs.deep_tables > 0) {
-        // (only on request, TSIM_AMD_DEEP_TABLES=1: the weight-4 table of a 200-bit component is 2.1 GB of rows read at
-        // random - every read a TLB miss that the kernel's four waves per SIMD cannot hide: C5 126 -> 277 us per 10^6 shots,
-        // profiles/r04/wide_depth.txt - while the rows it would tabulate cost the dense pass ~1/3 of that)
+      } else if (known && p->lw_cap_now < p->lw_cap_max && p->knobs.deep_tables >= 0) {
+        // The weight-4 table of a 200-bit component is 2.1 GB and 24 ms of build; it moves C5 from 46.8 to 42.1 us per 10^6
+        // shots (profiles/r04/shapes.txt) - 5 ms back per 10^9 shots.  So, as for the narrow programs: at once on request
+        // (TSIM_AMD_DEEP_TABLES=1), otherwise only for a handle that has launched deep_after rows in this state.
+        if ((double)missed > 0.2 * (double)fb_rows && p->knobs.deep_tables == 0) {
+          p->deep_rows += rows;
+          if (p->deep_rows < p->knobs.deep_after) return pl;
+        }
         p->lw_dense_launches = (double)missed > 0.2 * (double)fb_rows ? p->lw_dense_launches + 1 : 0;
         if (p->lw_dense_launches >= 3) {
           p->lw_dense_launches = 0;
@@ -154,7 +158,6 @@ static LaunchPlan make_plan(tsim_program *p, bool has_row_index, bool pipelined,
         }
       }
     }
-    (void)rows;
     return pl;
   }
   if (p->lw && p->h_feedback && p->knobs.adaptive) {

@@ -480,8 +480,8 @@ int tsim_program_info(const tsim_program *p, int32_t *n_components, int32_t *num
 
 /* packer statistics: out[0] fast formulation selected, [1] levels, [2] fixed-frame levels,
  * [3] product pairs, [4] counted NodePhases rows, [5] table entries, [6] graphs with tabled
- * PhasePairs, [7] full-evaluation kernel: 0 row kernel, 1 LDS chunk tables (k_sample4), 2 sparse columns for wide
- * components (k_sample4w) */
+ * PhasePairs, [7] low 4 bits: full-evaluation kernel: 0 row kernel, 1 LDS chunk tables (k_sample4), 2 sparse columns for wide
+ * components (k_sample4w); + 32: the program has a wide record (k_sample_wide serves it); + 16: with the shared column table */
 int tsim_program_stats(const tsim_program *p, int64_t out[8]);
 
 const char *tsim_last_error(void);

@@ -17,10 +17,11 @@ from tsim_amd import prng, synth
 pytestmark = pytest.mark.gpu
 
 
-def one_wide(seed, *, n=3, F=200, G=(1, 2, 2, 3), num_f=320, n_direct=118, shuffle=False, flips=0.0, identity=True, density=0.08):
-    comps = [dict(n=n, F=F, G=list(G), density=density)]
+def one_wide(seed, *, n=3, F=200, G=(1, 2, 2, 3), num_f=320, n_direct=118, shuffle=False, flips=0.0, identity=True, density=0.08,
+             live=False, **terms):
+    comps = [dict(n=n, F=F, G=list(G), density=density, **terms)]
     return synth.physical_program(num_f=num_f, n_direct=n_direct, components=comps, seed=seed, shuffle_outputs=shuffle,
-                                  direct_flip_fraction=flips, identity_direct=identity)
+                                  direct_flip_fraction=flips, identity_direct=identity, live_padding=live)
 
 
 def _packed(f, wf):
@@ -127,6 +128,59 @@ def test_shapes_through_the_steps_api(hip, shape, packed):
             np.testing.assert_array_equal(outs[i], np.packbits(want, axis=1, bitorder="little"), err_msg=f"batch {i}")
             assert np.float32(devs[i]) == np.float32(wdev[0]), f"normalisation deviation of batch {i}"
         hp.close()
+
+
+SHARED_SHAPES = [
+    dict(),                                                       # C5's shape: 8 graphs, 76 parity bits
+    dict(n=1, F=70, G=(2, 3), num_f=128, n_direct=20),
+    dict(n=2, F=255, G=(1, 2, 4), num_f=400, n_direct=90, shuffle=True, flips=0.3),
+    dict(n=3, F=150, G=(1, 1, 2, 2), num_f=256, n_direct=60, density=0.2),
+    dict(n=2, F=120, G=(1, 1, 2), num_f=192, n_direct=60, live=True, ta=(2, 4), tb=(4, 8), tc=(4, 8), td=(0, 2)),   # product pairs
+    dict(n=3, F=90, G=(1, 1, 1, 2), num_f=128, n_direct=29, live=True, ta=(2, 2), tb=(2, 6), tc=(2, 6), td=(1, 3), shuffle=True),
+    dict(n=8, F=100, G=(1, 1, 2, 2, 2, 3, 3, 3, 4), num_f=256, n_direct=180, shuffle=True, identity=False),  # too many bits: per-graph tables
+]
+
+
+@pytest.mark.parametrize("shape", SHARED_SHAPES)
+def test_shared_column_table_equals_the_per_graph_tables(hip, shape):
+    """When every graph's parity bits fit ONE 16-byte column entry (tsim_program.hip, WR_CCOL) the dense and generic passes of
+    k_sample_wide walk a row's set bits once for all graphs; TSIM_AMD_TUNE=wide_compact=0 keeps one table per graph.  Both
+    against the oracle, every row class (p_bit up to heavy rows), with the normalisation check."""
+    prog = one_wide(77, **shape)
+    nf = shape.get("num_f", 320)
+    F = shape.get("F", 200)
+    orc = OC.OracleProgram(prog)
+    B, n = 3000, 5
+    fs = [synth.synth_f(B, nf, (1.0 + 3.0 * i) / F, seed=90 + i) for i in range(n)]
+    key = prng.key(8)
+    subs = _subkeys(key, n)
+    packed = ((prog.num_outputs + 7) // 8) % 4 == 0
+    got = {}
+    prev = os.environ.get("TSIM_AMD_TUNE")
+    try:
+        for compact in (1, 0):
+            os.environ["TSIM_AMD_TUNE"] = f"wide_compact={compact}"
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                hp = hip.HipProgram(prog)
+                info = hp.info()
+                assert info["wide_fused_kernel"]
+                if compact == 0:
+                    assert not info["wide_shared_columns"]
+                elif len(shape.get("G", (1, 2, 2, 3))) < 9:
+                    assert info["wide_shared_columns"], "this shape's graphs fit one entry"
+                got[compact] = _steps(hp, prog, fs, key, nf, packed=packed, devs=True)
+                hp.close()
+    finally:
+        if prev is None:
+            os.environ.pop("TSIM_AMD_TUNE", None)
+        else:
+            os.environ["TSIM_AMD_TUNE"] = prev
+    for i in range(n):
+        want, wdev = orc.sample_program(fs[i], subs[i], return_devs=True)
+        for compact in (1, 0):
+            np.testing.assert_array_equal(got[compact][0][i], np.packbits(want, axis=1, bitorder="little"), err_msg=f"batch {i}, wide_compact={compact}")
+            assert np.float32(got[compact][1][i]) == np.float32(wdev[0])
 
 
 def test_c5_at_scale_equals_the_round2_path_and_the_row_kernel(hip):

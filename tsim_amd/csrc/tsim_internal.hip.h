@@ -229,6 +229,7 @@ struct tsim_program {
     int fused_max = 8;        // fused_max: batches per fused first pass (<= TSIMK_LWM_MAX_STEPS = 16)
     bool wide = true;         // wide=0: wide components on the row kernel alone
     bool wide_tables = true;  // wide_tables=0: no pattern tables in front of the wide kernels
+    bool wide_compact = true; // wide_compact=0: k_sample_wide keeps one 16-byte column table per graph even when all graphs fit one entry
     // fixed since round 4 (the experiments behind their switches are closed: DESIGN.md / HISTORY.md)
     bool hard_kernel = true;  // hard rows on k_sample4h, not k_sample4
     bool lane0_main = true;   // pipeline slot 0 runs on the handle's stream (a hardware queue of its own)

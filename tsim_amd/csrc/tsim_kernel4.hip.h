@@ -28,6 +28,7 @@ enum { L4_G = 0, L4_NTILES, L4_TABLES, L4_RECS, L4_NCH, L4_FLAGS, L4_FRAME, L4_S
 enum {
   // the first eight words are everything a fixed-frame graph needs: one s_load_dwordx8
   G4_M0 = 0, G4_M1, G4_M3, G4_PM, G4_N1, G4_DBITS /* 2*nD */, G4_TBL, G4_FLAGS, G4_TBL2,
+  G4_CFIELD = 9 /* LDS copies of k_sample_wide only: the graph's field of the shared column entry (WR_CREC) */,
   G4_APRE = 11, G4_APIM = 12, G4_WORDS = 16
 };
 #define TSIMK_G4FLAG_D_COMBINED 1u

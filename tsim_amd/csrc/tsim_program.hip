@@ -238,6 +238,7 @@ extern "C" int tsim_program_finalize(tsim_program *p, int32_t device) {
     p->knobs.fused_max = (int)std::max(1ll, std::min((long long)TSIMK_LWM_MAX_STEPS, tune_ll("fused_max", 8)));
     p->knobs.wide = tune_ll("wide", 1) != 0;
     p->knobs.wide_tables = tune_ll("wide_tables", 1) != 0;
+    p->knobs.wide_compact = tune_ll("wide_compact", 1) != 0;
   }
 
   // ---- choose the evaluation formulation ----
@@ -620,6 +621,81 @@ retry_pack:
             }
             size_t colbytes = 0;
             for (auto &lv : c.levels) colbytes += (size_t)lv.G * (size_t)(c.F + 33) * 16;
+            // Shared column table: when the parity words of ALL graphs of all levels fit one 16-byte entry (graph g owns a bit
+            // field of one 32-bit word: product rows U, V, counted rows, PhasePairs index bits, lambda, linear), a row's
+            // Y words for every graph are ONE walk over its set bits instead of one walk per graph.  Field layout from
+            // bit 0: U[h2] V[h2] O1[nc] D[2 nD] lambda lin.
+            uint32_t ccol_off = 0, crec_off = 0;
+            {
+              struct Fld { int w, off, h2, nc; };
+              std::vector<Fld> fl;
+              int fill[4] = {0, 0, 0, 0};
+              bool okc = p->knobs.wide_compact;
+              for (auto &lv : c.levels)
+                for (auto &fg : lv.fg) {
+                  const int h2 = (int)fg.us.size(), nc = (int)(fg.c0.size() + fg.c1.size() + fg.c3.size());
+                  const int width = 2 * h2 + nc + 2 * fg.nD + 2;
+                  int w = -1;
+                  for (int k = 0; k < 4 && w < 0 && width <= 32; ++k)
+                    if (fill[k] + width <= 32) w = k;
+                  if (w < 0) { okc = false; break; }
+                  fl.push_back({w, fill[w], h2, nc});
+                  fill[w] += width;
+                }
+              if (tsim_debug("pack")) {
+                size_t gi = 0;
+                for (size_t k = 0; k < c.levels.size(); ++k)
+                  for (size_t g = 0; g < c.levels[k].fg.size(); ++g, ++gi) {
+                    const FastGraph &fg = c.levels[k].fg[g];
+                    fprintf(stderr, "[tsim] wide level %zu graph %zu: product pairs %zu, counted rows %zu + %zu + %zu, PhasePairs terms %d (tabled %d), term table %u words", k, g,
+                            fg.us.size(), fg.c0.size(), fg.c1.size(), fg.c3.size(), fg.nD, fg.d_tabled ? 1 : 0, c.levels[k].tt_words);
+                    if (okc) fprintf(stderr, ", shared entry word %d bit %d", fl[gi].w, fl[gi].off);
+                    fprintf(stderr, "\n");
+                  }
+              }
+              if (okc) {
+                const int F = c.F;
+                std::vector<std::array<uint32_t, 4>> cc((size_t)F + 33, std::array<uint32_t, 4>{0u, 0u, 0u, 0u});
+                size_t gi = 0;
+                for (auto &lv : c.levels)
+                  for (auto &fg : lv.fg) {
+                    const Fld f = fl[gi++];
+                    const int P = lv.P;
+                    auto place = [&](const std::vector<uint64_t> &m, int bit, bool cst) {
+                      const uint32_t b = 1u << (f.off + bit);
+                      for (int i = 0; i < F && i < P; ++i)
+                        if ((m[(size_t)i >> 6] >> (i & 63)) & 1) cc[(size_t)i][(size_t)f.w] ^= b;
+                      for (int ch = 0; ch < 2; ++ch)
+                        for (int v = 0; v < 16; ++v) {
+                          bool par = ch == 0 && cst;  // row constants ride on the first chunk's entries
+                          for (int bb = 0; bb < 4; ++bb) {
+                            const int i = F + 4 * ch + bb;
+                            if (((v >> bb) & 1) && i < P && ((m[(size_t)i >> 6] >> (i & 63)) & 1)) par = !par;
+                          }
+                          if (par) cc[(size_t)(F + 1 + 16 * ch + v)][(size_t)f.w] ^= b;
+                        }
+                    };
+                    int bit = 0;
+                    for (int s = 0; s < f.h2; ++s) place(fg.us[(size_t)s], bit++, false);
+                    for (int s = 0; s < f.h2; ++s) place(fg.vs[(size_t)s], bit++, false);
+                    for (size_t t = 0; t < fg.c0.size(); ++t) place(fg.c0[t], bit++, fg.c0c[t] != 0);
+                    for (size_t t = 0; t < fg.c1.size(); ++t) place(fg.c1[t], bit++, fg.c1c[t] != 0);
+                    for (size_t t = 0; t < fg.c3.size(); ++t) place(fg.c3[t], bit++, fg.c3c[t] != 0);
+                    for (int t = 0; t < fg.nD; ++t) {  // index bits: term 0 holds the most significant pair (as emit_level4)
+                      place(fg.dal[(size_t)t], bit + 2 * (fg.nD - 1 - t), false);
+                      place(fg.dbe[(size_t)t], bit + 2 * (fg.nD - 1 - t) + 1, false);
+                    }
+                    bit += 2 * fg.nD;
+                    place(fg.lam, bit++, false);
+                    place(fg.lin, bit++, false);
+                  }
+                while (img.size() % 4) img.push_back(0u);
+                ccol_off = (uint32_t)img.size();
+                for (auto &e : cc) img.insert(img.end(), e.begin(), e.end());
+                crec_off = (uint32_t)img.size();
+                for (auto &f : fl) img.push_back((uint32_t)f.w | ((uint32_t)f.off << 8) | ((uint32_t)f.h2 << 16) | ((uint32_t)f.nc << 24));
+              }
+            }
             uint32_t *h = &img[p->wr_off];
             h[WR_NRUNS] = (uint32_t)(runs.size() / 2);
             h[WR_RUNS] = runs_off;
@@ -629,6 +705,9 @@ retry_pack:
             h[WR_LUTMASK] = lutmask;
             h[WR_WO32] = (uint32_t)wo32;
             h[WR_COLBYTES] = (uint32_t)colbytes;
+            h[WR_CCOL] = ccol_off;
+            h[WR_CREC] = crec_off;
+            p->stats[7] |= 32 | (ccol_off ? 16 : 0);
             {  // the term tables of every level, for a copy in LDS: (image offset, words) per level
               const uint32_t tt_rec = (uint32_t)img.size();
               uint32_t tt_total = 0;

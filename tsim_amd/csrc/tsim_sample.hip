@@ -451,6 +451,7 @@ static int fill_sample_args(tsim_program *p, tsim_program::Slot &sl, SampleArgs 
 // ---------------------------------------------------------------------------
 struct WideLayout {
   int block = 0;       // threads per block (0: the program does not fit)
+  int compact = 0;     // 1: the shared column table (WR_CCOL)
   size_t lds = 0;
   int l_rank, l_lut, l_runs, l_sel, l_ptrs, l_keys, l_tt, l_lvl, l_grec, l_wave, wave_bytes, w_q, w_ovf;
 };
@@ -460,40 +461,45 @@ static WideLayout wide_layout(const tsim_program *p, int WF32) {
   const uint32_t *wr = &p->img[p->wr_off];
   const int wo32 = (int)wr[WR_WO32];
   auto up = [](size_t v, size_t a) { return (v + a - 1) / a * a; };
-  size_t off = up(wr[WR_COLBYTES], 16);
-  L.l_rank = (int)off;  off += (size_t)4 * (c.F + 1) * 4;
-  off = up(off, 16);
-  L.l_lut = (int)off;   off += ((size_t)wo32 << c.n_out) * 4;
-  off = up(off, 16);
-  L.l_runs = (int)off;  off += (size_t)(2 * TSIMK_WIDE_MAX_RUNS + 48) * 4;
-  L.l_sel = (int)off;   off += 36 * 4;  // + the two statistics counters
-  L.l_ptrs = (int)off;  off += (size_t)TSIMK_LWM_MAX_STEPS * 4 * 4;
-  L.l_keys = (int)off;  off += (size_t)TSIMK_LWM_MAX_STEPS * 2 * TSIMK_LWM_KEYS * 4;
-  off = up(off, 16);
-  const size_t fixed_end = off;
-  size_t w = (size_t)64 * WF32 * 4;
-  w = up(w, 16);
-  L.w_q = (int)w;       w += (size_t)(4 + c.n_out + __builtin_popcount(wr[WR_LUTMASK])) * TSIMK_WIDE_QCAP * 4;
-  L.w_ovf = (int)w;     w += (size_t)TSIMK_WIDE_QCAP * 4;
-  L.wave_bytes = (int)up(w, 16);
-  // the levels' term tables join the column tables in LDS when 16 waves still fit next to them (C5: 3 KB)
-  // (+ the level table and the graph records: 16 bytes per level, 64 per graph)
-  const size_t tt_only = up(wr[WR_TTBYTES], 16);
-  const size_t tt_bytes = tt_only + 16 * (size_t)(c.n_out + 1) + 64 * (size_t)wr[WR_GTOT];
-  for (int with_tt = 1; with_tt >= 0 && !L.block; --with_tt) {
-    if (with_tt && (tt_only == 0 || tt_bytes > 24 * 1024)) continue;
-    off = fixed_end + (with_tt ? tt_bytes : 0);
-    for (int blk : {1024, 512, 256}) {  // 16 waves per CU when everything fits beside the tables, fewer otherwise
-      if (with_tt && blk != 1024) break;
-      const size_t tot = off + (size_t)(blk / 64) * L.wave_bytes + 64;  // + the kernel's static words
-      if (tot <= 160 * 1024) {
-        L.block = blk;
-        L.l_tt = with_tt ? (int)fixed_end : -1;
-        L.l_lvl = (int)(fixed_end + tt_only);
-        L.l_grec = L.l_lvl + 16 * (c.n_out + 1);
-        L.l_wave = (int)off;
-        L.lds = off + (size_t)(blk / 64) * L.wave_bytes;
-        break;
+  // the shared column table (one entry holds every graph's parity bits) when the packer made one and the term tables fit
+  // beside it; else one table per graph
+  for (int compact = wr[WR_CCOL] != 0u ? 1 : 0; compact >= 0 && !L.block; --compact) {
+    size_t off = compact ? (size_t)(c.F + 33) * 16 : up(wr[WR_COLBYTES], 16);
+    L.l_rank = (int)off;  off += (size_t)4 * (c.F + 1) * 4;
+    off = up(off, 16);
+    L.l_lut = (int)off;   off += ((size_t)wo32 << c.n_out) * 4;
+    off = up(off, 16);
+    L.l_runs = (int)off;  off += (size_t)(2 * TSIMK_WIDE_MAX_RUNS + 48) * 4;
+    L.l_sel = (int)off;   off += 36 * 4;  // + the two statistics counters
+    L.l_ptrs = (int)off;  off += (size_t)TSIMK_LWM_MAX_STEPS * 4 * 4;
+    L.l_keys = (int)off;  off += (size_t)TSIMK_LWM_MAX_STEPS * 2 * TSIMK_LWM_KEYS * 4;
+    off = up(off, 16);
+    const size_t fixed_end = off;
+    size_t w = (size_t)64 * WF32 * 4;
+    w = up(w, 16);
+    L.w_q = (int)w;       w += (size_t)(4 + c.n_out + __builtin_popcount(wr[WR_LUTMASK])) * TSIMK_WIDE_QCAP * 4;
+    L.w_ovf = (int)w;     w += (size_t)TSIMK_WIDE_QCAP * 4;
+    L.wave_bytes = (int)up(w, 16);
+    // the levels' term tables join the column tables in LDS when 16 waves still fit next to them (C5: 3 KB)
+    // (+ the level table and the graph records: 16 bytes per level, 64 per graph)
+    const size_t tt_only = up(wr[WR_TTBYTES], 16);
+    const size_t tt_bytes = tt_only + 16 * (size_t)(c.n_out + 1) + 64 * (size_t)wr[WR_GTOT];
+    for (int with_tt = 1; with_tt >= (compact ? 1 : 0) && !L.block; --with_tt) {
+      if (with_tt && tt_only == 0) continue;
+      off = fixed_end + (with_tt ? tt_bytes : 0);
+      for (int blk : {1024, 512, 256}) {  // 16 waves per CU when everything fits beside the tables, fewer otherwise
+        if (with_tt && blk != 1024) break;
+        const size_t tot = off + (size_t)(blk / 64) * L.wave_bytes + 64;  // + the kernel's static words
+        if (tot <= 160 * 1024) {
+          L.block = blk;
+          L.compact = compact;
+          L.l_tt = with_tt ? (int)fixed_end : -1;
+          L.l_lvl = (int)(fixed_end + tt_only);
+          L.l_grec = L.l_lvl + 16 * (c.n_out + 1);
+          L.l_wave = (int)off;
+          L.lds = off + (size_t)(blk / 64) * L.wave_bytes;
+          break;
+        }
       }
     }
   }
@@ -519,6 +525,11 @@ static int launch_wide(tsim_program *p, int n, const SampleArgs *const *args, in
   const int WF32 = 2 * std::max(1, (num_f + 63) / 64);
   const WideLayout L = wide_layout(p, WF32);
   if (!L.block) return tsim_fail(TSIM_ESTATE, "wide kernel does not fit");
+  if (tsim_debug("host")) {
+    static bool said = false;
+    if (!said) fprintf(stderr, "[tsim] k_sample_wide: block %d, LDS %zu bytes (per wave %d), shared column table %d, term tables in LDS %d\n", L.block, L.lds, L.wave_bytes, L.compact, L.l_tt >= 0 ? 1 : 0);
+    said = true;
+  }
   WideArgs W{};
   W.img = p->d_img;
   W.tab = p->d_lw_tab;
@@ -535,6 +546,7 @@ static int launch_wide(tsim_program *p, int n, const SampleArgs *const *args, in
   W.binom_off = p->lw_binom_off;
   W.tab_bytes = (uint32_t)p->lw_bytes;
   W.feedback = p->d_feedback;
+  W.compact = L.compact;
   W.l_rank = L.l_rank; W.l_lut = L.l_lut; W.l_runs = L.l_runs; W.l_sel = L.l_sel; W.l_ptrs = L.l_ptrs; W.l_keys = L.l_keys;
   W.l_tt = L.l_tt; W.l_lvl = L.l_lvl; W.l_grec = L.l_grec; W.l_wave = L.l_wave; W.wave_bytes = L.wave_bytes; W.w_q = L.w_q; W.w_ovf = L.w_ovf;
   for (int j = 0; j < n; ++j) {

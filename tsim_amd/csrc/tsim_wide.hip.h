@@ -44,6 +44,8 @@ enum {
   WR_TTBYTES,     // their total size in bytes
   WR_GTOT,        // graphs of all levels together
   WR_RUN1,        // image offset of WO32 x (ctl, mask) when every destination word has at most one run (mask 0: none), else 0
+  WR_CCOL,        // image offset of the shared column table (F + 33 entries of 16 bytes: every graph's parity bits in one entry), 0: none
+  WR_CREC,        // image offset of one word per graph: word of the entry | first bit << 8 | product pairs << 16 | counted rows << 24
   WR_WORDS = 16
 };
 #define TSIMK_WIDE_K 12        // set bits per row the dense pass takes
@@ -69,6 +71,7 @@ struct WideArgs {
   uint32_t tab_bytes;
   uint32_t *feedback;       // optional (mapped host memory): [4] rows with more than K set bits, [5] rows the tables missed, [6] rows - estimates from block 0
   // LDS layout in bytes, computed by the launcher (tsim_sample.hip: wide_layout)
+  int compact;      // 1: LDS holds the shared column table (WR_CCOL) instead of one table per graph; needs l_tt >= 0
   int l_rank, l_lut, l_runs, l_sel, l_ptrs, l_keys, l_tt, l_lvl, l_grec, l_wave, wave_bytes, w_q, w_ovf;  // l_tt < 0: the term tables stay in the image
   WideStep step[TSIMK_LWM_MAX_STEPS];
 };
@@ -102,7 +105,7 @@ struct GrecV {
   v4 a, b, c, d;
   __device__ __forceinline__ uint32_t operator[](int i) const {
     const uint32_t v = i < 4 ? a[i & 3] : i < 8 ? b[i & 3] : i < 12 ? c[i & 3] : d[i & 3];
-    return (i == G4_FLAGS || i == G4_DBITS || i == G4_TBL2) ? (uint32_t)__builtin_amdgcn_readfirstlane((int)v) : v;
+    return (i == G4_FLAGS || i == G4_DBITS || i == G4_TBL2 || i == G4_CFIELD) ? (uint32_t)__builtin_amdgcn_readfirstlane((int)v) : v;
   }
 };
 
@@ -151,11 +154,15 @@ __global__ void __launch_bounds__(1024) k_sample_wide(WideArgs A) {
   const uint32_t n_runs = wr[WR_NRUNS];
   {
     uint32_t off = 0;
-    for (uint32_t li = 0; li <= n_out; ++li) {  // the column tables of every level: one burst of LDS-DMA
-      cptr lvl = levels + li * L4_WORDS;
-      const uint32_t bytes = lvl[L4_G] * ent_bytes;
-      tile_copy(reinterpret_cast<const uint4 *>(A.img + lvl[L4_STAB]), lds8 + off, bytes >> 4, threadIdx.x, nthr);
-      off += bytes;
+    if (A.compact) {  // the shared column table: every graph's parity bits in one 16-byte entry per column
+      tile_copy(reinterpret_cast<const uint4 *>(A.img + wr[WR_CCOL]), lds8, F + 33u, threadIdx.x, nthr);
+    } else {
+      for (uint32_t li = 0; li <= n_out; ++li) {  // the column tables of every level: one burst of LDS-DMA
+        cptr lvl = levels + li * L4_WORDS;
+        const uint32_t bytes = lvl[L4_G] * ent_bytes;
+        tile_copy(reinterpret_cast<const uint4 *>(A.img + lvl[L4_STAB]), lds8 + off, bytes >> 4, threadIdx.x, nthr);
+        off += bytes;
+      }
     }
     if (A.l_tt >= 0) {  // the term tables of every level behind each other
       uint32_t toff = 0;
@@ -184,6 +191,7 @@ __global__ void __launch_bounds__(1024) k_sample_wide(WideArgs A) {
           uint32_t v = A.img[recs + i];
           const uint32_t k = i % (uint32_t)G4_WORDS;
           if (k == (uint32_t)G4_TBL || (k == (uint32_t)G4_TBL2 && v != 0u)) v = tt_word0 + (toff >> 2) + (v - src);
+          if (k == (uint32_t)G4_CFIELD && A.compact) v = A.img[wr[WR_CREC] + g0 + i / (uint32_t)G4_WORDS];
           l_grec[g0 * (uint32_t)G4_WORDS + i] = v;
         }
         g0 += G;
@@ -301,6 +309,19 @@ __global__ void __launch_bounds__(1024) k_sample_wide(WideArgs A) {
     }
   };
 
+  // shared column table: graph field `cf` (WR_CREC) of the entry-sized parity word yl -> the four words acc_graph4 takes
+  // (U, V: product rows; O1: counted rows, the masks of the record pick theirs; O2: index bits, lambda and linear on top)
+  auto field_words = [&](const u32x4 &yl, uint32_t cf, uint32_t dsh) -> u32x4 {
+    const uint32_t w = cf & 3u, off = (cf >> 8) & 31u, h2 = (cf >> 16) & 63u, s2 = 2u * h2 + (cf >> 24);
+    const uint32_t fld = ((w & 2u) ? ((w & 1u) ? yl.w : yl.z) : ((w & 1u) ? yl.y : yl.x)) >> off;
+    u32x4 y;
+    y.x = fld;
+    y.y = fld >> h2;
+    y.z = fld >> (2u * h2);
+    y.w = ((fld >> s2) & ((1u << dsh) - 1u)) | ((fld >> (s2 + dsh)) << 30);
+    return y;
+  };
+
   WT_DECL;
   // ------------------------------------------------------------------------------------------------------------
   // phase 2: n (<= 64) queued rows, slots qhead .. qhead + n - 1: the sparse-column evaluation on dense lanes
@@ -325,6 +346,16 @@ __global__ void __launch_bounds__(1024) k_sample_wide(WideArgs A) {
       if (__builtin_amdgcn_ballot_w64(col[2 * c] != F * 16u) != 0ull) need |= 1u << c;
     uint32_t mb = 0, leaf = 0, lvl_off = 0, tt_lds = 0;
     float prev = 0.0f;
+    u32x4 yf = {0u, 0u, 0u, 0u};  // shared column table: the f part of every graph's parity words, once per pass
+    if (A.compact) {
+#pragma unroll
+      for (int c = 0; c < K / 2; ++c)
+        if ((need >> c) & 1u) {
+          const u32x4 v = *(lds_u4p)(uintptr_t)(lds_col0 + col[2 * c]);
+          const u32x4 w = *(lds_u4p)(uintptr_t)(lds_col0 + col[2 * c + 1]);
+          yf.x = xor3(yf.x, v.x, w.x); yf.y = xor3(yf.y, v.y, w.y); yf.z = xor3(yf.z, v.z, w.z); yf.w = xor3(yf.w, v.w, w.w);
+        }
+    }
 #ifdef TSIMK_WIDE_TRACE
     asm volatile("" :: "v"(col[0]), "v"(col[K - 1]));
 #endif
@@ -341,6 +372,12 @@ __global__ void __launch_bounds__(1024) k_sample_wide(WideArgs A) {
         const uint32_t g0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)lv.w);
         const bool fixed = (flags & TSIMK_LFLAG_FIXED) != 0, approx = (flags & TSIMK_LFLAG_APPROX) != 0;
         Acc4 S;
+        u32x4 yl = yf;
+        if (A.compact) {  // + the level's outcome bits and row constants: two more entries for ALL its graphs
+          const u32x4 v = *(lds_u4p)(uintptr_t)(lds_col0 + e_lo);
+          const u32x4 w = *(lds_u4p)(uintptr_t)(lds_col0 + e_hi);
+          yl.x = xor3(yl.x, v.x, w.x); yl.y = xor3(yl.y, v.y, w.y); yl.z = xor3(yl.z, v.z, w.z); yl.w = xor3(yl.w, v.w, w.w);
+        }
         for (uint32_t g = 0; g < G; ++g) {
           const uint32_t base = lds_col0 + lvl_off + g * ent_bytes;
           const uint32_t rb = lds_col0 + (uint32_t)A.l_grec + (g0 + g) * (uint32_t)(G4_WORDS * 4);
@@ -350,18 +387,23 @@ __global__ void __launch_bounds__(1024) k_sample_wide(WideArgs A) {
           R.c = *(lds_u4p)(uintptr_t)(rb + 32u);
           R.d = R.c;
           if (approx) R.d = *(lds_u4p)(uintptr_t)(rb + 48u);
-          u32x4 y = *(lds_u4p)(uintptr_t)(base + e_lo);
-          {
-            const u32x4 t = *(lds_u4p)(uintptr_t)(base + e_hi);
-            y ^= t;
-          }
-#pragma unroll
-          for (int c = 0; c < K / 2; ++c)
-            if ((need >> c) & 1u) {
-              const u32x4 v = *(lds_u4p)(uintptr_t)(base + col[2 * c]);
-              const u32x4 w = *(lds_u4p)(uintptr_t)(base + col[2 * c + 1]);
-              y.x = xor3(y.x, v.x, w.x); y.y = xor3(y.y, v.y, w.y); y.z = xor3(y.z, v.z, w.z); y.w = xor3(y.w, v.w, w.w);
+          u32x4 y;
+          if (A.compact) {
+            y = field_words(yl, R[G4_CFIELD], R[G4_DBITS]);
+          } else {
+            y = *(lds_u4p)(uintptr_t)(base + e_lo);
+            {
+              const u32x4 t = *(lds_u4p)(uintptr_t)(base + e_hi);
+              y ^= t;
             }
+#pragma unroll
+            for (int c = 0; c < K / 2; ++c)
+              if ((need >> c) & 1u) {
+                const u32x4 v = *(lds_u4p)(uintptr_t)(base + col[2 * c]);
+                const u32x4 w = *(lds_u4p)(uintptr_t)(base + col[2 * c + 1]);
+                y.x = xor3(y.x, v.x, w.x); y.y = xor3(y.y, v.y, w.y); y.z = xor3(y.z, v.z, w.z); y.w = xor3(y.w, v.w, w.w);
+              }
+          }
           if (fixed) acc_graph4<true, true, const GrecV &>(S, A.img, R, y.x, y.y, y.z, y.w, approx, 0u);
           else acc_graph4<false, true, const GrecV &>(S, A.img, R, y.x, y.y, y.z, y.w, approx, 0u);
         }
@@ -444,8 +486,24 @@ __global__ void __launch_bounds__(1024) k_sample_wide(WideArgs A) {
     direct_words(frow, o);
     const uint32_t *keys = l_keys + st * (2u * TSIMK_LWM_KEYS) + 2u * keybase;
     const uint32_t slo = so_lo + row;
-    uint32_t mb = 0, leaf = 0, lvl_off = 0;
+    uint32_t mb = 0, leaf = 0, lvl_off = 0, gidx = 0;
     float prev = 0.0f, maxdev = 0.0f;
+    // XOR of the column entries of the row's set selected bits, from the table at `tbl`
+    auto walk = [&](const uint8_t *tbl, u32x4 &y) {
+      for (uint32_t w = 0; w < WF32 && w < 16u; ++w) {
+        const uint32_t sw = l_sel[w], base = l_sel[16u + w];
+        uint32_t m = frow[w] & sw;
+        while (m) {
+          const uint32_t p = (uint32_t)__builtin_ctz(m);
+          const uint32_t pos = base + (uint32_t)__builtin_popcount(sw & ((1u << p) - 1u));
+          const u32x4 t = *reinterpret_cast<const u32x4 *>(tbl + pos * 16u);
+          y.x ^= t.x; y.y ^= t.y; y.z ^= t.z; y.w ^= t.w;
+          m &= m - 1u;
+        }
+      }
+    };
+    u32x4 yf = {0u, 0u, 0u, 0u};
+    if (A.compact) walk(lds8, yf);  // shared column table: one walk for every graph of every level
     for (uint32_t li = 0; li <= n_out; ++li) {
       cptr lvl = levels + li * L4_WORDS;
       if (li > 0) mb = trial0 ? (mb & ~(1u << (li - 1u))) : (mb | (1u << (li - 1u)));
@@ -453,23 +511,24 @@ __global__ void __launch_bounds__(1024) k_sample_wide(WideArgs A) {
       const bool fixed = (lvl[L4_FLAGS] & TSIMK_LFLAG_FIXED) != 0, approx = (lvl[L4_FLAGS] & TSIMK_LFLAG_APPROX) != 0;
       cptr recs = img + lvl[L4_RECS];
       Acc4 S;
-      for (uint32_t g = 0; g < G; ++g) {
-        const uint8_t *tbl = lds8 + lvl_off + g * ent_bytes;
-        u32x4 y = *reinterpret_cast<const u32x4 *>(tbl + (F + 1u + (mb & 15u)) * 16u);
-        {
-          const u32x4 t = *reinterpret_cast<const u32x4 *>(tbl + (F + 17u + ((mb >> 4) & 15u)) * 16u);
-          y.x ^= t.x; y.y ^= t.y; y.z ^= t.z; y.w ^= t.w;
-        }
-        for (uint32_t w = 0; w < WF32 && w < 16u; ++w) {
-          const uint32_t sw = l_sel[w], base = l_sel[16u + w];
-          uint32_t m = frow[w] & sw;
-          while (m) {
-            const uint32_t p = (uint32_t)__builtin_ctz(m);
-            const uint32_t pos = base + (uint32_t)__builtin_popcount(sw & ((1u << p) - 1u));
-            const u32x4 t = *reinterpret_cast<const u32x4 *>(tbl + pos * 16u);
+      u32x4 yl = yf;
+      if (A.compact) {
+        const u32x4 v = *reinterpret_cast<const u32x4 *>(lds8 + (F + 1u + (mb & 15u)) * 16u);
+        const u32x4 t = *reinterpret_cast<const u32x4 *>(lds8 + (F + 17u + ((mb >> 4) & 15u)) * 16u);
+        yl.x ^= v.x ^ t.x; yl.y ^= v.y ^ t.y; yl.z ^= v.z ^ t.z; yl.w ^= v.w ^ t.w;
+      }
+      for (uint32_t g = 0; g < G; ++g, ++gidx) {
+        u32x4 y;
+        if (A.compact) {
+          y = field_words(yl, img[wr[WR_CREC] + gidx], recs[g * G4_WORDS + G4_DBITS]);
+        } else {
+          const uint8_t *tbl = lds8 + lvl_off + g * ent_bytes;
+          y = *reinterpret_cast<const u32x4 *>(tbl + (F + 1u + (mb & 15u)) * 16u);
+          {
+            const u32x4 t = *reinterpret_cast<const u32x4 *>(tbl + (F + 17u + ((mb >> 4) & 15u)) * 16u);
             y.x ^= t.x; y.y ^= t.y; y.z ^= t.z; y.w ^= t.w;
-            m &= m - 1u;
           }
+          walk(tbl, y);
         }
         if (fixed) acc_graph4<true>(S, A.img, recs + g * G4_WORDS, y.x, y.y, y.z, y.w, approx);
         else acc_graph4<false>(S, A.img, recs + g * G4_WORDS, y.x, y.y, y.z, y.w, approx);

@@ -115,7 +115,7 @@ def test_zero_shots_and_zero_outputs(hip):
 TUNE_CHOICES = {
     "defer_hard": [0, 1], "defer_group": [1, 3, 4, 8], "lw_fast": [0, 1], "wide_fused": [0, 1], "hard_wave": [0, 1],
     "hard_wave_rows": [0, 64, 1024, 100000], "hard_inline_rows": [0, 1 << 40], "hard_comp_par": [0, 1], "deep_after": [1, 20000000000],
-    "fused_lanes": [0, 1, 2, 3], "fused_max": [1, 3, 8, 16], "wide": [0, 1], "wide_tables": [0, 1], "wide_compact": [0, 1],
+    "fused_lanes": [0, 1, 2, 3], "fused_max": [1, 3, 8, 16], "wide": [0, 1], "wide_tables": [0, 1], "wide_compact": [0, 1], "hard_overflow": [0, 1],
 }
 PUBLIC_CHOICES = {"TSIM_AMD_ADAPTIVE": ["0", "1"], "TSIM_AMD_FUSED_STEPS": ["0", "1"], "TSIM_AMD_DEEP_TABLES": ["-1", "0", "1"]}
 

@@ -196,8 +196,8 @@ def test_component_parallel_hard_rows_agree_with_one_block_per_row(hip, packed, 
 def test_tables_deepen_when_the_hard_rows_are_too_many_for_the_block_per_row_kernel(hip):
     """C3 at weight-5 tables leaves ~340 hard rows per 10^6 shots: too many for k_sample_hw (more than
     hard_wave_rows per eight launches), far below the 1 % of the dense rule.  A handle that has launched
-    deep_after (TSIM_AMD_TUNE) rows in that state (here: 1) builds the weight-6 tables; TSIM_AMD_DEEP_TABLES=-1 never does.
-    Same rows from both, before and after the build."""
+    deep_after (TSIM_AMD_TUNE) rows in that state (here: 1) builds the weight-6 tables - in the background, while the
+    weight-5 tables keep serving; TSIM_AMD_DEEP_TABLES=-1 never does.  Same rows from both, before, during and after the build."""
     import os
 
     B, n = 400_000, 8
@@ -219,6 +219,13 @@ def test_tables_deepen_when_the_hard_rows_are_too_many_for_the_block_per_row_ker
             o, k2 = _run_steps(hp, prog, fs, key, nf, packed=True)
             key = np.array(k2, dtype=np.uint32)
             outs += [o[0], o[n - 1]]
+        # the deeper tables are built in the background, one slice per launch plan (tsim_tables.hip): keep sampling
+        extra = 0
+        while "deep_after" in str(env) and hp.info()["pattern_max_weight"] == [5] and extra < 600:
+            _run_steps(hp, prog, fs[:2], key, nf, packed=True)
+            extra += 1
+        o, k2 = _run_steps(hp, prog, fs, key, nf, packed=True)
+        outs += [o[0], o[n - 1]]
         depths.append(hp.info()["pattern_max_weight"])
         runs.append(outs)
         hp.close()
@@ -243,6 +250,53 @@ def test_steps_with_shot_offset_and_dense_rows(hip):
             want = op.sample_program(fs[i], subs[i], shot_offset=off)
             np.testing.assert_array_equal(outs[i], np.packbits(want, axis=1, bitorder="little"), err_msg=f"p_bit {p_bit} batch {i}")
     hp.close()
+
+
+@pytest.mark.parametrize("name,dense", [("C2", 0.3), ("C2", 0.08), ("C4", 0.2)])
+def test_a_jump_of_the_noise_level_goes_through_the_overflow_grid_and_back(hip, name, dense):
+    """The launch plan follows the hard-row counts of EARLIER launches.  The first group after a jump from sparse to dense
+    batches therefore hands lists of thousands of rows to kernels sized for ten: they take the head of every list,
+    k_sample4_over (tsim_kernel4.hip.h) the rest - including, when it lies there, the row of the normalisation check
+    (sampler.py:66-72).  Afterwards the plan must find its way back to the fused first pass (the probe launch of a dense
+    phase).  Every phase against the oracle; the same rows with the overflow grid switched off (whole lists on the latency
+    kernels)."""
+    import os
+
+    prog, cfg = synth.config_program(name)
+    nf, B, n = cfg["num_f"], 40_000, 8
+    op = OC.OracleProgram(prog)
+    phases = [cfg["p_bit"], cfg["p_bit"], dense, dense, cfg["p_bit"], cfg["p_bit"], cfg["p_bit"], cfg["p_bit"]]
+    results = {}
+    for over in (1, 0):
+        os.environ["TSIM_AMD_TUNE"] = f"hard_overflow={over}"
+        try:
+            hp = hip.HipProgram(prog)
+        finally:
+            os.environ.pop("TSIM_AMD_TUNE", None)
+        hp.profile_set_sampling(1)
+        hp.profile_enable(2)
+        key = prng.key(77)
+        outs, fused_steps = [], []
+        for ph, p_bit in enumerate(phases):
+            fs = [synth.synth_f(B, nf, p_bit, seed=1000 * ph + i) for i in range(n)]
+            hp.profile_read_steps()
+            o, k2 = _run_steps(hp, prog, fs, key, nf, packed=True)
+            fused_steps.append(hp.profile_read_steps())
+            if over == 1:
+                _, subs = _subkeys(key, n)
+                for i in (0, n - 1):
+                    want = op.sample_program(fs[i], subs[i])
+                    np.testing.assert_array_equal(o[i], np.packbits(want, axis=1, bitorder="little"), err_msg=f"phase {ph} (p_bit {p_bit}) batch {i}")
+            key = np.array(k2, dtype=np.uint32)
+            outs.append(o)
+        hp.profile_enable(False)
+        hp.close()
+        results[over] = outs
+        assert fused_steps[1] == n and fused_steps[2] == n, f"the jump was not taken by a fused group: {fused_steps}"
+        assert fused_steps[-1] == n, f"the plan did not return to the fused first pass: {fused_steps}"
+    for a, b in zip(results[1], results[0]):
+        for x, y in zip(a, b):
+            np.testing.assert_array_equal(x, y)
 
 
 @pytest.mark.parametrize("num_f,n_direct,B,n", [(24, 24, 5000, 11), (64, 40, 70001, 9), (128, 128, 3000, 3), (100, 1, 257, 17), (7, 7, 1, 2)])

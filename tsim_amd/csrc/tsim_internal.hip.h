@@ -26,6 +26,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cmath>
+#include <chrono>
 #include <cstring>
 #include <new>
 #include <string>
@@ -99,6 +100,18 @@ using tsimk::SampleArgs;
 using tsimhost::FastGraph;
 using tsimhost::HostComponent;
 using tsimhost::HostLevel;
+
+struct TsimTablePlan {  // pattern tables of one depth: per component the deepest weight and the patterns, bytes of all
+  std::vector<int> wmax;
+  std::vector<long long> npat;
+  long long bytes = 0;
+};
+
+struct TsimBuildJob {  // the table build of one component, cut into slices of patterns
+  tsimk::LwBuildArgs a;
+  int W, n_out;
+  long long next_pat;
+};
 
 struct tsim_program {
   // description
@@ -229,6 +242,7 @@ struct tsim_program {
     int fused_max = 8;        // fused_max: batches per fused first pass (<= TSIMK_LWM_MAX_STEPS = 16)
     bool wide = true;         // wide=0: wide components on the row kernel alone
     bool wide_tables = true;  // wide_tables=0: no pattern tables in front of the wide kernels
+    bool hard_overflow = true; // hard_overflow=0: the latency kernels of a hard-row batch walk whole lists (no k_sample4_over behind them)
     bool wide_compact = true; // wide_compact=0: k_sample_wide keeps one 16-byte column table per graph even when all graphs fit one entry
     // fixed since round 4 (the experiments behind their switches are closed: DESIGN.md / HISTORY.md)
     bool hard_kernel = true;  // hard rows on k_sample4h, not k_sample4
@@ -259,6 +273,18 @@ struct tsim_program {
   unsigned long long deep_rows = 0;  // rows launched while the hard rows were too many for k_sample_hw (knobs.deep_after)
   long long lw_bytes = 0;
   uint32_t *d_lw_tab = nullptr;  // integer Bernoulli thresholds (tsimk::bernoulli_threshold)
+  // deeper tables being built in the background (tsim_tables_extend_begin / _poll)
+  int lw_shadow_off = 0;         // image offset of the shadow copy of the LW records the build works from
+  bool ext_pending = false;
+  hipStream_t ext_stream = nullptr;
+  hipEvent_t ext_ev = nullptr;
+  uint32_t *ext_tab = nullptr;
+  std::vector<void *> ext_scratch;
+  std::vector<TsimBuildJob> ext_jobs;  // one per component; launched slice by slice
+  size_t ext_job = 0;
+  int ext_slices = 0;
+  TsimTablePlan ext_plan;
+  std::chrono::steady_clock::time_point ext_t0;
   // device allocations handed out by tsim_malloc_device and not yet freed: the handle owns them
   std::unordered_set<void *> owned;
   // scratch (host-buffer API)
@@ -301,6 +327,8 @@ std::vector<uint32_t> emit_rotmask_program(const std::vector<std::array<int, 3>>
 bool tsim_tables_plan(tsim_program *p, int cap, long long budget);
 int tsim_tables_build(tsim_program *p, uint32_t **old);
 int tsim_tables_extend(tsim_program *p);
+int tsim_tables_extend_begin(tsim_program *p);
+int tsim_tables_extend_poll(tsim_program *p, bool wait);
 
 // ---- tsim_sample.hip
 int tsim_flush_hard(tsim_program *p);

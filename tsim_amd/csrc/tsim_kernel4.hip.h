@@ -259,6 +259,9 @@ __device__ __forceinline__ void eval_level4(const uint32_t *gimg, cptr img, cptr
   acc_finish4<FIXED>(S, lvl, approx, out_re, out_im);
 }
 
+template <int GT, int NCH>
+__device__ __forceinline__ void sample4_block(const SampleArgs &A, int comp4_off, long long row, bool active, bool check_block);
+
 // sample_program for one batch, LDS chunk-table formulation.  Requires every sampled component to
 // have at most 64 parameters (2 words of x) - checked by the packer (p->v4).
 template <int GT, int NCH>
@@ -301,6 +304,13 @@ k_sample4(Sample4Args A4) {
     row = 0;
     active = (threadIdx.x < 2);
   }
+  sample4_block<GT, NCH>(A, A4.comp4_off, row, active, check_block);
+}
+
+// the rows of one block (thread t: `row`, or idle) through every component: stage f, direct outputs, the levels, the stores
+template <int GT, int NCH>
+__device__ __forceinline__ void sample4_block(const SampleArgs &A, int comp4_off, long long row, bool active, bool check_block) {
+  const int nthr = blockDim.x;
   // normalisation check (sampler.py:66-72): lane 1 of the check block evaluates every level with
   // trial bit 0 while lane 0 evaluates it with trial bit 1 - one pass gives both values
   const bool trial0 = check_block && threadIdx.x == 1;
@@ -323,7 +333,7 @@ k_sample4(Sample4Args A4) {
   direct_outputs(A, img, lds_f, lds_o, nthr);
 
   for (int ci = 0; ci < A.n_comp; ++ci) {
-    cptr comp = img + A4.comp4_off + ci * C4_WORDS;
+    cptr comp = img + comp4_off + ci * C4_WORDS;
     const uint32_t n_out = comp[C_NOUT], F = comp[C_F];
     cptr fsel = img + comp[C_FSEL];
     cptr levels = img + comp[C4_LEVELS];
@@ -424,6 +434,53 @@ k_sample4(Sample4Args A4) {
         orow[w] = (uint64_t)lds_o[(2 * w) * nthr] | ((uint64_t)lds_o[(2 * w + 1) * nthr] << 32);
     }
     store_compact_row(A, row, lds_o, nthr);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Hard-row lists that turn out LONG (the launch plan follows the counts of EARLIER launches: the first group after a jump of
+// the noise level hands lists of 10^5 rows to kernels sized for 10): the latency kernels (k_sample_hw, k_sample4h_multi) take
+// the first `slot_begin` slots of every list, this grid everything behind them - 512 rows per block and step at the per-shot
+// kernel's rate, a fixed number of chip-resident blocks striding over (launch, list, chunk).  Rows are recomputed whole
+// (a row is a function of its f row, the key and the shot index), so it does not matter what the first pass left in them.
+// When no list is longer than slot_begin - every launch but that one - a block reads the counts and exits.
+// ---------------------------------------------------------------------------------------------------------------------
+#ifndef TSIMK_H_MAX_CTX
+#define TSIMK_H_MAX_CTX 8
+#endif
+struct Over4Multi {
+  int n_ctx, comp4_off;
+  uint32_t slot_begin;
+  int masked;  // 1: list entries carry component masks in their top four bits (partial rows of the fused first pass)
+  SampleArgs ctx[TSIMK_H_MAX_CTX];
+};
+
+template <int GT, int NCH>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(TSIMK_V4_WAVES, 8))) k_sample4_over(Over4Multi M) {
+  const uint32_t nthr = blockDim.x;
+  uint32_t pair = 0;
+  for (int c = 0; c < M.n_ctx; ++c) {
+    const SampleArgs &A = M.ctx[c];
+    for (int k = 0; k < A.row_lists; ++k, ++pair) {
+      const uint32_t n = A.row_count[32u * (uint32_t)k];
+      if (n <= M.slot_begin) continue;  // block-uniform
+      const uint32_t chunks = (n - M.slot_begin + nthr - 1u) / nthr;
+      const uint32_t check_row = (A.no_check || !A.check_row) ? 0xFFFFFFFFu : *A.check_row;
+      for (uint32_t q = (blockIdx.x + gridDim.x - pair % gridDim.x) % gridDim.x; q < chunks; q += gridDim.x) {
+        const uint32_t slot = M.slot_begin + q * nthr + threadIdx.x;
+        const bool active = slot < n;
+        uint32_t entry = active ? A.row_index[(size_t)k * A.row_list_cap + slot] : 0u;
+        if (M.masked) entry &= 0x0FFFFFFFu;
+        // the row of the normalisation check (sampler.py:66-72) landed behind the latency kernel's share: replayed here
+        const bool has_check = __syncthreads_or(active && entry == check_row) != 0;
+        sample4_block<GT, NCH>(A, M.comp4_off, (long long)entry, active, false);
+        __syncthreads();  // the staging columns are reused by the next chunk
+        if (has_check) {
+          sample4_block<GT, NCH>(A, M.comp4_off, (long long)check_row, threadIdx.x < 2u, true);
+          __syncthreads();
+        }
+      }
+    }
   }
 }
 

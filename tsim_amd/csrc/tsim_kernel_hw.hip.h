@@ -31,6 +31,7 @@ struct HwMulti {
   int comp_par;                       // 1, or the program's component count: the lists carry component masks (LwMultiArgs.partial) and
                                       // block (slot, c) evaluates component c of its row alone
   int par_words;                      // LDS words per bit array: one parity bit per row of the longest level stream, + spare (8 arrays per block)
+  uint32_t slot_cap;                  // the grid serves the first slot_cap slots of every list (0: all); k_sample4_over takes the rest
   uint32_t *feedback;                 // launch-plan feedback of the first context (see sample4h_rows)
   SampleArgs ctx[TSIMK_HW_MAX_CTX];
 };
@@ -450,7 +451,8 @@ __global__ void __launch_bounds__(256) k_sample_hw(HwMulti M) {
     }
   }
   if ((int)k >= A.row_lists) return;
-  const uint32_t n = A.row_count[32u * k];
+  uint32_t n = A.row_count[32u * k];
+  if (M.slot_cap) n = min(n, M.slot_cap);
   const uint32_t check_row = (A.no_check || !A.check_row) ? 0xFFFFFFFFu : *A.check_row;
   for (uint32_t slot = j; slot < n; slot += (uint32_t)M.waves_per_list) {  // block-uniform
     const uint32_t entry = A.row_index[(size_t)k * A.row_list_cap + slot];

@@ -93,6 +93,7 @@ struct LwBuildArgs {
   int wide_binom_off, bases_off, wmax;
   float *p1;                          // scratch [npat << n_out]: |amp| of every node (k_lw_nodes), node 0 = the normalisation
   int depth;                          // k_lw_nodes: -1 = the normalisation level, d = the nodes with d prefix bits
+  int pat_begin, pat_count;           // this launch serves patterns [pat_begin, pat_begin + pat_count) (pat_count 0: to npat) - a build in slices
 };
 
 // the pattern of table row `pat` as f_sel-position bits
@@ -155,8 +156,10 @@ __global__ void __launch_bounds__(256) k_lw_nodes(LwBuildArgs A) {
   const uint32_t n_out = comp[C_NOUT], F = comp[C_F];
   cptr levels = img + comp[C_LEVELS];
   const int d = A.depth;
-  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= ((long long)A.npat << (d < 0 ? 0 : d))) return;
+  const int dd = d < 0 ? 0 : d;
+  const long long tl = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (tl >= ((long long)(A.pat_count ? A.pat_count : A.npat - A.pat_begin) << dd)) return;
+  const long long t = ((long long)A.pat_begin << dd) + tl;
   const uint32_t pat = d < 0 ? (uint32_t)t : (uint32_t)(t >> d);
   const uint32_t prefix = d < 0 ? 0u : ((uint32_t)t & ((1u << d) - 1u));
   uint32_t x[W];
@@ -184,8 +187,9 @@ template <bool FAST>
 __global__ void __launch_bounds__(256) k_lw_finish(LwBuildArgs A) {
   cptr img = (cptr)(uintptr_t)A.img;
   const uint32_t n_out = (img + A.comp_off)[C_NOUT];
-  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= ((long long)A.npat << n_out)) return;
+  const long long tl = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (tl >= ((long long)(A.pat_count ? A.pat_count : A.npat - A.pat_begin) << n_out)) return;
+  const long long t = ((long long)A.pat_begin << n_out) + tl;
   const uint32_t node = (uint32_t)t & ((1u << n_out) - 1u);
   const float *row = A.p1 + (((size_t)t >> n_out) << n_out);
   if (node == 0u) {

@@ -239,6 +239,7 @@ extern "C" int tsim_program_finalize(tsim_program *p, int32_t device) {
     p->knobs.wide = tune_ll("wide", 1) != 0;
     p->knobs.wide_tables = tune_ll("wide_tables", 1) != 0;
     p->knobs.wide_compact = tune_ll("wide_compact", 1) != 0;
+    p->knobs.hard_overflow = tune_ll("hard_overflow", 1) != 0;
   }
 
   // ---- choose the evaluation formulation ----
@@ -927,6 +928,11 @@ retry_pack:
       }
     }
   }
+  if (p->lw) {  // shadow copy of the LW records: what a table build in the background unranks from (tsim_tables.hip)
+    while (img.size() % 32) img.push_back(0u);
+    p->lw_shadow_off = (int)img.size();
+    img.resize(img.size() + p->comps.size() * LW_WORDS, 0u);
+  }
   img.resize(img.size() + 256, 0u);  // tail padding: wide scalar loads may over-read
   if (img.size() >= (1ull << 31)) return tsim_fail(TSIM_ENOTSUP, "program image too large");
 
@@ -951,6 +957,10 @@ retry_pack:
   if (p->lw) {
     if (int r = tsim_tables_build(p, nullptr)) return r;
     if (int r = alloc_feedback(p)) return r;
+    if (p->lw_cap_now < p->lw_cap_max) {  // deeper tables may be built in the background later: their stream now (creating one takes milliseconds)
+      HIP_TRY(hipStreamCreateWithFlags(&p->ext_stream, hipStreamNonBlocking));
+      HIP_TRY(hipEventCreateWithFlags(&p->ext_ev, hipEventDisableTiming));
+    }
   }
   p->finalized = true;
   return TSIM_OK;
@@ -977,8 +987,13 @@ extern "C" void tsim_program_destroy(tsim_program *p) {
       if (s) (void)hipFree(s);
     for (void *q : p->owned) (void)hipFree(q);  // buffers the caller never returned
     p->owned.clear();
+    if (p->ext_pending) (void)hipStreamSynchronize(p->ext_stream);  // a table build in the background reads the image
     if (p->d_img) (void)hipFree(p->d_img);
     if (p->d_dev) (void)hipFree(p->d_dev);
+    for (void *q : p->ext_scratch) (void)hipFree(q);
+    if (p->ext_tab) (void)hipFree(p->ext_tab);
+    if (p->ext_ev) (void)hipEventDestroy(p->ext_ev);
+    if (p->ext_stream) (void)hipStreamDestroy(p->ext_stream);
     if (p->d_lw_tab) (void)hipFree(p->d_lw_tab);
     if (p->h_feedback) (void)hipHostFree((void *)p->h_feedback);
     for (auto &sl : p->slots) {

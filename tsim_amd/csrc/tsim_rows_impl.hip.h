@@ -50,7 +50,7 @@ int TSIM_ROWS_NAME(lw_build)(int W, const LwBuildArgs &a0, int n_out, hipStream_
   for (int d = -1; d < n_out; ++d) {
     LwBuildArgs a = a0;
     a.depth = d;
-    const long long lanes = (long long)a.npat << (d < 0 ? 0 : d);
+    const long long lanes = (long long)(a.pat_count ? a.pat_count : a.npat - a.pat_begin) << (d < 0 ? 0 : d);
     const dim3 grid((unsigned)((lanes + 255) / 256));
     switch (W) {
 #define TSIM_X(WV)                                                                                 \
@@ -63,7 +63,7 @@ int TSIM_ROWS_NAME(lw_build)(int W, const LwBuildArgs &a0, int n_out, hipStream_
     }
     HIP_TRY(hipGetLastError());
   }
-  const long long lanes = (long long)a0.npat << n_out;
+  const long long lanes = (long long)(a0.pat_count ? a0.pat_count : a0.npat - a0.pat_begin) << n_out;
   hipLaunchKernelGGL((k_lw_finish<TSIM_ROWS_FAST>), dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, s, a0);
   HIP_TRY(hipGetLastError());
   return 0;

@@ -127,6 +127,11 @@ struct LaunchPlan {
 static LaunchPlan make_plan(tsim_program *p, bool has_row_index, bool pipelined, unsigned long long rows) {
   LaunchPlan pl;
   pl.use_tables = p->lw;
+  // deeper tables built in the background (tsim_tables_extend_begin) are done: swap them in - the lanes drain, ~0.1 ms
+  if (p->ext_pending && tsim_tables_extend_poll(p, false) == 1 && p->h_feedback) {
+    for (int i = 0; i < 8; ++i) p->h_feedback[i] = 0xFFFFFFFFu;  // the old counts describe the old tables
+    p->lw_direct_left = 0;
+  }
   if (p->lw && p->lw_wide && p->wr_off != 0 && p->knobs.wide_fused && p->knobs.wide && !has_row_index) {
     // One wide component (k_sample_wide): the kernel serves every row itself - nothing here decides coverage.  Two things
     // follow its statistics (block 0's share of the last launch): a deeper table when many rows miss the current one
@@ -153,8 +158,12 @@ static LaunchPlan make_plan(tsim_program *p, bool has_row_index, bool pipelined,
         p->lw_dense_launches = (double)missed > 0.2 * (double)fb_rows ? p->lw_dense_launches + 1 : 0;
         if (p->lw_dense_launches >= 3) {
           p->lw_dense_launches = 0;
-          if (tsim_synchronize(p) == TSIM_OK && tsim_tables_extend(p) == TSIM_OK)
-            for (int i = 4; i < 8; ++i) p->h_feedback[i] = 0xFFFFFFFFu;
+          if (p->knobs.deep_tables == 1) {  // asked for by name: now, with the one stall that costs
+            if (tsim_synchronize(p) == TSIM_OK && tsim_tables_extend(p) == TSIM_OK)
+              for (int i = 4; i < 8; ++i) p->h_feedback[i] = 0xFFFFFFFFu;
+          } else {
+            (void)tsim_tables_extend_begin(p);  // in the background, slice by slice; make_plan's poll puts them in place
+          }
         }
       }
     }
@@ -183,22 +192,29 @@ static LaunchPlan make_plan(tsim_program *p, bool has_row_index, bool pipelined,
       p->lw_dense_launches = ((double)fb_sum > 0.01 * (double)fb_rows || too_many_for_hw) ? p->lw_dense_launches + 1 : 0;
       if (p->lw_dense_launches >= 3) {
         p->lw_dense_launches = 0;
-        if (tsim_synchronize(p) == TSIM_OK && tsim_tables_extend(p) == TSIM_OK) {
-          for (int i = 0; i < 3; ++i) p->h_feedback[i] = 0xFFFFFFFFu;  // the old counts describe the old tables
-          p->lw_direct_left = 0;
-          known = false;
+        if (p->knobs.deep_tables == 1) {  // asked for by name: now, with the one stall that costs
+          if (tsim_synchronize(p) == TSIM_OK && tsim_tables_extend(p) == TSIM_OK) {
+            for (int i = 0; i < 3; ++i) p->h_feedback[i] = 0xFFFFFFFFu;  // the old counts describe the old tables
+            p->lw_direct_left = 0;
+            known = false;
+          }
+        } else {
+          (void)tsim_tables_extend_begin(p);  // in the background, slice by slice; the poll at the top puts them in place
         }
       }
     }
     // Many hard rows: they are throughput work for the full kernel, not latency work for the 8-waves-per-group one
     pl.hard_kernel = !(known && fb_sum > 16384u);
     bool dense = false;
-    if (p->lw_direct_left > 0) {
+    if (p->lw_direct_left > 0 && known && (double)fb_sum <= 0.5 * (double)fb_rows) {
+      p->lw_direct_left = 0;  // the probe's counts have arrived and say "sparse again": back to the tables now
+    } else if (p->lw_direct_left > 0) {
       --p->lw_direct_left;
       pl.use_tables = false;
     } else if (known && (double)fb_sum > 0.5 * (double)fb_rows && !has_row_index) {
-      p->lw_direct_left = 15;  // this launch is the probe
-      dense = true;
+      p->lw_direct_left = 15;  // this launch is the probe; the full-kernel launches behind it write no counts, so
+      dense = true;            // "unknown" until the probe has run, then its verdict (above)
+      for (int i = 0; i < 3; ++i) p->h_feedback[i] = 0xFFFFFFFFu;
     }
     if (known && fb_max <= 192u) pl.need_overflow = false;
     pl.fb_max = known ? fb_max : 0xFFFFFFFFu;
@@ -217,6 +233,8 @@ static LaunchPlan make_plan(tsim_program *p, bool has_row_index, bool pipelined,
   }
   return pl;
 }
+
+static thread_local const LaunchPlan *g_carry_plan = nullptr;  // a plan drawn by the caller of tsim_sample_batch_device_begin
 
 // k_sample4h geometry (LDS budget -> tiles per group), 0 tiles = the kernel cannot run this program
 static void hard_geometry(tsim_program *p, int WF, int WO) {
@@ -240,6 +258,38 @@ static bool hw_eligible(tsim_program *p, const SampleArgs &a, int n_ctx) {
   return p->fast && p->knobs.hard_wave && wmax <= 2 && a.WF <= 32 && a.WO <= 2 && p->hw_max_rows < 60000 &&
          (unsigned long long)fb_rows * (unsigned)n_ctx <= (unsigned long long)p->knobs.hard_wave_rows;
 }
+// Behind the latency kernels of a hard-row batch: the list slots they left (k_sample4_over, tsim_kernel4.hip.h).  A fixed
+// grid of chip-resident blocks; when every list ends before `slot_begin` - all launches but the first after a jump of
+// the noise level - they read the counts and exit (~3 us on the batch's stream).
+static int launch_over(tsim_program *p, const SampleArgs *ctx, int n_ctx, uint32_t slot_begin, bool masked, hipStream_t hs) {
+  Over4Multi M{};
+  M.n_ctx = n_ctx;
+  M.comp4_off = p->comp4_off;
+  M.slot_begin = slot_begin;
+  M.masked = masked ? 1 : 0;
+  for (int i = 0; i < n_ctx; ++i) {
+    M.ctx[i] = ctx[i];
+    M.ctx[i].kernarg_off = (int)(offsetof(Over4Multi, ctx) + (size_t)i * sizeof(SampleArgs));
+    M.ctx[i].row_slot_begin = 0;
+    M.ctx[i].row_slot_end = 0;
+  }
+  const int blk = p->knobs.v4_block;
+  const size_t tile_bytes = std::max((size_t)p->v4_max_nch * 16, (size_t)p->v4_max_sent) * p->v4_gt * 16;
+  const size_t lds4 = (size_t)(2 * ctx[0].WF + 2 * ctx[0].WO) * blk * 4 + 2 * tile_bytes;
+  if (lds4 > 64 * 1024) return tsim_fail(TSIM_ENOTSUP, "v4 kernel needs %zu B of LDS", lds4);
+  const unsigned grid = (unsigned)(2 * p->n_cu);
+  switch (p->v4_max_nch) {
+#define TSIM_LO(N) case N: hipLaunchKernelGGL((k_sample4_over<4, N>), dim3(grid), dim3(blk), lds4, hs, M); break;
+    TSIM_LO(2) TSIM_LO(4) TSIM_LO(6) TSIM_LO(8) TSIM_LO(10) TSIM_LO(12) TSIM_LO(14)
+#undef TSIM_LO
+    default: hipLaunchKernelGGL((k_sample4_over<4, 16>), dim3(grid), dim3(blk), lds4, hs, M); break;
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+// the per-shot overflow grid exists for this program (chunk tables) and is not switched off
+static bool over_available(const tsim_program *p) { return p->v4 && p->knobs.hard_overflow; }
+
 static int launch_hw(tsim_program *p, const SampleArgs *ctx, int n_ctx, int max_lists, hipStream_t hs, bool partial) {
   int wmax = 1;
   for (int w : p->comp_w) wmax = std::max(wmax, w);
@@ -256,6 +306,8 @@ static int launch_hw(tsim_program *p, const SampleArgs *ctx, int n_ctx, int max_
     H.ctx[i].kernarg_off = (int)(offsetof(HwMulti, ctx) + (size_t)i * sizeof(SampleArgs));
   }
   H.comp_par = partial ? (int)p->comps.size() : 1;  // the lists carry component masks: one block per (row, component)
+  // each block takes at most four turns; k_sample4_over serves what lies behind them (lists sized by STALE counts)
+  H.slot_cap = over_available(p) ? (uint32_t)H.waves_per_list * 4u : 0u;
   const unsigned gridw = (unsigned)((long long)H.n_ctx * H.max_lists * H.waves_per_list * H.comp_par);
   H.par_words = (int)(2 * ((p->hw_max_rows + 63) / 64) + 2);
   const size_t ldsw = (size_t)H.par_words * 8 * 4 + 16;  // two buffers of four bit arrays (previous bit x trial bit) + the sampled bit.s word
@@ -264,6 +316,7 @@ static int launch_hw(tsim_program *p, const SampleArgs *ctx, int n_ctx, int max_
   if (wmax == 1) hipLaunchKernelGGL(k_sample_hw<1>, dim3(gridw), dim3(256), ldsw, hs, H);
   else hipLaunchKernelGGL(k_sample_hw<2>, dim3(gridw), dim3(256), ldsw, hs, H);
   HIP_TRY(hipGetLastError());
+  if (H.slot_cap) return launch_over(p, ctx, n_ctx, H.slot_cap, partial, hs);
   return 0;
 }
 
@@ -324,6 +377,9 @@ static int flush_batch(tsim_program *p) {
   if (partial || hw_eligible(p, M.ctx[0], M.n_ctx)) {
     if (int r = launch_hw(p, M.ctx, M.n_ctx, max_lists, hs, partial)) return r;
   } else {
+  // (each block walks its list in strides of hb * 64 slots: at most 16 of them, the rest is k_sample4_over's)
+  const uint32_t cap4h = over_available(p) ? (uint32_t)M.loop_stride * 16u : 0u;
+  for (int i = 0; i < M.n_ctx; ++i) M.ctx[i].row_slot_end = (int)cap4h;
   const unsigned grid = (unsigned)(M.n_ctx * M.blocks_per_ctx);
   switch (p->v4_max_nch) {
 #define TSIM_LHM(N)                                                                                          \
@@ -339,6 +395,8 @@ static int flush_batch(tsim_program *p) {
   }
   HIP_TRY(hipGetLastError());
   p->hm_attr_set = true;
+  if (cap4h)
+    if (int r = launch_over(p, M.ctx, M.n_ctx, cap4h, false, hs)) return r;
   }
   ++p->stat_flushes;
   hipEvent_t &be = p->batch_ev[seq % 16u];
@@ -877,7 +935,8 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
         const size_t ldsh = p->h_lds;
         const long long gridh = (long long)kHardBlocks * nlists + a4.has_check;
         Sample4Args ah = a4;
-        ah.s.row_slot_end = need_overflow ? kHardBlocks * 64 : 0;
+        const int cap1 = over_available(p) ? kHardBlocks * 64 * 16 : 0;  // without an overflow launch: 16 strides, then k_sample4_over
+        ah.s.row_slot_end = need_overflow ? kHardBlocks * 64 : cap1;
         const int loop_stride = need_overflow ? 0 : kHardBlocks * 64;
         switch (p->v4_max_nch) {
 #define TSIM_LH(N)                                                                                          \
@@ -899,6 +958,8 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
         a4.s.no_check = 1;
         a4.s.row_slot_begin = kHardBlocks * 64;
         B2 = need_overflow ? std::max<long long>(0, B2 - kHardBlocks * 64) : 0;
+        if (!need_overflow && cap1)
+          if (int r = launch_over(p, &a, 1, (uint32_t)cap1, false, s)) return r;
       }
     }
     const long long grid4 = (B2 + blk - 1) / blk * nlists + a4.has_check;
@@ -950,6 +1011,9 @@ static int slot_order_after_previous(tsim_program *p, tsim_program::Slot &sl, hi
 extern "C" int tsim_sample_batch_device_begin(tsim_program *p, int32_t slot, const uint64_t *d_f, int64_t B,
                                               int32_t num_f, uint32_t key_hi, uint32_t key_lo, int64_t shot_offset,
                                               uint64_t *d_out, float *d_max_norm_dev, void *stream, uint32_t flags) {
+  const bool carried = g_carry_plan != nullptr;
+  const LaunchPlan carried_plan = carried ? *g_carry_plan : LaunchPlan{};
+  g_carry_plan = nullptr;
   if (int r = tsim_need_final(p)) return r;
   if (int r = tsim_set_device(p)) return r;
   if (slot < 0 || slot >= TSIM_PIPELINE_SLOTS) return tsim_fail(TSIM_EINVAL, "slot %d out of range", slot);
@@ -971,7 +1035,9 @@ extern "C" int tsim_sample_batch_device_begin(tsim_program *p, int32_t slot, con
   // waits for a second pass before it starts the next first pass.
   if (sl.deferred)  // begin twice without end: finish the earlier launch's hard rows first
     if (int r = tsim_flush_hard(p)) return r;
-  const LaunchPlan plan = make_plan(p, false, true, (unsigned long long)B);
+  // (tsim_sample_steps_device has already drawn the plan of this launch: drawing it twice would count the launch twice
+  // and swallow the probe that leads a dense phase back to the tables)
+  const LaunchPlan plan = carried ? carried_plan : make_plan(p, false, true, (unsigned long long)B);
   hipStream_t s = plan.defer ? p->slots[1 + (slot & 1)].side : sl.side;
   if (!plan.defer) {
     // the slot's own stream: tsim_pipeline_wait_stream orders only streams that carried work before - a first launch here
@@ -1367,6 +1433,8 @@ extern "C" int tsim_sample_steps_device(tsim_program *p, int32_t n_steps, const 
       continue;
     }
     // one wide component: groups of batches through k_sample_wide (bit_packed rows must be dwords)
+    LaunchPlan wide_plan;
+    bool have_wide_plan = false;
     if (p->knobs.fused_steps && wide_applies(p, B, num_f, shot_offset) && p->series_left == 0) {
       const int left = n_steps - done;
       const int gmax = std::min(TSIMK_LWM_MAX_STEPS, p->knobs.fused_max);
@@ -1394,9 +1462,16 @@ extern "C" int tsim_sample_steps_device(tsim_program *p, int32_t n_steps, const 
           done += n;
           continue;
         }
+        wide_plan = wplan;
+        have_wide_plan = true;
       }
     }
     LaunchPlan plan;
+    bool have_plan = false;
+    if (have_wide_plan) {
+      plan = wide_plan;
+      have_plan = true;
+    }
     if (fused) {
       if (!p->slots_ready) {  // as in _begin: every slot's stream / buffers now, not mid-run
         const size_t hard_bytes = (size_t)(((B + 255) / 256 + TSIMK_LW_LISTS - 1) / TSIMK_LW_LISTS * 1024) * TSIMK_LW_LISTS * 4;
@@ -1407,6 +1482,7 @@ extern "C" int tsim_sample_steps_device(tsim_program *p, int32_t n_steps, const 
       plan = make_plan(p, false, true, (unsigned long long)std::min(n_steps - done, std::min(TSIMK_LWM_MAX_STEPS, p->knobs.fused_max)) * (unsigned long long)B);
       hard_geometry(p, WF, WO);
       TSIM_MARK("plan");
+      have_plan = true;
       fused = plan.defer && plan.use_tables && p->h_group_tiles >= 1;
     }
     if (fused) {
@@ -1433,6 +1509,7 @@ extern "C" int tsim_sample_steps_device(tsim_program *p, int32_t n_steps, const 
       tsim_key_split(key[0], key[1], o);
       key[0] = o[0];
       key[1] = o[1];
+      g_carry_plan = have_plan ? &plan : nullptr;
       if (int r = tsim_sample_batch_device_begin(p, slot, d_f[done], B, num_f, o[2], o[3], shot_offset, (uint64_t *)d_out[done],
                                                  d_max_norm_dev ? d_max_norm_dev[done] : nullptr, nullptr, flags))
         return r;

@@ -23,12 +23,13 @@ static long long binom(long long n, int k) {
   return r;
 }
 
-// Fill p->lw_wmax / lw_npat / lw_bytes and the LW records' depth-dependent words for tables up to weight `cap`
-// within `budget` bytes per component (4 x that per program).  Returns false if some component gets no table.
-bool tsim_tables_plan(tsim_program *p, int cap, long long budget) {
+// The depth-dependent words of the LW records at image offset `rec_off` (the live records at p->lw_off, or their
+// shadow copy at p->lw_shadow_off that a build in the background works from) for tables up to weight `cap` within
+// `budget` bytes per component (4 x that per program).  Returns false if some component gets no table.
+bool tsim_tables_plan_at(tsim_program *p, int cap, long long budget, int rec_off, TsimTablePlan &out) {
   std::vector<uint32_t> &img = p->img;
-  p->lw_wmax.clear();
-  p->lw_npat.clear();
+  out.wmax.clear();
+  out.npat.clear();
   long long tab_off = 0;
   for (size_t ci = 0; ci < p->comps.size(); ++ci) {
     const HostComponent &c = p->comps[ci];
@@ -45,17 +46,29 @@ bool tsim_tables_plan(tsim_program *p, int cap, long long budget) {
       wmax = w;
     }
     if (wmax < 0) return false;
-    uint32_t *r = &img[p->lw_off + ci * LW_WORDS];
+    uint32_t *r = &img[(size_t)rec_off + ci * LW_WORDS];
     r[LW_WMAX] = (uint32_t)wmax;
     r[LW_TAB] = (uint32_t)tab_off;
     r[LW_NPAT] = (uint32_t)npat;
-    memcpy(&img[r[LW_BASES]], bases, sizeof bases);
-    p->lw_wmax.push_back(wmax);
-    p->lw_npat.push_back(npat);
+    memcpy(r + LW_BASES_INLINE, bases, sizeof bases);  // (LW_BASES of the live record points at these words)
+    out.wmax.push_back(wmax);
+    out.npat.push_back(npat);
     tab_off += npat << c.n_out;
     tab_off = (tab_off + 31) & ~31ll;  // 128-byte lines: the first pass reads a node's subtree as 8- and 16-byte words
   }
-  p->lw_bytes = tab_off * 4;
+  out.bytes = tab_off * 4;
+  return true;
+}
+
+// the live records (finalize): p->lw_wmax / lw_npat / lw_bytes follow
+bool tsim_tables_plan(tsim_program *p, int cap, long long budget) {
+  TsimTablePlan t;
+  p->lw_wmax.clear();
+  p->lw_npat.clear();
+  if (!tsim_tables_plan_at(p, cap, budget, p->lw_off, t)) return false;
+  p->lw_wmax = t.wmax;
+  p->lw_npat = t.npat;
+  p->lw_bytes = t.bytes;
   return true;
 }
 
@@ -80,41 +93,63 @@ static void enumerate_patterns(int F, int wmax, std::vector<unsigned long long> 
   }
 }
 
-// Allocate and fill the tables for the current plan (p->lw_wmax); the previous buffer, if any, is returned in
-// *old (the caller frees it once nothing in flight reads it).
-int tsim_tables_build(tsim_program *p, uint32_t **old) {
+// Allocate and fill the tables of plan `t`, whose records lie at image offset `rec_off` (host image; the device image must
+// hold them too), on stream `s`.  wait: return when they are built (scratch freed); otherwise the kernels are queued and
+// the scratch buffers handed back in `scratch` (the caller frees them once `s` has passed them).
+static int tables_build_at(tsim_program *p, int rec_off, const TsimTablePlan &t, hipStream_t s, bool wait, uint32_t **tab_out,
+                           std::vector<void *> &scratch, std::vector<TsimBuildJob> *jobs = nullptr) {
   uint32_t *tab = nullptr;
-  const auto t_start = std::chrono::steady_clock::now();
-  hipError_t me = hipMalloc((void **)&tab, std::max<size_t>(16, (size_t)p->lw_bytes));
-  if (me != hipSuccess) return tsim_fail(TSIM_ENOMEM, "hipMalloc(%lld) for the pattern tables failed: %s", p->lw_bytes, hipGetErrorString(me));
+  hipError_t me = hipMalloc((void **)&tab, std::max<size_t>(16, (size_t)t.bytes));
+  if (me != hipSuccess) return tsim_fail(TSIM_ENOMEM, "hipMalloc(%lld) for the pattern tables failed: %s", t.bytes, hipGetErrorString(me));
   for (size_t ci = 0; ci < p->comps.size(); ++ci) {
     const HostComponent &c = p->comps[ci];
-    const long long tab_off = (long long)p->img[p->lw_off + ci * LW_WORDS + LW_TAB];
+    const long long tab_off = (long long)p->img[(size_t)rec_off + ci * LW_WORDS + LW_TAB];
     // (no pattern list: the build kernels unrank the row index, narrow components on lw_rank_term, wide ones in
     // the binomial table - the host enumeration + copy of 14 million patterns cost as much as the kernels)
-    const long long lanes = p->lw_npat[ci] << c.n_out;
+    const long long lanes = t.npat[ci] << c.n_out;
     float *p1 = nullptr;
-    hipError_t e = hipMalloc((void **)&p1, std::max<size_t>(16, (size_t)lanes * 4));  // node values, freed below
+    hipError_t e = hipMalloc((void **)&p1, std::max<size_t>(16, (size_t)lanes * 4));  // node values
     LwBuildArgs a;
     a.img = p->d_img;
     a.patbits = nullptr;
     a.wide_binom_off = p->lw_wide ? p->lw_binom_off : 0;
-    a.bases_off = p->lw_off + (int)ci * LW_WORDS + LW_BASES_INLINE;
-    a.wmax = p->lw_wmax[ci];
+    a.bases_off = rec_off + (int)ci * LW_WORDS + LW_BASES_INLINE;
+    a.wmax = t.wmax[ci];
     a.tab = tab + tab_off;
     a.comp_off = p->comp_off + (int)ci * C_WORDS;
-    a.npat = (int)p->lw_npat[ci];
+    a.npat = (int)t.npat[ci];
     a.p1 = p1;
     a.depth = -1;
+    a.pat_begin = 0;
+    a.pat_count = 0;
     int r = 0;
-    if (e == hipSuccess) r = tsim_launch_lw_build(p->comp_w[ci], p->fast, a, c.n_out, p->stream);
-    if (e == hipSuccess && r == 0) e = hipStreamSynchronize(p->stream);
-    if (p1) (void)hipFree(p1);
+    if (e == hipSuccess && jobs) jobs->push_back(TsimBuildJob{a, p->comp_w[ci], c.n_out, 0});  // launched slice by slice (tsim_tables_extend_poll)
+    else if (e == hipSuccess) r = tsim_launch_lw_build(p->comp_w[ci], p->fast, a, c.n_out, s);
+    if (e == hipSuccess && r == 0 && wait) e = hipStreamSynchronize(s);
+    if (p1 && (wait || r || e != hipSuccess)) (void)hipFree(p1);
+    else if (p1) scratch.push_back(p1);
     if (r || e != hipSuccess) {
+      if (!wait) (void)hipStreamSynchronize(s);  // kernels of earlier components may still write
+      for (void *q : scratch) (void)hipFree(q);
+      scratch.clear();
       (void)hipFree(tab);
       return r ? r : tsim_fail(TSIM_EHIP, "pattern table build failed: %s", hipGetErrorString(e));
     }
   }
+  *tab_out = tab;
+  return 0;
+}
+
+// the tables of the current plan (finalize): built when this returns
+int tsim_tables_build(tsim_program *p, uint32_t **old) {
+  const auto t_start = std::chrono::steady_clock::now();
+  TsimTablePlan t;
+  t.wmax = p->lw_wmax;
+  t.npat = p->lw_npat;
+  t.bytes = p->lw_bytes;
+  uint32_t *tab = nullptr;
+  std::vector<void *> scratch;
+  if (int r = tables_build_at(p, p->lw_off, t, p->stream, true, &tab, scratch)) return r;
   if (old) *old = p->d_lw_tab;
   p->d_lw_tab = tab;
   static const bool timing = tsim_debug("tables");
@@ -124,42 +159,105 @@ int tsim_tables_build(tsim_program *p, uint32_t **old) {
   return 0;
 }
 
-// Deepen the tables to the largest weight the budget allows (called by the launch planner between launches,
-// with every lane idle: the records in the device image are rewritten).
-int tsim_tables_extend(tsim_program *p) {
-  if (!p->lw || p->lw_cap_now >= p->lw_cap_max) return 0;
-  // The component records in the device image are rewritten below and the old table is freed: nothing may be in
-  // flight - not on the handle's lanes (the planner drained them) and not on a stream the CALLER passed to the
-  // device entry points either (include/tsim_hip.h lets it).  Once per handle.
-  HIP_TRY(hipDeviceSynchronize());
-  const std::vector<int> before = p->lw_wmax;
-  const std::vector<long long> npat_before = p->lw_npat;
-  const long long bytes_before = p->lw_bytes;
-  std::vector<uint32_t> saved(p->img.begin() + p->lw_off, p->img.begin() + p->lw_off + p->comps.size() * LW_WORDS);
-  p->lw_cap_now = p->lw_cap_max;
-  if (!tsim_tables_plan(p, p->lw_cap_max, p->lw_budget) || p->lw_wmax == before) {
-    // nothing to gain (budget): restore the plan, never ask again
-    std::copy(saved.begin(), saved.end(), p->img.begin() + p->lw_off);
-    p->lw_wmax = before;
-    p->lw_npat = npat_before;
-    p->lw_bytes = bytes_before;
-    return 0;
-  }
-  uint32_t *old = nullptr;
-  const size_t rec_bytes = p->comps.size() * LW_WORDS * 4;
-  // the build kernels unrank with the NEW bases, read from the device image (every lane is idle)
-  HIP_TRY(hipMemcpy(p->d_img + p->lw_off, p->img.data() + p->lw_off, rec_bytes, hipMemcpyHostToDevice));
-  if (int r = tsim_tables_build(p, &old)) {  // e.g. out of memory: keep what we have
-    (void)r;
-    std::copy(saved.begin(), saved.end(), p->img.begin() + p->lw_off);
-    (void)hipMemcpy(p->d_img + p->lw_off, p->img.data() + p->lw_off, rec_bytes, hipMemcpyHostToDevice);
-    p->lw_wmax = before;
-    p->lw_npat = npat_before;
-    p->lw_bytes = bytes_before;
+// Deepen the tables to the largest weight the budget allows, in the background: the launch planner calls _begin when the
+// hard-row feedback says deeper tables would pay and polls at every later plan.  The new tables are built on a stream of
+// their own from a SHADOW copy of the component records (the build kernels unrank with the new bases; the sampling kernels
+// in flight keep the live records and the current tables), so nothing waits for the 4-60 ms of build kernels.  When
+// they are done the poll swaps: every lane drained (what is in flight reads the old records), the live records rewritten,
+// the table pointer exchanged, the old table freed - a fraction of a millisecond.
+int tsim_tables_extend_begin(tsim_program *p) {
+  if (!p->lw || p->lw_cap_now >= p->lw_cap_max || p->ext_pending) return 0;
+  p->lw_cap_now = p->lw_cap_max;  // asked once
+  const size_t rec_words = p->comps.size() * LW_WORDS;
+  std::copy(p->img.begin() + p->lw_off, p->img.begin() + p->lw_off + (long)rec_words, p->img.begin() + p->lw_shadow_off);
+  TsimTablePlan t;
+  if (!tsim_tables_plan_at(p, p->lw_cap_max, p->lw_budget, p->lw_shadow_off, t) || t.wmax == p->lw_wmax) return 0;  // nothing to gain (budget)
+  if (!p->ext_stream) HIP_TRY(hipStreamCreateWithFlags(&p->ext_stream, hipStreamNonBlocking));
+  if (!p->ext_ev) HIP_TRY(hipEventCreateWithFlags(&p->ext_ev, hipEventDisableTiming));
+  p->ext_t0 = std::chrono::steady_clock::now();
+  HIP_TRY(hipMemcpyAsync(p->d_img + p->lw_shadow_off, p->img.data() + p->lw_shadow_off, rec_words * 4, hipMemcpyHostToDevice, p->ext_stream));
+  p->ext_jobs.clear();
+  if (int r = tables_build_at(p, p->lw_shadow_off, t, p->ext_stream, false, &p->ext_tab, p->ext_scratch, &p->ext_jobs)) {
+    (void)r;  // e.g. out of memory: keep what we have
     (void)hipGetLastError();
     return 0;
   }
-  HIP_TRY(hipMemcpy(p->d_img + p->lw_off, p->img.data() + p->lw_off, p->comps.size() * LW_WORDS * 4, hipMemcpyHostToDevice));
-  if (old) HIP_TRY(hipFree(old));
+  p->ext_job = 0;
+  p->ext_slices = 0;
+  p->ext_plan = t;
+  p->ext_pending = true;
+  static const bool timing = tsim_debug("tables");
+  if (timing)
+    fprintf(stderr, "[tsim] pattern tables: build of %.1f MB prepared in %.2f ms of host time\n", (double)t.bytes / 1e6,
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - p->ext_t0).count());
   return 0;
+}
+
+// 1: the deeper tables are in place (the caller forgets the feedback of the old ones); 0: nothing changed
+int tsim_tables_extend_poll(tsim_program *p, bool wait) {
+  if (!p->ext_pending) return 0;
+  // The build goes out in slices of ~4 million table entries (a fraction of a millisecond of the whole chip), the next one
+  // when the one before is done: whatever the sampling lanes launch meanwhile shares the chip with ONE slice, not with
+  // 4-60 ms of queued build kernels (all at once, a first pass waited 8-18 ms for wave slots: its 512-thread blocks with
+  // their LDS do not fit into the slots that 256-thread build blocks free one by one - at lower stream priority too;
+  // confined to 64 CUs by a mask the build slowed the chip-resident first passes tenfold for its whole, longer, duration).
+  while (p->ext_job < p->ext_jobs.size()) {
+    if (!wait && p->ext_slices > 0 && hipEventQuery(p->ext_ev) != hipSuccess) {
+      (void)hipGetLastError();
+      return 0;
+    }
+    TsimBuildJob &j = p->ext_jobs[p->ext_job];
+    tsimk::LwBuildArgs a = j.a;
+    const long long per = std::max<long long>(1, (4ll << 20) >> j.n_out);
+    a.pat_begin = (int)j.next_pat;
+    a.pat_count = (int)std::min<long long>(per, (long long)a.npat - j.next_pat);
+    if (int r = tsim_launch_lw_build(j.W, p->fast, a, j.n_out, p->ext_stream)) return r;
+    HIP_TRY(hipEventRecord(p->ext_ev, p->ext_stream));
+    ++p->ext_slices;
+    j.next_pat += a.pat_count;
+    if (j.next_pat >= (long long)a.npat) ++p->ext_job;
+    if (!wait) return 0;  // one slice per poll
+  }
+  if (wait) {
+    HIP_TRY(hipEventSynchronize(p->ext_ev));
+  } else if (hipEventQuery(p->ext_ev) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  p->ext_pending = false;
+  // The component records in the device image are rewritten below and the old table is freed: nothing may be in
+  // flight - not on the handle's lanes and not on a stream the CALLER passed to the device entry points either
+  // (include/tsim_hip.h lets it).  Once per handle.
+  HIP_TRY(hipDeviceSynchronize());
+  const size_t rec_words = p->comps.size() * LW_WORDS;
+  for (size_t ci = 0; ci < p->comps.size(); ++ci) {
+    const uint32_t *sh = &p->img[(size_t)p->lw_shadow_off + ci * LW_WORDS];
+    uint32_t *r = &p->img[(size_t)p->lw_off + ci * LW_WORDS];
+    r[LW_WMAX] = sh[LW_WMAX];
+    r[LW_TAB] = sh[LW_TAB];
+    r[LW_NPAT] = sh[LW_NPAT];
+    memcpy(r + LW_BASES_INLINE, sh + LW_BASES_INLINE, 8 * sizeof(uint32_t));
+  }
+  HIP_TRY(hipMemcpy(p->d_img + p->lw_off, p->img.data() + p->lw_off, rec_words * 4, hipMemcpyHostToDevice));
+  uint32_t *old = p->d_lw_tab;
+  p->d_lw_tab = p->ext_tab;
+  p->ext_tab = nullptr;
+  p->lw_wmax = p->ext_plan.wmax;
+  p->lw_npat = p->ext_plan.npat;
+  p->lw_bytes = p->ext_plan.bytes;
+  for (void *q : p->ext_scratch) (void)hipFree(q);
+  p->ext_scratch.clear();
+  if (old) HIP_TRY(hipFree(old));
+  static const bool timing = tsim_debug("tables");
+  if (timing)
+    fprintf(stderr, "[tsim] pattern tables: %.1f MB in place %.1f ms after the build began (%d slices)\n", (double)p->lw_bytes / 1e6,
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - p->ext_t0).count(), p->ext_slices);
+  return 1;
+}
+
+// (blocking form: tests and callers that want the deeper tables NOW)
+int tsim_tables_extend(tsim_program *p) {
+  if (int r = tsim_tables_extend_begin(p)) return r;
+  const int r = tsim_tables_extend_poll(p, true);
+  return r < 0 ? r : 0;
 }

@@ -440,8 +440,10 @@ __device__ __forceinline__ void sample4_block(const SampleArgs &A, int comp4_off
 // ---------------------------------------------------------------------------------------------------------------------
 // Hard-row lists that turn out LONG (the launch plan follows the counts of EARLIER launches: the first group after a jump of
 // the noise level hands lists of 10^5 rows to kernels sized for 10): the latency kernels (k_sample_hw, k_sample4h_multi) take
-// the first `slot_begin` slots of every list, this grid everything behind them - 512 rows per block and step at the per-shot
-// kernel's rate, a fixed number of chip-resident blocks striding over (launch, list, chunk).  Rows are recomputed whole
+// the first `slot_begin` slots of every list, worker blocks everything behind them - a block of rows per step at the per-shot
+// kernel's rate, a fixed number of chip-resident blocks striding over (launch, list, chunk).  The workers of k_sample_hw
+// are blocks appended to ITS grid (one more kernel per group on a first-pass lane cost C2 2-4 %, an empty one too); behind
+// k_sample4h(_multi) they are a grid of their own, k_sample4_over.  Rows are recomputed whole
 // (a row is a function of its f row, the key and the shot index), so it does not matter what the first pass left in them.
 // When no list is longer than slot_begin - every launch but that one - a block reads the counts and exits.
 // ---------------------------------------------------------------------------------------------------------------------
@@ -455,33 +457,55 @@ struct Over4Multi {
   SampleArgs ctx[TSIMK_H_MAX_CTX];
 };
 
+// the overflow share of worker `worker` of `n_workers` blocks (the whole grid of k_sample4_over, or the blocks appended to
+// a k_sample_hw grid): `ctx` are the launch's contexts as they lie in the kernel arguments
 template <int GT, int NCH>
-__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(TSIMK_V4_WAVES, 8))) k_sample4_over(Over4Multi M) {
+__device__ __forceinline__ void over4_rows(const SampleArgs *ctx, int n_ctx, int comp4_off, uint32_t slot_begin, bool masked,
+                                           uint32_t worker, uint32_t n_workers) {
   const uint32_t nthr = blockDim.x;
+  // every list's length at once (one load per thread, not a chain of n_ctx x lists dependent loads per block), and
+  // out when none reaches slot_begin - all launches but the first after a jump of the noise level
+  __shared__ uint32_t s_cnt[TSIMK_H_MAX_CTX * 64];
+  {
+    bool any = false;
+    for (uint32_t i = threadIdx.x; i < (uint32_t)n_ctx * 64u; i += nthr) {
+      const SampleArgs &A = ctx[i >> 6];
+      const uint32_t k = i & 63u;
+      const uint32_t n = (int)k < A.row_lists ? A.row_count[32u * k] : 0u;
+      s_cnt[i] = n;
+      any = any || n > slot_begin;
+    }
+    if (!__syncthreads_or(any ? 1 : 0)) return;
+  }
   uint32_t pair = 0;
-  for (int c = 0; c < M.n_ctx; ++c) {
-    const SampleArgs &A = M.ctx[c];
+  for (int c = 0; c < n_ctx; ++c) {
+    const SampleArgs &A = ctx[c];
+    const uint32_t check_row = (A.no_check || !A.check_row) ? 0xFFFFFFFFu : *A.check_row;
     for (int k = 0; k < A.row_lists; ++k, ++pair) {
-      const uint32_t n = A.row_count[32u * (uint32_t)k];
-      if (n <= M.slot_begin) continue;  // block-uniform
-      const uint32_t chunks = (n - M.slot_begin + nthr - 1u) / nthr;
-      const uint32_t check_row = (A.no_check || !A.check_row) ? 0xFFFFFFFFu : *A.check_row;
-      for (uint32_t q = (blockIdx.x + gridDim.x - pair % gridDim.x) % gridDim.x; q < chunks; q += gridDim.x) {
-        const uint32_t slot = M.slot_begin + q * nthr + threadIdx.x;
+      const uint32_t n = s_cnt[64 * c + k];
+      if (n <= slot_begin) continue;  // block-uniform
+      const uint32_t chunks = (n - slot_begin + nthr - 1u) / nthr;
+      for (uint32_t q = (worker + n_workers - pair % n_workers) % n_workers; q < chunks; q += n_workers) {
+        const uint32_t slot = slot_begin + q * nthr + threadIdx.x;
         const bool active = slot < n;
         uint32_t entry = active ? A.row_index[(size_t)k * A.row_list_cap + slot] : 0u;
-        if (M.masked) entry &= 0x0FFFFFFFu;
+        if (masked) entry &= 0x0FFFFFFFu;
         // the row of the normalisation check (sampler.py:66-72) landed behind the latency kernel's share: replayed here
         const bool has_check = __syncthreads_or(active && entry == check_row) != 0;
-        sample4_block<GT, NCH>(A, M.comp4_off, (long long)entry, active, false);
+        sample4_block<GT, NCH>(A, comp4_off, (long long)entry, active, false);
         __syncthreads();  // the staging columns are reused by the next chunk
         if (has_check) {
-          sample4_block<GT, NCH>(A, M.comp4_off, (long long)check_row, threadIdx.x < 2u, true);
+          sample4_block<GT, NCH>(A, comp4_off, (long long)check_row, threadIdx.x < 2u, true);
           __syncthreads();
         }
       }
     }
   }
+}
+
+template <int GT, int NCH>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(TSIMK_V4_WAVES, 8))) k_sample4_over(Over4Multi M) {
+  over4_rows<GT, NCH>(M.ctx, M.n_ctx, M.comp4_off, M.slot_begin, M.masked != 0, blockIdx.x, gridDim.x);
 }
 
 }  // namespace tsimk

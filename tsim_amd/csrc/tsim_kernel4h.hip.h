@@ -357,11 +357,16 @@ struct Hard4Multi {
   int n_ctx, blocks_per_ctx, group_tiles, loop_stride;
   int comp4_off, check_mask;
   uint32_t *feedback;
+  uint32_t main_blocks, over_from;  // blocks of the NW-waves-per-64-rows part; the grid's further blocks are per-shot workers for the list slots from over_from on (over4_rows, tsim_kernel4.hip.h)
   SampleArgs ctx[TSIMK_H_MAX_CTX];
 };
 
 template <int GT, int NCH, int NW>
 __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(3, 8))) k_sample4h_multi(Hard4Multi M) {
+  if (blockIdx.x >= M.main_blocks) {  // block-uniform
+    over4_rows<GT, NCH>(M.ctx, M.n_ctx, M.comp4_off, M.over_from, false, blockIdx.x - M.main_blocks, gridDim.x - M.main_blocks);
+    return;
+  }
   const uint32_t c = blockIdx.x / (uint32_t)M.blocks_per_ctx;
   const uint32_t bidx = blockIdx.x - c * (uint32_t)M.blocks_per_ctx;
   const bool has_check = ((M.check_mask >> c) & 1) != 0;

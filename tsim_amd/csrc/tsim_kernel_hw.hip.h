@@ -22,6 +22,7 @@
 // epilogue, same draws (tests/test_gpu_hard_wave.py).
 #pragma once
 #include "tsim_kernels.hip.h"
+#include "tsim_kernel4.hip.h"   // over4_rows: the per-shot workers behind long lists
 
 namespace tsimk {
 
@@ -31,7 +32,9 @@ struct HwMulti {
   int comp_par;                       // 1, or the program's component count: the lists carry component masks (LwMultiArgs.partial) and
                                       // block (slot, c) evaluates component c of its row alone
   int par_words;                      // LDS words per bit array: one parity bit per row of the longest level stream, + spare (8 arrays per block)
-  uint32_t slot_cap;                  // the grid serves the first slot_cap slots of every list (0: all); k_sample4_over takes the rest
+  uint32_t slot_cap;                  // the block-per-row blocks serve the first slot_cap slots of every list (0: all); the worker blocks the rest
+  uint32_t hw_blocks;                 // blocks of the block-per-row part; the grid's further blocks are per-shot workers (over4_rows)
+  int comp4_off;
   uint32_t *feedback;                 // launch-plan feedback of the first context (see sample4h_rows)
   SampleArgs ctx[TSIMK_HW_MAX_CTX];
 };
@@ -422,8 +425,15 @@ __device__ __forceinline__ void hw_row(const SampleArgs &A, long long row, bool 
 
 // Every BLOCK (4 waves on one row at a time) serves ONE list of ONE launch: block j of a list takes its slots j,
 // j + waves_per_list, ...
-template <int W>
+// NCH: chunks per tile of the program's chunk tables (the workers' kernel), 0: a grid without workers
+template <int W, int NCH>
 __global__ void __launch_bounds__(256) k_sample_hw(HwMulti M) {
+  if constexpr (NCH > 0) {
+    if (blockIdx.x >= M.hw_blocks) {  // block-uniform
+      over4_rows<4, NCH>(M.ctx, M.n_ctx, M.comp4_off, M.slot_cap, M.comp_par > 1, blockIdx.x - M.hw_blocks, gridDim.x - M.hw_blocks);
+      return;
+    }
+  }
   __builtin_amdgcn_s_setprio(3);  // a few hundred latency-bound waves beside a chip-full of issue-bound ones: issue when ready
   const uint32_t cp = (uint32_t)M.comp_par;
   const uint32_t wv = blockIdx.x / cp;

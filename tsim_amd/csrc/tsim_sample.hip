@@ -234,6 +234,19 @@ static LaunchPlan make_plan(tsim_program *p, bool has_row_index, bool pipelined,
   return pl;
 }
 
+// (experiments: TSIM_AMD_TUNE2="key=value,..." read at every use - not a documented switch)
+static long long tsim_tune_dbg(const char *key, long long dflt) {
+  const char *e = getenv("TSIM_AMD_TUNE2");
+  if (!e) return dflt;
+  const size_t n = strlen(key);
+  for (const char *q = e; *q;) {
+    if (!strncmp(q, key, n) && q[n] == '=') return atoll(q + n + 1);
+    const char *c = strchr(q, ',');
+    if (!c) break;
+    q = c + 1;
+  }
+  return dflt;
+}
 static thread_local const LaunchPlan *g_carry_plan = nullptr;  // a plan drawn by the caller of tsim_sample_batch_device_begin
 
 // k_sample4h geometry (LDS budget -> tiles per group), 0 tiles = the kernel cannot run this program
@@ -273,11 +286,13 @@ static int launch_over(tsim_program *p, const SampleArgs *ctx, int n_ctx, uint32
     M.ctx[i].row_slot_begin = 0;
     M.ctx[i].row_slot_end = 0;
   }
-  const int blk = p->knobs.v4_block;
+  // (a small footprint: in all launches but one the blocks only read the counts - 256 threads and ~25 KB of LDS start beside
+  // a first pass that holds the chip, 512 threads with 60 KB wait for it and then delay the next one: 6-12 % of C2 / C3)
+  const int blk = (int)tsim_tune_dbg("over_blk", 256);
   const size_t tile_bytes = std::max((size_t)p->v4_max_nch * 16, (size_t)p->v4_max_sent) * p->v4_gt * 16;
   const size_t lds4 = (size_t)(2 * ctx[0].WF + 2 * ctx[0].WO) * blk * 4 + 2 * tile_bytes;
   if (lds4 > 64 * 1024) return tsim_fail(TSIM_ENOTSUP, "v4 kernel needs %zu B of LDS", lds4);
-  const unsigned grid = (unsigned)(2 * p->n_cu);
+  const unsigned grid = (unsigned)tsim_tune_dbg("over_grid", p->n_cu);
   switch (p->v4_max_nch) {
 #define TSIM_LO(N) case N: hipLaunchKernelGGL((k_sample4_over<4, N>), dim3(grid), dim3(blk), lds4, hs, M); break;
     TSIM_LO(2) TSIM_LO(4) TSIM_LO(6) TSIM_LO(8) TSIM_LO(10) TSIM_LO(12) TSIM_LO(14)
@@ -306,17 +321,35 @@ static int launch_hw(tsim_program *p, const SampleArgs *ctx, int n_ctx, int max_
     H.ctx[i].kernarg_off = (int)(offsetof(HwMulti, ctx) + (size_t)i * sizeof(SampleArgs));
   }
   H.comp_par = partial ? (int)p->comps.size() : 1;  // the lists carry component masks: one block per (row, component)
-  // each block takes at most four turns; k_sample4_over serves what lies behind them (lists sized by STALE counts)
-  H.slot_cap = over_available(p) ? (uint32_t)H.waves_per_list * 4u : 0u;
+  // each block takes at most four turns; per-shot worker blocks appended to the grid serve what lies behind them (lists
+  // sized by STALE counts: the first group after a jump of the noise level) and exit at once otherwise
+  const bool workers = over_available(p);
+  H.slot_cap = workers ? (uint32_t)H.waves_per_list * 4u : 0u;
+  H.comp4_off = p->comp4_off;
   const unsigned gridw = (unsigned)((long long)H.n_ctx * H.max_lists * H.waves_per_list * H.comp_par);
+  H.hw_blocks = gridw;
   H.par_words = (int)(2 * ((p->hw_max_rows + 63) / 64) + 2);
-  const size_t ldsw = (size_t)H.par_words * 8 * 4 + 16;  // two buffers of four bit arrays (previous bit x trial bit) + the sampled bit.s word
+  size_t ldsw = (size_t)H.par_words * 8 * 4 + 16;  // two buffers of four bit arrays (previous bit x trial bit) + the sampled bit.s word
+  unsigned grid = gridw;
+  if (workers) {
+    const size_t tile_bytes = std::max((size_t)p->v4_max_nch * 16, (size_t)p->v4_max_sent) * p->v4_gt * 16;
+    ldsw = std::max(ldsw, (size_t)(2 * ctx[0].WF + 2 * ctx[0].WO) * 256 * 4 + 2 * tile_bytes);
+    if (ldsw > 64 * 1024) return tsim_fail(TSIM_ENOTSUP, "v4 kernel needs %zu B of LDS", ldsw);
+    grid += (unsigned)tsim_tune_dbg("over_grid", 2 * p->n_cu);
+  }
   // (blocks of 512 / 1024 threads - more helper waves per row - were tried: no faster alone, the row pass is not the chain;
   // next to a first pass slower, 8.8 -> 8.3 / 5.9e10 at --steps 200)
-  if (wmax == 1) hipLaunchKernelGGL(k_sample_hw<1>, dim3(gridw), dim3(256), ldsw, hs, H);
-  else hipLaunchKernelGGL(k_sample_hw<2>, dim3(gridw), dim3(256), ldsw, hs, H);
+  const int nch = workers ? p->v4_max_nch : 0;
+#define TSIM_LHW(WV, N) case N: hipLaunchKernelGGL((k_sample_hw<WV, N>), dim3(grid), dim3(256), ldsw, hs, H); break;
+  if (wmax == 1) switch (nch) {
+    TSIM_LHW(1, 0) TSIM_LHW(1, 2) TSIM_LHW(1, 4) TSIM_LHW(1, 6) TSIM_LHW(1, 8) TSIM_LHW(1, 10) TSIM_LHW(1, 12) TSIM_LHW(1, 14) TSIM_LHW(1, 16)
+    default: return tsim_fail(TSIM_ESTATE, "bad chunk count %d", nch);
+  } else switch (nch) {
+    TSIM_LHW(2, 0) TSIM_LHW(2, 2) TSIM_LHW(2, 4) TSIM_LHW(2, 6) TSIM_LHW(2, 8) TSIM_LHW(2, 10) TSIM_LHW(2, 12) TSIM_LHW(2, 14) TSIM_LHW(2, 16)
+    default: return tsim_fail(TSIM_ESTATE, "bad chunk count %d", nch);
+  }
+#undef TSIM_LHW
   HIP_TRY(hipGetLastError());
-  if (H.slot_cap) return launch_over(p, ctx, n_ctx, H.slot_cap, partial, hs);
   return 0;
 }
 
@@ -375,19 +408,27 @@ static int flush_batch(tsim_program *p) {
   // (a group whose first pass stored partial rows and component masks - steps_group_fused - was promised this kernel)
   const bool partial = p->slots[p->deferred[0]].partial;
   if (partial || hw_eligible(p, M.ctx[0], M.n_ctx)) {
-    if (int r = launch_hw(p, M.ctx, M.n_ctx, max_lists, hs, partial)) return r;
+    if (int r = launch_hw(p, M.ctx, M.n_ctx, max_lists, hs, partial)) return r;  // (its overflow workers ride in the same grid)
   } else {
   // (each block walks its list in strides of hb * 64 slots: at most 16 of them, the rest is k_sample4_over's)
   const uint32_t cap4h = over_available(p) ? (uint32_t)M.loop_stride * 16u : 0u;
   for (int i = 0; i < M.n_ctx; ++i) M.ctx[i].row_slot_end = (int)cap4h;
-  const unsigned grid = (unsigned)(M.n_ctx * M.blocks_per_ctx);
+  unsigned grid = (unsigned)(M.n_ctx * M.blocks_per_ctx);
+  M.main_blocks = grid;
+  M.over_from = cap4h;
+  size_t lds_m = p->h_lds;
+  if (cap4h) {  // the workers ride in the same grid (a kernel of their own behind this one cost C3 4 %)
+    const size_t tile_bytes = std::max((size_t)p->v4_max_nch * 16, (size_t)p->v4_max_sent) * p->v4_gt * 16;
+    lds_m = std::max(lds_m, (size_t)(2 * M.ctx[0].WF + 2 * M.ctx[0].WO) * (NW * 64) * 4 + 2 * tile_bytes);
+    grid += (unsigned)p->n_cu;
+  }
   switch (p->v4_max_nch) {
 #define TSIM_LHM(N)                                                                                          \
   case N: {                                                                                                  \
     auto kfn = k_sample4h_multi<4, N, NW>;                                                                   \
-    if (!p->hm_attr_set)                                                                                     \
-      HIP_TRY(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-    hipLaunchKernelGGL(kfn, dim3(grid), dim3(NW * 64), p->h_lds, hs, M);                                     \
+    if (!p->hm_attr_set) /* (the workers' list counts are 2 KB of static LDS) */                            \
+      HIP_TRY(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024)); \
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(NW * 64), lds_m, hs, M);                                        \
   } break;
     TSIM_LHM(2) TSIM_LHM(4) TSIM_LHM(6) TSIM_LHM(8) TSIM_LHM(10) TSIM_LHM(12) TSIM_LHM(14) TSIM_LHM(16)
 #undef TSIM_LHM
@@ -395,8 +436,6 @@ static int flush_batch(tsim_program *p) {
   }
   HIP_TRY(hipGetLastError());
   p->hm_attr_set = true;
-  if (cap4h)
-    if (int r = launch_over(p, M.ctx, M.n_ctx, cap4h, false, hs)) return r;
   }
   ++p->stat_flushes;
   hipEvent_t &be = p->batch_ev[seq % 16u];

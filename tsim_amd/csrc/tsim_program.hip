@@ -957,10 +957,6 @@ retry_pack:
   if (p->lw) {
     if (int r = tsim_tables_build(p, nullptr)) return r;
     if (int r = alloc_feedback(p)) return r;
-    if (p->lw_cap_now < p->lw_cap_max) {  // deeper tables may be built in the background later: their stream now (creating one takes milliseconds)
-      HIP_TRY(hipStreamCreateWithFlags(&p->ext_stream, hipStreamNonBlocking));
-      HIP_TRY(hipEventCreateWithFlags(&p->ext_ev, hipEventDisableTiming));
-    }
   }
   p->finalized = true;
   return TSIM_OK;

@@ -247,6 +247,18 @@ static long long tsim_tune_dbg(const char *key, long long dflt) {
   }
   return dflt;
 }
+// Every pipeline slot has its stream: now the stream a table build in the background will use (tsim_tables.hip).  Not at
+// finalize: HIP deals streams to its few hardware queues in creation order, and one more stream in front of the lanes
+// moved two of them onto one queue (C4 at 10^5 shots per step: 1.73 -> 1.07e10).  Not at the build either: creating a
+// stream takes milliseconds.
+static int slots_now_ready(tsim_program *p) {
+  p->slots_ready = true;
+  if (p->lw && p->lw_cap_now < p->lw_cap_max && !p->ext_stream) {
+    HIP_TRY(hipStreamCreateWithFlags(&p->ext_stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&p->ext_ev, hipEventDisableTiming));
+  }
+  return 0;
+}
 static thread_local const LaunchPlan *g_carry_plan = nullptr;  // a plan drawn by the caller of tsim_sample_batch_device_begin
 
 // k_sample4h geometry (LDS budget -> tiles per group), 0 tiles = the kernel cannot run this program
@@ -1063,7 +1075,7 @@ extern "C" int tsim_sample_batch_device_begin(tsim_program *p, int32_t slot, con
     if (p->lw || p->v4w) hard_bytes = (size_t)(((B + 255) / 256 + TSIMK_LW_LISTS - 1) / TSIMK_LW_LISTS * 1024) * TSIMK_LW_LISTS * 4;
     for (int k = 1; k <= TSIM_PIPELINE_SLOTS; ++k)
       if (int r = slot_prepare(p, k, hard_bytes)) return r;
-    p->slots_ready = true;
+    if (int r = slots_now_ready(p)) return r;
   }
   if (int r = slot_prepare(p, 1 + slot, 0)) return r;
   // The whole launch runs on the slot's own stream (a "lane"): launches of one slot are ordered by the
@@ -1462,7 +1474,7 @@ extern "C" int tsim_sample_steps_device(tsim_program *p, int32_t n_steps, const 
       if (!p->slots_ready) {
         for (int k = 1; k <= TSIM_PIPELINE_SLOTS; ++k)
           if (int r = slot_prepare(p, k, 0)) return r;
-        p->slots_ready = true;
+        if (int r = slots_now_ready(p)) return r;
       }
       const int left = n_steps - done;
       const int groups = (left + TSIMK_DIRECT_MAX_STEPS - 1) / TSIMK_DIRECT_MAX_STEPS;
@@ -1491,7 +1503,7 @@ extern "C" int tsim_sample_steps_device(tsim_program *p, int32_t n_steps, const 
           const size_t hard_bytes = (size_t)(((B + 255) / 256 + TSIMK_LW_LISTS - 1) / TSIMK_LW_LISTS * 1024) * TSIMK_LW_LISTS * 4;
           for (int k = 1; k <= TSIM_PIPELINE_SLOTS; ++k)
             if (int r = slot_prepare(p, k, hard_bytes)) return r;
-          p->slots_ready = true;
+          if (int r = slots_now_ready(p)) return r;
         }
         const LaunchPlan wplan = make_plan(p, false, true, (unsigned long long)n * (unsigned long long)B);
         TSIM_MARK("plan");
@@ -1516,7 +1528,7 @@ extern "C" int tsim_sample_steps_device(tsim_program *p, int32_t n_steps, const 
         const size_t hard_bytes = (size_t)(((B + 255) / 256 + TSIMK_LW_LISTS - 1) / TSIMK_LW_LISTS * 1024) * TSIMK_LW_LISTS * 4;
         for (int k = 1; k <= TSIM_PIPELINE_SLOTS; ++k)
           if (int r = slot_prepare(p, k, hard_bytes)) return r;
-        p->slots_ready = true;
+        if (int r = slots_now_ready(p)) return r;
       }
       plan = make_plan(p, false, true, (unsigned long long)std::min(n_steps - done, std::min(TSIMK_LWM_MAX_STEPS, p->knobs.fused_max)) * (unsigned long long)B);
       hard_geometry(p, WF, WO);

@@ -2,7 +2,7 @@
 # The measurements behind profiles/r04 (run on the GPU box through gpurun; results under gpurun_out/r04/).
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r04; mkdir -p $O
 cd $R
-WHAT=" ${*:-all} "   # any of: bench shapes rocprof c5 tests (default: all)
+WHAT=" ${*:-all} "   # any of: bench shapes rocprof c5 transition tests (default: all)
 want() { [[ "$WHAT" == *" all "* || "$WHAT" == *" $1 "* ]]; }
 q() { scripts/bq.sh --no-config-legs "$@" | sed -e 's/enqueue_ms.*//'; }
 if want bench; then
@@ -43,6 +43,12 @@ if want c5; then
   f=$(find /tmp/ks_c5 -name "*kernel_stats.csv" | head -1); cp $f $O/c5_kernel_stats.csv
   cd $R
   scripts/pmc_kernel.sh c5 k_sample_wide --config C5 > /dev/null 2>&1; cp $O/pmc_c5.txt $O/c5_pmc.txt
+fi
+if want transition; then
+  { echo "C2, 10^6 shots per batch, 4 batches per call through tsim_sample_steps_device (scripts/dense_transition.py); ms per step of every call"
+    for x in 0.05 0.1 0.3; do echo "== p_bit 0.02 -> $x -> 0.02"; TSIM_AMD_DEBUG=tables python scripts/dense_transition.py $x; done
+    echo "== the jump to 0.3 with the overflow workers off (TSIM_AMD_TUNE=hard_overflow=0): the first dense call as in round 3"
+    TSIM_AMD_TUNE=hard_overflow=0 python scripts/dense_transition.py 0.3 | sed -n 4,8p; } > $O/dense_transition.txt 2>&1
 fi
 if want tests; then
   python -m pytest tests -q -m gpu > $O/gpu_tests_full.txt 2>&1; grep -E "passed|failed|error" $O/gpu_tests_full.txt | tail -3 > $O/gpu_tests.txt

@@ -189,7 +189,8 @@ static LaunchPlan make_plan(tsim_program *p, bool has_row_index, bool pipelined,
         p->deep_rows += rows;
         too_many_for_hw = p->deep_rows >= p->knobs.deep_after;
       }
-      p->lw_dense_launches = ((double)fb_sum > 0.01 * (double)fb_rows || too_many_for_hw) ? p->lw_dense_launches + 1 : 0;
+      // (not when MOST rows are hard: no table depth helps a dense phase, the full kernel takes it - below)
+      p->lw_dense_launches = (((double)fb_sum > 0.01 * (double)fb_rows && (double)fb_sum <= 0.5 * (double)fb_rows) || too_many_for_hw) ? p->lw_dense_launches + 1 : 0;
       if (p->lw_dense_launches >= 3) {
         p->lw_dense_launches = 0;
         if (p->knobs.deep_tables == 1) {  // asked for by name: now, with the one stall that costs

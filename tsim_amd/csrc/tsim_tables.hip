@@ -196,7 +196,7 @@ int tsim_tables_extend_begin(tsim_program *p) {
 // 1: the deeper tables are in place (the caller forgets the feedback of the old ones); 0: nothing changed
 int tsim_tables_extend_poll(tsim_program *p, bool wait) {
   if (!p->ext_pending) return 0;
-  // The build goes out in slices of ~4 million table entries (a fraction of a millisecond of the whole chip), the next one
+  // The build goes out in slices of a million table entries (0.1-0.2 ms of the whole chip), the next one
   // when the one before is done: whatever the sampling lanes launch meanwhile shares the chip with ONE slice, not with
   // 4-60 ms of queued build kernels (all at once, a first pass waited 8-18 ms for wave slots: its 512-thread blocks with
   // their LDS do not fit into the slots that 256-thread build blocks free one by one - at lower stream priority too;
@@ -208,7 +208,7 @@ int tsim_tables_extend_poll(tsim_program *p, bool wait) {
     }
     TsimBuildJob &j = p->ext_jobs[p->ext_job];
     tsimk::LwBuildArgs a = j.a;
-    const long long per = std::max<long long>(1, (4ll << 20) >> j.n_out);
+    const long long per = std::max<long long>(1, (1ll << 20) >> j.n_out);
     a.pat_begin = (int)j.next_pat;
     a.pat_count = (int)std::min<long long>(per, (long long)a.npat - j.next_pat);
     if (int r = tsim_launch_lw_build(j.W, p->fast, a, j.n_out, p->ext_stream)) return r;

@@ -18,7 +18,7 @@ if want shapes; then
     echo "== C5 p_bit 0.005"; q --config C5 --steps 100 --p-bit 0.005; echo "== C5 p_bit 0.05"; q --config C5 --steps 100 --p-bit 0.05;
     echo "== C5, tables to weight 4 on request (TSIM_AMD_DEEP_TABLES=1)"; TSIM_AMD_DEEP_TABLES=1 q --config C5 --steps 100;
     echo "== C2 approx, live padding"; q --steps 200 --approx; q --steps 200 --live-padding;
-    for p in 0.005 0.05 0.1 0.3; do echo "== C2 p_bit $p"; q --p-bit $p --steps 100; done;
+    for p in 0.005 0.05 0.1 0.3; do echo "== C2 p_bit $p (400 untimed steps first: deeper tables, where the plan wants them, are built in the background)"; q --p-bit $p --steps 100 --warmup 400; done;
     echo "== C2, every row on the full kernel (TSIM_AMD_PATTERN_TABLES=0)"; TSIM_AMD_PATTERN_TABLES=0 q --steps 20; TSIM_AMD_PATTERN_TABLES=0 q --steps 20 --p-bit 0.3; } > $O/shapes.txt 2>&1
 fi
 if want rocprof; then

@@ -26,10 +26,12 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cmath>
+#include <atomic>
 #include <chrono>
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
 #include <unordered_set>
 #include <vector>
 
@@ -227,7 +229,7 @@ struct tsim_program {
     bool adaptive = true;     // TSIM_AMD_ADAPTIVE=0 pins the default launch plan
     bool fused_steps = true;  // TSIM_AMD_FUSED_STEPS=0: tsim_sample_steps_device launches batch by batch
     int deep_tables = 0;      // TSIM_AMD_DEEP_TABLES: deeper pattern tables when the hard rows are merely too many for k_sample_hw -
-                              // 0: after deep_after rows in that state, 1: at once, -1: never (wide programs: only on 1)
+                              // 0: after deep_after rows in that state, 1: at once, -1: never
     // TSIM_AMD_TUNE keys (A/B parameters of tests/ and scripts/)
     bool defer = true;        // defer_hard=0: every pipelined launch runs its own second pass
     int defer_group = 4;      // defer_group: launches per deferred hard-row batch (<= TSIMK_H_MAX_CTX)
@@ -237,7 +239,7 @@ struct tsim_program {
     int hard_wave_rows = 1024;  // hard_wave_rows: ... while a batch of launches has at most this many hard rows (last feedback)
     long long hard_inline_rows = 1ll << 40;  // hard_inline_rows: fused groups of at most this many shots run their hard rows on their own lane
     bool hard_comp_par = true;  // hard_comp_par=0: the hard rows of multi-component programs one block per row (all components in turn)
-    unsigned long long deep_after = 20000000000ull;  // deep_after
+    unsigned long long deep_after = 4000000000ull;   // deep_after (the build runs in the background: it costs its 4-60 ms of GPU time, no stall)
     int fused_lanes = 0;      // fused_lanes: first-pass lanes the fused groups rotate over (1-4; 0 = 2, 3 for small groups)
     int fused_max = 8;        // fused_max: batches per fused first pass (<= TSIMK_LWM_MAX_STEPS = 16)
     bool wide = true;         // wide=0: wide components on the row kernel alone
@@ -276,13 +278,15 @@ struct tsim_program {
   // deeper tables being built in the background (tsim_tables_extend_begin / _poll)
   int lw_shadow_off = 0;         // image offset of the shadow copy of the LW records the build works from
   bool ext_pending = false;
-  hipStream_t ext_stream = nullptr;
   hipEvent_t ext_ev = nullptr;
   uint32_t *ext_tab = nullptr;
   std::vector<void *> ext_scratch;
   std::vector<TsimBuildJob> ext_jobs;  // one per component; launched slice by slice
   size_t ext_job = 0;
   int ext_slices = 0;
+  bool ext_uploaded = false, ext_slice_due = false, ext_recorded = false;
+  std::thread ext_thread;              // allocates the new table and the build scratch (hipMalloc of GBs: up to 30 ms)
+  std::atomic<int> ext_alloc{0};       // 0: running, 1: done, -1: failed
   TsimTablePlan ext_plan;
   std::chrono::steady_clock::time_point ext_t0;
   // device allocations handed out by tsim_malloc_device and not yet freed: the handle owns them
@@ -329,6 +333,7 @@ int tsim_tables_build(tsim_program *p, uint32_t **old);
 int tsim_tables_extend(tsim_program *p);
 int tsim_tables_extend_begin(tsim_program *p);
 int tsim_tables_extend_poll(tsim_program *p, bool wait);
+int tsim_tables_slice(tsim_program *p, hipStream_t s);
 
 // ---- tsim_sample.hip
 int tsim_flush_hard(tsim_program *p);

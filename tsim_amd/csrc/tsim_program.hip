@@ -233,7 +233,7 @@ extern "C" int tsim_program_finalize(tsim_program *p, int32_t device) {
     p->knobs.hard_wave_rows = (int)std::max(0ll, tune_ll("hard_wave_rows", 1024));
     p->knobs.hard_inline_rows = std::max(0ll, tune_ll("hard_inline_rows", 1ll << 40));
     p->knobs.hard_comp_par = tune_ll("hard_comp_par", 1) != 0;
-    p->knobs.deep_after = (unsigned long long)std::max(0ll, tune_ll("deep_after", 20000000000ll));
+    p->knobs.deep_after = (unsigned long long)std::max(0ll, tune_ll("deep_after", 4000000000ll));
     p->knobs.fused_lanes = (int)std::max(0ll, std::min(4ll, tune_ll("fused_lanes", 0)));
     p->knobs.fused_max = (int)std::max(1ll, std::min((long long)TSIMK_LWM_MAX_STEPS, tune_ll("fused_max", 8)));
     p->knobs.wide = tune_ll("wide", 1) != 0;
@@ -983,13 +983,12 @@ extern "C" void tsim_program_destroy(tsim_program *p) {
       if (s) (void)hipFree(s);
     for (void *q : p->owned) (void)hipFree(q);  // buffers the caller never returned
     p->owned.clear();
-    if (p->ext_pending) (void)hipStreamSynchronize(p->ext_stream);  // a table build in the background reads the image
+    if (p->ext_thread.joinable()) p->ext_thread.join();  // (a table build in the background: its slices ran on the lanes, drained above)
     if (p->d_img) (void)hipFree(p->d_img);
     if (p->d_dev) (void)hipFree(p->d_dev);
     for (void *q : p->ext_scratch) (void)hipFree(q);
     if (p->ext_tab) (void)hipFree(p->ext_tab);
     if (p->ext_ev) (void)hipEventDestroy(p->ext_ev);
-    if (p->ext_stream) (void)hipStreamDestroy(p->ext_stream);
     if (p->d_lw_tab) (void)hipFree(p->d_lw_tab);
     if (p->h_feedback) (void)hipHostFree((void *)p->h_feedback);
     for (auto &sl : p->slots) {

@@ -248,16 +248,11 @@ static long long tsim_tune_dbg(const char *key, long long dflt) {
   }
   return dflt;
 }
-// Every pipeline slot has its stream: now the stream a table build in the background will use (tsim_tables.hip).  Not at
-// finalize: HIP deals streams to its few hardware queues in creation order, and one more stream in front of the lanes
-// moved two of them onto one queue (C4 at 10^5 shots per step: 1.73 -> 1.07e10).  Not at the build either: creating a
-// stream takes milliseconds.
+// Every pipeline slot has its stream.  (Streams are created HERE, in one go, and nowhere earlier: HIP deals streams to its
+// few hardware queues in creation order, and one more stream in front of the lanes - created at finalize for the table
+// build of an earlier version - moved two lanes onto one queue: C4 at 10^5 shots per step 1.73 -> 1.07e10.)
 static int slots_now_ready(tsim_program *p) {
   p->slots_ready = true;
-  if (p->lw && p->lw_cap_now < p->lw_cap_max && !p->ext_stream) {
-    HIP_TRY(hipStreamCreateWithFlags(&p->ext_stream, hipStreamNonBlocking));
-    HIP_TRY(hipEventCreateWithFlags(&p->ext_ev, hipEventDisableTiming));
-  }
   return 0;
 }
 static thread_local const LaunchPlan *g_carry_plan = nullptr;  // a plan drawn by the caller of tsim_sample_batch_device_begin
@@ -738,6 +733,7 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
   };
   const LaunchPlan plan = plan_in ? *plan_in : make_plan(p, d_row_index != nullptr, false, (unsigned long long)B);
   const bool use_tables = plan.use_tables, need_overflow = plan.need_overflow;
+  if (int r = tsim_tables_slice(p, s)) return r;  // (a table build in the background: its next slice goes first)
   // The sparse-column pass (k_sample4w) over every row, or - behind a pattern-table first pass - over that pass's
   // hard-row lists (from_lists; `a` then describes them).  Its own overflow (more than K set bits, the check row)
   // goes to row lists of its own, which `a` describes afterwards: the row kernel below serves them.
@@ -1250,6 +1246,7 @@ static int steps_group_fused(tsim_program *p, int n, const uint64_t *const *d_f,
   const long long iters = (total + chip - 1) / chip;
   const long long grid = (total + iters - 1) / iters;
   TSIM_MARK("args");
+  if (int r = tsim_tables_slice(p, s)) return r;  // (a table build in the background: its next slice goes first)
   const bool prof = p->profiling && (p->prof_counter++ % p->prof_every == 0);
   if (prof) { if (int r = prof_event(p, s, PROF_BEGIN)) return r; }
   // one component of at most 8 outputs: the specialised pass (tsim_lw_fast.hip.h) - 32-bit byte offsets everywhere, so
@@ -1427,6 +1424,7 @@ static int steps_group_wide(tsim_program *p, int n, const uint64_t *const *d_f, 
   TSIM_MARK("args");
   const bool prof = p->profiling && (p->prof_counter++ % p->prof_every == 0);
   if (prof) { if (int r = prof_event(p, s, PROF_BEGIN)) return r; }
+  if (int r = tsim_tables_slice(p, s)) return r;  // (a table build in the background: its next slice goes first)
   if (int r = launch_wide(p, n, args, B, num_f, shot_offset, s)) return r;
   TSIM_MARK("launch");
   if (prof) {

@@ -9,8 +9,10 @@
 // (tsim_program_set_pattern_tables).  Results never depend on the depth.
 #include "tsim_internal.hip.h"
 
+#include <atomic>
 #include <chrono>
 #include <cstdio>
+#include <thread>
 #include <cstdlib>
 
 using namespace tsimk;
@@ -97,7 +99,7 @@ static void enumerate_patterns(int F, int wmax, std::vector<unsigned long long> 
 // hold them too), on stream `s`.  wait: return when they are built (scratch freed); otherwise the kernels are queued and
 // the scratch buffers handed back in `scratch` (the caller frees them once `s` has passed them).
 static int tables_build_at(tsim_program *p, int rec_off, const TsimTablePlan &t, hipStream_t s, bool wait, uint32_t **tab_out,
-                           std::vector<void *> &scratch, std::vector<TsimBuildJob> *jobs = nullptr) {
+                           std::vector<void *> &scratch) {
   uint32_t *tab = nullptr;
   hipError_t me = hipMalloc((void **)&tab, std::max<size_t>(16, (size_t)t.bytes));
   if (me != hipSuccess) return tsim_fail(TSIM_ENOMEM, "hipMalloc(%lld) for the pattern tables failed: %s", t.bytes, hipGetErrorString(me));
@@ -123,8 +125,7 @@ static int tables_build_at(tsim_program *p, int rec_off, const TsimTablePlan &t,
     a.pat_begin = 0;
     a.pat_count = 0;
     int r = 0;
-    if (e == hipSuccess && jobs) jobs->push_back(TsimBuildJob{a, p->comp_w[ci], c.n_out, 0});  // launched slice by slice (tsim_tables_extend_poll)
-    else if (e == hipSuccess) r = tsim_launch_lw_build(p->comp_w[ci], p->fast, a, c.n_out, s);
+    if (e == hipSuccess) r = tsim_launch_lw_build(p->comp_w[ci], p->fast, a, c.n_out, s);
     if (e == hipSuccess && r == 0 && wait) e = hipStreamSynchronize(s);
     if (p1 && (wait || r || e != hipSuccess)) (void)hipFree(p1);
     else if (p1) scratch.push_back(p1);
@@ -160,11 +161,58 @@ int tsim_tables_build(tsim_program *p, uint32_t **old) {
 }
 
 // Deepen the tables to the largest weight the budget allows, in the background: the launch planner calls _begin when the
-// hard-row feedback says deeper tables would pay and polls at every later plan.  The new tables are built on a stream of
-// their own from a SHADOW copy of the component records (the build kernels unrank with the new bases; the sampling kernels
-// in flight keep the live records and the current tables), so nothing waits for the 4-60 ms of build kernels.  When
-// they are done the poll swaps: every lane drained (what is in flight reads the old records), the live records rewritten,
-// the table pointer exchanged, the old table freed - a fraction of a millisecond.
+// hard-row feedback says deeper tables would pay and polls at every later plan.
+//  * The new depth is planned into a SHADOW copy of the component records: the build kernels unrank with the new bases,
+//    the sampling kernels in flight keep the live records and the current tables.
+//  * The buffers (0.5-2 GB each) are allocated by a helper thread: hipMalloc of that size takes 0.1-30 ms.
+//  * The build goes out in slices of 2^21 table entries (~0.25 ms of the chip), ONE per launch plan, each enqueued on the
+//    stream of the launch that plan is for, in front of it (tsim_tables_slice): build and sampling alternate in GPU time
+//    however far the host runs ahead, and no sampling kernel ever faces more than one slice.  (All slices at once on a
+//    stream of their own: a first pass waited 8-18 ms for wave slots - its 512-thread blocks with their LDS do not fit
+//    into the slots that 256-thread build blocks free one by one, at lower stream priority too; on 64 masked CUs the
+//    build slowed the chip-resident first passes tenfold for its whole, longer, duration; one slice per plan on its own
+//    stream, the next when the last was done: a host running ahead polls in a burst and the build never advances.)
+//  * When the last slice is done the poll swaps: every stream drained (what is in flight reads the old records), the live
+//    records rewritten, the table pointer exchanged, the old table freed - a fraction of a millisecond.
+static void ext_alloc_thread(tsim_program *p) {
+  int state = 1;
+  if (hipSetDevice(p->device) != hipSuccess) state = -1;
+  uint32_t *tab = nullptr;
+  if (state > 0 && hipMalloc((void **)&tab, std::max<size_t>(16, (size_t)p->ext_plan.bytes)) != hipSuccess) state = -1;
+  for (size_t ci = 0; state > 0 && ci < p->comps.size(); ++ci) {
+    const HostComponent &c = p->comps[ci];
+    const long long tab_off = (long long)p->img[(size_t)p->lw_shadow_off + ci * LW_WORDS + LW_TAB];
+    const long long lanes = p->ext_plan.npat[ci] << c.n_out;
+    float *p1 = nullptr;
+    if (hipMalloc((void **)&p1, std::max<size_t>(16, (size_t)lanes * 4)) != hipSuccess) { state = -1; break; }
+    p->ext_scratch.push_back(p1);
+    LwBuildArgs a;
+    a.img = p->d_img;
+    a.patbits = nullptr;
+    a.wide_binom_off = p->lw_wide ? p->lw_binom_off : 0;
+    a.bases_off = p->lw_shadow_off + (int)ci * LW_WORDS + LW_BASES_INLINE;
+    a.wmax = p->ext_plan.wmax[ci];
+    a.tab = tab + tab_off;
+    a.comp_off = p->comp_off + (int)ci * C_WORDS;
+    a.npat = (int)p->ext_plan.npat[ci];
+    a.p1 = p1;
+    a.depth = -1;
+    a.pat_begin = 0;
+    a.pat_count = 0;
+    p->ext_jobs.push_back(TsimBuildJob{a, p->comp_w[ci], c.n_out, 0});
+  }
+  if (state < 0) {
+    (void)hipGetLastError();
+    for (void *q : p->ext_scratch) (void)hipFree(q);
+    p->ext_scratch.clear();
+    p->ext_jobs.clear();
+    if (tab) (void)hipFree(tab);
+    tab = nullptr;
+  }
+  p->ext_tab = tab;
+  p->ext_alloc.store(state, std::memory_order_release);
+}
+
 int tsim_tables_extend_begin(tsim_program *p) {
   if (!p->lw || p->lw_cap_now >= p->lw_cap_max || p->ext_pending) return 0;
   p->lw_cap_now = p->lw_cap_max;  // asked once
@@ -172,52 +220,77 @@ int tsim_tables_extend_begin(tsim_program *p) {
   std::copy(p->img.begin() + p->lw_off, p->img.begin() + p->lw_off + (long)rec_words, p->img.begin() + p->lw_shadow_off);
   TsimTablePlan t;
   if (!tsim_tables_plan_at(p, p->lw_cap_max, p->lw_budget, p->lw_shadow_off, t) || t.wmax == p->lw_wmax) return 0;  // nothing to gain (budget)
-  if (!p->ext_stream) HIP_TRY(hipStreamCreateWithFlags(&p->ext_stream, hipStreamNonBlocking));
   if (!p->ext_ev) HIP_TRY(hipEventCreateWithFlags(&p->ext_ev, hipEventDisableTiming));
   p->ext_t0 = std::chrono::steady_clock::now();
-  HIP_TRY(hipMemcpyAsync(p->d_img + p->lw_shadow_off, p->img.data() + p->lw_shadow_off, rec_words * 4, hipMemcpyHostToDevice, p->ext_stream));
   p->ext_jobs.clear();
-  if (int r = tables_build_at(p, p->lw_shadow_off, t, p->ext_stream, false, &p->ext_tab, p->ext_scratch, &p->ext_jobs)) {
-    (void)r;  // e.g. out of memory: keep what we have
-    (void)hipGetLastError();
-    return 0;
-  }
+  p->ext_scratch.clear();
   p->ext_job = 0;
   p->ext_slices = 0;
   p->ext_plan = t;
+  p->ext_uploaded = false;
+  p->ext_slice_due = false;
+  p->ext_recorded = false;
+  p->ext_alloc.store(0, std::memory_order_release);
+  if (p->ext_thread.joinable()) p->ext_thread.join();
+  p->ext_thread = std::thread(ext_alloc_thread, p);
   p->ext_pending = true;
-  static const bool timing = tsim_debug("tables");
-  if (timing)
-    fprintf(stderr, "[tsim] pattern tables: build of %.1f MB prepared in %.2f ms of host time\n", (double)t.bytes / 1e6,
-            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - p->ext_t0).count());
+  return 0;
+}
+
+// the next slice of the build on stream `s`, in front of the launch the caller is about to enqueue there
+int tsim_tables_slice(tsim_program *p, hipStream_t s) {
+  if (!p->ext_pending || !p->ext_slice_due || p->ext_job >= p->ext_jobs.size()) return 0;
+  p->ext_slice_due = false;
+  TsimBuildJob &j = p->ext_jobs[p->ext_job];
+  tsimk::LwBuildArgs a = j.a;
+  const long long per = std::max<long long>(1, (2ll << 20) >> j.n_out);
+  a.pat_begin = (int)j.next_pat;
+  a.pat_count = (int)std::min<long long>(per, (long long)a.npat - j.next_pat);
+  if (int r = tsim_launch_lw_build(j.W, p->fast, a, j.n_out, s)) return r;
+  ++p->ext_slices;
+  j.next_pat += a.pat_count;
+  if (j.next_pat >= (long long)a.npat) ++p->ext_job;
+  if (p->ext_job >= p->ext_jobs.size()) {  // that was the last one
+    HIP_TRY(hipEventRecord(p->ext_ev, s));
+    p->ext_recorded = true;
+  }
   return 0;
 }
 
 // 1: the deeper tables are in place (the caller forgets the feedback of the old ones); 0: nothing changed
 int tsim_tables_extend_poll(tsim_program *p, bool wait) {
   if (!p->ext_pending) return 0;
-  // The build goes out in slices of a million table entries (0.1-0.2 ms of the whole chip), the next one
-  // when the one before is done: whatever the sampling lanes launch meanwhile shares the chip with ONE slice, not with
-  // 4-60 ms of queued build kernels (all at once, a first pass waited 8-18 ms for wave slots: its 512-thread blocks with
-  // their LDS do not fit into the slots that 256-thread build blocks free one by one - at lower stream priority too;
-  // confined to 64 CUs by a mask the build slowed the chip-resident first passes tenfold for its whole, longer, duration).
-  while (p->ext_job < p->ext_jobs.size()) {
-    if (!wait && p->ext_slices > 0 && hipEventQuery(p->ext_ev) != hipSuccess) {
-      (void)hipGetLastError();
+  int st = p->ext_alloc.load(std::memory_order_acquire);
+  if (st == 0 && wait) {
+    p->ext_thread.join();
+    st = p->ext_alloc.load(std::memory_order_acquire);
+  }
+  if (st == 0) return 0;  // the buffers are still being allocated
+  if (p->ext_thread.joinable()) p->ext_thread.join();
+  if (st < 0) {  // e.g. out of memory: keep what we have
+    p->ext_pending = false;
+    return 0;
+  }
+  const size_t rec_words = p->comps.size() * LW_WORDS;
+  if (!p->ext_uploaded) {  // (128 bytes per component; nothing reads the shadow records yet)
+    HIP_TRY(hipMemcpy(p->d_img + p->lw_shadow_off, p->img.data() + p->lw_shadow_off, rec_words * 4, hipMemcpyHostToDevice));
+    p->ext_uploaded = true;
+    static const bool timing = tsim_debug("tables");
+    if (timing)
+      fprintf(stderr, "[tsim] pattern tables: buffers for %.1f MB allocated %.2f ms after the plan asked\n", (double)p->ext_plan.bytes / 1e6,
+              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - p->ext_t0).count());
+  }
+  if (p->ext_job < p->ext_jobs.size()) {
+    if (!wait) {
+      p->ext_slice_due = true;  // the launch this plan is for takes one slice along (tsim_tables_slice)
       return 0;
     }
-    TsimBuildJob &j = p->ext_jobs[p->ext_job];
-    tsimk::LwBuildArgs a = j.a;
-    const long long per = std::max<long long>(1, (1ll << 20) >> j.n_out);
-    a.pat_begin = (int)j.next_pat;
-    a.pat_count = (int)std::min<long long>(per, (long long)a.npat - j.next_pat);
-    if (int r = tsim_launch_lw_build(j.W, p->fast, a, j.n_out, p->ext_stream)) return r;
-    HIP_TRY(hipEventRecord(p->ext_ev, p->ext_stream));
-    ++p->ext_slices;
-    j.next_pat += a.pat_count;
-    if (j.next_pat >= (long long)a.npat) ++p->ext_job;
-    if (!wait) return 0;  // one slice per poll
+    while (p->ext_job < p->ext_jobs.size()) {
+      p->ext_slice_due = true;
+      if (int r = tsim_tables_slice(p, p->stream)) return r;
+    }
   }
+  if (!p->ext_recorded) return 0;
   if (wait) {
     HIP_TRY(hipEventSynchronize(p->ext_ev));
   } else if (hipEventQuery(p->ext_ev) != hipSuccess) {
@@ -229,7 +302,6 @@ int tsim_tables_extend_poll(tsim_program *p, bool wait) {
   // flight - not on the handle's lanes and not on a stream the CALLER passed to the device entry points either
   // (include/tsim_hip.h lets it).  Once per handle.
   HIP_TRY(hipDeviceSynchronize());
-  const size_t rec_words = p->comps.size() * LW_WORDS;
   for (size_t ci = 0; ci < p->comps.size(); ++ci) {
     const uint32_t *sh = &p->img[(size_t)p->lw_shadow_off + ci * LW_WORDS];
     uint32_t *r = &p->img[(size_t)p->lw_off + ci * LW_WORDS];
@@ -250,12 +322,12 @@ int tsim_tables_extend_poll(tsim_program *p, bool wait) {
   if (old) HIP_TRY(hipFree(old));
   static const bool timing = tsim_debug("tables");
   if (timing)
-    fprintf(stderr, "[tsim] pattern tables: %.1f MB in place %.1f ms after the build began (%d slices)\n", (double)p->lw_bytes / 1e6,
+    fprintf(stderr, "[tsim] pattern tables: %.1f MB in place %.1f ms after the plan asked (%d slices)\n", (double)p->lw_bytes / 1e6,
             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - p->ext_t0).count(), p->ext_slices);
   return 1;
 }
 
-// (blocking form: tests and callers that want the deeper tables NOW)
+// (blocking form: TSIM_AMD_DEEP_TABLES=1 - the deeper tables NOW)
 int tsim_tables_extend(tsim_program *p) {
   if (int r = tsim_tables_extend_begin(p)) return r;
   const int r = tsim_tables_extend_poll(p, true);

@@ -42,7 +42,7 @@ if want c5; then
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_c5 -- python $R/bench.py --config C5 --steps 64 --no-cpu-baseline --no-extra-legs > $O/ks_c5.json 2>/dev/null
   f=$(find /tmp/ks_c5 -name "*kernel_stats.csv" | head -1); cp $f $O/c5_kernel_stats.csv
   cd $R
-  scripts/pmc_kernel.sh c5 k_sample_wide --config C5 > /dev/null 2>&1; cp $O/pmc_c5.txt $O/c5_pmc.txt
+  PMC_TOP=2 scripts/pmc_kernel.sh c5 k_sample_wide --config C5 --no-config-legs > /dev/null 2>&1; cp $O/pmc_c5.txt $O/c5_pmc.txt   # (PMC_TOP: the 8-batch groups; the median mixes them with the 4-batch ones)
 fi
 if want transition; then
   { echo "C2, 10^6 shots per batch, 4 batches per call through tsim_sample_steps_device (scripts/dense_transition.py); ms per step of every call"

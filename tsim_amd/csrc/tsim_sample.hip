@@ -235,19 +235,6 @@ static LaunchPlan make_plan(tsim_program *p, bool has_row_index, bool pipelined,
   return pl;
 }
 
-// (experiments: TSIM_AMD_TUNE2="key=value,..." read at every use - not a documented switch)
-static long long tsim_tune_dbg(const char *key, long long dflt) {
-  const char *e = getenv("TSIM_AMD_TUNE2");
-  if (!e) return dflt;
-  const size_t n = strlen(key);
-  for (const char *q = e; *q;) {
-    if (!strncmp(q, key, n) && q[n] == '=') return atoll(q + n + 1);
-    const char *c = strchr(q, ',');
-    if (!c) break;
-    q = c + 1;
-  }
-  return dflt;
-}
 // Every pipeline slot has its stream.  (Streams are created HERE, in one go, and nowhere earlier: HIP deals streams to its
 // few hardware queues in creation order, and one more stream in front of the lanes - created at finalize for the table
 // build of an earlier version - moved two lanes onto one queue: C4 at 10^5 shots per step 1.73 -> 1.07e10.)
@@ -296,11 +283,11 @@ static int launch_over(tsim_program *p, const SampleArgs *ctx, int n_ctx, uint32
   }
   // (a small footprint: in all launches but one the blocks only read the counts - 256 threads and ~25 KB of LDS start beside
   // a first pass that holds the chip, 512 threads with 60 KB wait for it and then delay the next one: 6-12 % of C2 / C3)
-  const int blk = (int)tsim_tune_dbg("over_blk", 256);
+  const int blk = 256;
   const size_t tile_bytes = std::max((size_t)p->v4_max_nch * 16, (size_t)p->v4_max_sent) * p->v4_gt * 16;
   const size_t lds4 = (size_t)(2 * ctx[0].WF + 2 * ctx[0].WO) * blk * 4 + 2 * tile_bytes;
   if (lds4 > 64 * 1024) return tsim_fail(TSIM_ENOTSUP, "v4 kernel needs %zu B of LDS", lds4);
-  const unsigned grid = (unsigned)tsim_tune_dbg("over_grid", p->n_cu);
+  const unsigned grid = (unsigned)p->n_cu;
   switch (p->v4_max_nch) {
 #define TSIM_LO(N) case N: hipLaunchKernelGGL((k_sample4_over<4, N>), dim3(grid), dim3(blk), lds4, hs, M); break;
     TSIM_LO(2) TSIM_LO(4) TSIM_LO(6) TSIM_LO(8) TSIM_LO(10) TSIM_LO(12) TSIM_LO(14)
@@ -343,7 +330,7 @@ static int launch_hw(tsim_program *p, const SampleArgs *ctx, int n_ctx, int max_
     const size_t tile_bytes = std::max((size_t)p->v4_max_nch * 16, (size_t)p->v4_max_sent) * p->v4_gt * 16;
     ldsw = std::max(ldsw, (size_t)(2 * ctx[0].WF + 2 * ctx[0].WO) * 256 * 4 + 2 * tile_bytes);
     if (ldsw > 64 * 1024) return tsim_fail(TSIM_ENOTSUP, "v4 kernel needs %zu B of LDS", ldsw);
-    grid += (unsigned)tsim_tune_dbg("over_grid", 2 * p->n_cu);
+    grid += (unsigned)(2 * p->n_cu);
   }
   // (blocks of 512 / 1024 threads - more helper waves per row - were tried: no faster alone, the row pass is not the chain;
   // next to a first pass slower, 8.8 -> 8.3 / 5.9e10 at --steps 200)

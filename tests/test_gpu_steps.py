@@ -27,22 +27,31 @@ def _subkeys(key, n):
     return key, subs
 
 
-def _run_steps(hp, prog, fs, key, nf, *, packed, shot_offset=0, calls=None):
-    """fs through sample_steps_device (optionally split into several calls of the given sizes); returns the rows."""
+def _run_steps(hp, prog, fs, key, nf, *, packed, shot_offset=0, calls=None, devs=None):
+    """fs through sample_steps_device (optionally split into several calls of the given sizes); returns the rows
+    (devs: a list that receives every batch's normalisation deviations, one float32 array per batch)."""
     B = len(fs[0])
     wf, wo, rb = (nf + 63) // 64, (prog.num_outputs + 63) // 64, (prog.num_outputs + 7) // 8
+    n_comp = max(1, len(prog.components))
     d_f = [hp.malloc(B * wf * 8) for _ in fs]
     d_o = [hp.malloc(max(B * wo * 8, 16)) for _ in fs]
+    d_d = [hp.malloc(4 * n_comp + 16) for _ in fs] if devs is not None else []
     for d, f in zip(d_f, fs):
         hp.h2d(d, _packed(f, wf))
     ks = (C.c_uint32 * 2)(key[0] & 0xFFFFFFFF, key[1] & 0xFFFFFFFF)
     i = 0
     for n in (calls or [len(fs)]):
         hp.sample_steps_device([d.ptr for d in d_f[i:i + n]], B, nf, ks, [d.ptr for d in d_o[i:i + n]],
-                               shot_offset=shot_offset, out_bit_packed=packed)
+                               shot_offset=shot_offset, out_bit_packed=packed,
+                               d_norm_dev=[d.ptr for d in d_d[i:i + n]] if devs is not None else None)
         i += n
     assert i == len(fs)
     hp.synchronize()
+    for d in d_d:
+        v = np.zeros(n_comp, np.float32)
+        hp.d2h(v, d)
+        devs.append(v)
+        d.free()
     outs = []
     for d in d_o:
         if packed:
@@ -280,13 +289,16 @@ def test_a_jump_of_the_noise_level_goes_through_the_overflow_grid_and_back(hip, 
         for ph, p_bit in enumerate(phases):
             fs = [synth.synth_f(B, nf, p_bit, seed=1000 * ph + i) for i in range(n)]
             hp.profile_read_steps()
-            o, k2 = _run_steps(hp, prog, fs, key, nf, packed=True)
+            dv = []
+            o, k2 = _run_steps(hp, prog, fs, key, nf, packed=True, devs=dv)
             fused_steps.append(hp.profile_read_steps())
             if over == 1:
                 _, subs = _subkeys(key, n)
                 for i in (0, n - 1):
-                    want = op.sample_program(fs[i], subs[i])
+                    want, wdev = op.sample_program(fs[i], subs[i], return_devs=True)
                     np.testing.assert_array_equal(o[i], np.packbits(want, axis=1, bitorder="little"), err_msg=f"phase {ph} (p_bit {p_bit}) batch {i}")
+                    # (the check row sits wherever the atomics put it in its list - in a dense batch mostly behind the latency kernel's share)
+                    np.testing.assert_array_equal(dv[i], np.asarray(wdev, np.float32), err_msg=f"normalisation deviation, phase {ph} batch {i}")
             key = np.array(k2, dtype=np.uint32)
             outs.append(o)
         hp.profile_enable(False)

@@ -75,3 +75,35 @@ def test_device_noise_no_channels_and_tiny_p(hip):
     tiny = hip.DeviceNoiseSampler(hp, ChannelSampler([error_probs(1e-5)] * 3, np.eye(3, dtype=np.uint8), seed=1))
     f = tiny.sample(4_000_000, (3, 4))
     assert abs(f.mean() - 1e-5) < 6 * np.sqrt(1e-5 / (3 * 4_000_000))
+
+
+def test_rare_outcomes_are_drawn(hip):
+    """The reference draws a float64 uniform against a float64 CDF (src/tsim/noise/channels.py:641-656).  The device twin
+    compares a 32-bit draw with the CDF rounded up to 2^-32 - round 3 compared a 24-bit uniform with a float32 CDF, and a
+    conditional outcome below 6e-8 could never come out.  One channel: fires half the time; given that, outcome B has
+    probability 4e-8 (the float32 CDF in front of it rounds to 1.0).  Over 1.2e9 shots B is expected 24 times."""
+    probs = [np.array([0.5, 0.5 - 2e-8, 2e-8, 0.0])]
+    T = np.eye(2, dtype=np.uint8)  # f0 = e0, f1 = e1: outcome A -> f = (1, 0), B -> (0, 1)
+    prog, _ = synth.config_program("C2")
+    hp = hip.HipProgram(prog)
+    cs = ChannelSampler(probs, T, seed=1)
+    dn = hip.DeviceNoiseSampler(hp, cs)
+    n, chunks = 20_000_000, 60
+    buf = hp.malloc(n * 8)
+    packed = np.zeros((n, 8), np.uint8)
+    count = {0: 0, 1: 0, 2: 0, 3: 0}
+    for c in range(chunks):
+        dn.sample_into(buf.ptr, n, (77, c))
+        hp.d2h(packed, buf)
+        v = packed[:, 0]
+        assert not packed[:, 1:].any()
+        for k in count:
+            count[k] += int(np.count_nonzero(v == k))
+    buf.free()
+    hp.close()
+    total = n * chunks
+    fires = count[1] + count[2] + count[3]
+    assert abs(fires - 0.5 * total) < 6 * np.sqrt(0.25 * total)
+    assert count[3] == 0
+    want = 2e-8 * total  # 24
+    assert 0 < count[2] and abs(count[2] - want) < 6 * np.sqrt(want) + 1, count

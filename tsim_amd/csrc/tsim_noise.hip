@@ -15,7 +15,7 @@ struct tsim_noise {
   float *d_inv = nullptr;  // 1 / log2(1 - p) per channel (k_noise_tile)
   int tile = 0, tseg = 0;  // k_noise_tile geometry; 0 = the tile form does not apply (rows too wide for LDS)
   uint32_t *d_off = nullptr;
-  float *d_cdf = nullptr;
+  uint32_t *d_cdf = nullptr;
   uint64_t *d_pat = nullptr;
 };
 
@@ -47,8 +47,13 @@ extern "C" int tsim_noise_create(tsim_program *p, int32_t num_f, int32_t n_chann
     pmax = std::max(pmax, p_fire[c]);
   }
   const size_t tot = off[n_channels];
-  std::vector<float> cdf(std::max<size_t>(1, tot));
-  for (size_t i = 0; i < tot; ++i) cdf[i] = (float)cond_cdf[i];
+  // outcome thresholds: u = w / 2^32 with a 32-bit draw w, outcome = #{i : cdf[i] <= u} = #{i : ceil(cdf[i] 2^32) <= w}
+  // (round 3 compared a 24-bit uniform with a float32 CDF: a conditional outcome below 6e-8 could never be drawn)
+  std::vector<uint32_t> cdf(std::max<size_t>(1, tot));
+  for (size_t i = 0; i < tot; ++i) {
+    const double t = std::ceil(std::min(std::max(cond_cdf[i], 0.0), 1.0) * 4294967296.0);
+    cdf[i] = t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t;
+  }
   std::vector<uint64_t> pat(std::max<size_t>(1, tot * n->WF), 0ull);
   for (size_t o = 0; o < tot; ++o)
     for (int i = 0; i < num_f; ++i)

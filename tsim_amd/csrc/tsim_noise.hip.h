@@ -20,7 +20,7 @@ struct NoiseArgs {
   int tile, n_tiles;         // k_noise_tile: shots per block (seg divides it)
   const double *log1m_p;     // [n_ch] log(1 - p_fire)  (0 -> channel always fires)
   const uint32_t *cdf_off;   // [n_ch + 1] offsets into cdf / pattern tables
-  const float *cdf;          // conditional CDF over the non-identity outcomes
+  const uint32_t *cdf;       // conditional CDF over the non-identity outcomes as 32-bit thresholds: ceil(cdf * 2^32), the last clamped
   const uint64_t *patterns;  // [total outcomes, WF] packed XOR patterns
   unsigned long long *f;     // [B, WF] packed rows, zeroed by the caller
   long long B;
@@ -57,9 +57,8 @@ __global__ void __launch_bounds__(256) k_noise(NoiseArgs A) {
     pos += gap;
     if (pos >= hi || pos < lo) break;
     // outcome: first index with cdf > u2
-    const float u2 = (float)(x1 >> 8) * (1.0f / 16777216.0f);
     uint32_t o = c0;
-    while (o + 1 < c1 && A.cdf[o] <= u2) ++o;
+    while (o + 1 < c1 && A.cdf[o] <= x1) ++o;  // searchsorted(cdf, u), u = x1 / 2^32 (channels.py:641-656): outcomes resolved to 2^-32
     const uint64_t *pat = A.patterns + (size_t)o * A.WF;
     for (int w = 0; w < A.WF; ++w) {
       const uint64_t v = pat[w];
@@ -118,8 +117,7 @@ __global__ void __launch_bounds__(256) k_noise_tile(NoiseArgs A) {
       pos += gap;
       uint32_t o = c0;
       if (!single) {
-        const float u2 = (float)(w_out >> 8) * (1.0f / 16777216.0f);
-        while (o + 1 < c1 && A.cdf[o] <= u2) ++o;
+        while (o + 1 < c1 && A.cdf[o] <= w_out) ++o;  // u = w_out / 2^32 against the float64 CDF rounded up to 2^-32
       }
       const uint64_t *pat = A.patterns + (size_t)o * A.WF;
       for (int w = 0; w < A.WF; ++w) {

@@ -261,8 +261,8 @@ def test_steps_with_shot_offset_and_dense_rows(hip):
     hp.close()
 
 
-@pytest.mark.parametrize("name,dense", [("C2", 0.3), ("C2", 0.08), ("C4", 0.2)])
-def test_a_jump_of_the_noise_level_goes_through_the_overflow_grid_and_back(hip, name, dense):
+@pytest.mark.parametrize("name,dense,extra", [("C2", 0.3, ""), ("C2", 0.08, ""), ("C4", 0.2, ""), ("C2", 0.3, ",hard_wave=0"), ("C3", 0.25, ",hard_wave=0")])
+def test_a_jump_of_the_noise_level_goes_through_the_overflow_grid_and_back(hip, name, dense, extra):
     """The launch plan follows the hard-row counts of EARLIER launches.  The first group after a jump from sparse to dense
     batches therefore hands lists of thousands of rows to kernels sized for ten: they take the head of every list,
     k_sample4_over (tsim_kernel4.hip.h) the rest - including, when it lies there, the row of the normalisation check
@@ -277,7 +277,7 @@ def test_a_jump_of_the_noise_level_goes_through_the_overflow_grid_and_back(hip, 
     phases = [cfg["p_bit"], cfg["p_bit"], dense, dense, cfg["p_bit"], cfg["p_bit"], cfg["p_bit"], cfg["p_bit"]]
     results = {}
     for over in (1, 0):
-        os.environ["TSIM_AMD_TUNE"] = f"hard_overflow={over}"
+        os.environ["TSIM_AMD_TUNE"] = f"hard_overflow={over}{extra}"  # (hard_wave=0: the jump group's lists go to k_sample4h_multi and ITS workers)
         try:
             hp = hip.HipProgram(prog)
         finally:

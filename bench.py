@@ -1143,20 +1143,41 @@ def full_kernel_leg(backend, program, device, f_bufs, B, num_f, key, d_out0) -> 
         hp_full.sample_batch_device(f_bufs[k % len(f_bufs)].ptr, B, num_f, key, d_out0.ptr)
     fms, fl = hp_full.profile_read(reset=True)
     hp_full.profile_enable(False)
+    # ... and the same kernel through the steps API (launches pipelined over the lanes: the rate a dense phase runs at)
+    ks = (C.c_uint32 * 2)(int(key[0]) & 0xFFFFFFFF, int(key[1]) & 0xFFFFFFFF)
+    outs = [hp_full.malloc(B * 8) for _ in range(8)]
+
+    def go(k):
+        hp_full.sample_steps_device([f_bufs[i % len(f_bufs)].ptr for i in range(k)], B, num_f, ks, [outs[i % 8].ptr for i in range(k)],
+                                    inputs_ready=True, out_bit_packed=True)
+
+    go(8)
+    hp_full.synchronize()
+    n_pipe = 24
+    t0 = time.perf_counter()
+    go(n_pipe)
+    hp_full.synchronize()
+    t_pipe = (time.perf_counter() - t0) / n_pipe
+    for o in outs:
+        o.free()
     hp_full.close()
     t = fms / max(fl, 1) * 1e-3
     bytes_per_shot = algorithmic_bytes_per_shot(num_f, program.num_outputs)
-    # executed vector instructions of this kernel on the benchmark shape: rocprofv3 SQ_INSTS_VALU (profiles/r01/v5_pmc.json,
-    # same kernel, same shape: 1.52e8 per 10^6 shots = 9.7k per 64 shots)
-    insts = 1.52e8 * B / 1e6
+    # executed vector instructions of this kernel on the benchmark shape: rocprofv3 SQ_INSTS_VALU (profiles/r04/full_kernel_pmc.txt,
+    # this round's tree: 1.516e8 per 10^6 shots = 9.7k per wave of 64 shots); op-class bound: profiles/r04/full_kernel.txt
+    insts = 1.516e8 * B / 1e6
     return {
         "kernel": "tsimk::k_sample4 (LDS chunk tables)" if fi.get("chunk_table_kernel") else "tsimk::k_sample",
         "kernel_avg_ms": t * 1e3, "shots_per_s": B / t, "launches": fl, "total_rows": fi["total_rows"], "table_bytes": fi["table_bytes"],
+        "pipelined": {"shots_per_s": B / t_pipe, "ms_per_step": t_pipe * 1e3, "steps": n_pipe,
+                      "note": "tsim_sample_steps_device with the tables off: launches overlap on the lanes; shots_per_s above is one launch at a time"},
         "roofline": {"bound": "hbm", "achieved": bytes_per_shot * B / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": bytes_per_shot * B / t / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_shot": bytes_per_shot},
         "valu": {"bound": "valu_issue", "executed_valu_wave_insts_per_launch": insts, "issue_peak_wave_insts_per_s": VALU_ISSUE_PEAK,
                  "frac_of_issue_peak": insts / t / VALU_ISSUE_PEAK,
-                 "pmc_source": "profiles/r01/v5_pmc.json (rocprofv3 SQ_INSTS_VALU of k_sample4 on the C2 shape; scaled to this batch)"},
+                 "op_class_bound_us_per_1e6_shots": 224.0,
+                 "pmc_source": "profiles/r04/full_kernel_pmc.txt (rocprofv3 SQ_INSTS_VALU of k_sample4 on the C2 shape, round-4 tree; scaled to this batch); "
+                               "op-class bound from profiles/r04/full_kernel_isa.json + profiles/r03/valu_table.txt"},
     }
 
 

@@ -244,7 +244,7 @@ struct tsim_program {
     int fused_max = 8;        // fused_max: batches per fused first pass (<= TSIMK_LWM_MAX_STEPS = 16)
     bool wide = true;         // wide=0: wide components on the row kernel alone
     bool wide_tables = true;  // wide_tables=0: no pattern tables in front of the wide kernels
-    bool hard_overflow = true; // hard_overflow=0: the latency kernels of a hard-row batch walk whole lists (no k_sample4_over behind them)
+    bool hard_overflow = true; // hard_overflow=0: the latency kernels of a hard-row batch walk whole lists (no per-shot workers behind them)
     bool wide_compact = true; // wide_compact=0: k_sample_wide keeps one 16-byte column table per graph even when all graphs fit one entry
     // fixed since round 4 (the experiments behind their switches are closed: DESIGN.md / HISTORY.md)
     bool hard_kernel = true;  // hard rows on k_sample4h, not k_sample4

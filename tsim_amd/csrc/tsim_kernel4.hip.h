@@ -443,7 +443,7 @@ __device__ __forceinline__ void sample4_block(const SampleArgs &A, int comp4_off
 // the first `slot_begin` slots of every list, worker blocks everything behind them - a block of rows per step at the per-shot
 // kernel's rate, a fixed number of chip-resident blocks striding over (launch, list, chunk).  The workers of k_sample_hw
 // are blocks appended to ITS grid (one more kernel per group on a first-pass lane cost C2 2-4 %, an empty one too); behind
-// k_sample4h(_multi) they are a grid of their own, k_sample4_over.  Rows are recomputed whole
+// the one-batch-per-call k_sample4h they are a grid of their own, k_sample4_over (k_sample4h_multi carries its own).  Rows are recomputed whole
 // (a row is a function of its f row, the key and the shot index), so it does not matter what the first pass left in them.
 // When no list is longer than slot_begin - every launch but that one - a block reads the counts and exits.
 // ---------------------------------------------------------------------------------------------------------------------

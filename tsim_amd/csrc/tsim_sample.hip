@@ -405,7 +405,7 @@ static int flush_batch(tsim_program *p) {
   if (partial || hw_eligible(p, M.ctx[0], M.n_ctx)) {
     if (int r = launch_hw(p, M.ctx, M.n_ctx, max_lists, hs, partial)) return r;  // (its overflow workers ride in the same grid)
   } else {
-  // (each block walks its list in strides of hb * 64 slots: at most 16 of them, the rest is k_sample4_over's)
+  // (each block walks its list in strides of hb * 64 slots: at most 16 of them, the rest is the worker blocks')
   const uint32_t cap4h = over_available(p) ? (uint32_t)M.loop_stride * 16u : 0u;
   for (int i = 0; i < M.n_ctx; ++i) M.ctx[i].row_slot_end = (int)cap4h;
   unsigned grid = (unsigned)(M.n_ctx * M.blocks_per_ctx);

@@ -95,6 +95,23 @@ def test_tables_deepen_on_demand_and_results_do_not_change(hip):
     hp.close()
 
 
+@pytest.mark.parametrize("launches", [3, 4, 6, 12])
+def test_handle_closed_while_deeper_tables_are_being_built(hip, launches):
+    """The background build (helper thread allocating, slices on the lanes) must let go whenever the handle goes: closed right
+    after the plan asked, mid-allocation, mid-build.  The rows sampled until then are the oracle's."""
+    prog, cfg = synth.config_program("C2")
+    nf = cfg["num_f"]
+    B = 20_000
+    for rep in range(3):
+        hp = hip.HipProgram(prog)
+        for i in range(launches):
+            f = synth.synth_f(B, nf, 0.12, seed=500 + i)
+            got, _ = hp.sample_batch(f, (rep, i))
+        want, _ = _oracle(prog, f, (rep, launches - 1))
+        np.testing.assert_array_equal(got, want)
+        hp.close()
+
+
 @pytest.mark.parametrize("mode", ["auto", "rows", "faithful"])
 def test_tables_with_every_full_kernel(hip, mode):
     prog, cfg = synth.config_program("C2")

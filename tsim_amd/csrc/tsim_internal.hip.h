@@ -285,6 +285,7 @@ struct tsim_program {
   size_t ext_job = 0;
   int ext_slices = 0;
   bool ext_uploaded = false, ext_slice_due = false, ext_recorded = false;
+  long long ext_entries = 1ll << 21;    // table entries per slice
   std::thread ext_thread;              // allocates the new table and the build scratch (hipMalloc of GBs: up to 30 ms)
   std::atomic<int> ext_alloc{0};       // 0: running, 1: done, -1: failed
   TsimTablePlan ext_plan;

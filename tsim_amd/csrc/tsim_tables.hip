@@ -165,7 +165,7 @@ int tsim_tables_build(tsim_program *p, uint32_t **old) {
 //  * The new depth is planned into a SHADOW copy of the component records: the build kernels unrank with the new bases,
 //    the sampling kernels in flight keep the live records and the current tables.
 //  * The buffers (0.5-2 GB each) are allocated by a helper thread: hipMalloc of that size takes 0.1-30 ms.
-//  * The build goes out in slices of 2^21 table entries (~0.25 ms of the chip), ONE per launch plan, each enqueued on the
+//  * The build goes out in slices of 2^21 table entries (0.3-1.5 ms next to a first pass), ONE per launch plan, each enqueued on the
 //    stream of the launch that plan is for, in front of it (tsim_tables_slice): build and sampling alternate in GPU time
 //    however far the host runs ahead, and no sampling kernel ever faces more than one slice.  (All slices at once on a
 //    stream of their own: a first pass waited 8-18 ms for wave slots - its 512-thread blocks with their LDS do not fit
@@ -226,6 +226,7 @@ int tsim_tables_extend_begin(tsim_program *p) {
   p->ext_scratch.clear();
   p->ext_job = 0;
   p->ext_slices = 0;
+  p->ext_entries = 1ll << 21;
   p->ext_plan = t;
   p->ext_uploaded = false;
   p->ext_slice_due = false;
@@ -243,7 +244,11 @@ int tsim_tables_slice(tsim_program *p, hipStream_t s) {
   p->ext_slice_due = false;
   TsimBuildJob &j = p->ext_jobs[p->ext_job];
   tsimk::LwBuildArgs a = j.a;
-  const long long per = std::max<long long>(1, (2ll << 20) >> j.n_out);
+  // Slice size: 2^21 table entries whatever the program.  A slice's kernels (one per tree depth, then the thresholds) start in
+  // the gaps the other lane's first pass leaves, so a slice lasts about one first pass however small it is: smaller slices
+  // for expensive programs (cultivation shape, 2^18: 1238 slices, 1.3 s instead of 143 slices, 0.27 s) and slices sized by
+  // their measured time (the events span the other lane's pass: the size collapsed) were both worse.
+  const long long per = std::max<long long>(1, p->ext_entries >> j.n_out);
   a.pat_begin = (int)j.next_pat;
   a.pat_count = (int)std::min<long long>(per, (long long)a.npat - j.next_pat);
   if (int r = tsim_launch_lw_build(j.W, p->fast, a, j.n_out, s)) return r;

@@ -2,7 +2,7 @@
 # The measurements behind profiles/r04 (run on the GPU box through gpurun; results under gpurun_out/r04/).
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r04; mkdir -p $O
 cd $R
-WHAT=" ${*:-all} "   # any of: bench shapes rocprof c5 transition tests (default: all)
+WHAT=" ${*:-all} "   # any of: bench shapes rocprof c5 transition long tests (default: all)
 want() { [[ "$WHAT" == *" all "* || "$WHAT" == *" $1 "* ]]; }
 q() { scripts/bq.sh --no-config-legs "$@" | sed -e 's/enqueue_ms.*//'; }
 if want bench; then
@@ -49,6 +49,11 @@ if want transition; then
     for x in 0.05 0.1 0.3; do echo "== p_bit 0.02 -> $x -> 0.02"; TSIM_AMD_DEBUG=tables python scripts/dense_transition.py $x; done
     echo "== the jump to 0.3 with the overflow workers off (TSIM_AMD_TUNE=hard_overflow=0): the first dense call as in round 3"
     TSIM_AMD_TUNE=hard_overflow=0 python scripts/dense_transition.py 0.3 | sed -n 4,8p; } > $O/dense_transition.txt 2>&1
+fi
+if want long; then
+  { echo "Long runs on one handle: scripts/bq.sh --no-config-legs --config X --steps 1500 (8 repetitions of 1500 steps of 10^6 shots), TSIM_AMD_DEBUG=tables, TSIM_AMD_TUNE=deep_after=4000000000."
+    echo "After deep_after rows with too many hard / missed rows the next table depth is built in the background and swapped in; reps = ms per step of the 8 repetitions."
+    for c in C3 C4 C5; do echo "== $c"; TSIM_AMD_TUNE=deep_after=4000000000 TSIM_AMD_DEBUG=tables scripts/bq.sh --no-config-legs --config $c --steps 1500 | sed -e "s/enqueue_ms.step [0-9.]* //"; grep "pattern tables" /tmp/bq.err | head -5; done; } > $O/long_runs.txt 2>&1
 fi
 if want tests; then
   python -m pytest tests -q -m gpu > $O/gpu_tests_full.txt 2>&1; grep -E "passed|failed|error" $O/gpu_tests_full.txt | tail -3 > $O/gpu_tests.txt

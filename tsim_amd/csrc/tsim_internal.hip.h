@@ -239,7 +239,7 @@ struct tsim_program {
     int hard_wave_rows = 1024;  // hard_wave_rows: ... while a batch of launches has at most this many hard rows (last feedback)
     long long hard_inline_rows = 1ll << 40;  // hard_inline_rows: fused groups of at most this many shots run their hard rows on their own lane
     bool hard_comp_par = true;  // hard_comp_par=0: the hard rows of multi-component programs one block per row (all components in turn)
-    unsigned long long deep_after = 4000000000ull;   // deep_after (the build runs in the background: it costs its 4-60 ms of GPU time, no stall)
+    unsigned long long deep_after = 0;        // deep_after: rows in that state before the next depth is built; 0 = by the estimated build time
     int fused_lanes = 0;      // fused_lanes: first-pass lanes the fused groups rotate over (1-4; 0 = 2, 3 for small groups)
     int fused_max = 8;        // fused_max: batches per fused first pass (<= TSIMK_LWM_MAX_STEPS = 16)
     bool wide = true;         // wide=0: wide components on the row kernel alone
@@ -272,6 +272,8 @@ struct tsim_program {
   int lw_cap_now = 0, lw_cap_max = 0;  // table depth built / allowed (tsim_tables_extend deepens on demand)
   long long lw_budget = 0;    // bytes per component
   int lw_dense_launches = 0;  // consecutive launches whose hard-row share says "deeper tables would pay"
+  unsigned long long deep_after_auto = 0;  // tsim_tables_deep_after's estimate (0: not made yet)
+  double lw_build_ms = 0.0;            // the finalize build of the tables, timed (entries per ms -> the estimate)
   unsigned long long deep_rows = 0;  // rows launched while the hard rows were too many for k_sample_hw (knobs.deep_after)
   long long lw_bytes = 0;
   uint32_t *d_lw_tab = nullptr;  // integer Bernoulli thresholds (tsimk::bernoulli_threshold)
@@ -335,6 +337,7 @@ int tsim_tables_extend(tsim_program *p);
 int tsim_tables_extend_begin(tsim_program *p);
 int tsim_tables_extend_poll(tsim_program *p, bool wait);
 int tsim_tables_slice(tsim_program *p, hipStream_t s);
+unsigned long long tsim_tables_deep_after(tsim_program *p);
 
 // ---- tsim_sample.hip
 int tsim_flush_hard(tsim_program *p);

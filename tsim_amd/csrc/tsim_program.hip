@@ -233,7 +233,7 @@ extern "C" int tsim_program_finalize(tsim_program *p, int32_t device) {
     p->knobs.hard_wave_rows = (int)std::max(0ll, tune_ll("hard_wave_rows", 1024));
     p->knobs.hard_inline_rows = std::max(0ll, tune_ll("hard_inline_rows", 1ll << 40));
     p->knobs.hard_comp_par = tune_ll("hard_comp_par", 1) != 0;
-    p->knobs.deep_after = (unsigned long long)std::max(0ll, tune_ll("deep_after", 4000000000ll));
+    p->knobs.deep_after = (unsigned long long)std::max(0ll, tune_ll("deep_after", 0));  // 0: by the estimated build time (tsim_tables_deep_after)
     p->knobs.fused_lanes = (int)std::max(0ll, std::min(4ll, tune_ll("fused_lanes", 0)));
     p->knobs.fused_max = (int)std::max(1ll, std::min((long long)TSIMK_LWM_MAX_STEPS, tune_ll("fused_max", 8)));
     p->knobs.wide = tune_ll("wide", 1) != 0;

@@ -153,7 +153,7 @@ static LaunchPlan make_plan(tsim_program *p, bool has_row_index, bool pipelined,
         // (TSIM_AMD_DEEP_TABLES=1), otherwise only for a handle that has launched deep_after rows in this state.
         if ((double)missed > 0.2 * (double)fb_rows && p->knobs.deep_tables == 0) {
           p->deep_rows += rows;
-          if (p->deep_rows < p->knobs.deep_after) return pl;
+          if (p->deep_rows < tsim_tables_deep_after(p)) return pl;
         }
         p->lw_dense_launches = (double)missed > 0.2 * (double)fb_rows ? p->lw_dense_launches + 1 : 0;
         if (p->lw_dense_launches >= 3) {
@@ -187,7 +187,7 @@ static LaunchPlan make_plan(tsim_program *p, bool has_row_index, bool pipelined,
                              (unsigned long long)fb_sum * 8ull > (unsigned long long)p->knobs.hard_wave_rows && fb_rows >= 65536u;
       if (too_many_for_hw && p->knobs.deep_tables == 0) {
         p->deep_rows += rows;
-        too_many_for_hw = p->deep_rows >= p->knobs.deep_after;
+        too_many_for_hw = p->deep_rows >= tsim_tables_deep_after(p);
       }
       // (not when MOST rows are hard: no table depth helps a dense phase, the full kernel takes it - below)
       p->lw_dense_launches = (((double)fb_sum > 0.01 * (double)fb_rows && (double)fb_sum <= 0.5 * (double)fb_rows) || too_many_for_hw) ? p->lw_dense_launches + 1 : 0;

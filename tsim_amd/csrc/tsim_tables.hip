@@ -153,6 +153,7 @@ int tsim_tables_build(tsim_program *p, uint32_t **old) {
   if (int r = tables_build_at(p, p->lw_off, t, p->stream, true, &tab, scratch)) return r;
   if (old) *old = p->d_lw_tab;
   p->d_lw_tab = tab;
+  p->lw_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
   static const bool timing = tsim_debug("tables");
   if (timing)
     fprintf(stderr, "[tsim] pattern tables: %.1f MB built in %.1f ms\n", (double)p->lw_bytes / 1e6,
@@ -330,6 +331,30 @@ int tsim_tables_extend_poll(tsim_program *p, bool wait) {
     fprintf(stderr, "[tsim] pattern tables: %.1f MB in place %.1f ms after the plan asked (%d slices)\n", (double)p->lw_bytes / 1e6,
             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - p->ext_t0).count(), p->ext_slices);
   return 1;
+}
+
+// Rows a handle samples with too many hard / missed rows before it builds the next depth: about twice the time the build
+// will take (table entries of the next depth at the rate the finalize build ran at; 4e10 rows/s assumed) - a job that
+// ends early then loses at most a third of its time to a build that never paid.  Measured break-evens (build time /
+// gain per row, profiles/r04/long_runs.txt): C5 4e9, C4 2e10, C3 3e10 rows; this gives 1.0e10, 1.8e10, 0.6e10.
+unsigned long long tsim_tables_deep_after(tsim_program *p) {
+  if (p->knobs.deep_after) return p->knobs.deep_after;
+  if (p->deep_after_auto) return p->deep_after_auto;
+  double rows = 4e9;
+  if (p->lw && p->lw_build_ms > 0.0 && p->lw_bytes > 0) {
+    const size_t rec_words = p->comps.size() * LW_WORDS;
+    std::copy(p->img.begin() + p->lw_off, p->img.begin() + p->lw_off + (long)rec_words, p->img.begin() + p->lw_shadow_off);
+    TsimTablePlan t;
+    if (tsim_tables_plan_at(p, p->lw_cap_max, p->lw_budget, p->lw_shadow_off, t)) {
+      const double entries_per_ms = (double)p->lw_bytes / 4.0 / p->lw_build_ms;
+      const double build_s = (double)t.bytes / 4.0 / entries_per_ms * 1e-3;
+      rows = 2.0 * build_s * 4e10;
+    }
+  }
+  p->deep_after_auto = (unsigned long long)std::min(1e11, std::max(1e9, rows));
+  static const bool timing = tsim_debug("tables");
+  if (timing) fprintf(stderr, "[tsim] pattern tables: the next depth after %.2e rows that want it\n", (double)p->deep_after_auto);
+  return p->deep_after_auto;
 }
 
 // (blocking form: TSIM_AMD_DEEP_TABLES=1 - the deeper tables NOW)

@@ -484,6 +484,16 @@ int tsim_program_info(const tsim_program *p, int32_t *n_components, int32_t *num
  * components (k_sample4w); + 32: the program has a wide record (k_sample_wide serves it); + 16: with the shared column table */
 int tsim_program_stats(const tsim_program *p, int64_t out[8]);
 
+/* Which kernel family served the launches of this handle so far (diagnostics: scripts/shape_map.py, tests of the
+ * eligibility rules - the reference takes every shape through one code path, src/tsim/sampler.py:117-167; here the shape
+ * picks the kernel).  out[k] = launches of family k since creation / the last reset, TSIM_PATH_COUNT entries:
+ * 0 k_sample_lw_fast (fused group), 1 k_sample_lw_fastm, 2 k_sample_lw_multi, 3 k_direct_multi, 4 k_sample_wide,
+ * 5 k_sample_lw_fast (one batch), 6 k_sample_lw_reg, 7 k_sample_lw<false>, 8 k_sample_lw<true>, 9 k_sample4w,
+ * 10 k_sample4, 11 k_sample4h, 12 k_sample_hw, 13 k_sample4_over, 14 row kernel (k_sample<W>), 15 k_sample4h_multi,
+ * 16 k_sample_gen (fused group, any shape). */
+#define TSIM_PATH_COUNT 24
+int tsim_program_path_counts(tsim_program *p, int64_t out[TSIM_PATH_COUNT], int32_t reset);
+
 const char *tsim_last_error(void);
 const char *tsim_version(void);
 

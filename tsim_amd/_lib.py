@@ -126,6 +126,7 @@ SYMBOLS: dict[str, tuple] = {
         [_P, C.POINTER(_I32), C.POINTER(_I32), C.POINTER(_I64), C.POINTER(_I64), C.POINTER(_I64)],
     ),
     "tsim_program_stats": (C.c_int, [_P, C.POINTER(_I64)]),
+    "tsim_program_path_counts": (C.c_int, [_P, C.POINTER(_I64), C.c_int32]),
     "tsim_key_split": (None, [_U32, _U32, C.POINTER(_U32)]),
     "tsim_sample_batch_device_begin_split": (C.c_int, [_P, _I32, _P, _I64, _I32, C.POINTER(_U32), _I64, _P, _P, _P, _U32]),
     "tsim_sample_steps_device": (C.c_int, [_P, _I32, C.POINTER(_P), _I64, _I32, C.POINTER(_U32), _I64, C.POINTER(_P), C.POINTER(_P), _U32]),

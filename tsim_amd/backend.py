@@ -228,6 +228,16 @@ class HipProgram:
                     pattern_tables=bool(en.value), pattern_table_bytes=tb.value,
                     pattern_max_weight=[int(mw[i]) for i in range(nc.value)])
 
+    PATH_NAMES = ("lw_fast", "lw_fastm", "lw_multi", "direct_multi", "wide", "lw_fast1", "lw_reg", "lw_lds", "lw_lds_wide",
+                  "sample4w", "sample4", "sample4h", "hw", "over", "rows", "sample4h_multi", "gen")
+
+    def path_counts(self, reset: bool = False) -> dict:
+        """Launches per kernel family since creation / the last reset (``tsim_program_path_counts``), non-zero entries only."""
+        n = 24
+        out = (C.c_int64 * n)()
+        _lib.check(self._lib.tsim_program_path_counts(self._h, out, 1 if reset else 0), "tsim_program_path_counts")
+        return {name: int(out[i]) for i, name in enumerate(self.PATH_NAMES) if out[i]}
+
     # -- the hot path, host buffers -------------------------------------------
     def sample_batch(self, f_params: np.ndarray, key, *, shot_offset: int = 0, bit_packed: bool = False):
         """One batch through the fused kernel.  Returns ``(samples, max_norm_dev[n_components])``."""

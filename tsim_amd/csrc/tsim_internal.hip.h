@@ -115,7 +115,12 @@ struct TsimBuildJob {  // the table build of one component, cut into slices of p
   long long next_pat;
 };
 
+// kernel families (tsim_program_path_counts, include/tsim_hip.h)
+enum TsimPath { TP_LW_FAST = 0, TP_LW_FASTM, TP_LW_MULTI, TP_DIRECT_MULTI, TP_WIDE, TP_LW_FAST1, TP_LW_REG, TP_LW_LDS, TP_LW_LDS_WIDE,
+                TP_SAMPLE4W, TP_SAMPLE4, TP_SAMPLE4H, TP_HW, TP_OVER, TP_ROWS, TP_SAMPLE4H_MULTI, TP_GEN };
+
 struct tsim_program {
+  long long path_count[TSIM_PATH_COUNT] = {};
   // description
   int num_outputs = 0, num_detectors = 0, n_direct = 0;
   std::vector<int32_t> direct_f, output_order;
@@ -161,6 +166,7 @@ struct tsim_program {
   bool lw_reg = false;        // the register form of pass 1 applies (narrow f rows, ascending f_selection)
   int lwfm_off = 0;           // fast record of programs with 2..4 components of <= 8 outputs each (k_sample_lw_fastm), 0 = none
   int wr_off = 0;             // image offset of the wide record (one wide component: k_sample_wide, tsim_wide.hip.h), 0 = none
+  int gr_off = 0;             // image offset of the gen record (any narrow program: k_sample_gen, tsim_gen.hip.h), 0 = none
   int lwf_off = 0;            // image offset of the fast record (one component of <= 8 outputs: k_sample_lw_fast), 0 = none
   // Launch slots: slot 0 serves the serial API (everything on the caller's stream); slots 1..4 serve
   // tsim_sample_batch_device_begin/_end: a slot's launches run on the slot's own stream (`side`) so
@@ -245,6 +251,7 @@ struct tsim_program {
     bool wide = true;         // wide=0: wide components on the row kernel alone
     bool wide_tables = true;  // wide_tables=0: no pattern tables in front of the wide kernels
     bool hard_overflow = true; // hard_overflow=0: the latency kernels of a hard-row batch walk whole lists (no per-shot workers behind them)
+    int gen = 1;              // gen: k_sample_gen for fused groups - 0 never, 1 where no register first pass applies, 2 wherever it applies
     bool wide_compact = true; // wide_compact=0: k_sample_wide keeps one 16-byte column table per graph even when all graphs fit one entry
     // fixed since round 4 (the experiments behind their switches are closed: DESIGN.md / HISTORY.md)
     bool hard_kernel = true;  // hard rows on k_sample4h, not k_sample4
@@ -263,6 +270,8 @@ struct tsim_program {
   } knobs;
   bool h_attr_set = false;    // k_sample4h: large dynamic LDS enabled
   bool hm_attr_set = false;   // k_sample4h_multi: the same
+  unsigned gen_attr_set = 0;  // k_sample_gen<WO32>: bit WO32
+  unsigned wide_attr_set = 0; // k_sample_wide<WO32, K>: bit WO32
   int lw_off = 0;             // image offset of the LW component records
   int lw_direct_prog = 0;     // image offset of the direct-output gather program
   int lw_direct_chunks = 0;

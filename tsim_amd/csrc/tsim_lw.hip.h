@@ -39,7 +39,7 @@ enum {
 // last chunk is padded with mask = 0 runs):
 //   ctl = src_shift | dst_shift << 8 | dst_word << 16 | src_word << 24
 //   dst_word[dst_shift ..] |= ((f32[src_word] >> src_shift) & mask) ^ flip
-#define TSIMK_LW_MAX_NOUT 10
+#define TSIMK_LW_MAX_NOUT 12
 #define TSIMK_LW_MAX_WEIGHT 7
 #define TSIMK_LW_LISTS 64   // hard-row sub-lists (one atomic counter each, 128 bytes apart)
 // Wide components (more than 64 parameters; first pass k_sample_lw<true> in front of the sparse-column kernel):

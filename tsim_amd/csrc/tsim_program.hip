@@ -4,6 +4,7 @@
 #include "tsim_lw_fastm.hip.h"
 #include "tsim_kernel4w.hip.h"  // C4_SELMASK
 #include "tsim_wide.hip.h"      // WR_*: the wide record
+#include "tsim_gen.hip.h"       // GR_*, GC_*: the gen record
 
 using namespace tsimk;
 using namespace tsimhost;
@@ -239,6 +240,7 @@ extern "C" int tsim_program_finalize(tsim_program *p, int32_t device) {
     p->knobs.wide = tune_ll("wide", 1) != 0;
     p->knobs.wide_tables = tune_ll("wide_tables", 1) != 0;
     p->knobs.wide_compact = tune_ll("wide_compact", 1) != 0;
+    p->knobs.gen = (int)std::max(0ll, std::min(2ll, tune_ll("gen", 1)));
     p->knobs.hard_overflow = tune_ll("hard_overflow", 1) != 0;
   }
 
@@ -923,6 +925,114 @@ retry_pack:
             h[4] = (uint32_t)p->comps.size();
           }
         }
+        // The gen record (k_sample_gen, tsim_gen.hip.h): ANY narrow program - f rows of up to 2048 bits, up to 512 outputs,
+        // up to TSIMK_GEN_MAX_COMP components, up to TSIMK_GEN_KEYS compiled outputs.  One block of words the kernel copies
+        // to LDS as it is: direct-output runs sorted by destination word, their boundaries, the constant flips, a record
+        // per component and behind the records, per component, the (f word, selection mask, selected bits below) triples
+        // of the words that hold selected bits, RANK[ordinal][position inside f_sel] and the output columns.
+        p->gr_off = 0;
+        {
+          const int wo32 = 2 * ((p->num_outputs + 63) / 64);
+          const int wf32 = (p->max_f_index >> 5) + 1;
+          bool okg = p->num_outputs >= 1 && wo32 <= 16 && p->max_f_index < 2048 && (int)p->comps.size() <= TSIMK_GEN_MAX_COMP &&
+                     p->total_keys >= 1 && p->total_keys <= TSIMK_GEN_KEYS;
+          for (auto &c : p->comps)
+            for (int j = 1; j < c.F; ++j) okg = okg && c.f_selection[j] > c.f_selection[j - 1];
+          std::vector<uint32_t> runs, runb(1, 0u), flips((size_t)wo32, 0u);
+          for (int d = 0; d < wo32 && okg; ++d) {
+            for (int sw = 0; sw < wf32; ++sw) {
+              std::vector<std::array<int, 2>> m;  // (src bit, dst bit) inside the words
+              for (int j = 0; j < p->n_direct; ++j) {
+                const int src = p->direct_f[j], dst = p->output_order[j];
+                if ((src >> 5) != sw || (dst >> 5) != d) continue;
+                m.push_back({src & 31, dst & 31});
+                if (p->direct_flips[j]) flips[(size_t)d] |= 1u << (dst & 31);
+              }
+              std::sort(m.begin(), m.end());
+              for (size_t i = 0; i < m.size();) {
+                size_t j = i + 1;
+                while (j < m.size() && m[j][0] == m[j - 1][0] + 1 && m[j][1] == m[j - 1][1] + 1) ++j;
+                const int len = (int)(j - i);
+                const uint32_t field = (len >= 32 ? 0xFFFFFFFFu : ((1u << len) - 1u)) << m[i][1];
+                runs.push_back((uint32_t)sw | ((uint32_t)((m[i][0] - m[i][1]) & 31) << 8));
+                runs.push_back(field);
+                i = j;
+              }
+            }
+            runb.push_back((uint32_t)(runs.size() / 2));
+          }
+          okg = okg && runs.size() / 2 <= TSIMK_GEN_MAX_RUNS;
+          if (okg) {
+            std::vector<uint32_t> blk;  // the static LDS block
+            auto align4 = [&]() { while (blk.size() % 4) blk.push_back(0u); };
+            const uint32_t l_runs = 0;
+            blk.insert(blk.end(), runs.begin(), runs.end());
+            align4();
+            const uint32_t l_runb = (uint32_t)blk.size();
+            blk.insert(blk.end(), runb.begin(), runb.end());
+            align4();
+            const uint32_t l_flips = (uint32_t)blk.size();
+            blk.insert(blk.end(), flips.begin(), flips.end());
+            align4();
+            const uint32_t l_comp = (uint32_t)blk.size();
+            blk.resize(blk.size() + p->comps.size() * GC_WORDS, 0u);
+            for (size_t ci = 0; ci < p->comps.size(); ++ci) {
+              const HostComponent &c = p->comps[ci];
+              std::vector<uint32_t> sel((size_t)wf32, 0u);
+              for (int v : c.f_selection) sel[(size_t)(v >> 5)] |= 1u << (v & 31);
+              const uint32_t l_words = (uint32_t)blk.size();
+              uint32_t below = 0, nwords = 0;
+              for (int w = 0; w < wf32; ++w)
+                if (sel[(size_t)w]) {
+                  blk.push_back((uint32_t)w);
+                  blk.push_back(sel[(size_t)w]);
+                  blk.push_back(below);
+                  below += (uint32_t)__builtin_popcount(sel[(size_t)w]);
+                  ++nwords;
+                }
+              align4();
+              const uint32_t l_rank = (uint32_t)blk.size();
+              for (int k = 0; k < TSIMK_LW_MAX_WEIGHT; ++k)
+                for (int b = 0; b < c.F; ++b) {
+                  unsigned long long v = 0;
+                  if (b >= k + 1) {
+                    v = 1;
+                    for (int i = 1; i <= k + 1; ++i) v = v * (unsigned long long)(b - (k + 1) + i) / (unsigned long long)i;
+                  }
+                  blk.push_back((uint32_t)v);
+                }
+              align4();
+              const uint32_t l_outpos = (uint32_t)blk.size();
+              const uint32_t outpos_off = img[p->lw_off + ci * LW_WORDS + LW_OUTPOS];
+              for (int i = 0; i < c.n_out; ++i) blk.push_back(img[outpos_off + (uint32_t)i]);
+              align4();
+              uint32_t *cr = &blk[l_comp + ci * GC_WORDS];
+              cr[GC_NOUT] = (uint32_t)c.n_out;
+              cr[GC_F] = (uint32_t)c.F;
+              cr[GC_KEYBASE] = img[p->lw_off + ci * LW_WORDS + LW_KEYBASE];
+              cr[GC_NWORDS] = nwords;
+              cr[GC_L_WORDS] = l_words;
+              cr[GC_L_RANK] = l_rank;
+              cr[GC_L_OUTPOS] = l_outpos;
+            }
+            if (blk.size() * 4 <= 48 * 1024) {  // (the launcher adds the subkeys and the waves' row buffers)
+              while (img.size() % 16) img.push_back(0u);
+              p->gr_off = (int)img.size();
+              img.resize(img.size() + GR_WORDS, 0u);
+              img.insert(img.end(), blk.begin(), blk.end());
+              uint32_t *h = &img[p->gr_off];
+              h[GR_NCOMP] = (uint32_t)p->comps.size();
+              h[GR_WO32] = (uint32_t)wo32;
+              h[GR_NRUNS] = (uint32_t)(runs.size() / 2);
+              h[GR_LDS_WORDS] = (uint32_t)blk.size();
+              h[GR_L_RUNS] = l_runs;
+              h[GR_L_RUNB] = l_runb;
+              h[GR_L_FLIPS] = l_flips;
+              h[GR_L_COMP] = l_comp;
+              h[GR_WF32_MIN] = (uint32_t)wf32;
+            }
+          }
+        }
       } else {
         p->lw_wmax.clear();
       }
@@ -1012,6 +1122,15 @@ extern "C" int tsim_program_stats(const tsim_program *p, int64_t out[8]) {
   if (!p->finalized) return tsim_fail(TSIM_ESTATE, "program not finalized");
   for (int i = 0; i < 8; ++i) out[i] = p->stats[i];
   out[0] = p->fast ? 1 : 0;
+  return TSIM_OK;
+}
+
+extern "C" int tsim_program_path_counts(tsim_program *p, int64_t out[TSIM_PATH_COUNT], int32_t reset) {
+  if (!p || !out) return tsim_fail(TSIM_EINVAL, "NULL argument");
+  for (int i = 0; i < TSIM_PATH_COUNT; ++i) {
+    out[i] = p->path_count[i];
+    if (reset) p->path_count[i] = 0;
+  }
   return TSIM_OK;
 }
 

@@ -14,6 +14,7 @@
 #include "tsim_direct.hip.h"
 #include "tsim_lw_fastm.hip.h"
 #include "tsim_wide.hip.h"
+#include "tsim_gen.hip.h"
 
 using namespace tsimk;
 using namespace tsimhost;
@@ -288,6 +289,7 @@ static int launch_over(tsim_program *p, const SampleArgs *ctx, int n_ctx, uint32
   const size_t lds4 = (size_t)(2 * ctx[0].WF + 2 * ctx[0].WO) * blk * 4 + 2 * tile_bytes;
   if (lds4 > 64 * 1024) return tsim_fail(TSIM_ENOTSUP, "v4 kernel needs %zu B of LDS", lds4);
   const unsigned grid = (unsigned)p->n_cu;
+  ++p->path_count[TP_OVER];
   switch (p->v4_max_nch) {
 #define TSIM_LO(N) case N: hipLaunchKernelGGL((k_sample4_over<4, N>), dim3(grid), dim3(blk), lds4, hs, M); break;
     TSIM_LO(2) TSIM_LO(4) TSIM_LO(6) TSIM_LO(8) TSIM_LO(10) TSIM_LO(12) TSIM_LO(14)
@@ -335,6 +337,7 @@ static int launch_hw(tsim_program *p, const SampleArgs *ctx, int n_ctx, int max_
   // (blocks of 512 / 1024 threads - more helper waves per row - were tried: no faster alone, the row pass is not the chain;
   // next to a first pass slower, 8.8 -> 8.3 / 5.9e10 at --steps 200)
   const int nch = workers ? p->v4_max_nch : 0;
+  ++p->path_count[TP_HW];
 #define TSIM_LHW(WV, N) case N: hipLaunchKernelGGL((k_sample_hw<WV, N>), dim3(grid), dim3(256), ldsw, hs, H); break;
   if (wmax == 1) switch (nch) {
     TSIM_LHW(1, 0) TSIM_LHW(1, 2) TSIM_LHW(1, 4) TSIM_LHW(1, 6) TSIM_LHW(1, 8) TSIM_LHW(1, 10) TSIM_LHW(1, 12) TSIM_LHW(1, 14) TSIM_LHW(1, 16)
@@ -423,6 +426,7 @@ static int flush_batch(tsim_program *p) {
     auto kfn = k_sample4h_multi<4, N, NW>;                                                                   \
     if (!p->hm_attr_set) /* (the workers' list counts are 2 KB of static LDS) */                            \
       HIP_TRY(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024)); \
+    ++p->path_count[TP_SAMPLE4H_MULTI];                                                                      \
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(NW * 64), lds_m, hs, M);                                        \
   } break;
     TSIM_LHM(2) TSIM_LHM(4) TSIM_LHM(6) TSIM_LHM(8) TSIM_LHM(10) TSIM_LHM(12) TSIM_LHM(14) TSIM_LHM(16)
@@ -659,11 +663,11 @@ static int launch_wide(tsim_program *p, int n, const SampleArgs *const *args, in
 #define TSIM_LWIDE(N)                                                                                                   \
   case N: {                                                                                                             \
     auto kfn = k_sample_wide<N, TSIMK_WIDE_K>;                                                                          \
-    static bool attr_set = false;                                                                                       \
-    if (!attr_set) {                                                                                                    \
+    if (!(p->wide_attr_set & (1u << N))) { /* per handle: the attribute is per device */                   \
       HIP_TRY(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));     \
-      attr_set = true;                                                                                                  \
+      p->wide_attr_set |= 1u << N;                                                                                      \
     }                                                                                                                   \
+    ++p->path_count[TP_WIDE];                                                                                           \
     hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(L.block), L.lds, s, W);                                          \
   } break;
   switch (wo32) {
@@ -779,6 +783,7 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
     w.list_cap = (int)list_cap;
     w.n_lists = kWideLists;
     w.resident = resident ? 1 : 0;
+    ++p->path_count[TP_SAMPLE4W];
     hipLaunchKernelGGL((k_sample4w<1, kWideK>), dim3((unsigned)grid1), dim3(kWideBlock), ldsw, s, w);
     HIP_TRY(hipGetLastError());
     if (prof && !(from_lists && p->prof_light)) { int r = prof_event(p, s, from_lists ? PROF_HARD : PROF_PASS1); if (r) return r; }
@@ -877,6 +882,7 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
     if (a.WF == 1) hipLaunchKernelGGL((k_sample_lw_fast<2, N>), dim3((unsigned)gridf), dim3(blk1), 0, s, M); \
     else hipLaunchKernelGGL((k_sample_lw_fast<4, N>), dim3((unsigned)gridf), dim3(blk1), 0, s, M);          \
     break;
+      ++p->path_count[TP_LW_FAST1];
       switch (n_out) {
         TSIM_LF1(1) TSIM_LF1(2) TSIM_LF1(3) TSIM_LF1(4) TSIM_LF1(5) TSIM_LF1(6) TSIM_LF1(7) TSIM_LF1(8)
         default: return tsim_fail(TSIM_ESTATE, "fast record with %d outputs", n_out);
@@ -885,10 +891,12 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
       l.list_cap = (int)cap1;
     } else if (reg_form) {
       // narrow rows: everything in registers, no LDS
+      ++p->path_count[TP_LW_REG];
       if (a.WF == 1) hipLaunchKernelGGL(k_sample_lw_reg<2>, dim3((unsigned)grid1), dim3(blk1), 0, s, l);
       else hipLaunchKernelGGL(k_sample_lw_reg<4>, dim3((unsigned)grid1), dim3(blk1), 0, s, l);
     } else {
       if (lds1 > 64 * 1024) return tsim_fail(TSIM_ENOTSUP, "num_f + num_outputs too large for LDS staging (%zu B)", lds1);
+      ++p->path_count[p->lw_wide ? TP_LW_LDS_WIDE : TP_LW_LDS];
       if (p->lw_wide) hipLaunchKernelGGL(k_sample_lw<true>, dim3((unsigned)grid1), dim3(blk1), lds1, s, l);
       else hipLaunchKernelGGL(k_sample_lw<false>, dim3((unsigned)grid1), dim3(blk1), lds1, s, l);
     }
@@ -979,6 +987,7 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
     auto kfn = k_sample4h<4, N, NW>;                                                                        \
     if (!p->h_attr_set)                                                                                     \
       HIP_TRY(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+    ++p->path_count[TP_SAMPLE4H];                                                                           \
     hipLaunchKernelGGL(kfn, dim3((unsigned)gridh), dim3(NW * 64), ldsh, s, ah, group_tiles, loop_stride,    \
                        p->d_feedback);                                                                      \
   } break;
@@ -999,6 +1008,7 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
     }
     const long long grid4 = (B2 + blk - 1) / blk * nlists + a4.has_check;
     if (grid4 > 0x7FFFFFFFll) return tsim_fail(TSIM_ENOTSUP, "batch too large");
+    if (grid4 > 0) ++p->path_count[TP_SAMPLE4];
     if (grid4 > 0) switch (p->v4_max_nch) {
 #define TSIM_L4(N) case N: hipLaunchKernelGGL((k_sample4<4, N>), dim3((unsigned)grid4), dim3(blk), lds4, s, a4); break;
       TSIM_L4(2) TSIM_L4(4) TSIM_L4(6) TSIM_L4(8) TSIM_L4(10) TSIM_L4(12) TSIM_L4(14)
@@ -1011,6 +1021,7 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
   }
   int wmax = 1;
   for (int w : p->comp_w) wmax = std::max(wmax, w);
+  ++p->path_count[TP_ROWS];
   if (int r = tsim_launch_rows(p, wmax, a, grid, block, lds, s)) return r;
   if (prof && !(p->prof_light && use_tables)) { int r = prof_event(p, s, PROF_FULL); if (r) return r; }
   return finish();
@@ -1250,6 +1261,7 @@ static int steps_group_fused(tsim_program *p, int n, const uint64_t *const *d_f,
     if (WF == 1) hipLaunchKernelGGL((k_sample_lw_fast<2, N>), dim3((unsigned)grid), dim3(blk1), 0, s, M); \
     else hipLaunchKernelGGL((k_sample_lw_fast<4, N>), dim3((unsigned)grid), dim3(blk1), 0, s, M);        \
     break;
+    ++p->path_count[TP_LW_FAST];
     switch (n_out) {
       TSIM_LF(1) TSIM_LF(2) TSIM_LF(3) TSIM_LF(4) TSIM_LF(5) TSIM_LF(6) TSIM_LF(7) TSIM_LF(8)
       default: return tsim_fail(TSIM_ESTATE, "fast record with %d outputs", n_out);
@@ -1283,11 +1295,15 @@ static int steps_group_fused(tsim_program *p, int n, const uint64_t *const *d_f,
       l = l_lut + (2u << c.n_out);
     }
     const size_t ldsb = (size_t)l * 4;
+    ++p->path_count[TP_LW_FASTM];
     if (WF == 1) hipLaunchKernelGGL(k_sample_lw_fastm<2>, dim3((unsigned)grid), dim3(blk1), ldsb, s, M);
     else hipLaunchKernelGGL(k_sample_lw_fastm<4>, dim3((unsigned)grid), dim3(blk1), ldsb, s, M);
     ++p->stat_fast;
-  } else if (WF == 1) hipLaunchKernelGGL(k_sample_lw_multi<2>, dim3((unsigned)grid), dim3(blk1), 0, s, M);
-  else hipLaunchKernelGGL(k_sample_lw_multi<4>, dim3((unsigned)grid), dim3(blk1), 0, s, M);
+  } else {
+    ++p->path_count[TP_LW_MULTI];
+    if (WF == 1) hipLaunchKernelGGL(k_sample_lw_multi<2>, dim3((unsigned)grid), dim3(blk1), 0, s, M);
+    else hipLaunchKernelGGL(k_sample_lw_multi<4>, dim3((unsigned)grid), dim3(blk1), 0, s, M);
+  }
   HIP_TRY(hipGetLastError());
   TSIM_MARK("launch");
   if (prof) {
@@ -1311,6 +1327,192 @@ static int steps_group_fused(tsim_program *p, int n, const uint64_t *const *d_f,
     // (letting the hard rows wait for the lane's NEXT first pass was tried - profiles/r03/hard_lag_experiment.txt: slower)
     p->flush_inline = s;
   }
+  const int rf = flush_chunks(p);
+  TSIM_MARK("hard");
+  return rf;
+}
+
+// Any narrow program (k_sample_gen, tsim_gen.hip.h): up to TSIMK_GEN_MAX_STEPS batches as one grid of chip-resident blocks, the
+// rows staged in LDS wave by wave; hard rows to each batch's lists, the group's hard-row grid behind it - the protocol of
+// steps_group_fused, whose bookkeeping this shares.
+struct GenLayout {
+  int block = 0, nbuf = 1;
+  size_t lds = 0;
+  int l_wave = 0, wave_bytes = 0;
+};
+static GenLayout gen_layout(const tsim_program *p, int WF32, int n_steps) {
+  GenLayout L;
+  if (!p->gr_off) return L;
+  const uint32_t *h = &p->img[p->gr_off];
+  auto up = [](size_t v, size_t a) { return (v + a - 1) / a * a; };
+  size_t off = up((size_t)h[GR_LDS_WORDS], 4) * 4;
+  off += (size_t)n_steps * 2 * TSIMK_GEN_KEYS * 4;
+  off = up(off, 16);
+  const size_t buf = (size_t)64 * WF32 * 4;
+  // two resident blocks of 16 waves per CU (the register budget of the kernel allows it) when the row buffers fit 80 KB
+  // each, double-buffered if that still fits; wider rows: fewer waves per block
+  for (int blk : {1024, 512, 256}) {
+    for (int nbuf : {2, 1}) {
+      const size_t tot = off + (size_t)(blk / 64) * nbuf * buf;
+      if (tot <= (blk == 1024 ? 80u : 64u) * 1024) {
+        L.block = blk;
+        L.nbuf = nbuf;
+        L.l_wave = (int)off;
+        L.wave_bytes = (int)(nbuf * buf);
+        L.lds = tot;
+        return L;
+      }
+    }
+  }
+  return L;
+}
+// can a fused group of this program go to k_sample_gen?  (32-bit row offsets: batches below 2^28 rows, a shot range that does
+// not cross a multiple of 2^32)
+static bool gen_applies(const tsim_program *p, int64_t B, int32_t num_f, int64_t shot_offset) {
+  if (!(p->lw && !p->lw_wide && p->gr_off != 0 && p->knobs.gen > 0)) return false;
+  if (B <= 0 || B >= (1ll << 28)) return false;
+  if (((unsigned long long)shot_offset >> 32) != ((unsigned long long)(shot_offset + B - 1) >> 32)) return false;
+  const int WF32 = 2 * std::max(1, (num_f + 63) / 64);
+  if (WF32 < (int)p->img[p->gr_off + GR_WF32_MIN] || WF32 > 64) return false;
+  return gen_layout(p, WF32, 1).block != 0;
+}
+
+static int steps_group_gen(tsim_program *p, int n, const uint64_t *const *d_f, int64_t B, int32_t num_f, uint32_t key[2],
+                           int64_t shot_offset, void *const *d_out, float *const *d_dev, uint32_t flags, const LaunchPlan &plan) {
+  const bool packed = (flags & TSIM_PIPE_OUT_BIT_PACKED) != 0;
+  if (!p->deferred.empty())
+    if (int r = flush_batch(p)) return r;
+  const int lanes = p->knobs.fused_lanes > 0 ? p->knobs.fused_lanes : ((long long)n * B <= (1ll << 21) ? 3 : 2);
+  hipStream_t s = p->slots[1 + (int)(p->steps_groups++ % (unsigned long long)lanes)].side;
+  if (!(flags & TSIM_PIPE_INPUTS_READY) && p->stream != s) {
+    if (!p->sync_ev) HIP_TRY(hipEventCreateWithFlags(&p->sync_ev, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(p->sync_ev, p->stream));
+    HIP_TRY(hipStreamWaitEvent(s, p->sync_ev, 0));
+  }
+  const int WF = std::max(1, (num_f + 63) / 64);
+  const GenLayout L = gen_layout(p, 2 * WF, n);
+  if (!L.block) return tsim_fail(TSIM_ESTATE, "k_sample_gen does not fit");
+  const long long bps = (B + 1023) / 1024;  // hard-row lists by row blocks of 1024 rows, whatever the kernel's block
+  const int n_lists = plan.lists;
+  const long long list_cap = (bps + n_lists - 1) / n_lists * 1024;
+  if (list_cap > 0x7FFFFFFFll) return tsim_fail(TSIM_ENOTSUP, "batch too large for the row lists");
+  const bool has_check = shot_offset == 0;
+  GenArgs G{};
+  G.img = p->d_img;
+  G.tab = p->d_lw_tab;
+  G.B = B;
+  G.shot_offset = shot_offset;
+  G.n_steps = n;
+  G.chunks_per_step = (int)((B + 63) / 64);
+  G.has_check = has_check ? 1 : 0;
+  G.out_rb = (p->num_outputs + 7) / 8;
+  G.WF32 = 2 * WF;
+  G.lw_off = p->lw_off;
+  G.gr_off = p->gr_off;
+  G.list_cap = (int)list_cap;
+  G.n_lists = n_lists;
+  G.nbuf = L.nbuf;
+  G.l_wave = L.l_wave;
+  G.wave_bytes = L.wave_bytes;
+  p->last_lists = n_lists;
+  int slots[TSIMK_GEN_MAX_STEPS];
+  for (int j = 0; j < n; ++j)
+    if (p->slots[1 + (int)((p->steps_slot + (unsigned long long)j) % (unsigned long long)TSIM_PIPELINE_SLOTS)].deferred) {
+      if (int r = tsim_flush_hard(p)) return r;
+      break;
+    }
+  for (int j = 0; j < n; ++j) {
+    const int sidx = 1 + (int)(p->steps_slot++ % (unsigned long long)TSIM_PIPELINE_SLOTS);
+    slots[j] = sidx;
+    tsim_program::Slot &sl = p->slots[sidx];
+    if (sl.deferred) return tsim_fail(TSIM_ESTATE, "pipeline slot %d still holds a parked launch", sidx - 1);
+    if ((size_t)list_cap * n_lists * 4 > sl.hard_sz) return tsim_fail(TSIM_ESTATE, "hard-row list too small");
+    if (int r = slot_order_after_previous(p, sl, s)) return r;
+    uint32_t o[4];
+    tsim_key_split(key[0], key[1], o);  // key, subkey = split(key)  (sampler.py:399)
+    key[0] = o[0];
+    key[1] = o[1];
+    SampleArgs &a = sl.ctx;
+    a = SampleArgs{};
+    if (int r = fill_sample_args(p, sl, a, d_f[j], B, num_f, o[2], o[3], shot_offset, (uint64_t *)d_out[j], d_dev ? d_dev[j] : nullptr, s,
+                                 sidx, packed))
+      return r;
+    GenStep &st = G.step[j];
+    st.f = d_f[j];
+    st.out = a.out;
+    st.out_compact = a.out_compact;
+    st.hard_index = (uint32_t *)sl.hard;
+    uint32_t *ctl = sl.ctl + sl.parity * (TSIMK_LW_LISTS + 1) * 32;
+    st.ctl = ctl;
+    st.ctl_next = sl.ctl + (sl.parity ^ 1) * (TSIMK_LW_LISTS + 1) * 32;
+    sl.parity ^= 1;
+    if (p->total_keys <= TSIMK_INLINE_KEYS) {
+      memcpy(st.keys, a.inline_keys, sizeof(uint32_t) * 2 * (size_t)p->total_keys);
+    } else {  // (the hard-row kernels read the k_keygen buffer; this pass wants the subkeys in its arguments)
+      uint32_t k0 = o[2], k1 = o[3];
+      for (int i = 0; i < p->total_keys; ++i) {
+        uint32_t a0 = 0u, a1 = 0u, b0 = 0u, b1 = 1u;
+        threefry2x32(k0, k1, a0, a1);
+        threefry2x32(k0, k1, b0, b1);
+        st.keys[2 * i] = b0;
+        st.keys[2 * i + 1] = b1;
+        k0 = a0;
+        k1 = a1;
+      }
+    }
+    a.row_index = st.hard_index;
+    a.row_count = ctl;
+    a.row_lists = n_lists;
+    a.row_list_cap = (int)list_cap;
+    a.check_row = has_check ? ctl + 32 * TSIMK_LW_LISTS : nullptr;
+    a.no_check = has_check ? 0 : 1;
+    a.row_slot_begin = 0;
+    a.row_slot_end = 0;
+  }
+  const long long chunks = (long long)G.chunks_per_step * n;
+  const int wpb = L.block / 64;
+  const int per_cu = std::max(1, std::min(2048 / L.block, (int)((160 * 1024) / (L.lds + 64))));
+  const long long grid = std::max(1ll, std::min((long long)p->n_cu * per_cu, (chunks + wpb - 1) / wpb));
+  TSIM_MARK("args");
+  if (int r = tsim_tables_slice(p, s)) return r;  // (a table build in the background: its next slice goes first)
+  const bool prof = p->profiling && (p->prof_counter++ % p->prof_every == 0);
+  if (prof) { if (int r = prof_event(p, s, PROF_BEGIN)) return r; }
+  const int wo32 = (int)p->img[p->gr_off + GR_WO32];
+  ++p->path_count[TP_GEN];
+#define TSIM_LGEN(N)                                                                                                    \
+  case N: {                                                                                                             \
+    auto kfn = k_sample_gen<N>;                                                                                         \
+    if (!(p->gen_attr_set & (1u << N))) {                                                                               \
+      HIP_TRY(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));           \
+      p->gen_attr_set |= 1u << N;                                                                                       \
+    }                                                                                                                   \
+    hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(L.block), L.lds, s, G);                                          \
+  } break;
+  switch (wo32) {
+    TSIM_LGEN(2) TSIM_LGEN(4) TSIM_LGEN(6) TSIM_LGEN(8) TSIM_LGEN(10) TSIM_LGEN(12) TSIM_LGEN(14) TSIM_LGEN(16)
+    default: return tsim_fail(TSIM_ESTATE, "gen record with %d output words", wo32);
+  }
+#undef TSIM_LGEN
+  HIP_TRY(hipGetLastError());
+  TSIM_MARK("launch");
+  if (prof) {
+    if (int r = prof_event(p, s, PROF_PASS1)) return r;
+    p->prof_steps += n;
+  }
+  hard_geometry(p, WF, (p->num_outputs + 63) / 64);
+  for (int j = 0; j < n; ++j) {
+    tsim_program::Slot &sl = p->slots[slots[j]];
+    sl.ctx_check = has_check;
+    sl.deferred = true;
+    sl.pending = true;
+    sl.p1_stream = s;
+    sl.partial = false;
+    p->deferred.push_back(slots[j]);
+  }
+  p->stat_begins += (unsigned long long)n;
+  p->stat_deferred += (unsigned long long)n;
+  ++p->stat_fused;
+  if ((long long)n * B <= p->knobs.hard_inline_rows) p->flush_inline = s;
   const int rf = flush_chunks(p);
   TSIM_MARK("hard");
   return rf;
@@ -1359,6 +1561,7 @@ static int steps_group_direct(tsim_program *p, int n, const uint64_t *const *d_f
     M.step[j].out_compact = packed ? (uint8_t *)d_out[j] : series;
     sl.compact_out = nullptr;
   }
+  ++p->path_count[TP_DIRECT_MULTI];
   if (WF == 1) hipLaunchKernelGGL(k_direct_multi<2>, dim3((unsigned)(bps * n)), dim3(256), 0, s, M);
   else hipLaunchKernelGGL(k_direct_multi<4>, dim3((unsigned)(bps * n)), dim3(256), 0, s, M);
   HIP_TRY(hipGetLastError());
@@ -1451,9 +1654,11 @@ extern "C" int tsim_sample_steps_device(tsim_program *p, int32_t n_steps, const 
   while (done < n_steps) {
     // the fused first pass applies when the register form does, the subkeys fit its records, and the launch plan
     // says "tables, short lists": decided per group - the plan follows the feedback of earlier launches
-    bool fused = p->lw && !p->lw_wide && p->lw_reg && p->knobs.lw_reg && p->knobs.fused_steps && (WF == 1 || WF == 2) && WO == 1 &&
-                 p->total_keys > 0 && p->total_keys <= TSIMK_LWM_KEYS && p->num_outputs > 0 && B > 0 && B <= 0x7FFFFFFFll &&
-                 p->knobs.defer_group >= 1;
+    const bool reg_fused = p->lw && !p->lw_wide && p->lw_reg && p->knobs.lw_reg && (WF == 1 || WF == 2) && WO == 1 && p->total_keys > 0 &&
+                           p->total_keys <= TSIMK_LWM_KEYS;
+    // ... and every other narrow program through k_sample_gen (rows in LDS: any row width, up to 256 outputs)
+    const bool gen_fused = gen_applies(p, B, num_f, shot_offset) && (p->knobs.gen == 2 || !reg_fused);
+    bool fused = (reg_fused || gen_fused) && p->knobs.fused_steps && p->num_outputs > 0 && B > 0 && B <= 0x7FFFFFFFll && p->knobs.defer_group >= 1;
     // no components at all: the streaming kernel for direct outputs (rows of at most 128 f bits and 128 outputs)
     if (p->comps.empty() && p->knobs.fused_steps && p->num_outputs > 0 && p->num_outputs <= 128 && WF <= 2 && p->lw_direct_chunks > 0 &&
         p->knobs.direct_runs && B > 0 && B <= 0x7FFFFFFFll) {
@@ -1525,7 +1730,7 @@ extern "C" int tsim_sample_steps_device(tsim_program *p, int32_t n_steps, const 
     if (fused) {
       // even groups of at most TSIMK_LWM_MAX_STEPS batches
       const int left = n_steps - done;
-      const int gmax = std::min(TSIMK_LWM_MAX_STEPS, p->knobs.fused_max);
+      const int gmax = std::min(gen_fused ? TSIMK_GEN_MAX_STEPS : TSIMK_LWM_MAX_STEPS, p->knobs.fused_max);
       // (20 batches as 7+7+6; 5+5+5+5 - both lanes ending together - measured slower: a launch more)
       const int groups = (left + gmax - 1) / gmax;
       const int n = (left + groups - 1) / groups;
@@ -1536,8 +1741,12 @@ extern "C" int tsim_sample_steps_device(tsim_program *p, int32_t n_steps, const 
         for (int j = 0; j < n; ++j)
           if (int r = slot_prepare(p, 1 + (int)((p->steps_slot + (unsigned long long)j) % TSIM_PIPELINE_SLOTS), hard_bytes)) return r;
       }
-      if (int r = steps_group_fused(p, n, d_f + done, B, num_f, key, shot_offset, d_out + done, d_max_norm_dev ? d_max_norm_dev + done : nullptr,
+      if (gen_fused) {
+        if (int r = steps_group_gen(p, n, d_f + done, B, num_f, key, shot_offset, d_out + done, d_max_norm_dev ? d_max_norm_dev + done : nullptr,
                                     flags, plan))
+          return r;
+      } else if (int r = steps_group_fused(p, n, d_f + done, B, num_f, key, shot_offset, d_out + done,
+                                           d_max_norm_dev ? d_max_norm_dev + done : nullptr, flags, plan))
         return r;
       done += n;
     } else {

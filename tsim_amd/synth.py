@@ -582,3 +582,73 @@ def physical_program(*, num_f: int, n_direct: int, components: list[dict], seed:
         pos += n
     nd = num_detectors if num_detectors is not None else n_direct
     return make_program(comps, direct, num_outputs, nd)
+
+
+# --------------------------------------------------------------------------
+# shape classes around the BASELINE estimates (scripts/shape_map.py, tests/test_gpu_shape_classes.py)
+# --------------------------------------------------------------------------
+#
+# SURVEY 8(a) marks F, T_x, n_direct and num_f of every BASELINE circuit as [ESTIMATE]: real compiled programs may land
+# anywhere around the five configurations above, and the reference treats every shape alike (sampler.py:117-167,
+# compile/pipeline.py:55-102).  A class = one wall of the kernels' eligibility rules moved on its own from the nearest
+# configuration (`near`): f-row width, output count, components (number, narrow / wide mix), outputs per component,
+# selected bits per component.
+
+
+def _graph_counts(n: int, top: int) -> list[int]:
+    """n + 1 non-decreasing graph counts growing to ``top`` (the C2 profile, scaled)."""
+    g = [max(1, int(round(top * (k + 1) / (n + 1)))) for k in range(n + 1)]
+    for k in range(1, n + 1):
+        g[k] = max(g[k], g[k - 1])
+    return g
+
+
+def _narrow(n: int, F: int, top: int = 40) -> dict:
+    return dict(n=n, F=F, G=_graph_counts(n, top))
+
+
+def _wide(n: int, F: int) -> dict:
+    return dict(n=n, F=F, G=[1, 2, 2, 3, 3, 4, 4, 5, 5][: n + 1], density=0.08)
+
+
+SHAPE_CLASSES = {
+    # ---- the f-row width wall (narrow component inside ever wider rows; C2 otherwise)
+    "f64": dict(near="C2", num_f=64, n_direct=15, components=[_narrow(5, 32)]),
+    "f128": dict(near="C2", num_f=128, n_direct=15, components=[_narrow(5, 32)]),
+    "f160": dict(near="C2", num_f=160, n_direct=15, components=[_narrow(5, 32)]),
+    "f320": dict(near="C2", num_f=320, n_direct=15, components=[_narrow(5, 32)]),
+    "f600": dict(near="C2", num_f=600, n_direct=15, components=[_narrow(5, 32)]),
+    # ---- the output-count wall
+    "out64": dict(near="C3", num_f=128, n_direct=59, components=[_narrow(5, 32)]),
+    "out65": dict(near="C3", num_f=128, n_direct=60, components=[_narrow(5, 32)]),
+    "out121": dict(near="C3", num_f=128, n_direct=116, components=[_narrow(5, 32)]),
+    "out121_f320": dict(near="C5", num_f=320, n_direct=118, components=[_narrow(3, 30, 8)]),  # the plausible REAL d = 5 surface + T shape
+    "out260_f320": dict(near="C5", num_f=320, n_direct=255, components=[_narrow(5, 32)]),
+    # ---- components: number and mix
+    "3narrow": dict(near="C4", num_f=64, n_direct=10, components=[_narrow(1, 12, 6), _narrow(1, 12, 6), _narrow(6, 40, 64)]),
+    "6narrow": dict(near="C4", num_f=64, n_direct=10, components=[_narrow(1, 8, 4), _narrow(1, 8, 4), _narrow(1, 10, 4), _narrow(2, 12, 8), _narrow(2, 16, 8), _narrow(3, 24, 16)]),
+    "6narrow_f320": dict(near="C4", num_f=320, n_direct=100, components=[_narrow(1, 8, 4), _narrow(1, 8, 4), _narrow(1, 10, 4), _narrow(2, 12, 8), _narrow(2, 16, 8), _narrow(3, 24, 16)]),
+    "1wide": dict(near="C5", num_f=320, n_direct=118, components=[_wide(3, 200)]),
+    "2wide": dict(near="C5", num_f=320, n_direct=118, components=[_wide(2, 100), _wide(3, 150)]),
+    "narrow+wide": dict(near="C5", num_f=320, n_direct=118, components=[_narrow(2, 20, 8), _wide(3, 200)]),
+    # ---- outputs per component
+    "n1": dict(near="C2", num_f=64, n_direct=15, components=[_narrow(1, 32, 8)]),
+    "n8": dict(near="C2", num_f=64, n_direct=15, components=[_narrow(8, 32)]),
+    "n9": dict(near="C2", num_f=64, n_direct=15, components=[_narrow(9, 32)]),
+    "n11": dict(near="C2", num_f=64, n_direct=15, components=[_narrow(11, 32)]),
+    "n17total": dict(near="C4", num_f=64, n_direct=10, components=[_narrow(5, 20, 24), _narrow(6, 20, 24), _narrow(6, 20, 24)]),
+    # ---- selected bits per component
+    "F16": dict(near="C2", num_f=64, n_direct=15, components=[_narrow(5, 16)]),
+    "F59": dict(near="C2", num_f=64, n_direct=5, components=[_narrow(5, 59)]),
+    "F60": dict(near="C2", num_f=64, n_direct=4, components=[_narrow(5, 60)]),  # F + n = 65 parameters: a "wide" component in narrow rows
+    "F255": dict(near="C5", num_f=320, n_direct=65, components=[_wide(3, 255)]),
+    "F300": dict(near="C5", num_f=320, n_direct=20, components=[_wide(3, 300)]),
+    "F200_f600": dict(near="C5", num_f=600, n_direct=118, components=[_wide(3, 200)]),  # max_f_index >= 512
+}
+
+
+def shape_class_program(name: str, *, seed: int = 42) -> tuple[CompiledProgram, dict]:
+    """``(program, class dict)`` of one entry of ``SHAPE_CLASSES`` (normalised probability model, shuffled output columns off)."""
+    c = SHAPE_CLASSES[name]
+    prog = physical_program(num_f=c["num_f"], n_direct=c["n_direct"], components=[dict(x) for x in c["components"]], seed=seed)
+    return prog, dict(c, name=name, p_bit=0.02)

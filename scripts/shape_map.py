@@ -98,6 +98,7 @@ def main():
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--check", action="store_true")
     ap.add_argument("--out", default="")
+    ap.add_argument("--no-base", action="store_true", help="skip the BASELINE configurations (profiling one class)")
     a = ap.parse_args()
     from tsim_amd import backend, synth
 
@@ -110,7 +111,7 @@ def main():
 
     emit(f"# shape map: {a.shots} shots per step, {a.steps} steps per region, median of 3 regions; p_bit 0.02; TSIM_AMD_TUNE={os.environ.get('TSIM_AMD_TUNE', '')!r}")
     base = {}
-    for cn in ("C2", "C3", "C4", "C5"):
+    for cn in (() if a.no_base else ("C2", "C3", "C4", "C5")):
         prog, cfg = synth.config_program(cn)
         r = measure(backend, prog, cfg["num_f"], cfg["p_bit"], a.shots, a.steps)
         base[cn] = r["rate"]
@@ -125,7 +126,7 @@ def main():
         except Exception as e:  # a class the library refuses is a cliff of its own
             emit(f"{n:14s} FAILED: {e}")
             continue
-        ratio = r["rate"] / base[c["near"]]
+        ratio = r["rate"] / base.get(c["near"], float("nan"))
         if worst is None or ratio < worst[1]:
             worst = (n, ratio)
         emit(f"{n:14s} num_f {c['num_f']:4d} outputs {prog.num_outputs:4d} comps {[(len(x.output_indices), len(x.f_selection)) for x in prog.components]}"

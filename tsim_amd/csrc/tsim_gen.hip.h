@@ -17,11 +17,13 @@
 //     triples): the lane walks ITS set bits, each adds RANK[ordinal][position inside f_sel] to the colex rank of the
 //     pattern (tsim_lw.hip.h) - weight <= table depth: the threshold tree of the pattern, n_out draws, three tree levels
 //     per memory access (tsim_lw_pass.hip.h);
-//   * everything wave-uniform lives in LDS, copied once per block: runs, component records, rank tables, subkeys.
+//   * everything wave-uniform comes by scalar loads from the program image / the kernel arguments (runs four at a time,
+//     component and word records, subkeys); LDS holds the rows, the rank tables and the pattern bases.
 // Same thresholds, same draws, same hard-row lists as the other first passes: bit-identical results
 // (tests/test_gpu_shape_classes.py runs every class through this kernel, the one-batch path and the oracle).
 #pragma once
 #include "tsim_lw_fast.hip.h"
+#include <type_traits>
 
 namespace tsimk {
 
@@ -30,30 +32,26 @@ namespace tsimk {
 #define TSIMK_GEN_MAX_RUNS 1024
 #define TSIMK_GEN_MAX_COMP 16
 
-// gen record in the program image (uint32 words, 64-byte aligned): header, then the static LDS block
+// gen record in the program image (uint32 words, 64-byte aligned): header, then its tables (image offsets)
 enum {
   GR_NCOMP = 0,
   GR_WO32,       // 32-bit words per output row the record was built for
-  GR_NRUNS,
-  GR_LDS_WORDS,  // words of the static block (copied to LDS word 0 ..)
-  GR_L_RUNS,     // LDS word offsets inside the static block: runs (2 words each: src_word | rot << 8, mask) ...
-  GR_L_RUNB,     // ... WO32 + 1 run boundaries ...
-  GR_L_FLIPS,    // ... WO32 constant-flip words ...
-  GR_L_COMP,     // ... component records (GC_WORDS each)
+  GR_LDS_WORDS,  // words of the LDS block (the components' rank tables, copied to LDS word 0 ..; behind them 8 pattern bases per component)
+  GR_LDS_SRC,    // image offset of that block
+  GR_DST,        // image offset of WO32 x (first run group, groups, flip word, 0)
+  GR_GROUPS,     // image offset of the run groups: 8 words = 2 x (f word, rotate right by, mask, 0), padded with mask 0
+  GR_COMP,       // image offset of the component records (GC_WORDS each)
   GR_WF32_MIN,   // the f row must have at least this many 32-bit words
   GR_WORDS = 16
 };
-// component record inside the static block
+// component record
 enum {
   GC_NOUT = 0, GC_F, GC_KEYBASE, GC_NWORDS,
-  GC_L_WORDS,   // LDS word offset of NWORDS x (f word index, selection mask, selected bits in lower words)
+  GC_WORDREC,   // image offset of NWORDS x (f word index, selection mask, selected bits in lower words, 0)
   GC_L_RANK,    // LDS word offset of RANK[TSIMK_LW_MAX_WEIGHT][F]: C(position, ordinal + 1)
-  GC_L_OUTPOS,  // LDS word offset of the n_out output columns
+  GC_OUTPOS,    // image offset of the n_out output columns
   GC_RSV,
-  // filled by the kernel from the live LW record (the table depth changes while a handle lives, tsim_tables.hip)
-  GC_WMAX = 8, GC_TAB_LO, GC_TAB_HI, GC_TAB_BYTES,
-  GC_BASES = 16,  // 8 words
-  GC_WORDS = 32
+  GC_WORDS = 8
 };
 
 struct GenStep {
@@ -80,12 +78,22 @@ struct GenArgs {
   GenStep step[TSIMK_GEN_MAX_STEPS];
 };
 
+#ifndef TSIMK_GEN_UNIFORM_WALK
+#define TSIMK_GEN_UNIFORM_WALK 1
+#endif
+#ifndef TSIMK_GEN_SGPRS
+#define TSIMK_GEN_SGPRS 96   // 8 waves per SIMD: two blocks of 16 waves per CU
+#endif
+
 template <int WO32>
-__global__ void __launch_bounds__(1024) k_sample_gen(GenArgs A) {
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(TSIMK_GEN_SGPRS))) k_sample_gen(GenArgs A) {
   typedef const __attribute__((address_space(4))) uint8_t *cbytes;
   typedef const __attribute__((address_space(4))) GenStep *cstep;
   typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+  typedef const __attribute__((address_space(4))) u32x4 *cptr4;
+  typedef const __attribute__((address_space(4))) u32x8 *cptr8;
   typedef __attribute__((address_space(3))) void *lds_ptr_t;
   typedef const __attribute__((address_space(1))) void *glb_ptr_t;
   const int nthr = blockDim.x;
@@ -93,50 +101,39 @@ __global__ void __launch_bounds__(1024) k_sample_gen(GenArgs A) {
   const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   cptr img = (cptr)(uintptr_t)A.img;
   cptr gr = img + A.gr_off;
-  const uint32_t n_comp = gr[GR_NCOMP], n_runs = gr[GR_NRUNS], lds_words = gr[GR_LDS_WORDS];
-  const uint32_t l_comp = gr[GR_L_COMP];
+  const uint32_t n_comp = gr[GR_NCOMP], lds_words = gr[GR_LDS_WORDS];
+  cptr g_dst = img + gr[GR_DST], g_groups = img + gr[GR_GROUPS], g_comp = img + gr[GR_COMP];
   const uint32_t WF32 = (uint32_t)A.WF32;
   uint32_t *L = tsimk_lds;
+  uint32_t *l_bases = L + lds_words;  // [n_comp][8]: index of the first pattern of weight w (live: the table depth changes, tsim_tables.hip)
   cstep steps = (cstep)((cbytes)__builtin_amdgcn_kernarg_segment_ptr() + __builtin_offsetof(GenArgs, step));
-  uint32_t *l_keys = L + ((lds_words + 3u) & ~3u);  // per step: 2 * TSIMK_GEN_KEYS subkey words
 
-  // ---- once per block: the static block, the live table records, the subkeys
+  // ---- once per block: the rank tables and the pattern bases into LDS
   {
-    const uint32_t *g = A.img + A.gr_off + GR_WORDS;
+    const uint32_t *g = A.img + gr[GR_LDS_SRC];
     for (uint32_t i = threadIdx.x; i < lds_words; i += nthr) L[i] = g[i];
-    for (uint32_t i = threadIdx.x; i < 2u * TSIMK_GEN_KEYS * (uint32_t)A.n_steps; i += nthr)
-      l_keys[i] = steps[i / (2u * TSIMK_GEN_KEYS)].keys[i % (2u * TSIMK_GEN_KEYS)];
-    __syncthreads();
-    if (threadIdx.x < n_comp) {
-      const uint32_t *rec = A.img + A.lw_off + threadIdx.x * LW_WORDS;
-      uint32_t *c = L + l_comp + threadIdx.x * GC_WORDS;
-      const uint64_t base = (uint64_t)(uintptr_t)A.tab + (uint64_t)rec[LW_TAB] * 4ull;
-      const uint64_t bytes = ((uint64_t)rec[LW_NPAT] << c[GC_NOUT]) * 4ull;
-      c[GC_WMAX] = rec[LW_WMAX];
-      c[GC_TAB_LO] = (uint32_t)base;
-      c[GC_TAB_HI] = (uint32_t)(base >> 32);
-      c[GC_TAB_BYTES] = bytes > 0xFFFFFFFCull ? 0xFFFFFFFCu : (uint32_t)bytes;
-      for (int k = 0; k < 8; ++k) c[GC_BASES + k] = rec[LW_BASES_INLINE + k];
-    }
+    if (threadIdx.x < 8u * n_comp) l_bases[threadIdx.x] = A.img[A.lw_off + (threadIdx.x >> 3) * LW_WORDS + LW_BASES_INLINE + (threadIdx.x & 7u)];
     __syncthreads();
   }
-  const uint32_t *l_runs = L + gr[GR_L_RUNS], *l_runb = L + gr[GR_L_RUNB], *l_flips = L + gr[GR_L_FLIPS];
 
-  uint8_t *w8 = reinterpret_cast<uint8_t *>(L) + A.l_wave + wv * (uint32_t)A.wave_bytes;
-  uint32_t *w_buf[2] = {reinterpret_cast<uint32_t *>(w8), reinterpret_cast<uint32_t *>(w8) + (A.nbuf == 2 ? 64u * WF32 : 0u)};
+  uint32_t *w0 = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(L) + A.l_wave + wv * (uint32_t)A.wave_bytes);
+  const uint32_t buf_words = A.nbuf == 2 ? 64u * WF32 : 0u;
 
   const uint32_t so_lo = (uint32_t)A.shot_offset, so_hi = (uint32_t)((unsigned long long)A.shot_offset >> 32);
   const uint32_t Bu = (uint32_t)A.B;
   const uint32_t cps = (uint32_t)A.chunks_per_step;
   const uint32_t total = cps * (uint32_t)A.n_steps;
-  (void)n_runs;
 
   // the f rows of chunk (st, ch) -> dst (LDS-DMA: 64 consecutive dwords per instruction, rows as they lie in HBM)
   auto stage_chunk = [&](uint32_t st, uint32_t ch, uint32_t *dst) {
     const uint32_t *src = reinterpret_cast<const uint32_t *>(steps[st].f) + (size_t)ch * 64u * WF32;
     const uint32_t valid = (Bu - ch * 64u < 64u ? Bu - ch * 64u : 64u) * WF32;  // dwords of this chunk inside the batch
     if (valid == 64u * WF32) {
-      for (uint32_t w = 0; w < WF32; ++w) __builtin_amdgcn_global_load_lds((glb_ptr_t)(src + w * 64u + lane), (lds_ptr_t)(dst + w * 64u), 4, 0, 0);
+      // 16 bytes per lane and instruction (1 KB of the chunk each), the last 512 bytes of an odd number of 64-bit words as dwords
+      const uint32_t n16 = WF32 >> 2;
+      for (uint32_t j = 0; j < n16; ++j)
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)(src + j * 256u + 4u * lane), (lds_ptr_t)(dst + j * 256u), 16, 0, 0);
+      for (uint32_t w = 4u * n16; w < WF32; ++w) __builtin_amdgcn_global_load_lds((glb_ptr_t)(src + w * 64u + lane), (lds_ptr_t)(dst + w * 64u), 4, 0, 0);
     } else {
       for (uint32_t w = 0; w < WF32; ++w) {
         const uint32_t j = w * 64u + lane;
@@ -150,8 +147,8 @@ __global__ void __launch_bounds__(1024) k_sample_gen(GenArgs A) {
   if (c >= total) return;
   uint32_t st = c / cps, ch = c - st * cps;  // once; afterwards by increments
   const uint32_t tw_st = tw / cps, tw_ch = tw - tw_st * cps;
-  uint32_t cur = 0;
-  stage_chunk(st, ch, w_buf[0]);
+  uint32_t cur = 0;  // 0 / buf_words: the buffer this chunk's rows are in
+  stage_chunk(st, ch, w0);
   for (;;) {
     cstep S = steps + st;
     const uint32_t row = ch * 64u + lane;
@@ -159,57 +156,80 @@ __global__ void __launch_bounds__(1024) k_sample_gen(GenArgs A) {
     uint32_t st_n = st + tw_st, ch_n = ch + tw_ch;
     if (ch_n >= cps) { ch_n -= cps; ++st_n; }
     const bool more = c + tw < total;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this chunk's rows are in LDS (and every earlier store of this wave has left)
-    if (more && A.nbuf == 2) stage_chunk(st_n, ch_n, w_buf[cur ^ 1u]);
-    const uint32_t *frow = w_buf[cur] + lane * WF32;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // this chunk's rows are in LDS; every read of the other buffer has returned
+    if (more && A.nbuf == 2) stage_chunk(st_n, ch_n, w0 + (cur ^ buf_words));
+    const uint32_t *frow = w0 + cur + lane * WF32;
     if (ch == 0u) {  // the wave that owns a batch's first rows resets the slot's other counter set
       S->ctl_next[32u * lane] = 0u;
       if (lane == 0u) S->ctl_next[32u * TSIMK_LW_LISTS] = 0xFFFFFFFFu;  // "no check row"
     }
-    // ---- K14: direct outputs f[idx] ^ flip (sampler.py:140-145): rotate-and-mask runs per destination word
+    // ---- K14: direct outputs f[idx] ^ flip (sampler.py:140-145): rotate-and-mask runs per destination word, two per group
     uint32_t o[WO32];
-#pragma unroll
-    for (int d = 0; d < WO32; ++d) {
-      uint32_t acc = l_flips[d];
-      const uint32_t r1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)l_runb[d + 1]);
-      for (uint32_t r = (uint32_t)__builtin_amdgcn_readfirstlane((int)l_runb[d]); r < r1; ++r) {
-        const u32x2 run = *reinterpret_cast<const u32x2 *>(&l_runs[2u * r]);
-        const uint32_t ctl = (uint32_t)__builtin_amdgcn_readfirstlane((int)run.x);
-        const uint32_t fw = frow[ctl & 255u];
-        acc ^= __builtin_amdgcn_alignbit(fw, fw, ctl >> 8) & run.y;
+    auto direct_word = [&](auto dc) {
+      constexpr int d = decltype(dc)::value;
+      if constexpr (d < WO32) {
+        const u32x4 dh = *(cptr4)(g_dst + 4 * d);  // first group, groups, flips
+        uint32_t acc = dh.z;
+        for (uint32_t g = 0; g < dh.y; ++g) {
+          const u32x8 grp = *(cptr8)(g_groups + 8u * (dh.x + g));  // two runs: (f word, rotation, mask, 0) each - nothing to decode
+          const uint32_t fw0 = frow[grp[0]], fw1 = frow[grp[4]];
+          acc ^= __builtin_amdgcn_alignbit(fw0, fw0, grp[1]) & grp[2];
+          acc ^= __builtin_amdgcn_alignbit(fw1, fw1, grp[5]) & grp[6];
+        }
+        o[d] = acc;
       }
-      o[d] = acc;
-    }
+    };
+    direct_word(std::integral_constant<int, 0>{});  direct_word(std::integral_constant<int, 1>{});
+    direct_word(std::integral_constant<int, 2>{});  direct_word(std::integral_constant<int, 3>{});
+    direct_word(std::integral_constant<int, 4>{});  direct_word(std::integral_constant<int, 5>{});
+    direct_word(std::integral_constant<int, 6>{});  direct_word(std::integral_constant<int, 7>{});
+    direct_word(std::integral_constant<int, 8>{});  direct_word(std::integral_constant<int, 9>{});
+    direct_word(std::integral_constant<int, 10>{}); direct_word(std::integral_constant<int, 11>{});
+    direct_word(std::integral_constant<int, 12>{}); direct_word(std::integral_constant<int, 13>{});
+    direct_word(std::integral_constant<int, 14>{}); direct_word(std::integral_constant<int, 15>{});
     bool hard = false;
     if (A.has_check && ch == 0u && lane == 0u) {  // the normalisation-check row (sampler.py:66-72): always hard
       hard = true;
       S->ctl[32 * TSIMK_LW_LISTS] = row;
     }
     const uint32_t slo = so_lo + row;  // (the launcher keeps shot_offset + B below the next multiple of 2^32)
-    const uint32_t *keys = l_keys + st * (2u * TSIMK_GEN_KEYS);
-    // ---- the components, in processing order (sampler.py:147-148)
+    cptr kp = (cptr)((cbytes)S + __builtin_offsetof(GenStep, keys));
+    // ---- the components, in processing order (sampler.py:147-148); everything wave-uniform by scalar loads from the image
     for (uint32_t ci = 0; ci < n_comp; ++ci) {
-      const uint32_t *cr = L + l_comp + ci * GC_WORDS;
-      const u32x4 c0 = *reinterpret_cast<const u32x4 *>(cr);
-      const u32x4 c1 = *reinterpret_cast<const u32x4 *>(cr + 4);
-      const u32x4 c2 = *reinterpret_cast<const u32x4 *>(cr + 8);
-      const uint32_t n_out = (uint32_t)__builtin_amdgcn_readfirstlane((int)c0.x), F = (uint32_t)__builtin_amdgcn_readfirstlane((int)c0.y);
-      const uint32_t keybase = (uint32_t)__builtin_amdgcn_readfirstlane((int)c0.z), nwords = (uint32_t)__builtin_amdgcn_readfirstlane((int)c0.w);
-      const uint32_t *cw = L + (uint32_t)__builtin_amdgcn_readfirstlane((int)c1.x);
-      const uint32_t *rank = L + (uint32_t)__builtin_amdgcn_readfirstlane((int)c1.y);
-      const uint32_t *outpos = L + (uint32_t)__builtin_amdgcn_readfirstlane((int)c1.z);
-      const uint32_t wmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)c2.x);
-      const uint64_t tbase = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)c2.z) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)c2.y);
-      const uint32_t tbytes = (uint32_t)__builtin_amdgcn_readfirstlane((int)c2.w);
+      const u32x8 cr = *(cptr8)(g_comp + ci * GC_WORDS);
+      cptr lw = img + A.lw_off + ci * LW_WORDS;
+      const uint32_t n_out = cr[GC_NOUT], F = cr[GC_F], keybase = cr[GC_KEYBASE], nwords = cr[GC_NWORDS];
+      cptr cw = img + cr[GC_WORDREC];
+      cptr outpos = img + cr[GC_OUTPOS];
+      const uint32_t *rank = L + cr[GC_L_RANK];
+      const uint32_t wmax = lw[LW_WMAX];
+      const uint64_t tbase = (uint64_t)(uintptr_t)A.tab + (uint64_t)lw[LW_TAB] * 4ull;
+      const uint64_t tb64 = ((uint64_t)lw[LW_NPAT] << n_out) * 4ull;
+      const uint32_t tbytes = tb64 > 0xFFFFFFFCull ? 0xFFFFFFFCu : (uint32_t)tb64;
       // the descriptor ends with the component's table: a lane whose pattern index means nothing reads zeros, never beyond
       const __amdgpu_buffer_rsrc_t r_tab = __builtin_amdgcn_make_buffer_rsrc((void *)(uintptr_t)tbase, 0, tbytes, 0x00020000);
       // colex rank = sum over the set selected bits, in ascending order, of C(position inside f_sel, ordinal + 1)
       uint32_t ord = 0u, pat = 0u;
+      u32x4 wr = nwords ? *(cptr4)cw : u32x4{0u, 0u, 0u, 0u};  // the next word's record travels while this word's bits are walked
       for (uint32_t wi = 0; wi < nwords; ++wi) {
-        const uint32_t widx = (uint32_t)__builtin_amdgcn_readfirstlane((int)cw[3u * wi]);
-        const uint32_t sw = (uint32_t)__builtin_amdgcn_readfirstlane((int)cw[3u * wi + 1u]);
-        const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)cw[3u * wi + 2u]);
+        const uint32_t widx = wr.x, sw = wr.y, base = wr.z;
         uint32_t m = active ? (frow[widx] & sw) : 0u;
+        if (wi + 1u < nwords) wr = *(cptr4)(cw + 4u * (wi + 1u));
+#if TSIMK_GEN_UNIFORM_WALK
+        // a UNIFORM loop (trip count = the heaviest lane of the wave in this word, no exec masking): lanes without a bit left
+        // run along and add nothing
+        while (__builtin_amdgcn_ballot_w64(m != 0u) != 0ull) {
+          const bool on = m != 0u;
+          uint32_t p;
+          asm("v_ffbl_b32 %0, %1" : "=v"(p) : "v"(m));  // (0xFFFFFFFF for m == 0: the shift below takes its low five bits)
+          const uint32_t pos = base + (uint32_t)__builtin_popcount(sw & ((1u << (p & 31u)) - 1u));
+          const uint32_t oc = ord < (uint32_t)(TSIMK_LW_MAX_WEIGHT - 1) ? ord : (uint32_t)(TSIMK_LW_MAX_WEIGHT - 1);
+          const uint32_t rv = rank[on ? oc * F + pos : 0u];
+          pat += on ? rv : 0u;
+          ord += on ? 1u : 0u;
+          m &= m - 1u;
+        }
+#else
         while (m) {
           const uint32_t p = (uint32_t)__builtin_ctz(m);
           const uint32_t pos = base + (uint32_t)__builtin_popcount(sw & ((1u << p) - 1u));
@@ -218,22 +238,23 @@ __global__ void __launch_bounds__(1024) k_sample_gen(GenArgs A) {
           ++ord;
           m &= m - 1u;
         }
+#endif
       }
       if (ord > wmax) hard = true;
-      pat += cr[GC_BASES + (ord < 7u ? ord : 7u)];
+      pat += l_bases[8u * ci + (ord < 7u ? ord : 7u)];
       pat = hard ? 0u : pat;
       const uint32_t thr = pat << (n_out + 2u);  // byte offset of the pattern's threshold tree inside the component's table
       auto draw = [&](uint32_t i) -> uint32_t {
-        const uint32_t k0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)keys[2u * (keybase + i)]);
-        const uint32_t k1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)keys[2u * (keybase + i) + 1u]);
+        const uint32_t k0 = kp[2u * (keybase + i)], k1 = kp[2u * (keybase + i) + 1u];
         return threefry_bits32_lo(k0, k1, k0 + so_hi, slo) >> 9;
       };
       auto emit = [&](uint32_t i, bool bit) {
-        const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)outpos[i]);
+        const uint32_t dst = outpos[i];
         const uint32_t v = (bit ? 1u : 0u) << (dst & 31u);
+        // (selects, not conditional stores: a chain of `if (word == d) o[d] |= v` is folded into ONE dynamically indexed access
+        // and the row's words move to scratch memory)
 #pragma unroll
-        for (int d = 0; d < WO32; ++d)
-          if ((dst >> 5) == (uint32_t)d) o[d] |= v;
+        for (int d = 0; d < WO32; ++d) o[d] |= ((dst >> 5) == (uint32_t)d) ? v : 0u;
       };
       // the threshold walk, three tree levels per memory access (tsim_lw_pass.hip.h: lw_walk_impl)
       uint32_t node = 1u, i = 0u;
@@ -268,7 +289,7 @@ __global__ void __launch_bounds__(1024) k_sample_gen(GenArgs A) {
     // ---- one buffer only: the next chunk's rows start to travel now (every read of this chunk has returned)
     if (more && A.nbuf != 2) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      stage_chunk(st_n, ch_n, w_buf[0]);
+      stage_chunk(st_n, ch_n, w0);
     }
     // ---- store the row (tabulated rows only: a hard row is written whole by the hard-row kernel)
     if (active && !hard) {
@@ -276,8 +297,10 @@ __global__ void __launch_bounds__(1024) k_sample_gen(GenArgs A) {
       uint8_t *oc = S->out_compact;
       if (out) {
         uint32_t *dst = reinterpret_cast<uint32_t *>(out) + (size_t)row * WO32;
-        if constexpr (WO32 == 4) *reinterpret_cast<u32x4 *>(dst) = u32x4{o[0], o[1], o[2], o[3]};
-        else {
+        if constexpr (WO32 % 4 == 0) {
+#pragma unroll
+          for (int d = 0; d < WO32; d += 4) *reinterpret_cast<u32x4 *>(dst + d) = u32x4{o[d], o[d + 1], o[d + 2], o[d + 3]};
+        } else {
 #pragma unroll
           for (int d = 0; d < WO32; d += 2) *reinterpret_cast<u32x2 *>(dst + d) = u32x2{o[d], o[d + 1]};
         }
@@ -313,7 +336,7 @@ __global__ void __launch_bounds__(1024) k_sample_gen(GenArgs A) {
     c += tw;
     st = st_n;
     ch = ch_n;
-    if (A.nbuf == 2) cur ^= 1u;
+    cur ^= buf_words;
   }
 }
 

@@ -926,10 +926,10 @@ retry_pack:
           }
         }
         // The gen record (k_sample_gen, tsim_gen.hip.h): ANY narrow program - f rows of up to 2048 bits, up to 512 outputs,
-        // up to TSIMK_GEN_MAX_COMP components, up to TSIMK_GEN_KEYS compiled outputs.  One block of words the kernel copies
-        // to LDS as it is: direct-output runs sorted by destination word, their boundaries, the constant flips, a record
-        // per component and behind the records, per component, the (f word, selection mask, selected bits below) triples
-        // of the words that hold selected bits, RANK[ordinal][position inside f_sel] and the output columns.
+        // up to TSIMK_GEN_MAX_COMP components, up to TSIMK_GEN_KEYS compiled outputs.  Direct-output runs sorted by destination
+        // word in groups of four (one scalar load each), the constant flips, a record per component, per component the
+        // (f word, selection mask, selected bits below) records of the words that hold selected bits and the output columns;
+        // RANK[ordinal][position inside f_sel] of every component as one block the kernel copies to LDS.
         p->gr_off = 0;
         {
           const int wo32 = 2 * ((p->num_outputs + 63) / 64);
@@ -963,35 +963,12 @@ retry_pack:
           }
           okg = okg && runs.size() / 2 <= TSIMK_GEN_MAX_RUNS;
           if (okg) {
-            std::vector<uint32_t> blk;  // the static LDS block
-            auto align4 = [&]() { while (blk.size() % 4) blk.push_back(0u); };
-            const uint32_t l_runs = 0;
-            blk.insert(blk.end(), runs.begin(), runs.end());
-            align4();
-            const uint32_t l_runb = (uint32_t)blk.size();
-            blk.insert(blk.end(), runb.begin(), runb.end());
-            align4();
-            const uint32_t l_flips = (uint32_t)blk.size();
-            blk.insert(blk.end(), flips.begin(), flips.end());
-            align4();
-            const uint32_t l_comp = (uint32_t)blk.size();
-            blk.resize(blk.size() + p->comps.size() * GC_WORDS, 0u);
-            for (size_t ci = 0; ci < p->comps.size(); ++ci) {
-              const HostComponent &c = p->comps[ci];
-              std::vector<uint32_t> sel((size_t)wf32, 0u);
-              for (int v : c.f_selection) sel[(size_t)(v >> 5)] |= 1u << (v & 31);
-              const uint32_t l_words = (uint32_t)blk.size();
-              uint32_t below = 0, nwords = 0;
-              for (int w = 0; w < wf32; ++w)
-                if (sel[(size_t)w]) {
-                  blk.push_back((uint32_t)w);
-                  blk.push_back(sel[(size_t)w]);
-                  blk.push_back(below);
-                  below += (uint32_t)__builtin_popcount(sel[(size_t)w]);
-                  ++nwords;
-                }
-              align4();
-              const uint32_t l_rank = (uint32_t)blk.size();
+            // LDS block: the rank tables of the components, one after the other
+            std::vector<uint32_t> blk;
+            std::vector<uint32_t> l_rank;
+            for (auto &c : p->comps) {
+              while (blk.size() % 4) blk.push_back(0u);
+              l_rank.push_back((uint32_t)blk.size());
               for (int k = 0; k < TSIMK_LW_MAX_WEIGHT; ++k)
                 for (int b = 0; b < c.F; ++b) {
                   unsigned long long v = 0;
@@ -1001,34 +978,76 @@ retry_pack:
                   }
                   blk.push_back((uint32_t)v);
                 }
-              align4();
-              const uint32_t l_outpos = (uint32_t)blk.size();
-              const uint32_t outpos_off = img[p->lw_off + ci * LW_WORDS + LW_OUTPOS];
-              for (int i = 0; i < c.n_out; ++i) blk.push_back(img[outpos_off + (uint32_t)i]);
-              align4();
-              uint32_t *cr = &blk[l_comp + ci * GC_WORDS];
-              cr[GC_NOUT] = (uint32_t)c.n_out;
-              cr[GC_F] = (uint32_t)c.F;
-              cr[GC_KEYBASE] = img[p->lw_off + ci * LW_WORDS + LW_KEYBASE];
-              cr[GC_NWORDS] = nwords;
-              cr[GC_L_WORDS] = l_words;
-              cr[GC_L_RANK] = l_rank;
-              cr[GC_L_OUTPOS] = l_outpos;
             }
-            if (blk.size() * 4 <= 48 * 1024) {  // (the launcher adds the subkeys and the waves' row buffers)
-              while (img.size() % 16) img.push_back(0u);
+            while (blk.size() % 4) blk.push_back(0u);
+            if (blk.size() * 4 <= 40 * 1024) {  // (the launcher adds the pattern bases and the waves' row buffers)
+              auto align16 = [&]() { while (img.size() % 16) img.push_back(0u); };
+              align16();
               p->gr_off = (int)img.size();
               img.resize(img.size() + GR_WORDS, 0u);
+              const uint32_t lds_src = (uint32_t)img.size();
               img.insert(img.end(), blk.begin(), blk.end());
+              align16();
+              // run groups: two runs per 32-byte group (one scalar load), every destination word's runs padded with mask 0
+              const uint32_t dst_off = (uint32_t)img.size();
+              img.resize(img.size() + 4 * (size_t)wo32, 0u);
+              align16();
+              const uint32_t groups_off = (uint32_t)img.size();
+              uint32_t ngroups = 0;
+              for (int d = 0; d < wo32; ++d) {
+                const uint32_t r0 = runb[(size_t)d], r1 = runb[(size_t)d + 1];
+                const uint32_t ng = (r1 - r0 + 1u) / 2u;
+                img[dst_off + 4 * (size_t)d] = ngroups;
+                img[dst_off + 4 * (size_t)d + 1] = ng;
+                img[dst_off + 4 * (size_t)d + 2] = flips[(size_t)d];
+                for (uint32_t r = r0; r < r0 + 2u * ng; ++r) {
+                  img.push_back(r < r1 ? (runs[2 * (size_t)r] & 255u) : 0u);
+                  img.push_back(r < r1 ? (runs[2 * (size_t)r] >> 8) : 0u);
+                  img.push_back(r < r1 ? runs[2 * (size_t)r + 1] : 0u);
+                  img.push_back(0u);
+                }
+                ngroups += ng;
+              }
+              align16();
+              const uint32_t comp_off = (uint32_t)img.size();
+              img.resize(img.size() + p->comps.size() * GC_WORDS, 0u);
+              for (size_t ci = 0; ci < p->comps.size(); ++ci) {
+                const HostComponent &c = p->comps[ci];
+                std::vector<uint32_t> sel((size_t)wf32, 0u);
+                for (int v : c.f_selection) sel[(size_t)(v >> 5)] |= 1u << (v & 31);
+                align16();
+                const uint32_t words_off = (uint32_t)img.size();
+                uint32_t below = 0, nwords = 0;
+                for (int w = 0; w < wf32; ++w)
+                  if (sel[(size_t)w]) {
+                    img.push_back((uint32_t)w);
+                    img.push_back(sel[(size_t)w]);
+                    img.push_back(below);
+                    img.push_back(0u);
+                    below += (uint32_t)__builtin_popcount(sel[(size_t)w]);
+                    ++nwords;
+                  }
+                align16();
+                const uint32_t outpos_new = (uint32_t)img.size();
+                const uint32_t outpos_off = img[p->lw_off + ci * LW_WORDS + LW_OUTPOS];
+                for (int i = 0; i < c.n_out; ++i) img.push_back(img[outpos_off + (uint32_t)i]);
+                uint32_t *cr = &img[comp_off + ci * GC_WORDS];
+                cr[GC_NOUT] = (uint32_t)c.n_out;
+                cr[GC_F] = (uint32_t)c.F;
+                cr[GC_KEYBASE] = img[p->lw_off + ci * LW_WORDS + LW_KEYBASE];
+                cr[GC_NWORDS] = nwords;
+                cr[GC_WORDREC] = words_off;
+                cr[GC_L_RANK] = l_rank[ci];
+                cr[GC_OUTPOS] = outpos_new;
+              }
               uint32_t *h = &img[p->gr_off];
               h[GR_NCOMP] = (uint32_t)p->comps.size();
               h[GR_WO32] = (uint32_t)wo32;
-              h[GR_NRUNS] = (uint32_t)(runs.size() / 2);
               h[GR_LDS_WORDS] = (uint32_t)blk.size();
-              h[GR_L_RUNS] = l_runs;
-              h[GR_L_RUNB] = l_runb;
-              h[GR_L_FLIPS] = l_flips;
-              h[GR_L_COMP] = l_comp;
+              h[GR_LDS_SRC] = lds_src;
+              h[GR_DST] = dst_off;
+              h[GR_GROUPS] = groups_off;
+              h[GR_COMP] = comp_off;
               h[GR_WF32_MIN] = (uint32_t)wf32;
             }
           }

@@ -1345,8 +1345,8 @@ static GenLayout gen_layout(const tsim_program *p, int WF32, int n_steps) {
   if (!p->gr_off) return L;
   const uint32_t *h = &p->img[p->gr_off];
   auto up = [](size_t v, size_t a) { return (v + a - 1) / a * a; };
-  size_t off = up((size_t)h[GR_LDS_WORDS], 4) * 4;
-  off += (size_t)n_steps * 2 * TSIMK_GEN_KEYS * 4;
+  (void)n_steps;
+  size_t off = ((size_t)h[GR_LDS_WORDS] + 8 * (size_t)h[GR_NCOMP]) * 4;  // rank tables, pattern bases
   off = up(off, 16);
   const size_t buf = (size_t)64 * WF32 * 4;
   // two resident blocks of 16 waves per CU (the register budget of the kernel allows it) when the row buffers fit 80 KB

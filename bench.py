@@ -728,6 +728,7 @@ def main() -> None:
                     hp.synchronize()
             hp.profile_enable(PROF_LEVEL)
         fence()
+        region_start = (int(key_state[0]), int(key_state[1]), step_no[0])  # what the in-run check below replays
         t0 = time.perf_counter()
         if os.environ.get("TSIM_BENCH_TRACE") == "2":
             stamps = []
@@ -761,6 +762,12 @@ def main() -> None:
     kern_ms, launches = hp.profile_read(reset=True)
     prof_steps = hp.profile_read_steps()  # batches covered by the bracketed (fused) first passes
     hp.profile_enable(False)
+    if not use_dist and rank == 0 and verify is None:
+        # (untimed) what the LAST timed region left in the output buffers, against the CPU oracle - before anything overwrites them
+        try:
+            verify = verify_last_region(hp, program, prng, f_bufs, d_outs, region_start, args.steps, NSLOT, B, num_f, WF, RB, shot_offset)
+        except Exception as exc:  # the check must never cost the headline line; a failure to CHECK is reported as such
+            verify = {"ok": None, "error": repr(exc)}
     elapsed = statistics.median(rep_elapsed)
     host_enqueue_s = statistics.median(rep_enqueue)
 
@@ -869,6 +876,14 @@ def main() -> None:
         pmc = load_pmc(args.config, B)
         # the PMC summary is per BATCH of B shots (scripts/summarize_pmc.py); `achieved` is per launch of batches_per_launch batches
         traffic = (2.0 * float(pmc["FETCH_SIZE"]) + float(pmc["WRITE_SIZE"])) * 1024.0 * batches_per_launch if pmc and "FETCH_SIZE" in pmc else None
+        traffic_note = ("profiles/latest_pmc.json (= profiles/r05/pmc.json, scripts/pmc_top.py): rocprofv3 PMC of the driver's command, one counter per pass, "
+                        f"mean of the two largest invocations of the first pass and of its hard-row grid ({pmc.get('_batches_per_launch', '?')} batches per launch, "
+                        "--nf 64: f read from HBM), per batch, x this line's batches per launch") if traffic is not None else "no committed PMC summary for this workload"
+        if traffic is not None and traffic < 0.98 * bytes_per_shot * B * batches_per_launch:
+            # HBM traffic below the bytes the launch must move is a broken figure (medians over launches of
+            # different group sizes gave 8.8 MB per 10^6 shots for 11 MB algorithmic) - never print one
+            traffic_note = f"REJECTED: the committed PMC summary gives {traffic:.3e} B per launch, below the {bytes_per_shot * B * batches_per_launch:.3e} algorithmic bytes"
+            traffic = None
         per_step = [e / args.steps * 1e3 for e in rep_elapsed]
         res = {
             "metric": "detector shots/sec, 35-qubit distillation circuit, 1/2/4/8 MI355X",
@@ -931,6 +946,8 @@ def main() -> None:
                 "frac": achieved_gbs / HBM_PEAK_GBS,
                 "traffic": traffic,
                 "traffic_unit": "bytes per launch, rocprofv3 PMC: 2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction)",
+                "traffic_source": traffic_note,
+                "traffic_over_algorithmic": (traffic / (bytes_per_shot * B * batches_per_launch)) if traffic else None,
                 "achieved_at_step_rate": bytes_per_shot * B / (elapsed / args.steps) / 1e9,
                 "frac_at_step_rate": bytes_per_shot * B / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
                 "kernel": kernel_name,
@@ -1071,6 +1088,43 @@ def config_leg(backend, synth, name: str, shots: int, steps_n: int, device: int,
                      "traffic": None,
                      "note": "achieved = algorithmic bytes of one launch / HIP-event time of the kernel every row goes through, inside the timed regions"},
     }
+
+
+def verify_last_region(hp, program, prng, f_bufs, d_outs, region_start, n_steps, nslot, B, num_f, WF, RB, shot_offset, rows=2048, buffers=3) -> dict:
+    """N = 1, untimed, right after the last timed repetition: the bit_packed rows that region wrote - the last `buffers`
+    steps, whose output buffers nothing has overwritten, the first and the last `rows` / 2 rows of each - against the C oracle
+    (oracle/oracle.c, test infrastructure: here as the CHECKER of the buffers the timed region wrote, never on the measured
+    path).  The inputs are the resident f batches those steps read (downloaded: what the kernels saw) and the subkeys of the
+    key chain replayed on the host from the region's start: key, subkey = split(key) per batch (sampler.py:399)."""
+    from oracle import oracle_c
+
+    k0, k1, j0 = region_start
+    op = oracle_c.OracleProgram(program)
+    key = (k0, k1)
+    subs = []
+    for _ in range(n_steps):
+        key, sub = prng.split(key)
+        subs.append(sub)
+    half = max(1, min(rows // 2, B))
+    checked, bad, total = [], 0, 0
+    for i in range(max(0, n_steps - min(buffers, nslot)), n_steps):
+        j = j0 + i
+        fi, oi = j % len(f_bufs), j % nslot
+        for lo in sorted({0, max(0, B - half)}):
+            n = min(half, B - lo)
+            fpk = np.zeros((n, WF * 8), np.uint8)
+            hp.d2h(fpk, f_bufs[fi].ptr + lo * WF * 8)
+            f = np.unpackbits(fpk, axis=1, bitorder="little")[:, :num_f]
+            got = np.zeros((n, RB), np.uint8)
+            hp.d2h(got, d_outs[oi].ptr + lo * RB)
+            want = np.packbits(op.sample_program(f, subs[i], shot_offset=shot_offset + lo), axis=1, bitorder="little")
+            nb = int((got != want).any(axis=1).sum())
+            bad += nb
+            total += n
+            checked.append({"step": i, "f_batch": fi, "out_buffer": oi, "first_row": lo, "rows": n, "mismatching_rows": nb})
+    return {"ok": bad == 0, "rows": total, "mismatching_rows": bad, "checked": checked,
+            "against": "oracle/oracle.c (CPU restatement of sampler.py:28-167) on the downloaded f rows and the replayed key chain; "
+                       "the rows compared are those the last timed region wrote"}
 
 
 def verify_collected(backend, prng, synth, program, cfg, hp, comm, lib, rank, N, B, num_f, n_out, RB, device, key_state, steps, drain,

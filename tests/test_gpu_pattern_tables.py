@@ -16,8 +16,12 @@ def _oracle(prog, f, key):
     return want, np.asarray(wdev, np.float32)
 
 
-def test_tables_selected_for_c2(hip):
+def test_tables_selected_for_c2(hip, monkeypatch):
     prog, _ = synth.config_program("C2")
+    # (since round 5 a handle STARTS shallow - C2: weight 4 - and reaches weight 5 in the background, test_shallow_start_* below;
+    # TSIM_AMD_TUNE=shallow=0 builds the default depth at finalize as rounds 2-4 did)
+    assert hip.HipProgram(prog).info()["pattern_max_weight"] == [4]
+    monkeypatch.setenv("TSIM_AMD_TUNE", "shallow=0")
     info = hip.HipProgram(prog).info()
     assert info["pattern_tables"] and info["pattern_max_weight"] == [5]
     assert 0 < info["pattern_table_bytes"] <= 256 << 20
@@ -43,13 +47,15 @@ def test_c2_every_depth_matches_oracle(hip, p_bit, cap):
     hp.close()  # weight-7 tables are 0.6 GB: do not keep eight handles alive
 
 
-def test_tables_deepen_on_demand_and_results_do_not_change(hip):
+def test_tables_deepen_on_demand_and_results_do_not_change(hip, monkeypatch):
     """Default depth: 5 at finalize; three launches in a row that leave more than 1 % of their rows to the full
     kernel make the planner build the weight-6/7 tables - in the background.  Launches before, during and after equal the oracle,
     on the serial and on the pipelined API, and sparse launches afterwards still take the short path."""
     prog, cfg = synth.config_program("C2")
     nf, n_out = cfg["num_f"], prog.num_outputs
+    monkeypatch.setenv("TSIM_AMD_TUNE", "shallow=0")
     hp = hip.HipProgram(prog)
+    monkeypatch.delenv("TSIM_AMD_TUNE")
     assert hp.info()["pattern_max_weight"] == [5]
     B = 20_000
     i = 0
@@ -544,3 +550,50 @@ def test_bit_packed_only_output_of_pipelined_launches(hip, name):
             got = np.zeros((B, rb), np.uint8)
             hp.d2h(got, d_c[i])
             np.testing.assert_array_equal(got, want[i])
+
+
+@pytest.mark.parametrize("name,start", [("C2", [4]), ("C4", [3, 3, 3]), ("C3", [3])])
+def test_shallow_start_reaches_the_default_depth_and_bits_do_not_change(hip, name, start):
+    """finalize builds only the tables that cost about half a millisecond (the BASELINE jobs are 10^5-10^6
+    shots; C4's weight-5 tables are 195 MB and 35 ms), the default depth (5) follows in the background, one slice per launch
+    plan.  Every batch - before, during and after the swap - equals the oracle, through the fused steps API and the serial one."""
+    from test_gpu_steps import _run_steps, _subkeys
+
+    prog, cfg = synth.config_program(name)
+    nf = cfg["num_f"]
+    hp = hip.HipProgram(prog)
+    assert hp.info()["pattern_max_weight"] == start
+    op = OC.OracleProgram(prog)
+    B, n = 2000, 3
+    key = prng.key(31)
+    rounds = 0
+    seen = {tuple(start)}
+    while rounds < 400:
+        fs = [synth.synth_f(B, nf, cfg["p_bit"] * (1 + (i % 2)), seed=7 * rounds + i) for i in range(n)]
+        outs, key_after = _run_steps(hp, prog, fs, key, nf, packed=True)
+        _, subs = _subkeys(key, n)
+        if rounds < 6 or rounds % 16 == 0 or tuple(hp.info()["pattern_max_weight"]) not in seen:
+            for i in range(n):
+                np.testing.assert_array_equal(outs[i], np.packbits(op.sample_program(fs[i], subs[i]), axis=1, bitorder="little"), err_msg=f"round {rounds} batch {i}")
+        seen.add(tuple(hp.info()["pattern_max_weight"]))
+        key = key_after
+        rounds += 1
+        if hp.info()["pattern_max_weight"] == [5] * len(start) and rounds > 8:
+            break
+    assert hp.info()["pattern_max_weight"] == [5] * len(start), f"still {hp.info()['pattern_max_weight']} after {rounds} calls"
+    f = synth.synth_f(3000, nf, cfg["p_bit"], seed=99)
+    got, gdev = hp.sample_batch(f, (4, 4))
+    want, wdev = op.sample_program(f, (4, 4), return_devs=True)
+    np.testing.assert_array_equal(got, want)
+    np.testing.assert_array_equal(np.asarray(gdev, np.float32), np.asarray(wdev, np.float32))
+    hp.close()
+
+
+def test_a_handle_destroyed_during_the_background_build(hip):
+    """close() right after creation, and after one call: the helper thread and the slices in flight are drained."""
+    prog, cfg = synth.config_program("C4")
+    for calls in (0, 1, 3):
+        hp = hip.HipProgram(prog)
+        for i in range(calls):
+            hp.sample_batch(synth.synth_f(500, cfg["num_f"], 0.02, seed=i), (i, 1))
+        hp.close()

@@ -211,7 +211,7 @@ def test_tables_deepen_when_the_hard_rows_are_too_many_for_the_block_per_row_ker
 
     B, n = 400_000, 8
     runs, depths = [], []
-    for env in ({"TSIM_AMD_TUNE": "deep_after=1"}, {"TSIM_AMD_DEEP_TABLES": "-1"}):
+    for env in ({"TSIM_AMD_TUNE": "deep_after=1,shallow=0"}, {"TSIM_AMD_DEEP_TABLES": "-1", "TSIM_AMD_TUNE": "shallow=0"}):
         os.environ.update(env)
         try:
             prog, cfg = synth.config_program("C3")
@@ -277,7 +277,9 @@ def test_a_jump_of_the_noise_level_goes_through_the_overflow_grid_and_back(hip, 
     phases = [cfg["p_bit"], cfg["p_bit"], dense, dense, cfg["p_bit"], cfg["p_bit"], cfg["p_bit"], cfg["p_bit"]]
     results = {}
     for over in (1, 0):
-        os.environ["TSIM_AMD_TUNE"] = f"hard_overflow={over}{extra}"  # (hard_wave=0: the jump group's lists go to k_sample4h_multi and ITS workers)
+        # (hard_wave=0: the jump group's lists go to k_sample4h_multi and ITS workers; shallow=0: the plan sequence this test
+        # follows starts from the default table depth - the shallow start has its own test, test_gpu_pattern_tables.py)
+        os.environ["TSIM_AMD_TUNE"] = f"hard_overflow={over}{extra},shallow=0"
         try:
             hp = hip.HipProgram(prog)
         finally:

@@ -63,3 +63,116 @@ def test_depth_on_demand_and_bits_do_not_change(hip, deepen, monkeypatch):
             got, _ = hp.sample_batch(f, (i, 3), shot_offset=7 * i)
             np.testing.assert_array_equal(got, orc.sample_program(f, (i, 3), shot_offset=7 * i))
     hp.close()
+
+
+def _tuned_program(hip, prog, tune, monkeypatch, **kw):
+    if tune:
+        monkeypatch.setenv("TSIM_AMD_TUNE", tune)
+    else:
+        monkeypatch.delenv("TSIM_AMD_TUNE", raising=False)
+    try:
+        return hip.HipProgram(prog, **kw)
+    finally:
+        monkeypatch.delenv("TSIM_AMD_TUNE", raising=False)
+
+
+@pytest.mark.parametrize("tune", ["", "wide_fused=0"])
+def test_pipelined_bit_packed_launches(hip, tune, monkeypatch):
+    """The begin / end API with per-slot shot_offset and slot reuse on a program with two wide components (round-2 path:
+    k_sample_lw<true> -> k_sample4w on its lists -> row kernel), non-dword bit_packed rows; brought back after ADVICE r04 -
+    the path is live for several wide components, dense phases and `wide_fused=0`."""
+    prog = wide_program(5)
+    nf, n_out = 320, prog.num_outputs
+    wf, rb = (nf + 63) // 64, (n_out + 7) // 8
+    hp = _tuned_program(hip, prog, tune, monkeypatch, pattern_tables=3)
+    B = 30_000
+    orc = OC.OracleProgram(prog)
+    bufs = []
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for rnd in range(2):  # the second round reuses the slots (counter sets alternate)
+            for i in range(5):
+                f = synth.synth_f(B, nf, 0.006 * (i + 1), seed=70 + i + 10 * rnd)
+                pk = np.zeros((B, wf * 8), np.uint8)
+                q = np.packbits(f, axis=1, bitorder="little")
+                pk[:, : q.shape[1]] = q
+                d_f, d_o = hp.malloc(pk.nbytes), hp.malloc(B * rb + 16)
+                hp.h2d(d_f, pk)
+                hp.sample_batch_device_begin(i, d_f.ptr, B, nf, (i, 4 + rnd), d_o.ptr, out_bit_packed=True, shot_offset=B * i)
+                bufs.append((f, d_f, d_o, (i, 4 + rnd), B * i))
+            for i in range(5):
+                hp.sample_batch_device_end(i)
+        hp.synchronize()
+        for f, d_f, d_o, key, off in bufs:
+            got = np.zeros((B, rb), np.uint8)
+            hp.d2h(got, d_o)
+            np.testing.assert_array_equal(got, np.packbits(orc.sample_program(f, key, shot_offset=off), axis=1, bitorder="little"))
+    hp.close()
+
+
+@pytest.mark.parametrize("tune", ["", "wide_fused=0"])
+def test_list_counters_survive_launches_that_skip_the_tables(hip, tune, monkeypatch):
+    """Dense batches make the planner skip the table pass for 15 launches; the sparse-column pass's own counter sets
+    (its overflow lists) are untouched by those launches and must still be the reset ones when the tables come
+    back.  A random walk over batch sizes and noise levels on ONE slot (seed 5 failed at launch 33 while the second
+    counter set followed the first one's parity: stale counts of a large batch pushed a later batch's rows past its
+    list capacity; found by scripts/fuzz_pipeline.py).  With the fused default the same walk crosses the
+    dense -> tables -> dense transitions of k_sample_wide."""
+    prog, cfg = synth.config_program("C5")
+    nf, n_out = cfg["num_f"], prog.num_outputs
+    wf, wo = (nf + 63) // 64, (n_out + 63) // 64
+    hp = _tuned_program(hip, prog, tune, monkeypatch, pattern_tables=3)
+    ref = hip.HipProgram(prog, pattern_tables=False)
+    rng = np.random.default_rng(5)
+    d_f, d_o = hp.malloc(20000 * wf * 8), hp.malloc(20000 * wo * 8)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for i in range(60):
+            B = int(rng.choice([64, 1000, 4097, 20000]))
+            p_bit = float(rng.choice([0.0, 0.005, 0.02, 0.06, 0.3]))
+            f = synth.synth_f(B, nf, p_bit, seed=int(rng.integers(0, 1 << 30)))
+            pk = np.zeros((B, wf * 8), np.uint8)
+            q = np.packbits(f, axis=1, bitorder="little")
+            pk[:, : q.shape[1]] = q
+            hp.h2d(d_f, pk)
+            hp.sample_batch_device_begin(5, d_f.ptr, B, nf, (i, 77), d_o.ptr)
+            hp.sample_batch_device_end(5)
+            hp.synchronize()
+            got = np.zeros((B, wo * 8), np.uint8)
+            hp.d2h(got, d_o)
+            want, _ = ref.sample_batch(f, (i, 77), bit_packed=True)
+            np.testing.assert_array_equal(got[:, : want.shape[1]], want, err_msg=f"launch {i} (B={B}, p_bit={p_bit})")
+    hp.close()
+    ref.close()
+
+
+def test_wait_slot_orders_a_refill_behind_a_consumed_launch(hip):
+    """tsim_pipeline_wait_slot: a producer that refills a slot's f buffer after `_end` was consumed by ANOTHER stream must wait
+    for the slot's launch itself (`_end` no longer waits once a consumer stream has joined the slot)."""
+    prog, cfg = synth.config_program("C2")
+    nf = cfg["num_f"]
+    wf, wo = (nf + 63) // 64, (prog.num_outputs + 63) // 64
+    hp = hip.HipProgram(prog)
+    orc = OC.OracleProgram(prog)
+    B = 50_000
+    d_f, d_o = hp.malloc(B * wf * 8), [hp.malloc(B * wo * 8) for _ in range(6)]
+    consumer = hp.aux_stream(0)
+    fs = []
+    for i in range(6):
+        f = synth.synth_f(B, nf, 0.02, seed=900 + i)
+        pk = np.zeros((B, wf * 8), np.uint8)
+        q = np.packbits(f, axis=1, bitorder="little")
+        pk[:, : q.shape[1]] = q
+        hp.pipeline_wait_slot(2)  # the launch that still reads d_f (if any) is done before the buffer is overwritten
+        hp.h2d(d_f, pk)
+        hp.sample_batch_device_begin(2, d_f.ptr, B, nf, (i, 5), d_o[i].ptr)
+        hp.sample_batch_device_end(2, consumer)  # joined by the consumer stream, not by the producer
+        fs.append(f)
+    hp.stream_synchronize(consumer)
+    hp.synchronize()
+    for i, f in enumerate(fs):
+        raw = np.zeros((B, wo * 8), np.uint8)
+        hp.d2h(raw, d_o[i])
+        got = np.unpackbits(raw, axis=1, bitorder="little")[:, : prog.num_outputs]
+        np.testing.assert_array_equal(got, orc.sample_program(f, (i, 5)).astype(np.uint8), err_msg=f"launch {i}")
+    hp.close()

@@ -27,6 +27,7 @@
 #include <cstdlib>
 #include <cmath>
 #include <atomic>
+#include <mutex>
 #include <chrono>
 #include <cstring>
 #include <new>
@@ -153,6 +154,7 @@ struct tsim_program {
   uint32_t *d_img = nullptr;
   float *d_dev = nullptr;
   hipStream_t stream = nullptr;
+  std::vector<int> stream_idx;             // creation indices of the pooled streams this handle holds (tsim_stream_acquire)
   hipStream_t aux[TSIM_AUX_STREAMS] = {};  // tsim_aux_stream
   // low-weight pattern tables (tsim_lw.hip.h)
   int lw_request = -1;        // -1 default (on in TSIM_MODE_AUTO), 0 off, 1 on
@@ -201,6 +203,7 @@ struct tsim_program {
     SampleArgs ctx;                   // the hard-row kernel's arguments for that launch
   };
   Slot slots[1 + TSIM_PIPELINE_SLOTS];
+  uint32_t *ctl_block = nullptr;  // the counter sets of every slot (Slot::ctl / ctl2 point into it)
   bool slots_ready = false;
   std::vector<int> deferred;  // slots whose hard rows are waiting, in launch order
   hipEvent_t lane_ev[2] = {nullptr, nullptr};  // "first passes enqueued so far on lane k are done"
@@ -251,6 +254,7 @@ struct tsim_program {
     bool wide = true;         // wide=0: wide components on the row kernel alone
     bool wide_tables = true;  // wide_tables=0: no pattern tables in front of the wide kernels
     bool hard_overflow = true; // hard_overflow=0: the latency kernels of a hard-row batch walk whole lists (no per-shot workers behind them)
+    bool shallow = true;      // shallow=0: finalize builds the default table depth at once (round 4) instead of starting shallow
     int gen = 1;              // gen: k_sample_gen for fused groups - 0 never, 1 where no register first pass applies, 2 wherever it applies
     bool wide_compact = true; // wide_compact=0: k_sample_wide keeps one 16-byte column table per graph even when all graphs fit one entry
     // fixed since round 4 (the experiments behind their switches are closed: DESIGN.md / HISTORY.md)
@@ -278,10 +282,12 @@ struct tsim_program {
   int lw_direct_rot = 0;      // the same moves in rotate-and-mask form (register first pass), 0 = none
   std::vector<int> lw_wmax;   // per component
   std::vector<long long> lw_npat;  // per component: tabulated patterns
+  int lw_cap_default = 0;     // the depth a handle reaches on its own soon after finalize (5 narrow, 3 wide, or the caller's)
   int lw_cap_now = 0, lw_cap_max = 0;  // table depth built / allowed (tsim_tables_extend deepens on demand)
   long long lw_budget = 0;    // bytes per component
   int lw_dense_launches = 0;  // consecutive launches whose hard-row share says "deeper tables would pay"
   unsigned long long deep_after_auto = 0;  // tsim_tables_deep_after's estimate (0: not made yet)
+  long long lw_build_bytes = 0;        // ... and their size
   double lw_build_ms = 0.0;            // the finalize build of the tables, timed (entries per ms -> the estimate)
   unsigned long long deep_rows = 0;  // rows launched while the hard rows were too many for k_sample_hw (knobs.deep_after)
   long long lw_bytes = 0;
@@ -321,6 +327,12 @@ struct tsim_program {
 };
 
 // ---- tsim_program.hip
+// Streams come from a process-wide pool per device: hipStreamCreate costs 2.5-3.3 ms on this box and hipStreamDestroy as much
+// (scripts/microbench/hip_setup_cost.hip) - a handle with its lanes paid ~100 ms to be born and ~75 ms to die.  A released
+// stream is drained first; a handle asks for streams on DIFFERENT hardware queues (HIP deals streams to its four queues in
+// creation order: `held` = the creation indices the handle already holds, profiles/r04/hw_queues.txt).
+int tsim_stream_acquire(int device, std::vector<int> &held, hipStream_t *out);
+void tsim_stream_release(int device, hipStream_t s);
 bool tsim_debug(const char *what);  // TSIM_AMD_DEBUG=tables,host,pipeline,pcg contains `what`
 int tsim_set_device(const tsim_program *p);
 int tsim_need_final(const tsim_program *p);
@@ -343,7 +355,8 @@ std::vector<uint32_t> emit_rotmask_program(const std::vector<std::array<int, 3>>
 bool tsim_tables_plan(tsim_program *p, int cap, long long budget);
 int tsim_tables_build(tsim_program *p, uint32_t **old);
 int tsim_tables_extend(tsim_program *p);
-int tsim_tables_extend_begin(tsim_program *p);
+int tsim_tables_extend_begin(tsim_program *p, int target_cap);
+bool tsim_tables_plan_at(tsim_program *p, int cap, long long budget, int rec_off, TsimTablePlan &out);
 int tsim_tables_extend_poll(tsim_program *p, bool wait);
 int tsim_tables_slice(tsim_program *p, hipStream_t s);
 unsigned long long tsim_tables_deep_after(tsim_program *p);

@@ -27,6 +27,49 @@ int tsim_fail(int code, const char *fmt, ...) {
   return code;
 }
 
+// ---------------------------------------------------------------------------
+// the stream pool (tsim_internal.hip.h)
+// ---------------------------------------------------------------------------
+namespace {
+struct PooledStream { hipStream_t s; int index; bool free; };
+struct StreamPool { std::mutex m; std::vector<PooledStream> all[16]; };
+StreamPool &stream_pool() { static StreamPool *sp = new StreamPool; return *sp; }  // (never destroyed: HIP may be gone at exit)
+}  // namespace
+
+int tsim_stream_acquire(int device, std::vector<int> &held, hipStream_t *out) {
+  StreamPool &sp = stream_pool();
+  std::lock_guard<std::mutex> lk(sp.m);
+  auto &v = sp.all[device & 15];
+  unsigned busy_q = 0;
+  for (int i : held) busy_q |= 1u << (i & 3);
+  PooledStream *pick = nullptr;
+  for (auto &e : v)  // a free stream on a hardware queue this handle does not use yet, else any free one
+    if (e.free && !((busy_q >> (e.index & 3)) & 1u)) { pick = &e; break; }
+  if (!pick && busy_q == 0xFu)
+    for (auto &e : v)
+      if (e.free) { pick = &e; break; }
+  if (!pick) {
+    hipStream_t s = nullptr;
+    HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    v.push_back(PooledStream{s, (int)v.size(), true});
+    pick = &v.back();
+  }
+  pick->free = false;
+  held.push_back(pick->index);
+  *out = pick->s;
+  return 0;
+}
+
+void tsim_stream_release(int device, hipStream_t s) {
+  if (!s) return;
+  (void)hipStreamSynchronize(s);
+  StreamPool &sp = stream_pool();
+  std::lock_guard<std::mutex> lk(sp.m);
+  for (auto &e : sp.all[device & 15])
+    if (e.s == s) { e.free = true; return; }
+  (void)hipStreamDestroy(s);  // not one of ours
+}
+
 extern "C" const char *tsim_last_error(void) { return g_err; }
 extern "C" const char *tsim_version(void) { return "tsim_amd-hip 0.2 (gfx950)"; }
 
@@ -241,9 +284,18 @@ extern "C" int tsim_program_finalize(tsim_program *p, int32_t device) {
     p->knobs.wide_tables = tune_ll("wide_tables", 1) != 0;
     p->knobs.wide_compact = tune_ll("wide_compact", 1) != 0;
     p->knobs.gen = (int)std::max(0ll, std::min(2ll, tune_ll("gen", 1)));
+    p->knobs.shallow = tune_ll("shallow", 1) != 0;
     p->knobs.hard_overflow = tune_ll("hard_overflow", 1) != 0;
   }
 
+  const bool fin_dbg = tsim_debug("finalize");
+  auto fin_t0 = std::chrono::steady_clock::now();
+  auto fin_mark = [&](const char *what) {
+    if (!fin_dbg) return;
+    const auto n = std::chrono::steady_clock::now();
+    fprintf(stderr, "[tsim] finalize: %s %.2f ms\n", what, std::chrono::duration<double, std::milli>(n - fin_t0).count());
+    fin_t0 = n;
+  };
   // ---- choose the evaluation formulation ----
   {
     const char *env = getenv("TSIM_AMD_MODE");
@@ -393,6 +445,7 @@ retry_pack:
     if (sequential) p->total_keys += c.n_out;
     memcpy(&img[p->comp_off + ci * C_WORDS], rec, sizeof rec);
   }
+  fin_mark("rows / fast formulation packed");
   // ---- v4 (chunk table) layout, when every sampled component qualifies ----
   p->v4 = false;
   p->v4w = false;
@@ -488,6 +541,7 @@ retry_pack:
   }
   p->stats[7] = p->v4 ? 1 : (p->v4w ? 2 : 0);
 
+  fin_mark("chunk / column tables");
   // ---- direct outputs as a gather program (bit-field runs), for every sampling kernel ----
   {
     std::vector<std::array<int, 3>> de;
@@ -534,7 +588,8 @@ retry_pack:
       const bool pinned = p->lw_weight_cap >= 0;
       const int hw_cap = p->lw_wide ? TSIMK_LWW_MAX_WEIGHT : TSIMK_LW_MAX_WEIGHT;
       p->lw_cap_max = pinned ? std::min(p->lw_weight_cap, hw_cap) : hw_cap;
-      p->lw_cap_now = pinned ? p->lw_cap_max : std::min(p->lw_wide ? 3 : 5, p->lw_cap_max);
+      p->lw_cap_default = pinned ? p->lw_cap_max : std::min(p->lw_wide ? 3 : 5, p->lw_cap_max);
+      p->lw_cap_now = p->lw_cap_default;
       p->lw_budget = 4096ll << 20;  // per component: HBM is 288 GB, and only the prefix is hot (C3's weight-6 table is 1.8 GB)
       // wide components: C(200, 4) patterns of 8 thresholds are 2.1 GB - what lifts the tabulated share of C5's
       // shots from 43 % to 63 %; still under 1 % of the HBM
@@ -554,6 +609,26 @@ retry_pack:
         r[LW_BASES] = (uint32_t)(p->lw_off + ci * LW_WORDS + LW_BASES_INLINE);
         lw_fsel_progs.push_back({});
         for (int j = 0; j < c.F; ++j) lw_fsel_progs.back().push_back({c.f_selection[j], j, 0});
+      }
+      // Start shallow: the BASELINE jobs are 10^5-10^6 shots, and a depth-5 table (C4: 195 MB, 35 ms of
+      // build) pays only from ~10^8 rows on.  Finalize builds the deepest tables that cost about half a millisecond (table
+      // entries x graphs per level: C2 depth 4, C3 / C4 depth 3); the default depth follows in the background, slice by slice
+      // next to the first launches (tsim_tables_extend_begin below, tsim_tables.hip).  A caller who named a depth gets it here.
+      if (!pinned && p->knobs.shallow && p->knobs.deep_tables <= 0 && !p->lw_wide) {
+        while (p->lw_cap_now > 2) {
+          TsimTablePlan t;
+          std::vector<uint32_t> keep(img.begin() + p->lw_off, img.begin() + p->lw_off + (long)(p->comps.size() * LW_WORDS));
+          double cost = 0;
+          if (tsim_tables_plan_at(p, p->lw_cap_now, p->lw_budget, p->lw_off, t))
+            for (size_t ci = 0; ci < p->comps.size(); ++ci) {
+              double g = 0;
+              for (auto &lv : p->comps[ci].levels) g += lv.G;
+              cost += (double)(t.npat[ci] << p->comps[ci].n_out) * g / (double)p->comps[ci].levels.size();
+            }
+          std::copy(keep.begin(), keep.end(), img.begin() + p->lw_off);
+          if (cost <= 1.2e8) break;
+          --p->lw_cap_now;
+        }
       }
       ok = tsim_tables_plan(p, p->lw_cap_now, p->lw_budget);
       if (ok && p->lw_wide) {
@@ -1068,6 +1143,7 @@ retry_pack:
   if (p->knobs.defer_group <= 0)  // (not told by TSIM_AMD_TUNE) launches per deferred batch: a batch lasts about as long as ONE hard-row
     p->knobs.defer_group = p->stats[5] > (4ll << 20) ? TSIMK_H_MAX_CTX : 4;  // pass; 4 for small programs, 8 beyond 4 MB of chunk tables (C4)
 
+  fin_mark("pattern-table plan, first-pass records");
   // ---- upload ----
   int ndev = 0;
   HIP_TRY(hipGetDeviceCount(&ndev));
@@ -1078,15 +1154,18 @@ retry_pack:
     int cu = 0;
     if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cu > 0) p->n_cu = cu;
   }
-  HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+  if (int r = tsim_stream_acquire(device, p->stream_idx, &p->stream)) return r;
   HIP_TRY(hipMalloc((void **)&p->d_img, img.size() * 4));
   HIP_TRY(hipMemcpy(p->d_img, img.data(), img.size() * 4, hipMemcpyHostToDevice));
   HIP_TRY(hipMalloc((void **)&p->d_dev, std::max<size_t>(1, p->comps.size()) * 4));
   HIP_TRY(hipMemset(p->d_dev, 0, std::max<size_t>(1, p->comps.size()) * 4));
+  fin_mark("stream, image upload");
   if (p->lw) {
     if (int r = tsim_tables_build(p, nullptr)) return r;
     if (int r = alloc_feedback(p)) return r;
   }
+  fin_mark("pattern tables built");
+  if (p->lw && p->lw_cap_now < p->lw_cap_default) (void)tsim_tables_extend_begin(p, p->lw_cap_default);  // the default depth, in the background
   p->finalized = true;
   return TSIM_OK;
 }
@@ -1094,7 +1173,7 @@ extern "C" void tsim_program_destroy(tsim_program *p) {
   if (!p) return;
   if (p->device >= 0) (void)hipSetDevice(p->device);
   for (hipStream_t &a : p->aux)
-    if (a) { (void)hipStreamSynchronize(a); (void)hipStreamDestroy(a); a = nullptr; }
+    if (a) { tsim_stream_release(p->device, a); a = nullptr; }
   if (p->finalized && p->device >= 0) {
     (void)hipSetDevice(p->device);
     (void)tsim_flush_hard(p);  // parked hard rows of launches that were never joined: finish them, then drain every lane
@@ -1112,26 +1191,28 @@ extern "C" void tsim_program_destroy(tsim_program *p) {
       if (s) (void)hipFree(s);
     for (void *q : p->owned) (void)hipFree(q);  // buffers the caller never returned
     p->owned.clear();
-    if (p->ext_thread.joinable()) p->ext_thread.join();  // (a table build in the background: its slices ran on the lanes, drained above)
+    if (p->ext_thread.joinable()) p->ext_thread.join();
+    // a table build in the background: its slices ran on whatever stream the next launch used - the lanes drained above, but
+    // tsim_sample_batch_device puts them on CALLER streams too, which the handle cannot drain one by one
+    if (p->ext_pending) (void)hipDeviceSynchronize();
     if (p->d_img) (void)hipFree(p->d_img);
     if (p->d_dev) (void)hipFree(p->d_dev);
     for (void *q : p->ext_scratch) (void)hipFree(q);
     if (p->ext_tab) (void)hipFree(p->ext_tab);
     if (p->ext_ev) (void)hipEventDestroy(p->ext_ev);
     if (p->d_lw_tab) (void)hipFree(p->d_lw_tab);
+    if (p->ctl_block) (void)hipFree(p->ctl_block);  // (the slots' counter sets: one allocation)
     if (p->h_feedback) (void)hipHostFree((void *)p->h_feedback);
     for (auto &sl : p->slots) {
-      if (sl.ctl) (void)hipFree(sl.ctl);
       if (sl.hard) (void)hipFree(sl.hard);
-      if (sl.ctl2) (void)hipFree(sl.ctl2);
       if (sl.hard2) (void)hipFree(sl.hard2);
       if (sl.keys) (void)hipFree(sl.keys);
       if (sl.ev1) (void)hipEventDestroy(sl.ev1);
       if (sl.ev2) (void)hipEventDestroy(sl.ev2);
 
-      if (sl.side && !sl.side_borrowed) (void)hipStreamDestroy(sl.side);
+      if (sl.side && !sl.side_borrowed) tsim_stream_release(p->device, sl.side);
     }
-    if (p->stream) (void)hipStreamDestroy(p->stream);
+    if (p->stream) tsim_stream_release(p->device, p->stream);
   }
   delete p;
 }
@@ -1300,7 +1381,8 @@ extern "C" int tsim_aux_stream(tsim_program *p, int32_t index, void **stream) {
   if (int r = tsim_need_final(p)) return r;
   if (int r = tsim_set_device(p)) return r;
   if (index < 0 || index >= TSIM_AUX_STREAMS || !stream) return tsim_fail(TSIM_EINVAL, "bad auxiliary stream %d", index);
-  if (!p->aux[index]) HIP_TRY(hipStreamCreateWithFlags(&p->aux[index], hipStreamNonBlocking));
+  if (!p->aux[index])
+    if (int r = tsim_stream_acquire(p->device, p->stream_idx, &p->aux[index])) return r;
   *stream = (void *)p->aux[index];
   return TSIM_OK;
 }

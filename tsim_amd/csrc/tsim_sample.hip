@@ -52,25 +52,32 @@ static int prof_drain(tsim_program *p) {
   return 0;
 }
 // per-slot resources, created on first use
-static int slot_prepare(tsim_program *p, int slot, size_t hard_bytes) {
+// `need_stream`: the slot's own stream too (the lanes - slots 1..4 - always; the others only when a launch runs on the slot's
+// own stream, tsim_sample_batch_device_begin outside the deferred plan: a stream costs ~3 ms to create, 32 of them 100 ms of
+// the first pipelined call of every handle - scripts/microbench/hip_setup_cost.hip)
+static int slot_prepare(tsim_program *p, int slot, size_t hard_bytes, bool need_stream = false) {
   tsim_program::Slot &sl = p->slots[slot];
   if ((p->lw || p->v4w) && !sl.ctl) {
-    // two counter sets used alternately: pass 1 of a launch resets the set of the slot's next one
-    const size_t set_bytes = (TSIMK_LW_LISTS + 1) * 128;
-    HIP_TRY(hipMalloc((void **)&sl.ctl, 2 * set_bytes));
-    HIP_TRY(hipMemset(sl.ctl, 0, 2 * set_bytes));
-    for (int st = 0; st < 2; ++st)
-      HIP_TRY(hipMemset(sl.ctl + st * (TSIMK_LW_LISTS + 1) * 32 + TSIMK_LW_LISTS * 32, 0xFF, 4));
-  }
-  if (p->lw_wide && !sl.ctl2) {  // the sparse-column pass behind a table pass: counters and lists of its own
-    const size_t set_bytes = (TSIMK_LW_LISTS + 1) * 128;
-    HIP_TRY(hipMalloc((void **)&sl.ctl2, 2 * set_bytes));
-    HIP_TRY(hipMemset(sl.ctl2, 0, 2 * set_bytes));
-    for (int st = 0; st < 2; ++st)
-      HIP_TRY(hipMemset(sl.ctl2 + st * (TSIMK_LW_LISTS + 1) * 32 + TSIMK_LW_LISTS * 32, 0xFF, 4));
+    // two counter sets per slot, used alternately: pass 1 of a launch resets the set of the slot's next one.  The sets of ALL
+    // slots (and, for wide programs, the sparse-column pass's own) are one allocation, initialised by one copy - 32 slots x
+    // (2 hipMalloc + 6 hipMemset on the null stream) were 1-4 ms of a handle's first pipelined call
+    const size_t set_words = (TSIMK_LW_LISTS + 1) * 32, slot_words = 2 * set_words, kinds = p->lw_wide ? 2 : 1;
+    if (!p->ctl_block) {
+      const size_t words = (size_t)(1 + TSIM_PIPELINE_SLOTS) * kinds * slot_words;
+      std::vector<uint32_t> init(words, 0u);
+      for (size_t q = 0; q < words / set_words; ++q) init[q * set_words + TSIMK_LW_LISTS * 32] = 0xFFFFFFFFu;  // "no check row"
+      HIP_TRY(hipMalloc((void **)&p->ctl_block, words * 4));
+      HIP_TRY(hipMemcpy(p->ctl_block, init.data(), words * 4, hipMemcpyHostToDevice));
+    }
+    sl.ctl = p->ctl_block + (size_t)slot * kinds * slot_words;
+    if (p->lw_wide) sl.ctl2 = sl.ctl + slot_words;
   }
   if (p->total_keys > TSIMK_INLINE_KEYS && !sl.keys) HIP_TRY(hipMalloc((void **)&sl.keys, (size_t)p->total_keys * 8));
-  if (slot > 0 && !sl.side_ready) {
+  if (slot > 0 && !sl.ev1) {
+    HIP_TRY(hipEventCreateWithFlags(&sl.ev1, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&sl.ev2, hipEventDisableTiming));
+  }
+  if (slot > 0 && !sl.side_ready && (slot <= 4 || need_stream)) {
     sl.side_ready = true;
     // default priority on purpose: a low- (or high-) priority lane lands on a different class of
     // hardware queue and tripled the step time (134 us vs 43 us, measured)
@@ -81,10 +88,8 @@ static int slot_prepare(tsim_program *p, int slot, size_t hard_bytes) {
       sl.side = p->stream;
       sl.side_borrowed = true;
     } else {
-      HIP_TRY(hipStreamCreateWithFlags(&sl.side, hipStreamNonBlocking));
+      if (int r = tsim_stream_acquire(p->device, p->stream_idx, &sl.side)) return r;  // (pooled: hardware queues the handle does not use yet first)
     }
-    HIP_TRY(hipEventCreateWithFlags(&sl.ev1, hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&sl.ev2, hipEventDisableTiming));
   }
   if (sl.hard_sz < hard_bytes) {
     if (sl.hard) {
@@ -132,6 +137,8 @@ static LaunchPlan make_plan(tsim_program *p, bool has_row_index, bool pipelined,
   if (p->ext_pending && tsim_tables_extend_poll(p, false) == 1 && p->h_feedback) {
     for (int i = 0; i < 8; ++i) p->h_feedback[i] = 0xFFFFFFFFu;  // the old counts describe the old tables
     p->lw_direct_left = 0;
+    p->deep_rows = 0;  // (rows counted against the old depth - the shallow start's - say nothing about the new one)
+    p->lw_dense_launches = 0;
   }
   if (p->lw && p->lw_wide && p->wr_off != 0 && p->knobs.wide_fused && p->knobs.wide && !has_row_index) {
     // One wide component (k_sample_wide): the kernel serves every row itself - nothing here decides coverage.  Two things
@@ -163,7 +170,7 @@ static LaunchPlan make_plan(tsim_program *p, bool has_row_index, bool pipelined,
             if (tsim_synchronize(p) == TSIM_OK && tsim_tables_extend(p) == TSIM_OK)
               for (int i = 4; i < 8; ++i) p->h_feedback[i] = 0xFFFFFFFFu;
           } else {
-            (void)tsim_tables_extend_begin(p);  // in the background, slice by slice; make_plan's poll puts them in place
+            (void)tsim_tables_extend_begin(p, p->lw_cap_max);  // in the background, slice by slice; make_plan's poll puts them in place
           }
         }
       }
@@ -201,7 +208,7 @@ static LaunchPlan make_plan(tsim_program *p, bool has_row_index, bool pipelined,
             known = false;
           }
         } else {
-          (void)tsim_tables_extend_begin(p);  // in the background, slice by slice; the poll at the top puts them in place
+          (void)tsim_tables_extend_begin(p, p->lw_cap_max);  // in the background, slice by slice; the poll at the top puts them in place
         }
       }
     }
@@ -621,6 +628,7 @@ static int launch_wide(tsim_program *p, int n, const SampleArgs *const *args, in
   const int WF32 = 2 * std::max(1, (num_f + 63) / 64);
   const WideLayout L = wide_layout(p, WF32);
   if (!L.block) return tsim_fail(TSIM_ESTATE, "wide kernel does not fit");
+  if (p->lw_bytes >= (1ll << 32)) return tsim_fail(TSIM_ESTATE, "pattern tables of %lld bytes: k_sample_wide addresses them with 32-bit offsets", p->lw_bytes);
   if (tsim_debug("host")) {
     static bool said = false;
     if (!said) fprintf(stderr, "[tsim] k_sample_wide: block %d, LDS %zu bytes (per wave %d), shared column table %d, term tables in LDS %d\n", L.block, L.lds, L.wave_bytes, L.compact, L.l_tt >= 0 ? 1 : 0);
@@ -1068,8 +1076,9 @@ extern "C" int tsim_sample_batch_device_begin(tsim_program *p, int32_t slot, con
   if (!p->slots_ready) {  // first pipelined launch: create every slot's stream/buffers now, not mid-run
     size_t hard_bytes = 0;
     if (p->lw || p->v4w) hard_bytes = (size_t)(((B + 255) / 256 + TSIMK_LW_LISTS - 1) / TSIMK_LW_LISTS * 1024) * TSIMK_LW_LISTS * 4;
-    for (int k = 1; k <= TSIM_PIPELINE_SLOTS; ++k)
-      if (int r = slot_prepare(p, k, hard_bytes)) return r;
+    (void)hard_bytes;  // (each launch sizes its own slot's lists: launch_sample)
+    for (int k = 1; k <= 4; ++k)  // the lanes, in one go (hardware queues follow the creation order); other slots' buffers on first use
+      if (int r = slot_prepare(p, k, 0)) return r;
     if (int r = slots_now_ready(p)) return r;
   }
   if (int r = slot_prepare(p, 1 + slot, 0)) return r;
@@ -1084,6 +1093,8 @@ extern "C" int tsim_sample_batch_device_begin(tsim_program *p, int32_t slot, con
   // (tsim_sample_steps_device has already drawn the plan of this launch: drawing it twice would count the launch twice
   // and swallow the probe that leads a dense phase back to the tables)
   const LaunchPlan plan = carried ? carried_plan : make_plan(p, false, true, (unsigned long long)B);
+  if (!plan.defer && !sl.side_ready)
+    if (int r = slot_prepare(p, 1 + slot, 0, true)) return r;
   hipStream_t s = plan.defer ? p->slots[1 + (slot & 1)].side : sl.side;
   if (!plan.defer) {
     // the slot's own stream: tsim_pipeline_wait_stream orders only streams that carried work before - a first launch here
@@ -1548,6 +1559,7 @@ static int steps_group_direct(tsim_program *p, int n, const uint64_t *const *d_f
   for (int j = 0; j < n; ++j) {
     const int sidx = 1 + (int)(p->steps_slot++ % (unsigned long long)TSIM_PIPELINE_SLOTS);
     if (j == 0) first = sidx;
+    if (int r = slot_prepare(p, sidx, 0)) return r;
     tsim_program::Slot &sl = p->slots[sidx];
     if (sl.deferred) return tsim_fail(TSIM_ESTATE, "pipeline slot %d still holds a parked launch", sidx - 1);
     if (int r = slot_order_after_previous(p, sl, s)) return r;
@@ -1597,6 +1609,7 @@ static int steps_group_wide(tsim_program *p, int n, const uint64_t *const *d_f, 
   for (int j = 0; j < n; ++j) {
     const int sidx = 1 + (int)(p->steps_slot++ % (unsigned long long)TSIM_PIPELINE_SLOTS);
     if (j == 0) first = sidx;
+    if (int r = slot_prepare(p, sidx, 0)) return r;  // (k_sample_wide leaves no row lists: counters, keys and events only)
     tsim_program::Slot &sl = p->slots[sidx];
     if (sl.deferred) return tsim_fail(TSIM_ESTATE, "pipeline slot %d still holds a parked launch", sidx - 1);
     if (int r = slot_order_after_previous(p, sl, s)) return r;
@@ -1663,7 +1676,7 @@ extern "C" int tsim_sample_steps_device(tsim_program *p, int32_t n_steps, const 
     if (p->comps.empty() && p->knobs.fused_steps && p->num_outputs > 0 && p->num_outputs <= 128 && WF <= 2 && p->lw_direct_chunks > 0 &&
         p->knobs.direct_runs && B > 0 && B <= 0x7FFFFFFFll) {
       if (!p->slots_ready) {
-        for (int k = 1; k <= TSIM_PIPELINE_SLOTS; ++k)
+        for (int k = 1; k <= 4; ++k)
           if (int r = slot_prepare(p, k, 0)) return r;
         if (int r = slots_now_ready(p)) return r;
       }
@@ -1691,14 +1704,14 @@ extern "C" int tsim_sample_steps_device(tsim_program *p, int32_t n_steps, const 
       }
       if (okb) {
         if (!p->slots_ready) {
-          const size_t hard_bytes = (size_t)(((B + 255) / 256 + TSIMK_LW_LISTS - 1) / TSIMK_LW_LISTS * 1024) * TSIMK_LW_LISTS * 4;
-          for (int k = 1; k <= TSIM_PIPELINE_SLOTS; ++k)
-            if (int r = slot_prepare(p, k, hard_bytes)) return r;
+          for (int k = 1; k <= 4; ++k)
+            if (int r = slot_prepare(p, k, 0)) return r;
           if (int r = slots_now_ready(p)) return r;
         }
         const LaunchPlan wplan = make_plan(p, false, true, (unsigned long long)n * (unsigned long long)B);
         TSIM_MARK("plan");
-        if (wplan.use_tables) {
+        // (make_plan may have swapped deeper tables in: the 32-bit offsets of k_sample_wide are checked against THOSE - ADVICE r04)
+        if (wplan.use_tables && wide_applies(p, B, num_f, shot_offset)) {
           if (int r = steps_group_wide(p, n, d_f + done, B, num_f, key, shot_offset, d_out + done, d_max_norm_dev ? d_max_norm_dev + done : nullptr, flags))
             return r;
           done += n;
@@ -1716,9 +1729,8 @@ extern "C" int tsim_sample_steps_device(tsim_program *p, int32_t n_steps, const 
     }
     if (fused) {
       if (!p->slots_ready) {  // as in _begin: every slot's stream / buffers now, not mid-run
-        const size_t hard_bytes = (size_t)(((B + 255) / 256 + TSIMK_LW_LISTS - 1) / TSIMK_LW_LISTS * 1024) * TSIMK_LW_LISTS * 4;
-        for (int k = 1; k <= TSIM_PIPELINE_SLOTS; ++k)
-          if (int r = slot_prepare(p, k, hard_bytes)) return r;
+        for (int k = 1; k <= 4; ++k)
+          if (int r = slot_prepare(p, k, 0)) return r;
         if (int r = slots_now_ready(p)) return r;
       }
       plan = make_plan(p, false, true, (unsigned long long)std::min(n_steps - done, std::min(TSIMK_LWM_MAX_STEPS, p->knobs.fused_max)) * (unsigned long long)B);
@@ -1774,7 +1786,7 @@ extern "C" int tsim_pipeline_lane_stream(tsim_program *p, int32_t lane, void **s
   if (int r = tsim_need_final(p)) return r;
   if (int r = tsim_set_device(p)) return r;
   if (lane < 0 || lane >= TSIM_PIPELINE_SLOTS || !stream) return tsim_fail(TSIM_EINVAL, "bad lane %d", lane);
-  if (int r = slot_prepare(p, 1 + lane, 0)) return r;
+  if (int r = slot_prepare(p, 1 + lane, 0, true)) return r;
   *stream = (void *)p->slots[1 + lane].side;
   return TSIM_OK;
 }
@@ -1791,7 +1803,11 @@ extern "C" int tsim_pipeline_wait_stream(tsim_program *p, void *stream) {
   std::vector<hipStream_t> seen;
   for (int k = 1; k <= TSIM_PIPELINE_SLOTS; ++k) {
     tsim_program::Slot &sl = p->slots[k];
-    if (!sl.side_ready || sl.side == s_user) continue;
+    if (!sl.side_ready) {  // (a slot whose own stream does not exist yet: created by its first launch there, which then waits)
+      if (k > 4) sl.needs_sync = true;
+      continue;
+    }
+    if (sl.side == s_user) continue;
     if (k > 4 && !sl.used) {  // never carried work: not worth a wait packet now - its first launch takes the wait (launch on a slot's own stream)
       sl.needs_sync = true;
       continue;

@@ -43,6 +43,9 @@ bool tsim_tables_plan_at(tsim_program *p, int cap, long long budget, int rec_off
       const long long bytes = ((npat + cnt) << c.n_out) * 4;  // (the component's table starts on a 128-byte line)
       if (bytes > budget || (w > 1 && tab_off * 4 + bytes > 4 * budget)) break;  // per component / all together
       if (((npat + cnt) << c.n_out) + tab_off >= (1ll << 32)) break;              // float offsets are 32-bit
+      // one wide component (k_sample_wide): byte offsets into the table are 32-bit there - a deeper table of 4 GiB or more would
+      // push the program off that kernel for good
+      if (p->lw_wide && p->comps.size() == 1 && tab_off * 4 + bytes >= (1ll << 32)) break;
       bases[w] = (uint32_t)npat;
       npat += cnt;
       wmax = w;
@@ -154,6 +157,7 @@ int tsim_tables_build(tsim_program *p, uint32_t **old) {
   if (old) *old = p->d_lw_tab;
   p->d_lw_tab = tab;
   p->lw_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
+  p->lw_build_bytes = p->lw_bytes;
   static const bool timing = tsim_debug("tables");
   if (timing)
     fprintf(stderr, "[tsim] pattern tables: %.1f MB built in %.1f ms\n", (double)p->lw_bytes / 1e6,
@@ -179,6 +183,17 @@ static void ext_alloc_thread(tsim_program *p) {
   int state = 1;
   if (hipSetDevice(p->device) != hipSuccess) state = -1;
   uint32_t *tab = nullptr;
+  {
+    // the new table and its scratch (node values: as many floats again) live next to the old table until the swap; a caller
+    // that sized its own buffers by tsim_mem_info must not find the memory gone - leave a quarter of what is free, and at
+    // least 1 GiB, alone
+    size_t fr = 0, tot = 0;
+    const size_t need = 2 * (size_t)p->ext_plan.bytes;
+    if (state > 0 && hipMemGetInfo(&fr, &tot) == hipSuccess && need + std::max<size_t>(fr / 4, (size_t)1 << 30) > fr) {
+      if (tsim_debug("tables")) fprintf(stderr, "[tsim] deeper tables (%zu MB with scratch) not built: %zu MB free\n", need >> 20, fr >> 20);
+      state = -1;
+    }
+  }
   if (state > 0 && hipMalloc((void **)&tab, std::max<size_t>(16, (size_t)p->ext_plan.bytes)) != hipSuccess) state = -1;
   for (size_t ci = 0; state > 0 && ci < p->comps.size(); ++ci) {
     const HostComponent &c = p->comps[ci];
@@ -204,6 +219,7 @@ static void ext_alloc_thread(tsim_program *p) {
   }
   if (state < 0) {
     (void)hipGetLastError();
+    if (tsim_debug("tables")) fprintf(stderr, "[tsim] deeper tables: allocation failed or skipped - the handle stays at its depth\n");
     for (void *q : p->ext_scratch) (void)hipFree(q);
     p->ext_scratch.clear();
     p->ext_jobs.clear();
@@ -214,13 +230,14 @@ static void ext_alloc_thread(tsim_program *p) {
   p->ext_alloc.store(state, std::memory_order_release);
 }
 
-int tsim_tables_extend_begin(tsim_program *p) {
-  if (!p->lw || p->lw_cap_now >= p->lw_cap_max || p->ext_pending) return 0;
-  p->lw_cap_now = p->lw_cap_max;  // asked once
+int tsim_tables_extend_begin(tsim_program *p, int target_cap) {
+  target_cap = std::min(target_cap, p->lw_cap_max);
+  if (!p->lw || p->lw_cap_now >= target_cap || p->ext_pending) return 0;
+  p->lw_cap_now = target_cap;  // asked once
   const size_t rec_words = p->comps.size() * LW_WORDS;
   std::copy(p->img.begin() + p->lw_off, p->img.begin() + p->lw_off + (long)rec_words, p->img.begin() + p->lw_shadow_off);
   TsimTablePlan t;
-  if (!tsim_tables_plan_at(p, p->lw_cap_max, p->lw_budget, p->lw_shadow_off, t) || t.wmax == p->lw_wmax) return 0;  // nothing to gain (budget)
+  if (!tsim_tables_plan_at(p, target_cap, p->lw_budget, p->lw_shadow_off, t) || t.wmax == p->lw_wmax) return 0;  // nothing to gain (budget)
   if (!p->ext_ev) HIP_TRY(hipEventCreateWithFlags(&p->ext_ev, hipEventDisableTiming));
   p->ext_t0 = std::chrono::steady_clock::now();
   p->ext_jobs.clear();
@@ -339,14 +356,15 @@ int tsim_tables_extend_poll(tsim_program *p, bool wait) {
 // gain per row, profiles/r04/long_runs.txt): C5 4e9, C4 2e10, C3 3e10 rows; this gives 1.0e10, 1.8e10, 0.6e10.
 unsigned long long tsim_tables_deep_after(tsim_program *p) {
   if (p->knobs.deep_after) return p->knobs.deep_after;
+  if (p->ext_pending) return ~0ull >> 1;  // (a build is under way - the shallow start's: its shadow records must not be replanned)
   if (p->deep_after_auto) return p->deep_after_auto;
   double rows = 4e9;
-  if (p->lw && p->lw_build_ms > 0.0 && p->lw_bytes > 0) {
+  if (p->lw && p->lw_build_ms > 0.0 && p->lw_build_bytes > 0) {
     const size_t rec_words = p->comps.size() * LW_WORDS;
     std::copy(p->img.begin() + p->lw_off, p->img.begin() + p->lw_off + (long)rec_words, p->img.begin() + p->lw_shadow_off);
     TsimTablePlan t;
     if (tsim_tables_plan_at(p, p->lw_cap_max, p->lw_budget, p->lw_shadow_off, t)) {
-      const double entries_per_ms = (double)p->lw_bytes / 4.0 / p->lw_build_ms;
+      const double entries_per_ms = (double)p->lw_build_bytes / 4.0 / p->lw_build_ms;  // (what finalize built - not what is in place now)
       const double build_s = (double)t.bytes / 4.0 / entries_per_ms * 1e-3;
       rows = 2.0 * build_s * 4e10;
     }
@@ -359,7 +377,11 @@ unsigned long long tsim_tables_deep_after(tsim_program *p) {
 
 // (blocking form: TSIM_AMD_DEEP_TABLES=1 - the deeper tables NOW)
 int tsim_tables_extend(tsim_program *p) {
-  if (int r = tsim_tables_extend_begin(p)) return r;
+  if (p->ext_pending) {  // (the shallow start's build of the default depth: finish it first)
+    const int r0 = tsim_tables_extend_poll(p, true);
+    if (r0 < 0) return r0;
+  }
+  if (int r = tsim_tables_extend_begin(p, p->lw_cap_max)) return r;
   const int r = tsim_tables_extend_poll(p, true);
   return r < 0 ? r : 0;
 }

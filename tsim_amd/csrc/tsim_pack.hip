@@ -278,10 +278,17 @@ bool pack_level_fast(HostLevel &h, int W, std::vector<uint32_t> &tables, bool &f
   std::vector<std::vector<ZW>> entries((size_t)G);   // per graph: the main table (entry 0 excluded)
   std::vector<std::vector<ZW>> dentries((size_t)G);  // per graph: the separate PhasePairs table, if any
   h.fg.assign((size_t)G, FastGraph());
-  for (int g = 0; g < G; ++g) {
+  // One graph's algebra is independent of the others': the graphs of a level are packed by up to 8 threads (C4: 1008 graphs,
+  // ~30 us each - 31 of the 38 ms a fresh handle took before its first launch), their rows concatenated afterwards.
+  std::vector<std::vector<uint32_t>> grows((size_t)G);
+  std::vector<long long> g_nrows((size_t)G, 0);
+  const auto t_fn0 = std::chrono::steady_clock::now();
+  std::atomic<long long> ns_a{0}, ns_b{0}, ns_c{0};
+  auto do_graph = [&](int g) -> bool {
+    const auto tg0 = std::chrono::steady_clock::now();
+    std::vector<uint32_t> &rows = grows[(size_t)g];
     FastGraph &fg = h.fg[(size_t)g];
     uint32_t *rec = &h.graph_rec[(size_t)g * G_WORDS];
-    rec[GF_ROWS] = (uint32_t)h.rows.size();
     const int nA = d.ta ? h.i32[0][g] : 0;
     std::vector<Affine> two;  // bits entering the exponent with coefficient 2
     QForm q4(P);              // bit entering with coefficient 4
@@ -300,8 +307,8 @@ bool pack_level_fast(HostLevel &h, int W, std::vector<uint32_t> &tables, bool &f
         ++n[cls];
         if (cls != 0) add_six(affine_from(bits, P, (ph >> 2) != 0));  // (-i)^(par')
         if (cls == 2) continue;
-        h.rows.push_back(ph >> 2);
-        pack_row(h.rows, bits, P, W);
+        rows.push_back(ph >> 2);
+        pack_row(rows, bits, P, W);
         auto &dstm = cls == 0 ? fg.c0 : (cls == 1 ? fg.c1 : fg.c3);
         auto &dstc = cls == 0 ? fg.c0c : (cls == 1 ? fg.c1c : fg.c3c);
         dstm.push_back(affine_from(bits, P, false).m);
@@ -331,8 +338,8 @@ bool pack_level_fast(HostLevel &h, int W, std::vector<uint32_t> &tables, bool &f
         }
         (void)w;
       }
-      pack_row(h.rows, &h.u8[9][((size_t)g * d.td + t) * P], P, W);
-      pack_row(h.rows, &h.u8[11][((size_t)g * d.td + t) * P], P, W);
+      pack_row(rows, &h.u8[9][((size_t)g * d.td + t) * P], P, W);
+      pack_row(rows, &h.u8[11][((size_t)g * d.td + t) * P], P, W);
       fg.dal.push_back(affine_from(&h.u8[9][((size_t)g * d.td + t) * P], P, false).m);
       fg.dbe.push_back(affine_from(&h.u8[11][((size_t)g * d.td + t) * P], P, false).m);
     }
@@ -376,22 +383,26 @@ bool pack_level_fast(HostLevel &h, int W, std::vector<uint32_t> &tables, bool &f
       y.c = false;
       q4.add_linear(y);
     }
+    const auto tg1 = std::chrono::steady_clock::now();
     q4.finish();
     std::vector<std::vector<uint64_t>> us, vs;
     dickson_reduce(q4, us, vs);
+    const auto tg2 = std::chrono::steady_clock::now();
+    ns_a += (tg1 - tg0).count();
+    ns_b += (tg2 - tg1).count();
     if (q4.c) k0 += 4;
     if (us.size() > 60000) return false;
     // ---- rows: lam, lin, then the product pairs
     uint32_t flags = d_tabled ? TSIMK_GFLAG_D_TABLED : 0u;
     {
       std::vector<uint32_t> tmp;
-      if (push_mask_row(tmp, lam.m, P, W)) { flags |= TSIMK_GFLAG_LAM; h.rows.insert(h.rows.end(), tmp.begin(), tmp.end()); }
+      if (push_mask_row(tmp, lam.m, P, W)) { flags |= TSIMK_GFLAG_LAM; rows.insert(rows.end(), tmp.begin(), tmp.end()); }
       tmp.clear();
-      if (push_mask_row(tmp, q4.lin, P, W)) { flags |= TSIMK_GFLAG_LIN; h.rows.insert(h.rows.end(), tmp.begin(), tmp.end()); }
+      if (push_mask_row(tmp, q4.lin, P, W)) { flags |= TSIMK_GFLAG_LIN; rows.insert(rows.end(), tmp.begin(), tmp.end()); }
     }
     for (size_t s = 0; s < us.size(); ++s) {
-      push_mask_row(h.rows, us[s], P, W);
-      push_mask_row(h.rows, vs[s], P, W);
+      push_mask_row(rows, us[s], P, W);
+      push_mask_row(rows, vs[s], P, W);
     }
     rec[GF_N3H] = (uint32_t)n[3] | ((uint32_t)us.size() << 16);
     rec[GF_FLAGS] = flags;
@@ -399,7 +410,7 @@ bool pack_level_fast(HostLevel &h, int W, std::vector<uint32_t> &tables, bool &f
     fg.lin = q4.lin;
     fg.us = us;
     fg.vs = vs;
-    h.n_rows += n[0] + n[1] + n[3] + ((flags & TSIMK_GFLAG_LAM) ? 1 : 0) + ((flags & TSIMK_GFLAG_LIN) ? 1 : 0) +
+    g_nrows[(size_t)g] = n[0] + n[1] + n[3] + ((flags & TSIMK_GFLAG_LAM) ? 1 : 0) + ((flags & TSIMK_GFLAG_LIN) ? 1 : 0) +
                 2 * (long long)us.size() + 2 * nD;
     // ---- table entries (index: ((delta + n1) << 2 nD | dbits) + 1; entry 0 is the exact zero)
     //   canon( 2^n0 (1+i)^n2 (1+w)^(n1-m1) (1-w)^m1 (1+w^3)^(n3-m3) (1-w^3)^m3 * i^(m1+m3)
@@ -453,6 +464,30 @@ bool pack_level_fast(HostLevel &h, int W, std::vector<uint32_t> &tables, bool &f
     }
     memcpy(&rec[GF_APRE], &h.approx_v[2 * (size_t)g], 4);
     memcpy(&rec[GF_APIM], &h.approx_v[2 * (size_t)g + 1], 4);
+    ns_c += (std::chrono::steady_clock::now() - tg2).count();
+    return true;
+  };
+  {
+    std::atomic<int> next{0};
+    std::atomic<bool> failed{false};
+    auto worker = [&]() {
+      for (;;) {
+        const int g = next.fetch_add(1);
+        if (g >= G || failed.load()) return;
+        if (!do_graph(g)) failed.store(true);
+      }
+    };
+    const int nthreads = G >= 16 ? std::min(G >= 64 ? 8 : 4, std::max(1, (int)std::thread::hardware_concurrency())) : 1;
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nthreads; ++t) pool.emplace_back(worker);
+    worker();
+    for (auto &t : pool) t.join();
+    if (failed.load()) return false;
+  }
+  for (int g = 0; g < G; ++g) {
+    h.graph_rec[(size_t)g * G_WORDS + GF_ROWS] = (uint32_t)h.rows.size();
+    h.rows.insert(h.rows.end(), grows[(size_t)g].begin(), grows[(size_t)g].end());
+    h.n_rows += g_nrows[(size_t)g];
   }
   // ---- fixed frame: every term of the level comes straight from a table and, shifted to the
   //      level's smallest power, the worst-case sum of all graphs stays inside int32
@@ -533,6 +568,9 @@ bool pack_level_fast(HostLevel &h, int W, std::vector<uint32_t> &tables, bool &f
       tables.push_back(0u); tables.push_back(0u); tables.push_back(0u);
     }
   }
+  if (tsim_debug("pack"))
+    fprintf(stderr, "[tsim] pack_level_fast G=%d P=%d: %.2f ms wall; per-graph sums: terms -> forms %.2f ms, finish + Dickson %.2f ms, rows + table entries %.2f ms\n", G, P,
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_fn0).count(), ns_a.load() * 1e-6, ns_b.load() * 1e-6, ns_c.load() * 1e-6);
   fixed_out = fixed;
   frame_out = fixed ? frame : 0;
   h.fixed = fixed;

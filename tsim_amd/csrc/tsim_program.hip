@@ -339,6 +339,29 @@ retry_pack:
   p->level_off.clear();
   p->level_base.clear();
   p->comp_w.clear();
+  // The fast formulation's pack-time algebra of every level, the levels side by side (C4: seven levels of 16-256 graphs, 1.1-2 ms
+  // each even with their graphs on eight threads - one after the other they were 12 of the 21 ms of a fresh handle)
+  struct PrePacked { std::vector<uint32_t> tables; bool fixed = false, ok = true; int frame = 0; };
+  std::vector<PrePacked> prepacked;
+  if (p->fast) {
+    std::vector<std::pair<HostLevel *, int>> jobs;
+    for (auto &c : p->comps) {
+      int maxP = 1;
+      for (auto &lv : c.levels) maxP = std::max(maxP, lv.P);
+      if (c.n_levels == c.n_out + 1) maxP = std::max(maxP, c.F + c.n_out);
+      const int W = round_w((maxP + 31) / 32);
+      for (auto &lv : c.levels) jobs.push_back({&lv, W});
+    }
+    prepacked.resize(jobs.size());
+    std::vector<std::thread> pool;
+    auto run = [&](size_t i) {
+      if (jobs[i].second < 0) { prepacked[i].ok = true; return; }  // (reported below: too many parameters)
+      prepacked[i].ok = pack_level_fast(*jobs[i].first, jobs[i].second, prepacked[i].tables, prepacked[i].fixed, prepacked[i].frame);
+    };
+    for (size_t i = 1; i < jobs.size(); ++i) pool.emplace_back(run, i);
+    if (!jobs.empty()) run(0);
+    for (auto &t : pool) t.join();
+  }
   for (size_t ci = 0; ci < p->comps.size(); ++ci) {
     HostComponent &c = p->comps[ci];
     int maxP = 1;
@@ -371,10 +394,15 @@ retry_pack:
       bool fixed = false;
       int frame = 0;
       if (p->fast) {
-        if (!pack_level_fast(h, W, tables, fixed, frame)) {  // a table entry exceeds int32: use the faithful layout
+        // (packed by the pre-pass above, all levels of the program side by side)
+        PrePacked &pp = prepacked[(size_t)p->level_off.size()];
+        if (!pp.ok) {  // a table entry exceeds int32: use the faithful layout
           p->fast = false;
           goto retry_pack;
         }
+        tables.swap(pp.tables);
+        fixed = pp.fixed;
+        frame = pp.frame;
       } else {
         pack_level(h, W);
       }
@@ -481,6 +509,28 @@ retry_pack:
         p->v4_max_nch = 0;
         p->v4_gt = 1;
       }
+      // the chunk / column tables of every level, emitted side by side (C4: 3.5 ms one after the other), assembled below
+      struct Emit4 { std::vector<uint32_t> recs4, tabs4, stabs4; int nch = 1, ntiles = 0, sparse_F = -1; };
+      std::vector<std::vector<Emit4>> emitted(p->comps.size());
+      {
+        std::vector<std::thread> pool;
+        for (size_t ci = 0; ci < p->comps.size(); ++ci) {
+          HostComponent &c = p->comps[ci];
+          emitted[ci].resize((size_t)c.n_levels);
+          for (int k = 0; k < c.n_levels; ++k) {
+            const bool sequential = (c.n_levels == c.n_out + 1);
+            emitted[ci][(size_t)k].sparse_F = (wide || (sequential && c.n_out <= 8 && c.F + c.n_out <= 64)) ? c.F : -1;
+            pool.emplace_back([&, ci, k]() {
+              HostLevel &h = p->comps[ci].levels[(size_t)k];
+              Emit4 &e = emitted[ci][(size_t)k];
+              const uint32_t v3recs = img[(size_t)p->level_off[p->level_base[ci] + k] + L_GRAPHS];
+              std::vector<uint32_t> v3copy(img.begin() + v3recs, img.begin() + v3recs + (size_t)h.G * G_WORDS);
+              emit_level4(h, p->v4_gt, p->v4_max_nch, v3copy.data(), e.recs4, e.tabs4, e.nch, e.ntiles, e.sparse_F, e.stabs4);
+            });
+          }
+        }
+        for (auto &t : pool) t.join();
+      }
       for (size_t ci = 0; ci < p->comps.size(); ++ci) {
         HostComponent &c = p->comps[ci];
         for (int w = 0; w < 8; ++w) img[p->comp4_off + ci * C4_WORDS + w] = img[p->comp_off + ci * C_WORDS + w];
@@ -492,12 +542,9 @@ retry_pack:
           HostLevel &h = c.levels[k];
           const uint32_t v3lvl = (uint32_t)p->level_off[p->level_base[ci] + k];
           const uint32_t v3recs = img[v3lvl + L_GRAPHS];
-          std::vector<uint32_t> recs4, tabs4, stabs4;
-          int nch = 1, ntiles = 0;
-          const bool sequential = (c.n_levels == c.n_out + 1);
-          const int sparse_F = (wide || (sequential && c.n_out <= 8 && c.F + c.n_out <= 64)) ? c.F : -1;
-          std::vector<uint32_t> v3copy(img.begin() + v3recs, img.begin() + v3recs + (size_t)h.G * G_WORDS);
-          emit_level4(h, p->v4_gt, p->v4_max_nch, v3copy.data(), recs4, tabs4, nch, ntiles, sparse_F, stabs4);
+          Emit4 &em = emitted[ci][(size_t)k];
+          std::vector<uint32_t> &recs4 = em.recs4, &tabs4 = em.tabs4, &stabs4 = em.stabs4;
+          const int nch = em.nch, ntiles = em.ntiles, sparse_F = em.sparse_F;
           while (img.size() % 16) img.push_back(0u);
           const uint32_t roff = (uint32_t)img.size();
           img.insert(img.end(), recs4.begin(), recs4.end());
@@ -626,7 +673,7 @@ retry_pack:
               cost += (double)(t.npat[ci] << p->comps[ci].n_out) * g / (double)p->comps[ci].levels.size();
             }
           std::copy(keep.begin(), keep.end(), img.begin() + p->lw_off);
-          if (cost <= 1.2e8) break;
+          if (cost <= 5e7) break;
           --p->lw_cap_now;
         }
       }

@@ -233,6 +233,9 @@ static void ext_alloc_thread(tsim_program *p) {
 int tsim_tables_extend_begin(tsim_program *p, int target_cap) {
   target_cap = std::min(target_cap, p->lw_cap_max);
   if (!p->lw || p->lw_cap_now >= target_cap || p->ext_pending) return 0;
+  // (the shallow start's build of the default depth goes out in slices four times as large: until it is in place most rows of
+  // an expensive program are hard rows - C4 at weight 2: 1.8e9 instead of 3e10 shots/s - so the build IS the work that matters)
+  const bool stage_a = p->lw_cap_now < p->lw_cap_default && target_cap <= p->lw_cap_default;
   p->lw_cap_now = target_cap;  // asked once
   const size_t rec_words = p->comps.size() * LW_WORDS;
   std::copy(p->img.begin() + p->lw_off, p->img.begin() + p->lw_off + (long)rec_words, p->img.begin() + p->lw_shadow_off);
@@ -244,7 +247,7 @@ int tsim_tables_extend_begin(tsim_program *p, int target_cap) {
   p->ext_scratch.clear();
   p->ext_job = 0;
   p->ext_slices = 0;
-  p->ext_entries = 1ll << 21;
+  p->ext_entries = stage_a ? (1ll << 23) : (1ll << 21);
   p->ext_plan = t;
   p->ext_uploaded = false;
   p->ext_slice_due = false;

@@ -1331,6 +1331,15 @@ def extra_legs(backend, synth, program, cfg, hp, info, B, num_f, n_out, key, f_b
     t_handle = time.perf_counter() - t0
     hp2.sample_batch_device(f_bufs[0].ptr, B, num_f, key, d_out0.ptr)
     hp2.synchronize()
+    try:  # cold start against the BASELINE job sizes: fresh handle + n shots, wall clock
+        from scripts.time_to_n import measure_time_to_n
+
+        out["time_to_n_shots"] = {"configs": measure_time_to_n(backend, synth, ["C2", "C4", "C5"], [100_000, 1_000_000, 10_000_000, 100_000_000]),
+                                  "note": "seconds from tsim_program_create to the last row of n shots (batches of <= 10^6, tsim_sample_steps_device, resident f, "
+                                          "bit_packed rows in HBM) on a FRESH handle in this process (HIP initialised, streams pooled): pack + upload + the shallow "
+                                          "pattern tables of finalize, the default depth built in the background; best of 3 (scripts/time_to_n.py)"}
+    except Exception as exc:
+        out["time_to_n_shots"] = {"error": repr(exc)}
     out["time_to_first_batch_s"] = {"first_handle_incl_hip_init": t_build, "fresh_handle": t_handle,
                                     "fresh_handle_plus_first_batch": time.perf_counter() - t0, "shots": B}
     hp2.close()

@@ -21,23 +21,18 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--configs", default="C2,C4,C5")
-    ap.add_argument("--ns", default="100000,1000000,10000000,100000000")
-    ap.add_argument("--json", action="store_true")
-    a = ap.parse_args()
-    from tsim_amd import backend, synth
+def measure_time_to_n(backend, synth, configs, ns, repeats=3, verbose=False) -> dict:
+    """{config: {n: {"seconds": best of `repeats`, "fresh_handle_s", "batches", "shots_per_batch", "table_depth_at_end"}}}"""
     from scripts.shape_map import device_f
 
     res = {}
-    for name in a.configs.split(","):
+    for name in configs:
         program, cfg = synth.config_program(name)
         num_f, n_out = cfg["num_f"], program.num_outputs
         WF, RB = max(1, (num_f + 63) // 64), (n_out + 7) // 8
         helper = backend.HipProgram(program)
         res[name] = {}
-        for n in [int(x) for x in a.ns.split(",")]:
+        for n in ns:
             B = min(n, 1_000_000)
             k = (n + B - 1) // B
             nf = min(k, 8)
@@ -45,7 +40,8 @@ def main():
             outs = [helper.malloc(max(16, B * RB)) for _ in range(min(k, backend.HipProgram.PIPELINE_SLOTS))]
             helper.synchronize()
             dts, fin = [], []
-            for _ in range(3):
+            depth = None
+            for _ in range(repeats):
                 t0 = time.perf_counter()
                 hp = backend.HipProgram(program)
                 t1 = time.perf_counter()
@@ -64,8 +60,21 @@ def main():
             for b in fl + outs:
                 b.free()
             res[name][str(n)] = {"seconds": min(dts), "fresh_handle_s": min(fin), "batches": k, "shots_per_batch": B, "table_depth_at_end": depth}
-            print(f"{name} n={n:>11d}: {min(dts) * 1e3:8.2f} ms (handle {min(fin) * 1e3:6.2f} ms), {k} x {B}, table depth at the end {depth}, all {[round(d * 1e3, 2) for d in dts]}", flush=True)
+            if verbose:
+                print(f"{name} n={n:>11d}: {min(dts) * 1e3:8.2f} ms (handle {min(fin) * 1e3:6.2f} ms), {k} x {B}, table depth at the end {depth}, all {[round(d * 1e3, 2) for d in dts]}", flush=True)
         helper.close()
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--configs", default="C2,C4,C5")
+    ap.add_argument("--ns", default="100000,1000000,10000000,100000000")
+    ap.add_argument("--json", action="store_true")
+    a = ap.parse_args()
+    from tsim_amd import backend, synth
+
+    res = measure_time_to_n(backend, synth, a.configs.split(","), [int(x) for x in a.ns.split(",")], verbose=True)
     if a.json:
         print(json.dumps(res))
 

@@ -254,6 +254,8 @@ struct tsim_program {
     bool wide = true;         // wide=0: wide components on the row kernel alone
     bool wide_tables = true;  // wide_tables=0: no pattern tables in front of the wide kernels
     bool hard_overflow = true; // hard_overflow=0: the latency kernels of a hard-row batch walk whole lists (no per-shot workers behind them)
+    bool hard_tree = false;   // hard_tree=1: the block-per-row kernel takes the levels in lookahead groups (hw_component_tree) - measured
+                              // slower, profiles/r05/hard_tree.txt: the grid waits for the normalisation-check row either way
     bool shallow = true;      // shallow=0: finalize builds the default table depth at once (round 4) instead of starting shallow
     int gen = 1;              // gen: k_sample_gen for fused groups - 0 never, 1 where no register first pass applies, 2 wherever it applies
     bool wide_compact = true; // wide_compact=0: k_sample_wide keeps one 16-byte column table per graph even when all graphs fit one entry

@@ -285,6 +285,7 @@ extern "C" int tsim_program_finalize(tsim_program *p, int32_t device) {
     p->knobs.wide_compact = tune_ll("wide_compact", 1) != 0;
     p->knobs.gen = (int)std::max(0ll, std::min(2ll, tune_ll("gen", 1)));
     p->knobs.shallow = tune_ll("shallow", 1) != 0;
+    p->knobs.hard_tree = tune_ll("hard_tree", 0) != 0;
     p->knobs.hard_overflow = tune_ll("hard_overflow", 1) != 0;
   }
 

@@ -1796,7 +1796,15 @@ extern "C" int tsim_pipeline_wait_stream(tsim_program *p, void *stream) {
   if (int r = tsim_need_final(p)) return r;
   if (int r = tsim_set_device(p)) return r;
   hipStream_t s_user = stream ? (hipStream_t)stream : p->stream;
-  if (!p->slots_ready) return TSIM_OK;  // no lane exists yet: the first launches order themselves
+  if (!p->slots_ready) {
+    // No lane exists yet.  Rounds 2-4 returned here ("the first launches order themselves") - they do not when the caller then
+    // launches with TSIM_PIPE_INPUTS_READY, as sampler.py does: the first group of a fresh handle raced with the noise kernel that
+    // fills its f buffers (hidden while creating the 32 slot streams took 80 ms; seen once the streams came from the pool:
+    // tests/test_gpu_sampler.py::test_device_postselection[rows] behind test_gpu_noise.py).  Create the lanes and order them.
+    for (int k = 1; k <= 4; ++k)
+      if (int r = slot_prepare(p, k, 0)) return r;
+    if (int r = slots_now_ready(p)) return r;
+  }
   if (!p->sync_ev) HIP_TRY(hipEventCreateWithFlags(&p->sync_ev, hipEventDisableTiming));
   HIP_TRY(hipEventRecord(p->sync_ev, s_user));
   // every lane a launch may run on: the slots' own streams that were used so far and the first three

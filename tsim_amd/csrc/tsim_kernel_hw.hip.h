@@ -579,7 +579,14 @@ __device__ __forceinline__ void hw_row(const SampleArgs &A, long long row, bool 
           else hw_component<2>(A, img, comp, ci, fbit, shot, check, par, pw, out_w);
         }
         break;
-      default: __builtin_trap();  // the host launches this kernel for narrow programs only
+      case 3:
+      case 4:  // (parameter rows of 65..128 bits: the overflow / check rows of the sparse-column path, tsim_sample.hip: launch_sample)
+        if constexpr (WMAX >= 4) {
+          if (comp[C_W] == 3u) hw_component<3>(A, img, comp, ci, fbit, shot, check, par, pw, out_w);
+          else hw_component<4>(A, img, comp, ci, fbit, shot, check, par, pw, out_w);
+        }
+        break;
+      default: __builtin_trap();  // the host launches this kernel for programs of at most 128 parameters only
     }
   }
 #pragma unroll

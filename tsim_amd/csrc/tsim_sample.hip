@@ -309,7 +309,7 @@ static int launch_over(tsim_program *p, const SampleArgs *ctx, int n_ctx, uint32
 // the per-shot overflow grid exists for this program (chunk tables) and is not switched off
 static bool over_available(const tsim_program *p) { return p->v4 && p->knobs.hard_overflow; }
 
-static int launch_hw(tsim_program *p, const SampleArgs *ctx, int n_ctx, int max_lists, hipStream_t hs, bool partial) {
+static int launch_hw(tsim_program *p, const SampleArgs *ctx, int n_ctx, int max_lists, hipStream_t hs, bool partial, bool with_feedback = true) {
   int wmax = 1;
   for (int w : p->comp_w) wmax = std::max(wmax, w);
   const uint32_t fb_max = p->h_feedback ? p->h_feedback[1] : 192u;
@@ -319,7 +319,7 @@ static int launch_hw(tsim_program *p, const SampleArgs *ctx, int n_ctx, int max_
   // as many blocks per list as the longest list of the last launch had rows (plus a margin): each block then takes one
   // row; longer lists are walked in turns (blocks of four waves: one row at a time each, see k_sample_hw)
   H.waves_per_list = (int)std::max(8u, std::min(128u, std::min(fb_max, 4096u) * 2u + 8u));
-  H.feedback = p->d_feedback;
+  H.feedback = with_feedback ? p->d_feedback : nullptr;
   for (int i = 0; i < n_ctx; ++i) {
     H.ctx[i] = ctx[i];
     H.ctx[i].kernarg_off = (int)(offsetof(HwMulti, ctx) + (size_t)i * sizeof(SampleArgs));
@@ -350,6 +350,9 @@ static int launch_hw(tsim_program *p, const SampleArgs *ctx, int n_ctx, int max_
   if (wmax == 1) switch (nch) {
     TSIM_LHW(1, 0) TSIM_LHW(1, 2) TSIM_LHW(1, 4) TSIM_LHW(1, 6) TSIM_LHW(1, 8) TSIM_LHW(1, 10) TSIM_LHW(1, 12) TSIM_LHW(1, 14) TSIM_LHW(1, 16)
     default: return tsim_fail(TSIM_ESTATE, "bad chunk count %d", nch);
+  } else if (wmax > 2) {  // parameter rows of 65..128 bits (no chunk tables, no workers)
+    if (nch != 0) return tsim_fail(TSIM_ESTATE, "hard-row workers need chunk tables");
+    hipLaunchKernelGGL((k_sample_hw<4, 0>), dim3(grid), dim3(256), ldsw, hs, H);
   } else switch (nch) {
     TSIM_LHW(2, 0) TSIM_LHW(2, 2) TSIM_LHW(2, 4) TSIM_LHW(2, 6) TSIM_LHW(2, 8) TSIM_LHW(2, 10) TSIM_LHW(2, 12) TSIM_LHW(2, 14) TSIM_LHW(2, 16)
     default: return tsim_fail(TSIM_ESTATE, "bad chunk count %d", nch);
@@ -1030,6 +1033,16 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
   }
   int wmax = 1;
   for (int w : p->comp_w) wmax = std::max(wmax, w);
+  // The rows left in lists behind the sparse-column pass (more than K set bits, the normalisation-check row): ONE lane of the row
+  // kernel walks all levels and graphs of such a row by itself - 280 us per batch for the check row of a 148-term program with
+  // 65 parameters (class F60, profiles/r05/shape_map.txt) - the block-per-row kernel takes ~25.  (Programs of a few graphs - the C5 family - are
+  // quicker on the one lane: 2wide 111 -> 127 us per step with the block-per-row kernel, measured.)
+  // (no feedback from this grid: the plan's counts are the sparse-column pass's - the rows that miss the tables - not its overflow)
+  if (a.row_lists > 1 && !p->v4 && use_tables && p->fast && p->knobs.hard_wave && wmax <= 4 && p->total_graphs >= 64 && a.WF <= 32 && a.WO <= 2 && p->hw_max_rows < 60000) {
+    if (int r = launch_hw(p, &a, 1, a.row_lists, s, false, false)) return r;
+    if (prof && !(p->prof_light && use_tables)) { int r = prof_event(p, s, PROF_FULL); if (r) return r; }
+    return finish();
+  }
   ++p->path_count[TP_ROWS];
   if (int r = tsim_launch_rows(p, wmax, a, grid, block, lds, s)) return r;
   if (prof && !(p->prof_light && use_tables)) { int r = prof_event(p, s, PROF_FULL); if (r) return r; }

@@ -552,7 +552,7 @@ def test_bit_packed_only_output_of_pipelined_launches(hip, name):
             np.testing.assert_array_equal(got, want[i])
 
 
-@pytest.mark.parametrize("name,start", [("C2", [4]), ("C4", [2, 2, 2]), ("C3", [3])])
+@pytest.mark.parametrize("name,start", [("C2", [4]), ("C4", [3, 3, 3]), ("C3", [3])])
 def test_shallow_start_reaches_the_default_depth_and_bits_do_not_change(hip, name, start):
     """finalize builds only the tables that cost about half a millisecond (the BASELINE jobs are 10^5-10^6
     shots; C4's weight-5 tables are 195 MB and 35 ms), the default depth (5) follows in the background, one slice per launch

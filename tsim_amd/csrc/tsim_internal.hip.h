@@ -306,7 +306,10 @@ struct tsim_program {
   bool ext_uploaded = false, ext_slice_due = false, ext_recorded = false;
   long long ext_entries = 1ll << 21;    // table entries per slice
   std::thread ext_thread;              // allocates the new table and the build scratch (hipMalloc of GBs: up to 30 ms)
-  std::atomic<int> ext_alloc{0};       // 0: running, 1: done, -1: failed
+  std::atomic<int> ext_alloc{0};       // 0: running, 1: buffers allocated (the launch plans drive the slices), 2: built by the thread, -1: failed
+  bool ext_self = false;               // this build is driven by the helper thread (the shallow start's default depth)
+  std::atomic<bool> ext_abort{false};  // destroy: stop between slices
+  hipStream_t ext_stream = nullptr;    // the thread's stream (pooled)
   TsimTablePlan ext_plan;
   std::chrono::steady_clock::time_point ext_t0;
   // device allocations handed out by tsim_malloc_device and not yet freed: the handle owns them

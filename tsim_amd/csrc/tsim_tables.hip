@@ -227,6 +227,42 @@ static void ext_alloc_thread(tsim_program *p) {
     tab = nullptr;
   }
   p->ext_tab = tab;
+  if (state > 0 && p->ext_self) {
+    // The shallow start's build of the default depth is driven from HERE, slice after slice on a stream of its own, each
+    // waited for before the next goes out (first passes get in between; nothing is ever queued behind a whole build).  The
+    // plan-driven form - one slice per launch plan - needs a host that plans no faster than the GPU samples: a caller that
+    // enqueues a 10^8-shot job in one go (scripts/time_to_n.py: 13 plans within 0.3 ms) had drawn its last plan before the
+    // buffers were even allocated, and sampled the whole job with the shallow tables (C4 at weight 2: 1.9e9 shots/s).
+    hipStream_t bs = nullptr;
+    std::vector<int> held;
+    if (tsim_stream_acquire(p->device, held, &bs) != 0) state = -1;
+    p->ext_stream = bs;
+    const size_t rec_words = p->comps.size() * LW_WORDS;
+    if (state > 0 && hipMemcpyAsync(p->d_img + p->lw_shadow_off, p->img.data() + p->lw_shadow_off, rec_words * 4, hipMemcpyHostToDevice, bs) != hipSuccess) state = -1;
+    for (size_t ji = 0; state > 0 && ji < p->ext_jobs.size(); ++ji) {
+      TsimBuildJob &j = p->ext_jobs[ji];
+      const long long per = std::max<long long>(1, p->ext_entries >> j.n_out);
+      while (state > 0 && j.next_pat < (long long)j.a.npat) {
+        if (p->ext_abort.load(std::memory_order_acquire)) { state = -1; break; }
+        tsimk::LwBuildArgs a = j.a;
+        a.pat_begin = (int)j.next_pat;
+        a.pat_count = (int)std::min<long long>(per, (long long)a.npat - j.next_pat);
+        if (tsim_launch_lw_build(j.W, p->fast, a, j.n_out, bs) != 0 || hipStreamSynchronize(bs) != hipSuccess) { state = -1; break; }
+        j.next_pat += a.pat_count;
+        ++p->ext_slices;
+      }
+    }
+    if (state > 0) state = 2;  // built
+    else {
+      (void)hipGetLastError();
+      if (bs) (void)hipStreamSynchronize(bs);
+      for (void *q : p->ext_scratch) (void)hipFree(q);
+      p->ext_scratch.clear();
+      p->ext_jobs.clear();
+      if (tab) (void)hipFree(tab);
+      p->ext_tab = nullptr;
+    }
+  }
   p->ext_alloc.store(state, std::memory_order_release);
 }
 
@@ -254,6 +290,8 @@ int tsim_tables_extend_begin(tsim_program *p, int target_cap) {
   p->ext_recorded = false;
   p->ext_alloc.store(0, std::memory_order_release);
   if (p->ext_thread.joinable()) p->ext_thread.join();
+  p->ext_self = stage_a;  // (the helper thread drives the shallow start's build itself; later depths go out with the launch plans)
+  p->ext_abort.store(false, std::memory_order_release);
   p->ext_thread = std::thread(ext_alloc_thread, p);
   p->ext_pending = true;
   return 0;
@@ -261,7 +299,7 @@ int tsim_tables_extend_begin(tsim_program *p, int target_cap) {
 
 // the next slice of the build on stream `s`, in front of the launch the caller is about to enqueue there
 int tsim_tables_slice(tsim_program *p, hipStream_t s) {
-  if (!p->ext_pending || !p->ext_slice_due || p->ext_job >= p->ext_jobs.size()) return 0;
+  if (!p->ext_pending || p->ext_self || !p->ext_slice_due || p->ext_job >= p->ext_jobs.size()) return 0;
   p->ext_slice_due = false;
   TsimBuildJob &j = p->ext_jobs[p->ext_job];
   tsimk::LwBuildArgs a = j.a;
@@ -298,6 +336,13 @@ int tsim_tables_extend_poll(tsim_program *p, bool wait) {
     return 0;
   }
   const size_t rec_words = p->comps.size() * LW_WORDS;
+  const bool self_built = p->ext_self;
+  if (self_built && st != 2) return 0;  // (cannot happen: the thread leaves 2 or a negative state behind)
+  if (self_built) {
+    p->ext_uploaded = true;
+    p->ext_job = p->ext_jobs.size();
+    p->ext_recorded = true;
+  }
   if (!p->ext_uploaded) {  // (128 bytes per component; nothing reads the shadow records yet)
     HIP_TRY(hipMemcpy(p->d_img + p->lw_shadow_off, p->img.data() + p->lw_shadow_off, rec_words * 4, hipMemcpyHostToDevice));
     p->ext_uploaded = true;
@@ -317,7 +362,9 @@ int tsim_tables_extend_poll(tsim_program *p, bool wait) {
     }
   }
   if (!p->ext_recorded) return 0;
-  if (wait) {
+  if (self_built) {
+    // (the thread waited for its last slice)
+  } else if (wait) {
     HIP_TRY(hipEventSynchronize(p->ext_ev));
   } else if (hipEventQuery(p->ext_ev) != hipSuccess) {
     (void)hipGetLastError();

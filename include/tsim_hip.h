@@ -143,6 +143,10 @@ int tsim_program_set_pattern_tables(tsim_program *p, int32_t enable, int32_t max
  * may be NULL) */
 int tsim_program_pattern_table_info(const tsim_program *p, int32_t *enabled, int64_t *table_bytes,
                                     int32_t *max_weight);
+/* *pending = 1 while pattern tables of another depth are being built in the background (the shallow start's default
+ * depth, or a deeper one the launch plan asked for); they are put in place at a later launch.  Rates measured while
+ * this is 1 are those of the transient.  (No reference counterpart: tsim_amd's own table machinery.) */
+int tsim_program_tables_pending(const tsim_program *p, int32_t *pending);
 
 /* Packs all levels into the device image and uploads it to HIP device `device`. */
 int tsim_program_finalize(tsim_program *p, int32_t device);

@@ -66,6 +66,7 @@ SYMBOLS: dict[str, tuple] = {
     "tsim_program_get_mode": (C.c_int, [_P, C.POINTER(_I32)]),
     "tsim_program_set_pattern_tables": (C.c_int, [_P, _I32, _I32]),
     "tsim_program_pattern_table_info": (C.c_int, [_P, C.POINTER(_I32), C.POINTER(_I64), C.POINTER(_I32)]),
+    "tsim_program_tables_pending": (C.c_int, [_P, C.POINTER(_I32)]),
     "tsim_program_finalize": (C.c_int, [_P, _I32]),
     "tsim_program_destroy": (None, [_P]),
     "tsim_sample_batch": (C.c_int, [_P, _P, _I64, _I32, _U32, _U32, _I64, _P, _I32, _P]),

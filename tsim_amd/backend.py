@@ -220,7 +220,9 @@ class HipProgram:
         mw = (C.c_int32 * max(1, nc.value))()
         _lib.check(self._lib.tsim_program_pattern_table_info(self._h, C.byref(en), C.byref(tb), mw),
                    "tsim_program_pattern_table_info")
-        return dict(n_components=nc.value, num_outputs=no.value, image_bytes=ib.value,
+        pend = C.c_int32()
+        _lib.check(self._lib.tsim_program_tables_pending(self._h, C.byref(pend)), "tsim_program_tables_pending")
+        return dict(n_components=nc.value, num_outputs=no.value, image_bytes=ib.value, pattern_build_pending=bool(pend.value),
                     total_graphs=tg.value, total_rows=tr.value, fast=bool(st[0]), levels=st[1],
                     fixed_frame_levels=st[2], product_pairs=st[3], counted_rows=st[4],
                     table_bytes=st[5], graphs_d_tabled=st[6], chunk_table_kernel=((st[7] & 15) == 1), wide_sparse_kernel=((st[7] & 15) == 2),

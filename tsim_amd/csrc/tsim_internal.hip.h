@@ -167,7 +167,8 @@ struct tsim_program {
   size_t v4w_occ_lds = 0;
   bool lw_reg = false;        // the register form of pass 1 applies (narrow f rows, ascending f_selection)
   int lwfm_off = 0;           // fast record of programs with 2..4 components of <= 8 outputs each (k_sample_lw_fastm), 0 = none
-  int wr_off = 0;             // image offset of the wide record (one wide component: k_sample_wide, tsim_wide.hip.h), 0 = none
+  int wr_off = 0;             // image offset of the first wide record (k_sample_wide, tsim_wide.hip.h), 0 = none
+  std::vector<int> wr_offs;   // one wide record per component (the passes of k_sample_wide, in component order)
   int gr_off = 0;             // image offset of the gen record (any narrow program: k_sample_gen, tsim_gen.hip.h), 0 = none
   int lwf_off = 0;            // image offset of the fast record (one component of <= 8 outputs: k_sample_lw_fast), 0 = none
   // Launch slots: slot 0 serves the serial API (everything on the caller's stream); slots 1..4 serve
@@ -258,6 +259,7 @@ struct tsim_program {
                               // slower, profiles/r05/hard_tree.txt: the grid waits for the normalisation-check row either way
     bool shallow = true;      // shallow=0: finalize builds the default table depth at once (round 4) instead of starting shallow
     int gen = 1;              // gen: k_sample_gen for fused groups - 0 never, 1 where no register first pass applies, 2 wherever it applies
+    int wide_passes = 8;      // wide_passes=N: programs of up to N wide-path components run as N k_sample_wide passes (1: round-4 behaviour)
     bool wide_compact = true; // wide_compact=0: k_sample_wide keeps one 16-byte column table per graph even when all graphs fit one entry
     // fixed since round 4 (the experiments behind their switches are closed: DESIGN.md / HISTORY.md)
     bool hard_kernel = true;  // hard rows on k_sample4h, not k_sample4

@@ -232,6 +232,12 @@ extern "C" int tsim_program_pattern_table_info(const tsim_program *p, int32_t *e
     for (size_t i = 0; i < p->comps.size(); ++i) max_weight[i] = p->lw ? p->lw_wmax[i] : -1;
   return TSIM_OK;
 }
+extern "C" int tsim_program_tables_pending(const tsim_program *p, int32_t *pending) {
+  if (!p) return tsim_fail(TSIM_EINVAL, "program is NULL");
+  if (!p->finalized) return tsim_fail(TSIM_ESTATE, "program not finalized");
+  if (pending) *pending = p->ext_pending ? 1 : 0;
+  return TSIM_OK;
+}
 // launch-plan feedback buffer (mapped pinned host memory the hard-row kernels write)
 static int alloc_feedback(tsim_program *p) {
   if (p->v4 || p->lw_wide) {
@@ -283,6 +289,7 @@ extern "C" int tsim_program_finalize(tsim_program *p, int32_t device) {
     p->knobs.wide = tune_ll("wide", 1) != 0;
     p->knobs.wide_tables = tune_ll("wide_tables", 1) != 0;
     p->knobs.wide_compact = tune_ll("wide_compact", 1) != 0;
+    p->knobs.wide_passes = (int)std::max(1ll, std::min(16ll, tune_ll("wide_passes", 8)));
     p->knobs.gen = (int)std::max(0ll, std::min(2ll, tune_ll("gen", 1)));
     p->knobs.shallow = tune_ll("shallow", 1) != 0;
     p->knobs.hard_tree = tune_ll("hard_tree", 0) != 0;
@@ -696,13 +703,20 @@ retry_pack:
         // The wide record (k_sample_wide, tsim_wide.hip.h): ONE component.  Direct outputs as rotate-and-mask runs sorted by
         // destination word, constant flips per word, the placement table LUT[leaf][word] of the sampled bits (leaf = the bits
         // in sampling order, first output most significant) and the mask of the words that hold component outputs.
+        // Several components (round 5): one record per component, one k_sample_wide pass each, in stream order.  The first
+        // pass writes whole rows (direct outputs + its component); the records of the later ones carry no runs and no flips
+        // and WR_MERGE: their passes OR the component's bits into the rows in place (words are private to a row).
         p->wr_off = 0;
+        p->wr_offs.clear();
         const int wo32 = 2 * ((p->num_outputs + 63) / 64);
-        if (p->comps.size() == 1 && p->comps[0].n_out >= 1 && p->comps[0].n_out <= 8 && wo32 >= 2 && wo32 <= 8) {
-          const HostComponent &c = p->comps[0];
+        bool wide_rec_ok = !p->comps.empty() && p->comps.size() <= (size_t)p->knobs.wide_passes && wo32 >= 2 && wo32 <= 8;
+        for (auto &c : p->comps) wide_rec_ok = wide_rec_ok && c.n_out >= 1 && c.n_out <= 8;
+        for (size_t wci = 0; wide_rec_ok && wci < p->comps.size(); ++wci) {
+          const HostComponent &c = p->comps[wci];
+          const bool merge = wci > 0;
           std::vector<uint32_t> runs, runb(1, 0u), flips((size_t)wo32, 0u);
           for (int d = 0; d < wo32; ++d) {
-            for (int sw = 0; sw < 2 * TSIMK_W_SELWORDS / 2; ++sw) {
+            for (int sw = 0; !merge && sw < 2 * TSIMK_W_SELWORDS / 2; ++sw) {
               std::vector<std::array<int, 2>> m;  // (src bit, dst bit) inside the words
               for (int j = 0; j < p->n_direct; ++j) {
                 const int src = p->direct_f[j], dst = p->output_order[j];
@@ -723,10 +737,17 @@ retry_pack:
             }
             runb.push_back((uint32_t)(runs.size() / 2));
           }
-          if (runs.size() / 2 <= TSIMK_WIDE_MAX_RUNS) {
+          if (runs.size() / 2 > TSIMK_WIDE_MAX_RUNS) {
+            wide_rec_ok = false;
+            p->wr_offs.clear();
+            break;
+          }
+          {
             while (img.size() % 16) img.push_back(0u);
-            p->wr_off = (int)img.size();
+            const int wr_this = (int)img.size();
+            p->wr_offs.push_back(wr_this);
             img.resize(img.size() + WR_WORDS, 0u);
+            img[(size_t)wr_this + WR_MERGE] = merge ? 1u : 0u;
             const uint32_t runs_off = (uint32_t)img.size();
             img.insert(img.end(), runs.begin(), runs.end());
             const uint32_t runb_off = (uint32_t)img.size();
@@ -822,7 +843,7 @@ retry_pack:
                 for (auto &f : fl) img.push_back((uint32_t)f.w | ((uint32_t)f.off << 8) | ((uint32_t)f.h2 << 16) | ((uint32_t)f.nc << 24));
               }
             }
-            uint32_t *h = &img[p->wr_off];
+            uint32_t *h = &img[(size_t)wr_this];
             h[WR_NRUNS] = (uint32_t)(runs.size() / 2);
             h[WR_RUNS] = runs_off;
             h[WR_RUNB] = runb_off;
@@ -844,9 +865,9 @@ retry_pack:
               }
               uint32_t gtot = 0;
               for (auto &lv : c.levels) gtot += (uint32_t)lv.G;
-              img[p->wr_off + WR_GTOT] = gtot;
-              img[p->wr_off + WR_TT] = tt_rec;
-              img[p->wr_off + WR_TTBYTES] = tt_total * 4u;
+              img[(size_t)wr_this + WR_GTOT] = gtot;
+              img[(size_t)wr_this + WR_TT] = tt_rec;
+              img[(size_t)wr_this + WR_TTBYTES] = tt_total * 4u;
             }
             bool one = true;
             for (int d = 0; d < wo32; ++d) one = one && runb[(size_t)d + 1] - runb[(size_t)d] <= 1u;
@@ -857,10 +878,12 @@ retry_pack:
                 img.push_back(has ? runs[2 * (size_t)runb[(size_t)d]] : 0u);
                 img.push_back(has ? runs[2 * (size_t)runb[(size_t)d] + 1] : 0u);
               }
-              img[p->wr_off + WR_RUN1] = r1_off;
+              img[(size_t)wr_this + WR_RUN1] = r1_off;
             }
           }
         }
+        if (!wide_rec_ok) p->wr_offs.clear();
+        p->wr_off = p->wr_offs.empty() ? 0 : p->wr_offs[0];
       } else if (ok) {
         p->lw = true;
         // gather programs of every component's f_sel (the LDS-staged first pass)

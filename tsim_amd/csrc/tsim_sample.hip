@@ -562,10 +562,10 @@ struct WideLayout {
   size_t lds = 0;
   int l_rank, l_lut, l_runs, l_sel, l_ptrs, l_keys, l_tt, l_lvl, l_grec, l_wave, wave_bytes, w_q, w_ovf;
 };
-static WideLayout wide_layout(const tsim_program *p, int WF32) {
+static WideLayout wide_layout(const tsim_program *p, int WF32, size_t ci = 0) {
   WideLayout L;
-  const HostComponent &c = p->comps[0];
-  const uint32_t *wr = &p->img[p->wr_off];
+  const HostComponent &c = p->comps[ci];
+  const uint32_t *wr = &p->img[p->wr_offs[ci]];
   const int wo32 = (int)wr[WR_WO32];
   auto up = [](size_t v, size_t a) { return (v + a - 1) / a * a; };
   // the shared column table (one entry holds every graph's parity bits) when the packer made one and the term tables fit
@@ -620,17 +620,26 @@ static bool wide_applies(const tsim_program *p, int64_t B, int32_t num_f, int64_
   if (p->total_keys <= 0 || p->total_keys > TSIMK_LWM_KEYS || B <= 0 || B >= (1ll << 28) || p->lw_bytes >= (1ll << 32)) return false;
   if (((unsigned long long)shot_offset >> 32) != ((unsigned long long)(shot_offset + B - 1) >> 32)) return false;
   const int WF = std::max(1, (num_f + 63) / 64);
-  return WF <= 8 && wide_layout(p, 2 * WF).block != 0;
+  if (WF > 8 || p->wr_offs.size() != p->comps.size()) return false;
+  for (size_t ci = 0; ci < p->comps.size(); ++ci)
+    if (wide_layout(p, 2 * WF, ci).block == 0) return false;
+  return true;
 }
 static bool wide_buffers_ok(const tsim_program *p, const SampleArgs &a) {
   if (!a.out_compact) return true;
-  return (a.out_rb & 3) == 0 && (((uintptr_t)a.out_compact) & 3u) == 0u && a.out_rb / 4 <= 2 * ((p->num_outputs + 63) / 64);
+  return (a.out_rb + 3) / 4 <= 2 * ((p->num_outputs + 63) / 64);  // (any row size, any alignment: tsim_wide.hip.h oc_put)
 }
 
 // `args[j]`: the SampleArgs of batch j as fill_sample_args made them (buffers, inline keys)
 static int launch_wide(tsim_program *p, int n, const SampleArgs *const *args, int64_t B, int32_t num_f, int64_t shot_offset, hipStream_t s) {
   const int WF32 = 2 * std::max(1, (num_f + 63) / 64);
-  const WideLayout L = wide_layout(p, WF32);
+  if (p->wr_offs.size() != p->comps.size()) return tsim_fail(TSIM_ESTATE, "wide records missing");
+  // the statistics the launch plan follows (missed / heavy rows) come from the pass of the component with most parameters
+  size_t fb_ci = 0;
+  for (size_t ci = 1; ci < p->comps.size(); ++ci)
+    if (p->comps[ci].F > p->comps[fb_ci].F) fb_ci = ci;
+  for (size_t ci = 0; ci < p->comps.size(); ++ci) {  // one pass per component, in stream order (tsim_wide.hip.h: WR_MERGE)
+  const WideLayout L = wide_layout(p, WF32, ci);
   if (!L.block) return tsim_fail(TSIM_ESTATE, "wide kernel does not fit");
   if (p->lw_bytes >= (1ll << 32)) return tsim_fail(TSIM_ESTATE, "pattern tables of %lld bytes: k_sample_wide addresses them with 32-bit offsets", p->lw_bytes);
   if (tsim_debug("host")) {
@@ -648,12 +657,14 @@ static int launch_wide(tsim_program *p, int n, const SampleArgs *const *args, in
   W.has_check = shot_offset == 0 ? 1 : 0;
   W.out_rb = (p->num_outputs + 7) / 8;
   W.WF32 = WF32;
-  W.lw_off = p->lw_off;
-  W.comp4_off = p->comp4_off;
-  W.wr_off = p->wr_off;
+  W.lw_off = p->lw_off + (int)ci * LW_WORDS;
+  W.comp4_off = p->comp4_off + (int)ci * C4_WORDS;
+  W.wr_off = p->wr_offs[ci];
   W.binom_off = p->lw_binom_off;
   W.tab_bytes = (uint32_t)p->lw_bytes;
-  W.feedback = p->d_feedback;
+  W.feedback = ci == fb_ci ? p->d_feedback : nullptr;
+  W.merge = ci > 0 ? 1 : 0;
+  W.dev_index = (int)ci;
   W.compact = L.compact;
   W.l_rank = L.l_rank; W.l_lut = L.l_lut; W.l_runs = L.l_runs; W.l_sel = L.l_sel; W.l_ptrs = L.l_ptrs; W.l_keys = L.l_keys;
   W.l_tt = L.l_tt; W.l_lvl = L.l_lvl; W.l_grec = L.l_grec; W.l_wave = L.l_wave; W.wave_bytes = L.wave_bytes; W.w_q = L.w_q; W.w_ovf = L.w_ovf;
@@ -671,7 +682,7 @@ static int launch_wide(tsim_program *p, int n, const SampleArgs *const *args, in
   // chip-resident blocks: as many as the LDS lets a CU hold (one of 1024 threads when the program is C5-sized)
   const int per_cu = std::max(1, (int)((160 * 1024) / (L.lds + 64)));
   const long long grid = std::max(1ll, std::min((long long)p->n_cu * per_cu, (chunks + wpb - 1) / wpb));
-  const int wo32 = (int)p->img[p->wr_off + WR_WO32];
+  const int wo32 = (int)p->img[p->wr_offs[ci] + WR_WO32];
 #define TSIM_LWIDE(N)                                                                                                   \
   case N: {                                                                                                             \
     auto kfn = k_sample_wide<N, TSIMK_WIDE_K>;                                                                          \
@@ -687,6 +698,7 @@ static int launch_wide(tsim_program *p, int n, const SampleArgs *const *args, in
     default: return tsim_fail(TSIM_ESTATE, "wide record with %d output words", wo32);
   }
 #undef TSIM_LWIDE
+  }
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -1635,7 +1647,7 @@ static int steps_group_wide(tsim_program *p, int n, const uint64_t *const *d_f, 
     a = SampleArgs{};
     if (int r = fill_sample_args(p, sl, a, d_f[j], B, num_f, o[2], o[3], shot_offset, (uint64_t *)d_out[j], d_dev ? d_dev[j] : nullptr, s, sidx, packed))
       return r;
-    if (!wide_buffers_ok(p, a)) return tsim_fail(TSIM_ESTATE, "bit_packed rows of the wide kernel must be dword-aligned");
+    if (!wide_buffers_ok(p, a)) return tsim_fail(TSIM_ESTATE, "bit_packed rows wider than the wide record's output words");
     args[j] = &a;
   }
   TSIM_MARK("args");
@@ -1701,7 +1713,7 @@ extern "C" int tsim_sample_steps_device(tsim_program *p, int32_t n_steps, const 
       done += n;
       continue;
     }
-    // one wide component: groups of batches through k_sample_wide (bit_packed rows must be dwords)
+    // wide components: groups of batches through k_sample_wide, one pass per component
     LaunchPlan wide_plan;
     bool have_wide_plan = false;
     if (p->knobs.fused_steps && wide_applies(p, B, num_f, shot_offset) && p->series_left == 0) {
@@ -1711,8 +1723,7 @@ extern "C" int tsim_sample_steps_device(tsim_program *p, int32_t n_steps, const 
       const int n = (left + groups - 1) / groups;
       bool okb = true;
       if (flags & TSIM_PIPE_OUT_BIT_PACKED) {
-        okb = (((p->num_outputs + 7) / 8) & 3) == 0;
-        for (int j = 0; j < n; ++j) okb = okb && (((uintptr_t)d_out[done + j]) & 3u) == 0u;
+        okb = true;  // (rows of any size and alignment since round 5: tsim_wide.hip.h oc_put)
       } else {
         for (int j = 0; j < n; ++j) okb = okb && !p->slots[1 + (int)((p->steps_slot + (unsigned long long)j) % (unsigned long long)TSIM_PIPELINE_SLOTS)].compact_out;
       }

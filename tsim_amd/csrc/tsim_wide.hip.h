@@ -46,6 +46,7 @@ enum {
   WR_RUN1,        // image offset of WO32 x (ctl, mask) when every destination word has at most one run (mask 0: none), else 0
   WR_CCOL,        // image offset of the shared column table (F + 33 entries of 16 bytes: every graph's parity bits in one entry), 0: none
   WR_CREC,        // image offset of one word per graph: word of the entry | first bit << 8 | product pairs << 16 | counted rows << 24
+  WR_MERGE,       // 1: a later component's pass - no direct outputs, the component's bits are ORed into the rows the first pass wrote
   WR_WORDS = 16
 };
 #define TSIMK_WIDE_K 12        // set bits per row the dense pass takes
@@ -55,8 +56,8 @@ enum {
 struct WideStep {
   const uint64_t *f;      // [B, WF] packed error-mechanism rows of this batch
   uint64_t *out;          // [B, WO] padded output rows, or nullptr
-  uint8_t *out_compact;   // [B, out_rb] bit_packed rows (out_rb a multiple of 4, 4-byte aligned), or nullptr
-  float *norm_dev;        // [1] or nullptr
+  uint8_t *out_compact;   // [B, out_rb] bit_packed rows (any out_rb, any alignment), or nullptr
+  float *norm_dev;        // [n_components] or nullptr (pass ci writes entry ci)
   uint32_t keys[2 * TSIMK_LWM_KEYS];  // per-output subkeys of this batch (sampler.py:74,147-148), host-computed
 };
 
@@ -71,6 +72,8 @@ struct WideArgs {
   uint32_t tab_bytes;
   uint32_t *feedback;       // optional (mapped host memory): [4] rows with more than K set bits, [5] rows the tables missed, [6] rows - estimates from block 0
   // LDS layout in bytes, computed by the launcher (tsim_sample.hip: wide_layout)
+  int merge;        // 1: a later component's pass (WR_MERGE): rows are completed in place
+  int dev_index;    // the component's slot in norm_dev[]
   int compact;      // 1: LDS holds the shared column table (WR_CCOL) instead of one table per graph; needs l_tt >= 0
   int l_rank, l_lut, l_runs, l_sel, l_ptrs, l_keys, l_tt, l_lvl, l_grec, l_wave, wave_bytes, w_q, w_ovf;  // l_tt < 0: the term tables stay in the image
   WideStep step[TSIMK_LWM_MAX_STEPS];
@@ -285,6 +288,24 @@ __global__ void __launch_bounds__(1024) k_sample_wide(WideArgs A) {
       o[d] = acc;
     }
   };
+  // word d of a bit_packed row of out_rb bytes (any out_rb since round 5: rows of 9 bytes start at odd addresses): a dword
+  // access at the row's own byte offset - gfx950 takes unaligned global dwords - or, for the row's last 1..3 bytes, bytes.
+  // Every byte touched belongs to this row.
+  typedef __attribute__((address_space(1))) uint8_t gu8;
+  typedef uint32_t u32_una __attribute__((aligned(1)));
+  typedef __attribute__((address_space(1))) u32_una gu32_una;
+  const uint32_t out_rb = (uint32_t)A.out_rb;
+  auto oc_put = [&](gu8 *rowp, uint32_t d, uint32_t v, bool merge) {
+    if (4u * d + 4u <= out_rb) {
+      gu32_una *q = (gu32_una *)(rowp + 4u * d);
+      *q = merge ? (*q | v) : v;
+    } else {
+      for (uint32_t b = 4u * d; b < out_rb; ++b) {
+        const uint8_t x = (uint8_t)(v >> (8u * (b - 4u * d)));
+        rowp[b] = merge ? (uint8_t)(rowp[b] | x) : x;
+      }
+    }
+  };
   // a row's words -> HBM (every word of the padded row / the whole bit_packed row: dword stores)
   auto store_row = [&](uint32_t st_lo_out, uint32_t st_hi_out, uint32_t st_lo_oc, uint32_t st_hi_oc, uint32_t row, const uint32_t (&o)[WO32]) {
     gu32 *out = (gu32 *)(uintptr_t)(((uint64_t)st_hi_out << 32) | st_lo_out);
@@ -298,15 +319,27 @@ __global__ void __launch_bounds__(1024) k_sample_wide(WideArgs A) {
       }
     }
     if (oc) {
-      const uint32_t nd = (uint32_t)A.out_rb >> 2;
-      gu32 *dst = oc + (size_t)row * nd;
-      if (WO32 == 4 && nd == 4u && (((uintptr_t)oc) & 15u) == 0u) *(gu32x4 *)dst = u32x4{o[0], o[1], o[2], o[WO32 > 3 ? 3 : 0]};
+      if (WO32 == 4 && out_rb == 16u && (((uintptr_t)oc) & 15u) == 0u) *(gu32x4 *)(oc + (size_t)row * 4u) = u32x4{o[0], o[1], o[2], o[WO32 > 3 ? 3 : 0]};
       else {
+        gu8 *rowp = (gu8 *)oc + (size_t)row * out_rb;
 #pragma unroll
         for (int d = 0; d < WO32; ++d)
-          if ((uint32_t)d < nd) dst[d] = o[d];
+          if (4u * (uint32_t)d < out_rb) oc_put(rowp, (uint32_t)d, o[d], false);
       }
     }
+  };
+
+  // a later component's pass (A.merge): OR this component's bits into the words of the row that hold them - the row is in
+  // HBM since the first pass, nothing else touches it in this grid (oc_put touches the row's own bytes only)
+  auto merge_row = [&](uint32_t st_lo_out, uint32_t st_hi_out, uint32_t st_lo_oc, uint32_t st_hi_oc, uint32_t row, const uint32_t (&o)[WO32]) {
+    gu32 *out = (gu32 *)(uintptr_t)(((uint64_t)st_hi_out << 32) | st_lo_out);
+    gu32 *oc = (gu32 *)(uintptr_t)(((uint64_t)st_hi_oc << 32) | st_lo_oc);
+#pragma unroll
+    for (int d = 0; d < WO32; ++d)
+      if (((lutmask >> d) & 1u) && o[d] != 0u) {
+        if (out) out[(size_t)row * WO32 + d] |= o[d];
+        if (oc && 4u * (uint32_t)d < out_rb) oc_put((gu8 *)oc + (size_t)row * out_rb, (uint32_t)d, o[d], true);
+      }
   };
 
   // shared column table: graph field `cf` (WR_CREC) of the entry-sized parity word yl -> the four words acc_graph4 takes
@@ -449,15 +482,21 @@ __global__ void __launch_bounds__(1024) k_sample_wide(WideArgs A) {
       const u32x4 pt = *reinterpret_cast<const u32x4 *>(&l_ptrs[4u * st]);
       gu32 *out = (gu32 *)(uintptr_t)(((uint64_t)pt.y << 32) | pt.x);
       gu32 *oc = (gu32 *)(uintptr_t)(((uint64_t)pt.w << 32) | pt.z);
-      const uint32_t nd = (uint32_t)A.out_rb >> 2;
       uint32_t cwi = 0;
 #pragma unroll
       for (int d = 0; d < WO32; ++d)
         if ((lutmask >> d) & 1u) {
           const uint32_t v = w_q[(4u + n_out + cwi) * QCAP + slot] | l_lut[leaf * (uint32_t)WO32 + (uint32_t)d];
           ++cwi;
-          if (out) out[(size_t)row * WO32 + d] = v;
-          if (oc && (uint32_t)d < nd) oc[(size_t)row * nd + d] = v;
+          if (A.merge) {  // (the queue word is 0: the first pass wrote the direct bits)
+            if (v != 0u) {
+              if (out) out[(size_t)row * WO32 + d] |= v;
+              if (oc && 4u * (uint32_t)d < out_rb) oc_put((gu8 *)oc + (size_t)row * out_rb, (uint32_t)d, v, true);
+            }
+          } else {
+            if (out) out[(size_t)row * WO32 + d] = v;
+            if (oc && 4u * (uint32_t)d < out_rb) oc_put((gu8 *)oc + (size_t)row * out_rb, (uint32_t)d, v, false);
+          }
         }
     }
     WT_MARK(16);
@@ -558,13 +597,14 @@ __global__ void __launch_bounds__(1024) k_sample_wide(WideArgs A) {
     }
     if (check) {
       float *nd = steps[check_step].norm_dev;
-      if (lane == 0u && nd) nd[0] = maxdev;
+      if (lane == 0u && nd) nd[A.dev_index] = maxdev;  // one deviation per component (include/tsim_hip.h: max_norm_dev[n_components])
     } else {
       if (on) {
 #pragma unroll
         for (int d = 0; d < WO32; ++d) o[d] |= l_lut[leaf * (uint32_t)WO32 + (uint32_t)d];
         const u32x4 pt = *reinterpret_cast<const u32x4 *>(&l_ptrs[4u * st]);
-        store_row(pt.x, pt.y, pt.z, pt.w, row, o);
+        if (A.merge) merge_row(pt.x, pt.y, pt.z, pt.w, row, o);
+        else store_row(pt.x, pt.y, pt.z, pt.w, row, o);
       }
       ohead += n;
     }
@@ -752,7 +792,10 @@ __global__ void __launch_bounds__(1024) k_sample_wide(WideArgs A) {
     // instructions per 8 x 10^6 shots, 46.6 -> 46.0 us.  The HBM-side write traffic stays 27 B per shot for 16: the word the
     // dense pass rewrites later leaves the L2 a second time as a 32-byte request; writing a missed row ONCE needs its direct
     // words in the queue - 24 KB of LDS the block does not have)
-    if ((hit || miss) && !(TSIMK_WIDE_SKIP & 32)) store_row((uint32_t)(uintptr_t)S->out, (uint32_t)((uint64_t)(uintptr_t)S->out >> 32), (uint32_t)(uintptr_t)S->out_compact,
+    if (A.merge) {  // a later component's pass: a tabulated row with sampled ones is completed in place; nothing else is touched here
+      if (hit && leaf != 0u) merge_row((uint32_t)(uintptr_t)S->out, (uint32_t)((uint64_t)(uintptr_t)S->out >> 32), (uint32_t)(uintptr_t)S->out_compact,
+                                       (uint32_t)((uint64_t)(uintptr_t)S->out_compact >> 32), row, o);
+    } else if ((hit || miss) && !(TSIMK_WIDE_SKIP & 32)) store_row((uint32_t)(uintptr_t)S->out, (uint32_t)((uint64_t)(uintptr_t)S->out >> 32), (uint32_t)(uintptr_t)S->out_compact,
                                                             (uint32_t)((uint64_t)(uintptr_t)S->out_compact >> 32), row, o);
     // ---- missed rows -> the queue (position list + draws); heavy rows -> their ring
     {

@@ -43,7 +43,7 @@ def device_f(backend, hp, num_f, p_bit, B, WF, count, seed):
     return bufs
 
 
-def measure(backend, program, num_f, p_bit, shots, steps_n, nf=12, repeats=3, check=False):
+def measure(backend, program, num_f, p_bit, shots, steps_n, nf=12, repeats=3, check=False, shot_offset=0):
     hp = backend.HipProgram(program)
     n_out = program.num_outputs
     WF, WO, RB = max(1, (num_f + 63) // 64), (n_out + 63) // 64, (n_out + 7) // 8
@@ -55,7 +55,7 @@ def measure(backend, program, num_f, p_bit, shots, steps_n, nf=12, repeats=3, ch
 
     def go(k):
         hp.sample_steps_device([fl[(j[0] + i) % nf].ptr for i in range(k)], shots, num_f, ks, [outs[(j[0] + i) % nslot].ptr for i in range(k)],
-                               inputs_ready=True, out_bit_packed=True)
+                               inputs_ready=True, out_bit_packed=True, shot_offset=shot_offset)
         j[0] += k
 
     for _ in range(4):  # launch-plan feedback
@@ -113,6 +113,7 @@ def main():
     ap.add_argument("--check", action="store_true")
     ap.add_argument("--out", default="")
     ap.add_argument("--no-base", action="store_true", help="skip the BASELINE configurations (profiling one class)")
+    ap.add_argument("--shot-offset", type=int, default=0, help="diagnostic: a shard that does not hold shot 0 runs no normalisation check")
     a = ap.parse_args()
     from tsim_amd import backend, synth
 
@@ -136,7 +137,7 @@ def main():
     for n in names:
         prog, c = synth.shape_class_program(n)
         try:
-            r = measure(backend, prog, c["num_f"], c["p_bit"], a.shots, a.steps, check=a.check)
+            r = measure(backend, prog, c["num_f"], c["p_bit"], a.shots, a.steps, check=a.check, shot_offset=a.shot_offset)
         except Exception as e:  # a class the library refuses is a cliff of its own
             emit(f"{n:14s} FAILED: {e}")
             continue

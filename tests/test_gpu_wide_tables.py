@@ -46,7 +46,11 @@ def test_depth_on_demand_and_bits_do_not_change(hip, deepen, monkeypatch):
     orc = OC.OracleProgram(prog)
     if deepen:
         monkeypatch.setenv("TSIM_AMD_DEEP_TABLES", "1")
+    # (round 5: weight 4 is the DEFAULT depth of a wide component, built in the background behind a weight-3 start -
+    # test_default_depth_arrives_in_the_background below; `wide_depth=3` keeps the on-demand rule this test is about)
+    monkeypatch.setenv("TSIM_AMD_TUNE", "wide_depth=3")
     hp = hip.HipProgram(prog)
+    monkeypatch.delenv("TSIM_AMD_TUNE")
     assert hp.info()["pattern_tables"] and hp.info()["pattern_max_weight"] == [3]
     B = 20_000
     with warnings.catch_warnings():
@@ -62,6 +66,36 @@ def test_depth_on_demand_and_bits_do_not_change(hip, deepen, monkeypatch):
             f = synth.synth_f(B, cfg["num_f"], 0.003, seed=400 + i)
             got, _ = hp.sample_batch(f, (i, 3), shot_offset=7 * i)
             np.testing.assert_array_equal(got, orc.sample_program(f, (i, 3), shot_offset=7 * i))
+    hp.close()
+
+
+def test_default_depth_arrives_in_the_background(hip):
+    """A fresh handle of a wide program samples with the weight-3 tables finalize built while the helper thread builds weight 4
+    (2.1 GB for C5); the swap happens at a later launch; the bits are the oracle's before, during and after."""
+    import time
+
+    prog, cfg = synth.config_program("C5")
+    orc = OC.OracleProgram(prog)
+    hp = hip.HipProgram(prog)
+    depths = set()
+    t0 = time.perf_counter()
+    i = 0
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        while True:
+            info = hp.info()
+            depths.add(tuple(info["pattern_max_weight"]))
+            settled = not info["pattern_build_pending"]
+            f = synth.synth_f(6000, cfg["num_f"], cfg["p_bit"], seed=700 + i)
+            want, wdev = orc.sample_program(f, (i, 5), return_devs=True)
+            got, gdev = hp.sample_batch(f, (i, 5))
+            np.testing.assert_array_equal(got, want, err_msg=f"call {i}, depth {info['pattern_max_weight']}")
+            np.testing.assert_array_equal(np.asarray(gdev, np.float32), np.asarray(wdev, np.float32))
+            i += 1
+            if (settled and i >= 3) or time.perf_counter() - t0 > 30.0:
+                break
+    assert hp.info()["pattern_max_weight"] == [4] and not hp.info()["pattern_build_pending"], (depths, hp.info())
+    assert hp.info()["pattern_table_bytes"] > 1 << 30
     hp.close()
 
 

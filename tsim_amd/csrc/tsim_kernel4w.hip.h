@@ -78,6 +78,33 @@ __device__ __forceinline__ void eval_level4_resident(const uint32_t *gimg, cptr 
   acc_finish4<FIXED>(S, lvl, approx, out_re, out_im);
 }
 
+// The same level with the column tables where the packer put them - in the program image (HBM, in practice the L2):
+// components whose tables do not fit the LDS (many graphs: 140 graphs x 93 entries are 208 KB).  k_sample_wide<.., GLOB>.
+template <int NR, bool FIXED>
+__device__ __forceinline__ void eval_level4_global(const uint32_t *gimg, cptr img, cptr lvl, const uint32_t (&e)[NR], uint32_t ent_bytes,
+                                                   float &out_re, float &out_im) {
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  typedef const __attribute__((address_space(1))) u32x4 *glb_u4p;
+  typedef const __attribute__((address_space(1))) uint8_t *glb_u8p;
+  const uint32_t G = lvl[L4_G];
+  const bool approx = (lvl[L4_FLAGS] & TSIMK_LFLAG_APPROX) != 0;
+  cptr recs = img + lvl[L4_RECS];
+  glb_u8p tab = (glb_u8p)(uintptr_t)(gimg + lvl[L4_STAB]);
+  Acc4 S;
+  for (uint32_t g = 0; g < G; ++g) {
+    glb_u8p base = tab + (size_t)g * ent_bytes;
+    uint32_t U = 0, V = 0, O1 = 0, O2 = 0;
+#pragma unroll
+    for (int c = 0; c < NR; c += 2) {
+      const u32x4 v = *(glb_u4p)(base + e[c]);
+      const u32x4 w = *(glb_u4p)(base + e[c + 1]);
+      U = xor3(U, v.x, w.x); V = xor3(V, v.y, w.y); O1 = xor3(O1, v.z, w.z); O2 = xor3(O2, v.w, w.w);
+    }
+    acc_graph4<FIXED, false>(S, gimg, recs + g * G4_WORDS, U, V, O1, O2, approx, 0u);
+  }
+  acc_finish4<FIXED>(S, lvl, approx, out_re, out_im);
+}
+
 // GT is 1 in the wide layout: one graph per tile, a level's tables are G consecutive (F + 33) x 16-byte blocks.
 template <int GT, int K>
 __global__ void __launch_bounds__(256) k_sample4w(Wide4Args W) {

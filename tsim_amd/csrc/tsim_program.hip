@@ -289,6 +289,8 @@ extern "C" int tsim_program_finalize(tsim_program *p, int32_t device) {
     p->knobs.wide = tune_ll("wide", 1) != 0;
     p->knobs.wide_tables = tune_ll("wide_tables", 1) != 0;
     p->knobs.wide_compact = tune_ll("wide_compact", 1) != 0;
+    p->knobs.wide_depth = (int)std::max(0ll, std::min(4ll, tune_ll("wide_depth", 4)));
+    p->knobs.wide_glob = (int)std::max(0ll, tune_ll("wide_glob", 48));
     p->knobs.wide_passes = (int)std::max(1ll, std::min(16ll, tune_ll("wide_passes", 8)));
     p->knobs.gen = (int)std::max(0ll, std::min(2ll, tune_ll("gen", 1)));
     p->knobs.shallow = tune_ll("shallow", 1) != 0;
@@ -643,7 +645,10 @@ retry_pack:
       const bool pinned = p->lw_weight_cap >= 0;
       const int hw_cap = p->lw_wide ? TSIMK_LWW_MAX_WEIGHT : TSIMK_LW_MAX_WEIGHT;
       p->lw_cap_max = pinned ? std::min(p->lw_weight_cap, hw_cap) : hw_cap;
-      p->lw_cap_default = pinned ? p->lw_cap_max : std::min(p->lw_wide ? 3 : 5, p->lw_cap_max);
+      // (wide components: weight 4 since round 5 - C5's 2.1 GB lift the tabulated share of its rows from 43 % to 63 %, 46 -> 41 us
+      // per 10^6 shots; finalize still builds weight 3 only, the rest follows in the background like every default depth.
+      // `wide_depth=3` keeps the round-4 default: the deeper table then waits for deep_after rows as before)
+      p->lw_cap_default = pinned ? p->lw_cap_max : std::min(p->lw_wide ? p->knobs.wide_depth : 5, p->lw_cap_max);
       p->lw_cap_now = p->lw_cap_default;
       p->lw_budget = 4096ll << 20;  // per component: HBM is 288 GB, and only the prefix is hot (C3's weight-6 table is 1.8 GB)
       // wide components: C(200, 4) patterns of 8 thresholds are 2.1 GB - what lifts the tabulated share of C5's
@@ -669,8 +674,8 @@ retry_pack:
       // build) pays only from ~10^8 rows on.  Finalize builds the deepest tables that cost about half a millisecond (table
       // entries x graphs per level <= 1.2e8: C2 depth 4, C3 and C4 depth 3 - at depth 2 C4 sampled 10^8 shots in 75 ms, 4.6 % of its rows hard); the default depth follows in the background, slice by slice
       // next to the first launches (tsim_tables_extend_begin below, tsim_tables.hip).  A caller who named a depth gets it here.
-      if (!pinned && p->knobs.shallow && p->knobs.deep_tables <= 0 && !p->lw_wide) {
-        while (p->lw_cap_now > 2) {
+      if (!pinned && p->knobs.shallow && p->knobs.deep_tables <= 0) {
+        while (p->lw_cap_now > (p->lw_wide ? 3 : 2)) {
           TsimTablePlan t;
           std::vector<uint32_t> keep(img.begin() + p->lw_off, img.begin() + p->lw_off + (long)(p->comps.size() * LW_WORDS));
           double cost = 0;

@@ -559,6 +559,7 @@ static int fill_sample_args(tsim_program *p, tsim_program::Slot &sl, SampleArgs 
 struct WideLayout {
   int block = 0;       // threads per block (0: the program does not fit)
   int compact = 0;     // 1: the shared column table (WR_CCOL)
+  int glob = 0;        // 1: the column tables stay in the image (k_sample_wide<.., GLOB>): they do not fit the LDS
   size_t lds = 0;
   int l_rank, l_lut, l_runs, l_sel, l_ptrs, l_keys, l_tt, l_lvl, l_grec, l_wave, wave_bytes, w_q, w_ovf;
 };
@@ -570,8 +571,12 @@ static WideLayout wide_layout(const tsim_program *p, int WF32, size_t ci = 0) {
   auto up = [](size_t v, size_t a) { return (v + a - 1) / a * a; };
   // the shared column table (one entry holds every graph's parity bits) when the packer made one and the term tables fit
   // beside it; else one table per graph
-  for (int compact = wr[WR_CCOL] != 0u ? 1 : 0; compact >= 0 && !L.block; --compact) {
-    size_t off = compact ? (size_t)(c.F + 33) * 16 : up(wr[WR_COLBYTES], 16);
+  // (third choice, compact = -1: no column table in LDS at all - components with many graphs, round 5)
+  // - up to knobs.wide_glob graphs: a dense pass walks the graphs one after the other, ~2.5 us each from the L2 (F60 class, 140
+  // graphs: 300-400 us per pass, 77 us per 10^6 shots against 59 on the round-2 kernels - profiles/r05/wide_glob.txt)
+  const int min_mode = (int)wr[WR_GTOT] <= p->knobs.wide_glob ? -1 : 0;
+  for (int compact = wr[WR_CCOL] != 0u ? 1 : 0; compact >= min_mode && !L.block; --compact) {
+    size_t off = compact > 0 ? (size_t)(c.F + 33) * 16 : compact == 0 ? up(wr[WR_COLBYTES], 16) : 0;
     L.l_rank = (int)off;  off += (size_t)4 * (c.F + 1) * 4;
     off = up(off, 16);
     L.l_lut = (int)off;   off += ((size_t)wo32 << c.n_out) * 4;
@@ -591,15 +596,17 @@ static WideLayout wide_layout(const tsim_program *p, int WF32, size_t ci = 0) {
     // (+ the level table and the graph records: 16 bytes per level, 64 per graph)
     const size_t tt_only = up(wr[WR_TTBYTES], 16);
     const size_t tt_bytes = tt_only + 16 * (size_t)(c.n_out + 1) + 64 * (size_t)wr[WR_GTOT];
-    for (int with_tt = 1; with_tt >= (compact ? 1 : 0) && !L.block; --with_tt) {
+    for (int with_tt = compact < 0 ? 0 : 1; with_tt >= (compact > 0 ? 1 : 0) && !L.block; --with_tt) {
       if (with_tt && tt_only == 0) continue;
       off = fixed_end + (with_tt ? tt_bytes : 0);
       for (int blk : {1024, 512, 256}) {  // 16 waves per CU when everything fits beside the tables, fewer otherwise
         if (with_tt && blk != 1024) break;
+        if (compact == 0 && blk < 512) break;  // (rather the tables in the L2 and 16 waves than 4 waves beside them)
         const size_t tot = off + (size_t)(blk / 64) * L.wave_bytes + 64;  // + the kernel's static words
         if (tot <= 160 * 1024) {
           L.block = blk;
-          L.compact = compact;
+          L.compact = compact > 0 ? 1 : 0;
+          L.glob = compact < 0 ? 1 : 0;
           L.l_tt = with_tt ? (int)fixed_end : -1;
           L.l_lvl = (int)(fixed_end + tt_only);
           L.l_grec = L.l_lvl + 16 * (c.n_out + 1);
@@ -617,7 +624,9 @@ static WideLayout wide_layout(const tsim_program *p, int WF32, size_t ci = 0) {
 // not cross a multiple of 2^32; bit_packed rows are written and merged as dwords)
 static bool wide_applies(const tsim_program *p, int64_t B, int32_t num_f, int64_t shot_offset) {
   if (!(p->lw && p->lw_wide && p->wr_off != 0 && p->knobs.wide_fused && p->knobs.wide)) return false;
-  if (p->total_keys <= 0 || p->total_keys > TSIMK_LWM_KEYS || B <= 0 || B >= (1ll << 28) || p->lw_bytes >= (1ll << 32)) return false;
+  if (p->total_keys <= 0 || p->total_keys > TSIMK_LWM_KEYS || B <= 0 || B >= (1ll << 28)) return false;
+  for (size_t ci = 0; ci < p->comps.size() && ci < p->lw_npat.size(); ++ci)  // 32-bit byte offsets inside a component's table
+    if (((p->lw_npat[ci] << p->comps[ci].n_out) * 4) >= (1ll << 32)) return false;
   if (((unsigned long long)shot_offset >> 32) != ((unsigned long long)(shot_offset + B - 1) >> 32)) return false;
   const int WF = std::max(1, (num_f + 63) / 64);
   if (WF > 8 || p->wr_offs.size() != p->comps.size()) return false;
@@ -641,15 +650,16 @@ static int launch_wide(tsim_program *p, int n, const SampleArgs *const *args, in
   for (size_t ci = 0; ci < p->comps.size(); ++ci) {  // one pass per component, in stream order (tsim_wide.hip.h: WR_MERGE)
   const WideLayout L = wide_layout(p, WF32, ci);
   if (!L.block) return tsim_fail(TSIM_ESTATE, "wide kernel does not fit");
-  if (p->lw_bytes >= (1ll << 32)) return tsim_fail(TSIM_ESTATE, "pattern tables of %lld bytes: k_sample_wide addresses them with 32-bit offsets", p->lw_bytes);
+  const long long comp_tab_bytes = (p->lw_npat[ci] << p->comps[ci].n_out) * 4;
+  if (comp_tab_bytes >= (1ll << 32)) return tsim_fail(TSIM_ESTATE, "pattern table of %lld bytes: k_sample_wide addresses a component's table with 32-bit offsets", comp_tab_bytes);
   if (tsim_debug("host")) {
     static bool said = false;
-    if (!said) fprintf(stderr, "[tsim] k_sample_wide: block %d, LDS %zu bytes (per wave %d), shared column table %d, term tables in LDS %d\n", L.block, L.lds, L.wave_bytes, L.compact, L.l_tt >= 0 ? 1 : 0);
+    if (!said) fprintf(stderr, "[tsim] k_sample_wide: block %d, LDS %zu bytes (per wave %d), shared column table %d, term tables in LDS %d, column tables in the image %d\n", L.block, L.lds, L.wave_bytes, L.compact, L.l_tt >= 0 ? 1 : 0, L.glob);
     said = true;
   }
   WideArgs W{};
   W.img = p->d_img;
-  W.tab = p->d_lw_tab;
+  W.tab = p->d_lw_tab + p->img[(size_t)p->lw_off + ci * LW_WORDS + LW_TAB];
   W.B = B;
   W.shot_offset = shot_offset;
   W.n_steps = n;
@@ -661,7 +671,7 @@ static int launch_wide(tsim_program *p, int n, const SampleArgs *const *args, in
   W.comp4_off = p->comp4_off + (int)ci * C4_WORDS;
   W.wr_off = p->wr_offs[ci];
   W.binom_off = p->lw_binom_off;
-  W.tab_bytes = (uint32_t)p->lw_bytes;
+  W.tab_bytes = (uint32_t)comp_tab_bytes;
   W.feedback = ci == fb_ci ? p->d_feedback : nullptr;
   W.merge = ci > 0 ? 1 : 0;
   W.dev_index = (int)ci;
@@ -685,10 +695,11 @@ static int launch_wide(tsim_program *p, int n, const SampleArgs *const *args, in
   const int wo32 = (int)p->img[p->wr_offs[ci] + WR_WO32];
 #define TSIM_LWIDE(N)                                                                                                   \
   case N: {                                                                                                             \
-    auto kfn = k_sample_wide<N, TSIMK_WIDE_K>;                                                                          \
-    if (!(p->wide_attr_set & (1u << N))) { /* per handle: the attribute is per device */                   \
+    auto kfn = L.glob ? k_sample_wide<N, TSIMK_WIDE_K, true> : k_sample_wide<N, TSIMK_WIDE_K, false>;                   \
+    const unsigned abit = 1u << (N + (L.glob ? 16 : 0));                                                                \
+    if (!(p->wide_attr_set & abit)) { /* per handle: the attribute is per device */                        \
       HIP_TRY(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));     \
-      p->wide_attr_set |= 1u << N;                                                                                      \
+      p->wide_attr_set |= abit;                                                                                         \
     }                                                                                                                   \
     ++p->path_count[TP_WIDE];                                                                                           \
     hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(L.block), L.lds, s, W);                                          \

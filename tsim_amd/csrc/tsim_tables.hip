@@ -45,7 +45,8 @@ bool tsim_tables_plan_at(tsim_program *p, int cap, long long budget, int rec_off
       if (((npat + cnt) << c.n_out) + tab_off >= (1ll << 32)) break;              // float offsets are 32-bit
       // one wide component (k_sample_wide): byte offsets into the table are 32-bit there - a deeper table of 4 GiB or more would
       // push the program off that kernel for good
-      if (p->lw_wide && p->comps.size() == 1 && tab_off * 4 + bytes >= (1ll << 32)) break;
+      // (per component since round 5: every pass of k_sample_wide gets its component's table as its base)
+      if (p->lw_wide && bytes >= (1ll << 32)) break;
       bases[w] = (uint32_t)npat;
       npat += cnt;
       wmax = w;

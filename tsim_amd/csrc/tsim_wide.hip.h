@@ -63,7 +63,7 @@ struct WideStep {
 
 struct WideArgs {
   const uint32_t *img;
-  const uint32_t *tab;      // integer thresholds (bernoulli_threshold) of the component
+  const uint32_t *tab;      // integer thresholds (bernoulli_threshold) of THIS pass's component (its LW_TAB offset applied by the launcher)
   long long B;              // rows per batch (< 2^28)
   long long shot_offset;    // in-batch index of row 0, the same for every batch of the group
   int n_steps, chunks_per_step;
@@ -120,7 +120,10 @@ struct GrecV {
 #define TSIMK_WIDE_STAGE 0   // 1: the next chunk is staged AFTER the dense passes; 2: staged through registers instead of LDS-DMA
 #endif
 
-template <int WO32, int K>
+// GLOB: the column tables stay in the program image (the L2) - components with too many graphs for the LDS; the dense and
+// generic passes read them there, everything else is the same kernel (an instantiation of its own: the register
+// allocation of the resident form, 4 waves per SIMD for C5, is not touched)
+template <int WO32, int K, bool GLOB = false>
 __global__ void __launch_bounds__(1024) k_sample_wide(WideArgs A) {
   typedef const __attribute__((address_space(4))) uint8_t *cbytes;
   typedef const __attribute__((address_space(4))) WideStep *cstep;
@@ -157,9 +160,9 @@ __global__ void __launch_bounds__(1024) k_sample_wide(WideArgs A) {
   const uint32_t n_runs = wr[WR_NRUNS];
   {
     uint32_t off = 0;
-    if (A.compact) {  // the shared column table: every graph's parity bits in one 16-byte entry per column
+    if (!GLOB && A.compact) {  // the shared column table: every graph's parity bits in one 16-byte entry per column
       tile_copy(reinterpret_cast<const uint4 *>(A.img + wr[WR_CCOL]), lds8, F + 33u, threadIdx.x, nthr);
-    } else {
+    } else if (!GLOB) {
       for (uint32_t li = 0; li <= n_out; ++li) {  // the column tables of every level: one burst of LDS-DMA
         cptr lvl = levels + li * L4_WORDS;
         const uint32_t bytes = lvl[L4_G] * ent_bytes;
@@ -167,7 +170,7 @@ __global__ void __launch_bounds__(1024) k_sample_wide(WideArgs A) {
         off += bytes;
       }
     }
-    if (A.l_tt >= 0) {  // the term tables of every level behind each other
+    if (!GLOB && A.l_tt >= 0) {  // the term tables of every level behind each other
       uint32_t toff = 0;
       for (uint32_t li = 0; li <= n_out; ++li) {
         const uint32_t src = img[wr[WR_TT] + 2u * li], words = img[wr[WR_TT] + 2u * li + 1u];
@@ -175,7 +178,7 @@ __global__ void __launch_bounds__(1024) k_sample_wide(WideArgs A) {
         toff += words * 4u;
       }
     }
-    if (A.l_tt >= 0) {
+    if (!GLOB && A.l_tt >= 0) {
       // ... and, with them, the level table (G, flags, frame power, first graph) and the graph records, their table offsets
       // turned into LDS word addresses: a dense pass then reads nothing but LDS until it stores its rows
       uint32_t g0 = 0, toff = 0;
@@ -194,7 +197,7 @@ __global__ void __launch_bounds__(1024) k_sample_wide(WideArgs A) {
           uint32_t v = A.img[recs + i];
           const uint32_t k = i % (uint32_t)G4_WORDS;
           if (k == (uint32_t)G4_TBL || (k == (uint32_t)G4_TBL2 && v != 0u)) v = tt_word0 + (toff >> 2) + (v - src);
-          if (k == (uint32_t)G4_CFIELD && A.compact) v = A.img[wr[WR_CREC] + g0 + i / (uint32_t)G4_WORDS];
+          if (k == (uint32_t)G4_CFIELD && !GLOB && A.compact) v = A.img[wr[WR_CREC] + g0 + i / (uint32_t)G4_WORDS];
           l_grec[g0 * (uint32_t)G4_WORDS + i] = v;
         }
         g0 += G;
@@ -232,7 +235,7 @@ __global__ void __launch_bounds__(1024) k_sample_wide(WideArgs A) {
   uint32_t n_missed = 0, n_heavy = 0;
 
   const uint32_t wmax = rec[LW_WMAX];
-  const uint32_t tab_byte = rec[LW_TAB] * 4u;
+  const uint32_t tab_byte = 0u;  // (A.tab is the COMPONENT's table since round 5: offsets below 4 GiB per component, not per program)
   const uint32_t keybase = rec[LW_KEYBASE];
   const uint32_t lutmask = wr[WR_LUTMASK];
   const __amdgpu_buffer_rsrc_t r_tab = __builtin_amdgcn_make_buffer_rsrc((void *)A.tab, 0, A.tab_bytes, 0x00020000);
@@ -380,7 +383,7 @@ __global__ void __launch_bounds__(1024) k_sample_wide(WideArgs A) {
     uint32_t mb = 0, leaf = 0, lvl_off = 0, tt_lds = 0;
     float prev = 0.0f;
     u32x4 yf = {0u, 0u, 0u, 0u};  // shared column table: the f part of every graph's parity words, once per pass
-    if (A.compact) {
+    if (!GLOB && A.compact) {
 #pragma unroll
       for (int c = 0; c < K / 2; ++c)
         if ((need >> c) & 1u) {
@@ -397,7 +400,7 @@ __global__ void __launch_bounds__(1024) k_sample_wide(WideArgs A) {
       if (li > 0) mb |= 1u << (li - 1u);  // trial bit 1 (sampler.py:65)
       const uint32_t e_lo = (F + 1u + (mb & 15u)) * 16u, e_hi = (F + 17u + ((mb >> 4) & 15u)) * 16u;
       float re, im;
-      if (A.l_tt >= 0) {
+      if (!GLOB && A.l_tt >= 0) {
         // everything of the level from LDS: its record, the graph records, the column entries, the term tables
         const u32x4 lv = *reinterpret_cast<const u32x4 *>(&tsimk_lds[(A.l_lvl >> 2) + 4u * li]);
         const uint32_t G = (uint32_t)__builtin_amdgcn_readfirstlane((int)lv.x), flags = (uint32_t)__builtin_amdgcn_readfirstlane((int)lv.y);
@@ -406,7 +409,7 @@ __global__ void __launch_bounds__(1024) k_sample_wide(WideArgs A) {
         const bool fixed = (flags & TSIMK_LFLAG_FIXED) != 0, approx = (flags & TSIMK_LFLAG_APPROX) != 0;
         Acc4 S;
         u32x4 yl = yf;
-        if (A.compact) {  // + the level's outcome bits and row constants: two more entries for ALL its graphs
+        if (!GLOB && A.compact) {  // + the level's outcome bits and row constants: two more entries for ALL its graphs
           const u32x4 v = *(lds_u4p)(uintptr_t)(lds_col0 + e_lo);
           const u32x4 w = *(lds_u4p)(uintptr_t)(lds_col0 + e_hi);
           yl.x = xor3(yl.x, v.x, w.x); yl.y = xor3(yl.y, v.y, w.y); yl.z = xor3(yl.z, v.z, w.z); yl.w = xor3(yl.w, v.w, w.w);
@@ -421,7 +424,7 @@ __global__ void __launch_bounds__(1024) k_sample_wide(WideArgs A) {
           R.d = R.c;
           if (approx) R.d = *(lds_u4p)(uintptr_t)(rb + 48u);
           u32x4 y;
-          if (A.compact) {
+          if (!GLOB && A.compact) {
             y = field_words(yl, R[G4_CFIELD], R[G4_DBITS]);
           } else {
             y = *(lds_u4p)(uintptr_t)(base + e_lo);
@@ -450,8 +453,13 @@ __global__ void __launch_bounds__(1024) k_sample_wide(WideArgs A) {
         for (int k = 0; k < K; ++k) e[k] = col[k];
         e[K] = e_lo;
         e[K + 1] = e_hi;
-        if ((lvl[L4_FLAGS] & TSIMK_LFLAG_FIXED) != 0) eval_level4_resident<K + 2, true>(A.img, img, lvl, e, lds_col0 + lvl_off, ent_bytes, re, im);
-        else eval_level4_resident<K + 2, false>(A.img, img, lvl, e, lds_col0 + lvl_off, ent_bytes, re, im);
+        if (GLOB) {
+          if ((lvl[L4_FLAGS] & TSIMK_LFLAG_FIXED) != 0) eval_level4_global<K + 2, true>(A.img, img, lvl, e, ent_bytes, re, im);
+          else eval_level4_global<K + 2, false>(A.img, img, lvl, e, ent_bytes, re, im);
+        } else {
+          if ((lvl[L4_FLAGS] & TSIMK_LFLAG_FIXED) != 0) eval_level4_resident<K + 2, true>(A.img, img, lvl, e, lds_col0 + lvl_off, ent_bytes, re, im);
+          else eval_level4_resident<K + 2, false>(A.img, img, lvl, e, lds_col0 + lvl_off, ent_bytes, re, im);
+        }
         lvl_off += lvl[L4_G] * ent_bytes;
       }
 #ifdef TSIMK_WIDE_TRACE
@@ -543,7 +551,7 @@ __global__ void __launch_bounds__(1024) k_sample_wide(WideArgs A) {
       }
     };
     u32x4 yf = {0u, 0u, 0u, 0u};
-    if (A.compact) walk(lds8, yf);  // shared column table: one walk for every graph of every level
+    if (!GLOB && A.compact) walk(lds8, yf);  // shared column table: one walk for every graph of every level
     for (uint32_t li = 0; li <= n_out; ++li) {
       cptr lvl = levels + li * L4_WORDS;
       if (li > 0) mb = trial0 ? (mb & ~(1u << (li - 1u))) : (mb | (1u << (li - 1u)));
@@ -552,17 +560,17 @@ __global__ void __launch_bounds__(1024) k_sample_wide(WideArgs A) {
       cptr recs = img + lvl[L4_RECS];
       Acc4 S;
       u32x4 yl = yf;
-      if (A.compact) {
+      if (!GLOB && A.compact) {
         const u32x4 v = *reinterpret_cast<const u32x4 *>(lds8 + (F + 1u + (mb & 15u)) * 16u);
         const u32x4 t = *reinterpret_cast<const u32x4 *>(lds8 + (F + 17u + ((mb >> 4) & 15u)) * 16u);
         yl.x ^= v.x ^ t.x; yl.y ^= v.y ^ t.y; yl.z ^= v.z ^ t.z; yl.w ^= v.w ^ t.w;
       }
       for (uint32_t g = 0; g < G; ++g, ++gidx) {
         u32x4 y;
-        if (A.compact) {
+        if (!GLOB && A.compact) {
           y = field_words(yl, img[wr[WR_CREC] + gidx], recs[g * G4_WORDS + G4_DBITS]);
         } else {
-          const uint8_t *tbl = lds8 + lvl_off + g * ent_bytes;
+          const uint8_t *tbl = GLOB ? reinterpret_cast<const uint8_t *>(A.img + lvl[L4_STAB]) + (size_t)g * ent_bytes : lds8 + lvl_off + g * ent_bytes;
           y = *reinterpret_cast<const u32x4 *>(tbl + (F + 1u + (mb & 15u)) * 16u);
           {
             const u32x4 t = *reinterpret_cast<const u32x4 *>(tbl + (F + 17u + ((mb >> 4) & 15u)) * 16u);

@@ -41,6 +41,7 @@ struct Wide4Args {
   const uint32_t *check_row_in;  // nullptr: the check row is slot 0
   uint32_t *feedback;            // optional: [rows in the lists, longest list, rows of the launch]
   int resident;          // 1: the LDS table area holds ALL levels of a component at once (one copy, no per-level barriers)
+  int stream_buf;        // resident = 0: bytes of each of the two LDS buffers the column tables are streamed through (groups of graphs)
 };
 
 // One level from LDS-resident column tables (graph g of the level at lds_level + g * ent_bytes): no copy, no barrier.
@@ -74,6 +75,54 @@ __device__ __forceinline__ void eval_level4_resident(const uint32_t *gimg, cptr 
 #else
     acc_graph4<FIXED, LT>(S, gimg, recs + g * G4_WORDS, U, V, O1, O2, approx, tt_bias);
 #endif
+  }
+  acc_finish4<FIXED>(S, lvl, approx, out_re, out_im);
+}
+
+// One level with the column tables STREAMED through LDS in groups of as many graphs as a buffer holds (the wide layout is
+// [graph][entry]: a level's graphs are consecutive (F + 33) x 16-byte blocks, so any run of them is one linear copy).
+// eval_level4<GT = 1> took a barrier per graph: 140 graphs (class F60 of scripts/shape_map.py) were 140 copy-and-barrier
+// round trips per level walk, 109 us per batch for the 0.8 % of the rows the tables miss; in groups of ~20 graphs it is 9.
+// All threads of the block must call this together.
+template <int NR, bool FIXED>
+__device__ __forceinline__ void eval_level4_groups(const uint32_t *gimg, cptr img, cptr lvl, const uint32_t (&ent0)[NR],
+                                                   uint32_t ent_bytes, uint32_t table_off, uint8_t *lds_tab, uint32_t buf_bytes,
+                                                   float &out_re, float &out_im) {
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  typedef const __attribute__((address_space(3))) u32x4 *lds_u4p;
+  const uint32_t G = lvl[L4_G];
+  const bool approx = (lvl[L4_FLAGS] & TSIMK_LFLAG_APPROX) != 0;
+  const uint32_t tg = buf_bytes / ent_bytes > 1u ? buf_bytes / ent_bytes : 1u;  // graphs per group
+  const uint32_t ngroups = (G + tg - 1u) / tg;
+  const uint32_t ent_vec = ent_bytes >> 4;
+  const uint4 *gtab = reinterpret_cast<const uint4 *>(gimg + table_off);
+  cptr recs = img + lvl[L4_RECS];
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const uint32_t tab0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)lds_tab;
+  auto copy = [&](uint32_t grp) {
+    const uint32_t g0 = grp * tg, n = G - g0 < tg ? G - g0 : tg;
+    tile_copy(gtab + (size_t)g0 * ent_vec, lds_tab + (grp & 1u) * buf_bytes, n * ent_vec, tid, nthr);
+  };
+  Acc4 S;
+  __syncthreads();  // previous users of the buffers are done
+  if (ngroups) copy(0u);
+  __syncthreads();
+  for (uint32_t grp = 0; grp < ngroups; ++grp) {
+    if (grp + 1u < ngroups) copy(grp + 1u);  // into the other buffer: its last readers passed the barrier that ended group grp - 1
+    const uint32_t g0 = grp * tg, n = G - g0 < tg ? G - g0 : tg;
+    uint32_t base = tab0 + (grp & 1u) * buf_bytes;
+    for (uint32_t j = 0; j < n; ++j, base += ent_bytes) {
+      uint32_t U = 0, V = 0, O1 = 0, O2 = 0;
+#pragma unroll
+      for (int c = 0; c < NR; c += 2) {
+        const u32x4 v = *(lds_u4p)(uintptr_t)(base + ent0[c]);
+        const u32x4 w = *(lds_u4p)(uintptr_t)(base + ent0[c + 1]);
+        U = xor3(U, v.x, w.x); V = xor3(V, v.y, w.y); O1 = xor3(O1, v.z, w.z); O2 = xor3(O2, v.w, w.w);
+        if (c % 6 == 4 && c + 2 < NR) __builtin_amdgcn_sched_barrier(0);
+      }
+      acc_graph4<FIXED>(S, gimg, recs + (g0 + j) * G4_WORDS, U, V, O1, O2, approx);
+    }
+    __syncthreads();
   }
   acc_finish4<FIXED>(S, lvl, approx, out_re, out_im);
 }
@@ -271,8 +320,8 @@ __global__ void __launch_bounds__(256) k_sample4w(Wide4Args W) {
         else eval_level4_resident<K + 2, false>(A.img, img, lvl, e, lds0 + lvl_off, tile_bytes, re, im);
         lvl_off += lvl[L4_G] * tile_bytes;
       } else {
-        if (fixed) eval_level4<GT, K + 2, true>(A.img, img, lvl, e, tile_bytes, lvl[L4_STAB], lds_tab, re, im);
-        else eval_level4<GT, K + 2, false>(A.img, img, lvl, e, tile_bytes, lvl[L4_STAB], lds_tab, re, im);
+        if (fixed) eval_level4_groups<K + 2, true>(A.img, img, lvl, e, tile_bytes, lvl[L4_STAB], lds_tab, (uint32_t)W.stream_buf, re, im);
+        else eval_level4_groups<K + 2, false>(A.img, img, lvl, e, tile_bytes, lvl[L4_STAB], lds_tab, (uint32_t)W.stream_buf, re, im);
       }
       const float v1 = cabs32(re, im);
       if (li == 0) { prev = v1; continue; }

@@ -768,7 +768,9 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
   auto wide_pass = [&](bool from_lists, int par) -> int {
     if (B > 0xFFFFFFFFll) return tsim_fail(TSIM_ENOTSUP, "batch too large for the row list");
     constexpr int kWideBlock = 256, kWideK = 10, kWideLists = 16;
-    const size_t stage_b = (size_t)(2 * a.WF + 2 * a.WO) * kWideBlock * 4, stream_b = 2 * (size_t)p->v4_max_sent * p->v4_gt * 16;
+    // (streamed tables: two buffers of up to 24 KB - groups of graphs, eval_level4_groups - never less than one graph's table)
+    const size_t stage_b = (size_t)(2 * a.WF + 2 * a.WO) * kWideBlock * 4, one_tile = (size_t)p->v4_max_sent * p->v4_gt * 16;
+    const size_t stream_buf = std::max(one_tile, std::min<size_t>(24 * 1024, (64 * 1024 - stage_b) / 2) / 16 * 16), stream_b = 2 * stream_buf;
     // all levels of a component resident in LDS when that still leaves room for two blocks per CU
     const bool resident = stage_b + p->v4w_resident_bytes <= 64 * 1024;
     const size_t ldsw = stage_b + (resident ? std::max(p->v4w_resident_bytes, (size_t)16) : stream_b);
@@ -818,6 +820,7 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
     w.list_cap = (int)list_cap;
     w.n_lists = kWideLists;
     w.resident = resident ? 1 : 0;
+    w.stream_buf = (int)stream_buf;
     ++p->path_count[TP_SAMPLE4W];
     hipLaunchKernelGGL((k_sample4w<1, kWideK>), dim3((unsigned)grid1), dim3(kWideBlock), ldsw, s, w);
     HIP_TRY(hipGetLastError());

@@ -34,6 +34,8 @@ SHAPES = {
                    direct_flip_fraction=0.2),
     # four components and no direct outputs at all: the first pass writes zeros + its component, 2-byte rows
     "4comps": dict(num_f=192, n_direct=0, components=[_w(1, 70), _w(2, 80), _w(3, 66), _w(5, 75)], shuffle_outputs=True),
+    # f rows of 1500 bits (24 words; the round-2 kernels read 16 mask words: f indices below 512), direct outputs from anywhere in the row
+    "bigrows": dict(num_f=1500, n_direct=100, components=[_w(3, 180), _w(2, 40)], shuffle_outputs=True, identity_direct=False, direct_flip_fraction=0.1),
     # eight outputs per component, 200 outputs: four output words
     "wide8": dict(num_f=448, n_direct=184, components=[_w(8, 100), _w(8, 120)], shuffle_outputs=True),
 }
@@ -125,6 +127,24 @@ def test_passes_equal_the_round2_path(hip, name):
     assert "wide" in res[0][1] and "wide" not in res[1][1], (res[0][1], res[1][1])
     for a, b in zip(res[0][0], res[1][0]):
         np.testing.assert_array_equal(a, b)
+
+
+def test_rows_too_wide_for_the_word_list_fall_back_to_the_row_kernel(hip):
+    """2000 f bits with 250 selected ones scattered over them: more than the 64 words k_sample_wide's list holds - the row
+    kernel serves the program (the round-2 wide kernels must not: their masks end at bit 511); same bits as the oracle."""
+    prog = synth.physical_program(seed=5, num_f=2000, n_direct=40, components=[_w(3, 250)], identity_direct=False)
+    orc = OC.OracleProgram(prog)
+    f = synth.synth_f(1200, 2000, 4.0 / 250, seed=2)
+    hp = _handle(hip, prog)
+    hp.path_counts(reset=True)
+    for i in range(3):
+        want, wdev = orc.sample_program(f, (i, 1), return_devs=True)
+        got, gdev = hp.sample_batch(f, (i, 1))
+        np.testing.assert_array_equal(got, want)
+        np.testing.assert_array_equal(np.asarray(gdev, np.float32), np.asarray(wdev, np.float32))
+    paths = hp.path_counts()
+    assert not ({"sample4w", "lw_lds_wide", "wide"} & set(paths)), paths
+    hp.close()
 
 
 def test_misaligned_bit_packed_buffers(hip):

@@ -168,6 +168,7 @@ struct tsim_program {
   bool lw_reg = false;        // the register form of pass 1 applies (narrow f rows, ascending f_selection)
   int lwfm_off = 0;           // fast record of programs with 2..4 components of <= 8 outputs each (k_sample_lw_fastm), 0 = none
   int wr_off = 0;             // image offset of the first wide record (k_sample_wide, tsim_wide.hip.h), 0 = none
+  bool wide_big = false;      // wide program with f indices >= 512: the round-2 wide kernels (16 selection-mask words) must not see it
   std::vector<int> wr_offs;   // one wide record per component (the passes of k_sample_wide, in component order)
   int gr_off = 0;             // image offset of the gen record (any narrow program: k_sample_gen, tsim_gen.hip.h), 0 = none
   int lwf_off = 0;            // image offset of the fast record (one component of <= 8 outputs: k_sample_lw_fast), 0 = none

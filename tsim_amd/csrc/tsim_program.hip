@@ -493,7 +493,9 @@ retry_pack:
       for (auto &lv : c.levels) ok = ok && level_v4_eligible(lv);
     // wide components (more than 64 parameters): column tables only, for the sparse-column kernel k_sample4w.
     // Needs sequential components of at most 8 outputs over at most 256 ascending f indices below 512.
-    bool wide = !ok && !p->comps.empty() && p->max_f_index < 32 * TSIMK_W_SELWORDS;
+    // (f indices up to 2047 since round 5: the round-2 kernels k_sample4w / k_sample_lw<true> read 16 mask words - f rows of at most
+    // 512 bits, p->wide_big below keeps them away from wider rows - k_sample_wide reads a list of the words that hold selected bits)
+    bool wide = !ok && !p->comps.empty() && p->max_f_index < 2048;
     for (auto &c : p->comps) {
       wide = wide && (c.n_levels == c.n_out + 1) && c.n_out <= 8 && c.F <= 256;
       for (int j = 1; j < c.F; ++j) wide = wide && c.f_selection[j] > c.f_selection[j - 1];
@@ -577,7 +579,8 @@ retry_pack:
         }
         if (wide) {  // selection masks over f bits 0..255 and, per word, the selected bits below it
           uint32_t sel[2 * TSIMK_W_SELWORDS] = {0};
-          for (int v : c.f_selection) sel[v >> 5] |= 1u << (v & 31);
+          for (int v : c.f_selection)
+            if (v < 32 * TSIMK_W_SELWORDS) sel[v >> 5] |= 1u << (v & 31);
           for (int w = 1; w < TSIMK_W_SELWORDS; ++w)
             sel[TSIMK_W_SELWORDS + w] = sel[TSIMK_W_SELWORDS + w - 1] + (uint32_t)__builtin_popcount(sel[w - 1]);
           while (img.size() % 16) img.push_back(0u);
@@ -587,6 +590,8 @@ retry_pack:
       }
       p->v4 = ok;
       p->v4w = wide;
+      // f rows of more than 512 bits: k_sample_wide or the row kernel, never the round-2 kernels (16 mask words)
+      p->wide_big = wide && p->max_f_index >= 32 * TSIMK_W_SELWORDS;
       p->v4w_resident_bytes = 0;
       if (wide)
         for (auto &c : p->comps) {
@@ -628,7 +633,7 @@ retry_pack:
     for (auto &c : p->comps) narrow = narrow && (c.n_levels == c.n_out + 1) && c.n_out <= TSIMK_LW_MAX_NOUT && c.F + c.n_out <= 64;
     // wide components (the sparse-column kernel's programs): tables to weight TSIMK_LWW_MAX_WEIGHT in front of it
     p->lw_wide = false;
-    if (ok && !narrow && p->v4w && p->max_f_index < 512) {
+    if (ok && !narrow && p->v4w && p->max_f_index < 2048) {
       bool wide_ok = true;
       wide_ok = p->knobs.wide_tables;
       for (auto &c : p->comps) {
@@ -721,7 +726,7 @@ retry_pack:
           const bool merge = wci > 0;
           std::vector<uint32_t> runs, runb(1, 0u), flips((size_t)wo32, 0u);
           for (int d = 0; d < wo32; ++d) {
-            for (int sw = 0; !merge && sw < 2 * TSIMK_W_SELWORDS / 2; ++sw) {
+            for (int sw = 0; !merge && sw <= p->max_f_index / 32 && sw < 256; ++sw) {
               std::vector<std::array<int, 2>> m;  // (src bit, dst bit) inside the words
               for (int j = 0; j < p->n_direct; ++j) {
                 const int src = p->direct_f[j], dst = p->output_order[j];
@@ -753,6 +758,24 @@ retry_pack:
             p->wr_offs.push_back(wr_this);
             img.resize(img.size() + WR_WORDS, 0u);
             img[(size_t)wr_this + WR_MERGE] = merge ? 1u : 0u;
+            {  // the f words that hold selected bits: masks, then (selected bits in the lower words | word index << 16)
+              std::vector<uint32_t> words, masks;
+              for (int v : c.f_selection) {
+                if (words.empty() || words.back() != (uint32_t)(v >> 5)) { words.push_back((uint32_t)(v >> 5)); masks.push_back(0u); }
+                masks.back() |= 1u << (v & 31);
+              }
+              if (words.empty()) { words.push_back(0u); masks.push_back(0u); }
+              if (words.size() > TSIMK_WIDE_SELMAX) wide_rec_ok = false;
+              const uint32_t sel_off = (uint32_t)img.size();
+              img.insert(img.end(), masks.begin(), masks.end());
+              uint32_t below = 0;
+              for (size_t k = 0; k < words.size(); ++k) {
+                img.push_back(below | (words[k] << 16));
+                below += (uint32_t)__builtin_popcount(masks[k]);
+              }
+              img[(size_t)wr_this + WR_SELN] = (uint32_t)words.size();
+              img[(size_t)wr_this + WR_SELREC] = sel_off;
+            }
             const uint32_t runs_off = (uint32_t)img.size();
             img.insert(img.end(), runs.begin(), runs.end());
             const uint32_t runb_off = (uint32_t)img.size();
@@ -889,6 +912,7 @@ retry_pack:
         }
         if (!wide_rec_ok) p->wr_offs.clear();
         p->wr_off = p->wr_offs.empty() ? 0 : p->wr_offs[0];
+
       } else if (ok) {
         p->lw = true;
         // gather programs of every component's f_sel (the LDS-staged first pass)

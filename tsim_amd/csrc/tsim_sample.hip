@@ -582,7 +582,7 @@ static WideLayout wide_layout(const tsim_program *p, int WF32, size_t ci = 0) {
     L.l_lut = (int)off;   off += ((size_t)wo32 << c.n_out) * 4;
     off = up(off, 16);
     L.l_runs = (int)off;  off += (size_t)(2 * TSIMK_WIDE_MAX_RUNS + 48) * 4;
-    L.l_sel = (int)off;   off += 36 * 4;  // + the two statistics counters
+    L.l_sel = (int)off;   off += (2 * TSIMK_WIDE_SELMAX + 4) * 4;  // + the two statistics counters
     L.l_ptrs = (int)off;  off += (size_t)TSIMK_LWM_MAX_STEPS * 4 * 4;
     L.l_keys = (int)off;  off += (size_t)TSIMK_LWM_MAX_STEPS * 2 * TSIMK_LWM_KEYS * 4;
     off = up(off, 16);
@@ -629,7 +629,7 @@ static bool wide_applies(const tsim_program *p, int64_t B, int32_t num_f, int64_
     if (((p->lw_npat[ci] << p->comps[ci].n_out) * 4) >= (1ll << 32)) return false;
   if (((unsigned long long)shot_offset >> 32) != ((unsigned long long)(shot_offset + B - 1) >> 32)) return false;
   const int WF = std::max(1, (num_f + 63) / 64);
-  if (WF > 8 || p->wr_offs.size() != p->comps.size()) return false;
+  if (WF > 32 || p->wr_offs.size() != p->comps.size()) return false;  // (f rows of up to 2048 bits; wide_layout says whether they fit)
   for (size_t ci = 0; ci < p->comps.size(); ++ci)
     if (wide_layout(p, 2 * WF, ci).block == 0) return false;
   return true;
@@ -758,12 +758,16 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
     return 0;
   };
   const LaunchPlan plan = plan_in ? *plan_in : make_plan(p, d_row_index != nullptr, false, (unsigned long long)B);
-  const bool use_tables = plan.use_tables, need_overflow = plan.need_overflow;
+  bool use_tables = plan.use_tables;
+  const bool need_overflow = plan.need_overflow;
+  // f rows wider than the round-2 wide kernels read (p->wide_big): k_sample_wide, or every row on the row kernel
+  const bool big_out = p->wide_big && !(use_tables && !d_row_index && wide_applies(p, B, num_f, shot_offset) && wide_buffers_ok(p, a));
+  if (big_out) use_tables = false;
   if (int r = tsim_tables_slice(p, s)) return r;  // (a table build in the background: its next slice goes first)
   // The sparse-column pass (k_sample4w) over every row, or - behind a pattern-table first pass - over that pass's
   // hard-row lists (from_lists; `a` then describes them).  Its own overflow (more than K set bits, the check row)
   // goes to row lists of its own, which `a` describes afterwards: the row kernel below serves them.
-  const bool wide_fits = p->v4w && p->knobs.wide &&
+  const bool wide_fits = p->v4w && !p->wide_big && p->knobs.wide &&
                          (size_t)(2 * a.WF + 2 * a.WO) * 256 * 4 + 2 * (size_t)p->v4_max_sent * p->v4_gt * 16 <= 64 * 1024;
   auto wide_pass = [&](bool from_lists, int par) -> int {
     if (B > 0xFFFFFFFFll) return tsim_fail(TSIM_ENOTSUP, "batch too large for the row list");

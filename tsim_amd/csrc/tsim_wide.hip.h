@@ -47,8 +47,11 @@ enum {
   WR_CCOL,        // image offset of the shared column table (F + 33 entries of 16 bytes: every graph's parity bits in one entry), 0: none
   WR_CREC,        // image offset of one word per graph: word of the entry | first bit << 8 | product pairs << 16 | counted rows << 24
   WR_MERGE,       // 1: a later component's pass - no direct outputs, the component's bits are ORed into the rows the first pass wrote
-  WR_WORDS = 16
+  WR_SELN,        // f words (32 bits) that hold selected bits of the component (<= TSIMK_WIDE_SELMAX): the only ones phase 1 looks at
+  WR_SELREC,      // image offset of SELN masks, then SELN x (selected bits in the lower words | word index << 16)
+  WR_WORDS = 32
 };
+#define TSIMK_WIDE_SELMAX 64   // (f rows of up to 2048 bits since round 5: max_f_index < 512 was the 16 mask words of the round-2 kernels)
 #define TSIMK_WIDE_K 12        // set bits per row the dense pass takes
 #define TSIMK_WIDE_QCAP 128    // ring capacities (power of two, >= 127)
 #define TSIMK_WIDE_MAX_RUNS 256
@@ -151,13 +154,14 @@ __global__ void __launch_bounds__(1024) k_sample_wide(WideArgs A) {
   uint32_t *l_rank = tsimk_lds + (A.l_rank >> 2);  // [4][F + 1]: C(position, ordinal + 1), 0 at position F
   uint32_t *l_lut = tsimk_lds + (A.l_lut >> 2);    // [2^n_out][WO32]
   uint32_t *l_runs = tsimk_lds + (A.l_runs >> 2);  // runs (2 words each), then RUNB[WO32 + 1], FLIPS[WO32], BASES[8]
-  uint32_t *l_sel = tsimk_lds + (A.l_sel >> 2);    // 16 selection masks, 16 prefix counts
+  uint32_t *l_sel = tsimk_lds + (A.l_sel >> 2);    // SELMAX selection masks, SELMAX x (prefix count | f word << 16), two statistics counters
   uint32_t *l_ptrs = tsimk_lds + (A.l_ptrs >> 2);  // per step: out (2 words), out_compact (2 words)
   uint32_t *l_keys = tsimk_lds + (A.l_keys >> 2);  // per step: 2 * TSIMK_LWM_KEYS subkey words
   cstep steps = (cstep)((cbytes)__builtin_amdgcn_kernarg_segment_ptr() + __builtin_offsetof(WideArgs, step));
 
   // ---- once per block: everything loop-invariant into LDS
   const uint32_t n_runs = wr[WR_NRUNS];
+  const uint32_t n_sel = wr[WR_SELN];
   {
     uint32_t off = 0;
     if (!GLOB && A.compact) {  // the shared column table: every graph's parity bits in one 16-byte entry per column
@@ -214,7 +218,7 @@ __global__ void __launch_bounds__(1024) k_sample_wide(WideArgs A) {
     if (threadIdx.x <= (uint32_t)WO32) l_runs[2u * TSIMK_WIDE_MAX_RUNS + threadIdx.x] = g[wr[WR_RUNB] + threadIdx.x];
     if (threadIdx.x < (uint32_t)WO32) l_runs[2u * TSIMK_WIDE_MAX_RUNS + 16u + threadIdx.x] = g[wr[WR_FLIPS] + threadIdx.x];
     if (threadIdx.x < 8u) l_runs[2u * TSIMK_WIDE_MAX_RUNS + 32u + threadIdx.x] = g[A.lw_off + LW_BASES_INLINE + threadIdx.x];
-    if (threadIdx.x < 32u) l_sel[threadIdx.x] = g[comp[C4_SELMASK] + threadIdx.x];
+    for (uint32_t i = threadIdx.x; i < 2u * n_sel; i += nthr) l_sel[i < n_sel ? i : TSIMK_WIDE_SELMAX + (i - n_sel)] = g[wr[WR_SELREC] + i];
     for (uint32_t i = threadIdx.x; i < 4u * (uint32_t)A.n_steps; i += nthr) {
       const uint64_t ptr = (i & 2u) ? (uint64_t)(uintptr_t)steps[i >> 2].out_compact : (uint64_t)(uintptr_t)steps[i >> 2].out;
       l_ptrs[i] = (i & 1u) ? (uint32_t)(ptr >> 32) : (uint32_t)ptr;
@@ -538,9 +542,9 @@ __global__ void __launch_bounds__(1024) k_sample_wide(WideArgs A) {
     float prev = 0.0f, maxdev = 0.0f;
     // XOR of the column entries of the row's set selected bits, from the table at `tbl`
     auto walk = [&](const uint8_t *tbl, u32x4 &y) {
-      for (uint32_t w = 0; w < WF32 && w < 16u; ++w) {
-        const uint32_t sw = l_sel[w], base = l_sel[16u + w];
-        uint32_t m = frow[w] & sw;
+      for (uint32_t w = 0; w < n_sel; ++w) {
+        const uint32_t sw = l_sel[w], bw = l_sel[TSIMK_WIDE_SELMAX + w], base = bw & 0xFFFFu;
+        uint32_t m = frow[bw >> 16] & sw;
         while (m) {
           const uint32_t p = (uint32_t)__builtin_ctz(m);
           const uint32_t pos = base + (uint32_t)__builtin_popcount(sw & ((1u << p) - 1u));
@@ -688,15 +692,15 @@ __global__ void __launch_bounds__(1024) k_sample_wide(WideArgs A) {
     // walked (one LDS latency per word, under the loop); nothing in the loop touches memory.
     uint32_t l0 = zsplat, l1 = zsplat, l2 = zsplat, cnt = 0;
     {
-      const uint32_t nw = WF32 < 16u ? WF32 : 16u;
-      uint32_t n_sw = l_sel[0], n_base = l_sel[16], n_fw = frow[0];
+      const uint32_t nw = n_sel;
+      uint32_t n_sw = l_sel[0], n_base = l_sel[TSIMK_WIDE_SELMAX], n_fw = frow[n_base >> 16];
       for (uint32_t w = 0; w < ((TSIMK_WIDE_SKIP & 16) ? 0u : nw); ++w) {
-        const uint32_t sw = n_sw, base = n_base;
+        const uint32_t sw = n_sw, base = n_base & 0xFFFFu;
         uint32_t m = active ? (n_fw & sw) : 0u;
         if (w + 1u < nw) {
           n_sw = l_sel[w + 1u];
-          n_base = l_sel[17u + w];
-          n_fw = frow[w + 1u];
+          n_base = l_sel[TSIMK_WIDE_SELMAX + 1u + w];
+          n_fw = frow[n_base >> 16];
         }
         while (m) {
           const uint32_t p = (uint32_t)__builtin_ctz(m);
@@ -848,7 +852,7 @@ __global__ void __launch_bounds__(1024) k_sample_wide(WideArgs A) {
   if (A.feedback && blockIdx.x == 0) {
     // (no static __shared__ here: it would sit in front of the dynamic segment and push the 16-byte table entries off their
     // alignment - 8 bytes of counters cost every ds_read_b128 of the kernel a split access, 120 -> 50 us per 10^6 shots)
-    uint32_t *s_cnt = l_sel + 32;
+    uint32_t *s_cnt = l_sel + 2 * TSIMK_WIDE_SELMAX;
     if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0u;
     __syncthreads();
     if (lane == 0u) {

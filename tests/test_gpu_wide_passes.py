@@ -129,22 +129,25 @@ def test_passes_equal_the_round2_path(hip, name):
         np.testing.assert_array_equal(a, b)
 
 
-def test_rows_too_wide_for_the_word_list_fall_back_to_the_row_kernel(hip):
-    """2000 f bits with 250 selected ones scattered over them: more than the 64 words k_sample_wide's list holds - the row
-    kernel serves the program (the round-2 wide kernels must not: their masks end at bit 511); same bits as the oracle."""
-    prog = synth.physical_program(seed=5, num_f=2000, n_direct=40, components=[_w(3, 250)], identity_direct=False)
-    orc = OC.OracleProgram(prog)
-    f = synth.synth_f(1200, 2000, 4.0 / 250, seed=2)
-    hp = _handle(hip, prog)
-    hp.path_counts(reset=True)
-    for i in range(3):
-        want, wdev = orc.sample_program(f, (i, 1), return_devs=True)
-        got, gdev = hp.sample_batch(f, (i, 1))
-        np.testing.assert_array_equal(got, want)
-        np.testing.assert_array_equal(np.asarray(gdev, np.float32), np.asarray(wdev, np.float32))
-    paths = hp.path_counts()
-    assert not ({"sample4w", "lw_lds_wide", "wide"} & set(paths)), paths
-    hp.close()
+def test_f_rows_of_2000_bits_and_beyond(hip):
+    """2000 f bits with 250 selected ones scattered over 63 of the 63 words: still k_sample_wide (its word list holds 64).
+    2500 bits: past every wide kernel's reach - the row kernel serves the program, and the round-2 wide kernels (masks up to
+    bit 511) must not be launched.  Same bits as the oracle either way."""
+    for num_f, wide in ((2000, True), (2500, False)):
+        prog = synth.physical_program(seed=5, num_f=num_f, n_direct=40, components=[_w(3, 250)], identity_direct=False)
+        orc = OC.OracleProgram(prog)
+        f = synth.synth_f(1200, num_f, 4.0 / 250, seed=2)
+        hp = _handle(hip, prog)
+        hp.path_counts(reset=True)
+        for i in range(3):
+            want, wdev = orc.sample_program(f, (i, 1), return_devs=True)
+            got, gdev = hp.sample_batch(f, (i, 1))
+            np.testing.assert_array_equal(got, want)
+            np.testing.assert_array_equal(np.asarray(gdev, np.float32), np.asarray(wdev, np.float32))
+        paths = hp.path_counts()
+        assert not ({"sample4w", "lw_lds_wide"} & set(paths)), paths
+        assert ("wide" in paths) == wide, (num_f, paths)
+        hp.close()
 
 
 def test_misaligned_bit_packed_buffers(hip):

@@ -340,7 +340,10 @@ __device__ __forceinline__ void sample4_block(const SampleArgs &A, int comp4_off
     cptr outpos = img + comp[C_OUTPOS];
     const uint32_t keybase = comp[C_KEYBASE];
 
-    uint32_t x[2] = {0u, 0u};
+    // x = (f_sel, outcome bits): two words - or three (NCH > 16, round 5): components of at most 64 selected f bits whose
+    // F + n_out parameters pass 64 (class F60 of scripts/shape_map.py).  The f bits never leave words 0 and 1.
+    constexpr int XW = NCH > 16 ? 3 : 2;
+    uint32_t x[3] = {0u, 0u, 0u};
 #pragma unroll
     for (int w = 0; w < 2; ++w) {
       uint32_t v = 0;
@@ -352,6 +355,13 @@ __device__ __forceinline__ void sample4_block(const SampleArgs &A, int comp4_off
       }
       x[w] = v;
     }
+    // bit `bitpos` of x := v (bitpos is wave-uniform: the word is picked by scalar branches, the array stays in registers)
+    auto set_bit = [&](uint32_t bitpos, bool v) {
+      const uint32_t bm = 1u << (bitpos & 31u), bw = bitpos >> 5;
+      if (bw == 0u) x[0] = v ? (x[0] | bm) : (x[0] & ~bm);
+      else if (bw == 1u || XW == 2) x[1] = v ? (x[1] | bm) : (x[1] & ~bm);
+      else x[2] = v ? (x[2] | bm) : (x[2] & ~bm);
+    };
 
     // Sparse-f decision, block-uniform: every lane has at most 4 set f bits and the component has
     // at most 8 outputs (the packer then emitted the column tables, L4_STAB != 0).
@@ -363,13 +373,8 @@ __device__ __forceinline__ void sample4_block(const SampleArgs &A, int comp4_off
     for (uint32_t li = 0; li <= n_out; ++li) {
       cptr lvl = levels + li * L4_WORDS;
       const uint32_t bitpos = F + li - 1u;
-      const uint32_t bm = (li > 0) ? (1u << (bitpos & 31u)) : 0u;
-      const bool hiw = (li > 0) && bitpos >= 32u;
       const bool lvl_fixed = (lvl[L4_FLAGS] & TSIMK_LFLAG_FIXED) != 0;
-      if (li > 0) {
-        if (hiw) x[1] = trial0 ? (x[1] & ~bm) : (x[1] | bm);
-        else x[0] = trial0 ? (x[0] & ~bm) : (x[0] | bm);
-      }
+      if (li > 0) set_bit(bitpos, !trial0);
       float v1, v0 = 0.0f;
       {
         float re, im;
@@ -397,7 +402,7 @@ __device__ __forceinline__ void sample4_block(const SampleArgs &A, int comp4_off
           uint32_t en[NCH];
 #pragma unroll
           for (int c = 0; c < NCH; ++c) {
-            const uint32_t w = (c < 8) ? x[0] : x[1];
+            const uint32_t w = (c < 8) ? x[0] : (c < 16) ? x[1] : x[2];
             en[c] = ((w >> (4 * (c & 7))) & 15u) * 16u + c * Tile4<GT>::kChunkBytes;
           }
           if (lvl_fixed) eval_level4<GT, NCH, true, 256>(A.img, img, lvl, en, NCH * Tile4<GT>::kChunkBytes, lvl[L4_TABLES], lds_tab, re, im);
@@ -418,8 +423,7 @@ __device__ __forceinline__ void sample4_block(const SampleArgs &A, int comp4_off
       }
       const float u = uniform01(subkey(A, keybase + i, 0), subkey(A, keybase + i, 1), shot);
       const bool bit = u < __fdiv_rn(p1, prev);
-      if (hiw) x[1] = bit ? (x[1] | bm) : (x[1] & ~bm);
-      else x[0] = bit ? (x[0] | bm) : (x[0] & ~bm);
+      set_bit(bitpos, bit);
       prev = bit ? p1 : __fsub_rn(prev, p1);
       const uint32_t dst = outpos[i];
       lds_o[(dst >> 5) * nthr] |= (bit ? 1u : 0u) << (dst & 31u);

@@ -274,7 +274,8 @@ __device__ __forceinline__ void sample4h_rows(const SampleArgs &A, int comp4_off
     cptr outpos = img + comp[C_OUTPOS];
     const uint32_t keybase = comp[C_KEYBASE];
 
-    uint32_t x[2] = {0u, 0u};
+    constexpr int XW = NCH > 16 ? 3 : 2;  // (a third word of x for F + n_out in 65..80, F <= 64: tsim_kernel4.hip.h sample4_block)
+    uint32_t x[3] = {0u, 0u, 0u};
 #pragma unroll
     for (int w = 0; w < 2; ++w) {
       uint32_t v = 0;
@@ -286,21 +287,22 @@ __device__ __forceinline__ void sample4h_rows(const SampleArgs &A, int comp4_off
       }
       x[w] = v;
     }
+    auto set_bit = [&](uint32_t bitpos, bool v) {
+      const uint32_t bm = 1u << (bitpos & 31u), bw = bitpos >> 5;
+      if (bw == 0u) x[0] = v ? (x[0] | bm) : (x[0] & ~bm);
+      else if (bw == 1u || XW == 2) x[1] = v ? (x[1] | bm) : (x[1] & ~bm);
+      else x[2] = v ? (x[2] | bm) : (x[2] & ~bm);
+    };
 
     float prev = 0.0f, maxdev = 0.0f;
     for (uint32_t li = 0; li <= n_out; ++li) {
       cptr lvl = levels + li * L4_WORDS;
       const uint32_t bitpos = F + li - 1u;
-      const uint32_t bm = (li > 0) ? (1u << (bitpos & 31u)) : 0u;
-      const bool hiw = (li > 0) && bitpos >= 32u;
-      if (li > 0) {
-        if (hiw) x[1] = trial0 ? (x[1] & ~bm) : (x[1] | bm);
-        else x[0] = trial0 ? (x[0] & ~bm) : (x[0] | bm);
-      }
+      if (li > 0) set_bit(bitpos, !trial0);
       uint32_t en[NCH];
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {
-        const uint32_t w = (c < 8) ? x[0] : x[1];
+        const uint32_t w = (c < 8) ? x[0] : (c < 16) ? x[1] : x[2];
         en[c] = ((w >> (4 * (c & 7))) & 15u) * 16u + c * Tile4<GT>::kChunkBytes;
       }
       float re, im;
@@ -319,8 +321,7 @@ __device__ __forceinline__ void sample4h_rows(const SampleArgs &A, int comp4_off
       }
       const float u = uniform01(subkey(A, keybase + i, 0), subkey(A, keybase + i, 1), shot);
       const bool bit = u < __fdiv_rn(p1, prev);
-      if (hiw) x[1] = bit ? (x[1] | bm) : (x[1] & ~bm);
-      else x[0] = bit ? (x[0] | bm) : (x[0] & ~bm);
+      set_bit(bitpos, bit);
       prev = bit ? p1 : __fsub_rn(prev, p1);
       if (wave == 0) {
         const uint32_t dst = outpos[i];

@@ -289,6 +289,7 @@ extern "C" int tsim_program_finalize(tsim_program *p, int32_t device) {
     p->knobs.wide = tune_ll("wide", 1) != 0;
     p->knobs.wide_tables = tune_ll("wide_tables", 1) != 0;
     p->knobs.wide_compact = tune_ll("wide_compact", 1) != 0;
+    p->knobs.x3 = tune_ll("x3", 1) != 0;
     p->knobs.wide_depth = (int)std::max(0ll, std::min(4ll, tune_ll("wide_depth", 4)));
     p->knobs.wide_glob = (int)std::max(0ll, tune_ll("wide_glob", 48));
     p->knobs.wide_passes = (int)std::max(1ll, std::min(16ll, tune_ll("wide_passes", 8)));
@@ -489,8 +490,13 @@ retry_pack:
   p->v4w = false;
   if (p->fast && p->sampleable) {
     bool ok = !p->comps.empty();
-    for (auto &c : p->comps)
+    for (auto &c : p->comps) {
       for (auto &lv : c.levels) ok = ok && level_v4_eligible(lv);
+      // more than 64 parameters (round 5, knobs.x3): only as f_sel (<= 64 bits, words 0 and 1 of x) + outcome bits of a sequential component
+      int maxp = 1;
+      for (auto &lv : c.levels) maxp = std::max(maxp, lv.P);
+      if (maxp > 64) ok = ok && p->knobs.x3 && c.F <= 64 && c.n_levels == c.n_out + 1;
+    }
     // wide components (more than 64 parameters): column tables only, for the sparse-column kernel k_sample4w.
     // Needs sequential components of at most 8 outputs over at most 256 ascending f indices below 512.
     // (f indices up to 2047 since round 5: the round-2 kernels k_sample4w / k_sample_lw<true> read 16 mask words - f rows of at most
@@ -513,8 +519,8 @@ retry_pack:
       int maxp = 1;
       for (auto &c : p->comps)
         for (auto &lv : c.levels) maxp = std::max(maxp, lv.P);
-      static const int kNch[] = {2, 4, 6, 8, 10, 12, 14, 16};
-      p->v4_max_nch = 16;
+      static const int kNch[] = {2, 4, 6, 8, 10, 12, 14, 16, 20};
+      p->v4_max_nch = 20;
       for (int v : kNch)
         if (4 * v >= maxp) { p->v4_max_nch = v; break; }
       if (wide) {  // no chunk tables at all, one graph per tile (column tables only)
@@ -630,7 +636,9 @@ retry_pack:
     if (const char *e = getenv("TSIM_AMD_PATTERN_TABLES")) want = atoi(e) != 0;
     bool ok = want && p->sampleable && !p->comps.empty();
     bool narrow = true;
-    for (auto &c : p->comps) narrow = narrow && (c.n_levels == c.n_out + 1) && c.n_out <= TSIMK_LW_MAX_NOUT && c.F + c.n_out <= 64;
+    // (F + n_out up to 80 with F <= 64 since round 5: the chunk-table kernels hold x in three words then - p->v4 says whether they took the program)
+    for (auto &c : p->comps)
+      narrow = narrow && (c.n_levels == c.n_out + 1) && c.n_out <= TSIMK_LW_MAX_NOUT && (c.F + c.n_out <= 64 || (p->v4 && c.F <= 64 && c.F + c.n_out <= 80));
     // wide components (the sparse-column kernel's programs): tables to weight TSIMK_LWW_MAX_WEIGHT in front of it
     p->lw_wide = false;
     if (ok && !narrow && p->v4w && p->max_f_index < 2048) {

@@ -271,7 +271,7 @@ static bool hw_eligible(tsim_program *p, const SampleArgs &a, int n_ctx) {
   int wmax = 1;
   for (int w : p->comp_w) wmax = std::max(wmax, w);
   const uint32_t fb_rows = p->h_feedback ? p->h_feedback[0] : 0u;
-  return p->fast && p->knobs.hard_wave && wmax <= 2 && a.WF <= 32 && a.WO <= 2 && p->hw_max_rows < 60000 &&
+  return p->fast && p->knobs.hard_wave && wmax <= 4 && a.WF <= 32 && a.WO <= 2 && p->hw_max_rows < 60000 &&
          (unsigned long long)fb_rows * (unsigned)n_ctx <= (unsigned long long)p->knobs.hard_wave_rows;
 }
 // Behind the latency kernels of a hard-row batch: the list slots they left (k_sample4_over, tsim_kernel4.hip.h).  A fixed
@@ -299,7 +299,7 @@ static int launch_over(tsim_program *p, const SampleArgs *ctx, int n_ctx, uint32
   ++p->path_count[TP_OVER];
   switch (p->v4_max_nch) {
 #define TSIM_LO(N) case N: hipLaunchKernelGGL((k_sample4_over<4, N>), dim3(grid), dim3(blk), lds4, hs, M); break;
-    TSIM_LO(2) TSIM_LO(4) TSIM_LO(6) TSIM_LO(8) TSIM_LO(10) TSIM_LO(12) TSIM_LO(14)
+    TSIM_LO(2) TSIM_LO(4) TSIM_LO(6) TSIM_LO(8) TSIM_LO(10) TSIM_LO(12) TSIM_LO(14) TSIM_LO(20)
 #undef TSIM_LO
     default: hipLaunchKernelGGL((k_sample4_over<4, 16>), dim3(grid), dim3(blk), lds4, hs, M); break;
   }
@@ -350,9 +350,11 @@ static int launch_hw(tsim_program *p, const SampleArgs *ctx, int n_ctx, int max_
   if (wmax == 1) switch (nch) {
     TSIM_LHW(1, 0) TSIM_LHW(1, 2) TSIM_LHW(1, 4) TSIM_LHW(1, 6) TSIM_LHW(1, 8) TSIM_LHW(1, 10) TSIM_LHW(1, 12) TSIM_LHW(1, 14) TSIM_LHW(1, 16)
     default: return tsim_fail(TSIM_ESTATE, "bad chunk count %d", nch);
-  } else if (wmax > 2) {  // parameter rows of 65..128 bits (no chunk tables, no workers)
-    if (nch != 0) return tsim_fail(TSIM_ESTATE, "hard-row workers need chunk tables");
-    hipLaunchKernelGGL((k_sample_hw<4, 0>), dim3(grid), dim3(256), ldsw, hs, H);
+  } else if (wmax > 2) {  // parameter rows of 65..128 bits (chunk tables, and so workers, only for 65..80 parameters: NCH = 20)
+    switch (nch) {
+      TSIM_LHW(4, 0) TSIM_LHW(4, 20)
+      default: return tsim_fail(TSIM_ESTATE, "hard-row workers need chunk tables (%d chunks)", nch);
+    }
   } else switch (nch) {
     TSIM_LHW(2, 0) TSIM_LHW(2, 2) TSIM_LHW(2, 4) TSIM_LHW(2, 6) TSIM_LHW(2, 8) TSIM_LHW(2, 10) TSIM_LHW(2, 12) TSIM_LHW(2, 14) TSIM_LHW(2, 16)
     default: return tsim_fail(TSIM_ESTATE, "bad chunk count %d", nch);
@@ -440,7 +442,7 @@ static int flush_batch(tsim_program *p) {
     ++p->path_count[TP_SAMPLE4H_MULTI];                                                                      \
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(NW * 64), lds_m, hs, M);                                        \
   } break;
-    TSIM_LHM(2) TSIM_LHM(4) TSIM_LHM(6) TSIM_LHM(8) TSIM_LHM(10) TSIM_LHM(12) TSIM_LHM(14) TSIM_LHM(16)
+    TSIM_LHM(2) TSIM_LHM(4) TSIM_LHM(6) TSIM_LHM(8) TSIM_LHM(10) TSIM_LHM(12) TSIM_LHM(14) TSIM_LHM(16) TSIM_LHM(20)
 #undef TSIM_LHM
     default: return tsim_fail(TSIM_ESTATE, "bad chunk count %d", p->v4_max_nch);
   }
@@ -1033,7 +1035,7 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
     hipLaunchKernelGGL(kfn, dim3((unsigned)gridh), dim3(NW * 64), ldsh, s, ah, group_tiles, loop_stride,    \
                        p->d_feedback);                                                                      \
   } break;
-          TSIM_LH(2) TSIM_LH(4) TSIM_LH(6) TSIM_LH(8) TSIM_LH(10) TSIM_LH(12) TSIM_LH(14) TSIM_LH(16)
+          TSIM_LH(2) TSIM_LH(4) TSIM_LH(6) TSIM_LH(8) TSIM_LH(10) TSIM_LH(12) TSIM_LH(14) TSIM_LH(16) TSIM_LH(20)
 #undef TSIM_LH
           default: return tsim_fail(TSIM_ESTATE, "bad chunk count %d", p->v4_max_nch);
         }
@@ -1053,7 +1055,7 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
     if (grid4 > 0) ++p->path_count[TP_SAMPLE4];
     if (grid4 > 0) switch (p->v4_max_nch) {
 #define TSIM_L4(N) case N: hipLaunchKernelGGL((k_sample4<4, N>), dim3((unsigned)grid4), dim3(blk), lds4, s, a4); break;
-      TSIM_L4(2) TSIM_L4(4) TSIM_L4(6) TSIM_L4(8) TSIM_L4(10) TSIM_L4(12) TSIM_L4(14)
+      TSIM_L4(2) TSIM_L4(4) TSIM_L4(6) TSIM_L4(8) TSIM_L4(10) TSIM_L4(12) TSIM_L4(14) TSIM_L4(20)
 #undef TSIM_L4
       default: hipLaunchKernelGGL((k_sample4<4, 16>), dim3((unsigned)grid4), dim3(blk), lds4, s, a4); break;
     }

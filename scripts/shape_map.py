@@ -43,8 +43,8 @@ def device_f(backend, hp, num_f, p_bit, B, WF, count, seed):
     return bufs
 
 
-def measure(backend, program, num_f, p_bit, shots, steps_n, nf=12, repeats=3, check=False, shot_offset=0):
-    hp = backend.HipProgram(program)
+def measure(backend, program, num_f, p_bit, shots, steps_n, nf=12, repeats=3, check=False, shot_offset=0, pattern_tables=None):
+    hp = backend.HipProgram(program, pattern_tables=pattern_tables)
     n_out = program.num_outputs
     WF, WO, RB = max(1, (num_f + 63) // 64), (n_out + 63) // 64, (n_out + 7) // 8
     fl = device_f(backend, hp, num_f, p_bit, shots, WF, nf, seed=47)

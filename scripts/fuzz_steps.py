@@ -20,13 +20,47 @@ seed0 = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 bad = 0
 for ps in range(seed0, seed0 + n_prog):
     rng = np.random.default_rng(31000 + ps)
-    kind = ps % 5
+    kind = ps % 8  # 5, 6, 7: the shapes round 5 opened (several wide-path components / wide rows, 65..80 parameters, the general fused pass)
     if kind == 0:
         prog, cfg = synth.config_program("C2", approx=bool(rng.integers(0, 2)), live_padding=bool(rng.integers(0, 2)))
         nf = cfg["num_f"]
     elif kind == 1:
         prog, cfg = synth.config_program(str(rng.choice(["C3", "C4"])), approx=bool(rng.integers(0, 2)))
         nf = cfg["num_f"]
+    elif kind == 5:  # k_sample_wide, one pass per component: 1..3 components of 66..250 selected bits (sometimes a narrow one too), f rows up to 1500 bits
+        nf = int(rng.choice([320, 600, 1500]))
+        comps = []
+        for _ in range(int(rng.integers(1, 4))):
+            n = int(rng.integers(1, 9)); F = int(rng.integers(66, 251))
+            G = [int(rng.integers(1, 3))]
+            for _k in range(n):
+                G.append(G[-1] + int(rng.integers(0, 2)))
+            comps.append(dict(n=n, F=F, G=G, density=0.08))
+        if rng.random() < 0.5:
+            comps.insert(int(rng.integers(0, len(comps) + 1)), dict(n=int(rng.integers(1, 4)), F=int(rng.integers(4, 40)), G=[2, 3, 4, 6][: int(rng.integers(2, 5))], density=0.2))
+        for c in comps:
+            c["G"] = (list(c["G"]) + [c["G"][-1]] * 9)[: c["n"] + 1]
+        prog = synth.physical_program(num_f=nf, n_direct=int(rng.integers(0, 200)), components=comps, seed=int(rng.integers(0, 2**31)),
+                                      shuffle_outputs=bool(rng.integers(0, 2)), direct_flip_fraction=0.2, identity_direct=bool(rng.integers(0, 2)))
+    elif kind == 6:  # 65..80 parameters with at most 64 selected bits: x in three words (tests/test_gpu_x3.py)
+        nf = int(rng.choice([64, 96, 128]))
+        n = int(rng.integers(2, 9)); F = int(rng.integers(max(57, 65 - n), 65))
+        G = [int(rng.integers(1, 4))]
+        for _k in range(n):
+            G.append(G[-1] + int(rng.integers(0, 5)))
+        prog = synth.physical_program(num_f=nf, n_direct=int(rng.integers(0, 30)), components=[dict(n=n, F=F, G=G)], seed=int(rng.integers(0, 2**31)),
+                                      shuffle_outputs=bool(rng.integers(0, 2)), direct_flip_fraction=0.3, approx=bool(rng.integers(0, 3) == 0))
+    elif kind == 7:  # k_sample_gen: wide rows / many outputs around narrow components
+        nf = int(rng.choice([160, 320, 600]))
+        comps = []
+        for _ in range(int(rng.integers(1, 5))):
+            n = int(rng.integers(1, 7)); F = int(rng.integers(2, 50))
+            G = [int(rng.integers(1, 3))]
+            for _k in range(n):
+                G.append(G[-1] + int(rng.integers(0, 4)))
+            comps.append(dict(n=n, F=F, G=G, density=0.2))
+        prog = synth.physical_program(num_f=nf, n_direct=int(rng.integers(40, min(nf, 240))), components=comps, seed=int(rng.integers(0, 2**31)),
+                                      shuffle_outputs=bool(rng.integers(0, 2)), direct_flip_fraction=0.3, identity_direct=bool(rng.integers(0, 2)))
     else:  # random shapes: one component of 1..8 outputs (the specialised pass) or several (the general fused pass)
         nf = int(rng.choice([20, 40, 64, 90, 128]))
         ncomp = 1 if kind in (2, 3) else int(rng.integers(2, 4))

@@ -1,5 +1,6 @@
-"""Narrow components of 65..80 parameters (at most 64 selected f bits + outcome bits): since round 5 the chunk-table kernels
-hold x in three words (tsim_kernel4.hip.h sample4_block, tsim_kernel4h.hip.h: NCH = 20), so such a program keeps the narrow
+"""Narrow components of 65..128 parameters: since round 5 the chunk-table kernels hold x in three words (at most 64 selected
+f bits + outcome bits up to bit 79: NCH = 20) or four (up to 128 parameters, f_sel itself beyond 64 bits: NCH = 32, first pass
+k_sample_gen, tables to weight 4) - tsim_kernel4.hip.h sample4_block, tsim_kernel4h.hip.h - so such a program keeps the narrow
 family - fused first pass, pattern tables to weight 5+, block-per-row / per-shot hard-row kernels - instead of the wide
 path (class F60 of scripts/shape_map.py: one bit past the old wall cost 3.3x).  The reference has no such wall
 (src/tsim/sampler.py:28-81 concatenates f_sel and the outcome bits whatever their number).  Every case against the C oracle:
@@ -32,7 +33,13 @@ SHAPES = {
     "F64n10": dict(num_f=96, n_direct=20, components=[_n(10, 64, 6)], shuffle_outputs=True),  # 74, ten outputs (k_sample_lw_multi / gen)
     "two": dict(num_f=128, n_direct=30, components=[_n(3, 63, 10), _n(6, 61, 16)], shuffle_outputs=True, direct_flip_fraction=0.2),  # 66 and 67
     "mixed": dict(num_f=64, n_direct=8, components=[_n(2, 20, 8), _n(4, 62, 20)]),        # an ordinary component + a 66-parameter one
+    # four words of x (NCH = 32): more than 64 SELECTED bits - first pass k_sample_gen, tables to weight 4 (wide binomials)
+    "F70n5": dict(num_f=96, n_direct=4, components=[_n(5, 70, 40)]),                      # 75 parameters (shape class F70)
+    "F100n6": dict(num_f=160, n_direct=30, components=[_n(6, 100, 10)], shuffle_outputs=True),  # 106
+    "F120n8": dict(num_f=128, n_direct=6, components=[_n(8, 120, 5)]),                    # 128: the last bit of the fourth word
+    "bigtwo": dict(num_f=192, n_direct=40, components=[_n(3, 30, 6), _n(4, 90, 12), _n(2, 70, 8)], shuffle_outputs=True, direct_flip_fraction=0.2),
 }
+BIG = ("F70n5", "F100n6", "F120n8", "bigtwo")
 
 
 def _program(name, **kw):
@@ -74,6 +81,8 @@ def test_steps_api_equals_oracle(hip, name, packed):
     outs, _ = _run_steps(hp, prog, fs, key, nf, packed=packed, calls=[4, 5], devs=devs)
     paths = hp.path_counts()
     assert not ({"sample4w", "lw_lds_wide", "wide", "rows"} & set(paths)), paths
+    if name in BIG:
+        assert paths.get("gen", 0) >= 1 and not ({"lw_fast", "lw_fastm", "lw_multi", "lw_reg", "lw_lds", "lw_fast1"} & set(paths)), paths  # f_sel beyond 64 bits: k_sample_gen only
     _, subs = _subkeys(key, n)
     for i in range(n):
         want, wdev = orc.sample_program(fs[i], subs[i], return_devs=True)
@@ -82,7 +91,7 @@ def test_steps_api_equals_oracle(hip, name, packed):
     hp.close()
 
 
-@pytest.mark.parametrize("name", ["F60n5", "F64n8", "two"])
+@pytest.mark.parametrize("name", ["F60n5", "F64n8", "two", "F70n5", "F120n8", "bigtwo"])
 @pytest.mark.parametrize("mode", ["tables_off", "dense", "approx"])
 def test_every_row_on_the_chunk_table_kernels(hip, name, mode):
     """Tables off: k_sample4<4, 20> on every row (and its normalisation-check block).  Dense noise: most rows hard - the
@@ -107,14 +116,15 @@ def test_every_row_on_the_chunk_table_kernels(hip, name, mode):
     hp.close()
 
 
-def test_three_words_equal_the_wide_path(hip):
-    """The same batches with x in three words and on the round-4 path (`x3=0`: the component is 'wide'): identical rows, and
-    each handle really took its path."""
-    prog, nf = _program("F60n5")
+@pytest.mark.parametrize("name,off", [("F60n5", "x3=0"), ("F70n5", "x4=0")])
+def test_three_and_four_words_equal_the_wide_path(hip, name, off):
+    """The same batches with x in three / four words and on the round-4 path (`x3=0` / `x4=0`: the component is 'wide'):
+    identical rows, and each handle really took its path."""
+    prog, nf = _program(name)
     fs = [synth.synth_f(5000, nf, (1.0 + i) / 60, seed=9 + i) for i in range(4)]
     key = prng.key(4)
     res = []
-    for tune in (None, "x3=0"):
+    for tune in (None, off):
         hp = _handle(hip, prog, env={"TSIM_AMD_TUNE": tune} if tune else None)
         info = hp.info()
         hp.path_counts(reset=True)

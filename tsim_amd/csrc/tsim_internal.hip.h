@@ -168,8 +168,13 @@ struct tsim_program {
   bool lw_reg = false;        // the register form of pass 1 applies (narrow f rows, ascending f_selection)
   int lwfm_off = 0;           // fast record of programs with 2..4 components of <= 8 outputs each (k_sample_lw_fastm), 0 = none
   int wr_off = 0;             // image offset of the first wide record (k_sample_wide, tsim_wide.hip.h), 0 = none
+  bool narrow_big = false;    // narrow program with a component of more than 64 selected bits: first pass k_sample_gen only, tables to weight 4
   bool wide_big = false;      // wide program with f indices >= 512: the round-2 wide kernels (16 selection-mask words) must not see it
   std::vector<int> wr_offs;   // one wide record per component (the passes of k_sample_wide, in component order)
+  // streams of the CALLER that carried sampling launches of this handle (the device entry points take one): what a table swap
+  // must drain besides the handle's own lanes.  More than 16 distinct ones: caller_streams_overflow, the swap drains the device.
+  std::vector<hipStream_t> caller_streams;
+  bool caller_streams_overflow = false;
   int gr_off = 0;             // image offset of the gen record (any narrow program: k_sample_gen, tsim_gen.hip.h), 0 = none
   int lwf_off = 0;            // image offset of the fast record (one component of <= 8 outputs: k_sample_lw_fast), 0 = none
   // Launch slots: slot 0 serves the serial API (everything on the caller's stream); slots 1..4 serve
@@ -260,6 +265,7 @@ struct tsim_program {
                               // slower, profiles/r05/hard_tree.txt: the grid waits for the normalisation-check row either way
     bool shallow = true;      // shallow=0: finalize builds the default table depth at once (round 4) instead of starting shallow
     int gen = 1;              // gen: k_sample_gen for fused groups - 0 never, 1 where no register first pass applies, 2 wherever it applies
+    bool x4 = true;           // x4=0: components of 81..128 parameters or more than 64 selected bits stay on the wide path
     bool x3 = true;           // x3=0: components of 65..80 parameters (F <= 64) stay on the wide path (round-4 behaviour)
     int wide_depth = 4;       // wide_depth=N: default table depth of wide components (finalize builds at most weight 3; the rest in the background)
     int wide_glob = 48;       // wide_glob=N: components of up to N graphs whose column tables do not fit the LDS run k_sample_wide with the tables in the L2
@@ -283,6 +289,7 @@ struct tsim_program {
   bool h_attr_set = false;    // k_sample4h: large dynamic LDS enabled
   bool hm_attr_set = false;   // k_sample4h_multi: the same
   unsigned gen_attr_set = 0;  // k_sample_gen<WO32>: bit WO32
+  unsigned x4_attr_set = 0;   // NCH = 32 instantiations (81..128 parameters) whose dynamic-LDS limit was raised: 1 over, 2 hw, 4 k_sample4
   unsigned wide_attr_set = 0; // k_sample_wide<WO32, K>: bit WO32
   int lw_off = 0;             // image offset of the LW component records
   int lw_direct_prog = 0;     // image offset of the direct-output gather program

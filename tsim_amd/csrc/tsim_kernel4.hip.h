@@ -342,10 +342,11 @@ __device__ __forceinline__ void sample4_block(const SampleArgs &A, int comp4_off
 
     // x = (f_sel, outcome bits): two words - or three (NCH > 16, round 5): components of at most 64 selected f bits whose
     // F + n_out parameters pass 64 (class F60 of scripts/shape_map.py).  The f bits never leave words 0 and 1.
-    constexpr int XW = NCH > 16 ? 3 : 2;
-    uint32_t x[3] = {0u, 0u, 0u};
+    // Four words (NCH = 32, end of round 5): up to 128 parameters, f_sel itself may pass 64 bits (class F70).
+    constexpr int XW = NCH > 24 ? 4 : NCH > 16 ? 3 : 2;
+    uint32_t x[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
-    for (int w = 0; w < 2; ++w) {
+    for (int w = 0; w < XW; ++w) {
       uint32_t v = 0;
       const int lo = w * 32;
       const int hi = min((int)F, lo + 32);
@@ -360,7 +361,8 @@ __device__ __forceinline__ void sample4_block(const SampleArgs &A, int comp4_off
       const uint32_t bm = 1u << (bitpos & 31u), bw = bitpos >> 5;
       if (bw == 0u) x[0] = v ? (x[0] | bm) : (x[0] & ~bm);
       else if (bw == 1u || XW == 2) x[1] = v ? (x[1] | bm) : (x[1] & ~bm);
-      else x[2] = v ? (x[2] | bm) : (x[2] & ~bm);
+      else if (bw == 2u || XW == 3) x[2] = v ? (x[2] | bm) : (x[2] & ~bm);
+      else x[3] = v ? (x[3] | bm) : (x[3] & ~bm);
     };
 
     // Sparse-f decision, block-uniform: every lane has at most 4 set f bits and the component has
@@ -402,7 +404,7 @@ __device__ __forceinline__ void sample4_block(const SampleArgs &A, int comp4_off
           uint32_t en[NCH];
 #pragma unroll
           for (int c = 0; c < NCH; ++c) {
-            const uint32_t w = (c < 8) ? x[0] : (c < 16) ? x[1] : x[2];
+            const uint32_t w = (c < 8) ? x[0] : (c < 16) ? x[1] : (c < 24) ? x[2] : x[3];
             en[c] = ((w >> (4 * (c & 7))) & 15u) * 16u + c * Tile4<GT>::kChunkBytes;
           }
           if (lvl_fixed) eval_level4<GT, NCH, true, 256>(A.img, img, lvl, en, NCH * Tile4<GT>::kChunkBytes, lvl[L4_TABLES], lds_tab, re, im);

@@ -274,10 +274,10 @@ __device__ __forceinline__ void sample4h_rows(const SampleArgs &A, int comp4_off
     cptr outpos = img + comp[C_OUTPOS];
     const uint32_t keybase = comp[C_KEYBASE];
 
-    constexpr int XW = NCH > 16 ? 3 : 2;  // (a third word of x for F + n_out in 65..80, F <= 64: tsim_kernel4.hip.h sample4_block)
-    uint32_t x[3] = {0u, 0u, 0u};
+    constexpr int XW = NCH > 24 ? 4 : NCH > 16 ? 3 : 2;  // (words of x: tsim_kernel4.hip.h sample4_block)
+    uint32_t x[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
-    for (int w = 0; w < 2; ++w) {
+    for (int w = 0; w < XW; ++w) {
       uint32_t v = 0;
       const int lo = w * 32;
       const int hi = min((int)F, lo + 32);
@@ -291,7 +291,8 @@ __device__ __forceinline__ void sample4h_rows(const SampleArgs &A, int comp4_off
       const uint32_t bm = 1u << (bitpos & 31u), bw = bitpos >> 5;
       if (bw == 0u) x[0] = v ? (x[0] | bm) : (x[0] & ~bm);
       else if (bw == 1u || XW == 2) x[1] = v ? (x[1] | bm) : (x[1] & ~bm);
-      else x[2] = v ? (x[2] | bm) : (x[2] & ~bm);
+      else if (bw == 2u || XW == 3) x[2] = v ? (x[2] | bm) : (x[2] & ~bm);
+      else x[3] = v ? (x[3] | bm) : (x[3] & ~bm);
     };
 
     float prev = 0.0f, maxdev = 0.0f;
@@ -302,7 +303,7 @@ __device__ __forceinline__ void sample4h_rows(const SampleArgs &A, int comp4_off
       uint32_t en[NCH];
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {
-        const uint32_t w = (c < 8) ? x[0] : (c < 16) ? x[1] : x[2];
+        const uint32_t w = (c < 8) ? x[0] : (c < 16) ? x[1] : (c < 24) ? x[2] : x[3];
         en[c] = ((w >> (4 * (c & 7))) & 15u) * 16u + c * Tile4<GT>::kChunkBytes;
       }
       float re, im;

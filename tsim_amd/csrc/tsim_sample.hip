@@ -294,13 +294,18 @@ static int launch_over(tsim_program *p, const SampleArgs *ctx, int n_ctx, uint32
   const int blk = 256;
   const size_t tile_bytes = std::max((size_t)p->v4_max_nch * 16, (size_t)p->v4_max_sent) * p->v4_gt * 16;
   const size_t lds4 = (size_t)(2 * ctx[0].WF + 2 * ctx[0].WO) * blk * 4 + 2 * tile_bytes;
-  if (lds4 > 64 * 1024) return tsim_fail(TSIM_ENOTSUP, "v4 kernel needs %zu B of LDS", lds4);
+  if (lds4 > (p->v4_max_nch == 32 ? 160 : 64) * 1024) return tsim_fail(TSIM_ENOTSUP, "v4 kernel needs %zu B of LDS", lds4);
   const unsigned grid = (unsigned)p->n_cu;
   ++p->path_count[TP_OVER];
   switch (p->v4_max_nch) {
 #define TSIM_LO(N) case N: hipLaunchKernelGGL((k_sample4_over<4, N>), dim3(grid), dim3(blk), lds4, hs, M); break;
     TSIM_LO(2) TSIM_LO(4) TSIM_LO(6) TSIM_LO(8) TSIM_LO(10) TSIM_LO(12) TSIM_LO(14) TSIM_LO(20)
 #undef TSIM_LO
+    case 32: {  // 81..128 parameters: two 32-KB tiles - more dynamic LDS than a kernel gets without asking
+      auto kfn = k_sample4_over<4, 32>;
+      if (!(p->x4_attr_set & 1u)) { HIP_TRY(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096)); p->x4_attr_set |= 1u; }
+      hipLaunchKernelGGL(kfn, dim3(grid), dim3(blk), lds4, hs, M);
+    } break;
     default: hipLaunchKernelGGL((k_sample4_over<4, 16>), dim3(grid), dim3(blk), lds4, hs, M); break;
   }
   HIP_TRY(hipGetLastError());
@@ -339,7 +344,7 @@ static int launch_hw(tsim_program *p, const SampleArgs *ctx, int n_ctx, int max_
   if (workers) {
     const size_t tile_bytes = std::max((size_t)p->v4_max_nch * 16, (size_t)p->v4_max_sent) * p->v4_gt * 16;
     ldsw = std::max(ldsw, (size_t)(2 * ctx[0].WF + 2 * ctx[0].WO) * 256 * 4 + 2 * tile_bytes);
-    if (ldsw > 64 * 1024) return tsim_fail(TSIM_ENOTSUP, "v4 kernel needs %zu B of LDS", ldsw);
+    if (ldsw > (p->v4_max_nch == 32 ? 160 : 64) * 1024) return tsim_fail(TSIM_ENOTSUP, "v4 kernel needs %zu B of LDS", ldsw);
     grid += (unsigned)(2 * p->n_cu);
   }
   // (blocks of 512 / 1024 threads - more helper waves per row - were tried: no faster alone, the row pass is not the chain;
@@ -353,6 +358,11 @@ static int launch_hw(tsim_program *p, const SampleArgs *ctx, int n_ctx, int max_
   } else if (wmax > 2) {  // parameter rows of 65..128 bits (chunk tables, and so workers, only for 65..80 parameters: NCH = 20)
     switch (nch) {
       TSIM_LHW(4, 0) TSIM_LHW(4, 20)
+      case 32: {
+        auto kfn = k_sample_hw<4, 32>;
+        if (!(p->x4_attr_set & 2u)) { HIP_TRY(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096)); p->x4_attr_set |= 2u; }
+        hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), ldsw, hs, H);
+      } break;
       default: return tsim_fail(TSIM_ESTATE, "hard-row workers need chunk tables (%d chunks)", nch);
     }
   } else switch (nch) {
@@ -442,7 +452,7 @@ static int flush_batch(tsim_program *p) {
     ++p->path_count[TP_SAMPLE4H_MULTI];                                                                      \
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(NW * 64), lds_m, hs, M);                                        \
   } break;
-    TSIM_LHM(2) TSIM_LHM(4) TSIM_LHM(6) TSIM_LHM(8) TSIM_LHM(10) TSIM_LHM(12) TSIM_LHM(14) TSIM_LHM(16) TSIM_LHM(20)
+    TSIM_LHM(2) TSIM_LHM(4) TSIM_LHM(6) TSIM_LHM(8) TSIM_LHM(10) TSIM_LHM(12) TSIM_LHM(14) TSIM_LHM(16) TSIM_LHM(20) TSIM_LHM(32)
 #undef TSIM_LHM
     default: return tsim_fail(TSIM_ESTATE, "bad chunk count %d", p->v4_max_nch);
   }
@@ -722,6 +732,14 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
                          int slot = 0, const LaunchPlan *plan_in = nullptr, bool out_bit_packed = false) {
   if (!p->sampleable) return tsim_fail(TSIM_ESTATE, "program has joint-mode components (evaluate-only)");
   if (B < 0 || num_f < 0 || shot_offset < 0) return tsim_fail(TSIM_EINVAL, "negative B/num_f/shot_offset");
+  {  // a stream that is not the handle's own: the caller's - a table swap has to drain it too (tsim_tables_extend_poll)
+    bool own = s == p->stream || s == p->ext_stream;
+    for (int k = 1; k <= TSIM_PIPELINE_SLOTS && !own; ++k) own = p->slots[k].side_ready && p->slots[k].side == s;
+    if (!own && std::find(p->caller_streams.begin(), p->caller_streams.end(), s) == p->caller_streams.end()) {
+      if (p->caller_streams.size() < 16) p->caller_streams.push_back(s);
+      else p->caller_streams_overflow = true;
+    }
+  }
   if (p->max_f_index >= num_f)
     return tsim_fail(TSIM_EINVAL, "program references f index %d but num_f=%d", p->max_f_index, num_f);
   if (B == 0 || p->num_outputs == 0) return 0;
@@ -765,6 +783,9 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
   // f rows wider than the round-2 wide kernels read (p->wide_big): k_sample_wide, or every row on the row kernel
   const bool big_out = p->wide_big && !(use_tables && !d_row_index && wide_applies(p, B, num_f, shot_offset) && wide_buffers_ok(p, a));
   if (big_out) use_tables = false;
+  // a narrow program with more than 64 selected bits in a component: the one-batch first passes (k_sample_lw / _lw_reg / _lw_fast as a
+  // group of one) hold f_sel in 64 bits - every row on the chunk-table kernel here; the fused groups ride k_sample_gen
+  if (p->narrow_big) use_tables = false;
   if (int r = tsim_tables_slice(p, s)) return r;  // (a table build in the background: its next slice goes first)
   // The sparse-column pass (k_sample4w) over every row, or - behind a pattern-table first pass - over that pass's
   // hard-row lists (from_lists; `a` then describes them).  Its own overflow (more than K set bits, the check row)
@@ -986,7 +1007,7 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
     const int blk = p->knobs.v4_block;
     const size_t tile_bytes = std::max((size_t)p->v4_max_nch * 16, (size_t)p->v4_max_sent) * p->v4_gt * 16;
     const size_t lds4 = (size_t)(2 * a.WF + 2 * a.WO) * blk * 4 + 2 * tile_bytes;
-    if (lds4 > 64 * 1024) return tsim_fail(TSIM_ENOTSUP, "v4 kernel needs %zu B of LDS", lds4);
+    if (lds4 > (p->v4_max_nch == 32 ? 160 : 64) * 1024) return tsim_fail(TSIM_ENOTSUP, "v4 kernel needs %zu B of LDS", lds4);
     if (a.row_lists > 1 && p->knobs.hard_kernel && plan.hard_kernel) {
       // short row lists (second pass of a two-pass launch): NW waves per 64 rows, tsim_kernel4h.hip.h
       constexpr int NW = TSIM_HARD_NW;
@@ -1035,7 +1056,7 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
     hipLaunchKernelGGL(kfn, dim3((unsigned)gridh), dim3(NW * 64), ldsh, s, ah, group_tiles, loop_stride,    \
                        p->d_feedback);                                                                      \
   } break;
-          TSIM_LH(2) TSIM_LH(4) TSIM_LH(6) TSIM_LH(8) TSIM_LH(10) TSIM_LH(12) TSIM_LH(14) TSIM_LH(16) TSIM_LH(20)
+          TSIM_LH(2) TSIM_LH(4) TSIM_LH(6) TSIM_LH(8) TSIM_LH(10) TSIM_LH(12) TSIM_LH(14) TSIM_LH(16) TSIM_LH(20) TSIM_LH(32)
 #undef TSIM_LH
           default: return tsim_fail(TSIM_ESTATE, "bad chunk count %d", p->v4_max_nch);
         }
@@ -1057,6 +1078,11 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
 #define TSIM_L4(N) case N: hipLaunchKernelGGL((k_sample4<4, N>), dim3((unsigned)grid4), dim3(blk), lds4, s, a4); break;
       TSIM_L4(2) TSIM_L4(4) TSIM_L4(6) TSIM_L4(8) TSIM_L4(10) TSIM_L4(12) TSIM_L4(14) TSIM_L4(20)
 #undef TSIM_L4
+      case 32: {
+        auto kfn = k_sample4<4, 32>;
+        if (!(p->x4_attr_set & 4u)) { HIP_TRY(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096)); p->x4_attr_set |= 4u; }
+        hipLaunchKernelGGL(kfn, dim3((unsigned)grid4), dim3(blk), lds4, s, a4);
+      } break;
       default: hipLaunchKernelGGL((k_sample4<4, 16>), dim3((unsigned)grid4), dim3(blk), lds4, s, a4); break;
     }
     HIP_TRY(hipGetLastError());

@@ -118,7 +118,7 @@ static int tables_build_at(tsim_program *p, int rec_off, const TsimTablePlan &t,
     LwBuildArgs a;
     a.img = p->d_img;
     a.patbits = nullptr;
-    a.wide_binom_off = p->lw_wide ? p->lw_binom_off : 0;
+    a.wide_binom_off = (p->lw_wide || p->narrow_big) ? p->lw_binom_off : 0;
     a.bases_off = rec_off + (int)ci * LW_WORDS + LW_BASES_INLINE;
     a.wmax = t.wmax[ci];
     a.tab = tab + tab_off;
@@ -206,7 +206,7 @@ static void ext_alloc_thread(tsim_program *p) {
     LwBuildArgs a;
     a.img = p->d_img;
     a.patbits = nullptr;
-    a.wide_binom_off = p->lw_wide ? p->lw_binom_off : 0;
+    a.wide_binom_off = (p->lw_wide || p->narrow_big) ? p->lw_binom_off : 0;
     a.bases_off = p->lw_shadow_off + (int)ci * LW_WORDS + LW_BASES_INLINE;
     a.wmax = p->ext_plan.wmax[ci];
     a.tab = tab + tab_off;
@@ -372,10 +372,26 @@ int tsim_tables_extend_poll(tsim_program *p, bool wait) {
     return 0;
   }
   p->ext_pending = false;
-  // The component records in the device image are rewritten below and the old table is freed: nothing may be in
-  // flight - not on the handle's lanes and not on a stream the CALLER passed to the device entry points either
-  // (include/tsim_hip.h lets it).  Once per handle.
-  HIP_TRY(hipDeviceSynchronize());
+  // The component records in the device image are rewritten below and the old table is freed: nothing of THIS handle may
+  // be in flight - not on its lanes and not on a stream the CALLER passed to the device entry points either
+  // (include/tsim_hip.h lets it; launch_sample notes them).  Round 4 drained the whole device here - other handles' and the
+  // host application's streams included; now only what can hold a reader of the old records.
+  if (p->caller_streams_overflow) {
+    HIP_TRY(hipDeviceSynchronize());
+  } else {
+    if (p->stream) HIP_TRY(hipStreamSynchronize(p->stream));
+    for (int k = 1; k <= TSIM_PIPELINE_SLOTS; ++k) {
+      tsim_program::Slot &sl = p->slots[k];
+      if (sl.side_ready && sl.side && sl.side != p->stream) HIP_TRY(hipStreamSynchronize(sl.side));
+    }
+    bool gone = false;  // (a caller may have destroyed its stream since: HIP refuses the handle - then the device-wide drain)
+    for (hipStream_t cs : p->caller_streams)
+      if (hipStreamSynchronize(cs) != hipSuccess) { (void)hipGetLastError(); gone = true; }
+    if (p->ext_stream) HIP_TRY(hipStreamSynchronize(p->ext_stream));
+    if (gone) HIP_TRY(hipDeviceSynchronize());
+  }
+  p->caller_streams.clear();  // (noted again by the launches that use them)
+  p->caller_streams_overflow = false;
   for (size_t ci = 0; ci < p->comps.size(); ++ci) {
     const uint32_t *sh = &p->img[(size_t)p->lw_shadow_off + ci * LW_WORDS];
     uint32_t *r = &p->img[(size_t)p->lw_off + ci * LW_WORDS];

@@ -43,11 +43,12 @@ for ps in range(seed0, seed0 + n_prog):
         prog = synth.physical_program(num_f=nf, n_direct=int(rng.integers(0, 200)), components=comps, seed=int(rng.integers(0, 2**31)),
                                       shuffle_outputs=bool(rng.integers(0, 2)), direct_flip_fraction=0.2, identity_direct=bool(rng.integers(0, 2)))
     elif kind == 6:  # 65..80 parameters with at most 64 selected bits: x in three words (tests/test_gpu_x3.py)
-        nf = int(rng.choice([64, 96, 128]))
-        n = int(rng.integers(2, 9)); F = int(rng.integers(max(57, 65 - n), 65))
-        G = [int(rng.integers(1, 4))]
+        nf = int(rng.choice([128, 160]))
+        n = int(rng.integers(2, 9))
+        F = int(rng.integers(max(57, 65 - n), 65)) if rng.random() < 0.5 else int(rng.integers(65, 129 - n))  # three / four words of x (with >= 32 graphs; fewer: the wide path)
+        G = [int(rng.integers(1, 6))]
         for _k in range(n):
-            G.append(G[-1] + int(rng.integers(0, 5)))
+            G.append(G[-1] + int(rng.integers(0, 8)))
         prog = synth.physical_program(num_f=nf, n_direct=int(rng.integers(0, 30)), components=[dict(n=n, F=F, G=G)], seed=int(rng.integers(0, 2**31)),
                                       shuffle_outputs=bool(rng.integers(0, 2)), direct_flip_fraction=0.3, approx=bool(rng.integers(0, 3) == 0))
     elif kind == 7:  # k_sample_gen: wide rows / many outputs around narrow components

@@ -35,9 +35,9 @@ SHAPES = {
     "mixed": dict(num_f=64, n_direct=8, components=[_n(2, 20, 8), _n(4, 62, 20)]),        # an ordinary component + a 66-parameter one
     # four words of x (NCH = 32): more than 64 SELECTED bits - first pass k_sample_gen, tables to weight 4 (wide binomials)
     "F70n5": dict(num_f=96, n_direct=4, components=[_n(5, 70, 40)]),                      # 75 parameters (shape class F70)
-    "F100n6": dict(num_f=160, n_direct=30, components=[_n(6, 100, 10)], shuffle_outputs=True),  # 106
-    "F120n8": dict(num_f=128, n_direct=6, components=[_n(8, 120, 5)]),                    # 128: the last bit of the fourth word
-    "bigtwo": dict(num_f=192, n_direct=40, components=[_n(3, 30, 6), _n(4, 90, 12), _n(2, 70, 8)], shuffle_outputs=True, direct_flip_fraction=0.2),
+    "F100n6": dict(num_f=160, n_direct=30, components=[_n(6, 100, 12)], shuffle_outputs=True),  # 106
+    "F120n8": dict(num_f=128, n_direct=6, components=[_n(8, 120, 8)]),                    # 128: the last bit of the fourth word
+    "bigtwo": dict(num_f=192, n_direct=40, components=[_n(3, 30, 6), _n(4, 90, 16), _n(2, 70, 20)], shuffle_outputs=True, direct_flip_fraction=0.2),
 }
 BIG = ("F70n5", "F100n6", "F120n8", "bigtwo")
 

@@ -265,7 +265,7 @@ struct tsim_program {
                               // slower, profiles/r05/hard_tree.txt: the grid waits for the normalisation-check row either way
     bool shallow = true;      // shallow=0: finalize builds the default table depth at once (round 4) instead of starting shallow
     int gen = 1;              // gen: k_sample_gen for fused groups - 0 never, 1 where no register first pass applies, 2 wherever it applies
-    bool x4 = true;           // x4=0: components of 81..128 parameters or more than 64 selected bits stay on the wide path
+    int x4 = 32;              // x4=N: components of 81..128 parameters or more than 64 selected bits AND at least N graphs take the narrow family (four words of x); 0: never
     bool x3 = true;           // x3=0: components of 65..80 parameters (F <= 64) stay on the wide path (round-4 behaviour)
     int wide_depth = 4;       // wide_depth=N: default table depth of wide components (finalize builds at most weight 3; the rest in the background)
     int wide_glob = 48;       // wide_glob=N: components of up to N graphs whose column tables do not fit the LDS run k_sample_wide with the tables in the L2

@@ -290,7 +290,7 @@ extern "C" int tsim_program_finalize(tsim_program *p, int32_t device) {
     p->knobs.wide_tables = tune_ll("wide_tables", 1) != 0;
     p->knobs.wide_compact = tune_ll("wide_compact", 1) != 0;
     p->knobs.x3 = tune_ll("x3", 1) != 0;
-    p->knobs.x4 = tune_ll("x4", 1) != 0;
+    p->knobs.x4 = (int)std::max(0ll, tune_ll("x4", 32));
     p->knobs.wide_depth = (int)std::max(0ll, std::min(4ll, tune_ll("wide_depth", 4)));
     p->knobs.wide_glob = (int)std::max(0ll, tune_ll("wide_glob", 48));
     p->knobs.wide_passes = (int)std::max(1ll, std::min(16ll, tune_ll("wide_passes", 8)));
@@ -497,7 +497,11 @@ retry_pack:
       int maxp = 1;
       for (auto &lv : c.levels) maxp = std::max(maxp, lv.P);
       // (81..128, or more than 64 SELECTED bits - knobs.x4, end of round 5: four words, and the first pass must be k_sample_gen)
-      if (maxp > 64) ok = ok && p->knobs.x3 && c.n_levels == c.n_out + 1 && ((c.F <= 64 && maxp <= 80) || (p->knobs.x4 && maxp <= 128));
+      // Four words only for components of MANY graphs (knobs.x4 = the least number, 32): those are what k_sample_wide cannot hold
+      // (column tables beyond the LDS, a chain of graphs per dense pass); a 100-bit component of 8 graphs is better off there.
+      int gtot = 0;
+      for (auto &lv : c.levels) gtot += lv.G;
+      if (maxp > 64) ok = ok && p->knobs.x3 && c.n_levels == c.n_out + 1 && ((c.F <= 64 && maxp <= 80) || (p->knobs.x4 > 0 && gtot >= p->knobs.x4 && maxp <= 128));
     }
     // wide components (more than 64 parameters): column tables only, for the sparse-column kernel k_sample4w.
     // Needs sequential components of at most 8 outputs over at most 256 ascending f indices below 512.
@@ -641,7 +645,7 @@ retry_pack:
     // (F + n_out up to 80 with F <= 64 since round 5: the chunk-table kernels hold x in three words then - p->v4 says whether they took the program)
     for (auto &c : p->comps)
       narrow = narrow && (c.n_levels == c.n_out + 1) && c.n_out <= TSIMK_LW_MAX_NOUT &&
-               (c.F + c.n_out <= 64 || (p->v4 && c.F <= 64 && c.F + c.n_out <= 80) || (p->v4 && p->knobs.x4 && c.F + c.n_out <= 128));
+               (c.F + c.n_out <= 64 || (p->v4 && c.F <= 64 && c.F + c.n_out <= 80) || (p->v4 && p->knobs.x4 > 0 && c.F + c.n_out <= 128));
     // more than 64 selected bits somewhere in a narrow program: every first pass but k_sample_gen holds f_sel in 64 bits, and the
     // closed-form binomials of the table builder end at b = 64 (tsim_lw.hip.h) - tables to weight 4 through the [4][256]
     // table of the wide path, gen or the full kernel (launch_sample)
@@ -665,7 +669,7 @@ retry_pack:
       // stored weight by weight, so the rows most shots read (weight 0..2) are a small cache-resident prefix
       // whatever the total; the heavier tail is read rarely.
       const bool pinned = p->lw_weight_cap >= 0;
-      const int hw_cap = (p->lw_wide || p->narrow_big) ? TSIMK_LWW_MAX_WEIGHT : TSIMK_LW_MAX_WEIGHT;
+      const int hw_cap = p->lw_wide ? TSIMK_LWW_MAX_WEIGHT : TSIMK_LW_MAX_WEIGHT;
       p->lw_cap_max = pinned ? std::min(p->lw_weight_cap, hw_cap) : hw_cap;
       // (wide components: weight 4 since round 5 - C5's 2.1 GB lift the tabulated share of its rows from 43 % to 63 %, 46 -> 41 us
       // per 10^6 shots; finalize still builds weight 3 only, the rest follows in the background like every default depth.
@@ -946,14 +950,16 @@ retry_pack:
         p->lw_reg = p->max_f_index < 128 && p->num_outputs <= 64 && !p->narrow_big;
         for (auto &c : p->comps)
           for (int j = 1; j < c.F; ++j) p->lw_reg = p->lw_reg && c.f_selection[j] > c.f_selection[j - 1];
-        if (p->narrow_big) {  // the table builder's binomials C(b, k + 1), k < 4, b < 256 (as the wide path's)
+        if (p->narrow_big) {  // the table builder's binomials C(b, k + 1), k < 8, b < 256 (the wide path's [k][256] layout, saturated:
+          // a value beyond 32 bits belongs to no tabulated pattern - the plan keeps a component's patterns below 2^32 - and must
+          // only compare greater than every rank)
           while (img.size() % 16) img.push_back(0u);
           p->lw_binom_off = (int)img.size();
-          for (int k = 0; k < 4; ++k)
+          for (int k = 0; k < 8; ++k)
             for (int b = 0; b < 256; ++b) {
-              unsigned long long c = 1;
-              for (int i = 1; i <= k + 1; ++i) c = c * (unsigned long long)(b - (k + 1) + i > 0 ? b - (k + 1) + i : 0) / (unsigned long long)i;
-              img.push_back(b >= k + 1 ? (uint32_t)c : 0u);
+              unsigned __int128 c = 1;
+              for (int i = 1; i <= k + 1; ++i) c = c * (unsigned __int128)(b - (k + 1) + i > 0 ? b - (k + 1) + i : 0) / (unsigned __int128)i;
+              img.push_back(b >= k + 1 ? (c > (unsigned __int128)0xFFFFFFFFu ? 0xFFFFFFFFu : (uint32_t)c) : 0u);
             }
         }
         if (p->lw_reg) {  // binomial table of the rank computation: C(b, k + 1), k < 8, b < 64

@@ -432,7 +432,12 @@ static int flush_batch(tsim_program *p) {
     if (int r = launch_hw(p, M.ctx, M.n_ctx, max_lists, hs, partial)) return r;  // (its overflow workers ride in the same grid)
   } else {
   // (each block walks its list in strides of hb * 64 slots: at most 16 of them, the rest is the worker blocks')
-  const uint32_t cap4h = over_available(p) ? (uint32_t)M.loop_stride * 16u : 0u;
+  // ... or ONE stride when the last launches left so many hard rows that they are throughput work (more than 16384 per group -
+  // programs whose tables stop at weight 4, class F70: 1.4 % of the rows, 112 000 per group, took 450 us on the 8-waves-per-64-rows
+  // form; the per-shot workers take them at the full kernel's rate)
+  const uint32_t fb_sum = p->h_feedback ? p->h_feedback[0] : 0xFFFFFFFFu;
+  const bool many = fb_sum != 0xFFFFFFFFu && (unsigned long long)fb_sum * (unsigned)M.n_ctx > 16384ull;
+  const uint32_t cap4h = over_available(p) ? (uint32_t)M.loop_stride * (many ? 1u : 16u) : 0u;
   for (int i = 0; i < M.n_ctx; ++i) M.ctx[i].row_slot_end = (int)cap4h;
   unsigned grid = (unsigned)(M.n_ctx * M.blocks_per_ctx);
   M.main_blocks = grid;
@@ -441,7 +446,7 @@ static int flush_batch(tsim_program *p) {
   if (cap4h) {  // the workers ride in the same grid (a kernel of their own behind this one cost C3 4 %)
     const size_t tile_bytes = std::max((size_t)p->v4_max_nch * 16, (size_t)p->v4_max_sent) * p->v4_gt * 16;
     lds_m = std::max(lds_m, (size_t)(2 * M.ctx[0].WF + 2 * M.ctx[0].WO) * (NW * 64) * 4 + 2 * tile_bytes);
-    grid += (unsigned)p->n_cu;
+    grid += (unsigned)p->n_cu * (many ? 2u : 1u);
   }
   switch (p->v4_max_nch) {
 #define TSIM_LHM(N)                                                                                          \
@@ -1808,7 +1813,9 @@ extern "C" int tsim_sample_steps_device(tsim_program *p, int32_t n_steps, const 
       hard_geometry(p, WF, WO);
       TSIM_MARK("plan");
       have_plan = true;
-      fused = plan.defer && plan.use_tables && p->h_group_tiles >= 1;
+      // (narrow_big: the one-batch path runs no table pass - f_sel beyond 64 bits - so it never reports the list lengths `defer`
+      // waits for: fused whenever the plan says "tables"; long lists are the hard-row grid's worker blocks' business)
+      fused = (plan.defer || p->narrow_big) && plan.use_tables && p->h_group_tiles >= 1;
     }
     if (fused) {
       // even groups of at most TSIMK_LWM_MAX_STEPS batches

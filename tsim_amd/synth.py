@@ -642,6 +642,7 @@ SHAPE_CLASSES = {
     "F59": dict(near="C2", num_f=64, n_direct=5, components=[_narrow(5, 59)]),
     "F60": dict(near="C2", num_f=64, n_direct=4, components=[_narrow(5, 60)]),  # F + n = 65 parameters: a "wide" component in narrow rows
     "F70": dict(near="C2", num_f=96, n_direct=4, components=[_narrow(5, 70)]),  # more than 64 SELECTED bits and 140 graphs: the wall after F60's (x in three words serves F <= 64)
+    "F140": dict(near="C2", num_f=160, n_direct=4, components=[_narrow(5, 140)]),  # beyond 128 parameters with 140 graphs: the wall behind F70's (x in four words)
     "F255": dict(near="C5", num_f=320, n_direct=65, components=[_wide(3, 255)]),
     "F300": dict(near="C5", num_f=320, n_direct=20, components=[_wide(3, 300)]),
     "F200_f600": dict(near="C5", num_f=600, n_direct=118, components=[_wide(3, 200)]),  # max_f_index >= 512

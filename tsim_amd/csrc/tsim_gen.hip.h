@@ -27,7 +27,9 @@
 
 namespace tsimk {
 
-#define TSIMK_GEN_MAX_STEPS 8
+#ifndef TSIMK_GEN_MAX_STEPS
+#define TSIMK_GEN_MAX_STEPS 8  // (also in tsim_sample_internal.hip.h: the steps driver sizes its groups by it)
+#endif
 #define TSIMK_GEN_KEYS 40
 #define TSIMK_GEN_MAX_RUNS 1024
 #define TSIMK_GEN_MAX_COMP 16

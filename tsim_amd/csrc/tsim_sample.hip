@@ -13,16 +13,15 @@
 #include "tsim_kernel_hw.hip.h"
 #include "tsim_direct.hip.h"
 #include "tsim_lw_fastm.hip.h"
-#include "tsim_wide.hip.h"
-#include "tsim_gen.hip.h"
+#include "tsim_sample_internal.hip.h"
 
 using namespace tsimk;
 using namespace tsimhost;
 
-// stage tags of the profiling events: 0 opens a launch, the others close a stage
-enum { PROF_BEGIN = 0, PROF_PASS1 = 1, PROF_HARD = 2, PROF_FULL = 3 };
+HostMarks *g_marks = nullptr;
 
-static int prof_event(tsim_program *p, hipStream_t s, int tag) {
+
+int prof_event(tsim_program *p, hipStream_t s, int tag) {
   if (p->ev_used == p->ev_pool.size()) {
     hipEvent_t e;
     HIP_TRY(hipEventCreate(&e));
@@ -55,7 +54,7 @@ static int prof_drain(tsim_program *p) {
 // `need_stream`: the slot's own stream too (the lanes - slots 1..4 - always; the others only when a launch runs on the slot's
 // own stream, tsim_sample_batch_device_begin outside the deferred plan: a stream costs ~3 ms to create, 32 of them 100 ms of
 // the first pipelined call of every handle - scripts/microbench/hip_setup_cost.hip)
-static int slot_prepare(tsim_program *p, int slot, size_t hard_bytes, bool need_stream = false) {
+int slot_prepare(tsim_program *p, int slot, size_t hard_bytes, bool need_stream) {
   tsim_program::Slot &sl = p->slots[slot];
   if ((p->lw || p->v4w) && !sl.ctl) {
     // two counter sets per slot, used alternately: pass 1 of a launch resets the set of the slot's next one.  The sets of ALL
@@ -122,12 +121,6 @@ static int slot_prepare(tsim_program *p, int slot, size_t hard_bytes, bool need_
 //  * hard-row lists short: k_sample4h walks them alone, no overflow launch of k_sample4 - and a
 //    pipelined launch may leave its hard rows to a later batch (flush_hard) instead of making its
 //    lane wait for them.
-struct LaunchPlan {
-  bool use_tables = false, need_overflow = true, defer = false;
-  bool hard_kernel = true;  // the NW-waves-per-64-rows kernel for the head of every list (few hard rows: latency)
-  uint32_t fb_max = 0xFFFFFFFFu;
-  int lists = TSIMK_LW_LISTS;  // hard-row sub-lists of this launch: about 40 expected rows each
-};
 
 // `rows`: the rows the launches made under this plan will carry (the deepening rule counts them)
 static LaunchPlan make_plan(tsim_program *p, bool has_row_index, bool pipelined, unsigned long long rows) {
@@ -253,7 +246,7 @@ static int slots_now_ready(tsim_program *p) {
 static thread_local const LaunchPlan *g_carry_plan = nullptr;  // a plan drawn by the caller of tsim_sample_batch_device_begin
 
 // k_sample4h geometry (LDS budget -> tiles per group), 0 tiles = the kernel cannot run this program
-static void hard_geometry(tsim_program *p, int WF, int WO) {
+void hard_geometry(tsim_program *p, int WF, int WO) {
   constexpr int NW = TSIM_HARD_NW;
   const size_t tile_b = (size_t)p->v4_max_nch * 16 * p->v4_gt * 16;
   const size_t fixed_b = (size_t)(2 * WF + 2 * WO) * 64 * 4 + (size_t)NW * 8 * 64 * 4;
@@ -376,7 +369,7 @@ static int launch_hw(tsim_program *p, const SampleArgs *ctx, int n_ctx, int max_
 
 // The deferred second pass: ONE k_sample4h_multi grid serves the hard rows of every launch whose
 // first pass is enqueued, on the third lane's stream, after those first passes.
-static int flush_batch(tsim_program *p) {
+int flush_batch(tsim_program *p) {
   if (p->deferred.empty()) {
     p->flush_inline = nullptr;
     return 0;
@@ -490,7 +483,7 @@ static int flush_batch(tsim_program *p) {
 
 // p->deferred in batches of at most TSIMK_H_MAX_CTX launches (a hard-row grid carries that many contexts in its kernel
 // arguments; fused groups may be larger), all on the stream the caller chose
-static int flush_chunks(tsim_program *p) {
+int flush_chunks(tsim_program *p) {
   if ((int)p->deferred.size() <= TSIMK_H_MAX_CTX) return flush_batch(p);
   std::vector<int> all;
   all.swap(p->deferred);
@@ -509,7 +502,7 @@ int tsim_flush_hard(tsim_program *p) { return flush_chunks(p); }
 // The arguments every sampling kernel of one launch shares (SampleArgs): per-output subkeys - key, subkey =
 // split(key) once per output, threaded through the components in processing order (sampler.py:74,147-148) - inline
 // for programs with at most TSIMK_INLINE_KEYS compiled outputs, else by k_keygen on `s`; buffers; output layout.
-static int fill_sample_args(tsim_program *p, tsim_program::Slot &sl, SampleArgs &a, const uint64_t *d_f, int64_t B, int32_t num_f,
+int fill_sample_args(tsim_program *p, tsim_program::Slot &sl, SampleArgs &a, const uint64_t *d_f, int64_t B, int32_t num_f,
                             uint32_t key_hi, uint32_t key_lo, int64_t shot_offset, uint64_t *d_out, float *d_dev, hipStream_t s,
                             int slot, bool out_bit_packed) {
   if (p->total_keys > 0 && p->total_keys <= TSIMK_INLINE_KEYS) {
@@ -568,169 +561,6 @@ static int fill_sample_args(tsim_program *p, tsim_program::Slot &sl, SampleArgs 
   if (num_f == 0) a.WF = 0;
   return 0;
 }
-
-// ---------------------------------------------------------------------------
-// One wide component (k_sample_wide, tsim_wide.hip.h): up to TSIMK_LWM_MAX_STEPS batches as ONE grid of chip-resident
-// blocks - tables, sparse-column evaluation of the rows they miss, heavy rows and the normalisation check all inside.
-// ---------------------------------------------------------------------------
-struct WideLayout {
-  int block = 0;       // threads per block (0: the program does not fit)
-  int compact = 0;     // 1: the shared column table (WR_CCOL)
-  int glob = 0;        // 1: the column tables stay in the image (k_sample_wide<.., GLOB>): they do not fit the LDS
-  size_t lds = 0;
-  int l_rank, l_lut, l_runs, l_sel, l_ptrs, l_keys, l_tt, l_lvl, l_grec, l_wave, wave_bytes, w_q, w_ovf;
-};
-static WideLayout wide_layout(const tsim_program *p, int WF32, size_t ci = 0) {
-  WideLayout L;
-  const HostComponent &c = p->comps[ci];
-  const uint32_t *wr = &p->img[p->wr_offs[ci]];
-  const int wo32 = (int)wr[WR_WO32];
-  auto up = [](size_t v, size_t a) { return (v + a - 1) / a * a; };
-  // the shared column table (one entry holds every graph's parity bits) when the packer made one and the term tables fit
-  // beside it; else one table per graph
-  // (third choice, compact = -1: no column table in LDS at all - components with many graphs, round 5)
-  // - up to knobs.wide_glob graphs: a dense pass walks the graphs one after the other, ~2.5 us each from the L2 (F60 class, 140
-  // graphs: 300-400 us per pass, 77 us per 10^6 shots against 59 on the round-2 kernels - profiles/r05/wide_glob.txt)
-  const int min_mode = (int)wr[WR_GTOT] <= p->knobs.wide_glob ? -1 : 0;
-  for (int compact = wr[WR_CCOL] != 0u ? 1 : 0; compact >= min_mode && !L.block; --compact) {
-    size_t off = compact > 0 ? (size_t)(c.F + 33) * 16 : compact == 0 ? up(wr[WR_COLBYTES], 16) : 0;
-    L.l_rank = (int)off;  off += (size_t)4 * (c.F + 1) * 4;
-    off = up(off, 16);
-    L.l_lut = (int)off;   off += ((size_t)wo32 << c.n_out) * 4;
-    off = up(off, 16);
-    L.l_runs = (int)off;  off += (size_t)(2 * TSIMK_WIDE_MAX_RUNS + 48) * 4;
-    L.l_sel = (int)off;   off += (2 * TSIMK_WIDE_SELMAX + 4) * 4;  // + the two statistics counters
-    L.l_ptrs = (int)off;  off += (size_t)TSIMK_LWM_MAX_STEPS * 4 * 4;
-    L.l_keys = (int)off;  off += (size_t)TSIMK_LWM_MAX_STEPS * 2 * TSIMK_LWM_KEYS * 4;
-    off = up(off, 16);
-    const size_t fixed_end = off;
-    size_t w = (size_t)64 * WF32 * 4;
-    w = up(w, 16);
-    L.w_q = (int)w;       w += (size_t)(4 + c.n_out + __builtin_popcount(wr[WR_LUTMASK])) * TSIMK_WIDE_QCAP * 4;
-    L.w_ovf = (int)w;     w += (size_t)TSIMK_WIDE_QCAP * 4;
-    L.wave_bytes = (int)up(w, 16);
-    // the levels' term tables join the column tables in LDS when 16 waves still fit next to them (C5: 3 KB)
-    // (+ the level table and the graph records: 16 bytes per level, 64 per graph)
-    const size_t tt_only = up(wr[WR_TTBYTES], 16);
-    const size_t tt_bytes = tt_only + 16 * (size_t)(c.n_out + 1) + 64 * (size_t)wr[WR_GTOT];
-    for (int with_tt = compact < 0 ? 0 : 1; with_tt >= (compact > 0 ? 1 : 0) && !L.block; --with_tt) {
-      if (with_tt && tt_only == 0) continue;
-      off = fixed_end + (with_tt ? tt_bytes : 0);
-      for (int blk : {1024, 512, 256}) {  // 16 waves per CU when everything fits beside the tables, fewer otherwise
-        if (with_tt && blk != 1024) break;
-        if (compact == 0 && blk < 512) break;  // (rather the tables in the L2 and 16 waves than 4 waves beside them)
-        const size_t tot = off + (size_t)(blk / 64) * L.wave_bytes + 64;  // + the kernel's static words
-        if (tot <= 160 * 1024) {
-          L.block = blk;
-          L.compact = compact > 0 ? 1 : 0;
-          L.glob = compact < 0 ? 1 : 0;
-          L.l_tt = with_tt ? (int)fixed_end : -1;
-          L.l_lvl = (int)(fixed_end + tt_only);
-          L.l_grec = L.l_lvl + 16 * (c.n_out + 1);
-          L.l_wave = (int)off;
-          L.lds = off + (size_t)(blk / 64) * L.wave_bytes;
-          break;
-        }
-      }
-    }
-  }
-  return L;
-}
-
-// can this launch go to k_sample_wide?  (32-bit offsets: batches below 2^28 rows, tables below 4 GB, a shot range that does
-// not cross a multiple of 2^32; bit_packed rows are written and merged as dwords)
-static bool wide_applies(const tsim_program *p, int64_t B, int32_t num_f, int64_t shot_offset) {
-  if (!(p->lw && p->lw_wide && p->wr_off != 0 && p->knobs.wide_fused && p->knobs.wide)) return false;
-  if (p->total_keys <= 0 || p->total_keys > TSIMK_LWM_KEYS || B <= 0 || B >= (1ll << 28)) return false;
-  for (size_t ci = 0; ci < p->comps.size() && ci < p->lw_npat.size(); ++ci)  // 32-bit byte offsets inside a component's table
-    if (((p->lw_npat[ci] << p->comps[ci].n_out) * 4) >= (1ll << 32)) return false;
-  if (((unsigned long long)shot_offset >> 32) != ((unsigned long long)(shot_offset + B - 1) >> 32)) return false;
-  const int WF = std::max(1, (num_f + 63) / 64);
-  if (WF > 32 || p->wr_offs.size() != p->comps.size()) return false;  // (f rows of up to 2048 bits; wide_layout says whether they fit)
-  for (size_t ci = 0; ci < p->comps.size(); ++ci)
-    if (wide_layout(p, 2 * WF, ci).block == 0) return false;
-  return true;
-}
-static bool wide_buffers_ok(const tsim_program *p, const SampleArgs &a) {
-  if (!a.out_compact) return true;
-  return (a.out_rb + 3) / 4 <= 2 * ((p->num_outputs + 63) / 64);  // (any row size, any alignment: tsim_wide.hip.h oc_put)
-}
-
-// `args[j]`: the SampleArgs of batch j as fill_sample_args made them (buffers, inline keys)
-static int launch_wide(tsim_program *p, int n, const SampleArgs *const *args, int64_t B, int32_t num_f, int64_t shot_offset, hipStream_t s) {
-  const int WF32 = 2 * std::max(1, (num_f + 63) / 64);
-  if (p->wr_offs.size() != p->comps.size()) return tsim_fail(TSIM_ESTATE, "wide records missing");
-  // the statistics the launch plan follows (missed / heavy rows) come from the pass of the component with most parameters
-  size_t fb_ci = 0;
-  for (size_t ci = 1; ci < p->comps.size(); ++ci)
-    if (p->comps[ci].F > p->comps[fb_ci].F) fb_ci = ci;
-  for (size_t ci = 0; ci < p->comps.size(); ++ci) {  // one pass per component, in stream order (tsim_wide.hip.h: WR_MERGE)
-  const WideLayout L = wide_layout(p, WF32, ci);
-  if (!L.block) return tsim_fail(TSIM_ESTATE, "wide kernel does not fit");
-  const long long comp_tab_bytes = (p->lw_npat[ci] << p->comps[ci].n_out) * 4;
-  if (comp_tab_bytes >= (1ll << 32)) return tsim_fail(TSIM_ESTATE, "pattern table of %lld bytes: k_sample_wide addresses a component's table with 32-bit offsets", comp_tab_bytes);
-  if (tsim_debug("host")) {
-    static bool said = false;
-    if (!said) fprintf(stderr, "[tsim] k_sample_wide: block %d, LDS %zu bytes (per wave %d), shared column table %d, term tables in LDS %d, column tables in the image %d\n", L.block, L.lds, L.wave_bytes, L.compact, L.l_tt >= 0 ? 1 : 0, L.glob);
-    said = true;
-  }
-  WideArgs W{};
-  W.img = p->d_img;
-  W.tab = p->d_lw_tab + p->img[(size_t)p->lw_off + ci * LW_WORDS + LW_TAB];
-  W.B = B;
-  W.shot_offset = shot_offset;
-  W.n_steps = n;
-  W.chunks_per_step = (int)((B + 63) / 64);
-  W.has_check = shot_offset == 0 ? 1 : 0;
-  W.out_rb = (p->num_outputs + 7) / 8;
-  W.WF32 = WF32;
-  W.lw_off = p->lw_off + (int)ci * LW_WORDS;
-  W.comp4_off = p->comp4_off + (int)ci * C4_WORDS;
-  W.wr_off = p->wr_offs[ci];
-  W.binom_off = p->lw_binom_off;
-  W.tab_bytes = (uint32_t)comp_tab_bytes;
-  W.feedback = ci == fb_ci ? p->d_feedback : nullptr;
-  W.merge = ci > 0 ? 1 : 0;
-  W.dev_index = (int)ci;
-  W.compact = L.compact;
-  W.l_rank = L.l_rank; W.l_lut = L.l_lut; W.l_runs = L.l_runs; W.l_sel = L.l_sel; W.l_ptrs = L.l_ptrs; W.l_keys = L.l_keys;
-  W.l_tt = L.l_tt; W.l_lvl = L.l_lvl; W.l_grec = L.l_grec; W.l_wave = L.l_wave; W.wave_bytes = L.wave_bytes; W.w_q = L.w_q; W.w_ovf = L.w_ovf;
-  for (int j = 0; j < n; ++j) {
-    const SampleArgs &a = *args[j];
-    WideStep &st = W.step[j];
-    st.f = a.f;
-    st.out = a.out;
-    st.out_compact = a.out_compact;
-    st.norm_dev = a.norm_dev;
-    memcpy(st.keys, a.inline_keys, sizeof(uint32_t) * 2 * (size_t)p->total_keys);
-  }
-  const long long chunks = (long long)W.chunks_per_step * n;
-  const int wpb = L.block / 64;
-  // chip-resident blocks: as many as the LDS lets a CU hold (one of 1024 threads when the program is C5-sized)
-  const int per_cu = std::max(1, (int)((160 * 1024) / (L.lds + 64)));
-  const long long grid = std::max(1ll, std::min((long long)p->n_cu * per_cu, (chunks + wpb - 1) / wpb));
-  const int wo32 = (int)p->img[p->wr_offs[ci] + WR_WO32];
-#define TSIM_LWIDE(N)                                                                                                   \
-  case N: {                                                                                                             \
-    auto kfn = L.glob ? k_sample_wide<N, TSIMK_WIDE_K, true> : k_sample_wide<N, TSIMK_WIDE_K, false>;                   \
-    const unsigned abit = 1u << (N + (L.glob ? 16 : 0));                                                                \
-    if (!(p->wide_attr_set & abit)) { /* per handle: the attribute is per device */                        \
-      HIP_TRY(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));     \
-      p->wide_attr_set |= abit;                                                                                         \
-    }                                                                                                                   \
-    ++p->path_count[TP_WIDE];                                                                                           \
-    hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(L.block), L.lds, s, W);                                          \
-  } break;
-  switch (wo32) {
-    TSIM_LWIDE(2) TSIM_LWIDE(4) TSIM_LWIDE(6) TSIM_LWIDE(8)
-    default: return tsim_fail(TSIM_ESTATE, "wide record with %d output words", wo32);
-  }
-#undef TSIM_LWIDE
-  }
-  HIP_TRY(hipGetLastError());
-  return 0;
-}
-
 static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_t num_f, uint32_t key_hi,
                          uint32_t key_lo, int64_t shot_offset, uint64_t *d_out, float *d_dev, hipStream_t s,
                          const uint32_t *d_row_index = nullptr, const uint32_t *d_row_count = nullptr,
@@ -1116,7 +946,7 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
 // waits for batch b it is behind every batch <= b.  The slots of a batch alternate over the two first-pass lanes, so
 // this is one stream wait per lane and batch - no event query (the host usually runs several batches ahead of the
 // GPU, the query would fail and cost as much as the wait).
-static int slot_order_after_previous(tsim_program *p, tsim_program::Slot &sl, hipStream_t s) {
+int slot_order_after_previous(tsim_program *p, tsim_program::Slot &sl, hipStream_t s) {
   if (!(sl.last_done && sl.last_done != s && sl.done_ev)) return 0;
   bool done = false;
   if (sl.batch_seq) {
@@ -1219,28 +1049,6 @@ extern "C" int tsim_sample_batch_device_begin(tsim_program *p, int32_t slot, con
 // (tsim_flush_hard) while the next group's first pass runs.  Anything else - dense plans, wide programs, row kernels -
 // goes through tsim_sample_batch_device_begin batch by batch: same results either way.
 // ---------------------------------------------------------------------------
-// TSIM_HOST_TIMING=1: where the host time of a several-batches call goes (stderr, one line per call)
-struct HostMarks {
-  bool on;
-  std::chrono::steady_clock::time_point t[24];
-  const char *name[24];
-  int n = 0;
-  HostMarks() {
-    static const bool e = tsim_debug("host");
-    on = e;
-  }
-  void mark(const char *what) {
-    if (on && n < 24) { name[n] = what; t[n++] = std::chrono::steady_clock::now(); }
-  }
-  void print() {
-    if (!on || n < 2) return;
-    fprintf(stderr, "[tsim] host:");
-    for (int i = 1; i < n; ++i) fprintf(stderr, " %s %.1f", name[i], std::chrono::duration<double, std::micro>(t[i] - t[i - 1]).count());
-    fprintf(stderr, " us\n");
-  }
-};
-static HostMarks *g_marks = nullptr;
-#define TSIM_MARK(w) do { if (g_marks) g_marks->mark(w); } while (0)
 
 static int steps_group_fused(tsim_program *p, int n, const uint64_t *const *d_f, int64_t B, int32_t num_f, uint32_t key[2],
                              int64_t shot_offset, void *const *d_out, float *const *d_dev, uint32_t flags, const LaunchPlan &plan) {
@@ -1420,192 +1228,6 @@ static int steps_group_fused(tsim_program *p, int n, const uint64_t *const *d_f,
   return rf;
 }
 
-// Any narrow program (k_sample_gen, tsim_gen.hip.h): up to TSIMK_GEN_MAX_STEPS batches as one grid of chip-resident blocks, the
-// rows staged in LDS wave by wave; hard rows to each batch's lists, the group's hard-row grid behind it - the protocol of
-// steps_group_fused, whose bookkeeping this shares.
-struct GenLayout {
-  int block = 0, nbuf = 1;
-  size_t lds = 0;
-  int l_wave = 0, wave_bytes = 0;
-};
-static GenLayout gen_layout(const tsim_program *p, int WF32, int n_steps) {
-  GenLayout L;
-  if (!p->gr_off) return L;
-  const uint32_t *h = &p->img[p->gr_off];
-  auto up = [](size_t v, size_t a) { return (v + a - 1) / a * a; };
-  (void)n_steps;
-  size_t off = ((size_t)h[GR_LDS_WORDS] + 8 * (size_t)h[GR_NCOMP]) * 4;  // rank tables, pattern bases
-  off = up(off, 16);
-  const size_t buf = (size_t)64 * WF32 * 4;
-  // two resident blocks of 16 waves per CU (the register budget of the kernel allows it) when the row buffers fit 80 KB
-  // each, double-buffered if that still fits; wider rows: fewer waves per block
-  for (int blk : {1024, 512, 256}) {
-    for (int nbuf : {2, 1}) {
-      const size_t tot = off + (size_t)(blk / 64) * nbuf * buf;
-      if (tot <= (blk == 1024 ? 80u : 64u) * 1024) {
-        L.block = blk;
-        L.nbuf = nbuf;
-        L.l_wave = (int)off;
-        L.wave_bytes = (int)(nbuf * buf);
-        L.lds = tot;
-        return L;
-      }
-    }
-  }
-  return L;
-}
-// can a fused group of this program go to k_sample_gen?  (32-bit row offsets: batches below 2^28 rows, a shot range that does
-// not cross a multiple of 2^32)
-static bool gen_applies(const tsim_program *p, int64_t B, int32_t num_f, int64_t shot_offset) {
-  if (!(p->lw && !p->lw_wide && p->gr_off != 0 && p->knobs.gen > 0)) return false;
-  if (B <= 0 || B >= (1ll << 28)) return false;
-  if (((unsigned long long)shot_offset >> 32) != ((unsigned long long)(shot_offset + B - 1) >> 32)) return false;
-  const int WF32 = 2 * std::max(1, (num_f + 63) / 64);
-  if (WF32 < (int)p->img[p->gr_off + GR_WF32_MIN] || WF32 > 64) return false;
-  return gen_layout(p, WF32, 1).block != 0;
-}
-
-static int steps_group_gen(tsim_program *p, int n, const uint64_t *const *d_f, int64_t B, int32_t num_f, uint32_t key[2],
-                           int64_t shot_offset, void *const *d_out, float *const *d_dev, uint32_t flags, const LaunchPlan &plan) {
-  const bool packed = (flags & TSIM_PIPE_OUT_BIT_PACKED) != 0;
-  if (!p->deferred.empty())
-    if (int r = flush_batch(p)) return r;
-  const int lanes = p->knobs.fused_lanes > 0 ? p->knobs.fused_lanes : ((long long)n * B <= (1ll << 21) ? 3 : 2);
-  hipStream_t s = p->slots[1 + (int)(p->steps_groups++ % (unsigned long long)lanes)].side;
-  if (!(flags & TSIM_PIPE_INPUTS_READY) && p->stream != s) {
-    if (!p->sync_ev) HIP_TRY(hipEventCreateWithFlags(&p->sync_ev, hipEventDisableTiming));
-    HIP_TRY(hipEventRecord(p->sync_ev, p->stream));
-    HIP_TRY(hipStreamWaitEvent(s, p->sync_ev, 0));
-  }
-  const int WF = std::max(1, (num_f + 63) / 64);
-  const GenLayout L = gen_layout(p, 2 * WF, n);
-  if (!L.block) return tsim_fail(TSIM_ESTATE, "k_sample_gen does not fit");
-  const long long bps = (B + 1023) / 1024;  // hard-row lists by row blocks of 1024 rows, whatever the kernel's block
-  const int n_lists = plan.lists;
-  const long long list_cap = (bps + n_lists - 1) / n_lists * 1024;
-  if (list_cap > 0x7FFFFFFFll) return tsim_fail(TSIM_ENOTSUP, "batch too large for the row lists");
-  const bool has_check = shot_offset == 0;
-  GenArgs G{};
-  G.img = p->d_img;
-  G.tab = p->d_lw_tab;
-  G.B = B;
-  G.shot_offset = shot_offset;
-  G.n_steps = n;
-  G.chunks_per_step = (int)((B + 63) / 64);
-  G.has_check = has_check ? 1 : 0;
-  G.out_rb = (p->num_outputs + 7) / 8;
-  G.WF32 = 2 * WF;
-  G.lw_off = p->lw_off;
-  G.gr_off = p->gr_off;
-  G.list_cap = (int)list_cap;
-  G.n_lists = n_lists;
-  G.nbuf = L.nbuf;
-  G.l_wave = L.l_wave;
-  G.wave_bytes = L.wave_bytes;
-  p->last_lists = n_lists;
-  int slots[TSIMK_GEN_MAX_STEPS];
-  for (int j = 0; j < n; ++j)
-    if (p->slots[1 + (int)((p->steps_slot + (unsigned long long)j) % (unsigned long long)TSIM_PIPELINE_SLOTS)].deferred) {
-      if (int r = tsim_flush_hard(p)) return r;
-      break;
-    }
-  for (int j = 0; j < n; ++j) {
-    const int sidx = 1 + (int)(p->steps_slot++ % (unsigned long long)TSIM_PIPELINE_SLOTS);
-    slots[j] = sidx;
-    tsim_program::Slot &sl = p->slots[sidx];
-    if (sl.deferred) return tsim_fail(TSIM_ESTATE, "pipeline slot %d still holds a parked launch", sidx - 1);
-    if ((size_t)list_cap * n_lists * 4 > sl.hard_sz) return tsim_fail(TSIM_ESTATE, "hard-row list too small");
-    if (int r = slot_order_after_previous(p, sl, s)) return r;
-    uint32_t o[4];
-    tsim_key_split(key[0], key[1], o);  // key, subkey = split(key)  (sampler.py:399)
-    key[0] = o[0];
-    key[1] = o[1];
-    SampleArgs &a = sl.ctx;
-    a = SampleArgs{};
-    if (int r = fill_sample_args(p, sl, a, d_f[j], B, num_f, o[2], o[3], shot_offset, (uint64_t *)d_out[j], d_dev ? d_dev[j] : nullptr, s,
-                                 sidx, packed))
-      return r;
-    GenStep &st = G.step[j];
-    st.f = d_f[j];
-    st.out = a.out;
-    st.out_compact = a.out_compact;
-    st.hard_index = (uint32_t *)sl.hard;
-    uint32_t *ctl = sl.ctl + sl.parity * (TSIMK_LW_LISTS + 1) * 32;
-    st.ctl = ctl;
-    st.ctl_next = sl.ctl + (sl.parity ^ 1) * (TSIMK_LW_LISTS + 1) * 32;
-    sl.parity ^= 1;
-    if (p->total_keys <= TSIMK_INLINE_KEYS) {
-      memcpy(st.keys, a.inline_keys, sizeof(uint32_t) * 2 * (size_t)p->total_keys);
-    } else {  // (the hard-row kernels read the k_keygen buffer; this pass wants the subkeys in its arguments)
-      uint32_t k0 = o[2], k1 = o[3];
-      for (int i = 0; i < p->total_keys; ++i) {
-        uint32_t a0 = 0u, a1 = 0u, b0 = 0u, b1 = 1u;
-        threefry2x32(k0, k1, a0, a1);
-        threefry2x32(k0, k1, b0, b1);
-        st.keys[2 * i] = b0;
-        st.keys[2 * i + 1] = b1;
-        k0 = a0;
-        k1 = a1;
-      }
-    }
-    a.row_index = st.hard_index;
-    a.row_count = ctl;
-    a.row_lists = n_lists;
-    a.row_list_cap = (int)list_cap;
-    a.check_row = has_check ? ctl + 32 * TSIMK_LW_LISTS : nullptr;
-    a.no_check = has_check ? 0 : 1;
-    a.row_slot_begin = 0;
-    a.row_slot_end = 0;
-  }
-  const long long chunks = (long long)G.chunks_per_step * n;
-  const int wpb = L.block / 64;
-  const int per_cu = std::max(1, std::min(2048 / L.block, (int)((160 * 1024) / (L.lds + 64))));
-  const long long grid = std::max(1ll, std::min((long long)p->n_cu * per_cu, (chunks + wpb - 1) / wpb));
-  TSIM_MARK("args");
-  if (int r = tsim_tables_slice(p, s)) return r;  // (a table build in the background: its next slice goes first)
-  const bool prof = p->profiling && (p->prof_counter++ % p->prof_every == 0);
-  if (prof) { if (int r = prof_event(p, s, PROF_BEGIN)) return r; }
-  const int wo32 = (int)p->img[p->gr_off + GR_WO32];
-  ++p->path_count[TP_GEN];
-#define TSIM_LGEN(N)                                                                                                    \
-  case N: {                                                                                                             \
-    auto kfn = k_sample_gen<N>;                                                                                         \
-    if (!(p->gen_attr_set & (1u << N))) {                                                                               \
-      HIP_TRY(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));           \
-      p->gen_attr_set |= 1u << N;                                                                                       \
-    }                                                                                                                   \
-    hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(L.block), L.lds, s, G);                                          \
-  } break;
-  switch (wo32) {
-    TSIM_LGEN(2) TSIM_LGEN(4) TSIM_LGEN(6) TSIM_LGEN(8) TSIM_LGEN(10) TSIM_LGEN(12) TSIM_LGEN(14) TSIM_LGEN(16)
-    default: return tsim_fail(TSIM_ESTATE, "gen record with %d output words", wo32);
-  }
-#undef TSIM_LGEN
-  HIP_TRY(hipGetLastError());
-  TSIM_MARK("launch");
-  if (prof) {
-    if (int r = prof_event(p, s, PROF_PASS1)) return r;
-    p->prof_steps += n;
-  }
-  hard_geometry(p, WF, (p->num_outputs + 63) / 64);
-  for (int j = 0; j < n; ++j) {
-    tsim_program::Slot &sl = p->slots[slots[j]];
-    sl.ctx_check = has_check;
-    sl.deferred = true;
-    sl.pending = true;
-    sl.p1_stream = s;
-    sl.partial = false;
-    p->deferred.push_back(slots[j]);
-  }
-  p->stat_begins += (unsigned long long)n;
-  p->stat_deferred += (unsigned long long)n;
-  ++p->stat_fused;
-  if ((long long)n * B <= p->knobs.hard_inline_rows) p->flush_inline = s;
-  const int rf = flush_chunks(p);
-  TSIM_MARK("hard");
-  return rf;
-}
-
 // Programs without components (Clifford-only circuits): up to TSIMK_DIRECT_MAX_STEPS batches as one streaming grid
 // (tsim_direct.hip.h), lanes alternating between groups.  The key is split once per batch all the same - the reference
 // does (sampler.py:399), and the caller's key state must not depend on what the program contains.
@@ -1667,64 +1289,6 @@ static int steps_group_direct(tsim_program *p, int n, const uint64_t *const *d_f
   ++p->stat_fused;
   return 0;
 }
-
-// One wide component: up to `n` batches as one k_sample_wide grid on a first-pass lane, lanes alternating between groups.
-// Nothing is left behind a group - no hard-row lists, no second kernel: the group's slots are done when the grid is.
-static int steps_group_wide(tsim_program *p, int n, const uint64_t *const *d_f, int64_t B, int32_t num_f, uint32_t key[2],
-                            int64_t shot_offset, void *const *d_out, float *const *d_dev, uint32_t flags) {
-  const bool packed = (flags & TSIM_PIPE_OUT_BIT_PACKED) != 0;
-  if (!p->deferred.empty())
-    if (int r = tsim_flush_hard(p)) return r;
-  hipStream_t s = p->slots[1 + (int)(p->steps_groups++ & 1ull)].side;
-  if (!(flags & TSIM_PIPE_INPUTS_READY) && p->stream != s) {
-    if (!p->sync_ev) HIP_TRY(hipEventCreateWithFlags(&p->sync_ev, hipEventDisableTiming));
-    HIP_TRY(hipEventRecord(p->sync_ev, p->stream));
-    HIP_TRY(hipStreamWaitEvent(s, p->sync_ev, 0));
-  }
-  const SampleArgs *args[TSIMK_LWM_MAX_STEPS];
-  int first = 0;
-  for (int j = 0; j < n; ++j) {
-    const int sidx = 1 + (int)(p->steps_slot++ % (unsigned long long)TSIM_PIPELINE_SLOTS);
-    if (j == 0) first = sidx;
-    if (int r = slot_prepare(p, sidx, 0)) return r;  // (k_sample_wide leaves no row lists: counters, keys and events only)
-    tsim_program::Slot &sl = p->slots[sidx];
-    if (sl.deferred) return tsim_fail(TSIM_ESTATE, "pipeline slot %d still holds a parked launch", sidx - 1);
-    if (int r = slot_order_after_previous(p, sl, s)) return r;
-    uint32_t o[4];
-    tsim_key_split(key[0], key[1], o);  // key, subkey = split(key)  (sampler.py:399)
-    key[0] = o[0];
-    key[1] = o[1];
-    SampleArgs &a = sl.ctx;
-    a = SampleArgs{};
-    if (int r = fill_sample_args(p, sl, a, d_f[j], B, num_f, o[2], o[3], shot_offset, (uint64_t *)d_out[j], d_dev ? d_dev[j] : nullptr, s, sidx, packed))
-      return r;
-    if (!wide_buffers_ok(p, a)) return tsim_fail(TSIM_ESTATE, "bit_packed rows wider than the wide record's output words");
-    args[j] = &a;
-  }
-  TSIM_MARK("args");
-  const bool prof = p->profiling && (p->prof_counter++ % p->prof_every == 0);
-  if (prof) { if (int r = prof_event(p, s, PROF_BEGIN)) return r; }
-  if (int r = tsim_tables_slice(p, s)) return r;  // (a table build in the background: its next slice goes first)
-  if (int r = launch_wide(p, n, args, B, num_f, shot_offset, s)) return r;
-  TSIM_MARK("launch");
-  if (prof) {
-    if (int r = prof_event(p, s, PROF_PASS1)) return r;
-    p->prof_steps += n;
-  }
-  hipEvent_t ev = p->slots[first].ev2;
-  HIP_TRY(hipEventRecord(ev, s));
-  for (int j = 0; j < n; ++j) {
-    tsim_program::Slot &sl = p->slots[1 + (int)((p->steps_slot - (unsigned long long)n + (unsigned long long)j) % (unsigned long long)TSIM_PIPELINE_SLOTS)];
-    sl.pending = true;
-    sl.last_done = s;
-    sl.done_ev = ev;
-    sl.batch_seq = 0;
-  }
-  p->stat_begins += (unsigned long long)n;
-  ++p->stat_fused;
-  return 0;
-}
-
 extern "C" int tsim_sample_steps_device(tsim_program *p, int32_t n_steps, const uint64_t *const *d_f, int64_t B, int32_t num_f,
                                         uint32_t key[2], int64_t shot_offset, void *const *d_out, float *const *d_max_norm_dev,
                                         uint32_t flags) {

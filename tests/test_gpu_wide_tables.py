@@ -99,6 +99,48 @@ def test_default_depth_arrives_in_the_background(hip):
     hp.close()
 
 
+def test_table_swap_under_launches_on_a_caller_stream(hip):
+    """The device entry points take a stream of the caller (include/tsim_hip.h).  A table swap rewrites the component records
+    and frees the old table: since round 5 it drains the handle's own lanes and the caller streams its launches were given
+    instead of the whole device.  Launches of a fresh C5 handle on a FOREIGN stream (another handle's
+    auxiliary stream) while the weight-4 tables arrive: the oracle's rows before, across and after the swap."""
+    import time
+
+    prog, cfg = synth.config_program("C5")
+    nf = cfg["num_f"]
+    orc = OC.OracleProgram(prog)
+    other = hip.HipProgram(synth.config_program("C2")[0])
+    stream = other.aux_stream(0)
+    hp = hip.HipProgram(prog)
+    B, wf, wo = 8000, (nf + 63) // 64, (prog.num_outputs + 63) // 64
+    d_f, d_o = hp.malloc(B * wf * 8), hp.malloc(B * wo * 8)
+    seen = set()
+    t0 = time.perf_counter()
+    i = 0
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        while True:
+            info = hp.info()
+            seen.add(tuple(info["pattern_max_weight"]))
+            settled = not info["pattern_build_pending"]
+            f = synth.synth_f(B, nf, cfg["p_bit"], seed=900 + i)
+            fp = np.packbits(f, axis=1, bitorder="little")
+            other.stream_synchronize(stream)  # (the buffers are reused: the previous launch on the foreign stream is done)
+            hp.h2d(d_f, np.ascontiguousarray(np.pad(fp, ((0, 0), (0, wf * 8 - fp.shape[1])))))
+            hp.sample_batch_device(d_f.ptr, B, nf, (i, 6), d_o.ptr, stream=stream)
+            other.stream_synchronize(stream)
+            raw = np.zeros((B, wo * 8), np.uint8)
+            hp.d2h(raw, d_o)
+            got = np.unpackbits(raw, axis=1, bitorder="little")[:, : prog.num_outputs]
+            np.testing.assert_array_equal(got, orc.sample_program(f, (i, 6)), err_msg=f"call {i}, depth {info['pattern_max_weight']}")
+            i += 1
+            if (settled and i >= 4) or time.perf_counter() - t0 > 30.0:
+                break
+    assert hp.info()["pattern_max_weight"] == [4], (seen, hp.info())
+    d_f.free(); d_o.free()
+    hp.close(); other.close()
+
+
 def _tuned_program(hip, prog, tune, monkeypatch, **kw):
     if tune:
         monkeypatch.setenv("TSIM_AMD_TUNE", tune)

@@ -368,13 +368,14 @@ class HipProgram:
                    "tsim_postselect_rows_device")
 
     def sample_batch_device(self, d_f: int, B: int, num_f: int, key, d_out: int, *,
-                            shot_offset: int = 0, d_norm_dev: int = 0) -> None:
-        """Asynchronous launch on the handle's stream; buffers are raw device pointers."""
+                            shot_offset: int = 0, d_norm_dev: int = 0, stream: int = 0) -> None:
+        """Asynchronous launch on the handle's stream (``stream``: a HIP stream of the caller instead); buffers are raw
+        device pointers."""
         _lib.check(
             self._lib.tsim_sample_batch_device(
                 self._h, C.c_void_p(d_f), int(B), int(num_f), int(key[0]) & 0xFFFFFFFF,
                 int(key[1]) & 0xFFFFFFFF, int(shot_offset), C.c_void_p(d_out),
-                C.c_void_p(d_norm_dev) if d_norm_dev else None, None,
+                C.c_void_p(d_norm_dev) if d_norm_dev else None, C.c_void_p(stream) if stream else None,
             ),
             "tsim_sample_batch_device",
         )

@@ -50,7 +50,7 @@ if want shape; then
 fi
 if want cold; then
   python scripts/time_to_n.py > $O/time_to_n.txt 2>&1
-  scripts/microbench/hip_setup_cost.bin > $O/hip_setup_cost.txt 2>&1
+  if [ -x scripts/microbench/hip_setup_cost.bin ] || hipcc --offload-arch=gfx950 -O2 scripts/microbench/hip_setup_cost.hip -o scripts/microbench/hip_setup_cost.bin 2>/dev/null; then scripts/microbench/hip_setup_cost.bin > $O/hip_setup_cost.txt 2>&1; fi
 fi
 if want legs; then
   { for c in C3 C4 C5; do echo "== $c"; q --config $c --steps 100; done; echo "== C4, 1e5 shots per step"; q --config C4 --shots 100000 --steps 100;

@@ -211,7 +211,7 @@ struct tsim_program {
   };
   Slot slots[1 + TSIM_PIPELINE_SLOTS];
   uint32_t *ctl_block = nullptr;  // the counter sets of every slot (Slot::ctl / ctl2 point into it)
-  bool slots_ready = false;
+  std::atomic<bool> slots_ready{false};  // (read by the table-build helper thread: it takes its stream once the lanes exist)
   std::vector<int> deferred;  // slots whose hard rows are waiting, in launch order
   hipEvent_t lane_ev[2] = {nullptr, nullptr};  // "first passes enqueued so far on lane k are done"
   hipEvent_t batch_ev[16] = {};

@@ -1,6 +1,7 @@
 // tsim_program.hip - handle life cycle of the C ABI (include/tsim_hip.h): program description ->
 // packed image -> upload, plus the memory / stream plumbing.  No kernels are defined here.
 #include "tsim_internal.hip.h"
+#include "tsim_sample_internal.hip.h"  // slot_prepare: the lanes are created before the table-build helper takes its stream
 #include "tsim_lw_fastm.hip.h"
 #include "tsim_kernel4w.hip.h"  // C4_SELMASK
 #include "tsim_wide.hip.h"      // WR_*: the wide record
@@ -1298,7 +1299,13 @@ retry_pack:
     if (int r = alloc_feedback(p)) return r;
   }
   fin_mark("pattern tables built");
-  if (p->lw && p->lw_cap_now < p->lw_cap_default) (void)tsim_tables_extend_begin(p, p->lw_cap_default);  // the default depth, in the background
+  if (p->lw && p->lw_cap_now < p->lw_cap_default) {
+    // the default depth, in the background - behind the handle's lanes in stream order of creation (tsim_tables.hip: ext_alloc_thread;
+    // pooled streams: only the first handles of a process pay for hipStreamCreate)
+    for (int k = 1; k <= 4; ++k)
+      if (int r = slot_prepare(p, k, 0)) return r;
+    (void)tsim_tables_extend_begin(p, p->lw_cap_default);
+  }
   p->finalized = true;
   return TSIM_OK;
 }

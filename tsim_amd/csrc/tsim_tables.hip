@@ -234,6 +234,11 @@ static void ext_alloc_thread(tsim_program *p) {
     // plan-driven form - one slice per launch plan - needs a host that plans no faster than the GPU samples: a caller that
     // enqueues a 10^8-shot job in one go (scripts/time_to_n.py: 13 plans within 0.3 ms) had drawn its last plan before the
     // buffers were even allocated, and sampled the whole job with the shallow tables (C4 at weight 2: 1.9e9 shots/s).
+    // ... a pooled stream of its own, taken AFTER the handle's lanes: tsim_program_finalize creates the lanes before it starts
+    // this thread.  In front of the lanes it moved them on the hardware queues - the cultivation shape at 10^5 shots per
+    // step ran at 1.05 instead of 1.73e10 for the handle's whole life (profiles/r05/hw_queues.txt: the round-4 finding, "one
+    // more stream in front of the lanes", through the back door).  On the handle's own stream instead: 1.71e10, but every
+    // synchronize then waits for the slice in flight (fresh C4 handle + 10^6 shots 15.5 -> 23 ms).
     hipStream_t bs = nullptr;
     std::vector<int> held;
     if (tsim_stream_acquire(p->device, held, &bs) != 0) state = -1;

@@ -7,8 +7,9 @@ set -e
 OUT=$(realpath -m $1); shift
 R=$(cd $(dirname $0)/.. && pwd)
 T=$(mktemp -d)
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC "$@" -c $R/tsim_amd/csrc/tsim_sample.hip -o $T/tsim_sample.hip.o 2>/dev/null
-OBJS=$(ls $R/tsim_amd/_build/*.o | grep -v tsim_sample.hip.o)
-hipcc --offload-arch=gfx950 -shared -fPIC $OBJS $T/tsim_sample.hip.o -o $OUT -lrccl
+TU=${TSIM_VARIANT_TU:-tsim_sample}
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC "$@" -c $R/tsim_amd/csrc/$TU.hip -o $T/$TU.hip.o 2>/dev/null
+OBJS=$(ls $R/tsim_amd/_build/*.o | grep -v "/$TU.hip.o")
+hipcc --offload-arch=gfx950 -shared -fPIC $OBJS $T/$TU.hip.o -o $OUT -lrccl
 rm -rf $T
 echo built $OUT

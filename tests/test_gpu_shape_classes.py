@@ -35,6 +35,13 @@ def _check_class(hip, name, B, n, packed, tune=None):
                 os.environ["TSIM_AMD_TUNE"] = old
     warm = [synth.synth_f(B, nf, c["p_bit"], seed=900 + i) for i in range(3)]
     _run_steps(hp, prog, warm, prng.key(1), nf, packed=packed)  # launch-plan feedback
+    # a fresh handle samples with shallow tables while its default depth is built in the background: which kernels serve the
+    # batches below must not depend on whether that build has landed yet (n8: 237 MB, ~10 ms) - wait for it
+    import time
+    t0 = time.perf_counter()
+    while hp.info()["pattern_build_pending"] and time.perf_counter() - t0 < 20.0:
+        _run_steps(hp, prog, warm[:1], prng.key(2), nf, packed=packed)
+    _run_steps(hp, prog, warm, prng.key(3), nf, packed=packed)  # ... and the plan's feedback on the tables now in place
     hp.path_counts(reset=True)
     # noise levels around the nominal one: weight > table depth rows (hard rows) occur in every batch at 3 x p_bit
     fs = [synth.synth_f(B, nf, c["p_bit"] * (1 + (i % 3)), seed=40 + i) for i in range(n)]

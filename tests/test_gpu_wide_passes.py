@@ -36,6 +36,10 @@ SHAPES = {
     "4comps": dict(num_f=192, n_direct=0, components=[_w(1, 70), _w(2, 80), _w(3, 66), _w(5, 75)], shuffle_outputs=True),
     # f rows of 1500 bits (24 words; the round-2 kernels read 16 mask words: f indices below 512), direct outputs from anywhere in the row
     "bigrows": dict(num_f=1500, n_direct=100, components=[_w(3, 180), _w(2, 40)], shuffle_outputs=True, identity_direct=False, direct_flip_fraction=0.1),
+    # more than 255 selected bits: positions in 16 bits (k_sample_wide<.., P16>; positions were bytes until round 5: the row kernel without tables)
+    "F300": dict(num_f=320, n_direct=20, components=[_w(3, 300)]),
+    "F400+narrow": dict(num_f=512, n_direct=70, components=[_w(2, 30, [2, 4, 8]), _w(4, 400, [1, 1, 1, 2, 2])], shuffle_outputs=True, direct_flip_fraction=0.2),
+    "F511": dict(num_f=640, n_direct=10, components=[_w(2, 511)], identity_direct=False),
     # eight outputs per component, 200 outputs: four output words
     "wide8": dict(num_f=448, n_direct=184, components=[_w(8, 100), _w(8, 120)], shuffle_outputs=True),
 }
@@ -87,7 +91,7 @@ def test_steps_api_equals_oracle(hip, name, packed):
     hp.close()
 
 
-@pytest.mark.parametrize("name", ["narrow+wide", "3mixed", "4comps"])
+@pytest.mark.parametrize("name", ["narrow+wide", "3mixed", "4comps", "F300", "F400+narrow"])
 @pytest.mark.parametrize("p_scale", [0.0, 1.0, 6.0])
 def test_serial_api_shards_and_dense_noise(hip, name, p_scale):
     """tsim_sample_batch: hits only (no set bit at all), the nominal level, and mostly heavy rows (generic passes that merge);

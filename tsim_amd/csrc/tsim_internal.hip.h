@@ -162,6 +162,7 @@ struct tsim_program {
   bool lw = false;            // tables built, pass 1 active
   bool lw_wide = false;       // ... for wide components: k_sample_lw<true> -> k_sample4w on its lists -> row kernel
   int lw_binom_off = 0;       // image offset of the binomial table of the register first pass
+  int lw_binom_stride = 256;    // words per row of that table in its wide layout ([4][256], [8][256] saturated, or [4][512] for components beyond 255 selected bits)
   int n_cu = 256;             // compute units of the device (grid sizing)
   int v4w_occ_blocks = 1;     // blocks of the sparse-column kernel a CU holds at once with v4w_occ_lds bytes of LDS
   size_t v4w_occ_lds = 0;

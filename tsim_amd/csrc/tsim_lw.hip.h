@@ -46,7 +46,7 @@ enum {
 // f_sel positions below 256, patterns to weight 4, rank from a [4][256] binomial table; the table-build kernel
 // gets no pattern list but unranks the pattern index itself.
 #define TSIMK_LWW_MAX_WEIGHT 4
-#define TSIMK_LWW_MAX_F 255
+#define TSIMK_LWW_MAX_F 511   // (255 until round 5: positions were bytes; k_sample_wide<.., P16> keeps them in 16 bits)
 
 // colex rank of a pattern with sorted set-bit positions b0 < b1 < b2 < b3 < b4 (missing ones passed as 0)
 __host__ __device__ __forceinline__ uint32_t lw_binom2(uint32_t b) { return (b * (b - 1u)) >> 1; }
@@ -91,6 +91,7 @@ struct LwBuildArgs {
   // C(b, i + 1) <= r.  Wide components (wide_binom_off != 0): binary search in the [4][256] table; narrow ones: the same
   // search on lw_rank_term (no 14-million-entry list built on the host and copied)
   int wide_binom_off, bases_off, wmax;
+  int binom_stride;                   // words per row of the wide binomial table (256; 512 for components beyond 255 selected bits)
   float *p1;                          // scratch [npat << n_out]: |amp| of every node (k_lw_nodes), node 0 = the normalisation
   int depth;                          // k_lw_nodes: -1 = the normalisation level, d = the nodes with d prefix bits
   int pat_begin, pat_count;           // this launch serves patterns [pat_begin, pat_begin + pat_count) (pat_count 0: to npat) - a build in slices
@@ -120,10 +121,10 @@ __device__ __forceinline__ void lw_pattern_bits(const LwBuildArgs &A, cptr img, 
       cptr bn = img + A.wide_binom_off;
       while (lo < up) {
         const int mid = (lo + up + 1) >> 1;
-        if (bn[i * 256 + mid] <= r) lo = mid;
+        if (bn[i * A.binom_stride + mid] <= r) lo = mid;
         else up = mid - 1;
       }
-      at_lo = bn[i * 256 + lo];
+      at_lo = bn[i * A.binom_stride + lo];
     } else {
       while (lo < up) {
         const int mid = (lo + up + 1) >> 1;

@@ -580,7 +580,7 @@ bool pack_level_fast(HostLevel &h, int W, std::vector<uint32_t> &tables, bool &f
 
 
 bool level_v4_eligible(const HostLevel &h, bool wide) {
-  if (h.P > (wide ? 256 + 8 : 128)) return false;  // wide: the sparse-column kernel (tsim_kernel4w.hip.h); chunk tables: x in two or three words (65..80 parameters: the caller checks F <= 64)
+  if (h.P > (wide ? TSIMK_LWW_MAX_F + 8 : 128)) return false;  // wide: the sparse-column kernel (tsim_kernel4w.hip.h); chunk tables: x in two or three words (65..80 parameters: the caller checks F <= 64)
   for (const FastGraph &fg : h.fg) {
     if (fg.us.size() > 32) return false;
     if (fg.c0.size() + fg.c1.size() + fg.c3.size() > 32) return false;

@@ -510,7 +510,7 @@ retry_pack:
     // 512 bits, p->wide_big below keeps them away from wider rows - k_sample_wide reads a list of the words that hold selected bits)
     bool wide = !ok && !p->comps.empty() && p->max_f_index < 2048;
     for (auto &c : p->comps) {
-      wide = wide && (c.n_levels == c.n_out + 1) && c.n_out <= 8 && c.F <= 256;
+      wide = wide && (c.n_levels == c.n_out + 1) && c.n_out <= 8 && c.F <= TSIMK_LWW_MAX_F;
       for (int j = 1; j < c.F; ++j) wide = wide && c.f_selection[j] > c.f_selection[j - 1];
       for (auto &lv : c.levels) wide = wide && level_v4_eligible(lv, true);
     }
@@ -605,6 +605,7 @@ retry_pack:
       p->v4w = wide;
       // f rows of more than 512 bits: k_sample_wide or the row kernel, never the round-2 kernels (16 mask words)
       p->wide_big = wide && p->max_f_index >= 32 * TSIMK_W_SELWORDS;
+      for (auto &c : p->comps) p->wide_big = p->wide_big || (wide && c.F > 255);  // (positions are bytes in the round-2 kernels too)
       p->v4w_resident_bytes = 0;
       if (wide)
         for (auto &c : p->comps) {
@@ -726,8 +727,11 @@ retry_pack:
           img[p->lw_off + ci * LW_WORDS + LW_SELMASK] = img[p->comp4_off + ci * C4_WORDS + C4_SELMASK];
         while (img.size() % 16) img.push_back(0u);
         p->lw_binom_off = (int)img.size();
+        p->lw_binom_stride = 256;
+        for (auto &c : p->comps)
+          if (c.F > 255) p->lw_binom_stride = 512;
         for (int k = 0; k < 4; ++k)
-          for (int b = 0; b < 256; ++b) {
+          for (int b = 0; b < p->lw_binom_stride; ++b) {
             unsigned long long c = 1;
             for (int i = 1; i <= k + 1; ++i) c = c * (unsigned long long)(b - (k + 1) + i > 0 ? b - (k + 1) + i : 0) / (unsigned long long)i;
             img.push_back(b >= k + 1 ? (uint32_t)c : 0u);
@@ -780,6 +784,7 @@ retry_pack:
             p->wr_offs.push_back(wr_this);
             img.resize(img.size() + WR_WORDS, 0u);
             img[(size_t)wr_this + WR_MERGE] = merge ? 1u : 0u;
+            img[(size_t)wr_this + WR_BSTRIDE] = (uint32_t)p->lw_binom_stride;
             {  // the f words that hold selected bits: masks, then (selected bits in the lower words | word index << 16)
               std::vector<uint32_t> words, masks;
               for (int v : c.f_selection) {

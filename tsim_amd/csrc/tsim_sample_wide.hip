@@ -37,7 +37,8 @@ WideLayout wide_layout(const tsim_program *p, int WF32, size_t ci) {
     const size_t fixed_end = off;
     size_t w = (size_t)64 * WF32 * 4;
     w = up(w, 16);
-    L.w_q = (int)w;       w += (size_t)(4 + c.n_out + __builtin_popcount(wr[WR_LUTMASK])) * TSIMK_WIDE_QCAP * 4;
+    const size_t np = c.F > 255 ? 6 : 3;  // position words of a queue entry (k_sample_wide<.., P16>)
+    L.w_q = (int)w;       w += (size_t)(1 + np + c.n_out + __builtin_popcount(wr[WR_LUTMASK])) * TSIMK_WIDE_QCAP * 4;
     L.w_ovf = (int)w;     w += (size_t)TSIMK_WIDE_QCAP * 4;
     L.wave_bytes = (int)up(w, 16);
     // the levels' term tables join the column tables in LDS when 16 waves still fit next to them (C5: 3 KB)
@@ -78,8 +79,10 @@ bool wide_applies(const tsim_program *p, int64_t B, int32_t num_f, int64_t shot_
   if (((unsigned long long)shot_offset >> 32) != ((unsigned long long)(shot_offset + B - 1) >> 32)) return false;
   const int WF = std::max(1, (num_f + 63) / 64);
   if (WF > 32 || p->wr_offs.size() != p->comps.size()) return false;  // (f rows of up to 2048 bits; wide_layout says whether they fit)
-  for (size_t ci = 0; ci < p->comps.size(); ++ci)
-    if (wide_layout(p, 2 * WF, ci).block == 0) return false;
+  for (size_t ci = 0; ci < p->comps.size(); ++ci) {
+    const WideLayout L = wide_layout(p, 2 * WF, ci);
+    if (L.block == 0 || (L.glob && p->comps[ci].F > 255)) return false;
+  }
   return true;
 }
 bool wide_buffers_ok(const tsim_program *p, const SampleArgs &a) {
@@ -119,6 +122,8 @@ int launch_wide(tsim_program *p, int n, const SampleArgs *const *args, int64_t B
   W.comp4_off = p->comp4_off + (int)ci * C4_WORDS;
   W.wr_off = p->wr_offs[ci];
   W.binom_off = p->lw_binom_off;
+  const bool p16 = p->comps[ci].F > 255;
+  if (p16 && L.glob) return tsim_fail(TSIM_ESTATE, "no instantiation of k_sample_wide for 16-bit positions with the column tables in the L2");
   W.tab_bytes = (uint32_t)comp_tab_bytes;
   W.feedback = ci == fb_ci ? p->d_feedback : nullptr;
   W.merge = ci > 0 ? 1 : 0;
@@ -143,8 +148,9 @@ int launch_wide(tsim_program *p, int n, const SampleArgs *const *args, int64_t B
   const int wo32 = (int)p->img[p->wr_offs[ci] + WR_WO32];
 #define TSIM_LWIDE(N)                                                                                                   \
   case N: {                                                                                                             \
-    auto kfn = L.glob ? k_sample_wide<N, TSIMK_WIDE_K, true> : k_sample_wide<N, TSIMK_WIDE_K, false>;                   \
-    const unsigned abit = 1u << (N + (L.glob ? 16 : 0));                                                                \
+    auto kfn = p16 ? k_sample_wide<N, TSIMK_WIDE_K, false, true>                                                        \
+                   : L.glob ? k_sample_wide<N, TSIMK_WIDE_K, true> : k_sample_wide<N, TSIMK_WIDE_K, false>;             \
+    const unsigned abit = 1u << (N + (L.glob ? 16 : 0) + (p16 ? 8 : 0));                                               \
     if (!(p->wide_attr_set & abit)) { /* per handle: the attribute is per device */                        \
       HIP_TRY(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));     \
       p->wide_attr_set |= abit;                                                                                         \

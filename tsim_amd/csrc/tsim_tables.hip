@@ -119,6 +119,7 @@ static int tables_build_at(tsim_program *p, int rec_off, const TsimTablePlan &t,
     a.img = p->d_img;
     a.patbits = nullptr;
     a.wide_binom_off = (p->lw_wide || p->narrow_big) ? p->lw_binom_off : 0;
+    a.binom_stride = p->lw_binom_stride;
     a.bases_off = rec_off + (int)ci * LW_WORDS + LW_BASES_INLINE;
     a.wmax = t.wmax[ci];
     a.tab = tab + tab_off;
@@ -207,6 +208,7 @@ static void ext_alloc_thread(tsim_program *p) {
     a.img = p->d_img;
     a.patbits = nullptr;
     a.wide_binom_off = (p->lw_wide || p->narrow_big) ? p->lw_binom_off : 0;
+    a.binom_stride = p->lw_binom_stride;
     a.bases_off = p->lw_shadow_off + (int)ci * LW_WORDS + LW_BASES_INLINE;
     a.wmax = p->ext_plan.wmax[ci];
     a.tab = tab + tab_off;

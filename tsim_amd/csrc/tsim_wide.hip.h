@@ -49,6 +49,7 @@ enum {
   WR_MERGE,       // 1: a later component's pass - no direct outputs, the component's bits are ORed into the rows the first pass wrote
   WR_SELN,        // f words (32 bits) that hold selected bits of the component (<= TSIMK_WIDE_SELMAX): the only ones phase 1 looks at
   WR_SELREC,      // image offset of SELN masks, then SELN x (selected bits in the lower words | word index << 16)
+  WR_BSTRIDE,     // words per row of the binomial table C(b, k + 1) at binom_off: 256, or 512 for components beyond 255 selected bits
   WR_WORDS = 32
 };
 #define TSIMK_WIDE_SELMAX 64   // (f rows of up to 2048 bits since round 5: max_f_index < 512 was the 16 mask words of the round-2 kernels)
@@ -126,7 +127,9 @@ struct GrecV {
 // GLOB: the column tables stay in the program image (the L2) - components with too many graphs for the LDS; the dense and
 // generic passes read them there, everything else is the same kernel (an instantiation of its own: the register
 // allocation of the resident form, 4 waves per SIMD for C5, is not touched)
-template <int WO32, int K, bool GLOB = false>
+// P16: positions inside f_sel as 16-bit fields (components of 256..511 selected bits: six position words per row instead of
+// three; class F300 of scripts/shape_map.py) - again an instantiation of its own
+template <int WO32, int K, bool GLOB = false, bool P16 = false>
 __global__ void __launch_bounds__(1024) k_sample_wide(WideArgs A) {
   typedef const __attribute__((address_space(4))) uint8_t *cbytes;
   typedef const __attribute__((address_space(4))) WideStep *cstep;
@@ -139,6 +142,8 @@ __global__ void __launch_bounds__(1024) k_sample_wide(WideArgs A) {
   typedef __attribute__((address_space(1))) u32x4 gu32x4;
   static_assert(K % 2 == 0 && K <= 12, "position lists are three words");
   constexpr uint32_t QCAP = TSIMK_WIDE_QCAP;
+  constexpr uint32_t NP = P16 ? 6u : 3u;   // position words of a queue entry (K positions of 8 or 16 bits)
+  constexpr uint32_t QD = 1u + NP;         // queue row of the first draw: id, NP position words, n_out draws, then the output words
   const int nthr = blockDim.x;
   const uint32_t lane = threadIdx.x & 63u, wpb = (uint32_t)nthr >> 6;
   const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform: everything derived from it stays scalar
@@ -211,7 +216,7 @@ __global__ void __launch_bounds__(1024) k_sample_wide(WideArgs A) {
     const uint32_t *g = A.img;
     for (uint32_t i = threadIdx.x; i < 4u * (F + 1u); i += nthr) {
       const uint32_t k = i / (F + 1u), b = i - k * (F + 1u);
-      l_rank[i] = b < F ? g[A.binom_off + k * 256u + b] : 0u;
+      l_rank[i] = b < F ? g[A.binom_off + k * wr[WR_BSTRIDE] + b] : 0u;
     }
     for (uint32_t i = threadIdx.x; i < ((uint32_t)WO32 << n_out); i += nthr) l_lut[i] = g[wr[WR_LUT] + i];
     for (uint32_t i = threadIdx.x; i < 2u * n_runs; i += nthr) l_runs[i] = g[wr[WR_RUNS] + i];
@@ -247,7 +252,7 @@ __global__ void __launch_bounds__(1024) k_sample_wide(WideArgs A) {
   const uint32_t Bu = (uint32_t)A.B;
   const uint32_t cps = (uint32_t)A.chunks_per_step;
   const uint32_t total = cps * (uint32_t)A.n_steps;
-  const uint32_t zsplat = F * 0x01010101u;
+  const uint32_t zsplat = F * (P16 ? 0x00010001u : 0x01010101u);
   // direct outputs with at most one run per destination word (identity-like tables): descriptors as scalars
   const bool run1 = wr[WR_RUN1] != 0u;
   uint32_t r1_ctl[WO32], r1_mask[WO32], r1_flip[WO32];
@@ -372,11 +377,22 @@ __global__ void __launch_bounds__(1024) k_sample_wide(WideArgs A) {
     const uint32_t slot = (qhead + lane) & (QCAP - 1u);
     const uint32_t id = on ? w_q[slot] : 0u;
     const uint32_t p0 = on ? w_q[QCAP + slot] : zsplat, p1 = on ? w_q[2u * QCAP + slot] : zsplat, p2 = on ? w_q[3u * QCAP + slot] : zsplat;
+    uint32_t p3 = zsplat, p4 = zsplat, p5 = zsplat;
+    if constexpr (P16) {
+      p3 = on ? w_q[4u * QCAP + slot] : zsplat;
+      p4 = on ? w_q[5u * QCAP + slot] : zsplat;
+      p5 = on ? w_q[6u * QCAP + slot] : zsplat;
+    }
     uint32_t col[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-      const uint32_t pw = (k < 4) ? p0 : (k < 8) ? p1 : p2;
-      col[k] = (k & 3) == 0 ? ((pw << 4) & 0xFF0u) : ((pw >> (8 * (k & 3) - 4)) & 0xFF0u);
+      if constexpr (P16) {
+        const uint32_t pw = (k < 2) ? p0 : (k < 4) ? p1 : (k < 6) ? p2 : (k < 8) ? p3 : (k < 10) ? p4 : p5;
+        col[k] = (k & 1) ? ((pw >> 12) & 0xFFFF0u) : ((pw << 4) & 0xFFFF0u);
+      } else {
+        const uint32_t pw = (k < 4) ? p0 : (k < 8) ? p1 : p2;
+        col[k] = (k & 3) == 0 ? ((pw << 4) & 0xFF0u) : ((pw >> (8 * (k & 3) - 4)) & 0xFF0u);
+      }
     }
     // which pairs of column reads any lane of this pass needs (a row of weight w uses entries 0 .. w - 1; the others are the
     // zero column): bit c = some lane has more than 2 c set bits
@@ -473,7 +489,7 @@ __global__ void __launch_bounds__(1024) k_sample_wide(WideArgs A) {
       const float v1 = cabs32(re, im);
       if (li == 0) { prev = v1; continue; }
       const uint32_t i = li - 1u;
-      const uint32_t m = w_q[(4u + i) * QCAP + slot];  // the draw phase 1 took for this output: bits >> 9
+      const uint32_t m = w_q[(QD + i) * QCAP + slot];  // the draw phase 1 took for this output: bits >> 9
       const float u = __uint_as_float(m | 0x3F800000u) - 1.0f;
       const bool bit = u < __fdiv_rn(v1, prev);  // sampler.py:74-75
       if (!bit) mb &= ~(1u << i);
@@ -498,7 +514,7 @@ __global__ void __launch_bounds__(1024) k_sample_wide(WideArgs A) {
 #pragma unroll
       for (int d = 0; d < WO32; ++d)
         if ((lutmask >> d) & 1u) {
-          const uint32_t v = w_q[(4u + n_out + cwi) * QCAP + slot] | l_lut[leaf * (uint32_t)WO32 + (uint32_t)d];
+          const uint32_t v = w_q[(QD + n_out + cwi) * QCAP + slot] | l_lut[leaf * (uint32_t)WO32 + (uint32_t)d];
           ++cwi;
           if (A.merge) {  // (the queue word is 0: the first pass wrote the direct bits)
             if (v != 0u) {
@@ -691,6 +707,7 @@ __global__ void __launch_bounds__(1024) k_sample_wide(WideArgs A) {
     // in byte 0; F = "none".  The next word's mask, prefix count and f word are requested before this word's bits are
     // walked (one LDS latency per word, under the loop); nothing in the loop touches memory.
     uint32_t l0 = zsplat, l1 = zsplat, l2 = zsplat, cnt = 0;
+    uint32_t l3 = zsplat, l4 = zsplat, l5 = zsplat;  // (P16 only)
     {
       const uint32_t nw = n_sel;
       uint32_t n_sw = l_sel[0], n_base = l_sel[TSIMK_WIDE_SELMAX], n_fw = frow[n_base >> 16];
@@ -705,9 +722,18 @@ __global__ void __launch_bounds__(1024) k_sample_wide(WideArgs A) {
         while (m) {
           const uint32_t p = (uint32_t)__builtin_ctz(m);
           const uint32_t pos = base + (uint32_t)__builtin_popcount(sw & ((1u << p) - 1u));
-          l2 = __builtin_amdgcn_alignbit(l2, l1, 24);
-          l1 = __builtin_amdgcn_alignbit(l1, l0, 24);
-          l0 = (l0 << 8) | pos;
+          if constexpr (P16) {
+            l5 = __builtin_amdgcn_alignbit(l5, l4, 16);
+            l4 = __builtin_amdgcn_alignbit(l4, l3, 16);
+            l3 = __builtin_amdgcn_alignbit(l3, l2, 16);
+            l2 = __builtin_amdgcn_alignbit(l2, l1, 16);
+            l1 = __builtin_amdgcn_alignbit(l1, l0, 16);
+            l0 = (l0 << 16) | pos;
+          } else {
+            l2 = __builtin_amdgcn_alignbit(l2, l1, 24);
+            l1 = __builtin_amdgcn_alignbit(l1, l0, 24);
+            l0 = (l0 << 8) | pos;
+          }
           ++cnt;
           m &= m - 1u;
         }
@@ -725,8 +751,13 @@ __global__ void __launch_bounds__(1024) k_sample_wide(WideArgs A) {
     // ---- colex rank of a tabulated pattern: sum over its set bits of C(position, ordinal + 1) (tsim_lw.hip.h); byte j of
     // l0 is the bit of ordinal cnt - 1 - j (unused bytes hold F: the zero at the end of every RANK row)
     uint32_t pat = l_bases[cnt < 7u ? cnt : 7u];
+    if constexpr (P16) {
 #pragma unroll
-    for (int j = 0; j < TSIMK_LWW_MAX_WEIGHT; ++j) pat += l_rank[((cnt - 1u - (uint32_t)j) & 3u) * (F + 1u) + ((l0 >> (8 * j)) & 255u)];
+      for (int j = 0; j < TSIMK_LWW_MAX_WEIGHT; ++j) pat += l_rank[((cnt - 1u - (uint32_t)j) & 3u) * (F + 1u) + (((j < 2 ? l0 : l1) >> (16 * (j & 1))) & 0xFFFFu)];
+    } else {
+#pragma unroll
+      for (int j = 0; j < TSIMK_LWW_MAX_WEIGHT; ++j) pat += l_rank[((cnt - 1u - (uint32_t)j) & 3u) * (F + 1u) + ((l0 >> (8 * j)) & 255u)];
+    }
     pat = hit ? pat : 0u;
     const uint32_t thr = (TSIMK_WIDE_SKIP & 4) ? 0u : tab_byte + (pat << (n_out + 2u));  // byte offset of the pattern's threshold tree
     // the first three levels of the tree are requested now: the draws below run while they travel
@@ -819,14 +850,19 @@ __global__ void __launch_bounds__(1024) k_sample_wide(WideArgs A) {
           w_q[QCAP + slot] = l0;
           w_q[2u * QCAP + slot] = l1;
           w_q[3u * QCAP + slot] = l2;
+          if constexpr (P16) {
+            w_q[4u * QCAP + slot] = l3;
+            w_q[5u * QCAP + slot] = l4;
+            w_q[6u * QCAP + slot] = l5;
+          }
 #pragma unroll
           for (int i = 0; i < 8; ++i)
-            if ((uint32_t)i < n_out) w_q[(4u + (uint32_t)i) * QCAP + slot] = dr[i];
+            if ((uint32_t)i < n_out) w_q[(QD + (uint32_t)i) * QCAP + slot] = dr[i];
           uint32_t cwi = 0;
 #pragma unroll
           for (int d = 0; d < WO32; ++d)
             if ((lutmask >> d) & 1u) {
-              w_q[(4u + n_out + cwi) * QCAP + slot] = o[d];
+              w_q[(QD + n_out + cwi) * QCAP + slot] = o[d];
               ++cwi;
             }
         }

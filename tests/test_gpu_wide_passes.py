@@ -184,3 +184,23 @@ def test_misaligned_bit_packed_buffers(hip):
         d_o.free()
     d_f.free()
     hp.close()
+
+
+@pytest.mark.parametrize("name", ["narrow+wide", "4comps", "F300"])
+def test_tiny_batches_and_large_shot_offsets(hip, name):
+    """Batches of 1, 63, 64, 65 rows (a chunk is 64 rows; the passes of the later components must touch nothing beyond the
+    batch) and shards whose shot range lies beyond 2^32 or crosses it (k_sample_wide counts the low word: the launcher
+    sends a crossing range to the other kernels) - the counter of the draws is the global shot index, sampler.py:74-75."""
+    prog, nf = _program(name)
+    orc = OC.OracleProgram(prog)
+    fmax = max(len(c.f_selection) for c in prog.components)
+    hp = _handle(hip, prog)
+    for B, off in ((1, 0), (63, 0), (64, 0), (65, 0), (130, (1 << 32) + 5), (200, (1 << 32) - 100), (97, (1 << 33) - 97)):
+        f = synth.synth_f(B, nf, 5.0 / fmax, seed=B + 7)
+        want = orc.sample_program(f, (B, 3), shot_offset=off)
+        got, _ = hp.sample_batch(f, (B, 3), shot_offset=off)
+        np.testing.assert_array_equal(got, want, err_msg=f"{name} B {B} shot_offset {off}")
+        rb = (prog.num_outputs + 7) // 8
+        pk, _ = hp.sample_batch(f, (B, 3), shot_offset=off, bit_packed=True)
+        np.testing.assert_array_equal(pk[:, :rb], np.packbits(want, axis=1, bitorder="little"), err_msg=f"{name} B {B} shot_offset {off} (bit_packed)")
+    hp.close()

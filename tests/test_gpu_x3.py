@@ -134,3 +134,27 @@ def test_three_and_four_words_equal_the_wide_path(hip, name, off):
     assert res[0][2] and not res[1][2], (res[0][1], res[1][1])
     for a, b in zip(res[0][0], res[1][0]):
         np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.parametrize("name", ["F60n5", "F70n5", "F120n8"])
+def test_tiny_batches_and_large_shot_offsets(hip, name):
+    """1, 63, 64, 65 rows and shot ranges beyond / across 2^32 through the three- and four-word kernels (serial API: tables for
+    F <= 64, every row on k_sample4<4, 32> beyond) and through one fused group of the steps API."""
+    prog, nf = _program(name)
+    orc = OC.OracleProgram(prog)
+    fmax = max(len(c.f_selection) for c in prog.components)
+    hp = _handle(hip, prog)
+    for B, off in ((1, 0), (63, 0), (64, 0), (65, 0), (130, (1 << 32) + 5), (200, (1 << 32) - 100)):
+        f = synth.synth_f(B, nf, 2.0 / fmax, seed=B + 3)
+        want = orc.sample_program(f, (B, 4), shot_offset=off)
+        got, _ = hp.sample_batch(f, (B, 4), shot_offset=off)
+        np.testing.assert_array_equal(got, want, err_msg=f"{name} B {B} shot_offset {off}")
+    for B, off in ((65, 0), (200, (1 << 32) + 64)):
+        fs = [synth.synth_f(B, nf, 2.0 / fmax, seed=B + i) for i in range(3)]
+        key = prng.key(B)
+        outs, _ = _run_steps(hp, prog, fs, key, nf, packed=True, shot_offset=off)
+        _, subs = _subkeys(key, 3)
+        for i in range(3):
+            np.testing.assert_array_equal(outs[i], np.packbits(orc.sample_program(fs[i], subs[i], shot_offset=off), axis=1, bitorder="little"),
+                                          err_msg=f"{name} steps B {B} shot_offset {off} batch {i}")
+    hp.close()

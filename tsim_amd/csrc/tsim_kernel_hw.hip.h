@@ -586,7 +586,14 @@ __device__ __forceinline__ void hw_row(const SampleArgs &A, long long row, bool 
           else hw_component<4>(A, img, comp, ci, fbit, shot, check, par, pw, out_w);
         }
         break;
-      default: __builtin_trap();  // the host launches this kernel for programs of at most 128 parameters only
+      case 6:
+      case 8:  // (129..256 bits: the check / overflow rows of wide components with many graphs, class F140)
+        if constexpr (WMAX >= 8) {
+          if (comp[C_W] == 6u) hw_component<6>(A, img, comp, ci, fbit, shot, check, par, pw, out_w);
+          else hw_component<8>(A, img, comp, ci, fbit, shot, check, par, pw, out_w);
+        }
+        break;
+      default: __builtin_trap();  // the host launches this kernel for programs of at most 256 parameters only
     }
   }
 #pragma unroll

@@ -348,6 +348,10 @@ static int launch_hw(tsim_program *p, const SampleArgs *ctx, int n_ctx, int max_
   if (wmax == 1) switch (nch) {
     TSIM_LHW(1, 0) TSIM_LHW(1, 2) TSIM_LHW(1, 4) TSIM_LHW(1, 6) TSIM_LHW(1, 8) TSIM_LHW(1, 10) TSIM_LHW(1, 12) TSIM_LHW(1, 14) TSIM_LHW(1, 16)
     default: return tsim_fail(TSIM_ESTATE, "bad chunk count %d", nch);
+  } else if (wmax > 4) {  // parameter rows of 129..256 bits: the check / overflow rows of wide components with many graphs (class F140:
+    // one lane of the row kernel took 413 us per batch for the check row of 140 graphs)
+    if (nch != 0 || wmax > 8) return tsim_fail(TSIM_ESTATE, "block-per-row kernel: %d parameter words, %d chunks", wmax, nch);
+    hipLaunchKernelGGL((k_sample_hw<8, 0>), dim3(grid), dim3(256), ldsw, hs, H);
   } else if (wmax > 2) {  // parameter rows of 65..128 bits (chunk tables, and so workers, only for 65..80 parameters: NCH = 20)
     switch (nch) {
       TSIM_LHW(4, 0) TSIM_LHW(4, 20)
@@ -931,7 +935,7 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
   // 65 parameters (class F60, profiles/r05/shape_map.txt) - the block-per-row kernel takes ~25.  (Programs of a few graphs - the C5 family - are
   // quicker on the one lane: 2wide 111 -> 127 us per step with the block-per-row kernel, measured.)
   // (no feedback from this grid: the plan's counts are the sparse-column pass's - the rows that miss the tables - not its overflow)
-  if (a.row_lists > 1 && !p->v4 && use_tables && p->fast && p->knobs.hard_wave && wmax <= 4 && p->total_graphs >= 64 && a.WF <= 32 && a.WO <= 2 && p->hw_max_rows < 60000) {
+  if (a.row_lists > 1 && !p->v4 && use_tables && p->fast && p->knobs.hard_wave && wmax <= 8 && p->total_graphs >= 64 && a.WF <= 32 && a.WO <= 2 && p->hw_max_rows < 60000) {
     if (int r = launch_hw(p, &a, 1, a.row_lists, s, false, false)) return r;
     if (prof && !(p->prof_light && use_tables)) { int r = prof_event(p, s, PROF_FULL); if (r) return r; }
     return finish();

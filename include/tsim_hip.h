@@ -103,7 +103,8 @@ int tsim_program_add_level(tsim_program *p, int32_t component, const tsim_level_
  *                       (src/tsim/core/exact_scalar.py:19-137), identical even where it wraps;
  *   TSIM_MODE_AUTO      use the faster exact-value formulation (NodePhases by class counting,
  *                       phase exponent as a Dickson-reduced GF(2) quadratic form, pack-time term
- *                       tables; LDS chunk-table kernel when every component has <= 64 parameters)
+ *                       tables; LDS chunk-table kernel when every component has <= 64 parameters - since
+ *                       round 5 up to 80 with <= 64 selected f bits, and up to 128 for components of many graphs)
  *                       whenever every graph qualifies (<= 30 NodePhases terms,
  *                       even HalfPi coefficients, small floatfactors); it yields the same canonical
  *                       (a,b,c,d,power) and float32 amplitude as the reference whenever the
@@ -124,13 +125,15 @@ int tsim_program_get_mode(const tsim_program *p, int32_t *fast);
  * 1 GiB table per component; TSIM_AMD_PATTERN_TABLE_MB overrides) they are tabulated by the sampling kernels' own
  * arithmetic, and shots carrying such patterns in every component are finished by a light first
  * pass (one Threefry draw + one table read per output); only the remaining rows run the full
- * kernel.  Bit-identical results.  Requires <= 10 outputs and <= 64 parameters per component - or, for the
- * programs of the sparse-column kernel (components of up to 255 selected f bits in ascending order, <= 8
- * outputs): weight <= 4, 4 GiB per component (C(200, <= 4) patterns of 8 thresholds are 2.1 GB), built on the
- * device by unranking the pattern index; there weight 3 at finalize, deepened once to 4 on demand.
- *   enable: 1 on, 0 off, -1 default (on in TSIM_MODE_AUTO);  max_weight: 0..7 pins the depth; -1 = weight 5 at
- *   finalize (6 ms for the 35-qubit shape), deepened once to 7 (0.1 s, 0.6 GB) if launches keep leaving more than
- *   1 % of their rows to the full kernel (dense error patterns).
+ * kernel.  Bit-identical results.  Requires <= 12 outputs and <= 64 parameters per component (round 5: <= 128, see
+ * TSIM_MODE_AUTO above) - or, for the programs of the sparse-column kernels (any number of components of up to 511
+ * selected f bits in ascending order, <= 8 outputs each, f indices below 2048): weight <= 4, below 4 GiB per component
+ * (C(200, <= 4) patterns of 8 thresholds are 2.1 GB), built on the device by unranking the pattern index.
+ *   enable: 1 on, 0 off, -1 default (on in TSIM_MODE_AUTO);  max_weight: 0..7 pins the depth and builds it at finalize;
+ *   -1 (round 5) = the deepest tables that cost about half a millisecond at finalize (weight 3-4), the default depth -
+ *   5, or 4 for the sparse-column programs - built in the background and put in place at a later launch
+ *   (tsim_program_tables_pending), one more weight (up to 7) after ~10^10 rows that leave too many rows to the
+ *   full kernels (TSIM_AMD_DEEP_TABLES=1: at once; -1: never).
  * The environment variable TSIM_AMD_PATTERN_TABLES=0/1 overrides `enable`.
  * Launch plan: the hard-row kernel reports the number of hard rows of each launch through mapped
  * host memory; when most rows of recent launches were hard (dense error patterns) the following

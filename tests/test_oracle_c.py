@@ -72,3 +72,18 @@ def test_overflow_flag_fires():
     prog = make_program([comp], [], 1, 0)
     _, _, ov = OC.OracleProgram(prog).evaluate(0, 1, np.zeros((1, 1), np.uint8), exact=True)
     assert ov
+
+
+@pytest.mark.parametrize("name", ["F60", "F70", "F140", "F300", "2wide", "narrow+wide", "n11", "out260_f320", "6narrow_f320"])
+def test_c_oracle_matches_numpy_on_shape_classes(name):
+    """The GPU parity tests of the round-5 shapes (65..128 parameters, several wide components, more than 255 selected
+    bits, 11 outputs per component, 260 outputs) use the C oracle as their checker: pin IT to the numpy restatement of the
+    reference's data movement on those shapes too (samples and normalisation deviations; small batches - numpy walks
+    byte-per-bit arrays)."""
+    prog, c = synth.shape_class_program(name)
+    f = synth.synth_f(48, c["num_f"], 2.5 * c["p_bit"], seed=13)
+    want, wd = O.sample_program(prog, f, (3, 7), return_devs=True)
+    got, gd, ov = OC.OracleProgram(prog).sample_program(f, (3, 7), return_devs=True, return_overflow=True)
+    assert not ov, "reference int32 arithmetic would wrap on this input"
+    np.testing.assert_array_equal(got, want)
+    np.testing.assert_array_equal(np.asarray(gd, np.float32), np.asarray(wd, np.float32))

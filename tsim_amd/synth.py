@@ -443,7 +443,8 @@ def _pad_neutral(rng, g: dict, P: int, density: float, ta, tb, tc, td) -> dict:
 
 def physical_component(rng, output_indices, f_selection, Gs, *, density: float = 0.3, ta=(4, 16), tb=(4, 24),
                        tc=(8, 40), td=(0, 4), approx: bool = False, delta_fraction: float = 0.08,
-                       signed_fraction: float = 0.35, live_padding: bool = False) -> CompiledComponent:
+                       signed_fraction: float = 0.35, live_padding: bool = False,
+                       shared_delta: float = 0.0) -> CompiledComponent:
     """One normalised component with ``Gs[k]`` graphs at level k (see the block comment above).
 
     ``live_padding``: the neutral pairs that bring a graph to the published term counts are exact no-ops, and the
@@ -454,7 +455,13 @@ def physical_component(rng, output_indices, f_selection, Gs, *, density: float =
         threshold are unchanged as real numbers while each graph's quadratic form has full rank (Dickson pairs) and the
         amplitudes are genuinely complex (the general |z| path);
       * per LINEAGE (identical in all its members, from level 0 on) ta/2 "T" pairs (k, 8 - k) on f rows: positive
-        f-dependent weights (2 +- sqrt2)/4 - counted NodePhases rows."""
+        f-dependent weights (2 +- sqrt2)/4 - counted NodePhases rows.
+
+    ``shared_delta``: the fraction of outputs whose conditional factor is ONE delta (1 + (-1)^(row . x + c)) / 2 shared by
+    every lineage - a detector that is a deterministic parity of the error bits and the earlier outcomes, the regime of real
+    detector components (most detectors of a connected component are fixed by f and a few genuinely random outcomes).
+    Without it every output multiplies every graph by a (2 +- sqrt2)-type weight, and beyond ~22 outputs the int32
+    coefficients of the reference's exact scalars wrap (normalisation deviation 1: the reference raises)."""
     n, F = len(output_indices), len(f_selection)
     if len(Gs) != n + 1:
         raise ValueError("need n+1 graph counts per component")
@@ -518,6 +525,21 @@ def physical_component(rng, output_indices, f_selection, Gs, *, density: float =
         grow = Gs[j + 1] - Gs[j]
         order = rng.permutation(len(lineages))
         split = set()
+        if shared_delta > 0.0 and rng.random() < shared_delta:
+            row = (_rand_row(rng, 0, bit, density) + [bit]) if bit > 0 else [bit]
+            cst = int(rng.choice([0, 4]))
+            for lin in lineages:
+                for g in lin:
+                    g["A"].append((cst, row))
+                    g["power2"] -= 1
+            while grow > 0:
+                lin = lineages[int(rng.integers(0, len(lineages)))]
+                src = int(rng.integers(0, len(lin)))
+                lin[src]["power2"] -= 1
+                lin.insert(src + 1, _copy_graph(lin[src]))
+                grow -= 1
+            levels.append(emit(j + 1))
+            continue
         for li in order:  # lineages that take the two-graph form of the factor
             s = len(lineages[int(li)])
             if s <= grow and rng.random() < 0.8:
@@ -576,7 +598,7 @@ def physical_program(*, num_f: int, n_direct: int, components: list[dict], seed:
     comps, pos = [], n_direct
     for c in components:
         n, F = int(c["n"]), int(c["F"])
-        kw = {k: v for k, v in c.items() if k in ("density", "ta", "tb", "tc", "td")}
+        kw = {k: v for k, v in c.items() if k in ("density", "ta", "tb", "tc", "td", "shared_delta")}
         fsel = np.sort(rng.choice(num_f, size=F, replace=False)).astype(np.int32)
         comps.append(physical_component(rng, out_ids[pos:pos + n], fsel, list(c["G"]), approx=approx, live_padding=live_padding, **kw))
         pos += n
@@ -603,12 +625,12 @@ def _graph_counts(n: int, top: int) -> list[int]:
     return g
 
 
-def _narrow(n: int, F: int, top: int = 40) -> dict:
-    return dict(n=n, F=F, G=_graph_counts(n, top))
+def _narrow(n: int, F: int, top: int = 40, **kw) -> dict:
+    return dict(n=n, F=F, G=_graph_counts(n, top), **kw)
 
 
 def _wide(n: int, F: int) -> dict:
-    return dict(n=n, F=F, G=[1, 2, 2, 3, 3, 4, 4, 5, 5][: n + 1], density=0.08)
+    return dict(n=n, F=F, G=[min(5, 1 + (k + 1) // 2) for k in range(n + 1)], density=0.08)
 
 
 SHAPE_CLASSES = {
@@ -646,6 +668,20 @@ SHAPE_CLASSES = {
     "F255": dict(near="C5", num_f=320, n_direct=65, components=[_wide(3, 255)]),
     "F300": dict(near="C5", num_f=320, n_direct=20, components=[_wide(3, 300)]),
     "F200_f600": dict(near="C5", num_f=600, n_direct=118, components=[_wide(3, 200)]),  # max_f_index >= 512
+    # ---- round 6: beyond the compiled-in walls - the reference loops over any number of levels
+    # (sampler.py:62) and components are whatever compile/pipeline.py:55-102 finds connected
+    "n13": dict(near="C2", num_f=64, n_direct=15, components=[_narrow(13, 32)]),
+    "n16": dict(near="C2", num_f=64, n_direct=15, components=[_narrow(16, 32)]),
+    # (n24 / n40: four of five outputs are deterministic parities of f and the earlier outcomes - see physical_component;
+    #  n24x is the unconstrained mixture, whose int32 coefficients wrap like the reference's would: nonsense marginals, parity only)
+    "n24": dict(near="C2", num_f=64, n_direct=15, components=[_narrow(24, 32, shared_delta=0.8)]),
+    "n40": dict(near="C2", num_f=64, n_direct=8, components=[_narrow(40, 32, shared_delta=0.8)]),
+    "n24x": dict(near="C2", num_f=64, n_direct=15, components=[_narrow(24, 32)]),
+    "w12": dict(near="C5", num_f=320, n_direct=100, components=[_wide(12, 200)]),  # a wide component of 12 outputs
+    "20narrow": dict(near="C4", num_f=192, n_direct=10,
+                     components=[_narrow(1 + (k % 3), 6 + (k % 5), 4 + 2 * (k % 4)) for k in range(20)]),  # more than 16 components
+    "9wide": dict(near="C5", num_f=704, n_direct=60, components=[_wide(2, 70) for _ in range(9)]),  # more than 8 wide passes
+    "F600": dict(near="C5", num_f=640, n_direct=20, components=[_wide(3, 600)]),  # >= 512 selected bits in one component
 }
 
 

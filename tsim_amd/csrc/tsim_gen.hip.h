@@ -32,7 +32,7 @@ namespace tsimk {
 #endif
 #define TSIMK_GEN_KEYS 40
 #define TSIMK_GEN_MAX_RUNS 1024
-#define TSIMK_GEN_MAX_COMP 16
+#define TSIMK_GEN_MAX_COMP 32
 
 // gen record in the program image (uint32 words, 64-byte aligned): header, then its tables (image offsets)
 enum {
@@ -206,7 +206,8 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(TSIMK_GEN
       const uint32_t *rank = L + cr[GC_L_RANK];
       const uint32_t wmax = lw[LW_WMAX];
       const uint64_t tbase = (uint64_t)(uintptr_t)A.tab + (uint64_t)lw[LW_TAB] * 4ull;
-      const uint64_t tb64 = ((uint64_t)lw[LW_NPAT] << n_out) * 4ull;
+      const bool trie = lw[LW_FMT] != 0u;  // the component's tables are a chunked prefix tree (tsim_trie.hip.h)
+      const uint64_t tb64 = trie ? (uint64_t)lw[LW_CHUNKS] * 32ull : ((uint64_t)lw[LW_NPAT] << n_out) * 4ull;
       const uint32_t tbytes = tb64 > 0xFFFFFFFCull ? 0xFFFFFFFCu : (uint32_t)tb64;
       // the descriptor ends with the component's table: a lane whose pattern index means nothing reads zeros, never beyond
       const __amdgpu_buffer_rsrc_t r_tab = __builtin_amdgcn_make_buffer_rsrc((void *)(uintptr_t)tbase, 0, tbytes, 0x00020000);
@@ -244,6 +245,7 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(TSIMK_GEN
       }
       if (ord > wmax) hard = true;
       pat += l_bases[8u * ci + (ord < 7u ? ord : 7u)];
+      if (pat >= lw[LW_NPAT_OK]) hard = true;  // (a prefix-tree build that the budget ended early, tsim_tables.hip)
       pat = hard ? 0u : pat;
       const uint32_t thr = pat << (n_out + 2u);  // byte offset of the pattern's threshold tree inside the component's table
       auto draw = [&](uint32_t i) -> uint32_t {
@@ -258,6 +260,43 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(TSIMK_GEN
 #pragma unroll
         for (int d = 0; d < WO32; ++d) o[d] |= ((dst >> 5) == (uint32_t)d) ? v : 0u;
       };
+      if (trie) {
+        // One 32-byte chunk per three outputs: thresholds of its seven nodes, the child-present mask, the first child.  A node
+        // whose threshold is 0 or 2^23 takes no draw (u < T is decided), and when that holds for the whole wave the Threefry
+        // block is skipped - detectors fixed by f and the outcomes before them cost a compare.
+        uint32_t chunk = pat;
+        auto bit_of = [&](uint32_t i, uint32_t T) -> bool {
+          const bool need = (T - 1u) < ((1u << 23) - 1u) && active && !hard;  // 0 < T < 2^23
+          uint32_t dr = 0u;  // (T = 2^23: 0 < T; T = 0: never)
+          if (__builtin_amdgcn_ballot_w64(need) != 0ull) dr = draw(i);
+          return dr < T;
+        };
+        // (the root chunk holds the n_out mod 3 odd outputs, every other chunk three: tsim_trie.hip.h)
+        uint32_t rem = n_out % 3u ? n_out % 3u : 3u;
+        for (uint32_t i = 0u; i < n_out; i += rem, rem = 3u) {
+          const u32x4 ca = __builtin_amdgcn_raw_buffer_load_b128(r_tab, chunk * 32u, 0, 0);
+          const u32x4 cb = __builtin_amdgcn_raw_buffer_load_b128(r_tab, chunk * 32u + 16u, 0, 0);
+          const uint32_t cmask = ca.y >> 24;
+          const bool b0 = bit_of(i, ca.y & 0xFFFFFFu);
+          emit(i, b0);
+          bool b1 = false, b2 = false;
+          if (rem > 1u) {
+            b1 = bit_of(i + 1u, b0 ? ca.w : ca.z);
+            emit(i + 1u, b1);
+          }
+          if (rem > 2u) {
+            const uint32_t lo = b1 ? cb.y : cb.x, hi = b1 ? cb.w : cb.z;
+            b2 = bit_of(i + 2u, b0 ? hi : lo);
+            emit(i + 2u, b2);
+          }
+          if (i + rem < n_out) {
+            const uint32_t leaf = rem == 3u ? (b0 ? 4u : 0u) + (b1 ? 2u : 0u) + (b2 ? 1u : 0u) : (rem == 2u ? (b0 ? 2u : 0u) + (b1 ? 1u : 0u) : (b0 ? 1u : 0u));
+            if (!((cmask >> leaf) & 1u)) hard = true;  // the tree ends here: the table's budget was spent (tsim_trie.hip.h)
+            chunk = ca.x + (uint32_t)__builtin_popcount(cmask & ((1u << leaf) - 1u));
+          }
+        }
+        continue;
+      }
       // the threshold walk, three tree levels per memory access (tsim_lw_pass.hip.h: lw_walk_impl)
       uint32_t node = 1u, i = 0u;
       for (; i + 3u <= n_out; i += 3u) {

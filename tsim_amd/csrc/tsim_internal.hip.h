@@ -87,6 +87,7 @@ struct HostComponent {
   int n_out = 0, F = 0, n_levels = 0;
   std::vector<int32_t> output_indices, f_selection;
   std::vector<HostLevel> levels;
+  bool trie = false;  // pattern tables as a chunked prefix tree (tsim_trie.hip.h): components of more than TSIMK_LW_MAX_NOUT outputs
 };
 
 static const int kWVariants[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64};
@@ -107,6 +108,7 @@ using tsimhost::HostLevel;
 struct TsimTablePlan {  // pattern tables of one depth: per component the deepest weight and the patterns, bytes of all
   std::vector<int> wmax;
   std::vector<long long> npat;
+  std::vector<long long> chunks;  // per component: chunks of its prefix tree (0: dense format)
   long long bytes = 0;
 };
 
@@ -169,6 +171,8 @@ struct tsim_program {
   bool lw_reg = false;        // the register form of pass 1 applies (narrow f rows, ascending f_selection)
   int lwfm_off = 0;           // fast record of programs with 2..4 components of <= 8 outputs each (k_sample_lw_fastm), 0 = none
   int wr_off = 0;             // image offset of the first wide record (k_sample_wide, tsim_wide.hip.h), 0 = none
+  bool lw_trie = false;       // some component's tables are a chunked prefix tree: first pass k_sample_gen only
+  std::vector<long long> lw_chunks;  // per component: chunks of its prefix tree (0: dense format)
   bool narrow_big = false;    // narrow program with a component of more than 64 selected bits: first pass k_sample_gen only, tables to weight 4
   bool wide_big = false;      // wide program with f indices >= 512: the round-2 wide kernels (16 selection-mask words) must not see it
   std::vector<int> wr_offs;   // one wide record per component (the passes of k_sample_wide, in component order)
@@ -265,6 +269,7 @@ struct tsim_program {
     bool hard_tree = false;   // hard_tree=1: the block-per-row kernel takes the levels in lookahead groups (hw_component_tree) - measured
                               // slower, profiles/r05/hard_tree.txt: the grid waits for the normalisation-check row either way
     bool shallow = true;      // shallow=0: finalize builds the default table depth at once (round 4) instead of starting shallow
+    int trie = 1;             // trie=0: no prefix-tree tables - components of more than 12 outputs run without tables (round 5); 2: prefix trees for every narrow component
     int gen = 1;              // gen: k_sample_gen for fused groups - 0 never, 1 where no register first pass applies, 2 wherever it applies
     int x4 = 32;              // x4=N: components of 81..128 parameters or more than 64 selected bits AND at least N graphs take the narrow family (four words of x); 0: never
     bool x3 = true;           // x3=0: components of 65..80 parameters (F <= 64) stay on the wide path (round-4 behaviour)
@@ -301,6 +306,7 @@ struct tsim_program {
   int lw_cap_default = 0;     // the depth a handle reaches on its own soon after finalize (5 narrow, 3 wide, or the caller's)
   int lw_cap_now = 0, lw_cap_max = 0;  // table depth built / allowed (tsim_tables_extend deepens on demand)
   long long lw_budget = 0;    // bytes per component
+  long long lw_trie_budget = 512ll << 20;  // ... of a prefix-tree table (tsim_trie.hip.h)
   int lw_dense_launches = 0;  // consecutive launches whose hard-row share says "deeper tables would pay"
   unsigned long long deep_after_auto = 0;  // tsim_tables_deep_after's estimate (0: not made yet)
   long long lw_build_bytes = 0;        // ... and their size

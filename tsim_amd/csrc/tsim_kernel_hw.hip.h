@@ -175,10 +175,17 @@ __device__ __forceinline__ HwLevelOut hw_phase2(const uint32_t *gimg, cptr img, 
       auto bits_of = [&](const uint32_t *pq) {
         GraphBits q;
         uint32_t pos = start;
-        const uint32_t n0 = n01 & 0xFFFFu, n1 = n01 >> 16, n3 = n3h & 0xFFFFu;  // at most 30 rows each (level_fast_eligible)
-        q.m0 = (uint32_t)__builtin_popcount(hw_bits(pq, pos, n0)); pos += n0;
-        q.m1 = (uint32_t)__builtin_popcount(hw_bits(pq, pos, n1)); pos += n1;
-        q.m3 = (uint32_t)__builtin_popcount(hw_bits(pq, pos, n3)); pos += n3;
+        // (usually at most 30 rows each; more when the terms are deltas - level_fast_eligible: components of many deterministic outputs)
+        const uint32_t n0 = n01 & 0xFFFFu, n1 = n01 >> 16, n3 = n3h & 0xFFFFu;
+        auto count = [&](uint32_t n) -> uint32_t {
+          uint32_t m = (uint32_t)__builtin_popcount(hw_bits(pq, pos, n));
+          for (uint32_t t0 = 32u; t0 < n; t0 += 32u) m += (uint32_t)__builtin_popcount(hw_bits(pq, pos + t0, n - t0));
+          pos += n;
+          return m;
+        };
+        q.m0 = count(n0);
+        q.m1 = count(n1);
+        q.m3 = count(n3);
         q.dbits = 0u;
         for (uint32_t t0 = 0; t0 < nD; t0 += 16u) {  // (pa, pb) per term, first term most significant
           const uint32_t nt = min(16u, nD - t0);

@@ -27,7 +27,9 @@ namespace tsimk {
 enum {
   LW_NOUT = 0, LW_F, LW_FSELP /* gather program f row -> x */, LW_OUTPOS, LW_KEYBASE, LW_WMAX,
   LW_TAB /* float offset into tab */, LW_BASES /* image offset of 8 words: index of the first pattern of weight w */,
-  LW_RSV0, LW_NPAT, LW_FSELN /* chunks of the gather program */, LW_RSV1, LW_RSV2,
+  LW_FMT /* 0: thr[pattern][2^n_out]; 1: chunked prefix tree (tsim_trie.hip.h) */, LW_NPAT, LW_FSELN /* chunks of the gather program */,
+  LW_CHUNKS /* trie: chunks the component's table holds */,
+  LW_NPAT_OK /* patterns below this index are complete (trie: the budget may end a build early; dense: = LW_NPAT) */,
   LW_SELMASK /* image offset of 4 selection-mask words + 4 prefix counts (register first pass), 0 = none */,
   // The masks and the bases live INSIDE the record (LW_SELMASK / LW_BASES point at these words): a wave has
   // everything it needs of a component after one 128-byte scalar load - no dependent load behind the record.
@@ -95,6 +97,11 @@ struct LwBuildArgs {
   float *p1;                          // scratch [npat << n_out]: |amp| of every node (k_lw_nodes), node 0 = the normalisation
   int depth;                          // k_lw_nodes: -1 = the normalisation level, d = the nodes with d prefix bits
   int pat_begin, pat_count;           // this launch serves patterns [pat_begin, pat_begin + pat_count) (pat_count 0: to npat) - a build in slices
+  // chunked prefix tree (tsim_trie.hip.h): `tab` = the component's chunks, `p1` = scratch: a header of TH_WORDS words, then one
+  // TrieMeta per chunk
+  int trie;                           // 1: build that format
+  int trie_level;                     // chunk level of this launch (outputs 3 L .. 3 L + 2)
+  uint32_t trie_cap;                  // chunks the table holds
 };
 
 // the pattern of table row `pat` as f_sel-position bits

@@ -245,7 +245,21 @@ bool level_fast_eligible(const HostLevel &h) {
   const tsim_level_desc &d = h.d;
   for (int g = 0; g < h.G; ++g) {
     const int nA = d.ta ? h.i32[0][g] : 0;
-    if (nA > 30) return false;  // beyond this the reference's own int32 scan may wrap
+    if (nA > 30) {
+      // Beyond 30 terms the reference's own int32 scan may wrap (each factor is at most 2 in both embeddings of Z[w]) - unless
+      // the terms say otherwise.  The scan multiplies one term at a time and takes ONE factor of two out after every product
+      // (exact_scalar.py:43-49,62-79): a term 1 + w^(4 par + c) with c in {0, 4} is 2 or 0, its product is even and reduced at
+      // once - the running value does not grow (detectors that are parities of f and earlier outcomes: any number of them);
+      // c in {2, 6}: |1 +- i| = sqrt 2; odd c: 1.848 in one embedding, 0.765 in the other.  A coefficient is at most the mean
+      // of the two embeddings' magnitudes, so log2 of the running coefficients is bounded by the sum of these costs (+ 1: the
+      // scan's first element enters unreduced); the product with the next term (a factor <= 2) must still fit 31 bits.
+      double cost = 1.0;
+      for (int t = 0; t < nA; ++t) {
+        const unsigned ph = h.u8[0][(size_t)g * d.ta + t] & 7u;
+        cost += (ph & 1u) ? 0.886 : ((ph & 2u) ? 0.5 : 0.0);
+      }
+      if (cost > 29.0) return false;
+    }
     for (int t = 0; t < d.tb; ++t) {
       const unsigned c = h.u8[2][(size_t)g * d.tb + t] & 7u;
       if (c & 1u) return false;  // odd eighth-turn coefficients never come out of the compiler

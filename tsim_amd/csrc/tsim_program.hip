@@ -296,6 +296,7 @@ extern "C" int tsim_program_finalize(tsim_program *p, int32_t device) {
     p->knobs.wide_glob = (int)std::max(0ll, tune_ll("wide_glob", 48));
     p->knobs.wide_passes = (int)std::max(1ll, std::min(16ll, tune_ll("wide_passes", 8)));
     p->knobs.gen = (int)std::max(0ll, std::min(2ll, tune_ll("gen", 1)));
+    p->knobs.trie = (int)std::max(0ll, std::min(2ll, tune_ll("trie", 1)));
     p->knobs.shallow = tune_ll("shallow", 1) != 0;
     p->knobs.hard_tree = tune_ll("hard_tree", 0) != 0;
     p->knobs.hard_overflow = tune_ll("hard_overflow", 1) != 0;
@@ -645,9 +646,25 @@ retry_pack:
     bool ok = want && p->sampleable && !p->comps.empty();
     bool narrow = true;
     // (F + n_out up to 80 with F <= 64 since round 5: the chunk-table kernels hold x in three words then - p->v4 says whether they took the program)
-    for (auto &c : p->comps)
-      narrow = narrow && (c.n_levels == c.n_out + 1) && c.n_out <= TSIMK_LW_MAX_NOUT &&
-               (c.F + c.n_out <= 64 || (p->v4 && c.F <= 64 && c.F + c.n_out <= 80) || (p->v4 && p->knobs.x4 > 0 && c.F + c.n_out <= 128));
+    // Components of more than TSIMK_LW_MAX_NOUT outputs (round 6): a pattern's 2^n_out thresholds no longer fit a row - their
+    // tables are pruned prefix trees in chunks of three levels (tsim_trie.hip.h), walked by k_sample_gen alone.  Without chunk
+    // tables (p->v4: more than 32 counted rows in some graph, say) their hard rows are the block-per-row kernel's, whose x
+    // holds up to 128 parameters (k_sample_hw<4, 0>: launch_hw)
+    int cw_max = 1;
+    for (int w : p->comp_w) cw_max = std::max(cw_max, w);
+    const bool hw_rows_ok = p->fast && cw_max <= 4 && p->num_outputs <= 128 && p->max_f_index < 2048 && p->hw_max_rows < 60000;
+    p->lw_trie = false;
+    for (auto &c : p->comps) {
+      c.trie = (c.n_out > TSIMK_LW_MAX_NOUT && p->knobs.trie) || (p->knobs.trie == 2 && c.n_out >= 1);  // (trie=2: every component - tests)
+      narrow = narrow && (c.n_levels == c.n_out + 1) && c.n_out <= (p->knobs.trie ? 64 : TSIMK_LW_MAX_NOUT) &&
+               (c.F + c.n_out <= 64 || (p->v4 && c.F <= 64 && c.F + c.n_out <= 80) || (p->v4 && p->knobs.x4 > 0 && c.F + c.n_out <= 128) ||
+                (c.trie && !p->v4 && hw_rows_ok && c.F + c.n_out <= 128));
+      p->lw_trie = p->lw_trie || c.trie;
+    }
+    if (p->lw_trie && !p->v4 && !hw_rows_ok) narrow = false;  // (nothing to serve the hard rows of a fused group)
+    if (tsim_debug("tables"))
+      fprintf(stderr, "[tsim] pattern tables: narrow %d trie %d (chunk tables %d, block-per-row hard rows possible %d: fast %d, x words %d, outputs %d, f index %d, rows per level %lld)\n",
+              narrow ? 1 : 0, p->lw_trie ? 1 : 0, p->v4 ? 1 : 0, hw_rows_ok ? 1 : 0, p->fast ? 1 : 0, cw_max, p->num_outputs, p->max_f_index, p->hw_max_rows);
     // more than 64 selected bits somewhere in a narrow program: every first pass but k_sample_gen holds f_sel in 64 bits, and the
     // closed-form binomials of the table builder end at b = 64 (tsim_lw.hip.h) - tables to weight 4 through the [4][256]
     // table of the wide path, gen or the full kernel (launch_sample)
@@ -682,7 +699,8 @@ retry_pack:
       // wide components: C(200, 4) patterns of 8 thresholds are 2.1 GB - what lifts the tabulated share of C5's
       // shots from 43 % to 63 %; still under 1 % of the HBM
       if (p->lw_wide) p->lw_budget = 4096ll << 20;
-      if (const char *e = getenv("TSIM_AMD_PATTERN_TABLE_MB")) p->lw_budget = std::max(1ll, atoll(e)) << 20;
+      p->lw_trie_budget = 512ll << 20;
+      if (const char *e = getenv("TSIM_AMD_PATTERN_TABLE_MB")) p->lw_budget = p->lw_trie_budget = std::max(1ll, atoll(e)) << 20;
       while (img.size() % 32) img.push_back(0u);
       p->lw_off = (int)img.size();
       img.resize(img.size() + p->comps.size() * LW_WORDS, 0u);  // records (selection masks and bases inline)
@@ -711,7 +729,7 @@ retry_pack:
             for (size_t ci = 0; ci < p->comps.size(); ++ci) {
               double g = 0;
               for (auto &lv : p->comps[ci].levels) g += lv.G;
-              cost += (double)(t.npat[ci] << p->comps[ci].n_out) * g / (double)p->comps[ci].levels.size();
+              cost += (double)(p->comps[ci].trie ? std::min(t.chunks[ci], t.npat[ci] * 64) * 8 : (t.npat[ci] << p->comps[ci].n_out)) * g / (double)p->comps[ci].levels.size();
             }
           std::copy(keep.begin(), keep.end(), img.begin() + p->lw_off);
           if (cost <= 1.2e8) break;
@@ -953,7 +971,7 @@ retry_pack:
         // register form of the first pass (k_sample_lw_reg): selection masks over the f row and, per word, the
         // number of selected bits in the lower words.  Needs ascending f_selection (then the position of an f bit
         // inside f_sel is a popcount), f indices below 128 and at most 64 outputs.
-        p->lw_reg = p->max_f_index < 128 && p->num_outputs <= 64 && !p->narrow_big;
+        p->lw_reg = p->max_f_index < 128 && p->num_outputs <= 64 && !p->narrow_big && !p->lw_trie;
         for (auto &c : p->comps)
           for (int j = 1; j < c.F; ++j) p->lw_reg = p->lw_reg && c.f_selection[j] > c.f_selection[j - 1];
         if (p->narrow_big) {  // the table builder's binomials C(b, k + 1), k < 8, b < 256 (the wide path's [k][256] layout, saturated:
@@ -1265,6 +1283,11 @@ retry_pack:
               h[GR_WF32_MIN] = (uint32_t)wf32;
             }
           }
+        }
+        if (p->lw_trie && !p->gr_off) {  // (only k_sample_gen walks the prefix trees)
+          p->lw = false;
+          p->lw_trie = false;
+          p->lw_wmax.clear();
         }
       } else {
         p->lw_wmax.clear();

@@ -2,6 +2,7 @@
 // (TSIM_ROWS_FAST = true: pack-time algebra / false: operation-by-operation mirror of the reference).
 // Included by tsim_rows_fast.hip and tsim_rows_faithful.hip so that the two sets compile in parallel.
 #include "tsim_internal.hip.h"
+#include "tsim_trie.hip.h"
 
 #ifndef TSIM_ROWS_FAST
 #error "define TSIM_ROWS_FAST (true/false) and TSIM_ROWS_NAME(sym) before including this file"
@@ -45,7 +46,43 @@ int TSIM_ROWS_NAME(eval)(int W, const EvalArgs &a, hipStream_t s) {
 
 // pattern-table build (tsim_lw.hip.h): components with <= 64 parameters use W = 1, 2; wide components
 // (multi-word patterns) the W of their rows
+// ... as a chunked prefix tree (tsim_trie.hip.h): breadth first, one chunk level (three outputs) after the other; per level
+// one launch per local depth (every lane of a launch evaluates the same level), then the thresholds and the children.  The
+// ranges live on the device (the scratch header): nothing here waits for the GPU.
+static int TSIM_ROWS_NAME(trie_build)(int W, const LwBuildArgs &a0, int n_out, hipStream_t s) {
+  const int nlev = trie_levels(n_out);
+  const long long roots = a0.pat_count ? a0.pat_count : a0.npat - a0.pat_begin;
+  hipLaunchKernelGGL((k_trie_begin<TSIM_ROWS_FAST>), dim3(1), dim3(1), 0, s, a0);
+  for (int L = 0; L < nlev; ++L) {
+    LwBuildArgs a = a0;
+    a.trie_level = L;
+    const int rem = trie_outputs(n_out, L);
+    // level 0 has exactly `roots` chunks; deeper levels hold what the device allocated: a chip-full of blocks strides over it
+    for (int d = (L == 0 ? -1 : 0); d < rem; ++d) {
+      a.depth = d;
+      const long long lanes = roots << (d < 0 ? 0 : d);
+      const unsigned grid = L == 0 ? (unsigned)std::min<long long>((lanes + 255) / 256, 8192) : 2048u;
+      switch (W) {
+#define TSIM_X(WV)                                                                                 \
+  case WV:                                                                                         \
+    hipLaunchKernelGGL((k_trie_nodes<WV, TSIM_ROWS_FAST>), dim3(grid), dim3(256), 0, s, a);        \
+    break;
+        TSIM_FOR_EACH_W(TSIM_X)
+#undef TSIM_X
+        default: return tsim_fail(TSIM_ENOTSUP, "pattern tables: unsupported word count %d", W);
+      }
+      HIP_TRY(hipGetLastError());
+    }
+    const unsigned gridf = L == 0 ? (unsigned)std::min<long long>((roots + 255) / 256, 8192) : 2048u;
+    hipLaunchKernelGGL((k_trie_finish<TSIM_ROWS_FAST>), dim3(gridf), dim3(256), 0, s, a);
+    if (L + 1 < nlev) hipLaunchKernelGGL((k_trie_advance<TSIM_ROWS_FAST>), dim3(1), dim3(1), 0, s, a);
+    HIP_TRY(hipGetLastError());
+  }
+  return 0;
+}
+
 int TSIM_ROWS_NAME(lw_build)(int W, const LwBuildArgs &a0, int n_out, hipStream_t s) {
+  if (a0.trie) return TSIM_ROWS_NAME(trie_build)(W, a0, n_out, s);
   // one launch per depth (every lane of a launch evaluates the same level), then the thresholds
   for (int d = -1; d < n_out; ++d) {
     LwBuildArgs a = a0;

@@ -425,7 +425,8 @@ int flush_batch(tsim_program *p) {
     }
   // (a group whose first pass stored partial rows and component masks - steps_group_fused - was promised this kernel)
   const bool partial = p->slots[p->deferred[0]].partial;
-  if (partial || hw_eligible(p, M.ctx[0], M.n_ctx)) {
+  // (no chunk tables - a program of prefix-tree tables whose graphs exceed them: the block-per-row kernel is all there is)
+  if (partial || hw_eligible(p, M.ctx[0], M.n_ctx) || !p->v4) {
     if (int r = launch_hw(p, M.ctx, M.n_ctx, max_lists, hs, partial)) return r;  // (its overflow workers ride in the same grid)
   } else {
   // (each block walks its list in strides of hb * 64 slots: at most 16 of them, the rest is the worker blocks')
@@ -624,7 +625,8 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
   if (big_out) use_tables = false;
   // a narrow program with more than 64 selected bits in a component: the one-batch first passes (k_sample_lw / _lw_reg / _lw_fast as a
   // group of one) hold f_sel in 64 bits - every row on the chunk-table kernel here; the fused groups ride k_sample_gen
-  if (p->narrow_big) use_tables = false;
+  // ... and prefix-tree tables (components of more than 12 outputs, tsim_trie.hip.h) are walked by k_sample_gen only
+  if (p->narrow_big || p->lw_trie) use_tables = false;
   if (int r = tsim_tables_slice(p, s)) return r;  // (a table build in the background: its next slice goes first)
   // The sparse-column pass (k_sample4w) over every row, or - behind a pattern-table first pass - over that pass's
   // hard-row lists (from_lists; `a` then describes them).  Its own overflow (more than K set bits, the check row)
@@ -1383,7 +1385,8 @@ extern "C" int tsim_sample_steps_device(tsim_program *p, int32_t n_steps, const 
       have_plan = true;
       // (narrow_big: the one-batch path runs no table pass - f_sel beyond 64 bits - so it never reports the list lengths `defer`
       // waits for: fused whenever the plan says "tables"; long lists are the hard-row grid's worker blocks' business)
-      fused = (plan.defer || p->narrow_big) && plan.use_tables && p->h_group_tiles >= 1;
+      // (prefix-tree tables: likewise - and without chunk tables, p->v4, the plan never defers)
+      fused = (plan.defer || p->narrow_big || p->lw_trie) && plan.use_tables && p->h_group_tiles >= 1;
     }
     if (fused) {
       // even groups of at most TSIMK_LWM_MAX_STEPS batches

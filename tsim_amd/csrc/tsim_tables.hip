@@ -8,6 +8,7 @@
 // feedback says that a deeper table would pay - unless the caller pinned the depth
 // (tsim_program_set_pattern_tables).  Results never depend on the depth.
 #include "tsim_internal.hip.h"
+#include "tsim_trie.hip.h"
 
 #include <atomic>
 #include <chrono>
@@ -25,6 +26,21 @@ static long long binom(long long n, int k) {
   return r;
 }
 
+// chunks of a pattern's FULL outcome tree (no node pruned), saturated
+static long long trie_full_chunks(int n_out) {
+  long long tot = 0, lvl = 1;
+  for (int k = 0; k < tsimk::trie_levels(n_out); ++k) {
+    tot += lvl;
+    if (tot > (1ll << 40)) return 1ll << 40;
+    lvl *= 1ll << tsimk::trie_outputs(n_out, k);
+  }
+  return tot;
+}
+// scratch of the build of component `ci` under plan `t` (bytes): node values (dense), header + one TrieMeta per chunk (trie)
+static size_t tables_scratch_bytes(const tsim_program *p, size_t ci, const TsimTablePlan &t) {
+  if (p->comps[ci].trie) return (size_t)tsimk::TH_WORDS * 4 + (size_t)t.chunks[ci] * sizeof(tsimk::TrieMeta);
+  return std::max<size_t>(16, (size_t)(t.npat[ci] << p->comps[ci].n_out) * 4);
+}
 // The depth-dependent words of the LW records at image offset `rec_off` (the live records at p->lw_off, or their
 // shadow copy at p->lw_shadow_off that a build in the background works from) for tables up to weight `cap` within
 // `budget` bytes per component (4 x that per program).  Returns false if some component gets no table.
@@ -32,34 +48,54 @@ bool tsim_tables_plan_at(tsim_program *p, int cap, long long budget, int rec_off
   std::vector<uint32_t> &img = p->img;
   out.wmax.clear();
   out.npat.clear();
+  out.chunks.clear();
   long long tab_off = 0;
   for (size_t ci = 0; ci < p->comps.size(); ++ci) {
     const HostComponent &c = p->comps[ci];
     long long npat = 0;
     int wmax = -1;
     uint32_t bases[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // Prefix-tree format: the roots of every tabulated pattern may take a quarter of the component's budget (512 MB unless the
+    // caller named one); the rest is handed out while the trees are built, lightest patterns first (tsim_trie.hip.h)
+    const long long tbudget = std::min(budget, p->lw_trie_budget);
     for (int w = 0; w <= cap && w <= TSIMK_LW_MAX_WEIGHT; ++w) {
       const long long cnt = binom(c.F, w);
-      const long long bytes = ((npat + cnt) << c.n_out) * 4;  // (the component's table starts on a 128-byte line)
-      if (bytes > budget || (w > 1 && tab_off * 4 + bytes > 4 * budget)) break;  // per component / all together
-      if (((npat + cnt) << c.n_out) + tab_off >= (1ll << 32)) break;              // float offsets are 32-bit
-      // one wide component (k_sample_wide): byte offsets into the table are 32-bit there - a deeper table of 4 GiB or more would
-      // push the program off that kernel for good
-      // (per component since round 5: every pass of k_sample_wide gets its component's table as its base)
-      if (p->lw_wide && bytes >= (1ll << 32)) break;
+      if (c.trie) {
+        if ((npat + cnt) * 32 > tbudget / 4 && w > 0) break;
+        if ((npat + cnt) * 32 > tbudget) break;
+      } else {
+        const long long bytes = ((npat + cnt) << c.n_out) * 4;  // (the component's table starts on a 128-byte line)
+        if (bytes > budget || (w > 1 && tab_off * 4 + bytes > 4 * budget)) break;  // per component / all together
+        if (((npat + cnt) << c.n_out) + tab_off >= (1ll << 32)) break;              // float offsets are 32-bit
+        // one wide component (k_sample_wide): byte offsets into the table are 32-bit there - a deeper table of 4 GiB or more would
+        // push the program off that kernel for good
+        // (per component since round 5: every pass of k_sample_wide gets its component's table as its base)
+        if (p->lw_wide && bytes >= (1ll << 32)) break;
+      }
       bases[w] = (uint32_t)npat;
       npat += cnt;
       wmax = w;
     }
     if (wmax < 0) return false;
+    long long chunks = 0;
+    if (c.trie) {
+      const long long full = trie_full_chunks(c.n_out);
+      chunks = std::max(npat, std::min(tbudget / 32, npat >= (1ll << 40) / full ? (1ll << 40) : npat * full));
+      if (chunks * 8 + tab_off >= (1ll << 32)) chunks = ((1ll << 32) - 64 - tab_off) / 8;
+      if (chunks < npat) return false;
+    }
     uint32_t *r = &img[(size_t)rec_off + ci * LW_WORDS];
     r[LW_WMAX] = (uint32_t)wmax;
     r[LW_TAB] = (uint32_t)tab_off;
     r[LW_NPAT] = (uint32_t)npat;
+    r[LW_FMT] = c.trie ? 1u : 0u;
+    r[LW_CHUNKS] = (uint32_t)chunks;
+    r[LW_NPAT_OK] = (uint32_t)npat;  // (a prefix-tree build lowers it when the budget ends it early: trie_build_sync)
     memcpy(r + LW_BASES_INLINE, bases, sizeof bases);  // (LW_BASES of the live record points at these words)
     out.wmax.push_back(wmax);
     out.npat.push_back(npat);
-    tab_off += npat << c.n_out;
+    out.chunks.push_back(chunks);
+    tab_off += c.trie ? chunks * 8 : (npat << c.n_out);
     tab_off = (tab_off + 31) & ~31ll;  // 128-byte lines: the first pass reads a node's subtree as 8- and 16-byte words
   }
   out.bytes = tab_off * 4;
@@ -74,6 +110,7 @@ bool tsim_tables_plan(tsim_program *p, int cap, long long budget) {
   if (!tsim_tables_plan_at(p, cap, budget, p->lw_off, t)) return false;
   p->lw_wmax = t.wmax;
   p->lw_npat = t.npat;
+  p->lw_chunks = t.chunks;
   p->lw_bytes = t.bytes;
   return true;
 }
@@ -99,6 +136,37 @@ static void enumerate_patterns(int F, int wmax, std::vector<unsigned long long> 
   }
 }
 
+// The prefix trees of one component, slice after slice of patterns in table order (weight by weight), each slice built to
+// its full depth and waited for before the next goes out: when the budget runs out inside a slice, the patterns before
+// that slice are complete and the first pass is told so (LW_NPAT_OK: a row whose pattern lies beyond is a hard row before
+// it reads anything).  Slice sizes follow what the patterns so far have cost: at most a quarter of the chunks left.
+static int trie_build_sync(tsim_program *p, const tsimk::LwBuildArgs &a0, int W, int n_out, hipStream_t s, std::atomic<bool> *abort,
+                           long long *npat_ok, int *slices) {
+  long long next = 0, per = 64;
+  *npat_ok = 0;
+  uint32_t h[tsimk::TH_WORDS] = {0};
+  while (next < (long long)a0.npat) {
+    if (abort && abort->load(std::memory_order_acquire)) return -1;
+    tsimk::LwBuildArgs a = a0;
+    a.pat_begin = (int)next;
+    a.pat_count = (int)std::min<long long>(per, (long long)a0.npat - next);
+    if (int r = tsim_launch_lw_build(W, p->fast, a, n_out, s)) return r;
+    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(hipMemcpy(h, a0.p1, sizeof h, hipMemcpyDeviceToHost));
+    if (slices) ++*slices;
+    if (h[tsimk::TH_LOST] != 0u) break;  // (some tree of this slice is cut short)
+    next += a.pat_count;
+    *npat_ok = next;
+    const long long used = (long long)h[tsimk::TH_NEXT] - (long long)a0.npat, left = (long long)a0.trie_cap - (long long)h[tsimk::TH_NEXT];
+    const long long avg = std::max<long long>(1, used / next);
+    per = std::max<long long>(64, std::min<long long>(1ll << 16, left / (4 * avg)));
+  }
+  if (tsim_debug("tables"))
+    fprintf(stderr, "[tsim] prefix-tree tables: %lld of %d patterns complete, %u of %u chunks (%.1f MB), %u children refused\n", *npat_ok, a0.npat,
+            std::min(h[tsimk::TH_NEXT], h[tsimk::TH_VALID_END]), a0.trie_cap, (double)std::min(h[tsimk::TH_NEXT], h[tsimk::TH_VALID_END]) * 32e-6, h[tsimk::TH_LOST]);
+  return 0;
+}
+
 // Allocate and fill the tables of plan `t`, whose records lie at image offset `rec_off` (host image; the device image must
 // hold them too), on stream `s`.  wait: return when they are built (scratch freed); otherwise the kernels are queued and
 // the scratch buffers handed back in `scratch` (the caller frees them once `s` has passed them).
@@ -112,9 +180,8 @@ static int tables_build_at(tsim_program *p, int rec_off, const TsimTablePlan &t,
     const long long tab_off = (long long)p->img[(size_t)rec_off + ci * LW_WORDS + LW_TAB];
     // (no pattern list: the build kernels unrank the row index, narrow components on lw_rank_term, wide ones in
     // the binomial table - the host enumeration + copy of 14 million patterns cost as much as the kernels)
-    const long long lanes = t.npat[ci] << c.n_out;
     float *p1 = nullptr;
-    hipError_t e = hipMalloc((void **)&p1, std::max<size_t>(16, (size_t)lanes * 4));  // node values
+    hipError_t e = hipMalloc((void **)&p1, tables_scratch_bytes(p, ci, t));  // node values
     LwBuildArgs a;
     a.img = p->d_img;
     a.patbits = nullptr;
@@ -129,8 +196,17 @@ static int tables_build_at(tsim_program *p, int rec_off, const TsimTablePlan &t,
     a.depth = -1;
     a.pat_begin = 0;
     a.pat_count = 0;
+    a.trie = c.trie ? 1 : 0;
+    a.trie_level = 0;
+    a.trie_cap = (uint32_t)t.chunks[ci];
     int r = 0;
-    if (e == hipSuccess) r = tsim_launch_lw_build(p->comp_w[ci], p->fast, a, c.n_out, s);
+    if (e == hipSuccess && c.trie) {
+      long long okp = 0;
+      r = trie_build_sync(p, a, p->comp_w[ci], c.n_out, s, nullptr, &okp, nullptr);
+      const uint32_t v = (uint32_t)okp;
+      p->img[(size_t)rec_off + ci * LW_WORDS + LW_NPAT_OK] = v;
+      if (r == 0) e = hipMemcpy(p->d_img + rec_off + ci * LW_WORDS + LW_NPAT_OK, &v, 4, hipMemcpyHostToDevice);
+    } else if (e == hipSuccess) r = tsim_launch_lw_build(p->comp_w[ci], p->fast, a, c.n_out, s);
     if (e == hipSuccess && r == 0 && wait) e = hipStreamSynchronize(s);
     if (p1 && (wait || r || e != hipSuccess)) (void)hipFree(p1);
     else if (p1) scratch.push_back(p1);
@@ -152,6 +228,7 @@ int tsim_tables_build(tsim_program *p, uint32_t **old) {
   TsimTablePlan t;
   t.wmax = p->lw_wmax;
   t.npat = p->lw_npat;
+  t.chunks = p->lw_chunks;
   t.bytes = p->lw_bytes;
   uint32_t *tab = nullptr;
   std::vector<void *> scratch;
@@ -200,9 +277,8 @@ static void ext_alloc_thread(tsim_program *p) {
   for (size_t ci = 0; state > 0 && ci < p->comps.size(); ++ci) {
     const HostComponent &c = p->comps[ci];
     const long long tab_off = (long long)p->img[(size_t)p->lw_shadow_off + ci * LW_WORDS + LW_TAB];
-    const long long lanes = p->ext_plan.npat[ci] << c.n_out;
     float *p1 = nullptr;
-    if (hipMalloc((void **)&p1, std::max<size_t>(16, (size_t)lanes * 4)) != hipSuccess) { state = -1; break; }
+    if (hipMalloc((void **)&p1, tables_scratch_bytes(p, ci, p->ext_plan)) != hipSuccess) { state = -1; break; }
     p->ext_scratch.push_back(p1);
     LwBuildArgs a;
     a.img = p->d_img;
@@ -218,6 +294,9 @@ static void ext_alloc_thread(tsim_program *p) {
     a.depth = -1;
     a.pat_begin = 0;
     a.pat_count = 0;
+    a.trie = c.trie ? 1 : 0;
+    a.trie_level = 0;
+    a.trie_cap = (uint32_t)p->ext_plan.chunks[ci];
     p->ext_jobs.push_back(TsimBuildJob{a, p->comp_w[ci], c.n_out, 0});
   }
   if (state < 0) {
@@ -249,7 +328,16 @@ static void ext_alloc_thread(tsim_program *p) {
     if (state > 0 && hipMemcpyAsync(p->d_img + p->lw_shadow_off, p->img.data() + p->lw_shadow_off, rec_words * 4, hipMemcpyHostToDevice, bs) != hipSuccess) state = -1;
     for (size_t ji = 0; state > 0 && ji < p->ext_jobs.size(); ++ji) {
       TsimBuildJob &j = p->ext_jobs[ji];
-      const long long per = std::max<long long>(1, p->ext_entries >> j.n_out);
+      if (j.a.trie) {  // (slices of its own: trie_build_sync)
+        long long okp = 0;
+        if (trie_build_sync(p, j.a, j.W, j.n_out, bs, &p->ext_abort, &okp, &p->ext_slices) != 0) { state = -1; break; }
+        const uint32_t v = (uint32_t)okp;
+        p->img[(size_t)p->lw_shadow_off + ji * LW_WORDS + LW_NPAT_OK] = v;
+        if (hipMemcpy(p->d_img + p->lw_shadow_off + ji * LW_WORDS + LW_NPAT_OK, &v, 4, hipMemcpyHostToDevice) != hipSuccess) { state = -1; break; }
+        j.next_pat = (long long)j.a.npat;
+        continue;
+      }
+      const long long per = std::max<long long>(1, j.a.trie ? p->ext_entries >> 9 : p->ext_entries >> j.n_out);
       while (state > 0 && j.next_pat < (long long)j.a.npat) {
         if (p->ext_abort.load(std::memory_order_acquire)) { state = -1; break; }
         tsimk::LwBuildArgs a = j.a;
@@ -277,6 +365,9 @@ static void ext_alloc_thread(tsim_program *p) {
 int tsim_tables_extend_begin(tsim_program *p, int target_cap) {
   target_cap = std::min(target_cap, p->lw_cap_max);
   if (!p->lw || p->lw_cap_now >= target_cap || p->ext_pending) return 0;
+  // (prefix-tree tables are built by the helper thread alone, slice by slice with the budget in view: the shallow start's
+  // default depth - nothing deeper, and never by the launch plans' slices)
+  if (p->lw_trie && !(p->lw_cap_now < p->lw_cap_default && target_cap <= p->lw_cap_default)) return 0;
   // (the shallow start's build of the default depth goes out in slices four times as large: until it is in place most rows of
   // an expensive program are hard rows - C4 at weight 2: 1.8e9 instead of 3e10 shots/s - so the build IS the work that matters)
   const bool stage_a = p->lw_cap_now < p->lw_cap_default && target_cap <= p->lw_cap_default;
@@ -315,7 +406,7 @@ int tsim_tables_slice(tsim_program *p, hipStream_t s) {
   // the gaps the other lane's first pass leaves, so a slice lasts about one first pass however small it is: smaller slices
   // for expensive programs (cultivation shape, 2^18: 1238 slices, 1.3 s instead of 143 slices, 0.27 s) and slices sized by
   // their measured time (the events span the other lane's pass: the size collapsed) were both worse.
-  const long long per = std::max<long long>(1, p->ext_entries >> j.n_out);
+  const long long per = std::max<long long>(1, j.a.trie ? p->ext_entries >> 9 : p->ext_entries >> j.n_out);
   a.pat_begin = (int)j.next_pat;
   a.pat_count = (int)std::min<long long>(per, (long long)a.npat - j.next_pat);
   if (int r = tsim_launch_lw_build(j.W, p->fast, a, j.n_out, s)) return r;
@@ -405,6 +496,8 @@ int tsim_tables_extend_poll(tsim_program *p, bool wait) {
     r[LW_WMAX] = sh[LW_WMAX];
     r[LW_TAB] = sh[LW_TAB];
     r[LW_NPAT] = sh[LW_NPAT];
+    r[LW_CHUNKS] = sh[LW_CHUNKS];
+    r[LW_NPAT_OK] = sh[LW_NPAT_OK];
     memcpy(r + LW_BASES_INLINE, sh + LW_BASES_INLINE, 8 * sizeof(uint32_t));
   }
   HIP_TRY(hipMemcpy(p->d_img + p->lw_off, p->img.data() + p->lw_off, rec_words * 4, hipMemcpyHostToDevice));
@@ -413,6 +506,7 @@ int tsim_tables_extend_poll(tsim_program *p, bool wait) {
   p->ext_tab = nullptr;
   p->lw_wmax = p->ext_plan.wmax;
   p->lw_npat = p->ext_plan.npat;
+  p->lw_chunks = p->ext_plan.chunks;
   p->lw_bytes = p->ext_plan.bytes;
   for (void *q : p->ext_scratch) (void)hipFree(q);
   p->ext_scratch.clear();

@@ -29,7 +29,10 @@ def test_c_oracle_matches_numpy_on_baseline_configs(name):
     f = synth.synth_f(n, cfg["num_f"], cfg["p_bit"] * 3, seed=7)
     want, wd = O.sample_program(prog, f, (3, 4), return_devs=True)
     got, gd, ov = OC.OracleProgram(prog).sample_program(f, (3, 4), return_devs=True, return_overflow=True)
-    assert not ov, "reference int32 arithmetic would wrap on this input"
+    if name == "n24x":  # the unconstrained 24-output mixture: the reference's int32 coefficients DO wrap - both restatements wrap alike
+        assert ov
+    else:
+        assert not ov, "reference int32 arithmetic would wrap on this input"
     np.testing.assert_array_equal(got, want)
     np.testing.assert_array_equal(np.asarray(gd, np.float32), np.asarray(wd, np.float32))
 
@@ -74,7 +77,8 @@ def test_overflow_flag_fires():
     assert ov
 
 
-@pytest.mark.parametrize("name", ["F60", "F70", "F140", "F300", "2wide", "narrow+wide", "n11", "out260_f320", "6narrow_f320"])
+@pytest.mark.parametrize("name", ["F60", "F70", "F140", "F300", "2wide", "narrow+wide", "n11", "out260_f320", "6narrow_f320",
+                                  "n16", "n40", "n24x", "w12", "20narrow", "9wide", "F600"])  # (the last row: round 6, beyond the compiled-in walls)
 def test_c_oracle_matches_numpy_on_shape_classes(name):
     """The GPU parity tests of the round-5 shapes (65..128 parameters, several wide components, more than 255 selected
     bits, 11 outputs per component, 260 outputs) use the C oracle as their checker: pin IT to the numpy restatement of the
@@ -84,6 +88,9 @@ def test_c_oracle_matches_numpy_on_shape_classes(name):
     f = synth.synth_f(48, c["num_f"], 2.5 * c["p_bit"], seed=13)
     want, wd = O.sample_program(prog, f, (3, 7), return_devs=True)
     got, gd, ov = OC.OracleProgram(prog).sample_program(f, (3, 7), return_devs=True, return_overflow=True)
-    assert not ov, "reference int32 arithmetic would wrap on this input"
+    if name == "n24x":  # the unconstrained 24-output mixture: the reference's int32 coefficients DO wrap - both restatements wrap alike
+        assert ov
+    else:
+        assert not ov, "reference int32 arithmetic would wrap on this input"
     np.testing.assert_array_equal(got, want)
     np.testing.assert_array_equal(np.asarray(gd, np.float32), np.asarray(wd, np.float32))

@@ -493,7 +493,10 @@ bool pack_level_fast(HostLevel &h, int W, std::vector<uint32_t> &tables, bool &f
     };
     const int nthreads = G >= 16 ? std::min(G >= 64 ? 8 : 4, std::max(1, (int)std::thread::hardware_concurrency())) : 1;
     std::vector<std::thread> pool;
-    for (int t = 1; t < nthreads; ++t) pool.emplace_back(worker);
+    try {  // (a thread that cannot be created: the ones that exist - at least this one - pack the level)
+      for (int t = 1; t < nthreads; ++t) pool.emplace_back(worker);
+    } catch (...) {
+    }
     worker();
     for (auto &t : pool) t.join();
     if (failed.load()) return false;

@@ -1,6 +1,7 @@
 // tsim_program.hip - handle life cycle of the C ABI (include/tsim_hip.h): program description ->
 // packed image -> upload, plus the memory / stream plumbing.  No kernels are defined here.
 #include "tsim_internal.hip.h"
+#include <map>
 #include "tsim_sample_internal.hip.h"  // slot_prepare: the lanes are created before the table-build helper takes its stream
 #include "tsim_lw_fastm.hip.h"
 #include "tsim_kernel4w.hip.h"  // C4_SELMASK
@@ -33,14 +34,14 @@ int tsim_fail(int code, const char *fmt, ...) {
 // ---------------------------------------------------------------------------
 namespace {
 struct PooledStream { hipStream_t s; int index; bool free; };
-struct StreamPool { std::mutex m; std::vector<PooledStream> all[16]; };
+struct StreamPool { std::mutex m; std::map<int, std::vector<PooledStream>> all; };  // keyed by the real device id (`device & 15` aliased devices 16+)
 StreamPool &stream_pool() { static StreamPool *sp = new StreamPool; return *sp; }  // (never destroyed: HIP may be gone at exit)
 }  // namespace
 
 int tsim_stream_acquire(int device, std::vector<int> &held, hipStream_t *out) {
   StreamPool &sp = stream_pool();
   std::lock_guard<std::mutex> lk(sp.m);
-  auto &v = sp.all[device & 15];
+  auto &v = sp.all[device];
   unsigned busy_q = 0;
   for (int i : held) busy_q |= 1u << (i & 3);
   PooledStream *pick = nullptr;
@@ -66,7 +67,7 @@ void tsim_stream_release(int device, hipStream_t s) {
   (void)hipStreamSynchronize(s);
   StreamPool &sp = stream_pool();
   std::lock_guard<std::mutex> lk(sp.m);
-  for (auto &e : sp.all[device & 15])
+  for (auto &e : sp.all[device])
     if (e.s == s) { e.free = true; return; }
   (void)hipStreamDestroy(s);  // not one of ours
 }
@@ -367,14 +368,11 @@ retry_pack:
       for (auto &lv : c.levels) jobs.push_back({&lv, W});
     }
     prepacked.resize(jobs.size());
-    std::vector<std::thread> pool;
-    auto run = [&](size_t i) {
+    // (at most 8 levels at a time, each with its graphs on up to 8 threads of pack_level_fast's own bounded pool)
+    tsim_parallel_for(jobs.size(), 8, [&](size_t i) {
       if (jobs[i].second < 0) { prepacked[i].ok = true; return; }  // (reported below: too many parameters)
       prepacked[i].ok = pack_level_fast(*jobs[i].first, jobs[i].second, prepacked[i].tables, prepacked[i].fixed, prepacked[i].frame);
-    };
-    for (size_t i = 1; i < jobs.size(); ++i) pool.emplace_back(run, i);
-    if (!jobs.empty()) run(0);
-    for (auto &t : pool) t.join();
+    });
   }
   for (size_t ci = 0; ci < p->comps.size(); ++ci) {
     HostComponent &c = p->comps[ci];
@@ -539,23 +537,25 @@ retry_pack:
       struct Emit4 { std::vector<uint32_t> recs4, tabs4, stabs4; int nch = 1, ntiles = 0, sparse_F = -1; };
       std::vector<std::vector<Emit4>> emitted(p->comps.size());
       {
-        std::vector<std::thread> pool;
+        std::vector<std::pair<size_t, int>> ejobs;
         for (size_t ci = 0; ci < p->comps.size(); ++ci) {
           HostComponent &c = p->comps[ci];
           emitted[ci].resize((size_t)c.n_levels);
           for (int k = 0; k < c.n_levels; ++k) {
             const bool sequential = (c.n_levels == c.n_out + 1);
             emitted[ci][(size_t)k].sparse_F = (wide || (sequential && c.n_out <= 8 && c.F + c.n_out <= 64)) ? c.F : -1;
-            pool.emplace_back([&, ci, k]() {
-              HostLevel &h = p->comps[ci].levels[(size_t)k];
-              Emit4 &e = emitted[ci][(size_t)k];
-              const uint32_t v3recs = img[(size_t)p->level_off[p->level_base[ci] + k] + L_GRAPHS];
-              std::vector<uint32_t> v3copy(img.begin() + v3recs, img.begin() + v3recs + (size_t)h.G * G_WORDS);
-              emit_level4(h, p->v4_gt, p->v4_max_nch, v3copy.data(), e.recs4, e.tabs4, e.nch, e.ntiles, e.sparse_F, e.stabs4);
-            });
+            ejobs.push_back({ci, k});
           }
         }
-        for (auto &t : pool) t.join();
+        tsim_parallel_for(ejobs.size(), 16, [&](size_t j) {
+          const size_t ci = ejobs[j].first;
+          const int k = ejobs[j].second;
+          HostLevel &h = p->comps[ci].levels[(size_t)k];
+          Emit4 &e = emitted[ci][(size_t)k];
+          const uint32_t v3recs = img[(size_t)p->level_off[p->level_base[ci] + k] + L_GRAPHS];
+          std::vector<uint32_t> v3copy(img.begin() + v3recs, img.begin() + v3recs + (size_t)h.G * G_WORDS);
+          emit_level4(h, p->v4_gt, p->v4_max_nch, v3copy.data(), e.recs4, e.tabs4, e.nch, e.ntiles, e.sparse_F, e.stabs4);
+        });
       }
       for (size_t ci = 0; ci < p->comps.size(); ++ci) {
         HostComponent &c = p->comps[ci];
@@ -1383,6 +1383,18 @@ extern "C" void tsim_program_destroy(tsim_program *p) {
       if (sl.side && !sl.side_borrowed) tsim_stream_release(p->device, sl.side);
     }
     if (p->stream) tsim_stream_release(p->device, p->stream);
+  } else if (p->device >= 0) {
+    // a finalize that failed after it had taken streams / device memory (the pooled streams stayed marked busy for good)
+    if (p->ext_thread.joinable()) { p->ext_abort.store(true, std::memory_order_release); p->ext_thread.join(); }
+    if (p->ext_stream) tsim_stream_release(p->device, p->ext_stream);
+    for (auto &sl : p->slots)
+      if (sl.side && !sl.side_borrowed) tsim_stream_release(p->device, sl.side);
+    if (p->stream) tsim_stream_release(p->device, p->stream);
+    if (p->d_img) (void)hipFree(p->d_img);
+    if (p->d_dev) (void)hipFree(p->d_dev);
+    if (p->d_lw_tab) (void)hipFree(p->d_lw_tab);
+    if (p->h_feedback) (void)hipHostFree((void *)p->h_feedback);
+    (void)hipGetLastError();
   }
   delete p;
 }

@@ -399,7 +399,11 @@ int flush_batch(tsim_program *p) {
   Hard4Multi M{};
   M.n_ctx = (int)p->deferred.size();
   const uint32_t fb_max = p->h_feedback ? p->h_feedback[1] : 192u;
-  const int hb = (int)std::max(1u, std::min(4u, (std::min(fb_max, 192u) + 32u + 63u) / 64u));
+  // (so many hard rows that they are throughput work - below: the 8-waves-per-64-rows blocks take ONE block's worth of every list,
+  // the per-shot workers everything behind it)
+  const uint32_t fb_sum0 = p->h_feedback ? p->h_feedback[0] : 0xFFFFFFFFu;
+  const bool many0 = over_available(p) && fb_sum0 != 0xFFFFFFFFu && (unsigned long long)fb_sum0 * (unsigned)p->deferred.size() > 16384ull;
+  const int hb = many0 ? 1 : (int)std::max(1u, std::min(4u, (std::min(fb_max, 192u) + 32u + 63u) / 64u));
   int max_lists = 1;
   for (int sidx : p->deferred) max_lists = std::max(max_lists, p->slots[sidx].ctx.row_lists);
   M.blocks_per_ctx = hb * max_lists + 1;

@@ -211,18 +211,31 @@ def test_modes_evaluate_exact(hip, mode, approx):
 
 
 def test_auto_falls_back_to_faithful_when_not_eligible(hip):
-    """> 30 NodePhases terms in one graph: the reference's int32 scan may wrap -> faithful layout."""
+    """So many NodePhases terms in one graph that the reference's int32 scan may wrap -> faithful layout.  The bound (round 6,
+    tsim_pack.hip: level_fast_eligible) prices a term by what it can add to log2 of the running coefficients under the scan's
+    one-reduction-per-product rule: 0 for deltas (phase 0 / 4), 1/2 for phase 2 / 6, 0.886 for odd phases; 29 bits is the limit."""
     from tsim_amd.program import CompiledComponent, empty_scalar_graphs, make_program, scalar_graphs_from_terms
 
-    lv = scalar_graphs_from_terms(3, [dict(A=[(1 + 2 * (t % 4), [t % 3]) for t in range(31)])])
-    comp = CompiledComponent((0, 1, 2), np.zeros(0, np.int32), (empty_scalar_graphs(0), lv))
-    prog = make_program([comp], [], 3, 0)
-    hp = hip.HipProgram(prog)
-    assert not hp.fast
-    pv = np.array([[0, 0, 0], [1, 0, 1], [1, 1, 1]], np.uint8)
-    z, ex = hp.evaluate(0, 1, pv, exact=True)
-    coeffs, power = O.evaluate_exact(lv, pv)
-    np.testing.assert_array_equal(ex[:, :4], coeffs)
+    pv = np.array([[0, 0, 0], [1, 0, 1], [1, 1, 1], [0, 1, 0]], np.uint8)
+    cases = [
+        ([(1 + 2 * (t % 4), [t % 3]) for t in range(40)], False),             # 40 odd phases: 36 bits
+        ([(1 + 2 * (t % 4), [t % 3]) for t in range(31)], True),              # 31 odd phases: 28.5 bits - cannot wrap
+        ([(4 * (t % 2), [t % 3, (t + 1) % 3][: 1 + t % 2]) for t in range(45)], True),   # 45 deltas: the running value never grows
+        ([(2 + 4 * (t % 2), [t % 3]) for t in range(50)] + [(1, [0]), (7, [1])], True),  # 50 x (1 +- i) and two odd: 27.8 bits
+        ([(2 + 4 * (t % 2), [t % 3]) for t in range(60)], False),             # 60 x (1 +- i): 31 bits
+    ]
+    for terms, want_fast in cases:
+        lv = scalar_graphs_from_terms(3, [dict(A=terms)])
+        comp = CompiledComponent((0, 1, 2), np.zeros(0, np.int32), (empty_scalar_graphs(0), lv))
+        prog = make_program([comp], [], 3, 0)
+        hp = hip.HipProgram(prog)
+        assert hp.fast == want_fast, (len(terms), hp.fast)
+        z, ex = hp.evaluate(0, 1, pv, exact=True)
+        coeffs, power = O.evaluate_exact(lv, pv)
+        np.testing.assert_array_equal(ex[:, :4], coeffs)
+        nz = np.any(np.asarray(coeffs) != 0, axis=1)
+        np.testing.assert_array_equal(ex[nz, 4], np.asarray(power)[nz])
+        hp.close()
 
 
 @pytest.mark.parametrize("mode", ["auto", "rows", "faithful"])

@@ -17,6 +17,10 @@ struct tsim_noise {
   uint32_t *d_off = nullptr;
   uint32_t *d_cdf = nullptr;
   uint64_t *d_pat = nullptr;
+  // k_noise_wave (round 6): groups of g lanes per (channel, tile); the outcomes' non-zero pattern words as records
+  int wave_g = 0;              // 0: that kernel does not apply
+  int wave_tile = 0;
+  uint32_t *d_pw_off = nullptr, *d_pw = nullptr;
 };
 
 extern "C" int tsim_noise_create(tsim_program *p, int32_t num_f, int32_t n_channels, const double *p_fire,
@@ -73,7 +77,44 @@ extern "C" int tsim_noise_create(tsim_program *p, int32_t num_f, int32_t n_chann
     while (ts < n->tile && ts * pmax < 4.0) ts *= 2;
     n->tseg = ts;
   }
+  // k_noise_wave: the tile as above (at most 4096 shots: the fires a channel expects in it decide the group size); lanes per
+  // group: about 1.5 x the expected fires of the most active channel / 2 gaps per lane.  TSIM_AMD_TUNE=noise_wave=0: k_noise_tile
+  std::vector<uint32_t> pw_off(tot + 1, 0u), pw;
+  for (size_t o = 0; o < tot; ++o) {
+    for (int w = 0; w < n->WF; ++w)
+      if (pat[o * n->WF + w]) {
+        pw.push_back((uint32_t)w);
+        pw.push_back((uint32_t)pat[o * n->WF + w]);
+        pw.push_back((uint32_t)(pat[o * n->WF + w] >> 32));
+        pw.push_back(0u);
+      }
+    pw_off[o + 1] = (uint32_t)(pw.size() / 4);
+  }
+  if (pw.empty()) pw.assign(4, 0u);
+  n->wave_g = 0;
+  {
+    const char *tn = getenv("TSIM_AMD_TUNE");
+    const bool off = tn && strstr(tn, "noise_wave=0");
+    if (n->WF * 8 * 64 <= 48 * 1024 && !off && (size_t)n_channels * 24 <= 24 * 1024) {
+      // rows of the tile in up to 48 KB of LDS, at most 4096 shots (C2: 4096 x 8 B, C3: 2048 x 16 B, C5: 1024 x 40 B)
+      n->wave_tile = 64;
+      while (n->wave_tile < 4096 && (size_t)n->wave_tile * 2 * n->WF * 8 <= 48 * 1024) n->wave_tile *= 2;
+      if (tn && strstr(tn, "noise_tile=")) n->wave_tile = std::max(64, std::min(8192, atoi(strstr(tn, "noise_tile=") + 11)));
+      // gaps per round: what covers the tile in ONE round but for ~2 % of the groups (mean + two sigma of the fires a channel expects)
+      const double fires = pmax * n->wave_tile;
+      int g = 8;
+      while (g < 64 && 2.0 * g < fires + 2.0 * std::sqrt(fires) + 2.0) g *= 2;
+      if (tn && strstr(tn, "noise_g=")) g = std::max(8, std::min(64, atoi(strstr(tn, "noise_g=") + 8)));
+      n->wave_g = g;
+    }
+  }
   hipError_t e = hipSuccess;
+  if ((e = hipMalloc((void **)&n->d_pw_off, pw_off.size() * 4)) != hipSuccess || (e = hipMalloc((void **)&n->d_pw, pw.size() * 4)) != hipSuccess ||
+      (e = hipMemcpy(n->d_pw_off, pw_off.data(), pw_off.size() * 4, hipMemcpyHostToDevice)) != hipSuccess ||
+      (e = hipMemcpy(n->d_pw, pw.data(), pw.size() * 4, hipMemcpyHostToDevice)) != hipSuccess) {
+    tsim_noise_destroy(n);
+    return tsim_fail(TSIM_ENOMEM, "noise sampler tables: %s", hipGetErrorString(e));
+  }
   if ((e = hipMalloc((void **)&n->d_l1p, l1p.size() * 8)) != hipSuccess ||
       (e = hipMalloc((void **)&n->d_inv, inv.size() * 4)) != hipSuccess ||
       (e = hipMalloc((void **)&n->d_off, off.size() * 4)) != hipSuccess ||
@@ -102,6 +143,34 @@ extern "C" int tsim_noise_sample_device(tsim_noise *n, int64_t B, uint32_t key_h
   if (B == 0) return TSIM_OK;
   if (!d_f) return tsim_fail(TSIM_EINVAL, "f buffer is NULL");
   hipStream_t s = stream ? (hipStream_t)stream : n->prog->stream;
+  if (n->wave_g > 0 && n->n_ch > 0) {  // ... with groups of lanes per (channel, tile): k_noise_wave
+    NoiseWaveArgs a{};
+    a.inv_log2_1mp = n->d_inv;
+    a.cdf_off = n->d_off;
+    a.cdf = n->d_cdf;
+    a.pw_off = n->d_pw_off;
+    a.pw = n->d_pw;
+    a.f = (unsigned long long *)d_f;
+    a.B = B;
+    a.n_ch = n->n_ch;
+    a.WF = n->WF;
+    a.tile = n->wave_tile;
+    a.g = n->wave_g;
+    a.k0 = key_hi;
+    a.k1 = key_lo;
+    const long long tiles = (B + n->wave_tile - 1) / n->wave_tile;
+    if (tiles > 0x7FFFFFFFll) return tsim_fail(TSIM_ENOTSUP, "noise launch too large");
+    // threads: one group of g lanes per channel, up to 1024 (a grid of 245 tiles is one block per CU: the block's own chain -
+    // channels per group - is the kernel's time)
+    int threads = 256;
+    while (threads < 1024 && threads < n->n_ch * n->wave_g) threads *= 2;
+    if (const char *tn = getenv("TSIM_AMD_TUNE"))
+      if (strstr(tn, "noise_threads=")) threads = std::max(64, std::min(1024, atoi(strstr(tn, "noise_threads=") + 14) / 64 * 64));
+    threads = std::max(threads, n->wave_g);
+    hipLaunchKernelGGL(k_noise_wave, dim3((unsigned)tiles), dim3(threads), (size_t)n->wave_tile * n->WF * 8 + (size_t)n->n_ch * 24, s, a);
+    HIP_TRY(hipGetLastError());
+    return TSIM_OK;
+  }
   if (n->tile > 0 && n->n_ch > 0) {  // one block per tile of shots: rows built in LDS, written once (tsim_noise.hip.h)
     NoiseArgs a{};
     a.inv_log2_1mp = n->d_inv;
@@ -152,5 +221,7 @@ extern "C" void tsim_noise_destroy(tsim_noise *n) {
   if (n->d_off) (void)hipFree(n->d_off);
   if (n->d_cdf) (void)hipFree(n->d_cdf);
   if (n->d_pat) (void)hipFree(n->d_pat);
+  if (n->d_pw_off) (void)hipFree(n->d_pw_off);
+  if (n->d_pw) (void)hipFree(n->d_pw);
   delete n;
 }

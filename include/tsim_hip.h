@@ -503,6 +503,9 @@ int tsim_program_path_counts(tsim_program *p, int64_t out[TSIM_PATH_COUNT], int3
 
 const char *tsim_last_error(void);
 const char *tsim_version(void);
+/* The keys TSIM_AMD_TUNE="key=value,..." understands, comma separated (the launch planner's A/B switches; results never depend
+ * on them - tests/test_gpu_knobs.py runs an oracle slice under every one).  No counterpart in the reference. */
+const char *tsim_tune_keys(void);
 
 #ifdef __cplusplus
 }

@@ -20,7 +20,8 @@ seed0 = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 bad = 0
 for ps in range(seed0, seed0 + n_prog):
     rng = np.random.default_rng(31000 + ps)
-    kind = ps % 8  # 5, 6, 7: the shapes round 5 opened (several wide-path components / wide rows, 65..80 parameters, the general fused pass)
+    kind = ps % 10  # 5, 6, 7: the shapes round 5 opened (several wide-path components / wide rows, 65..80 parameters, the general fused pass);
+    # 8, 9: round 6 - components of 9..24 outputs (prefix-tree tables, tsim_trie.hip.h) and programs of up to 20 components
     if kind == 0:
         prog, cfg = synth.config_program("C2", approx=bool(rng.integers(0, 2)), live_padding=bool(rng.integers(0, 2)))
         nf = cfg["num_f"]
@@ -61,6 +62,28 @@ for ps in range(seed0, seed0 + n_prog):
                 G.append(G[-1] + int(rng.integers(0, 4)))
             comps.append(dict(n=n, F=F, G=G, density=0.2))
         prog = synth.physical_program(num_f=nf, n_direct=int(rng.integers(40, min(nf, 240))), components=comps, seed=int(rng.integers(0, 2**31)),
+                                      shuffle_outputs=bool(rng.integers(0, 2)), direct_flip_fraction=0.3, identity_direct=bool(rng.integers(0, 2)))
+    elif kind == 8:  # one or two components of 9..24 outputs; mostly deterministic outputs beyond 16 (the unconstrained mixture wraps int32 there)
+        nf = int(rng.choice([64, 96, 160]))
+        comps = []
+        for _ in range(int(rng.integers(1, 3))):
+            n = int(rng.integers(9, 25)); F = int(rng.integers(4, min(nf, 40)))
+            G = [int(rng.integers(1, 4))]
+            for _k in range(n):
+                G.append(G[-1] + int(rng.integers(0, 3)))
+            comps.append(dict(n=n, F=F, G=G, density=0.2, shared_delta=(0.8 if n > 16 else float(rng.choice([0.0, 0.5])))))
+        prog = synth.physical_program(num_f=nf, n_direct=int(rng.integers(0, 30)), components=comps, seed=int(rng.integers(0, 2**31)),
+                                      shuffle_outputs=bool(rng.integers(0, 2)), direct_flip_fraction=0.3, identity_direct=bool(rng.integers(0, 2)))
+    elif kind == 9:  # 5..20 small components (more than 16: beyond round 5's k_sample_gen)
+        nf = int(rng.choice([128, 192, 320]))
+        comps = []
+        for _ in range(int(rng.integers(5, 21))):
+            n = int(rng.integers(1, 3)); F = int(rng.integers(2, 12))
+            G = [int(rng.integers(1, 3))]
+            for _k in range(n):
+                G.append(G[-1] + int(rng.integers(0, 3)))
+            comps.append(dict(n=n, F=F, G=G, density=0.3))
+        prog = synth.physical_program(num_f=nf, n_direct=int(rng.integers(0, 60)), components=comps, seed=int(rng.integers(0, 2**31)),
                                       shuffle_outputs=bool(rng.integers(0, 2)), direct_flip_fraction=0.3, identity_direct=bool(rng.integers(0, 2)))
     else:  # random shapes: one component of 1..8 outputs (the specialised pass) or several (the general fused pass)
         nf = int(rng.choice([20, 40, 64, 90, 128]))

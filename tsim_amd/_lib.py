@@ -139,6 +139,7 @@ SYMBOLS: dict[str, tuple] = {
     "tsim_pipeline_next_slot": (C.c_int, [_P, C.POINTER(_I32)]),
     "tsim_last_error": (C.c_char_p, []),
     "tsim_version": (C.c_char_p, []),
+    "tsim_tune_keys": (C.c_char_p, []),
 }
 
 _lib = None

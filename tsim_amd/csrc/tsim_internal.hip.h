@@ -37,6 +37,12 @@
 #include <vector>
 
 #define TSIMK_H_MAX_CTX 8   // launches served by one deferred hard-row batch (k_sample4h_multi)
+// Launch constants that were A/B switches until round 4 / 5 (the experiments are closed: HISTORY.md, profiles/r03 .. r05)
+constexpr int kListRows = 40;        // expected rows per hard-row sub-list
+constexpr int kMinLists = 4;
+constexpr int kHardLdsKb = 128;      // k_sample4h: a first-pass block still fits next to a hard-row block
+constexpr int kV4Block = 256;        // k_sample4 block
+constexpr int kWideGlobGraphs = 48;  // components of up to this many graphs whose column tables do not fit the LDS run k_sample_wide with the tables in the L2
 
 // ---------------------------------------------------------------------------
 // errors: every entry point returns 0 or a negative TSIM_E* code; the message is thread-local
@@ -290,34 +296,16 @@ struct tsim_program {
     unsigned long long deep_after = 0;        // deep_after: rows in that state before the next depth is built; 0 = by the estimated build time
     int fused_lanes = 0;      // fused_lanes: first-pass lanes the fused groups rotate over (1-4; 0 = 2, 3 for small groups)
     int fused_max = 8;        // fused_max: batches per fused first pass (<= TSIMK_LWM_MAX_STEPS = 16)
-    bool wide = true;         // wide=0: wide components on the row kernel alone
     bool wide_tables = true;  // wide_tables=0: no pattern tables in front of the wide kernels
     bool hard_overflow = true; // hard_overflow=0: the latency kernels of a hard-row batch walk whole lists (no per-shot workers behind them)
-    bool hard_tree = false;   // hard_tree=1: the block-per-row kernel takes the levels in lookahead groups (hw_component_tree) - measured
-                              // slower, profiles/r05/hard_tree.txt: the grid waits for the normalisation-check row either way
     bool shallow = true;      // shallow=0: finalize builds the default table depth at once (round 4) instead of starting shallow
     int trie = 1;             // trie=0: no prefix-tree tables - components of more than 12 outputs run without tables (round 5); 2: prefix trees for every narrow component
     int gen = 1;              // gen: k_sample_gen for fused groups - 0 never, 1 where no register first pass applies, 2 wherever it applies
     int x4 = 32;              // x4=N: components of 81..128 parameters or more than 64 selected bits AND at least N graphs take the narrow family (four words of x); 0: never
     bool x3 = true;           // x3=0: components of 65..80 parameters (F <= 64) stay on the wide path (round-4 behaviour)
     int wide_depth = 4;       // wide_depth=N: default table depth of wide components (finalize builds at most weight 3; the rest in the background)
-    int wide_glob = 48;       // wide_glob=N: components of up to N graphs whose column tables do not fit the LDS run k_sample_wide with the tables in the L2
     int wide_passes = 8;      // wide_passes=N: programs of up to N wide-path components run as N k_sample_wide passes (1: round-4 behaviour)
     bool wide_compact = true; // wide_compact=0: k_sample_wide keeps one 16-byte column table per graph even when all graphs fit one entry
-    // fixed since round 4 (the experiments behind their switches are closed: DESIGN.md / HISTORY.md)
-    bool hard_kernel = true;  // hard rows on k_sample4h, not k_sample4
-    bool lane0_main = true;   // pipeline slot 0 runs on the handle's stream (a hardware queue of its own)
-    int lw_block = 0;         // first-pass block: 1024 threads when the f/out staging fits 32 KB, else 256
-    int v4_block = 256;
-    int hard_lds_kb = 128;    // a first-pass block still fits next to a hard-row block
-    bool merge_lists = true;  // hard-row list count follows the load
-    int list_rows = 40;
-    int min_lists = 4;
-    bool direct_runs = true;  // direct outputs as bit-field runs
-    bool lw_reg = true;       // register form of the first pass where it applies
-    int lw_resident = 1;      // first-pass grid = one chip-full of blocks, rows by grid stride
-    int wide_list_blocks = 0;
-    bool prewait = true;      // mid-batch pre-wait of the first-pass lanes
   } knobs;
   bool h_attr_set = false;    // k_sample4h: large dynamic LDS enabled
   bool hm_attr_set = false;   // k_sample4h_multi: the same

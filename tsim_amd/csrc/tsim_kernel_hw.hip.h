@@ -35,7 +35,6 @@ struct HwMulti {
   uint32_t slot_cap;                  // the block-per-row blocks serve the first slot_cap slots of every list (0: all); the worker blocks the rest
   uint32_t hw_blocks;                 // blocks of the block-per-row part; the grid's further blocks are per-shot workers (over4_rows)
   int comp4_off;
-  int tree;                           // 1: levels in groups with every node of a group evaluated at once (hw_component_tree)
   uint32_t *feedback;                 // launch-plan feedback of the first context (see sample4h_rows)
   SampleArgs ctx[TSIMK_HW_MAX_CTX];
 };
@@ -357,195 +356,14 @@ __device__ __forceinline__ void hw_component(const SampleArgs &A, cptr img, cptr
   __syncthreads();  // the next component's level 0 overwrites buffer 0
 }
 
-// ---------------------------------------------------------------------------
-// Lookahead form of hw_component (round 5).  The level-sequential form above waits, per output, for one
-// phase 2 (the leading wave) and one barrier: n + 1 dependent steps of ~3.5 us.  But |amp| of a prefix-tree node depends on
-// (f_sel, the node's prefix bits) only - the table build evaluates every node of a pattern's tree level-parallel for the same
-// reason (k_lw_nodes, tsim_lw.hip.h).  Here the levels go in GROUPS of d (3; 2 for the row that carries the normalisation
-// check): for the d outputs of a group all 2^d - 1 nodes below the prefix sampled so far are evaluated at once -
-//   phase 1, every wave: the row stream of each level of the group ONCE, the parities of every node variant from it (a row's
-//            parity with prefix bit t = 0 is its parity with that bit = 1 XOR the row's own bit there: variant v = the set of
-//            unknown bits taken as 0, parity ^= popcount(row_field & v) & 1), one ballot per variant into its own bit array;
-//   phase 2, one wave per node (hw_phase2, the same code and values as above): |amp| of the node into LDS;
-//   the walk, every wave for itself (no broadcast, no third barrier): the stored draws against p1 / prev down the d levels.
-// Two barriers per group instead of one per level, and the phase 2s of a group side by side: C2 (5 outputs) 2 groups.
-// LDS: the 8 bit arrays the sequential form has (level 0 + 1 + 2 + 4 variants; check row: level 0 + 2 x (1 + 2)), then the node
-// values (two sets, alternating between groups) and the draws.
-// ---------------------------------------------------------------------------
-template <int W>
-__device__ __forceinline__ void hw_phase1_tree(const uint32_t *gimg, cptr lvl, const uint32_t (&x)[W], uint32_t pos0, uint32_t nb, uint32_t *arr,
-                                               uint32_t pw, uint32_t wv, uint32_t nwv) {
-  const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t n_rows = lvl[L_HWN];
-  const uint32_t *rows = gimg + lvl[L_HWROWS];
-  const uint32_t steps = (n_rows + 63u) >> 6;
-  const uint32_t V = 1u << nb;
-#pragma unroll 4
-  for (uint32_t st = wv; st < steps; st += nwv) {
-    const uint32_t r = st * 64u + lane;
-    uint32_t pb = 0u, fld = 0u;
-    if (r < n_rows) {
-      const uint32_t *q = rows + (size_t)r * (W + 1);
-      uint32_t rw[W + 1];
-#pragma unroll
-      for (int w = 0; w <= W; ++w) rw[w] = q[w];
-      uint32_t t = rw[W] & x[W - 1];
-#pragma unroll
-      for (int w = W - 2; w >= 0; --w) t = and_xor(rw[1 + w], x[w], t);
-      pb = ((uint32_t)__builtin_popcount(t) + rw[0]) & 1u;
-      unsigned long long m64 = rw[1];
-      if constexpr (W >= 2) m64 |= (unsigned long long)rw[2] << 32;
-      fld = (uint32_t)(m64 >> pos0) & (V - 1u);
-    }
-    uint32_t lo = 0u, hi = 0u;
-    for (uint32_t v = 0; v < V; ++v) {
-      const unsigned long long m = __builtin_amdgcn_ballot_w64(((pb ^ (uint32_t)__builtin_popcount(fld & v)) & 1u) != 0u);
-      lo = lane == v ? (uint32_t)m : lo;
-      hi = lane == v ? (uint32_t)(m >> 32) : hi;
-    }
-    if (lane < V) {
-      arr[lane * pw + 2u * st] = lo;
-      arr[lane * pw + 2u * st + 1u] = hi;
-    }
-  }
-  if (wv == 0u && lane < V) arr[lane * pw + 2u * steps] = 0u;  // the spare word hw_bits may touch
-}
-
-template <int W, class FBit>
-__device__ __forceinline__ void hw_component_tree(const SampleArgs &A, cptr img, cptr comp, int ci, FBit fbit, unsigned long long shot, bool check,
-                                                  uint32_t *par, uint32_t pw, uint32_t (&out_w)[4]) {
-  const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
-  const uint32_t n_out = comp[C_NOUT], F = comp[C_F];
-  cptr fsel = img + comp[C_FSEL];
-  cptr levels = img + comp[C_LEVELS];
-  cptr outpos = img + comp[C_OUTPOS];
-  const uint32_t keybase = comp[C_KEYBASE];
-  float *pv = reinterpret_cast<float *>(par + 8u * pw + 4u);  // [2][16]: |amp| of the group's nodes, trial bit 1 in 0..7, trial bit 0 in 8..15
-  uint32_t *ub = par + 8u * pw + 4u + 32u;                      // [16]: the draws (float bits)
-  uint32_t x[W];
-#pragma unroll
-  for (int w2 = 0; w2 < W; w2 += 2) {
-    const uint32_t j = 32u * (uint32_t)w2 + lane;
-    const uint32_t raw = fbit(fsel[j < F ? j : 0u]);
-    const unsigned long long m = __builtin_amdgcn_ballot_w64(j < F && raw != 0u);
-    x[w2] = (uint32_t)m;
-    if (w2 + 1 < W) x[w2 + 1] = (uint32_t)(m >> 32);
-  }
-  if (wv == 0u && lane < n_out) {  // the component's draws (sampler.py:74-75), all at once: lane i computes output i's uniform
-    const uint32_t o = keybase + lane;
-    uint32_t x0 = (uint32_t)(shot >> 32), x1 = (uint32_t)shot;
-    threefry2x32(subkey(A, o, 0), subkey(A, o, 1), x0, x1);
-    ub[lane] = __float_as_uint(__uint_as_float(((x0 ^ x1) >> 9) | 0x3F800000u) - 1.0f);
-  }
-  auto set_bit = [&](uint32_t pos, bool on) {
-    const uint32_t wi = pos >> 5, bm = 1u << (pos & 31u);
-#pragma unroll
-    for (int w = 0; w < W; ++w)
-      if ((uint32_t)w == wi) x[w] = on ? (x[w] | bm) : (x[w] & ~bm);
-  };
-  const uint32_t mult = check ? 2u : 1u, dmax = check ? 2u : 3u;
-  float prev = 0.0f, maxdev = 0.0f;
-  uint32_t i0 = 0u, grp = 0u;
-  bool first = true;
-  while (first || i0 < n_out) {
-    const uint32_t d = min(dmax, n_out - i0);
-    const uint32_t s0 = first ? 1u : 0u;
-    // the group's unknown bits and trial bits: all 1 in the base x (a variant takes some of them as 0)
-    for (uint32_t j = 0; j < d; ++j) set_bit(F + i0 + j, true);
-    // ---- phase 1: level 0 (first group) and the d levels of the group, ONE WAVE PER LEVEL (its whole row stream, the loads of
-    // all its steps in flight together): a wave that took a share of every level waited for one global-load round trip per level
-    for (uint32_t t = wv; t < s0 + d; t += nwv) {
-      if (first && t == 0u) {
-        uint32_t xf[W];
-#pragma unroll
-        for (int w = 0; w < W; ++w) xf[w] = x[w];
-        for (uint32_t j = 0; j < d; ++j) {
-          const uint32_t pos = F + j, wi = pos >> 5, bm = 1u << (pos & 31u);
-#pragma unroll
-          for (int w = 0; w < W; ++w)
-            if ((uint32_t)w == wi) xf[w] &= ~bm;
-        }
-        hw_phase1_tree<W>(A.img, levels, xf, 0u, 0u, par, pw, 0u, 1u);  // sampler.py:54: f_sel alone
-        continue;
-      }
-      const uint32_t j = t - s0;
-      // level i0 + j + 1: parameters f | b_0 .. b_(i0+j-1) | trial bit at F + i0 + j; the bits behind the trial bit are not its parameters
-      uint32_t xl[W];
-#pragma unroll
-      for (int w = 0; w < W; ++w) xl[w] = x[w];
-      for (uint32_t u2 = j + 1u; u2 < d; ++u2) {
-        const uint32_t pos = F + i0 + u2, wi = pos >> 5, bm = 1u << (pos & 31u);
-#pragma unroll
-        for (int w = 0; w < W; ++w)
-          if ((uint32_t)w == wi) xl[w] &= ~bm;
-      }
-      hw_phase1_tree<W>(A.img, levels + (i0 + j + 1u) * L_WORDS, xl, F + i0, j + (check ? 1u : 0u), par + (s0 + mult * ((1u << j) - 1u)) * pw, pw, 0u, 1u);
-    }
-    __syncthreads();
-    // ---- phase 2: one wave per node
-    float *pvg = pv + 16u * (grp & 1u);
-    const uint32_t n_tasks = s0 + ((1u << d) - 1u);
-    for (uint32_t t = wv; t < n_tasks; t += nwv) {
-      if (first && t == 0u) {
-        const HwRec rec = hw_load_rec(A.img, levels, lane);
-        const HwLevelOut o = hw_phase2<W, false>(A.img, img, levels, par, par, rec);
-        if (lane == 0u) pvg[0] = cabs32(o.re, o.im);
-        continue;
-      }
-      const uint32_t node = t - s0;                       // 0 .. 2^d - 2: level j = floor(log2(node + 1)), variant v = node + 1 - 2^j
-      const uint32_t j = 31u - (uint32_t)__builtin_clz(node + 1u), v = node + 1u - (1u << j);
-      cptr lvl = levels + (i0 + j + 1u) * L_WORDS;
-      const uint32_t *base = par + (s0 + mult * ((1u << j) - 1u)) * pw;
-      const HwRec rec = hw_load_rec(A.img, lvl, lane);
-      if (check) {  // variant bit j = the trial bit taken as 0 (sampler.py:66-72)
-        const HwLevelOut o = hw_phase2<W, true>(A.img, img, lvl, base + v * pw, base + (v | (1u << j)) * pw, rec);
-        if (lane == 0u) {
-          pvg[1u + node] = cabs32(o.re, o.im);
-          pvg[8u + 1u + node] = cabs32(o.re0, o.im0);
-        }
-      } else {
-        const HwLevelOut o = hw_phase2<W, false>(A.img, img, lvl, base + v * pw, base + v * pw, rec);
-        if (lane == 0u) pvg[1u + node] = cabs32(o.re, o.im);
-      }
-    }
-    __syncthreads();
-    // ---- the walk (every wave for itself: wave-uniform LDS reads), sampler.py:62-79
-    if (first) prev = pvg[0];
-    uint32_t v = 0u;
-    for (uint32_t j = 0; j < d; ++j) {
-      const uint32_t node = (1u << j) - 1u + v;
-      const float p1 = pvg[1u + node];
-      if (check) {
-        const float p0 = pvg[8u + 1u + node];
-        const float norm = __fdiv_rn(__fadd_rn(p0, p1), prev);
-        maxdev = nanmax(maxdev, fabsf(__fsub_rn(norm, 1.0f)));
-      }
-      const float u = __uint_as_float(ub[i0 + j]);
-      const bool bit = u < __fdiv_rn(p1, prev);
-      prev = bit ? p1 : __fsub_rn(prev, p1);
-      set_bit(F + i0 + j, bit);
-      v |= (bit ? 0u : 1u) << j;
-      const uint32_t dst = outpos[i0 + j];  // K15: the final column (sampler.py:164-166)
-      if (threadIdx.x == 0u) {
-#pragma unroll
-        for (int w = 0; w < 4; ++w)
-          if ((dst >> 5) == (uint32_t)w) out_w[w] |= (bit ? 1u : 0u) << (dst & 31u);
-      }
-    }
-    i0 += d;
-    ++grp;
-    first = false;
-  }
-  if (check && A.norm_dev && threadIdx.x == 0u) A.norm_dev[ci] = maxdev;
-  __syncthreads();  // the next component's (or row's) first group overwrites the arrays and the draws
-}
+// (The lookahead form of round 5 - levels in groups of three, every node of a group evaluated at once - was measured slower beside a
+// first pass and is gone: profiles/r05/hard_tree.txt, HISTORY.md.)
 
 // sample_program (sampler.py:117-167) for one row on one wave
 // only_comp >= 0: that component alone, its bits ORed into the row the first pass stored (direct outputs and the other
 // components' bits are there already)
 template <int WMAX>
-__device__ __forceinline__ void hw_row(const SampleArgs &A, long long row, bool check, uint32_t *par, uint32_t pw, int only_comp, bool tree) {
+__device__ __forceinline__ void hw_row(const SampleArgs &A, long long row, bool check, uint32_t *par, uint32_t pw, int only_comp) {
   cptr img = (cptr)(uintptr_t)A.img;
   const uint32_t lane = threadIdx.x & 63u;
   const unsigned long long shot = (unsigned long long)(A.shot_offset + row);
@@ -577,13 +395,11 @@ __device__ __forceinline__ void hw_row(const SampleArgs &A, long long row, bool 
     cptr comp = img + A.comp_off + ci * C_WORDS;
     switch (comp[C_W]) {  // rows are packed with the component's own word count
       case 1:
-        if (tree) hw_component_tree<1>(A, img, comp, ci, fbit, shot, check, par, pw, out_w);
-        else hw_component<1>(A, img, comp, ci, fbit, shot, check, par, pw, out_w);
+        hw_component<1>(A, img, comp, ci, fbit, shot, check, par, pw, out_w);
         break;
       case 2:
         if constexpr (WMAX >= 2) {
-          if (tree) hw_component_tree<2>(A, img, comp, ci, fbit, shot, check, par, pw, out_w);
-          else hw_component<2>(A, img, comp, ci, fbit, shot, check, par, pw, out_w);
+          hw_component<2>(A, img, comp, ci, fbit, shot, check, par, pw, out_w);
         }
         break;
       case 3:
@@ -683,9 +499,9 @@ __global__ void __launch_bounds__(256) k_sample_hw(HwMulti M) {
     if (only_comp >= 0) {
       if (!((entry >> (28 + only_comp)) & 1u)) continue;  // block-uniform: this component's bits came from the tables
       const uint32_t row = entry & 0x0FFFFFFFu;
-      hw_row<W>(A, (long long)row, row == check_row, tsimk_lds, (uint32_t)M.par_words, only_comp, M.tree != 0);
+      hw_row<W>(A, (long long)row, row == check_row, tsimk_lds, (uint32_t)M.par_words, only_comp);
     } else {
-      hw_row<W>(A, (long long)entry, entry == check_row, tsimk_lds, (uint32_t)M.par_words, -1, M.tree != 0);
+      hw_row<W>(A, (long long)entry, entry == check_row, tsimk_lds, (uint32_t)M.par_words, -1);
     }
   }
 }

@@ -99,12 +99,10 @@ extern "C" int tsim_noise_create(tsim_program *p, int32_t num_f, int32_t n_chann
       // rows of the tile in up to 48 KB of LDS, at most 4096 shots (C2: 4096 x 8 B, C3: 2048 x 16 B, C5: 1024 x 40 B)
       n->wave_tile = 64;
       while (n->wave_tile < 4096 && (size_t)n->wave_tile * 2 * n->WF * 8 <= 48 * 1024) n->wave_tile *= 2;
-      if (tn && strstr(tn, "noise_tile=")) n->wave_tile = std::max(64, std::min(8192, atoi(strstr(tn, "noise_tile=") + 11)));
       // gaps per round: what covers the tile in ONE round but for ~2 % of the groups (mean + two sigma of the fires a channel expects)
       const double fires = pmax * n->wave_tile;
       int g = 8;
       while (g < 64 && 2.0 * g < fires + 2.0 * std::sqrt(fires) + 2.0) g *= 2;
-      if (tn && strstr(tn, "noise_g=")) g = std::max(8, std::min(64, atoi(strstr(tn, "noise_g=") + 8)));
       n->wave_g = g;
     }
   }
@@ -164,8 +162,6 @@ extern "C" int tsim_noise_sample_device(tsim_noise *n, int64_t B, uint32_t key_h
     // channels per group - is the kernel's time)
     int threads = 256;
     while (threads < 1024 && threads < n->n_ch * n->wave_g) threads *= 2;
-    if (const char *tn = getenv("TSIM_AMD_TUNE"))
-      if (strstr(tn, "noise_threads=")) threads = std::max(64, std::min(1024, atoi(strstr(tn, "noise_threads=") + 14) / 64 * 64));
     threads = std::max(threads, n->wave_g);
     hipLaunchKernelGGL(k_noise_wave, dim3((unsigned)tiles), dim3(threads), (size_t)n->wave_tile * n->WF * 8 + (size_t)n->n_ch * 24, s, a);
     HIP_TRY(hipGetLastError());

@@ -73,6 +73,10 @@ void tsim_stream_release(int device, hipStream_t s) {
 }
 
 extern "C" const char *tsim_last_error(void) { return g_err; }
+extern "C" const char *tsim_tune_keys(void) {
+  return "defer_hard,defer_group,lw_fast,wide_fused,wide_compact,wide_tables,wide_depth,wide_passes,hard_wave,hard_wave_rows,hard_inline_rows,"
+         "hard_comp_par,hard_overflow,deep_after,fused_lanes,fused_max,gen,trie,shallow,x3,x4,noise_wave";
+}
 extern "C" const char *tsim_version(void) { return "tsim_amd-hip 0.2 (gfx950)"; }
 
 int tsim_set_device(const tsim_program *p) {
@@ -288,18 +292,15 @@ extern "C" int tsim_program_finalize(tsim_program *p, int32_t device) {
     p->knobs.deep_after = (unsigned long long)std::max(0ll, tune_ll("deep_after", 0));  // 0: by the estimated build time (tsim_tables_deep_after)
     p->knobs.fused_lanes = (int)std::max(0ll, std::min(4ll, tune_ll("fused_lanes", 0)));
     p->knobs.fused_max = (int)std::max(1ll, std::min((long long)TSIMK_LWM_MAX_STEPS, tune_ll("fused_max", 8)));
-    p->knobs.wide = tune_ll("wide", 1) != 0;
     p->knobs.wide_tables = tune_ll("wide_tables", 1) != 0;
     p->knobs.wide_compact = tune_ll("wide_compact", 1) != 0;
     p->knobs.x3 = tune_ll("x3", 1) != 0;
     p->knobs.x4 = (int)std::max(0ll, tune_ll("x4", 32));
     p->knobs.wide_depth = (int)std::max(0ll, std::min(4ll, tune_ll("wide_depth", 4)));
-    p->knobs.wide_glob = (int)std::max(0ll, tune_ll("wide_glob", 48));
     p->knobs.wide_passes = (int)std::max(1ll, std::min(16ll, tune_ll("wide_passes", 8)));
     p->knobs.gen = (int)std::max(0ll, std::min(2ll, tune_ll("gen", 1)));
     p->knobs.trie = (int)std::max(0ll, std::min(2ll, tune_ll("trie", 1)));
     p->knobs.shallow = tune_ll("shallow", 1) != 0;
-    p->knobs.hard_tree = tune_ll("hard_tree", 0) != 0;
     p->knobs.hard_overflow = tune_ll("hard_overflow", 1) != 0;
   }
 

@@ -80,7 +80,7 @@ int slot_prepare(tsim_program *p, int slot, size_t hard_bytes, bool need_stream)
     sl.side_ready = true;
     // default priority on purpose: a low- (or high-) priority lane lands on a different class of
     // hardware queue and tripled the step time (134 us vs 43 us, measured)
-    if (slot == 1 && p->knobs.lane0_main) {
+    if (slot == 1) {
       // The handle's own stream doubles as the first lane: HIP gave the lanes it created only two distinct
       // hardware queues (kernel trace: three created streams -> queues 3, 4, 4), the handle's stream sits on
       // a third one.  Three truly concurrent lanes: 36 us per step instead of 42.
@@ -133,7 +133,7 @@ static LaunchPlan make_plan(tsim_program *p, bool has_row_index, bool pipelined,
     p->deep_rows = 0;  // (rows counted against the old depth - the shallow start's - say nothing about the new one)
     p->lw_dense_launches = 0;
   }
-  if (p->lw && p->lw_wide && p->wr_off != 0 && p->knobs.wide_fused && p->knobs.wide && !has_row_index) {
+  if (p->lw && p->lw_wide && p->wr_off != 0 && p->knobs.wide_fused && !has_row_index) {
     // One wide component (k_sample_wide): the kernel serves every row itself - nothing here decides coverage.  Two things
     // follow its statistics (block 0's share of the last launch): a deeper table when many rows miss the current one
     // (C5 at depth 3: 57 % -> depth 4, 2.1 GB built once: 37 %), and the round-2 path (sparse-column kernel with K = 10
@@ -220,17 +220,17 @@ static LaunchPlan make_plan(tsim_program *p, bool has_row_index, bool pipelined,
     }
     if (known && fb_max <= 192u) pl.need_overflow = false;
     pl.fb_max = known ? fb_max : 0xFFFFFFFFu;
-    if (known && p->knobs.merge_lists) {
-      const uint32_t per = (uint32_t)std::max(8, p->knobs.list_rows);
+    if (known) {
+      const uint32_t per = (uint32_t)std::max(8, kListRows);
       const uint32_t want = (fb_sum + per - 1u) / per;
-      pl.lists = std::max(2, std::min(TSIMK_LW_LISTS, p->knobs.min_lists));
+      pl.lists = std::max(2, std::min(TSIMK_LW_LISTS, kMinLists));
       while ((uint32_t)pl.lists < want && pl.lists < TSIMK_LW_LISTS) pl.lists <<= 1;
       // the longest list of the last launch was measured with ITS list count: rescale the overflow test
       const uint32_t last = p->last_lists > 0 ? (uint32_t)p->last_lists : (uint32_t)TSIMK_LW_LISTS;
       const uint32_t est_max = (uint32_t)std::min<unsigned long long>(0xFFFFFFFFull, (unsigned long long)fb_max * last / (uint32_t)pl.lists + 16u);
       pl.need_overflow = !(pl.lists >= (int)last ? fb_max <= 192u : est_max <= 192u);
     }
-    pl.defer = pipelined && pl.use_tables && !dense && !pl.need_overflow && pl.hard_kernel && p->knobs.defer && p->knobs.hard_kernel &&
+    pl.defer = pipelined && pl.use_tables && !dense && !pl.need_overflow && pl.hard_kernel && p->knobs.defer &&
                p->v4 && !(p->profiling && !p->prof_light);
   }
   return pl;
@@ -250,7 +250,7 @@ void hard_geometry(tsim_program *p, int WF, int WO) {
   constexpr int NW = TSIM_HARD_NW;
   const size_t tile_b = (size_t)p->v4_max_nch * 16 * p->v4_gt * 16;
   const size_t fixed_b = (size_t)(2 * WF + 2 * WO) * 64 * 4 + (size_t)NW * 8 * 64 * 4;
-  const size_t budget = (size_t)p->knobs.hard_lds_kb * 1024;
+  const size_t budget = (size_t)kHardLdsKb * 1024;
   p->h_group_tiles = fixed_b + tile_b <= budget ? (int)std::min<size_t>(TSIMK_H_MAX_GROUP_TILES, (budget - fixed_b) / tile_b) : 0;
   p->h_lds = fixed_b + (size_t)std::max(1, p->h_group_tiles) * tile_b;
 }
@@ -331,8 +331,7 @@ static int launch_hw(tsim_program *p, const SampleArgs *ctx, int n_ctx, int max_
   const unsigned gridw = (unsigned)((long long)H.n_ctx * H.max_lists * H.waves_per_list * H.comp_par);
   H.hw_blocks = gridw;
   H.par_words = (int)(2 * ((p->hw_max_rows + 63) / 64) + 2);
-  H.tree = p->knobs.hard_tree ? 1 : 0;
-  size_t ldsw = (size_t)H.par_words * 8 * 4 + 16 + 256;  // (+ the node values and draws of the lookahead form)  // two buffers of four bit arrays (previous bit x trial bit) + the sampled bit.s word
+  size_t ldsw = (size_t)H.par_words * 8 * 4 + 16;  // two buffers of four bit arrays (previous bit x trial bit) + the sampled bit.s word
   unsigned grid = gridw;
   if (workers) {
     const size_t tile_bytes = std::max((size_t)p->v4_max_nch * 16, (size_t)p->v4_max_sent) * p->v4_gt * 16;
@@ -542,7 +541,7 @@ int fill_sample_args(tsim_program *p, tsim_program::Slot &sl, SampleArgs &a, con
   a.n_direct = p->n_direct;
   a.direct_off = p->direct_off;
   a.direct_prog = p->lw_direct_prog;
-  a.direct_chunks = p->knobs.direct_runs ? p->lw_direct_chunks : 0;
+  a.direct_chunks = p->lw_direct_chunks;
   a.n_comp = (int)p->comps.size();
   a.comp_off = p->comp_off;
   a.row_index = nullptr;  // (launch_sample sets an input row list)
@@ -635,7 +634,7 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
   // The sparse-column pass (k_sample4w) over every row, or - behind a pattern-table first pass - over that pass's
   // hard-row lists (from_lists; `a` then describes them).  Its own overflow (more than K set bits, the check row)
   // goes to row lists of its own, which `a` describes afterwards: the row kernel below serves them.
-  const bool wide_fits = p->v4w && !p->wide_big && p->knobs.wide &&
+  const bool wide_fits = p->v4w && !p->wide_big &&
                          (size_t)(2 * a.WF + 2 * a.WO) * 256 * 4 + 2 * (size_t)p->v4_max_sent * p->v4_gt * 16 <= 64 * 1024;
   auto wide_pass = [&](bool from_lists, int par) -> int {
     if (B > 0xFFFFFFFFll) return tsim_fail(TSIM_ENOTSUP, "batch too large for the row list");
@@ -655,11 +654,11 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
       p->v4w_occ_blocks = nb;
       p->v4w_occ_lds = ldsw;
     }
-    const long long chip = (long long)p->n_cu * p->v4w_occ_blocks * std::max(1, p->knobs.lw_resident);
+    const long long chip = (long long)p->n_cu * p->v4w_occ_blocks * 1;
     long long grid1, list_cap;
     if (from_lists) {
       // every input list gets the same number of blocks, which stride over it
-      const long long chip_l = p->knobs.wide_list_blocks > 0 ? (long long)p->n_cu * std::min(p->knobs.wide_list_blocks, p->v4w_occ_blocks) : chip;
+      const long long chip_l = chip;
       const long long per_list = std::max(1ll, std::min(chip_l / a.row_lists, ((long long)a.row_list_cap + kWideBlock - 1) / kWideBlock));
       grid1 = per_list * a.row_lists;
       const long long rows_per_block = ((long long)a.row_list_cap + per_list * kWideBlock - 1) / (per_list * kWideBlock) * kWideBlock;
@@ -670,7 +669,7 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
       // One component with resident tables: the kernel copies the tables once per block and strides over the rows, so
       // the grid is what the chip holds at once (occupancy of this kernel with this much LDS), not one block per 256 rows
       grid1 = blocks;
-      if (resident && p->comps.size() == 1 && p->knobs.lw_resident > 0) grid1 = std::min(blocks, chip);
+      if (resident && p->comps.size() == 1) grid1 = std::min(blocks, chip);
       const long long iters = (blocks + grid1 - 1) / grid1;
       list_cap = (grid1 + kWideLists - 1) / kWideLists * iters * kWideBlock;
     }
@@ -718,13 +717,13 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
     if (B > 0xFFFFFFFFll) return tsim_fail(TSIM_ENOTSUP, "batch too large for the row list");
     // few large blocks: 1024 threads finish a batch of 10^6 rows in 977 blocks - measurably better than
     // 3906 blocks of 256 when the blocks of several launches and of the hard-row kernel share the CUs
-    const int blk1 = p->knobs.lw_block ? p->knobs.lw_block : ((size_t)(2 * a.WF + 2 * a.WO) * 1024 * 4 <= 32 * 1024 ? 1024 : 256);
-    const bool reg_form = p->lw_reg && p->knobs.lw_reg && (a.WF == 1 || a.WF == 2) && a.WO == 1;
+    const int blk1 = ((size_t)(2 * a.WF + 2 * a.WO) * 1024 * 4 <= 32 * 1024 ? 1024 : 256);
+    const bool reg_form = p->lw_reg && (a.WF == 1 || a.WF == 2) && a.WO == 1;
     const long long blocks = (B + blk1 - 1) / blk1;
     // the register form strides over the rows: no more blocks than the chip holds at once (2048 threads per CU)
     long long grid1 = blocks;
-    if (reg_form && p->knobs.lw_resident > 0)
-      grid1 = std::min(blocks, (long long)p->n_cu * p->knobs.lw_resident * (2048 / blk1));
+    if (reg_form)
+      grid1 = std::min(blocks, (long long)p->n_cu * (2048 / blk1));
     const long long iters = (blocks + grid1 - 1) / grid1;
     // n_lists sub-lists share the buffer sized for TSIMK_LW_LISTS of them: a list can hold every row of
     // the blocks that feed it
@@ -783,7 +782,7 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
       st.ctl = l.ctl;
       st.ctl_next = l.ctl_next;
       memcpy(st.keys, a.inline_keys, sizeof(uint32_t) * 2 * (size_t)p->total_keys);
-      const long long chip = (long long)p->n_cu * std::max(1, p->knobs.lw_resident) * (2048 / blk1);
+      const long long chip = (long long)p->n_cu * (2048 / blk1);
       const long long it1 = (blocks + chip - 1) / chip;
       const long long gridf = (blocks + it1 - 1) / it1;
       const int n_out = p->comps[0].n_out;
@@ -848,12 +847,12 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
     a4.s = a;
     a4.comp4_off = p->comp4_off;
     a4.has_check = has_check ? 1 : 0;
-    a4.feedback = (a.row_lists > 1 && !(p->knobs.hard_kernel && plan.hard_kernel)) ? p->d_feedback : nullptr;
-    const int blk = p->knobs.v4_block;
+    a4.feedback = (a.row_lists > 1 && !plan.hard_kernel) ? p->d_feedback : nullptr;
+    const int blk = kV4Block;
     const size_t tile_bytes = std::max((size_t)p->v4_max_nch * 16, (size_t)p->v4_max_sent) * p->v4_gt * 16;
     const size_t lds4 = (size_t)(2 * a.WF + 2 * a.WO) * blk * 4 + 2 * tile_bytes;
     if (lds4 > (p->v4_max_nch == 32 ? 160 : 64) * 1024) return tsim_fail(TSIM_ENOTSUP, "v4 kernel needs %zu B of LDS", lds4);
-    if (a.row_lists > 1 && p->knobs.hard_kernel && plan.hard_kernel) {
+    if (a.row_lists > 1 && plan.hard_kernel) {
       // short row lists (second pass of a two-pass launch): NW waves per 64 rows, tsim_kernel4h.hip.h
       constexpr int NW = TSIM_HARD_NW;
       hard_geometry(p, a.WF, a.WO);
@@ -1029,7 +1028,7 @@ extern "C" int tsim_sample_batch_device_begin(tsim_program *p, int32_t slot, con
   // no wait of its own) already waits for the batch the first launch of the next batch will ask for - known from
   // how far back the last such wait reached (lane_reach) and at least two flushes old, i.e. complete; that launch
   // then finds the lane already behind it.  Ordering only ever gets stricter.
-  if (plan.defer && p->knobs.prewait && !p->inline_seen && p->deferred.size() >= 2) {
+  if (plan.defer && !p->inline_seen && p->deferred.size() >= 2) {
     const int lane = (s == p->slots[1].side) ? 0 : (s == p->slots[2].side) ? 1 : -1;
     if (lane >= 0 && p->lane_reach[lane] >= 3 && p->lane_reach[lane] <= 15 && p->batch_next > (unsigned long long)p->lane_reach[lane]) {
       const unsigned long long want = p->batch_next - (unsigned long long)(p->lane_reach[lane] - 1);
@@ -1075,7 +1074,7 @@ static int steps_group_fused(tsim_program *p, int n, const uint64_t *const *d_f,
     HIP_TRY(hipStreamWaitEvent(s, p->sync_ev, 0));
   }
   const int WF = std::max(1, (num_f + 63) / 64);
-  const int blk1 = p->knobs.lw_block ? p->knobs.lw_block : 1024;
+  const int blk1 = 1024;
   const long long bps = (B + blk1 - 1) / blk1;
   const int n_lists = plan.lists;
   if (p->stat_fused == 0 && tsim_debug("pipeline")) {
@@ -1146,7 +1145,7 @@ static int steps_group_fused(tsim_program *p, int n, const uint64_t *const *d_f,
   }
   // one chip-full of blocks (2048 threads per CU), every block the same number of (batch, row block) pairs
   const long long total = bps * n;
-  const long long chip = (long long)p->n_cu * std::max(1, p->knobs.lw_resident) * (2048 / blk1);
+  const long long chip = (long long)p->n_cu * (2048 / blk1);
   const long long iters = (total + chip - 1) / chip;
   const long long grid = (total + iters - 1) / iters;
   TSIM_MARK("args");
@@ -1318,14 +1317,14 @@ extern "C" int tsim_sample_steps_device(tsim_program *p, int32_t n_steps, const 
   while (done < n_steps) {
     // the fused first pass applies when the register form does, the subkeys fit its records, and the launch plan
     // says "tables, short lists": decided per group - the plan follows the feedback of earlier launches
-    const bool reg_fused = p->lw && !p->lw_wide && p->lw_reg && p->knobs.lw_reg && (WF == 1 || WF == 2) && WO == 1 && p->total_keys > 0 &&
+    const bool reg_fused = p->lw && !p->lw_wide && p->lw_reg && (WF == 1 || WF == 2) && WO == 1 && p->total_keys > 0 &&
                            p->total_keys <= TSIMK_LWM_KEYS;
     // ... and every other narrow program through k_sample_gen (rows in LDS: any row width, up to 256 outputs)
     const bool gen_fused = gen_applies(p, B, num_f, shot_offset) && (p->knobs.gen == 2 || !reg_fused);
     bool fused = (reg_fused || gen_fused) && p->knobs.fused_steps && p->num_outputs > 0 && B > 0 && B <= 0x7FFFFFFFll && p->knobs.defer_group >= 1;
     // no components at all: the streaming kernel for direct outputs (rows of at most 128 f bits and 128 outputs)
     if (p->comps.empty() && p->knobs.fused_steps && p->num_outputs > 0 && p->num_outputs <= 128 && WF <= 2 && p->lw_direct_chunks > 0 &&
-        p->knobs.direct_runs && B > 0 && B <= 0x7FFFFFFFll) {
+        B > 0 && B <= 0x7FFFFFFFll) {
       if (!p->slots_ready) {
         for (int k = 1; k <= 4; ++k)
           if (int r = slot_prepare(p, k, 0)) return r;

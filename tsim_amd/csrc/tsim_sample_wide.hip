@@ -20,9 +20,9 @@ WideLayout wide_layout(const tsim_program *p, int WF32, size_t ci) {
   // the shared column table (one entry holds every graph's parity bits) when the packer made one and the term tables fit
   // beside it; else one table per graph
   // (third choice, compact = -1: no column table in LDS at all - components with many graphs, round 5)
-  // - up to knobs.wide_glob graphs: a dense pass walks the graphs one after the other, ~2.5 us each from the L2 (F60 class, 140
+  // - up to kWideGlobGraphs graphs: a dense pass walks the graphs one after the other, ~2.5 us each from the L2 (F60 class, 140
   // graphs: 300-400 us per pass, 77 us per 10^6 shots against 59 on the round-2 kernels - profiles/r05/wide_glob.txt)
-  const int min_mode = (int)wr[WR_GTOT] <= p->knobs.wide_glob ? -1 : 0;
+  const int min_mode = (int)wr[WR_GTOT] <= kWideGlobGraphs ? -1 : 0;
   for (int compact = wr[WR_CCOL] != 0u ? 1 : 0; compact >= min_mode && !L.block; --compact) {
     size_t off = compact > 0 ? (size_t)(c.F + 33) * 16 : compact == 0 ? up(wr[WR_COLBYTES], 16) : 0;
     L.l_rank = (int)off;  off += (size_t)4 * (c.F + 1) * 4;
@@ -72,7 +72,7 @@ WideLayout wide_layout(const tsim_program *p, int WF32, size_t ci) {
 // can this launch go to k_sample_wide?  (32-bit offsets: batches below 2^28 rows, tables below 4 GB, a shot range that does
 // not cross a multiple of 2^32; bit_packed rows are written and merged as dwords)
 bool wide_applies(const tsim_program *p, int64_t B, int32_t num_f, int64_t shot_offset) {
-  if (!(p->lw && p->lw_wide && p->wr_off != 0 && p->knobs.wide_fused && p->knobs.wide)) return false;
+  if (!(p->lw && p->lw_wide && p->wr_off != 0 && p->knobs.wide_fused)) return false;
   if (p->total_keys <= 0 || p->total_keys > TSIMK_LWM_KEYS || B <= 0 || B >= (1ll << 28)) return false;
   for (size_t ci = 0; ci < p->comps.size() && ci < p->lw_npat.size(); ++ci)  // 32-bit byte offsets inside a component's table
     if (((p->lw_npat[ci] << p->comps[ci].n_out) * 4) >= (1ll << 32)) return false;

@@ -30,6 +30,7 @@
 #include <mutex>
 #include <chrono>
 #include <cstring>
+#include <functional>
 #include <new>
 #include <string>
 #include <thread>
@@ -55,31 +56,13 @@ int tsim_fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3
     if (e_ != hipSuccess) return tsim_fail(TSIM_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
   } while (0)
 
-// fn(0) .. fn(n - 1) on a BOUNDED pool: at most max_threads workers (the caller's thread is one of them) pulling indices from an
-// atomic counter.  A program of thousands of small components must not create a thread per level (std::thread
-// throwing EAGAIN inside an extern "C" function ends the host process); when a thread cannot be created the ones that
-// exist - at least the caller's - do the work.
+// fn(0) .. fn(n - 1) on the process-wide worker pool (tsim_pool.cpp): at most max_threads threads work on the call, the caller
+// among them; bounded however many components a program has, and safe to nest (a thread per level, created
+// before any join, could throw EAGAIN inside an extern "C" function).
+void tsim_parallel_for_impl(size_t n, int max_threads, const std::function<void(size_t)> &fn);
 template <class F>
 inline void tsim_parallel_for(size_t n, int max_threads, F &&fn) {
-  if (n == 0) return;
-  const int hw = (int)std::thread::hardware_concurrency();
-  const int nt = (int)std::min<size_t>(n, (size_t)std::max(1, std::min(max_threads, hw > 0 ? hw : 1)));
-  std::atomic<size_t> next{0};
-  auto worker = [&]() {
-    for (;;) {
-      const size_t i = next.fetch_add(1);
-      if (i >= n) return;
-      fn(i);
-    }
-  };
-  std::vector<std::thread> pool;
-  try {
-    pool.reserve((size_t)nt);
-    for (int t = 1; t < nt; ++t) pool.emplace_back(worker);
-  } catch (...) {
-  }
-  worker();
-  for (auto &t : pool) t.join();
+  tsim_parallel_for_impl(n, max_threads, std::function<void(size_t)>(std::forward<F>(fn)));
 }
 
 // ---------------------------------------------------------------------------

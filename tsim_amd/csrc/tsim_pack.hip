@@ -482,23 +482,12 @@ bool pack_level_fast(HostLevel &h, int W, std::vector<uint32_t> &tables, bool &f
     return true;
   };
   {
-    std::atomic<int> next{0};
+    // the graphs of a level on the process-wide pool (tsim_pool.cpp): big levels on up to 24 threads (C4: 256 graphs, ~50 us each)
     std::atomic<bool> failed{false};
-    auto worker = [&]() {
-      for (;;) {
-        const int g = next.fetch_add(1);
-        if (g >= G || failed.load()) return;
-        if (!do_graph(g)) failed.store(true);
-      }
-    };
-    const int nthreads = G >= 16 ? std::min(G >= 64 ? 8 : 4, std::max(1, (int)std::thread::hardware_concurrency())) : 1;
-    std::vector<std::thread> pool;
-    try {  // (a thread that cannot be created: the ones that exist - at least this one - pack the level)
-      for (int t = 1; t < nthreads; ++t) pool.emplace_back(worker);
-    } catch (...) {
-    }
-    worker();
-    for (auto &t : pool) t.join();
+    tsim_parallel_for((size_t)G, G >= 128 ? 24 : (G >= 32 ? 12 : (G >= 8 ? 4 : 1)), [&](size_t g) {
+      if (failed.load(std::memory_order_relaxed)) return;
+      if (!do_graph((int)g)) failed.store(true);
+    });
     if (failed.load()) return false;
   }
   for (int g = 0; g < G; ++g) {

@@ -369,8 +369,8 @@ retry_pack:
       for (auto &lv : c.levels) jobs.push_back({&lv, W});
     }
     prepacked.resize(jobs.size());
-    // (at most 8 levels at a time, each with its graphs on up to 8 threads of pack_level_fast's own bounded pool)
-    tsim_parallel_for(jobs.size(), 8, [&](size_t i) {
+    // (up to 16 levels at a time on the process-wide pool, each level's graphs through the same pool: tsim_pool.cpp)
+    tsim_parallel_for(jobs.size(), 16, [&](size_t i) {
       if (jobs[i].second < 0) { prepacked[i].ok = true; return; }  // (reported below: too many parameters)
       prepacked[i].ok = pack_level_fast(*jobs[i].first, jobs[i].second, prepacked[i].tables, prepacked[i].fixed, prepacked[i].frame);
     });

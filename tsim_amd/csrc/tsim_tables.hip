@@ -172,16 +172,26 @@ static int trie_build_sync(tsim_program *p, const tsimk::LwBuildArgs &a0, int W,
 // the scratch buffers handed back in `scratch` (the caller frees them once `s` has passed them).
 static int tables_build_at(tsim_program *p, int rec_off, const TsimTablePlan &t, hipStream_t s, bool wait, uint32_t **tab_out,
                            std::vector<void *> &scratch) {
+  // ONE allocation for the table and every component's scratch (node values / tree bookkeeping), one wait at the end: a fresh
+  // handle of the cultivation shape spent 2.5-3 ms here on three hipMalloc / synchronize / hipFree rounds (round 6, cold start)
+  std::vector<size_t> soff(p->comps.size() + 1, 0);
+  for (size_t ci = 0; ci < p->comps.size(); ++ci) soff[ci + 1] = soff[ci] + (tables_scratch_bytes(p, ci, t) + 255) / 256 * 256;
   uint32_t *tab = nullptr;
   hipError_t me = hipMalloc((void **)&tab, std::max<size_t>(16, (size_t)t.bytes));
   if (me != hipSuccess) return tsim_fail(TSIM_ENOMEM, "hipMalloc(%lld) for the pattern tables failed: %s", t.bytes, hipGetErrorString(me));
-  for (size_t ci = 0; ci < p->comps.size(); ++ci) {
+  char *sbase = nullptr;
+  me = hipMalloc((void **)&sbase, std::max<size_t>(256, soff.back()));
+  if (me != hipSuccess) {
+    (void)hipFree(tab);
+    return tsim_fail(TSIM_ENOMEM, "hipMalloc(%zu) for the pattern-table scratch failed: %s", soff.back(), hipGetErrorString(me));
+  }
+  int r = 0;
+  hipError_t e = hipSuccess;
+  for (size_t ci = 0; ci < p->comps.size() && r == 0 && e == hipSuccess; ++ci) {
     const HostComponent &c = p->comps[ci];
     const long long tab_off = (long long)p->img[(size_t)rec_off + ci * LW_WORDS + LW_TAB];
     // (no pattern list: the build kernels unrank the row index, narrow components on lw_rank_term, wide ones in
     // the binomial table - the host enumeration + copy of 14 million patterns cost as much as the kernels)
-    float *p1 = nullptr;
-    hipError_t e = hipMalloc((void **)&p1, tables_scratch_bytes(p, ci, t));  // node values
     LwBuildArgs a;
     a.img = p->d_img;
     a.patbits = nullptr;
@@ -192,32 +202,32 @@ static int tables_build_at(tsim_program *p, int rec_off, const TsimTablePlan &t,
     a.tab = tab + tab_off;
     a.comp_off = p->comp_off + (int)ci * C_WORDS;
     a.npat = (int)t.npat[ci];
-    a.p1 = p1;
+    a.p1 = reinterpret_cast<float *>(sbase + soff[ci]);
     a.depth = -1;
     a.pat_begin = 0;
     a.pat_count = 0;
     a.trie = c.trie ? 1 : 0;
     a.trie_level = 0;
     a.trie_cap = (uint32_t)t.chunks[ci];
-    int r = 0;
-    if (e == hipSuccess && c.trie) {
+    if (c.trie) {
       long long okp = 0;
       r = trie_build_sync(p, a, p->comp_w[ci], c.n_out, s, nullptr, &okp, nullptr);
       const uint32_t v = (uint32_t)okp;
       p->img[(size_t)rec_off + ci * LW_WORDS + LW_NPAT_OK] = v;
       if (r == 0) e = hipMemcpy(p->d_img + rec_off + ci * LW_WORDS + LW_NPAT_OK, &v, 4, hipMemcpyHostToDevice);
-    } else if (e == hipSuccess) r = tsim_launch_lw_build(p->comp_w[ci], p->fast, a, c.n_out, s);
-    if (e == hipSuccess && r == 0 && wait) e = hipStreamSynchronize(s);
-    if (p1 && (wait || r || e != hipSuccess)) (void)hipFree(p1);
-    else if (p1) scratch.push_back(p1);
-    if (r || e != hipSuccess) {
-      if (!wait) (void)hipStreamSynchronize(s);  // kernels of earlier components may still write
-      for (void *q : scratch) (void)hipFree(q);
-      scratch.clear();
-      (void)hipFree(tab);
-      return r ? r : tsim_fail(TSIM_EHIP, "pattern table build failed: %s", hipGetErrorString(e));
+    } else {
+      r = tsim_launch_lw_build(p->comp_w[ci], p->fast, a, c.n_out, s);
     }
   }
+  if (r == 0 && e == hipSuccess && wait) e = hipStreamSynchronize(s);
+  if (r || e != hipSuccess) {
+    (void)hipStreamSynchronize(s);  // kernels of earlier components may still write
+    (void)hipFree(sbase);
+    (void)hipFree(tab);
+    return r ? r : tsim_fail(TSIM_EHIP, "pattern table build failed: %s", hipGetErrorString(e));
+  }
+  if (wait) (void)hipFree(sbase);
+  else scratch.push_back(sbase);
   *tab_out = tab;
   return 0;
 }

@@ -803,6 +803,7 @@ retry_pack:
             p->wr_offs.push_back(wr_this);
             img.resize(img.size() + WR_WORDS, 0u);
             img[(size_t)wr_this + WR_MERGE] = merge ? 1u : 0u;
+            img[(size_t)wr_this + WR_KEYSUB] = p->total_keys > TSIMK_LWM_KEYS ? img[p->comp_off + wci * C_WORDS + C_KEYBASE] : 0u;
             img[(size_t)wr_this + WR_BSTRIDE] = (uint32_t)p->lw_binom_stride;
             {  // the f words that hold selected bits: masks, then (selected bits in the lower words | word index << 16)
               std::vector<uint32_t> words, masks;

@@ -73,7 +73,8 @@ WideLayout wide_layout(const tsim_program *p, int WF32, size_t ci) {
 // not cross a multiple of 2^32; bit_packed rows are written and merged as dwords)
 bool wide_applies(const tsim_program *p, int64_t B, int32_t num_f, int64_t shot_offset) {
   if (!(p->lw && p->lw_wide && p->wr_off != 0 && p->knobs.wide_fused)) return false;
-  if (p->total_keys <= 0 || p->total_keys > TSIMK_LWM_KEYS || B <= 0 || B >= (1ll << 28)) return false;
+  // (up to TSIMK_INLINE_KEYS compiled outputs: each pass carries its own component's subkeys - WR_KEYSUB - when they are more than TSIMK_LWM_KEYS)
+  if (p->total_keys <= 0 || p->total_keys > TSIMK_INLINE_KEYS || B <= 0 || B >= (1ll << 28)) return false;
   for (size_t ci = 0; ci < p->comps.size() && ci < p->lw_npat.size(); ++ci)  // 32-bit byte offsets inside a component's table
     if (((p->lw_npat[ci] << p->comps[ci].n_out) * 4) >= (1ll << 32)) return false;
   if (((unsigned long long)shot_offset >> 32) != ((unsigned long long)(shot_offset + B - 1) >> 32)) return false;
@@ -138,7 +139,8 @@ int launch_wide(tsim_program *p, int n, const SampleArgs *const *args, int64_t B
     st.out = a.out;
     st.out_compact = a.out_compact;
     st.norm_dev = a.norm_dev;
-    memcpy(st.keys, a.inline_keys, sizeof(uint32_t) * 2 * (size_t)p->total_keys);
+    const int ksub = (int)p->img[(size_t)p->wr_offs[ci] + WR_KEYSUB];
+    memcpy(st.keys, a.inline_keys + 2 * ksub, sizeof(uint32_t) * 2 * (size_t)std::min(TSIMK_LWM_KEYS, p->total_keys - ksub));
   }
   const long long chunks = (long long)W.chunks_per_step * n;
   const int wpb = L.block / 64;

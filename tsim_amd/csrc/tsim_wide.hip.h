@@ -50,6 +50,7 @@ enum {
   WR_SELN,        // f words (32 bits) that hold selected bits of the component (<= TSIMK_WIDE_SELMAX): the only ones phase 1 looks at
   WR_SELREC,      // image offset of SELN masks, then SELN x (selected bits in the lower words | word index << 16)
   WR_BSTRIDE,     // words per row of the binomial table C(b, k + 1) at binom_off: 256, or 512 for components beyond 255 selected bits
+  WR_KEYSUB,      // the launch's key records start at this compiled output (programs of more than TSIMK_LWM_KEYS outputs: every pass gets ITS component's subkeys)
   WR_WORDS = 32
 };
 #define TSIMK_WIDE_SELMAX 64   // (f rows of up to 2048 bits since round 5: max_f_index < 512 was the 16 mask words of the round-2 kernels)
@@ -245,7 +246,7 @@ __global__ void __launch_bounds__(1024) k_sample_wide(WideArgs A) {
 
   const uint32_t wmax = rec[LW_WMAX];
   const uint32_t tab_byte = 0u;  // (A.tab is the COMPONENT's table since round 5: offsets below 4 GiB per component, not per program)
-  const uint32_t keybase = rec[LW_KEYBASE];
+  const uint32_t keybase = rec[LW_KEYBASE] - wr[WR_KEYSUB];
   const uint32_t lutmask = wr[WR_LUTMASK];
   const __amdgpu_buffer_rsrc_t r_tab = __builtin_amdgcn_make_buffer_rsrc((void *)A.tab, 0, A.tab_bytes, 0x00020000);
   const uint32_t so_lo = (uint32_t)A.shot_offset, so_hi = (uint32_t)((unsigned long long)A.shot_offset >> 32);

@@ -1456,24 +1456,22 @@ def extra_legs(backend, synth, program, cfg, hp, info, B, num_f, n_out, key, f_b
             ks = (C.c_uint32 * 2)(5, 6)
             kn = prng.key(11)
 
-            aux = hp3.aux_stream(0) if os.environ.get("TSIM_BENCH_NOISE_SERIAL", "0") != "1" else 0
-
-            def noise_group(g, gsz):
-                nonlocal kn
-                for i in range(gsz):
-                    kn, sub = hp3.split_key(kn)
-                    dn.sample_into(fb[g * gsz + i].ptr, B, sub, stream=aux)
+            nks = (C.c_uint32 * 2)(7, 8)
+            two_kernels = os.environ.get("TSIM_BENCH_NOISE_TWO_KERNELS", "0") == "1"
 
             def cycle(n_groups=8, gsz=8):
-                # the noise of group g + 1 (its own stream) runs beside the sampling of group g (the lanes, ordered behind group g's noise)
-                noise_group(0, gsz)
+                # one call per group: tsim_sample_steps_noise_device (C2 / C3: noise + first pass in ONE kernel, k_noise_sample_fast)
+                nonlocal kn
                 for g in range(n_groups):
-                    if aux:
-                        hp3.pipeline_wait_stream(aux)
-                    if g + 1 < n_groups:
-                        noise_group(g + 1, gsz)
-                    hp3.sample_steps_device([fb[g * gsz + i].ptr for i in range(gsz)], B, num_f, ks, [ob[(g * gsz + i) % 32].ptr for i in range(gsz)],
-                                            inputs_ready=bool(aux), out_bit_packed=True)
+                    fl = [fb[g * gsz + i].ptr for i in range(gsz)]
+                    ol = [ob[(g * gsz + i) % 32].ptr for i in range(gsz)]
+                    if two_kernels:  # (A/B: the noise kernel per batch on the handle's stream, then the group)
+                        for i in range(gsz):
+                            kn, sub = hp3.split_key(kn)
+                            dn.sample_into(fl[i], B, sub)
+                        hp3.sample_steps_device(fl, B, num_f, ks, ol, inputs_ready=False, out_bit_packed=True)
+                    else:
+                        hp3.sample_steps_noise_device(dn, fl, B, num_f, ks, nks, ol, out_bit_packed=True)
                 hp3.synchronize()
 
             for _ in range(3):
@@ -1491,19 +1489,17 @@ def extra_legs(backend, synth, program, cfg, hp, info, B, num_f, n_out, key, f_b
             t0 = time.perf_counter()
             for i in range(ring):
                 kn, sub = hp3.split_key(kn)
-                dn.sample_into(fb[i].ptr, B, sub, stream=aux)
-            if aux:
-                hp3.pipeline_wait_stream(aux)
+                dn.sample_into(fb[i].ptr, B, sub)
             hp3.synchronize()
             dt_noise = time.perf_counter() - t0
-            leg[mname] = {"noise_model": desc, "shots_per_s": ring * B / dt, "us_per_step": dt / ring * 1e6, "steps_per_cycle": ring,
+            leg[mname] = {"noise_model": desc, "kernels": hp3.path_counts(), "shots_per_s": ring * B / dt, "us_per_step": dt / ring * 1e6, "steps_per_cycle": ring,
                           "noise_kernel_alone_us_per_step": dt_noise / ring * 1e6,
                           "noise_algorithmic_bytes_per_shot": 8 * WF,
                           "noise_hbm_frac_alone": 8 * WF * B / (dt_noise / ring) / 1e9 / HBM_PEAK_GBS}
             for b in fb + ob:
                 b.free()
             hp3.close()
-        leg["note"] = ("device noise (k_noise_wave, statistically equivalent to the reference's ChannelSampler) + sampling, inputs and results in HBM; "
+        leg["note"] = ("tsim_sample_steps_noise_device: device noise (statistically equivalent to the reference's ChannelSampler) + sampling, f rows and results in HBM; "
                        "never `value`: the headline's inputs are resident before the timed region")
         out["resident_device_noise"] = leg
     except Exception as exc:  # context only

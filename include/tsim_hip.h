@@ -368,6 +368,15 @@ int tsim_noise_create(tsim_program *p, int32_t num_f, int32_t n_channels, const 
 /* d_f: uint64 [B, ceil(num_f/64)] (device); overwritten with a fresh batch keyed by (key_hi, key_lo). */
 int tsim_noise_sample_device(tsim_noise *n, int64_t B, uint32_t key_hi, uint32_t key_lo, uint64_t *d_f,
                              void *stream);
+/* tsim_sample_steps_device with the f rows drawn on the device, in the same call (the reference's batch loop,
+ * src/tsim/sampler.py:393-400: channel sampler, then sample_program, per batch).  Batch j's noise key is the j-th
+ * split of noise_key (advanced like `key`); its f rows are written to d_f[j] - the bytes tsim_noise_sample_device
+ * writes for that key.  Programs of one component of at most 8 outputs over f rows of at most 128 bits draw the noise
+ * INSIDE their first pass (one kernel: csrc/tsim_noise_fused.hip.h); every other program runs the noise kernel in
+ * front of its first pass.  Results do not depend on which. */
+int tsim_sample_steps_noise_device(tsim_program *p, tsim_noise *n, int32_t n_steps, uint64_t *const *d_f, int64_t B,
+                                   int32_t num_f, uint32_t key[2], uint32_t noise_key[2], int64_t shot_offset,
+                                   void *const *d_out, float *const *d_max_norm_dev, uint32_t flags);
 void tsim_noise_destroy(tsim_noise *n);
 
 /* ---- multi-GPU: RCCL over xGMI, issued by the library (no PyTorch) --------------------------------------

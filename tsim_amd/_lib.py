@@ -131,6 +131,8 @@ SYMBOLS: dict[str, tuple] = {
     "tsim_key_split": (None, [_U32, _U32, C.POINTER(_U32)]),
     "tsim_sample_batch_device_begin_split": (C.c_int, [_P, _I32, _P, _I64, _I32, C.POINTER(_U32), _I64, _P, _P, _P, _U32]),
     "tsim_sample_steps_device": (C.c_int, [_P, _I32, C.POINTER(_P), _I64, _I32, C.POINTER(_U32), _I64, C.POINTER(_P), C.POINTER(_P), _U32]),
+    "tsim_sample_steps_noise_device": (C.c_int, [_P, _P, _I32, C.POINTER(_P), _I64, _I32, C.POINTER(_U32), C.POINTER(_U32), _I64, C.POINTER(_P),
+                                                 C.POINTER(_P), _U32]),
     "tsim_profile_read_steps": (C.c_int, [_P, C.POINTER(_I64), _I32]),
     "tsim_memcpy_d2h_async": (C.c_int, [_P, _P, _P, _I64, _P]),
     "tsim_memcpy_h2d_async": (C.c_int, [_P, _P, _P, _I64, _P]),

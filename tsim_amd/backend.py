@@ -231,7 +231,7 @@ class HipProgram:
                     pattern_max_weight=[int(mw[i]) for i in range(nc.value)])
 
     PATH_NAMES = ("lw_fast", "lw_fastm", "lw_multi", "direct_multi", "wide", "lw_fast1", "lw_reg", "lw_lds", "lw_lds_wide",
-                  "sample4w", "sample4", "sample4h", "hw", "over", "rows", "sample4h_multi", "gen")
+                  "sample4w", "sample4", "sample4h", "hw", "over", "rows", "sample4h_multi", "gen", "noise_fast")
 
     def path_counts(self, reset: bool = False) -> dict:
         """Launches per kernel family since creation / the last reset (``tsim_program_path_counts``), non-zero entries only."""
@@ -439,6 +439,21 @@ class HipProgram:
                                                 (1 if inputs_ready else 0) | (2 if out_bit_packed else 0))
         if rc < 0:
             _lib.check(rc, "tsim_sample_steps_device")
+
+    def sample_steps_noise_device(self, noise: "DeviceNoiseSampler", d_f, B: int, num_f: int, key_state, noise_key_state, d_out, *,
+                                  shot_offset: int = 0, out_bit_packed: bool = False, d_norm_dev=None) -> None:
+        """:meth:`sample_steps_device` with the f rows drawn on the device in the same call (``tsim_sample_steps_noise_device``):
+        batch j's noise key is the j-th split of ``noise_key_state`` (a ``(c_uint32 * 2)``, advanced in place); its rows are
+        written to ``d_f[j]`` - the bytes ``noise.sample_into`` writes for that key.  One-component programs of at most 8
+        outputs over f rows of at most 128 bits draw the noise inside their first pass (one kernel)."""
+        n = len(d_f)
+        fa = d_f if isinstance(d_f, C.Array) else (C.c_void_p * n)(*[int(x) for x in d_f])
+        oa = d_out if isinstance(d_out, C.Array) else (C.c_void_p * n)(*[int(x) for x in d_out])
+        da = None if d_norm_dev is None else (C.c_void_p * n)(*[int(x) for x in d_norm_dev])
+        rc = self._lib.tsim_sample_steps_noise_device(self._h, noise._n, n, fa, int(B), int(num_f), key_state, noise_key_state, int(shot_offset),
+                                                      oa, da, 2 if out_bit_packed else 0)
+        if rc < 0:
+            _lib.check(rc, "tsim_sample_steps_noise_device")
 
     def profile_read_steps(self, reset: bool = True) -> int:
         n = C.c_int64(0)

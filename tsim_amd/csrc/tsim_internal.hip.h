@@ -136,7 +136,7 @@ struct TsimBuildJob {  // the table build of one component, cut into slices of p
 
 // kernel families (tsim_program_path_counts, include/tsim_hip.h)
 enum TsimPath { TP_LW_FAST = 0, TP_LW_FASTM, TP_LW_MULTI, TP_DIRECT_MULTI, TP_WIDE, TP_LW_FAST1, TP_LW_REG, TP_LW_LDS, TP_LW_LDS_WIDE,
-                TP_SAMPLE4W, TP_SAMPLE4, TP_SAMPLE4H, TP_HW, TP_OVER, TP_ROWS, TP_SAMPLE4H_MULTI, TP_GEN };
+                TP_SAMPLE4W, TP_SAMPLE4, TP_SAMPLE4H, TP_HW, TP_OVER, TP_ROWS, TP_SAMPLE4H_MULTI, TP_GEN, TP_NOISE_FAST };
 
 struct tsim_program {
   long long path_count[TSIM_PATH_COUNT] = {};
@@ -282,6 +282,7 @@ struct tsim_program {
     bool wide_tables = true;  // wide_tables=0: no pattern tables in front of the wide kernels
     bool hard_overflow = true; // hard_overflow=0: the latency kernels of a hard-row batch walk whole lists (no per-shot workers behind them)
     bool shallow = true;      // shallow=0: finalize builds the default table depth at once (round 4) instead of starting shallow
+    bool noise_fused = true;  // noise_fused=0: tsim_sample_steps_noise_device runs k_noise_wave in front of every first pass (no k_noise_sample_fast)
     int trie = 1;             // trie=0: no prefix-tree tables - components of more than 12 outputs run without tables (round 5); 2: prefix trees for every narrow component
     int gen = 1;              // gen: k_sample_gen for fused groups - 0 never, 1 where no register first pass applies, 2 wherever it applies
     int x4 = 32;              // x4=N: components of 81..128 parameters or more than 64 selected bits AND at least N graphs take the narrow family (four words of x); 0: never

@@ -1,6 +1,7 @@
 // tsim_noise.hip - device-side channel sampler (statistical twin of ChannelSampler.sample).
 #include "tsim_internal.hip.h"
 #include "tsim_noise.hip.h"
+#include "tsim_sample_internal.hip.h"
 
 using namespace tsimk;
 
@@ -207,6 +208,59 @@ extern "C" int tsim_noise_sample_device(tsim_noise *n, int64_t B, uint32_t key_h
   hipLaunchKernelGGL(k_noise, dim3((unsigned)grid), dim3(256), 0, s, a);
   HIP_TRY(hipGetLastError());
   return TSIM_OK;
+}
+
+// the request's batch launcher (tsim_sample.hip calls it for the paths that do not fuse the noise into their first pass)
+static int noise_launch_one(void *noise, int64_t B, uint32_t k0, uint32_t k1, uint64_t *d_f, hipStream_t s) {
+  return tsim_noise_sample_device((tsim_noise *)noise, B, k0, k1, d_f, (void *)s);
+}
+
+// sample_program over n_steps batches whose f rows are drawn HERE (reference: src/tsim/sampler.py:393-400 - channel sampler, then
+// sample_program, per batch): batch j's noise key is split(noise_key) threaded like the sampling key (noise_key advances by one
+// split per batch); its f rows land in d_f[j] (the caller's buffers: the hard-row kernels read them, and so may the caller).
+extern "C" int tsim_sample_steps_noise_device(tsim_program *p, tsim_noise *n, int32_t n_steps, uint64_t *const *d_f, int64_t B, int32_t num_f,
+                                              uint32_t key[2], uint32_t noise_key[2], int64_t shot_offset, void *const *d_out,
+                                              float *const *d_max_norm_dev, uint32_t flags) {
+  if (!n || n->prog != p) return tsim_fail(TSIM_EINVAL, "noise sampler is NULL or belongs to another program");
+  if (!noise_key) return tsim_fail(TSIM_EINVAL, "NULL argument");
+  if (num_f != n->num_f) return tsim_fail(TSIM_EINVAL, "the noise sampler draws %d f bits, the call says %d", n->num_f, num_f);
+  if (n_steps <= 0) return tsim_sample_steps_device(p, n_steps, (const uint64_t *const *)d_f, B, num_f, key, shot_offset, d_out, d_max_norm_dev, flags);
+  std::vector<uint32_t> keys(2 * (size_t)n_steps);
+  for (int j = 0; j < n_steps; ++j) {
+    uint32_t o[4];
+    tsim_key_split(noise_key[0], noise_key[1], o);
+    noise_key[0] = o[0];
+    noise_key[1] = o[1];
+    keys[2 * (size_t)j] = o[2];
+    keys[2 * (size_t)j + 1] = o[3];
+  }
+  TsimNoiseRequest rq{};
+  rq.noise = n;
+  rq.launch = noise_launch_one;
+  rq.keys = keys.data();
+  rq.base = 0;
+  rq.fusable = false;
+  if (n->wave_g > 0 && n->n_ch > 0) {
+    rq.N.inv_log2_1mp = n->d_inv;
+    rq.N.cdf_off = n->d_off;
+    rq.N.cdf = n->d_cdf;
+    rq.N.pw_off = n->d_pw_off;
+    rq.N.pw = n->d_pw;
+    rq.N.f = nullptr;
+    rq.N.B = B;
+    rq.N.n_ch = n->n_ch;
+    rq.N.WF = n->WF;
+    rq.N.tile = n->wave_tile;
+    rq.N.g = n->wave_g;
+    // (the fused kernel's blocks are 1024 threads: groups of g lanes for up to 1024 / g channels at a time; LDS: the tile, the
+    // channel records and the first pass's ~5 KB of tables - two blocks per CU)
+    rq.fusable = (n->wave_tile % 1024) == 0 && (size_t)n->wave_tile * n->WF * 8 + (size_t)n->n_ch * 24 <= 56 * 1024;
+  }
+  g_noise_req = &rq;
+  // (the f rows do not exist before this call: whatever the caller says about its inputs, every path orders its reads behind the noise)
+  const int r = tsim_sample_steps_device(p, n_steps, (const uint64_t *const *)d_f, B, num_f, key, shot_offset, d_out, d_max_norm_dev, flags);
+  g_noise_req = nullptr;
+  return r;
 }
 
 extern "C" void tsim_noise_destroy(tsim_noise *n) {

@@ -75,7 +75,7 @@ void tsim_stream_release(int device, hipStream_t s) {
 extern "C" const char *tsim_last_error(void) { return g_err; }
 extern "C" const char *tsim_tune_keys(void) {
   return "defer_hard,defer_group,lw_fast,wide_fused,wide_compact,wide_tables,wide_depth,wide_passes,hard_wave,hard_wave_rows,hard_inline_rows,"
-         "hard_comp_par,hard_overflow,deep_after,fused_lanes,fused_max,gen,trie,shallow,x3,x4,noise_wave";
+         "hard_comp_par,hard_overflow,deep_after,fused_lanes,fused_max,gen,trie,shallow,x3,x4,noise_wave,noise_fused";
 }
 extern "C" const char *tsim_version(void) { return "tsim_amd-hip 0.2 (gfx950)"; }
 
@@ -300,6 +300,7 @@ extern "C" int tsim_program_finalize(tsim_program *p, int32_t device) {
     p->knobs.wide_passes = (int)std::max(1ll, std::min(16ll, tune_ll("wide_passes", 8)));
     p->knobs.gen = (int)std::max(0ll, std::min(2ll, tune_ll("gen", 1)));
     p->knobs.trie = (int)std::max(0ll, std::min(2ll, tune_ll("trie", 1)));
+    p->knobs.noise_fused = tune_ll("noise_fused", 1) != 0;
     p->knobs.shallow = tune_ll("shallow", 1) != 0;
     p->knobs.hard_overflow = tune_ll("hard_overflow", 1) != 0;
   }

@@ -14,10 +14,12 @@
 #include "tsim_direct.hip.h"
 #include "tsim_lw_fastm.hip.h"
 #include "tsim_sample_internal.hip.h"
+#include "tsim_noise_fused.hip.h"
 
 using namespace tsimk;
 using namespace tsimhost;
 
+thread_local TsimNoiseRequest *g_noise_req = nullptr;
 HostMarks *g_marks = nullptr;
 
 
@@ -1159,7 +1161,38 @@ static int steps_group_fused(tsim_program *p, int n, const uint64_t *const *d_f,
                     ((unsigned long long)shot_offset >> 32) == ((unsigned long long)(shot_offset + B - 1) >> 32);
   M.lwf_off = fast ? p->lwf_off : 0;
   M.tab_bytes = fast ? (uint32_t)p->lw_bytes : 0u;
-  if (fast) {
+  // device noise in front of this group (tsim_sample_steps_noise_device): inside the first pass when that is the one-component
+  // register pass and the sampler's tile is a whole number of row blocks, else k_noise_wave for every batch on this lane
+  TsimNoiseRequest *nq = g_noise_req;
+  const bool fuse_noise = nq && fast && nq->fusable && nq->N.WF == WF && (nq->N.tile % blk1) == 0 && p->knobs.noise_fused;
+  if (nq && !fuse_noise)
+    for (int j = 0; j < n; ++j)
+      if (int r = nq->launch(nq->noise, B, nq->keys[2 * (nq->base + j)], nq->keys[2 * (nq->base + j) + 1], const_cast<uint64_t *>(d_f[j]), s)) return r;
+  if (fuse_noise) {
+    NoiseFusedArgs FA{};
+    FA.M = M;
+    FA.N = nq->N;
+    for (int j = 0; j < n; ++j) {
+      FA.nkeys[2 * j] = nq->keys[2 * (nq->base + j)];
+      FA.nkeys[2 * j + 1] = nq->keys[2 * (nq->base + j) + 1];
+    }
+    const long long tiles = ((B + nq->N.tile - 1) / nq->N.tile) * n;
+    const long long gridn = std::max<long long>(1, std::min<long long>((long long)p->n_cu * 2, tiles));
+    const size_t ldsn = (size_t)nq->N.tile * nq->N.WF * 8 + (size_t)nq->N.n_ch * 24;
+    const int n_out = p->comps[0].n_out;
+#define TSIM_LNF(N)                                                                                              \
+  case N:                                                                                                        \
+    if (WF == 1) hipLaunchKernelGGL((k_noise_sample_fast<2, N>), dim3((unsigned)gridn), dim3(blk1), ldsn, s, FA); \
+    else hipLaunchKernelGGL((k_noise_sample_fast<4, N>), dim3((unsigned)gridn), dim3(blk1), ldsn, s, FA);        \
+    break;
+    ++p->path_count[TP_NOISE_FAST];
+    switch (n_out) {
+      TSIM_LNF(1) TSIM_LNF(2) TSIM_LNF(3) TSIM_LNF(4) TSIM_LNF(5) TSIM_LNF(6) TSIM_LNF(7) TSIM_LNF(8)
+      default: return tsim_fail(TSIM_ESTATE, "fast record with %d outputs", n_out);
+    }
+#undef TSIM_LNF
+    ++p->stat_fast;
+  } else if (fast) {
     const int n_out = p->comps[0].n_out;
 #define TSIM_LF(N)                                                                                     \
   case N:                                                                                              \
@@ -1315,6 +1348,16 @@ extern "C" int tsim_sample_steps_device(tsim_program *p, int32_t n_steps, const 
   TSIM_MARK("entry");
   int done = 0;
   while (done < n_steps) {
+    if (g_noise_req) g_noise_req->base = done;
+    // (every path but the register first passes' fused groups: the batches' noise on the handle's stream, the lanes wait for it)
+    auto noise_first = [&](int n) -> int {
+      TsimNoiseRequest *nq = g_noise_req;
+      if (!nq) return 0;
+      for (int j = 0; j < n; ++j)
+        if (int r = nq->launch(nq->noise, B, nq->keys[2 * (done + j)], nq->keys[2 * (done + j) + 1], const_cast<uint64_t *>(d_f[done + j]), p->stream)) return r;
+      flags &= ~(uint32_t)TSIM_PIPE_INPUTS_READY;
+      return 0;
+    };
     // the fused first pass applies when the register form does, the subkeys fit its records, and the launch plan
     // says "tables, short lists": decided per group - the plan follows the feedback of earlier launches
     const bool reg_fused = p->lw && !p->lw_wide && p->lw_reg && (WF == 1 || WF == 2) && WO == 1 && p->total_keys > 0 &&
@@ -1333,6 +1376,7 @@ extern "C" int tsim_sample_steps_device(tsim_program *p, int32_t n_steps, const 
       const int left = n_steps - done;
       const int groups = (left + TSIMK_DIRECT_MAX_STEPS - 1) / TSIMK_DIRECT_MAX_STEPS;
       const int n = (left + groups - 1) / groups;
+      if (int r = noise_first(n)) return r;
       if (int r = steps_group_direct(p, n, d_f + done, B, num_f, key, d_out + done, flags)) return r;
       done += n;
       continue;
@@ -1361,6 +1405,7 @@ extern "C" int tsim_sample_steps_device(tsim_program *p, int32_t n_steps, const 
         TSIM_MARK("plan");
         // (make_plan may have swapped deeper tables in: the 32-bit offsets of k_sample_wide are checked against THOSE - ADVICE r04)
         if (wplan.use_tables && wide_applies(p, B, num_f, shot_offset)) {
+          if (int r = noise_first(n)) return r;
           if (int r = steps_group_wide(p, n, d_f + done, B, num_f, key, shot_offset, d_out + done, d_max_norm_dev ? d_max_norm_dev + done : nullptr, flags))
             return r;
           done += n;
@@ -1406,6 +1451,7 @@ extern "C" int tsim_sample_steps_device(tsim_program *p, int32_t n_steps, const 
           if (int r = slot_prepare(p, 1 + (int)((p->steps_slot + (unsigned long long)j) % TSIM_PIPELINE_SLOTS), hard_bytes)) return r;
       }
       if (gen_fused) {
+        if (int r = noise_first(n)) return r;
         if (int r = steps_group_gen(p, n, d_f + done, B, num_f, key, shot_offset, d_out + done, d_max_norm_dev ? d_max_norm_dev + done : nullptr,
                                     flags, plan))
           return r;
@@ -1420,6 +1466,7 @@ extern "C" int tsim_sample_steps_device(tsim_program *p, int32_t n_steps, const 
       key[0] = o[0];
       key[1] = o[1];
       g_carry_plan = have_plan ? &plan : nullptr;
+      if (int r = noise_first(1)) return r;
       if (int r = tsim_sample_batch_device_begin(p, slot, d_f[done], B, num_f, o[2], o[3], shot_offset, (uint64_t *)d_out[done],
                                                  d_max_norm_dev ? d_max_norm_dev[done] : nullptr, nullptr, flags))
         return r;

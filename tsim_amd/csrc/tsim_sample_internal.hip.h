@@ -9,6 +9,7 @@
 #include <chrono>
 #include "tsim_kernels.hip.h"
 #include "tsim_lw.hip.h"
+#include "tsim_noise_wave.hip.h"
 
 // stage tags of the profiling events: 0 opens a launch, the others close a stage
 enum { PROF_BEGIN = 0, PROF_PASS1 = 1, PROF_HARD = 2, PROF_FULL = 3 };
@@ -53,6 +54,19 @@ int fill_sample_args(tsim_program *p, tsim_program::Slot &sl, tsimk::SampleArgs 
 int flush_batch(tsim_program *p);
 int flush_chunks(tsim_program *p);
 void hard_geometry(tsim_program *p, int WF, int WO);
+
+// ---- device noise in front of the steps (tsim_sample_steps_noise_device, tsim_noise.hip): the request travels thread-locally
+// through tsim_sample_steps_device.  A fused group of the one-component register pass runs k_noise_sample_fast (noise + first
+// pass in one kernel, tsim_noise_fused.hip.h); every other path gets k_noise_wave on its stream in front of its first pass.
+struct TsimNoiseRequest {
+  tsimk::NoiseWaveArgs N;        // the sampler's tables and tile geometry (f, B, k0, k1 unset)
+  void *noise;                   // tsim_noise *
+  int (*launch)(void *noise, int64_t B, uint32_t k0, uint32_t k1, uint64_t *d_f, hipStream_t s);  // k_noise_wave for one batch
+  const uint32_t *keys;          // per step: the batch's noise key (2 words)
+  int base;                      // step index of the first batch of the group being dispatched
+  bool fusable;                  // the tile is a whole number of 1024-row blocks, the channel records fit beside the first pass's tables
+};
+extern thread_local TsimNoiseRequest *g_noise_req;
 
 // ---- tsim_sample_wide.hip
 struct WideLayout {

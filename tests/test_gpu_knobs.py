@@ -19,7 +19,7 @@ TUNE = {
     "defer_hard": ["0"], "defer_group": ["1", "8"], "lw_fast": ["0"], "wide_fused": ["0"], "wide_compact": ["0"], "wide_tables": ["0"],
     "wide_depth": ["3"], "wide_passes": ["1"], "hard_wave": ["0"], "hard_wave_rows": ["0", "100000"], "hard_inline_rows": ["0"],
     "hard_comp_par": ["0"], "hard_overflow": ["0"], "deep_after": ["1"], "fused_lanes": ["1", "4"], "fused_max": ["3", "16"],
-    "gen": ["0", "2"], "trie": ["0", "2"], "shallow": ["0"], "x3": ["0"], "x4": ["0", "1"], "noise_wave": ["0"],
+    "gen": ["0", "2"], "trie": ["0", "2"], "shallow": ["0"], "x3": ["0"], "x4": ["0", "1"], "noise_wave": ["0"], "noise_fused": ["0"],
 }
 ENV = [{"TSIM_AMD_ADAPTIVE": "0"}, {"TSIM_AMD_FUSED_STEPS": "0"}, {"TSIM_AMD_DEEP_TABLES": "1"}, {"TSIM_AMD_DEEP_TABLES": "-1"},
        {"TSIM_AMD_MODE": "faithful"}, {"TSIM_AMD_KERNEL": "rows"}, {"TSIM_AMD_PATTERN_TABLES": "0"}, {"TSIM_AMD_PATTERN_TABLE_MB": "2"}]

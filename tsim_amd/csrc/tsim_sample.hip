@@ -1353,6 +1353,14 @@ extern "C" int tsim_sample_steps_device(tsim_program *p, int32_t n_steps, const 
     auto noise_first = [&](int n) -> int {
       TsimNoiseRequest *nq = g_noise_req;
       if (!nq) return 0;
+      // (the f buffer of a batch is its pipeline slot's as far as this call can tell: the handle's stream first gets behind the
+      // launches those slots carried last - their hard rows may still read the rows the noise is about to overwrite)
+      for (int j = 0; j < n; ++j) {
+        tsim_program::Slot &sl = p->slots[1 + (int)((p->steps_slot + (unsigned long long)j) % (unsigned long long)TSIM_PIPELINE_SLOTS)];
+        if (sl.deferred)
+          if (int r = tsim_flush_hard(p)) return r;
+        if (int r = slot_order_after_previous(p, sl, p->stream)) return r;
+      }
       for (int j = 0; j < n; ++j)
         if (int r = nq->launch(nq->noise, B, nq->keys[2 * (done + j)], nq->keys[2 * (done + j) + 1], const_cast<uint64_t *>(d_f[done + j]), p->stream)) return r;
       flags &= ~(uint32_t)TSIM_PIPE_INPUTS_READY;

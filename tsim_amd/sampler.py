@@ -657,7 +657,7 @@ class _CompiledSamplerBase:
         row_bytes = (n_out + 7) // 8 if direct_packed else wo * 8
         d_rows, d_devs = self._scratch(hp, "rows", total * row_bytes + 16), self._scratch(hp, "devs", plan.count * n_comp * 4)
         noise = self._device_noise_sampler(hp)
-        s_noise, s_copy = hp.aux_stream(0), hp.aux_stream(1)
+        s_copy = hp.aux_stream(1)
         # results land in recycled pinned memory (backend.PinnedPool): truly asynchronous copies, no first-touch page faults
         pool = result_pool()
         blocks = None
@@ -712,20 +712,17 @@ class _CompiledSamplerBase:
                 hp.unpack_bits_device(d_rows.ptr + r0 * row_bytes, r1 - r0, n_out, d_u8.ptr + r0 * n_out, stream=s_copy)
                 hp.d2h_async(out[r0:r1], d_u8.ptr + r0 * n_out, s_copy)
 
+        noise_key_state = (C.c_uint32 * 2)(self._noise_key[0] & 0xFFFFFFFF, self._noise_key[1] & 0xFFFFFFFF)
         for n in sizes:
             first = hp.pipeline_next_slot()
             slots = [(first + i) % nslot for i in range(n)]
-            for sl in slots:
-                # the slot's previous batch no longer reads its f buffer.  (Not sample_batch_device_end: download() has
-                # usually joined the slot on the copy stream already, and a joined slot adds no wait - the noise kernel of
-                # batch k + 32 would overwrite rows batch k still samples.)
-                hp.pipeline_wait_slot(sl, s_noise)
-                self._noise_key, nk = hp.split_key(self._noise_key)
-                noise.sample_into(f_ring[sl].ptr, size, nk, stream=s_noise)
-            hp.pipeline_wait_stream(s_noise)  # every lane is behind the noise queued so far
-            hp.sample_steps_device([f_ring[sl].ptr for sl in slots], size, num_f, key_state,
-                                   [d_rows.ptr + (b0 + i) * size * row_bytes for i in range(n)], inputs_ready=True,
-                                   out_bit_packed=direct_packed, d_norm_dev=[d_devs.ptr + (b0 + i) * n_comp * 4 for i in range(n)])
+            # noise and sampling of the group in ONE call (round 6, tsim_sample_steps_noise_device): batch j's noise key is the next split
+            # of the sampler's noise key chain, its f rows go to the buffer of its pipeline slot - which the library orders behind
+            # the slot's previous launch, hard rows included, before anything overwrites it.  One-component programs over narrow
+            # rows (the distillation shapes) draw the noise inside their first pass: one kernel per group instead of n + 1.
+            hp.sample_steps_noise_device(noise, [f_ring[sl].ptr for sl in slots], size, num_f, key_state, noise_key_state,
+                                         [d_rows.ptr + (b0 + i) * size * row_bytes for i in range(n)],
+                                         out_bit_packed=direct_packed, d_norm_dev=[d_devs.ptr + (b0 + i) * n_comp * 4 for i in range(n)])
             groups.append((b0, n, slots))
             b0 += n
             if len(groups) >= 2:  # the previous group's rows leave while this group is sampled (pinned target: the call returns at once)
@@ -735,6 +732,7 @@ class _CompiledSamplerBase:
             download(groups[done])
             done += 1
         self._key = (int(key_state[0]), int(key_state[1]))
+        self._noise_key = (int(noise_key_state[0]), int(noise_key_state[1]))
         # the copy stream is behind every batch (download() joined each slot on it): once it has drained, every kernel
         # that writes d_devs has finished - only then may the handle's stream read them
         hp.stream_synchronize(s_copy)

@@ -65,7 +65,10 @@ bool tsim_tables_plan_at(tsim_program *p, int cap, long long budget, int rec_off
         if ((npat + cnt) * 32 > tbudget) break;
       } else {
         const long long bytes = ((npat + cnt) << c.n_out) * 4;  // (the component's table starts on a 128-byte line)
-        if (bytes > budget || (w > 1 && tab_off * 4 + bytes > 4 * budget)) break;  // per component / all together
+        // (10..12 outputs: a pattern is 4-16 KB of thresholds - the prefix-tree budget applies, n11: 1.9 GB at weight 5 -> 324 MB at weight 4
+        // for 15 % of its rate; fewer outputs keep the large budget: F59's weight-5 class is 640 MB and worth 4x, profiles/r06/budget_512.txt)
+        const long long dbudget = c.n_out >= 10 ? std::min(budget, p->lw_trie_budget) : budget;
+        if (bytes > dbudget || (w > 1 && tab_off * 4 + bytes > 4 * budget)) break;  // per component / all together
         if (((npat + cnt) << c.n_out) + tab_off >= (1ll << 32)) break;              // float offsets are 32-bit
         // one wide component (k_sample_wide): byte offsets into the table are 32-bit there - a deeper table of 4 GiB or more would
         // push the program off that kernel for good

@@ -53,8 +53,7 @@ enum {
   GC_L_RANK,    // LDS word offset of RANK[TSIMK_LW_MAX_WEIGHT][F]: C(position, ordinal + 1)
   GC_OUTPOS,    // image offset of the n_out output columns
   GC_RSV,
-  GC_WORD0 = 8, // the FIRST word record inline (4 words): a component's records arrive with one pair of scalar loads
-  GC_WORDS = 16
+  GC_WORDS = 8
 };
 
 struct GenStep {
@@ -198,40 +197,23 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(TSIMK_GEN
     const uint32_t slo = so_lo + row;  // (the launcher keeps shot_offset + B below the next multiple of 2^32)
     cptr kp = (cptr)((cbytes)S + __builtin_offsetof(GenStep, keys));
     // ---- the components, in processing order (sampler.py:147-148); everything wave-uniform by scalar loads from the image
-    // (the records of component ci + 1 - gen record, first word record, the depth-dependent words of its LW record - are requested
-    // while component ci is worked on: three dependent scalar-memory round trips per component were ~40 % of a small component's
-    // time, class 20narrow; round 6)
-    static_assert(LW_WMAX == 5 && LW_TAB == 6 && LW_FMT == 8 && LW_NPAT == 9 && LW_CHUNKS == 11 && LW_NPAT_OK == 12, "LW words 4..12 are read as two 16-byte loads and a dword");
-    u32x8 cr_n = *(cptr8)g_comp;
-    u32x4 w0_n = *(cptr4)(g_comp + GC_WORD0);
-    u32x4 la_n = *(cptr4)(img + A.lw_off + 4), lb_n = *(cptr4)(img + A.lw_off + 8);
-    uint32_t lc_n = (img + A.lw_off)[LW_NPAT_OK];
     for (uint32_t ci = 0; ci < n_comp; ++ci) {
-      const u32x8 cr = cr_n;
-      const u32x4 w0 = w0_n, la = la_n, lb = lb_n;
-      const uint32_t npat_ok = lc_n;
-      if (ci + 1u < n_comp) {
-        cr_n = *(cptr8)(g_comp + (ci + 1u) * GC_WORDS);
-        w0_n = *(cptr4)(g_comp + (ci + 1u) * GC_WORDS + GC_WORD0);
-        cptr lwn = img + A.lw_off + (ci + 1u) * LW_WORDS;
-        la_n = *(cptr4)(lwn + 4);
-        lb_n = *(cptr4)(lwn + 8);
-        lc_n = lwn[LW_NPAT_OK];
-      }
+      const u32x8 cr = *(cptr8)(g_comp + ci * GC_WORDS);
+      cptr lw = img + A.lw_off + ci * LW_WORDS;
       const uint32_t n_out = cr[GC_NOUT], F = cr[GC_F], keybase = cr[GC_KEYBASE], nwords = cr[GC_NWORDS];
       cptr cw = img + cr[GC_WORDREC];
       cptr outpos = img + cr[GC_OUTPOS];
       const uint32_t *rank = L + cr[GC_L_RANK];
-      const uint32_t wmax = la.y;  // LW_WMAX
-      const uint64_t tbase = (uint64_t)(uintptr_t)A.tab + (uint64_t)la.z * 4ull;  // LW_TAB
-      const bool trie = lb.x != 0u;  // LW_FMT: the component's tables are a chunked prefix tree (tsim_trie.hip.h)
-      const uint64_t tb64 = trie ? (uint64_t)lb.w * 32ull : ((uint64_t)lb.y << n_out) * 4ull;  // LW_CHUNKS / LW_NPAT
+      const uint32_t wmax = lw[LW_WMAX];
+      const uint64_t tbase = (uint64_t)(uintptr_t)A.tab + (uint64_t)lw[LW_TAB] * 4ull;
+      const bool trie = lw[LW_FMT] != 0u;  // the component's tables are a chunked prefix tree (tsim_trie.hip.h)
+      const uint64_t tb64 = trie ? (uint64_t)lw[LW_CHUNKS] * 32ull : ((uint64_t)lw[LW_NPAT] << n_out) * 4ull;
       const uint32_t tbytes = tb64 > 0xFFFFFFFCull ? 0xFFFFFFFCu : (uint32_t)tb64;
       // the descriptor ends with the component's table: a lane whose pattern index means nothing reads zeros, never beyond
       const __amdgpu_buffer_rsrc_t r_tab = __builtin_amdgcn_make_buffer_rsrc((void *)(uintptr_t)tbase, 0, tbytes, 0x00020000);
       // colex rank = sum over the set selected bits, in ascending order, of C(position inside f_sel, ordinal + 1)
       uint32_t ord = 0u, pat = 0u;
-      u32x4 wr = w0;  // (zeros for a component without selected bits) the next word's record travels while this word's bits are walked
+      u32x4 wr = nwords ? *(cptr4)cw : u32x4{0u, 0u, 0u, 0u};  // the next word's record travels while this word's bits are walked
       for (uint32_t wi = 0; wi < nwords; ++wi) {
         const uint32_t widx = wr.x, sw = wr.y, base = wr.z;
         uint32_t m = active ? (frow[widx] & sw) : 0u;
@@ -263,7 +245,7 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(TSIMK_GEN
       }
       if (ord > wmax) hard = true;
       pat += l_bases[8u * ci + (ord < 7u ? ord : 7u)];
-      if (pat >= npat_ok) hard = true;  // (a prefix-tree build that the budget ended early, tsim_tables.hip)
+      if (pat >= lw[LW_NPAT_OK]) hard = true;  // (a prefix-tree build that the budget ended early, tsim_tables.hip)
       pat = hard ? 0u : pat;
       const uint32_t thr = pat << (n_out + 2u);  // byte offset of the pattern's threshold tree inside the component's table
       auto draw = [&](uint32_t i) -> uint32_t {

@@ -1267,7 +1267,6 @@ retry_pack:
                 const uint32_t outpos_off = img[p->lw_off + ci * LW_WORDS + LW_OUTPOS];
                 for (int i = 0; i < c.n_out; ++i) img.push_back(img[outpos_off + (uint32_t)i]);
                 uint32_t *cr = &img[comp_off + ci * GC_WORDS];
-                for (int q = 0; q < 4; ++q) cr[GC_WORD0 + q] = nwords ? img[words_off + (uint32_t)q] : 0u;  // the first word record, inline
                 cr[GC_NOUT] = (uint32_t)c.n_out;
                 cr[GC_F] = (uint32_t)c.F;
                 cr[GC_KEYBASE] = img[p->lw_off + ci * LW_WORDS + LW_KEYBASE];

@@ -13,7 +13,8 @@ from tsim_amd.sampler import CompiledDetectorSampler
 
 pytestmark = pytest.mark.gpu
 
-CLASSES = ["2wide", "narrow+wide", "F255", "F60", "F70", "F300", "out260_f320", "6narrow_f320"]
+CLASSES = ["2wide", "narrow+wide", "F255", "F60", "F70", "F300", "out260_f320", "6narrow_f320",
+           "n16", "n24", "20narrow"]  # (round 6: prefix-tree tables, more than 16 components)
 
 
 def _noise(num_f, p):
@@ -34,7 +35,7 @@ def test_default_engine_equals_row_kernel_engine(hip, name):
     np.testing.assert_array_equal(pa, np.packbits(full, axis=1, bitorder="little"))
 
 
-@pytest.mark.parametrize("name", ["2wide", "F70", "F255"])
+@pytest.mark.parametrize("name", ["2wide", "F70", "F255", "n24"])
 def test_device_noise_pipeline(hip, name):
     prog, c = synth.shape_class_program(name)
     noise = _noise(c["num_f"], c["p_bit"])

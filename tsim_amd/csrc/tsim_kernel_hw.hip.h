@@ -144,12 +144,8 @@ __device__ __forceinline__ HwRec hw_load_rec(const uint32_t *gimg, cptr lvl, uin
 
 // phase 2 on the calling wave: pa = the bit array for trial bit 1, pa0 (DUAL) = for trial bit 0; `first` = the records of
 // graphs 0..63 (hw_load_rec(…, lane), requested earlier)
-// (g_begin, g_step): the rounds of 64 graphs this wave takes - 0, 64: all of them, in order (the level's value: reduced and finished
-// below); 64 w, 64 nwv: wave w's share of a FIXED-FRAME level of many graphs (plain integer sums: any order), whose per-lane partial
-// sums are left in S / S0 for the caller (hw_component: split levels)
 template <int W, bool DUAL>
-__device__ __forceinline__ void hw_phase2_acc(const uint32_t *gimg, cptr img, cptr lvl, const uint32_t *pa, const uint32_t *pa0, const HwRec &first,
-                                              uint32_t g_begin, uint32_t g_step, LevelSum &S, LevelSum &S0) {
+__device__ __forceinline__ HwLevelOut hw_phase2(const uint32_t *gimg, cptr img, cptr lvl, const uint32_t *pa, const uint32_t *pa0, const HwRec &first) {
   const uint32_t G = lvl[L_G];
   const bool approx = (lvl[L_FLAGS] & TSIMK_LFLAG_APPROX) != 0;
   const bool fixed = (lvl[L_FLAGS] & TSIMK_LFLAG_FIXED) != 0;
@@ -157,10 +153,11 @@ __device__ __forceinline__ void hw_phase2_acc(const uint32_t *gimg, cptr img, cp
   const uint32_t lane = threadIdx.x & 63u;
   hw_u32x4 rec0 = first.r0, rec1 = first.r1, rec2 = first.r2, rec3 = first.r3;
   auto load_rec = [&](uint32_t g) {
-    const hw_u32x4 *q4 = reinterpret_cast<const hw_u32x4 *>(gimg + graphs + (size_t)g * G_WORDS);  // 64-byte aligned records
+    const hw_u32x4 *q4 = reinterpret_cast<const hw_u32x4 *>(gimg + graphs + (size_t)g * G_WORDS);
     rec0 = q4[0]; rec1 = q4[1]; rec2 = q4[2]; rec3 = q4[3];
   };
-  for (uint32_t g0 = g_begin; g0 < G; g0 += g_step) {
+  LevelSum S, S0;
+  for (uint32_t g0 = 0; g0 < G; g0 += 64u) {
     const uint32_t g = g0 + lane;
     const bool mine = g < G;
     int a = 0, b = 0, c = 0, d = 0, p = 0, a0 = 0, b0 = 0, c0 = 0, d0 = 0, p0 = 0;
@@ -241,14 +238,6 @@ __device__ __forceinline__ void hw_phase2_acc(const uint32_t *gimg, cptr img, cp
       }
     }
   }
-}
-
-template <int W, bool DUAL>
-__device__ __forceinline__ HwLevelOut hw_phase2(const uint32_t *gimg, cptr img, cptr lvl, const uint32_t *pa, const uint32_t *pa0, const HwRec &first) {
-  const bool approx = (lvl[L_FLAGS] & TSIMK_LFLAG_APPROX) != 0;
-  const bool fixed = (lvl[L_FLAGS] & TSIMK_LFLAG_FIXED) != 0;
-  LevelSum S, S0;
-  hw_phase2_acc<W, DUAL>(gimg, img, lvl, pa, pa0, first, 0u, 64u, S, S0);
   if (fixed) {
     S.sa = hw_sum_i32(S.sa); S.sb = hw_sum_i32(S.sb); S.sc = hw_sum_i32(S.sc); S.sd = hw_sum_i32(S.sd);
     if constexpr (DUAL) { S0.sa = hw_sum_i32(S0.sa); S0.sb = hw_sum_i32(S0.sb); S0.sc = hw_sum_i32(S0.sc); S0.sd = hw_sum_i32(S0.sd); }
@@ -320,64 +309,7 @@ __device__ __forceinline__ void hw_component(const SampleArgs &A, cptr img, cptr
     cptr lvl = levels + (i + 1) * L_WORDS;
     const uint32_t bitpos = F + i;
     uint32_t *buf = par + (((i + 1u) & 1u) ? 4u * pw : 0u);
-    // A FIXED-FRAME level of more than 64 graphs (cultivation shape: up to 256; round 6): the leading wave alone took its graphs in
-    // rounds of 64 - a record load, the bit fields and a term-table gather each, ~3 us per round, 57 of the 62 us of C4's grid -
-    // while the helpers finished the next level's row pass in a quarter of that and waited.  Here EVERY wave takes rounds
-    // (plain integer sums: any order), then every wave joins the next level's row pass; the leading wave adds the four partial
-    // sums behind a barrier, finishes the level and draws.  Same integers, same float epilogue: bit-identical.
-    const bool split = nwv >= 2u && lvl[L_G] > 64u && (lvl[L_FLAGS] & TSIMK_LFLAG_FIXED) != 0u && (lvl[L_FLAGS] & TSIMK_LFLAG_APPROX) == 0u;
-    if (split) {
-      int *part = reinterpret_cast<int *>(par + 8u * pw + 4u);  // [nwv][8]: (sa, sb, sc, sd) for trial bit 1, then for trial bit 0
-      const uint32_t *pa = buf + (prev_bit ? 0u : pw);
-      HwRec nxt = HwRec{};
-      if (lead && i + 1u < n_out) nxt = hw_load_rec(A.img, lvl + L_WORDS, lane);
-      LevelSum S, S0;
-      if (check) hw_phase2_acc<W, true>(A.img, img, lvl, pa, pa + 2u * pw, cur, 64u * wv, 64u * nwv, S, S0);
-      else hw_phase2_acc<W, false>(A.img, img, lvl, pa, pa, cur, 64u * wv, 64u * nwv, S, S0);
-      {
-        const int sa = hw_sum_i32(S.sa), sb = hw_sum_i32(S.sb), sc = hw_sum_i32(S.sc), sd = hw_sum_i32(S.sd);
-        if (lane == 0u) { part[8u * wv] = sa; part[8u * wv + 1u] = sb; part[8u * wv + 2u] = sc; part[8u * wv + 3u] = sd; }
-        if (check) {
-          const int ta = hw_sum_i32(S0.sa), tb = hw_sum_i32(S0.sb), tc = hw_sum_i32(S0.sc), td = hw_sum_i32(S0.sd);
-          if (lane == 0u) { part[8u * wv + 4u] = ta; part[8u * wv + 5u] = tb; part[8u * wv + 6u] = tc; part[8u * wv + 7u] = td; }
-        }
-      }
-      if (i + 1u < n_out) {  // the next level's row pass, for both values of the bit being drawn, by every wave
-        uint32_t xn[W];
-#pragma unroll
-        for (int w = 0; w < W; ++w) xn[w] = x[w];
-        const uint32_t np = bitpos + 1u, wi = np >> 5, bm = 1u << (np & 31u);
-#pragma unroll
-        for (int w = 0; w < W; ++w)
-          if ((uint32_t)w == wi) xn[w] |= bm;
-        hw_phase1<W>(A.img, lvl + L_WORDS, xn, true, bitpos, check, np, par + (((i + 2u) & 1u) ? 4u * pw : 0u), pw, wv, nwv);
-      }
-      __syncthreads();
-      if (lead) {
-        LevelSum T, T0;
-        T.sa = T.sb = T.sc = T.sd = 0;
-        T0.sa = T0.sb = T0.sc = T0.sd = 0;
-        for (uint32_t w2 = 0; w2 < nwv; ++w2) {
-          T.sa += part[8u * w2]; T.sb += part[8u * w2 + 1u]; T.sc += part[8u * w2 + 2u]; T.sd += part[8u * w2 + 3u];
-          if (check) { T0.sa += part[8u * w2 + 4u]; T0.sb += part[8u * w2 + 5u]; T0.sc += part[8u * w2 + 6u]; T0.sd += part[8u * w2 + 7u]; }
-        }
-        float re = 0.0f, im = 0.0f;
-        level_finish(T, lvl, false, true, re, im, nullptr);
-        const float p1 = cabs32(re, im);
-        if (check) {
-          float re0 = 0.0f, im0 = 0.0f;
-          level_finish(T0, lvl, false, true, re0, im0, nullptr);
-          const float p0 = cabs32(re0, im0);
-          const float norm = __fdiv_rn(__fadd_rn(p0, p1), prev);
-          maxdev = nanmax(maxdev, fabsf(__fsub_rn(norm, 1.0f)));
-        }
-        const float u = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)u_bits, (int)i));
-        const bool bit = u < __fdiv_rn(p1, prev);
-        prev = bit ? p1 : __fsub_rn(prev, p1);
-        if (lane == 0u) *bit_word = bit ? 1u : 0u;
-        cur = nxt;
-      }
-    } else if (lead) {
+    if (lead) {
       const uint32_t *pa = buf + (prev_bit ? 0u : pw);
       const HwRec nxt = i + 1u < n_out ? hw_load_rec(A.img, lvl + L_WORDS, lane) : HwRec{};
       float p1;

@@ -333,7 +333,7 @@ static int launch_hw(tsim_program *p, const SampleArgs *ctx, int n_ctx, int max_
   const unsigned gridw = (unsigned)((long long)H.n_ctx * H.max_lists * H.waves_per_list * H.comp_par);
   H.hw_blocks = gridw;
   H.par_words = (int)(2 * ((p->hw_max_rows + 63) / 64) + 2);
-  size_t ldsw = (size_t)H.par_words * 8 * 4 + 16 + 512;  // (+ the waves' partial sums of a split level) two buffers of four bit arrays (previous bit x trial bit) + the sampled bit.s word
+  size_t ldsw = (size_t)H.par_words * 8 * 4 + 16;  // two buffers of four bit arrays (previous bit x trial bit) + the sampled bit.s word
   unsigned grid = gridw;
   if (workers) {
     const size_t tile_bytes = std::max((size_t)p->v4_max_nch * 16, (size_t)p->v4_max_sent) * p->v4_gt * 16;

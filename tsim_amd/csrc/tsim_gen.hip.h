@@ -52,7 +52,7 @@ enum {
   GC_WORDREC,   // image offset of NWORDS x (f word index, selection mask, selected bits in lower words, 0)
   GC_L_RANK,    // LDS word offset of RANK[TSIMK_LW_MAX_WEIGHT][F]: C(position, ordinal + 1)
   GC_OUTPOS,    // image offset of the n_out output columns
-  GC_RSV,
+  GC_OUTBASE,   // the output columns are GC_OUTBASE, + 1, + 2, ... (the usual case: a component's outputs are consecutive columns); 0xFFFFFFFF: see GC_OUTPOS
   GC_WORDS = 8
 };
 
@@ -265,6 +265,14 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(TSIMK_GEN
         // whose threshold is 0 or 2^23 takes no draw (u < T is decided), and when that holds for the whole wave the Threefry
         // block is skipped - detectors fixed by f and the outcomes before them cost a compare.
         uint32_t chunk = pat;
+        // the sampled bits in output order (n_out <= 64); placed once behind the walk - with consecutive output columns two shifts
+        // instead of a column load and WO32 selects per output (24-40 outputs: a tenth of the pass)
+        uint32_t acc_lo = 0u, acc_hi = 0u;
+        auto keep = [&](uint32_t i, bool bit) {
+          const uint32_t v = (bit ? 1u : 0u) << (i & 31u);
+          if (i < 32u) acc_lo |= v;
+          else acc_hi |= v;
+        };
         auto bit_of = [&](uint32_t i, uint32_t T) -> bool {
           const bool need = (T - 1u) < ((1u << 23) - 1u) && active && !hard;  // 0 < T < 2^23
           uint32_t dr = 0u;  // (T = 2^23: 0 < T; T = 0: never)
@@ -278,21 +286,34 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(TSIMK_GEN
           const u32x4 cb = __builtin_amdgcn_raw_buffer_load_b128(r_tab, chunk * 32u + 16u, 0, 0);
           const uint32_t cmask = ca.y >> 24;
           const bool b0 = bit_of(i, ca.y & 0xFFFFFFu);
-          emit(i, b0);
+          keep(i, b0);
           bool b1 = false, b2 = false;
           if (rem > 1u) {
             b1 = bit_of(i + 1u, b0 ? ca.w : ca.z);
-            emit(i + 1u, b1);
+            keep(i + 1u, b1);
           }
           if (rem > 2u) {
             const uint32_t lo = b1 ? cb.y : cb.x, hi = b1 ? cb.w : cb.z;
             b2 = bit_of(i + 2u, b0 ? hi : lo);
-            emit(i + 2u, b2);
+            keep(i + 2u, b2);
           }
           if (i + rem < n_out) {
             const uint32_t leaf = rem == 3u ? (b0 ? 4u : 0u) + (b1 ? 2u : 0u) + (b2 ? 1u : 0u) : (rem == 2u ? (b0 ? 2u : 0u) + (b1 ? 1u : 0u) : (b0 ? 1u : 0u));
             if (!((cmask >> leaf) & 1u)) hard = true;  // the tree ends here: the table's budget was spent (tsim_trie.hip.h)
             chunk = ca.x + (uint32_t)__builtin_popcount(cmask & ((1u << leaf) - 1u));
+          }
+        }
+        {
+          const uint32_t ob = cr[GC_OUTBASE];
+          if (ob != 0xFFFFFFFFu) {  // wave-uniform
+            const uint32_t w0 = ob >> 5, sh = ob & 31u;
+            const uint32_t v0 = acc_lo << sh;
+            const uint32_t v1 = sh ? ((acc_lo >> (32u - sh)) | (acc_hi << sh)) : acc_hi;
+            const uint32_t v2 = sh ? (acc_hi >> (32u - sh)) : 0u;
+#pragma unroll
+            for (int d = 0; d < WO32; ++d) o[d] |= ((uint32_t)d == w0) ? v0 : ((uint32_t)d == w0 + 1u) ? v1 : ((uint32_t)d == w0 + 2u) ? v2 : 0u;
+          } else {
+            for (uint32_t i = 0u; i < n_out; ++i) emit(i, (((i < 32u ? acc_lo : acc_hi) >> (i & 31u)) & 1u) != 0u);
           }
         }
         continue;

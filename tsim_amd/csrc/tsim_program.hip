@@ -1274,6 +1274,11 @@ retry_pack:
                 cr[GC_WORDREC] = words_off;
                 cr[GC_L_RANK] = l_rank[ci];
                 cr[GC_OUTPOS] = outpos_new;
+                {
+                  bool affine = c.n_out > 0;
+                  for (int i = 1; i < c.n_out; ++i) affine = affine && img[outpos_off + (uint32_t)i] == img[outpos_off] + (uint32_t)i;
+                  cr[GC_OUTBASE] = affine ? img[outpos_off] : 0xFFFFFFFFu;
+                }
               }
               uint32_t *h = &img[p->gr_off];
               h[GR_NCOMP] = (uint32_t)p->comps.size();

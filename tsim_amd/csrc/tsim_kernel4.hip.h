@@ -97,7 +97,11 @@ __device__ __forceinline__ void acc_graph4(Acc4 &S, const uint32_t *gimg, GR gr,
       const tt_u32x4 v = *(const __attribute__((address_space(3))) tt_u32x4 *)(uintptr_t)(tt_bias + 4u * w);
       return make_uint4(v.x, v.y, v.z, v.w);
     } else {
-      return *reinterpret_cast<const uint4 *>(gimg + w);
+      // (a buffer descriptor over the image and a 32-bit byte offset: two instructions of address arithmetic per gather instead of
+      // seven 64-bit ones - profiles/r06/full_kernel_floor.txt; the image is below 4 GB: tsim_program_finalize refuses 2^30 words)
+      const __amdgpu_buffer_rsrc_t r_img = __builtin_amdgcn_make_buffer_rsrc((void *)gimg, 0, 0xFFFFFFFF, 0x00020000);
+      const tt_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r_img, 4u * w, 0, 0);
+      return make_uint4(v.x, v.y, v.z, v.w);
     }
   };
   auto ld1 = [&](uint32_t w) -> uint32_t {

@@ -1308,7 +1308,7 @@ retry_pack:
     img.resize(img.size() + p->comps.size() * LW_WORDS, 0u);
   }
   img.resize(img.size() + 256, 0u);  // tail padding: wide scalar loads may over-read
-  if (img.size() >= (1ull << 31)) return tsim_fail(TSIM_ENOTSUP, "program image too large");
+  if (img.size() >= (1ull << 30)) return tsim_fail(TSIM_ENOTSUP, "program image too large");  // (4 GB: the term-table gathers use 32-bit byte offsets)
 
   if (p->knobs.defer_group <= 0)  // (not told by TSIM_AMD_TUNE) launches per deferred batch: a batch lasts about as long as ONE hard-row
     p->knobs.defer_group = p->stats[5] > (4ll << 20) ? TSIMK_H_MAX_CTX : 4;  // pass; 4 for small programs, 8 beyond 4 MB of chunk tables (C4)

@@ -74,3 +74,39 @@ def test_nonsense_marginals_n24x(hip):
     """n24x: int32 coefficients wrap like the reference's (normalisation deviation ~1: the reference raises) - whatever path
     serves it, the bytes are the oracle's."""
     _check_class(hip, "n24x", B=700, n=3, packed=True)
+
+
+@pytest.mark.parametrize("comps", [[(24, 20), (24, 24)], [(26, 16), (20, 12), (28, 20)], [(13, 10)] * 6])
+def test_more_than_forty_compiled_outputs(hip, comps):
+    """48, 74 and 78 compiled outputs: the fused groups of k_sample_gen carry fewer batches (its subkey records are a pool of
+    batches x outputs); round 5's limit of 40 sent such a program to the row kernel."""
+    rng_seed = 10
+    cl = []
+    for n, F in comps:
+        G = [2]
+        for _ in range(n):
+            G.append(min(6, G[-1] + (1 if len(G) % 5 == 0 else 0)))
+        cl.append(dict(n=n, F=F, G=G, density=0.2, shared_delta=0.8))
+    nf = 96
+    prog = synth.physical_program(num_f=nf, n_direct=9, components=cl, seed=rng_seed)
+    hp = hip.HipProgram(prog)
+    B, n = 1200, 9
+    fs = [synth.synth_f(B, nf, 0.02 * (1 + i % 3), seed=500 + i) for i in range(n)]
+    _run_steps(hp, prog, fs[:3], prng.key(1), nf, packed=True)
+    import time
+    t0 = time.perf_counter()
+    while hp.info()["pattern_build_pending"] and time.perf_counter() - t0 < 20.0:
+        _run_steps(hp, prog, fs[:1], prng.key(2), nf, packed=True)
+    hp.path_counts(reset=True)
+    key = prng.key(77)
+    devs = []
+    outs, _ = _run_steps(hp, prog, fs, key, nf, packed=True, devs=devs)
+    paths = hp.path_counts()
+    assert paths.get("gen", 0) >= 1, paths
+    _, subs = _subkeys(key, n)
+    op = OC.OracleProgram(prog)
+    for i in range(n):
+        want, wdev = op.sample_program(fs[i], subs[i], return_devs=True)
+        np.testing.assert_array_equal(outs[i], np.packbits(want, axis=1, bitorder="little"), err_msg=f"batch {i} ({paths})")
+        np.testing.assert_array_equal(devs[i][: len(prog.components)], np.asarray(wdev, np.float32))
+    hp.close()

@@ -30,7 +30,9 @@ namespace tsimk {
 #ifndef TSIMK_GEN_MAX_STEPS
 #define TSIMK_GEN_MAX_STEPS 8  // (also in tsim_sample_internal.hip.h: the steps driver sizes its groups by it)
 #endif
-#define TSIMK_GEN_KEYS 40
+#ifndef TSIMK_GEN_KEYS
+#define TSIMK_GEN_KEYS 320     // subkey records of ONE launch: batches x compiled outputs (a group of 8 batches: 40 outputs; 64 outputs: 5 batches; 320: one)
+#endif
 #define TSIMK_GEN_MAX_RUNS 1024
 #define TSIMK_GEN_MAX_COMP 32
 
@@ -63,7 +65,6 @@ struct GenStep {
   uint32_t *hard_index;   // this batch's hard-row lists
   uint32_t *ctl;          // its counters: ctl[32 k] = entries of list k, ctl[32 LISTS] = check row
   uint32_t *ctl_next;     // the counter set of the slot's NEXT launch: reset here
-  uint32_t keys[2 * TSIMK_GEN_KEYS];  // per-output subkeys of this batch (sampler.py:74,147-148), host-computed
 };
 
 struct GenArgs {
@@ -78,7 +79,10 @@ struct GenArgs {
   int nbuf;                 // row buffers per wave: 2 = the next chunk travels while this one is worked on
   int l_wave, wave_bytes;   // LDS byte offset of wave 0's buffers, bytes per wave
   GenStep step[TSIMK_GEN_MAX_STEPS];
+  int total_keys;           // compiled outputs of the program: batch st's subkeys (sampler.py:74,147-148, host-computed) are keys[2 st total_keys ..]
+  uint32_t keys[2 * TSIMK_GEN_KEYS];
 };
+static_assert(sizeof(GenArgs) <= 4096, "kernel arguments");
 
 #ifndef TSIMK_GEN_UNIFORM_WALK
 #define TSIMK_GEN_UNIFORM_WALK 1
@@ -195,7 +199,7 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(TSIMK_GEN
       S->ctl[32 * TSIMK_LW_LISTS] = row;
     }
     const uint32_t slo = so_lo + row;  // (the launcher keeps shot_offset + B below the next multiple of 2^32)
-    cptr kp = (cptr)((cbytes)S + __builtin_offsetof(GenStep, keys));
+    cptr kp = (cptr)((cbytes)__builtin_amdgcn_kernarg_segment_ptr() + __builtin_offsetof(GenArgs, keys)) + 2u * st * (uint32_t)A.total_keys;
     // ---- the components, in processing order (sampler.py:147-148); everything wave-uniform by scalar loads from the image
     for (uint32_t ci = 0; ci < n_comp; ++ci) {
       const u32x8 cr = *(cptr8)(g_comp + ci * GC_WORDS);

@@ -1447,7 +1447,8 @@ extern "C" int tsim_sample_steps_device(tsim_program *p, int32_t n_steps, const 
     if (fused) {
       // even groups of at most TSIMK_LWM_MAX_STEPS batches
       const int left = n_steps - done;
-      const int gmax = std::min(gen_fused ? TSIMK_GEN_MAX_STEPS : TSIMK_LWM_MAX_STEPS, p->knobs.fused_max);
+      // (k_sample_gen carries batches x compiled outputs subkey records per launch: 8 batches up to 40 outputs, fewer beyond)
+      const int gmax = std::min(gen_fused ? std::min(TSIMK_GEN_MAX_STEPS, std::max(1, TSIMK_GEN_KEYS / std::max(1, p->total_keys))) : TSIMK_LWM_MAX_STEPS, p->knobs.fused_max);
       // (20 batches as 7+7+6; 5+5+5+5 - both lanes ending together - measured slower: a launch more)
       const int groups = (left + gmax - 1) / gmax;
       const int n = (left + groups - 1) / groups;

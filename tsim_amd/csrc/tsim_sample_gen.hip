@@ -77,7 +77,9 @@ int steps_group_gen(tsim_program *p, int n, const uint64_t *const *d_f, int64_t 
   G.tab = p->d_lw_tab;
   G.B = B;
   G.shot_offset = shot_offset;
+  if ((long long)n * p->total_keys > TSIMK_GEN_KEYS) return tsim_fail(TSIM_ESTATE, "k_sample_gen: %d batches of %d compiled outputs in one launch", n, p->total_keys);
   G.n_steps = n;
+  G.total_keys = p->total_keys;
   G.chunks_per_step = (int)((B + 63) / 64);
   G.has_check = has_check ? 1 : 0;
   G.out_rb = (p->num_outputs + 7) / 8;
@@ -121,16 +123,17 @@ int steps_group_gen(tsim_program *p, int n, const uint64_t *const *d_f, int64_t 
     st.ctl = ctl;
     st.ctl_next = sl.ctl + (sl.parity ^ 1) * (TSIMK_LW_LISTS + 1) * 32;
     sl.parity ^= 1;
+    uint32_t *stkeys = G.keys + 2 * (size_t)j * (size_t)p->total_keys;
     if (p->total_keys <= TSIMK_INLINE_KEYS) {
-      memcpy(st.keys, a.inline_keys, sizeof(uint32_t) * 2 * (size_t)p->total_keys);
+      memcpy(stkeys, a.inline_keys, sizeof(uint32_t) * 2 * (size_t)p->total_keys);
     } else {  // (the hard-row kernels read the k_keygen buffer; this pass wants the subkeys in its arguments)
       uint32_t k0 = o[2], k1 = o[3];
       for (int i = 0; i < p->total_keys; ++i) {
         uint32_t a0 = 0u, a1 = 0u, b0 = 0u, b1 = 1u;
         threefry2x32(k0, k1, a0, a1);
         threefry2x32(k0, k1, b0, b1);
-        st.keys[2 * i] = b0;
-        st.keys[2 * i + 1] = b1;
+        stkeys[2 * i] = b0;
+        stkeys[2 * i + 1] = b1;
         k0 = a0;
         k1 = a1;
       }

@@ -87,6 +87,9 @@ int steps_group_wide(tsim_program *p, int n, const uint64_t *const *d_f, int64_t
 #ifndef TSIMK_GEN_MAX_STEPS
 #define TSIMK_GEN_MAX_STEPS 8  // batches per fused group of k_sample_gen (tsim_gen.hip.h)
 #endif
+#ifndef TSIMK_GEN_KEYS
+#define TSIMK_GEN_KEYS 320     // subkey records per launch of k_sample_gen: batches x compiled outputs (tsim_gen.hip.h)
+#endif
 bool gen_applies(const tsim_program *p, int64_t B, int32_t num_f, int64_t shot_offset);
 int steps_group_gen(tsim_program *p, int n, const uint64_t *const *d_f, int64_t B, int32_t num_f, uint32_t key[2],
                     int64_t shot_offset, void *const *d_out, float *const *d_dev, uint32_t flags, const LaunchPlan &plan);

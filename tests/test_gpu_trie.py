@@ -110,3 +110,51 @@ def test_more_than_forty_compiled_outputs(hip, comps):
         np.testing.assert_array_equal(outs[i], np.packbits(want, axis=1, bitorder="little"), err_msg=f"batch {i} ({paths})")
         np.testing.assert_array_equal(devs[i][: len(prog.components)], np.asarray(wdev, np.float32))
     hp.close()
+
+
+@pytest.mark.parametrize("name", ["n13", "n16", "n24", "n40", "F70"])
+@pytest.mark.parametrize("B,shot_offset", [(1, 0), (777, 0), (5000, 0), (3001, 1 << 16)])
+def test_one_batch_api_rides_the_general_first_pass(hip, name, B, shot_offset):
+    """``tsim_sample_batch`` (the seam of ``backend.sample_program``) on programs whose tables only k_sample_gen reads: the batch
+    is a group of one (gen_one in csrc/tsim_sample_gen.hip) instead of every row on the full kernel - same bytes as the oracle,
+    padded and bit_packed, with and without the normalisation-check row."""
+    prog, c = synth.shape_class_program(name)
+    nf = c["num_f"]
+    hp = hip.HipProgram(prog)
+    op = OC.OracleProgram(prog)
+    hp.path_counts(reset=True)
+    for i, packed in enumerate([False, True, False]):
+        f = synth.synth_f(B, nf, c["p_bit"] * (1 + i), seed=300 + i)
+        key = prng.key(50 + i)
+        got, gdev = hp.sample_batch(f, key, shot_offset=shot_offset, bit_packed=packed)
+        want, wdev = op.sample_program(f, key, return_devs=True, shot_offset=shot_offset)
+        if packed:
+            want = np.packbits(want, axis=1, bitorder="little")
+            got = got[:, : want.shape[1]]
+        np.testing.assert_array_equal(np.asarray(got, np.uint8), np.asarray(want, np.uint8), err_msg=f"{name} call {i}")
+        if shot_offset == 0:
+            np.testing.assert_array_equal(gdev[: len(prog.components)], np.asarray(wdev, np.float32))
+    paths = hp.path_counts()
+    hp.close()
+    assert paths.get("gen", 0) >= 1, paths
+
+
+@pytest.mark.parametrize("name", ["n16", "n40"])
+def test_one_batch_api_general_pass_off_equals_on(hip, name):
+    prog, c = synth.shape_class_program(name)
+    nf, B = c["num_f"], 30_000
+    f = synth.synth_f(B, nf, 0.03, seed=5)
+    res = []
+    for tune in ("gen=0", "gen=1"):
+        def run():
+            hp = hip.HipProgram(synth.shape_class_program(name)[0])
+            hp.sample_batch(f[:1000], prng.key(1))
+            hp.path_counts(reset=True)
+            out, dev = hp.sample_batch(f, prng.key(9))
+            pc = hp.path_counts()
+            hp.close()
+            return out, dev, pc
+        res.append(_with_env({"TSIM_AMD_TUNE": tune}, run))
+    assert "gen" not in res[0][2] and res[1][2].get("gen", 0) >= 1, (res[0][2], res[1][2])
+    np.testing.assert_array_equal(res[0][0], res[1][0])
+    np.testing.assert_array_equal(res[0][1], res[1][1])

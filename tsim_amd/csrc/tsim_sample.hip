@@ -631,7 +631,10 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
   // a narrow program with more than 64 selected bits in a component: the one-batch first passes (k_sample_lw / _lw_reg / _lw_fast as a
   // group of one) hold f_sel in 64 bits - every row on the chunk-table kernel here; the fused groups ride k_sample_gen
   // ... and prefix-tree tables (components of more than 12 outputs, tsim_trie.hip.h) are walked by k_sample_gen only
-  if (p->narrow_big || p->lw_trie) use_tables = false;
+  // - unless k_sample_gen takes the batch as a group of one (gen_one)
+  const bool gen1 = (p->narrow_big || p->lw_trie) && use_tables && !d_row_index && gen_applies(p, B, num_f, shot_offset) &&
+                    p->total_keys <= TSIMK_GEN_KEYS;
+  if ((p->narrow_big || p->lw_trie) && !gen1) use_tables = false;
   if (int r = tsim_tables_slice(p, s)) return r;  // (a table build in the background: its next slice goes first)
   // The sparse-column pass (k_sample4w) over every row, or - behind a pattern-table first pass - over that pass's
   // hard-row lists (from_lists; `a` then describes them).  Its own overflow (more than K set bits, the check row)
@@ -756,7 +759,12 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
     const bool fast1 = reg_form && p->lwf_off != 0 && p->knobs.lw_fast && blk1 == 1024 && a.n_inline_keys > 0 && p->total_keys <= TSIMK_LWM_KEYS &&
                        B < (1ll << 28) && p->lw_bytes < (1ll << 32) && (n_lists & (n_lists - 1)) == 0 && a.WO == 1 &&
                        ((unsigned long long)shot_offset >> 32) == ((unsigned long long)(shot_offset + B - 1) >> 32);
-    if (fast1) {
+    if (gen1) {
+      long long cap1 = 0;
+      if (int r = gen_one(p, a, B, num_f, key_hi, key_lo, shot_offset, l.hard_index, l.ctl, l.ctl_next, n_lists, has_check, &cap1, s)) return r;
+      if ((size_t)cap1 * n_lists * 4 > sl.hard_sz) return tsim_fail(TSIM_ESTATE, "hard-row list too small");
+      l.list_cap = (int)cap1;
+    } else if (fast1) {
       const long long cap1 = (blocks + n_lists - 1) / n_lists * blk1;  // the fused kernels' list geometry: row block rb -> list rb % n_lists
       if ((size_t)cap1 * n_lists * 4 > sl.hard_sz) return tsim_fail(TSIM_ESTATE, "hard-row list too small");
       LwMultiArgs M{};
@@ -942,7 +950,8 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
   // 65 parameters (class F60, profiles/r05/shape_map.txt) - the block-per-row kernel takes ~25.  (Programs of a few graphs - the C5 family - are
   // quicker on the one lane: 2wide 111 -> 127 us per step with the block-per-row kernel, measured.)
   // (no feedback from this grid: the plan's counts are the sparse-column pass's - the rows that miss the tables - not its overflow)
-  if (a.row_lists > 1 && !p->v4 && use_tables && p->fast && p->knobs.hard_wave && wmax <= 8 && p->total_graphs >= 64 && a.WF <= 32 && a.WO <= 2 && p->hw_max_rows < 60000) {
+  if (a.row_lists > 1 && !p->v4 && use_tables &&
+      ((gen1 && p->lw_trie) || (p->fast && p->knobs.hard_wave && wmax <= 8 && p->total_graphs >= 64 && a.WF <= 32 && a.WO <= 2 && p->hw_max_rows < 60000))) {  // (gen1: as flush_batch does)
     if (int r = launch_hw(p, &a, 1, a.row_lists, s, false, false)) return r;
     if (prof && !(p->prof_light && use_tables)) { int r = prof_event(p, s, PROF_FULL); if (r) return r; }
     return finish();

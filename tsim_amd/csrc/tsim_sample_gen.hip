@@ -52,6 +52,94 @@ bool gen_applies(const tsim_program *p, int64_t B, int32_t num_f, int64_t shot_o
   return gen_layout(p, WF32, 1).block != 0;
 }
 
+static int gen_launch(tsim_program *p, const GenArgs &G, const GenLayout &L, long long grid, hipStream_t s) {
+  const int wo32 = (int)p->img[p->gr_off + GR_WO32];
+#define TSIM_LGEN(N)                                                                                                    \
+  case N: {                                                                                                             \
+    auto kfn = k_sample_gen<N>;                                                                                         \
+    if (!(p->gen_attr_set & (1u << N))) {                                                                               \
+      HIP_TRY(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));           \
+      p->gen_attr_set |= 1u << N;                                                                                       \
+    }                                                                                                                   \
+    hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(L.block), L.lds, s, G);                                          \
+  } break;
+  switch (wo32) {
+    TSIM_LGEN(2) TSIM_LGEN(4) TSIM_LGEN(6) TSIM_LGEN(8) TSIM_LGEN(10) TSIM_LGEN(12) TSIM_LGEN(14) TSIM_LGEN(16)
+    default: return tsim_fail(TSIM_ESTATE, "gen record with %d output words", wo32);
+  }
+#undef TSIM_LGEN
+  return 0;
+}
+// the subkeys of one batch as k_sample_gen wants them: the inline copy, or the chain of splits (sampler.py:399's key schedule)
+static void gen_step_keys(const tsim_program *p, const SampleArgs &a, uint32_t k0, uint32_t k1, uint32_t *stkeys) {
+  if (p->total_keys <= TSIMK_INLINE_KEYS) {
+    memcpy(stkeys, a.inline_keys, sizeof(uint32_t) * 2 * (size_t)p->total_keys);
+    return;
+  }
+  for (int i = 0; i < p->total_keys; ++i) {  // (the hard-row kernels read the k_keygen buffer; this pass wants the subkeys in its arguments)
+    uint32_t a0 = 0u, a1 = 0u, b0 = 0u, b1 = 1u;
+    threefry2x32(k0, k1, a0, a1);
+    threefry2x32(k0, k1, b0, b1);
+    stkeys[2 * i] = b0;
+    stkeys[2 * i + 1] = b1;
+    k0 = a0;
+    k1 = a1;
+  }
+}
+static void gen_common_args(const tsim_program *p, GenArgs &G, const GenLayout &L, int64_t B, int64_t shot_offset, int n, int WF, bool has_check,
+                            long long list_cap, int n_lists) {
+  G.img = p->d_img;
+  G.tab = p->d_lw_tab;
+  G.B = B;
+  G.shot_offset = shot_offset;
+  G.n_steps = n;
+  G.total_keys = p->total_keys;
+  G.chunks_per_step = (int)((B + 63) / 64);
+  G.has_check = has_check ? 1 : 0;
+  G.out_rb = (p->num_outputs + 7) / 8;
+  G.WF32 = 2 * WF;
+  G.lw_off = p->lw_off;
+  G.gr_off = p->gr_off;
+  G.list_cap = (int)list_cap;
+  G.n_lists = n_lists;
+  G.nbuf = L.nbuf;
+  G.l_wave = L.l_wave;
+  G.wave_bytes = L.wave_bytes;
+}
+static long long gen_grid(const tsim_program *p, const GenLayout &L, long long chunks) {
+  const int wpb = L.block / 64;
+  const int per_cu = std::max(1, std::min(2048 / L.block, (int)((160 * 1024) / (L.lds + 64))));
+  return std::max(1ll, std::min((long long)p->n_cu * per_cu, (chunks + wpb - 1) / wpb));
+}
+// The serial API (tsim_sample_batch*, the seam of backend.sample_program) on a program whose tables only k_sample_gen reads
+// (prefix trees, narrow_big): the same first pass as a group of ONE batch on the caller's stream, with the subkey as given.
+// launch_sample goes on with the hard-row lists this leaves (list geometry as in steps_group_gen).
+int gen_one(tsim_program *p, const SampleArgs &a, int64_t B, int32_t num_f, uint32_t key_hi, uint32_t key_lo, int64_t shot_offset,
+            uint32_t *hard_index, uint32_t *ctl, uint32_t *ctl_next, int n_lists, bool has_check, long long *list_cap_out, hipStream_t s) {
+  const int WF = std::max(1, (num_f + 63) / 64);
+  const GenLayout L = gen_layout(p, 2 * WF, 1);
+  if (!L.block) return tsim_fail(TSIM_ESTATE, "k_sample_gen does not fit");
+  if (p->total_keys > TSIMK_GEN_KEYS) return tsim_fail(TSIM_ESTATE, "k_sample_gen: %d compiled outputs", p->total_keys);
+  const long long bps = (B + 1023) / 1024;
+  const long long list_cap = (bps + n_lists - 1) / n_lists * 1024;
+  if (list_cap > 0x7FFFFFFFll) return tsim_fail(TSIM_ENOTSUP, "batch too large for the row lists");
+  GenArgs G{};
+  gen_common_args(p, G, L, B, shot_offset, 1, WF, has_check, list_cap, n_lists);
+  GenStep &st = G.step[0];
+  st.f = a.f;
+  st.out = a.out;
+  st.out_compact = a.out_compact;
+  st.hard_index = hard_index;
+  st.ctl = ctl;
+  st.ctl_next = ctl_next;
+  gen_step_keys(p, a, key_hi, key_lo, G.keys);
+  ++p->path_count[TP_GEN];
+  if (int r = gen_launch(p, G, L, gen_grid(p, L, G.chunks_per_step), s)) return r;
+  HIP_TRY(hipGetLastError());
+  *list_cap_out = list_cap;
+  return 0;
+}
+
 int steps_group_gen(tsim_program *p, int n, const uint64_t *const *d_f, int64_t B, int32_t num_f, uint32_t key[2],
                            int64_t shot_offset, void *const *d_out, float *const *d_dev, uint32_t flags, const LaunchPlan &plan) {
   const bool packed = (flags & TSIM_PIPE_OUT_BIT_PACKED) != 0;
@@ -73,24 +161,8 @@ int steps_group_gen(tsim_program *p, int n, const uint64_t *const *d_f, int64_t 
   if (list_cap > 0x7FFFFFFFll) return tsim_fail(TSIM_ENOTSUP, "batch too large for the row lists");
   const bool has_check = shot_offset == 0;
   GenArgs G{};
-  G.img = p->d_img;
-  G.tab = p->d_lw_tab;
-  G.B = B;
-  G.shot_offset = shot_offset;
   if ((long long)n * p->total_keys > TSIMK_GEN_KEYS) return tsim_fail(TSIM_ESTATE, "k_sample_gen: %d batches of %d compiled outputs in one launch", n, p->total_keys);
-  G.n_steps = n;
-  G.total_keys = p->total_keys;
-  G.chunks_per_step = (int)((B + 63) / 64);
-  G.has_check = has_check ? 1 : 0;
-  G.out_rb = (p->num_outputs + 7) / 8;
-  G.WF32 = 2 * WF;
-  G.lw_off = p->lw_off;
-  G.gr_off = p->gr_off;
-  G.list_cap = (int)list_cap;
-  G.n_lists = n_lists;
-  G.nbuf = L.nbuf;
-  G.l_wave = L.l_wave;
-  G.wave_bytes = L.wave_bytes;
+  gen_common_args(p, G, L, B, shot_offset, n, WF, has_check, list_cap, n_lists);
   p->last_lists = n_lists;
   int slots[TSIMK_GEN_MAX_STEPS];
   for (int j = 0; j < n; ++j)
@@ -123,21 +195,7 @@ int steps_group_gen(tsim_program *p, int n, const uint64_t *const *d_f, int64_t 
     st.ctl = ctl;
     st.ctl_next = sl.ctl + (sl.parity ^ 1) * (TSIMK_LW_LISTS + 1) * 32;
     sl.parity ^= 1;
-    uint32_t *stkeys = G.keys + 2 * (size_t)j * (size_t)p->total_keys;
-    if (p->total_keys <= TSIMK_INLINE_KEYS) {
-      memcpy(stkeys, a.inline_keys, sizeof(uint32_t) * 2 * (size_t)p->total_keys);
-    } else {  // (the hard-row kernels read the k_keygen buffer; this pass wants the subkeys in its arguments)
-      uint32_t k0 = o[2], k1 = o[3];
-      for (int i = 0; i < p->total_keys; ++i) {
-        uint32_t a0 = 0u, a1 = 0u, b0 = 0u, b1 = 1u;
-        threefry2x32(k0, k1, a0, a1);
-        threefry2x32(k0, k1, b0, b1);
-        stkeys[2 * i] = b0;
-        stkeys[2 * i + 1] = b1;
-        k0 = a0;
-        k1 = a1;
-      }
-    }
+    gen_step_keys(p, a, o[2], o[3], G.keys + 2 * (size_t)j * (size_t)p->total_keys);
     a.row_index = st.hard_index;
     a.row_count = ctl;
     a.row_lists = n_lists;
@@ -148,29 +206,13 @@ int steps_group_gen(tsim_program *p, int n, const uint64_t *const *d_f, int64_t 
     a.row_slot_end = 0;
   }
   const long long chunks = (long long)G.chunks_per_step * n;
-  const int wpb = L.block / 64;
-  const int per_cu = std::max(1, std::min(2048 / L.block, (int)((160 * 1024) / (L.lds + 64))));
-  const long long grid = std::max(1ll, std::min((long long)p->n_cu * per_cu, (chunks + wpb - 1) / wpb));
+  const long long grid = gen_grid(p, L, chunks);
   TSIM_MARK("args");
   if (int r = tsim_tables_slice(p, s)) return r;  // (a table build in the background: its next slice goes first)
   const bool prof = p->profiling && (p->prof_counter++ % p->prof_every == 0);
   if (prof) { if (int r = prof_event(p, s, PROF_BEGIN)) return r; }
-  const int wo32 = (int)p->img[p->gr_off + GR_WO32];
   ++p->path_count[TP_GEN];
-#define TSIM_LGEN(N)                                                                                                    \
-  case N: {                                                                                                             \
-    auto kfn = k_sample_gen<N>;                                                                                         \
-    if (!(p->gen_attr_set & (1u << N))) {                                                                               \
-      HIP_TRY(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));           \
-      p->gen_attr_set |= 1u << N;                                                                                       \
-    }                                                                                                                   \
-    hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(L.block), L.lds, s, G);                                          \
-  } break;
-  switch (wo32) {
-    TSIM_LGEN(2) TSIM_LGEN(4) TSIM_LGEN(6) TSIM_LGEN(8) TSIM_LGEN(10) TSIM_LGEN(12) TSIM_LGEN(14) TSIM_LGEN(16)
-    default: return tsim_fail(TSIM_ESTATE, "gen record with %d output words", wo32);
-  }
-#undef TSIM_LGEN
+  if (int r = gen_launch(p, G, L, grid, s)) return r;
   HIP_TRY(hipGetLastError());
   TSIM_MARK("launch");
   if (prof) {

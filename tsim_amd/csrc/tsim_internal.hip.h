@@ -235,6 +235,7 @@ struct tsim_program {
   std::atomic<bool> slots_ready{false};  // (read by the table-build helper thread: it takes its stream once the lanes exist)
   std::vector<int> deferred;  // slots whose hard rows are waiting, in launch order
   hipEvent_t lane_ev[2] = {nullptr, nullptr};  // "first passes enqueued so far on lane k are done"
+  hipEvent_t over_ev[2] = {nullptr, nullptr};  // long hard-row lists: the per-shot workers run on a lane of their own beside the latency kernel (flush_batch)
   hipEvent_t batch_ev[16] = {};
   int batch_ev_lane[16] = {};                  // ... and the stream (batch_lane) it was recorded on
   hipStream_t flush_inline = nullptr;          // set by a caller of tsim_flush_hard: run this batch on that first-pass lane itself

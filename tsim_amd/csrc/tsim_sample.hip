@@ -272,7 +272,7 @@ static bool hw_eligible(tsim_program *p, const SampleArgs &a, int n_ctx) {
 // Behind the latency kernels of a hard-row batch: the list slots they left (k_sample4_over, tsim_kernel4.hip.h).  A fixed
 // grid of chip-resident blocks; when every list ends before `slot_begin` - all launches but the first after a jump of
 // the noise level - they read the counts and exit (~3 us on the batch's stream).
-static int launch_over(tsim_program *p, const SampleArgs *ctx, int n_ctx, uint32_t slot_begin, bool masked, hipStream_t hs) {
+static int launch_over(tsim_program *p, const SampleArgs *ctx, int n_ctx, uint32_t slot_begin, bool masked, hipStream_t hs, bool fill_chip = false) {
   Over4Multi M{};
   M.n_ctx = n_ctx;
   M.comp4_off = p->comp4_off;
@@ -290,7 +290,8 @@ static int launch_over(tsim_program *p, const SampleArgs *ctx, int n_ctx, uint32
   const size_t tile_bytes = std::max((size_t)p->v4_max_nch * 16, (size_t)p->v4_max_sent) * p->v4_gt * 16;
   const size_t lds4 = (size_t)(2 * ctx[0].WF + 2 * ctx[0].WO) * blk * 4 + 2 * tile_bytes;
   if (lds4 > (p->v4_max_nch == 32 ? 160 : 64) * 1024) return tsim_fail(TSIM_ENOTSUP, "v4 kernel needs %zu B of LDS", lds4);
-  const unsigned grid = (unsigned)p->n_cu;
+  // fill_chip: the lists are known to be long (throughput work) - as many blocks as the chip holds at once
+  const unsigned grid = (unsigned)p->n_cu * (fill_chip ? (unsigned)std::max<size_t>(1, std::min<size_t>(2048 / blk, (160 * 1024) / (lds4 + 256))) : 1u);
   ++p->path_count[TP_OVER];
   switch (p->v4_max_nch) {
 #define TSIM_LO(N) case N: hipLaunchKernelGGL((k_sample4_over<4, N>), dim3(grid), dim3(blk), lds4, hs, M); break;
@@ -446,10 +447,18 @@ int flush_batch(tsim_program *p) {
   M.main_blocks = grid;
   M.over_from = cap4h;
   size_t lds_m = p->h_lds;
-  if (cap4h) {  // the workers ride in the same grid (a kernel of their own behind this one cost C3 4 %)
+  // many: the workers are a grid of their own behind this one - inside it they would run with ITS dynamic LDS (up to 128 KB of
+  // resident tiles: one block of eight waves per CU)
+  const bool over_apart = many && cap4h != 0;
+  if (cap4h && !over_apart) {  // the workers ride in the same grid (a kernel of their own behind this one cost C3 4 %)
     const size_t tile_bytes = std::max((size_t)p->v4_max_nch * 16, (size_t)p->v4_max_sent) * p->v4_gt * 16;
     lds_m = std::max(lds_m, (size_t)(2 * M.ctx[0].WF + 2 * M.ctx[0].WO) * (NW * 64) * 4 + 2 * tile_bytes);
     grid += (unsigned)p->n_cu * (many ? 2u : 1u);
+  }
+  if (over_apart) {
+    for (hipEvent_t &e : p->over_ev)
+      if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(p->over_ev[0], hs));
   }
   switch (p->v4_max_nch) {
 #define TSIM_LHM(N)                                                                                          \
@@ -466,6 +475,15 @@ int flush_batch(tsim_program *p) {
   }
   HIP_TRY(hipGetLastError());
   p->hm_attr_set = true;
+  if (over_apart) {
+    // ... and on a lane of its own: the latency kernel above is ONE pass's latency on a few CUs, the workers are throughput work
+    // that need not wait for it (n16: 363 + 707 us per group one behind the other; 10^6 shots: n13 77 -> 66 us, n16 152 -> 124)
+    hipStream_t os = p->slots[4].side != hs ? p->slots[4].side : p->slots[3].side;
+    HIP_TRY(hipStreamWaitEvent(os, p->over_ev[0], 0));  // (recorded on hs in front of the latency kernel: behind the group's first passes)
+    if (int r = launch_over(p, M.ctx, M.n_ctx, cap4h, false, os, true)) return r;
+    HIP_TRY(hipEventRecord(p->over_ev[1], os));
+    HIP_TRY(hipStreamWaitEvent(hs, p->over_ev[1], 0));
+  }
   }
   ++p->stat_flushes;
   hipEvent_t &be = p->batch_ev[seq % 16u];

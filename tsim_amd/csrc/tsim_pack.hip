@@ -12,16 +12,29 @@ using namespace tsimk;
 namespace tsimhost {
 
 // pack one byte-per-bit row into W 32-bit words appended to `dst`; returns true if any bit set
+// eight 0/1 bytes -> eight bits (byte k -> bit k); reference bit-matrices hold 0/1 (compile.py:40-238)
+static inline uint32_t bits_of_8_bytes(const uint8_t *b) {
+  uint64_t x;
+  memcpy(&x, b, 8);
+  return (uint32_t)(((x & 0x0101010101010101ull) * 0x0102040810204080ull) >> 56);
+}
 static bool pack_row(std::vector<uint32_t> &dst, const uint8_t *bits, int P, int W) {
-  bool any = false;
-  size_t base = dst.size();
+  uint32_t any = 0;
+  const size_t base = dst.size();
   dst.resize(base + W, 0u);
-  for (int i = 0; i < P; ++i)
-    if (bits[i] & 1) {  // reference bit-matrices hold 0/1 (compile.py:40-238)
-      dst[base + (i >> 5)] |= 1u << (i & 31);
-      any = true;
+  uint32_t *o = &dst[base];
+  int i = 0;
+  for (; i + 8 <= P; i += 8) {
+    const uint32_t b = bits_of_8_bytes(bits + i);
+    o[i >> 5] |= b << (i & 31);
+    any |= b;
+  }
+  for (; i < P; ++i)
+    if (bits[i] & 1) {
+      o[i >> 5] |= 1u << (i & 31);
+      any = 1;
     }
-  return any;
+  return any != 0;
 }
 
 static const int8_t kUnit[8][4] = {{1, 0, 0, 0}, {0, 1, 0, 0},  {0, 0, 1, 0},  {0, 0, 0, -1},
@@ -131,20 +144,37 @@ static void unit_plus_one(int k, long long out[4]) {  // 1 + w^k
 }
 
 // ---- GF(2) algebra used by the fast packer -------------------------------------------------
-// An affine form c ^ <m, x> over the level's P parameters.
+// An affine form c ^ <m, x> over the level's P parameters: `m` points at PW = (P + 63) / 64 + 1 words (a graph's forms live
+// in one arena - a vector per form was a third of the time a graph took to pack).
 struct Affine {
-  std::vector<uint64_t> m;
+  const uint64_t *m = nullptr;
   bool c = false;
 };
+struct MaskArena {
+  std::vector<uint64_t> buf;
+  size_t used = 0;
+  int PW;
+  MaskArena(int P, size_t forms) : buf(forms * (size_t)((P + 63) / 64 + 1), 0ull), PW((P + 63) / 64 + 1) {}
+  uint64_t *take() {
+    if (used + (size_t)PW > buf.size()) return nullptr;
+    uint64_t *r = &buf[used];
+    used += (size_t)PW;
+    return r;
+  }
+};
 
-static Affine affine_from(const uint8_t *bits, int P, bool c) {
+static Affine affine_from(MaskArena &ar, const uint8_t *bits, int P, bool c) {
   Affine a;
-  a.m.assign((size_t)(P + 63) / 64 + 1, 0ull);
-  for (int i = 0; i < P; ++i)
-    if (bits[i] & 1) a.m[i >> 6] ^= 1ull << (i & 63);
+  uint64_t *m = ar.take();
+  int i = 0;
+  for (; i + 8 <= P; i += 8) m[i >> 6] |= (uint64_t)bits_of_8_bytes(bits + i) << (i & 63);
+  for (; i < P; ++i)
+    if (bits[i] & 1) m[i >> 6] |= 1ull << (i & 63);
+  a.m = m;
   a.c = c;
   return a;
 }
+static std::vector<uint64_t> mask_vec(const Affine &a, int PW) { return std::vector<uint64_t>(a.m, a.m + PW); }
 
 // A quadratic form over GF(2): q(x) = sum_{i<j} B[i][j] x_i x_j  ^  <lin, x>  ^  c.
 // B is kept symmetric with zero diagonal (x_i^2 = x_i goes to `lin`).
@@ -156,20 +186,22 @@ struct QForm {
   explicit QForm(int p) : P(p), PW((p + 63) / 64 + 1), B((size_t)p * ((p + 63) / 64 + 1), 0ull), lin((p + 63) / 64 + 1, 0ull) {}
   uint64_t *row(int i) { return &B[(size_t)i * PW]; }
   void add_linear(const Affine &a) {
-    for (int w = 0; w < PW && w < (int)a.m.size(); ++w) lin[w] ^= a.m[w];
+    for (int w = 0; w < PW; ++w) lin[w] ^= a.m[w];
     c ^= a.c;
   }
   // q ^= (a.c ^ <a.m,x>) * (b.c ^ <b.m,x>)
   void add_product(const Affine &a, const Affine &b) {
-    for (int i = 0; i < P; ++i) {
-      if (!((a.m[i >> 6] >> (i & 63)) & 1)) continue;
-      uint64_t *ri = row(i);
-      for (int w = 0; w < PW && w < (int)b.m.size(); ++w) ri[w] ^= b.m[w];  // row i ^= b (may set the diagonal)
-    }
+    for (int wa = 0; wa < PW; ++wa)
+      for (uint64_t rest = a.m[wa]; rest; rest &= rest - 1) {
+        const int i = 64 * wa + __builtin_ctzll(rest);
+        if (i >= P) break;
+        uint64_t *ri = row(i);
+        for (int w = 0; w < PW; ++w) ri[w] ^= b.m[w];  // row i ^= b (may set the diagonal)
+      }
     // symmetrise: the loop above added the ordered pairs (i in a, j in b); fold (i,j) and (j,i) together
     // by rebuilding the symmetric part lazily in `finish()`.
-    if (a.c) for (int w = 0; w < PW && w < (int)b.m.size(); ++w) lin[w] ^= b.m[w];
-    if (b.c) for (int w = 0; w < PW && w < (int)a.m.size(); ++w) lin[w] ^= a.m[w];
+    if (a.c) for (int w = 0; w < PW; ++w) lin[w] ^= b.m[w];
+    if (b.c) for (int w = 0; w < PW; ++w) lin[w] ^= a.m[w];
     c ^= (a.c && b.c);
   }
   // After all add_product calls B holds an arbitrary (non-symmetric) bilinear matrix M with
@@ -180,15 +212,27 @@ struct QForm {
         lin[i >> 6] ^= 1ull << (i & 63);
         row(i)[i >> 6] ^= 1ull << (i & 63);
       }
+    // B' = M ^ M^T: every set bit (i, j) of M toggles (j, i) of a copy
+    std::vector<uint64_t> S(B);
     for (int i = 0; i < P; ++i)
-      for (int j = i + 1; j < P; ++j) {
-        const bool mij = (row(i)[j >> 6] >> (j & 63)) & 1, mji = (row(j)[i >> 6] >> (i & 63)) & 1;
-        const bool s = mij ^ mji;
-        if (mij != s) row(i)[j >> 6] ^= 1ull << (j & 63);
-        if (mji != s) row(j)[i >> 6] ^= 1ull << (i & 63);
-      }
+      for (int w = 0; w < PW; ++w)
+        for (uint64_t rest = B[(size_t)i * PW + w]; rest; rest &= rest - 1) {
+          const int j = 64 * w + __builtin_ctzll(rest);
+          if (j < P) S[(size_t)j * PW + (i >> 6)] ^= 1ull << (i & 63);
+        }
+    B.swap(S);
   }
   bool get(int i, int j) { return (row(i)[j >> 6] >> (j & 63)) & 1; }
+  // the first set column of row i, -1 if the row is empty
+  int first(int i) {
+    const uint64_t *r = row(i);
+    for (int w = 0; w < PW; ++w)
+      if (r[w]) {
+        const int j = 64 * w + __builtin_ctzll(r[w]);
+        return j < P ? j : -1;
+      }
+    return -1;
+  }
 };
 
 // Dickson reduction: q = XOR_s <u_s,x><v_s,x> ^ <lin,x> ^ c with rank(B)/2 product pairs.
@@ -196,48 +240,59 @@ struct QForm {
 //   x_i x_j ^ x_i<alpha,x> ^ x_j<beta,x> = (x_i ^ <beta,x>)(x_j ^ <alpha,x>) ^ <alpha,x><beta,x>.
 static void dickson_reduce(QForm &q, std::vector<std::vector<uint64_t>> &us, std::vector<std::vector<uint64_t>> &vs) {
   const int P = q.P, PW = q.PW;
+  std::vector<uint64_t> alpha((size_t)PW), beta((size_t)PW);
   for (int i = 0; i < P; ++i) {
     for (;;) {
-      int j = -1;
-      for (int t = 0; t < P; ++t)
-        if (q.get(i, t)) { j = t; break; }
+      const int j = q.first(i);
       if (j < 0) break;
-      std::vector<uint64_t> alpha(q.row(i), q.row(i) + PW), beta(q.row(j), q.row(j) + PW);
+      std::copy(q.row(i), q.row(i) + PW, alpha.begin());
+      std::copy(q.row(j), q.row(j) + PW, beta.begin());
       alpha[j >> 6] &= ~(1ull << (j & 63));  // B[i][i] is 0 already
       beta[i >> 6] &= ~(1ull << (i & 63));
-      std::vector<uint64_t> u = beta, v = alpha;
-      u[i >> 6] ^= 1ull << (i & 63);
-      v[j >> 6] ^= 1ull << (j & 63);
-      us.push_back(u);
-      vs.push_back(v);
-      // remove variables i and j from B
+      us.push_back(beta);
+      vs.push_back(alpha);
+      us.back()[i >> 6] ^= 1ull << (i & 63);
+      vs.back()[j >> 6] ^= 1ull << (j & 63);
+      // remove variables i and j from B (B is symmetric: the rows that hold column i / j are the set bits of row i / j)
+      for (int w = 0; w < PW; ++w) {
+        for (uint64_t rest = q.row(i)[w]; rest; rest &= rest - 1) {
+          const int k = 64 * w + __builtin_ctzll(rest);
+          if (k < P) q.row(k)[i >> 6] &= ~(1ull << (i & 63));
+        }
+        for (uint64_t rest = q.row(j)[w]; rest; rest &= rest - 1) {
+          const int k = 64 * w + __builtin_ctzll(rest);
+          if (k < P) q.row(k)[j >> 6] &= ~(1ull << (j & 63));
+        }
+      }
       for (int w = 0; w < PW; ++w) q.row(i)[w] = q.row(j)[w] = 0ull;
-      for (int k = 0; k < P; ++k) {
-        q.row(k)[i >> 6] &= ~(1ull << (i & 63));
-        q.row(k)[j >> 6] &= ~(1ull << (j & 63));
-      }
       // q ^= <alpha,x><beta,x>: B[k][l] ^= alpha_k beta_l ^ alpha_l beta_k ; lin_k ^= alpha_k beta_k
-      for (int k = 0; k < P; ++k) {
-        const bool ak = (alpha[k >> 6] >> (k & 63)) & 1, bk = (beta[k >> 6] >> (k & 63)) & 1;
-        if (ak) for (int w = 0; w < PW; ++w) q.row(k)[w] ^= beta[w];
-        if (bk) for (int w = 0; w < PW; ++w) q.row(k)[w] ^= alpha[w];
-        if (ak && bk) q.lin[k >> 6] ^= 1ull << (k & 63);
-        q.row(k)[k >> 6] &= ~(1ull << (k & 63));  // diagonal stays zero
-      }
+      for (int w = 0; w < PW; ++w)
+        for (uint64_t rest = alpha[w] | beta[w]; rest; rest &= rest - 1) {
+          const int k = 64 * w + __builtin_ctzll(rest);
+          if (k >= P) break;
+          const bool ak = (alpha[w] >> (k & 63)) & 1, bk = (beta[w] >> (k & 63)) & 1;
+          uint64_t *rk = q.row(k);
+          if (ak) for (int x = 0; x < PW; ++x) rk[x] ^= beta[x];
+          if (bk) for (int x = 0; x < PW; ++x) rk[x] ^= alpha[x];
+          if (ak && bk) q.lin[k >> 6] ^= 1ull << (k & 63);
+          rk[k >> 6] &= ~(1ull << (k & 63));  // diagonal stays zero
+        }
     }
   }
 }
 
-static bool push_mask_row(std::vector<uint32_t> &dst, const std::vector<uint64_t> &m, int P, int W) {
-  bool any = false;
+static bool push_mask_row(std::vector<uint32_t> &dst, const uint64_t *m, int P, int W) {
+  uint64_t any = 0;
   const size_t base = dst.size();
   dst.resize(base + W, 0u);
-  for (int i = 0; i < P; ++i)
-    if ((m[i >> 6] >> (i & 63)) & 1) {
-      dst[base + (i >> 5)] |= 1u << (i & 31);
-      any = true;
-    }
-  return any;
+  const int nw = (P + 31) / 32;
+  for (int w = 0; w < nw && w < W; ++w) {
+    uint64_t v = m[w >> 1] >> (32 * (w & 1));
+    if (w == nw - 1 && (P & 31)) v &= (1ull << (P & 31)) - 1ull;
+    dst[base + w] = (uint32_t)v;
+    any |= (uint32_t)v;
+  }
+  return any != 0;
 }
 
 // Can this level be evaluated by the counting formulation?  (see eval_level_fast)
@@ -304,7 +359,10 @@ bool pack_level_fast(HostLevel &h, int W, std::vector<uint32_t> &tables, bool &f
     FastGraph &fg = h.fg[(size_t)g];
     uint32_t *rec = &h.graph_rec[(size_t)g * G_WORDS];
     const int nA = d.ta ? h.i32[0][g] : 0;
+    MaskArena arena(P, (size_t)2 * std::max(0, nA) + (size_t)d.tb + 2 * (size_t)d.tc + 2 * (size_t)std::max(0, d.td) + 4);
+    const int PW = arena.PW;
     std::vector<Affine> two;  // bits entering the exponent with coefficient 2
+    two.reserve((size_t)std::max(0, nA) + (size_t)d.tb);
     QForm q4(P);              // bit entering with coefficient 4
     int k0 = h.u8[12][g] & 7; // static phase
     auto add_six = [&](const Affine &a) {  // 6*p = 2*p + 4*p
@@ -319,13 +377,14 @@ bool pack_level_fast(HostLevel &h, int W, std::vector<uint32_t> &tables, bool &f
         if ((int)(ph & 3u) != cls) continue;
         const uint8_t *bits = &h.u8[1][((size_t)g * d.ta + t) * P];
         ++n[cls];
-        if (cls != 0) add_six(affine_from(bits, P, (ph >> 2) != 0));  // (-i)^(par')
+        const Affine ab = affine_from(arena, bits, P, (ph >> 2) != 0);
+        if (cls != 0) add_six(ab);  // (-i)^(par')
         if (cls == 2) continue;
         rows.push_back(ph >> 2);
-        pack_row(rows, bits, P, W);
+        push_mask_row(rows, ab.m, P, W);
         auto &dstm = cls == 0 ? fg.c0 : (cls == 1 ? fg.c1 : fg.c3);
         auto &dstc = cls == 0 ? fg.c0c : (cls == 1 ? fg.c1c : fg.c3c);
-        dstm.push_back(affine_from(bits, P, false).m);
+        dstm.push_back(mask_vec(ab, PW));
         dstc.push_back((uint8_t)(ph >> 2));
       }
     rec[GF_N01] = (uint32_t)n[0] | ((uint32_t)n[1] << 16);
@@ -352,10 +411,12 @@ bool pack_level_fast(HostLevel &h, int W, std::vector<uint32_t> &tables, bool &f
         }
         (void)w;
       }
-      pack_row(rows, &h.u8[9][((size_t)g * d.td + t) * P], P, W);
-      pack_row(rows, &h.u8[11][((size_t)g * d.td + t) * P], P, W);
-      fg.dal.push_back(affine_from(&h.u8[9][((size_t)g * d.td + t) * P], P, false).m);
-      fg.dbe.push_back(affine_from(&h.u8[11][((size_t)g * d.td + t) * P], P, false).m);
+      const Affine da = affine_from(arena, &h.u8[9][((size_t)g * d.td + t) * P], P, false);
+      const Affine db = affine_from(arena, &h.u8[11][((size_t)g * d.td + t) * P], P, false);
+      push_mask_row(rows, da.m, P, W);
+      push_mask_row(rows, db.m, P, W);
+      fg.dal.push_back(mask_vec(da, PW));
+      fg.dbe.push_back(mask_vec(db, PW));
     }
     rec[GF_ND] = (uint32_t)nD;
     fg.nD = nD;
@@ -364,38 +425,38 @@ bool pack_level_fast(HostLevel &h, int W, std::vector<uint32_t> &tables, bool &f
     for (int t = 0; t < d.tb; ++t) {
       const uint32_t coeff = h.u8[2][(size_t)g * d.tb + t] & 7u;
       if (!coeff) continue;
-      const Affine a = affine_from(&h.u8[3][((size_t)g * d.tb + t) * P], P, false);
+      const Affine a = affine_from(arena, &h.u8[3][((size_t)g * d.tb + t) * P], P, false);
       if (coeff == 2) two.push_back(a);
       else if (coeff == 4) q4.add_linear(a);
       else add_six(a);
     }
     // ---- PiProducts: 4 * psi * phi
     for (int t = 0; t < d.tc; ++t) {
-      const Affine psi = affine_from(&h.u8[5][((size_t)g * d.tc + t) * P], P, h.u8[4][(size_t)g * d.tc + t] & 1u);
-      const Affine phi = affine_from(&h.u8[7][((size_t)g * d.tc + t) * P], P, h.u8[6][(size_t)g * d.tc + t] & 1u);
+      const Affine psi = affine_from(arena, &h.u8[5][((size_t)g * d.tc + t) * P], P, h.u8[4][(size_t)g * d.tc + t] & 1u);
+      const Affine phi = affine_from(arena, &h.u8[7][((size_t)g * d.tc + t) * P], P, h.u8[6][(size_t)g * d.tc + t] & 1u);
       q4.add_product(psi, phi);
+      arena.used -= 2 * (size_t)PW;  // (consumed at once: the two slots are the next term's)
+      std::fill(arena.buf.begin() + (long)arena.used, arena.buf.begin() + (long)arena.used + 2 * PW, 0ull);
     }
     // ---- 2 * sum(two) = 2 * XOR(two) + 4 * e2(two)
-    Affine lam;
-    lam.m.assign((size_t)(P + 63) / 64 + 1, 0ull);
+    std::vector<uint64_t> lam_m((size_t)PW, 0ull);
+    bool lam_c = false;
     // e2 = XOR_{s < t} a_s a_t = XOR_s a_s (XOR_{t > s} a_t): one product per row against the XOR of the rows behind it
     // (the pairwise form - |two|^2 / 2 products of P x P bits each - was 35 of the 38 ms C4's 1024 graphs took to pack)
     {
-      Affine suffix;
-      suffix.m.assign(lam.m.size(), 0ull);
+      std::vector<uint64_t> suffix_m((size_t)PW, 0ull);
+      bool suffix_c = false;
       for (size_t s = two.size(); s-- > 0;) {
-        for (size_t w = 0; w < lam.m.size(); ++w) lam.m[w] ^= two[s].m[w];
-        lam.c ^= two[s].c;
-        if (s + 1 < two.size()) q4.add_product(two[s], suffix);
-        for (size_t w = 0; w < suffix.m.size(); ++w) suffix.m[w] ^= two[s].m[w];
-        suffix.c ^= two[s].c;
+        for (int w = 0; w < PW; ++w) lam_m[(size_t)w] ^= two[s].m[w];
+        lam_c ^= two[s].c;
+        if (s + 1 < two.size()) q4.add_product(two[s], Affine{suffix_m.data(), suffix_c});
+        for (int w = 0; w < PW; ++w) suffix_m[(size_t)w] ^= two[s].m[w];
+        suffix_c ^= two[s].c;
       }
     }
-    if (lam.c) {  // 2*(1 ^ y) = 2 + 6*y = 2 + 2*y + 4*y
+    if (lam_c) {  // 2*(1 ^ y) = 2 + 6*y = 2 + 2*y + 4*y
       k0 += 2;
-      Affine y = lam;
-      y.c = false;
-      q4.add_linear(y);
+      q4.add_linear(Affine{lam_m.data(), false});
     }
     const auto tg1 = std::chrono::steady_clock::now();
     q4.finish();
@@ -410,17 +471,17 @@ bool pack_level_fast(HostLevel &h, int W, std::vector<uint32_t> &tables, bool &f
     uint32_t flags = d_tabled ? TSIMK_GFLAG_D_TABLED : 0u;
     {
       std::vector<uint32_t> tmp;
-      if (push_mask_row(tmp, lam.m, P, W)) { flags |= TSIMK_GFLAG_LAM; rows.insert(rows.end(), tmp.begin(), tmp.end()); }
+      if (push_mask_row(tmp, lam_m.data(), P, W)) { flags |= TSIMK_GFLAG_LAM; rows.insert(rows.end(), tmp.begin(), tmp.end()); }
       tmp.clear();
-      if (push_mask_row(tmp, q4.lin, P, W)) { flags |= TSIMK_GFLAG_LIN; rows.insert(rows.end(), tmp.begin(), tmp.end()); }
+      if (push_mask_row(tmp, q4.lin.data(), P, W)) { flags |= TSIMK_GFLAG_LIN; rows.insert(rows.end(), tmp.begin(), tmp.end()); }
     }
     for (size_t s = 0; s < us.size(); ++s) {
-      push_mask_row(rows, us[s], P, W);
-      push_mask_row(rows, vs[s], P, W);
+      push_mask_row(rows, us[s].data(), P, W);
+      push_mask_row(rows, vs[s].data(), P, W);
     }
     rec[GF_N3H] = (uint32_t)n[3] | ((uint32_t)us.size() << 16);
     rec[GF_FLAGS] = flags;
-    fg.lam = lam.m;
+    fg.lam = lam_m;
     fg.lin = q4.lin;
     fg.us = us;
     fg.vs = vs;
@@ -433,25 +494,45 @@ bool pack_level_fast(HostLevel &h, int W, std::vector<uint32_t> &tables, bool &f
     const long long ff[4] = {h.i32[2][(size_t)g * 4], h.i32[2][(size_t)g * 4 + 1], h.i32[2][(size_t)g * 4 + 2],
                              h.i32[2][(size_t)g * 4 + 3]};
     const int ndb = d_tabled ? (1 << (2 * nD)) : 1;
+    // (1 + w^k)^j for the four factors whose exponent moves with delta, once per graph; the rest is common to every entry.
+    // (The canonical form of an element of Z[w] * 2^p is unique, so the order of the exact products does not matter; zeros get
+    // their power below.)
+    auto powers = [&](int k, int upto) {
+      std::vector<ZW> pw((size_t)upto + 1);
+      pw[0] = ZW{{1, 0, 0, 0}, 0};
+      long long f[4];
+      unit_plus_one(k, f);
+      for (int j = 1; j <= upto; ++j) {
+        pw[(size_t)j] = pw[(size_t)j - 1];
+        zw_mul(pw[(size_t)j], f);
+      }
+      return pw;
+    };
+    const std::vector<ZW> pw1 = powers(1, n[1]), pw5 = powers(5, n[1]), pw3 = powers(3, n[3]), pw7 = powers(7, n[3]);
+    ZW common{{1, 0, 0, 0}, 0};
+    {
+      long long f[4];
+      unit_plus_one(0, f);
+      for (int i = 0; i < n[0]; ++i) zw_mul(common, f);
+      unit_plus_one(2, f);
+      for (int i = 0; i < n[2]; ++i) zw_mul(common, f);
+      zw_mul(common, ff);
+      common.p += h.i32[3][g];  // power2
+    }
+    auto mul_zw = [](ZW &x, const ZW &y) {
+      zw_mul(x, y.c);
+      x.p += y.p;
+    };
     for (int delta = -n[1]; delta <= n[3]; ++delta) {
       const int m3 = delta > 0 ? delta : 0, m1 = delta < 0 ? -delta : 0;
-      ZW z{{1, 0, 0, 0}, 0};
-      long long f[4];
-      auto mul_k = [&](int k, int times) {
-        unit_plus_one(k, f);
-        for (int i = 0; i < times; ++i) zw_mul(z, f);
-      };
-      mul_k(0, n[0]);
-      mul_k(2, n[2]);
-      mul_k(1, n[1] - m1);
-      mul_k(5, m1);
-      mul_k(3, n[3] - m3);
-      mul_k(7, m3);
+      ZW z = common;
+      mul_zw(z, pw1[(size_t)(n[1] - m1)]);
+      mul_zw(z, pw5[(size_t)m1]);
+      mul_zw(z, pw3[(size_t)(n[3] - m3)]);
+      mul_zw(z, pw7[(size_t)m3]);
       const int r = (2 * (m1 + m3) + k0) & 7;
       const long long rot[4] = {kUnit[r][0], kUnit[r][1], kUnit[r][2], kUnit[r][3]};
       zw_mul(z, rot);
-      zw_mul(z, ff);
-      z.p += h.i32[3][g];  // power2
       for (int db = 0; db < ndb; ++db) {
         ZW e = z;
         for (int t = 0; t < nD && d_tabled; ++t) {

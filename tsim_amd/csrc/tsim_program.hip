@@ -310,8 +310,11 @@ extern "C" int tsim_program_finalize(tsim_program *p, int32_t device) {
   auto fin_mark = [&](const char *what) {
     if (!fin_dbg) return;
     const auto n = std::chrono::steady_clock::now();
-    fprintf(stderr, "[tsim] finalize: %s %.2f ms\n", what, std::chrono::duration<double, std::milli>(n - fin_t0).count());
-    fin_t0 = n;
+    unsigned long long hsh = 1469598103934665603ull;  // (FNV-1a of the image so far: a packer change that must not move a word shows here)
+    for (uint32_t w : p->img) hsh = (hsh ^ w) * 1099511628211ull;
+    fprintf(stderr, "[tsim] finalize: %s %.2f ms (image %zu words, hash %016llx)\n", what, std::chrono::duration<double, std::milli>(n - fin_t0).count(),
+            p->img.size(), hsh);
+    fin_t0 = std::chrono::steady_clock::now();
   };
   // ---- choose the evaluation formulation ----
   {

@@ -696,14 +696,18 @@ void emit_level4(const HostLevel &h, int GT, int nch, const uint32_t *v3recs, st
   // offsets are immediates), the one-graph tiles of the wide layout do not
   const int sent = sparse_F < 0 ? 0 : (GT > 1 ? std::max(TSIMK_SPARSE_ENTRIES, sparse_F + 33) : sparse_F + 33);
   stabs4.assign((size_t)ntiles * sent * GT * 4, 0u);
-  std::vector<std::array<uint32_t, 4>> col((size_t)std::max(P, 1));
-  for (int g = 0; g < G; ++g) {
+  // (one graph's tables are independent of the others': the graphs of a level go through the process-wide pool - C4's level of
+  // 256 graphs took 3 ms on one thread, the longest pole of the chunk-table phase)
+  auto do_graph = [&](int g) {
     const FastGraph &fg = h.fg[(size_t)g];
-    for (auto &c : col) c = {0u, 0u, 0u, 0u};
+    std::vector<std::array<uint32_t, 4>> col((size_t)std::max(P, 1), std::array<uint32_t, 4>{0u, 0u, 0u, 0u});
     std::array<uint32_t, 4> cst = {0u, 0u, 0u, 0u};
     auto place = [&](const std::vector<uint64_t> &m, int word, int bit) {
-      for (int i = 0; i < P; ++i)
-        if (mask_bit(m, i)) col[(size_t)i][(size_t)word] |= 1u << bit;
+      for (size_t w = 0; w < m.size(); ++w)
+        for (uint64_t rest = m[w]; rest; rest &= rest - 1) {
+          const int i = 64 * (int)w + __builtin_ctzll(rest);
+          if (i < P) col[(size_t)i][(size_t)word] |= 1u << bit;
+        }
     };
     const int h2 = (int)fg.us.size();
     for (int s = 0; s < h2; ++s) {
@@ -722,20 +726,24 @@ void emit_level4(const HostLevel &h, int GT, int nch, const uint32_t *v3recs, st
     place(fg.lam, 3, 30);
     place(fg.lin, 3, 31);
     const int tile = g / GT, j = g % GT;
-    for (int c = 0; c < nch; ++c)
+    for (int c = 0; c < nch; ++c) {
+      std::array<uint32_t, 4> vals[16];
+      vals[0] = (c == 0) ? cst : std::array<uint32_t, 4>{0u, 0u, 0u, 0u};
+      for (int v = 1; v < 16; ++v) {  // value v = value (v without its lowest bit) ^ that bit's column
+        const int i = 4 * c + __builtin_ctz((unsigned)v);
+        vals[v] = vals[v & (v - 1)];
+        if (i < P)
+          for (int w = 0; w < 4; ++w) vals[v][(size_t)w] ^= col[(size_t)i][(size_t)w];
+      }
       for (int v = 0; v < 16; ++v) {
-        std::array<uint32_t, 4> val = (c == 0) ? cst : std::array<uint32_t, 4>{0u, 0u, 0u, 0u};
-        for (int bb = 0; bb < 4; ++bb) {
-          const int i = 4 * c + bb;
-          if (!((v >> bb) & 1) || i >= P) continue;
-          for (int w = 0; w < 4; ++w) val[(size_t)w] ^= col[(size_t)i][(size_t)w];
-        }
+        const std::array<uint32_t, 4> &val = vals[v];
         // [tile][chunk][graph][value]: the lanes of a wave read ONE graph's entry for THEIR chunk value - 16 bytes apart per value,
         // so the 16 values fall on 16 different groups of banks (value-major entries of GT x 16 bytes put values v and v + 4 on
         // the same banks: k_sample4's LDS pipe spent 2.4 x its busy time in bank conflicts, profiles/r04/full_kernel_pmc.txt)
         uint32_t *dst = &tabs4[((((size_t)tile * nch + c) * GT + j) * 16 + v) * 4];
         for (int w = 0; w < 4; ++w) dst[w] = val[(size_t)w];
       }
+    }
     if (sent) {
       auto put = [&](int e, const std::array<uint32_t, 4> &val) {
         uint32_t *dst = &stabs4[(((size_t)tile * GT + j) * sent + e) * 4];  // [tile][graph][entry]: consecutive entries on consecutive bank groups
@@ -764,7 +772,8 @@ void emit_level4(const HostLevel &h, int GT, int nch, const uint32_t *v3recs, st
     r4[G4_FLAGS] = fg.nD == 0 ? 0u : (fg.d_tabled ? TSIMK_G4FLAG_D_COMBINED : TSIMK_G4FLAG_D_SEPARATE);
     r4[G4_APRE] = r3[GF_APRE];
     r4[G4_APIM] = r3[GF_APIM];
-  }
+  };
+  tsim_parallel_for((size_t)G, G >= 128 ? 16 : (G >= 32 ? 8 : (G >= 8 ? 2 : 1)), [&](size_t g) { do_graph((int)g); });
 }
 
 // Gather program (tsim_lw.hip.h): bit moves (src f bit -> dst bit, flip) merged into runs that are

@@ -311,7 +311,8 @@ extern "C" int tsim_program_finalize(tsim_program *p, int32_t device) {
     if (!fin_dbg) return;
     const auto n = std::chrono::steady_clock::now();
     unsigned long long hsh = 1469598103934665603ull;  // (FNV-1a of the image so far: a packer change that must not move a word shows here)
-    for (uint32_t w : p->img) hsh = (hsh ^ w) * 1099511628211ull;
+    if (tsim_debug("imghash"))
+      for (uint32_t w : p->img) hsh = (hsh ^ w) * 1099511628211ull;
     fprintf(stderr, "[tsim] finalize: %s %.2f ms (image %zu words, hash %016llx)\n", what, std::chrono::duration<double, std::milli>(n - fin_t0).count(),
             p->img.size(), hsh);
     fin_t0 = std::chrono::steady_clock::now();
@@ -379,6 +380,37 @@ retry_pack:
       prepacked[i].ok = pack_level_fast(*jobs[i].first, jobs[i].second, prepacked[i].tables, prepacked[i].fixed, prepacked[i].frame);
     });
   }
+  fin_mark("  levels packed (pool)");
+  // The bulk of the image - graph records, rows, term tables, the block-per-row kernel's row streams, the chunk tables below - is
+  // laid out here (space reserved, zero-filled) and copied in by the pool afterwards: one thread appending 12 MB piece by piece
+  // was 5 of the 12 ms of a fresh C4 handle.
+  std::vector<std::function<void()>> copy_jobs;
+  auto img_grow = [&](size_t n) {
+    const size_t o = img.size();
+    img.resize(o + n, 0u);
+    return o;
+  };
+  auto img_align16 = [&]() { img.resize((img.size() + 15) / 16 * 16, 0u); };
+  auto copy_later = [&](const std::vector<uint32_t> &v) {
+    const size_t o = img_grow(v.size());
+    if (!v.empty()) copy_jobs.push_back([&img, &v, o]() { memcpy(&img[o], v.data(), v.size() * sizeof(uint32_t)); });
+    return o;
+  };
+  auto run_copy_jobs = [&]() {
+    tsim_parallel_for(copy_jobs.size(), 16, [&](size_t i) { copy_jobs[i](); });
+    copy_jobs.clear();
+  };
+  if (p->fast) {  // (an upper bound: address space only - no reallocation while the pieces are laid out)
+    size_t need = img.size() + 4096, li = 0;
+    for (auto &c : p->comps) {
+      need += (size_t)c.F + (size_t)c.n_out + (size_t)c.n_levels * (L_WORDS + L4_WORDS) + 256;
+      for (auto &lv : c.levels) {
+        need += lv.graph_rec.size() + 3 * lv.rows.size() + prepacked[li++].tables.size() + 256;
+        need += (size_t)lv.G * G4_WORDS + (size_t)((lv.G + 3) / 4) * (32 * 16 * 4 * 4 + (size_t)std::max(TSIMK_SPARSE_ENTRIES, c.F + 33) * 16) + 64;
+      }
+    }
+    img.reserve(need);
+  }
   for (size_t ci = 0; ci < p->comps.size(); ++ci) {
     HostComponent &c = p->comps[ci];
     int maxP = 1;
@@ -407,7 +439,8 @@ retry_pack:
     p->level_base.push_back((int)p->level_off.size());
     for (int k = 0; k < c.n_levels; ++k) {
       HostLevel &h = c.levels[k];
-      std::vector<uint32_t> tables;
+      static const std::vector<uint32_t> no_tables;
+      const std::vector<uint32_t> *tables_p = &no_tables;
       bool fixed = false;
       int frame = 0;
       if (p->fast) {
@@ -417,53 +450,72 @@ retry_pack:
           p->fast = false;
           goto retry_pack;
         }
-        tables.swap(pp.tables);
+        tables_p = &pp.tables;
         fixed = pp.fixed;
         frame = pp.frame;
       } else {
         pack_level(h, W);
       }
+      const std::vector<uint32_t> &tables = *tables_p;
       // align graph records to 16 words (one s_load_dwordx16 each)
-      while (img.size() % 16) img.push_back(0u);
-      const uint32_t goff = (uint32_t)img.size();
-      img.insert(img.end(), h.graph_rec.begin(), h.graph_rec.end());
-      const uint32_t roff = (uint32_t)img.size();
-      img.insert(img.end(), h.rows.begin(), h.rows.end());
+      img_align16();
+      const uint32_t goff = (uint32_t)img_grow(h.graph_rec.size());  // (copied by the job below, which also patches the offsets in)
+      const uint32_t roff = (uint32_t)copy_later(h.rows);
       static_assert((int)G_ROWS == (int)GF_ROWS, "row offset slot is shared by both layouts");
-      for (int g = 0; g < h.G; ++g) img[goff + (size_t)g * G_WORDS + G_ROWS] += roff;
+      uint32_t toff = 0;
       if (p->fast) {
-        while (img.size() % 16) img.push_back(0u);  // 64-byte aligned table entries (uint4 loads)
-        const uint32_t toff = (uint32_t)img.size();
-        img.insert(img.end(), tables.begin(), tables.end());
+        img_align16();  // 64-byte aligned table entries (uint4 loads)
+        toff = (uint32_t)copy_later(tables);
         h.tt_off = toff;
         h.tt_words = (uint32_t)tables.size();
-        for (int g = 0; g < h.G; ++g) {
-          img[goff + (size_t)g * G_WORDS + GF_TBL] += toff;
-          if (img[goff + (size_t)g * G_WORDS + GF_TBL2]) img[goff + (size_t)g * G_WORDS + GF_TBL2] += toff;
-        }
       }
       // The same rows once more as ONE stream of uniform stride per level - [const, w_0 .. w_(W-1)] per row, graph after
       // graph in the order eval_graph_fast reads them - for the wave-per-row kernel (tsim_kernel_hw.hip.h), whose lanes
       // take one ROW each (coalesced) and whose graphs then read their parities by position.
       uint32_t hw_off = 0, hw_n = 0;
+      std::vector<uint32_t> hw_start;
       if (p->fast) {
-        while (img.size() % 16) img.push_back(0u);
-        hw_off = (uint32_t)img.size();
+        img_align16();
+        hw_start.resize((size_t)h.G);
         for (int g = 0; g < h.G; ++g) {
           const uint32_t *r = &h.graph_rec[(size_t)g * G_WORDS];
           const uint32_t n_meta = (r[GF_N01] & 0xFFFFu) + (r[GF_N01] >> 16) + (r[GF_N3H] & 0xFFFFu);
           const uint32_t n_plain = 2u * r[GF_ND] + ((r[GF_FLAGS] & TSIMK_GFLAG_LAM) ? 1u : 0u) + ((r[GF_FLAGS] & TSIMK_GFLAG_LIN) ? 1u : 0u) +
                                    2u * (r[GF_N3H] >> 16);
-          img[goff + (size_t)g * G_WORDS + GF_HWROW] = hw_n;
-          const uint32_t *src = &h.rows[r[GF_ROWS]];
-          for (uint32_t t = 0; t < n_meta; ++t, src += 1 + W) img.insert(img.end(), src, src + 1 + W);
-          for (uint32_t t = 0; t < n_plain; ++t, src += W) {
-            img.push_back(0u);
-            img.insert(img.end(), src, src + W);
-          }
+          hw_start[(size_t)g] = hw_n;
           hw_n += n_meta + n_plain;
         }
+        hw_off = (uint32_t)img_grow((size_t)hw_n * (size_t)(1 + W));
         p->hw_max_rows = std::max(p->hw_max_rows, (long long)hw_n);
+      }
+      {  // (behind the copies of this level's records: the offsets of the image, the row streams)
+        const HostLevel *hp = &h;
+        const bool fast = p->fast;
+        copy_jobs.push_back([&img, hp, goff, roff, toff, hw_off, W, fast, hs = std::move(hw_start)]() {
+          const HostLevel &h = *hp;
+          if (!h.graph_rec.empty()) memcpy(&img[goff], h.graph_rec.data(), h.graph_rec.size() * sizeof(uint32_t));
+          for (int g = 0; g < h.G; ++g) {
+            uint32_t *gr = &img[goff + (size_t)g * G_WORDS];
+            const uint32_t *r = &h.graph_rec[(size_t)g * G_WORDS];
+            gr[G_ROWS] = r[G_ROWS] + roff;
+            if (!fast) continue;
+            gr[GF_TBL] = r[GF_TBL] + toff;
+            if (r[GF_TBL2]) gr[GF_TBL2] = r[GF_TBL2] + toff;
+            gr[GF_HWROW] = hs[(size_t)g];
+            const uint32_t n_meta = (r[GF_N01] & 0xFFFFu) + (r[GF_N01] >> 16) + (r[GF_N3H] & 0xFFFFu);
+            const uint32_t n_plain = 2u * r[GF_ND] + ((r[GF_FLAGS] & TSIMK_GFLAG_LAM) ? 1u : 0u) + ((r[GF_FLAGS] & TSIMK_GFLAG_LIN) ? 1u : 0u) +
+                                     2u * (r[GF_N3H] >> 16);
+            const uint32_t *src = &h.rows[r[GF_ROWS]];
+            uint32_t *dst = &img[hw_off + (size_t)hs[(size_t)g] * (size_t)(1 + W)];
+            memcpy(dst, src, (size_t)n_meta * (size_t)(1 + W) * sizeof(uint32_t));
+            src += (size_t)n_meta * (size_t)(1 + W);
+            dst += (size_t)n_meta * (size_t)(1 + W);
+            for (uint32_t t = 0; t < n_plain; ++t, src += W, dst += 1 + W) {
+              dst[0] = 0u;
+              memcpy(dst + 1, src, (size_t)W * sizeof(uint32_t));
+            }
+          }
+        });
       }
       uint32_t *lr = &img[lrec + (size_t)k * L_WORDS];
       lr[L_G] = (uint32_t)h.G;
@@ -490,6 +542,8 @@ retry_pack:
     if (sequential) p->total_keys += c.n_out;
     memcpy(&img[p->comp_off + ci * C_WORDS], rec, sizeof rec);
   }
+  fin_mark("  records laid out");
+  run_copy_jobs();
   fin_mark("rows / fast formulation packed");
   // ---- v4 (chunk table) layout, when every sampled component qualifies ----
   p->v4 = false;
@@ -552,6 +606,7 @@ retry_pack:
             ejobs.push_back({ci, k});
           }
         }
+        fin_mark("  chunk-table setup");
         tsim_parallel_for(ejobs.size(), 16, [&](size_t j) {
           const size_t ci = ejobs[j].first;
           const int k = ejobs[j].second;
@@ -562,10 +617,11 @@ retry_pack:
           emit_level4(h, p->v4_gt, p->v4_max_nch, v3copy.data(), e.recs4, e.tabs4, e.nch, e.ntiles, e.sparse_F, e.stabs4);
         });
       }
+      fin_mark("  chunk tables emitted (pool)");
       for (size_t ci = 0; ci < p->comps.size(); ++ci) {
         HostComponent &c = p->comps[ci];
         for (int w = 0; w < 8; ++w) img[p->comp4_off + ci * C4_WORDS + w] = img[p->comp_off + ci * C_WORDS + w];
-        while (img.size() % 16) img.push_back(0u);
+        img_align16();
         const size_t l4 = img.size();
         img[p->comp4_off + ci * C4_WORDS + C4_LEVELS] = (uint32_t)l4;
         img.resize(img.size() + (size_t)c.n_levels * L4_WORDS, 0u);
@@ -576,15 +632,13 @@ retry_pack:
           Emit4 &em = emitted[ci][(size_t)k];
           std::vector<uint32_t> &recs4 = em.recs4, &tabs4 = em.tabs4, &stabs4 = em.stabs4;
           const int nch = em.nch, ntiles = em.ntiles, sparse_F = em.sparse_F;
-          while (img.size() % 16) img.push_back(0u);
-          const uint32_t roff = (uint32_t)img.size();
-          img.insert(img.end(), recs4.begin(), recs4.end());
-          while (img.size() % 16) img.push_back(0u);
-          const uint32_t toff = (uint32_t)img.size();
-          img.insert(img.end(), tabs4.begin(), tabs4.end());
-          while (img.size() % 16) img.push_back(0u);
+          img_align16();
+          const uint32_t roff = (uint32_t)copy_later(recs4);
+          img_align16();
+          const uint32_t toff = (uint32_t)copy_later(tabs4);
+          img_align16();
           const uint32_t stoff = stabs4.empty() ? 0u : (uint32_t)img.size();
-          img.insert(img.end(), stabs4.begin(), stabs4.end());
+          copy_later(stabs4);
           p->v4_max_sent = std::max(p->v4_max_sent, sparse_F < 0 ? 0 : (p->v4_gt > 1 ? std::max(TSIMK_SPARSE_ENTRIES, sparse_F + 33) : sparse_F + 33));
           uint32_t *lr = &img[l4 + (size_t)k * L4_WORDS];
           lr[L4_STAB] = stoff;
@@ -607,6 +661,7 @@ retry_pack:
           img.insert(img.end(), sel, sel + 2 * TSIMK_W_SELWORDS);
         }
       }
+      run_copy_jobs();
       p->v4 = ok;
       p->v4w = wide;
       // f rows of more than 512 bits: k_sample_wide or the row kernel, never the round-2 kernels (16 mask words)
@@ -722,8 +777,11 @@ retry_pack:
         for (int j = 0; j < c.F; ++j) lw_fsel_progs.back().push_back({c.f_selection[j], j, 0});
       }
       // Start shallow: the BASELINE jobs are 10^5-10^6 shots, and a depth-5 table (C4: 195 MB, 35 ms of
-      // build) pays only from ~10^8 rows on.  Finalize builds the deepest tables that cost about half a millisecond (table
-      // entries x graphs per level <= 1.2e8: C2 depth 4, C3 and C4 depth 3 - at depth 2 C4 sampled 10^8 shots in 75 ms, 4.6 % of its rows hard); the default depth follows in the background, slice by slice
+      // build) pays only from ~10^8 rows on.  Finalize builds the deepest tables that cost a millisecond or two (table
+      // entries x graphs per level <= 1.2e8, ~2.4e-8 ms each: C2 depth 4 in 0.7 ms, C3 depth 3, C4 depth 3 in 2.4 ms - a third of
+      // its fresh handle; at depth 2 it starts 2 ms sooner, and a job enqueued in one go, whose launch plans are all drawn before
+      // any deeper table lands, pays for it: 10^8 shots in 46-75 instead of 32 ms, 4.6 % of the rows hard - also with the next
+      // depth alone as a first stage of the background build, measured); the default depth follows in the background, slice by slice
       // next to the first launches (tsim_tables_extend_begin below, tsim_tables.hip).  A caller who named a depth gets it here.
       if (!pinned && p->knobs.shallow && p->knobs.deep_tables <= 0) {
         while (p->lw_cap_now > (p->lw_wide ? 3 : 2)) {

@@ -129,8 +129,8 @@ static LaunchPlan make_plan(tsim_program *p, bool has_row_index, bool pipelined,
   LaunchPlan pl;
   pl.use_tables = p->lw;
   // deeper tables built in the background (tsim_tables_extend_begin) are done: swap them in - the lanes drain, ~0.1 ms
-  if (p->ext_pending && tsim_tables_extend_poll(p, false) == 1 && p->h_feedback) {
-    for (int i = 0; i < 8; ++i) p->h_feedback[i] = 0xFFFFFFFFu;  // the old counts describe the old tables
+  if (p->ext_pending && tsim_tables_extend_poll(p, false) == 1) {
+    for (int i = 0; i < 8 && p->h_feedback; ++i) p->h_feedback[i] = 0xFFFFFFFFu;  // the old counts describe the old tables
     p->lw_direct_left = 0;
     p->deep_rows = 0;  // (rows counted against the old depth - the shallow start's - say nothing about the new one)
     p->lw_dense_launches = 0;

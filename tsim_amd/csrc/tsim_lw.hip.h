@@ -95,7 +95,7 @@ struct LwBuildArgs {
   int wide_binom_off, bases_off, wmax;
   int binom_stride;                   // words per row of the wide binomial table (256; 512 for components beyond 255 selected bits)
   float *p1;                          // scratch [npat << n_out]: |amp| of every node (k_lw_nodes), node 0 = the normalisation
-  int depth;                          // k_lw_nodes: -1 = the normalisation level, d = the nodes with d prefix bits
+  int depth;                          // k_lw_nodes: -1 = the normalisation level, d = the nodes with d prefix bits, -2 = all of them
   int pat_begin, pat_count;           // this launch serves patterns [pat_begin, pat_begin + pat_count) (pat_count 0: to npat) - a build in slices
   // chunked prefix tree (tsim_trie.hip.h): `tab` = the component's chunks, `p1` = scratch: a header of TH_WORDS words, then one
   // TrieMeta per chunk
@@ -163,13 +163,26 @@ __global__ void __launch_bounds__(256) k_lw_nodes(LwBuildArgs A) {
   cptr comp = img + A.comp_off;
   const uint32_t n_out = comp[C_NOUT], F = comp[C_F];
   cptr levels = img + comp[C_LEVELS];
-  const int d = A.depth;
-  const int dd = d < 0 ? 0 : d;
+  int d = A.depth;
   const long long tl = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (tl >= ((long long)(A.pat_count ? A.pat_count : A.npat - A.pat_begin) << dd)) return;
-  const long long t = ((long long)A.pat_begin << dd) + tl;
-  const uint32_t pat = d < 0 ? (uint32_t)t : (uint32_t)(t >> d);
-  const uint32_t prefix = d < 0 ? 0u : ((uint32_t)t & ((1u << d) - 1u));
+  const long long np = (long long)(A.pat_count ? A.pat_count : A.npat - A.pat_begin);
+  uint32_t pat, prefix;
+  if (d == -2) {
+    // every node of every pattern in ONE launch, node-major (a wave's lanes evaluate the same level but for its ends), the deepest
+    // nodes first: one launch per depth was seven launches one behind the other, each as long as ONE lane's walk over the graphs
+    // of its level when the patterns are few (C4 at weight 3: 10 701 patterns, 2.4 ms of a fresh handle's 7)
+    if (tl >= (np << n_out)) return;
+    const uint32_t node = ((1u << n_out) - 1u) - (uint32_t)(tl / np);
+    pat = (uint32_t)A.pat_begin + (uint32_t)(tl % np);
+    d = node == 0u ? -1 : 31 - __builtin_clz(node);
+    prefix = d < 0 ? 0u : node - (1u << d);
+  } else {
+    const int dd = d < 0 ? 0 : d;
+    if (tl >= (np << dd)) return;
+    const long long t = ((long long)A.pat_begin << dd) + tl;
+    pat = d < 0 ? (uint32_t)t : (uint32_t)(t >> d);
+    prefix = d < 0 ? 0u : ((uint32_t)t & ((1u << d) - 1u));
+  }
   uint32_t x[W];
   lw_pattern_bits<W>(A, img, F, pat, x);
   float re, im;

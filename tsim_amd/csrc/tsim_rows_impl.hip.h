@@ -83,11 +83,12 @@ static int TSIM_ROWS_NAME(trie_build)(int W, const LwBuildArgs &a0, int n_out, h
 
 int TSIM_ROWS_NAME(lw_build)(int W, const LwBuildArgs &a0, int n_out, hipStream_t s) {
   if (a0.trie) return TSIM_ROWS_NAME(trie_build)(W, a0, n_out, s);
-  // one launch per depth (every lane of a launch evaluates the same level), then the thresholds
-  for (int d = -1; d < n_out; ++d) {
+  // every node in one launch (k_lw_nodes, depth -2), then the thresholds
+  {
     LwBuildArgs a = a0;
-    a.depth = d;
-    const long long lanes = (long long)(a.pat_count ? a.pat_count : a.npat - a.pat_begin) << (d < 0 ? 0 : d);
+    a.depth = -2;
+    const long long lanes = (long long)(a.pat_count ? a.pat_count : a.npat - a.pat_begin) << n_out;
+    if (lanes > 0x7FFFFFFFll * 256) return tsim_fail(TSIM_ENOTSUP, "pattern tables: slice too large");
     const dim3 grid((unsigned)((lanes + 255) / 256));
     switch (W) {
 #define TSIM_X(WV)                                                                                 \

@@ -76,4 +76,15 @@ __global__ void k_keygen(uint32_t k0, uint32_t k1, int n, uint32_t *__restrict__
   }
 }
 
+// ... computed on the host when they fit the kernel arguments (the chain is 2 n dependent Threefry blocks: 44 us on one lane for
+// 39 outputs, per batch, in front of the first pass - class 20narrow; ~3 us on a host core): this kernel only stores them.
+#define TSIMK_KEYPUT_MAX 320
+struct KeyPutArgs {
+  int n;
+  uint32_t keys[2 * TSIMK_KEYPUT_MAX];
+};
+__global__ void k_keyput(KeyPutArgs K, uint32_t *__restrict__ subkeys) {
+  for (int i = (int)threadIdx.x; i < 2 * K.n; i += (int)blockDim.x) subkeys[i] = K.keys[i];
+}
+
 }  // namespace tsimk

@@ -211,6 +211,7 @@ struct tsim_program {
     void *hard2 = nullptr;
     size_t hard2_sz = 0;
     uint32_t *keys = nullptr;     // k_keygen output (programs with > TSIMK_INLINE_KEYS outputs)
+    std::vector<uint32_t> host_keys;  // ... the same subkeys on the host, when fill_sample_args computed them there (k_keyput)
     hipStream_t side = nullptr;
     hipEvent_t ev1 = nullptr, ev2 = nullptr;  // input dependency, launch done
     bool pending = false;         // second pass enqueued on `side`, not yet joined

@@ -545,7 +545,24 @@ int fill_sample_args(tsim_program *p, tsim_program::Slot &sl, SampleArgs &a, con
       k1 = a1;
     }
     a.n_inline_keys = p->total_keys;
+  } else if (p->total_keys > 0 && p->total_keys <= TSIMK_KEYPUT_MAX) {
+    sl.host_keys.resize(2 * (size_t)p->total_keys);  // (k_sample_gen takes them from here: gen_step_keys)
+    KeyPutArgs K;
+    K.n = p->total_keys;
+    uint32_t k0 = key_hi, k1 = key_lo;
+    for (int i = 0; i < p->total_keys; ++i) {
+      uint32_t a0 = 0u, a1 = 0u, b0 = 0u, b1 = 1u;
+      threefry2x32(k0, k1, a0, a1);
+      threefry2x32(k0, k1, b0, b1);
+      K.keys[2 * i] = sl.host_keys[2 * (size_t)i] = b0;
+      K.keys[2 * i + 1] = sl.host_keys[2 * (size_t)i + 1] = b1;
+      k0 = a0;
+      k1 = a1;
+    }
+    hipLaunchKernelGGL(k_keyput, dim3(1), dim3(64), 0, s, K, sl.keys);
+    HIP_TRY(hipGetLastError());
   } else if (p->total_keys > 0) {
+    sl.host_keys.clear();
     hipLaunchKernelGGL(k_keygen, dim3(1), dim3(1), 0, s, key_hi, key_lo, p->total_keys, sl.keys);
     HIP_TRY(hipGetLastError());
   }
@@ -779,7 +796,7 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
                        ((unsigned long long)shot_offset >> 32) == ((unsigned long long)(shot_offset + B - 1) >> 32);
     if (gen1) {
       long long cap1 = 0;
-      if (int r = gen_one(p, a, B, num_f, key_hi, key_lo, shot_offset, l.hard_index, l.ctl, l.ctl_next, n_lists, has_check, &cap1, s)) return r;
+      if (int r = gen_one(p, sl, a, B, num_f, key_hi, key_lo, shot_offset, l.hard_index, l.ctl, l.ctl_next, n_lists, has_check, &cap1, s)) return r;
       if ((size_t)cap1 * n_lists * 4 > sl.hard_sz) return tsim_fail(TSIM_ESTATE, "hard-row list too small");
       l.list_cap = (int)cap1;
     } else if (fast1) {

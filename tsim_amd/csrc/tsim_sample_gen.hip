@@ -71,9 +71,13 @@ static int gen_launch(tsim_program *p, const GenArgs &G, const GenLayout &L, lon
   return 0;
 }
 // the subkeys of one batch as k_sample_gen wants them: the inline copy, or the chain of splits (sampler.py:399's key schedule)
-static void gen_step_keys(const tsim_program *p, const SampleArgs &a, uint32_t k0, uint32_t k1, uint32_t *stkeys) {
+static void gen_step_keys(const tsim_program *p, const tsim_program::Slot &sl, const SampleArgs &a, uint32_t k0, uint32_t k1, uint32_t *stkeys) {
   if (p->total_keys <= TSIMK_INLINE_KEYS) {
     memcpy(stkeys, a.inline_keys, sizeof(uint32_t) * 2 * (size_t)p->total_keys);
+    return;
+  }
+  if (sl.host_keys.size() == 2 * (size_t)p->total_keys) {  // (fill_sample_args has just computed them)
+    memcpy(stkeys, sl.host_keys.data(), sizeof(uint32_t) * 2 * (size_t)p->total_keys);
     return;
   }
   for (int i = 0; i < p->total_keys; ++i) {  // (the hard-row kernels read the k_keygen buffer; this pass wants the subkeys in its arguments)
@@ -114,7 +118,7 @@ static long long gen_grid(const tsim_program *p, const GenLayout &L, long long c
 // The serial API (tsim_sample_batch*, the seam of backend.sample_program) on a program whose tables only k_sample_gen reads
 // (prefix trees, narrow_big): the same first pass as a group of ONE batch on the caller's stream, with the subkey as given.
 // launch_sample goes on with the hard-row lists this leaves (list geometry as in steps_group_gen).
-int gen_one(tsim_program *p, const SampleArgs &a, int64_t B, int32_t num_f, uint32_t key_hi, uint32_t key_lo, int64_t shot_offset,
+int gen_one(tsim_program *p, const tsim_program::Slot &sl, const SampleArgs &a, int64_t B, int32_t num_f, uint32_t key_hi, uint32_t key_lo, int64_t shot_offset,
             uint32_t *hard_index, uint32_t *ctl, uint32_t *ctl_next, int n_lists, bool has_check, long long *list_cap_out, hipStream_t s) {
   const int WF = std::max(1, (num_f + 63) / 64);
   const GenLayout L = gen_layout(p, 2 * WF, 1);
@@ -132,7 +136,7 @@ int gen_one(tsim_program *p, const SampleArgs &a, int64_t B, int32_t num_f, uint
   st.hard_index = hard_index;
   st.ctl = ctl;
   st.ctl_next = ctl_next;
-  gen_step_keys(p, a, key_hi, key_lo, G.keys);
+  gen_step_keys(p, sl, a, key_hi, key_lo, G.keys);
   ++p->path_count[TP_GEN];
   if (int r = gen_launch(p, G, L, gen_grid(p, L, G.chunks_per_step), s)) return r;
   HIP_TRY(hipGetLastError());
@@ -195,7 +199,7 @@ int steps_group_gen(tsim_program *p, int n, const uint64_t *const *d_f, int64_t 
     st.ctl = ctl;
     st.ctl_next = sl.ctl + (sl.parity ^ 1) * (TSIMK_LW_LISTS + 1) * 32;
     sl.parity ^= 1;
-    gen_step_keys(p, a, o[2], o[3], G.keys + 2 * (size_t)j * (size_t)p->total_keys);
+    gen_step_keys(p, sl, a, o[2], o[3], G.keys + 2 * (size_t)j * (size_t)p->total_keys);
     a.row_index = st.hard_index;
     a.row_count = ctl;
     a.row_lists = n_lists;

@@ -91,7 +91,7 @@ int steps_group_wide(tsim_program *p, int n, const uint64_t *const *d_f, int64_t
 #define TSIMK_GEN_KEYS 320     // subkey records per launch of k_sample_gen: batches x compiled outputs (tsim_gen.hip.h)
 #endif
 bool gen_applies(const tsim_program *p, int64_t B, int32_t num_f, int64_t shot_offset);
-int gen_one(tsim_program *p, const SampleArgs &a, int64_t B, int32_t num_f, uint32_t key_hi, uint32_t key_lo, int64_t shot_offset,
+int gen_one(tsim_program *p, const tsim_program::Slot &sl, const SampleArgs &a, int64_t B, int32_t num_f, uint32_t key_hi, uint32_t key_lo, int64_t shot_offset,
             uint32_t *hard_index, uint32_t *ctl, uint32_t *ctl_next, int n_lists, bool has_check, long long *list_cap_out, hipStream_t s);
 int steps_group_gen(tsim_program *p, int n, const uint64_t *const *d_f, int64_t B, int32_t num_f, uint32_t key[2],
                     int64_t shot_offset, void *const *d_out, float *const *d_dev, uint32_t flags, const LaunchPlan &plan);

@@ -1,6 +1,6 @@
 #!/bin/bash
 # The measurements behind profiles/r06 (run on the GPU box through gpurun; results under gpurun_out/r06/).
-# usage: scripts/r06_profiles.sh [bench] [approx] [rocprof] [pmc] [noise] [shape] [classes] [cold] [legs] [tests] [fuzz]   (default: all)
+# usage: scripts/r06_profiles.sh [bench] [approx] [rocprof] [pmc] [noise] [shape] [classes] [cold] [seam] [legs] [tests] [fuzz]   (default: all)
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r06; mkdir -p $O
 cd $R
 WHAT=" ${*:-all} "
@@ -65,7 +65,7 @@ if want shape; then
 fi
 if want classes; then  # kernel stats of the classes round 6 added (which kernel serves them, how long a launch takes)
   cd /tmp && export TMPDIR=/tmp
-  for c in n13 n16 n24 n40 20narrow w12 9wide F600; do
+  for c in n13 n16 n24 n40 20narrow w12 9wide F600 F140; do
     rm -rf /tmp/ksc_$c
     timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ksc_$c -- python $R/scripts/shape_map.py --classes $c --no-base > /tmp/ksc_$c.txt 2>/dev/null
     f=$(find /tmp/ksc_$c -name "*kernel_stats.csv" | head -1)
@@ -75,6 +75,12 @@ if want classes; then  # kernel stats of the classes round 6 added (which kernel
 fi
 if want cold; then
   python scripts/time_to_n.py > $O/time_to_n.txt 2>&1
+  # where a fresh handle's time goes (marks of tsim_program_finalize; the third handle of each configuration is the settled one)
+  TSIM_AMD_DEBUG=finalize python scripts/cold_probe.py C4 C2 2>&1 | sed -e 's/ (image.*//' > $O/cold_breakdown.txt
+fi
+if want seam; then  # the one-batch API (backend.sample_program's seam) on programs whose tables only k_sample_gen reads: before / after
+  { for t in "gen=0" ""; do echo "== TSIM_AMD_TUNE='$t'"; TSIM_AMD_TUNE=$t python scripts/one_batch_probe.py n16 n24 n40 F70 2>&1 | grep "one-batch"; done; } > $O/one_batch_api.txt 2>&1
+  scripts/pmc_shape.sh gen20 k_sample_gen 20narrow > /dev/null 2>&1; cp $R/gpurun_out/r05/pmc_gen20.txt $O/pmc_gen_20narrow.txt
 fi
 if want legs; then
   { for c in C3 C4 C5; do echo "== $c"; q --config $c --steps 100; done; echo "== C4, 1e5 shots per step"; q --config C4 --shots 100000 --steps 100;

@@ -611,49 +611,59 @@ bool pack_level_fast(HostLevel &h, int W, std::vector<uint32_t> &tables, bool &f
     }
     if (total >= 2147483000.0L) fixed = false;
   }
-  for (int g = 0; g < G; ++g) {
-    uint32_t *rec = &h.graph_rec[(size_t)g * G_WORDS];
-    rec[GF_TBL] = (uint32_t)tables.size();
-    if (fixed) {
-      // fixed-frame levels: an entry is 16 words = the value times i^r for r = 0..3 (4 words each),
-      // pre-shifted to the frame power, so the kernel adds the selected rotation without any
-      // per-lane rotate/shift.  Entry 0 is the exact zero.
-      for (int j = 0; j < 16; ++j) tables.push_back(0u);
-      for (auto &e : entries[g]) {
-        const bool nz = (e.c[0] | e.c[1] | e.c[2] | e.c[3]) != 0;
-        const int sh = nz ? e.p - frame : 0;
-        long long v[4] = {e.c[0] * (1ll << sh), e.c[1] * (1ll << sh), e.c[2] * (1ll << sh), e.c[3] * (1ll << sh)};
-        for (int r = 0; r < 4; ++r) {
-          for (int j = 0; j < 4; ++j) tables.push_back((uint32_t)(int32_t)v[j]);
-          const long long t[4] = {-v[2], v[3], v[0], -v[1]};  // times i: (a,b,c,d) -> (-c, d, a, -b)
-          for (int j = 0; j < 4; ++j) v[j] = t[j];
+  // the tables, graph by graph through the pool into their places (the sizes are known now): one thread pushing a level's words
+  // one at a time - 630 000 for C4's level of 256 graphs - was most of that level's 1.5 ms
+  {
+    std::vector<size_t> off_main((size_t)G + 1, 0), off_d((size_t)G + 1, 0);
+    for (int g = 0; g < G; ++g) off_main[(size_t)g + 1] = off_main[(size_t)g] + (fixed ? 16 : 8) * (1 + entries[(size_t)g].size());
+    for (int g = 0; g < G; ++g) off_d[(size_t)g + 1] = off_d[(size_t)g] + 8 * dentries[(size_t)g].size();
+    const size_t d_base = off_main[(size_t)G];
+    tables.assign(d_base + off_d[(size_t)G], 0u);
+    std::atomic<bool> overflow{false};
+    tsim_parallel_for((size_t)G, G >= 128 ? 16 : (G >= 32 ? 8 : (G >= 8 ? 2 : 1)), [&](size_t gs) {
+      const int g = (int)gs;
+      uint32_t *rec = &h.graph_rec[(size_t)g * G_WORDS];
+      rec[GF_TBL] = (uint32_t)off_main[gs];
+      uint32_t *t = &tables[off_main[gs]];
+      if (fixed) {
+        // fixed-frame levels: an entry is 16 words = the value times i^r for r = 0..3 (4 words each),
+        // pre-shifted to the frame power, so the kernel adds the selected rotation without any
+        // per-lane rotate/shift.  Entry 0 is the exact zero.
+        t += 16;
+        for (auto &e : entries[gs]) {
+          const bool nz = (e.c[0] | e.c[1] | e.c[2] | e.c[3]) != 0;
+          const int sh = nz ? e.p - frame : 0;
+          long long v[4] = {e.c[0] * (1ll << sh), e.c[1] * (1ll << sh), e.c[2] * (1ll << sh), e.c[3] * (1ll << sh)};
+          for (int r = 0; r < 4; ++r) {
+            for (int j = 0; j < 4; ++j) *t++ = (uint32_t)(int32_t)v[j];
+            const long long tt[4] = {-v[2], v[3], v[0], -v[1]};  // times i: (a,b,c,d) -> (-c, d, a, -b)
+            for (int j = 0; j < 4; ++j) v[j] = tt[j];
+          }
+        }
+      } else {
+        t[4] = (uint32_t)(h.approx ? 0 : TSIMK_ZERO_POWER);  // entry 0: exact zero
+        t += 8;
+        for (auto &e : entries[gs]) {
+          for (int j = 0; j < 4; ++j) t[j] = (uint32_t)(int32_t)e.c[j];
+          t[4] = (uint32_t)e.p;
+          t += 8;
         }
       }
-    } else {
-      for (int j = 0; j < 4; ++j) tables.push_back(0u);  // entry 0: exact zero
-      tables.push_back((uint32_t)(h.approx ? 0 : TSIMK_ZERO_POWER));
-      tables.push_back(0u); tables.push_back(0u); tables.push_back(0u);
-      for (auto &e : entries[g]) {
-        for (int j = 0; j < 4; ++j) tables.push_back((uint32_t)(int32_t)e.c[j]);
-        tables.push_back((uint32_t)e.p);
-        tables.push_back(0u); tables.push_back(0u); tables.push_back(0u);
+      if (dentries[gs].empty()) return;
+      rec[GF_TBL2] = (uint32_t)(d_base + off_d[gs]);
+      uint32_t *d2 = &tables[d_base + off_d[gs]];
+      for (auto &e : dentries[gs]) {
+        const int sh = fixed ? e.p : 0;
+        for (int j = 0; j < 4; ++j) {
+          const long long v = e.c[j] * (1ll << sh);
+          if (v > INT32_MAX || v < INT32_MIN) overflow.store(true);
+          d2[j] = (uint32_t)(int32_t)v;
+        }
+        d2[4] = (uint32_t)(fixed ? 0 : e.p);
+        d2 += 8;
       }
-    }
-  }
-  for (int g = 0; g < G; ++g) {
-    if (dentries[g].empty()) continue;
-    uint32_t *rec = &h.graph_rec[(size_t)g * G_WORDS];
-    rec[GF_TBL2] = (uint32_t)tables.size();
-    for (auto &e : dentries[g]) {
-      const int sh = fixed ? e.p : 0;
-      for (int j = 0; j < 4; ++j) {
-        const long long v = e.c[j] * (1ll << sh);
-        if (v > INT32_MAX || v < INT32_MIN) return false;
-        tables.push_back((uint32_t)(int32_t)v);
-      }
-      tables.push_back((uint32_t)(fixed ? 0 : e.p));
-      tables.push_back(0u); tables.push_back(0u); tables.push_back(0u);
-    }
+    });
+    if (overflow.load()) return false;
   }
   if (tsim_debug("pack"))
     fprintf(stderr, "[tsim] pack_level_fast G=%d P=%d: %.2f ms wall; per-graph sums: terms -> forms %.2f ms, finish + Dickson %.2f ms, rows + table entries %.2f ms\n", G, P,

@@ -206,7 +206,7 @@ static int tables_build_at(tsim_program *p, int rec_off, const TsimTablePlan &t,
     a.comp_off = p->comp_off + (int)ci * C_WORDS;
     a.npat = (int)t.npat[ci];
     a.p1 = reinterpret_cast<float *>(sbase + soff[ci]);
-    a.depth = -1;
+    a.depth = wait ? -2 : -1;  // (-2: all nodes of the trees in one launch - nothing of this handle runs beside a build that is waited for)
     a.pat_begin = 0;
     a.pat_count = 0;
     a.trie = c.trie ? 1 : 0;

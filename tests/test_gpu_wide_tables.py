@@ -141,6 +141,56 @@ def test_table_swap_under_launches_on_a_caller_stream(hip):
     hp.close(); other.close()
 
 
+def test_table_swap_after_the_caller_destroyed_its_stream(hip):
+    """the swap must not touch a caller stream's handle again - the caller may have destroyed it.  The handle records
+    an event of its own behind every launch on a foreign stream and the swap waits for that.  A raw ``hipStream_t`` made and
+    destroyed here through libamdhip64 carries the launches of a fresh C5 handle; the swap to weight 4 happens afterwards."""
+    import ctypes as C
+    import time
+
+    prog, cfg = synth.config_program("C5")
+    nf = cfg["num_f"]
+    orc = OC.OracleProgram(prog)
+    hp = hip.HipProgram(prog)
+    # the HIP runtime the library itself is linked to (another copy of libamdhip64 in the process would hand out streams of ITS own)
+    with open("/proc/self/maps") as f:
+        paths = sorted({ln.split()[-1] for ln in f if "libamdhip64" in ln})
+    assert paths, "libamdhip64 is not mapped"
+    rt = C.CDLL(paths[0])
+    B, wf, wo = 6000, (nf + 63) // 64, (prog.num_outputs + 63) // 64
+    d_f, d_o = hp.malloc(B * wf * 8), hp.malloc(B * wo * 8)
+
+    def run(i, stream):
+        f = synth.synth_f(B, nf, cfg["p_bit"], seed=400 + i)
+        fp = np.packbits(f, axis=1, bitorder="little")
+        hp.h2d(d_f, np.ascontiguousarray(np.pad(fp, ((0, 0), (0, wf * 8 - fp.shape[1])))))
+        hp.sample_batch_device(d_f.ptr, B, nf, (i, 3), d_o.ptr, stream=stream)
+        if stream:
+            assert rt.hipStreamSynchronize(C.c_void_p(stream)) == 0
+        else:
+            hp.synchronize()
+        raw = np.zeros((B, wo * 8), np.uint8)
+        hp.d2h(raw, d_o)
+        got = np.unpackbits(raw, axis=1, bitorder="little")[:, : prog.num_outputs]
+        np.testing.assert_array_equal(got, orc.sample_program(f, (i, 3)), err_msg=f"call {i}")
+
+    st = C.c_void_p()
+    assert rt.hipStreamCreate(C.byref(st)) == 0
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for i in range(3):
+            run(i, st.value)
+        assert rt.hipStreamDestroy(st) == 0  # gone before the deeper tables arrive
+        t0 = time.perf_counter()
+        i = 3
+        while (hp.info()["pattern_build_pending"] or i < 6) and time.perf_counter() - t0 < 30.0:
+            run(i, 0)
+            i += 1
+    assert hp.info()["pattern_max_weight"] == [4], hp.info()
+    d_f.free(); d_o.free()
+    hp.close()
+
+
 def _tuned_program(hip, prog, tune, monkeypatch, **kw):
     if tune:
         monkeypatch.setenv("TSIM_AMD_TUNE", tune)

@@ -193,8 +193,11 @@ struct tsim_program {
   bool wide_big = false;      // wide program with f indices >= 512: the round-2 wide kernels (16 selection-mask words) must not see it
   std::vector<int> wr_offs;   // one wide record per component (the passes of k_sample_wide, in component order)
   // streams of the CALLER that carried sampling launches of this handle (the device entry points take one): what a table swap
-  // must drain besides the handle's own lanes.  More than 16 distinct ones: caller_streams_overflow, the swap drains the device.
-  std::vector<hipStream_t> caller_streams;
+  // must wait for besides the handle's own lanes - through an EVENT of the handle's, recorded behind every such launch: the stream
+  // handle itself is never used again (the caller may have destroyed it, its address may be another stream's by then: ADVICE r05).
+  // More than 16 distinct ones: caller_streams_overflow, the swap drains the device.
+  struct CallerStream { hipStream_t s; hipEvent_t ev; };
+  std::vector<CallerStream> caller_streams;
   bool caller_streams_overflow = false;
   int gr_off = 0;             // image offset of the gen record (any narrow program: k_sample_gen, tsim_gen.hip.h), 0 = none
   int lwf_off = 0;            // image offset of the fast record (one component of <= 8 outputs: k_sample_lw_fast), 0 = none

@@ -1423,6 +1423,7 @@ extern "C" void tsim_program_destroy(tsim_program *p) {
               p->stat_begins, p->stat_deferred, p->stat_flushes, p->stat_queries, p->stat_waits, p->stat_fused, p->stat_fast, p->stat_partial);
     if (p->sync_ev) (void)hipEventDestroy(p->sync_ev);
     for (hipEvent_t e : p->lane_ev) if (e) (void)hipEventDestroy(e);
+    for (auto &cs : p->caller_streams) if (cs.ev) (void)hipEventDestroy(cs.ev);
     for (hipEvent_t e : p->over_ev) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : p->batch_ev) if (e) (void)hipEventDestroy(e);
     for (void *s : p->scratch)

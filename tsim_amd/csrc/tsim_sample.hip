@@ -612,14 +612,10 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
                          int slot = 0, const LaunchPlan *plan_in = nullptr, bool out_bit_packed = false) {
   if (!p->sampleable) return tsim_fail(TSIM_ESTATE, "program has joint-mode components (evaluate-only)");
   if (B < 0 || num_f < 0 || shot_offset < 0) return tsim_fail(TSIM_EINVAL, "negative B/num_f/shot_offset");
-  {  // a stream that is not the handle's own: the caller's - a table swap has to drain it too (tsim_tables_extend_poll)
-    bool own = s == p->stream || s == p->ext_stream;
-    for (int k = 1; k <= TSIM_PIPELINE_SLOTS && !own; ++k) own = p->slots[k].side_ready && p->slots[k].side == s;
-    if (!own && std::find(p->caller_streams.begin(), p->caller_streams.end(), s) == p->caller_streams.end()) {
-      if (p->caller_streams.size() < 16) p->caller_streams.push_back(s);
-      else p->caller_streams_overflow = true;
-    }
-  }
+  // a stream that is not the handle's own: the caller's - a table swap has to wait for what it carries too (tsim_tables_extend_poll):
+  // an event of the handle's is recorded behind this launch's last kernel (finish)
+  bool foreign = !(s == p->stream || s == p->ext_stream);
+  for (int k = 1; k <= TSIM_PIPELINE_SLOTS && foreign; ++k) foreign = !(p->slots[k].side_ready && p->slots[k].side == s);
   if (p->max_f_index >= num_f)
     return tsim_fail(TSIM_EINVAL, "program references f index %d but num_f=%d", p->max_f_index, num_f);
   if (B == 0 || p->num_outputs == 0) return 0;
@@ -648,6 +644,17 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
   long long B2 = B;  // slots per row list of the full kernel's launch
   const bool pipelined = slot > 0;  // lane launch: the caller passed the slot's own stream as `s`
   auto finish = [&]() -> int {
+    if (foreign) {  // (looked up HERE: the launch plan drawn above may have swapped tables and dropped the events noted so far)
+      hipEvent_t ev = nullptr;
+      for (auto &cs : p->caller_streams)
+        if (cs.s == s) ev = cs.ev;
+      if (!ev && p->caller_streams.size() < 16) {
+        HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        p->caller_streams.push_back({s, ev});
+      }
+      if (ev) HIP_TRY(hipEventRecord(ev, s));
+      else p->caller_streams_overflow = true;
+    }
     if (pipelined) {
       HIP_TRY(hipEventRecord(sl.ev2, s));
       sl.pending = true;

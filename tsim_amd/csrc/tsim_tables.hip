@@ -504,12 +504,13 @@ int tsim_tables_extend_poll(tsim_program *p, bool wait) {
       tsim_program::Slot &sl = p->slots[k];
       if (sl.side_ready && sl.side && sl.side != p->stream) HIP_TRY(hipStreamSynchronize(sl.side));
     }
-    bool gone = false;  // (a caller may have destroyed its stream since: HIP refuses the handle - then the device-wide drain)
-    for (hipStream_t cs : p->caller_streams)
-      if (hipStreamSynchronize(cs) != hipSuccess) { (void)hipGetLastError(); gone = true; }
+    bool gone = false;  // (the handle's own event behind the last launch on each caller stream - never the stream itself)
+    for (auto &cs : p->caller_streams)
+      if (hipEventSynchronize(cs.ev) != hipSuccess) { (void)hipGetLastError(); gone = true; }
     if (p->ext_stream) HIP_TRY(hipStreamSynchronize(p->ext_stream));
     if (gone) HIP_TRY(hipDeviceSynchronize());
   }
+  for (auto &cs : p->caller_streams) (void)hipEventDestroy(cs.ev);
   p->caller_streams.clear();  // (noted again by the launches that use them)
   p->caller_streams_overflow = false;
   for (size_t ci = 0; ci < p->comps.size(); ++ci) {

@@ -597,3 +597,35 @@ def test_a_handle_destroyed_during_the_background_build(hip):
         for i in range(calls):
             hp.sample_batch(synth.synth_f(500, cfg["num_f"], 0.02, seed=i), (i, 1))
         hp.close()
+
+
+@pytest.mark.parametrize("name", ["C2", "C3", "C4", "F60", "F70", "n9", "6narrow"])
+def test_chunk_table_builder_equals_row_builder(hip, name, monkeypatch):
+    """The finalize build of the pattern tables runs on the LDS chunk tables where the program has them (csrc/tsim_build4.hip);
+    ``TSIM_AMD_TABLE_BUILD=rows`` keeps the row formulation's builder.  Same thresholds: the same bytes for batches that the
+    tables serve (and the oracle's), at a pinned depth so that no background build interferes."""
+    from oracle import oracle_c as OC
+    from tsim_amd import synth
+
+    if name in ("C2", "C3", "C4"):
+        prog, cfg = synth.config_program(name)
+    else:
+        prog, cfg = synth.shape_class_program(name)
+    nf = cfg["num_f"]
+    B = 20000
+    f = synth.synth_f(B, nf, cfg["p_bit"], seed=77)
+    outs = []
+    for build in ("rows", ""):
+        if build:
+            monkeypatch.setenv("TSIM_AMD_TABLE_BUILD", build)
+        else:
+            monkeypatch.delenv("TSIM_AMD_TABLE_BUILD", raising=False)
+        hp = hip.HipProgram(prog, pattern_tables=3)
+        hp.path_counts(reset=True)
+        out, dev = hp.sample_batch(f, (5, 9))
+        outs.append((np.asarray(out), np.asarray(dev), hp.path_counts()))
+        hp.close()
+    np.testing.assert_array_equal(outs[0][0], outs[1][0])
+    np.testing.assert_array_equal(outs[0][1], outs[1][1])
+    want = OC.OracleProgram(prog).sample_program(f, (5, 9))
+    np.testing.assert_array_equal(outs[1][0], want)

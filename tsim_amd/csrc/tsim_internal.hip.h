@@ -331,6 +331,7 @@ struct tsim_program {
   long long ext_entries = 1ll << 21;    // table entries per slice
   std::thread ext_thread;              // allocates the new table and the build scratch (hipMalloc of GBs: up to 30 ms)
   std::atomic<int> ext_alloc{0};       // 0: running, 1: buffers allocated (the launch plans drive the slices), 2: built by the thread, -1: failed
+  std::atomic<bool> first_call_out{false};  // a sampling call of this handle has been enqueued (the shallow start's helper thread waits for it, briefly)
   bool ext_self = false;               // this build is driven by the helper thread (the shallow start's default depth)
   std::atomic<bool> ext_abort{false};  // destroy: stop between slices
   hipStream_t ext_stream = nullptr;    // the thread's stream (pooled)
@@ -397,6 +398,7 @@ int tsim_flush_hard(tsim_program *p);
 int tsim_launch_rows(tsim_program *p, int wmax, const tsimk::SampleArgs &a, long long grid, int block, size_t lds,
                      hipStream_t s);
 int tsim_launch_lw_build(int W, bool fast, const tsimk::LwBuildArgs &a, int n_out, hipStream_t s);
+int tsim_launch_lw_build4(tsim_program *p, int ci, const tsimk::LwBuildArgs &a, int n_out, hipStream_t s);  // tsim_build4.hip: on the chunk tables
 namespace tsimrows {
 int sample_fast(int wmax, const tsimk::SampleArgs &a, long long grid, int block, size_t lds, hipStream_t s);
 int sample_faithful(int wmax, const tsimk::SampleArgs &a, long long grid, int block, size_t lds, hipStream_t s);

@@ -644,6 +644,7 @@ static int launch_sample(tsim_program *p, const uint64_t *d_f, int64_t B, int32_
   long long B2 = B;  // slots per row list of the full kernel's launch
   const bool pipelined = slot > 0;  // lane launch: the caller passed the slot's own stream as `s`
   auto finish = [&]() -> int {
+    if (!pipelined) p->first_call_out.store(true, std::memory_order_release);
     if (foreign) {  // (looked up HERE: the launch plan drawn above may have swapped tables and dropped the events noted so far)
       hipEvent_t ev = nullptr;
       for (auto &cs : p->caller_streams)
@@ -1538,6 +1539,7 @@ extern "C" int tsim_sample_steps_device(tsim_program *p, int32_t n_steps, const 
   TSIM_MARK("end");
   marks.print();
   g_marks = nullptr;
+  p->first_call_out.store(true, std::memory_order_release);
   return rfl;
 }
 

@@ -139,6 +139,17 @@ static void enumerate_patterns(int F, int wmax, std::vector<unsigned long long> 
   }
 }
 
+// One slice of a component's dense tables: on the LDS chunk tables when the program has them (tsim_build4.hip: a 16-byte LDS read
+// per 4-bit chunk of x and graph instead of the row kernel's walk over every parameter row), else the row formulation.
+// TSIM_AMD_TABLE_BUILD=rows: always the latter (tests compare the two builders' tables word for word).
+static int launch_table_build(tsim_program *p, int W, const tsimk::LwBuildArgs &a, int n_out, hipStream_t s) {
+  const char *e = getenv("TSIM_AMD_TABLE_BUILD");  // (read per build: the tests switch it inside one process)
+  const bool rows_only = e && strcmp(e, "rows") == 0;
+  if (p->v4 && p->fast && !a.trie && !rows_only && p->v4_max_nch > 0)
+    return tsim_launch_lw_build4(p, (a.comp_off - p->comp_off) / C_WORDS, a, n_out, s);
+  return tsim_launch_lw_build(W, p->fast, a, n_out, s);
+}
+
 // The prefix trees of one component, slice after slice of patterns in table order (weight by weight), each slice built to
 // its full depth and waited for before the next goes out: when the budget runs out inside a slice, the patterns before
 // that slice are complete and the first pass is told so (LW_NPAT_OK: a row whose pattern lies beyond is a hard row before
@@ -219,7 +230,7 @@ static int tables_build_at(tsim_program *p, int rec_off, const TsimTablePlan &t,
       p->img[(size_t)rec_off + ci * LW_WORDS + LW_NPAT_OK] = v;
       if (r == 0) e = hipMemcpy(p->d_img + rec_off + ci * LW_WORDS + LW_NPAT_OK, &v, 4, hipMemcpyHostToDevice);
     } else {
-      r = tsim_launch_lw_build(p->comp_w[ci], p->fast, a, c.n_out, s);
+      r = launch_table_build(p, p->comp_w[ci], a, c.n_out, s);
     }
   }
   if (r == 0 && e == hipSuccess && wait) e = hipStreamSynchronize(s);
@@ -274,6 +285,12 @@ int tsim_tables_build(tsim_program *p, uint32_t **old) {
 static void ext_alloc_thread(tsim_program *p) {
   int state = 1;
   if (hipSetDevice(p->device) != hipSuccess) state = -1;
+  // The shallow start's build: let the handle's FIRST sampling call go out first (at most 3 ms).  The allocations below - twice
+  // the table, hundreds of MB - hold the runtime's lock for milliseconds, and a first call that met them took 10-20 ms instead
+  // of 0.03 to enqueue (C3 fresh handle + 10^6 shots: 1.5 or 19 ms by the luck of the timing).
+  if (p->ext_self)
+    for (int i = 0; i < 30 && !p->first_call_out.load(std::memory_order_acquire) && !p->ext_abort.load(std::memory_order_acquire); ++i)
+      std::this_thread::sleep_for(std::chrono::microseconds(100));
   uint32_t *tab = nullptr;
   {
     // the new table and its scratch (node values: as many floats again) live next to the old table until the swap; a caller
@@ -356,7 +373,7 @@ static void ext_alloc_thread(tsim_program *p) {
         tsimk::LwBuildArgs a = j.a;
         a.pat_begin = (int)j.next_pat;
         a.pat_count = (int)std::min<long long>(per, (long long)a.npat - j.next_pat);
-        if (tsim_launch_lw_build(j.W, p->fast, a, j.n_out, bs) != 0 || hipStreamSynchronize(bs) != hipSuccess) { state = -1; break; }
+        if (launch_table_build(p, j.W, a, j.n_out, bs) != 0 || hipStreamSynchronize(bs) != hipSuccess) { state = -1; break; }
         j.next_pat += a.pat_count;
         ++p->ext_slices;
       }
@@ -431,7 +448,7 @@ int tsim_tables_slice(tsim_program *p, hipStream_t s) {
   const long long per = std::max<long long>(1, j.a.trie ? p->ext_entries >> 9 : p->ext_entries >> j.n_out);
   a.pat_begin = (int)j.next_pat;
   a.pat_count = (int)std::min<long long>(per, (long long)a.npat - j.next_pat);
-  if (int r = tsim_launch_lw_build(j.W, p->fast, a, j.n_out, s)) return r;
+  if (int r = launch_table_build(p, j.W, a, j.n_out, s)) return r;
   ++p->ext_slices;
   j.next_pat += a.pat_count;
   if (j.next_pat >= (long long)a.npat) ++p->ext_job;

@@ -599,11 +599,12 @@ def test_a_handle_destroyed_during_the_background_build(hip):
         hp.close()
 
 
-@pytest.mark.parametrize("name", ["C2", "C3", "C4", "F60", "F70", "n9", "6narrow"])
+@pytest.mark.parametrize("name", ["C2", "C3", "C4", "F60", "F70", "n9", "6narrow", "n13", "n16"])
 def test_chunk_table_builder_equals_row_builder(hip, name, monkeypatch):
     """The finalize build of the pattern tables runs on the LDS chunk tables where the program has them (csrc/tsim_build4.hip);
     ``TSIM_AMD_TABLE_BUILD=rows`` keeps the row formulation's builder.  Same thresholds: the same bytes for batches that the
-    tables serve (and the oracle's), at a pinned depth so that no background build interferes."""
+    tables serve (and the oracle's), at a pinned depth so that no background build interferes.  n13 / n16: prefix-tree tables,
+    whose node pass takes the same route (k_trie_nodes4)."""
     from oracle import oracle_c as OC
     from tsim_amd import synth
 

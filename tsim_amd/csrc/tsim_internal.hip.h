@@ -398,6 +398,7 @@ int tsim_flush_hard(tsim_program *p);
 int tsim_launch_rows(tsim_program *p, int wmax, const tsimk::SampleArgs &a, long long grid, int block, size_t lds,
                      hipStream_t s);
 int tsim_launch_lw_build(int W, bool fast, const tsimk::LwBuildArgs &a, int n_out, hipStream_t s);
+int tsim_launch_trie_nodes4(const tsimk::LwBuildArgs &a, unsigned grid, hipStream_t s);  // tsim_build4.hip: k_trie_nodes on the chunk tables (a.comp4 != 0)
 int tsim_launch_lw_build4(tsim_program *p, int ci, const tsimk::LwBuildArgs &a, int n_out, hipStream_t s);  // tsim_build4.hip: on the chunk tables
 namespace tsimrows {
 int sample_fast(int wmax, const tsimk::SampleArgs &a, long long grid, int block, size_t lds, hipStream_t s);

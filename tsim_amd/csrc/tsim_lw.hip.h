@@ -102,6 +102,7 @@ struct LwBuildArgs {
   int trie;                           // 1: build that format
   int trie_level;                     // chunk level of this launch (outputs 3 L .. 3 L + 2)
   uint32_t trie_cap;                  // chunks the table holds
+  int comp4, nch;                     // the component's chunk-table record (C4_*) and the chunks per tile, 0 = none: the prefix-tree nodes on the LDS chunk tables (tsim_build4.hip)
 };
 
 // the pattern of table row `pat` as f_sel-position bits

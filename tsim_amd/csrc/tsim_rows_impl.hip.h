@@ -62,6 +62,10 @@ static int TSIM_ROWS_NAME(trie_build)(int W, const LwBuildArgs &a0, int n_out, h
       a.depth = d;
       const long long lanes = roots << (d < 0 ? 0 : d);
       const unsigned grid = L == 0 ? (unsigned)std::min<long long>((lanes + 255) / 256, 8192) : 2048u;
+      if (a.comp4 != 0 && TSIM_ROWS_FAST) {  // (the program has chunk tables: the same nodes through eval_level4)
+        if (int r = tsim_launch_trie_nodes4(a, grid, s)) return r;
+        continue;
+      }
       switch (W) {
 #define TSIM_X(WV)                                                                                 \
   case WV:                                                                                         \

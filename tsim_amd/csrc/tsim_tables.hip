@@ -139,6 +139,12 @@ static void enumerate_patterns(int F, int wmax, std::vector<unsigned long long> 
   }
 }
 
+// (the prefix-tree builder's node kernel on the chunk tables too: tsim_build4.hip, k_trie_nodes4)
+static bool trie_on_chunk_tables(const tsim_program *p) {
+  const char *e = getenv("TSIM_AMD_TABLE_BUILD");
+  return p->v4 && p->fast && p->v4_max_nch > 0 && !(e && strcmp(e, "rows") == 0);
+}
+
 // One slice of a component's dense tables: on the LDS chunk tables when the program has them (tsim_build4.hip: a 16-byte LDS read
 // per 4-bit chunk of x and graph instead of the row kernel's walk over every parameter row), else the row formulation.
 // TSIM_AMD_TABLE_BUILD=rows: always the latter (tests compare the two builders' tables word for word).
@@ -223,6 +229,8 @@ static int tables_build_at(tsim_program *p, int rec_off, const TsimTablePlan &t,
     a.trie = c.trie ? 1 : 0;
     a.trie_level = 0;
     a.trie_cap = (uint32_t)t.chunks[ci];
+    a.comp4 = trie_on_chunk_tables(p) ? p->comp4_off + (int)ci * C4_WORDS : 0;
+    a.nch = p->v4_max_nch;
     if (c.trie) {
       long long okp = 0;
       r = trie_build_sync(p, a, p->comp_w[ci], c.n_out, s, nullptr, &okp, nullptr);
@@ -327,6 +335,8 @@ static void ext_alloc_thread(tsim_program *p) {
     a.trie = c.trie ? 1 : 0;
     a.trie_level = 0;
     a.trie_cap = (uint32_t)p->ext_plan.chunks[ci];
+    a.comp4 = trie_on_chunk_tables(p) ? p->comp4_off + (int)ci * C4_WORDS : 0;
+    a.nch = p->v4_max_nch;
     p->ext_jobs.push_back(TsimBuildJob{a, p->comp_w[ci], c.n_out, 0});
   }
   if (state < 0) {

@@ -891,7 +891,7 @@ def main() -> None:
         pmc = load_pmc(args.config, B)
         # the PMC summary is per BATCH of B shots (scripts/summarize_pmc.py); `achieved` is per launch of batches_per_launch batches
         traffic = (2.0 * float(pmc["FETCH_SIZE"]) + float(pmc["WRITE_SIZE"])) * 1024.0 * batches_per_launch if pmc and "FETCH_SIZE" in pmc else None
-        traffic_note = ("profiles/latest_pmc.json (= profiles/r05/pmc.json, scripts/pmc_top.py): rocprofv3 PMC of the driver's command, one counter per pass, "
+        traffic_note = ("profiles/latest_pmc.json (= profiles/r06/pmc.json, scripts/pmc_top.py): rocprofv3 PMC of the driver's command, one counter per pass, "
                         f"mean of the two largest invocations of the first pass and of its hard-row grid ({pmc.get('_batches_per_launch', '?')} batches per launch, "
                         "--nf 64: f read from HBM), per batch, x this line's batches per launch") if traffic is not None else "no committed PMC summary for this workload"
         if traffic is not None and traffic < 0.98 * bytes_per_shot * B * batches_per_launch:

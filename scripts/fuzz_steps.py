@@ -17,7 +17,7 @@ from tsim_amd import backend as hip, prng, synth
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 n_prog = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 seed0 = int(sys.argv[3]) if len(sys.argv) > 3 else 0
-bad = 0
+bad = wrapped = 0
 for ps in range(seed0, seed0 + n_prog):
     rng = np.random.default_rng(31000 + ps)
     kind = ps % 10  # 5, 6, 7: the shapes round 5 opened (several wide-path components / wide rows, 65..80 parameters, the general fused pass);
@@ -148,8 +148,14 @@ for ps in range(seed0, seed0 + n_prog):
                 bad += 1
                 print("MISMATCH program", ps, "round", r, "batch", i, "of", n, "B", B, "p", p, "packed", packed, "off", off, int((got != want).any(axis=1).sum()), "rows differ", flush=True)
             if B <= 1000 and off == 0 and i < 2:
-                w2 = np.packbits(op.sample_program(fs[i], subs[i]), axis=1, bitorder="little")
-                if not np.array_equal(got, w2):
+                w2raw, ovf = op.sample_program(fs[i], subs[i], return_overflow=True)
+                w2 = np.packbits(w2raw, axis=1, bitorder="little")
+                if ovf:
+                    # the reference's own int32 arithmetic wraps on this input (oracle.c flags it; tests/fuzz_many.py skips such
+                    # programs too): the exact formulation gives the unwrapped value there - DESIGN.md section 5, "where the
+                    # reference wraps"; mode="faithful" mirrors the wrap (tests/test_gpu_parity.py)
+                    wrapped += 1
+                elif not np.array_equal(got, w2):
                     bad += 1
                     print("ORACLE MISMATCH program", ps, "round", r, "batch", i, flush=True)
         # a serial and a per-step launch in between (they share the handle's lanes, lists and plan)
@@ -172,5 +178,5 @@ for ps in range(seed0, seed0 + n_prog):
     inf = hp.info()
     print("program", ps, "kind", kind, "outputs", prog.num_outputs, "components", [len(c.output_indices) for c in prog.components], "tables", inf["pattern_max_weight"], "ok" if not bad else "", flush=True)
     hp.close(); ref.close()
-print("programs", n_prog, "rounds each", rounds, "mismatches", bad)
+print("programs", n_prog, "rounds each", rounds, "mismatches", bad, "oracle comparisons skipped because the reference itself wraps int32:", wrapped)
 sys.exit(1 if bad else 0)

@@ -7,7 +7,7 @@ import pytest
 
 from conftest import run_batches
 from oracle import oracle_np as O
-from tsim_amd import synth
+from tsim_amd import prng, synth
 
 pytestmark = pytest.mark.gpu
 
@@ -253,3 +253,56 @@ def test_modes_small_programs_with_norm_check(hip, mode, approx):
         got, gdev = hip.HipProgram(prog, mode=mode).sample_batch(f, (9, seed))
         np.testing.assert_array_equal(got, want)
         np.testing.assert_array_equal(np.asarray(gdev, np.float32), np.asarray(wdev, np.float32))
+
+
+def _delta_heavy_program():
+    """Fuzz program 7048 of scripts/fuzz_steps.py (kind 8): components of 13 and 24 outputs, the second with 36 NodePhases terms per
+    graph, most of them deltas.  At p >= 0.02 the REFERENCE's running sum of some levels wraps int32 (a zero-valued graph brings a
+    low power, the carry is aligned to it: exact_scalar.py:74-84) - oracle.c flags it."""
+    rng = np.random.default_rng(31000 + 7048)
+    nf = int(rng.choice([64, 96, 160]))
+    comps = []
+    for _ in range(int(rng.integers(1, 3))):
+        n = int(rng.integers(9, 25)); F = int(rng.integers(4, min(nf, 40)))
+        G = [int(rng.integers(1, 4))]
+        for _k in range(n):
+            G.append(G[-1] + int(rng.integers(0, 3)))
+        comps.append(dict(n=n, F=F, G=G, density=0.2, shared_delta=(0.8 if n > 16 else float(rng.choice([0.0, 0.5])))))
+    prog = synth.physical_program(num_f=nf, n_direct=int(rng.integers(0, 30)), components=comps, seed=int(rng.integers(0, 2**31)),
+                                  shuffle_outputs=bool(rng.integers(0, 2)), direct_flip_fraction=0.3, identity_direct=bool(rng.integers(0, 2)))
+    return prog, nf
+
+
+def test_where_the_reference_wraps_int32(hip):
+    """The policy for the reference's own int32 overflow.  Products: ruled out statically, else the faithful formulation
+    (test_auto_falls_back_to_faithful_when_not_eligible).  Running sums: ``info()["reference_sum_wrap_possible"]`` says whether the
+    packer could rule a wrap out (the BASELINE configurations: yes); where it could not, the exact formulation still runs - it
+    equals the reference on every input the reference's arithmetic does not wrap on, and ``mode="faithful"`` mirrors the wrap
+    bit for bit."""
+    from oracle import oracle_c as OC
+
+    prog, nf = _delta_heavy_program()
+    op = OC.OracleProgram(prog)
+    auto = hip.HipProgram(prog)
+    faithful = hip.HipProgram(prog, mode="faithful")
+    assert auto.fast and auto.info()["reference_sum_wrap_possible"]
+    assert not faithful.fast
+    seen_wrap = False
+    for p in (0.0, 0.02, 0.3):
+        f = synth.synth_f(1000, nf, p, seed=3)
+        want, wdev, ov = op.sample_program(f, prng.key(5), return_devs=True, return_overflow=True)
+        got_f, dev_f = faithful.sample_batch(f, prng.key(5))
+        np.testing.assert_array_equal(got_f, want, err_msg=f"faithful, p {p}, reference wraps: {bool(ov)}")
+        np.testing.assert_array_equal(np.asarray(dev_f, np.float32), np.asarray(wdev, np.float32))
+        got_a, _ = auto.sample_batch(f, prng.key(5))
+        if ov:
+            seen_wrap = True
+            assert int((np.asarray(got_a) != want).any(axis=1).sum()) < 50  # (a handful of rows: those whose sums wrapped)
+        else:
+            np.testing.assert_array_equal(got_a, want, err_msg=f"auto, p {p}")
+    assert seen_wrap
+    auto.close(); faithful.close()
+    for name in ("C2", "C3", "C4", "C5"):
+        hp = hip.HipProgram(synth.config_program(name)[0])
+        assert hp.fast and not hp.info()["reference_sum_wrap_possible"], name
+        hp.close()

@@ -229,7 +229,7 @@ class HipProgram:
                     total_graphs=tg.value, total_rows=tr.value, fast=bool(st[0]), levels=st[1],
                     fixed_frame_levels=st[2], product_pairs=st[3], counted_rows=st[4],
                     table_bytes=st[5], graphs_d_tabled=st[6], chunk_table_kernel=((st[7] & 15) == 1), wide_sparse_kernel=((st[7] & 15) == 2),
-                    wide_fused_kernel=bool(st[7] & 32), wide_shared_columns=bool(st[7] & 16),
+                    wide_fused_kernel=bool(st[7] & 32), wide_shared_columns=bool(st[7] & 16), reference_sum_wrap_possible=bool(st[7] & 64),
                     pattern_tables=bool(en.value), pattern_table_bytes=tb.value,
                     pattern_max_weight=[int(mw[i]) for i in range(nc.value)])
 

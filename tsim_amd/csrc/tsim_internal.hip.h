@@ -84,6 +84,7 @@ struct FastGraph {
 struct HostLevel {
   std::vector<FastGraph> fg;
   bool fixed = false;
+  bool sum_wrap_possible = false;  // the reference's int32 running sum of this level cannot be ruled out to wrap (pack_level_fast)
   int frame = 0;
   int G = 0, P = 0;
   bool approx = false;

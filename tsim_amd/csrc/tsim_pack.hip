@@ -351,6 +351,7 @@ bool pack_level_fast(HostLevel &h, int W, std::vector<uint32_t> &tables, bool &f
   // ~30 us each - 31 of the 38 ms a fresh handle took before its first launch), their rows concatenated afterwards.
   std::vector<std::vector<uint32_t>> grows((size_t)G);
   std::vector<long long> g_nrows((size_t)G, 0);
+  std::vector<char> can_be_zero((size_t)G, 0);  // delta rows, PhasePairs terms or a zero floatfactor: the graph's value can be exactly 0
   const auto t_fn0 = std::chrono::steady_clock::now();
   std::atomic<long long> ns_a{0}, ns_b{0}, ns_c{0};
   auto do_graph = [&](int g) -> bool {
@@ -388,6 +389,8 @@ bool pack_level_fast(HostLevel &h, int W, std::vector<uint32_t> &tables, bool &f
         dstc.push_back((uint8_t)(ph >> 2));
       }
     rec[GF_N01] = (uint32_t)n[0] | ((uint32_t)n[1] << 16);
+    can_be_zero[(size_t)g] = (char)(n[0] > 0 || (d.td && h.i32[1][g] > 0) ||
+                                    !(h.i32[2][(size_t)g * 4] | h.i32[2][(size_t)g * 4 + 1] | h.i32[2][(size_t)g * 4 + 2] | h.i32[2][(size_t)g * 4 + 3]));
     fg.n1 = n[1];
     rec[GF_N1] = (uint32_t)n[1];
     // ---- PhasePairs rows: two table-index bits per term when the combined table stays small,
@@ -575,6 +578,45 @@ bool pack_level_fast(HostLevel &h, int W, std::vector<uint32_t> &tables, bool &f
     h.graph_rec[(size_t)g * G_WORDS + GF_ROWS] = (uint32_t)h.rows.size();
     h.rows.insert(h.rows.end(), grows[(size_t)g].begin(), grows[(size_t)g].end());
     h.n_rows += g_nrows[(size_t)g];
+  }
+  // ---- can the REFERENCE's running sum of this level leave int32 (exact_scalar.py:74-84,173-189)?  Its carry takes the smallest
+  //      power seen so far and is reduced by ONE factor of two per addition; a graph whose value is exactly zero still brings
+  //      a power - as low as its power2, when the zero factor comes first in the scan - and aligning the carry to a lower power
+  //      multiplies its coefficients (fuzz program 7048: carry 3.2e7 x 2^-30 met a zero term of power -37: x 2^7, wrapped; the
+  //      exact formulation here has no power for a zero).  Ruled out when every graph's largest |coefficient|, counted in units
+  //      of the lowest power any term of the level can take, sums to less than 2^31.  Not ruled out: `sum_wrap_possible` - the
+  //      program still runs on the exact formulation (it differs from the reference only on inputs where the reference's own
+  //      arithmetic wraps; TSIM_AMD_MODE=faithful mirrors the wrap), tsim_program_stats reports it.
+  h.sum_wrap_possible = false;
+  if (!h.approx && G > 0) {
+    int plow = INT32_MAX;
+    for (int g = 0; g < G; ++g) {
+      const int32_t *ffg = &h.i32[2][(size_t)g * 4];
+      const uint32_t o = (uint32_t)(ffg[0] | ffg[1] | ffg[2] | ffg[3]);
+      const int v2 = o ? __builtin_ctz(o) : 0;  // (the product with the floatfactor is reduced once: its content can stay in the coefficients)
+      if (can_be_zero[(size_t)g]) plow = std::min(plow, h.i32[3][g]);
+      for (auto &e : entries[(size_t)g])
+        if (e.c[0] | e.c[1] | e.c[2] | e.c[3]) plow = std::min(plow, e.p - std::max(0, v2 - 1));
+    }
+    long double tot = 0;
+    for (int g = 0; g < G && plow != INT32_MAX; ++g) {
+      long double worst = 0;
+      for (auto &e : entries[(size_t)g]) {
+        if (!(e.c[0] | e.c[1] | e.c[2] | e.c[3])) continue;
+        long double m = 0;
+        for (auto v : e.c) m = std::max(m, (long double)std::llabs(v));
+        worst = std::max(worst, m * powl(2.0L, (long double)(e.p - plow)));
+      }
+      long double dworst = 0;
+      for (auto &e : dentries[(size_t)g]) {
+        long double m = 0;
+        for (auto v : e.c) m = std::max(m, (long double)std::llabs(v));
+        dworst = std::max(dworst, m * powl(2.0L, (long double)e.p));
+      }
+      if (!dentries[(size_t)g].empty()) worst = 4 * worst * dworst;
+      tot += worst;
+    }
+    h.sum_wrap_possible = tot >= 2147483000.0L;
   }
   // ---- fixed frame: every term of the level comes straight from a table and, shifted to the
   //      level's smallest power, the worst-case sum of all graphs stays inside int32

@@ -384,6 +384,7 @@ retry_pack:
   // The bulk of the image - graph records, rows, term tables, the block-per-row kernel's row streams, the chunk tables below - is
   // laid out here (space reserved, zero-filled) and copied in by the pool afterwards: one thread appending 12 MB piece by piece
   // was 5 of the 12 ms of a fresh C4 handle.
+  bool sum_wrap = false;  // some level's reference sum cannot be ruled out to wrap int32 (pack_level_fast)
   std::vector<std::function<void()>> copy_jobs;
   auto img_grow = [&](size_t n) {
     const size_t o = img.size();
@@ -526,6 +527,7 @@ retry_pack:
       lr[L_FRAME] = (uint32_t)frame;
       p->stats[1] += 1;
       p->stats[2] += fixed ? 1 : 0;
+      if (p->fast && h.sum_wrap_possible) sum_wrap = true;
       p->stats[5] += (long long)tables.size() * 4;  // table bytes
       if (p->fast)
         for (int g = 0; g < h.G; ++g) {
@@ -676,7 +678,8 @@ retry_pack:
         }
     }
   }
-  p->stats[7] = p->v4 ? 1 : (p->v4w ? 2 : 0);
+  p->stats[7] = (p->v4 ? 1 : (p->v4w ? 2 : 0)) | (sum_wrap ? 64 : 0);
+  if (fin_dbg) fprintf(stderr, "[tsim] finalize: the reference's int32 sums %s\n", sum_wrap ? "CAN wrap on some level (sum_wrap_possible)" : "cannot wrap");
 
   fin_mark("chunk / column tables");
   // ---- direct outputs as a gather program (bit-field runs), for every sampling kernel ----

@@ -22,7 +22,7 @@ TUNE = {
     "gen": ["0", "2"], "trie": ["0", "2"], "shallow": ["0"], "x3": ["0"], "x4": ["0", "1"], "noise_wave": ["0"], "noise_fused": ["0"],
 }
 ENV = [{"TSIM_AMD_ADAPTIVE": "0"}, {"TSIM_AMD_FUSED_STEPS": "0"}, {"TSIM_AMD_DEEP_TABLES": "1"}, {"TSIM_AMD_DEEP_TABLES": "-1"},
-       {"TSIM_AMD_MODE": "faithful"}, {"TSIM_AMD_KERNEL": "rows"}, {"TSIM_AMD_PATTERN_TABLES": "0"}, {"TSIM_AMD_PATTERN_TABLE_MB": "2"}, {"TSIM_AMD_TABLE_BUILD": "rows"}]
+       {"TSIM_AMD_MODE": "faithful"}, {"TSIM_AMD_MODE": "strict"}, {"TSIM_AMD_KERNEL": "rows"}, {"TSIM_AMD_PATTERN_TABLES": "0"}, {"TSIM_AMD_PATTERN_TABLE_MB": "2"}, {"TSIM_AMD_TABLE_BUILD": "rows"}]
 
 
 def test_every_tune_key_has_a_case():

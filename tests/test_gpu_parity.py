@@ -302,6 +302,20 @@ def test_where_the_reference_wraps_int32(hip):
             np.testing.assert_array_equal(got_a, want, err_msg=f"auto, p {p}")
     assert seen_wrap
     auto.close(); faithful.close()
+    import os
+    os.environ["TSIM_AMD_MODE"] = "strict"  # the exact formulation only where no int32 operation of the reference can wrap
+    try:
+        strict = hip.HipProgram(prog)
+        assert not strict.fast
+        f = synth.synth_f(1000, nf, 0.3, seed=3)
+        got_s, _ = strict.sample_batch(f, prng.key(5))
+        np.testing.assert_array_equal(got_s, op.sample_program(f, prng.key(5)))
+        strict.close()
+        c2 = hip.HipProgram(synth.config_program("C2")[0])
+        assert c2.fast
+        c2.close()
+    finally:
+        os.environ.pop("TSIM_AMD_MODE", None)
     for name in ("C2", "C3", "C4", "C5"):
         hp = hip.HipProgram(synth.config_program(name)[0])
         assert hp.fast and not hp.info()["reference_sum_wrap_possible"], name

@@ -544,6 +544,14 @@ retry_pack:
     if (sequential) p->total_keys += c.n_out;
     memcpy(&img[p->comp_off + ci * C_WORDS], rec, sizeof rec);
   }
+  {  // TSIM_AMD_MODE=strict: the exact formulation only where NO int32 operation of the reference can wrap - products (above) and
+    // the levels' running sums (pack_level_fast: sum_wrap_possible); everything else on the faithful formulation
+    const char *env = getenv("TSIM_AMD_MODE");
+    if (p->fast && sum_wrap && env && strcmp(env, "strict") == 0) {
+      p->fast = false;
+      goto retry_pack;
+    }
+  }
   fin_mark("  records laid out");
   run_copy_jobs();
   fin_mark("rows / fast formulation packed");

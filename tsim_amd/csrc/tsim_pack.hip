@@ -352,6 +352,10 @@ bool pack_level_fast(HostLevel &h, int W, std::vector<uint32_t> &tables, bool &f
   std::vector<std::vector<uint32_t>> grows((size_t)G);
   std::vector<long long> g_nrows((size_t)G, 0);
   std::vector<char> can_be_zero((size_t)G, 0);  // delta rows, PhasePairs terms or a zero floatfactor: the graph's value can be exactly 0
+  // what the two bounds below need of a graph's table, gathered where the table is made (the pool): the powers of its nonzero
+  // entries, the largest |coefficient| x 2^power among them, the same for its separate PhasePairs table
+  struct GraphAgg { int minp = INT32_MAX, maxp = INT32_MIN; long double big = 0, dbig = 0; bool has_d = false, d_bad = false; };
+  std::vector<GraphAgg> agg((size_t)G);
   const auto t_fn0 = std::chrono::steady_clock::now();
   std::atomic<long long> ns_a{0}, ns_b{0}, ns_c{0};
   auto do_graph = [&](int g) -> bool {
@@ -562,6 +566,25 @@ bool pack_level_fast(HostLevel &h, int W, std::vector<uint32_t> &tables, bool &f
     }
     memcpy(&rec[GF_APRE], &h.approx_v[2 * (size_t)g], 4);
     memcpy(&rec[GF_APIM], &h.approx_v[2 * (size_t)g + 1], 4);
+    {
+      GraphAgg &A = agg[(size_t)g];
+      for (auto &e : entries[(size_t)g]) {
+        if (!(e.c[0] | e.c[1] | e.c[2] | e.c[3])) continue;
+        A.minp = std::min(A.minp, e.p);
+        A.maxp = std::max(A.maxp, e.p);
+        // a rotation by i permutes/negates coefficients: bound by the largest one
+        long double m = 0;
+        for (auto v : e.c) m = std::max(m, (long double)std::llabs(v));
+        A.big = std::max(A.big, ldexpl(m, e.p));
+      }
+      A.has_d = !dentries[(size_t)g].empty();
+      for (auto &e : dentries[(size_t)g]) {
+        if (e.p < 0 || e.p > 40) { A.d_bad = true; continue; }
+        long double m = 0;
+        for (auto v : e.c) m = std::max(m, (long double)std::llabs(v));
+        A.dbig = std::max(A.dbig, ldexpl(m, e.p));
+      }
+    }
     ns_c += (std::chrono::steady_clock::now() - tg2).count();
     return true;
   };
@@ -595,25 +618,13 @@ bool pack_level_fast(HostLevel &h, int W, std::vector<uint32_t> &tables, bool &f
       const uint32_t o = (uint32_t)(ffg[0] | ffg[1] | ffg[2] | ffg[3]);
       const int v2 = o ? __builtin_ctz(o) : 0;  // (the product with the floatfactor is reduced once: its content can stay in the coefficients)
       if (can_be_zero[(size_t)g]) plow = std::min(plow, h.i32[3][g]);
-      for (auto &e : entries[(size_t)g])
-        if (e.c[0] | e.c[1] | e.c[2] | e.c[3]) plow = std::min(plow, e.p - std::max(0, v2 - 1));
+      if (agg[(size_t)g].minp != INT32_MAX) plow = std::min(plow, agg[(size_t)g].minp - std::max(0, v2 - 1));
     }
     long double tot = 0;
     for (int g = 0; g < G && plow != INT32_MAX; ++g) {
-      long double worst = 0;
-      for (auto &e : entries[(size_t)g]) {
-        if (!(e.c[0] | e.c[1] | e.c[2] | e.c[3])) continue;
-        long double m = 0;
-        for (auto v : e.c) m = std::max(m, (long double)std::llabs(v));
-        worst = std::max(worst, m * powl(2.0L, (long double)(e.p - plow)));
-      }
-      long double dworst = 0;
-      for (auto &e : dentries[(size_t)g]) {
-        long double m = 0;
-        for (auto v : e.c) m = std::max(m, (long double)std::llabs(v));
-        dworst = std::max(dworst, m * powl(2.0L, (long double)e.p));
-      }
-      if (!dentries[(size_t)g].empty()) worst = 4 * worst * dworst;
+      const GraphAgg &A = agg[(size_t)g];
+      long double worst = ldexpl(A.big, -plow);
+      if (A.has_d) worst = A.d_bad ? 1e30L : 4 * worst * A.dbig;
       tot += worst;
     }
     h.sum_wrap_possible = tot >= 2147483000.0L;
@@ -623,32 +634,17 @@ bool pack_level_fast(HostLevel &h, int W, std::vector<uint32_t> &tables, bool &f
   bool fixed = !h.approx && G > 0;
   int frame = INT32_MAX;
   if (fixed) {
-    for (auto &ge : entries)
-      for (auto &e : ge)
-        if (e.c[0] | e.c[1] | e.c[2] | e.c[3]) frame = std::min(frame, e.p);
+    for (auto &A : agg) frame = std::min(frame, A.minp);
     if (frame == INT32_MAX) frame = 0;
     long double total = 0;
     for (int g = 0; g < G && fixed; ++g) {
-      long double worst = 0;
-      for (auto &e : entries[g]) {
-        if (!(e.c[0] | e.c[1] | e.c[2] | e.c[3])) continue;
-        const int sh = e.p - frame;
-        if (sh > 40) { fixed = false; break; }
-        // a rotation by i permutes/negates coefficients: bound by the largest one
-        long double m = 0;
-        for (auto v : e.c) m = std::max(m, (long double)std::llabs(v));
-        worst = std::max(worst, m * (long double)(1ll << sh));
-      }
+      const GraphAgg &A = agg[(size_t)g];
+      if (A.maxp != INT32_MIN && A.maxp - frame > 40) { fixed = false; break; }
       // separate PhasePairs table: entries become plain integers c * 2^p (p >= 0); the product
       // with the main entry is a sum of four coefficient products
-      long double dworst = 0;
-      for (auto &e : dentries[g]) {
-        if (e.p < 0 || e.p > 40) { fixed = false; break; }
-        long double m = 0;
-        for (auto v : e.c) m = std::max(m, (long double)std::llabs(v));
-        dworst = std::max(dworst, m * (long double)(1ll << e.p));
-      }
-      if (!dentries[g].empty()) worst = 4 * worst * dworst;
+      if (A.d_bad) { fixed = false; break; }
+      long double worst = ldexpl(A.big, -frame);
+      if (A.has_d) worst = 4 * worst * A.dbig;
       total += worst;
     }
     if (total >= 2147483000.0L) fixed = false;

@@ -497,7 +497,10 @@ int tsim_program_info(const tsim_program *p, int32_t *n_components, int32_t *num
 /* packer statistics: out[0] fast formulation selected, [1] levels, [2] fixed-frame levels,
  * [3] product pairs, [4] counted NodePhases rows, [5] table entries, [6] graphs with tabled
  * PhasePairs, [7] low 4 bits: full-evaluation kernel: 0 row kernel, 1 LDS chunk tables (k_sample4), 2 sparse columns for wide
- * components (k_sample4w); + 32: the program has a wide record (k_sample_wide serves it); + 16: with the shared column table */
+ * components (k_sample4w); + 32: the program has a wide record (k_sample_wide serves it); + 16: with the shared column table;
+ * + 64: the packer could NOT rule out that the reference's int32 running sum of some level wraps (exact_scalar.py:74-84,173-189) - the
+ * exact formulation then differs from the reference on the inputs where the reference's own arithmetic wraps; TSIM_AMD_MODE=faithful
+ * (every program) or =strict (exactly these programs) mirrors the wrap on the int32-faithful formulation */
 int tsim_program_stats(const tsim_program *p, int64_t out[8]);
 
 /* Which kernel family served the launches of this handle so far (diagnostics: scripts/shape_map.py, tests of the
